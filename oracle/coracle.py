@@ -1,0 +1,139 @@
+"""ctypes loader for liboracle.so (oracle/oracle.c).  TEST INFRASTRUCTURE ONLY.
+
+Numpy conventions shared with aleo_amd: Fr arrays are uint64[n,4], Fq uint64[n,6], affine bases are
+uint8[n,104] (snarkVM Affine layout: x, y Montgomery + infinity byte), Jacobian results uint64[18].
+"""
+from __future__ import annotations
+import ctypes, os, subprocess
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def build() -> str:
+    so = os.path.join(_HERE, 'liboracle.so')
+    src = os.path.join(_HERE, 'oracle.c')
+    if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(['make', '-C', _HERE, 'liboracle.so'], stdout=subprocess.DEVNULL)
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        L = ctypes.CDLL(build())
+        vp, sz, ci, cu = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_uint
+        L.oracle_msm_g1.argtypes = [vp, vp, sz, vp, sz, ci, ci]; L.oracle_msm_g1.restype = ci
+        L.oracle_msm_g1_naive.argtypes = [vp, vp, sz, vp, sz]; L.oracle_msm_g1_naive.restype = ci
+        L.oracle_g1_to_affine.argtypes = [vp, vp]; L.oracle_g1_to_affine.restype = None
+        L.oracle_g1_on_curve.argtypes = [vp]; L.oracle_g1_on_curve.restype = ci
+        L.oracle_g1_mul.argtypes = [vp, vp, vp]; L.oracle_g1_mul.restype = None
+        L.oracle_g1_multiples.argtypes = [vp, vp, sz]; L.oracle_g1_multiples.restype = None
+        for f in ('oracle_fr_to_mont', 'oracle_fr_from_mont', 'oracle_fq_to_mont', 'oracle_fq_from_mont'):
+            getattr(L, f).argtypes = [vp, sz]; getattr(L, f).restype = None
+        for f in ('oracle_fr_mul', 'oracle_fq_mul'):
+            getattr(L, f).argtypes = [vp, vp, vp, sz]; getattr(L, f).restype = None
+        L.oracle_ntt_fr.argtypes = [vp, cu, ci, ci, ci]; L.oracle_ntt_fr.restype = ci
+        L.oracle_kzg_commit.argtypes = [vp, vp, vp, sz, ci]; L.oracle_kzg_commit.restype = ci
+        _LIB = L
+    return _LIB
+
+
+def _p(a): return a.ctypes.data_as(ctypes.c_void_p)
+
+
+# ---- int <-> limb helpers --------------------------------------------------------------------
+def ints_to_limbs(vals, nl) -> np.ndarray:
+    out = np.zeros((len(vals), nl), dtype=np.uint64)
+    m = (1 << 64) - 1
+    for i, v in enumerate(vals):
+        for j in range(nl):
+            out[i, j] = (v >> (64 * j)) & m
+    return out
+
+
+def limbs_to_ints(arr) -> list:
+    arr = np.asarray(arr, dtype=np.uint64)
+    if arr.ndim == 1: arr = arr[None, :]
+    return [sum(int(arr[i, j]) << (64 * j) for j in range(arr.shape[1])) for i in range(arr.shape[0])]
+
+
+def fr_to_mont(a): a = np.ascontiguousarray(a, dtype=np.uint64).copy(); lib().oracle_fr_to_mont(_p(a), a.shape[0]); return a
+def fr_from_mont(a): a = np.ascontiguousarray(a, dtype=np.uint64).copy(); lib().oracle_fr_from_mont(_p(a), a.shape[0]); return a
+def fq_to_mont(a): a = np.ascontiguousarray(a, dtype=np.uint64).copy(); lib().oracle_fq_to_mont(_p(a), a.shape[0]); return a
+def fq_from_mont(a): a = np.ascontiguousarray(a, dtype=np.uint64).copy(); lib().oracle_fq_from_mont(_p(a), a.shape[0]); return a
+
+
+def affine_from_ints(points) -> np.ndarray:
+    """[(x,y)|None] canonical ints -> uint8[n,104] snarkVM Affine (Montgomery)."""
+    n = len(points)
+    out = np.zeros((n, 104), dtype=np.uint8)
+    xs = [p[0] if p else 0 for p in points]; ys = [p[1] if p else 1 for p in points]
+    xm = fq_to_mont(ints_to_limbs(xs, 6)); ym = fq_to_mont(ints_to_limbs(ys, 6))
+    out[:, 0:48] = xm.view(np.uint8).reshape(n, 48); out[:, 48:96] = ym.view(np.uint8).reshape(n, 48)
+    for i, p in enumerate(points):
+        if p is None: out[i, 96] = 1
+    return out
+
+
+def affine_to_ints(aff) -> list:
+    aff = np.ascontiguousarray(aff, dtype=np.uint8).reshape(-1, 104)
+    n = aff.shape[0]
+    x = fq_from_mont(np.ascontiguousarray(aff[:, 0:48]).view(np.uint64).reshape(n, 6))
+    y = fq_from_mont(np.ascontiguousarray(aff[:, 48:96]).view(np.uint64).reshape(n, 6))
+    xi, yi = limbs_to_ints(x), limbs_to_ints(y)
+    return [None if aff[i, 96] else (xi[i], yi[i]) for i in range(n)]
+
+
+def jac_to_affine(jac) -> np.ndarray:
+    jac = np.ascontiguousarray(jac, dtype=np.uint64).reshape(18)
+    out = np.zeros(104, dtype=np.uint8); lib().oracle_g1_to_affine(_p(out), _p(jac)); return out
+
+
+def jac_to_int_point(jac):
+    return affine_to_ints(jac_to_affine(jac))[0]
+
+
+def msm_g1(bases, scalars, threads=1, variant=0) -> np.ndarray:
+    """bases uint8[n,104|96], scalars uint64[n,4] canonical -> Jacobian uint64[18]."""
+    bases = np.ascontiguousarray(bases, dtype=np.uint8); scalars = np.ascontiguousarray(scalars, dtype=np.uint64)
+    n = scalars.shape[0]; stride = bases.shape[1] if n else 104
+    out = np.zeros(18, dtype=np.uint64)
+    rc = lib().oracle_msm_g1(_p(out), _p(bases), stride, _p(scalars), n, threads, variant)
+    assert rc == 0
+    return out
+
+
+def msm_g1_naive(bases, scalars) -> np.ndarray:
+    bases = np.ascontiguousarray(bases, dtype=np.uint8); scalars = np.ascontiguousarray(scalars, dtype=np.uint64)
+    out = np.zeros(18, dtype=np.uint64)
+    lib().oracle_msm_g1_naive(_p(out), _p(bases), bases.shape[1] if len(bases) else 104, _p(scalars), scalars.shape[0])
+    return out
+
+
+def g1_multiples(base104, n) -> np.ndarray:
+    out = np.zeros((n, 104), dtype=np.uint8)
+    b = np.ascontiguousarray(base104, dtype=np.uint8)
+    lib().oracle_g1_multiples(_p(out), _p(b), n); return out
+
+
+def g1_mul(base104, scalar4) -> np.ndarray:
+    out = np.zeros(104, dtype=np.uint8)
+    b = np.ascontiguousarray(base104, dtype=np.uint8); s = np.ascontiguousarray(scalar4, dtype=np.uint64)
+    lib().oracle_g1_mul(_p(out), _p(b), _p(s)); return out
+
+
+def ntt_fr(data, order=0, direction=0, type=0) -> np.ndarray:
+    """data uint64[n,4] Montgomery -> transformed copy."""
+    a = np.ascontiguousarray(data, dtype=np.uint64).copy()
+    n = a.shape[0]; lg = n.bit_length() - 1; assert 1 << lg == n
+    rc = lib().oracle_ntt_fr(_p(a), lg, order, direction, type); assert rc == 0
+    return a
+
+
+def kzg_commit(bases104, coeffs_mont, threads=1) -> np.ndarray:
+    out = np.zeros(104, dtype=np.uint8)
+    b = np.ascontiguousarray(bases104, dtype=np.uint8); c = np.ascontiguousarray(coeffs_mont, dtype=np.uint64)
+    rc = lib().oracle_kzg_commit(_p(out), _p(b), _p(c), c.shape[0], threads); assert rc == 0
+    return out
