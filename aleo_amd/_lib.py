@@ -1,0 +1,64 @@
+"""ctypes binding of libaleo_mi355x.so (include/aleo_mi355x.h).  There is no CPU fallback: if the HIP library
+is missing or a call fails, an exception is raised (the Rust caller would fall back to snarkVM's CPU path; this
+package never does, so a silent fallback cannot hide behind a green test)."""
+from __future__ import annotations
+import ctypes, os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'lib', 'libaleo_mi355x.so')
+
+EXPORTS = [
+    'aleo_mi355x_init', 'aleo_mi355x_msm_g1', 'aleo_mi355x_bases_pin', 'aleo_mi355x_bases_unpin',
+    'aleo_mi355x_msm_g1_pinned', 'aleo_mi355x_msm_g1_device', 'aleo_mi355x_g1_sum', 'aleo_mi355x_ntt_fr',
+    'aleo_mi355x_ntt_fr_device', 'aleo_mi355x_kzg_commit', 'aleo_mi355x_kzg_commit_device', 'aleo_mi355x_fq_mul',
+    'aleo_mi355x_fr_mul', 'aleo_mi355x_last_msm_timing', 'aleo_mi355x_strerror', 'aleo_mi355x_last_error',
+    'aleo_mi355x_version',
+]
+
+
+class AleoMi355xError(RuntimeError):
+    pass
+
+
+_LIB = None
+
+
+def lib():
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise AleoMi355xError(f'{LIB_PATH} not built: run `python -c "import __graft_entry__ as g; g.build()"` '
+                              '(aleo_amd/csrc/build.sh).  There is no CPU fallback.')
+    L = ctypes.CDLL(LIB_PATH)
+    vp, sz, i32, u32, u64 = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int32, ctypes.c_uint32, ctypes.c_uint64
+    sig = {
+        'aleo_mi355x_init': ([i32], i32),
+        'aleo_mi355x_msm_g1': ([vp, vp, sz, vp, sz], i32),
+        'aleo_mi355x_bases_pin': ([vp, sz, sz, ctypes.POINTER(u64)], i32),
+        'aleo_mi355x_bases_unpin': ([u64], i32),
+        'aleo_mi355x_msm_g1_pinned': ([vp, u64, vp, sz], i32),
+        'aleo_mi355x_msm_g1_device': ([vp, u64, vp, sz, vp], i32),
+        'aleo_mi355x_g1_sum': ([vp, vp, sz], i32),
+        'aleo_mi355x_ntt_fr': ([vp, u32, i32, i32, i32], i32),
+        'aleo_mi355x_ntt_fr_device': ([vp, u32, i32, i32, i32, vp], i32),
+        'aleo_mi355x_kzg_commit': ([vp, u64, vp, sz], i32),
+        'aleo_mi355x_kzg_commit_device': ([vp, u64, vp, sz, vp], i32),
+        'aleo_mi355x_fq_mul': ([vp, vp, vp, sz], i32),
+        'aleo_mi355x_fr_mul': ([vp, vp, vp, sz], i32),
+        'aleo_mi355x_last_msm_timing': ([ctypes.POINTER(ctypes.c_double), i32], i32),
+        'aleo_mi355x_strerror': ([i32], ctypes.c_char_p),
+        'aleo_mi355x_last_error': ([], ctypes.c_char_p),
+        'aleo_mi355x_version': ([], ctypes.c_char_p),
+    }
+    for name, (args, res) in sig.items():
+        f = getattr(L, name); f.argtypes = args; f.restype = res
+    _LIB = L
+    return L
+
+
+def check(status: int, what: str):
+    if status != 0:
+        L = lib()
+        raise AleoMi355xError(f'{what}: {L.aleo_mi355x_strerror(status).decode()} '
+                              f'[{L.aleo_mi355x_last_error().decode()}]')

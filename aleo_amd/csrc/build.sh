@@ -1,0 +1,17 @@
+#!/bin/bash
+# Builds libaleo_mi355x.so for gfx950 in-tree (aleo_amd/lib/).  hipcc cross-compiles without a GPU.
+set -euo pipefail
+here="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
+out="$here/../lib"; mkdir -p "$out"
+python3 "$here/../../tools/gen_fp_asm.py" "$here/fp_mont_gen.h"
+HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fgpu-rdc-never 2>/dev/null"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Wno-unused-variable"
+objs=()
+for f in api msm ntt; do
+  "$HIPCC" $FLAGS -c "$here/$f.hip" -o "$out/$f.o" &
+  objs+=("$out/$f.o")
+done
+wait
+"$HIPCC" --offload-arch=gfx950 -shared -fPIC -o "$out/libaleo_mi355x.so" "${objs[@]}"
+echo "built $out/libaleo_mi355x.so"

@@ -1,0 +1,75 @@
+// ctx.h — per-device context of libaleo_mi355x.so: stream, grow-only HBM workspaces, pinned base sets.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+#include "../../include/aleo_mi355x.h"
+
+namespace aleo_mi355x {
+
+extern thread_local std::string g_last_error;
+
+#define HIPCHK(expr)                                                                                   \
+  do {                                                                                                 \
+    hipError_t e__ = (expr);                                                                           \
+    if (e__ != hipSuccess) {                                                                           \
+      char buf__[512];                                                                                 \
+      snprintf(buf__, sizeof buf__, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, __LINE__); \
+      g_last_error = buf__;                                                                            \
+      return (e__ == hipErrorOutOfMemory) ? ALEO_MI355X_ERR_OOM : ALEO_MI355X_ERR_HIP;                 \
+    }                                                                                                  \
+  } while (0)
+
+// A grow-only device buffer (hipMalloc is slow and synchronising; the prove path calls MSM/NTT repeatedly
+// with the same few sizes, so buffers are kept at their high-water mark — there are 288 GB to spend).
+struct DevBuf {
+  void* p = nullptr; size_t cap = 0;
+  int32_t reserve(size_t bytes) {
+    if (bytes <= cap) return ALEO_MI355X_OK;
+    if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+    size_t want = bytes + bytes / 8;
+    HIPCHK(hipMalloc(&p, want));
+    cap = want; return ALEO_MI355X_OK;
+  }
+  template <class T> T* as() const { return (T*)p; }
+};
+
+struct PinnedBases {
+  void* d_xy = nullptr;        // n x 96 bytes: x | y, Montgomery, canonical
+  uint8_t* d_inf = nullptr;    // n bytes, nullptr when no base is the point at infinity
+  size_t n = 0;
+};
+
+struct MsmTiming { double total = 0, sort = 0, accum = 0, reduce = 0, host = 0; };
+
+struct NttTables;   // ntt.hip
+
+struct Ctx {
+  int device = -1;
+  hipStream_t stream = nullptr;
+  std::mutex mu;                       // serialises calls on this device
+  hipEvent_t ev[6] = {};
+  // MSM workspaces
+  DevBuf hist, scan_local, scan_blk, sorted, partial, task_g, meta, vbuf, scalars_stage, out_stage;
+  void* h_pinned = nullptr; size_t h_pinned_cap = 0;    // pinned host staging for small D2H results
+  std::map<uint64_t, PinnedBases> bases; uint64_t next_handle = 1;
+  MsmTiming last_msm;
+  // NTT
+  std::map<uint64_t, NttTables*> ntt_tables; DevBuf ntt_tmp, ntt_stage;
+};
+
+int32_t get_ctx(Ctx** out);            // lazily initialises the current device's context
+int32_t ensure_host_pinned(Ctx* c, size_t bytes);
+
+// msm.hip
+int32_t msm_run(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, const void* d_scalars, size_t n, bool scalars_are_mont, hipStream_t s);
+int32_t launch_fq_mul(Ctx* c, void* r, const void* a, const void* b, size_t n);
+int32_t launch_fr_mul(Ctx* c, void* r, const void* a, const void* b, size_t n);
+// ntt.hip
+int32_t ntt_run(Ctx* c, void* d_inout, uint32_t lg_n, int32_t order, int32_t direction, int32_t type, hipStream_t s);
+
+}  // namespace aleo_mi355x

@@ -1,0 +1,166 @@
+// host_field.hpp — host-side (CPU) BLS12-377 arithmetic used by the PRODUCT library for the O(W) tail work
+// that must not run on a single GPU lane: the final Horner combination of the window sums, affine
+// normalisation of the result, partial-sum combination across GPUs, and twiddle/table generation.
+// (A dependent chain of ~250 doublings costs ~2 ms on one GPU lane and ~0.1 ms on a host core.)
+//
+// This is independent of oracle/ (which is test infrastructure): nothing here includes or links it.
+// Layouts match snarkVM 0.14.5 (fields/src/fp_256.rs, fp_384.rs; curves/.../short_weierstrass_jacobian):
+// u64 limbs little-endian, Montgomery form with R = 2^(64*N).
+#pragma once
+#include <cstdint>
+#include <cstring>
+
+namespace aleo_mi355x { namespace host {
+
+typedef unsigned __int128 u128;
+
+template <int N> struct HParams;
+template <> struct HParams<4> {  // Fr
+  static constexpr uint64_t P[4] = {0x0a11800000000001ULL, 0x59aa76fed0000001ULL, 0x60b44d1e5c37b001ULL, 0x12ab655e9a2ca556ULL};
+  static constexpr uint64_t ONE[4] = {0x7d1c7ffffffffff3ULL, 0x7257f50f6ffffff2ULL, 0x16d81575512c0feeULL, 0x0d4bda322bbb9a9dULL};
+  static constexpr uint64_t R2[4] = {0x25d577bab861857bULL, 0xcc2c27b58860591fULL, 0xa7cc008fe5dc8593ULL, 0x011fdae7eff1c939ULL};
+  static constexpr uint64_t INV = 0x0a117fffffffffffULL;
+};
+template <> struct HParams<6> {  // Fq
+  static constexpr uint64_t P[6] = {0x8508c00000000001ULL, 0x170b5d4430000000ULL, 0x1ef3622fba094800ULL, 0x1a22d9f300f5138fULL, 0xc63b05c06ca1493bULL, 0x01ae3a4617c510eaULL};
+  static constexpr uint64_t ONE[6] = {0x02cdffffffffff68ULL, 0x51409f837fffffb1ULL, 0x9f7db3a98a7d3ff2ULL, 0x7b4e97b76e7c6305ULL, 0x4cf495bf803c84e8ULL, 0x008d6661e2fdf49aULL};
+  static constexpr uint64_t R2[6] = {0xb786686c9400cd22ULL, 0x0329fcaab00431b1ULL, 0x22a5f11162d6b46dULL, 0xbfdf7d03827dc3acULL, 0x837e92f041790bf9ULL, 0x006dfccb1e914b88ULL};
+  static constexpr uint64_t INV = 0x8508bfffffffffffULL;
+};
+
+// Fully reduced Montgomery field element on the host.
+template <int N> struct HFp {
+  uint64_t l[N];
+  using Pm = HParams<N>;
+
+  static HFp zero() { HFp r; std::memset(r.l, 0, sizeof r.l); return r; }
+  static HFp one() { HFp r; std::memcpy(r.l, Pm::ONE, sizeof r.l); return r; }
+  static HFp from_u64(uint64_t v) { HFp t = zero(); t.l[0] = v; HFp r2; std::memcpy(r2.l, Pm::R2, sizeof r2.l); return mul(t, r2); }
+  bool is_zero() const { uint64_t o = 0; for (int i = 0; i < N; ++i) o |= l[i]; return o == 0; }
+  bool operator==(const HFp& b) const { uint64_t o = 0; for (int i = 0; i < N; ++i) o |= l[i] ^ b.l[i]; return o == 0; }
+
+  static bool geq_p(const uint64_t* a) {
+    for (int i = N - 1; i >= 0; --i) { if (a[i] > Pm::P[i]) return true; if (a[i] < Pm::P[i]) return false; }
+    return true;
+  }
+  static void sub_p(uint64_t* a) {
+    uint64_t br = 0;
+    for (int i = 0; i < N; ++i) { u128 t = (u128)a[i] - Pm::P[i] - br; a[i] = (uint64_t)t; br = (uint64_t)(t >> 64) & 1; }
+  }
+  // Reduce an arbitrary N-limb value (e.g. a lazily reduced device result < 16p) to canonical form.
+  static HFp reduce_lazy(const uint64_t* a) {
+    HFp r; std::memcpy(r.l, a, sizeof r.l);
+    while (geq_p(r.l)) sub_p(r.l);
+    return r;
+  }
+  static HFp add(const HFp& a, const HFp& b) {
+    HFp r; uint64_t c = 0;
+    for (int i = 0; i < N; ++i) { u128 s = (u128)a.l[i] + b.l[i] + c; r.l[i] = (uint64_t)s; c = (uint64_t)(s >> 64); }
+    if (c || geq_p(r.l)) sub_p(r.l);
+    return r;
+  }
+  static HFp sub(const HFp& a, const HFp& b) {
+    HFp r; uint64_t br = 0;
+    for (int i = 0; i < N; ++i) { u128 s = (u128)a.l[i] - b.l[i] - br; r.l[i] = (uint64_t)s; br = (uint64_t)(s >> 64) & 1; }
+    if (br) { uint64_t c = 0; for (int i = 0; i < N; ++i) { u128 s = (u128)r.l[i] + Pm::P[i] + c; r.l[i] = (uint64_t)s; c = (uint64_t)(s >> 64); } }
+    return r;
+  }
+  static HFp dbl(const HFp& a) { return add(a, a); }
+  static HFp neg(const HFp& a) { return a.is_zero() ? a : sub(zero(), a); }
+  // Montgomery product (coarsely integrated operand scanning)
+  static HFp mul(const HFp& a, const HFp& b) {
+    uint64_t t[N + 2]; std::memset(t, 0, sizeof t);
+    for (int i = 0; i < N; ++i) {
+      uint64_t c = 0;
+      for (int j = 0; j < N; ++j) { u128 s = (u128)a.l[j] * b.l[i] + t[j] + c; t[j] = (uint64_t)s; c = (uint64_t)(s >> 64); }
+      u128 s = (u128)t[N] + c; t[N] = (uint64_t)s; t[N + 1] = (uint64_t)(s >> 64);
+      uint64_t m = t[0] * Pm::INV;
+      s = (u128)m * Pm::P[0] + t[0]; c = (uint64_t)(s >> 64);
+      for (int j = 1; j < N; ++j) { s = (u128)m * Pm::P[j] + t[j] + c; t[j - 1] = (uint64_t)s; c = (uint64_t)(s >> 64); }
+      s = (u128)t[N] + c; t[N - 1] = (uint64_t)s; t[N] = t[N + 1] + (uint64_t)(s >> 64);
+    }
+    if (t[N] || geq_p(t)) sub_p(t);
+    HFp r; std::memcpy(r.l, t, sizeof r.l); return r;
+  }
+  static HFp sqr(const HFp& a) { return mul(a, a); }
+  static HFp pow(const HFp& a, const uint64_t* e, int nl) {
+    HFp acc = one();
+    for (int i = nl * 64 - 1; i >= 0; --i) { acc = sqr(acc); if ((e[i / 64] >> (i % 64)) & 1) acc = mul(acc, a); }
+    return acc;
+  }
+  static HFp pow_u64(const HFp& a, uint64_t e) { return pow(a, &e, 1); }
+  static HFp inv(const HFp& a) { uint64_t e[N]; std::memcpy(e, Pm::P, sizeof e); e[0] -= 2; return pow(a, e, N); }
+  static HFp to_mont(const HFp& a) { HFp r2; std::memcpy(r2.l, Pm::R2, sizeof r2.l); return mul(a, r2); }
+  static HFp from_mont(const HFp& a) { HFp o = zero(); o.l[0] = 1; return mul(a, o); }
+};
+
+using HFr = HFp<4>;
+using HFq = HFp<6>;
+
+// Fr constants of the evaluation domain (snarkvm-curves bls12_377/fr.rs)
+static constexpr uint64_t FR_TWO_ADIC_ROOT_CANON[4] = {0x476ef4a4ec2a895eULL, 0x9b506ee363e3f04aULL, 0x60c69477d1a8a12fULL, 0x11d4b7f60cb92cc1ULL};
+static constexpr int FR_TWO_ADICITY = 47;
+static constexpr uint64_t FR_GENERATOR = 22;
+
+// ---- G1 on the host: extended Jacobian (X, Y, ZZ, ZZZ), fully reduced coordinates -------------
+struct HXYZZ {
+  HFq X, Y, ZZ, ZZZ;
+  static HXYZZ infinity() { HXYZZ r; r.X = HFq::zero(); r.Y = HFq::zero(); r.ZZ = HFq::zero(); r.ZZZ = HFq::zero(); return r; }
+  bool is_inf() const { return ZZ.is_zero(); }
+};
+
+inline HXYZZ hdouble(const HXYZZ& p) {  // dbl-2008-s-1, a = 0
+  if (p.is_inf()) return p;
+  HXYZZ r;
+  HFq U = HFq::dbl(p.Y), V = HFq::sqr(U), W = HFq::mul(U, V), S = HFq::mul(p.X, V);
+  HFq xx = HFq::sqr(p.X), M = HFq::add(HFq::dbl(xx), xx);
+  r.X = HFq::sub(HFq::sqr(M), HFq::dbl(S));
+  r.Y = HFq::sub(HFq::mul(M, HFq::sub(S, r.X)), HFq::mul(W, p.Y));
+  r.ZZ = HFq::mul(V, p.ZZ); r.ZZZ = HFq::mul(W, p.ZZZ);
+  if (r.ZZ.is_zero()) return HXYZZ::infinity();
+  return r;
+}
+
+inline HXYZZ hadd(const HXYZZ& a, const HXYZZ& b) {  // add-2008-s
+  if (a.is_inf()) return b;
+  if (b.is_inf()) return a;
+  HFq U1 = HFq::mul(a.X, b.ZZ), U2 = HFq::mul(b.X, a.ZZ), S1 = HFq::mul(a.Y, b.ZZZ), S2 = HFq::mul(b.Y, a.ZZZ);
+  HFq P = HFq::sub(U2, U1), R = HFq::sub(S2, S1);
+  if (P.is_zero()) { if (R.is_zero()) return hdouble(a); return HXYZZ::infinity(); }
+  HFq PP = HFq::sqr(P), PPP = HFq::mul(P, PP), Q = HFq::mul(U1, PP);
+  HXYZZ r;
+  r.X = HFq::sub(HFq::sub(HFq::sqr(R), PPP), HFq::dbl(Q));
+  r.Y = HFq::sub(HFq::mul(R, HFq::sub(Q, r.X)), HFq::mul(S1, PPP));
+  r.ZZ = HFq::mul(HFq::mul(a.ZZ, b.ZZ), PP);
+  r.ZZZ = HFq::mul(HFq::mul(a.ZZZ, b.ZZZ), PPP);
+  return r;
+}
+
+// (x, y) affine of an XYZZ point; returns false for infinity
+inline bool hto_affine(const HXYZZ& p, HFq& x, HFq& y) {
+  if (p.is_inf()) return false;
+  HFq zi3 = HFq::inv(p.ZZZ);                 // 1/Z^3
+  HFq zi2 = HFq::sqr(HFq::mul(zi3, p.ZZ));    // (Z^2/Z^3)^2 = 1/Z^2
+  x = HFq::mul(p.X, zi2); y = HFq::mul(p.Y, zi3);
+  return true;
+}
+
+// Jacobian (X, Y, Z) as snarkVM's Projective stores it (144 bytes) <-> XYZZ
+inline HXYZZ hfrom_jacobian(const uint64_t* j18) {
+  HXYZZ r; HFq Z;
+  std::memcpy(r.X.l, j18, 48); std::memcpy(r.Y.l, j18 + 6, 48); std::memcpy(Z.l, j18 + 12, 48);
+  if (Z.is_zero()) return HXYZZ::infinity();
+  r.ZZ = HFq::sqr(Z); r.ZZZ = HFq::mul(r.ZZ, Z);
+  return r;
+}
+// Writes the affine-normalised point as Jacobian (x, y, 1); infinity as snarkVM's Projective::zero() = (1, 1, 0).
+inline void hstore_jacobian_normalized(uint64_t* j18, const HXYZZ& p) {
+  HFq x, y;
+  if (!hto_affine(p, x, y)) {
+    HFq o = HFq::one(); std::memcpy(j18, o.l, 48); std::memcpy(j18 + 6, o.l, 48); std::memset(j18 + 12, 0, 48); return;
+  }
+  HFq o = HFq::one();
+  std::memcpy(j18, x.l, 48); std::memcpy(j18 + 6, y.l, 48); std::memcpy(j18 + 12, o.l, 48);
+}
+
+}}  // namespace aleo_mi355x::host

@@ -1,0 +1,262 @@
+// ntt.hip — radix-2 number-theoretic transform over the BLS12-377 scalar field Fr for MI355X (gfx950).
+//
+// Replaces snarkvm-algorithms 0.14.5  algorithms/src/fft/domain.rs  EvaluationDomain::<Fr>::
+// {fft,ifft,coset_fft,coset_ifft}_in_place  [UPSTREAM-RECALL; pin /root/reference/Cargo.lock:2200], the second
+// operator of Varuna's prover.  Same function: out[k] = sum_j x[j] * w^(jk) with
+// w = TWO_ADIC_ROOT_OF_UNITY^(2^(47-lg_n)), natural order in and out; coset variants shift by g = 22;
+// the inverse multiplies by n^-1.  The schedule is GPU-first:
+//
+//   n = n1*n2*n3 (each <= 2^10).  Pass i runs all length-n_i DFTs of its axis inside LDS (one HBM read and one
+//   HBM write of the data per pass: 2-3 passes instead of lg_n), as radix-2 DIF butterflies over limb-planar
+//   LDS tiles (conflict-free 4-byte accesses), followed by the inter-pass twiddle w^(k*j_rest) taken from a
+//   two-level table (hi*lo).  Tiles are T adjacent transforms wide so every HBM access is a >=128-byte run; the
+//   last pass writes straight to the natural-order position (index-transposed store), so there is no separate
+//   bit-reversal pass.  Values stay lazily reduced in [0, 2r) (fp.h) and are made canonical at the final store.
+//
+// HBM traffic: 64 bytes per element per pass (read + write), algorithmic minimum 64 bytes per element.
+#include "ctx.h"
+#include "fp.h"
+#include "host_field.hpp"
+
+namespace aleo_mi355x {
+
+static constexpr uint32_t TILE_ELEMS = 2048;        // elements per LDS tile: 8 limb planes x 2048 x 4 B = 64 KiB
+static constexpr uint32_t INNER_MAX_LG = 10;        // longest in-LDS transform
+
+struct NttTables {
+  uint32_t lg_n = 0, lo_bits = 0;
+  void* d_inner = nullptr;     // w_{1024}^t, t < 512             (inner butterflies; shorter transforms stride it)
+  void* d_tw_hi = nullptr;     // w_n^(e_hi << lo_bits)
+  void* d_tw_lo = nullptr;     // w_n^(e_lo)
+  void* d_cs_hi = nullptr;     // coset powers: g^(j_hi << lo_bits)        (inverse: g^-(...))
+  void* d_cs_lo = nullptr;     // g^(j_lo)                                  (inverse: g^-(j_lo) * n^-1)
+  uint32_t scale[8];           // n^-1 (Montgomery): applied at the final store of a plain inverse transform
+};
+
+struct FrArg { uint32_t v[8]; };
+
+__device__ __forceinline__ uint32_t bitrev(uint32_t x, uint32_t bits) { return bits ? (__brev(x) >> (32 - bits)) : 0u; }
+
+// planar LDS tile: limb l of element e at lds[l * TILE_ELEMS + e]
+__device__ __forceinline__ Fr lds_load(const uint32_t* lds, uint32_t e) {
+  Fr r;
+#pragma unroll
+  for (int l = 0; l < 8; ++l) r.v[l] = lds[l * TILE_ELEMS + e];
+  return r;
+}
+__device__ __forceinline__ void lds_store(uint32_t* lds, uint32_t e, const Fr& a) {
+#pragma unroll
+  for (int l = 0; l < 8; ++l) lds[l * TILE_ELEMS + e] = a.v[l];
+}
+
+// w^e from the two-level table (one product, result < 2r)
+__device__ __forceinline__ Fr two_level(const char* hi, const char* lo, uint32_t e, uint32_t lo_bits) {
+  Fr a = load_fp<Fr>(hi + (size_t)(e >> lo_bits) * 32), b = load_fp<Fr>(lo + (size_t)(e & ((1u << lo_bits) - 1u)) * 32);
+  return Fr::mul(a, b);
+}
+
+// All radix-2 DIF stages of T length-L transforms held in the tile (row t at [t*L, (t+1)*L)).
+// Output k of row t ends at position t*L + bitrev(k).  Values in and out are < 2r.
+__device__ __forceinline__ void tile_dif(uint32_t* lds, uint32_t lgL, uint32_t T, const char* __restrict__ inner) {
+  const uint32_t L = 1u << lgL, nbf = (T * L) >> 1;
+  for (uint32_t s = 0; s < lgL; ++s) {
+    const uint32_t lgh = lgL - 1 - s, half = 1u << lgh;
+    for (uint32_t i = threadIdx.x; i < nbf; i += 256) {
+      uint32_t row = i >> (lgL - 1), bi = i & ((L >> 1) - 1u);
+      uint32_t grp = bi >> lgh, pos = bi & (half - 1u);
+      uint32_t i0 = row * L + (grp << (lgh + 1)) + pos, i1 = i0 + half;
+      Fr u = lds_load(lds, i0), v = lds_load(lds, i1);
+      Fr sum = Fr::cond_sub<2>(Fr::add(u, v));               // < 4r -> < 2r
+      Fr dif = Fr::sub<2>(u, v);                             // u + 2r - v < 4r
+      if (lgh) {                                             // twiddle w_{2*half}^pos = w_1024^(pos * 512/half)
+        Fr w = load_fp<Fr>(inner + (size_t)(pos << (INNER_MAX_LG - 1 - lgh)) * 32);
+        dif = Fr::mul(dif, w);                               // 4*1/13.7 + 1 -> < 2r
+      } else dif = Fr::cond_sub<2>(dif);
+      lds_store(lds, i0, sum); lds_store(lds, i1, dif);
+    }
+    __syncthreads();
+  }
+}
+
+// Pass over axis l of the view [A][L][Bn] (index = (a*L + l)*Bn + b), tile = one a, T adjacent b.
+// dst may alias src (same positions).  After the transform, element (k, b) is multiplied by w_n^(tw_scale*k*b).
+__global__ void __launch_bounds__(256) k_ntt_strided(const char* src, char* dst, uint32_t lgL, uint32_t lgBn, uint32_t lgT,
+                                                     uint32_t tw_scale, uint32_t lg_n, uint32_t lo_bits, const char* __restrict__ inner,
+                                                     const char* __restrict__ tw_hi, const char* __restrict__ tw_lo,
+                                                     const char* __restrict__ cs_hi, const char* __restrict__ cs_lo, int pre_coset) {
+  __shared__ uint32_t lds[8 * TILE_ELEMS];
+  const uint32_t L = 1u << lgL, T = 1u << lgT, tiles_per_a = 1u << (lgBn - lgT);
+  const uint32_t a = blockIdx.x / tiles_per_a, b0 = (blockIdx.x % tiles_per_a) << lgT;
+  const uint32_t nq = (T * L) << 1;
+  for (uint32_t q = threadIdx.x; q < nq; q += 256) {
+    uint32_t elem = q >> 1, hf = q & 1, t = elem & (T - 1u), l = elem >> lgT;
+    size_t gi = ((((size_t)a << lgL) + l) << lgBn) + b0 + t;
+    uint4 v = *(const uint4*)(src + gi * 32 + hf * 16);
+    uint32_t e = t * L + l, p = hf * 4;
+    lds[(p + 0) * TILE_ELEMS + e] = v.x; lds[(p + 1) * TILE_ELEMS + e] = v.y; lds[(p + 2) * TILE_ELEMS + e] = v.z; lds[(p + 3) * TILE_ELEMS + e] = v.w;
+  }
+  __syncthreads();
+  if (pre_coset) {   // coset_fft: x[j] *= g^j before the transform (only the first pass: A == 1, j = l*Bn + b)
+    for (uint32_t e = threadIdx.x; e < T * L; e += 256) {
+      uint32_t t = e >> lgL, l = e & (L - 1u);
+      uint32_t j = (l << lgBn) + b0 + t;
+      Fr x = lds_load(lds, e);
+      x = Fr::mul(x, two_level(cs_hi, cs_lo, j, lo_bits));   // 1*2/13.7+1 -> < 2r
+      lds_store(lds, e, x);
+    }
+    __syncthreads();
+  }
+  tile_dif(lds, lgL, T, inner);
+  const uint32_t nmask = (lg_n >= 32) ? 0xffffffffu : ((1u << lg_n) - 1u);
+  for (uint32_t e = threadIdx.x; e < T * L; e += 256) {
+    uint32_t t = e & (T - 1u), k = e >> lgT;
+    Fr x = lds_load(lds, t * L + bitrev(k, lgL));
+    uint32_t b = b0 + t;
+    uint32_t ex = (uint32_t)(((uint64_t)tw_scale * k * b) & nmask);
+    x = Fr::mul(x, two_level(tw_hi, tw_lo, ex, lo_bits));     // 2*2/13.7+1 -> < 2r
+    size_t gi = ((((size_t)a << lgL) + k) << lgBn) + b;
+    store_fp<Fr>(dst + gi * 32, x);
+  }
+}
+
+// Last pass: rows a = k1*n2 + k2 are contiguous (Bn == 1); tile = T adjacent k1 at one k2; output k of that row
+// goes to natural position k1 + n1*(k2 + n2*k).  src != dst unless n1 == n2 == 1.
+__global__ void __launch_bounds__(256) k_ntt_final(const char* src, char* dst, uint32_t lgL, uint32_t lgN1, uint32_t lgN2, uint32_t lgT,
+                                                   uint32_t lo_bits, const char* __restrict__ inner, const char* __restrict__ cs_hi, const char* __restrict__ cs_lo,
+                                                   int pre_coset, int post_coset, int do_scale, FrArg scale) {
+  __shared__ uint32_t lds[8 * TILE_ELEMS];
+  const uint32_t L = 1u << lgL, T = 1u << lgT;
+  const uint32_t tiles_k1 = 1u << (lgN1 - lgT);
+  const uint32_t k2 = blockIdx.x / tiles_k1, k10 = (blockIdx.x % tiles_k1) << lgT;
+  const uint32_t nq = (T * L) << 1;
+  for (uint32_t q = threadIdx.x; q < nq; q += 256) {
+    uint32_t elem = q >> 1, hf = q & 1, l = elem & (L - 1u), t = elem >> lgL;
+    size_t row = ((size_t)(k10 + t) << lgN2) + k2;
+    uint4 v = *(const uint4*)(src + ((row << lgL) + l) * 32 + hf * 16);
+    uint32_t e = t * L + l, p = hf * 4;
+    lds[(p + 0) * TILE_ELEMS + e] = v.x; lds[(p + 1) * TILE_ELEMS + e] = v.y; lds[(p + 2) * TILE_ELEMS + e] = v.z; lds[(p + 3) * TILE_ELEMS + e] = v.w;
+  }
+  __syncthreads();
+  if (pre_coset) {   // single-pass coset_fft: j = l
+    for (uint32_t e = threadIdx.x; e < T * L; e += 256) {
+      uint32_t l = e & (L - 1u);
+      Fr x = lds_load(lds, e);
+      x = Fr::mul(x, two_level(cs_hi, cs_lo, l, lo_bits));
+      lds_store(lds, e, x);
+    }
+    __syncthreads();
+  }
+  tile_dif(lds, lgL, T, inner);
+  Fr sc; for (int i = 0; i < 8; ++i) sc.v[i] = scale.v[i];
+  for (uint32_t e = threadIdx.x; e < T * L; e += 256) {
+    uint32_t t = e & (T - 1u), k = e >> lgT;
+    Fr x = lds_load(lds, t * L + bitrev(k, lgL));
+    size_t o = (size_t)(k10 + t) + (((size_t)k2 + ((size_t)k << lgN2)) << lgN1);
+    if (post_coset) x = Fr::mul(x, two_level(cs_hi, cs_lo, (uint32_t)o, lo_bits));   // g^-o * n^-1
+    else if (do_scale) x = Fr::mul(x, sc);
+    x = Fr::reduce(x);
+    store_fp<Fr>(dst + o * 32, x);
+  }
+}
+
+__global__ void __launch_bounds__(256) k_bitrev_copy(const char* __restrict__ src, char* __restrict__ dst, uint32_t lg_n) {
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= ((size_t)1 << lg_n)) return;
+  uint32_t j = bitrev((uint32_t)i, lg_n);
+  const uint4* s = (const uint4*)(src + i * 32); uint4* d = (uint4*)(dst + (size_t)j * 32);
+  d[0] = s[0]; d[1] = s[1];
+}
+
+// ---- host side: tables -----------------------------------------------------------------------------
+static int32_t upload_fr(void** d, const std::vector<host::HFr>& v) {
+  HIPCHK(hipMalloc(d, v.size() * 32));
+  HIPCHK(hipMemcpy(*d, v.data(), v.size() * 32, hipMemcpyHostToDevice));
+  return ALEO_MI355X_OK;
+}
+
+static int32_t build_tables(NttTables* t, uint32_t lg_n, int direction) {
+  using namespace host;
+  t->lg_n = lg_n; t->lo_bits = (lg_n + 1) / 2;
+  const uint32_t hi_bits = lg_n - t->lo_bits;
+  HFr root; std::memcpy(root.l, FR_TWO_ADIC_ROOT_CANON, 32); root = HFr::to_mont(root);
+  // w_n = TWO_ADIC_ROOT^(2^(47 - lg_n)); w_1024 likewise
+  HFr wn = root; for (uint32_t i = lg_n; i < (uint32_t)FR_TWO_ADICITY; ++i) wn = HFr::sqr(wn);
+  HFr w1k = root; for (uint32_t i = INNER_MAX_LG; i < (uint32_t)FR_TWO_ADICITY; ++i) w1k = HFr::sqr(w1k);
+  HFr g = HFr::from_u64(FR_GENERATOR);
+  HFr ninv = HFr::inv(HFr::from_u64((uint64_t)1 << lg_n));
+  if (direction == ALEO_NTT_INVERSE) { wn = HFr::inv(wn); w1k = HFr::inv(w1k); g = HFr::inv(g); }
+  const HFr lo_scale = direction == ALEO_NTT_INVERSE ? ninv : HFr::one();
+  std::memcpy(t->scale, ninv.l, 32);
+  std::vector<HFr> inner(512), hi((size_t)1 << hi_bits), lo((size_t)1 << t->lo_bits), chi((size_t)1 << hi_bits), clo((size_t)1 << t->lo_bits);
+  inner[0] = HFr::one(); for (size_t i = 1; i < inner.size(); ++i) inner[i] = HFr::mul(inner[i - 1], w1k);
+  auto fill = [&](std::vector<HFr>& v, HFr first, HFr step) { v[0] = first; for (size_t i = 1; i < v.size(); ++i) v[i] = HFr::mul(v[i - 1], step); };
+  HFr wn_hi = wn, g_hi = g;
+  for (uint32_t i = 0; i < t->lo_bits; ++i) { wn_hi = HFr::sqr(wn_hi); g_hi = HFr::sqr(g_hi); }
+  fill(lo, HFr::one(), wn); fill(hi, HFr::one(), wn_hi);
+  fill(clo, lo_scale, g); fill(chi, HFr::one(), g_hi);
+  int32_t rc;
+  if ((rc = upload_fr(&t->d_inner, inner))) return rc;
+  if ((rc = upload_fr(&t->d_tw_hi, hi))) return rc;
+  if ((rc = upload_fr(&t->d_tw_lo, lo))) return rc;
+  if ((rc = upload_fr(&t->d_cs_hi, chi))) return rc;
+  if ((rc = upload_fr(&t->d_cs_lo, clo))) return rc;
+  return ALEO_MI355X_OK;
+}
+
+static inline uint32_t umin(uint32_t a, uint32_t b) { return a < b ? a : b; }
+
+int32_t ntt_run(Ctx* c, void* d_inout, uint32_t lg_n, int32_t order, int32_t direction, int32_t type, hipStream_t s) {
+  if (lg_n == 0) return ALEO_MI355X_OK;     // n = 1: every variant is the identity (g^0 = 1, 1^-1 = 1)
+  const size_t n = (size_t)1 << lg_n, bytes = n * 32;
+  int32_t rc;
+  uint64_t key = ((uint64_t)lg_n << 1) | (uint64_t)direction;
+  NttTables* t = nullptr;
+  auto it = c->ntt_tables.find(key);
+  if (it == c->ntt_tables.end()) {
+    t = new NttTables();
+    if ((rc = build_tables(t, lg_n, direction))) { delete t; return rc; }
+    c->ntt_tables[key] = t;
+  } else t = it->second;
+  if ((rc = c->ntt_tmp.reserve(bytes))) return rc;
+  char* buf = (char*)d_inout; char* tmp = c->ntt_tmp.as<char>();
+  const bool in_rev = (order == ALEO_NTT_ORDER_RN || order == ALEO_NTT_ORDER_RR), out_rev = (order == ALEO_NTT_ORDER_NR || order == ALEO_NTT_ORDER_RR);
+  const uint32_t gperm = (uint32_t)((n + 255) / 256);
+  if (in_rev) {
+    hipLaunchKernelGGL(k_bitrev_copy, dim3(gperm), dim3(256), 0, s, buf, tmp, lg_n);
+    HIPCHK(hipMemcpyAsync(buf, tmp, bytes, hipMemcpyDeviceToDevice, s));
+  }
+  const int coset = (type == ALEO_NTT_COSET), inv = (direction == ALEO_NTT_INVERSE);
+  const int pre_coset = coset && !inv, post_coset = coset && inv, do_scale = inv && !coset;   // cs_lo carries n^-1 for coset_ifft
+  FrArg sc; std::memcpy(sc.v, t->scale, 32);
+  const char* inner = (const char*)t->d_inner; const char* twh = (const char*)t->d_tw_hi; const char* twl = (const char*)t->d_tw_lo;
+  const char* csh = (const char*)t->d_cs_hi; const char* csl = (const char*)t->d_cs_lo;
+  uint32_t npass = lg_n <= INNER_MAX_LG ? 1 : (lg_n <= 18 ? 2 : 3);
+  uint32_t s1 = 0, s2 = 0, s3 = 0;
+  if (npass == 1) s3 = lg_n;
+  else if (npass == 2) { s1 = (lg_n + 1) / 2; s3 = lg_n - s1; }
+  else { s1 = (lg_n + 2) / 3; s2 = (lg_n - s1 + 1) / 2; s3 = lg_n - s1 - s2; }
+  auto lgT_for = [](uint32_t lgL, uint32_t lg_limit) { uint32_t lgT = 11 - lgL; return lgT < lg_limit ? lgT : lg_limit; };
+  if (npass == 1) {
+    hipLaunchKernelGGL(k_ntt_final, dim3(1), dim3(256), 0, s, buf, buf, s3, 0u, 0u, 0u, t->lo_bits, inner, csh, csl, pre_coset, post_coset, do_scale, sc);
+  } else if (npass == 2) {
+    uint32_t lgBn = s3, lgT = lgT_for(s1, lgBn);
+    hipLaunchKernelGGL(k_ntt_strided, dim3(1u << (lgBn - lgT)), dim3(256), 0, s, buf, tmp, s1, lgBn, lgT, 1u, lg_n, t->lo_bits, inner, twh, twl, csh, csl, pre_coset);
+    uint32_t lgTf = lgT_for(s3, s1);
+    hipLaunchKernelGGL(k_ntt_final, dim3(1u << (s1 - lgTf)), dim3(256), 0, s, tmp, buf, s3, s1, 0u, lgTf, t->lo_bits, inner, csh, csl, 0, post_coset, do_scale, sc);
+  } else {
+    uint32_t lgBn1 = s2 + s3, lgT1 = lgT_for(s1, lgBn1);
+    hipLaunchKernelGGL(k_ntt_strided, dim3(1u << (lgBn1 - lgT1)), dim3(256), 0, s, buf, buf, s1, lgBn1, lgT1, 1u, lg_n, t->lo_bits, inner, twh, twl, csh, csl, pre_coset);
+    uint32_t lgBn2 = s3, lgT2 = lgT_for(s2, lgBn2);
+    hipLaunchKernelGGL(k_ntt_strided, dim3((1u << s1) << (lgBn2 - lgT2)), dim3(256), 0, s, buf, tmp, s2, lgBn2, lgT2, 1u << s1, lg_n, t->lo_bits, inner, twh, twl, csh, csl, 0);
+    uint32_t lgTf = lgT_for(s3, s1);
+    hipLaunchKernelGGL(k_ntt_final, dim3((1u << s2) << (s1 - lgTf)), dim3(256), 0, s, tmp, buf, s3, s1, s2, lgTf, t->lo_bits, inner, csh, csl, 0, post_coset, do_scale, sc);
+  }
+  if (out_rev) {
+    hipLaunchKernelGGL(k_bitrev_copy, dim3(gperm), dim3(256), 0, s, buf, tmp, lg_n);
+    HIPCHK(hipMemcpyAsync(buf, tmp, bytes, hipMemcpyDeviceToDevice, s));
+  }
+  HIPCHK(hipGetLastError());
+  return ALEO_MI355X_OK;
+}
+
+}  // namespace aleo_mi355x

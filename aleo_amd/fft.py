@@ -1,0 +1,58 @@
+"""Host-side mirror of snarkvm_algorithms::fft::EvaluationDomain<Fr> for the MI355X backend.
+
+Reference interface (snarkVM 0.14.5, algorithms/src/fft/domain.rs [UPSTREAM-RECALL]; used by Varuna's prover behind
+/root/reference/rust/src/program/execute.rs:74):  EvaluationDomain::new(num_coeffs) -> Option<Self>;
+fft / ifft / coset_fft / coset_ifft (and *_in_place) on slices of Fr in Montgomery form; `fft` zero-pads to `size`.
+Arrays are uint64[n,4] (Montgomery limbs, as snarkVM stores Fr)."""
+from __future__ import annotations
+import ctypes
+import numpy as np
+from ._lib import lib, check
+
+ORDER_NN, ORDER_NR, ORDER_RN, ORDER_RR = 0, 1, 2, 3
+FORWARD, INVERSE = 0, 1
+STANDARD, COSET = 0, 1
+FR_TWO_ADICITY = 47
+
+
+def _p(a): return a.ctypes.data_as(ctypes.c_void_p)
+
+
+class EvaluationDomain:
+    def __init__(self, num_coeffs: int):
+        size = 1
+        while size < num_coeffs: size *= 2
+        lg = size.bit_length() - 1
+        if lg > FR_TWO_ADICITY:           # reference: EvaluationDomain::new returns None
+            raise ValueError('domain larger than the two-adicity of Fr')
+        self.size, self.log_size_of_group = size, lg
+
+    @classmethod
+    def new(cls, num_coeffs: int):
+        try: return cls(num_coeffs)
+        except ValueError: return None
+
+    def _run(self, x: np.ndarray, direction: int, type_: int, order: int = ORDER_NN) -> np.ndarray:
+        x = np.ascontiguousarray(x, dtype=np.uint64).reshape(-1, 4)
+        if x.shape[0] > self.size: raise ValueError('more coefficients than the domain size')
+        buf = np.zeros((self.size, 4), dtype=np.uint64); buf[:x.shape[0]] = x     # resize(size, zero) as the reference
+        check(lib().aleo_mi355x_ntt_fr(_p(buf), self.log_size_of_group, order, direction, type_), 'ntt_fr')
+        return buf
+
+    def fft(self, coeffs): return self._run(coeffs, FORWARD, STANDARD)
+    def ifft(self, evals): return self._run(evals, INVERSE, STANDARD)
+    def coset_fft(self, coeffs): return self._run(coeffs, FORWARD, COSET)
+    def coset_ifft(self, evals): return self._run(evals, INVERSE, COSET)
+
+    def fft_in_place(self, x: np.ndarray): x[...] = self.fft(x)
+    def ifft_in_place(self, x: np.ndarray): x[...] = self.ifft(x)
+    def coset_fft_in_place(self, x: np.ndarray): x[...] = self.coset_fft(x)
+    def coset_ifft_in_place(self, x: np.ndarray): x[...] = self.coset_ifft(x)
+
+    def ntt(self, x, order=ORDER_NN, direction=FORWARD, type_=STANDARD):
+        """The snarkvm_algorithms_cuda::NTT shape: explicit order / direction / type."""
+        return self._run(x, direction, type_, order)
+
+    def ntt_device(self, d_ptr: int, order=ORDER_NN, direction=FORWARD, type_=STANDARD, stream: int = 0):
+        check(lib().aleo_mi355x_ntt_fr_device(ctypes.c_void_p(d_ptr), self.log_size_of_group, order, direction, type_,
+                                              ctypes.c_void_p(stream)), 'ntt_fr_device')

@@ -1,0 +1,31 @@
+"""Host-side mirror of snarkvm_algorithms::polycommit::kzg10::KZG10::commit (the non-hiding MSM part).
+
+Reference (snarkVM 0.14.5 algorithms/src/polycommit/kzg10/mod.rs [UPSTREAM-RECALL]): coefficients (Montgomery Fr)
+-> canonical bigints -> VariableBase::msm(powers_of_beta_g[..len], coeffs) -> to_affine().  The conversion runs on the
+device, so a polynomial that is already in HBM (e.g. straight from an iNTT) is committed without a host round trip."""
+from __future__ import annotations
+import ctypes
+import numpy as np
+from ._lib import lib, check
+from .msm import PinnedBases
+
+
+def _p(a): return a.ctypes.data_as(ctypes.c_void_p)
+
+
+class KZG10:
+    @staticmethod
+    def commit(powers: PinnedBases, coeffs_mont: np.ndarray) -> np.ndarray:
+        c = np.ascontiguousarray(coeffs_mont, dtype=np.uint64).reshape(-1, 4)
+        n = c.shape[0]
+        while n and not c[n - 1].any(): n -= 1          # skip leading zeros, as the reference does
+        out = np.zeros(104, dtype=np.uint8)
+        check(lib().aleo_mi355x_kzg_commit(_p(out), powers.handle, _p(c), n), 'kzg_commit')
+        return out
+
+    @staticmethod
+    def commit_device(powers: PinnedBases, d_coeffs_ptr: int, n: int, stream: int = 0) -> np.ndarray:
+        out = np.zeros(104, dtype=np.uint8)
+        check(lib().aleo_mi355x_kzg_commit_device(_p(out), powers.handle, ctypes.c_void_p(d_coeffs_ptr), n,
+                                                  ctypes.c_void_p(stream)), 'kzg_commit_device')
+        return out

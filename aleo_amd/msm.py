@@ -1,0 +1,87 @@
+"""Host-side mirror of snarkvm_algorithms::msm::VariableBase for the MI355X backend.
+
+Reference interface (snarkVM 0.14.5, algorithms/src/msm/variable_base/mod.rs [UPSTREAM-RECALL], reached from
+/root/reference/rust/src/program/execute.rs:74):
+    VariableBase::msm(bases: &[G1Affine], scalars: &[BigInteger256]) -> G1Projective
+Arrays: bases uint8[n,104] (snarkVM Affine layout) or uint8[n,96]; scalars uint64[n,4] canonical;
+result uint64[18] = Jacobian (x, y, z), affine-normalised (z = 1, or (1,1,0) for the identity).
+"""
+from __future__ import annotations
+import ctypes
+import numpy as np
+from ._lib import lib, check
+
+
+def _p(a): return a.ctypes.data_as(ctypes.c_void_p)
+
+
+class PinnedBases:
+    """A base set resident in HBM (one SRS / proving key).  Mirrors the lifetime of an Arc<Vec<G1Affine>>."""
+
+    def __init__(self, bases: np.ndarray):
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        assert bases.ndim == 2 and bases.shape[1] in (96, 104)
+        self.n = bases.shape[0]
+        h = ctypes.c_uint64(0)
+        check(lib().aleo_mi355x_bases_pin(_p(bases), bases.shape[1], self.n, ctypes.byref(h)), 'bases_pin')
+        self.handle = h.value
+
+    def close(self):
+        if self.handle:
+            lib().aleo_mi355x_bases_unpin(self.handle); self.handle = 0
+
+    def __enter__(self): return self
+    def __exit__(self, *a): self.close()
+    def __del__(self):
+        try: self.close()
+        except Exception: pass
+
+
+class VariableBase:
+    @staticmethod
+    def msm(bases, scalars: np.ndarray) -> np.ndarray:
+        """sum_i scalars[i] * bases[i]; zips to the shorter length like the reference."""
+        scalars = np.ascontiguousarray(scalars, dtype=np.uint64).reshape(-1, 4)
+        out = np.zeros(18, dtype=np.uint64)
+        if isinstance(bases, PinnedBases):
+            n = min(bases.n, scalars.shape[0])
+            check(lib().aleo_mi355x_msm_g1_pinned(_p(out), bases.handle, _p(scalars), n), 'msm_g1_pinned')
+            return out
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        n = min(bases.shape[0], scalars.shape[0])
+        stride = bases.shape[1] if bases.ndim == 2 and bases.shape[0] else 104
+        check(lib().aleo_mi355x_msm_g1(_p(out), _p(bases), stride, _p(scalars), n), 'msm_g1')
+        return out
+
+    @staticmethod
+    def msm_device(bases: PinnedBases, d_scalars_ptr: int, n: int, stream: int = 0) -> np.ndarray:
+        """Scalars already in HBM (device pointer, e.g. torch tensor .data_ptr())."""
+        out = np.zeros(18, dtype=np.uint64)
+        check(lib().aleo_mi355x_msm_g1_device(_p(out), bases.handle, ctypes.c_void_p(d_scalars_ptr), n,
+                                              ctypes.c_void_p(stream)), 'msm_g1_device')
+        return out
+
+
+def g1_sum(points: np.ndarray) -> np.ndarray:
+    """Group sum of Jacobian points uint64[k,18] (the local add after the all-gather of per-GPU partials)."""
+    pts = np.ascontiguousarray(points, dtype=np.uint64).reshape(-1, 18)
+    out = np.zeros(18, dtype=np.uint64)
+    check(lib().aleo_mi355x_g1_sum(_p(out), _p(pts), pts.shape[0]), 'g1_sum')
+    return out
+
+
+def last_msm_timing() -> dict:
+    buf = (ctypes.c_double * 5)()
+    k = lib().aleo_mi355x_last_msm_timing(buf, 5)
+    names = ['total_ms', 'sort_ms', 'accum_ms', 'reduce_ms', 'host_ms']
+    return {names[i]: buf[i] for i in range(k)}
+
+
+def fq_mul(a: np.ndarray, b: np.ndarray) -> np.ndarray:
+    a = np.ascontiguousarray(a, dtype=np.uint64).reshape(-1, 6); b = np.ascontiguousarray(b, dtype=np.uint64).reshape(-1, 6)
+    r = np.zeros_like(a); check(lib().aleo_mi355x_fq_mul(_p(r), _p(a), _p(b), a.shape[0]), 'fq_mul'); return r
+
+
+def fr_mul(a: np.ndarray, b: np.ndarray) -> np.ndarray:
+    a = np.ascontiguousarray(a, dtype=np.uint64).reshape(-1, 4); b = np.ascontiguousarray(b, dtype=np.uint64).reshape(-1, 4)
+    r = np.zeros_like(a); check(lib().aleo_mi355x_fr_mul(_p(r), _p(a), _p(b), a.shape[0]), 'fr_mul'); return r

@@ -1,0 +1,111 @@
+/*
+ * aleo_mi355x.h — C ABI of libaleo_mi355x.so: the MI355X (gfx950) backend for the two operators that dominate
+ * the Aleo SDK's execute/prove path:
+ *
+ *   a1  snarkvm_algorithms::msm::VariableBase::msm::<G1Affine>      (BLS12-377 G1 Pippenger MSM)
+ *   a2  snarkvm_algorithms::fft::EvaluationDomain::<Fr>::{fft,ifft,coset_fft,coset_ifft}_in_place
+ *
+ * Reference interfaces this ABI replaces.  The prover is crates.io snarkVM =0.14.5 (pins:
+ * /root/reference/Cargo.toml:28-53, /root/reference/Cargo.lock:2200 snarkvm-algorithms), entered from
+ *   /root/reference/rust/src/program/execute.rs:74   trace.prove_execution::<A,_>(…)
+ *   /root/reference/rust/src/program/execute.rs:177  vm.execute(…)
+ *   /root/reference/rust/src/program/transfer.rs:99  vm.execute(… "credits.aleo","transfer_public" …)
+ * and the seam is the one upstream's optional `cuda` feature uses [UPSTREAM-RECALL]:
+ *   algorithms/src/msm/variable_base/mod.rs   VariableBase::msm  -> snarkvm_algorithms_cuda::msm(bases, scalars)
+ *   algorithms/src/fft/domain.rs              in_order_{fft,ifft}_in_place -> snarkvm_algorithms_cuda::NTT(size, data,
+ *                                             NTTInputOutputOrder, NTTDirection, NTTType)
+ * with the same contract: a non-zero return means "not computed" and the Rust caller falls back to its CPU path.
+ * INTEGRATION.md shows the Rust `extern "C"` block a maintainer adds on the snarkVM side.
+ *
+ * Data layouts are snarkVM's in-memory layouts (no conversion at the boundary):
+ *   Fr      4 x u64 little-endian limbs, Montgomery form (R = 2^256)                         32 bytes
+ *   scalar  BigInteger256: 4 x u64 little-endian limbs, CANONICAL (non-Montgomery), < r      32 bytes
+ *   G1Affine {x: Fq, y: Fq, infinity: bool}: 6+6 x u64 Montgomery (R = 2^384) + flag byte    stride 104
+ *            (stride 96 = x,y only, no flag, is also accepted)
+ *   G1Projective (Jacobian) {x, y, z: Fq}                                                    144 bytes
+ * MSM results are returned affine-normalised as Jacobian (x, y, 1), or (1, 1, 0) for the identity; compare
+ * group elements after to_affine(), never raw Jacobian limbs.
+ *
+ * Threading: every entry point may be called concurrently from many host threads (snarkVM commits the
+ * polynomials of one round from a rayon pool); calls on one device serialise on an internal lock.
+ * Ownership: the caller owns every buffer; nothing is retained after return except through bases_pin.
+ * No exceptions cross the boundary.
+ */
+#ifndef ALEO_MI355X_H
+#define ALEO_MI355X_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* status codes (0 = OK; anything else: caller recomputes on CPU) */
+#define ALEO_MI355X_OK 0
+#define ALEO_MI355X_ERR_NO_DEVICE 1      /* no gfx950 device / HIP runtime failure at init */
+#define ALEO_MI355X_ERR_BAD_ARG 2        /* null pointer, bad stride, lg_n out of range, … */
+#define ALEO_MI355X_ERR_HIP 3            /* a HIP call failed; see aleo_mi355x_last_error() */
+#define ALEO_MI355X_ERR_BAD_HANDLE 4
+#define ALEO_MI355X_ERR_OOM 5
+
+/* NTT enums: mirror snarkvm_algorithms_cuda::{NTTInputOutputOrder, NTTDirection, NTTType} */
+#define ALEO_NTT_ORDER_NN 0   /* natural in, natural out (what fft_in_place exposes) */
+#define ALEO_NTT_ORDER_NR 1   /* natural in, bit-reversed out */
+#define ALEO_NTT_ORDER_RN 2   /* bit-reversed in, natural out */
+#define ALEO_NTT_ORDER_RR 3
+#define ALEO_NTT_FORWARD 0
+#define ALEO_NTT_INVERSE 1    /* multiplies by size_inv, as EvaluationDomain::ifft_in_place */
+#define ALEO_NTT_STANDARD 0
+#define ALEO_NTT_COSET 1      /* coset shift g = Fr::multiplicative_generator() = 22 */
+
+/* Selects and initialises a device (-1 = current HIP device).  Idempotent, thread-safe; every other entry
+ * point initialises lazily on the current device if this was never called. */
+int32_t aleo_mi355x_init(int32_t device);
+
+/* a1 — VariableBase::msm(bases: &[G1Affine], scalars: &[BigInteger256]) -> G1Projective.
+ * Host pointers.  n = min(len(bases), len(scalars)) is the caller's job (the reference zips the slices). */
+int32_t aleo_mi355x_msm_g1(void* out_jacobian, const void* bases, size_t base_stride, const void* scalars, size_t n);
+
+/* SRS residency: upload + convert a base set once per proving key (SURVEY.md §5 "device-resident SRS").
+ * The handle stays valid until unpin.  bases: host pointer. */
+int32_t aleo_mi355x_bases_pin(const void* bases, size_t base_stride, size_t n, uint64_t* handle);
+int32_t aleo_mi355x_bases_unpin(uint64_t handle);
+/* MSM over the first n pinned bases; scalars: host pointer. */
+int32_t aleo_mi355x_msm_g1_pinned(void* out_jacobian, uint64_t handle, const void* scalars, size_t n);
+/* Same, scalars already resident in device memory (hipMalloc'ed or a torch CUDA tensor's data_ptr).
+ * The result (144 bytes) is written to HOST memory.  `stream` is a hipStream_t or NULL. */
+int32_t aleo_mi355x_msm_g1_device(void* out_jacobian, uint64_t handle, const void* d_scalars, size_t n, void* stream);
+/* Sum of `count` Jacobian points (144 bytes each, host memory): the local group-add that follows the
+ * all-gather of per-GPU partial MSM results.  Result affine-normalised as above. */
+int32_t aleo_mi355x_g1_sum(void* out_jacobian, const void* jacobian_points, size_t count);
+
+/* a2 — EvaluationDomain NTT over Fr, in place, n = 2^lg_n elements (lg_n <= 30), host pointer. */
+int32_t aleo_mi355x_ntt_fr(void* inout, uint32_t lg_n, int32_t order, int32_t direction, int32_t type);
+/* Same on device-resident data (in place). */
+int32_t aleo_mi355x_ntt_fr_device(void* d_inout, uint32_t lg_n, int32_t order, int32_t direction, int32_t type, void* stream);
+
+/* a5 — KZG10::commit shape: coefficients in Montgomery form (as polynomials are stored), converted to canonical
+ * bigints on the device, MSM over the first n pinned bases; affine result as snarkVM Affine (104 bytes, host). */
+int32_t aleo_mi355x_kzg_commit(void* out_affine104, uint64_t handle, const void* coeffs_mont, size_t n);
+/* Device-resident coefficients (e.g. straight out of aleo_mi355x_ntt_fr_device: no host round trip). */
+int32_t aleo_mi355x_kzg_commit_device(void* out_affine104, uint64_t handle, const void* d_coeffs_mont, size_t n, void* stream);
+
+/* Element-wise field products on the device (host pointers): r[i] = a[i]*b[i], Montgomery form, canonical
+ * output.  Used by the parity tests to pin the device arithmetic against the oracle limb for limb. */
+int32_t aleo_mi355x_fq_mul(void* r, const void* a, const void* b, size_t n);
+int32_t aleo_mi355x_fr_mul(void* r, const void* a, const void* b, size_t n);
+
+/* Per-call instrumentation of the last MSM on this thread's device: milliseconds per phase
+ * [0] total device time, [1] digit/sort, [2] bucket accumulation, [3] bucket reduction, [4] host tail.
+ * Returns the number of doubles written (<= cap). */
+int32_t aleo_mi355x_last_msm_timing(double* out_ms, int32_t cap);
+
+const char* aleo_mi355x_strerror(int32_t status);
+const char* aleo_mi355x_last_error(void);   /* thread-local detail string of the last failure */
+const char* aleo_mi355x_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ALEO_MI355X_H */
