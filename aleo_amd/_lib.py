@@ -9,6 +9,7 @@ LIB_PATH = os.path.join(_HERE, 'lib', 'libaleo_mi355x.so')
 
 EXPORTS = [
     'aleo_mi355x_init', 'aleo_mi355x_msm_g1', 'aleo_mi355x_bases_pin', 'aleo_mi355x_bases_unpin',
+    'aleo_mi355x_bases_generate', 'aleo_mi355x_bases_download',
     'aleo_mi355x_msm_g1_pinned', 'aleo_mi355x_msm_g1_device', 'aleo_mi355x_g1_sum', 'aleo_mi355x_ntt_fr',
     'aleo_mi355x_ntt_fr_device', 'aleo_mi355x_kzg_commit', 'aleo_mi355x_kzg_commit_device', 'aleo_mi355x_fq_mul',
     'aleo_mi355x_fr_mul', 'aleo_mi355x_last_msm_timing', 'aleo_mi355x_strerror', 'aleo_mi355x_last_error',
@@ -30,6 +31,13 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise AleoMi355xError(f'{LIB_PATH} not built: run `python -c "import __graft_entry__ as g; g.build()"` '
                               '(aleo_amd/csrc/build.sh).  There is no CPU fallback.')
+    # PyTorch-ROCm is the plumbing for device memory / streams / torch.distributed and ships its own HIP runtime
+    # (libamdhip64.so with the same SONAME as /opt/rocm's).  Load torch's first so one process never ends up with
+    # /opt/rocm's runtime under torch: that combination makes torch report "No HIP GPUs are available".
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
     L = ctypes.CDLL(LIB_PATH)
     vp, sz, i32, u32, u64 = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int32, ctypes.c_uint32, ctypes.c_uint64
     sig = {
@@ -37,6 +45,8 @@ def lib():
         'aleo_mi355x_msm_g1': ([vp, vp, sz, vp, sz], i32),
         'aleo_mi355x_bases_pin': ([vp, sz, sz, ctypes.POINTER(u64)], i32),
         'aleo_mi355x_bases_unpin': ([u64], i32),
+        'aleo_mi355x_bases_generate': ([vp, u64, sz, ctypes.POINTER(u64)], i32),
+        'aleo_mi355x_bases_download': ([u64, sz, sz, vp], i32),
         'aleo_mi355x_msm_g1_pinned': ([vp, u64, vp, sz], i32),
         'aleo_mi355x_msm_g1_device': ([vp, u64, vp, sz, vp], i32),
         'aleo_mi355x_g1_sum': ([vp, vp, sz], i32),

@@ -125,6 +125,33 @@ int32_t aleo_mi355x_bases_pin(const void* bases, size_t base_stride, size_t n, u
   } catch (...) { return ALEO_MI355X_ERR_HIP; }
 }
 
+int32_t aleo_mi355x_bases_generate(const void* base104, uint64_t first, size_t n, uint64_t* handle) {
+  try {
+    if (!base104 || !handle) return ALEO_MI355X_ERR_BAD_ARG;
+    API_BEGIN
+    PinnedBases pb; int32_t rc = generate_multiples(c, base104, first, n, &pb);
+    if (rc) return rc;
+    uint64_t h = c->next_handle++; c->bases[h] = pb; *handle = h;
+    return ALEO_MI355X_OK;
+  } catch (...) { return ALEO_MI355X_ERR_HIP; }
+}
+
+int32_t aleo_mi355x_bases_download(uint64_t handle, size_t offset, size_t n, void* out104) {
+  try {
+    if (!out104 && n) return ALEO_MI355X_ERR_BAD_ARG;
+    API_BEGIN
+    auto it = c->bases.find(handle);
+    if (it == c->bases.end()) { g_last_error = "unknown bases handle"; return ALEO_MI355X_ERR_BAD_HANDLE; }
+    if (offset + n > it->second.n) { g_last_error = "bases_download: range"; return ALEO_MI355X_ERR_BAD_ARG; }
+    std::vector<uint8_t> xy(n * 96 + 1), inf(n + 1, 0);
+    HIPCHK(hipMemcpy(xy.data(), (const char*)it->second.d_xy + offset * 96, n * 96, hipMemcpyDeviceToHost));
+    if (it->second.d_inf) HIPCHK(hipMemcpy(inf.data(), it->second.d_inf + offset, n, hipMemcpyDeviceToHost));
+    uint8_t* o = (uint8_t*)out104;
+    for (size_t i = 0; i < n; ++i) { std::memcpy(o + i * 104, &xy[i * 96], 96); std::memset(o + i * 104 + 96, 0, 8); o[i * 104 + 96] = inf[i]; }
+    return ALEO_MI355X_OK;
+  } catch (...) { return ALEO_MI355X_ERR_HIP; }
+}
+
 int32_t aleo_mi355x_bases_unpin(uint64_t handle) {
   try { API_BEGIN return unpin_locked(c, handle); } catch (...) { return ALEO_MI355X_ERR_HIP; }
 }
@@ -232,8 +259,8 @@ int32_t aleo_mi355x_last_msm_timing(double* out_ms, int32_t cap) {
   try {
     if (!out_ms || cap <= 0) return 0;
     API_BEGIN
-    double v[5] = {c->last_msm.total, c->last_msm.sort, c->last_msm.accum, c->last_msm.reduce, c->last_msm.host};
-    int32_t k = cap < 5 ? cap : 5;
+    double v[6] = {c->last_msm.total, c->last_msm.sort, c->last_msm.accum, c->last_msm.reduce, c->last_msm.host, c->last_msm.accum_kernel};
+    int32_t k = cap < 6 ? cap : 6;
     for (int32_t i = 0; i < k; ++i) out_ms[i] = v[i];
     return k;
   } catch (...) { return 0; }

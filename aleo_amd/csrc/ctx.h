@@ -44,7 +44,7 @@ struct PinnedBases {
   size_t n = 0;
 };
 
-struct MsmTiming { double total = 0, sort = 0, accum = 0, reduce = 0, host = 0; };
+struct MsmTiming { double total = 0, sort = 0, accum = 0, reduce = 0, host = 0, accum_kernel = 0; };
 
 struct NttTables;   // ntt.hip
 
@@ -52,7 +52,7 @@ struct Ctx {
   int device = -1;
   hipStream_t stream = nullptr;
   std::mutex mu;                       // serialises calls on this device
-  hipEvent_t ev[6] = {};
+  hipEvent_t ev[8] = {};
   // MSM workspaces
   DevBuf hist, scan_local, scan_blk, sorted, partial, task_g, meta, vbuf, scalars_stage, out_stage;
   void* h_pinned = nullptr; size_t h_pinned_cap = 0;    // pinned host staging for small D2H results
@@ -69,6 +69,7 @@ int32_t ensure_host_pinned(Ctx* c, size_t bytes);
 int32_t msm_run(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, const void* d_scalars, size_t n, bool scalars_are_mont, hipStream_t s);
 int32_t launch_fq_mul(Ctx* c, void* r, const void* a, const void* b, size_t n);
 int32_t launch_fr_mul(Ctx* c, void* r, const void* a, const void* b, size_t n);
+int32_t generate_multiples(Ctx* c, const void* base104, uint64_t first, size_t n, PinnedBases* out);
 // ntt.hip
 int32_t ntt_run(Ctx* c, void* d_inout, uint32_t lg_n, int32_t order, int32_t direction, int32_t type, hipStream_t s);
 

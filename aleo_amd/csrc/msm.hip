@@ -322,8 +322,10 @@ int32_t msm_run(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, const void* 
   HIPCHK(hipStreamSynchronize(s));
   const uint32_t NT = h_meta[0], max_m = h_meta[1];
   if (NT > slices_max) { g_last_error = "msm: internal slice count overflow"; return ALEO_MI355X_ERR_HIP; }
+  HIPCHK(hipEventRecord(c->ev[6], s));
   if (NT) {
     hipLaunchKernelGGL(k_accum, dim3((NT + 255) / 256), dim3(256), 0, s, bases, sorted, hist, scan_local, scan_blk, M, P.T0, meta, partial, task_g);
+    HIPCHK(hipEventRecord(c->ev[5], s));
     for (uint32_t pass = 0, L = max_m; L > 1; ++pass, L = (L + 1) >> 1)
       hipLaunchKernelGGL(k_tree_pass, dim3((NT + 255) / 256), dim3(256), 0, s, partial, task_g, scan_local, scan_blk, M, meta, pass);
   }
@@ -358,8 +360,83 @@ int32_t msm_run(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, const void* 
   HIPCHK(hipEventElapsedTime(&ms, c->ev[2], c->ev[3])); tm.reduce = ms;
   HIPCHK(hipEventElapsedTime(&ms, c->ev[3], c->ev[4])); tm.host = ms;
   HIPCHK(hipEventElapsedTime(&ms, c->ev[0], c->ev[4])); tm.total = ms;
+  if (NT) { HIPCHK(hipEventElapsedTime(&ms, c->ev[6], c->ev[5])); tm.accum_kernel = ms; }
   c->last_msm = tm;
   return ALEO_MI355X_OK;
+}
+
+// ---- synthetic base sets generated in HBM: P_i = (first + i) * G --------------------------------------
+// Off the hot path (setup): every group operation is an out-of-line call, code size over speed.
+static constexpr uint32_t GEN_K = 64;      // consecutive points per lane
+__device__ __constant__ uint32_t FQ_P_MINUS_2[12] = {0xffffffffu, 0x8508bfffu, 0x30000000u, 0x170b5d44u, 0xba094800u, 0x1ef3622fu,
+                                                     0x00f5138fu, 0x1a22d9f3u, 0x6ca1493bu, 0xc63b05c0u, 0x17c510eau, 0x01ae3a46u};
+__device__ __noinline__ void fq_mul_ni(Fq* r, const Fq* a, const Fq* b) { *r = Fq::mul(*a, *b); }
+__device__ __noinline__ void fq_inverse_ni(Fq* io) {   // a^(q-2), a < 2q
+  Fq a = *io, acc = Fq::one();
+  for (int bit = 376; bit >= 0; --bit) {
+    fq_mul_ni(&acc, &acc, &acc);
+    if ((FQ_P_MINUS_2[bit >> 5] >> (bit & 31)) & 1u) fq_mul_ni(&acc, &acc, &a);
+  }
+  *io = acc;
+}
+
+__global__ void __launch_bounds__(256) k_gen_xyzz(const char* __restrict__ g_affine, uint64_t first, uint32_t n, char* __restrict__ tmp) {
+  uint32_t t = blockIdx.x * 256 + threadIdx.x;
+  uint64_t i0 = (uint64_t)t * GEN_K; if (i0 >= n) return;
+  AffinePt g = load_affine(g_affine);
+  XYZZ G; G.X = g.x; G.Y = g.y; G.ZZ = Fq::one(); G.ZZZ = Fq::one();
+  uint64_t k = first + i0;
+  XYZZ acc = xyzz_infinity();
+  for (int bit = 63 - __clzll(k); bit >= 0; --bit) {
+    xyzz_double_ni(&acc);
+    if ((k >> bit) & 1ull) xyzz_add_ni(&acc, &G);
+  }
+  for (uint32_t j = 0; j < GEN_K && i0 + j < n; ++j) {
+    store_xyzz(tmp + (i0 + j) * 192, acc);
+    xyzz_add_ni(&acc, &G);
+  }
+}
+// XYZZ -> affine with one shared inversion per lane (Montgomery's trick over the lane's GEN_K points)
+__global__ void __launch_bounds__(256) k_gen_normalize(char* __restrict__ tmp, uint32_t n, char* __restrict__ prefix, char* __restrict__ out_xy) {
+  uint32_t t = blockIdx.x * 256 + threadIdx.x;
+  uint64_t i0 = (uint64_t)t * GEN_K; if (i0 >= n) return;
+  uint32_t cnt = (uint32_t)((n - i0) < GEN_K ? (n - i0) : GEN_K);
+  Fq prod = Fq::one();
+  for (uint32_t j = 0; j < cnt; ++j) {
+    store_fp<Fq>(prefix + (i0 + j) * 48, prod);
+    Fq zzz = load_fp<Fq>(tmp + (i0 + j) * 192 + 144);
+    fq_mul_ni(&prod, &prod, &zzz);
+  }
+  fq_inverse_ni(&prod);
+  for (uint32_t jj = cnt; jj-- > 0;) {
+    const char* src = tmp + (i0 + jj) * 192;
+    Fq pre = load_fp<Fq>(prefix + (i0 + jj) * 48), zzz = load_fp<Fq>(src + 144), zz = load_fp<Fq>(src + 96);
+    Fq zi3, zi, zi2, x, y;
+    fq_mul_ni(&zi3, &prod, &pre);            // 1/ZZZ_j
+    fq_mul_ni(&prod, &prod, &zzz);
+    fq_mul_ni(&zi, &zz, &zi3);               // 1/Z
+    fq_mul_ni(&zi2, &zi, &zi);               // 1/ZZ
+    Fq X = load_fp<Fq>(src), Y = load_fp<Fq>(src + 48);
+    fq_mul_ni(&x, &X, &zi2); fq_mul_ni(&y, &Y, &zi3);
+    store_fp<Fq>(out_xy + (i0 + jj) * 96, Fq::reduce(x));
+    store_fp<Fq>(out_xy + (i0 + jj) * 96 + 48, Fq::reduce(y));
+  }
+}
+
+int32_t generate_multiples(Ctx* c, const void* base104, uint64_t first, size_t n, PinnedBases* out) {
+  if (n == 0 || n >= (1ull << 31) || first == 0) { g_last_error = "bases_generate: bad range"; return ALEO_MI355X_ERR_BAD_ARG; }
+  PinnedBases pb; pb.n = n;
+  HIPCHK(hipMalloc(&pb.d_xy, n * 96));
+  void *d_g = nullptr, *d_tmp = nullptr, *d_pre = nullptr;
+  HIPCHK(hipMalloc(&d_g, 96)); HIPCHK(hipMalloc(&d_tmp, n * 192)); HIPCHK(hipMalloc(&d_pre, n * 48));
+  HIPCHK(hipMemcpyAsync(d_g, base104, 96, hipMemcpyHostToDevice, c->stream));
+  uint32_t lanes = (uint32_t)((n + GEN_K - 1) / GEN_K), grid = (lanes + 255) / 256;
+  hipLaunchKernelGGL(k_gen_xyzz, dim3(grid), dim3(256), 0, c->stream, (const char*)d_g, first, (uint32_t)n, (char*)d_tmp);
+  hipLaunchKernelGGL(k_gen_normalize, dim3(grid), dim3(256), 0, c->stream, (char*)d_tmp, (uint32_t)n, (char*)d_pre, (char*)pb.d_xy);
+  HIPCHK(hipStreamSynchronize(c->stream));
+  HIPCHK(hipGetLastError());
+  (void)hipFree(d_g); (void)hipFree(d_tmp); (void)hipFree(d_pre);
+  *out = pb; return ALEO_MI355X_OK;
 }
 
 // ---- element-wise products (parity tests pin the device arithmetic with these) -------------------

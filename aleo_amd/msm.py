@@ -18,13 +18,30 @@ def _p(a): return a.ctypes.data_as(ctypes.c_void_p)
 class PinnedBases:
     """A base set resident in HBM (one SRS / proving key).  Mirrors the lifetime of an Arc<Vec<G1Affine>>."""
 
-    def __init__(self, bases: np.ndarray):
+    def __init__(self, bases: np.ndarray = None, _handle: int = 0, _n: int = 0):
+        if bases is None:
+            self.handle, self.n = _handle, _n
+            return
         bases = np.ascontiguousarray(bases, dtype=np.uint8)
         assert bases.ndim == 2 and bases.shape[1] in (96, 104)
         self.n = bases.shape[0]
         h = ctypes.c_uint64(0)
         check(lib().aleo_mi355x_bases_pin(_p(bases), bases.shape[1], self.n, ctypes.byref(h)), 'bases_pin')
         self.handle = h.value
+
+    @classmethod
+    def generate_multiples(cls, base_affine104: np.ndarray, first_multiple: int, n: int) -> 'PinnedBases':
+        """P_i = (first_multiple + i) * base, generated in HBM (synthetic SRS-shaped base set)."""
+        b = np.ascontiguousarray(base_affine104, dtype=np.uint8).reshape(104)
+        h = ctypes.c_uint64(0)
+        check(lib().aleo_mi355x_bases_generate(_p(b), first_multiple, n, ctypes.byref(h)), 'bases_generate')
+        return cls(None, h.value, n)
+
+    def download(self, offset: int = 0, n: int = None) -> np.ndarray:
+        n = self.n - offset if n is None else n
+        out = np.zeros((n, 104), dtype=np.uint8)
+        check(lib().aleo_mi355x_bases_download(self.handle, offset, n, _p(out)), 'bases_download')
+        return out
 
     def close(self):
         if self.handle:
@@ -71,9 +88,9 @@ def g1_sum(points: np.ndarray) -> np.ndarray:
 
 
 def last_msm_timing() -> dict:
-    buf = (ctypes.c_double * 5)()
-    k = lib().aleo_mi355x_last_msm_timing(buf, 5)
-    names = ['total_ms', 'sort_ms', 'accum_ms', 'reduce_ms', 'host_ms']
+    buf = (ctypes.c_double * 6)()
+    k = lib().aleo_mi355x_last_msm_timing(buf, 6)
+    names = ['total_ms', 'sort_ms', 'accum_ms', 'reduce_ms', 'host_ms', 'accum_kernel_ms']
     return {names[i]: buf[i] for i in range(k)}
 
 

@@ -1,0 +1,143 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the MI355X prover backend (BASELINE.json metric, config[1]):
+standalone 2^20-point BLS12-377 G1 Pippenger MSM, scalars and bases resident in HBM, result on the host.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
+
+A step = one MSM pass: every rank runs the full Pippenger over its own shard of 2^20 (scalar, base) pairs
+(weak scaling: the shard per GPU is fixed), then the 144-byte partials are all-gathered (RCCL) and added locally
+(SURVEY.md §8e).  value = points processed by all ranks / max-over-ranks wall time.  Prints ONE JSON line on rank 0."""
+from __future__ import annotations
+import argparse, json, os, sys, time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import numpy as np
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--lg-n', type=int, default=20, help='log2 of the points per GPU (BASELINE config[1]: 20)')
+    ap.add_argument('--scalars', default='uniform', choices=['uniform', 'witness'])
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-sample-lg', type=int, default=18)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import aleo_amd
+    from aleo_amd import synth
+    from aleo_amd import dist as adist
+
+    rank = int(os.environ.get('RANK', '0')); world = int(os.environ.get('WORLD_SIZE', '1'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X: the HIP path has no CPU fallback')
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+    L = aleo_amd.lib()
+    aleo_amd._lib.check(L.aleo_mi355x_init(local_rank), 'init')
+
+    n = 1 << args.lg_n
+    first = rank * n + 1
+    gen = synth.generator_affine104()
+    pb = aleo_amd.PinnedBases.generate_multiples(gen, first, n)           # P_i = (first + i) * G, generated in HBM
+    mk = synth.uniform_scalars if args.scalars == 'uniform' else synth.witness_like_scalars
+    scalars = mk(n, 0xA1E00002 + rank)
+    d_scalars = torch.from_numpy(scalars.view(np.int64)).to(dev)           # resident in HBM before the timed region
+    torch.cuda.synchronize()
+
+    def step():
+        part = aleo_amd.VariableBase.msm_device(pb, d_scalars.data_ptr(), n)
+        if world > 1:
+            return aleo_amd.g1_sum(adist.all_gather_partials(part, device=dev))
+        return part
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        res = step()
+    acc_kernel_ms, phases = [], []
+    barrier(); t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = step()
+        tm = aleo_amd.last_msm_timing(); acc_kernel_ms.append(tm['accum_kernel_ms']); phases.append(tm)
+    barrier(); t1 = time.perf_counter()
+    elapsed = t1 - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX); elapsed = float(t.item())
+
+    # correctness gate: the result must equal k*G with k = sum_i s_i * (first+i) over all ranks (an O(n) identity)
+    k = synth.weighted_scalar_sum(scalars, first)
+    if world > 1:
+        ks = [None] * world; dist.all_gather_object(ks, k); k = sum(ks) % synth.FR_MODULUS
+    kG = aleo_amd.VariableBase.msm(gen.reshape(1, 104), synth.int_to_limbs(k, 4).reshape(1, 4))
+    if not (np.asarray(res) == kG).all():
+        raise SystemExit('bench: MSM result does not equal k*G — refusing to report a number for a wrong result')
+
+    if rank == 0:
+        ms_step = elapsed / args.steps * 1e3
+        value = world * n * args.steps / elapsed
+        ak = float(np.mean(acc_kernel_ms)) * 1e-3
+        alg_bytes = 128.0 * n                                  # 32 B scalar + 96 B affine base per point
+        achieved = alg_bytes / ak / 1e9
+        traffic = None
+        tf = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
+        if os.path.exists(tf):
+            try: traffic = json.load(open(tf)).get('k_accum_hbm_bytes_per_launch')
+            except Exception: traffic = None
+        out = {
+            'metric': 'MSM G1 scalar-muls/sec (2^%d bases per GPU, BLS12-377, bit-exact)' % args.lg_n,
+            'value': value, 'unit': 'scalar-muls/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': ms_step, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'u32',
+            'data': 'synthetic',
+            'config': {'workload': 'standalone 2^%d-point BLS12-377 G1 Pippenger MSM (BASELINE configs[1])' % args.lg_n,
+                       'points_per_gpu': n, 'scalars': args.scalars, 'bases': 'P_i=(i+1)G generated in HBM',
+                       'sharding': 'point-sharded, all-gather of 144-byte partials' if world > 1 else 'single GPU'},
+            'roofline': {'bound': 'hbm', 'kernel': 'k_accum (bucket accumulation)', 'achieved': achieved, 'peak': 8000.0,
+                         'unit': 'GB/s', 'frac': achieved / 8000.0, 'traffic': traffic,
+                         'note': 'integer-VALU bound by construction (SURVEY.md §8d): ~%d Fq products per point' % (10 * ((254 + 15) // 16))},
+            'phases_ms': {kk: float(np.mean([p_[kk] for p_ in phases])) for kk in phases[0]},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(args, pb, scalars, aleo_amd)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier(); dist.destroy_process_group()
+
+
+def cpu_baseline(args, pb, scalars, aleo_amd):
+    """The oracle (C restatement of snarkVM's batched Pippenger, all host cores) on a bounded sample of the same
+    workload; also re-checks GPU == oracle on that sample.  kind 'port': it is not the Rust binary."""
+    from oracle import coracle as c
+    ns = 1 << min(args.cpu_sample_lg, args.lg_n)
+    # the restated algorithm (like snarkVM's rayon version) runs one window per thread: c = ln(n)+2 bits -> ceil(253/c)
+    # windows is the most threads it can use, whatever the box has
+    lg = ns.bit_length() - 1; nwin = -(-253 // (lg * 69 // 100 + 2))
+    cores = min(os.cpu_count() or 1, nwin)
+    bases = pb.download(0, ns)
+    s = np.ascontiguousarray(scalars[:ns])
+    c.msm_g1(bases[:256], s[:256], threads=1, variant=1)                    # load the library outside the timing
+    t0 = time.perf_counter(); ref = c.msm_g1(bases, s, threads=cores, variant=1); dt = time.perf_counter() - t0
+    got = aleo_amd.VariableBase.msm(pb, s)
+    return {'value': ns / dt, 'unit': 'scalar-muls/s', 'cores': cores, 'kind': 'port', 'seconds': dt,
+            'host_cpus': os.cpu_count(),
+            'sample': '2^%d-point prefix of the same bases/scalars; C restatement of snarkvm-algorithms 0.14.5 batched MSM, '
+                      'not the Rust binary' % (ns.bit_length() - 1),
+            'gpu_matches_oracle_on_sample': bool(c.jac_to_int_point(got) == c.jac_to_int_point(ref))}
+
+
+if __name__ == '__main__':
+    main()

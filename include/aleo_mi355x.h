@@ -71,6 +71,12 @@ int32_t aleo_mi355x_msm_g1(void* out_jacobian, const void* bases, size_t base_st
  * The handle stays valid until unpin.  bases: host pointer. */
 int32_t aleo_mi355x_bases_pin(const void* bases, size_t base_stride, size_t n, uint64_t* handle);
 int32_t aleo_mi355x_bases_unpin(uint64_t handle);
+/* Synthetic SRS-shaped base set generated in HBM: P_i = (first_multiple + i) * base for i in [0, n)
+ * ("P_i = (i+1)*G generated on device" — 2^26 points never cross PCIe).  base_affine: one
+ * snarkVM Affine (104 bytes, host).  first_multiple >= 1 and first_multiple + n must stay below r. */
+int32_t aleo_mi355x_bases_generate(const void* base_affine104, uint64_t first_multiple, size_t n, uint64_t* handle);
+/* Copies pinned bases [offset, offset+n) back to the host as snarkVM Affine (stride 104). */
+int32_t aleo_mi355x_bases_download(uint64_t handle, size_t offset, size_t n, void* out_affine104);
 /* MSM over the first n pinned bases; scalars: host pointer. */
 int32_t aleo_mi355x_msm_g1_pinned(void* out_jacobian, uint64_t handle, const void* scalars, size_t n);
 /* Same, scalars already resident in device memory (hipMalloc'ed or a torch CUDA tensor's data_ptr).
@@ -97,7 +103,8 @@ int32_t aleo_mi355x_fq_mul(void* r, const void* a, const void* b, size_t n);
 int32_t aleo_mi355x_fr_mul(void* r, const void* a, const void* b, size_t n);
 
 /* Per-call instrumentation of the last MSM on this thread's device: milliseconds per phase
- * [0] total device time, [1] digit/sort, [2] bucket accumulation, [3] bucket reduction, [4] host tail.
+ * [0] total, [1] digit/sort, [2] bucket accumulation incl. slice tree, [3] bucket reduction, [4] host tail,
+ * [5] the bucket-accumulation kernel alone (the dominant kernel bench.py prices against the roofline).
  * Returns the number of doubles written (<= cap). */
 int32_t aleo_mi355x_last_msm_timing(double* out_ms, int32_t cap);
 

@@ -1,0 +1,87 @@
+#!/usr/bin/env python3
+"""Generates the golden fixtures in this directory.
+
+  reference_proof.json  DATA held by the reference's own test (the `proof1…` string inside TRANSACTION_STRING at
+                        /root/reference/wasm/src/programs/transaction.rs:100), plus its decoding by oracle/pyref.py:
+                        the ten KZG commitments (compressed G1) and the field evaluations.  Needs /root/reference.
+  msm_small.json        Python big-integer MSM known answers (oracle/pyref.py msm_naive: double-and-add, no windows).
+  ntt_small.json        O(n^2) DFT known answers for fft / ifft / coset_fft / coset_ifft.
+
+Run from the repo root:  python tests/golden/gen_golden.py
+The reference cannot be built or imported here (Rust, crates.io snarkVM 0.14.5): these vectors come from the
+independent big-integer restatement, and from the reference's own data file for reference_proof.json."""
+import json, os, re, sys
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+from oracle import pyref as p
+
+COMMIT_OFFSETS = {'w': 17, 'z_a': 65, 'z_b': 113, 'mask_poly': 162, 'g_1': 210, 'h_1': 258, 'g_a': 306, 'g_b': 354, 'g_c': 402, 'h_2': 450}
+EVAL_RANGES = {'evaluations': (498, 5), 'sums': (666, 3)}
+
+
+def gen_reference_proof():
+    src = '/root/reference/wasm/src/programs/transaction.rs'
+    if not os.path.exists(src):
+        print('skip reference_proof.json (no /root/reference)'); return
+    proof = re.findall(r'proof1[0-9a-z]+', open(src).read())[0]
+    hrp, raw = p.bech32m_decode(proof)
+    out = {'source': 'wasm/src/programs/transaction.rs:100 (TRANSACTION_STRING, field "proof")', 'proof': proof,
+           'hrp': hrp, 'payload_len': len(raw), 'commitments': {}, 'field_elements': {}}
+    for name, off in COMMIT_OFFSETS.items():
+        pt = p.g1_decompress(raw[off:off + 48])
+        out['commitments'][name] = {'offset': off, 'compressed': raw[off:off + 48].hex(), 'x': hex(pt[0]), 'y': hex(pt[1])}
+    for name, (off, cnt) in EVAL_RANGES.items():
+        out['field_elements'][name] = [hex(int.from_bytes(raw[off + 32 * i: off + 32 * i + 32], 'little')) for i in range(cnt)]
+    json.dump(out, open(os.path.join(HERE, 'reference_proof.json'), 'w'), indent=1)
+
+
+def gen_msm():
+    rng = p.SplitMix64(0xA1E00002)
+    cases = []
+    r = p.FR_MODULUS
+
+    def scal(kind, n):
+        if kind == 'uniform': return [rng.fr() for _ in range(n)]
+        if kind == 'zero': return [0] * n
+        if kind == 'one': return [1] * n
+        if kind == 'r_minus_1': return [r - 1] * n
+        if kind == 'small': return [rng.next() & 0xFFFF for _ in range(n)]
+        if kind == 'mixed': return [[0, 1, r - 1, rng.fr(), rng.next() & 0xFFFF][i % 5] for i in range(n)]
+        raise ValueError(kind)
+
+    for n in (1, 2, 31, 32, 33, 100):
+        for kind in ('uniform', 'zero', 'one', 'r_minus_1', 'small', 'mixed'):
+            if n > 33 and kind in ('zero', 'one', 'r_minus_1'): continue
+            mult = [(rng.next() % 1000) + 1 for _ in range(n)]         # bases k_i * G, small k so bases repeat/collide
+            bases = [p.g1_mul(p.G1_GENERATOR, k) for k in mult]
+            sc = scal(kind, n)
+            res = p.msm_naive(bases, sc)
+            k = sum(m * s for m, s in zip(mult, sc)) % r               # cross-check: result must be k*G
+            assert res == p.g1_mul(p.G1_GENERATOR, k)
+            cases.append({'n': n, 'kind': kind, 'base_multipliers': mult, 'scalars': [hex(s) for s in sc],
+                          'result': None if res is None else [hex(res[0]), hex(res[1])]})
+    # infinity among the bases, and P / -P pairs
+    mult = [3, 5, 7, 9]; bases = [p.g1_mul(p.G1_GENERATOR, k) for k in mult]; bases[1] = None
+    sc = [rng.fr() for _ in range(4)]
+    res = p.msm_naive([b for b in bases], sc)
+    cases.append({'n': 4, 'kind': 'with_infinity_base', 'base_multipliers': [3, 0, 7, 9], 'scalars': [hex(s) for s in sc], 'result': [hex(res[0]), hex(res[1])]})
+    json.dump({'generator': [hex(p.G1_GENERATOR[0]), hex(p.G1_GENERATOR[1])], 'cases': cases}, open(os.path.join(HERE, 'msm_small.json'), 'w'))
+
+
+def gen_ntt():
+    rng = p.SplitMix64(0xA1E00003)
+    cases = []
+    for n in (1, 2, 4, 8, 64, 256):
+        x = [rng.fr() for _ in range(n)]
+        d = p.EvaluationDomain(n)
+        cases.append({'n': n, 'input': [hex(v) for v in x], 'fft': [hex(v) for v in d.fft(x)], 'ifft': [hex(v) for v in d.ifft(x)],
+                      'coset_fft': [hex(v) for v in d.coset_fft(x)], 'coset_ifft': [hex(v) for v in d.coset_ifft(x)]})
+    # zero-padded input (fft of 5 coefficients over the size-8 domain), as EvaluationDomain::fft resizes
+    x = [rng.fr() for _ in range(5)]; d = p.EvaluationDomain(5)
+    cases.append({'n': 8, 'ragged': 5, 'input': [hex(v) for v in x], 'fft': [hex(v) for v in d.fft(x)], 'coset_fft': [hex(v) for v in d.coset_fft(x)]})
+    json.dump({'two_adic_root': hex(p.FR_TWO_ADIC_ROOT), 'generator': p.FR_GENERATOR, 'cases': cases}, open(os.path.join(HERE, 'ntt_small.json'), 'w'))
+
+
+if __name__ == '__main__':
+    gen_reference_proof(); gen_msm(); gen_ntt()
+    print('golden fixtures written to', HERE)

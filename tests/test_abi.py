@@ -1,0 +1,71 @@
+"""CPU tests of the drop-in boundary: the C-ABI library loads and exports every symbol include/*.h declares.
+No compute call is made here (there is no GPU in this tier)."""
+import ctypes, os, re
+import numpy as np
+import aleo_amd
+from aleo_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions():
+    names = []
+    for fn in os.listdir(os.path.join(ROOT, 'include')):
+        if not fn.endswith('.h'): continue
+        src = open(os.path.join(ROOT, 'include', fn)).read()
+        src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+        names += re.findall(r'\b(aleo_mi355x_[a-z0-9_]+)\s*\(', src)
+    return sorted(set(names))
+
+
+def test_header_and_library_agree():
+    L = aleo_amd.lib()
+    decl = declared_functions()
+    assert len(decl) >= 15
+    for name in decl:
+        assert hasattr(L, name), f'{name} declared in include/ but not exported by libaleo_mi355x.so'
+    assert sorted(_lib.EXPORTS) == decl, 'python binding list and header drifted apart'
+
+
+def test_strerror_and_version_do_not_need_a_gpu():
+    L = aleo_amd.lib()
+    assert L.aleo_mi355x_version().startswith(b'aleo_mi355x')
+    assert L.aleo_mi355x_strerror(0) == b'ok'
+    assert L.aleo_mi355x_strerror(2) == b'bad argument'
+    assert b'unknown' in L.aleo_mi355x_strerror(12345)
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    import pytest
+    monkeypatch.setattr(_lib, '_LIB', None)
+    monkeypatch.setattr(_lib, 'LIB_PATH', '/nonexistent/libaleo_mi355x.so')
+    with pytest.raises(_lib.AleoMi355xError):
+        _lib.lib()
+
+
+def test_g1_sum_host_tail_matches_oracle(oracle):
+    """aleo_mi355x_g1_sum is the host-side group add that follows the all-gather of per-GPU partials: pure CPU."""
+    from oracle import pyref as p
+    c = oracle
+    G1 = c.affine_from_ints([p.G1_GENERATOR])[0]
+    B = c.g1_multiples(G1, 8)
+    parts = []
+    for i in range(8):   # Jacobian (x, y, 1) of (i+1)G
+        one = c.fq_to_mont(c.ints_to_limbs([1], 6)).reshape(6)
+        parts.append(np.concatenate([np.ascontiguousarray(B[i, :96]).view(np.uint64), one]))
+    parts.append(np.concatenate([one, one, np.zeros(6, dtype=np.uint64)]))     # identity (1,1,0)
+    got = aleo_amd.g1_sum(np.stack(parts))
+    assert c.jac_to_int_point(got) == p.g1_mul(p.G1_GENERATOR, 36)
+    same = aleo_amd.g1_sum(np.stack([parts[2], parts[2]]))                      # doubling branch
+    assert c.jac_to_int_point(same) == p.g1_mul(p.G1_GENERATOR, 6)
+    neg = c.affine_from_ints([p.g1_neg(p.g1_mul(p.G1_GENERATOR, 3))])[0]
+    pneg = np.concatenate([np.ascontiguousarray(neg[:96]).view(np.uint64), one])
+    assert c.jac_to_int_point(aleo_amd.g1_sum(np.stack([parts[2], pneg]))) is None
+    assert c.jac_to_int_point(aleo_amd.g1_sum(np.zeros((0, 18), dtype=np.uint64))) is None
+
+
+def test_evaluation_domain_host_logic():
+    d = aleo_amd.EvaluationDomain(5)
+    assert d.size == 8 and d.log_size_of_group == 3
+    assert aleo_amd.EvaluationDomain(1).size == 1
+    assert aleo_amd.EvaluationDomain.new(1 << 48) is None          # beyond the two-adicity of Fr: reference returns None

@@ -1,0 +1,59 @@
+"""World-size-2 gloo test of the sharded-MSM path (CPU): shard ranges, the 144-byte all-gather and the local
+group add.  The per-rank partial comes from the oracle here (no GPU in this tier); on the GPU box the same
+aleo_amd.dist functions are fed by the HIP MSM (tests/test_gpu_parity.py::test_sharded_msm_two_shards)."""
+import os, sys, socket
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close(); return port
+
+
+def _worker(rank, world, port, n, q):
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    os.environ['MASTER_ADDR'] = '127.0.0.1'; os.environ['MASTER_PORT'] = str(port)
+    import torch.distributed as dist
+    import aleo_amd
+    from aleo_amd import dist as adist
+    from oracle import coracle as c
+    import util
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        B = util.multiples_bases(n); S = util.uniform_scalars(n, 4242)
+        lo, hi = adist.shard_range(n, rank, world)
+        total = adist.sharded_msm(lambda: c.msm_g1(B[lo:hi], S[lo:hi], threads=1, variant=1), aleo_amd.g1_sum)
+        q.put((rank, lo, hi, total.tolist()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_shard_ranges_cover_everything():
+    from aleo_amd.dist import shard_range
+    for n in (0, 1, 7, 8, 1000, (1 << 20) + 3):
+        for world in (1, 2, 3, 8):
+            rs = [shard_range(n, r, world) for r in range(world)]
+            assert rs[0][0] == 0 and rs[-1][1] == n
+            assert all(rs[i][1] == rs[i + 1][0] for i in range(world - 1))
+            sizes = [b - a for a, b in rs]; assert max(sizes) - min(sizes) <= 1
+
+
+@pytest.mark.timeout(300)
+def test_sharded_msm_world2_gloo():
+    import torch.multiprocessing as mp
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    from oracle import coracle as c
+    import util
+    n, world, port = 301, 2, _free_port()
+    ctx = mp.get_context('spawn'); q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, q)) for r in range(world)]
+    for p_ in procs: p_.start()
+    res = [q.get(timeout=240) for _ in range(world)]
+    for p_ in procs: p_.join(60); assert p_.exitcode == 0
+    res.sort()
+    assert res[0][3] == res[1][3], 'ranks disagree on the combined result'
+    got = c.jac_to_int_point(np.array(res[0][3], dtype=np.uint64))
+    assert got == util.expected_multiples_msm(util.uniform_scalars(n, 4242), n)
+    assert (res[0][1], res[0][2], res[1][1], res[1][2]) == (0, 151, 151, 301)

@@ -1,0 +1,246 @@
+"""GPU parity tests (run by the driver with `-m gpu` on a real MI355X): the HIP path, called through the C ABI,
+against the oracle on the same seeded inputs, against the committed golden vectors, and — at BASELINE.json's full
+sizes — through size-independent identities.  Integer work: every comparison is bit-exact."""
+import json, os
+import numpy as np
+import pytest
+
+import aleo_amd
+from aleo_amd import msm as M, synth
+from oracle import coracle as c, pyref as p
+import util
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), 'golden')
+
+
+def _ints(hexes): return [int(h, 16) for h in hexes]
+
+
+@pytest.fixture(scope='module', autouse=True)
+def device():
+    L = aleo_amd.lib()
+    aleo_amd._lib.check(L.aleo_mi355x_init(-1), 'init')     # no GPU -> hard failure, never a fallback
+
+
+def _fq_random(n, seed):
+    a = np.concatenate([util.uniform_scalars(n, seed), util.uniform_scalars(n, seed + 1)[:, :2]], axis=1)
+    a[:, 5] &= np.uint64((1 << 56) - 1)       # < 2^376 < q
+    return a
+
+
+# ---- field arithmetic -----------------------------------------------------------------------------
+def test_fq_fr_products_bit_exact():
+    n = 20000
+    a, b = _fq_random(n, 1), _fq_random(n, 3)
+    a[0] = 0; b[1] = 0; a[2] = c.ints_to_limbs([p.FQ_MODULUS - 1], 6)[0]; b[2] = a[2]     # edge operands
+    e = np.zeros_like(a); c.lib().oracle_fq_mul(c._p(e), c._p(a), c._p(b), n)
+    assert (M.fq_mul(a, b) == e).all()
+    x, y = util.uniform_scalars(n, 5), util.uniform_scalars(n, 6)
+    x[0] = 0; x[1] = c.ints_to_limbs([p.FR_MODULUS - 1], 4)[0]; y[1] = x[1]
+    e = np.zeros_like(x); c.lib().oracle_fr_mul(c._p(e), c._p(x), c._p(y), n)
+    assert (M.fr_mul(x, y) == e).all()
+
+
+# ---- NTT ----------------------------------------------------------------------------------------------
+def test_ntt_golden_vectors():
+    fx = json.load(open(os.path.join(G, 'ntt_small.json')))
+    for case in fx['cases']:
+        x = c.fr_to_mont(c.ints_to_limbs(_ints(case['input']), 4))
+        d = aleo_amd.EvaluationDomain(case['n'])
+        for name, fn in {'fft': d.fft, 'ifft': d.ifft, 'coset_fft': d.coset_fft, 'coset_ifft': d.coset_ifft}.items():
+            if name not in case: continue
+            got = c.limbs_to_ints(c.fr_from_mont(fn(x)))        # ragged inputs are zero-padded by the domain
+            assert got == _ints(case[name]), (case['n'], name)
+
+
+@pytest.mark.parametrize('lg', [1, 2, 3, 7, 10, 11, 12, 15, 18, 19, 20])
+def test_ntt_matches_oracle_all_variants(lg):
+    x = c.fr_to_mont(util.uniform_scalars(1 << lg, 100 + lg))
+    d = aleo_amd.EvaluationDomain(1 << lg)
+    for direction in (0, 1):
+        for type_ in (0, 1):
+            assert (d.ntt(x, 0, direction, type_) == c.ntt_fr(x, 0, direction, type_)).all(), (lg, direction, type_)
+
+
+@pytest.mark.parametrize('lg', [3, 9, 13])
+def test_ntt_orders(lg):
+    x = c.fr_to_mont(util.uniform_scalars(1 << lg, 300 + lg))
+    d = aleo_amd.EvaluationDomain(1 << lg)
+    for order in (1, 2, 3):
+        for direction in (0, 1):
+            assert (d.ntt(x, order, direction, 0) == c.ntt_fr(x, order, direction, 0)).all(), (lg, order, direction)
+
+
+def test_ntt_full_size_properties_2_22():
+    """BASELINE config[2] size: round trips, linearity and a spot check of the definition at 2^22."""
+    lg = 22; n = 1 << lg
+    d = aleo_amd.EvaluationDomain(n)
+    x = c.fr_to_mont(util.uniform_scalars(n, 2222)); y = c.fr_to_mont(util.uniform_scalars(n, 2223))
+    fx = d.fft(x)
+    assert (d.ifft(fx) == x).all()
+    assert (d.coset_ifft(d.coset_fft(x)) == x).all()
+    # linearity: fft(x + y) == fft(x) + fft(y), checked with python ints on 4096 sampled output positions
+    fy = d.fft(y)
+    idx = (util.splitmix_limbs(77, 4096) % np.uint64(n)).astype(np.int64)
+    xy = _mont_add(x, y)
+    fxy = d.fft(xy)
+    FX = c.limbs_to_ints(fx[idx]); FY = c.limbs_to_ints(fy[idx]); FXY = c.limbs_to_ints(fxy[idx])
+    assert all((a + b) % p.FR_MODULUS == s_ for a, b, s_ in zip(FX, FY, FXY))
+    # definition spot check: out[k] = sum_j x[j] w^(jk) for k = 0 (plain sum) and k = n/2 (alternating sum)
+    xc = c.limbs_to_ints(c.fr_from_mont(x))
+    out = c.limbs_to_ints(c.fr_from_mont(fx[[0, n // 2]]))
+    assert out[0] == sum(xc) % p.FR_MODULUS
+    assert out[1] == (sum(xc[0::2]) - sum(xc[1::2])) % p.FR_MODULUS
+
+
+def _mont_add(a, b):
+    """limb-wise (a + b) mod r on uint64[n,4] arrays with numpy (test helper)."""
+    r = np.array([(p.FR_MODULUS >> (64 * i)) & ((1 << 64) - 1) for i in range(4)], dtype=np.uint64)
+    out = np.zeros_like(a); carry = np.zeros(a.shape[0], dtype=np.uint64)
+    for i in range(4):
+        s = a[:, i] + b[:, i]; c1 = (s < a[:, i]).astype(np.uint64)
+        s2 = s + carry; c2 = (s2 < s).astype(np.uint64)
+        out[:, i] = s2; carry = c1 + c2
+    # conditional subtract r (sum < 2r < 2^254 so carry is 0)
+    ge = np.zeros(a.shape[0], dtype=bool); eq = np.ones(a.shape[0], dtype=bool)
+    for i in (3, 2, 1, 0):
+        ge |= eq & (out[:, i] > r[i]); eq &= out[:, i] == r[i]
+    ge |= eq
+    borrow = np.zeros(a.shape[0], dtype=np.uint64); res = out.copy()
+    for i in range(4):
+        d1 = out[:, i] - r[i]; b1 = (out[:, i] < r[i]).astype(np.uint64)
+        d2 = d1 - borrow; b2 = (d1 < borrow).astype(np.uint64)
+        res[:, i] = d2; borrow = b1 + b2
+    out[ge] = res[ge]
+    return out
+
+
+# ---- MSM ----------------------------------------------------------------------------------------------
+def test_msm_golden_vectors():
+    fx = json.load(open(os.path.join(G, 'msm_small.json')))
+    for case in fx['cases']:
+        pts = [p.g1_mul(p.G1_GENERATOR, k) if k else None for k in case['base_multipliers']]
+        B = c.affine_from_ints(pts); S = c.ints_to_limbs(_ints(case['scalars']), 4)
+        exp = None if case['result'] is None else (int(case['result'][0], 16), int(case['result'][1], 16))
+        assert c.jac_to_int_point(M.VariableBase.msm(B, S)) == exp, (case['n'], case['kind'])
+
+
+@pytest.mark.parametrize('n', [1, 2, 3, 15, 31, 32, 33, 255, 1000, 4097, 1 << 14])
+@pytest.mark.parametrize('kind', ['uniform', 'witness'])
+def test_msm_matches_oracle(n, kind):
+    B = util.multiples_bases(n)
+    S = util.uniform_scalars(n, 500 + n) if kind == 'uniform' else util.witness_like_scalars(n, 600 + n)
+    exp = c.jac_to_int_point(c.msm_g1(B, S, threads=8, variant=1))
+    assert c.jac_to_int_point(M.VariableBase.msm(B, S)) == exp
+    assert c.jac_to_int_point(M.VariableBase.msm(np.ascontiguousarray(B[:, :96]), S)) == exp      # stride 96
+
+
+def test_msm_edge_cases():
+    n = 600
+    B = util.multiples_bases(n)
+    ident = None
+    assert c.jac_to_int_point(M.VariableBase.msm(B[:0], np.zeros((0, 4), dtype=np.uint64))) is ident       # empty
+    assert c.jac_to_int_point(M.VariableBase.msm(B, np.zeros((n, 4), dtype=np.uint64))) is ident            # all zero
+    ones = np.zeros((n, 4), dtype=np.uint64); ones[:, 0] = 1
+    assert c.jac_to_int_point(M.VariableBase.msm(B, ones)) == p.g1_mul(p.G1_GENERATOR, n * (n + 1) // 2)    # all one
+    rm1 = np.tile(c.ints_to_limbs([p.FR_MODULUS - 1], 4), (n, 1))
+    assert c.jac_to_int_point(M.VariableBase.msm(B, rm1)) == p.g1_neg(p.g1_mul(p.G1_GENERATOR, n * (n + 1) // 2))
+    eq = np.tile(util.uniform_scalars(1, 9), (n, 1))                                                          # all equal -> one bucket per window
+    assert c.jac_to_int_point(M.VariableBase.msm(B, eq)) == c.jac_to_int_point(c.msm_g1(B, eq, threads=4, variant=1))
+    same = np.repeat(B[:1], n, axis=0); S = util.uniform_scalars(n, 10)                                       # one base repeated: doublings
+    assert c.jac_to_int_point(M.VariableBase.msm(same, S)) == p.g1_mul(p.G1_GENERATOR, sum(c.limbs_to_ints(S)) % p.FR_MODULUS)
+    five = np.zeros((n, 4), dtype=np.uint64); five[:, 0] = 5
+    assert c.jac_to_int_point(M.VariableBase.msm(same, five)) == p.g1_mul(p.G1_GENERATOR, 5 * n)
+    neg = c.affine_from_ints([p.g1_neg(p.G1_GENERATOR)])
+    pm = np.concatenate([B[:1], neg] * 50, axis=0); s77 = np.zeros((100, 4), dtype=np.uint64); s77[:, 0] = 77   # P, -P cancel
+    assert c.jac_to_int_point(M.VariableBase.msm(pm, s77)) is ident
+    Binf = B.copy(); Binf[5] = 0; Binf[5, 96] = 1; Binf[77] = 0; Binf[77, 96] = 1                             # infinity bases are skipped
+    S = util.uniform_scalars(n, 11)
+    assert c.jac_to_int_point(M.VariableBase.msm(Binf, S)) == c.jac_to_int_point(c.msm_g1(Binf, S, threads=4, variant=1))
+    # zip semantics: more scalars than bases / more bases than scalars
+    assert c.jac_to_int_point(M.VariableBase.msm(B[:100], S)) == c.jac_to_int_point(c.msm_g1(B[:100], S[:100], variant=1))
+
+
+def test_msm_heavy_buckets_witness_like_2_17():
+    n = 1 << 17
+    with M.PinnedBases.generate_multiples(synth.generator_affine104(), 1, n) as pb:
+        S = util.witness_like_scalars(n, 1717)
+        got = M.VariableBase.msm(pb, S)
+        assert c.jac_to_int_point(got) == util.expected_multiples_msm(S, n)
+        eq = np.tile(util.uniform_scalars(1, 5), (n, 1))          # adversarial: every scalar equal
+        assert c.jac_to_int_point(M.VariableBase.msm(pb, eq)) == util.expected_multiples_msm(eq, n)
+
+
+def test_generated_bases_match_oracle():
+    n = 1000
+    with M.PinnedBases.generate_multiples(synth.generator_affine104(), 1, n) as pb:
+        assert (pb.download() == util.multiples_bases(n)).all()
+    with M.PinnedBases.generate_multiples(synth.generator_affine104(), 12345678901, 130) as pb:
+        got = c.affine_to_ints(pb.download())
+        assert got[0] == p.g1_mul(p.G1_GENERATOR, 12345678901) and got[129] == p.g1_mul(p.G1_GENERATOR, 12345678901 + 129)
+
+
+def test_msm_full_size_2_20_structured_identity():
+    """BASELINE config[1] size.  Bases (i+1)G make sum_i s_i P_i = (sum_i s_i (i+1) mod r) G — an O(n) oracle."""
+    n = 1 << 20
+    with M.PinnedBases.generate_multiples(synth.generator_affine104(), 1, n) as pb:
+        for kind, S in (('uniform', util.uniform_scalars(n, 0xA1E00002)), ('witness', util.witness_like_scalars(n, 0xA1E00012))):
+            got = M.VariableBase.msm(pb, S)
+            assert c.jac_to_int_point(got) == util.expected_multiples_msm(S, n), kind
+        # the device-pointer entry (scalars resident in HBM) and a prefix of the pinned set
+        import torch
+        S = util.uniform_scalars(n, 0xA1E00003)
+        dS = torch.from_numpy(S.view(np.int64)).cuda(); torch.cuda.synchronize()
+        got = M.VariableBase.msm_device(pb, dS.data_ptr(), n)
+        assert c.jac_to_int_point(got) == util.expected_multiples_msm(S, n)
+        got = M.VariableBase.msm_device(pb, dS.data_ptr(), 1 << 18)
+        assert c.jac_to_int_point(got) == util.expected_multiples_msm(S, 1 << 18)
+        # oracle on a 2^16 prefix (seconds on the host cores)
+        B = pb.download(0, 1 << 16)
+        assert c.jac_to_int_point(M.VariableBase.msm(pb, S[: 1 << 16])) == c.jac_to_int_point(c.msm_g1(B, S[: 1 << 16], threads=os.cpu_count(), variant=1))
+
+
+def test_sharded_msm_two_shards():
+    """The multi-GPU path on one device: two shards -> two partials -> g1_sum, against the unsharded result."""
+    from aleo_amd.dist import shard_range
+    n = 50001
+    B = util.multiples_bases(n); S = util.uniform_scalars(n, 31337)
+    parts = []
+    for r in range(2):
+        lo, hi = shard_range(n, r, 2)
+        parts.append(M.VariableBase.msm(B[lo:hi], S[lo:hi]))
+    total = aleo_amd.g1_sum(np.stack(parts))
+    assert (total == M.VariableBase.msm(B, S)).all()
+    assert c.jac_to_int_point(total) == util.expected_multiples_msm(S, n)
+
+
+# ---- KZG commit shape (NTT output fed to the MSM without leaving HBM) ----------------------------------
+def test_kzg_commit_matches_oracle_and_device_chain():
+    import torch
+    lg = 14; n = 1 << lg
+    with M.PinnedBases.generate_multiples(synth.generator_affine104(), 1, n) as pb:
+        B = pb.download()
+        evals = c.fr_to_mont(util.uniform_scalars(n, 4321))
+        coeffs = c.ntt_fr(evals, 0, 1, 0)                                     # oracle iNTT
+        exp = c.kzg_commit(B, coeffs, threads=8)
+        d = aleo_amd.EvaluationDomain(n)
+        got = aleo_amd.KZG10.commit(pb, d.ifft(evals))
+        assert (got == exp).all()
+        # device chain: iNTT in HBM -> commit from the same buffer (config[2] shape: no host round trip)
+        dbuf = torch.from_numpy(evals.view(np.int64)).cuda(); torch.cuda.synchronize()
+        d.ntt_device(dbuf.data_ptr(), 0, 1, 0)
+        got2 = aleo_amd.KZG10.commit_device(pb, dbuf.data_ptr(), n)
+        assert (got2 == exp).all()
+        # leading zeros are skipped like the reference does
+        cz = coeffs.copy(); cz[n - 100:] = 0
+        assert (aleo_amd.KZG10.commit(pb, cz) == c.kzg_commit(B, cz, threads=8)).all()
+
+
+def test_bad_arguments_are_rejected():
+    L = aleo_amd.lib()
+    assert L.aleo_mi355x_msm_g1(None, None, 104, None, 5) == 2
+    out = np.zeros(18, dtype=np.uint64)
+    assert L.aleo_mi355x_msm_g1(out.ctypes.data, out.ctypes.data, 100, out.ctypes.data, 1) == 2        # bad stride
+    assert L.aleo_mi355x_ntt_fr(out.ctypes.data, 31, 0, 0, 0) == 2
+    assert L.aleo_mi355x_msm_g1_pinned(out.ctypes.data, 987654321, out.ctypes.data, 1) == 4            # unknown handle

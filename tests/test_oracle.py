@@ -1,0 +1,127 @@
+"""CPU tests: the oracle against the reference's own fixture and the committed golden vectors (not gpu)."""
+import json, os
+import numpy as np
+import pytest
+from oracle import pyref as p, coracle as c
+
+G = os.path.join(os.path.dirname(__file__), 'golden')
+
+
+def _ints(hexes): return [int(h, 16) for h in hexes]
+
+
+def test_constants():
+    assert pow(p.FR_GENERATOR, (p.FR_MODULUS - 1) >> 47, p.FR_MODULUS) == p.FR_TWO_ADIC_ROOT
+    assert pow(p.FR_TWO_ADIC_ROOT, 1 << 46, p.FR_MODULUS) == p.FR_MODULUS - 1          # order exactly 2^47
+    assert p.g1_is_on_curve(p.G1_GENERATOR) and p.g1_in_subgroup(p.G1_GENERATOR)
+    assert (-pow(p.FR_MODULUS, -1, 1 << 64)) % (1 << 64) == 0x0a117fffffffffff
+    assert (-pow(p.FQ_MODULUS, -1, 1 << 64)) % (1 << 64) == 0x8508bfffffffffff
+
+
+def test_reference_proof_fixture_pins_curve_and_encoding():
+    """The ten KZG commitments inside the reference's own `proof1…` test string must decompress to on-curve,
+    r-torsion points, and recompress to the same bytes (pins q, the curve, Fq sqrt, the compressed encoding)."""
+    fx = json.load(open(os.path.join(G, 'reference_proof.json')))
+    hrp, raw = p.bech32m_decode(fx['proof'])
+    assert hrp == 'proof' and len(raw) == fx['payload_len'] == 901
+    assert raw[0] == 0 and int.from_bytes(raw[1:9], 'little') == 1 and int.from_bytes(raw[9:17], 'little') == 1
+    for name, cm in fx['commitments'].items():
+        buf = raw[cm['offset']:cm['offset'] + 48]
+        assert buf.hex() == cm['compressed']
+        pt = p.g1_decompress(buf)
+        assert pt == (int(cm['x'], 16), int(cm['y'], 16))
+        assert p.g1_is_on_curve(pt) and p.g1_in_subgroup(pt), name
+        assert p.g1_compress(pt) == buf
+        # the C oracle agrees that the point is on the curve after a Montgomery round trip
+        aff = c.affine_from_ints([pt])
+        assert c.lib().oracle_g1_on_curve(c._p(aff)) == 1
+        assert c.affine_to_ints(aff)[0] == pt
+    for name, vals in fx['field_elements'].items():
+        assert all(int(v, 16) < p.FR_MODULUS for v in vals), name
+
+
+def test_oracle_field_products_match_bigint():
+    rng = p.SplitMix64(7)
+    a = [rng.fr() for _ in range(64)]; b = [rng.fr() for _ in range(64)]
+    am, bm = c.fr_to_mont(c.ints_to_limbs(a, 4)), c.fr_to_mont(c.ints_to_limbs(b, 4))
+    assert c.limbs_to_ints(am) == [p.fr_to_mont(x) for x in a]
+    r = np.zeros_like(am); c.lib().oracle_fr_mul(c._p(r), c._p(am), c._p(bm), 64)
+    assert c.limbs_to_ints(c.fr_from_mont(r)) == [x * y % p.FR_MODULUS for x, y in zip(a, b)]
+    qa = [(rng.fr() * rng.fr()) % p.FQ_MODULUS for _ in range(64)]; qb = [(rng.fr() * rng.fr() + 5) % p.FQ_MODULUS for _ in range(64)]
+    qam, qbm = c.fq_to_mont(c.ints_to_limbs(qa, 6)), c.fq_to_mont(c.ints_to_limbs(qb, 6))
+    r = np.zeros_like(qam); c.lib().oracle_fq_mul(c._p(r), c._p(qam), c._p(qbm), 64)
+    assert c.limbs_to_ints(c.fq_from_mont(r)) == [x * y % p.FQ_MODULUS for x, y in zip(qa, qb)]
+
+
+def golden_msm_cases():
+    fx = json.load(open(os.path.join(G, 'msm_small.json')))
+    gen = (int(fx['generator'][0], 16), int(fx['generator'][1], 16))
+    assert gen == p.G1_GENERATOR
+    return fx['cases']
+
+
+def bases_for_case(case):
+    pts = [p.g1_mul(p.G1_GENERATOR, k) if k else None for k in case['base_multipliers']]
+    return c.affine_from_ints(pts)
+
+
+@pytest.mark.parametrize('variant', [0, 1])
+def test_oracle_msm_matches_golden(variant):
+    for case in golden_msm_cases():
+        B = bases_for_case(case); S = c.ints_to_limbs(_ints(case['scalars']), 4)
+        exp = None if case['result'] is None else (int(case['result'][0], 16), int(case['result'][1], 16))
+        for threads in (1, 3):
+            assert c.jac_to_int_point(c.msm_g1(B, S, threads=threads, variant=variant)) == exp, (case['n'], case['kind'])
+        if case['n'] <= 33:
+            assert c.jac_to_int_point(c.msm_g1_naive(B, S)) == exp
+
+
+def test_oracle_msm_stride96_and_edge_cases():
+    rng = p.SplitMix64(11)
+    G1 = c.affine_from_ints([p.G1_GENERATOR])[0]
+    B = c.g1_multiples(G1, 50); S = c.ints_to_limbs([rng.fr() for _ in range(50)], 4)
+    a = c.jac_to_int_point(c.msm_g1(B, S, variant=1))
+    assert a == c.jac_to_int_point(c.msm_g1(np.ascontiguousarray(B[:, :96]), S, variant=1))
+    assert c.jac_to_int_point(c.msm_g1(B[:0], S[:0])) is None                      # empty input -> identity
+    same = np.repeat(B[:1], 40, axis=0); five = c.ints_to_limbs([5] * 40, 4)          # every pair collides: doublings
+    assert c.jac_to_int_point(c.msm_g1(same, five, variant=1)) == p.g1_mul(p.G1_GENERATOR, 200)
+    neg = c.affine_from_ints([p.g1_neg(p.G1_GENERATOR)])
+    pm = np.concatenate([B[:1], neg] * 6, axis=0); s77 = c.ints_to_limbs([77] * 12, 4)  # P and -P cancel
+    assert c.jac_to_int_point(c.msm_g1(pm, s77, variant=1)) is None
+    assert c.jac_to_int_point(c.msm_g1(pm, s77, variant=0)) is None
+
+
+def test_oracle_ntt_matches_golden():
+    fx = json.load(open(os.path.join(G, 'ntt_small.json')))
+    assert int(fx['two_adic_root'], 16) == p.FR_TWO_ADIC_ROOT and fx['generator'] == 22
+    for case in fx['cases']:
+        n = case['n']; x = _ints(case['input']); x = x + [0] * (n - len(x))            # fft() zero-pads to the domain
+        xm = c.fr_to_mont(c.ints_to_limbs(x, 4))
+        for name, (direction, type_) in {'fft': (0, 0), 'ifft': (1, 0), 'coset_fft': (0, 1), 'coset_ifft': (1, 1)}.items():
+            if name not in case: continue
+            got = c.limbs_to_ints(c.fr_from_mont(c.ntt_fr(xm, 0, direction, type_)))
+            assert got == _ints(case[name]), (n, name)
+
+
+def test_oracle_ntt_orders_and_roundtrip():
+    rng = p.SplitMix64(13)
+    n = 512; x = [rng.fr() for _ in range(n)]; xm = c.fr_to_mont(c.ints_to_limbs(x, 4))
+    nat = c.ntt_fr(xm, 0, 0, 0)
+    assert (c.ntt_fr(nat, 0, 1, 0) == xm).all()                                        # ifft(fft(x)) == x
+    assert (c.ntt_fr(c.ntt_fr(xm, 0, 0, 1), 0, 1, 1) == xm).all()                      # coset round trip
+    nat_i = c.limbs_to_ints(nat)
+    assert c.limbs_to_ints(c.ntt_fr(xm, 1, 0, 0)) == p.bit_reverse_permute(nat_i)      # NR
+    xr = c.fr_to_mont(c.ints_to_limbs(p.bit_reverse_permute(x), 4))
+    assert c.limbs_to_ints(c.ntt_fr(xr, 2, 0, 0)) == nat_i                             # RN
+    assert c.limbs_to_ints(c.ntt_fr(xr, 3, 0, 0)) == p.bit_reverse_permute(nat_i)      # RR
+    assert c.limbs_to_ints(c.fr_from_mont(nat)) == p.fft_fast(x, p.EvaluationDomain(n).group_gen)
+
+
+def test_oracle_kzg_commit_shape():
+    rng = p.SplitMix64(17)
+    G1 = c.affine_from_ints([p.G1_GENERATOR])[0]
+    n = 40; B = c.g1_multiples(G1, n); coeff = [rng.fr() for _ in range(n)]
+    cm = c.fr_to_mont(c.ints_to_limbs(coeff, 4))
+    got = c.affine_to_ints(c.kzg_commit(B, cm, threads=2))[0]
+    k = sum((i + 1) * v for i, v in enumerate(coeff)) % p.FR_MODULUS
+    assert got == p.g1_mul(p.G1_GENERATOR, k)
