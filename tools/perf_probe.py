@@ -1,0 +1,40 @@
+"""Device-side timing probe (not a test): NTT and MSM phase times at several sizes, HIP events on the launch stream."""
+import os, sys, time, json
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+import numpy as np, torch
+import aleo_amd
+from aleo_amd import synth, msm as M
+
+dev = torch.device('cuda', 0); torch.cuda.set_device(0)
+aleo_amd._lib.check(aleo_amd.lib().aleo_mi355x_init(0), 'init')
+st = torch.cuda.current_stream().cuda_stream
+what = sys.argv[1] if len(sys.argv) > 1 else 'all'
+if what in ('all', 'ntt'):
+    for lg in (16, 20, 22, 24):
+        n = 1 << lg
+        x = torch.from_numpy(synth.uniform_scalars(n, lg).view(np.int64)).to(dev)
+        d = aleo_amd.EvaluationDomain(n)
+        for (direction, type_) in ((0, 0), (1, 1)):
+            d.ntt_device(x.data_ptr(), 0, direction, type_, st); torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(True), torch.cuda.Event(True)
+            reps = 10
+            e0.record()
+            for _ in range(reps): d.ntt_device(x.data_ptr(), 0, direction, type_, st)
+            e1.record(); torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / reps
+            print(json.dumps({'ntt_lg': lg, 'dir': direction, 'coset': type_, 'ms': ms, 'GBps_alg': 64.0 * n / ms / 1e6, 'frac_hbm': 64.0 * n / ms / 1e6 / 8000}), flush=True)
+if what in ('all', 'msm'):
+    for lg in (16, 18, 20, 22):
+        n = 1 << lg
+        pb = M.PinnedBases.generate_multiples(synth.generator_affine104(), 1, n)
+        for kind, mk in (('uniform', synth.uniform_scalars), ('witness', synth.witness_like_scalars)):
+            s = torch.from_numpy(mk(n, 77 + lg).view(np.int64)).to(dev); torch.cuda.synchronize()
+            M.VariableBase.msm_device(pb, s.data_ptr(), n)
+            t0 = time.perf_counter(); reps = 5
+            tms = []
+            for _ in range(reps):
+                M.VariableBase.msm_device(pb, s.data_ptr(), n); tms.append(M.last_msm_timing())
+            dt = (time.perf_counter() - t0) / reps
+            avg = {k: float(np.mean([t[k] for t in tms])) for k in tms[0]}
+            print(json.dumps({'msm_lg': lg, 'scalars': kind, 'wall_ms': dt * 1e3, 'Mpts_s': n / dt / 1e6, **avg}), flush=True)
+        pb.close()
