@@ -54,7 +54,7 @@ struct Ctx {
   std::mutex mu;                       // serialises calls on this device
   hipEvent_t ev[8] = {};
   // MSM workspaces
-  DevBuf hist, scan_local, scan_blk, sorted, partial, task_g, meta, vbuf, scalars_stage, out_stage;
+  DevBuf hist, scan_local, scan_blk, sorted, part_cnt, part_items, partial, task_g, meta, vbuf, scalars_stage, out_stage;
   void* h_pinned = nullptr; size_t h_pinned_cap = 0;    // pinned host staging for small D2H results
   std::map<uint64_t, PinnedBases> bases; uint64_t next_handle = 1;
   MsmTiming last_msm;

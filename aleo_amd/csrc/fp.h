@@ -59,18 +59,16 @@ template <class Pm> struct Fp {
 
   // Montgomery product, lazily reduced (see header).
   __device__ __forceinline__ static Fp mul(const Fp& a, const Fp& b) {
-    Fp r;
-    constexpr Limbs<N> q = Pm::P;
-    if constexpr (N == 12) mont_mul_12(r.v, a.v, b.v, q.v); else mont_mul_8(r.v, a.v, b.v, q.v);
+    Fp r = a;    // the asm block works in place (a <- a*b); the copy is elided when `a` is dead afterwards
+    if constexpr (N == 12) mont_mul_12_inplace(r.v, b.v); else mont_mul_8_inplace(r.v, b.v);
     return r;
   }
   __device__ __forceinline__ static Fp sqr(const Fp& a) { return mul(a, a); }
 
   // a + b, no reduction.  Caller guarantees the sum stays below 2^(32N).
   __device__ __forceinline__ static Fp add(const Fp& a, const Fp& b) {
-    Fp r; uint64_t c = 0;
-#pragma unroll
-    for (int i = 0; i < N; ++i) { c += (uint64_t)a.v[i] + b.v[i]; r.v[i] = (uint32_t)c; c >>= 32; }
+    Fp r = a;    // generated carry chain works in place
+    if constexpr (N == 12) fp_add_12(r.v, b.v); else fp_add_8(r.v, b.v);
     return r;
   }
   // a - b as integers mod 2^(32N) (used as a building block; callers add a multiple of p).
@@ -84,11 +82,15 @@ template <class Pm> struct Fp {
   }
   // a + K*p - b   (b < K*p  =>  result in [0, a + K*p))
   template <int K> __device__ __forceinline__ static Fp sub(const Fp& a, const Fp& b) {
-    constexpr Limbs<N> kp = limbs_mul_small<N>(Pm::P, (uint32_t)K);
-    uint32_t br; Fp t = sub_raw(a, b, br);
-    Fp r; uint64_t c = 0;
-#pragma unroll
-    for (int i = 0; i < N; ++i) { c += (uint64_t)t.v[i] + kp.v[i]; r.v[i] = (uint32_t)c; c >>= 32; }
+    static_assert(K == 1 || K == 2 || K == 4 || K == 8, "sub<K>: K*p literals are generated for K in {1,2,4,8}");
+    Fp r = a;
+    if constexpr (N == 12) {
+      if constexpr (K == 1) fp_sub_12_k1(r.v, b.v); else if constexpr (K == 2) fp_sub_12_k2(r.v, b.v);
+      else if constexpr (K == 4) fp_sub_12_k4(r.v, b.v); else fp_sub_12_k8(r.v, b.v);
+    } else {
+      if constexpr (K == 1) fp_sub_8_k1(r.v, b.v); else if constexpr (K == 2) fp_sub_8_k2(r.v, b.v);
+      else if constexpr (K == 4) fp_sub_8_k4(r.v, b.v); else fp_sub_8_k8(r.v, b.v);
+    }
     return r;
   }
   __device__ __forceinline__ static Fp dbl(const Fp& a) { return add(a, a); }

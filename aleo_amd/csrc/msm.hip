@@ -35,7 +35,9 @@ static MsmPlan make_plan(size_t n) {
   uint32_t lg = 0; while (((size_t)1 << (lg + 1)) <= n) ++lg;
   int c = (int)lg - 4; if (c < 2) c = 2; if (c > 16) c = 16;
   p.c = (uint32_t)c; p.W = (SCALAR_BITS + p.c - 1) / p.c; p.B = 1u << (p.c - 1); p.M = p.W * p.B;
-  p.T0 = 32;                                 // max points per slice
+  // Max points per slice.  64 keeps (almost) every Poisson(32) bucket of a large uniform MSM in ONE slice, so the
+  // slice tree has nothing to do; smaller inputs use shorter slices to keep every SIMD busy.
+  p.T0 = (n * (size_t)p.W / 64 + p.M >= 4 * 65536) ? 64 : 32;
   p.S = p.B >= 8 ? 8 : p.B;                  // buckets per running-sum chunk
   return p;
 }
@@ -74,13 +76,135 @@ template <int C, int W_IDX, class F> __device__ __forceinline__ void for_each_di
   }
 }
 
+// ---- counting sort of the n*W (bucket, point) pairs: two LDS-partitioned levels, no global atomics ----
+// (A first version drew one global atomic per pair: 1.5 ms at 2^20 uniform and 4.9 ms on witness-like scalars,
+//  whose 0/1 values pile onto a few counters — profiles/r01_v1_kernel_stats.csv.)
+// Level 1 splits by (window, high bucket bits) into <= 2048 coarse bins: every block histograms a tile of 2048
+// scalars in LDS, an exclusive scan over the [bin][block] count matrix gives each block a private output run per
+// bin, and the scatter pass ranks items with LDS atomics.  Level 2 gives one block per coarse bin: an LDS
+// histogram over the low 8 bucket bits yields the final per-bucket counts and positions.
+static constexpr uint32_t PART_TILE = 2048;       // scalars per block in the level-1 passes
+static constexpr uint32_t MAX_COARSE = 2048;      // W * (B >> LB) at c = 16
+
+template <int C> struct SortGeom {
+  static constexpr uint32_t W = (SCALAR_BITS + C - 1) / C, B = 1u << (C - 1);
+  static constexpr uint32_t LB = (C - 1) < 8 ? (C - 1) : 8;       // low bucket bits, sorted in level 2
+  static constexpr uint32_t CB = B >> LB, NCB = W * CB;
+  static_assert(NCB <= MAX_COARSE, "coarse bin table too small");
+};
+
 template <int C, bool MONT>
-__global__ void __launch_bounds__(256) k_hist(const void* scalars, const uint8_t* inf, uint32_t n, uint32_t* hist) {
-  uint32_t i = blockIdx.x * 256 + threadIdx.x; if (i >= n) return;
-  if (inf && inf[i]) return;
-  uint32_t s[8]; load_scalar<MONT>(scalars, i, s);
-  constexpr uint32_t B = 1u << (C - 1);
-  for_each_digit<C, 0>(s, 0u, [&](uint32_t w, uint32_t b, uint32_t) { atomicAdd(&hist[w * B + b], 1u); });
+__global__ void __launch_bounds__(256) k_part_count(const void* scalars, const uint8_t* inf, uint32_t n, uint32_t nblk, uint32_t* __restrict__ cnt) {
+  using Gm = SortGeom<C>;
+  __shared__ uint32_t h[MAX_COARSE];
+  for (uint32_t i = threadIdx.x; i < Gm::NCB; i += 256) h[i] = 0;
+  __syncthreads();
+  const uint32_t base = blockIdx.x * PART_TILE;
+  for (uint32_t q = 0; q < PART_TILE / 256; ++q) {
+    uint32_t i = base + q * 256 + threadIdx.x;
+    if (i < n && !(inf && inf[i])) {
+      uint32_t s[8]; load_scalar<MONT>(scalars, i, s);
+      for_each_digit<C, 0>(s, 0u, [&](uint32_t w, uint32_t b, uint32_t) { atomicAdd(&h[w * Gm::CB + (b >> Gm::LB)], 1u); });
+    }
+  }
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < Gm::NCB; i += 256) cnt[(size_t)i * nblk + blockIdx.x] = h[i];     // [bin][block]
+}
+
+// plain exclusive scan of uint32 (tiles of SCAN_TILE + one top block); position(i) = local[i] + blk[i / SCAN_TILE]
+__global__ void __launch_bounds__(256) k_scan32_tiles(const uint32_t* __restrict__ in, uint32_t len, uint32_t* __restrict__ local, uint32_t* __restrict__ tile_tot) {
+  __shared__ uint32_t wsum[4];
+  uint32_t base = blockIdx.x * SCAN_TILE + threadIdx.x * 8;
+  uint32_t c[8], pre[8], run = 0;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) c[k] = (base + k < len) ? in[base + k] : 0u;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { pre[k] = run; run += c[k]; }
+  uint32_t inc = run; int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) { uint32_t o = __shfl_up(inc, d); if (lane >= d) inc += o; }
+  if (lane == 63) wsum[wv] = inc;
+  __syncthreads();
+  uint32_t woff = 0; for (int k = 0; k < wv; ++k) woff += wsum[k];
+  uint32_t excl = woff + inc - run;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) if (base + k < len) local[base + k] = excl + pre[k];
+  if (threadIdx.x == 255) tile_tot[blockIdx.x] = woff + inc;
+}
+__global__ void __launch_bounds__(256) k_scan32_top(const uint32_t* __restrict__ tile_tot, uint32_t ntiles, uint32_t* __restrict__ blk) {
+  __shared__ uint32_t sh[256]; __shared__ uint32_t carry;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (uint32_t b0 = 0; b0 < ntiles; b0 += 256) {
+    uint32_t i = b0 + threadIdx.x, v = i < ntiles ? tile_tot[i] : 0u;
+    sh[threadIdx.x] = v; __syncthreads();
+    for (int d = 1; d < 256; d <<= 1) {
+      uint32_t o = threadIdx.x >= (uint32_t)d ? sh[threadIdx.x - d] : 0u;
+      __syncthreads(); sh[threadIdx.x] += o; __syncthreads();
+    }
+    uint32_t inc = sh[threadIdx.x], cr = carry;
+    if (i < ntiles) blk[i] = cr + inc - v;
+    __syncthreads();
+    if (threadIdx.x == 255) carry = cr + inc;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) blk[ntiles] = carry;       // grand total
+}
+__device__ __forceinline__ uint32_t scan32_at(const uint32_t* local, const uint32_t* blk, size_t i) { return local[i] + blk[i / SCAN_TILE]; }
+
+template <int C, bool MONT>
+__global__ void __launch_bounds__(256) k_part_scatter(const void* scalars, const uint8_t* inf, uint32_t n, uint32_t nblk,
+                                                      const uint32_t* __restrict__ off_local, const uint32_t* __restrict__ off_blk, uint2* __restrict__ items) {
+  using Gm = SortGeom<C>;
+  __shared__ uint32_t cur[MAX_COARSE];
+  for (uint32_t i = threadIdx.x; i < Gm::NCB; i += 256) cur[i] = scan32_at(off_local, off_blk, (size_t)i * nblk + blockIdx.x);
+  __syncthreads();
+  const uint32_t base = blockIdx.x * PART_TILE;
+  for (uint32_t q = 0; q < PART_TILE / 256; ++q) {
+    uint32_t i = base + q * 256 + threadIdx.x;
+    if (i < n && !(inf && inf[i])) {
+      uint32_t s[8]; load_scalar<MONT>(scalars, i, s);
+      for_each_digit<C, 0>(s, 0u, [&](uint32_t w, uint32_t b, uint32_t neg) {
+        uint32_t pos = atomicAdd(&cur[w * Gm::CB + (b >> Gm::LB)], 1u);
+        items[pos] = make_uint2(i | (neg << 31), b & ((1u << Gm::LB) - 1u));
+      });
+    }
+  }
+}
+
+// Level 2: one block per coarse bin.  Writes hist[g] for the bin's 2^LB buckets and the sorted index stream.
+__global__ void __launch_bounds__(256) k_bin_sort(const uint2* __restrict__ items, const uint32_t* __restrict__ off_local, const uint32_t* __restrict__ off_blk,
+                                                  uint32_t nblk, uint32_t ncb, uint32_t cnt_tiles, uint32_t LB, uint32_t* __restrict__ hist, uint32_t* __restrict__ sorted) {
+  __shared__ uint32_t h[256], o[256];
+  const uint32_t bin = blockIdx.x, tid = threadIdx.x;
+  const uint32_t start = scan32_at(off_local, off_blk, (size_t)bin * nblk);
+  const uint32_t end = (bin + 1 < ncb) ? scan32_at(off_local, off_blk, (size_t)(bin + 1) * nblk) : off_blk[cnt_tiles];
+  h[tid] = 0;
+  __syncthreads();
+  for (uint32_t i0 = start; i0 < end; i0 += 256 * 4) {
+    uint32_t key[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { uint32_t i = i0 + u * 256 + tid; key[u] = i < end ? items[i].y : 0xffffffffu; }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) if (key[u] != 0xffffffffu) atomicAdd(&h[key[u]], 1u);
+  }
+  __syncthreads();
+  const uint32_t v = h[tid];
+  if (tid < (1u << LB)) hist[((size_t)bin << LB) + tid] = v;
+  o[tid] = v; __syncthreads();
+  for (int d = 1; d < 256; d <<= 1) {
+    uint32_t t = tid >= (uint32_t)d ? o[tid - d] : 0u;
+    __syncthreads(); o[tid] += t; __syncthreads();
+  }
+  h[tid] = start + o[tid] - v;          // absolute cursor of fine bucket tid
+  __syncthreads();
+  for (uint32_t i0 = start; i0 < end; i0 += 256 * 4) {
+    uint2 it[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { uint32_t i = i0 + u * 256 + tid; it[u] = i < end ? items[i] : make_uint2(0u, 0xffffffffu); }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) if (it[u].y != 0xffffffffu) sorted[atomicAdd(&h[it[u].y], 1u)] = it[u].x;
+  }
 }
 
 // ---- exclusive scan of (count, slices) over the M buckets --------------------------------------
@@ -144,46 +268,84 @@ __device__ __forceinline__ uint2 scan_at(const uint2* local, const uint2* blk, u
   uint2 a = local[g], b = blk[g / SCAN_TILE]; return make_uint2(a.x + b.x, a.y + b.y);
 }
 
-template <int C, bool MONT>
-__global__ void __launch_bounds__(256) k_scatter(const void* scalars, const uint8_t* inf, uint32_t n, const uint2* scan_local, const uint2* scan_blk, uint32_t* cursor, uint32_t* sorted) {
-  uint32_t i = blockIdx.x * 256 + threadIdx.x; if (i >= n) return;
-  if (inf && inf[i]) return;
-  uint32_t s[8]; load_scalar<MONT>(scalars, i, s);
-  constexpr uint32_t B = 1u << (C - 1);
-  for_each_digit<C, 0>(s, 0u, [&](uint32_t w, uint32_t b, uint32_t neg) {
-    uint32_t g = w * B + b;
-    uint32_t pos = scan_at(scan_local, scan_blk, g).x + atomicAdd(&cursor[g], 1u);
-    sorted[pos] = i | (neg << 31);
-  });
+// ---- slice ordering: lanes of one wave should run the same trip count --------------------------------
+// Slices are at most T0 <= 64 points long; bucket sizes are Poisson, so slice lengths vary 2:1 inside a wave if
+// taken in bucket order (measured: 31 % of the accumulation's lanes idle).  A counting sort by length (longest
+// first) costs two tiny launches: block-local LDS histograms + <= 65 global atomics per block.
+static constexpr uint32_t MAX_T0 = 64;
+__device__ __forceinline__ uint32_t slice_len(uint32_t cnt, uint32_t m, uint32_t k) {
+  return (uint32_t)(((uint64_t)(k + 1) * cnt) / m) - (uint32_t)(((uint64_t)k * cnt) / m);
+}
+
+// sid -> bucket (binary search over first_slice), stores task_g[sid], counts slice lengths
+__global__ void __launch_bounds__(256) k_slice_count(const uint32_t* __restrict__ hist, const uint2* __restrict__ scan_local, const uint2* __restrict__ scan_blk,
+                                                     uint32_t M, uint32_t T0, const uint32_t* __restrict__ meta, uint32_t* __restrict__ task_g,
+                                                     uint32_t* __restrict__ len_count) {
+  __shared__ uint32_t h[MAX_T0 + 1];
+  if (threadIdx.x <= MAX_T0) h[threadIdx.x] = 0;
+  __syncthreads();
+  uint32_t t = blockIdx.x * 256 + threadIdx.x;
+  if (t < meta[0]) {
+    uint32_t lo = 0, hi = M - 1;        // largest g with first_slice(g) <= t
+    while (lo < hi) {
+      uint32_t mid = (lo + hi + 1) >> 1;
+      if (scan_at(scan_local, scan_blk, mid).y <= t) lo = mid; else hi = mid - 1;
+    }
+    uint32_t g = lo, cnt = hist[g], m = slices_of(cnt, T0), k = t - scan_at(scan_local, scan_blk, g).y;
+    task_g[t] = g;
+    atomicAdd(&h[slice_len(cnt, m, k)], 1u);
+  }
+  __syncthreads();
+  if (threadIdx.x <= MAX_T0 && h[threadIdx.x]) atomicAdd(&len_count[threadIdx.x], h[threadIdx.x]);
+}
+
+// order[pos] = sid, longest slices first
+__global__ void __launch_bounds__(256) k_slice_order(const uint32_t* __restrict__ hist, const uint2* __restrict__ scan_local, const uint2* __restrict__ scan_blk,
+                                                     uint32_t T0, const uint32_t* __restrict__ meta, const uint32_t* __restrict__ task_g,
+                                                     const uint32_t* __restrict__ len_count, uint32_t* __restrict__ len_cursor, uint32_t* __restrict__ order) {
+  __shared__ uint32_t h[MAX_T0 + 1], base[MAX_T0 + 1];
+  if (threadIdx.x <= MAX_T0) h[threadIdx.x] = 0;
+  __syncthreads();
+  uint32_t t = blockIdx.x * 256 + threadIdx.x, len = 0, rank = 0;
+  bool live = t < meta[0];
+  if (live) {
+    uint32_t g = task_g[t], cnt = hist[g], m = slices_of(cnt, T0), k = t - scan_at(scan_local, scan_blk, g).y;
+    len = slice_len(cnt, m, k);
+    rank = atomicAdd(&h[len], 1u);
+  }
+  __syncthreads();
+  if (threadIdx.x <= MAX_T0) {
+    uint32_t start = 0;                       // slices longer than this one come first
+    for (uint32_t l = threadIdx.x + 1; l <= MAX_T0; ++l) start += len_count[l];
+    base[threadIdx.x] = start + (h[threadIdx.x] ? atomicAdd(&len_cursor[threadIdx.x], h[threadIdx.x]) : 0u);
+  }
+  __syncthreads();
+  if (live) order[base[len] + rank] = t;
 }
 
 // ---- bucket accumulation: one lane per slice ----------------------------------------------------
 __global__ void __launch_bounds__(256) k_accum(const char* __restrict__ bases, const uint32_t* __restrict__ sorted, const uint32_t* __restrict__ hist,
-                                               const uint2* __restrict__ scan_local, const uint2* __restrict__ scan_blk, uint32_t M, uint32_t T0,
-                                               const uint32_t* __restrict__ meta, char* __restrict__ partial, uint32_t* __restrict__ task_g) {
+                                               const uint2* __restrict__ scan_local, const uint2* __restrict__ scan_blk, uint32_t T0,
+                                               const uint32_t* __restrict__ meta, const uint32_t* __restrict__ order, const uint32_t* __restrict__ task_g,
+                                               char* __restrict__ partial) {
   uint32_t t = blockIdx.x * 256 + threadIdx.x;
   if (t >= meta[0]) return;
-  // largest g with first_slice(g) <= t
-  uint32_t lo = 0, hi = M - 1;
-  while (lo < hi) {
-    uint32_t mid = (lo + hi + 1) >> 1;
-    if (scan_at(scan_local, scan_blk, mid).y <= t) lo = mid; else hi = mid - 1;
-  }
-  uint32_t g = lo;
+  const uint32_t sid = order[t], g = task_g[sid];
   uint2 st = scan_at(scan_local, scan_blk, g);
-  uint32_t cnt = hist[g], m = slices_of(cnt, T0), k = t - st.y;
+  uint32_t cnt = hist[g], m = slices_of(cnt, T0), k = sid - st.y;
   uint32_t j0 = (uint32_t)(((uint64_t)k * cnt) / m), j1 = (uint32_t)(((uint64_t)(k + 1) * cnt) / m);
   const uint32_t* run = sorted + st.x;
-  XYZZ acc; bool inf = true;
-  acc = xyzz_infinity();
+  XYZZ acc = xyzz_infinity(); bool inf = true;
+  // software prefetch: the next point's 96-byte gather is in flight under the current mixed addition
+  uint32_t e_next = run[j0];
+  AffinePt p_next = load_affine(bases + (size_t)(e_next & 0x7fffffffu) * 96);
   for (uint32_t j = j0; j < j1; ++j) {
-    uint32_t e = run[j];
-    AffinePt p = load_affine(bases + (size_t)(e & 0x7fffffffu) * 96);
+    uint32_t e = e_next; AffinePt p = p_next;
+    if (j + 1 < j1) { e_next = run[j + 1]; p_next = load_affine(bases + (size_t)(e_next & 0x7fffffffu) * 96); }
     if (e >> 31) p.y = fq_neg_canonical(p.y);
     xyzz_madd(acc, inf, p.x, p.y);
   }
-  xyzz_store_normalized(partial + (size_t)t * 192, acc, inf);
-  task_g[t] = g;
+  xyzz_store_normalized(partial + (size_t)sid * 192, acc, inf);
 }
 
 // partial[t] += partial[t + half] inside every bucket that still has more than one slice
@@ -262,16 +424,14 @@ __global__ void k_gather_windows(const char* __restrict__ V, uint32_t seg_len, u
 }
 
 // ---- dispatch on the window width ---------------------------------------------------------------
-template <bool MONT> static void launch_hist(int c, dim3 g, hipStream_t s, const void* sc, const uint8_t* inf, uint32_t n, uint32_t* hist) {
-  switch (c) {
-#define CASE(C) case C: hipLaunchKernelGGL((k_hist<C, MONT>), g, dim3(256), 0, s, sc, inf, n, hist); break;
-    CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8) CASE(9) CASE(10) CASE(11) CASE(12) CASE(13) CASE(14) CASE(15) CASE(16)
-#undef CASE
-  }
+struct SortArgs { const void* scalars; const uint8_t* inf; uint32_t n, nblk; uint32_t* cnt; uint32_t* off_local; uint32_t* off_blk; uint2* items; };
+template <int C, bool MONT> static void launch_sort_c(const SortArgs& a, int phase, hipStream_t s) {
+  if (phase == 0) hipLaunchKernelGGL((k_part_count<C, MONT>), dim3(a.nblk), dim3(256), 0, s, a.scalars, a.inf, a.n, a.nblk, a.cnt);
+  else hipLaunchKernelGGL((k_part_scatter<C, MONT>), dim3(a.nblk), dim3(256), 0, s, a.scalars, a.inf, a.n, a.nblk, a.off_local, a.off_blk, a.items);
 }
-template <bool MONT> static void launch_scatter(int c, dim3 g, hipStream_t s, const void* sc, const uint8_t* inf, uint32_t n, const uint2* sl, const uint2* sb, uint32_t* cur, uint32_t* sorted) {
+template <bool MONT> static void launch_sort(int c, const SortArgs& a, int phase, hipStream_t s) {
   switch (c) {
-#define CASE(C) case C: hipLaunchKernelGGL((k_scatter<C, MONT>), g, dim3(256), 0, s, sc, inf, n, sl, sb, cur, sorted); break;
+#define CASE(C) case C: launch_sort_c<C, MONT>(a, phase, s); break;
     CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8) CASE(9) CASE(10) CASE(11) CASE(12) CASE(13) CASE(14) CASE(15) CASE(16)
 #undef CASE
   }
@@ -289,12 +449,19 @@ int32_t msm_run(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, const void* 
   const size_t slices_max = pairs_max / P.T0 + M + 1;
   int32_t rc;
   // hist | cursor | meta live in one zero-initialised allocation
-  if ((rc = c->hist.reserve((2 * (size_t)M + 16) * 4))) return rc;
+  if ((rc = c->hist.reserve((2 * (size_t)M + 128) * 4))) return rc;
   if ((rc = c->scan_local.reserve((size_t)M * 8))) return rc;
   if ((rc = c->scan_blk.reserve(2 * (size_t)ntiles * 8 + 64))) return rc;
   if ((rc = c->sorted.reserve(pairs_max * 4))) return rc;
+  const uint32_t LB = (P.c - 1) < 8 ? (P.c - 1) : 8, ncb = P.W * (P.B >> LB);
+  const uint32_t nblk = (uint32_t)((n + PART_TILE - 1) / PART_TILE);
+  const size_t cnt_len = (size_t)ncb * nblk;
+  if (cnt_len >= (1ull << 32)) { g_last_error = "msm: partition table too large"; return ALEO_MI355X_ERR_BAD_ARG; }
+  const uint32_t cnt_tiles = (uint32_t)((cnt_len + SCAN_TILE - 1) / SCAN_TILE);
+  if ((rc = c->part_cnt.reserve((2 * cnt_len + 2 * (size_t)cnt_tiles + 8) * 4))) return rc;     // cnt | off_local | tile_tot | off_blk
+  if ((rc = c->part_items.reserve(pairs_max * 8))) return rc;
   if ((rc = c->partial.reserve(slices_max * 192))) return rc;
-  if ((rc = c->task_g.reserve(slices_max * 4))) return rc;
+  if ((rc = c->task_g.reserve(2 * slices_max * 4))) return rc;     // task_g | order
   const uint32_t cpw = P.B / P.S, nchunks = cpw * P.W;
   if ((rc = c->vbuf.reserve(((size_t)nchunks + P.W) * 192))) return rc;
   if ((rc = ensure_host_pinned(c, 64 + (size_t)P.W * 192))) return rc;
@@ -302,19 +469,24 @@ int32_t msm_run(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, const void* 
   uint32_t* hist = c->hist.as<uint32_t>(); uint32_t* cursor = hist + M; uint32_t* meta = cursor + M;
   uint2* scan_local = c->scan_local.as<uint2>();
   uint2* tile_tot = c->scan_blk.as<uint2>(); uint2* scan_blk = tile_tot + ntiles;
-  uint32_t* sorted = c->sorted.as<uint32_t>(); char* partial = c->partial.as<char>(); uint32_t* task_g = c->task_g.as<uint32_t>();
+  uint32_t* sorted = c->sorted.as<uint32_t>(); char* partial = c->partial.as<char>(); uint32_t* task_g = c->task_g.as<uint32_t>(); uint32_t* order = task_g + slices_max;
   char* V = c->vbuf.as<char>(); char* Vout = V + (size_t)nchunks * 192;
   const char* bases = (const char*)pb.d_xy;
 
   HIPCHK(hipEventRecord(c->ev[0], s));
-  HIPCHK(hipMemsetAsync(hist, 0, (2 * (size_t)M + 16) * 4, s));
-  dim3 gn((uint32_t)((n + 255) / 256));
-  if (scalars_are_mont) launch_hist<true>(P.c, gn, s, d_scalars, pb.d_inf, (uint32_t)n, hist);
-  else launch_hist<false>(P.c, gn, s, d_scalars, pb.d_inf, (uint32_t)n, hist);
+  HIPCHK(hipMemsetAsync(hist, 0, (2 * (size_t)M + 128) * 4, s));
+  SortArgs sa;
+  sa.scalars = d_scalars; sa.inf = pb.d_inf; sa.n = (uint32_t)n; sa.nblk = nblk;
+  sa.cnt = c->part_cnt.as<uint32_t>(); sa.off_local = sa.cnt + cnt_len;
+  uint32_t* cnt_tile_tot = sa.off_local + cnt_len; sa.off_blk = cnt_tile_tot + cnt_tiles;
+  sa.items = c->part_items.as<uint2>();
+  if (scalars_are_mont) launch_sort<true>(P.c, sa, 0, s); else launch_sort<false>(P.c, sa, 0, s);
+  hipLaunchKernelGGL(k_scan32_tiles, dim3(cnt_tiles), dim3(256), 0, s, sa.cnt, (uint32_t)cnt_len, sa.off_local, cnt_tile_tot);
+  hipLaunchKernelGGL(k_scan32_top, dim3(1), dim3(256), 0, s, cnt_tile_tot, cnt_tiles, sa.off_blk);
+  if (scalars_are_mont) launch_sort<true>(P.c, sa, 1, s); else launch_sort<false>(P.c, sa, 1, s);
+  hipLaunchKernelGGL(k_bin_sort, dim3(ncb), dim3(256), 0, s, sa.items, sa.off_local, sa.off_blk, nblk, ncb, cnt_tiles, LB, hist, sorted);
   hipLaunchKernelGGL(k_scan_tiles, dim3(ntiles), dim3(256), 0, s, hist, M, P.T0, scan_local, tile_tot, meta);
   hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(256), 0, s, tile_tot, ntiles, scan_blk, meta);
-  if (scalars_are_mont) launch_scatter<true>(P.c, gn, s, d_scalars, pb.d_inf, (uint32_t)n, scan_local, scan_blk, cursor, sorted);
-  else launch_scatter<false>(P.c, gn, s, d_scalars, pb.d_inf, (uint32_t)n, scan_local, scan_blk, cursor, sorted);
   // slice count / max slices per bucket decide the grid of the accumulation and the number of tree passes
   uint32_t* h_meta = (uint32_t*)c->h_pinned;
   HIPCHK(hipMemcpyAsync(h_meta, meta, 16, hipMemcpyDeviceToHost, s));
@@ -324,7 +496,10 @@ int32_t msm_run(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, const void* 
   if (NT > slices_max) { g_last_error = "msm: internal slice count overflow"; return ALEO_MI355X_ERR_HIP; }
   HIPCHK(hipEventRecord(c->ev[6], s));
   if (NT) {
-    hipLaunchKernelGGL(k_accum, dim3((NT + 255) / 256), dim3(256), 0, s, bases, sorted, hist, scan_local, scan_blk, M, P.T0, meta, partial, task_g);
+    uint32_t* len_count = meta + 4; uint32_t* len_cursor = len_count + MAX_T0 + 1;     // zeroed with hist/cursor/meta
+    hipLaunchKernelGGL(k_slice_count, dim3((NT + 255) / 256), dim3(256), 0, s, hist, scan_local, scan_blk, M, P.T0, meta, task_g, len_count);
+    hipLaunchKernelGGL(k_slice_order, dim3((NT + 255) / 256), dim3(256), 0, s, hist, scan_local, scan_blk, P.T0, meta, task_g, len_count, len_cursor, order);
+    hipLaunchKernelGGL(k_accum, dim3((NT + 255) / 256), dim3(256), 0, s, bases, sorted, hist, scan_local, scan_blk, P.T0, meta, order, task_g, partial);
     HIPCHK(hipEventRecord(c->ev[5], s));
     for (uint32_t pass = 0, L = max_m; L > 1; ++pass, L = (L + 1) >> 1)
       hipLaunchKernelGGL(k_tree_pass, dim3((NT + 255) / 256), dim3(256), 0, s, partial, task_g, scan_local, scan_blk, M, meta, pass);
