@@ -108,6 +108,32 @@ __device__ __forceinline__ void xyzz_madd(XYZZ& acc, bool& acc_inf, const Fq& x2
   acc.ZZZ = Fq::mul(acc.ZZZ, PPP);            // < 2q
 }
 
+// Hot-loop form of the mixed addition: acc is a finite point, no infinity flag, no doubling branch, nothing whose
+// address is taken (a call in the rare branch made hipcc spill the point to scratch on EVERY iteration: 1.6 GB of
+// scratch writes per 2^20 MSM, profiles/r01_pmc_*).  Returns false — leaving acc untouched — when the point has
+// the same x as acc (P == +-acc); the caller then finishes its slice with the general code out of line.
+__device__ __forceinline__ bool xyzz_madd_fast(XYZZ& acc, const Fq& x2, const Fq& y2) {
+  Fq U2 = Fq::mul(x2, acc.ZZ);                // < 2q
+  Fq S2 = Fq::mul(y2, acc.ZZZ);               // < 2q
+  Fq P = Fq::sub<8>(U2, acc.X);               // < 10q
+  Fq R = Fq::sub<4>(S2, acc.Y);               // < 6q
+  Fq PP = Fq::sqr(P);                         // < 2q
+  Fq ZZ3 = Fq::mul(acc.ZZ, PP);               // < 2q
+  if (__builtin_expect(ZZ3.is_zero_mod_lt2p(), 0)) return false;
+  Fq PPP = Fq::mul(P, PP);                    // < 2q
+  Fq Q = Fq::mul(acc.X, PP);                  // < 2q
+  Fq RR = Fq::sqr(R);                         // < 2q
+  Fq X3 = Fq::sub<4>(Fq::sub<2>(RR, PPP), Fq::dbl(Q));   // < 8q
+  Fq t = Fq::sub<8>(Q, X3);                   // < 10q
+  Fq Rt = Fq::mul(R, t);                      // < 2q
+  Fq YP = Fq::mul(acc.Y, PPP);                // < 2q
+  acc.X = X3;
+  acc.Y = Fq::sub<2>(Rt, YP);                 // < 4q
+  acc.ZZ = ZZ3;
+  acc.ZZZ = Fq::mul(acc.ZZZ, PPP);            // < 2q
+  return true;
+}
+
 // acc += b, both XYZZ (EFD add-2008-s).  Infinity encoded as raw ZZ == 0 on both sides.
 __device__ __forceinline__ void xyzz_add(XYZZ& acc, const XYZZ& b) {
   if (xyzz_is_inf(b)) return;

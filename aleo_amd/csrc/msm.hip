@@ -35,9 +35,7 @@ static MsmPlan make_plan(size_t n) {
   uint32_t lg = 0; while (((size_t)1 << (lg + 1)) <= n) ++lg;
   int c = (int)lg - 4; if (c < 2) c = 2; if (c > 16) c = 16;
   p.c = (uint32_t)c; p.W = (SCALAR_BITS + p.c - 1) / p.c; p.B = 1u << (p.c - 1); p.M = p.W * p.B;
-  // Max points per slice.  64 keeps (almost) every Poisson(32) bucket of a large uniform MSM in ONE slice, so the
-  // slice tree has nothing to do; smaller inputs use shorter slices to keep every SIMD busy.
-  p.T0 = (n * (size_t)p.W / 64 + p.M >= 4 * 65536) ? 64 : 32;
+  p.T0 = 0;                                  // chosen on the device: pick_t0()
   p.S = p.B >= 8 ? 8 : p.B;                  // buckets per running-sum chunk
   return p;
 }
@@ -211,10 +209,15 @@ __global__ void __launch_bounds__(256) k_bin_sort(const uint2* __restrict__ item
 // scan_local[g] = prefix inside the 2048-bucket tile; scan_blk[tile] = prefix of the tiles.  meta[0] = total
 // slices, meta[1] = max slices of one bucket, meta[2] = total pairs.
 __device__ __forceinline__ uint32_t slices_of(uint32_t cnt, uint32_t T0) { return (cnt + T0 - 1) / T0; }
+// Max points per slice, chosen on the device from the number of non-zero digits the sort found: 64 keeps (almost)
+// every Poisson(32) bucket of a large uniform MSM in ONE slice (the slice tree then has nothing to do); sparser
+// inputs (witness-like scalars, small n) use 32 so that the accumulation still fills every SIMD.
+__device__ __forceinline__ uint32_t pick_t0(const uint32_t* total_pairs) { return *total_pairs >= (8u << 20) ? 64u : 32u; }
 
-__global__ void __launch_bounds__(256) k_scan_tiles(const uint32_t* hist, uint32_t M, uint32_t T0, uint2* scan_local, uint2* tile_tot, uint32_t* meta) {
+__global__ void __launch_bounds__(256) k_scan_tiles(const uint32_t* hist, uint32_t M, const uint32_t* total_pairs, uint2* scan_local, uint2* tile_tot, uint32_t* meta) {
   __shared__ uint2 wsum[4];
   uint32_t base = blockIdx.x * SCAN_TILE + threadIdx.x * 8;
+  const uint32_t T0 = pick_t0(total_pairs);
   uint32_t c[8]; uint32_t mx = 0;
 #pragma unroll
   for (int k = 0; k < 8; ++k) c[k] = (base + k < M) ? hist[base + k] : 0u;
@@ -279,7 +282,7 @@ __device__ __forceinline__ uint32_t slice_len(uint32_t cnt, uint32_t m, uint32_t
 
 // sid -> bucket (binary search over first_slice), stores task_g[sid], counts slice lengths
 __global__ void __launch_bounds__(256) k_slice_count(const uint32_t* __restrict__ hist, const uint2* __restrict__ scan_local, const uint2* __restrict__ scan_blk,
-                                                     uint32_t M, uint32_t T0, const uint32_t* __restrict__ meta, uint32_t* __restrict__ task_g,
+                                                     uint32_t M, const uint32_t* __restrict__ total_pairs, const uint32_t* __restrict__ meta, uint32_t* __restrict__ task_g,
                                                      uint32_t* __restrict__ len_count) {
   __shared__ uint32_t h[MAX_T0 + 1];
   if (threadIdx.x <= MAX_T0) h[threadIdx.x] = 0;
@@ -291,7 +294,7 @@ __global__ void __launch_bounds__(256) k_slice_count(const uint32_t* __restrict_
       uint32_t mid = (lo + hi + 1) >> 1;
       if (scan_at(scan_local, scan_blk, mid).y <= t) lo = mid; else hi = mid - 1;
     }
-    uint32_t g = lo, cnt = hist[g], m = slices_of(cnt, T0), k = t - scan_at(scan_local, scan_blk, g).y;
+    uint32_t g = lo, cnt = hist[g], m = slices_of(cnt, pick_t0(total_pairs)), k = t - scan_at(scan_local, scan_blk, g).y;
     task_g[t] = g;
     atomicAdd(&h[slice_len(cnt, m, k)], 1u);
   }
@@ -301,7 +304,7 @@ __global__ void __launch_bounds__(256) k_slice_count(const uint32_t* __restrict_
 
 // order[pos] = sid, longest slices first
 __global__ void __launch_bounds__(256) k_slice_order(const uint32_t* __restrict__ hist, const uint2* __restrict__ scan_local, const uint2* __restrict__ scan_blk,
-                                                     uint32_t T0, const uint32_t* __restrict__ meta, const uint32_t* __restrict__ task_g,
+                                                     const uint32_t* __restrict__ total_pairs, const uint32_t* __restrict__ meta, const uint32_t* __restrict__ task_g,
                                                      const uint32_t* __restrict__ len_count, uint32_t* __restrict__ len_cursor, uint32_t* __restrict__ order) {
   __shared__ uint32_t h[MAX_T0 + 1], base[MAX_T0 + 1];
   if (threadIdx.x <= MAX_T0) h[threadIdx.x] = 0;
@@ -309,7 +312,7 @@ __global__ void __launch_bounds__(256) k_slice_order(const uint32_t* __restrict_
   uint32_t t = blockIdx.x * 256 + threadIdx.x, len = 0, rank = 0;
   bool live = t < meta[0];
   if (live) {
-    uint32_t g = task_g[t], cnt = hist[g], m = slices_of(cnt, T0), k = t - scan_at(scan_local, scan_blk, g).y;
+    uint32_t g = task_g[t], cnt = hist[g], m = slices_of(cnt, pick_t0(total_pairs)), k = t - scan_at(scan_local, scan_blk, g).y;
     len = slice_len(cnt, m, k);
     rank = atomicAdd(&h[len], 1u);
   }
@@ -324,26 +327,50 @@ __global__ void __launch_bounds__(256) k_slice_order(const uint32_t* __restrict_
 }
 
 // ---- bucket accumulation: one lane per slice ----------------------------------------------------
+__device__ __noinline__ void slice_slow_path(const char* bases, const uint32_t* run, uint32_t j, uint32_t j1, XYZZ* acc_io, bool* inf_io) {
+  XYZZ acc = *acc_io; bool inf = *inf_io;
+  for (; j < j1; ++j) {
+    uint32_t e = run[j];
+    AffinePt p = load_affine(bases + (size_t)(e & 0x7fffffffu) * 96);
+    if (e >> 31) p.y = fq_neg_canonical(p.y);
+    xyzz_madd(acc, inf, p.x, p.y);
+  }
+  *acc_io = acc; *inf_io = inf;
+}
+
 __global__ void __launch_bounds__(256) k_accum(const char* __restrict__ bases, const uint32_t* __restrict__ sorted, const uint32_t* __restrict__ hist,
-                                               const uint2* __restrict__ scan_local, const uint2* __restrict__ scan_blk, uint32_t T0,
+                                               const uint2* __restrict__ scan_local, const uint2* __restrict__ scan_blk, const uint32_t* __restrict__ total_pairs,
                                                const uint32_t* __restrict__ meta, const uint32_t* __restrict__ order, const uint32_t* __restrict__ task_g,
                                                char* __restrict__ partial) {
   uint32_t t = blockIdx.x * 256 + threadIdx.x;
   if (t >= meta[0]) return;
   const uint32_t sid = order[t], g = task_g[sid];
   uint2 st = scan_at(scan_local, scan_blk, g);
-  uint32_t cnt = hist[g], m = slices_of(cnt, T0), k = sid - st.y;
+  uint32_t cnt = hist[g], m = slices_of(cnt, pick_t0(total_pairs)), k = sid - st.y;
   uint32_t j0 = (uint32_t)(((uint64_t)k * cnt) / m), j1 = (uint32_t)(((uint64_t)(k + 1) * cnt) / m);
   const uint32_t* run = sorted + st.x;
-  XYZZ acc = xyzz_infinity(); bool inf = true;
   // software prefetch: the next point's 96-byte gather is in flight under the current mixed addition
   uint32_t e_next = run[j0];
   AffinePt p_next = load_affine(bases + (size_t)(e_next & 0x7fffffffu) * 96);
-  for (uint32_t j = j0; j < j1; ++j) {
+  XYZZ acc; bool inf = false, ok = true;
+  uint32_t j = j0;
+  {   // first point of the slice: acc = (x, +-y, 1, 1)
     uint32_t e = e_next; AffinePt p = p_next;
     if (j + 1 < j1) { e_next = run[j + 1]; p_next = load_affine(bases + (size_t)(e_next & 0x7fffffffu) * 96); }
     if (e >> 31) p.y = fq_neg_canonical(p.y);
-    xyzz_madd(acc, inf, p.x, p.y);
+    acc.X = p.x; acc.Y = p.y; acc.ZZ = Fq::one(); acc.ZZZ = Fq::one();
+    ++j;
+  }
+  for (; j < j1; ++j) {
+    uint32_t e = e_next; AffinePt p = p_next;
+    if (j + 1 < j1) { e_next = run[j + 1]; p_next = load_affine(bases + (size_t)(e_next & 0x7fffffffu) * 96); }
+    if (e >> 31) p.y = fq_neg_canonical(p.y);
+    if (!xyzz_madd_fast(acc, p.x, p.y)) { ok = false; break; }
+  }
+  if (!ok) {   // P == +-acc (repeated or opposite bases): finish the slice with the general, out-of-line code
+    XYZZ tmp = acc; bool tinf = false;
+    slice_slow_path(bases, run, j, j1, &tmp, &tinf);
+    acc = tmp; inf = tinf;
   }
   xyzz_store_normalized(partial + (size_t)sid * 192, acc, inf);
 }
@@ -446,10 +473,10 @@ int32_t msm_run(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, const void* 
   MsmPlan P = make_plan(n);
   const uint32_t M = P.M, ntiles = (M + SCAN_TILE - 1) / SCAN_TILE;
   const size_t pairs_max = n * (size_t)P.W;
-  const size_t slices_max = pairs_max / P.T0 + M + 1;
+  const size_t slices_max = pairs_max / 32 + M + 1;          // worst case of pick_t0()
   int32_t rc;
   // hist | cursor | meta live in one zero-initialised allocation
-  if ((rc = c->hist.reserve((2 * (size_t)M + 128) * 4))) return rc;
+  if ((rc = c->hist.reserve((2 * (size_t)M + 256) * 4))) return rc;
   if ((rc = c->scan_local.reserve((size_t)M * 8))) return rc;
   if ((rc = c->scan_blk.reserve(2 * (size_t)ntiles * 8 + 64))) return rc;
   if ((rc = c->sorted.reserve(pairs_max * 4))) return rc;
@@ -474,18 +501,19 @@ int32_t msm_run(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, const void* 
   const char* bases = (const char*)pb.d_xy;
 
   HIPCHK(hipEventRecord(c->ev[0], s));
-  HIPCHK(hipMemsetAsync(hist, 0, (2 * (size_t)M + 128) * 4, s));
+  HIPCHK(hipMemsetAsync(hist, 0, (2 * (size_t)M + 256) * 4, s));
   SortArgs sa;
   sa.scalars = d_scalars; sa.inf = pb.d_inf; sa.n = (uint32_t)n; sa.nblk = nblk;
   sa.cnt = c->part_cnt.as<uint32_t>(); sa.off_local = sa.cnt + cnt_len;
   uint32_t* cnt_tile_tot = sa.off_local + cnt_len; sa.off_blk = cnt_tile_tot + cnt_tiles;
   sa.items = c->part_items.as<uint2>();
+  const uint32_t* total_pairs = sa.off_blk + cnt_tiles;          // grand total of the level-1 scan
   if (scalars_are_mont) launch_sort<true>(P.c, sa, 0, s); else launch_sort<false>(P.c, sa, 0, s);
   hipLaunchKernelGGL(k_scan32_tiles, dim3(cnt_tiles), dim3(256), 0, s, sa.cnt, (uint32_t)cnt_len, sa.off_local, cnt_tile_tot);
   hipLaunchKernelGGL(k_scan32_top, dim3(1), dim3(256), 0, s, cnt_tile_tot, cnt_tiles, sa.off_blk);
   if (scalars_are_mont) launch_sort<true>(P.c, sa, 1, s); else launch_sort<false>(P.c, sa, 1, s);
   hipLaunchKernelGGL(k_bin_sort, dim3(ncb), dim3(256), 0, s, sa.items, sa.off_local, sa.off_blk, nblk, ncb, cnt_tiles, LB, hist, sorted);
-  hipLaunchKernelGGL(k_scan_tiles, dim3(ntiles), dim3(256), 0, s, hist, M, P.T0, scan_local, tile_tot, meta);
+  hipLaunchKernelGGL(k_scan_tiles, dim3(ntiles), dim3(256), 0, s, hist, M, total_pairs, scan_local, tile_tot, meta);
   hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(256), 0, s, tile_tot, ntiles, scan_blk, meta);
   // slice count / max slices per bucket decide the grid of the accumulation and the number of tree passes
   uint32_t* h_meta = (uint32_t*)c->h_pinned;
@@ -497,9 +525,9 @@ int32_t msm_run(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, const void* 
   HIPCHK(hipEventRecord(c->ev[6], s));
   if (NT) {
     uint32_t* len_count = meta + 4; uint32_t* len_cursor = len_count + MAX_T0 + 1;     // zeroed with hist/cursor/meta
-    hipLaunchKernelGGL(k_slice_count, dim3((NT + 255) / 256), dim3(256), 0, s, hist, scan_local, scan_blk, M, P.T0, meta, task_g, len_count);
-    hipLaunchKernelGGL(k_slice_order, dim3((NT + 255) / 256), dim3(256), 0, s, hist, scan_local, scan_blk, P.T0, meta, task_g, len_count, len_cursor, order);
-    hipLaunchKernelGGL(k_accum, dim3((NT + 255) / 256), dim3(256), 0, s, bases, sorted, hist, scan_local, scan_blk, P.T0, meta, order, task_g, partial);
+    hipLaunchKernelGGL(k_slice_count, dim3((NT + 255) / 256), dim3(256), 0, s, hist, scan_local, scan_blk, M, total_pairs, meta, task_g, len_count);
+    hipLaunchKernelGGL(k_slice_order, dim3((NT + 255) / 256), dim3(256), 0, s, hist, scan_local, scan_blk, total_pairs, meta, task_g, len_count, len_cursor, order);
+    hipLaunchKernelGGL(k_accum, dim3((NT + 255) / 256), dim3(256), 0, s, bases, sorted, hist, scan_local, scan_blk, total_pairs, meta, order, task_g, partial);
     HIPCHK(hipEventRecord(c->ev[5], s));
     for (uint32_t pass = 0, L = max_m; L > 1; ++pass, L = (L + 1) >> 1)
       hipLaunchKernelGGL(k_tree_pass, dim3((NT + 255) / 256), dim3(256), 0, s, partial, task_g, scan_local, scan_blk, M, meta, pass);

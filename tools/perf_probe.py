@@ -7,10 +7,10 @@ from aleo_amd import synth, msm as M
 
 dev = torch.device('cuda', 0); torch.cuda.set_device(0)
 aleo_amd._lib.check(aleo_amd.lib().aleo_mi355x_init(0), 'init')
-st = torch.cuda.current_stream().cuda_stream
+tstream = torch.cuda.Stream(); torch.cuda.set_stream(tstream); st = tstream.cuda_stream   # a real (non-null) stream: HIP events and the library share it
 what = sys.argv[1] if len(sys.argv) > 1 else 'all'
 if what in ('all', 'ntt'):
-    for lg in (16, 20, 22, 24):
+    for lg in (16, 20, 22, 24, 26):
         n = 1 << lg
         x = torch.from_numpy(synth.uniform_scalars(n, lg).view(np.int64)).to(dev)
         d = aleo_amd.EvaluationDomain(n)
