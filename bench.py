@@ -26,6 +26,8 @@ def main():
     ap.add_argument('--scalars', default='uniform', choices=['uniform', 'witness'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-sample-lg', type=int, default=18)
+    ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
+                    help="'gloo' is only for rehearsing the N>1 path with several ranks sharing one GPU")
     args = ap.parse_args()
 
     import torch
@@ -38,13 +40,18 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: the HIP path has no CPU fallback')
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
+    dev_index = local_rank % torch.cuda.device_count()          # one rank per GPU (ranks share a GPU only under --backend gloo)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device('cuda', dev_index)
+    gather_dev = dev if args.backend == 'nccl' else None       # RCCL gathers device tensors; gloo gathers host tensors
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        if args.backend == 'nccl':
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group('gloo', rank=rank, world_size=world)
     L = aleo_amd.lib()
-    aleo_amd._lib.check(L.aleo_mi355x_init(local_rank), 'init')
+    aleo_amd._lib.check(L.aleo_mi355x_init(dev_index), 'init')
 
     n = 1 << args.lg_n
     first = rank * n + 1
@@ -58,7 +65,7 @@ def main():
     def step():
         part = aleo_amd.VariableBase.msm_device(pb, d_scalars.data_ptr(), n)
         if world > 1:
-            return aleo_amd.g1_sum(adist.all_gather_partials(part, device=dev))
+            return aleo_amd.g1_sum(adist.all_gather_partials(part, device=gather_dev))
         return part
 
     def barrier():
@@ -76,7 +83,7 @@ def main():
     barrier(); t1 = time.perf_counter()
     elapsed = t1 - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=gather_dev if gather_dev is not None else 'cpu')
         dist.all_reduce(t, op=dist.ReduceOp.MAX); elapsed = float(t.item())
 
     # correctness gate: the result must equal k*G with k = sum_i s_i * (first+i) over all ranks (an O(n) identity)
