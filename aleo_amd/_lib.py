@@ -9,7 +9,7 @@ LIB_PATH = os.path.join(_HERE, 'lib', 'libaleo_mi355x.so')
 
 EXPORTS = [
     'aleo_mi355x_init', 'aleo_mi355x_msm_g1', 'aleo_mi355x_bases_pin', 'aleo_mi355x_bases_unpin',
-    'aleo_mi355x_bases_generate', 'aleo_mi355x_bases_download',
+    'aleo_mi355x_bases_generate', 'aleo_mi355x_bases_download', 'aleo_mi355x_bases_precompute',
     'aleo_mi355x_msm_g1_pinned', 'aleo_mi355x_msm_g1_device', 'aleo_mi355x_g1_sum', 'aleo_mi355x_ntt_fr',
     'aleo_mi355x_ntt_fr_device', 'aleo_mi355x_kzg_commit', 'aleo_mi355x_kzg_commit_device', 'aleo_mi355x_fq_mul',
     'aleo_mi355x_fr_mul', 'aleo_mi355x_last_msm_timing', 'aleo_mi355x_strerror', 'aleo_mi355x_last_error',
@@ -47,6 +47,7 @@ def lib():
         'aleo_mi355x_bases_unpin': ([u64], i32),
         'aleo_mi355x_bases_generate': ([vp, u64, sz, ctypes.POINTER(u64)], i32),
         'aleo_mi355x_bases_download': ([u64, sz, sz, vp], i32),
+        'aleo_mi355x_bases_precompute': ([u64], i32),
         'aleo_mi355x_msm_g1_pinned': ([vp, u64, vp, sz], i32),
         'aleo_mi355x_msm_g1_device': ([vp, u64, vp, sz, vp], i32),
         'aleo_mi355x_g1_sum': ([vp, vp, sz], i32),

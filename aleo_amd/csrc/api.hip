@@ -87,6 +87,7 @@ static int32_t unpin_locked(Ctx* c, uint64_t handle) {
   if (it == c->bases.end()) { g_last_error = "unknown bases handle"; return ALEO_MI355X_ERR_BAD_HANDLE; }
   if (it->second.d_xy) (void)hipFree(it->second.d_xy);
   if (it->second.d_inf) (void)hipFree(it->second.d_inf);
+  if (it->second.d_pre) (void)hipFree(it->second.d_pre);
   c->bases.erase(it);
   return ALEO_MI355X_OK;
 }
@@ -133,6 +134,15 @@ int32_t aleo_mi355x_bases_generate(const void* base104, uint64_t first, size_t n
     if (rc) return rc;
     uint64_t h = c->next_handle++; c->bases[h] = pb; *handle = h;
     return ALEO_MI355X_OK;
+  } catch (...) { return ALEO_MI355X_ERR_HIP; }
+}
+
+int32_t aleo_mi355x_bases_precompute(uint64_t handle) {
+  try {
+    API_BEGIN
+    auto it = c->bases.find(handle);
+    if (it == c->bases.end()) { g_last_error = "unknown bases handle"; return ALEO_MI355X_ERR_BAD_HANDLE; }
+    return msm_precompute(c, &it->second);
   } catch (...) { return ALEO_MI355X_ERR_HIP; }
 }
 

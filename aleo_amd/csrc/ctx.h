@@ -41,6 +41,7 @@ struct DevBuf {
 struct PinnedBases {
   void* d_xy = nullptr;        // n x 96 bytes: x | y, Montgomery, canonical
   uint8_t* d_inf = nullptr;    // n bytes, nullptr when no base is the point at infinity
+  void* d_pre = nullptr;       // optional fixed-base table: W x n x 96 bytes, row w holds 2^(20 w) * P_i (msm_precompute)
   size_t n = 0;
 };
 
@@ -70,6 +71,7 @@ int32_t msm_run(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, const void* 
 int32_t launch_fq_mul(Ctx* c, void* r, const void* a, const void* b, size_t n);
 int32_t launch_fr_mul(Ctx* c, void* r, const void* a, const void* b, size_t n);
 int32_t generate_multiples(Ctx* c, const void* base104, uint64_t first, size_t n, PinnedBases* out);
+int32_t msm_precompute(Ctx* c, PinnedBases* pb);
 // ntt.hip
 int32_t ntt_run(Ctx* c, void* d_inout, uint32_t lg_n, int32_t order, int32_t direction, int32_t type, hipStream_t s);
 

@@ -30,8 +30,14 @@ static constexpr uint32_t SCALAR_BITS = 254;    // 253-bit scalars + 1 bit of si
 
 struct MsmPlan { uint32_t c, W, B, M, T0, S; };
 
-static MsmPlan make_plan(size_t n) {
+static constexpr int PRE_C = 20;      // window width of the fixed-base table: W = 13 windows share 2^19 buckets
+
+static MsmPlan make_plan(size_t n, bool pre) {
   MsmPlan p;
+  if (pre) {   // one shared bucket set: "W = 1 window of 2^19 buckets" for everything after the sort
+    p.c = PRE_C; p.W = 1; p.B = 1u << (PRE_C - 1); p.M = p.B; p.T0 = 0; p.S = 8;
+    return p;
+  }
   uint32_t lg = 0; while (((size_t)1 << (lg + 1)) <= n) ++lg;
   int c = (int)lg - 4; if (c < 2) c = 2; if (c > 16) c = 16;
   p.c = (uint32_t)c; p.W = (SCALAR_BITS + p.c - 1) / p.c; p.B = 1u << (p.c - 1); p.M = p.W * p.B;
@@ -84,16 +90,19 @@ template <int C, int W_IDX, class F> __device__ __forceinline__ void for_each_di
 static constexpr uint32_t PART_TILE = 2048;       // scalars per block in the level-1 passes
 static constexpr uint32_t MAX_COARSE = 2048;      // W * (B >> LB) at c = 16
 
-template <int C> struct SortGeom {
+// PRE = the base set carries precomputed window multiples 2^(c*w) * P_i (fixed-base MSM, see msm_precompute):
+// every window then feeds ONE shared set of buckets, and the point of digit w of scalar i is table entry w*n + i.
+template <int C, bool PRE> struct SortGeom {
   static constexpr uint32_t W = (SCALAR_BITS + C - 1) / C, B = 1u << (C - 1);
   static constexpr uint32_t LB = (C - 1) < 8 ? (C - 1) : 8;       // low bucket bits, sorted in level 2
-  static constexpr uint32_t CB = B >> LB, NCB = W * CB;
+  static constexpr uint32_t CB = B >> LB, NCB = PRE ? CB : W * CB;
   static_assert(NCB <= MAX_COARSE, "coarse bin table too small");
+  __device__ static uint32_t bin(uint32_t w, uint32_t b) { return PRE ? (b >> LB) : w * CB + (b >> LB); }
 };
 
-template <int C, bool MONT>
+template <int C, bool MONT, bool PRE>
 __global__ void __launch_bounds__(256) k_part_count(const void* scalars, const uint8_t* inf, uint32_t n, uint32_t nblk, uint32_t* __restrict__ cnt) {
-  using Gm = SortGeom<C>;
+  using Gm = SortGeom<C, PRE>;
   __shared__ uint32_t h[MAX_COARSE];
   for (uint32_t i = threadIdx.x; i < Gm::NCB; i += 256) h[i] = 0;
   __syncthreads();
@@ -102,7 +111,7 @@ __global__ void __launch_bounds__(256) k_part_count(const void* scalars, const u
     uint32_t i = base + q * 256 + threadIdx.x;
     if (i < n && !(inf && inf[i])) {
       uint32_t s[8]; load_scalar<MONT>(scalars, i, s);
-      for_each_digit<C, 0>(s, 0u, [&](uint32_t w, uint32_t b, uint32_t) { atomicAdd(&h[w * Gm::CB + (b >> Gm::LB)], 1u); });
+      for_each_digit<C, 0>(s, 0u, [&](uint32_t w, uint32_t b, uint32_t) { atomicAdd(&h[Gm::bin(w, b)], 1u); });
     }
   }
   __syncthreads();
@@ -150,10 +159,10 @@ __global__ void __launch_bounds__(256) k_scan32_top(const uint32_t* __restrict__
 }
 __device__ __forceinline__ uint32_t scan32_at(const uint32_t* local, const uint32_t* blk, size_t i) { return local[i] + blk[i / SCAN_TILE]; }
 
-template <int C, bool MONT>
+template <int C, bool MONT, bool PRE>
 __global__ void __launch_bounds__(256) k_part_scatter(const void* scalars, const uint8_t* inf, uint32_t n, uint32_t nblk,
                                                       const uint32_t* __restrict__ off_local, const uint32_t* __restrict__ off_blk, uint2* __restrict__ items) {
-  using Gm = SortGeom<C>;
+  using Gm = SortGeom<C, PRE>;
   __shared__ uint32_t cur[MAX_COARSE];
   for (uint32_t i = threadIdx.x; i < Gm::NCB; i += 256) cur[i] = scan32_at(off_local, off_blk, (size_t)i * nblk + blockIdx.x);
   __syncthreads();
@@ -163,8 +172,8 @@ __global__ void __launch_bounds__(256) k_part_scatter(const void* scalars, const
     if (i < n && !(inf && inf[i])) {
       uint32_t s[8]; load_scalar<MONT>(scalars, i, s);
       for_each_digit<C, 0>(s, 0u, [&](uint32_t w, uint32_t b, uint32_t neg) {
-        uint32_t pos = atomicAdd(&cur[w * Gm::CB + (b >> Gm::LB)], 1u);
-        items[pos] = make_uint2(i | (neg << 31), b & ((1u << Gm::LB) - 1u));
+        uint32_t pos = atomicAdd(&cur[Gm::bin(w, b)], 1u);
+        items[pos] = make_uint2((PRE ? w * n + i : i) | (neg << 31), b & ((1u << Gm::LB) - 1u));
       });
     }
   }
@@ -209,10 +218,10 @@ __global__ void __launch_bounds__(256) k_bin_sort(const uint2* __restrict__ item
 // scan_local[g] = prefix inside the 2048-bucket tile; scan_blk[tile] = prefix of the tiles.  meta[0] = total
 // slices, meta[1] = max slices of one bucket, meta[2] = total pairs.
 __device__ __forceinline__ uint32_t slices_of(uint32_t cnt, uint32_t T0) { return (cnt + T0 - 1) / T0; }
-// Max points per slice, chosen on the device from the number of non-zero digits the sort found: 64 keeps (almost)
+// Max points per slice, chosen on the device from the number of non-zero digits the sort found: 128 keeps
 // every Poisson(32) bucket of a large uniform MSM in ONE slice (the slice tree then has nothing to do); sparser
 // inputs (witness-like scalars, small n) use 32 so that the accumulation still fills every SIMD.
-__device__ __forceinline__ uint32_t pick_t0(const uint32_t* total_pairs) { return *total_pairs >= (8u << 20) ? 64u : 32u; }
+__device__ __forceinline__ uint32_t pick_t0(const uint32_t* total_pairs) { return *total_pairs >= (8u << 20) ? 128u : 32u; }
 
 __global__ void __launch_bounds__(256) k_scan_tiles(const uint32_t* hist, uint32_t M, const uint32_t* total_pairs, uint2* scan_local, uint2* tile_tot, uint32_t* meta) {
   __shared__ uint2 wsum[4];
@@ -272,10 +281,10 @@ __device__ __forceinline__ uint2 scan_at(const uint2* local, const uint2* blk, u
 }
 
 // ---- slice ordering: lanes of one wave should run the same trip count --------------------------------
-// Slices are at most T0 <= 64 points long; bucket sizes are Poisson, so slice lengths vary 2:1 inside a wave if
+// Slices are at most T0 <= 128 points long; bucket sizes are Poisson, so slice lengths vary 2:1 inside a wave if
 // taken in bucket order (measured: 31 % of the accumulation's lanes idle).  A counting sort by length (longest
-// first) costs two tiny launches: block-local LDS histograms + <= 65 global atomics per block.
-static constexpr uint32_t MAX_T0 = 64;
+// first) costs two tiny launches: block-local LDS histograms + <= 129 global atomics per block.
+static constexpr uint32_t MAX_T0 = 128;
 __device__ __forceinline__ uint32_t slice_len(uint32_t cnt, uint32_t m, uint32_t k) {
   return (uint32_t)(((uint64_t)(k + 1) * cnt) / m) - (uint32_t)(((uint64_t)k * cnt) / m);
 }
@@ -398,7 +407,8 @@ __global__ void __launch_bounds__(256) k_tree_pass(char* __restrict__ partial, c
 // One lane per chunk of S consecutive buckets of one window: V = sum_{b in chunk} (b+1) * S_b, computed as a
 // running sum inside the chunk plus (chunk_base) * (chunk total) by double-and-add.  One xyzz_add call site.
 __global__ void __launch_bounds__(256) k_bucket_chunks(const char* __restrict__ partial, const uint32_t* __restrict__ hist, const uint2* __restrict__ scan_local,
-                                                       const uint2* __restrict__ scan_blk, uint32_t B, uint32_t S, uint32_t nchunks_total, char* __restrict__ V) {
+                                                       const uint2* __restrict__ scan_blk, uint32_t B, uint32_t S, uint32_t nchunks_total, char* __restrict__ V,
+                                                       char* __restrict__ Vrun) {
   uint32_t t = blockIdx.x * 256 + threadIdx.x;
   if (t >= nchunks_total) return;
   uint32_t cpw = B / S, w = t / cpw, j = t % cpw;
@@ -416,9 +426,11 @@ __global__ void __launch_bounds__(256) k_bucket_chunks(const char* __restrict__ 
     xyzz_add(x, y);
     if (odd) acc = x; else run = x;
   }
-  // acc = sum (b - base + 1) S_b ; add base * run with base = j*S
+  // acc = sum (b - base + 1) S_b ; add base * run with base = j*S — unless the caller weights the chunk totals itself
+  // (fixed-base path: masked trees over Vrun, see msm_run)
   uint32_t base = j * S;
-  if (base) {
+  if (Vrun) store_xyzz(Vrun + (size_t)t * 192, run);
+  else if (base) {
     XYZZ r = xyzz_infinity();
     int top = 31 - __clz(base);
     for (int bit = top; bit >= 0; --bit) {
@@ -442,6 +454,61 @@ __global__ void __launch_bounds__(256) k_seg_tree_pass(char* __restrict__ V, uin
   store_xyzz(pa, a);
 }
 
+// Fixed-base path: sum_j j * run_j = sum_l 2^l * T_l with T_l = sum of run_j over the j that have bit l set.  This
+// kernel does the first pairwise level of all lg(N) masked sums at once: T_l[k] = run[ins_l(2k)] + run[ins_l(2k+1)],
+// ins_l(x) = x with a 1 inserted at bit l.  The remaining levels are k_seg_tree_pass; the 2^l Horner runs on the host.
+__global__ void __launch_bounds__(256) k_masked_pairs(const char* __restrict__ Vrun, uint32_t lgN, char* __restrict__ T) {
+  const uint32_t seg_len = 1u << (lgN - 2);
+  uint32_t t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= seg_len * lgN) return;
+  const uint32_t l = t / seg_len, k = t % seg_len;
+  auto ins = [&](uint32_t x) { return ((x >> l) << (l + 1)) | (1u << l) | (x & ((1u << l) - 1u)); };
+  XYZZ a = load_xyzz(Vrun + (size_t)ins(2 * k) * 192), b = load_xyzz(Vrun + (size_t)ins(2 * k + 1) * 192);
+  xyzz_add(a, b);
+  store_xyzz(T + (size_t)t * 192, a);
+}
+// One block folds up to 512 consecutive points of one segment into a single point (9 tree levels through LDS):
+// two launches replace the ~16 latency-bound pairwise launches of k_seg_tree_pass on the fixed-base path.
+__global__ void __launch_bounds__(256) k_seg_fold512(const char* __restrict__ in, uint32_t in_stride, uint32_t L, uint32_t nseg,
+                                                     char* __restrict__ out, uint32_t out_stride) {
+  __shared__ uint32_t lds[256 * 48];
+  const uint32_t bps = (L + 511) / 512, seg = blockIdx.x / bps, blk = blockIdx.x % bps, tid = threadIdx.x;
+  if (seg >= nseg) return;
+  const uint32_t i0 = blk * 512 + 2 * tid;
+  const char* src = in + ((size_t)seg * in_stride + i0) * 192;
+  XYZZ a = i0 < L ? load_xyzz(src) : xyzz_infinity();
+  XYZZ b = i0 + 1 < L ? load_xyzz(src + 192) : xyzz_infinity();
+  for (uint32_t n = 256;; n >>= 1) {          // n = number of lanes holding a live (a, b) pair
+    if (tid < n) {
+      xyzz_add(a, b);
+      store_xyzz(lds + tid * 48, a);
+    }
+    __syncthreads();
+    if (n == 1) break;
+    if (tid < (n >> 1)) { a = load_xyzz(lds + (2 * tid) * 48); b = load_xyzz(lds + (2 * tid + 1) * 48); }
+    __syncthreads();
+  }
+  if (tid == 0) store_xyzz(out + ((size_t)seg * out_stride + blk) * 192, a);
+}
+// out[seg][i] = in[seg][2i] + in[seg][2i+1]: the wide (throughput-bound) levels of the segment sums
+__global__ void __launch_bounds__(256) k_seg_pair_pass(const char* __restrict__ in, uint32_t in_stride, uint32_t L, uint32_t nseg,
+                                                       char* __restrict__ out, uint32_t out_stride) {
+  const uint32_t half = (L + 1) >> 1;
+  uint32_t t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= half * nseg) return;
+  const uint32_t seg = t / half, i = t % half;
+  const char* src = in + ((size_t)seg * in_stride + 2 * i) * 192;
+  XYZZ a = load_xyzz(src);
+  if (2 * i + 1 < L) { XYZZ b = load_xyzz(src + 192); xyzz_add(a, b); }
+  store_xyzz(out + ((size_t)seg * out_stride + i) * 192, a);
+}
+__global__ void k_gather_strided(const char* __restrict__ V, uint32_t stride, uint32_t count, char* __restrict__ out) {
+  uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= count * 12) return;
+  uint32_t w = t / 12, q = t % 12;
+  ((uint4*)out)[t] = ((const uint4*)(V + (size_t)w * stride * 192))[q];
+}
+
 // gathers V[w*seg_len] (the window sums) into a dense array for one D2H copy
 __global__ void k_gather_windows(const char* __restrict__ V, uint32_t seg_len, uint32_t W, char* __restrict__ out) {
   uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -452,15 +519,16 @@ __global__ void k_gather_windows(const char* __restrict__ V, uint32_t seg_len, u
 
 // ---- dispatch on the window width ---------------------------------------------------------------
 struct SortArgs { const void* scalars; const uint8_t* inf; uint32_t n, nblk; uint32_t* cnt; uint32_t* off_local; uint32_t* off_blk; uint2* items; };
-template <int C, bool MONT> static void launch_sort_c(const SortArgs& a, int phase, hipStream_t s) {
-  if (phase == 0) hipLaunchKernelGGL((k_part_count<C, MONT>), dim3(a.nblk), dim3(256), 0, s, a.scalars, a.inf, a.n, a.nblk, a.cnt);
-  else hipLaunchKernelGGL((k_part_scatter<C, MONT>), dim3(a.nblk), dim3(256), 0, s, a.scalars, a.inf, a.n, a.nblk, a.off_local, a.off_blk, a.items);
+template <int C, bool MONT, bool PRE> static void launch_sort_c(const SortArgs& a, int phase, hipStream_t s) {
+  if (phase == 0) hipLaunchKernelGGL((k_part_count<C, MONT, PRE>), dim3(a.nblk), dim3(256), 0, s, a.scalars, a.inf, a.n, a.nblk, a.cnt);
+  else hipLaunchKernelGGL((k_part_scatter<C, MONT, PRE>), dim3(a.nblk), dim3(256), 0, s, a.scalars, a.inf, a.n, a.nblk, a.off_local, a.off_blk, a.items);
 }
 template <bool MONT> static void launch_sort(int c, const SortArgs& a, int phase, hipStream_t s) {
   switch (c) {
-#define CASE(C) case C: launch_sort_c<C, MONT>(a, phase, s); break;
+#define CASE(C) case C: launch_sort_c<C, MONT, false>(a, phase, s); break;
     CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8) CASE(9) CASE(10) CASE(11) CASE(12) CASE(13) CASE(14) CASE(15) CASE(16)
 #undef CASE
+    case PRE_C: launch_sort_c<PRE_C, MONT, true>(a, phase, s); break;
   }
 }
 
@@ -470,17 +538,19 @@ int32_t msm_run(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, const void* 
   using namespace host;
   if (n == 0) { hstore_jacobian_normalized(out_jac18, HXYZZ::infinity()); return ALEO_MI355X_OK; }
   if (n > pb.n || n >= (1ull << 31)) { g_last_error = "msm: n exceeds the pinned base count (or 2^31)"; return ALEO_MI355X_ERR_BAD_ARG; }
-  MsmPlan P = make_plan(n);
+  const bool pre = pb.d_pre != nullptr && n == pb.n;      // the table is laid out for the full set
+  MsmPlan P = make_plan(n, pre);
+  const uint32_t digitsW = pre ? (SCALAR_BITS + PRE_C - 1) / PRE_C : P.W;
   const uint32_t M = P.M, ntiles = (M + SCAN_TILE - 1) / SCAN_TILE;
-  const size_t pairs_max = n * (size_t)P.W;
+  const size_t pairs_max = n * (size_t)digitsW;
   const size_t slices_max = pairs_max / 32 + M + 1;          // worst case of pick_t0()
   int32_t rc;
   // hist | cursor | meta live in one zero-initialised allocation
-  if ((rc = c->hist.reserve((2 * (size_t)M + 256) * 4))) return rc;
+  if ((rc = c->hist.reserve((2 * (size_t)M + 512) * 4))) return rc;
   if ((rc = c->scan_local.reserve((size_t)M * 8))) return rc;
   if ((rc = c->scan_blk.reserve(2 * (size_t)ntiles * 8 + 64))) return rc;
   if ((rc = c->sorted.reserve(pairs_max * 4))) return rc;
-  const uint32_t LB = (P.c - 1) < 8 ? (P.c - 1) : 8, ncb = P.W * (P.B >> LB);
+  const uint32_t LB = (P.c - 1) < 8 ? (P.c - 1) : 8, ncb = P.W * (P.B >> LB);      // P.W == 1 with a table
   const uint32_t nblk = (uint32_t)((n + PART_TILE - 1) / PART_TILE);
   const size_t cnt_len = (size_t)ncb * nblk;
   if (cnt_len >= (1ull << 32)) { g_last_error = "msm: partition table too large"; return ALEO_MI355X_ERR_BAD_ARG; }
@@ -490,18 +560,21 @@ int32_t msm_run(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, const void* 
   if ((rc = c->partial.reserve(slices_max * 192))) return rc;
   if ((rc = c->task_g.reserve(2 * slices_max * 4))) return rc;     // task_g | order
   const uint32_t cpw = P.B / P.S, nchunks = cpw * P.W;
-  if ((rc = c->vbuf.reserve(((size_t)nchunks + P.W) * 192))) return rc;
-  if ((rc = ensure_host_pinned(c, 64 + (size_t)P.W * 192))) return rc;
+  uint32_t lgN = 0; while ((1u << lgN) < cpw) ++lgN;
+  const bool masked = pre && lgN >= 2 && (1u << lgN) == cpw;          // fixed-base path: weights by masked trees
+  const size_t vwords = masked ? 2 * (size_t)nchunks + (size_t)lgN * (cpw / 4) + (size_t)(lgN + 5) * (1 + (size_t)cpw / 4) : (size_t)nchunks + P.W;
+  if ((rc = c->vbuf.reserve(vwords * 192))) return rc;
+  if ((rc = ensure_host_pinned(c, 64 + (size_t)(P.W + lgN + 5) * 192))) return rc;
 
   uint32_t* hist = c->hist.as<uint32_t>(); uint32_t* cursor = hist + M; uint32_t* meta = cursor + M;
   uint2* scan_local = c->scan_local.as<uint2>();
   uint2* tile_tot = c->scan_blk.as<uint2>(); uint2* scan_blk = tile_tot + ntiles;
   uint32_t* sorted = c->sorted.as<uint32_t>(); char* partial = c->partial.as<char>(); uint32_t* task_g = c->task_g.as<uint32_t>(); uint32_t* order = task_g + slices_max;
   char* V = c->vbuf.as<char>(); char* Vout = V + (size_t)nchunks * 192;
-  const char* bases = (const char*)pb.d_xy;
+  const char* bases = (const char*)(pre ? pb.d_pre : pb.d_xy);
 
   HIPCHK(hipEventRecord(c->ev[0], s));
-  HIPCHK(hipMemsetAsync(hist, 0, (2 * (size_t)M + 256) * 4, s));
+  HIPCHK(hipMemsetAsync(hist, 0, (2 * (size_t)M + 512) * 4, s));
   SortArgs sa;
   sa.scalars = d_scalars; sa.inf = pb.d_inf; sa.n = (uint32_t)n; sa.nblk = nblk;
   sa.cnt = c->part_cnt.as<uint32_t>(); sa.off_local = sa.cnt + cnt_len;
@@ -533,25 +606,57 @@ int32_t msm_run(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, const void* 
       hipLaunchKernelGGL(k_tree_pass, dim3((NT + 255) / 256), dim3(256), 0, s, partial, task_g, scan_local, scan_blk, M, meta, pass);
   }
   HIPCHK(hipEventRecord(c->ev[2], s));
-  hipLaunchKernelGGL(k_bucket_chunks, dim3((nchunks + 255) / 256), dim3(256), 0, s, partial, hist, scan_local, scan_blk, P.B, P.S, nchunks, V);
-  for (uint32_t L = cpw; L > 1; L = (L + 1) >> 1) {
-    uint32_t pairs = (L - ((L + 1) >> 1)) * P.W;
-    hipLaunchKernelGGL(k_seg_tree_pass, dim3((pairs + 255) / 256), dim3(256), 0, s, V, cpw, P.W, L);
-  }
-  hipLaunchKernelGGL(k_gather_windows, dim3((P.W * 12 + 255) / 256), dim3(256), 0, s, V, cpw, P.W, Vout);
   char* h_win = (char*)c->h_pinned + 64;
-  HIPCHK(hipMemcpyAsync(h_win, Vout, (size_t)P.W * 192, hipMemcpyDeviceToHost, s));
-  HIPCHK(hipEventRecord(c->ev[3], s));
-  HIPCHK(hipStreamSynchronize(s));
-  HIPCHK(hipGetLastError());
-
-  // host tail: total = sum_w 2^(c*w) * S_w  (Horner from the top window), then affine normalisation
+  auto lazy_point = [&](const char* p) {
+    const uint64_t* src = (const uint64_t*)p;
+    HXYZZ v; v.X = HFq::reduce_lazy(src); v.Y = HFq::reduce_lazy(src + 6); v.ZZ = HFq::reduce_lazy(src + 12); v.ZZZ = HFq::reduce_lazy(src + 18);
+    return v;
+  };
   HXYZZ total = HXYZZ::infinity();
-  for (int w = (int)P.W - 1; w >= 0; --w) {
-    for (uint32_t d = 0; d < P.c; ++d) total = hdouble(total);
-    const uint64_t* src = (const uint64_t*)(h_win + (size_t)w * 192);
-    HXYZZ sw; sw.X = HFq::reduce_lazy(src); sw.Y = HFq::reduce_lazy(src + 6); sw.ZZ = HFq::reduce_lazy(src + 12); sw.ZZZ = HFq::reduce_lazy(src + 18);
-    total = hadd(total, sw);
+  if (masked) {
+    // sum_b (b+1) S_b = sum_j acc_j + S * sum_j j * run_j ; the second sum by lg(N) masked pairwise trees
+    char* T = V + (size_t)nchunks * 192; char* Vrun = T + (size_t)lgN * (cpw / 4) * 192; char* Tout = Vrun + (size_t)nchunks * 192;
+    hipLaunchKernelGGL(k_bucket_chunks, dim3((nchunks + 255) / 256), dim3(256), 0, s, partial, hist, scan_local, scan_blk, P.B, P.S, nchunks, V, Vrun);
+    const uint32_t tseg = cpw / 4, fseg = lgN + 4;      // Vacc viewed as 4 segments of cpw/4, followed by the lgN masked sums
+    hipLaunchKernelGGL(k_masked_pairs, dim3((tseg * lgN + 255) / 256), dim3(256), 0, s, Vrun, lgN, T);
+    // (lgN+4) segment sums: pairwise launches while a level still fills the chip, then ONE block per segment folds the
+    // last 512 points through LDS (9 levels at one wave per SIMD: the latency floor of the chain, no launch gaps)
+    char* F1 = Tout + (size_t)(fseg + 1) * 192; char* F2 = F1 + (size_t)fseg * (tseg / 2) * 192;
+    const char* cur = V; uint32_t L = tseg, stride = tseg;
+    while (L > 512) {
+      char* dst = (cur == F1) ? F2 : F1; uint32_t half = (L + 1) >> 1;
+      hipLaunchKernelGGL(k_seg_pair_pass, dim3((half * fseg + 255) / 256), dim3(256), 0, s, cur, stride, L, fseg, dst, half);
+      cur = dst; stride = half; L = half;
+    }
+    if (L > 1) {
+      char* dst = (cur == F1) ? F2 : F1;
+      hipLaunchKernelGGL(k_seg_fold512, dim3(fseg), dim3(256), 0, s, cur, stride, L, fseg, dst, 1u);
+      cur = dst; stride = 1; L = 1;
+    }
+    hipLaunchKernelGGL(k_gather_strided, dim3((fseg * 12 + 255) / 256), dim3(256), 0, s, cur, stride, fseg, Tout);
+    HIPCHK(hipMemcpyAsync(h_win, Tout, (size_t)fseg * 192, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipEventRecord(c->ev[3], s));
+    HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(hipGetLastError());
+    for (int l = (int)lgN - 1; l >= 0; --l) { total = hdouble(total); total = hadd(total, lazy_point(h_win + (size_t)(4 + l) * 192)); }
+    for (uint32_t sft = P.S; sft > 1; sft >>= 1) total = hdouble(total);
+    for (int q = 0; q < 4; ++q) total = hadd(total, lazy_point(h_win + (size_t)q * 192));
+  } else {
+    hipLaunchKernelGGL(k_bucket_chunks, dim3((nchunks + 255) / 256), dim3(256), 0, s, partial, hist, scan_local, scan_blk, P.B, P.S, nchunks, V, (char*)nullptr);
+    for (uint32_t L = cpw; L > 1; L = (L + 1) >> 1) {
+      uint32_t pairs = (L - ((L + 1) >> 1)) * P.W;
+      hipLaunchKernelGGL(k_seg_tree_pass, dim3((pairs + 255) / 256), dim3(256), 0, s, V, cpw, P.W, L);
+    }
+    hipLaunchKernelGGL(k_gather_windows, dim3((P.W * 12 + 255) / 256), dim3(256), 0, s, V, cpw, P.W, Vout);
+    HIPCHK(hipMemcpyAsync(h_win, Vout, (size_t)P.W * 192, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipEventRecord(c->ev[3], s));
+    HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(hipGetLastError());
+    // host tail: total = sum_w 2^(c*w) * S_w  (Horner from the top window), then affine normalisation
+    for (int w = (int)P.W - 1; w >= 0; --w) {
+      for (uint32_t d = 0; d < P.c; ++d) total = hdouble(total);
+      total = hadd(total, lazy_point(h_win + (size_t)w * 192));
+    }
   }
   hstore_jacobian_normalized(out_jac18, total);
   HIPCHK(hipEventRecord(c->ev[4], s));
@@ -608,6 +713,7 @@ __global__ void __launch_bounds__(256) k_gen_normalize(char* __restrict__ tmp, u
   for (uint32_t j = 0; j < cnt; ++j) {
     store_fp<Fq>(prefix + (i0 + j) * 48, prod);
     Fq zzz = load_fp<Fq>(tmp + (i0 + j) * 192 + 144);
+    if (zzz.is_zero_mod_lt2p()) zzz = Fq::one();      // the identity: keep it out of the shared inversion
     fq_mul_ni(&prod, &prod, &zzz);
   }
   fq_inverse_ni(&prod);
@@ -615,6 +721,10 @@ __global__ void __launch_bounds__(256) k_gen_normalize(char* __restrict__ tmp, u
     const char* src = tmp + (i0 + jj) * 192;
     Fq pre = load_fp<Fq>(prefix + (i0 + jj) * 48), zzz = load_fp<Fq>(src + 144), zz = load_fp<Fq>(src + 96);
     Fq zi3, zi, zi2, x, y;
+    if (zzz.is_zero_mod_lt2p()) {                       // identity -> (0, 0): never on the curve, callers skip it
+      store_fp<Fq>(out_xy + (i0 + jj) * 96, Fq::zero()); store_fp<Fq>(out_xy + (i0 + jj) * 96 + 48, Fq::zero());
+      continue;
+    }
     fq_mul_ni(&zi3, &prod, &pre);            // 1/ZZZ_j
     fq_mul_ni(&prod, &prod, &zzz);
     fq_mul_ni(&zi, &zz, &zi3);               // 1/Z
@@ -640,6 +750,46 @@ int32_t generate_multiples(Ctx* c, const void* base104, uint64_t first, size_t n
   HIPCHK(hipGetLastError());
   (void)hipFree(d_g); (void)hipFree(d_tmp); (void)hipFree(d_pre);
   *out = pb; return ALEO_MI355X_OK;
+}
+
+// ---- fixed-base table: row w = 2^(PRE_C * w) * P_i  (setup, once per pinned base set) ---------------
+// With the table every window of a scalar feeds the same 2^19 buckets: 13 instead of 16 additions per point at
+// 2^20, one bucket reduction instead of 16, and no Horner tail.  Costs W x 96 bytes of HBM per point (there are
+// 288 GB) and ~250 doublings per point once, at pin time — the SRS of a proving key never changes.
+__global__ void __launch_bounds__(256) k_pre_init(const char* __restrict__ xy, uint32_t n, char* __restrict__ cur) {
+  uint32_t i = blockIdx.x * 256 + threadIdx.x; if (i >= n) return;
+  AffinePt p = load_affine(xy + (size_t)i * 96);
+  XYZZ a; a.X = p.x; a.Y = p.y; a.ZZ = Fq::one(); a.ZZZ = Fq::one();
+  if (p.x.is_zero_raw() && p.y.is_zero_raw()) a = xyzz_infinity();
+  store_xyzz(cur + (size_t)i * 192, a);
+}
+__global__ void __launch_bounds__(256) k_pre_double(char* __restrict__ cur, uint32_t n, int doublings) {
+  uint32_t i = blockIdx.x * 256 + threadIdx.x; if (i >= n) return;
+  XYZZ a = load_xyzz(cur + (size_t)i * 192);
+  for (int d = 0; d < doublings; ++d) xyzz_double_ni(&a);
+  store_xyzz(cur + (size_t)i * 192, a);
+}
+
+int32_t msm_precompute(Ctx* c, PinnedBases* pb) {
+  if (pb->d_pre || pb->n == 0) return ALEO_MI355X_OK;
+  const size_t n = pb->n; const uint32_t W = (SCALAR_BITS + PRE_C - 1) / PRE_C;
+  if (n * (size_t)W >= (1ull << 31)) { g_last_error = "bases_precompute: table index would exceed 31 bits"; return ALEO_MI355X_ERR_BAD_ARG; }
+  void *d_tab = nullptr, *d_cur = nullptr, *d_prefix = nullptr;
+  HIPCHK(hipMalloc(&d_tab, n * 96 * W));
+  HIPCHK(hipMalloc(&d_cur, n * 192)); HIPCHK(hipMalloc(&d_prefix, n * 48));
+  hipStream_t s = c->stream;
+  HIPCHK(hipMemcpyAsync(d_tab, pb->d_xy, n * 96, hipMemcpyDeviceToDevice, s));
+  const uint32_t g = (uint32_t)((n + 255) / 256), lanes = (uint32_t)((n + GEN_K - 1) / GEN_K), gl = (lanes + 255) / 256;
+  hipLaunchKernelGGL(k_pre_init, dim3(g), dim3(256), 0, s, (const char*)pb->d_xy, (uint32_t)n, (char*)d_cur);
+  for (uint32_t w = 1; w < W; ++w) {
+    hipLaunchKernelGGL(k_pre_double, dim3(g), dim3(256), 0, s, (char*)d_cur, (uint32_t)n, PRE_C);
+    hipLaunchKernelGGL(k_gen_normalize, dim3(gl), dim3(256), 0, s, (char*)d_cur, (uint32_t)n, (char*)d_prefix, (char*)d_tab + (size_t)w * n * 96);
+  }
+  HIPCHK(hipStreamSynchronize(s));
+  HIPCHK(hipGetLastError());
+  (void)hipFree(d_cur); (void)hipFree(d_prefix);
+  pb->d_pre = d_tab;
+  return ALEO_MI355X_OK;
 }
 
 // ---- element-wise products (parity tests pin the device arithmetic with these) -------------------

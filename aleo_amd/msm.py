@@ -37,6 +37,11 @@ class PinnedBases:
         check(lib().aleo_mi355x_bases_generate(_p(b), first_multiple, n, ctypes.byref(h)), 'bases_generate')
         return cls(None, h.value, n)
 
+    def precompute(self) -> 'PinnedBases':
+        """Build the fixed-base window table in HBM (13 x 96 B per point); full-length MSMs then take the fast path."""
+        check(lib().aleo_mi355x_bases_precompute(self.handle), 'bases_precompute')
+        return self
+
     def download(self, offset: int = 0, n: int = None) -> np.ndarray:
         n = self.n - offset if n is None else n
         out = np.zeros((n, 104), dtype=np.uint8)

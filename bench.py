@@ -25,7 +25,8 @@ def main():
     ap.add_argument('--lg-n', type=int, default=20, help='log2 of the points per GPU (BASELINE config[1]: 20)')
     ap.add_argument('--scalars', default='uniform', choices=['uniform', 'witness'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-sample-lg', type=int, default=18)
+    ap.add_argument('--cpu-sample-lg', type=int, default=20)
+    ap.add_argument('--no-precompute', action='store_true', help='skip the fixed-base window table (one-shot MSM path)')
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
                     help="'gloo' is only for rehearsing the N>1 path with several ranks sharing one GPU")
     args = ap.parse_args()
@@ -57,6 +58,8 @@ def main():
     first = rank * n + 1
     gen = synth.generator_affine104()
     pb = aleo_amd.PinnedBases.generate_multiples(gen, first, n)           # P_i = (first + i) * G, generated in HBM
+    if not args.no_precompute:
+        pb.precompute()           # setup, outside the timed region: the SRS of a proving key is fixed (bases_pin contract)
     mk = synth.uniform_scalars if args.scalars == 'uniform' else synth.witness_like_scalars
     scalars = mk(n, 0xA1E00002 + rank)
     d_scalars = torch.from_numpy(scalars.view(np.int64)).to(dev)           # resident in HBM before the timed region
@@ -111,11 +114,12 @@ def main():
             'ms_per_step': ms_step, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'u32',
             'data': 'synthetic',
             'config': {'workload': 'standalone 2^%d-point BLS12-377 G1 Pippenger MSM (BASELINE configs[1])' % args.lg_n,
-                       'points_per_gpu': n, 'scalars': args.scalars, 'bases': 'P_i=(i+1)G generated in HBM',
+                       'points_per_gpu': n, 'scalars': args.scalars, 'bases': 'P_i=(i+1)G generated in HBM' + ('' if args.no_precompute else '; fixed-base window table (13 x 2^20-bit windows) built at pin time'),
                        'sharding': 'point-sharded, all-gather of 144-byte partials' if world > 1 else 'single GPU'},
             'roofline': {'bound': 'hbm', 'kernel': 'k_accum (bucket accumulation)', 'achieved': achieved, 'peak': 8000.0,
                          'unit': 'GB/s', 'frac': achieved / 8000.0, 'traffic': traffic,
-                         'note': 'integer-VALU bound by construction (SURVEY.md §8d): ~%d Fq products per point' % (10 * ((254 + 15) // 16))},
+                         'note': 'integer-VALU bound by construction (SURVEY.md §8d): %d mixed additions x 10 Fq products per point; '
+                                 'measured Fq product peak 60 G/s (tools/ubench/fq_mul_bench.hip)' % (16 if args.no_precompute else 13)},
             'phases_ms': {kk: float(np.mean([p_[kk] for p_ in phases])) for kk in phases[0]},
         }
         if world == 1 and not args.no_cpu_baseline:

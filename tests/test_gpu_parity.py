@@ -244,3 +244,26 @@ def test_bad_arguments_are_rejected():
     assert L.aleo_mi355x_msm_g1(out.ctypes.data, out.ctypes.data, 100, out.ctypes.data, 1) == 2        # bad stride
     assert L.aleo_mi355x_ntt_fr(out.ctypes.data, 31, 0, 0, 0) == 2
     assert L.aleo_mi355x_msm_g1_pinned(out.ctypes.data, 987654321, out.ctypes.data, 1) == 4            # unknown handle
+
+
+def test_msm_fixed_base_table_path():
+    """bases_precompute(): the 13-window fixed-base table must give the same group element as the plain path."""
+    for n in (1000, 1 << 16):
+        with M.PinnedBases.generate_multiples(synth.generator_affine104(), 1, n) as pb:
+            S = util.uniform_scalars(n, 8800 + n); Wt = util.witness_like_scalars(n, 8900 + n)
+            plain_u, plain_w = M.VariableBase.msm(pb, S), M.VariableBase.msm(pb, Wt)
+            pb.precompute()
+            assert (M.VariableBase.msm(pb, S) == plain_u).all() and (M.VariableBase.msm(pb, Wt) == plain_w).all()
+            assert c.jac_to_int_point(plain_u) == util.expected_multiples_msm(S, n)
+            rm1 = np.tile(c.ints_to_limbs([p.FR_MODULUS - 1], 4), (n, 1))                  # top-window carry
+            assert c.jac_to_int_point(M.VariableBase.msm(pb, rm1)) == util.expected_multiples_msm(rm1, n)
+            assert c.jac_to_int_point(M.VariableBase.msm(pb, S[: n // 2])) == util.expected_multiples_msm(S, n // 2)   # prefix: plain path
+    # a pinned set with an infinity base and a repeated base
+    n = 500
+    B = util.multiples_bases(n); B[7] = 0; B[7, 96] = 1; B[9] = B[8]
+    S = util.uniform_scalars(n, 4242)
+    with M.PinnedBases(B) as pb:
+        exp = c.jac_to_int_point(c.msm_g1(B, S, threads=4, variant=1))
+        assert c.jac_to_int_point(M.VariableBase.msm(pb, S)) == exp
+        pb.precompute()
+        assert c.jac_to_int_point(M.VariableBase.msm(pb, S)) == exp

@@ -1,0 +1,15 @@
+"""Runs a few 2^lg MSMs (fixed-base table path by default) — a small target for rocprofv3 kernel traces."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+import numpy as np, torch
+import aleo_amd
+from aleo_amd import synth, msm as M
+lg = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+pre = (sys.argv[2] != 'plain') if len(sys.argv) > 2 else True
+n = 1 << lg
+aleo_amd._lib.check(aleo_amd.lib().aleo_mi355x_init(0), 'init')
+pb = M.PinnedBases.generate_multiples(synth.generator_affine104(), 1, n)
+if pre: pb.precompute()
+s = torch.from_numpy(synth.uniform_scalars(n, 5).view(np.int64)).cuda(); torch.cuda.synchronize()
+for _ in range(6): M.VariableBase.msm_device(pb, s.data_ptr(), n)
+print(M.last_msm_timing())

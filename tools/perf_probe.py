@@ -27,6 +27,7 @@ if what in ('all', 'msm'):
     for lg in (16, 18, 20, 22):
         n = 1 << lg
         pb = M.PinnedBases.generate_multiples(synth.generator_affine104(), 1, n)
+        if 'pre' in sys.argv: t0 = time.perf_counter(); pb.precompute(); print('precompute s', time.perf_counter() - t0)
         for kind, mk in (('uniform', synth.uniform_scalars), ('witness', synth.witness_like_scalars)):
             s = torch.from_numpy(mk(n, 77 + lg).view(np.int64)).to(dev); torch.cuda.synchronize()
             M.VariableBase.msm_device(pb, s.data_ptr(), n)
