@@ -217,22 +217,36 @@ __global__ void __launch_bounds__(256) k_bin_sort(const uint2* __restrict__ item
 // ---- exclusive scan of (count, slices) over the M buckets --------------------------------------
 // scan_local[g] = prefix inside the 2048-bucket tile; scan_blk[tile] = prefix of the tiles.  meta[0] = total
 // slices, meta[1] = max slices of one bucket, meta[2] = total pairs.
-__device__ __forceinline__ uint32_t slices_of(uint32_t cnt, uint32_t T0) { return (cnt + T0 - 1) / T0; }
-// Max points per slice, chosen on the device from the number of non-zero digits the sort found: 128 keeps
-// every Poisson(32) bucket of a large uniform MSM in ONE slice (the slice tree then has nothing to do); sparser
-// inputs (witness-like scalars, small n) use 32 so that the accumulation still fills every SIMD.
-__device__ __forceinline__ uint32_t pick_t0(const uint32_t* total_pairs) { return *total_pairs >= (8u << 20) ? 128u : 32u; }
+// Slice sizing.  A bucket of <= T_SINGLE points is one slice (one lane); larger buckets are cut into slices of
+// <= T_SPLIT.  One lane needs ~10-20 us per mixed addition, so the longest slice bounds the kernel from below: 128-point
+// slices (tried) put a 2.7 ms floor under a 2.4 ms kernel, because the top window of a 253-bit scalar only has 13 bits
+// and its 4779 buckets hold ~300 points each.  64/32 keeps the floor at about half the kernel time.
+// Sparse inputs (witness-like scalars, small n) use 32/32 so that the accumulation still fills every SIMD.
+struct SliceRule { uint32_t single, split; };
+__device__ __forceinline__ SliceRule pick_rule(const uint32_t* total_pairs) {
+  const uint32_t tp = *total_pairs;       // more pairs per resident lane -> longer slices stay far below the kernel time
+  SliceRule r;
+  if (tp < (8u << 20)) { r.single = 32u; r.split = 32u; }
+  else if (tp < (32u << 20)) { r.single = 64u; r.split = 32u; }
+  else { r.single = 128u; r.split = 64u; }
+  return r;
+}
+__device__ __forceinline__ uint32_t slices_of(uint32_t cnt, SliceRule r) { return cnt <= r.single ? (cnt ? 1u : 0u) : (cnt + r.split - 1) / r.split; }
 
-__global__ void __launch_bounds__(256) k_scan_tiles(const uint32_t* hist, uint32_t M, const uint32_t* total_pairs, uint2* scan_local, uint2* tile_tot, uint32_t* meta) {
+__global__ void __launch_bounds__(256) k_scan_tiles(const uint32_t* hist, uint32_t M, const uint32_t* total_pairs, uint2* scan_local, uint2* tile_tot, uint32_t* meta,
+                                                    uint32_t* __restrict__ heavy) {
   __shared__ uint2 wsum[4];
   uint32_t base = blockIdx.x * SCAN_TILE + threadIdx.x * 8;
-  const uint32_t T0 = pick_t0(total_pairs);
+  const SliceRule T0 = pick_rule(total_pairs);
   uint32_t c[8]; uint32_t mx = 0;
 #pragma unroll
   for (int k = 0; k < 8; ++k) c[k] = (base + k < M) ? hist[base + k] : 0u;
   uint2 pre[8]; uint2 run = make_uint2(0, 0);
 #pragma unroll
-  for (int k = 0; k < 8; ++k) { pre[k] = run; uint32_t m = slices_of(c[k], T0); run.x += c[k]; run.y += m; mx = mx > m ? mx : m; }
+  for (int k = 0; k < 8; ++k) {
+    pre[k] = run; uint32_t m = slices_of(c[k], T0); run.x += c[k]; run.y += m; mx = mx > m ? mx : m;
+    if (m > 1) heavy[atomicAdd(&meta[3], 1u)] = base + k;       // multi-slice buckets: the only work of the slice tree
+  }
   // wave inclusive scan of the per-thread totals
   uint2 inc = run; int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #pragma unroll
@@ -281,7 +295,7 @@ __device__ __forceinline__ uint2 scan_at(const uint2* local, const uint2* blk, u
 }
 
 // ---- slice ordering: lanes of one wave should run the same trip count --------------------------------
-// Slices are at most T0 <= 128 points long; bucket sizes are Poisson, so slice lengths vary 2:1 inside a wave if
+// Slices are at most 128 points long; bucket sizes are Poisson, so slice lengths vary 2:1 inside a wave if
 // taken in bucket order (measured: 31 % of the accumulation's lanes idle).  A counting sort by length (longest
 // first) costs two tiny launches: block-local LDS histograms + <= 129 global atomics per block.
 static constexpr uint32_t MAX_T0 = 128;
@@ -303,7 +317,7 @@ __global__ void __launch_bounds__(256) k_slice_count(const uint32_t* __restrict_
       uint32_t mid = (lo + hi + 1) >> 1;
       if (scan_at(scan_local, scan_blk, mid).y <= t) lo = mid; else hi = mid - 1;
     }
-    uint32_t g = lo, cnt = hist[g], m = slices_of(cnt, pick_t0(total_pairs)), k = t - scan_at(scan_local, scan_blk, g).y;
+    uint32_t g = lo, cnt = hist[g], m = slices_of(cnt, pick_rule(total_pairs)), k = t - scan_at(scan_local, scan_blk, g).y;
     task_g[t] = g;
     atomicAdd(&h[slice_len(cnt, m, k)], 1u);
   }
@@ -321,7 +335,7 @@ __global__ void __launch_bounds__(256) k_slice_order(const uint32_t* __restrict_
   uint32_t t = blockIdx.x * 256 + threadIdx.x, len = 0, rank = 0;
   bool live = t < meta[0];
   if (live) {
-    uint32_t g = task_g[t], cnt = hist[g], m = slices_of(cnt, pick_t0(total_pairs)), k = t - scan_at(scan_local, scan_blk, g).y;
+    uint32_t g = task_g[t], cnt = hist[g], m = slices_of(cnt, pick_rule(total_pairs)), k = t - scan_at(scan_local, scan_blk, g).y;
     len = slice_len(cnt, m, k);
     rank = atomicAdd(&h[len], 1u);
   }
@@ -355,7 +369,7 @@ __global__ void __launch_bounds__(256) k_accum(const char* __restrict__ bases, c
   if (t >= meta[0]) return;
   const uint32_t sid = order[t], g = task_g[sid];
   uint2 st = scan_at(scan_local, scan_blk, g);
-  uint32_t cnt = hist[g], m = slices_of(cnt, pick_t0(total_pairs)), k = sid - st.y;
+  uint32_t cnt = hist[g], m = slices_of(cnt, pick_rule(total_pairs)), k = sid - st.y;
   uint32_t j0 = (uint32_t)(((uint64_t)k * cnt) / m), j1 = (uint32_t)(((uint64_t)(k + 1) * cnt) / m);
   const uint32_t* run = sorted + st.x;
   // software prefetch: the next point's 96-byte gather is in flight under the current mixed addition
@@ -384,23 +398,24 @@ __global__ void __launch_bounds__(256) k_accum(const char* __restrict__ bases, c
   xyzz_store_normalized(partial + (size_t)sid * 192, acc, inf);
 }
 
-// partial[t] += partial[t + half] inside every bucket that still has more than one slice
-__global__ void __launch_bounds__(256) k_tree_pass(char* __restrict__ partial, const uint32_t* __restrict__ task_g, const uint2* __restrict__ scan_local,
-                                                   const uint2* __restrict__ scan_blk, uint32_t M, const uint32_t* __restrict__ meta, uint32_t pass) {
+// partial[ft + i] += partial[ft + i + half] inside every multi-slice bucket (listed in heavy[] by the scan)
+__global__ void __launch_bounds__(256) k_tree_pass(char* __restrict__ partial, const uint32_t* __restrict__ heavy, const uint2* __restrict__ scan_local,
+                                                   const uint2* __restrict__ scan_blk, uint32_t M, const uint32_t* __restrict__ meta, uint32_t pass, uint32_t max_pairs) {
   uint32_t t = blockIdx.x * 256 + threadIdx.x;
-  uint32_t NT = meta[0];
-  if (t >= NT) return;
-  uint32_t g = task_g[t];
+  uint32_t h = t / max_pairs, i = t % max_pairs;
+  if (h >= meta[3]) return;
+  uint32_t g = heavy[h];
   uint32_t ft = scan_at(scan_local, scan_blk, g).y;
-  uint32_t fn = (g + 1 < M) ? scan_at(scan_local, scan_blk, g + 1).y : NT;
-  uint32_t L = fn - ft, i = t - ft;
+  uint32_t fn = (g + 1 < M) ? scan_at(scan_local, scan_blk, g + 1).y : meta[0];
+  uint32_t L = fn - ft;
   for (uint32_t p = 0; p < pass; ++p) L = (L + 1) >> 1;
   if (L <= 1) return;
   uint32_t half = (L + 1) >> 1;
   if (i >= L - half) return;
-  XYZZ a = load_xyzz(partial + (size_t)t * 192), b = load_xyzz(partial + (size_t)(t + half) * 192);
+  char* pa = partial + (size_t)(ft + i) * 192;
+  XYZZ a = load_xyzz(pa), b = load_xyzz(pa + (size_t)half * 192);
   xyzz_add(a, b);
-  store_xyzz(partial + (size_t)t * 192, a);
+  store_xyzz(pa, a);
 }
 
 // ---- bucket reduction -----------------------------------------------------------------------------
@@ -566,7 +581,7 @@ int32_t msm_run(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, const void* 
   if ((rc = c->vbuf.reserve(vwords * 192))) return rc;
   if ((rc = ensure_host_pinned(c, 64 + (size_t)(P.W + lgN + 5) * 192))) return rc;
 
-  uint32_t* hist = c->hist.as<uint32_t>(); uint32_t* cursor = hist + M; uint32_t* meta = cursor + M;
+  uint32_t* hist = c->hist.as<uint32_t>(); uint32_t* heavy = hist + M; uint32_t* meta = heavy + M;     // heavy: <= M bucket ids
   uint2* scan_local = c->scan_local.as<uint2>();
   uint2* tile_tot = c->scan_blk.as<uint2>(); uint2* scan_blk = tile_tot + ntiles;
   uint32_t* sorted = c->sorted.as<uint32_t>(); char* partial = c->partial.as<char>(); uint32_t* task_g = c->task_g.as<uint32_t>(); uint32_t* order = task_g + slices_max;
@@ -586,14 +601,14 @@ int32_t msm_run(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, const void* 
   hipLaunchKernelGGL(k_scan32_top, dim3(1), dim3(256), 0, s, cnt_tile_tot, cnt_tiles, sa.off_blk);
   if (scalars_are_mont) launch_sort<true>(P.c, sa, 1, s); else launch_sort<false>(P.c, sa, 1, s);
   hipLaunchKernelGGL(k_bin_sort, dim3(ncb), dim3(256), 0, s, sa.items, sa.off_local, sa.off_blk, nblk, ncb, cnt_tiles, LB, hist, sorted);
-  hipLaunchKernelGGL(k_scan_tiles, dim3(ntiles), dim3(256), 0, s, hist, M, total_pairs, scan_local, tile_tot, meta);
+  hipLaunchKernelGGL(k_scan_tiles, dim3(ntiles), dim3(256), 0, s, hist, M, total_pairs, scan_local, tile_tot, meta, heavy);
   hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(256), 0, s, tile_tot, ntiles, scan_blk, meta);
   // slice count / max slices per bucket decide the grid of the accumulation and the number of tree passes
   uint32_t* h_meta = (uint32_t*)c->h_pinned;
   HIPCHK(hipMemcpyAsync(h_meta, meta, 16, hipMemcpyDeviceToHost, s));
   HIPCHK(hipEventRecord(c->ev[1], s));
   HIPCHK(hipStreamSynchronize(s));
-  const uint32_t NT = h_meta[0], max_m = h_meta[1];
+  const uint32_t NT = h_meta[0], max_m = h_meta[1], n_heavy = h_meta[3];
   if (NT > slices_max) { g_last_error = "msm: internal slice count overflow"; return ALEO_MI355X_ERR_HIP; }
   HIPCHK(hipEventRecord(c->ev[6], s));
   if (NT) {
@@ -602,8 +617,11 @@ int32_t msm_run(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, const void* 
     hipLaunchKernelGGL(k_slice_order, dim3((NT + 255) / 256), dim3(256), 0, s, hist, scan_local, scan_blk, total_pairs, meta, task_g, len_count, len_cursor, order);
     hipLaunchKernelGGL(k_accum, dim3((NT + 255) / 256), dim3(256), 0, s, bases, sorted, hist, scan_local, scan_blk, total_pairs, meta, order, task_g, partial);
     HIPCHK(hipEventRecord(c->ev[5], s));
-    for (uint32_t pass = 0, L = max_m; L > 1; ++pass, L = (L + 1) >> 1)
-      hipLaunchKernelGGL(k_tree_pass, dim3((NT + 255) / 256), dim3(256), 0, s, partial, task_g, scan_local, scan_blk, M, meta, pass);
+    for (uint32_t pass = 0, L = max_m; L > 1 && n_heavy; ++pass, L = (L + 1) >> 1) {
+      uint32_t max_pairs = L >> 1;                          // pairs of the longest bucket at this level
+      uint64_t threads = (uint64_t)n_heavy * max_pairs;
+      hipLaunchKernelGGL(k_tree_pass, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, s, partial, heavy, scan_local, scan_blk, M, meta, pass, max_pairs);
+    }
   }
   HIPCHK(hipEventRecord(c->ev[2], s));
   char* h_win = (char*)c->h_pinned + 64;

@@ -10,6 +10,7 @@ n = 1 << lg
 aleo_amd._lib.check(aleo_amd.lib().aleo_mi355x_init(0), 'init')
 pb = M.PinnedBases.generate_multiples(synth.generator_affine104(), 1, n)
 if pre: pb.precompute()
-s = torch.from_numpy(synth.uniform_scalars(n, 5).view(np.int64)).cuda(); torch.cuda.synchronize()
+seed = int(sys.argv[3], 0) if len(sys.argv) > 3 else 5
+s = torch.from_numpy(synth.uniform_scalars(n, seed).view(np.int64)).cuda(); torch.cuda.synchronize()
 for _ in range(6): M.VariableBase.msm_device(pb, s.data_ptr(), n)
 print(M.last_msm_timing())
