@@ -222,13 +222,15 @@ __global__ void __launch_bounds__(256) k_bin_sort(const uint2* __restrict__ item
 // slices (tried) put a 2.7 ms floor under a 2.4 ms kernel, because the top window of a 253-bit scalar only has 13 bits
 // and its 4779 buckets hold ~300 points each.  64/32 keeps the floor at about half the kernel time.
 // Sparse inputs (witness-like scalars, small n) use 32/32 so that the accumulation still fills every SIMD.
+static constexpr uint32_t SUPER_CAP = 4096;    // buckets with > 16 slices kept in their own list
 struct SliceRule { uint32_t single, split; };
-__device__ __forceinline__ SliceRule pick_rule(const uint32_t* total_pairs) {
-  const uint32_t tp = *total_pairs;       // more pairs per resident lane -> longer slices stay far below the kernel time
-  SliceRule r;
-  if (tp < (8u << 20)) { r.single = 32u; r.split = 32u; }
-  else if (tp < (32u << 20)) { r.single = 64u; r.split = 32u; }
-  else { r.single = 128u; r.split = 64u; }
+__device__ __forceinline__ SliceRule pick_rule(const uint32_t* total_pairs, uint32_t M) {
+  // single = 2 x the mean bucket size rounded up to a power of two (32..512), split = single / 2: the longest slice
+  // then stays near half of (pairs / resident lanes) whatever n is; sparse inputs (mean < 16) use 32/32.
+  const uint32_t mean = *total_pairs / M;
+  SliceRule r; r.single = 32u;
+  while (r.single < 2u * mean && r.single < 512u) r.single <<= 1;
+  r.split = r.single > 32u ? r.single >> 1 : 32u;
   return r;
 }
 __device__ __forceinline__ uint32_t slices_of(uint32_t cnt, SliceRule r) { return cnt <= r.single ? (cnt ? 1u : 0u) : (cnt + r.split - 1) / r.split; }
@@ -237,7 +239,7 @@ __global__ void __launch_bounds__(256) k_scan_tiles(const uint32_t* hist, uint32
                                                     uint32_t* __restrict__ heavy) {
   __shared__ uint2 wsum[4];
   uint32_t base = blockIdx.x * SCAN_TILE + threadIdx.x * 8;
-  const SliceRule T0 = pick_rule(total_pairs);
+  const SliceRule T0 = pick_rule(total_pairs, M);
   uint32_t c[8]; uint32_t mx = 0;
 #pragma unroll
   for (int k = 0; k < 8; ++k) c[k] = (base + k < M) ? hist[base + k] : 0u;
@@ -245,7 +247,10 @@ __global__ void __launch_bounds__(256) k_scan_tiles(const uint32_t* hist, uint32
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
     pre[k] = run; uint32_t m = slices_of(c[k], T0); run.x += c[k]; run.y += m; mx = mx > m ? mx : m;
-    if (m > 1) heavy[atomicAdd(&meta[3], 1u)] = base + k;       // multi-slice buckets: the only work of the slice tree
+    // multi-slice buckets are the only work of the slice tree; the few with > 16 slices (skewed scalars) get their own
+    // list so that the launch width of the common list stays at 8 pairs per bucket
+    if (m > 16) { uint32_t q = atomicAdd(&meta[5], 1u); if (q < SUPER_CAP) heavy[M + 2048 + q] = base + k; else heavy[atomicAdd(&meta[3], 1u)] = base + k; }
+    else if (m > 1) heavy[atomicAdd(&meta[3], 1u)] = base + k;
   }
   // wave inclusive scan of the per-thread totals
   uint2 inc = run; int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -295,10 +300,10 @@ __device__ __forceinline__ uint2 scan_at(const uint2* local, const uint2* blk, u
 }
 
 // ---- slice ordering: lanes of one wave should run the same trip count --------------------------------
-// Slices are at most 128 points long; bucket sizes are Poisson, so slice lengths vary 2:1 inside a wave if
+// Slices are at most 512 points long; bucket sizes are Poisson, so slice lengths vary 2:1 inside a wave if
 // taken in bucket order (measured: 31 % of the accumulation's lanes idle).  A counting sort by length (longest
-// first) costs two tiny launches: block-local LDS histograms + <= 129 global atomics per block.
-static constexpr uint32_t MAX_T0 = 128;
+// first) costs two tiny launches: block-local LDS histograms + a handful of global atomics per block.
+static constexpr uint32_t MAX_T0 = 512;
 __device__ __forceinline__ uint32_t slice_len(uint32_t cnt, uint32_t m, uint32_t k) {
   return (uint32_t)(((uint64_t)(k + 1) * cnt) / m) - (uint32_t)(((uint64_t)k * cnt) / m);
 }
@@ -308,7 +313,7 @@ __global__ void __launch_bounds__(256) k_slice_count(const uint32_t* __restrict_
                                                      uint32_t M, const uint32_t* __restrict__ total_pairs, const uint32_t* __restrict__ meta, uint32_t* __restrict__ task_g,
                                                      uint32_t* __restrict__ len_count) {
   __shared__ uint32_t h[MAX_T0 + 1];
-  if (threadIdx.x <= MAX_T0) h[threadIdx.x] = 0;
+  for (uint32_t i = threadIdx.x; i <= MAX_T0; i += 256) h[i] = 0;
   __syncthreads();
   uint32_t t = blockIdx.x * 256 + threadIdx.x;
   if (t < meta[0]) {
@@ -317,34 +322,41 @@ __global__ void __launch_bounds__(256) k_slice_count(const uint32_t* __restrict_
       uint32_t mid = (lo + hi + 1) >> 1;
       if (scan_at(scan_local, scan_blk, mid).y <= t) lo = mid; else hi = mid - 1;
     }
-    uint32_t g = lo, cnt = hist[g], m = slices_of(cnt, pick_rule(total_pairs)), k = t - scan_at(scan_local, scan_blk, g).y;
+    uint32_t g = lo, cnt = hist[g], m = slices_of(cnt, pick_rule(total_pairs, M)), k = t - scan_at(scan_local, scan_blk, g).y;
     task_g[t] = g;
     atomicAdd(&h[slice_len(cnt, m, k)], 1u);
   }
   __syncthreads();
-  if (threadIdx.x <= MAX_T0 && h[threadIdx.x]) atomicAdd(&len_count[threadIdx.x], h[threadIdx.x]);
+  for (uint32_t i = threadIdx.x; i <= MAX_T0; i += 256) if (h[i]) atomicAdd(&len_count[i], h[i]);
+}
+
+// len_start[l] = number of slices longer than l (they come first); one block
+__global__ void __launch_bounds__(256) k_len_starts(const uint32_t* __restrict__ len_count, uint32_t* __restrict__ len_start) {
+  __shared__ uint32_t c[MAX_T0 + 2];
+  for (uint32_t i = threadIdx.x; i <= MAX_T0; i += 256) c[i] = len_count[i];
+  __syncthreads();
+  if (threadIdx.x == 0) { uint32_t run = 0; for (int l = (int)MAX_T0; l >= 0; --l) { uint32_t v = c[l]; c[l] = run; run += v; } }
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i <= MAX_T0; i += 256) len_start[i] = c[i];
 }
 
 // order[pos] = sid, longest slices first
 __global__ void __launch_bounds__(256) k_slice_order(const uint32_t* __restrict__ hist, const uint2* __restrict__ scan_local, const uint2* __restrict__ scan_blk,
-                                                     const uint32_t* __restrict__ total_pairs, const uint32_t* __restrict__ meta, const uint32_t* __restrict__ task_g,
-                                                     const uint32_t* __restrict__ len_count, uint32_t* __restrict__ len_cursor, uint32_t* __restrict__ order) {
+                                                     const uint32_t* __restrict__ total_pairs, uint32_t M, const uint32_t* __restrict__ meta, const uint32_t* __restrict__ task_g,
+                                                     const uint32_t* __restrict__ len_start, uint32_t* __restrict__ len_cursor, uint32_t* __restrict__ order) {
   __shared__ uint32_t h[MAX_T0 + 1], base[MAX_T0 + 1];
-  if (threadIdx.x <= MAX_T0) h[threadIdx.x] = 0;
+  for (uint32_t i = threadIdx.x; i <= MAX_T0; i += 256) h[i] = 0;
   __syncthreads();
   uint32_t t = blockIdx.x * 256 + threadIdx.x, len = 0, rank = 0;
   bool live = t < meta[0];
   if (live) {
-    uint32_t g = task_g[t], cnt = hist[g], m = slices_of(cnt, pick_rule(total_pairs)), k = t - scan_at(scan_local, scan_blk, g).y;
+    uint32_t g = task_g[t], cnt = hist[g], m = slices_of(cnt, pick_rule(total_pairs, M)), k = t - scan_at(scan_local, scan_blk, g).y;
     len = slice_len(cnt, m, k);
     rank = atomicAdd(&h[len], 1u);
   }
   __syncthreads();
-  if (threadIdx.x <= MAX_T0) {
-    uint32_t start = 0;                       // slices longer than this one come first
-    for (uint32_t l = threadIdx.x + 1; l <= MAX_T0; ++l) start += len_count[l];
-    base[threadIdx.x] = start + (h[threadIdx.x] ? atomicAdd(&len_cursor[threadIdx.x], h[threadIdx.x]) : 0u);
-  }
+  for (uint32_t i = threadIdx.x; i <= MAX_T0; i += 256)
+    if (h[i]) base[i] = len_start[i] + atomicAdd(&len_cursor[i], h[i]);
   __syncthreads();
   if (live) order[base[len] + rank] = t;
 }
@@ -362,14 +374,14 @@ __device__ __noinline__ void slice_slow_path(const char* bases, const uint32_t* 
 }
 
 __global__ void __launch_bounds__(256) k_accum(const char* __restrict__ bases, const uint32_t* __restrict__ sorted, const uint32_t* __restrict__ hist,
-                                               const uint2* __restrict__ scan_local, const uint2* __restrict__ scan_blk, const uint32_t* __restrict__ total_pairs,
+                                               const uint2* __restrict__ scan_local, const uint2* __restrict__ scan_blk, const uint32_t* __restrict__ total_pairs, uint32_t M,
                                                const uint32_t* __restrict__ meta, const uint32_t* __restrict__ order, const uint32_t* __restrict__ task_g,
                                                char* __restrict__ partial) {
   uint32_t t = blockIdx.x * 256 + threadIdx.x;
   if (t >= meta[0]) return;
   const uint32_t sid = order[t], g = task_g[sid];
   uint2 st = scan_at(scan_local, scan_blk, g);
-  uint32_t cnt = hist[g], m = slices_of(cnt, pick_rule(total_pairs)), k = sid - st.y;
+  uint32_t cnt = hist[g], m = slices_of(cnt, pick_rule(total_pairs, M)), k = sid - st.y;
   uint32_t j0 = (uint32_t)(((uint64_t)k * cnt) / m), j1 = (uint32_t)(((uint64_t)(k + 1) * cnt) / m);
   const uint32_t* run = sorted + st.x;
   // software prefetch: the next point's 96-byte gather is in flight under the current mixed addition
@@ -400,10 +412,11 @@ __global__ void __launch_bounds__(256) k_accum(const char* __restrict__ bases, c
 
 // partial[ft + i] += partial[ft + i + half] inside every multi-slice bucket (listed in heavy[] by the scan)
 __global__ void __launch_bounds__(256) k_tree_pass(char* __restrict__ partial, const uint32_t* __restrict__ heavy, const uint2* __restrict__ scan_local,
-                                                   const uint2* __restrict__ scan_blk, uint32_t M, const uint32_t* __restrict__ meta, uint32_t pass, uint32_t max_pairs) {
+                                                   const uint2* __restrict__ scan_blk, uint32_t M, const uint32_t* __restrict__ meta, uint32_t pass, uint32_t max_pairs,
+                                                   uint32_t list_len) {
   uint32_t t = blockIdx.x * 256 + threadIdx.x;
   uint32_t h = t / max_pairs, i = t % max_pairs;
-  if (h >= meta[3]) return;
+  if (h >= list_len) return;
   uint32_t g = heavy[h];
   uint32_t ft = scan_at(scan_local, scan_blk, g).y;
   uint32_t fn = (g + 1 < M) ? scan_at(scan_local, scan_blk, g + 1).y : meta[0];
@@ -561,7 +574,7 @@ int32_t msm_run(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, const void* 
   const size_t slices_max = pairs_max / 32 + M + 1;          // worst case of pick_t0()
   int32_t rc;
   // hist | cursor | meta live in one zero-initialised allocation
-  if ((rc = c->hist.reserve((2 * (size_t)M + 512) * 4))) return rc;
+  if ((rc = c->hist.reserve((2 * (size_t)M + 2048 + SUPER_CAP) * 4))) return rc;
   if ((rc = c->scan_local.reserve((size_t)M * 8))) return rc;
   if ((rc = c->scan_blk.reserve(2 * (size_t)ntiles * 8 + 64))) return rc;
   if ((rc = c->sorted.reserve(pairs_max * 4))) return rc;
@@ -589,7 +602,7 @@ int32_t msm_run(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, const void* 
   const char* bases = (const char*)(pre ? pb.d_pre : pb.d_xy);
 
   HIPCHK(hipEventRecord(c->ev[0], s));
-  HIPCHK(hipMemsetAsync(hist, 0, (2 * (size_t)M + 512) * 4, s));
+  HIPCHK(hipMemsetAsync(hist, 0, (2 * (size_t)M + 2048 + SUPER_CAP) * 4, s));
   SortArgs sa;
   sa.scalars = d_scalars; sa.inf = pb.d_inf; sa.n = (uint32_t)n; sa.nblk = nblk;
   sa.cnt = c->part_cnt.as<uint32_t>(); sa.off_local = sa.cnt + cnt_len;
@@ -605,22 +618,32 @@ int32_t msm_run(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, const void* 
   hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(256), 0, s, tile_tot, ntiles, scan_blk, meta);
   // slice count / max slices per bucket decide the grid of the accumulation and the number of tree passes
   uint32_t* h_meta = (uint32_t*)c->h_pinned;
-  HIPCHK(hipMemcpyAsync(h_meta, meta, 16, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipMemcpyAsync(h_meta, meta, 32, hipMemcpyDeviceToHost, s));
   HIPCHK(hipEventRecord(c->ev[1], s));
   HIPCHK(hipStreamSynchronize(s));
-  const uint32_t NT = h_meta[0], max_m = h_meta[1], n_heavy = h_meta[3];
+  const uint32_t NT = h_meta[0], max_m = h_meta[1];
+  uint32_t n_heavy = h_meta[3], n_super = h_meta[5] < SUPER_CAP ? h_meta[5] : SUPER_CAP;
+  const bool super_overflow = h_meta[5] > SUPER_CAP;          // then the common list also holds very long buckets
   if (NT > slices_max) { g_last_error = "msm: internal slice count overflow"; return ALEO_MI355X_ERR_HIP; }
   HIPCHK(hipEventRecord(c->ev[6], s));
   if (NT) {
-    uint32_t* len_count = meta + 4; uint32_t* len_cursor = len_count + MAX_T0 + 1;     // zeroed with hist/cursor/meta
+    uint32_t* len_count = meta + 16; uint32_t* len_cursor = len_count + MAX_T0 + 1; uint32_t* len_start = len_cursor + MAX_T0 + 1;   // zeroed with hist/meta
     hipLaunchKernelGGL(k_slice_count, dim3((NT + 255) / 256), dim3(256), 0, s, hist, scan_local, scan_blk, M, total_pairs, meta, task_g, len_count);
-    hipLaunchKernelGGL(k_slice_order, dim3((NT + 255) / 256), dim3(256), 0, s, hist, scan_local, scan_blk, total_pairs, meta, task_g, len_count, len_cursor, order);
-    hipLaunchKernelGGL(k_accum, dim3((NT + 255) / 256), dim3(256), 0, s, bases, sorted, hist, scan_local, scan_blk, total_pairs, meta, order, task_g, partial);
+    hipLaunchKernelGGL(k_len_starts, dim3(1), dim3(256), 0, s, len_count, len_start);
+    hipLaunchKernelGGL(k_slice_order, dim3((NT + 255) / 256), dim3(256), 0, s, hist, scan_local, scan_blk, total_pairs, M, meta, task_g, len_start, len_cursor, order);
+    hipLaunchKernelGGL(k_accum, dim3((NT + 255) / 256), dim3(256), 0, s, bases, sorted, hist, scan_local, scan_blk, total_pairs, M, meta, order, task_g, partial);
     HIPCHK(hipEventRecord(c->ev[5], s));
-    for (uint32_t pass = 0, L = max_m; L > 1 && n_heavy; ++pass, L = (L + 1) >> 1) {
-      uint32_t max_pairs = L >> 1;                          // pairs of the longest bucket at this level
-      uint64_t threads = (uint64_t)n_heavy * max_pairs;
-      hipLaunchKernelGGL(k_tree_pass, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, s, partial, heavy, scan_local, scan_blk, M, meta, pass, max_pairs);
+    const uint32_t* super_list = heavy + M + 2048;
+    for (uint32_t pass = 0, L = max_m; L > 1; ++pass, L = (L + 1) >> 1) {
+      const uint32_t Lc = super_overflow ? L : (L < 16u ? L : (16u >> (pass < 4 ? pass : 4)));       // longest bucket of the common list at this level
+      if (n_heavy && Lc > 1) {
+        uint32_t mp = Lc >> 1; uint64_t threads = (uint64_t)n_heavy * mp;
+        hipLaunchKernelGGL(k_tree_pass, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, s, partial, heavy, scan_local, scan_blk, M, meta, pass, mp, n_heavy);
+      }
+      if (n_super) {
+        uint32_t mp = L >> 1; uint64_t threads = (uint64_t)n_super * mp;
+        hipLaunchKernelGGL(k_tree_pass, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, s, partial, super_list, scan_local, scan_blk, M, meta, pass, mp, n_super);
+      }
     }
   }
   HIPCHK(hipEventRecord(c->ev[2], s));

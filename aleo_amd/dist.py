@@ -17,11 +17,12 @@ def shard_range(n: int, rank: int, world: int):
 
 
 def all_gather_partials(partial: np.ndarray, group=None, device=None) -> np.ndarray:
-    """partial: uint64[18] on the host -> uint64[world,18] on every rank (144-byte all-gather)."""
+    """partial: uint64[k] on the host (k = 18 for a Jacobian point) -> uint64[world,k] on every rank.
+    With backend "nccl" (= RCCL) pass the rank's device: the 144-byte payload travels over xGMI."""
     import torch
     import torch.distributed as dist
     world = dist.get_world_size(group)
-    t = torch.from_numpy(np.ascontiguousarray(partial, dtype=np.uint64).view(np.int64).copy())
+    t = torch.from_numpy(np.ascontiguousarray(partial, dtype=np.uint64).reshape(-1).view(np.int64).copy())
     if device is not None:
         t = t.to(device)
     outs = [torch.empty_like(t) for _ in range(world)]

@@ -92,7 +92,8 @@ def main():
     # correctness gate: the result must equal k*G with k = sum_i s_i * (first+i) over all ranks (an O(n) identity)
     k = synth.weighted_scalar_sum(scalars, first)
     if world > 1:
-        ks = [None] * world; dist.all_gather_object(ks, k); k = sum(ks) % synth.FR_MODULUS
+        ks = adist.all_gather_partials(synth.int_to_limbs(k, 4), device=gather_dev)      # 4 limbs per rank, same collective
+        k = sum(synth.limbs_to_int(row) for row in ks) % synth.FR_MODULUS
     kG = aleo_amd.VariableBase.msm(gen.reshape(1, 104), synth.int_to_limbs(k, 4).reshape(1, 4))
     if not (np.asarray(res) == kG).all():
         raise SystemExit('bench: MSM result does not equal k*G — refusing to report a number for a wrong result')
