@@ -27,6 +27,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-sample-lg', type=int, default=20)
     ap.add_argument('--no-precompute', action='store_true', help='skip the fixed-base window table (one-shot MSM path)')
+    ap.add_argument('--no-kzg-chain', action='store_true', help='skip the secondary 2^22 iNTT -> commit measurement (config[2])')
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
                     help="'gloo' is only for rehearsing the N>1 path with several ranks sharing one GPU")
     args = ap.parse_args()
@@ -123,11 +124,43 @@ def main():
                                  'measured Fq product peak 60 G/s (tools/ubench/fq_mul_bench.hip)' % (16 if args.no_precompute else 13)},
             'phases_ms': {kk: float(np.mean([p_[kk] for p_ in phases])) for kk in phases[0]},
         }
+        if world == 1 and not args.no_kzg_chain:
+            out['kzg_chain_2^22'] = kzg_chain(aleo_amd, synth, torch, dev)
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args, pb, scalars, aleo_amd)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier(); dist.destroy_process_group()
+
+
+def kzg_chain(aleo_amd, synth, torch, dev, lg=22, reps=5):
+    """BASELINE configs[2]: 2^22 scalar-field iNTT followed by a 2^22 G1 MSM over the result without leaving HBM
+    (the KZG10::commit shape).  Secondary measurement: NTT time by HIP events on the launch stream, algorithmic bytes
+    64 B per element; the commit through the library's own phase timers."""
+    n = 1 << lg
+    pb = aleo_amd.PinnedBases.generate_multiples(synth.generator_affine104(), 1, n).precompute()
+    evals = torch.from_numpy(synth.uniform_scalars(n, 0xA1E00003).view(np.int64)).to(dev)      # canonical < r, read as Montgomery
+    d = aleo_amd.EvaluationDomain(n)
+    st = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(st):
+        buf = evals.clone()
+        d.ntt_device(buf.data_ptr(), 0, 1, 0, st.cuda_stream); st.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(st)
+        for _ in range(reps):
+            d.ntt_device(buf.data_ptr(), 0, 1, 0, st.cuda_stream)
+        e1.record(st); st.synchronize()
+        ntt_ms = e0.elapsed_time(e1) / reps
+        buf.copy_(evals); d.ntt_device(buf.data_ptr(), 0, 1, 0, st.cuda_stream); st.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        cm = aleo_amd.KZG10.commit_device(pb, buf.data_ptr(), n)
+    commit_ms = (time.perf_counter() - t0) / reps * 1e3
+    pb.close()
+    gbps = 64.0 * n / (ntt_ms * 1e-3) / 1e9
+    return {'ntt_ms': ntt_ms, 'ntt_alg_GBps': gbps, 'ntt_frac_hbm': gbps / 8000.0, 'commit_ms': commit_ms,
+            'commit_scalar_muls_per_s': n / (commit_ms * 1e-3), 'chain_ms': ntt_ms + commit_ms,
+            'commitment_x_limb0': int(np.frombuffer(cm.tobytes()[:8], dtype=np.uint64)[0])}
 
 
 def cpu_baseline(args, pb, scalars, aleo_amd):
