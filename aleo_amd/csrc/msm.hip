@@ -625,12 +625,12 @@ int32_t msm_run(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, const void* 
   uint32_t n_heavy = h_meta[3], n_super = h_meta[5] < SUPER_CAP ? h_meta[5] : SUPER_CAP;
   const bool super_overflow = h_meta[5] > SUPER_CAP;          // then the common list also holds very long buckets
   if (NT > slices_max) { g_last_error = "msm: internal slice count overflow"; return ALEO_MI355X_ERR_HIP; }
-  HIPCHK(hipEventRecord(c->ev[6], s));
   if (NT) {
     uint32_t* len_count = meta + 16; uint32_t* len_cursor = len_count + MAX_T0 + 1; uint32_t* len_start = len_cursor + MAX_T0 + 1;   // zeroed with hist/meta
     hipLaunchKernelGGL(k_slice_count, dim3((NT + 255) / 256), dim3(256), 0, s, hist, scan_local, scan_blk, M, total_pairs, meta, task_g, len_count);
     hipLaunchKernelGGL(k_len_starts, dim3(1), dim3(256), 0, s, len_count, len_start);
     hipLaunchKernelGGL(k_slice_order, dim3((NT + 255) / 256), dim3(256), 0, s, hist, scan_local, scan_blk, total_pairs, M, meta, task_g, len_start, len_cursor, order);
+    HIPCHK(hipEventRecord(c->ev[6], s));          // ev[6]..ev[5] bracket k_accum alone (bench.py's roofline kernel)
     hipLaunchKernelGGL(k_accum, dim3((NT + 255) / 256), dim3(256), 0, s, bases, sorted, hist, scan_local, scan_blk, total_pairs, M, meta, order, task_g, partial);
     HIPCHK(hipEventRecord(c->ev[5], s));
     const uint32_t* super_list = heavy + M + 2048;
