@@ -2,6 +2,7 @@
 // host<->HBM staging, and the host-side tails.  Kernels live in msm.hip / ntt.hip.
 #include "ctx.h"
 #include "host_field.hpp"
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 
@@ -99,6 +100,55 @@ static int32_t msm_host_scalars_locked(Ctx* c, void* out, const PinnedBases& pb,
   return msm_run(c, (uint64_t*)out, pb, c->scalars_stage.p, n, mont, c->stream);
 }
 
+// ---- SRS cache for the one-shot entry point ----------------------------------------------------------
+static uint64_t hash96(const uint8_t* p) {      // FNV-1a over the 96 coordinate bytes of one point
+  uint64_t h = 1469598103934665603ull;
+  for (int i = 0; i < 96; ++i) { h ^= p[i]; h *= 1099511628211ull; }
+  return h;
+}
+static constexpr size_t SRS_SAMPLES = 256, SRS_CACHE_ENTRIES = 8, SRS_MIN_N = 1024;
+
+static bool srs_cache_enabled() {
+  static int on = -1;
+  if (on < 0) { const char* e = std::getenv("ALEO_MI355X_SRS_CACHE"); on = (e && e[0] == '0') ? 0 : 1; }
+  return on == 1;
+}
+// Returns the cached pinned set for (bases, stride) that covers n points, or nullptr.
+static SrsCacheEntry* srs_lookup(Ctx* c, const void* bases, size_t stride, size_t n) {
+  for (auto& e : c->srs_cache) {
+    if (e.host_ptr != bases || e.stride != stride || e.n < n) continue;
+    bool ok = true; size_t checked = 0;
+    for (auto& sm : e.samples) {                 // only samples inside the caller's slice may be read
+      if (sm.first >= n) continue;
+      ++checked;
+      if (hash96((const uint8_t*)bases + sm.first * stride) != sm.second) { ok = false; break; }
+    }
+    if (ok && checked) return &e;
+  }
+  return nullptr;
+}
+static int32_t srs_insert(Ctx* c, const void* bases, size_t stride, size_t n, SrsCacheEntry** out) {
+  // drop stale entries for the same pointer, then the least recently used one if the cache is full
+  for (size_t i = 0; i < c->srs_cache.size();) {
+    if (c->srs_cache[i].host_ptr == bases) { unpin_locked(c, c->srs_cache[i].handle); c->srs_cache.erase(c->srs_cache.begin() + i); } else ++i;
+  }
+  if (c->srs_cache.size() >= SRS_CACHE_ENTRIES) {
+    size_t lru = 0; for (size_t i = 1; i < c->srs_cache.size(); ++i) if (c->srs_cache[i].last_use < c->srs_cache[lru].last_use) lru = i;
+    unpin_locked(c, c->srs_cache[lru].handle); c->srs_cache.erase(c->srs_cache.begin() + lru);
+  }
+  SrsCacheEntry e; e.host_ptr = bases; e.stride = stride; e.n = n;
+  int32_t rc = pin_locked(c, bases, stride, n, &e.handle);
+  if (rc) return rc;
+  // dense samples at the front (every prefix request can be checked), sparse ones over the rest
+  for (size_t k = 0; k < SRS_SAMPLES; ++k) {
+    size_t idx = k < 32 ? k : (size_t)((double)(k - 31) / (SRS_SAMPLES - 31) * (n - 1));
+    if (idx >= n) break;
+    e.samples.emplace_back(idx, hash96((const uint8_t*)bases + idx * stride));
+  }
+  c->srs_cache.push_back(e); *out = &c->srs_cache.back();
+  return ALEO_MI355X_OK;
+}
+
 static void jacobian_to_affine104(void* out104, const uint64_t* jac18) {
   uint8_t* o = (uint8_t*)out104; std::memset(o, 0, 104);
   bool inf = true; for (int i = 12; i < 18; ++i) if (jac18[i]) inf = false;
@@ -170,6 +220,18 @@ int32_t aleo_mi355x_msm_g1(void* out, const void* bases, size_t base_stride, con
   try {
     if (!out || ((!bases || !scalars) && n) || (base_stride != 104 && base_stride != 96)) { g_last_error = "msm_g1: bad argument"; return ALEO_MI355X_ERR_BAD_ARG; }
     API_BEGIN
+    if (n >= SRS_MIN_N && srs_cache_enabled()) {
+      // KZG10::commit multiplies against prefixes of one SRS: keep it in HBM between calls (ALEO_MI355X_SRS_CACHE=0
+      // turns this off; a caller that rewrites a base array in place between calls must do so)
+      SrsCacheEntry* e = srs_lookup(c, bases, base_stride, n);
+      int32_t rc = ALEO_MI355X_OK;
+      if (!e) rc = srs_insert(c, bases, base_stride, n, &e);
+      if (rc) return rc;
+      e->last_use = ++c->srs_clock; e->hits++;
+      PinnedBases& pb = c->bases[e->handle];
+      if (e->hits == 3 && e->n >= (1u << 17) && !pb.d_pre) (void)msm_precompute(c, &pb);     // third use: worth the one-off table
+      return msm_host_scalars_locked(c, out, pb, scalars, n, false);
+    }
     uint64_t h = 0; int32_t rc = pin_locked(c, bases, base_stride, n, &h);
     if (rc) return rc;
     rc = msm_host_scalars_locked(c, out, c->bases[h], scalars, n, false);

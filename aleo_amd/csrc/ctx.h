@@ -45,6 +45,13 @@ struct PinnedBases {
   size_t n = 0;
 };
 
+// One-shot aleo_mi355x_msm_g1 calls keep their base array resident between calls ("device-resident SRS
+// cache keyed by host pointer + length + hash"): KZG10::commit always multiplies against a prefix of the same powers.
+struct SrsCacheEntry {
+  const void* host_ptr = nullptr; size_t n = 0, stride = 0; uint64_t handle = 0, last_use = 0; uint32_t hits = 0;
+  std::vector<std::pair<size_t, uint64_t>> samples;      // (point index, hash of its 96 bytes)
+};
+
 struct MsmTiming { double total = 0, sort = 0, accum = 0, reduce = 0, host = 0, accum_kernel = 0; };
 
 struct NttTables;   // ntt.hip
@@ -59,6 +66,7 @@ struct Ctx {
   void* h_pinned = nullptr; size_t h_pinned_cap = 0;    // pinned host staging for small D2H results
   std::map<uint64_t, PinnedBases> bases; uint64_t next_handle = 1;
   MsmTiming last_msm;
+  std::vector<SrsCacheEntry> srs_cache; uint64_t srs_clock = 0;
   // NTT
   std::map<uint64_t, NttTables*> ntt_tables; DevBuf ntt_tmp, ntt_stage;
 };

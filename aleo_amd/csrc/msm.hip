@@ -160,7 +160,7 @@ __global__ void __launch_bounds__(256) k_scan32_top(const uint32_t* __restrict__
 __device__ __forceinline__ uint32_t scan32_at(const uint32_t* local, const uint32_t* blk, size_t i) { return local[i] + blk[i / SCAN_TILE]; }
 
 template <int C, bool MONT, bool PRE>
-__global__ void __launch_bounds__(256) k_part_scatter(const void* scalars, const uint8_t* inf, uint32_t n, uint32_t nblk,
+__global__ void __launch_bounds__(256) k_part_scatter(const void* scalars, const uint8_t* inf, uint32_t n, uint32_t nblk, uint32_t row_stride,
                                                       const uint32_t* __restrict__ off_local, const uint32_t* __restrict__ off_blk, uint2* __restrict__ items) {
   using Gm = SortGeom<C, PRE>;
   __shared__ uint32_t cur[MAX_COARSE];
@@ -173,7 +173,7 @@ __global__ void __launch_bounds__(256) k_part_scatter(const void* scalars, const
       uint32_t s[8]; load_scalar<MONT>(scalars, i, s);
       for_each_digit<C, 0>(s, 0u, [&](uint32_t w, uint32_t b, uint32_t neg) {
         uint32_t pos = atomicAdd(&cur[Gm::bin(w, b)], 1u);
-        items[pos] = make_uint2((PRE ? w * n + i : i) | (neg << 31), b & ((1u << Gm::LB) - 1u));
+        items[pos] = make_uint2((PRE ? w * row_stride + i : i) | (neg << 31), b & ((1u << Gm::LB) - 1u));
       });
     }
   }
@@ -546,10 +546,10 @@ __global__ void k_gather_windows(const char* __restrict__ V, uint32_t seg_len, u
 }
 
 // ---- dispatch on the window width ---------------------------------------------------------------
-struct SortArgs { const void* scalars; const uint8_t* inf; uint32_t n, nblk; uint32_t* cnt; uint32_t* off_local; uint32_t* off_blk; uint2* items; };
+struct SortArgs { const void* scalars; const uint8_t* inf; uint32_t n, nblk, row_stride; uint32_t* cnt; uint32_t* off_local; uint32_t* off_blk; uint2* items; };
 template <int C, bool MONT, bool PRE> static void launch_sort_c(const SortArgs& a, int phase, hipStream_t s) {
   if (phase == 0) hipLaunchKernelGGL((k_part_count<C, MONT, PRE>), dim3(a.nblk), dim3(256), 0, s, a.scalars, a.inf, a.n, a.nblk, a.cnt);
-  else hipLaunchKernelGGL((k_part_scatter<C, MONT, PRE>), dim3(a.nblk), dim3(256), 0, s, a.scalars, a.inf, a.n, a.nblk, a.off_local, a.off_blk, a.items);
+  else hipLaunchKernelGGL((k_part_scatter<C, MONT, PRE>), dim3(a.nblk), dim3(256), 0, s, a.scalars, a.inf, a.n, a.nblk, a.row_stride, a.off_local, a.off_blk, a.items);
 }
 template <bool MONT> static void launch_sort(int c, const SortArgs& a, int phase, hipStream_t s) {
   switch (c) {
@@ -566,7 +566,9 @@ int32_t msm_run(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, const void* 
   using namespace host;
   if (n == 0) { hstore_jacobian_normalized(out_jac18, HXYZZ::infinity()); return ALEO_MI355X_OK; }
   if (n > pb.n || n >= (1ull << 31)) { g_last_error = "msm: n exceeds the pinned base count (or 2^31)"; return ALEO_MI355X_ERR_BAD_ARG; }
-  const bool pre = pb.d_pre != nullptr && n == pb.n;      // the table is laid out for the full set
+  // the fixed-base table serves any prefix of the pinned set (row stride = pinned count); below 2^17 points the plain
+  // path with its small bucket count is faster than reducing 2^19 mostly empty buckets
+  const bool pre = pb.d_pre != nullptr && n >= (1u << 17);
   MsmPlan P = make_plan(n, pre);
   const uint32_t digitsW = pre ? (SCALAR_BITS + PRE_C - 1) / PRE_C : P.W;
   const uint32_t M = P.M, ntiles = (M + SCAN_TILE - 1) / SCAN_TILE;
@@ -604,7 +606,7 @@ int32_t msm_run(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, const void* 
   HIPCHK(hipEventRecord(c->ev[0], s));
   HIPCHK(hipMemsetAsync(hist, 0, (2 * (size_t)M + 2048 + SUPER_CAP) * 4, s));
   SortArgs sa;
-  sa.scalars = d_scalars; sa.inf = pb.d_inf; sa.n = (uint32_t)n; sa.nblk = nblk;
+  sa.scalars = d_scalars; sa.inf = pb.d_inf; sa.n = (uint32_t)n; sa.nblk = nblk; sa.row_stride = (uint32_t)pb.n;
   sa.cnt = c->part_cnt.as<uint32_t>(); sa.off_local = sa.cnt + cnt_len;
   uint32_t* cnt_tile_tot = sa.off_local + cnt_len; sa.off_blk = cnt_tile_tot + cnt_tiles;
   sa.items = c->part_items.as<uint2>();

@@ -267,3 +267,20 @@ def test_msm_fixed_base_table_path():
         assert c.jac_to_int_point(M.VariableBase.msm(pb, S)) == exp
         pb.precompute()
         assert c.jac_to_int_point(M.VariableBase.msm(pb, S)) == exp
+
+
+def test_one_shot_msm_srs_cache_and_prefixes():
+    """aleo_mi355x_msm_g1 keeps a base array resident between calls (pointer + sampled-content key), serves prefixes of
+    it, switches to the fixed-base table on the third use, and notices when the array's contents change."""
+    n = 1 << 17
+    B = util.multiples_bases(n)
+    S = util.uniform_scalars(n, 777)
+    exp = util.expected_multiples_msm(S, n)
+    for _ in range(4):                                   # miss, hit, hit (+ table build), hit on the table path
+        assert c.jac_to_int_point(M.VariableBase.msm(B, S)) == exp
+    for m in (n // 2, 5000, 1024):                       # prefixes of the cached array
+        assert c.jac_to_int_point(M.VariableBase.msm(B[:m], S[:m])) == util.expected_multiples_msm(S, m)
+    B[3] = B[10]                                         # same buffer, new contents: the sampled check must reject the entry
+    got = c.jac_to_int_point(M.VariableBase.msm(B, S))
+    k = (synth.weighted_scalar_sum(S, 1) + (11 - 4) * synth.limbs_to_int(S[3])) % p.FR_MODULUS
+    assert got == p.g1_mul(p.G1_GENERATOR, k)
