@@ -14,3 +14,9 @@ seed = int(sys.argv[3], 0) if len(sys.argv) > 3 else 5
 s = torch.from_numpy(synth.uniform_scalars(n, seed).view(np.int64)).cuda(); torch.cuda.synchronize()
 for _ in range(6): M.VariableBase.msm_device(pb, s.data_ptr(), n)
 print(M.last_msm_timing())
+if len(sys.argv) > 4 and sys.argv[4] == 'check':
+    sc = synth.uniform_scalars(n, seed)
+    got = M.VariableBase.msm_device(pb, s.data_ptr(), n)
+    k = synth.weighted_scalar_sum(sc, 1)
+    kG = M.VariableBase.msm(synth.generator_affine104().reshape(1, 104), synth.int_to_limbs(k, 4).reshape(1, 4))
+    print('structured identity ok:', bool((got == kG).all()), 'Mpts/s', n / M.last_msm_timing()['total_ms'] / 1e3)
