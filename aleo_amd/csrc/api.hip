@@ -298,6 +298,39 @@ int32_t aleo_mi355x_kzg_commit_device(void* out104, uint64_t handle, const void*
   } catch (...) { return ALEO_MI355X_ERR_HIP; }
 }
 
+int32_t aleo_mi355x_kzg_commit_hiding(void* out104, uint64_t h_powers, const void* coeffs, size_t n, uint64_t h_gamma, const void* blind, size_t m) {
+  try {
+    if (!out104 || (!coeffs && n) || (!blind && m)) return ALEO_MI355X_ERR_BAD_ARG;
+    API_BEGIN
+    auto ip = c->bases.find(h_powers), ig = c->bases.find(h_gamma);
+    if (ip == c->bases.end() || ig == c->bases.end()) { g_last_error = "unknown bases handle"; return ALEO_MI355X_ERR_BAD_HANDLE; }
+    uint64_t parts[36];
+    int32_t rc = msm_host_scalars_locked(c, parts, ip->second, coeffs, n, true);
+    if (rc) return rc;
+    if ((rc = msm_host_scalars_locked(c, parts + 18, ig->second, blind, m, true))) return rc;
+    host::HXYZZ t = host::hadd(host::hfrom_jacobian(parts), host::hfrom_jacobian(parts + 18));
+    uint64_t jac[18]; host::hstore_jacobian_normalized(jac, t);
+    jacobian_to_affine104(out104, jac);
+    return ALEO_MI355X_OK;
+  } catch (...) { return ALEO_MI355X_ERR_HIP; }
+}
+
+int32_t aleo_mi355x_fr_vec_op_device(void* d_dst, const void* d_a, const void* d_b, size_t n, int32_t op, void* stream) {
+  try {
+    if ((!d_dst || !d_a || !d_b) && n) return ALEO_MI355X_ERR_BAD_ARG;
+    API_BEGIN
+    return fr_vec_op(c, d_dst, d_a, d_b, n, op, stream ? (hipStream_t)stream : c->stream);
+  } catch (...) { return ALEO_MI355X_ERR_HIP; }
+}
+
+int32_t aleo_mi355x_fr_batch_inverse_device(void* d_inout, size_t n, void* stream) {
+  try {
+    if (!d_inout && n) return ALEO_MI355X_ERR_BAD_ARG;
+    API_BEGIN
+    return fr_batch_inverse(c, d_inout, n, stream ? (hipStream_t)stream : c->stream);
+  } catch (...) { return ALEO_MI355X_ERR_HIP; }
+}
+
 int32_t aleo_mi355x_ntt_fr(void* inout, uint32_t lg_n, int32_t order, int32_t direction, int32_t type) {
   try {
     if (!inout || lg_n > 30 || order < 0 || order > 3 || direction < 0 || direction > 1 || type < 0 || type > 1) { g_last_error = "ntt_fr: bad argument"; return ALEO_MI355X_ERR_BAD_ARG; }

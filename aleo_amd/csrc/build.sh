@@ -8,7 +8,7 @@ HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fgpu-rdc-never 2>/dev/null"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Wno-unused-variable"
 objs=()
-for f in api msm ntt; do
+for f in api msm ntt frops; do
   "$HIPCC" $FLAGS -c "$here/$f.hip" -o "$out/$f.o" &
   objs+=("$out/$f.o")
 done

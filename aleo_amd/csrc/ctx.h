@@ -80,6 +80,9 @@ int32_t launch_fq_mul(Ctx* c, void* r, const void* a, const void* b, size_t n);
 int32_t launch_fr_mul(Ctx* c, void* r, const void* a, const void* b, size_t n);
 int32_t generate_multiples(Ctx* c, const void* base104, uint64_t first, size_t n, PinnedBases* out);
 int32_t msm_precompute(Ctx* c, PinnedBases* pb);
+// frops.hip
+int32_t fr_vec_op(Ctx* c, void* d_dst, const void* d_a, const void* d_b, size_t n, int32_t op, hipStream_t s);
+int32_t fr_batch_inverse(Ctx* c, void* d_inout, size_t n, hipStream_t s);
 // ntt.hip
 int32_t ntt_run(Ctx* c, void* d_inout, uint32_t lg_n, int32_t order, int32_t direction, int32_t type, hipStream_t s);
 

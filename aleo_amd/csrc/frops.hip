@@ -1,0 +1,90 @@
+// frops.hip — field-only vector kernels around the two operators: element-wise Fr products /
+// sums / differences of evaluation vectors and batch inversion, on data that already lives in HBM between an NTT and
+// the next NTT / commitment.
+//
+// Replaces (on the device) the loops snarkVM 0.14.5 runs on the CPU between FFTs in Varuna's rounds [UPSTREAM-RECALL]:
+//   algorithms/src/fft/evaluations.rs      Evaluations::{mul_assign, add_assign, sub_assign}  (pointwise on a domain)
+//   fields/src/traits/field.rs / lib.rs    snarkvm_fields::batch_inversion (Montgomery's trick; zeros stay zero)
+// reached from the same call sites as the NTT: /root/reference/rust/src/program/execute.rs:74,177, transfer.rs:99.
+//
+// Element-wise ops are HBM-bound (96 algorithmic bytes per element against one 305-instruction product): 16-byte
+// coalesced accesses, one element per lane, grid-stride.  Batch inversion: every lane owns a strided subsequence (so a
+// wave's accesses stay contiguous), keeps prefix products in an HBM scratch vector and shares ONE Fermat inversion
+// (a^(r-2), ~380 products) over its K elements: 3 + 380/K products per element.
+#include "ctx.h"
+#include "fp.h"
+
+namespace aleo_mi355x {
+
+__device__ __forceinline__ Fr fr_canonical_lt4r(const Fr& a) { return Fr::cond_sub<1>(Fr::cond_sub<2>(a)); }
+
+template <int OP>
+__global__ void __launch_bounds__(256) k_fr_vec_op(char* __restrict__ dst, const char* a, const char* b, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    Fr x = load_fp<Fr>(a + i * 32), y = load_fp<Fr>(b + i * 32), r;
+    if constexpr (OP == 0) r = Fr::mul(x, y);               // canonical inputs: < 2r
+    else if constexpr (OP == 1) r = Fr::add(x, y);          // < 2r
+    else r = Fr::sub<1>(x, y);                              // x + r - y < 2r
+    store_fp<Fr>(dst + i * 32, Fr::cond_sub<1>(r));
+  }
+}
+
+__device__ __constant__ uint32_t FR_R_MINUS_2[8] = {0xffffffffu, 0x0a117fffu, 0xd0000001u, 0x59aa76feu, 0x5c37b001u, 0x60b44d1eu, 0x9a2ca556u, 0x12ab655eu};
+__device__ __noinline__ void fr_mul_ni(Fr* r, const Fr* a, const Fr* b) { *r = Fr::mul(*a, *b); }
+__device__ __noinline__ void fr_inverse_ni(Fr* io) {       // a^(r-2); a < 2r, result < 2r
+  Fr a = *io, acc = Fr::one();
+  for (int bit = 252; bit >= 0; --bit) {
+    fr_mul_ni(&acc, &acc, &acc);
+    if ((FR_R_MINUS_2[bit >> 5] >> (bit & 31)) & 1u) fr_mul_ni(&acc, &acc, &a);
+  }
+  *io = acc;
+}
+
+// lane t owns elements t, t + T, t + 2T, ... (T = total lanes)
+__global__ void __launch_bounds__(256) k_fr_batch_inverse(char* __restrict__ data, char* __restrict__ prefix, size_t n, size_t T) {
+  size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= T) return;
+  Fr prod = Fr::one();
+  for (size_t i = t; i < n; i += T) {
+    store_fp<Fr>(prefix + i * 32, prod);                      // product of this lane's earlier non-zero elements (< 2r)
+    Fr v = load_fp<Fr>(data + i * 32);
+    if (!v.is_zero_raw()) prod = Fr::mul(prod, v);
+  }
+  fr_inverse_ni(&prod);
+  size_t cnt = (n - t + T - 1) / T;
+  for (size_t k = cnt; k-- > 0;) {
+    size_t i = t + k * T;
+    Fr v = load_fp<Fr>(data + i * 32);
+    if (v.is_zero_raw()) continue;                            // batch_inversion leaves zeros in place
+    Fr pre = load_fp<Fr>(prefix + i * 32);
+    Fr inv = Fr::mul(prod, pre);
+    prod = Fr::mul(prod, v);
+    store_fp<Fr>(data + i * 32, Fr::reduce(inv));
+  }
+}
+
+int32_t fr_vec_op(Ctx* c, void* d_dst, const void* d_a, const void* d_b, size_t n, int32_t op, hipStream_t s) {
+  (void)c;
+  if (n == 0) return ALEO_MI355X_OK;
+  size_t want = (n + 255) / 256; uint32_t grid = (uint32_t)(want < 8192 ? want : 8192);
+  switch (op) {
+    case 0: hipLaunchKernelGGL(k_fr_vec_op<0>, dim3(grid), dim3(256), 0, s, (char*)d_dst, (const char*)d_a, (const char*)d_b, n); break;
+    case 1: hipLaunchKernelGGL(k_fr_vec_op<1>, dim3(grid), dim3(256), 0, s, (char*)d_dst, (const char*)d_a, (const char*)d_b, n); break;
+    case 2: hipLaunchKernelGGL(k_fr_vec_op<2>, dim3(grid), dim3(256), 0, s, (char*)d_dst, (const char*)d_a, (const char*)d_b, n); break;
+    default: g_last_error = "fr_vec_op: unknown op"; return ALEO_MI355X_ERR_BAD_ARG;
+  }
+  HIPCHK(hipGetLastError());
+  return ALEO_MI355X_OK;
+}
+
+int32_t fr_batch_inverse(Ctx* c, void* d_inout, size_t n, hipStream_t s) {
+  if (n == 0) return ALEO_MI355X_OK;
+  int32_t rc; if ((rc = c->ntt_tmp.reserve(n * 32))) return rc;
+  // ~64 elements per lane keeps the shared inversion at ~6 products per element; small inputs use fewer per lane
+  size_t T = (n + 63) / 64; if (T < 4096) T = n < 4096 ? n : 4096;
+  hipLaunchKernelGGL(k_fr_batch_inverse, dim3((uint32_t)((T + 255) / 256)), dim3(256), 0, s, (char*)d_inout, c->ntt_tmp.as<char>(), n, T);
+  HIPCHK(hipGetLastError());
+  return ALEO_MI355X_OK;
+}
+
+}  // namespace aleo_mi355x

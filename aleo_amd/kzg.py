@@ -29,3 +29,13 @@ class KZG10:
         check(lib().aleo_mi355x_kzg_commit_device(_p(out), powers.handle, ctypes.c_void_p(d_coeffs_ptr), n,
                                                   ctypes.c_void_p(stream)), 'kzg_commit_device')
         return out
+
+    @staticmethod
+    def commit_hiding(powers: PinnedBases, coeffs_mont: np.ndarray, gamma_powers: PinnedBases, blinding_mont: np.ndarray) -> np.ndarray:
+        """KZG10::commit with hiding_bound: adds msm(powers_of_beta_times_gamma_g, random polynomial)."""
+        c = np.ascontiguousarray(coeffs_mont, dtype=np.uint64).reshape(-1, 4)
+        b = np.ascontiguousarray(blinding_mont, dtype=np.uint64).reshape(-1, 4)
+        out = np.zeros(104, dtype=np.uint8)
+        check(lib().aleo_mi355x_kzg_commit_hiding(_p(out), powers.handle, _p(c), c.shape[0], gamma_powers.handle, _p(b), b.shape[0]),
+              'kzg_commit_hiding')
+        return out

@@ -1,0 +1,16 @@
+"""Host-side mirror of the field-only vector work between NTTs (snarkVM 0.14.5 Evaluations::{mul,add,sub}_assign and
+snarkvm_fields::batch_inversion [UPSTREAM-RECALL]) on device-resident Montgomery Fr vectors (torch tensors or raw pointers)."""
+from __future__ import annotations
+import ctypes
+from ._lib import lib, check
+
+OP_MUL, OP_ADD, OP_SUB = 0, 1, 2
+
+
+def fr_vec_op_device(d_dst: int, d_a: int, d_b: int, n: int, op: int, stream: int = 0):
+    check(lib().aleo_mi355x_fr_vec_op_device(ctypes.c_void_p(d_dst), ctypes.c_void_p(d_a), ctypes.c_void_p(d_b), n, op,
+                                             ctypes.c_void_p(stream)), 'fr_vec_op_device')
+
+
+def batch_inversion_device(d_inout: int, n: int, stream: int = 0):
+    check(lib().aleo_mi355x_fr_batch_inverse_device(ctypes.c_void_p(d_inout), n, ctypes.c_void_p(stream)), 'fr_batch_inverse_device')

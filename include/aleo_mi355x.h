@@ -102,6 +102,20 @@ int32_t aleo_mi355x_kzg_commit(void* out_affine104, uint64_t handle, const void*
 /* Device-resident coefficients (e.g. straight out of aleo_mi355x_ntt_fr_device: no host round trip). */
 int32_t aleo_mi355x_kzg_commit_device(void* out_affine104, uint64_t handle, const void* d_coeffs_mont, size_t n, void* stream);
 
+/* KZG10::commit with a hiding bound: msm(powers, coeffs) + msm(gamma_powers, blinding_coeffs), affine result.
+ * Both coefficient vectors are Montgomery Fr on the host; both base sets are pinned handles. */
+int32_t aleo_mi355x_kzg_commit_hiding(void* out_affine104, uint64_t h_powers, const void* coeffs_mont, size_t n,
+                                      uint64_t h_gamma_powers, const void* blinding_mont, size_t m);
+
+/* Field-only vector kernels on device-resident Montgomery Fr data (the pointwise work between
+ * NTTs in Varuna's rounds — Evaluations::{mul,add,sub}_assign, snarkvm_fields::batch_inversion).
+ * op: 0 = a*b, 1 = a+b, 2 = a-b; dst may alias a or b; outputs canonical.  batch_inverse leaves zeros in place. */
+#define ALEO_FR_OP_MUL 0
+#define ALEO_FR_OP_ADD 1
+#define ALEO_FR_OP_SUB 2
+int32_t aleo_mi355x_fr_vec_op_device(void* d_dst, const void* d_a, const void* d_b, size_t n, int32_t op, void* stream);
+int32_t aleo_mi355x_fr_batch_inverse_device(void* d_inout, size_t n, void* stream);
+
 /* Element-wise field products on the device (host pointers): r[i] = a[i]*b[i], Montgomery form, canonical
  * output.  Used by the parity tests to pin the device arithmetic against the oracle limb for limb. */
 int32_t aleo_mi355x_fq_mul(void* r, const void* a, const void* b, size_t n);

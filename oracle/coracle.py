@@ -36,6 +36,8 @@ def lib():
             getattr(L, f).argtypes = [vp, vp, vp, sz]; getattr(L, f).restype = None
         L.oracle_ntt_fr.argtypes = [vp, cu, ci, ci, ci]; L.oracle_ntt_fr.restype = ci
         L.oracle_kzg_commit.argtypes = [vp, vp, vp, sz, ci]; L.oracle_kzg_commit.restype = ci
+        L.oracle_fr_batch_inverse.argtypes = [vp, sz]; L.oracle_fr_batch_inverse.restype = None
+        L.oracle_fr_vec_op.argtypes = [vp, vp, vp, sz, ci]; L.oracle_fr_vec_op.restype = None
         _LIB = L
     return _LIB
 
@@ -137,3 +139,12 @@ def kzg_commit(bases104, coeffs_mont, threads=1) -> np.ndarray:
     b = np.ascontiguousarray(bases104, dtype=np.uint8); c = np.ascontiguousarray(coeffs_mont, dtype=np.uint64)
     rc = lib().oracle_kzg_commit(_p(out), _p(b), _p(c), c.shape[0], threads); assert rc == 0
     return out
+
+
+def fr_batch_inverse(a) -> np.ndarray:
+    a = np.ascontiguousarray(a, dtype=np.uint64).copy(); lib().oracle_fr_batch_inverse(_p(a), a.shape[0]); return a
+
+
+def fr_vec_op(a, b, op: int) -> np.ndarray:
+    a = np.ascontiguousarray(a, dtype=np.uint64); b = np.ascontiguousarray(b, dtype=np.uint64)
+    r = np.zeros_like(a); lib().oracle_fr_vec_op(_p(r), _p(a), _p(b), a.shape[0], op); return r

@@ -464,3 +464,17 @@ int oracle_kzg_commit(void* out104, const void* bases104, const void* coeffs_mon
   free(c); if (rc) return rc;
   oracle_g1_to_affine(out104, &t); return 0;
 }
+
+/* snarkvm_fields::batch_inversion semantics (fields/src/lib.rs [UPSTREAM-RECALL]): every non-zero element is replaced
+ * by its inverse, zeros stay zero.  Element-wise add/sub/mul of Montgomery Fr vectors (Evaluations::*_assign). */
+void oracle_fr_batch_inverse(void* io, size_t n) {
+  Fr* p = (Fr*)io;
+  for (size_t i = 0; i < n; ++i) if (!Fr_is_zero(&p[i])) Fr_inv(&p[i], &p[i]);
+}
+void oracle_fr_vec_op(void* r, const void* a, const void* b, size_t n, int op) {
+  for (size_t i = 0; i < n; ++i) {
+    if (op == 0) Fr_mul((Fr*)r + i, (const Fr*)a + i, (const Fr*)b + i);
+    else if (op == 1) Fr_add((Fr*)r + i, (const Fr*)a + i, (const Fr*)b + i);
+    else Fr_sub((Fr*)r + i, (const Fr*)a + i, (const Fr*)b + i);
+  }
+}

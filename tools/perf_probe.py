@@ -39,3 +39,19 @@ if what in ('all', 'msm'):
             avg = {k: float(np.mean([t[k] for t in tms])) for k in tms[0]}
             print(json.dumps({'msm_lg': lg, 'scalars': kind, 'wall_ms': dt * 1e3, 'Mpts_s': n / dt / 1e6, **avg}), flush=True)
         pb.close()
+if what in ('all', 'frops'):
+    from aleo_amd import poly
+    for lg in (22, 24):
+        n = 1 << lg
+        a = torch.from_numpy(synth.uniform_scalars(n, 1).view(np.int64)).to(dev); b = torch.from_numpy(synth.uniform_scalars(n, 2).view(np.int64)).to(dev)
+        d = torch.empty_like(a); torch.cuda.synchronize()
+        for name, fn, bytes_per in (('mul', lambda: poly.fr_vec_op_device(d.data_ptr(), a.data_ptr(), b.data_ptr(), n, 0, st), 96),
+                                    ('add', lambda: poly.fr_vec_op_device(d.data_ptr(), a.data_ptr(), b.data_ptr(), n, 1, st), 96),
+                                    ('batch_inverse', lambda: poly.batch_inversion_device(d.data_ptr(), n, st), 64)):
+            fn(); torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(True), torch.cuda.Event(True)
+            e0.record()
+            for _ in range(10): fn()
+            e1.record(); torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / 10
+            print(json.dumps({'frop': name, 'lg': lg, 'ms': ms, 'GBps_alg': bytes_per * n / ms / 1e6, 'frac_hbm': bytes_per * n / ms / 1e6 / 8000}), flush=True)
