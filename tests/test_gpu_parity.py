@@ -326,3 +326,29 @@ def test_kzg_commit_hiding_matches_oracle():
         a = c.affine_to_ints(c.kzg_commit(powers.download(), coeffs, threads=4))[0]
         b = c.affine_to_ints(c.kzg_commit(gamma.download(), blind, threads=1))[0]
         assert got == p.g1_add(a, b)
+
+
+def test_concurrent_callers_share_the_device_safely():
+    """snarkVM commits the polynomials of one round from a rayon pool: many host threads call the library at once
+    (ctypes releases the GIL).  Results must match the serial ones."""
+    import threading
+    n = 20000
+    B = util.multiples_bases(n)
+    jobs = [(util.uniform_scalars(n - 100 * t, 5000 + t), n - 100 * t) for t in range(6)]
+    exp = [util.expected_multiples_msm(s, m) for s, m in jobs]
+    got = [None] * len(jobs); errs = []
+
+    def work(i):
+        try:
+            s, m = jobs[i]
+            for _ in range(3):
+                got[i] = c.jac_to_int_point(M.VariableBase.msm(B[:m], s))
+            x = c.fr_to_mont(util.uniform_scalars(1 << 12, 6000 + i))
+            assert (aleo_amd.EvaluationDomain(1 << 12).fft(x) == c.ntt_fr(x, 0, 0, 0)).all()
+        except Exception as e:      # noqa: BLE001
+            errs.append(e)
+    ths = [threading.Thread(target=work, args=(i,)) for i in range(len(jobs))]
+    for t in ths: t.start()
+    for t in ths: t.join()
+    assert not errs, errs
+    assert got == exp
