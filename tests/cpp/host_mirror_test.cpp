@@ -1,0 +1,83 @@
+// C++ host-mirror test (built and run by tests/test_gpu_parity.py::test_cpp_host_mirror on the GPU box; only compiled
+// and linked by the CPU tier).  Checks the drop-in boundary the way a snarkVM unit test would: VariableBase::msm against
+// the structured identity sum_i s_i*(i+1)G == (sum_i s_i*(i+1))G, the one-shot call against the pinned call, and
+// EvaluationDomain round trips / zero padding.  Exit code 0 = all checks passed.
+#include <cstdio>
+#include <cstring>
+#include <vector>
+#include "aleo_mi355x.hpp"
+using namespace aleo_mi355x;
+
+typedef unsigned __int128 u128;
+static const uint64_t R_MOD[4] = {0x0a11800000000001ULL, 0x59aa76fed0000001ULL, 0x60b44d1e5c37b001ULL, 0x12ab655e9a2ca556ULL};
+
+static uint64_t sm_state;
+static uint64_t splitmix() { sm_state += 0x9E3779B97F4A7C15ULL; uint64_t z = sm_state; z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL; z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL; return z ^ (z >> 31); }
+static bool lt_r(const uint64_t* a) { for (int i = 3; i >= 0; --i) { if (a[i] < R_MOD[i]) return true; if (a[i] > R_MOD[i]) return false; } return false; }
+static BigInteger256 rand_scalar() { BigInteger256 s; do { for (auto& l : s.l) l = splitmix(); s.l[3] &= (1ULL << 61) - 1; } while (!lt_r(s.l)); return s; }
+
+// (acc + s * w) mod r with w < 2^32, all 256-bit: schoolbook then conditional subtractions (test helper)
+static void mac_mod_r(uint64_t acc[4], const uint64_t s[4], uint64_t w) {
+  uint64_t t[5] = {0, 0, 0, 0, 0}; u128 c = 0;
+  for (int i = 0; i < 4; ++i) { c += (u128)s[i] * w + acc[i]; t[i] = (uint64_t)c; c >>= 64; }
+  t[4] = (uint64_t)c;
+  // reduce t (< 2^32 * r + r) by subtracting r << k for k = 40..0 (binary long division by comparison)
+  for (int k = 40; k >= 0; --k) {
+    uint64_t m[5] = {0, 0, 0, 0, 0};
+    int limb = k / 64, sh = k % 64;
+    for (int i = 0; i < 4; ++i) { m[i + limb] |= R_MOD[i] << sh; if (sh && i + limb + 1 < 5) m[i + limb + 1] |= R_MOD[i] >> (64 - sh); }
+    bool ge = true; for (int i = 4; i >= 0; --i) { if (t[i] > m[i]) break; if (t[i] < m[i]) { ge = false; break; } }
+    if (ge) { uint64_t br = 0; for (int i = 0; i < 5; ++i) { u128 d = (u128)t[i] - m[i] - br; t[i] = (uint64_t)d; br = (uint64_t)(d >> 64) & 1; } }
+  }
+  memcpy(acc, t, 32);
+}
+
+#define CHECK(cond, what) do { if (!(cond)) { printf("FAIL: %s\n", what); return 1; } else printf("ok: %s\n", what); } while (0)
+
+int main() {
+  if (aleo_mi355x_init(-1) != 0) { printf("FAIL: init: %s\n", aleo_mi355x_last_error()); return 2; }
+  // G1 generator in Montgomery form (curves/src/bls12_377/g1.rs)
+  G1Affine g{}; const uint64_t gx[6] = {0x1042a645ec301b95ULL, 0x5a990780c1060f28ULL, 0x684a8ab3a9007a5bULL, 0x1c35a184257ba63fULL, 0xb2b2abd2fea8e32eULL, 0x017df3a223fb2017ULL};
+  const uint64_t gy[6] = {0xbc5a1ae8e2801ab9ULL, 0xd4f3c861cbfe13b0ULL, 0xecdd5ffc4e949f13ULL, 0x8f87199b7503667dULL, 0x0f0b1b837dc4fe1cULL, 0x004bcc7e053eaabeULL};
+  memcpy(g.x, gx, 48); memcpy(g.y, gy, 48);
+  const size_t n = 5000;
+  auto pinned = PinnedBases::generate_multiples(g, 1, n);
+  CHECK(pinned.is_ok(), "bases_generate");
+  std::vector<G1Affine> bases(n);
+  CHECK(aleo_mi355x_bases_download(pinned.value->handle(), 0, n, bases.data()) == 0, "bases_download");
+  CHECK(memcmp(bases[0].x, gx, 48) == 0 && memcmp(bases[0].y, gy, 48) == 0, "first generated base is the generator (Montgomery constants agree)");
+  sm_state = 0xA1E00002; std::vector<BigInteger256> s(n + 7);
+  uint64_t k[4] = {0, 0, 0, 0};
+  for (size_t i = 0; i < n + 7; ++i) { s[i] = rand_scalar(); if (i < n) mac_mod_r(k, s[i].l, i + 1); }
+  auto a = VariableBase::msm(bases.data(), n, s.data(), n + 7);          // zips to the shorter slice
+  auto b = VariableBase::msm(*pinned.value, s.data(), n);
+  CHECK(a.is_ok() && b.is_ok(), "VariableBase::msm returns Ok");
+  CHECK(memcmp(&*a.value, &*b.value, sizeof(G1Projective)) == 0, "one-shot msm == pinned msm");
+  BigInteger256 kk; memcpy(kk.l, k, 32);
+  auto kg = VariableBase::msm(&g, 1, &kk, 1);
+  CHECK(kg.is_ok() && memcmp(&*a.value, &*kg.value, sizeof(G1Projective)) == 0, "sum_i s_i*(i+1)G == (sum_i s_i*(i+1) mod r)G");
+  std::vector<BigInteger256> zeros(n, BigInteger256{{0, 0, 0, 0}});
+  auto z = VariableBase::msm(bases.data(), n, zeros.data(), n);
+  CHECK(z.is_ok() && z.value->is_zero(), "all-zero scalars give the identity");
+  auto empty = VariableBase::msm(bases.data(), 0, s.data(), 0);
+  CHECK(empty.is_ok() && empty.value->is_zero(), "empty msm is the identity");
+  auto bad = VariableBase::msm(PinnedBases(), s.data(), 1);
+  CHECK(!bad.is_ok() && bad.error.code == ALEO_MI355X_ERR_BAD_HANDLE, "an unknown handle is an Err (caller falls back to the CPU)");
+
+  auto dom = EvaluationDomain::new_(1000);
+  CHECK(dom && dom->size == 1024 && dom->log_size_of_group == 10, "EvaluationDomain::new(1000) -> size 1024");
+  CHECK(!EvaluationDomain::new_((size_t)1 << 48).has_value(), "EvaluationDomain::new beyond the two-adicity is None");
+  std::vector<Fr> x(1000); for (auto& e : x) { BigInteger256 v = rand_scalar(); memcpy(e.l, v.l, 32); }   // any canonical value is a valid Montgomery residue
+  std::vector<Fr> y = x;
+  CHECK(dom->fft_in_place(y).is_ok() && y.size() == 1024, "fft_in_place pads to the domain");
+  CHECK(dom->ifft_in_place(y).is_ok(), "ifft_in_place");
+  bool same = true; for (size_t i = 0; i < 1024; ++i) { Fr e = i < 1000 ? x[i] : Fr{{0, 0, 0, 0}}; same &= memcmp(&e, &y[i], 32) == 0; }
+  CHECK(same, "ifft(fft(x)) == x (zero padded)");
+  y = x; CHECK(dom->coset_fft_in_place(y).is_ok() && dom->coset_ifft_in_place(y).is_ok(), "coset round trip runs");
+  same = true; for (size_t i = 0; i < 1000; ++i) same &= memcmp(&x[i], &y[i], 32) == 0;
+  CHECK(same, "coset_ifft(coset_fft(x)) == x");
+  std::vector<Fr> too_long(2000);
+  CHECK(!dom->fft_in_place(too_long).is_ok(), "more coefficients than the domain is an Err");
+  printf("ALL OK\n");
+  return 0;
+}

@@ -69,3 +69,21 @@ def test_evaluation_domain_host_logic():
     assert d.size == 8 and d.log_size_of_group == 3
     assert aleo_amd.EvaluationDomain(1).size == 1
     assert aleo_amd.EvaluationDomain.new(1 << 48) is None          # beyond the two-adicity of Fr: reference returns None
+
+
+def build_cpp_host_mirror(tmpdir):
+    """g++ the C++ host-mirror test against the in-tree library; returns the binary path."""
+    import subprocess
+    exe = os.path.join(str(tmpdir), 'host_mirror_test')
+    libdir = os.path.join(ROOT, 'aleo_amd', 'lib')
+    subprocess.check_call(['g++', '-std=c++17', '-O2', '-I', os.path.join(ROOT, 'include'),
+                           os.path.join(ROOT, 'tests', 'cpp', 'host_mirror_test.cpp'), '-o', exe,
+                           '-L', libdir, '-laleo_mi355x', '-Wl,-rpath,' + libdir])
+    return exe
+
+
+def test_cpp_host_mirror_compiles_and_links(tmp_path):
+    """include/aleo_mi355x.hpp (the C++ mirror of VariableBase / EvaluationDomain) builds and links against the C ABI;
+    the program itself needs a GPU and is run by tests/test_gpu_parity.py::test_cpp_host_mirror."""
+    exe = build_cpp_host_mirror(tmp_path)
+    assert os.path.exists(exe)

@@ -352,3 +352,12 @@ def test_concurrent_callers_share_the_device_safely():
     for t in ths: t.join()
     assert not errs, errs
     assert got == exp
+
+
+def test_cpp_host_mirror(tmp_path):
+    """The C++ host side above the C ABI (include/aleo_mi355x.hpp), exercised like a snarkVM unit test."""
+    import subprocess
+    from test_abi import build_cpp_host_mirror
+    exe = build_cpp_host_mirror(tmp_path)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and 'ALL OK' in r.stdout, r.stdout + r.stderr
