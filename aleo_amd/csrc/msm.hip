@@ -5,17 +5,19 @@
 // /root/reference/rust/src/program/execute.rs:74,177 and transfer.rs:99 through Varuna's KZG commitments.
 // Same mathematical function (sum_i s_i * P_i); the schedule is GPU-first, not a translation:
 //
-//   digits    signed c-bit windows (c <= 16): |d| <= 2^(c-1), so half the buckets of the reference's unsigned
-//             windows; W = ceil(254/c) windows cover the 253-bit scalar plus the recoding carry.
-//   sort      counting sort of the n*W (bucket, point) pairs: histogram -> exclusive scan -> scatter.  The
+//   digits    signed c-bit windows: |d| <= 2^(c-1), so half the buckets of the reference's unsigned windows.  Plain
+//             schedule: c <= 16, W = ceil(254/c) windows with their own buckets.  Fixed-base schedule (pinned SRS with
+//             msm_precompute's table of 2^(20w) * P_i): c = 20, 13 windows that all feed ONE set of 2^19 buckets.
+//   sort      counting sort of the n*W (bucket, point) pairs in two LDS-partitioned levels, no global atomics.  The
 //             sorted stream holds 4-byte point indices (bit 31 = negate), so a bucket is a contiguous run.
-//   tasks     every bucket run is cut into slices of <= T0 points; one lane accumulates one slice with XYZZ
-//             mixed additions (ec.h), reading 96-byte affine points straight from the HBM-resident base table.
-//             Heavy buckets (skewed witnesses: 0/1-valued scalars) become many slices instead of one long lane.
-//   tree      slices of one bucket are folded pairwise, log2(#slices) short launches.
-//   reduce    per window sum_b (b+1) * S_b by chunked running sums + a pairwise tree.
-//   tail      the W window sums go to the host, which runs the 2^c Horner chain (host_field.hpp) and
-//             normalises to affine: ~250 dependent doublings are ~0.1 ms on a host core, ~4 ms on one GPU lane.
+//   slices    bucket runs are cut into slices (pick_rule: whole buckets up to 2x the mean size, longer ones split at the
+//             mean), counting-sorted by length so the lanes of a wave run equal trip counts; one lane accumulates one
+//             slice with XYZZ mixed additions (ec.h), reading 96-byte affine points straight from HBM.
+//   tree      slices of multi-slice buckets are folded pairwise (short launches over the listed buckets only).
+//   reduce    sum_b (b+1) * S_b: 8-bucket running sums, then either a double-and-add of the chunk base + pairwise tree
+//             (plain) or 16 masked pairwise sums folded through LDS blocks (fixed-base).
+//   tail      plain: the W window sums go to the host for the 2^c Horner chain (~250 dependent doublings are ~0.1 ms on
+//             a host core, ~4 ms on one GPU lane); fixed-base: a 20-point Horner.  Then affine normalisation.
 //
 // HBM layout: bases n x 96 B (x|y Montgomery, AoS so a gathered point is 1-2 cache lines); sorted stream
 // n*W x 4 B; partial sums #slices x 192 B (XYZZ).  Algorithmic bytes per point: 32 (scalar) + 96 (base).
@@ -28,20 +30,19 @@ namespace aleo_mi355x {
 static constexpr uint32_t SCAN_TILE = 2048;     // elements per scan block (256 threads x 8)
 static constexpr uint32_t SCALAR_BITS = 254;    // 253-bit scalars + 1 bit of signed-digit carry
 
-struct MsmPlan { uint32_t c, W, B, M, T0, S; };
+struct MsmPlan { uint32_t c, W, B, M, S; };
 
 static constexpr int PRE_C = 20;      // window width of the fixed-base table: W = 13 windows share 2^19 buckets
 
 static MsmPlan make_plan(size_t n, bool pre) {
   MsmPlan p;
   if (pre) {   // one shared bucket set: "W = 1 window of 2^19 buckets" for everything after the sort
-    p.c = PRE_C; p.W = 1; p.B = 1u << (PRE_C - 1); p.M = p.B; p.T0 = 0; p.S = 8;
+    p.c = PRE_C; p.W = 1; p.B = 1u << (PRE_C - 1); p.M = p.B; p.S = 8;
     return p;
   }
   uint32_t lg = 0; while (((size_t)1 << (lg + 1)) <= n) ++lg;
   int c = (int)lg - 4; if (c < 2) c = 2; if (c > 16) c = 16;
   p.c = (uint32_t)c; p.W = (SCALAR_BITS + p.c - 1) / p.c; p.B = 1u << (p.c - 1); p.M = p.W * p.B;
-  p.T0 = 0;                                  // chosen on the device: pick_t0()
   p.S = p.B >= 8 ? 8 : p.B;                  // buckets per running-sum chunk
   return p;
 }
@@ -239,14 +240,14 @@ __global__ void __launch_bounds__(256) k_scan_tiles(const uint32_t* hist, uint32
                                                     uint32_t* __restrict__ heavy) {
   __shared__ uint2 wsum[4];
   uint32_t base = blockIdx.x * SCAN_TILE + threadIdx.x * 8;
-  const SliceRule T0 = pick_rule(total_pairs, M);
+  const SliceRule rule = pick_rule(total_pairs, M);
   uint32_t c[8]; uint32_t mx = 0;
 #pragma unroll
   for (int k = 0; k < 8; ++k) c[k] = (base + k < M) ? hist[base + k] : 0u;
   uint2 pre[8]; uint2 run = make_uint2(0, 0);
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
-    pre[k] = run; uint32_t m = slices_of(c[k], T0); run.x += c[k]; run.y += m; mx = mx > m ? mx : m;
+    pre[k] = run; uint32_t m = slices_of(c[k], rule); run.x += c[k]; run.y += m; mx = mx > m ? mx : m;
     // multi-slice buckets are the only work of the slice tree; the few with > 16 slices (skewed scalars) get their own
     // list so that the launch width of the common list stays at 8 pairs per bucket
     if (m > 16) { uint32_t q = atomicAdd(&meta[5], 1u); if (q < SUPER_CAP) heavy[M + 2048 + q] = base + k; else heavy[atomicAdd(&meta[3], 1u)] = base + k; }
@@ -294,7 +295,6 @@ __global__ void __launch_bounds__(256) k_scan_top(const uint2* tile_tot, uint32_
   if (threadIdx.x == 0) { meta[0] = carry.y; meta[2] = carry.x; }
 }
 
-struct ScanView { const uint2* local; const uint2* blk; uint32_t M; uint32_t total_cnt; uint32_t total_slices; };
 __device__ __forceinline__ uint2 scan_at(const uint2* local, const uint2* blk, uint32_t g) {
   uint2 a = local[g], b = blk[g / SCAN_TILE]; return make_uint2(a.x + b.x, a.y + b.y);
 }
@@ -303,7 +303,7 @@ __device__ __forceinline__ uint2 scan_at(const uint2* local, const uint2* blk, u
 // Slices are at most 512 points long; bucket sizes are Poisson, so slice lengths vary 2:1 inside a wave if
 // taken in bucket order (measured: 31 % of the accumulation's lanes idle).  A counting sort by length (longest
 // first) costs two tiny launches: block-local LDS histograms + a handful of global atomics per block.
-static constexpr uint32_t MAX_T0 = 512;
+static constexpr uint32_t MAX_SLICE = 512;       // longest slice pick_rule() can produce
 __device__ __forceinline__ uint32_t slice_len(uint32_t cnt, uint32_t m, uint32_t k) {
   return (uint32_t)(((uint64_t)(k + 1) * cnt) / m) - (uint32_t)(((uint64_t)k * cnt) / m);
 }
@@ -312,8 +312,8 @@ __device__ __forceinline__ uint32_t slice_len(uint32_t cnt, uint32_t m, uint32_t
 __global__ void __launch_bounds__(256) k_slice_count(const uint32_t* __restrict__ hist, const uint2* __restrict__ scan_local, const uint2* __restrict__ scan_blk,
                                                      uint32_t M, const uint32_t* __restrict__ total_pairs, const uint32_t* __restrict__ meta, uint32_t* __restrict__ task_g,
                                                      uint32_t* __restrict__ len_count) {
-  __shared__ uint32_t h[MAX_T0 + 1];
-  for (uint32_t i = threadIdx.x; i <= MAX_T0; i += 256) h[i] = 0;
+  __shared__ uint32_t h[MAX_SLICE + 1];
+  for (uint32_t i = threadIdx.x; i <= MAX_SLICE; i += 256) h[i] = 0;
   __syncthreads();
   uint32_t t = blockIdx.x * 256 + threadIdx.x;
   if (t < meta[0]) {
@@ -327,25 +327,25 @@ __global__ void __launch_bounds__(256) k_slice_count(const uint32_t* __restrict_
     atomicAdd(&h[slice_len(cnt, m, k)], 1u);
   }
   __syncthreads();
-  for (uint32_t i = threadIdx.x; i <= MAX_T0; i += 256) if (h[i]) atomicAdd(&len_count[i], h[i]);
+  for (uint32_t i = threadIdx.x; i <= MAX_SLICE; i += 256) if (h[i]) atomicAdd(&len_count[i], h[i]);
 }
 
 // len_start[l] = number of slices longer than l (they come first); one block
 __global__ void __launch_bounds__(256) k_len_starts(const uint32_t* __restrict__ len_count, uint32_t* __restrict__ len_start) {
-  __shared__ uint32_t c[MAX_T0 + 2];
-  for (uint32_t i = threadIdx.x; i <= MAX_T0; i += 256) c[i] = len_count[i];
+  __shared__ uint32_t c[MAX_SLICE + 2];
+  for (uint32_t i = threadIdx.x; i <= MAX_SLICE; i += 256) c[i] = len_count[i];
   __syncthreads();
-  if (threadIdx.x == 0) { uint32_t run = 0; for (int l = (int)MAX_T0; l >= 0; --l) { uint32_t v = c[l]; c[l] = run; run += v; } }
+  if (threadIdx.x == 0) { uint32_t run = 0; for (int l = (int)MAX_SLICE; l >= 0; --l) { uint32_t v = c[l]; c[l] = run; run += v; } }
   __syncthreads();
-  for (uint32_t i = threadIdx.x; i <= MAX_T0; i += 256) len_start[i] = c[i];
+  for (uint32_t i = threadIdx.x; i <= MAX_SLICE; i += 256) len_start[i] = c[i];
 }
 
 // order[pos] = sid, longest slices first
 __global__ void __launch_bounds__(256) k_slice_order(const uint32_t* __restrict__ hist, const uint2* __restrict__ scan_local, const uint2* __restrict__ scan_blk,
                                                      const uint32_t* __restrict__ total_pairs, uint32_t M, const uint32_t* __restrict__ meta, const uint32_t* __restrict__ task_g,
                                                      const uint32_t* __restrict__ len_start, uint32_t* __restrict__ len_cursor, uint32_t* __restrict__ order) {
-  __shared__ uint32_t h[MAX_T0 + 1], base[MAX_T0 + 1];
-  for (uint32_t i = threadIdx.x; i <= MAX_T0; i += 256) h[i] = 0;
+  __shared__ uint32_t h[MAX_SLICE + 1], base[MAX_SLICE + 1];
+  for (uint32_t i = threadIdx.x; i <= MAX_SLICE; i += 256) h[i] = 0;
   __syncthreads();
   uint32_t t = blockIdx.x * 256 + threadIdx.x, len = 0, rank = 0;
   bool live = t < meta[0];
@@ -355,7 +355,7 @@ __global__ void __launch_bounds__(256) k_slice_order(const uint32_t* __restrict_
     rank = atomicAdd(&h[len], 1u);
   }
   __syncthreads();
-  for (uint32_t i = threadIdx.x; i <= MAX_T0; i += 256)
+  for (uint32_t i = threadIdx.x; i <= MAX_SLICE; i += 256)
     if (h[i]) base[i] = len_start[i] + atomicAdd(&len_cursor[i], h[i]);
   __syncthreads();
   if (live) order[base[len] + rank] = t;
@@ -560,7 +560,6 @@ template <bool MONT> static void launch_sort(int c, const SortArgs& a, int phase
   }
 }
 
-static inline uint32_t ceil_log2(uint32_t v) { uint32_t l = 0; while ((1u << l) < v) ++l; return l; }
 
 int32_t msm_run(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, const void* d_scalars, size_t n, bool scalars_are_mont, hipStream_t s) {
   using namespace host;
@@ -573,7 +572,8 @@ int32_t msm_run(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, const void* 
   const uint32_t digitsW = pre ? (SCALAR_BITS + PRE_C - 1) / PRE_C : P.W;
   const uint32_t M = P.M, ntiles = (M + SCAN_TILE - 1) / SCAN_TILE;
   const size_t pairs_max = n * (size_t)digitsW;
-  const size_t slices_max = pairs_max / 32 + M + 1;          // worst case of pick_t0()
+  if (pairs_max >= (1ull << 32)) { g_last_error = "msm: n * windows exceeds 2^32 (shard the MSM across GPUs)"; return ALEO_MI355X_ERR_BAD_ARG; }
+  const size_t slices_max = pairs_max / 32 + M + 1;          // worst case of pick_rule(): splits are never shorter than 32
   int32_t rc;
   // hist | cursor | meta live in one zero-initialised allocation
   if ((rc = c->hist.reserve((2 * (size_t)M + 2048 + SUPER_CAP) * 4))) return rc;
@@ -628,7 +628,7 @@ int32_t msm_run(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, const void* 
   const bool super_overflow = h_meta[5] > SUPER_CAP;          // then the common list also holds very long buckets
   if (NT > slices_max) { g_last_error = "msm: internal slice count overflow"; return ALEO_MI355X_ERR_HIP; }
   if (NT) {
-    uint32_t* len_count = meta + 16; uint32_t* len_cursor = len_count + MAX_T0 + 1; uint32_t* len_start = len_cursor + MAX_T0 + 1;   // zeroed with hist/meta
+    uint32_t* len_count = meta + 16; uint32_t* len_cursor = len_count + MAX_SLICE + 1; uint32_t* len_start = len_cursor + MAX_SLICE + 1;   // zeroed with hist/meta
     hipLaunchKernelGGL(k_slice_count, dim3((NT + 255) / 256), dim3(256), 0, s, hist, scan_local, scan_blk, M, total_pairs, meta, task_g, len_count);
     hipLaunchKernelGGL(k_len_starts, dim3(1), dim3(256), 0, s, len_count, len_start);
     hipLaunchKernelGGL(k_slice_order, dim3((NT + 255) / 256), dim3(256), 0, s, hist, scan_local, scan_blk, total_pairs, M, meta, task_g, len_start, len_cursor, order);
