@@ -229,7 +229,7 @@ int32_t aleo_mi355x_msm_g1(void* out, const void* bases, size_t base_stride, con
       if (rc) return rc;
       e->last_use = ++c->srs_clock; e->hits++;
       PinnedBases& pb = c->bases[e->handle];
-      if (e->hits == 3 && e->n >= (1u << 17) && !pb.d_pre) (void)msm_precompute(c, &pb);     // third use: worth the one-off table
+      if (e->hits == 3 && e->n >= (1u << 14) && !pb.d_pre) (void)msm_precompute(c, &pb);     // third use: worth the one-off table
       return msm_host_scalars_locked(c, out, pb, scalars, n, false);
     }
     uint64_t h = 0; int32_t rc = pin_locked(c, bases, base_stride, n, &h);

@@ -41,7 +41,8 @@ struct DevBuf {
 struct PinnedBases {
   void* d_xy = nullptr;        // n x 96 bytes: x | y, Montgomery, canonical
   uint8_t* d_inf = nullptr;    // n bytes, nullptr when no base is the point at infinity
-  void* d_pre = nullptr;       // optional fixed-base table: W x n x 96 bytes, row w holds 2^(20 w) * P_i (msm_precompute)
+  void* d_pre = nullptr;       // optional fixed-base table: W x n x 96 bytes, row w holds 2^(pre_c w) * P_i (msm_precompute)
+  int pre_c = 0;               // window width the table was built for (16, 17 or 20 by pinned count)
   size_t n = 0;
 };
 

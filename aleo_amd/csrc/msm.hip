@@ -32,12 +32,17 @@ static constexpr uint32_t SCALAR_BITS = 254;    // 253-bit scalars + 1 bit of si
 
 struct MsmPlan { uint32_t c, W, B, M, S; };
 
-static constexpr int PRE_C = 20;      // window width of the fixed-base table: W = 13 windows share 2^19 buckets
+// Window width of the fixed-base table, by size of the pinned set: the bucket reduction is latency-bound and its work
+// grows with 2^(c-1), so small SRS (real Aleo circuits are 2^15..2^17) get narrower windows than the 2^20+ sets.
+//   c = 20: 13 rows, 2^19 shared buckets   c = 17: 15 rows, 2^16 buckets   c = 16: 16 rows, 2^15 buckets
+// (widths whose TOP window keeps >= 13 bits of the 253-bit scalar: c = 18 or 19 would leave it 1 or 6 bits, i.e. a
+// handful of buckets holding n/2 points each)
+static int pre_c_for(size_t pinned_n) { return pinned_n >= (1u << 19) ? 20 : (pinned_n >= (1u << 17) ? 17 : 16); }
 
-static MsmPlan make_plan(size_t n, bool pre) {
+static MsmPlan make_plan(size_t n, int pre_c) {
   MsmPlan p;
-  if (pre) {   // one shared bucket set: "W = 1 window of 2^19 buckets" for everything after the sort
-    p.c = PRE_C; p.W = 1; p.B = 1u << (PRE_C - 1); p.M = p.B; p.S = 8;
+  if (pre_c) {   // one shared bucket set: "W = 1 window of 2^(c-1) buckets" for everything after the sort
+    p.c = (uint32_t)pre_c; p.W = 1; p.B = 1u << (pre_c - 1); p.M = p.B; p.S = 8;
     return p;
   }
   uint32_t lg = 0; while (((size_t)1 << (lg + 1)) <= n) ++lg;
@@ -226,12 +231,15 @@ __global__ void __launch_bounds__(256) k_bin_sort(const uint2* __restrict__ item
 static constexpr uint32_t SUPER_CAP = 4096;    // buckets with > 16 slices kept in their own list
 struct SliceRule { uint32_t single, split; };
 __device__ __forceinline__ SliceRule pick_rule(const uint32_t* total_pairs, uint32_t M) {
-  // single = 2 x the mean bucket size rounded up to a power of two (32..512), split = single / 2: the longest slice
-  // then stays near half of (pairs / resident lanes) whatever n is; sparse inputs (mean < 16) use 32/32.
-  const uint32_t mean = *total_pairs / M;
-  SliceRule r; r.single = 32u;
-  while (r.single < 2u * mean && r.single < 512u) r.single <<= 1;
-  r.split = r.single > 32u ? r.single >> 1 : 32u;
+  // Two pulls.  Keep buckets whole where possible (every extra slice is a 14-product tree addition): single = 2 x the
+  // mean bucket size.  But fill the chip: the launch wants >= 2^18 slices (2 waves per SIMD), and a lane needs ~11 us per
+  // addition, so when there are few pairs (small n, sparse scalars) slices are cut down to pairs / 2^18 points even if
+  // that splits ordinary buckets.  Everything in powers of two, 16 <= single <= 512, split = single / 2.
+  const uint32_t pairs = *total_pairs, mean = pairs / M;
+  uint32_t by_mean = 32u; while (by_mean < 2u * mean && by_mean < 512u) by_mean <<= 1;
+  uint32_t fill = 8u; while (fill < (pairs >> 18) && fill < 256u) fill <<= 1;
+  SliceRule r; r.single = by_mean < 2u * fill ? by_mean : 2u * fill;
+  r.split = r.single >> 1;
   return r;
 }
 __device__ __forceinline__ uint32_t slices_of(uint32_t cnt, SliceRule r) { return cnt <= r.single ? (cnt ? 1u : 0u) : (cnt + r.split - 1) / r.split; }
@@ -551,12 +559,19 @@ template <int C, bool MONT, bool PRE> static void launch_sort_c(const SortArgs& 
   if (phase == 0) hipLaunchKernelGGL((k_part_count<C, MONT, PRE>), dim3(a.nblk), dim3(256), 0, s, a.scalars, a.inf, a.n, a.nblk, a.cnt);
   else hipLaunchKernelGGL((k_part_scatter<C, MONT, PRE>), dim3(a.nblk), dim3(256), 0, s, a.scalars, a.inf, a.n, a.nblk, a.row_stride, a.off_local, a.off_blk, a.items);
 }
-template <bool MONT> static void launch_sort(int c, const SortArgs& a, int phase, hipStream_t s) {
+template <bool MONT> static void launch_sort(int c, bool pre, const SortArgs& a, int phase, hipStream_t s) {
+  if (pre) {
+    switch (c) {
+      case 16: launch_sort_c<16, MONT, true>(a, phase, s); break;
+      case 17: launch_sort_c<17, MONT, true>(a, phase, s); break;
+      case 20: launch_sort_c<20, MONT, true>(a, phase, s); break;
+    }
+    return;
+  }
   switch (c) {
 #define CASE(C) case C: launch_sort_c<C, MONT, false>(a, phase, s); break;
     CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8) CASE(9) CASE(10) CASE(11) CASE(12) CASE(13) CASE(14) CASE(15) CASE(16)
 #undef CASE
-    case PRE_C: launch_sort_c<PRE_C, MONT, true>(a, phase, s); break;
   }
 }
 
@@ -565,15 +580,16 @@ int32_t msm_run(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, const void* 
   using namespace host;
   if (n == 0) { hstore_jacobian_normalized(out_jac18, HXYZZ::infinity()); return ALEO_MI355X_OK; }
   if (n > pb.n || n >= (1ull << 31)) { g_last_error = "msm: n exceeds the pinned base count (or 2^31)"; return ALEO_MI355X_ERR_BAD_ARG; }
-  // the fixed-base table serves any prefix of the pinned set (row stride = pinned count); below 2^17 points the plain
-  // path with its small bucket count is faster than reducing 2^19 mostly empty buckets
-  const bool pre = pb.d_pre != nullptr && n >= (1u << 17);
-  MsmPlan P = make_plan(n, pre);
-  const uint32_t digitsW = pre ? (SCALAR_BITS + PRE_C - 1) / PRE_C : P.W;
+  // the fixed-base table serves any prefix of the pinned set (row stride = pinned count) as long as the prefix still
+  // puts about one point into every bucket; shorter prefixes use the plain path with its small bucket count
+  const bool pre = pb.d_pre != nullptr && n >= ((size_t)1 << (pb.pre_c - 3));
+  MsmPlan P = make_plan(n, pre ? pb.pre_c : 0);
+  const uint32_t digitsW = pre ? (SCALAR_BITS + pb.pre_c - 1) / pb.pre_c : P.W;
   const uint32_t M = P.M, ntiles = (M + SCAN_TILE - 1) / SCAN_TILE;
   const size_t pairs_max = n * (size_t)digitsW;
   if (pairs_max >= (1ull << 32)) { g_last_error = "msm: n * windows exceeds 2^32 (shard the MSM across GPUs)"; return ALEO_MI355X_ERR_BAD_ARG; }
-  const size_t slices_max = pairs_max / 32 + M + 1;          // worst case of pick_rule(): splits are never shorter than 32
+  // pick_rule() keeps the slice count near 2^19..2^20 (+ one per bucket) until its 256-point cap takes over
+  const size_t slices_max = pairs_max / 128 + 2 * (size_t)M + (1u << 21);
   int32_t rc;
   // hist | cursor | meta live in one zero-initialised allocation
   if ((rc = c->hist.reserve((2 * (size_t)M + 2048 + SUPER_CAP) * 4))) return rc;
@@ -611,10 +627,10 @@ int32_t msm_run(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, const void* 
   uint32_t* cnt_tile_tot = sa.off_local + cnt_len; sa.off_blk = cnt_tile_tot + cnt_tiles;
   sa.items = c->part_items.as<uint2>();
   const uint32_t* total_pairs = sa.off_blk + cnt_tiles;          // grand total of the level-1 scan
-  if (scalars_are_mont) launch_sort<true>(P.c, sa, 0, s); else launch_sort<false>(P.c, sa, 0, s);
+  if (scalars_are_mont) launch_sort<true>(P.c, pre, sa, 0, s); else launch_sort<false>(P.c, pre, sa, 0, s);
   hipLaunchKernelGGL(k_scan32_tiles, dim3(cnt_tiles), dim3(256), 0, s, sa.cnt, (uint32_t)cnt_len, sa.off_local, cnt_tile_tot);
   hipLaunchKernelGGL(k_scan32_top, dim3(1), dim3(256), 0, s, cnt_tile_tot, cnt_tiles, sa.off_blk);
-  if (scalars_are_mont) launch_sort<true>(P.c, sa, 1, s); else launch_sort<false>(P.c, sa, 1, s);
+  if (scalars_are_mont) launch_sort<true>(P.c, pre, sa, 1, s); else launch_sort<false>(P.c, pre, sa, 1, s);
   hipLaunchKernelGGL(k_bin_sort, dim3(ncb), dim3(256), 0, s, sa.items, sa.off_local, sa.off_blk, nblk, ncb, cnt_tiles, LB, hist, sorted);
   hipLaunchKernelGGL(k_scan_tiles, dim3(ntiles), dim3(256), 0, s, hist, M, total_pairs, scan_local, tile_tot, meta, heavy);
   hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(256), 0, s, tile_tot, ntiles, scan_blk, meta);
@@ -795,9 +811,9 @@ int32_t generate_multiples(Ctx* c, const void* base104, uint64_t first, size_t n
   *out = pb; return ALEO_MI355X_OK;
 }
 
-// ---- fixed-base table: row w = 2^(PRE_C * w) * P_i  (setup, once per pinned base set) ---------------
-// With the table every window of a scalar feeds the same 2^19 buckets: 13 instead of 16 additions per point at
-// 2^20, one bucket reduction instead of 16, and no Horner tail.  Costs W x 96 bytes of HBM per point (there are
+// ---- fixed-base table: row w = 2^(c * w) * P_i  (setup, once per pinned base set) -------------------
+// With the table every window of a scalar feeds the same 2^(c-1) buckets (c = 20 at 2^20: 13 instead of 16 additions
+// per point), one bucket reduction instead of W, and no Horner tail.  Costs W x 96 bytes of HBM per point (there are
 // 288 GB) and ~250 doublings per point once, at pin time — the SRS of a proving key never changes.
 __global__ void __launch_bounds__(256) k_pre_init(const char* __restrict__ xy, uint32_t n, char* __restrict__ cur) {
   uint32_t i = blockIdx.x * 256 + threadIdx.x; if (i >= n) return;
@@ -815,7 +831,7 @@ __global__ void __launch_bounds__(256) k_pre_double(char* __restrict__ cur, uint
 
 int32_t msm_precompute(Ctx* c, PinnedBases* pb) {
   if (pb->d_pre || pb->n == 0) return ALEO_MI355X_OK;
-  const size_t n = pb->n; const uint32_t W = (SCALAR_BITS + PRE_C - 1) / PRE_C;
+  const size_t n = pb->n; const int pre_c = pre_c_for(n); const uint32_t W = (SCALAR_BITS + pre_c - 1) / pre_c;
   if (n * (size_t)W >= (1ull << 31)) { g_last_error = "bases_precompute: table index would exceed 31 bits"; return ALEO_MI355X_ERR_BAD_ARG; }
   void *d_tab = nullptr, *d_cur = nullptr, *d_prefix = nullptr;
   HIPCHK(hipMalloc(&d_tab, n * 96 * W));
@@ -825,13 +841,13 @@ int32_t msm_precompute(Ctx* c, PinnedBases* pb) {
   const uint32_t g = (uint32_t)((n + 255) / 256), lanes = (uint32_t)((n + GEN_K - 1) / GEN_K), gl = (lanes + 255) / 256;
   hipLaunchKernelGGL(k_pre_init, dim3(g), dim3(256), 0, s, (const char*)pb->d_xy, (uint32_t)n, (char*)d_cur);
   for (uint32_t w = 1; w < W; ++w) {
-    hipLaunchKernelGGL(k_pre_double, dim3(g), dim3(256), 0, s, (char*)d_cur, (uint32_t)n, PRE_C);
+    hipLaunchKernelGGL(k_pre_double, dim3(g), dim3(256), 0, s, (char*)d_cur, (uint32_t)n, pre_c);
     hipLaunchKernelGGL(k_gen_normalize, dim3(gl), dim3(256), 0, s, (char*)d_cur, (uint32_t)n, (char*)d_prefix, (char*)d_tab + (size_t)w * n * 96);
   }
   HIPCHK(hipStreamSynchronize(s));
   HIPCHK(hipGetLastError());
   (void)hipFree(d_cur); (void)hipFree(d_prefix);
-  pb->d_pre = d_tab;
+  pb->d_pre = d_tab; pb->pre_c = pre_c;
   return ALEO_MI355X_OK;
 }
 

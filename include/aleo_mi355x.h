@@ -76,9 +76,9 @@ int32_t aleo_mi355x_bases_unpin(uint64_t handle);
  * snarkVM Affine (104 bytes, host).  first_multiple >= 1 and first_multiple + n must stay below r. */
 int32_t aleo_mi355x_bases_generate(const void* base_affine104, uint64_t first_multiple, size_t n, uint64_t* handle);
 /* Optional fixed-base acceleration for a pinned set (an SRS never changes): builds the table of window multiples
- * 2^(20 w) * P_i, w < 13, in HBM (13 x 96 bytes per point).  Full-length MSMs over this handle then add 13 instead of
- * 16 points per scalar into one shared bucket set and skip the Horner tail; prefix MSMs (n < pinned count) keep using
- * the plain path.  Same results, bit for bit after normalisation. */
+ * 2^(c w) * P_i in HBM (c = 20 / 17 / 16 by pinned count: 13-16 x 96 bytes per point).  MSMs over this handle — any
+ * prefix that still fills the buckets — then add one table entry per window into ONE shared bucket set (13 instead of
+ * 16 additions per point at 2^20) and skip the Horner tail.  Same results, bit for bit after normalisation. */
 int32_t aleo_mi355x_bases_precompute(uint64_t handle);
 /* Copies pinned bases [offset, offset+n) back to the host as snarkVM Affine (stride 104). */
 int32_t aleo_mi355x_bases_download(uint64_t handle, size_t offset, size_t n, void* out_affine104);

@@ -248,7 +248,7 @@ def test_bad_arguments_are_rejected():
 
 def test_msm_fixed_base_table_path():
     """bases_precompute(): the 13-window fixed-base table must give the same group element as the plain path."""
-    for n in (1000, 1 << 16):
+    for n in (1000, 1 << 14, 1 << 16, 1 << 18):
         with M.PinnedBases.generate_multiples(synth.generator_affine104(), 1, n) as pb:
             S = util.uniform_scalars(n, 8800 + n); Wt = util.witness_like_scalars(n, 8900 + n)
             plain_u, plain_w = M.VariableBase.msm(pb, S), M.VariableBase.msm(pb, Wt)
