@@ -166,6 +166,77 @@ __device__ __forceinline__ void xyzz_add(XYZZ& acc, const XYZZ& b) {
 // Out-of-line copy for call sites off the hot path (keeps kernels with several additions at one inlined body).
 __device__ __noinline__ void xyzz_add_ni(XYZZ* a, const XYZZ* b) { XYZZ x = *a; const XYZZ y = *b; xyzz_add(x, y); *a = x; }
 
+// ---- lane-pair cooperative addition ---------------------------------------------------------------------------
+// A full XYZZ addition is 14 dependent-ish Fq products = ~15 us on one lane, and the phases after the bucket
+// accumulation (slice tree, chunk running sums, segment folds) are chains of them with little parallelism.  The 14
+// products pack perfectly into 7 levels x 2 lanes, so two adjacent lanes (2k, 2k+1) share one addition: same total
+// work, half the latency.  Both lanes execute the same instruction stream on operands chosen by lane parity; values
+// cross with one DPP/swizzle exchange per level (__shfl_xor 1).
+//     level   even lane (a)             odd lane (b)
+//       1     U1 = X1*ZZ2               U2 = X2*ZZ1
+//       2     S1 = Y1*ZZZ2              S2 = Y2*ZZZ1
+//       3     PP = P^2                  RR = R^2                 (P = U2-U1, R = S2-S1 on both)
+//       4     Z12 = ZZ1*ZZ2             ZZZ12 = ZZZ1*ZZZ2
+//       5     PPP = P*PP                Q = U1*PP
+//       6     ZZ3 = Z12*PP              SP = S1*PPP
+//       7     ZZZ3 = ZZZ12*PPP          Rt = R*(Q - X3)          (X3 = RR - PPP - 2Q on both)
+// a stores ZZ3, ZZZ3; b stores X3, Y3 = Rt - SP.  Operands come from memory (global or LDS, generic pointers) so each
+// lane loads exactly the coordinates its levels need.  out may alias pa or pb.  Both lanes must call it together.
+__device__ __forceinline__ Fq fq_xchg(const Fq& a) {
+  Fq r;
+#pragma unroll
+  for (int i = 0; i < Fq::N; ++i) r.v[i] = (uint32_t)__shfl_xor((int)a.v[i], 1);
+  return r;
+}
+__device__ __forceinline__ Fq fq_sel(bool take_b, const Fq& a, const Fq& b) {
+  Fq r;
+#pragma unroll
+  for (int i = 0; i < Fq::N; ++i) r.v[i] = take_b ? b.v[i] : a.v[i];
+  return r;
+}
+__device__ __noinline__ void xyzz_add_pair_rare(const char* pa, const char* pb, char* out) {   // P == +-Q: one lane, general code
+  XYZZ a = load_xyzz(pa), b = load_xyzz(pb);
+  xyzz_add(a, b);
+  store_xyzz(out, a);
+}
+__device__ __forceinline__ void xyzz_add_pair(const char* pa, const char* pb, char* out) {
+  const bool odd = threadIdx.x & 1;
+  const Fq zzA = load_fp<Fq>(pa + 96), zzB = load_fp<Fq>(pb + 96);
+  const bool infA = zzA.is_zero_raw(), infB = zzB.is_zero_raw();
+  if (infA || infB) {              // pair-uniform: both lanes see the same two points
+    const char* src = infB ? pa : pb;          // A + O = A ; O + B = B ; O + O = O (either)
+    if (src != out) {              // each lane copies half of the 192 bytes
+      const uint4* s4 = (const uint4*)(src + (odd ? 96 : 0)); uint4* d4 = (uint4*)(out + (odd ? 96 : 0));
+#pragma unroll
+      for (int i = 0; i < 6; ++i) d4[i] = s4[i];
+    }
+    return;
+  }
+  const char* own = odd ? pb : pa; const char* oth = odd ? pa : pb;
+  Fq u = Fq::mul(load_fp<Fq>(own), odd ? zzA : zzB);                          // a: U1   b: U2     (< 2q)
+  Fq s = Fq::mul(load_fp<Fq>(own + 48), load_fp<Fq>(oth + 144));               // a: S1   b: S2
+  Fq pu = fq_xchg(u), ps = fq_xchg(s);
+  Fq U1 = fq_sel(odd, u, pu), U2 = fq_sel(odd, pu, u), S1 = fq_sel(odd, s, ps), S2 = fq_sel(odd, ps, s);
+  Fq P = Fq::sub<2>(U2, U1), R = Fq::sub<2>(S2, S1);                            // < 4q
+  Fq t3 = Fq::sqr(fq_sel(odd, P, R));                                          // a: PP   b: RR
+  Fq t4 = Fq::mul(load_fp<Fq>(pa + (odd ? 144 : 96)), load_fp<Fq>(pb + (odd ? 144 : 96)));   // a: ZZ1*ZZ2   b: ZZZ1*ZZZ2
+  Fq pt3 = fq_xchg(t3);
+  Fq PP = fq_sel(odd, t3, pt3), RR = fq_sel(odd, pt3, t3);
+  Fq t5 = Fq::mul(fq_sel(odd, P, U1), PP);                                     // a: PPP  b: Q
+  Fq pt5 = fq_xchg(t5);
+  Fq PPP = fq_sel(odd, t5, pt5), Q = fq_sel(odd, pt5, t5);
+  Fq X3 = Fq::sub<4>(Fq::sub<2>(RR, PPP), Fq::dbl(Q));                          // < 8q
+  Fq t6 = Fq::mul(fq_sel(odd, t4, S1), fq_sel(odd, PP, PPP));                  // a: ZZ3  b: SP
+  Fq pt4 = fq_xchg(t4);                                                        // a receives ZZZ12
+  Fq t7 = Fq::mul(fq_sel(odd, pt4, R), fq_sel(odd, PPP, Fq::sub<8>(Q, X3)));   // a: ZZZ3 b: Rt
+  // same-x case (doubling / cancellation): ZZ3 == 0 mod q, seen by the even lane
+  int z = (!odd && t6.is_zero_mod_lt2p()) ? 1 : 0;
+  z = __shfl(z, (int)(threadIdx.x & 63u & ~1u));
+  if (__builtin_expect(z, 0)) { if (!odd) xyzz_add_pair_rare(pa, pb, out); return; }
+  if (odd) { store_fp<Fq>(out, X3); store_fp<Fq>(out + 48, Fq::sub<2>(t7, t6)); }
+  else { store_fp<Fq>(out + 96, t6); store_fp<Fq>(out + 144, t7); }
+}
+
 // Normalise the infinity encoding before a store: a lazily reduced ZZ that is 0 mod q becomes raw 0.
 __device__ __forceinline__ void xyzz_store_normalized(void* p, XYZZ a, bool inf) {
   if (inf) a = xyzz_infinity();

@@ -418,12 +418,27 @@ __global__ void __launch_bounds__(256) k_accum(const char* __restrict__ bases, c
   xyzz_store_normalized(partial + (size_t)sid * 192, acc, inf);
 }
 
+// Every kernel from here to the host tail is a chain of full XYZZ additions with little parallelism, so each addition
+// is shared by a lane pair (ec.h xyzz_add_pair: same work, half the latency).  "op" below = pair index = thread / 2.
+__device__ __forceinline__ void pair_fence() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void pair_copy(const char* src, char* dst) {      // 192 bytes, half per lane
+  const uint32_t o = (threadIdx.x & 1) ? 96 : 0;
+  const uint4* s4 = (const uint4*)(src + o); uint4* d4 = (uint4*)(dst + o);
+#pragma unroll
+  for (int i = 0; i < 6; ++i) d4[i] = s4[i];
+}
+__device__ __forceinline__ void pair_zero(char* dst) {
+  uint4* d4 = (uint4*)(dst + ((threadIdx.x & 1) ? 96 : 0));
+#pragma unroll
+  for (int i = 0; i < 6; ++i) d4[i] = make_uint4(0, 0, 0, 0);
+}
+
 // partial[ft + i] += partial[ft + i + half] inside every multi-slice bucket (listed in heavy[] by the scan)
 __global__ void __launch_bounds__(256) k_tree_pass(char* __restrict__ partial, const uint32_t* __restrict__ heavy, const uint2* __restrict__ scan_local,
                                                    const uint2* __restrict__ scan_blk, uint32_t M, const uint32_t* __restrict__ meta, uint32_t pass, uint32_t max_pairs,
                                                    uint32_t list_len) {
-  uint32_t t = blockIdx.x * 256 + threadIdx.x;
-  uint32_t h = t / max_pairs, i = t % max_pairs;
+  const uint32_t op = (blockIdx.x * 256 + threadIdx.x) >> 1;
+  uint32_t h = op / max_pairs, i = op % max_pairs;
   if (h >= list_len) return;
   uint32_t g = heavy[h];
   uint32_t ft = scan_at(scan_local, scan_blk, g).y;
@@ -434,23 +449,42 @@ __global__ void __launch_bounds__(256) k_tree_pass(char* __restrict__ partial, c
   uint32_t half = (L + 1) >> 1;
   if (i >= L - half) return;
   char* pa = partial + (size_t)(ft + i) * 192;
-  XYZZ a = load_xyzz(pa), b = load_xyzz(pa + (size_t)half * 192);
-  xyzz_add(a, b);
-  store_xyzz(pa, a);
+  xyzz_add_pair(pa, pa + (size_t)half * 192, pa);
 }
 
 // ---- bucket reduction -----------------------------------------------------------------------------
-// One lane per chunk of S consecutive buckets of one window: V = sum_{b in chunk} (b+1) * S_b, computed as a
-// running sum inside the chunk plus (chunk_base) * (chunk total) by double-and-add.  One xyzz_add call site.
+// One lane PAIR per chunk of S consecutive buckets of one window: running sums run += S_b, acc += run (b descending)
+// kept in LDS between the cooperative additions, so acc = sum_{b in chunk} (b - base + 1) * S_b and run = chunk total.
+// Both go to HBM (V, Vrun); the chunk weights are applied by masked sums (fixed-base path).
+static constexpr uint32_t CHUNK_PAIRS = 128;        // chunks per 256-thread block
 __global__ void __launch_bounds__(256) k_bucket_chunks(const char* __restrict__ partial, const uint32_t* __restrict__ hist, const uint2* __restrict__ scan_local,
                                                        const uint2* __restrict__ scan_blk, uint32_t B, uint32_t S, uint32_t nchunks_total, char* __restrict__ V,
                                                        char* __restrict__ Vrun) {
+  __shared__ __attribute__((aligned(16))) uint32_t lds[2 * CHUNK_PAIRS * 48];
+  const uint32_t pr = threadIdx.x >> 1, t = blockIdx.x * CHUNK_PAIRS + pr;
+  if (t >= nchunks_total) return;
+  char* run = (char*)(lds + pr * 48); char* acc = (char*)(lds + (CHUNK_PAIRS + pr) * 48);
+  pair_zero(run); pair_zero(acc);
+  pair_fence();
+  const uint32_t cpw = B / S, w = t / cpw, j = t % cpw, g0 = w * B + j * S;
+  for (uint32_t k = 0; k < S; ++k) {
+    const uint32_t g = g0 + (S - 1 - k);
+    if (hist[g]) { xyzz_add_pair(run, partial + (size_t)scan_at(scan_local, scan_blk, g).y * 192, run); pair_fence(); }
+    xyzz_add_pair(acc, run, acc); pair_fence();
+  }
+  pair_copy(run, Vrun + (size_t)t * 192); pair_copy(acc, V + (size_t)t * 192);
+}
+
+// Plain path (one window set per window): one lane per chunk, V = sum_{b in chunk} (b+1) * S_b with the chunk base applied
+// by double-and-add.  (The pair form loses here: the double-and-add tail is most of the chain and would idle odd lanes.)
+__global__ void __launch_bounds__(256) k_bucket_chunks_plain(const char* __restrict__ partial, const uint32_t* __restrict__ hist, const uint2* __restrict__ scan_local,
+                                                             const uint2* __restrict__ scan_blk, uint32_t B, uint32_t S, uint32_t nchunks_total, char* __restrict__ V) {
   uint32_t t = blockIdx.x * 256 + threadIdx.x;
   if (t >= nchunks_total) return;
   uint32_t cpw = B / S, w = t / cpw, j = t % cpw;
   uint32_t g0 = w * B + j * S;
   XYZZ run = xyzz_infinity(), acc = xyzz_infinity();
-  // steps 2k: run += S_b (b descending); steps 2k+1: acc += run
+  // steps 2k: run += S_b (b descending); steps 2k+1: acc += run   (one inlined xyzz_add call site)
   for (uint32_t k = 0; k < 2 * S; ++k) {
     bool odd = k & 1;
     XYZZ y;
@@ -462,14 +496,10 @@ __global__ void __launch_bounds__(256) k_bucket_chunks(const char* __restrict__ 
     xyzz_add(x, y);
     if (odd) acc = x; else run = x;
   }
-  // acc = sum (b - base + 1) S_b ; add base * run with base = j*S — unless the caller weights the chunk totals itself
-  // (fixed-base path: masked trees over Vrun, see msm_run)
   uint32_t base = j * S;
-  if (Vrun) store_xyzz(Vrun + (size_t)t * 192, run);
-  else if (base) {
+  if (base) {
     XYZZ r = xyzz_infinity();
-    int top = 31 - __clz(base);
-    for (int bit = top; bit >= 0; --bit) {
+    for (int bit = 31 - __clz(base); bit >= 0; --bit) {
       xyzz_double_ni(&r);
       if ((base >> bit) & 1) xyzz_add_ni(&r, &run);
     }
@@ -480,63 +510,61 @@ __global__ void __launch_bounds__(256) k_bucket_chunks(const char* __restrict__ 
 
 // V[seg*seg_len + i] += V[seg*seg_len + i + half] for i < L - half, L = current length of every segment
 __global__ void __launch_bounds__(256) k_seg_tree_pass(char* __restrict__ V, uint32_t seg_len, uint32_t nseg, uint32_t L) {
-  uint32_t half = (L + 1) >> 1, pairs = L - half;
-  uint32_t t = blockIdx.x * 256 + threadIdx.x;
-  if (t >= pairs * nseg) return;
-  uint32_t seg = t / pairs, i = t % pairs;
+  const uint32_t half = (L + 1) >> 1, pairs = L - half;
+  const uint32_t op = (blockIdx.x * 256 + threadIdx.x) >> 1;
+  if (op >= pairs * nseg) return;
+  const uint32_t seg = op / pairs, i = op % pairs;
   char* pa = V + ((size_t)seg * seg_len + i) * 192;
-  XYZZ a = load_xyzz(pa), b = load_xyzz(pa + (size_t)half * 192);
-  xyzz_add(a, b);
-  store_xyzz(pa, a);
+  xyzz_add_pair(pa, pa + (size_t)half * 192, pa);
 }
 
 // Fixed-base path: sum_j j * run_j = sum_l 2^l * T_l with T_l = sum of run_j over the j that have bit l set.  This
 // kernel does the first pairwise level of all lg(N) masked sums at once: T_l[k] = run[ins_l(2k)] + run[ins_l(2k+1)],
-// ins_l(x) = x with a 1 inserted at bit l.  The remaining levels are k_seg_tree_pass; the 2^l Horner runs on the host.
+// ins_l(x) = x with a 1 inserted at bit l.  The remaining levels are k_seg_pair_pass / k_seg_fold; the 2^l Horner runs
+// on the host.
 __global__ void __launch_bounds__(256) k_masked_pairs(const char* __restrict__ Vrun, uint32_t lgN, char* __restrict__ T) {
   const uint32_t seg_len = 1u << (lgN - 2);
-  uint32_t t = blockIdx.x * 256 + threadIdx.x;
-  if (t >= seg_len * lgN) return;
-  const uint32_t l = t / seg_len, k = t % seg_len;
+  const uint32_t op = (blockIdx.x * 256 + threadIdx.x) >> 1;
+  if (op >= seg_len * lgN) return;
+  const uint32_t l = op / seg_len, k = op % seg_len;
   auto ins = [&](uint32_t x) { return ((x >> l) << (l + 1)) | (1u << l) | (x & ((1u << l) - 1u)); };
-  XYZZ a = load_xyzz(Vrun + (size_t)ins(2 * k) * 192), b = load_xyzz(Vrun + (size_t)ins(2 * k + 1) * 192);
-  xyzz_add(a, b);
-  store_xyzz(T + (size_t)t * 192, a);
+  xyzz_add_pair(Vrun + (size_t)ins(2 * k) * 192, Vrun + (size_t)ins(2 * k + 1) * 192, T + (size_t)op * 192);
 }
-// One block folds up to 512 consecutive points of one segment into a single point (9 tree levels through LDS):
-// two launches replace the ~16 latency-bound pairwise launches of k_seg_tree_pass on the fixed-base path.
-__global__ void __launch_bounds__(256) k_seg_fold512(const char* __restrict__ in, uint32_t in_stride, uint32_t L, uint32_t nseg,
-                                                     char* __restrict__ out, uint32_t out_stride) {
-  __shared__ uint32_t lds[256 * 48];
-  const uint32_t bps = (L + 511) / 512, seg = blockIdx.x / bps, blk = blockIdx.x % bps, tid = threadIdx.x;
+// One block folds up to 256 consecutive points of one segment into a single point: 8 tree levels through two LDS
+// buffers, 128 lane pairs — the latency floor of the chain with no launch gaps.
+static constexpr uint32_t FOLD = 256;
+__global__ void __launch_bounds__(256) k_seg_fold(const char* __restrict__ in, uint32_t in_stride, uint32_t L, uint32_t nseg,
+                                                  char* __restrict__ out, uint32_t out_stride) {
+  __shared__ __attribute__((aligned(16))) uint32_t lds[2][(FOLD / 2) * 48];
+  const uint32_t bps = (L + FOLD - 1) / FOLD, seg = blockIdx.x / bps, blk = blockIdx.x % bps, pr = threadIdx.x >> 1;
   if (seg >= nseg) return;
-  const uint32_t i0 = blk * 512 + 2 * tid;
-  const char* src = in + ((size_t)seg * in_stride + i0) * 192;
-  XYZZ a = i0 < L ? load_xyzz(src) : xyzz_infinity();
-  XYZZ b = i0 + 1 < L ? load_xyzz(src + 192) : xyzz_infinity();
-  for (uint32_t n = 256;; n >>= 1) {          // n = number of lanes holding a live (a, b) pair
-    if (tid < n) {
-      xyzz_add(a, b);
-      store_xyzz(lds + tid * 48, a);
-    }
-    __syncthreads();
-    if (n == 1) break;
-    if (tid < (n >> 1)) { a = load_xyzz(lds + (2 * tid) * 48); b = load_xyzz(lds + (2 * tid + 1) * 48); }
-    __syncthreads();
+  {
+    const uint32_t e0 = blk * FOLD + 2 * pr;
+    const char* src = in + ((size_t)seg * in_stride + e0) * 192;
+    char* dst = (char*)(lds[0] + pr * 48);
+    if (e0 + 1 < L) xyzz_add_pair(src, src + 192, dst);
+    else if (e0 < L) pair_copy(src, dst);
+    else pair_zero(dst);
   }
-  if (tid == 0) store_xyzz(out + ((size_t)seg * out_stride + blk) * 192, a);
+  uint32_t cur = 0;
+  for (uint32_t n = FOLD / 2; n > 1; n >>= 1) {
+    __syncthreads();
+    if (pr < (n >> 1)) xyzz_add_pair((const char*)(lds[cur] + (2 * pr) * 48), (const char*)(lds[cur] + (2 * pr + 1) * 48), (char*)(lds[cur ^ 1] + pr * 48));
+    cur ^= 1;
+  }
+  __syncthreads();
+  if (pr == 0) pair_copy((const char*)lds[cur], out + ((size_t)seg * out_stride + blk) * 192);
 }
 // out[seg][i] = in[seg][2i] + in[seg][2i+1]: the wide (throughput-bound) levels of the segment sums
 __global__ void __launch_bounds__(256) k_seg_pair_pass(const char* __restrict__ in, uint32_t in_stride, uint32_t L, uint32_t nseg,
                                                        char* __restrict__ out, uint32_t out_stride) {
   const uint32_t half = (L + 1) >> 1;
-  uint32_t t = blockIdx.x * 256 + threadIdx.x;
-  if (t >= half * nseg) return;
-  const uint32_t seg = t / half, i = t % half;
+  const uint32_t op = (blockIdx.x * 256 + threadIdx.x) >> 1;
+  if (op >= half * nseg) return;
+  const uint32_t seg = op / half, i = op % half;
   const char* src = in + ((size_t)seg * in_stride + 2 * i) * 192;
-  XYZZ a = load_xyzz(src);
-  if (2 * i + 1 < L) { XYZZ b = load_xyzz(src + 192); xyzz_add(a, b); }
-  store_xyzz(out + ((size_t)seg * out_stride + i) * 192, a);
+  char* dst = out + ((size_t)seg * out_stride + i) * 192;
+  if (2 * i + 1 < L) xyzz_add_pair(src, src + 192, dst); else pair_copy(src, dst);
 }
 __global__ void k_gather_strided(const char* __restrict__ V, uint32_t stride, uint32_t count, char* __restrict__ out) {
   uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -655,11 +683,11 @@ int32_t msm_run(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, const void* 
     for (uint32_t pass = 0, L = max_m; L > 1; ++pass, L = (L + 1) >> 1) {
       const uint32_t Lc = super_overflow ? L : (L < 16u ? L : (16u >> (pass < 4 ? pass : 4)));       // longest bucket of the common list at this level
       if (n_heavy && Lc > 1) {
-        uint32_t mp = Lc >> 1; uint64_t threads = (uint64_t)n_heavy * mp;
+        uint32_t mp = Lc >> 1; uint64_t threads = 2ull * n_heavy * mp;
         hipLaunchKernelGGL(k_tree_pass, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, s, partial, heavy, scan_local, scan_blk, M, meta, pass, mp, n_heavy);
       }
       if (n_super) {
-        uint32_t mp = L >> 1; uint64_t threads = (uint64_t)n_super * mp;
+        uint32_t mp = L >> 1; uint64_t threads = 2ull * n_super * mp;
         hipLaunchKernelGGL(k_tree_pass, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, s, partial, super_list, scan_local, scan_blk, M, meta, pass, mp, n_super);
       }
     }
@@ -675,21 +703,21 @@ int32_t msm_run(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, const void* 
   if (masked) {
     // sum_b (b+1) S_b = sum_j acc_j + S * sum_j j * run_j ; the second sum by lg(N) masked pairwise trees
     char* T = V + (size_t)nchunks * 192; char* Vrun = T + (size_t)lgN * (cpw / 4) * 192; char* Tout = Vrun + (size_t)nchunks * 192;
-    hipLaunchKernelGGL(k_bucket_chunks, dim3((nchunks + 255) / 256), dim3(256), 0, s, partial, hist, scan_local, scan_blk, P.B, P.S, nchunks, V, Vrun);
+    hipLaunchKernelGGL(k_bucket_chunks, dim3((nchunks + CHUNK_PAIRS - 1) / CHUNK_PAIRS), dim3(256), 0, s, partial, hist, scan_local, scan_blk, P.B, P.S, nchunks, V, Vrun);
     const uint32_t tseg = cpw / 4, fseg = lgN + 4;      // Vacc viewed as 4 segments of cpw/4, followed by the lgN masked sums
-    hipLaunchKernelGGL(k_masked_pairs, dim3((tseg * lgN + 255) / 256), dim3(256), 0, s, Vrun, lgN, T);
+    hipLaunchKernelGGL(k_masked_pairs, dim3((2 * tseg * lgN + 255) / 256), dim3(256), 0, s, Vrun, lgN, T);
     // (lgN+4) segment sums: pairwise launches while a level still fills the chip, then ONE block per segment folds the
-    // last 512 points through LDS (9 levels at one wave per SIMD: the latency floor of the chain, no launch gaps)
+    // last 256 points through LDS (8 levels of lane-pair additions: the latency floor of the chain, no launch gaps)
     char* F1 = Tout + (size_t)(fseg + 1) * 192; char* F2 = F1 + (size_t)fseg * (tseg / 2) * 192;
     const char* cur = V; uint32_t L = tseg, stride = tseg;
-    while (L > 512) {
+    while (L > FOLD) {
       char* dst = (cur == F1) ? F2 : F1; uint32_t half = (L + 1) >> 1;
-      hipLaunchKernelGGL(k_seg_pair_pass, dim3((half * fseg + 255) / 256), dim3(256), 0, s, cur, stride, L, fseg, dst, half);
+      hipLaunchKernelGGL(k_seg_pair_pass, dim3((2 * half * fseg + 255) / 256), dim3(256), 0, s, cur, stride, L, fseg, dst, half);
       cur = dst; stride = half; L = half;
     }
     if (L > 1) {
       char* dst = (cur == F1) ? F2 : F1;
-      hipLaunchKernelGGL(k_seg_fold512, dim3(fseg), dim3(256), 0, s, cur, stride, L, fseg, dst, 1u);
+      hipLaunchKernelGGL(k_seg_fold, dim3(fseg), dim3(256), 0, s, cur, stride, L, fseg, dst, 1u);
       cur = dst; stride = 1; L = 1;
     }
     hipLaunchKernelGGL(k_gather_strided, dim3((fseg * 12 + 255) / 256), dim3(256), 0, s, cur, stride, fseg, Tout);
@@ -701,10 +729,10 @@ int32_t msm_run(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, const void* 
     for (uint32_t sft = P.S; sft > 1; sft >>= 1) total = hdouble(total);
     for (int q = 0; q < 4; ++q) total = hadd(total, lazy_point(h_win + (size_t)q * 192));
   } else {
-    hipLaunchKernelGGL(k_bucket_chunks, dim3((nchunks + 255) / 256), dim3(256), 0, s, partial, hist, scan_local, scan_blk, P.B, P.S, nchunks, V, (char*)nullptr);
+    hipLaunchKernelGGL(k_bucket_chunks_plain, dim3((nchunks + 255) / 256), dim3(256), 0, s, partial, hist, scan_local, scan_blk, P.B, P.S, nchunks, V);
     for (uint32_t L = cpw; L > 1; L = (L + 1) >> 1) {
       uint32_t pairs = (L - ((L + 1) >> 1)) * P.W;
-      hipLaunchKernelGGL(k_seg_tree_pass, dim3((pairs + 255) / 256), dim3(256), 0, s, V, cpw, P.W, L);
+      hipLaunchKernelGGL(k_seg_tree_pass, dim3((2 * pairs + 255) / 256), dim3(256), 0, s, V, cpw, P.W, L);
     }
     hipLaunchKernelGGL(k_gather_windows, dim3((P.W * 12 + 255) / 256), dim3(256), 0, s, V, cpw, P.W, Vout);
     HIPCHK(hipMemcpyAsync(h_win, Vout, (size_t)P.W * 192, hipMemcpyDeviceToHost, s));
