@@ -5,13 +5,16 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <thread>
+#include <functional>
 
 namespace aleo_mi355x {
 
 thread_local std::string g_last_error;
+thread_local MsmTiming g_last_msm;
 
-static std::mutex g_ctx_mu;
-static std::map<int, Ctx*> g_ctxs;
+static std::mutex g_dev_mu;
+static std::map<int, Device*> g_devs;
 
 int32_t ensure_host_pinned(Ctx* c, size_t bytes) {
   if (bytes <= c->h_pinned_cap) return ALEO_MI355X_OK;
@@ -22,14 +25,14 @@ int32_t ensure_host_pinned(Ctx* c, size_t bytes) {
   c->h_pinned_cap = want; return ALEO_MI355X_OK;
 }
 
-static int32_t init_device(int device, Ctx** out) {
-  std::lock_guard<std::mutex> lk(g_ctx_mu);
+static int32_t init_device(int device, Device** out) {
+  std::lock_guard<std::mutex> lk(g_dev_mu);
   int count = 0;
   if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) { g_last_error = "no HIP device visible"; return ALEO_MI355X_ERR_NO_DEVICE; }
   if (device < 0) { if (hipGetDevice(&device) != hipSuccess) { g_last_error = "hipGetDevice failed"; return ALEO_MI355X_ERR_NO_DEVICE; } }
   if (device >= count) { g_last_error = "device index out of range"; return ALEO_MI355X_ERR_BAD_ARG; }
-  auto it = g_ctxs.find(device);
-  if (it != g_ctxs.end()) { *out = it->second; return ALEO_MI355X_OK; }
+  auto it = g_devs.find(device);
+  if (it != g_devs.end()) { *out = it->second; return ALEO_MI355X_OK; }
   HIPCHK(hipSetDevice(device));
   hipDeviceProp_t prop;
   HIPCHK(hipGetDeviceProperties(&prop, device));
@@ -37,28 +40,48 @@ static int32_t init_device(int device, Ctx** out) {
     g_last_error = std::string("device is ") + prop.gcnArchName + ", this library carries gfx950 code only";
     return ALEO_MI355X_ERR_NO_DEVICE;
   }
-  std::unique_ptr<Ctx> c(new Ctx());
-  c->device = device;
-  HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-  for (auto& e : c->ev) HIPCHK(hipEventCreate(&e));
-  *out = c.get();
-  g_ctxs[device] = c.release();
+  std::unique_ptr<Device> d(new Device());
+  d->device = device;
+  if (const char* e = std::getenv("ALEO_MI355X_SLOTS")) { int k = std::atoi(e); if (k >= 1 && k <= MAX_SLOTS) d->n_slots = k; }
+  for (int i = 0; i < MAX_SLOTS; ++i) { d->slots[i].dev = d.get(); d->slots[i].device = device; }
+  *out = d.get();
+  g_devs[device] = d.release();
   return ALEO_MI355X_OK;
 }
 
-int32_t get_ctx(Ctx** out) {
+static int32_t get_device(Device** out) {
   int device = -1;
   if (hipGetDevice(&device) != hipSuccess) { g_last_error = "no HIP device visible"; return ALEO_MI355X_ERR_NO_DEVICE; }
   {
-    std::lock_guard<std::mutex> lk(g_ctx_mu);
-    auto it = g_ctxs.find(device);
-    if (it != g_ctxs.end()) { *out = it->second; return ALEO_MI355X_OK; }
+    std::lock_guard<std::mutex> lk(g_dev_mu);
+    auto it = g_devs.find(device);
+    if (it != g_devs.end()) { *out = it->second; return ALEO_MI355X_OK; }
   }
   return init_device(device, out);
 }
 
-static int32_t pin_locked(Ctx* c, const void* bases, size_t stride, size_t n, uint64_t* handle) {
-  PinnedBases pb; pb.n = n;
+// Picks a free slot (or waits on one chosen by thread id) and locks it for the duration of the call.
+static int32_t acquire_slot(Device* d, Ctx** out, std::unique_lock<std::mutex>& lk) {
+  Ctx* c = nullptr;
+  for (int i = 0; i < d->n_slots && !c; ++i) {
+    std::unique_lock<std::mutex> t(d->slots[i].mu, std::try_to_lock);
+    if (t.owns_lock()) { lk = std::move(t); c = &d->slots[i]; }
+  }
+  if (!c) {
+    size_t i = std::hash<std::thread::id>()(std::this_thread::get_id()) % (size_t)d->n_slots;
+    lk = std::unique_lock<std::mutex>(d->slots[i].mu); c = &d->slots[i];
+  }
+  if (hipSetDevice(d->device) != hipSuccess) { g_last_error = "hipSetDevice failed"; return ALEO_MI355X_ERR_HIP; }
+  if (!c->stream) {                         // first use of this slot
+    HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    for (auto& e : c->ev) HIPCHK(hipEventCreate(&e));
+  }
+  *out = c; return ALEO_MI355X_OK;
+}
+
+// ---- pinned base sets (shared by all slots) ----------------------------------------------------------
+static int32_t upload_bases(const void* bases, size_t stride, size_t n, std::shared_ptr<PinnedOwner>* out) {
+  auto o = std::make_shared<PinnedOwner>(); PinnedBases& pb = o->pb; pb.n = n;
   size_t bytes = (n ? n : 1) * 96;
   HIPCHK(hipMalloc(&pb.d_xy, bytes));
   bool any_inf = false;
@@ -78,22 +101,43 @@ static int32_t pin_locked(Ctx* c, const void* bases, size_t stride, size_t n, ui
       HIPCHK(hipMemcpy(pb.d_inf, inf.data(), n, hipMemcpyHostToDevice));
     }
   }
-  uint64_t h = c->next_handle++;
-  c->bases[h] = pb; *handle = h;
+  *out = std::move(o); return ALEO_MI355X_OK;
+}
+static uint64_t register_bases(Device* d, std::shared_ptr<PinnedOwner> o) {
+  std::lock_guard<std::mutex> lk(d->mu);
+  uint64_t h = d->next_handle++; d->bases[h] = std::move(o); return h;
+}
+// The set behind a handle plus a snapshot of its fields (the table pointer may be published by another slot at any time).
+static int32_t find_bases(Device* d, uint64_t handle, std::shared_ptr<PinnedOwner>* keep, PinnedBases* snap) {
+  std::lock_guard<std::mutex> lk(d->mu);
+  auto it = d->bases.find(handle);
+  if (it == d->bases.end()) { g_last_error = "unknown bases handle"; return ALEO_MI355X_ERR_BAD_HANDLE; }
+  *keep = it->second; *snap = it->second->pb; return ALEO_MI355X_OK;
+}
+static int32_t unpin(Device* d, uint64_t handle) {
+  std::shared_ptr<PinnedOwner> dead;          // freed (hipFree synchronises) after the lock is dropped, once no call uses it
+  std::lock_guard<std::mutex> lk(d->mu);
+  auto it = d->bases.find(handle);
+  if (it == d->bases.end()) { g_last_error = "unknown bases handle"; return ALEO_MI355X_ERR_BAD_HANDLE; }
+  dead = std::move(it->second); d->bases.erase(it);
   return ALEO_MI355X_OK;
 }
-
-static int32_t unpin_locked(Ctx* c, uint64_t handle) {
-  auto it = c->bases.find(handle);
-  if (it == c->bases.end()) { g_last_error = "unknown bases handle"; return ALEO_MI355X_ERR_BAD_HANDLE; }
-  if (it->second.d_xy) (void)hipFree(it->second.d_xy);
-  if (it->second.d_inf) (void)hipFree(it->second.d_inf);
-  if (it->second.d_pre) (void)hipFree(it->second.d_pre);
-  c->bases.erase(it);
-  return ALEO_MI355X_OK;
+// Builds the fixed-base table of a set on slot c unless it exists or another slot is building it; publishes it under the lock.
+static int32_t precompute_once(Ctx* c, const std::shared_ptr<PinnedOwner>& o) {
+  Device* d = c->dev; PinnedBases work;
+  {
+    std::lock_guard<std::mutex> lk(d->mu);
+    if (o->pb.d_pre || o->building) return ALEO_MI355X_OK;
+    o->building = true; work = o->pb;
+  }
+  int32_t rc = msm_precompute(c, &work);
+  std::lock_guard<std::mutex> lk(d->mu);
+  o->building = false;
+  if (rc == ALEO_MI355X_OK) { o->pb.pre_c = work.pre_c; o->pb.d_pre = work.d_pre; }
+  return rc;
 }
 
-static int32_t msm_host_scalars_locked(Ctx* c, void* out, const PinnedBases& pb, const void* scalars, size_t n, bool mont) {
+static int32_t msm_host_scalars(Ctx* c, void* out, const PinnedBases& pb, const void* scalars, size_t n, bool mont) {
   int32_t rc;
   if ((rc = c->scalars_stage.reserve((n ? n : 1) * 32))) return rc;
   if (n) HIPCHK(hipMemcpyAsync(c->scalars_stage.p, scalars, n * 32, hipMemcpyHostToDevice, c->stream));
@@ -113,9 +157,9 @@ static bool srs_cache_enabled() {
   if (on < 0) { const char* e = std::getenv("ALEO_MI355X_SRS_CACHE"); on = (e && e[0] == '0') ? 0 : 1; }
   return on == 1;
 }
-// Returns the cached pinned set for (bases, stride) that covers n points, or nullptr.
-static SrsCacheEntry* srs_lookup(Ctx* c, const void* bases, size_t stride, size_t n) {
-  for (auto& e : c->srs_cache) {
+// Caller holds d->mu.  Returns the cached entry for (bases, stride) that covers n points, or nullptr.
+static SrsCacheEntry* srs_lookup(Device* d, const void* bases, size_t stride, size_t n) {
+  for (auto& e : d->srs_cache) {
     if (e.host_ptr != bases || e.stride != stride || e.n < n) continue;
     bool ok = true; size_t checked = 0;
     for (auto& sm : e.samples) {                 // only samples inside the caller's slice may be read
@@ -127,25 +171,46 @@ static SrsCacheEntry* srs_lookup(Ctx* c, const void* bases, size_t stride, size_
   }
   return nullptr;
 }
-static int32_t srs_insert(Ctx* c, const void* bases, size_t stride, size_t n, SrsCacheEntry** out) {
-  // drop stale entries for the same pointer, then the least recently used one if the cache is full
-  for (size_t i = 0; i < c->srs_cache.size();) {
-    if (c->srs_cache[i].host_ptr == bases) { unpin_locked(c, c->srs_cache[i].handle); c->srs_cache.erase(c->srs_cache.begin() + i); } else ++i;
+// The resident set for a one-shot call's base array: a cache hit, or a fresh upload that replaces stale / least recently
+// used entries.  `want_table` is set on the third use of a set large enough to repay the one-off table build.
+static int32_t srs_get(Device* d, const void* bases, size_t stride, size_t n, std::shared_ptr<PinnedOwner>* keep, bool* want_table) {
+  *want_table = false;
+  {
+    std::lock_guard<std::mutex> lk(d->mu);
+    if (SrsCacheEntry* e = srs_lookup(d, bases, stride, n)) {
+      e->last_use = ++d->srs_clock; e->hits++;
+      *keep = d->bases[e->handle];
+      *want_table = e->hits >= 3 && e->n >= (1u << 14) && !(*keep)->pb.d_pre;
+      return ALEO_MI355X_OK;
+    }
   }
-  if (c->srs_cache.size() >= SRS_CACHE_ENTRIES) {
-    size_t lru = 0; for (size_t i = 1; i < c->srs_cache.size(); ++i) if (c->srs_cache[i].last_use < c->srs_cache[lru].last_use) lru = i;
-    unpin_locked(c, c->srs_cache[lru].handle); c->srs_cache.erase(c->srs_cache.begin() + lru);
-  }
-  SrsCacheEntry e; e.host_ptr = bases; e.stride = stride; e.n = n;
-  int32_t rc = pin_locked(c, bases, stride, n, &e.handle);
+  std::shared_ptr<PinnedOwner> o;              // the bulk upload runs without the lock
+  int32_t rc = upload_bases(bases, stride, n, &o);
   if (rc) return rc;
+  SrsCacheEntry e; e.host_ptr = bases; e.stride = stride; e.n = n; e.hits = 1;
   // dense samples at the front (every prefix request can be checked), sparse ones over the rest
   for (size_t k = 0; k < SRS_SAMPLES; ++k) {
     size_t idx = k < 32 ? k : (size_t)((double)(k - 31) / (SRS_SAMPLES - 31) * (n - 1));
     if (idx >= n) break;
     e.samples.emplace_back(idx, hash96((const uint8_t*)bases + idx * stride));
   }
-  c->srs_cache.push_back(e); *out = &c->srs_cache.back();
+  std::vector<std::shared_ptr<PinnedOwner>> dead;
+  {
+    std::lock_guard<std::mutex> lk(d->mu);
+    auto drop = [&](size_t i) {
+      auto it = d->bases.find(d->srs_cache[i].handle);
+      if (it != d->bases.end()) { dead.push_back(std::move(it->second)); d->bases.erase(it); }
+      d->srs_cache.erase(d->srs_cache.begin() + i);
+    };
+    for (size_t i = 0; i < d->srs_cache.size();) { if (d->srs_cache[i].host_ptr == bases) drop(i); else ++i; }
+    if (d->srs_cache.size() >= SRS_CACHE_ENTRIES) {
+      size_t lru = 0; for (size_t i = 1; i < d->srs_cache.size(); ++i) if (d->srs_cache[i].last_use < d->srs_cache[lru].last_use) lru = i;
+      drop(lru);
+    }
+    e.handle = d->next_handle++; e.last_use = ++d->srs_clock;
+    d->bases[e.handle] = o; d->srs_cache.push_back(e);
+  }
+  *keep = std::move(o);
   return ALEO_MI355X_OK;
 }
 
@@ -160,19 +225,25 @@ static void jacobian_to_affine104(void* out104, const uint64_t* jac18) {
 
 using namespace aleo_mi355x;
 
-#define API_BEGIN Ctx* c = nullptr; { int32_t rc0 = get_ctx(&c); if (rc0) return rc0; } std::lock_guard<std::mutex> lk(c->mu); if (hipSetDevice(c->device) != hipSuccess) return ALEO_MI355X_ERR_HIP;
+// every entry point: the calling thread's device, then a slot of it locked for the duration of the call
+#define API_BEGIN Device* d = nullptr; Ctx* c = nullptr; std::unique_lock<std::mutex> lk; \
+  { int32_t rc0 = get_device(&d); if (rc0) return rc0; if ((rc0 = acquire_slot(d, &c, lk))) return rc0; }
+#define FIND_BASES(handle) std::shared_ptr<PinnedOwner> keep; PinnedBases pb; { int32_t rcb = find_bases(d, handle, &keep, &pb); if (rcb) return rcb; }
 
 extern "C" {
 
 int32_t aleo_mi355x_init(int32_t device) {
-  try { Ctx* c = nullptr; return init_device(device, &c); } catch (...) { return ALEO_MI355X_ERR_HIP; }
+  try { Device* d = nullptr; return init_device(device, &d); } catch (...) { return ALEO_MI355X_ERR_HIP; }
 }
 
 int32_t aleo_mi355x_bases_pin(const void* bases, size_t base_stride, size_t n, uint64_t* handle) {
   try {
     if (!handle || (!bases && n) || (base_stride != 104 && base_stride != 96)) { g_last_error = "bases_pin: bad argument"; return ALEO_MI355X_ERR_BAD_ARG; }
     API_BEGIN
-    return pin_locked(c, bases, base_stride, n, handle);
+    std::shared_ptr<PinnedOwner> o; int32_t rc = upload_bases(bases, base_stride, n, &o);
+    if (rc) return rc;
+    *handle = register_bases(d, std::move(o));
+    return ALEO_MI355X_OK;
   } catch (...) { return ALEO_MI355X_ERR_HIP; }
 }
 
@@ -180,9 +251,10 @@ int32_t aleo_mi355x_bases_generate(const void* base104, uint64_t first, size_t n
   try {
     if (!base104 || !handle) return ALEO_MI355X_ERR_BAD_ARG;
     API_BEGIN
-    PinnedBases pb; int32_t rc = generate_multiples(c, base104, first, n, &pb);
+    auto o = std::make_shared<PinnedOwner>();
+    int32_t rc = generate_multiples(c, base104, first, n, &o->pb);
     if (rc) return rc;
-    uint64_t h = c->next_handle++; c->bases[h] = pb; *handle = h;
+    *handle = register_bases(d, std::move(o));
     return ALEO_MI355X_OK;
   } catch (...) { return ALEO_MI355X_ERR_HIP; }
 }
@@ -190,9 +262,8 @@ int32_t aleo_mi355x_bases_generate(const void* base104, uint64_t first, size_t n
 int32_t aleo_mi355x_bases_precompute(uint64_t handle) {
   try {
     API_BEGIN
-    auto it = c->bases.find(handle);
-    if (it == c->bases.end()) { g_last_error = "unknown bases handle"; return ALEO_MI355X_ERR_BAD_HANDLE; }
-    return msm_precompute(c, &it->second);
+    FIND_BASES(handle)
+    return precompute_once(c, keep);
   } catch (...) { return ALEO_MI355X_ERR_HIP; }
 }
 
@@ -200,12 +271,11 @@ int32_t aleo_mi355x_bases_download(uint64_t handle, size_t offset, size_t n, voi
   try {
     if (!out104 && n) return ALEO_MI355X_ERR_BAD_ARG;
     API_BEGIN
-    auto it = c->bases.find(handle);
-    if (it == c->bases.end()) { g_last_error = "unknown bases handle"; return ALEO_MI355X_ERR_BAD_HANDLE; }
-    if (offset + n > it->second.n) { g_last_error = "bases_download: range"; return ALEO_MI355X_ERR_BAD_ARG; }
+    FIND_BASES(handle)
+    if (offset + n > pb.n) { g_last_error = "bases_download: range"; return ALEO_MI355X_ERR_BAD_ARG; }
     std::vector<uint8_t> xy(n * 96 + 1), inf(n + 1, 0);
-    HIPCHK(hipMemcpy(xy.data(), (const char*)it->second.d_xy + offset * 96, n * 96, hipMemcpyDeviceToHost));
-    if (it->second.d_inf) HIPCHK(hipMemcpy(inf.data(), it->second.d_inf + offset, n, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(xy.data(), (const char*)pb.d_xy + offset * 96, n * 96, hipMemcpyDeviceToHost));
+    if (pb.d_inf) HIPCHK(hipMemcpy(inf.data(), pb.d_inf + offset, n, hipMemcpyDeviceToHost));
     uint8_t* o = (uint8_t*)out104;
     for (size_t i = 0; i < n; ++i) { std::memcpy(o + i * 104, &xy[i * 96], 96); std::memset(o + i * 104 + 96, 0, 8); o[i * 104 + 96] = inf[i]; }
     return ALEO_MI355X_OK;
@@ -213,7 +283,7 @@ int32_t aleo_mi355x_bases_download(uint64_t handle, size_t offset, size_t n, voi
 }
 
 int32_t aleo_mi355x_bases_unpin(uint64_t handle) {
-  try { API_BEGIN return unpin_locked(c, handle); } catch (...) { return ALEO_MI355X_ERR_HIP; }
+  try { API_BEGIN return unpin(d, handle); } catch (...) { return ALEO_MI355X_ERR_HIP; }
 }
 
 int32_t aleo_mi355x_msm_g1(void* out, const void* bases, size_t base_stride, const void* scalars, size_t n) {
@@ -223,20 +293,16 @@ int32_t aleo_mi355x_msm_g1(void* out, const void* bases, size_t base_stride, con
     if (n >= SRS_MIN_N && srs_cache_enabled()) {
       // KZG10::commit multiplies against prefixes of one SRS: keep it in HBM between calls (ALEO_MI355X_SRS_CACHE=0
       // turns this off; a caller that rewrites a base array in place between calls must do so)
-      SrsCacheEntry* e = srs_lookup(c, bases, base_stride, n);
-      int32_t rc = ALEO_MI355X_OK;
-      if (!e) rc = srs_insert(c, bases, base_stride, n, &e);
+      std::shared_ptr<PinnedOwner> keep; bool want_table = false;
+      int32_t rc = srs_get(d, bases, base_stride, n, &keep, &want_table);
       if (rc) return rc;
-      e->last_use = ++c->srs_clock; e->hits++;
-      PinnedBases& pb = c->bases[e->handle];
-      if (e->hits == 3 && e->n >= (1u << 14) && !pb.d_pre) (void)msm_precompute(c, &pb);     // third use: worth the one-off table
-      return msm_host_scalars_locked(c, out, pb, scalars, n, false);
+      if (want_table) (void)precompute_once(c, keep);                       // third use: worth the one-off table
+      PinnedBases pb; { std::lock_guard<std::mutex> g(d->mu); pb = keep->pb; }
+      return msm_host_scalars(c, out, pb, scalars, n, false);
     }
-    uint64_t h = 0; int32_t rc = pin_locked(c, bases, base_stride, n, &h);
+    std::shared_ptr<PinnedOwner> o; int32_t rc = upload_bases(bases, base_stride, n, &o);
     if (rc) return rc;
-    rc = msm_host_scalars_locked(c, out, c->bases[h], scalars, n, false);
-    unpin_locked(c, h);
-    return rc;
+    return msm_host_scalars(c, out, o->pb, scalars, n, false);
   } catch (...) { return ALEO_MI355X_ERR_HIP; }
 }
 
@@ -244,9 +310,8 @@ int32_t aleo_mi355x_msm_g1_pinned(void* out, uint64_t handle, const void* scalar
   try {
     if (!out || (!scalars && n)) { g_last_error = "msm_g1_pinned: bad argument"; return ALEO_MI355X_ERR_BAD_ARG; }
     API_BEGIN
-    auto it = c->bases.find(handle);
-    if (it == c->bases.end()) { g_last_error = "unknown bases handle"; return ALEO_MI355X_ERR_BAD_HANDLE; }
-    return msm_host_scalars_locked(c, out, it->second, scalars, n, false);
+    FIND_BASES(handle)
+    return msm_host_scalars(c, out, pb, scalars, n, false);
   } catch (...) { return ALEO_MI355X_ERR_HIP; }
 }
 
@@ -254,9 +319,8 @@ int32_t aleo_mi355x_msm_g1_device(void* out, uint64_t handle, const void* d_scal
   try {
     if (!out || (!d_scalars && n)) { g_last_error = "msm_g1_device: bad argument"; return ALEO_MI355X_ERR_BAD_ARG; }
     API_BEGIN
-    auto it = c->bases.find(handle);
-    if (it == c->bases.end()) { g_last_error = "unknown bases handle"; return ALEO_MI355X_ERR_BAD_HANDLE; }
-    return msm_run(c, (uint64_t*)out, it->second, d_scalars, n, false, stream ? (hipStream_t)stream : c->stream);
+    FIND_BASES(handle)
+    return msm_run(c, (uint64_t*)out, pb, d_scalars, n, false, stream ? (hipStream_t)stream : c->stream);
   } catch (...) { return ALEO_MI355X_ERR_HIP; }
 }
 
@@ -274,10 +338,9 @@ int32_t aleo_mi355x_kzg_commit(void* out104, uint64_t handle, const void* coeffs
   try {
     if (!out104 || (!coeffs && n)) return ALEO_MI355X_ERR_BAD_ARG;
     API_BEGIN
-    auto it = c->bases.find(handle);
-    if (it == c->bases.end()) { g_last_error = "unknown bases handle"; return ALEO_MI355X_ERR_BAD_HANDLE; }
+    FIND_BASES(handle)
     uint64_t jac[18];
-    int32_t rc = msm_host_scalars_locked(c, jac, it->second, coeffs, n, true);
+    int32_t rc = msm_host_scalars(c, jac, pb, coeffs, n, true);
     if (rc) return rc;
     jacobian_to_affine104(out104, jac);
     return ALEO_MI355X_OK;
@@ -288,10 +351,9 @@ int32_t aleo_mi355x_kzg_commit_device(void* out104, uint64_t handle, const void*
   try {
     if (!out104 || (!d_coeffs && n)) return ALEO_MI355X_ERR_BAD_ARG;
     API_BEGIN
-    auto it = c->bases.find(handle);
-    if (it == c->bases.end()) { g_last_error = "unknown bases handle"; return ALEO_MI355X_ERR_BAD_HANDLE; }
+    FIND_BASES(handle)
     uint64_t jac[18];
-    int32_t rc = msm_run(c, jac, it->second, d_coeffs, n, true, stream ? (hipStream_t)stream : c->stream);
+    int32_t rc = msm_run(c, jac, pb, d_coeffs, n, true, stream ? (hipStream_t)stream : c->stream);
     if (rc) return rc;
     jacobian_to_affine104(out104, jac);
     return ALEO_MI355X_OK;
@@ -302,12 +364,11 @@ int32_t aleo_mi355x_kzg_commit_hiding(void* out104, uint64_t h_powers, const voi
   try {
     if (!out104 || (!coeffs && n) || (!blind && m)) return ALEO_MI355X_ERR_BAD_ARG;
     API_BEGIN
-    auto ip = c->bases.find(h_powers), ig = c->bases.find(h_gamma);
-    if (ip == c->bases.end() || ig == c->bases.end()) { g_last_error = "unknown bases handle"; return ALEO_MI355X_ERR_BAD_HANDLE; }
+    std::shared_ptr<PinnedOwner> kp, kg; PinnedBases pp, pg; int32_t rc;
+    if ((rc = find_bases(d, h_powers, &kp, &pp)) || (rc = find_bases(d, h_gamma, &kg, &pg))) return rc;
     uint64_t parts[36];
-    int32_t rc = msm_host_scalars_locked(c, parts, ip->second, coeffs, n, true);
-    if (rc) return rc;
-    if ((rc = msm_host_scalars_locked(c, parts + 18, ig->second, blind, m, true))) return rc;
+    if ((rc = msm_host_scalars(c, parts, pp, coeffs, n, true))) return rc;
+    if ((rc = msm_host_scalars(c, parts + 18, pg, blind, m, true))) return rc;
     host::HXYZZ t = host::hadd(host::hfrom_jacobian(parts), host::hfrom_jacobian(parts + 18));
     uint64_t jac[18]; host::hstore_jacobian_normalized(jac, t);
     jacobian_to_affine104(out104, jac);
@@ -363,8 +424,8 @@ int32_t aleo_mi355x_fr_mul(void* r, const void* a, const void* b, size_t n) {
 int32_t aleo_mi355x_last_msm_timing(double* out_ms, int32_t cap) {
   try {
     if (!out_ms || cap <= 0) return 0;
-    API_BEGIN
-    double v[6] = {c->last_msm.total, c->last_msm.sort, c->last_msm.accum, c->last_msm.reduce, c->last_msm.host, c->last_msm.accum_kernel};
+    const MsmTiming& t = g_last_msm;          // of the calling thread's most recent MSM
+    double v[6] = {t.total, t.sort, t.accum, t.reduce, t.host, t.accum_kernel};
     int32_t k = cap < 6 ? cap : 6;
     for (int32_t i = 0; i < k; ++i) out_ms[i] = v[i];
     return k;

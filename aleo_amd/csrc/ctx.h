@@ -1,9 +1,12 @@
-// ctx.h — per-device context of libaleo_mi355x.so: stream, grow-only HBM workspaces, pinned base sets.
+// ctx.h — per-device state of libaleo_mi355x.so.  A Device holds what calls share (pinned base sets, SRS cache, NTT
+// tables) behind one short-held mutex; each call runs on one of its Ctx slots (own stream, events, grow-only HBM
+// workspaces), so the rayon threads of one prover round overlap their MSMs/NTTs on the GPU instead of queueing.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cstdio>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -48,6 +51,12 @@ struct PinnedBases {
 
 // One-shot aleo_mi355x_msm_g1 calls keep their base array resident between calls ("device-resident SRS
 // cache keyed by host pointer + length + hash"): KZG10::commit always multiplies against a prefix of the same powers.
+// owner of a pinned set's HBM; calls hold a shared_ptr while they run, so an unpin from another thread cannot free it under them
+struct PinnedOwner {
+  PinnedBases pb; bool building = false;     // building: a table build for this set is in flight on some slot
+  ~PinnedOwner() { if (pb.d_xy) (void)hipFree(pb.d_xy); if (pb.d_inf) (void)hipFree(pb.d_inf); if (pb.d_pre) (void)hipFree(pb.d_pre); }
+};
+
 struct SrsCacheEntry {
   const void* host_ptr = nullptr; size_t n = 0, stride = 0; uint64_t handle = 0, last_use = 0; uint32_t hits = 0;
   std::vector<std::pair<size_t, uint64_t>> samples;      // (point index, hash of its 96 bytes)
@@ -57,22 +66,34 @@ struct MsmTiming { double total = 0, sort = 0, accum = 0, reduce = 0, host = 0, 
 
 struct NttTables;   // ntt.hip
 
-struct Ctx {
+struct Device;
+
+struct Ctx {                           // one concurrency slot
+  Device* dev = nullptr;
   int device = -1;
   hipStream_t stream = nullptr;
-  std::mutex mu;                       // serialises calls on this device
+  std::mutex mu;                       // held for the duration of one API call
   hipEvent_t ev[8] = {};
   // MSM workspaces
   DevBuf hist, scan_local, scan_blk, sorted, part_cnt, part_items, partial, task_g, meta, vbuf, scalars_stage, out_stage;
   void* h_pinned = nullptr; size_t h_pinned_cap = 0;    // pinned host staging for small D2H results
-  std::map<uint64_t, PinnedBases> bases; uint64_t next_handle = 1;
   MsmTiming last_msm;
-  std::vector<SrsCacheEntry> srs_cache; uint64_t srs_clock = 0;
-  // NTT
-  std::map<uint64_t, NttTables*> ntt_tables; DevBuf ntt_tmp, ntt_stage;
+  DevBuf ntt_tmp, ntt_stage;
 };
 
-int32_t get_ctx(Ctx** out);            // lazily initialises the current device's context
+static constexpr int MAX_SLOTS = 8;
+
+struct Device {
+  int device = -1;
+  int n_slots = 4;                     // ALEO_MI355X_SLOTS (1..8)
+  std::mutex mu;                       // guards everything below; never held across a kernel launch or a copy of bulk data
+  std::map<uint64_t, std::shared_ptr<PinnedOwner>> bases; uint64_t next_handle = 1;
+  std::vector<SrsCacheEntry> srs_cache; uint64_t srs_clock = 0;
+  std::map<uint64_t, NttTables*> ntt_tables;
+  Ctx slots[MAX_SLOTS];
+};
+
+extern thread_local MsmTiming g_last_msm;   // phase times of the calling thread's most recent MSM
 int32_t ensure_host_pinned(Ctx* c, size_t bytes);
 
 // msm.hip

@@ -756,7 +756,7 @@ int32_t msm_run(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, const void* 
   HIPCHK(hipEventElapsedTime(&ms, c->ev[3], c->ev[4])); tm.host = ms;
   HIPCHK(hipEventElapsedTime(&ms, c->ev[0], c->ev[4])); tm.total = ms;
   if (NT) { HIPCHK(hipEventElapsedTime(&ms, c->ev[6], c->ev[5])); tm.accum_kernel = ms; }
-  c->last_msm = tm;
+  c->last_msm = tm; g_last_msm = tm;
   return ALEO_MI355X_OK;
 }
 

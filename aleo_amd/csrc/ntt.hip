@@ -251,12 +251,15 @@ int32_t ntt_run(Ctx* c, void* d_inout, uint32_t lg_n, int32_t order, int32_t dir
   int32_t rc;
   uint64_t key = ((uint64_t)lg_n << 1) | (uint64_t)direction;
   NttTables* t = nullptr;
-  auto it = c->ntt_tables.find(key);
-  if (it == c->ntt_tables.end()) {
-    t = new NttTables();
-    if ((rc = build_tables(t, lg_n, direction))) { delete t; return rc; }
-    c->ntt_tables[key] = t;
-  } else t = it->second;
+  {
+    std::lock_guard<std::mutex> lk(c->dev->mu);       // tables are shared by all slots and immutable once built
+    auto it = c->dev->ntt_tables.find(key);
+    if (it == c->dev->ntt_tables.end()) {
+      t = new NttTables();
+      if ((rc = build_tables(t, lg_n, direction))) { delete t; return rc; }
+      c->dev->ntt_tables[key] = t;
+    } else t = it->second;
+  }
   if ((rc = c->ntt_tmp.reserve(bytes))) return rc;
   char* buf = (char*)d_inout; char* tmp = c->ntt_tmp.as<char>();
   const bool in_rev = (order == ALEO_NTT_ORDER_RN || order == ALEO_NTT_ORDER_RR), out_rev = (order == ALEO_NTT_ORDER_NR || order == ALEO_NTT_ORDER_RR);

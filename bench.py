@@ -28,6 +28,8 @@ def main():
     ap.add_argument('--cpu-sample-lg', type=int, default=20)
     ap.add_argument('--no-precompute', action='store_true', help='skip the fixed-base window table (one-shot MSM path)')
     ap.add_argument('--no-kzg-chain', action='store_true', help='skip the secondary 2^22 iNTT -> commit measurement (config[2])')
+    ap.add_argument('--proof-proxy-lg', type=int, default=20, help='log2 constraints of the Varuna operator-schedule replay (0 = skip)')
+    ap.add_argument('--proof-proxy-cpu-lg', type=int, default=15, help='size of the same replay on the CPU oracle (cpu_baseline leg)')
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
                     help="'gloo' is only for rehearsing the N>1 path with several ranks sharing one GPU")
     args = ap.parse_args()
@@ -126,6 +128,12 @@ def main():
         }
         if world == 1 and not args.no_kzg_chain:
             out['kzg_chain_2^22'] = kzg_chain(aleo_amd, synth, torch, dev)
+        if world == 1 and args.proof_proxy_lg:
+            pb.close()
+            out['proof_proxy'] = {'2^%d' % lg_: proof_proxy_gpu(aleo_amd, synth, torch, dev, lg_)
+                                  for lg_ in sorted({args.proof_proxy_lg, args.proof_proxy_cpu_lg})}
+            out['proof_proxy']['schedule'] = PROXY_NOTE
+            pb = aleo_amd.PinnedBases.generate_multiples(gen, first, n)
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args, pb, scalars, aleo_amd)
         print(json.dumps(out), flush=True)
@@ -163,6 +171,89 @@ def kzg_chain(aleo_amd, synth, torch, dev, lg=22, reps=5):
             'commitment_x_limb0': int(np.frombuffer(cm.tobytes()[:8], dtype=np.uint64)[0])}
 
 
+PROXY_NOTE = ('operator-level proxy for constraints/s (SURVEY.md §8d): the MSM/NTT/field-op schedule of one single-instance Varuna proof with '
+              '|H| = |K| = 2^k, replayed on synthetic vectors of those sizes [schedule UPSTREAM-RECALL, see DESIGN.md §4c]; not a proof')
+
+
+def proxy_schedule(lg):
+    """[(op, arg, size)] of one Varuna prove_batch for one circuit / one instance with 2^lg constraints, variables and
+    non-zeros per matrix (snarkvm-algorithms 0.14.5 snark/varuna/ahp/prover/round_functions [UPSTREAM-RECALL]):
+    12 KZG MSMs (3 + 1 + 2 + 3 + 1 commitments, 2 openings) and the transforms between them."""
+    H = 1 << lg
+    ops = []
+    ops += [('msm', 'witness', H)] * 3 + [('ntt', (1, 0), H)] * 3                      # round 1: w, z_a, z_b (Lagrange-basis commits) + interpolation
+    ops += [('msm', 'uniform', 3 * H)]                                                  #          mask_poly, degree 3|H|
+    ops += [('ntt', (0, 1), 4 * H)] * 4 + [('vec', 0, 4 * H)] * 6 + [('ntt', (1, 1), 4 * H)]      # round 2: h_1 on the 4|H| coset
+    ops += [('ntt', (0, 0), H)] * 2 + [('msm', 'uniform', H), ('msm', 'uniform', 2 * H)]            #          g_1, h_1
+    for _ in range(3):                                                                  # round 3: g_a, g_b, g_c over K
+        ops += [('ntt', (0, 0), H)] * 2 + [('inv', 0, H)] + [('vec', 0, H)] * 4 + [('ntt', (1, 0), H), ('msm', 'uniform', H)]
+    ops += [('ntt', (0, 1), 2 * H)] * 3 + [('vec', 0, 2 * H)] * 4 + [('ntt', (1, 1), 2 * H), ('msm', 'uniform', H)]   # round 4: h_2
+    ops += [('msm', 'uniform', 3 * H)] * 2                                              # two batched KZG opening proofs
+    return ops
+
+
+def proof_proxy_gpu(aleo_amd, synth, torch, dev, lg, reps=3):
+    from aleo_amd import poly
+    H = 1 << lg
+    pb = aleo_amd.PinnedBases.generate_multiples(synth.generator_affine104(), 1, 3 * H).precompute()
+    buf = torch.from_numpy(synth.uniform_scalars(4 * H, 0xA1E00010 + lg).view(np.int64)).to(dev)      # canonical < r, read as Montgomery
+    aux = buf.clone()
+    s_uni = torch.from_numpy(synth.uniform_scalars(3 * H, 0xA1E00011 + lg).view(np.int64)).to(dev)
+    s_wit = torch.from_numpy(synth.witness_like_scalars(H, 0xA1E00012 + lg).view(np.int64)).to(dev)
+    doms = {}
+    ops = proxy_schedule(lg)
+    torch.cuda.synchronize()
+
+    def run():
+        t_msm = 0.0
+        for op, arg, size in ops:
+            if op == 'msm':
+                t0 = time.perf_counter()
+                if arg == 'witness': aleo_amd.VariableBase.msm_device(pb, s_wit.data_ptr(), size)
+                else: aleo_amd.KZG10.commit_device(pb, buf.data_ptr(), size)      # Montgomery -> canonical on the device, then MSM
+                t_msm += time.perf_counter() - t0
+            elif op == 'ntt':
+                d = doms.get(size) or doms.setdefault(size, aleo_amd.EvaluationDomain(size))
+                d.ntt_device(buf.data_ptr(), 0, arg[0], arg[1])
+            elif op == 'vec':
+                poly.fr_vec_op_device(aux.data_ptr(), aux.data_ptr(), buf.data_ptr(), size, 0)
+            else:
+                poly.batch_inversion_device(aux.data_ptr(), size)
+        torch.cuda.synchronize()
+        return t_msm
+    run()
+    ts, tm = [], []
+    for _ in range(reps):
+        t0 = time.perf_counter(); m = run(); ts.append(time.perf_counter() - t0); tm.append(m)
+    pb.close()
+    dt = float(np.median(ts)); m = float(np.median(tm))
+    return {'constraints': H, 'ms': dt * 1e3, 'constraints_per_s': H / dt, 'msm_ms': m * 1e3, 'ntt_and_field_ms': (dt - m) * 1e3,
+            'n_msm': sum(1 for o in ops if o[0] == 'msm'), 'n_ntt': sum(1 for o in ops if o[0] == 'ntt')}
+
+
+def proof_proxy_cpu(c, aleo_amd, synth, lg, cores):
+    """The same schedule through the oracle (MSMs on `cores` threads, transforms and field ops on one)."""
+    H = 1 << lg
+    with aleo_amd.PinnedBases.generate_multiples(synth.generator_affine104(), 1, 3 * H) as pb:
+        bases = pb.download()
+    buf = synth.uniform_scalars(4 * H, 0xA1E00010 + lg); aux = buf.copy()
+    s_uni = synth.uniform_scalars(3 * H, 0xA1E00011 + lg); s_wit = synth.witness_like_scalars(H, 0xA1E00012 + lg)
+    t0 = time.perf_counter(); t_msm = 0.0
+    for op, arg, size in proxy_schedule(lg):
+        if op == 'msm':
+            t1 = time.perf_counter()
+            c.msm_g1(bases[:size], (s_wit if arg == 'witness' else s_uni)[:size], threads=cores, variant=1)
+            t_msm += time.perf_counter() - t1
+        elif op == 'ntt':
+            buf[:size] = c.ntt_fr(buf[:size], 0, arg[0], arg[1])
+        elif op == 'vec':
+            aux[:size] = c.fr_vec_op(aux[:size], buf[:size], 0)
+        else:
+            aux[:size] = c.fr_batch_inverse(aux[:size])
+    dt = time.perf_counter() - t0
+    return {'constraints': H, 'seconds': dt, 'constraints_per_s': H / dt, 'msm_seconds': t_msm, 'msm_threads': cores, 'other_threads': 1}
+
+
 def cpu_baseline(args, pb, scalars, aleo_amd):
     """The oracle (C restatement of snarkVM's batched Pippenger, all host cores) on a bounded sample of the same
     workload; also re-checks GPU == oracle on that sample.  kind 'port': it is not the Rust binary."""
@@ -177,7 +268,11 @@ def cpu_baseline(args, pb, scalars, aleo_amd):
     c.msm_g1(bases[:256], s[:256], threads=1, variant=1)                    # load the library outside the timing
     t0 = time.perf_counter(); ref = c.msm_g1(bases, s, threads=cores, variant=1); dt = time.perf_counter() - t0
     got = aleo_amd.VariableBase.msm(pb, s)
-    return {'value': ns / dt, 'unit': 'scalar-muls/s', 'cores': cores, 'kind': 'port', 'seconds': dt,
+    proxy = None
+    if args.proof_proxy_lg and args.proof_proxy_cpu_lg:
+        from aleo_amd import synth
+        proxy = proof_proxy_cpu(c, aleo_amd, synth, args.proof_proxy_cpu_lg, os.cpu_count() or 1)
+    return {'proof_proxy': proxy, 'value': ns / dt, 'unit': 'scalar-muls/s', 'cores': cores, 'kind': 'port', 'seconds': dt,
             'host_cpus': os.cpu_count(),
             'sample': '2^%d-point prefix of the same bases/scalars; C restatement of snarkvm-algorithms 0.14.5 batched MSM, '
                       'not the Rust binary' % (ns.bit_length() - 1),

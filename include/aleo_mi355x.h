@@ -27,7 +27,9 @@
  * group elements after to_affine(), never raw Jacobian limbs.
  *
  * Threading: every entry point may be called concurrently from many host threads (snarkVM commits the
- * polynomials of one round from a rayon pool); calls on one device serialise on an internal lock.
+ * polynomials of one round from a rayon pool).  Each call runs on one of the device's slots (own stream and
+ * workspaces; ALEO_MI355X_SLOTS = 1..8, default 4), so concurrent calls overlap on the GPU; a pinned set
+ * stays alive until the calls using it return, even if another thread unpins it meanwhile.
  * Ownership: the caller owns every buffer; nothing is retained after return except through bases_pin.
  * No exceptions cross the boundary.
  */
@@ -121,7 +123,7 @@ int32_t aleo_mi355x_fr_batch_inverse_device(void* d_inout, size_t n, void* strea
 int32_t aleo_mi355x_fq_mul(void* r, const void* a, const void* b, size_t n);
 int32_t aleo_mi355x_fr_mul(void* r, const void* a, const void* b, size_t n);
 
-/* Per-call instrumentation of the last MSM on this thread's device: milliseconds per phase
+/* Per-call instrumentation of the calling thread's most recent MSM: milliseconds per phase
  * [0] total, [1] digit/sort, [2] bucket accumulation incl. slice tree, [3] bucket reduction, [4] host tail,
  * [5] the bucket-accumulation kernel alone (the dominant kernel bench.py prices against the roofline).
  * Returns the number of doubles written (<= cap). */

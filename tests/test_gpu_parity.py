@@ -354,6 +354,38 @@ def test_concurrent_callers_share_the_device_safely():
     assert got == exp
 
 
+def test_concurrent_slots_share_one_pinned_set():
+    """Calls from different threads run on different slots (own stream + workspaces) against ONE pinned set: the table
+    build races with running MSMs, and an unpin from another thread must not free the set under a call in flight."""
+    import threading, torch
+    n = 1 << 16
+    pb = M.PinnedBases.generate_multiples(synth.generator_affine104(), 1, n)
+    S = [util.uniform_scalars(n, 7100 + t) for t in range(4)]
+    dS = [torch.from_numpy(x.view(np.int64)).cuda() for x in S]; torch.cuda.synchronize()
+    exp = [util.expected_multiples_msm(x, n) for x in S]
+    errs = []; started = threading.Barrier(5)
+
+    def work(t):
+        try:
+            torch.cuda.set_device(0); started.wait()
+            for _ in range(6):
+                assert c.jac_to_int_point(M.VariableBase.msm_device(pb, dS[t].data_ptr(), n)) == exp[t]
+        except Exception as e:      # noqa: BLE001
+            errs.append(e)
+    ths = [threading.Thread(target=work, args=(t,)) for t in range(4)]
+    for t in ths: t.start()
+    started.wait()
+    pb.precompute()                      # published while the workers are mid-flight: later calls switch to the table path
+    for t in ths: t.join()
+    assert not errs, errs
+    out = []
+    th = threading.Thread(target=lambda: (torch.cuda.set_device(0), out.append(c.jac_to_int_point(M.VariableBase.msm_device(pb, dS[0].data_ptr(), n)))))
+    th.start(); pb.close(); th.join()    # the unpin either lands first (clean BAD_HANDLE error in the thread) or the call keeps the set alive
+    assert out == [] or out == [exp[0]]
+    tm = M.last_msm_timing()             # per calling thread: this thread ran no MSM since precompute
+    assert set(tm) >= {'total_ms', 'accum_kernel_ms'}
+
+
 def test_cpp_host_mirror(tmp_path):
     """The C++ host side above the C ABI (include/aleo_mi355x.hpp), exercised like a snarkVM unit test."""
     import subprocess
