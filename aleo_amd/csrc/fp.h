@@ -63,7 +63,13 @@ template <class Pm> struct Fp {
     if constexpr (N == 12) mont_mul_12_inplace(r.v, b.v); else mont_mul_8_inplace(r.v, b.v);
     return r;
   }
-  __device__ __forceinline__ static Fp sqr(const Fp& a) { return mul(a, a); }
+  // Montgomery square: N(N+1)/2 limb products instead of N^2 (fp_mont_gen.h).  Needs a < 2^(32N-1): every lazy bound in
+  // use (Fq < 16q < 2^381, Fr < 8r < 2^256 only up to 4r < 2^255) — callers keep Fr squares below 4r.
+  __device__ __forceinline__ static Fp sqr(const Fp& a) {
+    Fp r = a;
+    if constexpr (N == 12) mont_sqr_12_inplace(r.v); else mont_sqr_8_inplace(r.v);
+    return r;
+  }
 
   // a + b, no reduction.  Caller guarantees the sum stays below 2^(32N).
   __device__ __forceinline__ static Fp add(const Fp& a, const Fp& b) {

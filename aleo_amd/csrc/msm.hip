@@ -880,11 +880,11 @@ int32_t msm_precompute(Ctx* c, PinnedBases* pb) {
 }
 
 // ---- element-wise products (parity tests pin the device arithmetic with these) -------------------
-template <class F> __global__ void __launch_bounds__(256) k_fp_mul(char* r, const char* a, const char* b, uint32_t n) {
+template <class F, bool SQR> __global__ void __launch_bounds__(256) k_fp_mul(char* r, const char* a, const char* b, uint32_t n) {
   uint32_t i = blockIdx.x * 256 + threadIdx.x; if (i >= n) return;
   constexpr int bytes = F::N * 4;
   F x = load_fp<F>(a + (size_t)i * bytes), y = load_fp<F>(b + (size_t)i * bytes);
-  store_fp<F>(r + (size_t)i * bytes, F::reduce(F::mul(x, y)));
+  store_fp<F>(r + (size_t)i * bytes, F::reduce(SQR ? F::sqr(x) : F::mul(x, y)));
 }
 template <class F> static int32_t launch_fp_mul(Ctx* c, void* r, const void* a, const void* b, size_t n) {
   constexpr size_t bytes = F::N * 4;
@@ -893,7 +893,10 @@ template <class F> static int32_t launch_fp_mul(Ctx* c, void* r, const void* a, 
   char* da = c->scalars_stage.as<char>(); char* db = da + n * bytes; char* dr = db + n * bytes;
   HIPCHK(hipMemcpyAsync(da, a, n * bytes, hipMemcpyHostToDevice, c->stream));
   HIPCHK(hipMemcpyAsync(db, b, n * bytes, hipMemcpyHostToDevice, c->stream));
-  hipLaunchKernelGGL((k_fp_mul<F>), dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, c->stream, dr, da, db, (uint32_t)n);
+  if (a == b)     // same host buffer for both operands: pin the dedicated squaring block instead of the general product
+    hipLaunchKernelGGL((k_fp_mul<F, true>), dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, c->stream, dr, da, db, (uint32_t)n);
+  else
+    hipLaunchKernelGGL((k_fp_mul<F, false>), dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, c->stream, dr, da, db, (uint32_t)n);
   HIPCHK(hipMemcpyAsync(r, dr, n * bytes, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
   HIPCHK(hipGetLastError());

@@ -119,7 +119,8 @@ int32_t aleo_mi355x_fr_vec_op_device(void* d_dst, const void* d_a, const void* d
 int32_t aleo_mi355x_fr_batch_inverse_device(void* d_inout, size_t n, void* stream);
 
 /* Element-wise field products on the device (host pointers): r[i] = a[i]*b[i], Montgomery form, canonical
- * output.  Used by the parity tests to pin the device arithmetic against the oracle limb for limb. */
+ * output.  Used by the parity tests to pin the device arithmetic against the oracle limb for limb; when a and b
+ * are the same buffer the dedicated squaring block runs instead of the general product. */
 int32_t aleo_mi355x_fq_mul(void* r, const void* a, const void* b, size_t n);
 int32_t aleo_mi355x_fr_mul(void* r, const void* a, const void* b, size_t n);
 

@@ -36,10 +36,16 @@ def test_fq_fr_products_bit_exact():
     a[0] = 0; b[1] = 0; a[2] = c.ints_to_limbs([p.FQ_MODULUS - 1], 6)[0]; b[2] = a[2]     # edge operands
     e = np.zeros_like(a); c.lib().oracle_fq_mul(c._p(e), c._p(a), c._p(b), n)
     assert (M.fq_mul(a, b) == e).all()
+    a[3] = c.ints_to_limbs([(1 << 377) - 1], 6)[0]; a[4, :] = np.uint64(0xffffffffffffffff); a[4, 5] = np.uint64((1 << 58) - 1)   # unreduced operands: carries between the doubled limbs
+    e = np.zeros_like(a); c.lib().oracle_fq_mul(c._p(e), c._p(a), c._p(a), n)
+    assert (M.fq_mul(a, a) == e).all()                         # same buffer twice -> the squaring block
     x, y = util.uniform_scalars(n, 5), util.uniform_scalars(n, 6)
     x[0] = 0; x[1] = c.ints_to_limbs([p.FR_MODULUS - 1], 4)[0]; y[1] = x[1]
     e = np.zeros_like(x); c.lib().oracle_fr_mul(c._p(e), c._p(x), c._p(y), n)
     assert (M.fr_mul(x, y) == e).all()
+    x[2, :] = np.uint64(0xffffffffffffffff); x[2, 3] = np.uint64((1 << 62) - 1)
+    e = np.zeros_like(x); c.lib().oracle_fr_mul(c._p(e), c._p(x), c._p(x), n)
+    assert (M.fr_mul(x, x) == e).all()
 
 
 # ---- NTT ----------------------------------------------------------------------------------------------
