@@ -42,7 +42,9 @@ static int pre_c_for(size_t pinned_n) { return pinned_n >= (1u << 19) ? 20 : (pi
 static MsmPlan make_plan(size_t n, int pre_c) {
   MsmPlan p;
   if (pre_c) {   // one shared bucket set: "W = 1 window of 2^(c-1) buckets" for everything after the sort
-    p.c = (uint32_t)pre_c; p.W = 1; p.B = 1u << (pre_c - 1); p.M = p.B; p.S = 8;
+    // running-sum chunk: 2S dependent additions per lane pair vs. one more level of masked sums per halving; measured
+    // best at 16 for 2^19 buckets (enough chunks to fill the chip) and 4 for 2^15..2^16 buckets (latency only)
+    p.c = (uint32_t)pre_c; p.W = 1; p.B = 1u << (pre_c - 1); p.M = p.B; p.S = pre_c >= 20 ? 16 : 4;
     return p;
   }
   uint32_t lg = 0; while (((size_t)1 << (lg + 1)) <= n) ++lg;
@@ -185,39 +187,135 @@ __global__ void __launch_bounds__(256) k_part_scatter(const void* scalars, const
   }
 }
 
-// Level 2: one block per coarse bin.  Writes hist[g] for the bin's 2^LB buckets and the sorted index stream.
-__global__ void __launch_bounds__(256) k_bin_sort(const uint2* __restrict__ items, const uint32_t* __restrict__ off_local, const uint32_t* __restrict__ off_blk,
-                                                  uint32_t nblk, uint32_t ncb, uint32_t cnt_tiles, uint32_t LB, uint32_t* __restrict__ hist, uint32_t* __restrict__ sorted) {
-  __shared__ uint32_t h[256], o[256];
-  const uint32_t bin = blockIdx.x, tid = threadIdx.x;
-  const uint32_t start = scan32_at(off_local, off_blk, (size_t)bin * nblk);
-  const uint32_t end = (bin + 1 < ncb) ? scan32_at(off_local, off_blk, (size_t)(bin + 1) * nblk) : off_blk[cnt_tiles];
+// Level 2: the low LB bucket bits.  A coarse bin is cut into parts of BIN_PART items, one block each, so a bin that
+// skewed scalars overfill (a fifth of a witness vector is the constant 1: one bucket, one bin) is sorted by many blocks
+// instead of one (it was 1.5 ms of a 4.1 ms MSM at 2^22), and every part is ranked and staged in LDS so that the index
+// stream is written in runs per bucket rather than as scattered 4-byte stores (64-byte write granules: 3.5 GB for 54 M
+// stores at 2^22).  k_bin_hist adds the parts' LDS histograms into hist[]; k_bin_scatter claims each part's range
+// of a bucket with one global atomic per (part, bucket).
+static constexpr uint32_t BIN_PART = 4096;
+
+__global__ void __launch_bounds__(256) k_bin_parts(const uint32_t* __restrict__ off_local, const uint32_t* __restrict__ off_blk, uint32_t nblk, uint32_t ncb,
+                                                   uint32_t cnt_tiles, uint32_t* __restrict__ part_start) {
+  __shared__ uint32_t wsum[4];
+  const uint32_t tid = threadIdx.x; const int lane = tid & 63, wv = tid >> 6;
+  uint32_t pre[8], run = 0;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const uint32_t bin = tid * 8 + k; pre[k] = run;
+    if (bin < ncb) {
+      const uint32_t st = scan32_at(off_local, off_blk, (size_t)bin * nblk);
+      const uint32_t en = (bin + 1 < ncb) ? scan32_at(off_local, off_blk, (size_t)(bin + 1) * nblk) : off_blk[cnt_tiles];
+      run += (en - st + BIN_PART - 1) / BIN_PART;
+    }
+  }
+  uint32_t inc = run;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) { uint32_t o = __shfl_up(inc, d); if (lane >= d) inc += o; }
+  if (lane == 63) wsum[wv] = inc;
+  __syncthreads();
+  uint32_t woff = 0; for (int k = 0; k < wv; ++k) woff += wsum[k];
+  const uint32_t excl = woff + inc - run;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) if (tid * 8 + k < ncb) part_start[tid * 8 + k] = excl + pre[k];
+  if (tid == 255) part_start[ncb] = woff + inc;
+}
+
+struct BinPart { uint32_t bin, bstart, lo, hi; bool live; };
+__device__ __forceinline__ BinPart locate_part(const uint32_t* __restrict__ off_local, const uint32_t* __restrict__ off_blk, uint32_t nblk, uint32_t ncb,
+                                               uint32_t cnt_tiles, const uint32_t* __restrict__ part_start) {
+  BinPart r; r.live = blockIdx.x < part_start[ncb];
+  if (!r.live) return r;
+  uint32_t lo = 0, hi = ncb;                           // largest bin with part_start[bin] <= block (empty bins share their successor's start)
+  while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (part_start[mid] <= blockIdx.x) lo = mid; else hi = mid; }
+  r.bin = lo;
+  r.bstart = scan32_at(off_local, off_blk, (size_t)lo * nblk);
+  const uint32_t bend = (lo + 1 < ncb) ? scan32_at(off_local, off_blk, (size_t)(lo + 1) * nblk) : off_blk[cnt_tiles];
+  r.lo = r.bstart + (blockIdx.x - part_start[lo]) * BIN_PART;
+  r.hi = r.lo + BIN_PART < bend ? r.lo + BIN_PART : bend;
+  return r;
+}
+
+// Rank of each of the wave's keys in the block's LDS histogram.  The lanes that share the first lane's key go through one
+// LDS atomic (the all-equal case of skewed scalars would otherwise serialise 4096 atomics on one address).
+__device__ __forceinline__ uint32_t lds_rank(uint32_t* h, uint32_t key, bool valid, int lane) {
+  const uint64_t vm = __ballot(valid);
+  if (!vm) return 0u;
+  const int first = __ffsll((unsigned long long)vm) - 1;
+  const uint32_t k0 = __shfl(key, first);
+  const bool grp = valid && key == k0;
+  const uint64_t same = __ballot(grp);
+  uint32_t base = 0;
+  if (lane == first) base = atomicAdd(&h[k0], (uint32_t)__popcll(same));
+  base = __shfl(base, first);
+  if (grp) return base + (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
+  return valid ? atomicAdd(&h[key], 1u) : 0u;
+}
+
+__device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* wsum, int lane, int wv) {    // 256 threads; wsum: 4 words of LDS
+  uint32_t inc = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) { uint32_t o = __shfl_up(inc, d); if (lane >= d) inc += o; }
+  __syncthreads();
+  if (lane == 63) wsum[wv] = inc;
+  __syncthreads();
+  uint32_t woff = 0; for (int k = 0; k < wv; ++k) woff += wsum[k];
+  return woff + inc - v;
+}
+
+__global__ void __launch_bounds__(256) k_bin_hist(const uint2* __restrict__ items, const uint32_t* __restrict__ off_local, const uint32_t* __restrict__ off_blk,
+                                                  uint32_t nblk, uint32_t ncb, uint32_t cnt_tiles, uint32_t LB, const uint32_t* __restrict__ part_start,
+                                                  uint32_t* __restrict__ hist) {
+  __shared__ uint32_t h[256];
+  const uint32_t tid = threadIdx.x; const int lane = tid & 63;
+  const BinPart P = locate_part(off_local, off_blk, nblk, ncb, cnt_tiles, part_start);
+  if (!P.live) return;
   h[tid] = 0;
   __syncthreads();
-  for (uint32_t i0 = start; i0 < end; i0 += 256 * 4) {
-    uint32_t key[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) { uint32_t i = i0 + u * 256 + tid; key[u] = i < end ? items[i].y : 0xffffffffu; }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) if (key[u] != 0xffffffffu) atomicAdd(&h[key[u]], 1u);
+#pragma unroll 4
+  for (uint32_t u = 0; u < BIN_PART / 256; ++u) {
+    const uint32_t i = P.lo + u * 256 + tid; const bool valid = i < P.hi;
+    const uint32_t key = valid ? items[i].y : 0u;
+    (void)lds_rank(h, key, valid, lane);
   }
   __syncthreads();
   const uint32_t v = h[tid];
-  if (tid < (1u << LB)) hist[((size_t)bin << LB) + tid] = v;
-  o[tid] = v; __syncthreads();
-  for (int d = 1; d < 256; d <<= 1) {
-    uint32_t t = tid >= (uint32_t)d ? o[tid - d] : 0u;
-    __syncthreads(); o[tid] += t; __syncthreads();
-  }
-  h[tid] = start + o[tid] - v;          // absolute cursor of fine bucket tid
+  if (v && tid < (1u << LB)) atomicAdd(&hist[((size_t)P.bin << LB) + tid], v);
+}
+
+__global__ void __launch_bounds__(256) k_bin_scatter(const uint2* __restrict__ items, const uint32_t* __restrict__ off_local, const uint32_t* __restrict__ off_blk,
+                                                     uint32_t nblk, uint32_t ncb, uint32_t cnt_tiles, uint32_t LB, const uint32_t* __restrict__ part_start,
+                                                     const uint32_t* __restrict__ hist, uint32_t* __restrict__ cursor, uint32_t* __restrict__ sorted) {
+  __shared__ uint32_t h[256], gb[256], wsum[4];
+  __shared__ uint32_t l_idx[BIN_PART], l_dst[BIN_PART];
+  const uint32_t tid = threadIdx.x; const int lane = tid & 63, wv = tid >> 6;
+  const BinPart P = locate_part(off_local, off_blk, nblk, ncb, cnt_tiles, part_start);
+  if (!P.live) return;
+  h[tid] = 0;
   __syncthreads();
-  for (uint32_t i0 = start; i0 < end; i0 += 256 * 4) {
-    uint2 it[4];
+  constexpr int U = BIN_PART / 256;
+  uint2 it[U]; uint32_t rank[U];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) { uint32_t i = i0 + u * 256 + tid; it[u] = i < end ? items[i] : make_uint2(0u, 0xffffffffu); }
+  for (int u = 0; u < U; ++u) { const uint32_t i = P.lo + u * 256 + tid; it[u] = i < P.hi ? items[i] : make_uint2(0u, 0xffffffffu); }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) if (it[u].y != 0xffffffffu) sorted[atomicAdd(&h[it[u].y], 1u)] = it[u].x;
+  for (int u = 0; u < U; ++u) rank[u] = lds_rank(h, it[u].y, it[u].y != 0xffffffffu, lane);
+  __syncthreads();
+  const uint32_t v = h[tid];                                                 // this part's count of bucket tid
+  const uint32_t loff = block_excl_scan(v, wsum, lane, wv);                  // its offset inside the part's sorted tile
+  const uint32_t g = tid < (1u << LB) ? hist[((size_t)P.bin << LB) + tid] : 0u;
+  const uint32_t gexcl = block_excl_scan(g, wsum, lane, wv);                 // the bucket's offset inside the bin
+  gb[tid] = P.bstart + gexcl + (v ? atomicAdd(&cursor[((size_t)P.bin << LB) + tid], v) : 0u);
+  __syncthreads();
+  h[tid] = loff;
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < U; ++u) if (it[u].y != 0xffffffffu) {
+    const uint32_t lp = h[it[u].y] + rank[u];
+    l_idx[lp] = it[u].x; l_dst[lp] = gb[it[u].y] + rank[u];
   }
+  __syncthreads();
+  const uint32_t cnt = P.hi - P.lo;
+  for (uint32_t q = tid; q < cnt; q += 256) sorted[l_dst[q]] = l_idx[q];
 }
 
 // ---- exclusive scan of (count, slices) over the M buckets --------------------------------------
@@ -619,8 +717,9 @@ int32_t msm_run(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, const void* 
   // pick_rule() keeps the slice count near 2^19..2^20 (+ one per bucket) until its 256-point cap takes over
   const size_t slices_max = pairs_max / 128 + 2 * (size_t)M + (1u << 21);
   int32_t rc;
-  // hist | cursor | meta live in one zero-initialised allocation
-  if ((rc = c->hist.reserve((2 * (size_t)M + 2048 + SUPER_CAP) * 4))) return rc;
+  // hist | heavy list | meta | super list | level-2 cursors live in one zero-initialised allocation
+  const size_t hist_words = 3 * (size_t)M + 2048 + SUPER_CAP;
+  if ((rc = c->hist.reserve(hist_words * 4))) return rc;
   if ((rc = c->scan_local.reserve((size_t)M * 8))) return rc;
   if ((rc = c->scan_blk.reserve(2 * (size_t)ntiles * 8 + 64))) return rc;
   if ((rc = c->sorted.reserve(pairs_max * 4))) return rc;
@@ -629,7 +728,7 @@ int32_t msm_run(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, const void* 
   const size_t cnt_len = (size_t)ncb * nblk;
   if (cnt_len >= (1ull << 32)) { g_last_error = "msm: partition table too large"; return ALEO_MI355X_ERR_BAD_ARG; }
   const uint32_t cnt_tiles = (uint32_t)((cnt_len + SCAN_TILE - 1) / SCAN_TILE);
-  if ((rc = c->part_cnt.reserve((2 * cnt_len + 2 * (size_t)cnt_tiles + 8) * 4))) return rc;     // cnt | off_local | tile_tot | off_blk
+  if ((rc = c->part_cnt.reserve((2 * cnt_len + 2 * (size_t)cnt_tiles + 16 + MAX_COARSE) * 4))) return rc;     // cnt | off_local | tile_tot | off_blk | part_start
   if ((rc = c->part_items.reserve(pairs_max * 8))) return rc;
   if ((rc = c->partial.reserve(slices_max * 192))) return rc;
   if ((rc = c->task_g.reserve(2 * slices_max * 4))) return rc;     // task_g | order
@@ -641,6 +740,7 @@ int32_t msm_run(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, const void* 
   if ((rc = ensure_host_pinned(c, 64 + (size_t)(P.W + lgN + 5) * 192))) return rc;
 
   uint32_t* hist = c->hist.as<uint32_t>(); uint32_t* heavy = hist + M; uint32_t* meta = heavy + M;     // heavy: <= M bucket ids
+  uint32_t* bin_cursor = hist + 2 * (size_t)M + 2048 + SUPER_CAP;
   uint2* scan_local = c->scan_local.as<uint2>();
   uint2* tile_tot = c->scan_blk.as<uint2>(); uint2* scan_blk = tile_tot + ntiles;
   uint32_t* sorted = c->sorted.as<uint32_t>(); char* partial = c->partial.as<char>(); uint32_t* task_g = c->task_g.as<uint32_t>(); uint32_t* order = task_g + slices_max;
@@ -648,18 +748,22 @@ int32_t msm_run(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, const void* 
   const char* bases = (const char*)(pre ? pb.d_pre : pb.d_xy);
 
   HIPCHK(hipEventRecord(c->ev[0], s));
-  HIPCHK(hipMemsetAsync(hist, 0, (2 * (size_t)M + 2048 + SUPER_CAP) * 4, s));
+  HIPCHK(hipMemsetAsync(hist, 0, hist_words * 4, s));
   SortArgs sa;
   sa.scalars = d_scalars; sa.inf = pb.d_inf; sa.n = (uint32_t)n; sa.nblk = nblk; sa.row_stride = (uint32_t)pb.n;
   sa.cnt = c->part_cnt.as<uint32_t>(); sa.off_local = sa.cnt + cnt_len;
   uint32_t* cnt_tile_tot = sa.off_local + cnt_len; sa.off_blk = cnt_tile_tot + cnt_tiles;
   sa.items = c->part_items.as<uint2>();
   const uint32_t* total_pairs = sa.off_blk + cnt_tiles;          // grand total of the level-1 scan
+  uint32_t* part_start = sa.off_blk + cnt_tiles + 4;             // ncb + 1 prefix counts of the level-2 parts
+  const uint32_t nparts_max = ncb + (uint32_t)(pairs_max / BIN_PART) + 1;
   if (scalars_are_mont) launch_sort<true>(P.c, pre, sa, 0, s); else launch_sort<false>(P.c, pre, sa, 0, s);
   hipLaunchKernelGGL(k_scan32_tiles, dim3(cnt_tiles), dim3(256), 0, s, sa.cnt, (uint32_t)cnt_len, sa.off_local, cnt_tile_tot);
   hipLaunchKernelGGL(k_scan32_top, dim3(1), dim3(256), 0, s, cnt_tile_tot, cnt_tiles, sa.off_blk);
   if (scalars_are_mont) launch_sort<true>(P.c, pre, sa, 1, s); else launch_sort<false>(P.c, pre, sa, 1, s);
-  hipLaunchKernelGGL(k_bin_sort, dim3(ncb), dim3(256), 0, s, sa.items, sa.off_local, sa.off_blk, nblk, ncb, cnt_tiles, LB, hist, sorted);
+  hipLaunchKernelGGL(k_bin_parts, dim3(1), dim3(256), 0, s, sa.off_local, sa.off_blk, nblk, ncb, cnt_tiles, part_start);
+  hipLaunchKernelGGL(k_bin_hist, dim3(nparts_max), dim3(256), 0, s, sa.items, sa.off_local, sa.off_blk, nblk, ncb, cnt_tiles, LB, part_start, hist);
+  hipLaunchKernelGGL(k_bin_scatter, dim3(nparts_max), dim3(256), 0, s, sa.items, sa.off_local, sa.off_blk, nblk, ncb, cnt_tiles, LB, part_start, hist, bin_cursor, sorted);
   hipLaunchKernelGGL(k_scan_tiles, dim3(ntiles), dim3(256), 0, s, hist, M, total_pairs, scan_local, tile_tot, meta, heavy);
   hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(256), 0, s, tile_tot, ntiles, scan_blk, meta);
   // slice count / max slices per bucket decide the grid of the accumulation and the number of tree passes

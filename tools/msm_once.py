@@ -11,11 +11,12 @@ aleo_amd._lib.check(aleo_amd.lib().aleo_mi355x_init(0), 'init')
 pb = M.PinnedBases.generate_multiples(synth.generator_affine104(), 1, n)
 if pre: pb.precompute()
 seed = int(sys.argv[3], 0) if len(sys.argv) > 3 else 5
-s = torch.from_numpy(synth.uniform_scalars(n, seed).view(np.int64)).cuda(); torch.cuda.synchronize()
+mk = synth.witness_like_scalars if 'witness' in sys.argv else synth.uniform_scalars
+s = torch.from_numpy(mk(n, seed).view(np.int64)).cuda(); torch.cuda.synchronize()
 for _ in range(6): M.VariableBase.msm_device(pb, s.data_ptr(), n)
 print(M.last_msm_timing())
 if len(sys.argv) > 4 and sys.argv[4] == 'check':
-    sc = synth.uniform_scalars(n, seed)
+    sc = mk(n, seed)
     got = M.VariableBase.msm_device(pb, s.data_ptr(), n)
     k = synth.weighted_scalar_sum(sc, 1)
     kG = M.VariableBase.msm(synth.generator_affine104().reshape(1, 104), synth.int_to_limbs(k, 4).reshape(1, 4))
