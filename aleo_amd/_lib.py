@@ -11,7 +11,7 @@ EXPORTS = [
     'aleo_mi355x_init', 'aleo_mi355x_msm_g1', 'aleo_mi355x_bases_pin', 'aleo_mi355x_bases_unpin',
     'aleo_mi355x_bases_generate', 'aleo_mi355x_bases_download', 'aleo_mi355x_bases_precompute',
     'aleo_mi355x_msm_g1_pinned', 'aleo_mi355x_msm_g1_device', 'aleo_mi355x_g1_sum', 'aleo_mi355x_ntt_fr',
-    'aleo_mi355x_ntt_fr_device', 'aleo_mi355x_kzg_commit', 'aleo_mi355x_kzg_commit_device', 'aleo_mi355x_kzg_commit_hiding',
+    'aleo_mi355x_ntt_fr_device', 'aleo_mi355x_ntt_fr_batch_device', 'aleo_mi355x_fr_grid_scale_device', 'aleo_mi355x_kzg_commit', 'aleo_mi355x_kzg_commit_device', 'aleo_mi355x_kzg_commit_hiding',
     'aleo_mi355x_fr_vec_op_device', 'aleo_mi355x_fr_batch_inverse_device', 'aleo_mi355x_fq_mul',
     'aleo_mi355x_fr_mul', 'aleo_mi355x_last_msm_timing', 'aleo_mi355x_strerror', 'aleo_mi355x_last_error',
     'aleo_mi355x_version',
@@ -54,6 +54,8 @@ def lib():
         'aleo_mi355x_g1_sum': ([vp, vp, sz], i32),
         'aleo_mi355x_ntt_fr': ([vp, u32, i32, i32, i32], i32),
         'aleo_mi355x_ntt_fr_device': ([vp, u32, i32, i32, i32, vp], i32),
+        'aleo_mi355x_ntt_fr_batch_device': ([vp, u32, sz, i32, i32, i32, vp], i32),
+        'aleo_mi355x_fr_grid_scale_device': ([vp, u32, u64, u64, u64, u64, u64, i32, i32, vp], i32),
         'aleo_mi355x_kzg_commit': ([vp, u64, vp, sz], i32),
         'aleo_mi355x_kzg_commit_device': ([vp, u64, vp, sz, vp], i32),
         'aleo_mi355x_kzg_commit_hiding': ([vp, u64, vp, sz, u64, vp, sz], i32),

@@ -399,7 +399,7 @@ int32_t aleo_mi355x_ntt_fr(void* inout, uint32_t lg_n, int32_t order, int32_t di
     size_t bytes = ((size_t)1 << lg_n) * 32;
     int32_t rc; if ((rc = c->ntt_stage.reserve(bytes))) return rc;
     HIPCHK(hipMemcpyAsync(c->ntt_stage.p, inout, bytes, hipMemcpyHostToDevice, c->stream));
-    if ((rc = ntt_run(c, c->ntt_stage.p, lg_n, order, direction, type, c->stream))) return rc;
+    if ((rc = ntt_run(c, c->ntt_stage.p, lg_n, 1, order, direction, type, c->stream))) return rc;
     HIPCHK(hipMemcpyAsync(inout, c->ntt_stage.p, bytes, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     return ALEO_MI355X_OK;
@@ -410,7 +410,24 @@ int32_t aleo_mi355x_ntt_fr_device(void* d_inout, uint32_t lg_n, int32_t order, i
   try {
     if (!d_inout || lg_n > 30 || order < 0 || order > 3 || direction < 0 || direction > 1 || type < 0 || type > 1) { g_last_error = "ntt_fr_device: bad argument"; return ALEO_MI355X_ERR_BAD_ARG; }
     API_BEGIN
-    return ntt_run(c, d_inout, lg_n, order, direction, type, stream ? (hipStream_t)stream : c->stream);
+    return ntt_run(c, d_inout, lg_n, 1, order, direction, type, stream ? (hipStream_t)stream : c->stream);
+  } catch (...) { return ALEO_MI355X_ERR_HIP; }
+}
+
+int32_t aleo_mi355x_ntt_fr_batch_device(void* d_inout, uint32_t lg_n, size_t batch, int32_t order, int32_t direction, int32_t type, void* stream) {
+  try {
+    if ((!d_inout && batch) || lg_n > 30 || order < 0 || order > 3 || direction < 0 || direction > 1 || type < 0 || type > 1) { g_last_error = "ntt_fr_batch_device: bad argument"; return ALEO_MI355X_ERR_BAD_ARG; }
+    API_BEGIN
+    return ntt_run(c, d_inout, lg_n, batch, order, direction, type, stream ? (hipStream_t)stream : c->stream);
+  } catch (...) { return ALEO_MI355X_ERR_HIP; }
+}
+
+int32_t aleo_mi355x_fr_grid_scale_device(void* d_data, uint32_t lg_n, uint64_t rows, uint64_t cols, uint64_t row0, uint64_t col0, uint64_t ld,
+                                         int32_t mode, int32_t direction, void* stream) {
+  try {
+    if ((!d_data && rows && cols) || lg_n == 0 || lg_n > 40 || mode < 0 || mode > 1 || direction < 0 || direction > 1) { g_last_error = "fr_grid_scale_device: bad argument"; return ALEO_MI355X_ERR_BAD_ARG; }
+    API_BEGIN
+    return fr_grid_scale(c, d_data, lg_n, rows, cols, row0, col0, ld, mode, direction, stream ? (hipStream_t)stream : c->stream);
   } catch (...) { return ALEO_MI355X_ERR_HIP; }
 }
 

@@ -106,6 +106,9 @@ int32_t msm_precompute(Ctx* c, PinnedBases* pb);
 int32_t fr_vec_op(Ctx* c, void* d_dst, const void* d_a, const void* d_b, size_t n, int32_t op, hipStream_t s);
 int32_t fr_batch_inverse(Ctx* c, void* d_inout, size_t n, hipStream_t s);
 // ntt.hip
-int32_t ntt_run(Ctx* c, void* d_inout, uint32_t lg_n, int32_t order, int32_t direction, int32_t type, hipStream_t s);
+int32_t ntt_run(Ctx* c, void* d_inout, uint32_t lg_n, size_t batch, int32_t order, int32_t direction, int32_t type, hipStream_t s);
+
+int32_t fr_grid_scale(Ctx* c, void* d_data, uint32_t lg_n, uint64_t rows, uint64_t cols, uint64_t row0, uint64_t col0, uint64_t ld, int32_t mode,
+                      int32_t direction, hipStream_t s);
 
 }  // namespace aleo_mi355x

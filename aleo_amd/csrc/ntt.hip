@@ -88,6 +88,7 @@ __global__ void __launch_bounds__(NT) k_ntt_strided(const char* src, char* dst, 
                                                      const char* __restrict__ tw_hi, const char* __restrict__ tw_lo,
                                                      const char* __restrict__ cs_hi, const char* __restrict__ cs_lo, int pre_coset) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+  src += (size_t)blockIdx.y << (lg_n + 5); dst += (size_t)blockIdx.y << (lg_n + 5);      // blockIdx.y: independent transform of a batch
   const uint32_t L = 1u << lgL, T = 1u << lgT, tiles_per_a = 1u << (lgBn - lgT);
   const uint32_t a = blockIdx.x / tiles_per_a, b0 = (blockIdx.x % tiles_per_a) << lgT;
   const uint32_t nq = (T * L) << 1;
@@ -129,6 +130,7 @@ __global__ void __launch_bounds__(NT) k_ntt_final(const char* src, char* dst, ui
                                                    uint32_t lo_bits, const char* __restrict__ inner, const char* __restrict__ cs_hi, const char* __restrict__ cs_lo,
                                                    int pre_coset, int post_coset, int do_scale, FrArg scale) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+  src += (size_t)blockIdx.y << (lgL + lgN1 + lgN2 + 5); dst += (size_t)blockIdx.y << (lgL + lgN1 + lgN2 + 5);
   const uint32_t L = 1u << lgL, T = 1u << lgT;
   const uint32_t tiles_k1 = 1u << (lgN1 - lgT);
   const uint32_t k2 = blockIdx.x / tiles_k1, k10 = (blockIdx.x % tiles_k1) << lgT;
@@ -166,6 +168,7 @@ __global__ void __launch_bounds__(NT) k_ntt_final(const char* src, char* dst, ui
 __global__ void __launch_bounds__(256) k_bitrev_copy(const char* __restrict__ src, char* __restrict__ dst, uint32_t lg_n) {
   size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= ((size_t)1 << lg_n)) return;
+  src += (size_t)blockIdx.y << (lg_n + 5); dst += (size_t)blockIdx.y << (lg_n + 5);
   uint32_t j = bitrev((uint32_t)i, lg_n);
   const uint4* s = (const uint4*)(src + i * 32); uint4* d = (uint4*)(dst + (size_t)j * 32);
   d[0] = s[0]; d[1] = s[1];
@@ -208,7 +211,7 @@ static int32_t build_tables(NttTables* t, uint32_t lg_n, int direction) {
 }
 
 template <uint32_t TE, uint32_t NT>
-static int32_t run_passes(char* buf, char* tmp, uint32_t lg_n, const NttTables* t, int pre_coset, int post_coset, int do_scale, FrArg sc, hipStream_t s) {
+static int32_t run_passes(char* buf, char* tmp, uint32_t lg_n, uint32_t batch, const NttTables* t, int pre_coset, int post_coset, int do_scale, FrArg sc, hipStream_t s) {
   constexpr uint32_t lgTE = TE == 4096 ? 12 : 11;
   constexpr size_t lds_bytes = (size_t)TE * 32;
   static bool attr_set = false;
@@ -227,45 +230,98 @@ static int32_t run_passes(char* buf, char* tmp, uint32_t lg_n, const NttTables* 
   else { s1 = (lg_n + 2) / 3; s2 = (lg_n - s1 + 1) / 2; s3 = lg_n - s1 - s2; }
   auto lgT_for = [](uint32_t lgL, uint32_t lg_limit) { uint32_t lgT = lgTE - lgL; return lgT < lg_limit ? lgT : lg_limit; };
   if (npass == 1) {
-    hipLaunchKernelGGL((k_ntt_final<TE, NT>), dim3(1), dim3(NT), lds_bytes, s, buf, buf, s3, 0u, 0u, 0u, t->lo_bits, inner, csh, csl, pre_coset, post_coset, do_scale, sc);
+    hipLaunchKernelGGL((k_ntt_final<TE, NT>), dim3(1, batch), dim3(NT), lds_bytes, s, buf, buf, s3, 0u, 0u, 0u, t->lo_bits, inner, csh, csl, pre_coset, post_coset, do_scale, sc);
   } else if (npass == 2) {
     uint32_t lgBn = s3, lgT = lgT_for(s1, lgBn);
-    hipLaunchKernelGGL((k_ntt_strided<TE, NT>), dim3(1u << (lgBn - lgT)), dim3(NT), lds_bytes, s, buf, tmp, s1, lgBn, lgT, 1u, lg_n, t->lo_bits, inner, twh, twl, csh, csl, pre_coset);
+    hipLaunchKernelGGL((k_ntt_strided<TE, NT>), dim3(1u << (lgBn - lgT), batch), dim3(NT), lds_bytes, s, buf, tmp, s1, lgBn, lgT, 1u, lg_n, t->lo_bits, inner, twh, twl, csh, csl, pre_coset);
     uint32_t lgTf = lgT_for(s3, s1);
-    hipLaunchKernelGGL((k_ntt_final<TE, NT>), dim3(1u << (s1 - lgTf)), dim3(NT), lds_bytes, s, tmp, buf, s3, s1, 0u, lgTf, t->lo_bits, inner, csh, csl, 0, post_coset, do_scale, sc);
+    hipLaunchKernelGGL((k_ntt_final<TE, NT>), dim3(1u << (s1 - lgTf), batch), dim3(NT), lds_bytes, s, tmp, buf, s3, s1, 0u, lgTf, t->lo_bits, inner, csh, csl, 0, post_coset, do_scale, sc);
   } else {
     uint32_t lgBn1 = s2 + s3, lgT1 = lgT_for(s1, lgBn1);
-    hipLaunchKernelGGL((k_ntt_strided<TE, NT>), dim3(1u << (lgBn1 - lgT1)), dim3(NT), lds_bytes, s, buf, buf, s1, lgBn1, lgT1, 1u, lg_n, t->lo_bits, inner, twh, twl, csh, csl, pre_coset);
+    hipLaunchKernelGGL((k_ntt_strided<TE, NT>), dim3(1u << (lgBn1 - lgT1), batch), dim3(NT), lds_bytes, s, buf, buf, s1, lgBn1, lgT1, 1u, lg_n, t->lo_bits, inner, twh, twl, csh, csl, pre_coset);
     uint32_t lgBn2 = s3, lgT2 = lgT_for(s2, lgBn2);
-    hipLaunchKernelGGL((k_ntt_strided<TE, NT>), dim3((1u << s1) << (lgBn2 - lgT2)), dim3(NT), lds_bytes, s, buf, tmp, s2, lgBn2, lgT2, 1u << s1, lg_n, t->lo_bits, inner, twh, twl, csh, csl, 0);
+    hipLaunchKernelGGL((k_ntt_strided<TE, NT>), dim3((1u << s1) << (lgBn2 - lgT2), batch), dim3(NT), lds_bytes, s, buf, tmp, s2, lgBn2, lgT2, 1u << s1, lg_n, t->lo_bits, inner, twh, twl, csh, csl, 0);
     uint32_t lgTf = lgT_for(s3, s1);
-    hipLaunchKernelGGL((k_ntt_final<TE, NT>), dim3((1u << s2) << (s1 - lgTf)), dim3(NT), lds_bytes, s, tmp, buf, s3, s1, s2, lgTf, t->lo_bits, inner, csh, csl, 0, post_coset, do_scale, sc);
+    hipLaunchKernelGGL((k_ntt_final<TE, NT>), dim3((1u << s2) << (s1 - lgTf), batch), dim3(NT), lds_bytes, s, tmp, buf, s3, s1, s2, lgTf, t->lo_bits, inner, csh, csl, 0, post_coset, do_scale, sc);
   }
   return ALEO_MI355X_OK;
 }
 
 
-int32_t ntt_run(Ctx* c, void* d_inout, uint32_t lg_n, int32_t order, int32_t direction, int32_t type, hipStream_t s) {
-  if (lg_n == 0) return ALEO_MI355X_OK;     // n = 1: every variant is the identity (g^0 = 1, 1^-1 = 1)
-  const size_t n = (size_t)1 << lg_n, bytes = n * 32;
-  int32_t rc;
-  uint64_t key = ((uint64_t)lg_n << 1) | (uint64_t)direction;
-  NttTables* t = nullptr;
-  {
-    std::lock_guard<std::mutex> lk(c->dev->mu);       // tables are shared by all slots and immutable once built
-    auto it = c->dev->ntt_tables.find(key);
-    if (it == c->dev->ntt_tables.end()) {
-      t = new NttTables();
-      if ((rc = build_tables(t, lg_n, direction))) { delete t; return rc; }
-      c->dev->ntt_tables[key] = t;
-    } else t = it->second;
+// ---- sharded (4-step) transform support: per-element factors over a 2-D block of the size-n index space -----------
+// mode 0: x[r][c] *= w_n^((row0 + r) * (col0 + c))       (the twiddle between the column and the row transforms)
+// mode 1: x[r][c] *= g^((row0 + r) * ld + col0 + c)      (coset shift of a block of the coefficient matrix)
+// inverse direction: w^-1 / g^-1 (tables of the inverse domain; the n^-1 folded into its coset table is cancelled by K = n).
+__global__ void __launch_bounds__(256) k_grid_scale(char* __restrict__ data, uint64_t rows, uint64_t cols, uint64_t row0, uint64_t col0, uint64_t ld,
+                                                    int mode, uint32_t lg_n, uint32_t lo_bits, const char* __restrict__ hi, const char* __restrict__ lo,
+                                                    int use_k, FrArg K) {
+  const uint64_t total = rows * cols, nmask = ((uint64_t)1 << lg_n) - 1u;
+  Fr k; for (int i = 0; i < 8; ++i) k.v[i] = K.v[i];
+  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (uint64_t)gridDim.x * 256) {
+    const uint64_t r = row0 + i / cols, c = col0 + i % cols;
+    const uint32_t e = (uint32_t)((mode == 0 ? r * c : r * ld + c) & nmask);
+    Fr f = two_level(hi, lo, e, lo_bits);                     // < 2r
+    if (use_k) f = Fr::mul(f, k);
+    Fr x = load_fp<Fr>(data + i * 32);
+    store_fp<Fr>(data + i * 32, Fr::reduce(Fr::mul(x, f)));
   }
+}
+
+static int32_t get_tables(Ctx* c, uint32_t lg_n, int32_t direction, NttTables** out);
+
+int32_t fr_grid_scale(Ctx* c, void* d_data, uint32_t lg_n, uint64_t rows, uint64_t cols, uint64_t row0, uint64_t col0, uint64_t ld, int32_t mode,
+                      int32_t direction, hipStream_t s) {
+  if (rows == 0 || cols == 0) return ALEO_MI355X_OK;
+  NttTables* t = nullptr; int32_t rc;
+  if ((rc = get_tables(c, lg_n, direction, &t))) return rc;
+  FrArg K; std::memset(K.v, 0, 32); int use_k = 0;
+  if (mode == 1 && direction == ALEO_NTT_INVERSE) {           // cs_lo of the inverse domain carries n^-1: multiply it back out
+    host::HFr nn = host::HFr::from_u64((uint64_t)1 << lg_n); std::memcpy(K.v, nn.l, 32); use_k = 1;
+  }
+  const uint64_t total = rows * cols; const uint32_t grid = (uint32_t)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+  const char* hi = (const char*)(mode == 0 ? t->d_tw_hi : t->d_cs_hi); const char* lo = (const char*)(mode == 0 ? t->d_tw_lo : t->d_cs_lo);
+  hipLaunchKernelGGL(k_grid_scale, dim3(grid), dim3(256), 0, s, (char*)d_data, rows, cols, row0, col0, ld, mode, lg_n, t->lo_bits, hi, lo, use_k, K);
+  HIPCHK(hipGetLastError());
+  return ALEO_MI355X_OK;
+}
+
+static int32_t get_tables(Ctx* c, uint32_t lg_n, int32_t direction, NttTables** out) {
+  uint64_t key = ((uint64_t)lg_n << 1) | (uint64_t)direction;
+  std::lock_guard<std::mutex> lk(c->dev->mu);       // tables are shared by all slots and immutable once built
+  auto it = c->dev->ntt_tables.find(key);
+  if (it == c->dev->ntt_tables.end()) {
+    NttTables* t = new NttTables();
+    int32_t rc = build_tables(t, lg_n, direction);
+    if (rc) { delete t; return rc; }
+    c->dev->ntt_tables[key] = t; *out = t;
+  } else *out = it->second;
+  return ALEO_MI355X_OK;
+}
+
+static int32_t ntt_run_chunk(Ctx* c, void* d_inout, uint32_t lg_n, uint32_t batch, int32_t order, int32_t direction, int32_t type, hipStream_t s);
+// `batch` independent transforms of 2^lg_n elements each, contiguous in d_inout (blockIdx.y walks them)
+int32_t ntt_run(Ctx* c, void* d_inout, uint32_t lg_n, size_t batch_total, int32_t order, int32_t direction, int32_t type, hipStream_t s) {
+  if (lg_n == 0 || batch_total == 0) return ALEO_MI355X_OK;     // n = 1: every variant is the identity (g^0 = 1, 1^-1 = 1)
+  const size_t n = (size_t)1 << lg_n;
+  for (size_t b0 = 0; b0 < batch_total; b0 += 32768) {            // gridDim.y <= 65535
+    const uint32_t batch = (uint32_t)(batch_total - b0 < 32768 ? batch_total - b0 : 32768);
+    int32_t rcb = ntt_run_chunk(c, (char*)d_inout + b0 * n * 32, lg_n, batch, order, direction, type, s);
+    if (rcb) return rcb;
+  }
+  return ALEO_MI355X_OK;
+}
+
+static int32_t ntt_run_chunk(Ctx* c, void* d_inout, uint32_t lg_n, uint32_t batch, int32_t order, int32_t direction, int32_t type, hipStream_t s) {
+  const size_t n = (size_t)1 << lg_n, bytes = n * 32 * batch;
+  int32_t rc;
+  NttTables* t = nullptr;
+  if ((rc = get_tables(c, lg_n, direction, &t))) return rc;
   if ((rc = c->ntt_tmp.reserve(bytes))) return rc;
   char* buf = (char*)d_inout; char* tmp = c->ntt_tmp.as<char>();
   const bool in_rev = (order == ALEO_NTT_ORDER_RN || order == ALEO_NTT_ORDER_RR), out_rev = (order == ALEO_NTT_ORDER_NR || order == ALEO_NTT_ORDER_RR);
-  const uint32_t gperm = (uint32_t)((n + 255) / 256);
+  const dim3 gperm((uint32_t)((n + 255) / 256), batch);
   if (in_rev) {
-    hipLaunchKernelGGL(k_bitrev_copy, dim3(gperm), dim3(256), 0, s, buf, tmp, lg_n);
+    hipLaunchKernelGGL(k_bitrev_copy, gperm, dim3(256), 0, s, buf, tmp, lg_n);
     HIPCHK(hipMemcpyAsync(buf, tmp, bytes, hipMemcpyDeviceToDevice, s));
   }
   const int coset = (type == ALEO_NTT_COSET), inv = (direction == ALEO_NTT_INVERSE);
@@ -273,11 +329,11 @@ int32_t ntt_run(Ctx* c, void* d_inout, uint32_t lg_n, int32_t order, int32_t dir
   FrArg sc; std::memcpy(sc.v, t->scale, 32);
   // 128 KiB tiles: 2^19..2^22 run in two passes (measured 6-16 % faster than three 64 KiB passes); beyond 2^22 three
   // passes are needed either way and two 64 KiB blocks per CU overlap their HBM phases better (2^24: 3.5 vs 4.0 ms)
-  if (lg_n >= 19 && lg_n <= 22) rc = run_passes<4096, 512>(buf, tmp, lg_n, t, pre_coset, post_coset, do_scale, sc, s);
-  else rc = run_passes<2048, 256>(buf, tmp, lg_n, t, pre_coset, post_coset, do_scale, sc, s);
+  if (lg_n >= 19 && lg_n <= 22) rc = run_passes<4096, 512>(buf, tmp, lg_n, batch, t, pre_coset, post_coset, do_scale, sc, s);
+  else rc = run_passes<2048, 256>(buf, tmp, lg_n, batch, t, pre_coset, post_coset, do_scale, sc, s);
   if (rc) return rc;
   if (out_rev) {
-    hipLaunchKernelGGL(k_bitrev_copy, dim3(gperm), dim3(256), 0, s, buf, tmp, lg_n);
+    hipLaunchKernelGGL(k_bitrev_copy, gperm, dim3(256), 0, s, buf, tmp, lg_n);
     HIPCHK(hipMemcpyAsync(buf, tmp, bytes, hipMemcpyDeviceToDevice, s));
   }
   HIPCHK(hipGetLastError());

@@ -30,6 +30,7 @@ def main():
     ap.add_argument('--no-kzg-chain', action='store_true', help='skip the secondary 2^22 iNTT -> commit measurement (config[2])')
     ap.add_argument('--proof-proxy-lg', type=int, default=20, help='log2 constraints of the Varuna operator-schedule replay (0 = skip)')
     ap.add_argument('--proof-proxy-cpu-lg', type=int, default=15, help='size of the same replay on the CPU oracle (cpu_baseline leg)')
+    ap.add_argument('--sharded-ntt-lg', type=int, default=24, help='size of the secondary sharded-NTT measurement at N > 1 (stderr)')
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
                     help="'gloo' is only for rehearsing the N>1 path with several ranks sharing one GPU")
     args = ap.parse_args()
@@ -138,7 +139,40 @@ def main():
             out['cpu_baseline'] = cpu_baseline(args, pb, scalars, aleo_amd)
         print(json.dumps(out), flush=True)
     if world > 1:
+        # secondary, outside the timed region: the sharded (4-step) NTT with its one all-to-all; never fails the MSM line
+        try:
+            sn = sharded_ntt_probe(aleo_amd, adist, synth, torch, dist, dev, rank, world, args.sharded_ntt_lg)
+        except Exception as e:      # noqa: BLE001
+            sn = {'error': repr(e)}
+        if rank == 0:
+            print(json.dumps({'aux': 'sharded_ntt', **sn}), file=sys.stderr, flush=True)
         dist.barrier(); dist.destroy_process_group()
+
+
+def sharded_ntt_probe(aleo_amd, adist, synth, torch, dist, dev, rank, world, lg_n, reps=5):
+    """2^lg_n-point NTT spread over the ranks (aleo_amd.dist.ShardedDomain): local column transforms, twiddle, ONE
+    all-to-all, local row transforms.  Each rank checks its evaluation block against a single-GPU transform of the same
+    vector, then the forward transform is timed (max over ranks)."""
+    if world & (world - 1) or lg_n < 2 * (world.bit_length() - 1): return {'skipped': 'needs a power-of-two world'}
+    n = 1 << lg_n
+    x = synth.uniform_scalars(n, 0xA1E00020)                                  # canonical < r, read as Montgomery
+    dom = adist.ShardedDomain(lg_n, rank, world)
+    mine = torch.from_numpy(dom.coefficient_shard(x).view(np.int64).copy()).to(dev)
+    full = torch.from_numpy(x.view(np.int64).copy()).to(dev)
+    aleo_amd.EvaluationDomain(n).ntt_device(full.data_ptr(), 0, 0, 0, adist._torch_stream_handle())
+    ev = dom.forward(mine.clone()); torch.cuda.synchronize()
+    idx = torch.from_numpy(dom.evaluation_indices()).to(dev)
+    ok = bool((ev == full[idx]).all())
+    back_ok = bool((dom.inverse(ev.clone()) == mine).all())
+    del full, idx
+    dist.barrier(); torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(reps):
+        ev = dom.forward(mine.clone())
+    torch.cuda.synchronize(); dist.barrier(); dt = (time.perf_counter() - t0) / reps
+    t = torch.tensor([dt, 0.0 if (ok and back_ok) else 1.0], dtype=torch.float64, device=dev if dist.get_backend() == 'nccl' else 'cpu')
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return {'lg_n': lg_n, 'ranks': world, 'ms': float(t[0]) * 1e3, 'alg_GBps_aggregate': 64.0 * n / float(t[0]) / 1e9,
+            'matches_single_gpu_transform_on_all_ranks': float(t[1]) == 0.0}
 
 
 def kzg_chain(aleo_amd, synth, torch, dev, lg=22, reps=5):

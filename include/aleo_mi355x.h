@@ -87,7 +87,9 @@ int32_t aleo_mi355x_bases_download(uint64_t handle, size_t offset, size_t n, voi
 /* MSM over the first n pinned bases; scalars: host pointer. */
 int32_t aleo_mi355x_msm_g1_pinned(void* out_jacobian, uint64_t handle, const void* scalars, size_t n);
 /* Same, scalars already resident in device memory (hipMalloc'ed or a torch CUDA tensor's data_ptr).
- * The result (144 bytes) is written to HOST memory.  `stream` is a hipStream_t or NULL. */
+ * The result (144 bytes) is written to HOST memory.  `stream` (here and in every *_device entry point) is a hipStream_t;
+ * NULL = the stream of the library slot serving the call, which is NOT ordered with the caller's other streams — a caller
+ * whose data was produced on the legacy default stream passes hipStreamLegacy. */
 int32_t aleo_mi355x_msm_g1_device(void* out_jacobian, uint64_t handle, const void* d_scalars, size_t n, void* stream);
 /* Sum of `count` Jacobian points (144 bytes each, host memory): the local group-add that follows the
  * all-gather of per-GPU partial MSM results.  Result affine-normalised as above. */
@@ -97,6 +99,17 @@ int32_t aleo_mi355x_g1_sum(void* out_jacobian, const void* jacobian_points, size
 int32_t aleo_mi355x_ntt_fr(void* inout, uint32_t lg_n, int32_t order, int32_t direction, int32_t type);
 /* Same on device-resident data (in place). */
 int32_t aleo_mi355x_ntt_fr_device(void* d_inout, uint32_t lg_n, int32_t order, int32_t direction, int32_t type, void* stream);
+/* `batch` independent transforms of 2^lg_n elements each, contiguous in d_inout (the local row / column transforms of a
+ * transform sharded over several GPUs, SURVEY.md §8e "4-step"; also one call for the polynomials of a prover round). */
+int32_t aleo_mi355x_ntt_fr_batch_device(void* d_inout, uint32_t lg_n, size_t batch, int32_t order, int32_t direction, int32_t type, void* stream);
+/* Factors over a rows x cols block (row-major, in place) of the index space of the size-2^lg_n domain:
+ *   mode 0: x[r][c] *= w^((row0 + r) * (col0 + c))   — the twiddle between the two axes of a 4-step transform
+ *   mode 1: x[r][c] *= g^((row0 + r) * ld + col0 + c) — the coset shift (g = 22) of a block of the coefficient matrix
+ *           (every index must stay below 2^lg_n)
+ * direction 1 uses w^-1 / g^-1 (no n^-1: the inverse sub-transforms carry their own scale).  lg_n <= 40 here: the domain
+ * may be larger than one GPU's share. */
+int32_t aleo_mi355x_fr_grid_scale_device(void* d_data, uint32_t lg_n, uint64_t rows, uint64_t cols, uint64_t row0, uint64_t col0, uint64_t ld,
+                                         int32_t mode, int32_t direction, void* stream);
 
 /* a5 — KZG10::commit shape: coefficients in Montgomery form (as polynomials are stored), converted to canonical
  * bigints on the device, MSM over the first n pinned bases; affine result as snarkVM Affine (104 bytes, host). */

@@ -424,3 +424,64 @@ def test_large_sizes_properties():
         got = M.VariableBase.msm_device(pb, dS.data_ptr(), n)
         kG = M.VariableBase.msm(synth.generator_affine104().reshape(1, 104), synth.int_to_limbs(synth.weighted_scalar_sum(S, 1), 4).reshape(1, 4))
         assert (got == kG).all()
+
+
+# ---- batched / sharded NTT -------------------------------------------------------------------------------------
+def test_ntt_batch_and_grid_scale_match_oracle():
+    import torch
+    from aleo_amd import dist as adist
+    ops = adist.HipLocalOps()
+    for lg, batch in ((3, 5), (9, 7), (12, 3), (13, 2)):
+        x = c.fr_to_mont(util.uniform_scalars(batch << lg, 8100 + lg))
+        for direction in (0, 1):
+            t = torch.from_numpy(x.view(np.int64).copy()).cuda()
+            ops.batch_ntt(t, lg, batch, direction); torch.cuda.synchronize()
+            got = t.cpu().numpy().view(np.uint64).reshape(batch, 1 << lg, 4)
+            for b in range(batch):
+                assert (got[b] == c.ntt_fr(x[b << lg:(b + 1) << lg], 0, direction, 0)).all(), (lg, b, direction)
+    lg_n, rows, cols, row0, col0, ld = 20, 37, 53, 900, 77, 1024            # mode 1 needs (row0 + rows) * ld <= n: g^j is not periodic in n
+    x = c.fr_to_mont(util.uniform_scalars(rows * cols, 8200))
+    for mode in (0, 1):
+        for direction in (0, 1):
+            t = torch.from_numpy(x.view(np.int64).copy()).cuda()
+            ops.grid_scale(t, lg_n, rows, cols, row0, col0, ld, mode, direction); torch.cuda.synchronize()
+            e = torch.from_numpy(x.view(np.int64).copy())
+            util.OracleLocalOps().grid_scale(e, lg_n, rows, cols, row0, col0, ld, mode, direction)
+            assert (t.cpu() == e).all(), (mode, direction)
+
+
+@pytest.mark.parametrize('lg_n,world', [(10, 4), (16, 2), (20, 4)])
+def test_sharded_ntt_ranks_on_one_gpu(lg_n, world):
+    """The 4-step transform of aleo_amd.dist.ShardedDomain with the HIP local steps; the `world` ranks run as threads of this
+    process (each call takes its own library slot) and exchange blocks through a barrier instead of RCCL."""
+    import threading, torch
+    from aleo_amd import dist as adist
+    x = c.fr_to_mont(util.uniform_scalars(1 << lg_n, 8300 + lg_n))
+    d = aleo_amd.EvaluationDomain(1 << lg_n)
+    full = {False: d.fft(x), True: d.coset_fft(x)}
+    box = [None] * world; bar = threading.Barrier(world); errs = []
+
+    def exchange(send, rank):
+        box[rank] = send; bar.wait()
+        recv = torch.stack([box[p][rank] for p in range(world)])
+        bar.wait()
+        return recv
+
+    def work(rank):
+        try:
+            torch.cuda.set_device(0)
+            with torch.cuda.stream(torch.cuda.Stream()):
+                dom = adist.ShardedDomain(lg_n, rank, world, exchange=exchange)
+                idx = dom.evaluation_indices()
+                for coset in (False, True):
+                    mine = torch.from_numpy(dom.coefficient_shard(x).view(np.int64).copy()).cuda()
+                    ev = dom.forward(mine.clone(), coset=coset); torch.cuda.current_stream().synchronize()
+                    assert (ev.cpu().numpy().view(np.uint64) == full[coset][idx]).all(), (rank, coset)
+                    back = dom.inverse(ev, coset=coset); torch.cuda.current_stream().synchronize()
+                    assert (back == mine).all(), (rank, coset)
+        except Exception as e:      # noqa: BLE001
+            errs.append(e); bar.abort()
+    ths = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+    for t in ths: t.start()
+    for t in ths: t.join()
+    assert not errs, errs
