@@ -12,7 +12,7 @@ EXPORTS = [
     'aleo_mi355x_bases_generate', 'aleo_mi355x_bases_download', 'aleo_mi355x_bases_precompute',
     'aleo_mi355x_msm_g1_pinned', 'aleo_mi355x_msm_g1_device', 'aleo_mi355x_g1_sum', 'aleo_mi355x_ntt_fr',
     'aleo_mi355x_ntt_fr_device', 'aleo_mi355x_ntt_fr_batch_device', 'aleo_mi355x_fr_grid_scale_device', 'aleo_mi355x_kzg_commit', 'aleo_mi355x_kzg_commit_device', 'aleo_mi355x_kzg_commit_hiding',
-    'aleo_mi355x_fr_vec_op_device', 'aleo_mi355x_fr_batch_inverse_device', 'aleo_mi355x_fq_mul',
+    'aleo_mi355x_fr_vec_op_device', 'aleo_mi355x_fr_batch_inverse_device', 'aleo_mi355x_fr_spmv_device', 'aleo_mi355x_fq_mul',
     'aleo_mi355x_fr_mul', 'aleo_mi355x_last_msm_timing', 'aleo_mi355x_strerror', 'aleo_mi355x_last_error',
     'aleo_mi355x_version',
 ]
@@ -61,6 +61,7 @@ def lib():
         'aleo_mi355x_kzg_commit_hiding': ([vp, u64, vp, sz, u64, vp, sz], i32),
         'aleo_mi355x_fr_vec_op_device': ([vp, vp, vp, sz, i32, vp], i32),
         'aleo_mi355x_fr_batch_inverse_device': ([vp, sz, vp], i32),
+        'aleo_mi355x_fr_spmv_device': ([vp, vp, vp, vp, vp, sz, vp], i32),
         'aleo_mi355x_fq_mul': ([vp, vp, vp, sz], i32),
         'aleo_mi355x_fr_mul': ([vp, vp, vp, sz], i32),
         'aleo_mi355x_last_msm_timing': ([ctypes.POINTER(ctypes.c_double), i32], i32),

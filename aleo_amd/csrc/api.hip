@@ -392,6 +392,14 @@ int32_t aleo_mi355x_fr_batch_inverse_device(void* d_inout, size_t n, void* strea
   } catch (...) { return ALEO_MI355X_ERR_HIP; }
 }
 
+int32_t aleo_mi355x_fr_spmv_device(void* d_y, const void* d_row_ptr, const void* d_col_idx, const void* d_vals, const void* d_x, size_t rows, void* stream) {
+  try {
+    if ((!d_y || !d_row_ptr) && rows) return ALEO_MI355X_ERR_BAD_ARG;
+    API_BEGIN
+    return fr_spmv(c, d_y, d_row_ptr, d_col_idx, d_vals, d_x, rows, stream ? (hipStream_t)stream : c->stream);
+  } catch (...) { return ALEO_MI355X_ERR_HIP; }
+}
+
 int32_t aleo_mi355x_ntt_fr(void* inout, uint32_t lg_n, int32_t order, int32_t direction, int32_t type) {
   try {
     if (!inout || lg_n > 30 || order < 0 || order > 3 || direction < 0 || direction > 1 || type < 0 || type > 1) { g_last_error = "ntt_fr: bad argument"; return ALEO_MI355X_ERR_BAD_ARG; }

@@ -77,6 +77,64 @@ int32_t fr_vec_op(Ctx* c, void* d_dst, const void* d_a, const void* d_b, size_t 
   return ALEO_MI355X_OK;
 }
 
+// ---- sparse matrix x vector over Fr: z_M = M * z for the R1CS matrices A, B, C ----------------
+// Replaces the per-row inner products snarkVM's Varuna prover runs on rayon before committing z_a, z_b
+// (`matrix row: Vec<(F, usize)>` dotted with the assignment [UPSTREAM-RECALL: snark/varuna/ahp/prover/round_functions/first.rs]).
+// CSR in HBM: row_ptr u32[rows + 1], col_idx u32[nnz], vals Fr Montgomery [nnz].  Constraint rows are short (a handful
+// of entries) with a few very long linear combinations, so: one lane per row for rows of <= SPMV_LANE_MAX entries; longer
+// rows are queued (one global atomic each) and a second kernel gives each a whole wave, folding the 64 partial sums
+// with shuffles.  68 algorithmic bytes per non-zero (32 value + 4 index + 32 gathered operand) against one product.
+static constexpr uint32_t SPMV_LANE_MAX = 64;
+
+__device__ __forceinline__ Fr spmv_term(const char* __restrict__ vals, const uint32_t* __restrict__ col, const char* __restrict__ x, uint32_t k) {
+  return Fr::mul(load_fp<Fr>(vals + (size_t)k * 32), load_fp<Fr>(x + (size_t)col[k] * 32));       // < 2r
+}
+
+__global__ void __launch_bounds__(256) k_spmv_rows(char* __restrict__ y, const uint32_t* __restrict__ row_ptr, const uint32_t* __restrict__ col,
+                                                   const char* __restrict__ vals, const char* __restrict__ x, uint32_t rows,
+                                                   uint32_t* __restrict__ long_rows, uint32_t* __restrict__ n_long) {
+  for (uint32_t r = blockIdx.x * 256 + threadIdx.x; r < rows; r += gridDim.x * 256) {
+    const uint32_t k0 = row_ptr[r], k1 = row_ptr[r + 1];
+    if (k1 - k0 > SPMV_LANE_MAX) { long_rows[atomicAdd(n_long, 1u)] = r; continue; }
+    Fr acc = Fr::zero();
+    for (uint32_t k = k0; k < k1; ++k) acc = Fr::cond_sub<2>(Fr::add(acc, spmv_term(vals, col, x, k)));     // < 4r -> < 2r
+    store_fp<Fr>(y + (size_t)r * 32, Fr::cond_sub<1>(acc));
+  }
+}
+
+__global__ void __launch_bounds__(256) k_spmv_long(char* __restrict__ y, const uint32_t* __restrict__ row_ptr, const uint32_t* __restrict__ col,
+                                                   const char* __restrict__ vals, const char* __restrict__ x,
+                                                   const uint32_t* __restrict__ long_rows, const uint32_t* __restrict__ n_long) {
+  const uint32_t lane = threadIdx.x & 63, wave = (blockIdx.x * 256 + threadIdx.x) >> 6, nwaves = (gridDim.x * 256) >> 6;
+  for (uint32_t q = wave; q < *n_long; q += nwaves) {
+    const uint32_t r = long_rows[q], k0 = row_ptr[r], k1 = row_ptr[r + 1];
+    Fr acc = Fr::zero();
+    for (uint32_t k = k0 + lane; k < k1; k += 64) acc = Fr::cond_sub<2>(Fr::add(acc, spmv_term(vals, col, x, k)));
+    for (int d = 32; d >= 1; d >>= 1) {
+      Fr o;
+#pragma unroll
+      for (int l = 0; l < 8; ++l) o.v[l] = __shfl_xor(acc.v[l], d);
+      acc = Fr::cond_sub<2>(Fr::add(acc, o));
+    }
+    if (lane == 0) store_fp<Fr>(y + (size_t)r * 32, Fr::cond_sub<1>(acc));
+  }
+}
+
+int32_t fr_spmv(Ctx* c, void* d_y, const void* d_row_ptr, const void* d_col, const void* d_vals, const void* d_x, size_t rows, hipStream_t s) {
+  if (rows == 0) return ALEO_MI355X_OK;
+  if (rows >= (1ull << 32)) { g_last_error = "fr_spmv: row count exceeds 2^32"; return ALEO_MI355X_ERR_BAD_ARG; }
+  int32_t rc; if ((rc = c->ntt_tmp.reserve((rows + 16) * 4))) return rc;
+  uint32_t* n_long = c->ntt_tmp.as<uint32_t>(); uint32_t* long_rows = n_long + 16;
+  HIPCHK(hipMemsetAsync(n_long, 0, 4, s));
+  const size_t want = (rows + 255) / 256; const uint32_t grid = (uint32_t)(want < 16384 ? want : 16384);
+  hipLaunchKernelGGL(k_spmv_rows, dim3(grid), dim3(256), 0, s, (char*)d_y, (const uint32_t*)d_row_ptr, (const uint32_t*)d_col, (const char*)d_vals,
+                     (const char*)d_x, (uint32_t)rows, long_rows, n_long);
+  hipLaunchKernelGGL(k_spmv_long, dim3(1024), dim3(256), 0, s, (char*)d_y, (const uint32_t*)d_row_ptr, (const uint32_t*)d_col, (const char*)d_vals,
+                     (const char*)d_x, long_rows, n_long);
+  HIPCHK(hipGetLastError());
+  return ALEO_MI355X_OK;
+}
+
 int32_t fr_batch_inverse(Ctx* c, void* d_inout, size_t n, hipStream_t s) {
   if (n == 0) return ALEO_MI355X_OK;
   int32_t rc; if ((rc = c->ntt_tmp.reserve(n * 32))) return rc;

@@ -14,3 +14,9 @@ def fr_vec_op_device(d_dst: int, d_a: int, d_b: int, n: int, op: int, stream: in
 
 def batch_inversion_device(d_inout: int, n: int, stream: int = 0):
     check(lib().aleo_mi355x_fr_batch_inverse_device(ctypes.c_void_p(d_inout), n, ctypes.c_void_p(stream)), 'fr_batch_inverse_device')
+
+
+def spmv_device(d_y: int, d_row_ptr: int, d_col_idx: int, d_vals: int, d_x: int, rows: int, stream: int = 0):
+    """y = M x for a CSR matrix over Fr (uint32 row_ptr / col_idx, Montgomery values): z_a = A z, z_b = B z."""
+    vp = ctypes.c_void_p
+    check(lib().aleo_mi355x_fr_spmv_device(vp(d_y), vp(d_row_ptr), vp(d_col_idx), vp(d_vals), vp(d_x), rows, vp(stream)), 'fr_spmv_device')

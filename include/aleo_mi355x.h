@@ -130,6 +130,10 @@ int32_t aleo_mi355x_kzg_commit_hiding(void* out_affine104, uint64_t h_powers, co
 #define ALEO_FR_OP_SUB 2
 int32_t aleo_mi355x_fr_vec_op_device(void* d_dst, const void* d_a, const void* d_b, size_t n, int32_t op, void* stream);
 int32_t aleo_mi355x_fr_batch_inverse_device(void* d_inout, size_t n, void* stream);
+/* y = M * x over Fr for a CSR matrix in device memory (row_ptr: uint32[rows + 1], col_idx: uint32[nnz], vals: Montgomery
+ * Fr[nnz]); x and y Montgomery Fr vectors.  The z_a = A z, z_b = B z products of the R1CS matrices before round 1
+ * [UPSTREAM-RECALL: snark/varuna/ahp/prover/round_functions/first.rs].  Empty rows give 0. */
+int32_t aleo_mi355x_fr_spmv_device(void* d_y, const void* d_row_ptr, const void* d_col_idx, const void* d_vals, const void* d_x, size_t rows, void* stream);
 
 /* Element-wise field products on the device (host pointers): r[i] = a[i]*b[i], Montgomery form, canonical
  * output.  Used by the parity tests to pin the device arithmetic against the oracle limb for limb; when a and b

@@ -38,6 +38,7 @@ def lib():
         L.oracle_kzg_commit.argtypes = [vp, vp, vp, sz, ci]; L.oracle_kzg_commit.restype = ci
         L.oracle_fr_batch_inverse.argtypes = [vp, sz]; L.oracle_fr_batch_inverse.restype = None
         L.oracle_fr_vec_op.argtypes = [vp, vp, vp, sz, ci]; L.oracle_fr_vec_op.restype = None
+        L.oracle_fr_spmv.argtypes = [vp, vp, vp, vp, vp, sz]; L.oracle_fr_spmv.restype = None
         _LIB = L
     return _LIB
 
@@ -148,3 +149,11 @@ def fr_batch_inverse(a) -> np.ndarray:
 def fr_vec_op(a, b, op: int) -> np.ndarray:
     a = np.ascontiguousarray(a, dtype=np.uint64); b = np.ascontiguousarray(b, dtype=np.uint64)
     r = np.zeros_like(a); lib().oracle_fr_vec_op(_p(r), _p(a), _p(b), a.shape[0], op); return r
+
+
+def fr_spmv(row_ptr, col_idx, vals, x) -> np.ndarray:
+    """CSR matrix (uint32 row_ptr / col_idx, uint64[nnz,4] Montgomery values) times a Montgomery Fr vector."""
+    rp = np.ascontiguousarray(row_ptr, dtype=np.uint32); ci = np.ascontiguousarray(col_idx, dtype=np.uint32)
+    v = np.ascontiguousarray(vals, dtype=np.uint64); xx = np.ascontiguousarray(x, dtype=np.uint64)
+    y = np.zeros((rp.shape[0] - 1, 4), dtype=np.uint64)
+    lib().oracle_fr_spmv(_p(y), _p(rp), _p(ci), _p(v), _p(xx), y.shape[0]); return y

@@ -471,6 +471,14 @@ void oracle_fr_batch_inverse(void* io, size_t n) {
   Fr* p = (Fr*)io;
   for (size_t i = 0; i < n; ++i) if (!Fr_is_zero(&p[i])) Fr_inv(&p[i], &p[i]);
 }
+/* y = M x, CSR (row_ptr u32[rows+1], col u32[nnz], vals Fr mont): the matrix-row inner products of the Varuna prover. */
+void oracle_fr_spmv(void* y, const uint32_t* row_ptr, const uint32_t* col, const void* vals, const void* x, size_t rows) {
+  for (size_t r = 0; r < rows; ++r) {
+    Fr acc; memset(&acc, 0, sizeof acc);
+    for (uint32_t k = row_ptr[r]; k < row_ptr[r + 1]; ++k) { Fr t; Fr_mul(&t, (const Fr*)vals + k, (const Fr*)x + col[k]); Fr_add(&acc, &acc, &t); }
+    ((Fr*)y)[r] = acc;
+  }
+}
 void oracle_fr_vec_op(void* r, const void* a, const void* b, size_t n, int op) {
   for (size_t i = 0; i < n; ++i) {
     if (op == 0) Fr_mul((Fr*)r + i, (const Fr*)a + i, (const Fr*)b + i);

@@ -485,3 +485,29 @@ def test_sharded_ntt_ranks_on_one_gpu(lg_n, world):
     for t in ths: t.start()
     for t in ths: t.join()
     assert not errs, errs
+
+
+def test_fr_spmv_matches_oracle():
+    """z_M = M z over a ragged CSR matrix: empty rows, one-entry rows, typical short rows and a few very long linear
+    combinations (the wave-per-row path), coefficients mostly 1 / -1 / small like an R1CS matrix."""
+    import torch
+    from aleo_amd import poly
+    rows, cols = 20011, 7001
+    rng = np.random.default_rng(99)
+    lens = rng.choice([0, 1, 2, 3, 5, 9, 64, 65], size=rows, p=[0.05, 0.3, 0.3, 0.2, 0.1, 0.03, 0.01, 0.01]).astype(np.int64)
+    lens[[7, 4000, rows - 1]] = [3000, 129, 70000]                                       # long rows, also as the very last row
+    row_ptr = np.zeros(rows + 1, dtype=np.uint32); row_ptr[1:] = np.cumsum(lens)
+    nnz = int(row_ptr[-1])
+    col = rng.integers(0, cols, size=nnz, dtype=np.uint32)
+    vals_c = util.uniform_scalars(nnz, 9100)
+    small = rng.random(nnz) < 0.8
+    vals_c[small] = 0; vals_c[small, 0] = rng.integers(1, 5, size=int(small.sum()), dtype=np.uint64)
+    neg = rng.random(nnz) < 0.2
+    vals_c[neg] = c.ints_to_limbs([p.FR_MODULUS - 1], 4)[0]
+    vals = c.fr_to_mont(vals_c); x = c.fr_to_mont(util.uniform_scalars(cols, 9101))
+    exp = c.fr_spmv(row_ptr, col, vals, x)
+    d = lambda a: torch.from_numpy(a.view(np.int32 if a.dtype == np.uint32 else np.int64).copy()).cuda()
+    drp, dcol, dv, dx = d(row_ptr), d(col), d(vals), d(x)
+    dy = torch.zeros((rows, 4), dtype=torch.int64, device='cuda'); torch.cuda.synchronize()
+    poly.spmv_device(dy.data_ptr(), drp.data_ptr(), dcol.data_ptr(), dv.data_ptr(), dx.data_ptr(), rows); torch.cuda.synchronize()
+    assert (dy.cpu().numpy().view(np.uint64) == exp).all()

@@ -55,3 +55,22 @@ if what in ('all', 'frops'):
             e1.record(); torch.cuda.synchronize()
             ms = e0.elapsed_time(e1) / 10
             print(json.dumps({'frop': name, 'lg': lg, 'ms': ms, 'GBps_alg': bytes_per * n / ms / 1e6, 'frac_hbm': bytes_per * n / ms / 1e6 / 8000}), flush=True)
+if what in ('all', 'spmv'):
+    from aleo_amd import poly
+    rng = np.random.default_rng(5)
+    for lg in (20, 22):
+        rows = 1 << lg; cols = rows
+        lens = rng.choice([1, 2, 3, 4, 8], size=rows, p=[0.35, 0.3, 0.2, 0.1, 0.05]).astype(np.int64); lens[:8] = 20000
+        row_ptr = np.zeros(rows + 1, dtype=np.uint32); row_ptr[1:] = np.cumsum(lens); nnz = int(row_ptr[-1])
+        col = rng.integers(0, cols, size=nnz, dtype=np.uint32)
+        dv = torch.from_numpy(synth.uniform_scalars(nnz, 3).view(np.int64)).to(dev); dx = torch.from_numpy(synth.uniform_scalars(cols, 4).view(np.int64)).to(dev)
+        drp = torch.from_numpy(row_ptr.view(np.int32)).to(dev); dcol = torch.from_numpy(col.view(np.int32)).to(dev)
+        dy = torch.empty((rows, 4), dtype=torch.int64, device=dev)
+        fn = lambda: poly.spmv_device(dy.data_ptr(), drp.data_ptr(), dcol.data_ptr(), dv.data_ptr(), dx.data_ptr(), rows, st)
+        fn(); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(True), torch.cuda.Event(True)
+        e0.record()
+        for _ in range(10): fn()
+        e1.record(); torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 10
+        print(json.dumps({'spmv_rows_lg': lg, 'nnz': nnz, 'ms': ms, 'GBps_alg': 68.0 * nnz / ms / 1e6, 'frac_hbm': 68.0 * nnz / ms / 1e6 / 8000, 'Gnnz_s': nnz / ms / 1e6}), flush=True)
