@@ -511,3 +511,25 @@ def test_fr_spmv_matches_oracle():
     dy = torch.zeros((rows, 4), dtype=torch.int64, device='cuda'); torch.cuda.synchronize()
     poly.spmv_device(dy.data_ptr(), drp.data_ptr(), dcol.data_ptr(), dv.data_ptr(), dx.data_ptr(), rows); torch.cuda.synchronize()
     assert (dy.cpu().numpy().view(np.uint64) == exp).all()
+
+
+def test_msm_randomized_prefixes_and_distributions():
+    """Differential sweep on one pinned 2^17-point set with its table: random prefix lengths (both sides of the
+    table / plain switch at n = 2^(c-3)) x scalar distributions (uniform, witness-like, all-equal, small, top-heavy,
+    single non-zero), each against the O(n) structured identity."""
+    N = 1 << 17
+    rng = np.random.default_rng(20260101)
+    with M.PinnedBases.generate_multiples(synth.generator_affine104(), 1, N) as pb:
+        pb.precompute()
+        lens = [1, 2, 63, 64, 65, (1 << 14) - 1, 1 << 14, (1 << 14) + 1, N - 1, N] + [int(v) for v in rng.integers(1, N, size=14)]
+        for i, n in enumerate(lens):
+            kind = i % 6
+            if kind == 0: S = util.uniform_scalars(n, 31000 + i)
+            elif kind == 1: S = util.witness_like_scalars(n, 31000 + i)
+            elif kind == 2: S = np.tile(util.uniform_scalars(1, 31000 + i), (n, 1))                       # one bucket per window
+            elif kind == 3: S = np.zeros((n, 4), dtype=np.uint64); S[:, 0] = rng.integers(0, 1 << 16, size=n, dtype=np.uint64)
+            elif kind == 4:                                                                                # only the top window differs
+                S = np.tile(c.ints_to_limbs([p.FR_MODULUS - 1], 4), (n, 1)); S[:, 0] -= rng.integers(0, 4, size=n, dtype=np.uint64)
+            else: S = np.zeros((n, 4), dtype=np.uint64); S[n // 2] = util.uniform_scalars(1, 31000 + i)[0]
+            got = c.jac_to_int_point(M.VariableBase.msm(pb, S))
+            assert got == util.expected_multiples_msm(S, n), (n, kind)
