@@ -30,6 +30,7 @@ def main():
     ap.add_argument('--no-kzg-chain', action='store_true', help='skip the secondary 2^22 iNTT -> commit measurement (config[2])')
     ap.add_argument('--proof-proxy-lg', type=int, default=20, help='log2 constraints of the Varuna operator-schedule replay (0 = skip)')
     ap.add_argument('--proof-proxy-cpu-lg', type=int, default=15, help='size of the same replay on the CPU oracle (cpu_baseline leg)')
+    ap.add_argument('--concurrent-callers', type=int, default=4, help='secondary: aggregate rate with this many caller threads (0/1 = skip)')
     ap.add_argument('--sharded-ntt-lg', type=int, default=24, help='size of the secondary sharded-NTT measurement at N > 1 (stderr)')
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
                     help="'gloo' is only for rehearsing the N>1 path with several ranks sharing one GPU")
@@ -127,6 +128,8 @@ def main():
                                  'measured Fq product peak 60 G/s (tools/ubench/fq_mul_bench.hip)' % (16 if args.no_precompute else 13)},
             'phases_ms': {kk: float(np.mean([p_[kk] for p_ in phases])) for kk in phases[0]},
         }
+        if world == 1 and args.concurrent_callers > 1:
+            out['concurrent_callers'] = concurrent_callers(aleo_amd, synth, torch, dev, pb, n, args.concurrent_callers)
         if world == 1 and not args.no_kzg_chain:
             out['kzg_chain_2^22'] = kzg_chain(aleo_amd, synth, torch, dev)
         if world == 1 and args.proof_proxy_lg:
@@ -147,6 +150,27 @@ def main():
         if rank == 0:
             print(json.dumps({'aux': 'sharded_ntt', **sn}), file=sys.stderr, flush=True)
         dist.barrier(); dist.destroy_process_group()
+
+
+def concurrent_callers(aleo_amd, synth, torch, dev, pb, n, T, reps=8):
+    """Secondary: T host threads (snarkVM's rayon commitments of one round) each running MSMs of the headline size against
+    the same pinned set; every call takes its own library slot, so sort / reduce phases of one call overlap another's
+    accumulation.  Aggregate rate, NOT the headline `value` (which has one call in flight)."""
+    import threading
+    ds = [torch.from_numpy(synth.uniform_scalars(n, 0xA1E00030 + t).view(np.int64)).to(dev) for t in range(T)]
+    torch.cuda.synchronize()
+
+    def work(t):
+        torch.cuda.set_device(dev)
+        for _ in range(reps): aleo_amd.VariableBase.msm_device(pb, ds[t].data_ptr(), n)
+    dt = None
+    for _ in range(2):                       # first round warms the slots' workspaces
+        th = [threading.Thread(target=work, args=(t,)) for t in range(T)]
+        t0 = time.perf_counter()
+        for x in th: x.start()
+        for x in th: x.join()
+        dt = time.perf_counter() - t0
+    return {'threads': T, 'ms_per_msm_aggregate': dt / (T * reps) * 1e3, 'scalar_muls_per_s': T * reps * n / dt}
 
 
 def sharded_ntt_probe(aleo_amd, adist, synth, torch, dist, dev, rank, world, lg_n, reps=5):
