@@ -4,6 +4,7 @@ set -euo pipefail
 here="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
 out="$here/../lib"; mkdir -p "$out"
 python3 "$here/../../tools/gen_fp_asm.py" "$here/fp_mont_gen.h"
+python3 "$here/../../tools/gen_fp28_asm.py" "$here/fp28_mont_gen.h"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fgpu-rdc-never 2>/dev/null"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Wno-unused-variable"

@@ -1,0 +1,161 @@
+// fp28.h — Fq on 14 x 28-bit limbs (R' = 2^392): the representation of the bucket-accumulation inner loop.
+//
+// Why a second representation (fp.h keeps 12 x 32-bit limbs, snarkVM's layout, for everything that crosses the ABI).
+// With 32-bit limbs every v_mad_u64_u32 needs a v_addc to catch its carry-out: 288 + 288 of the 649 instructions of a
+// product.  With 28-bit limbs a 64-bit accumulator holds a whole column, so a product is 392 mads + 71 simple instructions
+// (tools/gen_fp28_asm.py): 81 G products/s against 60.7 (profiles/r01_fq28_mul_bench.txt).  Additions and subtractions
+// become carry-free limb-wise operations; what they cost instead is bookkeeping of LIMB bounds next to the value bounds.
+//
+// Value bounds: R'/q ~ 2^15.2, so a product of a < A*q, b < B*q is < (A*B/38000 + 1)*q — every product below is < 2q.
+// Limb bounds ("class"): the product block needs a_i * b_j < 2^59.1 for all i, j (28 terms + carry-in < 2^64):
+//   N  : limbs < 2^28 (exact base-2^28 digits; what a product or normalise() returns)
+//   L3 : limbs < 3 * 2^28 (an N value minus an N value through sub<K, 1>; or N + N)
+//   products used: N x N, N x L3 (2^57.6 * 28 < 2^62.5), never L3 x L3.
+// sub<K, S>(a, b) = a - b + K*q limb-wise, with K*q spread so that every limb of the constant is >= S * 2^28 - S:
+// needs b's limbs < S * 2^28 - S + (K*q)_i and b < K*q as a value; the result's limbs are < a_max + (S + 1) * 2^28.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "fp.h"
+#include "fp28_mont_gen.h"
+
+namespace aleo_mi355x {
+
+struct F28 {
+  static constexpr int N = 14;
+  static constexpr uint32_t MASK = 0x0fffffffu;
+  uint32_t v[N];
+};
+
+struct Limbs14 { uint32_t v[14]; };
+static constexpr Limbs14 Q28 = {{0x00000001u, 0x008c0000u, 0x00000085u, 0x05d44300u, 0x0800170bu, 0x02fba094u, 0x0f1ef362u, 0x000f5138u, 0x0a22d9f3u,
+                                 0x0a1493b1u, 0x0b05c06cu, 0x010eac63u, 0x0a4617c5u, 0x00001ae3u}};
+static constexpr Limbs14 ONE28 = {{0x0fff67acu, 0x020fffffu, 0x0fb0d727u, 0x0e9203ffu, 0x0249b0e4u, 0x0e172345u, 0x0955d771u, 0x02bf89aau, 0x0b2833b2u,
+                                   0x098e116bu, 0x07dc5c97u, 0x00d43e93u, 0x02e3314bu, 0x000003b4u}};      // 2^392 mod q
+static constexpr Limbs14 R32_28 = {{0x0fffff68u, 0x0cdfffffu, 0x0fffb102u, 0x09f837ffu, 0x0ff25140u, 0x0a98a7d3u, 0x059f7db3u, 0x06e7c630u, 0x0b4e97b7u,
+                                    0x03c84e87u, 0x0495bf80u, 0x0f49a4cfu, 0x0661e2fdu, 0x000008d6u}};     // 2^384 mod q (plain digits)
+// 2^392 mod q as 12 x 32-bit limbs: Fq::mul(X, K256_32) turns x * 2^384 into x * 2^392
+static constexpr Limbs<12> K256_32 = {{0xffff67acu, 0x2720ffffu, 0x3fffb0d7u, 0xb0e4e920u, 0x72345249u, 0x55d771e1u, 0x2bf89aa9u, 0xbb2833b2u, 0x9798e116u,
+                                       0xe937dc5cu, 0x314b0d43u, 0x003b42e3u}};
+
+// K*q with the borrow spread described above: c_0 = d_0 + S*2^28, c_i = d_i + S*2^28 - S, c_13 = d_13 - S
+constexpr Limbs14 spread_kq(uint32_t K, uint32_t S) {
+  Limbs14 d{}; uint64_t carry = 0;
+  for (int i = 0; i < 14; ++i) { uint64_t t = (uint64_t)Q28.v[i] * K + carry; d.v[i] = (uint32_t)(t & F28::MASK); carry = t >> 28; }
+  Limbs14 c{};
+  for (int i = 0; i < 14; ++i) c.v[i] = d.v[i] + (i < 13 ? S << 28 : 0u) - (i > 0 ? S : 0u);
+  return c;
+}
+
+__device__ __forceinline__ F28 f28_const(const Limbs14& k) { F28 r; for (int i = 0; i < 14; ++i) r.v[i] = k.v[i]; return r; }
+__device__ __forceinline__ F28 f28_mul(const F28& a, const F28& b) { F28 r = a; mont28_mul_inplace(r.v, b.v); return r; }
+__device__ __forceinline__ F28 f28_sqr(const F28& a) { F28 r = a; mont28_sqr_inplace(r.v); return r; }
+__device__ __forceinline__ F28 f28_add(const F28& a, const F28& b) {
+  F28 r;
+#pragma unroll
+  for (int i = 0; i < 14; ++i) r.v[i] = a.v[i] + b.v[i];
+  return r;
+}
+template <uint32_t K, uint32_t S> __device__ __forceinline__ F28 f28_sub(const F28& a, const F28& b) {
+  constexpr Limbs14 c = spread_kq(K, S);
+  static_assert(c.v[13] < 0x80000000u, "K too small for this spread");
+  F28 r;
+#pragma unroll
+  for (int i = 0; i < 14; ++i) r.v[i] = a.v[i] + c.v[i] - b.v[i];
+  return r;
+}
+// carry-propagate to exact base-2^28 digits (the value must be < 2^392; the top limb keeps what is left)
+__device__ __forceinline__ F28 f28_normalise(const F28& a) {
+  F28 r = a;
+#pragma unroll
+  for (int i = 0; i < 13; ++i) { r.v[i + 1] += r.v[i] >> 28; r.v[i] &= F28::MASK; }
+  return r;
+}
+// a == 0 (mod q) for an exact-digit value < 2q
+__device__ __forceinline__ bool f28_is_zero_mod_lt2q(const F28& a) {
+  uint32_t z = 0, e = 0;
+#pragma unroll
+  for (int i = 0; i < 14; ++i) { z |= a.v[i]; e |= a.v[i] ^ Q28.v[i]; }
+  return z == 0 || e == 0;
+}
+
+// ---- conversions (12 x 32-bit Montgomery R = 2^384  <->  14 x 28-bit Montgomery R' = 2^392) ------------------------
+__device__ __forceinline__ F28 relimb_32_to_28(const Fq& x) {      // same integer, value < 2^384
+  F28 r;
+#pragma unroll
+  for (int i = 0; i < 14; ++i) {
+    const int bit = 28 * i, j = bit >> 5, sh = bit & 31;
+    uint32_t w = j < 12 ? x.v[j] >> sh : 0u;
+    if (sh > 4 && j + 1 < 12) w |= x.v[j + 1] << (32 - sh);
+    r.v[i] = i < 13 ? (w & F28::MASK) : w;
+  }
+  return r;
+}
+__device__ __forceinline__ Fq relimb_28_to_32(const F28& a) {      // exact digits, value < 2^384
+  Fq r;
+#pragma unroll
+  for (int j = 0; j < 12; ++j) {
+    const int bit = 32 * j, i = bit / 28, sh = bit % 28;
+    uint32_t w = a.v[i] >> sh;
+    if (i + 1 < 14) w |= a.v[i + 1] << (28 - sh);
+    if (sh > 24 && i + 2 < 14) w |= a.v[i + 2] << (56 - sh);
+    r.v[j] = w;
+  }
+  return r;
+}
+// x * 2^384 (canonical or lazily reduced, < 16q)  ->  x * 2^392, exact digits, canonical
+__device__ __forceinline__ F28 f28_from_fq(const Fq& x) {
+  Fq k; for (int i = 0; i < 12; ++i) k.v[i] = K256_32.v[i];
+  return relimb_32_to_28(Fq::reduce(Fq::mul(x, k)));
+}
+// x * 2^392 (class N or L3, value < 64q)  ->  x * 2^384 as a lazily reduced Fq (< 2q)
+__device__ __forceinline__ Fq f28_to_fq(const F28& a) { return relimb_28_to_32(f28_mul(f28_const(R32_28), a)); }
+
+// 112-byte rows: x'[14] | y'[14]
+__device__ __forceinline__ void load_affine28(const void* p, F28& x, F28& y) {
+  const uint4* s = (const uint4*)p; uint32_t w[28];
+#pragma unroll
+  for (int i = 0; i < 7; ++i) { uint4 t = s[i]; w[4 * i] = t.x; w[4 * i + 1] = t.y; w[4 * i + 2] = t.z; w[4 * i + 3] = t.w; }
+#pragma unroll
+  for (int i = 0; i < 14; ++i) { x.v[i] = w[i]; y.v[i] = w[14 + i]; }
+}
+__device__ __forceinline__ void store_affine28(void* p, const F28& x, const F28& y) {
+  uint32_t w[28];
+#pragma unroll
+  for (int i = 0; i < 14; ++i) { w[i] = x.v[i]; w[14 + i] = y.v[i]; }
+  uint4* d = (uint4*)p;
+#pragma unroll
+  for (int i = 0; i < 7; ++i) d[i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
+}
+
+// ---- the mixed addition of the accumulation loop (EFD madd-2008-s, same formulas as ec.h xyzz_madd_fast) -----------------
+// Invariant of acc between additions: X exact digits (N) < 16q; Y class L3 < 8q; ZZ, ZZZ exact digits < 2q.
+// x2, y2: table entries, canonical exact digits (y2 may be the L3 negation).  Returns false — acc untouched — when
+// P == +-acc (ZZ3 == 0 mod q); the caller finishes the slice with the general 32-bit code.
+struct XYZZ28 { F28 X, Y, ZZ, ZZZ; };
+
+__device__ __forceinline__ bool xyzz28_madd_fast(XYZZ28& acc, const F28& x2, const F28& y2) {
+  // operand order: the product block works in place on its FIRST argument, so the argument that dies there goes first
+  F28 U2 = f28_mul(x2, acc.ZZ);                              // N x N  -> < 2q
+  F28 S2 = f28_mul(y2, acc.ZZZ);                             // L3 x N -> < 2q
+  F28 P = f28_normalise(f28_sub<16, 1>(U2, acc.X));          // U2 + 16q - X1 < 18q; digits
+  F28 R = f28_normalise(f28_sub<8, 4>(S2, acc.Y));           // Y1 limbs < 3 * 2^28 < 2^30 - 4; S2 + 8q - Y1 < 10q; digits
+  F28 PP = f28_sqr(P);                                       // 324/38000 + 1 -> < 2q
+  F28 ZZ3 = f28_mul(acc.ZZ, PP);                             // < 2q (copy: acc must survive a failed check)
+  if (__builtin_expect(f28_is_zero_mod_lt2q(ZZ3), 0)) return false;
+  F28 PPP = f28_mul(P, PP);                                  // < 2q
+  F28 Q = f28_mul(acc.X, PP);                                // < 2q
+  F28 RR = f28_sqr(R);                                       // < 2q
+  F28 t0 = f28_sub<4, 1>(RR, PPP);                           // < 6q, limbs < 3*2^28
+  F28 X3 = f28_normalise(f28_sub<6, 2>(t0, f28_add(Q, Q)));  // 2Q: limbs < 2^29, < 4q; X3 < 12q; digits
+  F28 t1 = f28_sub<16, 1>(Q, X3);                            // Q + 16q - X3 < 18q, limbs < 3*2^28
+  F28 Rt = f28_mul(R, t1);                                   // N x L3 -> < 2q
+  F28 YP = f28_mul(acc.Y, PPP);                              // L3 x N -> < 2q
+  acc.X = X3;
+  acc.Y = f28_sub<4, 1>(Rt, YP);                             // < 6q, limbs < 3*2^28
+  acc.ZZ = ZZ3;
+  acc.ZZZ = f28_mul(acc.ZZZ, PPP);                           // < 2q
+  return true;
+}
+
+}  // namespace aleo_mi355x

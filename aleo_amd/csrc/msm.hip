@@ -23,6 +23,7 @@
 // n*W x 4 B; partial sums #slices x 192 B (XYZZ).  Algorithmic bytes per point: 32 (scalar) + 96 (base).
 #include "ctx.h"
 #include "ec.h"
+#include "fp28.h"
 #include "host_field.hpp"
 
 namespace aleo_mi355x {
@@ -516,6 +517,71 @@ __global__ void __launch_bounds__(256) k_accum(const char* __restrict__ bases, c
   xyzz_store_normalized(partial + (size_t)sid * 192, acc, inf);
 }
 
+// ---- the same loop on the fixed-base table, in the 14 x 28-bit representation (fp28.h) ---------------------------------
+// Table rows are 112 bytes (x'[14] | y'[14], value * 2^392 mod q as exact base-2^28 digits).  The slice sum is handed on
+// as an ordinary 32-bit XYZZ point (4 conversions per slice, ~0.3 of an addition), so nothing after this kernel changes.
+__device__ __forceinline__ XYZZ xyzz28_to_xyzz(const XYZZ28& a) {
+  XYZZ r; r.X = f28_to_fq(a.X); r.Y = f28_to_fq(a.Y); r.ZZ = f28_to_fq(a.ZZ); r.ZZZ = f28_to_fq(a.ZZZ); return r;     // all < 2q
+}
+__device__ __noinline__ void slice_slow_path28(const char* bases, const uint32_t* run, uint32_t j, uint32_t j1, const XYZZ28* acc28, XYZZ* acc_out, bool* inf_out) {
+  XYZZ acc = xyzz28_to_xyzz(*acc28); bool inf = false;
+  for (; j < j1; ++j) {
+    uint32_t e = run[j];
+    F28 x, y; load_affine28(bases + (size_t)(e & 0x7fffffffu) * 112, x, y);
+    AffinePt p; p.x = Fq::reduce(f28_to_fq(x)); p.y = Fq::reduce(f28_to_fq(y));
+    if (e >> 31) p.y = fq_neg_canonical(p.y);
+    xyzz_madd(acc, inf, p.x, p.y);
+  }
+  *acc_out = acc; *inf_out = inf;
+}
+
+__global__ void __launch_bounds__(256) k_accum28(const char* __restrict__ bases, const uint32_t* __restrict__ sorted, const uint32_t* __restrict__ hist,
+                                                 const uint2* __restrict__ scan_local, const uint2* __restrict__ scan_blk, const uint32_t* __restrict__ total_pairs, uint32_t M,
+                                                 const uint32_t* __restrict__ meta, const uint32_t* __restrict__ order, const uint32_t* __restrict__ task_g,
+                                                 char* __restrict__ partial) {
+  uint32_t t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= meta[0]) return;
+  const uint32_t sid = order[t], g = task_g[sid];
+  uint2 st = scan_at(scan_local, scan_blk, g);
+  uint32_t cnt = hist[g], m = slices_of(cnt, pick_rule(total_pairs, M)), k = sid - st.y;
+  uint32_t j0 = (uint32_t)(((uint64_t)k * cnt) / m), j1 = (uint32_t)(((uint64_t)(k + 1) * cnt) / m);
+  const uint32_t* run = sorted + st.x;
+  uint32_t e_next = run[j0];
+  F28 xn, yn; load_affine28(bases + (size_t)(e_next & 0x7fffffffu) * 112, xn, yn);      // next point's 112-byte gather in flight under the current addition
+  XYZZ28 acc; bool ok = true;
+  uint32_t j = j0;
+  {   // first point of the slice: acc = (x, +-y, 1, 1)
+    uint32_t e = e_next; F28 x = xn, y = yn;
+    if (j + 1 < j1) { e_next = run[j + 1]; load_affine28(bases + (size_t)(e_next & 0x7fffffffu) * 112, xn, yn); }
+    if (e >> 31) y = f28_sub<2, 1>(f28_const(Limbs14{}), y);                            // 2q - y: limbs < 2^29
+    acc.X = x; acc.Y = y; acc.ZZ = f28_const(ONE28); acc.ZZZ = f28_const(ONE28);
+    ++j;
+  }
+  for (; j < j1; ++j) {
+    uint32_t e = e_next; F28 x = xn, y = yn;
+    if (j + 1 < j1) { e_next = run[j + 1]; load_affine28(bases + (size_t)(e_next & 0x7fffffffu) * 112, xn, yn); }
+    if (e >> 31) y = f28_sub<2, 1>(f28_const(Limbs14{}), y);
+    if (!xyzz28_madd_fast(acc, x, y)) { ok = false; break; }
+  }
+  XYZZ out; bool inf = false;
+  if (ok) out = xyzz28_to_xyzz(acc);
+  else {      // P == +-acc (repeated or opposite bases): finish the slice with the general 32-bit code, out of line
+    XYZZ28 tmp = acc;
+    slice_slow_path28(bases, run, j, j1, &tmp, &out, &inf);
+  }
+  xyzz_store_normalized(partial + (size_t)sid * 192, out, inf);
+}
+
+// 96-byte rows (x | y, 12 x 32-bit Montgomery) -> 112-byte rows of the 28-bit table; (0, 0) marks the identity and stays 0
+__global__ void __launch_bounds__(256) k_rows_to28(const char* __restrict__ src96, char* __restrict__ dst112, uint32_t n) {
+  uint32_t i = blockIdx.x * 256 + threadIdx.x; if (i >= n) return;
+  AffinePt p = load_affine(src96 + (size_t)i * 96);
+  F28 x, y;
+  if (p.x.is_zero_raw() && p.y.is_zero_raw()) { x = f28_const(Limbs14{}); y = x; }
+  else { x = f28_from_fq(p.x); y = f28_from_fq(p.y); }
+  store_affine28(dst112 + (size_t)i * 112, x, y);
+}
+
 // Every kernel from here to the host tail is a chain of full XYZZ additions with little parallelism, so each addition
 // is shared by a lane pair (ec.h xyzz_add_pair: same work, half the latency).  "op" below = pair index = thread / 2.
 __device__ __forceinline__ void pair_fence() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); }
@@ -781,7 +847,8 @@ int32_t msm_run(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, const void* 
     hipLaunchKernelGGL(k_len_starts, dim3(1), dim3(256), 0, s, len_count, len_start);
     hipLaunchKernelGGL(k_slice_order, dim3((NT + 255) / 256), dim3(256), 0, s, hist, scan_local, scan_blk, total_pairs, M, meta, task_g, len_start, len_cursor, order);
     HIPCHK(hipEventRecord(c->ev[6], s));          // ev[6]..ev[5] bracket k_accum alone (bench.py's roofline kernel)
-    hipLaunchKernelGGL(k_accum, dim3((NT + 255) / 256), dim3(256), 0, s, bases, sorted, hist, scan_local, scan_blk, total_pairs, M, meta, order, task_g, partial);
+    if (pre) hipLaunchKernelGGL(k_accum28, dim3((NT + 255) / 256), dim3(256), 0, s, bases, sorted, hist, scan_local, scan_blk, total_pairs, M, meta, order, task_g, partial);
+    else hipLaunchKernelGGL(k_accum, dim3((NT + 255) / 256), dim3(256), 0, s, bases, sorted, hist, scan_local, scan_blk, total_pairs, M, meta, order, task_g, partial);
     HIPCHK(hipEventRecord(c->ev[5], s));
     const uint32_t* super_list = heavy + M + 2048;
     for (uint32_t pass = 0, L = max_m; L > 1; ++pass, L = (L + 1) >> 1) {
@@ -965,20 +1032,21 @@ int32_t msm_precompute(Ctx* c, PinnedBases* pb) {
   if (pb->d_pre || pb->n == 0) return ALEO_MI355X_OK;
   const size_t n = pb->n; const int pre_c = pre_c_for(n); const uint32_t W = (SCALAR_BITS + pre_c - 1) / pre_c;
   if (n * (size_t)W >= (1ull << 31)) { g_last_error = "bases_precompute: table index would exceed 31 bits"; return ALEO_MI355X_ERR_BAD_ARG; }
-  void *d_tab = nullptr, *d_cur = nullptr, *d_prefix = nullptr;
-  HIPCHK(hipMalloc(&d_tab, n * 96 * W));
-  HIPCHK(hipMalloc(&d_cur, n * 192)); HIPCHK(hipMalloc(&d_prefix, n * 48));
+  void *d_tab = nullptr, *d_cur = nullptr, *d_prefix = nullptr, *d_row = nullptr;
+  HIPCHK(hipMalloc(&d_tab, n * 112 * W));                                    // rows in the accumulation kernel's 28-bit format (fp28.h)
+  HIPCHK(hipMalloc(&d_cur, n * 192)); HIPCHK(hipMalloc(&d_prefix, n * 48)); HIPCHK(hipMalloc(&d_row, n * 96));
   hipStream_t s = c->stream;
-  HIPCHK(hipMemcpyAsync(d_tab, pb->d_xy, n * 96, hipMemcpyDeviceToDevice, s));
   const uint32_t g = (uint32_t)((n + 255) / 256), lanes = (uint32_t)((n + GEN_K - 1) / GEN_K), gl = (lanes + 255) / 256;
+  hipLaunchKernelGGL(k_rows_to28, dim3(g), dim3(256), 0, s, (const char*)pb->d_xy, (char*)d_tab, (uint32_t)n);
   hipLaunchKernelGGL(k_pre_init, dim3(g), dim3(256), 0, s, (const char*)pb->d_xy, (uint32_t)n, (char*)d_cur);
   for (uint32_t w = 1; w < W; ++w) {
     hipLaunchKernelGGL(k_pre_double, dim3(g), dim3(256), 0, s, (char*)d_cur, (uint32_t)n, pre_c);
-    hipLaunchKernelGGL(k_gen_normalize, dim3(gl), dim3(256), 0, s, (char*)d_cur, (uint32_t)n, (char*)d_prefix, (char*)d_tab + (size_t)w * n * 96);
+    hipLaunchKernelGGL(k_gen_normalize, dim3(gl), dim3(256), 0, s, (char*)d_cur, (uint32_t)n, (char*)d_prefix, (char*)d_row);
+    hipLaunchKernelGGL(k_rows_to28, dim3(g), dim3(256), 0, s, (const char*)d_row, (char*)d_tab + (size_t)w * n * 112, (uint32_t)n);
   }
   HIPCHK(hipStreamSynchronize(s));
   HIPCHK(hipGetLastError());
-  (void)hipFree(d_cur); (void)hipFree(d_prefix);
+  (void)hipFree(d_cur); (void)hipFree(d_prefix); (void)hipFree(d_row);
   pb->d_pre = d_tab; pb->pre_c = pre_c;
   return ALEO_MI355X_OK;
 }

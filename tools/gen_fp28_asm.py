@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""EXPERIMENT (not part of the library).  Generates tools/ubench/fp28_mont_gen.h: Fq Montgomery product on 14 x 28-bit limbs (R = 2^392) for gfx950.
+"""Generates aleo_amd/csrc/fp28_mont_gen.h: Fq Montgomery product on 14 x 28-bit limbs (R = 2^392) for gfx950.
 
 Why a second representation.  With 32-bit limbs every v_mad_u64_u32 needs a v_addc to catch its carry-out (the 64-bit
 column accumulator can overflow): 288 + 288 instructions per product.  With 28-bit limbs a 64-bit accumulator holds a
@@ -9,10 +9,10 @@ instructions per column = ~465 VALU instead of 649.  q == 1 mod 2^28 as well, so
 Limb bounds ("classes").  N: every limb < 2^28.  Products accept limbs a_i * b_j < 2^58.2 for all i, j (28 of them plus
 the carry-in stay below 2^64); the result is class N with the value < (A*B*q/R + 1) * q, R/q ~ 2^15.2.
 
-Outcome (profiles/r01_fq28_mul_bench.txt, tools/ubench/fq28_mul_bench.hip): 463 VALU / 392 mads per product, 62 G products/s at
-the 2 waves/SIMD the accumulation kernel runs at (12 x 32-bit: 53-60), 81 G/s only at 4 waves x 2 products per lane.  The
-mads issue at ~5.5 cycles each whatever sits between them, so removing the 288 carry catches buys less than the count
-suggests; with the limb-class bookkeeping and a second table format it was not worth rewriting the group law for.
+Measured (profiles/r01_fq28_mul_bench.txt, tools/ubench/fq28_mul_bench.hip): 463 VALU / 392 mads per product, 81 G products/s
+at sustained clocks against 60.7 G/s for the 12 x 32-bit block (short runs of either read low: the clock is still ramping).
+Two accumulator chains per column were tried and are slower: a wave issues a mad every ~10 cycles whether or not it depends
+on the previous one (profiles/r01_mad_dep_ubench.txt), so only the instruction count matters.
 """
 import sys
 
@@ -103,7 +103,7 @@ namespace aleo_mi355x {
 
 
 def main():
-    path = sys.argv[1] if len(sys.argv) > 1 else 'tools/ubench/fp28_mont_gen.h'
+    path = sys.argv[1] if len(sys.argv) > 1 else 'aleo_amd/csrc/fp28_mont_gen.h'
     s = HEADER + gen('mont28_mul_inplace') + '\n' + gen('mont28_sqr_inplace', square=True) + '\n}  // namespace aleo_mi355x\n'
     open(path, 'w').write(s)
 
