@@ -38,7 +38,7 @@ class PinnedBases:
         return cls(None, h.value, n)
 
     def precompute(self) -> 'PinnedBases':
-        """Build the fixed-base window table in HBM (13 x 96 B per point); full-length MSMs then take the fast path."""
+        """Build the fixed-base window table in HBM (13 x 112 B per point at 2^20); full-length MSMs then take the fast path."""
         check(lib().aleo_mi355x_bases_precompute(self.handle), 'bases_precompute')
         return self
 

@@ -78,7 +78,7 @@ int32_t aleo_mi355x_bases_unpin(uint64_t handle);
  * snarkVM Affine (104 bytes, host).  first_multiple >= 1 and first_multiple + n must stay below r. */
 int32_t aleo_mi355x_bases_generate(const void* base_affine104, uint64_t first_multiple, size_t n, uint64_t* handle);
 /* Optional fixed-base acceleration for a pinned set (an SRS never changes): builds the table of window multiples
- * 2^(c w) * P_i in HBM (c = 20 / 17 / 16 by pinned count: 13-16 x 96 bytes per point).  MSMs over this handle — any
+ * 2^(c w) * P_i in HBM (c = 20 / 17 / 16 by pinned count: 13-16 x 112 bytes per point, stored in the 28-bit-limb form the accumulation kernel computes in).  MSMs over this handle — any
  * prefix that still fills the buckets — then add one table entry per window into ONE shared bucket set (13 instead of
  * 16 additions per point at 2^20) and skip the Horner tail.  Same results, bit for bit after normalisation. */
 int32_t aleo_mi355x_bases_precompute(uint64_t handle);
