@@ -13,7 +13,7 @@ EXPORTS = [
     'aleo_mi355x_msm_g1_pinned', 'aleo_mi355x_msm_g1_device', 'aleo_mi355x_g1_sum', 'aleo_mi355x_ntt_fr',
     'aleo_mi355x_ntt_fr_device', 'aleo_mi355x_ntt_fr_batch_device', 'aleo_mi355x_fr_grid_scale_device', 'aleo_mi355x_kzg_commit', 'aleo_mi355x_kzg_commit_device', 'aleo_mi355x_kzg_commit_hiding',
     'aleo_mi355x_fr_vec_op_device', 'aleo_mi355x_fr_batch_inverse_device', 'aleo_mi355x_fr_spmv_device', 'aleo_mi355x_fq_mul',
-    'aleo_mi355x_fr_mul', 'aleo_mi355x_last_msm_timing', 'aleo_mi355x_strerror', 'aleo_mi355x_last_error',
+    'aleo_mi355x_fr_mul', 'aleo_mi355x_selftest_madd28', 'aleo_mi355x_last_msm_timing', 'aleo_mi355x_strerror', 'aleo_mi355x_last_error',
     'aleo_mi355x_version',
 ]
 
@@ -64,6 +64,7 @@ def lib():
         'aleo_mi355x_fr_spmv_device': ([vp, vp, vp, vp, vp, sz, vp], i32),
         'aleo_mi355x_fq_mul': ([vp, vp, vp, sz], i32),
         'aleo_mi355x_fr_mul': ([vp, vp, vp, sz], i32),
+        'aleo_mi355x_selftest_madd28': ([u32, u32, u64, ctypes.POINTER(u32)], i32),
         'aleo_mi355x_last_msm_timing': ([ctypes.POINTER(ctypes.c_double), i32], i32),
         'aleo_mi355x_strerror': ([i32], ctypes.c_char_p),
         'aleo_mi355x_last_error': ([], ctypes.c_char_p),

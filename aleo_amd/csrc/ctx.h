@@ -102,6 +102,7 @@ int32_t launch_fq_mul(Ctx* c, void* r, const void* a, const void* b, size_t n);
 int32_t launch_fr_mul(Ctx* c, void* r, const void* a, const void* b, size_t n);
 int32_t generate_multiples(Ctx* c, const void* base104, uint64_t first, size_t n, PinnedBases* out);
 int32_t msm_precompute(Ctx* c, PinnedBases* pb);
+int32_t selftest_madd28(Ctx* c, uint32_t lanes, uint32_t steps, uint64_t seed, uint32_t* failures);
 // frops.hip
 int32_t fr_vec_op(Ctx* c, void* d_dst, const void* d_a, const void* d_b, size_t n, int32_t op, hipStream_t s);
 int32_t fr_batch_inverse(Ctx* c, void* d_inout, size_t n, hipStream_t s);

@@ -1051,6 +1051,41 @@ int32_t msm_precompute(Ctx* c, PinnedBases* pb) {
   return ALEO_MI355X_OK;
 }
 
+// ---- self-test of the 28-bit-limb mixed addition against the 32-bit formulas (test hook; tools/ubench/madd28_check.hip) ----
+__device__ __forceinline__ uint32_t st_rng(uint64_t& s) { s = s * 6364136223846793005ull + 1442695040888963407ull; return (uint32_t)(s >> 32); }
+__device__ __forceinline__ Fq st_rnd_fq(uint64_t& s) { Fq r; for (int i = 0; i < 12; ++i) r.v[i] = st_rng(s); r.v[11] &= 0x00ffffffu; return Fq::reduce(r); }
+__device__ __forceinline__ bool st_same(const Fq& a, const Fq& b) { Fq x = Fq::reduce(a), y = Fq::reduce(b); uint32_t d = 0; for (int i = 0; i < 12; ++i) d |= x.v[i] ^ y.v[i]; return d == 0; }
+__global__ void __launch_bounds__(256) k_selftest_madd28(uint32_t* bad, uint32_t steps, uint64_t seed) {
+  uint64_t s = seed * (blockIdx.x * 256 + threadIdx.x + 1);
+  Fq z = st_rnd_fq(s);
+  if (!st_same(f28_to_fq(f28_from_fq(z)), z)) { atomicAdd(bad, 1u); return; }                 // representation round trip
+  XYZZ a; a.X = st_rnd_fq(s); a.Y = st_rnd_fq(s); a.ZZ = Fq::one(); a.ZZZ = Fq::one();
+  XYZZ28 b; b.X = f28_from_fq(a.X); b.Y = f28_from_fq(a.Y); b.ZZ = f28_const(ONE28); b.ZZZ = f28_const(ONE28);
+  for (uint32_t it = 0; it < steps; ++it) {
+    Fq x = st_rnd_fq(s), y = st_rnd_fq(s);
+    F28 x28 = f28_from_fq(x), y28 = f28_from_fq(y);
+    if (st_rng(s) & 1) { y = fq_neg_canonical(y); y28 = f28_sub<2, 1>(f28_const(Limbs14{}), y28); }
+    if (it == steps / 2) { x = Fq::reduce(a.X); x28 = f28_from_fq(x); }                       // same x as acc (ZZ == 1 only at it == 0, so usually a plain point)
+    const bool ok32 = xyzz_madd_fast(a, x, y), ok28 = xyzz28_madd_fast(b, x28, y28);
+    if (ok32 != ok28) { atomicAdd(bad, 1u); return; }
+    if (!ok32) break;
+    if (!st_same(f28_to_fq(b.X), a.X) || !st_same(f28_to_fq(b.Y), a.Y) || !st_same(f28_to_fq(b.ZZ), a.ZZ) || !st_same(f28_to_fq(b.ZZZ), a.ZZZ)) { atomicAdd(bad, 1u); return; }
+  }
+  XYZZ c; c.X = st_rnd_fq(s); c.Y = st_rnd_fq(s); c.ZZ = Fq::one(); c.ZZZ = Fq::one();        // P == acc must be refused by both
+  XYZZ28 d; d.X = f28_from_fq(c.X); d.Y = f28_from_fq(c.Y); d.ZZ = f28_const(ONE28); d.ZZZ = f28_const(ONE28);
+  if (xyzz_madd_fast(c, c.X, c.Y) || xyzz28_madd_fast(d, d.X, d.Y)) atomicAdd(bad, 1u);
+}
+int32_t selftest_madd28(Ctx* c, uint32_t lanes, uint32_t steps, uint64_t seed, uint32_t* failures) {
+  int32_t rc; if ((rc = c->scalars_stage.reserve(64))) return rc;
+  uint32_t* d = c->scalars_stage.as<uint32_t>();
+  HIPCHK(hipMemsetAsync(d, 0, 4, c->stream));
+  hipLaunchKernelGGL(k_selftest_madd28, dim3((lanes + 255) / 256), dim3(256), 0, c->stream, d, steps, seed | 1ull);
+  HIPCHK(hipMemcpyAsync(failures, d, 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  HIPCHK(hipGetLastError());
+  return ALEO_MI355X_OK;
+}
+
 // ---- element-wise products (parity tests pin the device arithmetic with these) -------------------
 template <class F, bool SQR> __global__ void __launch_bounds__(256) k_fp_mul(char* r, const char* a, const char* b, uint32_t n) {
   uint32_t i = blockIdx.x * 256 + threadIdx.x; if (i >= n) return;

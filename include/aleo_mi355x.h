@@ -141,6 +141,11 @@ int32_t aleo_mi355x_fr_spmv_device(void* d_y, const void* d_row_ptr, const void*
 int32_t aleo_mi355x_fq_mul(void* r, const void* a, const void* b, size_t n);
 int32_t aleo_mi355x_fr_mul(void* r, const void* a, const void* b, size_t n);
 
+/* Test hook: `lanes` device lanes each run `steps` mixed additions of pseudo-random field elements through the 28-bit-limb
+ * formulas of the accumulation kernel and through the 32-bit ones, comparing every intermediate as canonical residues
+ * (and that both refuse P == acc).  *failures = number of lanes that disagreed. */
+int32_t aleo_mi355x_selftest_madd28(uint32_t lanes, uint32_t steps, uint64_t seed, uint32_t* failures);
+
 /* Per-call instrumentation of the calling thread's most recent MSM: milliseconds per phase
  * [0] total, [1] digit/sort, [2] bucket accumulation incl. slice tree, [3] bucket reduction, [4] host tail,
  * [5] the bucket-accumulation kernel alone (the dominant kernel bench.py prices against the roofline).

@@ -48,6 +48,15 @@ def test_fq_fr_products_bit_exact():
     assert (M.fr_mul(x, x) == e).all()
 
 
+def test_accumulation_arithmetic_28bit_limbs_matches_32bit():
+    """The bucket-accumulation kernel computes in a 14 x 28-bit-limb representation (fp28.h); its mixed addition must agree
+    with the 32-bit formulas (which the product tests above pin to the oracle) on every intermediate, mod q."""
+    import ctypes
+    bad = ctypes.c_uint32(123)
+    aleo_amd._lib.check(aleo_amd.lib().aleo_mi355x_selftest_madd28(1 << 16, 32, 0x9E3779B97F4A7C15, ctypes.byref(bad)), 'selftest')
+    assert bad.value == 0
+
+
 # ---- NTT ----------------------------------------------------------------------------------------------
 def test_ntt_golden_vectors():
     fx = json.load(open(os.path.join(G, 'ntt_small.json')))
