@@ -621,7 +621,7 @@ __global__ void __launch_bounds__(256) k_tree_pass(char* __restrict__ partial, c
 // kept in LDS between the cooperative additions, so acc = sum_{b in chunk} (b - base + 1) * S_b and run = chunk total.
 // Both go to HBM (V, Vrun); the chunk weights are applied by masked sums (fixed-base path).
 static constexpr uint32_t CHUNK_PAIRS = 128;        // chunks per 256-thread block
-__global__ void __launch_bounds__(256) k_bucket_chunks(const char* __restrict__ partial, const uint32_t* __restrict__ hist, const uint2* __restrict__ scan_local,
+__global__ void __launch_bounds__(256) k_bucket_chunks_pair(const char* __restrict__ partial, const uint32_t* __restrict__ hist, const uint2* __restrict__ scan_local,
                                                        const uint2* __restrict__ scan_blk, uint32_t B, uint32_t S, uint32_t nchunks_total, char* __restrict__ V,
                                                        char* __restrict__ Vrun) {
   __shared__ __attribute__((aligned(16))) uint32_t lds[2 * CHUNK_PAIRS * 48];
@@ -637,6 +637,38 @@ __global__ void __launch_bounds__(256) k_bucket_chunks(const char* __restrict__ 
     xyzz_add_pair(acc, run, acc); pair_fence();
   }
   pair_copy(run, Vrun + (size_t)t * 192); pair_copy(acc, V + (size_t)t * 192);
+}
+
+// One lane QUAD per chunk of S consecutive buckets: running sums run_k = run_{k-1} + S_b (b descending) and acc += run_{k-1}
+// are independent once run_{k-1} exists, so two lane pairs work one step apart (S + 1 dependent additions instead of 2S):
+// sub-pair 0 extends the running sum (double-buffered in LDS), sub-pair 1 folds the previous one into acc.  Both make the
+// SAME xyzz_add_pair call with per-lane pointers (a branch per sub-pair would serialise them inside the wave).
+// acc = sum_{b in chunk} (b - base + 1) * S_b and run = chunk total go to HBM (V, Vrun); the chunk weights are applied by
+// masked sums (fixed-base path).
+static constexpr uint32_t CHUNK_QUADS = 64;         // chunks per 256-thread block
+__global__ void __launch_bounds__(256) k_bucket_chunks(const char* __restrict__ partial, const uint32_t* __restrict__ hist, const uint2* __restrict__ scan_local,
+                                                       const uint2* __restrict__ scan_blk, uint32_t B, uint32_t S, uint32_t nchunks_total, char* __restrict__ V,
+                                                       char* __restrict__ Vrun) {
+  __shared__ __attribute__((aligned(16))) uint32_t lds[(3 * CHUNK_QUADS + 1) * 48];
+  const uint32_t qd = threadIdx.x >> 2, sp = (threadIdx.x >> 1) & 1u, t = blockIdx.x * CHUNK_QUADS + qd;
+  char* zero = (char*)(lds + 3 * CHUNK_QUADS * 48);
+  if (threadIdx.x < 2) pair_zero(zero);
+  __syncthreads();
+  if (t >= nchunks_total) return;
+  char* buf0 = (char*)(lds + (3 * qd) * 48); char* buf1 = buf0 + 192; char* acc = buf1 + 192;
+  pair_zero(sp ? acc : buf0); if (!sp) pair_zero(buf1);
+  pair_fence();
+  const uint32_t cpw = B / S, w = t / cpw, j = t % cpw, g0 = w * B + j * S;
+  for (uint32_t k = 0; k <= S; ++k) {
+    char* rprev = (k & 1) ? buf0 : buf1; char* rnext = (k & 1) ? buf1 : buf0;      // run_k lives in buf[k & 1]; run_{-1} = 0
+    const char* add = zero;
+    if (!sp && k < S) { const uint32_t g = g0 + (S - 1 - k); if (hist[g]) add = partial + (size_t)scan_at(scan_local, scan_blk, g).y * 192; }
+    const char* pa = sp ? acc : rprev; const char* pb = sp ? rprev : add; char* out = sp ? acc : rnext;
+    xyzz_add_pair(pa, pb, out);
+    pair_fence();
+  }
+  // after step S: buf[S & 1] holds run_{S-1} again (step S copied it forward), acc holds sum_k run_k
+  pair_copy(sp ? acc : ((S & 1) ? buf1 : buf0), (sp ? V : Vrun) + (size_t)t * 192);
 }
 
 // Plain path (one window set per window): one lane per chunk, V = sum_{b in chunk} (b+1) * S_b with the chunk base applied
@@ -874,7 +906,9 @@ int32_t msm_run(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, const void* 
   if (masked) {
     // sum_b (b+1) S_b = sum_j acc_j + S * sum_j j * run_j ; the second sum by lg(N) masked pairwise trees
     char* T = V + (size_t)nchunks * 192; char* Vrun = T + (size_t)lgN * (cpw / 4) * 192; char* Tout = Vrun + (size_t)nchunks * 192;
-    hipLaunchKernelGGL(k_bucket_chunks, dim3((nchunks + CHUNK_PAIRS - 1) / CHUNK_PAIRS), dim3(256), 0, s, partial, hist, scan_local, scan_blk, P.B, P.S, nchunks, V, Vrun);
+    // 2^19 buckets keep the chip busy with one lane pair per chunk; the small bucket sets (<= 2^16) are pure latency and take the quad form
+    if (P.c >= 20) hipLaunchKernelGGL(k_bucket_chunks_pair, dim3((nchunks + CHUNK_PAIRS - 1) / CHUNK_PAIRS), dim3(256), 0, s, partial, hist, scan_local, scan_blk, P.B, P.S, nchunks, V, Vrun);
+    else hipLaunchKernelGGL(k_bucket_chunks, dim3((nchunks + CHUNK_QUADS - 1) / CHUNK_QUADS), dim3(256), 0, s, partial, hist, scan_local, scan_blk, P.B, P.S, nchunks, V, Vrun);
     const uint32_t tseg = cpw / 4, fseg = lgN + 4;      // Vacc viewed as 4 segments of cpw/4, followed by the lgN masked sums
     hipLaunchKernelGGL(k_masked_pairs, dim3((2 * tseg * lgN + 255) / 256), dim3(256), 0, s, Vrun, lgN, T);
     // (lgN+4) segment sums: pairwise launches while a level still fills the chip, then ONE block per segment folds the
