@@ -7,10 +7,10 @@
 // become carry-free limb-wise operations; what they cost instead is bookkeeping of LIMB bounds next to the value bounds.
 //
 // Value bounds: R'/q ~ 2^15.2, so a product of a < A*q, b < B*q is < (A*B/38000 + 1)*q — every product below is < 2q.
-// Limb bounds ("class"): the product block needs a_i * b_j < 2^59.1 for all i, j (28 terms + carry-in < 2^64):
-//   N  : limbs < 2^28 (exact base-2^28 digits; what a product or normalise() returns)
-//   L3 : limbs < 3 * 2^28 (an N value minus an N value through sub<K, 1>; or N + N)
-//   products used: N x N, N x L3 (2^57.6 * 28 < 2^62.5), never L3 x L3.
+// Limb bounds ("class Lk": every limb < k * 2^28; L1 = exact base-2^28 digits, what a product or normalise() returns).
+// A column of a product holds at most 14 terms a_i*b_j plus 14 terms m_i*p_j (< 2^56 each) plus a carry-in < 2^36, all in
+// one 64-bit accumulator, so   14 * ka * kb + 14 < 256   for a La x Lb product (e.g. L3 x L3: 140, L4 x L3: 182);
+// a squaring doubles the cross terms: 7 * 2 * k^2 + 14 < 256 (L3: 140, L4: 238); muladd adds both products' terms.
 // sub<K, S>(a, b) = a - b + K*q limb-wise, with K*q spread so that every limb of the constant is >= S * 2^28 - S:
 // needs b's limbs < S * 2^28 - S + (K*q)_i and b < K*q as a value; the result's limbs are < a_max + (S + 1) * 2^28.
 #pragma once
@@ -50,6 +50,8 @@ constexpr Limbs14 spread_kq(uint32_t K, uint32_t S) {
 __device__ __forceinline__ F28 f28_const(const Limbs14& k) { F28 r; for (int i = 0; i < 14; ++i) r.v[i] = k.v[i]; return r; }
 __device__ __forceinline__ F28 f28_mul(const F28& a, const F28& b) { F28 r = a; mont28_mul_inplace(r.v, b.v); return r; }
 __device__ __forceinline__ F28 f28_sqr(const F28& a) { F28 r = a; mont28_sqr_inplace(r.v); return r; }
+// (a*b + c*d) * 2^-392 under ONE Montgomery reduction (588 mads instead of 2 x 392)
+__device__ __forceinline__ F28 f28_muladd(const F28& a, const F28& b, const F28& c, const F28& d) { F28 r = a; mont28_muladd_inplace(r.v, b.v, c.v, d.v); return r; }
 __device__ __forceinline__ F28 f28_add(const F28& a, const F28& b) {
   F28 r;
 #pragma unroll
@@ -129,30 +131,29 @@ __device__ __forceinline__ void store_affine28(void* p, const F28& x, const F28&
 }
 
 // ---- the mixed addition of the accumulation loop (EFD madd-2008-s, same formulas as ec.h xyzz_madd_fast) -----------------
-// Invariant of acc between additions: X exact digits (N) < 16q; Y class L3 < 8q; ZZ, ZZZ exact digits < 2q.
-// x2, y2: table entries, canonical exact digits (y2 may be the L3 negation).  Returns false — acc untouched — when
-// P == +-acc (ZZ3 == 0 mod q); the caller finishes the slice with the general 32-bit code.
+// Invariant of acc between additions: X exact digits < 12q; Y < 2q as exact digits (or the first point's 2q - y, class L2);
+// ZZ, ZZZ exact digits < 2q.  x2, y2: table entries, canonical exact digits (y2 may be the L2 negation 2q - y).
+// Returns false — acc untouched — when P == +-acc (ZZ3 == 0 mod q); the caller finishes the slice with the general 32-bit code.
 struct XYZZ28 { F28 X, Y, ZZ, ZZZ; };
 
 __device__ __forceinline__ bool xyzz28_madd_fast(XYZZ28& acc, const F28& x2, const F28& y2) {
   // operand order: the product block works in place on its FIRST argument, so the argument that dies there goes first
-  F28 U2 = f28_mul(x2, acc.ZZ);                              // N x N  -> < 2q
-  F28 S2 = f28_mul(y2, acc.ZZZ);                             // L3 x N -> < 2q
-  F28 P = f28_normalise(f28_sub<16, 1>(U2, acc.X));          // U2 + 16q - X1 < 18q; digits
-  F28 R = f28_normalise(f28_sub<8, 4>(S2, acc.Y));           // Y1 limbs < 3 * 2^28 < 2^30 - 4; S2 + 8q - Y1 < 10q; digits
-  F28 PP = f28_sqr(P);                                       // 324/38000 + 1 -> < 2q
+  F28 U2 = f28_mul(x2, acc.ZZ);                              // < 2q
+  F28 S2 = f28_mul(y2, acc.ZZZ);                             // L2 x L1 -> < 2q
+  F28 P = f28_sub<16, 1>(U2, acc.X);                         // U2 + 16q - X1 < 18q, class L3
+  F28 R = f28_sub<4, 2>(S2, acc.Y);                          // Y1 limbs < 2^29 - 2; S2 + 4q - Y1 < 6q, class L4
+  F28 PP = f28_sqr(P);                                       // L3 squared: 140 < 256; 324/38000 + 1 -> < 2q
   F28 ZZ3 = f28_mul(acc.ZZ, PP);                             // < 2q (copy: acc must survive a failed check)
   if (__builtin_expect(f28_is_zero_mod_lt2q(ZZ3), 0)) return false;
-  F28 PPP = f28_mul(P, PP);                                  // < 2q
+  F28 PPP = f28_mul(P, PP);                                  // L3 x L1 -> < 2q
   F28 Q = f28_mul(acc.X, PP);                                // < 2q
-  F28 RR = f28_sqr(R);                                       // < 2q
-  F28 t0 = f28_sub<4, 1>(RR, PPP);                           // < 6q, limbs < 3*2^28
-  F28 X3 = f28_normalise(f28_sub<6, 2>(t0, f28_add(Q, Q)));  // 2Q: limbs < 2^29, < 4q; X3 < 12q; digits
-  F28 t1 = f28_sub<16, 1>(Q, X3);                            // Q + 16q - X3 < 18q, limbs < 3*2^28
-  F28 Rt = f28_mul(R, t1);                                   // N x L3 -> < 2q
-  F28 YP = f28_mul(acc.Y, PPP);                              // L3 x N -> < 2q
+  F28 RR = f28_sqr(R);                                       // L4 squared: 238 < 256 -> < 2q
+  F28 t0 = f28_sub<4, 1>(RR, PPP);                           // < 6q, class L3
+  F28 X3 = f28_normalise(f28_sub<6, 2>(t0, f28_add(Q, Q)));  // 2Q: class L2, < 4q; X3 < 12q; exact digits (it is the next P's subtrahend)
+  F28 t1 = f28_sub<16, 1>(Q, X3);                            // Q + 16q - X3 < 18q, class L3
+  F28 nY = f28_sub<4, 2>(f28_const(Limbs14{}), acc.Y);       // 4q - Y1 <= 4q, class L3
+  acc.Y = f28_muladd(R, t1, nY, PPP);                        // R*t1 - Y1*PPP: 14*(4*3 + 3*1) + 14 = 224 < 256; (108 + 8)/38000 + 1 -> < 2q
   acc.X = X3;
-  acc.Y = f28_sub<4, 1>(Rt, YP);                             // < 6q, limbs < 3*2^28
   acc.ZZ = ZZ3;
   acc.ZZZ = f28_mul(acc.ZZZ, PPP);                           // < 2q
   return true;
