@@ -111,7 +111,8 @@ int32_t aleo_mi355x_ntt_fr_batch_device(void* d_inout, uint32_t lg_n, size_t bat
 int32_t aleo_mi355x_fr_grid_scale_device(void* d_data, uint32_t lg_n, uint64_t rows, uint64_t cols, uint64_t row0, uint64_t col0, uint64_t ld,
                                          int32_t mode, int32_t direction, void* stream);
 
-/* a5 — KZG10::commit shape: coefficients in Montgomery form (as polynomials are stored), converted to canonical
+/* a5 — KZG10::commit shape (commit_lagrange is the same call over the pinned Lagrange-basis powers with evaluations as
+ * the scalars): coefficients in Montgomery form (as polynomials are stored), converted to canonical
  * bigints on the device, MSM over the first n pinned bases; affine result as snarkVM Affine (104 bytes, host). */
 int32_t aleo_mi355x_kzg_commit(void* out_affine104, uint64_t handle, const void* coeffs_mont, size_t n);
 /* Device-resident coefficients (e.g. straight out of aleo_mi355x_ntt_fr_device: no host round trip). */
