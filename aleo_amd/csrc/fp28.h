@@ -17,6 +17,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "fp.h"
+#include "ec.h"
 #include "fp28_mont_gen.h"
 
 namespace aleo_mi355x {
@@ -157,6 +158,93 @@ __device__ __forceinline__ bool xyzz28_madd_fast(XYZZ28& acc, const F28& x2, con
   acc.ZZ = ZZ3;
   acc.ZZZ = f28_mul(acc.ZZZ, PPP);                           // < 2q
   return true;
+}
+
+// ---- XYZZ points stored in the 28-bit form: 224 bytes, X[14] | Y[14] | ZZ[14] | ZZZ[14] --------------------------------
+// Stored invariant: X exact digits < 12q; Y class L3, < 6q; ZZ, ZZZ exact digits < 2q; infinity <=> ZZ all zero.
+__device__ __forceinline__ F28 load_f28(const void* p) {
+  F28 r; const uint2* s = (const uint2*)p;
+#pragma unroll
+  for (int i = 0; i < 7; ++i) { uint2 t = s[i]; r.v[2 * i] = t.x; r.v[2 * i + 1] = t.y; }
+  return r;
+}
+__device__ __forceinline__ void store_f28(void* p, const F28& a) {
+  uint2* d = (uint2*)p;
+#pragma unroll
+  for (int i = 0; i < 7; ++i) d[i] = make_uint2(a.v[2 * i], a.v[2 * i + 1]);
+}
+__device__ __forceinline__ bool f28_is_zero_raw(const F28& a) { uint32_t z = 0; for (int i = 0; i < 14; ++i) z |= a.v[i]; return z == 0; }
+__device__ __forceinline__ void store_xyzz28(void* p, const XYZZ28& a) {
+  char* c = (char*)p; store_f28(c, a.X); store_f28(c + 56, a.Y); store_f28(c + 112, a.ZZ); store_f28(c + 168, a.ZZZ);
+}
+__device__ __forceinline__ void store_xyzz28_from32(void* p, const XYZZ& a, bool inf) {     // off the hot path
+  XYZZ28 r;
+  if (inf || a.ZZ.is_zero_raw() || a.ZZ.is_zero_mod()) { r.X = f28_const(Limbs14{}); r.Y = r.X; r.ZZ = r.X; r.ZZZ = r.X; }
+  else { r.X = f28_from_fq(a.X); r.Y = f28_from_fq(a.Y); r.ZZ = f28_from_fq(a.ZZ); r.ZZZ = f28_from_fq(a.ZZZ); }
+  store_xyzz28(p, r);
+}
+__device__ __forceinline__ XYZZ load_xyzz_from28(const void* p) {
+  const char* c = (const char*)p; XYZZ r;
+  F28 zz = load_f28(c + 112);
+  if (f28_is_zero_raw(zz)) return xyzz_infinity();
+  r.X = f28_to_fq(load_f28(c)); r.Y = f28_to_fq(load_f28(c + 56)); r.ZZ = f28_to_fq(zz); r.ZZZ = f28_to_fq(load_f28(c + 168));
+  return r;
+}
+
+// ---- lane-pair cooperative addition in the 28-bit form (same level plan as ec.h xyzz_add_pair) ---------------------------
+__device__ __forceinline__ F28 f28_xchg(const F28& a) {
+  F28 r;
+#pragma unroll
+  for (int i = 0; i < 14; ++i) r.v[i] = (uint32_t)__shfl_xor((int)a.v[i], 1);
+  return r;
+}
+__device__ __forceinline__ F28 f28_sel(bool take_b, const F28& a, const F28& b) {
+  F28 r;
+#pragma unroll
+  for (int i = 0; i < 14; ++i) r.v[i] = take_b ? b.v[i] : a.v[i];
+  return r;
+}
+__device__ __noinline__ void xyzz28_add_pair_rare(const char* pa, const char* pb, char* out) {   // P == +-Q: one lane, general 32-bit code
+  XYZZ a = load_xyzz_from28(pa), b = load_xyzz_from28(pb);
+  xyzz_add(a, b);
+  store_xyzz28_from32(out, a, false);
+}
+__device__ __forceinline__ void xyzz28_add_pair(const char* pa, const char* pb, char* out) {
+  const bool odd = threadIdx.x & 1;
+  const F28 zzA = load_f28(pa + 112), zzB = load_f28(pb + 112);
+  const bool infA = f28_is_zero_raw(zzA), infB = f28_is_zero_raw(zzB);
+  if (infA || infB) {              // pair-uniform: both lanes see the same two points
+    const char* src = infB ? pa : pb;          // A + O = A ; O + B = B ; O + O = O (either)
+    if (src != out) {              // each lane copies half of the 224 bytes
+      const uint4* s4 = (const uint4*)(src + (odd ? 112 : 0)); uint4* d4 = (uint4*)(out + (odd ? 112 : 0));
+#pragma unroll
+      for (int i = 0; i < 7; ++i) d4[i] = s4[i];
+    }
+    return;
+  }
+  const char* own = odd ? pb : pa; const char* oth = odd ? pa : pb;
+  F28 u = f28_mul(load_f28(own), odd ? zzA : zzB);                              // a: U1 = X1*ZZ2   b: U2 = X2*ZZ1   (< 2q)
+  F28 s = f28_mul(load_f28(oth + 168), load_f28(own + 56));                     // a: S1 = ZZZ2*Y1  b: S2 = ZZZ1*Y2  (L1 x L3)
+  F28 pu = f28_xchg(u), ps = f28_xchg(s);
+  F28 U1 = f28_sel(odd, u, pu), U2 = f28_sel(odd, pu, u), S1 = f28_sel(odd, s, ps), S2 = f28_sel(odd, ps, s);
+  F28 P = f28_sub<4, 1>(U2, U1), R = f28_sub<4, 1>(S2, S1);                      // < 6q, class L3
+  F28 t3 = f28_sqr(f28_sel(odd, P, R));                                        // a: PP   b: RR   (L3 squared: 140 < 256)
+  F28 t4 = f28_mul(load_f28(pa + (odd ? 168 : 112)), load_f28(pb + (odd ? 168 : 112)));   // a: ZZ1*ZZ2   b: ZZZ1*ZZZ2
+  F28 pt3 = f28_xchg(t3);
+  F28 PP = f28_sel(odd, t3, pt3), RR = f28_sel(odd, pt3, t3);
+  F28 t5 = f28_mul(f28_sel(odd, P, U1), PP);                                   // a: PPP  b: Q
+  F28 pt5 = f28_xchg(t5);
+  F28 PPP = f28_sel(odd, t5, pt5), Q = f28_sel(odd, pt5, t5);
+  F28 X3 = f28_normalise(f28_sub<6, 2>(f28_sub<4, 1>(RR, PPP), f28_add(Q, Q)));  // < 12q, exact digits
+  F28 t6 = f28_mul(f28_sel(odd, t4, S1), f28_sel(odd, PP, PPP));               // a: ZZ3  b: SP
+  F28 pt4 = f28_xchg(t4);                                                      // a receives ZZZ12
+  F28 t7 = f28_mul(f28_sel(odd, pt4, R), f28_sel(odd, PPP, f28_sub<16, 1>(Q, X3)));   // a: ZZZ3  b: Rt (L3 x L3: 140 < 256)
+  // same-x case (doubling / cancellation): ZZ3 == 0 mod q, seen by the even lane
+  int z = (!odd && f28_is_zero_mod_lt2q(t6)) ? 1 : 0;
+  z = __shfl(z, (int)(threadIdx.x & 63u & ~1u));
+  if (__builtin_expect(z, 0)) { if (!odd) xyzz28_add_pair_rare(pa, pb, out); return; }
+  if (odd) { store_f28(out, X3); store_f28(out + 56, f28_sub<4, 1>(t7, t6)); }   // Y3 = Rt - SP: class L3, < 6q
+  else { store_f28(out + 112, t6); store_f28(out + 168, t7); }
 }
 
 }  // namespace aleo_mi355x

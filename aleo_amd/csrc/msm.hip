@@ -518,8 +518,8 @@ __global__ void __launch_bounds__(256) k_accum(const char* __restrict__ bases, c
 }
 
 // ---- the same loop on the fixed-base table, in the 14 x 28-bit representation (fp28.h) ---------------------------------
-// Table rows are 112 bytes (x'[14] | y'[14], value * 2^392 mod q as exact base-2^28 digits).  The slice sum is handed on
-// as an ordinary 32-bit XYZZ point (4 conversions per slice, ~0.3 of an addition), so nothing after this kernel changes.
+// Table rows are 112 bytes (x'[14] | y'[14], value * 2^392 mod q as exact base-2^28 digits).  The slice sum is stored as a
+// 224-byte 28-bit XYZZ point; the slice tree and the chunk kernels continue in that form.
 __device__ __forceinline__ XYZZ xyzz28_to_xyzz(const XYZZ28& a) {
   XYZZ r; r.X = f28_to_fq(a.X); r.Y = f28_to_fq(a.Y); r.ZZ = f28_to_fq(a.ZZ); r.ZZZ = f28_to_fq(a.ZZZ); return r;     // all < 2q
 }
@@ -563,13 +563,12 @@ __global__ void __launch_bounds__(256) k_accum28(const char* __restrict__ bases,
     if (e >> 31) y = f28_sub<2, 1>(f28_const(Limbs14{}), y);
     if (!xyzz28_madd_fast(acc, x, y)) { ok = false; break; }
   }
-  XYZZ out; bool inf = false;
-  if (ok) out = xyzz28_to_xyzz(acc);
+  if (ok) store_xyzz28(partial + (size_t)sid * 224, acc);           // X exact < 12q, Y exact < 2q, ZZ / ZZZ exact < 2q: the stored invariant of fp28.h
   else {      // P == +-acc (repeated or opposite bases): finish the slice with the general 32-bit code, out of line
-    XYZZ28 tmp = acc;
+    XYZZ28 tmp = acc; XYZZ out; bool inf = false;
     slice_slow_path28(bases, run, j, j1, &tmp, &out, &inf);
+    store_xyzz28_from32(partial + (size_t)sid * 224, out, inf);
   }
-  xyzz_store_normalized(partial + (size_t)sid * 192, out, inf);
 }
 
 // 96-byte rows (x | y, 12 x 32-bit Montgomery) -> 112-byte rows of the 28-bit table; (0, 0) marks the identity and stays 0
@@ -585,22 +584,41 @@ __global__ void __launch_bounds__(256) k_rows_to28(const char* __restrict__ src9
 // Every kernel from here to the host tail is a chain of full XYZZ additions with little parallelism, so each addition
 // is shared by a lane pair (ec.h xyzz_add_pair: same work, half the latency).  "op" below = pair index = thread / 2.
 __device__ __forceinline__ void pair_fence() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); }
-__device__ __forceinline__ void pair_copy(const char* src, char* dst) {      // 192 bytes, half per lane
-  const uint32_t o = (threadIdx.x & 1) ? 96 : 0;
+// Point formats of the partial sums: 32-bit XYZZ (192 B, ec.h) on the plain path, 28-bit XYZZ (224 B, fp28.h) on the table path,
+// where the slice tree and the chunk running sums — the two throughput-heavy reduction steps — stay in the representation the
+// accumulation kernel computes in (its products are ~14 % cheaper and the slice sums need no conversion); the chunk kernels
+// hand V / Vrun on as 32-bit points, so the latency-bound masked sums and the host tail are unchanged.
+template <bool F28> struct PtFmt { static constexpr uint32_t BYTES = F28 ? 224u : 192u, WORDS = BYTES / 4; };
+template <uint32_t BYTES = 192> __device__ __forceinline__ void pair_copy(const char* src, char* dst) {      // half per lane
+  const uint32_t o = (threadIdx.x & 1) ? BYTES / 2 : 0;
   const uint4* s4 = (const uint4*)(src + o); uint4* d4 = (uint4*)(dst + o);
 #pragma unroll
-  for (int i = 0; i < 6; ++i) d4[i] = s4[i];
+  for (int i = 0; i < (int)(BYTES / 32); ++i) d4[i] = s4[i];
 }
-__device__ __forceinline__ void pair_zero(char* dst) {
-  uint4* d4 = (uint4*)(dst + ((threadIdx.x & 1) ? 96 : 0));
+template <uint32_t BYTES = 192> __device__ __forceinline__ void pair_zero(char* dst) {
+  uint4* d4 = (uint4*)(dst + ((threadIdx.x & 1) ? BYTES / 2 : 0));
 #pragma unroll
-  for (int i = 0; i < 6; ++i) d4[i] = make_uint4(0, 0, 0, 0);
+  for (int i = 0; i < (int)(BYTES / 32); ++i) d4[i] = make_uint4(0, 0, 0, 0);
+}
+template <bool F28> __device__ __forceinline__ void pt_add_pair(const char* pa, const char* pb, char* out) {
+  if constexpr (F28) xyzz28_add_pair(pa, pb, out); else xyzz_add_pair(pa, pb, out);
+}
+// LDS point -> 32-bit XYZZ in HBM (192 B): a copy, or the pair converts two coordinates each (zero limbs stay zero: infinity)
+template <bool F28> __device__ __forceinline__ void pair_store32(const char* src, char* dst192) {
+  if constexpr (!F28) pair_copy<192>(src, dst192);
+  else {
+    const bool odd = threadIdx.x & 1;
+    Fq a = f28_to_fq(load_f28(src + (odd ? 112 : 0))), b = f28_to_fq(load_f28(src + (odd ? 168 : 56)));      // even: X, Y   odd: ZZ, ZZZ
+    store_fp<Fq>(dst192 + (odd ? 96 : 0), a); store_fp<Fq>(dst192 + (odd ? 144 : 48), b);
+  }
 }
 
 // partial[ft + i] += partial[ft + i + half] inside every multi-slice bucket (listed in heavy[] by the scan)
+template <bool F28>
 __global__ void __launch_bounds__(256) k_tree_pass(char* __restrict__ partial, const uint32_t* __restrict__ heavy, const uint2* __restrict__ scan_local,
                                                    const uint2* __restrict__ scan_blk, uint32_t M, const uint32_t* __restrict__ meta, uint32_t pass, uint32_t max_pairs,
                                                    uint32_t list_len) {
+  constexpr uint32_t PB = PtFmt<F28>::BYTES;
   const uint32_t op = (blockIdx.x * 256 + threadIdx.x) >> 1;
   uint32_t h = op / max_pairs, i = op % max_pairs;
   if (h >= list_len) return;
@@ -612,8 +630,8 @@ __global__ void __launch_bounds__(256) k_tree_pass(char* __restrict__ partial, c
   if (L <= 1) return;
   uint32_t half = (L + 1) >> 1;
   if (i >= L - half) return;
-  char* pa = partial + (size_t)(ft + i) * 192;
-  xyzz_add_pair(pa, pa + (size_t)half * 192, pa);
+  char* pa = partial + (size_t)(ft + i) * PB;
+  pt_add_pair<F28>(pa, pa + (size_t)half * PB, pa);
 }
 
 // ---- bucket reduction -----------------------------------------------------------------------------
@@ -621,54 +639,58 @@ __global__ void __launch_bounds__(256) k_tree_pass(char* __restrict__ partial, c
 // kept in LDS between the cooperative additions, so acc = sum_{b in chunk} (b - base + 1) * S_b and run = chunk total.
 // Both go to HBM (V, Vrun); the chunk weights are applied by masked sums (fixed-base path).
 static constexpr uint32_t CHUNK_PAIRS = 128;        // chunks per 256-thread block
+template <bool F28>
 __global__ void __launch_bounds__(256) k_bucket_chunks_pair(const char* __restrict__ partial, const uint32_t* __restrict__ hist, const uint2* __restrict__ scan_local,
                                                        const uint2* __restrict__ scan_blk, uint32_t B, uint32_t S, uint32_t nchunks_total, char* __restrict__ V,
                                                        char* __restrict__ Vrun) {
-  __shared__ __attribute__((aligned(16))) uint32_t lds[2 * CHUNK_PAIRS * 48];
+  constexpr uint32_t PB = PtFmt<F28>::BYTES, PW = PtFmt<F28>::WORDS;
+  __shared__ __attribute__((aligned(16))) uint32_t lds[2 * CHUNK_PAIRS * PW];
   const uint32_t pr = threadIdx.x >> 1, t = blockIdx.x * CHUNK_PAIRS + pr;
   if (t >= nchunks_total) return;
-  char* run = (char*)(lds + pr * 48); char* acc = (char*)(lds + (CHUNK_PAIRS + pr) * 48);
-  pair_zero(run); pair_zero(acc);
+  char* run = (char*)(lds + pr * PW); char* acc = (char*)(lds + (CHUNK_PAIRS + pr) * PW);
+  pair_zero<PB>(run); pair_zero<PB>(acc);
   pair_fence();
   const uint32_t cpw = B / S, w = t / cpw, j = t % cpw, g0 = w * B + j * S;
   for (uint32_t k = 0; k < S; ++k) {
     const uint32_t g = g0 + (S - 1 - k);
-    if (hist[g]) { xyzz_add_pair(run, partial + (size_t)scan_at(scan_local, scan_blk, g).y * 192, run); pair_fence(); }
-    xyzz_add_pair(acc, run, acc); pair_fence();
+    if (hist[g]) { pt_add_pair<F28>(run, partial + (size_t)scan_at(scan_local, scan_blk, g).y * PB, run); pair_fence(); }
+    pt_add_pair<F28>(acc, run, acc); pair_fence();
   }
-  pair_copy(run, Vrun + (size_t)t * 192); pair_copy(acc, V + (size_t)t * 192);
+  pair_store32<F28>(run, Vrun + (size_t)t * 192); pair_store32<F28>(acc, V + (size_t)t * 192);
 }
 
 // One lane QUAD per chunk of S consecutive buckets: running sums run_k = run_{k-1} + S_b (b descending) and acc += run_{k-1}
 // are independent once run_{k-1} exists, so two lane pairs work one step apart (S + 1 dependent additions instead of 2S):
 // sub-pair 0 extends the running sum (double-buffered in LDS), sub-pair 1 folds the previous one into acc.  Both make the
-// SAME xyzz_add_pair call with per-lane pointers (a branch per sub-pair would serialise them inside the wave).
+// SAME addition call with per-lane pointers (a branch per sub-pair would serialise them inside the wave).
 // acc = sum_{b in chunk} (b - base + 1) * S_b and run = chunk total go to HBM (V, Vrun); the chunk weights are applied by
 // masked sums (fixed-base path).
 static constexpr uint32_t CHUNK_QUADS = 64;         // chunks per 256-thread block
+template <bool F28>
 __global__ void __launch_bounds__(256) k_bucket_chunks(const char* __restrict__ partial, const uint32_t* __restrict__ hist, const uint2* __restrict__ scan_local,
                                                        const uint2* __restrict__ scan_blk, uint32_t B, uint32_t S, uint32_t nchunks_total, char* __restrict__ V,
                                                        char* __restrict__ Vrun) {
-  __shared__ __attribute__((aligned(16))) uint32_t lds[(3 * CHUNK_QUADS + 1) * 48];
+  constexpr uint32_t PB = PtFmt<F28>::BYTES, PW = PtFmt<F28>::WORDS;
+  __shared__ __attribute__((aligned(16))) uint32_t lds[(3 * CHUNK_QUADS + 1) * PW];
   const uint32_t qd = threadIdx.x >> 2, sp = (threadIdx.x >> 1) & 1u, t = blockIdx.x * CHUNK_QUADS + qd;
-  char* zero = (char*)(lds + 3 * CHUNK_QUADS * 48);
-  if (threadIdx.x < 2) pair_zero(zero);
+  char* zero = (char*)(lds + 3 * CHUNK_QUADS * PW);
+  if (threadIdx.x < 2) pair_zero<PB>(zero);
   __syncthreads();
   if (t >= nchunks_total) return;
-  char* buf0 = (char*)(lds + (3 * qd) * 48); char* buf1 = buf0 + 192; char* acc = buf1 + 192;
-  pair_zero(sp ? acc : buf0); if (!sp) pair_zero(buf1);
+  char* buf0 = (char*)(lds + (3 * qd) * PW); char* buf1 = buf0 + PB; char* acc = buf1 + PB;
+  pair_zero<PB>(sp ? acc : buf0); if (!sp) pair_zero<PB>(buf1);
   pair_fence();
   const uint32_t cpw = B / S, w = t / cpw, j = t % cpw, g0 = w * B + j * S;
   for (uint32_t k = 0; k <= S; ++k) {
     char* rprev = (k & 1) ? buf0 : buf1; char* rnext = (k & 1) ? buf1 : buf0;      // run_k lives in buf[k & 1]; run_{-1} = 0
     const char* add = zero;
-    if (!sp && k < S) { const uint32_t g = g0 + (S - 1 - k); if (hist[g]) add = partial + (size_t)scan_at(scan_local, scan_blk, g).y * 192; }
+    if (!sp && k < S) { const uint32_t g = g0 + (S - 1 - k); if (hist[g]) add = partial + (size_t)scan_at(scan_local, scan_blk, g).y * PB; }
     const char* pa = sp ? acc : rprev; const char* pb = sp ? rprev : add; char* out = sp ? acc : rnext;
-    xyzz_add_pair(pa, pb, out);
+    pt_add_pair<F28>(pa, pb, out);
     pair_fence();
   }
   // after step S: buf[S & 1] holds run_{S-1} again (step S copied it forward), acc holds sum_k run_k
-  pair_copy(sp ? acc : ((S & 1) ? buf1 : buf0), (sp ? V : Vrun) + (size_t)t * 192);
+  pair_store32<F28>(sp ? acc : ((S & 1) ? buf1 : buf0), (sp ? V : Vrun) + (size_t)t * 192);
 }
 
 // Plain path (one window set per window): one lane per chunk, V = sum_{b in chunk} (b+1) * S_b with the chunk base applied
@@ -828,11 +850,12 @@ int32_t msm_run(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, const void* 
   const uint32_t cnt_tiles = (uint32_t)((cnt_len + SCAN_TILE - 1) / SCAN_TILE);
   if ((rc = c->part_cnt.reserve((2 * cnt_len + 2 * (size_t)cnt_tiles + 16 + MAX_COARSE) * 4))) return rc;     // cnt | off_local | tile_tot | off_blk | part_start
   if ((rc = c->part_items.reserve(pairs_max * 8))) return rc;
-  if ((rc = c->partial.reserve(slices_max * 192))) return rc;
+  if ((rc = c->partial.reserve(slices_max * (pre ? 224 : 192)))) return rc;
   if ((rc = c->task_g.reserve(2 * slices_max * 4))) return rc;     // task_g | order
   const uint32_t cpw = P.B / P.S, nchunks = cpw * P.W;
   uint32_t lgN = 0; while ((1u << lgN) < cpw) ++lgN;
   const bool masked = pre && lgN >= 2 && (1u << lgN) == cpw;          // fixed-base path: weights by masked trees
+  if (pre && !masked) { g_last_error = "msm: internal: table path without masked reduction"; return ALEO_MI355X_ERR_HIP; }
   const size_t vwords = masked ? 2 * (size_t)nchunks + (size_t)lgN * (cpw / 4) + (size_t)(lgN + 5) * (1 + (size_t)cpw / 4) : (size_t)nchunks + P.W;
   if ((rc = c->vbuf.reserve(vwords * 192))) return rc;
   if ((rc = ensure_host_pinned(c, 64 + (size_t)(P.W + lgN + 5) * 192))) return rc;
@@ -887,11 +910,13 @@ int32_t msm_run(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, const void* 
       const uint32_t Lc = super_overflow ? L : (L < 16u ? L : (16u >> (pass < 4 ? pass : 4)));       // longest bucket of the common list at this level
       if (n_heavy && Lc > 1) {
         uint32_t mp = Lc >> 1; uint64_t threads = 2ull * n_heavy * mp;
-        hipLaunchKernelGGL(k_tree_pass, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, s, partial, heavy, scan_local, scan_blk, M, meta, pass, mp, n_heavy);
+        if (pre) hipLaunchKernelGGL(k_tree_pass<true>, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, s, partial, heavy, scan_local, scan_blk, M, meta, pass, mp, n_heavy);
+        else hipLaunchKernelGGL(k_tree_pass<false>, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, s, partial, heavy, scan_local, scan_blk, M, meta, pass, mp, n_heavy);
       }
       if (n_super) {
         uint32_t mp = L >> 1; uint64_t threads = 2ull * n_super * mp;
-        hipLaunchKernelGGL(k_tree_pass, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, s, partial, super_list, scan_local, scan_blk, M, meta, pass, mp, n_super);
+        if (pre) hipLaunchKernelGGL(k_tree_pass<true>, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, s, partial, super_list, scan_local, scan_blk, M, meta, pass, mp, n_super);
+        else hipLaunchKernelGGL(k_tree_pass<false>, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, s, partial, super_list, scan_local, scan_blk, M, meta, pass, mp, n_super);
       }
     }
   }
@@ -907,8 +932,9 @@ int32_t msm_run(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, const void* 
     // sum_b (b+1) S_b = sum_j acc_j + S * sum_j j * run_j ; the second sum by lg(N) masked pairwise trees
     char* T = V + (size_t)nchunks * 192; char* Vrun = T + (size_t)lgN * (cpw / 4) * 192; char* Tout = Vrun + (size_t)nchunks * 192;
     // 2^19 buckets keep the chip busy with one lane pair per chunk; the small bucket sets (<= 2^16) are pure latency and take the quad form
-    if (P.c >= 20) hipLaunchKernelGGL(k_bucket_chunks_pair, dim3((nchunks + CHUNK_PAIRS - 1) / CHUNK_PAIRS), dim3(256), 0, s, partial, hist, scan_local, scan_blk, P.B, P.S, nchunks, V, Vrun);
-    else hipLaunchKernelGGL(k_bucket_chunks, dim3((nchunks + CHUNK_QUADS - 1) / CHUNK_QUADS), dim3(256), 0, s, partial, hist, scan_local, scan_blk, P.B, P.S, nchunks, V, Vrun);
+    // (masked => pre: the partial sums are 28-bit points)
+    if (P.c >= 20) hipLaunchKernelGGL(k_bucket_chunks_pair<true>, dim3((nchunks + CHUNK_PAIRS - 1) / CHUNK_PAIRS), dim3(256), 0, s, partial, hist, scan_local, scan_blk, P.B, P.S, nchunks, V, Vrun);
+    else hipLaunchKernelGGL(k_bucket_chunks<true>, dim3((nchunks + CHUNK_QUADS - 1) / CHUNK_QUADS), dim3(256), 0, s, partial, hist, scan_local, scan_blk, P.B, P.S, nchunks, V, Vrun);
     const uint32_t tseg = cpw / 4, fseg = lgN + 4;      // Vacc viewed as 4 segments of cpw/4, followed by the lgN masked sums
     hipLaunchKernelGGL(k_masked_pairs, dim3((2 * tseg * lgN + 255) / 256), dim3(256), 0, s, Vrun, lgN, T);
     // (lgN+4) segment sums: pairwise launches while a level still fills the chip, then ONE block per segment folds the
