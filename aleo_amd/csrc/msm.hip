@@ -585,9 +585,9 @@ __global__ void __launch_bounds__(256) k_rows_to28(const char* __restrict__ src9
 // is shared by a lane pair (ec.h xyzz_add_pair: same work, half the latency).  "op" below = pair index = thread / 2.
 __device__ __forceinline__ void pair_fence() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); }
 // Point formats of the partial sums: 32-bit XYZZ (192 B, ec.h) on the plain path, 28-bit XYZZ (224 B, fp28.h) on the table path,
-// where the slice tree and the chunk running sums — the two throughput-heavy reduction steps — stay in the representation the
-// accumulation kernel computes in (its products are ~14 % cheaper and the slice sums need no conversion); the chunk kernels
-// hand V / Vrun on as 32-bit points, so the latency-bound masked sums and the host tail are unchanged.
+// where everything after the accumulation kernel — slice tree, chunk running sums, masked sums, segment folds — stays in the
+// representation that kernel computes in (its products are ~14 % cheaper and nothing is converted on the device); the host
+// tail turns the lg(N) + 4 final points into its 64-bit-limb Montgomery form.
 template <bool F28> struct PtFmt { static constexpr uint32_t BYTES = F28 ? 224u : 192u, WORDS = BYTES / 4; };
 template <uint32_t BYTES = 192> __device__ __forceinline__ void pair_copy(const char* src, char* dst) {      // half per lane
   const uint32_t o = (threadIdx.x & 1) ? BYTES / 2 : 0;
@@ -603,16 +603,6 @@ template <uint32_t BYTES = 192> __device__ __forceinline__ void pair_zero(char* 
 template <bool F28> __device__ __forceinline__ void pt_add_pair(const char* pa, const char* pb, char* out) {
   if constexpr (F28) xyzz28_add_pair(pa, pb, out); else xyzz_add_pair(pa, pb, out);
 }
-// LDS point -> 32-bit XYZZ in HBM (192 B): a copy, or the pair converts two coordinates each (zero limbs stay zero: infinity)
-template <bool F28> __device__ __forceinline__ void pair_store32(const char* src, char* dst192) {
-  if constexpr (!F28) pair_copy<192>(src, dst192);
-  else {
-    const bool odd = threadIdx.x & 1;
-    Fq a = f28_to_fq(load_f28(src + (odd ? 112 : 0))), b = f28_to_fq(load_f28(src + (odd ? 168 : 56)));      // even: X, Y   odd: ZZ, ZZZ
-    store_fp<Fq>(dst192 + (odd ? 96 : 0), a); store_fp<Fq>(dst192 + (odd ? 144 : 48), b);
-  }
-}
-
 // partial[ft + i] += partial[ft + i + half] inside every multi-slice bucket (listed in heavy[] by the scan)
 template <bool F28>
 __global__ void __launch_bounds__(256) k_tree_pass(char* __restrict__ partial, const uint32_t* __restrict__ heavy, const uint2* __restrict__ scan_local,
@@ -656,7 +646,7 @@ __global__ void __launch_bounds__(256) k_bucket_chunks_pair(const char* __restri
     if (hist[g]) { pt_add_pair<F28>(run, partial + (size_t)scan_at(scan_local, scan_blk, g).y * PB, run); pair_fence(); }
     pt_add_pair<F28>(acc, run, acc); pair_fence();
   }
-  pair_store32<F28>(run, Vrun + (size_t)t * 192); pair_store32<F28>(acc, V + (size_t)t * 192);
+  pair_copy<PB>(run, Vrun + (size_t)t * PB); pair_copy<PB>(acc, V + (size_t)t * PB);
 }
 
 // One lane QUAD per chunk of S consecutive buckets: running sums run_k = run_{k-1} + S_b (b descending) and acc += run_{k-1}
@@ -690,7 +680,7 @@ __global__ void __launch_bounds__(256) k_bucket_chunks(const char* __restrict__ 
     pair_fence();
   }
   // after step S: buf[S & 1] holds run_{S-1} again (step S copied it forward), acc holds sum_k run_k
-  pair_store32<F28>(sp ? acc : ((S & 1) ? buf1 : buf0), (sp ? V : Vrun) + (size_t)t * 192);
+  pair_copy<PB>(sp ? acc : ((S & 1) ? buf1 : buf0), (sp ? V : Vrun) + (size_t)t * PB);
 }
 
 // Plain path (one window set per window): one lane per chunk, V = sum_{b in chunk} (b+1) * S_b with the chunk base applied
@@ -740,38 +730,40 @@ __global__ void __launch_bounds__(256) k_seg_tree_pass(char* __restrict__ V, uin
 // kernel does the first pairwise level of all lg(N) masked sums at once: T_l[k] = run[ins_l(2k)] + run[ins_l(2k+1)],
 // ins_l(x) = x with a 1 inserted at bit l.  The remaining levels are k_seg_pair_pass / k_seg_fold; the 2^l Horner runs
 // on the host.
+// (These kernels only run on the table path, whose points are 224-byte 28-bit XYZZ: PB below.)
+static constexpr uint32_t PB28 = 224, PW28 = 56;
 __global__ void __launch_bounds__(256) k_masked_pairs(const char* __restrict__ Vrun, uint32_t lgN, char* __restrict__ T) {
   const uint32_t seg_len = 1u << (lgN - 2);
   const uint32_t op = (blockIdx.x * 256 + threadIdx.x) >> 1;
   if (op >= seg_len * lgN) return;
   const uint32_t l = op / seg_len, k = op % seg_len;
   auto ins = [&](uint32_t x) { return ((x >> l) << (l + 1)) | (1u << l) | (x & ((1u << l) - 1u)); };
-  xyzz_add_pair(Vrun + (size_t)ins(2 * k) * 192, Vrun + (size_t)ins(2 * k + 1) * 192, T + (size_t)op * 192);
+  xyzz28_add_pair(Vrun + (size_t)ins(2 * k) * PB28, Vrun + (size_t)ins(2 * k + 1) * PB28, T + (size_t)op * PB28);
 }
 // One block folds up to 256 consecutive points of one segment into a single point: 8 tree levels through two LDS
 // buffers, 128 lane pairs — the latency floor of the chain with no launch gaps.
 static constexpr uint32_t FOLD = 256;
 __global__ void __launch_bounds__(256) k_seg_fold(const char* __restrict__ in, uint32_t in_stride, uint32_t L, uint32_t nseg,
                                                   char* __restrict__ out, uint32_t out_stride) {
-  __shared__ __attribute__((aligned(16))) uint32_t lds[2][(FOLD / 2) * 48];
+  __shared__ __attribute__((aligned(16))) uint32_t lds[2][(FOLD / 2) * PW28];
   const uint32_t bps = (L + FOLD - 1) / FOLD, seg = blockIdx.x / bps, blk = blockIdx.x % bps, pr = threadIdx.x >> 1;
   if (seg >= nseg) return;
   {
     const uint32_t e0 = blk * FOLD + 2 * pr;
-    const char* src = in + ((size_t)seg * in_stride + e0) * 192;
-    char* dst = (char*)(lds[0] + pr * 48);
-    if (e0 + 1 < L) xyzz_add_pair(src, src + 192, dst);
-    else if (e0 < L) pair_copy(src, dst);
-    else pair_zero(dst);
+    const char* src = in + ((size_t)seg * in_stride + e0) * PB28;
+    char* dst = (char*)(lds[0] + pr * PW28);
+    if (e0 + 1 < L) xyzz28_add_pair(src, src + PB28, dst);
+    else if (e0 < L) pair_copy<PB28>(src, dst);
+    else pair_zero<PB28>(dst);
   }
   uint32_t cur = 0;
   for (uint32_t n = FOLD / 2; n > 1; n >>= 1) {
     __syncthreads();
-    if (pr < (n >> 1)) xyzz_add_pair((const char*)(lds[cur] + (2 * pr) * 48), (const char*)(lds[cur] + (2 * pr + 1) * 48), (char*)(lds[cur ^ 1] + pr * 48));
+    if (pr < (n >> 1)) xyzz28_add_pair((const char*)(lds[cur] + (2 * pr) * PW28), (const char*)(lds[cur] + (2 * pr + 1) * PW28), (char*)(lds[cur ^ 1] + pr * PW28));
     cur ^= 1;
   }
   __syncthreads();
-  if (pr == 0) pair_copy((const char*)lds[cur], out + ((size_t)seg * out_stride + blk) * 192);
+  if (pr == 0) pair_copy<PB28>((const char*)lds[cur], out + ((size_t)seg * out_stride + blk) * PB28);
 }
 // out[seg][i] = in[seg][2i] + in[seg][2i+1]: the wide (throughput-bound) levels of the segment sums
 __global__ void __launch_bounds__(256) k_seg_pair_pass(const char* __restrict__ in, uint32_t in_stride, uint32_t L, uint32_t nseg,
@@ -780,15 +772,15 @@ __global__ void __launch_bounds__(256) k_seg_pair_pass(const char* __restrict__ 
   const uint32_t op = (blockIdx.x * 256 + threadIdx.x) >> 1;
   if (op >= half * nseg) return;
   const uint32_t seg = op / half, i = op % half;
-  const char* src = in + ((size_t)seg * in_stride + 2 * i) * 192;
-  char* dst = out + ((size_t)seg * out_stride + i) * 192;
-  if (2 * i + 1 < L) xyzz_add_pair(src, src + 192, dst); else pair_copy(src, dst);
+  const char* src = in + ((size_t)seg * in_stride + 2 * i) * PB28;
+  char* dst = out + ((size_t)seg * out_stride + i) * PB28;
+  if (2 * i + 1 < L) xyzz28_add_pair(src, src + PB28, dst); else pair_copy<PB28>(src, dst);
 }
 __global__ void k_gather_strided(const char* __restrict__ V, uint32_t stride, uint32_t count, char* __restrict__ out) {
   uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= count * 12) return;
-  uint32_t w = t / 12, q = t % 12;
-  ((uint4*)out)[t] = ((const uint4*)(V + (size_t)w * stride * 192))[q];
+  if (t >= count * 14) return;
+  uint32_t w = t / 14, q = t % 14;
+  ((uint4*)out)[t] = ((const uint4*)(V + (size_t)w * stride * PB28))[q];
 }
 
 // gathers V[w*seg_len] (the window sums) into a dense array for one D2H copy
@@ -857,8 +849,8 @@ int32_t msm_run(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, const void* 
   const bool masked = pre && lgN >= 2 && (1u << lgN) == cpw;          // fixed-base path: weights by masked trees
   if (pre && !masked) { g_last_error = "msm: internal: table path without masked reduction"; return ALEO_MI355X_ERR_HIP; }
   const size_t vwords = masked ? 2 * (size_t)nchunks + (size_t)lgN * (cpw / 4) + (size_t)(lgN + 5) * (1 + (size_t)cpw / 4) : (size_t)nchunks + P.W;
-  if ((rc = c->vbuf.reserve(vwords * 192))) return rc;
-  if ((rc = ensure_host_pinned(c, 64 + (size_t)(P.W + lgN + 5) * 192))) return rc;
+  if ((rc = c->vbuf.reserve(vwords * 224))) return rc;
+  if ((rc = ensure_host_pinned(c, 64 + (size_t)(P.W + lgN + 5) * 224))) return rc;
 
   uint32_t* hist = c->hist.as<uint32_t>(); uint32_t* heavy = hist + M; uint32_t* meta = heavy + M;     // heavy: <= M bucket ids
   uint32_t* bin_cursor = hist + 2 * (size_t)M + 2048 + SUPER_CAP;
@@ -927,10 +919,33 @@ int32_t msm_run(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, const void* 
     HXYZZ v; v.X = HFq::reduce_lazy(src); v.Y = HFq::reduce_lazy(src + 6); v.ZZ = HFq::reduce_lazy(src + 12); v.ZZZ = HFq::reduce_lazy(src + 18);
     return v;
   };
+  // a 224-byte point of the table path: every coordinate is value * 2^392 mod q (+ a few q) as 14 x 28-bit limbs (possibly
+  // loose); * 2^376 under the 2^-384 of the host Montgomery product gives value * 2^384, the HFq form
+  auto lazy_point28 = [&](const char* p) {
+    const uint32_t* w = (const uint32_t*)p;
+    HFq c376 = HFq::zero(); c376.l[5] = 1ull << 56;
+    HFq co[4]; bool inf = true;
+    for (int k = 0; k < 4; ++k) {
+      uint64_t big[8] = {0, 0, 0, 0, 0, 0, 0, 0};           // sum_i w_i * 2^(28 i), limbs may exceed 28 bits
+      for (int i = 0; i < 14; ++i) {
+        const int pos = 28 * i, j = pos >> 6, sh = pos & 63;
+        const unsigned __int128 add = (unsigned __int128)w[14 * k + i] << sh;
+        unsigned __int128 t = (unsigned __int128)big[j] + (uint64_t)add; big[j] = (uint64_t)t;
+        t = (unsigned __int128)big[j + 1] + (uint64_t)(add >> 64) + (uint64_t)(t >> 64); big[j + 1] = (uint64_t)t;
+        uint64_t cr = (uint64_t)(t >> 64);
+        for (int q = j + 2; q < 8 && cr; ++q) { t = (unsigned __int128)big[q] + cr; big[q] = (uint64_t)t; cr = (uint64_t)(t >> 64); }
+      }
+      if (k == 2) for (int q = 0; q < 8; ++q) if (big[q]) inf = false;
+      co[k] = HFq::mul(HFq::reduce_lazy(big), c376);        // value < 64q < 2^384: six limbs hold it
+    }
+    if (inf) return HXYZZ::infinity();
+    HXYZZ v; v.X = co[0]; v.Y = co[1]; v.ZZ = co[2]; v.ZZZ = co[3];
+    return v;
+  };
   HXYZZ total = HXYZZ::infinity();
   if (masked) {
     // sum_b (b+1) S_b = sum_j acc_j + S * sum_j j * run_j ; the second sum by lg(N) masked pairwise trees
-    char* T = V + (size_t)nchunks * 192; char* Vrun = T + (size_t)lgN * (cpw / 4) * 192; char* Tout = Vrun + (size_t)nchunks * 192;
+    char* T = V + (size_t)nchunks * PB28; char* Vrun = T + (size_t)lgN * (cpw / 4) * PB28; char* Tout = Vrun + (size_t)nchunks * PB28;
     // 2^19 buckets keep the chip busy with one lane pair per chunk; the small bucket sets (<= 2^16) are pure latency and take the quad form
     // (masked => pre: the partial sums are 28-bit points)
     if (P.c >= 20) hipLaunchKernelGGL(k_bucket_chunks_pair<true>, dim3((nchunks + CHUNK_PAIRS - 1) / CHUNK_PAIRS), dim3(256), 0, s, partial, hist, scan_local, scan_blk, P.B, P.S, nchunks, V, Vrun);
@@ -939,7 +954,7 @@ int32_t msm_run(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, const void* 
     hipLaunchKernelGGL(k_masked_pairs, dim3((2 * tseg * lgN + 255) / 256), dim3(256), 0, s, Vrun, lgN, T);
     // (lgN+4) segment sums: pairwise launches while a level still fills the chip, then ONE block per segment folds the
     // last 256 points through LDS (8 levels of lane-pair additions: the latency floor of the chain, no launch gaps)
-    char* F1 = Tout + (size_t)(fseg + 1) * 192; char* F2 = F1 + (size_t)fseg * (tseg / 2) * 192;
+    char* F1 = Tout + (size_t)(fseg + 1) * PB28; char* F2 = F1 + (size_t)fseg * (tseg / 2) * PB28;
     const char* cur = V; uint32_t L = tseg, stride = tseg;
     while (L > FOLD) {
       char* dst = (cur == F1) ? F2 : F1; uint32_t half = (L + 1) >> 1;
@@ -951,14 +966,14 @@ int32_t msm_run(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, const void* 
       hipLaunchKernelGGL(k_seg_fold, dim3(fseg), dim3(256), 0, s, cur, stride, L, fseg, dst, 1u);
       cur = dst; stride = 1; L = 1;
     }
-    hipLaunchKernelGGL(k_gather_strided, dim3((fseg * 12 + 255) / 256), dim3(256), 0, s, cur, stride, fseg, Tout);
-    HIPCHK(hipMemcpyAsync(h_win, Tout, (size_t)fseg * 192, hipMemcpyDeviceToHost, s));
+    hipLaunchKernelGGL(k_gather_strided, dim3((fseg * 14 + 255) / 256), dim3(256), 0, s, cur, stride, fseg, Tout);
+    HIPCHK(hipMemcpyAsync(h_win, Tout, (size_t)fseg * PB28, hipMemcpyDeviceToHost, s));
     HIPCHK(hipEventRecord(c->ev[3], s));
     HIPCHK(hipStreamSynchronize(s));
     HIPCHK(hipGetLastError());
-    for (int l = (int)lgN - 1; l >= 0; --l) { total = hdouble(total); total = hadd(total, lazy_point(h_win + (size_t)(4 + l) * 192)); }
+    for (int l = (int)lgN - 1; l >= 0; --l) { total = hdouble(total); total = hadd(total, lazy_point28(h_win + (size_t)(4 + l) * PB28)); }
     for (uint32_t sft = P.S; sft > 1; sft >>= 1) total = hdouble(total);
-    for (int q = 0; q < 4; ++q) total = hadd(total, lazy_point(h_win + (size_t)q * 192));
+    for (int q = 0; q < 4; ++q) total = hadd(total, lazy_point28(h_win + (size_t)q * PB28));
   } else {
     hipLaunchKernelGGL(k_bucket_chunks_plain, dim3((nchunks + 255) / 256), dim3(256), 0, s, partial, hist, scan_local, scan_blk, P.B, P.S, nchunks, V);
     for (uint32_t L = cpw; L > 1; L = (L + 1) >> 1) {
