@@ -103,12 +103,17 @@ template <class Pm> struct Fp {
 
   // if (a >= K*p) a -= K*p
   template <int K> __device__ __forceinline__ static Fp cond_sub(const Fp& a) {
+    static_assert(K == 1 || K == 2 || K == 4 || K == 8, "cond_sub<K>: generated for K in {1,2,4,8}");
     constexpr Limbs<N> kp = limbs_mul_small<N>(Pm::P, (uint32_t)K);
-    Fp kpe; for (int i = 0; i < N; ++i) kpe.v[i] = kp.v[i];
-    uint32_t br; Fp d = sub_raw(a, kpe, br);
-    Fp r;
-#pragma unroll
-    for (int i = 0; i < N; ++i) r.v[i] = br ? a.v[i] : d.v[i];
+    uint32_t kpe[N]; for (int i = 0; i < N; ++i) kpe[i] = kp.v[i];
+    Fp r = a;    // one borrow chain + one select per limb (fp_mont_gen.h); the C form costs ~7 instructions per limb
+    if constexpr (N == 12) {
+      if constexpr (K == 1) fp_cond_sub_12_k1(r.v, kpe); else if constexpr (K == 2) fp_cond_sub_12_k2(r.v, kpe);
+      else if constexpr (K == 4) fp_cond_sub_12_k4(r.v, kpe); else fp_cond_sub_12_k8(r.v, kpe);
+    } else {
+      if constexpr (K == 1) fp_cond_sub_8_k1(r.v, kpe); else if constexpr (K == 2) fp_cond_sub_8_k2(r.v, kpe);
+      else if constexpr (K == 4) fp_cond_sub_8_k4(r.v, kpe); else fp_cond_sub_8_k8(r.v, kpe);
+    }
     return r;
   }
   // canonical representative of a value < 16p (Fq) / < 8p (Fr)
