@@ -89,13 +89,15 @@ template <class Pm> struct Fp {
   // a + K*p - b   (b < K*p  =>  result in [0, a + K*p))
   template <int K> __device__ __forceinline__ static Fp sub(const Fp& a, const Fp& b) {
     static_assert(K == 1 || K == 2 || K == 4 || K == 8, "sub<K>: K*p literals are generated for K in {1,2,4,8}");
+    constexpr Limbs<N> kp = limbs_mul_small<N>(Pm::P, (uint32_t)K);
+    uint32_t kpe[N]; for (int i = 0; i < N; ++i) kpe[i] = kp.v[i];
     Fp r = a;
     if constexpr (N == 12) {
-      if constexpr (K == 1) fp_sub_12_k1(r.v, b.v); else if constexpr (K == 2) fp_sub_12_k2(r.v, b.v);
-      else if constexpr (K == 4) fp_sub_12_k4(r.v, b.v); else fp_sub_12_k8(r.v, b.v);
+      if constexpr (K == 1) fp_sub_12_k1(r.v, b.v, kpe); else if constexpr (K == 2) fp_sub_12_k2(r.v, b.v, kpe);
+      else if constexpr (K == 4) fp_sub_12_k4(r.v, b.v, kpe); else fp_sub_12_k8(r.v, b.v, kpe);
     } else {
-      if constexpr (K == 1) fp_sub_8_k1(r.v, b.v); else if constexpr (K == 2) fp_sub_8_k2(r.v, b.v);
-      else if constexpr (K == 4) fp_sub_8_k4(r.v, b.v); else fp_sub_8_k8(r.v, b.v);
+      if constexpr (K == 1) fp_sub_8_k1(r.v, b.v, kpe); else if constexpr (K == 2) fp_sub_8_k2(r.v, b.v, kpe);
+      else if constexpr (K == 4) fp_sub_8_k4(r.v, b.v, kpe); else fp_sub_8_k8(r.v, b.v, kpe);
     }
     return r;
   }
