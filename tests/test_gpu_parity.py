@@ -542,3 +542,35 @@ def test_msm_randomized_prefixes_and_distributions():
             else: S = np.zeros((n, 4), dtype=np.uint64); S[n // 2] = util.uniform_scalars(1, 31000 + i)[0]
             got = c.jac_to_int_point(M.VariableBase.msm(pb, S))
             assert got == util.expected_multiples_msm(S, n), (n, kind)
+
+
+def test_table_path_repeated_opposite_and_infinity_bases():
+    """The rare branches of the 28-bit accumulation / pair additions on the TABLE path (n above the table threshold):
+    repeated bases with equal scalars (P == acc: doubling), opposite bases with equal scalars (P == -acc: cancellation to
+    the identity inside a slice and in the slice tree), bases at infinity, all against the oracle."""
+    n = 1 << 14
+    B = util.multiples_bases(n)
+    rng = np.random.default_rng(77)
+    S = util.uniform_scalars(n, 9900)
+    neg_y = lambda row: c.affine_from_ints([p.g1_neg(c.affine_to_ints(row.reshape(1, 104))[0])])[0]
+    for k in range(0, 4000, 8):                                    # 500 groups: duplicate / opposite / infinity patterns
+        kind = (k // 8) % 4
+        if kind == 0: B[k + 1] = B[k]; S[k + 1] = S[k]                              # P == acc in the same buckets
+        elif kind == 1: B[k + 1] = neg_y(B[k]); S[k + 1] = S[k]                     # P == -acc
+        elif kind == 2: B[k + 1] = B[k]; B[k + 2] = B[k]; S[k + 1] = S[k]; S[k + 2] = S[k]      # tripled
+        else: B[k + 1] = 0; B[k + 1, 96] = 1                                         # infinity base
+    S[5000:5200] = S[5000]; B[5000:5200] = B[5000]                                  # 200 copies of one (point, scalar): a slice of doublings
+    exp = c.jac_to_int_point(c.msm_g1(B, S, threads=8, variant=1))
+    with M.PinnedBases(B) as pb:
+        assert c.jac_to_int_point(M.VariableBase.msm(pb, S)) == exp                 # plain path
+        pb.precompute()
+        assert c.jac_to_int_point(M.VariableBase.msm(pb, S)) == exp                 # table path, 28-bit arithmetic
+        Z = S.copy(); Z[:] = S[0]; Bz = B.copy()
+        assert c.jac_to_int_point(M.VariableBase.msm(pb, Z)) == c.jac_to_int_point(c.msm_g1(Bz, Z, threads=8, variant=1))   # all-equal scalars
+    # every contribution cancels: pairs (P, s), (P, r - s) -> the identity, through every stage of the table path
+    B2 = util.multiples_bases(n); B2[1::2] = B2[0::2]
+    S2 = util.uniform_scalars(n, 9901)
+    ints = c.limbs_to_ints(S2[0::2]); S2[1::2] = c.ints_to_limbs([(p.FR_MODULUS - v) % p.FR_MODULUS for v in ints], 4)
+    with M.PinnedBases(B2) as pb:
+        pb.precompute()
+        assert c.jac_to_int_point(M.VariableBase.msm(pb, S2)) is None
