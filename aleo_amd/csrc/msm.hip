@@ -12,15 +12,18 @@
 //             sorted stream holds 4-byte point indices (bit 31 = negate), so a bucket is a contiguous run.
 //   slices    bucket runs are cut into slices (pick_rule: whole buckets up to 2x the mean size, longer ones split at the
 //             mean), counting-sorted by length so the lanes of a wave run equal trip counts; one lane accumulates one
-//             slice with XYZZ mixed additions (ec.h), reading 96-byte affine points straight from HBM.
+//             slice with XYZZ mixed additions, reading affine points straight from HBM: 96-byte rows and 12 x 32-bit
+//             limbs (ec.h) on the plain path, 112-byte table rows and 14 x 28-bit limbs (fp28.h) on the fixed-base path.
 //   tree      slices of multi-slice buckets are folded pairwise (short launches over the listed buckets only).
-//   reduce    sum_b (b+1) * S_b: 8-bucket running sums, then either a double-and-add of the chunk base + pairwise tree
-//             (plain) or 16 masked pairwise sums folded through LDS blocks (fixed-base).
+//   reduce    sum_b (b+1) * S_b: S-bucket running sums, then either a double-and-add of the chunk base + pairwise tree
+//             (plain) or lg(N) masked pairwise sums folded through LDS blocks (fixed-base); every addition after the
+//             accumulation kernel is shared by a lane pair (xyzz_add_pair / xyzz28_add_pair).
 //   tail      plain: the W window sums go to the host for the 2^c Horner chain (~250 dependent doublings are ~0.1 ms on
-//             a host core, ~4 ms on one GPU lane); fixed-base: a 20-point Horner.  Then affine normalisation.
+//             a host core, ~4 ms on one GPU lane); fixed-base: a lg(N) + 4-point Horner.  Then affine normalisation.
 //
-// HBM layout: bases n x 96 B (x|y Montgomery, AoS so a gathered point is 1-2 cache lines); sorted stream
-// n*W x 4 B; partial sums #slices x 192 B (XYZZ).  Algorithmic bytes per point: 32 (scalar) + 96 (base).
+// HBM layout: bases n x 96 B (x|y Montgomery, AoS so a gathered point is 1-2 cache lines), table W x n x 112 B; sorted
+// stream n*W x 4 B; partial sums #slices x 192 B (XYZZ) or 224 B (28-bit XYZZ).  Algorithmic bytes per point: 32 (scalar)
+// + 96 (base).
 #include "ctx.h"
 #include "ec.h"
 #include "fp28.h"
