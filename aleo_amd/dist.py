@@ -25,9 +25,14 @@ def all_gather_partials(partial: np.ndarray, group=None, device=None) -> np.ndar
     t = torch.from_numpy(np.ascontiguousarray(partial, dtype=np.uint64).reshape(-1).view(np.int64).copy())
     if device is not None:
         t = t.to(device)
-    outs = [torch.empty_like(t) for _ in range(world)]
-    dist.all_gather(outs, t, group=group)
-    return np.stack([o.cpu().numpy().view(np.uint64) for o in outs])
+    out = torch.empty((world, t.numel()), dtype=t.dtype, device=t.device)
+    try:
+        dist.all_gather_into_tensor(out.view(-1), t, group=group)          # one collective, one read-back
+    except (RuntimeError, NotImplementedError, AttributeError):
+        outs = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(outs, t, group=group)
+        out = torch.stack(outs)
+    return out.cpu().numpy().view(np.uint64)
 
 
 def sharded_msm(local_msm, combine, partial_for_rank=None, group=None, device=None) -> np.ndarray:
