@@ -127,13 +127,13 @@ static int32_t precompute_once(Ctx* c, const std::shared_ptr<PinnedOwner>& o) {
   Device* d = c->dev; PinnedBases work;
   {
     std::lock_guard<std::mutex> lk(d->mu);
-    if (o->pb.d_pre || o->building) return ALEO_MI355X_OK;
+    if (o->pb.tabled || o->building) return ALEO_MI355X_OK;
     o->building = true; work = o->pb;
   }
   int32_t rc = msm_precompute(c, &work);
   std::lock_guard<std::mutex> lk(d->mu);
   o->building = false;
-  if (rc == ALEO_MI355X_OK) { o->pb.pre_c = work.pre_c; o->pb.d_pre = work.d_pre; }
+  if (rc == ALEO_MI355X_OK) { for (int i = 0; i < 3; ++i) o->pb.tab[i] = work.tab[i]; o->pb.tabled = true; }
   return rc;
 }
 
@@ -180,7 +180,7 @@ static int32_t srs_get(Device* d, const void* bases, size_t stride, size_t n, st
     if (SrsCacheEntry* e = srs_lookup(d, bases, stride, n)) {
       e->last_use = ++d->srs_clock; e->hits++;
       *keep = d->bases[e->handle];
-      *want_table = e->hits >= 3 && e->n >= (1u << 14) && !(*keep)->pb.d_pre;
+      *want_table = e->hits >= 3 && e->n >= (1u << 10) && !(*keep)->pb.tabled;
       return ALEO_MI355X_OK;
     }
   }

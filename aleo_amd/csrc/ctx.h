@@ -44,8 +44,12 @@ struct DevBuf {
 struct PinnedBases {
   void* d_xy = nullptr;        // n x 96 bytes: x | y, Montgomery, canonical
   uint8_t* d_inf = nullptr;    // n bytes, nullptr when no base is the point at infinity
-  void* d_pre = nullptr;       // optional fixed-base table: W x n x 96 bytes, row w holds 2^(pre_c w) * P_i (msm_precompute)
-  int pre_c = 0;               // window width the table was built for (16, 17 or 20 by pinned count)
+  // optional fixed-base tables (msm_precompute): up to three tiers so that every call size against one SRS gets a window width
+  // that suits it — the full set at c = 20 / 17, its first 2^17 points at c = 16, its first 2^15 points at c = 13.
+  // Rows: W x cover x 112 bytes, row w holds 2^(c w) * P_i in the 28-bit-limb form (fp28.h); serves min_n <= n <= cover.
+  struct PreTable { void* d = nullptr; int c = 0; size_t cover = 0, min_n = 0; };
+  PreTable tab[3];
+  bool tabled = false;         // msm_precompute has run (a set below 2^10 points gets no table)
   size_t n = 0;
 };
 
@@ -54,7 +58,7 @@ struct PinnedBases {
 // owner of a pinned set's HBM; calls hold a shared_ptr while they run, so an unpin from another thread cannot free it under them
 struct PinnedOwner {
   PinnedBases pb; bool building = false;     // building: a table build for this set is in flight on some slot
-  ~PinnedOwner() { if (pb.d_xy) (void)hipFree(pb.d_xy); if (pb.d_inf) (void)hipFree(pb.d_inf); if (pb.d_pre) (void)hipFree(pb.d_pre); }
+  ~PinnedOwner() { if (pb.d_xy) (void)hipFree(pb.d_xy); if (pb.d_inf) (void)hipFree(pb.d_inf); for (auto& t : pb.tab) if (t.d) (void)hipFree(t.d); }
 };
 
 struct SrsCacheEntry {

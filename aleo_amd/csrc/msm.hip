@@ -41,7 +41,6 @@ struct MsmPlan { uint32_t c, W, B, M, S; };
 //   c = 20: 13 rows, 2^19 shared buckets   c = 17: 15 rows, 2^16 buckets   c = 16: 16 rows, 2^15 buckets
 // (widths whose TOP window keeps >= 13 bits of the 253-bit scalar: c = 18 or 19 would leave it 1 or 6 bits, i.e. a
 // handful of buckets holding n/2 points each)
-static int pre_c_for(size_t pinned_n) { return pinned_n >= (1u << 19) ? 20 : (pinned_n >= (1u << 17) ? 17 : 16); }
 
 static MsmPlan make_plan(size_t n, int pre_c) {
   MsmPlan p;
@@ -803,6 +802,7 @@ template <int C, bool MONT, bool PRE> static void launch_sort_c(const SortArgs& 
 template <bool MONT> static void launch_sort(int c, bool pre, const SortArgs& a, int phase, hipStream_t s) {
   if (pre) {
     switch (c) {
+      case 13: launch_sort_c<13, MONT, true>(a, phase, s); break;
       case 16: launch_sort_c<16, MONT, true>(a, phase, s); break;
       case 17: launch_sort_c<17, MONT, true>(a, phase, s); break;
       case 20: launch_sort_c<20, MONT, true>(a, phase, s); break;
@@ -823,9 +823,11 @@ int32_t msm_run(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, const void* 
   if (n > pb.n || n >= (1ull << 31)) { g_last_error = "msm: n exceeds the pinned base count (or 2^31)"; return ALEO_MI355X_ERR_BAD_ARG; }
   // the fixed-base table serves any prefix of the pinned set (row stride = pinned count) as long as the prefix still
   // puts about one point into every bucket; shorter prefixes use the plain path with its small bucket count
-  const bool pre = pb.d_pre != nullptr && n >= ((size_t)1 << (pb.pre_c - 3));
-  MsmPlan P = make_plan(n, pre ? pb.pre_c : 0);
-  const uint32_t digitsW = pre ? (SCALAR_BITS + pb.pre_c - 1) / pb.pre_c : P.W;
+  const PinnedBases::PreTable* T = nullptr;
+  for (const auto& t : pb.tab) if (t.d && n >= t.min_n && n <= t.cover) { T = &t; break; }
+  const bool pre = T != nullptr;
+  MsmPlan P = make_plan(n, pre ? T->c : 0);
+  const uint32_t digitsW = pre ? (SCALAR_BITS + T->c - 1) / T->c : P.W;
   const uint32_t M = P.M, ntiles = (M + SCAN_TILE - 1) / SCAN_TILE;
   const size_t pairs_max = n * (size_t)digitsW;
   if (pairs_max >= (1ull << 32)) { g_last_error = "msm: n * windows exceeds 2^32 (shard the MSM across GPUs)"; return ALEO_MI355X_ERR_BAD_ARG; }
@@ -861,12 +863,12 @@ int32_t msm_run(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, const void* 
   uint2* tile_tot = c->scan_blk.as<uint2>(); uint2* scan_blk = tile_tot + ntiles;
   uint32_t* sorted = c->sorted.as<uint32_t>(); char* partial = c->partial.as<char>(); uint32_t* task_g = c->task_g.as<uint32_t>(); uint32_t* order = task_g + slices_max;
   char* V = c->vbuf.as<char>(); char* Vout = V + (size_t)nchunks * 192;
-  const char* bases = (const char*)(pre ? pb.d_pre : pb.d_xy);
+  const char* bases = (const char*)(pre ? T->d : pb.d_xy);
 
   HIPCHK(hipEventRecord(c->ev[0], s));
   HIPCHK(hipMemsetAsync(hist, 0, hist_words * 4, s));
   SortArgs sa;
-  sa.scalars = d_scalars; sa.inf = pb.d_inf; sa.n = (uint32_t)n; sa.nblk = nblk; sa.row_stride = (uint32_t)pb.n;
+  sa.scalars = d_scalars; sa.inf = pb.d_inf; sa.n = (uint32_t)n; sa.nblk = nblk; sa.row_stride = (uint32_t)(pre ? T->cover : pb.n);
   sa.cnt = c->part_cnt.as<uint32_t>(); sa.off_local = sa.cnt + cnt_len;
   uint32_t* cnt_tile_tot = sa.off_local + cnt_len; sa.off_blk = cnt_tile_tot + cnt_tiles;
   sa.items = c->part_items.as<uint2>();
@@ -1106,9 +1108,8 @@ __global__ void __launch_bounds__(256) k_pre_double(char* __restrict__ cur, uint
   store_xyzz(cur + (size_t)i * 192, a);
 }
 
-int32_t msm_precompute(Ctx* c, PinnedBases* pb) {
-  if (pb->d_pre || pb->n == 0) return ALEO_MI355X_OK;
-  const size_t n = pb->n; const int pre_c = pre_c_for(n); const uint32_t W = (SCALAR_BITS + pre_c - 1) / pre_c;
+static int32_t build_table(Ctx* c, const PinnedBases* pb, int pre_c, size_t n, PinnedBases::PreTable* out) {
+  const uint32_t W = (SCALAR_BITS + pre_c - 1) / pre_c;
   if (n * (size_t)W >= (1ull << 31)) { g_last_error = "bases_precompute: table index would exceed 31 bits"; return ALEO_MI355X_ERR_BAD_ARG; }
   void *d_tab = nullptr, *d_cur = nullptr, *d_prefix = nullptr, *d_row = nullptr;
   HIPCHK(hipMalloc(&d_tab, n * 112 * W));                                    // rows in the accumulation kernel's 28-bit format (fp28.h)
@@ -1125,7 +1126,22 @@ int32_t msm_precompute(Ctx* c, PinnedBases* pb) {
   HIPCHK(hipStreamSynchronize(s));
   HIPCHK(hipGetLastError());
   (void)hipFree(d_cur); (void)hipFree(d_prefix); (void)hipFree(d_row);
-  pb->d_pre = d_tab; pb->pre_c = pre_c;
+  out->d = d_tab; out->c = pre_c; out->cover = n;
+  return ALEO_MI355X_OK;
+}
+
+// Tiers (measured, tools/small_probe.py): c = 20 needs >= 2^17 points per call to fill its 2^19 buckets, c = 16 wins from 2^15,
+// c = 13 from 2^10 (0.5 ms against 1.1-1.4 ms on the plain path); KZG10::commit multiplies polynomials of every degree against
+// prefixes of ONE SRS, so a pinned set carries a table for each range it can serve.  The two small tiers cost < 20 % extra HBM
+// and build time of a 2^20-point set.
+int32_t msm_precompute(Ctx* c, PinnedBases* pb) {
+  if (pb->tabled || pb->n == 0) return ALEO_MI355X_OK;
+  const size_t N = pb->n; int32_t rc; int k = 0;
+  auto lim = [&](size_t cap) { return N < cap ? N : cap; };
+  if (N >= (1u << 17)) { if ((rc = build_table(c, pb, N >= (1u << 19) ? 20 : 17, N, &pb->tab[k]))) return rc; pb->tab[k++].min_n = ((size_t)1 << 17) + 1; }      // exactly 2^17 points: the c = 16 tier is faster (0.90 vs 1.18 ms)
+  if (N >= (1u << 15)) { if ((rc = build_table(c, pb, 16, lim((size_t)1 << 17), &pb->tab[k]))) return rc; pb->tab[k++].min_n = (size_t)1 << 15; }
+  if (N >= (1u << 10)) { if ((rc = build_table(c, pb, 13, lim((size_t)1 << 15), &pb->tab[k]))) return rc; pb->tab[k++].min_n = (size_t)1 << 10; }
+  pb->tabled = true;
   return ALEO_MI355X_OK;
 }
 
