@@ -214,6 +214,11 @@ def test_msm_full_size_2_20_structured_identity():
         # oracle on a 2^16 prefix (seconds on the host cores)
         B = pb.download(0, 1 << 16)
         assert c.jac_to_int_point(M.VariableBase.msm(pb, S[: 1 << 16])) == c.jac_to_int_point(c.msm_g1(B, S[: 1 << 16], threads=os.cpu_count(), variant=1))
+        # tiered tables: every prefix length of the one pinned set, on both sides of each tier boundary (c = 13 / 16 / 20)
+        pb.precompute()
+        for m in (1000, 1 << 10, (1 << 15) - 1, 1 << 15, 1 << 17, (1 << 17) + 1, 3 << 18, n):
+            got = M.VariableBase.msm_device(pb, dS.data_ptr(), m)
+            assert c.jac_to_int_point(got) == util.expected_multiples_msm(S, m), m
 
 
 def test_sharded_msm_two_shards():
