@@ -80,7 +80,7 @@ static int32_t acquire_slot(Device* d, Ctx** out, std::unique_lock<std::mutex>& 
 }
 
 // ---- pinned base sets (shared by all slots) ----------------------------------------------------------
-static int32_t upload_bases(const void* bases, size_t stride, size_t n, std::shared_ptr<PinnedOwner>* out) {
+static int32_t upload_bases(Ctx* c, const void* bases, size_t stride, size_t n, std::shared_ptr<PinnedOwner>* out) {
   auto o = std::make_shared<PinnedOwner>(); PinnedBases& pb = o->pb; pb.n = n;
   size_t bytes = (n ? n : 1) * 96;
   HIPCHK(hipMalloc(&pb.d_xy, bytes));
@@ -101,6 +101,7 @@ static int32_t upload_bases(const void* bases, size_t stride, size_t n, std::sha
       HIPCHK(hipMemcpy(pb.d_inf, inf.data(), n, hipMemcpyHostToDevice));
     }
   }
+  { int32_t rc28 = make_rows28(c, &pb); if (rc28) return rc28; }
   *out = std::move(o); return ALEO_MI355X_OK;
 }
 static uint64_t register_bases(Device* d, std::shared_ptr<PinnedOwner> o) {
@@ -173,7 +174,7 @@ static SrsCacheEntry* srs_lookup(Device* d, const void* bases, size_t stride, si
 }
 // The resident set for a one-shot call's base array: a cache hit, or a fresh upload that replaces stale / least recently
 // used entries.  `want_table` is set on the third use of a set large enough to repay the one-off table build.
-static int32_t srs_get(Device* d, const void* bases, size_t stride, size_t n, std::shared_ptr<PinnedOwner>* keep, bool* want_table) {
+static int32_t srs_get(Ctx* c, Device* d, const void* bases, size_t stride, size_t n, std::shared_ptr<PinnedOwner>* keep, bool* want_table) {
   *want_table = false;
   {
     std::lock_guard<std::mutex> lk(d->mu);
@@ -185,7 +186,7 @@ static int32_t srs_get(Device* d, const void* bases, size_t stride, size_t n, st
     }
   }
   std::shared_ptr<PinnedOwner> o;              // the bulk upload runs without the lock
-  int32_t rc = upload_bases(bases, stride, n, &o);
+  int32_t rc = upload_bases(c, bases, stride, n, &o);
   if (rc) return rc;
   SrsCacheEntry e; e.host_ptr = bases; e.stride = stride; e.n = n; e.hits = 1;
   // dense samples at the front (every prefix request can be checked), sparse ones over the rest
@@ -240,7 +241,7 @@ int32_t aleo_mi355x_bases_pin(const void* bases, size_t base_stride, size_t n, u
   try {
     if (!handle || (!bases && n) || (base_stride != 104 && base_stride != 96)) { g_last_error = "bases_pin: bad argument"; return ALEO_MI355X_ERR_BAD_ARG; }
     API_BEGIN
-    std::shared_ptr<PinnedOwner> o; int32_t rc = upload_bases(bases, base_stride, n, &o);
+    std::shared_ptr<PinnedOwner> o; int32_t rc = upload_bases(c, bases, base_stride, n, &o);
     if (rc) return rc;
     *handle = register_bases(d, std::move(o));
     return ALEO_MI355X_OK;
@@ -294,13 +295,13 @@ int32_t aleo_mi355x_msm_g1(void* out, const void* bases, size_t base_stride, con
       // KZG10::commit multiplies against prefixes of one SRS: keep it in HBM between calls (ALEO_MI355X_SRS_CACHE=0
       // turns this off; a caller that rewrites a base array in place between calls must do so)
       std::shared_ptr<PinnedOwner> keep; bool want_table = false;
-      int32_t rc = srs_get(d, bases, base_stride, n, &keep, &want_table);
+      int32_t rc = srs_get(c, d, bases, base_stride, n, &keep, &want_table);
       if (rc) return rc;
       if (want_table) (void)precompute_once(c, keep);                       // third use: worth the one-off table
       PinnedBases pb; { std::lock_guard<std::mutex> g(d->mu); pb = keep->pb; }
       return msm_host_scalars(c, out, pb, scalars, n, false);
     }
-    std::shared_ptr<PinnedOwner> o; int32_t rc = upload_bases(bases, base_stride, n, &o);
+    std::shared_ptr<PinnedOwner> o; int32_t rc = upload_bases(c, bases, base_stride, n, &o);
     if (rc) return rc;
     return msm_host_scalars(c, out, o->pb, scalars, n, false);
   } catch (...) { return ALEO_MI355X_ERR_HIP; }

@@ -43,6 +43,7 @@ struct DevBuf {
 
 struct PinnedBases {
   void* d_xy = nullptr;        // n x 96 bytes: x | y, Montgomery, canonical
+  void* d_xy28 = nullptr;      // n x 112 bytes: the same points in the 28-bit-limb form the accumulation kernels compute in (fp28.h)
   uint8_t* d_inf = nullptr;    // n bytes, nullptr when no base is the point at infinity
   // optional fixed-base tables (msm_precompute): up to three tiers so that every call size against one SRS gets a window width
   // that suits it — the full set at c = 20 / 17, its first 2^17 points at c = 16, its first 2^15 points at c = 13.
@@ -58,7 +59,7 @@ struct PinnedBases {
 // owner of a pinned set's HBM; calls hold a shared_ptr while they run, so an unpin from another thread cannot free it under them
 struct PinnedOwner {
   PinnedBases pb; bool building = false;     // building: a table build for this set is in flight on some slot
-  ~PinnedOwner() { if (pb.d_xy) (void)hipFree(pb.d_xy); if (pb.d_inf) (void)hipFree(pb.d_inf); for (auto& t : pb.tab) if (t.d) (void)hipFree(t.d); }
+  ~PinnedOwner() { if (pb.d_xy) (void)hipFree(pb.d_xy); if (pb.d_xy28) (void)hipFree(pb.d_xy28); if (pb.d_inf) (void)hipFree(pb.d_inf); for (auto& t : pb.tab) if (t.d) (void)hipFree(t.d); }
 };
 
 struct SrsCacheEntry {
@@ -106,6 +107,7 @@ int32_t launch_fq_mul(Ctx* c, void* r, const void* a, const void* b, size_t n);
 int32_t launch_fr_mul(Ctx* c, void* r, const void* a, const void* b, size_t n);
 int32_t generate_multiples(Ctx* c, const void* base104, uint64_t first, size_t n, PinnedBases* out);
 int32_t msm_precompute(Ctx* c, PinnedBases* pb);
+int32_t make_rows28(Ctx* c, PinnedBases* pb);          // fills pb->d_xy28 from pb->d_xy
 int32_t selftest_madd28(Ctx* c, uint32_t lanes, uint32_t steps, uint64_t seed, uint32_t* failures);
 // frops.hip
 int32_t fr_vec_op(Ctx* c, void* d_dst, const void* d_a, const void* d_b, size_t n, int32_t op, hipStream_t s);

@@ -537,6 +537,7 @@ __device__ __noinline__ void slice_slow_path28(const char* bases, const uint32_t
   *acc_out = acc; *inf_out = inf;
 }
 
+template <bool OUT28>
 __global__ void __launch_bounds__(256) k_accum28(const char* __restrict__ bases, const uint32_t* __restrict__ sorted, const uint32_t* __restrict__ hist,
                                                  const uint2* __restrict__ scan_local, const uint2* __restrict__ scan_blk, const uint32_t* __restrict__ total_pairs, uint32_t M,
                                                  const uint32_t* __restrict__ meta, const uint32_t* __restrict__ order, const uint32_t* __restrict__ task_g,
@@ -565,11 +566,14 @@ __global__ void __launch_bounds__(256) k_accum28(const char* __restrict__ bases,
     if (e >> 31) y = f28_sub<2, 1>(f28_const(Limbs14{}), y);
     if (!xyzz28_madd_fast(acc, x, y)) { ok = false; break; }
   }
-  if (ok) store_xyzz28(partial + (size_t)sid * 224, acc);           // X exact < 12q, Y exact < 2q, ZZ / ZZZ exact < 2q: the stored invariant of fp28.h
-  else {      // P == +-acc (repeated or opposite bases): finish the slice with the general 32-bit code, out of line
+  if (ok) {
+    if constexpr (OUT28) store_xyzz28(partial + (size_t)sid * 224, acc);      // X exact < 12q, Y exact < 2q, ZZ / ZZZ exact < 2q: the stored invariant of fp28.h
+    else xyzz_store_normalized(partial + (size_t)sid * 192, xyzz28_to_xyzz(acc), false);   // plain path: its reduction kernels work on 32-bit points
+  } else {    // P == +-acc (repeated or opposite bases): finish the slice with the general 32-bit code, out of line
     XYZZ28 tmp = acc; XYZZ out; bool inf = false;
     slice_slow_path28(bases, run, j, j1, &tmp, &out, &inf);
-    store_xyzz28_from32(partial + (size_t)sid * 224, out, inf);
+    if constexpr (OUT28) store_xyzz28_from32(partial + (size_t)sid * 224, out, inf);
+    else xyzz_store_normalized(partial + (size_t)sid * 192, out, inf);
   }
 }
 
@@ -899,7 +903,8 @@ int32_t msm_run(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, const void* 
     hipLaunchKernelGGL(k_len_starts, dim3(1), dim3(256), 0, s, len_count, len_start);
     hipLaunchKernelGGL(k_slice_order, dim3((NT + 255) / 256), dim3(256), 0, s, hist, scan_local, scan_blk, total_pairs, M, meta, task_g, len_start, len_cursor, order);
     HIPCHK(hipEventRecord(c->ev[6], s));          // ev[6]..ev[5] bracket k_accum alone (bench.py's roofline kernel)
-    if (pre) hipLaunchKernelGGL(k_accum28, dim3((NT + 255) / 256), dim3(256), 0, s, bases, sorted, hist, scan_local, scan_blk, total_pairs, M, meta, order, task_g, partial);
+    if (pre) hipLaunchKernelGGL(k_accum28<true>, dim3((NT + 255) / 256), dim3(256), 0, s, bases, sorted, hist, scan_local, scan_blk, total_pairs, M, meta, order, task_g, partial);
+    else if (pb.d_xy28) hipLaunchKernelGGL(k_accum28<false>, dim3((NT + 255) / 256), dim3(256), 0, s, (const char*)pb.d_xy28, sorted, hist, scan_local, scan_blk, total_pairs, M, meta, order, task_g, partial);
     else hipLaunchKernelGGL(k_accum, dim3((NT + 255) / 256), dim3(256), 0, s, bases, sorted, hist, scan_local, scan_blk, total_pairs, M, meta, order, task_g, partial);
     HIPCHK(hipEventRecord(c->ev[5], s));
     const uint32_t* super_list = heavy + M + 2048;
@@ -1087,6 +1092,7 @@ int32_t generate_multiples(Ctx* c, const void* base104, uint64_t first, size_t n
   HIPCHK(hipStreamSynchronize(c->stream));
   HIPCHK(hipGetLastError());
   (void)hipFree(d_g); (void)hipFree(d_tmp); (void)hipFree(d_pre);
+  { int32_t rc28 = make_rows28(c, &pb); if (rc28) return rc28; }
   *out = pb; return ALEO_MI355X_OK;
 }
 
@@ -1108,6 +1114,15 @@ __global__ void __launch_bounds__(256) k_pre_double(char* __restrict__ cur, uint
   store_xyzz(cur + (size_t)i * 192, a);
 }
 
+int32_t make_rows28(Ctx* c, PinnedBases* pb) {
+  if (pb->d_xy28 || pb->n == 0) return ALEO_MI355X_OK;
+  HIPCHK(hipMalloc(&pb->d_xy28, pb->n * 112));
+  hipLaunchKernelGGL(k_rows_to28, dim3((uint32_t)((pb->n + 255) / 256)), dim3(256), 0, c->stream, (const char*)pb->d_xy, (char*)pb->d_xy28, (uint32_t)pb->n);
+  HIPCHK(hipStreamSynchronize(c->stream));
+  HIPCHK(hipGetLastError());
+  return ALEO_MI355X_OK;
+}
+
 static int32_t build_table(Ctx* c, const PinnedBases* pb, int pre_c, size_t n, PinnedBases::PreTable* out) {
   const uint32_t W = (SCALAR_BITS + pre_c - 1) / pre_c;
   if (n * (size_t)W >= (1ull << 31)) { g_last_error = "bases_precompute: table index would exceed 31 bits"; return ALEO_MI355X_ERR_BAD_ARG; }
@@ -1116,7 +1131,8 @@ static int32_t build_table(Ctx* c, const PinnedBases* pb, int pre_c, size_t n, P
   HIPCHK(hipMalloc(&d_cur, n * 192)); HIPCHK(hipMalloc(&d_prefix, n * 48)); HIPCHK(hipMalloc(&d_row, n * 96));
   hipStream_t s = c->stream;
   const uint32_t g = (uint32_t)((n + 255) / 256), lanes = (uint32_t)((n + GEN_K - 1) / GEN_K), gl = (lanes + 255) / 256;
-  hipLaunchKernelGGL(k_rows_to28, dim3(g), dim3(256), 0, s, (const char*)pb->d_xy, (char*)d_tab, (uint32_t)n);
+  if (pb->d_xy28) HIPCHK(hipMemcpyAsync(d_tab, pb->d_xy28, n * 112, hipMemcpyDeviceToDevice, s));
+  else hipLaunchKernelGGL(k_rows_to28, dim3(g), dim3(256), 0, s, (const char*)pb->d_xy, (char*)d_tab, (uint32_t)n);
   hipLaunchKernelGGL(k_pre_init, dim3(g), dim3(256), 0, s, (const char*)pb->d_xy, (uint32_t)n, (char*)d_cur);
   for (uint32_t w = 1; w < W; ++w) {
     hipLaunchKernelGGL(k_pre_double, dim3(g), dim3(256), 0, s, (char*)d_cur, (uint32_t)n, pre_c);
