@@ -12,8 +12,8 @@
 //             sorted stream holds 4-byte point indices (bit 31 = negate), so a bucket is a contiguous run.
 //   slices    bucket runs are cut into slices (pick_rule: whole buckets up to 2x the mean size, longer ones split at the
 //             mean), counting-sorted by length so the lanes of a wave run equal trip counts; one lane accumulates one
-//             slice with XYZZ mixed additions, reading affine points straight from HBM: 96-byte rows and 12 x 32-bit
-//             limbs (ec.h) on the plain path, 112-byte table rows and 14 x 28-bit limbs (fp28.h) on the fixed-base path.
+//             slice with XYZZ mixed additions on 14 x 28-bit limbs (fp28.h), reading 112-byte affine rows straight from HBM
+//             (table rows on the fixed-base path, the pinned set's 28-bit copy on the plain path).
 //   tree      slices of multi-slice buckets are folded pairwise (short launches over the listed buckets only).
 //   reduce    sum_b (b+1) * S_b: S-bucket running sums, then either a double-and-add of the chunk base + pairwise tree
 //             (plain) or lg(N) masked pairwise sums folded through LDS blocks (fixed-base); every addition after the
@@ -470,58 +470,11 @@ __global__ void __launch_bounds__(256) k_slice_order(const uint32_t* __restrict_
   if (live) order[base[len] + rank] = t;
 }
 
-// ---- bucket accumulation: one lane per slice ----------------------------------------------------
-__device__ __noinline__ void slice_slow_path(const char* bases, const uint32_t* run, uint32_t j, uint32_t j1, XYZZ* acc_io, bool* inf_io) {
-  XYZZ acc = *acc_io; bool inf = *inf_io;
-  for (; j < j1; ++j) {
-    uint32_t e = run[j];
-    AffinePt p = load_affine(bases + (size_t)(e & 0x7fffffffu) * 96);
-    if (e >> 31) p.y = fq_neg_canonical(p.y);
-    xyzz_madd(acc, inf, p.x, p.y);
-  }
-  *acc_io = acc; *inf_io = inf;
-}
-
-__global__ void __launch_bounds__(256) k_accum(const char* __restrict__ bases, const uint32_t* __restrict__ sorted, const uint32_t* __restrict__ hist,
-                                               const uint2* __restrict__ scan_local, const uint2* __restrict__ scan_blk, const uint32_t* __restrict__ total_pairs, uint32_t M,
-                                               const uint32_t* __restrict__ meta, const uint32_t* __restrict__ order, const uint32_t* __restrict__ task_g,
-                                               char* __restrict__ partial) {
-  uint32_t t = blockIdx.x * 256 + threadIdx.x;
-  if (t >= meta[0]) return;
-  const uint32_t sid = order[t], g = task_g[sid];
-  uint2 st = scan_at(scan_local, scan_blk, g);
-  uint32_t cnt = hist[g], m = slices_of(cnt, pick_rule(total_pairs, M)), k = sid - st.y;
-  uint32_t j0 = (uint32_t)(((uint64_t)k * cnt) / m), j1 = (uint32_t)(((uint64_t)(k + 1) * cnt) / m);
-  const uint32_t* run = sorted + st.x;
-  // software prefetch: the next point's 96-byte gather is in flight under the current mixed addition
-  uint32_t e_next = run[j0];
-  AffinePt p_next = load_affine(bases + (size_t)(e_next & 0x7fffffffu) * 96);
-  XYZZ acc; bool inf = false, ok = true;
-  uint32_t j = j0;
-  {   // first point of the slice: acc = (x, +-y, 1, 1)
-    uint32_t e = e_next; AffinePt p = p_next;
-    if (j + 1 < j1) { e_next = run[j + 1]; p_next = load_affine(bases + (size_t)(e_next & 0x7fffffffu) * 96); }
-    if (e >> 31) p.y = fq_neg_canonical(p.y);
-    acc.X = p.x; acc.Y = p.y; acc.ZZ = Fq::one(); acc.ZZZ = Fq::one();
-    ++j;
-  }
-  for (; j < j1; ++j) {
-    uint32_t e = e_next; AffinePt p = p_next;
-    if (j + 1 < j1) { e_next = run[j + 1]; p_next = load_affine(bases + (size_t)(e_next & 0x7fffffffu) * 96); }
-    if (e >> 31) p.y = fq_neg_canonical(p.y);
-    if (!xyzz_madd_fast(acc, p.x, p.y)) { ok = false; break; }
-  }
-  if (!ok) {   // P == +-acc (repeated or opposite bases): finish the slice with the general, out-of-line code
-    XYZZ tmp = acc; bool tinf = false;
-    slice_slow_path(bases, run, j, j1, &tmp, &tinf);
-    acc = tmp; inf = tinf;
-  }
-  xyzz_store_normalized(partial + (size_t)sid * 192, acc, inf);
-}
-
-// ---- the same loop on the fixed-base table, in the 14 x 28-bit representation (fp28.h) ---------------------------------
-// Table rows are 112 bytes (x'[14] | y'[14], value * 2^392 mod q as exact base-2^28 digits).  The slice sum is stored as a
-// 224-byte 28-bit XYZZ point; the slice tree and the chunk kernels continue in that form.
+// ---- bucket accumulation: one lane per slice, in the 14 x 28-bit representation (fp28.h) -----------------------------
+// Point rows are 112 bytes (x'[14] | y'[14], value * 2^392 mod q as exact base-2^28 digits): table rows on the fixed-base path,
+// the pinned set's own 28-bit rows on the plain path.  OUT28: the slice sum is stored as a 224-byte 28-bit XYZZ point (the
+// table path's reduction continues in that form); otherwise it is converted to a 32-bit XYZZ point for the plain path's
+// per-window reduction kernels.
 __device__ __forceinline__ XYZZ xyzz28_to_xyzz(const XYZZ28& a) {
   XYZZ r; r.X = f28_to_fq(a.X); r.Y = f28_to_fq(a.Y); r.ZZ = f28_to_fq(a.ZZ); r.ZZZ = f28_to_fq(a.ZZZ); return r;     // all < 2q
 }
@@ -867,7 +820,8 @@ int32_t msm_run(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, const void* 
   uint2* tile_tot = c->scan_blk.as<uint2>(); uint2* scan_blk = tile_tot + ntiles;
   uint32_t* sorted = c->sorted.as<uint32_t>(); char* partial = c->partial.as<char>(); uint32_t* task_g = c->task_g.as<uint32_t>(); uint32_t* order = task_g + slices_max;
   char* V = c->vbuf.as<char>(); char* Vout = V + (size_t)nchunks * 192;
-  const char* bases = (const char*)(pre ? T->d : pb.d_xy);
+  if (!pre && !pb.d_xy28) { g_last_error = "msm: pinned set without 28-bit rows"; return ALEO_MI355X_ERR_HIP; }
+  const char* bases = (const char*)(pre ? T->d : pb.d_xy28);          // 112-byte rows either way
 
   HIPCHK(hipEventRecord(c->ev[0], s));
   HIPCHK(hipMemsetAsync(hist, 0, hist_words * 4, s));
@@ -902,10 +856,9 @@ int32_t msm_run(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, const void* 
     hipLaunchKernelGGL(k_slice_count, dim3((NT + 255) / 256), dim3(256), 0, s, hist, scan_local, scan_blk, M, total_pairs, meta, task_g, len_count);
     hipLaunchKernelGGL(k_len_starts, dim3(1), dim3(256), 0, s, len_count, len_start);
     hipLaunchKernelGGL(k_slice_order, dim3((NT + 255) / 256), dim3(256), 0, s, hist, scan_local, scan_blk, total_pairs, M, meta, task_g, len_start, len_cursor, order);
-    HIPCHK(hipEventRecord(c->ev[6], s));          // ev[6]..ev[5] bracket k_accum alone (bench.py's roofline kernel)
+    HIPCHK(hipEventRecord(c->ev[6], s));          // ev[6]..ev[5] bracket k_accum28 alone (bench.py's roofline kernel)
     if (pre) hipLaunchKernelGGL(k_accum28<true>, dim3((NT + 255) / 256), dim3(256), 0, s, bases, sorted, hist, scan_local, scan_blk, total_pairs, M, meta, order, task_g, partial);
-    else if (pb.d_xy28) hipLaunchKernelGGL(k_accum28<false>, dim3((NT + 255) / 256), dim3(256), 0, s, (const char*)pb.d_xy28, sorted, hist, scan_local, scan_blk, total_pairs, M, meta, order, task_g, partial);
-    else hipLaunchKernelGGL(k_accum, dim3((NT + 255) / 256), dim3(256), 0, s, bases, sorted, hist, scan_local, scan_blk, total_pairs, M, meta, order, task_g, partial);
+    else hipLaunchKernelGGL(k_accum28<false>, dim3((NT + 255) / 256), dim3(256), 0, s, bases, sorted, hist, scan_local, scan_blk, total_pairs, M, meta, order, task_g, partial);
     HIPCHK(hipEventRecord(c->ev[5], s));
     const uint32_t* super_list = heavy + M + 2048;
     for (uint32_t pass = 0, L = max_m; L > 1; ++pass, L = (L + 1) >> 1) {

@@ -122,7 +122,7 @@ def main():
             'config': {'workload': 'standalone 2^%d-point BLS12-377 G1 Pippenger MSM (BASELINE configs[1])' % args.lg_n,
                        'points_per_gpu': n, 'scalars': args.scalars, 'bases': 'P_i=(i+1)G generated in HBM' + ('' if args.no_precompute else '; fixed-base window table (13 x 2^20-bit windows) built at pin time'),
                        'sharding': 'point-sharded, all-gather of 144-byte partials' if world > 1 else 'single GPU'},
-            'roofline': {'bound': 'hbm', 'kernel': 'k_accum28 (bucket accumulation, 28-bit-limb table path)' if not args.no_precompute else 'k_accum (bucket accumulation)', 'achieved': achieved, 'peak': 8000.0,
+            'roofline': {'bound': 'hbm', 'kernel': 'k_accum28 (bucket accumulation, 28-bit limbs)', 'achieved': achieved, 'peak': 8000.0,
                          'unit': 'GB/s', 'frac': achieved / 8000.0, 'traffic': traffic,
                          'note': 'integer-VALU bound by construction (SURVEY.md §8d): %d mixed additions x 10 Fq products per point; '
                                  'measured Fq product peak 81 G/s with 28-bit limbs, 61 G/s with 32-bit limbs (tools/ubench/fq28_mul_bench.hip, fq_mul_bench.hip)' % (16 if args.no_precompute else 13)},
