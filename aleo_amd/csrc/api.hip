@@ -7,6 +7,7 @@
 #include <memory>
 #include <thread>
 #include <functional>
+#include <vector>
 
 namespace aleo_mi355x {
 
@@ -23,6 +24,18 @@ int32_t ensure_host_pinned(Ctx* c, size_t bytes) {
   size_t want = bytes < 65536 ? 65536 : bytes;
   HIPCHK(hipHostMalloc(&c->h_pinned, want, hipHostMallocDefault));
   c->h_pinned_cap = want; return ALEO_MI355X_OK;
+}
+
+// ---- slot scratch shared by asynchronous calls (ctx.h) --------------------------------------------------
+int32_t scratch_acquire(Ctx* c, DevBuf& b, size_t bytes, hipStream_t s) {
+  if (c->scratch_busy) {
+    if (bytes > b.cap) { HIPCHK(hipEventSynchronize(c->scratch_ev)); c->scratch_busy = false; }   // reserve() is about to free it
+    else HIPCHK(hipStreamWaitEvent(s, c->scratch_ev, 0));
+  }
+  return b.reserve(bytes);
+}
+int32_t scratch_release(Ctx* c, hipStream_t s) {
+  HIPCHK(hipEventRecord(c->scratch_ev, s)); c->scratch_busy = true; return ALEO_MI355X_OK;
 }
 
 static int32_t init_device(int device, Device** out) {
@@ -74,7 +87,9 @@ static int32_t acquire_slot(Device* d, Ctx** out, std::unique_lock<std::mutex>& 
   if (hipSetDevice(d->device) != hipSuccess) { g_last_error = "hipSetDevice failed"; return ALEO_MI355X_ERR_HIP; }
   if (!c->stream) {                         // first use of this slot
     HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
     for (auto& e : c->ev) HIPCHK(hipEventCreate(&e));
+    HIPCHK(hipEventCreateWithFlags(&c->scratch_ev, hipEventDisableTiming));
   }
   *out = c; return ALEO_MI355X_OK;
 }
@@ -142,7 +157,7 @@ static int32_t msm_host_scalars(Ctx* c, void* out, const PinnedBases& pb, const 
   int32_t rc;
   if ((rc = c->scalars_stage.reserve((n ? n : 1) * 32))) return rc;
   if (n) HIPCHK(hipMemcpyAsync(c->scalars_stage.p, scalars, n * 32, hipMemcpyHostToDevice, c->stream));
-  return msm_run(c, (uint64_t*)out, pb, c->scalars_stage.p, n, mont, c->stream);
+  return msm_run1(c, (uint64_t*)out, pb, c->scalars_stage.p, n, mont, c->stream);
 }
 
 // ---- SRS cache for the one-shot entry point ----------------------------------------------------------
@@ -153,10 +168,9 @@ static uint64_t hash96(const uint8_t* p) {      // FNV-1a over the 96 coordinate
 }
 static constexpr size_t SRS_SAMPLES = 256, SRS_CACHE_ENTRIES = 8, SRS_MIN_N = 1024;
 
-static bool srs_cache_enabled() {
-  static int on = -1;
-  if (on < 0) { const char* e = std::getenv("ALEO_MI355X_SRS_CACHE"); on = (e && e[0] == '0') ? 0 : 1; }
-  return on == 1;
+static bool srs_cache_enabled() {          // opt-in (see the header); read per call so a host can switch it around a phase
+  const char* e = std::getenv("ALEO_MI355X_SRS_CACHE");
+  return e && e[0] == '1';
 }
 // Caller holds d->mu.  Returns the cached entry for (bases, stride) that covers n points, or nullptr.
 static SrsCacheEntry* srs_lookup(Device* d, const void* bases, size_t stride, size_t n) {
@@ -231,6 +245,24 @@ using namespace aleo_mi355x;
   { int32_t rc0 = get_device(&d); if (rc0) return rc0; if ((rc0 = acquire_slot(d, &c, lk))) return rc0; }
 #define FIND_BASES(handle) std::shared_ptr<PinnedOwner> keep; PinnedBases pb; { int32_t rcb = find_bases(d, handle, &keep, &pb); if (rcb) return rcb; }
 
+// *_device entry points that only enqueue work.  On the caller's stream they return without synchronising (the caller orders
+// its own work there).  With stream == NULL they run on the serving slot's stream, which the caller cannot order anything
+// against — a following call may be served by another slot — so the work is complete when they return.
+// The stream a call works on: the caller's, or the slot's own for NULL.  hipStreamLegacy is passed on as the null stream it
+// names (this library is not built with a per-thread default stream): the runtime takes the special handle for launches but
+// not for every event call.
+static hipStream_t pick_stream(Ctx* c, void* stream) {
+  if (!stream) return c->stream;
+  return (hipStream_t)stream == hipStreamLegacy ? (hipStream_t)nullptr : (hipStream_t)stream;
+}
+template <class F> static int32_t run_enqueue(Ctx* c, void* stream, F&& f) {
+  hipStream_t s = pick_stream(c, stream);
+  int32_t rc = f(s);
+  if (rc) return rc;
+  if (!stream) HIPCHK(hipStreamSynchronize(s));
+  return ALEO_MI355X_OK;
+}
+
 extern "C" {
 
 int32_t aleo_mi355x_init(int32_t device) {
@@ -268,6 +300,21 @@ int32_t aleo_mi355x_bases_precompute(uint64_t handle) {
   } catch (...) { return ALEO_MI355X_ERR_HIP; }
 }
 
+int32_t aleo_mi355x_bases_info(uint64_t handle, uint64_t* out, int32_t cap) {
+  try {
+    if (!out || cap <= 0) return 0;
+    Device* d = nullptr; if (get_device(&d)) return 0;
+    std::shared_ptr<PinnedOwner> keep; PinnedBases pb; if (find_bases(d, handle, &keep, &pb)) return 0;
+    uint64_t v[8] = {pb.n, pb.n * (96 + 112) + (pb.d_inf ? pb.n : 0), 0, 0, 0, 0, 0, 0};
+    int k = 0;
+    for (const auto& t : pb.tab) if (t.d) { const uint64_t W = (254 + t.c - 1) / t.c; v[2] += W * t.cover * 112; v[3 + k] = (uint64_t)t.c; ++k; }
+    v[6] = (uint64_t)k;
+    const int32_t m = cap < 8 ? cap : 8;
+    for (int32_t i = 0; i < m; ++i) out[i] = v[i];
+    return m;
+  } catch (...) { return 0; }
+}
+
 int32_t aleo_mi355x_bases_download(uint64_t handle, size_t offset, size_t n, void* out104) {
   try {
     if (!out104 && n) return ALEO_MI355X_ERR_BAD_ARG;
@@ -292,8 +339,9 @@ int32_t aleo_mi355x_msm_g1(void* out, const void* bases, size_t base_stride, con
     if (!out || ((!bases || !scalars) && n) || (base_stride != 104 && base_stride != 96)) { g_last_error = "msm_g1: bad argument"; return ALEO_MI355X_ERR_BAD_ARG; }
     API_BEGIN
     if (n >= SRS_MIN_N && srs_cache_enabled()) {
-      // KZG10::commit multiplies against prefixes of one SRS: keep it in HBM between calls (ALEO_MI355X_SRS_CACHE=0
-      // turns this off; a caller that rewrites a base array in place between calls must do so)
+      // ALEO_MI355X_SRS_CACHE=1 (opt-in): KZG10::commit multiplies against prefixes of one SRS, so the base array is kept in
+      // HBM between calls, recognised by host pointer + sampled content.  Off by default: it reads caller memory the ABI
+      // otherwise does not retain, and an array rewritten in place at unsampled entries would be served stale.
       std::shared_ptr<PinnedOwner> keep; bool want_table = false;
       int32_t rc = srs_get(c, d, bases, base_stride, n, &keep, &want_table);
       if (rc) return rc;
@@ -321,7 +369,7 @@ int32_t aleo_mi355x_msm_g1_device(void* out, uint64_t handle, const void* d_scal
     if (!out || (!d_scalars && n)) { g_last_error = "msm_g1_device: bad argument"; return ALEO_MI355X_ERR_BAD_ARG; }
     API_BEGIN
     FIND_BASES(handle)
-    return msm_run(c, (uint64_t*)out, pb, d_scalars, n, false, stream ? (hipStream_t)stream : c->stream);
+    return msm_run1(c, (uint64_t*)out, pb, d_scalars, n, false, pick_stream(c, stream));
   } catch (...) { return ALEO_MI355X_ERR_HIP; }
 }
 
@@ -354,9 +402,67 @@ int32_t aleo_mi355x_kzg_commit_device(void* out104, uint64_t handle, const void*
     API_BEGIN
     FIND_BASES(handle)
     uint64_t jac[18];
-    int32_t rc = msm_run(c, jac, pb, d_coeffs, n, true, stream ? (hipStream_t)stream : c->stream);
+    int32_t rc = msm_run1(c, jac, pb, d_coeffs, n, true, pick_stream(c, stream));
     if (rc) return rc;
     jacobian_to_affine104(out104, jac);
+    return ALEO_MI355X_OK;
+  } catch (...) { return ALEO_MI355X_ERR_HIP; }
+}
+
+// ---- one prover round's commitments in one call -------------------------------------------------------------------
+static int32_t batch_args_ok(const void* out, const void* const* ptrs, const size_t* lens, size_t k) {
+  if (k == 0) return ALEO_MI355X_OK;
+  if (!out || !ptrs || !lens) { g_last_error = "batch: null argument"; return ALEO_MI355X_ERR_BAD_ARG; }
+  for (size_t q = 0; q < k; ++q) if (!ptrs[q] && lens[q]) { g_last_error = "batch: null vector with a non-zero length"; return ALEO_MI355X_ERR_BAD_ARG; }
+  return ALEO_MI355X_OK;
+}
+static void jac_to_affine_rows(void* out104, const uint64_t* jac, size_t k) {
+  for (size_t q = 0; q < k; ++q) jacobian_to_affine104((uint8_t*)out104 + 104 * q, jac + 18 * q);
+}
+
+int32_t aleo_mi355x_msm_g1_batch_device(void* out_jac, uint64_t handle, const void* const* d_scalars, const size_t* lens, size_t k, void* stream) {
+  try {
+    int32_t rc = batch_args_ok(out_jac, d_scalars, lens, k); if (rc || !k) return rc;
+    API_BEGIN
+    FIND_BASES(handle)
+    MsmJob j; j.d_sets = d_scalars; j.lens = lens; j.k = (uint32_t)k; j.mont = false;
+    if (k >= (1u << 20)) { g_last_error = "batch: too many vectors"; return ALEO_MI355X_ERR_BAD_ARG; }
+    return msm_batch(c, (uint64_t*)out_jac, pb, j, pick_stream(c, stream));
+  } catch (...) { return ALEO_MI355X_ERR_HIP; }
+}
+
+int32_t aleo_mi355x_kzg_commit_batch_device(void* out104, uint64_t handle, const void* const* d_coeffs, const size_t* lens, size_t k, void* stream) {
+  try {
+    int32_t rc = batch_args_ok(out104, d_coeffs, lens, k); if (rc || !k) return rc;
+    if (k >= (1u << 20)) { g_last_error = "batch: too many vectors"; return ALEO_MI355X_ERR_BAD_ARG; }
+    API_BEGIN
+    FIND_BASES(handle)
+    std::vector<uint64_t> jac(18 * k);
+    MsmJob j; j.d_sets = d_coeffs; j.lens = lens; j.k = (uint32_t)k; j.mont = true;
+    if ((rc = msm_batch(c, jac.data(), pb, j, pick_stream(c, stream)))) return rc;
+    jac_to_affine_rows(out104, jac.data(), k);
+    return ALEO_MI355X_OK;
+  } catch (...) { return ALEO_MI355X_ERR_HIP; }
+}
+
+int32_t aleo_mi355x_kzg_commit_batch(void* out104, uint64_t handle, const void* const* coeffs, const size_t* lens, size_t k) {
+  try {
+    int32_t rc = batch_args_ok(out104, coeffs, lens, k); if (rc || !k) return rc;
+    if (k >= (1u << 20)) { g_last_error = "batch: too many vectors"; return ALEO_MI355X_ERR_BAD_ARG; }
+    API_BEGIN
+    FIND_BASES(handle)
+    size_t total = 0; for (size_t q = 0; q < k; ++q) total += lens[q];
+    if ((rc = c->scalars_stage.reserve((total ? total : 1) * 32))) return rc;
+    std::vector<const void*> dptr(k); size_t off = 0;
+    for (size_t q = 0; q < k; ++q) {          // one staging buffer, k uploads queued back to back on the slot's stream
+      dptr[q] = (const char*)c->scalars_stage.p + off * 32;
+      if (lens[q]) HIPCHK(hipMemcpyAsync((char*)c->scalars_stage.p + off * 32, coeffs[q], lens[q] * 32, hipMemcpyHostToDevice, c->stream));
+      off += lens[q];
+    }
+    std::vector<uint64_t> jac(18 * k);
+    MsmJob j; j.d_sets = dptr.data(); j.lens = lens; j.k = (uint32_t)k; j.mont = true;
+    if ((rc = msm_batch(c, jac.data(), pb, j, c->stream))) return rc;
+    jac_to_affine_rows(out104, jac.data(), k);
     return ALEO_MI355X_OK;
   } catch (...) { return ALEO_MI355X_ERR_HIP; }
 }
@@ -381,7 +487,7 @@ int32_t aleo_mi355x_fr_vec_op_device(void* d_dst, const void* d_a, const void* d
   try {
     if ((!d_dst || !d_a || !d_b) && n) return ALEO_MI355X_ERR_BAD_ARG;
     API_BEGIN
-    return fr_vec_op(c, d_dst, d_a, d_b, n, op, stream ? (hipStream_t)stream : c->stream);
+    return run_enqueue(c, stream, [&](hipStream_t s) { return fr_vec_op(c, d_dst, d_a, d_b, n, op, s); });
   } catch (...) { return ALEO_MI355X_ERR_HIP; }
 }
 
@@ -389,7 +495,7 @@ int32_t aleo_mi355x_fr_batch_inverse_device(void* d_inout, size_t n, void* strea
   try {
     if (!d_inout && n) return ALEO_MI355X_ERR_BAD_ARG;
     API_BEGIN
-    return fr_batch_inverse(c, d_inout, n, stream ? (hipStream_t)stream : c->stream);
+    return run_enqueue(c, stream, [&](hipStream_t s) { return fr_batch_inverse(c, d_inout, n, s); });
   } catch (...) { return ALEO_MI355X_ERR_HIP; }
 }
 
@@ -397,7 +503,7 @@ int32_t aleo_mi355x_fr_spmv_device(void* d_y, const void* d_row_ptr, const void*
   try {
     if ((!d_y || !d_row_ptr) && rows) return ALEO_MI355X_ERR_BAD_ARG;
     API_BEGIN
-    return fr_spmv(c, d_y, d_row_ptr, d_col_idx, d_vals, d_x, rows, stream ? (hipStream_t)stream : c->stream);
+    return run_enqueue(c, stream, [&](hipStream_t s) { return fr_spmv(c, d_y, d_row_ptr, d_col_idx, d_vals, d_x, rows, s); });
   } catch (...) { return ALEO_MI355X_ERR_HIP; }
 }
 
@@ -419,7 +525,7 @@ int32_t aleo_mi355x_ntt_fr_device(void* d_inout, uint32_t lg_n, int32_t order, i
   try {
     if (!d_inout || lg_n > 30 || order < 0 || order > 3 || direction < 0 || direction > 1 || type < 0 || type > 1) { g_last_error = "ntt_fr_device: bad argument"; return ALEO_MI355X_ERR_BAD_ARG; }
     API_BEGIN
-    return ntt_run(c, d_inout, lg_n, 1, order, direction, type, stream ? (hipStream_t)stream : c->stream);
+    return run_enqueue(c, stream, [&](hipStream_t s) { return ntt_run(c, d_inout, lg_n, 1, order, direction, type, s); });
   } catch (...) { return ALEO_MI355X_ERR_HIP; }
 }
 
@@ -427,16 +533,16 @@ int32_t aleo_mi355x_ntt_fr_batch_device(void* d_inout, uint32_t lg_n, size_t bat
   try {
     if ((!d_inout && batch) || lg_n > 30 || order < 0 || order > 3 || direction < 0 || direction > 1 || type < 0 || type > 1) { g_last_error = "ntt_fr_batch_device: bad argument"; return ALEO_MI355X_ERR_BAD_ARG; }
     API_BEGIN
-    return ntt_run(c, d_inout, lg_n, batch, order, direction, type, stream ? (hipStream_t)stream : c->stream);
+    return run_enqueue(c, stream, [&](hipStream_t s) { return ntt_run(c, d_inout, lg_n, batch, order, direction, type, s); });
   } catch (...) { return ALEO_MI355X_ERR_HIP; }
 }
 
 int32_t aleo_mi355x_fr_grid_scale_device(void* d_data, uint32_t lg_n, uint64_t rows, uint64_t cols, uint64_t row0, uint64_t col0, uint64_t ld,
                                          int32_t mode, int32_t direction, void* stream) {
   try {
-    if ((!d_data && rows && cols) || lg_n == 0 || lg_n > 40 || mode < 0 || mode > 1 || direction < 0 || direction > 1) { g_last_error = "fr_grid_scale_device: bad argument"; return ALEO_MI355X_ERR_BAD_ARG; }
+    if ((!d_data && rows && cols) || lg_n == 0 || lg_n > 32 || mode < 0 || mode > 1 || direction < 0 || direction > 1) { g_last_error = "fr_grid_scale_device: bad argument"; return ALEO_MI355X_ERR_BAD_ARG; }
     API_BEGIN
-    return fr_grid_scale(c, d_data, lg_n, rows, cols, row0, col0, ld, mode, direction, stream ? (hipStream_t)stream : c->stream);
+    return run_enqueue(c, stream, [&](hipStream_t s) { return fr_grid_scale(c, d_data, lg_n, rows, cols, row0, col0, ld, mode, direction, s); });
   } catch (...) { return ALEO_MI355X_ERR_HIP; }
 }
 

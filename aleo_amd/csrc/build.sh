@@ -6,13 +6,13 @@ out="$here/../lib"; mkdir -p "$out"
 python3 "$here/../../tools/gen_fp_asm.py" "$here/fp_mont_gen.h"
 python3 "$here/../../tools/gen_fp28_asm.py" "$here/fp28_mont_gen.h"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fgpu-rdc-never 2>/dev/null"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Wno-unused-variable"
-objs=()
+objs=(); pids=()
 for f in api msm ntt frops; do
+  rm -f "$out/$f.o"                      # a failed compile must not link a stale object
   "$HIPCC" $FLAGS -c "$here/$f.hip" -o "$out/$f.o" &
-  objs+=("$out/$f.o")
+  pids+=("$!"); objs+=("$out/$f.o")
 done
-wait
+for p in "${pids[@]}"; do wait "$p" || { echo "build.sh: a compile failed" >&2; exit 1; }; done
 "$HIPCC" --offload-arch=gfx950 -shared -fPIC -o "$out/libaleo_mi355x.so" "${objs[@]}"
 echo "built $out/libaleo_mi355x.so"

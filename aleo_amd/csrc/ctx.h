@@ -3,6 +3,7 @@
 // workspaces), so the rayon threads of one prover round overlap their MSMs/NTTs on the GPU instead of queueing.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <cstdint>
 #include <cstdio>
 #include <map>
@@ -39,6 +40,15 @@ struct DevBuf {
     cap = want; return ALEO_MI355X_OK;
   }
   template <class T> T* as() const { return (T*)p; }
+};
+
+// A temporary device allocation that is freed on every return path (setup code: base generation, table builds).
+struct DevTmp {
+  void* p = nullptr;
+  DevTmp() = default; DevTmp(const DevTmp&) = delete; DevTmp& operator=(const DevTmp&) = delete;
+  ~DevTmp() { if (p) (void)hipFree(p); }
+  int32_t alloc(size_t bytes) { HIPCHK(hipMalloc(&p, bytes ? bytes : 1)); return ALEO_MI355X_OK; }
+  void* release() { void* q = p; p = nullptr; return q; }
 };
 
 struct PinnedBases {
@@ -84,7 +94,16 @@ struct Ctx {                           // one concurrency slot
   void* h_pinned = nullptr; size_t h_pinned_cap = 0;    // pinned host staging for small D2H results
   MsmTiming last_msm;
   DevBuf ntt_tmp, ntt_stage;
+  // ntt_tmp is scratch of the *_device entry points, which enqueue on the CALLER's stream and return without synchronising;
+  // the slot is then handed to the next call, possibly on another stream.  scratch_ev is recorded after the last kernel that
+  // touches the scratch; the next user waits on it (scratch_acquire) before its first kernel, or synchronises on it before
+  // the buffer is freed to grow.
+  hipEvent_t scratch_ev = nullptr; bool scratch_busy = false;
+  hipStream_t side = nullptr;          // second stream of the slot: small read-backs that must not wait for the kernels queued behind them
 };
+
+int32_t scratch_acquire(Ctx* c, DevBuf& b, size_t bytes, hipStream_t s);
+int32_t scratch_release(Ctx* c, hipStream_t s);
 
 static constexpr int MAX_SLOTS = 8;
 
@@ -95,6 +114,7 @@ struct Device {
   std::map<uint64_t, std::shared_ptr<PinnedOwner>> bases; uint64_t next_handle = 1;
   std::vector<SrsCacheEntry> srs_cache; uint64_t srs_clock = 0;
   std::map<uint64_t, NttTables*> ntt_tables;
+  std::atomic<int> ntt_attr_mask{0};   // which NTT kernel instances had their LDS limit raised on THIS device
   Ctx slots[MAX_SLOTS];
 };
 
@@ -102,7 +122,16 @@ extern thread_local MsmTiming g_last_msm;   // phase times of the calling thread
 int32_t ensure_host_pinned(Ctx* c, size_t bytes);
 
 // msm.hip
-int32_t msm_run(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, const void* d_scalars, size_t n, bool scalars_are_mont, hipStream_t s);
+// job.k scalar vectors ("sets") against prefixes of one pinned set: set q = lens[q] scalars at the DEVICE pointer d_sets[q]
+// (both arrays in host memory); out_jac18 receives k results.  k > 1 needs a table tier serving the longest set and
+// k <= msm_max_sets(pb, longest); msm_batch() groups arbitrary requests accordingly.
+struct MsmJob { const void* const* d_sets = nullptr; const size_t* lens = nullptr; uint32_t k = 0; bool mont = false; };
+int32_t msm_run(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, const MsmJob& job, hipStream_t s);
+inline int32_t msm_run1(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, const void* d_scalars, size_t n, bool mont, hipStream_t s) {
+  MsmJob j; j.d_sets = &d_scalars; j.lens = &n; j.k = 1; j.mont = mont; return msm_run(c, out_jac18, pb, j, s);
+}
+int32_t msm_batch(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, const MsmJob& job, hipStream_t s);
+uint32_t msm_max_sets(const PinnedBases& pb, size_t n);
 int32_t launch_fq_mul(Ctx* c, void* r, const void* a, const void* b, size_t n);
 int32_t launch_fr_mul(Ctx* c, void* r, const void* a, const void* b, size_t n);
 int32_t generate_multiples(Ctx* c, const void* base104, uint64_t first, size_t n, PinnedBases* out);

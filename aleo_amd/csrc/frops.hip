@@ -123,7 +123,7 @@ __global__ void __launch_bounds__(256) k_spmv_long(char* __restrict__ y, const u
 int32_t fr_spmv(Ctx* c, void* d_y, const void* d_row_ptr, const void* d_col, const void* d_vals, const void* d_x, size_t rows, hipStream_t s) {
   if (rows == 0) return ALEO_MI355X_OK;
   if (rows >= (1ull << 32)) { g_last_error = "fr_spmv: row count exceeds 2^32"; return ALEO_MI355X_ERR_BAD_ARG; }
-  int32_t rc; if ((rc = c->ntt_tmp.reserve((rows + 16) * 4))) return rc;
+  int32_t rc; if ((rc = scratch_acquire(c, c->ntt_tmp, (rows + 16) * 4, s))) return rc;
   uint32_t* n_long = c->ntt_tmp.as<uint32_t>(); uint32_t* long_rows = n_long + 16;
   HIPCHK(hipMemsetAsync(n_long, 0, 4, s));
   const size_t want = (rows + 255) / 256; const uint32_t grid = (uint32_t)(want < 16384 ? want : 16384);
@@ -132,17 +132,17 @@ int32_t fr_spmv(Ctx* c, void* d_y, const void* d_row_ptr, const void* d_col, con
   hipLaunchKernelGGL(k_spmv_long, dim3(1024), dim3(256), 0, s, (char*)d_y, (const uint32_t*)d_row_ptr, (const uint32_t*)d_col, (const char*)d_vals,
                      (const char*)d_x, long_rows, n_long);
   HIPCHK(hipGetLastError());
-  return ALEO_MI355X_OK;
+  return scratch_release(c, s);
 }
 
 int32_t fr_batch_inverse(Ctx* c, void* d_inout, size_t n, hipStream_t s) {
   if (n == 0) return ALEO_MI355X_OK;
-  int32_t rc; if ((rc = c->ntt_tmp.reserve(n * 32))) return rc;
+  int32_t rc; if ((rc = scratch_acquire(c, c->ntt_tmp, n * 32, s))) return rc;
   // ~64 elements per lane keeps the shared inversion at ~6 products per element; small inputs use fewer per lane
   size_t T = (n + 63) / 64; if (T < 4096) T = n < 4096 ? n : 4096;
   hipLaunchKernelGGL(k_fr_batch_inverse, dim3((uint32_t)((T + 255) / 256)), dim3(256), 0, s, (char*)d_inout, c->ntt_tmp.as<char>(), n, T);
   HIPCHK(hipGetLastError());
-  return ALEO_MI355X_OK;
+  return scratch_release(c, s);
 }
 
 }  // namespace aleo_mi355x

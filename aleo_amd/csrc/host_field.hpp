@@ -163,4 +163,27 @@ inline void hstore_jacobian_normalized(uint64_t* j18, const HXYZZ& p) {
   std::memcpy(j18, x.l, 48); std::memcpy(j18 + 6, y.l, 48); std::memcpy(j18 + 12, o.l, 48);
 }
 
+// Affine normalisation of `count` results with ONE field inversion (Montgomery's trick over the ZZZ coordinates): the tail
+// of a batched call, where k inversions (~570 products each) would cost more than everything else the host does.
+inline void hstore_jacobian_normalized_batch(uint64_t* j18, const HXYZZ* pts, size_t count) {
+  if (count == 1) { hstore_jacobian_normalized(j18, pts[0]); return; }
+  HFq acc = HFq::one(); HFq pre[64];
+  for (size_t base = 0; base < count; base += 64) {
+    const size_t m = count - base < 64 ? count - base : 64;
+    acc = HFq::one();
+    for (size_t i = 0; i < m; ++i) { pre[i] = acc; if (!pts[base + i].is_inf()) acc = HFq::mul(acc, pts[base + i].ZZZ); }
+    HFq inv = HFq::inv(acc);
+    for (size_t i = m; i-- > 0;) {
+      const HXYZZ& p = pts[base + i]; uint64_t* o = j18 + 18 * (base + i);
+      const HFq one = HFq::one();
+      if (p.is_inf()) { std::memcpy(o, one.l, 48); std::memcpy(o + 6, one.l, 48); std::memset(o + 12, 0, 48); continue; }
+      const HFq zi3 = HFq::mul(inv, pre[i]);                 // 1/ZZZ_i
+      inv = HFq::mul(inv, p.ZZZ);
+      const HFq zi2 = HFq::sqr(HFq::mul(zi3, p.ZZ));         // (ZZ/ZZZ)^2 = 1/ZZ
+      const HFq x = HFq::mul(p.X, zi2), y = HFq::mul(p.Y, zi3);
+      std::memcpy(o, x.l, 48); std::memcpy(o + 6, y.l, 48); std::memcpy(o + 12, one.l, 48);
+    }
+  }
+}
+
 }}  // namespace aleo_mi355x::host

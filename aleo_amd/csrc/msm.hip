@@ -103,20 +103,27 @@ static constexpr uint32_t MAX_COARSE = 2048;      // W * (B >> LB) at c = 16
 
 // PRE = the base set carries precomputed window multiples 2^(c*w) * P_i (fixed-base MSM, see msm_precompute):
 // every window then feeds ONE shared set of buckets, and the point of digit w of scalar i is table entry w*n + i.
+// Batched calls (several scalar vectors against ONE pinned set, msm_run's `k`): blockIdx.y is the vector ("set"); every
+// set owns its own 2^(c-1) buckets, so its coarse bins are [set * CB, (set + 1) * CB) and everything after the sort sees
+// k * 2^(c-1) buckets.  Only the table path batches (PRE), where one set is one window's worth of buckets.
+static constexpr uint32_t MAX_SETS = 32;
+struct SetArgs { const char* ptr[MAX_SETS]; uint32_t n[MAX_SETS]; };          // scalar vector and length of every set (kernel argument)
 template <int C, bool PRE> struct SortGeom {
   static constexpr uint32_t W = (SCALAR_BITS + C - 1) / C, B = 1u << (C - 1);
   static constexpr uint32_t LB = (C - 1) < 8 ? (C - 1) : 8;       // low bucket bits, sorted in level 2
-  static constexpr uint32_t CB = B >> LB, NCB = PRE ? CB : W * CB;
+  static constexpr uint32_t CB = B >> LB, NCB = PRE ? CB : W * CB;      // coarse bins of ONE set
   static_assert(NCB <= MAX_COARSE, "coarse bin table too small");
   __device__ static uint32_t bin(uint32_t w, uint32_t b) { return PRE ? (b >> LB) : w * CB + (b >> LB); }
 };
 
 template <int C, bool MONT, bool PRE>
-__global__ void __launch_bounds__(256) k_part_count(const void* scalars, const uint8_t* inf, uint32_t n, uint32_t nblk, uint32_t* __restrict__ cnt) {
+__global__ void __launch_bounds__(256) k_part_count(SetArgs sets, const uint8_t* inf, uint32_t nblk, uint32_t* __restrict__ cnt) {
   using Gm = SortGeom<C, PRE>;
   __shared__ uint32_t h[MAX_COARSE];
   for (uint32_t i = threadIdx.x; i < Gm::NCB; i += 256) h[i] = 0;
   __syncthreads();
+  const uint32_t n = sets.n[blockIdx.y]; const char* scalars = sets.ptr[blockIdx.y];
+  cnt += (size_t)blockIdx.y * Gm::NCB * nblk;
   const uint32_t base = blockIdx.x * PART_TILE;
   for (uint32_t q = 0; q < PART_TILE / 256; ++q) {
     uint32_t i = base + q * 256 + threadIdx.x;
@@ -171,11 +178,12 @@ __global__ void __launch_bounds__(256) k_scan32_top(const uint32_t* __restrict__
 __device__ __forceinline__ uint32_t scan32_at(const uint32_t* local, const uint32_t* blk, size_t i) { return local[i] + blk[i / SCAN_TILE]; }
 
 template <int C, bool MONT, bool PRE>
-__global__ void __launch_bounds__(256) k_part_scatter(const void* scalars, const uint8_t* inf, uint32_t n, uint32_t nblk, uint32_t row_stride,
+__global__ void __launch_bounds__(256) k_part_scatter(SetArgs sets, const uint8_t* inf, uint32_t nblk, uint32_t row_stride,
                                                       const uint32_t* __restrict__ off_local, const uint32_t* __restrict__ off_blk, uint2* __restrict__ items) {
   using Gm = SortGeom<C, PRE>;
   __shared__ uint32_t cur[MAX_COARSE];
-  for (uint32_t i = threadIdx.x; i < Gm::NCB; i += 256) cur[i] = scan32_at(off_local, off_blk, (size_t)i * nblk + blockIdx.x);
+  const uint32_t n = sets.n[blockIdx.y]; const char* scalars = sets.ptr[blockIdx.y];
+  for (uint32_t i = threadIdx.x; i < Gm::NCB; i += 256) cur[i] = scan32_at(off_local, off_blk, ((size_t)blockIdx.y * Gm::NCB + i) * nblk + blockIdx.x);
   __syncthreads();
   const uint32_t base = blockIdx.x * PART_TILE;
   for (uint32_t q = 0; q < PART_TILE / 256; ++q) {
@@ -591,7 +599,7 @@ static constexpr uint32_t CHUNK_PAIRS = 128;        // chunks per 256-thread blo
 template <bool F28>
 __global__ void __launch_bounds__(256) k_bucket_chunks_pair(const char* __restrict__ partial, const uint32_t* __restrict__ hist, const uint2* __restrict__ scan_local,
                                                        const uint2* __restrict__ scan_blk, uint32_t B, uint32_t S, uint32_t nchunks_total, char* __restrict__ V,
-                                                       char* __restrict__ Vrun) {
+                                                       uint32_t v_set_stride, char* __restrict__ Vrun) {
   constexpr uint32_t PB = PtFmt<F28>::BYTES, PW = PtFmt<F28>::WORDS;
   __shared__ __attribute__((aligned(16))) uint32_t lds[2 * CHUNK_PAIRS * PW];
   const uint32_t pr = threadIdx.x >> 1, t = blockIdx.x * CHUNK_PAIRS + pr;
@@ -605,7 +613,7 @@ __global__ void __launch_bounds__(256) k_bucket_chunks_pair(const char* __restri
     if (hist[g]) { pt_add_pair<F28>(run, partial + (size_t)scan_at(scan_local, scan_blk, g).y * PB, run); pair_fence(); }
     pt_add_pair<F28>(acc, run, acc); pair_fence();
   }
-  pair_copy<PB>(run, Vrun + (size_t)t * PB); pair_copy<PB>(acc, V + (size_t)t * PB);
+  pair_copy<PB>(run, Vrun + (size_t)t * PB); pair_copy<PB>(acc, V + ((size_t)w * v_set_stride + j) * PB);
 }
 
 // One lane QUAD per chunk of S consecutive buckets: running sums run_k = run_{k-1} + S_b (b descending) and acc += run_{k-1}
@@ -618,7 +626,7 @@ static constexpr uint32_t CHUNK_QUADS = 64;         // chunks per 256-thread blo
 template <bool F28>
 __global__ void __launch_bounds__(256) k_bucket_chunks(const char* __restrict__ partial, const uint32_t* __restrict__ hist, const uint2* __restrict__ scan_local,
                                                        const uint2* __restrict__ scan_blk, uint32_t B, uint32_t S, uint32_t nchunks_total, char* __restrict__ V,
-                                                       char* __restrict__ Vrun) {
+                                                       uint32_t v_set_stride, char* __restrict__ Vrun) {
   constexpr uint32_t PB = PtFmt<F28>::BYTES, PW = PtFmt<F28>::WORDS;
   __shared__ __attribute__((aligned(16))) uint32_t lds[(3 * CHUNK_QUADS + 1) * PW];
   const uint32_t qd = threadIdx.x >> 2, sp = (threadIdx.x >> 1) & 1u, t = blockIdx.x * CHUNK_QUADS + qd;
@@ -639,7 +647,7 @@ __global__ void __launch_bounds__(256) k_bucket_chunks(const char* __restrict__ 
     pair_fence();
   }
   // after step S: buf[S & 1] holds run_{S-1} again (step S copied it forward), acc holds sum_k run_k
-  pair_copy<PB>(sp ? acc : ((S & 1) ? buf1 : buf0), (sp ? V : Vrun) + (size_t)t * PB);
+  pair_copy<PB>(sp ? acc : ((S & 1) ? buf1 : buf0), sp ? V + ((size_t)w * v_set_stride + j) * PB : Vrun + (size_t)t * PB);
 }
 
 // Plain path (one window set per window): one lane per chunk, V = sum_{b in chunk} (b+1) * S_b with the chunk base applied
@@ -691,13 +699,16 @@ __global__ void __launch_bounds__(256) k_seg_tree_pass(char* __restrict__ V, uin
 // on the host.
 // (These kernels only run on the table path, whose points are 224-byte 28-bit XYZZ: PB below.)
 static constexpr uint32_t PB28 = 224, PW28 = 56;
-__global__ void __launch_bounds__(256) k_masked_pairs(const char* __restrict__ Vrun, uint32_t lgN, char* __restrict__ T) {
+// Sets (batched calls): set q reads Vrun[q * 2^lgN ...] and writes its lgN sums behind its chunk sums, at
+// V[q * v_set_stride + 2^lgN ...] (v_set_stride = (lgN + 4) * 2^(lgN-2): the set's 4 + lgN segments are contiguous).
+__global__ void __launch_bounds__(256) k_masked_pairs(const char* __restrict__ Vrun, uint32_t lgN, uint32_t nsets, char* __restrict__ V, uint32_t v_set_stride) {
   const uint32_t seg_len = 1u << (lgN - 2);
   const uint32_t op = (blockIdx.x * 256 + threadIdx.x) >> 1;
-  if (op >= seg_len * lgN) return;
-  const uint32_t l = op / seg_len, k = op % seg_len;
+  if (op >= seg_len * lgN * nsets) return;
+  const uint32_t q = op / (seg_len * lgN), r = op % (seg_len * lgN), l = r / seg_len, k = r % seg_len;
   auto ins = [&](uint32_t x) { return ((x >> l) << (l + 1)) | (1u << l) | (x & ((1u << l) - 1u)); };
-  xyzz28_add_pair(Vrun + (size_t)ins(2 * k) * PB28, Vrun + (size_t)ins(2 * k + 1) * PB28, T + (size_t)op * PB28);
+  const char* run = Vrun + ((size_t)q << lgN) * PB28;
+  xyzz28_add_pair(run + (size_t)ins(2 * k) * PB28, run + (size_t)ins(2 * k + 1) * PB28, V + ((size_t)q * v_set_stride + (1u << lgN) + r) * PB28);
 }
 // One block folds up to 256 consecutive points of one segment into a single point: 8 tree levels through two LDS
 // buffers, 128 lane pairs — the latency floor of the chain with no launch gaps.
@@ -751,10 +762,10 @@ __global__ void k_gather_windows(const char* __restrict__ V, uint32_t seg_len, u
 }
 
 // ---- dispatch on the window width ---------------------------------------------------------------
-struct SortArgs { const void* scalars; const uint8_t* inf; uint32_t n, nblk, row_stride; uint32_t* cnt; uint32_t* off_local; uint32_t* off_blk; uint2* items; };
+struct SortArgs { SetArgs sets; uint32_t nsets; const uint8_t* inf; uint32_t nblk, row_stride; uint32_t* cnt; uint32_t* off_local; uint32_t* off_blk; uint2* items; };
 template <int C, bool MONT, bool PRE> static void launch_sort_c(const SortArgs& a, int phase, hipStream_t s) {
-  if (phase == 0) hipLaunchKernelGGL((k_part_count<C, MONT, PRE>), dim3(a.nblk), dim3(256), 0, s, a.scalars, a.inf, a.n, a.nblk, a.cnt);
-  else hipLaunchKernelGGL((k_part_scatter<C, MONT, PRE>), dim3(a.nblk), dim3(256), 0, s, a.scalars, a.inf, a.n, a.nblk, a.row_stride, a.off_local, a.off_blk, a.items);
+  if (phase == 0) hipLaunchKernelGGL((k_part_count<C, MONT, PRE>), dim3(a.nblk, a.nsets), dim3(256), 0, s, a.sets, a.inf, a.nblk, a.cnt);
+  else hipLaunchKernelGGL((k_part_scatter<C, MONT, PRE>), dim3(a.nblk, a.nsets), dim3(256), 0, s, a.sets, a.inf, a.nblk, a.row_stride, a.off_local, a.off_blk, a.items);
 }
 template <bool MONT> static void launch_sort(int c, bool pre, const SortArgs& a, int phase, hipStream_t s) {
   if (pre) {
@@ -774,22 +785,57 @@ template <bool MONT> static void launch_sort(int c, bool pre, const SortArgs& a,
 }
 
 
-int32_t msm_run(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, const void* d_scalars, size_t n, bool scalars_are_mont, hipStream_t s) {
+// Upper bound of the slice count the device will compute (k_scan_tiles / pick_rule), from what the host knows: `pairs_max`
+// (>= the real pair count) and the bucket count M.  Every non-empty bucket is at least one slice; a bucket cut at `split`
+// adds cnt / split more.  pick_rule's split is >= 8 always; it is >= pairs / 2^18 / 1.125 while the fill rule decides and
+// >= the mean bucket size while the mean rule decides, until the 256-point cap takes over.  The grids of the slice kernels
+// and of the accumulation are sized by this bound, so no launch waits for the device's own count to reach the host.
+static size_t slice_bound(size_t pairs_max, size_t M) {
+  const size_t nonempty = M < pairs_max ? M : pairs_max;
+  const size_t by_rule = (M > 294912 ? M : 294912) + pairs_max / 256;
+  const size_t by_min = pairs_max / 8;
+  return nonempty + (by_min < by_rule ? by_min : by_rule) + 1;
+}
+
+// One call = `job.k` independent MSMs ("sets") over prefixes of ONE pinned base set: set q multiplies the first lens[q] bases
+// by the scalars at d_scalars + q * set_stride bytes.  k > 1 needs a fixed-base table tier that serves job.n (the longest
+// set) and k <= msm_max_sets(): the sets then share every launch — one sort over k * 2^(c-1) buckets, one accumulation, one
+// reduction — which is what the commitments of one prover round need (2^14..2^17 points each: alone they are latency-bound).
+uint32_t msm_max_sets(const PinnedBases& pb, size_t n) {
+  for (const auto& t : pb.tab) if (t.d && n >= t.min_n && n <= t.cover) {
+    const uint32_t B = 1u << (t.c - 1), LB = 8, cb = B >> LB, cap = MAX_COARSE / (cb ? cb : 1);
+    return cap < MAX_SETS ? (cap ? cap : 1) : MAX_SETS;
+  }
+  return 1;
+}
+
+int32_t msm_run(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, const MsmJob& job, hipStream_t s) {
   using namespace host;
-  if (n == 0) { hstore_jacobian_normalized(out_jac18, HXYZZ::infinity()); return ALEO_MI355X_OK; }
+  const uint32_t K = job.k;
+  if (K == 0) return ALEO_MI355X_OK;
+  size_t n = 0, pts = 0; SetArgs sets{};
+  if (K > MAX_SETS) { g_last_error = "msm: too many sets in one call"; return ALEO_MI355X_ERR_BAD_ARG; }
+  for (uint32_t q = 0; q < K; ++q) {
+    const size_t l = job.lens[q];
+    if (l >= (1ull << 31)) { g_last_error = "msm: set longer than 2^31"; return ALEO_MI355X_ERR_BAD_ARG; }
+    sets.ptr[q] = (const char*)job.d_sets[q]; sets.n[q] = (uint32_t)l; n = l > n ? l : n; pts += l;
+  }
+  if (n == 0) { for (uint32_t q = 0; q < K; ++q) hstore_jacobian_normalized(out_jac18 + 18 * q, HXYZZ::infinity()); return ALEO_MI355X_OK; }
   if (n > pb.n || n >= (1ull << 31)) { g_last_error = "msm: n exceeds the pinned base count (or 2^31)"; return ALEO_MI355X_ERR_BAD_ARG; }
   // the fixed-base table serves any prefix of the pinned set (row stride = pinned count) as long as the prefix still
   // puts about one point into every bucket; shorter prefixes use the plain path with its small bucket count
   const PinnedBases::PreTable* T = nullptr;
   for (const auto& t : pb.tab) if (t.d && n >= t.min_n && n <= t.cover) { T = &t; break; }
   const bool pre = T != nullptr;
+  if (K > 1 && (!pre || K > msm_max_sets(pb, n))) { g_last_error = "msm: internal: batch without a table tier (or too many sets)"; return ALEO_MI355X_ERR_BAD_ARG; }
   MsmPlan P = make_plan(n, pre ? T->c : 0);
+  if (pre) { P.W = K; P.M = K * P.B; }                       // after the sort a set is "a window with its own buckets"
   const uint32_t digitsW = pre ? (SCALAR_BITS + T->c - 1) / T->c : P.W;
   const uint32_t M = P.M, ntiles = (M + SCAN_TILE - 1) / SCAN_TILE;
-  const size_t pairs_max = n * (size_t)digitsW;
+  const size_t pairs_max = pts * (size_t)digitsW;
   if (pairs_max >= (1ull << 32)) { g_last_error = "msm: n * windows exceeds 2^32 (shard the MSM across GPUs)"; return ALEO_MI355X_ERR_BAD_ARG; }
-  // pick_rule() keeps the slice count near 2^19..2^20 (+ one per bucket) until its 256-point cap takes over
-  const size_t slices_max = pairs_max / 128 + 2 * (size_t)M + (1u << 21);
+  const size_t slices_max = slice_bound(pairs_max, M);
+  const uint32_t slice_blocks = (uint32_t)((slices_max + 255) / 256);
   int32_t rc;
   // hist | heavy list | meta | super list | level-2 cursors live in one zero-initialised allocation
   const size_t hist_words = 3 * (size_t)M + 2048 + SUPER_CAP;
@@ -797,10 +843,10 @@ int32_t msm_run(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, const void* 
   if ((rc = c->scan_local.reserve((size_t)M * 8))) return rc;
   if ((rc = c->scan_blk.reserve(2 * (size_t)ntiles * 8 + 64))) return rc;
   if ((rc = c->sorted.reserve(pairs_max * 4))) return rc;
-  const uint32_t LB = (P.c - 1) < 8 ? (P.c - 1) : 8, ncb = P.W * (P.B >> LB);      // P.W == 1 with a table
+  const uint32_t LB = (P.c - 1) < 8 ? (P.c - 1) : 8, ncb = P.W * (P.B >> LB);      // coarse bins of all sets / windows
   const uint32_t nblk = (uint32_t)((n + PART_TILE - 1) / PART_TILE);
   const size_t cnt_len = (size_t)ncb * nblk;
-  if (cnt_len >= (1ull << 32)) { g_last_error = "msm: partition table too large"; return ALEO_MI355X_ERR_BAD_ARG; }
+  if (ncb > MAX_COARSE || cnt_len >= (1ull << 32)) { g_last_error = "msm: partition table too large"; return ALEO_MI355X_ERR_BAD_ARG; }
   const uint32_t cnt_tiles = (uint32_t)((cnt_len + SCAN_TILE - 1) / SCAN_TILE);
   if ((rc = c->part_cnt.reserve((2 * cnt_len + 2 * (size_t)cnt_tiles + 16 + MAX_COARSE) * 4))) return rc;     // cnt | off_local | tile_tot | off_blk | part_start
   if ((rc = c->part_items.reserve(pairs_max * 8))) return rc;
@@ -810,9 +856,11 @@ int32_t msm_run(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, const void* 
   uint32_t lgN = 0; while ((1u << lgN) < cpw) ++lgN;
   const bool masked = pre && lgN >= 2 && (1u << lgN) == cpw;          // fixed-base path: weights by masked trees
   if (pre && !masked) { g_last_error = "msm: internal: table path without masked reduction"; return ALEO_MI355X_ERR_HIP; }
-  const size_t vwords = masked ? 2 * (size_t)nchunks + (size_t)lgN * (cpw / 4) + (size_t)(lgN + 5) * (1 + (size_t)cpw / 4) : (size_t)nchunks + P.W;
-  if ((rc = c->vbuf.reserve(vwords * 224))) return rc;
-  if ((rc = ensure_host_pinned(c, 64 + (size_t)(P.W + lgN + 5) * 224))) return rc;
+  // table path, per set: [acc of its cpw chunks | lgN masked sums of cpw/4] = (lgN + 4) segments of tseg points
+  const uint32_t tseg = cpw / 4, fseg = lgN + 4, nseg = K * fseg, setw = fseg * tseg;
+  const size_t vpoints = masked ? (size_t)K * setw + nchunks + (nseg + 1) + (size_t)nseg * (tseg / 2 + tseg / 4 + 2) : (size_t)nchunks + P.W;
+  if ((rc = c->vbuf.reserve(vpoints * 224))) return rc;
+  if ((rc = ensure_host_pinned(c, 64 + (size_t)(masked ? nseg : P.W) * 224))) return rc;
 
   uint32_t* hist = c->hist.as<uint32_t>(); uint32_t* heavy = hist + M; uint32_t* meta = heavy + M;     // heavy: <= M bucket ids
   uint32_t* bin_cursor = hist + 2 * (size_t)M + 2048 + SUPER_CAP;
@@ -826,40 +874,51 @@ int32_t msm_run(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, const void* 
   HIPCHK(hipEventRecord(c->ev[0], s));
   HIPCHK(hipMemsetAsync(hist, 0, hist_words * 4, s));
   SortArgs sa;
-  sa.scalars = d_scalars; sa.inf = pb.d_inf; sa.n = (uint32_t)n; sa.nblk = nblk; sa.row_stride = (uint32_t)(pre ? T->cover : pb.n);
+  sa.sets = sets; sa.nsets = K;
+  sa.inf = pb.d_inf; sa.nblk = nblk; sa.row_stride = (uint32_t)(pre ? T->cover : pb.n);
   sa.cnt = c->part_cnt.as<uint32_t>(); sa.off_local = sa.cnt + cnt_len;
   uint32_t* cnt_tile_tot = sa.off_local + cnt_len; sa.off_blk = cnt_tile_tot + cnt_tiles;
   sa.items = c->part_items.as<uint2>();
   const uint32_t* total_pairs = sa.off_blk + cnt_tiles;          // grand total of the level-1 scan
   uint32_t* part_start = sa.off_blk + cnt_tiles + 4;             // ncb + 1 prefix counts of the level-2 parts
   const uint32_t nparts_max = ncb + (uint32_t)(pairs_max / BIN_PART) + 1;
-  if (scalars_are_mont) launch_sort<true>(P.c, pre, sa, 0, s); else launch_sort<false>(P.c, pre, sa, 0, s);
+  if (job.mont) launch_sort<true>(P.c, pre, sa, 0, s); else launch_sort<false>(P.c, pre, sa, 0, s);
   hipLaunchKernelGGL(k_scan32_tiles, dim3(cnt_tiles), dim3(256), 0, s, sa.cnt, (uint32_t)cnt_len, sa.off_local, cnt_tile_tot);
   hipLaunchKernelGGL(k_scan32_top, dim3(1), dim3(256), 0, s, cnt_tile_tot, cnt_tiles, sa.off_blk);
-  if (scalars_are_mont) launch_sort<true>(P.c, pre, sa, 1, s); else launch_sort<false>(P.c, pre, sa, 1, s);
+  if (job.mont) launch_sort<true>(P.c, pre, sa, 1, s); else launch_sort<false>(P.c, pre, sa, 1, s);
   hipLaunchKernelGGL(k_bin_parts, dim3(1), dim3(256), 0, s, sa.off_local, sa.off_blk, nblk, ncb, cnt_tiles, part_start);
   hipLaunchKernelGGL(k_bin_hist, dim3(nparts_max), dim3(256), 0, s, sa.items, sa.off_local, sa.off_blk, nblk, ncb, cnt_tiles, LB, part_start, hist);
   hipLaunchKernelGGL(k_bin_scatter, dim3(nparts_max), dim3(256), 0, s, sa.items, sa.off_local, sa.off_blk, nblk, ncb, cnt_tiles, LB, part_start, hist, bin_cursor, sorted);
   hipLaunchKernelGGL(k_scan_tiles, dim3(ntiles), dim3(256), 0, s, hist, M, total_pairs, scan_local, tile_tot, meta, heavy);
   hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(256), 0, s, tile_tot, ntiles, scan_blk, meta);
-  // slice count / max slices per bucket decide the grid of the accumulation and the number of tree passes
-  uint32_t* h_meta = (uint32_t*)c->h_pinned;
-  HIPCHK(hipMemcpyAsync(h_meta, meta, 32, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(c->ev[1], s));
-  HIPCHK(hipStreamSynchronize(s));
+  // The slice count, the longest bucket and the list lengths size the slice-tree launches.  They come back on the slot's side
+  // stream while the slice kernels and the accumulation — launched with grids from slice_bound() — already run on `s`:
+  // the host reads them long before the accumulation ends, so the GPU never waits for the round trip.
+  uint32_t* h_meta = (uint32_t*)c->h_pinned;
+  HIPCHK(hipStreamWaitEvent(c->side, c->ev[1], 0));
+  HIPCHK(hipMemcpyAsync(h_meta, meta, 32, hipMemcpyDeviceToHost, c->side));
+  HIPCHK(hipEventRecord(c->ev[7], c->side));
+  {
+    uint32_t* len_count = meta + 16; uint32_t* len_cursor = len_count + MAX_SLICE + 1; uint32_t* len_start = len_cursor + MAX_SLICE + 1;   // zeroed with hist/meta
+    hipLaunchKernelGGL(k_slice_count, dim3(slice_blocks), dim3(256), 0, s, hist, scan_local, scan_blk, M, total_pairs, meta, task_g, len_count);
+    hipLaunchKernelGGL(k_len_starts, dim3(1), dim3(256), 0, s, len_count, len_start);
+    hipLaunchKernelGGL(k_slice_order, dim3(slice_blocks), dim3(256), 0, s, hist, scan_local, scan_blk, total_pairs, M, meta, task_g, len_start, len_cursor, order);
+    HIPCHK(hipEventRecord(c->ev[6], s));          // ev[6]..ev[5] bracket k_accum28 alone (bench.py's roofline kernel)
+    if (pre) hipLaunchKernelGGL(k_accum28<true>, dim3(slice_blocks), dim3(256), 0, s, bases, sorted, hist, scan_local, scan_blk, total_pairs, M, meta, order, task_g, partial);
+    else hipLaunchKernelGGL(k_accum28<false>, dim3(slice_blocks), dim3(256), 0, s, bases, sorted, hist, scan_local, scan_blk, total_pairs, M, meta, order, task_g, partial);
+    HIPCHK(hipEventRecord(c->ev[5], s));
+    HIPCHK(hipGetLastError());
+  }
+  HIPCHK(hipEventSynchronize(c->ev[7]));
   const uint32_t NT = h_meta[0], max_m = h_meta[1];
   uint32_t n_heavy = h_meta[3], n_super = h_meta[5] < SUPER_CAP ? h_meta[5] : SUPER_CAP;
   const bool super_overflow = h_meta[5] > SUPER_CAP;          // then the common list also holds very long buckets
-  if (NT > slices_max) { g_last_error = "msm: internal slice count overflow"; return ALEO_MI355X_ERR_HIP; }
+  if (NT > slices_max) {          // cannot happen (slice_bound); the kernels above only touched threads below the bound
+    (void)hipStreamSynchronize(s); g_last_error = "msm: internal slice count overflow"; return ALEO_MI355X_ERR_HIP;
+  }
   if (NT) {
-    uint32_t* len_count = meta + 16; uint32_t* len_cursor = len_count + MAX_SLICE + 1; uint32_t* len_start = len_cursor + MAX_SLICE + 1;   // zeroed with hist/meta
-    hipLaunchKernelGGL(k_slice_count, dim3((NT + 255) / 256), dim3(256), 0, s, hist, scan_local, scan_blk, M, total_pairs, meta, task_g, len_count);
-    hipLaunchKernelGGL(k_len_starts, dim3(1), dim3(256), 0, s, len_count, len_start);
-    hipLaunchKernelGGL(k_slice_order, dim3((NT + 255) / 256), dim3(256), 0, s, hist, scan_local, scan_blk, total_pairs, M, meta, task_g, len_start, len_cursor, order);
-    HIPCHK(hipEventRecord(c->ev[6], s));          // ev[6]..ev[5] bracket k_accum28 alone (bench.py's roofline kernel)
-    if (pre) hipLaunchKernelGGL(k_accum28<true>, dim3((NT + 255) / 256), dim3(256), 0, s, bases, sorted, hist, scan_local, scan_blk, total_pairs, M, meta, order, task_g, partial);
-    else hipLaunchKernelGGL(k_accum28<false>, dim3((NT + 255) / 256), dim3(256), 0, s, bases, sorted, hist, scan_local, scan_blk, total_pairs, M, meta, order, task_g, partial);
-    HIPCHK(hipEventRecord(c->ev[5], s));
     const uint32_t* super_list = heavy + M + 2048;
     for (uint32_t pass = 0, L = max_m; L > 1; ++pass, L = (L + 1) >> 1) {
       const uint32_t Lc = super_overflow ? L : (L < 16u ? L : (16u >> (pass < 4 ? pass : 4)));       // longest bucket of the common list at this level
@@ -905,39 +964,45 @@ int32_t msm_run(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, const void* 
     HXYZZ v; v.X = co[0]; v.Y = co[1]; v.ZZ = co[2]; v.ZZZ = co[3];
     return v;
   };
-  HXYZZ total = HXYZZ::infinity();
   if (masked) {
-    // sum_b (b+1) S_b = sum_j acc_j + S * sum_j j * run_j ; the second sum by lg(N) masked pairwise trees
-    char* T = V + (size_t)nchunks * PB28; char* Vrun = T + (size_t)lgN * (cpw / 4) * PB28; char* Tout = Vrun + (size_t)nchunks * PB28;
+    // per set: sum_b (b+1) S_b = sum_j acc_j + S * sum_j j * run_j ; the second sum by lg(N) masked pairwise trees
+    char* Vrun = V + (size_t)K * setw * PB28; char* Tout = Vrun + (size_t)nchunks * PB28;
     // 2^19 buckets keep the chip busy with one lane pair per chunk; the small bucket sets (<= 2^16) are pure latency and take the quad form
     // (masked => pre: the partial sums are 28-bit points)
-    if (P.c >= 20) hipLaunchKernelGGL(k_bucket_chunks_pair<true>, dim3((nchunks + CHUNK_PAIRS - 1) / CHUNK_PAIRS), dim3(256), 0, s, partial, hist, scan_local, scan_blk, P.B, P.S, nchunks, V, Vrun);
-    else hipLaunchKernelGGL(k_bucket_chunks<true>, dim3((nchunks + CHUNK_QUADS - 1) / CHUNK_QUADS), dim3(256), 0, s, partial, hist, scan_local, scan_blk, P.B, P.S, nchunks, V, Vrun);
-    const uint32_t tseg = cpw / 4, fseg = lgN + 4;      // Vacc viewed as 4 segments of cpw/4, followed by the lgN masked sums
-    hipLaunchKernelGGL(k_masked_pairs, dim3((2 * tseg * lgN + 255) / 256), dim3(256), 0, s, Vrun, lgN, T);
-    // (lgN+4) segment sums: pairwise launches while a level still fills the chip, then ONE block per segment folds the
+    if (P.c >= 20) hipLaunchKernelGGL(k_bucket_chunks_pair<true>, dim3((nchunks + CHUNK_PAIRS - 1) / CHUNK_PAIRS), dim3(256), 0, s, partial, hist, scan_local, scan_blk, P.B, P.S, nchunks, V, setw, Vrun);
+    else hipLaunchKernelGGL(k_bucket_chunks<true>, dim3((nchunks + CHUNK_QUADS - 1) / CHUNK_QUADS), dim3(256), 0, s, partial, hist, scan_local, scan_blk, P.B, P.S, nchunks, V, setw, Vrun);
+    hipLaunchKernelGGL(k_masked_pairs, dim3((2 * tseg * lgN * K + 255) / 256), dim3(256), 0, s, Vrun, lgN, K, V, setw);
+    // K * (lgN+4) segment sums: pairwise launches while a level still fills the chip, then ONE block per segment folds the
     // last 256 points through LDS (8 levels of lane-pair additions: the latency floor of the chain, no launch gaps)
-    char* F1 = Tout + (size_t)(fseg + 1) * PB28; char* F2 = F1 + (size_t)fseg * (tseg / 2) * PB28;
+    char* F1 = Tout + (size_t)(nseg + 1) * PB28; char* F2 = F1 + (size_t)nseg * (tseg / 2 + 1) * PB28;
     const char* cur = V; uint32_t L = tseg, stride = tseg;
     while (L > FOLD) {
       char* dst = (cur == F1) ? F2 : F1; uint32_t half = (L + 1) >> 1;
-      hipLaunchKernelGGL(k_seg_pair_pass, dim3((2 * half * fseg + 255) / 256), dim3(256), 0, s, cur, stride, L, fseg, dst, half);
+      hipLaunchKernelGGL(k_seg_pair_pass, dim3((2 * half * nseg + 255) / 256), dim3(256), 0, s, cur, stride, L, nseg, dst, half);
       cur = dst; stride = half; L = half;
     }
     if (L > 1) {
       char* dst = (cur == F1) ? F2 : F1;
-      hipLaunchKernelGGL(k_seg_fold, dim3(fseg), dim3(256), 0, s, cur, stride, L, fseg, dst, 1u);
+      hipLaunchKernelGGL(k_seg_fold, dim3(nseg), dim3(256), 0, s, cur, stride, L, nseg, dst, 1u);
       cur = dst; stride = 1; L = 1;
     }
-    hipLaunchKernelGGL(k_gather_strided, dim3((fseg * 14 + 255) / 256), dim3(256), 0, s, cur, stride, fseg, Tout);
-    HIPCHK(hipMemcpyAsync(h_win, Tout, (size_t)fseg * PB28, hipMemcpyDeviceToHost, s));
+    hipLaunchKernelGGL(k_gather_strided, dim3((nseg * 14 + 255) / 256), dim3(256), 0, s, cur, stride, nseg, Tout);
+    HIPCHK(hipMemcpyAsync(h_win, Tout, (size_t)nseg * PB28, hipMemcpyDeviceToHost, s));
     HIPCHK(hipEventRecord(c->ev[3], s));
     HIPCHK(hipStreamSynchronize(s));
     HIPCHK(hipGetLastError());
-    for (int l = (int)lgN - 1; l >= 0; --l) { total = hdouble(total); total = hadd(total, lazy_point28(h_win + (size_t)(4 + l) * PB28)); }
-    for (uint32_t sft = P.S; sft > 1; sft >>= 1) total = hdouble(total);
-    for (int q = 0; q < 4; ++q) total = hadd(total, lazy_point28(h_win + (size_t)q * PB28));
+    HXYZZ totals[MAX_SETS];
+    for (uint32_t q = 0; q < K; ++q) {
+      const char* hw = h_win + (size_t)q * fseg * PB28;
+      HXYZZ total = HXYZZ::infinity();
+      for (int l = (int)lgN - 1; l >= 0; --l) { total = hdouble(total); total = hadd(total, lazy_point28(hw + (size_t)(4 + l) * PB28)); }
+      for (uint32_t sft = P.S; sft > 1; sft >>= 1) total = hdouble(total);
+      for (int r = 0; r < 4; ++r) total = hadd(total, lazy_point28(hw + (size_t)r * PB28));
+      totals[q] = total;
+    }
+    hstore_jacobian_normalized_batch(out_jac18, totals, K);          // one shared inversion for the K results
   } else {
+    HXYZZ total = HXYZZ::infinity();
     hipLaunchKernelGGL(k_bucket_chunks_plain, dim3((nchunks + 255) / 256), dim3(256), 0, s, partial, hist, scan_local, scan_blk, P.B, P.S, nchunks, V);
     for (uint32_t L = cpw; L > 1; L = (L + 1) >> 1) {
       uint32_t pairs = (L - ((L + 1) >> 1)) * P.W;
@@ -953,8 +1018,8 @@ int32_t msm_run(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, const void* 
       for (uint32_t d = 0; d < P.c; ++d) total = hdouble(total);
       total = hadd(total, lazy_point(h_win + (size_t)w * 192));
     }
+    hstore_jacobian_normalized(out_jac18, total);
   }
-  hstore_jacobian_normalized(out_jac18, total);
   HIPCHK(hipEventRecord(c->ev[4], s));
   HIPCHK(hipEventSynchronize(c->ev[4]));
   float ms;
@@ -964,8 +1029,37 @@ int32_t msm_run(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, const void* 
   HIPCHK(hipEventElapsedTime(&ms, c->ev[2], c->ev[3])); tm.reduce = ms;
   HIPCHK(hipEventElapsedTime(&ms, c->ev[3], c->ev[4])); tm.host = ms;
   HIPCHK(hipEventElapsedTime(&ms, c->ev[0], c->ev[4])); tm.total = ms;
-  if (NT) { HIPCHK(hipEventElapsedTime(&ms, c->ev[6], c->ev[5])); tm.accum_kernel = ms; }
+  HIPCHK(hipEventElapsedTime(&ms, c->ev[6], c->ev[5])); tm.accum_kernel = ms;
   c->last_msm = tm; g_last_msm = tm;
+  return ALEO_MI355X_OK;
+}
+
+
+// Arbitrary batch: sets are grouped by the table tier their own length selects (longest tier first) and every group goes
+// through msm_run in chunks of msm_max_sets(); sets no tier serves (no table, or fewer than 2^10 points) run one by one.
+int32_t msm_batch(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, const MsmJob& job, hipStream_t s) {
+  const uint32_t K = job.k;
+  auto tier_of = [&](size_t n) { for (int t = 0; t < 3; ++t) if (pb.tab[t].d && n >= pb.tab[t].min_n && n <= pb.tab[t].cover) return t; return -1; };
+  std::vector<uint32_t> todo; todo.reserve(K);
+  for (int t = -1; t < 3; ++t) {
+    todo.clear();
+    for (uint32_t q = 0; q < K; ++q) if (tier_of(job.lens[q]) == t) todo.push_back(q);
+    size_t pos = 0;
+    while (pos < todo.size()) {
+      size_t nmax = 0, take = 0; const void* ptrs[MAX_SETS]; size_t lens[MAX_SETS]; uint64_t res[MAX_SETS * 18];
+      const size_t cap = t < 0 ? 1 : msm_max_sets(pb, job.lens[todo[pos]]);
+      // 2^32 pairs per launch: chunks are also cut by total points
+      size_t pts = 0;
+      while (pos + take < todo.size() && take < cap && (take == 0 || pts + job.lens[todo[pos + take]] <= ((size_t)1 << 26))) {
+        const uint32_t q = todo[pos + take]; ptrs[take] = job.d_sets[q]; lens[take] = job.lens[q]; pts += lens[take]; nmax = lens[take] > nmax ? lens[take] : nmax; ++take;
+      }
+      MsmJob g; g.d_sets = ptrs; g.lens = lens; g.k = (uint32_t)take; g.mont = job.mont;
+      int32_t rc = msm_run(c, res, pb, g, s);
+      if (rc) return rc;
+      for (size_t i = 0; i < take; ++i) std::memcpy(out_jac18 + 18 * (size_t)todo[pos + i], res + 18 * i, 144);
+      pos += take;
+    }
+  }
   return ALEO_MI355X_OK;
 }
 
@@ -1034,18 +1128,17 @@ __global__ void __launch_bounds__(256) k_gen_normalize(char* __restrict__ tmp, u
 
 int32_t generate_multiples(Ctx* c, const void* base104, uint64_t first, size_t n, PinnedBases* out) {
   if (n == 0 || n >= (1ull << 31) || first == 0) { g_last_error = "bases_generate: bad range"; return ALEO_MI355X_ERR_BAD_ARG; }
-  PinnedBases pb; pb.n = n;
-  HIPCHK(hipMalloc(&pb.d_xy, n * 96));
-  void *d_g = nullptr, *d_tmp = nullptr, *d_pre = nullptr;
-  HIPCHK(hipMalloc(&d_g, 96)); HIPCHK(hipMalloc(&d_tmp, n * 192)); HIPCHK(hipMalloc(&d_pre, n * 48));
-  HIPCHK(hipMemcpyAsync(d_g, base104, 96, hipMemcpyHostToDevice, c->stream));
+  DevTmp xy, g, tmp, pre; int32_t rc;           // freed on every return path; xy is handed to the caller at the end
+  if ((rc = xy.alloc(n * 96)) || (rc = g.alloc(96)) || (rc = tmp.alloc(n * 192)) || (rc = pre.alloc(n * 48))) return rc;
+  HIPCHK(hipMemcpyAsync(g.p, base104, 96, hipMemcpyHostToDevice, c->stream));
   uint32_t lanes = (uint32_t)((n + GEN_K - 1) / GEN_K), grid = (lanes + 255) / 256;
-  hipLaunchKernelGGL(k_gen_xyzz, dim3(grid), dim3(256), 0, c->stream, (const char*)d_g, first, (uint32_t)n, (char*)d_tmp);
-  hipLaunchKernelGGL(k_gen_normalize, dim3(grid), dim3(256), 0, c->stream, (char*)d_tmp, (uint32_t)n, (char*)d_pre, (char*)pb.d_xy);
-  HIPCHK(hipStreamSynchronize(c->stream));
+  hipLaunchKernelGGL(k_gen_xyzz, dim3(grid), dim3(256), 0, c->stream, (const char*)g.p, first, (uint32_t)n, (char*)tmp.p);
+  hipLaunchKernelGGL(k_gen_normalize, dim3(grid), dim3(256), 0, c->stream, (char*)tmp.p, (uint32_t)n, (char*)pre.p, (char*)xy.p);
   HIPCHK(hipGetLastError());
-  (void)hipFree(d_g); (void)hipFree(d_tmp); (void)hipFree(d_pre);
-  { int32_t rc28 = make_rows28(c, &pb); if (rc28) return rc28; }
+  HIPCHK(hipStreamSynchronize(c->stream));
+  PinnedBases pb; pb.n = n; pb.d_xy = xy.p;
+  if ((rc = make_rows28(c, &pb))) return rc;    // xy still owned here: freed on failure
+  xy.release();
   *out = pb; return ALEO_MI355X_OK;
 }
 
@@ -1069,33 +1162,34 @@ __global__ void __launch_bounds__(256) k_pre_double(char* __restrict__ cur, uint
 
 int32_t make_rows28(Ctx* c, PinnedBases* pb) {
   if (pb->d_xy28 || pb->n == 0) return ALEO_MI355X_OK;
-  HIPCHK(hipMalloc(&pb->d_xy28, pb->n * 112));
-  hipLaunchKernelGGL(k_rows_to28, dim3((uint32_t)((pb->n + 255) / 256)), dim3(256), 0, c->stream, (const char*)pb->d_xy, (char*)pb->d_xy28, (uint32_t)pb->n);
-  HIPCHK(hipStreamSynchronize(c->stream));
+  DevTmp rows; int32_t rc;
+  if ((rc = rows.alloc(pb->n * 112))) return rc;
+  hipLaunchKernelGGL(k_rows_to28, dim3((uint32_t)((pb->n + 255) / 256)), dim3(256), 0, c->stream, (const char*)pb->d_xy, (char*)rows.p, (uint32_t)pb->n);
   HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(c->stream));
+  pb->d_xy28 = rows.release();
   return ALEO_MI355X_OK;
 }
 
 static int32_t build_table(Ctx* c, const PinnedBases* pb, int pre_c, size_t n, PinnedBases::PreTable* out) {
   const uint32_t W = (SCALAR_BITS + pre_c - 1) / pre_c;
   if (n * (size_t)W >= (1ull << 31)) { g_last_error = "bases_precompute: table index would exceed 31 bits"; return ALEO_MI355X_ERR_BAD_ARG; }
-  void *d_tab = nullptr, *d_cur = nullptr, *d_prefix = nullptr, *d_row = nullptr;
-  HIPCHK(hipMalloc(&d_tab, n * 112 * W));                                    // rows in the accumulation kernel's 28-bit format (fp28.h)
-  HIPCHK(hipMalloc(&d_cur, n * 192)); HIPCHK(hipMalloc(&d_prefix, n * 48)); HIPCHK(hipMalloc(&d_row, n * 96));
+  DevTmp tab, cur, prefix, row; int32_t rc;     // freed on every return path; tab is handed over at the end
+  if ((rc = tab.alloc(n * 112 * W))) return rc;                              // rows in the accumulation kernel's 28-bit format (fp28.h)
+  if ((rc = cur.alloc(n * 192)) || (rc = prefix.alloc(n * 48)) || (rc = row.alloc(n * 96))) return rc;
   hipStream_t s = c->stream;
   const uint32_t g = (uint32_t)((n + 255) / 256), lanes = (uint32_t)((n + GEN_K - 1) / GEN_K), gl = (lanes + 255) / 256;
-  if (pb->d_xy28) HIPCHK(hipMemcpyAsync(d_tab, pb->d_xy28, n * 112, hipMemcpyDeviceToDevice, s));
-  else hipLaunchKernelGGL(k_rows_to28, dim3(g), dim3(256), 0, s, (const char*)pb->d_xy, (char*)d_tab, (uint32_t)n);
-  hipLaunchKernelGGL(k_pre_init, dim3(g), dim3(256), 0, s, (const char*)pb->d_xy, (uint32_t)n, (char*)d_cur);
+  if (pb->d_xy28) HIPCHK(hipMemcpyAsync(tab.p, pb->d_xy28, n * 112, hipMemcpyDeviceToDevice, s));
+  else hipLaunchKernelGGL(k_rows_to28, dim3(g), dim3(256), 0, s, (const char*)pb->d_xy, (char*)tab.p, (uint32_t)n);
+  hipLaunchKernelGGL(k_pre_init, dim3(g), dim3(256), 0, s, (const char*)pb->d_xy, (uint32_t)n, (char*)cur.p);
   for (uint32_t w = 1; w < W; ++w) {
-    hipLaunchKernelGGL(k_pre_double, dim3(g), dim3(256), 0, s, (char*)d_cur, (uint32_t)n, pre_c);
-    hipLaunchKernelGGL(k_gen_normalize, dim3(gl), dim3(256), 0, s, (char*)d_cur, (uint32_t)n, (char*)d_prefix, (char*)d_row);
-    hipLaunchKernelGGL(k_rows_to28, dim3(g), dim3(256), 0, s, (const char*)d_row, (char*)d_tab + (size_t)w * n * 112, (uint32_t)n);
+    hipLaunchKernelGGL(k_pre_double, dim3(g), dim3(256), 0, s, (char*)cur.p, (uint32_t)n, pre_c);
+    hipLaunchKernelGGL(k_gen_normalize, dim3(gl), dim3(256), 0, s, (char*)cur.p, (uint32_t)n, (char*)prefix.p, (char*)row.p);
+    hipLaunchKernelGGL(k_rows_to28, dim3(g), dim3(256), 0, s, (const char*)row.p, (char*)tab.p + (size_t)w * n * 112, (uint32_t)n);
   }
-  HIPCHK(hipStreamSynchronize(s));
   HIPCHK(hipGetLastError());
-  (void)hipFree(d_cur); (void)hipFree(d_prefix); (void)hipFree(d_row);
-  out->d = d_tab; out->c = pre_c; out->cover = n;
+  HIPCHK(hipStreamSynchronize(s));
+  out->d = tab.release(); out->c = pre_c; out->cover = n;
   return ALEO_MI355X_OK;
 }
 
@@ -1105,11 +1199,19 @@ static int32_t build_table(Ctx* c, const PinnedBases* pb, int pre_c, size_t n, P
 // and build time of a 2^20-point set.
 int32_t msm_precompute(Ctx* c, PinnedBases* pb) {
   if (pb->tabled || pb->n == 0) return ALEO_MI355X_OK;
-  const size_t N = pb->n; int32_t rc; int k = 0;
+  const size_t N = pb->n; int32_t rc = ALEO_MI355X_OK; int k = 0;
   auto lim = [&](size_t cap) { return N < cap ? N : cap; };
-  if (N >= (1u << 17)) { if ((rc = build_table(c, pb, N >= (1u << 19) ? 20 : 17, N, &pb->tab[k]))) return rc; pb->tab[k++].min_n = ((size_t)1 << 17) + 1; }      // exactly 2^17 points: the c = 16 tier is faster (0.90 vs 1.18 ms)
-  if (N >= (1u << 15)) { if ((rc = build_table(c, pb, 16, lim((size_t)1 << 17), &pb->tab[k]))) return rc; pb->tab[k++].min_n = (size_t)1 << 15; }
-  if (N >= (1u << 10)) { if ((rc = build_table(c, pb, 13, lim((size_t)1 << 15), &pb->tab[k]))) return rc; pb->tab[k++].min_n = (size_t)1 << 10; }
+  auto tier = [&](int cbits, size_t cover, size_t min_n) {
+    if (rc) return;
+    if ((rc = build_table(c, pb, cbits, cover, &pb->tab[k])) == ALEO_MI355X_OK) pb->tab[k++].min_n = min_n;
+  };
+  if (N >= (1u << 17)) tier(N >= (1u << 19) ? 20 : 17, N, ((size_t)1 << 17) + 1);      // exactly 2^17 points: the c = 16 tier is faster (0.90 vs 1.18 ms)
+  if (N >= (1u << 15)) tier(16, lim((size_t)1 << 17), (size_t)1 << 15);
+  if (N >= (1u << 10)) tier(13, lim((size_t)1 << 15), (size_t)1 << 10);
+  if (rc) {                                     // a later tier failed (out of memory): give back the ones already built
+    for (auto& t : pb->tab) { if (t.d) (void)hipFree(t.d); t = PinnedBases::PreTable(); }
+    return rc;
+  }
   pb->tabled = true;
   return ALEO_MI355X_OK;
 }

@@ -241,14 +241,14 @@ static int32_t build_tables(NttTables* t, uint32_t lg_n, int direction) {
 }
 
 template <uint32_t TE, uint32_t NT>
-static int32_t run_passes(char* buf, char* tmp, uint32_t lg_n, uint32_t batch, const NttTables* t, int pre_coset, int post_coset, int do_scale, FrArg sc, hipStream_t s) {
+static int32_t run_passes(Ctx* c, char* buf, char* tmp, uint32_t lg_n, uint32_t batch, const NttTables* t, int pre_coset, int post_coset, int do_scale, FrArg sc, hipStream_t s) {
   constexpr uint32_t lgTE = TE == 4096 ? 12 : 11;
   constexpr size_t lds_bytes = (size_t)TE * 32;
-  static bool attr_set = false;
-  if (!attr_set && lds_bytes > 65536) {
+  constexpr int attr_bit = TE == 4096 ? 2 : 1;          // the LDS limit is a property of (kernel, device): remembered per device
+  if (lds_bytes > 65536 && !(c->dev->ntt_attr_mask.load() & attr_bit)) {
     HIPCHK(hipFuncSetAttribute((const void*)k_ntt_strided<TE, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     HIPCHK(hipFuncSetAttribute((const void*)k_ntt_final<TE, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    attr_set = true;
+    c->dev->ntt_attr_mask.fetch_or(attr_bit);
   }
   const char* inner = (const char*)t->d_inner; const char* twh = (const char*)t->d_tw_hi; const char* twl = (const char*)t->d_tw_lo;
   const char* csh = (const char*)t->d_cs_hi; const char* csl = (const char*)t->d_cs_lo;
@@ -346,7 +346,7 @@ static int32_t ntt_run_chunk(Ctx* c, void* d_inout, uint32_t lg_n, uint32_t batc
   int32_t rc;
   NttTables* t = nullptr;
   if ((rc = get_tables(c, lg_n, direction, &t))) return rc;
-  if ((rc = c->ntt_tmp.reserve(bytes))) return rc;
+  if ((rc = scratch_acquire(c, c->ntt_tmp, bytes, s))) return rc;      // ordered after the slot's previous asynchronous user
   char* buf = (char*)d_inout; char* tmp = c->ntt_tmp.as<char>();
   const bool in_rev = (order == ALEO_NTT_ORDER_RN || order == ALEO_NTT_ORDER_RR), out_rev = (order == ALEO_NTT_ORDER_NR || order == ALEO_NTT_ORDER_RR);
   const dim3 gperm((uint32_t)((n + 255) / 256), batch);
@@ -359,15 +359,15 @@ static int32_t ntt_run_chunk(Ctx* c, void* d_inout, uint32_t lg_n, uint32_t batc
   FrArg sc; std::memcpy(sc.v, t->scale, 32);
   // 128 KiB tiles: 2^19..2^22 run in two passes (measured 6-16 % faster than three 64 KiB passes); beyond 2^22 three
   // passes are needed either way and two 64 KiB blocks per CU overlap their HBM phases better (2^24: 3.5 vs 4.0 ms)
-  if (lg_n >= 19 && lg_n <= 22) rc = run_passes<4096, 512>(buf, tmp, lg_n, batch, t, pre_coset, post_coset, do_scale, sc, s);
-  else rc = run_passes<2048, 256>(buf, tmp, lg_n, batch, t, pre_coset, post_coset, do_scale, sc, s);
+  if (lg_n >= 19 && lg_n <= 22) rc = run_passes<4096, 512>(c, buf, tmp, lg_n, batch, t, pre_coset, post_coset, do_scale, sc, s);
+  else rc = run_passes<2048, 256>(c, buf, tmp, lg_n, batch, t, pre_coset, post_coset, do_scale, sc, s);
   if (rc) return rc;
   if (out_rev) {
     hipLaunchKernelGGL(k_bitrev_copy, gperm, dim3(256), 0, s, buf, tmp, lg_n);
     HIPCHK(hipMemcpyAsync(buf, tmp, bytes, hipMemcpyDeviceToDevice, s));
   }
   HIPCHK(hipGetLastError());
-  return ALEO_MI355X_OK;
+  return scratch_release(c, s);
 }
 
 }  // namespace aleo_mi355x

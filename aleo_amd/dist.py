@@ -35,6 +35,30 @@ def all_gather_partials(partial: np.ndarray, group=None, device=None) -> np.ndar
     return out.cpu().numpy().view(np.uint64)
 
 
+class PartialGather:
+    """The per-step exchange of the sharded MSM with its buffers allocated once: a 144-byte partial goes from the host tail
+    into a resident device tensor, ONE all-gather (RCCL over xGMI for a device, gloo for host tensors), one read-back."""
+
+    def __init__(self, world: int, device=None, group=None, words: int = 18):
+        import torch
+        self.world, self.group = world, group
+        self.src = torch.zeros(words, dtype=torch.int64, device=device if device is not None else 'cpu')
+        self.dst = torch.zeros((world, words), dtype=torch.int64, device=self.src.device)
+        self.pin = torch.zeros(words, dtype=torch.int64).pin_memory() if device is not None else None
+
+    def __call__(self, partial: np.ndarray) -> np.ndarray:
+        import torch
+        import torch.distributed as dist
+        p = np.ascontiguousarray(partial, dtype=np.uint64).reshape(-1).view(np.int64)
+        k = p.shape[0]
+        if self.pin is not None:
+            self.pin[:k].copy_(torch.from_numpy(p)); self.src[:k].copy_(self.pin[:k], non_blocking=True)
+        else:
+            self.src[:k].copy_(torch.from_numpy(p))
+        dist.all_gather_into_tensor(self.dst.view(-1), self.src, group=self.group)
+        return self.dst.cpu().numpy().view(np.uint64)[:, :k]
+
+
 def sharded_msm(local_msm, combine, partial_for_rank=None, group=None, device=None) -> np.ndarray:
     """local_msm() -> uint64[18] partial of this rank's shard; combine(uint64[G,18]) -> uint64[18].
     The product passes VariableBase.msm over the rank's pinned shard and aleo_amd.g1_sum."""

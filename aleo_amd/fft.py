@@ -56,3 +56,8 @@ class EvaluationDomain:
     def ntt_device(self, d_ptr: int, order=ORDER_NN, direction=FORWARD, type_=STANDARD, stream: int = 0):
         check(lib().aleo_mi355x_ntt_fr_device(ctypes.c_void_p(d_ptr), self.log_size_of_group, order, direction, type_,
                                               ctypes.c_void_p(stream)), 'ntt_fr_device')
+
+    def ntt_batch_device(self, d_ptr: int, batch: int, order=ORDER_NN, direction=FORWARD, type_=STANDARD, stream: int = 0):
+        """`batch` contiguous transforms of this domain's size in one call."""
+        check(lib().aleo_mi355x_ntt_fr_batch_device(ctypes.c_void_p(d_ptr), self.log_size_of_group, batch, order, direction, type_,
+                                                    ctypes.c_void_p(stream)), 'ntt_fr_batch_device')

@@ -31,6 +31,29 @@ class KZG10:
         return out
 
     @staticmethod
+    def commit_batch(powers: PinnedBases, polys) -> np.ndarray:
+        """The commitments of one prover round (host coefficient vectors, Montgomery): one call, shared launches.  uint8[k,104]."""
+        cs = []
+        for c in polys:
+            c = np.ascontiguousarray(c, dtype=np.uint64).reshape(-1, 4); n = c.shape[0]
+            while n and not c[n - 1].any(): n -= 1      # skip leading zeros, as the reference does
+            cs.append((c, n))
+        k = len(cs)
+        ptrs = (ctypes.c_void_p * max(k, 1))(*[c.ctypes.data for c, _ in cs]); ln = (ctypes.c_size_t * max(k, 1))(*[n for _, n in cs])
+        out = np.zeros((k, 104), dtype=np.uint8)
+        check(lib().aleo_mi355x_kzg_commit_batch(_p(out), powers.handle, ptrs, ln, k), 'kzg_commit_batch')
+        return out
+
+    @staticmethod
+    def commit_batch_device(powers: PinnedBases, d_ptrs, lens, stream: int = 0) -> np.ndarray:
+        """Same with the coefficient vectors already in HBM (k device pointers, k lengths)."""
+        k = len(d_ptrs)
+        ptrs = (ctypes.c_void_p * max(k, 1))(*[int(x) for x in d_ptrs]); ln = (ctypes.c_size_t * max(k, 1))(*[int(x) for x in lens])
+        out = np.zeros((k, 104), dtype=np.uint8)
+        check(lib().aleo_mi355x_kzg_commit_batch_device(_p(out), powers.handle, ptrs, ln, k, ctypes.c_void_p(stream)), 'kzg_commit_batch_device')
+        return out
+
+    @staticmethod
     def commit_hiding(powers: PinnedBases, coeffs_mont: np.ndarray, gamma_powers: PinnedBases, blinding_mont: np.ndarray) -> np.ndarray:
         """KZG10::commit with hiding_bound: adds msm(powers_of_beta_times_gamma_g, random polynomial)."""
         c = np.ascontiguousarray(coeffs_mont, dtype=np.uint64).reshape(-1, 4)

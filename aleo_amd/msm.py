@@ -42,6 +42,13 @@ class PinnedBases:
         check(lib().aleo_mi355x_bases_precompute(self.handle), 'bases_precompute')
         return self
 
+    def info(self) -> dict:
+        """Points and HBM footprint of the set: rows, fixed-base tables, window width of every table tier."""
+        buf = (ctypes.c_uint64 * 8)()
+        k = lib().aleo_mi355x_bases_info(self.handle, buf, 8)
+        if k < 7: raise ValueError('unknown bases handle')
+        return {'points': int(buf[0]), 'row_bytes': int(buf[1]), 'table_bytes': int(buf[2]), 'tier_window_bits': [int(buf[3 + i]) for i in range(int(buf[6]))]}
+
     def download(self, offset: int = 0, n: int = None) -> np.ndarray:
         n = self.n - offset if n is None else n
         out = np.zeros((n, 104), dtype=np.uint8)
@@ -81,6 +88,17 @@ class VariableBase:
         out = np.zeros(18, dtype=np.uint64)
         check(lib().aleo_mi355x_msm_g1_device(_p(out), bases.handle, ctypes.c_void_p(d_scalars_ptr), n,
                                               ctypes.c_void_p(stream)), 'msm_g1_device')
+        return out
+
+
+    @staticmethod
+    def msm_batch_device(bases: PinnedBases, d_ptrs, lens, stream: int = 0) -> np.ndarray:
+        """k MSMs against prefixes of one pinned set in one call (the commitments of one prover round): d_ptrs[q] is the device
+        pointer of lens[q] canonical scalars.  Returns uint64[k,18]."""
+        k = len(d_ptrs)
+        ptrs = (ctypes.c_void_p * max(k, 1))(*[int(x) for x in d_ptrs]); ln = (ctypes.c_size_t * max(k, 1))(*[int(x) for x in lens])
+        out = np.zeros((k, 18), dtype=np.uint64)
+        check(lib().aleo_mi355x_msm_g1_batch_device(_p(out), bases.handle, ptrs, ln, k, ctypes.c_void_p(stream)), 'msm_g1_batch_device')
         return out
 
 

@@ -70,10 +70,19 @@ def generator_affine104() -> np.ndarray:
 
 
 def weighted_scalar_sum(scalars: np.ndarray, first_multiple: int = 1) -> int:
-    """sum_i s_i * (first_multiple + i) mod r — the discrete log (base G) of an MSM over bases (first+i)*G."""
-    s = np.asarray(scalars, dtype=np.uint64).reshape(-1, 4)
+    """sum_i s_i * (first_multiple + i) mod r — the discrete log (base G) of an MSM over bases (first+i)*G.
+    Exact integer arithmetic in numpy: 16-bit pieces of the scalars times weights below 2^31, 2^15 terms per dot product."""
+    s = np.ascontiguousarray(np.asarray(scalars, dtype=np.uint64).reshape(-1, 4))
+    n = s.shape[0]
+    if n == 0: return 0
+    if first_multiple + n >= (1 << 31):      # weights too wide for the fast path
+        w = np.arange(first_multiple, first_multiple + n, dtype=object); total = 0
+        for limb in range(4): total += int((s[:, limb].astype(object) * w).sum()) << (64 * limb)
+        return total % FR_MODULUS
+    q = s.view(np.uint16).reshape(n, 16).astype(np.uint64)           # little-endian 16-bit pieces
+    w = np.arange(first_multiple, first_multiple + n, dtype=np.uint64)
     total = 0
-    w = np.arange(first_multiple, first_multiple + s.shape[0], dtype=object)
-    for limb in range(4):
-        total += int((s[:, limb].astype(object) * w).sum()) << (64 * limb)
+    for lo in range(0, n, 1 << 15):                                    # 2^16 * 2^31 * 2^15 = 2^62 < 2^64
+        part = w[lo:lo + (1 << 15)] @ q[lo:lo + (1 << 15)]             # uint64[16], exact
+        total += sum(int(v) << (16 * j) for j, v in enumerate(part))
     return total % FR_MODULUS

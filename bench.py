@@ -1,14 +1,18 @@
 #!/usr/bin/env python3
-"""bench.py — headline benchmark of the MI355X prover backend (BASELINE.json metric, config[1]):
-standalone 2^20-point BLS12-377 G1 Pippenger MSM, scalars and bases resident in HBM, result on the host.
+"""bench.py — headline benchmark of the MI355X prover backend (BASELINE.json metric, configs[1]):
+standalone 2^20-point BLS12-377 G1 Pippenger MSM = one `aleo_mi355x_msm_g1_pinned` call per step — bases resident in
+HBM (the SRS of a proving key is pinned once), the 32 MB of canonical scalars in HOST memory and uploaded inside the timed
+region, result on the host.  The same line carries the variants beside it: scalars already resident, no fixed-base
+table, the table's build time and size.
 
   python bench.py --gpus 1 --steps K --warmup W
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-         bench.py --gpus N --steps K --warmup W
+         bench.py --gpus N --steps K --warmup W [--config 4]
 
-A step = one MSM pass: every rank runs the full Pippenger over its own shard of 2^20 (scalar, base) pairs
-(weak scaling: the shard per GPU is fixed), then the 144-byte partials are all-gathered (RCCL) and added locally
-(SURVEY.md §8e).  value = points processed by all ranks / max-over-ranks wall time.  Prints ONE JSON line on rank 0."""
+A step = one MSM pass: every rank runs the full Pippenger over its own shard of (scalar, base) pairs, then the 144-byte
+partials are all-gathered (RCCL) and added locally.  Default: weak scaling, 2^20 pairs per GPU.
+`--config 4` names BASELINE configs[4] instead: a 2^26-point MSM split over the ranks (2^23 per GPU at N = 8; strong
+scaling).  value = points processed by all ranks / max-over-ranks wall time.  Prints ONE JSON line on rank 0."""
 from __future__ import annotations
 import argparse, json, os, sys, time
 
@@ -22,11 +26,14 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--lg-n', type=int, default=20, help='log2 of the points per GPU (BASELINE config[1]: 20)')
+    ap.add_argument('--config', type=int, default=1, choices=[1, 4],
+                    help='BASELINE configs index: 1 = 2^20 points per GPU (weak scaling); 4 = 2^26 points split over the ranks (strong scaling)')
+    ap.add_argument('--lg-n', type=int, default=None, help='log2 of the points per GPU (default 20; with --config 4: log2 of the TOTAL, default 26)')
     ap.add_argument('--scalars', default='uniform', choices=['uniform', 'witness'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-sample-lg', type=int, default=20)
-    ap.add_argument('--no-precompute', action='store_true', help='skip the fixed-base window table (one-shot MSM path)')
+    ap.add_argument('--no-precompute', action='store_true', help='headline without the fixed-base window table')
+    ap.add_argument('--no-variants', action='store_true', help='skip the resident-scalars / no-table variants')
     ap.add_argument('--no-kzg-chain', action='store_true', help='skip the secondary 2^22 iNTT -> commit measurement (config[2])')
     ap.add_argument('--proof-proxy-lg', type=int, default=20, help='log2 constraints of the Varuna operator-schedule replay (0 = skip)')
     ap.add_argument('--proof-proxy-cpu-lg', type=int, default=15, help='size of the same replay on the CPU oracle (cpu_baseline leg)')
@@ -59,21 +66,32 @@ def main():
     L = aleo_amd.lib()
     aleo_amd._lib.check(L.aleo_mi355x_init(dev_index), 'init')
 
-    n = 1 << args.lg_n
-    first = rank * n + 1
+    strong = args.config == 4
+    if strong:
+        total = 1 << (args.lg_n if args.lg_n is not None else 26)
+        lo, hi = adist.shard_range(total, rank, world)          # rank r owns points [lo, hi) of the one big MSM
+        n, first = hi - lo, lo + 1
+        if n * 13 >= (1 << 32):
+            raise SystemExit('bench --config 4: %d points per GPU exceed one launch (2^32 (bucket, point) pairs); use more ranks or --lg-n' % n)
+    else:
+        lg = args.lg_n if args.lg_n is not None else 20
+        n = 1 << lg; total = n * world; first = rank * n + 1
     gen = synth.generator_affine104()
     pb = aleo_amd.PinnedBases.generate_multiples(gen, first, n)           # P_i = (first + i) * G, generated in HBM
+    precompute_s = None
     if not args.no_precompute:
+        torch.cuda.synchronize(); t0 = time.perf_counter()
         pb.precompute()           # setup, outside the timed region: the SRS of a proving key is fixed (bases_pin contract)
+        precompute_s = time.perf_counter() - t0
+    info = pb.info()
     mk = synth.uniform_scalars if args.scalars == 'uniform' else synth.witness_like_scalars
-    scalars = mk(n, 0xA1E00002 + rank)
-    d_scalars = torch.from_numpy(scalars.view(np.int64)).to(dev)           # resident in HBM before the timed region
-    torch.cuda.synchronize()
+    scalars = mk(n, 0xA1E00002 + rank)                                     # HOST memory (pageable, as a Rust Vec would be)
+    gather = adist.PartialGather(world, gather_dev) if world > 1 else None
 
     def step():
-        part = aleo_amd.VariableBase.msm_device(pb, d_scalars.data_ptr(), n)
+        part = aleo_amd.VariableBase.msm(pb, scalars)                      # aleo_mi355x_msm_g1_pinned: upload + MSM + result on host
         if world > 1:
-            return aleo_amd.g1_sum(adist.all_gather_partials(part, device=gather_dev))
+            return aleo_amd.g1_sum(gather(part))
         return part
 
     def barrier():
@@ -97,15 +115,37 @@ def main():
     # correctness gate: the result must equal k*G with k = sum_i s_i * (first+i) over all ranks (an O(n) identity)
     k = synth.weighted_scalar_sum(scalars, first)
     if world > 1:
-        ks = adist.all_gather_partials(synth.int_to_limbs(k, 4), device=gather_dev)      # 4 limbs per rank, same collective
+        ks = gather(synth.int_to_limbs(k, 4))                                # 4 limbs per rank, same collective
         k = sum(synth.limbs_to_int(row) for row in ks) % synth.FR_MODULUS
     kG = aleo_amd.VariableBase.msm(gen.reshape(1, 104), synth.int_to_limbs(k, 4).reshape(1, 4))
     if not (np.asarray(res) == kG).all():
         raise SystemExit('bench: MSM result does not equal k*G — refusing to report a number for a wrong result')
 
+    # variants of the same MSM, outside the timed region (every rank runs them so the ranks stay in step; rank 0 reports)
+    variants = {}
+    if not args.no_variants:
+        d_scalars = torch.from_numpy(scalars.view(np.int64)).to(dev); torch.cuda.synchronize()
+        reps = max(3, min(args.steps, 10))
+
+        def timed(fn):
+            fn(); torch.cuda.synchronize(); t0 = time.perf_counter()
+            for _ in range(reps): r_ = fn()
+            dt = (time.perf_counter() - t0) / reps
+            if not (np.asarray(r_) == (res if world == 1 else part_ref)).all(): raise SystemExit('bench: a variant disagrees with the headline result')
+            return dt
+        part_ref = aleo_amd.VariableBase.msm(pb, scalars)
+        dt = timed(lambda: aleo_amd.VariableBase.msm_device(pb, d_scalars.data_ptr(), n))
+        variants['value_scalars_resident'] = n / dt; variants['ms_scalars_resident'] = dt * 1e3
+        if not args.no_precompute and n <= (1 << 22):
+            pb2 = aleo_amd.PinnedBases.generate_multiples(gen, first, n)       # the same points, no table: the one-shot path's schedule
+            dt = timed(lambda: aleo_amd.VariableBase.msm(pb2, scalars))
+            variants['value_no_table'] = n / dt; variants['ms_no_table'] = dt * 1e3
+            pb2.close()
+        del d_scalars
+
     if rank == 0:
         ms_step = elapsed / args.steps * 1e3
-        value = world * n * args.steps / elapsed
+        value = total * args.steps / elapsed if strong else world * n * args.steps / elapsed
         ak = float(np.mean(acc_kernel_ms)) * 1e-3
         alg_bytes = 128.0 * n                                  # 32 B scalar + 96 B affine base per point
         achieved = alg_bytes / ak / 1e9
@@ -114,16 +154,22 @@ def main():
         if os.path.exists(tf):
             try: traffic = json.load(open(tf)).get('k_accum_hbm_bytes_per_launch')
             except Exception: traffic = None
+        wl = ('2^%d-point BLS12-377 G1 Pippenger MSM split over %d GPUs (BASELINE configs[4])' % (total.bit_length() - 1, world)) if strong else \
+             ('standalone 2^%d-point BLS12-377 G1 Pippenger MSM (BASELINE configs[1])' % (n.bit_length() - 1))
         out = {
-            'metric': 'MSM G1 scalar-muls/sec (2^%d bases per GPU, BLS12-377, bit-exact)' % args.lg_n,
+            'metric': 'MSM G1 scalar-muls/sec (2^%d bases%s, BLS12-377, bit-exact)' % ((total.bit_length() - 1, ' total') if strong else (n.bit_length() - 1, ' per GPU')),
             'value': value, 'unit': 'scalar-muls/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': ms_step, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'u32',
+            'ms_per_step': ms_step, 'higher_is_better': True, 'scaling': 'strong' if strong else 'weak', 'vs_baseline': None, 'dtype': 'u32',
             'data': 'synthetic',
-            'config': {'workload': 'standalone 2^%d-point BLS12-377 G1 Pippenger MSM (BASELINE configs[1])' % args.lg_n,
-                       'points_per_gpu': n, 'scalars': args.scalars, 'bases': 'P_i=(i+1)G generated in HBM' + ('' if args.no_precompute else '; fixed-base window table (13 x 2^20-bit windows) built at pin time'),
-                       'sharding': 'point-sharded, all-gather of 144-byte partials' if world > 1 else 'single GPU'},
+            'config': {'workload': wl, 'points_per_gpu': n, 'scalar_distribution': args.scalars,
+                       'scalars': 'host memory (pageable), uploaded inside every timed step (SURVEY.md 8d(i)); value_scalars_resident is the variant with scalars already in HBM',
+                       'bases': 'pinned in HBM, P_i=(i+1)G generated on device' + ('' if args.no_precompute else '; fixed-base window tables built at pin time (precompute_s, table_bytes)'),
+                       'entry_point': 'aleo_mi355x_msm_g1_pinned',
+                       'sharding': ('point-sharded, all-gather of 144-byte partials' if world > 1 else 'single GPU')},
+            'precompute_s': precompute_s, 'table_bytes': info['table_bytes'], 'base_row_bytes': info['row_bytes'], 'table_window_bits': info['tier_window_bits'],
+            **variants,
             'roofline': {'bound': 'hbm', 'kernel': 'k_accum28 (bucket accumulation, 28-bit limbs)', 'achieved': achieved, 'peak': 8000.0,
-                         'unit': 'GB/s', 'frac': achieved / 8000.0, 'traffic': traffic,
+                         'unit': 'GB/s', 'frac': achieved / 8000.0, 'traffic': traffic, 'alg_bytes_per_launch': alg_bytes, 'kernel_ms': ak * 1e3,
                          'note': 'integer-VALU bound by construction (SURVEY.md §8d): %d mixed additions x 10 Fq products per point; '
                                  'measured Fq product peak 81 G/s with 28-bit limbs, 61 G/s with 32-bit limbs (tools/ubench/fq28_mul_bench.hip, fq_mul_bench.hip)' % (16 if args.no_precompute else 13)},
             'phases_ms': {kk: float(np.mean([p_[kk] for p_ in phases])) for kk in phases[0]},
@@ -143,11 +189,15 @@ def main():
         print(json.dumps(out), flush=True)
     if world > 1:
         # secondary, outside the timed region and AFTER the MSM line is out: the sharded (4-step) NTT with its one all-to-all.
-        # It must never cost the headline run: an exception is reported on stderr, and a watchdog ends every rank cleanly if
-        # a collective of the probe does not return (its result is then simply missing).
+        # It must never cost the headline run: an exception is reported on stderr.  A watchdog ends a rank whose probe
+        # collective does not return — with a NON-zero status and a line on stderr, so a hang never reads as success.
         import threading
         sys.stdout.flush()
-        dog = threading.Timer(120.0, lambda: os._exit(0)); dog.daemon = True; dog.start()
+
+        def _hung():
+            print(json.dumps({'aux': 'sharded_ntt', 'error': 'timeout: a collective of the probe did not return within 120 s', 'rank': rank}), file=sys.stderr, flush=True)
+            os._exit(3)
+        dog = threading.Timer(120.0, _hung); dog.daemon = True; dog.start()
         try:
             sn = sharded_ntt_probe(aleo_amd, adist, synth, torch, dist, dev, rank, world, args.sharded_ntt_lg) if args.sharded_ntt_lg else {'skipped': 'disabled'}
         except Exception as e:      # noqa: BLE001

@@ -30,7 +30,13 @@
  * polynomials of one round from a rayon pool).  Each call runs on one of the device's slots (own stream and
  * workspaces; ALEO_MI355X_SLOTS = 1..8, default 4), so concurrent calls overlap on the GPU; a pinned set
  * stays alive until the calls using it return, even if another thread unpins it meanwhile.
- * Ownership: the caller owns every buffer; nothing is retained after return except through bases_pin.
+ * Streams: the *_device entry points that return a result to HOST memory (msm, kzg_commit) complete before they return.
+ * Those that only transform device data (ntt_fr*_device, fr_*_device) enqueue on the caller's `stream` and return at once:
+ * the caller orders its own work on that stream, and the library orders its internal scratch between calls by events.
+ * With stream == NULL they run on the serving slot's stream — which the caller cannot order against — and therefore
+ * complete before returning.
+ * Ownership: the caller owns every buffer; nothing is retained after return except through bases_pin (and, when the
+ * caller opts in with ALEO_MI355X_SRS_CACHE=1, the one-shot msm_g1's base-array cache described there).
  * No exceptions cross the boundary.
  */
 #ifndef ALEO_MI355X_H
@@ -66,7 +72,12 @@ extern "C" {
 int32_t aleo_mi355x_init(int32_t device);
 
 /* a1 — VariableBase::msm(bases: &[G1Affine], scalars: &[BigInteger256]) -> G1Projective.
- * Host pointers.  n = min(len(bases), len(scalars)) is the caller's job (the reference zips the slices). */
+ * Host pointers.  n = min(len(bases), len(scalars)) is the caller's job (the reference zips the slices).
+ * By default every call uploads and converts its base array and keeps nothing.  ALEO_MI355X_SRS_CACHE=1 (read once)
+ * opts in to a cache for callers that cannot hold a bases_pin handle: arrays of >= 1024 points stay in HBM keyed by host
+ * pointer + stride and are re-validated on each call by hashing 256 sampled points (32 at the front, the rest spread);
+ * the third use builds the fixed-base table (~0.15 s, inside that call).  Contract when opted in: a base array must not
+ * be rewritten in place (nor its address reused for different points) between calls — unsampled changes are not seen. */
 int32_t aleo_mi355x_msm_g1(void* out_jacobian, const void* bases, size_t base_stride, const void* scalars, size_t n);
 
 /* SRS residency: upload + convert a base set once per proving key (SURVEY.md §5 "device-resident SRS").
@@ -85,6 +96,10 @@ int32_t aleo_mi355x_bases_generate(const void* base_affine104, uint64_t first_mu
  * set (13 instead of 16 additions per point at 2^20) and skip the Horner tail.  Same results, bit for bit after
  * normalisation.  About 0.15 s and 1.8 GB for a 2^20-point set. */
 int32_t aleo_mi355x_bases_precompute(uint64_t handle);
+/* What a pinned set holds in HBM: out[0] points, [1] bytes of the base rows (96-byte snarkVM rows + their 112-byte
+ * 28-bit-limb copies), [2] bytes of the fixed-base tables, [3..5] window width c of each table tier (0 = none), [6] tiers.
+ * Returns the number of values written (<= cap), 0 for an unknown handle. */
+int32_t aleo_mi355x_bases_info(uint64_t handle, uint64_t* out, int32_t cap);
 /* Copies pinned bases [offset, offset+n) back to the host as snarkVM Affine (stride 104). */
 int32_t aleo_mi355x_bases_download(uint64_t handle, size_t offset, size_t n, void* out_affine104);
 /* MSM over the first n pinned bases; scalars: host pointer. */
@@ -109,8 +124,8 @@ int32_t aleo_mi355x_ntt_fr_batch_device(void* d_inout, uint32_t lg_n, size_t bat
  *   mode 0: x[r][c] *= w^((row0 + r) * (col0 + c))   — the twiddle between the two axes of a 4-step transform
  *   mode 1: x[r][c] *= g^((row0 + r) * ld + col0 + c) — the coset shift (g = 22) of a block of the coefficient matrix
  *           (every index must stay below 2^lg_n)
- * direction 1 uses w^-1 / g^-1 (no n^-1: the inverse sub-transforms carry their own scale).  lg_n <= 40 here: the domain
- * may be larger than one GPU's share. */
+ * direction 1 uses w^-1 / g^-1 (no n^-1: the inverse sub-transforms carry their own scale).  lg_n <= 32 here: the domain
+ * may be larger than one GPU's share (exponents are carried in 32 bits). */
 int32_t aleo_mi355x_fr_grid_scale_device(void* d_data, uint32_t lg_n, uint64_t rows, uint64_t cols, uint64_t row0, uint64_t col0, uint64_t ld,
                                          int32_t mode, int32_t direction, void* stream);
 
@@ -120,6 +135,19 @@ int32_t aleo_mi355x_fr_grid_scale_device(void* d_data, uint32_t lg_n, uint64_t r
 int32_t aleo_mi355x_kzg_commit(void* out_affine104, uint64_t handle, const void* coeffs_mont, size_t n);
 /* Device-resident coefficients (e.g. straight out of aleo_mi355x_ntt_fr_device: no host round trip). */
 int32_t aleo_mi355x_kzg_commit_device(void* out_affine104, uint64_t handle, const void* d_coeffs_mont, size_t n, void* stream);
+
+/* The commitments of ONE prover round in one call.  Varuna commits 3*instances+1, then 2, 3 and 1 polynomials per round
+ * (snarkvm-algorithms 0.14.5 snark/varuna/ahp/prover/round_functions [UPSTREAM-RECALL], reached from
+ * /root/reference/rust/src/program/execute.rs:74), each by its own KZG10::commit -> VariableBase::msm from a rayon worker; at real
+ * circuit sizes (2^14..2^17 coefficients) one such MSM is latency-bound on a GPU.  Here k coefficient vectors (k DEVICE
+ * pointers and k lengths, both arrays in host memory) go against prefixes of ONE pinned SRS and share every launch: one sort
+ * over k bucket sets, one accumulation, one reduction (pinned sets with a precomputed table; otherwise the call degrades to
+ * k MSMs).  Results: k rows, in the order given — 144-byte Jacobian for msm_g1_batch_device (canonical scalars), snarkVM Affine
+ * (104 bytes) for the kzg_commit_batch forms (Montgomery coefficients).  Each result is bit-identical to the single-vector call. */
+int32_t aleo_mi355x_msm_g1_batch_device(void* out_jacobian, uint64_t handle, const void* const* d_scalars, const size_t* lens, size_t k, void* stream);
+int32_t aleo_mi355x_kzg_commit_batch_device(void* out_affine104, uint64_t handle, const void* const* d_coeffs_mont, const size_t* lens, size_t k, void* stream);
+/* Same with the k coefficient vectors in host memory (k host pointers). */
+int32_t aleo_mi355x_kzg_commit_batch(void* out_affine104, uint64_t handle, const void* const* coeffs_mont, const size_t* lens, size_t k);
 
 /* KZG10::commit with a hiding bound: msm(powers, coeffs) + msm(gamma_powers, blinding_coeffs), affine result.
  * Both coefficient vectors are Montgomery Fr on the host; both base sets are pinned handles. */

@@ -289,9 +289,23 @@ def test_msm_fixed_base_table_path():
         assert c.jac_to_int_point(M.VariableBase.msm(pb, S)) == exp
 
 
-def test_one_shot_msm_srs_cache_and_prefixes():
-    """aleo_mi355x_msm_g1 keeps a base array resident between calls (pointer + sampled-content key), serves prefixes of
-    it, switches to the fixed-base table on the third use, and notices when the array's contents change."""
+def test_one_shot_msm_keeps_nothing_by_default():
+    """Ownership rule of the boundary: without the opt-in the one-shot call retains nothing, so a base array
+    rewritten in place at ANY index between calls is seen."""
+    n = 1 << 12
+    B = util.multiples_bases(n); S = util.uniform_scalars(n, 778)
+    os.environ.pop('ALEO_MI355X_SRS_CACHE', None)
+    for _ in range(3):
+        assert c.jac_to_int_point(M.VariableBase.msm(B, S)) == util.expected_multiples_msm(S, n)
+    B[2001] = B[10]                                      # an index the opt-in cache does not sample
+    k = (synth.weighted_scalar_sum(S, 1) + (11 - 2002) * synth.limbs_to_int(S[2001])) % p.FR_MODULUS
+    assert c.jac_to_int_point(M.VariableBase.msm(B, S)) == p.g1_mul(p.G1_GENERATOR, k)
+
+
+def test_one_shot_msm_srs_cache_and_prefixes(monkeypatch):
+    """With ALEO_MI355X_SRS_CACHE=1 aleo_mi355x_msm_g1 keeps a base array resident between calls (pointer + sampled-content
+    key), serves prefixes of it, switches to the fixed-base table on the third use, and notices when sampled contents change."""
+    monkeypatch.setenv('ALEO_MI355X_SRS_CACHE', '1')
     n = 1 << 17
     B = util.multiples_bases(n)
     S = util.uniform_scalars(n, 777)
@@ -579,3 +593,67 @@ def test_table_path_repeated_opposite_and_infinity_bases():
     with M.PinnedBases(B2) as pb:
         pb.precompute()
         assert c.jac_to_int_point(M.VariableBase.msm(pb, S2)) is None
+
+
+# ---- batched commitments: one call for the polynomials of a prover round ------------------------------------------------
+@pytest.mark.parametrize('k', [1, 3, 4, 12])
+def test_batched_commit_matches_oracle_per_polynomial(k):
+    """k coefficient vectors against one pinned SRS in ONE call (shared sort / accumulation / reduction, k bucket sets):
+    every row must equal the oracle's KZG10::commit of that polynomial, and the single-vector call, bit for bit."""
+    import torch
+    n = 1 << 12
+    with M.PinnedBases.generate_multiples(synth.generator_affine104(), 1, n) as pb:
+        pb.precompute()
+        B = pb.download()
+        polys = [c.fr_to_mont(util.uniform_scalars(n, 12000 + 17 * k + j)) for j in range(k)]
+        if k >= 3:
+            polys[1] = c.fr_to_mont(util.witness_like_scalars(n, 12500 + k))          # sparse: 60 % zero coefficients
+            polys[2] = polys[2][: n - 1234]                                             # ragged: lower degree
+        exp = [c.kzg_commit(B[: len(f)], f, threads=8) for f in polys]
+        got = aleo_amd.KZG10.commit_batch(pb, polys)
+        for j in range(k):
+            assert (got[j] == exp[j]).all(), j
+            assert (aleo_amd.KZG10.commit(pb, polys[j]) == exp[j]).all(), j
+        d = [torch.from_numpy(f.view(np.int64).copy()).cuda() for f in polys]; torch.cuda.synchronize()
+        got_d = aleo_amd.KZG10.commit_batch_device(pb, [t.data_ptr() for t in d], [len(f) for f in polys])
+        assert (got_d == got).all()
+
+
+def test_batched_msm_mixed_tiers_and_degenerate_sets():
+    """One batched call whose vectors select different table tiers (c = 13 / 16 / 17), a vector too short for any tier
+    (plain path), an empty one, an all-zero one and an all-equal one; more vectors than one launch can hold (chunking).
+    Bases (i+1)G: every result against the O(n) structured identity."""
+    import torch
+    N = 1 << 18
+    with M.PinnedBases.generate_multiples(synth.generator_affine104(), 1, N) as pb:
+        pb.precompute()
+        lens = [1 << 14, 300, 0, (1 << 15) + 77, 1 << 17, (1 << 17) + 5, 5000, N, 1 << 10, 40000] + [3000 + 11 * i for i in range(40)]
+        S = [util.uniform_scalars(max(m, 1), 13000 + i)[:m] for i, m in enumerate(lens)]
+        S[6] = np.zeros((lens[6], 4), dtype=np.uint64)
+        S[8] = np.tile(util.uniform_scalars(1, 13999), (lens[8], 1))
+        S[9] = util.witness_like_scalars(lens[9], 13998)
+        d = [torch.from_numpy(np.ascontiguousarray(x).view(np.int64).copy()).cuda() if len(x) else torch.zeros((1, 4), dtype=torch.int64, device='cuda') for x in S]
+        torch.cuda.synchronize()
+        got = M.VariableBase.msm_batch_device(pb, [t.data_ptr() for t in d], lens)
+        for i, m in enumerate(lens):
+            exp = util.expected_multiples_msm(S[i], m) if m else None
+            assert c.jac_to_int_point(got[i]) == exp, (i, m)
+            if i < 10 and m: assert (M.VariableBase.msm_device(pb, d[i].data_ptr(), m) == got[i]).all(), (i, m)
+    # no table: the batch degrades to one MSM per vector
+    with M.PinnedBases.generate_multiples(synth.generator_affine104(), 1, 5000) as pb:
+        lens = [5000, 1234, 1]
+        S = [util.uniform_scalars(m, 13100 + i) for i, m in enumerate(lens)]
+        d = [torch.from_numpy(x.view(np.int64).copy()).cuda() for x in S]; torch.cuda.synchronize()
+        got = M.VariableBase.msm_batch_device(pb, [t.data_ptr() for t in d], lens)
+        for i, m in enumerate(lens): assert c.jac_to_int_point(got[i]) == util.expected_multiples_msm(S[i], m)
+
+
+def test_async_device_calls_order_their_scratch_across_streams(tmp_path):
+    """The *_device transforms enqueue on the caller's stream and return at once; with ONE slot (ALEO_MI355X_SLOTS=1) two
+    threads on two streams keep handing the same scratch buffer to each other while the previous user's kernels are still
+    in flight.  Batched 2^20-element NTTs, batch inversions and an NTT -> commit chain with stream == NULL, all against the
+    oracle (tools/scratch_race_check.py, run in a child process because the slot count is read once at init)."""
+    import subprocess, sys
+    env = dict(os.environ, ALEO_MI355X_SLOTS='1')
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(G), '..', 'tools', 'scratch_race_check.py')], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0 and 'SCRATCH OK' in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
