@@ -16,6 +16,8 @@ EXPORTS = [
     'aleo_mi355x_fr_vec_op_device', 'aleo_mi355x_fr_batch_inverse_device', 'aleo_mi355x_fr_spmv_device', 'aleo_mi355x_fq_mul',
     'aleo_mi355x_fr_mul', 'aleo_mi355x_selftest_madd28', 'aleo_mi355x_last_msm_timing', 'aleo_mi355x_strerror', 'aleo_mi355x_last_error',
     'aleo_mi355x_version',
+    'aleo_mi355x_g1_compress', 'aleo_mi355x_g1_decompress', 'aleo_mi355x_fr_to_bytes', 'aleo_mi355x_fr_from_bytes',
+    'aleo_mi355x_bech32m_encode', 'aleo_mi355x_bech32m_decode', 'aleo_mi355x_proof_to_bytes',
 ]
 
 
@@ -74,6 +76,13 @@ def lib():
         'aleo_mi355x_strerror': ([i32], ctypes.c_char_p),
         'aleo_mi355x_last_error': ([], ctypes.c_char_p),
         'aleo_mi355x_version': ([], ctypes.c_char_p),
+        'aleo_mi355x_g1_compress': ([vp, vp, sz], i32),
+        'aleo_mi355x_g1_decompress': ([vp, vp, sz, i32], i32),
+        'aleo_mi355x_fr_to_bytes': ([vp, vp, sz], i32),
+        'aleo_mi355x_fr_from_bytes': ([vp, vp, sz], i32),
+        'aleo_mi355x_bech32m_encode': ([ctypes.c_char_p, sz, ctypes.c_char_p, vp, sz], i32),
+        'aleo_mi355x_bech32m_decode': ([vp, ctypes.POINTER(sz), ctypes.c_char_p, sz, ctypes.c_char_p], i32),
+        'aleo_mi355x_proof_to_bytes': ([vp, ctypes.POINTER(sz), vp], i32),
     }
     for name, (args, res) in sig.items():
         f = getattr(L, name); f.argtypes = args; f.restype = res

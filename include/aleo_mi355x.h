@@ -167,6 +167,37 @@ int32_t aleo_mi355x_fr_batch_inverse_device(void* d_inout, size_t n, void* strea
  * [UPSTREAM-RECALL: snark/varuna/ahp/prover/round_functions/first.rs].  Empty rows give 0. */
 int32_t aleo_mi355x_fr_spmv_device(void* d_y, const void* d_row_ptr, const void* d_col_idx, const void* d_vals, const void* d_x, size_t rows, void* stream);
 
+/* ---- wire formats of the results (host code, no GPU needed) -------------------------------------------
+ * What snarkVM does when a commitment / proof leaves the prover [UPSTREAM-RECALL: utilities/src/serialize, curves/.../affine.rs
+ * CanonicalSerialize, synthesizer/snark Proof::to_bytes_le + bech32m Display]; pinned byte for byte by the `proof1...` string the
+ * reference's own test holds (/root/reference/wasm/src/programs/transaction.rs:100, round-tripped at :104-120).
+ * Compressed G1: 48 bytes little-endian canonical x; last byte bit 7 = y is the lexicographically larger root, bit 6 = infinity.
+ * decompress rejects non-canonical x, x off the curve and (check_subgroup != 0) points outside the prime-order subgroup. */
+int32_t aleo_mi355x_g1_compress(void* out48, const void* affine104, size_t n);
+int32_t aleo_mi355x_g1_decompress(void* out_affine104, const void* in48, size_t n, int32_t check_subgroup);
+/* Fr <-> 32 canonical little-endian bytes (Fr::to_bytes_le / from_bytes_le); from_bytes rejects values >= r. */
+int32_t aleo_mi355x_fr_to_bytes(void* out32, const void* fr_mont, size_t n);
+int32_t aleo_mi355x_fr_from_bytes(void* out_fr_mont, const void* in32, size_t n);
+/* bech32m (BIP-350) strings: "proof1...", and every other Aleo object id.  encode writes a NUL-terminated string;
+ * decode: *len in = capacity of out, out = payload bytes; hrp_out may be NULL. */
+int32_t aleo_mi355x_bech32m_encode(char* out, size_t cap, const char* hrp, const void* data, size_t len);
+int32_t aleo_mi355x_bech32m_decode(void* out, size_t* len, char* hrp_out, size_t hrp_cap, const char* s);
+/* The byte layout of a Varuna proof (Proof::to_bytes_le) from its parts; points as snarkVM Affine (104 bytes), field elements
+ * Montgomery Fr.  Field order read off the reference's own proof (one circuit, one instance); for several circuits the order
+ * of g_a/g_b/g_c and of the evaluations is [UPSTREAM-RECALL].  *len: in = capacity of out, out = bytes written. */
+typedef struct {
+  const uint64_t* batch_sizes; size_t n_circuits;      /* instances per circuit */
+  const void* witness_commitments;                      /* 3 per instance: w, z_a, z_b */
+  const void* mask_poly;                                /* NULL = None (non-hiding) */
+  const void* g_1; const void* h_1;
+  const void* g_abc;                                    /* 3 per circuit: g_a, g_b, g_c */
+  const void* h_2;
+  const void* evaluations; size_t n_evaluations;        /* z_b per instance, g_1, then g_a, g_b, g_c per circuit */
+  const void* sums;                                     /* 3 per circuit (third-round sums) */
+  const void* opening_points; const void* opening_random_v; const uint8_t* opening_has_v; size_t n_openings;   /* KZG10 proofs: w, Option<random_v> */
+} aleo_mi355x_proof_parts;
+int32_t aleo_mi355x_proof_to_bytes(void* out, size_t* len, const aleo_mi355x_proof_parts* parts);
+
 /* Element-wise field products on the device (host pointers): r[i] = a[i]*b[i], Montgomery form, canonical
  * output.  Used by the parity tests to pin the device arithmetic against the oracle limb for limb; when a and b
  * are the same buffer the dedicated squaring block runs instead of the general product. */

@@ -168,6 +168,33 @@ def fq_sqrt(a: int):
     return x
 
 
+def fr_sqrt(a: int):
+    """Tonelli-Shanks over Fr (two-adicity 47); None for a non-residue."""
+    r = FR_MODULUS; a %= r
+    if a == 0: return 0
+    if pow(a, (r - 1) // 2, r) != 1: return None
+    s, t = FR_TWO_ADICITY, (r - 1) >> FR_TWO_ADICITY
+    c = FR_TWO_ADIC_ROOT; x = pow(a, (t + 1) // 2, r); b = pow(a, t, r); m = s
+    while b != 1:
+        i, b2 = 0, b
+        while b2 != 1: b2 = b2 * b2 % r; i += 1
+        e = pow(c, 1 << (m - i - 1), r)
+        x = x * e % r; c = e * e % r; b = b * c % r; m = i
+    return x
+
+
+def bech32m_encode(hrp: str, data: bytes) -> str:
+    acc = bits = 0; d = []
+    for byte in data:
+        acc = (acc << 8) | byte; bits += 8
+        while bits >= 5: bits -= 5; d.append((acc >> bits) & 31)
+    if bits: d.append((acc << (5 - bits)) & 31)
+    exp = [ord(c) >> 5 for c in hrp] + [0] + [ord(c) & 31 for c in hrp]
+    pm = _polymod(exp + d + [0] * 6) ^ 0x2BC830A3
+    d += [(pm >> (5 * (5 - i))) & 31 for i in range(6)]
+    return hrp + '1' + ''.join(_B32[v] for v in d)
+
+
 def g1_decompress(buf: bytes):
     assert len(buf) == 48
     flags = buf[47]

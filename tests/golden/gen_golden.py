@@ -4,6 +4,9 @@
   reference_proof.json  DATA held by the reference's own test (the `proof1…` string inside TRANSACTION_STRING at
                         /root/reference/wasm/src/programs/transaction.rs:100), plus its decoding by oracle/pyref.py:
                         the ten KZG commitments (compressed G1) and the field evaluations.  Needs /root/reference.
+  reference_literals.json  other DATA the reference's tests hold: the `...group` / `...field` decimal literals and the bech32m strings
+                        (aleo1 addresses, at1 / as1 / ar1 ids, record1 ciphertexts) in transaction.rs:100, rust/src/test_utils/mod.rs:
+                        132-142 and wasm/tests/offchain.rs:106, with their decoding (Edwards-BLS12 y for every group x).  Needs /root/reference.
   msm_small.json        Python big-integer MSM known answers (oracle/pyref.py msm_naive: double-and-add, no windows).
   ntt_small.json        O(n^2) DFT known answers for fft / ifft / coset_fft / coset_ifft.
 
@@ -32,7 +35,56 @@ def gen_reference_proof():
         out['commitments'][name] = {'offset': off, 'compressed': raw[off:off + 48].hex(), 'x': hex(pt[0]), 'y': hex(pt[1])}
     for name, (off, cnt) in EVAL_RANGES.items():
         out['field_elements'][name] = [hex(int.from_bytes(raw[off + 32 * i: off + 32 * i + 32], 'little')) for i in range(cnt)]
+    # the two KZG10 opening proofs: [762] u64 = 2; 770: w, tag 1, random_v; 851: w, tag 0; [900] = 0
+    assert int.from_bytes(raw[762:770], 'little') == 2 and raw[818] == 1 and raw[899] == 0 and raw[900] == 0
+    out['openings'] = []
+    for off, has_v in ((770, True), (851, False)):
+        pt = p.g1_decompress(raw[off:off + 48])
+        o = {'offset': off, 'compressed': raw[off:off + 48].hex(), 'x': hex(pt[0]), 'y': hex(pt[1])}
+        if has_v: o['random_v'] = hex(int.from_bytes(raw[off + 49:off + 81], 'little'))
+        out['openings'].append(o)
+    out['layout'] = {'version': raw[0], 'batch_sizes': [int.from_bytes(raw[9:17], 'little')], 'mask_poly_tag': raw[161],
+                     'sums_len': int.from_bytes(raw[658:666], 'little'), 'openings_len': 2, 'trailer': raw[900]}
     json.dump(out, open(os.path.join(HERE, 'reference_proof.json'), 'w'), indent=1)
+
+
+ED_D = 3021          # Edwards-BLS12: -x^2 + y^2 = 1 + 3021 x^2 y^2 over Fr (snarkvm-curves edwards_bls12 [UPSTREAM-RECALL])
+
+
+def edwards_y(x):
+    """A y with (x, y) on the curve, or None: y^2 = (1 + x^2) / (1 - d x^2)."""
+    r = p.FR_MODULUS
+    den = (1 - ED_D * x * x) % r
+    if den == 0: return None
+    return p.fr_sqrt((1 + x * x) * pow(den, -1, r) % r)
+
+
+def gen_reference_literals():
+    files = {'wasm/src/programs/transaction.rs': None, 'rust/src/test_utils/mod.rs': None, 'wasm/tests/offchain.rs': None}
+    if not os.path.exists('/root/reference'):
+        print('skip reference_literals.json (no /root/reference)'); return
+    out = {'groups': [], 'fields': [], 'bech32m': []}
+    seen = set()
+    for rel in files:
+        for ln, line in enumerate(open(os.path.join('/root/reference', rel)).read().split('\n'), 1):
+            for m in re.finditer(r'(\d{20,})(group|field)', line):
+                v, kind = int(m.group(1)), m.group(2)
+                if (v, kind) in seen: continue
+                seen.add((v, kind))
+                if kind == 'group':
+                    y = edwards_y(v)
+                    out['groups'].append({'source': '%s:%d' % (rel, ln), 'x': str(v), 'y': None if y is None else hex(y)})
+                else:
+                    out['fields'].append({'source': '%s:%d' % (rel, ln), 'value': str(v)})
+            for m in re.finditer(r'\b(aleo|at|as|ar|record)1[0-9a-z]{20,}', line):
+                sv = m.group(0)
+                if sv in seen: continue
+                seen.add(sv)
+                hrp, raw = p.bech32m_decode(sv)
+                e = {'source': '%s:%d' % (rel, ln), 'string': sv, 'hrp': hrp, 'payload': raw.hex()}
+                if hrp in ('aleo', 'at', 'as', 'ar'): e['value'] = str(int.from_bytes(raw, 'little'))
+                out['bech32m'].append(e)
+    json.dump(out, open(os.path.join(HERE, 'reference_literals.json'), 'w'), indent=1)
 
 
 def gen_msm():
@@ -83,5 +135,5 @@ def gen_ntt():
 
 
 if __name__ == '__main__':
-    gen_reference_proof(); gen_msm(); gen_ntt()
+    gen_reference_proof(); gen_reference_literals(); gen_msm(); gen_ntt()
     print('golden fixtures written to', HERE)

@@ -657,3 +657,104 @@ def test_async_device_calls_order_their_scratch_across_streams(tmp_path):
     env = dict(os.environ, ALEO_MI355X_SLOTS='1')
     r = subprocess.run([sys.executable, os.path.join(os.path.dirname(G), '..', 'tools', 'scratch_race_check.py')], capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0 and 'SCRATCH OK' in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+# ---- reference-held data through the HIP path ------------------------------------------------------------------------------
+def _reference_g1_points():
+    """The twelve G1 points of the reference's own proof string (wasm/src/programs/transaction.rs:100): ten commitments and
+    two KZG opening witnesses, decompressed by the PRODUCT's wire code from the fixture bytes."""
+    from aleo_amd import wire
+    fx = json.load(open(os.path.join(G, 'reference_proof.json')))
+    comp = [bytes.fromhex(v['compressed']) for v in fx['commitments'].values()] + [bytes.fromhex(o['compressed']) for o in fx['openings']]
+    ints = [(int(v['x'], 16), int(v['y'], 16)) for v in fx['commitments'].values()] + [(int(o['x'], 16), int(o['y'], 16)) for o in fx['openings']]
+    aff = wire.g1_decompress(np.stack([np.frombuffer(b, dtype=np.uint8) for b in comp]))
+    assert c.affine_to_ints(aff) == ints
+    return aff, ints, comp
+
+
+def test_reference_points_as_msm_bases():
+    """MSMs whose BASES are the reference-held points (not multiples of the generator the oracle made up): (r-1) P == -P,
+    single-scalar products against big-integer double-and-add, a 12-point MSM against the oracle, and a 4800-point MSM over
+    repeated reference points against sum_j (sum of its scalars) * P_j — plain path and fixed-base table path."""
+    from aleo_amd import wire
+    aff, ints, comp = _reference_g1_points()
+    rm1 = c.ints_to_limbs([p.FR_MODULUS - 1], 4)
+    for j in range(12):
+        got = c.jac_to_int_point(M.VariableBase.msm(aff[j:j + 1], rm1))
+        assert got == p.g1_neg(ints[j]), j
+    S = util.uniform_scalars(12, 777001)
+    sv = c.limbs_to_ints(S)
+    for j in (0, 5, 11):
+        assert c.jac_to_int_point(M.VariableBase.msm(aff[j:j + 1], S[j:j + 1])) == p.g1_mul(ints[j], sv[j])
+    exp12 = None
+    for j in range(12): exp12 = p.g1_add(exp12, p.g1_mul(ints[j], sv[j]))
+    assert c.jac_to_int_point(M.VariableBase.msm(aff, S)) == exp12
+    assert c.jac_to_int_point(c.msm_g1(aff, S, threads=4, variant=1)) == exp12
+    n = 4800
+    B = np.tile(aff, (n // 12, 1)); S = util.uniform_scalars(n, 777002); S[7::97] = 0; S[11::101, 1:] = 0
+    sv = c.limbs_to_ints(S)
+    exp = None
+    for j in range(12): exp = p.g1_add(exp, p.g1_mul(ints[j], sum(sv[j::12]) % p.FR_MODULUS))
+    assert c.jac_to_int_point(c.msm_g1(B, S, threads=8, variant=1)) == exp
+    with M.PinnedBases(B) as pb:
+        plain = M.VariableBase.msm(pb, S)
+        assert c.jac_to_int_point(plain) == exp
+        pb.precompute()                                                           # tables of 2^(13 w) * P for the reference points
+        assert (M.VariableBase.msm(pb, S) == plain).all()
+        # KZG10::commit shape over these bases, result through the product's compressed serialisation and back
+        coeffs = c.fr_to_mont(S)
+        cm = aleo_amd.KZG10.commit(pb, coeffs)
+        assert c.affine_to_ints(cm.reshape(1, 104))[0] == exp
+        cc = wire.g1_compress(cm.reshape(1, 104))
+        assert cc.tobytes() == p.g1_compress(exp)
+        assert (wire.g1_decompress(cc) == cm.reshape(1, 104)).all()
+        # batched: three polynomials over the same reference-point SRS
+        polys = [coeffs, c.fr_to_mont(util.uniform_scalars(n, 777003)), coeffs[:2000]]
+        got = aleo_amd.KZG10.commit_batch(pb, polys)
+        for q, f in enumerate(polys): assert (got[q] == c.kzg_commit(B[: len(f)], f, threads=8)).all(), q
+
+
+def test_reference_field_elements_through_the_device_arithmetic():
+    """The eight Fr values and random_v of the reference's proof, its `…field` / `…group` literals: products and batch inversion
+    on the device against big integers (Montgomery form in and out)."""
+    import torch
+    from aleo_amd import poly
+    fx = json.load(open(os.path.join(G, 'reference_proof.json'))); lit = json.load(open(os.path.join(G, 'reference_literals.json')))
+    vals = [int(v, 16) for v in fx['field_elements']['evaluations'] + fx['field_elements']['sums']] + [int(fx['openings'][0]['random_v'], 16)]
+    vals += [int(f['value']) for f in lit['fields']] + [int(g['x']) for g in lit['groups']]
+    r = p.FR_MODULUS
+    a = c.fr_to_mont(c.ints_to_limbs(vals, 4)); b = c.fr_to_mont(c.ints_to_limbs(vals[::-1], 4))
+    assert c.limbs_to_ints(c.fr_from_mont(M.fr_mul(a, b))) == [x * y % r for x, y in zip(vals, vals[::-1])]
+    d = torch.from_numpy(a.view(np.int64).copy()).cuda(); torch.cuda.synchronize()
+    poly.batch_inversion_device(d.data_ptr(), len(vals))
+    assert c.limbs_to_ints(c.fr_from_mont(_sync_to_numpy(d, len(vals)))) == [pow(x, -1, r) for x in vals]
+    # Edwards relation of the reference's group literals on the device: (1 + x^2) == y^2 (1 - 3021 x^2)
+    xs = [int(g['x']) for g in lit['groups']]; ys = [int(g['y'], 16) for g in lit['groups']]
+    X = c.fr_to_mont(c.ints_to_limbs(xs, 4)); Y = c.fr_to_mont(c.ints_to_limbs(ys, 4))
+    D = c.fr_to_mont(c.ints_to_limbs([3021] * len(xs), 4)); one = c.fr_to_mont(c.ints_to_limbs([1] * len(xs), 4))
+    XX, YY = M.fr_mul(X, X), M.fr_mul(Y, Y)
+    lhs = c.fr_vec_op(one, XX, 1); rhs = M.fr_mul(YY, c.fr_vec_op(one, M.fr_mul(D, XX), 2))
+    assert (lhs == rhs).all()
+
+
+def test_config2_full_size_chain_known_polynomial():
+    """BASELINE configs[2] at full size, checked (not only timed): 2^22 coefficients -> fft -> ifft in HBM -> kzg_commit_device
+    over bases (i+1)G must give (sum_i c_i (i+1)) G; the evaluations in between must differ from the coefficients."""
+    import torch
+    lg = 22; n = 1 << lg
+    coeffs = util.uniform_scalars(n, 0xA1E00003)                               # canonical values < r, read as Montgomery residues
+    canon = c.fr_from_mont(coeffs[: 1 << 12])                                  # spot check of the convention on a prefix
+    d = aleo_amd.EvaluationDomain(n)
+    with M.PinnedBases.generate_multiples(synth.generator_affine104(), 1, n) as pb:
+        pb.precompute()
+        buf = torch.from_numpy(coeffs.view(np.int64).copy()).cuda(); torch.cuda.synchronize()
+        d.ntt_device(buf.data_ptr(), 0, 0, 0)                                  # evaluations
+        mid = _sync_to_numpy(buf, n)
+        assert not (mid[:4096] == coeffs[:4096]).all()
+        d.ntt_device(buf.data_ptr(), 0, 1, 0)                                  # back to coefficients, never leaving HBM
+        cm = aleo_amd.KZG10.commit_device(pb, buf.data_ptr(), n)
+        # discrete log of the expected commitment: sum_i from_mont(c_i) * (i+1); from_mont is linear: R^-1 * sum_i c_i (i+1)
+        k = synth.weighted_scalar_sum(coeffs, 1) * pow(1 << 256, -1, p.FR_MODULUS) % p.FR_MODULUS
+        assert c.limbs_to_ints(canon)[:3] == [v * pow(1 << 256, -1, p.FR_MODULUS) % p.FR_MODULUS for v in c.limbs_to_ints(coeffs[:3])]
+        kG = M.VariableBase.msm(synth.generator_affine104().reshape(1, 104), synth.int_to_limbs(k, 4).reshape(1, 4))
+        assert (cm[:96].view(np.uint64) == kG[:12]).all() and cm[96] == 0
