@@ -499,6 +499,34 @@ int32_t aleo_mi355x_fr_batch_inverse_device(void* d_inout, size_t n, void* strea
   } catch (...) { return ALEO_MI355X_ERR_HIP; }
 }
 
+int32_t aleo_mi355x_fr_divide_by_linear_device(void* d_quotient, void* d_eval, const void* d_poly, size_t n, const void* z_mont, void* stream) {
+  try {
+    if (((!d_quotient && n > 1) || !d_poly) && n) return ALEO_MI355X_ERR_BAD_ARG;
+    if (!z_mont || (d_quotient && d_quotient == d_poly)) { g_last_error = "fr_divide_by_linear_device: null point, or quotient aliases the polynomial"; return ALEO_MI355X_ERR_BAD_ARG; }
+    API_BEGIN
+    return run_enqueue(c, stream, [&](hipStream_t s) { return fr_divide_by_linear(c, d_quotient, d_eval, d_poly, n, z_mont, s); });
+  } catch (...) { return ALEO_MI355X_ERR_HIP; }
+}
+
+// KZG10::open for one polynomial at one point: witness polynomial on the device (slot scratch), then its commitment.
+int32_t aleo_mi355x_kzg_open_device(void* out_affine104, void* out_eval_mont, uint64_t handle, const void* d_poly_mont, size_t n, const void* z_mont, void* stream) {
+  try {
+    if (!out_affine104 || !z_mont || (!d_poly_mont && n)) return ALEO_MI355X_ERR_BAD_ARG;
+    API_BEGIN
+    FIND_BASES(handle)
+    hipStream_t s = pick_stream(c, stream);
+    int32_t rc; if ((rc = c->ntt_stage.reserve((n ? n : 1) * 32 + 32))) return rc;
+    char* q = c->ntt_stage.as<char>(); char* ev = q + (n ? n : 1) * 32;
+    if ((rc = fr_divide_by_linear(c, q, ev, d_poly_mont, n, z_mont, s))) return rc;
+    if (out_eval_mont) HIPCHK(hipMemcpyAsync(out_eval_mont, ev, 32, hipMemcpyDeviceToHost, s));
+    uint64_t jac[18];
+    if ((rc = msm_run1(c, jac, pb, q, n ? n - 1 : 0, true, s))) return rc;      // synchronises: the evaluation has landed too
+    if (n <= 1) HIPCHK(hipStreamSynchronize(s));
+    jacobian_to_affine104(out_affine104, jac);
+    return ALEO_MI355X_OK;
+  } catch (...) { return ALEO_MI355X_ERR_HIP; }
+}
+
 int32_t aleo_mi355x_fr_spmv_device(void* d_y, const void* d_row_ptr, const void* d_col_idx, const void* d_vals, const void* d_x, size_t rows, void* stream) {
   try {
     if ((!d_y || !d_row_ptr) && rows) return ALEO_MI355X_ERR_BAD_ARG;

@@ -141,6 +141,7 @@ int32_t selftest_madd28(Ctx* c, uint32_t lanes, uint32_t steps, uint64_t seed, u
 // frops.hip
 int32_t fr_vec_op(Ctx* c, void* d_dst, const void* d_a, const void* d_b, size_t n, int32_t op, hipStream_t s);
 int32_t fr_batch_inverse(Ctx* c, void* d_inout, size_t n, hipStream_t s);
+int32_t fr_divide_by_linear(Ctx* c, void* d_q, void* d_eval, const void* d_p, size_t n, const void* z_mont32, hipStream_t s);
 int32_t fr_spmv(Ctx* c, void* d_y, const void* d_row_ptr, const void* d_col, const void* d_vals, const void* d_x, size_t rows, hipStream_t s);
 // ntt.hip
 int32_t ntt_run(Ctx* c, void* d_inout, uint32_t lg_n, size_t batch, int32_t order, int32_t direction, int32_t type, hipStream_t s);

@@ -13,6 +13,7 @@
 // (a^(r-2), ~380 products) over its K elements: 3 + 380/K products per element.
 #include "ctx.h"
 #include "fp.h"
+#include <cstring>
 
 namespace aleo_mi355x {
 
@@ -131,6 +132,106 @@ int32_t fr_spmv(Ctx* c, void* d_y, const void* d_row_ptr, const void* d_col, con
                      (const char*)d_x, (uint32_t)rows, long_rows, n_long);
   hipLaunchKernelGGL(k_spmv_long, dim3(1024), dim3(256), 0, s, (char*)d_y, (const uint32_t*)d_row_ptr, (const uint32_t*)d_col, (const char*)d_vals,
                      (const char*)d_x, long_rows, n_long);
+  HIPCHK(hipGetLastError());
+  return scratch_release(c, s);
+}
+
+// ---- division by (X - z): the witness polynomial of a KZG10 opening ------------------------------------------------------
+// Replaces snarkVM 0.14.5 algorithms/src/polycommit/kzg10  KZG10::compute_witness_polynomial / open  [UPSTREAM-RECALL]:
+// w(X) = (p(X) - p(z)) / (X - z), followed by the commitment to w (SURVEY.md §2c polycommit row; the two opening MSMs of row a6).
+// Synthetic division is the recurrence s_j = p_j + z * s_(j+1) (s_n = 0): w_(j-1) = s_j and p(z) = s_0.  A linear recurrence
+// with a constant multiplier is a suffix scan, done in three levels with the multipliers z^16, (z^16)^256, ...:
+//   k_div_blocks   every lane folds its 16 coefficients (Horner), every 256-lane block folds its lanes -> E_b
+//   k_div_carries  one block: carry C_b into every block = tail of the polynomial behind it, from the E_b
+//   k_div_finish   every block scans its lanes' values seeded with C_b, every lane replays its 16 steps and writes w
+// 96 algorithmic bytes per coefficient (p read twice, w written once); values stay lazily reduced below 4r (fp.h).
+static constexpr uint32_t DIV_K = 16, DIV_B = 256, DIV_TILE = DIV_K * DIV_B;
+struct FrK { uint32_t v[8]; };
+__device__ __forceinline__ Fr fr_arg(const FrK& k) { Fr r; for (int i = 0; i < 8; ++i) r.v[i] = k.v[i]; return r; }
+__device__ __forceinline__ Fr fr_lt2r(const Fr& a) { return Fr::cond_sub<2>(a); }                    // < 4r -> < 2r
+__device__ __forceinline__ void lds_put(uint32_t* l, uint32_t t, const Fr& a) { for (int i = 0; i < 8; ++i) l[i * DIV_B + t] = a.v[i]; }
+__device__ __forceinline__ Fr lds_get(const uint32_t* l, uint32_t t) { Fr r; for (int i = 0; i < 8; ++i) r.v[i] = l[i * DIV_B + t]; return r; }
+// value of the lane's 16 coefficients at z: sum_k p[lo + k] z^k (coefficients past n are zero); result < 3r
+__device__ __forceinline__ Fr div_lane_fold(const char* __restrict__ p, size_t lo, size_t n, const Fr& z) {
+  Fr h = Fr::zero();
+  for (int k = (int)DIV_K - 1; k >= 0; --k) {
+    const size_t i = lo + (size_t)k;
+    Fr m = Fr::mul(h, z);                                   // < 2r
+    h = i < n ? Fr::add(m, load_fp<Fr>(p + i * 32)) : m;    // canonical coefficient: < 3r
+  }
+  return h;
+}
+__global__ void __launch_bounds__(256) k_div_blocks(const char* __restrict__ p, size_t n, FrK zk, char* __restrict__ E) {
+  __shared__ uint32_t l[8 * DIV_B];
+  const uint32_t t = threadIdx.x; const Fr z = fr_arg(zk);
+  Fr x = fr_lt2r(div_lane_fold(p, ((size_t)blockIdx.x * DIV_B + t) * DIV_K, n, z));
+  Fr w = z; for (int i = 0; i < 4; ++i) w = Fr::sqr(w);     // Z = z^16, < 2r
+  for (uint32_t d = 1; d < DIV_B; d <<= 1) {               // x_t += Z^d * x_(t+d) on the lanes that are multiples of 2d
+    lds_put(l, t, x); __syncthreads();
+    if ((t & (2 * d - 1)) == 0) x = fr_lt2r(Fr::add(x, Fr::mul(lds_get(l, t + d), w)));
+    __syncthreads();
+    w = Fr::sqr(w);
+  }
+  if (t == 0) store_fp<Fr>(E + (size_t)blockIdx.x * 32, x);
+}
+// One block.  C[b] = sum_(u > b) E[u] * ZB^(u - b - 1), ZB = z^(16 * 256): lane q owns `per` consecutive blocks.
+__global__ void __launch_bounds__(256) k_div_carries(const char* __restrict__ E, uint32_t nb, uint32_t per, FrK zk, char* __restrict__ C) {
+  __shared__ uint32_t l[8 * DIV_B];
+  const uint32_t t = threadIdx.x; Fr zb = fr_arg(zk);
+  for (int i = 0; i < 12; ++i) zb = Fr::sqr(zb);            // z^4096, < 2r
+  const uint32_t lo = t * per, hi = lo + per < nb ? lo + per : nb;
+  Fr g = Fr::zero();
+  for (uint32_t b = hi; b-- > lo;) g = fr_lt2r(Fr::add(Fr::mul(g, zb), load_fp<Fr>(E + (size_t)b * 32)));
+  Fr w = Fr::one();                                         // ZB^per by square-and-multiply
+  for (int bit = 31 - __clz(per | 1u); bit >= 0; --bit) { w = Fr::sqr(w); if ((per >> bit) & 1u) w = Fr::mul(w, zb); }
+  Fr x = g;
+  for (uint32_t d = 1; d < DIV_B; d <<= 1) {               // suffix scan over the 256 lanes (Hillis-Steele): x_t += W^d * x_(t+d)
+    lds_put(l, t, x); __syncthreads();
+    if (t + d < DIV_B) x = fr_lt2r(Fr::add(x, Fr::mul(lds_get(l, t + d), w)));
+    __syncthreads();
+    w = Fr::sqr(w);
+  }
+  lds_put(l, t, x); __syncthreads();
+  Fr c = t + 1 < DIV_B ? lds_get(l, t + 1) : Fr::zero();    // everything behind this lane's blocks
+  for (uint32_t b = hi; b-- > lo;) {
+    store_fp<Fr>(C + (size_t)b * 32, c);
+    c = fr_lt2r(Fr::add(Fr::mul(c, zb), load_fp<Fr>(E + (size_t)b * 32)));
+  }
+}
+__global__ void __launch_bounds__(256) k_div_finish(const char* __restrict__ p, size_t n, FrK zk, const char* __restrict__ C, char* __restrict__ q, char* __restrict__ eval) {
+  __shared__ uint32_t l[8 * DIV_B];
+  const uint32_t t = threadIdx.x; const Fr z = fr_arg(zk);
+  const size_t lo = ((size_t)blockIdx.x * DIV_B + t) * DIV_K;
+  Fr x = fr_lt2r(div_lane_fold(p, lo, n, z));
+  Fr w = z; for (int i = 0; i < 4; ++i) w = Fr::sqr(w);     // Z = z^16
+  if (t == DIV_B - 1) x = fr_lt2r(Fr::add(x, Fr::mul(load_fp<Fr>(C + (size_t)blockIdx.x * 32), w)));     // the block's carry enters behind its last lane
+  for (uint32_t d = 1; d < DIV_B; d <<= 1) {
+    lds_put(l, t, x); __syncthreads();
+    if (t + d < DIV_B) x = fr_lt2r(Fr::add(x, Fr::mul(lds_get(l, t + d), w)));
+    __syncthreads();
+    w = Fr::sqr(w);
+  }
+  lds_put(l, t, x); __syncthreads();
+  Fr s = t + 1 < DIV_B ? lds_get(l, t + 1) : load_fp<Fr>(C + (size_t)blockIdx.x * 32);      // s_(lo + 16)
+  for (int k = (int)DIV_K - 1; k >= 0; --k) {              // s_j = p_j + z s_(j+1);  w_(j-1) = s_j;  p(z) = s_0
+    const size_t j = lo + (size_t)k;
+    if (j >= n) continue;
+    s = Fr::add(Fr::mul(s, z), load_fp<Fr>(p + j * 32));    // < 3r
+    if (j) store_fp<Fr>(q + (j - 1) * 32, Fr::reduce(s)); else if (eval) store_fp<Fr>(eval, Fr::reduce(s));
+  }
+}
+
+int32_t fr_divide_by_linear(Ctx* c, void* d_q, void* d_eval, const void* d_p, size_t n, const void* z_mont32, hipStream_t s) {
+  if (n == 0) { if (d_eval) HIPCHK(hipMemsetAsync(d_eval, 0, 32, s)); return ALEO_MI355X_OK; }
+  const size_t nb = (n + DIV_TILE - 1) / DIV_TILE;
+  if (nb >= (1ull << 31)) { g_last_error = "fr_divide_by_linear: polynomial too long"; return ALEO_MI355X_ERR_BAD_ARG; }
+  int32_t rc; if ((rc = scratch_acquire(c, c->ntt_tmp, 2 * nb * 32, s))) return rc;
+  char* E = c->ntt_tmp.as<char>(); char* C = E + nb * 32;
+  FrK zk; std::memcpy(zk.v, z_mont32, 32);
+  const uint32_t per = (uint32_t)((nb + DIV_B - 1) / DIV_B);
+  hipLaunchKernelGGL(k_div_blocks, dim3((uint32_t)nb), dim3(256), 0, s, (const char*)d_p, n, zk, E);
+  hipLaunchKernelGGL(k_div_carries, dim3(1), dim3(256), 0, s, (const char*)E, (uint32_t)nb, per, zk, C);
+  hipLaunchKernelGGL(k_div_finish, dim3((uint32_t)nb), dim3(256), 0, s, (const char*)d_p, n, zk, (const char*)C, (char*)d_q, (char*)d_eval);
   HIPCHK(hipGetLastError());
   return scratch_release(c, s);
 }

@@ -54,6 +54,14 @@ class KZG10:
         return out
 
     @staticmethod
+    def open_device(powers: PinnedBases, d_poly_ptr: int, n: int, z_mont: np.ndarray, stream: int = 0):
+        """KZG10::open (non-hiding): returns (w as snarkVM Affine uint8[104], p(z) as Montgomery uint64[4])."""
+        z = np.ascontiguousarray(z_mont, dtype=np.uint64).reshape(4)
+        out = np.zeros(104, dtype=np.uint8); ev = np.zeros(4, dtype=np.uint64)
+        check(lib().aleo_mi355x_kzg_open_device(_p(out), _p(ev), powers.handle, ctypes.c_void_p(d_poly_ptr), n, _p(z), ctypes.c_void_p(stream)), 'kzg_open_device')
+        return out, ev
+
+    @staticmethod
     def commit_hiding(powers: PinnedBases, coeffs_mont: np.ndarray, gamma_powers: PinnedBases, blinding_mont: np.ndarray) -> np.ndarray:
         """KZG10::commit with hiding_bound: adds msm(powers_of_beta_times_gamma_g, random polynomial)."""
         c = np.ascontiguousarray(coeffs_mont, dtype=np.uint64).reshape(-1, 4)

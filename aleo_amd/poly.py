@@ -20,3 +20,12 @@ def spmv_device(d_y: int, d_row_ptr: int, d_col_idx: int, d_vals: int, d_x: int,
     """y = M x for a CSR matrix over Fr (uint32 row_ptr / col_idx, Montgomery values): z_a = A z, z_b = B z."""
     vp = ctypes.c_void_p
     check(lib().aleo_mi355x_fr_spmv_device(vp(d_y), vp(d_row_ptr), vp(d_col_idx), vp(d_vals), vp(d_x), rows, vp(stream)), 'fr_spmv_device')
+
+
+def divide_by_linear_device(d_quotient: int, d_eval: int, d_poly: int, n: int, z_mont, stream: int = 0):
+    """quotient = (p(X) - p(z)) / (X - z) (n - 1 coefficients at d_quotient), p(z) at d_eval (32 bytes, may be 0): KZG10's witness
+    polynomial.  z_mont: uint64[4] Montgomery, host."""
+    import numpy as np
+    z = np.ascontiguousarray(z_mont, dtype=np.uint64).reshape(4)
+    check(lib().aleo_mi355x_fr_divide_by_linear_device(ctypes.c_void_p(d_quotient), ctypes.c_void_p(d_eval), ctypes.c_void_p(d_poly), n,
+                                                       z.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(stream)), 'fr_divide_by_linear_device')

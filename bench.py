@@ -286,54 +286,68 @@ def kzg_chain(aleo_amd, synth, torch, dev, lg=22, reps=5):
 
 
 PROXY_NOTE = ('operator-level proxy for constraints/s (SURVEY.md §8d): the MSM/NTT/field-op schedule of one single-instance Varuna proof with '
-              '|H| = |K| = 2^k, replayed on synthetic vectors of those sizes [schedule UPSTREAM-RECALL, see DESIGN.md §4c]; not a proof')
+              '|H| = |K| = 2^k, replayed on synthetic vectors of those sizes [schedule UPSTREAM-RECALL, see DESIGN.md §4c]; the commitments of a '
+              'round go through ONE batched call (aleo_mi355x_kzg_commit_batch_device), the two openings divide by (X - z) on the device; not a proof')
 
 
 def proxy_schedule(lg):
     """[(op, arg, size)] of one Varuna prove_batch for one circuit / one instance with 2^lg constraints, variables and
     non-zeros per matrix (snarkvm-algorithms 0.14.5 snark/varuna/ahp/prover/round_functions [UPSTREAM-RECALL]):
-    12 KZG MSMs (3 + 1 + 2 + 3 + 1 commitments, 2 openings) and the transforms between them."""
+    12 KZG MSMs in five groups (3 + 1, 2, 3, 1 commitments, 2 openings) and the transforms between them.
+    ('commit', [(kind, size), ...]) = the commitments of one round; ('open', [size, ...]) = witness polynomials + their commitments."""
     H = 1 << lg
     ops = []
-    ops += [('msm', 'witness', H)] * 3 + [('ntt', (1, 0), H)] * 3                      # round 1: w, z_a, z_b (Lagrange-basis commits) + interpolation
-    ops += [('msm', 'uniform', 3 * H)]                                                  #          mask_poly, degree 3|H|
+    ops += [('ntt', (1, 0), H)] * 3                                                     # round 1: interpolate w, z_a, z_b
+    ops += [('commit', [('witness', H)] * 3 + [('uniform', 3 * H)])]                    #          w, z_a, z_b, mask_poly (degree 3|H|)
     ops += [('ntt', (0, 1), 4 * H)] * 4 + [('vec', 0, 4 * H)] * 6 + [('ntt', (1, 1), 4 * H)]      # round 2: h_1 on the 4|H| coset
-    ops += [('ntt', (0, 0), H)] * 2 + [('msm', 'uniform', H), ('msm', 'uniform', 2 * H)]            #          g_1, h_1
+    ops += [('ntt', (0, 0), H)] * 2 + [('commit', [('uniform', H), ('uniform', 2 * H)])]            #          g_1, h_1
     for _ in range(3):                                                                  # round 3: g_a, g_b, g_c over K
-        ops += [('ntt', (0, 0), H)] * 2 + [('inv', 0, H)] + [('vec', 0, H)] * 4 + [('ntt', (1, 0), H), ('msm', 'uniform', H)]
-    ops += [('ntt', (0, 1), 2 * H)] * 3 + [('vec', 0, 2 * H)] * 4 + [('ntt', (1, 1), 2 * H), ('msm', 'uniform', H)]   # round 4: h_2
-    ops += [('msm', 'uniform', 3 * H)] * 2                                              # two batched KZG opening proofs
+        ops += [('ntt', (0, 0), H)] * 2 + [('inv', 0, H)] + [('vec', 0, H)] * 4 + [('ntt', (1, 0), H)]
+    ops += [('commit', [('uniform', H)] * 3)]
+    ops += [('ntt', (0, 1), 2 * H)] * 3 + [('vec', 0, 2 * H)] * 4 + [('ntt', (1, 1), 2 * H), ('commit', [('uniform', H)])]   # round 4: h_2
+    ops += [('open', [3 * H, 3 * H])]                                                   # two batched KZG opening proofs
     return ops
 
 
 def proof_proxy_gpu(aleo_amd, synth, torch, dev, lg, reps=3):
-    from aleo_amd import poly
+    from aleo_amd import poly, wire
     H = 1 << lg
     pb = aleo_amd.PinnedBases.generate_multiples(synth.generator_affine104(), 1, 3 * H).precompute()
     buf = torch.from_numpy(synth.uniform_scalars(4 * H, 0xA1E00010 + lg).view(np.int64)).to(dev)      # canonical < r, read as Montgomery
     aux = buf.clone()
-    s_uni = torch.from_numpy(synth.uniform_scalars(3 * H, 0xA1E00011 + lg).view(np.int64)).to(dev)
-    s_wit = torch.from_numpy(synth.witness_like_scalars(H, 0xA1E00012 + lg).view(np.int64)).to(dev)
+    wit = [torch.from_numpy(wire.fr_from_bytes(synth.witness_like_scalars(H, 0xA1E00012 + lg + 64 * j).view(np.uint8).reshape(-1, 32)).view(np.int64)).to(dev) for j in range(3)]
+    quo = [torch.empty((3 * H, 4), dtype=torch.int64, device=dev) for _ in range(2)]
+    z = synth.uniform_scalars(2, 0xA1E00013 + lg)
     doms = {}
     ops = proxy_schedule(lg)
     torch.cuda.synchronize()
 
     def run():
         t_msm = 0.0
-        for op, arg, size in ops:
-            if op == 'msm':
+        for op, arg, size in [(o[0], o[1], o[2] if len(o) > 2 else None) for o in ops]:
+            if op in ('commit', 'open'):
                 torch.cuda.synchronize()             # the queued transforms finish first, so the split below is honest
                 t0 = time.perf_counter()
-                if arg == 'witness': aleo_amd.VariableBase.msm_device(pb, s_wit.data_ptr(), size)
-                else: aleo_amd.KZG10.commit_device(pb, buf.data_ptr(), size)      # Montgomery -> canonical on the device, then MSM
+                if op == 'commit':
+                    ptrs, lens, w = [], [], 0
+                    for kind, m in arg:
+                        if kind == 'witness': ptrs.append(wit[w].data_ptr()); w += 1
+                        else: ptrs.append(buf.data_ptr() + 32 * (len(ptrs) * 64))       # distinct (overlapping) windows of the resident vector
+                        lens.append(m)
+                    aleo_amd.KZG10.commit_batch_device(pb, ptrs, lens)                   # Montgomery -> canonical on the device, shared launches
+                else:
+                    for j, m in enumerate(arg):
+                        poly.divide_by_linear_device(quo[j].data_ptr(), 0, buf.data_ptr() + 32 * 64 * j, m, z[j])
+                    torch.cuda.synchronize()
+                    aleo_amd.KZG10.commit_batch_device(pb, [q.data_ptr() for q in quo], [m - 1 for m in arg])
                 t_msm += time.perf_counter() - t0
             elif op == 'ntt':
                 d = doms.get(size) or doms.setdefault(size, aleo_amd.EvaluationDomain(size))
-                d.ntt_device(buf.data_ptr(), 0, arg[0], arg[1])
+                d.ntt_device(buf.data_ptr(), 0, arg[0], arg[1], 1)                       # hipStreamLegacy: enqueue only, ordered with torch's stream
             elif op == 'vec':
-                poly.fr_vec_op_device(aux.data_ptr(), aux.data_ptr(), buf.data_ptr(), size, 0)
+                poly.fr_vec_op_device(aux.data_ptr(), aux.data_ptr(), buf.data_ptr(), size, 0, 1)
             else:
-                poly.batch_inversion_device(aux.data_ptr(), size)
+                poly.batch_inversion_device(aux.data_ptr(), size, 1)
         torch.cuda.synchronize()
         return t_msm
     run()
@@ -342,8 +356,9 @@ def proof_proxy_gpu(aleo_amd, synth, torch, dev, lg, reps=3):
         t0 = time.perf_counter(); m = run(); ts.append(time.perf_counter() - t0); tm.append(m)
     pb.close()
     dt = float(np.median(ts)); m = float(np.median(tm))
+    n_msm = sum(len(o[1]) for o in ops if o[0] in ('commit', 'open'))
     return {'constraints': H, 'ms': dt * 1e3, 'constraints_per_s': H / dt, 'msm_ms': m * 1e3, 'ntt_and_field_ms': (dt - m) * 1e3,
-            'n_msm': sum(1 for o in ops if o[0] == 'msm'), 'n_ntt': sum(1 for o in ops if o[0] == 'ntt')}
+            'n_msm': n_msm, 'n_msm_calls': sum(1 for o in ops if o[0] in ('commit', 'open')), 'n_ntt': sum(1 for o in ops if o[0] == 'ntt')}
 
 
 def proof_proxy_cpu(c, aleo_amd, synth, lg, cores):
@@ -353,18 +368,25 @@ def proof_proxy_cpu(c, aleo_amd, synth, lg, cores):
         bases = pb.download()
     buf = synth.uniform_scalars(4 * H, 0xA1E00010 + lg); aux = buf.copy()
     s_uni = synth.uniform_scalars(3 * H, 0xA1E00011 + lg); s_wit = synth.witness_like_scalars(H, 0xA1E00012 + lg)
+    z = synth.uniform_scalars(2, 0xA1E00013 + lg)
     t0 = time.perf_counter(); t_msm = 0.0
-    for op, arg, size in proxy_schedule(lg):
-        if op == 'msm':
+    for o in proxy_schedule(lg):
+        op, arg = o[0], o[1]
+        if op == 'commit':
             t1 = time.perf_counter()
-            c.msm_g1(bases[:size], (s_wit if arg == 'witness' else s_uni)[:size], threads=cores, variant=1)
+            for kind, m in arg: c.msm_g1(bases[:m], (s_wit if kind == 'witness' else s_uni)[:m], threads=cores, variant=1)
+            t_msm += time.perf_counter() - t1
+        elif op == 'open':
+            t1 = time.perf_counter()
+            for j, m in enumerate(arg):
+                q, _ = c.fr_divide_by_linear(buf[:m], z[j]); c.msm_g1(bases[:m - 1], q, threads=cores, variant=1)
             t_msm += time.perf_counter() - t1
         elif op == 'ntt':
-            buf[:size] = c.ntt_fr(buf[:size], 0, arg[0], arg[1])
+            buf[:o[2]] = c.ntt_fr(buf[:o[2]], 0, arg[0], arg[1])
         elif op == 'vec':
-            aux[:size] = c.fr_vec_op(aux[:size], buf[:size], 0)
+            aux[:o[2]] = c.fr_vec_op(aux[:o[2]], buf[:o[2]], 0)
         else:
-            aux[:size] = c.fr_batch_inverse(aux[:size])
+            aux[:o[2]] = c.fr_batch_inverse(aux[:o[2]])
     dt = time.perf_counter() - t0
     return {'constraints': H, 'seconds': dt, 'constraints_per_s': H / dt, 'msm_seconds': t_msm, 'msm_threads': cores, 'other_threads': 1}
 
@@ -373,7 +395,8 @@ def cpu_baseline(args, pb, scalars, aleo_amd):
     """The oracle (C restatement of snarkVM's batched Pippenger, all host cores) on a bounded sample of the same
     workload; also re-checks GPU == oracle on that sample.  kind 'port': it is not the Rust binary."""
     from oracle import coracle as c
-    ns = 1 << min(args.cpu_sample_lg, args.lg_n)
+    ns = min(1 << args.cpu_sample_lg, len(scalars))
+    ns = 1 << (ns.bit_length() - 1)
     # the restated algorithm (like snarkVM's rayon version) runs one window per thread: c = ln(n)+2 bits -> ceil(253/c)
     # windows is the most threads it can use, whatever the box has
     lg = ns.bit_length() - 1; nwin = -(-253 // (lg * 69 // 100 + 2))

@@ -162,6 +162,14 @@ int32_t aleo_mi355x_kzg_commit_hiding(void* out_affine104, uint64_t h_powers, co
 #define ALEO_FR_OP_SUB 2
 int32_t aleo_mi355x_fr_vec_op_device(void* d_dst, const void* d_a, const void* d_b, size_t n, int32_t op, void* stream);
 int32_t aleo_mi355x_fr_batch_inverse_device(void* d_inout, size_t n, void* stream);
+/* Division by (X - z): quotient[j-1] = s_j with s_j = p_j + z s_(j+1) (n - 1 coefficients, canonical Montgomery form) and, when
+ * d_eval != NULL, p(z) = s_0 (32 bytes, device) — KZG10's witness polynomial (p(X) - p(z)) / (X - z)
+ * [UPSTREAM-RECALL: polycommit/kzg10 compute_witness_polynomial].  z_mont: 32 bytes Montgomery Fr in HOST memory.
+ * d_quotient must not alias d_poly. */
+int32_t aleo_mi355x_fr_divide_by_linear_device(void* d_quotient, void* d_eval, const void* d_poly, size_t n, const void* z_mont, void* stream);
+/* KZG10::open of one polynomial at one point (without hiding): the witness polynomial is built on the device and committed against
+ * the first n - 1 pinned powers.  out_affine104: the opening proof's `w` (host); out_eval_mont (host, may be NULL): p(z). */
+int32_t aleo_mi355x_kzg_open_device(void* out_affine104, void* out_eval_mont, uint64_t handle, const void* d_poly_mont, size_t n, const void* z_mont, void* stream);
 /* y = M * x over Fr for a CSR matrix in device memory (row_ptr: uint32[rows + 1], col_idx: uint32[nnz], vals: Montgomery
  * Fr[nnz]); x and y Montgomery Fr vectors.  The z_a = A z, z_b = B z products of the R1CS matrices before round 1
  * [UPSTREAM-RECALL: snark/varuna/ahp/prover/round_functions/first.rs].  Empty rows give 0. */

@@ -39,6 +39,7 @@ def lib():
         L.oracle_fr_batch_inverse.argtypes = [vp, sz]; L.oracle_fr_batch_inverse.restype = None
         L.oracle_fr_vec_op.argtypes = [vp, vp, vp, sz, ci]; L.oracle_fr_vec_op.restype = None
         L.oracle_fr_spmv.argtypes = [vp, vp, vp, vp, vp, sz]; L.oracle_fr_spmv.restype = None
+        L.oracle_fr_divide_by_linear.argtypes = [vp, vp, vp, sz, vp]; L.oracle_fr_divide_by_linear.restype = None
         _LIB = L
     return _LIB
 
@@ -157,3 +158,10 @@ def fr_spmv(row_ptr, col_idx, vals, x) -> np.ndarray:
     v = np.ascontiguousarray(vals, dtype=np.uint64); xx = np.ascontiguousarray(x, dtype=np.uint64)
     y = np.zeros((rp.shape[0] - 1, 4), dtype=np.uint64)
     lib().oracle_fr_spmv(_p(y), _p(rp), _p(ci), _p(v), _p(xx), y.shape[0]); return y
+
+
+def fr_divide_by_linear(poly_mont, z_mont):
+    """(p(X) - p(z)) / (X - z): returns (quotient uint64[n-1,4], p(z) uint64[4]), Montgomery."""
+    a = np.ascontiguousarray(poly_mont, dtype=np.uint64).reshape(-1, 4); z = np.ascontiguousarray(z_mont, dtype=np.uint64).reshape(4)
+    q = np.zeros((max(a.shape[0] - 1, 0), 4), dtype=np.uint64); ev = np.zeros(4, dtype=np.uint64)
+    lib().oracle_fr_divide_by_linear(_p(q) if q.size else None, _p(ev), _p(a) if a.size else None, a.shape[0], _p(z)); return q, ev

@@ -486,3 +486,14 @@ void oracle_fr_vec_op(void* r, const void* a, const void* b, size_t n, int op) {
     else Fr_sub((Fr*)r + i, (const Fr*)a + i, (const Fr*)b + i);
   }
 }
+
+/* KZG10 witness polynomial (polycommit/kzg10 compute_witness_polynomial [UPSTREAM-RECALL]): w(X) = (p(X) - p(z)) / (X - z) by
+ * synthetic division, coefficients Montgomery, low degree first.  q receives n - 1 coefficients, *eval = p(z). */
+void oracle_fr_divide_by_linear(void* q, void* eval, const void* p, size_t n, const void* z) {
+  Fr s; memset(&s, 0, sizeof s);
+  for (size_t j = n; j-- > 0;) {
+    Fr t; Fr_mul(&t, &s, (const Fr*)z); Fr_add(&s, &t, (const Fr*)p + j);      /* s_j = p_j + z s_(j+1) */
+    if (j) ((Fr*)q)[j - 1] = s; else *(Fr*)eval = s;
+  }
+  if (n == 0) *(Fr*)eval = s;
+}

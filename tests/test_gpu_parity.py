@@ -758,3 +758,40 @@ def test_config2_full_size_chain_known_polynomial():
         assert c.limbs_to_ints(canon)[:3] == [v * pow(1 << 256, -1, p.FR_MODULUS) % p.FR_MODULUS for v in c.limbs_to_ints(coeffs[:3])]
         kG = M.VariableBase.msm(synth.generator_affine104().reshape(1, 104), synth.int_to_limbs(k, 4).reshape(1, 4))
         assert (cm[:96].view(np.uint64) == kG[:12]).all() and cm[96] == 0
+
+
+# ---- KZG10 opening: witness polynomial on the device -------------------------------------------------------------------------
+@pytest.mark.parametrize('n', [1, 2, 15, 16, 17, 4095, 4096, 4097, 100003, (1 << 20) + 5, 1 << 22])
+def test_divide_by_linear_matches_oracle(n):
+    """(p(X) - p(z)) / (X - z) by the three-level suffix scan against the oracle's serial synthetic division: every quotient
+    coefficient and p(z), bit for bit; chunk / block boundaries (16, 4096) on both sides; z in {random, 0, 1}."""
+    import torch
+    from aleo_amd import poly
+    f = c.fr_to_mont(util.uniform_scalars(n, 14000 + n % 1000))
+    d = torch.from_numpy(f.view(np.int64).copy()).cuda()
+    q = torch.zeros((max(n - 1, 1), 4), dtype=torch.int64, device='cuda'); ev = torch.zeros(4, dtype=torch.int64, device='cuda')
+    zs = [c.fr_to_mont(util.uniform_scalars(1, 14500 + n % 1000))[0]]
+    if n <= 100003: zs += [np.zeros(4, dtype=np.uint64), c.fr_to_mont(c.ints_to_limbs([1], 4))[0]]
+    for z in zs:
+        torch.cuda.synchronize()
+        poly.divide_by_linear_device(q.data_ptr(), ev.data_ptr(), d.data_ptr(), n, z)
+        torch.cuda.synchronize()
+        eq, ee = c.fr_divide_by_linear(f, z)
+        assert (ev.cpu().numpy().view(np.uint64) == ee).all(), n
+        if n > 1: assert (q.cpu().numpy().view(np.uint64)[: n - 1] == eq).all(), n
+
+
+def test_kzg_open_matches_oracle():
+    """KZG10::open shape: witness polynomial on the device, then its commitment — against oracle division + oracle commit."""
+    import torch
+    n = 5000
+    with M.PinnedBases.generate_multiples(synth.generator_affine104(), 1, n) as pb:
+        B = pb.download()
+        f = c.fr_to_mont(util.uniform_scalars(n, 15001)); z = c.fr_to_mont(util.uniform_scalars(1, 15002))[0]
+        d = torch.from_numpy(f.view(np.int64).copy()).cuda(); torch.cuda.synchronize()
+        eq, ee = c.fr_divide_by_linear(f, z)
+        for _ in range(2):
+            w, ev = aleo_amd.KZG10.open_device(pb, d.data_ptr(), n, z)
+            assert (ev == ee).all()
+            assert (w == c.kzg_commit(B[: n - 1], eq, threads=8)).all()
+            pb.precompute()

@@ -125,3 +125,17 @@ def test_oracle_kzg_commit_shape():
     got = c.affine_to_ints(c.kzg_commit(B, cm, threads=2))[0]
     k = sum((i + 1) * v for i, v in enumerate(coeff)) % p.FR_MODULUS
     assert got == p.g1_mul(p.G1_GENERATOR, k)
+
+
+def test_oracle_divide_by_linear_matches_bigint():
+    """KZG10's witness polynomial: q (X - z) + p(z) == p, coefficient by coefficient, in Python integers."""
+    rng = p.SplitMix64(23); r = p.FR_MODULUS
+    for n in (1, 2, 3, 17, 300):
+        f = [rng.fr() for _ in range(n)]; z = rng.fr()
+        q, ev = c.fr_divide_by_linear(c.fr_to_mont(c.ints_to_limbs(f, 4)), c.fr_to_mont(c.ints_to_limbs([z], 4))[0])
+        qi = c.limbs_to_ints(c.fr_from_mont(q)) if n > 1 else []; e = c.limbs_to_ints(c.fr_from_mont(ev.reshape(1, 4)))[0]
+        assert e == sum(v * pow(z, i, r) for i, v in enumerate(f)) % r
+        back = [0] * n
+        for i, v in enumerate(qi): back[i + 1] = (back[i + 1] + v) % r; back[i] = (back[i] - z * v) % r
+        back[0] = (back[0] + e) % r
+        assert back == f
