@@ -10,7 +10,7 @@ LIB_PATH = os.path.join(_HERE, 'lib', 'libaleo_mi355x.so')
 EXPORTS = [
     'aleo_mi355x_init', 'aleo_mi355x_msm_g1', 'aleo_mi355x_bases_pin', 'aleo_mi355x_bases_unpin',
     'aleo_mi355x_bases_generate', 'aleo_mi355x_bases_download', 'aleo_mi355x_bases_info', 'aleo_mi355x_bases_precompute',
-    'aleo_mi355x_msm_g1_pinned', 'aleo_mi355x_msm_g1_device', 'aleo_mi355x_g1_sum', 'aleo_mi355x_ntt_fr',
+    'aleo_mi355x_msm_g1_pinned', 'aleo_mi355x_msm_g1_device', 'aleo_mi355x_g1_sum', 'aleo_mi355x_msm_g2', 'aleo_mi355x_g2_sum', 'aleo_mi355x_ntt_fr',
     'aleo_mi355x_ntt_fr_device', 'aleo_mi355x_ntt_fr_batch_device', 'aleo_mi355x_fr_grid_scale_device', 'aleo_mi355x_kzg_commit', 'aleo_mi355x_kzg_commit_device', 'aleo_mi355x_kzg_commit_hiding',
     'aleo_mi355x_msm_g1_batch_device', 'aleo_mi355x_kzg_commit_batch_device', 'aleo_mi355x_kzg_commit_batch',
     'aleo_mi355x_fr_vec_op_device', 'aleo_mi355x_fr_batch_inverse_device', 'aleo_mi355x_fr_spmv_device', 'aleo_mi355x_fr_divide_by_linear_device', 'aleo_mi355x_kzg_open_device', 'aleo_mi355x_fq_mul',
@@ -56,6 +56,8 @@ def lib():
         'aleo_mi355x_msm_g1_pinned': ([vp, u64, vp, sz], i32),
         'aleo_mi355x_msm_g1_device': ([vp, u64, vp, sz, vp], i32),
         'aleo_mi355x_g1_sum': ([vp, vp, sz], i32),
+        'aleo_mi355x_msm_g2': ([vp, vp, sz, vp, sz], i32),
+        'aleo_mi355x_g2_sum': ([vp, vp, sz], i32),
         'aleo_mi355x_ntt_fr': ([vp, u32, i32, i32, i32], i32),
         'aleo_mi355x_ntt_fr_device': ([vp, u32, i32, i32, i32, vp], i32),
         'aleo_mi355x_ntt_fr_batch_device': ([vp, u32, sz, i32, i32, i32, vp], i32),

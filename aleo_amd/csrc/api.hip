@@ -373,6 +373,35 @@ int32_t aleo_mi355x_msm_g1_device(void* out, uint64_t handle, const void* d_scal
   } catch (...) { return ALEO_MI355X_ERR_HIP; }
 }
 
+// VariableBase::msm::<G2Affine>: one-shot, host pointers (G2 appears in SRS setup and verifying keys, never in the prover's loop:
+// no residency handle).  bases: snarkVM G2Affine rows, stride 200 (flag byte at 192) or 192.
+int32_t aleo_mi355x_msm_g2(void* out_jac288, const void* bases, size_t base_stride, const void* scalars, size_t n) {
+  try {
+    if (!out_jac288 || ((!bases || !scalars) && n) || (base_stride != 200 && base_stride != 192)) { g_last_error = "msm_g2: bad argument"; return ALEO_MI355X_ERR_BAD_ARG; }
+    API_BEGIN
+    DevTmp xy, inf; int32_t rc; bool any_inf = false;
+    if ((rc = xy.alloc((n ? n : 1) * 192))) return rc;
+    if (base_stride == 192) { if (n) HIPCHK(hipMemcpy(xy.p, bases, n * 192, hipMemcpyHostToDevice)); }
+    else {
+      std::vector<uint8_t> packed((n ? n : 1) * 192), fl(n ? n : 1, 0);
+      const uint8_t* src = (const uint8_t*)bases;
+      for (size_t i = 0; i < n; ++i) { std::memcpy(&packed[i * 192], src + i * 200, 192); if (src[i * 200 + 192]) { fl[i] = 1; any_inf = true; } }
+      if (n) HIPCHK(hipMemcpy(xy.p, packed.data(), n * 192, hipMemcpyHostToDevice));
+      if (any_inf) { if ((rc = inf.alloc(n))) return rc; HIPCHK(hipMemcpy(inf.p, fl.data(), n, hipMemcpyHostToDevice)); }
+    }
+    if ((rc = c->scalars_stage.reserve((n ? n : 1) * 32))) return rc;
+    if (n) HIPCHK(hipMemcpyAsync(c->scalars_stage.p, scalars, n * 32, hipMemcpyHostToDevice, c->stream));
+    return msm_g2_run(c, (uint64_t*)out_jac288, xy.p, any_inf ? (const uint8_t*)inf.p : nullptr, c->scalars_stage.p, n, c->stream);
+  } catch (...) { return ALEO_MI355X_ERR_HIP; }
+}
+
+int32_t aleo_mi355x_g2_sum(void* out, const void* pts, size_t count) {
+  try {
+    if (!out || (!pts && count)) return ALEO_MI355X_ERR_BAD_ARG;
+    return g2_sum_host((uint64_t*)out, (const uint64_t*)pts, count);
+  } catch (...) { return ALEO_MI355X_ERR_HIP; }
+}
+
 int32_t aleo_mi355x_g1_sum(void* out, const void* pts, size_t count) {
   try {
     if (!out || (!pts && count)) return ALEO_MI355X_ERR_BAD_ARG;

@@ -138,6 +138,9 @@ int32_t generate_multiples(Ctx* c, const void* base104, uint64_t first, size_t n
 int32_t msm_precompute(Ctx* c, PinnedBases* pb);
 int32_t make_rows28(Ctx* c, PinnedBases* pb);          // fills pb->d_xy28 from pb->d_xy
 int32_t selftest_madd28(Ctx* c, uint32_t lanes, uint32_t steps, uint64_t seed, uint32_t* failures);
+// g2.hip
+int32_t msm_g2_run(Ctx* c, uint64_t* out_jac36, const void* d_xy192, const uint8_t* d_inf, const void* d_scalars, size_t n, hipStream_t s);
+int32_t g2_sum_host(uint64_t* out36, const uint64_t* pts36, size_t count);
 // frops.hip
 int32_t fr_vec_op(Ctx* c, void* d_dst, const void* d_a, const void* d_b, size_t n, int32_t op, hipStream_t s);
 int32_t fr_batch_inverse(Ctx* c, void* d_inout, size_t n, hipStream_t s);

@@ -28,13 +28,9 @@
 #include "ec.h"
 #include "fp28.h"
 #include "host_field.hpp"
+#include "msm_common.h"
 
 namespace aleo_mi355x {
-
-static constexpr uint32_t SCAN_TILE = 2048;     // elements per scan block (256 threads x 8)
-static constexpr uint32_t SCALAR_BITS = 254;    // 253-bit scalars + 1 bit of signed-digit carry
-
-struct MsmPlan { uint32_t c, W, B, M, S; };
 
 // Window width of the fixed-base table, by size of the pinned set: the bucket reduction is latency-bound and its work
 // grows with 2^(c-1), so small SRS (real Aleo circuits are 2^15..2^17) get narrower windows than the 2^20+ sets.
@@ -42,7 +38,7 @@ struct MsmPlan { uint32_t c, W, B, M, S; };
 // (widths whose TOP window keeps >= 13 bits of the 253-bit scalar: c = 18 or 19 would leave it 1 or 6 bits, i.e. a
 // handful of buckets holding n/2 points each)
 
-static MsmPlan make_plan(size_t n, int pre_c) {
+MsmPlan make_plan(size_t n, int pre_c) {
   MsmPlan p;
   if (pre_c) {   // one shared bucket set: "W = 1 window of 2^(c-1) buckets" for everything after the sort
     // running-sum chunk: 2S dependent additions per lane pair vs. one more level of masked sums per halving; measured
@@ -106,8 +102,6 @@ static constexpr uint32_t MAX_COARSE = 2048;      // W * (B >> LB) at c = 16
 // Batched calls (several scalar vectors against ONE pinned set, msm_run's `k`): blockIdx.y is the vector ("set"); every
 // set owns its own 2^(c-1) buckets, so its coarse bins are [set * CB, (set + 1) * CB) and everything after the sort sees
 // k * 2^(c-1) buckets.  Only the table path batches (PRE), where one set is one window's worth of buckets.
-static constexpr uint32_t MAX_SETS = 32;
-struct SetArgs { const char* ptr[MAX_SETS]; uint32_t n[MAX_SETS]; };          // scalar vector and length of every set (kernel argument)
 template <int C, bool PRE> struct SortGeom {
   static constexpr uint32_t W = (SCALAR_BITS + C - 1) / C, B = 1u << (C - 1);
   static constexpr uint32_t LB = (C - 1) < 8 ? (C - 1) : 8;       // low bucket bits, sorted in level 2
@@ -337,22 +331,6 @@ __global__ void __launch_bounds__(256) k_bin_scatter(const uint2* __restrict__ i
 // slices (tried) put a 2.7 ms floor under a 2.4 ms kernel, because the top window of a 253-bit scalar only has 13 bits
 // and its 4779 buckets hold ~300 points each.  64/32 keeps the floor at about half the kernel time.
 // Sparse inputs (witness-like scalars, small n) use 32/32 so that the accumulation still fills every SIMD.
-static constexpr uint32_t SUPER_CAP = 4096;    // buckets with > 16 slices kept in their own list
-struct SliceRule { uint32_t single, split; };
-__device__ __forceinline__ SliceRule pick_rule(const uint32_t* total_pairs, uint32_t M) {
-  // Two pulls.  Keep buckets whole where possible (every extra slice is a 14-product tree addition): single = 2 x the
-  // mean bucket size.  But fill the chip: the launch wants >= 2^18 slices (2 waves per SIMD), and a lane needs ~11 us per
-  // addition, so when there are few pairs (small n, sparse scalars) slices are cut down to pairs / 2^18 points even if
-  // that splits ordinary buckets.  Everything in powers of two, 16 <= single <= 512, split = single / 2.
-  const uint32_t pairs = *total_pairs, mean = pairs / M;
-  uint32_t by_mean = 32u; while (by_mean < 2u * mean && by_mean < 512u) by_mean <<= 1;
-  uint32_t fill = 8u; while (fill < (pairs >> 18) && fill < 256u) fill <<= 1;
-  SliceRule r; r.single = by_mean < 2u * fill ? by_mean : 2u * fill;
-  r.split = r.single >> 1;
-  return r;
-}
-__device__ __forceinline__ uint32_t slices_of(uint32_t cnt, SliceRule r) { return cnt <= r.single ? (cnt ? 1u : 0u) : (cnt + r.split - 1) / r.split; }
-
 __global__ void __launch_bounds__(256) k_scan_tiles(const uint32_t* hist, uint32_t M, const uint32_t* total_pairs, uint2* scan_local, uint2* tile_tot, uint32_t* meta,
                                                     uint32_t* __restrict__ heavy) {
   __shared__ uint2 wsum[4];
@@ -412,19 +390,10 @@ __global__ void __launch_bounds__(256) k_scan_top(const uint2* tile_tot, uint32_
   if (threadIdx.x == 0) { meta[0] = carry.y; meta[2] = carry.x; }
 }
 
-__device__ __forceinline__ uint2 scan_at(const uint2* local, const uint2* blk, uint32_t g) {
-  uint2 a = local[g], b = blk[g / SCAN_TILE]; return make_uint2(a.x + b.x, a.y + b.y);
-}
-
 // ---- slice ordering: lanes of one wave should run the same trip count --------------------------------
 // Slices are at most 512 points long; bucket sizes are Poisson, so slice lengths vary 2:1 inside a wave if
 // taken in bucket order (measured: 31 % of the accumulation's lanes idle).  A counting sort by length (longest
 // first) costs two tiny launches: block-local LDS histograms + a handful of global atomics per block.
-static constexpr uint32_t MAX_SLICE = 512;       // longest slice pick_rule() can produce
-__device__ __forceinline__ uint32_t slice_len(uint32_t cnt, uint32_t m, uint32_t k) {
-  return (uint32_t)(((uint64_t)(k + 1) * cnt) / m) - (uint32_t)(((uint64_t)k * cnt) / m);
-}
-
 // sid -> bucket (binary search over first_slice), stores task_g[sid], counts slice lengths
 __global__ void __launch_bounds__(256) k_slice_count(const uint32_t* __restrict__ hist, const uint2* __restrict__ scan_local, const uint2* __restrict__ scan_blk,
                                                      uint32_t M, const uint32_t* __restrict__ total_pairs, const uint32_t* __restrict__ meta, uint32_t* __restrict__ task_g,
@@ -809,6 +778,87 @@ uint32_t msm_max_sets(const PinnedBases& pb, size_t n) {
   return 1;
 }
 
+int32_t msm_sort_phase(Ctx* c, const SetArgs& sets, uint32_t K, size_t n, size_t pts, bool mont, const uint8_t* d_inf, uint32_t row_stride,
+                       const MsmPlan& P, bool pre, hipStream_t s, SortPhase* out) {
+  SortPhase& sp = *out; sp.P = P;
+  sp.digitsW = (SCALAR_BITS + P.c - 1) / P.c;
+  const uint32_t M = sp.M = P.M, ntiles = (M + SCAN_TILE - 1) / SCAN_TILE;
+  const size_t pairs_max = sp.pairs_max = pts * (size_t)sp.digitsW;
+  if (pairs_max >= (1ull << 32)) { g_last_error = "msm: n * windows exceeds 2^32 (shard the MSM across GPUs)"; return ALEO_MI355X_ERR_BAD_ARG; }
+  const size_t slices_max = sp.slices_max = slice_bound(pairs_max, M);
+  sp.slice_blocks = (uint32_t)((slices_max + 255) / 256);
+  int32_t rc;
+  // hist | heavy list | meta | super list | level-2 cursors live in one zero-initialised allocation
+  const size_t hist_words = 3 * (size_t)M + 2048 + SUPER_CAP;
+  if ((rc = c->hist.reserve(hist_words * 4))) return rc;
+  if ((rc = c->scan_local.reserve((size_t)M * 8))) return rc;
+  if ((rc = c->scan_blk.reserve(2 * (size_t)ntiles * 8 + 64))) return rc;
+  if ((rc = c->sorted.reserve(pairs_max * 4))) return rc;
+  const uint32_t LB = (P.c - 1) < 8 ? (P.c - 1) : 8, ncb = P.W * (P.B >> LB);      // coarse bins of all sets / windows
+  const uint32_t nblk = (uint32_t)((n + PART_TILE - 1) / PART_TILE);
+  const size_t cnt_len = (size_t)ncb * nblk;
+  if (ncb > MAX_COARSE || cnt_len >= (1ull << 32)) { g_last_error = "msm: partition table too large"; return ALEO_MI355X_ERR_BAD_ARG; }
+  const uint32_t cnt_tiles = (uint32_t)((cnt_len + SCAN_TILE - 1) / SCAN_TILE);
+  if ((rc = c->part_cnt.reserve((2 * cnt_len + 2 * (size_t)cnt_tiles + 16 + MAX_COARSE) * 4))) return rc;     // cnt | off_local | tile_tot | off_blk | part_start
+  if ((rc = c->part_items.reserve(pairs_max * 8))) return rc;
+  if ((rc = c->task_g.reserve(2 * slices_max * 4))) return rc;     // task_g | order
+  if ((rc = ensure_host_pinned(c, 64))) return rc;
+
+  uint32_t* hist = sp.hist = c->hist.as<uint32_t>(); uint32_t* heavy = sp.heavy = hist + M; uint32_t* meta = sp.meta = heavy + M;     // heavy: <= M bucket ids
+  sp.super_list = heavy + M + 2048;
+  uint32_t* bin_cursor = hist + 2 * (size_t)M + 2048 + SUPER_CAP;
+  uint2* scan_local = sp.scan_local = c->scan_local.as<uint2>();
+  uint2* tile_tot = c->scan_blk.as<uint2>(); uint2* scan_blk = sp.scan_blk = tile_tot + ntiles;
+  uint32_t* sorted = sp.sorted = c->sorted.as<uint32_t>(); uint32_t* task_g = sp.task_g = c->task_g.as<uint32_t>(); uint32_t* order = sp.order = task_g + slices_max;
+
+  HIPCHK(hipEventRecord(c->ev[0], s));
+  HIPCHK(hipMemsetAsync(hist, 0, hist_words * 4, s));
+  SortArgs sa;
+  sa.sets = sets; sa.nsets = pre ? K : 1;
+  sa.inf = d_inf; sa.nblk = nblk; sa.row_stride = row_stride;
+  sa.cnt = c->part_cnt.as<uint32_t>(); sa.off_local = sa.cnt + cnt_len;
+  uint32_t* cnt_tile_tot = sa.off_local + cnt_len; sa.off_blk = cnt_tile_tot + cnt_tiles;
+  sa.items = c->part_items.as<uint2>();
+  const uint32_t* total_pairs = sp.total_pairs = sa.off_blk + cnt_tiles;          // grand total of the level-1 scan
+  uint32_t* part_start = sa.off_blk + cnt_tiles + 4;             // ncb + 1 prefix counts of the level-2 parts
+  const uint32_t nparts_max = ncb + (uint32_t)(pairs_max / BIN_PART) + 1;
+  if (mont) launch_sort<true>(P.c, pre, sa, 0, s); else launch_sort<false>(P.c, pre, sa, 0, s);
+  hipLaunchKernelGGL(k_scan32_tiles, dim3(cnt_tiles), dim3(256), 0, s, sa.cnt, (uint32_t)cnt_len, sa.off_local, cnt_tile_tot);
+  hipLaunchKernelGGL(k_scan32_top, dim3(1), dim3(256), 0, s, cnt_tile_tot, cnt_tiles, sa.off_blk);
+  if (mont) launch_sort<true>(P.c, pre, sa, 1, s); else launch_sort<false>(P.c, pre, sa, 1, s);
+  hipLaunchKernelGGL(k_bin_parts, dim3(1), dim3(256), 0, s, sa.off_local, sa.off_blk, nblk, ncb, cnt_tiles, part_start);
+  hipLaunchKernelGGL(k_bin_hist, dim3(nparts_max), dim3(256), 0, s, sa.items, sa.off_local, sa.off_blk, nblk, ncb, cnt_tiles, LB, part_start, hist);
+  hipLaunchKernelGGL(k_bin_scatter, dim3(nparts_max), dim3(256), 0, s, sa.items, sa.off_local, sa.off_blk, nblk, ncb, cnt_tiles, LB, part_start, hist, bin_cursor, sorted);
+  hipLaunchKernelGGL(k_scan_tiles, dim3(ntiles), dim3(256), 0, s, hist, M, total_pairs, scan_local, tile_tot, meta, heavy);
+  hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(256), 0, s, tile_tot, ntiles, scan_blk, meta);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipEventRecord(c->ev[1], s));
+  // The slice count, the longest bucket and the list lengths size the slice-tree launches.  They come back on the slot's side
+  // stream while the slice kernels and the accumulation — launched with grids from slice_bound() — already run on `s`:
+  // the host reads them long before the accumulation ends, so the GPU never waits for the round trip.
+  HIPCHK(hipStreamWaitEvent(c->side, c->ev[1], 0));
+  HIPCHK(hipMemcpyAsync(c->h_pinned, meta, 32, hipMemcpyDeviceToHost, c->side));
+  HIPCHK(hipEventRecord(c->ev[7], c->side));
+  uint32_t* len_count = meta + 16; uint32_t* len_cursor = len_count + MAX_SLICE + 1; uint32_t* len_start = len_cursor + MAX_SLICE + 1;   // zeroed with hist/meta
+  hipLaunchKernelGGL(k_slice_count, dim3(sp.slice_blocks), dim3(256), 0, s, hist, scan_local, scan_blk, M, total_pairs, meta, task_g, len_count);
+  hipLaunchKernelGGL(k_len_starts, dim3(1), dim3(256), 0, s, len_count, len_start);
+  hipLaunchKernelGGL(k_slice_order, dim3(sp.slice_blocks), dim3(256), 0, s, hist, scan_local, scan_blk, total_pairs, M, meta, task_g, len_start, len_cursor, order);
+  HIPCHK(hipGetLastError());
+  return ALEO_MI355X_OK;
+}
+
+int32_t msm_wait_meta(Ctx* c, const SortPhase& sp, hipStream_t s, SliceMeta* m) {
+  HIPCHK(hipEventSynchronize(c->ev[7]));
+  const uint32_t* h_meta = (const uint32_t*)c->h_pinned;
+  m->NT = h_meta[0]; m->max_m = h_meta[1]; m->n_heavy = h_meta[3];
+  m->n_super = h_meta[5] < SUPER_CAP ? h_meta[5] : SUPER_CAP;
+  m->super_overflow = h_meta[5] > SUPER_CAP;          // then the common list also holds very long buckets
+  if (m->NT > sp.slices_max) {          // cannot happen (slice_bound); the kernels only touched threads below the bound
+    (void)hipStreamSynchronize(s); g_last_error = "msm: internal slice count overflow"; return ALEO_MI355X_ERR_HIP;
+  }
+  return ALEO_MI355X_OK;
+}
+
 int32_t msm_run(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, const MsmJob& job, hipStream_t s) {
   using namespace host;
   const uint32_t K = job.k;
@@ -830,107 +880,45 @@ int32_t msm_run(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, const MsmJob
   if (K > 1 && (!pre || K > msm_max_sets(pb, n))) { g_last_error = "msm: internal: batch without a table tier (or too many sets)"; return ALEO_MI355X_ERR_BAD_ARG; }
   MsmPlan P = make_plan(n, pre ? T->c : 0);
   if (pre) { P.W = K; P.M = K * P.B; }                       // after the sort a set is "a window with its own buckets"
-  const uint32_t digitsW = pre ? (SCALAR_BITS + T->c - 1) / T->c : P.W;
-  const uint32_t M = P.M, ntiles = (M + SCAN_TILE - 1) / SCAN_TILE;
-  const size_t pairs_max = pts * (size_t)digitsW;
-  if (pairs_max >= (1ull << 32)) { g_last_error = "msm: n * windows exceeds 2^32 (shard the MSM across GPUs)"; return ALEO_MI355X_ERR_BAD_ARG; }
-  const size_t slices_max = slice_bound(pairs_max, M);
-  const uint32_t slice_blocks = (uint32_t)((slices_max + 255) / 256);
-  int32_t rc;
-  // hist | heavy list | meta | super list | level-2 cursors live in one zero-initialised allocation
-  const size_t hist_words = 3 * (size_t)M + 2048 + SUPER_CAP;
-  if ((rc = c->hist.reserve(hist_words * 4))) return rc;
-  if ((rc = c->scan_local.reserve((size_t)M * 8))) return rc;
-  if ((rc = c->scan_blk.reserve(2 * (size_t)ntiles * 8 + 64))) return rc;
-  if ((rc = c->sorted.reserve(pairs_max * 4))) return rc;
-  const uint32_t LB = (P.c - 1) < 8 ? (P.c - 1) : 8, ncb = P.W * (P.B >> LB);      // coarse bins of all sets / windows
-  const uint32_t nblk = (uint32_t)((n + PART_TILE - 1) / PART_TILE);
-  const size_t cnt_len = (size_t)ncb * nblk;
-  if (ncb > MAX_COARSE || cnt_len >= (1ull << 32)) { g_last_error = "msm: partition table too large"; return ALEO_MI355X_ERR_BAD_ARG; }
-  const uint32_t cnt_tiles = (uint32_t)((cnt_len + SCAN_TILE - 1) / SCAN_TILE);
-  if ((rc = c->part_cnt.reserve((2 * cnt_len + 2 * (size_t)cnt_tiles + 16 + MAX_COARSE) * 4))) return rc;     // cnt | off_local | tile_tot | off_blk | part_start
-  if ((rc = c->part_items.reserve(pairs_max * 8))) return rc;
-  if ((rc = c->partial.reserve(slices_max * (pre ? 224 : 192)))) return rc;
-  if ((rc = c->task_g.reserve(2 * slices_max * 4))) return rc;     // task_g | order
+  if (!pre && !pb.d_xy28) { g_last_error = "msm: pinned set without 28-bit rows"; return ALEO_MI355X_ERR_HIP; }
+  const char* bases = (const char*)(pre ? T->d : pb.d_xy28);          // 112-byte rows either way
   const uint32_t cpw = P.B / P.S, nchunks = cpw * P.W;
   uint32_t lgN = 0; while ((1u << lgN) < cpw) ++lgN;
   const bool masked = pre && lgN >= 2 && (1u << lgN) == cpw;          // fixed-base path: weights by masked trees
   if (pre && !masked) { g_last_error = "msm: internal: table path without masked reduction"; return ALEO_MI355X_ERR_HIP; }
+  int32_t rc;
   // table path, per set: [acc of its cpw chunks | lgN masked sums of cpw/4] = (lgN + 4) segments of tseg points
   const uint32_t tseg = cpw / 4, fseg = lgN + 4, nseg = K * fseg, setw = fseg * tseg;
   const size_t vpoints = masked ? (size_t)K * setw + nchunks + (nseg + 1) + (size_t)nseg * (tseg / 2 + tseg / 4 + 2) : (size_t)nchunks + P.W;
+  if ((rc = ensure_host_pinned(c, 64 + (size_t)(masked ? nseg : P.W) * 224))) return rc;      // before the sort phase: its read-back lands in this buffer
+  SortPhase sp;
+  if ((rc = msm_sort_phase(c, sets, K, n, pts, job.mont, pb.d_inf, (uint32_t)(pre ? T->cover : pb.n), P, pre, s, &sp))) return rc;
+  const uint32_t M = sp.M;
+  if ((rc = c->partial.reserve(sp.slices_max * (pre ? 224 : 192)))) return rc;
   if ((rc = c->vbuf.reserve(vpoints * 224))) return rc;
-  if ((rc = ensure_host_pinned(c, 64 + (size_t)(masked ? nseg : P.W) * 224))) return rc;
-
-  uint32_t* hist = c->hist.as<uint32_t>(); uint32_t* heavy = hist + M; uint32_t* meta = heavy + M;     // heavy: <= M bucket ids
-  uint32_t* bin_cursor = hist + 2 * (size_t)M + 2048 + SUPER_CAP;
-  uint2* scan_local = c->scan_local.as<uint2>();
-  uint2* tile_tot = c->scan_blk.as<uint2>(); uint2* scan_blk = tile_tot + ntiles;
-  uint32_t* sorted = c->sorted.as<uint32_t>(); char* partial = c->partial.as<char>(); uint32_t* task_g = c->task_g.as<uint32_t>(); uint32_t* order = task_g + slices_max;
+  uint32_t* hist = sp.hist; uint32_t* heavy = sp.heavy; uint32_t* meta = sp.meta; uint2* scan_local = sp.scan_local; uint2* scan_blk = sp.scan_blk;
+  const uint32_t* total_pairs = sp.total_pairs;
+  char* partial = c->partial.as<char>();
   char* V = c->vbuf.as<char>(); char* Vout = V + (size_t)nchunks * 192;
-  if (!pre && !pb.d_xy28) { g_last_error = "msm: pinned set without 28-bit rows"; return ALEO_MI355X_ERR_HIP; }
-  const char* bases = (const char*)(pre ? T->d : pb.d_xy28);          // 112-byte rows either way
-
-  HIPCHK(hipEventRecord(c->ev[0], s));
-  HIPCHK(hipMemsetAsync(hist, 0, hist_words * 4, s));
-  SortArgs sa;
-  sa.sets = sets; sa.nsets = K;
-  sa.inf = pb.d_inf; sa.nblk = nblk; sa.row_stride = (uint32_t)(pre ? T->cover : pb.n);
-  sa.cnt = c->part_cnt.as<uint32_t>(); sa.off_local = sa.cnt + cnt_len;
-  uint32_t* cnt_tile_tot = sa.off_local + cnt_len; sa.off_blk = cnt_tile_tot + cnt_tiles;
-  sa.items = c->part_items.as<uint2>();
-  const uint32_t* total_pairs = sa.off_blk + cnt_tiles;          // grand total of the level-1 scan
-  uint32_t* part_start = sa.off_blk + cnt_tiles + 4;             // ncb + 1 prefix counts of the level-2 parts
-  const uint32_t nparts_max = ncb + (uint32_t)(pairs_max / BIN_PART) + 1;
-  if (job.mont) launch_sort<true>(P.c, pre, sa, 0, s); else launch_sort<false>(P.c, pre, sa, 0, s);
-  hipLaunchKernelGGL(k_scan32_tiles, dim3(cnt_tiles), dim3(256), 0, s, sa.cnt, (uint32_t)cnt_len, sa.off_local, cnt_tile_tot);
-  hipLaunchKernelGGL(k_scan32_top, dim3(1), dim3(256), 0, s, cnt_tile_tot, cnt_tiles, sa.off_blk);
-  if (job.mont) launch_sort<true>(P.c, pre, sa, 1, s); else launch_sort<false>(P.c, pre, sa, 1, s);
-  hipLaunchKernelGGL(k_bin_parts, dim3(1), dim3(256), 0, s, sa.off_local, sa.off_blk, nblk, ncb, cnt_tiles, part_start);
-  hipLaunchKernelGGL(k_bin_hist, dim3(nparts_max), dim3(256), 0, s, sa.items, sa.off_local, sa.off_blk, nblk, ncb, cnt_tiles, LB, part_start, hist);
-  hipLaunchKernelGGL(k_bin_scatter, dim3(nparts_max), dim3(256), 0, s, sa.items, sa.off_local, sa.off_blk, nblk, ncb, cnt_tiles, LB, part_start, hist, bin_cursor, sorted);
-  hipLaunchKernelGGL(k_scan_tiles, dim3(ntiles), dim3(256), 0, s, hist, M, total_pairs, scan_local, tile_tot, meta, heavy);
-  hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(256), 0, s, tile_tot, ntiles, scan_blk, meta);
+  HIPCHK(hipEventRecord(c->ev[6], s));          // ev[6]..ev[5] bracket k_accum28 alone (bench.py's roofline kernel)
+  if (pre) hipLaunchKernelGGL(k_accum28<true>, dim3(sp.slice_blocks), dim3(256), 0, s, bases, sp.sorted, hist, scan_local, scan_blk, total_pairs, M, meta, sp.order, sp.task_g, partial);
+  else hipLaunchKernelGGL(k_accum28<false>, dim3(sp.slice_blocks), dim3(256), 0, s, bases, sp.sorted, hist, scan_local, scan_blk, total_pairs, M, meta, sp.order, sp.task_g, partial);
+  HIPCHK(hipEventRecord(c->ev[5], s));
   HIPCHK(hipGetLastError());
-  HIPCHK(hipEventRecord(c->ev[1], s));
-  // The slice count, the longest bucket and the list lengths size the slice-tree launches.  They come back on the slot's side
-  // stream while the slice kernels and the accumulation — launched with grids from slice_bound() — already run on `s`:
-  // the host reads them long before the accumulation ends, so the GPU never waits for the round trip.
-  uint32_t* h_meta = (uint32_t*)c->h_pinned;
-  HIPCHK(hipStreamWaitEvent(c->side, c->ev[1], 0));
-  HIPCHK(hipMemcpyAsync(h_meta, meta, 32, hipMemcpyDeviceToHost, c->side));
-  HIPCHK(hipEventRecord(c->ev[7], c->side));
-  {
-    uint32_t* len_count = meta + 16; uint32_t* len_cursor = len_count + MAX_SLICE + 1; uint32_t* len_start = len_cursor + MAX_SLICE + 1;   // zeroed with hist/meta
-    hipLaunchKernelGGL(k_slice_count, dim3(slice_blocks), dim3(256), 0, s, hist, scan_local, scan_blk, M, total_pairs, meta, task_g, len_count);
-    hipLaunchKernelGGL(k_len_starts, dim3(1), dim3(256), 0, s, len_count, len_start);
-    hipLaunchKernelGGL(k_slice_order, dim3(slice_blocks), dim3(256), 0, s, hist, scan_local, scan_blk, total_pairs, M, meta, task_g, len_start, len_cursor, order);
-    HIPCHK(hipEventRecord(c->ev[6], s));          // ev[6]..ev[5] bracket k_accum28 alone (bench.py's roofline kernel)
-    if (pre) hipLaunchKernelGGL(k_accum28<true>, dim3(slice_blocks), dim3(256), 0, s, bases, sorted, hist, scan_local, scan_blk, total_pairs, M, meta, order, task_g, partial);
-    else hipLaunchKernelGGL(k_accum28<false>, dim3(slice_blocks), dim3(256), 0, s, bases, sorted, hist, scan_local, scan_blk, total_pairs, M, meta, order, task_g, partial);
-    HIPCHK(hipEventRecord(c->ev[5], s));
-    HIPCHK(hipGetLastError());
-  }
-  HIPCHK(hipEventSynchronize(c->ev[7]));
-  const uint32_t NT = h_meta[0], max_m = h_meta[1];
-  uint32_t n_heavy = h_meta[3], n_super = h_meta[5] < SUPER_CAP ? h_meta[5] : SUPER_CAP;
-  const bool super_overflow = h_meta[5] > SUPER_CAP;          // then the common list also holds very long buckets
-  if (NT > slices_max) {          // cannot happen (slice_bound); the kernels above only touched threads below the bound
-    (void)hipStreamSynchronize(s); g_last_error = "msm: internal slice count overflow"; return ALEO_MI355X_ERR_HIP;
-  }
-  if (NT) {
-    const uint32_t* super_list = heavy + M + 2048;
-    for (uint32_t pass = 0, L = max_m; L > 1; ++pass, L = (L + 1) >> 1) {
-      const uint32_t Lc = super_overflow ? L : (L < 16u ? L : (16u >> (pass < 4 ? pass : 4)));       // longest bucket of the common list at this level
-      if (n_heavy && Lc > 1) {
-        uint32_t mp = Lc >> 1; uint64_t threads = 2ull * n_heavy * mp;
-        if (pre) hipLaunchKernelGGL(k_tree_pass<true>, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, s, partial, heavy, scan_local, scan_blk, M, meta, pass, mp, n_heavy);
-        else hipLaunchKernelGGL(k_tree_pass<false>, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, s, partial, heavy, scan_local, scan_blk, M, meta, pass, mp, n_heavy);
+  SliceMeta sm;
+  if ((rc = msm_wait_meta(c, sp, s, &sm))) return rc;
+  if (sm.NT) {
+    for (uint32_t pass = 0, L = sm.max_m; L > 1; ++pass, L = (L + 1) >> 1) {
+      const uint32_t Lc = sm.super_overflow ? L : (L < 16u ? L : (16u >> (pass < 4 ? pass : 4)));       // longest bucket of the common list at this level
+      if (sm.n_heavy && Lc > 1) {
+        uint32_t mp = Lc >> 1; uint64_t threads = 2ull * sm.n_heavy * mp;
+        if (pre) hipLaunchKernelGGL(k_tree_pass<true>, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, s, partial, heavy, scan_local, scan_blk, M, meta, pass, mp, sm.n_heavy);
+        else hipLaunchKernelGGL(k_tree_pass<false>, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, s, partial, heavy, scan_local, scan_blk, M, meta, pass, mp, sm.n_heavy);
       }
-      if (n_super) {
-        uint32_t mp = L >> 1; uint64_t threads = 2ull * n_super * mp;
-        if (pre) hipLaunchKernelGGL(k_tree_pass<true>, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, s, partial, super_list, scan_local, scan_blk, M, meta, pass, mp, n_super);
-        else hipLaunchKernelGGL(k_tree_pass<false>, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, s, partial, super_list, scan_local, scan_blk, M, meta, pass, mp, n_super);
+      if (sm.n_super) {
+        uint32_t mp = L >> 1; uint64_t threads = 2ull * sm.n_super * mp;
+        if (pre) hipLaunchKernelGGL(k_tree_pass<true>, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, s, partial, sp.super_list, scan_local, scan_blk, M, meta, pass, mp, sm.n_super);
+        else hipLaunchKernelGGL(k_tree_pass<false>, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, s, partial, sp.super_list, scan_local, scan_blk, M, meta, pass, mp, sm.n_super);
       }
     }
   }

@@ -1,0 +1,56 @@
+// msm_common.h — what the G1 and G2 multi-scalar multiplications share (msm.hip, g2.hip): the plan, the results of the sort /
+// slice phase (which depends on the scalars only, not on the group) and the device helpers that read them.
+#pragma once
+#include "ctx.h"
+
+namespace aleo_mi355x {
+
+static constexpr uint32_t SCAN_TILE = 2048;     // elements per scan block (256 threads x 8)
+static constexpr uint32_t SCALAR_BITS = 254;    // 253-bit scalars + 1 bit of signed-digit carry
+static constexpr uint32_t MAX_SETS = 32;
+static constexpr uint32_t SUPER_CAP = 4096;     // buckets with > 16 slices kept in their own list
+static constexpr uint32_t MAX_SLICE = 512;      // longest slice pick_rule() can produce
+
+struct MsmPlan { uint32_t c, W, B, M, S; };
+MsmPlan make_plan(size_t n, int pre_c);
+struct SetArgs { const char* ptr[MAX_SETS]; uint32_t n[MAX_SETS]; };          // scalar vector and length of every set (kernel argument)
+
+// Slice sizing.  A bucket of <= single points is one slice (one lane); larger buckets are cut into slices of <= split.
+struct SliceRule { uint32_t single, split; };
+__device__ __forceinline__ SliceRule pick_rule(const uint32_t* total_pairs, uint32_t M) {
+  // Two pulls.  Keep buckets whole where possible (every extra slice is a 14-product tree addition): single = 2 x the
+  // mean bucket size.  But fill the chip: the launch wants >= 2^18 slices (2 waves per SIMD), and a lane needs ~11 us per
+  // addition, so when there are few pairs (small n, sparse scalars) slices are cut down to pairs / 2^18 points even if
+  // that splits ordinary buckets.  Everything in powers of two, 16 <= single <= 512, split = single / 2.
+  const uint32_t pairs = *total_pairs, mean = pairs / M;
+  uint32_t by_mean = 32u; while (by_mean < 2u * mean && by_mean < 512u) by_mean <<= 1;
+  uint32_t fill = 8u; while (fill < (pairs >> 18) && fill < 256u) fill <<= 1;
+  SliceRule r; r.single = by_mean < 2u * fill ? by_mean : 2u * fill;
+  r.split = r.single >> 1;
+  return r;
+}
+__device__ __forceinline__ uint32_t slices_of(uint32_t cnt, SliceRule r) { return cnt <= r.single ? (cnt ? 1u : 0u) : (cnt + r.split - 1) / r.split; }
+__device__ __forceinline__ uint2 scan_at(const uint2* local, const uint2* blk, uint32_t g) {
+  uint2 a = local[g], b = blk[g / SCAN_TILE]; return make_uint2(a.x + b.x, a.y + b.y);
+}
+__device__ __forceinline__ uint32_t slice_len(uint32_t cnt, uint32_t m, uint32_t k) {
+  return (uint32_t)(((uint64_t)(k + 1) * cnt) / m) - (uint32_t)(((uint64_t)k * cnt) / m);
+}
+
+// What msm_sort_phase leaves in the slot's workspaces (device pointers), enqueued on `s`, nothing synchronised:
+//   hist[g] points of bucket g | scan_local/scan_blk: exclusive (points, slices) prefix per bucket (scan_at) | sorted: the point index
+//   stream (bit 31 = negate), bucket runs contiguous | task_g[sid] bucket of slice sid | order[t] slice ids, longest first |
+//   meta[0] slices, [1] most slices in one bucket, [2] pairs, [3] multi-slice buckets (listed in heavy[]), [5] super-heavy ones
+struct SortPhase {
+  MsmPlan P; uint32_t M = 0, digitsW = 0, slice_blocks = 0; size_t slices_max = 0, pairs_max = 0;
+  uint32_t *hist = nullptr, *heavy = nullptr, *meta = nullptr; uint2 *scan_local = nullptr, *scan_blk = nullptr;
+  uint32_t *sorted = nullptr, *task_g = nullptr, *order = nullptr; const uint32_t* total_pairs = nullptr; const uint32_t* super_list = nullptr;
+};
+struct SliceMeta { uint32_t NT = 0, max_m = 0, n_heavy = 0, n_super = 0; bool super_overflow = false; };
+// P: the plan (P.W windows / sets of P.B buckets).  pre: table path (digits address row w * row_stride + i of a table, all windows share
+// a set's buckets).  Records ev[0] before and ev[1] after the sort; ev[7] on the side stream carries the slice metadata back.
+int32_t msm_sort_phase(Ctx* c, const SetArgs& sets, uint32_t K, size_t n_max, size_t pts, bool mont, const uint8_t* d_inf, uint32_t row_stride,
+                       const MsmPlan& P, bool pre, hipStream_t s, SortPhase* out);
+int32_t msm_wait_meta(Ctx* c, const SortPhase& sp, hipStream_t s, SliceMeta* m);
+
+}  // namespace aleo_mi355x

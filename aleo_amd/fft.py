@@ -44,10 +44,17 @@ class EvaluationDomain:
     def coset_fft(self, coeffs): return self._run(coeffs, FORWARD, COSET)
     def coset_ifft(self, evals): return self._run(evals, INVERSE, COSET)
 
-    def fft_in_place(self, x: np.ndarray): x[...] = self.fft(x)
-    def ifft_in_place(self, x: np.ndarray): x[...] = self.ifft(x)
-    def coset_fft_in_place(self, x: np.ndarray): x[...] = self.coset_fft(x)
-    def coset_ifft_in_place(self, x: np.ndarray): x[...] = self.coset_ifft(x)
+    def _run_in_place(self, x: np.ndarray, direction: int, type_: int):
+        """The reference's *_in_place shape: the caller's own buffer (full domain size, contiguous uint64[n,4]) goes to the C ABI as it
+        is — one upload, the transform, one download into the same memory, no intermediate copy on the host."""
+        if not (isinstance(x, np.ndarray) and x.dtype == np.uint64 and x.flags.c_contiguous and x.size == 4 * self.size):
+            x[...] = self._run(x, direction, type_); return
+        check(lib().aleo_mi355x_ntt_fr(_p(x), self.log_size_of_group, ORDER_NN, direction, type_), 'ntt_fr')
+
+    def fft_in_place(self, x: np.ndarray): self._run_in_place(x, FORWARD, STANDARD)
+    def ifft_in_place(self, x: np.ndarray): self._run_in_place(x, INVERSE, STANDARD)
+    def coset_fft_in_place(self, x: np.ndarray): self._run_in_place(x, FORWARD, COSET)
+    def coset_ifft_in_place(self, x: np.ndarray): self._run_in_place(x, INVERSE, COSET)
 
     def ntt(self, x, order=ORDER_NN, direction=FORWARD, type_=STANDARD):
         """The snarkvm_algorithms_cuda::NTT shape: explicit order / direction / type."""

@@ -102,6 +102,24 @@ class VariableBase:
         return out
 
 
+def msm_g2(bases: np.ndarray, scalars: np.ndarray) -> np.ndarray:
+    """VariableBase::msm over BLS12-377 G2: bases uint8[n,200] (snarkVM G2Affine) or uint8[n,192], scalars uint64[n,4] canonical;
+    result uint64[36] = Jacobian (x, y, z) over Fq2, affine-normalised."""
+    bases = np.ascontiguousarray(bases, dtype=np.uint8); scalars = np.ascontiguousarray(scalars, dtype=np.uint64).reshape(-1, 4)
+    n = min(bases.shape[0], scalars.shape[0])
+    stride = bases.shape[1] if bases.ndim == 2 and bases.shape[0] else 200
+    out = np.zeros(36, dtype=np.uint64)
+    check(lib().aleo_mi355x_msm_g2(_p(out), _p(bases), stride, _p(scalars), n), 'msm_g2')
+    return out
+
+
+def g2_sum(points: np.ndarray) -> np.ndarray:
+    pts = np.ascontiguousarray(points, dtype=np.uint64).reshape(-1, 36)
+    out = np.zeros(36, dtype=np.uint64)
+    check(lib().aleo_mi355x_g2_sum(_p(out), _p(pts), pts.shape[0]), 'g2_sum')
+    return out
+
+
 def g1_sum(points: np.ndarray) -> np.ndarray:
     """Group sum of Jacobian points uint64[k,18] (the local add after the all-gather of per-GPU partials)."""
     pts = np.ascontiguousarray(points, dtype=np.uint64).reshape(-1, 18)

@@ -113,6 +113,13 @@ int32_t aleo_mi355x_msm_g1_device(void* out_jacobian, uint64_t handle, const voi
  * all-gather of per-GPU partial MSM results.  Result affine-normalised as above. */
 int32_t aleo_mi355x_g1_sum(void* out_jacobian, const void* jacobian_points, size_t count);
 
+/* VariableBase::msm::<G2Affine> (SRS / setup paths; the prover itself never runs one).  BLS12-377 G2 over
+ * Fq2 = Fq[u]/(u^2 + 5).  bases: snarkVM G2Affine {x: Fq2 (c0, c1), y: Fq2, infinity: bool}, Montgomery limbs, stride 200 (flag byte
+ * at 192) or 192; scalars as for G1; result G2Projective (Jacobian x, y, z: Fq2 = 288 bytes), affine-normalised like the G1 result:
+ * (x, y, 1), or (1, 1, 0) for the identity.  Host pointers; nothing is retained.  g2_sum: the group add after an all-gather. */
+int32_t aleo_mi355x_msm_g2(void* out_jacobian288, const void* bases, size_t base_stride, const void* scalars, size_t n);
+int32_t aleo_mi355x_g2_sum(void* out_jacobian288, const void* jacobian_points288, size_t count);
+
 /* a2 — EvaluationDomain NTT over Fr, in place, n = 2^lg_n elements (lg_n <= 30), host pointer. */
 int32_t aleo_mi355x_ntt_fr(void* inout, uint32_t lg_n, int32_t order, int32_t direction, int32_t type);
 /* Same on device-resident data (in place). */

@@ -39,6 +39,9 @@ def lib():
         L.oracle_fr_batch_inverse.argtypes = [vp, sz]; L.oracle_fr_batch_inverse.restype = None
         L.oracle_fr_vec_op.argtypes = [vp, vp, vp, sz, ci]; L.oracle_fr_vec_op.restype = None
         L.oracle_fr_spmv.argtypes = [vp, vp, vp, vp, vp, sz]; L.oracle_fr_spmv.restype = None
+        L.oracle_msm_g2.argtypes = [vp, vp, sz, vp, sz, ci]; L.oracle_msm_g2.restype = ci
+        L.oracle_g2_to_affine.argtypes = [vp, vp]; L.oracle_g2_to_affine.restype = None
+        L.oracle_g2_multiples.argtypes = [vp, vp, sz]; L.oracle_g2_multiples.restype = None
         L.oracle_fr_divide_by_linear.argtypes = [vp, vp, vp, sz, vp]; L.oracle_fr_divide_by_linear.restype = None
         _LIB = L
     return _LIB
@@ -165,3 +168,41 @@ def fr_divide_by_linear(poly_mont, z_mont):
     a = np.ascontiguousarray(poly_mont, dtype=np.uint64).reshape(-1, 4); z = np.ascontiguousarray(z_mont, dtype=np.uint64).reshape(4)
     q = np.zeros((max(a.shape[0] - 1, 0), 4), dtype=np.uint64); ev = np.zeros(4, dtype=np.uint64)
     lib().oracle_fr_divide_by_linear(_p(q) if q.size else None, _p(ev), _p(a) if a.size else None, a.shape[0], _p(z)); return q, ev
+
+
+# ---- G2: uint8[n,200] snarkVM G2Affine rows (x.c0, x.c1, y.c0, y.c1 Montgomery + infinity byte at 192); Jacobian uint64[36]
+def g2_affine_from_ints(points) -> np.ndarray:
+    """[((x0,x1),(y0,y1))|None] canonical ints -> uint8[n,200]."""
+    n = len(points); out = np.zeros((n, 200), dtype=np.uint8)
+    flat = []
+    for P in points: flat += [0, 0, 1, 0] if P is None else [P[0][0], P[0][1], P[1][0], P[1][1]]
+    m = fq_to_mont(ints_to_limbs(flat, 6)).view(np.uint8).reshape(n, 192)
+    out[:, :192] = m
+    for i, P in enumerate(points):
+        if P is None: out[i, 192] = 1
+    return out
+
+
+def g2_affine_to_ints(aff) -> list:
+    aff = np.ascontiguousarray(aff, dtype=np.uint8).reshape(-1, 200); n = aff.shape[0]
+    v = limbs_to_ints(fq_from_mont(np.ascontiguousarray(aff[:, :192]).view(np.uint64).reshape(4 * n, 6)))
+    return [None if aff[i, 192] else ((v[4 * i], v[4 * i + 1]), (v[4 * i + 2], v[4 * i + 3])) for i in range(n)]
+
+
+def g2_jac_to_int_point(jac):
+    jac = np.ascontiguousarray(jac, dtype=np.uint64).reshape(36)
+    out = np.zeros(200, dtype=np.uint8); lib().oracle_g2_to_affine(_p(out), _p(jac))
+    return g2_affine_to_ints(out)[0]
+
+
+def msm_g2(bases, scalars, threads=1) -> np.ndarray:
+    bases = np.ascontiguousarray(bases, dtype=np.uint8); scalars = np.ascontiguousarray(scalars, dtype=np.uint64)
+    n = scalars.shape[0]; stride = bases.shape[1] if n else 200
+    out = np.zeros(36, dtype=np.uint64)
+    rc = lib().oracle_msm_g2(_p(out), _p(bases), stride, _p(scalars), n, threads); assert rc == 0
+    return out
+
+
+def g2_multiples(base200, n) -> np.ndarray:
+    out = np.zeros((n, 200), dtype=np.uint8); b = np.ascontiguousarray(base200, dtype=np.uint8)
+    lib().oracle_g2_multiples(_p(out), _p(b), n); return out

@@ -497,3 +497,117 @@ void oracle_fr_divide_by_linear(void* q, void* eval, const void* p, size_t n, co
   }
   if (n == 0) *(Fr*)eval = s;
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * G2 (curves/src/bls12_377/{fq2,g2}.rs + the same short_weierstrass_jacobian templates [UPSTREAM-RECALL]):
+ * Fq2 = Fq[u] / (u^2 + 5)  (NONRESIDUE = -5), y^2 = x^3 + B with B = (0, 155198...874906) — constants checked in
+ * tests/test_oracle.py (generator on the curve, r * G2 = O).  VariableBase::msm sends every curve except BLS12-377 G1 to
+ * standard::msm, restated below for G2Affine = {x: Fq2, y: Fq2, infinity: bool} (200-byte stride), result Jacobian (288 bytes).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct { Fq c0, c1; } Fq2;
+typedef struct { Fq2 x, y; uint8_t infinity; uint8_t pad[7]; } G2Affine;   /* sizeof == 200 */
+typedef struct { Fq2 x, y, z; } G2Proj;
+
+static inline int Fq2_is_zero(const Fq2* a) { return Fq_is_zero(&a->c0) && Fq_is_zero(&a->c1); }
+static inline int Fq2_eq(const Fq2* a, const Fq2* b) { return Fq_eq(&a->c0, &b->c0) && Fq_eq(&a->c1, &b->c1); }
+static inline void Fq2_add(Fq2* r, const Fq2* a, const Fq2* b) { Fq_add(&r->c0, &a->c0, &b->c0); Fq_add(&r->c1, &a->c1, &b->c1); }
+static inline void Fq2_sub(Fq2* r, const Fq2* a, const Fq2* b) { Fq_sub(&r->c0, &a->c0, &b->c0); Fq_sub(&r->c1, &a->c1, &b->c1); }
+static inline void Fq2_dbl(Fq2* r, const Fq2* a) { Fq2_add(r, a, a); }
+static inline void Fq2_neg(Fq2* r, const Fq2* a) { Fq_neg(&r->c0, &a->c0); Fq_neg(&r->c1, &a->c1); }
+static inline void Fq_mul5(Fq* r, const Fq* a) { Fq t; Fq_dbl(&t, a); Fq_dbl(&t, &t); Fq_add(r, &t, a); }
+static void Fq2_mul(Fq2* r, const Fq2* a, const Fq2* b) {              /* schoolbook: (a0 b0 - 5 a1 b1, a0 b1 + a1 b0) */
+  Fq v0, v1, t0, t1, n5; Fq_mul(&v0, &a->c0, &b->c0); Fq_mul(&v1, &a->c1, &b->c1);
+  Fq_mul(&t0, &a->c0, &b->c1); Fq_mul(&t1, &a->c1, &b->c0);
+  Fq_mul5(&n5, &v1); Fq_sub(&r->c0, &v0, &n5); Fq_add(&r->c1, &t0, &t1);
+}
+static inline void Fq2_sqr(Fq2* r, const Fq2* a) { Fq2 t = *a; Fq2_mul(r, &t, &t); }
+static void Fq2_inv(Fq2* r, const Fq2* a) {                             /* (a0 - a1 u) / (a0^2 + 5 a1^2) */
+  Fq n, t, s5; Fq_sqr(&n, &a->c0); Fq_sqr(&t, &a->c1); Fq_mul5(&s5, &t); Fq_add(&n, &n, &s5); Fq_inv(&n, &n);
+  Fq_mul(&r->c0, &a->c0, &n); Fq_mul(&t, &a->c1, &n); Fq_neg(&r->c1, &t);
+}
+static const Fq2 FQ2_ONE_INIT = {{{0x02cdffffffffff68ULL, 0x51409f837fffffb1ULL, 0x9f7db3a98a7d3ff2ULL, 0x7b4e97b76e7c6305ULL, 0x4cf495bf803c84e8ULL, 0x008d6661e2fdf49aULL}}, {{0, 0, 0, 0, 0, 0}}};
+static inline void g2p_zero(G2Proj* p) { p->x = FQ2_ONE_INIT; p->y = FQ2_ONE_INIT; memset(&p->z, 0, sizeof p->z); }
+static inline int g2p_is_zero(const G2Proj* p) { return Fq2_is_zero(&p->z); }
+static void g2p_double(G2Proj* p) {                                     /* dbl-2009-l (a = 0) */
+  if (g2p_is_zero(p)) return;
+  Fq2 A, B, C, D, E, F, t; Fq2_sqr(&A, &p->x); Fq2_sqr(&B, &p->y); Fq2_sqr(&C, &B);
+  Fq2_add(&t, &p->x, &B); Fq2_sqr(&t, &t); Fq2_sub(&t, &t, &A); Fq2_sub(&t, &t, &C); Fq2_dbl(&D, &t);
+  Fq2_dbl(&E, &A); Fq2_add(&E, &E, &A); Fq2_sqr(&F, &E);
+  Fq2 z3; Fq2_mul(&z3, &p->y, &p->z); Fq2_dbl(&z3, &z3);
+  Fq2 x3; Fq2_dbl(&t, &D); Fq2_sub(&x3, &F, &t);
+  Fq2 c8; Fq2_dbl(&c8, &C); Fq2_dbl(&c8, &c8); Fq2_dbl(&c8, &c8);
+  Fq2 y3; Fq2_sub(&t, &D, &x3); Fq2_mul(&y3, &E, &t); Fq2_sub(&y3, &y3, &c8);
+  p->x = x3; p->y = y3; p->z = z3;
+}
+static void g2p_add_mixed(G2Proj* p, const G2Affine* q) {               /* madd-2007-bl */
+  if (q->infinity) return;
+  if (g2p_is_zero(p)) { p->x = q->x; p->y = q->y; p->z = FQ2_ONE_INIT; return; }
+  Fq2 z1z1, u2, s2, t; Fq2_sqr(&z1z1, &p->z); Fq2_mul(&u2, &q->x, &z1z1); Fq2_mul(&t, &q->y, &p->z); Fq2_mul(&s2, &t, &z1z1);
+  if (Fq2_eq(&p->x, &u2) && Fq2_eq(&p->y, &s2)) { g2p_double(p); return; }
+  Fq2 h, hh, i, j, r, v; Fq2_sub(&h, &u2, &p->x); Fq2_sqr(&hh, &h); Fq2_dbl(&i, &hh); Fq2_dbl(&i, &i); Fq2_mul(&j, &h, &i);
+  Fq2_sub(&r, &s2, &p->y); Fq2_dbl(&r, &r); Fq2_mul(&v, &p->x, &i);
+  Fq2 x3, y3, z3; Fq2_sqr(&x3, &r); Fq2_sub(&x3, &x3, &j); Fq2_dbl(&t, &v); Fq2_sub(&x3, &x3, &t);
+  Fq2_sub(&t, &v, &x3); Fq2_mul(&y3, &r, &t); Fq2_mul(&t, &p->y, &j); Fq2_dbl(&t, &t); Fq2_sub(&y3, &y3, &t);
+  Fq2_add(&z3, &p->z, &h); Fq2_sqr(&z3, &z3); Fq2_sub(&z3, &z3, &z1z1); Fq2_sub(&z3, &z3, &hh);
+  p->x = x3; p->y = y3; p->z = z3;
+}
+static void g2p_add(G2Proj* p, const G2Proj* q) {                       /* add-2007-bl */
+  if (g2p_is_zero(q)) return;
+  if (g2p_is_zero(p)) { *p = *q; return; }
+  Fq2 z1z1, z2z2, u1, u2, s1, s2, t; Fq2_sqr(&z1z1, &p->z); Fq2_sqr(&z2z2, &q->z);
+  Fq2_mul(&u1, &p->x, &z2z2); Fq2_mul(&u2, &q->x, &z1z1);
+  Fq2_mul(&t, &p->y, &q->z); Fq2_mul(&s1, &t, &z2z2); Fq2_mul(&t, &q->y, &p->z); Fq2_mul(&s2, &t, &z1z1);
+  if (Fq2_eq(&u1, &u2) && Fq2_eq(&s1, &s2)) { g2p_double(p); return; }
+  Fq2 h, i, j, r, v; Fq2_sub(&h, &u2, &u1); Fq2_dbl(&i, &h); Fq2_sqr(&i, &i); Fq2_mul(&j, &h, &i);
+  Fq2_sub(&r, &s2, &s1); Fq2_dbl(&r, &r); Fq2_mul(&v, &u1, &i);
+  Fq2 x3, y3, z3; Fq2_sqr(&x3, &r); Fq2_sub(&x3, &x3, &j); Fq2_dbl(&t, &v); Fq2_sub(&x3, &x3, &t);
+  Fq2_sub(&t, &v, &x3); Fq2_mul(&y3, &r, &t); Fq2_mul(&t, &s1, &j); Fq2_dbl(&t, &t); Fq2_sub(&y3, &y3, &t);
+  Fq2_add(&z3, &p->z, &q->z); Fq2_sqr(&z3, &z3); Fq2_sub(&z3, &z3, &z1z1); Fq2_sub(&z3, &z3, &z2z2); Fq2_mul(&z3, &z3, &h);
+  p->x = x3; p->y = y3; p->z = z3;
+}
+static void g2p_to_affine(G2Affine* a, const G2Proj* p) {
+  memset(a, 0, sizeof *a);
+  if (g2p_is_zero(p)) { a->y = FQ2_ONE_INIT; a->infinity = 1; return; }
+  Fq2 zi, zi2, zi3; Fq2_inv(&zi, &p->z); Fq2_sqr(&zi2, &zi); Fq2_mul(&zi3, &zi2, &zi);
+  Fq2_mul(&a->x, &p->x, &zi2); Fq2_mul(&a->y, &p->y, &zi3);
+}
+static void g2_load(G2Affine* b, const uint8_t* src, size_t stride) { memset(b, 0, sizeof *b); memcpy(b, src, 192); b->infinity = (stride == 200) ? (src[192] != 0) : 0; }
+
+/* standard::msm over G2 (windows run one after the other; `threads` is accepted for symmetry and ignored) */
+int oracle_msm_g2(void* out, const void* bases_, size_t stride, const void* scalars_, size_t n, int threads) {
+  (void)threads;
+  if (stride != 200 && stride != 192) return -1;
+  G2Affine* bases = (G2Affine*)malloc(sizeof(G2Affine) * (n ? n : 1));
+  for (size_t i = 0; i < n; ++i) g2_load(&bases[i], (const uint8_t*)bases_ + i * stride, stride);
+  const u64* scalars = (const u64*)scalars_;
+  unsigned c = n < 32 ? 3 : ln_without_floats(n) + 2;
+  int nw = (FR_BITS + c - 1) / c; size_t nb = ((size_t)1 << c) - 1;
+  G2Proj* win = (G2Proj*)malloc(sizeof(G2Proj) * nw); G2Proj* buckets = (G2Proj*)malloc(sizeof(G2Proj) * nb);
+  for (int w = 0; w < nw; ++w) {
+    G2Proj res; g2p_zero(&res);
+    for (size_t i = 0; i < nb; ++i) g2p_zero(&buckets[i]);
+    for (size_t i = 0; i < n; ++i) {
+      const u64* s = scalars + 4 * i;
+      if (scalar_is_zero(s)) continue;
+      if (scalar_is_one(s)) { if (w == 0) g2p_add_mixed(&res, &bases[i]); continue; }
+      u64 d = scalar_window(s, w * c, c);
+      if (d != 0) g2p_add_mixed(&buckets[d - 1], &bases[i]);
+    }
+    G2Proj running; g2p_zero(&running);
+    for (size_t b = nb; b-- > 0;) { g2p_add(&running, &buckets[b]); g2p_add(&res, &running); }
+    win[w] = res;
+  }
+  G2Proj total; g2p_zero(&total);
+  for (int w = nw - 1; w >= 1; --w) { g2p_add(&total, &win[w]); for (unsigned d = 0; d < c; ++d) g2p_double(&total); }
+  g2p_add(&total, &win[0]);
+  memcpy(out, &total, sizeof total);
+  free(win); free(buckets); free(bases);
+  return 0;
+}
+void oracle_g2_to_affine(void* out200, const void* jac288) { G2Proj p; memcpy(&p, jac288, sizeof p); G2Affine a; g2p_to_affine(&a, &p); memcpy(out200, &a, 200); }
+/* P_i = (i + 1) * base by repeated mixed addition, affine out (200-byte rows) */
+void oracle_g2_multiples(void* out200, const void* base200, size_t n) {
+  G2Affine g; g2_load(&g, (const uint8_t*)base200, 200);
+  G2Proj run; g2p_zero(&run);
+  for (size_t i = 0; i < n; ++i) { g2p_add_mixed(&run, &g); G2Affine a; g2p_to_affine(&a, &run); memcpy((uint8_t*)out200 + 200 * i, &a, 200); }
+}

@@ -217,6 +217,73 @@ def g1_compress(P) -> bytes:
 
 
 # ----------------------------------------------------------------------------------------------
+# G2 over Fq2 = Fq[u]/(u^2 + 5)  (snarkvm-curves bls12_377/{fq2,g2}.rs [UPSTREAM-RECALL]; constants checked in tests/test_oracle.py:
+# the generator lies on y^2 = x^3 + G2_COEFF_B and r * G2_GENERATOR = O).  Elements are (c0, c1) tuples of canonical ints.
+# ----------------------------------------------------------------------------------------------
+FQ2_NONRESIDUE = Q - 5
+G2_COEFF_B = (0, 155198655607781456406391640216936120121836107652948796323930557600032281009004493664981332883744016074664192874906)
+G2_GENERATOR = (
+    (233578398248691099356572568220835526895379068987715365179118596935057653620464273615301663571204657964920925606294,
+     140913150380207355837477652521042157274541796891053068589147167627541651775299824604154852141315666357241556069118),
+    (63160294768292073209381361943935198908131692476676907196754037919244929611450776219210369229519898517858833747423,
+     149157405641012693445398062341192467754805999074082136895788947234480009303640899064710353187729182149407503257491),
+)
+
+
+def fq2_add(a, b): return ((a[0] + b[0]) % Q, (a[1] + b[1]) % Q)
+def fq2_sub(a, b): return ((a[0] - b[0]) % Q, (a[1] - b[1]) % Q)
+def fq2_mul(a, b): return ((a[0] * b[0] + FQ2_NONRESIDUE * a[1] * b[1]) % Q, (a[0] * b[1] + a[1] * b[0]) % Q)
+def fq2_inv(a):
+    n = pow((a[0] * a[0] - FQ2_NONRESIDUE * a[1] * a[1]) % Q, -1, Q)
+    return (a[0] * n % Q, (-a[1] * n) % Q)
+
+
+def g2_is_on_curve(P) -> bool:
+    if P is None: return True
+    x, y = P
+    return fq2_mul(y, y) == fq2_add(fq2_mul(fq2_mul(x, x), x), G2_COEFF_B)
+
+
+def g2_neg(P): return None if P is None else (P[0], ((-P[1][0]) % Q, (-P[1][1]) % Q))
+
+
+def g2_add(P, S):
+    if P is None: return S
+    if S is None: return P
+    if P[0] == S[0]:
+        if P[1] != S[1] or P[1] == (0, 0): return None
+        lam = fq2_mul(fq2_mul((3, 0), fq2_mul(P[0], P[0])), fq2_inv(fq2_mul((2, 0), P[1])))
+    else:
+        lam = fq2_mul(fq2_sub(S[1], P[1]), fq2_inv(fq2_sub(S[0], P[0])))
+    x = fq2_sub(fq2_sub(fq2_mul(lam, lam), P[0]), S[0])
+    return (x, fq2_sub(fq2_mul(lam, fq2_sub(P[0], x)), P[1]))
+
+
+def g2_mul(P, k: int):
+    acc = None
+    for bit in bin(k % FR_MODULUS)[2:] if k % FR_MODULUS else '':
+        acc = g2_add(acc, acc)
+        if bit == '1': acc = g2_add(acc, P)
+    return acc
+
+
+def g2_mul_raw(P, k: int):
+    """k * P without reducing k mod r (subgroup check)."""
+    acc = None
+    for bit in bin(k)[2:]:
+        acc = g2_add(acc, acc)
+        if bit == '1': acc = g2_add(acc, P)
+    return acc
+
+
+def msm_naive_g2(bases, scalars):
+    acc = None
+    for P, s in zip(bases, scalars):
+        if P is not None and s % FR_MODULUS: acc = g2_add(acc, g2_mul(P, s))
+    return acc
+
+
+# ----------------------------------------------------------------------------------------------
 # bech32m (BIP-350) decode, for the `proof1…` fixture
 # ----------------------------------------------------------------------------------------------
 _B32 = 'qpzry9x8gf2tvdw0s3jn54khce6mua7l'

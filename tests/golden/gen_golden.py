@@ -8,6 +8,7 @@
                         (aleo1 addresses, at1 / as1 / ar1 ids, record1 ciphertexts) in transaction.rs:100, rust/src/test_utils/mod.rs:
                         132-142 and wasm/tests/offchain.rs:106, with their decoding (Edwards-BLS12 y for every group x).  Needs /root/reference.
   msm_small.json        Python big-integer MSM known answers (oracle/pyref.py msm_naive: double-and-add, no windows).
+  msm_g2_small.json     the same for G2 over Fq2 (oracle/pyref.py msm_naive_g2).
   ntt_small.json        O(n^2) DFT known answers for fft / ifft / coset_fft / coset_ifft.
 
 Run from the repo root:  python tests/golden/gen_golden.py
@@ -120,6 +121,25 @@ def gen_msm():
     json.dump({'generator': [hex(p.G1_GENERATOR[0]), hex(p.G1_GENERATOR[1])], 'cases': cases}, open(os.path.join(HERE, 'msm_small.json'), 'w'))
 
 
+def gen_msm_g2():
+    rng = p.SplitMix64(0xA1E00005); r = p.FR_MODULUS
+    cases = []
+    for n, kind in ((1, 'uniform'), (2, 'uniform'), (7, 'r_minus_1'), (31, 'mixed'), (33, 'uniform'), (64, 'small')):
+        mult = [(rng.next() % 200) + 1 for _ in range(n)]
+        bases = [p.g2_mul(p.G2_GENERATOR, k) for k in mult]
+        if kind == 'uniform': sc = [rng.fr() for _ in range(n)]
+        elif kind == 'r_minus_1': sc = [r - 1] * n
+        elif kind == 'small': sc = [rng.next() & 0xFFFF for _ in range(n)]
+        else: sc = [[0, 1, r - 1, rng.fr(), rng.next() & 0xFFFF][i % 5] for i in range(n)]
+        res = p.msm_naive_g2(bases, sc)
+        assert res == p.g2_mul(p.G2_GENERATOR, sum(m * v for m, v in zip(mult, sc)) % r)
+        cases.append({'n': n, 'kind': kind, 'base_multipliers': mult, 'scalars': [hex(v) for v in sc],
+                      'result': None if res is None else [[hex(res[0][0]), hex(res[0][1])], [hex(res[1][0]), hex(res[1][1])]]})
+    g = p.G2_GENERATOR
+    json.dump({'generator': [[hex(g[0][0]), hex(g[0][1])], [hex(g[1][0]), hex(g[1][1])]], 'coeff_b': [hex(v) for v in p.G2_COEFF_B], 'cases': cases},
+              open(os.path.join(HERE, 'msm_g2_small.json'), 'w'))
+
+
 def gen_ntt():
     rng = p.SplitMix64(0xA1E00003)
     cases = []
@@ -135,5 +155,5 @@ def gen_ntt():
 
 
 if __name__ == '__main__':
-    gen_reference_proof(); gen_reference_literals(); gen_msm(); gen_ntt()
+    gen_reference_proof(); gen_reference_literals(); gen_msm(); gen_msm_g2(); gen_ntt()
     print('golden fixtures written to', HERE)

@@ -795,3 +795,60 @@ def test_kzg_open_matches_oracle():
             assert (ev == ee).all()
             assert (w == c.kzg_commit(B[: n - 1], eq, threads=8)).all()
             pb.precompute()
+
+
+# ---- G2 MSM ------------------------------------------------------------------------------------------------
+def _g2pt(v): return None if v is None else ((int(v[0][0], 16), int(v[0][1], 16)), (int(v[1][0], 16), int(v[1][1], 16)))
+
+
+def _g2_multiples(n):
+    return c.g2_multiples(c.g2_affine_from_ints([p.G2_GENERATOR])[0], n)
+
+
+def test_msm_g2_golden_vectors():
+    fx = json.load(open(os.path.join(G, 'msm_g2_small.json')))
+    mult = _g2_multiples(200)
+    for case in fx['cases']:
+        B = mult[np.array(case['base_multipliers']) - 1]; S = c.ints_to_limbs(_ints(case['scalars']), 4)
+        assert c.g2_jac_to_int_point(M.msm_g2(B, S)) == _g2pt(case['result']), (case['n'], case['kind'])
+
+
+@pytest.mark.parametrize('n', [1, 2, 3, 31, 32, 33, 255, 1000, 4097, 1 << 14])
+def test_msm_g2_matches_oracle(n):
+    B = _g2_multiples(n)
+    for kind in ('uniform', 'witness'):
+        S = util.uniform_scalars(n, 16000 + n) if kind == 'uniform' else util.witness_like_scalars(n, 16500 + n)
+        got = M.msm_g2(B, S)
+        k = synth.weighted_scalar_sum(S, 1)
+        assert c.g2_jac_to_int_point(got) == p.g2_mul(p.G2_GENERATOR, k), (n, kind)          # structured identity in big integers
+        if n <= 4097: assert c.g2_jac_to_int_point(c.msm_g2(B, S)) == c.g2_jac_to_int_point(got)      # and the oracle's standard::msm
+        assert (M.msm_g2(np.ascontiguousarray(B[:, :192]), S) == got).all()                           # stride 192
+
+
+def test_msm_g2_edge_cases():
+    n = 300
+    B = _g2_multiples(n)
+    assert c.g2_jac_to_int_point(M.msm_g2(B[:0], np.zeros((0, 4), dtype=np.uint64))) is None              # empty
+    assert c.g2_jac_to_int_point(M.msm_g2(B, np.zeros((n, 4), dtype=np.uint64))) is None                   # all zero
+    ones = np.zeros((n, 4), dtype=np.uint64); ones[:, 0] = 1
+    assert c.g2_jac_to_int_point(M.msm_g2(B, ones)) == p.g2_mul(p.G2_GENERATOR, n * (n + 1) // 2)
+    rm1 = np.tile(c.ints_to_limbs([p.FR_MODULUS - 1], 4), (n, 1))
+    assert c.g2_jac_to_int_point(M.msm_g2(B, rm1)) == p.g2_neg(p.g2_mul(p.G2_GENERATOR, n * (n + 1) // 2))
+    same = np.repeat(B[:1], n, axis=0); S = util.uniform_scalars(n, 16900)                                  # one base repeated: doublings
+    assert c.g2_jac_to_int_point(M.msm_g2(same, S)) == p.g2_mul(p.G2_GENERATOR, sum(c.limbs_to_ints(S)) % p.FR_MODULUS)
+    eq = np.tile(util.uniform_scalars(1, 16901), (n, 1))                                                    # one bucket per window
+    assert c.g2_jac_to_int_point(M.msm_g2(B, eq)) == p.g2_mul(p.G2_GENERATOR, synth.weighted_scalar_sum(eq, 1))
+    neg = c.g2_affine_from_ints([p.g2_neg(p.G2_GENERATOR)])
+    pm = np.concatenate([B[:1], neg] * 40, axis=0); s77 = np.zeros((80, 4), dtype=np.uint64); s77[:, 0] = 77  # P, -P cancel
+    assert c.g2_jac_to_int_point(M.msm_g2(pm, s77)) is None
+    Binf = B.copy(); Binf[5] = 0; Binf[5, 192] = 1; Binf[77] = 0; Binf[77, 192] = 1                          # infinity bases are skipped
+    S = util.uniform_scalars(n, 16902)
+    assert c.g2_jac_to_int_point(M.msm_g2(Binf, S)) == c.g2_jac_to_int_point(c.msm_g2(Binf, S))
+    parts = np.stack([M.msm_g2(B[:100], S[:100]), M.msm_g2(B[100:], S[100:]), M.msm_g2(B[:0], S[:0])])      # shard + g2_sum (identity included)
+    assert (M.g2_sum(parts) == M.msm_g2(B, S)).all()
+
+
+def test_msm_g2_2_16_structured_identity():
+    n = 1 << 16
+    B = _g2_multiples(n); S = util.uniform_scalars(n, 16999)
+    assert c.g2_jac_to_int_point(M.msm_g2(B, S)) == p.g2_mul(p.G2_GENERATOR, synth.weighted_scalar_sum(S, 1))

@@ -139,3 +139,22 @@ def test_oracle_divide_by_linear_matches_bigint():
         for i, v in enumerate(qi): back[i + 1] = (back[i + 1] + v) % r; back[i] = (back[i] - z * v) % r
         back[0] = (back[0] + e) % r
         assert back == f
+
+
+def _g2pt(v): return None if v is None else ((int(v[0][0], 16), int(v[0][1], 16)), (int(v[1][0], 16), int(v[1][1], 16)))
+
+
+def test_g2_constants_and_oracle_msm_match_golden():
+    """Fq2 non-residue -5, the G2 curve coefficient and generator [UPSTREAM-RECALL] are self-consistent (on the curve, r-torsion);
+    the C oracle's G2 standard::msm equals the big-integer known answers."""
+    assert pow(p.FQ2_NONRESIDUE, (p.FQ_MODULUS - 1) // 2, p.FQ_MODULUS) == p.FQ_MODULUS - 1
+    assert p.g2_is_on_curve(p.G2_GENERATOR) and p.g2_mul_raw(p.G2_GENERATOR, p.FR_MODULUS) is None
+    fx = json.load(open(os.path.join(G, 'msm_g2_small.json')))
+    assert _g2pt(fx['generator']) == p.G2_GENERATOR
+    gen = c.g2_affine_from_ints([p.G2_GENERATOR])[0]
+    mult = c.g2_multiples(gen, 200)
+    assert c.g2_affine_to_ints(mult[[0, 6, 199]]) == [p.g2_mul(p.G2_GENERATOR, k) for k in (1, 7, 200)]
+    for case in fx['cases']:
+        B = mult[np.array(case['base_multipliers']) - 1]; S = c.ints_to_limbs(_ints(case['scalars']), 4)
+        assert c.g2_jac_to_int_point(c.msm_g2(B, S)) == _g2pt(case['result']), (case['n'], case['kind'])
+        assert c.g2_jac_to_int_point(c.msm_g2(np.ascontiguousarray(B[:, :192]), S)) == _g2pt(case['result'])       # stride 192
