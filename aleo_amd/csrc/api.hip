@@ -305,9 +305,9 @@ int32_t aleo_mi355x_bases_info(uint64_t handle, uint64_t* out, int32_t cap) {
     if (!out || cap <= 0) return 0;
     Device* d = nullptr; if (get_device(&d)) return 0;
     std::shared_ptr<PinnedOwner> keep; PinnedBases pb; if (find_bases(d, handle, &keep, &pb)) return 0;
-    uint64_t v[8] = {pb.n, pb.n * (96 + 112) + (pb.d_inf ? pb.n : 0), 0, 0, 0, 0, 0, 0};
+    uint64_t v[8] = {pb.n, pb.n * (96 + ROW28) + (pb.d_inf ? pb.n : 0), 0, 0, 0, 0, 0, 0};
     int k = 0;
-    for (const auto& t : pb.tab) if (t.d) { const uint64_t W = (254 + t.c - 1) / t.c; v[2] += W * t.cover * 112; v[3 + k] = (uint64_t)t.c; ++k; }
+    for (const auto& t : pb.tab) if (t.d) { const uint64_t W = (254 + t.c - 1) / t.c; v[2] += W * t.cover * ROW28; v[3 + k] = (uint64_t)t.c; ++k; }
     v[6] = (uint64_t)k;
     const int32_t m = cap < 8 ? cap : 8;
     for (int32_t i = 0; i < m; ++i) out[i] = v[i];

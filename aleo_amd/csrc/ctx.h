@@ -51,6 +51,14 @@ struct DevTmp {
   void* release() { void* q = p; p = nullptr; return q; }
 };
 
+// Stride of a point row in the 28-bit-limb form (x'[14] | y'[14] = 112 payload bytes).  112 packs the rows; 128 gives every row its
+// own 128-byte line (one memory request per gathered point instead of 1.75 on average) for 14 % more HBM per table.
+#ifndef ALEO_ROW28
+#define ALEO_ROW28 128
+#endif
+static constexpr size_t ROW28 = ALEO_ROW28;
+static_assert(ROW28 == 112 || ROW28 == 128, "row stride of the 28-bit tables");
+
 struct PinnedBases {
   void* d_xy = nullptr;        // n x 96 bytes: x | y, Montgomery, canonical
   void* d_xy28 = nullptr;      // n x 112 bytes: the same points in the 28-bit-limb form the accumulation kernels compute in (fp28.h)

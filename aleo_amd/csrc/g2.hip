@@ -312,7 +312,7 @@ int32_t msm_g2_run(Ctx* c, uint64_t* out_jac36, const void* d_xy, const uint8_t*
   auto lazy2 = [](const uint64_t* p) { HFq2 r; r.a = HFq::reduce_lazy(p); r.b = HFq::reduce_lazy(p + 6); return r; };
   HXYZZ2 total = HXYZZ2::infinity();
   for (int w = (int)P.W - 1; w >= 0; --w) {
-    for (uint32_t d = 0; d < P.c; ++d) total = h2double(total);
+    for (int d = 0; d < plan_win_width((int)P.c, w); ++d) total = h2double(total);
     const uint64_t* src = (const uint64_t*)(h_win + (size_t)w * 384);
     HXYZZ2 v; v.X = lazy2(src); v.Y = lazy2(src + 12); v.ZZ = lazy2(src + 24); v.ZZZ = lazy2(src + 36);
     total = h2add(total, v);

@@ -64,24 +64,34 @@ template <bool MONT> __device__ __forceinline__ void load_scalar(const void* sca
     for (int k = 0; k < 8; ++k) s[k] = f.v[k];
   }
 }
+// Balanced windows.  W = ceil(254 / C) windows cover exactly 254 bits: the top D = W*C - 254 windows are C-1 bits wide, so no
+// window is short.  (With W uniform C-bit windows the last one keeps 254 - (W-1)*C bits — 14 of 20 at C = 20, 7 of 13 at C = 13 — and
+// its few buckets receive n / 2^13 .. n / 2^6 points each: on the table path, where all windows share one bucket set, those
+// buckets had to be cut into slices and folded by 3-10 extra tree launches.)  Window w starts at bit win_offset(C, w).
+__host__ __device__ constexpr int win_count(int c) { return ((int)SCALAR_BITS + c - 1) / c; }
+__host__ __device__ constexpr int win_full(int c) { return win_count(c) - (win_count(c) * c - (int)SCALAR_BITS); }      // windows of the full width c
+__host__ __device__ constexpr int win_width(int c, int w) { return w < win_full(c) ? c : c - 1; }
+__host__ __device__ constexpr int win_offset(int c, int w) { return w <= win_full(c) ? w * c : win_full(c) * c + (w - win_full(c)) * (c - 1); }
+
 template <int C, int W_IDX> __device__ __forceinline__ uint32_t window_raw(const uint32_t (&s)[8]) {
-  constexpr int bit = C * W_IDX, limb = bit >> 5, off = bit & 31;
+  constexpr int bit = win_offset(C, W_IDX), width = win_width(C, W_IDX), limb = bit >> 5, off = bit & 31;
   uint32_t v = 0;
   if constexpr (limb < 8) {
     v = s[limb] >> off;
-    if constexpr (off + C > 32 && limb + 1 < 8) v |= s[limb + 1] << (32 - off);
+    if constexpr (off + width > 32 && limb + 1 < 8) v |= s[limb + 1] << (32 - off);
   }
-  return v & ((1u << C) - 1u);
+  return v & ((1u << width) - 1u);
 }
 
 // Calls f(w, bucket_index_0based, negate) for every non-zero signed digit of the scalar.
 template <int C, int W_IDX, class F> __device__ __forceinline__ void for_each_digit(const uint32_t (&s)[8], uint32_t carry, F&& f) {
-  constexpr int W = (SCALAR_BITS + C - 1) / C;
+  constexpr int W = win_count(C);
   if constexpr (W_IDX < W) {
-    constexpr uint32_t B = 1u << (C - 1);
+    constexpr int width = win_width(C, W_IDX);
+    constexpr uint32_t B = 1u << (width - 1);
     uint32_t d = window_raw<C, W_IDX>(s) + carry;
     uint32_t neg = d > B ? 1u : 0u;
-    uint32_t mag = neg ? (1u << C) - d : d;
+    uint32_t mag = neg ? (1u << width) - d : d;
     if (mag) f((uint32_t)W_IDX, mag - 1u, neg);
     for_each_digit<C, W_IDX + 1>(s, neg, f);
   }
@@ -459,7 +469,7 @@ __device__ __noinline__ void slice_slow_path28(const char* bases, const uint32_t
   XYZZ acc = xyzz28_to_xyzz(*acc28); bool inf = false;
   for (; j < j1; ++j) {
     uint32_t e = run[j];
-    F28 x, y; load_affine28(bases + (size_t)(e & 0x7fffffffu) * 112, x, y);
+    F28 x, y; load_affine28(bases + (size_t)(e & 0x7fffffffu) * ROW28, x, y);
     AffinePt p; p.x = Fq::reduce(f28_to_fq(x)); p.y = Fq::reduce(f28_to_fq(y));
     if (e >> 31) p.y = fq_neg_canonical(p.y);
     xyzz_madd(acc, inf, p.x, p.y);
@@ -480,19 +490,19 @@ __global__ void __launch_bounds__(256) k_accum28(const char* __restrict__ bases,
   uint32_t j0 = (uint32_t)(((uint64_t)k * cnt) / m), j1 = (uint32_t)(((uint64_t)(k + 1) * cnt) / m);
   const uint32_t* run = sorted + st.x;
   uint32_t e_next = run[j0];
-  F28 xn, yn; load_affine28(bases + (size_t)(e_next & 0x7fffffffu) * 112, xn, yn);      // next point's 112-byte gather in flight under the current addition
+  F28 xn, yn; load_affine28(bases + (size_t)(e_next & 0x7fffffffu) * ROW28, xn, yn);      // next point's 112-byte gather in flight under the current addition
   XYZZ28 acc; bool ok = true;
   uint32_t j = j0;
   {   // first point of the slice: acc = (x, +-y, 1, 1)
     uint32_t e = e_next; F28 x = xn, y = yn;
-    if (j + 1 < j1) { e_next = run[j + 1]; load_affine28(bases + (size_t)(e_next & 0x7fffffffu) * 112, xn, yn); }
+    if (j + 1 < j1) { e_next = run[j + 1]; load_affine28(bases + (size_t)(e_next & 0x7fffffffu) * ROW28, xn, yn); }
     if (e >> 31) y = f28_sub<2, 1>(f28_const(Limbs14{}), y);                            // 2q - y: limbs < 2^29
     acc.X = x; acc.Y = y; acc.ZZ = f28_const(ONE28); acc.ZZZ = f28_const(ONE28);
     ++j;
   }
   for (; j < j1; ++j) {
     uint32_t e = e_next; F28 x = xn, y = yn;
-    if (j + 1 < j1) { e_next = run[j + 1]; load_affine28(bases + (size_t)(e_next & 0x7fffffffu) * 112, xn, yn); }
+    if (j + 1 < j1) { e_next = run[j + 1]; load_affine28(bases + (size_t)(e_next & 0x7fffffffu) * ROW28, xn, yn); }
     if (e >> 31) y = f28_sub<2, 1>(f28_const(Limbs14{}), y);
     if (!xyzz28_madd_fast(acc, x, y)) { ok = false; break; }
   }
@@ -514,7 +524,7 @@ __global__ void __launch_bounds__(256) k_rows_to28(const char* __restrict__ src9
   F28 x, y;
   if (p.x.is_zero_raw() && p.y.is_zero_raw()) { x = f28_const(Limbs14{}); y = x; }
   else { x = f28_from_fq(p.x); y = f28_from_fq(p.y); }
-  store_affine28(dst112 + (size_t)i * 112, x, y);
+  store_affine28(dst112 + (size_t)i * ROW28, x, y);
 }
 
 // Every kernel from here to the host tail is a chain of full XYZZ additions with little parallelism, so each addition
@@ -1003,7 +1013,7 @@ int32_t msm_run(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, const MsmJob
     HIPCHK(hipGetLastError());
     // host tail: total = sum_w 2^(c*w) * S_w  (Horner from the top window), then affine normalisation
     for (int w = (int)P.W - 1; w >= 0; --w) {
-      for (uint32_t d = 0; d < P.c; ++d) total = hdouble(total);
+      for (int d = 0; d < win_width((int)P.c, w); ++d) total = hdouble(total);          // window w spans win_width bits (balanced windows)
       total = hadd(total, lazy_point(h_win + (size_t)w * 192));
     }
     hstore_jacobian_normalized(out_jac18, total);
@@ -1151,7 +1161,7 @@ __global__ void __launch_bounds__(256) k_pre_double(char* __restrict__ cur, uint
 int32_t make_rows28(Ctx* c, PinnedBases* pb) {
   if (pb->d_xy28 || pb->n == 0) return ALEO_MI355X_OK;
   DevTmp rows; int32_t rc;
-  if ((rc = rows.alloc(pb->n * 112))) return rc;
+  if ((rc = rows.alloc(pb->n * ROW28))) return rc;
   hipLaunchKernelGGL(k_rows_to28, dim3((uint32_t)((pb->n + 255) / 256)), dim3(256), 0, c->stream, (const char*)pb->d_xy, (char*)rows.p, (uint32_t)pb->n);
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(c->stream));
@@ -1163,17 +1173,17 @@ static int32_t build_table(Ctx* c, const PinnedBases* pb, int pre_c, size_t n, P
   const uint32_t W = (SCALAR_BITS + pre_c - 1) / pre_c;
   if (n * (size_t)W >= (1ull << 31)) { g_last_error = "bases_precompute: table index would exceed 31 bits"; return ALEO_MI355X_ERR_BAD_ARG; }
   DevTmp tab, cur, prefix, row; int32_t rc;     // freed on every return path; tab is handed over at the end
-  if ((rc = tab.alloc(n * 112 * W))) return rc;                              // rows in the accumulation kernel's 28-bit format (fp28.h)
+  if ((rc = tab.alloc(n * ROW28 * W))) return rc;                              // rows in the accumulation kernel's 28-bit format (fp28.h)
   if ((rc = cur.alloc(n * 192)) || (rc = prefix.alloc(n * 48)) || (rc = row.alloc(n * 96))) return rc;
   hipStream_t s = c->stream;
   const uint32_t g = (uint32_t)((n + 255) / 256), lanes = (uint32_t)((n + GEN_K - 1) / GEN_K), gl = (lanes + 255) / 256;
-  if (pb->d_xy28) HIPCHK(hipMemcpyAsync(tab.p, pb->d_xy28, n * 112, hipMemcpyDeviceToDevice, s));
+  if (pb->d_xy28) HIPCHK(hipMemcpyAsync(tab.p, pb->d_xy28, n * ROW28, hipMemcpyDeviceToDevice, s));
   else hipLaunchKernelGGL(k_rows_to28, dim3(g), dim3(256), 0, s, (const char*)pb->d_xy, (char*)tab.p, (uint32_t)n);
   hipLaunchKernelGGL(k_pre_init, dim3(g), dim3(256), 0, s, (const char*)pb->d_xy, (uint32_t)n, (char*)cur.p);
   for (uint32_t w = 1; w < W; ++w) {
-    hipLaunchKernelGGL(k_pre_double, dim3(g), dim3(256), 0, s, (char*)cur.p, (uint32_t)n, pre_c);
+    hipLaunchKernelGGL(k_pre_double, dim3(g), dim3(256), 0, s, (char*)cur.p, (uint32_t)n, win_width(pre_c, (int)w - 1));      // row w = 2^win_offset(w) * P
     hipLaunchKernelGGL(k_gen_normalize, dim3(gl), dim3(256), 0, s, (char*)cur.p, (uint32_t)n, (char*)prefix.p, (char*)row.p);
-    hipLaunchKernelGGL(k_rows_to28, dim3(g), dim3(256), 0, s, (const char*)row.p, (char*)tab.p + (size_t)w * n * 112, (uint32_t)n);
+    hipLaunchKernelGGL(k_rows_to28, dim3(g), dim3(256), 0, s, (const char*)row.p, (char*)tab.p + (size_t)w * n * ROW28, (uint32_t)n);
   }
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(s));

@@ -12,6 +12,8 @@ static constexpr uint32_t SUPER_CAP = 4096;     // buckets with > 16 slices kept
 static constexpr uint32_t MAX_SLICE = 512;      // longest slice pick_rule() can produce
 
 struct MsmPlan { uint32_t c, W, B, M, S; };
+// Balanced windows (msm.hip): the top W*c - 254 windows are c-1 bits wide.
+inline int plan_win_width(int c, int w) { const int W = ((int)SCALAR_BITS + c - 1) / c, full = W - (W * c - (int)SCALAR_BITS); return w < full ? c : c - 1; }
 MsmPlan make_plan(size_t n, int pre_c);
 struct SetArgs { const char* ptr[MAX_SETS]; uint32_t n[MAX_SETS]; };          // scalar vector and length of every set (kernel argument)
 

@@ -183,6 +183,8 @@ def main():
             out['proof_proxy'] = {'2^%d' % lg_: proof_proxy_gpu(aleo_amd, synth, torch, dev, lg_)
                                   for lg_ in sorted({args.proof_proxy_lg, args.proof_proxy_cpu_lg})}
             out['proof_proxy']['schedule'] = PROXY_NOTE
+            out['key_synthesis_proxy'] = {'2^%d' % lg_: index_proxy_gpu(aleo_amd, synth, torch, dev, lg_) for lg_ in sorted({args.proof_proxy_lg, args.proof_proxy_cpu_lg})}
+            out['key_synthesis_proxy']['schedule'] = INDEX_NOTE
             pb = aleo_amd.PinnedBases.generate_multiples(gen, first, n)
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args, pb, scalars, aleo_amd)
@@ -359,6 +361,37 @@ def proof_proxy_gpu(aleo_amd, synth, torch, dev, lg, reps=3):
     n_msm = sum(len(o[1]) for o in ops if o[0] in ('commit', 'open'))
     return {'constraints': H, 'ms': dt * 1e3, 'constraints_per_s': H / dt, 'msm_ms': m * 1e3, 'ntt_and_field_ms': (dt - m) * 1e3,
             'n_msm': n_msm, 'n_msm_calls': sum(1 for o in ops if o[0] in ('commit', 'open')), 'n_ntt': sum(1 for o in ops if o[0] == 'ntt')}
+
+
+INDEX_NOTE = ('operator-level proxy for key synthesis (Process::synthesize_key / vm.deploy -> Varuna circuit indexing, '
+              '/root/reference/wasm/src/programs/manager/mod.rs:164-177, rust/src/program/deploy.rs:142,151): per R1CS matrix A, B, C the four '
+              'arithmetisation polynomials row, col, row_col, row_col_val over the non-zero domain K (batch inversion + products on evaluations), '
+              'interpolated (12 iNTTs in ONE batched call) and committed (12 commitments in ONE batched call) [schedule UPSTREAM-RECALL]; not a key')
+
+
+def index_proxy_gpu(aleo_amd, synth, torch, dev, lg, reps=3):
+    """Key-synthesis shape at |K| = 2^lg non-zeros per matrix."""
+    from aleo_amd import poly
+    K = 1 << lg
+    pb = aleo_amd.PinnedBases.generate_multiples(synth.generator_affine104(), 1, K).precompute()
+    ev = torch.from_numpy(synth.uniform_scalars(12 * K, 0xA1E00040 + lg).view(np.int64)).to(dev)      # 12 evaluation vectors over K, contiguous
+    aux = ev.clone()
+    d = aleo_amd.EvaluationDomain(K)
+    torch.cuda.synchronize()
+
+    def run():
+        for m in range(3):                                   # per matrix: denominators inverted in one pass, then the products that form the four vectors
+            poly.batch_inversion_device(aux.data_ptr() + 32 * 4 * m * K, K, 1)
+            for j in range(4): poly.fr_vec_op_device(ev.data_ptr() + 32 * (4 * m + j) * K, ev.data_ptr() + 32 * (4 * m + j) * K, aux.data_ptr() + 32 * 4 * m * K, K, 0, 1)
+        d.ntt_batch_device(ev.data_ptr(), 12, 0, 1, 0, 1)    # 12 iNTTs, one call
+        torch.cuda.synchronize()
+        return aleo_amd.KZG10.commit_batch_device(pb, [ev.data_ptr() + 32 * j * K for j in range(12)], [K] * 12)
+    run(); ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter(); run(); ts.append(time.perf_counter() - t0)
+    pb.close()
+    dt = float(np.median(ts))
+    return {'nonzeros_per_matrix': K, 'ms': dt * 1e3, 'polynomials': 12, 'nonzeros_per_s': 3 * K / dt}
 
 
 def proof_proxy_cpu(c, aleo_amd, synth, lg, cores):

@@ -3,6 +3,7 @@ hand over pageable host memory, so these wall times include the H2D/D2H copies t
 import os, sys, time, json
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import numpy as np, torch
+os.environ.setdefault('ALEO_MI355X_SRS_CACHE', '1')        # the one-shot probe below measures the opt-in cache
 import aleo_amd
 from aleo_amd import synth, msm as M
 
