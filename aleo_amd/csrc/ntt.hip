@@ -242,7 +242,8 @@ static int32_t build_tables(NttTables* t, uint32_t lg_n, int direction) {
 
 template <uint32_t TE, uint32_t NT>
 static int32_t run_passes(Ctx* c, char* buf, char* tmp, uint32_t lg_n, uint32_t batch, const NttTables* t, int pre_coset, int post_coset, int do_scale, FrArg sc, hipStream_t s) {
-  constexpr uint32_t lgTE = TE == 4096 ? 12 : 11;
+  constexpr uint32_t lgTE = TE == 4096 ? 12 : (TE == 2048 ? 11 : 9);
+  static_assert(TE == 4096 || TE == 2048 || TE == 512, "tile sizes with a kernel instance");
   constexpr size_t lds_bytes = (size_t)TE * 32;
   constexpr int attr_bit = TE == 4096 ? 2 : 1;          // the LDS limit is a property of (kernel, device): remembered per device
   if (lds_bytes > 65536 && !(c->dev->ntt_attr_mask.load() & attr_bit)) {
@@ -359,7 +360,10 @@ static int32_t ntt_run_chunk(Ctx* c, void* d_inout, uint32_t lg_n, uint32_t batc
   FrArg sc; std::memcpy(sc.v, t->scale, 32);
   // 128 KiB tiles: 2^19..2^22 run in two passes (measured 6-16 % faster than three 64 KiB passes); beyond 2^22 three
   // passes are needed either way and two 64 KiB blocks per CU overlap their HBM phases better (2^24: 3.5 vs 4.0 ms)
+  // small transforms are latency-bound on the few blocks a 2048-element tile leaves them (2^16: 32 blocks on 256 CUs): 512-element
+  // tiles of one wave each spread them over the chip (2^16: 0.085 -> see profiles/); batches already have the blocks
   if (lg_n >= 19 && lg_n <= 22) rc = run_passes<4096, 512>(c, buf, tmp, lg_n, batch, t, pre_coset, post_coset, do_scale, sc, s);
+  else if (lg_n >= 10 && lg_n <= 18 && ((size_t)batch << lg_n) <= ((size_t)1 << 18)) rc = run_passes<512, 64>(c, buf, tmp, lg_n, batch, t, pre_coset, post_coset, do_scale, sc, s);
   else rc = run_passes<2048, 256>(c, buf, tmp, lg_n, batch, t, pre_coset, post_coset, do_scale, sc, s);
   if (rc) return rc;
   if (out_rev) {
