@@ -295,18 +295,18 @@ PROXY_NOTE = ('operator-level proxy for constraints/s (SURVEY.md §8d): the MSM/
 def proxy_schedule(lg):
     """[(op, arg, size)] of one Varuna prove_batch for one circuit / one instance with 2^lg constraints, variables and
     non-zeros per matrix (snarkvm-algorithms 0.14.5 snark/varuna/ahp/prover/round_functions [UPSTREAM-RECALL]):
-    12 KZG MSMs in five groups (3 + 1, 2, 3, 1 commitments, 2 openings) and the transforms between them.
-    ('commit', [(kind, size), ...]) = the commitments of one round; ('open', [size, ...]) = witness polynomials + their commitments."""
+    12 KZG MSMs in five groups (3 + 1, 2, 3, 1 commitments, 2 openings) and the 23 transforms between them.
+    ('commit', [(kind, size), ...]) = the commitments of one round; ('open', [size, ...]) = witness polynomials + their commitments;
+    ('ntt', (direction, coset), size, count) = `count` independent transforms of one size issued as ONE batched call."""
     H = 1 << lg
     ops = []
-    ops += [('ntt', (1, 0), H)] * 3                                                     # round 1: interpolate w, z_a, z_b
+    ops += [('ntt', (1, 0), H, 3)]                                                      # round 1: interpolate w, z_a, z_b (independent: one batched call)
     ops += [('commit', [('witness', H)] * 3 + [('uniform', 3 * H)])]                    #          w, z_a, z_b, mask_poly (degree 3|H|)
-    ops += [('ntt', (0, 1), 4 * H)] * 4 + [('vec', 0, 4 * H)] * 6 + [('ntt', (1, 1), 4 * H)]      # round 2: h_1 on the 4|H| coset
-    ops += [('ntt', (0, 0), H)] * 2 + [('commit', [('uniform', H), ('uniform', 2 * H)])]            #          g_1, h_1
-    for _ in range(3):                                                                  # round 3: g_a, g_b, g_c over K
-        ops += [('ntt', (0, 0), H)] * 2 + [('inv', 0, H)] + [('vec', 0, H)] * 4 + [('ntt', (1, 0), H)]
+    ops += [('ntt', (0, 1), 4 * H, 4)] + [('vec', 0, 4 * H)] * 6 + [('ntt', (1, 1), 4 * H, 1)]      # round 2: h_1 on the 4|H| coset
+    ops += [('ntt', (0, 0), H, 2), ('commit', [('uniform', H), ('uniform', 2 * H)])]                #          g_1, h_1
+    ops += [('ntt', (0, 0), H, 6)] + [('inv', 0, H)] * 3 + [('vec', 0, H)] * 12 + [('ntt', (1, 0), H, 3)]   # round 3: g_a, g_b, g_c over K (three matrices side by side)
     ops += [('commit', [('uniform', H)] * 3)]
-    ops += [('ntt', (0, 1), 2 * H)] * 3 + [('vec', 0, 2 * H)] * 4 + [('ntt', (1, 1), 2 * H), ('commit', [('uniform', H)])]   # round 4: h_2
+    ops += [('ntt', (0, 1), 2 * H, 3)] + [('vec', 0, 2 * H)] * 4 + [('ntt', (1, 1), 2 * H, 1), ('commit', [('uniform', H)])]   # round 4: h_2
     ops += [('open', [3 * H, 3 * H])]                                                   # two batched KZG opening proofs
     return ops
 
@@ -315,7 +315,7 @@ def proof_proxy_gpu(aleo_amd, synth, torch, dev, lg, reps=3):
     from aleo_amd import poly, wire
     H = 1 << lg
     pb = aleo_amd.PinnedBases.generate_multiples(synth.generator_affine104(), 1, 3 * H).precompute()
-    buf = torch.from_numpy(synth.uniform_scalars(4 * H, 0xA1E00010 + lg).view(np.int64)).to(dev)      # canonical < r, read as Montgomery
+    buf = torch.from_numpy(synth.uniform_scalars(16 * H, 0xA1E00010 + lg).view(np.int64)).to(dev)     # canonical < r, read as Montgomery; room for 4 x 4H side by side
     aux = buf.clone()
     wit = [torch.from_numpy(wire.fr_from_bytes(synth.witness_like_scalars(H, 0xA1E00012 + lg + 64 * j).view(np.uint8).reshape(-1, 32)).view(np.int64)).to(dev) for j in range(3)]
     quo = [torch.empty((3 * H, 4), dtype=torch.int64, device=dev) for _ in range(2)]
@@ -326,7 +326,7 @@ def proof_proxy_gpu(aleo_amd, synth, torch, dev, lg, reps=3):
 
     def run():
         t_msm = 0.0
-        for op, arg, size in [(o[0], o[1], o[2] if len(o) > 2 else None) for o in ops]:
+        for op, arg, size, cnt in [(o[0], o[1], o[2] if len(o) > 2 else None, o[3] if len(o) > 3 else 1) for o in ops]:
             if op in ('commit', 'open'):
                 torch.cuda.synchronize()             # the queued transforms finish first, so the split below is honest
                 t0 = time.perf_counter()
@@ -345,7 +345,7 @@ def proof_proxy_gpu(aleo_amd, synth, torch, dev, lg, reps=3):
                 t_msm += time.perf_counter() - t0
             elif op == 'ntt':
                 d = doms.get(size) or doms.setdefault(size, aleo_amd.EvaluationDomain(size))
-                d.ntt_device(buf.data_ptr(), 0, arg[0], arg[1], 1)                       # hipStreamLegacy: enqueue only, ordered with torch's stream
+                d.ntt_batch_device(buf.data_ptr(), cnt, 0, arg[0], arg[1], 1)            # hipStreamLegacy: enqueue only, ordered with torch's stream
             elif op == 'vec':
                 poly.fr_vec_op_device(aux.data_ptr(), aux.data_ptr(), buf.data_ptr(), size, 0, 1)
             else:
@@ -360,7 +360,8 @@ def proof_proxy_gpu(aleo_amd, synth, torch, dev, lg, reps=3):
     dt = float(np.median(ts)); m = float(np.median(tm))
     n_msm = sum(len(o[1]) for o in ops if o[0] in ('commit', 'open'))
     return {'constraints': H, 'ms': dt * 1e3, 'constraints_per_s': H / dt, 'msm_ms': m * 1e3, 'ntt_and_field_ms': (dt - m) * 1e3,
-            'n_msm': n_msm, 'n_msm_calls': sum(1 for o in ops if o[0] in ('commit', 'open')), 'n_ntt': sum(1 for o in ops if o[0] == 'ntt')}
+            'n_msm': n_msm, 'n_msm_calls': sum(1 for o in ops if o[0] in ('commit', 'open')), 'n_ntt': sum(o[3] for o in ops if o[0] == 'ntt'),
+            'n_ntt_calls': sum(1 for o in ops if o[0] == 'ntt')}
 
 
 INDEX_NOTE = ('operator-level proxy for key synthesis (Process::synthesize_key / vm.deploy -> Varuna circuit indexing, '
@@ -415,7 +416,7 @@ def proof_proxy_cpu(c, aleo_amd, synth, lg, cores):
                 q, _ = c.fr_divide_by_linear(buf[:m], z[j]); c.msm_g1(bases[:m - 1], q, threads=cores, variant=1)
             t_msm += time.perf_counter() - t1
         elif op == 'ntt':
-            buf[:o[2]] = c.ntt_fr(buf[:o[2]], 0, arg[0], arg[1])
+            for _ in range(o[3]): buf[:o[2]] = c.ntt_fr(buf[:o[2]], 0, arg[0], arg[1])
         elif op == 'vec':
             aux[:o[2]] = c.fr_vec_op(aux[:o[2]], buf[:o[2]], 0)
         else:
