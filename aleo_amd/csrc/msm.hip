@@ -519,91 +519,6 @@ __global__ void __launch_bounds__(256) k_accum28(const char* __restrict__ bases,
   }
 }
 
-// Lane-PAIR form of the accumulation for the latency-bound regime (fewer slices than lanes: lone MSMs of 2^12..2^16 points).  One
-// slice per lane pair; the ten products of a mixed addition run as 4 product blocks + the merged Y block (5.5 product times instead
-// of 9.5), each lane computing what it owns:
-//     block      even lane (holds X, ZZ)        odd lane (holds X, Y, ZZZ)
-//     mul        U2  = x2 * ZZ                  S2   = y2 * ZZZ                 (each lane loads its own half of the point's row)
-//     sqr        PP  = (U2 - X)^2               RR   = (S2 - Y)^2
-//     mul        PPP = P * PP                   Q    = X * PP                   (PP crosses to the odd lane)
-//     mul        ZZ3 = ZZ * PP                  ZZZ3 = ZZZ * PPP                (PPP crosses)
-//     muladd     -                              Y3   = R (Q - X3) - Y PPP       (X3 = RR - PPP - 2Q on the odd lane, crosses back)
-// Same formulas, bounds and limb classes as xyzz28_madd_fast (fp28.h); the same-x case (ZZ3 == 0 mod q, seen by the even lane) hands
-// the rest of the slice to the general code on the even lane.
-template <bool OUT28>
-__global__ void __launch_bounds__(256) k_accum28_pair(const char* __restrict__ bases, const uint32_t* __restrict__ sorted, const uint32_t* __restrict__ hist,
-                                                      const uint2* __restrict__ scan_local, const uint2* __restrict__ scan_blk, const uint32_t* __restrict__ total_pairs, uint32_t M,
-                                                      const uint32_t* __restrict__ meta, const uint32_t* __restrict__ order, const uint32_t* __restrict__ task_g,
-                                                      char* __restrict__ partial) {
-  const uint32_t t = (blockIdx.x * 256 + threadIdx.x) >> 1; const bool odd = threadIdx.x & 1;
-  if (t >= meta[0]) return;                                   // pair-uniform
-  const uint32_t sid = order[t], g = task_g[sid];
-  uint2 st = scan_at(scan_local, scan_blk, g);
-  uint32_t cnt = hist[g], m = slices_of(cnt, pick_rule(total_pairs, M)), k = sid - st.y;
-  uint32_t j0 = (uint32_t)(((uint64_t)k * cnt) / m), j1 = (uint32_t)(((uint64_t)(k + 1) * cnt) / m);
-  const uint32_t* run = sorted + st.x;
-  const uint32_t half = odd ? 56u : 0u;                       // even lane: x', odd lane: y'
-  uint32_t e_next = run[j0];
-  F28 hn = load_f28(bases + (size_t)(e_next & 0x7fffffffu) * ROW28 + half);
-  F28 X, A, B;                                                // X on both lanes; A = ZZ (even) / Y (odd); B = - (even) / ZZZ (odd)
-  bool ok = true; uint32_t j = j0;
-  {   // first point of the slice: acc = (x, +-y, 1, 1)
-    uint32_t e = e_next; F28 h = hn;
-    if (j + 1 < j1) { e_next = run[j + 1]; hn = load_f28(bases + (size_t)(e_next & 0x7fffffffu) * ROW28 + half); }
-    if (odd && (e >> 31)) h = f28_sub<2, 1>(f28_const(Limbs14{}), h);               // 2q - y: limbs < 2^29
-    const F28 other = f28_xchg(h);                                                    // odd lane receives x
-    X = odd ? other : h; A = odd ? h : f28_const(ONE28); B = f28_const(ONE28);
-    ++j;
-  }
-  for (; j < j1; ++j) {
-    uint32_t e = e_next; F28 h = hn;
-    if (j + 1 < j1) { e_next = run[j + 1]; hn = load_f28(bases + (size_t)(e_next & 0x7fffffffu) * ROW28 + half); }
-    if (odd && (e >> 31)) h = f28_sub<2, 1>(f28_const(Limbs14{}), h);
-    F28 m1 = f28_mul(h, odd ? B : A);                                                // even: U2 = x2 * ZZ     odd: S2 = y2 * ZZZ      (< 2q)
-    F28 d = odd ? f28_sub<4, 2>(m1, A) : f28_sub<16, 1>(m1, X);                     // even: P = U2 + 16q - X (L3)   odd: R = S2 + 4q - Y (L4)
-    F28 sq = f28_sqr(d);                                                             // even: PP               odd: RR
-    const F28 sqx = f28_xchg(sq);                                                    // both lanes run every exchange
-    const F28 PP = odd ? sqx : sq;                                                   // PP reaches the odd lane
-    F28 m3 = f28_mul(odd ? X : d, PP);                                               // even: PPP = P * PP     odd: Q = X * PP
-    const F28 x3in = f28_xchg(m3);                                                   // odd lane receives PPP (even lane: Q, unused)
-    const F28 PPP = odd ? x3in : m3;
-    F28 m4 = f28_mul(odd ? B : A, odd ? PPP : PP);                                   // even: ZZ3 = ZZ * PP    odd: ZZZ3 = ZZZ * PPP
-    int z = (!odd && f28_is_zero_mod_lt2q(m4)) ? 1 : 0;
-    z = __shfl(z, (int)(threadIdx.x & 63u & ~1u));
-    if (__builtin_expect(z, 0)) { ok = false; break; }
-    // odd lane: X3 = RR - PPP - 2Q, Y3 = R (Q - X3) - Y PPP; the even lane runs the same blocks on its own values (results unused)
-    F28 t0 = f28_sub<4, 1>(sq, PPP);                                                 // < 6q, class L3
-    F28 X3 = f28_normalise(f28_sub<6, 2>(t0, f28_add(m3, m3)));                      // < 12q, exact digits
-    F28 t1 = f28_sub<16, 1>(m3, X3);                                                 // Q + 16q - X3 < 18q, class L3
-    F28 nY = f28_sub<4, 2>(f28_const(Limbs14{}), A);                                 // 4q - Y, class L3
-    F28 Y3 = f28_muladd(d, t1, nY, PPP);                                             // < 2q
-    const F28 X3e = f28_xchg(X3);                                                    // even lane receives X3
-    X = odd ? X3 : X3e;
-    A = odd ? Y3 : m4;                                                               // even: ZZ3     odd: Y3
-    if (odd) B = m4;                                                                 // odd: ZZZ3
-  }
-  if (ok) {
-    // even lane stores ZZ (from A) and ZZZ (from the odd lane's B); odd lane stores X and Y
-    const F28 zzz = f28_xchg(B);                                                     // even lane receives ZZZ
-    if constexpr (OUT28) {
-      char* o = partial + (size_t)sid * 224;
-      if (odd) { store_f28(o, X); store_f28(o + 56, A); } else { store_f28(o + 112, A); store_f28(o + 168, zzz); }
-    } else {
-      char* o = partial + (size_t)sid * 192;
-      if (odd) { store_fp<Fq>(o, f28_to_fq(X)); store_fp<Fq>(o + 48, f28_to_fq(A)); } else { store_fp<Fq>(o + 96, f28_to_fq(A)); store_fp<Fq>(o + 144, f28_to_fq(zzz)); }
-    }
-  } else {    // P == +-acc: the even lane collects the accumulator and finishes the slice with the general 32-bit code
-    const F28 fromodd_Y = f28_xchg(A), fromodd_ZZZ = f28_xchg(B);
-    if (!odd) {
-      XYZZ28 tmp; tmp.X = X; tmp.Y = fromodd_Y; tmp.ZZ = A; tmp.ZZZ = fromodd_ZZZ;
-      XYZZ out; bool inf = false;
-      slice_slow_path28(bases, run, j, j1, &tmp, &out, &inf);
-      if constexpr (OUT28) store_xyzz28_from32(partial + (size_t)sid * 224, out, inf);
-      else xyzz_store_normalized(partial + (size_t)sid * 192, out, inf);
-    }
-  }
-}
-
 // 96-byte rows (x | y, 12 x 32-bit Montgomery) -> 112-byte rows of the 28-bit table; (0, 0) marks the identity and stays 0
 __global__ void __launch_bounds__(256) k_rows_to28(const char* __restrict__ src96, char* __restrict__ dst112, uint32_t n) {
   uint32_t i = blockIdx.x * 256 + threadIdx.x; if (i >= n) return;
@@ -851,29 +766,23 @@ template <bool MONT> static void launch_sort(int c, bool pre, const SortArgs& a,
 }
 
 
-// lg of the slice count pick_rule() aims for when it cuts buckets to fill the chip (2^18 = 4 waves per SIMD); ALEO_MI355X_FILL_SHIFT
+// lg of the slice count pick_rule() aims for when it cuts buckets to fill the chip (2^17 = 2 waves per SIMD: measured equal to 2^18 on uniform input, 4 % better on witness-like scalars); ALEO_MI355X_FILL_SHIFT
 // overrides it for experiments
 static uint32_t fill_shift() {
-  static const uint32_t v = [] { const char* e = std::getenv("ALEO_MI355X_FILL_SHIFT"); int k = e ? std::atoi(e) : 18; return (uint32_t)(k >= 14 && k <= 22 ? k : 18); }();
-  return v;
-}
-
-// up to this many (bucket, point) pairs the accumulation runs in its lane-pair form (ALEO_MI355X_PAIR_ACCUM_PAIRS overrides; 0 = never)
-static size_t pair_accum_max_pairs() {
-  static const size_t v = [] { const char* e = std::getenv("ALEO_MI355X_PAIR_ACCUM_PAIRS"); return e ? (size_t)std::strtoull(e, nullptr, 10) : ((size_t)3 << 19); }();
+  static const uint32_t v = [] { const char* e = std::getenv("ALEO_MI355X_FILL_SHIFT"); int k = e ? std::atoi(e) : 17; return (uint32_t)(k >= 14 && k <= 22 ? k : 17); }();
   return v;
 }
 
 // Upper bound of the slice count the device will compute (k_scan_tiles / pick_rule), from what the host knows: `pairs_max`
 // (>= the real pair count) and the bucket count M.  Every non-empty bucket is at least one slice; a bucket cut at `split`
-// adds cnt / split more.  pick_rule's split is >= 8 always; it is >= pairs / 2^fill_shift / 1.125 while the fill rule decides and
+// adds cnt / split more.  pick_rule's split is >= 8 (4 below 2^18 pairs) always; it is >= pairs / 2^fill_shift / 1.125 while the fill rule decides and
 // >= the mean bucket size while the mean rule decides, until the 256-point cap takes over.  The grids of the slice kernels
 // and of the accumulation are sized by this bound, so no launch waits for the device's own count to reach the host.
 static size_t slice_bound(size_t pairs_max, size_t M) {
   const size_t nonempty = M < pairs_max ? M : pairs_max;
   const size_t fill_cap = ((size_t)9 << fill_shift()) >> 3;          // pairs / fill < 1.125 * 2^fill_shift while the fill rule decides
   const size_t by_rule = (M > fill_cap ? M : fill_cap) + pairs_max / 256;
-  const size_t by_min = pairs_max / 8;
+  const size_t by_min = pairs_max / 4;          // pick_rule's shortest split (the device decides 4 or 8 from its own pair count, which may be far below pairs_max)
   return nonempty + (by_min < by_rule ? by_min : by_rule) + 1;
 }
 
@@ -1012,13 +921,7 @@ int32_t msm_run(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, const MsmJob
   char* partial = c->partial.as<char>();
   char* V = c->vbuf.as<char>(); char* Vout = V + (size_t)nchunks * 192;
   HIPCHK(hipEventRecord(c->ev[6], s));          // ev[6]..ev[5] bracket k_accum28 alone (bench.py's roofline kernel)
-  // few pairs = fewer slices than lanes: the lane-pair form halves the dependent chain of every slice; with many pairs the chip is
-  // full either way and the single-lane form does the same work in fewer instruction slots
-  const bool pair_form = sp.pairs_max <= pair_accum_max_pairs();
-  if (pair_form) {
-    if (pre) hipLaunchKernelGGL(k_accum28_pair<true>, dim3(2 * sp.slice_blocks), dim3(256), 0, s, bases, sp.sorted, hist, scan_local, scan_blk, total_pairs, M, meta, sp.order, sp.task_g, partial);
-    else hipLaunchKernelGGL(k_accum28_pair<false>, dim3(2 * sp.slice_blocks), dim3(256), 0, s, bases, sp.sorted, hist, scan_local, scan_blk, total_pairs, M, meta, sp.order, sp.task_g, partial);
-  } else if (pre) hipLaunchKernelGGL(k_accum28<true>, dim3(sp.slice_blocks), dim3(256), 0, s, bases, sp.sorted, hist, scan_local, scan_blk, total_pairs, M, meta, sp.order, sp.task_g, partial);
+  if (pre) hipLaunchKernelGGL(k_accum28<true>, dim3(sp.slice_blocks), dim3(256), 0, s, bases, sp.sorted, hist, scan_local, scan_blk, total_pairs, M, meta, sp.order, sp.task_g, partial);
   else hipLaunchKernelGGL(k_accum28<false>, dim3(sp.slice_blocks), dim3(256), 0, s, bases, sp.sorted, hist, scan_local, scan_blk, total_pairs, M, meta, sp.order, sp.task_g, partial);
   HIPCHK(hipEventRecord(c->ev[5], s));
   HIPCHK(hipGetLastError());

@@ -5,6 +5,8 @@
 // error behaviour follow the reference interfaces [UPSTREAM-RECALL]:
 //   snarkvm_algorithms::msm::VariableBase::msm(bases, scalars) -> Projective        (zips to the shorter slice)
 //   snarkvm_algorithms::fft::EvaluationDomain::{new, fft_in_place, ifft_in_place, coset_fft_in_place, coset_ifft_in_place}
+//   snarkvm_algorithms::polycommit::kzg10::KZG10::commit(powers, polynomial) -> Commitment (G1Affine); the commitments of one
+//       prover round (SonicKZG10::commit over several labelled polynomials) as ONE call; CanonicalSerialize (compressed) of it
 //   snarkvm_algorithms_cuda::{msm, NTT}: Result<_, Error> — an Err means "recompute on the CPU"
 // Layouts are snarkVM's: Fr = 4 x u64 Montgomery, scalar = 4 x u64 canonical, G1Affine = 104 bytes, Projective = 144 bytes.
 #pragma once
@@ -74,6 +76,39 @@ struct VariableBase {
     return {out, Error{0}};
   }
 };
+
+// KZG10::commit over a pinned SRS.  Polynomials are coefficient vectors in Montgomery form (DensePolynomial::coeffs); trailing zero
+// coefficients are skipped like the reference's `skip_leading_zeros_and_convert_to_bigints`.
+struct KZG10 {
+  static size_t degree_plus_one(const std::vector<Fr>& p) { size_t n = p.size(); while (n && !(p[n - 1].l[0] | p[n - 1].l[1] | p[n - 1].l[2] | p[n - 1].l[3])) --n; return n; }
+  static Result<G1Affine> commit(const PinnedBases& powers, const std::vector<Fr>& poly) {
+    G1Affine out{}; int32_t rc = aleo_mi355x_kzg_commit(&out, powers.handle(), poly.data(), degree_plus_one(poly));
+    if (rc) return {std::nullopt, Error{rc}};
+    return {out, Error{0}};
+  }
+  // the commitments of one prover round: k polynomials, one call (shared launches on the device), results in the order given
+  static Result<std::vector<G1Affine>> commit_batch(const PinnedBases& powers, const std::vector<const std::vector<Fr>*>& polys) {
+    std::vector<const void*> ptrs; std::vector<size_t> lens;
+    for (auto* p : polys) { ptrs.push_back(p->data()); lens.push_back(degree_plus_one(*p)); }
+    std::vector<G1Affine> out(polys.size());
+    int32_t rc = aleo_mi355x_kzg_commit_batch(out.data(), powers.handle(), ptrs.data(), lens.data(), polys.size());
+    if (rc) return {std::nullopt, Error{rc}};
+    return {std::move(out), Error{0}};
+  }
+};
+
+// CanonicalSerialize / CanonicalDeserialize (compressed) of G1Affine: 48 bytes
+struct CompressedG1 { uint8_t b[48]; };
+inline Result<CompressedG1> serialize_compressed(const G1Affine& p) {
+  CompressedG1 c{}; int32_t rc = aleo_mi355x_g1_compress(c.b, &p, 1);
+  if (rc) return {std::nullopt, Error{rc}};
+  return {c, Error{0}};
+}
+inline Result<G1Affine> deserialize_compressed(const CompressedG1& c, bool validate_subgroup = true) {
+  G1Affine p{}; int32_t rc = aleo_mi355x_g1_decompress(&p, c.b, 1, validate_subgroup ? 1 : 0);
+  if (rc) return {std::nullopt, Error{rc}};
+  return {p, Error{0}};
+}
 
 enum class NTTInputOutputOrder : int32_t { NN = 0, NR = 1, RN = 2, RR = 3 };
 enum class NTTDirection : int32_t { Forward = 0, Inverse = 1 };

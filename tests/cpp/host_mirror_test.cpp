@@ -78,6 +78,23 @@ int main() {
   CHECK(same, "coset_ifft(coset_fft(x)) == x");
   std::vector<Fr> too_long(2000);
   CHECK(!dom->fft_in_place(too_long).is_ok(), "more coefficients than the domain is an Err");
+  // KZG10::commit, one polynomial and one round's worth in a single call; compressed serialisation round trip
+  CHECK(pinned.value->precompute() == 0, "bases_precompute");
+  std::vector<Fr> p0(4096), p1(3000), p2(4096);
+  for (auto* p : {&p0, &p1, &p2}) for (auto& e : *p) { BigInteger256 v = rand_scalar(); memcpy(e.l, v.l, 32); }
+  for (size_t i = 4000; i < 4096; ++i) p2[i] = Fr{{0, 0, 0, 0}};                                       // trailing zeros are skipped
+  auto c0 = KZG10::commit(*pinned.value, p0); auto c1 = KZG10::commit(*pinned.value, p1); auto c2 = KZG10::commit(*pinned.value, p2);
+  CHECK(c0.is_ok() && c1.is_ok() && c2.is_ok(), "KZG10::commit returns Ok");
+  auto cb = KZG10::commit_batch(*pinned.value, {&p0, &p1, &p2});
+  CHECK(cb.is_ok() && cb.value->size() == 3, "KZG10::commit_batch returns Ok");
+  CHECK(memcmp(&(*cb.value)[0], &*c0.value, 104) == 0 && memcmp(&(*cb.value)[1], &*c1.value, 104) == 0 && memcmp(&(*cb.value)[2], &*c2.value, 104) == 0,
+        "batched commitments == one-by-one commitments, bit for bit");
+  auto ser = serialize_compressed(*c0.value);
+  CHECK(ser.is_ok(), "serialize_compressed");
+  auto de = deserialize_compressed(*ser.value);
+  CHECK(de.is_ok() && memcmp(&*de.value, &*c0.value, 104) == 0, "deserialize_compressed(serialize_compressed(C)) == C (subgroup checked)");
+  CompressedG1 junk = *ser.value; junk.b[47] |= 0x40;
+  CHECK(!deserialize_compressed(junk).is_ok(), "an infinity flag with a non-zero x is an Err");
   printf("ALL OK\n");
   return 0;
 }
