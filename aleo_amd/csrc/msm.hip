@@ -551,16 +551,21 @@ template <uint32_t BYTES = 192> __device__ __forceinline__ void pair_zero(char* 
 template <bool F28> __device__ __forceinline__ void pt_add_pair(const char* pa, const char* pb, char* out) {
   if constexpr (F28) xyzz28_add_pair(pa, pb, out); else xyzz_add_pair(pa, pb, out);
 }
-// partial[ft + i] += partial[ft + i + half] inside every multi-slice bucket (listed in heavy[] by the scan)
+// partial[ft + i] += partial[ft + i + half] inside every multi-slice bucket: one launch per level serves both lists of the scan —
+// the common one (buckets of <= 16 slices, `pairs_a` lane pairs each) and the super-heavy one (`pairs_b` each; skewed scalars).
 template <bool F28>
-__global__ void __launch_bounds__(256) k_tree_pass(char* __restrict__ partial, const uint32_t* __restrict__ heavy, const uint2* __restrict__ scan_local,
-                                                   const uint2* __restrict__ scan_blk, uint32_t M, const uint32_t* __restrict__ meta, uint32_t pass, uint32_t max_pairs,
-                                                   uint32_t list_len) {
+__global__ void __launch_bounds__(256) k_tree_pass(char* __restrict__ partial, const uint32_t* __restrict__ list_a, uint32_t len_a, uint32_t pairs_a,
+                                                   const uint32_t* __restrict__ list_b, uint32_t len_b, uint32_t pairs_b, const uint2* __restrict__ scan_local,
+                                                   const uint2* __restrict__ scan_blk, uint32_t M, const uint32_t* __restrict__ meta, uint32_t pass) {
   constexpr uint32_t PB = PtFmt<F28>::BYTES;
-  const uint32_t op = (blockIdx.x * 256 + threadIdx.x) >> 1;
+  uint32_t op = (blockIdx.x * 256 + threadIdx.x) >> 1;
+  const uint32_t ops_a = len_a * pairs_a;
+  const uint32_t* list = list_a; uint32_t max_pairs = pairs_a, list_len = len_a;
+  if (op >= ops_a) { op -= ops_a; list = list_b; max_pairs = pairs_b; list_len = len_b; }
+  if (max_pairs == 0) return;
   uint32_t h = op / max_pairs, i = op % max_pairs;
   if (h >= list_len) return;
-  uint32_t g = heavy[h];
+  uint32_t g = list[h];
   uint32_t ft = scan_at(scan_local, scan_blk, g).y;
   uint32_t fn = (g + 1 < M) ? scan_at(scan_local, scan_blk, g + 1).y : meta[0];
   uint32_t L = fn - ft;
@@ -930,16 +935,13 @@ int32_t msm_run(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, const MsmJob
   if (sm.NT) {
     for (uint32_t pass = 0, L = sm.max_m; L > 1; ++pass, L = (L + 1) >> 1) {
       const uint32_t Lc = sm.super_overflow ? L : (L < 16u ? L : (16u >> (pass < 4 ? pass : 4)));       // longest bucket of the common list at this level
-      if (sm.n_heavy && Lc > 1) {
-        uint32_t mp = Lc >> 1; uint64_t threads = 2ull * sm.n_heavy * mp;
-        if (pre) hipLaunchKernelGGL(k_tree_pass<true>, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, s, partial, heavy, scan_local, scan_blk, M, meta, pass, mp, sm.n_heavy);
-        else hipLaunchKernelGGL(k_tree_pass<false>, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, s, partial, heavy, scan_local, scan_blk, M, meta, pass, mp, sm.n_heavy);
-      }
-      if (sm.n_super) {
-        uint32_t mp = L >> 1; uint64_t threads = 2ull * sm.n_super * mp;
-        if (pre) hipLaunchKernelGGL(k_tree_pass<true>, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, s, partial, sp.super_list, scan_local, scan_blk, M, meta, pass, mp, sm.n_super);
-        else hipLaunchKernelGGL(k_tree_pass<false>, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, s, partial, sp.super_list, scan_local, scan_blk, M, meta, pass, mp, sm.n_super);
-      }
+      const uint32_t len_a = (sm.n_heavy && Lc > 1) ? sm.n_heavy : 0, pairs_a = len_a ? Lc >> 1 : 0;
+      const uint32_t len_b = sm.n_super, pairs_b = len_b ? L >> 1 : 0;
+      const uint64_t threads = 2ull * ((uint64_t)len_a * pairs_a + (uint64_t)len_b * pairs_b);
+      if (!threads) continue;
+      if (threads >= (1ull << 32)) { (void)hipStreamSynchronize(s); g_last_error = "msm: slice tree too wide"; return ALEO_MI355X_ERR_HIP; }
+      if (pre) hipLaunchKernelGGL(k_tree_pass<true>, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, s, partial, heavy, len_a, pairs_a, sp.super_list, len_b, pairs_b, scan_local, scan_blk, M, meta, pass);
+      else hipLaunchKernelGGL(k_tree_pass<false>, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, s, partial, heavy, len_a, pairs_a, sp.super_list, len_b, pairs_b, scan_local, scan_blk, M, meta, pass);
     }
   }
   HIPCHK(hipEventRecord(c->ev[2], s));

@@ -16,7 +16,22 @@ aleo_amd._lib.check(aleo_amd.lib().aleo_mi355x_init(0), 'init')
 name = sys.argv[1]; reps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 f = name.split(':')
 out = {'workload': name, 'reps': reps}
-if f[0] in ('msm', 'host_msm', 'batch'):
+if f[0] == 'round1':
+    # the first Varuna round at 2^lg constraints: w, z_a, z_b (witness-like, Montgomery) + mask_poly (3 * 2^lg, uniform) in one batched commit
+    from aleo_amd import wire, kzg
+    lg = int(f[1]); H = 1 << lg
+    pb = M.PinnedBases.generate_multiples(synth.generator_affine104(), 1, 3 * H).precompute()
+    wit = [torch.from_numpy(wire.fr_from_bytes(synth.witness_like_scalars(H, 2 + j).view(np.uint8).reshape(-1, 32)).view(np.int64)).to(dev) for j in range(3)]
+    uni = torch.from_numpy(synth.uniform_scalars(3 * H, 9).view(np.int64)).to(dev); torch.cuda.synchronize()
+    ptrs = [w.data_ptr() for w in wit] + [uni.data_ptr()]; lens = [H, H, H, 3 * H]
+    run = lambda: kzg.KZG10.commit_batch_device(pb, ptrs, lens)
+    run(); run()
+    t0 = time.perf_counter(); tms = []
+    for _ in range(reps):
+        run(); tms.append(M.last_msm_timing())
+    out['wall_ms'] = (time.perf_counter() - t0) / reps * 1e3
+    out.update({k_: float(np.mean([t[k_] for t in tms])) for k_ in tms[0]})
+elif f[0] in ('msm', 'host_msm', 'batch'):
     lg = int(f[1]); n = 1 << lg
     if f[0] == 'msm':
         kind, table = f[2], f[3] == 'table'; lg_set = int(f[4]) if len(f) > 4 else lg
