@@ -32,6 +32,8 @@ struct NttTables {
   void* d_tw_lo = nullptr;     // w_n^(e_lo)
   void* d_cs_hi = nullptr;     // coset powers: g^(j_hi << lo_bits)        (inverse: g^-(...))
   void* d_cs_lo = nullptr;     // g^(j_lo)                                  (inverse: g^-(j_lo) * n^-1)
+  void* d_direct = nullptr;    // two-pass sizes: w_n^(k * b) at the position (k << lgBn) + b of the element it multiplies after pass 1
+  uint32_t direct_lgBn = 0;    // the pass split d_direct was built for
   uint32_t scale[8];           // n^-1 (Montgomery): applied at the final store of a plain inverse transform
 };
 
@@ -116,7 +118,8 @@ template <uint32_t TE, uint32_t NT>
 __global__ void __launch_bounds__(NT) k_ntt_strided(const char* src, char* dst, uint32_t lgL, uint32_t lgBn, uint32_t lgT,
                                                      uint32_t tw_scale, uint32_t lg_n, uint32_t lo_bits, const char* __restrict__ inner,
                                                      const char* __restrict__ tw_hi, const char* __restrict__ tw_lo,
-                                                     const char* __restrict__ cs_hi, const char* __restrict__ cs_lo, int pre_coset) {
+                                                     const char* __restrict__ cs_hi, const char* __restrict__ cs_lo, int pre_coset,
+                                                     const char* __restrict__ direct) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   src += (size_t)blockIdx.y << (lg_n + 5); dst += (size_t)blockIdx.y << (lg_n + 5);      // blockIdx.y: independent transform of a batch
   const uint32_t L = 1u << lgL, T = 1u << lgT, tiles_per_a = 1u << (lgBn - lgT);
@@ -146,9 +149,12 @@ __global__ void __launch_bounds__(NT) k_ntt_strided(const char* src, char* dst, 
     uint32_t t = e & (T - 1u), k = e >> lgT;
     Fr x = lds_load<TE>(lds, t * L + bitrev(k, lgL));
     uint32_t b = b0 + t;
-    uint32_t ex = (uint32_t)(((uint64_t)tw_scale * k * b) & nmask);
-    x = Fr::mul(x, two_level(tw_hi, tw_lo, ex, lo_bits));     // 2*2/13.7+1 -> < 2r
     size_t gi = ((((size_t)a << lgL) + k) << lgBn) + b;
+    if (direct) x = Fr::mul(x, load_fp<Fr>(direct + gi * 32));     // the factor sits where its element goes: one coalesced 32-byte read instead of a product
+    else {
+      uint32_t ex = (uint32_t)(((uint64_t)tw_scale * k * b) & nmask);
+      x = Fr::mul(x, two_level(tw_hi, tw_lo, ex, lo_bits));     // 2*2/13.7+1 -> < 2r
+    }
     store_fp<Fr>(dst + gi * 32, x);
   }
 }
@@ -193,6 +199,17 @@ __global__ void __launch_bounds__(NT) k_ntt_final(const char* src, char* dst, ui
     x = Fr::reduce(x);
     store_fp<Fr>(dst + o * 32, x);
   }
+}
+
+// direct[(k << lgBn) + b] = w_n^(k * b): the inter-pass factor of a two-pass transform, one entry per element (built once per
+// (size, direction) on first use; 32 n bytes of HBM buy one product per element per transform)
+__global__ void __launch_bounds__(256) k_build_direct(char* __restrict__ out, uint32_t lg_n, uint32_t lgBn, uint32_t lo_bits, const char* __restrict__ tw_hi,
+                                                      const char* __restrict__ tw_lo) {
+  const size_t gi = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (gi >> lg_n) return;
+  const uint32_t k = (uint32_t)(gi >> lgBn), b = (uint32_t)(gi & (((size_t)1 << lgBn) - 1));
+  const uint32_t nmask = (lg_n >= 32) ? 0xffffffffu : ((1u << lg_n) - 1u);
+  store_fp<Fr>(out + gi * 32, Fr::reduce(two_level(tw_hi, tw_lo, (uint32_t)(((uint64_t)k * b) & nmask), lo_bits)));
 }
 
 __global__ void __launch_bounds__(256) k_bitrev_copy(const char* __restrict__ src, char* __restrict__ dst, uint32_t lg_n) {
@@ -264,14 +281,26 @@ static int32_t run_passes(Ctx* c, char* buf, char* tmp, uint32_t lg_n, uint32_t 
     hipLaunchKernelGGL((k_ntt_final<TE, NT>), dim3(1, batch), dim3(NT), lds_bytes, s, buf, buf, s3, 0u, 0u, 0u, t->lo_bits, inner, csh, csl, pre_coset, post_coset, do_scale, sc);
   } else if (npass == 2) {
     uint32_t lgBn = s3, lgT = lgT_for(s1, lgBn);
-    hipLaunchKernelGGL((k_ntt_strided<TE, NT>), dim3(1u << (lgBn - lgT), batch), dim3(NT), lds_bytes, s, buf, tmp, s1, lgBn, lgT, 1u, lg_n, t->lo_bits, inner, twh, twl, csh, csl, pre_coset);
+    const char* direct = nullptr;
+    if (lg_n >= 12 && lg_n <= 20) {                 // (2^21, 2^22: the extra 32 B per element of HBM reads cost what the product saves) lazily built, shared by all slots; the split (s1, s3) is a function of lg_n and the tile, stored with the table
+      std::lock_guard<std::mutex> lk(c->dev->mu);
+      NttTables* tm = const_cast<NttTables*>(t);
+      if (!tm->d_direct) {
+        HIPCHK(hipMalloc(&tm->d_direct, (size_t)32 << lg_n));
+        hipLaunchKernelGGL(k_build_direct, dim3((uint32_t)((((size_t)1 << lg_n) + 255) / 256)), dim3(256), 0, s, (char*)tm->d_direct, lg_n, lgBn, t->lo_bits, twh, twl);
+        HIPCHK(hipStreamSynchronize(s));           // once per (size, direction): later calls on other streams may use it at once
+        tm->direct_lgBn = lgBn;
+      }
+      if (tm->direct_lgBn == lgBn) direct = (const char*)tm->d_direct;      // (always: the split of a two-pass size is (lg_n + 1) / 2 whatever the tile)
+    }
+    hipLaunchKernelGGL((k_ntt_strided<TE, NT>), dim3(1u << (lgBn - lgT), batch), dim3(NT), lds_bytes, s, buf, tmp, s1, lgBn, lgT, 1u, lg_n, t->lo_bits, inner, twh, twl, csh, csl, pre_coset, direct);
     uint32_t lgTf = lgT_for(s3, s1);
     hipLaunchKernelGGL((k_ntt_final<TE, NT>), dim3(1u << (s1 - lgTf), batch), dim3(NT), lds_bytes, s, tmp, buf, s3, s1, 0u, lgTf, t->lo_bits, inner, csh, csl, 0, post_coset, do_scale, sc);
   } else {
     uint32_t lgBn1 = s2 + s3, lgT1 = lgT_for(s1, lgBn1);
-    hipLaunchKernelGGL((k_ntt_strided<TE, NT>), dim3(1u << (lgBn1 - lgT1), batch), dim3(NT), lds_bytes, s, buf, buf, s1, lgBn1, lgT1, 1u, lg_n, t->lo_bits, inner, twh, twl, csh, csl, pre_coset);
+    hipLaunchKernelGGL((k_ntt_strided<TE, NT>), dim3(1u << (lgBn1 - lgT1), batch), dim3(NT), lds_bytes, s, buf, buf, s1, lgBn1, lgT1, 1u, lg_n, t->lo_bits, inner, twh, twl, csh, csl, pre_coset, (const char*)nullptr);
     uint32_t lgBn2 = s3, lgT2 = lgT_for(s2, lgBn2);
-    hipLaunchKernelGGL((k_ntt_strided<TE, NT>), dim3((1u << s1) << (lgBn2 - lgT2), batch), dim3(NT), lds_bytes, s, buf, tmp, s2, lgBn2, lgT2, 1u << s1, lg_n, t->lo_bits, inner, twh, twl, csh, csl, 0);
+    hipLaunchKernelGGL((k_ntt_strided<TE, NT>), dim3((1u << s1) << (lgBn2 - lgT2), batch), dim3(NT), lds_bytes, s, buf, tmp, s2, lgBn2, lgT2, 1u << s1, lg_n, t->lo_bits, inner, twh, twl, csh, csl, 0, (const char*)nullptr);
     uint32_t lgTf = lgT_for(s3, s1);
     hipLaunchKernelGGL((k_ntt_final<TE, NT>), dim3((1u << s2) << (s1 - lgTf), batch), dim3(NT), lds_bytes, s, tmp, buf, s3, s1, s2, lgTf, t->lo_bits, inner, csh, csl, 0, post_coset, do_scale, sc);
   }

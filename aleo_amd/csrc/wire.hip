@@ -195,6 +195,8 @@ int32_t aleo_mi355x_proof_to_bytes(void* out, size_t* len, const aleo_mi355x_pro
     size_t instances = 0; for (size_t i = 0; i < p->n_circuits; ++i) instances += p->batch_sizes[i];
     if (!p->witness_commitments || !p->g_1 || !p->h_1 || !p->g_abc || !p->h_2 || (!p->evaluations && p->n_evaluations) || !p->sums ||
         (!p->opening_points && p->n_openings)) { g_last_error = "proof_to_bytes: missing part"; return ALEO_MI355X_ERR_BAD_ARG; }
+    for (size_t i = 0; i < p->n_openings; ++i)
+      if (p->opening_has_v && p->opening_has_v[i] && !p->opening_random_v) { g_last_error = "proof_to_bytes: random_v flagged but not given"; return ALEO_MI355X_ERR_BAD_ARG; }
     std::vector<uint8_t> b;
     auto u64le = [&](uint64_t v) { for (int i = 0; i < 8; ++i) b.push_back((uint8_t)(v >> (8 * i))); };
     int32_t rc = ALEO_MI355X_OK;
