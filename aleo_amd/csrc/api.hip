@@ -251,12 +251,15 @@ using namespace aleo_mi355x;
 // The stream a call works on: the caller's, or the slot's own for NULL.  hipStreamLegacy is passed on as the null stream it
 // names (this library is not built with a per-thread default stream): the runtime takes the special handle for launches but
 // not for every event call.
-static hipStream_t pick_stream(Ctx* c, void* stream) {
-  if (!stream) return c->stream;
-  return (hipStream_t)stream == hipStreamLegacy ? (hipStream_t)nullptr : (hipStream_t)stream;
+// hipStreamPerThread is refused: it names a different stream on every host thread, and a slot's events may be waited on by another.
+static int32_t pick_stream(Ctx* c, void* stream, hipStream_t* out) {
+  if ((hipStream_t)stream == hipStreamPerThread) { g_last_error = "stream: hipStreamPerThread is not supported (pass a created stream, hipStreamLegacy or NULL)"; return ALEO_MI355X_ERR_BAD_ARG; }
+  *out = !stream ? c->stream : ((hipStream_t)stream == hipStreamLegacy ? (hipStream_t)nullptr : (hipStream_t)stream);
+  return ALEO_MI355X_OK;
 }
+#define PICK_STREAM(var) hipStream_t var = nullptr; { int32_t rcs = pick_stream(c, stream, &var); if (rcs) return rcs; }
 template <class F> static int32_t run_enqueue(Ctx* c, void* stream, F&& f) {
-  hipStream_t s = pick_stream(c, stream);
+  PICK_STREAM(s)
   int32_t rc = f(s);
   if (rc) return rc;
   if (!stream) HIPCHK(hipStreamSynchronize(s));
@@ -369,7 +372,8 @@ int32_t aleo_mi355x_msm_g1_device(void* out, uint64_t handle, const void* d_scal
     if (!out || (!d_scalars && n)) { g_last_error = "msm_g1_device: bad argument"; return ALEO_MI355X_ERR_BAD_ARG; }
     API_BEGIN
     FIND_BASES(handle)
-    return msm_run1(c, (uint64_t*)out, pb, d_scalars, n, false, pick_stream(c, stream));
+    PICK_STREAM(s)
+    return msm_run1(c, (uint64_t*)out, pb, d_scalars, n, false, s);
   } catch (...) { return ALEO_MI355X_ERR_HIP; }
 }
 
@@ -431,7 +435,8 @@ int32_t aleo_mi355x_kzg_commit_device(void* out104, uint64_t handle, const void*
     API_BEGIN
     FIND_BASES(handle)
     uint64_t jac[18];
-    int32_t rc = msm_run1(c, jac, pb, d_coeffs, n, true, pick_stream(c, stream));
+    PICK_STREAM(s)
+    int32_t rc = msm_run1(c, jac, pb, d_coeffs, n, true, s);
     if (rc) return rc;
     jacobian_to_affine104(out104, jac);
     return ALEO_MI355X_OK;
@@ -456,7 +461,8 @@ int32_t aleo_mi355x_msm_g1_batch_device(void* out_jac, uint64_t handle, const vo
     FIND_BASES(handle)
     MsmJob j; j.d_sets = d_scalars; j.lens = lens; j.k = (uint32_t)k; j.mont = false;
     if (k >= (1u << 20)) { g_last_error = "batch: too many vectors"; return ALEO_MI355X_ERR_BAD_ARG; }
-    return msm_batch(c, (uint64_t*)out_jac, pb, j, pick_stream(c, stream));
+    PICK_STREAM(s)
+    return msm_batch(c, (uint64_t*)out_jac, pb, j, s);
   } catch (...) { return ALEO_MI355X_ERR_HIP; }
 }
 
@@ -468,7 +474,8 @@ int32_t aleo_mi355x_kzg_commit_batch_device(void* out104, uint64_t handle, const
     FIND_BASES(handle)
     std::vector<uint64_t> jac(18 * k);
     MsmJob j; j.d_sets = d_coeffs; j.lens = lens; j.k = (uint32_t)k; j.mont = true;
-    if ((rc = msm_batch(c, jac.data(), pb, j, pick_stream(c, stream)))) return rc;
+    PICK_STREAM(s)
+    if ((rc = msm_batch(c, jac.data(), pb, j, s))) return rc;
     jac_to_affine_rows(out104, jac.data(), k);
     return ALEO_MI355X_OK;
   } catch (...) { return ALEO_MI355X_ERR_HIP; }
@@ -543,7 +550,7 @@ int32_t aleo_mi355x_kzg_open_device(void* out_affine104, void* out_eval_mont, ui
     if (!out_affine104 || !z_mont || (!d_poly_mont && n)) return ALEO_MI355X_ERR_BAD_ARG;
     API_BEGIN
     FIND_BASES(handle)
-    hipStream_t s = pick_stream(c, stream);
+    PICK_STREAM(s)
     int32_t rc; if ((rc = c->ntt_stage.reserve((n ? n : 1) * 32 + 32))) return rc;
     char* q = c->ntt_stage.as<char>(); char* ev = q + (n ? n : 1) * 32;
     if ((rc = fr_divide_by_linear(c, q, ev, d_poly_mont, n, z_mont, s))) return rc;

@@ -41,16 +41,21 @@ struct FrArg { uint32_t v[8]; };
 
 __device__ __forceinline__ uint32_t bitrev(uint32_t x, uint32_t bits) { return bits ? (__brev(x) >> (32 - bits)) : 0u; }
 
-// planar LDS tile: limb l of element e at lds[l * TE + e]
+// planar LDS tile: limb l of element e at lds[l * TE + sw(e)].  sw() XORs the low five index bits with the next five: a bijection
+// that leaves runs of consecutive elements conflict-free and spreads the stride-4 / stride-8 accesses of the last register groups
+// (elements base + j * q with q = 1, 4: every lane of a wave used to hit the same 4-8 of the 32 banks) over the banks.
+__device__ __forceinline__ uint32_t sw(uint32_t e) { return e ^ ((e >> 5) & 31u); }
 template <uint32_t TE> __device__ __forceinline__ Fr lds_load(const uint32_t* lds, uint32_t e) {
   Fr r;
+  const uint32_t x = sw(e);
 #pragma unroll
-  for (int l = 0; l < 8; ++l) r.v[l] = lds[l * TE + e];
+  for (int l = 0; l < 8; ++l) r.v[l] = lds[l * TE + x];
   return r;
 }
 template <uint32_t TE> __device__ __forceinline__ void lds_store(uint32_t* lds, uint32_t e, const Fr& a) {
+  const uint32_t x = sw(e);
 #pragma unroll
-  for (int l = 0; l < 8; ++l) lds[l * TE + e] = a.v[l];
+  for (int l = 0; l < 8; ++l) lds[l * TE + x] = a.v[l];
 }
 
 // w^e from the two-level table (one product, result < 2r)
@@ -130,7 +135,8 @@ __global__ void __launch_bounds__(NT) k_ntt_strided(const char* src, char* dst, 
     size_t gi = ((((size_t)a << lgL) + l) << lgBn) + b0 + t;
     uint4 v = *(const uint4*)(src + gi * 32 + hf * 16);
     uint32_t e = t * L + l, p = hf * 4;
-    lds[(p + 0) * TE + e] = v.x; lds[(p + 1) * TE + e] = v.y; lds[(p + 2) * TE + e] = v.z; lds[(p + 3) * TE + e] = v.w;
+    const uint32_t ex = sw(e);
+    lds[(p + 0) * TE + ex] = v.x; lds[(p + 1) * TE + ex] = v.y; lds[(p + 2) * TE + ex] = v.z; lds[(p + 3) * TE + ex] = v.w;
   }
   __syncthreads();
   if (pre_coset) {   // coset_fft: x[j] *= g^j before the transform (only the first pass: A == 1, j = l*Bn + b)
@@ -176,7 +182,8 @@ __global__ void __launch_bounds__(NT) k_ntt_final(const char* src, char* dst, ui
     size_t row = ((size_t)(k10 + t) << lgN2) + k2;
     uint4 v = *(const uint4*)(src + ((row << lgL) + l) * 32 + hf * 16);
     uint32_t e = t * L + l, p = hf * 4;
-    lds[(p + 0) * TE + e] = v.x; lds[(p + 1) * TE + e] = v.y; lds[(p + 2) * TE + e] = v.z; lds[(p + 3) * TE + e] = v.w;
+    const uint32_t ex = sw(e);
+    lds[(p + 0) * TE + ex] = v.x; lds[(p + 1) * TE + ex] = v.y; lds[(p + 2) * TE + ex] = v.z; lds[(p + 3) * TE + ex] = v.w;
   }
   __syncthreads();
   if (pre_coset) {   // single-pass coset_fft: j = l

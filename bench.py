@@ -295,11 +295,13 @@ PROXY_NOTE = ('operator-level proxy for constraints/s (SURVEY.md §8d): the MSM/
 def proxy_schedule(lg):
     """[(op, arg, size)] of one Varuna prove_batch for one circuit / one instance with 2^lg constraints, variables and
     non-zeros per matrix (snarkvm-algorithms 0.14.5 snark/varuna/ahp/prover/round_functions [UPSTREAM-RECALL]):
-    12 KZG MSMs in five groups (3 + 1, 2, 3, 1 commitments, 2 openings) and the 23 transforms between them.
+    12 KZG MSMs in five groups (3 + 1, 2, 3, 1 commitments, 2 openings), the 23 transforms between them, and the two
+    matrix-vector products z_a = A z, z_b = B z that precede round 1.
     ('commit', [(kind, size), ...]) = the commitments of one round; ('open', [size, ...]) = witness polynomials + their commitments;
     ('ntt', (direction, coset), size, count) = `count` independent transforms of one size issued as ONE batched call."""
     H = 1 << lg
     ops = []
+    ops += [('spmv', 3, H)] * 2                                                         # before round 1: z_a = A z, z_b = B z (3 non-zeros per constraint row)
     ops += [('ntt', (1, 0), H, 3)]                                                      # round 1: interpolate w, z_a, z_b (independent: one batched call)
     ops += [('commit', [('witness', H)] * 3 + [('uniform', 3 * H)])]                    #          w, z_a, z_b, mask_poly (degree 3|H|)
     ops += [('ntt', (0, 1), 4 * H, 4)] + [('vec', 0, 4 * H)] * 6 + [('ntt', (1, 1), 4 * H, 1)]      # round 2: h_1 on the 4|H| coset
@@ -311,6 +313,14 @@ def proxy_schedule(lg):
     return ops
 
 
+def _proxy_csr(rows, per_row):
+    """A synthetic R1CS-matrix shape: `per_row` non-zeros in every row, columns spread by a fixed stride (CSR with u32 indices)."""
+    row_ptr = (np.arange(rows + 1, dtype=np.uint64) * per_row).astype(np.uint32)
+    k = np.arange(rows * per_row, dtype=np.uint64)
+    col = ((k * np.uint64(2654435761)) % np.uint64(rows)).astype(np.uint32)
+    return row_ptr, col
+
+
 def proof_proxy_gpu(aleo_amd, synth, torch, dev, lg, reps=3):
     from aleo_amd import poly, wire
     H = 1 << lg
@@ -320,6 +330,9 @@ def proof_proxy_gpu(aleo_amd, synth, torch, dev, lg, reps=3):
     wit = [torch.from_numpy(wire.fr_from_bytes(synth.witness_like_scalars(H, 0xA1E00012 + lg + 64 * j).view(np.uint8).reshape(-1, 32)).view(np.int64)).to(dev) for j in range(3)]
     quo = [torch.empty((3 * H, 4), dtype=torch.int64, device=dev) for _ in range(2)]
     z = synth.uniform_scalars(2, 0xA1E00013 + lg)
+    csr = _proxy_csr(H, 3)
+    d_rp = torch.from_numpy(csr[0].view(np.int32)).to(dev); d_ci = torch.from_numpy(csr[1].view(np.int32)).to(dev)
+    d_vals = torch.from_numpy(synth.uniform_scalars(csr[1].shape[0], 0xA1E00014 + lg).view(np.int64)).to(dev)
     doms = {}
     ops = proxy_schedule(lg)
     torch.cuda.synchronize()
@@ -346,6 +359,8 @@ def proof_proxy_gpu(aleo_amd, synth, torch, dev, lg, reps=3):
             elif op == 'ntt':
                 d = doms.get(size) or doms.setdefault(size, aleo_amd.EvaluationDomain(size))
                 d.ntt_batch_device(buf.data_ptr(), cnt, 0, arg[0], arg[1], 1)            # hipStreamLegacy: enqueue only, ordered with torch's stream
+            elif op == 'spmv':
+                poly.spmv_device(aux.data_ptr(), d_rp.data_ptr(), d_ci.data_ptr(), d_vals.data_ptr(), buf.data_ptr(), size, 1)
             elif op == 'vec':
                 poly.fr_vec_op_device(aux.data_ptr(), aux.data_ptr(), buf.data_ptr(), size, 0, 1)
             else:
@@ -415,6 +430,9 @@ def proof_proxy_cpu(c, aleo_amd, synth, lg, cores):
             for j, m in enumerate(arg):
                 q, _ = c.fr_divide_by_linear(buf[:m], z[j]); c.msm_g1(bases[:m - 1], q, threads=cores, variant=1)
             t_msm += time.perf_counter() - t1
+        elif op == 'spmv':
+            rp, ci = _proxy_csr(o[2], arg)
+            aux[:o[2]] = c.fr_spmv(rp, ci, s_uni[:ci.shape[0]], buf[:o[2]])
         elif op == 'ntt':
             for _ in range(o[3]): buf[:o[2]] = c.ntt_fr(buf[:o[2]], 0, arg[0], arg[1])
         elif op == 'vec':

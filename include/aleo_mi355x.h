@@ -34,7 +34,7 @@
  * Those that only transform device data (ntt_fr*_device, fr_*_device) enqueue on the caller's `stream` and return at once:
  * the caller orders its own work on that stream, and the library orders its internal scratch between calls by events.
  * With stream == NULL they run on the serving slot's stream — which the caller cannot order against — and therefore
- * complete before returning.
+ * complete before returning.  hipStreamLegacy names the null stream; hipStreamPerThread is refused (BAD_ARG).
  * Ownership: the caller owns every buffer; nothing is retained after return except through bases_pin (and, when the
  * caller opts in with ALEO_MI355X_SRS_CACHE=1, the one-shot msm_g1's base-array cache described there).
  * No exceptions cross the boundary.

@@ -264,6 +264,11 @@ def test_bad_arguments_are_rejected():
     assert L.aleo_mi355x_msm_g1(out.ctypes.data, out.ctypes.data, 100, out.ctypes.data, 1) == 2        # bad stride
     assert L.aleo_mi355x_ntt_fr(out.ctypes.data, 31, 0, 0, 0) == 2
     assert L.aleo_mi355x_msm_g1_pinned(out.ctypes.data, 987654321, out.ctypes.data, 1) == 4            # unknown handle
+    import torch
+    t = torch.zeros((16, 4), dtype=torch.int64, device='cuda'); torch.cuda.synchronize()
+    assert L.aleo_mi355x_ntt_fr_device(t.data_ptr(), 4, 0, 0, 0, 2) == 2                                 # hipStreamPerThread is refused
+    assert L.aleo_mi355x_fr_divide_by_linear_device(t.data_ptr(), None, t.data_ptr(), 16, out.ctypes.data, None) == 2      # quotient aliases the polynomial
+    assert L.aleo_mi355x_msm_g2(out.ctypes.data, out.ctypes.data, 104, out.ctypes.data, 1) == 2          # bad G2 stride
 
 
 def test_msm_fixed_base_table_path():
