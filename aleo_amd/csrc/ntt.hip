@@ -17,6 +17,7 @@
 #include "ctx.h"
 #include "fp.h"
 #include "host_field.hpp"
+#include <cstdlib>
 
 namespace aleo_mi355x {
 
@@ -394,11 +395,15 @@ static int32_t ntt_run_chunk(Ctx* c, void* d_inout, uint32_t lg_n, uint32_t batc
   const int coset = (type == ALEO_NTT_COSET), inv = (direction == ALEO_NTT_INVERSE);
   const int pre_coset = coset && !inv, post_coset = coset && inv, do_scale = inv && !coset;   // cs_lo carries n^-1 for coset_ifft
   FrArg sc; std::memcpy(sc.v, t->scale, 32);
-  // 128 KiB tiles: 2^19..2^22 run in two passes (measured 6-16 % faster than three 64 KiB passes); beyond 2^22 three
+  // 128 KiB tiles: 2^20..2^22 (at 2^19 they are only 128 blocks for 256 CUs: 242 against 343 GB/s with 64 KiB tiles); beyond 2^22 three
   // passes are needed either way and two 64 KiB blocks per CU overlap their HBM phases better (2^24: 3.5 vs 4.0 ms)
   // small transforms are latency-bound on the few blocks a 2048-element tile leaves them (2^16: 32 blocks on 256 CUs): 512-element
   // tiles of one wave each spread them over the chip (2^16: 0.085 -> see profiles/); batches already have the blocks
-  if (lg_n >= 19 && lg_n <= 22) rc = run_passes<4096, 512>(c, buf, tmp, lg_n, batch, t, pre_coset, post_coset, do_scale, sc, s);
+  static const int force_tile = [] { const char* e = std::getenv("ALEO_MI355X_NTT_TILE"); return e ? std::atoi(e) : 0; }();      // experiments only
+  if (force_tile == 2048) rc = run_passes<2048, 256>(c, buf, tmp, lg_n, batch, t, pre_coset, post_coset, do_scale, sc, s);
+  else if (force_tile == 4096) rc = run_passes<4096, 512>(c, buf, tmp, lg_n, batch, t, pre_coset, post_coset, do_scale, sc, s);
+  else if (force_tile == 512 && lg_n <= 18) rc = run_passes<512, 64>(c, buf, tmp, lg_n, batch, t, pre_coset, post_coset, do_scale, sc, s);
+  else if (lg_n >= 20 && lg_n <= 22) rc = run_passes<4096, 512>(c, buf, tmp, lg_n, batch, t, pre_coset, post_coset, do_scale, sc, s);
   else if (lg_n >= 10 && lg_n <= 18 && ((size_t)batch << lg_n) <= ((size_t)1 << 18)) rc = run_passes<512, 64>(c, buf, tmp, lg_n, batch, t, pre_coset, post_coset, do_scale, sc, s);
   else rc = run_passes<2048, 256>(c, buf, tmp, lg_n, batch, t, pre_coset, post_coset, do_scale, sc, s);
   if (rc) return rc;
