@@ -5,4 +5,4 @@ mirrors of the reference's operator interfaces (msm.VariableBase, fft.Evaluation
 from ._lib import lib, LIB_PATH, EXPORTS, AleoMi355xError          # noqa: F401
 from .msm import VariableBase, PinnedBases, g1_sum, last_msm_timing  # noqa: F401
 from .fft import EvaluationDomain                                   # noqa: F401
-from .kzg import KZG10                                              # noqa: F401
+from .kzg import KZG10, SonicKZG10, CommitterKey                    # noqa: F401

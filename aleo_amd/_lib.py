@@ -12,7 +12,7 @@ EXPORTS = [
     'aleo_mi355x_bases_generate', 'aleo_mi355x_bases_download', 'aleo_mi355x_bases_info', 'aleo_mi355x_bases_precompute',
     'aleo_mi355x_msm_g1_pinned', 'aleo_mi355x_msm_g1_device', 'aleo_mi355x_g1_sum', 'aleo_mi355x_msm_g2', 'aleo_mi355x_g2_sum', 'aleo_mi355x_ntt_fr',
     'aleo_mi355x_ntt_fr_device', 'aleo_mi355x_ntt_fr_batch_device', 'aleo_mi355x_fr_grid_scale_device', 'aleo_mi355x_kzg_commit', 'aleo_mi355x_kzg_commit_device', 'aleo_mi355x_kzg_commit_hiding',
-    'aleo_mi355x_msm_g1_batch_device', 'aleo_mi355x_kzg_commit_batch_device', 'aleo_mi355x_kzg_commit_batch',
+    'aleo_mi355x_msm_g1_batch_device', 'aleo_mi355x_kzg_commit_batch_device', 'aleo_mi355x_kzg_commit_batch', 'aleo_mi355x_kzg_commit_segments', 'aleo_mi355x_kzg_commit_segments_device',
     'aleo_mi355x_fr_vec_op_device', 'aleo_mi355x_fr_batch_inverse_device', 'aleo_mi355x_fr_spmv_device', 'aleo_mi355x_fr_divide_by_linear_device', 'aleo_mi355x_kzg_open_device', 'aleo_mi355x_fq_mul',
     'aleo_mi355x_fr_mul', 'aleo_mi355x_selftest_madd28', 'aleo_mi355x_last_msm_timing', 'aleo_mi355x_strerror', 'aleo_mi355x_last_error',
     'aleo_mi355x_version',
@@ -68,6 +68,8 @@ def lib():
         'aleo_mi355x_msm_g1_batch_device': ([vp, u64, vp, vp, sz, vp], i32),
         'aleo_mi355x_kzg_commit_batch_device': ([vp, u64, vp, vp, sz, vp], i32),
         'aleo_mi355x_kzg_commit_batch': ([vp, u64, vp, vp, sz], i32),
+        'aleo_mi355x_kzg_commit_segments': ([vp, sz, u64, vp, sz], i32),
+        'aleo_mi355x_kzg_commit_segments_device': ([vp, sz, u64, vp, sz, vp], i32),
         'aleo_mi355x_fr_vec_op_device': ([vp, vp, vp, sz, i32, vp], i32),
         'aleo_mi355x_fr_batch_inverse_device': ([vp, sz, vp], i32),
         'aleo_mi355x_fr_spmv_device': ([vp, vp, vp, vp, vp, sz, vp], i32),

@@ -459,7 +459,8 @@ int32_t aleo_mi355x_msm_g1_batch_device(void* out_jac, uint64_t handle, const vo
     int32_t rc = batch_args_ok(out_jac, d_scalars, lens, k); if (rc || !k) return rc;
     API_BEGIN
     FIND_BASES(handle)
-    MsmJob j; j.d_sets = d_scalars; j.lens = lens; j.k = (uint32_t)k; j.mont = false;
+    std::vector<MsmSeg> sg(k); for (size_t q = 0; q < k; ++q) { sg[q].d_ptr = d_scalars[q]; sg[q].len = lens[q]; sg[q].out = (uint32_t)q; }
+    MsmJob j; j.segs = sg.data(); j.nseg = (uint32_t)k; j.k = (uint32_t)k; j.mont = false;
     if (k >= (1u << 20)) { g_last_error = "batch: too many vectors"; return ALEO_MI355X_ERR_BAD_ARG; }
     PICK_STREAM(s)
     return msm_batch(c, (uint64_t*)out_jac, pb, j, s);
@@ -473,7 +474,8 @@ int32_t aleo_mi355x_kzg_commit_batch_device(void* out104, uint64_t handle, const
     API_BEGIN
     FIND_BASES(handle)
     std::vector<uint64_t> jac(18 * k);
-    MsmJob j; j.d_sets = d_coeffs; j.lens = lens; j.k = (uint32_t)k; j.mont = true;
+    std::vector<MsmSeg> sg(k); for (size_t q = 0; q < k; ++q) { sg[q].d_ptr = d_coeffs[q]; sg[q].len = lens[q]; sg[q].out = (uint32_t)q; }
+    MsmJob j; j.segs = sg.data(); j.nseg = (uint32_t)k; j.k = (uint32_t)k; j.mont = true;
     PICK_STREAM(s)
     if ((rc = msm_batch(c, jac.data(), pb, j, s))) return rc;
     jac_to_affine_rows(out104, jac.data(), k);
@@ -496,11 +498,45 @@ int32_t aleo_mi355x_kzg_commit_batch(void* out104, uint64_t handle, const void* 
       off += lens[q];
     }
     std::vector<uint64_t> jac(18 * k);
-    MsmJob j; j.d_sets = dptr.data(); j.lens = lens; j.k = (uint32_t)k; j.mont = true;
+    std::vector<MsmSeg> sg(k); for (size_t q = 0; q < k; ++q) { sg[q].d_ptr = dptr[q]; sg[q].len = lens[q]; sg[q].out = (uint32_t)q; }
+    MsmJob j; j.segs = sg.data(); j.nseg = (uint32_t)k; j.k = (uint32_t)k; j.mont = true;
     if ((rc = msm_batch(c, jac.data(), pb, j, c->stream))) return rc;
     jac_to_affine_rows(out104, jac.data(), k);
     return ALEO_MI355X_OK;
   } catch (...) { return ALEO_MI355X_ERR_HIP; }
+}
+
+// SonicKZG10::commit shape: every commitment is a sum of segments (coefficient vector x base offset) over ONE pinned set.
+static int32_t commit_segments(Ctx* c, Device* d, void* out104, size_t n_out, uint64_t handle, const aleo_mi355x_commit_segment* segs, size_t n_segs,
+                               bool host_scalars, hipStream_t s) {
+  if (!n_out) return ALEO_MI355X_OK;
+  if (!out104 || (!segs && n_segs) || n_out >= (1u << 20) || n_segs >= (1u << 22)) { g_last_error = "commit_segments: bad argument"; return ALEO_MI355X_ERR_BAD_ARG; }
+  std::shared_ptr<PinnedOwner> keep; PinnedBases pb; { int32_t rcb = find_bases(d, handle, &keep, &pb); if (rcb) return rcb; }
+  std::vector<MsmSeg> sg(n_segs); size_t total = 0; int32_t rc;
+  for (size_t q = 0; q < n_segs; ++q) {
+    if ((!segs[q].scalars && segs[q].len) || segs[q].output >= n_out || segs[q].base_offset + segs[q].len > pb.n) { g_last_error = "commit_segments: segment out of range"; return ALEO_MI355X_ERR_BAD_ARG; }
+    sg[q].d_ptr = segs[q].scalars; sg[q].len = segs[q].len; sg[q].off = segs[q].base_offset; sg[q].out = segs[q].output; total += segs[q].len;
+  }
+  if (host_scalars) {          // one staging buffer, the uploads queued back to back on the slot's stream
+    if ((rc = c->scalars_stage.reserve((total ? total : 1) * 32))) return rc;
+    size_t off = 0;
+    for (size_t q = 0; q < n_segs; ++q) {
+      if (sg[q].len) HIPCHK(hipMemcpyAsync((char*)c->scalars_stage.p + off * 32, segs[q].scalars, sg[q].len * 32, hipMemcpyHostToDevice, s));
+      sg[q].d_ptr = (const char*)c->scalars_stage.p + off * 32; off += sg[q].len;
+    }
+  }
+  std::vector<uint64_t> jac(18 * n_out);
+  MsmJob j; j.segs = sg.data(); j.nseg = (uint32_t)n_segs; j.k = (uint32_t)n_out; j.mont = true;
+  if ((rc = msm_batch(c, jac.data(), pb, j, s))) return rc;
+  jac_to_affine_rows(out104, jac.data(), n_out);
+  return ALEO_MI355X_OK;
+}
+
+int32_t aleo_mi355x_kzg_commit_segments(void* out104, size_t n_out, uint64_t handle, const aleo_mi355x_commit_segment* segs, size_t n_segs) {
+  try { API_BEGIN return commit_segments(c, d, out104, n_out, handle, segs, n_segs, true, c->stream); } catch (...) { return ALEO_MI355X_ERR_HIP; }
+}
+int32_t aleo_mi355x_kzg_commit_segments_device(void* out104, size_t n_out, uint64_t handle, const aleo_mi355x_commit_segment* segs, size_t n_segs, void* stream) {
+  try { API_BEGIN PICK_STREAM(s) return commit_segments(c, d, out104, n_out, handle, segs, n_segs, false, s); } catch (...) { return ALEO_MI355X_ERR_HIP; }
 }
 
 int32_t aleo_mi355x_kzg_commit_hiding(void* out104, uint64_t h_powers, const void* coeffs, size_t n, uint64_t h_gamma, const void* blind, size_t m) {

@@ -130,13 +130,15 @@ extern thread_local MsmTiming g_last_msm;   // phase times of the calling thread
 int32_t ensure_host_pinned(Ctx* c, size_t bytes);
 
 // msm.hip
-// job.k scalar vectors ("sets") against prefixes of one pinned set: set q = lens[q] scalars at the DEVICE pointer d_sets[q]
-// (both arrays in host memory); out_jac18 receives k results.  k > 1 needs a table tier serving the longest set and
-// k <= msm_max_sets(pb, longest); msm_batch() groups arbitrary requests accordingly.
-struct MsmJob { const void* const* d_sets = nullptr; const size_t* lens = nullptr; uint32_t k = 0; bool mont = false; };
+// One launch chain computes job.k results ("sets"); result q is the sum over the segments with out == q of
+//   sum_i scalar[i] * base[off + i],  i < len    (scalars at the DEVICE pointer d_ptr; the segment array itself is host memory).
+// k > 1 needs a table tier that covers every base reached and k <= msm_max_sets(); msm_batch() groups arbitrary requests accordingly.
+struct MsmSeg { const void* d_ptr = nullptr; size_t len = 0, off = 0; uint32_t out = 0; };
+struct MsmJob { const MsmSeg* segs = nullptr; uint32_t nseg = 0, k = 0; bool mont = false; };
 int32_t msm_run(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, const MsmJob& job, hipStream_t s);
 inline int32_t msm_run1(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, const void* d_scalars, size_t n, bool mont, hipStream_t s) {
-  MsmJob j; j.d_sets = &d_scalars; j.lens = &n; j.k = 1; j.mont = mont; return msm_run(c, out_jac18, pb, j, s);
+  MsmSeg g; g.d_ptr = d_scalars; g.len = n;
+  MsmJob j; j.segs = &g; j.nseg = 1; j.k = 1; j.mont = mont; return msm_run(c, out_jac18, pb, j, s);
 }
 int32_t msm_batch(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, const MsmJob& job, hipStream_t s);
 uint32_t msm_max_sets(const PinnedBases& pb, size_t n);

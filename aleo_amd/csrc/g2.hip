@@ -273,11 +273,11 @@ int32_t msm_g2_run(Ctx* c, uint64_t* out_jac36, const void* d_xy, const uint8_t*
   if (n == 0) { h2store_jacobian_normalized(out_jac36, HXYZZ2::infinity()); return ALEO_MI355X_OK; }
   if (n >= (1ull << 31)) { g_last_error = "msm_g2: n exceeds 2^31"; return ALEO_MI355X_ERR_BAD_ARG; }
   MsmPlan P = make_plan(n, 0);
-  SetArgs sets{}; sets.ptr[0] = (const char*)d_scalars; sets.n[0] = (uint32_t)n;
+  SegArgs segs{}; segs.nseg = 1; segs.ptr[0] = (const char*)d_scalars; segs.n[0] = (uint32_t)n;
   int32_t rc;
   if ((rc = ensure_host_pinned(c, 64 + (size_t)P.W * 384))) return rc;
   SortPhase sp;
-  if ((rc = msm_sort_phase(c, sets, 1, n, n, false, d_inf, (uint32_t)n, P, false, s, &sp))) return rc;
+  if ((rc = msm_sort_phase(c, segs, n, false, d_inf, (uint32_t)n, P, false, s, &sp))) return rc;
   const uint32_t M = sp.M, cpw = P.B / P.S, nchunks = cpw * P.W;
   if ((rc = c->partial.reserve(sp.slices_max * 384))) return rc;
   if ((rc = c->vbuf.reserve(((size_t)nchunks + P.W) * 384))) return rc;

@@ -123,17 +123,18 @@ template <int C, bool PRE> struct SortGeom {
 };
 
 template <int C, bool MONT, bool PRE>
-__global__ void __launch_bounds__(256) k_part_count(SetArgs sets, const uint8_t* inf, uint32_t nblk, uint32_t* __restrict__ cnt) {
+__global__ void __launch_bounds__(256) k_part_count(SegArgs segs, const uint8_t* inf, uint32_t* __restrict__ cnt) {
   using Gm = SortGeom<C, PRE>;
   __shared__ uint32_t h[MAX_COARSE];
+  const uint32_t n = segs.n[blockIdx.y], base = blockIdx.x * PART_TILE;
+  if (base >= n) return;                                      // the grid is as wide as the longest segment
   for (uint32_t i = threadIdx.x; i < Gm::NCB; i += 256) h[i] = 0;
   __syncthreads();
-  const uint32_t n = sets.n[blockIdx.y]; const char* scalars = sets.ptr[blockIdx.y];
-  cnt += (size_t)blockIdx.y * Gm::NCB * nblk;
-  const uint32_t base = blockIdx.x * PART_TILE;
+  const char* scalars = segs.ptr[blockIdx.y]; const uint32_t off = segs.off[blockIdx.y], nblk = segs.ncol;
+  cnt += (size_t)segs.set[blockIdx.y] * Gm::NCB * nblk + segs.col0[blockIdx.y];
   for (uint32_t q = 0; q < PART_TILE / 256; ++q) {
     uint32_t i = base + q * 256 + threadIdx.x;
-    if (i < n && !(inf && inf[i])) {
+    if (i < n && !(inf && inf[off + i])) {
       uint32_t s[8]; load_scalar<MONT>(scalars, i, s);
       for_each_digit<C, 0>(s, 0u, [&](uint32_t w, uint32_t b, uint32_t) { atomicAdd(&h[Gm::bin(w, b)], 1u); });
     }
@@ -184,21 +185,23 @@ __global__ void __launch_bounds__(256) k_scan32_top(const uint32_t* __restrict__
 __device__ __forceinline__ uint32_t scan32_at(const uint32_t* local, const uint32_t* blk, size_t i) { return local[i] + blk[i / SCAN_TILE]; }
 
 template <int C, bool MONT, bool PRE>
-__global__ void __launch_bounds__(256) k_part_scatter(SetArgs sets, const uint8_t* inf, uint32_t nblk, uint32_t row_stride,
+__global__ void __launch_bounds__(256) k_part_scatter(SegArgs segs, const uint8_t* inf, uint32_t row_stride,
                                                       const uint32_t* __restrict__ off_local, const uint32_t* __restrict__ off_blk, uint2* __restrict__ items) {
   using Gm = SortGeom<C, PRE>;
   __shared__ uint32_t cur[MAX_COARSE];
-  const uint32_t n = sets.n[blockIdx.y]; const char* scalars = sets.ptr[blockIdx.y];
-  for (uint32_t i = threadIdx.x; i < Gm::NCB; i += 256) cur[i] = scan32_at(off_local, off_blk, ((size_t)blockIdx.y * Gm::NCB + i) * nblk + blockIdx.x);
+  const uint32_t n = segs.n[blockIdx.y], base = blockIdx.x * PART_TILE;
+  if (base >= n) return;
+  const char* scalars = segs.ptr[blockIdx.y]; const uint32_t off = segs.off[blockIdx.y], nblk = segs.ncol;
+  const size_t row0 = (size_t)segs.set[blockIdx.y] * Gm::NCB; const uint32_t col = segs.col0[blockIdx.y] + blockIdx.x;
+  for (uint32_t i = threadIdx.x; i < Gm::NCB; i += 256) cur[i] = scan32_at(off_local, off_blk, (row0 + i) * nblk + col);
   __syncthreads();
-  const uint32_t base = blockIdx.x * PART_TILE;
   for (uint32_t q = 0; q < PART_TILE / 256; ++q) {
     uint32_t i = base + q * 256 + threadIdx.x;
-    if (i < n && !(inf && inf[i])) {
+    if (i < n && !(inf && inf[off + i])) {
       uint32_t s[8]; load_scalar<MONT>(scalars, i, s);
       for_each_digit<C, 0>(s, 0u, [&](uint32_t w, uint32_t b, uint32_t neg) {
         uint32_t pos = atomicAdd(&cur[Gm::bin(w, b)], 1u);
-        items[pos] = make_uint2((PRE ? w * row_stride + i : i) | (neg << 31), b & ((1u << Gm::LB) - 1u));
+        items[pos] = make_uint2((PRE ? w * row_stride + off + i : off + i) | (neg << 31), b & ((1u << Gm::LB) - 1u));
       });
     }
   }
@@ -748,10 +751,10 @@ __global__ void k_gather_windows(const char* __restrict__ V, uint32_t seg_len, u
 }
 
 // ---- dispatch on the window width ---------------------------------------------------------------
-struct SortArgs { SetArgs sets; uint32_t nsets; const uint8_t* inf; uint32_t nblk, row_stride; uint32_t* cnt; uint32_t* off_local; uint32_t* off_blk; uint2* items; };
+struct SortArgs { SegArgs segs; const uint8_t* inf; uint32_t nblk_x, row_stride; uint32_t* cnt; uint32_t* off_local; uint32_t* off_blk; uint2* items; };
 template <int C, bool MONT, bool PRE> static void launch_sort_c(const SortArgs& a, int phase, hipStream_t s) {
-  if (phase == 0) hipLaunchKernelGGL((k_part_count<C, MONT, PRE>), dim3(a.nblk, a.nsets), dim3(256), 0, s, a.sets, a.inf, a.nblk, a.cnt);
-  else hipLaunchKernelGGL((k_part_scatter<C, MONT, PRE>), dim3(a.nblk, a.nsets), dim3(256), 0, s, a.sets, a.inf, a.nblk, a.row_stride, a.off_local, a.off_blk, a.items);
+  if (phase == 0) hipLaunchKernelGGL((k_part_count<C, MONT, PRE>), dim3(a.nblk_x, a.segs.nseg), dim3(256), 0, s, a.segs, a.inf, a.cnt);
+  else hipLaunchKernelGGL((k_part_scatter<C, MONT, PRE>), dim3(a.nblk_x, a.segs.nseg), dim3(256), 0, s, a.segs, a.inf, a.row_stride, a.off_local, a.off_blk, a.items);
 }
 template <bool MONT> static void launch_sort(int c, bool pre, const SortArgs& a, int phase, hipStream_t s) {
   if (pre) {
@@ -803,9 +806,17 @@ uint32_t msm_max_sets(const PinnedBases& pb, size_t n) {
   return 1;
 }
 
-int32_t msm_sort_phase(Ctx* c, const SetArgs& sets, uint32_t K, size_t n, size_t pts, bool mont, const uint8_t* d_inf, uint32_t row_stride,
+int32_t msm_sort_phase(Ctx* c, SegArgs& segs, size_t pts, bool mont, const uint8_t* d_inf, uint32_t row_stride,
                        const MsmPlan& P, bool pre, hipStream_t s, SortPhase* out) {
   SortPhase& sp = *out; sp.P = P;
+  // columns of the level-1 count matrix: the blocks of a set's segments side by side; every row is as wide as the widest set
+  uint32_t width[MAX_SETS] = {}, nblk_x = 0;
+  for (uint32_t q = 0; q < segs.nseg; ++q) {
+    const uint32_t nb = (segs.n[q] + PART_TILE - 1) / PART_TILE, st = pre ? segs.set[q] : 0;
+    segs.col0[q] = width[st]; width[st] += nb; nblk_x = nb > nblk_x ? nb : nblk_x;
+  }
+  uint32_t nblk = 1; for (uint32_t w : width) nblk = w > nblk ? w : nblk;
+  segs.ncol = nblk;
   sp.digitsW = (SCALAR_BITS + P.c - 1) / P.c;
   const uint32_t M = sp.M = P.M, ntiles = (M + SCAN_TILE - 1) / SCAN_TILE;
   const size_t pairs_max = sp.pairs_max = pts * (size_t)sp.digitsW;
@@ -820,7 +831,6 @@ int32_t msm_sort_phase(Ctx* c, const SetArgs& sets, uint32_t K, size_t n, size_t
   if ((rc = c->scan_blk.reserve(2 * (size_t)ntiles * 8 + 64))) return rc;
   if ((rc = c->sorted.reserve(pairs_max * 4))) return rc;
   const uint32_t LB = (P.c - 1) < 8 ? (P.c - 1) : 8, ncb = P.W * (P.B >> LB);      // coarse bins of all sets / windows
-  const uint32_t nblk = (uint32_t)((n + PART_TILE - 1) / PART_TILE);
   const size_t cnt_len = (size_t)ncb * nblk;
   if (ncb > MAX_COARSE || cnt_len >= (1ull << 32)) { g_last_error = "msm: partition table too large"; return ALEO_MI355X_ERR_BAD_ARG; }
   const uint32_t cnt_tiles = (uint32_t)((cnt_len + SCAN_TILE - 1) / SCAN_TILE);
@@ -838,9 +848,10 @@ int32_t msm_sort_phase(Ctx* c, const SetArgs& sets, uint32_t K, size_t n, size_t
 
   HIPCHK(hipEventRecord(c->ev[0], s));
   HIPCHK(hipMemsetAsync(hist, 0, hist_words * 4, s));
+  HIPCHK(hipMemsetAsync(c->part_cnt.p, 0, cnt_len * 4, s));          // columns no block of a set owns (and tiles past a segment's end) count zero
   SortArgs sa;
-  sa.sets = sets; sa.nsets = pre ? K : 1;
-  sa.inf = d_inf; sa.nblk = nblk; sa.row_stride = row_stride;
+  sa.segs = segs; sa.nblk_x = nblk_x ? nblk_x : 1;
+  sa.inf = d_inf; sa.row_stride = row_stride;
   sa.cnt = c->part_cnt.as<uint32_t>(); sa.off_local = sa.cnt + cnt_len;
   uint32_t* cnt_tile_tot = sa.off_local + cnt_len; sa.off_blk = cnt_tile_tot + cnt_tiles;
   sa.items = c->part_items.as<uint2>();
@@ -888,22 +899,25 @@ int32_t msm_run(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, const MsmJob
   using namespace host;
   const uint32_t K = job.k;
   if (K == 0) return ALEO_MI355X_OK;
-  size_t n = 0, pts = 0; SetArgs sets{};
-  if (K > MAX_SETS) { g_last_error = "msm: too many sets in one call"; return ALEO_MI355X_ERR_BAD_ARG; }
-  for (uint32_t q = 0; q < K; ++q) {
-    const size_t l = job.lens[q];
-    if (l >= (1ull << 31)) { g_last_error = "msm: set longer than 2^31"; return ALEO_MI355X_ERR_BAD_ARG; }
-    sets.ptr[q] = (const char*)job.d_sets[q]; sets.n[q] = (uint32_t)l; n = l > n ? l : n; pts += l;
+  size_t n = 0, pts = 0; SegArgs segs{};
+  if (K > MAX_SETS || job.nseg > MAX_SEGS) { g_last_error = "msm: too many sets / segments in one call"; return ALEO_MI355X_ERR_BAD_ARG; }
+  for (uint32_t q = 0; q < job.nseg; ++q) {
+    const MsmSeg& g = job.segs[q];
+    if (g.len == 0) continue;
+    if (g.out >= K || g.off + g.len >= (1ull << 31)) { g_last_error = "msm: segment out of range"; return ALEO_MI355X_ERR_BAD_ARG; }
+    const uint32_t i = segs.nseg++;
+    segs.ptr[i] = (const char*)g.d_ptr; segs.n[i] = (uint32_t)g.len; segs.off[i] = (uint32_t)g.off; segs.set[i] = (uint8_t)g.out;
+    n = g.off + g.len > n ? g.off + g.len : n; pts += g.len;
   }
   if (n == 0) { for (uint32_t q = 0; q < K; ++q) hstore_jacobian_normalized(out_jac18 + 18 * q, HXYZZ::infinity()); return ALEO_MI355X_OK; }
-  if (n > pb.n || n >= (1ull << 31)) { g_last_error = "msm: n exceeds the pinned base count (or 2^31)"; return ALEO_MI355X_ERR_BAD_ARG; }
+  if (n > pb.n) { g_last_error = "msm: a segment reaches past the pinned bases"; return ALEO_MI355X_ERR_BAD_ARG; }
   // the fixed-base table serves any prefix of the pinned set (row stride = pinned count) as long as the prefix still
   // puts about one point into every bucket; shorter prefixes use the plain path with its small bucket count
   const PinnedBases::PreTable* T = nullptr;
   for (const auto& t : pb.tab) if (t.d && n >= t.min_n && n <= t.cover) { T = &t; break; }
   const bool pre = T != nullptr;
   if (K > 1 && (!pre || K > msm_max_sets(pb, n))) { g_last_error = "msm: internal: batch without a table tier (or too many sets)"; return ALEO_MI355X_ERR_BAD_ARG; }
-  MsmPlan P = make_plan(n, pre ? T->c : 0);
+  MsmPlan P = make_plan(pre ? n : pts, pre ? T->c : 0);
   if (pre) { P.W = K; P.M = K * P.B; }                       // after the sort a set is "a window with its own buckets"
   if (!pre && !pb.d_xy28) { g_last_error = "msm: pinned set without 28-bit rows"; return ALEO_MI355X_ERR_HIP; }
   const char* bases = (const char*)(pre ? T->d : pb.d_xy28);          // 112-byte rows either way
@@ -917,7 +931,7 @@ int32_t msm_run(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, const MsmJob
   const size_t vpoints = masked ? (size_t)K * setw + nchunks + (nseg + 1) + (size_t)nseg * (tseg / 2 + tseg / 4 + 2) : (size_t)nchunks + P.W;
   if ((rc = ensure_host_pinned(c, 64 + (size_t)(masked ? nseg : P.W) * 224))) return rc;      // before the sort phase: its read-back lands in this buffer
   SortPhase sp;
-  if ((rc = msm_sort_phase(c, sets, K, n, pts, job.mont, pb.d_inf, (uint32_t)(pre ? T->cover : pb.n), P, pre, s, &sp))) return rc;
+  if ((rc = msm_sort_phase(c, segs, pts, job.mont, pb.d_inf, (uint32_t)(pre ? T->cover : pb.n), P, pre, s, &sp))) return rc;
   const uint32_t M = sp.M;
   if ((rc = c->partial.reserve(sp.slices_max * (pre ? 224 : 192)))) return rc;
   if ((rc = c->vbuf.reserve(vpoints * 224))) return rc;
@@ -1048,25 +1062,41 @@ int32_t msm_run(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, const MsmJob
 }
 
 
-// Arbitrary batch: sets are grouped by the table tier their own length selects (longest tier first) and every group goes
-// through msm_run in chunks of msm_max_sets(); sets no tier serves (no table, or fewer than 2^10 points) run one by one.
+// Arbitrary request: k results, each the sum of its segments.  Results are grouped by the table tier the bases they reach select
+// (longest tier first) and every group goes through msm_run in chunks of msm_max_sets() results / MAX_SEGS segments; results no tier
+// serves (no table, or fewer than 2^10 bases reached) run one by one.
 int32_t msm_batch(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, const MsmJob& job, hipStream_t s) {
   const uint32_t K = job.k;
   auto tier_of = [&](size_t n) { for (int t = 0; t < 3; ++t) if (pb.tab[t].d && n >= pb.tab[t].min_n && n <= pb.tab[t].cover) return t; return -1; };
+  std::vector<size_t> reach(K, 0), points(K, 0); std::vector<uint32_t> nsegs(K, 0);
+  for (uint32_t q = 0; q < job.nseg; ++q) {
+    const MsmSeg& g = job.segs[q];
+    if (g.out >= K) { g_last_error = "msm: segment names a result that does not exist"; return ALEO_MI355X_ERR_BAD_ARG; }
+    if (!g.len) continue;
+    reach[g.out] = g.off + g.len > reach[g.out] ? g.off + g.len : reach[g.out]; points[g.out] += g.len; nsegs[g.out]++;
+  }
   std::vector<uint32_t> todo; todo.reserve(K);
   for (int t = -1; t < 3; ++t) {
     todo.clear();
-    for (uint32_t q = 0; q < K; ++q) if (tier_of(job.lens[q]) == t) todo.push_back(q);
+    for (uint32_t q = 0; q < K; ++q) if (tier_of(reach[q]) == t) todo.push_back(q);
     size_t pos = 0;
     while (pos < todo.size()) {
-      size_t nmax = 0, take = 0; const void* ptrs[MAX_SETS]; size_t lens[MAX_SETS]; uint64_t res[MAX_SETS * 18];
-      const size_t cap = t < 0 ? 1 : msm_max_sets(pb, job.lens[todo[pos]]);
-      // 2^32 pairs per launch: chunks are also cut by total points
-      size_t pts = 0;
-      while (pos + take < todo.size() && take < cap && (take == 0 || pts + job.lens[todo[pos + take]] <= ((size_t)1 << 26))) {
-        const uint32_t q = todo[pos + take]; ptrs[take] = job.d_sets[q]; lens[take] = job.lens[q]; pts += lens[take]; nmax = lens[take] > nmax ? lens[take] : nmax; ++take;
+      const size_t cap = t < 0 ? 1 : msm_max_sets(pb, reach[todo[pos]]);
+      size_t take = 0, pts = 0, sg = 0; uint32_t local[MAX_SETS];
+      // 2^32 pairs and MAX_SEGS segments per launch chain: chunks are also cut by total points and segments
+      while (pos + take < todo.size() && take < cap && (take == 0 || (pts + points[todo[pos + take]] <= ((size_t)1 << 26) && sg + nsegs[todo[pos + take]] <= MAX_SEGS))) {
+        pts += points[todo[pos + take]]; sg += nsegs[todo[pos + take]]; ++take;
       }
-      MsmJob g; g.d_sets = ptrs; g.lens = lens; g.k = (uint32_t)take; g.mont = job.mont;
+      if (sg > MAX_SEGS) { g_last_error = "msm: one result with more than 64 segments"; return ALEO_MI355X_ERR_BAD_ARG; }
+      std::vector<MsmSeg> segs; segs.reserve(sg);
+      for (size_t i = 0; i < take; ++i) local[i] = todo[pos + i];
+      for (uint32_t q = 0; q < job.nseg; ++q) {
+        const MsmSeg& g = job.segs[q];
+        if (!g.len) continue;
+        for (size_t i = 0; i < take; ++i) if (local[i] == g.out) { MsmSeg h = g; h.out = (uint32_t)i; segs.push_back(h); break; }
+      }
+      uint64_t res[MAX_SETS * 18];
+      MsmJob g; g.segs = segs.data(); g.nseg = (uint32_t)segs.size(); g.k = (uint32_t)take; g.mont = job.mont;
       int32_t rc = msm_run(c, res, pb, g, s);
       if (rc) return rc;
       for (size_t i = 0; i < take; ++i) std::memcpy(out_jac18 + 18 * (size_t)todo[pos + i], res + 18 * i, 144);

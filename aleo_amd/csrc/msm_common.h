@@ -7,7 +7,8 @@ namespace aleo_mi355x {
 
 static constexpr uint32_t SCAN_TILE = 2048;     // elements per scan block (256 threads x 8)
 static constexpr uint32_t SCALAR_BITS = 254;    // 253-bit scalars + 1 bit of signed-digit carry
-static constexpr uint32_t MAX_SETS = 32;
+static constexpr uint32_t MAX_SETS = 32;          // results ("sets": each owns 2^(c-1) buckets) of one launch chain
+static constexpr uint32_t MAX_SEGS = 64;          // scalar vectors of one launch chain
 static constexpr uint32_t SUPER_CAP = 4096;     // buckets with > 16 slices kept in their own list
 static constexpr uint32_t MAX_SLICE = 512;      // longest slice pick_rule() can produce
 
@@ -15,7 +16,11 @@ struct MsmPlan { uint32_t c, W, B, M, S; };
 // Balanced windows (msm.hip): the top W*c - 254 windows are c-1 bits wide.
 inline int plan_win_width(int c, int w) { const int W = ((int)SCALAR_BITS + c - 1) / c, full = W - (W * c - (int)SCALAR_BITS); return w < full ? c : c - 1; }
 MsmPlan make_plan(size_t n, int pre_c);
-struct SetArgs { const char* ptr[MAX_SETS]; uint32_t n[MAX_SETS]; };          // scalar vector and length of every set (kernel argument)
+// A segment = one scalar vector: n scalars at ptr multiply the bases [off, off + n) of the pinned set and add into result `set`.
+// Several segments may feed one set (KZG10::commit with hiding: the polynomial against the powers and the blinding polynomial against
+// the gamma powers behind them; a degree-bounded polynomial is one segment at the shifted powers' offset).  col0: first column of the
+// segment's blocks in its set's rows of the level-1 count matrix [set][bin][columns of the set's segments].  (kernel argument)
+struct SegArgs { const char* ptr[MAX_SEGS]; uint32_t n[MAX_SEGS], off[MAX_SEGS], col0[MAX_SEGS]; uint8_t set[MAX_SEGS]; uint32_t nseg = 0, ncol = 0; };
 
 // Slice sizing.  A bucket of <= single points is one slice (one lane); larger buckets are cut into slices of <= split.
 struct SliceRule { uint32_t single, split; };
@@ -54,7 +59,8 @@ struct SortPhase {
 struct SliceMeta { uint32_t NT = 0, max_m = 0, n_heavy = 0, n_super = 0; bool super_overflow = false; };
 // P: the plan (P.W windows / sets of P.B buckets).  pre: table path (digits address row w * row_stride + i of a table, all windows share
 // a set's buckets).  Records ev[0] before and ev[1] after the sort; ev[7] on the side stream carries the slice metadata back.
-int32_t msm_sort_phase(Ctx* c, const SetArgs& sets, uint32_t K, size_t n_max, size_t pts, bool mont, const uint8_t* d_inf, uint32_t row_stride,
+// segs: ptr / n / off / set filled in by the caller; col0, ncol are computed here.  pts = sum of the segment lengths.
+int32_t msm_sort_phase(Ctx* c, SegArgs& segs, size_t pts, bool mont, const uint8_t* d_inf, uint32_t row_stride,
                        const MsmPlan& P, bool pre, hipStream_t s, SortPhase* out);
 int32_t msm_wait_meta(Ctx* c, const SortPhase& sp, hipStream_t s, SliceMeta* m);
 

@@ -70,3 +70,63 @@ class KZG10:
         check(lib().aleo_mi355x_kzg_commit_hiding(_p(out), powers.handle, _p(c), c.shape[0], gamma_powers.handle, _p(b), b.shape[0]),
               'kzg_commit_hiding')
         return out
+
+
+class _Segment(ctypes.Structure):
+    _fields_ = [('scalars', ctypes.c_void_p), ('len', ctypes.c_size_t), ('base_offset', ctypes.c_size_t), ('output', ctypes.c_uint32)]
+
+
+class CommitterKey:
+    """Mirror of sonic_pc::CommitterKey [UPSTREAM-RECALL]: powers_of_beta_g, powers_of_beta_times_gamma_g, max_degree.  Both power
+    arrays are pinned as ONE resident set (powers | gamma powers), so a hiding commitment is a single sum of segments."""
+
+    def __init__(self, powers_of_beta_g: np.ndarray, powers_of_beta_times_gamma_g: np.ndarray = None, precompute: bool = True):
+        pw = np.ascontiguousarray(powers_of_beta_g, dtype=np.uint8).reshape(-1, 104)
+        self.max_degree = pw.shape[0] - 1
+        self.gamma_offset = pw.shape[0]
+        if powers_of_beta_times_gamma_g is not None:
+            pw = np.concatenate([pw, np.ascontiguousarray(powers_of_beta_times_gamma_g, dtype=np.uint8).reshape(-1, 104)])
+        self.n_gamma = pw.shape[0] - self.gamma_offset
+        self.bases = PinnedBases(pw)
+        if precompute: self.bases.precompute()
+
+    def close(self): self.bases.close()
+    def __enter__(self): return self
+    def __exit__(self, *a): self.close()
+
+
+class SonicKZG10:
+    """Mirror of sonic_pc::SonicKZG10::commit for the labelled polynomials of one round: one call, shared launches."""
+
+    @staticmethod
+    def commit(ck: CommitterKey, polynomials, device: bool = False, stream: int = 0) -> np.ndarray:
+        """polynomials: iterable of (coeffs, degree_bound, blinding) — coeffs uint64[n,4] Montgomery (or a device pointer + length
+        tuple when device=True), degree_bound None or an int <= max_degree (the commitment then uses the shifted powers
+        powers[max_degree - bound ..]), blinding None or uint64[m,4] Montgomery (the random polynomial of a hiding commitment, committed
+        against the gamma powers).  Returns uint8[k,104]."""
+        segs, keep = [], []
+        for q, (coeffs, bound, blind) in enumerate(polynomials):
+            if device: ptr, n = int(coeffs[0]), int(coeffs[1])
+            else:
+                a = np.ascontiguousarray(coeffs, dtype=np.uint64).reshape(-1, 4); n = a.shape[0]
+                while n and not a[n - 1].any(): n -= 1
+                keep.append(a); ptr = a.ctypes.data
+            off = 0
+            if bound is not None:
+                if bound > ck.max_degree or n > bound + 1: raise ValueError('degree bound below the degree or above max_degree')
+                off = ck.max_degree - bound
+            segs.append((ptr, n, off, q))
+            if blind is not None:
+                if device: bptr, m = int(blind[0]), int(blind[1])
+                else:
+                    b = np.ascontiguousarray(blind, dtype=np.uint64).reshape(-1, 4); m = b.shape[0]; keep.append(b); bptr = b.ctypes.data
+                if m > ck.n_gamma: raise ValueError('blinding polynomial longer than the gamma powers')
+                segs.append((bptr, m, ck.gamma_offset, q))
+        k = len(polynomials) if hasattr(polynomials, '__len__') else (segs[-1][3] + 1 if segs else 0)
+        arr = (_Segment * max(len(segs), 1))(*[_Segment(p_, n_, o_, q_) for p_, n_, o_, q_ in segs])
+        out = np.zeros((k, 104), dtype=np.uint8)
+        if device:
+            check(lib().aleo_mi355x_kzg_commit_segments_device(_p(out), k, ck.bases.handle, arr, len(segs), ctypes.c_void_p(stream)), 'kzg_commit_segments_device')
+        else:
+            check(lib().aleo_mi355x_kzg_commit_segments(_p(out), k, ck.bases.handle, arr, len(segs)), 'kzg_commit_segments')
+        return out

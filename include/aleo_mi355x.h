@@ -156,6 +156,17 @@ int32_t aleo_mi355x_kzg_commit_batch_device(void* out_affine104, uint64_t handle
 /* Same with the k coefficient vectors in host memory (k host pointers). */
 int32_t aleo_mi355x_kzg_commit_batch(void* out_affine104, uint64_t handle, const void* const* coeffs_mont, const size_t* lens, size_t k);
 
+/* SonicKZG10::commit for the labelled polynomials of one round [UPSTREAM-RECALL: algorithms/src/polycommit/sonic_pc/mod.rs commit() ->
+ * kzg10::KZG10::commit per polynomial with `powers` or, for a degree bound d, `shifted_powers` = powers_of_beta_g[max_degree - d ..], plus
+ * a random polynomial against powers_of_beta_times_gamma_g when a hiding bound is set].  Every commitment is a SUM OF SEGMENTS over one
+ * pinned set: a segment multiplies `len` Montgomery coefficients with the bases [base_offset, base_offset + len) and adds into commitment
+ * `output`.  Plain polynomial: one segment at offset 0.  Degree bound d: one segment at offset max_degree - d.  Hiding: a second segment
+ * for the blinding polynomial at the offset where the caller pinned the gamma powers behind the powers (one pinned array: powers |
+ * gamma powers).  All segments of all commitments share one launch chain, like kzg_commit_batch.  out: n_outputs snarkVM Affine rows. */
+typedef struct { const void* scalars; size_t len; size_t base_offset; uint32_t output; } aleo_mi355x_commit_segment;
+int32_t aleo_mi355x_kzg_commit_segments(void* out_affine104, size_t n_outputs, uint64_t handle, const aleo_mi355x_commit_segment* segments, size_t n_segments);
+int32_t aleo_mi355x_kzg_commit_segments_device(void* out_affine104, size_t n_outputs, uint64_t handle, const aleo_mi355x_commit_segment* segments, size_t n_segments, void* stream);
+
 /* KZG10::commit with a hiding bound: msm(powers, coeffs) + msm(gamma_powers, blinding_coeffs), affine result.
  * Both coefficient vectors are Montgomery Fr on the host; both base sets are pinned handles. */
 int32_t aleo_mi355x_kzg_commit_hiding(void* out_affine104, uint64_t h_powers, const void* coeffs_mont, size_t n,

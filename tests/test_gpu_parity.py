@@ -857,3 +857,38 @@ def test_msm_g2_2_16_structured_identity():
     n = 1 << 16
     B = _g2_multiples(n); S = util.uniform_scalars(n, 16999)
     assert c.g2_jac_to_int_point(M.msm_g2(B, S)) == p.g2_mul(p.G2_GENERATOR, synth.weighted_scalar_sum(S, 1))
+
+
+# ---- SonicKZG10::commit shape: degree bounds (shifted powers) and hiding (gamma powers) as segments of one launch chain ------------
+def test_sonic_commit_degree_bounds_and_hiding_match_oracle():
+    """Labelled polynomials of one round with and without degree bounds and hiding bounds, all in ONE call over one pinned
+    (powers | gamma powers) set.  Expected per polynomial: oracle KZG10::commit over the bases its segment addresses
+    (powers[max_degree - bound ..] for a bounded polynomial) plus, when hiding, the oracle commitment of the blinding polynomial over the
+    gamma powers — added as group elements in big integers."""
+    import torch
+    N = 1 << 13; m = 8
+    gen = synth.generator_affine104()
+    with M.PinnedBases.generate_multiples(gen, 1, N) as tmp: powers = tmp.download()
+    with M.PinnedBases.generate_multiples(gen, 7_000_003, m) as tmp: gamma = tmp.download()
+    for precompute in (False, True):
+        with aleo_amd.CommitterKey(powers, gamma, precompute=precompute) as ck:
+            assert ck.max_degree == N - 1 and ck.gamma_offset == N
+            f = lambda n, seed: c.fr_to_mont(util.uniform_scalars(n, seed))
+            polys = [(f(N, 17001), None, None),                               # plain, full degree
+                     (f(5000, 17002), None, f(3, 17003)),                      # hiding
+                     (f(4096, 17004), 4095, None),                             # degree bound = its degree: shifted powers
+                     (f(3000, 17005), 6000, f(m, 17006)),                      # degree bound above the degree + hiding
+                     (c.fr_to_mont(util.witness_like_scalars(N, 17007)), None, f(1, 17008)),
+                     (f(1, 17009), 0, None)]                                   # constant polynomial at the very last power
+            got = aleo_amd.SonicKZG10.commit(ck, polys)
+            for q, (co, bound, blind) in enumerate(polys):
+                off = 0 if bound is None else ck.max_degree - bound
+                exp = c.affine_to_ints(c.kzg_commit(powers[off: off + len(co)], co, threads=8))[0]
+                if blind is not None: exp = p.g1_add(exp, c.affine_to_ints(c.kzg_commit(gamma[: len(blind)], blind, threads=1))[0])
+                assert c.affine_to_ints(got[q].reshape(1, 104))[0] == exp, (precompute, q)
+            # device-resident coefficients: same commitments
+            dev = [(torch.from_numpy(co.view(np.int64).copy()).cuda(), None if bl is None else torch.from_numpy(bl.view(np.int64).copy()).cuda()) for co, _, bl in polys]
+            torch.cuda.synchronize()
+            dpolys = [((d0.data_ptr(), len(co)), bound, None if d1 is None else (d1.data_ptr(), len(bl))) for (co, bound, bl), (d0, d1) in zip(polys, dev)]
+            assert (aleo_amd.SonicKZG10.commit(ck, dpolys, device=True) == got).all()
+            with pytest.raises(ValueError): aleo_amd.SonicKZG10.commit(ck, [(f(100, 1), 50, None)])          # bound below the degree
