@@ -39,9 +39,12 @@ def main():
     ap.add_argument('--proof-proxy-cpu-lg', type=int, default=15, help='size of the same replay on the CPU oracle (cpu_baseline leg)')
     ap.add_argument('--concurrent-callers', type=int, default=4, help='secondary: aggregate rate with this many caller threads (0/1 = skip)')
     ap.add_argument('--sharded-ntt-lg', type=int, default=24, help='size of the secondary sharded-NTT measurement at N > 1 (stderr)')
+    ap.add_argument('--aux-sharded-ntt', action='store_true', help=argparse.SUPPRESS)
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
                     help="'gloo' is only for rehearsing the N>1 path with several ranks sharing one GPU")
     args = ap.parse_args()
+    if args.aux_sharded_ntt:
+        raise SystemExit(aux_sharded_ntt(args))
 
     import torch
     import torch.distributed as dist
@@ -190,24 +193,46 @@ def main():
             out['cpu_baseline'] = cpu_baseline(args, pb, scalars, aleo_amd)
         print(json.dumps(out), flush=True)
     if world > 1:
-        # secondary, outside the timed region and AFTER the MSM line is out: the sharded (4-step) NTT with its one all-to-all.
-        # It must never cost the headline run: an exception is reported on stderr.  A watchdog ends a rank whose probe
-        # collective does not return — with a NON-zero status and a line on stderr, so a hang never reads as success.
-        import threading
+        # Secondary, outside the timed region and AFTER the MSM line is out: the sharded (4-step) NTT with its one RCCL all-to-all.
+        # It must never cost the headline run, so it runs in a CHILD process per rank (own process group on the next port): the
+        # parent has already printed its line and exits 0 whatever happens to the probe; a child that hangs is killed after 150 s
+        # and reported on stderr, never as success.
         sys.stdout.flush()
-
-        def _hung():
-            print(json.dumps({'aux': 'sharded_ntt', 'error': 'timeout: a collective of the probe did not return within 120 s', 'rank': rank}), file=sys.stderr, flush=True)
-            os._exit(3)
-        dog = threading.Timer(120.0, _hung); dog.daemon = True; dog.start()
-        try:
-            sn = sharded_ntt_probe(aleo_amd, adist, synth, torch, dist, dev, rank, world, args.sharded_ntt_lg) if args.sharded_ntt_lg else {'skipped': 'disabled'}
-        except Exception as e:      # noqa: BLE001
-            sn = {'error': repr(e)}
-        if rank == 0:
-            print(json.dumps({'aux': 'sharded_ntt', **sn}), file=sys.stderr, flush=True)
         dist.barrier(); dist.destroy_process_group()
-        dog.cancel()
+        if args.sharded_ntt_lg:
+            import subprocess
+            env = dict(os.environ, MASTER_PORT=str(int(os.environ.get('MASTER_PORT', '29500')) + 1), MASTER_ADDR=os.environ.get('MASTER_ADDR', '127.0.0.1'))
+            env.pop('TORCHELASTIC_USE_AGENT_STORE', None)          # the children rendezvous on their own store (rank 0 hosts it), not the launcher's
+            cmd = [sys.executable, os.path.abspath(__file__), '--aux-sharded-ntt', '--gpus', str(world), '--sharded-ntt-lg', str(args.sharded_ntt_lg), '--backend', args.backend]
+            try:
+                r = subprocess.run(cmd, env=env, timeout=150, capture_output=True, text=True)
+                if rank == 0:
+                    line = [l for l in r.stderr.splitlines() if l.startswith('{"aux"')]
+                    print(line[-1] if line else json.dumps({'aux': 'sharded_ntt', 'error': 'probe exited with %d' % r.returncode, 'stderr_tail': r.stderr[-400:]}), file=sys.stderr, flush=True)
+            except subprocess.TimeoutExpired:
+                print(json.dumps({'aux': 'sharded_ntt', 'error': 'timeout: the probe did not finish within 150 s (child killed)', 'rank': rank}), file=sys.stderr, flush=True)
+
+
+def aux_sharded_ntt(args):
+    """Child-process entry (bench.py --aux-sharded-ntt): only the sharded-NTT probe, on its own process group."""
+    import torch
+    import torch.distributed as dist
+    import aleo_amd
+    from aleo_amd import synth
+    from aleo_amd import dist as adist
+    rank = int(os.environ.get('RANK', '0')); world = int(os.environ.get('WORLD_SIZE', '1')); local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    dev_index = local_rank % torch.cuda.device_count(); torch.cuda.set_device(dev_index); dev = torch.device('cuda', dev_index)
+    if args.backend == 'nccl': dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+    else: dist.init_process_group('gloo', rank=rank, world_size=world)
+    aleo_amd._lib.check(aleo_amd.lib().aleo_mi355x_init(dev_index), 'init')
+    try:
+        sn = sharded_ntt_probe(aleo_amd, adist, synth, torch, dist, dev, rank, world, args.sharded_ntt_lg)
+    except Exception as e:      # noqa: BLE001
+        sn = {'error': repr(e)}
+    if rank == 0:
+        print(json.dumps({'aux': 'sharded_ntt', **sn}), file=sys.stderr, flush=True)
+    dist.barrier(); dist.destroy_process_group()
+    return 1 if 'error' in sn else 0
 
 
 def concurrent_callers(aleo_amd, synth, torch, dev, pb, n, T, reps=8):
