@@ -329,7 +329,8 @@ static void* pool_worker(void* arg) {
 }
 
 /* out: Jacobian (x,y,z) Montgomery, 144 bytes.  bases: stride bytes per element (104 = snarkVM Affine, or 96
- * = x,y only with no infinity flag).  threads <= 0 -> 1.  variant 0 = standard.rs, 1 = batched.rs */
+ * = x,y only with no infinity flag).  threads <= 0 -> 1.  variant 0 = standard.rs, 1 = batched.rs; 2 / 3 = the same with the points of
+ * every window also split over the threads (not how the reference parallelises: used for the all-cores CPU baseline) */
 int oracle_msm_g1(void* out, const void* bases_, size_t stride, const void* scalars_, size_t n, int threads, int variant) {
   if (stride != 104 && stride != 96) return -1;
   G1Affine* bases = (G1Affine*)malloc(sizeof(G1Affine) * (n ? n : 1));
@@ -341,9 +342,15 @@ int oracle_msm_g1(void* out, const void* bases_, size_t stride, const void* scal
   const u64* scalars = (const u64*)scalars_;
   unsigned c = n < 32 ? 3 : ln_without_floats(n) + 2;
   int nw = (FR_BITS + c - 1) / c;
-  window_job* jobs = (window_job*)calloc(nw, sizeof(window_job));
-  for (int w = 0; w < nw; ++w) { jobs[w].bases = bases; jobs[w].scalars = scalars; jobs[w].n = n; jobs[w].c = c; jobs[w].w_start = w * c; jobs[w].batched = variant; }
-  job_pool P; P.jobs = jobs; P.njobs = nw; P.next = 0; pthread_mutex_init(&P.mu, NULL);
+  /* variant 2/3 = variant 0/1 with every window's points cut into `parts` contiguous ranges (one job each, partial window sums added
+   * afterwards): the reference parallelises over windows only, i.e. <= ceil(253/c) threads; this lets the CPU baseline use a whole box. */
+  int parts = 1; if (variant >= 2) { variant -= 2; parts = threads > nw ? (threads + nw - 1) / nw : 1; if ((size_t)parts > n / 1024 + 1) parts = (int)(n / 1024 + 1); }
+  window_job* jobs = (window_job*)calloc((size_t)nw * parts, sizeof(window_job));
+  for (int w = 0; w < nw; ++w) for (int p = 0; p < parts; ++p) {
+    window_job* J = &jobs[w * parts + p]; size_t lo = n * (size_t)p / parts, hi = n * (size_t)(p + 1) / parts;
+    J->bases = bases + lo; J->scalars = scalars + 4 * lo; J->n = hi - lo; J->c = c; J->w_start = w * c; J->batched = variant;
+  }
+  job_pool P; P.jobs = jobs; P.njobs = nw * parts; P.next = 0; pthread_mutex_init(&P.mu, NULL);
   if (threads <= 1) pool_worker(&P);
   else {
     pthread_t* th = (pthread_t*)malloc(sizeof(pthread_t) * threads);
@@ -351,6 +358,8 @@ int oracle_msm_g1(void* out, const void* bases_, size_t stride, const void* scal
     for (int t = 0; t < threads; ++t) pthread_join(th[t], NULL);
     free(th);
   }
+  for (int w = 0; w < nw; ++w) for (int p = 1; p < parts; ++p) g1p_add(&jobs[w * parts].out, &jobs[w * parts + p].out);
+  if (parts > 1) for (int w = 1; w < nw; ++w) jobs[w] = jobs[w * parts];          /* compact: window sums at jobs[0..nw) */
   /* standard.rs: lowest + fold(rest.rev(), |total, w| { total += w; c doublings }) */
   G1Proj total; g1p_zero(&total);
   for (int w = nw - 1; w >= 1; --w) { g1p_add(&total, &jobs[w].out); for (unsigned d = 0; d < c; ++d) g1p_double(&total); }

@@ -65,7 +65,7 @@ def bases_for_case(case):
     return c.affine_from_ints(pts)
 
 
-@pytest.mark.parametrize('variant', [0, 1])
+@pytest.mark.parametrize('variant', [0, 1, 2, 3])
 def test_oracle_msm_matches_golden(variant):
     for case in golden_msm_cases():
         B = bases_for_case(case); S = c.ints_to_limbs(_ints(case['scalars']), 4)
