@@ -28,15 +28,17 @@ __device__ __forceinline__ SliceRule pick_rule(const uint32_t* total_pairs, uint
   // Two pulls.  Keep buckets whole where possible (every extra slice is a 14-product tree addition): single = 2 x the
   // mean bucket size.  But fill the chip: the launch wants >= 2^18 slices (2 waves per SIMD), and a lane needs ~11 us per
   // addition, so when there are few pairs (small n, sparse scalars) slices are cut down to pairs / 2^18 points even if
-  // that splits ordinary buckets.  Everything in powers of two, 8 <= single <= 512, split = single / 2.
+  // that splits ordinary buckets.  Everything in powers of two, 4 <= split <= single <= 512.
   const uint32_t pairs = total_pairs[0], mean = pairs / M, fill_shift = total_pairs[1];      // [1]: lg of the slice count the launch aims for (msm_sort_phase)
   // below 2^18 pairs (2^10..2^13-point MSMs) the accumulation is a chain of a few ~19 us additions per lane on a mostly idle chip:
   // slices of 4 instead of 8 halve it for one more slice-tree level (2^12: 0.50 -> 0.44 ms; from 2^14 up the extra level costs what it saves)
   const uint32_t fill_min = pairs < (1u << 18) ? 4u : 8u;
   uint32_t by_mean = 32u; while (by_mean < 2u * mean && by_mean < 512u) by_mean <<= 1;
   uint32_t fill = fill_min; while (fill < (pairs >> fill_shift) && fill < 256u) fill <<= 1;
-  SliceRule r; r.single = by_mean < 2u * fill ? by_mean : 2u * fill;
-  r.split = r.single >> 1;
+  SliceRule r; r.single = by_mean; r.split = by_mean >> 1;          // plenty of pairs: whole buckets up to 2 x the mean size, larger ones cut at the mean
+  // few pairs: every bucket above `fill` points is cut into slices of <= fill — no hysteresis: a bucket of 1.5 fill left whole was the
+  // longest chain of the launch (2^15..2^18 points: -4..-16 % wall time; 2^20 unchanged)
+  if (by_mean >= 2u * fill) { r.single = fill; r.split = fill; }
   return r;
 }
 __device__ __forceinline__ uint32_t slices_of(uint32_t cnt, SliceRule r) { return cnt <= r.single ? (cnt ? 1u : 0u) : (cnt + r.split - 1) / r.split; }
