@@ -789,7 +789,7 @@ static uint32_t fill_shift() {
 static size_t slice_bound(size_t pairs_max, size_t M) {
   const size_t nonempty = M < pairs_max ? M : pairs_max;
   const size_t fill_cap = ((size_t)9 << fill_shift()) >> 3;          // pairs / fill < 1.125 * 2^fill_shift while the fill rule decides
-  const size_t by_rule = (M > fill_cap ? M : fill_cap) + pairs_max / 256;
+  const size_t by_rule = M + fill_cap + pairs_max / 256;
   const size_t by_min = pairs_max / 4;          // pick_rule's shortest split (the device decides 4 or 8 from its own pair count, which may be far below pairs_max)
   return nonempty + (by_min < by_rule ? by_min : by_rule) + 1;
 }

@@ -34,7 +34,11 @@ __device__ __forceinline__ SliceRule pick_rule(const uint32_t* total_pairs, uint
   // slices of 4 instead of 8 halve it for one more slice-tree level (2^12: 0.50 -> 0.44 ms; from 2^14 up the extra level costs what it saves)
   const uint32_t fill_min = pairs < (1u << 18) ? 4u : 8u;
   uint32_t by_mean = 32u; while (by_mean < 2u * mean && by_mean < 512u) by_mean <<= 1;
-  uint32_t fill = fill_min; while (fill < (pairs >> fill_shift) && fill < 256u) fill <<= 1;
+  // the accumulation kernel holds two waves per SIMD (248 VGPRs): 2^17 lanes, and its slices start longest first, so the launch lasts
+  // about max(longest slice, pairs / 2^17) additions: cut at exactly that many points (not the next power of two: 1.57 M pairs want
+  // slices of 12, not 16), a little over 2^17 slices is harmless — the surplus are the shortest ones
+  uint32_t fill = (pairs + (1u << fill_shift) - 1) >> fill_shift;
+  fill = fill < fill_min ? fill_min : (fill > 256u ? 256u : fill);
   SliceRule r; r.single = by_mean; r.split = by_mean >> 1;          // plenty of pairs: whole buckets up to 2 x the mean size, larger ones cut at the mean
   // few pairs: every bucket above `fill` points is cut into slices of <= fill — no hysteresis: a bucket of 1.5 fill left whole was the
   // longest chain of the launch (2^15..2^18 points: -4..-16 % wall time; 2^20 unchanged)
