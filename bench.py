@@ -468,6 +468,22 @@ def proof_proxy_cpu(c, aleo_amd, synth, lg, cores):
     return {'constraints': H, 'seconds': dt, 'constraints_per_s': H / dt, 'msm_seconds': t_msm, 'msm_threads': cores, 'other_threads': 1}
 
 
+def effective_cpus():
+    """Host cores this process may actually use: the cgroup CPU quota when there is one (a GPU box reports all 256 hardware threads
+    but grants a share of them), else the scheduler affinity."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        q, per = open('/sys/fs/cgroup/cpu.max').read().split()[:2]
+        if q != 'max': n = min(n, max(1, int(int(q) / int(per) + 0.5)))
+    except Exception:
+        try:
+            q = int(open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us').read()); per = int(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+            if q > 0: n = min(n, max(1, int(q / per + 0.5)))
+        except Exception:
+            pass
+    return n
+
+
 def cpu_baseline(args, pb, scalars, aleo_amd):
     """The oracle (C restatement of snarkVM's batched Pippenger, all host cores) on a bounded sample of the same
     workload; also re-checks GPU == oracle on that sample.  kind 'port': it is not the Rust binary."""
@@ -477,13 +493,13 @@ def cpu_baseline(args, pb, scalars, aleo_amd):
     # the restated algorithm (like snarkVM's rayon version) runs one window per thread: c = ln(n)+2 bits -> ceil(253/c)
     # windows is the most threads it can use, whatever the box has
     lg = ns.bit_length() - 1; nwin = -(-253 // (lg * 69 // 100 + 2))
-    cores = min(os.cpu_count() or 1, nwin)
+    cores = min(effective_cpus(), nwin)
     bases = pb.download(0, ns)
     s = np.ascontiguousarray(scalars[:ns])
     c.msm_g1(bases[:256], s[:256], threads=1, variant=1)                    # load the library outside the timing
     t0 = time.perf_counter(); ref = c.msm_g1(bases, s, threads=cores, variant=1); dt_ref = time.perf_counter() - t0
     # ... and with the points of every window also split over the threads, so that the baseline uses the whole box
-    all_cores = os.cpu_count() or 1
+    all_cores = effective_cpus()
     t0 = time.perf_counter(); ref2 = c.msm_g1(bases, s, threads=all_cores, variant=3); dt = time.perf_counter() - t0
     if c.jac_to_int_point(ref2) != c.jac_to_int_point(ref): raise SystemExit('bench: the two CPU baselines disagree')
     got = aleo_amd.VariableBase.msm(pb, s)
@@ -492,10 +508,10 @@ def cpu_baseline(args, pb, scalars, aleo_amd):
     proxy = None
     if args.proof_proxy_lg and args.proof_proxy_cpu_lg:
         from aleo_amd import synth
-        proxy = proof_proxy_cpu(c, aleo_amd, synth, args.proof_proxy_cpu_lg, os.cpu_count() or 1)
+        proxy = proof_proxy_cpu(c, aleo_amd, synth, args.proof_proxy_cpu_lg, effective_cpus())
     return {'proof_proxy': proxy, 'one_core': {'value': n1 / dt1, 'unit': 'scalar-muls/s', 'cores': 1, 'seconds': dt1, 'sample': '2^%d-point prefix' % (n1.bit_length() - 1)},
             'value': ns / dt, 'unit': 'scalar-muls/s', 'cores': all_cores, 'kind': 'port', 'seconds': dt,
-            'host_cpus': os.cpu_count(),
+            'host_cpus': os.cpu_count(), 'usable_cpus': effective_cpus(),
             'window_parallel_only': {'value': ns / dt_ref, 'unit': 'scalar-muls/s', 'cores': cores, 'seconds': dt_ref,
                                      'note': 'the reference parallelises over windows only (rayon over ceil(253/c) windows): this is its shape'},
             'sample': '2^%d-point prefix of the same bases/scalars; C restatement of snarkvm-algorithms 0.14.5 batched MSM with the points of '

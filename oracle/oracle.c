@@ -340,17 +340,24 @@ int oracle_msm_g1(void* out, const void* bases_, size_t stride, const void* scal
     bases[i].infinity = (stride == 104) ? (src[96] != 0) : 0;
   }
   const u64* scalars = (const u64*)scalars_;
-  unsigned c = n < 32 ? 3 : ln_without_floats(n) + 2;
-  int nw = (FR_BITS + c - 1) / c;
-  /* variant 2/3 = variant 0/1 with every window's points cut into `parts` contiguous ranges (one job each, partial window sums added
-   * afterwards): the reference parallelises over windows only, i.e. <= ceil(253/c) threads; this lets the CPU baseline use a whole box. */
-  int parts = 1; if (variant >= 2) { variant -= 2; parts = threads > nw ? (threads + nw - 1) / nw : 1; if ((size_t)parts > n / 1024 + 1) parts = (int)(n / 1024 + 1); }
-  window_job* jobs = (window_job*)calloc((size_t)nw * parts, sizeof(window_job));
-  for (int w = 0; w < nw; ++w) for (int p = 0; p < parts; ++p) {
-    window_job* J = &jobs[w * parts + p]; size_t lo = n * (size_t)p / parts, hi = n * (size_t)(p + 1) / parts;
-    J->bases = bases + lo; J->scalars = scalars + 4 * lo; J->n = hi - lo; J->c = c; J->w_start = w * c; J->batched = variant;
+  /* variant 2/3 = variant 0/1 with the points cut into `parts` contiguous ranges, every range a full MSM of its own (its own window
+   * size from its own length, its windows as parallel jobs, its own Horner), the range results added: the reference parallelises over
+   * windows only, i.e. <= ceil(253/c) threads; this lets the CPU baseline use a whole box. */
+  int parts = 1;
+  { unsigned c0 = n < 32 ? 3 : ln_without_floats(n) + 2; int nw0 = (FR_BITS + c0 - 1) / c0;
+    if (variant >= 2) { variant -= 2; parts = threads > 1 ? (4 * threads + nw0 - 1) / nw0 : 1;          /* ~4 jobs per thread: the last round of jobs stays short */
+      if ((size_t)parts > n / 4096 + 1) parts = (int)(n / 4096 + 1); } }
+  unsigned* pc = (unsigned*)malloc(sizeof(unsigned) * parts); int* pw0 = (int*)malloc(sizeof(int) * (parts + 1)); pw0[0] = 0;
+  for (int p = 0; p < parts; ++p) {
+    size_t np = n * (size_t)(p + 1) / parts - n * (size_t)p / parts;
+    pc[p] = np < 32 ? 3 : ln_without_floats(np) + 2; pw0[p + 1] = pw0[p] + (int)((FR_BITS + pc[p] - 1) / pc[p]);
   }
-  job_pool P; P.jobs = jobs; P.njobs = nw * parts; P.next = 0; pthread_mutex_init(&P.mu, NULL);
+  window_job* jobs = (window_job*)calloc((size_t)pw0[parts], sizeof(window_job));
+  for (int p = 0; p < parts; ++p) for (int w = 0; w < pw0[p + 1] - pw0[p]; ++w) {
+    window_job* J = &jobs[pw0[p] + w]; size_t lo = n * (size_t)p / parts, hi = n * (size_t)(p + 1) / parts;
+    J->bases = bases + lo; J->scalars = scalars + 4 * lo; J->n = hi - lo; J->c = pc[p]; J->w_start = w * pc[p]; J->batched = variant;
+  }
+  job_pool P; P.jobs = jobs; P.njobs = pw0[parts]; P.next = 0; pthread_mutex_init(&P.mu, NULL);
   if (threads <= 1) pool_worker(&P);
   else {
     pthread_t* th = (pthread_t*)malloc(sizeof(pthread_t) * threads);
@@ -358,12 +365,15 @@ int oracle_msm_g1(void* out, const void* bases_, size_t stride, const void* scal
     for (int t = 0; t < threads; ++t) pthread_join(th[t], NULL);
     free(th);
   }
-  for (int w = 0; w < nw; ++w) for (int p = 1; p < parts; ++p) g1p_add(&jobs[w * parts].out, &jobs[w * parts + p].out);
-  if (parts > 1) for (int w = 1; w < nw; ++w) jobs[w] = jobs[w * parts];          /* compact: window sums at jobs[0..nw) */
-  /* standard.rs: lowest + fold(rest.rev(), |total, w| { total += w; c doublings }) */
+  /* standard.rs: lowest + fold(rest.rev(), |total, w| { total += w; c doublings }), per range */
   G1Proj total; g1p_zero(&total);
-  for (int w = nw - 1; w >= 1; --w) { g1p_add(&total, &jobs[w].out); for (unsigned d = 0; d < c; ++d) g1p_double(&total); }
-  g1p_add(&total, &jobs[0].out);
+  for (int p = 0; p < parts; ++p) {
+    G1Proj t; g1p_zero(&t); const window_job* Jp = jobs + pw0[p]; int nw = pw0[p + 1] - pw0[p]; unsigned c = pc[p];
+    for (int w = nw - 1; w >= 1; --w) { g1p_add(&t, &Jp[w].out); for (unsigned d = 0; d < c; ++d) g1p_double(&t); }
+    g1p_add(&t, &Jp[0].out);
+    g1p_add(&total, &t);
+  }
+  free(pc); free(pw0);
   memcpy(out, &total, sizeof total);
   free(jobs); free(bases);
   return 0;
