@@ -22,7 +22,7 @@ int32_t ensure_host_pinned(Ctx* c, size_t bytes) {
   if (c->h_pinned) (void)hipHostFree(c->h_pinned);
   c->h_pinned = nullptr; c->h_pinned_cap = 0;
   size_t want = bytes < 65536 ? 65536 : bytes;
-  HIPCHK(hipHostMalloc(&c->h_pinned, want, hipHostMallocDefault));
+  HIPCHK(hipHostMalloc(&c->h_pinned, want, hipHostMallocMapped));      // device-mapped: the last fold kernel of an MSM stores its result here
   c->h_pinned_cap = want; return ALEO_MI355X_OK;
 }
 

@@ -1007,12 +1007,15 @@ int32_t msm_run(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, const MsmJob
       cur = dst; stride = half; L = half;
     }
     if (L > 1) {
-      char* dst = (cur == F1) ? F2 : F1;
+      // the last fold leaves one point per segment, contiguous: it stores them straight into the slot's pinned host buffer (device-
+      // mapped), so the result needs neither a gather launch nor a copy — the stream synchronisation below is all that is left
+      char* dst = nullptr;
+      HIPCHK(hipHostGetDevicePointer((void**)&dst, h_win, 0));
       hipLaunchKernelGGL(k_seg_fold, dim3(nseg), dim3(256), 0, s, cur, stride, L, nseg, dst, 1u);
-      cur = dst; stride = 1; L = 1;
+    } else {
+      hipLaunchKernelGGL(k_gather_strided, dim3((nseg * 14 + 255) / 256), dim3(256), 0, s, cur, stride, nseg, Tout);
+      HIPCHK(hipMemcpyAsync(h_win, Tout, (size_t)nseg * PB28, hipMemcpyDeviceToHost, s));
     }
-    hipLaunchKernelGGL(k_gather_strided, dim3((nseg * 14 + 255) / 256), dim3(256), 0, s, cur, stride, nseg, Tout);
-    HIPCHK(hipMemcpyAsync(h_win, Tout, (size_t)nseg * PB28, hipMemcpyDeviceToHost, s));
     HIPCHK(hipEventRecord(c->ev[3], s));
     HIPCHK(hipStreamSynchronize(s));
     HIPCHK(hipGetLastError());
