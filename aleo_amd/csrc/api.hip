@@ -295,6 +295,18 @@ int32_t aleo_mi355x_bases_generate(const void* base104, uint64_t first, size_t n
   } catch (...) { return ALEO_MI355X_ERR_HIP; }
 }
 
+int32_t aleo_mi355x_bases_from_scalars(const void* base104, const void* scalars, size_t n, uint64_t* handle) {
+  try {
+    if (!base104 || !handle || !scalars) return ALEO_MI355X_ERR_BAD_ARG;
+    API_BEGIN
+    auto o = std::make_shared<PinnedOwner>();
+    int32_t rc = generate_from_scalars(c, base104, scalars, n, &o->pb);
+    if (rc) return rc;
+    *handle = register_bases(d, std::move(o));
+    return ALEO_MI355X_OK;
+  } catch (...) { return ALEO_MI355X_ERR_HIP; }
+}
+
 int32_t aleo_mi355x_bases_precompute(uint64_t handle) {
   try {
     API_BEGIN
@@ -563,6 +575,14 @@ int32_t aleo_mi355x_fr_vec_op_device(void* d_dst, const void* d_a, const void* d
   } catch (...) { return ALEO_MI355X_ERR_HIP; }
 }
 
+int32_t aleo_mi355x_fr_lin_device(void* d_dst, size_t n, const void* c0_mont, const void* c1_mont, const void* d_a, const void* c2_mont, const void* d_b, void* stream) {
+  try {
+    if (!d_dst && n) return ALEO_MI355X_ERR_BAD_ARG;
+    API_BEGIN
+    return run_enqueue(c, stream, [&](hipStream_t s) { return fr_lin(c, d_dst, n, c0_mont, c1_mont, d_a, c2_mont, d_b, s); });
+  } catch (...) { return ALEO_MI355X_ERR_HIP; }
+}
+
 int32_t aleo_mi355x_fr_batch_inverse_device(void* d_inout, size_t n, void* stream) {
   try {
     if (!d_inout && n) return ALEO_MI355X_ERR_BAD_ARG;
@@ -573,7 +593,7 @@ int32_t aleo_mi355x_fr_batch_inverse_device(void* d_inout, size_t n, void* strea
 
 int32_t aleo_mi355x_fr_divide_by_linear_device(void* d_quotient, void* d_eval, const void* d_poly, size_t n, const void* z_mont, void* stream) {
   try {
-    if (((!d_quotient && n > 1) || !d_poly) && n) return ALEO_MI355X_ERR_BAD_ARG;
+    if ((!d_poly && n) || (!d_quotient && !d_eval)) return ALEO_MI355X_ERR_BAD_ARG;
     if (!z_mont || (d_quotient && d_quotient == d_poly)) { g_last_error = "fr_divide_by_linear_device: null point, or quotient aliases the polynomial"; return ALEO_MI355X_ERR_BAD_ARG; }
     API_BEGIN
     return run_enqueue(c, stream, [&](hipStream_t s) { return fr_divide_by_linear(c, d_quotient, d_eval, d_poly, n, z_mont, s); });

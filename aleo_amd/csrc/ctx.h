@@ -145,6 +145,7 @@ uint32_t msm_max_sets(const PinnedBases& pb, size_t n);
 int32_t launch_fq_mul(Ctx* c, void* r, const void* a, const void* b, size_t n);
 int32_t launch_fr_mul(Ctx* c, void* r, const void* a, const void* b, size_t n);
 int32_t generate_multiples(Ctx* c, const void* base104, uint64_t first, size_t n, PinnedBases* out);
+int32_t generate_from_scalars(Ctx* c, const void* base104, const void* scalars32, size_t n, PinnedBases* out);
 int32_t msm_precompute(Ctx* c, PinnedBases* pb);
 int32_t make_rows28(Ctx* c, PinnedBases* pb);          // fills pb->d_xy28 from pb->d_xy
 int32_t selftest_madd28(Ctx* c, uint32_t lanes, uint32_t steps, uint64_t seed, uint32_t* failures);
@@ -152,6 +153,7 @@ int32_t selftest_madd28(Ctx* c, uint32_t lanes, uint32_t steps, uint64_t seed, u
 int32_t msm_g2_run(Ctx* c, uint64_t* out_jac36, const void* d_xy192, const uint8_t* d_inf, const void* d_scalars, size_t n, hipStream_t s);
 int32_t g2_sum_host(uint64_t* out36, const uint64_t* pts36, size_t count);
 // frops.hip
+int32_t fr_lin(Ctx* c, void* d_dst, size_t n, const void* c0, const void* c1, const void* d_a, const void* c2, const void* d_b, hipStream_t s);
 int32_t fr_vec_op(Ctx* c, void* d_dst, const void* d_a, const void* d_b, size_t n, int32_t op, hipStream_t s);
 int32_t fr_batch_inverse(Ctx* c, void* d_inout, size_t n, hipStream_t s);
 int32_t fr_divide_by_linear(Ctx* c, void* d_q, void* d_eval, const void* d_p, size_t n, const void* z_mont32, hipStream_t s);

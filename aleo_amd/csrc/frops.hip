@@ -78,6 +78,39 @@ int32_t fr_vec_op(Ctx* c, void* d_dst, const void* d_a, const void* d_b, size_t 
   return ALEO_MI355X_OK;
 }
 
+// dst[i] = c0 + c1 * a[i] + c2 * b[i] with host-side constants (Montgomery): the scalar-times-vector, shifted and blended forms
+// of the AHP rounds (alpha - h_i before a batch inversion, eta-weighted sums of z_a, z_b, the linear combinations opened at
+// beta and gamma) [UPSTREAM-RECALL: snark/varuna/ahp/prover/round_functions/{second,third,fourth}.rs run these as rayon maps].
+struct FrK { uint32_t v[8]; };
+__device__ __forceinline__ Fr fr_arg(const FrK& k) { Fr r; for (int i = 0; i < 8; ++i) r.v[i] = k.v[i]; return r; }
+template <bool HAS_A, bool HAS_B>
+__global__ void __launch_bounds__(256) k_fr_lin(char* __restrict__ dst, size_t n, FrK k0, FrK k1, const char* a, FrK k2, const char* b) {
+  const Fr c0 = fr_arg(k0), c1 = fr_arg(k1), c2 = fr_arg(k2);
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    Fr r = c0;                                                                                    // canonical: < r
+    if constexpr (HAS_A) r = Fr::cond_sub<2>(Fr::add(r, Fr::mul(c1, load_fp<Fr>(a + i * 32))));    // < 3r -> < 2r
+    if constexpr (HAS_B) r = Fr::cond_sub<2>(Fr::add(r, Fr::mul(c2, load_fp<Fr>(b + i * 32))));    // < 4r -> < 2r
+    store_fp<Fr>(dst + i * 32, Fr::cond_sub<1>(r));
+  }
+}
+
+int32_t fr_lin(Ctx* c, void* d_dst, size_t n, const void* c0, const void* c1, const void* d_a, const void* c2, const void* d_b, hipStream_t s) {
+  (void)c;
+  if (n == 0) return ALEO_MI355X_OK;
+  FrK k0{}, k1{}, k2{};
+  if (c0) std::memcpy(k0.v, c0, 32);
+  if (d_a) { if (!c1) { g_last_error = "fr_lin: a without c1"; return ALEO_MI355X_ERR_BAD_ARG; } std::memcpy(k1.v, c1, 32); }
+  if (d_b) { if (!c2) { g_last_error = "fr_lin: b without c2"; return ALEO_MI355X_ERR_BAD_ARG; } std::memcpy(k2.v, c2, 32); }
+  size_t want = (n + 255) / 256; dim3 grid((uint32_t)(want < 8192 ? want : 8192)), blk(256);
+  char* dst = (char*)d_dst; const char* a = (const char*)d_a; const char* b = (const char*)d_b;
+  if (a && b) hipLaunchKernelGGL((k_fr_lin<true, true>), grid, blk, 0, s, dst, n, k0, k1, a, k2, b);
+  else if (a) hipLaunchKernelGGL((k_fr_lin<true, false>), grid, blk, 0, s, dst, n, k0, k1, a, k2, b);
+  else if (b) hipLaunchKernelGGL((k_fr_lin<false, true>), grid, blk, 0, s, dst, n, k0, k1, a, k2, b);
+  else hipLaunchKernelGGL((k_fr_lin<false, false>), grid, blk, 0, s, dst, n, k0, k1, a, k2, b);
+  HIPCHK(hipGetLastError());
+  return ALEO_MI355X_OK;
+}
+
 // ---- sparse matrix x vector over Fr: z_M = M * z for the R1CS matrices A, B, C ----------------
 // Replaces the per-row inner products snarkVM's Varuna prover runs on rayon before committing z_a, z_b
 // (`matrix row: Vec<(F, usize)>` dotted with the assignment [UPSTREAM-RECALL: snark/varuna/ahp/prover/round_functions/first.rs]).
@@ -146,8 +179,6 @@ int32_t fr_spmv(Ctx* c, void* d_y, const void* d_row_ptr, const void* d_col, con
 //   k_div_finish   every block scans its lanes' values seeded with C_b, every lane replays its 16 steps and writes w
 // 96 algorithmic bytes per coefficient (p read twice, w written once); values stay lazily reduced below 4r (fp.h).
 static constexpr uint32_t DIV_K = 16, DIV_B = 256, DIV_TILE = DIV_K * DIV_B;
-struct FrK { uint32_t v[8]; };
-__device__ __forceinline__ Fr fr_arg(const FrK& k) { Fr r; for (int i = 0; i < 8; ++i) r.v[i] = k.v[i]; return r; }
 __device__ __forceinline__ Fr fr_lt2r(const Fr& a) { return Fr::cond_sub<2>(a); }                    // < 4r -> < 2r
 __device__ __forceinline__ void lds_put(uint32_t* l, uint32_t t, const Fr& a) { for (int i = 0; i < 8; ++i) l[i * DIV_B + t] = a.v[i]; }
 __device__ __forceinline__ Fr lds_get(const uint32_t* l, uint32_t t) { Fr r; for (int i = 0; i < 8; ++i) r.v[i] = l[i * DIV_B + t]; return r; }
@@ -217,7 +248,7 @@ __global__ void __launch_bounds__(256) k_div_finish(const char* __restrict__ p, 
     const size_t j = lo + (size_t)k;
     if (j >= n) continue;
     s = Fr::add(Fr::mul(s, z), load_fp<Fr>(p + j * 32));    // < 3r
-    if (j) store_fp<Fr>(q + (j - 1) * 32, Fr::reduce(s)); else if (eval) store_fp<Fr>(eval, Fr::reduce(s));
+    if (j) { if (q) store_fp<Fr>(q + (j - 1) * 32, Fr::reduce(s)); } else if (eval) store_fp<Fr>(eval, Fr::reduce(s));
   }
 }
 

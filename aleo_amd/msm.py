@@ -37,6 +37,15 @@ class PinnedBases:
         check(lib().aleo_mi355x_bases_generate(_p(b), first_multiple, n, ctypes.byref(h)), 'bases_generate')
         return cls(None, h.value, n)
 
+    @classmethod
+    def from_scalars(cls, base_affine104: np.ndarray, scalars: np.ndarray) -> 'PinnedBases':
+        """P_i = s_i * base for canonical scalars uint64[n,4] (e.g. s_i = beta^i: a synthetic universal-setup SRS), built in HBM."""
+        b = np.ascontiguousarray(base_affine104, dtype=np.uint8).reshape(104)
+        sc = np.ascontiguousarray(scalars, dtype=np.uint64).reshape(-1, 4)
+        h = ctypes.c_uint64(0)
+        check(lib().aleo_mi355x_bases_from_scalars(_p(b), _p(sc), sc.shape[0], ctypes.byref(h)), 'bases_from_scalars')
+        return cls(None, h.value, sc.shape[0])
+
     def precompute(self) -> 'PinnedBases':
         """Build the fixed-base window table in HBM (13 x 112 B per point at 2^20); full-length MSMs then take the fast path."""
         check(lib().aleo_mi355x_bases_precompute(self.handle), 'bases_precompute')

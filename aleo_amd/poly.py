@@ -12,6 +12,15 @@ def fr_vec_op_device(d_dst: int, d_a: int, d_b: int, n: int, op: int, stream: in
                                              ctypes.c_void_p(stream)), 'fr_vec_op_device')
 
 
+def fr_lin_device(d_dst: int, n: int, c0, c1=None, d_a: int = 0, c2=None, d_b: int = 0, stream: int = 0):
+    """dst[i] = c0 + c1 * a[i] + c2 * b[i]; c0/c1/c2: uint64[4] Montgomery on the host (None = absent term)."""
+    import numpy as np
+    keep = [None if c is None else np.ascontiguousarray(c, dtype=np.uint64).reshape(4) for c in (c0, c1, c2)]
+    ptr = [ctypes.c_void_p(0) if k is None else k.ctypes.data_as(ctypes.c_void_p) for k in keep]
+    check(lib().aleo_mi355x_fr_lin_device(ctypes.c_void_p(d_dst), n, ptr[0], ptr[1], ctypes.c_void_p(d_a), ptr[2], ctypes.c_void_p(d_b),
+                                          ctypes.c_void_p(stream)), 'fr_lin_device')
+
+
 def batch_inversion_device(d_inout: int, n: int, stream: int = 0):
     check(lib().aleo_mi355x_fr_batch_inverse_device(ctypes.c_void_p(d_inout), n, ctypes.c_void_p(stream)), 'fr_batch_inverse_device')
 

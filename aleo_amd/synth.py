@@ -86,3 +86,43 @@ def weighted_scalar_sum(scalars: np.ndarray, first_multiple: int = 1) -> int:
         part = w[lo:lo + (1 << 15)] @ q[lo:lo + (1 << 15)]             # uint64[16], exact
         total += sum(int(v) << (16 * j) for j, v in enumerate(part))
     return total % FR_MODULUS
+
+
+def synthetic_r1cs(n_constraints: int, n_public: int, seed: int, long_rows: int = 4):
+    """A satisfiable R1CS with its assignment, shaped like a compiled program (SURVEY.md §8d "synthetic witness vectors"): constraint
+    i multiplies two short linear combinations of earlier variables into a NEW private variable (C row = that variable), except for
+    `long_rows` constraints whose A side is a long linear combination (the few wide rows real circuits have).  Variables: public first
+    (z_0 = 1).  Returns (csr, z): csr[m] = (row_ptr uint32[n+1], col uint32[nnz], val uint64[nnz,4] canonical) for m in 'abc',
+    z = python ints."""
+    r = FR_MODULUS
+    rnd = splitmix_limbs(seed, 8 * n_constraints + 64)
+    small = uniform_scalars(n_constraints * 2 + n_public + 8, seed ^ 0x77)
+    coef = [limbs_to_int(x) for x in small]
+    z = [1] + [coef[n_constraints * 2 + i] for i in range(1, n_public)]
+    rows = {'a': [], 'b': [], 'c': []}
+    wide = set(int(x) % n_constraints for x in rnd[-long_rows:]) if long_rows else set()
+    for i in range(n_constraints):
+        nv = len(z)
+        def lc(k, salt):
+            out = {}
+            for j in range(k):
+                v = int(rnd[(8 * i + 4 * salt + j) % len(rnd)] % np.uint64(nv))
+                c_ = coef[(2 * i + salt + 3 * j) % len(coef)] if j else 1 + (int(rnd[8 * i + salt]) & 0xFFFF)
+                out[v] = (out.get(v, 0) + c_) % r
+            return sorted(out.items())
+        ka = 1 + (int(rnd[8 * i + 6]) % 3); kb = 1 + (int(rnd[8 * i + 7]) % 2)
+        if i in wide: ka = min(nv, 200)
+        a = lc(ka, 0) if i not in wide else sorted({(int(rnd[(8 * i + j) % len(rnd)] % np.uint64(nv))): coef[(i + j) % len(coef)] for j in range(ka)}.items())
+        b = lc(kb, 1)
+        va = sum(c_ * z[v] for v, c_ in a) % r; vb = sum(c_ * z[v] for v, c_ in b) % r
+        z.append(va * vb % r)
+        rows['a'].append(a); rows['b'].append(b); rows['c'].append([(nv, 1)])
+    csr = {}
+    for m, rr in rows.items():
+        ptr = np.zeros(n_constraints + 1, dtype=np.uint32); ptr[1:] = np.cumsum([len(x) for x in rr])
+        col = np.array([v for x in rr for v, _ in x], dtype=np.uint32)
+        flat = [c_ for x in rr for _, c_ in x]
+        val = np.zeros((len(flat), 4), dtype=np.uint64)
+        for limb in range(4): val[:, limb] = np.array([(c_ >> (64 * limb)) & _M64 for c_ in flat], dtype=np.uint64)
+        csr[m] = (ptr, col, val)
+    return csr, z

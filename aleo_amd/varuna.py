@@ -1,0 +1,385 @@
+"""AHP prover for R1CS above the MI355X operators — the shape of snarkVM 0.14.5 `Varuna::prove_batch` /
+`AHPForR1CS::prover_{first,second,third,fourth}_round` [UPSTREAM-RECALL: algorithms/src/snark/varuna/{varuna.rs, ahp/prover/round_functions/*.rs}],
+reached from /root/reference/rust/src/program/execute.rs:74 (`trace.prove_execution`) and transfer.rs:99.
+
+Everything that scales with the circuit runs on the device through the C ABI (sparse matrix-vector products, NTTs, pointwise field
+kernels, batch inversion, division by X − z, batched SonicKZG10 commitments and the two opening MSMs); the host keeps the transcript, the
+handful of challenge-dependent constants and the O(|X|) public-input polynomial.  The protocol is Marlin's AHP for R1CS in snarkVM's
+arrangement (see oracle/varuna_ref.py for the statement of every identity; that CPU restatement is what tests compare this module with,
+byte for byte).  Differences from upstream that make the proofs NOT interchangeable with snarkVM's: SHA-256 transcript instead of the
+Poseidon sponge, one shared non-zero domain K for A, B, C, a synthetic SRS.  The proof's byte layout is upstream's (aleo_mi355x_proof_to_bytes)."""
+from __future__ import annotations
+import hashlib
+import numpy as np
+import torch
+from . import synth, wire
+from .fft import EvaluationDomain, FORWARD, INVERSE
+from .kzg import CommitterKey, SonicKZG10, KZG10
+from .msm import PinnedBases
+from .poly import fr_vec_op_device, fr_lin_device, batch_inversion_device, spmv_device, divide_by_linear_device, OP_MUL, OP_ADD, OP_SUB
+
+R = synth.FR_MODULUS
+_RM = (1 << 256) % R
+_R2 = _RM * _RM % R
+LABEL = b'aleo-mi355x/varuna-synthetic/v1'
+HIDING_COEFFS = 3
+TWO_ADIC_ROOT = 8065159656716812877374967518403273466521432693661810619979959746626482506078
+
+
+def _inv(a): return pow(a % R, -1, R)
+def _mont(v): return synth.int_to_limbs(v % R * _RM % R, 4)                    # host constant -> Montgomery limbs
+def _mont_rows(vals): return np.stack([_mont(v) for v in vals]) if len(vals) else np.zeros((0, 4), dtype=np.uint64)
+def _from_mont(limbs): return synth.limbs_to_int(limbs) * _inv(_RM) % R
+def _fr_bytes(v): return int(v % R).to_bytes(32, 'little')
+def _gen(size): return pow(TWO_ADIC_ROOT, 1 << (47 - (size.bit_length() - 1)), R)
+def _vanish(size, x): return (pow(x, size, R) - 1) % R
+
+
+class _Vec:
+    """n Montgomery Fr values in HBM (a torch tensor is the allocation; every operation goes through the C ABI)."""
+    def __init__(self, n, data: np.ndarray = None):
+        self.n = n
+        if data is None: self.t = torch.zeros((max(n, 1), 4), dtype=torch.int64, device='cuda')
+        else: self.t = torch.from_numpy(np.ascontiguousarray(data, dtype=np.uint64).reshape(-1, 4).view(np.int64)).cuda()
+    def ptr(self, off=0): return self.t.data_ptr() + 32 * off
+    def host(self, off=0, n=None): return self.t[off:off + (self.n - off if n is None else n)].cpu().numpy().view(np.uint64)
+
+
+def h_positions(n_vars, n_public, n_x, n_h) -> np.ndarray:
+    """Index on H of every variable: public i -> i |H|/|X|, the j-th private one -> the j-th element of H \\ X."""
+    ratio = n_h // n_x
+    v = np.arange(n_vars, dtype=np.int64); j = v - n_public
+    return np.where(v < n_public, v * ratio, j + j // max(ratio - 1, 1) + 1).astype(np.int64)
+
+
+class Transcript:
+    def __init__(self): self.state = hashlib.sha256(LABEL).digest()
+    def absorb(self, data: bytes): self.state = hashlib.sha256(self.state + bytes(data)).digest()
+    def challenge(self, label: bytes) -> int:
+        self.state = hashlib.sha256(self.state + label).digest()
+        return int.from_bytes(self.state, 'little') % R
+
+
+def synthetic_committer_key(tau: int, s_gamma: int, max_degree: int, n_gamma: int = HIDING_COEFFS) -> CommitterKey:
+    """powers τ^i·G (i <= max_degree) followed by the hiding powers s·τ^i·G, built in HBM (SRS-shaped bases)."""
+    sc = np.zeros((max_degree + 1 + n_gamma, 4), dtype=np.uint64); a = 1
+    for i in range(max_degree + 1):
+        sc[i] = synth.int_to_limbs(a, 4); a = a * tau % R
+    a = s_gamma % R
+    for i in range(n_gamma):
+        sc[max_degree + 1 + i] = synth.int_to_limbs(a, 4); a = a * tau % R
+    ck = CommitterKey.__new__(CommitterKey)
+    ck.max_degree, ck.gamma_offset, ck.n_gamma = max_degree, max_degree + 1, n_gamma
+    ck.bases = PinnedBases.from_scalars(synth.generator_affine104(), sc).precompute()
+    return ck
+
+
+def _csr_on_h(csr, pos, n_h):
+    """The matrix with its columns moved to positions on H and its rows padded to |H| (row_ptr, col, val canonical)."""
+    ptr, col, val = csr
+    rp = np.full(n_h + 1, ptr[-1], dtype=np.uint32); rp[:len(ptr)] = ptr
+    return rp, pos[col].astype(np.uint32), val
+
+
+class CircuitIndex:
+    """Index of one circuit (the prover-key material): matrices in HBM, their arithmetisation over K (evaluations on K and on 2K,
+    coefficient forms) and the twelve index commitments [UPSTREAM-RECALL: varuna/ahp/indexer — AHPForR1CS::index]."""
+
+    def __init__(self, csr, n_constraints: int, n_public: int, n_private: int, ck: CommitterKey, stream: torch.cuda.Stream = None):
+        self.ck = ck
+        self.n_constraints, self.n_public, self.n_private = n_constraints, n_public, n_private
+        n_x = 1
+        while n_x < n_public: n_x *= 2
+        n_h = 1
+        while n_h < max(n_constraints, n_x + n_private, 2 * n_x): n_h *= 2
+        nnz = max(int(csr[m][0][-1]) for m in 'abc')
+        n_k = 2
+        while n_k < nnz: n_k *= 2
+        self.n_x, self.n_h, self.n_k = n_x, n_h, n_k
+        if max(3 * n_h, n_k) > ck.max_degree + 1: raise ValueError('committer key too small for this circuit')
+        self.H, self.K, self.H4, self.K2 = EvaluationDomain(n_h), EvaluationDomain(n_k), EvaluationDomain(4 * n_h), EvaluationDomain(2 * n_k)
+        self.pos = h_positions(n_public + n_private, n_public, n_x, n_h)
+        self.stream = stream or torch.cuda.Stream()
+        s = self.stream.cuda_stream
+        with torch.cuda.stream(self.stream):
+            one = _mont(1); r2 = synth.int_to_limbs(_R2, 4)
+            def to_mont(v: _Vec): fr_lin_device(v.ptr(), v.n, None, r2, v.ptr(), stream=s); return v
+            # forward matrices on H (z_a = A z, z_b = B z) and the stacked transpose (t = sum_M eta_M M^T r_alpha)
+            self.fwd = {}
+            trip = []
+            for k, m in enumerate('abc'):
+                rp, col, val = _csr_on_h(csr[m], self.pos, n_h)
+                if m != 'c': self.fwd[m] = (torch.from_numpy(rp.view(np.int32)).cuda(), torch.from_numpy(col.view(np.int32)).cuda(), to_mont(_Vec(len(col), val)))
+                rows = np.repeat(np.arange(n_h, dtype=np.int64), np.diff(rp.astype(np.int64)))
+                trip.append((col.astype(np.int64), rows + k * n_h, val))
+            tc = np.concatenate([t[0] for t in trip]); tr_ = np.concatenate([t[1] for t in trip]); tv = np.concatenate([t[2] for t in trip])
+            order = np.argsort(tc, kind='stable')
+            tp = np.zeros(n_h + 1, dtype=np.uint32); tp[1:] = np.cumsum(np.bincount(tc, minlength=n_h))
+            self.tr = (torch.from_numpy(tp.view(np.int32)).cuda(), torch.from_numpy(tr_[order].astype(np.uint32).view(np.int32)).cuda(), to_mont(_Vec(len(order), tv[order])))
+            # elements of H (NTT of the second unit vector), 1 / v_X on H \ X
+            e1 = np.zeros((n_h, 4), dtype=np.uint64); e1[1] = one
+            self.h_elems = _Vec(n_h, e1); self.H.ntt_device(self.h_elems.ptr(), stream=s)
+            ratio = n_h // n_x; wx = pow(_gen(n_h), n_x, R)
+            per = [0 if i == 0 else _inv(pow(wx, i, R) - 1) for i in range(ratio)]      # v_X(w^p) depends on p mod |H|/|X|
+            self.vx_inv = _Vec(n_h, np.tile(_mont_rows(per), (n_x, 1)))
+            # arithmetisation over K: row, col, val, row_col
+            self.k_evals = _Vec(12 * n_k)                                            # [matrix][row, col, val, row_col][|K|]
+            host_h = self.h_elems.host()
+            n_h_inv = _mont(_inv(n_h))
+            for k, m in enumerate('abc'):
+                rp, col, val = _csr_on_h(csr[m], self.pos, n_h)
+                rows = np.repeat(np.arange(n_h, dtype=np.int64), np.diff(rp.astype(np.int64)))
+                nz = len(col)
+                ev = np.tile(one, (4 * n_k, 1)).reshape(4, n_k, 4)
+                ev[0, :nz] = host_h[rows]; ev[1, :nz] = host_h[col.astype(np.int64)]
+                ev[2] = 0
+                base = self.k_evals.ptr((4 * k) * n_k)
+                self.k_evals.t[(4 * k) * n_k:(4 * k + 4) * n_k] = torch.from_numpy(ev.reshape(-1, 4).view(np.int64)).cuda()
+                vraw = to_mont(_Vec(nz, val))
+                fr_vec_op_device(base + 2 * n_k * 32, vraw.ptr(), base + 1 * n_k * 32, nz, OP_MUL, s)          # v * col
+                fr_lin_device(base + 2 * n_k * 32, nz, None, n_h_inv, base + 2 * n_k * 32, stream=s)              # / |H|
+                fr_vec_op_device(base + 3 * n_k * 32, base, base + n_k * 32, n_k, OP_MUL, s)                       # row * col
+            self.k_polys = _Vec(12 * n_k); self.k_polys.t.copy_(self.k_evals.t)
+            self.K.ntt_batch_device(self.k_polys.ptr(), 12, direction=INVERSE, stream=s)
+            self.k2_evals = _Vec(24 * n_k)                                            # the same twelve polynomials on 2K
+            self.k2_evals.t.view(12, 2 * n_k, 4)[:, :n_k].copy_(self.k_polys.t.view(12, n_k, 4))
+            self.K2.ntt_batch_device(self.k2_evals.ptr(), 12, stream=s)
+            self.stream.synchronize()
+            self.index_commitments = KZG10.commit_batch_device(ck.bases, [self.k_polys.ptr(i * n_k) for i in range(12)], [n_k] * 12, stream=s)
+        self.vk_bytes = wire.g1_compress(self.index_commitments).tobytes() + n_h.to_bytes(8, 'little') + n_k.to_bytes(8, 'little') + n_x.to_bytes(8, 'little')
+
+
+class Proof:
+    def __init__(self, commitments, evaluations, sums, openings):
+        self.commitments, self.evaluations, self.sums, self.openings = commitments, evaluations, sums, openings
+
+    def to_bytes(self) -> bytes:
+        c = self.commitments
+        return wire.proof_to_bytes([1], np.stack([c['w'], c['z_a'], c['z_b']]), c['mask'], c['g_1'], c['h_1'], np.stack([c['g_a'], c['g_b'], c['g_c']]), c['h_2'],
+                                   _mont_rows(self.evaluations), _mont_rows(self.sums), np.stack([o[0] for o in self.openings]),
+                                   [None if o[1] is None else _mont(o[1]) for o in self.openings])
+
+    def to_string(self) -> str: return wire.proof_to_string(self.to_bytes())
+
+
+def randomness_layout(n_h):
+    o = {'rho_w': 0, 'rho_a': 1, 'rho_b': 2, 'mask': 3}
+    base = 3 + 3 * n_h
+    for i, k in enumerate(('blind_w', 'blind_a', 'blind_b', 'blind_mask')): o[k] = base + HIDING_COEFFS * i
+    o['total'] = base + 4 * HIDING_COEFFS
+    return o
+
+
+class Prover:
+    """State of one proof: the round functions in the order upstream calls them."""
+
+    def __init__(self, index: CircuitIndex, assignment: np.ndarray, rand: np.ndarray):
+        """assignment: canonical uint64[n_vars,4], public variables first (z_0 = 1); rand: canonical uint64[>= layout total, 4]."""
+        self.ix = index; self.s = index.stream.cuda_stream
+        self.z = np.ascontiguousarray(assignment, dtype=np.uint64).reshape(-1, 4)
+        self.rand = np.ascontiguousarray(rand, dtype=np.uint64).reshape(-1, 4)
+        self.lay = randomness_layout(index.n_h)
+        if self.rand.shape[0] < self.lay['total']: raise ValueError('not enough randomness')
+        self.tr = Transcript(); self.c = {}; self.timing = {}
+
+    def _ri(self, k, n=1):
+        o = self.lay[k]; return [synth.limbs_to_int(self.rand[o + i]) for i in range(n)]
+
+    # ---- round 1 ------------------------------------------------------------------------------------------------------------------
+    def first_round(self):
+        ix, s = self.ix, self.s; n_h, n_x = ix.n_h, ix.n_x
+        r2 = synth.int_to_limbs(_R2, 4); one = _mont(1); neg1 = _mont(R - 1)
+        zh = np.zeros((n_h, 4), dtype=np.uint64); zh[ix.pos[:self.z.shape[0]]] = self.z
+        self.x_evals = [synth.limbs_to_int(self.z[i]) if i < ix.n_public else 0 for i in range(n_x)]
+        gx_inv = _inv(_gen(n_x)); nxi = _inv(n_x)
+        self.x_poly = [sum(v * pow(gx_inv, i * j, R) for j, v in enumerate(self.x_evals)) * nxi % R for i in range(n_x)]     # O(|X|^2): |X| is tiny
+        zH = _Vec(n_h, zh); fr_lin_device(zH.ptr(), n_h, None, r2, zH.ptr(), stream=s)
+        ev = _Vec(3 * n_h)                                                          # w, z_a, z_b on H
+        for k, m in ((1, 'a'), (2, 'b')):
+            rp, col, val = ix.fwd[m]
+            spmv_device(ev.ptr(k * n_h), rp.data_ptr(), col.data_ptr(), val.ptr(), zH.ptr(), n_h, s)
+        xh = _Vec(n_h); xh.t[:n_x] = torch.from_numpy(_mont_rows(self.x_poly).view(np.int64)).cuda()
+        ix.H.ntt_device(xh.ptr(), stream=s)
+        fr_vec_op_device(ev.ptr(), zH.ptr(), xh.ptr(), n_h, OP_SUB, s)
+        fr_vec_op_device(ev.ptr(), ev.ptr(), ix.vx_inv.ptr(), n_h, OP_MUL, s)
+        ix.H.ntt_batch_device(ev.ptr(), 3, direction=INVERSE, stream=s)
+        L = n_h + 1
+        self.w, self.za, self.zb = _Vec(L), _Vec(L), _Vec(L)
+        for k, (v, rk) in enumerate(((self.w, 'rho_w'), (self.za, 'rho_a'), (self.zb, 'rho_b'))):
+            rho = self._ri(rk)[0]
+            v.t[:n_h].copy_(ev.t[k * n_h:(k + 1) * n_h])
+            fr_lin_device(v.ptr(), 1, _mont(-rho), one, v.ptr(), stream=s)           # + rho (X^|H| − 1)
+            fr_lin_device(v.ptr(n_h), 1, _mont(rho), stream=s)
+        m = self.rand[self.lay['mask']:self.lay['mask'] + 3 * n_h].copy()
+        m[0] = synth.int_to_limbs((-(synth.limbs_to_int(m[n_h]) + synth.limbs_to_int(m[2 * n_h]))) % R, 4)
+        self.mask = _Vec(3 * n_h, m); fr_lin_device(self.mask.ptr(), 3 * n_h, None, r2, self.mask.ptr(), stream=s)
+        self.blind = {k: self._ri(k, HIDING_COEFFS) for k in ('blind_w', 'blind_a', 'blind_b', 'blind_mask')}
+        bl = _Vec(4 * HIDING_COEFFS, _mont_rows(sum((self.blind[k] for k in ('blind_w', 'blind_a', 'blind_b', 'blind_mask')), [])))
+        polys = [((v.ptr(), n), None, (bl.ptr(HIDING_COEFFS * i), HIDING_COEFFS)) for i, (v, n) in enumerate(((self.w, L), (self.za, L), (self.zb, L), (self.mask, 3 * n_h)))]
+        out = SonicKZG10.commit(ix.ck, polys, device=True, stream=s)
+        for k, name in enumerate(('w', 'z_a', 'z_b', 'mask')): self.c[name] = out[k]
+        self.tr.absorb(ix.vk_bytes); self.tr.absorb(b''.join(_fr_bytes(v) for v in self.x_evals))
+        self.tr.absorb(wire.g1_compress(out).tobytes())
+        self.alpha, self.eta_b, self.eta_c = self.tr.challenge(b'alpha'), self.tr.challenge(b'eta_b'), self.tr.challenge(b'eta_c')
+
+    # ---- round 2: the first sumcheck -----------------------------------------------------------------------------------------------
+    def second_round(self):
+        ix, s = self.ix, self.s; n_h, n_x = ix.n_h, ix.n_x
+        one = _mont(1); neg1 = _mont(R - 1)
+        alpha = self.alpha; vh_alpha = _vanish(n_h, alpha)
+        if vh_alpha == 0: raise ArithmeticError('alpha landed in H')
+        ext = _Vec(3 * n_h)                                                         # r_alpha, eta_b r_alpha, eta_c r_alpha
+        fr_lin_device(ext.ptr(), n_h, _mont(alpha), neg1, ix.h_elems.ptr(), stream=s)
+        batch_inversion_device(ext.ptr(), n_h, s)
+        fr_lin_device(ext.ptr(), n_h, None, _mont(vh_alpha), ext.ptr(), stream=s)
+        fr_lin_device(ext.ptr(n_h), n_h, None, _mont(self.eta_b), ext.ptr(), stream=s)
+        fr_lin_device(ext.ptr(2 * n_h), n_h, None, _mont(self.eta_c), ext.ptr(), stream=s)
+        rt = _Vec(2 * n_h); rt.t[:n_h].copy_(ext.t[:n_h])
+        tp, tcol, tval = ix.tr
+        spmv_device(rt.ptr(n_h), tp.data_ptr(), tcol.data_ptr(), tval.ptr(), ext.ptr(), n_h, s)
+        ix.H.ntt_batch_device(rt.ptr(), 2, direction=INVERSE, stream=s)               # r(alpha, X), t(X)
+        L = n_h + 1; n4 = 4 * n_h
+        E = _Vec(5 * n4)                                                            # r, t, z, z_a, z_b on the domain of size 4|H|
+        E.t[0:n_h].copy_(rt.t[:n_h]); E.t[n4:n4 + n_h].copy_(rt.t[n_h:])
+        zp = 2 * n4                                                                 # ẑ = w (X^|X| − 1) + x̂
+        fr_lin_device(E.ptr(zp), L, None, neg1, self.w.ptr(), stream=s)
+        fr_vec_op_device(E.ptr(zp + n_x), E.ptr(zp + n_x), self.w.ptr(), L, OP_ADD, s)
+        xp = _Vec(n_x, _mont_rows(self.x_poly))
+        fr_vec_op_device(E.ptr(zp), E.ptr(zp), xp.ptr(), n_x, OP_ADD, s)
+        E.t[3 * n4:3 * n4 + L].copy_(self.za.t[:L]); E.t[4 * n4:4 * n4 + L].copy_(self.zb.t[:L])
+        ix.H4.ntt_batch_device(E.ptr(), 5, stream=s)
+        e_r, e_t, e_z, e_a, e_b = (E.ptr(i * n4) for i in range(5))
+        T = _Vec(n4)
+        fr_vec_op_device(T.ptr(), e_a, e_b, n4, OP_MUL, s)                           # z_a z_b
+        fr_lin_device(e_a, n4, None, one, e_a, _mont(self.eta_b), e_b, stream=s)      # z_a + eta_b z_b
+        fr_lin_device(e_a, n4, None, one, e_a, _mont(self.eta_c), T.ptr(), stream=s)  # + eta_c z_a z_b
+        fr_vec_op_device(e_a, e_a, e_r, n4, OP_MUL, s)
+        fr_vec_op_device(e_t, e_t, e_z, n4, OP_MUL, s)
+        fr_vec_op_device(e_a, e_a, e_t, n4, OP_SUB, s)
+        ix.H4.ntt_device(e_a, direction=INVERSE, stream=s)
+        fr_vec_op_device(e_a, e_a, self.mask.ptr(), 3 * n_h, OP_ADD, s)               # q_1 = h_1 (X^|H| − 1) + X g_1, degree < 3|H|
+        self.h1 = _Vec(2 * n_h); self.g1 = _Vec(n_h)
+        p0, p1, p2 = e_a, e_a + 32 * n_h, e_a + 64 * n_h
+        self.h1.t[n_h:].copy_(E.t[3 * n4 + 2 * n_h:3 * n4 + 3 * n_h])                # quotient blocks: p2, p1 + p2; remainder p0 + p1 + p2
+        fr_vec_op_device(self.h1.ptr(), p1, p2, n_h, OP_ADD, s)
+        fr_vec_op_device(self.g1.ptr(), p0, self.h1.ptr(), n_h, OP_ADD, s)             # remainder; its constant term is the sum over H / |H| = 0
+        out = SonicKZG10.commit(ix.ck, [((self.g1.ptr(1), n_h - 1), n_h - 2, None), ((self.h1.ptr(), 2 * n_h), None, None)], device=True, stream=s)
+        self.c['g_1'], self.c['h_1'] = out[0], out[1]
+        self.tr.absorb(wire.g1_compress(out).tobytes())
+        self.beta = self.tr.challenge(b'beta')
+
+    # ---- round 3: three rational sumchecks over K -----------------------------------------------------------------------------------
+    def third_round(self):
+        ix, s = self.ix, self.s; n_h, n_k = ix.n_h, ix.n_k
+        neg1 = _mont(R - 1)
+        vh_beta = _vanish(n_h, self.beta)
+        if vh_beta == 0: raise ArithmeticError('beta landed in H')
+        self.vv = _vanish(n_h, self.alpha) * vh_beta % R
+        self.f = _Vec(3 * n_k); d2 = _Vec(n_k)
+        for k in range(3):
+            base = ix.k_evals.ptr(4 * k * n_k); f = self.f.ptr(k * n_k)
+            fr_lin_device(f, n_k, _mont(self.alpha), neg1, base, stream=s)                        # alpha − row
+            fr_lin_device(d2.ptr(), n_k, _mont(self.beta), neg1, base + 32 * n_k, stream=s)       # beta − col
+            fr_vec_op_device(f, f, d2.ptr(), n_k, OP_MUL, s)
+        batch_inversion_device(self.f.ptr(), 3 * n_k, s)
+        for k in range(3):
+            f = self.f.ptr(k * n_k)
+            fr_vec_op_device(f, f, ix.k_evals.ptr((4 * k + 2) * n_k), n_k, OP_MUL, s)
+        fr_lin_device(self.f.ptr(), 3 * n_k, None, _mont(self.vv), self.f.ptr(), stream=s)
+        ix.K.ntt_batch_device(self.f.ptr(), 3, direction=INVERSE, stream=s)
+        ix.stream.synchronize()
+        f0 = self.f.t.view(3, n_k, 4)[:, 0].cpu().numpy().view(np.uint64)
+        self.sigma = [_from_mont(f0[k]) * n_k % R for k in range(3)]
+        out = SonicKZG10.commit(ix.ck, [((self.f.ptr(k * n_k + 1), n_k - 1), n_k - 2, None) for k in range(3)], device=True, stream=s)
+        for k, name in enumerate(('g_a', 'g_b', 'g_c')): self.c[name] = out[k]
+        self.tr.absorb(b''.join(_fr_bytes(v) for v in self.sigma) + wire.g1_compress(out).tobytes())
+        self.delta = [1, self.tr.challenge(b'delta_b'), self.tr.challenge(b'delta_c')]
+
+    # ---- round 4 ----------------------------------------------------------------------------------------------------------------------
+    def fourth_round(self):
+        ix, s = self.ix, self.s; n_k = ix.n_k; n2 = 2 * n_k
+        one = _mont(1); neg1 = _mont(R - 1)
+        F = _Vec(3 * n2); F.t.view(3, n2, 4)[:, :n_k].copy_(self.f.t.view(3, n_k, 4))
+        ix.K2.ntt_batch_device(F.ptr(), 3, stream=s)
+        B = _Vec(3 * n2)
+        for k in range(3):
+            e = ix.k2_evals.ptr(4 * k * n2); b = B.ptr(k * n2)          # row, col, val, row_col on 2K
+            fr_lin_device(b, n2, _mont(self.alpha * self.beta), _mont(-self.beta), e, _mont(-self.alpha), e + 32 * n2, stream=s)
+            fr_vec_op_device(b, b, e + 96 * n2, n2, OP_ADD, s)
+            fr_vec_op_device(b, b, F.ptr(k * n2), n2, OP_MUL, s)         # b_M f_M
+            fr_lin_device(b, n2, None, _mont(self.vv), e + 64 * n2, neg1, b, stream=s)                   # a_M − b_M f_M
+        fr_lin_device(B.ptr(), n2, None, one, B.ptr(), _mont(self.delta[1]), B.ptr(n2), stream=s)
+        fr_lin_device(B.ptr(), n2, None, one, B.ptr(), _mont(self.delta[2]), B.ptr(2 * n2), stream=s)
+        ix.K2.ntt_device(B.ptr(), direction=INVERSE, stream=s)
+        self.h2 = _Vec(n_k); self.h2.t.copy_(B.t[n_k:n2])                # P = h_2 (X^|K| − 1)
+        out = SonicKZG10.commit(ix.ck, [((self.h2.ptr(), n_k), None, None)], device=True, stream=s)
+        self.c['h_2'] = out[0]
+        self.tr.absorb(wire.g1_compress(out).tobytes())
+        self.gamma = self.tr.challenge(b'gamma')
+
+    # ---- evaluations and openings ------------------------------------------------------------------------------------------------------
+    def _eval(self, ptr, n, z, slot):
+        divide_by_linear_device(0, self._ev.ptr(slot), ptr, n, _mont(z), self.s)
+
+    def finish(self) -> Proof:
+        ix, s = self.ix, self.s; n_h, n_k, n_x = ix.n_h, ix.n_k, ix.n_x
+        one = _mont(1)
+        self._ev = _Vec(8)
+        self._eval(self.zb.ptr(), n_h + 1, self.beta, 0); self._eval(self.g1.ptr(1), n_h - 1, self.beta, 1)
+        for k in range(3): self._eval(self.f.ptr(k * n_k + 1), n_k - 1, self.gamma, 2 + k)
+        ix.stream.synchronize()
+        evals = [_from_mont(v) for v in self._ev.host(0, 5)]
+        zb_beta, g1_beta, ga, gb, gc = evals
+        self.tr.absorb(b''.join(_fr_bytes(v) for v in evals)); xi = self.tr.challenge(b'xi')
+        alpha, beta, gamma = self.alpha, self.beta, self.gamma
+        # linear combination of the first sumcheck, opened at beta together with g_1 and z_b
+        r_ab = (_vanish(n_h, alpha) - _vanish(n_h, beta)) * _inv(alpha - beta) % R
+        t_beta = (self.sigma[0] + self.eta_b * self.sigma[1] + self.eta_c * self.sigma[2]) % R
+        x_beta = 0
+        for v in reversed(self.x_poly): x_beta = (x_beta * beta + v) % R
+        k_mask, k_za, k_w, k_h1 = 1, r_ab * (1 + self.eta_c * zb_beta) % R, (-t_beta * _vanish(n_x, beta)) % R, (-_vanish(n_h, beta)) % R
+        const = (r_ab * self.eta_b % R * zb_beta - t_beta * x_beta - beta * g1_beta) % R
+        xi2 = xi * xi % R; L = n_h + 1
+        pb = _Vec(3 * n_h)
+        fr_lin_device(pb.ptr(), 3 * n_h, None, _mont(xi2 * k_mask), self.mask.ptr(), stream=s)
+        fr_lin_device(pb.ptr(), 2 * n_h, None, one, pb.ptr(), _mont(xi2 * k_h1), self.h1.ptr(), stream=s)
+        fr_lin_device(pb.ptr(), L, None, one, pb.ptr(), _mont(xi2 * k_za), self.za.ptr(), stream=s)
+        fr_lin_device(pb.ptr(), L, None, one, pb.ptr(), _mont(xi2 * k_w), self.w.ptr(), stream=s)
+        fr_lin_device(pb.ptr(), L, None, one, pb.ptr(), _mont(xi), self.zb.ptr(), stream=s)
+        fr_lin_device(pb.ptr(), n_h - 1, None, one, pb.ptr(), one, self.g1.ptr(1), stream=s)
+        fr_lin_device(pb.ptr(), 1, _mont(xi2 * const), one, pb.ptr(), stream=s)
+        bl = [0] * HIDING_COEFFS
+        for coef, key in ((xi, 'blind_b'), (xi2 * k_mask, 'blind_mask'), (xi2 * k_za, 'blind_a'), (xi2 * k_w, 'blind_w')):
+            for i, v in enumerate(self.blind[key]): bl[i] = (bl[i] + coef * v) % R
+        random_v = 0
+        for v in reversed(bl): random_v = (random_v * beta + v) % R
+        blw = [0] * (HIDING_COEFFS - 1); acc = 0
+        for j in range(HIDING_COEFFS - 1, 0, -1): acc = (bl[j] + beta * acc) % R; blw[j - 1] = acc
+        wq = _Vec(3 * n_h); blq = _Vec(HIDING_COEFFS - 1, _mont_rows(blw))
+        divide_by_linear_device(wq.ptr(), self._ev.ptr(5), pb.ptr(), 3 * n_h, _mont(beta), s)
+        open_beta = SonicKZG10.commit(ix.ck, [((wq.ptr(), 3 * n_h - 1), None, (blq.ptr(), HIDING_COEFFS - 1))], device=True, stream=s)[0]
+        # linear combination of the second sumcheck, opened at gamma together with g_a, g_b, g_c
+        xi3 = xi2 * xi % R; n_k_inv = _inv(n_k); vk_gamma = _vanish(n_k, gamma)
+        pg = _Vec(n_k); const = 0
+        for k, gk in enumerate((ga, gb, gc)):
+            fm = (gamma * gk + self.sigma[k] * n_k_inv) % R; d = self.delta[k]
+            pol = lambda j: ix.k_polys.ptr((4 * k + j) * n_k)
+            fr_lin_device(pg.ptr(), n_k, None, one, pg.ptr(), _mont(xi3 * d % R * self.vv), pol(2), stream=s)
+            fr_lin_device(pg.ptr(), n_k, None, one, pg.ptr(), _mont(xi3 * d % R * fm % R * beta), pol(0), stream=s)
+            fr_lin_device(pg.ptr(), n_k, None, one, pg.ptr(), _mont(xi3 * d % R * fm % R * alpha), pol(1), stream=s)
+            fr_lin_device(pg.ptr(), n_k, None, one, pg.ptr(), _mont(-xi3 * d % R * fm), pol(3), stream=s)
+            const = (const - d * fm % R * alpha % R * beta) % R
+        fr_lin_device(pg.ptr(), n_k, None, one, pg.ptr(), _mont(-xi3 * vk_gamma), self.h2.ptr(), stream=s)
+        for k, coef in enumerate((1, xi, xi2)):
+            fr_lin_device(pg.ptr(), n_k - 1, None, one, pg.ptr(), _mont(coef), self.f.ptr(k * n_k + 1), stream=s)
+        fr_lin_device(pg.ptr(), 1, _mont(xi3 * const), one, pg.ptr(), stream=s)
+        open_gamma, _ = KZG10.open_device(ix.ck.bases, pg.ptr(), n_k, _mont(gamma), stream=s)
+        return Proof(dict(self.c), evals, list(self.sigma), [(open_beta, random_v), (open_gamma, None)])
+
+
+def prove(index: CircuitIndex, assignment: np.ndarray, rand: np.ndarray) -> Proof:
+    """Varuna::prove_batch for one circuit with one instance."""
+    with torch.cuda.stream(index.stream):
+        p = Prover(index, assignment, rand)
+        p.first_round(); p.second_round(); p.third_round(); p.fourth_round()
+        return p.finish()

@@ -88,6 +88,9 @@ int32_t aleo_mi355x_bases_unpin(uint64_t handle);
  * ("P_i = (i+1)*G generated on device" — 2^26 points never cross PCIe).  base_affine: one
  * snarkVM Affine (104 bytes, host).  first_multiple >= 1 and first_multiple + n must stay below r. */
 int32_t aleo_mi355x_bases_generate(const void* base_affine104, uint64_t first_multiple, size_t n, uint64_t* handle);
+/* Synthetic SRS-shaped set: P_i = s_i * base for n canonical 32-byte scalars in host memory (P_i = beta^i * G, the
+ * shape of a universal setup's powers_of_beta_g, for which a commitment to p is p(beta) * G).  A zero scalar gives the identity. */
+int32_t aleo_mi355x_bases_from_scalars(const void* base_affine104, const void* scalars, size_t n, uint64_t* handle);
 /* Optional fixed-base acceleration for a pinned set (an SRS never changes): builds tables of window multiples
  * 2^(c w) * P_i in HBM, stored in the 28-bit-limb form the accumulation kernel computes in (112 bytes per entry), in up to
  * three tiers so that a prefix of ANY length >= 2^10 gets a window width that suits it (KZG10::commit multiplies polynomials
@@ -180,10 +183,15 @@ int32_t aleo_mi355x_kzg_commit_hiding(void* out_affine104, uint64_t h_powers, co
 #define ALEO_FR_OP_SUB 2
 int32_t aleo_mi355x_fr_vec_op_device(void* d_dst, const void* d_a, const void* d_b, size_t n, int32_t op, void* stream);
 int32_t aleo_mi355x_fr_batch_inverse_device(void* d_inout, size_t n, void* stream);
+/* dst[i] = c0 + c1 * a[i] + c2 * b[i]: c0, c1, c2 are 32-byte Montgomery Fr in HOST memory (c0 NULL = 0); d_a / d_b may be NULL
+ * (the term drops out; its constant is then ignored); dst may alias a or b.  The scalar-times-vector and blended forms of the AHP
+ * rounds: alpha - h_i ahead of a batch inversion, eta-weighted sums, the linear combinations opened at beta and gamma
+ * [UPSTREAM-RECALL: snark/varuna/ahp/prover/round_functions/{second,third,fourth}.rs]. */
+int32_t aleo_mi355x_fr_lin_device(void* d_dst, size_t n, const void* c0_mont, const void* c1_mont, const void* d_a, const void* c2_mont, const void* d_b, void* stream);
 /* Division by (X - z): quotient[j-1] = s_j with s_j = p_j + z s_(j+1) (n - 1 coefficients, canonical Montgomery form) and, when
  * d_eval != NULL, p(z) = s_0 (32 bytes, device) — KZG10's witness polynomial (p(X) - p(z)) / (X - z)
  * [UPSTREAM-RECALL: polycommit/kzg10 compute_witness_polynomial].  z_mont: 32 bytes Montgomery Fr in HOST memory.
- * d_quotient must not alias d_poly. */
+ * d_quotient must not alias d_poly; it may be NULL when only the evaluation is wanted (d_eval then non-NULL). */
 int32_t aleo_mi355x_fr_divide_by_linear_device(void* d_quotient, void* d_eval, const void* d_poly, size_t n, const void* z_mont, void* stream);
 /* KZG10::open of one polynomial at one point (without hiding): the witness polynomial is built on the device and committed against
  * the first n - 1 pinned powers.  out_affine104: the opening proof's `w` (host); out_eval_mont (host, may be NULL): p(z). */

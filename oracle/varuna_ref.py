@@ -1,0 +1,391 @@
+"""TEST INFRASTRUCTURE — CPU restatement (plain Python integers) of the AHP prover for R1CS that the MI355X path runs above its
+operators, and a verifier for its proofs.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+leg may import this module.
+
+What it restates.  snarkVM 0.14.5 `snarkvm_algorithms::snark::varuna` (`Varuna::prove_batch`, `AHPForR1CS::prover_{first..fourth}_round`)
+is a third-party dependency of the reference (Cargo.lock:2200) and absent from /root/reference; its published algorithm is Marlin
+(Chiesa, Hu, Maller, Mishra, Vesely, Ward — EUROCRYPT 2020, §5 "AHP for R1CS") with the arrangement snarkVM uses [UPSTREAM-RECALL]:
+  * z = (public ‖ private) laid out on the constraint domain H with the public inputs on the subgroup X ⊂ H; w = (ẑ − x̂) / v_X;
+  * only ẑ_a, ẑ_b are committed (ẑ_c = ẑ_a ẑ_b inside the first sumcheck); a mask polynomial of degree 3|H| + 2b − 3 (b = 1);
+  * matrices arithmetised as row / col / val / row_col over K with val = M[r,c] / u_H(col, col);
+  * commitments per proof w, z_a, z_b, mask | g_1, h_1 | g_a, g_b, g_c (+ three sums) | h_2, evaluations z_b(β), g_1(β), g_a(γ), g_b(γ), g_c(γ),
+    two batched KZG openings (at β with the hiding `random_v`, at γ without) — the 901-byte layout of the `proof1…` string held at
+    /root/reference/wasm/src/programs/transaction.rs:100 (decoded in tests/golden/reference_proof.json);
+  * SonicKZG10 commitments: hiding polynomials of degree 2 against the γ-powers, degree bounds through shifted powers.
+Deliberate differences, because the corresponding upstream data is not available offline: challenges come from a SHA-256 transcript
+(upstream: a Poseidon sponge over Fq whose parameters are not in /root/reference), one non-zero domain K is shared by A, B, C, and the
+pairing check of the verifier is replaced by the equivalent equation in G1 using the trapdoor of the synthetic SRS (τ is known here:
+bases are τ^i·G).  **Parity unpinned**: the reference holds no proof this restatement could be compared with value
+for value; what pins it is (i) the verifier below accepting its proofs and rejecting tampered ones, and (ii) the byte layout above."""
+from __future__ import annotations
+import hashlib
+from . import pyref as P
+
+R = P.FR_MODULUS
+LABEL = b'aleo-mi355x/varuna-synthetic/v1'
+HIDING_COEFFS = 3            # hiding bound 1 -> random polynomial of degree 2 [UPSTREAM-RECALL: kzg10 calculate_hiding_polynomial_degree]
+
+
+def inv(a): return pow(a % R, -1, R)
+
+
+class Domain:
+    def __init__(self, size):
+        assert size & (size - 1) == 0
+        self.size = size; self.lg = size.bit_length() - 1
+        self.gen = pow(P.FR_TWO_ADIC_ROOT, 1 << (P.FR_TWO_ADICITY - self.lg), R)
+        self.size_inv = inv(size)
+
+    def fft(self, coeffs):
+        x = list(coeffs) + [0] * (self.size - len(coeffs)); assert len(x) == self.size
+        return P.fft_fast(x, self.gen)
+
+    def ifft(self, evals):
+        assert len(evals) == self.size
+        return [v * self.size_inv % R for v in P.fft_fast(list(evals), inv(self.gen))]
+
+    def vanishing(self, x): return (pow(x, self.size, R) - 1) % R
+    def elements(self):
+        out, a = [], 1
+        for _ in range(self.size): out.append(a); a = a * self.gen % R
+        return out
+
+
+def poly_eval(c, x):
+    acc = 0
+    for v in reversed(c): acc = (acc * x + v) % R
+    return acc
+
+
+def h_position(var, n_public, n_x, n_h):
+    """Index on H of variable `var` (public variables first): public i -> i * |H|/|X|; the j-th private variable -> the j-th
+    element of H \\ X [UPSTREAM-RECALL: EvaluationDomain::reindex_by_subdomain]."""
+    ratio = n_h // n_x
+    if var < n_public: return var * ratio
+    j = var - n_public
+    return j + j // (ratio - 1) + 1
+
+
+class Transcript:
+    def __init__(self): self.state = hashlib.sha256(LABEL).digest()
+    def absorb(self, data: bytes): self.state = hashlib.sha256(self.state + bytes(data)).digest()
+    def challenge(self, label: bytes) -> int:
+        self.state = hashlib.sha256(self.state + label).digest()
+        return int.from_bytes(self.state, 'little') % R
+
+
+def fr_bytes(v): return int(v % R).to_bytes(32, 'little')
+
+
+class Circuit:
+    """R1CS in CSR-like python form: rows of (variable, value) for A, B, C; n_public counts the leading 1."""
+    def __init__(self, n_constraints, n_public, n_private, a, b, c):
+        self.n_constraints, self.n_public, self.n_private = n_constraints, n_public, n_private
+        self.m = {'a': a, 'b': b, 'c': c}
+        n_x = 1
+        while n_x < n_public: n_x *= 2
+        n_h = 1
+        while n_h < max(n_constraints, n_x + n_private, 2 * n_x): n_h *= 2
+        nnz = max(sum(len(r) for r in rows) for rows in (a, b, c))
+        n_k = 2
+        while n_k < nnz: n_k *= 2
+        self.n_x, self.n_h, self.n_k = n_x, n_h, n_k
+
+
+class Setup:
+    """Synthetic universal setup with its trapdoor: powers τ^i·G for i <= max_degree, hiding powers s·τ^i·G."""
+    def __init__(self, tau, s_gamma, max_degree):
+        self.tau, self.s_gamma, self.max_degree = tau % R, s_gamma % R, max_degree
+
+
+def _commit_scalar(setup, coeffs, bound=None, blind=None):
+    """Discrete log (base G) of SonicKZG10::commit: τ^(D − bound)·p(τ) + s·blind(τ)."""
+    v = poly_eval(coeffs, setup.tau)
+    if bound is not None:
+        assert len(coeffs) <= bound + 1 <= setup.max_degree + 1
+        v = v * pow(setup.tau, setup.max_degree - bound, R) % R
+    if blind is not None: v = (v + setup.s_gamma * poly_eval(blind, setup.tau)) % R
+    return v
+
+
+def _point_bytes(scalar):
+    return P.g1_compress(P.g1_mul(P.G1_GENERATOR, scalar % R))
+
+
+class Index:
+    """The index ("proving key" material) of one circuit: the arithmetisation of A, B, C over K, and the index commitments."""
+    def __init__(self, circuit: Circuit, setup: Setup):
+        c = self.circuit = circuit
+        self.H, self.K, self.X = Domain(c.n_h), Domain(c.n_k), Domain(c.n_x)
+        he = self.H.elements(); n_h_inv = self.H.size_inv
+        self.entries, self.evals, self.polys = {}, {}, {}
+        for name, rows in c.m.items():
+            ent = [(r, h_position(v, c.n_public, c.n_x, c.n_h), val % R) for r, row in enumerate(rows) for v, val in row]
+            row = [he[r] for r, _, _ in ent]; col = [he[cp] for _, cp, _ in ent]
+            val = [v * he[cp] % R * n_h_inv % R for _, cp, v in ent]          # M[r,c] / u_H(col, col), u_H(x, x) = |H| / x on H
+            pad = c.n_k - len(ent)
+            row += [1] * pad; col += [1] * pad; val += [0] * pad
+            rc = [a * b % R for a, b in zip(row, col)]
+            self.entries[name] = ent
+            self.evals[name] = {'row': row, 'col': col, 'val': val, 'row_col': rc}
+            self.polys[name] = {k: self.K.ifft(v) for k, v in self.evals[name].items()}
+        self.commit_scalars = {(m, k): _commit_scalar(setup, self.polys[m][k]) for m in 'abc' for k in ('row', 'col', 'val', 'row_col')}
+
+    def vk_bytes(self):
+        out = b''
+        for m in 'abc':
+            for k in ('row', 'col', 'val', 'row_col'): out += _point_bytes(self.commit_scalars[(m, k)])
+        c = self.circuit
+        return out + c.n_h.to_bytes(8, 'little') + c.n_k.to_bytes(8, 'little') + c.n_x.to_bytes(8, 'little')
+
+
+def randomness_layout(n_h):
+    """Offsets into the prover's random vector (canonical Fr): rho_w, rho_a, rho_b, mask[3|H|], then four hiding polynomials."""
+    o = {'rho_w': 0, 'rho_a': 1, 'rho_b': 2, 'mask': 3}
+    base = 3 + 3 * n_h
+    for i, k in enumerate(('blind_w', 'blind_a', 'blind_b', 'blind_mask')): o[k] = base + HIDING_COEFFS * i
+    o['total'] = base + 4 * HIDING_COEFFS
+    return o
+
+
+def _blinded(H, evals, rho):
+    p = H.ifft(evals) + [0]
+    p[0] = (p[0] - rho) % R; p[H.size] = rho % R
+    return p
+
+
+def prove(index: Index, setup: Setup, z_assignment, rand, vk_bytes=None):
+    """One proof for one instance.  z_assignment: ints, public first (z[0] = 1).  rand: list of canonical Fr (randomness_layout).
+    Returns (proof dict, proof bytes in the reference's layout)."""
+    c = index.circuit; H, K, X = index.H, index.K, index.X
+    n_h, n_k, n_x = c.n_h, c.n_k, c.n_x
+    lay = randomness_layout(n_h); assert len(rand) >= lay['total']
+    he = H.elements()
+    D = setup.max_degree
+    # ---- first round --------------------------------------------------------------------------------------------------------
+    zH = [0] * n_h
+    for v, val in enumerate(z_assignment): zH[h_position(v, c.n_public, n_x, n_h)] = val % R
+    z_m = {}
+    for name in 'ab':
+        out = [0] * n_h
+        for r, row in enumerate(c.m[name]): out[r] = sum(val * z_assignment[v] for v, val in row) % R
+        z_m[name] = out
+    x_evals = [z_assignment[i] % R if i < c.n_public else 0 for i in range(n_x)]
+    x_poly = X.ifft(x_evals)
+    ratio = n_h // n_x
+    w_evals = [0] * n_h
+    for p in range(n_h):
+        if p % ratio == 0: continue
+        w_evals[p] = (zH[p] - poly_eval(x_poly, he[p])) * inv(X.vanishing(he[p])) % R
+    w = _blinded(H, w_evals, rand[lay['rho_w']])
+    za = _blinded(H, z_m['a'], rand[lay['rho_a']])
+    zb = _blinded(H, z_m['b'], rand[lay['rho_b']])
+    mask = [v % R for v in rand[lay['mask']:lay['mask'] + 3 * n_h]]
+    mask[0] = (-(mask[n_h] + mask[2 * n_h])) % R                                  # sum over H = |H| (m_0 + m_|H| + m_2|H|) = 0
+    blind = {k: [v % R for v in rand[lay[k]:lay[k] + HIDING_COEFFS]] for k in ('blind_w', 'blind_a', 'blind_b', 'blind_mask')}
+    cs = {'w': _commit_scalar(setup, w, blind=blind['blind_w']), 'z_a': _commit_scalar(setup, za, blind=blind['blind_a']),
+          'z_b': _commit_scalar(setup, zb, blind=blind['blind_b']), 'mask': _commit_scalar(setup, mask, blind=blind['blind_mask'])}
+    cb = {k: _point_bytes(v) for k, v in cs.items()}
+    tr = Transcript(); tr.absorb(vk_bytes if vk_bytes is not None else index.vk_bytes())
+    tr.absorb(b''.join(fr_bytes(v) for v in x_evals))
+    tr.absorb(cb['w'] + cb['z_a'] + cb['z_b'] + cb['mask'])
+    alpha, eta_b, eta_c = tr.challenge(b'alpha'), tr.challenge(b'eta_b'), tr.challenge(b'eta_c')
+    eta = {'a': 1, 'b': eta_b, 'c': eta_c}
+    # ---- second round: first sumcheck --------------------------------------------------------------------------------------
+    vh_alpha = H.vanishing(alpha); assert vh_alpha != 0
+    r_alpha = [vh_alpha * inv(alpha - h) % R for h in he]                         # u_H(alpha, h) on H
+    t_evals = [0] * n_h
+    for name in 'abc':
+        for r, cp, v in index.entries[name]: t_evals[cp] = (t_evals[cp] + eta[name] * r_alpha[r] % R * v) % R
+    r_poly, t_poly = H.ifft(r_alpha), H.ifft(t_evals)
+    z_poly = [0] * (n_h + 1 + n_x)                                                # ẑ = w v_X + x̂
+    for i, v in enumerate(w): z_poly[i] = (z_poly[i] - v) % R; z_poly[i + n_x] = (z_poly[i + n_x] + v) % R
+    for i, v in enumerate(x_poly): z_poly[i] = (z_poly[i] + v) % R
+    D4 = Domain(4 * n_h)
+    e_r, e_t, e_z, e_a, e_b = D4.fft(r_poly), D4.fft(t_poly), D4.fft(z_poly), D4.fft(za), D4.fft(zb)
+    q1 = D4.ifft([(e_r[i] * ((e_a[i] + eta_b * e_b[i] + eta_c * e_a[i] % R * e_b[i]) % R) - e_t[i] * e_z[i]) % R for i in range(4 * n_h)])
+    for i, v in enumerate(mask): q1[i] = (q1[i] + v) % R
+    q = [0] * (3 * n_h)                                                           # q1 = h_1 (X^|H| − 1) + remainder
+    for i in range(4 * n_h - 1, n_h - 1, -1):
+        q[i - n_h] = (q1[i] + (q[i] if i < 3 * n_h else 0)) % R
+    rem = [(q1[i] + q[i]) % R for i in range(n_h)]
+    assert rem[0] == 0, 'first sumcheck: the sum over H is not zero (unsatisfied assignment?)'
+    h1 = q[:2 * n_h]; assert not any(q[2 * n_h:])
+    g1 = rem[1:]
+    cs['g_1'] = _commit_scalar(setup, g1, bound=n_h - 2); cs['h_1'] = _commit_scalar(setup, h1)
+    cb['g_1'], cb['h_1'] = _point_bytes(cs['g_1']), _point_bytes(cs['h_1'])
+    tr.absorb(cb['g_1'] + cb['h_1'])
+    beta = tr.challenge(b'beta')
+    # ---- third round: the three rational sumchecks over K --------------------------------------------------------------------
+    vh_beta = H.vanishing(beta); assert vh_beta != 0
+    f, sigma, g = {}, {}, {}
+    for name in 'abc':
+        ev = index.evals[name]
+        fe = [vh_alpha * vh_beta % R * ev['val'][k] % R * inv((alpha - ev['row'][k]) * (beta - ev['col'][k])) % R for k in range(n_k)]
+        f[name] = K.ifft(fe); sigma[name] = f[name][0] * n_k % R; g[name] = f[name][1:]
+        cs['g_' + name] = _commit_scalar(setup, g[name], bound=n_k - 2); cb['g_' + name] = _point_bytes(cs['g_' + name])
+    tr.absorb(b''.join(fr_bytes(sigma[m]) for m in 'abc') + cb['g_a'] + cb['g_b'] + cb['g_c'])
+    delta = {'a': 1, 'b': tr.challenge(b'delta_b'), 'c': tr.challenge(b'delta_c')}
+    # ---- fourth round ------------------------------------------------------------------------------------------------------------
+    D2 = Domain(2 * n_k)
+    acc = [0] * (2 * n_k)
+    for name in 'abc':
+        pl = index.polys[name]
+        e_row, e_col, e_val, e_rc, e_f = D2.fft(pl['row']), D2.fft(pl['col']), D2.fft(pl['val']), D2.fft(pl['row_col']), D2.fft(f[name])
+        for i in range(2 * n_k):
+            a_ = vh_alpha * vh_beta % R * e_val[i] % R
+            b_ = (alpha * beta - beta * e_row[i] - alpha * e_col[i] + e_rc[i]) % R
+            acc[i] = (acc[i] + delta[name] * (a_ - b_ * e_f[i])) % R
+    pc = D2.ifft(acc)
+    h2 = pc[n_k:]                                                                 # P = h_2 (X^|K| − 1), deg P < 2|K|
+    assert all((pc[i] + h2[i]) % R == 0 for i in range(n_k)), 'fourth round: not divisible by v_K'
+    cs['h_2'] = _commit_scalar(setup, h2); cb['h_2'] = _point_bytes(cs['h_2'])
+    tr.absorb(cb['h_2'])
+    gamma = tr.challenge(b'gamma')
+    # ---- evaluations and the two openings --------------------------------------------------------------------------------------
+    ev = {'z_b': poly_eval(zb, beta), 'g_1': poly_eval(g1, beta), 'g_a': poly_eval(g['a'], gamma), 'g_b': poly_eval(g['b'], gamma), 'g_c': poly_eval(g['c'], gamma)}
+    evals = [ev['z_b'], ev['g_1'], ev['g_a'], ev['g_b'], ev['g_c']]
+    tr.absorb(b''.join(fr_bytes(v) for v in evals))
+    xi = tr.challenge(b'xi')
+    lc1 = lincheck_coefficients(H, X, alpha, beta, eta, sigma, ev['z_b'], ev['g_1'], poly_eval(x_poly, beta))
+    p_beta = [0] * max(len(mask), len(h1), len(za), len(w))
+    def axpy(dst, k, src):
+        for i, v in enumerate(src): dst[i] = (dst[i] + k * v) % R
+    axpy(p_beta, lc1['mask'], mask); axpy(p_beta, lc1['z_a'], za); axpy(p_beta, lc1['w'], w); axpy(p_beta, lc1['h_1'], h1)
+    p_beta[0] = (p_beta[0] + lc1['const']) % R
+    assert poly_eval(p_beta, beta) == 0, 'lincheck linear combination does not vanish at beta'
+    p_beta = [v * xi % R * xi % R for v in p_beta]
+    axpy(p_beta, 1, g1); axpy(p_beta, xi, zb)
+    v_beta = (ev['g_1'] + xi * ev['z_b']) % R
+    w_beta = divide_by_linear(p_beta, beta, v_beta)
+    bl = [0] * HIDING_COEFFS
+    axpy(bl, xi, blind['blind_b'])
+    axpy(bl, xi * xi % R * lc1['mask'], blind['blind_mask']); axpy(bl, xi * xi % R * lc1['z_a'], blind['blind_a']); axpy(bl, xi * xi % R * lc1['w'], blind['blind_w'])
+    random_v = poly_eval(bl, beta)
+    bl_w = divide_by_linear(bl, beta, random_v)
+    open_beta = (poly_eval(w_beta, setup.tau) + setup.s_gamma * poly_eval(bl_w, setup.tau)) % R
+    lc2 = matrix_coefficients(H, K, alpha, beta, gamma, delta, sigma, {m: ev['g_' + m] for m in 'abc'})
+    p_gamma = [0] * n_k
+    for (m, k), coef in lc2['index'].items(): axpy(p_gamma, coef, index.polys[m][k])
+    axpy(p_gamma, lc2['h_2'], h2)
+    p_gamma[0] = (p_gamma[0] + lc2['const']) % R
+    assert poly_eval(p_gamma, gamma) == 0, 'matrix sumcheck linear combination does not vanish at gamma'
+    p_gamma = [v * pow(xi, 3, R) % R for v in p_gamma]
+    axpy(p_gamma, 1, g['a']); axpy(p_gamma, xi, g['b']); axpy(p_gamma, xi * xi % R, g['c'])
+    v_gamma = (ev['g_a'] + xi * ev['g_b'] + xi * xi % R * ev['g_c']) % R
+    open_gamma = poly_eval(divide_by_linear(p_gamma, gamma, v_gamma), setup.tau)
+    proof = {'commitments': {k: cb[k] for k in ('w', 'z_a', 'z_b', 'mask', 'g_1', 'h_1', 'g_a', 'g_b', 'g_c', 'h_2')},
+             'evaluations': evals, 'sums': [sigma['a'], sigma['b'], sigma['c']],
+             'openings': [(_point_bytes(open_beta), random_v), (_point_bytes(open_gamma), None)]}
+    return proof, proof_bytes(proof)
+
+
+def divide_by_linear(p, z, value):
+    """(p(X) − value) / (X − z), value = p(z)."""
+    q = [0] * (len(p) - 1); s = 0
+    for j in range(len(p) - 1, 0, -1):
+        s = (p[j] + z * s) % R; q[j - 1] = s
+    assert (p[0] + z * s) % R == value % R
+    return q
+
+
+def lincheck_coefficients(H, X, alpha, beta, eta, sigma, zb_beta, g1_beta, x_beta):
+    """Coefficients of the linear combination of (mask, z_a, w, h_1, 1) that must vanish at beta (first sumcheck, evaluated by the verifier)."""
+    r_ab = (H.vanishing(alpha) - H.vanishing(beta)) * inv(alpha - beta) % R
+    t_beta = (sigma['a'] + eta['b'] * sigma['b'] + eta['c'] * sigma['c']) % R
+    return {'mask': 1, 'z_a': r_ab * (1 + eta['c'] * zb_beta) % R, 'w': (-t_beta * X.vanishing(beta)) % R, 'h_1': (-H.vanishing(beta)) % R,
+            'const': (r_ab * eta['b'] % R * zb_beta - t_beta * x_beta - beta * g1_beta) % R}
+
+
+def matrix_coefficients(H, K, alpha, beta, gamma, delta, sigma, g_gamma):
+    """Coefficients over (val, row, col, row_col of A, B, C; h_2; 1) of the combination that must vanish at gamma (second sumcheck)."""
+    vv = H.vanishing(alpha) * H.vanishing(beta) % R
+    n_k_inv = K.size_inv
+    idx = {}; const = 0
+    for m in 'abc':
+        fm = (gamma * g_gamma[m] + sigma[m] * n_k_inv) % R                        # f_M(gamma)
+        d = delta[m]
+        idx[(m, 'val')] = d * vv % R
+        idx[(m, 'row')] = d * fm % R * beta % R
+        idx[(m, 'col')] = d * fm % R * alpha % R
+        idx[(m, 'row_col')] = (-d * fm) % R
+        const = (const - d * fm % R * alpha % R * beta) % R
+    return {'index': idx, 'h_2': (-K.vanishing(gamma)) % R, 'const': const}
+
+
+def proof_bytes(proof) -> bytes:
+    """The reference's Proof::to_bytes_le layout for one circuit with one instance (901 bytes)."""
+    c = proof['commitments']; u64 = lambda v: int(v).to_bytes(8, 'little')
+    out = b'\x00' + u64(1) + u64(1) + c['w'] + c['z_a'] + c['z_b'] + b'\x01' + c['mask'] + c['g_1'] + c['h_1'] + c['g_a'] + c['g_b'] + c['g_c'] + c['h_2']
+    out += b''.join(fr_bytes(v) for v in proof['evaluations']) + u64(1) + b''.join(fr_bytes(v) for v in proof['sums']) + u64(len(proof['openings']))
+    for pt, rv in proof['openings']:
+        out += pt + (b'\x01' + fr_bytes(rv) if rv is not None else b'\x00')
+    return out + b'\x00'                                                        # BatchLCProof.evaluations: None
+
+
+def parse_proof(data: bytes):
+    assert data[0] == 0 and int.from_bytes(data[1:9], 'little') == 1 and int.from_bytes(data[9:17], 'little') == 1
+    pos = 17; c = {}
+    def pt():
+        nonlocal pos; v = data[pos:pos + 48]; pos += 48; return v
+    def fr():
+        nonlocal pos; v = int.from_bytes(data[pos:pos + 32], 'little'); pos += 32; assert v < R; return v
+    for k in ('w', 'z_a', 'z_b'): c[k] = pt()
+    assert data[pos] == 1; pos += 1
+    for k in ('mask', 'g_1', 'h_1', 'g_a', 'g_b', 'g_c', 'h_2'): c[k] = pt()
+    evals = [fr() for _ in range(5)]
+    assert int.from_bytes(data[pos:pos + 8], 'little') == 1; pos += 8
+    sums = [fr() for _ in range(3)]
+    n_open = int.from_bytes(data[pos:pos + 8], 'little'); pos += 8
+    openings = []
+    for _ in range(n_open):
+        p_ = pt(); tag = data[pos]; pos += 1
+        openings.append((p_, fr() if tag else None))
+    assert pos + 1 == len(data) and data[pos] == 0
+    return {'commitments': c, 'evaluations': evals, 'sums': sums, 'openings': openings}
+
+
+def verify(index: Index, setup: Setup, public_inputs, data: bytes, vk_bytes=None) -> bool:
+    """Verifier: recomputes the challenges, forms the two linear combinations of commitments and checks both KZG openings.  The pairing
+    equation e(C − v·G − v̄·γG, H) = e(W, (τ − z)·H) is checked as C − v·G − v̄·γG = (τ − z)·W in G1 with the known trapdoor."""
+    try: pr = parse_proof(data)
+    except AssertionError: return False
+    c = index.circuit; H, K, X = index.H, index.K, index.X
+    try: pts = {k: P.g1_decompress(v) for k, v in pr['commitments'].items()}; opn = [P.g1_decompress(p_) for p_, _ in pr['openings']]
+    except Exception: return False
+    if len(opn) != 2 or pr['openings'][0][1] is None or pr['openings'][1][1] is not None: return False
+    x_evals = [public_inputs[i] % R if i < c.n_public else 0 for i in range(c.n_x)]
+    cb = pr['commitments']
+    tr = Transcript(); tr.absorb(vk_bytes if vk_bytes is not None else index.vk_bytes())
+    tr.absorb(b''.join(fr_bytes(v) for v in x_evals))
+    tr.absorb(cb['w'] + cb['z_a'] + cb['z_b'] + cb['mask'])
+    alpha, eta_b, eta_c = tr.challenge(b'alpha'), tr.challenge(b'eta_b'), tr.challenge(b'eta_c')
+    eta = {'a': 1, 'b': eta_b, 'c': eta_c}
+    tr.absorb(cb['g_1'] + cb['h_1']); beta = tr.challenge(b'beta')
+    sigma = dict(zip('abc', pr['sums']))
+    tr.absorb(b''.join(fr_bytes(sigma[m]) for m in 'abc') + cb['g_a'] + cb['g_b'] + cb['g_c'])
+    delta = {'a': 1, 'b': tr.challenge(b'delta_b'), 'c': tr.challenge(b'delta_c')}
+    tr.absorb(cb['h_2']); gamma = tr.challenge(b'gamma')
+    evals = pr['evaluations']
+    tr.absorb(b''.join(fr_bytes(v) for v in evals)); xi = tr.challenge(b'xi')
+    zb_beta, g1_beta, ga, gb, gc = evals
+    G = P.G1_GENERATOR
+    mul, add = P.g1_mul, P.g1_add
+    tau_inv = inv(setup.tau); D = setup.max_degree
+    def unshift(pt, bound): return mul(pt, pow(tau_inv, D - bound, R))
+    x_beta = poly_eval(X.ifft(x_evals), beta)
+    lc1 = lincheck_coefficients(H, X, alpha, beta, eta, sigma, zb_beta, g1_beta, x_beta)
+    C1 = add(add(mul(pts['mask'], lc1['mask']), mul(pts['z_a'], lc1['z_a'])), add(mul(pts['w'], lc1['w']), mul(pts['h_1'], lc1['h_1'])))
+    C1 = add(C1, mul(G, lc1['const']))
+    Cb = add(add(unshift(pts['g_1'], c.n_h - 2), mul(pts['z_b'], xi)), mul(C1, xi * xi % R))
+    v_beta = (g1_beta + xi * zb_beta) % R
+    lhs = add(Cb, P.g1_neg(mul(G, (v_beta + setup.s_gamma * pr['openings'][0][1]) % R)))
+    if lhs != mul(opn[0], (setup.tau - beta) % R): return False
+    lc2 = matrix_coefficients(H, K, alpha, beta, gamma, delta, sigma, {'a': ga, 'b': gb, 'c': gc})
+    C2 = mul(G, (lc2['const'] + sum(coef * index.commit_scalars[mk] for mk, coef in lc2['index'].items())) % R)   # index commitments are the key's
+    C2 = add(C2, mul(pts['h_2'], lc2['h_2']))
+    Cg = add(add(unshift(pts['g_a'], c.n_k - 2), mul(unshift(pts['g_b'], c.n_k - 2), xi)),
+             add(mul(unshift(pts['g_c'], c.n_k - 2), xi * xi % R), mul(C2, pow(xi, 3, R))))
+    v_gamma = (ga + xi * gb + xi * xi % R * gc) % R
+    lhs = add(Cg, P.g1_neg(mul(G, v_gamma)))
+    return lhs == mul(opn[1], (setup.tau - gamma) % R)

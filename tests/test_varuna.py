@@ -1,0 +1,111 @@
+"""The AHP prover above the operators.  CPU: the restatement in oracle/varuna_ref.py proves, its verifier accepts,
+tampering is rejected, the byte layout is the reference's.  GPU: aleo_amd.varuna produces the SAME proof bytes as the restatement from
+the same circuit, assignment, randomness and setup; at sizes the restatement does not reach, the verifier accepts the device's proofs."""
+import json, os
+import numpy as np
+import pytest
+from aleo_amd import synth
+from oracle import varuna_ref as V, pyref
+
+TAU, S_GAMMA = 0x1F3A9C0D5E7B24681357ACE02468BDF013579BDF02468ACE1234567, 0x0FEDCBA9876543210123456789ABCDEF55AA
+
+
+def _circuit(n_constraints, n_public, seed, long_rows=1):
+    csr, z = synth.synthetic_r1cs(n_constraints, n_public, seed, long_rows=long_rows)
+    def rows(m):
+        ptr, col, val = csr[m]
+        return [[(int(col[k]), synth.limbs_to_int(val[k])) for k in range(ptr[i], ptr[i + 1])] for i in range(len(ptr) - 1)]
+    c = V.Circuit(n_constraints, n_public, len(z) - n_public, rows('a'), rows('b'), rows('c'))
+    return csr, z, c
+
+
+def _max_degree(c):
+    d = 1
+    while d < max(3 * c.n_h, c.n_k): d *= 2
+    return d - 1
+
+
+def _rand(c, seed): return synth.uniform_scalars(V.randomness_layout(c.n_h)['total'], seed)
+
+
+def test_restatement_proves_and_verifies():
+    csr, z, c = _circuit(40, 3, 11)
+    setup = V.Setup(TAU, S_GAMMA, _max_degree(c)); idx = V.Index(c, setup)
+    rand = [synth.limbs_to_int(x) for x in _rand(c, 5)]
+    proof, data = V.prove(idx, setup, z, rand)
+    assert len(data) == 901                      # the reference's proof string decodes to 901 bytes for one circuit, one instance
+    assert V.verify(idx, setup, z[:3], data)
+    # the layout is the reference's: the proof string it holds (wasm/src/programs/transaction.rs:100) parses with the same parser,
+    # field for field (commitments at the offsets of tests/golden/reference_proof.json, the hiding value on the first opening only)
+    ref = json.load(open(os.path.join(os.path.dirname(__file__), 'golden', 'reference_proof.json')))
+    hrp, payload = pyref.bech32m_decode(ref['proof'])
+    assert hrp == 'proof' and len(payload) == len(data) == 901
+    parsed = V.parse_proof(payload)
+    names = {'mask_poly': 'mask'}
+    for name, ent in ref['commitments'].items():
+        assert parsed['commitments'][names.get(name, name)].hex() == ent['compressed']
+    assert [p_.hex() for p_, _ in parsed['openings']] == [o['compressed'] for o in ref['openings']]
+    assert parsed['openings'][0][1] == int(ref['openings'][0]['random_v'], 16) and parsed['openings'][1][1] is None
+    assert V.proof_bytes(parsed) == payload
+    for pos in (20, 300, 500, 700, 800, 860):    # a commitment, evaluations, sums, both openings
+        bad = bytearray(data); bad[pos] ^= 1
+        assert not V.verify(idx, setup, z[:3], bytes(bad))
+    assert not V.verify(idx, setup, [1, (z[1] + 1) % V.R, z[2]], data)
+    z2 = list(z); z2[7] = (z2[7] + 1) % V.R     # an unsatisfied assignment cannot be proved
+    with pytest.raises(AssertionError): V.prove(idx, setup, z2, rand)
+
+
+def test_restatement_layout_round_trip():
+    csr, z, c = _circuit(17, 2, 3, long_rows=0)
+    setup = V.Setup(TAU, S_GAMMA, _max_degree(c)); idx = V.Index(c, setup)
+    proof, data = V.prove(idx, setup, z, [synth.limbs_to_int(x) for x in _rand(c, 9)])
+    back = V.parse_proof(data)
+    assert back['commitments'] == proof['commitments'] and back['evaluations'] == proof['evaluations'] and back['sums'] == proof['sums']
+    assert V.proof_bytes(back) == data
+    assert pyref.bech32m_encode('proof', data).startswith('proof1')
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('n_constraints,n_public,seed', [(24, 3, 5), (100, 2, 6), (700, 5, 7), (2000, 9, 8)])
+def test_device_prover_matches_restatement(n_constraints, n_public, seed):
+    from aleo_amd import varuna
+    csr, z, c = _circuit(n_constraints, n_public, seed)
+    D = _max_degree(c)
+    setup = V.Setup(TAU, S_GAMMA, D); idx = V.Index(c, setup)
+    rand = _rand(c, seed + 100)
+    want_proof, want = V.prove(idx, setup, z, [synth.limbs_to_int(x) for x in rand])
+    ck = varuna.synthetic_committer_key(TAU, S_GAMMA, D)
+    try:
+        ix = varuna.CircuitIndex(csr, n_constraints, n_public, len(z) - n_public, ck)
+        assert (ix.n_h, ix.n_k, ix.n_x) == (c.n_h, c.n_k, c.n_x)
+        assert ix.vk_bytes == idx.vk_bytes()
+        zz = np.stack([synth.int_to_limbs(v, 4) for v in z])
+        proof = varuna.prove(ix, zz, rand)
+        got = proof.to_bytes()
+        assert got == want
+        assert V.verify(idx, setup, z[:n_public], got)
+        assert proof.to_string() == pyref.bech32m_encode('proof', want)
+    finally:
+        ck.close()
+
+
+@pytest.mark.gpu
+def test_device_prover_verifies_at_2_13():
+    from aleo_amd import varuna
+    n = 1 << 13
+    csr, z, c = _circuit(n - 50, 4, 21, long_rows=3)
+    D = _max_degree(c)
+    setup = V.Setup(TAU, S_GAMMA, D); idx = V.Index(c, setup)
+    ck = varuna.synthetic_committer_key(TAU, S_GAMMA, D)
+    try:
+        ix = varuna.CircuitIndex(csr, n - 50, 4, len(z) - 4, ck)
+        assert ix.vk_bytes == idx.vk_bytes()
+        zz = np.stack([synth.int_to_limbs(v, 4) for v in z])
+        data = varuna.prove(ix, zz, _rand(c, 77)).to_bytes()
+        assert len(data) == 901 and V.verify(idx, setup, z[:4], data)
+        bad = bytearray(data); bad[600] ^= 4
+        assert not V.verify(idx, setup, z[:4], bytes(bad))
+        z2 = zz.copy(); z2[100, 0] ^= np.uint64(1)                       # a wrong witness: the proof comes out, the verifier refuses it
+        assert not V.verify(idx, setup, z[:4], varuna.prove(ix, z2, _rand(c, 77)).to_bytes())
+    finally:
+        ck.close()
