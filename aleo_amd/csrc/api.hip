@@ -583,6 +583,30 @@ int32_t aleo_mi355x_fr_lin_device(void* d_dst, size_t n, const void* c0_mont, co
   } catch (...) { return ALEO_MI355X_ERR_HIP; }
 }
 
+int32_t aleo_mi355x_fr_powers_device(void* d_dst, size_t n, const void* first_mont, const void* ratio_mont, void* stream) {
+  try {
+    if ((!d_dst && n) || !first_mont || !ratio_mont) return ALEO_MI355X_ERR_BAD_ARG;
+    API_BEGIN
+    return run_enqueue(c, stream, [&](hipStream_t s) { return fr_powers(c, d_dst, n, first_mont, ratio_mont, s); });
+  } catch (...) { return ALEO_MI355X_ERR_HIP; }
+}
+
+int32_t aleo_mi355x_fr_gather_mul_device(void* d_dst, size_t n, const void* d_scale, const void* d_table1, const void* d_idx1, const void* d_table2, const void* d_idx2, void* stream) {
+  try {
+    if (n && (!d_dst || !d_table1 || !d_idx1 || (d_table2 && !d_idx2))) return ALEO_MI355X_ERR_BAD_ARG;
+    API_BEGIN
+    return run_enqueue(c, stream, [&](hipStream_t s) { return fr_gather_mul(c, d_dst, n, d_scale, d_table1, d_idx1, d_table2, d_idx2, s); });
+  } catch (...) { return ALEO_MI355X_ERR_HIP; }
+}
+
+int32_t aleo_mi355x_fr_eval_batch_device(void* d_out, const void* const* d_polys, const size_t* lens, const void* z_mont, size_t k, void* stream) {
+  try {
+    if (k && (!d_out || !d_polys || !lens || !z_mont)) return ALEO_MI355X_ERR_BAD_ARG;
+    API_BEGIN
+    return run_enqueue(c, stream, [&](hipStream_t s) { return fr_eval_batch(c, d_out, d_polys, lens, z_mont, k, s); });
+  } catch (...) { return ALEO_MI355X_ERR_HIP; }
+}
+
 int32_t aleo_mi355x_fr_batch_inverse_device(void* d_inout, size_t n, void* stream) {
   try {
     if (!d_inout && n) return ALEO_MI355X_ERR_BAD_ARG;

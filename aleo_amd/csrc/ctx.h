@@ -154,6 +154,9 @@ int32_t msm_g2_run(Ctx* c, uint64_t* out_jac36, const void* d_xy192, const uint8
 int32_t g2_sum_host(uint64_t* out36, const uint64_t* pts36, size_t count);
 // frops.hip
 int32_t fr_lin(Ctx* c, void* d_dst, size_t n, const void* c0, const void* c1, const void* d_a, const void* c2, const void* d_b, hipStream_t s);
+int32_t fr_powers(Ctx* c, void* d_dst, size_t n, const void* first, const void* ratio, hipStream_t s);
+int32_t fr_gather_mul(Ctx* c, void* d_dst, size_t n, const void* d_scale, const void* d_t1, const void* d_idx1, const void* d_t2, const void* d_idx2, hipStream_t s);
+int32_t fr_eval_batch(Ctx* c, void* d_out, const void* const* d_polys, const size_t* lens, const void* z_mont, size_t k, hipStream_t s);
 int32_t fr_vec_op(Ctx* c, void* d_dst, const void* d_a, const void* d_b, size_t n, int32_t op, hipStream_t s);
 int32_t fr_batch_inverse(Ctx* c, void* d_inout, size_t n, hipStream_t s);
 int32_t fr_divide_by_linear(Ctx* c, void* d_q, void* d_eval, const void* d_p, size_t n, const void* z_mont32, hipStream_t s);

@@ -267,6 +267,118 @@ int32_t fr_divide_by_linear(Ctx* c, void* d_q, void* d_eval, const void* d_p, si
   return scratch_release(c, s);
 }
 
+// ---- geometric sequences, gathers and batched evaluation: what lets the AHP rounds run without a single field inversion on the device ----
+// u_H(a, X) = (v_H(a) - v_H(X)) / (a - X) = sum_k a^(|H|-1-k) X^k, so the polynomial r(alpha, X) IS the reversed powers of alpha and its
+// values v_H(alpha) / (alpha - h) over H are one NTT of them; the third round's 1 / ((alpha - row)(beta - col)) are then two gathers from
+// those tables by the row / column index of every non-zero entry [UPSTREAM-RECALL: snarkVM gets the same values through batch inversions
+// in round_functions/{second,third}.rs].
+static constexpr uint32_t POW_K = 16;
+__device__ __noinline__ void fr_pow_u64_ni(Fr* io, uint64_t e) {          // io^e, io < 2r
+  Fr b = *io, acc = Fr::one();
+  for (; e; e >>= 1) { if (e & 1) acc = Fr::mul(acc, b); b = Fr::sqr(b); }
+  *io = acc;
+}
+// dst[k] = first * ratio^k: every lane raises ratio to its first index, then walks POW_K consecutive elements
+__global__ void __launch_bounds__(256) k_fr_powers(char* __restrict__ dst, size_t n, FrK kfirst, FrK kratio) {
+  const size_t lo = ((size_t)blockIdx.x * 256 + threadIdx.x) * POW_K;
+  if (lo >= n) return;
+  const Fr ratio = fr_arg(kratio);
+  Fr x = ratio; fr_pow_u64_ni(&x, lo);
+  x = Fr::mul(x, fr_arg(kfirst));
+  for (uint32_t k = 0; k < POW_K && lo + k < n; ++k) {
+    store_fp<Fr>(dst + (lo + k) * 32, Fr::reduce(x));
+    x = Fr::mul(x, ratio);
+  }
+}
+int32_t fr_powers(Ctx* c, void* d_dst, size_t n, const void* first, const void* ratio, hipStream_t s) {
+  (void)c;
+  if (n == 0) return ALEO_MI355X_OK;
+  FrK kf, kr; std::memcpy(kf.v, first, 32); std::memcpy(kr.v, ratio, 32);
+  const size_t lanes = (n + POW_K - 1) / POW_K;
+  hipLaunchKernelGGL(k_fr_powers, dim3((uint32_t)((lanes + 255) / 256)), dim3(256), 0, s, (char*)d_dst, n, kf, kr);
+  HIPCHK(hipGetLastError());
+  return ALEO_MI355X_OK;
+}
+
+// dst[i] = scale[i] * t1[idx1[i]] * t2[idx2[i]]   (scale and the second table optional)
+template <bool HAS_SCALE, bool HAS_T2>
+__global__ void __launch_bounds__(256) k_fr_gather_mul(char* __restrict__ dst, size_t n, const char* scale, const char* __restrict__ t1,
+                                                       const uint32_t* __restrict__ idx1, const char* __restrict__ t2, const uint32_t* __restrict__ idx2) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    Fr r = load_fp<Fr>(t1 + (size_t)idx1[i] * 32);
+    if constexpr (HAS_T2) r = Fr::mul(r, load_fp<Fr>(t2 + (size_t)idx2[i] * 32));
+    if constexpr (HAS_SCALE) r = Fr::mul(r, load_fp<Fr>(scale + i * 32));
+    store_fp<Fr>(dst + i * 32, Fr::reduce(r));
+  }
+}
+int32_t fr_gather_mul(Ctx* c, void* d_dst, size_t n, const void* d_scale, const void* d_t1, const void* d_idx1, const void* d_t2, const void* d_idx2, hipStream_t s) {
+  (void)c;
+  if (n == 0) return ALEO_MI355X_OK;
+  size_t want = (n + 255) / 256; dim3 grid((uint32_t)(want < 16384 ? want : 16384)), blk(256);
+  char* dst = (char*)d_dst; const char* sc = (const char*)d_scale; const char* t1 = (const char*)d_t1; const char* t2 = (const char*)d_t2;
+  const uint32_t* i1 = (const uint32_t*)d_idx1; const uint32_t* i2 = (const uint32_t*)d_idx2;
+  if (sc && t2) hipLaunchKernelGGL((k_fr_gather_mul<true, true>), grid, blk, 0, s, dst, n, sc, t1, i1, t2, i2);
+  else if (sc) hipLaunchKernelGGL((k_fr_gather_mul<true, false>), grid, blk, 0, s, dst, n, sc, t1, i1, t2, i2);
+  else if (t2) hipLaunchKernelGGL((k_fr_gather_mul<false, true>), grid, blk, 0, s, dst, n, sc, t1, i1, t2, i2);
+  else hipLaunchKernelGGL((k_fr_gather_mul<false, false>), grid, blk, 0, s, dst, n, sc, t1, i1, t2, i2);
+  HIPCHK(hipGetLastError());
+  return ALEO_MI355X_OK;
+}
+
+// p_q(z_q) for up to EVAL_MAX polynomials in two launches: the per-block folds of k_div_blocks for all of them at once, then one
+// block per polynomial combines its folds (Horner over its lanes' runs of blocks, then a sum over the lanes weighted by powers of z^4096).
+static constexpr uint32_t EVAL_MAX = 8;
+struct EvalArgs { const char* p[EVAL_MAX]; size_t n[EVAL_MAX]; FrK z[EVAL_MAX]; uint32_t first_block[EVAL_MAX + 1]; uint32_t k; };
+__global__ void __launch_bounds__(256) k_eval_blocks(EvalArgs a, char* __restrict__ E) {
+  __shared__ uint32_t l[8 * DIV_B];
+  uint32_t q = 0; while (q + 1 < a.k && blockIdx.x >= a.first_block[q + 1]) ++q;
+  const uint32_t t = threadIdx.x, b = blockIdx.x - a.first_block[q]; const Fr z = fr_arg(a.z[q]);
+  Fr x = fr_lt2r(div_lane_fold(a.p[q], ((size_t)b * DIV_B + t) * DIV_K, a.n[q], z));
+  Fr w = z; for (int i = 0; i < 4; ++i) w = Fr::sqr(w);
+  for (uint32_t d = 1; d < DIV_B; d <<= 1) {
+    lds_put(l, t, x); __syncthreads();
+    if ((t & (2 * d - 1)) == 0) x = fr_lt2r(Fr::add(x, Fr::mul(lds_get(l, t + d), w)));
+    __syncthreads();
+    w = Fr::sqr(w);
+  }
+  if (t == 0) store_fp<Fr>(E + (size_t)blockIdx.x * 32, x);
+}
+__global__ void __launch_bounds__(256) k_eval_combine(EvalArgs a, const char* __restrict__ E, char* __restrict__ out) {
+  __shared__ uint32_t l[8 * DIV_B];
+  const uint32_t q = blockIdx.x, t = threadIdx.x, nb = a.first_block[q + 1] - a.first_block[q];
+  const char* Eq = E + (size_t)a.first_block[q] * 32;
+  Fr zb = fr_arg(a.z[q]); for (int i = 0; i < 12; ++i) zb = Fr::sqr(zb);                 // z^4096
+  const uint32_t per = (nb + DIV_B - 1) / DIV_B, lo = t * per, hi = lo + per < nb ? lo + per : nb;
+  Fr g = Fr::zero();
+  for (uint32_t b = hi; b-- > lo && hi > lo;) g = fr_lt2r(Fr::add(Fr::mul(g, zb), load_fp<Fr>(Eq + (size_t)b * 32)));
+  Fr w = zb; fr_pow_u64_ni(&w, (uint64_t)lo);                                             // weight of this lane's run
+  Fr x = lo < nb ? Fr::cond_sub<1>(Fr::mul(g, w)) : Fr::zero();                            // < r
+  for (uint32_t d = DIV_B / 2; d >= 1; d >>= 1) {
+    lds_put(l, t, x); __syncthreads();
+    if (t < d) x = Fr::cond_sub<1>(Fr::add(x, lds_get(l, t + d)));                          // < 2r -> < r
+    __syncthreads();
+  }
+  if (t == 0) store_fp<Fr>(out + (size_t)q * 32, x);
+}
+int32_t fr_eval_batch(Ctx* c, void* d_out, const void* const* d_polys, const size_t* lens, const void* z_mont, size_t k, hipStream_t s) {
+  if (k == 0) return ALEO_MI355X_OK;
+  if (k > EVAL_MAX) { g_last_error = "fr_eval_batch: more than 8 polynomials in one call"; return ALEO_MI355X_ERR_BAD_ARG; }
+  EvalArgs a{}; a.k = (uint32_t)k; uint64_t total = 0;
+  for (size_t q = 0; q < k; ++q) {
+    if (!d_polys[q] && lens[q]) { g_last_error = "fr_eval_batch: null polynomial"; return ALEO_MI355X_ERR_BAD_ARG; }
+    a.p[q] = (const char*)d_polys[q]; a.n[q] = lens[q]; std::memcpy(a.z[q].v, (const char*)z_mont + 32 * q, 32);
+    a.first_block[q] = (uint32_t)total; total += (lens[q] + DIV_TILE - 1) / DIV_TILE;     // an empty polynomial owns no block: its value is 0
+    if (total >= (1ull << 31)) { g_last_error = "fr_eval_batch: polynomials too long"; return ALEO_MI355X_ERR_BAD_ARG; }
+  }
+  a.first_block[k] = (uint32_t)total;
+  int32_t rc; if ((rc = scratch_acquire(c, c->ntt_tmp, (total + 1) * 32, s))) return rc;
+  char* E = c->ntt_tmp.as<char>();
+  if (total) hipLaunchKernelGGL(k_eval_blocks, dim3((uint32_t)total), dim3(256), 0, s, a, E);
+  hipLaunchKernelGGL(k_eval_combine, dim3((uint32_t)k), dim3(256), 0, s, a, (const char*)E, (char*)d_out);
+  HIPCHK(hipGetLastError());
+  return scratch_release(c, s);
+}
+
 int32_t fr_batch_inverse(Ctx* c, void* d_inout, size_t n, hipStream_t s) {
   if (n == 0) return ALEO_MI355X_OK;
   int32_t rc; if ((rc = scratch_acquire(c, c->ntt_tmp, n * 32, s))) return rc;

@@ -1190,7 +1190,8 @@ int32_t generate_multiples(Ctx* c, const void* base104, uint64_t first, size_t n
 
 // P_i = s_i * G for caller-supplied canonical scalars (SRS-shaped bases P_i = beta^i * G, whose commitment to p
 // is p(beta) * G — what the opening equation of KZG10 needs).  One lane per point, plain double-and-add (setup, not timed).
-__global__ void __launch_bounds__(256) k_gen_scalar_mul(const char* __restrict__ g_affine, const uint32_t* __restrict__ scalars, uint32_t n, char* __restrict__ tmp) {
+__global__ void __launch_bounds__(256) k_gen_scalar_mul(const char* __restrict__ g_affine, const uint32_t* __restrict__ scalars, uint32_t n, char* __restrict__ tmp,
+                                                        uint8_t* __restrict__ inf, uint32_t* __restrict__ n_inf) {
   uint32_t i = blockIdx.x * 256 + threadIdx.x; if (i >= n) return;
   AffinePt g = load_affine(g_affine);
   XYZZ G; G.X = g.x; G.Y = g.y; G.ZZ = Fq::one(); G.ZZZ = Fq::one();
@@ -1202,22 +1203,31 @@ __global__ void __launch_bounds__(256) k_gen_scalar_mul(const char* __restrict__
     if ((k[bit >> 5] >> (bit & 31)) & 1u) xyzz_add_ni(&acc, &G);
   }
   store_xyzz(tmp + (size_t)i * 192, acc);
+  const bool is_inf = acc.ZZZ.is_zero_mod();                 // s_i = 0 mod r: flagged like an uploaded Affine with infinity = true
+  inf[i] = is_inf ? 1 : 0;
+  if (is_inf) atomicAdd(n_inf, 1u);
 }
 
 int32_t generate_from_scalars(Ctx* c, const void* base104, const void* scalars32, size_t n, PinnedBases* out) {
   if (n == 0 || n >= (1ull << 31) || !scalars32) { g_last_error = "bases_from_scalars: bad range"; return ALEO_MI355X_ERR_BAD_ARG; }
-  DevTmp xy, g, tmp, pre, sc; int32_t rc;
-  if ((rc = xy.alloc(n * 96)) || (rc = g.alloc(96)) || (rc = tmp.alloc(n * 192)) || (rc = pre.alloc(n * 48)) || (rc = sc.alloc(n * 32))) return rc;
+  DevTmp xy, g, tmp, pre, sc, inf, cnt; int32_t rc;
+  if ((rc = xy.alloc(n * 96)) || (rc = g.alloc(96)) || (rc = tmp.alloc(n * 192)) || (rc = pre.alloc(n * 48)) || (rc = sc.alloc(n * 32)) ||
+      (rc = inf.alloc(n)) || (rc = cnt.alloc(4))) return rc;
   HIPCHK(hipMemcpyAsync(g.p, base104, 96, hipMemcpyHostToDevice, c->stream));
   HIPCHK(hipMemcpyAsync(sc.p, scalars32, n * 32, hipMemcpyHostToDevice, c->stream));
-  hipLaunchKernelGGL(k_gen_scalar_mul, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, c->stream, (const char*)g.p, (const uint32_t*)sc.p, (uint32_t)n, (char*)tmp.p);
+  HIPCHK(hipMemsetAsync(cnt.p, 0, 4, c->stream));
+  hipLaunchKernelGGL(k_gen_scalar_mul, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, c->stream, (const char*)g.p, (const uint32_t*)sc.p, (uint32_t)n, (char*)tmp.p,
+                     (uint8_t*)inf.p, (uint32_t*)cnt.p);
   uint32_t lanes = (uint32_t)((n + GEN_K - 1) / GEN_K), grid = (lanes + 255) / 256;
   hipLaunchKernelGGL(k_gen_normalize, dim3(grid), dim3(256), 0, c->stream, (char*)tmp.p, (uint32_t)n, (char*)pre.p, (char*)xy.p);
   HIPCHK(hipGetLastError());
+  uint32_t n_inf = 0;
+  HIPCHK(hipMemcpyAsync(&n_inf, cnt.p, 4, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
   PinnedBases pb; pb.n = n; pb.d_xy = xy.p;
   if ((rc = make_rows28(c, &pb))) return rc;
   xy.release();
+  if (n_inf) pb.d_inf = (uint8_t*)inf.release();             // only sets that hold the identity carry flags (as uploaded sets do)
   *out = pb; return ALEO_MI355X_OK;
 }
 

@@ -21,6 +21,29 @@ def fr_lin_device(d_dst: int, n: int, c0, c1=None, d_a: int = 0, c2=None, d_b: i
                                           ctypes.c_void_p(stream)), 'fr_lin_device')
 
 
+def fr_powers_device(d_dst: int, n: int, first, ratio, stream: int = 0):
+    """dst[k] = first * ratio^k (first, ratio: uint64[4] Montgomery on the host)."""
+    import numpy as np
+    f = np.ascontiguousarray(first, dtype=np.uint64).reshape(4); r = np.ascontiguousarray(ratio, dtype=np.uint64).reshape(4)
+    check(lib().aleo_mi355x_fr_powers_device(ctypes.c_void_p(d_dst), n, f.ctypes.data_as(ctypes.c_void_p), r.ctypes.data_as(ctypes.c_void_p),
+                                             ctypes.c_void_p(stream)), 'fr_powers_device')
+
+
+def fr_gather_mul_device(d_dst: int, n: int, d_scale: int, d_table1: int, d_idx1: int, d_table2: int = 0, d_idx2: int = 0, stream: int = 0):
+    """dst[i] = scale[i] * table1[idx1[i]] * table2[idx2[i]] (uint32 indices; scale / table2 may be 0)."""
+    vp = ctypes.c_void_p
+    check(lib().aleo_mi355x_fr_gather_mul_device(vp(d_dst), n, vp(d_scale), vp(d_table1), vp(d_idx1), vp(d_table2), vp(d_idx2), vp(stream)), 'fr_gather_mul_device')
+
+
+def fr_eval_batch_device(d_out: int, d_polys, lens, points_mont, stream: int = 0):
+    """out[q] = p_q(z_q) for up to 8 polynomials; points_mont: uint64[k,4] Montgomery on the host."""
+    import numpy as np
+    k = len(d_polys)
+    z = np.ascontiguousarray(points_mont, dtype=np.uint64).reshape(k, 4)
+    ptrs = (ctypes.c_void_p * max(k, 1))(*[int(x) for x in d_polys]); ln = (ctypes.c_size_t * max(k, 1))(*[int(x) for x in lens])
+    check(lib().aleo_mi355x_fr_eval_batch_device(ctypes.c_void_p(d_out), ptrs, ln, z.ctypes.data_as(ctypes.c_void_p), k, ctypes.c_void_p(stream)), 'fr_eval_batch_device')
+
+
 def batch_inversion_device(d_inout: int, n: int, stream: int = 0):
     check(lib().aleo_mi355x_fr_batch_inverse_device(ctypes.c_void_p(d_inout), n, ctypes.c_void_p(stream)), 'fr_batch_inverse_device')
 

@@ -16,7 +16,8 @@ from . import synth, wire
 from .fft import EvaluationDomain, FORWARD, INVERSE
 from .kzg import CommitterKey, SonicKZG10, KZG10
 from .msm import PinnedBases
-from .poly import fr_vec_op_device, fr_lin_device, batch_inversion_device, spmv_device, divide_by_linear_device, OP_MUL, OP_ADD, OP_SUB
+from .poly import (fr_vec_op_device, fr_lin_device, fr_powers_device, fr_gather_mul_device, fr_eval_batch_device, spmv_device, divide_by_linear_device,
+                   OP_MUL, OP_ADD, OP_SUB)
 
 R = synth.FR_MODULUS
 _RM = (1 << 256) % R
@@ -124,12 +125,14 @@ class CircuitIndex:
             self.vx_inv = _Vec(n_h, np.tile(_mont_rows(per), (n_x, 1)))
             # arithmetisation over K: row, col, val, row_col
             self.k_evals = _Vec(12 * n_k)                                            # [matrix][row, col, val, row_col][|K|]
+            kidx = np.zeros((3, 2, n_k), dtype=np.uint32)                            # [matrix][row, col][|K|]: positions on H (padding: 0, the element 1)
             host_h = self.h_elems.host()
             n_h_inv = _mont(_inv(n_h))
             for k, m in enumerate('abc'):
                 rp, col, val = _csr_on_h(csr[m], self.pos, n_h)
                 rows = np.repeat(np.arange(n_h, dtype=np.int64), np.diff(rp.astype(np.int64)))
                 nz = len(col)
+                kidx[k, 0, :nz] = rows; kidx[k, 1, :nz] = col
                 ev = np.tile(one, (4 * n_k, 1)).reshape(4, n_k, 4)
                 ev[0, :nz] = host_h[rows]; ev[1, :nz] = host_h[col.astype(np.int64)]
                 ev[2] = 0
@@ -139,6 +142,7 @@ class CircuitIndex:
                 fr_vec_op_device(base + 2 * n_k * 32, vraw.ptr(), base + 1 * n_k * 32, nz, OP_MUL, s)          # v * col
                 fr_lin_device(base + 2 * n_k * 32, nz, None, n_h_inv, base + 2 * n_k * 32, stream=s)              # / |H|
                 fr_vec_op_device(base + 3 * n_k * 32, base, base + n_k * 32, n_k, OP_MUL, s)                       # row * col
+            self.k_idx = torch.from_numpy(kidx.view(np.int32)).cuda()
             self.k_polys = _Vec(12 * n_k); self.k_polys.t.copy_(self.k_evals.t)
             self.K.ntt_batch_device(self.k_polys.ptr(), 12, direction=INVERSE, stream=s)
             self.k2_evals = _Vec(24 * n_k)                                            # the same twelve polynomials on 2K
@@ -228,16 +232,15 @@ class Prover:
         one = _mont(1); neg1 = _mont(R - 1)
         alpha = self.alpha; vh_alpha = _vanish(n_h, alpha)
         if vh_alpha == 0: raise ArithmeticError('alpha landed in H')
-        ext = _Vec(3 * n_h)                                                         # r_alpha, eta_b r_alpha, eta_c r_alpha
-        fr_lin_device(ext.ptr(), n_h, _mont(alpha), neg1, ix.h_elems.ptr(), stream=s)
-        batch_inversion_device(ext.ptr(), n_h, s)
-        fr_lin_device(ext.ptr(), n_h, None, _mont(vh_alpha), ext.ptr(), stream=s)
+        ext = self.r_alpha = _Vec(3 * n_h)                                          # r_alpha, eta_b r_alpha, eta_c r_alpha on H
+        rt = _Vec(2 * n_h)                                                          # r(alpha, X) = sum_k alpha^(|H|-1-k) X^k, then t(X)
+        fr_powers_device(rt.ptr(), n_h, _mont(pow(alpha, n_h - 1, R)), _mont(_inv(alpha)), s)
+        ext.t[:n_h].copy_(rt.t[:n_h]); ix.H.ntt_device(ext.ptr(), stream=s)           # v_H(alpha) / (alpha − h): no inversion on the device
         fr_lin_device(ext.ptr(n_h), n_h, None, _mont(self.eta_b), ext.ptr(), stream=s)
         fr_lin_device(ext.ptr(2 * n_h), n_h, None, _mont(self.eta_c), ext.ptr(), stream=s)
-        rt = _Vec(2 * n_h); rt.t[:n_h].copy_(ext.t[:n_h])
         tp, tcol, tval = ix.tr
         spmv_device(rt.ptr(n_h), tp.data_ptr(), tcol.data_ptr(), tval.ptr(), ext.ptr(), n_h, s)
-        ix.H.ntt_batch_device(rt.ptr(), 2, direction=INVERSE, stream=s)               # r(alpha, X), t(X)
+        ix.H.ntt_device(rt.ptr(n_h), direction=INVERSE, stream=s)                     # t(X)
         L = n_h + 1; n4 = 4 * n_h
         E = _Vec(5 * n4)                                                            # r, t, z, z_a, z_b on the domain of size 4|H|
         E.t[0:n_h].copy_(rt.t[:n_h]); E.t[n4:n4 + n_h].copy_(rt.t[n_h:])
@@ -275,17 +278,13 @@ class Prover:
         vh_beta = _vanish(n_h, self.beta)
         if vh_beta == 0: raise ArithmeticError('beta landed in H')
         self.vv = _vanish(n_h, self.alpha) * vh_beta % R
-        self.f = _Vec(3 * n_k); d2 = _Vec(n_k)
-        for k in range(3):
-            base = ix.k_evals.ptr(4 * k * n_k); f = self.f.ptr(k * n_k)
-            fr_lin_device(f, n_k, _mont(self.alpha), neg1, base, stream=s)                        # alpha − row
-            fr_lin_device(d2.ptr(), n_k, _mont(self.beta), neg1, base + 32 * n_k, stream=s)       # beta − col
-            fr_vec_op_device(f, f, d2.ptr(), n_k, OP_MUL, s)
-        batch_inversion_device(self.f.ptr(), 3 * n_k, s)
-        for k in range(3):
-            f = self.f.ptr(k * n_k)
-            fr_vec_op_device(f, f, ix.k_evals.ptr((4 * k + 2) * n_k), n_k, OP_MUL, s)
-        fr_lin_device(self.f.ptr(), 3 * n_k, None, _mont(self.vv), self.f.ptr(), stream=s)
+        self.f = _Vec(3 * n_k)
+        rb = _Vec(n_h)                                                              # v_H(beta) / (beta − h) on H, the same way
+        fr_powers_device(rb.ptr(), n_h, _mont(pow(self.beta, n_h - 1, R)), _mont(_inv(self.beta)), s)
+        ix.H.ntt_device(rb.ptr(), stream=s)
+        for k in range(3):                                                          # f_M = val u_H(alpha, row) u_H(beta, col) on K: two gathers
+            fr_gather_mul_device(self.f.ptr(k * n_k), n_k, ix.k_evals.ptr((4 * k + 2) * n_k), self.r_alpha.ptr(), ix.k_idx[k, 0].data_ptr(),
+                                 rb.ptr(), ix.k_idx[k, 1].data_ptr(), s)
         ix.K.ntt_batch_device(self.f.ptr(), 3, direction=INVERSE, stream=s)
         ix.stream.synchronize()
         f0 = self.f.t.view(3, n_k, 4)[:, 0].cpu().numpy().view(np.uint64)
@@ -318,15 +317,12 @@ class Prover:
         self.gamma = self.tr.challenge(b'gamma')
 
     # ---- evaluations and openings ------------------------------------------------------------------------------------------------------
-    def _eval(self, ptr, n, z, slot):
-        divide_by_linear_device(0, self._ev.ptr(slot), ptr, n, _mont(z), self.s)
-
     def finish(self) -> Proof:
         ix, s = self.ix, self.s; n_h, n_k, n_x = ix.n_h, ix.n_k, ix.n_x
         one = _mont(1)
         self._ev = _Vec(8)
-        self._eval(self.zb.ptr(), n_h + 1, self.beta, 0); self._eval(self.g1.ptr(1), n_h - 1, self.beta, 1)
-        for k in range(3): self._eval(self.f.ptr(k * n_k + 1), n_k - 1, self.gamma, 2 + k)
+        fr_eval_batch_device(self._ev.ptr(), [self.zb.ptr(), self.g1.ptr(1)] + [self.f.ptr(k * n_k + 1) for k in range(3)],
+                             [n_h + 1, n_h - 1] + [n_k - 1] * 3, _mont_rows([self.beta, self.beta, self.gamma, self.gamma, self.gamma]), s)
         ix.stream.synchronize()
         evals = [_from_mont(v) for v in self._ev.host(0, 5)]
         zb_beta, g1_beta, ga, gb, gc = evals
@@ -357,7 +353,6 @@ class Prover:
         for j in range(HIDING_COEFFS - 1, 0, -1): acc = (bl[j] + beta * acc) % R; blw[j - 1] = acc
         wq = _Vec(3 * n_h); blq = _Vec(HIDING_COEFFS - 1, _mont_rows(blw))
         divide_by_linear_device(wq.ptr(), self._ev.ptr(5), pb.ptr(), 3 * n_h, _mont(beta), s)
-        open_beta = SonicKZG10.commit(ix.ck, [((wq.ptr(), 3 * n_h - 1), None, (blq.ptr(), HIDING_COEFFS - 1))], device=True, stream=s)[0]
         # linear combination of the second sumcheck, opened at gamma together with g_a, g_b, g_c
         xi3 = xi2 * xi % R; n_k_inv = _inv(n_k); vk_gamma = _vanish(n_k, gamma)
         pg = _Vec(n_k); const = 0
@@ -373,13 +368,20 @@ class Prover:
         for k, coef in enumerate((1, xi, xi2)):
             fr_lin_device(pg.ptr(), n_k - 1, None, one, pg.ptr(), _mont(coef), self.f.ptr(k * n_k + 1), stream=s)
         fr_lin_device(pg.ptr(), 1, _mont(xi3 * const), one, pg.ptr(), stream=s)
-        open_gamma, _ = KZG10.open_device(ix.ck.bases, pg.ptr(), n_k, _mont(gamma), stream=s)
+        gq = _Vec(n_k)
+        divide_by_linear_device(gq.ptr(), self._ev.ptr(6), pg.ptr(), n_k, _mont(gamma), s)
+        opn = SonicKZG10.commit(ix.ck, [((wq.ptr(), 3 * n_h - 1), None, (blq.ptr(), HIDING_COEFFS - 1)), ((gq.ptr(), n_k - 1), None, None)], device=True, stream=s)
+        open_beta, open_gamma = opn[0], opn[1]                                      # both witness commitments in one call
         return Proof(dict(self.c), evals, list(self.sigma), [(open_beta, random_v), (open_gamma, None)])
 
 
 def prove(index: CircuitIndex, assignment: np.ndarray, rand: np.ndarray) -> Proof:
     """Varuna::prove_batch for one circuit with one instance."""
+    import time
     with torch.cuda.stream(index.stream):
-        p = Prover(index, assignment, rand)
-        p.first_round(); p.second_round(); p.third_round(); p.fourth_round()
-        return p.finish()
+        p = Prover(index, assignment, rand); t = [time.perf_counter()]
+        for step in (p.first_round, p.second_round, p.third_round, p.fourth_round):
+            step(); t.append(time.perf_counter())                     # every round ends on its commitments: the host has them
+        proof = p.finish(); t.append(time.perf_counter())
+    proof.timing_ms = {k: (t[i + 1] - t[i]) * 1e3 for i, k in enumerate(('round1', 'round2', 'round3', 'round4', 'openings'))}
+    return proof

@@ -188,6 +188,16 @@ int32_t aleo_mi355x_fr_batch_inverse_device(void* d_inout, size_t n, void* strea
  * rounds: alpha - h_i ahead of a batch inversion, eta-weighted sums, the linear combinations opened at beta and gamma
  * [UPSTREAM-RECALL: snark/varuna/ahp/prover/round_functions/{second,third,fourth}.rs]. */
 int32_t aleo_mi355x_fr_lin_device(void* d_dst, size_t n, const void* c0_mont, const void* c1_mont, const void* d_a, const void* c2_mont, const void* d_b, void* stream);
+/* dst[k] = first * ratio^k (first, ratio: 32-byte Montgomery Fr in HOST memory).  With first = a^(n-1), ratio = 1/a this is the
+ * coefficient vector of u_H(a, X) = (v_H(a) - v_H(X)) / (a - X) for |H| = n, whose NTT over H is v_H(a) / (a - h): the values the second
+ * and third AHP rounds need, without a field inversion on the device. */
+int32_t aleo_mi355x_fr_powers_device(void* d_dst, size_t n, const void* first_mont, const void* ratio_mont, void* stream);
+/* dst[i] = scale[i] * table1[idx1[i]] * table2[idx2[i]] (uint32 indices; d_scale and the second table may be NULL): the third round's
+ * val(k) / ((alpha - row(k)) (beta - col(k))) from the two tables above, by the row / column index of every non-zero entry. */
+int32_t aleo_mi355x_fr_gather_mul_device(void* d_dst, size_t n, const void* d_scale, const void* d_table1, const void* d_idx1, const void* d_table2, const void* d_idx2, void* stream);
+/* out[q] = p_q(z_q) for k <= 8 polynomials in two launches (d_polys, lens, z_mont: host arrays of k device pointers / lengths /
+ * 32-byte Montgomery points; d_out: k x 32 bytes, device): the evaluations a proof carries (z_b, g_1 at beta; g_a, g_b, g_c at gamma). */
+int32_t aleo_mi355x_fr_eval_batch_device(void* d_out, const void* const* d_polys, const size_t* lens, const void* z_mont, size_t k, void* stream);
 /* Division by (X - z): quotient[j-1] = s_j with s_j = p_j + z s_(j+1) (n - 1 coefficients, canonical Montgomery form) and, when
  * d_eval != NULL, p(z) = s_0 (32 bytes, device) — KZG10's witness polynomial (p(X) - p(z)) / (X - z)
  * [UPSTREAM-RECALL: polycommit/kzg10 compute_witness_polynomial].  z_mont: 32 bytes Montgomery Fr in HOST memory.

@@ -892,3 +892,124 @@ def test_sonic_commit_degree_bounds_and_hiding_match_oracle():
             dpolys = [((d0.data_ptr(), len(co)), bound, None if d1 is None else (d1.data_ptr(), len(bl))) for (co, bound, bl), (d0, d1) in zip(polys, dev)]
             assert (aleo_amd.SonicKZG10.commit(ck, dpolys, device=True) == got).all()
             with pytest.raises(ValueError): aleo_amd.SonicKZG10.commit(ck, [(f(100, 1), 50, None)])          # bound below the degree
+
+
+# ---- field kernels of the AHP rounds: blends, geometric sequences, gathers, batched evaluation, SRS-shaped sets ------------------
+def _dev(a):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.uint64).view(np.int64).copy()).cuda()
+
+
+def _mont1(v): return c.fr_to_mont(c.ints_to_limbs([v % p.FR_MODULUS], 4))[0]
+
+
+@pytest.mark.parametrize('n', [1, 255, 256, 257, 70001])
+def test_fr_lin_matches_bigint(n):
+    """dst = c0 + c1 a + c2 b in all four shapes (terms present / absent), aliasing dst = a, against Python integers."""
+    import torch
+    from aleo_amd import poly
+    r = p.FR_MODULUS
+    A = util.uniform_scalars(n, 21000 + n); B = util.uniform_scalars(n, 22000 + n)
+    a, b = c.limbs_to_ints(A), c.limbs_to_ints(B)
+    c0, c1, c2 = (int(x) for x in c.limbs_to_ints(util.uniform_scalars(3, 23000 + n)))
+    dA, dB = _dev(c.fr_to_mont(A)), _dev(c.fr_to_mont(B)); dst = torch.zeros((n, 4), dtype=torch.int64, device='cuda'); torch.cuda.synchronize()
+    def got(): torch.cuda.synchronize(); return c.limbs_to_ints(c.fr_from_mont(dst.cpu().numpy().view(np.uint64)))
+    poly.fr_lin_device(dst.data_ptr(), n, _mont1(c0), _mont1(c1), dA.data_ptr(), _mont1(c2), dB.data_ptr())
+    assert got() == [(c0 + c1 * x + c2 * y) % r for x, y in zip(a, b)]
+    poly.fr_lin_device(dst.data_ptr(), n, None, _mont1(r - 1), dA.data_ptr())
+    assert got() == [(-x) % r for x in a]
+    poly.fr_lin_device(dst.data_ptr(), n, _mont1(c0), None, 0, _mont1(c2), dB.data_ptr())
+    assert got() == [(c0 + c2 * y) % r for y in b]
+    poly.fr_lin_device(dst.data_ptr(), n, _mont1(c0))
+    assert got() == [c0] * n
+    poly.fr_lin_device(dA.data_ptr(), n, None, _mont1(1), dA.data_ptr(), _mont1(c2), dB.data_ptr())              # in place
+    torch.cuda.synchronize()
+    assert c.limbs_to_ints(c.fr_from_mont(dA.cpu().numpy().view(np.uint64))) == [(x + c2 * y) % r for x, y in zip(a, b)]
+
+
+@pytest.mark.parametrize('n', [1, 15, 16, 17, 4096, 100001])
+def test_fr_powers_and_the_inversion_free_tables(n):
+    """dst[k] = first * ratio^k; and for a domain H: NTT of (a^(|H|-1-k))_k equals v_H(a) / (a - h) for every h in H."""
+    import torch
+    from aleo_amd import poly
+    r = p.FR_MODULUS
+    first, ratio = (int(x) for x in c.limbs_to_ints(util.uniform_scalars(2, 24000 + n)))
+    dst = torch.zeros((n, 4), dtype=torch.int64, device='cuda'); torch.cuda.synchronize()
+    poly.fr_powers_device(dst.data_ptr(), n, _mont1(first), _mont1(ratio)); torch.cuda.synchronize()
+    want, acc = [], first
+    for _ in range(n): want.append(acc); acc = acc * ratio % r
+    assert c.limbs_to_ints(c.fr_from_mont(dst.cpu().numpy().view(np.uint64))) == want
+    if n == 4096:
+        a = ratio; dom = p.EvaluationDomain(n)
+        poly.fr_powers_device(dst.data_ptr(), n, _mont1(pow(a, n - 1, r)), _mont1(pow(a, -1, r)))
+        aleo_amd.EvaluationDomain(n).ntt_device(dst.data_ptr()); torch.cuda.synchronize()
+        got = c.limbs_to_ints(c.fr_from_mont(dst.cpu().numpy().view(np.uint64)))
+        vh = (pow(a, n, r) - 1) % r; h = 1
+        for i in range(n):
+            assert got[i] == vh * pow(a - h, -1, r) % r
+            h = h * dom.group_gen % r
+
+
+def test_fr_gather_mul_matches_bigint():
+    import torch
+    from aleo_amd import poly
+    r = p.FR_MODULUS; n, m1, m2 = 50001, 777, 4100
+    S, T1, T2 = util.uniform_scalars(n, 25001), util.uniform_scalars(m1, 25002), util.uniform_scalars(m2, 25003)
+    i1 = (synth.splitmix_limbs(25004, n) % np.uint64(m1)).astype(np.uint32); i2 = (synth.splitmix_limbs(25005, n) % np.uint64(m2)).astype(np.uint32)
+    s_, t1, t2 = c.limbs_to_ints(S), c.limbs_to_ints(T1), c.limbs_to_ints(T2)
+    dS, d1, d2 = _dev(c.fr_to_mont(S)), _dev(c.fr_to_mont(T1)), _dev(c.fr_to_mont(T2))
+    di1, di2 = torch.from_numpy(i1.view(np.int32)).cuda(), torch.from_numpy(i2.view(np.int32)).cuda()
+    dst = torch.zeros((n, 4), dtype=torch.int64, device='cuda'); torch.cuda.synchronize()
+    def got(): torch.cuda.synchronize(); return c.limbs_to_ints(c.fr_from_mont(dst.cpu().numpy().view(np.uint64)))
+    poly.fr_gather_mul_device(dst.data_ptr(), n, dS.data_ptr(), d1.data_ptr(), di1.data_ptr(), d2.data_ptr(), di2.data_ptr())
+    assert got() == [s_[i] * t1[i1[i]] % r * t2[i2[i]] % r for i in range(n)]
+    poly.fr_gather_mul_device(dst.data_ptr(), n, 0, d1.data_ptr(), di1.data_ptr(), d2.data_ptr(), di2.data_ptr())
+    assert got() == [t1[i1[i]] * t2[i2[i]] % r for i in range(n)]
+    poly.fr_gather_mul_device(dst.data_ptr(), n, dS.data_ptr(), d1.data_ptr(), di1.data_ptr())
+    assert got() == [s_[i] * t1[i1[i]] % r for i in range(n)]
+    poly.fr_gather_mul_device(dst.data_ptr(), n, 0, d1.data_ptr(), di1.data_ptr())
+    assert got() == [t1[i1[i]] for i in range(n)]
+
+
+def test_fr_eval_batch_matches_oracle():
+    """Up to eight polynomials of ragged lengths (empty, one coefficient, block boundaries, > 256 blocks) at their own points: each
+    value equals the oracle's synthetic division remainder; a ninth polynomial is refused."""
+    import torch
+    from aleo_amd import poly
+    lens = [0, 1, 16, 4095, 4096, 4097, 300001, (1 << 20) + 77]
+    F = [c.fr_to_mont(util.uniform_scalars(max(n, 1), 26000 + i)) for i, n in enumerate(lens)]
+    Z = c.fr_to_mont(util.uniform_scalars(len(lens), 26100)); Z[2] = 0; Z[3] = _mont1(1)
+    D = [_dev(f) for f in F]
+    out = torch.zeros((8, 4), dtype=torch.int64, device='cuda'); torch.cuda.synchronize()
+    poly.fr_eval_batch_device(out.data_ptr(), [d.data_ptr() for d in D], lens, Z); torch.cuda.synchronize()
+    got = out.cpu().numpy().view(np.uint64)
+    for i, n in enumerate(lens):
+        want = c.fr_divide_by_linear(F[i][:n], Z[i])[1] if n else np.zeros(4, dtype=np.uint64)
+        assert (got[i] == want).all(), (i, n)
+    with pytest.raises(aleo_amd.AleoMi355xError):
+        poly.fr_eval_batch_device(out.data_ptr(), [D[1].data_ptr()] * 9, [1] * 9, np.zeros((9, 4), dtype=np.uint64))
+    ev = torch.zeros(4, dtype=torch.int64, device='cuda')                      # the division entry point with no quotient: evaluation only
+    poly.divide_by_linear_device(0, ev.data_ptr(), D[6].data_ptr(), lens[6], Z[6]); torch.cuda.synchronize()
+    assert (ev.cpu().numpy().view(np.uint64) == got[6]).all()
+
+
+def test_bases_from_scalars_is_an_srs():
+    """P_i = s_i G built in HBM: equal to the oracle's scalar multiples (incl. s = 0 -> identity, s = r - 1), and for s_i = tau^i a
+    commitment is p(tau) G — the property KZG10 openings rest on."""
+    r = p.FR_MODULUS; tau = 0x1234567890ABCDEF1234567890ABCDEF12345
+    sc = [0, 1, 2, r - 1] + [pow(tau, i, r) for i in range(300)]
+    S = c.ints_to_limbs(sc, 4)
+    with M.PinnedBases.from_scalars(synth.generator_affine104(), S) as pb:
+        B = pb.download()
+        G = util.generator_affine()
+        for i in (1, 2, 3, 4, 5, 150, 303):
+            want = c.affine_to_ints(c.g1_mul(G, S[i]).reshape(1, 104))[0]
+            assert c.affine_to_ints(B[i:i + 1])[0] == want
+        coeffs = util.uniform_scalars(300, 27001)
+        with M.PinnedBases(B[4:]) as srs:
+            cm = aleo_amd.KZG10.commit(srs, c.fr_to_mont(coeffs))
+        k = sum(v * pow(tau, i, r) for i, v in enumerate(c.limbs_to_ints(coeffs))) % r
+        assert c.affine_to_ints(cm.reshape(1, 104))[0] == p.g1_mul(p.G1_GENERATOR, k)
+        w = util.uniform_scalars(4, 27002); wi = c.limbs_to_ints(w)            # the identity as a base contributes nothing
+        got = c.jac_to_int_point(M.VariableBase.msm(pb, w))
+        assert got == p.g1_mul(p.G1_GENERATOR, (wi[1] + 2 * wi[2] + (r - 1) * wi[3]) % r)

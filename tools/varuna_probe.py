@@ -1,0 +1,27 @@
+"""Wall time of aleo_amd.varuna.prove at several circuit sizes (not a test): per-round breakdown, constraints/s."""
+import os, sys, time, json
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+import numpy as np, torch
+import aleo_amd
+from aleo_amd import synth, varuna
+
+TAU, S_GAMMA = 0x1F3A9C0D5E7B24681357ACE02468BDF013579BDF02468ACE1234567, 0x0FEDCBA9876543210123456789ABCDEF55AA
+torch.cuda.set_device(0)
+for lg in [int(a) for a in sys.argv[1:]] or [13, 15, 16]:
+    n = (1 << lg) - 64
+    csr, z = synth.synthetic_r1cs(n, 4, 40 + lg, long_rows=4)
+    zz = np.stack([synth.int_to_limbs(v, 4) for v in z])
+    nnz = max(int(csr[m][0][-1]) for m in 'abc'); n_k = 2
+    while n_k < nnz: n_k *= 2
+    D = 1
+    while D < max(3 << lg, n_k): D *= 2
+    t0 = time.perf_counter(); ck = varuna.synthetic_committer_key(TAU, S_GAMMA, D - 1); t1 = time.perf_counter()
+    ix = varuna.CircuitIndex(csr, n, 4, len(z) - 4, ck); t2 = time.perf_counter()
+    rand = synth.uniform_scalars(varuna.randomness_layout(ix.n_h)['total'], 3)
+    ts, rounds = [], []
+    for rep in range(7):
+        t = time.perf_counter(); pr = varuna.prove(ix, zz, rand); ts.append((time.perf_counter() - t) * 1e3); rounds.append(pr.timing_ms)
+    med = float(np.median(ts[2:]))
+    print(json.dumps({'lg_constraints': lg, 'constraints': n, 'n_h': ix.n_h, 'n_k': ix.n_k, 'setup_s': t1 - t0, 'index_s': t2 - t1, 'prove_ms': med,
+                      'constraints_per_s': n / med * 1e3, 'rounds_ms': {k: float(np.median([r[k] for r in rounds[2:]])) for k in rounds[0]}}), flush=True)
+    ck.close()
