@@ -607,6 +607,39 @@ int32_t aleo_mi355x_fr_eval_batch_device(void* d_out, const void* const* d_polys
   } catch (...) { return ALEO_MI355X_ERR_HIP; }
 }
 
+int32_t aleo_mi355x_fr_random_device(void* d_dst, size_t n, uint64_t seed, uint64_t first_index, int32_t montgomery, void* stream) {
+  try {
+    if (!d_dst && n) return ALEO_MI355X_ERR_BAD_ARG;
+    API_BEGIN
+    return run_enqueue(c, stream, [&](hipStream_t s) { return fr_random(c, d_dst, n, seed, first_index, montgomery, s); });
+  } catch (...) { return ALEO_MI355X_ERR_HIP; }
+}
+
+int32_t aleo_mi355x_fr_lincomb_device(void* d_dst, size_t n, const void* c0_mont, const void* const* d_terms, const size_t* lens, const void* coeffs_mont, size_t k, void* stream) {
+  try {
+    if ((!d_dst && n) || (k && (!d_terms || !lens || !coeffs_mont))) return ALEO_MI355X_ERR_BAD_ARG;
+    API_BEGIN
+    return run_enqueue(c, stream, [&](hipStream_t s) { return fr_lincomb(c, d_dst, n, c0_mont, d_terms, lens, coeffs_mont, k, s); });
+  } catch (...) { return ALEO_MI355X_ERR_HIP; }
+}
+
+int32_t aleo_mi355x_ahp_first_sumcheck_device(void* d_dst, size_t n, const void* d_r, const void* d_za, const void* d_zb, const void* d_t, const void* d_z,
+                                              const void* eta_b_mont, const void* eta_c_mont, void* stream) {
+  try {
+    if (n && (!d_dst || !d_r || !d_za || !d_zb || !d_t || !d_z || !eta_b_mont || !eta_c_mont)) return ALEO_MI355X_ERR_BAD_ARG;
+    API_BEGIN
+    return run_enqueue(c, stream, [&](hipStream_t s) { return ahp_first_sumcheck(c, d_dst, n, d_r, d_za, d_zb, d_t, d_z, eta_b_mont, eta_c_mont, s); });
+  } catch (...) { return ALEO_MI355X_ERR_HIP; }
+}
+
+int32_t aleo_mi355x_ahp_matrix_sumcheck_device(void* d_dst, size_t n, const void* const* d_index, size_t index_stride, const void* const* d_f, const void* consts_mont, void* stream) {
+  try {
+    if (n && (!d_dst || !d_index || !d_f || !consts_mont || !d_index[0] || !d_index[1] || !d_index[2] || !d_f[0] || !d_f[1] || !d_f[2])) return ALEO_MI355X_ERR_BAD_ARG;
+    API_BEGIN
+    return run_enqueue(c, stream, [&](hipStream_t s) { return ahp_matrix_sumcheck(c, d_dst, n, d_index, index_stride, d_f, consts_mont, s); });
+  } catch (...) { return ALEO_MI355X_ERR_HIP; }
+}
+
 int32_t aleo_mi355x_fr_batch_inverse_device(void* d_inout, size_t n, void* stream) {
   try {
     if (!d_inout && n) return ALEO_MI355X_ERR_BAD_ARG;

@@ -379,6 +379,126 @@ int32_t fr_eval_batch(Ctx* c, void* d_out, const void* const* d_polys, const siz
   return scratch_release(c, s);
 }
 
+// ---- prover randomness generated where it is used ------------------------------------------------------------------------------
+// Element i of the stream `seed` is the first of the candidates j = 0, 1, ... that is below r, candidate (i, j) being the 253 low bits
+// of four SplitMix64 outputs mix(seed + (4 i + l + 1) * 0x9E3779B97F4A7C15 + j * 0xD1B54A32D192ED03), l = 0..3 (little-endian limbs).
+// A counter-based definition: any element can be produced anywhere (the host draws the handful of blinding scalars it needs, the device
+// the 3|H| mask coefficients) [UPSTREAM-RECALL: snarkVM draws Fr::rand from the caller's RNG in prover/round_functions/first.rs].
+__device__ __forceinline__ uint64_t splitmix_at(uint64_t z) {
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; return z ^ (z >> 31);
+}
+__global__ void __launch_bounds__(256) k_fr_random(char* __restrict__ dst, size_t n, uint64_t seed, uint64_t first, int mont) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const uint64_t e = first + i;
+    Fr v;
+    for (uint64_t j = 0;; ++j) {
+      uint64_t l[4];
+      for (int k = 0; k < 4; ++k) l[k] = splitmix_at(seed + (4 * e + (uint64_t)k + 1) * 0x9E3779B97F4A7C15ull + j * 0xD1B54A32D192ED03ull);
+      l[3] &= (1ull << 61) - 1;
+      for (int k = 0; k < 4; ++k) { v.v[2 * k] = (uint32_t)l[k]; v.v[2 * k + 1] = (uint32_t)(l[k] >> 32); }
+      bool lt = false, eq = true;                               // v < r ?
+      for (int k = 7; k >= 0; --k) { const uint32_t m = FrParams::P.v[k]; if (eq && v.v[k] != m) { lt = v.v[k] < m; eq = false; } }
+      if (lt) break;                                            // accepted with probability r / 2^253 = 0.58 per candidate
+    }
+    if (mont) v = Fr::to_mont(v);
+    store_fp<Fr>(dst + i * 32, v);
+  }
+}
+int32_t fr_random(Ctx* c, void* d_dst, size_t n, uint64_t seed, uint64_t first, int32_t mont, hipStream_t s) {
+  (void)c;
+  if (n == 0) return ALEO_MI355X_OK;
+  size_t want = (n + 255) / 256;
+  hipLaunchKernelGGL(k_fr_random, dim3((uint32_t)(want < 8192 ? want : 8192)), dim3(256), 0, s, (char*)d_dst, n, seed, first, mont ? 1 : 0);
+  HIPCHK(hipGetLastError());
+  return ALEO_MI355X_OK;
+}
+
+// dst[i] = c0 [i == 0] + sum_j coeff_j * term_j[i] over up to LC_MAX ragged terms (term j ends at len_j): the linear combinations a
+// proof opens at beta and gamma, and the delta-weighted sum of the fourth round, in one pass over the data.
+static constexpr uint32_t LC_MAX = 20;
+struct LcArgs { const char* p[LC_MAX]; size_t n[LC_MAX]; FrK k[LC_MAX]; uint32_t terms; };
+__global__ void __launch_bounds__(256) k_fr_lincomb(char* __restrict__ dst, size_t n, LcArgs a, FrK k0) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    Fr r = i == 0 ? fr_arg(k0) : Fr::zero();
+    for (uint32_t j = 0; j < a.terms; ++j)
+      if (i < a.n[j]) r = Fr::cond_sub<2>(Fr::add(r, Fr::mul(fr_arg(a.k[j]), load_fp<Fr>(a.p[j] + i * 32))));      // < 4r -> < 2r
+    store_fp<Fr>(dst + i * 32, Fr::cond_sub<1>(r));
+  }
+}
+int32_t fr_lincomb(Ctx* c, void* d_dst, size_t n, const void* c0, const void* const* d_terms, const size_t* lens, const void* coeffs, size_t k, hipStream_t s) {
+  (void)c;
+  if (n == 0) return ALEO_MI355X_OK;
+  if (k > LC_MAX) { g_last_error = "fr_lincomb: more than 20 terms in one call"; return ALEO_MI355X_ERR_BAD_ARG; }
+  LcArgs a{}; a.terms = (uint32_t)k; FrK k0{};
+  if (c0) std::memcpy(k0.v, c0, 32);
+  for (size_t j = 0; j < k; ++j) {
+    if (!d_terms[j] && lens[j]) { g_last_error = "fr_lincomb: null term"; return ALEO_MI355X_ERR_BAD_ARG; }
+    a.p[j] = (const char*)d_terms[j]; a.n[j] = lens[j] < n ? lens[j] : n; std::memcpy(a.k[j].v, (const char*)coeffs + 32 * j, 32);
+  }
+  size_t want = (n + 255) / 256;
+  hipLaunchKernelGGL(k_fr_lincomb, dim3((uint32_t)(want < 8192 ? want : 8192)), dim3(256), 0, s, (char*)d_dst, n, a, k0);
+  HIPCHK(hipGetLastError());
+  return ALEO_MI355X_OK;
+}
+
+// The two sumcheck numerators, each one pass over evaluations that already sit in HBM (values of the operands on the larger domain):
+//   first  (domain 4|H|): dst = r * (a + eta_b b + eta_c a b) − t * z          [UPSTREAM-RECALL: round_functions/second.rs, the summed polynomial]
+//   matrix (domain 2|K|): dst = sum_M delta_M (vv val_M − (alpha beta − beta row_M − alpha col_M + row_col_M) f_M)   [fourth.rs]
+__global__ void __launch_bounds__(256) k_ahp_first_sumcheck(char* __restrict__ dst, size_t n, const char* r, const char* a, const char* b, const char* t,
+                                                            const char* z, FrK keb, FrK kec) {
+  const Fr eb = fr_arg(keb), ec = fr_arg(kec);
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const Fr va = load_fp<Fr>(a + i * 32), vb = load_fp<Fr>(b + i * 32);
+    Fr u = Fr::cond_sub<2>(Fr::add(va, Fr::mul(eb, vb)));                                  // < 3r -> < 2r
+    u = Fr::cond_sub<2>(Fr::add(u, Fr::mul(ec, Fr::mul(va, vb))));                          // < 4r -> < 2r
+    u = Fr::mul(load_fp<Fr>(r + i * 32), u);                                                // < 2r
+    const Fr w = Fr::mul(load_fp<Fr>(t + i * 32), load_fp<Fr>(z + i * 32));                 // < 2r
+    store_fp<Fr>(dst + i * 32, Fr::reduce(Fr::sub<2>(u, w)));                               // u + 2r − w < 4r
+  }
+}
+int32_t ahp_first_sumcheck(Ctx* c, void* d_dst, size_t n, const void* d_r, const void* d_a, const void* d_b, const void* d_t, const void* d_z,
+                           const void* eta_b, const void* eta_c, hipStream_t s) {
+  (void)c;
+  if (n == 0) return ALEO_MI355X_OK;
+  FrK kb, kc; std::memcpy(kb.v, eta_b, 32); std::memcpy(kc.v, eta_c, 32);
+  size_t want = (n + 255) / 256;
+  hipLaunchKernelGGL(k_ahp_first_sumcheck, dim3((uint32_t)(want < 16384 ? want : 16384)), dim3(256), 0, s, (char*)d_dst, n, (const char*)d_r, (const char*)d_a,
+                     (const char*)d_b, (const char*)d_t, (const char*)d_z, kb, kc);
+  HIPCHK(hipGetLastError());
+  return ALEO_MI355X_OK;
+}
+struct MatArgs { const char* idx[3]; const char* f[3]; FrK delta[3]; FrK ab, nalpha, nbeta, vv; size_t stride; };
+__global__ void __launch_bounds__(256) k_ahp_matrix_sumcheck(char* __restrict__ dst, size_t n, MatArgs a) {
+  const Fr ab = fr_arg(a.ab), na = fr_arg(a.nalpha), nb = fr_arg(a.nbeta), vv = fr_arg(a.vv);
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    Fr acc = Fr::zero();
+    for (int m = 0; m < 3; ++m) {
+      const char* e = a.idx[m] + i * 32;                                                    // row, col, val, row_col: `stride` bytes apart
+      Fr bq = Fr::cond_sub<2>(Fr::add(ab, Fr::mul(nb, load_fp<Fr>(e))));                     // alpha beta − beta row            < 2r
+      bq = Fr::cond_sub<2>(Fr::add(bq, Fr::mul(na, load_fp<Fr>(e + a.stride))));             // − alpha col                      < 2r
+      bq = Fr::cond_sub<2>(Fr::add(bq, load_fp<Fr>(e + 3 * a.stride)));                      // + row_col                        < 2r
+      const Fr bf = Fr::mul(bq, load_fp<Fr>(a.f[m] + i * 32));                               // < 2r
+      const Fr pm = Fr::cond_sub<2>(Fr::sub<2>(Fr::mul(vv, load_fp<Fr>(e + 2 * a.stride)), bf));      // vv val − b f: < 4r -> < 2r
+      acc = Fr::cond_sub<2>(Fr::add(acc, Fr::mul(fr_arg(a.delta[m]), pm)));                  // < 2r
+    }
+    store_fp<Fr>(dst + i * 32, Fr::cond_sub<1>(acc));
+  }
+}
+// consts: 7 Montgomery values on the host — delta_a, delta_b, delta_c, alpha beta, −alpha, −beta, v_H(alpha) v_H(beta)
+int32_t ahp_matrix_sumcheck(Ctx* c, void* d_dst, size_t n, const void* const* d_index, size_t index_stride_elems, const void* const* d_f, const void* consts,
+                            hipStream_t s) {
+  (void)c;
+  if (n == 0) return ALEO_MI355X_OK;
+  MatArgs a{}; const char* k = (const char*)consts;
+  for (int m = 0; m < 3; ++m) { a.idx[m] = (const char*)d_index[m]; a.f[m] = (const char*)d_f[m]; std::memcpy(a.delta[m].v, k + 32 * m, 32); }
+  std::memcpy(a.ab.v, k + 96, 32); std::memcpy(a.nalpha.v, k + 128, 32); std::memcpy(a.nbeta.v, k + 160, 32); std::memcpy(a.vv.v, k + 192, 32);
+  a.stride = index_stride_elems * 32;
+  size_t want = (n + 255) / 256;
+  hipLaunchKernelGGL(k_ahp_matrix_sumcheck, dim3((uint32_t)(want < 16384 ? want : 16384)), dim3(256), 0, s, (char*)d_dst, n, a);
+  HIPCHK(hipGetLastError());
+  return ALEO_MI355X_OK;
+}
+
 int32_t fr_batch_inverse(Ctx* c, void* d_inout, size_t n, hipStream_t s) {
   if (n == 0) return ALEO_MI355X_OK;
   int32_t rc; if ((rc = scratch_acquire(c, c->ntt_tmp, n * 32, s))) return rc;

@@ -44,6 +44,59 @@ def fr_eval_batch_device(d_out: int, d_polys, lens, points_mont, stream: int = 0
     check(lib().aleo_mi355x_fr_eval_batch_device(ctypes.c_void_p(d_out), ptrs, ln, z.ctypes.data_as(ctypes.c_void_p), k, ctypes.c_void_p(stream)), 'fr_eval_batch_device')
 
 
+def fr_random_device(d_dst: int, n: int, seed: int, first_index: int = 0, montgomery: bool = True, stream: int = 0):
+    """Elements first_index.. of the counter-based random stream `seed` (see random_fr for the definition), written in HBM."""
+    check(lib().aleo_mi355x_fr_random_device(ctypes.c_void_p(d_dst), n, seed & 0xFFFFFFFFFFFFFFFF, first_index, 1 if montgomery else 0, ctypes.c_void_p(stream)), 'fr_random_device')
+
+
+_M64 = (1 << 64) - 1
+
+
+def _mix(z):
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & _M64; z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & _M64
+    return z ^ (z >> 31)
+
+
+def random_fr(seed: int, index: int) -> int:
+    """Element `index` of the stream the device kernel writes, on the host (python int): first candidate below r."""
+    from .synth import FR_MODULUS
+    j = 0
+    while True:
+        v = 0
+        for l in range(4): v |= _mix((seed + (4 * index + l + 1) * 0x9E3779B97F4A7C15 + j * 0xD1B54A32D192ED03) & _M64) << (64 * l)
+        v &= (1 << 253) - 1
+        if v < FR_MODULUS: return v
+        j += 1
+
+
+def fr_lincomb_device(d_dst: int, n: int, c0, terms, stream: int = 0):
+    """dst[i] = c0 [i == 0] + sum_j coeff_j term_j[i]; terms: list of (device pointer, length, coeff uint64[4] Montgomery)."""
+    import numpy as np
+    k = len(terms)
+    ptrs = (ctypes.c_void_p * max(k, 1))(*[int(t[0]) for t in terms]); ln = (ctypes.c_size_t * max(k, 1))(*[int(t[1]) for t in terms])
+    co = np.ascontiguousarray(np.stack([np.asarray(t[2], dtype=np.uint64).reshape(4) for t in terms]) if k else np.zeros((1, 4), dtype=np.uint64))
+    k0 = None if c0 is None else np.ascontiguousarray(c0, dtype=np.uint64).reshape(4)
+    check(lib().aleo_mi355x_fr_lincomb_device(ctypes.c_void_p(d_dst), n, ctypes.c_void_p(0) if k0 is None else k0.ctypes.data_as(ctypes.c_void_p), ptrs, ln,
+                                              co.ctypes.data_as(ctypes.c_void_p), k, ctypes.c_void_p(stream)), 'fr_lincomb_device')
+
+
+def ahp_first_sumcheck_device(d_dst: int, n: int, d_r: int, d_za: int, d_zb: int, d_t: int, d_z: int, eta_b, eta_c, stream: int = 0):
+    import numpy as np
+    vp = ctypes.c_void_p
+    eb = np.ascontiguousarray(eta_b, dtype=np.uint64).reshape(4); ec = np.ascontiguousarray(eta_c, dtype=np.uint64).reshape(4)
+    check(lib().aleo_mi355x_ahp_first_sumcheck_device(vp(d_dst), n, vp(d_r), vp(d_za), vp(d_zb), vp(d_t), vp(d_z), eb.ctypes.data_as(vp), ec.ctypes.data_as(vp),
+                                                      vp(stream)), 'ahp_first_sumcheck_device')
+
+
+def ahp_matrix_sumcheck_device(d_dst: int, n: int, d_index, index_stride: int, d_f, consts_mont, stream: int = 0):
+    """consts_mont: uint64[7,4] — delta_a, delta_b, delta_c, alpha beta, −alpha, −beta, v_H(alpha) v_H(beta)."""
+    import numpy as np
+    vp = ctypes.c_void_p
+    ix = (vp * 3)(*[int(x) for x in d_index]); ff = (vp * 3)(*[int(x) for x in d_f])
+    k = np.ascontiguousarray(consts_mont, dtype=np.uint64).reshape(7, 4)
+    check(lib().aleo_mi355x_ahp_matrix_sumcheck_device(vp(d_dst), n, ix, index_stride, ff, k.ctypes.data_as(vp), vp(stream)), 'ahp_matrix_sumcheck_device')
+
+
 def batch_inversion_device(d_inout: int, n: int, stream: int = 0):
     check(lib().aleo_mi355x_fr_batch_inverse_device(ctypes.c_void_p(d_inout), n, ctypes.c_void_p(stream)), 'fr_batch_inverse_device')
 

@@ -16,8 +16,8 @@ from . import synth, wire
 from .fft import EvaluationDomain, FORWARD, INVERSE
 from .kzg import CommitterKey, SonicKZG10, KZG10
 from .msm import PinnedBases
-from .poly import (fr_vec_op_device, fr_lin_device, fr_powers_device, fr_gather_mul_device, fr_eval_batch_device, spmv_device, divide_by_linear_device,
-                   OP_MUL, OP_ADD, OP_SUB)
+from .poly import (fr_vec_op_device, fr_lin_device, fr_powers_device, fr_gather_mul_device, fr_eval_batch_device, fr_random_device, fr_lincomb_device,
+                   ahp_first_sumcheck_device, ahp_matrix_sumcheck_device, random_fr, spmv_device, divide_by_linear_device, OP_MUL, OP_ADD, OP_SUB)
 
 R = synth.FR_MODULUS
 _RM = (1 << 256) % R
@@ -177,17 +177,17 @@ def randomness_layout(n_h):
 class Prover:
     """State of one proof: the round functions in the order upstream calls them."""
 
-    def __init__(self, index: CircuitIndex, assignment: np.ndarray, rand: np.ndarray):
-        """assignment: canonical uint64[n_vars,4], public variables first (z_0 = 1); rand: canonical uint64[>= layout total, 4]."""
+    def __init__(self, index: CircuitIndex, assignment: np.ndarray, seed: int):
+        """assignment: canonical uint64[n_vars,4], public variables first (z_0 = 1); seed: of the proof's random stream (poly.random_fr):
+        the device draws the mask polynomial from it, the host the blinding scalars (positions: randomness_layout)."""
         self.ix = index; self.s = index.stream.cuda_stream
         self.z = np.ascontiguousarray(assignment, dtype=np.uint64).reshape(-1, 4)
-        self.rand = np.ascontiguousarray(rand, dtype=np.uint64).reshape(-1, 4)
+        self.seed = seed & 0xFFFFFFFFFFFFFFFF
         self.lay = randomness_layout(index.n_h)
-        if self.rand.shape[0] < self.lay['total']: raise ValueError('not enough randomness')
-        self.tr = Transcript(); self.c = {}; self.timing = {}
+        self.tr = Transcript(); self.c = {}
 
     def _ri(self, k, n=1):
-        o = self.lay[k]; return [synth.limbs_to_int(self.rand[o + i]) for i in range(n)]
+        o = self.lay[k]; return [random_fr(self.seed, o + i) for i in range(n)]
 
     # ---- round 1 ------------------------------------------------------------------------------------------------------------------
     def first_round(self):
@@ -214,9 +214,9 @@ class Prover:
             v.t[:n_h].copy_(ev.t[k * n_h:(k + 1) * n_h])
             fr_lin_device(v.ptr(), 1, _mont(-rho), one, v.ptr(), stream=s)           # + rho (X^|H| − 1)
             fr_lin_device(v.ptr(n_h), 1, _mont(rho), stream=s)
-        m = self.rand[self.lay['mask']:self.lay['mask'] + 3 * n_h].copy()
-        m[0] = synth.int_to_limbs((-(synth.limbs_to_int(m[n_h]) + synth.limbs_to_int(m[2 * n_h]))) % R, 4)
-        self.mask = _Vec(3 * n_h, m); fr_lin_device(self.mask.ptr(), 3 * n_h, None, r2, self.mask.ptr(), stream=s)
+        self.mask = _Vec(3 * n_h)                                                   # drawn in HBM; its sum over H is made zero through m_0
+        fr_random_device(self.mask.ptr(), 3 * n_h, self.seed, self.lay['mask'], True, s)
+        fr_lin_device(self.mask.ptr(), 1, None, neg1, self.mask.ptr(n_h), neg1, self.mask.ptr(2 * n_h), stream=s)
         self.blind = {k: self._ri(k, HIDING_COEFFS) for k in ('blind_w', 'blind_a', 'blind_b', 'blind_mask')}
         bl = _Vec(4 * HIDING_COEFFS, _mont_rows(sum((self.blind[k] for k in ('blind_w', 'blind_a', 'blind_b', 'blind_mask')), [])))
         polys = [((v.ptr(), n), None, (bl.ptr(HIDING_COEFFS * i), HIDING_COEFFS)) for i, (v, n) in enumerate(((self.w, L), (self.za, L), (self.zb, L), (self.mask, 3 * n_h)))]
@@ -252,13 +252,7 @@ class Prover:
         E.t[3 * n4:3 * n4 + L].copy_(self.za.t[:L]); E.t[4 * n4:4 * n4 + L].copy_(self.zb.t[:L])
         ix.H4.ntt_batch_device(E.ptr(), 5, stream=s)
         e_r, e_t, e_z, e_a, e_b = (E.ptr(i * n4) for i in range(5))
-        T = _Vec(n4)
-        fr_vec_op_device(T.ptr(), e_a, e_b, n4, OP_MUL, s)                           # z_a z_b
-        fr_lin_device(e_a, n4, None, one, e_a, _mont(self.eta_b), e_b, stream=s)      # z_a + eta_b z_b
-        fr_lin_device(e_a, n4, None, one, e_a, _mont(self.eta_c), T.ptr(), stream=s)  # + eta_c z_a z_b
-        fr_vec_op_device(e_a, e_a, e_r, n4, OP_MUL, s)
-        fr_vec_op_device(e_t, e_t, e_z, n4, OP_MUL, s)
-        fr_vec_op_device(e_a, e_a, e_t, n4, OP_SUB, s)
+        ahp_first_sumcheck_device(e_a, n4, e_r, e_a, e_b, e_t, e_z, _mont(self.eta_b), _mont(self.eta_c), s)
         ix.H4.ntt_device(e_a, direction=INVERSE, stream=s)
         fr_vec_op_device(e_a, e_a, self.mask.ptr(), 3 * n_h, OP_ADD, s)               # q_1 = h_1 (X^|H| − 1) + X g_1, degree < 3|H|
         self.h1 = _Vec(2 * n_h); self.g1 = _Vec(n_h)
@@ -300,15 +294,9 @@ class Prover:
         one = _mont(1); neg1 = _mont(R - 1)
         F = _Vec(3 * n2); F.t.view(3, n2, 4)[:, :n_k].copy_(self.f.t.view(3, n_k, 4))
         ix.K2.ntt_batch_device(F.ptr(), 3, stream=s)
-        B = _Vec(3 * n2)
-        for k in range(3):
-            e = ix.k2_evals.ptr(4 * k * n2); b = B.ptr(k * n2)          # row, col, val, row_col on 2K
-            fr_lin_device(b, n2, _mont(self.alpha * self.beta), _mont(-self.beta), e, _mont(-self.alpha), e + 32 * n2, stream=s)
-            fr_vec_op_device(b, b, e + 96 * n2, n2, OP_ADD, s)
-            fr_vec_op_device(b, b, F.ptr(k * n2), n2, OP_MUL, s)         # b_M f_M
-            fr_lin_device(b, n2, None, _mont(self.vv), e + 64 * n2, neg1, b, stream=s)                   # a_M − b_M f_M
-        fr_lin_device(B.ptr(), n2, None, one, B.ptr(), _mont(self.delta[1]), B.ptr(n2), stream=s)
-        fr_lin_device(B.ptr(), n2, None, one, B.ptr(), _mont(self.delta[2]), B.ptr(2 * n2), stream=s)
+        B = _Vec(n2)
+        ahp_matrix_sumcheck_device(B.ptr(), n2, [ix.k2_evals.ptr(4 * k * n2) for k in range(3)], n2, [F.ptr(k * n2) for k in range(3)],
+                                   _mont_rows(self.delta + [self.alpha * self.beta, -self.alpha, -self.beta, self.vv]), s)
         ix.K2.ntt_device(B.ptr(), direction=INVERSE, stream=s)
         self.h2 = _Vec(n_k); self.h2.t.copy_(B.t[n_k:n2])                # P = h_2 (X^|K| − 1)
         out = SonicKZG10.commit(ix.ck, [((self.h2.ptr(), n_k), None, None)], device=True, stream=s)
@@ -337,13 +325,9 @@ class Prover:
         const = (r_ab * self.eta_b % R * zb_beta - t_beta * x_beta - beta * g1_beta) % R
         xi2 = xi * xi % R; L = n_h + 1
         pb = _Vec(3 * n_h)
-        fr_lin_device(pb.ptr(), 3 * n_h, None, _mont(xi2 * k_mask), self.mask.ptr(), stream=s)
-        fr_lin_device(pb.ptr(), 2 * n_h, None, one, pb.ptr(), _mont(xi2 * k_h1), self.h1.ptr(), stream=s)
-        fr_lin_device(pb.ptr(), L, None, one, pb.ptr(), _mont(xi2 * k_za), self.za.ptr(), stream=s)
-        fr_lin_device(pb.ptr(), L, None, one, pb.ptr(), _mont(xi2 * k_w), self.w.ptr(), stream=s)
-        fr_lin_device(pb.ptr(), L, None, one, pb.ptr(), _mont(xi), self.zb.ptr(), stream=s)
-        fr_lin_device(pb.ptr(), n_h - 1, None, one, pb.ptr(), one, self.g1.ptr(1), stream=s)
-        fr_lin_device(pb.ptr(), 1, _mont(xi2 * const), one, pb.ptr(), stream=s)
+        fr_lincomb_device(pb.ptr(), 3 * n_h, _mont(xi2 * const), [(self.mask.ptr(), 3 * n_h, _mont(xi2 * k_mask)), (self.h1.ptr(), 2 * n_h, _mont(xi2 * k_h1)),
+                                                               (self.za.ptr(), L, _mont(xi2 * k_za)), (self.w.ptr(), L, _mont(xi2 * k_w)),
+                                                               (self.zb.ptr(), L, _mont(xi)), (self.g1.ptr(1), n_h - 1, one)], s)
         bl = [0] * HIDING_COEFFS
         for coef, key in ((xi, 'blind_b'), (xi2 * k_mask, 'blind_mask'), (xi2 * k_za, 'blind_a'), (xi2 * k_w, 'blind_w')):
             for i, v in enumerate(self.blind[key]): bl[i] = (bl[i] + coef * v) % R
@@ -355,19 +339,15 @@ class Prover:
         divide_by_linear_device(wq.ptr(), self._ev.ptr(5), pb.ptr(), 3 * n_h, _mont(beta), s)
         # linear combination of the second sumcheck, opened at gamma together with g_a, g_b, g_c
         xi3 = xi2 * xi % R; n_k_inv = _inv(n_k); vk_gamma = _vanish(n_k, gamma)
-        pg = _Vec(n_k); const = 0
+        pg = _Vec(n_k); const = 0; terms = []
         for k, gk in enumerate((ga, gb, gc)):
-            fm = (gamma * gk + self.sigma[k] * n_k_inv) % R; d = self.delta[k]
-            pol = lambda j: ix.k_polys.ptr((4 * k + j) * n_k)
-            fr_lin_device(pg.ptr(), n_k, None, one, pg.ptr(), _mont(xi3 * d % R * self.vv), pol(2), stream=s)
-            fr_lin_device(pg.ptr(), n_k, None, one, pg.ptr(), _mont(xi3 * d % R * fm % R * beta), pol(0), stream=s)
-            fr_lin_device(pg.ptr(), n_k, None, one, pg.ptr(), _mont(xi3 * d % R * fm % R * alpha), pol(1), stream=s)
-            fr_lin_device(pg.ptr(), n_k, None, one, pg.ptr(), _mont(-xi3 * d % R * fm), pol(3), stream=s)
+            fm = (gamma * gk + self.sigma[k] * n_k_inv) % R; d = self.delta[k] * xi3 % R
+            for j, coef in ((2, d * self.vv), (0, d * fm % R * beta), (1, d * fm % R * alpha), (3, -d * fm)):       # val, row, col, row_col
+                terms.append((ix.k_polys.ptr((4 * k + j) * n_k), n_k, _mont(coef)))
             const = (const - d * fm % R * alpha % R * beta) % R
-        fr_lin_device(pg.ptr(), n_k, None, one, pg.ptr(), _mont(-xi3 * vk_gamma), self.h2.ptr(), stream=s)
-        for k, coef in enumerate((1, xi, xi2)):
-            fr_lin_device(pg.ptr(), n_k - 1, None, one, pg.ptr(), _mont(coef), self.f.ptr(k * n_k + 1), stream=s)
-        fr_lin_device(pg.ptr(), 1, _mont(xi3 * const), one, pg.ptr(), stream=s)
+        terms.append((self.h2.ptr(), n_k, _mont(-xi3 * vk_gamma)))
+        terms += [(self.f.ptr(k * n_k + 1), n_k - 1, _mont(coef)) for k, coef in enumerate((1, xi, xi2))]
+        fr_lincomb_device(pg.ptr(), n_k, _mont(const), terms, s)
         gq = _Vec(n_k)
         divide_by_linear_device(gq.ptr(), self._ev.ptr(6), pg.ptr(), n_k, _mont(gamma), s)
         opn = SonicKZG10.commit(ix.ck, [((wq.ptr(), 3 * n_h - 1), None, (blq.ptr(), HIDING_COEFFS - 1)), ((gq.ptr(), n_k - 1), None, None)], device=True, stream=s)
@@ -375,11 +355,11 @@ class Prover:
         return Proof(dict(self.c), evals, list(self.sigma), [(open_beta, random_v), (open_gamma, None)])
 
 
-def prove(index: CircuitIndex, assignment: np.ndarray, rand: np.ndarray) -> Proof:
-    """Varuna::prove_batch for one circuit with one instance."""
+def prove(index: CircuitIndex, assignment: np.ndarray, seed: int) -> Proof:
+    """Varuna::prove_batch for one circuit with one instance; `seed` selects the proof's random stream."""
     import time
     with torch.cuda.stream(index.stream):
-        p = Prover(index, assignment, rand); t = [time.perf_counter()]
+        p = Prover(index, assignment, seed); t = [time.perf_counter()]
         for step in (p.first_round, p.second_round, p.third_round, p.fourth_round):
             step(); t.append(time.perf_counter())                     # every round ends on its commitments: the host has them
         proof = p.finish(); t.append(time.perf_counter())

@@ -198,6 +198,22 @@ int32_t aleo_mi355x_fr_gather_mul_device(void* d_dst, size_t n, const void* d_sc
 /* out[q] = p_q(z_q) for k <= 8 polynomials in two launches (d_polys, lens, z_mont: host arrays of k device pointers / lengths /
  * 32-byte Montgomery points; d_out: k x 32 bytes, device): the evaluations a proof carries (z_b, g_1 at beta; g_a, g_b, g_c at gamma). */
 int32_t aleo_mi355x_fr_eval_batch_device(void* d_out, const void* const* d_polys, const size_t* lens, const void* z_mont, size_t k, void* stream);
+/* Prover randomness generated in HBM.  Element i of stream `seed` = the first candidate j = 0, 1, ... below r, candidate (i, j) being the
+ * low 253 bits of four SplitMix64 outputs mix(seed + (4 i + l + 1) * 0x9E3779B97F4A7C15 + j * 0xD1B54A32D192ED03), l = 0..3 (little-endian
+ * 64-bit limbs; mix = the SplitMix64 finaliser).  Writes elements first_index .. first_index + n - 1, canonical or (montgomery != 0)
+ * Montgomery.  Counter-based: the host can draw single elements of the same stream (the blinding scalars) without the device. */
+int32_t aleo_mi355x_fr_random_device(void* d_dst, size_t n, uint64_t seed, uint64_t first_index, int32_t montgomery, void* stream);
+/* dst[i] = c0 [i == 0] + sum_j coeffs[j] * terms[j][i], term j contributing for i < lens[j] (k <= 20 terms; d_terms / lens / coeffs_mont
+ * host arrays; c0_mont may be NULL): the linear combinations opened at beta and gamma, in one pass.  dst must not alias a term. */
+int32_t aleo_mi355x_fr_lincomb_device(void* d_dst, size_t n, const void* c0_mont, const void* const* d_terms, const size_t* lens, const void* coeffs_mont, size_t k, void* stream);
+/* The numerators of the two sumchecks from evaluations already in HBM [UPSTREAM-RECALL: varuna/ahp/prover/round_functions/{second,fourth}.rs]:
+ *   first:  dst = r (z_a + eta_b z_b + eta_c z_a z_b) - t z                  (n = 4|H| values each)
+ *   matrix: dst = sum_M delta_M (vv val_M - (alpha beta - beta row_M - alpha col_M + row_col_M) f_M)   (n = 2|K| values; d_index[M] points at
+ *           row_M, with col_M, val_M, row_col_M following at index_stride elements each; consts_mont = delta_a, delta_b, delta_c,
+ *           alpha beta, -alpha, -beta, v_H(alpha) v_H(beta): 7 x 32 bytes on the host).  dst may alias an operand. */
+int32_t aleo_mi355x_ahp_first_sumcheck_device(void* d_dst, size_t n, const void* d_r, const void* d_za, const void* d_zb, const void* d_t, const void* d_z,
+                                              const void* eta_b_mont, const void* eta_c_mont, void* stream);
+int32_t aleo_mi355x_ahp_matrix_sumcheck_device(void* d_dst, size_t n, const void* const* d_index, size_t index_stride, const void* const* d_f, const void* consts_mont, void* stream);
 /* Division by (X - z): quotient[j-1] = s_j with s_j = p_j + z s_(j+1) (n - 1 coefficients, canonical Montgomery form) and, when
  * d_eval != NULL, p(z) = s_0 (32 bytes, device) — KZG10's witness polynomial (p(X) - p(z)) / (X - z)
  * [UPSTREAM-RECALL: polycommit/kzg10 compute_witness_polynomial].  z_mont: 32 bytes Montgomery Fr in HOST memory.

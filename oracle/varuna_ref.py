@@ -139,6 +139,30 @@ class Index:
         return out + c.n_h.to_bytes(8, 'little') + c.n_k.to_bytes(8, 'little') + c.n_x.to_bytes(8, 'little')
 
 
+_M64 = (1 << 64) - 1
+
+
+def _mix(z):
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & _M64; z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & _M64
+    return z ^ (z >> 31)
+
+
+def random_fr(seed: int, index: int) -> int:
+    """Element `index` of the proof's random stream: the first candidate j = 0, 1, ... below r, a candidate being the low 253 bits of
+    four SplitMix64 outputs mix(seed + (4 index + l + 1) * 0x9E3779B97F4A7C15 + j * 0xD1B54A32D192ED03), l = 0..3, little-endian."""
+    j = 0
+    while True:
+        v = 0
+        for l in range(4): v |= _mix((seed + (4 * index + l + 1) * 0x9E3779B97F4A7C15 + j * 0xD1B54A32D192ED03) & _M64) << (64 * l)
+        v &= (1 << 253) - 1
+        if v < R: return v
+        j += 1
+
+
+def random_stream(seed: int, n_h: int) -> list:
+    return [random_fr(seed, i) for i in range(randomness_layout(n_h)['total'])]
+
+
 def randomness_layout(n_h):
     """Offsets into the prover's random vector (canonical Fr): rho_w, rho_a, rho_b, mask[3|H|], then four hiding polynomials."""
     o = {'rho_w': 0, 'rho_a': 1, 'rho_b': 2, 'mask': 3}

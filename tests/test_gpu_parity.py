@@ -1013,3 +1013,74 @@ def test_bases_from_scalars_is_an_srs():
         w = util.uniform_scalars(4, 27002); wi = c.limbs_to_ints(w)            # the identity as a base contributes nothing
         got = c.jac_to_int_point(M.VariableBase.msm(pb, w))
         assert got == p.g1_mul(p.G1_GENERATOR, (wi[1] + 2 * wi[2] + (r - 1) * wi[3]) % r)
+
+
+def test_fr_random_stream_is_the_counter_based_definition():
+    """The device's random stream equals the definition in the header element for element (oracle/varuna_ref.random_fr, and the
+    host-side drawer in aleo_amd.poly), canonical and Montgomery, at an offset; every value is below r; streams differ by seed."""
+    import torch
+    from aleo_amd import poly
+    from oracle import varuna_ref as V
+    n, seed, first = 5000, 0xDEADBEEFCAFE, 12345
+    dst = torch.zeros((n, 4), dtype=torch.int64, device='cuda'); torch.cuda.synchronize()
+    poly.fr_random_device(dst.data_ptr(), n, seed, first, False); torch.cuda.synchronize()
+    got = c.limbs_to_ints(dst.cpu().numpy().view(np.uint64))
+    assert all(v < p.FR_MODULUS for v in got)
+    for i in list(range(40)) + [n - 1]:
+        assert got[i] == V.random_fr(seed, first + i) == poly.random_fr(seed, first + i)
+    poly.fr_random_device(dst.data_ptr(), n, seed, first, True); torch.cuda.synchronize()
+    assert c.limbs_to_ints(c.fr_from_mont(dst.cpu().numpy().view(np.uint64))) == got
+    poly.fr_random_device(dst.data_ptr(), n, seed + 1, first, False); torch.cuda.synchronize()
+    other = c.limbs_to_ints(dst.cpu().numpy().view(np.uint64))
+    assert sum(a == b for a, b in zip(got, other)) == 0
+    assert abs(sum(v >> 252 for v in got) / n - (p.FR_MODULUS - (1 << 252)) / p.FR_MODULUS) < 0.05        # top bit as often as uniformity says
+
+
+def test_fr_lincomb_ragged_terms():
+    import torch
+    from aleo_amd import poly
+    r = p.FR_MODULUS; n = 30011
+    lens = [n, n - 1, 1, 0, 257, 4096, n + 50]                                  # a term longer than dst is cut at n
+    T = [util.uniform_scalars(max(l, 1), 28000 + j) for j, l in enumerate(lens)]
+    K = [int(x) for x in c.limbs_to_ints(util.uniform_scalars(len(lens) + 1, 28100))]
+    D = [_dev(c.fr_to_mont(t)) for t in T]
+    dst = torch.zeros((n, 4), dtype=torch.int64, device='cuda'); torch.cuda.synchronize()
+    poly.fr_lincomb_device(dst.data_ptr(), n, _mont1(K[-1]), [(d.data_ptr(), l, _mont1(k)) for d, l, k in zip(D, lens, K)]); torch.cuda.synchronize()
+    want = [0] * n; want[0] = K[-1]
+    for t, l, k in zip(T, lens, K):
+        for i, v in enumerate(c.limbs_to_ints(t[:min(l, n)])): want[i] = (want[i] + k * v) % r
+    assert c.limbs_to_ints(c.fr_from_mont(dst.cpu().numpy().view(np.uint64))) == want
+    with pytest.raises(aleo_amd.AleoMi355xError):
+        poly.fr_lincomb_device(dst.data_ptr(), n, None, [(D[0].data_ptr(), 1, _mont1(1))] * 21)
+
+
+def test_ahp_sumcheck_numerators_match_bigint():
+    import torch
+    from aleo_amd import poly
+    r = p.FR_MODULUS; n = 20003
+    V5 = [util.uniform_scalars(n, 29000 + j) for j in range(5)]
+    vr, va, vb, vt, vz = (c.limbs_to_ints(v) for v in V5)
+    eb, ec = (int(x) for x in c.limbs_to_ints(util.uniform_scalars(2, 29100)))
+    D = [_dev(c.fr_to_mont(v)) for v in V5]
+    dst = torch.zeros((n, 4), dtype=torch.int64, device='cuda'); torch.cuda.synchronize()
+    poly.ahp_first_sumcheck_device(dst.data_ptr(), n, D[0].data_ptr(), D[1].data_ptr(), D[2].data_ptr(), D[3].data_ptr(), D[4].data_ptr(), _mont1(eb), _mont1(ec))
+    torch.cuda.synchronize()
+    want = [(vr[i] * (va[i] + eb * vb[i] + ec * va[i] * vb[i]) - vt[i] * vz[i]) % r for i in range(n)]
+    assert c.limbs_to_ints(c.fr_from_mont(dst.cpu().numpy().view(np.uint64))) == want
+    poly.ahp_first_sumcheck_device(D[1].data_ptr(), n, D[0].data_ptr(), D[1].data_ptr(), D[2].data_ptr(), D[3].data_ptr(), D[4].data_ptr(), _mont1(eb), _mont1(ec))
+    torch.cuda.synchronize()                                                    # in place over z_a, as the prover runs it
+    assert c.limbs_to_ints(c.fr_from_mont(D[1].cpu().numpy().view(np.uint64))) == want
+    # matrix sumcheck: three blocks of (row, col, val, row_col) + f
+    IDX = [util.uniform_scalars(4 * n, 29200 + m) for m in range(3)]; F = [util.uniform_scalars(n, 29300 + m) for m in range(3)]
+    ks = [int(x) for x in c.limbs_to_ints(util.uniform_scalars(6, 29400))]
+    da, db_, dc, alpha, beta, vv = ks
+    DI = [_dev(c.fr_to_mont(x)) for x in IDX]; DF = [_dev(c.fr_to_mont(x)) for x in F]
+    consts = np.stack([_mont1(v) for v in (da, db_, dc, alpha * beta, -alpha, -beta, vv)])
+    poly.ahp_matrix_sumcheck_device(dst.data_ptr(), n, [d.data_ptr() for d in DI], n, [d.data_ptr() for d in DF], consts); torch.cuda.synchronize()
+    want = [0] * n
+    for m, dl in enumerate((da, db_, dc)):
+        e = c.limbs_to_ints(IDX[m]); f = c.limbs_to_ints(F[m])
+        for i in range(n):
+            bq = (alpha * beta - beta * e[i] - alpha * e[n + i] + e[3 * n + i]) % r
+            want[i] = (want[i] + dl * (vv * e[2 * n + i] - bq * f[i])) % r
+    assert c.limbs_to_ints(c.fr_from_mont(dst.cpu().numpy().view(np.uint64))) == want

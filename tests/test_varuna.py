@@ -25,13 +25,13 @@ def _max_degree(c):
     return d - 1
 
 
-def _rand(c, seed): return synth.uniform_scalars(V.randomness_layout(c.n_h)['total'], seed)
+def _rand(c, seed): return V.random_stream(seed, c.n_h)
 
 
 def test_restatement_proves_and_verifies():
     csr, z, c = _circuit(40, 3, 11)
     setup = V.Setup(TAU, S_GAMMA, _max_degree(c)); idx = V.Index(c, setup)
-    rand = [synth.limbs_to_int(x) for x in _rand(c, 5)]
+    rand = _rand(c, 5)
     proof, data = V.prove(idx, setup, z, rand)
     assert len(data) == 901                      # the reference's proof string decodes to 901 bytes for one circuit, one instance
     assert V.verify(idx, setup, z[:3], data)
@@ -58,7 +58,7 @@ def test_restatement_proves_and_verifies():
 def test_restatement_layout_round_trip():
     csr, z, c = _circuit(17, 2, 3, long_rows=0)
     setup = V.Setup(TAU, S_GAMMA, _max_degree(c)); idx = V.Index(c, setup)
-    proof, data = V.prove(idx, setup, z, [synth.limbs_to_int(x) for x in _rand(c, 9)])
+    proof, data = V.prove(idx, setup, z, _rand(c, 9))
     back = V.parse_proof(data)
     assert back['commitments'] == proof['commitments'] and back['evaluations'] == proof['evaluations'] and back['sums'] == proof['sums']
     assert V.proof_bytes(back) == data
@@ -72,15 +72,14 @@ def test_device_prover_matches_restatement(n_constraints, n_public, seed):
     csr, z, c = _circuit(n_constraints, n_public, seed)
     D = _max_degree(c)
     setup = V.Setup(TAU, S_GAMMA, D); idx = V.Index(c, setup)
-    rand = _rand(c, seed + 100)
-    want_proof, want = V.prove(idx, setup, z, [synth.limbs_to_int(x) for x in rand])
+    want_proof, want = V.prove(idx, setup, z, _rand(c, seed + 100))
     ck = varuna.synthetic_committer_key(TAU, S_GAMMA, D)
     try:
         ix = varuna.CircuitIndex(csr, n_constraints, n_public, len(z) - n_public, ck)
         assert (ix.n_h, ix.n_k, ix.n_x) == (c.n_h, c.n_k, c.n_x)
         assert ix.vk_bytes == idx.vk_bytes()
         zz = np.stack([synth.int_to_limbs(v, 4) for v in z])
-        proof = varuna.prove(ix, zz, rand)
+        proof = varuna.prove(ix, zz, seed + 100)
         got = proof.to_bytes()
         assert got == want
         assert V.verify(idx, setup, z[:n_public], got)
@@ -101,11 +100,11 @@ def test_device_prover_verifies_at_2_13():
         ix = varuna.CircuitIndex(csr, n - 50, 4, len(z) - 4, ck)
         assert ix.vk_bytes == idx.vk_bytes()
         zz = np.stack([synth.int_to_limbs(v, 4) for v in z])
-        data = varuna.prove(ix, zz, _rand(c, 77)).to_bytes()
+        data = varuna.prove(ix, zz, 77).to_bytes()
         assert len(data) == 901 and V.verify(idx, setup, z[:4], data)
         bad = bytearray(data); bad[600] ^= 4
         assert not V.verify(idx, setup, z[:4], bytes(bad))
         z2 = zz.copy(); z2[100, 0] ^= np.uint64(1)                       # a wrong witness: the proof comes out, the verifier refuses it
-        assert not V.verify(idx, setup, z[:4], varuna.prove(ix, z2, _rand(c, 77)).to_bytes())
+        assert not V.verify(idx, setup, z[:4], varuna.prove(ix, z2, 77).to_bytes())
     finally:
         ck.close()

@@ -17,10 +17,9 @@ for lg in [int(a) for a in sys.argv[1:]] or [13, 15, 16]:
     while D < max(3 << lg, n_k): D *= 2
     t0 = time.perf_counter(); ck = varuna.synthetic_committer_key(TAU, S_GAMMA, D - 1); t1 = time.perf_counter()
     ix = varuna.CircuitIndex(csr, n, 4, len(z) - 4, ck); t2 = time.perf_counter()
-    rand = synth.uniform_scalars(varuna.randomness_layout(ix.n_h)['total'], 3)
     ts, rounds = [], []
     for rep in range(7):
-        t = time.perf_counter(); pr = varuna.prove(ix, zz, rand); ts.append((time.perf_counter() - t) * 1e3); rounds.append(pr.timing_ms)
+        t = time.perf_counter(); pr = varuna.prove(ix, zz, 1000 + rep); ts.append((time.perf_counter() - t) * 1e3); rounds.append(pr.timing_ms)
     med = float(np.median(ts[2:]))
     print(json.dumps({'lg_constraints': lg, 'constraints': n, 'n_h': ix.n_h, 'n_k': ix.n_k, 'setup_s': t1 - t0, 'index_s': t2 - t1, 'prove_ms': med,
                       'constraints_per_s': n / med * 1e3, 'rounds_ms': {k: float(np.median([r[k] for r in rounds[2:]])) for k in rounds[0]}}), flush=True)
