@@ -177,10 +177,10 @@ def randomness_layout(n_h):
 class Prover:
     """State of one proof: the round functions in the order upstream calls them."""
 
-    def __init__(self, index: CircuitIndex, assignment: np.ndarray, seed: int):
+    def __init__(self, index: CircuitIndex, assignment: np.ndarray, seed: int, stream: torch.cuda.Stream = None):
         """assignment: canonical uint64[n_vars,4], public variables first (z_0 = 1); seed: of the proof's random stream (poly.random_fr):
         the device draws the mask polynomial from it, the host the blinding scalars (positions: randomness_layout)."""
-        self.ix = index; self.s = index.stream.cuda_stream
+        self.ix = index; self.stream = stream or index.stream; self.s = self.stream.cuda_stream
         self.z = np.ascontiguousarray(assignment, dtype=np.uint64).reshape(-1, 4)
         self.seed = seed & 0xFFFFFFFFFFFFFFFF
         self.lay = randomness_layout(index.n_h)
@@ -280,7 +280,7 @@ class Prover:
             fr_gather_mul_device(self.f.ptr(k * n_k), n_k, ix.k_evals.ptr((4 * k + 2) * n_k), self.r_alpha.ptr(), ix.k_idx[k, 0].data_ptr(),
                                  rb.ptr(), ix.k_idx[k, 1].data_ptr(), s)
         ix.K.ntt_batch_device(self.f.ptr(), 3, direction=INVERSE, stream=s)
-        ix.stream.synchronize()
+        self.stream.synchronize()
         f0 = self.f.t.view(3, n_k, 4)[:, 0].cpu().numpy().view(np.uint64)
         self.sigma = [_from_mont(f0[k]) * n_k % R for k in range(3)]
         out = SonicKZG10.commit(ix.ck, [((self.f.ptr(k * n_k + 1), n_k - 1), n_k - 2, None) for k in range(3)], device=True, stream=s)
@@ -311,7 +311,7 @@ class Prover:
         self._ev = _Vec(8)
         fr_eval_batch_device(self._ev.ptr(), [self.zb.ptr(), self.g1.ptr(1)] + [self.f.ptr(k * n_k + 1) for k in range(3)],
                              [n_h + 1, n_h - 1] + [n_k - 1] * 3, _mont_rows([self.beta, self.beta, self.gamma, self.gamma, self.gamma]), s)
-        ix.stream.synchronize()
+        self.stream.synchronize()
         evals = [_from_mont(v) for v in self._ev.host(0, 5)]
         zb_beta, g1_beta, ga, gb, gc = evals
         self.tr.absorb(b''.join(_fr_bytes(v) for v in evals)); xi = self.tr.challenge(b'xi')
@@ -355,11 +355,12 @@ class Prover:
         return Proof(dict(self.c), evals, list(self.sigma), [(open_beta, random_v), (open_gamma, None)])
 
 
-def prove(index: CircuitIndex, assignment: np.ndarray, seed: int) -> Proof:
-    """Varuna::prove_batch for one circuit with one instance; `seed` selects the proof's random stream."""
+def prove(index: CircuitIndex, assignment: np.ndarray, seed: int, stream: torch.cuda.Stream = None) -> Proof:
+    """Varuna::prove_batch for one circuit with one instance; `seed` selects the proof's random stream.  Proofs of one index may be
+    produced concurrently from several host threads, each on its own `stream` (the index is read-only while proving)."""
     import time
-    with torch.cuda.stream(index.stream):
-        p = Prover(index, assignment, seed); t = [time.perf_counter()]
+    with torch.cuda.stream(stream or index.stream):
+        p = Prover(index, assignment, seed, stream); t = [time.perf_counter()]
         for step in (p.first_round, p.second_round, p.third_round, p.fourth_round):
             step(); t.append(time.perf_counter())                     # every round ends on its commitments: the host has them
         proof = p.finish(); t.append(time.perf_counter())

@@ -37,6 +37,8 @@ def main():
     ap.add_argument('--no-kzg-chain', action='store_true', help='skip the secondary 2^22 iNTT -> commit measurement (config[2])')
     ap.add_argument('--proof-proxy-lg', type=int, default=20, help='log2 constraints of the Varuna operator-schedule replay (0 = skip)')
     ap.add_argument('--proof-proxy-cpu-lg', type=int, default=15, help='size of the same replay on the CPU oracle (cpu_baseline leg)')
+    ap.add_argument('--varuna-lg', type=int, default=15, help='log2 constraints of the AHP prover measurement (row a6; 0 = skip)')
+    ap.add_argument('--varuna-cpu-lg', type=int, default=10, help='size at which the CPU restatement of the prover is timed and the device proof verified (cpu_baseline leg)')
     ap.add_argument('--concurrent-callers', type=int, default=4, help='secondary: aggregate rate with this many caller threads (0/1 = skip)')
     ap.add_argument('--sharded-ntt-lg', type=int, default=24, help='size of the secondary sharded-NTT measurement at N > 1 (stderr)')
     ap.add_argument('--aux-sharded-ntt', action='store_true', help=argparse.SUPPRESS)
@@ -189,6 +191,10 @@ def main():
             out['key_synthesis_proxy'] = {'2^%d' % lg_: index_proxy_gpu(aleo_amd, synth, torch, dev, lg_) for lg_ in sorted({args.proof_proxy_lg, args.proof_proxy_cpu_lg})}
             out['key_synthesis_proxy']['schedule'] = INDEX_NOTE
             pb = aleo_amd.PinnedBases.generate_multiples(gen, first, n)
+        if world == 1 and args.varuna_lg:
+            pb.close()
+            out['varuna_prove'] = varuna_prove(synth, torch, args.varuna_lg)
+            pb = aleo_amd.PinnedBases.generate_multiples(gen, first, n)
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args, pb, scalars, aleo_amd)
         print(json.dumps(out), flush=True)
@@ -315,6 +321,78 @@ def kzg_chain(aleo_amd, synth, torch, dev, lg=22, reps=5):
 PROXY_NOTE = ('operator-level proxy for constraints/s (SURVEY.md §8d): the MSM/NTT/field-op schedule of one single-instance Varuna proof with '
               '|H| = |K| = 2^k, replayed on synthetic vectors of those sizes [schedule UPSTREAM-RECALL, see DESIGN.md §4c]; the commitments of a '
               'round go through ONE batched call (aleo_mi355x_kzg_commit_batch_device), the two openings divide by (X - z) on the device; not a proof')
+
+
+VARUNA_TAU, VARUNA_S = 0x1F3A9C0D5E7B24681357ACE02468BDF013579BDF02468ACE1234567, 0x0FEDCBA9876543210123456789ABCDEF55AA
+VARUNA_NOTE = ('aleo_amd.varuna.prove: the four AHP rounds, evaluations and both KZG openings of one Marlin/Varuna-shaped proof for a synthetic satisfiable R1CS '
+               '(every constraint multiplies two short linear combinations; a few wide rows), all circuit-sized work on the device through the C ABI; '
+               'SHA-256 transcript and synthetic SRS, so proofs are checked by the restatement in oracle/varuna_ref.py, not by snarkVM (DESIGN.md)')
+
+
+def _varuna_instance(synth, lg, seed):
+    from aleo_amd import varuna
+    n = (1 << lg) - 64 if lg >= 8 else (1 << lg) - 4
+    csr, z = synth.synthetic_r1cs(n, 4, seed, long_rows=4 if lg >= 10 else 1)
+    zz = np.stack([synth.int_to_limbs(v, 4) for v in z])
+    nnz = max(int(csr[m][0][-1]) for m in 'abc'); n_k = 2
+    while n_k < nnz: n_k *= 2
+    n_h = 1
+    while n_h < max(n, 4 + len(z) - 4, 8): n_h *= 2
+    D = 1
+    while D < max(3 * n_h, n_k): D *= 2
+    ck = varuna.synthetic_committer_key(VARUNA_TAU, VARUNA_S, D - 1)
+    return n, csr, z, zz, ck, D - 1
+
+
+def varuna_prove(synth, torch, lg, reps=7, in_flight=4):
+    """constraints/s of the prover above the operators: one proof at a time, and `in_flight` proofs of the
+    same circuit from as many host threads, each on its own stream."""
+    import threading
+    from aleo_amd import varuna
+    n, csr, z, zz, ck, D = _varuna_instance(synth, lg, 40 + lg)
+    try:
+        t0 = time.perf_counter(); ix = varuna.CircuitIndex(csr, n, 4, len(z) - 4, ck); index_s = time.perf_counter() - t0
+        ts, rounds = [], []
+        for rep in range(reps + 2):
+            t = time.perf_counter(); pr = varuna.prove(ix, zz, 1000 + rep); ts.append((time.perf_counter() - t) * 1e3); rounds.append(pr.timing_ms)
+        med = float(np.median(ts[2:]))
+        streams = [torch.cuda.Stream() for _ in range(in_flight)]; per = 6
+        def work(k):
+            for rep in range(per): varuna.prove(ix, zz, 5000 + 100 * k + rep, streams[k])
+        for _ in range(2):
+            th = [threading.Thread(target=work, args=(k,)) for k in range(in_flight)]
+            t = time.perf_counter()
+            for x in th: x.start()
+            for x in th: x.join()
+            dt = time.perf_counter() - t
+        return {'constraints': n, 'domain_h': ix.n_h, 'domain_k': ix.n_k, 'max_degree': D, 'index_s': index_s, 'prove_ms': med, 'constraints_per_s': n / med * 1e3,
+                'rounds_ms': {k: float(np.median([r[k] for r in rounds[2:]])) for k in rounds[0]}, 'proof_bytes': len(pr.to_bytes()),
+                'in_flight_%d' % in_flight: {'proofs_per_s': in_flight * per / dt, 'constraints_per_s': n * in_flight * per / dt}, 'what': VARUNA_NOTE}
+    finally:
+        ck.close()
+
+
+def varuna_cpu(synth, lg):
+    """cpu_baseline leg: the device's proof for a 2^lg circuit checked by the restatement's verifier, byte-compared with the restatement's own
+    proof, and the restatement prover (plain Python integers, one core) timed on the same instance."""
+    from aleo_amd import varuna
+    from oracle import varuna_ref as V
+    n, csr, z, zz, ck, D = _varuna_instance(synth, lg, 90 + lg)
+    try:
+        ix = varuna.CircuitIndex(csr, n, 4, len(z) - 4, ck)
+        data = varuna.prove(ix, zz, 4242).to_bytes()
+        def rows(m):
+            ptr, col, val = csr[m]
+            return [[(int(col[k]), synth.limbs_to_int(val[k])) for k in range(ptr[i], ptr[i + 1])] for i in range(len(ptr) - 1)]
+        c = V.Circuit(n, 4, len(z) - 4, rows('a'), rows('b'), rows('c'))
+        setup = V.Setup(VARUNA_TAU, VARUNA_S, D); idx = V.Index(c, setup)
+        rand = V.random_stream(4242, c.n_h)
+        t0 = time.perf_counter(); _, want = V.prove(idx, setup, z, rand); dt = time.perf_counter() - t0
+        return {'constraints': n, 'device_proof_verifies': bool(V.verify(idx, setup, z[:4], data)), 'device_proof_equals_restatement': bool(data == want),
+                'restatement_prove_s': dt, 'restatement_constraints_per_s': n / dt, 'cores': 1,
+                'note': 'oracle/varuna_ref.py in plain Python integers: a checker, not a tuned CPU prover and not the Rust binary'}
+    finally:
+        ck.close()
 
 
 def proxy_schedule(lg):
@@ -484,6 +562,11 @@ def effective_cpus():
     return n
 
 
+def synth_mod():
+    from aleo_amd import synth
+    return synth
+
+
 def cpu_baseline(args, pb, scalars, aleo_amd):
     """The oracle (C restatement of snarkVM's batched Pippenger, all host cores) on a bounded sample of the same
     workload; also re-checks GPU == oracle on that sample.  kind 'port': it is not the Rust binary."""
@@ -509,7 +592,8 @@ def cpu_baseline(args, pb, scalars, aleo_amd):
     if args.proof_proxy_lg and args.proof_proxy_cpu_lg:
         from aleo_amd import synth
         proxy = proof_proxy_cpu(c, aleo_amd, synth, args.proof_proxy_cpu_lg, effective_cpus())
-    return {'proof_proxy': proxy, 'one_core': {'value': n1 / dt1, 'unit': 'scalar-muls/s', 'cores': 1, 'seconds': dt1, 'sample': '2^%d-point prefix' % (n1.bit_length() - 1)},
+    vcpu = varuna_cpu(synth_mod(), args.varuna_cpu_lg) if (args.varuna_lg and args.varuna_cpu_lg) else None
+    return {'proof_proxy': proxy, 'varuna': vcpu, 'one_core': {'value': n1 / dt1, 'unit': 'scalar-muls/s', 'cores': 1, 'seconds': dt1, 'sample': '2^%d-point prefix' % (n1.bit_length() - 1)},
             'value': ns / dt, 'unit': 'scalar-muls/s', 'cores': all_cores, 'kind': 'port', 'seconds': dt,
             'host_cpus': os.cpu_count(), 'usable_cpus': effective_cpus(),
             'window_parallel_only': {'value': ns / dt_ref, 'unit': 'scalar-muls/s', 'cores': cores, 'seconds': dt_ref,

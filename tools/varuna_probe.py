@@ -21,6 +21,19 @@ for lg in [int(a) for a in sys.argv[1:]] or [13, 15, 16]:
     for rep in range(7):
         t = time.perf_counter(); pr = varuna.prove(ix, zz, 1000 + rep); ts.append((time.perf_counter() - t) * 1e3); rounds.append(pr.timing_ms)
     med = float(np.median(ts[2:]))
-    print(json.dumps({'lg_constraints': lg, 'constraints': n, 'n_h': ix.n_h, 'n_k': ix.n_k, 'setup_s': t1 - t0, 'index_s': t2 - t1, 'prove_ms': med,
+    import threading
+    conc = {}
+    for T in (2, 4):
+        streams = [torch.cuda.Stream() for _ in range(T)]; per = 6
+        def work(k):
+            for rep in range(per): varuna.prove(ix, zz, 5000 + 100 * k + rep, streams[k])
+        for warm in range(2):
+            th = [threading.Thread(target=work, args=(k,)) for k in range(T)]
+            t = time.perf_counter()
+            for x in th: x.start()
+            for x in th: x.join()
+            dt = time.perf_counter() - t
+        conc[str(T)] = {'proofs_per_s': T * per / dt, 'constraints_per_s': n * T * per / dt}
+    print(json.dumps({'lg_constraints': lg, 'in_flight': conc, 'constraints': n, 'n_h': ix.n_h, 'n_k': ix.n_k, 'setup_s': t1 - t0, 'index_s': t2 - t1, 'prove_ms': med,
                       'constraints_per_s': n / med * 1e3, 'rounds_ms': {k: float(np.median([r[k] for r in rounds[2:]])) for k in rounds[0]}}), flush=True)
     ck.close()
