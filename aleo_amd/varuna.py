@@ -38,9 +38,9 @@ def _vanish(size, x): return (pow(x, size, R) - 1) % R
 
 class _Vec:
     """n Montgomery Fr values in HBM (a torch tensor is the allocation; every operation goes through the C ABI)."""
-    def __init__(self, n, data: np.ndarray = None):
+    def __init__(self, n, data: np.ndarray = None, zero: bool = False):
         self.n = n
-        if data is None: self.t = torch.zeros((max(n, 1), 4), dtype=torch.int64, device='cuda')
+        if data is None: self.t = (torch.zeros if zero else torch.empty)((max(n, 1), 4), dtype=torch.int64, device='cuda')
         else: self.t = torch.from_numpy(np.ascontiguousarray(data, dtype=np.uint64).reshape(-1, 4).view(np.int64)).cuda()
     def ptr(self, off=0): return self.t.data_ptr() + 32 * off
     def host(self, off=0, n=None): return self.t[off:off + (self.n - off if n is None else n)].cpu().numpy().view(np.uint64)
@@ -124,7 +124,7 @@ class CircuitIndex:
             per = [0 if i == 0 else _inv(pow(wx, i, R) - 1) for i in range(ratio)]      # v_X(w^p) depends on p mod |H|/|X|
             self.vx_inv = _Vec(n_h, np.tile(_mont_rows(per), (n_x, 1)))
             # arithmetisation over K: row, col, val, row_col
-            self.k_evals = _Vec(12 * n_k)                                            # [matrix][row, col, val, row_col][|K|]
+            self.k_evals = _Vec(12 * n_k, zero=True)                                            # [matrix][row, col, val, row_col][|K|]
             kidx = np.zeros((3, 2, n_k), dtype=np.uint32)                            # [matrix][row, col][|K|]: positions on H (padding: 0, the element 1)
             host_h = self.h_elems.host()
             n_h_inv = _mont(_inv(n_h))
@@ -145,7 +145,7 @@ class CircuitIndex:
             self.k_idx = torch.from_numpy(kidx.view(np.int32)).cuda()
             self.k_polys = _Vec(12 * n_k); self.k_polys.t.copy_(self.k_evals.t)
             self.K.ntt_batch_device(self.k_polys.ptr(), 12, direction=INVERSE, stream=s)
-            self.k2_evals = _Vec(24 * n_k)                                            # the same twelve polynomials on 2K
+            self.k2_evals = _Vec(24 * n_k, zero=True)                                            # the same twelve polynomials on 2K
             self.k2_evals.t.view(12, 2 * n_k, 4)[:, :n_k].copy_(self.k_polys.t.view(12, n_k, 4))
             self.K2.ntt_batch_device(self.k2_evals.ptr(), 12, stream=s)
             self.stream.synchronize()
@@ -202,7 +202,7 @@ class Prover:
         for k, m in ((1, 'a'), (2, 'b')):
             rp, col, val = ix.fwd[m]
             spmv_device(ev.ptr(k * n_h), rp.data_ptr(), col.data_ptr(), val.ptr(), zH.ptr(), n_h, s)
-        xh = _Vec(n_h); xh.t[:n_x] = torch.from_numpy(_mont_rows(self.x_poly).view(np.int64)).cuda()
+        xh = _Vec(n_h, zero=True); xh.t[:n_x] = torch.from_numpy(_mont_rows(self.x_poly).view(np.int64)).cuda()
         ix.H.ntt_device(xh.ptr(), stream=s)
         fr_vec_op_device(ev.ptr(), zH.ptr(), xh.ptr(), n_h, OP_SUB, s)
         fr_vec_op_device(ev.ptr(), ev.ptr(), ix.vx_inv.ptr(), n_h, OP_MUL, s)
@@ -242,7 +242,7 @@ class Prover:
         spmv_device(rt.ptr(n_h), tp.data_ptr(), tcol.data_ptr(), tval.ptr(), ext.ptr(), n_h, s)
         ix.H.ntt_device(rt.ptr(n_h), direction=INVERSE, stream=s)                     # t(X)
         L = n_h + 1; n4 = 4 * n_h
-        E = _Vec(5 * n4)                                                            # r, t, z, z_a, z_b on the domain of size 4|H|
+        E = _Vec(5 * n4, zero=True)                                                            # r, t, z, z_a, z_b on the domain of size 4|H|
         E.t[0:n_h].copy_(rt.t[:n_h]); E.t[n4:n4 + n_h].copy_(rt.t[n_h:])
         zp = 2 * n4                                                                 # ẑ = w (X^|X| − 1) + x̂
         fr_lin_device(E.ptr(zp), L, None, neg1, self.w.ptr(), stream=s)
@@ -292,7 +292,7 @@ class Prover:
     def fourth_round(self):
         ix, s = self.ix, self.s; n_k = ix.n_k; n2 = 2 * n_k
         one = _mont(1); neg1 = _mont(R - 1)
-        F = _Vec(3 * n2); F.t.view(3, n2, 4)[:, :n_k].copy_(self.f.t.view(3, n_k, 4))
+        F = _Vec(3 * n2, zero=True); F.t.view(3, n2, 4)[:, :n_k].copy_(self.f.t.view(3, n_k, 4))
         ix.K2.ntt_batch_device(F.ptr(), 3, stream=s)
         B = _Vec(n2)
         ahp_matrix_sumcheck_device(B.ptr(), n2, [ix.k2_evals.ptr(4 * k * n2) for k in range(3)], n2, [F.ptr(k * n2) for k in range(3)],
