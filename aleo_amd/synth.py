@@ -126,3 +126,18 @@ def synthetic_r1cs(n_constraints: int, n_public: int, seed: int, long_rows: int 
         for limb in range(4): val[:, limb] = np.array([(c_ >> (64 * limb)) & _M64 for c_ in flat], dtype=np.uint64)
         csr[m] = (ptr, col, val)
     return csr, z
+
+
+def resolve_synthetic(csr, n_public: int, publics) -> list:
+    """Another assignment of a synthetic_r1cs circuit: the same constraints solved for other public inputs (publics[0] must be 1).
+    Constraint i defines variable n_public + i as (A_i . z)(B_i . z)."""
+    r = FR_MODULUS
+    z = [int(v) % r for v in publics]
+    assert len(z) == n_public and z[0] == 1
+    (pa, ca, va), (pb_, cb, vb) = csr['a'], csr['b']
+    va_i = [limbs_to_int(x) for x in va]; vb_i = [limbs_to_int(x) for x in vb]
+    for i in range(len(pa) - 1):
+        a = sum(va_i[k] * z[ca[k]] for k in range(pa[i], pa[i + 1])) % r
+        b = sum(vb_i[k] * z[cb[k]] for k in range(pb_[i], pb_[i + 1])) % r
+        z.append(a * b % r)
+    return z

@@ -153,82 +153,100 @@ class CircuitIndex:
         self.vk_bytes = wire.g1_compress(self.index_commitments).tobytes() + n_h.to_bytes(8, 'little') + n_k.to_bytes(8, 'little') + n_x.to_bytes(8, 'little')
 
 
+MAX_INSTANCES = 4        # k + 4 evaluations go through one fr_eval_batch call (8 polynomials), 3k + 3 terms through one fr_lincomb call (20)
+
+
 class Proof:
-    def __init__(self, commitments, evaluations, sums, openings):
-        self.commitments, self.evaluations, self.sums, self.openings = commitments, evaluations, sums, openings
+    def __init__(self, witness, commitments, evaluations, sums, openings):
+        self.witness, self.commitments, self.evaluations, self.sums, self.openings = witness, commitments, evaluations, sums, openings
 
     def to_bytes(self) -> bytes:
         c = self.commitments
-        return wire.proof_to_bytes([1], np.stack([c['w'], c['z_a'], c['z_b']]), c['mask'], c['g_1'], c['h_1'], np.stack([c['g_a'], c['g_b'], c['g_c']]), c['h_2'],
+        return wire.proof_to_bytes([self.witness.shape[0] // 3], self.witness, c['mask'], c['g_1'], c['h_1'], np.stack([c['g_a'], c['g_b'], c['g_c']]), c['h_2'],
                                    _mont_rows(self.evaluations), _mont_rows(self.sums), np.stack([o[0] for o in self.openings]),
                                    [None if o[1] is None else _mont(o[1]) for o in self.openings])
 
     def to_string(self) -> str: return wire.proof_to_string(self.to_bytes())
 
 
-def randomness_layout(n_h):
-    o = {'rho_w': 0, 'rho_a': 1, 'rho_b': 2, 'mask': 3}
-    base = 3 + 3 * n_h
-    for i, k in enumerate(('blind_w', 'blind_a', 'blind_b', 'blind_mask')): o[k] = base + HIDING_COEFFS * i
-    o['total'] = base + 4 * HIDING_COEFFS
+def randomness_layout(n_h, k=1):
+    """Positions in the proof's random stream: rho_w, rho_a, rho_b per instance, the mask's 3|H| coefficients, the hiding polynomials of
+    w_i, z_a,i, z_b,i per instance and of the mask."""
+    o = {'rho': [3 * i for i in range(k)], 'mask': 3 * k}
+    base = 3 * k + 3 * n_h
+    o['blind'] = [base + 3 * HIDING_COEFFS * i for i in range(k)]
+    o['blind_mask'] = base + 3 * HIDING_COEFFS * k
+    o['total'] = o['blind_mask'] + HIDING_COEFFS
     return o
 
 
 class Prover:
-    """State of one proof: the round functions in the order upstream calls them."""
+    """State of one proof (one circuit, k instances): the round functions in the order upstream calls them."""
 
-    def __init__(self, index: CircuitIndex, assignment: np.ndarray, seed: int, stream: torch.cuda.Stream = None):
-        """assignment: canonical uint64[n_vars,4], public variables first (z_0 = 1); seed: of the proof's random stream (poly.random_fr):
-        the device draws the mask polynomial from it, the host the blinding scalars (positions: randomness_layout)."""
+    def __init__(self, index: CircuitIndex, assignments, seed: int, stream: torch.cuda.Stream = None):
+        """assignments: one canonical uint64[n_vars,4] array per instance (or a single array), public variables first (z_0 = 1); seed: of the
+        proof's random stream (poly.random_fr): the device draws the mask polynomial from it, the host the blinding scalars."""
         self.ix = index; self.stream = stream or index.stream; self.s = self.stream.cuda_stream
-        self.z = np.ascontiguousarray(assignment, dtype=np.uint64).reshape(-1, 4)
+        if isinstance(assignments, np.ndarray) and assignments.ndim == 2: assignments = [assignments]
+        self.z = [np.ascontiguousarray(a, dtype=np.uint64).reshape(-1, 4) for a in assignments]
+        self.k = len(self.z)
+        if not 1 <= self.k <= MAX_INSTANCES: raise ValueError('between 1 and %d instances per proof' % MAX_INSTANCES)
         self.seed = seed & 0xFFFFFFFFFFFFFFFF
-        self.lay = randomness_layout(index.n_h)
+        self.lay = randomness_layout(index.n_h, self.k)
         self.tr = Transcript(); self.c = {}
 
-    def _ri(self, k, n=1):
-        o = self.lay[k]; return [random_fr(self.seed, o + i) for i in range(n)]
+    def _ri(self, first, n=1): return [random_fr(self.seed, first + i) for i in range(n)]
 
     # ---- round 1 ------------------------------------------------------------------------------------------------------------------
     def first_round(self):
-        ix, s = self.ix, self.s; n_h, n_x = ix.n_h, ix.n_x
+        ix, s, k = self.ix, self.s, self.k; n_h, n_x = ix.n_h, ix.n_x
         r2 = synth.int_to_limbs(_R2, 4); one = _mont(1); neg1 = _mont(R - 1)
-        zh = np.zeros((n_h, 4), dtype=np.uint64); zh[ix.pos[:self.z.shape[0]]] = self.z
-        self.x_evals = [synth.limbs_to_int(self.z[i]) if i < ix.n_public else 0 for i in range(n_x)]
         gx_inv = _inv(_gen(n_x)); nxi = _inv(n_x)
-        self.x_poly = [sum(v * pow(gx_inv, i * j, R) for j, v in enumerate(self.x_evals)) * nxi % R for i in range(n_x)]     # O(|X|^2): |X| is tiny
-        zH = _Vec(n_h, zh); fr_lin_device(zH.ptr(), n_h, None, r2, zH.ptr(), stream=s)
-        ev = _Vec(3 * n_h)                                                          # w, z_a, z_b on H
-        for k, m in ((1, 'a'), (2, 'b')):
-            rp, col, val = ix.fwd[m]
-            spmv_device(ev.ptr(k * n_h), rp.data_ptr(), col.data_ptr(), val.ptr(), zH.ptr(), n_h, s)
-        xh = _Vec(n_h, zero=True); xh.t[:n_x] = torch.from_numpy(_mont_rows(self.x_poly).view(np.int64)).cuda()
-        ix.H.ntt_device(xh.ptr(), stream=s)
-        fr_vec_op_device(ev.ptr(), zH.ptr(), xh.ptr(), n_h, OP_SUB, s)
-        fr_vec_op_device(ev.ptr(), ev.ptr(), ix.vx_inv.ptr(), n_h, OP_MUL, s)
-        ix.H.ntt_batch_device(ev.ptr(), 3, direction=INVERSE, stream=s)
         L = n_h + 1
-        self.w, self.za, self.zb = _Vec(L), _Vec(L), _Vec(L)
-        for k, (v, rk) in enumerate(((self.w, 'rho_w'), (self.za, 'rho_a'), (self.zb, 'rho_b'))):
-            rho = self._ri(rk)[0]
-            v.t[:n_h].copy_(ev.t[k * n_h:(k + 1) * n_h])
-            fr_lin_device(v.ptr(), 1, _mont(-rho), one, v.ptr(), stream=s)           # + rho (X^|H| − 1)
-            fr_lin_device(v.ptr(n_h), 1, _mont(rho), stream=s)
+        ev = _Vec(3 * k * n_h)                                                      # w_i, z_a,i, z_b,i on H, instance after instance
+        self.x_evals, self.x_poly = [], []
+        for i, z in enumerate(self.z):
+            zh = np.zeros((n_h, 4), dtype=np.uint64); zh[ix.pos[:z.shape[0]]] = z
+            xe = [synth.limbs_to_int(z[j]) if j < ix.n_public else 0 for j in range(n_x)]
+            xp = [sum(v * pow(gx_inv, a * j, R) for j, v in enumerate(xe)) * nxi % R for a in range(n_x)]      # O(|X|^2): |X| is tiny
+            self.x_evals.append(xe); self.x_poly.append(xp)
+            zH = _Vec(n_h, zh); fr_lin_device(zH.ptr(), n_h, None, r2, zH.ptr(), stream=s)
+            base = 3 * i * n_h
+            for j, m in ((1, 'a'), (2, 'b')):
+                rp, col, val = ix.fwd[m]
+                spmv_device(ev.ptr(base + j * n_h), rp.data_ptr(), col.data_ptr(), val.ptr(), zH.ptr(), n_h, s)
+            xh = _Vec(n_h, zero=True); xh.t[:n_x] = torch.from_numpy(_mont_rows(xp).view(np.int64)).cuda()
+            ix.H.ntt_device(xh.ptr(), stream=s)
+            fr_vec_op_device(ev.ptr(base), zH.ptr(), xh.ptr(), n_h, OP_SUB, s)
+            fr_vec_op_device(ev.ptr(base), ev.ptr(base), ix.vx_inv.ptr(), n_h, OP_MUL, s)
+        ix.H.ntt_batch_device(ev.ptr(), 3 * k, direction=INVERSE, stream=s)
+        self.wit = _Vec(3 * k * L)                                                  # w_i, z_a,i, z_b,i as polynomials of |H| + 1 coefficients
+        self.blind = []; blinds = []
+        for q in range(3 * k):
+            i, j = divmod(q, 3)
+            rho = self._ri(self.lay['rho'][i] + j)[0]
+            self.wit.t[q * L:q * L + n_h].copy_(ev.t[q * n_h:(q + 1) * n_h])
+            fr_lin_device(self.wit.ptr(q * L), 1, _mont(-rho), one, self.wit.ptr(q * L), stream=s)       # + rho (X^|H| − 1)
+            fr_lin_device(self.wit.ptr(q * L + n_h), 1, _mont(rho), stream=s)
+            bq = self._ri(self.lay['blind'][i] + HIDING_COEFFS * j, HIDING_COEFFS); self.blind.append(bq); blinds += bq
+        self.w = lambda i: self.wit.ptr((3 * i) * L); self.za = lambda i: self.wit.ptr((3 * i + 1) * L); self.zb = lambda i: self.wit.ptr((3 * i + 2) * L)
         self.mask = _Vec(3 * n_h)                                                   # drawn in HBM; its sum over H is made zero through m_0
         fr_random_device(self.mask.ptr(), 3 * n_h, self.seed, self.lay['mask'], True, s)
         fr_lin_device(self.mask.ptr(), 1, None, neg1, self.mask.ptr(n_h), neg1, self.mask.ptr(2 * n_h), stream=s)
-        self.blind = {k: self._ri(k, HIDING_COEFFS) for k in ('blind_w', 'blind_a', 'blind_b', 'blind_mask')}
-        bl = _Vec(4 * HIDING_COEFFS, _mont_rows(sum((self.blind[k] for k in ('blind_w', 'blind_a', 'blind_b', 'blind_mask')), [])))
-        polys = [((v.ptr(), n), None, (bl.ptr(HIDING_COEFFS * i), HIDING_COEFFS)) for i, (v, n) in enumerate(((self.w, L), (self.za, L), (self.zb, L), (self.mask, 3 * n_h)))]
+        self.blind_mask = self._ri(self.lay['blind_mask'], HIDING_COEFFS)
+        bl = _Vec((3 * k + 1) * HIDING_COEFFS, _mont_rows(blinds + self.blind_mask))
+        polys = [((self.wit.ptr(q * L), L), None, (bl.ptr(HIDING_COEFFS * q), HIDING_COEFFS)) for q in range(3 * k)]
+        polys.append(((self.mask.ptr(), 3 * n_h), None, (bl.ptr(HIDING_COEFFS * 3 * k), HIDING_COEFFS)))
         out = SonicKZG10.commit(ix.ck, polys, device=True, stream=s)
-        for k, name in enumerate(('w', 'z_a', 'z_b', 'mask')): self.c[name] = out[k]
-        self.tr.absorb(ix.vk_bytes); self.tr.absorb(b''.join(_fr_bytes(v) for v in self.x_evals))
+        self.witness_commitments = out[:3 * k]; self.c['mask'] = out[3 * k]
+        self.tr.absorb(ix.vk_bytes); self.tr.absorb(b''.join(_fr_bytes(v) for xe in self.x_evals for v in xe))
         self.tr.absorb(wire.g1_compress(out).tobytes())
         self.alpha, self.eta_b, self.eta_c = self.tr.challenge(b'alpha'), self.tr.challenge(b'eta_b'), self.tr.challenge(b'eta_c')
+        self.comb = [1] + [self.tr.challenge(b'combiner' + i.to_bytes(4, 'little')) for i in range(1, k)]
 
     # ---- round 2: the first sumcheck -----------------------------------------------------------------------------------------------
     def second_round(self):
-        ix, s = self.ix, self.s; n_h, n_x = ix.n_h, ix.n_x
+        ix, s, k = self.ix, self.s, self.k; n_h, n_x = ix.n_h, ix.n_x
         one = _mont(1); neg1 = _mont(R - 1)
         alpha = self.alpha; vh_alpha = _vanish(n_h, alpha)
         if vh_alpha == 0: raise ArithmeticError('alpha landed in H')
@@ -242,22 +260,29 @@ class Prover:
         spmv_device(rt.ptr(n_h), tp.data_ptr(), tcol.data_ptr(), tval.ptr(), ext.ptr(), n_h, s)
         ix.H.ntt_device(rt.ptr(n_h), direction=INVERSE, stream=s)                     # t(X)
         L = n_h + 1; n4 = 4 * n_h
-        E = _Vec(5 * n4, zero=True)                                                            # r, t, z, z_a, z_b on the domain of size 4|H|
+        E = _Vec((2 + 3 * k) * n4, zero=True)                                       # r, t, then z_i, z_a,i, z_b,i on the domain of size 4|H|
         E.t[0:n_h].copy_(rt.t[:n_h]); E.t[n4:n4 + n_h].copy_(rt.t[n_h:])
-        zp = 2 * n4                                                                 # ẑ = w (X^|X| − 1) + x̂
-        fr_lin_device(E.ptr(zp), L, None, neg1, self.w.ptr(), stream=s)
-        fr_vec_op_device(E.ptr(zp + n_x), E.ptr(zp + n_x), self.w.ptr(), L, OP_ADD, s)
-        xp = _Vec(n_x, _mont_rows(self.x_poly))
-        fr_vec_op_device(E.ptr(zp), E.ptr(zp), xp.ptr(), n_x, OP_ADD, s)
-        E.t[3 * n4:3 * n4 + L].copy_(self.za.t[:L]); E.t[4 * n4:4 * n4 + L].copy_(self.zb.t[:L])
-        ix.H4.ntt_batch_device(E.ptr(), 5, stream=s)
-        e_r, e_t, e_z, e_a, e_b = (E.ptr(i * n4) for i in range(5))
-        ahp_first_sumcheck_device(e_a, n4, e_r, e_a, e_b, e_t, e_z, _mont(self.eta_b), _mont(self.eta_c), s)
-        ix.H4.ntt_device(e_a, direction=INVERSE, stream=s)
-        fr_vec_op_device(e_a, e_a, self.mask.ptr(), 3 * n_h, OP_ADD, s)               # q_1 = h_1 (X^|H| − 1) + X g_1, degree < 3|H|
+        for i in range(k):
+            zp = (2 + 3 * i) * n4                                                   # ẑ_i = w_i (X^|X| − 1) + x̂_i
+            fr_lin_device(E.ptr(zp), L, None, neg1, self.w(i), stream=s)
+            fr_vec_op_device(E.ptr(zp + n_x), E.ptr(zp + n_x), self.w(i), L, OP_ADD, s)
+            xp = _Vec(n_x, _mont_rows(self.x_poly[i]))
+            fr_vec_op_device(E.ptr(zp), E.ptr(zp), xp.ptr(), n_x, OP_ADD, s)
+            E.t[zp + n4:zp + n4 + L].copy_(self.wit.t[(3 * i + 1) * L:(3 * i + 2) * L]); E.t[zp + 2 * n4:zp + 2 * n4 + L].copy_(self.wit.t[(3 * i + 2) * L:(3 * i + 3) * L])
+        ix.H4.ntt_batch_device(E.ptr(), 2 + 3 * k, stream=s)
+        e_r, e_t = E.ptr(0), E.ptr(n4)
+        for i in range(k):                                                          # numerator of instance i, in place over its z_a row
+            e_z, e_a, e_b = (E.ptr((2 + 3 * i + j) * n4) for j in range(3))
+            ahp_first_sumcheck_device(e_a, n4, e_r, e_a, e_b, e_t, e_z, _mont(self.eta_b), _mont(self.eta_c), s)
+        if k == 1: q1 = E.ptr(3 * n4)
+        else:                                                                       # sum_i c_i numerator_i
+            Q = _Vec(n4); q1 = Q.ptr()
+            fr_lincomb_device(q1, n4, None, [(E.ptr((3 + 3 * i) * n4), n4, _mont(self.comb[i])) for i in range(k)], s)
+        ix.H4.ntt_device(q1, direction=INVERSE, stream=s)
+        fr_vec_op_device(q1, q1, self.mask.ptr(), 3 * n_h, OP_ADD, s)                 # q_1 = h_1 (X^|H| − 1) + X g_1, degree < 3|H|
         self.h1 = _Vec(2 * n_h); self.g1 = _Vec(n_h)
-        p0, p1, p2 = e_a, e_a + 32 * n_h, e_a + 64 * n_h
-        self.h1.t[n_h:].copy_(E.t[3 * n4 + 2 * n_h:3 * n4 + 3 * n_h])                # quotient blocks: p2, p1 + p2; remainder p0 + p1 + p2
+        p0, p1, p2 = q1, q1 + 32 * n_h, q1 + 64 * n_h
+        fr_lin_device(self.h1.ptr(n_h), n_h, None, one, p2, stream=s)                 # quotient blocks: p2, p1 + p2; remainder p0 + p1 + p2
         fr_vec_op_device(self.h1.ptr(), p1, p2, n_h, OP_ADD, s)
         fr_vec_op_device(self.g1.ptr(), p0, self.h1.ptr(), n_h, OP_ADD, s)             # remainder; its constant term is the sum over H / |H| = 0
         out = SonicKZG10.commit(ix.ck, [((self.g1.ptr(1), n_h - 1), n_h - 2, None), ((self.h1.ptr(), 2 * n_h), None, None)], device=True, stream=s)
@@ -268,7 +293,6 @@ class Prover:
     # ---- round 3: three rational sumchecks over K -----------------------------------------------------------------------------------
     def third_round(self):
         ix, s = self.ix, self.s; n_h, n_k = ix.n_h, ix.n_k
-        neg1 = _mont(R - 1)
         vh_beta = _vanish(n_h, self.beta)
         if vh_beta == 0: raise ArithmeticError('beta landed in H')
         self.vv = _vanish(n_h, self.alpha) * vh_beta % R
@@ -291,7 +315,6 @@ class Prover:
     # ---- round 4 ----------------------------------------------------------------------------------------------------------------------
     def fourth_round(self):
         ix, s = self.ix, self.s; n_k = ix.n_k; n2 = 2 * n_k
-        one = _mont(1); neg1 = _mont(R - 1)
         F = _Vec(3 * n2, zero=True); F.t.view(3, n2, 4)[:, :n_k].copy_(self.f.t.view(3, n_k, 4))
         ix.K2.ntt_batch_device(F.ptr(), 3, stream=s)
         B = _Vec(n2)
@@ -306,57 +329,62 @@ class Prover:
 
     # ---- evaluations and openings ------------------------------------------------------------------------------------------------------
     def finish(self) -> Proof:
-        ix, s = self.ix, self.s; n_h, n_k, n_x = ix.n_h, ix.n_k, ix.n_x
-        one = _mont(1)
-        self._ev = _Vec(8)
-        fr_eval_batch_device(self._ev.ptr(), [self.zb.ptr(), self.g1.ptr(1)] + [self.f.ptr(k * n_k + 1) for k in range(3)],
-                             [n_h + 1, n_h - 1] + [n_k - 1] * 3, _mont_rows([self.beta, self.beta, self.gamma, self.gamma, self.gamma]), s)
+        ix, s, k = self.ix, self.s, self.k; n_h, n_k, n_x = ix.n_h, ix.n_k, ix.n_x
+        one = _mont(1); L = n_h + 1
+        self._ev = _Vec(k + 8)
+        fr_eval_batch_device(self._ev.ptr(), [self.zb(i) for i in range(k)] + [self.g1.ptr(1)] + [self.f.ptr(j * n_k + 1) for j in range(3)],
+                             [L] * k + [n_h - 1] + [n_k - 1] * 3, _mont_rows([self.beta] * (k + 1) + [self.gamma] * 3), s)
         self.stream.synchronize()
-        evals = [_from_mont(v) for v in self._ev.host(0, 5)]
-        zb_beta, g1_beta, ga, gb, gc = evals
+        evals = [_from_mont(v) for v in self._ev.host(0, k + 4)]
+        zb_beta = evals[:k]; g1_beta, ga, gb, gc = evals[k:]
         self.tr.absorb(b''.join(_fr_bytes(v) for v in evals)); xi = self.tr.challenge(b'xi')
         alpha, beta, gamma = self.alpha, self.beta, self.gamma
-        # linear combination of the first sumcheck, opened at beta together with g_1 and z_b
+        # linear combination of the first sumcheck, opened at beta together with g_1 and the z_b,i
         r_ab = (_vanish(n_h, alpha) - _vanish(n_h, beta)) * _inv(alpha - beta) % R
         t_beta = (self.sigma[0] + self.eta_b * self.sigma[1] + self.eta_c * self.sigma[2]) % R
-        x_beta = 0
-        for v in reversed(self.x_poly): x_beta = (x_beta * beta + v) % R
-        k_mask, k_za, k_w, k_h1 = 1, r_ab * (1 + self.eta_c * zb_beta) % R, (-t_beta * _vanish(n_x, beta)) % R, (-_vanish(n_h, beta)) % R
-        const = (r_ab * self.eta_b % R * zb_beta - t_beta * x_beta - beta * g1_beta) % R
-        xi2 = xi * xi % R; L = n_h + 1
-        pb = _Vec(3 * n_h)
-        fr_lincomb_device(pb.ptr(), 3 * n_h, _mont(xi2 * const), [(self.mask.ptr(), 3 * n_h, _mont(xi2 * k_mask)), (self.h1.ptr(), 2 * n_h, _mont(xi2 * k_h1)),
-                                                               (self.za.ptr(), L, _mont(xi2 * k_za)), (self.w.ptr(), L, _mont(xi2 * k_w)),
-                                                               (self.zb.ptr(), L, _mont(xi)), (self.g1.ptr(1), n_h - 1, one)], s)
+        xl = pow(xi, k + 1, R); const = (-beta * g1_beta) % R
+        terms = [(self.mask.ptr(), 3 * n_h, _mont(xl)), (self.h1.ptr(), 2 * n_h, _mont(-xl * _vanish(n_h, beta))), (self.g1.ptr(1), n_h - 1, one)]
         bl = [0] * HIDING_COEFFS
-        for coef, key in ((xi, 'blind_b'), (xi2 * k_mask, 'blind_mask'), (xi2 * k_za, 'blind_a'), (xi2 * k_w, 'blind_w')):
-            for i, v in enumerate(self.blind[key]): bl[i] = (bl[i] + coef * v) % R
+        def axpy(coef, src):
+            for j, v in enumerate(src): bl[j] = (bl[j] + coef * v) % R
+        axpy(xl, self.blind_mask)
+        for i in range(k):
+            x_beta = 0
+            for v in reversed(self.x_poly[i]): x_beta = (x_beta * beta + v) % R
+            ci = self.comb[i]
+            k_za = xl * ci % R * r_ab % R * (1 + self.eta_c * zb_beta[i]) % R; k_w = (-xl * ci % R * t_beta % R * _vanish(n_x, beta)) % R; k_zb = pow(xi, 1 + i, R)
+            const = (const + ci * (r_ab * self.eta_b % R * zb_beta[i] - t_beta * x_beta)) % R
+            terms += [(self.za(i), L, _mont(k_za)), (self.w(i), L, _mont(k_w)), (self.zb(i), L, _mont(k_zb))]
+            axpy(k_w, self.blind[3 * i]); axpy(k_za, self.blind[3 * i + 1]); axpy(k_zb, self.blind[3 * i + 2])
+        pb = _Vec(3 * n_h)
+        fr_lincomb_device(pb.ptr(), 3 * n_h, _mont(xl * const), terms, s)
         random_v = 0
         for v in reversed(bl): random_v = (random_v * beta + v) % R
         blw = [0] * (HIDING_COEFFS - 1); acc = 0
         for j in range(HIDING_COEFFS - 1, 0, -1): acc = (bl[j] + beta * acc) % R; blw[j - 1] = acc
         wq = _Vec(3 * n_h); blq = _Vec(HIDING_COEFFS - 1, _mont_rows(blw))
-        divide_by_linear_device(wq.ptr(), self._ev.ptr(5), pb.ptr(), 3 * n_h, _mont(beta), s)
+        divide_by_linear_device(wq.ptr(), self._ev.ptr(k + 5), pb.ptr(), 3 * n_h, _mont(beta), s)
         # linear combination of the second sumcheck, opened at gamma together with g_a, g_b, g_c
-        xi3 = xi2 * xi % R; n_k_inv = _inv(n_k); vk_gamma = _vanish(n_k, gamma)
+        xi2 = xi * xi % R; xi3 = xi2 * xi % R; n_k_inv = _inv(n_k); vk_gamma = _vanish(n_k, gamma)
         pg = _Vec(n_k); const = 0; terms = []
-        for k, gk in enumerate((ga, gb, gc)):
-            fm = (gamma * gk + self.sigma[k] * n_k_inv) % R; d = self.delta[k] * xi3 % R
+        for m, gk in enumerate((ga, gb, gc)):
+            fm = (gamma * gk + self.sigma[m] * n_k_inv) % R; d = self.delta[m] * xi3 % R
             for j, coef in ((2, d * self.vv), (0, d * fm % R * beta), (1, d * fm % R * alpha), (3, -d * fm)):       # val, row, col, row_col
-                terms.append((ix.k_polys.ptr((4 * k + j) * n_k), n_k, _mont(coef)))
+                terms.append((ix.k_polys.ptr((4 * m + j) * n_k), n_k, _mont(coef)))
             const = (const - d * fm % R * alpha % R * beta) % R
         terms.append((self.h2.ptr(), n_k, _mont(-xi3 * vk_gamma)))
-        terms += [(self.f.ptr(k * n_k + 1), n_k - 1, _mont(coef)) for k, coef in enumerate((1, xi, xi2))]
+        terms += [(self.f.ptr(m * n_k + 1), n_k - 1, _mont(coef)) for m, coef in enumerate((1, xi, xi2))]
         fr_lincomb_device(pg.ptr(), n_k, _mont(const), terms, s)
         gq = _Vec(n_k)
-        divide_by_linear_device(gq.ptr(), self._ev.ptr(6), pg.ptr(), n_k, _mont(gamma), s)
+        divide_by_linear_device(gq.ptr(), self._ev.ptr(k + 6), pg.ptr(), n_k, _mont(gamma), s)
         opn = SonicKZG10.commit(ix.ck, [((wq.ptr(), 3 * n_h - 1), None, (blq.ptr(), HIDING_COEFFS - 1)), ((gq.ptr(), n_k - 1), None, None)], device=True, stream=s)
         open_beta, open_gamma = opn[0], opn[1]                                      # both witness commitments in one call
-        return Proof(dict(self.c), evals, list(self.sigma), [(open_beta, random_v), (open_gamma, None)])
+        return Proof(self.witness_commitments, dict(self.c), evals, list(self.sigma), [(open_beta, random_v), (open_gamma, None)])
 
 
-def prove(index: CircuitIndex, assignment: np.ndarray, seed: int, stream: torch.cuda.Stream = None) -> Proof:
-    """Varuna::prove_batch for one circuit with one instance; `seed` selects the proof's random stream.  Proofs of one index may be
+def prove(index: CircuitIndex, assignment, seed: int, stream: torch.cuda.Stream = None) -> Proof:
+    """Varuna::prove_batch for one circuit with one to four instances (one assignment array, or a list of them); `seed` selects the proof's
+    random stream.  Proofs of one index may be
     produced concurrently from several host threads, each on its own `stream` (the index is read-only while proving)."""
     import time
     with torch.cuda.stream(stream or index.stream):

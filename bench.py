@@ -356,6 +356,10 @@ def varuna_prove(synth, torch, lg, reps=7, in_flight=4):
         for rep in range(reps + 2):
             t = time.perf_counter(); pr = varuna.prove(ix, zz, 1000 + rep); ts.append((time.perf_counter() - t) * 1e3); rounds.append(pr.timing_ms)
         med = float(np.median(ts[2:]))
+        tb = []
+        for rep in range(5):                               # prove_batch shape: four instances of the circuit in one proof
+            t = time.perf_counter(); prb = varuna.prove(ix, [zz] * 4, 2000 + rep); tb.append((time.perf_counter() - t) * 1e3)
+        mb = float(np.median(tb[1:]))
         streams = [torch.cuda.Stream() for _ in range(in_flight)]; per = 6
         def work(k):
             for rep in range(per): varuna.prove(ix, zz, 5000 + 100 * k + rep, streams[k])
@@ -367,6 +371,7 @@ def varuna_prove(synth, torch, lg, reps=7, in_flight=4):
             dt = time.perf_counter() - t
         return {'constraints': n, 'domain_h': ix.n_h, 'domain_k': ix.n_k, 'max_degree': D, 'index_s': index_s, 'prove_ms': med, 'constraints_per_s': n / med * 1e3,
                 'rounds_ms': {k: float(np.median([r[k] for r in rounds[2:]])) for k in rounds[0]}, 'proof_bytes': len(pr.to_bytes()),
+                'instances_4': {'prove_ms': mb, 'constraints_per_s': 4 * n / mb * 1e3, 'proof_bytes': len(prb.to_bytes())},
                 'in_flight_%d' % in_flight: {'proofs_per_s': in_flight * per / dt, 'constraints_per_s': n * in_flight * per / dt}, 'what': VARUNA_NOTE}
     finally:
         ck.close()

@@ -159,17 +159,19 @@ def random_fr(seed: int, index: int) -> int:
         j += 1
 
 
-def random_stream(seed: int, n_h: int) -> list:
-    return [random_fr(seed, i) for i in range(randomness_layout(n_h)['total'])]
-
-
-def randomness_layout(n_h):
-    """Offsets into the prover's random vector (canonical Fr): rho_w, rho_a, rho_b, mask[3|H|], then four hiding polynomials."""
-    o = {'rho_w': 0, 'rho_a': 1, 'rho_b': 2, 'mask': 3}
-    base = 3 + 3 * n_h
-    for i, k in enumerate(('blind_w', 'blind_a', 'blind_b', 'blind_mask')): o[k] = base + HIDING_COEFFS * i
-    o['total'] = base + 4 * HIDING_COEFFS
+def randomness_layout(n_h, k=1):
+    """Offsets into the prover's random stream (canonical Fr) for k instances: rho_w, rho_a, rho_b per instance, mask[3|H|], then the
+    hiding polynomials of w_i, z_a,i, z_b,i per instance and of the mask."""
+    o = {'rho': [3 * i for i in range(k)], 'mask': 3 * k}
+    base = 3 * k + 3 * n_h
+    o['blind'] = [base + 3 * HIDING_COEFFS * i for i in range(k)]                 # w, z_a, z_b of instance i: HIDING_COEFFS each
+    o['blind_mask'] = base + 3 * HIDING_COEFFS * k
+    o['total'] = o['blind_mask'] + HIDING_COEFFS
     return o
+
+
+def random_stream(seed: int, n_h: int, k: int = 1) -> list:
+    return [random_fr(seed, i) for i in range(randomness_layout(n_h, k)['total'])]
 
 
 def _blinded(H, evals, rho):
@@ -178,43 +180,57 @@ def _blinded(H, evals, rho):
     return p
 
 
-def prove(index: Index, setup: Setup, z_assignment, rand, vk_bytes=None):
-    """One proof for one instance.  z_assignment: ints, public first (z[0] = 1).  rand: list of canonical Fr (randomness_layout).
+def _axpy(dst, k, src):
+    for i, v in enumerate(src): dst[i] = (dst[i] + k * v) % R
+
+
+def _challenges_after_round1(tr, k):
+    alpha, eta_b, eta_c = tr.challenge(b'alpha'), tr.challenge(b'eta_b'), tr.challenge(b'eta_c')
+    comb = [1] + [tr.challenge(b'combiner' + i.to_bytes(4, 'little')) for i in range(1, k)]      # batch combiners of the instances
+    return alpha, {'a': 1, 'b': eta_b, 'c': eta_c}, comb
+
+
+def prove(index: Index, setup: Setup, assignments, rand, vk_bytes=None):
+    """One proof for k instances of one circuit (Varuna::prove_batch with one circuit).  assignments: one list of ints per instance (or a
+    single such list), public variables first (z[0] = 1).  rand: the random stream (randomness_layout(n_h, k)).
     Returns (proof dict, proof bytes in the reference's layout)."""
+    if assignments and not isinstance(assignments[0], (list, tuple)): assignments = [assignments]
+    k = len(assignments)
     c = index.circuit; H, K, X = index.H, index.K, index.X
     n_h, n_k, n_x = c.n_h, c.n_k, c.n_x
-    lay = randomness_layout(n_h); assert len(rand) >= lay['total']
-    he = H.elements()
-    D = setup.max_degree
+    lay = randomness_layout(n_h, k); assert len(rand) >= lay['total']
+    he = H.elements(); ratio = n_h // n_x
     # ---- first round --------------------------------------------------------------------------------------------------------
-    zH = [0] * n_h
-    for v, val in enumerate(z_assignment): zH[h_position(v, c.n_public, n_x, n_h)] = val % R
-    z_m = {}
-    for name in 'ab':
-        out = [0] * n_h
-        for r, row in enumerate(c.m[name]): out[r] = sum(val * z_assignment[v] for v, val in row) % R
-        z_m[name] = out
-    x_evals = [z_assignment[i] % R if i < c.n_public else 0 for i in range(n_x)]
-    x_poly = X.ifft(x_evals)
-    ratio = n_h // n_x
-    w_evals = [0] * n_h
-    for p in range(n_h):
-        if p % ratio == 0: continue
-        w_evals[p] = (zH[p] - poly_eval(x_poly, he[p])) * inv(X.vanishing(he[p])) % R
-    w = _blinded(H, w_evals, rand[lay['rho_w']])
-    za = _blinded(H, z_m['a'], rand[lay['rho_a']])
-    zb = _blinded(H, z_m['b'], rand[lay['rho_b']])
+    inst = []
+    for i, z_assignment in enumerate(assignments):
+        zH = [0] * n_h
+        for v, val in enumerate(z_assignment): zH[h_position(v, c.n_public, n_x, n_h)] = val % R
+        z_m = {}
+        for name in 'ab':
+            out = [0] * n_h
+            for r, row in enumerate(c.m[name]): out[r] = sum(val * z_assignment[v] for v, val in row) % R
+            z_m[name] = out
+        x_evals = [z_assignment[j] % R if j < c.n_public else 0 for j in range(n_x)]
+        x_poly = X.ifft(x_evals)
+        w_evals = [0] * n_h
+        for p in range(n_h):
+            if p % ratio == 0: continue
+            w_evals[p] = (zH[p] - poly_eval(x_poly, he[p])) * inv(X.vanishing(he[p])) % R
+        rho = rand[lay['rho'][i]:lay['rho'][i] + 3]
+        bl = [[v % R for v in rand[lay['blind'][i] + HIDING_COEFFS * j:lay['blind'][i] + HIDING_COEFFS * (j + 1)]] for j in range(3)]
+        d = {'x_evals': x_evals, 'x_poly': x_poly, 'w': _blinded(H, w_evals, rho[0]), 'za': _blinded(H, z_m['a'], rho[1]), 'zb': _blinded(H, z_m['b'], rho[2]),
+             'blind': {'w': bl[0], 'za': bl[1], 'zb': bl[2]}}
+        d['cb'] = {p_: _point_bytes(_commit_scalar(setup, d[p_], blind=d['blind'][p_])) for p_ in ('w', 'za', 'zb')}
+        inst.append(d)
     mask = [v % R for v in rand[lay['mask']:lay['mask'] + 3 * n_h]]
     mask[0] = (-(mask[n_h] + mask[2 * n_h])) % R                                  # sum over H = |H| (m_0 + m_|H| + m_2|H|) = 0
-    blind = {k: [v % R for v in rand[lay[k]:lay[k] + HIDING_COEFFS]] for k in ('blind_w', 'blind_a', 'blind_b', 'blind_mask')}
-    cs = {'w': _commit_scalar(setup, w, blind=blind['blind_w']), 'z_a': _commit_scalar(setup, za, blind=blind['blind_a']),
-          'z_b': _commit_scalar(setup, zb, blind=blind['blind_b']), 'mask': _commit_scalar(setup, mask, blind=blind['blind_mask'])}
-    cb = {k: _point_bytes(v) for k, v in cs.items()}
+    blind_mask = [v % R for v in rand[lay['blind_mask']:lay['blind_mask'] + HIDING_COEFFS]]
+    cb = {'mask': _point_bytes(_commit_scalar(setup, mask, blind=blind_mask))}
     tr = Transcript(); tr.absorb(vk_bytes if vk_bytes is not None else index.vk_bytes())
-    tr.absorb(b''.join(fr_bytes(v) for v in x_evals))
-    tr.absorb(cb['w'] + cb['z_a'] + cb['z_b'] + cb['mask'])
-    alpha, eta_b, eta_c = tr.challenge(b'alpha'), tr.challenge(b'eta_b'), tr.challenge(b'eta_c')
-    eta = {'a': 1, 'b': eta_b, 'c': eta_c}
+    tr.absorb(b''.join(fr_bytes(v) for d in inst for v in d['x_evals']))
+    tr.absorb(b''.join(d['cb']['w'] + d['cb']['za'] + d['cb']['zb'] for d in inst) + cb['mask'])
+    alpha, eta, comb = _challenges_after_round1(tr, k)
+    eta_b, eta_c = eta['b'], eta['c']
     # ---- second round: first sumcheck --------------------------------------------------------------------------------------
     vh_alpha = H.vanishing(alpha); assert vh_alpha != 0
     r_alpha = [vh_alpha * inv(alpha - h) % R for h in he]                         # u_H(alpha, h) on H
@@ -222,12 +238,18 @@ def prove(index: Index, setup: Setup, z_assignment, rand, vk_bytes=None):
     for name in 'abc':
         for r, cp, v in index.entries[name]: t_evals[cp] = (t_evals[cp] + eta[name] * r_alpha[r] % R * v) % R
     r_poly, t_poly = H.ifft(r_alpha), H.ifft(t_evals)
-    z_poly = [0] * (n_h + 1 + n_x)                                                # ẑ = w v_X + x̂
-    for i, v in enumerate(w): z_poly[i] = (z_poly[i] - v) % R; z_poly[i + n_x] = (z_poly[i + n_x] + v) % R
-    for i, v in enumerate(x_poly): z_poly[i] = (z_poly[i] + v) % R
     D4 = Domain(4 * n_h)
-    e_r, e_t, e_z, e_a, e_b = D4.fft(r_poly), D4.fft(t_poly), D4.fft(z_poly), D4.fft(za), D4.fft(zb)
-    q1 = D4.ifft([(e_r[i] * ((e_a[i] + eta_b * e_b[i] + eta_c * e_a[i] % R * e_b[i]) % R) - e_t[i] * e_z[i]) % R for i in range(4 * n_h)])
+    e_r, e_t = D4.fft(r_poly), D4.fft(t_poly)
+    acc4 = [0] * (4 * n_h)
+    for d, ci in zip(inst, comb):
+        w = d['w']
+        z_poly = [0] * (n_h + 1 + n_x)                                            # ẑ = w v_X + x̂
+        for i, v in enumerate(w): z_poly[i] = (z_poly[i] - v) % R; z_poly[i + n_x] = (z_poly[i + n_x] + v) % R
+        for i, v in enumerate(d['x_poly']): z_poly[i] = (z_poly[i] + v) % R
+        e_z, e_a, e_b = D4.fft(z_poly), D4.fft(d['za']), D4.fft(d['zb'])
+        for i in range(4 * n_h):
+            acc4[i] = (acc4[i] + ci * (e_r[i] * ((e_a[i] + eta_b * e_b[i] + eta_c * e_a[i] % R * e_b[i]) % R) - e_t[i] * e_z[i])) % R
+    q1 = D4.ifft(acc4)
     for i, v in enumerate(mask): q1[i] = (q1[i] + v) % R
     q = [0] * (3 * n_h)                                                           # q1 = h_1 (X^|H| − 1) + remainder
     for i in range(4 * n_h - 1, n_h - 1, -1):
@@ -236,8 +258,7 @@ def prove(index: Index, setup: Setup, z_assignment, rand, vk_bytes=None):
     assert rem[0] == 0, 'first sumcheck: the sum over H is not zero (unsatisfied assignment?)'
     h1 = q[:2 * n_h]; assert not any(q[2 * n_h:])
     g1 = rem[1:]
-    cs['g_1'] = _commit_scalar(setup, g1, bound=n_h - 2); cs['h_1'] = _commit_scalar(setup, h1)
-    cb['g_1'], cb['h_1'] = _point_bytes(cs['g_1']), _point_bytes(cs['h_1'])
+    cb['g_1'], cb['h_1'] = _point_bytes(_commit_scalar(setup, g1, bound=n_h - 2)), _point_bytes(_commit_scalar(setup, h1))
     tr.absorb(cb['g_1'] + cb['h_1'])
     beta = tr.challenge(b'beta')
     # ---- third round: the three rational sumchecks over K --------------------------------------------------------------------
@@ -245,9 +266,9 @@ def prove(index: Index, setup: Setup, z_assignment, rand, vk_bytes=None):
     f, sigma, g = {}, {}, {}
     for name in 'abc':
         ev = index.evals[name]
-        fe = [vh_alpha * vh_beta % R * ev['val'][k] % R * inv((alpha - ev['row'][k]) * (beta - ev['col'][k])) % R for k in range(n_k)]
+        fe = [vh_alpha * vh_beta % R * ev['val'][j] % R * inv((alpha - ev['row'][j]) * (beta - ev['col'][j])) % R for j in range(n_k)]
         f[name] = K.ifft(fe); sigma[name] = f[name][0] * n_k % R; g[name] = f[name][1:]
-        cs['g_' + name] = _commit_scalar(setup, g[name], bound=n_k - 2); cb['g_' + name] = _point_bytes(cs['g_' + name])
+        cb['g_' + name] = _point_bytes(_commit_scalar(setup, g[name], bound=n_k - 2))
     tr.absorb(b''.join(fr_bytes(sigma[m]) for m in 'abc') + cb['g_a'] + cb['g_b'] + cb['g_c'])
     delta = {'a': 1, 'b': tr.challenge(b'delta_b'), 'c': tr.challenge(b'delta_c')}
     # ---- fourth round ------------------------------------------------------------------------------------------------------------
@@ -263,42 +284,46 @@ def prove(index: Index, setup: Setup, z_assignment, rand, vk_bytes=None):
     pc = D2.ifft(acc)
     h2 = pc[n_k:]                                                                 # P = h_2 (X^|K| − 1), deg P < 2|K|
     assert all((pc[i] + h2[i]) % R == 0 for i in range(n_k)), 'fourth round: not divisible by v_K'
-    cs['h_2'] = _commit_scalar(setup, h2); cb['h_2'] = _point_bytes(cs['h_2'])
+    cb['h_2'] = _point_bytes(_commit_scalar(setup, h2))
     tr.absorb(cb['h_2'])
     gamma = tr.challenge(b'gamma')
     # ---- evaluations and the two openings --------------------------------------------------------------------------------------
-    ev = {'z_b': poly_eval(zb, beta), 'g_1': poly_eval(g1, beta), 'g_a': poly_eval(g['a'], gamma), 'g_b': poly_eval(g['b'], gamma), 'g_c': poly_eval(g['c'], gamma)}
-    evals = [ev['z_b'], ev['g_1'], ev['g_a'], ev['g_b'], ev['g_c']]
+    zb_beta = [poly_eval(d['zb'], beta) for d in inst]
+    g1_beta = poly_eval(g1, beta); g_gamma = {m: poly_eval(g[m], gamma) for m in 'abc'}
+    evals = zb_beta + [g1_beta, g_gamma['a'], g_gamma['b'], g_gamma['c']]
     tr.absorb(b''.join(fr_bytes(v) for v in evals))
     xi = tr.challenge(b'xi')
-    lc1 = lincheck_coefficients(H, X, alpha, beta, eta, sigma, ev['z_b'], ev['g_1'], poly_eval(x_poly, beta))
-    p_beta = [0] * max(len(mask), len(h1), len(za), len(w))
-    def axpy(dst, k, src):
-        for i, v in enumerate(src): dst[i] = (dst[i] + k * v) % R
-    axpy(p_beta, lc1['mask'], mask); axpy(p_beta, lc1['z_a'], za); axpy(p_beta, lc1['w'], w); axpy(p_beta, lc1['h_1'], h1)
+    lc1 = lincheck_coefficients(H, X, alpha, beta, eta, comb, sigma, zb_beta, g1_beta, [poly_eval(d['x_poly'], beta) for d in inst])
+    p_beta = [0] * (3 * n_h)
+    _axpy(p_beta, lc1['mask'], mask); _axpy(p_beta, lc1['h_1'], h1)
+    for d, kz, kw in zip(inst, lc1['z_a'], lc1['w']): _axpy(p_beta, kz, d['za']); _axpy(p_beta, kw, d['w'])
     p_beta[0] = (p_beta[0] + lc1['const']) % R
     assert poly_eval(p_beta, beta) == 0, 'lincheck linear combination does not vanish at beta'
-    p_beta = [v * xi % R * xi % R for v in p_beta]
-    axpy(p_beta, 1, g1); axpy(p_beta, xi, zb)
-    v_beta = (ev['g_1'] + xi * ev['z_b']) % R
+    xl = pow(xi, k + 1, R)                                                        # g_1 + sum_i xi^(1+i) z_b,i + xi^(k+1) LC1
+    p_beta = [v * xl % R for v in p_beta]
+    _axpy(p_beta, 1, g1)
+    for i, d in enumerate(inst): _axpy(p_beta, pow(xi, 1 + i, R), d['zb'])
+    v_beta = (g1_beta + sum(pow(xi, 1 + i, R) * v for i, v in enumerate(zb_beta))) % R
     w_beta = divide_by_linear(p_beta, beta, v_beta)
     bl = [0] * HIDING_COEFFS
-    axpy(bl, xi, blind['blind_b'])
-    axpy(bl, xi * xi % R * lc1['mask'], blind['blind_mask']); axpy(bl, xi * xi % R * lc1['z_a'], blind['blind_a']); axpy(bl, xi * xi % R * lc1['w'], blind['blind_w'])
+    _axpy(bl, xl * lc1['mask'] % R, blind_mask)
+    for i, (d, kz, kw) in enumerate(zip(inst, lc1['z_a'], lc1['w'])):
+        _axpy(bl, pow(xi, 1 + i, R), d['blind']['zb']); _axpy(bl, xl * kz % R, d['blind']['za']); _axpy(bl, xl * kw % R, d['blind']['w'])
     random_v = poly_eval(bl, beta)
     bl_w = divide_by_linear(bl, beta, random_v)
     open_beta = (poly_eval(w_beta, setup.tau) + setup.s_gamma * poly_eval(bl_w, setup.tau)) % R
-    lc2 = matrix_coefficients(H, K, alpha, beta, gamma, delta, sigma, {m: ev['g_' + m] for m in 'abc'})
+    lc2 = matrix_coefficients(H, K, alpha, beta, gamma, delta, sigma, g_gamma)
     p_gamma = [0] * n_k
-    for (m, k), coef in lc2['index'].items(): axpy(p_gamma, coef, index.polys[m][k])
-    axpy(p_gamma, lc2['h_2'], h2)
+    for (m, kind), coef in lc2['index'].items(): _axpy(p_gamma, coef, index.polys[m][kind])
+    _axpy(p_gamma, lc2['h_2'], h2)
     p_gamma[0] = (p_gamma[0] + lc2['const']) % R
     assert poly_eval(p_gamma, gamma) == 0, 'matrix sumcheck linear combination does not vanish at gamma'
     p_gamma = [v * pow(xi, 3, R) % R for v in p_gamma]
-    axpy(p_gamma, 1, g['a']); axpy(p_gamma, xi, g['b']); axpy(p_gamma, xi * xi % R, g['c'])
-    v_gamma = (ev['g_a'] + xi * ev['g_b'] + xi * xi % R * ev['g_c']) % R
+    _axpy(p_gamma, 1, g['a']); _axpy(p_gamma, xi, g['b']); _axpy(p_gamma, xi * xi % R, g['c'])
+    v_gamma = (g_gamma['a'] + xi * g_gamma['b'] + xi * xi % R * g_gamma['c']) % R
     open_gamma = poly_eval(divide_by_linear(p_gamma, gamma, v_gamma), setup.tau)
-    proof = {'commitments': {k: cb[k] for k in ('w', 'z_a', 'z_b', 'mask', 'g_1', 'h_1', 'g_a', 'g_b', 'g_c', 'h_2')},
+    proof = {'instances': k, 'witness': [(d['cb']['w'], d['cb']['za'], d['cb']['zb']) for d in inst],
+             'commitments': {n_: cb[n_] for n_ in ('mask', 'g_1', 'h_1', 'g_a', 'g_b', 'g_c', 'h_2')},
              'evaluations': evals, 'sums': [sigma['a'], sigma['b'], sigma['c']],
              'openings': [(_point_bytes(open_beta), random_v), (_point_bytes(open_gamma), None)]}
     return proof, proof_bytes(proof)
@@ -313,12 +338,15 @@ def divide_by_linear(p, z, value):
     return q
 
 
-def lincheck_coefficients(H, X, alpha, beta, eta, sigma, zb_beta, g1_beta, x_beta):
-    """Coefficients of the linear combination of (mask, z_a, w, h_1, 1) that must vanish at beta (first sumcheck, evaluated by the verifier)."""
+def lincheck_coefficients(H, X, alpha, beta, eta, comb, sigma, zb_beta, g1_beta, x_beta):
+    """Coefficients of the linear combination of (mask, z_a,i, w_i, h_1, 1) that must vanish at beta (first sumcheck as the verifier evaluates it):
+    mask + sum_i c_i [r(alpha, beta)(z_a,i + eta_b z_b,i(beta) + eta_c z_a,i z_b,i(beta)) − t(beta)(w_i v_X(beta) + x̂_i(beta))] − v_H(beta) h_1 − beta g_1(beta)."""
     r_ab = (H.vanishing(alpha) - H.vanishing(beta)) * inv(alpha - beta) % R
     t_beta = (sigma['a'] + eta['b'] * sigma['b'] + eta['c'] * sigma['c']) % R
-    return {'mask': 1, 'z_a': r_ab * (1 + eta['c'] * zb_beta) % R, 'w': (-t_beta * X.vanishing(beta)) % R, 'h_1': (-H.vanishing(beta)) % R,
-            'const': (r_ab * eta['b'] % R * zb_beta - t_beta * x_beta - beta * g1_beta) % R}
+    const = (-beta * g1_beta) % R
+    for ci, zb, xb in zip(comb, zb_beta, x_beta): const = (const + ci * (r_ab * eta['b'] % R * zb - t_beta * xb)) % R
+    return {'mask': 1, 'z_a': [ci * r_ab % R * (1 + eta['c'] * zb) % R for ci, zb in zip(comb, zb_beta)],
+            'w': [(-ci * t_beta % R * X.vanishing(beta)) % R for ci in comb], 'h_1': (-H.vanishing(beta)) % R, 'const': const}
 
 
 def matrix_coefficients(H, K, alpha, beta, gamma, delta, sigma, g_gamma):
@@ -338,9 +366,10 @@ def matrix_coefficients(H, K, alpha, beta, gamma, delta, sigma, g_gamma):
 
 
 def proof_bytes(proof) -> bytes:
-    """The reference's Proof::to_bytes_le layout for one circuit with one instance (SURVEY.md §8c; 901 bytes)."""
+    """The reference's Proof::to_bytes_le layout for one circuit with k instances (SURVEY.md §8c; 901 bytes for k = 1)."""
     c = proof['commitments']; u64 = lambda v: int(v).to_bytes(8, 'little')
-    out = b'\x00' + u64(1) + u64(1) + c['w'] + c['z_a'] + c['z_b'] + b'\x01' + c['mask'] + c['g_1'] + c['h_1'] + c['g_a'] + c['g_b'] + c['g_c'] + c['h_2']
+    out = b'\x00' + u64(1) + u64(proof['instances']) + b''.join(w + a + b for w, a, b in proof['witness'])
+    out += b'\x01' + c['mask'] + c['g_1'] + c['h_1'] + c['g_a'] + c['g_b'] + c['g_c'] + c['h_2']
     out += b''.join(fr_bytes(v) for v in proof['evaluations']) + u64(1) + b''.join(fr_bytes(v) for v in proof['sums']) + u64(len(proof['openings']))
     for pt, rv in proof['openings']:
         out += pt + (b'\x01' + fr_bytes(rv) if rv is not None else b'\x00')
@@ -348,16 +377,17 @@ def proof_bytes(proof) -> bytes:
 
 
 def parse_proof(data: bytes):
-    assert data[0] == 0 and int.from_bytes(data[1:9], 'little') == 1 and int.from_bytes(data[9:17], 'little') == 1
+    assert data[0] == 0 and int.from_bytes(data[1:9], 'little') == 1
+    k = int.from_bytes(data[9:17], 'little'); assert 1 <= k <= 64
     pos = 17; c = {}
     def pt():
-        nonlocal pos; v = data[pos:pos + 48]; pos += 48; return v
+        nonlocal pos; v = data[pos:pos + 48]; pos += 48; assert len(v) == 48; return v
     def fr():
         nonlocal pos; v = int.from_bytes(data[pos:pos + 32], 'little'); pos += 32; assert v < R; return v
-    for k in ('w', 'z_a', 'z_b'): c[k] = pt()
+    witness = [(pt(), pt(), pt()) for _ in range(k)]
     assert data[pos] == 1; pos += 1
-    for k in ('mask', 'g_1', 'h_1', 'g_a', 'g_b', 'g_c', 'h_2'): c[k] = pt()
-    evals = [fr() for _ in range(5)]
+    for name in ('mask', 'g_1', 'h_1', 'g_a', 'g_b', 'g_c', 'h_2'): c[name] = pt()
+    evals = [fr() for _ in range(k + 4)]
     assert int.from_bytes(data[pos:pos + 8], 'little') == 1; pos += 8
     sums = [fr() for _ in range(3)]
     n_open = int.from_bytes(data[pos:pos + 8], 'little'); pos += 8
@@ -366,25 +396,30 @@ def parse_proof(data: bytes):
         p_ = pt(); tag = data[pos]; pos += 1
         openings.append((p_, fr() if tag else None))
     assert pos + 1 == len(data) and data[pos] == 0
-    return {'commitments': c, 'evaluations': evals, 'sums': sums, 'openings': openings}
+    return {'instances': k, 'witness': witness, 'commitments': c, 'evaluations': evals, 'sums': sums, 'openings': openings}
 
 
 def verify(index: Index, setup: Setup, public_inputs, data: bytes, vk_bytes=None) -> bool:
     """Verifier: recomputes the challenges, forms the two linear combinations of commitments and checks both KZG openings.  The pairing
-    equation e(C − v·G − v̄·γG, H) = e(W, (τ − z)·H) is checked as C − v·G − v̄·γG = (τ − z)·W in G1 with the known trapdoor."""
+    equation e(C − v·G − v̄·γG, H) = e(W, (τ − z)·H) is checked as C − v·G − v̄·γG = (τ − z)·W in G1 with the known trapdoor.
+    public_inputs: one list per instance (or a single list for one instance)."""
     try: pr = parse_proof(data)
     except AssertionError: return False
+    if public_inputs and not isinstance(public_inputs[0], (list, tuple)): public_inputs = [public_inputs]
+    k = pr['instances']
+    if len(public_inputs) != k: return False
     c = index.circuit; H, K, X = index.H, index.K, index.X
-    try: pts = {k: P.g1_decompress(v) for k, v in pr['commitments'].items()}; opn = [P.g1_decompress(p_) for p_, _ in pr['openings']]
+    try:
+        pts = {n_: P.g1_decompress(v) for n_, v in pr['commitments'].items()}; opn = [P.g1_decompress(p_) for p_, _ in pr['openings']]
+        wit = [tuple(P.g1_decompress(v) for v in t) for t in pr['witness']]
     except Exception: return False
     if len(opn) != 2 or pr['openings'][0][1] is None or pr['openings'][1][1] is not None: return False
-    x_evals = [public_inputs[i] % R if i < c.n_public else 0 for i in range(c.n_x)]
+    x_evals = [[pub[i] % R if i < c.n_public else 0 for i in range(c.n_x)] for pub in public_inputs]
     cb = pr['commitments']
     tr = Transcript(); tr.absorb(vk_bytes if vk_bytes is not None else index.vk_bytes())
-    tr.absorb(b''.join(fr_bytes(v) for v in x_evals))
-    tr.absorb(cb['w'] + cb['z_a'] + cb['z_b'] + cb['mask'])
-    alpha, eta_b, eta_c = tr.challenge(b'alpha'), tr.challenge(b'eta_b'), tr.challenge(b'eta_c')
-    eta = {'a': 1, 'b': eta_b, 'c': eta_c}
+    tr.absorb(b''.join(fr_bytes(v) for xe in x_evals for v in xe))
+    tr.absorb(b''.join(w + a + b for w, a, b in pr['witness']) + cb['mask'])
+    alpha, eta, comb = _challenges_after_round1(tr, k)
     tr.absorb(cb['g_1'] + cb['h_1']); beta = tr.challenge(b'beta')
     sigma = dict(zip('abc', pr['sums']))
     tr.absorb(b''.join(fr_bytes(sigma[m]) for m in 'abc') + cb['g_a'] + cb['g_b'] + cb['g_c'])
@@ -392,17 +427,18 @@ def verify(index: Index, setup: Setup, public_inputs, data: bytes, vk_bytes=None
     tr.absorb(cb['h_2']); gamma = tr.challenge(b'gamma')
     evals = pr['evaluations']
     tr.absorb(b''.join(fr_bytes(v) for v in evals)); xi = tr.challenge(b'xi')
-    zb_beta, g1_beta, ga, gb, gc = evals
+    zb_beta = evals[:k]; g1_beta, ga, gb, gc = evals[k:]
     G = P.G1_GENERATOR
     mul, add = P.g1_mul, P.g1_add
     tau_inv = inv(setup.tau); D = setup.max_degree
     def unshift(pt, bound): return mul(pt, pow(tau_inv, D - bound, R))
-    x_beta = poly_eval(X.ifft(x_evals), beta)
-    lc1 = lincheck_coefficients(H, X, alpha, beta, eta, sigma, zb_beta, g1_beta, x_beta)
-    C1 = add(add(mul(pts['mask'], lc1['mask']), mul(pts['z_a'], lc1['z_a'])), add(mul(pts['w'], lc1['w']), mul(pts['h_1'], lc1['h_1'])))
-    C1 = add(C1, mul(G, lc1['const']))
-    Cb = add(add(unshift(pts['g_1'], c.n_h - 2), mul(pts['z_b'], xi)), mul(C1, xi * xi % R))
-    v_beta = (g1_beta + xi * zb_beta) % R
+    x_beta = [poly_eval(X.ifft(xe), beta) for xe in x_evals]
+    lc1 = lincheck_coefficients(H, X, alpha, beta, eta, comb, sigma, zb_beta, g1_beta, x_beta)
+    C1 = add(add(mul(pts['mask'], lc1['mask']), mul(pts['h_1'], lc1['h_1'])), mul(G, lc1['const']))
+    for (w_, a_, b_), kz, kw in zip(wit, lc1['z_a'], lc1['w']): C1 = add(C1, add(mul(a_, kz), mul(w_, kw)))
+    Cb = add(unshift(pts['g_1'], c.n_h - 2), mul(C1, pow(xi, k + 1, R)))
+    for i, (w_, a_, b_) in enumerate(wit): Cb = add(Cb, mul(b_, pow(xi, 1 + i, R)))
+    v_beta = (g1_beta + sum(pow(xi, 1 + i, R) * v for i, v in enumerate(zb_beta))) % R
     lhs = add(Cb, P.g1_neg(mul(G, (v_beta + setup.s_gamma * pr['openings'][0][1]) % R)))
     if lhs != mul(opn[0], (setup.tau - beta) % R): return False
     lc2 = matrix_coefficients(H, K, alpha, beta, gamma, delta, sigma, {'a': ga, 'b': gb, 'c': gc})

@@ -25,7 +25,7 @@ def _max_degree(c):
     return d - 1
 
 
-def _rand(c, seed): return V.random_stream(seed, c.n_h)
+def _rand(c, seed, k=1): return V.random_stream(seed, c.n_h, k)
 
 
 def test_restatement_proves_and_verifies():
@@ -41,9 +41,9 @@ def test_restatement_proves_and_verifies():
     hrp, payload = pyref.bech32m_decode(ref['proof'])
     assert hrp == 'proof' and len(payload) == len(data) == 901
     parsed = V.parse_proof(payload)
-    names = {'mask_poly': 'mask'}
+    found = dict(parsed['commitments'], mask_poly=parsed['commitments']['mask'], **dict(zip(('w', 'z_a', 'z_b'), parsed['witness'][0])))
     for name, ent in ref['commitments'].items():
-        assert parsed['commitments'][names.get(name, name)].hex() == ent['compressed']
+        assert found[name].hex() == ent['compressed']
     assert [p_.hex() for p_, _ in parsed['openings']] == [o['compressed'] for o in ref['openings']]
     assert parsed['openings'][0][1] == int(ref['openings'][0]['random_v'], 16) and parsed['openings'][1][1] is None
     assert V.proof_bytes(parsed) == payload
@@ -63,6 +63,43 @@ def test_restatement_layout_round_trip():
     assert back['commitments'] == proof['commitments'] and back['evaluations'] == proof['evaluations'] and back['sums'] == proof['sums']
     assert V.proof_bytes(back) == data
     assert pyref.bech32m_encode('proof', data).startswith('proof1')
+
+
+def test_restatement_batch_of_instances():
+    """Varuna::prove_batch shape: k instances of one circuit share the mask, g_1, h_1 and everything after; 3k + 1 first-round commitments,
+    k + 4 evaluations.  The verifier needs every instance's public inputs, rejects a swapped pair and a tampered instance commitment."""
+    csr, z, c = _circuit(33, 3, 4)
+    zs = [z, synth.resolve_synthetic(csr, 3, [1, 5, 7]), synth.resolve_synthetic(csr, 3, [1, V.R - 2, 0])]
+    assert zs[0] == synth.resolve_synthetic(csr, 3, z[:3])
+    setup = V.Setup(TAU, S_GAMMA, _max_degree(c)); idx = V.Index(c, setup)
+    proof, data = V.prove(idx, setup, zs, _rand(c, 31, 3))
+    assert len(data) == 901 + 2 * (3 * 48 + 32) and proof['instances'] == 3
+    pubs = [q[:3] for q in zs]
+    assert V.verify(idx, setup, pubs, data)
+    assert not V.verify(idx, setup, [pubs[1], pubs[0], pubs[2]], data)
+    assert not V.verify(idx, setup, pubs[:2], data)
+    bad = bytearray(data); bad[17 + 48 * 5 + 3] ^= 1                          # z_b of the second instance
+    assert not V.verify(idx, setup, pubs, bytes(bad))
+    assert V.parse_proof(data)['witness'] == proof['witness'] and V.proof_bytes(V.parse_proof(data)) == data
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('k', [2, 3, 4])
+def test_device_prover_batch_matches_restatement(k):
+    from aleo_amd import varuna
+    csr, z, c = _circuit(150, 3, 40 + k)
+    zs = [z] + [synth.resolve_synthetic(csr, 3, [1, 10 + i, 20 * i + 1]) for i in range(1, k)]
+    D = _max_degree(c)
+    setup = V.Setup(TAU, S_GAMMA, D); idx = V.Index(c, setup)
+    _, want = V.prove(idx, setup, zs, _rand(c, 500 + k, k))
+    ck = varuna.synthetic_committer_key(TAU, S_GAMMA, D)
+    try:
+        ix = varuna.CircuitIndex(csr, 150, 3, len(z) - 3, ck)
+        got = varuna.prove(ix, [np.stack([synth.int_to_limbs(v, 4) for v in q]) for q in zs], 500 + k).to_bytes()
+        assert got == want and V.verify(idx, setup, [q[:3] for q in zs], got)
+        with pytest.raises(ValueError): varuna.prove(ix, [np.zeros((len(z), 4), dtype=np.uint64)] * 5, 1)
+    finally:
+        ck.close()
 
 
 @pytest.mark.gpu
