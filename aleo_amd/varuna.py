@@ -17,7 +17,7 @@ from .fft import EvaluationDomain, FORWARD, INVERSE
 from .kzg import CommitterKey, SonicKZG10, KZG10
 from .msm import PinnedBases
 from .poly import (fr_vec_op_device, fr_lin_device, fr_powers_device, fr_gather_mul_device, fr_eval_batch_device, fr_random_device, fr_lincomb_device,
-                   ahp_first_sumcheck_device, ahp_matrix_sumcheck_device, random_fr, spmv_device, divide_by_linear_device, OP_MUL, OP_ADD, OP_SUB)
+                   ahp_first_sumcheck_device, ahp_matrix_sumcheck_device, batch_inversion_device, random_fr, spmv_device, divide_by_linear_device, OP_MUL, OP_ADD, OP_SUB)
 
 R = synth.FR_MODULUS
 _RM = (1 << 256) % R
@@ -120,9 +120,11 @@ class CircuitIndex:
             # elements of H (NTT of the second unit vector), 1 / v_X on H \ X
             e1 = np.zeros((n_h, 4), dtype=np.uint64); e1[1] = one
             self.h_elems = _Vec(n_h, e1); self.H.ntt_device(self.h_elems.ptr(), stream=s)
-            ratio = n_h // n_x; wx = pow(_gen(n_h), n_x, R)
-            per = [0 if i == 0 else _inv(pow(wx, i, R) - 1) for i in range(ratio)]      # v_X(w^p) depends on p mod |H|/|X|
-            self.vx_inv = _Vec(n_h, np.tile(_mont_rows(per), (n_x, 1)))
+            ratio = n_h // n_x; wx = pow(_gen(n_h), n_x, R)                            # v_X(w^p) = wx^p − 1 depends on p mod |H|/|X|
+            self.vx_inv = _Vec(n_h)
+            fr_powers_device(self.vx_inv.ptr(), n_h, one, _mont(wx), s)
+            fr_lin_device(self.vx_inv.ptr(), n_h, _mont(R - 1), one, self.vx_inv.ptr(), stream=s)
+            batch_inversion_device(self.vx_inv.ptr(), n_h, s)                        # zeros (the positions of X) stay zero
             # arithmetisation over K: row, col, val, row_col
             self.k_evals = _Vec(12 * n_k, zero=True)                                            # [matrix][row, col, val, row_col][|K|]
             kidx = np.zeros((3, 2, n_k), dtype=np.uint32)                            # [matrix][row, col][|K|]: positions on H (padding: 0, the element 1)

@@ -145,3 +145,32 @@ def test_device_prover_verifies_at_2_13():
         assert not V.verify(idx, setup, z[:4], varuna.prove(ix, z2, 77).to_bytes())
     finally:
         ck.close()
+
+
+@pytest.mark.gpu
+def test_device_prover_concurrent_streams():
+    """Proofs of one index from three host threads, each on its own stream, equal the proofs produced one after the other (the index is
+    read-only while proving; scratch inside the library is per call slot and stream-ordered)."""
+    import threading, torch
+    from aleo_amd import varuna
+    csr, z, c = _circuit(900, 3, 61)
+    D = _max_degree(c)
+    ck = varuna.synthetic_committer_key(TAU, S_GAMMA, D)
+    try:
+        ix = varuna.CircuitIndex(csr, 900, 3, len(z) - 3, ck)
+        zz = np.stack([synth.int_to_limbs(v, 4) for v in z])
+        want = {(t, r): varuna.prove(ix, zz, 9000 + 10 * t + r).to_bytes() for t in range(3) for r in range(3)}
+        got, err = {}, []
+        def work(t):
+            try:
+                st = torch.cuda.Stream()
+                for r in range(3): got[(t, r)] = varuna.prove(ix, zz, 9000 + 10 * t + r, st).to_bytes()
+            except Exception as e: err.append(e)
+        th = [threading.Thread(target=work, args=(t,)) for t in range(3)]
+        for x in th: x.start()
+        for x in th: x.join()
+        assert not err and got == want
+        setup = V.Setup(TAU, S_GAMMA, D); idx = V.Index(c, setup)
+        assert V.verify(idx, setup, z[:3], got[(2, 2)])
+    finally:
+        ck.close()
