@@ -236,6 +236,10 @@ static void jacobian_to_affine104(void* out104, const uint64_t* jac18) {
   std::memcpy(o, jac18, 96);   // results are normalised: z == 1
 }
 
+void jacobian_rows_to_affine104(void* out104, const uint64_t* jac18, size_t k) {
+  for (size_t q = 0; q < k; ++q) jacobian_to_affine104((uint8_t*)out104 + 104 * q, jac18 + 18 * q);
+}
+
 }  // namespace aleo_mi355x
 
 using namespace aleo_mi355x;
@@ -605,6 +609,22 @@ int32_t aleo_mi355x_fr_eval_batch_device(void* d_out, const void* const* d_polys
     API_BEGIN
     return run_enqueue(c, stream, [&](hipStream_t s) { return fr_eval_batch(c, d_out, d_polys, lens, z_mont, k, s); });
   } catch (...) { return ALEO_MI355X_ERR_HIP; }
+}
+
+int32_t aleo_mi355x_varuna_prove(const aleo_mi355x_varuna_index* index, const void* const* assignments, size_t n_instances, uint64_t seed, void* out_proof, size_t* len) {
+  try {
+    if (!index || !assignments || !out_proof || !len || !index->positions || !index->vk_bytes) { g_last_error = "varuna_prove: null argument"; return ALEO_MI355X_ERR_BAD_ARG; }
+    for (size_t i = 0; i < n_instances && i < 4; ++i) if (!assignments[i]) { g_last_error = "varuna_prove: null assignment"; return ALEO_MI355X_ERR_BAD_ARG; }
+    API_BEGIN
+    FIND_BASES(index->committer_key)
+    return varuna_prove(c, pb, *index, assignments, n_instances, seed, (uint8_t*)out_proof, len);
+  } catch (...) { return ALEO_MI355X_ERR_HIP; }
+}
+
+int32_t aleo_mi355x_varuna_last_timing(double* out_ms, int32_t cap) {
+  int32_t n = cap < 6 ? cap : 6;
+  for (int32_t i = 0; i < n; ++i) out_ms[i] = g_varuna_timing[i];
+  return n;
 }
 
 int32_t aleo_mi355x_fr_random_device(void* d_dst, size_t n, uint64_t seed, uint64_t first_index, int32_t montgomery, void* stream) {

@@ -100,6 +100,7 @@ struct Ctx {                           // one concurrency slot
   // MSM workspaces
   DevBuf hist, scan_local, scan_blk, sorted, part_cnt, part_items, partial, task_g, meta, vbuf, scalars_stage, out_stage;
   void* h_pinned = nullptr; size_t h_pinned_cap = 0;    // pinned host staging for small D2H results
+  DevBuf prover_ws; void* prover_pin = nullptr; size_t prover_pin_cap = 0;      // varuna.hip: one proof's device workspace, pinned staging of the assignments
   MsmTiming last_msm;
   DevBuf ntt_tmp, ntt_stage;
   // ntt_tmp is scratch of the *_device entry points, which enqueue on the CALLER's stream and return without synchronising;
@@ -165,6 +166,10 @@ int32_t fr_vec_op(Ctx* c, void* d_dst, const void* d_a, const void* d_b, size_t 
 int32_t fr_batch_inverse(Ctx* c, void* d_inout, size_t n, hipStream_t s);
 int32_t fr_divide_by_linear(Ctx* c, void* d_q, void* d_eval, const void* d_p, size_t n, const void* z_mont32, hipStream_t s);
 int32_t fr_spmv(Ctx* c, void* d_y, const void* d_row_ptr, const void* d_col, const void* d_vals, const void* d_x, size_t rows, hipStream_t s);
+// varuna.hip / api.hip
+int32_t varuna_prove(Ctx* c, const PinnedBases& pb, const aleo_mi355x_varuna_index& ix, const void* const* assignments, size_t k, uint64_t seed, uint8_t* out, size_t* out_len);
+extern thread_local double g_varuna_timing[8];
+void jacobian_rows_to_affine104(void* out104, const uint64_t* jac18, size_t k);
 // ntt.hip
 int32_t ntt_run(Ctx* c, void* d_inout, uint32_t lg_n, size_t batch, int32_t order, int32_t direction, int32_t type, hipStream_t s);
 

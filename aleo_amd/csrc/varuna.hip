@@ -1,0 +1,399 @@
+// varuna.hip — the host side of one proof, native: the four AHP rounds, the evaluations and the two openings of
+// `Varuna::prove_batch` (one circuit, up to four instances) as ONE call of the C ABI (`aleo_mi355x_varuna_prove`).
+//
+// Replaces (shape, not bytes — see DESIGN.md §4d for what differs from upstream and why) snarkVM 0.14.5
+//   algorithms/src/snark/varuna/varuna.rs                      Varuna::prove_batch
+//   algorithms/src/snark/varuna/ahp/prover/round_functions/*   AHPForR1CS::prover_{first,second,third,fourth}_round   [UPSTREAM-RECALL]
+// reached from /root/reference/rust/src/program/execute.rs:74 (`trace.prove_execution`) and transfer.rs:99.
+// Every circuit-sized step is a kernel of msm.hip / ntt.hip / frops.hip queued on the calling slot's stream; this file keeps what
+// upstream keeps on the CPU between them: the transcript, the challenge-dependent constants (host Fr arithmetic, host_field.hpp)
+// and the O(|X|) public-input polynomial.  aleo_amd/varuna.py is the same sequence written against the public entry points; both
+// must produce the bytes of the restatement in oracle/varuna_ref.py (tests/test_varuna.py).
+#include "ctx.h"
+#include "host_field.hpp"
+#include <cstring>
+#include <vector>
+#include <chrono>
+
+namespace aleo_mi355x {
+
+using host::HFr;
+
+// ---- SHA-256 (FIPS 180-4) for the transcript -------------------------------------------------------------------------------------
+namespace {
+struct Sha256 {
+  uint32_t h[8]; uint8_t buf[64]; uint64_t len = 0; size_t fill = 0;
+  static uint32_t rotr(uint32_t x, int n) { return (x >> n) | (x << (32 - n)); }
+  Sha256() { static const uint32_t iv[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19}; std::memcpy(h, iv, 32); }
+  void block(const uint8_t* p) {
+    static const uint32_t K[64] = {
+      0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5, 0xd807aa98, 0x12835b01, 0x243185be, 0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174,
+      0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc, 0x2de92c6f, 0x4a7484aa, 0x5cb0a9dc, 0x76f988da, 0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147, 0x06ca6351, 0x14292967,
+      0x27b70a85, 0x2e1b2138, 0x4d2c6dfc, 0x53380d13, 0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85, 0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3, 0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070,
+      0x19a4c116, 0x1e376c08, 0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f, 0x682e6ff3, 0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208, 0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
+    uint32_t w[64];
+    for (int i = 0; i < 16; ++i) w[i] = ((uint32_t)p[4 * i] << 24) | ((uint32_t)p[4 * i + 1] << 16) | ((uint32_t)p[4 * i + 2] << 8) | p[4 * i + 3];
+    for (int i = 16; i < 64; ++i) {
+      uint32_t s0 = rotr(w[i - 15], 7) ^ rotr(w[i - 15], 18) ^ (w[i - 15] >> 3), s1 = rotr(w[i - 2], 17) ^ rotr(w[i - 2], 19) ^ (w[i - 2] >> 10);
+      w[i] = w[i - 16] + s0 + w[i - 7] + s1;
+    }
+    uint32_t a = h[0], b = h[1], c = h[2], d = h[3], e = h[4], f = h[5], g = h[6], hh = h[7];
+    for (int i = 0; i < 64; ++i) {
+      uint32_t S1 = rotr(e, 6) ^ rotr(e, 11) ^ rotr(e, 25), ch = (e & f) ^ (~e & g), t1 = hh + S1 + ch + K[i] + w[i];
+      uint32_t S0 = rotr(a, 2) ^ rotr(a, 13) ^ rotr(a, 22), mj = (a & b) ^ (a & c) ^ (b & c), t2 = S0 + mj;
+      hh = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
+    }
+    h[0] += a; h[1] += b; h[2] += c; h[3] += d; h[4] += e; h[5] += f; h[6] += g; h[7] += hh;
+  }
+  void update(const void* data, size_t n) {
+    const uint8_t* p = (const uint8_t*)data; len += n;
+    while (n) {
+      size_t take = 64 - fill < n ? 64 - fill : n;
+      std::memcpy(buf + fill, p, take); fill += take; p += take; n -= take;
+      if (fill == 64) { block(buf); fill = 0; }
+    }
+  }
+  void finish(uint8_t out[32]) {
+    uint64_t bits = len * 8; uint8_t pad = 0x80; update(&pad, 1);
+    uint8_t z = 0; while (fill != 56) update(&z, 1);
+    uint8_t lb[8]; for (int i = 0; i < 8; ++i) lb[i] = (uint8_t)(bits >> (56 - 8 * i));
+    update(lb, 8);
+    for (int i = 0; i < 8; ++i) { out[4 * i] = (uint8_t)(h[i] >> 24); out[4 * i + 1] = (uint8_t)(h[i] >> 16); out[4 * i + 2] = (uint8_t)(h[i] >> 8); out[4 * i + 3] = (uint8_t)h[i]; }
+  }
+};
+
+const char LABEL[] = "aleo-mi355x/varuna-synthetic/v1";
+
+// state = SHA-256(state ‖ data); a challenge is the new state read as a little-endian integer mod r
+struct Transcript {
+  uint8_t state[32];
+  Transcript() { Sha256 s; s.update(LABEL, sizeof LABEL - 1); s.finish(state); }
+  void absorb(const void* data, size_t n) { Sha256 s; s.update(state, 32); s.update(data, n); s.finish(state); }
+  HFr challenge(const char* label, size_t n) {           // Montgomery form
+    absorb(label, n);
+    uint64_t v[4]; std::memcpy(v, state, 32);
+    HFr c = HFr::reduce_lazy(v);                           // < 2^256 < 14 r: a few subtractions
+    return HFr::to_mont(c);
+  }
+};
+
+inline uint64_t mix64(uint64_t z) { z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; return z ^ (z >> 31); }
+// element `index` of the proof's random stream (same definition as k_fr_random in frops.hip), Montgomery form
+HFr random_fr(uint64_t seed, uint64_t index) {
+  for (uint64_t j = 0;; ++j) {
+    uint64_t l[4];
+    for (int k = 0; k < 4; ++k) l[k] = mix64(seed + (4 * index + (uint64_t)k + 1) * 0x9E3779B97F4A7C15ull + j * 0xD1B54A32D192ED03ull);
+    l[3] &= (1ull << 61) - 1;
+    if (!HFr::geq_p(l)) { HFr v; std::memcpy(v.l, l, 32); return HFr::to_mont(v); }
+  }
+}
+
+inline HFr fr_u64(uint64_t v) { return HFr::from_u64(v); }
+inline HFr vanish(uint64_t size, const HFr& x) { return HFr::sub(HFr::pow_u64(x, size), HFr::one()); }     // x^size − 1
+inline void fr_bytes(uint8_t* out, const HFr& m) { HFr c = HFr::from_mont(m); std::memcpy(out, c.l, 32); }
+inline HFr domain_gen(uint64_t size) {                    // TWO_ADIC_ROOT^(2^(47 − lg size))
+  HFr g; std::memcpy(g.l, host::FR_TWO_ADIC_ROOT_CANON, 32); g = HFr::to_mont(g);
+  int lg = 0; while ((1ull << lg) < size) ++lg;
+  for (int i = lg; i < host::FR_TWO_ADICITY; ++i) g = HFr::sqr(g);
+  return g;
+}
+inline HFr horner(const std::vector<HFr>& p, const HFr& x) { HFr a = HFr::zero(); for (size_t i = p.size(); i-- > 0;) a = HFr::add(HFr::mul(a, x), p[i]); return a; }
+
+struct Arena {                                             // bump allocation inside the slot's prover workspace
+  char* base; size_t off = 0, cap;
+  char* take(size_t elems) { char* p = base + off; off += (elems * 32 + 255) & ~(size_t)255; return off <= cap ? p : nullptr; }
+};
+#define TAKE(var, elems) char* var = ar.take(elems); if (!var) { g_last_error = "varuna_prove: workspace accounting"; return ALEO_MI355X_ERR_HIP; }
+#define RC(call) { int32_t rc_ = (call); if (rc_) return rc_; }
+
+double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+}  // namespace
+
+thread_local double g_varuna_timing[8] = {};
+
+static int32_t commit(Ctx* c, const PinnedBases& pb, const std::vector<MsmSeg>& segs, uint32_t k, uint8_t* out104, hipStream_t s) {
+  std::vector<uint64_t> jac(18 * (size_t)k);
+  MsmJob j; j.segs = segs.data(); j.nseg = (uint32_t)segs.size(); j.k = k; j.mont = true;
+  RC(msm_batch(c, jac.data(), pb, j, s));
+  jacobian_rows_to_affine104(out104, jac.data(), k);
+  return ALEO_MI355X_OK;
+}
+
+int32_t varuna_prove(Ctx* c, const PinnedBases& pb, const aleo_mi355x_varuna_index& ix, const void* const* assignments, size_t k, uint64_t seed,
+                     uint8_t* out, size_t* out_len) {
+  const size_t n_h = ix.n_h, n_k = ix.n_k, n_x = ix.n_x, L = n_h + 1, n4 = 4 * n_h, n2 = 2 * n_k, HC = 3;      // HC: coefficients of a hiding polynomial
+  const uint64_t D = ix.max_degree;
+  if (k < 1 || k > 4 || n_h < 2 || n_k < 2 || n_x < 1 || n_h < 2 * n_x || (n_h & (n_h - 1)) || (n_k & (n_k - 1)) || (n_x & (n_x - 1)) ||
+      ix.n_public > n_x || ix.n_vars > n_h || ix.gamma_offset + HC > pb.n || D + 1 > pb.n || 3 * n_h > D + 1 || n_k > D + 1) {
+    g_last_error = "varuna_prove: inconsistent index / key sizes"; return ALEO_MI355X_ERR_BAD_ARG;
+  }
+  uint32_t lg_h = 0, lg_k = 0; while ((1ull << lg_h) < n_h) ++lg_h; while ((1ull << lg_k) < n_k) ++lg_k;
+  hipStream_t s = c->stream;
+  double t_mark[7]; t_mark[0] = now_ms();
+  // ---- workspace ------------------------------------------------------------------------------------------------------------------
+  const size_t elems = n_h * (40 + 20 * k) + n_k * 16 + 4096;
+  RC(c->prover_ws.reserve(elems * 32 + (64 << 10)));
+  Arena ar{(char*)c->prover_ws.p, 0, c->prover_ws.cap};
+  const size_t pin_need = k * n_h * 32 + 4096;
+  if (c->prover_pin_cap < pin_need) {
+    if (c->prover_pin) { HIPCHK(hipStreamSynchronize(s)); (void)hipHostFree(c->prover_pin); c->prover_pin = nullptr; c->prover_pin_cap = 0; }
+    HIPCHK(hipHostMalloc(&c->prover_pin, pin_need + pin_need / 8, hipHostMallocDefault)); c->prover_pin_cap = pin_need + pin_need / 8;
+  }
+  char* pin = (char*)c->prover_pin; char* pin_small = pin + k * n_h * 32;      // 4 KB for small read-backs
+  const HFr one = HFr::one(), neg1 = HFr::neg(one);
+  HFr r2; std::memcpy(r2.l, host::HParams<4>::R2, 32);
+  Transcript tr;
+  // randomness layout (oracle/varuna_ref.py randomness_layout)
+  const uint64_t lay_mask = 3 * k, lay_blind = 3 * k + 3 * n_h, lay_blind_mask = lay_blind + 3 * HC * k;
+  // ---- round 1 ------------------------------------------------------------------------------------------------------------------------
+  TAKE(zH, k * n_h) TAKE(ev, 3 * k * n_h) TAKE(xh, k * n_h) TAKE(wit, 3 * k * L) TAKE(mask, 3 * n_h) TAKE(bl, (3 * k + 1) * HC)
+  std::vector<std::vector<HFr>> x_poly(k); std::vector<uint8_t> x_bytes(k * n_x * 32, 0);
+  const HFr gx_inv = HFr::inv(domain_gen(n_x)), nx_inv = HFr::inv(fr_u64(n_x));
+  std::memset(pin, 0, k * n_h * 32);
+  const uint32_t* pos = (const uint32_t*)ix.positions;
+  for (size_t i = 0; i < k; ++i) {
+    const uint8_t* z = (const uint8_t*)assignments[i];
+    for (size_t v = 0; v < ix.n_vars; ++v) {
+      if (pos[v] >= n_h) { g_last_error = "varuna_prove: variable position outside H"; return ALEO_MI355X_ERR_BAD_ARG; }
+      std::memcpy(pin + (i * n_h + pos[v]) * 32, z + v * 32, 32);
+    }
+    std::vector<HFr> xe(n_x, HFr::zero());
+    for (size_t j = 0; j < ix.n_public; ++j) { HFr v; std::memcpy(v.l, z + j * 32, 32); if (HFr::geq_p(v.l)) { g_last_error = "varuna_prove: assignment not canonical"; return ALEO_MI355X_ERR_BAD_ARG; } std::memcpy(&x_bytes[(i * n_x + j) * 32], v.l, 32); xe[j] = HFr::to_mont(v); }
+    x_poly[i].assign(n_x, HFr::zero());                    // inverse DFT over X, O(|X|^2): |X| is the (padded) number of public inputs
+    HFr wa = one;                                          // gx_inv^a
+    for (size_t a = 0; a < n_x; ++a) {
+      HFr acc = HFr::zero(), w = one;
+      for (size_t j = 0; j < n_x; ++j) { acc = HFr::add(acc, HFr::mul(xe[j], w)); w = HFr::mul(w, wa); }
+      x_poly[i][a] = HFr::mul(acc, nx_inv); wa = HFr::mul(wa, gx_inv);
+    }
+  }
+  HIPCHK(hipMemcpyAsync(zH, pin, k * n_h * 32, hipMemcpyHostToDevice, s));
+  RC(fr_lin(c, zH, k * n_h, nullptr, r2.l, zH, nullptr, nullptr, s));                     // canonical -> Montgomery
+  HIPCHK(hipMemsetAsync(xh, 0, k * n_h * 32, s));
+  for (size_t i = 0; i < k; ++i) {
+    char* e0 = ev + 3 * i * n_h * 32; char* z_i = zH + i * n_h * 32; char* xh_i = xh + i * n_h * 32;
+    RC(fr_spmv(c, e0 + n_h * 32, ix.a_row_ptr, ix.a_col, ix.a_val, z_i, n_h, s));
+    RC(fr_spmv(c, e0 + 2 * n_h * 32, ix.b_row_ptr, ix.b_col, ix.b_val, z_i, n_h, s));
+    HIPCHK(hipMemcpyAsync(xh_i, x_poly[i].data(), n_x * 32, hipMemcpyHostToDevice, s));     // pageable, tiny: copied before the call returns
+    RC(ntt_run(c, xh_i, lg_h, 1, 0, 0, 0, s));
+    RC(fr_vec_op(c, e0, z_i, xh_i, n_h, 2, s));                                             // z − x̂ on H
+    RC(fr_vec_op(c, e0, e0, ix.vx_inv, n_h, 0, s));                                         // / v_X off X, 0 on X
+  }
+  RC(ntt_run(c, ev, lg_h, 3 * k, 0, 1, 0, s));
+  std::vector<HFr> blind((3 * k + 1) * HC);
+  for (size_t q = 0; q < 3 * k; ++q) {
+    const HFr rho = random_fr(seed, q);                                                     // rho_w, rho_a, rho_b of instance q / 3
+    char* p = wit + q * L * 32;
+    HIPCHK(hipMemcpyAsync(p, ev + q * n_h * 32, n_h * 32, hipMemcpyDeviceToDevice, s));
+    HFr nrho = HFr::neg(rho);
+    RC(fr_lin(c, p, 1, nrho.l, one.l, p, nullptr, nullptr, s));                             // + rho (X^|H| − 1)
+    RC(fr_lin(c, p + n_h * 32, 1, rho.l, nullptr, nullptr, nullptr, nullptr, s));
+    for (size_t j = 0; j < HC; ++j) blind[q * HC + j] = random_fr(seed, lay_blind + HC * q + j);
+  }
+  for (size_t j = 0; j < HC; ++j) blind[3 * k * HC + j] = random_fr(seed, lay_blind_mask + j);
+  RC(fr_random(c, mask, 3 * n_h, seed, lay_mask, 1, s));
+  RC(fr_lin(c, mask, 1, nullptr, neg1.l, mask + n_h * 32, neg1.l, mask + 2 * n_h * 32, s));   // sum over H = |H| (m_0 + m_|H| + m_2|H|) = 0
+  HIPCHK(hipMemcpyAsync(bl, blind.data(), blind.size() * 32, hipMemcpyHostToDevice, s));
+  std::vector<uint8_t> wit_aff(104 * (3 * k + 1)), comp(48 * 8);
+  {
+    std::vector<MsmSeg> sg;
+    for (size_t q = 0; q <= 3 * k; ++q) {
+      MsmSeg a; a.d_ptr = q < 3 * k ? wit + q * L * 32 : mask; a.len = q < 3 * k ? L : 3 * n_h; a.off = 0; a.out = (uint32_t)q; sg.push_back(a);
+      MsmSeg b; b.d_ptr = bl + q * HC * 32; b.len = HC; b.off = ix.gamma_offset; b.out = (uint32_t)q; sg.push_back(b);
+    }
+    RC(commit(c, pb, sg, (uint32_t)(3 * k + 1), wit_aff.data(), s));
+  }
+  std::vector<uint8_t> c1(48 * (3 * k + 1));
+  RC(aleo_mi355x_g1_compress(c1.data(), wit_aff.data(), 3 * k + 1));
+  tr.absorb(ix.vk_bytes, ix.vk_len); tr.absorb(x_bytes.data(), x_bytes.size()); tr.absorb(c1.data(), c1.size());
+  const HFr alpha = tr.challenge("alpha", 5), eta_b = tr.challenge("eta_b", 5), eta_c = tr.challenge("eta_c", 5);
+  std::vector<HFr> comb(k, one);
+  for (size_t i = 1; i < k; ++i) { char lab[12] = "combiner"; uint32_t ii = (uint32_t)i; std::memcpy(lab + 8, &ii, 4); comb[i] = tr.challenge(lab, 12); }
+  t_mark[1] = now_ms();
+  // ---- round 2: the first sumcheck --------------------------------------------------------------------------------------------------------
+  const HFr vh_alpha = vanish(n_h, alpha);
+  if (vh_alpha.is_zero()) { g_last_error = "varuna_prove: alpha landed in H"; return ALEO_MI355X_ERR_HIP; }
+  TAKE(ext, 3 * n_h) TAKE(rt, 2 * n_h) TAKE(E, (2 + 3 * k) * n4) TAKE(xp, k * n_x) TAKE(Q, n4) TAKE(h1, 2 * n_h) TAKE(g1, n_h)
+  {
+    const HFr first = HFr::pow_u64(alpha, n_h - 1), ratio = HFr::inv(alpha);
+    RC(fr_powers(c, rt, n_h, first.l, ratio.l, s));                                          // r(alpha, X) = sum_k alpha^(|H|-1-k) X^k
+  }
+  HIPCHK(hipMemcpyAsync(ext, rt, n_h * 32, hipMemcpyDeviceToDevice, s));
+  RC(ntt_run(c, ext, lg_h, 1, 0, 0, 0, s));                                                 // v_H(alpha) / (alpha − h) on H: no inversion on the device
+  RC(fr_lin(c, ext + n_h * 32, n_h, nullptr, eta_b.l, ext, nullptr, nullptr, s));
+  RC(fr_lin(c, ext + 2 * n_h * 32, n_h, nullptr, eta_c.l, ext, nullptr, nullptr, s));
+  RC(fr_spmv(c, rt + n_h * 32, ix.t_row_ptr, ix.t_col, ix.t_val, ext, n_h, s));
+  RC(ntt_run(c, rt + n_h * 32, lg_h, 1, 0, 1, 0, s));                                       // t(X)
+  HIPCHK(hipMemsetAsync(E, 0, (2 + 3 * k) * n4 * 32, s));
+  HIPCHK(hipMemcpyAsync(E, rt, n_h * 32, hipMemcpyDeviceToDevice, s));
+  HIPCHK(hipMemcpyAsync(E + n4 * 32, rt + n_h * 32, n_h * 32, hipMemcpyDeviceToDevice, s));
+  for (size_t i = 0; i < k; ++i) {
+    char* zp = E + (2 + 3 * i) * n4 * 32; const char* w_i = wit + (3 * i) * L * 32;          // ẑ_i = w_i (X^|X| − 1) + x̂_i
+    RC(fr_lin(c, zp, L, nullptr, neg1.l, w_i, nullptr, nullptr, s));
+    RC(fr_vec_op(c, zp + n_x * 32, zp + n_x * 32, w_i, L, 1, s));
+    HIPCHK(hipMemcpyAsync(xp + i * n_x * 32, x_poly[i].data(), n_x * 32, hipMemcpyHostToDevice, s));
+    RC(fr_vec_op(c, zp, zp, xp + i * n_x * 32, n_x, 1, s));
+    HIPCHK(hipMemcpyAsync(zp + n4 * 32, wit + (3 * i + 1) * L * 32, L * 32, hipMemcpyDeviceToDevice, s));
+    HIPCHK(hipMemcpyAsync(zp + 2 * n4 * 32, wit + (3 * i + 2) * L * 32, L * 32, hipMemcpyDeviceToDevice, s));
+  }
+  RC(ntt_run(c, E, lg_h + 2, 2 + 3 * k, 0, 0, 0, s));
+  for (size_t i = 0; i < k; ++i) {
+    char* e_z = E + (2 + 3 * i) * n4 * 32;
+    RC(ahp_first_sumcheck(c, e_z + n4 * 32, n4, E, e_z + n4 * 32, e_z + 2 * n4 * 32, E + n4 * 32, e_z, eta_b.l, eta_c.l, s));
+  }
+  char* q1 = E + 3 * n4 * 32;
+  if (k > 1) {
+    const void* terms[4]; size_t lens[4]; HFr co[4];
+    for (size_t i = 0; i < k; ++i) { terms[i] = E + (3 + 3 * i) * n4 * 32; lens[i] = n4; co[i] = comb[i]; }
+    RC(fr_lincomb(c, Q, n4, nullptr, terms, lens, co, k, s)); q1 = Q;
+  }
+  RC(ntt_run(c, q1, lg_h + 2, 1, 0, 1, 0, s));
+  RC(fr_vec_op(c, q1, q1, mask, 3 * n_h, 1, s));                                            // q_1 = h_1 (X^|H| − 1) + X g_1, degree < 3|H|
+  HIPCHK(hipMemcpyAsync(h1 + n_h * 32, q1 + 2 * n_h * 32, n_h * 32, hipMemcpyDeviceToDevice, s));   // quotient blocks: p2, p1 + p2; remainder p0 + p1 + p2
+  RC(fr_vec_op(c, h1, q1 + n_h * 32, q1 + 2 * n_h * 32, n_h, 1, s));
+  RC(fr_vec_op(c, g1, q1, h1, n_h, 1, s));
+  uint8_t aff2[208], aff3[312], aff4[104], aff5[208];
+  {
+    std::vector<MsmSeg> sg(2);
+    sg[0].d_ptr = g1 + 32; sg[0].len = n_h - 1; sg[0].off = D - (n_h - 2); sg[0].out = 0;    // degree bound |H| − 2: shifted powers
+    sg[1].d_ptr = h1; sg[1].len = 2 * n_h; sg[1].off = 0; sg[1].out = 1;
+    RC(commit(c, pb, sg, 2, aff2, s));
+  }
+  RC(aleo_mi355x_g1_compress(comp.data(), aff2, 2)); tr.absorb(comp.data(), 96);
+  const HFr beta = tr.challenge("beta", 4);
+  t_mark[2] = now_ms();
+  // ---- round 3: three rational sumchecks over K ----------------------------------------------------------------------------------------------
+  const HFr vh_beta = vanish(n_h, beta);
+  if (vh_beta.is_zero()) { g_last_error = "varuna_prove: beta landed in H"; return ALEO_MI355X_ERR_HIP; }
+  const HFr vv = HFr::mul(vh_alpha, vh_beta);
+  TAKE(f, 3 * n_k) TAKE(rb, n_h)
+  {
+    const HFr first = HFr::pow_u64(beta, n_h - 1), ratio = HFr::inv(beta);
+    RC(fr_powers(c, rb, n_h, first.l, ratio.l, s));
+  }
+  RC(ntt_run(c, rb, lg_h, 1, 0, 0, 0, s));
+  for (size_t m = 0; m < 3; ++m)                                                             // f_M = val u_H(alpha, row) u_H(beta, col) on K: two gathers
+    RC(fr_gather_mul(c, f + m * n_k * 32, n_k, (const char*)ix.k_evals + (4 * m + 2) * n_k * 32, ext, (const uint32_t*)ix.k_idx + (2 * m) * n_k, rb,
+                     (const uint32_t*)ix.k_idx + (2 * m + 1) * n_k, s));
+  RC(ntt_run(c, f, lg_k, 3, 0, 1, 0, s));
+  for (size_t m = 0; m < 3; ++m) HIPCHK(hipMemcpyAsync(pin_small + 32 * m, f + m * n_k * 32, 32, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  HFr sigma[3]; uint8_t sig_bytes[96];
+  for (size_t m = 0; m < 3; ++m) { HFr v; std::memcpy(v.l, pin_small + 32 * m, 32); sigma[m] = HFr::mul(v, fr_u64(n_k)); fr_bytes(sig_bytes + 32 * m, sigma[m]); }
+  {
+    std::vector<MsmSeg> sg(3);
+    for (size_t m = 0; m < 3; ++m) { sg[m].d_ptr = f + (m * n_k + 1) * 32; sg[m].len = n_k - 1; sg[m].off = D - (n_k - 2); sg[m].out = (uint32_t)m; }
+    RC(commit(c, pb, sg, 3, aff3, s));
+  }
+  RC(aleo_mi355x_g1_compress(comp.data(), aff3, 3));
+  { uint8_t b[96 + 144]; std::memcpy(b, sig_bytes, 96); std::memcpy(b + 96, comp.data(), 144); tr.absorb(b, sizeof b); }
+  HFr delta[3] = {one, tr.challenge("delta_b", 7), tr.challenge("delta_c", 7)};
+  t_mark[3] = now_ms();
+  // ---- round 4 ----------------------------------------------------------------------------------------------------------------------------------
+  TAKE(F, 3 * n2) TAKE(B, n2) TAKE(h2, n_k)
+  HIPCHK(hipMemsetAsync(F, 0, 3 * n2 * 32, s));
+  for (size_t m = 0; m < 3; ++m) HIPCHK(hipMemcpyAsync(F + m * n2 * 32, f + m * n_k * 32, n_k * 32, hipMemcpyDeviceToDevice, s));
+  RC(ntt_run(c, F, lg_k + 1, 3, 0, 0, 0, s));
+  {
+    const void* idx[3]; const void* ff[3]; HFr consts[7] = {delta[0], delta[1], delta[2], HFr::mul(alpha, beta), HFr::neg(alpha), HFr::neg(beta), vv};
+    for (size_t m = 0; m < 3; ++m) { idx[m] = (const char*)ix.k2_evals + 4 * m * n2 * 32; ff[m] = F + m * n2 * 32; }
+    RC(ahp_matrix_sumcheck(c, B, n2, idx, n2, ff, consts, s));
+  }
+  RC(ntt_run(c, B, lg_k + 1, 1, 0, 1, 0, s));
+  HIPCHK(hipMemcpyAsync(h2, B + n_k * 32, n_k * 32, hipMemcpyDeviceToDevice, s));             // P = h_2 (X^|K| − 1)
+  {
+    std::vector<MsmSeg> sg(1); sg[0].d_ptr = h2; sg[0].len = n_k; sg[0].off = 0; sg[0].out = 0;
+    RC(commit(c, pb, sg, 1, aff4, s));
+  }
+  RC(aleo_mi355x_g1_compress(comp.data(), aff4, 1)); tr.absorb(comp.data(), 48);
+  const HFr gamma = tr.challenge("gamma", 5);
+  t_mark[4] = now_ms();
+  // ---- evaluations -------------------------------------------------------------------------------------------------------------------------------
+  TAKE(evd, k + 8) TAKE(pbeta, 3 * n_h) TAKE(wq, 3 * n_h) TAKE(blq, HC) TAKE(pg, n_k) TAKE(gq, n_k)
+  {
+    const void* polys[8]; size_t lens[8]; HFr pts[8];
+    for (size_t i = 0; i < k; ++i) { polys[i] = wit + (3 * i + 2) * L * 32; lens[i] = L; pts[i] = beta; }
+    polys[k] = g1 + 32; lens[k] = n_h - 1; pts[k] = beta;
+    for (size_t m = 0; m < 3; ++m) { polys[k + 1 + m] = f + (m * n_k + 1) * 32; lens[k + 1 + m] = n_k - 1; pts[k + 1 + m] = gamma; }
+    RC(fr_eval_batch(c, evd, polys, lens, pts, k + 4, s));
+  }
+  HIPCHK(hipMemcpyAsync(pin_small, evd, (k + 4) * 32, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  std::vector<HFr> evals(k + 4); std::vector<uint8_t> ev_bytes((k + 4) * 32);
+  for (size_t i = 0; i < k + 4; ++i) { std::memcpy(evals[i].l, pin_small + 32 * i, 32); fr_bytes(&ev_bytes[32 * i], evals[i]); }
+  tr.absorb(ev_bytes.data(), ev_bytes.size());
+  const HFr xi = tr.challenge("xi", 2);
+  const HFr g1_beta = evals[k], ga = evals[k + 1], gb = evals[k + 2], gc = evals[k + 3];
+  // ---- the linear combination of the first sumcheck, opened at beta together with g_1 and the z_b,i -----------------------------------------------
+  const HFr r_ab = HFr::mul(HFr::sub(vh_alpha, vh_beta), HFr::inv(HFr::sub(alpha, beta)));
+  const HFr t_beta = HFr::add(sigma[0], HFr::add(HFr::mul(eta_b, sigma[1]), HFr::mul(eta_c, sigma[2])));
+  const HFr xl = HFr::pow_u64(xi, k + 1), vx_beta = vanish(n_x, beta);
+  HFr cst = HFr::neg(HFr::mul(beta, g1_beta));
+  HFr random_v, blw[3];                                                                     // blw: (bl(X) − bl(beta)) / (X − beta), uploaded below
+  {
+    const void* terms[20]; size_t lens[20]; HFr co[20]; size_t nt = 0;
+    terms[nt] = mask; lens[nt] = 3 * n_h; co[nt++] = xl;
+    terms[nt] = h1; lens[nt] = 2 * n_h; co[nt++] = HFr::neg(HFr::mul(xl, vh_beta));
+    terms[nt] = g1 + 32; lens[nt] = n_h - 1; co[nt++] = one;
+    HFr blc[3] = {HFr::zero(), HFr::zero(), HFr::zero()};
+    auto axpy = [&](const HFr& coef, const HFr* src) { for (size_t j = 0; j < HC; ++j) blc[j] = HFr::add(blc[j], HFr::mul(coef, src[j])); };
+    axpy(xl, &blind[3 * k * HC]);
+    HFr xpow = xi;                                                                           // xi^(1+i)
+    for (size_t i = 0; i < k; ++i) {
+      const HFr x_beta = horner(x_poly[i], beta), zb = evals[i], ci = comb[i];
+      const HFr k_za = HFr::mul(HFr::mul(xl, ci), HFr::mul(r_ab, HFr::add(one, HFr::mul(eta_c, zb))));
+      const HFr k_w = HFr::neg(HFr::mul(HFr::mul(xl, ci), HFr::mul(t_beta, vx_beta)));
+      cst = HFr::add(cst, HFr::mul(ci, HFr::sub(HFr::mul(HFr::mul(r_ab, eta_b), zb), HFr::mul(t_beta, x_beta))));
+      terms[nt] = wit + (3 * i + 1) * L * 32; lens[nt] = L; co[nt++] = k_za;
+      terms[nt] = wit + (3 * i) * L * 32; lens[nt] = L; co[nt++] = k_w;
+      terms[nt] = wit + (3 * i + 2) * L * 32; lens[nt] = L; co[nt++] = xpow;
+      axpy(k_w, &blind[(3 * i) * HC]); axpy(k_za, &blind[(3 * i + 1) * HC]); axpy(xpow, &blind[(3 * i + 2) * HC]);
+      xpow = HFr::mul(xpow, xi);
+    }
+    const HFr c0 = HFr::mul(xl, cst);
+    RC(fr_lincomb(c, pbeta, 3 * n_h, c0.l, terms, lens, co, nt, s));
+    random_v = HFr::add(blc[0], HFr::mul(beta, HFr::add(blc[1], HFr::mul(beta, blc[2]))));
+    blw[1] = blc[2]; blw[0] = HFr::add(blc[1], HFr::mul(beta, blc[2])); blw[2] = HFr::zero();
+    HIPCHK(hipMemcpyAsync(blq, blw, HC * 32, hipMemcpyHostToDevice, s));
+  }
+  RC(fr_divide_by_linear(c, wq, evd + (k + 5) * 32, pbeta, 3 * n_h, beta.l, s));
+  // ---- the linear combination of the second sumcheck, opened at gamma together with g_a, g_b, g_c --------------------------------------------------
+  {
+    const HFr xi2 = HFr::sqr(xi), xi3 = HFr::mul(xi2, xi), nk_inv = HFr::inv(fr_u64(n_k)), vk_gamma = vanish(n_k, gamma);
+    const void* terms[20]; size_t lens[20]; HFr co[20]; size_t nt = 0; HFr cg = HFr::zero();
+    const HFr gk[3] = {ga, gb, gc};
+    for (size_t m = 0; m < 3; ++m) {
+      const HFr fm = HFr::add(HFr::mul(gamma, gk[m]), HFr::mul(sigma[m], nk_inv)), d = HFr::mul(delta[m], xi3), dfm = HFr::mul(d, fm);
+      const HFr cf[4] = {HFr::mul(dfm, beta), HFr::mul(dfm, alpha), HFr::mul(d, vv), HFr::neg(dfm)};      // row, col, val, row_col
+      const int order[4] = {2, 0, 1, 3};
+      for (int o = 0; o < 4; ++o) { const int j = order[o]; terms[nt] = (const char*)ix.k_polys + (4 * m + j) * n_k * 32; lens[nt] = n_k; co[nt++] = cf[j]; }
+      cg = HFr::sub(cg, HFr::mul(HFr::mul(dfm, alpha), beta));
+    }
+    terms[nt] = h2; lens[nt] = n_k; co[nt++] = HFr::neg(HFr::mul(xi3, vk_gamma));
+    const HFr gco[3] = {one, xi, xi2};
+    for (size_t m = 0; m < 3; ++m) { terms[nt] = f + (m * n_k + 1) * 32; lens[nt] = n_k - 1; co[nt++] = gco[m]; }
+    RC(fr_lincomb(c, pg, n_k, cg.l, terms, lens, co, nt, s));
+  }
+  RC(fr_divide_by_linear(c, gq, evd + (k + 6) * 32, pg, n_k, gamma.l, s));
+  {
+    std::vector<MsmSeg> sg(3);
+    sg[0].d_ptr = wq; sg[0].len = 3 * n_h - 1; sg[0].off = 0; sg[0].out = 0;
+    sg[1].d_ptr = blq; sg[1].len = HC - 1; sg[1].off = ix.gamma_offset; sg[1].out = 0;
+    sg[2].d_ptr = gq; sg[2].len = n_k - 1; sg[2].off = 0; sg[2].out = 1;
+    RC(commit(c, pb, sg, 2, aff5, s));                                                       // both witness commitments in one call
+  }
+  t_mark[5] = now_ms();
+  // ---- the proof in upstream's layout ---------------------------------------------------------------------------------------------------------------
+  aleo_mi355x_proof_parts parts{}; uint64_t batch = k;
+  std::vector<HFr> ev_m(evals); uint8_t has_v[2] = {1, 0}; HFr rv[2] = {random_v, HFr::zero()};
+  parts.batch_sizes = &batch; parts.n_circuits = 1; parts.witness_commitments = wit_aff.data(); parts.mask_poly = wit_aff.data() + 104 * 3 * k;
+  parts.g_1 = aff2; parts.h_1 = aff2 + 104; parts.g_abc = aff3; parts.h_2 = aff4;
+  parts.evaluations = ev_m.data(); parts.n_evaluations = k + 4; parts.sums = sigma;
+  parts.opening_points = aff5; parts.opening_random_v = rv; parts.opening_has_v = has_v; parts.n_openings = 2;
+  RC(aleo_mi355x_proof_to_bytes(out, out_len, &parts));
+  for (int i = 0; i < 5; ++i) g_varuna_timing[i] = t_mark[i + 1] - t_mark[i];
+  g_varuna_timing[5] = t_mark[5] - t_mark[0];
+  return ALEO_MI355X_OK;
+}
+
+}  // namespace aleo_mi355x

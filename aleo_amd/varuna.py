@@ -9,10 +9,12 @@ arrangement (see oracle/varuna_ref.py for the statement of every identity; that 
 byte for byte).  Differences from upstream that make the proofs NOT interchangeable with snarkVM's: SHA-256 transcript instead of the
 Poseidon sponge, one shared non-zero domain K for A, B, C, a synthetic SRS.  The proof's byte layout is upstream's (aleo_mi355x_proof_to_bytes)."""
 from __future__ import annotations
+import ctypes
 import hashlib
 import numpy as np
 import torch
 from . import synth, wire
+from ._lib import lib, check
 from .fft import EvaluationDomain, FORWARD, INVERSE
 from .kzg import CommitterKey, SonicKZG10, KZG10
 from .msm import PinnedBases
@@ -156,6 +158,49 @@ class CircuitIndex:
 
 
 MAX_INSTANCES = 4        # k + 4 evaluations go through one fr_eval_batch call (8 polynomials), 3k + 3 terms through one fr_lincomb call (20)
+
+
+class _NativeIndex(ctypes.Structure):
+    """aleo_mi355x_varuna_index (include/aleo_mi355x.h)."""
+    _fields_ = ([(n, ctypes.c_uint64) for n in ('n_h', 'n_k', 'n_x', 'n_public', 'n_vars', 'committer_key', 'max_degree', 'gamma_offset')] +
+                [(n, ctypes.c_void_p) for n in ('positions', 'a_row_ptr', 'a_col', 'a_val', 'b_row_ptr', 'b_col', 'b_val', 't_row_ptr', 't_col', 't_val',
+                                                'vx_inv', 'k_evals', 'k_idx', 'k_polys', 'k2_evals', 'vk_bytes')] + [('vk_len', ctypes.c_size_t)])
+
+
+def native_index(ix: CircuitIndex) -> _NativeIndex:
+    """The index as the C ABI takes it: sizes, the committer key's handle, device pointers (the arrays stay owned by `ix`)."""
+    if getattr(ix, '_native', None) is not None: return ix._native
+    n = _NativeIndex()
+    n.n_h, n.n_k, n.n_x, n.n_public, n.n_vars = ix.n_h, ix.n_k, ix.n_x, ix.n_public, ix.n_public + ix.n_private
+    n.committer_key, n.max_degree, n.gamma_offset = ix.ck.bases.handle, ix.ck.max_degree, ix.ck.gamma_offset
+    ix._pos32 = np.ascontiguousarray(ix.pos, dtype=np.uint32); ix._vk = np.frombuffer(ix.vk_bytes, dtype=np.uint8).copy()
+    n.positions = ix._pos32.ctypes.data; n.vk_bytes = ix._vk.ctypes.data; n.vk_len = ix._vk.shape[0]
+    for m in 'ab':
+        rp, col, val = ix.fwd[m]
+        setattr(n, m + '_row_ptr', rp.data_ptr()); setattr(n, m + '_col', col.data_ptr()); setattr(n, m + '_val', val.ptr())
+    n.t_row_ptr, n.t_col, n.t_val = ix.tr[0].data_ptr(), ix.tr[1].data_ptr(), ix.tr[2].ptr()
+    n.vx_inv, n.k_evals, n.k_idx, n.k_polys, n.k2_evals = ix.vx_inv.ptr(), ix.k_evals.ptr(), ix.k_idx.data_ptr(), ix.k_polys.ptr(), ix.k2_evals.ptr()
+    ix._native = n
+    return n
+
+
+def prove_native(index: CircuitIndex, assignment, seed: int) -> bytes:
+    """The same proof through ONE call of the C ABI (aleo_mi355x_varuna_prove: transcript, constants and all launches in C++); returns the
+    proof bytes.  Thread-safe: concurrent calls are served by separate slots of the library."""
+    if isinstance(assignment, np.ndarray) and assignment.ndim == 2: assignment = [assignment]
+    zs = [np.ascontiguousarray(a, dtype=np.uint64).reshape(-1, 4) for a in assignment]
+    nv = index.n_public + index.n_private
+    if any(z.shape[0] != nv for z in zs): raise ValueError('assignment length differs from the number of variables of the circuit')
+    ptrs = (ctypes.c_void_p * len(zs))(*[z.ctypes.data for z in zs])
+    out = np.zeros(1100 + 200 * len(zs), dtype=np.uint8); n = ctypes.c_size_t(out.shape[0])
+    check(lib().aleo_mi355x_varuna_prove(ctypes.byref(native_index(index)), ptrs, len(zs), seed & 0xFFFFFFFFFFFFFFFF, out.ctypes.data_as(ctypes.c_void_p),
+                                         ctypes.byref(n)), 'varuna_prove')
+    return out[:n.value].tobytes()
+
+
+def native_timing() -> dict:
+    t = (ctypes.c_double * 6)(); lib().aleo_mi355x_varuna_last_timing(t, 6)
+    return dict(zip(('round1', 'round2', 'round3', 'round4', 'openings', 'total'), t))
 
 
 class Proof:

@@ -258,6 +258,34 @@ typedef struct {
 } aleo_mi355x_proof_parts;
 int32_t aleo_mi355x_proof_to_bytes(void* out, size_t* len, const aleo_mi355x_proof_parts* parts);
 
+/* ---- one proof in one call: the host side of Varuna::prove_batch, native (aleo_amd/csrc/varuna.hip) -------------------------------
+ * Replaces the CPU work snarkVM 0.14.5 does in algorithms/src/snark/varuna/{varuna.rs, ahp/prover/round_functions} [UPSTREAM-RECALL]
+ * under /root/reference/rust/src/program/execute.rs:74 and transfer.rs:99 — for one circuit with 1..4 instances, a SHA-256 transcript and
+ * the committer key the caller pinned (DESIGN.md 4d lists what differs from upstream).  The index is the prover-key material of the
+ * circuit, built once (aleo_amd/varuna.py CircuitIndex does it through the entry points above) and described by device pointers:
+ *   positions     host, uint32[n_vars]: index on H of every variable (public inputs on the subgroup X)
+ *   a_*, b_*      device CSR of A, B with columns moved to positions on H and rows padded to n_h (uint32 row_ptr[n_h+1], col[], Montgomery val[])
+ *   t_*           device CSR of the stacked transpose [A^T | B^T | C^T] (rows = positions on H, columns = matrix * n_h + row)
+ *   vx_inv        device Fr[n_h]: 1 / v_X on H \ X, 0 on X
+ *   k_evals       device Fr[3][4][n_k]: row, col, val, row_col of A, B, C on K;  k_idx  device uint32[3][2][n_k]: their row / column positions
+ *   k_polys       device Fr[3][4][n_k]: the same as coefficients;  k2_evals  device Fr[3][4][2 n_k]: their values on the domain of size 2 n_k
+ *   vk_bytes      host: what the transcript absorbs first (compressed index commitments, domain sizes)
+ * committer_key: a pinned set holding powers[0..max_degree] and, from gamma_offset, at least 3 hiding powers.
+ * assignments: n_instances host pointers to n_vars x 32 bytes canonical (public variables first, z_0 = 1).  seed: the proof's random stream
+ * (aleo_mi355x_fr_random_device).  out_proof / len: Proof::to_bytes_le layout, 901 + 176 (n_instances - 1) bytes; *len in = capacity.
+ * Blocking; concurrent calls from several threads run on separate slots.  aleo_mi355x_varuna_last_timing: wall ms of the calling thread's
+ * last proof: rounds 1..4, openings, total. */
+typedef struct {
+  uint64_t n_h, n_k, n_x, n_public, n_vars;
+  uint64_t committer_key, max_degree, gamma_offset;
+  const uint32_t* positions;
+  const void *a_row_ptr, *a_col, *a_val, *b_row_ptr, *b_col, *b_val, *t_row_ptr, *t_col, *t_val;
+  const void *vx_inv, *k_evals, *k_idx, *k_polys, *k2_evals;
+  const void* vk_bytes; size_t vk_len;
+} aleo_mi355x_varuna_index;
+int32_t aleo_mi355x_varuna_prove(const aleo_mi355x_varuna_index* index, const void* const* assignments, size_t n_instances, uint64_t seed, void* out_proof, size_t* len);
+int32_t aleo_mi355x_varuna_last_timing(double* out_ms, int32_t cap);
+
 /* Element-wise field products on the device (host pointers): r[i] = a[i]*b[i], Montgomery form, canonical
  * output.  Used by the parity tests to pin the device arithmetic against the oracle limb for limb; when a and b
  * are the same buffer the dedicated squaring block runs instead of the general product. */

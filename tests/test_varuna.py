@@ -97,6 +97,7 @@ def test_device_prover_batch_matches_restatement(k):
         ix = varuna.CircuitIndex(csr, 150, 3, len(z) - 3, ck)
         got = varuna.prove(ix, [np.stack([synth.int_to_limbs(v, 4) for v in q]) for q in zs], 500 + k).to_bytes()
         assert got == want and V.verify(idx, setup, [q[:3] for q in zs], got)
+        assert varuna.prove_native(ix, [np.stack([synth.int_to_limbs(v, 4) for v in q]) for q in zs], 500 + k) == want      # the one-call C++ host side
         with pytest.raises(ValueError): varuna.prove(ix, [np.zeros((len(z), 4), dtype=np.uint64)] * 5, 1)
     finally:
         ck.close()
@@ -119,6 +120,7 @@ def test_device_prover_matches_restatement(n_constraints, n_public, seed):
         proof = varuna.prove(ix, zz, seed + 100)
         got = proof.to_bytes()
         assert got == want
+        assert varuna.prove_native(ix, zz, seed + 100) == want                         # the one-call C++ host side
         assert V.verify(idx, setup, z[:n_public], got)
         assert proof.to_string() == pyref.bech32m_encode('proof', want)
     finally:

@@ -21,6 +21,14 @@ for lg in [int(a) for a in sys.argv[1:]] or [13, 15, 16]:
     for rep in range(7):
         t = time.perf_counter(); pr = varuna.prove(ix, zz, 1000 + rep); ts.append((time.perf_counter() - t) * 1e3); rounds.append(pr.timing_ms)
     med = float(np.median(ts[2:]))
+    tn = []
+    for rep in range(7):
+        t = time.perf_counter(); varuna.prove_native(ix, zz, 1000 + rep); tn.append((time.perf_counter() - t) * 1e3)
+    native = {'prove_ms': float(np.median(tn[2:])), 'rounds_ms': varuna.native_timing()}
+    tn4 = []
+    for rep in range(5):
+        t = time.perf_counter(); varuna.prove_native(ix, [zz] * 4, 2000 + rep); tn4.append((time.perf_counter() - t) * 1e3)
+    native['instances_4_ms'] = float(np.median(tn4[1:]))
     batch = {}
     for kb in (2, 4):                                  # instances of the same circuit proved together (here: the same assignment k times)
         tb = []
@@ -40,6 +48,6 @@ for lg in [int(a) for a in sys.argv[1:]] or [13, 15, 16]:
             for x in th: x.join()
             dt = time.perf_counter() - t
         conc[str(T)] = {'proofs_per_s': T * per / dt, 'constraints_per_s': n * T * per / dt}
-    print(json.dumps({'lg_constraints': lg, 'instances': batch, 'in_flight': conc, 'constraints': n, 'n_h': ix.n_h, 'n_k': ix.n_k, 'setup_s': t1 - t0, 'index_s': t2 - t1, 'prove_ms': med,
+    print(json.dumps({'lg_constraints': lg, 'native': native, 'instances': batch, 'in_flight': conc, 'constraints': n, 'n_h': ix.n_h, 'n_k': ix.n_k, 'setup_s': t1 - t0, 'index_s': t2 - t1, 'prove_ms': med,
                       'constraints_per_s': n / med * 1e3, 'rounds_ms': {k: float(np.median([r[k] for r in rounds[2:]])) for k in rounds[0]}}), flush=True)
     ck.close()
