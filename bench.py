@@ -324,7 +324,7 @@ PROXY_NOTE = ('operator-level proxy for constraints/s (SURVEY.md §8d): the MSM/
 
 
 VARUNA_TAU, VARUNA_S = 0x1F3A9C0D5E7B24681357ACE02468BDF013579BDF02468ACE1234567, 0x0FEDCBA9876543210123456789ABCDEF55AA
-VARUNA_NOTE = ('aleo_amd.varuna.prove: the four AHP rounds, evaluations and both KZG openings of one Marlin/Varuna-shaped proof for a synthetic satisfiable R1CS '
+VARUNA_NOTE = ('aleo_mi355x_varuna_prove (one C call per proof): the four AHP rounds, evaluations and both KZG openings of one Marlin/Varuna-shaped proof for a synthetic satisfiable R1CS '
                '(every constraint multiplies two short linear combinations; a few wide rows), all circuit-sized work on the device through the C ABI; '
                'SHA-256 transcript and synthetic SRS, so proofs are checked by the restatement in oracle/varuna_ref.py, not by snarkVM (DESIGN.md)')
 
@@ -352,17 +352,21 @@ def varuna_prove(synth, torch, lg, reps=7, in_flight=4):
     n, csr, z, zz, ck, D = _varuna_instance(synth, lg, 40 + lg)
     try:
         t0 = time.perf_counter(); ix = varuna.CircuitIndex(csr, n, 4, len(z) - 4, ck); index_s = time.perf_counter() - t0
-        ts, rounds = [], []
-        for rep in range(reps + 2):
-            t = time.perf_counter(); pr = varuna.prove(ix, zz, 1000 + rep); ts.append((time.perf_counter() - t) * 1e3); rounds.append(pr.timing_ms)
-        med = float(np.median(ts[2:]))
+        ts = []
+        for rep in range(reps + 2):                        # one call of the C ABI per proof (aleo_mi355x_varuna_prove)
+            t = time.perf_counter(); data = varuna.prove_native(ix, zz, 1000 + rep); ts.append((time.perf_counter() - t) * 1e3)
+        med = float(np.median(ts[2:])); rounds = varuna.native_timing()
+        tp = []
+        for rep in range(5):                               # the same sequence driven from Python through the public entry points
+            t = time.perf_counter(); pr = varuna.prove(ix, zz, 1000 + rep); tp.append((time.perf_counter() - t) * 1e3)
+        if pr.to_bytes() != varuna.prove_native(ix, zz, 1004): raise SystemExit('bench: the two host sides of the prover disagree')
         tb = []
         for rep in range(5):                               # prove_batch shape: four instances of the circuit in one proof
-            t = time.perf_counter(); prb = varuna.prove(ix, [zz] * 4, 2000 + rep); tb.append((time.perf_counter() - t) * 1e3)
+            t = time.perf_counter(); datab = varuna.prove_native(ix, [zz] * 4, 2000 + rep); tb.append((time.perf_counter() - t) * 1e3)
         mb = float(np.median(tb[1:]))
-        streams = [torch.cuda.Stream() for _ in range(in_flight)]; per = 6
+        per = 6
         def work(k):
-            for rep in range(per): varuna.prove(ix, zz, 5000 + 100 * k + rep, streams[k])
+            for rep in range(per): varuna.prove_native(ix, zz, 5000 + 100 * k + rep)
         for _ in range(2):
             th = [threading.Thread(target=work, args=(k,)) for k in range(in_flight)]
             t = time.perf_counter()
@@ -370,8 +374,9 @@ def varuna_prove(synth, torch, lg, reps=7, in_flight=4):
             for x in th: x.join()
             dt = time.perf_counter() - t
         return {'constraints': n, 'domain_h': ix.n_h, 'domain_k': ix.n_k, 'max_degree': D, 'index_s': index_s, 'prove_ms': med, 'constraints_per_s': n / med * 1e3,
-                'rounds_ms': {k: float(np.median([r[k] for r in rounds[2:]])) for k in rounds[0]}, 'proof_bytes': len(pr.to_bytes()),
-                'instances_4': {'prove_ms': mb, 'constraints_per_s': 4 * n / mb * 1e3, 'proof_bytes': len(prb.to_bytes())},
+                'rounds_ms': rounds, 'proof_bytes': len(data), 'entry_point': 'aleo_mi355x_varuna_prove',
+                'python_host_ms': float(np.median(tp[1:])),
+                'instances_4': {'prove_ms': mb, 'constraints_per_s': 4 * n / mb * 1e3, 'proof_bytes': len(datab)},
                 'in_flight_%d' % in_flight: {'proofs_per_s': in_flight * per / dt, 'constraints_per_s': n * in_flight * per / dt}, 'what': VARUNA_NOTE}
     finally:
         ck.close()
@@ -385,7 +390,7 @@ def varuna_cpu(synth, lg):
     n, csr, z, zz, ck, D = _varuna_instance(synth, lg, 90 + lg)
     try:
         ix = varuna.CircuitIndex(csr, n, 4, len(z) - 4, ck)
-        data = varuna.prove(ix, zz, 4242).to_bytes()
+        data = varuna.prove_native(ix, zz, 4242)
         def rows(m):
             ptr, col, val = csr[m]
             return [[(int(col[k]), synth.limbs_to_int(val[k])) for k in range(ptr[i], ptr[i + 1])] for i in range(len(ptr) - 1)]
