@@ -1078,6 +1078,23 @@ int32_t msm_batch(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, const MsmJ
     if (!g.len) continue;
     reach[g.out] = g.off + g.len > reach[g.out] ? g.off + g.len : reach[g.out]; points[g.out] += g.len; nsegs[g.out]++;
   }
+  // Latency-bound requests (one prover round: a few results of <= 2^17 points each): ONE launch chain on the tier that covers the
+  // longest reach beats one chain per tier — a second chain costs ~0.45 ms of dependent steps, a wider window than a short member
+  // would have picked costs nothing measurable at these sizes.
+  {
+    size_t far = 0, pts = 0, sg = 0;
+    for (uint32_t q = 0; q < K; ++q) { far = reach[q] > far ? reach[q] : far; pts += points[q]; sg += nsegs[q]; }
+    if (K > 1 && K <= MAX_SETS && tier_of(far) >= 0 && K <= msm_max_sets(pb, far) && pts <= ((size_t)1 << 21) && sg <= MAX_SEGS) {
+      bool split = false;
+      for (uint32_t q = 0; q < K; ++q) if (points[q] && tier_of(reach[q]) != tier_of(far)) split = true;
+      if (split) {
+        std::vector<MsmSeg> segs; segs.reserve(sg);
+        for (uint32_t q = 0; q < job.nseg; ++q) if (job.segs[q].len) segs.push_back(job.segs[q]);
+        MsmJob g; g.segs = segs.data(); g.nseg = (uint32_t)segs.size(); g.k = K; g.mont = job.mont;
+        return msm_run(c, out_jac18, pb, g, s);
+      }
+    }
+  }
   std::vector<uint32_t> todo; todo.reserve(K);
   for (int t = -1; t < 3; ++t) {
     todo.clear();
