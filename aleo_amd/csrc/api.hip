@@ -621,6 +621,75 @@ int32_t aleo_mi355x_varuna_prove(const aleo_mi355x_varuna_index* index, const vo
   } catch (...) { return ALEO_MI355X_ERR_HIP; }
 }
 
+static int32_t find_varuna(Device* d, uint64_t handle, std::shared_ptr<VarunaIndexOwner>* keep) {
+  std::lock_guard<std::mutex> lk(d->mu);
+  auto it = d->varuna.find(handle);
+  if (it == d->varuna.end()) { g_last_error = "unknown index handle"; return ALEO_MI355X_ERR_BAD_HANDLE; }
+  *keep = it->second; return ALEO_MI355X_OK;
+}
+
+int32_t aleo_mi355x_varuna_index_build(uint64_t* index_handle, uint64_t committer_key, uint64_t max_degree, uint64_t gamma_offset,
+                                       const aleo_mi355x_r1cs_matrix abc[3], size_t n_constraints, size_t n_public, size_t n_private) {
+  try {
+    if (!index_handle || !abc) return ALEO_MI355X_ERR_BAD_ARG;
+    API_BEGIN
+    FIND_BASES(committer_key)
+    VarunaIndexOwner* raw = nullptr;
+    int32_t rc = varuna_index_build(c, pb, keep, committer_key, max_degree, gamma_offset, abc, n_constraints, n_public, n_private, &raw);
+    if (rc) return rc;
+    std::shared_ptr<VarunaIndexOwner> o(raw, varuna_index_delete);
+    std::lock_guard<std::mutex> g(d->mu);
+    *index_handle = d->next_varuna++; d->varuna[*index_handle] = std::move(o);
+    return ALEO_MI355X_OK;
+  } catch (...) { return ALEO_MI355X_ERR_HIP; }
+}
+
+int32_t aleo_mi355x_varuna_index_export(uint64_t index_handle, aleo_mi355x_varuna_index* out) {
+  try {
+    if (!out) return ALEO_MI355X_ERR_BAD_ARG;
+    Device* d = nullptr; int32_t rc = get_device(&d); if (rc) return rc;
+    std::shared_ptr<VarunaIndexOwner> keep; if ((rc = find_varuna(d, index_handle, &keep))) return rc;
+    *out = *varuna_index_view(keep.get());
+    return ALEO_MI355X_OK;
+  } catch (...) { return ALEO_MI355X_ERR_HIP; }
+}
+
+int32_t aleo_mi355x_varuna_index_vk(uint64_t index_handle, void* out, size_t* len) {
+  try {
+    if (!out || !len) return ALEO_MI355X_ERR_BAD_ARG;
+    Device* d = nullptr; int32_t rc = get_device(&d); if (rc) return rc;
+    std::shared_ptr<VarunaIndexOwner> keep; if ((rc = find_varuna(d, index_handle, &keep))) return rc;
+    const std::vector<uint8_t>& vk = varuna_index_vk(keep.get());
+    if (*len < vk.size()) { *len = vk.size(); g_last_error = "index_vk: output buffer too small"; return ALEO_MI355X_ERR_BAD_ARG; }
+    std::memcpy(out, vk.data(), vk.size()); *len = vk.size();
+    return ALEO_MI355X_OK;
+  } catch (...) { return ALEO_MI355X_ERR_HIP; }
+}
+
+int32_t aleo_mi355x_varuna_index_free(uint64_t index_handle) {
+  try {
+    Device* d = nullptr; int32_t rc = get_device(&d); if (rc) return rc;
+    std::shared_ptr<VarunaIndexOwner> dead;              // freed after the lock is dropped, once no proof uses it
+    std::lock_guard<std::mutex> lk(d->mu);
+    auto it = d->varuna.find(index_handle);
+    if (it == d->varuna.end()) { g_last_error = "unknown index handle"; return ALEO_MI355X_ERR_BAD_HANDLE; }
+    dead = std::move(it->second); d->varuna.erase(it);
+    return ALEO_MI355X_OK;
+  } catch (...) { return ALEO_MI355X_ERR_HIP; }
+}
+
+int32_t aleo_mi355x_varuna_prove_indexed(uint64_t index_handle, const void* const* assignments, size_t n_instances, uint64_t seed, void* out_proof, size_t* len) {
+  try {
+    if (!assignments || !out_proof || !len) return ALEO_MI355X_ERR_BAD_ARG;
+    for (size_t i = 0; i < n_instances && i < 4; ++i) if (!assignments[i]) { g_last_error = "varuna_prove: null assignment"; return ALEO_MI355X_ERR_BAD_ARG; }
+    API_BEGIN
+    std::shared_ptr<VarunaIndexOwner> ixk; { int32_t rci = find_varuna(d, index_handle, &ixk); if (rci) return rci; }
+    const aleo_mi355x_varuna_index* ix = varuna_index_view(ixk.get());
+    FIND_BASES(ix->committer_key)
+    return varuna_prove(c, pb, *ix, assignments, n_instances, seed, (uint8_t*)out_proof, len);
+  } catch (...) { return ALEO_MI355X_ERR_HIP; }
+}
+
 int32_t aleo_mi355x_varuna_last_timing(double* out_ms, int32_t cap) {
   int32_t n = cap < 6 ? cap : 6;
   for (int32_t i = 0; i < n; ++i) out_ms[i] = g_varuna_timing[i];

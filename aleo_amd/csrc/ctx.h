@@ -123,6 +123,7 @@ struct Device {
   std::map<uint64_t, std::shared_ptr<PinnedOwner>> bases; uint64_t next_handle = 1;
   std::vector<SrsCacheEntry> srs_cache; uint64_t srs_clock = 0;
   std::map<uint64_t, NttTables*> ntt_tables;
+  std::map<uint64_t, std::shared_ptr<struct VarunaIndexOwner>> varuna; uint64_t next_varuna = 1;      // circuit indices (varuna.hip)
   std::atomic<int> ntt_attr_mask{0};   // which NTT kernel instances had their LDS limit raised on THIS device
   Ctx slots[MAX_SLOTS];
 };
@@ -169,6 +170,12 @@ int32_t fr_spmv(Ctx* c, void* d_y, const void* d_row_ptr, const void* d_col, con
 // varuna.hip / api.hip
 int32_t varuna_prove(Ctx* c, const PinnedBases& pb, const aleo_mi355x_varuna_index& ix, const void* const* assignments, size_t k, uint64_t seed, uint8_t* out, size_t* out_len);
 extern thread_local double g_varuna_timing[8];
+struct VarunaIndexOwner;
+int32_t varuna_index_build(Ctx* c, const PinnedBases& pb, std::shared_ptr<PinnedOwner> key, uint64_t key_handle, uint64_t max_degree, uint64_t gamma_offset,
+                           const aleo_mi355x_r1cs_matrix* abc, size_t n_constraints, size_t n_public, size_t n_private, VarunaIndexOwner** out);
+void varuna_index_delete(VarunaIndexOwner* o);
+const aleo_mi355x_varuna_index* varuna_index_view(const VarunaIndexOwner* o);
+const std::vector<uint8_t>& varuna_index_vk(const VarunaIndexOwner* o);
 void jacobian_rows_to_affine104(void* out104, const uint64_t* jac18, size_t k);
 // ntt.hip
 int32_t ntt_run(Ctx* c, void* d_inout, uint32_t lg_n, size_t batch, int32_t order, int32_t direction, int32_t type, hipStream_t s);

@@ -13,6 +13,7 @@
 #include "host_field.hpp"
 #include <cstring>
 #include <vector>
+#include <memory>
 #include <chrono>
 
 namespace aleo_mi355x {
@@ -111,6 +112,7 @@ double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::
 
 thread_local double g_varuna_timing[8] = {};
 
+
 static int32_t commit(Ctx* c, const PinnedBases& pb, const std::vector<MsmSeg>& segs, uint32_t k, uint8_t* out104, hipStream_t s) {
   std::vector<uint64_t> jac(18 * (size_t)k);
   MsmJob j; j.segs = segs.data(); j.nseg = (uint32_t)segs.size(); j.k = k; j.mont = true;
@@ -118,6 +120,124 @@ static int32_t commit(Ctx* c, const PinnedBases& pb, const std::vector<MsmSeg>& 
   jacobian_rows_to_affine104(out104, jac.data(), k);
   return ALEO_MI355X_OK;
 }
+
+// ---- the index of a circuit, built once per proving key ---------------------------------------------------------------------------------
+// [UPSTREAM-RECALL: varuna/ahp/indexer — AHPForR1CS::index: matrix arithmetisation over the non-zero domain, index commitments; reached from
+// Process::synthesize_key, /root/reference/wasm/src/programs/manager/mod.rs:164-177, rust/src/program/deploy.rs:142,151.]
+struct VarunaIndexOwner {
+  aleo_mi355x_varuna_index view{};
+  std::vector<uint32_t> positions; std::vector<uint8_t> vk;
+  std::vector<void*> dev;                                  // every device allocation of the index
+  std::shared_ptr<PinnedOwner> key;                        // the committer key stays pinned while the index lives
+  ~VarunaIndexOwner() { for (void* p : dev) if (p) (void)hipFree(p); }
+  int32_t alloc(void** out, size_t bytes) { void* p = nullptr; HIPCHK(hipMalloc(&p, bytes ? bytes : 32)); dev.push_back(p); *out = p; return ALEO_MI355X_OK; }
+};
+void varuna_index_delete(VarunaIndexOwner* o) { delete o; }
+const aleo_mi355x_varuna_index* varuna_index_view(const VarunaIndexOwner* o) { return &o->view; }
+const std::vector<uint8_t>& varuna_index_vk(const VarunaIndexOwner* o) { return o->vk; }
+
+static uint64_t pow2_at_least(uint64_t v, uint64_t lo) { uint64_t p = lo; while (p < v) p <<= 1; return p; }
+
+int32_t varuna_index_build(Ctx* c, const PinnedBases& pb, std::shared_ptr<PinnedOwner> key, uint64_t key_handle, uint64_t max_degree, uint64_t gamma_offset,
+                           const aleo_mi355x_r1cs_matrix* abc, size_t n_constraints, size_t n_public, size_t n_private, VarunaIndexOwner** out) {
+  std::unique_ptr<VarunaIndexOwner> o(new VarunaIndexOwner()); o->key = std::move(key);
+  hipStream_t s = c->stream;
+  if (!n_constraints || !n_public || n_constraints >= (1ull << 28)) { g_last_error = "varuna_index: bad sizes"; return ALEO_MI355X_ERR_BAD_ARG; }
+  const uint64_t n_vars = n_public + n_private, n_x = pow2_at_least(n_public, 1);
+  uint64_t n_h = pow2_at_least(n_constraints, 2); n_h = pow2_at_least(n_x + n_private, n_h); n_h = pow2_at_least(2 * n_x, n_h);
+  uint64_t nnz[3], nnz_max = 0, nnz_sum = 0;
+  for (int m = 0; m < 3; ++m) {
+    if (!abc[m].row_ptr || abc[m].row_ptr[0] != 0) { g_last_error = "varuna_index: row_ptr must start at 0"; return ALEO_MI355X_ERR_BAD_ARG; }
+    nnz[m] = abc[m].row_ptr[n_constraints]; nnz_max = nnz[m] > nnz_max ? nnz[m] : nnz_max; nnz_sum += nnz[m];
+    if (nnz[m] && (!abc[m].col || !abc[m].val)) { g_last_error = "varuna_index: null matrix arrays"; return ALEO_MI355X_ERR_BAD_ARG; }
+    for (uint64_t e = 0; e < nnz[m]; ++e) if (abc[m].col[e] >= n_vars) { g_last_error = "varuna_index: column outside the variables"; return ALEO_MI355X_ERR_BAD_ARG; }
+    for (size_t r = 0; r < n_constraints; ++r) if (abc[m].row_ptr[r + 1] < abc[m].row_ptr[r]) { g_last_error = "varuna_index: row_ptr not monotone"; return ALEO_MI355X_ERR_BAD_ARG; }
+  }
+  const uint64_t n_k = pow2_at_least(nnz_max, 2);
+  if (3 * n_h > max_degree + 1 || n_k > max_degree + 1 || max_degree + 1 > pb.n || gamma_offset + 3 > pb.n) { g_last_error = "varuna_index: committer key too small for this circuit"; return ALEO_MI355X_ERR_BAD_ARG; }
+  uint32_t lg_k = 0; while ((1ull << lg_k) < n_k) ++lg_k;
+  // variable -> position on H: public i -> i |H|/|X|, the j-th private one -> the j-th element of H \ X
+  const uint64_t ratio = n_h / n_x;
+  o->positions.resize(n_vars);
+  for (uint64_t v = 0; v < n_vars; ++v) { if (v < n_public) o->positions[v] = (uint32_t)(v * ratio); else { const uint64_t j = v - n_public; o->positions[v] = (uint32_t)(j + j / (ratio - 1) + 1); } }
+  HFr r2; std::memcpy(r2.l, host::HParams<4>::R2, 32);
+  const HFr one = HFr::one();
+  aleo_mi355x_varuna_index& V = o->view;
+  V.n_h = n_h; V.n_k = n_k; V.n_x = n_x; V.n_public = n_public; V.n_vars = n_vars; V.committer_key = key_handle; V.max_degree = max_degree; V.gamma_offset = gamma_offset;
+  // host staging of everything that is index arithmetic on integers
+  std::vector<uint32_t> rp(n_h + 1), tp(n_h + 1, 0), kidx(6 * n_k, 0);
+  std::vector<uint32_t> cpos[3]; std::vector<uint32_t> tcol(nnz_sum); std::vector<uint8_t> tval(nnz_sum * 32), kval(3 * n_k * 32, 0);
+  for (int m = 0; m < 3; ++m) {
+    cpos[m].resize(nnz[m]);
+    for (uint64_t e = 0; e < nnz[m]; ++e) { cpos[m][e] = o->positions[abc[m].col[e]]; tp[cpos[m][e] + 1]++; }
+    for (size_t r = 0; r < n_constraints; ++r)
+      for (uint64_t e = abc[m].row_ptr[r]; e < abc[m].row_ptr[r + 1]; ++e) { kidx[(2 * m) * n_k + e] = (uint32_t)r; kidx[(2 * m + 1) * n_k + e] = cpos[m][e]; }
+    if (nnz[m]) std::memcpy(&kval[m * n_k * 32], abc[m].val, nnz[m] * 32);
+  }
+  for (uint64_t i = 0; i < n_h; ++i) tp[i + 1] += tp[i];
+  {
+    std::vector<uint32_t> cur(tp.begin(), tp.end() - 1);
+    for (int m = 0; m < 3; ++m)
+      for (size_t r = 0; r < n_constraints; ++r)
+        for (uint64_t e = abc[m].row_ptr[r]; e < abc[m].row_ptr[r + 1]; ++e) {
+          const uint32_t at = cur[cpos[m][e]]++;
+          tcol[at] = (uint32_t)(m * n_h + r); std::memcpy(&tval[(size_t)at * 32], (const uint8_t*)abc[m].val + e * 32, 32);
+        }
+  }
+  auto up = [&](void** dst, const void* src, size_t bytes) -> int32_t { RC(o->alloc(dst, bytes)); if (bytes) HIPCHK(hipMemcpyAsync(*dst, src, bytes, hipMemcpyHostToDevice, s)); return ALEO_MI355X_OK; };
+  auto to_mont = [&](void* p, size_t n) -> int32_t { return fr_lin(c, p, n, nullptr, r2.l, p, nullptr, nullptr, s); };
+  void* d;
+  for (int m = 0; m < 2; ++m) {                            // forward matrices with columns on H, rows padded to |H|
+    for (uint64_t i = 0; i <= n_h; ++i) rp[i] = i <= n_constraints ? abc[m].row_ptr[i] : (uint32_t)nnz[m];
+    void *drp, *dcol, *dval;
+    RC(up(&drp, rp.data(), (n_h + 1) * 4)); RC(up(&dcol, cpos[m].data(), nnz[m] * 4)); RC(up(&dval, abc[m].val, nnz[m] * 32)); RC(to_mont(dval, nnz[m]));
+    HIPCHK(hipStreamSynchronize(s));                       // rp is reused by the next matrix
+    if (m == 0) { V.a_row_ptr = drp; V.a_col = dcol; V.a_val = dval; } else { V.b_row_ptr = drp; V.b_col = dcol; V.b_val = dval; }
+  }
+  RC(up(&d, tp.data(), (n_h + 1) * 4)); V.t_row_ptr = d; RC(up(&d, tcol.data(), nnz_sum * 4)); V.t_col = d;
+  RC(up(&d, tval.data(), nnz_sum * 32)); RC(to_mont(d, nnz_sum)); V.t_val = d;
+  // 1 / v_X on H \ X (v_X(w^p) = wx^p − 1, wx = w^|X|; zeros stay zero through the batch inversion), elements of H
+  void *vx, *he;
+  RC(o->alloc(&vx, n_h * 32)); RC(o->alloc(&he, n_h * 32));
+  const HFr gen_h = domain_gen(n_h), wx = HFr::pow_u64(gen_h, n_x), neg1 = HFr::neg(one);
+  RC(fr_powers(c, vx, n_h, one.l, wx.l, s)); RC(fr_lin(c, vx, n_h, neg1.l, one.l, vx, nullptr, nullptr, s)); RC(fr_batch_inverse(c, vx, n_h, s));
+  RC(fr_powers(c, he, n_h, one.l, gen_h.l, s));
+  V.vx_inv = vx;
+  // arithmetisation over K: row, col, val = M[r,c] col / |H|, row_col — padding: row = col = 1 (position 0), val = 0
+  void *kev, *kid, *kpo, *k2, *kv;
+  RC(o->alloc(&kev, 12 * n_k * 32)); RC(o->alloc(&kpo, 12 * n_k * 32)); RC(o->alloc(&k2, 24 * n_k * 32));
+  RC(up(&kid, kidx.data(), 6 * n_k * 4)); RC(up(&kv, kval.data(), 3 * n_k * 32)); RC(to_mont(kv, 3 * n_k));
+  const HFr nh_inv = HFr::inv(fr_u64(n_h));
+  for (int m = 0; m < 3; ++m) {
+    char* e = (char*)kev + 4 * m * n_k * 32; const uint32_t* ri = (const uint32_t*)kid + (2 * m) * n_k; const uint32_t* ci = ri + n_k;
+    RC(fr_gather_mul(c, e, n_k, nullptr, he, ri, nullptr, nullptr, s));
+    RC(fr_gather_mul(c, e + n_k * 32, n_k, nullptr, he, ci, nullptr, nullptr, s));
+    RC(fr_vec_op(c, e + 2 * n_k * 32, (char*)kv + m * n_k * 32, e + n_k * 32, n_k, 0, s));
+    RC(fr_lin(c, e + 2 * n_k * 32, n_k, nullptr, nh_inv.l, e + 2 * n_k * 32, nullptr, nullptr, s));
+    RC(fr_vec_op(c, e + 3 * n_k * 32, e, e + n_k * 32, n_k, 0, s));
+  }
+  HIPCHK(hipMemcpyAsync(kpo, kev, 12 * n_k * 32, hipMemcpyDeviceToDevice, s));
+  RC(ntt_run(c, kpo, lg_k, 12, 0, 1, 0, s));
+  HIPCHK(hipMemsetAsync(k2, 0, 24 * n_k * 32, s));
+  for (int q = 0; q < 12; ++q) HIPCHK(hipMemcpyAsync((char*)k2 + (size_t)q * 2 * n_k * 32, (char*)kpo + (size_t)q * n_k * 32, n_k * 32, hipMemcpyDeviceToDevice, s));
+  RC(ntt_run(c, k2, lg_k + 1, 12, 0, 0, 0, s));
+  V.k_evals = kev; V.k_idx = kid; V.k_polys = kpo; V.k2_evals = k2; V.positions = o->positions.data();
+  // index commitments -> what the transcript absorbs first
+  uint8_t aff[12 * 104];
+  {
+    std::vector<MsmSeg> sg(12);
+    for (int q = 0; q < 12; ++q) { sg[q].d_ptr = (char*)kpo + (size_t)q * n_k * 32; sg[q].len = n_k; sg[q].off = 0; sg[q].out = (uint32_t)q; }
+    RC(commit(c, pb, sg, 12, aff, s));
+  }
+  HIPCHK(hipStreamSynchronize(s));
+  o->vk.resize(12 * 48 + 24);
+  RC(aleo_mi355x_g1_compress(o->vk.data(), aff, 12));
+  const uint64_t dims[3] = {n_h, n_k, n_x}; std::memcpy(&o->vk[12 * 48], dims, 24);
+  V.vk_bytes = o->vk.data(); V.vk_len = o->vk.size();
+  *out = o.release();
+  return ALEO_MI355X_OK;
+}
+
 
 int32_t varuna_prove(Ctx* c, const PinnedBases& pb, const aleo_mi355x_varuna_index& ix, const void* const* assignments, size_t k, uint64_t seed,
                      uint8_t* out, size_t* out_len) {

@@ -198,6 +198,47 @@ def prove_native(index: CircuitIndex, assignment, seed: int) -> bytes:
     return out[:n.value].tobytes()
 
 
+class _R1csMatrix(ctypes.Structure):
+    _fields_ = [('row_ptr', ctypes.c_void_p), ('col', ctypes.c_void_p), ('val', ctypes.c_void_p)]
+
+
+class NativeCircuitIndex:
+    """The index built and owned by the library (aleo_mi355x_varuna_index_build): the key-synthesis step of one circuit in one call.
+    csr[m] = (row_ptr uint32[n+1], col uint32[nnz] variable indices, val uint64[nnz,4] canonical) for m in 'abc'."""
+
+    def __init__(self, csr, n_constraints: int, n_public: int, n_private: int, ck: CommitterKey):
+        self.ck = ck; keep = []; mats = (_R1csMatrix * 3)()
+        for i, m in enumerate('abc'):
+            rp, col, val = (np.ascontiguousarray(csr[m][0], dtype=np.uint32), np.ascontiguousarray(csr[m][1], dtype=np.uint32),
+                            np.ascontiguousarray(csr[m][2], dtype=np.uint64).reshape(-1, 4))
+            keep += [rp, col, val]
+            mats[i].row_ptr, mats[i].col, mats[i].val = rp.ctypes.data, col.ctypes.data, val.ctypes.data
+        h = ctypes.c_uint64(0)
+        check(lib().aleo_mi355x_varuna_index_build(ctypes.byref(h), ck.bases.handle, ck.max_degree, ck.gamma_offset, mats, n_constraints, n_public, n_private),
+              'varuna_index_build')
+        self.handle = h.value
+        view = _NativeIndex(); check(lib().aleo_mi355x_varuna_index_export(self.handle, ctypes.byref(view)), 'varuna_index_export')
+        self.n_h, self.n_k, self.n_x, self.n_vars = view.n_h, view.n_k, view.n_x, view.n_vars
+        buf = np.zeros(12 * 48 + 24, dtype=np.uint8); n = ctypes.c_size_t(buf.shape[0])
+        check(lib().aleo_mi355x_varuna_index_vk(self.handle, buf.ctypes.data_as(ctypes.c_void_p), ctypes.byref(n)), 'varuna_index_vk')
+        self.vk_bytes = buf[:n.value].tobytes()
+
+    def prove(self, assignment, seed: int) -> bytes:
+        if isinstance(assignment, np.ndarray) and assignment.ndim == 2: assignment = [assignment]
+        zs = [np.ascontiguousarray(a, dtype=np.uint64).reshape(-1, 4) for a in assignment]
+        if any(z.shape[0] != self.n_vars for z in zs): raise ValueError('assignment length differs from the number of variables of the circuit')
+        ptrs = (ctypes.c_void_p * len(zs))(*[z.ctypes.data for z in zs])
+        out = np.zeros(1100 + 200 * len(zs), dtype=np.uint8); n = ctypes.c_size_t(out.shape[0])
+        check(lib().aleo_mi355x_varuna_prove_indexed(self.handle, ptrs, len(zs), seed & 0xFFFFFFFFFFFFFFFF, out.ctypes.data_as(ctypes.c_void_p), ctypes.byref(n)),
+              'varuna_prove_indexed')
+        return out[:n.value].tobytes()
+
+    def close(self):
+        if self.handle: lib().aleo_mi355x_varuna_index_free(self.handle); self.handle = 0
+    def __enter__(self): return self
+    def __exit__(self, *a): self.close()
+
+
 def native_timing() -> dict:
     t = (ctypes.c_double * 6)(); lib().aleo_mi355x_varuna_last_timing(t, 6)
     return dict(zip(('round1', 'round2', 'round3', 'round4', 'openings', 'total'), t))

@@ -283,6 +283,20 @@ typedef struct {
   const void *vx_inv, *k_evals, *k_idx, *k_polys, *k2_evals;
   const void* vk_bytes; size_t vk_len;
 } aleo_mi355x_varuna_index;
+/* The index built by the library itself from the R1CS (AHPForR1CS::index shape: the arithmetisation above + the twelve index commitments)
+ * and kept in HBM under a handle.  Matrices: CSR over the variables (uint32 row_ptr[n_constraints + 1], uint32 col[nnz] = variable index
+ * with the n_public public variables first, val[nnz] canonical 32-byte Fr), host memory.  Domains: |X| = 2^ceil(lg n_public), |H| = the power
+ * of two >= max(n_constraints, |X| + n_private, 2|X|), |K| = the power of two >= the largest non-zero count (>= 2).  The committer key
+ * (powers[0..max_degree], >= 3 hiding powers from gamma_offset) must hold max(3|H|, |K|) powers and stays pinned while the index lives.
+ * index_export fills the struct view (pointers owned by the library, valid until index_free); index_vk copies the bytes the transcript absorbs
+ * first: 12 compressed index commitments (row, col, val, row_col of A, B, C) then |H|, |K|, |X| as u64 LE.  prove_indexed = varuna_prove. */
+typedef struct { const uint32_t* row_ptr; const uint32_t* col; const void* val; } aleo_mi355x_r1cs_matrix;
+int32_t aleo_mi355x_varuna_index_build(uint64_t* index_handle, uint64_t committer_key, uint64_t max_degree, uint64_t gamma_offset,
+                                       const aleo_mi355x_r1cs_matrix abc[3], size_t n_constraints, size_t n_public, size_t n_private);
+int32_t aleo_mi355x_varuna_index_export(uint64_t index_handle, aleo_mi355x_varuna_index* out);
+int32_t aleo_mi355x_varuna_index_vk(uint64_t index_handle, void* out, size_t* len);
+int32_t aleo_mi355x_varuna_index_free(uint64_t index_handle);
+int32_t aleo_mi355x_varuna_prove_indexed(uint64_t index_handle, const void* const* assignments, size_t n_instances, uint64_t seed, void* out_proof, size_t* len);
 int32_t aleo_mi355x_varuna_prove(const aleo_mi355x_varuna_index* index, const void* const* assignments, size_t n_instances, uint64_t seed, void* out_proof, size_t* len);
 int32_t aleo_mi355x_varuna_last_timing(double* out_ms, int32_t cap);
 

@@ -4,6 +4,7 @@ the same circuit, assignment, randomness and setup; at sizes the restatement doe
 import json, os
 import numpy as np
 import pytest
+import aleo_amd
 from aleo_amd import synth
 from oracle import varuna_ref as V, pyref
 
@@ -97,7 +98,9 @@ def test_device_prover_batch_matches_restatement(k):
         ix = varuna.CircuitIndex(csr, 150, 3, len(z) - 3, ck)
         got = varuna.prove(ix, [np.stack([synth.int_to_limbs(v, 4) for v in q]) for q in zs], 500 + k).to_bytes()
         assert got == want and V.verify(idx, setup, [q[:3] for q in zs], got)
-        assert varuna.prove_native(ix, [np.stack([synth.int_to_limbs(v, 4) for v in q]) for q in zs], 500 + k) == want      # the one-call C++ host side
+        zq = [np.stack([synth.int_to_limbs(v, 4) for v in q]) for q in zs]
+        assert varuna.prove_native(ix, zq, 500 + k) == want                            # the one-call C++ host side
+        with varuna.NativeCircuitIndex(csr, 150, 3, len(z) - 3, ck) as nx: assert nx.prove(zq, 500 + k) == want
         with pytest.raises(ValueError): varuna.prove(ix, [np.zeros((len(z), 4), dtype=np.uint64)] * 5, 1)
     finally:
         ck.close()
@@ -121,6 +124,11 @@ def test_device_prover_matches_restatement(n_constraints, n_public, seed):
         got = proof.to_bytes()
         assert got == want
         assert varuna.prove_native(ix, zz, seed + 100) == want                         # the one-call C++ host side
+        with varuna.NativeCircuitIndex(csr, n_constraints, n_public, len(z) - n_public, ck) as nx:     # index built by the library itself
+            assert (nx.n_h, nx.n_k, nx.n_x) == (c.n_h, c.n_k, c.n_x) and nx.vk_bytes == idx.vk_bytes()
+            assert nx.prove(zz, seed + 100) == want
+            handle = nx.handle
+        with pytest.raises(aleo_amd.AleoMi355xError): aleo_amd._lib.check(aleo_amd.lib().aleo_mi355x_varuna_index_free(handle), 'index_free')   # already freed
         assert V.verify(idx, setup, z[:n_public], got)
         assert proof.to_string() == pyref.bech32m_encode('proof', want)
     finally:

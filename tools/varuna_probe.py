@@ -21,10 +21,12 @@ for lg in [int(a) for a in sys.argv[1:]] or [13, 15, 16]:
     for rep in range(7):
         t = time.perf_counter(); pr = varuna.prove(ix, zz, 1000 + rep); ts.append((time.perf_counter() - t) * 1e3); rounds.append(pr.timing_ms)
     med = float(np.median(ts[2:]))
+    t0n = time.perf_counter(); nx = varuna.NativeCircuitIndex(csr, n, 4, len(z) - 4, ck); native_index_s = time.perf_counter() - t0n
+    assert nx.vk_bytes == ix.vk_bytes; nx.close()
     tn = []
     for rep in range(7):
         t = time.perf_counter(); varuna.prove_native(ix, zz, 1000 + rep); tn.append((time.perf_counter() - t) * 1e3)
-    native = {'prove_ms': float(np.median(tn[2:])), 'rounds_ms': varuna.native_timing()}
+    native = {'index_s': native_index_s, 'prove_ms': float(np.median(tn[2:])), 'rounds_ms': varuna.native_timing()}
     tn4 = []
     for rep in range(5):
         t = time.perf_counter(); varuna.prove_native(ix, [zz] * 4, 2000 + rep); tn4.append((time.perf_counter() - t) * 1e3)
