@@ -1,0 +1,51 @@
+// A caller of the whole-proof entry points with nothing but the C ABI (no Python, no torch): reads a circuit, its assignments and the
+// scalars of a synthetic committer key from a file written by tests/test_varuna.py, pins the key, builds the index, proves, writes the
+// proof and the verifier-key bytes.  What a Rust Varuna::prove_batch would do through FFI.
+#include "aleo_mi355x.h"
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+static bool rd(FILE* f, void* p, size_t n) { return n == 0 || fread(p, 1, n, f) == n; }
+#define OK(call, what) do { int32_t rc_ = (call); if (rc_) { fprintf(stderr, "%s: %s (%s)\n", what, aleo_mi355x_strerror(rc_), aleo_mi355x_last_error()); return 1; } } while (0)
+
+int main(int argc, char** argv) {
+  if (argc != 3) { fprintf(stderr, "usage: varuna_prove_test <in> <out>\n"); return 2; }
+  FILE* f = fopen(argv[1], "rb"); if (!f) return 2;
+  uint64_t h[8];          // n_constraints, n_public, n_private, max_degree, n_gamma, seed, instances, reserved
+  if (!rd(f, h, sizeof h)) return 2;
+  const uint64_t nc = h[0], npub = h[1], npriv = h[2], D = h[3], ng = h[4], seed = h[5], k = h[6], nv = npub + npriv;
+  std::vector<uint8_t> gen(104), srs((D + 1 + ng) * 32);
+  if (!rd(f, gen.data(), 104) || !rd(f, srs.data(), srs.size())) return 2;
+  std::vector<uint32_t> rp[3], col[3]; std::vector<uint8_t> val[3]; aleo_mi355x_r1cs_matrix abc[3];
+  for (int m = 0; m < 3; ++m) {
+    uint64_t nnz; if (!rd(f, &nnz, 8)) return 2;
+    rp[m].resize(nc + 1); col[m].resize(nnz); val[m].resize(nnz * 32);
+    if (!rd(f, rp[m].data(), (nc + 1) * 4) || !rd(f, col[m].data(), nnz * 4) || !rd(f, val[m].data(), nnz * 32)) return 2;
+    abc[m].row_ptr = rp[m].data(); abc[m].col = col[m].data(); abc[m].val = val[m].data();
+  }
+  std::vector<std::vector<uint8_t>> z(k, std::vector<uint8_t>(nv * 32)); std::vector<const void*> zp(k);
+  for (uint64_t i = 0; i < k; ++i) { if (!rd(f, z[i].data(), nv * 32)) return 2; zp[i] = z[i].data(); }
+  fclose(f);
+
+  OK(aleo_mi355x_init(0), "init");
+  uint64_t key = 0, index = 0;
+  OK(aleo_mi355x_bases_from_scalars(gen.data(), srs.data(), D + 1 + ng, &key), "bases_from_scalars");       // powers | hiding powers
+  OK(aleo_mi355x_bases_precompute(key), "bases_precompute");
+  OK(aleo_mi355x_varuna_index_build(&index, key, D, D + 1, abc, nc, npub, npriv), "varuna_index_build");
+  uint8_t vk[12 * 48 + 24]; size_t vk_len = sizeof vk;
+  OK(aleo_mi355x_varuna_index_vk(index, vk, &vk_len), "varuna_index_vk");
+  std::vector<uint8_t> proof(2048); size_t len = proof.size();
+  OK(aleo_mi355x_varuna_prove_indexed(index, zp.data(), k, seed, proof.data(), &len), "varuna_prove_indexed");
+  size_t len2 = 16;                                          // a buffer that is too small is an error that reports the size needed
+  if (aleo_mi355x_varuna_prove_indexed(index, zp.data(), k, seed, proof.data() + 1024, &len2) == 0 || len2 != len) { fprintf(stderr, "short buffer not refused\n"); return 1; }
+  OK(aleo_mi355x_varuna_index_free(index), "varuna_index_free");
+  if (aleo_mi355x_varuna_prove_indexed(index, zp.data(), k, seed, proof.data(), &len2) == 0) { fprintf(stderr, "freed index still usable\n"); return 1; }
+  OK(aleo_mi355x_bases_unpin(key), "bases_unpin");
+  FILE* o = fopen(argv[2], "wb"); if (!o) return 2;
+  uint64_t l2[2] = {vk_len, len};
+  fwrite(l2, 8, 2, o); fwrite(vk, 1, vk_len, o); fwrite(proof.data(), 1, len, o); fclose(o);
+  printf("ALL OK\n");
+  return 0;
+}

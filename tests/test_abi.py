@@ -71,13 +71,13 @@ def test_evaluation_domain_host_logic():
     assert aleo_amd.EvaluationDomain.new(1 << 48) is None          # beyond the two-adicity of Fr: reference returns None
 
 
-def build_cpp_host_mirror(tmpdir):
-    """g++ the C++ host-mirror test against the in-tree library; returns the binary path."""
+def build_cpp_host_mirror(tmpdir, name='host_mirror_test'):
+    """g++ a C++ caller of the C ABI (tests/cpp/<name>.cpp) against the in-tree library; returns the binary path."""
     import subprocess
-    exe = os.path.join(str(tmpdir), 'host_mirror_test')
+    exe = os.path.join(str(tmpdir), name)
     libdir = os.path.join(ROOT, 'aleo_amd', 'lib')
     subprocess.check_call(['g++', '-std=c++17', '-O2', '-I', os.path.join(ROOT, 'include'),
-                           os.path.join(ROOT, 'tests', 'cpp', 'host_mirror_test.cpp'), '-o', exe,
+                           os.path.join(ROOT, 'tests', 'cpp', name + '.cpp'), '-o', exe,
                            '-L', libdir, '-laleo_mi355x', '-Wl,-rpath,' + libdir])
     return exe
 
@@ -87,3 +87,4 @@ def test_cpp_host_mirror_compiles_and_links(tmp_path):
     the program itself needs a GPU and is run by tests/test_gpu_parity.py::test_cpp_host_mirror."""
     exe = build_cpp_host_mirror(tmp_path)
     assert os.path.exists(exe)
+    assert os.path.exists(build_cpp_host_mirror(tmp_path, 'varuna_prove_test'))      # the whole-proof entry points from plain C++

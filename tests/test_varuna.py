@@ -184,3 +184,36 @@ def test_device_prover_concurrent_streams():
         assert V.verify(idx, setup, z[:3], got[(2, 2)])
     finally:
         ck.close()
+
+
+@pytest.mark.gpu
+def test_whole_proof_entry_points_from_plain_cpp(tmp_path):
+    """tests/cpp/varuna_prove_test.cpp: key pinned from scalars, index built, two instances proved through the C ABI alone (no Python in the
+    process); its proof and verifier-key bytes equal the restatement's; misuse (short buffer, freed index) is refused."""
+    import struct, subprocess, sys
+    sys.path.insert(0, os.path.dirname(__file__))
+    from test_abi import build_cpp_host_mirror
+    csr, z, c = _circuit(300, 3, 71)
+    zs = [z, synth.resolve_synthetic(csr, 3, [1, 2, 3])]
+    D = _max_degree(c); ng = 3; seed = 31337
+    setup = V.Setup(TAU, S_GAMMA, D); idx = V.Index(c, setup)
+    _, want = V.prove(idx, setup, zs, _rand(c, seed, 2))
+    sc, a = [], 1
+    for i in range(D + 1): sc.append(a); a = a * TAU % V.R
+    a = S_GAMMA % V.R
+    for i in range(ng): sc.append(a); a = a * TAU % V.R
+    blob = struct.pack('<8Q', 300, 3, len(z) - 3, D, ng, seed, 2, 0) + synth.generator_affine104().tobytes()
+    blob += b''.join(int(v).to_bytes(32, 'little') for v in sc)
+    for m in 'abc':
+        ptr, col, val = csr[m]
+        blob += struct.pack('<Q', int(ptr[-1])) + np.ascontiguousarray(ptr, dtype=np.uint32).tobytes() + np.ascontiguousarray(col, dtype=np.uint32).tobytes()
+        blob += np.ascontiguousarray(val, dtype=np.uint64).tobytes()
+    for q in zs: blob += b''.join(int(v).to_bytes(32, 'little') for v in q)
+    fin, fout = os.path.join(str(tmp_path), 'in.bin'), os.path.join(str(tmp_path), 'out.bin')
+    open(fin, 'wb').write(blob)
+    exe = build_cpp_host_mirror(tmp_path, 'varuna_prove_test')
+    r = subprocess.run([exe, fin, fout], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and 'ALL OK' in r.stdout, r.stdout + r.stderr
+    out = open(fout, 'rb').read(); vk_len, plen = struct.unpack('<2Q', out[:16])
+    assert out[16:16 + vk_len] == idx.vk_bytes() and out[16 + vk_len:16 + vk_len + plen] == want
+    assert V.verify(idx, setup, [q[:3] for q in zs], out[16 + vk_len:16 + vk_len + plen])
