@@ -1084,3 +1084,25 @@ def test_ahp_sumcheck_numerators_match_bigint():
             bq = (alpha * beta - beta * e[i] - alpha * e[n + i] + e[3 * n + i]) % r
             want[i] = (want[i] + dl * (vv * e[2 * n + i] - bq * f[i])) % r
     assert c.limbs_to_ints(c.fr_from_mont(dst.cpu().numpy().view(np.uint64))) == want
+
+
+def test_commit_lagrange_equals_commit_of_the_interpolant():
+    """KZG10::commit_lagrange is the same MSM over the Lagrange-basis powers L_i(tau) G of the domain: committing the EVALUATIONS against
+    them equals committing the interpolated coefficients against the monomial powers tau^i G (here both sets come from the synthetic
+    setup's trapdoor; upstream derives the Lagrange set from the powers).  Witness-like evaluations stay witness-like scalars for the MSM."""
+    import torch
+    r = p.FR_MODULUS; n = 1024; tau = 0x2468ACE13579BDF02468ACE13579BDF
+    dom = p.EvaluationDomain(n)
+    vh = (pow(tau, n, r) - 1) % r; ninv = pow(n, -1, r)
+    lag = []; w = 1
+    for i in range(n):
+        lag.append(w * ninv % r * vh % r * pow(tau - w, -1, r) % r); w = w * dom.group_gen % r
+    mono = [pow(tau, i, r) for i in range(n)]
+    evals = util.witness_like_scalars(n, 31001)
+    coeffs = aleo_amd.EvaluationDomain(n).ifft(c.fr_to_mont(evals))
+    with M.PinnedBases.from_scalars(synth.generator_affine104(), c.ints_to_limbs(lag, 4)) as pl, \
+         M.PinnedBases.from_scalars(synth.generator_affine104(), c.ints_to_limbs(mono, 4)) as pm:
+        a = aleo_amd.KZG10.commit(pl, c.fr_to_mont(evals)); b = aleo_amd.KZG10.commit(pm, coeffs)
+        assert (a == b).all()
+        k = sum(e * l for e, l in zip(c.limbs_to_ints(evals), lag)) % r
+        assert c.affine_to_ints(a.reshape(1, 104))[0] == p.g1_mul(p.G1_GENERATOR, k)
