@@ -614,7 +614,7 @@ int32_t aleo_mi355x_fr_eval_batch_device(void* d_out, const void* const* d_polys
 int32_t aleo_mi355x_varuna_prove(const aleo_mi355x_varuna_index* index, const void* const* assignments, size_t n_instances, uint64_t seed, void* out_proof, size_t* len) {
   try {
     if (!index || !assignments || !out_proof || !len || !index->positions || !index->vk_bytes) { g_last_error = "varuna_prove: null argument"; return ALEO_MI355X_ERR_BAD_ARG; }
-    for (size_t i = 0; i < n_instances && i < 4; ++i) if (!assignments[i]) { g_last_error = "varuna_prove: null assignment"; return ALEO_MI355X_ERR_BAD_ARG; }
+    for (size_t i = 0; i < n_instances && i < 8; ++i) if (!assignments[i]) { g_last_error = "varuna_prove: null assignment"; return ALEO_MI355X_ERR_BAD_ARG; }
     API_BEGIN
     FIND_BASES(index->committer_key)
     return varuna_prove(c, pb, *index, assignments, n_instances, seed, (uint8_t*)out_proof, len);
@@ -681,7 +681,7 @@ int32_t aleo_mi355x_varuna_index_free(uint64_t index_handle) {
 int32_t aleo_mi355x_varuna_prove_indexed(uint64_t index_handle, const void* const* assignments, size_t n_instances, uint64_t seed, void* out_proof, size_t* len) {
   try {
     if (!assignments || !out_proof || !len) return ALEO_MI355X_ERR_BAD_ARG;
-    for (size_t i = 0; i < n_instances && i < 4; ++i) if (!assignments[i]) { g_last_error = "varuna_prove: null assignment"; return ALEO_MI355X_ERR_BAD_ARG; }
+    for (size_t i = 0; i < n_instances && i < 8; ++i) if (!assignments[i]) { g_last_error = "varuna_prove: null assignment"; return ALEO_MI355X_ERR_BAD_ARG; }
     API_BEGIN
     std::shared_ptr<VarunaIndexOwner> ixk; { int32_t rci = find_varuna(d, index_handle, &ixk); if (rci) return rci; }
     const aleo_mi355x_varuna_index* ix = varuna_index_view(ixk.get());

@@ -325,9 +325,9 @@ int32_t fr_gather_mul(Ctx* c, void* d_dst, size_t n, const void* d_scale, const 
   return ALEO_MI355X_OK;
 }
 
-// p_q(z_q) for up to EVAL_MAX polynomials in two launches: the per-block folds of k_div_blocks for all of them at once, then one
+// p_q(z_q) for up to EVAL_MAX (12) polynomials in two launches: the per-block folds of k_div_blocks for all of them at once, then one
 // block per polynomial combines its folds (Horner over its lanes' runs of blocks, then a sum over the lanes weighted by powers of z^4096).
-static constexpr uint32_t EVAL_MAX = 8;
+static constexpr uint32_t EVAL_MAX = 12;
 struct EvalArgs { const char* p[EVAL_MAX]; size_t n[EVAL_MAX]; FrK z[EVAL_MAX]; uint32_t first_block[EVAL_MAX + 1]; uint32_t k; };
 __global__ void __launch_bounds__(256) k_eval_blocks(EvalArgs a, char* __restrict__ E) {
   __shared__ uint32_t l[8 * DIV_B];
@@ -362,7 +362,7 @@ __global__ void __launch_bounds__(256) k_eval_combine(EvalArgs a, const char* __
 }
 int32_t fr_eval_batch(Ctx* c, void* d_out, const void* const* d_polys, const size_t* lens, const void* z_mont, size_t k, hipStream_t s) {
   if (k == 0) return ALEO_MI355X_OK;
-  if (k > EVAL_MAX) { g_last_error = "fr_eval_batch: more than 8 polynomials in one call"; return ALEO_MI355X_ERR_BAD_ARG; }
+  if (k > EVAL_MAX) { g_last_error = "fr_eval_batch: more than 12 polynomials in one call"; return ALEO_MI355X_ERR_BAD_ARG; }
   EvalArgs a{}; a.k = (uint32_t)k; uint64_t total = 0;
   for (size_t q = 0; q < k; ++q) {
     if (!d_polys[q] && lens[q]) { g_last_error = "fr_eval_batch: null polynomial"; return ALEO_MI355X_ERR_BAD_ARG; }
@@ -415,7 +415,7 @@ int32_t fr_random(Ctx* c, void* d_dst, size_t n, uint64_t seed, uint64_t first, 
 
 // dst[i] = c0 [i == 0] + sum_j coeff_j * term_j[i] over up to LC_MAX ragged terms (term j ends at len_j): the linear combinations a
 // proof opens at beta and gamma, and the delta-weighted sum of the fourth round, in one pass over the data.
-static constexpr uint32_t LC_MAX = 20;
+static constexpr uint32_t LC_MAX = 28;
 struct LcArgs { const char* p[LC_MAX]; size_t n[LC_MAX]; FrK k[LC_MAX]; uint32_t terms; };
 __global__ void __launch_bounds__(256) k_fr_lincomb(char* __restrict__ dst, size_t n, LcArgs a, FrK k0) {
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
@@ -428,7 +428,7 @@ __global__ void __launch_bounds__(256) k_fr_lincomb(char* __restrict__ dst, size
 int32_t fr_lincomb(Ctx* c, void* d_dst, size_t n, const void* c0, const void* const* d_terms, const size_t* lens, const void* coeffs, size_t k, hipStream_t s) {
   (void)c;
   if (n == 0) return ALEO_MI355X_OK;
-  if (k > LC_MAX) { g_last_error = "fr_lincomb: more than 20 terms in one call"; return ALEO_MI355X_ERR_BAD_ARG; }
+  if (k > LC_MAX) { g_last_error = "fr_lincomb: more than 28 terms in one call"; return ALEO_MI355X_ERR_BAD_ARG; }
   LcArgs a{}; a.terms = (uint32_t)k; FrK k0{};
   if (c0) std::memcpy(k0.v, c0, 32);
   for (size_t j = 0; j < k; ++j) {

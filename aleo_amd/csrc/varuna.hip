@@ -1,5 +1,5 @@
 // varuna.hip — the host side of one proof, native: the four AHP rounds, the evaluations and the two openings of
-// `Varuna::prove_batch` (one circuit, up to four instances) as ONE call of the C ABI (`aleo_mi355x_varuna_prove`).
+// `Varuna::prove_batch` (one circuit, up to eight instances) as ONE call of the C ABI (`aleo_mi355x_varuna_prove`).
 //
 // Replaces (shape, not bytes — see DESIGN.md §4d for what differs from upstream and why) snarkVM 0.14.5
 //   algorithms/src/snark/varuna/varuna.rs                      Varuna::prove_batch
@@ -243,7 +243,7 @@ int32_t varuna_prove(Ctx* c, const PinnedBases& pb, const aleo_mi355x_varuna_ind
                      uint8_t* out, size_t* out_len) {
   const size_t n_h = ix.n_h, n_k = ix.n_k, n_x = ix.n_x, L = n_h + 1, n4 = 4 * n_h, n2 = 2 * n_k, HC = 3;      // HC: coefficients of a hiding polynomial
   const uint64_t D = ix.max_degree;
-  if (k < 1 || k > 4 || n_h < 2 || n_k < 2 || n_x < 1 || n_h < 2 * n_x || (n_h & (n_h - 1)) || (n_k & (n_k - 1)) || (n_x & (n_x - 1)) ||
+  if (k < 1 || k > 8 || n_h < 2 || n_k < 2 || n_x < 1 || n_h < 2 * n_x || (n_h & (n_h - 1)) || (n_k & (n_k - 1)) || (n_x & (n_x - 1)) ||
       ix.n_public > n_x || ix.n_vars > n_h || ix.gamma_offset + HC > pb.n || D + 1 > pb.n || 3 * n_h > D + 1 || n_k > D + 1) {
     g_last_error = "varuna_prove: inconsistent index / key sizes"; return ALEO_MI355X_ERR_BAD_ARG;
   }
@@ -363,7 +363,7 @@ int32_t varuna_prove(Ctx* c, const PinnedBases& pb, const aleo_mi355x_varuna_ind
   }
   char* q1 = E + 3 * n4 * 32;
   if (k > 1) {
-    const void* terms[4]; size_t lens[4]; HFr co[4];
+    const void* terms[8]; size_t lens[8]; HFr co[8];
     for (size_t i = 0; i < k; ++i) { terms[i] = E + (3 + 3 * i) * n4 * 32; lens[i] = n4; co[i] = comb[i]; }
     RC(fr_lincomb(c, Q, n4, nullptr, terms, lens, co, k, s)); q1 = Q;
   }
@@ -431,7 +431,7 @@ int32_t varuna_prove(Ctx* c, const PinnedBases& pb, const aleo_mi355x_varuna_ind
   // ---- evaluations -------------------------------------------------------------------------------------------------------------------------------
   TAKE(evd, k + 8) TAKE(pbeta, 3 * n_h) TAKE(wq, 3 * n_h) TAKE(blq, HC) TAKE(pg, n_k) TAKE(gq, n_k)
   {
-    const void* polys[8]; size_t lens[8]; HFr pts[8];
+    const void* polys[12]; size_t lens[12]; HFr pts[12];
     for (size_t i = 0; i < k; ++i) { polys[i] = wit + (3 * i + 2) * L * 32; lens[i] = L; pts[i] = beta; }
     polys[k] = g1 + 32; lens[k] = n_h - 1; pts[k] = beta;
     for (size_t m = 0; m < 3; ++m) { polys[k + 1 + m] = f + (m * n_k + 1) * 32; lens[k + 1 + m] = n_k - 1; pts[k + 1 + m] = gamma; }
@@ -451,7 +451,7 @@ int32_t varuna_prove(Ctx* c, const PinnedBases& pb, const aleo_mi355x_varuna_ind
   HFr cst = HFr::neg(HFr::mul(beta, g1_beta));
   HFr random_v, blw[3];                                                                     // blw: (bl(X) − bl(beta)) / (X − beta), uploaded below
   {
-    const void* terms[20]; size_t lens[20]; HFr co[20]; size_t nt = 0;
+    const void* terms[28]; size_t lens[28]; HFr co[28]; size_t nt = 0;
     terms[nt] = mask; lens[nt] = 3 * n_h; co[nt++] = xl;
     terms[nt] = h1; lens[nt] = 2 * n_h; co[nt++] = HFr::neg(HFr::mul(xl, vh_beta));
     terms[nt] = g1 + 32; lens[nt] = n_h - 1; co[nt++] = one;

@@ -157,7 +157,7 @@ class CircuitIndex:
         self.vk_bytes = wire.g1_compress(self.index_commitments).tobytes() + n_h.to_bytes(8, 'little') + n_k.to_bytes(8, 'little') + n_x.to_bytes(8, 'little')
 
 
-MAX_INSTANCES = 4        # k + 4 evaluations go through one fr_eval_batch call (8 polynomials), 3k + 3 terms through one fr_lincomb call (20)
+MAX_INSTANCES = 8        # k + 4 evaluations go through one fr_eval_batch call (12 polynomials), 3k + 3 terms through one fr_lincomb call (28)
 
 
 class _NativeIndex(ctypes.Structure):
@@ -471,7 +471,7 @@ class Prover:
 
 
 def prove(index: CircuitIndex, assignment, seed: int, stream: torch.cuda.Stream = None) -> Proof:
-    """Varuna::prove_batch for one circuit with one to four instances (one assignment array, or a list of them); `seed` selects the proof's
+    """Varuna::prove_batch for one circuit with one to eight instances (one assignment array, or a list of them); `seed` selects the proof's
     random stream.  Proofs of one index may be
     produced concurrently from several host threads, each on its own `stream` (the index is read-only while proving)."""
     import time

@@ -368,6 +368,10 @@ def varuna_prove(synth, torch, lg, reps=7, in_flight=4):
         for rep in range(5):                               # prove_batch shape: four instances of the circuit in one proof
             t = time.perf_counter(); datab = varuna.prove_native(ix, [zz] * 4, 2000 + rep); tb.append((time.perf_counter() - t) * 1e3)
         mb = float(np.median(tb[1:]))
+        tb8 = []
+        for rep in range(4):
+            t = time.perf_counter(); varuna.prove_native(ix, [zz] * 8, 3000 + rep); tb8.append((time.perf_counter() - t) * 1e3)
+        mb8 = float(np.median(tb8[1:]))
         per = 6
         def work(k):
             for rep in range(per): varuna.prove_native(ix, zz, 5000 + 100 * k + rep)
@@ -381,6 +385,7 @@ def varuna_prove(synth, torch, lg, reps=7, in_flight=4):
                 'rounds_ms': rounds, 'proof_bytes': len(data), 'entry_point': 'aleo_mi355x_varuna_prove',
                 'python_host_ms': float(np.median(tp[1:])),
                 'instances_4': {'prove_ms': mb, 'constraints_per_s': 4 * n / mb * 1e3, 'proof_bytes': len(datab)},
+                'instances_8': {'prove_ms': mb8, 'constraints_per_s': 8 * n / mb8 * 1e3},
                 'in_flight_%d' % in_flight: {'proofs_per_s': in_flight * per / dt, 'constraints_per_s': n * in_flight * per / dt}, 'what': VARUNA_NOTE}
     finally:
         ck.close()

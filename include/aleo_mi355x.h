@@ -195,7 +195,7 @@ int32_t aleo_mi355x_fr_powers_device(void* d_dst, size_t n, const void* first_mo
 /* dst[i] = scale[i] * table1[idx1[i]] * table2[idx2[i]] (uint32 indices; d_scale and the second table may be NULL): the third round's
  * val(k) / ((alpha - row(k)) (beta - col(k))) from the two tables above, by the row / column index of every non-zero entry. */
 int32_t aleo_mi355x_fr_gather_mul_device(void* d_dst, size_t n, const void* d_scale, const void* d_table1, const void* d_idx1, const void* d_table2, const void* d_idx2, void* stream);
-/* out[q] = p_q(z_q) for k <= 8 polynomials in two launches (d_polys, lens, z_mont: host arrays of k device pointers / lengths /
+/* out[q] = p_q(z_q) for k <= 12 polynomials in two launches (d_polys, lens, z_mont: host arrays of k device pointers / lengths /
  * 32-byte Montgomery points; d_out: k x 32 bytes, device): the evaluations a proof carries (z_b, g_1 at beta; g_a, g_b, g_c at gamma). */
 int32_t aleo_mi355x_fr_eval_batch_device(void* d_out, const void* const* d_polys, const size_t* lens, const void* z_mont, size_t k, void* stream);
 /* Prover randomness generated in HBM.  Element i of stream `seed` = the first candidate j = 0, 1, ... below r, candidate (i, j) being the
@@ -203,8 +203,8 @@ int32_t aleo_mi355x_fr_eval_batch_device(void* d_out, const void* const* d_polys
  * 64-bit limbs; mix = the SplitMix64 finaliser).  Writes elements first_index .. first_index + n - 1, canonical or (montgomery != 0)
  * Montgomery.  Counter-based: the host can draw single elements of the same stream (the blinding scalars) without the device. */
 int32_t aleo_mi355x_fr_random_device(void* d_dst, size_t n, uint64_t seed, uint64_t first_index, int32_t montgomery, void* stream);
-/* dst[i] = c0 [i == 0] + sum_j coeffs[j] * terms[j][i], term j contributing for i < lens[j] (k <= 20 terms; d_terms / lens / coeffs_mont
- * host arrays; c0_mont may be NULL): the linear combinations opened at beta and gamma, in one pass.  dst must not alias a term. */
+/* dst[i] = c0 [i == 0] + sum_j coeffs[j] * terms[j][i], term j contributing for i < lens[j] (k <= 28 terms; d_terms / lens / coeffs_mont
+ * host arrays; c0_mont may be NULL): the linear combinations opened at beta and gamma, in one pass.  dst may be one of the terms (same offset). */
 int32_t aleo_mi355x_fr_lincomb_device(void* d_dst, size_t n, const void* c0_mont, const void* const* d_terms, const size_t* lens, const void* coeffs_mont, size_t k, void* stream);
 /* The numerators of the two sumchecks from evaluations already in HBM [UPSTREAM-RECALL: varuna/ahp/prover/round_functions/{second,fourth}.rs]:
  *   first:  dst = r (z_a + eta_b z_b + eta_c z_a z_b) - t z                  (n = 4|H| values each)
@@ -260,7 +260,7 @@ int32_t aleo_mi355x_proof_to_bytes(void* out, size_t* len, const aleo_mi355x_pro
 
 /* ---- one proof in one call: the host side of Varuna::prove_batch, native (aleo_amd/csrc/varuna.hip) -------------------------------
  * Replaces the CPU work snarkVM 0.14.5 does in algorithms/src/snark/varuna/{varuna.rs, ahp/prover/round_functions} [UPSTREAM-RECALL]
- * under /root/reference/rust/src/program/execute.rs:74 and transfer.rs:99 — for one circuit with 1..4 instances, a SHA-256 transcript and
+ * under /root/reference/rust/src/program/execute.rs:74 and transfer.rs:99 — for one circuit with 1..8 instances, a SHA-256 transcript and
  * the committer key the caller pinned (DESIGN.md 4d lists what differs from upstream).  The index is the prover-key material of the
  * circuit, built once (aleo_amd/varuna.py CircuitIndex does it through the entry points above) and described by device pointers:
  *   positions     host, uint32[n_vars]: index on H of every variable (public inputs on the subgroup X)

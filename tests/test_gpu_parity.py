@@ -973,21 +973,21 @@ def test_fr_gather_mul_matches_bigint():
 
 def test_fr_eval_batch_matches_oracle():
     """Up to eight polynomials of ragged lengths (empty, one coefficient, block boundaries, > 256 blocks) at their own points: each
-    value equals the oracle's synthetic division remainder; a ninth polynomial is refused."""
+    value equals the oracle's synthetic division remainder; a thirteenth polynomial is refused."""
     import torch
     from aleo_amd import poly
     lens = [0, 1, 16, 4095, 4096, 4097, 300001, (1 << 20) + 77]
     F = [c.fr_to_mont(util.uniform_scalars(max(n, 1), 26000 + i)) for i, n in enumerate(lens)]
     Z = c.fr_to_mont(util.uniform_scalars(len(lens), 26100)); Z[2] = 0; Z[3] = _mont1(1)
     D = [_dev(f) for f in F]
-    out = torch.zeros((8, 4), dtype=torch.int64, device='cuda'); torch.cuda.synchronize()
+    out = torch.zeros((16, 4), dtype=torch.int64, device='cuda'); torch.cuda.synchronize()
     poly.fr_eval_batch_device(out.data_ptr(), [d.data_ptr() for d in D], lens, Z); torch.cuda.synchronize()
     got = out.cpu().numpy().view(np.uint64)
     for i, n in enumerate(lens):
         want = c.fr_divide_by_linear(F[i][:n], Z[i])[1] if n else np.zeros(4, dtype=np.uint64)
         assert (got[i] == want).all(), (i, n)
     with pytest.raises(aleo_amd.AleoMi355xError):
-        poly.fr_eval_batch_device(out.data_ptr(), [D[1].data_ptr()] * 9, [1] * 9, np.zeros((9, 4), dtype=np.uint64))
+        poly.fr_eval_batch_device(out.data_ptr(), [D[1].data_ptr()] * 13, [1] * 13, np.zeros((13, 4), dtype=np.uint64))
     ev = torch.zeros(4, dtype=torch.int64, device='cuda')                      # the division entry point with no quotient: evaluation only
     poly.divide_by_linear_device(0, ev.data_ptr(), D[6].data_ptr(), lens[6], Z[6]); torch.cuda.synchronize()
     assert (ev.cpu().numpy().view(np.uint64) == got[6]).all()
@@ -1051,7 +1051,7 @@ def test_fr_lincomb_ragged_terms():
         for i, v in enumerate(c.limbs_to_ints(t[:min(l, n)])): want[i] = (want[i] + k * v) % r
     assert c.limbs_to_ints(c.fr_from_mont(dst.cpu().numpy().view(np.uint64))) == want
     with pytest.raises(aleo_amd.AleoMi355xError):
-        poly.fr_lincomb_device(dst.data_ptr(), n, None, [(D[0].data_ptr(), 1, _mont1(1))] * 21)
+        poly.fr_lincomb_device(dst.data_ptr(), n, None, [(D[0].data_ptr(), 1, _mont1(1))] * 29)
 
 
 def test_ahp_sumcheck_numerators_match_bigint():

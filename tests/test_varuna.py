@@ -85,7 +85,7 @@ def test_restatement_batch_of_instances():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('k', [2, 3, 4])
+@pytest.mark.parametrize('k', [2, 3, 4, 5, 8])
 def test_device_prover_batch_matches_restatement(k):
     from aleo_amd import varuna
     csr, z, c = _circuit(150, 3, 40 + k)
@@ -101,7 +101,7 @@ def test_device_prover_batch_matches_restatement(k):
         zq = [np.stack([synth.int_to_limbs(v, 4) for v in q]) for q in zs]
         assert varuna.prove_native(ix, zq, 500 + k) == want                            # the one-call C++ host side
         with varuna.NativeCircuitIndex(csr, 150, 3, len(z) - 3, ck) as nx: assert nx.prove(zq, 500 + k) == want
-        with pytest.raises(ValueError): varuna.prove(ix, [np.zeros((len(z), 4), dtype=np.uint64)] * 5, 1)
+        with pytest.raises(ValueError): varuna.prove(ix, [np.zeros((len(z), 4), dtype=np.uint64)] * 9, 1)
     finally:
         ck.close()
 

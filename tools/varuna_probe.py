@@ -31,6 +31,10 @@ for lg in [int(a) for a in sys.argv[1:]] or [13, 15, 16]:
     for rep in range(5):
         t = time.perf_counter(); varuna.prove_native(ix, [zz] * 4, 2000 + rep); tn4.append((time.perf_counter() - t) * 1e3)
     native['instances_4_ms'] = float(np.median(tn4[1:]))
+    tn8 = []
+    for rep in range(5):
+        t = time.perf_counter(); varuna.prove_native(ix, [zz] * 8, 3000 + rep); tn8.append((time.perf_counter() - t) * 1e3)
+    native['instances_8_ms'] = float(np.median(tn8[1:])); native['instances_8_constraints_per_s'] = 8 * n / native['instances_8_ms'] * 1e3
     batch = {}
     for kb in (2, 4):                                  # instances of the same circuit proved together (here: the same assignment k times)
         tb = []
