@@ -217,3 +217,53 @@ def test_whole_proof_entry_points_from_plain_cpp(tmp_path):
     out = open(fout, 'rb').read(); vk_len, plen = struct.unpack('<2Q', out[:16])
     assert out[16:16 + vk_len] == idx.vk_bytes() and out[16 + vk_len:16 + vk_len + plen] == want
     assert V.verify(idx, setup, [q[:3] for q in zs], out[16 + vk_len:16 + vk_len + plen])
+
+
+@pytest.mark.gpu
+def test_whole_proof_entry_points_refuse_misuse():
+    """Bad arguments come back as error codes (the caller falls back to its CPU prover), never as a fault: instance counts, inconsistent
+    index structs, non-canonical public inputs, foreign handles, malformed matrices, a committer key that is too small."""
+    import ctypes
+    from aleo_amd import varuna
+    L = aleo_amd.lib()
+    csr, z, c = _circuit(50, 2, 81)
+    D = _max_degree(c)
+    ck = varuna.synthetic_committer_key(TAU, S_GAMMA, D)
+    try:
+        ix = varuna.CircuitIndex(csr, 50, 2, len(z) - 2, ck)
+        zz = np.stack([synth.int_to_limbs(v, 4) for v in z])
+        good = varuna.prove_native(ix, zz, 5)
+        for k in (0, 9):
+            with pytest.raises((aleo_amd.AleoMi355xError, ValueError, IndexError)): varuna.prove_native(ix, [zz] * k, 5)
+        view = varuna.native_index(ix)
+        out = np.zeros(2048, dtype=np.uint8); n = ctypes.c_size_t(2048); ptrs = (ctypes.c_void_p * 1)(zz.ctypes.data)
+        def call(v): n.value = 2048; return L.aleo_mi355x_varuna_prove(ctypes.byref(v), ptrs, 1, 5, out.ctypes.data_as(ctypes.c_void_p), ctypes.byref(n))
+        def variant(**kw):
+            v = varuna._NativeIndex(); ctypes.memmove(ctypes.byref(v), ctypes.byref(view), ctypes.sizeof(v))
+            for a, b in kw.items(): setattr(v, a, b)
+            return v
+        assert call(variant()) == 0 and out[:n.value].tobytes() == good
+        assert call(variant(n_h=view.n_h - 1)) == 2 and call(variant(n_vars=view.n_h + 1)) == 2 and call(variant(n_x=view.n_h)) == 2
+        assert call(variant(max_degree=view.n_h)) == 2 and call(variant(gamma_offset=1 << 40)) == 2
+        assert call(variant(committer_key=987654321)) == 4
+        bad = zz.copy(); bad[1] = synth.int_to_limbs(V.R, 4)                       # a public input that is not below r
+        ptrs[0] = bad.ctypes.data; assert call(variant()) == 2; ptrs[0] = zz.ctypes.data
+        def build(rows_a=None, **kw):
+            mats = (varuna._R1csMatrix * 3)(); keep = []
+            for i, m in enumerate('abc'):
+                rp, col, val = (np.ascontiguousarray(x).copy() for x in csr[m])
+                if i == 0 and rows_a: rows_a(rp, col)
+                keep += [rp, col, val]; mats[i].row_ptr, mats[i].col, mats[i].val = rp.ctypes.data, col.ctypes.data, val.ctypes.data
+            h = ctypes.c_uint64(0)
+            a = dict(key=ck.bases.handle, max_degree=ck.max_degree, gamma_offset=ck.gamma_offset, n=50, pub=2, priv=len(z) - 2); a.update(kw)
+            rc = L.aleo_mi355x_varuna_index_build(ctypes.byref(h), a['key'], a['max_degree'], a['gamma_offset'], mats, a['n'], a['pub'], a['priv'])
+            if rc == 0: L.aleo_mi355x_varuna_index_free(h.value)
+            return rc
+        assert build() == 0
+        def shift(rp, col): rp[0] = 1
+        def wild(rp, col): col[3] = 10 ** 6
+        def back(rp, col): rp[5] = rp[6] + 1
+        assert build(shift) == 2 and build(wild) == 2 and build(back) == 2
+        assert build(max_degree=7) == 2 and build(key=123456789) == 4 and build(pub=0) == 2 and build(priv=len(z) + 10 ** 6) == 2
+    finally:
+        ck.close()
