@@ -407,7 +407,7 @@ def varuna_cpu(synth, lg):
         setup = V.Setup(VARUNA_TAU, VARUNA_S, D); idx = V.Index(c, setup)
         rand = V.random_stream(4242, c.n_h)
         t0 = time.perf_counter(); _, want = V.prove(idx, setup, z, rand); dt = time.perf_counter() - t0
-        return {'constraints': n, 'device_proof_verifies': bool(V.verify(idx, setup, z[:4], data)), 'device_proof_equals_restatement': bool(data == want),
+        return {'constraints': n, 'device_proof_verifies': bool(V.verify_pairing(idx, setup.verifier_key(c), z[:4], data)), 'verifier': 'pairing products over public G2 elements (oracle/pairing.py), no trapdoor', 'device_proof_equals_restatement': bool(data == want),
                 'restatement_prove_s': dt, 'restatement_constraints_per_s': n / dt, 'cores': 1,
                 'note': 'oracle/varuna_ref.py in plain Python integers: a checker, not a tuned CPU prover and not the Rust binary'}
     finally:

@@ -13,9 +13,9 @@ is a third-party dependency of the reference (Cargo.lock:2200) and absent from /
     /root/reference/wasm/src/programs/transaction.rs:100 (decoded in tests/golden/reference_proof.json);
   * SonicKZG10 commitments: hiding polynomials of degree 2 against the γ-powers, degree bounds through shifted powers.
 Deliberate differences, because the corresponding upstream data is not available offline: challenges come from a SHA-256 transcript
-(upstream: a Poseidon sponge over Fq whose parameters are not in /root/reference), one non-zero domain K is shared by A, B, C, and the
-pairing check of the verifier is replaced by the equivalent equation in G1 using the trapdoor of the synthetic SRS (τ is known here:
-bases are τ^i·G).  **Parity unpinned**: the reference holds no proof this restatement could be compared with value
+(upstream: a Poseidon sponge over Fq whose parameters are not in /root/reference), one non-zero domain K is shared by A, B, C.  Two verifiers:
+`verify_pairing` checks the openings as pairing products over public G2 elements (oracle/pairing.py); `verify` is the same check with the pairing
+replaced by the equivalent G1 equation under the synthetic setup's trapdoor (fast; used where many proofs are verified).  **Parity unpinned**: the reference holds no proof this restatement could be compared with value
 for value; what pins it is (i) the verifier below accepting its proofs and rejecting tampered ones, and (ii) the byte layout above."""
 from __future__ import annotations
 import hashlib
@@ -97,6 +97,13 @@ class Setup:
     def __init__(self, tau, s_gamma, max_degree):
         self.tau, self.s_gamma, self.max_degree = tau % R, s_gamma % R, max_degree
 
+    def verifier_key(self, circuit):
+        """What a verifier holds (public; derived from the trapdoor here as a ceremony would): γG, H, τH and the negative powers of τ in G2 that
+        un-shift degree-bounded commitments [UPSTREAM-RECALL: sonic_pc VerifierKey — h, beta_h, prepared_neg_powers_of_beta_h, gamma_g]."""
+        H = P.G2_GENERATOR; ti = inv(self.tau)
+        return {'gamma_g': P.g1_mul(P.G1_GENERATOR, self.s_gamma), 'h': H, 'tau_h': P.g2_mul(H, self.tau),
+                'neg_h': P.g2_mul(H, pow(ti, self.max_degree - (circuit.n_h - 2), R)), 'neg_k': P.g2_mul(H, pow(ti, self.max_degree - (circuit.n_k - 2), R))}
+
 
 def _commit_scalar(setup, coeffs, bound=None, blind=None):
     """Discrete log (base G) of SonicKZG10::commit: τ^(D − bound)·p(τ) + s·blind(τ)."""
@@ -130,6 +137,12 @@ class Index:
             self.evals[name] = {'row': row, 'col': col, 'val': val, 'row_col': rc}
             self.polys[name] = {k: self.K.ifft(v) for k, v in self.evals[name].items()}
         self.commit_scalars = {(m, k): _commit_scalar(setup, self.polys[m][k]) for m in 'abc' for k in ('row', 'col', 'val', 'row_col')}
+        self._points = None
+
+    def commit_points(self):
+        """The twelve index commitments as points (the circuit's verifying key)."""
+        if self._points is None: self._points = {mk: P.g1_mul(P.G1_GENERATOR, v) for mk, v in self.commit_scalars.items()}
+        return self._points
 
     def vk_bytes(self):
         out = b''
@@ -399,21 +412,19 @@ def parse_proof(data: bytes):
     return {'instances': k, 'witness': witness, 'commitments': c, 'evaluations': evals, 'sums': sums, 'openings': openings}
 
 
-def verify(index: Index, setup: Setup, public_inputs, data: bytes, vk_bytes=None) -> bool:
-    """Verifier: recomputes the challenges, forms the two linear combinations of commitments and checks both KZG openings.  The pairing
-    equation e(C − v·G − v̄·γG, H) = e(W, (τ − z)·H) is checked as C − v·G − v̄·γG = (τ − z)·W in G1 with the known trapdoor.
-    public_inputs: one list per instance (or a single list for one instance)."""
+def _verifier_state(index: Index, public_inputs, data: bytes, vk_bytes=None):
+    """Everything a verifier derives before the opening checks: parsed proof, challenges, the two linear-combination coefficient sets."""
     try: pr = parse_proof(data)
-    except AssertionError: return False
+    except AssertionError: return None
     if public_inputs and not isinstance(public_inputs[0], (list, tuple)): public_inputs = [public_inputs]
     k = pr['instances']
-    if len(public_inputs) != k: return False
+    if len(public_inputs) != k: return None
     c = index.circuit; H, K, X = index.H, index.K, index.X
     try:
         pts = {n_: P.g1_decompress(v) for n_, v in pr['commitments'].items()}; opn = [P.g1_decompress(p_) for p_, _ in pr['openings']]
         wit = [tuple(P.g1_decompress(v) for v in t) for t in pr['witness']]
-    except Exception: return False
-    if len(opn) != 2 or pr['openings'][0][1] is None or pr['openings'][1][1] is not None: return False
+    except Exception: return None
+    if len(opn) != 2 or pr['openings'][0][1] is None or pr['openings'][1][1] is not None: return None
     x_evals = [[pub[i] % R if i < c.n_public else 0 for i in range(c.n_x)] for pub in public_inputs]
     cb = pr['commitments']
     tr = Transcript(); tr.absorb(vk_bytes if vk_bytes is not None else index.vk_bytes())
@@ -428,24 +439,57 @@ def verify(index: Index, setup: Setup, public_inputs, data: bytes, vk_bytes=None
     evals = pr['evaluations']
     tr.absorb(b''.join(fr_bytes(v) for v in evals)); xi = tr.challenge(b'xi')
     zb_beta = evals[:k]; g1_beta, ga, gb, gc = evals[k:]
-    G = P.G1_GENERATOR
-    mul, add = P.g1_mul, P.g1_add
-    tau_inv = inv(setup.tau); D = setup.max_degree
-    def unshift(pt, bound): return mul(pt, pow(tau_inv, D - bound, R))
     x_beta = [poly_eval(X.ifft(xe), beta) for xe in x_evals]
-    lc1 = lincheck_coefficients(H, X, alpha, beta, eta, comb, sigma, zb_beta, g1_beta, x_beta)
+    return {'k': k, 'pts': pts, 'opn': opn, 'wit': wit, 'beta': beta, 'gamma': gamma, 'xi': xi, 'random_v': pr['openings'][0][1],
+            'lc1': lincheck_coefficients(H, X, alpha, beta, eta, comb, sigma, zb_beta, g1_beta, x_beta),
+            'lc2': matrix_coefficients(H, K, alpha, beta, gamma, delta, sigma, {'a': ga, 'b': gb, 'c': gc}),
+            'v_beta': (g1_beta + sum(pow(xi, 1 + i, R) * v for i, v in enumerate(zb_beta))) % R,
+            'v_gamma': (ga + xi * gb + xi * xi % R * gc) % R}
+
+
+def _unshifted_parts(st, index_points):
+    """The G1 sides of the two checks that carry no degree shift: sum_i xi^(1+i) z_b,i + xi^(k+1) LC1  and  xi^3 LC2."""
+    G = P.G1_GENERATOR; mul, add = P.g1_mul, P.g1_add
+    pts, wit, lc1, lc2, xi, k = st['pts'], st['wit'], st['lc1'], st['lc2'], st['xi'], st['k']
     C1 = add(add(mul(pts['mask'], lc1['mask']), mul(pts['h_1'], lc1['h_1'])), mul(G, lc1['const']))
     for (w_, a_, b_), kz, kw in zip(wit, lc1['z_a'], lc1['w']): C1 = add(C1, add(mul(a_, kz), mul(w_, kw)))
-    Cb = add(unshift(pts['g_1'], c.n_h - 2), mul(C1, pow(xi, k + 1, R)))
-    for i, (w_, a_, b_) in enumerate(wit): Cb = add(Cb, mul(b_, pow(xi, 1 + i, R)))
-    v_beta = (g1_beta + sum(pow(xi, 1 + i, R) * v for i, v in enumerate(zb_beta))) % R
-    lhs = add(Cb, P.g1_neg(mul(G, (v_beta + setup.s_gamma * pr['openings'][0][1]) % R)))
-    if lhs != mul(opn[0], (setup.tau - beta) % R): return False
-    lc2 = matrix_coefficients(H, K, alpha, beta, gamma, delta, sigma, {'a': ga, 'b': gb, 'c': gc})
-    C2 = mul(G, (lc2['const'] + sum(coef * index.commit_scalars[mk] for mk, coef in lc2['index'].items())) % R)   # index commitments are the key's
-    C2 = add(C2, mul(pts['h_2'], lc2['h_2']))
-    Cg = add(add(unshift(pts['g_a'], c.n_k - 2), mul(unshift(pts['g_b'], c.n_k - 2), xi)),
-             add(mul(unshift(pts['g_c'], c.n_k - 2), xi * xi % R), mul(C2, pow(xi, 3, R))))
-    v_gamma = (ga + xi * gb + xi * xi % R * gc) % R
-    lhs = add(Cg, P.g1_neg(mul(G, v_gamma)))
-    return lhs == mul(opn[1], (setup.tau - gamma) % R)
+    Rb = mul(C1, pow(xi, k + 1, R))
+    for i, (w_, a_, b_) in enumerate(wit): Rb = add(Rb, mul(b_, pow(xi, 1 + i, R)))
+    C2 = add(mul(G, lc2['const']), mul(pts['h_2'], lc2['h_2']))
+    for mk, coef in lc2['index'].items(): C2 = add(C2, mul(index_points[mk], coef))
+    return Rb, mul(C2, pow(xi, 3, R))
+
+
+def verify_pairing(index: Index, vk, public_inputs, data: bytes, vk_bytes=None) -> bool:
+    """The verifier proper: no trapdoor.  vk = Setup.verifier_key(circuit): gamma G, H, tau H and two negative powers of tau in G2; the
+    circuit's verifying key = the twelve index commitments.  Both batched KZG openings are checked as pairing products
+      e(shifted commitments, tau^-s H) · e(unshifted part − v G − v̄ gamma G, H) · e(−W, tau H − z H) = 1   (oracle/pairing.py)."""
+    from . import pairing as E
+    st = _verifier_state(index, public_inputs, data, vk_bytes)
+    if st is None: return False
+    G = P.G1_GENERATOR; mul, add, neg = P.g1_mul, P.g1_add, P.g1_neg
+    pts, xi = st['pts'], st['xi']
+    Rb, Rg = _unshifted_parts(st, index.commit_points())
+    Rb = add(Rb, neg(add(mul(G, st['v_beta']), mul(vk['gamma_g'], st['random_v']))))
+    Rg = add(Rg, neg(mul(G, st['v_gamma'])))
+    Sg = add(add(pts['g_a'], mul(pts['g_b'], xi)), mul(pts['g_c'], xi * xi % R))
+    zh = lambda z: P.g2_add(vk['tau_h'], P.g2_neg(P.g2_mul(vk['h'], z)))
+    if not E.pairing_product_is_one([(pts['g_1'], vk['neg_h']), (Rb, vk['h']), (neg(st['opn'][0]), zh(st['beta']))]): return False
+    return E.pairing_product_is_one([(Sg, vk['neg_k']), (Rg, vk['h']), (neg(st['opn'][1]), zh(st['gamma']))])
+
+
+def verify(index: Index, setup: Setup, public_inputs, data: bytes, vk_bytes=None) -> bool:
+    """The same two checks without pairings, for tests that verify many proofs: with the synthetic setup's trapdoor the pairing equation
+    e(C − v·G − v̄·γG, H) = e(W, (τ − z)·H) is the G1 equation C − v·G − v̄·γG = (τ − z)·W (verify_pairing is the verifier that needs no trapdoor)."""
+    st = _verifier_state(index, public_inputs, data, vk_bytes)
+    if st is None: return False
+    c = index.circuit; G = P.G1_GENERATOR; mul, add, neg = P.g1_mul, P.g1_add, P.g1_neg
+    pts, xi = st['pts'], st['xi']
+    tau_inv = inv(setup.tau); D = setup.max_degree
+    def unshift(pt, bound): return mul(pt, pow(tau_inv, D - bound, R))
+    Rb, Rg = _unshifted_parts(st, index.commit_points())
+    lhs = add(add(unshift(pts['g_1'], c.n_h - 2), Rb), neg(mul(G, (st['v_beta'] + setup.s_gamma * st['random_v']) % R)))
+    if lhs != mul(st['opn'][0], (setup.tau - st['beta']) % R): return False
+    Sg = add(add(unshift(pts['g_a'], c.n_k - 2), mul(unshift(pts['g_b'], c.n_k - 2), xi)), mul(unshift(pts['g_c'], c.n_k - 2), xi * xi % R))
+    lhs = add(add(Sg, Rg), neg(mul(G, st['v_gamma'])))
+    return lhs == mul(st['opn'][1], (setup.tau - st['gamma']) % R)

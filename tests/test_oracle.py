@@ -158,3 +158,20 @@ def test_g2_constants_and_oracle_msm_match_golden():
         B = mult[np.array(case['base_multipliers']) - 1]; S = c.ints_to_limbs(_ints(case['scalars']), 4)
         assert c.g2_jac_to_int_point(c.msm_g2(B, S)) == _g2pt(case['result']), (case['n'], case['kind'])
         assert c.g2_jac_to_int_point(c.msm_g2(np.ascontiguousarray(B[:, :192]), S)) == _g2pt(case['result'])       # stride 192
+
+
+def test_pairing_is_bilinear_and_of_order_r():
+    """oracle/pairing.py (the ate pairing over Fq12 = Fq[w]/(w^12 + 5), used by the prover's verifier): non-degenerate, of order r,
+    bilinear in both arguments, additive, trivial on the identity; the twist constant is 1/u."""
+    from oracle import pairing as E
+    q, r = p.FQ_MODULUS, p.FR_MODULUS
+    assert p.G2_COEFF_B == (0, (-pow(5, -1, q)) % q) and r == E.X_PARAM ** 4 - E.X_PARAM ** 2 + 1 and (q ** 12 - 1) % r == 0
+    G, H = p.G1_GENERATOR, p.G2_GENERATOR
+    e = E.pairing(G, H)
+    assert e != E.ONE12 and E.f12_pow(e, r) == E.ONE12
+    a, b = 0x1234567890ABCDEF123, 0xFEDCBA0987654321
+    assert E.pairing(p.g1_mul(G, a), p.g2_mul(H, b)) == E.f12_pow(e, a * b % r)
+    assert E.pairing(p.g1_add(p.g1_mul(G, a), p.g1_mul(G, b)), H) == E.f12_mul(E.pairing(p.g1_mul(G, a), H), E.pairing(p.g1_mul(G, b), H))
+    assert E.pairing(None, H) == E.ONE12 and E.pairing(G, None) == E.ONE12
+    assert E.pairing_product_is_one([(p.g1_mul(G, a), H), (p.g1_neg(G), p.g2_mul(H, a))])
+    assert not E.pairing_product_is_one([(p.g1_mul(G, a), H), (p.g1_neg(G), p.g2_mul(H, a + 1))])

@@ -36,6 +36,12 @@ def test_restatement_proves_and_verifies():
     proof, data = V.prove(idx, setup, z, rand)
     assert len(data) == 901                      # the reference's proof string decodes to 901 bytes for one circuit, one instance
     assert V.verify(idx, setup, z[:3], data)
+    vk = setup.verifier_key(c)                   # the verifier proper: pairing products over public G2 elements, no trapdoor
+    assert V.verify_pairing(idx, vk, z[:3], data)
+    for pos in (100, 520, 700, 800, 860):
+        bad = bytearray(data); bad[pos] ^= 1
+        assert not V.verify_pairing(idx, vk, z[:3], bytes(bad))
+    assert not V.verify_pairing(idx, vk, [1, (z[1] + 1) % V.R, z[2]], data)
     # the layout is the reference's: the proof string it holds (wasm/src/programs/transaction.rs:100) parses with the same parser,
     # field for field (commitments at the offsets of tests/golden/reference_proof.json, the hiding value on the first opening only)
     ref = json.load(open(os.path.join(os.path.dirname(__file__), 'golden', 'reference_proof.json')))
@@ -76,7 +82,7 @@ def test_restatement_batch_of_instances():
     proof, data = V.prove(idx, setup, zs, _rand(c, 31, 3))
     assert len(data) == 901 + 2 * (3 * 48 + 32) and proof['instances'] == 3
     pubs = [q[:3] for q in zs]
-    assert V.verify(idx, setup, pubs, data)
+    assert V.verify(idx, setup, pubs, data) and V.verify_pairing(idx, setup.verifier_key(c), pubs, data)
     assert not V.verify(idx, setup, [pubs[1], pubs[0], pubs[2]], data)
     assert not V.verify(idx, setup, pubs[:2], data)
     bad = bytearray(data); bad[17 + 48 * 5 + 3] ^= 1                          # z_b of the second instance
@@ -149,6 +155,7 @@ def test_device_prover_verifies_at_2_13():
         zz = np.stack([synth.int_to_limbs(v, 4) for v in z])
         data = varuna.prove(ix, zz, 77).to_bytes()
         assert len(data) == 901 and V.verify(idx, setup, z[:4], data)
+        assert V.verify_pairing(idx, setup.verifier_key(c), z[:4], data)          # and by the verifier that holds no trapdoor
         bad = bytearray(data); bad[600] ^= 4
         assert not V.verify(idx, setup, z[:4], bytes(bad))
         z2 = zz.copy(); z2[100, 0] ^= np.uint64(1)                       # a wrong witness: the proof comes out, the verifier refuses it
