@@ -723,7 +723,7 @@ int32_t aleo_mi355x_ahp_first_sumcheck_device(void* d_dst, size_t n, const void*
 
 int32_t aleo_mi355x_ahp_matrix_sumcheck_device(void* d_dst, size_t n, const void* const* d_index, size_t index_stride, const void* const* d_f, const void* consts_mont, void* stream) {
   try {
-    if (n && (!d_dst || !d_index || !d_f || !consts_mont || !d_index[0] || !d_index[1] || !d_index[2] || !d_f[0] || !d_f[1] || !d_f[2])) return ALEO_MI355X_ERR_BAD_ARG;
+    if (n && (!d_dst || !d_index || !d_f || !consts_mont || (d_index[0] && !d_f[0]) || (d_index[1] && !d_f[1]) || (d_index[2] && !d_f[2]))) return ALEO_MI355X_ERR_BAD_ARG;
     API_BEGIN
     return run_enqueue(c, stream, [&](hipStream_t s) { return ahp_matrix_sumcheck(c, d_dst, n, d_index, index_stride, d_f, consts_mont, s); });
   } catch (...) { return ALEO_MI355X_ERR_HIP; }

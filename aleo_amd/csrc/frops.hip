@@ -467,12 +467,13 @@ int32_t ahp_first_sumcheck(Ctx* c, void* d_dst, size_t n, const void* d_r, const
   HIPCHK(hipGetLastError());
   return ALEO_MI355X_OK;
 }
-struct MatArgs { const char* idx[3]; const char* f[3]; FrK delta[3]; FrK ab, nalpha, nbeta, vv; size_t stride; };
+struct MatArgs { const char* idx[3]; const char* f[3]; FrK delta[3]; FrK ab, nalpha, nbeta, vv; size_t stride; };      // idx[m] == nullptr: matrix m is absent
 __global__ void __launch_bounds__(256) k_ahp_matrix_sumcheck(char* __restrict__ dst, size_t n, MatArgs a) {
   const Fr ab = fr_arg(a.ab), na = fr_arg(a.nalpha), nb = fr_arg(a.nbeta), vv = fr_arg(a.vv);
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
     Fr acc = Fr::zero();
     for (int m = 0; m < 3; ++m) {
+      if (!a.idx[m]) continue;                                                                // (uniform across the grid)
       const char* e = a.idx[m] + i * 32;                                                    // row, col, val, row_col: `stride` bytes apart
       Fr bq = Fr::cond_sub<2>(Fr::add(ab, Fr::mul(nb, load_fp<Fr>(e))));                     // alpha beta − beta row            < 2r
       bq = Fr::cond_sub<2>(Fr::add(bq, Fr::mul(na, load_fp<Fr>(e + a.stride))));             // − alpha col                      < 2r

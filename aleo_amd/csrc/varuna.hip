@@ -153,9 +153,10 @@ int32_t varuna_index_build(Ctx* c, const PinnedBases& pb, std::shared_ptr<Pinned
     for (uint64_t e = 0; e < nnz[m]; ++e) if (abc[m].col[e] >= n_vars) { g_last_error = "varuna_index: column outside the variables"; return ALEO_MI355X_ERR_BAD_ARG; }
     for (size_t r = 0; r < n_constraints; ++r) if (abc[m].row_ptr[r + 1] < abc[m].row_ptr[r]) { g_last_error = "varuna_index: row_ptr not monotone"; return ALEO_MI355X_ERR_BAD_ARG; }
   }
-  const uint64_t n_k = pow2_at_least(nnz_max, 2);
+  uint64_t nk[3], ko[3], k_sum = 0, n_k = 0;                 // one non-zero domain per matrix; ko: elements of the earlier matrices
+  for (int m = 0; m < 3; ++m) { nk[m] = pow2_at_least(nnz[m], 2); ko[m] = k_sum; k_sum += nk[m]; n_k = nk[m] > n_k ? nk[m] : n_k; }
+  (void)nnz_max;
   if (3 * n_h > max_degree + 1 || n_k > max_degree + 1 || max_degree + 1 > pb.n || gamma_offset + 3 > pb.n) { g_last_error = "varuna_index: committer key too small for this circuit"; return ALEO_MI355X_ERR_BAD_ARG; }
-  uint32_t lg_k = 0; while ((1ull << lg_k) < n_k) ++lg_k;
   // variable -> position on H: public i -> i |H|/|X|, the j-th private one -> the j-th element of H \ X
   const uint64_t ratio = n_h / n_x;
   o->positions.resize(n_vars);
@@ -163,16 +164,16 @@ int32_t varuna_index_build(Ctx* c, const PinnedBases& pb, std::shared_ptr<Pinned
   HFr r2; std::memcpy(r2.l, host::HParams<4>::R2, 32);
   const HFr one = HFr::one();
   aleo_mi355x_varuna_index& V = o->view;
-  V.n_h = n_h; V.n_k = n_k; V.n_x = n_x; V.n_public = n_public; V.n_vars = n_vars; V.committer_key = key_handle; V.max_degree = max_degree; V.gamma_offset = gamma_offset;
+  V.n_h = n_h; V.n_k_a = nk[0]; V.n_k_b = nk[1]; V.n_k_c = nk[2]; V.n_x = n_x; V.n_public = n_public; V.n_vars = n_vars; V.committer_key = key_handle; V.max_degree = max_degree; V.gamma_offset = gamma_offset;
   // host staging of everything that is index arithmetic on integers
-  std::vector<uint32_t> rp(n_h + 1), tp(n_h + 1, 0), kidx(6 * n_k, 0);
-  std::vector<uint32_t> cpos[3]; std::vector<uint32_t> tcol(nnz_sum); std::vector<uint8_t> tval(nnz_sum * 32), kval(3 * n_k * 32, 0);
+  std::vector<uint32_t> rp(n_h + 1), tp(n_h + 1, 0), kidx(2 * k_sum, 0);
+  std::vector<uint32_t> cpos[3]; std::vector<uint32_t> tcol(nnz_sum); std::vector<uint8_t> tval(nnz_sum * 32), kval(k_sum * 32, 0);
   for (int m = 0; m < 3; ++m) {
     cpos[m].resize(nnz[m]);
     for (uint64_t e = 0; e < nnz[m]; ++e) { cpos[m][e] = o->positions[abc[m].col[e]]; tp[cpos[m][e] + 1]++; }
     for (size_t r = 0; r < n_constraints; ++r)
-      for (uint64_t e = abc[m].row_ptr[r]; e < abc[m].row_ptr[r + 1]; ++e) { kidx[(2 * m) * n_k + e] = (uint32_t)r; kidx[(2 * m + 1) * n_k + e] = cpos[m][e]; }
-    if (nnz[m]) std::memcpy(&kval[m * n_k * 32], abc[m].val, nnz[m] * 32);
+      for (uint64_t e = abc[m].row_ptr[r]; e < abc[m].row_ptr[r + 1]; ++e) { kidx[2 * ko[m] + e] = (uint32_t)r; kidx[2 * ko[m] + nk[m] + e] = cpos[m][e]; }
+    if (nnz[m]) std::memcpy(&kval[ko[m] * 32], abc[m].val, nnz[m] * 32);
   }
   for (uint64_t i = 0; i < n_h; ++i) tp[i + 1] += tp[i];
   {
@@ -205,34 +206,36 @@ int32_t varuna_index_build(Ctx* c, const PinnedBases& pb, std::shared_ptr<Pinned
   V.vx_inv = vx;
   // arithmetisation over K: row, col, val = M[r,c] col / |H|, row_col — padding: row = col = 1 (position 0), val = 0
   void *kev, *kid, *kpo, *k2, *kv;
-  RC(o->alloc(&kev, 12 * n_k * 32)); RC(o->alloc(&kpo, 12 * n_k * 32)); RC(o->alloc(&k2, 24 * n_k * 32));
-  RC(up(&kid, kidx.data(), 6 * n_k * 4)); RC(up(&kv, kval.data(), 3 * n_k * 32)); RC(to_mont(kv, 3 * n_k));
+  RC(o->alloc(&kev, 4 * k_sum * 32)); RC(o->alloc(&kpo, 4 * k_sum * 32)); RC(o->alloc(&k2, 8 * k_sum * 32));
+  RC(up(&kid, kidx.data(), 2 * k_sum * 4)); RC(up(&kv, kval.data(), k_sum * 32)); RC(to_mont(kv, k_sum));
   const HFr nh_inv = HFr::inv(fr_u64(n_h));
+  HIPCHK(hipMemsetAsync(k2, 0, 8 * k_sum * 32, s));
   for (int m = 0; m < 3; ++m) {
-    char* e = (char*)kev + 4 * m * n_k * 32; const uint32_t* ri = (const uint32_t*)kid + (2 * m) * n_k; const uint32_t* ci = ri + n_k;
-    RC(fr_gather_mul(c, e, n_k, nullptr, he, ri, nullptr, nullptr, s));
-    RC(fr_gather_mul(c, e + n_k * 32, n_k, nullptr, he, ci, nullptr, nullptr, s));
-    RC(fr_vec_op(c, e + 2 * n_k * 32, (char*)kv + m * n_k * 32, e + n_k * 32, n_k, 0, s));
-    RC(fr_lin(c, e + 2 * n_k * 32, n_k, nullptr, nh_inv.l, e + 2 * n_k * 32, nullptr, nullptr, s));
-    RC(fr_vec_op(c, e + 3 * n_k * 32, e, e + n_k * 32, n_k, 0, s));
+    const uint64_t n = nk[m]; uint32_t lg = 0; while ((1ull << lg) < n) ++lg;
+    char* e = (char*)kev + 4 * ko[m] * 32; const uint32_t* ri = (const uint32_t*)kid + 2 * ko[m]; const uint32_t* ci = ri + n;
+    RC(fr_gather_mul(c, e, n, nullptr, he, ri, nullptr, nullptr, s));
+    RC(fr_gather_mul(c, e + n * 32, n, nullptr, he, ci, nullptr, nullptr, s));
+    RC(fr_vec_op(c, e + 2 * n * 32, (char*)kv + ko[m] * 32, e + n * 32, n, 0, s));
+    RC(fr_lin(c, e + 2 * n * 32, n, nullptr, nh_inv.l, e + 2 * n * 32, nullptr, nullptr, s));
+    RC(fr_vec_op(c, e + 3 * n * 32, e, e + n * 32, n, 0, s));
+    char* po = (char*)kpo + 4 * ko[m] * 32; char* e2 = (char*)k2 + 8 * ko[m] * 32;
+    HIPCHK(hipMemcpyAsync(po, e, 4 * n * 32, hipMemcpyDeviceToDevice, s));
+    RC(ntt_run(c, po, lg, 4, 0, 1, 0, s));
+    for (int j = 0; j < 4; ++j) HIPCHK(hipMemcpyAsync(e2 + (size_t)j * 2 * n * 32, po + (size_t)j * n * 32, n * 32, hipMemcpyDeviceToDevice, s));
+    RC(ntt_run(c, e2, lg + 1, 4, 0, 0, 0, s));
   }
-  HIPCHK(hipMemcpyAsync(kpo, kev, 12 * n_k * 32, hipMemcpyDeviceToDevice, s));
-  RC(ntt_run(c, kpo, lg_k, 12, 0, 1, 0, s));
-  HIPCHK(hipMemsetAsync(k2, 0, 24 * n_k * 32, s));
-  for (int q = 0; q < 12; ++q) HIPCHK(hipMemcpyAsync((char*)k2 + (size_t)q * 2 * n_k * 32, (char*)kpo + (size_t)q * n_k * 32, n_k * 32, hipMemcpyDeviceToDevice, s));
-  RC(ntt_run(c, k2, lg_k + 1, 12, 0, 0, 0, s));
   V.k_evals = kev; V.k_idx = kid; V.k_polys = kpo; V.k2_evals = k2; V.positions = o->positions.data();
   // index commitments -> what the transcript absorbs first
   uint8_t aff[12 * 104];
   {
     std::vector<MsmSeg> sg(12);
-    for (int q = 0; q < 12; ++q) { sg[q].d_ptr = (char*)kpo + (size_t)q * n_k * 32; sg[q].len = n_k; sg[q].off = 0; sg[q].out = (uint32_t)q; }
+    for (int q = 0; q < 12; ++q) { const int m = q / 4, j = q % 4; sg[q].d_ptr = (char*)kpo + (4 * ko[m] + (size_t)j * nk[m]) * 32; sg[q].len = nk[m]; sg[q].off = 0; sg[q].out = (uint32_t)q; }
     RC(commit(c, pb, sg, 12, aff, s));
   }
   HIPCHK(hipStreamSynchronize(s));
-  o->vk.resize(12 * 48 + 24);
+  o->vk.resize(12 * 48 + 40);
   RC(aleo_mi355x_g1_compress(o->vk.data(), aff, 12));
-  const uint64_t dims[3] = {n_h, n_k, n_x}; std::memcpy(&o->vk[12 * 48], dims, 24);
+  const uint64_t dims[5] = {n_h, nk[0], nk[1], nk[2], n_x}; std::memcpy(&o->vk[12 * 48], dims, 40);
   V.vk_bytes = o->vk.data(); V.vk_len = o->vk.size();
   *out = o.release();
   return ALEO_MI355X_OK;
@@ -241,17 +244,21 @@ int32_t varuna_index_build(Ctx* c, const PinnedBases& pb, std::shared_ptr<Pinned
 
 int32_t varuna_prove(Ctx* c, const PinnedBases& pb, const aleo_mi355x_varuna_index& ix, const void* const* assignments, size_t k, uint64_t seed,
                      uint8_t* out, size_t* out_len) {
-  const size_t n_h = ix.n_h, n_k = ix.n_k, n_x = ix.n_x, L = n_h + 1, n4 = 4 * n_h, n2 = 2 * n_k, HC = 3;      // HC: coefficients of a hiding polynomial
+  const size_t n_h = ix.n_h, n_x = ix.n_x, L = n_h + 1, n4 = 4 * n_h, HC = 3;      // HC: coefficients of a hiding polynomial
+  const size_t nk[3] = {(size_t)ix.n_k_a, (size_t)ix.n_k_b, (size_t)ix.n_k_c}, ko[3] = {0, nk[0], nk[0] + nk[1]}, k_sum = nk[0] + nk[1] + nk[2];
+  const size_t n_k = nk[0] > nk[1] ? (nk[0] > nk[2] ? nk[0] : nk[2]) : (nk[1] > nk[2] ? nk[1] : nk[2]);      // K: the largest non-zero domain
   const uint64_t D = ix.max_degree;
-  if (k < 1 || k > 8 || n_h < 2 || n_k < 2 || n_x < 1 || n_h < 2 * n_x || (n_h & (n_h - 1)) || (n_k & (n_k - 1)) || (n_x & (n_x - 1)) ||
+  bool k_ok = true; for (int m = 0; m < 3; ++m) k_ok = k_ok && nk[m] >= 2 && !(nk[m] & (nk[m] - 1));
+  if (k < 1 || k > 8 || n_h < 2 || !k_ok || n_x < 1 || n_h < 2 * n_x || (n_h & (n_h - 1)) || (n_x & (n_x - 1)) ||
       ix.n_public > n_x || ix.n_vars > n_h || ix.gamma_offset + HC > pb.n || D + 1 > pb.n || 3 * n_h > D + 1 || n_k > D + 1) {
     g_last_error = "varuna_prove: inconsistent index / key sizes"; return ALEO_MI355X_ERR_BAD_ARG;
   }
-  uint32_t lg_h = 0, lg_k = 0; while ((1ull << lg_h) < n_h) ++lg_h; while ((1ull << lg_k) < n_k) ++lg_k;
+  uint32_t lg_h = 0, lg_km[3] = {0, 0, 0}; while ((1ull << lg_h) < n_h) ++lg_h;
+  for (int m = 0; m < 3; ++m) while ((1ull << lg_km[m]) < nk[m]) ++lg_km[m];
   hipStream_t s = c->stream;
   double t_mark[7]; t_mark[0] = now_ms();
   // ---- workspace ------------------------------------------------------------------------------------------------------------------
-  const size_t elems = n_h * (40 + 20 * k) + n_k * 16 + 4096;
+  const size_t elems = n_h * (40 + 20 * k) + k_sum * 6 + n_k * 4 + 4096;
   RC(c->prover_ws.reserve(elems * 32 + (64 << 10)));
   Arena ar{(char*)c->prover_ws.p, 0, c->prover_ws.cap};
   const size_t pin_need = k * n_h * 32 + 4096;
@@ -386,23 +393,24 @@ int32_t varuna_prove(Ctx* c, const PinnedBases& pb, const aleo_mi355x_varuna_ind
   const HFr vh_beta = vanish(n_h, beta);
   if (vh_beta.is_zero()) { g_last_error = "varuna_prove: beta landed in H"; return ALEO_MI355X_ERR_HIP; }
   const HFr vv = HFr::mul(vh_alpha, vh_beta);
-  TAKE(f, 3 * n_k) TAKE(rb, n_h)
+  TAKE(f, k_sum) TAKE(rb, n_h)                                                              // f_M at element ko[M], |K_M| values
   {
     const HFr first = HFr::pow_u64(beta, n_h - 1), ratio = HFr::inv(beta);
     RC(fr_powers(c, rb, n_h, first.l, ratio.l, s));
   }
   RC(ntt_run(c, rb, lg_h, 1, 0, 0, 0, s));
-  for (size_t m = 0; m < 3; ++m)                                                             // f_M = val u_H(alpha, row) u_H(beta, col) on K: two gathers
-    RC(fr_gather_mul(c, f + m * n_k * 32, n_k, (const char*)ix.k_evals + (4 * m + 2) * n_k * 32, ext, (const uint32_t*)ix.k_idx + (2 * m) * n_k, rb,
-                     (const uint32_t*)ix.k_idx + (2 * m + 1) * n_k, s));
-  RC(ntt_run(c, f, lg_k, 3, 0, 1, 0, s));
-  for (size_t m = 0; m < 3; ++m) HIPCHK(hipMemcpyAsync(pin_small + 32 * m, f + m * n_k * 32, 32, hipMemcpyDeviceToHost, s));
+  for (size_t m = 0; m < 3; ++m) {                                                           // f_M = val u_H(alpha, row) u_H(beta, col) on K_M: two gathers
+    const uint32_t* ri = (const uint32_t*)ix.k_idx + 2 * ko[m];
+    RC(fr_gather_mul(c, f + ko[m] * 32, nk[m], (const char*)ix.k_evals + (4 * ko[m] + 2 * nk[m]) * 32, ext, ri, rb, ri + nk[m], s));
+    RC(ntt_run(c, f + ko[m] * 32, lg_km[m], 1, 0, 1, 0, s));
+    HIPCHK(hipMemcpyAsync(pin_small + 32 * m, f + ko[m] * 32, 32, hipMemcpyDeviceToHost, s));
+  }
   HIPCHK(hipStreamSynchronize(s));
   HFr sigma[3]; uint8_t sig_bytes[96];
-  for (size_t m = 0; m < 3; ++m) { HFr v; std::memcpy(v.l, pin_small + 32 * m, 32); sigma[m] = HFr::mul(v, fr_u64(n_k)); fr_bytes(sig_bytes + 32 * m, sigma[m]); }
+  for (size_t m = 0; m < 3; ++m) { HFr v; std::memcpy(v.l, pin_small + 32 * m, 32); sigma[m] = HFr::mul(v, fr_u64(nk[m])); fr_bytes(sig_bytes + 32 * m, sigma[m]); }
   {
     std::vector<MsmSeg> sg(3);
-    for (size_t m = 0; m < 3; ++m) { sg[m].d_ptr = f + (m * n_k + 1) * 32; sg[m].len = n_k - 1; sg[m].off = D - (n_k - 2); sg[m].out = (uint32_t)m; }
+    for (size_t m = 0; m < 3; ++m) { sg[m].d_ptr = f + (ko[m] + 1) * 32; sg[m].len = nk[m] - 1; sg[m].off = D - (nk[m] - 2); sg[m].out = (uint32_t)m; }
     RC(commit(c, pb, sg, 3, aff3, s));
   }
   RC(aleo_mi355x_g1_compress(comp.data(), aff3, 3));
@@ -410,17 +418,22 @@ int32_t varuna_prove(Ctx* c, const PinnedBases& pb, const aleo_mi355x_varuna_ind
   HFr delta[3] = {one, tr.challenge("delta_b", 7), tr.challenge("delta_c", 7)};
   t_mark[3] = now_ms();
   // ---- round 4 ----------------------------------------------------------------------------------------------------------------------------------
-  TAKE(F, 3 * n2) TAKE(B, n2) TAKE(h2, n_k)
-  HIPCHK(hipMemsetAsync(F, 0, 3 * n2 * 32, s));
-  for (size_t m = 0; m < 3; ++m) HIPCHK(hipMemcpyAsync(F + m * n2 * 32, f + m * n_k * 32, n_k * 32, hipMemcpyDeviceToDevice, s));
-  RC(ntt_run(c, F, lg_k + 1, 3, 0, 0, 0, s));
+  TAKE(F, 2 * k_sum) TAKE(B, 2 * k_sum) TAKE(h2, n_k)                                          // per matrix on its own domain of size 2|K_M|
+  HIPCHK(hipMemsetAsync(F, 0, 2 * k_sum * 32, s));
   {
-    const void* idx[3]; const void* ff[3]; HFr consts[7] = {delta[0], delta[1], delta[2], HFr::mul(alpha, beta), HFr::neg(alpha), HFr::neg(beta), vv};
-    for (size_t m = 0; m < 3; ++m) { idx[m] = (const char*)ix.k2_evals + 4 * m * n2 * 32; ff[m] = F + m * n2 * 32; }
-    RC(ahp_matrix_sumcheck(c, B, n2, idx, n2, ff, consts, s));
+    const void* terms[3]; size_t lens[3]; HFr co[3];
+    HFr consts[7] = {one, one, one, HFr::mul(alpha, beta), HFr::neg(alpha), HFr::neg(beta), vv};
+    for (size_t m = 0; m < 3; ++m) {
+      const size_t n2 = 2 * nk[m]; char* Fm = F + 2 * ko[m] * 32; char* Bm = B + 2 * ko[m] * 32;
+      HIPCHK(hipMemcpyAsync(Fm, f + ko[m] * 32, nk[m] * 32, hipMemcpyDeviceToDevice, s));
+      RC(ntt_run(c, Fm, lg_km[m] + 1, 1, 0, 0, 0, s));
+      const void* idx[3] = {(const char*)ix.k2_evals + 8 * ko[m] * 32, nullptr, nullptr}; const void* ff[3] = {Fm, nullptr, nullptr};
+      RC(ahp_matrix_sumcheck(c, Bm, n2, idx, n2, ff, consts, s));                                // vv val − b f
+      RC(ntt_run(c, Bm, lg_km[m] + 1, 1, 0, 1, 0, s));
+      terms[m] = Bm + nk[m] * 32; lens[m] = nk[m]; co[m] = delta[m];                           // P_M = h_M (X^|K_M| − 1): h_M is the upper half
+    }
+    RC(fr_lincomb(c, h2, n_k, nullptr, terms, lens, co, 3, s));                                 // h_2 = sum_M delta_M h_M
   }
-  RC(ntt_run(c, B, lg_k + 1, 1, 0, 1, 0, s));
-  HIPCHK(hipMemcpyAsync(h2, B + n_k * 32, n_k * 32, hipMemcpyDeviceToDevice, s));             // P = h_2 (X^|K| − 1)
   {
     std::vector<MsmSeg> sg(1); sg[0].d_ptr = h2; sg[0].len = n_k; sg[0].off = 0; sg[0].out = 0;
     RC(commit(c, pb, sg, 1, aff4, s));
@@ -434,7 +447,7 @@ int32_t varuna_prove(Ctx* c, const PinnedBases& pb, const aleo_mi355x_varuna_ind
     const void* polys[12]; size_t lens[12]; HFr pts[12];
     for (size_t i = 0; i < k; ++i) { polys[i] = wit + (3 * i + 2) * L * 32; lens[i] = L; pts[i] = beta; }
     polys[k] = g1 + 32; lens[k] = n_h - 1; pts[k] = beta;
-    for (size_t m = 0; m < 3; ++m) { polys[k + 1 + m] = f + (m * n_k + 1) * 32; lens[k + 1 + m] = n_k - 1; pts[k + 1 + m] = gamma; }
+    for (size_t m = 0; m < 3; ++m) { polys[k + 1 + m] = f + (ko[m] + 1) * 32; lens[k + 1 + m] = nk[m] - 1; pts[k + 1 + m] = gamma; }
     RC(fr_eval_batch(c, evd, polys, lens, pts, k + 4, s));
   }
   HIPCHK(hipMemcpyAsync(pin_small, evd, (k + 4) * 32, hipMemcpyDeviceToHost, s));
@@ -479,19 +492,20 @@ int32_t varuna_prove(Ctx* c, const PinnedBases& pb, const aleo_mi355x_varuna_ind
   RC(fr_divide_by_linear(c, wq, evd + (k + 5) * 32, pbeta, 3 * n_h, beta.l, s));
   // ---- the linear combination of the second sumcheck, opened at gamma together with g_a, g_b, g_c --------------------------------------------------
   {
-    const HFr xi2 = HFr::sqr(xi), xi3 = HFr::mul(xi2, xi), nk_inv = HFr::inv(fr_u64(n_k)), vk_gamma = vanish(n_k, gamma);
+    const HFr xi2 = HFr::sqr(xi), xi3 = HFr::mul(xi2, xi), vk_gamma = vanish(n_k, gamma);
     const void* terms[20]; size_t lens[20]; HFr co[20]; size_t nt = 0; HFr cg = HFr::zero();
     const HFr gk[3] = {ga, gb, gc};
     for (size_t m = 0; m < 3; ++m) {
-      const HFr fm = HFr::add(HFr::mul(gamma, gk[m]), HFr::mul(sigma[m], nk_inv)), d = HFr::mul(delta[m], xi3), dfm = HFr::mul(d, fm);
+      const HFr fm = HFr::add(HFr::mul(gamma, gk[m]), HFr::mul(sigma[m], HFr::inv(fr_u64(nk[m]))));
+      const HFr d = HFr::mul(HFr::mul(delta[m], xi3), HFr::mul(vk_gamma, HFr::inv(vanish(nk[m], gamma))));     // selector v_K / v_{K_M} at gamma
+      const HFr dfm = HFr::mul(d, fm);
       const HFr cf[4] = {HFr::mul(dfm, beta), HFr::mul(dfm, alpha), HFr::mul(d, vv), HFr::neg(dfm)};      // row, col, val, row_col
-      const int order[4] = {2, 0, 1, 3};
-      for (int o = 0; o < 4; ++o) { const int j = order[o]; terms[nt] = (const char*)ix.k_polys + (4 * m + j) * n_k * 32; lens[nt] = n_k; co[nt++] = cf[j]; }
+      for (int j = 0; j < 4; ++j) { terms[nt] = (const char*)ix.k_polys + (4 * ko[m] + (size_t)j * nk[m]) * 32; lens[nt] = nk[m]; co[nt++] = cf[j]; }
       cg = HFr::sub(cg, HFr::mul(HFr::mul(dfm, alpha), beta));
     }
     terms[nt] = h2; lens[nt] = n_k; co[nt++] = HFr::neg(HFr::mul(xi3, vk_gamma));
     const HFr gco[3] = {one, xi, xi2};
-    for (size_t m = 0; m < 3; ++m) { terms[nt] = f + (m * n_k + 1) * 32; lens[nt] = n_k - 1; co[nt++] = gco[m]; }
+    for (size_t m = 0; m < 3; ++m) { terms[nt] = f + (ko[m] + 1) * 32; lens[nt] = nk[m] - 1; co[nt++] = gco[m]; }
     RC(fr_lincomb(c, pg, n_k, cg.l, terms, lens, co, nt, s));
   }
   RC(fr_divide_by_linear(c, gq, evd + (k + 6) * 32, pg, n_k, gamma.l, s));

@@ -7,7 +7,7 @@ kernels, batch inversion, division by X − z, batched SonicKZG10 commitments an
 handful of challenge-dependent constants and the O(|X|) public-input polynomial.  The protocol is Marlin's AHP for R1CS in snarkVM's
 arrangement (see oracle/varuna_ref.py for the statement of every identity; that CPU restatement is what tests compare this module with,
 byte for byte).  Differences from upstream that make the proofs NOT interchangeable with snarkVM's: SHA-256 transcript instead of the
-Poseidon sponge, one shared non-zero domain K for A, B, C, a synthetic SRS.  The proof's byte layout is upstream's (aleo_mi355x_proof_to_bytes)."""
+Poseidon sponge, a synthetic SRS.  The proof's byte layout is upstream's (aleo_mi355x_proof_to_bytes)."""
 from __future__ import annotations
 import ctypes
 import hashlib
@@ -95,12 +95,16 @@ class CircuitIndex:
         while n_x < n_public: n_x *= 2
         n_h = 1
         while n_h < max(n_constraints, n_x + n_private, 2 * n_x): n_h *= 2
-        nnz = max(int(csr[m][0][-1]) for m in 'abc')
-        n_k = 2
-        while n_k < nnz: n_k *= 2
+        self.n_k_m = []                                     # one non-zero domain per matrix [UPSTREAM-RECALL: non_zero_{a,b,c}_domain]
+        for m in 'abc':
+            nk = 2
+            while nk < int(csr[m][0][-1]): nk *= 2
+            self.n_k_m.append(nk)
+        n_k = max(self.n_k_m); self.k_off = [0, self.n_k_m[0], self.n_k_m[0] + self.n_k_m[1]]; k_sum = sum(self.n_k_m)
         self.n_x, self.n_h, self.n_k = n_x, n_h, n_k
         if max(3 * n_h, n_k) > ck.max_degree + 1: raise ValueError('committer key too small for this circuit')
-        self.H, self.K, self.H4, self.K2 = EvaluationDomain(n_h), EvaluationDomain(n_k), EvaluationDomain(4 * n_h), EvaluationDomain(2 * n_k)
+        self.H, self.H4 = EvaluationDomain(n_h), EvaluationDomain(4 * n_h)
+        self.K_m = [EvaluationDomain(nk) for nk in self.n_k_m]; self.K2_m = [EvaluationDomain(2 * nk) for nk in self.n_k_m]
         self.pos = h_positions(n_public + n_private, n_public, n_x, n_h)
         self.stream = stream or torch.cuda.Stream()
         s = self.stream.cuda_stream
@@ -128,41 +132,51 @@ class CircuitIndex:
             fr_lin_device(self.vx_inv.ptr(), n_h, _mont(R - 1), one, self.vx_inv.ptr(), stream=s)
             batch_inversion_device(self.vx_inv.ptr(), n_h, s)                        # zeros (the positions of X) stay zero
             # arithmetisation over K: row, col, val, row_col
-            self.k_evals = _Vec(12 * n_k, zero=True)                                            # [matrix][row, col, val, row_col][|K|]
-            kidx = np.zeros((3, 2, n_k), dtype=np.uint32)                            # [matrix][row, col][|K|]: positions on H (padding: 0, the element 1)
+            # per matrix m (|K_m| = n_k_m[m], first element at 4 k_off[m]): row, col, val, row_col, |K_m| values each
+            self.k_evals = _Vec(4 * k_sum, zero=True)
+            kidx = np.zeros(2 * k_sum, dtype=np.uint32)                              # per matrix: row positions, col positions on H (padding: 0, the element 1)
             host_h = self.h_elems.host()
             n_h_inv = _mont(_inv(n_h))
             for k, m in enumerate('abc'):
+                nk = self.n_k_m[k]
                 rp, col, val = _csr_on_h(csr[m], self.pos, n_h)
                 rows = np.repeat(np.arange(n_h, dtype=np.int64), np.diff(rp.astype(np.int64)))
                 nz = len(col)
-                kidx[k, 0, :nz] = rows; kidx[k, 1, :nz] = col
-                ev = np.tile(one, (4 * n_k, 1)).reshape(4, n_k, 4)
+                kidx[2 * self.k_off[k]:2 * self.k_off[k] + nz] = rows; kidx[2 * self.k_off[k] + nk:2 * self.k_off[k] + nk + nz] = col
+                ev = np.tile(one, (4 * nk, 1)).reshape(4, nk, 4)
                 ev[0, :nz] = host_h[rows]; ev[1, :nz] = host_h[col.astype(np.int64)]
                 ev[2] = 0
-                base = self.k_evals.ptr((4 * k) * n_k)
-                self.k_evals.t[(4 * k) * n_k:(4 * k + 4) * n_k] = torch.from_numpy(ev.reshape(-1, 4).view(np.int64)).cuda()
+                base = self.k_evals.ptr(4 * self.k_off[k])
+                self.k_evals.t[4 * self.k_off[k]:4 * self.k_off[k] + 4 * nk] = torch.from_numpy(ev.reshape(-1, 4).view(np.int64)).cuda()
                 vraw = to_mont(_Vec(nz, val))
-                fr_vec_op_device(base + 2 * n_k * 32, vraw.ptr(), base + 1 * n_k * 32, nz, OP_MUL, s)          # v * col
-                fr_lin_device(base + 2 * n_k * 32, nz, None, n_h_inv, base + 2 * n_k * 32, stream=s)              # / |H|
-                fr_vec_op_device(base + 3 * n_k * 32, base, base + n_k * 32, n_k, OP_MUL, s)                       # row * col
+                fr_vec_op_device(base + 2 * nk * 32, vraw.ptr(), base + 1 * nk * 32, nz, OP_MUL, s)          # v * col
+                fr_lin_device(base + 2 * nk * 32, nz, None, n_h_inv, base + 2 * nk * 32, stream=s)              # / |H|
+                fr_vec_op_device(base + 3 * nk * 32, base, base + nk * 32, nk, OP_MUL, s)                       # row * col
             self.k_idx = torch.from_numpy(kidx.view(np.int32)).cuda()
-            self.k_polys = _Vec(12 * n_k); self.k_polys.t.copy_(self.k_evals.t)
-            self.K.ntt_batch_device(self.k_polys.ptr(), 12, direction=INVERSE, stream=s)
-            self.k2_evals = _Vec(24 * n_k, zero=True)                                            # the same twelve polynomials on 2K
-            self.k2_evals.t.view(12, 2 * n_k, 4)[:, :n_k].copy_(self.k_polys.t.view(12, n_k, 4))
-            self.K2.ntt_batch_device(self.k2_evals.ptr(), 12, stream=s)
+            self.k_polys = _Vec(4 * k_sum); self.k_polys.t.copy_(self.k_evals.t)
+            self.k2_evals = _Vec(8 * k_sum, zero=True)                               # the same polynomials on the domains of size 2|K_m| (first element at 8 k_off[m])
+            for k in range(3):
+                nk = self.n_k_m[k]
+                self.K_m[k].ntt_batch_device(self.k_polys.ptr(4 * self.k_off[k]), 4, direction=INVERSE, stream=s)
+                self.k2_evals.t[8 * self.k_off[k]:8 * self.k_off[k] + 8 * nk].view(4, 2 * nk, 4)[:, :nk].copy_(self.k_polys.t[4 * self.k_off[k]:4 * self.k_off[k] + 4 * nk].view(4, nk, 4))
+                self.K2_m[k].ntt_batch_device(self.k2_evals.ptr(8 * self.k_off[k]), 4, stream=s)
             self.stream.synchronize()
-            self.index_commitments = KZG10.commit_batch_device(ck.bases, [self.k_polys.ptr(i * n_k) for i in range(12)], [n_k] * 12, stream=s)
-        self.vk_bytes = wire.g1_compress(self.index_commitments).tobytes() + n_h.to_bytes(8, 'little') + n_k.to_bytes(8, 'little') + n_x.to_bytes(8, 'little')
+            self.index_commitments = KZG10.commit_batch_device(ck.bases, [self.k_polys.ptr(4 * self.k_off[k] + j * self.n_k_m[k]) for k in range(3) for j in range(4)],
+                                                               [self.n_k_m[k] for k in range(3) for j in range(4)], stream=s)
+        self.vk_bytes = wire.g1_compress(self.index_commitments).tobytes() + b''.join(int(v).to_bytes(8, 'little') for v in (n_h, *self.n_k_m, n_x))
 
 
 MAX_INSTANCES = 8        # k + 4 evaluations go through one fr_eval_batch call (12 polynomials), 3k + 3 terms through one fr_lincomb call (28)
 
 
+def _kp(ix, vec, m, j, mult=1):
+    """Pointer to array j (row, col, val, row_col) of matrix m in one of the index's ragged buffers (mult = 2 for the 2|K| evaluations)."""
+    return vec.ptr(4 * mult * ix.k_off[m] + j * mult * ix.n_k_m[m])
+
+
 class _NativeIndex(ctypes.Structure):
     """aleo_mi355x_varuna_index (include/aleo_mi355x.h)."""
-    _fields_ = ([(n, ctypes.c_uint64) for n in ('n_h', 'n_k', 'n_x', 'n_public', 'n_vars', 'committer_key', 'max_degree', 'gamma_offset')] +
+    _fields_ = ([(n, ctypes.c_uint64) for n in ('n_h', 'n_k_a', 'n_k_b', 'n_k_c', 'n_x', 'n_public', 'n_vars', 'committer_key', 'max_degree', 'gamma_offset')] +
                 [(n, ctypes.c_void_p) for n in ('positions', 'a_row_ptr', 'a_col', 'a_val', 'b_row_ptr', 'b_col', 'b_val', 't_row_ptr', 't_col', 't_val',
                                                 'vx_inv', 'k_evals', 'k_idx', 'k_polys', 'k2_evals', 'vk_bytes')] + [('vk_len', ctypes.c_size_t)])
 
@@ -171,7 +185,8 @@ def native_index(ix: CircuitIndex) -> _NativeIndex:
     """The index as the C ABI takes it: sizes, the committer key's handle, device pointers (the arrays stay owned by `ix`)."""
     if getattr(ix, '_native', None) is not None: return ix._native
     n = _NativeIndex()
-    n.n_h, n.n_k, n.n_x, n.n_public, n.n_vars = ix.n_h, ix.n_k, ix.n_x, ix.n_public, ix.n_public + ix.n_private
+    n.n_h, n.n_x, n.n_public, n.n_vars = ix.n_h, ix.n_x, ix.n_public, ix.n_public + ix.n_private
+    n.n_k_a, n.n_k_b, n.n_k_c = ix.n_k_m
     n.committer_key, n.max_degree, n.gamma_offset = ix.ck.bases.handle, ix.ck.max_degree, ix.ck.gamma_offset
     ix._pos32 = np.ascontiguousarray(ix.pos, dtype=np.uint32); ix._vk = np.frombuffer(ix.vk_bytes, dtype=np.uint8).copy()
     n.positions = ix._pos32.ctypes.data; n.vk_bytes = ix._vk.ctypes.data; n.vk_len = ix._vk.shape[0]
@@ -218,8 +233,9 @@ class NativeCircuitIndex:
               'varuna_index_build')
         self.handle = h.value
         view = _NativeIndex(); check(lib().aleo_mi355x_varuna_index_export(self.handle, ctypes.byref(view)), 'varuna_index_export')
-        self.n_h, self.n_k, self.n_x, self.n_vars = view.n_h, view.n_k, view.n_x, view.n_vars
-        buf = np.zeros(12 * 48 + 24, dtype=np.uint8); n = ctypes.c_size_t(buf.shape[0])
+        self.n_h, self.n_x, self.n_vars = view.n_h, view.n_x, view.n_vars
+        self.n_k_m = [view.n_k_a, view.n_k_b, view.n_k_c]; self.n_k = max(self.n_k_m)
+        buf = np.zeros(12 * 48 + 40, dtype=np.uint8); n = ctypes.c_size_t(buf.shape[0])
         check(lib().aleo_mi355x_varuna_index_vk(self.handle, buf.ctypes.data_as(ctypes.c_void_p), ctypes.byref(n)), 'varuna_index_vk')
         self.vk_bytes = buf[:n.value].tobytes()
 
@@ -384,32 +400,39 @@ class Prover:
         vh_beta = _vanish(n_h, self.beta)
         if vh_beta == 0: raise ArithmeticError('beta landed in H')
         self.vv = _vanish(n_h, self.alpha) * vh_beta % R
-        self.f = _Vec(3 * n_k)
+        km, ko = ix.n_k_m, ix.k_off
+        self.f = _Vec(sum(km))                                                      # f_M at offset k_off[M], |K_M| values
+        self.fp = lambda m, off=0: self.f.ptr(ko[m] + off)
         rb = _Vec(n_h)                                                              # v_H(beta) / (beta − h) on H, the same way
         fr_powers_device(rb.ptr(), n_h, _mont(pow(self.beta, n_h - 1, R)), _mont(_inv(self.beta)), s)
         ix.H.ntt_device(rb.ptr(), stream=s)
-        for k in range(3):                                                          # f_M = val u_H(alpha, row) u_H(beta, col) on K: two gathers
-            fr_gather_mul_device(self.f.ptr(k * n_k), n_k, ix.k_evals.ptr((4 * k + 2) * n_k), self.r_alpha.ptr(), ix.k_idx[k, 0].data_ptr(),
-                                 rb.ptr(), ix.k_idx[k, 1].data_ptr(), s)
-        ix.K.ntt_batch_device(self.f.ptr(), 3, direction=INVERSE, stream=s)
+        for m in range(3):                                                          # f_M = val u_H(alpha, row) u_H(beta, col) on K_M: two gathers
+            fr_gather_mul_device(self.fp(m), km[m], _kp(ix, ix.k_evals, m, 2), self.r_alpha.ptr(), ix.k_idx.data_ptr() + 4 * 2 * ko[m],
+                                 rb.ptr(), ix.k_idx.data_ptr() + 4 * (2 * ko[m] + km[m]), s)
+            ix.K_m[m].ntt_device(self.fp(m), direction=INVERSE, stream=s)
         self.stream.synchronize()
-        f0 = self.f.t.view(3, n_k, 4)[:, 0].cpu().numpy().view(np.uint64)
-        self.sigma = [_from_mont(f0[k]) * n_k % R for k in range(3)]
-        out = SonicKZG10.commit(ix.ck, [((self.f.ptr(k * n_k + 1), n_k - 1), n_k - 2, None) for k in range(3)], device=True, stream=s)
+        f0 = self.f.t[ko].cpu().numpy().view(np.uint64)
+        self.sigma = [_from_mont(f0[m]) * km[m] % R for m in range(3)]
+        out = SonicKZG10.commit(ix.ck, [((self.fp(m, 1), km[m] - 1), km[m] - 2, None) for m in range(3)], device=True, stream=s)
         for k, name in enumerate(('g_a', 'g_b', 'g_c')): self.c[name] = out[k]
         self.tr.absorb(b''.join(_fr_bytes(v) for v in self.sigma) + wire.g1_compress(out).tobytes())
         self.delta = [1, self.tr.challenge(b'delta_b'), self.tr.challenge(b'delta_c')]
 
     # ---- round 4 ----------------------------------------------------------------------------------------------------------------------
     def fourth_round(self):
-        ix, s = self.ix, self.s; n_k = ix.n_k; n2 = 2 * n_k
-        F = _Vec(3 * n2, zero=True); F.t.view(3, n2, 4)[:, :n_k].copy_(self.f.t.view(3, n_k, 4))
-        ix.K2.ntt_batch_device(F.ptr(), 3, stream=s)
-        B = _Vec(n2)
-        ahp_matrix_sumcheck_device(B.ptr(), n2, [ix.k2_evals.ptr(4 * k * n2) for k in range(3)], n2, [F.ptr(k * n2) for k in range(3)],
-                                   _mont_rows(self.delta + [self.alpha * self.beta, -self.alpha, -self.beta, self.vv]), s)
-        ix.K2.ntt_device(B.ptr(), direction=INVERSE, stream=s)
-        self.h2 = _Vec(n_k); self.h2.t.copy_(B.t[n_k:n2])                # P = h_2 (X^|K| − 1)
+        ix, s = self.ix, self.s; n_k = ix.n_k; km, ko = ix.n_k_m, ix.k_off
+        F = _Vec(2 * sum(km), zero=True); B = _Vec(2 * sum(km))                     # per matrix on its own domain of size 2|K_M|
+        consts = _mont_rows([1, 1, 1, self.alpha * self.beta, -self.alpha, -self.beta, self.vv])
+        terms = []
+        for m in range(3):
+            n2 = 2 * km[m]
+            F.t[2 * ko[m]:2 * ko[m] + km[m]].copy_(self.f.t[ko[m]:ko[m] + km[m]])
+            ix.K2_m[m].ntt_device(F.ptr(2 * ko[m]), stream=s)
+            ahp_matrix_sumcheck_device(B.ptr(2 * ko[m]), n2, [_kp(ix, ix.k2_evals, m, 0, 2), 0, 0], n2, [F.ptr(2 * ko[m]), 0, 0], consts, s)     # vv val − b f
+            ix.K2_m[m].ntt_device(B.ptr(2 * ko[m]), direction=INVERSE, stream=s)
+            terms.append((B.ptr(2 * ko[m] + km[m]), km[m], _mont(self.delta[m])))    # P_M = h_M (X^|K_M| − 1): h_M is the upper half
+        self.h2 = _Vec(n_k)
+        fr_lincomb_device(self.h2.ptr(), n_k, None, terms, s)                         # h_2 = sum_M delta_M h_M
         out = SonicKZG10.commit(ix.ck, [((self.h2.ptr(), n_k), None, None)], device=True, stream=s)
         self.c['h_2'] = out[0]
         self.tr.absorb(wire.g1_compress(out).tobytes())
@@ -420,8 +443,9 @@ class Prover:
         ix, s, k = self.ix, self.s, self.k; n_h, n_k, n_x = ix.n_h, ix.n_k, ix.n_x
         one = _mont(1); L = n_h + 1
         self._ev = _Vec(k + 8)
-        fr_eval_batch_device(self._ev.ptr(), [self.zb(i) for i in range(k)] + [self.g1.ptr(1)] + [self.f.ptr(j * n_k + 1) for j in range(3)],
-                             [L] * k + [n_h - 1] + [n_k - 1] * 3, _mont_rows([self.beta] * (k + 1) + [self.gamma] * 3), s)
+        km = ix.n_k_m
+        fr_eval_batch_device(self._ev.ptr(), [self.zb(i) for i in range(k)] + [self.g1.ptr(1)] + [self.fp(m, 1) for m in range(3)],
+                             [L] * k + [n_h - 1] + [km[m] - 1 for m in range(3)], _mont_rows([self.beta] * (k + 1) + [self.gamma] * 3), s)
         self.stream.synchronize()
         evals = [_from_mont(v) for v in self._ev.host(0, k + 4)]
         zb_beta = evals[:k]; g1_beta, ga, gb, gc = evals[k:]
@@ -453,15 +477,16 @@ class Prover:
         wq = _Vec(3 * n_h); blq = _Vec(HIDING_COEFFS - 1, _mont_rows(blw))
         divide_by_linear_device(wq.ptr(), self._ev.ptr(k + 5), pb.ptr(), 3 * n_h, _mont(beta), s)
         # linear combination of the second sumcheck, opened at gamma together with g_a, g_b, g_c
-        xi2 = xi * xi % R; xi3 = xi2 * xi % R; n_k_inv = _inv(n_k); vk_gamma = _vanish(n_k, gamma)
+        xi2 = xi * xi % R; xi3 = xi2 * xi % R; vk_gamma = _vanish(n_k, gamma)          # K: the largest non-zero domain
         pg = _Vec(n_k); const = 0; terms = []
         for m, gk in enumerate((ga, gb, gc)):
-            fm = (gamma * gk + self.sigma[m] * n_k_inv) % R; d = self.delta[m] * xi3 % R
+            fm = (gamma * gk + self.sigma[m] * _inv(km[m])) % R
+            d = self.delta[m] * xi3 % R * vk_gamma % R * _inv(_vanish(km[m], gamma)) % R          # selector v_K / v_{K_M} at gamma
             for j, coef in ((2, d * self.vv), (0, d * fm % R * beta), (1, d * fm % R * alpha), (3, -d * fm)):       # val, row, col, row_col
-                terms.append((ix.k_polys.ptr((4 * m + j) * n_k), n_k, _mont(coef)))
+                terms.append((_kp(ix, ix.k_polys, m, j), km[m], _mont(coef)))
             const = (const - d * fm % R * alpha % R * beta) % R
         terms.append((self.h2.ptr(), n_k, _mont(-xi3 * vk_gamma)))
-        terms += [(self.f.ptr(m * n_k + 1), n_k - 1, _mont(coef)) for m, coef in enumerate((1, xi, xi2))]
+        terms += [(self.fp(m, 1), km[m] - 1, _mont(coef)) for m, coef in enumerate((1, xi, xi2))]
         fr_lincomb_device(pg.ptr(), n_k, _mont(const), terms, s)
         gq = _Vec(n_k)
         divide_by_linear_device(gq.ptr(), self._ev.ptr(k + 6), pg.ptr(), n_k, _mont(gamma), s)

@@ -210,7 +210,8 @@ int32_t aleo_mi355x_fr_lincomb_device(void* d_dst, size_t n, const void* c0_mont
  *   first:  dst = r (z_a + eta_b z_b + eta_c z_a z_b) - t z                  (n = 4|H| values each)
  *   matrix: dst = sum_M delta_M (vv val_M - (alpha beta - beta row_M - alpha col_M + row_col_M) f_M)   (n = 2|K| values; d_index[M] points at
  *           row_M, with col_M, val_M, row_col_M following at index_stride elements each; consts_mont = delta_a, delta_b, delta_c,
- *           alpha beta, -alpha, -beta, v_H(alpha) v_H(beta): 7 x 32 bytes on the host).  dst may alias an operand. */
+ *           alpha beta, -alpha, -beta, v_H(alpha) v_H(beta): 7 x 32 bytes on the host; a NULL d_index[M] leaves matrix M out — matrices whose
+ *           non-zero domains differ in size are done one call each).  dst may alias an operand. */
 int32_t aleo_mi355x_ahp_first_sumcheck_device(void* d_dst, size_t n, const void* d_r, const void* d_za, const void* d_zb, const void* d_t, const void* d_z,
                                               const void* eta_b_mont, const void* eta_c_mont, void* stream);
 int32_t aleo_mi355x_ahp_matrix_sumcheck_device(void* d_dst, size_t n, const void* const* d_index, size_t index_stride, const void* const* d_f, const void* consts_mont, void* stream);
@@ -267,8 +268,10 @@ int32_t aleo_mi355x_proof_to_bytes(void* out, size_t* len, const aleo_mi355x_pro
  *   a_*, b_*      device CSR of A, B with columns moved to positions on H and rows padded to n_h (uint32 row_ptr[n_h+1], col[], Montgomery val[])
  *   t_*           device CSR of the stacked transpose [A^T | B^T | C^T] (rows = positions on H, columns = matrix * n_h + row)
  *   vx_inv        device Fr[n_h]: 1 / v_X on H \ X, 0 on X
- *   k_evals       device Fr[3][4][n_k]: row, col, val, row_col of A, B, C on K;  k_idx  device uint32[3][2][n_k]: their row / column positions
- *   k_polys       device Fr[3][4][n_k]: the same as coefficients;  k2_evals  device Fr[3][4][2 n_k]: their values on the domain of size 2 n_k
+ *   k_evals       device Fr, matrix after matrix: row, col, val, row_col of M on K_M (|K_M| values each; matrix M starts at element 4 * (sum of the
+ *                 earlier |K|));  k_idx  device uint32, matrix after matrix: row positions, column positions (|K_M| each; M starts at 2 * sum)
+ *   k_polys       the same four polynomials per matrix as coefficients (layout of k_evals);  k2_evals  their values on the domain of size 2|K_M|
+ *                 (2|K_M| each; M starts at element 8 * sum)
  *   vk_bytes      host: what the transcript absorbs first (compressed index commitments, domain sizes)
  * committer_key: a pinned set holding powers[0..max_degree] and, from gamma_offset, at least 3 hiding powers.
  * assignments: n_instances host pointers to n_vars x 32 bytes canonical (public variables first, z_0 = 1).  seed: the proof's random stream
@@ -276,7 +279,7 @@ int32_t aleo_mi355x_proof_to_bytes(void* out, size_t* len, const aleo_mi355x_pro
  * Blocking; concurrent calls from several threads run on separate slots.  aleo_mi355x_varuna_last_timing: wall ms of the calling thread's
  * last proof: rounds 1..4, openings, total. */
 typedef struct {
-  uint64_t n_h, n_k, n_x, n_public, n_vars;
+  uint64_t n_h, n_k_a, n_k_b, n_k_c, n_x, n_public, n_vars;      /* |H|, the non-zero domains |K_A|, |K_B|, |K_C|, |X| */
   uint64_t committer_key, max_degree, gamma_offset;
   const uint32_t* positions;
   const void *a_row_ptr, *a_col, *a_val, *b_row_ptr, *b_col, *b_val, *t_row_ptr, *t_col, *t_val;
@@ -286,10 +289,10 @@ typedef struct {
 /* The index built by the library itself from the R1CS (AHPForR1CS::index shape: the arithmetisation above + the twelve index commitments)
  * and kept in HBM under a handle.  Matrices: CSR over the variables (uint32 row_ptr[n_constraints + 1], uint32 col[nnz] = variable index
  * with the n_public public variables first, val[nnz] canonical 32-byte Fr), host memory.  Domains: |X| = 2^ceil(lg n_public), |H| = the power
- * of two >= max(n_constraints, |X| + n_private, 2|X|), |K| = the power of two >= the largest non-zero count (>= 2).  The committer key
- * (powers[0..max_degree], >= 3 hiding powers from gamma_offset) must hold max(3|H|, |K|) powers and stays pinned while the index lives.
+ * of two >= max(n_constraints, |X| + n_private, 2|X|), |K_M| = the power of two >= the non-zero count of M (>= 2), one per matrix.  The
+ * committer key (powers[0..max_degree], >= 3 hiding powers from gamma_offset) must hold max(3|H|, max |K_M|) powers and stays pinned while the index lives.
  * index_export fills the struct view (pointers owned by the library, valid until index_free); index_vk copies the bytes the transcript absorbs
- * first: 12 compressed index commitments (row, col, val, row_col of A, B, C) then |H|, |K|, |X| as u64 LE.  prove_indexed = varuna_prove. */
+ * first: 12 compressed index commitments (row, col, val, row_col of A, B, C) then |H|, |K_A|, |K_B|, |K_C|, |X| as u64 LE.  prove_indexed = varuna_prove. */
 typedef struct { const uint32_t* row_ptr; const uint32_t* col; const void* val; } aleo_mi355x_r1cs_matrix;
 int32_t aleo_mi355x_varuna_index_build(uint64_t* index_handle, uint64_t committer_key, uint64_t max_degree, uint64_t gamma_offset,
                                        const aleo_mi355x_r1cs_matrix abc[3], size_t n_constraints, size_t n_public, size_t n_private);

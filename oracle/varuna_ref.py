@@ -13,7 +13,7 @@ is a third-party dependency of the reference (Cargo.lock:2200) and absent from /
     /root/reference/wasm/src/programs/transaction.rs:100 (decoded in tests/golden/reference_proof.json);
   * SonicKZG10 commitments: hiding polynomials of degree 2 against the γ-powers, degree bounds through shifted powers.
 Deliberate differences, because the corresponding upstream data is not available offline: challenges come from a SHA-256 transcript
-(upstream: a Poseidon sponge over Fq whose parameters are not in /root/reference), one non-zero domain K is shared by A, B, C.  Two verifiers:
+(upstream: a Poseidon sponge over Fq whose parameters are not in /root/reference).  Two verifiers:
 `verify_pairing` checks the openings as pairing products over public G2 elements (oracle/pairing.py); `verify` is the same check with the pairing
 replaced by the equivalent G1 equation under the synthetic setup's trapdoor (fast; used where many proofs are verified).  **Parity unpinned**: the reference holds no proof this restatement could be compared with value
 for value; what pins it is (i) the verifier below accepting its proofs and rejecting tampered ones, and (ii) the byte layout above."""
@@ -86,10 +86,12 @@ class Circuit:
         while n_x < n_public: n_x *= 2
         n_h = 1
         while n_h < max(n_constraints, n_x + n_private, 2 * n_x): n_h *= 2
-        nnz = max(sum(len(r) for r in rows) for rows in (a, b, c))
-        n_k = 2
-        while n_k < nnz: n_k *= 2
-        self.n_x, self.n_h, self.n_k = n_x, n_h, n_k
+        self.n_k_m = {}
+        for name, rows in (('a', a), ('b', b), ('c', c)):                        # one non-zero domain per matrix [UPSTREAM-RECALL: non_zero_{a,b,c}_domain]
+            nnz = sum(len(r) for r in rows); n_k = 2
+            while n_k < nnz: n_k *= 2
+            self.n_k_m[name] = n_k
+        self.n_x, self.n_h, self.n_k = n_x, n_h, max(self.n_k_m.values())
 
 
 class Setup:
@@ -102,7 +104,8 @@ class Setup:
         un-shift degree-bounded commitments [UPSTREAM-RECALL: sonic_pc VerifierKey — h, beta_h, prepared_neg_powers_of_beta_h, gamma_g]."""
         H = P.G2_GENERATOR; ti = inv(self.tau)
         return {'gamma_g': P.g1_mul(P.G1_GENERATOR, self.s_gamma), 'h': H, 'tau_h': P.g2_mul(H, self.tau),
-                'neg_h': P.g2_mul(H, pow(ti, self.max_degree - (circuit.n_h - 2), R)), 'neg_k': P.g2_mul(H, pow(ti, self.max_degree - (circuit.n_k - 2), R))}
+                'neg_h': P.g2_mul(H, pow(ti, self.max_degree - (circuit.n_h - 2), R)),
+                'neg_k': {m: P.g2_mul(H, pow(ti, self.max_degree - (circuit.n_k_m[m] - 2), R)) for m in 'abc'}}
 
 
 def _commit_scalar(setup, coeffs, bound=None, blind=None):
@@ -123,19 +126,20 @@ class Index:
     """The index ("proving key" material) of one circuit: the arithmetisation of A, B, C over K, and the index commitments."""
     def __init__(self, circuit: Circuit, setup: Setup):
         c = self.circuit = circuit
-        self.H, self.K, self.X = Domain(c.n_h), Domain(c.n_k), Domain(c.n_x)
+        self.H, self.K, self.X = Domain(c.n_h), Domain(c.n_k), Domain(c.n_x)      # K: the largest of the three non-zero domains
+        self.K_m = {m: Domain(c.n_k_m[m]) for m in 'abc'}
         he = self.H.elements(); n_h_inv = self.H.size_inv
         self.entries, self.evals, self.polys = {}, {}, {}
         for name, rows in c.m.items():
             ent = [(r, h_position(v, c.n_public, c.n_x, c.n_h), val % R) for r, row in enumerate(rows) for v, val in row]
             row = [he[r] for r, _, _ in ent]; col = [he[cp] for _, cp, _ in ent]
             val = [v * he[cp] % R * n_h_inv % R for _, cp, v in ent]          # M[r,c] / u_H(col, col), u_H(x, x) = |H| / x on H
-            pad = c.n_k - len(ent)
+            pad = c.n_k_m[name] - len(ent)
             row += [1] * pad; col += [1] * pad; val += [0] * pad
             rc = [a * b % R for a, b in zip(row, col)]
             self.entries[name] = ent
             self.evals[name] = {'row': row, 'col': col, 'val': val, 'row_col': rc}
-            self.polys[name] = {k: self.K.ifft(v) for k, v in self.evals[name].items()}
+            self.polys[name] = {k: self.K_m[name].ifft(v) for k, v in self.evals[name].items()}
         self.commit_scalars = {(m, k): _commit_scalar(setup, self.polys[m][k]) for m in 'abc' for k in ('row', 'col', 'val', 'row_col')}
         self._points = None
 
@@ -149,7 +153,7 @@ class Index:
         for m in 'abc':
             for k in ('row', 'col', 'val', 'row_col'): out += _point_bytes(self.commit_scalars[(m, k)])
         c = self.circuit
-        return out + c.n_h.to_bytes(8, 'little') + c.n_k.to_bytes(8, 'little') + c.n_x.to_bytes(8, 'little')
+        return out + b''.join(int(v).to_bytes(8, 'little') for v in (c.n_h, c.n_k_m['a'], c.n_k_m['b'], c.n_k_m['c'], c.n_x))
 
 
 _M64 = (1 << 64) - 1
@@ -279,24 +283,26 @@ def prove(index: Index, setup: Setup, assignments, rand, vk_bytes=None):
     f, sigma, g = {}, {}, {}
     for name in 'abc':
         ev = index.evals[name]
-        fe = [vh_alpha * vh_beta % R * ev['val'][j] % R * inv((alpha - ev['row'][j]) * (beta - ev['col'][j])) % R for j in range(n_k)]
-        f[name] = K.ifft(fe); sigma[name] = f[name][0] * n_k % R; g[name] = f[name][1:]
-        cb['g_' + name] = _point_bytes(_commit_scalar(setup, g[name], bound=n_k - 2))
+        nkm = c.n_k_m[name]
+        fe = [vh_alpha * vh_beta % R * ev['val'][j] % R * inv((alpha - ev['row'][j]) * (beta - ev['col'][j])) % R for j in range(nkm)]
+        f[name] = index.K_m[name].ifft(fe); sigma[name] = f[name][0] * nkm % R; g[name] = f[name][1:]
+        cb['g_' + name] = _point_bytes(_commit_scalar(setup, g[name], bound=nkm - 2))
     tr.absorb(b''.join(fr_bytes(sigma[m]) for m in 'abc') + cb['g_a'] + cb['g_b'] + cb['g_c'])
     delta = {'a': 1, 'b': tr.challenge(b'delta_b'), 'c': tr.challenge(b'delta_c')}
     # ---- fourth round ------------------------------------------------------------------------------------------------------------
-    D2 = Domain(2 * n_k)
-    acc = [0] * (2 * n_k)
+    h2 = [0] * n_k                                                                # h_2 = sum_M delta_M (a_M − b_M f_M) / v_{K_M}, each quotient on its own domain
     for name in 'abc':
-        pl = index.polys[name]
+        nkm = c.n_k_m[name]; D2 = Domain(2 * nkm); pl = index.polys[name]
         e_row, e_col, e_val, e_rc, e_f = D2.fft(pl['row']), D2.fft(pl['col']), D2.fft(pl['val']), D2.fft(pl['row_col']), D2.fft(f[name])
-        for i in range(2 * n_k):
+        num = []
+        for i in range(2 * nkm):
             a_ = vh_alpha * vh_beta % R * e_val[i] % R
             b_ = (alpha * beta - beta * e_row[i] - alpha * e_col[i] + e_rc[i]) % R
-            acc[i] = (acc[i] + delta[name] * (a_ - b_ * e_f[i])) % R
-    pc = D2.ifft(acc)
-    h2 = pc[n_k:]                                                                 # P = h_2 (X^|K| − 1), deg P < 2|K|
-    assert all((pc[i] + h2[i]) % R == 0 for i in range(n_k)), 'fourth round: not divisible by v_K'
+            num.append((a_ - b_ * e_f[i]) % R)
+        pc = D2.ifft(num)
+        hm = pc[nkm:]                                                             # P = h_M (X^|K_M| − 1), deg P < 2|K_M|
+        assert all((pc[i] + hm[i]) % R == 0 for i in range(nkm)), 'fourth round: not divisible by v_K'
+        _axpy(h2, delta[name], hm)
     cb['h_2'] = _point_bytes(_commit_scalar(setup, h2))
     tr.absorb(cb['h_2'])
     gamma = tr.challenge(b'gamma')
@@ -325,7 +331,7 @@ def prove(index: Index, setup: Setup, assignments, rand, vk_bytes=None):
     random_v = poly_eval(bl, beta)
     bl_w = divide_by_linear(bl, beta, random_v)
     open_beta = (poly_eval(w_beta, setup.tau) + setup.s_gamma * poly_eval(bl_w, setup.tau)) % R
-    lc2 = matrix_coefficients(H, K, alpha, beta, gamma, delta, sigma, g_gamma)
+    lc2 = matrix_coefficients(H, K, index.K_m, alpha, beta, gamma, delta, sigma, g_gamma)
     p_gamma = [0] * n_k
     for (m, kind), coef in lc2['index'].items(): _axpy(p_gamma, coef, index.polys[m][kind])
     _axpy(p_gamma, lc2['h_2'], h2)
@@ -362,14 +368,15 @@ def lincheck_coefficients(H, X, alpha, beta, eta, comb, sigma, zb_beta, g1_beta,
             'w': [(-ci * t_beta % R * X.vanishing(beta)) % R for ci in comb], 'h_1': (-H.vanishing(beta)) % R, 'const': const}
 
 
-def matrix_coefficients(H, K, alpha, beta, gamma, delta, sigma, g_gamma):
-    """Coefficients over (val, row, col, row_col of A, B, C; h_2; 1) of the combination that must vanish at gamma (second sumcheck)."""
+def matrix_coefficients(H, K, K_m, alpha, beta, gamma, delta, sigma, g_gamma):
+    """Coefficients over (val, row, col, row_col of A, B, C; h_2; 1) of the combination that must vanish at gamma (second sumcheck):
+    sum_M delta_M s_M(gamma) (vv val_M − f_M(gamma) (alpha beta − beta row_M − alpha col_M + row_col_M)) − v_K(gamma) h_2, with the selector
+    s_M = v_K / v_{K_M} (K the largest non-zero domain) and f_M(gamma) = gamma g_M(gamma) + sigma_M / |K_M|."""
     vv = H.vanishing(alpha) * H.vanishing(beta) % R
-    n_k_inv = K.size_inv
     idx = {}; const = 0
     for m in 'abc':
-        fm = (gamma * g_gamma[m] + sigma[m] * n_k_inv) % R                        # f_M(gamma)
-        d = delta[m]
+        fm = (gamma * g_gamma[m] + sigma[m] * K_m[m].size_inv) % R               # f_M(gamma)
+        d = delta[m] * K.vanishing(gamma) % R * inv(K_m[m].vanishing(gamma)) % R
         idx[(m, 'val')] = d * vv % R
         idx[(m, 'row')] = d * fm % R * beta % R
         idx[(m, 'col')] = d * fm % R * alpha % R
@@ -442,7 +449,7 @@ def _verifier_state(index: Index, public_inputs, data: bytes, vk_bytes=None):
     x_beta = [poly_eval(X.ifft(xe), beta) for xe in x_evals]
     return {'k': k, 'pts': pts, 'opn': opn, 'wit': wit, 'beta': beta, 'gamma': gamma, 'xi': xi, 'random_v': pr['openings'][0][1],
             'lc1': lincheck_coefficients(H, X, alpha, beta, eta, comb, sigma, zb_beta, g1_beta, x_beta),
-            'lc2': matrix_coefficients(H, K, alpha, beta, gamma, delta, sigma, {'a': ga, 'b': gb, 'c': gc}),
+            'lc2': matrix_coefficients(H, K, index.K_m, alpha, beta, gamma, delta, sigma, {'a': ga, 'b': gb, 'c': gc}),
             'v_beta': (g1_beta + sum(pow(xi, 1 + i, R) * v for i, v in enumerate(zb_beta))) % R,
             'v_gamma': (ga + xi * gb + xi * xi % R * gc) % R}
 
@@ -472,10 +479,13 @@ def verify_pairing(index: Index, vk, public_inputs, data: bytes, vk_bytes=None) 
     Rb, Rg = _unshifted_parts(st, index.commit_points())
     Rb = add(Rb, neg(add(mul(G, st['v_beta']), mul(vk['gamma_g'], st['random_v']))))
     Rg = add(Rg, neg(mul(G, st['v_gamma'])))
-    Sg = add(add(pts['g_a'], mul(pts['g_b'], xi)), mul(pts['g_c'], xi * xi % R))
     zh = lambda z: P.g2_add(vk['tau_h'], P.g2_neg(P.g2_mul(vk['h'], z)))
     if not E.pairing_product_is_one([(pts['g_1'], vk['neg_h']), (Rb, vk['h']), (neg(st['opn'][0]), zh(st['beta']))]): return False
-    return E.pairing_product_is_one([(Sg, vk['neg_k']), (Rg, vk['h']), (neg(st['opn'][1]), zh(st['gamma']))])
+    shifted = {}                                                                  # g_a + xi g_b + xi^2 g_c, grouped by the shift of their degree bound
+    for m, coef in zip('abc', (1, xi, xi * xi % R)):
+        key = index.circuit.n_k_m[m]; term = mul(pts['g_' + m], coef)
+        shifted[key] = (add(shifted[key][0], term), vk['neg_k'][m]) if key in shifted else (term, vk['neg_k'][m])
+    return E.pairing_product_is_one(list(shifted.values()) + [(Rg, vk['h']), (neg(st['opn'][1]), zh(st['gamma']))])
 
 
 def verify(index: Index, setup: Setup, public_inputs, data: bytes, vk_bytes=None) -> bool:
@@ -490,6 +500,6 @@ def verify(index: Index, setup: Setup, public_inputs, data: bytes, vk_bytes=None
     Rb, Rg = _unshifted_parts(st, index.commit_points())
     lhs = add(add(unshift(pts['g_1'], c.n_h - 2), Rb), neg(mul(G, (st['v_beta'] + setup.s_gamma * st['random_v']) % R)))
     if lhs != mul(st['opn'][0], (setup.tau - st['beta']) % R): return False
-    Sg = add(add(unshift(pts['g_a'], c.n_k - 2), mul(unshift(pts['g_b'], c.n_k - 2), xi)), mul(unshift(pts['g_c'], c.n_k - 2), xi * xi % R))
+    Sg = add(add(unshift(pts['g_a'], c.n_k_m['a'] - 2), mul(unshift(pts['g_b'], c.n_k_m['b'] - 2), xi)), mul(unshift(pts['g_c'], c.n_k_m['c'] - 2), xi * xi % R))
     lhs = add(add(Sg, Rg), neg(mul(G, st['v_gamma'])))
     return lhs == mul(st['opn'][1], (setup.tau - st['gamma']) % R)

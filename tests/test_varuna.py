@@ -123,7 +123,7 @@ def test_device_prover_matches_restatement(n_constraints, n_public, seed):
     ck = varuna.synthetic_committer_key(TAU, S_GAMMA, D)
     try:
         ix = varuna.CircuitIndex(csr, n_constraints, n_public, len(z) - n_public, ck)
-        assert (ix.n_h, ix.n_k, ix.n_x) == (c.n_h, c.n_k, c.n_x)
+        assert (ix.n_h, ix.n_k, ix.n_x) == (c.n_h, c.n_k, c.n_x) and ix.n_k_m == [c.n_k_m[m] for m in 'abc']
         assert ix.vk_bytes == idx.vk_bytes()
         zz = np.stack([synth.int_to_limbs(v, 4) for v in z])
         proof = varuna.prove(ix, zz, seed + 100)
@@ -131,7 +131,7 @@ def test_device_prover_matches_restatement(n_constraints, n_public, seed):
         assert got == want
         assert varuna.prove_native(ix, zz, seed + 100) == want                         # the one-call C++ host side
         with varuna.NativeCircuitIndex(csr, n_constraints, n_public, len(z) - n_public, ck) as nx:     # index built by the library itself
-            assert (nx.n_h, nx.n_k, nx.n_x) == (c.n_h, c.n_k, c.n_x) and nx.vk_bytes == idx.vk_bytes()
+            assert (nx.n_h, nx.n_k_m, nx.n_x) == (c.n_h, [c.n_k_m[m] for m in 'abc'], c.n_x) and nx.vk_bytes == idx.vk_bytes()
             assert nx.prove(zz, seed + 100) == want
             handle = nx.handle
         with pytest.raises(aleo_amd.AleoMi355xError): aleo_amd._lib.check(aleo_amd.lib().aleo_mi355x_varuna_index_free(handle), 'index_free')   # already freed
