@@ -54,7 +54,7 @@ def lib():
         'aleo_mi355x_fr_lin_device': ([vp, sz, vp, vp, vp, vp, vp, vp], i32),
         'aleo_mi355x_fr_powers_device': ([vp, sz, vp, vp, vp], i32),
         'aleo_mi355x_varuna_prove': ([vp, ctypes.POINTER(vp), sz, u64, vp, ctypes.POINTER(sz)], i32),
-        'aleo_mi355x_varuna_index_build': ([ctypes.POINTER(u64), u64, u64, u64, vp, sz, sz, sz], i32),
+        'aleo_mi355x_varuna_index_build': ([ctypes.POINTER(u64), u64, u64, u64, vp, sz, sz, sz, ctypes.c_uint32], i32),
         'aleo_mi355x_varuna_index_export': ([u64, vp], i32),
         'aleo_mi355x_varuna_index_vk': ([u64, vp, ctypes.POINTER(sz)], i32),
         'aleo_mi355x_varuna_index_free': ([u64], i32),

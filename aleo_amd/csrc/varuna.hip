@@ -139,7 +139,7 @@ const std::vector<uint8_t>& varuna_index_vk(const VarunaIndexOwner* o) { return 
 static uint64_t pow2_at_least(uint64_t v, uint64_t lo) { uint64_t p = lo; while (p < v) p <<= 1; return p; }
 
 int32_t varuna_index_build(Ctx* c, const PinnedBases& pb, std::shared_ptr<PinnedOwner> key, uint64_t key_handle, uint64_t max_degree, uint64_t gamma_offset,
-                           const aleo_mi355x_r1cs_matrix* abc, size_t n_constraints, size_t n_public, size_t n_private, VarunaIndexOwner** out) {
+                           const aleo_mi355x_r1cs_matrix* abc, size_t n_constraints, size_t n_public, size_t n_private, uint32_t domain_flags, VarunaIndexOwner** out) {
   std::unique_ptr<VarunaIndexOwner> o(new VarunaIndexOwner()); o->key = std::move(key);
   hipStream_t s = c->stream;
   if (!n_constraints || !n_public || n_constraints >= (1ull << 28)) { g_last_error = "varuna_index: bad sizes"; return ALEO_MI355X_ERR_BAD_ARG; }
@@ -154,7 +154,9 @@ int32_t varuna_index_build(Ctx* c, const PinnedBases& pb, std::shared_ptr<Pinned
     for (size_t r = 0; r < n_constraints; ++r) if (abc[m].row_ptr[r + 1] < abc[m].row_ptr[r]) { g_last_error = "varuna_index: row_ptr not monotone"; return ALEO_MI355X_ERR_BAD_ARG; }
   }
   uint64_t nk[3], ko[3], k_sum = 0, n_k = 0;                 // one non-zero domain per matrix; ko: elements of the earlier matrices
-  for (int m = 0; m < 3; ++m) { nk[m] = pow2_at_least(nnz[m], 2); ko[m] = k_sum; k_sum += nk[m]; n_k = nk[m] > n_k ? nk[m] : n_k; }
+  for (int m = 0; m < 3; ++m) { nk[m] = pow2_at_least(nnz[m], 2); n_k = nk[m] > n_k ? nk[m] : n_k; }
+  if (domain_flags == 2 || (domain_flags == 0 && n_k < (1ull << 18))) nk[0] = nk[1] = nk[2] = n_k;      // shared: latency-bound sizes (header)
+  for (int m = 0; m < 3; ++m) { ko[m] = k_sum; k_sum += nk[m]; }
   (void)nnz_max;
   if (3 * n_h > max_degree + 1 || n_k > max_degree + 1 || max_degree + 1 > pb.n || gamma_offset + 3 > pb.n) { g_last_error = "varuna_index: committer key too small for this circuit"; return ALEO_MI355X_ERR_BAD_ARG; }
   // variable -> position on H: public i -> i |H|/|X|, the j-th private one -> the j-th element of H \ X
@@ -402,9 +404,12 @@ int32_t varuna_prove(Ctx* c, const PinnedBases& pb, const aleo_mi355x_varuna_ind
   for (size_t m = 0; m < 3; ++m) {                                                           // f_M = val u_H(alpha, row) u_H(beta, col) on K_M: two gathers
     const uint32_t* ri = (const uint32_t*)ix.k_idx + 2 * ko[m];
     RC(fr_gather_mul(c, f + ko[m] * 32, nk[m], (const char*)ix.k_evals + (4 * ko[m] + 2 * nk[m]) * 32, ext, ri, rb, ri + nk[m], s));
-    RC(ntt_run(c, f + ko[m] * 32, lg_km[m], 1, 0, 1, 0, s));
-    HIPCHK(hipMemcpyAsync(pin_small + 32 * m, f + ko[m] * 32, 32, hipMemcpyDeviceToHost, s));
   }
+  // maximal runs of consecutive matrices with equal domains share batched transforms (and, in round 4, one numerator pass)
+  size_t run0[3], runc[3], nrun = 0;
+  for (size_t m = 0; m < 3;) { size_t cnt = 1; while (m + cnt < 3 && nk[m + cnt] == nk[m]) ++cnt; run0[nrun] = m; runc[nrun++] = cnt; m += cnt; }
+  for (size_t r = 0; r < nrun; ++r) RC(ntt_run(c, f + ko[run0[r]] * 32, lg_km[run0[r]], runc[r], 0, 1, 0, s));
+  for (size_t m = 0; m < 3; ++m) HIPCHK(hipMemcpyAsync(pin_small + 32 * m, f + ko[m] * 32, 32, hipMemcpyDeviceToHost, s));
   HIPCHK(hipStreamSynchronize(s));
   HFr sigma[3]; uint8_t sig_bytes[96];
   for (size_t m = 0; m < 3; ++m) { HFr v; std::memcpy(v.l, pin_small + 32 * m, 32); sigma[m] = HFr::mul(v, fr_u64(nk[m])); fr_bytes(sig_bytes + 32 * m, sigma[m]); }
@@ -422,17 +427,21 @@ int32_t varuna_prove(Ctx* c, const PinnedBases& pb, const aleo_mi355x_varuna_ind
   HIPCHK(hipMemsetAsync(F, 0, 2 * k_sum * 32, s));
   {
     const void* terms[3]; size_t lens[3]; HFr co[3];
-    HFr consts[7] = {one, one, one, HFr::mul(alpha, beta), HFr::neg(alpha), HFr::neg(beta), vv};
-    for (size_t m = 0; m < 3; ++m) {
-      const size_t n2 = 2 * nk[m]; char* Fm = F + 2 * ko[m] * 32; char* Bm = B + 2 * ko[m] * 32;
-      HIPCHK(hipMemcpyAsync(Fm, f + ko[m] * 32, nk[m] * 32, hipMemcpyDeviceToDevice, s));
-      RC(ntt_run(c, Fm, lg_km[m] + 1, 1, 0, 0, 0, s));
-      const void* idx[3] = {(const char*)ix.k2_evals + 8 * ko[m] * 32, nullptr, nullptr}; const void* ff[3] = {Fm, nullptr, nullptr};
-      RC(ahp_matrix_sumcheck(c, Bm, n2, idx, n2, ff, consts, s));                                // vv val − b f
-      RC(ntt_run(c, Bm, lg_km[m] + 1, 1, 0, 1, 0, s));
-      terms[m] = Bm + nk[m] * 32; lens[m] = nk[m]; co[m] = delta[m];                           // P_M = h_M (X^|K_M| − 1): h_M is the upper half
+    for (size_t r = 0; r < nrun; ++r) {
+      const size_t m0 = run0[r], cnt = runc[r], n2 = 2 * nk[m0]; char* Fr0 = F + 2 * ko[m0] * 32; char* Br = B + 2 * ko[m0] * 32;
+      HFr consts[7] = {HFr::zero(), HFr::zero(), HFr::zero(), HFr::mul(alpha, beta), HFr::neg(alpha), HFr::neg(beta), vv};
+      const void* idx[3] = {nullptr, nullptr, nullptr}; const void* ff[3] = {nullptr, nullptr, nullptr};
+      for (size_t j = 0; j < cnt; ++j) {
+        const size_t m = m0 + j;
+        HIPCHK(hipMemcpyAsync(F + 2 * ko[m] * 32, f + ko[m] * 32, nk[m] * 32, hipMemcpyDeviceToDevice, s));
+        idx[j] = (const char*)ix.k2_evals + 8 * ko[m] * 32; ff[j] = F + 2 * ko[m] * 32; consts[j] = delta[m];
+      }
+      RC(ntt_run(c, Fr0, lg_km[m0] + 1, cnt, 0, 0, 0, s));
+      RC(ahp_matrix_sumcheck(c, Br, n2, idx, n2, ff, consts, s));                                // sum over the run of delta_M (vv val_M − b_M f_M) = h (X^|K| − 1)
+      RC(ntt_run(c, Br, lg_km[m0] + 1, 1, 0, 1, 0, s));
+      terms[r] = Br + nk[m0] * 32; lens[r] = nk[m0]; co[r] = one;                              // its upper half
     }
-    RC(fr_lincomb(c, h2, n_k, nullptr, terms, lens, co, 3, s));                                 // h_2 = sum_M delta_M h_M
+    RC(fr_lincomb(c, h2, n_k, nullptr, terms, lens, co, nrun, s));                                 // h_2 = sum_M delta_M h_M
   }
   {
     std::vector<MsmSeg> sg(1); sg[0].d_ptr = h2; sg[0].len = n_k; sg[0].off = 0; sg[0].out = 0;

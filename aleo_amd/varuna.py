@@ -77,6 +77,27 @@ def synthetic_committer_key(tau: int, s_gamma: int, max_degree: int, n_gamma: in
     return ck
 
 
+DOMAIN_FLAGS = {'auto': 0, 'per_matrix': 1, 'shared': 2}
+
+
+def domain_policy(n_k_m, domains='auto'):
+    """Non-zero domains of A, B, C: 'per_matrix' keeps each matrix's own power of two, 'shared' gives all three the largest, 'auto' shares
+    below 2^18 (latency-bound rounds: one batched transform beats three short ones) and separates from there on (fewer points to commit)."""
+    if domains not in DOMAIN_FLAGS: raise ValueError('domains: auto, per_matrix or shared')
+    big = max(n_k_m)
+    return [big] * 3 if domains == 'shared' or (domains == 'auto' and big < (1 << 18)) else list(n_k_m)
+
+
+def _runs(n_k_m):
+    """Maximal runs of consecutive matrices with equal domains: [(first, count)] — a run shares batched transforms and one numerator pass."""
+    out, m = [], 0
+    while m < 3:
+        c = 1
+        while m + c < 3 and n_k_m[m + c] == n_k_m[m]: c += 1
+        out.append((m, c)); m += c
+    return out
+
+
 def _csr_on_h(csr, pos, n_h):
     """The matrix with its columns moved to positions on H and its rows padded to |H| (row_ptr, col, val canonical)."""
     ptr, col, val = csr
@@ -88,7 +109,7 @@ class CircuitIndex:
     """Index of one circuit (the prover-key material): matrices in HBM, their arithmetisation over K (evaluations on K and on 2K,
     coefficient forms) and the twelve index commitments [UPSTREAM-RECALL: varuna/ahp/indexer — AHPForR1CS::index]."""
 
-    def __init__(self, csr, n_constraints: int, n_public: int, n_private: int, ck: CommitterKey, stream: torch.cuda.Stream = None):
+    def __init__(self, csr, n_constraints: int, n_public: int, n_private: int, ck: CommitterKey, stream: torch.cuda.Stream = None, domains: str = 'auto'):
         self.ck = ck
         self.n_constraints, self.n_public, self.n_private = n_constraints, n_public, n_private
         n_x = 1
@@ -100,7 +121,9 @@ class CircuitIndex:
             nk = 2
             while nk < int(csr[m][0][-1]): nk *= 2
             self.n_k_m.append(nk)
-        n_k = max(self.n_k_m); self.k_off = [0, self.n_k_m[0], self.n_k_m[0] + self.n_k_m[1]]; k_sum = sum(self.n_k_m)
+        n_k = max(self.n_k_m)
+        self.n_k_m = domain_policy(self.n_k_m, domains)
+        self.k_off = [0, self.n_k_m[0], self.n_k_m[0] + self.n_k_m[1]]; k_sum = sum(self.n_k_m)
         self.n_x, self.n_h, self.n_k = n_x, n_h, n_k
         if max(3 * n_h, n_k) > ck.max_degree + 1: raise ValueError('committer key too small for this circuit')
         self.H, self.H4 = EvaluationDomain(n_h), EvaluationDomain(4 * n_h)
@@ -221,7 +244,8 @@ class NativeCircuitIndex:
     """The index built and owned by the library (aleo_mi355x_varuna_index_build): the key-synthesis step of one circuit in one call.
     csr[m] = (row_ptr uint32[n+1], col uint32[nnz] variable indices, val uint64[nnz,4] canonical) for m in 'abc'."""
 
-    def __init__(self, csr, n_constraints: int, n_public: int, n_private: int, ck: CommitterKey):
+    def __init__(self, csr, n_constraints: int, n_public: int, n_private: int, ck: CommitterKey, domains: str = 'auto'):
+        if domains not in DOMAIN_FLAGS: raise ValueError('domains: auto, per_matrix or shared')
         self.ck = ck; keep = []; mats = (_R1csMatrix * 3)()
         for i, m in enumerate('abc'):
             rp, col, val = (np.ascontiguousarray(csr[m][0], dtype=np.uint32), np.ascontiguousarray(csr[m][1], dtype=np.uint32),
@@ -229,7 +253,7 @@ class NativeCircuitIndex:
             keep += [rp, col, val]
             mats[i].row_ptr, mats[i].col, mats[i].val = rp.ctypes.data, col.ctypes.data, val.ctypes.data
         h = ctypes.c_uint64(0)
-        check(lib().aleo_mi355x_varuna_index_build(ctypes.byref(h), ck.bases.handle, ck.max_degree, ck.gamma_offset, mats, n_constraints, n_public, n_private),
+        check(lib().aleo_mi355x_varuna_index_build(ctypes.byref(h), ck.bases.handle, ck.max_degree, ck.gamma_offset, mats, n_constraints, n_public, n_private, DOMAIN_FLAGS[domains]),
               'varuna_index_build')
         self.handle = h.value
         view = _NativeIndex(); check(lib().aleo_mi355x_varuna_index_export(self.handle, ctypes.byref(view)), 'varuna_index_export')
@@ -409,7 +433,7 @@ class Prover:
         for m in range(3):                                                          # f_M = val u_H(alpha, row) u_H(beta, col) on K_M: two gathers
             fr_gather_mul_device(self.fp(m), km[m], _kp(ix, ix.k_evals, m, 2), self.r_alpha.ptr(), ix.k_idx.data_ptr() + 4 * 2 * ko[m],
                                  rb.ptr(), ix.k_idx.data_ptr() + 4 * (2 * ko[m] + km[m]), s)
-            ix.K_m[m].ntt_device(self.fp(m), direction=INVERSE, stream=s)
+        for m0, cnt in _runs(km): ix.K_m[m0].ntt_batch_device(self.fp(m0), cnt, direction=INVERSE, stream=s)
         self.stream.synchronize()
         f0 = self.f.t[ko].cpu().numpy().view(np.uint64)
         self.sigma = [_from_mont(f0[m]) * km[m] % R for m in range(3)]
@@ -422,15 +446,16 @@ class Prover:
     def fourth_round(self):
         ix, s = self.ix, self.s; n_k = ix.n_k; km, ko = ix.n_k_m, ix.k_off
         F = _Vec(2 * sum(km), zero=True); B = _Vec(2 * sum(km))                     # per matrix on its own domain of size 2|K_M|
-        consts = _mont_rows([1, 1, 1, self.alpha * self.beta, -self.alpha, -self.beta, self.vv])
         terms = []
-        for m in range(3):
-            n2 = 2 * km[m]
-            F.t[2 * ko[m]:2 * ko[m] + km[m]].copy_(self.f.t[ko[m]:ko[m] + km[m]])
-            ix.K2_m[m].ntt_device(F.ptr(2 * ko[m]), stream=s)
-            ahp_matrix_sumcheck_device(B.ptr(2 * ko[m]), n2, [_kp(ix, ix.k2_evals, m, 0, 2), 0, 0], n2, [F.ptr(2 * ko[m]), 0, 0], consts, s)     # vv val − b f
-            ix.K2_m[m].ntt_device(B.ptr(2 * ko[m]), direction=INVERSE, stream=s)
-            terms.append((B.ptr(2 * ko[m] + km[m]), km[m], _mont(self.delta[m])))    # P_M = h_M (X^|K_M| − 1): h_M is the upper half
+        for m0, cnt in _runs(km):                                                   # matrices with equal domains share the transforms and one numerator pass
+            n2 = 2 * km[m0]; mem = list(range(m0, m0 + cnt))
+            for m in mem: F.t[2 * ko[m]:2 * ko[m] + km[m]].copy_(self.f.t[ko[m]:ko[m] + km[m]])
+            ix.K2_m[m0].ntt_batch_device(F.ptr(2 * ko[m0]), cnt, stream=s)
+            pad = [0] * (3 - cnt)
+            consts = _mont_rows([self.delta[m] for m in mem] + pad + [self.alpha * self.beta, -self.alpha, -self.beta, self.vv])
+            ahp_matrix_sumcheck_device(B.ptr(2 * ko[m0]), n2, [_kp(ix, ix.k2_evals, m, 0, 2) for m in mem] + pad, n2, [F.ptr(2 * ko[m]) for m in mem] + pad, consts, s)
+            ix.K2_m[m0].ntt_device(B.ptr(2 * ko[m0]), direction=INVERSE, stream=s)     # sum over the run of delta_M (vv val_M − b_M f_M) = h (X^|K| − 1)
+            terms.append((B.ptr(2 * ko[m0] + km[m0]), km[m0], _mont(1)))             # its upper half
         self.h2 = _Vec(n_k)
         fr_lincomb_device(self.h2.ptr(), n_k, None, terms, s)                         # h_2 = sum_M delta_M h_M
         out = SonicKZG10.commit(ix.ck, [((self.h2.ptr(), n_k), None, None)], device=True, stream=s)

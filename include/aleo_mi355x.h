@@ -289,13 +289,15 @@ typedef struct {
 /* The index built by the library itself from the R1CS (AHPForR1CS::index shape: the arithmetisation above + the twelve index commitments)
  * and kept in HBM under a handle.  Matrices: CSR over the variables (uint32 row_ptr[n_constraints + 1], uint32 col[nnz] = variable index
  * with the n_public public variables first, val[nnz] canonical 32-byte Fr), host memory.  Domains: |X| = 2^ceil(lg n_public), |H| = the power
- * of two >= max(n_constraints, |X| + n_private, 2|X|), |K_M| = the power of two >= the non-zero count of M (>= 2), one per matrix.  The
+ * of two >= max(n_constraints, |X| + n_private, 2|X|), |K_M| = the power of two >= the non-zero count of M (>= 2), one per matrix
+ * (domain_flags 1), all three the largest of them (2), or (0) shared below 2^18 — latency-bound rounds, one batched transform beats three short
+ * ones — and per matrix from there on.  The
  * committer key (powers[0..max_degree], >= 3 hiding powers from gamma_offset) must hold max(3|H|, max |K_M|) powers and stays pinned while the index lives.
  * index_export fills the struct view (pointers owned by the library, valid until index_free); index_vk copies the bytes the transcript absorbs
  * first: 12 compressed index commitments (row, col, val, row_col of A, B, C) then |H|, |K_A|, |K_B|, |K_C|, |X| as u64 LE.  prove_indexed = varuna_prove. */
 typedef struct { const uint32_t* row_ptr; const uint32_t* col; const void* val; } aleo_mi355x_r1cs_matrix;
 int32_t aleo_mi355x_varuna_index_build(uint64_t* index_handle, uint64_t committer_key, uint64_t max_degree, uint64_t gamma_offset,
-                                       const aleo_mi355x_r1cs_matrix abc[3], size_t n_constraints, size_t n_public, size_t n_private);
+                                       const aleo_mi355x_r1cs_matrix abc[3], size_t n_constraints, size_t n_public, size_t n_private, uint32_t domain_flags);
 int32_t aleo_mi355x_varuna_index_export(uint64_t index_handle, aleo_mi355x_varuna_index* out);
 int32_t aleo_mi355x_varuna_index_vk(uint64_t index_handle, void* out, size_t* len);
 int32_t aleo_mi355x_varuna_index_free(uint64_t index_handle);

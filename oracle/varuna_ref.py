@@ -79,7 +79,7 @@ def fr_bytes(v): return int(v % R).to_bytes(32, 'little')
 
 class Circuit:
     """R1CS in CSR-like python form: rows of (variable, value) for A, B, C; n_public counts the leading 1."""
-    def __init__(self, n_constraints, n_public, n_private, a, b, c):
+    def __init__(self, n_constraints, n_public, n_private, a, b, c, domains='auto'):
         self.n_constraints, self.n_public, self.n_private = n_constraints, n_public, n_private
         self.m = {'a': a, 'b': b, 'c': c}
         n_x = 1
@@ -91,7 +91,12 @@ class Circuit:
             nnz = sum(len(r) for r in rows); n_k = 2
             while n_k < nnz: n_k *= 2
             self.n_k_m[name] = n_k
-        self.n_x, self.n_h, self.n_k = n_x, n_h, max(self.n_k_m.values())
+        # 'per_matrix': as above; 'shared': all three use the largest; 'auto' (the provers' default): shared below 2^18, where the rounds are
+        # latency-bound and one batched transform beats three short ones, per matrix from there on (fewer points to commit)
+        big = max(self.n_k_m.values())
+        if domains == 'shared' or (domains == 'auto' and big < (1 << 18)): self.n_k_m = {m: big for m in 'abc'}
+        else: assert domains in ('auto', 'per_matrix')
+        self.n_x, self.n_h, self.n_k = n_x, n_h, big
 
 
 class Setup:

@@ -16,11 +16,12 @@ int main(int argc, char** argv) {
   uint64_t h[8];          // n_constraints, n_public, n_private, max_degree, n_gamma, seed, instances, reserved
   if (!rd(f, h, sizeof h)) return 2;
   const uint64_t nc = h[0], npub = h[1], npriv = h[2], D = h[3], ng = h[4], seed = h[5], k = h[6], nv = npub + npriv;
+  if (nc > (1ull << 28) || nv > (1ull << 28) || D > (1ull << 28) || ng > 64 || k > 8) return 2;
   std::vector<uint8_t> gen(104), srs((D + 1 + ng) * 32);
   if (!rd(f, gen.data(), 104) || !rd(f, srs.data(), srs.size())) return 2;
   std::vector<uint32_t> rp[3], col[3]; std::vector<uint8_t> val[3]; aleo_mi355x_r1cs_matrix abc[3];
   for (int m = 0; m < 3; ++m) {
-    uint64_t nnz; if (!rd(f, &nnz, 8)) return 2;
+    uint64_t nnz; if (!rd(f, &nnz, 8) || nnz > (1ull << 28)) return 2;          // a malformed file must not turn into an allocation
     rp[m].resize(nc + 1); col[m].resize(nnz); val[m].resize(nnz * 32);
     if (!rd(f, rp[m].data(), (nc + 1) * 4) || !rd(f, col[m].data(), nnz * 4) || !rd(f, val[m].data(), nnz * 32)) return 2;
     abc[m].row_ptr = rp[m].data(); abc[m].col = col[m].data(); abc[m].val = val[m].data();
@@ -33,7 +34,7 @@ int main(int argc, char** argv) {
   uint64_t key = 0, index = 0;
   OK(aleo_mi355x_bases_from_scalars(gen.data(), srs.data(), D + 1 + ng, &key), "bases_from_scalars");       // powers | hiding powers
   OK(aleo_mi355x_bases_precompute(key), "bases_precompute");
-  OK(aleo_mi355x_varuna_index_build(&index, key, D, D + 1, abc, nc, npub, npriv), "varuna_index_build");
+  OK(aleo_mi355x_varuna_index_build(&index, key, D, D + 1, abc, nc, npub, npriv, (uint32_t)h[7]), "varuna_index_build");       // h[7]: domain flags
   uint8_t vk[12 * 48 + 64]; size_t vk_len = sizeof vk;
   OK(aleo_mi355x_varuna_index_vk(index, vk, &vk_len), "varuna_index_vk");
   std::vector<uint8_t> proof(2048); size_t len = proof.size();

@@ -11,12 +11,12 @@ from oracle import varuna_ref as V, pyref
 TAU, S_GAMMA = 0x1F3A9C0D5E7B24681357ACE02468BDF013579BDF02468ACE1234567, 0x0FEDCBA9876543210123456789ABCDEF55AA
 
 
-def _circuit(n_constraints, n_public, seed, long_rows=1):
+def _circuit(n_constraints, n_public, seed, long_rows=1, domains='auto'):
     csr, z = synth.synthetic_r1cs(n_constraints, n_public, seed, long_rows=long_rows)
     def rows(m):
         ptr, col, val = csr[m]
         return [[(int(col[k]), synth.limbs_to_int(val[k])) for k in range(ptr[i], ptr[i + 1])] for i in range(len(ptr) - 1)]
-    c = V.Circuit(n_constraints, n_public, len(z) - n_public, rows('a'), rows('b'), rows('c'))
+    c = V.Circuit(n_constraints, n_public, len(z) - n_public, rows('a'), rows('b'), rows('c'), domains=domains)
     return csr, z, c
 
 
@@ -29,8 +29,10 @@ def _max_degree(c):
 def _rand(c, seed, k=1): return V.random_stream(seed, c.n_h, k)
 
 
-def test_restatement_proves_and_verifies():
-    csr, z, c = _circuit(40, 3, 11)
+@pytest.mark.parametrize('domains', ['shared', 'per_matrix'])
+def test_restatement_proves_and_verifies(domains):
+    csr, z, c = _circuit(40, 3, 11, domains=domains)
+    assert len(set(c.n_k_m.values())) == (1 if domains == 'shared' else 2)
     setup = V.Setup(TAU, S_GAMMA, _max_degree(c)); idx = V.Index(c, setup)
     rand = _rand(c, 5)
     proof, data = V.prove(idx, setup, z, rand)
@@ -94,35 +96,37 @@ def test_restatement_batch_of_instances():
 @pytest.mark.parametrize('k', [2, 3, 4, 5, 8])
 def test_device_prover_batch_matches_restatement(k):
     from aleo_amd import varuna
-    csr, z, c = _circuit(150, 3, 40 + k)
+    domains = 'per_matrix' if k % 2 else 'auto'
+    csr, z, c = _circuit(150, 3, 40 + k, domains=domains)
     zs = [z] + [synth.resolve_synthetic(csr, 3, [1, 10 + i, 20 * i + 1]) for i in range(1, k)]
     D = _max_degree(c)
     setup = V.Setup(TAU, S_GAMMA, D); idx = V.Index(c, setup)
     _, want = V.prove(idx, setup, zs, _rand(c, 500 + k, k))
     ck = varuna.synthetic_committer_key(TAU, S_GAMMA, D)
     try:
-        ix = varuna.CircuitIndex(csr, 150, 3, len(z) - 3, ck)
+        ix = varuna.CircuitIndex(csr, 150, 3, len(z) - 3, ck, domains=domains)
         got = varuna.prove(ix, [np.stack([synth.int_to_limbs(v, 4) for v in q]) for q in zs], 500 + k).to_bytes()
         assert got == want and V.verify(idx, setup, [q[:3] for q in zs], got)
         zq = [np.stack([synth.int_to_limbs(v, 4) for v in q]) for q in zs]
         assert varuna.prove_native(ix, zq, 500 + k) == want                            # the one-call C++ host side
-        with varuna.NativeCircuitIndex(csr, 150, 3, len(z) - 3, ck) as nx: assert nx.prove(zq, 500 + k) == want
+        with varuna.NativeCircuitIndex(csr, 150, 3, len(z) - 3, ck, domains=domains) as nx: assert nx.prove(zq, 500 + k) == want
         with pytest.raises(ValueError): varuna.prove(ix, [np.zeros((len(z), 4), dtype=np.uint64)] * 9, 1)
     finally:
         ck.close()
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('domains', ['shared', 'per_matrix'])
 @pytest.mark.parametrize('n_constraints,n_public,seed', [(1, 1, 1), (2, 1, 2), (3, 2, 3), (8, 8, 4), (24, 3, 5), (31, 4, 9), (65, 3, 10), (100, 2, 6), (700, 5, 7), (2000, 9, 8)])
-def test_device_prover_matches_restatement(n_constraints, n_public, seed):
+def test_device_prover_matches_restatement(n_constraints, n_public, seed, domains):
     from aleo_amd import varuna
-    csr, z, c = _circuit(n_constraints, n_public, seed, long_rows=1 if n_constraints > 8 else 0)
+    csr, z, c = _circuit(n_constraints, n_public, seed, long_rows=1 if n_constraints > 8 else 0, domains=domains)
     D = _max_degree(c)
     setup = V.Setup(TAU, S_GAMMA, D); idx = V.Index(c, setup)
     want_proof, want = V.prove(idx, setup, z, _rand(c, seed + 100))
     ck = varuna.synthetic_committer_key(TAU, S_GAMMA, D)
     try:
-        ix = varuna.CircuitIndex(csr, n_constraints, n_public, len(z) - n_public, ck)
+        ix = varuna.CircuitIndex(csr, n_constraints, n_public, len(z) - n_public, ck, domains=domains)
         assert (ix.n_h, ix.n_k, ix.n_x) == (c.n_h, c.n_k, c.n_x) and ix.n_k_m == [c.n_k_m[m] for m in 'abc']
         assert ix.vk_bytes == idx.vk_bytes()
         zz = np.stack([synth.int_to_limbs(v, 4) for v in z])
@@ -130,7 +134,7 @@ def test_device_prover_matches_restatement(n_constraints, n_public, seed):
         got = proof.to_bytes()
         assert got == want
         assert varuna.prove_native(ix, zz, seed + 100) == want                         # the one-call C++ host side
-        with varuna.NativeCircuitIndex(csr, n_constraints, n_public, len(z) - n_public, ck) as nx:     # index built by the library itself
+        with varuna.NativeCircuitIndex(csr, n_constraints, n_public, len(z) - n_public, ck, domains=domains) as nx:     # index built by the library itself
             assert (nx.n_h, nx.n_k_m, nx.n_x) == (c.n_h, [c.n_k_m[m] for m in 'abc'], c.n_x) and nx.vk_bytes == idx.vk_bytes()
             assert nx.prove(zz, seed + 100) == want
             handle = nx.handle
@@ -145,12 +149,12 @@ def test_device_prover_matches_restatement(n_constraints, n_public, seed):
 def test_device_prover_verifies_at_2_13():
     from aleo_amd import varuna
     n = 1 << 13
-    csr, z, c = _circuit(n - 50, 4, 21, long_rows=3)
+    csr, z, c = _circuit(n - 50, 4, 21, long_rows=3, domains='per_matrix')
     D = _max_degree(c)
     setup = V.Setup(TAU, S_GAMMA, D); idx = V.Index(c, setup)
     ck = varuna.synthetic_committer_key(TAU, S_GAMMA, D)
     try:
-        ix = varuna.CircuitIndex(csr, n - 50, 4, len(z) - 4, ck)
+        ix = varuna.CircuitIndex(csr, n - 50, 4, len(z) - 4, ck, domains='per_matrix')
         assert ix.vk_bytes == idx.vk_bytes()
         zz = np.stack([synth.int_to_limbs(v, 4) for v in z])
         data = varuna.prove(ix, zz, 77).to_bytes()
@@ -200,7 +204,7 @@ def test_whole_proof_entry_points_from_plain_cpp(tmp_path):
     import struct, subprocess, sys
     sys.path.insert(0, os.path.dirname(__file__))
     from test_abi import build_cpp_host_mirror
-    csr, z, c = _circuit(300, 3, 71)
+    csr, z, c = _circuit(300, 3, 71, domains='per_matrix')
     zs = [z, synth.resolve_synthetic(csr, 3, [1, 2, 3])]
     D = _max_degree(c); ng = 3; seed = 31337
     setup = V.Setup(TAU, S_GAMMA, D); idx = V.Index(c, setup)
@@ -209,7 +213,7 @@ def test_whole_proof_entry_points_from_plain_cpp(tmp_path):
     for i in range(D + 1): sc.append(a); a = a * TAU % V.R
     a = S_GAMMA % V.R
     for i in range(ng): sc.append(a); a = a * TAU % V.R
-    blob = struct.pack('<8Q', 300, 3, len(z) - 3, D, ng, seed, 2, 0) + synth.generator_affine104().tobytes()
+    blob = struct.pack('<8Q', 300, 3, len(z) - 3, D, ng, seed, 2, 1) + synth.generator_affine104().tobytes()      # last header field: domain flags (1 = per matrix)
     blob += b''.join(int(v).to_bytes(32, 'little') for v in sc)
     for m in 'abc':
         ptr, col, val = csr[m]
@@ -263,7 +267,7 @@ def test_whole_proof_entry_points_refuse_misuse():
                 keep += [rp, col, val]; mats[i].row_ptr, mats[i].col, mats[i].val = rp.ctypes.data, col.ctypes.data, val.ctypes.data
             h = ctypes.c_uint64(0)
             a = dict(key=ck.bases.handle, max_degree=ck.max_degree, gamma_offset=ck.gamma_offset, n=50, pub=2, priv=len(z) - 2); a.update(kw)
-            rc = L.aleo_mi355x_varuna_index_build(ctypes.byref(h), a['key'], a['max_degree'], a['gamma_offset'], mats, a['n'], a['pub'], a['priv'])
+            rc = L.aleo_mi355x_varuna_index_build(ctypes.byref(h), a['key'], a['max_degree'], a['gamma_offset'], mats, a['n'], a['pub'], a['priv'], a.get('flags', 0))
             if rc == 0: L.aleo_mi355x_varuna_index_free(h.value)
             return rc
         assert build() == 0
@@ -271,6 +275,7 @@ def test_whole_proof_entry_points_refuse_misuse():
         def wild(rp, col): col[3] = 10 ** 6
         def back(rp, col): rp[5] = rp[6] + 1
         assert build(shift) == 2 and build(wild) == 2 and build(back) == 2
+        assert build(flags=3) == 2 and build(flags=1) == 0 and build(flags=2) == 0
         assert build(max_degree=7) == 2 and build(key=123456789) == 4 and build(pub=0) == 2 and build(priv=len(z) + 10 ** 6) == 2
     finally:
         ck.close()
