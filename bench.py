@@ -38,6 +38,7 @@ def main():
     ap.add_argument('--proof-proxy-lg', type=int, default=20, help='log2 constraints of the Varuna operator-schedule replay (0 = skip)')
     ap.add_argument('--proof-proxy-cpu-lg', type=int, default=15, help='size of the same replay on the CPU oracle (cpu_baseline leg)')
     ap.add_argument('--varuna-lg', type=int, default=15, help='log2 constraints of the AHP prover measurement (row a6; 0 = skip)')
+    ap.add_argument('--varuna-big-lg', type=int, default=20, help='a second, large circuit for the prover: single proof and 8 instances only (0 = skip)')
     ap.add_argument('--varuna-cpu-lg', type=int, default=10, help='size at which the CPU restatement of the prover is timed and the device proof verified (cpu_baseline leg)')
     ap.add_argument('--concurrent-callers', type=int, default=4, help='secondary: aggregate rate with this many caller threads (0/1 = skip)')
     ap.add_argument('--sharded-ntt-lg', type=int, default=24, help='size of the secondary sharded-NTT measurement at N > 1 (stderr)')
@@ -194,6 +195,9 @@ def main():
         if world == 1 and args.varuna_lg:
             pb.close()
             out['varuna_prove'] = varuna_prove(synth, torch, args.varuna_lg)
+            if args.varuna_big_lg and args.varuna_big_lg != args.varuna_lg:
+                try: out['varuna_prove_2^%d' % args.varuna_big_lg] = varuna_prove_big(synth, args.varuna_big_lg)
+                except Exception as e: out['varuna_prove_2^%d' % args.varuna_big_lg] = {'error': repr(e)[:300]}      # secondary: never costs the headline line
             pb = aleo_amd.PinnedBases.generate_multiples(gen, first, n)
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args, pb, scalars, aleo_amd)
@@ -387,6 +391,31 @@ def varuna_prove(synth, torch, lg, reps=7, in_flight=4):
                 'instances_4': {'prove_ms': mb, 'constraints_per_s': 4 * n / mb * 1e3, 'proof_bytes': len(datab)},
                 'instances_8': {'prove_ms': mb8, 'constraints_per_s': 8 * n / mb8 * 1e3},
                 'in_flight_%d' % in_flight: {'proofs_per_s': in_flight * per / dt, 'constraints_per_s': n * in_flight * per / dt}, 'what': VARUNA_NOTE}
+    finally:
+        ck.close()
+
+
+def varuna_prove_big(synth, lg):
+    """The same prover on a circuit the size of the headline MSM: key synthesis, one proof, eight instances in one proof (native entry points)."""
+    from aleo_amd import varuna
+    t0 = time.perf_counter(); n, csr, z, zz, ck, D = _varuna_instance(synth, lg, 40 + lg); prep_s = time.perf_counter() - t0
+    try:
+        t0 = time.perf_counter(); nx = varuna.NativeCircuitIndex(csr, n, 4, len(z) - 4, ck); index_s = time.perf_counter() - t0
+        try:
+            nx.prove(zz, 1)
+            t1 = []
+            for rep in range(3):
+                t = time.perf_counter(); nx.prove(zz, 10 + rep); t1.append((time.perf_counter() - t) * 1e3)
+            rounds = varuna.native_timing()
+            t8 = []
+            for rep in range(3):
+                t = time.perf_counter(); data = nx.prove([zz] * 8, 20 + rep); t8.append((time.perf_counter() - t) * 1e3)
+            m1, m8 = float(np.median(t1)), float(np.median(t8[1:]))
+            return {'constraints': n, 'domain_h': nx.n_h, 'domains_k': nx.n_k_m, 'max_degree': D, 'index_s': index_s, 'prove_ms': m1, 'constraints_per_s': n / m1 * 1e3,
+                    'rounds_ms': rounds, 'instances_8': {'prove_ms': m8, 'constraints_per_s': 8 * n / m8 * 1e3, 'proof_bytes': len(data)},
+                    'host_prep_s': prep_s, 'entry_point': 'aleo_mi355x_varuna_index_build + aleo_mi355x_varuna_prove_indexed'}
+        finally:
+            nx.close()
     finally:
         ck.close()
 
