@@ -8,6 +8,8 @@
 //   snarkvm_algorithms::polycommit::kzg10::KZG10::commit(powers, polynomial) -> Commitment (G1Affine); the commitments of one
 //       prover round (SonicKZG10::commit over several labelled polynomials) as ONE call; CanonicalSerialize (compressed) of it
 //   snarkvm_algorithms_cuda::{msm, NTT}: Result<_, Error> — an Err means "recompute on the CPU"
+//   snarkvm_synthesizer_snark::ProvingKey::prove_batch / snarkvm_algorithms::snark::varuna::{CircuitProvingKey, Proof}: a proving key bound
+//       to one circuit, `prove_batch(&[assignment])` -> Proof, Proof Display as bech32m `proof1…` (rows a6 / a7 of SURVEY.md §8)
 // Layouts are snarkVM's: Fr = 4 x u64 Montgomery, scalar = 4 x u64 canonical, G1Affine = 104 bytes, Projective = 144 bytes.
 #pragma once
 #include <cstddef>
@@ -56,6 +58,7 @@ class PinnedBases {
   int32_t precompute() { return aleo_mi355x_bases_precompute(handle_); }
   uint64_t handle() const { return handle_; }
   size_t len() const { return n_; }
+  static PinnedBases adopt(uint64_t handle, size_t n) { PinnedBases p; p.handle_ = handle; p.n_ = n; return p; }      // takes ownership of a handle the C ABI returned
  private:
   void release() { if (handle_) { aleo_mi355x_bases_unpin(handle_); handle_ = 0; } }
   uint64_t handle_ = 0; size_t n_ = 0;
@@ -143,6 +146,91 @@ class EvaluationDomain {
     x.resize(size, Fr{{0, 0, 0, 0}});
     return NTT(size, x.data(), NTTInputOutputOrder::NN, d, t);
   }
+};
+
+
+// ---- the prove call of one proving key ------------------------------------------------------------------------
+// Mirrors what sits under `trace.prove_execution::<A, _>(…)` (/root/reference/rust/src/program/execute.rs:74) and `vm.execute(…)` (:177,
+// transfer.rs:99): Trace::prove_execution -> ProvingKey::prove_batch(&[(pk, assignments)]) -> Varuna::prove_batch [UPSTREAM-RECALL], for ONE
+// circuit with 1..8 instances.  CommitterKey = the universal SRS trimmed for the circuit (powers ‖ hiding powers, pinned in HBM);
+// ProvingKey = the circuit's index in HBM (AHPForR1CS::index); prove_batch = one call of the C ABI.
+struct R1CSMatrix { std::vector<uint32_t> row_ptr, col; std::vector<BigInteger256> val; };      // CSR over the variables, public ones first
+struct R1CS { R1CSMatrix a, b, c; size_t num_constraints = 0, num_public = 0, num_private = 0; };
+enum class DomainPolicy : uint32_t { Auto = 0, PerMatrix = 1, Shared = 2 };
+
+class CommitterKey {
+ public:
+  // powers_of_beta_g[0..=max_degree] followed by powers_of_beta_times_gamma_g (>= 3): one resident set, fixed-base tables built once
+  static Result<CommitterKey> pin(const G1Affine* powers_then_gamma_powers, size_t max_degree, size_t n_gamma) {
+    auto b = PinnedBases::pin(powers_then_gamma_powers, max_degree + 1 + n_gamma);
+    if (!b.is_ok()) return {std::nullopt, b.error};
+    return finish(std::move(*b.value), max_degree, n_gamma);
+  }
+  // synthetic setup: P_i = s_i * base for canonical scalars s = (tau^i)_{i <= max_degree} ‖ (gamma tau^i)_{i < n_gamma}
+  static Result<CommitterKey> from_scalars(const G1Affine& base, const BigInteger256* scalars, size_t max_degree, size_t n_gamma) {
+    uint64_t h = 0; int32_t rc = aleo_mi355x_bases_from_scalars(&base, scalars, max_degree + 1 + n_gamma, &h);
+    if (rc) return {std::nullopt, Error{rc}};
+    return finish(PinnedBases::adopt(h, max_degree + 1 + n_gamma), max_degree, n_gamma);
+  }
+  uint64_t handle() const { return bases_.handle(); }
+  size_t max_degree() const { return max_degree_; }
+  size_t gamma_offset() const { return max_degree_ + 1; }
+ private:
+  static Result<CommitterKey> finish(PinnedBases b, size_t max_degree, size_t n_gamma) {
+    if (n_gamma < 3) return {std::nullopt, Error{ALEO_MI355X_ERR_BAD_ARG}};
+    int32_t rc = b.precompute(); if (rc) return {std::nullopt, Error{rc}};
+    CommitterKey k; k.bases_ = std::move(b); k.max_degree_ = max_degree; return {std::move(k), Error{0}};
+  }
+  PinnedBases bases_; size_t max_degree_ = 0;
+};
+
+struct Proof {
+  std::vector<uint8_t> bytes;                                   // Proof::write_le layout
+  Result<std::string> to_string() const {                       // Display: bech32m, hrp "proof"
+    std::string s(2 * bytes.size() + 16, '\0');
+    int32_t rc = aleo_mi355x_bech32m_encode(s.data(), s.size(), "proof", bytes.data(), bytes.size());
+    if (rc) return {std::nullopt, Error{rc}};
+    s.resize(std::char_traits<char>::length(s.c_str())); return {std::move(s), Error{0}};
+  }
+};
+
+class ProvingKey {
+ public:
+  // AHPForR1CS::index + the circuit's commitments (Process::synthesize_key, /root/reference/wasm/src/programs/manager/mod.rs:164-177)
+  static Result<ProvingKey> index(const CommitterKey& ck, const R1CS& cs, DomainPolicy policy = DomainPolicy::Auto) {
+    aleo_mi355x_r1cs_matrix m[3] = {{cs.a.row_ptr.data(), cs.a.col.data(), cs.a.val.data()}, {cs.b.row_ptr.data(), cs.b.col.data(), cs.b.val.data()},
+                                    {cs.c.row_ptr.data(), cs.c.col.data(), cs.c.val.data()}};
+    for (auto* q : {&cs.a, &cs.b, &cs.c}) if (q->row_ptr.size() != cs.num_constraints + 1 || q->col.size() != q->val.size()) return {std::nullopt, Error{ALEO_MI355X_ERR_BAD_ARG}};
+    ProvingKey pk;
+    int32_t rc = aleo_mi355x_varuna_index_build(&pk.handle_, ck.handle(), ck.max_degree(), ck.gamma_offset(), m, cs.num_constraints, cs.num_public, cs.num_private, (uint32_t)policy);
+    if (rc) return {std::nullopt, Error{rc}};
+    pk.num_variables_ = cs.num_public + cs.num_private;
+    return {std::move(pk), Error{0}};
+  }
+  // ProvingKey::prove_batch: one assignment (public variables first, z_0 = 1, canonical) per instance; `seed` stands for the caller's RNG
+  Result<Proof> prove_batch(const std::vector<const std::vector<BigInteger256>*>& assignments, uint64_t seed) const {
+    std::vector<const void*> p;
+    for (auto* a : assignments) { if (!a || a->size() != num_variables_) return {std::nullopt, Error{ALEO_MI355X_ERR_BAD_ARG}}; p.push_back(a->data()); }
+    Proof out; out.bytes.resize(1024 + 192 * assignments.size()); size_t len = out.bytes.size();
+    int32_t rc = aleo_mi355x_varuna_prove_indexed(handle_, p.data(), p.size(), seed, out.bytes.data(), &len);
+    if (rc) return {std::nullopt, Error{rc}};
+    out.bytes.resize(len); return {std::move(out), Error{0}};
+  }
+  // what the verifier's transcript starts from: 12 compressed index commitments + the domain sizes
+  Result<std::vector<uint8_t>> verifying_key_bytes() const {
+    std::vector<uint8_t> v(1024); size_t len = v.size();
+    int32_t rc = aleo_mi355x_varuna_index_vk(handle_, v.data(), &len);
+    if (rc) return {std::nullopt, Error{rc}};
+    v.resize(len); return {std::move(v), Error{0}};
+  }
+  ProvingKey() = default;
+  ProvingKey(ProvingKey&& o) noexcept : handle_(o.handle_), num_variables_(o.num_variables_) { o.handle_ = 0; }
+  ProvingKey& operator=(ProvingKey&& o) noexcept { release(); handle_ = o.handle_; num_variables_ = o.num_variables_; o.handle_ = 0; return *this; }
+  ProvingKey(const ProvingKey&) = delete; ProvingKey& operator=(const ProvingKey&) = delete;
+  ~ProvingKey() { release(); }
+ private:
+  void release() { if (handle_) { aleo_mi355x_varuna_index_free(handle_); handle_ = 0; } }
+  uint64_t handle_ = 0; size_t num_variables_ = 0;
 };
 
 }  // namespace aleo_mi355x

@@ -1,7 +1,7 @@
 // A caller of the whole-proof entry points with nothing but the C ABI (no Python, no torch): reads a circuit, its assignments and the
 // scalars of a synthetic committer key from a file written by tests/test_varuna.py, pins the key, builds the index, proves, writes the
 // proof and the verifier-key bytes.  What a Rust Varuna::prove_batch would do through FFI.
-#include "aleo_mi355x.h"
+#include "aleo_mi355x.hpp"
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -47,6 +47,27 @@ int main(int argc, char** argv) {
   FILE* o = fopen(argv[2], "wb"); if (!o) return 2;
   uint64_t l2[2] = {vk_len, len};
   fwrite(l2, 8, 2, o); fwrite(vk, 1, vk_len, o); fwrite(proof.data(), 1, len, o); fclose(o);
+  // the same through the C++ mirror of ProvingKey::prove_batch (include/aleo_mi355x.hpp): same bytes, Display as proof1…
+  {
+    using namespace aleo_mi355x;
+    auto ck = CommitterKey::from_scalars(*(const G1Affine*)gen.data(), (const BigInteger256*)srs.data(), D, ng);
+    if (!ck.is_ok()) { fprintf(stderr, "CommitterKey: %s\n", ck.error.message().c_str()); return 1; }
+    R1CS cs; cs.num_constraints = nc; cs.num_public = npub; cs.num_private = npriv;
+    R1CSMatrix* mm[3] = {&cs.a, &cs.b, &cs.c};
+    for (int m = 0; m < 3; ++m) { mm[m]->row_ptr = rp[m]; mm[m]->col = col[m]; mm[m]->val.resize(col[m].size()); memcpy(mm[m]->val.data(), val[m].data(), val[m].size()); }
+    auto pk = ProvingKey::index(*ck.value, cs, (DomainPolicy)h[7]);
+    if (!pk.is_ok()) { fprintf(stderr, "ProvingKey::index: %s\n", pk.error.message().c_str()); return 1; }
+    std::vector<std::vector<BigInteger256>> za(k, std::vector<BigInteger256>(nv)); std::vector<const std::vector<BigInteger256>*> zs;
+    for (uint64_t i = 0; i < k; ++i) { memcpy(za[i].data(), z[i].data(), nv * 32); zs.push_back(&za[i]); }
+    auto pr = pk.value->prove_batch(zs, seed);
+    if (!pr.is_ok() || pr.value->bytes.size() != len || memcmp(pr.value->bytes.data(), proof.data(), len)) { fprintf(stderr, "prove_batch differs from the raw call\n"); return 1; }
+    auto str = pr.value->to_string();
+    if (!str.is_ok() || str.value->rfind("proof1", 0) != 0) { fprintf(stderr, "Proof::to_string\n"); return 1; }
+    auto vk2 = pk.value->verifying_key_bytes();
+    if (!vk2.is_ok() || vk2.value->size() != vk_len || memcmp(vk2.value->data(), vk, vk_len)) { fprintf(stderr, "verifying_key_bytes\n"); return 1; }
+    std::vector<BigInteger256> shorter(nv - 1); std::vector<const std::vector<BigInteger256>*> bad = {&shorter};
+    if (pk.value->prove_batch(bad, seed).is_ok()) { fprintf(stderr, "wrong assignment length accepted\n"); return 1; }
+  }
   printf("ALL OK\n");
   return 0;
 }
