@@ -244,39 +244,67 @@ int32_t varuna_index_build(Ctx* c, const PinnedBases& pb, std::shared_ptr<Pinned
 }
 
 
-int32_t varuna_prove(Ctx* c, const PinnedBases& pb, const aleo_mi355x_varuna_index& ix, const void* const* assignments, size_t k, uint64_t seed,
-                     uint8_t* out, size_t* out_len) {
-  const size_t n_h = ix.n_h, n_x = ix.n_x, L = n_h + 1, n4 = 4 * n_h, HC = 3;      // HC: coefficients of a hiding polynomial
-  const size_t nk[3] = {(size_t)ix.n_k_a, (size_t)ix.n_k_b, (size_t)ix.n_k_c}, ko[3] = {0, nk[0], nk[0] + nk[1]}, k_sum = nk[0] + nk[1] + nk[2];
-  const size_t n_k = nk[0] > nk[1] ? (nk[0] > nk[2] ? nk[0] : nk[2]) : (nk[1] > nk[2] ? nk[1] : nk[2]);      // K: the largest non-zero domain
-  const uint64_t D = ix.max_degree;
+// The state of one proof between the rounds (upstream: varuna::ahp::prover::State) and the round functions in the order upstream calls them.
+#define TAKE_M(var, elems) var = ar.take(elems); if (!var) { g_last_error = "varuna_prove: workspace accounting"; return ALEO_MI355X_ERR_HIP; }
+struct Prover {
+  static constexpr size_t HC = 3;                          // coefficients of a hiding polynomial (hiding bound 1)
+  Ctx* c; const PinnedBases& pb; const aleo_mi355x_varuna_index& ix; const size_t k; const uint64_t seed;
+  Prover(Ctx* c_, const PinnedBases& pb_, const aleo_mi355x_varuna_index& ix_, size_t k_, uint64_t seed_) : c(c_), pb(pb_), ix(ix_), k(k_), seed(seed_) {}
+  // sizes, stream, workspace
+  size_t n_h = 0, n_x = 0, L = 0, n4 = 0, nk[3] = {}, ko[3] = {}, k_sum = 0, n_k = 0; uint64_t D = 0; uint32_t lg_h = 0, lg_km[3] = {};
+  hipStream_t s = nullptr; double t_mark[7] = {}; Arena ar{nullptr, 0, 0}; char* pin = nullptr; char* pin_small = nullptr;
+  HFr one, neg1, r2; Transcript tr; uint64_t lay_mask = 0, lay_blind = 0, lay_blind_mask = 0;
+  // what the rounds hand on: polynomials in HBM, commitments, challenges
+  char *wit = nullptr, *mask = nullptr, *ext = nullptr, *h1 = nullptr, *g1 = nullptr, *f = nullptr, *h2 = nullptr;
+  std::vector<std::vector<HFr>> x_poly; std::vector<HFr> blind, comb, evals; std::vector<uint8_t> wit_aff, comp;
+  uint8_t aff2[208], aff3[312], aff4[104], aff5[208];
+  HFr alpha, eta_b, eta_c, vh_alpha, beta, vh_beta, vv, sigma[3], delta[3], gamma, random_v;
+  size_t run0[3] = {}, runc[3] = {}, nrun = 0;
+
+  int32_t setup(const void* const* assignments);
+  int32_t first_round(const void* const* assignments);     // AHPForR1CS::prover_first_round + the 3k + 1 hiding commitments
+  int32_t second_round();                                  // prover_second_round: t, the first sumcheck, g_1, h_1
+  int32_t third_round();                                   // prover_third_round: f_M, sigma_M, g_M
+  int32_t fourth_round();                                  // prover_fourth_round: h_2
+  int32_t open();                                          // evaluations, the two linear combinations, both KZG openings
+  int32_t write(uint8_t* out, size_t* out_len);            // Proof::write_le
+};
+
+int32_t Prover::setup(const void* const* assignments) {
+  (void)assignments;
+  n_h = ix.n_h; n_x = ix.n_x; L = n_h + 1; n4 = 4 * n_h;
+  nk[0] = ix.n_k_a; nk[1] = ix.n_k_b; nk[2] = ix.n_k_c; ko[0] = 0; ko[1] = nk[0]; ko[2] = nk[0] + nk[1]; k_sum = nk[0] + nk[1] + nk[2];
+  n_k = nk[0] > nk[1] ? (nk[0] > nk[2] ? nk[0] : nk[2]) : (nk[1] > nk[2] ? nk[1] : nk[2]);      // K: the largest non-zero domain
+  D = ix.max_degree;
   bool k_ok = true; for (int m = 0; m < 3; ++m) k_ok = k_ok && nk[m] >= 2 && !(nk[m] & (nk[m] - 1));
   if (k < 1 || k > 8 || n_h < 2 || !k_ok || n_x < 1 || n_h < 2 * n_x || (n_h & (n_h - 1)) || (n_x & (n_x - 1)) ||
       ix.n_public > n_x || ix.n_vars > n_h || ix.gamma_offset + HC > pb.n || D + 1 > pb.n || 3 * n_h > D + 1 || n_k > D + 1) {
     g_last_error = "varuna_prove: inconsistent index / key sizes"; return ALEO_MI355X_ERR_BAD_ARG;
   }
-  uint32_t lg_h = 0, lg_km[3] = {0, 0, 0}; while ((1ull << lg_h) < n_h) ++lg_h;
+  lg_h = 0; lg_km[0] = lg_km[1] = lg_km[2] = 0; while ((1ull << lg_h) < n_h) ++lg_h;
   for (int m = 0; m < 3; ++m) while ((1ull << lg_km[m]) < nk[m]) ++lg_km[m];
-  hipStream_t s = c->stream;
-  double t_mark[7]; t_mark[0] = now_ms();
+  s = c->stream;
+  t_mark[0] = now_ms();
   // ---- workspace ------------------------------------------------------------------------------------------------------------------
   const size_t elems = n_h * (40 + 20 * k) + k_sum * 6 + n_k * 4 + 4096;
   RC(c->prover_ws.reserve(elems * 32 + (64 << 10)));
-  Arena ar{(char*)c->prover_ws.p, 0, c->prover_ws.cap};
+  ar = Arena{(char*)c->prover_ws.p, 0, c->prover_ws.cap};
   const size_t pin_need = k * n_h * 32 + 4096;
   if (c->prover_pin_cap < pin_need) {
     if (c->prover_pin) { HIPCHK(hipStreamSynchronize(s)); (void)hipHostFree(c->prover_pin); c->prover_pin = nullptr; c->prover_pin_cap = 0; }
     HIPCHK(hipHostMalloc(&c->prover_pin, pin_need + pin_need / 8, hipHostMallocDefault)); c->prover_pin_cap = pin_need + pin_need / 8;
   }
-  char* pin = (char*)c->prover_pin; char* pin_small = pin + k * n_h * 32;      // 4 KB for small read-backs
-  const HFr one = HFr::one(), neg1 = HFr::neg(one);
-  HFr r2; std::memcpy(r2.l, host::HParams<4>::R2, 32);
-  Transcript tr;
+  pin = (char*)c->prover_pin; pin_small = pin + k * n_h * 32;      // 4 KB for small read-backs
+  one = HFr::one(); neg1 = HFr::neg(one); std::memcpy(r2.l, host::HParams<4>::R2, 32);
   // randomness layout (oracle/varuna_ref.py randomness_layout)
-  const uint64_t lay_mask = 3 * k, lay_blind = 3 * k + 3 * n_h, lay_blind_mask = lay_blind + 3 * HC * k;
+  lay_mask = 3 * k; lay_blind = 3 * k + 3 * n_h; lay_blind_mask = lay_blind + 3 * HC * k;
+  return ALEO_MI355X_OK;
+}
+
+int32_t Prover::first_round(const void* const* assignments) {
   // ---- round 1 ------------------------------------------------------------------------------------------------------------------------
-  TAKE(zH, k * n_h) TAKE(ev, 3 * k * n_h) TAKE(xh, k * n_h) TAKE(wit, 3 * k * L) TAKE(mask, 3 * n_h) TAKE(bl, (3 * k + 1) * HC)
-  std::vector<std::vector<HFr>> x_poly(k); std::vector<uint8_t> x_bytes(k * n_x * 32, 0);
+  TAKE(zH, k * n_h) TAKE(ev, 3 * k * n_h) TAKE(xh, k * n_h) TAKE_M(wit, 3 * k * L) TAKE_M(mask, 3 * n_h) TAKE(bl, (3 * k + 1) * HC)
+  x_poly.assign(k, {}); std::vector<uint8_t> x_bytes(k * n_x * 32, 0);
   const HFr gx_inv = HFr::inv(domain_gen(n_x)), nx_inv = HFr::inv(fr_u64(n_x));
   std::memset(pin, 0, k * n_h * 32);
   const uint32_t* pos = (const uint32_t*)ix.positions;
@@ -309,7 +337,7 @@ int32_t varuna_prove(Ctx* c, const PinnedBases& pb, const aleo_mi355x_varuna_ind
     RC(fr_vec_op(c, e0, e0, ix.vx_inv, n_h, 0, s));                                         // / v_X off X, 0 on X
   }
   RC(ntt_run(c, ev, lg_h, 3 * k, 0, 1, 0, s));
-  std::vector<HFr> blind((3 * k + 1) * HC);
+  blind.assign((3 * k + 1) * HC, HFr::zero());
   for (size_t q = 0; q < 3 * k; ++q) {
     const HFr rho = random_fr(seed, q);                                                     // rho_w, rho_a, rho_b of instance q / 3
     char* p = wit + q * L * 32;
@@ -323,7 +351,7 @@ int32_t varuna_prove(Ctx* c, const PinnedBases& pb, const aleo_mi355x_varuna_ind
   RC(fr_random(c, mask, 3 * n_h, seed, lay_mask, 1, s));
   RC(fr_lin(c, mask, 1, nullptr, neg1.l, mask + n_h * 32, neg1.l, mask + 2 * n_h * 32, s));   // sum over H = |H| (m_0 + m_|H| + m_2|H|) = 0
   HIPCHK(hipMemcpyAsync(bl, blind.data(), blind.size() * 32, hipMemcpyHostToDevice, s));
-  std::vector<uint8_t> wit_aff(104 * (3 * k + 1)), comp(48 * 8);
+  wit_aff.assign(104 * (3 * k + 1), 0); comp.assign(48 * 8, 0);
   {
     std::vector<MsmSeg> sg;
     for (size_t q = 0; q <= 3 * k; ++q) {
@@ -335,14 +363,18 @@ int32_t varuna_prove(Ctx* c, const PinnedBases& pb, const aleo_mi355x_varuna_ind
   std::vector<uint8_t> c1(48 * (3 * k + 1));
   RC(aleo_mi355x_g1_compress(c1.data(), wit_aff.data(), 3 * k + 1));
   tr.absorb(ix.vk_bytes, ix.vk_len); tr.absorb(x_bytes.data(), x_bytes.size()); tr.absorb(c1.data(), c1.size());
-  const HFr alpha = tr.challenge("alpha", 5), eta_b = tr.challenge("eta_b", 5), eta_c = tr.challenge("eta_c", 5);
-  std::vector<HFr> comb(k, one);
+  alpha = tr.challenge("alpha", 5); eta_b = tr.challenge("eta_b", 5); eta_c = tr.challenge("eta_c", 5);
+  comb.assign(k, one);
   for (size_t i = 1; i < k; ++i) { char lab[12] = "combiner"; uint32_t ii = (uint32_t)i; std::memcpy(lab + 8, &ii, 4); comb[i] = tr.challenge(lab, 12); }
   t_mark[1] = now_ms();
+  return ALEO_MI355X_OK;
+}
+
+int32_t Prover::second_round() {
   // ---- round 2: the first sumcheck --------------------------------------------------------------------------------------------------------
-  const HFr vh_alpha = vanish(n_h, alpha);
+  vh_alpha = vanish(n_h, alpha);
   if (vh_alpha.is_zero()) { g_last_error = "varuna_prove: alpha landed in H"; return ALEO_MI355X_ERR_HIP; }
-  TAKE(ext, 3 * n_h) TAKE(rt, 2 * n_h) TAKE(E, (2 + 3 * k) * n4) TAKE(xp, k * n_x) TAKE(Q, n4) TAKE(h1, 2 * n_h) TAKE(g1, n_h)
+  TAKE_M(ext, 3 * n_h) TAKE(rt, 2 * n_h) TAKE(E, (2 + 3 * k) * n4) TAKE(xp, k * n_x) TAKE(Q, n4) TAKE_M(h1, 2 * n_h) TAKE_M(g1, n_h)
   {
     const HFr first = HFr::pow_u64(alpha, n_h - 1), ratio = HFr::inv(alpha);
     RC(fr_powers(c, rt, n_h, first.l, ratio.l, s));                                          // r(alpha, X) = sum_k alpha^(|H|-1-k) X^k
@@ -381,7 +413,6 @@ int32_t varuna_prove(Ctx* c, const PinnedBases& pb, const aleo_mi355x_varuna_ind
   HIPCHK(hipMemcpyAsync(h1 + n_h * 32, q1 + 2 * n_h * 32, n_h * 32, hipMemcpyDeviceToDevice, s));   // quotient blocks: p2, p1 + p2; remainder p0 + p1 + p2
   RC(fr_vec_op(c, h1, q1 + n_h * 32, q1 + 2 * n_h * 32, n_h, 1, s));
   RC(fr_vec_op(c, g1, q1, h1, n_h, 1, s));
-  uint8_t aff2[208], aff3[312], aff4[104], aff5[208];
   {
     std::vector<MsmSeg> sg(2);
     sg[0].d_ptr = g1 + 32; sg[0].len = n_h - 1; sg[0].off = D - (n_h - 2); sg[0].out = 0;    // degree bound |H| − 2: shifted powers
@@ -389,13 +420,17 @@ int32_t varuna_prove(Ctx* c, const PinnedBases& pb, const aleo_mi355x_varuna_ind
     RC(commit(c, pb, sg, 2, aff2, s));
   }
   RC(aleo_mi355x_g1_compress(comp.data(), aff2, 2)); tr.absorb(comp.data(), 96);
-  const HFr beta = tr.challenge("beta", 4);
+  beta = tr.challenge("beta", 4);
   t_mark[2] = now_ms();
+  return ALEO_MI355X_OK;
+}
+
+int32_t Prover::third_round() {
   // ---- round 3: three rational sumchecks over K ----------------------------------------------------------------------------------------------
-  const HFr vh_beta = vanish(n_h, beta);
+  vh_beta = vanish(n_h, beta);
   if (vh_beta.is_zero()) { g_last_error = "varuna_prove: beta landed in H"; return ALEO_MI355X_ERR_HIP; }
-  const HFr vv = HFr::mul(vh_alpha, vh_beta);
-  TAKE(f, k_sum) TAKE(rb, n_h)                                                              // f_M at element ko[M], |K_M| values
+  vv = HFr::mul(vh_alpha, vh_beta);
+  TAKE_M(f, k_sum) TAKE(rb, n_h)                                                              // f_M at element ko[M], |K_M| values
   {
     const HFr first = HFr::pow_u64(beta, n_h - 1), ratio = HFr::inv(beta);
     RC(fr_powers(c, rb, n_h, first.l, ratio.l, s));
@@ -406,12 +441,12 @@ int32_t varuna_prove(Ctx* c, const PinnedBases& pb, const aleo_mi355x_varuna_ind
     RC(fr_gather_mul(c, f + ko[m] * 32, nk[m], (const char*)ix.k_evals + (4 * ko[m] + 2 * nk[m]) * 32, ext, ri, rb, ri + nk[m], s));
   }
   // maximal runs of consecutive matrices with equal domains share batched transforms (and, in round 4, one numerator pass)
-  size_t run0[3], runc[3], nrun = 0;
+  nrun = 0;
   for (size_t m = 0; m < 3;) { size_t cnt = 1; while (m + cnt < 3 && nk[m + cnt] == nk[m]) ++cnt; run0[nrun] = m; runc[nrun++] = cnt; m += cnt; }
   for (size_t r = 0; r < nrun; ++r) RC(ntt_run(c, f + ko[run0[r]] * 32, lg_km[run0[r]], runc[r], 0, 1, 0, s));
   for (size_t m = 0; m < 3; ++m) HIPCHK(hipMemcpyAsync(pin_small + 32 * m, f + ko[m] * 32, 32, hipMemcpyDeviceToHost, s));
   HIPCHK(hipStreamSynchronize(s));
-  HFr sigma[3]; uint8_t sig_bytes[96];
+  uint8_t sig_bytes[96];
   for (size_t m = 0; m < 3; ++m) { HFr v; std::memcpy(v.l, pin_small + 32 * m, 32); sigma[m] = HFr::mul(v, fr_u64(nk[m])); fr_bytes(sig_bytes + 32 * m, sigma[m]); }
   {
     std::vector<MsmSeg> sg(3);
@@ -420,10 +455,14 @@ int32_t varuna_prove(Ctx* c, const PinnedBases& pb, const aleo_mi355x_varuna_ind
   }
   RC(aleo_mi355x_g1_compress(comp.data(), aff3, 3));
   { uint8_t b[96 + 144]; std::memcpy(b, sig_bytes, 96); std::memcpy(b + 96, comp.data(), 144); tr.absorb(b, sizeof b); }
-  HFr delta[3] = {one, tr.challenge("delta_b", 7), tr.challenge("delta_c", 7)};
+  delta[0] = one; delta[1] = tr.challenge("delta_b", 7); delta[2] = tr.challenge("delta_c", 7);
   t_mark[3] = now_ms();
+  return ALEO_MI355X_OK;
+}
+
+int32_t Prover::fourth_round() {
   // ---- round 4 ----------------------------------------------------------------------------------------------------------------------------------
-  TAKE(F, 2 * k_sum) TAKE(B, 2 * k_sum) TAKE(h2, n_k)                                          // per matrix on its own domain of size 2|K_M|
+  TAKE(F, 2 * k_sum) TAKE(B, 2 * k_sum) TAKE_M(h2, n_k)                                          // per matrix on its own domain of size 2|K_M|
   HIPCHK(hipMemsetAsync(F, 0, 2 * k_sum * 32, s));
   {
     const void* terms[3]; size_t lens[3]; HFr co[3];
@@ -448,8 +487,12 @@ int32_t varuna_prove(Ctx* c, const PinnedBases& pb, const aleo_mi355x_varuna_ind
     RC(commit(c, pb, sg, 1, aff4, s));
   }
   RC(aleo_mi355x_g1_compress(comp.data(), aff4, 1)); tr.absorb(comp.data(), 48);
-  const HFr gamma = tr.challenge("gamma", 5);
+  gamma = tr.challenge("gamma", 5);
   t_mark[4] = now_ms();
+  return ALEO_MI355X_OK;
+}
+
+int32_t Prover::open() {
   // ---- evaluations -------------------------------------------------------------------------------------------------------------------------------
   TAKE(evd, k + 8) TAKE(pbeta, 3 * n_h) TAKE(wq, 3 * n_h) TAKE(blq, HC) TAKE(pg, n_k) TAKE(gq, n_k)
   {
@@ -461,7 +504,7 @@ int32_t varuna_prove(Ctx* c, const PinnedBases& pb, const aleo_mi355x_varuna_ind
   }
   HIPCHK(hipMemcpyAsync(pin_small, evd, (k + 4) * 32, hipMemcpyDeviceToHost, s));
   HIPCHK(hipStreamSynchronize(s));
-  std::vector<HFr> evals(k + 4); std::vector<uint8_t> ev_bytes((k + 4) * 32);
+  evals.assign(k + 4, HFr::zero()); std::vector<uint8_t> ev_bytes((k + 4) * 32);
   for (size_t i = 0; i < k + 4; ++i) { std::memcpy(evals[i].l, pin_small + 32 * i, 32); fr_bytes(&ev_bytes[32 * i], evals[i]); }
   tr.absorb(ev_bytes.data(), ev_bytes.size());
   const HFr xi = tr.challenge("xi", 2);
@@ -471,7 +514,7 @@ int32_t varuna_prove(Ctx* c, const PinnedBases& pb, const aleo_mi355x_varuna_ind
   const HFr t_beta = HFr::add(sigma[0], HFr::add(HFr::mul(eta_b, sigma[1]), HFr::mul(eta_c, sigma[2])));
   const HFr xl = HFr::pow_u64(xi, k + 1), vx_beta = vanish(n_x, beta);
   HFr cst = HFr::neg(HFr::mul(beta, g1_beta));
-  HFr random_v, blw[3];                                                                     // blw: (bl(X) − bl(beta)) / (X − beta), uploaded below
+  HFr blw[3];                                                                     // blw: (bl(X) − bl(beta)) / (X − beta), uploaded below
   {
     const void* terms[28]; size_t lens[28]; HFr co[28]; size_t nt = 0;
     terms[nt] = mask; lens[nt] = 3 * n_h; co[nt++] = xl;
@@ -526,17 +569,28 @@ int32_t varuna_prove(Ctx* c, const PinnedBases& pb, const aleo_mi355x_varuna_ind
     RC(commit(c, pb, sg, 2, aff5, s));                                                       // both witness commitments in one call
   }
   t_mark[5] = now_ms();
+  return ALEO_MI355X_OK;
+}
+
+int32_t Prover::write(uint8_t* out, size_t* out_len) {
   // ---- the proof in upstream's layout ---------------------------------------------------------------------------------------------------------------
   aleo_mi355x_proof_parts parts{}; uint64_t batch = k;
-  std::vector<HFr> ev_m(evals); uint8_t has_v[2] = {1, 0}; HFr rv[2] = {random_v, HFr::zero()};
+  uint8_t has_v[2] = {1, 0}; HFr rv[2] = {random_v, HFr::zero()};
   parts.batch_sizes = &batch; parts.n_circuits = 1; parts.witness_commitments = wit_aff.data(); parts.mask_poly = wit_aff.data() + 104 * 3 * k;
   parts.g_1 = aff2; parts.h_1 = aff2 + 104; parts.g_abc = aff3; parts.h_2 = aff4;
-  parts.evaluations = ev_m.data(); parts.n_evaluations = k + 4; parts.sums = sigma;
+  parts.evaluations = evals.data(); parts.n_evaluations = k + 4; parts.sums = sigma;
   parts.opening_points = aff5; parts.opening_random_v = rv; parts.opening_has_v = has_v; parts.n_openings = 2;
   RC(aleo_mi355x_proof_to_bytes(out, out_len, &parts));
   for (int i = 0; i < 5; ++i) g_varuna_timing[i] = t_mark[i + 1] - t_mark[i];
   g_varuna_timing[5] = t_mark[5] - t_mark[0];
   return ALEO_MI355X_OK;
+}
+
+int32_t varuna_prove(Ctx* c, const PinnedBases& pb, const aleo_mi355x_varuna_index& ix, const void* const* assignments, size_t k, uint64_t seed,
+                     uint8_t* out, size_t* out_len) {
+  Prover p(c, pb, ix, k, seed);
+  RC(p.setup(assignments)); RC(p.first_round(assignments)); RC(p.second_round()); RC(p.third_round()); RC(p.fourth_round()); RC(p.open());
+  return p.write(out, out_len);
 }
 
 }  // namespace aleo_mi355x
