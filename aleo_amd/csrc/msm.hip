@@ -1311,9 +1311,14 @@ int32_t msm_precompute(Ctx* c, PinnedBases* pb) {
     if (rc) return;
     if ((rc = build_table(c, pb, cbits, cover, &pb->tab[k])) == ALEO_MI355X_OK) pb->tab[k++].min_n = min_n;
   };
-  if (N >= (1u << 17)) tier(N >= (1u << 19) ? 20 : 17, N, ((size_t)1 << 17) + 1);      // exactly 2^17 points: the c = 16 tier is faster (0.90 vs 1.18 ms)
-  if (N >= (1u << 15)) tier(16, lim((size_t)1 << 17), (size_t)1 << 15);
-  if (N >= (1u << 10)) tier(13, lim((size_t)1 << 15), (size_t)1 << 10);
+  // Prefix tiers reach TIER_SLACK points past their power of two: a committer key is a power of two of powers FOLLOWED by a few hiding
+  // powers, and commitments that touch those (every hiding one) would otherwise fall through to the next wider window (2x the buckets per
+  // result: with 25 results in a chain, as many as a batch of 8 instances commits in its first round, most of the reduction time).
+  constexpr size_t TIER_SLACK = 64;
+  const size_t cover16 = lim(((size_t)1 << 17) + TIER_SLACK), cover13 = lim(((size_t)1 << 15) + TIER_SLACK);
+  if (N > cover16) tier(N >= (1u << 19) ? 20 : 17, N, cover16 + 1);      // up to cover16 points the c = 16 tier is faster (2^17: 0.90 vs 1.18 ms)
+  if (N >= (1u << 15)) tier(16, cover16, (size_t)1 << 15);
+  if (N >= (1u << 10)) tier(13, cover13, (size_t)1 << 10);
   if (rc) {                                     // a later tier failed (out of memory): give back the ones already built
     for (auto& t : pb->tab) { if (t.d) (void)hipFree(t.d); t = PinnedBases::PreTable(); }
     return rc;
