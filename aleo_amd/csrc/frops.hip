@@ -500,6 +500,56 @@ int32_t ahp_matrix_sumcheck(Ctx* c, void* d_dst, size_t n, const void* const* d_
   return ALEO_MI355X_OK;
 }
 
+// Two layout steps of the prover's first two rounds, one launch each for all instances (they were 3 launches per polynomial and 5 per instance):
+//   blind rows:  dst[q] (n + 1 coefficients) = src[q] (n coefficients) + rho_q (X^n − 1)        — w, z_a, z_b after the inverse transform
+//   sumcheck operands of instance i on the 4n domain, zero padded:  z_i = w_i (X^|X| − 1) + x̂_i,  z_a,i,  z_b,i   (rows 3i, 3i+1, 3i+2 of dst)
+static constexpr uint32_t BLIND_MAX = 24;
+struct BlindArgs { FrK rho[BLIND_MAX]; };
+__global__ void __launch_bounds__(256) k_blind_rows(char* __restrict__ dst, const char* __restrict__ src, size_t n, uint32_t rows, BlindArgs a) {
+  const size_t L = n + 1;
+  for (size_t t = (size_t)blockIdx.x * 256 + threadIdx.x; t < L * rows; t += (size_t)gridDim.x * 256) {
+    const uint32_t q = (uint32_t)(t / L); const size_t i = t % L;
+    Fr v = i < n ? load_fp<Fr>(src + ((size_t)q * n + i) * 32) : fr_arg(a.rho[q]);
+    if (i == 0) v = Fr::cond_sub<1>(Fr::sub<1>(v, fr_arg(a.rho[q])));                         // v + r − rho < 2r -> < r
+    store_fp<Fr>(dst + t * 32, v);
+  }
+}
+int32_t fr_blind_rows(Ctx* c, void* d_dst, const void* d_src, size_t n, size_t rows, const void* rho_mont, hipStream_t s) {
+  (void)c;
+  if (!rows || !n) return ALEO_MI355X_OK;
+  if (rows > BLIND_MAX) { g_last_error = "fr_blind_rows: more than 24 rows"; return ALEO_MI355X_ERR_BAD_ARG; }
+  BlindArgs a{}; std::memcpy(a.rho, rho_mont, rows * 32);
+  const size_t want = ((n + 1) * rows + 255) / 256;
+  hipLaunchKernelGGL(k_blind_rows, dim3((uint32_t)(want < 16384 ? want : 16384)), dim3(256), 0, s, (char*)d_dst, (const char*)d_src, n, (uint32_t)rows, a);
+  HIPCHK(hipGetLastError());
+  return ALEO_MI355X_OK;
+}
+// wit: 3 rows of n + 1 coefficients per instance (w, z_a, z_b); xp: |X| coefficients of x̂ per instance; dst: 3 rows of n4 per instance
+__global__ void __launch_bounds__(256) k_sumcheck_operands(char* __restrict__ dst, const char* __restrict__ wit, const char* __restrict__ xp, size_t n, size_t n_x,
+                                                           size_t n4, uint32_t instances) {
+  const size_t L = n + 1;
+  for (size_t t = (size_t)blockIdx.x * 256 + threadIdx.x; t < n4 * 3 * instances; t += (size_t)gridDim.x * 256) {
+    const size_t row = t / n4, j = t % n4, i = row / 3, kind = row % 3;
+    const char* w = wit + (3 * i) * L * 32;
+    Fr v = Fr::zero();
+    if (kind == 0) {
+      if (j >= n_x && j < L + n_x) v = load_fp<Fr>(w + (j - n_x) * 32);                       // + w X^|X|
+      if (j < L) v = Fr::sub<1>(v, load_fp<Fr>(w + j * 32));                                  // − w             (< 2r)
+      if (j < n_x) v = Fr::add(v, load_fp<Fr>(xp + (i * n_x + j) * 32));                      // + x̂             (< 3r)
+      v = Fr::cond_sub<1>(Fr::cond_sub<2>(v));
+    } else if (j < L) v = load_fp<Fr>(w + (kind * L + j) * 32);
+    store_fp<Fr>(dst + t * 32, v);
+  }
+}
+int32_t ahp_sumcheck_operands(Ctx* c, void* d_dst, const void* d_wit, const void* d_xp, size_t n, size_t n_x, size_t instances, hipStream_t s) {
+  (void)c;
+  if (!instances || !n) return ALEO_MI355X_OK;
+  const size_t n4 = 4 * n, want = (n4 * 3 * instances + 255) / 256;
+  hipLaunchKernelGGL(k_sumcheck_operands, dim3((uint32_t)(want < 32768 ? want : 32768)), dim3(256), 0, s, (char*)d_dst, (const char*)d_wit, (const char*)d_xp, n, n_x, n4, (uint32_t)instances);
+  HIPCHK(hipGetLastError());
+  return ALEO_MI355X_OK;
+}
+
 int32_t fr_batch_inverse(Ctx* c, void* d_inout, size_t n, hipStream_t s) {
   if (n == 0) return ALEO_MI355X_OK;
   int32_t rc; if ((rc = scratch_acquire(c, c->ntt_tmp, n * 32, s))) return rc;

@@ -338,14 +338,13 @@ int32_t Prover::first_round(const void* const* assignments) {
   }
   RC(ntt_run(c, ev, lg_h, 3 * k, 0, 1, 0, s));
   blind.assign((3 * k + 1) * HC, HFr::zero());
-  for (size_t q = 0; q < 3 * k; ++q) {
-    const HFr rho = random_fr(seed, q);                                                     // rho_w, rho_a, rho_b of instance q / 3
-    char* p = wit + q * L * 32;
-    HIPCHK(hipMemcpyAsync(p, ev + q * n_h * 32, n_h * 32, hipMemcpyDeviceToDevice, s));
-    HFr nrho = HFr::neg(rho);
-    RC(fr_lin(c, p, 1, nrho.l, one.l, p, nullptr, nullptr, s));                             // + rho (X^|H| − 1)
-    RC(fr_lin(c, p + n_h * 32, 1, rho.l, nullptr, nullptr, nullptr, nullptr, s));
-    for (size_t j = 0; j < HC; ++j) blind[q * HC + j] = random_fr(seed, lay_blind + HC * q + j);
+  {
+    HFr rho[24];                                                                            // rho_w, rho_a, rho_b of instance q / 3
+    for (size_t q = 0; q < 3 * k; ++q) {
+      rho[q] = random_fr(seed, q);
+      for (size_t j = 0; j < HC; ++j) blind[q * HC + j] = random_fr(seed, lay_blind + HC * q + j);
+    }
+    RC(fr_blind_rows(c, wit, ev, n_h, 3 * k, rho, s));                                      // + rho (X^|H| − 1), all 3k polynomials in one launch
   }
   for (size_t j = 0; j < HC; ++j) blind[3 * k * HC + j] = random_fr(seed, lay_blind_mask + j);
   RC(fr_random(c, mask, 3 * n_h, seed, lay_mask, 1, s));
@@ -385,18 +384,11 @@ int32_t Prover::second_round() {
   RC(fr_lin(c, ext + 2 * n_h * 32, n_h, nullptr, eta_c.l, ext, nullptr, nullptr, s));
   RC(fr_spmv(c, rt + n_h * 32, ix.t_row_ptr, ix.t_col, ix.t_val, ext, n_h, s));
   RC(ntt_run(c, rt + n_h * 32, lg_h, 1, 0, 1, 0, s));                                       // t(X)
-  HIPCHK(hipMemsetAsync(E, 0, (2 + 3 * k) * n4 * 32, s));
+  HIPCHK(hipMemsetAsync(E, 0, 2 * n4 * 32, s));                                             // r, t: |H| coefficients each, zero padded to 4|H|
   HIPCHK(hipMemcpyAsync(E, rt, n_h * 32, hipMemcpyDeviceToDevice, s));
   HIPCHK(hipMemcpyAsync(E + n4 * 32, rt + n_h * 32, n_h * 32, hipMemcpyDeviceToDevice, s));
-  for (size_t i = 0; i < k; ++i) {
-    char* zp = E + (2 + 3 * i) * n4 * 32; const char* w_i = wit + (3 * i) * L * 32;          // ẑ_i = w_i (X^|X| − 1) + x̂_i
-    RC(fr_lin(c, zp, L, nullptr, neg1.l, w_i, nullptr, nullptr, s));
-    RC(fr_vec_op(c, zp + n_x * 32, zp + n_x * 32, w_i, L, 1, s));
-    HIPCHK(hipMemcpyAsync(xp + i * n_x * 32, x_poly[i].data(), n_x * 32, hipMemcpyHostToDevice, s));
-    RC(fr_vec_op(c, zp, zp, xp + i * n_x * 32, n_x, 1, s));
-    HIPCHK(hipMemcpyAsync(zp + n4 * 32, wit + (3 * i + 1) * L * 32, L * 32, hipMemcpyDeviceToDevice, s));
-    HIPCHK(hipMemcpyAsync(zp + 2 * n4 * 32, wit + (3 * i + 2) * L * 32, L * 32, hipMemcpyDeviceToDevice, s));
-  }
+  for (size_t i = 0; i < k; ++i) HIPCHK(hipMemcpyAsync(xp + i * n_x * 32, x_poly[i].data(), n_x * 32, hipMemcpyHostToDevice, s));
+  RC(ahp_sumcheck_operands(c, E + 2 * n4 * 32, wit, xp, n_h, n_x, k, s));                    // ẑ_i = w_i (X^|X| − 1) + x̂_i, z_a,i, z_b,i — every row written in full
   RC(ntt_run(c, E, lg_h + 2, 2 + 3 * k, 0, 0, 0, s));
   for (size_t i = 0; i < k; ++i) {
     char* e_z = E + (2 + 3 * i) * n4 * 32;
