@@ -107,7 +107,8 @@ template <int C, int W_IDX, class F> __device__ __forceinline__ void for_each_di
 // bin, and the scatter pass ranks items with LDS atomics.  Level 2 gives one block per coarse bin: an LDS
 // histogram over the low 8 bucket bits yields the final per-bucket counts and positions.
 static constexpr uint32_t PART_TILE = 2048;       // scalars per block in the level-1 passes
-static constexpr uint32_t MAX_COARSE = 2048;      // W * (B >> LB) at c = 16
+static constexpr uint32_t MAX_COARSE = 2048;      // coarse bins of ONE set: W * (B >> LB) at c = 16 (the LDS tables of the level-1 passes)
+static constexpr uint32_t MAX_COARSE_ALL = 4096;  // coarse bins of all sets of a chain (k_bin_parts: one block, 16 bins per lane): 32 sets at c = 16, 16 at c = 17
 
 // PRE = the base set carries precomputed window multiples 2^(c*w) * P_i (fixed-base MSM, see msm_precompute):
 // every window then feeds ONE shared set of buckets, and the point of digit w of scalar i is table entry w*n + i.
@@ -219,10 +220,11 @@ __global__ void __launch_bounds__(256) k_bin_parts(const uint32_t* __restrict__ 
                                                    uint32_t cnt_tiles, uint32_t* __restrict__ part_start) {
   __shared__ uint32_t wsum[4];
   const uint32_t tid = threadIdx.x; const int lane = tid & 63, wv = tid >> 6;
-  uint32_t pre[8], run = 0;
+  constexpr int PER = MAX_COARSE_ALL / 256;
+  uint32_t pre[PER], run = 0;
 #pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    const uint32_t bin = tid * 8 + k; pre[k] = run;
+  for (int k = 0; k < PER; ++k) {
+    const uint32_t bin = tid * PER + k; pre[k] = run;
     if (bin < ncb) {
       const uint32_t st = scan32_at(off_local, off_blk, (size_t)bin * nblk);
       const uint32_t en = (bin + 1 < ncb) ? scan32_at(off_local, off_blk, (size_t)(bin + 1) * nblk) : off_blk[cnt_tiles];
@@ -237,7 +239,7 @@ __global__ void __launch_bounds__(256) k_bin_parts(const uint32_t* __restrict__ 
   uint32_t woff = 0; for (int k = 0; k < wv; ++k) woff += wsum[k];
   const uint32_t excl = woff + inc - run;
 #pragma unroll
-  for (int k = 0; k < 8; ++k) if (tid * 8 + k < ncb) part_start[tid * 8 + k] = excl + pre[k];
+  for (int k = 0; k < PER; ++k) if (tid * PER + k < ncb) part_start[tid * PER + k] = excl + pre[k];
   if (tid == 255) part_start[ncb] = woff + inc;
 }
 
@@ -800,7 +802,7 @@ static size_t slice_bound(size_t pairs_max, size_t M) {
 // reduction — which is what the commitments of one prover round need (2^14..2^17 points each: alone they are latency-bound).
 uint32_t msm_max_sets(const PinnedBases& pb, size_t n) {
   for (const auto& t : pb.tab) if (t.d && n >= t.min_n && n <= t.cover) {
-    const uint32_t B = 1u << (t.c - 1), LB = 8, cb = B >> LB, cap = MAX_COARSE / (cb ? cb : 1);
+    const uint32_t B = 1u << (t.c - 1), LB = 8, cb = B >> LB, cap = MAX_COARSE_ALL / (cb ? cb : 1);
     return cap < MAX_SETS ? (cap ? cap : 1) : MAX_SETS;
   }
   return 1;
@@ -832,9 +834,9 @@ int32_t msm_sort_phase(Ctx* c, SegArgs& segs, size_t pts, bool mont, const uint8
   if ((rc = c->sorted.reserve(pairs_max * 4))) return rc;
   const uint32_t LB = (P.c - 1) < 8 ? (P.c - 1) : 8, ncb = P.W * (P.B >> LB);      // coarse bins of all sets / windows
   const size_t cnt_len = (size_t)ncb * nblk;
-  if (ncb > MAX_COARSE || cnt_len >= (1ull << 32)) { g_last_error = "msm: partition table too large"; return ALEO_MI355X_ERR_BAD_ARG; }
+  if (ncb > MAX_COARSE_ALL || cnt_len >= (1ull << 32)) { g_last_error = "msm: partition table too large"; return ALEO_MI355X_ERR_BAD_ARG; }
   const uint32_t cnt_tiles = (uint32_t)((cnt_len + SCAN_TILE - 1) / SCAN_TILE);
-  if ((rc = c->part_cnt.reserve((2 * cnt_len + 2 * (size_t)cnt_tiles + 16 + MAX_COARSE) * 4))) return rc;     // cnt | off_local | tile_tot | off_blk | part_start
+  if ((rc = c->part_cnt.reserve((2 * cnt_len + 2 * (size_t)cnt_tiles + 16 + MAX_COARSE_ALL) * 4))) return rc;     // cnt | off_local | tile_tot | off_blk | part_start
   if ((rc = c->part_items.reserve(pairs_max * 8))) return rc;
   if ((rc = c->task_g.reserve(2 * slices_max * 4))) return rc;     // task_g | order
   if ((rc = ensure_host_pinned(c, 64))) return rc;
