@@ -729,6 +729,22 @@ int32_t aleo_mi355x_ahp_matrix_sumcheck_device(void* d_dst, size_t n, const void
   } catch (...) { return ALEO_MI355X_ERR_HIP; }
 }
 
+int32_t aleo_mi355x_fr_blind_rows_device(void* d_dst, const void* d_src, size_t n, size_t rows, const void* rho_mont, void* stream) {
+  try {
+    if (rows && n && (!d_dst || !d_src || !rho_mont)) return ALEO_MI355X_ERR_BAD_ARG;
+    API_BEGIN
+    return run_enqueue(c, stream, [&](hipStream_t s) { return fr_blind_rows(c, d_dst, d_src, n, rows, rho_mont, s); });
+  } catch (...) { return ALEO_MI355X_ERR_HIP; }
+}
+
+int32_t aleo_mi355x_ahp_sumcheck_operands_device(void* d_dst, const void* d_witness_polys, const void* d_x_polys, size_t n, size_t n_x, size_t instances, void* stream) {
+  try {
+    if (instances && n && (!d_dst || !d_witness_polys || (!d_x_polys && n_x))) return ALEO_MI355X_ERR_BAD_ARG;
+    API_BEGIN
+    return run_enqueue(c, stream, [&](hipStream_t s) { return ahp_sumcheck_operands(c, d_dst, d_witness_polys, d_x_polys, n, n_x, instances, s); });
+  } catch (...) { return ALEO_MI355X_ERR_HIP; }
+}
+
 int32_t aleo_mi355x_fr_batch_inverse_device(void* d_inout, size_t n, void* stream) {
   try {
     if (!d_inout && n) return ALEO_MI355X_ERR_BAD_ARG;

@@ -97,6 +97,18 @@ def ahp_matrix_sumcheck_device(d_dst: int, n: int, d_index, index_stride: int, d
     check(lib().aleo_mi355x_ahp_matrix_sumcheck_device(vp(d_dst), n, ix, index_stride, ff, k.ctypes.data_as(vp), vp(stream)), 'ahp_matrix_sumcheck_device')
 
 
+def fr_blind_rows_device(d_dst: int, d_src: int, n: int, rho_mont, stream: int = 0):
+    """dst row q (n + 1 coefficients) = src row q (n coefficients) + rho_q (X^n − 1); rho_mont: uint64[rows,4] Montgomery on the host."""
+    import numpy as np
+    r = np.ascontiguousarray(rho_mont, dtype=np.uint64).reshape(-1, 4); vp = ctypes.c_void_p
+    check(lib().aleo_mi355x_fr_blind_rows_device(vp(d_dst), vp(d_src), n, r.shape[0], r.ctypes.data_as(vp), vp(stream)), 'fr_blind_rows_device')
+
+
+def ahp_sumcheck_operands_device(d_dst: int, d_witness_polys: int, d_x_polys: int, n: int, n_x: int, instances: int, stream: int = 0):
+    vp = ctypes.c_void_p
+    check(lib().aleo_mi355x_ahp_sumcheck_operands_device(vp(d_dst), vp(d_witness_polys), vp(d_x_polys), n, n_x, instances, vp(stream)), 'ahp_sumcheck_operands_device')
+
+
 def batch_inversion_device(d_inout: int, n: int, stream: int = 0):
     check(lib().aleo_mi355x_fr_batch_inverse_device(ctypes.c_void_p(d_inout), n, ctypes.c_void_p(stream)), 'fr_batch_inverse_device')
 

@@ -19,7 +19,7 @@ from .fft import EvaluationDomain, FORWARD, INVERSE
 from .kzg import CommitterKey, SonicKZG10, KZG10
 from .msm import PinnedBases
 from .poly import (fr_vec_op_device, fr_lin_device, fr_powers_device, fr_gather_mul_device, fr_eval_batch_device, fr_random_device, fr_lincomb_device,
-                   ahp_first_sumcheck_device, ahp_matrix_sumcheck_device, batch_inversion_device, random_fr, spmv_device, divide_by_linear_device, OP_MUL, OP_ADD, OP_SUB)
+                   ahp_first_sumcheck_device, ahp_matrix_sumcheck_device, ahp_sumcheck_operands_device, fr_blind_rows_device, batch_inversion_device, random_fr, spmv_device, divide_by_linear_device, OP_MUL, OP_ADD, OP_SUB)
 
 R = synth.FR_MODULUS
 _RM = (1 << 256) % R
@@ -349,14 +349,12 @@ class Prover:
             fr_vec_op_device(ev.ptr(base), ev.ptr(base), ix.vx_inv.ptr(), n_h, OP_MUL, s)
         ix.H.ntt_batch_device(ev.ptr(), 3 * k, direction=INVERSE, stream=s)
         self.wit = _Vec(3 * k * L)                                                  # w_i, z_a,i, z_b,i as polynomials of |H| + 1 coefficients
-        self.blind = []; blinds = []
+        self.blind = []; blinds = []; rhos = []
         for q in range(3 * k):
             i, j = divmod(q, 3)
-            rho = self._ri(self.lay['rho'][i] + j)[0]
-            self.wit.t[q * L:q * L + n_h].copy_(ev.t[q * n_h:(q + 1) * n_h])
-            fr_lin_device(self.wit.ptr(q * L), 1, _mont(-rho), one, self.wit.ptr(q * L), stream=s)       # + rho (X^|H| − 1)
-            fr_lin_device(self.wit.ptr(q * L + n_h), 1, _mont(rho), stream=s)
+            rhos.append(self._ri(self.lay['rho'][i] + j)[0])
             bq = self._ri(self.lay['blind'][i] + HIDING_COEFFS * j, HIDING_COEFFS); self.blind.append(bq); blinds += bq
+        fr_blind_rows_device(self.wit.ptr(), ev.ptr(), n_h, _mont_rows(rhos), s)            # + rho_q (X^|H| − 1), all 3k polynomials in one launch
         self.w = lambda i: self.wit.ptr((3 * i) * L); self.za = lambda i: self.wit.ptr((3 * i + 1) * L); self.zb = lambda i: self.wit.ptr((3 * i + 2) * L)
         self.mask = _Vec(3 * n_h)                                                   # drawn in HBM; its sum over H is made zero through m_0
         fr_random_device(self.mask.ptr(), 3 * n_h, self.seed, self.lay['mask'], True, s)
@@ -388,15 +386,11 @@ class Prover:
         spmv_device(rt.ptr(n_h), tp.data_ptr(), tcol.data_ptr(), tval.ptr(), ext.ptr(), n_h, s)
         ix.H.ntt_device(rt.ptr(n_h), direction=INVERSE, stream=s)                     # t(X)
         L = n_h + 1; n4 = 4 * n_h
-        E = _Vec((2 + 3 * k) * n4, zero=True)                                       # r, t, then z_i, z_a,i, z_b,i on the domain of size 4|H|
+        E = _Vec((2 + 3 * k) * n4)                                                  # r, t, then z_i, z_a,i, z_b,i on the domain of size 4|H|
+        E.t[:2 * n4].zero_()
         E.t[0:n_h].copy_(rt.t[:n_h]); E.t[n4:n4 + n_h].copy_(rt.t[n_h:])
-        for i in range(k):
-            zp = (2 + 3 * i) * n4                                                   # ẑ_i = w_i (X^|X| − 1) + x̂_i
-            fr_lin_device(E.ptr(zp), L, None, neg1, self.w(i), stream=s)
-            fr_vec_op_device(E.ptr(zp + n_x), E.ptr(zp + n_x), self.w(i), L, OP_ADD, s)
-            xp = _Vec(n_x, _mont_rows(self.x_poly[i]))
-            fr_vec_op_device(E.ptr(zp), E.ptr(zp), xp.ptr(), n_x, OP_ADD, s)
-            E.t[zp + n4:zp + n4 + L].copy_(self.wit.t[(3 * i + 1) * L:(3 * i + 2) * L]); E.t[zp + 2 * n4:zp + 2 * n4 + L].copy_(self.wit.t[(3 * i + 2) * L:(3 * i + 3) * L])
+        xp = _Vec(k * n_x, _mont_rows([v for i in range(k) for v in self.x_poly[i]]))
+        ahp_sumcheck_operands_device(E.ptr(2 * n4), self.wit.ptr(), xp.ptr(), n_h, n_x, k, s)   # ẑ_i = w_i (X^|X| − 1) + x̂_i, z_a,i, z_b,i: every row written in full
         ix.H4.ntt_batch_device(E.ptr(), 2 + 3 * k, stream=s)
         e_r, e_t = E.ptr(0), E.ptr(n4)
         for i in range(k):                                                          # numerator of instance i, in place over its z_a row

@@ -212,6 +212,12 @@ int32_t aleo_mi355x_fr_lincomb_device(void* d_dst, size_t n, const void* c0_mont
  *           row_M, with col_M, val_M, row_col_M following at index_stride elements each; consts_mont = delta_a, delta_b, delta_c,
  *           alpha beta, -alpha, -beta, v_H(alpha) v_H(beta): 7 x 32 bytes on the host; a NULL d_index[M] leaves matrix M out — matrices whose
  *           non-zero domains differ in size are done one call each).  dst may alias an operand. */
+/* Two layout steps of the first two rounds, one launch for all instances [UPSTREAM-RECALL: round_functions/{first,second}.rs]:
+ *   blind_rows:         dst row q (n + 1 coefficients) = src row q (n coefficients) + rho_q (X^n - 1); rows <= 24, rho_mont: rows x 32 bytes on the host
+ *   sumcheck_operands:  per instance i the rows  z_i = w_i (X^n_x - 1) + x_i,  z_a,i,  z_b,i  on 4n coefficients, zero padded (dst: 3 rows of 4n per
+ *                       instance; d_witness_polys: 3 rows of n + 1 per instance in the order w, z_a, z_b; d_x_polys: n_x coefficients per instance) */
+int32_t aleo_mi355x_fr_blind_rows_device(void* d_dst, const void* d_src, size_t n, size_t rows, const void* rho_mont, void* stream);
+int32_t aleo_mi355x_ahp_sumcheck_operands_device(void* d_dst, const void* d_witness_polys, const void* d_x_polys, size_t n, size_t n_x, size_t instances, void* stream);
 int32_t aleo_mi355x_ahp_first_sumcheck_device(void* d_dst, size_t n, const void* d_r, const void* d_za, const void* d_zb, const void* d_t, const void* d_z,
                                               const void* eta_b_mont, const void* eta_c_mont, void* stream);
 int32_t aleo_mi355x_ahp_matrix_sumcheck_device(void* d_dst, size_t n, const void* const* d_index, size_t index_stride, const void* const* d_f, const void* consts_mont, void* stream);

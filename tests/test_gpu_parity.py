@@ -1106,3 +1106,30 @@ def test_commit_lagrange_equals_commit_of_the_interpolant():
         assert (a == b).all()
         k = sum(e * l for e, l in zip(c.limbs_to_ints(evals), lag)) % r
         assert c.affine_to_ints(a.reshape(1, 104))[0] == p.g1_mul(p.G1_GENERATOR, k)
+
+
+def test_prover_layout_kernels_match_bigint():
+    """fr_blind_rows (+ rho (X^n − 1) per row) and ahp_sumcheck_operands (z = w (X^|X| − 1) + x̂ and the zero-padded z_a, z_b on 4n
+    coefficients, all instances in one launch) against Python integers."""
+    import torch
+    from aleo_amd import poly
+    r = p.FR_MODULUS; n, n_x, k = 1024, 4, 3
+    src = util.uniform_scalars(3 * k * n, 32001); rho = util.uniform_scalars(3 * k, 32002)
+    d_src = _dev(c.fr_to_mont(src)); dst = torch.zeros((3 * k * (n + 1), 4), dtype=torch.int64, device='cuda'); torch.cuda.synchronize()
+    poly.fr_blind_rows_device(dst.data_ptr(), d_src.data_ptr(), n, c.fr_to_mont(rho)); torch.cuda.synchronize()
+    got = c.limbs_to_ints(c.fr_from_mont(dst.cpu().numpy().view(np.uint64))); s_, rh = c.limbs_to_ints(src), c.limbs_to_ints(rho)
+    want = []
+    for q in range(3 * k):
+        row = s_[q * n:(q + 1) * n] + [rh[q]]; row[0] = (row[0] - rh[q]) % r; want += row
+    assert got == want
+    xp = util.uniform_scalars(k * n_x, 32003); d_xp = _dev(c.fr_to_mont(xp)); xs = c.limbs_to_ints(xp)
+    out = torch.zeros((3 * k * 4 * n, 4), dtype=torch.int64, device='cuda'); torch.cuda.synchronize()
+    poly.ahp_sumcheck_operands_device(out.data_ptr(), dst.data_ptr(), d_xp.data_ptr(), n, n_x, k); torch.cuda.synchronize()
+    got2 = c.limbs_to_ints(c.fr_from_mont(out.cpu().numpy().view(np.uint64))); L = n + 1
+    for i in range(k):
+        w, za, zb = (want[(3 * i + j) * L:(3 * i + j + 1) * L] for j in range(3))
+        z = [0] * (4 * n)
+        for j, v in enumerate(w): z[j] = (z[j] - v) % r; z[j + n_x] = (z[j + n_x] + v) % r
+        for j in range(n_x): z[j] = (z[j] + xs[i * n_x + j]) % r
+        assert got2[(3 * i) * 4 * n:(3 * i + 1) * 4 * n] == z
+        assert got2[(3 * i + 1) * 4 * n:(3 * i + 2) * 4 * n] == za + [0] * (4 * n - L) and got2[(3 * i + 2) * 4 * n:(3 * i + 3) * 4 * n] == zb + [0] * (4 * n - L)
