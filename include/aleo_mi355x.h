@@ -94,8 +94,8 @@ int32_t aleo_mi355x_bases_from_scalars(const void* base_affine104, const void* s
 /* Optional fixed-base acceleration for a pinned set (an SRS never changes): builds tables of window multiples
  * 2^(c w) * P_i in HBM, stored in the 28-bit-limb form the accumulation kernel computes in (112 bytes per entry), in up to
  * three tiers so that a prefix of ANY length >= 2^10 gets a window width that suits it (KZG10::commit multiplies polynomials
- * of every degree against one SRS): the whole set at c = 20 (>= 2^19 points; 13 rows) or c = 17, its first 2^17 points at
- * c = 16, its first 2^15 points at c = 13.  MSMs over this handle then add one table entry per window into ONE shared bucket
+ * of every degree against one SRS): the whole set at c = 20 (>= 2^19 points; 13 rows) or c = 17, its first 2^17 + 64 points at
+ * c = 16, its first 2^15 + 64 points at c = 13 (the 64: a committer key is a power of two of powers followed by a few hiding powers).  MSMs over this handle then add one table entry per window into ONE shared bucket
  * set (13 instead of 16 additions per point at 2^20) and skip the Horner tail.  Same results, bit for bit after
  * normalisation.  About 0.15 s and 1.8 GB for a 2^20-point set. */
 int32_t aleo_mi355x_bases_precompute(uint64_t handle);
