@@ -1133,3 +1133,22 @@ def test_prover_layout_kernels_match_bigint():
         for j in range(n_x): z[j] = (z[j] + xs[i * n_x + j]) % r
         assert got2[(3 * i) * 4 * n:(3 * i + 1) * 4 * n] == z
         assert got2[(3 * i + 1) * 4 * n:(3 * i + 2) * 4 * n] == za + [0] * (4 * n - L) and got2[(3 * i + 2) * 4 * n:(3 * i + 3) * 4 * n] == zb + [0] * (4 * n - L)
+
+
+def test_batched_msm_two_sets_on_the_widest_window():
+    """Two result sets in ONE launch chain at c = 20 (2 x 2^19 buckets: the capacity the 4096 coarse bins allow) and a third that needs its own chain:
+    the commitments of a 2^20-constraint proof's third round.  Against the structured identity and the single-vector calls; witness-like and
+    uniform members, unequal lengths."""
+    import torch
+    N = 1 << 20
+    with M.PinnedBases.generate_multiples(synth.generator_affine104(), 1, N) as pb:
+        pb.precompute()
+        lens = [N, (1 << 19) + 12345, N - 7]
+        S = [util.uniform_scalars(lens[0], 33001), util.witness_like_scalars(lens[1], 33002), util.uniform_scalars(lens[2], 33003)]
+        d = [torch.from_numpy(x.view(np.int64).copy()).cuda() for x in S]; torch.cuda.synchronize()
+        got = M.VariableBase.msm_batch_device(pb, [t.data_ptr() for t in d], lens)
+        for i, m in enumerate(lens):
+            assert c.jac_to_int_point(got[i]) == util.expected_multiples_msm(S[i], m), (i, m)
+            assert (M.VariableBase.msm_device(pb, d[i].data_ptr(), m) == got[i]).all(), (i, m)
+        got2 = M.VariableBase.msm_batch_device(pb, [d[0].data_ptr(), d[2].data_ptr()], [lens[0], lens[2]])      # exactly one two-set chain
+        assert (got2[0] == got[0]).all() and (got2[1] == got[2]).all()
