@@ -691,7 +691,7 @@ int32_t aleo_mi355x_varuna_prove_indexed(uint64_t index_handle, const void* cons
 }
 
 int32_t aleo_mi355x_varuna_last_timing(double* out_ms, int32_t cap) {
-  int32_t n = cap < 6 ? cap : 6;
+  int32_t n = cap < 8 ? cap : 8;
   for (int32_t i = 0; i < n; ++i) out_ms[i] = g_varuna_timing[i];
   return n;
 }

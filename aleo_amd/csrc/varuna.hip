@@ -98,6 +98,16 @@ inline HFr domain_gen(uint64_t size) {                    // TWO_ADIC_ROOT^(2^(4
   for (int i = lg; i < host::FR_TWO_ADICITY; ++i) g = HFr::sqr(g);
   return g;
 }
+inline HFr inv_pow2(uint32_t lg) {                          // 1 / 2^lg: lg products by 1/2 instead of a Fermat chain
+  static const HFr half = HFr::inv(fr_u64(2));
+  HFr r = HFr::one(); for (uint32_t i = 0; i < lg; ++i) r = HFr::mul(r, half); return r;
+}
+inline void batch_inverse(HFr* v, size_t n) {               // Montgomery's trick on the host: one inversion for n non-zero values (n <= 8)
+  HFr pre[8], acc = HFr::one();
+  for (size_t i = 0; i < n; ++i) { pre[i] = acc; acc = HFr::mul(acc, v[i]); }
+  acc = HFr::inv(acc);
+  for (size_t i = n; i-- > 0;) { const HFr t = HFr::mul(acc, pre[i]); acc = HFr::mul(acc, v[i]); v[i] = t; }
+}
 inline HFr horner(const std::vector<HFr>& p, const HFr& x) { HFr a = HFr::zero(); for (size_t i = p.size(); i-- > 0;) a = HFr::add(HFr::mul(a, x), p[i]); return a; }
 
 struct Arena {                                             // bump allocation inside the slot's prover workspace
@@ -116,8 +126,10 @@ thread_local double g_varuna_timing[8] = {};
 static int32_t commit(Ctx* c, const PinnedBases& pb, const std::vector<MsmSeg>& segs, uint32_t k, uint8_t* out104, hipStream_t s) {
   std::vector<uint64_t> jac(18 * (size_t)k);
   MsmJob j; j.segs = segs.data(); j.nseg = (uint32_t)segs.size(); j.k = k; j.mont = true;
+  const double t0 = now_ms();
   RC(msm_batch(c, jac.data(), pb, j, s));
   jacobian_rows_to_affine104(out104, jac.data(), k);
+  g_varuna_timing[6] += now_ms() - t0; g_varuna_timing[7] += c->last_msm.host;      // time inside the commitment calls / their host tails (last chain of each call)
   return ALEO_MI355X_OK;
 }
 
@@ -210,7 +222,8 @@ int32_t varuna_index_build(Ctx* c, const PinnedBases& pb, std::shared_ptr<Pinned
   void *kev, *kid, *kpo, *k2, *kv;
   RC(o->alloc(&kev, 4 * k_sum * 32)); RC(o->alloc(&kpo, 4 * k_sum * 32)); RC(o->alloc(&k2, 8 * k_sum * 32));
   RC(up(&kid, kidx.data(), 2 * k_sum * 4)); RC(up(&kv, kval.data(), k_sum * 32)); RC(to_mont(kv, k_sum));
-  const HFr nh_inv = HFr::inv(fr_u64(n_h));
+  uint32_t lg_nh = 0; while ((1ull << lg_nh) < n_h) ++lg_nh;
+  const HFr nh_inv = inv_pow2(lg_nh);
   HIPCHK(hipMemsetAsync(k2, 0, 8 * k_sum * 32, s));
   for (int m = 0; m < 3; ++m) {
     const uint64_t n = nk[m]; uint32_t lg = 0; while ((1ull << lg) < n) ++lg;
@@ -252,10 +265,10 @@ struct Prover {
   Prover(Ctx* c_, const PinnedBases& pb_, const aleo_mi355x_varuna_index& ix_, size_t k_, uint64_t seed_) : c(c_), pb(pb_), ix(ix_), k(k_), seed(seed_) {}
   // sizes, stream, workspace
   size_t n_h = 0, n_x = 0, L = 0, n4 = 0, nk[3] = {}, ko[3] = {}, k_sum = 0, n_k = 0; uint64_t D = 0; uint32_t lg_h = 0, lg_km[3] = {};
-  hipStream_t s = nullptr; double t_mark[7] = {}; Arena ar{nullptr, 0, 0}; char* pin = nullptr; char* pin_small = nullptr;
+  hipStream_t s = nullptr; double t_mark[7] = {}; Arena ar{nullptr, 0, 0}; char* pin = nullptr; char* stage = nullptr; char* pin_small = nullptr;
   HFr one, neg1, r2; Transcript tr; uint64_t lay_mask = 0, lay_blind = 0, lay_blind_mask = 0;
   // what the rounds hand on: polynomials in HBM, commitments, challenges
-  char *wit = nullptr, *mask = nullptr, *ext = nullptr, *h1 = nullptr, *g1 = nullptr, *f = nullptr, *h2 = nullptr;
+  char *xp = nullptr, *wit = nullptr, *mask = nullptr, *ext = nullptr, *h1 = nullptr, *g1 = nullptr, *f = nullptr, *h2 = nullptr;
   std::vector<std::vector<HFr>> x_poly; std::vector<HFr> blind, comb, evals; std::vector<uint8_t> wit_aff, comp;
   uint8_t aff2[208], aff3[312], aff4[104], aff5[208];
   HFr alpha, eta_b, eta_c, vh_alpha, beta, vh_beta, vv, sigma[3], delta[3], gamma, random_v;
@@ -289,12 +302,13 @@ int32_t Prover::setup(const void* const* assignments) {
   const size_t elems = n_h * (40 + 20 * k) + k_sum * 6 + n_k * 4 + 4096;
   RC(c->prover_ws.reserve(elems * 32 + (64 << 10)));
   ar = Arena{(char*)c->prover_ws.p, 0, c->prover_ws.cap};
-  const size_t pin_need = k * n_h * 32 + 4096;
+  const size_t stage_elems = k * n_x + (3 * k + 1) * HC + HC;      // x̂ coefficients, hiding polynomials, the opening's hiding quotient: staged through pinned memory
+  const size_t pin_need = (k * n_h + stage_elems) * 32 + 4096;
   if (c->prover_pin_cap < pin_need) {
     if (c->prover_pin) { HIPCHK(hipStreamSynchronize(s)); (void)hipHostFree(c->prover_pin); c->prover_pin = nullptr; c->prover_pin_cap = 0; }
     HIPCHK(hipHostMalloc(&c->prover_pin, pin_need + pin_need / 8, hipHostMallocDefault)); c->prover_pin_cap = pin_need + pin_need / 8;
   }
-  pin = (char*)c->prover_pin; pin_small = pin + k * n_h * 32;      // 4 KB for small read-backs
+  pin = (char*)c->prover_pin; stage = pin + k * n_h * 32; pin_small = stage + stage_elems * 32;      // 4 KB for small read-backs
   one = HFr::one(); neg1 = HFr::neg(one); std::memcpy(r2.l, host::HParams<4>::R2, 32);
   // randomness layout (oracle/varuna_ref.py randomness_layout)
   lay_mask = 3 * k; lay_blind = 3 * k + 3 * n_h; lay_blind_mask = lay_blind + 3 * HC * k;
@@ -303,9 +317,10 @@ int32_t Prover::setup(const void* const* assignments) {
 
 int32_t Prover::first_round(const void* const* assignments) {
   // ---- round 1 ------------------------------------------------------------------------------------------------------------------------
-  TAKE(zH, k * n_h) TAKE(ev, 3 * k * n_h) TAKE(xh, k * n_h) TAKE_M(wit, 3 * k * L) TAKE_M(mask, 3 * n_h) TAKE(bl, (3 * k + 1) * HC)
+  TAKE(zH, k * n_h) TAKE(ev, 3 * k * n_h) TAKE(xh, k * n_h) TAKE_M(xp, k * n_x) TAKE_M(wit, 3 * k * L) TAKE_M(mask, 3 * n_h) TAKE(bl, (3 * k + 1) * HC)
   x_poly.assign(k, {}); std::vector<uint8_t> x_bytes(k * n_x * 32, 0);
-  const HFr gx_inv = HFr::inv(domain_gen(n_x)), nx_inv = HFr::inv(fr_u64(n_x));
+  uint32_t lg_x = 0; while ((1ull << lg_x) < n_x) ++lg_x;
+  const HFr gx_inv = HFr::inv(domain_gen(n_x)), nx_inv = inv_pow2(lg_x);
   std::memset(pin, 0, k * n_h * 32);
   const uint32_t* pos = (const uint32_t*)ix.positions;
   for (size_t i = 0; i < k; ++i) {
@@ -324,14 +339,16 @@ int32_t Prover::first_round(const void* const* assignments) {
       x_poly[i][a] = HFr::mul(acc, nx_inv); wa = HFr::mul(wa, gx_inv);
     }
   }
+  for (size_t i = 0; i < k; ++i) std::memcpy(stage + i * n_x * 32, x_poly[i].data(), n_x * 32);
   HIPCHK(hipMemcpyAsync(zH, pin, k * n_h * 32, hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemcpyAsync(xp, stage, k * n_x * 32, hipMemcpyHostToDevice, s));
   RC(fr_lin(c, zH, k * n_h, nullptr, r2.l, zH, nullptr, nullptr, s));                     // canonical -> Montgomery
   HIPCHK(hipMemsetAsync(xh, 0, k * n_h * 32, s));
   for (size_t i = 0; i < k; ++i) {
     char* e0 = ev + 3 * i * n_h * 32; char* z_i = zH + i * n_h * 32; char* xh_i = xh + i * n_h * 32;
     RC(fr_spmv(c, e0 + n_h * 32, ix.a_row_ptr, ix.a_col, ix.a_val, z_i, n_h, s));
     RC(fr_spmv(c, e0 + 2 * n_h * 32, ix.b_row_ptr, ix.b_col, ix.b_val, z_i, n_h, s));
-    HIPCHK(hipMemcpyAsync(xh_i, x_poly[i].data(), n_x * 32, hipMemcpyHostToDevice, s));     // pageable, tiny: copied before the call returns
+    HIPCHK(hipMemcpyAsync(xh_i, xp + i * n_x * 32, n_x * 32, hipMemcpyDeviceToDevice, s));
     RC(ntt_run(c, xh_i, lg_h, 1, 0, 0, 0, s));
     RC(fr_vec_op(c, e0, z_i, xh_i, n_h, 2, s));                                             // z − x̂ on H
     RC(fr_vec_op(c, e0, e0, ix.vx_inv, n_h, 0, s));                                         // / v_X off X, 0 on X
@@ -349,7 +366,8 @@ int32_t Prover::first_round(const void* const* assignments) {
   for (size_t j = 0; j < HC; ++j) blind[3 * k * HC + j] = random_fr(seed, lay_blind_mask + j);
   RC(fr_random(c, mask, 3 * n_h, seed, lay_mask, 1, s));
   RC(fr_lin(c, mask, 1, nullptr, neg1.l, mask + n_h * 32, neg1.l, mask + 2 * n_h * 32, s));   // sum over H = |H| (m_0 + m_|H| + m_2|H|) = 0
-  HIPCHK(hipMemcpyAsync(bl, blind.data(), blind.size() * 32, hipMemcpyHostToDevice, s));
+  std::memcpy(stage + k * n_x * 32, blind.data(), blind.size() * 32);
+  HIPCHK(hipMemcpyAsync(bl, stage + k * n_x * 32, blind.size() * 32, hipMemcpyHostToDevice, s));
   wit_aff.assign(104 * (3 * k + 1), 0); comp.assign(48 * 8, 0);
   {
     std::vector<MsmSeg> sg;
@@ -373,7 +391,7 @@ int32_t Prover::second_round() {
   // ---- round 2: the first sumcheck --------------------------------------------------------------------------------------------------------
   vh_alpha = vanish(n_h, alpha);
   if (vh_alpha.is_zero()) { g_last_error = "varuna_prove: alpha landed in H"; return ALEO_MI355X_ERR_HIP; }
-  TAKE_M(ext, 3 * n_h) TAKE(rt, 2 * n_h) TAKE(E, (2 + 3 * k) * n4) TAKE(xp, k * n_x) TAKE(Q, n4) TAKE_M(h1, 2 * n_h) TAKE_M(g1, n_h)
+  TAKE_M(ext, 3 * n_h) TAKE(rt, 2 * n_h) TAKE(E, (2 + 3 * k) * n4) TAKE(Q, n4) TAKE_M(h1, 2 * n_h) TAKE_M(g1, n_h)
   {
     const HFr first = HFr::pow_u64(alpha, n_h - 1), ratio = HFr::inv(alpha);
     RC(fr_powers(c, rt, n_h, first.l, ratio.l, s));                                          // r(alpha, X) = sum_k alpha^(|H|-1-k) X^k
@@ -387,7 +405,6 @@ int32_t Prover::second_round() {
   HIPCHK(hipMemsetAsync(E, 0, 2 * n4 * 32, s));                                             // r, t: |H| coefficients each, zero padded to 4|H|
   HIPCHK(hipMemcpyAsync(E, rt, n_h * 32, hipMemcpyDeviceToDevice, s));
   HIPCHK(hipMemcpyAsync(E + n4 * 32, rt + n_h * 32, n_h * 32, hipMemcpyDeviceToDevice, s));
-  for (size_t i = 0; i < k; ++i) HIPCHK(hipMemcpyAsync(xp + i * n_x * 32, x_poly[i].data(), n_x * 32, hipMemcpyHostToDevice, s));
   RC(ahp_sumcheck_operands(c, E + 2 * n4 * 32, wit, xp, n_h, n_x, k, s));                    // ẑ_i = w_i (X^|X| − 1) + x̂_i, z_a,i, z_b,i — every row written in full
   RC(ntt_run(c, E, lg_h + 2, 2 + 3 * k, 0, 0, 0, s));
   for (size_t i = 0; i < k; ++i) {
@@ -502,7 +519,11 @@ int32_t Prover::open() {
   const HFr xi = tr.challenge("xi", 2);
   const HFr g1_beta = evals[k], ga = evals[k + 1], gb = evals[k + 2], gc = evals[k + 3];
   // ---- the linear combination of the first sumcheck, opened at beta together with g_1 and the z_b,i -----------------------------------------------
-  const HFr r_ab = HFr::mul(HFr::sub(vh_alpha, vh_beta), HFr::inv(HFr::sub(alpha, beta)));
+  HFr inv4[4] = {HFr::sub(alpha, beta), vanish(nk[0], gamma), vanish(nk[1], gamma), vanish(nk[2], gamma)};      // one inversion for the four the openings need
+  for (int m = 1; m < 4; ++m) if (inv4[m].is_zero()) { g_last_error = "varuna_prove: gamma landed in K"; return ALEO_MI355X_ERR_HIP; }
+  if (inv4[0].is_zero()) { g_last_error = "varuna_prove: alpha equals beta"; return ALEO_MI355X_ERR_HIP; }
+  batch_inverse(inv4, 4);
+  const HFr r_ab = HFr::mul(HFr::sub(vh_alpha, vh_beta), inv4[0]);
   const HFr t_beta = HFr::add(sigma[0], HFr::add(HFr::mul(eta_b, sigma[1]), HFr::mul(eta_c, sigma[2])));
   const HFr xl = HFr::pow_u64(xi, k + 1), vx_beta = vanish(n_x, beta);
   HFr cst = HFr::neg(HFr::mul(beta, g1_beta));
@@ -531,7 +552,8 @@ int32_t Prover::open() {
     RC(fr_lincomb(c, pbeta, 3 * n_h, c0.l, terms, lens, co, nt, s));
     random_v = HFr::add(blc[0], HFr::mul(beta, HFr::add(blc[1], HFr::mul(beta, blc[2]))));
     blw[1] = blc[2]; blw[0] = HFr::add(blc[1], HFr::mul(beta, blc[2])); blw[2] = HFr::zero();
-    HIPCHK(hipMemcpyAsync(blq, blw, HC * 32, hipMemcpyHostToDevice, s));
+    char* st = stage + (k * n_x + (3 * k + 1) * HC) * 32; std::memcpy(st, blw, HC * 32);
+    HIPCHK(hipMemcpyAsync(blq, st, HC * 32, hipMemcpyHostToDevice, s));
   }
   RC(fr_divide_by_linear(c, wq, evd + (k + 5) * 32, pbeta, 3 * n_h, beta.l, s));
   // ---- the linear combination of the second sumcheck, opened at gamma together with g_a, g_b, g_c --------------------------------------------------
@@ -540,8 +562,8 @@ int32_t Prover::open() {
     const void* terms[20]; size_t lens[20]; HFr co[20]; size_t nt = 0; HFr cg = HFr::zero();
     const HFr gk[3] = {ga, gb, gc};
     for (size_t m = 0; m < 3; ++m) {
-      const HFr fm = HFr::add(HFr::mul(gamma, gk[m]), HFr::mul(sigma[m], HFr::inv(fr_u64(nk[m]))));
-      const HFr d = HFr::mul(HFr::mul(delta[m], xi3), HFr::mul(vk_gamma, HFr::inv(vanish(nk[m], gamma))));     // selector v_K / v_{K_M} at gamma
+      const HFr fm = HFr::add(HFr::mul(gamma, gk[m]), HFr::mul(sigma[m], inv_pow2(lg_km[m])));
+      const HFr d = HFr::mul(HFr::mul(delta[m], xi3), HFr::mul(vk_gamma, inv4[1 + m]));     // selector v_K / v_{K_M} at gamma
       const HFr dfm = HFr::mul(d, fm);
       const HFr cf[4] = {HFr::mul(dfm, beta), HFr::mul(dfm, alpha), HFr::mul(d, vv), HFr::neg(dfm)};      // row, col, val, row_col
       for (int j = 0; j < 4; ++j) { terms[nt] = (const char*)ix.k_polys + (4 * ko[m] + (size_t)j * nk[m]) * 32; lens[nt] = nk[m]; co[nt++] = cf[j]; }
@@ -580,6 +602,7 @@ int32_t Prover::write(uint8_t* out, size_t* out_len) {
 
 int32_t varuna_prove(Ctx* c, const PinnedBases& pb, const aleo_mi355x_varuna_index& ix, const void* const* assignments, size_t k, uint64_t seed,
                      uint8_t* out, size_t* out_len) {
+  g_varuna_timing[6] = g_varuna_timing[7] = 0;
   Prover p(c, pb, ix, k, seed);
   RC(p.setup(assignments)); RC(p.first_round(assignments)); RC(p.second_round()); RC(p.third_round()); RC(p.fourth_round()); RC(p.open());
   return p.write(out, out_len);

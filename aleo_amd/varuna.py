@@ -280,8 +280,8 @@ class NativeCircuitIndex:
 
 
 def native_timing() -> dict:
-    t = (ctypes.c_double * 6)(); lib().aleo_mi355x_varuna_last_timing(t, 6)
-    return dict(zip(('round1', 'round2', 'round3', 'round4', 'openings', 'total'), t))
+    t = (ctypes.c_double * 8)(); lib().aleo_mi355x_varuna_last_timing(t, 8)
+    return dict(zip(('round1', 'round2', 'round3', 'round4', 'openings', 'total', 'commit_calls', 'commit_host_tails'), t))
 
 
 class Proof:

@@ -283,7 +283,7 @@ int32_t aleo_mi355x_proof_to_bytes(void* out, size_t* len, const aleo_mi355x_pro
  * assignments: n_instances host pointers to n_vars x 32 bytes canonical (public variables first, z_0 = 1).  seed: the proof's random stream
  * (aleo_mi355x_fr_random_device).  out_proof / len: Proof::to_bytes_le layout, 901 + 176 (n_instances - 1) bytes; *len in = capacity.
  * Blocking; concurrent calls from several threads run on separate slots.  aleo_mi355x_varuna_last_timing: wall ms of the calling thread's
- * last proof: rounds 1..4, openings, total. */
+ * last proof: rounds 1..4, openings, total, time inside the five commitment calls, their host tails. */
 typedef struct {
   uint64_t n_h, n_k_a, n_k_b, n_k_c, n_x, n_public, n_vars;      /* |H|, the non-zero domains |K_A|, |K_B|, |K_C|, |X| */
   uint64_t committer_key, max_degree, gamma_offset;
