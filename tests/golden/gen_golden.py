@@ -10,6 +10,8 @@
   msm_small.json        Python big-integer MSM known answers (oracle/pyref.py msm_naive: double-and-add, no windows).
   msm_g2_small.json     the same for G2 over Fq2 (oracle/pyref.py msm_naive_g2).
   ntt_small.json        O(n^2) DFT known answers for fft / ifft / coset_fft / coset_ifft.
+  varuna_small.json     proofs of the restatement of the prover (oracle/varuna_ref.py) for small synthetic circuits: seeds, sizes, the verifying-key
+                        bytes and the proof bytes — what the device prover has to reproduce, frozen so that neither side can drift unnoticed.
 
 Run from the repo root:  python tests/golden/gen_golden.py
 The reference cannot be built or imported here (Rust, crates.io snarkVM 0.14.5): these vectors come from the
@@ -154,6 +156,27 @@ def gen_ntt():
     json.dump({'two_adic_root': hex(p.FR_TWO_ADIC_ROOT), 'generator': p.FR_GENERATOR, 'cases': cases}, open(os.path.join(HERE, 'ntt_small.json'), 'w'))
 
 
+def gen_varuna():
+    from aleo_amd import synth
+    from oracle import varuna_ref as V
+    TAU, S_GAMMA = 0x1F3A9C0D5E7B24681357ACE02468BDF013579BDF02468ACE1234567, 0x0FEDCBA9876543210123456789ABCDEF55AA
+    cases = []
+    for (n, pub, seed, instances, domains) in [(12, 2, 101, 1, 'shared'), (60, 3, 102, 1, 'per_matrix'), (45, 4, 103, 3, 'per_matrix'), (200, 1, 104, 2, 'shared')]:
+        csr, z = synth.synthetic_r1cs(n, pub, seed, long_rows=1 if n > 20 else 0)
+        rows = lambda m: [[(int(csr[m][1][k]), synth.limbs_to_int(csr[m][2][k])) for k in range(csr[m][0][i], csr[m][0][i + 1])] for i in range(n)]
+        c = V.Circuit(n, pub, len(z) - pub, rows('a'), rows('b'), rows('c'), domains=domains)
+        D = 1
+        while D < max(3 * c.n_h, c.n_k): D *= 2
+        setup = V.Setup(TAU, S_GAMMA, D - 1); idx = V.Index(c, setup)
+        zs = [z] + [synth.resolve_synthetic(csr, pub, [1] + [7 * i + j for j in range(1, pub)]) for i in range(1, instances)]
+        proof, data = V.prove(idx, setup, zs, V.random_stream(seed + 1000, c.n_h, instances))
+        assert V.verify_pairing(idx, setup.verifier_key(c), [q[:pub] for q in zs], data)
+        cases.append({'n_constraints': n, 'n_public': pub, 'circuit_seed': seed, 'instances': instances, 'domains': domains, 'proof_seed': seed + 1000,
+                      'other_publics': [[1] + [7 * i + j for j in range(1, pub)] for i in range(1, instances)], 'max_degree': D - 1,
+                      'domain_sizes': [c.n_h, c.n_k_m['a'], c.n_k_m['b'], c.n_k_m['c'], c.n_x], 'vk': idx.vk_bytes().hex(), 'proof': data.hex()})
+    json.dump({'tau': hex(TAU), 's_gamma': hex(S_GAMMA), 'cases': cases}, open(os.path.join(HERE, 'varuna_small.json'), 'w'))
+
+
 if __name__ == '__main__':
-    gen_reference_proof(); gen_reference_literals(); gen_msm(); gen_msm_g2(); gen_ntt()
+    gen_reference_proof(); gen_reference_literals(); gen_msm(); gen_msm_g2(); gen_ntt(); gen_varuna()
     print('golden fixtures written to', HERE)

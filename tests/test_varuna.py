@@ -279,3 +279,49 @@ def test_whole_proof_entry_points_refuse_misuse():
         assert build(max_degree=7) == 2 and build(key=123456789) == 4 and build(pub=0) == 2 and build(priv=len(z) + 10 ** 6) == 2
     finally:
         ck.close()
+
+
+def _golden_cases():
+    g = json.load(open(os.path.join(os.path.dirname(__file__), 'golden', 'varuna_small.json')))
+    return int(g['tau'], 16), int(g['s_gamma'], 16), g['cases']
+
+
+def _golden_instance(case):
+    csr, z, c = _circuit(case['n_constraints'], case['n_public'], case['circuit_seed'], long_rows=1 if case['n_constraints'] > 20 else 0, domains=case['domains'])
+    zs = [z] + [synth.resolve_synthetic(csr, case['n_public'], pub) for pub in case['other_publics']]
+    assert [c.n_h, c.n_k_m['a'], c.n_k_m['b'], c.n_k_m['c'], c.n_x] == case['domain_sizes']
+    return csr, zs, c
+
+
+def test_restatement_reproduces_the_frozen_proofs():
+    """tests/golden/varuna_small.json (written by gen_golden.py from the restatement): today's restatement gives the same verifying-key and
+    proof bytes, and its pairing verifier accepts them — so a change of either side of the parity tests shows up here first."""
+    tau, sg, cases = _golden_cases()
+    assert (tau, sg) == (TAU, S_GAMMA)
+    for case in cases:
+        csr, zs, c = _golden_instance(case)
+        setup = V.Setup(tau, sg, case['max_degree']); idx = V.Index(c, setup)
+        assert idx.vk_bytes().hex() == case['vk']
+        _, data = V.prove(idx, setup, zs, V.random_stream(case['proof_seed'], c.n_h, case['instances']))
+        assert data.hex() == case['proof']
+    csr, zs, c = _golden_instance(cases[1])
+    setup = V.Setup(tau, sg, cases[1]['max_degree'])
+    assert V.verify_pairing(V.Index(c, setup), setup.verifier_key(c), [q[:cases[1]['n_public']] for q in zs], bytes.fromhex(cases[1]['proof']))
+
+
+@pytest.mark.gpu
+def test_device_provers_reproduce_the_frozen_proofs():
+    """The frozen proofs from the native index + prover, and from the step-by-step host side."""
+    from aleo_amd import varuna
+    tau, sg, cases = _golden_cases()
+    for case in cases:
+        csr, zs, c = _golden_instance(case)
+        zq = [np.stack([synth.int_to_limbs(v, 4) for v in q]) for q in zs]
+        ck = varuna.synthetic_committer_key(tau, sg, case['max_degree'])
+        try:
+            with varuna.NativeCircuitIndex(csr, case['n_constraints'], case['n_public'], len(zs[0]) - case['n_public'], ck, domains=case['domains']) as nx:
+                assert nx.vk_bytes.hex() == case['vk'] and nx.prove(zq, case['proof_seed']).hex() == case['proof']
+            ix = varuna.CircuitIndex(csr, case['n_constraints'], case['n_public'], len(zs[0]) - case['n_public'], ck, domains=case['domains'])
+            assert ix.vk_bytes.hex() == case['vk'] and varuna.prove(ix, zq, case['proof_seed']).to_bytes().hex() == case['proof']
+        finally:
+            ck.close()
