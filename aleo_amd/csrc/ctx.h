@@ -165,6 +165,7 @@ int32_t ahp_first_sumcheck(Ctx* c, void* d_dst, size_t n, const void* d_r, const
 int32_t ahp_matrix_sumcheck(Ctx* c, void* d_dst, size_t n, const void* const* d_index, size_t index_stride_elems, const void* const* d_f, const void* consts, hipStream_t s);
 int32_t fr_blind_rows(Ctx* c, void* d_dst, const void* d_src, size_t n, size_t rows, const void* rho_mont, hipStream_t s);
 int32_t ahp_sumcheck_operands(Ctx* c, void* d_dst, const void* d_wit, const void* d_xp, size_t n, size_t n_x, size_t instances, hipStream_t s);
+int32_t fr_scatter_to_mont(Ctx* c, void* d_dst, const void* d_src, const void* d_pos, size_t n, hipStream_t s);
 int32_t fr_vec_op(Ctx* c, void* d_dst, const void* d_a, const void* d_b, size_t n, int32_t op, hipStream_t s);
 int32_t fr_batch_inverse(Ctx* c, void* d_inout, size_t n, hipStream_t s);
 int32_t fr_divide_by_linear(Ctx* c, void* d_q, void* d_eval, const void* d_p, size_t n, const void* z_mont32, hipStream_t s);

@@ -550,6 +550,20 @@ int32_t ahp_sumcheck_operands(Ctx* c, void* d_dst, const void* d_wit, const void
   return ALEO_MI355X_OK;
 }
 
+// dst[pos[v]] = to_mont(src[v]): the assignment (canonical, variable order) laid out on H in Montgomery form — dst zeroed by the caller
+__global__ void __launch_bounds__(256) k_scatter_to_mont(char* __restrict__ dst, const char* __restrict__ src, const uint32_t* __restrict__ pos, size_t n) {
+  for (size_t v = (size_t)blockIdx.x * 256 + threadIdx.x; v < n; v += (size_t)gridDim.x * 256)
+    store_fp<Fr>(dst + (size_t)pos[v] * 32, Fr::to_mont(load_fp<Fr>(src + v * 32)));
+}
+int32_t fr_scatter_to_mont(Ctx* c, void* d_dst, const void* d_src, const void* d_pos, size_t n, hipStream_t s) {
+  (void)c;
+  if (!n) return ALEO_MI355X_OK;
+  const size_t want = (n + 255) / 256;
+  hipLaunchKernelGGL(k_scatter_to_mont, dim3((uint32_t)(want < 8192 ? want : 8192)), dim3(256), 0, s, (char*)d_dst, (const char*)d_src, (const uint32_t*)d_pos, n);
+  HIPCHK(hipGetLastError());
+  return ALEO_MI355X_OK;
+}
+
 int32_t fr_batch_inverse(Ctx* c, void* d_inout, size_t n, hipStream_t s) {
   if (n == 0) return ALEO_MI355X_OK;
   int32_t rc; if ((rc = scratch_acquire(c, c->ntt_tmp, n * 32, s))) return rc;

@@ -240,6 +240,7 @@ int32_t varuna_index_build(Ctx* c, const PinnedBases& pb, std::shared_ptr<Pinned
     RC(ntt_run(c, e2, lg + 1, 4, 0, 0, 0, s));
   }
   V.k_evals = kev; V.k_idx = kid; V.k_polys = kpo; V.k2_evals = k2; V.positions = o->positions.data();
+  { void* dp; RC(up(&dp, o->positions.data(), n_vars * 4)); V.positions_device = dp; }
   // index commitments -> what the transcript absorbs first
   uint8_t aff[12 * 104];
   {
@@ -299,7 +300,7 @@ int32_t Prover::setup(const void* const* assignments) {
   s = c->stream;
   t_mark[0] = now_ms();
   // ---- workspace ------------------------------------------------------------------------------------------------------------------
-  const size_t elems = n_h * (40 + 20 * k) + k_sum * 6 + n_k * 4 + 4096;
+  const size_t elems = n_h * (41 + 21 * k) + k_sum * 6 + n_k * 4 + 4096;
   RC(c->prover_ws.reserve(elems * 32 + (64 << 10)));
   ar = Arena{(char*)c->prover_ws.p, 0, c->prover_ws.cap};
   const size_t stage_elems = k * n_x + (3 * k + 1) * HC + HC;      // x̂ coefficients, hiding polynomials, the opening's hiding quotient: staged through pinned memory
@@ -321,14 +322,17 @@ int32_t Prover::first_round(const void* const* assignments) {
   x_poly.assign(k, {}); std::vector<uint8_t> x_bytes(k * n_x * 32, 0);
   uint32_t lg_x = 0; while ((1ull << lg_x) < n_x) ++lg_x;
   const HFr gx_inv = HFr::inv(domain_gen(n_x)), nx_inv = inv_pow2(lg_x);
-  std::memset(pin, 0, k * n_h * 32);
   const uint32_t* pos = (const uint32_t*)ix.positions;
+  const bool host_layout = ix.positions_device == nullptr;      // without the positions in HBM the host lays the assignment out on H (pinned staging)
+  if (host_layout) std::memset(pin, 0, k * n_h * 32);
+  else for (size_t v = 0; v < ix.n_vars; ++v) if (pos[v] >= n_h) { g_last_error = "varuna_prove: variable position outside H"; return ALEO_MI355X_ERR_BAD_ARG; }
   for (size_t i = 0; i < k; ++i) {
     const uint8_t* z = (const uint8_t*)assignments[i];
-    for (size_t v = 0; v < ix.n_vars; ++v) {
-      if (pos[v] >= n_h) { g_last_error = "varuna_prove: variable position outside H"; return ALEO_MI355X_ERR_BAD_ARG; }
-      std::memcpy(pin + (i * n_h + pos[v]) * 32, z + v * 32, 32);
-    }
+    if (host_layout)
+      for (size_t v = 0; v < ix.n_vars; ++v) {
+        if (pos[v] >= n_h) { g_last_error = "varuna_prove: variable position outside H"; return ALEO_MI355X_ERR_BAD_ARG; }
+        std::memcpy(pin + (i * n_h + pos[v]) * 32, z + v * 32, 32);
+      }
     std::vector<HFr> xe(n_x, HFr::zero());
     for (size_t j = 0; j < ix.n_public; ++j) { HFr v; std::memcpy(v.l, z + j * 32, 32); if (HFr::geq_p(v.l)) { g_last_error = "varuna_prove: assignment not canonical"; return ALEO_MI355X_ERR_BAD_ARG; } std::memcpy(&x_bytes[(i * n_x + j) * 32], v.l, 32); xe[j] = HFr::to_mont(v); }
     x_poly[i].assign(n_x, HFr::zero());                    // inverse DFT over X, O(|X|^2): |X| is the (padded) number of public inputs
@@ -340,9 +344,18 @@ int32_t Prover::first_round(const void* const* assignments) {
     }
   }
   for (size_t i = 0; i < k; ++i) std::memcpy(stage + i * n_x * 32, x_poly[i].data(), n_x * 32);
-  HIPCHK(hipMemcpyAsync(zH, pin, k * n_h * 32, hipMemcpyHostToDevice, s));
+  if (host_layout) {
+    HIPCHK(hipMemcpyAsync(zH, pin, k * n_h * 32, hipMemcpyHostToDevice, s));
+    RC(fr_lin(c, zH, k * n_h, nullptr, r2.l, zH, nullptr, nullptr, s));                   // canonical -> Montgomery
+  } else {                                                                                  // upload in variable order; scatter + Montgomery form on the device
+    TAKE(zraw, k * ix.n_vars)
+    HIPCHK(hipMemsetAsync(zH, 0, k * n_h * 32, s));
+    for (size_t i = 0; i < k; ++i) {
+      HIPCHK(hipMemcpyAsync(zraw + i * ix.n_vars * 32, assignments[i], ix.n_vars * 32, hipMemcpyHostToDevice, s));
+      RC(fr_scatter_to_mont(c, zH + i * n_h * 32, zraw + i * ix.n_vars * 32, ix.positions_device, ix.n_vars, s));
+    }
+  }
   HIPCHK(hipMemcpyAsync(xp, stage, k * n_x * 32, hipMemcpyHostToDevice, s));
-  RC(fr_lin(c, zH, k * n_h, nullptr, r2.l, zH, nullptr, nullptr, s));                     // canonical -> Montgomery
   HIPCHK(hipMemsetAsync(xh, 0, k * n_h * 32, s));
   for (size_t i = 0; i < k; ++i) {
     char* e0 = ev + 3 * i * n_h * 32; char* z_i = zH + i * n_h * 32; char* xh_i = xh + i * n_h * 32;

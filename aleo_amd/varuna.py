@@ -200,7 +200,7 @@ def _kp(ix, vec, m, j, mult=1):
 class _NativeIndex(ctypes.Structure):
     """aleo_mi355x_varuna_index (include/aleo_mi355x.h)."""
     _fields_ = ([(n, ctypes.c_uint64) for n in ('n_h', 'n_k_a', 'n_k_b', 'n_k_c', 'n_x', 'n_public', 'n_vars', 'committer_key', 'max_degree', 'gamma_offset')] +
-                [(n, ctypes.c_void_p) for n in ('positions', 'a_row_ptr', 'a_col', 'a_val', 'b_row_ptr', 'b_col', 'b_val', 't_row_ptr', 't_col', 't_val',
+                [(n, ctypes.c_void_p) for n in ('positions', 'positions_device', 'a_row_ptr', 'a_col', 'a_val', 'b_row_ptr', 'b_col', 'b_val', 't_row_ptr', 't_col', 't_val',
                                                 'vx_inv', 'k_evals', 'k_idx', 'k_polys', 'k2_evals', 'vk_bytes')] + [('vk_len', ctypes.c_size_t)])
 
 
@@ -212,7 +212,8 @@ def native_index(ix: CircuitIndex) -> _NativeIndex:
     n.n_k_a, n.n_k_b, n.n_k_c = ix.n_k_m
     n.committer_key, n.max_degree, n.gamma_offset = ix.ck.bases.handle, ix.ck.max_degree, ix.ck.gamma_offset
     ix._pos32 = np.ascontiguousarray(ix.pos, dtype=np.uint32); ix._vk = np.frombuffer(ix.vk_bytes, dtype=np.uint8).copy()
-    n.positions = ix._pos32.ctypes.data; n.vk_bytes = ix._vk.ctypes.data; n.vk_len = ix._vk.shape[0]
+    ix._pos_dev = torch.from_numpy(ix._pos32.view(np.int32)).cuda()
+    n.positions = ix._pos32.ctypes.data; n.positions_device = ix._pos_dev.data_ptr(); n.vk_bytes = ix._vk.ctypes.data; n.vk_len = ix._vk.shape[0]
     for m in 'ab':
         rp, col, val = ix.fwd[m]
         setattr(n, m + '_row_ptr', rp.data_ptr()); setattr(n, m + '_col', col.data_ptr()); setattr(n, m + '_val', val.ptr())

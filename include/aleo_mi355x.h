@@ -270,7 +270,7 @@ int32_t aleo_mi355x_proof_to_bytes(void* out, size_t* len, const aleo_mi355x_pro
  * under /root/reference/rust/src/program/execute.rs:74 and transfer.rs:99 — for one circuit with 1..8 instances, a SHA-256 transcript and
  * the committer key the caller pinned (DESIGN.md 4d lists what differs from upstream).  The index is the prover-key material of the
  * circuit, built once (aleo_amd/varuna.py CircuitIndex does it through the entry points above) and described by device pointers:
- *   positions     host, uint32[n_vars]: index on H of every variable (public inputs on the subgroup X)
+ *   positions     host, uint32[n_vars]: index on H of every variable (public inputs on the subgroup X); positions_device: a copy in HBM (optional)
  *   a_*, b_*      device CSR of A, B with columns moved to positions on H and rows padded to n_h (uint32 row_ptr[n_h+1], col[], Montgomery val[])
  *   t_*           device CSR of the stacked transpose [A^T | B^T | C^T] (rows = positions on H, columns = matrix * n_h + row)
  *   vx_inv        device Fr[n_h]: 1 / v_X on H \ X, 0 on X
@@ -288,6 +288,7 @@ typedef struct {
   uint64_t n_h, n_k_a, n_k_b, n_k_c, n_x, n_public, n_vars;      /* |H|, the non-zero domains |K_A|, |K_B|, |K_C|, |X| */
   uint64_t committer_key, max_degree, gamma_offset;
   const uint32_t* positions;
+  const void* positions_device;      /* the same array in HBM (may be NULL: the assignment is then laid out on H by the host) */
   const void *a_row_ptr, *a_col, *a_val, *b_row_ptr, *b_col, *b_val, *t_row_ptr, *t_col, *t_val;
   const void *vx_inv, *k_evals, *k_idx, *k_polys, *k2_evals;
   const void* vk_bytes; size_t vk_len;
