@@ -56,7 +56,7 @@ def lib():
         'aleo_mi355x_fr_blind_rows_device': ([vp, vp, sz, sz, vp, vp], i32),
         'aleo_mi355x_ahp_sumcheck_operands_device': ([vp, vp, vp, sz, sz, sz, vp], i32),
         'aleo_mi355x_varuna_prove': ([vp, ctypes.POINTER(vp), sz, u64, vp, ctypes.POINTER(sz)], i32),
-        'aleo_mi355x_varuna_index_build': ([ctypes.POINTER(u64), u64, u64, u64, vp, sz, sz, sz, ctypes.c_uint32], i32),
+        'aleo_mi355x_varuna_index_build': ([ctypes.POINTER(u64), u64, u64, u64, u64, vp, sz, sz, sz, ctypes.c_uint32], i32),
         'aleo_mi355x_varuna_index_export': ([u64, vp], i32),
         'aleo_mi355x_varuna_index_vk': ([u64, vp, ctypes.POINTER(sz)], i32),
         'aleo_mi355x_varuna_index_free': ([u64], i32),

@@ -628,14 +628,14 @@ static int32_t find_varuna(Device* d, uint64_t handle, std::shared_ptr<VarunaInd
   *keep = it->second; return ALEO_MI355X_OK;
 }
 
-int32_t aleo_mi355x_varuna_index_build(uint64_t* index_handle, uint64_t committer_key, uint64_t max_degree, uint64_t gamma_offset,
+int32_t aleo_mi355x_varuna_index_build(uint64_t* index_handle, uint64_t committer_key, uint64_t max_degree, uint64_t gamma_offset, uint64_t lagrange_offset,
                                        const aleo_mi355x_r1cs_matrix abc[3], size_t n_constraints, size_t n_public, size_t n_private, uint32_t domain_flags) {
   try {
     if (!index_handle || !abc || domain_flags > 2) return ALEO_MI355X_ERR_BAD_ARG;
     API_BEGIN
     FIND_BASES(committer_key)
     VarunaIndexOwner* raw = nullptr;
-    int32_t rc = varuna_index_build(c, pb, keep, committer_key, max_degree, gamma_offset, abc, n_constraints, n_public, n_private, domain_flags, &raw);
+    int32_t rc = varuna_index_build(c, pb, keep, committer_key, max_degree, gamma_offset, lagrange_offset, abc, n_constraints, n_public, n_private, domain_flags, &raw);
     if (rc) return rc;
     std::shared_ptr<VarunaIndexOwner> o(raw, varuna_index_delete);
     std::lock_guard<std::mutex> g(d->mu);

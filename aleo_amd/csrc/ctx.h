@@ -175,7 +175,7 @@ int32_t varuna_prove(Ctx* c, const PinnedBases& pb, const aleo_mi355x_varuna_ind
 extern thread_local double g_varuna_timing[8];
 struct VarunaIndexOwner;
 int32_t varuna_index_build(Ctx* c, const PinnedBases& pb, std::shared_ptr<PinnedOwner> key, uint64_t key_handle, uint64_t max_degree, uint64_t gamma_offset,
-                           const aleo_mi355x_r1cs_matrix* abc, size_t n_constraints, size_t n_public, size_t n_private, uint32_t domain_flags, VarunaIndexOwner** out);
+                           uint64_t lagrange_offset, const aleo_mi355x_r1cs_matrix* abc, size_t n_constraints, size_t n_public, size_t n_private, uint32_t domain_flags, VarunaIndexOwner** out);
 void varuna_index_delete(VarunaIndexOwner* o);
 const aleo_mi355x_varuna_index* varuna_index_view(const VarunaIndexOwner* o);
 const std::vector<uint8_t>& varuna_index_vk(const VarunaIndexOwner* o);

@@ -151,7 +151,7 @@ const std::vector<uint8_t>& varuna_index_vk(const VarunaIndexOwner* o) { return 
 static uint64_t pow2_at_least(uint64_t v, uint64_t lo) { uint64_t p = lo; while (p < v) p <<= 1; return p; }
 
 int32_t varuna_index_build(Ctx* c, const PinnedBases& pb, std::shared_ptr<PinnedOwner> key, uint64_t key_handle, uint64_t max_degree, uint64_t gamma_offset,
-                           const aleo_mi355x_r1cs_matrix* abc, size_t n_constraints, size_t n_public, size_t n_private, uint32_t domain_flags, VarunaIndexOwner** out) {
+                           uint64_t lagrange_offset, const aleo_mi355x_r1cs_matrix* abc, size_t n_constraints, size_t n_public, size_t n_private, uint32_t domain_flags, VarunaIndexOwner** out) {
   std::unique_ptr<VarunaIndexOwner> o(new VarunaIndexOwner()); o->key = std::move(key);
   hipStream_t s = c->stream;
   if (!n_constraints || !n_public || n_constraints >= (1ull << 28)) { g_last_error = "varuna_index: bad sizes"; return ALEO_MI355X_ERR_BAD_ARG; }
@@ -178,7 +178,8 @@ int32_t varuna_index_build(Ctx* c, const PinnedBases& pb, std::shared_ptr<Pinned
   HFr r2; std::memcpy(r2.l, host::HParams<4>::R2, 32);
   const HFr one = HFr::one();
   aleo_mi355x_varuna_index& V = o->view;
-  V.n_h = n_h; V.n_k_a = nk[0]; V.n_k_b = nk[1]; V.n_k_c = nk[2]; V.n_x = n_x; V.n_public = n_public; V.n_vars = n_vars; V.committer_key = key_handle; V.max_degree = max_degree; V.gamma_offset = gamma_offset;
+  V.n_h = n_h; V.n_k_a = nk[0]; V.n_k_b = nk[1]; V.n_k_c = nk[2]; V.n_x = n_x; V.n_public = n_public; V.n_vars = n_vars; V.committer_key = key_handle; V.max_degree = max_degree; V.gamma_offset = gamma_offset; V.lagrange_offset = lagrange_offset;
+  if (lagrange_offset && lagrange_offset + n_h + 1 > pb.n) { g_last_error = "varuna_index: the Lagrange powers do not fit the committer key"; return ALEO_MI355X_ERR_BAD_ARG; }
   // host staging of everything that is index arithmetic on integers
   std::vector<uint32_t> rp(n_h + 1), tp(n_h + 1, 0), kidx(2 * k_sum, 0);
   std::vector<uint32_t> cpos[3]; std::vector<uint32_t> tcol(nnz_sum); std::vector<uint8_t> tval(nnz_sum * 32), kval(k_sum * 32, 0);
@@ -292,7 +293,7 @@ int32_t Prover::setup(const void* const* assignments) {
   D = ix.max_degree;
   bool k_ok = true; for (int m = 0; m < 3; ++m) k_ok = k_ok && nk[m] >= 2 && !(nk[m] & (nk[m] - 1));
   if (k < 1 || k > 8 || n_h < 2 || !k_ok || n_x < 1 || n_h < 2 * n_x || (n_h & (n_h - 1)) || (n_x & (n_x - 1)) ||
-      ix.n_public > n_x || ix.n_vars > n_h || ix.gamma_offset + HC > pb.n || D + 1 > pb.n || 3 * n_h > D + 1 || n_k > D + 1) {
+      ix.n_public > n_x || ix.n_vars > n_h || ix.gamma_offset + HC > pb.n || (ix.lagrange_offset && ix.lagrange_offset + n_h + 1 > pb.n) || D + 1 > pb.n || 3 * n_h > D + 1 || n_k > D + 1) {
     g_last_error = "varuna_prove: inconsistent index / key sizes"; return ALEO_MI355X_ERR_BAD_ARG;
   }
   lg_h = 0; lg_km[0] = lg_km[1] = lg_km[2] = 0; while ((1ull << lg_h) < n_h) ++lg_h;
@@ -300,10 +301,10 @@ int32_t Prover::setup(const void* const* assignments) {
   s = c->stream;
   t_mark[0] = now_ms();
   // ---- workspace ------------------------------------------------------------------------------------------------------------------
-  const size_t elems = n_h * (41 + 21 * k) + k_sum * 6 + n_k * 4 + 4096;
+  const size_t elems = n_h * (41 + 24 * k) + k_sum * 6 + n_k * 4 + 4096;
   RC(c->prover_ws.reserve(elems * 32 + (64 << 10)));
   ar = Arena{(char*)c->prover_ws.p, 0, c->prover_ws.cap};
-  const size_t stage_elems = k * n_x + (3 * k + 1) * HC + HC;      // x̂ coefficients, hiding polynomials, the opening's hiding quotient: staged through pinned memory
+  const size_t stage_elems = k * n_x + (3 * k + 1) * HC + HC + 3 * k;      // x̂ coefficients, hiding polynomials, the opening's hiding quotient: staged through pinned memory
   const size_t pin_need = (k * n_h + stage_elems) * 32 + 4096;
   if (c->prover_pin_cap < pin_need) {
     if (c->prover_pin) { HIPCHK(hipStreamSynchronize(s)); (void)hipHostFree(c->prover_pin); c->prover_pin = nullptr; c->prover_pin_cap = 0; }
@@ -366,6 +367,13 @@ int32_t Prover::first_round(const void* const* assignments) {
     RC(fr_vec_op(c, e0, z_i, xh_i, n_h, 2, s));                                             // z − x̂ on H
     RC(fr_vec_op(c, e0, e0, ix.vx_inv, n_h, 0, s));                                         // / v_X off X, 0 on X
   }
+  const bool lagrange = ix.lagrange_offset != 0;          // KZG10::commit_lagrange for w, z_a, z_b: commit the evaluations (kept here) against L_i(tau) G
+  char* evals_h = nullptr; char* rho_dev = nullptr;
+  if (lagrange) {
+    evals_h = ar.take(3 * k * n_h); rho_dev = ar.take(3 * k);
+    if (!evals_h || !rho_dev) { g_last_error = "varuna_prove: workspace accounting"; return ALEO_MI355X_ERR_HIP; }
+    HIPCHK(hipMemcpyAsync(evals_h, ev, 3 * k * n_h * 32, hipMemcpyDeviceToDevice, s));
+  }
   RC(ntt_run(c, ev, lg_h, 3 * k, 0, 1, 0, s));
   blind.assign((3 * k + 1) * HC, HFr::zero());
   {
@@ -375,6 +383,7 @@ int32_t Prover::first_round(const void* const* assignments) {
       for (size_t j = 0; j < HC; ++j) blind[q * HC + j] = random_fr(seed, lay_blind + HC * q + j);
     }
     RC(fr_blind_rows(c, wit, ev, n_h, 3 * k, rho, s));                                      // + rho (X^|H| − 1), all 3k polynomials in one launch
+    if (lagrange) { char* st = stage + (k * n_x + (3 * k + 1) * HC + HC) * 32; std::memcpy(st, rho, 3 * k * 32); HIPCHK(hipMemcpyAsync(rho_dev, st, 3 * k * 32, hipMemcpyHostToDevice, s)); }
   }
   for (size_t j = 0; j < HC; ++j) blind[3 * k * HC + j] = random_fr(seed, lay_blind_mask + j);
   RC(fr_random(c, mask, 3 * n_h, seed, lay_mask, 1, s));
@@ -385,7 +394,11 @@ int32_t Prover::first_round(const void* const* assignments) {
   {
     std::vector<MsmSeg> sg;
     for (size_t q = 0; q <= 3 * k; ++q) {
-      MsmSeg a; a.d_ptr = q < 3 * k ? wit + q * L * 32 : mask; a.len = q < 3 * k ? L : 3 * n_h; a.off = 0; a.out = (uint32_t)q; sg.push_back(a);
+      MsmSeg a; a.out = (uint32_t)q;
+      if (q < 3 * k && lagrange) {                                                            // sum_i evals_i L_i(tau) G + rho v_H(tau) G
+        a.d_ptr = evals_h + q * n_h * 32; a.len = n_h; a.off = ix.lagrange_offset; sg.push_back(a);
+        MsmSeg v; v.d_ptr = rho_dev + q * 32; v.len = 1; v.off = ix.lagrange_offset + n_h; v.out = (uint32_t)q; sg.push_back(v);
+      } else { a.d_ptr = q < 3 * k ? wit + q * L * 32 : mask; a.len = q < 3 * k ? L : 3 * n_h; a.off = 0; sg.push_back(a); }
       MsmSeg b; b.d_ptr = bl + q * HC * 32; b.len = HC; b.off = ix.gamma_offset; b.out = (uint32_t)q; sg.push_back(b);
     }
     RC(commit(c, pb, sg, (uint32_t)(3 * k + 1), wit_aff.data(), s));

@@ -77,6 +77,7 @@ class _Segment(ctypes.Structure):
 
 
 class CommitterKey:
+    lagrange_offset = 0; lagrange_size = 0      # > 0: the set also holds the Lagrange-basis powers of one domain (varuna.synthetic_committer_key)
     """Mirror of sonic_pc::CommitterKey [UPSTREAM-RECALL]: powers_of_beta_g, powers_of_beta_times_gamma_g, max_degree.  Both power
     arrays are pinned as ONE resident set (powers | gamma powers), so a hiding commitment is a single sum of segments."""
 
@@ -97,6 +98,16 @@ class CommitterKey:
 
 class SonicKZG10:
     """Mirror of sonic_pc::SonicKZG10::commit for the labelled polynomials of one round: one call, shared launches."""
+
+    @staticmethod
+    def commit_segments_device(ck: 'CommitterKey', segments, k: int, stream: int = 0) -> np.ndarray:
+        """The general form: result q = sum over its segments of <device coefficient vector, bases[offset ..]>; segments: (ptr, len, offset, q).
+        Used directly where a commitment mixes bases (commit_lagrange with a blinding term: evaluations against the Lagrange powers, the
+        blinding scalar against v_H(tau) G, the hiding polynomial against the gamma powers)."""
+        arr = (_Segment * max(len(segments), 1))(*[_Segment(int(p_), int(n_), int(o_), int(q_)) for p_, n_, o_, q_ in segments])
+        out = np.zeros((k, 104), dtype=np.uint8)
+        check(lib().aleo_mi355x_kzg_commit_segments_device(_p(out), k, ck.bases.handle, arr, len(segments), ctypes.c_void_p(stream)), 'kzg_commit_segments_device')
+        return out
 
     @staticmethod
     def commit(ck: CommitterKey, polynomials, device: bool = False, stream: int = 0) -> np.ndarray:

@@ -129,15 +129,57 @@ def synthetic_r1cs(n_constraints: int, n_public: int, seed: int, long_rows: int 
 
 
 def resolve_synthetic(csr, n_public: int, publics) -> list:
-    """Another assignment of a synthetic_r1cs circuit: the same constraints solved for other public inputs (publics[0] must be 1).
-    Constraint i defines variable n_public + i as (A_i . z)(B_i . z)."""
+    """Another assignment of a synthetic circuit: the same constraints solved for other public inputs (publics[0] must be 1).
+    Constraint i defines variable n_public + i: it appears in row i of C (coefficient c_n), everything else in the row is known:
+    z_new = ((A_i . z)(B_i . z) − sum of the known terms of C_i) / c_n."""
     r = FR_MODULUS
     z = [int(v) % r for v in publics]
     assert len(z) == n_public and z[0] == 1
-    (pa, ca, va), (pb_, cb, vb) = csr['a'], csr['b']
-    va_i = [limbs_to_int(x) for x in va]; vb_i = [limbs_to_int(x) for x in vb]
+    (pa, ca, va), (pb_, cb, vb), (pc, cc, vc) = csr['a'], csr['b'], csr['c']
+    va_i = [limbs_to_int(x) for x in va]; vb_i = [limbs_to_int(x) for x in vb]; vc_i = [limbs_to_int(x) for x in vc]
     for i in range(len(pa) - 1):
         a = sum(va_i[k] * z[ca[k]] for k in range(pa[i], pa[i + 1])) % r
         b = sum(vb_i[k] * z[cb[k]] for k in range(pb_[i], pb_[i + 1])) % r
-        z.append(a * b % r)
+        known, cn = 0, None
+        for k in range(pc[i], pc[i + 1]):
+            if cc[k] == n_public + i: cn = vc_i[k]
+            else: known += vc_i[k] * z[cc[k]]
+        z.append((a * b - known) * pow(cn, -1, r) % r)
     return z
+
+
+def synthetic_r1cs_bits(n_constraints: int, n_public: int, seed: int):
+    """A satisfiable R1CS whose assignment looks like a compiled program's — mostly bits, evenly 0 and 1: 50 % XOR gates of two earlier bits
+    ((2a) b = a + b − c), 20 % AND gates, 20 % negations ((1 − a) 1 = c), 10 % products of two short linear combinations with small coefficients
+    (a field element).  Same return shape as synthetic_r1cs; resolve_synthetic solves it for other public inputs."""
+    r = FR_MODULUS
+    rnd = splitmix_limbs(seed, 6 * n_constraints + 64)
+    z = [1] + [int(rnd[-1 - i] & np.uint64(1)) for i in range(1, n_public)]
+    bits = list(range(1, n_public)) or [0]                            # variables known to hold 0 / 1
+    rows = {'a': [], 'b': [], 'c': []}
+    for i in range(n_constraints):
+        nv = len(z); kind = int(rnd[6 * i] % np.uint64(10))
+        pick = lambda j: bits[int(rnd[6 * i + j] % np.uint64(len(bits)))]
+        if kind < 5:                                                   # XOR
+            u, v = pick(1), pick(2); a, b, c_ = [(u, 2)], [(v, 1)], sorted({u: 1, v: 1}.items()) if u != v else [(u, 2)]
+            c_ = c_ + [(nv, r - 1)]; new = (z[u] + z[v] - 2 * z[u] * z[v]) % r
+        elif kind < 7:                                                 # AND
+            u, v = pick(1), pick(2); a, b, c_ = [(u, 1)], [(v, 1)], [(nv, 1)]; new = z[u] * z[v] % r
+        elif kind < 9:                                                 # NOT
+            u = pick(1); a, b, c_ = ([(0, 1), (u, r - 1)] if u else [(0, 0)]), [(0, 1)], [(nv, 1)]; new = (1 - z[u]) % r if u else 0
+        else:                                                          # (small combination) * (small combination)
+            a = sorted({int(rnd[6 * i + 1] % np.uint64(nv)): 1 + int(rnd[6 * i + 3] & np.uint64(0xFF)), pick(2): 1}.items())
+            b = sorted({int(rnd[6 * i + 4] % np.uint64(nv)): 1 + int(rnd[6 * i + 5] & np.uint64(0xF))}.items()); c_ = [(nv, 1)]
+            new = sum(k_ * z[v] for v, k_ in a) % r * (sum(k_ * z[v] for v, k_ in b) % r) % r
+        z.append(new)
+        if kind < 9: bits.append(nv)
+        rows['a'].append(a); rows['b'].append(b); rows['c'].append(c_)
+    csr = {}
+    for m, rr in rows.items():
+        ptr = np.zeros(n_constraints + 1, dtype=np.uint32); ptr[1:] = np.cumsum([len(x) for x in rr])
+        col = np.array([v for x in rr for v, _ in x], dtype=np.uint32)
+        flat = [c_ for x in rr for _, c_ in x]
+        val = np.zeros((len(flat), 4), dtype=np.uint64)
+        for limb in range(4): val[:, limb] = np.array([(c_ >> (64 * limb)) & _M64 for c_ in flat], dtype=np.uint64)
+        csr[m] = (ptr, col, val)
+    return csr, z

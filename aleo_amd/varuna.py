@@ -63,16 +63,33 @@ class Transcript:
         return int.from_bytes(self.state, 'little') % R
 
 
-def synthetic_committer_key(tau: int, s_gamma: int, max_degree: int, n_gamma: int = HIDING_COEFFS) -> CommitterKey:
-    """powers τ^i·G (i <= max_degree) followed by the hiding powers s·τ^i·G, built in HBM (SRS-shaped bases)."""
-    sc = np.zeros((max_degree + 1 + n_gamma, 4), dtype=np.uint64); a = 1
+def synthetic_committer_key(tau: int, s_gamma: int, max_degree: int, n_gamma: int = HIDING_COEFFS, lagrange_size: int = 0) -> CommitterKey:
+    """powers τ^i·G (i <= max_degree), then the hiding powers s·τ^i·G, then — for lagrange_size = |H| > 0 — the Lagrange-basis powers L_i(τ)·G of
+    the domain H followed by v_H(τ)·G [UPSTREAM-RECALL: CommitterKey::lagrange_bases_at_beta_g]; built in HBM (SURVEY.md §8d: SRS-shaped bases)."""
+    n_l = lagrange_size + 1 if lagrange_size else 0
+    vals, a = [], 1
     for i in range(max_degree + 1):
-        sc[i] = synth.int_to_limbs(a, 4); a = a * tau % R
+        vals.append(a); a = a * tau % R
     a = s_gamma % R
     for i in range(n_gamma):
-        sc[max_degree + 1 + i] = synth.int_to_limbs(a, 4); a = a * tau % R
+        vals.append(a); a = a * tau % R
+    if lagrange_size:
+        n = lagrange_size; w = _gen(n); vh = _vanish(n, tau); n_inv_vh = vh * _inv(n) % R
+        den, x = [], 1
+        for i in range(n): den.append((tau - x) % R); x = x * w % R
+        pre, acc = [], 1                                   # batch inversion of tau − w^i
+        for d in den: pre.append(acc); acc = acc * d % R
+        inv_acc = _inv(acc); x_pows = 1; lag = [0] * n
+        xs = [1] * n
+        for i in range(1, n): xs[i] = xs[i - 1] * w % R
+        for i in range(n - 1, -1, -1):
+            lag[i] = xs[i] * n_inv_vh % R * (inv_acc * pre[i] % R) % R; inv_acc = inv_acc * den[i] % R
+        vals += lag + [vh]
+    sc = np.zeros((len(vals), 4), dtype=np.uint64)
+    for limb in range(4): sc[:, limb] = np.array([(v >> (64 * limb)) & 0xFFFFFFFFFFFFFFFF for v in vals], dtype=np.uint64)
     ck = CommitterKey.__new__(CommitterKey)
     ck.max_degree, ck.gamma_offset, ck.n_gamma = max_degree, max_degree + 1, n_gamma
+    ck.lagrange_offset = max_degree + 1 + n_gamma if lagrange_size else 0; ck.lagrange_size = lagrange_size
     ck.bases = PinnedBases.from_scalars(synth.generator_affine104(), sc).precompute()
     return ck
 
@@ -199,7 +216,7 @@ def _kp(ix, vec, m, j, mult=1):
 
 class _NativeIndex(ctypes.Structure):
     """aleo_mi355x_varuna_index (include/aleo_mi355x.h)."""
-    _fields_ = ([(n, ctypes.c_uint64) for n in ('n_h', 'n_k_a', 'n_k_b', 'n_k_c', 'n_x', 'n_public', 'n_vars', 'committer_key', 'max_degree', 'gamma_offset')] +
+    _fields_ = ([(n, ctypes.c_uint64) for n in ('n_h', 'n_k_a', 'n_k_b', 'n_k_c', 'n_x', 'n_public', 'n_vars', 'committer_key', 'max_degree', 'gamma_offset', 'lagrange_offset')] +
                 [(n, ctypes.c_void_p) for n in ('positions', 'positions_device', 'a_row_ptr', 'a_col', 'a_val', 'b_row_ptr', 'b_col', 'b_val', 't_row_ptr', 't_col', 't_val',
                                                 'vx_inv', 'k_evals', 'k_idx', 'k_polys', 'k2_evals', 'vk_bytes')] + [('vk_len', ctypes.c_size_t)])
 
@@ -211,6 +228,7 @@ def native_index(ix: CircuitIndex) -> _NativeIndex:
     n.n_h, n.n_x, n.n_public, n.n_vars = ix.n_h, ix.n_x, ix.n_public, ix.n_public + ix.n_private
     n.n_k_a, n.n_k_b, n.n_k_c = ix.n_k_m
     n.committer_key, n.max_degree, n.gamma_offset = ix.ck.bases.handle, ix.ck.max_degree, ix.ck.gamma_offset
+    n.lagrange_offset = ix.ck.lagrange_offset if ix.ck.lagrange_size == ix.n_h else 0
     ix._pos32 = np.ascontiguousarray(ix.pos, dtype=np.uint32); ix._vk = np.frombuffer(ix.vk_bytes, dtype=np.uint8).copy()
     ix._pos_dev = torch.from_numpy(ix._pos32.view(np.int32)).cuda()
     n.positions = ix._pos32.ctypes.data; n.positions_device = ix._pos_dev.data_ptr(); n.vk_bytes = ix._vk.ctypes.data; n.vk_len = ix._vk.shape[0]
@@ -254,7 +272,7 @@ class NativeCircuitIndex:
             keep += [rp, col, val]
             mats[i].row_ptr, mats[i].col, mats[i].val = rp.ctypes.data, col.ctypes.data, val.ctypes.data
         h = ctypes.c_uint64(0)
-        check(lib().aleo_mi355x_varuna_index_build(ctypes.byref(h), ck.bases.handle, ck.max_degree, ck.gamma_offset, mats, n_constraints, n_public, n_private, DOMAIN_FLAGS[domains]),
+        check(lib().aleo_mi355x_varuna_index_build(ctypes.byref(h), ck.bases.handle, ck.max_degree, ck.gamma_offset, self._lagrange_offset(csr, n_constraints, n_public, n_private, ck), mats, n_constraints, n_public, n_private, DOMAIN_FLAGS[domains]),
               'varuna_index_build')
         self.handle = h.value
         view = _NativeIndex(); check(lib().aleo_mi355x_varuna_index_export(self.handle, ctypes.byref(view)), 'varuna_index_export')
@@ -263,6 +281,14 @@ class NativeCircuitIndex:
         buf = np.zeros(12 * 48 + 40, dtype=np.uint8); n = ctypes.c_size_t(buf.shape[0])
         check(lib().aleo_mi355x_varuna_index_vk(self.handle, buf.ctypes.data_as(ctypes.c_void_p), ctypes.byref(n)), 'varuna_index_vk')
         self.vk_bytes = buf[:n.value].tobytes()
+
+    @staticmethod
+    def _lagrange_offset(csr, n_constraints, n_public, n_private, ck):
+        n_x = 1
+        while n_x < n_public: n_x *= 2
+        n_h = 1
+        while n_h < max(n_constraints, n_x + n_private, 2 * n_x): n_h *= 2
+        return ck.lagrange_offset if ck.lagrange_size == n_h else 0      # only the Lagrange powers of THIS circuit's domain are of use
 
     def prove(self, assignment, seed: int) -> bytes:
         if isinstance(assignment, np.ndarray) and assignment.ndim == 2: assignment = [assignment]
@@ -348,6 +374,8 @@ class Prover:
             ix.H.ntt_device(xh.ptr(), stream=s)
             fr_vec_op_device(ev.ptr(base), zH.ptr(), xh.ptr(), n_h, OP_SUB, s)
             fr_vec_op_device(ev.ptr(base), ev.ptr(base), ix.vx_inv.ptr(), n_h, OP_MUL, s)
+        lagrange = ix.ck.lagrange_offset != 0 and ix.ck.lagrange_size == n_h      # KZG10::commit_lagrange for w, z_a, z_b: commit their evaluations
+        if lagrange: evals_h = _Vec(3 * k * n_h); evals_h.t.copy_(ev.t)
         ix.H.ntt_batch_device(ev.ptr(), 3 * k, direction=INVERSE, stream=s)
         self.wit = _Vec(3 * k * L)                                                  # w_i, z_a,i, z_b,i as polynomials of |H| + 1 coefficients
         self.blind = []; blinds = []; rhos = []
@@ -362,9 +390,14 @@ class Prover:
         fr_lin_device(self.mask.ptr(), 1, None, neg1, self.mask.ptr(n_h), neg1, self.mask.ptr(2 * n_h), stream=s)
         self.blind_mask = self._ri(self.lay['blind_mask'], HIDING_COEFFS)
         bl = _Vec((3 * k + 1) * HIDING_COEFFS, _mont_rows(blinds + self.blind_mask))
-        polys = [((self.wit.ptr(q * L), L), None, (bl.ptr(HIDING_COEFFS * q), HIDING_COEFFS)) for q in range(3 * k)]
-        polys.append(((self.mask.ptr(), 3 * n_h), None, (bl.ptr(HIDING_COEFFS * 3 * k), HIDING_COEFFS)))
-        out = SonicKZG10.commit(ix.ck, polys, device=True, stream=s)
+        segs = []
+        if lagrange: rho_dev = _Vec(3 * k, _mont_rows(rhos))
+        for q in range(3 * k):
+            if lagrange: segs += [(evals_h.ptr(q * n_h), n_h, ix.ck.lagrange_offset, q), (rho_dev.ptr(q), 1, ix.ck.lagrange_offset + n_h, q)]   # sum_i evals_i L_i(tau) G + rho v_H(tau) G
+            else: segs.append((self.wit.ptr(q * L), L, 0, q))
+            segs.append((bl.ptr(HIDING_COEFFS * q), HIDING_COEFFS, ix.ck.gamma_offset, q))
+        segs += [(self.mask.ptr(), 3 * n_h, 0, 3 * k), (bl.ptr(HIDING_COEFFS * 3 * k), HIDING_COEFFS, ix.ck.gamma_offset, 3 * k)]
+        out = SonicKZG10.commit_segments_device(ix.ck, segs, 3 * k + 1, s)
         self.witness_commitments = out[:3 * k]; self.c['mask'] = out[3 * k]
         self.tr.absorb(ix.vk_bytes); self.tr.absorb(b''.join(_fr_bytes(v) for xe in self.x_evals for v in xe))
         self.tr.absorb(wire.g1_compress(out).tobytes())

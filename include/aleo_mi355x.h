@@ -279,14 +279,16 @@ int32_t aleo_mi355x_proof_to_bytes(void* out, size_t* len, const aleo_mi355x_pro
  *   k_polys       the same four polynomials per matrix as coefficients (layout of k_evals);  k2_evals  their values on the domain of size 2|K_M|
  *                 (2|K_M| each; M starts at element 8 * sum)
  *   vk_bytes      host: what the transcript absorbs first (compressed index commitments, domain sizes)
- * committer_key: a pinned set holding powers[0..max_degree] and, from gamma_offset, at least 3 hiding powers.
+ * committer_key: a pinned set holding powers[0..max_degree] and, from gamma_offset, at least 3 hiding powers; when lagrange_offset != 0 also, from
+ * lagrange_offset, the n_h Lagrange-basis powers L_i(tau) G of the domain H followed by v_H(tau) G: w, z_a, z_b are then committed from their
+ * EVALUATIONS (KZG10::commit_lagrange: the same group elements; a witness of bits stays a vector of small scalars for the MSM).
  * assignments: n_instances host pointers to n_vars x 32 bytes canonical (public variables first, z_0 = 1).  seed: the proof's random stream
  * (aleo_mi355x_fr_random_device).  out_proof / len: Proof::to_bytes_le layout, 901 + 176 (n_instances - 1) bytes; *len in = capacity.
  * Blocking; concurrent calls from several threads run on separate slots.  aleo_mi355x_varuna_last_timing: wall ms of the calling thread's
  * last proof: rounds 1..4, openings, total, time inside the five commitment calls, their host tails. */
 typedef struct {
   uint64_t n_h, n_k_a, n_k_b, n_k_c, n_x, n_public, n_vars;      /* |H|, the non-zero domains |K_A|, |K_B|, |K_C|, |X| */
-  uint64_t committer_key, max_degree, gamma_offset;
+  uint64_t committer_key, max_degree, gamma_offset, lagrange_offset;
   const uint32_t* positions;
   const void* positions_device;      /* the same array in HBM (may be NULL: the assignment is then laid out on H by the host) */
   const void *a_row_ptr, *a_col, *a_val, *b_row_ptr, *b_col, *b_val, *t_row_ptr, *t_col, *t_val;
@@ -303,7 +305,7 @@ typedef struct {
  * index_export fills the struct view (pointers owned by the library, valid until index_free); index_vk copies the bytes the transcript absorbs
  * first: 12 compressed index commitments (row, col, val, row_col of A, B, C) then |H|, |K_A|, |K_B|, |K_C|, |X| as u64 LE.  prove_indexed = varuna_prove. */
 typedef struct { const uint32_t* row_ptr; const uint32_t* col; const void* val; } aleo_mi355x_r1cs_matrix;
-int32_t aleo_mi355x_varuna_index_build(uint64_t* index_handle, uint64_t committer_key, uint64_t max_degree, uint64_t gamma_offset,
+int32_t aleo_mi355x_varuna_index_build(uint64_t* index_handle, uint64_t committer_key, uint64_t max_degree, uint64_t gamma_offset, uint64_t lagrange_offset,
                                        const aleo_mi355x_r1cs_matrix abc[3], size_t n_constraints, size_t n_public, size_t n_private, uint32_t domain_flags);
 int32_t aleo_mi355x_varuna_index_export(uint64_t index_handle, aleo_mi355x_varuna_index* out);
 int32_t aleo_mi355x_varuna_index_vk(uint64_t index_handle, void* out, size_t* len);

@@ -175,13 +175,15 @@ class CommitterKey {
   uint64_t handle() const { return bases_.handle(); }
   size_t max_degree() const { return max_degree_; }
   size_t gamma_offset() const { return max_degree_ + 1; }
+  size_t lagrange_offset() const { return lagrange_offset_; }      // 0: no Lagrange-basis powers pinned (commitments from coefficients)
+  void set_lagrange_offset(size_t off) { lagrange_offset_ = off; }  // the set pinned holds L_i(tau) G of the circuit's domain H, then v_H(tau) G, from `off`
  private:
   static Result<CommitterKey> finish(PinnedBases b, size_t max_degree, size_t n_gamma) {
     if (n_gamma < 3) return {std::nullopt, Error{ALEO_MI355X_ERR_BAD_ARG}};
     int32_t rc = b.precompute(); if (rc) return {std::nullopt, Error{rc}};
     CommitterKey k; k.bases_ = std::move(b); k.max_degree_ = max_degree; return {std::move(k), Error{0}};
   }
-  PinnedBases bases_; size_t max_degree_ = 0;
+  PinnedBases bases_; size_t max_degree_ = 0, lagrange_offset_ = 0;
 };
 
 struct Proof {
@@ -202,7 +204,7 @@ class ProvingKey {
                                     {cs.c.row_ptr.data(), cs.c.col.data(), cs.c.val.data()}};
     for (auto* q : {&cs.a, &cs.b, &cs.c}) if (q->row_ptr.size() != cs.num_constraints + 1 || q->col.size() != q->val.size()) return {std::nullopt, Error{ALEO_MI355X_ERR_BAD_ARG}};
     ProvingKey pk;
-    int32_t rc = aleo_mi355x_varuna_index_build(&pk.handle_, ck.handle(), ck.max_degree(), ck.gamma_offset(), m, cs.num_constraints, cs.num_public, cs.num_private, (uint32_t)policy);
+    int32_t rc = aleo_mi355x_varuna_index_build(&pk.handle_, ck.handle(), ck.max_degree(), ck.gamma_offset(), ck.lagrange_offset(), m, cs.num_constraints, cs.num_public, cs.num_private, (uint32_t)policy);
     if (rc) return {std::nullopt, Error{rc}};
     pk.num_variables_ = cs.num_public + cs.num_private;
     return {std::move(pk), Error{0}};

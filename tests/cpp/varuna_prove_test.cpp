@@ -34,7 +34,7 @@ int main(int argc, char** argv) {
   uint64_t key = 0, index = 0;
   OK(aleo_mi355x_bases_from_scalars(gen.data(), srs.data(), D + 1 + ng, &key), "bases_from_scalars");       // powers | hiding powers
   OK(aleo_mi355x_bases_precompute(key), "bases_precompute");
-  OK(aleo_mi355x_varuna_index_build(&index, key, D, D + 1, abc, nc, npub, npriv, (uint32_t)h[7]), "varuna_index_build");       // h[7]: domain flags
+  OK(aleo_mi355x_varuna_index_build(&index, key, D, D + 1, 0, abc, nc, npub, npriv, (uint32_t)h[7]), "varuna_index_build");       // h[7]: domain flags
   uint8_t vk[12 * 48 + 64]; size_t vk_len = sizeof vk;
   OK(aleo_mi355x_varuna_index_vk(index, vk, &vk_len), "varuna_index_vk");
   std::vector<uint8_t> proof(2048); size_t len = proof.size();

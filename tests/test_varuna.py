@@ -267,7 +267,7 @@ def test_whole_proof_entry_points_refuse_misuse():
                 keep += [rp, col, val]; mats[i].row_ptr, mats[i].col, mats[i].val = rp.ctypes.data, col.ctypes.data, val.ctypes.data
             h = ctypes.c_uint64(0)
             a = dict(key=ck.bases.handle, max_degree=ck.max_degree, gamma_offset=ck.gamma_offset, n=50, pub=2, priv=len(z) - 2); a.update(kw)
-            rc = L.aleo_mi355x_varuna_index_build(ctypes.byref(h), a['key'], a['max_degree'], a['gamma_offset'], mats, a['n'], a['pub'], a['priv'], a.get('flags', 0))
+            rc = L.aleo_mi355x_varuna_index_build(ctypes.byref(h), a['key'], a['max_degree'], a['gamma_offset'], a.get('lagrange', 0), mats, a['n'], a['pub'], a['priv'], a.get('flags', 0))
             if rc == 0: L.aleo_mi355x_varuna_index_free(h.value)
             return rc
         assert build() == 0
@@ -276,6 +276,7 @@ def test_whole_proof_entry_points_refuse_misuse():
         def back(rp, col): rp[5] = rp[6] + 1
         assert build(shift) == 2 and build(wild) == 2 and build(back) == 2
         assert build(flags=3) == 2 and build(flags=1) == 0 and build(flags=2) == 0
+        assert build(lagrange=ck.max_degree + 4) == 2                          # Lagrange powers announced where the key has none
         assert build(max_degree=7) == 2 and build(key=123456789) == 4 and build(pub=0) == 2 and build(priv=len(z) + 10 ** 6) == 2
     finally:
         ck.close()
@@ -325,3 +326,28 @@ def test_device_provers_reproduce_the_frozen_proofs():
             assert ix.vk_bytes.hex() == case['vk'] and varuna.prove(ix, zq, case['proof_seed']).to_bytes().hex() == case['proof']
         finally:
             ck.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('k', [1, 3])
+def test_commit_lagrange_in_the_first_round(k):
+    """With the Lagrange-basis powers of H pinned behind the key, w, z_a, z_b are committed from their evaluations (KZG10::commit_lagrange with the
+    blinding term against v_H(tau) G): the same group elements, hence the same proof bytes as the restatement's; bit-heavy circuit."""
+    from aleo_amd import varuna
+    csr, z = synth.synthetic_r1cs_bits(500, 3, 90 + k)
+    rows = lambda m: [[(int(csr[m][1][j]), synth.limbs_to_int(csr[m][2][j])) for j in range(csr[m][0][i], csr[m][0][i + 1])] for i in range(500)]
+    c = V.Circuit(500, 3, len(z) - 3, rows('a'), rows('b'), rows('c'))
+    zs = [z] + [synth.resolve_synthetic(csr, 3, [1, i & 1, (i >> 1) & 1]) for i in range(1, k)]
+    D = _max_degree(c); setup = V.Setup(TAU, S_GAMMA, D); idx = V.Index(c, setup)
+    _, want = V.prove(idx, setup, zs, _rand(c, 640 + k, k))
+    assert V.verify(idx, setup, [q[:3] for q in zs], want)
+    zq = [np.stack([synth.int_to_limbs(v, 4) for v in q]) for q in zs]
+    ck = varuna.synthetic_committer_key(TAU, S_GAMMA, D, lagrange_size=c.n_h)
+    try:
+        assert ck.lagrange_offset == D + 1 + 3
+        with varuna.NativeCircuitIndex(csr, 500, 3, len(z) - 3, ck) as nx: assert nx.vk_bytes == idx.vk_bytes() and nx.prove(zq, 640 + k) == want
+        ix = varuna.CircuitIndex(csr, 500, 3, len(z) - 3, ck)
+        assert varuna.native_index(ix).lagrange_offset == ck.lagrange_offset
+        assert varuna.prove(ix, zq, 640 + k).to_bytes() == want and varuna.prove_native(ix, zq, 640 + k) == want
+    finally:
+        ck.close()
