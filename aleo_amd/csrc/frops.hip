@@ -124,47 +124,94 @@ __device__ __forceinline__ Fr spmv_term(const char* __restrict__ vals, const uin
   return Fr::mul(load_fp<Fr>(vals + (size_t)k * 32), load_fp<Fr>(x + (size_t)col[k] * 32));       // < 2r
 }
 
+// Rows beyond SPMV_WAVE_MAX entries (the column of the constant 1 in a transposed constraint matrix: a fifth of all constraints of a
+// compiled program touch it) would keep ONE wave busy for milliseconds: up to SPMV_HUGE_ROWS of them are spread over the whole grid instead —
+// every wave sums a strided share into a partial, one block per row folds the partials.
+static constexpr uint32_t SPMV_WAVE_MAX = 8192, SPMV_HUGE_ROWS = 64, SPMV_HUGE_WAVES = 4096;
+
 __global__ void __launch_bounds__(256) k_spmv_rows(char* __restrict__ y, const uint32_t* __restrict__ row_ptr, const uint32_t* __restrict__ col,
                                                    const char* __restrict__ vals, const char* __restrict__ x, uint32_t rows,
-                                                   uint32_t* __restrict__ long_rows, uint32_t* __restrict__ n_long) {
+                                                   uint32_t* __restrict__ long_rows, uint32_t* __restrict__ huge_rows, uint32_t* __restrict__ counters) {
   for (uint32_t r = blockIdx.x * 256 + threadIdx.x; r < rows; r += gridDim.x * 256) {
     const uint32_t k0 = row_ptr[r], k1 = row_ptr[r + 1];
-    if (k1 - k0 > SPMV_LANE_MAX) { long_rows[atomicAdd(n_long, 1u)] = r; continue; }
+    if (k1 - k0 > SPMV_LANE_MAX) {
+      if (k1 - k0 > SPMV_WAVE_MAX) { const uint32_t h = atomicAdd(counters + 1, 1u); if (h < SPMV_HUGE_ROWS) { huge_rows[h] = r; continue; } }
+      long_rows[atomicAdd(counters, 1u)] = r; continue;
+    }
     Fr acc = Fr::zero();
     for (uint32_t k = k0; k < k1; ++k) acc = Fr::cond_sub<2>(Fr::add(acc, spmv_term(vals, col, x, k)));     // < 4r -> < 2r
     store_fp<Fr>(y + (size_t)r * 32, Fr::cond_sub<1>(acc));
   }
 }
 
+__device__ __forceinline__ Fr spmv_wave_sum(Fr acc) {        // sum over the 64 lanes, result in every lane, < 2r
+  for (int d = 32; d >= 1; d >>= 1) {
+    Fr o;
+#pragma unroll
+    for (int l = 0; l < 8; ++l) o.v[l] = __shfl_xor(acc.v[l], d);
+    acc = Fr::cond_sub<2>(Fr::add(acc, o));
+  }
+  return acc;
+}
+
 __global__ void __launch_bounds__(256) k_spmv_long(char* __restrict__ y, const uint32_t* __restrict__ row_ptr, const uint32_t* __restrict__ col,
                                                    const char* __restrict__ vals, const char* __restrict__ x,
-                                                   const uint32_t* __restrict__ long_rows, const uint32_t* __restrict__ n_long) {
+                                                   const uint32_t* __restrict__ long_rows, const uint32_t* __restrict__ counters) {
   const uint32_t lane = threadIdx.x & 63, wave = (blockIdx.x * 256 + threadIdx.x) >> 6, nwaves = (gridDim.x * 256) >> 6;
-  for (uint32_t q = wave; q < *n_long; q += nwaves) {
+  for (uint32_t q = wave; q < counters[0]; q += nwaves) {
     const uint32_t r = long_rows[q], k0 = row_ptr[r], k1 = row_ptr[r + 1];
     Fr acc = Fr::zero();
     for (uint32_t k = k0 + lane; k < k1; k += 64) acc = Fr::cond_sub<2>(Fr::add(acc, spmv_term(vals, col, x, k)));
-    for (int d = 32; d >= 1; d >>= 1) {
-      Fr o;
-#pragma unroll
-      for (int l = 0; l < 8; ++l) o.v[l] = __shfl_xor(acc.v[l], d);
-      acc = Fr::cond_sub<2>(Fr::add(acc, o));
-    }
+    acc = spmv_wave_sum(acc);
     if (lane == 0) store_fp<Fr>(y + (size_t)r * 32, Fr::cond_sub<1>(acc));
+  }
+}
+// grid = SPMV_HUGE_WAVES waves; wave w of the grid takes entries w*64 + lane, + SPMV_HUGE_WAVES*64, ... of every huge row
+__global__ void __launch_bounds__(256) k_spmv_huge_partial(const uint32_t* __restrict__ row_ptr, const uint32_t* __restrict__ col, const char* __restrict__ vals,
+                                                           const char* __restrict__ x, const uint32_t* __restrict__ huge_rows, const uint32_t* __restrict__ counters,
+                                                           char* __restrict__ partial) {
+  const uint32_t lane = threadIdx.x & 63, wave = (blockIdx.x * 256 + threadIdx.x) >> 6;
+  const uint32_t nh = counters[1] < SPMV_HUGE_ROWS ? counters[1] : SPMV_HUGE_ROWS;
+  for (uint32_t q = 0; q < nh; ++q) {
+    const uint32_t r = huge_rows[q], k0 = row_ptr[r], k1 = row_ptr[r + 1];
+    Fr acc = Fr::zero();
+    for (uint32_t k = k0 + wave * 64 + lane; k < k1; k += SPMV_HUGE_WAVES * 64) acc = Fr::cond_sub<2>(Fr::add(acc, spmv_term(vals, col, x, k)));
+    acc = spmv_wave_sum(acc);
+    if (lane == 0) store_fp<Fr>(partial + ((size_t)q * SPMV_HUGE_WAVES + wave) * 32, acc);      // < 2r
+  }
+}
+// one block per huge row: 4096 partials -> y[row]
+__global__ void __launch_bounds__(256) k_spmv_huge_fold(char* __restrict__ y, const uint32_t* __restrict__ huge_rows, const uint32_t* __restrict__ counters,
+                                                        const char* __restrict__ partial) {
+  __shared__ uint32_t l[4][8];
+  const uint32_t nh = counters[1] < SPMV_HUGE_ROWS ? counters[1] : SPMV_HUGE_ROWS, q = blockIdx.x;
+  if (q >= nh) return;
+  Fr acc = Fr::zero();
+  for (uint32_t i = threadIdx.x; i < SPMV_HUGE_WAVES; i += 256) acc = Fr::cond_sub<2>(Fr::add(acc, load_fp<Fr>(partial + ((size_t)q * SPMV_HUGE_WAVES + i) * 32)));
+  acc = spmv_wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) for (int k = 0; k < 8; ++k) l[threadIdx.x >> 6][k] = acc.v[k];
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    Fr t = Fr::zero();
+    for (int w = 0; w < 4; ++w) { Fr o; for (int k = 0; k < 8; ++k) o.v[k] = l[w][k]; t = Fr::cond_sub<2>(Fr::add(t, o)); }
+    store_fp<Fr>(y + (size_t)huge_rows[q] * 32, Fr::cond_sub<1>(t));
   }
 }
 
 int32_t fr_spmv(Ctx* c, void* d_y, const void* d_row_ptr, const void* d_col, const void* d_vals, const void* d_x, size_t rows, hipStream_t s) {
   if (rows == 0) return ALEO_MI355X_OK;
   if (rows >= (1ull << 32)) { g_last_error = "fr_spmv: row count exceeds 2^32"; return ALEO_MI355X_ERR_BAD_ARG; }
-  int32_t rc; if ((rc = scratch_acquire(c, c->ntt_tmp, (rows + 16) * 4, s))) return rc;
-  uint32_t* n_long = c->ntt_tmp.as<uint32_t>(); uint32_t* long_rows = n_long + 16;
-  HIPCHK(hipMemsetAsync(n_long, 0, 4, s));
+  const size_t head = ((rows + 16 + SPMV_HUGE_ROWS) * 4 + 255) & ~(size_t)255;
+  int32_t rc; if ((rc = scratch_acquire(c, c->ntt_tmp, head + (size_t)SPMV_HUGE_ROWS * SPMV_HUGE_WAVES * 32, s))) return rc;
+  uint32_t* counters = c->ntt_tmp.as<uint32_t>(); uint32_t* huge_rows = counters + 16; uint32_t* long_rows = huge_rows + SPMV_HUGE_ROWS;
+  char* partial = c->ntt_tmp.as<char>() + head;
+  HIPCHK(hipMemsetAsync(counters, 0, 8, s));
   const size_t want = (rows + 255) / 256; const uint32_t grid = (uint32_t)(want < 16384 ? want : 16384);
-  hipLaunchKernelGGL(k_spmv_rows, dim3(grid), dim3(256), 0, s, (char*)d_y, (const uint32_t*)d_row_ptr, (const uint32_t*)d_col, (const char*)d_vals,
-                     (const char*)d_x, (uint32_t)rows, long_rows, n_long);
-  hipLaunchKernelGGL(k_spmv_long, dim3(1024), dim3(256), 0, s, (char*)d_y, (const uint32_t*)d_row_ptr, (const uint32_t*)d_col, (const char*)d_vals,
-                     (const char*)d_x, long_rows, n_long);
+  const uint32_t* rp = (const uint32_t*)d_row_ptr; const uint32_t* cl = (const uint32_t*)d_col; const char* vl = (const char*)d_vals; const char* xx = (const char*)d_x;
+  hipLaunchKernelGGL(k_spmv_rows, dim3(grid), dim3(256), 0, s, (char*)d_y, rp, cl, vl, xx, (uint32_t)rows, long_rows, huge_rows, counters);
+  hipLaunchKernelGGL(k_spmv_long, dim3(1024), dim3(256), 0, s, (char*)d_y, rp, cl, vl, xx, long_rows, counters);
+  hipLaunchKernelGGL(k_spmv_huge_partial, dim3(SPMV_HUGE_WAVES / 4), dim3(256), 0, s, rp, cl, vl, xx, huge_rows, counters, partial);
+  hipLaunchKernelGGL(k_spmv_huge_fold, dim3(SPMV_HUGE_ROWS), dim3(256), 0, s, (char*)d_y, huge_rows, counters, (const char*)partial);
   HIPCHK(hipGetLastError());
   return scratch_release(c, s);
 }

@@ -528,7 +528,9 @@ def test_fr_spmv_matches_oracle():
     rows, cols = 20011, 7001
     rng = np.random.default_rng(99)
     lens = rng.choice([0, 1, 2, 3, 5, 9, 64, 65], size=rows, p=[0.05, 0.3, 0.3, 0.2, 0.1, 0.03, 0.01, 0.01]).astype(np.int64)
-    lens[[7, 4000, rows - 1]] = [3000, 129, 70000]                                       # long rows, also as the very last row
+    lens[[7, 4000, rows - 1]] = [3000, 129, 70000]                                       # long rows, also as the very last row (70000: spread over the grid)
+    lens[[11, 12]] = [8192, 8193]                                                        # both sides of the wave-per-row / whole-grid switch
+    lens[100:170] = 8200 + np.arange(70)                                                 # more grid-wide rows than the 64 that path takes: the rest fall back
     row_ptr = np.zeros(rows + 1, dtype=np.uint32); row_ptr[1:] = np.cumsum(lens)
     nnz = int(row_ptr[-1])
     col = rng.integers(0, cols, size=nnz, dtype=np.uint32)
