@@ -333,10 +333,10 @@ VARUNA_NOTE = ('aleo_mi355x_varuna_prove (one C call per proof): the four AHP ro
                'SHA-256 transcript and synthetic SRS, so proofs are checked by the restatement in oracle/varuna_ref.py, not by snarkVM (DESIGN.md)')
 
 
-def _varuna_instance(synth, lg, seed):
+def _varuna_instance(synth, lg, seed, bits=False, lagrange=False):
     from aleo_amd import varuna
     n = (1 << lg) - 64 if lg >= 8 else (1 << lg) - 4
-    csr, z = synth.synthetic_r1cs(n, 4, seed, long_rows=4 if lg >= 10 else 1)
+    csr, z = synth.synthetic_r1cs_bits(n, 4, seed) if bits else synth.synthetic_r1cs(n, 4, seed, long_rows=4 if lg >= 10 else 1)
     zz = np.stack([synth.int_to_limbs(v, 4) for v in z])
     nnz = max(int(csr[m][0][-1]) for m in 'abc'); n_k = 2
     while n_k < nnz: n_k *= 2
@@ -344,7 +344,7 @@ def _varuna_instance(synth, lg, seed):
     while n_h < max(n, 4 + len(z) - 4, 8): n_h *= 2
     D = 1
     while D < max(3 * n_h, n_k): D *= 2
-    ck = varuna.synthetic_committer_key(VARUNA_TAU, VARUNA_S, D - 1)
+    ck = varuna.synthetic_committer_key(VARUNA_TAU, VARUNA_S, D - 1, lagrange_size=n_h if lagrange else 0)
     return n, csr, z, zz, ck, D - 1
 
 
@@ -395,10 +395,9 @@ def varuna_prove(synth, torch, lg, reps=7, in_flight=4):
         ck.close()
 
 
-def varuna_prove_big(synth, lg):
-    """The same prover on a circuit the size of the headline MSM: key synthesis, one proof, eight instances in one proof (native entry points)."""
+def _varuna_big_once(synth, lg, bits, lagrange):
     from aleo_amd import varuna
-    t0 = time.perf_counter(); n, csr, z, zz, ck, D = _varuna_instance(synth, lg, 40 + lg); prep_s = time.perf_counter() - t0
+    t0 = time.perf_counter(); n, csr, z, zz, ck, D = _varuna_instance(synth, lg, 40 + lg, bits, lagrange); prep_s = time.perf_counter() - t0
     try:
         t0 = time.perf_counter(); nx = varuna.NativeCircuitIndex(csr, n, 4, len(z) - 4, ck); index_s = time.perf_counter() - t0
         try:
@@ -418,6 +417,15 @@ def varuna_prove_big(synth, lg):
             nx.close()
     finally:
         ck.close()
+
+
+def varuna_prove_big(synth, lg):
+    """The same prover on a circuit the size of the headline MSM: key synthesis, one proof, eight instances in one proof (native entry points) — on the
+    uniform synthetic circuit, and on the bit-heavy one with the Lagrange-basis powers pinned (commit_lagrange in the first round)."""
+    out = _varuna_big_once(synth, lg, False, False)
+    try: out['bit_heavy_witness_commit_lagrange'] = _varuna_big_once(synth, lg, True, True)
+    except Exception as e: out['bit_heavy_witness_commit_lagrange'] = {'error': repr(e)[:300]}
+    return out
 
 
 def varuna_cpu(synth, lg):
