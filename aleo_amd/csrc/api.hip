@@ -319,6 +319,19 @@ int32_t aleo_mi355x_bases_precompute(uint64_t handle) {
   } catch (...) { return ALEO_MI355X_ERR_HIP; }
 }
 
+int32_t aleo_mi355x_bases_precompute_range(uint64_t handle, size_t offset, size_t n, int32_t window_bits) {
+  try {
+    API_BEGIN
+    std::shared_ptr<PinnedOwner> keep; PinnedBases work; { int32_t rcb = find_bases(d, handle, &keep, &work); if (rcb) return rcb; }
+    { std::lock_guard<std::mutex> g(d->mu); if (keep->building) { g_last_error = "bases_precompute_range: a table build is in flight"; return ALEO_MI355X_ERR_BAD_ARG; } keep->building = true; work = keep->pb; }
+    int32_t rc = msm_precompute_range(c, &work, offset, n, window_bits);
+    std::lock_guard<std::mutex> g(d->mu);
+    keep->building = false;
+    if (rc == ALEO_MI355X_OK) { keep->pb.range = work.range; keep->pb.range_off = work.range_off; }
+    return rc;
+  } catch (...) { return ALEO_MI355X_ERR_HIP; }
+}
+
 int32_t aleo_mi355x_bases_info(uint64_t handle, uint64_t* out, int32_t cap) {
   try {
     if (!out || cap <= 0) return 0;
@@ -524,7 +537,7 @@ int32_t aleo_mi355x_kzg_commit_batch(void* out104, uint64_t handle, const void* 
 
 // SonicKZG10::commit shape: every commitment is a sum of segments (coefficient vector x base offset) over ONE pinned set.
 static int32_t commit_segments(Ctx* c, Device* d, void* out104, size_t n_out, uint64_t handle, const aleo_mi355x_commit_segment* segs, size_t n_segs,
-                               bool host_scalars, hipStream_t s) {
+                               bool host_scalars, hipStream_t s, bool sparse = false) {
   if (!n_out) return ALEO_MI355X_OK;
   if (!out104 || (!segs && n_segs) || n_out >= (1u << 20) || n_segs >= (1u << 22)) { g_last_error = "commit_segments: bad argument"; return ALEO_MI355X_ERR_BAD_ARG; }
   std::shared_ptr<PinnedOwner> keep; PinnedBases pb; { int32_t rcb = find_bases(d, handle, &keep, &pb); if (rcb) return rcb; }
@@ -542,7 +555,7 @@ static int32_t commit_segments(Ctx* c, Device* d, void* out104, size_t n_out, ui
     }
   }
   std::vector<uint64_t> jac(18 * n_out);
-  MsmJob j; j.segs = sg.data(); j.nseg = (uint32_t)n_segs; j.k = (uint32_t)n_out; j.mont = true;
+  MsmJob j; j.segs = sg.data(); j.nseg = (uint32_t)n_segs; j.k = (uint32_t)n_out; j.mont = true; j.sparse = sparse;
   if ((rc = msm_batch(c, jac.data(), pb, j, s))) return rc;
   jac_to_affine_rows(out104, jac.data(), n_out);
   return ALEO_MI355X_OK;
@@ -553,6 +566,10 @@ int32_t aleo_mi355x_kzg_commit_segments(void* out104, size_t n_out, uint64_t han
 }
 int32_t aleo_mi355x_kzg_commit_segments_device(void* out104, size_t n_out, uint64_t handle, const aleo_mi355x_commit_segment* segs, size_t n_segs, void* stream) {
   try { API_BEGIN PICK_STREAM(s) return commit_segments(c, d, out104, n_out, handle, segs, n_segs, false, s); } catch (...) { return ALEO_MI355X_ERR_HIP; }
+}
+
+int32_t aleo_mi355x_kzg_commit_segments_sparse_device(void* out104, size_t n_out, uint64_t handle, const aleo_mi355x_commit_segment* segs, size_t n_segs, void* stream) {
+  try { API_BEGIN PICK_STREAM(s) return commit_segments(c, d, out104, n_out, handle, segs, n_segs, false, s, true); } catch (...) { return ALEO_MI355X_ERR_HIP; }
 }
 
 int32_t aleo_mi355x_kzg_commit_hiding(void* out104, uint64_t h_powers, const void* coeffs, size_t n, uint64_t h_gamma, const void* blind, size_t m) {

@@ -68,6 +68,9 @@ struct PinnedBases {
   // Rows: W x cover x 112 bytes, row w holds 2^(c w) * P_i in the 28-bit-limb form (fp28.h); serves min_n <= n <= cover.
   struct PreTable { void* d = nullptr; int c = 0; size_t cover = 0, min_n = 0; };
   PreTable tab[3];
+  // optional table over ONE sub-range [range_off, range_off + range.cover) with a narrow window (aleo_mi355x_bases_precompute_range): MSMs whose
+  // scalars are mostly 0 / 1 (a witness in evaluation form against the Lagrange-basis powers) put too few points into the wide windows' buckets
+  PreTable range; size_t range_off = 0;
   bool tabled = false;         // msm_precompute has run (a set below 2^10 points gets no table)
   size_t n = 0;
 };
@@ -77,7 +80,7 @@ struct PinnedBases {
 // owner of a pinned set's HBM; calls hold a shared_ptr while they run, so an unpin from another thread cannot free it under them
 struct PinnedOwner {
   PinnedBases pb; bool building = false;     // building: a table build for this set is in flight on some slot
-  ~PinnedOwner() { if (pb.d_xy) (void)hipFree(pb.d_xy); if (pb.d_xy28) (void)hipFree(pb.d_xy28); if (pb.d_inf) (void)hipFree(pb.d_inf); for (auto& t : pb.tab) if (t.d) (void)hipFree(t.d); }
+  ~PinnedOwner() { if (pb.d_xy) (void)hipFree(pb.d_xy); if (pb.d_xy28) (void)hipFree(pb.d_xy28); if (pb.d_inf) (void)hipFree(pb.d_inf); for (auto& t : pb.tab) if (t.d) (void)hipFree(t.d); if (pb.range.d) (void)hipFree(pb.range.d); }
 };
 
 struct SrsCacheEntry {
@@ -136,7 +139,7 @@ int32_t ensure_host_pinned(Ctx* c, size_t bytes);
 //   sum_i scalar[i] * base[off + i],  i < len    (scalars at the DEVICE pointer d_ptr; the segment array itself is host memory).
 // k > 1 needs a table tier that covers every base reached and k <= msm_max_sets(); msm_batch() groups arbitrary requests accordingly.
 struct MsmSeg { const void* d_ptr = nullptr; size_t len = 0, off = 0; uint32_t out = 0; };
-struct MsmJob { const MsmSeg* segs = nullptr; uint32_t nseg = 0, k = 0; bool mont = false; };
+struct MsmJob { const MsmSeg* segs = nullptr; uint32_t nseg = 0, k = 0; bool mont = false; bool sparse = false; };      // sparse: hint — use the set's range table when every segment lies inside it
 int32_t msm_run(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, const MsmJob& job, hipStream_t s);
 inline int32_t msm_run1(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, const void* d_scalars, size_t n, bool mont, hipStream_t s) {
   MsmSeg g; g.d_ptr = d_scalars; g.len = n;
@@ -149,6 +152,7 @@ int32_t launch_fr_mul(Ctx* c, void* r, const void* a, const void* b, size_t n);
 int32_t generate_multiples(Ctx* c, const void* base104, uint64_t first, size_t n, PinnedBases* out);
 int32_t generate_from_scalars(Ctx* c, const void* base104, const void* scalars32, size_t n, PinnedBases* out);
 int32_t msm_precompute(Ctx* c, PinnedBases* pb);
+int32_t msm_precompute_range(Ctx* c, PinnedBases* pb, size_t off, size_t n, int window_bits);
 int32_t make_rows28(Ctx* c, PinnedBases* pb);          // fills pb->d_xy28 from pb->d_xy
 int32_t selftest_madd28(Ctx* c, uint32_t lanes, uint32_t steps, uint64_t seed, uint32_t* failures);
 // g2.hip

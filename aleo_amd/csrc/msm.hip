@@ -916,9 +916,17 @@ int32_t msm_run(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, const MsmJob
   // the fixed-base table serves any prefix of the pinned set (row stride = pinned count) as long as the prefix still
   // puts about one point into every bucket; shorter prefixes use the plain path with its small bucket count
   const PinnedBases::PreTable* T = nullptr;
-  for (const auto& t : pb.tab) if (t.d && n >= t.min_n && n <= t.cover) { T = &t; break; }
+  const uint8_t* d_inf = pb.d_inf;
+  bool ranged = job.sparse && pb.range.d != nullptr;       // the narrow-window table of one sub-range, when every segment lies inside it
+  for (uint32_t i = 0; ranged && i < segs.nseg; ++i) ranged = segs.off[i] >= pb.range_off && (size_t)segs.off[i] + segs.n[i] <= pb.range_off + pb.range.cover;
+  if (ranged) {
+    T = &pb.range; n = 0;
+    for (uint32_t i = 0; i < segs.nseg; ++i) { segs.off[i] -= (uint32_t)pb.range_off; n = (size_t)segs.off[i] + segs.n[i] > n ? (size_t)segs.off[i] + segs.n[i] : n; }
+    if (d_inf) d_inf += pb.range_off;
+  } else for (const auto& t : pb.tab) if (t.d && n >= t.min_n && n <= t.cover) { T = &t; break; }
   const bool pre = T != nullptr;
-  if (K > 1 && (!pre || K > msm_max_sets(pb, n))) { g_last_error = "msm: internal: batch without a table tier (or too many sets)"; return ALEO_MI355X_ERR_BAD_ARG; }
+  const uint32_t set_cap = ranged ? MAX_COARSE_ALL / ((1u << (pb.range.c - 1)) >> 8) : msm_max_sets(pb, n);
+  if (K > 1 && (!pre || K > (set_cap < MAX_SETS ? set_cap : MAX_SETS))) { g_last_error = "msm: internal: batch without a table tier (or too many sets)"; return ALEO_MI355X_ERR_BAD_ARG; }
   MsmPlan P = make_plan(pre ? n : pts, pre ? T->c : 0);
   if (pre) { P.W = K; P.M = K * P.B; }                       // after the sort a set is "a window with its own buckets"
   if (!pre && !pb.d_xy28) { g_last_error = "msm: pinned set without 28-bit rows"; return ALEO_MI355X_ERR_HIP; }
@@ -933,7 +941,7 @@ int32_t msm_run(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, const MsmJob
   const size_t vpoints = masked ? (size_t)K * setw + nchunks + (nseg + 1) + (size_t)nseg * (tseg / 2 + tseg / 4 + 2) : (size_t)nchunks + P.W;
   if ((rc = ensure_host_pinned(c, 64 + (size_t)(masked ? nseg : P.W) * 224))) return rc;      // before the sort phase: its read-back lands in this buffer
   SortPhase sp;
-  if ((rc = msm_sort_phase(c, segs, pts, job.mont, pb.d_inf, (uint32_t)(pre ? T->cover : pb.n), P, pre, s, &sp))) return rc;
+  if ((rc = msm_sort_phase(c, segs, pts, job.mont, d_inf, (uint32_t)(pre ? T->cover : pb.n), P, pre, s, &sp))) return rc;
   const uint32_t M = sp.M;
   if ((rc = c->partial.reserve(sp.slices_max * (pre ? 224 : 192)))) return rc;
   if ((rc = c->vbuf.reserve(vpoints * 224))) return rc;
@@ -1079,6 +1087,26 @@ int32_t msm_batch(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, const MsmJ
     if (g.out >= K) { g_last_error = "msm: segment names a result that does not exist"; return ALEO_MI355X_ERR_BAD_ARG; }
     if (!g.len) continue;
     reach[g.out] = g.off + g.len > reach[g.out] ? g.off + g.len : reach[g.out]; points[g.out] += g.len; nsegs[g.out]++;
+  }
+  // Sparse hint + a range table that holds every segment: chains of up to its set capacity, whatever the reach (the table is indexed from range_off)
+  if (job.sparse && pb.range.d) {
+    bool inside = true;
+    for (uint32_t q = 0; q < job.nseg && inside; ++q) { const MsmSeg& g = job.segs[q]; if (g.len) inside = g.off >= pb.range_off && g.off + g.len <= pb.range_off + pb.range.cover; }
+    if (inside) {
+      uint32_t cap = MAX_COARSE_ALL / ((1u << (pb.range.c - 1)) >> 8); cap = cap < MAX_SETS ? cap : MAX_SETS;
+      for (uint32_t q0 = 0; q0 < K;) {
+        uint32_t take = 0, sg = 0; size_t pts = 0;
+        while (q0 + take < K && take < cap && (take == 0 || (pts + points[q0 + take] <= ((size_t)1 << 26) && sg + nsegs[q0 + take] <= MAX_SEGS))) { pts += points[q0 + take]; sg += nsegs[q0 + take]; ++take; }
+        if (sg > MAX_SEGS) { g_last_error = "msm: one result with more than 64 segments"; return ALEO_MI355X_ERR_BAD_ARG; }
+        std::vector<MsmSeg> segs; segs.reserve(sg);
+        for (uint32_t q = 0; q < job.nseg; ++q) { const MsmSeg& g = job.segs[q]; if (g.len && g.out >= q0 && g.out < q0 + take) { MsmSeg h = g; h.out = g.out - q0; segs.push_back(h); } }
+        MsmJob g; g.segs = segs.data(); g.nseg = (uint32_t)segs.size(); g.k = take; g.mont = job.mont; g.sparse = true;
+        int32_t rc = msm_run(c, out_jac18 + 18 * (size_t)q0, pb, g, s);
+        if (rc) return rc;
+        q0 += take;
+      }
+      return ALEO_MI355X_OK;
+    }
   }
   // Latency-bound requests (one prover round: a few results of <= 2^17 points each): ONE launch chain on the tier that covers the
   // longest reach beats one chain per tier — a second chain costs ~0.45 ms of dependent steps, a wider window than a short member
@@ -1279,7 +1307,7 @@ int32_t make_rows28(Ctx* c, PinnedBases* pb) {
   return ALEO_MI355X_OK;
 }
 
-static int32_t build_table(Ctx* c, const PinnedBases* pb, int pre_c, size_t n, PinnedBases::PreTable* out) {
+static int32_t build_table(Ctx* c, const PinnedBases* pb, int pre_c, size_t n, PinnedBases::PreTable* out, size_t off = 0) {
   const uint32_t W = (SCALAR_BITS + pre_c - 1) / pre_c;
   if (n * (size_t)W >= (1ull << 31)) { g_last_error = "bases_precompute: table index would exceed 31 bits"; return ALEO_MI355X_ERR_BAD_ARG; }
   DevTmp tab, cur, prefix, row; int32_t rc;     // freed on every return path; tab is handed over at the end
@@ -1287,9 +1315,10 @@ static int32_t build_table(Ctx* c, const PinnedBases* pb, int pre_c, size_t n, P
   if ((rc = cur.alloc(n * 192)) || (rc = prefix.alloc(n * 48)) || (rc = row.alloc(n * 96))) return rc;
   hipStream_t s = c->stream;
   const uint32_t g = (uint32_t)((n + 255) / 256), lanes = (uint32_t)((n + GEN_K - 1) / GEN_K), gl = (lanes + 255) / 256;
-  if (pb->d_xy28) HIPCHK(hipMemcpyAsync(tab.p, pb->d_xy28, n * ROW28, hipMemcpyDeviceToDevice, s));
-  else hipLaunchKernelGGL(k_rows_to28, dim3(g), dim3(256), 0, s, (const char*)pb->d_xy, (char*)tab.p, (uint32_t)n);
-  hipLaunchKernelGGL(k_pre_init, dim3(g), dim3(256), 0, s, (const char*)pb->d_xy, (uint32_t)n, (char*)cur.p);
+  const char* xy = (const char*)pb->d_xy + off * 96;      // the table covers points [off, off + n) of the set
+  if (pb->d_xy28) HIPCHK(hipMemcpyAsync(tab.p, (const char*)pb->d_xy28 + off * ROW28, n * ROW28, hipMemcpyDeviceToDevice, s));
+  else hipLaunchKernelGGL(k_rows_to28, dim3(g), dim3(256), 0, s, xy, (char*)tab.p, (uint32_t)n);
+  hipLaunchKernelGGL(k_pre_init, dim3(g), dim3(256), 0, s, xy, (uint32_t)n, (char*)cur.p);
   for (uint32_t w = 1; w < W; ++w) {
     hipLaunchKernelGGL(k_pre_double, dim3(g), dim3(256), 0, s, (char*)cur.p, (uint32_t)n, win_width(pre_c, (int)w - 1));      // row w = 2^win_offset(w) * P
     hipLaunchKernelGGL(k_gen_normalize, dim3(gl), dim3(256), 0, s, (char*)cur.p, (uint32_t)n, (char*)prefix.p, (char*)row.p);
@@ -1326,6 +1355,15 @@ int32_t msm_precompute(Ctx* c, PinnedBases* pb) {
     return rc;
   }
   pb->tabled = true;
+  return ALEO_MI355X_OK;
+}
+
+int32_t msm_precompute_range(Ctx* c, PinnedBases* pb, size_t off, size_t n, int window_bits) {
+  if (pb->range.d) { g_last_error = "bases_precompute_range: this set already has a range table"; return ALEO_MI355X_ERR_BAD_ARG; }
+  if (!n || off + n > pb->n || (window_bits != 13 && window_bits != 16)) { g_last_error = "bases_precompute_range: bad range or window (13 or 16 bits)"; return ALEO_MI355X_ERR_BAD_ARG; }
+  int32_t rc = build_table(c, pb, window_bits, n, &pb->range, off);
+  if (rc) return rc;
+  pb->range.min_n = 0; pb->range_off = off;
   return ALEO_MI355X_OK;
 }
 

@@ -100,13 +100,14 @@ class SonicKZG10:
     """Mirror of sonic_pc::SonicKZG10::commit for the labelled polynomials of one round: one call, shared launches."""
 
     @staticmethod
-    def commit_segments_device(ck: 'CommitterKey', segments, k: int, stream: int = 0) -> np.ndarray:
+    def commit_segments_device(ck: 'CommitterKey', segments, k: int, stream: int = 0, sparse: bool = False) -> np.ndarray:
         """The general form: result q = sum over its segments of <device coefficient vector, bases[offset ..]>; segments: (ptr, len, offset, q).
         Used directly where a commitment mixes bases (commit_lagrange with a blinding term: evaluations against the Lagrange powers, the
         blinding scalar against v_H(tau) G, the hiding polynomial against the gamma powers)."""
         arr = (_Segment * max(len(segments), 1))(*[_Segment(int(p_), int(n_), int(o_), int(q_)) for p_, n_, o_, q_ in segments])
         out = np.zeros((k, 104), dtype=np.uint8)
-        check(lib().aleo_mi355x_kzg_commit_segments_device(_p(out), k, ck.bases.handle, arr, len(segments), ctypes.c_void_p(stream)), 'kzg_commit_segments_device')
+        fn = lib().aleo_mi355x_kzg_commit_segments_sparse_device if sparse else lib().aleo_mi355x_kzg_commit_segments_device      # sparse: hint, see bases_precompute_range
+        check(fn(_p(out), k, ck.bases.handle, arr, len(segments), ctypes.c_void_p(stream)), 'kzg_commit_segments_device')
         return out
 
     @staticmethod

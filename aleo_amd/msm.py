@@ -51,6 +51,11 @@ class PinnedBases:
         check(lib().aleo_mi355x_bases_precompute(self.handle), 'bases_precompute')
         return self
 
+    def precompute_range(self, offset: int, n: int, window_bits: int = 13) -> 'PinnedBases':
+        """A narrow-window table over points [offset, offset + n) for sparse (mostly 0 / 1) scalar vectors — see aleo_mi355x_bases_precompute_range."""
+        check(lib().aleo_mi355x_bases_precompute_range(self.handle, offset, n, window_bits), 'bases_precompute_range')
+        return self
+
     def info(self) -> dict:
         """Points and HBM footprint of the set: rows, fixed-base tables, window width of every table tier."""
         buf = (ctypes.c_uint64 * 8)()

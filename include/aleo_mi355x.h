@@ -102,6 +102,11 @@ int32_t aleo_mi355x_bases_precompute(uint64_t handle);
 /* What a pinned set holds in HBM: out[0] points, [1] bytes of the base rows (96-byte snarkVM rows + their 112-byte
  * 28-bit-limb copies), [2] bytes of the fixed-base tables, [3..5] window width c of each table tier (0 = none), [6] tiers.
  * Returns the number of values written (<= cap), 0 for an unknown handle. */
+/* A second, narrow-window table (window_bits 13 or 16) over ONE sub-range [offset, offset + n) of a pinned set, for MSMs whose scalars are mostly
+ * 0 / 1 — a witness committed in evaluation form against Lagrange-basis powers (KZG10::commit_lagrange): such vectors put hardly a point per bucket into
+ * the 2^19 buckets of the wide window, and a proof commits three of them per instance.  Used by aleo_mi355x_kzg_commit_segments_sparse_device (and by
+ * the prover's first round) when every segment of the call lies inside the range; up to 32 results share one launch chain.  One range per set. */
+int32_t aleo_mi355x_bases_precompute_range(uint64_t handle, size_t offset, size_t n, int32_t window_bits);
 int32_t aleo_mi355x_bases_info(uint64_t handle, uint64_t* out, int32_t cap);
 /* Copies pinned bases [offset, offset+n) back to the host as snarkVM Affine (stride 104). */
 int32_t aleo_mi355x_bases_download(uint64_t handle, size_t offset, size_t n, void* out_affine104);
@@ -169,6 +174,8 @@ int32_t aleo_mi355x_kzg_commit_batch(void* out_affine104, uint64_t handle, const
 typedef struct { const void* scalars; size_t len; size_t base_offset; uint32_t output; } aleo_mi355x_commit_segment;
 int32_t aleo_mi355x_kzg_commit_segments(void* out_affine104, size_t n_outputs, uint64_t handle, const aleo_mi355x_commit_segment* segments, size_t n_segments);
 int32_t aleo_mi355x_kzg_commit_segments_device(void* out_affine104, size_t n_outputs, uint64_t handle, const aleo_mi355x_commit_segment* segments, size_t n_segments, void* stream);
+/* the same with the hint that the scalars are sparse (mostly 0 / 1): served from the set's range table (bases_precompute_range) when all segments lie inside it */
+int32_t aleo_mi355x_kzg_commit_segments_sparse_device(void* out_affine104, size_t n_outputs, uint64_t handle, const aleo_mi355x_commit_segment* segments, size_t n_segments, void* stream);
 
 /* KZG10::commit with a hiding bound: msm(powers, coeffs) + msm(gamma_powers, blinding_coeffs), affine result.
  * Both coefficient vectors are Montgomery Fr on the host; both base sets are pinned handles. */

@@ -1154,3 +1154,28 @@ def test_batched_msm_two_sets_on_the_widest_window():
             assert (M.VariableBase.msm_device(pb, d[i].data_ptr(), m) == got[i]).all(), (i, m)
         got2 = M.VariableBase.msm_batch_device(pb, [d[0].data_ptr(), d[2].data_ptr()], [lens[0], lens[2]])      # exactly one two-set chain
         assert (got2[0] == got[0]).all() and (got2[1] == got[2]).all()
+
+
+def test_range_table_serves_sparse_commitments():
+    """aleo_mi355x_bases_precompute_range + the sparse hint: results whose segments all lie inside the range come from the narrow-window table (here 9 results in
+    one chain, witness-like and uniform members, a 1-element segment, unequal lengths) and equal the ordinary path's bit for bit; a call with a segment outside
+    the range, and a call without the hint, are served the ordinary way; a second range on the same set is refused."""
+    import torch
+    from aleo_amd.kzg import CommitterKey, SonicKZG10
+    N = 1 << 18; off = (1 << 17) + 3; rn = (1 << 16) + 77
+    with M.PinnedBases.generate_multiples(synth.generator_affine104(), 1, N) as pb:
+        pb.precompute(); pb.precompute_range(off, rn, 13)
+        with pytest.raises(aleo_amd.AleoMi355xError): pb.precompute_range(0, 1024, 13)
+        ck = CommitterKey.__new__(CommitterKey); ck.bases = pb; ck.max_degree = N - 1; ck.gamma_offset = 0; ck.n_gamma = 0
+        lens = [rn - 1, 1 << 15, 40000, 5, rn - 1, 3000, 1 << 16, 1, 777]
+        S = [util.witness_like_scalars(m, 34000 + i) if i % 3 else util.uniform_scalars(m, 34000 + i) for i, m in enumerate(lens)]
+        d = [torch.from_numpy(c.fr_to_mont(x).view(np.int64).copy()).cuda() for x in S]; torch.cuda.synchronize()
+        one = torch.from_numpy(c.fr_to_mont(util.uniform_scalars(1, 34100)).view(np.int64).copy()).cuda()
+        segs = [(d[q].data_ptr(), lens[q], off, q) for q in range(9)] + [(one.data_ptr(), 1, off + rn - 1, 0), (one.data_ptr(), 1, off + rn - 1, 4)]
+        want = SonicKZG10.commit_segments_device(ck, segs, 9)
+        got = SonicKZG10.commit_segments_device(ck, segs, 9, sparse=True)
+        assert (got == want).all()
+        k0 = (synth.weighted_scalar_sum(S[3], off + 1)) % p.FR_MODULUS                    # bases are (i+1) G: result 3 is sum s_j (off + 1 + j) G
+        assert c.affine_to_ints(got[3].reshape(1, 104))[0] == p.g1_mul(p.G1_GENERATOR, k0)
+        outside = segs + [(one.data_ptr(), 1, 5, 2)]                                       # one segment outside the range: the whole call goes the ordinary way
+        assert (SonicKZG10.commit_segments_device(ck, outside, 9, sparse=True) == SonicKZG10.commit_segments_device(ck, outside, 9)).all()
