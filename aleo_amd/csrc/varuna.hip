@@ -123,9 +123,9 @@ double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::
 thread_local double g_varuna_timing[8] = {};
 
 
-static int32_t commit(Ctx* c, const PinnedBases& pb, const std::vector<MsmSeg>& segs, uint32_t k, uint8_t* out104, hipStream_t s) {
+static int32_t commit(Ctx* c, const PinnedBases& pb, const std::vector<MsmSeg>& segs, uint32_t k, uint8_t* out104, hipStream_t s, bool sparse = false) {
   std::vector<uint64_t> jac(18 * (size_t)k);
-  MsmJob j; j.segs = segs.data(); j.nseg = (uint32_t)segs.size(); j.k = k; j.mont = true;
+  MsmJob j; j.segs = segs.data(); j.nseg = (uint32_t)segs.size(); j.k = k; j.mont = true; j.sparse = sparse;
   const double t0 = now_ms();
   RC(msm_batch(c, jac.data(), pb, j, s));
   jacobian_rows_to_affine104(out104, jac.data(), k);
@@ -392,16 +392,22 @@ int32_t Prover::first_round(const void* const* assignments) {
   HIPCHK(hipMemcpyAsync(bl, stage + k * n_x * 32, blind.size() * 32, hipMemcpyHostToDevice, s));
   wit_aff.assign(104 * (3 * k + 1), 0); comp.assign(48 * 8, 0);
   {
-    std::vector<MsmSeg> sg;
+    // with the evaluations against the Lagrange powers AND a narrow-window table over [hiding powers | Lagrange powers | v_H G] the 3k witness
+    // commitments are one sparse chain (their scalars are mostly 0 / 1), the mask (uniform coefficients against the monomial powers) another
+    const bool split = lagrange && pb.range.d && pb.range_off <= ix.gamma_offset && ix.lagrange_offset + n_h + 1 <= pb.range_off + pb.range.cover &&
+                       ix.gamma_offset + HC <= pb.range_off + pb.range.cover;
+    std::vector<MsmSeg> sg, sm;
     for (size_t q = 0; q <= 3 * k; ++q) {
-      MsmSeg a; a.out = (uint32_t)q;
+      std::vector<MsmSeg>& dst = (split && q == 3 * k) ? sm : sg;
+      MsmSeg a; a.out = (split && q == 3 * k) ? 0u : (uint32_t)q;
       if (q < 3 * k && lagrange) {                                                            // sum_i evals_i L_i(tau) G + rho v_H(tau) G
-        a.d_ptr = evals_h + q * n_h * 32; a.len = n_h; a.off = ix.lagrange_offset; sg.push_back(a);
-        MsmSeg v; v.d_ptr = rho_dev + q * 32; v.len = 1; v.off = ix.lagrange_offset + n_h; v.out = (uint32_t)q; sg.push_back(v);
-      } else { a.d_ptr = q < 3 * k ? wit + q * L * 32 : mask; a.len = q < 3 * k ? L : 3 * n_h; a.off = 0; sg.push_back(a); }
-      MsmSeg b; b.d_ptr = bl + q * HC * 32; b.len = HC; b.off = ix.gamma_offset; b.out = (uint32_t)q; sg.push_back(b);
+        a.d_ptr = evals_h + q * n_h * 32; a.len = n_h; a.off = ix.lagrange_offset; dst.push_back(a);
+        MsmSeg v; v.d_ptr = rho_dev + q * 32; v.len = 1; v.off = ix.lagrange_offset + n_h; v.out = a.out; dst.push_back(v);
+      } else { a.d_ptr = q < 3 * k ? wit + q * L * 32 : mask; a.len = q < 3 * k ? L : 3 * n_h; a.off = 0; dst.push_back(a); }
+      MsmSeg b; b.d_ptr = bl + q * HC * 32; b.len = HC; b.off = ix.gamma_offset; b.out = a.out; dst.push_back(b);
     }
-    RC(commit(c, pb, sg, (uint32_t)(3 * k + 1), wit_aff.data(), s));
+    if (split) { RC(commit(c, pb, sg, (uint32_t)(3 * k), wit_aff.data(), s, true)); RC(commit(c, pb, sm, 1, wit_aff.data() + 104 * 3 * k, s)); }
+    else RC(commit(c, pb, sg, (uint32_t)(3 * k + 1), wit_aff.data(), s));
   }
   std::vector<uint8_t> c1(48 * (3 * k + 1));
   RC(aleo_mi355x_g1_compress(c1.data(), wit_aff.data(), 3 * k + 1));

@@ -77,7 +77,7 @@ class _Segment(ctypes.Structure):
 
 
 class CommitterKey:
-    lagrange_offset = 0; lagrange_size = 0      # > 0: the set also holds the Lagrange-basis powers of one domain (varuna.synthetic_committer_key)
+    sparse_range = False; lagrange_offset = 0; lagrange_size = 0      # > 0: the set also holds the Lagrange-basis powers of one domain (varuna.synthetic_committer_key)
     """Mirror of sonic_pc::CommitterKey [UPSTREAM-RECALL]: powers_of_beta_g, powers_of_beta_times_gamma_g, max_degree.  Both power
     arrays are pinned as ONE resident set (powers | gamma powers), so a hiding commitment is a single sum of segments."""
 

@@ -63,7 +63,7 @@ class Transcript:
         return int.from_bytes(self.state, 'little') % R
 
 
-def synthetic_committer_key(tau: int, s_gamma: int, max_degree: int, n_gamma: int = HIDING_COEFFS, lagrange_size: int = 0) -> CommitterKey:
+def synthetic_committer_key(tau: int, s_gamma: int, max_degree: int, n_gamma: int = HIDING_COEFFS, lagrange_size: int = 0, range_window: int = 0) -> CommitterKey:
     """powers τ^i·G (i <= max_degree), then the hiding powers s·τ^i·G, then — for lagrange_size = |H| > 0 — the Lagrange-basis powers L_i(τ)·G of
     the domain H followed by v_H(τ)·G [UPSTREAM-RECALL: CommitterKey::lagrange_bases_at_beta_g]; built in HBM (SURVEY.md §8d: SRS-shaped bases)."""
     n_l = lagrange_size + 1 if lagrange_size else 0
@@ -91,6 +91,9 @@ def synthetic_committer_key(tau: int, s_gamma: int, max_degree: int, n_gamma: in
     ck.max_degree, ck.gamma_offset, ck.n_gamma = max_degree, max_degree + 1, n_gamma
     ck.lagrange_offset = max_degree + 1 + n_gamma if lagrange_size else 0; ck.lagrange_size = lagrange_size
     ck.bases = PinnedBases.from_scalars(synth.generator_affine104(), sc).precompute()
+    ck.sparse_range = False
+    if lagrange_size and range_window:      # narrow-window table over [hiding powers | Lagrange powers | v_H G]: the first round's witness commitments as one sparse chain
+        ck.bases.precompute_range(ck.gamma_offset, n_gamma + lagrange_size + 1, range_window); ck.sparse_range = True
     return ck
 
 
@@ -396,8 +399,12 @@ class Prover:
             if lagrange: segs += [(evals_h.ptr(q * n_h), n_h, ix.ck.lagrange_offset, q), (rho_dev.ptr(q), 1, ix.ck.lagrange_offset + n_h, q)]   # sum_i evals_i L_i(tau) G + rho v_H(tau) G
             else: segs.append((self.wit.ptr(q * L), L, 0, q))
             segs.append((bl.ptr(HIDING_COEFFS * q), HIDING_COEFFS, ix.ck.gamma_offset, q))
-        segs += [(self.mask.ptr(), 3 * n_h, 0, 3 * k), (bl.ptr(HIDING_COEFFS * 3 * k), HIDING_COEFFS, ix.ck.gamma_offset, 3 * k)]
-        out = SonicKZG10.commit_segments_device(ix.ck, segs, 3 * k + 1, s)
+        if lagrange and getattr(ix.ck, 'sparse_range', False):                          # the witness commitments as one sparse chain, the mask as another
+            out = np.concatenate([SonicKZG10.commit_segments_device(ix.ck, segs, 3 * k, s, sparse=True),
+                                  SonicKZG10.commit_segments_device(ix.ck, [(self.mask.ptr(), 3 * n_h, 0, 0), (bl.ptr(HIDING_COEFFS * 3 * k), HIDING_COEFFS, ix.ck.gamma_offset, 0)], 1, s)])
+        else:
+            segs += [(self.mask.ptr(), 3 * n_h, 0, 3 * k), (bl.ptr(HIDING_COEFFS * 3 * k), HIDING_COEFFS, ix.ck.gamma_offset, 3 * k)]
+            out = SonicKZG10.commit_segments_device(ix.ck, segs, 3 * k + 1, s)
         self.witness_commitments = out[:3 * k]; self.c['mask'] = out[3 * k]
         self.tr.absorb(ix.vk_bytes); self.tr.absorb(b''.join(_fr_bytes(v) for xe in self.x_evals for v in xe))
         self.tr.absorb(wire.g1_compress(out).tobytes())

@@ -329,8 +329,8 @@ def test_device_provers_reproduce_the_frozen_proofs():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('k', [1, 3])
-def test_commit_lagrange_in_the_first_round(k):
+@pytest.mark.parametrize('k,range_window', [(1, 0), (3, 0), (2, 13), (8, 13)])
+def test_commit_lagrange_in_the_first_round(k, range_window):
     """With the Lagrange-basis powers of H pinned behind the key, w, z_a, z_b are committed from their evaluations (KZG10::commit_lagrange with the
     blinding term against v_H(tau) G): the same group elements, hence the same proof bytes as the restatement's; bit-heavy circuit."""
     from aleo_amd import varuna
@@ -342,9 +342,9 @@ def test_commit_lagrange_in_the_first_round(k):
     _, want = V.prove(idx, setup, zs, _rand(c, 640 + k, k))
     assert V.verify(idx, setup, [q[:3] for q in zs], want)
     zq = [np.stack([synth.int_to_limbs(v, 4) for v in q]) for q in zs]
-    ck = varuna.synthetic_committer_key(TAU, S_GAMMA, D, lagrange_size=c.n_h)
+    ck = varuna.synthetic_committer_key(TAU, S_GAMMA, D, lagrange_size=c.n_h, range_window=range_window)      # with a window: the witness commitments as a sparse chain
     try:
-        assert ck.lagrange_offset == D + 1 + 3
+        assert ck.lagrange_offset == D + 1 + 3 and ck.sparse_range == bool(range_window)
         with varuna.NativeCircuitIndex(csr, 500, 3, len(z) - 3, ck) as nx: assert nx.vk_bytes == idx.vk_bytes() and nx.prove(zq, 640 + k) == want
         ix = varuna.CircuitIndex(csr, 500, 3, len(z) - 3, ck)
         assert varuna.native_index(ix).lagrange_offset == ck.lagrange_offset
