@@ -344,7 +344,7 @@ def _varuna_instance(synth, lg, seed, bits=False, lagrange=False):
     while n_h < max(n, 4 + len(z) - 4, 8): n_h *= 2
     D = 1
     while D < max(3 * n_h, n_k): D *= 2
-    ck = varuna.synthetic_committer_key(VARUNA_TAU, VARUNA_S, D - 1, lagrange_size=n_h if lagrange else 0)
+    ck = varuna.synthetic_committer_key(VARUNA_TAU, VARUNA_S, D - 1, lagrange_size=n_h if lagrange else 0, range_window=(16 if n_h >= (1 << 18) else 13) if lagrange else 0)
     return n, csr, z, zz, ck, D - 1
 
 

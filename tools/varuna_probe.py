@@ -7,7 +7,7 @@ from aleo_amd import synth, varuna
 
 TAU, S_GAMMA = 0x1F3A9C0D5E7B24681357ACE02468BDF013579BDF02468ACE1234567, 0x0FEDCBA9876543210123456789ABCDEF55AA
 torch.cuda.set_device(0)
-BITS = '--bits' in sys.argv; LAGRANGE = '--lagrange' in sys.argv      # bit-heavy witness; Lagrange-basis powers pinned (commit_lagrange in round 1)
+BITS = '--bits' in sys.argv; LAGRANGE = '--lagrange' in sys.argv; RANGE = -1 if '--range' in sys.argv else 0      # -1: 16-bit window from 2^18 constraints, 13 below      # bit-heavy witness; Lagrange-basis powers pinned (commit_lagrange in round 1)
 for lg in [int(a) for a in sys.argv[1:] if not a.startswith('--')] or [13, 15, 16]:
     n = (1 << lg) - 64
     csr, z = synth.synthetic_r1cs_bits(n, 4, 40 + lg) if BITS else synth.synthetic_r1cs(n, 4, 40 + lg, long_rows=4)
@@ -16,7 +16,7 @@ for lg in [int(a) for a in sys.argv[1:] if not a.startswith('--')] or [13, 15, 1
     while n_k < nnz: n_k *= 2
     D = 1
     while D < max(3 << lg, n_k): D *= 2
-    t0 = time.perf_counter(); ck = varuna.synthetic_committer_key(TAU, S_GAMMA, D - 1, lagrange_size=(1 << lg) if LAGRANGE else 0); t1 = time.perf_counter()
+    t0 = time.perf_counter(); ck = varuna.synthetic_committer_key(TAU, S_GAMMA, D - 1, lagrange_size=(1 << lg) if LAGRANGE else 0, range_window=(16 if lg >= 18 else 13) if RANGE else 0); t1 = time.perf_counter()
     ix = varuna.CircuitIndex(csr, n, 4, len(z) - 4, ck); t2 = time.perf_counter()
     ts, rounds = [], []
     for rep in range(7):
@@ -55,6 +55,6 @@ for lg in [int(a) for a in sys.argv[1:] if not a.startswith('--')] or [13, 15, 1
             for x in th: x.join()
             dt = time.perf_counter() - t
         conc[str(T)] = {'proofs_per_s': T * per / dt, 'constraints_per_s': n * T * per / dt}
-    print(json.dumps({'lg_constraints': lg, 'bits': BITS, 'lagrange': LAGRANGE, 'native': native, 'instances': batch, 'in_flight': conc, 'constraints': n, 'n_h': ix.n_h, 'n_k': ix.n_k, 'setup_s': t1 - t0, 'index_s': t2 - t1, 'prove_ms': med,
+    print(json.dumps({'lg_constraints': lg, 'bits': BITS, 'lagrange': LAGRANGE, 'range_window': RANGE, 'native': native, 'instances': batch, 'in_flight': conc, 'constraints': n, 'n_h': ix.n_h, 'n_k': ix.n_k, 'setup_s': t1 - t0, 'index_s': t2 - t1, 'prove_ms': med,
                       'constraints_per_s': n / med * 1e3, 'rounds_ms': {k: float(np.median([r[k] for r in rounds[2:]])) for k in rounds[0]}}), flush=True)
     ck.close()
