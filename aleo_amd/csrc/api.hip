@@ -153,11 +153,20 @@ static int32_t precompute_once(Ctx* c, const std::shared_ptr<PinnedOwner>& o) {
   return rc;
 }
 
+// Canonical host scalars whose sample is mostly 0 / 1 / short (a witness: SURVEY.md §8d "witness-like") take the set's range table when it has one
+// and covers the call: 257 scalars spread over the vector, sparse = at least half of them below 2^32.
+static bool looks_sparse(const void* scalars, size_t n) {
+  if (n < 4096) return false;
+  const uint64_t* s = (const uint64_t*)scalars; size_t small = 0; const size_t step = n / 257;
+  for (size_t i = 0; i < 257; ++i) { const uint64_t* v = s + 4 * (i * step); small += (v[1] | v[2] | v[3]) == 0 && v[0] < (1ull << 32); }
+  return small >= 129;
+}
 static int32_t msm_host_scalars(Ctx* c, void* out, const PinnedBases& pb, const void* scalars, size_t n, bool mont) {
   int32_t rc;
   if ((rc = c->scalars_stage.reserve((n ? n : 1) * 32))) return rc;
+  const bool sparse = !mont && pb.range.d && pb.range_off == 0 && n <= pb.range.cover && looks_sparse(scalars, n);
   if (n) HIPCHK(hipMemcpyAsync(c->scalars_stage.p, scalars, n * 32, hipMemcpyHostToDevice, c->stream));
-  return msm_run1(c, (uint64_t*)out, pb, c->scalars_stage.p, n, mont, c->stream);
+  return msm_run1(c, (uint64_t*)out, pb, c->scalars_stage.p, n, mont, c->stream, sparse);
 }
 
 // ---- SRS cache for the one-shot entry point ----------------------------------------------------------
@@ -403,6 +412,16 @@ int32_t aleo_mi355x_msm_g1_device(void* out, uint64_t handle, const void* d_scal
     FIND_BASES(handle)
     PICK_STREAM(s)
     return msm_run1(c, (uint64_t*)out, pb, d_scalars, n, false, s);
+  } catch (...) { return ALEO_MI355X_ERR_HIP; }
+}
+
+int32_t aleo_mi355x_msm_g1_device_sparse(void* out, uint64_t handle, const void* d_scalars, size_t n, void* stream) {
+  try {
+    if (!out || (!d_scalars && n)) { g_last_error = "msm_g1_device_sparse: bad argument"; return ALEO_MI355X_ERR_BAD_ARG; }
+    API_BEGIN
+    FIND_BASES(handle)
+    PICK_STREAM(s)
+    return msm_run1(c, (uint64_t*)out, pb, d_scalars, n, false, s, true);
   } catch (...) { return ALEO_MI355X_ERR_HIP; }
 }
 

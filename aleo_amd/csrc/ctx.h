@@ -141,9 +141,9 @@ int32_t ensure_host_pinned(Ctx* c, size_t bytes);
 struct MsmSeg { const void* d_ptr = nullptr; size_t len = 0, off = 0; uint32_t out = 0; };
 struct MsmJob { const MsmSeg* segs = nullptr; uint32_t nseg = 0, k = 0; bool mont = false; bool sparse = false; };      // sparse: hint — use the set's range table when every segment lies inside it
 int32_t msm_run(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, const MsmJob& job, hipStream_t s);
-inline int32_t msm_run1(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, const void* d_scalars, size_t n, bool mont, hipStream_t s) {
+inline int32_t msm_run1(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, const void* d_scalars, size_t n, bool mont, hipStream_t s, bool sparse = false) {
   MsmSeg g; g.d_ptr = d_scalars; g.len = n;
-  MsmJob j; j.segs = &g; j.nseg = 1; j.k = 1; j.mont = mont; return msm_run(c, out_jac18, pb, j, s);
+  MsmJob j; j.segs = &g; j.nseg = 1; j.k = 1; j.mont = mont; j.sparse = sparse; return msm_run(c, out_jac18, pb, j, s);
 }
 int32_t msm_batch(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, const MsmJob& job, hipStream_t s);
 uint32_t msm_max_sets(const PinnedBases& pb, size_t n);

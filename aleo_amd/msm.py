@@ -97,11 +97,11 @@ class VariableBase:
         return out
 
     @staticmethod
-    def msm_device(bases: PinnedBases, d_scalars_ptr: int, n: int, stream: int = 0) -> np.ndarray:
-        """Scalars already in HBM (device pointer, e.g. torch tensor .data_ptr())."""
+    def msm_device(bases: PinnedBases, d_scalars_ptr: int, n: int, stream: int = 0, sparse: bool = False) -> np.ndarray:
+        """Scalars already in HBM (device pointer, e.g. torch tensor .data_ptr()).  sparse: the hint that they are witness-like (range table)."""
         out = np.zeros(18, dtype=np.uint64)
-        check(lib().aleo_mi355x_msm_g1_device(_p(out), bases.handle, ctypes.c_void_p(d_scalars_ptr), n,
-                                              ctypes.c_void_p(stream)), 'msm_g1_device')
+        fn = lib().aleo_mi355x_msm_g1_device_sparse if sparse else lib().aleo_mi355x_msm_g1_device
+        check(fn(_p(out), bases.handle, ctypes.c_void_p(d_scalars_ptr), n, ctypes.c_void_p(stream)), 'msm_g1_device')
         return out
 
 

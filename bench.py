@@ -147,6 +147,24 @@ def main():
             dt = timed(lambda: aleo_amd.VariableBase.msm(pb2, scalars))
             variants['value_no_table'] = n / dt; variants['ms_no_table'] = dt * 1e3
             pb2.close()
+        if world == 1 and not args.no_precompute and n <= (1 << 22):
+            # witness-like scalars (60 % zero, 20 % one, 10 % < 2^16, 10 % uniform), resident: on the wide window, and on a 16-bit range
+            # table over the whole set with the sparse hint (bases_precompute_range; built after every number above was taken)
+            ws = synth.witness_like_scalars(n, 0xA1E00002); d_ws = torch.from_numpy(ws.view(np.int64)).to(dev); torch.cuda.synchronize()
+            def timed_w(fn):
+                r0 = fn(); torch.cuda.synchronize(); t0 = time.perf_counter()
+                for _ in range(reps): r_ = fn()
+                dt_ = (time.perf_counter() - t0) / reps
+                if not (np.asarray(r_) == np.asarray(r0)).all(): raise SystemExit('bench: unstable witness-like result')
+                return dt_, r0
+            dt_wide, r_wide = timed_w(lambda: aleo_amd.VariableBase.msm_device(pb, d_ws.data_ptr(), n))
+            t0 = time.perf_counter(); pb.precompute_range(0, n, 16); range_s = time.perf_counter() - t0
+            dt_rng, r_rng = timed_w(lambda: aleo_amd.VariableBase.msm_device(pb, d_ws.data_ptr(), n, sparse=True))
+            dt_host, r_host = timed_w(lambda: aleo_amd.VariableBase.msm(pb, ws))
+            if not ((np.asarray(r_wide) == np.asarray(r_rng)).all() and (np.asarray(r_wide) == np.asarray(r_host)).all()): raise SystemExit('bench: the range table changes the result')
+            variants['witness_like'] = {'ms_resident_wide_window': dt_wide * 1e3, 'ms_resident_range_table': dt_rng * 1e3, 'ms_host_scalars_range_table': dt_host * 1e3,
+                                        'value_resident_range_table': n / dt_rng, 'range_table_build_s': range_s, 'range_table_window_bits': 16}
+            del d_ws
         del d_scalars
 
     if rank == 0:

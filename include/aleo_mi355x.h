@@ -117,6 +117,10 @@ int32_t aleo_mi355x_msm_g1_pinned(void* out_jacobian, uint64_t handle, const voi
  * NULL = the stream of the library slot serving the call, which is NOT ordered with the caller's other streams — a caller
  * whose data was produced on the legacy default stream passes hipStreamLegacy. */
 int32_t aleo_mi355x_msm_g1_device(void* out_jacobian, uint64_t handle, const void* d_scalars, size_t n, void* stream);
+/* The same with the hint that the scalars are witness-like (mostly 0 / 1 / short): served from the set's range table (bases_precompute_range) when the call
+ * lies inside it, otherwise exactly like msm_g1_device.  The host-scalar call msm_g1_pinned looks at 257 of its scalars and takes the hint by itself
+ * when the range table starts at point 0. */
+int32_t aleo_mi355x_msm_g1_device_sparse(void* out_jacobian, uint64_t handle, const void* d_scalars, size_t n, void* stream);
 /* Sum of `count` Jacobian points (144 bytes each, host memory): the local group-add that follows the
  * all-gather of per-GPU partial MSM results.  Result affine-normalised as above. */
 int32_t aleo_mi355x_g1_sum(void* out_jacobian, const void* jacobian_points, size_t count);

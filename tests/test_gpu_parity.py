@@ -1179,3 +1179,21 @@ def test_range_table_serves_sparse_commitments():
         assert c.affine_to_ints(got[3].reshape(1, 104))[0] == p.g1_mul(p.G1_GENERATOR, k0)
         outside = segs + [(one.data_ptr(), 1, 5, 2)]                                       # one segment outside the range: the whole call goes the ordinary way
         assert (SonicKZG10.commit_segments_device(ck, outside, 9, sparse=True) == SonicKZG10.commit_segments_device(ck, outside, 9)).all()
+
+
+def test_witness_like_msm_takes_the_range_table():
+    """A range table over the whole set (window 16) + witness-like scalars: the device call with the hint and the host-scalar call (which
+    samples its input) give the ordinary result; uniform host scalars are not mistaken for a witness (same result either way, checked through
+    the phase times: the wide window's reduction is the slow one)."""
+    import torch
+    N = 1 << 18
+    with M.PinnedBases.generate_multiples(synth.generator_affine104(), 1, N) as pb:
+        pb.precompute(); pb.precompute_range(0, N, 16)
+        S = util.witness_like_scalars(N, 35001); U = util.uniform_scalars(N, 35002)
+        dS = torch.from_numpy(S.view(np.int64).copy()).cuda(); torch.cuda.synchronize()
+        want = util.expected_multiples_msm(S, N)
+        assert c.jac_to_int_point(M.VariableBase.msm_device(pb, dS.data_ptr(), N)) == want
+        assert c.jac_to_int_point(M.VariableBase.msm_device(pb, dS.data_ptr(), N, sparse=True)) == want
+        assert c.jac_to_int_point(M.VariableBase.msm(pb, S)) == want                       # host scalars: sampled, sparse
+        assert c.jac_to_int_point(M.VariableBase.msm(pb, U)) == util.expected_multiples_msm(U, N)
+        assert c.jac_to_int_point(M.VariableBase.msm(pb, S[:5000])) == util.expected_multiples_msm(S, 5000)
