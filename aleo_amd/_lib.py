@@ -22,7 +22,12 @@ EXPORTS = [
 
 
 class AleoMi355xError(RuntimeError):
-    pass
+    status = None
+
+
+class UnsatisfiedAssignment(AleoMi355xError):
+    """ALEO_MI355X_ERR_UNSATISFIED: a prover was handed an assignment that does not satisfy its circuit."""
+    status = 6
 
 
 _LIB = None
@@ -120,5 +125,7 @@ def lib():
 def check(status: int, what: str):
     if status != 0:
         L = lib()
-        raise AleoMi355xError(f'{what}: {L.aleo_mi355x_strerror(status).decode()} '
-                              f'[{L.aleo_mi355x_last_error().decode()}]')
+        e = (UnsatisfiedAssignment if status == UnsatisfiedAssignment.status else AleoMi355xError)(
+            f'{what}: {L.aleo_mi355x_strerror(status).decode()} [{L.aleo_mi355x_last_error().decode()}]')
+        e.status = status
+        raise e

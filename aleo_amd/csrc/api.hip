@@ -894,6 +894,7 @@ const char* aleo_mi355x_strerror(int32_t status) {
     case ALEO_MI355X_ERR_HIP: return "HIP runtime error";
     case ALEO_MI355X_ERR_BAD_HANDLE: return "unknown handle";
     case ALEO_MI355X_ERR_OOM: return "out of device memory";
+    case ALEO_MI355X_ERR_UNSATISFIED: return "assignment does not satisfy the circuit";
     default: return "unknown status";
   }
 }

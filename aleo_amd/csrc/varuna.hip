@@ -454,11 +454,16 @@ int32_t Prover::second_round() {
   HIPCHK(hipMemcpyAsync(h1 + n_h * 32, q1 + 2 * n_h * 32, n_h * 32, hipMemcpyDeviceToDevice, s));   // quotient blocks: p2, p1 + p2; remainder p0 + p1 + p2
   RC(fr_vec_op(c, h1, q1 + n_h * 32, q1 + 2 * n_h * 32, n_h, 1, s));
   RC(fr_vec_op(c, g1, q1, h1, n_h, 1, s));
+  HIPCHK(hipMemcpyAsync(pin_small + 3584, g1, 32, hipMemcpyDeviceToHost, s));               // the sum over H (remainder's constant term): read with the commitments
   {
     std::vector<MsmSeg> sg(2);
     sg[0].d_ptr = g1 + 32; sg[0].len = n_h - 1; sg[0].off = D - (n_h - 2); sg[0].out = 0;    // degree bound |H| − 2: shifted powers
     sg[1].d_ptr = h1; sg[1].len = 2 * n_h; sg[1].off = 0; sg[1].out = 1;
     RC(commit(c, pb, sg, 2, aff2, s));
+  }
+  {                                                                                         // commit() returned after the stream drained: the copy above has landed
+    uint64_t sum[4]; std::memcpy(sum, pin_small + 3584, 32);
+    if (sum[0] | sum[1] | sum[2] | sum[3]) { g_last_error = "varuna_prove: the assignment does not satisfy the circuit (first sumcheck: the sum over H is not zero)"; return ALEO_MI355X_ERR_UNSATISFIED; }
   }
   RC(aleo_mi355x_g1_compress(comp.data(), aff2, 2)); tr.absorb(comp.data(), 96);
   beta = tr.challenge("beta", 4);

@@ -14,7 +14,7 @@ import hashlib
 import numpy as np
 import torch
 from . import synth, wire
-from ._lib import lib, check
+from ._lib import lib, check, UnsatisfiedAssignment
 from .fft import EvaluationDomain, FORWARD, INVERSE
 from .kzg import CommitterKey, SonicKZG10, KZG10
 from .msm import PinnedBases
@@ -449,6 +449,8 @@ class Prover:
         fr_vec_op_device(self.h1.ptr(), p1, p2, n_h, OP_ADD, s)
         fr_vec_op_device(self.g1.ptr(), p0, self.h1.ptr(), n_h, OP_ADD, s)             # remainder; its constant term is the sum over H / |H| = 0
         out = SonicKZG10.commit(ix.ck, [((self.g1.ptr(1), n_h - 1), n_h - 2, None), ((self.h1.ptr(), 2 * n_h), None, None)], device=True, stream=s)
+        if self.g1.host(0, 1).any():                                                   # after the commitments (the stream has drained): 32 bytes
+            raise UnsatisfiedAssignment('the assignment does not satisfy the circuit (first sumcheck: the sum over H is not zero)')
         self.c['g_1'], self.c['h_1'] = out[0], out[1]
         self.tr.absorb(wire.g1_compress(out).tobytes())
         self.beta = self.tr.challenge(b'beta')

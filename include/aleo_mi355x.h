@@ -56,6 +56,7 @@ extern "C" {
 #define ALEO_MI355X_ERR_HIP 3            /* a HIP call failed; see aleo_mi355x_last_error() */
 #define ALEO_MI355X_ERR_BAD_HANDLE 4
 #define ALEO_MI355X_ERR_OOM 5
+#define ALEO_MI355X_ERR_UNSATISFIED 6  /* varuna_prove*: an assignment does not satisfy its circuit (upstream: the synthesiser's is_satisfied check) */
 
 /* NTT enums: mirror snarkvm_algorithms_cuda::{NTTInputOutputOrder, NTTDirection, NTTType} */
 #define ALEO_NTT_ORDER_NN 0   /* natural in, natural out (what fft_in_place exposes) */

@@ -31,6 +31,7 @@ static_assert(sizeof(G1Projective) == 144, "snarkVM Projective layout");
 struct Error {
   int32_t code;
   std::string message() const { return std::string(aleo_mi355x_strerror(code)) + " [" + aleo_mi355x_last_error() + "]"; }
+  bool unsatisfied() const { return code == ALEO_MI355X_ERR_UNSATISFIED; }      // a prover refused an assignment that violates its circuit
 };
 template <class T> struct Result {       // Ok(value) or Err(Error), like the Rust side sees it
   std::optional<T> value; Error error{0};

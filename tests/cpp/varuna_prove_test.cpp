@@ -67,6 +67,12 @@ int main(int argc, char** argv) {
     if (!vk2.is_ok() || vk2.value->size() != vk_len || memcmp(vk2.value->data(), vk, vk_len)) { fprintf(stderr, "verifying_key_bytes\n"); return 1; }
     std::vector<BigInteger256> shorter(nv - 1); std::vector<const std::vector<BigInteger256>*> bad = {&shorter};
     if (pk.value->prove_batch(bad, seed).is_ok()) { fprintf(stderr, "wrong assignment length accepted\n"); return 1; }
+    za[k - 1][nv - 1].l[0] ^= 1;                         // a witness that violates the circuit: refused with its own error code
+    auto un = pk.value->prove_batch(zs, seed);
+    if (un.is_ok() || !un.error.unsatisfied()) { fprintf(stderr, "unsatisfied assignment: expected ERR_UNSATISFIED, got %d\n", un.error.code); return 1; }
+    za[k - 1][nv - 1].l[0] ^= 1;
+    auto again = pk.value->prove_batch(zs, seed);
+    if (!again.is_ok() || memcmp(again.value->bytes.data(), proof.data(), len)) { fprintf(stderr, "proof after a refused one differs\n"); return 1; }
   }
   printf("ALL OK\n");
   return 0;

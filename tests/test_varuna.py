@@ -162,8 +162,8 @@ def test_device_prover_verifies_at_2_13():
         assert V.verify_pairing(idx, setup.verifier_key(c), z[:4], data)          # and by the verifier that holds no trapdoor
         bad = bytearray(data); bad[600] ^= 4
         assert not V.verify(idx, setup, z[:4], bytes(bad))
-        z2 = zz.copy(); z2[100, 0] ^= np.uint64(1)                       # a wrong witness: the proof comes out, the verifier refuses it
-        assert not V.verify(idx, setup, z[:4], varuna.prove(ix, z2, 77).to_bytes())
+        z2 = zz.copy(); z2[100, 0] ^= np.uint64(1)                       # a wrong witness never becomes a proof (test_unsatisfied_assignment_is_refused)
+        with pytest.raises(aleo_amd.UnsatisfiedAssignment): varuna.prove(ix, z2, 77)
     finally:
         ck.close()
 
@@ -278,6 +278,28 @@ def test_whole_proof_entry_points_refuse_misuse():
         assert build(flags=3) == 2 and build(flags=1) == 0 and build(flags=2) == 0
         assert build(lagrange=ck.max_degree + 4) == 2                          # Lagrange powers announced where the key has none
         assert build(max_degree=7) == 2 and build(key=123456789) == 4 and build(pub=0) == 2 and build(priv=len(z) + 10 ** 6) == 2
+    finally:
+        ck.close()
+
+
+@pytest.mark.gpu
+def test_unsatisfied_assignment_is_refused():
+    """An assignment that violates a constraint must not turn into bytes that look like a proof: both provers stop at the first sumcheck
+    (sum over H != 0) — the one-call entry with ALEO_MI355X_ERR_UNSATISFIED (6), also when only one instance of a batch is bad — and the
+    slot keeps working afterwards.  (Upstream refuses earlier, at synthesis: `A::is_satisfied()`; the restatement asserts the same sum.)"""
+    from aleo_amd import varuna
+    csr, z, c = _circuit(120, 3, 4)
+    ck = varuna.synthetic_committer_key(TAU, S_GAMMA, _max_degree(c))
+    try:
+        ix = varuna.CircuitIndex(csr, 120, 3, len(z) - 3, ck)
+        lim = lambda a: np.stack([synth.int_to_limbs(v, 4) for v in a])
+        bad = list(z); bad[9] = (bad[9] + 1) % V.R
+        good = varuna.prove_native(ix, lim(z), 5)
+        with pytest.raises(aleo_amd.UnsatisfiedAssignment) as e: varuna.prove_native(ix, lim(bad), 5)
+        assert e.value.status == 6 and 'satisfy' in str(e.value)
+        with pytest.raises(aleo_amd.UnsatisfiedAssignment): varuna.prove_native(ix, [lim(z), lim(bad), lim(z)], 5)
+        with pytest.raises(aleo_amd.UnsatisfiedAssignment): varuna.prove(ix, lim(bad), 5)
+        assert varuna.prove_native(ix, lim(z), 5) == good and varuna.prove(ix, lim(z), 5).to_bytes() == good
     finally:
         ck.close()
 
