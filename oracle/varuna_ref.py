@@ -106,11 +106,14 @@ class Setup:
 
     def verifier_key(self, circuit):
         """What a verifier holds (public; derived from the trapdoor here as a ceremony would): γG, H, τH and the negative powers of τ in G2 that
-        un-shift degree-bounded commitments [UPSTREAM-RECALL: sonic_pc VerifierKey — h, beta_h, prepared_neg_powers_of_beta_h, gamma_g]."""
+        un-shift degree-bounded commitments [UPSTREAM-RECALL: sonic_pc VerifierKey — h, beta_h, prepared_neg_powers_of_beta_h, gamma_g].
+        circuit: one Circuit or the list a batch proof covers (bounds: the largest |H| − 2, every |K_M| − 2)."""
+        circuits = [circuit] if isinstance(circuit, Circuit) else list(circuit)
         H = P.G2_GENERATOR; ti = inv(self.tau)
+        neg = lambda bound: P.g2_mul(H, pow(ti, self.max_degree - bound, R))
         return {'gamma_g': P.g1_mul(P.G1_GENERATOR, self.s_gamma), 'h': H, 'tau_h': P.g2_mul(H, self.tau),
-                'neg_h': P.g2_mul(H, pow(ti, self.max_degree - (circuit.n_h - 2), R)),
-                'neg_k': {m: P.g2_mul(H, pow(ti, self.max_degree - (circuit.n_k_m[m] - 2), R)) for m in 'abc'}}
+                'neg_h': neg(max(c.n_h for c in circuits) - 2),
+                'neg_k_by_size': {n: neg(n - 2) for n in sorted({c.n_k_m[M] for c in circuits for M in 'abc'})}}
 
 
 def _commit_scalar(setup, coeffs, bound=None, blind=None):
@@ -208,8 +211,15 @@ def _axpy(dst, k, src):
 
 def _challenges_after_round1(tr, k):
     alpha, eta_b, eta_c = tr.challenge(b'alpha'), tr.challenge(b'eta_b'), tr.challenge(b'eta_c')
-    comb = [1] + [tr.challenge(b'combiner' + i.to_bytes(4, 'little')) for i in range(1, k)]      # batch combiners of the instances
+    comb = [1] + [tr.challenge(b'combiner' + i.to_bytes(4, 'little')) for i in range(1, k)]      # batch combiners of the instances (all circuits, in order)
     return alpha, {'a': 1, 'b': eta_b, 'c': eta_c}, comb
+
+
+def _challenges_after_round3(tr, m):
+    """delta_{j,M}: the first is 1; circuit 0 keeps the single-circuit labels."""
+    delta = [{'a': 1, 'b': tr.challenge(b'delta_b'), 'c': tr.challenge(b'delta_c')}]
+    for j in range(1, m): delta.append({M: tr.challenge(b'delta_' + M.encode() + j.to_bytes(4, 'little')) for M in 'abc'})
+    return delta
 
 
 def prove(index: Index, setup: Setup, assignments, rand, vk_bytes=None):
@@ -217,108 +227,137 @@ def prove(index: Index, setup: Setup, assignments, rand, vk_bytes=None):
     single such list), public variables first (z[0] = 1).  rand: the random stream (randomness_layout(n_h, k)).
     Returns (proof dict, proof bytes in the reference's layout)."""
     if assignments and not isinstance(assignments[0], (list, tuple)): assignments = [assignments]
-    k = len(assignments)
-    c = index.circuit; H, K, X = index.H, index.K, index.X
-    n_h, n_k, n_x = c.n_h, c.n_k, c.n_x
-    lay = randomness_layout(n_h, k); assert len(rand) >= lay['total']
-    he = H.elements(); ratio = n_h // n_x
+    return prove_batch([(index, assignments)], setup, rand, None if vk_bytes is None else [vk_bytes])
+
+
+def prove_batch(items, setup: Setup, rand, vk_bytes=None):
+    """One proof for several circuits, each with its own instances — `Varuna::prove_batch(keys_to_constraints: BTreeMap<&ProvingKey, &[Assignment]>)`.
+    items: [(Index, [assignment, ...]), ...] in the order the proof lists them; rand: randomness_layout(max |H|, total instances).
+    What the circuits share [UPSTREAM-RECALL: varuna's batching over circuits]: the transcript and every challenge; ONE mask, g_1, h_1 for the first
+    sumcheck, taken over the largest constraint domain H* with the selector s_j = v_{H*} / v_{H_j} in front of circuit j's summand
+    (sum over H* of s_j F_j = |H*|/|H_j| times the sum of F_j over H_j; s_j (h_j v_{H_j} + X g_j) = h_j v_{H*} + X (s_j g_j), and multiplying by
+    s_j = sum_t X^(t |H_j|) tiles g_j's remainder block |H*|/|H_j| times); ONE h_2 over the largest non-zero domain K* with selectors
+    v_{K*} / v_{K_{j,M}}; two openings for everything.  With one circuit this is prove() above, byte for byte."""
+    m = len(items); ks = [len(a) for _, a in items]; k = sum(ks)
+    N = max(ix.circuit.n_h for ix, _ in items); n_k = max(ix.circuit.n_k for ix, _ in items)
+    lead = [ix.circuit.n_h for ix, _ in items].index(N)
+    HN = Domain(N); KN = Domain(n_k)
+    lay = randomness_layout(N, k); assert len(rand) >= lay['total']
     # ---- first round --------------------------------------------------------------------------------------------------------
-    inst = []
-    for i, z_assignment in enumerate(assignments):
-        zH = [0] * n_h
-        for v, val in enumerate(z_assignment): zH[h_position(v, c.n_public, n_x, n_h)] = val % R
-        z_m = {}
-        for name in 'ab':
-            out = [0] * n_h
-            for r, row in enumerate(c.m[name]): out[r] = sum(val * z_assignment[v] for v, val in row) % R
-            z_m[name] = out
-        x_evals = [z_assignment[j] % R if j < c.n_public else 0 for j in range(n_x)]
-        x_poly = X.ifft(x_evals)
-        w_evals = [0] * n_h
-        for p in range(n_h):
-            if p % ratio == 0: continue
-            w_evals[p] = (zH[p] - poly_eval(x_poly, he[p])) * inv(X.vanishing(he[p])) % R
-        rho = rand[lay['rho'][i]:lay['rho'][i] + 3]
-        bl = [[v % R for v in rand[lay['blind'][i] + HIDING_COEFFS * j:lay['blind'][i] + HIDING_COEFFS * (j + 1)]] for j in range(3)]
-        d = {'x_evals': x_evals, 'x_poly': x_poly, 'w': _blinded(H, w_evals, rho[0]), 'za': _blinded(H, z_m['a'], rho[1]), 'zb': _blinded(H, z_m['b'], rho[2]),
-             'blind': {'w': bl[0], 'za': bl[1], 'zb': bl[2]}}
-        d['cb'] = {p_: _point_bytes(_commit_scalar(setup, d[p_], blind=d['blind'][p_])) for p_ in ('w', 'za', 'zb')}
-        inst.append(d)
-    mask = [v % R for v in rand[lay['mask']:lay['mask'] + 3 * n_h]]
-    mask[0] = (-(mask[n_h] + mask[2 * n_h])) % R                                  # sum over H = |H| (m_0 + m_|H| + m_2|H|) = 0
+    inst = []                                                                     # all instances, circuit after circuit
+    for j, (index, assignments) in enumerate(items):
+        c = index.circuit; H, X = index.H, index.X
+        n_h, n_x = c.n_h, c.n_x; he = H.elements(); ratio = n_h // n_x
+        for z_assignment in assignments:
+            i = len(inst)
+            zH = [0] * n_h
+            for v, val in enumerate(z_assignment): zH[h_position(v, c.n_public, n_x, n_h)] = val % R
+            z_m = {}
+            for name in 'ab':
+                out = [0] * n_h
+                for r, row in enumerate(c.m[name]): out[r] = sum(val * z_assignment[v] for v, val in row) % R
+                z_m[name] = out
+            x_evals = [z_assignment[t] % R if t < c.n_public else 0 for t in range(n_x)]
+            x_poly = X.ifft(x_evals)
+            w_evals = [0] * n_h
+            for p in range(n_h):
+                if p % ratio == 0: continue
+                w_evals[p] = (zH[p] - poly_eval(x_poly, he[p])) * inv(X.vanishing(he[p])) % R
+            rho = rand[lay['rho'][i]:lay['rho'][i] + 3]
+            bl = [[v % R for v in rand[lay['blind'][i] + HIDING_COEFFS * t:lay['blind'][i] + HIDING_COEFFS * (t + 1)]] for t in range(3)]
+            d = {'circuit': j, 'x_evals': x_evals, 'x_poly': x_poly, 'w': _blinded(H, w_evals, rho[0]), 'za': _blinded(H, z_m['a'], rho[1]),
+                 'zb': _blinded(H, z_m['b'], rho[2]), 'blind': {'w': bl[0], 'za': bl[1], 'zb': bl[2]}}
+            d['cb'] = {p_: _point_bytes(_commit_scalar(setup, d[p_], blind=d['blind'][p_])) for p_ in ('w', 'za', 'zb')}
+            inst.append(d)
+    mask = [v % R for v in rand[lay['mask']:lay['mask'] + 3 * N]]
+    mask[0] = (-(mask[N] + mask[2 * N])) % R                                      # sum over H* = |H*| (m_0 + m_|H*| + m_2|H*|) = 0
     blind_mask = [v % R for v in rand[lay['blind_mask']:lay['blind_mask'] + HIDING_COEFFS]]
     cb = {'mask': _point_bytes(_commit_scalar(setup, mask, blind=blind_mask))}
-    tr = Transcript(); tr.absorb(vk_bytes if vk_bytes is not None else index.vk_bytes())
+    tr = Transcript(); tr.absorb(b''.join(vk_bytes) if vk_bytes is not None else b''.join(ix.vk_bytes() for ix, _ in items))
     tr.absorb(b''.join(fr_bytes(v) for d in inst for v in d['x_evals']))
     tr.absorb(b''.join(d['cb']['w'] + d['cb']['za'] + d['cb']['zb'] for d in inst) + cb['mask'])
     alpha, eta, comb = _challenges_after_round1(tr, k)
     eta_b, eta_c = eta['b'], eta['c']
     # ---- second round: first sumcheck --------------------------------------------------------------------------------------
-    vh_alpha = H.vanishing(alpha); assert vh_alpha != 0
-    r_alpha = [vh_alpha * inv(alpha - h) % R for h in he]                         # u_H(alpha, h) on H
-    t_evals = [0] * n_h
-    for name in 'abc':
-        for r, cp, v in index.entries[name]: t_evals[cp] = (t_evals[cp] + eta[name] * r_alpha[r] % R * v) % R
-    r_poly, t_poly = H.ifft(r_alpha), H.ifft(t_evals)
-    D4 = Domain(4 * n_h)
-    e_r, e_t = D4.fft(r_poly), D4.fft(t_poly)
-    acc4 = [0] * (4 * n_h)
-    for d, ci in zip(inst, comb):
-        w = d['w']
-        z_poly = [0] * (n_h + 1 + n_x)                                            # ẑ = w v_X + x̂
-        for i, v in enumerate(w): z_poly[i] = (z_poly[i] - v) % R; z_poly[i + n_x] = (z_poly[i + n_x] + v) % R
-        for i, v in enumerate(d['x_poly']): z_poly[i] = (z_poly[i] + v) % R
-        e_z, e_a, e_b = D4.fft(z_poly), D4.fft(d['za']), D4.fft(d['zb'])
-        for i in range(4 * n_h):
-            acc4[i] = (acc4[i] + ci * (e_r[i] * ((e_a[i] + eta_b * e_b[i] + eta_c * e_a[i] % R * e_b[i]) % R) - e_t[i] * e_z[i])) % R
-    q1 = D4.ifft(acc4)
-    for i, v in enumerate(mask): q1[i] = (q1[i] + v) % R
-    q = [0] * (3 * n_h)                                                           # q1 = h_1 (X^|H| − 1) + remainder
-    for i in range(4 * n_h - 1, n_h - 1, -1):
-        q[i - n_h] = (q1[i] + (q[i] if i < 3 * n_h else 0)) % R
-    rem = [(q1[i] + q[i]) % R for i in range(n_h)]
-    assert rem[0] == 0, 'first sumcheck: the sum over H is not zero (unsatisfied assignment?)'
-    h1 = q[:2 * n_h]; assert not any(q[2 * n_h:])
-    g1 = rem[1:]
-    cb['g_1'], cb['h_1'] = _point_bytes(_commit_scalar(setup, g1, bound=n_h - 2)), _point_bytes(_commit_scalar(setup, h1))
+    h1 = [0] * (2 * N); rem_all = [0] * N
+    vh_alpha = []
+    for j, (index, _) in enumerate(items):
+        c = index.circuit; H, X = index.H, index.X; n_h, n_x = c.n_h, c.n_x; he = H.elements()
+        va = H.vanishing(alpha); assert va != 0; vh_alpha.append(va)
+        r_alpha = [va * inv(alpha - h) % R for h in he]                           # u_H(alpha, h) on H
+        t_evals = [0] * n_h
+        for name in 'abc':
+            for r, cp, v in index.entries[name]: t_evals[cp] = (t_evals[cp] + eta[name] * r_alpha[r] % R * v) % R
+        r_poly, t_poly = H.ifft(r_alpha), H.ifft(t_evals)
+        D4 = Domain(4 * n_h)
+        e_r, e_t = D4.fft(r_poly), D4.fft(t_poly)
+        acc4 = [0] * (4 * n_h)
+        for d, ci in zip(inst, comb):
+            if d['circuit'] != j: continue
+            w = d['w']
+            z_poly = [0] * (n_h + 1 + n_x)                                        # ẑ = w v_X + x̂
+            for i, v in enumerate(w): z_poly[i] = (z_poly[i] - v) % R; z_poly[i + n_x] = (z_poly[i + n_x] + v) % R
+            for i, v in enumerate(d['x_poly']): z_poly[i] = (z_poly[i] + v) % R
+            e_z, e_a, e_b = D4.fft(z_poly), D4.fft(d['za']), D4.fft(d['zb'])
+            for i in range(4 * n_h):
+                acc4[i] = (acc4[i] + ci * (e_r[i] * ((e_a[i] + eta_b * e_b[i] + eta_c * e_a[i] % R * e_b[i]) % R) - e_t[i] * e_z[i])) % R
+        q1 = D4.ifft(acc4)
+        if j == lead:
+            for i, v in enumerate(mask): q1[i] = (q1[i] + v) % R
+        q = [0] * (3 * n_h)                                                       # q1 = h (X^|H| − 1) + remainder
+        for i in range(4 * n_h - 1, n_h - 1, -1):
+            q[i - n_h] = (q1[i] + (q[i] if i < 3 * n_h else 0)) % R
+        rem = [(q1[i] + q[i]) % R for i in range(n_h)]
+        assert rem[0] == 0, 'first sumcheck: the sum over H is not zero (unsatisfied assignment?)'
+        assert not any(q[2 * n_h:])
+        _axpy(h1, 1, q[:2 * n_h])
+        for i in range(N): rem_all[i] = (rem_all[i] + rem[i % n_h]) % R          # X (s_j g_j): the remainder block tiled over H*
+    g1 = rem_all[1:]
+    cb['g_1'], cb['h_1'] = _point_bytes(_commit_scalar(setup, g1, bound=N - 2)), _point_bytes(_commit_scalar(setup, h1))
     tr.absorb(cb['g_1'] + cb['h_1'])
     beta = tr.challenge(b'beta')
-    # ---- third round: the three rational sumchecks over K --------------------------------------------------------------------
-    vh_beta = H.vanishing(beta); assert vh_beta != 0
-    f, sigma, g = {}, {}, {}
-    for name in 'abc':
-        ev = index.evals[name]
-        nkm = c.n_k_m[name]
-        fe = [vh_alpha * vh_beta % R * ev['val'][j] % R * inv((alpha - ev['row'][j]) * (beta - ev['col'][j])) % R for j in range(nkm)]
-        f[name] = index.K_m[name].ifft(fe); sigma[name] = f[name][0] * nkm % R; g[name] = f[name][1:]
-        cb['g_' + name] = _point_bytes(_commit_scalar(setup, g[name], bound=nkm - 2))
-    tr.absorb(b''.join(fr_bytes(sigma[m]) for m in 'abc') + cb['g_a'] + cb['g_b'] + cb['g_c'])
-    delta = {'a': 1, 'b': tr.challenge(b'delta_b'), 'c': tr.challenge(b'delta_c')}
+    # ---- third round: the rational sumchecks over the K_{j,M} --------------------------------------------------------------------
+    f, sigma, g, gcb = [], [], [], []
+    for j, (index, _) in enumerate(items):
+        c = index.circuit
+        vh_beta = index.H.vanishing(beta); assert vh_beta != 0
+        fj, sj, gj, cj = {}, {}, {}, {}
+        for name in 'abc':
+            ev = index.evals[name]; nkm = c.n_k_m[name]
+            fe = [vh_alpha[j] * vh_beta % R * ev['val'][t] % R * inv((alpha - ev['row'][t]) * (beta - ev['col'][t])) % R for t in range(nkm)]
+            fj[name] = index.K_m[name].ifft(fe); sj[name] = fj[name][0] * nkm % R; gj[name] = fj[name][1:]
+            cj[name] = _point_bytes(_commit_scalar(setup, gj[name], bound=nkm - 2))
+        f.append(fj); sigma.append(sj); g.append(gj); gcb.append(cj)
+    tr.absorb(b''.join(fr_bytes(sj[M]) for sj in sigma for M in 'abc') + b''.join(cj[M] for cj in gcb for M in 'abc'))
+    delta = _challenges_after_round3(tr, m)
     # ---- fourth round ------------------------------------------------------------------------------------------------------------
-    h2 = [0] * n_k                                                                # h_2 = sum_M delta_M (a_M − b_M f_M) / v_{K_M}, each quotient on its own domain
-    for name in 'abc':
-        nkm = c.n_k_m[name]; D2 = Domain(2 * nkm); pl = index.polys[name]
-        e_row, e_col, e_val, e_rc, e_f = D2.fft(pl['row']), D2.fft(pl['col']), D2.fft(pl['val']), D2.fft(pl['row_col']), D2.fft(f[name])
-        num = []
-        for i in range(2 * nkm):
-            a_ = vh_alpha * vh_beta % R * e_val[i] % R
-            b_ = (alpha * beta - beta * e_row[i] - alpha * e_col[i] + e_rc[i]) % R
-            num.append((a_ - b_ * e_f[i]) % R)
-        pc = D2.ifft(num)
-        hm = pc[nkm:]                                                             # P = h_M (X^|K_M| − 1), deg P < 2|K_M|
-        assert all((pc[i] + hm[i]) % R == 0 for i in range(nkm)), 'fourth round: not divisible by v_K'
-        _axpy(h2, delta[name], hm)
+    h2 = [0] * n_k                                                                # h_2 = sum_{j,M} delta_{j,M} (a − b f) / v_{K_{j,M}}, each quotient on its own domain
+    for j, (index, _) in enumerate(items):
+        c = index.circuit; vh_beta = index.H.vanishing(beta)
+        for name in 'abc':
+            nkm = c.n_k_m[name]; D2 = Domain(2 * nkm); pl = index.polys[name]
+            e_row, e_col, e_val, e_rc, e_f = D2.fft(pl['row']), D2.fft(pl['col']), D2.fft(pl['val']), D2.fft(pl['row_col']), D2.fft(f[j][name])
+            num = []
+            for i in range(2 * nkm):
+                a_ = vh_alpha[j] * vh_beta % R * e_val[i] % R
+                b_ = (alpha * beta - beta * e_row[i] - alpha * e_col[i] + e_rc[i]) % R
+                num.append((a_ - b_ * e_f[i]) % R)
+            pc = D2.ifft(num)
+            hm = pc[nkm:]                                                         # P = h_M (X^|K_M| − 1), deg P < 2|K_M|
+            assert all((pc[i] + hm[i]) % R == 0 for i in range(nkm)), 'fourth round: not divisible by v_K'
+            _axpy(h2, delta[j][name], hm)
     cb['h_2'] = _point_bytes(_commit_scalar(setup, h2))
     tr.absorb(cb['h_2'])
     gamma = tr.challenge(b'gamma')
     # ---- evaluations and the two openings --------------------------------------------------------------------------------------
     zb_beta = [poly_eval(d['zb'], beta) for d in inst]
-    g1_beta = poly_eval(g1, beta); g_gamma = {m: poly_eval(g[m], gamma) for m in 'abc'}
-    evals = zb_beta + [g1_beta, g_gamma['a'], g_gamma['b'], g_gamma['c']]
+    g1_beta = poly_eval(g1, beta); g_gamma = [{M: poly_eval(gj[M], gamma) for M in 'abc'} for gj in g]
+    evals = zb_beta + [g1_beta] + [gg[M] for gg in g_gamma for M in 'abc']
     tr.absorb(b''.join(fr_bytes(v) for v in evals))
     xi = tr.challenge(b'xi')
-    lc1 = lincheck_coefficients(H, X, alpha, beta, eta, comb, sigma, zb_beta, g1_beta, [poly_eval(d['x_poly'], beta) for d in inst])
-    p_beta = [0] * (3 * n_h)
+    circuits = [ix for ix, _ in items]
+    lc1 = lincheck_coefficients(circuits, [d['circuit'] for d in inst], HN, alpha, beta, eta, comb, sigma, zb_beta, g1_beta, [poly_eval(d['x_poly'], beta) for d in inst])
+    p_beta = [0] * (3 * N)
     _axpy(p_beta, lc1['mask'], mask); _axpy(p_beta, lc1['h_1'], h1)
     for d, kz, kw in zip(inst, lc1['z_a'], lc1['w']): _axpy(p_beta, kz, d['za']); _axpy(p_beta, kw, d['w'])
     p_beta[0] = (p_beta[0] + lc1['const']) % R
@@ -336,20 +375,23 @@ def prove(index: Index, setup: Setup, assignments, rand, vk_bytes=None):
     random_v = poly_eval(bl, beta)
     bl_w = divide_by_linear(bl, beta, random_v)
     open_beta = (poly_eval(w_beta, setup.tau) + setup.s_gamma * poly_eval(bl_w, setup.tau)) % R
-    lc2 = matrix_coefficients(H, K, index.K_m, alpha, beta, gamma, delta, sigma, g_gamma)
+    lc2 = matrix_coefficients(circuits, KN, alpha, beta, gamma, delta, sigma, g_gamma)
     p_gamma = [0] * n_k
-    for (m, kind), coef in lc2['index'].items(): _axpy(p_gamma, coef, index.polys[m][kind])
+    for (j, M, kind), coef in lc2['index'].items(): _axpy(p_gamma, coef, circuits[j].polys[M][kind])
     _axpy(p_gamma, lc2['h_2'], h2)
     p_gamma[0] = (p_gamma[0] + lc2['const']) % R
     assert poly_eval(p_gamma, gamma) == 0, 'matrix sumcheck linear combination does not vanish at gamma'
-    p_gamma = [v * pow(xi, 3, R) % R for v in p_gamma]
-    _axpy(p_gamma, 1, g['a']); _axpy(p_gamma, xi, g['b']); _axpy(p_gamma, xi * xi % R, g['c'])
-    v_gamma = (g_gamma['a'] + xi * g_gamma['b'] + xi * xi % R * g_gamma['c']) % R
+    p_gamma = [v * pow(xi, 3 * m, R) % R for v in p_gamma]                       # sum_{j,M} xi^(3j+M) g_{j,M} + xi^(3m) LC2
+    v_gamma = 0
+    for j in range(m):
+        for t, M in enumerate('abc'):
+            _axpy(p_gamma, pow(xi, 3 * j + t, R), g[j][M]); v_gamma = (v_gamma + pow(xi, 3 * j + t, R) * g_gamma[j][M]) % R
     open_gamma = poly_eval(divide_by_linear(p_gamma, gamma, v_gamma), setup.tau)
-    proof = {'instances': k, 'witness': [(d['cb']['w'], d['cb']['za'], d['cb']['zb']) for d in inst],
-             'commitments': {n_: cb[n_] for n_ in ('mask', 'g_1', 'h_1', 'g_a', 'g_b', 'g_c', 'h_2')},
-             'evaluations': evals, 'sums': [sigma['a'], sigma['b'], sigma['c']],
+    proof = {'batch_sizes': ks, 'instances': k, 'witness': [(d['cb']['w'], d['cb']['za'], d['cb']['zb']) for d in inst],
+             'commitments': {'mask': cb['mask'], 'g_1': cb['g_1'], 'h_1': cb['h_1'], 'h_2': cb['h_2'], 'g_abc': [cj[M] for cj in gcb for M in 'abc']},
+             'evaluations': evals, 'sums': [sj[M] for sj in sigma for M in 'abc'],
              'openings': [(_point_bytes(open_beta), random_v), (_point_bytes(open_gamma), None)]}
+    if m == 1: proof['commitments'].update({'g_a': gcb[0]['a'], 'g_b': gcb[0]['b'], 'g_c': gcb[0]['c']})
     return proof, proof_bytes(proof)
 
 
@@ -362,105 +404,131 @@ def divide_by_linear(p, z, value):
     return q
 
 
-def lincheck_coefficients(H, X, alpha, beta, eta, comb, sigma, zb_beta, g1_beta, x_beta):
+def lincheck_coefficients(circuits, inst_circuit, HN, alpha, beta, eta, comb, sigma, zb_beta, g1_beta, x_beta):
     """Coefficients of the linear combination of (mask, z_a,i, w_i, h_1, 1) that must vanish at beta (first sumcheck as the verifier evaluates it):
-    mask + sum_i c_i [r(alpha, beta)(z_a,i + eta_b z_b,i(beta) + eta_c z_a,i z_b,i(beta)) − t(beta)(w_i v_X(beta) + x̂_i(beta))] − v_H(beta) h_1 − beta g_1(beta)."""
-    r_ab = (H.vanishing(alpha) - H.vanishing(beta)) * inv(alpha - beta) % R
-    t_beta = (sigma['a'] + eta['b'] * sigma['b'] + eta['c'] * sigma['c']) % R
-    const = (-beta * g1_beta) % R
-    for ci, zb, xb in zip(comb, zb_beta, x_beta): const = (const + ci * (r_ab * eta['b'] % R * zb - t_beta * xb)) % R
-    return {'mask': 1, 'z_a': [ci * r_ab % R * (1 + eta['c'] * zb) % R for ci, zb in zip(comb, zb_beta)],
-            'w': [(-ci * t_beta % R * X.vanishing(beta)) % R for ci in comb], 'h_1': (-H.vanishing(beta)) % R, 'const': const}
+    mask + sum_i c_i s_j(beta) [r_j(alpha, beta)(z_a,i + eta_b z_b,i(beta) + eta_c z_a,i z_b,i(beta)) − t_j(beta)(w_i v_{X_j}(beta) + x̂_i(beta))]
+    − v_{H*}(beta) h_1 − beta g_1(beta), j = the circuit of instance i, s_j = v_{H*} / v_{H_j} (1 for the largest domain H*)."""
+    per = []
+    for ix, sg in zip(circuits, sigma):
+        H = ix.H
+        r_ab = (H.vanishing(alpha) - H.vanishing(beta)) * inv(alpha - beta) % R
+        t_beta = (sg['a'] + eta['b'] * sg['b'] + eta['c'] * sg['c']) % R
+        sel = 1 if H.size == HN.size else HN.vanishing(beta) * inv(H.vanishing(beta)) % R
+        per.append((r_ab, t_beta, sel, ix.X.vanishing(beta)))
+    const = (-beta * g1_beta) % R; ka, kw = [], []
+    for j, ci, zb, xb in zip(inst_circuit, comb, zb_beta, x_beta):
+        r_ab, t_beta, sel, vx = per[j]; cs = ci * sel % R
+        const = (const + cs * (r_ab * eta['b'] % R * zb - t_beta * xb)) % R
+        ka.append(cs * r_ab % R * (1 + eta['c'] * zb) % R); kw.append((-cs * t_beta % R * vx) % R)
+    return {'mask': 1, 'z_a': ka, 'w': kw, 'h_1': (-HN.vanishing(beta)) % R, 'const': const}
 
 
-def matrix_coefficients(H, K, K_m, alpha, beta, gamma, delta, sigma, g_gamma):
-    """Coefficients over (val, row, col, row_col of A, B, C; h_2; 1) of the combination that must vanish at gamma (second sumcheck):
-    sum_M delta_M s_M(gamma) (vv val_M − f_M(gamma) (alpha beta − beta row_M − alpha col_M + row_col_M)) − v_K(gamma) h_2, with the selector
-    s_M = v_K / v_{K_M} (K the largest non-zero domain) and f_M(gamma) = gamma g_M(gamma) + sigma_M / |K_M|."""
-    vv = H.vanishing(alpha) * H.vanishing(beta) % R
+def matrix_coefficients(circuits, KN, alpha, beta, gamma, delta, sigma, g_gamma):
+    """Coefficients over (val, row, col, row_col of every circuit's A, B, C; h_2; 1) of the combination that must vanish at gamma (second sumcheck):
+    sum_{j,M} delta_{j,M} s_{j,M}(gamma) (vv_j val − f_{j,M}(gamma) (alpha beta − beta row − alpha col + row_col)) − v_{K*}(gamma) h_2, with the selector
+    s_{j,M} = v_{K*} / v_{K_{j,M}} (K* the largest non-zero domain), vv_j = v_{H_j}(alpha) v_{H_j}(beta) and f_{j,M}(gamma) = gamma g_{j,M}(gamma) + sigma_{j,M} / |K_{j,M}|."""
     idx = {}; const = 0
-    for m in 'abc':
-        fm = (gamma * g_gamma[m] + sigma[m] * K_m[m].size_inv) % R               # f_M(gamma)
-        d = delta[m] * K.vanishing(gamma) % R * inv(K_m[m].vanishing(gamma)) % R
-        idx[(m, 'val')] = d * vv % R
-        idx[(m, 'row')] = d * fm % R * beta % R
-        idx[(m, 'col')] = d * fm % R * alpha % R
-        idx[(m, 'row_col')] = (-d * fm) % R
-        const = (const - d * fm % R * alpha % R * beta) % R
-    return {'index': idx, 'h_2': (-K.vanishing(gamma)) % R, 'const': const}
+    for j, ix in enumerate(circuits):
+        vv = ix.H.vanishing(alpha) * ix.H.vanishing(beta) % R
+        for M in 'abc':
+            Km = ix.K_m[M]
+            fm = (gamma * g_gamma[j][M] + sigma[j][M] * Km.size_inv) % R          # f_M(gamma)
+            d = delta[j][M] * KN.vanishing(gamma) % R * inv(Km.vanishing(gamma)) % R
+            idx[(j, M, 'val')] = d * vv % R
+            idx[(j, M, 'row')] = d * fm % R * beta % R
+            idx[(j, M, 'col')] = d * fm % R * alpha % R
+            idx[(j, M, 'row_col')] = (-d * fm) % R
+            const = (const - d * fm % R * alpha % R * beta) % R
+    return {'index': idx, 'h_2': (-KN.vanishing(gamma)) % R, 'const': const}
 
 
 def proof_bytes(proof) -> bytes:
-    """The reference's Proof::to_bytes_le layout for one circuit with k instances (SURVEY.md §8c; 901 bytes for k = 1)."""
-    c = proof['commitments']; u64 = lambda v: int(v).to_bytes(8, 'little')
-    out = b'\x00' + u64(1) + u64(proof['instances']) + b''.join(w + a + b for w, a, b in proof['witness'])
-    out += b'\x01' + c['mask'] + c['g_1'] + c['h_1'] + c['g_a'] + c['g_b'] + c['g_c'] + c['h_2']
-    out += b''.join(fr_bytes(v) for v in proof['evaluations']) + u64(1) + b''.join(fr_bytes(v) for v in proof['sums']) + u64(len(proof['openings']))
+    """The reference's Proof::to_bytes_le layout (SURVEY.md §8c; 901 bytes for one circuit with one instance): version, the batch sizes, the
+    witness commitments instance after instance, mask, g_1, h_1, g_a/g_b/g_c circuit after circuit, h_2, the evaluations, the sums, the openings."""
+    c = proof['commitments']; u64 = lambda v: int(v).to_bytes(8, 'little'); ks = proof['batch_sizes']
+    out = b'\x00' + u64(len(ks)) + b''.join(u64(v) for v in ks) + b''.join(w + a + b for w, a, b in proof['witness'])
+    out += b'\x01' + c['mask'] + c['g_1'] + c['h_1'] + b''.join(c['g_abc']) + c['h_2']
+    out += b''.join(fr_bytes(v) for v in proof['evaluations']) + u64(len(ks)) + b''.join(fr_bytes(v) for v in proof['sums']) + u64(len(proof['openings']))
     for pt, rv in proof['openings']:
         out += pt + (b'\x01' + fr_bytes(rv) if rv is not None else b'\x00')
     return out + b'\x00'                                                        # BatchLCProof.evaluations: None
 
 
 def parse_proof(data: bytes):
-    assert data[0] == 0 and int.from_bytes(data[1:9], 'little') == 1
-    k = int.from_bytes(data[9:17], 'little'); assert 1 <= k <= 64
-    pos = 17; c = {}
+    assert data[0] == 0
+    m = int.from_bytes(data[1:9], 'little'); assert 1 <= m <= 64
+    ks = [int.from_bytes(data[9 + 8 * j:17 + 8 * j], 'little') for j in range(m)]; k = sum(ks); assert all(1 <= v <= 64 for v in ks)
+    pos = 9 + 8 * m; c = {}
     def pt():
         nonlocal pos; v = data[pos:pos + 48]; pos += 48; assert len(v) == 48; return v
     def fr():
         nonlocal pos; v = int.from_bytes(data[pos:pos + 32], 'little'); pos += 32; assert v < R; return v
     witness = [(pt(), pt(), pt()) for _ in range(k)]
     assert data[pos] == 1; pos += 1
-    for name in ('mask', 'g_1', 'h_1', 'g_a', 'g_b', 'g_c', 'h_2'): c[name] = pt()
-    evals = [fr() for _ in range(k + 4)]
-    assert int.from_bytes(data[pos:pos + 8], 'little') == 1; pos += 8
-    sums = [fr() for _ in range(3)]
+    for name in ('mask', 'g_1', 'h_1'): c[name] = pt()
+    c['g_abc'] = [pt() for _ in range(3 * m)]; c['h_2'] = pt()
+    if m == 1: c['g_a'], c['g_b'], c['g_c'] = c['g_abc']
+    evals = [fr() for _ in range(k + 1 + 3 * m)]
+    assert int.from_bytes(data[pos:pos + 8], 'little') == m; pos += 8
+    sums = [fr() for _ in range(3 * m)]
     n_open = int.from_bytes(data[pos:pos + 8], 'little'); pos += 8
     openings = []
     for _ in range(n_open):
         p_ = pt(); tag = data[pos]; pos += 1
         openings.append((p_, fr() if tag else None))
     assert pos + 1 == len(data) and data[pos] == 0
-    return {'instances': k, 'witness': witness, 'commitments': c, 'evaluations': evals, 'sums': sums, 'openings': openings}
+    return {'batch_sizes': ks, 'instances': k, 'witness': witness, 'commitments': c, 'evaluations': evals, 'sums': sums, 'openings': openings}
 
 
-def _verifier_state(index: Index, public_inputs, data: bytes, vk_bytes=None):
+def _as_batch(index, public_inputs):
+    """(list of Index, list per circuit of lists of public inputs) from the single-circuit or the batch calling form."""
+    if isinstance(index, Index):
+        if public_inputs and not isinstance(public_inputs[0], (list, tuple)): public_inputs = [public_inputs]
+        return [index], [list(public_inputs)]
+    return list(index), [list(p_) for p_ in public_inputs]
+
+
+def _verifier_state(index, public_inputs, data: bytes, vk_bytes=None):
     """Everything a verifier derives before the opening checks: parsed proof, challenges, the two linear-combination coefficient sets."""
     try: pr = parse_proof(data)
     except AssertionError: return None
-    if public_inputs and not isinstance(public_inputs[0], (list, tuple)): public_inputs = [public_inputs]
-    k = pr['instances']
-    if len(public_inputs) != k: return None
-    c = index.circuit; H, K, X = index.H, index.K, index.X
+    circuits, publics = _as_batch(index, public_inputs)
+    m = len(circuits); ks = pr['batch_sizes']; k = pr['instances']
+    if len(ks) != m or [len(p_) for p_ in publics] != ks: return None
+    if vk_bytes is not None and isinstance(vk_bytes, (bytes, bytearray)): vk_bytes = [vk_bytes]
     try:
-        pts = {n_: P.g1_decompress(v) for n_, v in pr['commitments'].items()}; opn = [P.g1_decompress(p_) for p_, _ in pr['openings']]
+        cbs = pr['commitments']
+        pts = {n_: P.g1_decompress(cbs[n_]) for n_ in ('mask', 'g_1', 'h_1', 'h_2')}; pts['g_abc'] = [P.g1_decompress(v) for v in cbs['g_abc']]
+        opn = [P.g1_decompress(p_) for p_, _ in pr['openings']]
         wit = [tuple(P.g1_decompress(v) for v in t) for t in pr['witness']]
     except Exception: return None
     if len(opn) != 2 or pr['openings'][0][1] is None or pr['openings'][1][1] is not None: return None
-    x_evals = [[pub[i] % R if i < c.n_public else 0 for i in range(c.n_x)] for pub in public_inputs]
-    cb = pr['commitments']
-    tr = Transcript(); tr.absorb(vk_bytes if vk_bytes is not None else index.vk_bytes())
+    inst_circuit = [j for j, kj in enumerate(ks) for _ in range(kj)]
+    x_evals = [[pub[i] % R if i < circuits[j].circuit.n_public else 0 for i in range(circuits[j].circuit.n_x)] for j, pubs in enumerate(publics) for pub in pubs]
+    N = max(ix.circuit.n_h for ix in circuits); n_k = max(ix.circuit.n_k for ix in circuits)
+    HN, KN = Domain(N), Domain(n_k)
+    tr = Transcript(); tr.absorb(b''.join(vk_bytes) if vk_bytes is not None else b''.join(ix.vk_bytes() for ix in circuits))
     tr.absorb(b''.join(fr_bytes(v) for xe in x_evals for v in xe))
-    tr.absorb(b''.join(w + a + b for w, a, b in pr['witness']) + cb['mask'])
+    tr.absorb(b''.join(w + a + b for w, a, b in pr['witness']) + cbs['mask'])
     alpha, eta, comb = _challenges_after_round1(tr, k)
-    tr.absorb(cb['g_1'] + cb['h_1']); beta = tr.challenge(b'beta')
-    sigma = dict(zip('abc', pr['sums']))
-    tr.absorb(b''.join(fr_bytes(sigma[m]) for m in 'abc') + cb['g_a'] + cb['g_b'] + cb['g_c'])
-    delta = {'a': 1, 'b': tr.challenge(b'delta_b'), 'c': tr.challenge(b'delta_c')}
-    tr.absorb(cb['h_2']); gamma = tr.challenge(b'gamma')
+    tr.absorb(cbs['g_1'] + cbs['h_1']); beta = tr.challenge(b'beta')
+    sigma = [dict(zip('abc', pr['sums'][3 * j:3 * j + 3])) for j in range(m)]
+    tr.absorb(b''.join(fr_bytes(v) for v in pr['sums']) + b''.join(cbs['g_abc']))
+    delta = _challenges_after_round3(tr, m)
+    tr.absorb(cbs['h_2']); gamma = tr.challenge(b'gamma')
     evals = pr['evaluations']
     tr.absorb(b''.join(fr_bytes(v) for v in evals)); xi = tr.challenge(b'xi')
-    zb_beta = evals[:k]; g1_beta, ga, gb, gc = evals[k:]
-    x_beta = [poly_eval(X.ifft(xe), beta) for xe in x_evals]
-    return {'k': k, 'pts': pts, 'opn': opn, 'wit': wit, 'beta': beta, 'gamma': gamma, 'xi': xi, 'random_v': pr['openings'][0][1],
-            'lc1': lincheck_coefficients(H, X, alpha, beta, eta, comb, sigma, zb_beta, g1_beta, x_beta),
-            'lc2': matrix_coefficients(H, K, index.K_m, alpha, beta, gamma, delta, sigma, {'a': ga, 'b': gb, 'c': gc}),
+    zb_beta = evals[:k]; g1_beta = evals[k]; g_gamma = [dict(zip('abc', evals[k + 1 + 3 * j:k + 4 + 3 * j])) for j in range(m)]
+    x_beta = [poly_eval(circuits[j].X.ifft(xe), beta) for j, xe in zip(inst_circuit, x_evals)]
+    return {'k': k, 'm': m, 'circuits': circuits, 'n_h': N, 'pts': pts, 'opn': opn, 'wit': wit, 'beta': beta, 'gamma': gamma, 'xi': xi, 'random_v': pr['openings'][0][1],
+            'lc1': lincheck_coefficients(circuits, inst_circuit, HN, alpha, beta, eta, comb, sigma, zb_beta, g1_beta, x_beta),
+            'lc2': matrix_coefficients(circuits, KN, alpha, beta, gamma, delta, sigma, g_gamma),
             'v_beta': (g1_beta + sum(pow(xi, 1 + i, R) * v for i, v in enumerate(zb_beta))) % R,
-            'v_gamma': (ga + xi * gb + xi * xi % R * gc) % R}
+            'v_gamma': sum(pow(xi, 3 * j + t, R) * g_gamma[j][M] for j in range(m) for t, M in enumerate('abc')) % R}
 
 
-def _unshifted_parts(st, index_points):
-    """The G1 sides of the two checks that carry no degree shift: sum_i xi^(1+i) z_b,i + xi^(k+1) LC1  and  xi^3 LC2."""
+def _unshifted_parts(st):
+    """The G1 sides of the two checks that carry no degree shift: sum_i xi^(1+i) z_b,i + xi^(k+1) LC1  and  xi^(3m) LC2."""
     G = P.G1_GENERATOR; mul, add = P.g1_mul, P.g1_add
     pts, wit, lc1, lc2, xi, k = st['pts'], st['wit'], st['lc1'], st['lc2'], st['xi'], st['k']
     C1 = add(add(mul(pts['mask'], lc1['mask']), mul(pts['h_1'], lc1['h_1'])), mul(G, lc1['const']))
@@ -468,43 +536,48 @@ def _unshifted_parts(st, index_points):
     Rb = mul(C1, pow(xi, k + 1, R))
     for i, (w_, a_, b_) in enumerate(wit): Rb = add(Rb, mul(b_, pow(xi, 1 + i, R)))
     C2 = add(mul(G, lc2['const']), mul(pts['h_2'], lc2['h_2']))
-    for mk, coef in lc2['index'].items(): C2 = add(C2, mul(index_points[mk], coef))
-    return Rb, mul(C2, pow(xi, 3, R))
+    index_points = [ix.commit_points() for ix in st['circuits']]
+    for (j, M, kind), coef in lc2['index'].items(): C2 = add(C2, mul(index_points[j][(M, kind)], coef))
+    return Rb, mul(C2, pow(xi, 3 * st['m'], R))
 
 
-def verify_pairing(index: Index, vk, public_inputs, data: bytes, vk_bytes=None) -> bool:
-    """The verifier proper: no trapdoor.  vk = Setup.verifier_key(circuit): gamma G, H, tau H and two negative powers of tau in G2; the
-    circuit's verifying key = the twelve index commitments.  Both batched KZG openings are checked as pairing products
+def verify_pairing(index, vk, public_inputs, data: bytes, vk_bytes=None) -> bool:
+    """The verifier proper: no trapdoor.  vk = Setup.verifier_key(circuit or list of circuits): gamma G, H, tau H and the negative powers of tau in
+    G2 the degree bounds need; each circuit's verifying key = its twelve index commitments.  index / public_inputs: one Index with the public inputs of
+    its instances, or lists of both (a proof over several circuits).  Both batched KZG openings are checked as pairing products
       e(shifted commitments, tau^-s H) · e(unshifted part − v G − v̄ gamma G, H) · e(−W, tau H − z H) = 1   (oracle/pairing.py)."""
     from . import pairing as E
     st = _verifier_state(index, public_inputs, data, vk_bytes)
     if st is None: return False
     G = P.G1_GENERATOR; mul, add, neg = P.g1_mul, P.g1_add, P.g1_neg
     pts, xi = st['pts'], st['xi']
-    Rb, Rg = _unshifted_parts(st, index.commit_points())
+    Rb, Rg = _unshifted_parts(st)
     Rb = add(Rb, neg(add(mul(G, st['v_beta']), mul(vk['gamma_g'], st['random_v']))))
     Rg = add(Rg, neg(mul(G, st['v_gamma'])))
     zh = lambda z: P.g2_add(vk['tau_h'], P.g2_neg(P.g2_mul(vk['h'], z)))
     if not E.pairing_product_is_one([(pts['g_1'], vk['neg_h']), (Rb, vk['h']), (neg(st['opn'][0]), zh(st['beta']))]): return False
-    shifted = {}                                                                  # g_a + xi g_b + xi^2 g_c, grouped by the shift of their degree bound
-    for m, coef in zip('abc', (1, xi, xi * xi % R)):
-        key = index.circuit.n_k_m[m]; term = mul(pts['g_' + m], coef)
-        shifted[key] = (add(shifted[key][0], term), vk['neg_k'][m]) if key in shifted else (term, vk['neg_k'][m])
+    shifted = {}                                                                  # sum xi^(3j+M) g_{j,M}, grouped by the shift of their degree bound
+    for j, ix in enumerate(st['circuits']):
+        for t, M in enumerate('abc'):
+            key = ix.circuit.n_k_m[M]; term = mul(pts['g_abc'][3 * j + t], pow(xi, 3 * j + t, R))
+            shifted[key] = (add(shifted[key][0], term), shifted[key][1]) if key in shifted else (term, vk['neg_k_by_size'][key])
     return E.pairing_product_is_one(list(shifted.values()) + [(Rg, vk['h']), (neg(st['opn'][1]), zh(st['gamma']))])
 
 
-def verify(index: Index, setup: Setup, public_inputs, data: bytes, vk_bytes=None) -> bool:
+def verify(index, setup: Setup, public_inputs, data: bytes, vk_bytes=None) -> bool:
     """The same two checks without pairings, for tests that verify many proofs: with the synthetic setup's trapdoor the pairing equation
     e(C − v·G − v̄·γG, H) = e(W, (τ − z)·H) is the G1 equation C − v·G − v̄·γG = (τ − z)·W (verify_pairing is the verifier that needs no trapdoor)."""
     st = _verifier_state(index, public_inputs, data, vk_bytes)
     if st is None: return False
-    c = index.circuit; G = P.G1_GENERATOR; mul, add, neg = P.g1_mul, P.g1_add, P.g1_neg
+    G = P.G1_GENERATOR; mul, add, neg = P.g1_mul, P.g1_add, P.g1_neg
     pts, xi = st['pts'], st['xi']
     tau_inv = inv(setup.tau); D = setup.max_degree
     def unshift(pt, bound): return mul(pt, pow(tau_inv, D - bound, R))
-    Rb, Rg = _unshifted_parts(st, index.commit_points())
-    lhs = add(add(unshift(pts['g_1'], c.n_h - 2), Rb), neg(mul(G, (st['v_beta'] + setup.s_gamma * st['random_v']) % R)))
+    Rb, Rg = _unshifted_parts(st)
+    lhs = add(add(unshift(pts['g_1'], st['n_h'] - 2), Rb), neg(mul(G, (st['v_beta'] + setup.s_gamma * st['random_v']) % R)))
     if lhs != mul(st['opn'][0], (setup.tau - st['beta']) % R): return False
-    Sg = add(add(unshift(pts['g_a'], c.n_k_m['a'] - 2), mul(unshift(pts['g_b'], c.n_k_m['b'] - 2), xi)), mul(unshift(pts['g_c'], c.n_k_m['c'] - 2), xi * xi % R))
+    Sg = None
+    for j, ix in enumerate(st['circuits']):
+        for t, M in enumerate('abc'): Sg = add(Sg, mul(unshift(pts['g_abc'][3 * j + t], ix.circuit.n_k_m[M] - 2), pow(xi, 3 * j + t, R)))
     lhs = add(add(Sg, Rg), neg(mul(G, st['v_gamma'])))
     return lhs == mul(st['opn'][1], (setup.tau - st['gamma']) % R)

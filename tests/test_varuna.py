@@ -92,6 +92,48 @@ def test_restatement_batch_of_instances():
     assert V.parse_proof(data)['witness'] == proof['witness'] and V.proof_bytes(V.parse_proof(data)) == data
 
 
+def _batch_case(shapes, seed=77, domains='auto'):
+    """shapes: [(n_constraints, n_public, circuit_seed, instances), ...] -> (circuits, csrs, assignments per circuit, max degree)."""
+    cs, csrs, zs = [], [], []
+    for n, npub, cseed, k in shapes:
+        csr, z, c = _circuit(n, npub, cseed, long_rows=1 if n > 8 else 0, domains=domains)
+        cs.append(c); csrs.append(csr)
+        zs.append([z] + [synth.resolve_synthetic(csr, npub, [1] + [(seed * 31 + 7 * i + t) % V.R for t in range(1, npub)]) for i in range(1, k)])
+    d = 1
+    while d < max(max(3 * c.n_h, c.n_k) for c in cs): d *= 2
+    return cs, csrs, zs, d - 1
+
+
+def test_restatement_batch_over_circuits():
+    """Varuna::prove_batch over several circuits (different |H|, |K|, |X|, instance counts): one proof, accepted by both verifiers, refused when a
+    byte, a public input or the order of the circuits changes; a one-circuit batch is prove() byte for byte."""
+    shapes = [(20, 2, 5, 2), (50, 3, 6, 1), (9, 1, 7, 2)]
+    cs, _, zs, D = _batch_case(shapes)
+    assert len({c.n_h for c in cs}) == 3
+    setup = V.Setup(TAU, S_GAMMA, D); idx = [V.Index(c, setup) for c in cs]
+    rand = V.random_stream(123, max(c.n_h for c in cs), sum(len(z) for z in zs))
+    proof, data = V.prove_batch(list(zip(idx, zs)), setup, rand)
+    assert proof['batch_sizes'] == [2, 1, 2] and len(data) == 1 + 8 * 4 + 48 * (15 + 4 + 9) + 1 + 32 * (5 + 1 + 9) + 8 + 32 * 9 + 8 + 48 + 33 + 48 + 1 + 1
+    assert V.parse_proof(data)['evaluations'] == proof['evaluations']
+    pubs = [[z[:c.n_public] for z in zz] for c, zz in zip(cs, zs)]
+    assert V.verify(idx, setup, pubs, data)
+    assert V.verify_pairing(idx, setup.verifier_key(cs), pubs, data)
+    bad = bytearray(data); bad[len(data) // 2] ^= 1
+    assert not V.verify(idx, setup, pubs, bytes(bad))
+    wrong = [[list(p_) for p_ in pp] for pp in pubs]; wrong[2][1][0] = 2
+    assert not V.verify(idx, setup, wrong, data)
+    assert not V.verify([idx[1], idx[0], idx[2]], setup, [pubs[1], pubs[0], pubs[2]], data)
+    z_bad = [list(z) for z in zs[1]]; z_bad[0][9] = (z_bad[0][9] + 1) % V.R
+    with pytest.raises(AssertionError): V.prove_batch([(idx[0], zs[0]), (idx[1], z_bad), (idx[2], zs[2])], setup, rand)
+    # the largest circuit need not come first, and equal sizes are fine
+    cs2, _, zs2, D2 = _batch_case([(30, 2, 8, 1), (30, 2, 9, 1)])
+    setup2 = V.Setup(TAU, S_GAMMA, D2); idx2 = [V.Index(c, setup2) for c in cs2]
+    _, d2 = V.prove_batch(list(zip(idx2, zs2)), setup2, V.random_stream(5, cs2[0].n_h, 2))
+    assert V.verify(idx2, setup2, [[z[:2] for z in zz] for zz in zs2], d2)
+    one, single = V.prove_batch([(idx2[0], zs2[0])], setup2, V.random_stream(6, cs2[0].n_h, 1))[1], V.prove(idx2[0], setup2, zs2[0][0], V.random_stream(6, cs2[0].n_h, 1))[1]
+    assert one == single
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize('k', [2, 3, 4, 5, 8])
 def test_device_prover_batch_matches_restatement(k):
