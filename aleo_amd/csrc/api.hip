@@ -726,6 +726,21 @@ int32_t aleo_mi355x_varuna_prove_indexed(uint64_t index_handle, const void* cons
   } catch (...) { return ALEO_MI355X_ERR_HIP; }
 }
 
+int32_t aleo_mi355x_varuna_prove_batch_indexed(const uint64_t* index_handles, size_t n_circuits, const void* const* assignments, const size_t* n_instances, uint64_t seed,
+                                               void* out_proof, size_t* len) {
+  try {
+    if (!index_handles || !assignments || !n_instances || !out_proof || !len || n_circuits < 1 || n_circuits > 8) { g_last_error = "varuna_prove_batch: null argument or circuit count outside 1..8"; return ALEO_MI355X_ERR_BAD_ARG; }
+    size_t total = 0;
+    for (size_t j = 0; j < n_circuits; ++j) { if (n_instances[j] < 1 || n_instances[j] > 8) { g_last_error = "varuna_prove_batch: 1..8 instances per circuit"; return ALEO_MI355X_ERR_BAD_ARG; } total += n_instances[j]; }
+    for (size_t i = 0; i < total; ++i) if (!assignments[i]) { g_last_error = "varuna_prove_batch: null assignment"; return ALEO_MI355X_ERR_BAD_ARG; }
+    API_BEGIN
+    std::vector<std::shared_ptr<VarunaIndexOwner>> ixk(n_circuits); std::vector<const aleo_mi355x_varuna_index*> views(n_circuits);
+    for (size_t j = 0; j < n_circuits; ++j) { int32_t rci = find_varuna(d, index_handles[j], &ixk[j]); if (rci) return rci; views[j] = varuna_index_view(ixk[j].get()); }
+    FIND_BASES(views[0]->committer_key)
+    return varuna_prove_batch(c, pb, views.data(), n_circuits, assignments, n_instances, seed, (uint8_t*)out_proof, len);
+  } catch (...) { return ALEO_MI355X_ERR_HIP; }
+}
+
 int32_t aleo_mi355x_varuna_last_timing(double* out_ms, int32_t cap) {
   int32_t n = cap < 8 ? cap : 8;
   for (int32_t i = 0; i < n; ++i) out_ms[i] = g_varuna_timing[i];

@@ -488,6 +488,22 @@ int32_t fr_lincomb(Ctx* c, void* d_dst, size_t n, const void* c0, const void* co
   return ALEO_MI355X_OK;
 }
 
+// dst[i] += src[i mod n_src] (n_src a power of two dividing n): multiplication of a block of n_src coefficients by 1 + X^n_src + X^(2 n_src) + ...,
+// the selector v_{H*} / v_H that puts a smaller circuit's remainder on the largest constraint domain of a proof (varuna.hip).
+__global__ void __launch_bounds__(256) k_fr_add_tiled(char* __restrict__ dst, size_t n, const char* __restrict__ src, size_t mask) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+    store_fp<Fr>(dst + i * 32, Fr::cond_sub<1>(Fr::add(load_fp<Fr>(dst + i * 32), load_fp<Fr>(src + (i & mask) * 32))));      // canonical inputs: < 2r
+}
+int32_t fr_add_tiled(Ctx* c, void* d_dst, size_t n, const void* d_src, size_t n_src, hipStream_t s) {
+  (void)c;
+  if (!n_src || (n_src & (n_src - 1)) || n % n_src) { g_last_error = "fr_add_tiled: block size must be a power of two dividing n"; return ALEO_MI355X_ERR_BAD_ARG; }
+  if (n == 0) return ALEO_MI355X_OK;
+  size_t want = (n + 255) / 256;
+  hipLaunchKernelGGL(k_fr_add_tiled, dim3((uint32_t)(want < 8192 ? want : 8192)), dim3(256), 0, s, (char*)d_dst, n, (const char*)d_src, n_src - 1);
+  HIPCHK(hipGetLastError());
+  return ALEO_MI355X_OK;
+}
+
 // The two sumcheck numerators, each one pass over evaluations that already sit in HBM (values of the operands on the larger domain):
 //   first  (domain 4|H|): dst = r * (a + eta_b b + eta_c a b) − t * z          [UPSTREAM-RECALL: round_functions/second.rs, the summed polynomial]
 //   matrix (domain 2|K|): dst = sum_M delta_M (vv val_M − (alpha beta − beta row_M − alpha col_M + row_col_M) f_M)   [fourth.rs]

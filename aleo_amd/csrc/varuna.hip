@@ -1,5 +1,5 @@
 // varuna.hip — the host side of one proof, native: the four AHP rounds, the evaluations and the two openings of
-// `Varuna::prove_batch` (one circuit, up to eight instances) as ONE call of the C ABI (`aleo_mi355x_varuna_prove`).
+// `Varuna::prove_batch` (up to eight circuits, each with up to eight instances) as ONE call of the C ABI (`aleo_mi355x_varuna_prove[_batch_indexed]`).
 //
 // Replaces (shape, not bytes — see DESIGN.md §4d for what differs from upstream and why) snarkVM 0.14.5
 //   algorithms/src/snark/varuna/varuna.rs                      Varuna::prove_batch
@@ -260,69 +260,74 @@ int32_t varuna_index_build(Ctx* c, const PinnedBases& pb, std::shared_ptr<Pinned
 
 
 // The state of one proof between the rounds (upstream: varuna::ahp::prover::State) and the round functions in the order upstream calls them.
-#define TAKE_M(var, elems) var = ar.take(elems); if (!var) { g_last_error = "varuna_prove: workspace accounting"; return ALEO_MI355X_ERR_HIP; }
-struct Prover {
-  static constexpr size_t HC = 3;                          // coefficients of a hiding polynomial (hiding bound 1)
-  Ctx* c; const PinnedBases& pb; const aleo_mi355x_varuna_index& ix; const size_t k; const uint64_t seed;
-  Prover(Ctx* c_, const PinnedBases& pb_, const aleo_mi355x_varuna_index& ix_, size_t k_, uint64_t seed_) : c(c_), pb(pb_), ix(ix_), k(k_), seed(seed_) {}
-  // sizes, stream, workspace
-  size_t n_h = 0, n_x = 0, L = 0, n4 = 0, nk[3] = {}, ko[3] = {}, k_sum = 0, n_k = 0; uint64_t D = 0; uint32_t lg_h = 0, lg_km[3] = {};
+// A proof covers m circuits (`keys_to_constraints: BTreeMap<&ProvingKey, &[Assignment]>`), each with its own instances: `Shared` is what they share —
+// the transcript and every challenge, the mask and g_1, h_1 over the largest constraint domain H*, h_2 over the largest non-zero domain K*, the two
+// openings — and one `Prover` per circuit holds that circuit's polynomials.  Circuit j enters the first sumcheck behind the selector
+// s_j = v_{H*} / v_{H_j} = sum_t X^(t |H_j|): its quotient adds into h_1 as it is, its remainder block tiles over H* (fr_add_tiled); see
+// oracle/varuna_ref.py prove_batch for the algebra.  With one circuit nothing is added or tiled: the circuit writes the shared buffers directly.
+#define TAKE_M(var, elems) var = sh.ar.take(elems); if (!var) { g_last_error = "varuna_prove: workspace accounting"; return ALEO_MI355X_ERR_HIP; }
+#define TAKE_S(var, elems) char* var = sh.ar.take(elems); if (!var) { g_last_error = "varuna_prove: workspace accounting"; return ALEO_MI355X_ERR_HIP; }
+static constexpr size_t HC = 3;                            // coefficients of a hiding polynomial (hiding bound 1)
+static constexpr size_t MAX_CIRCUITS = 8, MAX_INSTANCES = 8, MAX_TOTAL_INSTANCES = 32;
+
+struct Shared {
+  Ctx* c; const PinnedBases& pb; uint64_t seed;
+  Shared(Ctx* c_, const PinnedBases& pb_, uint64_t seed_) : c(c_), pb(pb_), seed(seed_) {}
+  size_t m = 0, K = 0, N = 0, n_kmax = 0, lead = 0, x_total = 0; uint64_t D = 0, gamma_offset = 0;
   hipStream_t s = nullptr; double t_mark[7] = {}; Arena ar{nullptr, 0, 0}; char* pin = nullptr; char* stage = nullptr; char* pin_small = nullptr;
   HFr one, neg1, r2; Transcript tr; uint64_t lay_mask = 0, lay_blind = 0, lay_blind_mask = 0;
-  // what the rounds hand on: polynomials in HBM, commitments, challenges
-  char *xp = nullptr, *wit = nullptr, *mask = nullptr, *ext = nullptr, *h1 = nullptr, *g1 = nullptr, *f = nullptr, *h2 = nullptr;
-  std::vector<std::vector<HFr>> x_poly; std::vector<HFr> blind, comb, evals; std::vector<uint8_t> wit_aff, comp;
-  uint8_t aff2[208], aff3[312], aff4[104], aff5[208];
-  HFr alpha, eta_b, eta_c, vh_alpha, beta, vh_beta, vv, sigma[3], delta[3], gamma, random_v;
-  size_t run0[3] = {}, runc[3] = {}, nrun = 0;
-
-  int32_t setup(const void* const* assignments);
-  int32_t first_round(const void* const* assignments);     // AHPForR1CS::prover_first_round + the 3k + 1 hiding commitments
-  int32_t second_round();                                  // prover_second_round: t, the first sumcheck, g_1, h_1
-  int32_t third_round();                                   // prover_third_round: f_M, sigma_M, g_M
-  int32_t fourth_round();                                  // prover_fourth_round: h_2
-  int32_t open();                                          // evaluations, the two linear combinations, both KZG openings
-  int32_t write(uint8_t* out, size_t* out_len);            // Proof::write_le
+  char *mask = nullptr, *bl = nullptr, *h1 = nullptr, *g1 = nullptr, *h2 = nullptr;
+  std::vector<HFr> blind, comb, evals; std::vector<uint8_t> wit_aff, aff3, comp, x_bytes;
+  uint8_t aff2[208], aff4[104], aff5[208];
+  HFr alpha, eta_b, eta_c, beta, gamma, random_v;
+  // staging offsets (elements of 32 bytes inside `stage`): x̂ coefficients | hiding polynomials | the opening's hiding quotient | rho
+  size_t st_blind() const { return x_total; }
+  size_t st_blq() const { return x_total + (3 * K + 1) * HC; }
+  size_t st_rho() const { return st_blq() + HC; }
 };
 
-int32_t Prover::setup(const void* const* assignments) {
-  (void)assignments;
+struct Prover {                                            // one circuit of the proof
+  Shared& sh; const aleo_mi355x_varuna_index& ix; const size_t j, k, q0;      // circuit number, its instances, the number of its first instance in the proof
+  Prover(Shared& sh_, const aleo_mi355x_varuna_index& ix_, size_t j_, size_t k_, size_t q0_) : sh(sh_), ix(ix_), j(j_), k(k_), q0(q0_) {}
+  size_t n_h = 0, n_x = 0, L = 0, n4 = 0, nk[3] = {}, ko[3] = {}, k_sum = 0, n_k = 0, x_off = 0, pin_off = 0; uint32_t lg_h = 0, lg_km[3] = {};
+  char *xp = nullptr, *wit = nullptr, *ext = nullptr, *hq = nullptr, *rq = nullptr, *f = nullptr, *evals_h = nullptr, *rho_dev = nullptr;
+  char *r4_terms[3] = {}; size_t r4_lens[3] = {};
+  std::vector<std::vector<HFr>> x_poly;
+  HFr vh_alpha, vh_beta, vv, sigma[3], delta[3];
+  size_t run0[3] = {}, runc[3] = {}, nrun = 0;
+  bool lead() const { return sh.lead == j; }
+  bool lagrange() const { return ix.lagrange_offset != 0; }
+
+  int32_t setup();
+  size_t workspace_elems() const { return n_h * (41 + 24 * k) + k_sum * 6 + n_k * 4 + 4096; }
+  int32_t first_round(const void* const* assignments, std::vector<MsmSeg>& sg);      // AHPForR1CS::prover_first_round for this circuit's instances
+  int32_t second_round();                                  // prover_second_round: t, this circuit's summand of the first sumcheck, its quotient and remainder
+  int32_t third_round();                                   // prover_third_round: f_M (sigma_M, g_M follow the read-back)
+  int32_t fourth_round();                                  // prover_fourth_round: the quotients h_M of this circuit, delta-weighted, run by run
+};
+
+int32_t Prover::setup() {
   n_h = ix.n_h; n_x = ix.n_x; L = n_h + 1; n4 = 4 * n_h;
   nk[0] = ix.n_k_a; nk[1] = ix.n_k_b; nk[2] = ix.n_k_c; ko[0] = 0; ko[1] = nk[0]; ko[2] = nk[0] + nk[1]; k_sum = nk[0] + nk[1] + nk[2];
-  n_k = nk[0] > nk[1] ? (nk[0] > nk[2] ? nk[0] : nk[2]) : (nk[1] > nk[2] ? nk[1] : nk[2]);      // K: the largest non-zero domain
-  D = ix.max_degree;
+  n_k = nk[0] > nk[1] ? (nk[0] > nk[2] ? nk[0] : nk[2]) : (nk[1] > nk[2] ? nk[1] : nk[2]);      // the largest non-zero domain of this circuit
+  const uint64_t D = ix.max_degree; const PinnedBases& pb = sh.pb;
   bool k_ok = true; for (int m = 0; m < 3; ++m) k_ok = k_ok && nk[m] >= 2 && !(nk[m] & (nk[m] - 1));
-  if (k < 1 || k > 8 || n_h < 2 || !k_ok || n_x < 1 || n_h < 2 * n_x || (n_h & (n_h - 1)) || (n_x & (n_x - 1)) ||
+  if (k < 1 || k > MAX_INSTANCES || n_h < 2 || !k_ok || n_x < 1 || n_h < 2 * n_x || (n_h & (n_h - 1)) || (n_x & (n_x - 1)) ||
       ix.n_public > n_x || ix.n_vars > n_h || ix.gamma_offset + HC > pb.n || (ix.lagrange_offset && ix.lagrange_offset + n_h + 1 > pb.n) || D + 1 > pb.n || 3 * n_h > D + 1 || n_k > D + 1) {
     g_last_error = "varuna_prove: inconsistent index / key sizes"; return ALEO_MI355X_ERR_BAD_ARG;
   }
   lg_h = 0; lg_km[0] = lg_km[1] = lg_km[2] = 0; while ((1ull << lg_h) < n_h) ++lg_h;
   for (int m = 0; m < 3; ++m) while ((1ull << lg_km[m]) < nk[m]) ++lg_km[m];
-  s = c->stream;
-  t_mark[0] = now_ms();
-  // ---- workspace ------------------------------------------------------------------------------------------------------------------
-  const size_t elems = n_h * (41 + 24 * k) + k_sum * 6 + n_k * 4 + 4096;
-  RC(c->prover_ws.reserve(elems * 32 + (64 << 10)));
-  ar = Arena{(char*)c->prover_ws.p, 0, c->prover_ws.cap};
-  const size_t stage_elems = k * n_x + (3 * k + 1) * HC + HC + 3 * k;      // x̂ coefficients, hiding polynomials, the opening's hiding quotient: staged through pinned memory
-  const size_t pin_need = (k * n_h + stage_elems) * 32 + 4096;
-  if (c->prover_pin_cap < pin_need) {
-    if (c->prover_pin) { HIPCHK(hipStreamSynchronize(s)); (void)hipHostFree(c->prover_pin); c->prover_pin = nullptr; c->prover_pin_cap = 0; }
-    HIPCHK(hipHostMalloc(&c->prover_pin, pin_need + pin_need / 8, hipHostMallocDefault)); c->prover_pin_cap = pin_need + pin_need / 8;
-  }
-  pin = (char*)c->prover_pin; stage = pin + k * n_h * 32; pin_small = stage + stage_elems * 32;      // 4 KB for small read-backs
-  one = HFr::one(); neg1 = HFr::neg(one); std::memcpy(r2.l, host::HParams<4>::R2, 32);
-  // randomness layout (oracle/varuna_ref.py randomness_layout)
-  lay_mask = 3 * k; lay_blind = 3 * k + 3 * n_h; lay_blind_mask = lay_blind + 3 * HC * k;
   return ALEO_MI355X_OK;
 }
 
-int32_t Prover::first_round(const void* const* assignments) {
-  // ---- round 1 ------------------------------------------------------------------------------------------------------------------------
-  TAKE(zH, k * n_h) TAKE(ev, 3 * k * n_h) TAKE(xh, k * n_h) TAKE_M(xp, k * n_x) TAKE_M(wit, 3 * k * L) TAKE_M(mask, 3 * n_h) TAKE(bl, (3 * k + 1) * HC)
-  x_poly.assign(k, {}); std::vector<uint8_t> x_bytes(k * n_x * 32, 0);
+int32_t Prover::first_round(const void* const* assignments, std::vector<MsmSeg>& sg) {
+  Ctx* c = sh.c; hipStream_t s = sh.s; Arena& ar = sh.ar; char* pin = sh.pin + pin_off * 32; char* stage = sh.stage;
+  TAKE(zH, k * n_h) TAKE(ev, 3 * k * n_h) TAKE(xh, k * n_h) TAKE_M(xp, k * n_x) TAKE_M(wit, 3 * k * L)
+  x_poly.assign(k, {});
+  const size_t xb0 = sh.x_bytes.size(); sh.x_bytes.resize(xb0 + k * n_x * 32, 0); uint8_t* x_bytes = sh.x_bytes.data() + xb0;
   uint32_t lg_x = 0; while ((1ull << lg_x) < n_x) ++lg_x;
-  const HFr gx_inv = HFr::inv(domain_gen(n_x)), nx_inv = inv_pow2(lg_x);
+  const HFr one = sh.one, gx_inv = HFr::inv(domain_gen(n_x)), nx_inv = inv_pow2(lg_x);
   const uint32_t* pos = (const uint32_t*)ix.positions;
   const bool host_layout = ix.positions_device == nullptr;      // without the positions in HBM the host lays the assignment out on H (pinned staging)
   if (host_layout) std::memset(pin, 0, k * n_h * 32);
@@ -335,19 +340,19 @@ int32_t Prover::first_round(const void* const* assignments) {
         std::memcpy(pin + (i * n_h + pos[v]) * 32, z + v * 32, 32);
       }
     std::vector<HFr> xe(n_x, HFr::zero());
-    for (size_t j = 0; j < ix.n_public; ++j) { HFr v; std::memcpy(v.l, z + j * 32, 32); if (HFr::geq_p(v.l)) { g_last_error = "varuna_prove: assignment not canonical"; return ALEO_MI355X_ERR_BAD_ARG; } std::memcpy(&x_bytes[(i * n_x + j) * 32], v.l, 32); xe[j] = HFr::to_mont(v); }
+    for (size_t t = 0; t < ix.n_public; ++t) { HFr v; std::memcpy(v.l, z + t * 32, 32); if (HFr::geq_p(v.l)) { g_last_error = "varuna_prove: assignment not canonical"; return ALEO_MI355X_ERR_BAD_ARG; } std::memcpy(&x_bytes[(i * n_x + t) * 32], v.l, 32); xe[t] = HFr::to_mont(v); }
     x_poly[i].assign(n_x, HFr::zero());                    // inverse DFT over X, O(|X|^2): |X| is the (padded) number of public inputs
     HFr wa = one;                                          // gx_inv^a
     for (size_t a = 0; a < n_x; ++a) {
       HFr acc = HFr::zero(), w = one;
-      for (size_t j = 0; j < n_x; ++j) { acc = HFr::add(acc, HFr::mul(xe[j], w)); w = HFr::mul(w, wa); }
+      for (size_t t = 0; t < n_x; ++t) { acc = HFr::add(acc, HFr::mul(xe[t], w)); w = HFr::mul(w, wa); }
       x_poly[i][a] = HFr::mul(acc, nx_inv); wa = HFr::mul(wa, gx_inv);
     }
   }
-  for (size_t i = 0; i < k; ++i) std::memcpy(stage + i * n_x * 32, x_poly[i].data(), n_x * 32);
+  for (size_t i = 0; i < k; ++i) std::memcpy(stage + (x_off + i * n_x) * 32, x_poly[i].data(), n_x * 32);
   if (host_layout) {
     HIPCHK(hipMemcpyAsync(zH, pin, k * n_h * 32, hipMemcpyHostToDevice, s));
-    RC(fr_lin(c, zH, k * n_h, nullptr, r2.l, zH, nullptr, nullptr, s));                   // canonical -> Montgomery
+    RC(fr_lin(c, zH, k * n_h, nullptr, sh.r2.l, zH, nullptr, nullptr, s));                // canonical -> Montgomery
   } else {                                                                                  // upload in variable order; scatter + Montgomery form on the device
     TAKE(zraw, k * ix.n_vars)
     HIPCHK(hipMemsetAsync(zH, 0, k * n_h * 32, s));
@@ -356,7 +361,7 @@ int32_t Prover::first_round(const void* const* assignments) {
       RC(fr_scatter_to_mont(c, zH + i * n_h * 32, zraw + i * ix.n_vars * 32, ix.positions_device, ix.n_vars, s));
     }
   }
-  HIPCHK(hipMemcpyAsync(xp, stage, k * n_x * 32, hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemcpyAsync(xp, stage + x_off * 32, k * n_x * 32, hipMemcpyHostToDevice, s));
   HIPCHK(hipMemsetAsync(xh, 0, k * n_h * 32, s));
   for (size_t i = 0; i < k; ++i) {
     char* e0 = ev + 3 * i * n_h * 32; char* z_i = zH + i * n_h * 32; char* xh_i = xh + i * n_h * 32;
@@ -367,63 +372,38 @@ int32_t Prover::first_round(const void* const* assignments) {
     RC(fr_vec_op(c, e0, z_i, xh_i, n_h, 2, s));                                             // z − x̂ on H
     RC(fr_vec_op(c, e0, e0, ix.vx_inv, n_h, 0, s));                                         // / v_X off X, 0 on X
   }
-  const bool lagrange = ix.lagrange_offset != 0;          // KZG10::commit_lagrange for w, z_a, z_b: commit the evaluations (kept here) against L_i(tau) G
-  char* evals_h = nullptr; char* rho_dev = nullptr;
-  if (lagrange) {
+  if (lagrange()) {                                        // KZG10::commit_lagrange for w, z_a, z_b: commit the evaluations (kept here) against L_i(tau) G
     evals_h = ar.take(3 * k * n_h); rho_dev = ar.take(3 * k);
     if (!evals_h || !rho_dev) { g_last_error = "varuna_prove: workspace accounting"; return ALEO_MI355X_ERR_HIP; }
     HIPCHK(hipMemcpyAsync(evals_h, ev, 3 * k * n_h * 32, hipMemcpyDeviceToDevice, s));
   }
   RC(ntt_run(c, ev, lg_h, 3 * k, 0, 1, 0, s));
-  blind.assign((3 * k + 1) * HC, HFr::zero());
   {
-    HFr rho[24];                                                                            // rho_w, rho_a, rho_b of instance q / 3
+    HFr rho[3 * MAX_INSTANCES];                                                             // rho_w, rho_a, rho_b of instance q / 3
     for (size_t q = 0; q < 3 * k; ++q) {
-      rho[q] = random_fr(seed, q);
-      for (size_t j = 0; j < HC; ++j) blind[q * HC + j] = random_fr(seed, lay_blind + HC * q + j);
+      rho[q] = random_fr(sh.seed, 3 * q0 + q);
+      for (size_t t = 0; t < HC; ++t) sh.blind[(3 * q0 + q) * HC + t] = random_fr(sh.seed, sh.lay_blind + HC * (3 * q0 + q) + t);
     }
     RC(fr_blind_rows(c, wit, ev, n_h, 3 * k, rho, s));                                      // + rho (X^|H| − 1), all 3k polynomials in one launch
-    if (lagrange) { char* st = stage + (k * n_x + (3 * k + 1) * HC + HC) * 32; std::memcpy(st, rho, 3 * k * 32); HIPCHK(hipMemcpyAsync(rho_dev, st, 3 * k * 32, hipMemcpyHostToDevice, s)); }
+    if (lagrange()) { char* st = stage + (sh.st_rho() + 3 * q0) * 32; std::memcpy(st, rho, 3 * k * 32); HIPCHK(hipMemcpyAsync(rho_dev, st, 3 * k * 32, hipMemcpyHostToDevice, s)); }
   }
-  for (size_t j = 0; j < HC; ++j) blind[3 * k * HC + j] = random_fr(seed, lay_blind_mask + j);
-  RC(fr_random(c, mask, 3 * n_h, seed, lay_mask, 1, s));
-  RC(fr_lin(c, mask, 1, nullptr, neg1.l, mask + n_h * 32, neg1.l, mask + 2 * n_h * 32, s));   // sum over H = |H| (m_0 + m_|H| + m_2|H|) = 0
-  std::memcpy(stage + k * n_x * 32, blind.data(), blind.size() * 32);
-  HIPCHK(hipMemcpyAsync(bl, stage + k * n_x * 32, blind.size() * 32, hipMemcpyHostToDevice, s));
-  wit_aff.assign(104 * (3 * k + 1), 0); comp.assign(48 * 8, 0);
-  {
-    // with the evaluations against the Lagrange powers AND a narrow-window table over [hiding powers | Lagrange powers | v_H G] the 3k witness
-    // commitments are one sparse chain (their scalars are mostly 0 / 1), the mask (uniform coefficients against the monomial powers) another
-    const bool split = lagrange && pb.range.d && pb.range_off <= ix.gamma_offset && ix.lagrange_offset + n_h + 1 <= pb.range_off + pb.range.cover &&
-                       ix.gamma_offset + HC <= pb.range_off + pb.range.cover;
-    std::vector<MsmSeg> sg, sm;
-    for (size_t q = 0; q <= 3 * k; ++q) {
-      std::vector<MsmSeg>& dst = (split && q == 3 * k) ? sm : sg;
-      MsmSeg a; a.out = (split && q == 3 * k) ? 0u : (uint32_t)q;
-      if (q < 3 * k && lagrange) {                                                            // sum_i evals_i L_i(tau) G + rho v_H(tau) G
-        a.d_ptr = evals_h + q * n_h * 32; a.len = n_h; a.off = ix.lagrange_offset; dst.push_back(a);
-        MsmSeg v; v.d_ptr = rho_dev + q * 32; v.len = 1; v.off = ix.lagrange_offset + n_h; v.out = a.out; dst.push_back(v);
-      } else { a.d_ptr = q < 3 * k ? wit + q * L * 32 : mask; a.len = q < 3 * k ? L : 3 * n_h; a.off = 0; dst.push_back(a); }
-      MsmSeg b; b.d_ptr = bl + q * HC * 32; b.len = HC; b.off = ix.gamma_offset; b.out = a.out; dst.push_back(b);
-    }
-    if (split) { RC(commit(c, pb, sg, (uint32_t)(3 * k), wit_aff.data(), s, true)); RC(commit(c, pb, sm, 1, wit_aff.data() + 104 * 3 * k, s)); }
-    else RC(commit(c, pb, sg, (uint32_t)(3 * k + 1), wit_aff.data(), s));
+  for (size_t q = 0; q < 3 * k; ++q) {
+    MsmSeg a; a.out = (uint32_t)(3 * q0 + q);
+    if (lagrange()) {                                                                       // sum_i evals_i L_i(tau) G + rho v_H(tau) G
+      a.d_ptr = evals_h + q * n_h * 32; a.len = n_h; a.off = ix.lagrange_offset; sg.push_back(a);
+      MsmSeg v; v.d_ptr = rho_dev + q * 32; v.len = 1; v.off = ix.lagrange_offset + n_h; v.out = a.out; sg.push_back(v);
+    } else { a.d_ptr = wit + q * L * 32; a.len = L; a.off = 0; sg.push_back(a); }
+    MsmSeg b; b.d_ptr = sh.bl + (3 * q0 + q) * HC * 32; b.len = HC; b.off = ix.gamma_offset; b.out = a.out; sg.push_back(b);
   }
-  std::vector<uint8_t> c1(48 * (3 * k + 1));
-  RC(aleo_mi355x_g1_compress(c1.data(), wit_aff.data(), 3 * k + 1));
-  tr.absorb(ix.vk_bytes, ix.vk_len); tr.absorb(x_bytes.data(), x_bytes.size()); tr.absorb(c1.data(), c1.size());
-  alpha = tr.challenge("alpha", 5); eta_b = tr.challenge("eta_b", 5); eta_c = tr.challenge("eta_c", 5);
-  comb.assign(k, one);
-  for (size_t i = 1; i < k; ++i) { char lab[12] = "combiner"; uint32_t ii = (uint32_t)i; std::memcpy(lab + 8, &ii, 4); comb[i] = tr.challenge(lab, 12); }
-  t_mark[1] = now_ms();
   return ALEO_MI355X_OK;
 }
 
 int32_t Prover::second_round() {
-  // ---- round 2: the first sumcheck --------------------------------------------------------------------------------------------------------
+  Ctx* c = sh.c; hipStream_t s = sh.s; Arena& ar = sh.ar; const HFr &alpha = sh.alpha, &eta_b = sh.eta_b, &eta_c = sh.eta_c;
   vh_alpha = vanish(n_h, alpha);
   if (vh_alpha.is_zero()) { g_last_error = "varuna_prove: alpha landed in H"; return ALEO_MI355X_ERR_HIP; }
-  TAKE_M(ext, 3 * n_h) TAKE(rt, 2 * n_h) TAKE(E, (2 + 3 * k) * n4) TAKE(Q, n4) TAKE_M(h1, 2 * n_h) TAKE_M(g1, n_h)
+  TAKE_M(ext, 3 * n_h) TAKE(rt, 2 * n_h) TAKE(E, (2 + 3 * k) * n4) TAKE(Q, n4)
+  if (lead()) { hq = sh.h1; rq = sh.g1; } else { TAKE_M(hq, 2 * n_h) TAKE_M(rq, n_h) }
   {
     const HFr first = HFr::pow_u64(alpha, n_h - 1), ratio = HFr::inv(alpha);
     RC(fr_powers(c, rt, n_h, first.l, ratio.l, s));                                          // r(alpha, X) = sum_k alpha^(|H|-1-k) X^k
@@ -444,35 +424,22 @@ int32_t Prover::second_round() {
     RC(ahp_first_sumcheck(c, e_z + n4 * 32, n4, E, e_z + n4 * 32, e_z + 2 * n4 * 32, E + n4 * 32, e_z, eta_b.l, eta_c.l, s));
   }
   char* q1 = E + 3 * n4 * 32;
-  if (k > 1) {
-    const void* terms[8]; size_t lens[8]; HFr co[8];
-    for (size_t i = 0; i < k; ++i) { terms[i] = E + (3 + 3 * i) * n4 * 32; lens[i] = n4; co[i] = comb[i]; }
+  if (k > 1 || q0 != 0) {                                                 // sum_i c_i numerator_i (the proof's first instance has c = 1)
+    const void* terms[MAX_INSTANCES]; size_t lens[MAX_INSTANCES]; HFr co[MAX_INSTANCES];
+    for (size_t i = 0; i < k; ++i) { terms[i] = E + (3 + 3 * i) * n4 * 32; lens[i] = n4; co[i] = sh.comb[q0 + i]; }
     RC(fr_lincomb(c, Q, n4, nullptr, terms, lens, co, k, s)); q1 = Q;
   }
   RC(ntt_run(c, q1, lg_h + 2, 1, 0, 1, 0, s));
-  RC(fr_vec_op(c, q1, q1, mask, 3 * n_h, 1, s));                                            // q_1 = h_1 (X^|H| − 1) + X g_1, degree < 3|H|
-  HIPCHK(hipMemcpyAsync(h1 + n_h * 32, q1 + 2 * n_h * 32, n_h * 32, hipMemcpyDeviceToDevice, s));   // quotient blocks: p2, p1 + p2; remainder p0 + p1 + p2
-  RC(fr_vec_op(c, h1, q1 + n_h * 32, q1 + 2 * n_h * 32, n_h, 1, s));
-  RC(fr_vec_op(c, g1, q1, h1, n_h, 1, s));
-  HIPCHK(hipMemcpyAsync(pin_small + 3584, g1, 32, hipMemcpyDeviceToHost, s));               // the sum over H (remainder's constant term): read with the commitments
-  {
-    std::vector<MsmSeg> sg(2);
-    sg[0].d_ptr = g1 + 32; sg[0].len = n_h - 1; sg[0].off = D - (n_h - 2); sg[0].out = 0;    // degree bound |H| − 2: shifted powers
-    sg[1].d_ptr = h1; sg[1].len = 2 * n_h; sg[1].off = 0; sg[1].out = 1;
-    RC(commit(c, pb, sg, 2, aff2, s));
-  }
-  {                                                                                         // commit() returned after the stream drained: the copy above has landed
-    uint64_t sum[4]; std::memcpy(sum, pin_small + 3584, 32);
-    if (sum[0] | sum[1] | sum[2] | sum[3]) { g_last_error = "varuna_prove: the assignment does not satisfy the circuit (first sumcheck: the sum over H is not zero)"; return ALEO_MI355X_ERR_UNSATISFIED; }
-  }
-  RC(aleo_mi355x_g1_compress(comp.data(), aff2, 2)); tr.absorb(comp.data(), 96);
-  beta = tr.challenge("beta", 4);
-  t_mark[2] = now_ms();
+  if (lead()) RC(fr_vec_op(c, q1, q1, sh.mask, 3 * n_h, 1, s));                             // q = h (X^|H| − 1) + X g, degree < 3|H|; the mask rides with the largest domain
+  HIPCHK(hipMemcpyAsync(hq + n_h * 32, q1 + 2 * n_h * 32, n_h * 32, hipMemcpyDeviceToDevice, s));   // quotient blocks: p2, p1 + p2; remainder p0 + p1 + p2
+  RC(fr_vec_op(c, hq, q1 + n_h * 32, q1 + 2 * n_h * 32, n_h, 1, s));
+  RC(fr_vec_op(c, rq, q1, hq, n_h, 1, s));
+  HIPCHK(hipMemcpyAsync(sh.pin_small + 3584 + 32 * j, rq, 32, hipMemcpyDeviceToHost, s));   // this circuit's sum over H (the remainder's constant term): read with the commitments
   return ALEO_MI355X_OK;
 }
 
 int32_t Prover::third_round() {
-  // ---- round 3: three rational sumchecks over K ----------------------------------------------------------------------------------------------
+  Ctx* c = sh.c; hipStream_t s = sh.s; Arena& ar = sh.ar; const HFr& beta = sh.beta;
   vh_beta = vanish(n_h, beta);
   if (vh_beta.is_zero()) { g_last_error = "varuna_prove: beta landed in H"; return ALEO_MI355X_ERR_HIP; }
   vv = HFr::mul(vh_alpha, vh_beta);
@@ -490,159 +457,333 @@ int32_t Prover::third_round() {
   nrun = 0;
   for (size_t m = 0; m < 3;) { size_t cnt = 1; while (m + cnt < 3 && nk[m + cnt] == nk[m]) ++cnt; run0[nrun] = m; runc[nrun++] = cnt; m += cnt; }
   for (size_t r = 0; r < nrun; ++r) RC(ntt_run(c, f + ko[run0[r]] * 32, lg_km[run0[r]], runc[r], 0, 1, 0, s));
-  for (size_t m = 0; m < 3; ++m) HIPCHK(hipMemcpyAsync(pin_small + 32 * m, f + ko[m] * 32, 32, hipMemcpyDeviceToHost, s));
-  HIPCHK(hipStreamSynchronize(s));
-  uint8_t sig_bytes[96];
-  for (size_t m = 0; m < 3; ++m) { HFr v; std::memcpy(v.l, pin_small + 32 * m, 32); sigma[m] = HFr::mul(v, fr_u64(nk[m])); fr_bytes(sig_bytes + 32 * m, sigma[m]); }
-  {
-    std::vector<MsmSeg> sg(3);
-    for (size_t m = 0; m < 3; ++m) { sg[m].d_ptr = f + (ko[m] + 1) * 32; sg[m].len = nk[m] - 1; sg[m].off = D - (nk[m] - 2); sg[m].out = (uint32_t)m; }
-    RC(commit(c, pb, sg, 3, aff3, s));
-  }
-  RC(aleo_mi355x_g1_compress(comp.data(), aff3, 3));
-  { uint8_t b[96 + 144]; std::memcpy(b, sig_bytes, 96); std::memcpy(b + 96, comp.data(), 144); tr.absorb(b, sizeof b); }
-  delta[0] = one; delta[1] = tr.challenge("delta_b", 7); delta[2] = tr.challenge("delta_c", 7);
-  t_mark[3] = now_ms();
+  for (size_t m = 0; m < 3; ++m) HIPCHK(hipMemcpyAsync(sh.pin_small + 32 * (3 * j + m), f + ko[m] * 32, 32, hipMemcpyDeviceToHost, s));
   return ALEO_MI355X_OK;
 }
 
 int32_t Prover::fourth_round() {
-  // ---- round 4 ----------------------------------------------------------------------------------------------------------------------------------
-  TAKE(F, 2 * k_sum) TAKE(B, 2 * k_sum) TAKE_M(h2, n_k)                                          // per matrix on its own domain of size 2|K_M|
+  Ctx* c = sh.c; hipStream_t s = sh.s; Arena& ar = sh.ar; const HFr &alpha = sh.alpha, &beta = sh.beta;
+  TAKE(F, 2 * k_sum) TAKE(B, 2 * k_sum)                                                       // per matrix on its own domain of size 2|K_M|
   HIPCHK(hipMemsetAsync(F, 0, 2 * k_sum * 32, s));
-  {
-    const void* terms[3]; size_t lens[3]; HFr co[3];
-    for (size_t r = 0; r < nrun; ++r) {
-      const size_t m0 = run0[r], cnt = runc[r], n2 = 2 * nk[m0]; char* Fr0 = F + 2 * ko[m0] * 32; char* Br = B + 2 * ko[m0] * 32;
-      HFr consts[7] = {HFr::zero(), HFr::zero(), HFr::zero(), HFr::mul(alpha, beta), HFr::neg(alpha), HFr::neg(beta), vv};
-      const void* idx[3] = {nullptr, nullptr, nullptr}; const void* ff[3] = {nullptr, nullptr, nullptr};
-      for (size_t j = 0; j < cnt; ++j) {
-        const size_t m = m0 + j;
-        HIPCHK(hipMemcpyAsync(F + 2 * ko[m] * 32, f + ko[m] * 32, nk[m] * 32, hipMemcpyDeviceToDevice, s));
-        idx[j] = (const char*)ix.k2_evals + 8 * ko[m] * 32; ff[j] = F + 2 * ko[m] * 32; consts[j] = delta[m];
-      }
-      RC(ntt_run(c, Fr0, lg_km[m0] + 1, cnt, 0, 0, 0, s));
-      RC(ahp_matrix_sumcheck(c, Br, n2, idx, n2, ff, consts, s));                                // sum over the run of delta_M (vv val_M − b_M f_M) = h (X^|K| − 1)
-      RC(ntt_run(c, Br, lg_km[m0] + 1, 1, 0, 1, 0, s));
-      terms[r] = Br + nk[m0] * 32; lens[r] = nk[m0]; co[r] = one;                              // its upper half
+  for (size_t r = 0; r < nrun; ++r) {
+    const size_t m0 = run0[r], cnt = runc[r], n2 = 2 * nk[m0]; char* Fr0 = F + 2 * ko[m0] * 32; char* Br = B + 2 * ko[m0] * 32;
+    HFr consts[7] = {HFr::zero(), HFr::zero(), HFr::zero(), HFr::mul(alpha, beta), HFr::neg(alpha), HFr::neg(beta), vv};
+    const void* idx[3] = {nullptr, nullptr, nullptr}; const void* ff[3] = {nullptr, nullptr, nullptr};
+    for (size_t t = 0; t < cnt; ++t) {
+      const size_t m = m0 + t;
+      HIPCHK(hipMemcpyAsync(F + 2 * ko[m] * 32, f + ko[m] * 32, nk[m] * 32, hipMemcpyDeviceToDevice, s));
+      idx[t] = (const char*)ix.k2_evals + 8 * ko[m] * 32; ff[t] = F + 2 * ko[m] * 32; consts[t] = delta[m];
     }
-    RC(fr_lincomb(c, h2, n_k, nullptr, terms, lens, co, nrun, s));                                 // h_2 = sum_M delta_M h_M
+    RC(ntt_run(c, Fr0, lg_km[m0] + 1, cnt, 0, 0, 0, s));
+    RC(ahp_matrix_sumcheck(c, Br, n2, idx, n2, ff, consts, s));                                // sum over the run of delta_M (vv val_M − b_M f_M) = h (X^|K| − 1)
+    RC(ntt_run(c, Br, lg_km[m0] + 1, 1, 0, 1, 0, s));
+    r4_terms[r] = Br + nk[m0] * 32; r4_lens[r] = nk[m0];                                     // its upper half
   }
-  {
-    std::vector<MsmSeg> sg(1); sg[0].d_ptr = h2; sg[0].len = n_k; sg[0].off = 0; sg[0].out = 0;
-    RC(commit(c, pb, sg, 1, aff4, s));
-  }
-  RC(aleo_mi355x_g1_compress(comp.data(), aff4, 1)); tr.absorb(comp.data(), 48);
-  gamma = tr.challenge("gamma", 5);
-  t_mark[4] = now_ms();
   return ALEO_MI355X_OK;
 }
 
-int32_t Prover::open() {
-  // ---- evaluations -------------------------------------------------------------------------------------------------------------------------------
-  TAKE(evd, k + 8) TAKE(pbeta, 3 * n_h) TAKE(wq, 3 * n_h) TAKE(blq, HC) TAKE(pg, n_k) TAKE(gq, n_k)
-  {
-    const void* polys[12]; size_t lens[12]; HFr pts[12];
-    for (size_t i = 0; i < k; ++i) { polys[i] = wit + (3 * i + 2) * L * 32; lens[i] = L; pts[i] = beta; }
-    polys[k] = g1 + 32; lens[k] = n_h - 1; pts[k] = beta;
-    for (size_t m = 0; m < 3; ++m) { polys[k + 1 + m] = f + (ko[m] + 1) * 32; lens[k + 1 + m] = nk[m] - 1; pts[k + 1 + m] = gamma; }
-    RC(fr_eval_batch(c, evd, polys, lens, pts, k + 4, s));
+// ---- the proof: rounds over all circuits, commitments and transcript in between -----------------------------------------------------------------------
+struct Batch {
+  Shared sh; std::vector<std::unique_ptr<Prover>> P;
+  Batch(Ctx* c, const PinnedBases& pb, uint64_t seed) : sh(c, pb, seed) {}
+  int32_t setup(const aleo_mi355x_varuna_index* const* ixs, size_t m, const size_t* ks);
+  int32_t first_round(const void* const* assignments);     // + the 3K + 1 hiding commitments
+  int32_t second_round();                                  // g_1, h_1
+  int32_t third_round();                                   // sigma_{j,M}, g_{j,M}
+  int32_t fourth_round();                                  // h_2
+  int32_t open();                                          // evaluations, the two linear combinations, both KZG openings
+  int32_t write(uint8_t* out, size_t* out_len);            // Proof::write_le
+};
+
+static void batch_inverse_vec(std::vector<HFr>& v) {        // Montgomery's trick on the host: one inversion for all (non-zero) values
+  std::vector<HFr> pre(v.size()); HFr acc = HFr::one();
+  for (size_t i = 0; i < v.size(); ++i) { pre[i] = acc; acc = HFr::mul(acc, v[i]); }
+  acc = HFr::inv(acc);
+  for (size_t i = v.size(); i-- > 0;) { const HFr t = HFr::mul(acc, pre[i]); acc = HFr::mul(acc, v[i]); v[i] = t; }
+}
+// dst (n values) = c0 at X^0 + sum of terms, any number of them: fr_lincomb takes 28 per launch, later launches carry dst along as a term
+static int32_t lincomb_any(Ctx* c, char* dst, size_t n, const HFr& c0, std::vector<const void*>& terms, std::vector<size_t>& lens, std::vector<HFr>& co, hipStream_t s) {
+  constexpr size_t LC = 28; size_t at = 0; bool first = true;
+  do {
+    const void* t[LC]; size_t l[LC]; HFr k[LC]; size_t nt = 0;
+    if (!first) { t[nt] = dst; l[nt] = n; k[nt++] = HFr::one(); }
+    while (nt < LC && at < terms.size()) { t[nt] = terms[at]; l[nt] = lens[at]; k[nt++] = co[at++]; }
+    RC(fr_lincomb(c, dst, n, first ? c0.l : nullptr, t, l, k, nt, s));
+    first = false;
+  } while (at < terms.size());
+  return ALEO_MI355X_OK;
+}
+
+int32_t Batch::setup(const aleo_mi355x_varuna_index* const* ixs, size_t m, const size_t* ks) {
+  Ctx* c = sh.c;
+  if (m < 1 || m > MAX_CIRCUITS) { g_last_error = "varuna_prove: 1..8 circuits per proof"; return ALEO_MI355X_ERR_BAD_ARG; }
+  sh.m = m; sh.K = 0;
+  for (size_t j = 0; j < m; ++j) {
+    if (!ixs[j] || !ixs[j]->positions || !ixs[j]->vk_bytes) { g_last_error = "varuna_prove: null index"; return ALEO_MI355X_ERR_BAD_ARG; }
+    if (ks[j] < 1 || ks[j] > MAX_INSTANCES) { g_last_error = "varuna_prove: 1..8 instances per circuit"; return ALEO_MI355X_ERR_BAD_ARG; }
+    P.emplace_back(new Prover(sh, *ixs[j], j, ks[j], sh.K)); sh.K += ks[j];
+    RC(P[j]->setup());
+    if (ixs[j]->committer_key != ixs[0]->committer_key || ixs[j]->max_degree != ixs[0]->max_degree || ixs[j]->gamma_offset != ixs[0]->gamma_offset) {
+      g_last_error = "varuna_prove: the circuits of one proof must share one committer key"; return ALEO_MI355X_ERR_BAD_ARG;
+    }
   }
-  HIPCHK(hipMemcpyAsync(pin_small, evd, (k + 4) * 32, hipMemcpyDeviceToHost, s));
+  if (sh.K > MAX_TOTAL_INSTANCES) { g_last_error = "varuna_prove: at most 32 instances per proof"; return ALEO_MI355X_ERR_BAD_ARG; }
+  sh.D = ixs[0]->max_degree; sh.gamma_offset = ixs[0]->gamma_offset;
+  sh.N = 0; sh.n_kmax = 0; sh.x_total = 0; size_t pin_elems = 0, elems = 0;
+  for (size_t j = 0; j < m; ++j) {
+    Prover& p = *P[j];
+    if (p.n_h > sh.N) { sh.N = p.n_h; sh.lead = j; }                                        // the first circuit with the largest constraint domain carries mask, g_1, h_1
+    if (p.n_k > sh.n_kmax) sh.n_kmax = p.n_k;
+    p.x_off = sh.x_total; sh.x_total += p.k * p.n_x; p.pin_off = pin_elems; pin_elems += p.k * p.n_h; elems += p.workspace_elems();
+  }
+  sh.s = c->stream;
+  sh.t_mark[0] = now_ms();
+  // ---- workspace ------------------------------------------------------------------------------------------------------------------
+  elems += m > 1 ? 16 * sh.N + 4 * sh.n_kmax + 4096 : 0;                                  // the shared polynomials beside the per-circuit accounting (which already covers one circuit's)
+  RC(c->prover_ws.reserve(elems * 32 + (64 << 10)));
+  sh.ar = Arena{(char*)c->prover_ws.p, 0, c->prover_ws.cap};
+  const size_t stage_elems = sh.x_total + (3 * sh.K + 1) * HC + HC + 3 * sh.K;             // x̂ coefficients, hiding polynomials, the opening's hiding quotient, rho: staged through pinned memory
+  const size_t pin_need = (pin_elems + stage_elems) * 32 + 4096;
+  if (c->prover_pin_cap < pin_need) {
+    if (c->prover_pin) { HIPCHK(hipStreamSynchronize(sh.s)); (void)hipHostFree(c->prover_pin); c->prover_pin = nullptr; c->prover_pin_cap = 0; }
+    HIPCHK(hipHostMalloc(&c->prover_pin, pin_need + pin_need / 8, hipHostMallocDefault)); c->prover_pin_cap = pin_need + pin_need / 8;
+  }
+  sh.pin = (char*)c->prover_pin; sh.stage = sh.pin + pin_elems * 32; sh.pin_small = sh.stage + stage_elems * 32;      // 4 KB for small read-backs
+  sh.one = HFr::one(); sh.neg1 = HFr::neg(sh.one); std::memcpy(sh.r2.l, host::HParams<4>::R2, 32);
+  // randomness layout (oracle/varuna_ref.py randomness_layout over the largest |H| and all instances)
+  sh.lay_mask = 3 * sh.K; sh.lay_blind = 3 * sh.K + 3 * sh.N; sh.lay_blind_mask = sh.lay_blind + 3 * HC * sh.K;
+  return ALEO_MI355X_OK;
+}
+
+int32_t Batch::first_round(const void* const* assignments) {
+  Ctx* c = sh.c; hipStream_t s = sh.s; const size_t K = sh.K, N = sh.N;
+  TAKE_M(sh.bl, (3 * K + 1) * HC) TAKE_M(sh.mask, 3 * N)
+  sh.blind.assign((3 * K + 1) * HC, HFr::zero()); sh.x_bytes.clear();
+  std::vector<MsmSeg> sg, sm;
+  for (auto& p : P) RC(p->first_round(assignments + p->q0, sg));
+  for (size_t t = 0; t < HC; ++t) sh.blind[3 * K * HC + t] = random_fr(sh.seed, sh.lay_blind_mask + t);
+  RC(fr_random(c, sh.mask, 3 * N, sh.seed, sh.lay_mask, 1, s));
+  RC(fr_lin(c, sh.mask, 1, nullptr, sh.neg1.l, sh.mask + N * 32, sh.neg1.l, sh.mask + 2 * N * 32, s));   // sum over H* = |H*| (m_0 + m_|H*| + m_2|H*|) = 0
+  std::memcpy(sh.stage + sh.st_blind() * 32, sh.blind.data(), sh.blind.size() * 32);
+  HIPCHK(hipMemcpyAsync(sh.bl, sh.stage + sh.st_blind() * 32, sh.blind.size() * 32, hipMemcpyHostToDevice, s));
+  sh.wit_aff.assign(104 * (3 * K + 1), 0); sh.comp.assign(48 * (3 * MAX_CIRCUITS > 8 ? 3 * MAX_CIRCUITS : 8), 0);
+  {
+    // with the evaluations against the Lagrange powers AND a narrow-window table over [hiding powers | Lagrange powers | v_H G] the 3K witness
+    // commitments are one sparse chain (their scalars are mostly 0 / 1), the mask (uniform coefficients against the monomial powers) another
+    const PinnedBases& pb = sh.pb;
+    bool split = pb.range.d != nullptr;
+    for (auto& p : P) split = split && p->lagrange() && pb.range_off <= p->ix.gamma_offset && p->ix.lagrange_offset + p->n_h + 1 <= pb.range_off + pb.range.cover &&
+                              p->ix.lagrange_offset >= pb.range_off && p->ix.gamma_offset + HC <= pb.range_off + pb.range.cover;
+    std::vector<MsmSeg>& dst = split ? sm : sg;
+    MsmSeg a; a.d_ptr = sh.mask; a.len = 3 * N; a.off = 0; a.out = split ? 0u : (uint32_t)(3 * K); dst.push_back(a);
+    MsmSeg b; b.d_ptr = sh.bl + 3 * K * HC * 32; b.len = HC; b.off = sh.gamma_offset; b.out = a.out; dst.push_back(b);
+    if (split) { RC(commit(c, pb, sg, (uint32_t)(3 * K), sh.wit_aff.data(), s, true)); RC(commit(c, pb, sm, 1, sh.wit_aff.data() + 104 * 3 * K, s)); }
+    else RC(commit(c, pb, sg, (uint32_t)(3 * K + 1), sh.wit_aff.data(), s));
+  }
+  std::vector<uint8_t> c1(48 * (3 * K + 1));
+  RC(aleo_mi355x_g1_compress(c1.data(), sh.wit_aff.data(), 3 * K + 1));
+  {
+    std::vector<uint8_t> vk; for (auto& p : P) vk.insert(vk.end(), (const uint8_t*)p->ix.vk_bytes, (const uint8_t*)p->ix.vk_bytes + p->ix.vk_len);
+    sh.tr.absorb(vk.data(), vk.size());
+  }
+  sh.tr.absorb(sh.x_bytes.data(), sh.x_bytes.size()); sh.tr.absorb(c1.data(), c1.size());
+  sh.alpha = sh.tr.challenge("alpha", 5); sh.eta_b = sh.tr.challenge("eta_b", 5); sh.eta_c = sh.tr.challenge("eta_c", 5);
+  sh.comb.assign(K, sh.one);
+  for (size_t i = 1; i < K; ++i) { char lab[12] = "combiner"; uint32_t ii = (uint32_t)i; std::memcpy(lab + 8, &ii, 4); sh.comb[i] = sh.tr.challenge(lab, 12); }
+  sh.t_mark[1] = now_ms();
+  return ALEO_MI355X_OK;
+}
+
+int32_t Batch::second_round() {
+  Ctx* c = sh.c; hipStream_t s = sh.s; const size_t N = sh.N;
+  TAKE_M(sh.h1, 2 * N) TAKE_M(sh.g1, N)
+  RC(P[sh.lead]->second_round());                                                             // writes h_1, X g_1 (with the mask) in place
+  for (auto& p : P) {
+    if (p->lead()) continue;
+    RC(p->second_round());
+    RC(fr_vec_op(c, sh.h1, sh.h1, p->hq, 2 * p->n_h, 1, s));                                  // s_j h_j v_{H_j} = h_j v_{H*}
+    RC(fr_add_tiled(c, sh.g1, N, p->rq, p->n_h, s));                                          // s_j (X g_j): the remainder block repeated |H*| / |H_j| times
+  }
+  {
+    std::vector<MsmSeg> sg(2);
+    sg[0].d_ptr = sh.g1 + 32; sg[0].len = N - 1; sg[0].off = sh.D - (N - 2); sg[0].out = 0;    // degree bound |H*| − 2: shifted powers
+    sg[1].d_ptr = sh.h1; sg[1].len = 2 * N; sg[1].off = 0; sg[1].out = 1;
+    RC(commit(c, sh.pb, sg, 2, sh.aff2, s));
+  }
+  for (size_t j = 0; j < sh.m; ++j) {                                                         // commit() returned after the stream drained: the copies have landed
+    uint64_t sum[4]; std::memcpy(sum, sh.pin_small + 3584 + 32 * j, 32);
+    if (sum[0] | sum[1] | sum[2] | sum[3]) { g_last_error = "varuna_prove: the assignment does not satisfy the circuit (first sumcheck: the sum over H is not zero)"; return ALEO_MI355X_ERR_UNSATISFIED; }
+  }
+  RC(aleo_mi355x_g1_compress(sh.comp.data(), sh.aff2, 2)); sh.tr.absorb(sh.comp.data(), 96);
+  sh.beta = sh.tr.challenge("beta", 4);
+  sh.t_mark[2] = now_ms();
+  return ALEO_MI355X_OK;
+}
+
+int32_t Batch::third_round() {
+  Ctx* c = sh.c; hipStream_t s = sh.s; const size_t m = sh.m;
+  for (auto& p : P) RC(p->third_round());
   HIPCHK(hipStreamSynchronize(s));
-  evals.assign(k + 4, HFr::zero()); std::vector<uint8_t> ev_bytes((k + 4) * 32);
-  for (size_t i = 0; i < k + 4; ++i) { std::memcpy(evals[i].l, pin_small + 32 * i, 32); fr_bytes(&ev_bytes[32 * i], evals[i]); }
-  tr.absorb(ev_bytes.data(), ev_bytes.size());
-  const HFr xi = tr.challenge("xi", 2);
-  const HFr g1_beta = evals[k], ga = evals[k + 1], gb = evals[k + 2], gc = evals[k + 3];
+  std::vector<uint8_t> buf(96 * m + 144 * m);
+  std::vector<MsmSeg> sg(3 * m);
+  for (auto& p : P)
+    for (size_t M = 0; M < 3; ++M) {
+      HFr v; std::memcpy(v.l, sh.pin_small + 32 * (3 * p->j + M), 32); p->sigma[M] = HFr::mul(v, fr_u64(p->nk[M])); fr_bytes(&buf[32 * (3 * p->j + M)], p->sigma[M]);
+      MsmSeg& g = sg[3 * p->j + M]; g.d_ptr = p->f + (p->ko[M] + 1) * 32; g.len = p->nk[M] - 1; g.off = sh.D - (p->nk[M] - 2); g.out = (uint32_t)(3 * p->j + M);
+    }
+  sh.aff3.assign(312 * m, 0);
+  RC(commit(c, sh.pb, sg, (uint32_t)(3 * m), sh.aff3.data(), s));
+  RC(aleo_mi355x_g1_compress(&buf[96 * m], sh.aff3.data(), 3 * m));
+  sh.tr.absorb(buf.data(), buf.size());
+  for (auto& p : P) {
+    for (size_t M = 0; M < 3; ++M) {
+      if (p->j == 0) { p->delta[M] = M == 0 ? sh.one : sh.tr.challenge(M == 1 ? "delta_b" : "delta_c", 7); continue; }
+      char lab[11] = "delta_a"; lab[6] = (char)('a' + M); uint32_t jj = (uint32_t)p->j; std::memcpy(lab + 7, &jj, 4);
+      p->delta[M] = sh.tr.challenge(lab, 11);
+    }
+  }
+  sh.t_mark[3] = now_ms();
+  return ALEO_MI355X_OK;
+}
+
+int32_t Batch::fourth_round() {
+  Ctx* c = sh.c; hipStream_t s = sh.s;
+  TAKE_M(sh.h2, sh.n_kmax)
+  std::vector<const void*> terms; std::vector<size_t> lens; std::vector<HFr> co;
+  for (auto& p : P) { RC(p->fourth_round()); for (size_t r = 0; r < p->nrun; ++r) { terms.push_back(p->r4_terms[r]); lens.push_back(p->r4_lens[r]); co.push_back(sh.one); } }
+  RC(lincomb_any(c, sh.h2, sh.n_kmax, HFr::zero(), terms, lens, co, s));                       // h_2 = sum_{j,M} delta_{j,M} h_{j,M}
+  {
+    std::vector<MsmSeg> sg(1); sg[0].d_ptr = sh.h2; sg[0].len = sh.n_kmax; sg[0].off = 0; sg[0].out = 0;
+    RC(commit(c, sh.pb, sg, 1, sh.aff4, s));
+  }
+  RC(aleo_mi355x_g1_compress(sh.comp.data(), sh.aff4, 1)); sh.tr.absorb(sh.comp.data(), 48);
+  sh.gamma = sh.tr.challenge("gamma", 5);
+  sh.t_mark[4] = now_ms();
+  return ALEO_MI355X_OK;
+}
+
+int32_t Batch::open() {
+  Ctx* c = sh.c; hipStream_t s = sh.s; const size_t K = sh.K, N = sh.N, m = sh.m, n_k = sh.n_kmax, ne = K + 1 + 3 * m;
+  const HFr &alpha = sh.alpha, &beta = sh.beta, &gamma = sh.gamma, &eta_b = sh.eta_b, &eta_c = sh.eta_c, &one = sh.one;
+  // ---- evaluations -------------------------------------------------------------------------------------------------------------------------------
+  TAKE_S(evd, ne + 8) TAKE_S(pbeta, 3 * N) TAKE_S(wq, 3 * N) TAKE_S(blq, HC) TAKE_S(pg, n_k) TAKE_S(gq, n_k)
+  {
+    std::vector<const void*> polys; std::vector<size_t> lens; std::vector<HFr> pts;
+    for (auto& p : P) for (size_t i = 0; i < p->k; ++i) { polys.push_back(p->wit + (3 * i + 2) * p->L * 32); lens.push_back(p->L); pts.push_back(beta); }
+    polys.push_back(sh.g1 + 32); lens.push_back(N - 1); pts.push_back(beta);
+    for (auto& p : P) for (size_t M = 0; M < 3; ++M) { polys.push_back(p->f + (p->ko[M] + 1) * 32); lens.push_back(p->nk[M] - 1); pts.push_back(gamma); }
+    for (size_t at = 0; at < ne; at += 12) { const size_t cnt = ne - at < 12 ? ne - at : 12; RC(fr_eval_batch(c, evd + at * 32, polys.data() + at, lens.data() + at, pts.data() + at, cnt, s)); }
+  }
+  HIPCHK(hipMemcpyAsync(sh.pin_small, evd, ne * 32, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  sh.evals.assign(ne, HFr::zero()); std::vector<uint8_t> ev_bytes(ne * 32);
+  for (size_t i = 0; i < ne; ++i) { std::memcpy(sh.evals[i].l, sh.pin_small + 32 * i, 32); fr_bytes(&ev_bytes[32 * i], sh.evals[i]); }
+  sh.tr.absorb(ev_bytes.data(), ev_bytes.size());
+  const HFr xi = sh.tr.challenge("xi", 2);
+  const HFr g1_beta = sh.evals[K];
+  // one inversion for everything the openings divide by: alpha − beta, v_{H_j}(beta) (selectors), v_{K_{j,M}}(gamma)
+  std::vector<HFr> inv(1 + 4 * m);
+  inv[0] = HFr::sub(alpha, beta);
+  for (auto& p : P) { inv[1 + p->j] = p->vh_beta; for (size_t M = 0; M < 3; ++M) inv[1 + m + 3 * p->j + M] = vanish(p->nk[M], gamma); }
+  for (size_t i = 1 + m; i < inv.size(); ++i) if (inv[i].is_zero()) { g_last_error = "varuna_prove: gamma landed in K"; return ALEO_MI355X_ERR_HIP; }
+  if (inv[0].is_zero()) { g_last_error = "varuna_prove: alpha equals beta"; return ALEO_MI355X_ERR_HIP; }
+  batch_inverse_vec(inv);
   // ---- the linear combination of the first sumcheck, opened at beta together with g_1 and the z_b,i -----------------------------------------------
-  HFr inv4[4] = {HFr::sub(alpha, beta), vanish(nk[0], gamma), vanish(nk[1], gamma), vanish(nk[2], gamma)};      // one inversion for the four the openings need
-  for (int m = 1; m < 4; ++m) if (inv4[m].is_zero()) { g_last_error = "varuna_prove: gamma landed in K"; return ALEO_MI355X_ERR_HIP; }
-  if (inv4[0].is_zero()) { g_last_error = "varuna_prove: alpha equals beta"; return ALEO_MI355X_ERR_HIP; }
-  batch_inverse(inv4, 4);
-  const HFr r_ab = HFr::mul(HFr::sub(vh_alpha, vh_beta), inv4[0]);
-  const HFr t_beta = HFr::add(sigma[0], HFr::add(HFr::mul(eta_b, sigma[1]), HFr::mul(eta_c, sigma[2])));
-  const HFr xl = HFr::pow_u64(xi, k + 1), vx_beta = vanish(n_x, beta);
+  const HFr xl = HFr::pow_u64(xi, K + 1), vN_beta = vanish(N, beta);
   HFr cst = HFr::neg(HFr::mul(beta, g1_beta));
   HFr blw[3];                                                                     // blw: (bl(X) − bl(beta)) / (X − beta), uploaded below
   {
-    const void* terms[28]; size_t lens[28]; HFr co[28]; size_t nt = 0;
-    terms[nt] = mask; lens[nt] = 3 * n_h; co[nt++] = xl;
-    terms[nt] = h1; lens[nt] = 2 * n_h; co[nt++] = HFr::neg(HFr::mul(xl, vh_beta));
-    terms[nt] = g1 + 32; lens[nt] = n_h - 1; co[nt++] = one;
+    std::vector<const void*> terms; std::vector<size_t> lens; std::vector<HFr> co;
+    auto term = [&](const void* p, size_t n, const HFr& k) { terms.push_back(p); lens.push_back(n); co.push_back(k); };
+    term(sh.mask, 3 * N, xl); term(sh.h1, 2 * N, HFr::neg(HFr::mul(xl, vN_beta))); term(sh.g1 + 32, N - 1, one);
     HFr blc[3] = {HFr::zero(), HFr::zero(), HFr::zero()};
-    auto axpy = [&](const HFr& coef, const HFr* src) { for (size_t j = 0; j < HC; ++j) blc[j] = HFr::add(blc[j], HFr::mul(coef, src[j])); };
-    axpy(xl, &blind[3 * k * HC]);
-    HFr xpow = xi;                                                                           // xi^(1+i)
-    for (size_t i = 0; i < k; ++i) {
-      const HFr x_beta = horner(x_poly[i], beta), zb = evals[i], ci = comb[i];
-      const HFr k_za = HFr::mul(HFr::mul(xl, ci), HFr::mul(r_ab, HFr::add(one, HFr::mul(eta_c, zb))));
-      const HFr k_w = HFr::neg(HFr::mul(HFr::mul(xl, ci), HFr::mul(t_beta, vx_beta)));
-      cst = HFr::add(cst, HFr::mul(ci, HFr::sub(HFr::mul(HFr::mul(r_ab, eta_b), zb), HFr::mul(t_beta, x_beta))));
-      terms[nt] = wit + (3 * i + 1) * L * 32; lens[nt] = L; co[nt++] = k_za;
-      terms[nt] = wit + (3 * i) * L * 32; lens[nt] = L; co[nt++] = k_w;
-      terms[nt] = wit + (3 * i + 2) * L * 32; lens[nt] = L; co[nt++] = xpow;
-      axpy(k_w, &blind[(3 * i) * HC]); axpy(k_za, &blind[(3 * i + 1) * HC]); axpy(xpow, &blind[(3 * i + 2) * HC]);
-      xpow = HFr::mul(xpow, xi);
+    auto axpy = [&](const HFr& coef, const HFr* src) { for (size_t t = 0; t < HC; ++t) blc[t] = HFr::add(blc[t], HFr::mul(coef, src[t])); };
+    axpy(xl, &sh.blind[3 * K * HC]);
+    HFr xpow = xi;                                                                           // xi^(1+q)
+    for (auto& pp : P) {
+      Prover& p = *pp;
+      const HFr r_ab = HFr::mul(HFr::sub(p.vh_alpha, p.vh_beta), inv[0]);
+      const HFr t_beta = HFr::add(p.sigma[0], HFr::add(HFr::mul(eta_b, p.sigma[1]), HFr::mul(eta_c, p.sigma[2])));
+      const HFr sel = p.n_h == N ? one : HFr::mul(vN_beta, inv[1 + p.j]), vx_beta = vanish(p.n_x, beta);      // s_j(beta) = v_{H*}(beta) / v_{H_j}(beta)
+      for (size_t i = 0; i < p.k; ++i) {
+        const size_t q = p.q0 + i;
+        const HFr x_beta = horner(p.x_poly[i], beta), zb = sh.evals[q], ci = HFr::mul(sh.comb[q], sel);
+        const HFr k_za = HFr::mul(HFr::mul(xl, ci), HFr::mul(r_ab, HFr::add(one, HFr::mul(eta_c, zb))));
+        const HFr k_w = HFr::neg(HFr::mul(HFr::mul(xl, ci), HFr::mul(t_beta, vx_beta)));
+        cst = HFr::add(cst, HFr::mul(ci, HFr::sub(HFr::mul(HFr::mul(r_ab, eta_b), zb), HFr::mul(t_beta, x_beta))));
+        term(p.wit + (3 * i + 1) * p.L * 32, p.L, k_za); term(p.wit + (3 * i) * p.L * 32, p.L, k_w); term(p.wit + (3 * i + 2) * p.L * 32, p.L, xpow);
+        axpy(k_w, &sh.blind[(3 * q) * HC]); axpy(k_za, &sh.blind[(3 * q + 1) * HC]); axpy(xpow, &sh.blind[(3 * q + 2) * HC]);
+        xpow = HFr::mul(xpow, xi);
+      }
     }
-    const HFr c0 = HFr::mul(xl, cst);
-    RC(fr_lincomb(c, pbeta, 3 * n_h, c0.l, terms, lens, co, nt, s));
-    random_v = HFr::add(blc[0], HFr::mul(beta, HFr::add(blc[1], HFr::mul(beta, blc[2]))));
+    RC(lincomb_any(c, pbeta, 3 * N, HFr::mul(xl, cst), terms, lens, co, s));
+    sh.random_v = HFr::add(blc[0], HFr::mul(beta, HFr::add(blc[1], HFr::mul(beta, blc[2]))));
     blw[1] = blc[2]; blw[0] = HFr::add(blc[1], HFr::mul(beta, blc[2])); blw[2] = HFr::zero();
-    char* st = stage + (k * n_x + (3 * k + 1) * HC) * 32; std::memcpy(st, blw, HC * 32);
+    char* st = sh.stage + sh.st_blq() * 32; std::memcpy(st, blw, HC * 32);
     HIPCHK(hipMemcpyAsync(blq, st, HC * 32, hipMemcpyHostToDevice, s));
   }
-  RC(fr_divide_by_linear(c, wq, evd + (k + 5) * 32, pbeta, 3 * n_h, beta.l, s));
-  // ---- the linear combination of the second sumcheck, opened at gamma together with g_a, g_b, g_c --------------------------------------------------
+  RC(fr_divide_by_linear(c, wq, evd + (ne + 1) * 32, pbeta, 3 * N, beta.l, s));
+  // ---- the linear combination of the second sumcheck, opened at gamma together with every g_{j,M} ------------------------------------------------------
   {
-    const HFr xi2 = HFr::sqr(xi), xi3 = HFr::mul(xi2, xi), vk_gamma = vanish(n_k, gamma);
-    const void* terms[20]; size_t lens[20]; HFr co[20]; size_t nt = 0; HFr cg = HFr::zero();
-    const HFr gk[3] = {ga, gb, gc};
-    for (size_t m = 0; m < 3; ++m) {
-      const HFr fm = HFr::add(HFr::mul(gamma, gk[m]), HFr::mul(sigma[m], inv_pow2(lg_km[m])));
-      const HFr d = HFr::mul(HFr::mul(delta[m], xi3), HFr::mul(vk_gamma, inv4[1 + m]));     // selector v_K / v_{K_M} at gamma
-      const HFr dfm = HFr::mul(d, fm);
-      const HFr cf[4] = {HFr::mul(dfm, beta), HFr::mul(dfm, alpha), HFr::mul(d, vv), HFr::neg(dfm)};      // row, col, val, row_col
-      for (int j = 0; j < 4; ++j) { terms[nt] = (const char*)ix.k_polys + (4 * ko[m] + (size_t)j * nk[m]) * 32; lens[nt] = nk[m]; co[nt++] = cf[j]; }
-      cg = HFr::sub(cg, HFr::mul(HFr::mul(dfm, alpha), beta));
+    const HFr xi3m = HFr::pow_u64(xi, 3 * m), vk_gamma = vanish(n_k, gamma);
+    std::vector<const void*> terms; std::vector<size_t> lens; std::vector<HFr> co; HFr cg = HFr::zero();
+    auto term = [&](const void* p, size_t n, const HFr& k) { terms.push_back(p); lens.push_back(n); co.push_back(k); };
+    for (auto& pp : P) {
+      Prover& p = *pp;
+      for (size_t M = 0; M < 3; ++M) {
+        const HFr fm = HFr::add(HFr::mul(gamma, sh.evals[K + 1 + 3 * p.j + M]), HFr::mul(p.sigma[M], inv_pow2(p.lg_km[M])));
+        const HFr d = HFr::mul(HFr::mul(p.delta[M], xi3m), HFr::mul(vk_gamma, inv[1 + m + 3 * p.j + M]));     // selector v_{K*} / v_{K_M} at gamma
+        const HFr dfm = HFr::mul(d, fm);
+        const HFr cf[4] = {HFr::mul(dfm, beta), HFr::mul(dfm, alpha), HFr::mul(d, p.vv), HFr::neg(dfm)};      // row, col, val, row_col
+        for (int t = 0; t < 4; ++t) term((const char*)p.ix.k_polys + (4 * p.ko[M] + (size_t)t * p.nk[M]) * 32, p.nk[M], cf[t]);
+        cg = HFr::sub(cg, HFr::mul(HFr::mul(dfm, alpha), beta));
+      }
     }
-    terms[nt] = h2; lens[nt] = n_k; co[nt++] = HFr::neg(HFr::mul(xi3, vk_gamma));
-    const HFr gco[3] = {one, xi, xi2};
-    for (size_t m = 0; m < 3; ++m) { terms[nt] = f + (ko[m] + 1) * 32; lens[nt] = nk[m] - 1; co[nt++] = gco[m]; }
-    RC(fr_lincomb(c, pg, n_k, cg.l, terms, lens, co, nt, s));
+    term(sh.h2, n_k, HFr::neg(HFr::mul(xi3m, vk_gamma)));
+    HFr xp = one;                                                                            // xi^(3j+M)
+    for (auto& pp : P) for (size_t M = 0; M < 3; ++M) { term(pp->f + (pp->ko[M] + 1) * 32, pp->nk[M] - 1, xp); xp = HFr::mul(xp, xi); }
+    RC(lincomb_any(c, pg, n_k, cg, terms, lens, co, s));
   }
-  RC(fr_divide_by_linear(c, gq, evd + (k + 6) * 32, pg, n_k, gamma.l, s));
+  RC(fr_divide_by_linear(c, gq, evd + (ne + 2) * 32, pg, n_k, gamma.l, s));
   {
     std::vector<MsmSeg> sg(3);
-    sg[0].d_ptr = wq; sg[0].len = 3 * n_h - 1; sg[0].off = 0; sg[0].out = 0;
-    sg[1].d_ptr = blq; sg[1].len = HC - 1; sg[1].off = ix.gamma_offset; sg[1].out = 0;
+    sg[0].d_ptr = wq; sg[0].len = 3 * N - 1; sg[0].off = 0; sg[0].out = 0;
+    sg[1].d_ptr = blq; sg[1].len = HC - 1; sg[1].off = sh.gamma_offset; sg[1].out = 0;
     sg[2].d_ptr = gq; sg[2].len = n_k - 1; sg[2].off = 0; sg[2].out = 1;
-    RC(commit(c, pb, sg, 2, aff5, s));                                                       // both witness commitments in one call
+    RC(commit(c, sh.pb, sg, 2, sh.aff5, s));                                                 // both witness commitments in one call
   }
-  t_mark[5] = now_ms();
+  sh.t_mark[5] = now_ms();
   return ALEO_MI355X_OK;
 }
 
-int32_t Prover::write(uint8_t* out, size_t* out_len) {
+int32_t Batch::write(uint8_t* out, size_t* out_len) {
   // ---- the proof in upstream's layout ---------------------------------------------------------------------------------------------------------------
-  aleo_mi355x_proof_parts parts{}; uint64_t batch = k;
-  uint8_t has_v[2] = {1, 0}; HFr rv[2] = {random_v, HFr::zero()};
-  parts.batch_sizes = &batch; parts.n_circuits = 1; parts.witness_commitments = wit_aff.data(); parts.mask_poly = wit_aff.data() + 104 * 3 * k;
-  parts.g_1 = aff2; parts.h_1 = aff2 + 104; parts.g_abc = aff3; parts.h_2 = aff4;
-  parts.evaluations = evals.data(); parts.n_evaluations = k + 4; parts.sums = sigma;
-  parts.opening_points = aff5; parts.opening_random_v = rv; parts.opening_has_v = has_v; parts.n_openings = 2;
+  aleo_mi355x_proof_parts parts{}; std::vector<uint64_t> batch; std::vector<HFr> sums;
+  for (auto& p : P) { batch.push_back(p->k); for (size_t M = 0; M < 3; ++M) sums.push_back(p->sigma[M]); }
+  uint8_t has_v[2] = {1, 0}; HFr rv[2] = {sh.random_v, HFr::zero()};
+  parts.batch_sizes = batch.data(); parts.n_circuits = sh.m; parts.witness_commitments = sh.wit_aff.data(); parts.mask_poly = sh.wit_aff.data() + 104 * 3 * sh.K;
+  parts.g_1 = sh.aff2; parts.h_1 = sh.aff2 + 104; parts.g_abc = sh.aff3.data(); parts.h_2 = sh.aff4;
+  parts.evaluations = sh.evals.data(); parts.n_evaluations = sh.evals.size(); parts.sums = sums.data();
+  parts.opening_points = sh.aff5; parts.opening_random_v = rv; parts.opening_has_v = has_v; parts.n_openings = 2;
   RC(aleo_mi355x_proof_to_bytes(out, out_len, &parts));
-  for (int i = 0; i < 5; ++i) g_varuna_timing[i] = t_mark[i + 1] - t_mark[i];
-  g_varuna_timing[5] = t_mark[5] - t_mark[0];
+  for (int i = 0; i < 5; ++i) g_varuna_timing[i] = sh.t_mark[i + 1] - sh.t_mark[i];
+  g_varuna_timing[5] = sh.t_mark[5] - sh.t_mark[0];
   return ALEO_MI355X_OK;
+}
+
+// assignments: the instances of circuit 0, then of circuit 1, ... (sum of ks pointers)
+int32_t varuna_prove_batch(Ctx* c, const PinnedBases& pb, const aleo_mi355x_varuna_index* const* ixs, size_t m, const void* const* assignments, const size_t* ks,
+                           uint64_t seed, uint8_t* out, size_t* out_len) {
+  g_varuna_timing[6] = g_varuna_timing[7] = 0;
+  Batch b(c, pb, seed);
+  RC(b.setup(ixs, m, ks)); RC(b.first_round(assignments)); RC(b.second_round()); RC(b.third_round()); RC(b.fourth_round()); RC(b.open());
+  return b.write(out, out_len);
 }
 
 int32_t varuna_prove(Ctx* c, const PinnedBases& pb, const aleo_mi355x_varuna_index& ix, const void* const* assignments, size_t k, uint64_t seed,
                      uint8_t* out, size_t* out_len) {
-  g_varuna_timing[6] = g_varuna_timing[7] = 0;
-  Prover p(c, pb, ix, k, seed);
-  RC(p.setup(assignments)); RC(p.first_round(assignments)); RC(p.second_round()); RC(p.third_round()); RC(p.fourth_round()); RC(p.open());
-  return p.write(out, out_len);
+  const aleo_mi355x_varuna_index* one[1] = {&ix};
+  return varuna_prove_batch(c, pb, one, 1, assignments, &k, seed, out, out_len);
 }
 
 }  // namespace aleo_mi355x

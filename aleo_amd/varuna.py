@@ -258,6 +258,25 @@ def prove_native(index: CircuitIndex, assignment, seed: int) -> bytes:
     return out[:n.value].tobytes()
 
 
+def prove_batch_native(indexes, assignments, seed: int) -> bytes:
+    """One proof over several circuits (`Varuna::prove_batch` with a map of proving keys): indexes = NativeCircuitIndex objects built against one
+    committer key, assignments[j] = the list of instances (uint64[n_vars, 4] canonical) of circuit j.  One call of the C ABI
+    (aleo_mi355x_varuna_prove_batch_indexed); returns the proof bytes."""
+    zs, ks = [], []
+    for ix, inst in zip(indexes, assignments):
+        if isinstance(inst, np.ndarray) and inst.ndim == 2: inst = [inst]
+        rows = [np.ascontiguousarray(a, dtype=np.uint64).reshape(-1, 4) for a in inst]
+        if any(z.shape[0] != ix.n_vars for z in rows): raise ValueError('assignment length differs from the number of variables of its circuit')
+        zs += rows; ks.append(len(rows))
+    if len(ks) != len(indexes): raise ValueError('one list of instances per circuit')
+    handles = (ctypes.c_uint64 * len(indexes))(*[ix.handle for ix in indexes]); counts = (ctypes.c_size_t * len(ks))(*ks)
+    ptrs = (ctypes.c_void_p * len(zs))(*[z.ctypes.data for z in zs])
+    out = np.zeros(1200 + 400 * len(ks) + 200 * len(zs), dtype=np.uint8); n = ctypes.c_size_t(out.shape[0])
+    check(lib().aleo_mi355x_varuna_prove_batch_indexed(handles, len(indexes), ptrs, counts, seed & 0xFFFFFFFFFFFFFFFF, out.ctypes.data_as(ctypes.c_void_p), ctypes.byref(n)),
+          'varuna_prove_batch')
+    return out[:n.value].tobytes()
+
+
 class _R1csMatrix(ctypes.Structure):
     _fields_ = [('row_ptr', ctypes.c_void_p), ('col', ctypes.c_void_p), ('val', ctypes.c_void_p)]
 

@@ -324,6 +324,16 @@ int32_t aleo_mi355x_varuna_index_vk(uint64_t index_handle, void* out, size_t* le
 int32_t aleo_mi355x_varuna_index_free(uint64_t index_handle);
 int32_t aleo_mi355x_varuna_prove_indexed(uint64_t index_handle, const void* const* assignments, size_t n_instances, uint64_t seed, void* out_proof, size_t* len);
 int32_t aleo_mi355x_varuna_prove(const aleo_mi355x_varuna_index* index, const void* const* assignments, size_t n_instances, uint64_t seed, void* out_proof, size_t* len);
+/* One proof over SEVERAL circuits — upstream's `Varuna::prove_batch(keys_to_constraints: BTreeMap<&ProvingKey, &[Assignment]>)`, what
+ * `Trace::prove_execution` / `prove_fee` build from the transitions of a transaction (/root/reference/rust/src/program/execute.rs:74).
+ * index_handles: 1..8 indexes built against ONE committer key (same max_degree / gamma_offset), in the order the proof lists them;
+ * n_instances[j]: 1..8 assignments of circuit j (at most 32 in all); assignments: the pointers of circuit 0's instances, then circuit 1's, ...
+ * The circuits share the transcript and every challenge, one mask / g_1 / h_1 over the largest constraint domain, one h_2 over the largest non-zero
+ * domain and the two openings; a smaller circuit enters behind the selector v_{H*} / v_{H_j}.  out_proof: Proof::to_bytes_le layout —
+ * batch sizes, 3 witness commitments per instance, mask, g_1, h_1, g_a/g_b/g_c per circuit, h_2, evaluations, sums, openings.  With one circuit
+ * the bytes are those of aleo_mi355x_varuna_prove_indexed.  ALEO_MI355X_ERR_UNSATISFIED if any assignment violates its circuit. */
+int32_t aleo_mi355x_varuna_prove_batch_indexed(const uint64_t* index_handles, size_t n_circuits, const void* const* assignments, const size_t* n_instances, uint64_t seed,
+                                               void* out_proof, size_t* len);
 int32_t aleo_mi355x_varuna_last_timing(double* out_ms, int32_t cap);
 
 /* Element-wise field products on the device (host pointers): r[i] = a[i]*b[i], Montgomery form, canonical

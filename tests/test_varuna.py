@@ -325,6 +325,42 @@ def test_whole_proof_entry_points_refuse_misuse():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('shapes,domains', [
+    ([(20, 2, 5, 2), (50, 3, 6, 1), (9, 1, 7, 2)], 'auto'),                       # three sizes of H, the largest in the middle
+    ([(300, 4, 8, 1), (300, 4, 9, 1)], 'per_matrix'),                              # equal domains
+    ([(40, 2, 10, 3), (700, 5, 11, 2), (1, 1, 12, 1), (130, 3, 13, 8)], 'auto'),   # 14 instances: linear combinations beyond one launch (28 terms)
+    ([(2000, 9, 14, 1), (24, 3, 15, 1)], 'per_matrix')])
+def test_device_prover_batch_over_circuits(shapes, domains):
+    """aleo_mi355x_varuna_prove_batch_indexed: one proof over several circuits, byte for byte the restatement's, accepted by its verifier; an
+    assignment that violates any one circuit is refused; a one-circuit batch equals the single-circuit entry point."""
+    from aleo_amd import varuna
+    cs, csrs, zs, D = _batch_case(shapes, domains=domains)
+    setup = V.Setup(TAU, S_GAMMA, D); idx = [V.Index(c, setup) for c in cs]
+    seed = 900 + len(shapes)
+    rand = V.random_stream(seed, max(c.n_h for c in cs), sum(len(z) for z in zs))
+    want = V.prove_batch(list(zip(idx, zs)), setup, rand)[1]
+    ck = varuna.synthetic_committer_key(TAU, S_GAMMA, D)
+    lim = lambda a: np.stack([synth.int_to_limbs(v, 4) for v in a])
+    nx = []
+    try:
+        for (n, npub, _, _), csr, z in zip(shapes, csrs, zs): nx.append(varuna.NativeCircuitIndex(csr, n, npub, len(z[0]) - npub, ck, domains=domains))
+        assert [x.vk_bytes for x in nx] == [i.vk_bytes() for i in idx]
+        za = [[lim(z) for z in zz] for zz in zs]
+        got = varuna.prove_batch_native(nx, za, seed)
+        assert got == want
+        assert V.verify(idx, setup, [[z[:c.n_public] for z in zz] for c, zz in zip(cs, zs)], got)
+        assert varuna.prove_batch_native(nx[:1], za[:1], seed) == nx[0].prove(za[0], seed)
+        bad = [list(zz) for zz in za]; t = len(shapes) - 1
+        bad[t][-1] = bad[t][-1].copy(); bad[t][-1][-1, 0] ^= np.uint64(1)              # the last variable of the last instance of the last circuit
+        with pytest.raises(aleo_amd.UnsatisfiedAssignment): varuna.prove_batch_native(nx, bad, seed)
+        assert varuna.prove_batch_native(nx, za, seed) == want
+        with pytest.raises(aleo_amd.AleoMi355xError): varuna.prove_batch_native(nx * 5, za * 5, seed)      # more than eight circuits
+    finally:
+        for x in nx: x.close()
+        ck.close()
+
+
+@pytest.mark.gpu
 def test_unsatisfied_assignment_is_refused():
     """An assignment that violates a constraint must not turn into bytes that look like a proof: both provers stop at the first sumcheck
     (sum over H != 0) — the one-call entry with ALEO_MI355X_ERR_UNSATISFIED (6), also when only one instance of a batch is bad — and the
