@@ -9,13 +9,15 @@
 //       prover round (SonicKZG10::commit over several labelled polynomials) as ONE call; CanonicalSerialize (compressed) of it
 //   snarkvm_algorithms_cuda::{msm, NTT}: Result<_, Error> — an Err means "recompute on the CPU"
 //   snarkvm_synthesizer_snark::ProvingKey::prove_batch / snarkvm_algorithms::snark::varuna::{CircuitProvingKey, Proof}: a proving key bound
-//       to one circuit, `prove_batch(&[assignment])` -> Proof, Proof Display as bech32m `proof1…` (rows a6 / a7 of SURVEY.md §8)
+//       to one circuit, `prove_batch(&[assignment])` -> Proof, Proof Display as bech32m `proof1…`; `prove_batch(keys -> assignments)` over several
+//       keys and `Trace::prove_execution / prove_fee` above it (rows a6 / a7 of SURVEY.md §8)
 // Layouts are snarkVM's: Fr = 4 x u64 Montgomery, scalar = 4 x u64 canonical, G1Affine = 104 bytes, Projective = 144 bytes.
 #pragma once
 #include <cstddef>
 #include <cstdint>
 #include <optional>
 #include <string>
+#include <utility>
 #include <vector>
 #include "aleo_mi355x.h"
 
@@ -231,9 +233,47 @@ class ProvingKey {
   ProvingKey& operator=(ProvingKey&& o) noexcept { release(); handle_ = o.handle_; num_variables_ = o.num_variables_; o.handle_ = 0; return *this; }
   ProvingKey(const ProvingKey&) = delete; ProvingKey& operator=(const ProvingKey&) = delete;
   ~ProvingKey() { release(); }
+  uint64_t handle() const { return handle_; }
+  size_t num_variables() const { return num_variables_; }
  private:
   void release() { if (handle_) { aleo_mi355x_varuna_index_free(handle_); handle_ = 0; } }
   uint64_t handle_ = 0; size_t num_variables_ = 0;
+};
+
+// Varuna::prove_batch(keys_to_constraints: &BTreeMap<&ProvingKey, &[Assignment]>): ONE proof for several proving keys, each with its instances, in
+// the order given (upstream: the map's key order).  All keys must have been indexed against the same CommitterKey.
+using KeyedAssignments = std::vector<std::pair<const ProvingKey*, std::vector<const std::vector<BigInteger256>*>>>;
+inline Result<Proof> prove_batch(const KeyedAssignments& keyed, uint64_t seed) {
+  std::vector<uint64_t> handles; std::vector<size_t> counts; std::vector<const void*> p;
+  for (auto& [pk, zs] : keyed) {
+    if (!pk || zs.empty()) return {std::nullopt, Error{ALEO_MI355X_ERR_BAD_ARG}};
+    handles.push_back(pk->handle()); counts.push_back(zs.size());
+    for (auto* a : zs) { if (!a || a->size() != pk->num_variables()) return {std::nullopt, Error{ALEO_MI355X_ERR_BAD_ARG}}; p.push_back(a->data()); }
+  }
+  Proof out; out.bytes.resize(1024 + 400 * handles.size() + 192 * p.size()); size_t len = out.bytes.size();
+  int32_t rc = aleo_mi355x_varuna_prove_batch_indexed(handles.data(), handles.size(), p.data(), counts.data(), seed, out.bytes.data(), &len);
+  if (rc) return {std::nullopt, Error{rc}};
+  out.bytes.resize(len); return {std::move(out), Error{0}};
+}
+
+// snarkvm_synthesizer_process::Trace as the prover sees it: the transitions of one transaction, each the proving key of its
+// function and the assignment its execution produced.  prove_execution / prove_fee group the assignments per proving key (order of first
+// appearance; upstream: BTreeMap order of the keys) and make ONE proof for all of them — the call under
+// `trace.prove_execution::<A, _>(locator, rng)` at /root/reference/rust/src/program/execute.rs:74.  Inclusion proofs (state paths from the
+// ledger) are further assignments of one more circuit and enter the same way; fetching them is the SDK's business.
+class Trace {
+ public:
+  void insert_transition(const ProvingKey& pk, const std::vector<BigInteger256>& assignment) {
+    for (auto& e : keyed_) if (e.first == &pk) { e.second.push_back(&assignment); return; }
+    keyed_.push_back({&pk, {&assignment}});
+  }
+  size_t transitions() const { size_t n = 0; for (auto& e : keyed_) n += e.second.size(); return n; }
+  Result<Proof> prove_execution(uint64_t seed) const { return keyed_.empty() ? Result<Proof>{std::nullopt, Error{ALEO_MI355X_ERR_BAD_ARG}} : prove_batch(keyed_, seed); }
+  Result<Proof> prove_fee(uint64_t seed) const {              // a fee is exactly one transition
+    return transitions() != 1 ? Result<Proof>{std::nullopt, Error{ALEO_MI355X_ERR_BAD_ARG}} : prove_batch(keyed_, seed);
+  }
+ private:
+  KeyedAssignments keyed_;
 };
 
 }  // namespace aleo_mi355x

@@ -73,6 +73,21 @@ int main(int argc, char** argv) {
     za[k - 1][nv - 1].l[0] ^= 1;
     auto again = pk.value->prove_batch(zs, seed);
     if (!again.is_ok() || memcmp(again.value->bytes.data(), proof.data(), len)) { fprintf(stderr, "proof after a refused one differs\n"); return 1; }
+    // a transaction with two functions: every instance under the first key, the first instance again under a second key of the same circuit —
+    // Trace::prove_execution makes ONE proof; its bytes go to the output file for the restatement to compare
+    auto pk2 = ProvingKey::index(*ck.value, cs, (DomainPolicy)h[7]);
+    if (!pk2.is_ok()) { fprintf(stderr, "second ProvingKey::index\n"); return 1; }
+    Trace trace;
+    for (uint64_t i = 0; i < k; ++i) trace.insert_transition(*pk.value, za[i]);
+    trace.insert_transition(*pk2.value, za[0]);
+    if (trace.prove_fee(seed).is_ok()) { fprintf(stderr, "prove_fee accepted several transitions\n"); return 1; }
+    auto ex = trace.prove_execution(seed);
+    if (!ex.is_ok()) { fprintf(stderr, "Trace::prove_execution: %s\n", ex.error.message().c_str()); return 1; }
+    Trace fee; fee.insert_transition(*pk.value, za[0]);
+    auto fp = fee.prove_fee(seed + 1), direct = pk.value->prove_batch({&za[0]}, seed + 1);
+    if (!fp.is_ok() || !direct.is_ok() || fp.value->bytes != direct.value->bytes) { fprintf(stderr, "Trace::prove_fee differs from prove_batch\n"); return 1; }
+    FILE* o2 = fopen(argv[2], "ab"); if (!o2) return 2;
+    uint64_t el = ex.value->bytes.size(); fwrite(&el, 8, 1, o2); fwrite(ex.value->bytes.data(), 1, el, o2); fclose(o2);
   }
   printf("ALL OK\n");
   return 0;

@@ -270,6 +270,11 @@ def test_whole_proof_entry_points_from_plain_cpp(tmp_path):
     out = open(fout, 'rb').read(); vk_len, plen = struct.unpack('<2Q', out[:16])
     assert out[16:16 + vk_len] == idx.vk_bytes() and out[16 + vk_len:16 + vk_len + plen] == want
     assert V.verify(idx, setup, [q[:3] for q in zs], out[16 + vk_len:16 + vk_len + plen])
+    # the C++ Trace mirror: one proof for (key 1: every instance, key 2 of the same circuit: the first instance)
+    at = 16 + vk_len + plen; elen, = struct.unpack('<Q', out[at:at + 8]); execution = out[at + 8:at + 8 + elen]
+    n_inst = len(zs) + 1
+    assert execution == V.prove_batch([(idx, zs), (idx, zs[:1])], setup, V.random_stream(seed, c.n_h, n_inst))[1]
+    assert V.verify([idx, idx], setup, [[q[:3] for q in zs], [zs[0][:3]]], execution)
 
 
 @pytest.mark.gpu
