@@ -403,14 +403,45 @@ def varuna_prove(synth, torch, lg, reps=7, in_flight=4):
             for x in th: x.start()
             for x in th: x.join()
             dt = time.perf_counter() - t
+        try: several = varuna_prove_several(synth, ck, lg)
+        except Exception as e: several = {'error': repr(e)[:300]}
         return {'constraints': n, 'domain_h': ix.n_h, 'domain_k': ix.n_k, 'max_degree': D, 'index_s': index_s, 'prove_ms': med, 'constraints_per_s': n / med * 1e3,
-                'rounds_ms': rounds, 'proof_bytes': len(data), 'entry_point': 'aleo_mi355x_varuna_prove',
+                'rounds_ms': rounds, 'proof_bytes': len(data), 'entry_point': 'aleo_mi355x_varuna_prove', 'several_circuits': several,
                 'python_host_ms': float(np.median(tp[1:])),
                 'instances_4': {'prove_ms': mb, 'constraints_per_s': 4 * n / mb * 1e3, 'proof_bytes': len(datab)},
                 'instances_8': {'prove_ms': mb8, 'constraints_per_s': 8 * n / mb8 * 1e3},
                 'in_flight_%d' % in_flight: {'proofs_per_s': in_flight * per / dt, 'constraints_per_s': n * in_flight * per / dt}, 'what': VARUNA_NOTE}
     finally:
         ck.close()
+
+
+def varuna_prove_several(synth, ck, lg):
+    """One proof over several circuits (Varuna::prove_batch with a map of proving keys — the shape of a transaction: a function, a second function
+    called twice, a fee): circuits of 2^lg, 2^(lg-1) (two instances) and 2^(lg-2) constraints against the committer key of the largest, proved in ONE
+    call (aleo_mi355x_varuna_prove_batch_indexed) and, for comparison, as three separate proofs."""
+    from aleo_amd import varuna
+    shapes = [(lg, 1), (lg - 1, 2), (lg - 2, 1)]
+    nx, za, total = [], [], 0
+    try:
+        for j, (l, k) in enumerate(shapes):
+            n = (1 << l) - 64
+            csr, z = synth.synthetic_r1cs(n, 4, 140 + 7 * j + l, long_rows=4)
+            nx.append(varuna.NativeCircuitIndex(csr, n, 4, len(z) - 4, ck))
+            za.append([np.stack([synth.int_to_limbs(v, 4) for v in z])] * k); total += n * k
+        varuna.prove_batch_native(nx, za, 1)
+        tb = []
+        for rep in range(6):
+            t = time.perf_counter(); data = varuna.prove_batch_native(nx, za, 50 + rep); tb.append((time.perf_counter() - t) * 1e3)
+        ts = []
+        for rep in range(6):
+            t = time.perf_counter()
+            for x, zz in zip(nx, za): x.prove(zz, 70 + rep)
+            ts.append((time.perf_counter() - t) * 1e3)
+        mb, ms = float(np.median(tb[1:])), float(np.median(ts[1:]))
+        return {'circuits': [{'constraints': (1 << l) - 64, 'instances': k} for l, k in shapes], 'constraints': total, 'one_proof_ms': mb, 'constraints_per_s': total / mb * 1e3,
+                'proof_bytes': len(data), 'three_separate_proofs_ms': ms, 'entry_point': 'aleo_mi355x_varuna_prove_batch_indexed'}
+    finally:
+        for x in nx: x.close()
 
 
 def _varuna_big_once(synth, lg, bits, lagrange):
