@@ -174,7 +174,21 @@ def gen_varuna():
         cases.append({'n_constraints': n, 'n_public': pub, 'circuit_seed': seed, 'instances': instances, 'domains': domains, 'proof_seed': seed + 1000,
                       'other_publics': [[1] + [7 * i + j for j in range(1, pub)] for i in range(1, instances)], 'max_degree': D - 1,
                       'domain_sizes': [c.n_h, c.n_k_m['a'], c.n_k_m['b'], c.n_k_m['c'], c.n_x], 'vk': idx.vk_bytes().hex(), 'proof': data.hex()})
-    json.dump({'tau': hex(TAU), 's_gamma': hex(S_GAMMA), 'cases': cases}, open(os.path.join(HERE, 'varuna_small.json'), 'w'))
+    # proofs over several of the circuits above (every instance of each member, in the order listed): Varuna::prove_batch with a map of proving keys
+    batches = []
+    for members, seed in [([1, 0, 3], 5001), ([2, 2], 5002)]:
+        D = max(cases[j]['max_degree'] for j in members); setup = V.Setup(TAU, S_GAMMA, D); items = []
+        for j in members:
+            cj = cases[j]; n, pub = cj['n_constraints'], cj['n_public']
+            csr, z = synth.synthetic_r1cs(n, pub, cj['circuit_seed'], long_rows=1 if n > 20 else 0)
+            rows = lambda m: [[(int(csr[m][1][k]), synth.limbs_to_int(csr[m][2][k])) for k in range(csr[m][0][i], csr[m][0][i + 1])] for i in range(n)]
+            c = V.Circuit(n, pub, len(z) - pub, rows('a'), rows('b'), rows('c'), domains=cj['domains'])
+            items.append((V.Index(c, setup), [z] + [synth.resolve_synthetic(csr, pub, p_) for p_ in cj['other_publics']]))
+        total = sum(len(zz) for _, zz in items)
+        proof, data = V.prove_batch(items, setup, V.random_stream(seed, max(ix.circuit.n_h for ix, _ in items), total))
+        assert V.verify_pairing([ix for ix, _ in items], setup.verifier_key([ix.circuit for ix, _ in items]), [[q[:ix.circuit.n_public] for q in zz] for ix, zz in items], data)
+        batches.append({'members': members, 'proof_seed': seed, 'max_degree': D, 'proof': data.hex()})
+    json.dump({'tau': hex(TAU), 's_gamma': hex(S_GAMMA), 'cases': cases, 'batches': batches}, open(os.path.join(HERE, 'varuna_small.json'), 'w'))
 
 
 if __name__ == '__main__':

@@ -415,6 +415,43 @@ def test_restatement_reproduces_the_frozen_proofs():
     assert V.verify_pairing(V.Index(c, setup), setup.verifier_key(c), [q[:cases[1]['n_public']] for q in zs], bytes.fromhex(cases[1]['proof']))
 
 
+def _golden_batches():
+    g = json.load(open(os.path.join(os.path.dirname(__file__), 'golden', 'varuna_small.json')))
+    return g['cases'], g['batches']
+
+
+def test_restatement_reproduces_the_frozen_batch_proofs():
+    """The frozen proofs over several circuits (members = cases of the same file, every instance of each)."""
+    cases, batches = _golden_batches()
+    assert batches
+    for b in batches:
+        setup = V.Setup(TAU, S_GAMMA, b['max_degree']); items = []
+        for j in b['members']:
+            csr, zs, c = _golden_instance(cases[j]); items.append((V.Index(c, setup), zs))
+        total = sum(len(zz) for _, zz in items)
+        data = V.prove_batch(items, setup, V.random_stream(b['proof_seed'], max(ix.circuit.n_h for ix, _ in items), total))[1]
+        assert data.hex() == b['proof']
+        assert V.verify([ix for ix, _ in items], setup, [[q[:ix.circuit.n_public] for q in zz] for ix, zz in items], data)
+
+
+@pytest.mark.gpu
+def test_device_prover_reproduces_the_frozen_batch_proofs():
+    from aleo_amd import varuna
+    cases, batches = _golden_batches()
+    for b in batches:
+        ck = varuna.synthetic_committer_key(TAU, S_GAMMA, b['max_degree']); nx, za = [], []
+        try:
+            for j in b['members']:
+                case = cases[j]; csr, zs, c = _golden_instance(case)
+                nx.append(varuna.NativeCircuitIndex(csr, case['n_constraints'], case['n_public'], len(zs[0]) - case['n_public'], ck, domains=case['domains']))
+                assert nx[-1].vk_bytes.hex() == case['vk']
+                za.append([np.stack([synth.int_to_limbs(v, 4) for v in q]) for q in zs])
+            assert varuna.prove_batch_native(nx, za, b['proof_seed']).hex() == b['proof']
+        finally:
+            for x in nx: x.close()
+            ck.close()
+
+
 @pytest.mark.gpu
 def test_device_provers_reproduce_the_frozen_proofs():
     """The frozen proofs from the native index + prover, and from the step-by-step host side."""
@@ -455,4 +492,36 @@ def test_commit_lagrange_in_the_first_round(k, range_window):
         assert varuna.native_index(ix).lagrange_offset == ck.lagrange_offset
         assert varuna.prove(ix, zq, 640 + k).to_bytes() == want and varuna.prove_native(ix, zq, 640 + k) == want
     finally:
+        ck.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('with_small,range_window', [(False, 0), (False, 13), (True, 13), (True, 0)])
+def test_commit_lagrange_in_a_proof_over_circuits(with_small, range_window):
+    """Several circuits with Lagrange powers pinned for |H| = 512: two bit-heavy circuits on that domain commit their witness polynomials from
+    evaluations (with a range window: the sparse chain + the mask's own chain); with a smaller circuit in the proof — which has no Lagrange
+    powers of its size and commits coefficients — everything goes through one mixed chain.  Bytes equal the restatement's either way."""
+    from aleo_amd import varuna
+    def bits(n, seed, k):
+        csr, z = synth.synthetic_r1cs_bits(n, 3, seed)
+        rows = lambda m: [[(int(csr[m][1][j]), synth.limbs_to_int(csr[m][2][j])) for j in range(csr[m][0][i], csr[m][0][i + 1])] for i in range(n)]
+        return csr, [z] + [synth.resolve_synthetic(csr, 3, [1, i & 1, (i >> 1) & 1]) for i in range(1, k)], V.Circuit(n, 3, len(z) - 3, rows('a'), rows('b'), rows('c')), n
+    parts = [bits(500, 301, 2), bits(400, 302, 1)] + ([bits(90, 303, 2)] if with_small else [])
+    cs = [p[2] for p in parts]
+    assert cs[0].n_h == cs[1].n_h == 512 and (not with_small or cs[2].n_h == 128)
+    D = 1
+    while D < max(max(3 * c.n_h, c.n_k) for c in cs): D *= 2
+    D -= 1
+    setup = V.Setup(TAU, S_GAMMA, D); idx = [V.Index(c, setup) for c in cs]
+    zs = [p[1] for p in parts]; seed = 1200 + range_window + with_small
+    want = V.prove_batch(list(zip(idx, zs)), setup, V.random_stream(seed, 512, sum(len(z) for z in zs)))[1]
+    ck = varuna.synthetic_committer_key(TAU, S_GAMMA, D, lagrange_size=512, range_window=range_window)
+    nx = []
+    try:
+        for csr, z, c, n in parts: nx.append(varuna.NativeCircuitIndex(csr, n, 3, len(z[0]) - 3, ck))
+        za = [[np.stack([synth.int_to_limbs(v, 4) for v in q]) for q in z] for z in zs]
+        assert varuna.prove_batch_native(nx, za, seed) == want
+        assert V.verify(idx, setup, [[q[:3] for q in z] for z in zs], want)
+    finally:
+        for x in nx: x.close()
         ck.close()
