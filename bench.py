@@ -444,6 +444,9 @@ def varuna_prove_several(synth, ck, lg):
         for x in nx: x.close()
 
 
+_BIG_PROOFS = []       # device proofs of the large circuit, verified in the cpu_baseline leg (the only place bench.py may use oracle/)
+
+
 def _varuna_big_once(synth, lg, bits, lagrange):
     from aleo_amd import varuna
     t0 = time.perf_counter(); n, csr, z, zz, ck, D = _varuna_instance(synth, lg, 40 + lg, bits, lagrange); prep_s = time.perf_counter() - t0
@@ -459,6 +462,7 @@ def _varuna_big_once(synth, lg, bits, lagrange):
             for rep in range(3):
                 t = time.perf_counter(); data = nx.prove([zz] * 8, 20 + rep); t8.append((time.perf_counter() - t) * 1e3)
             m1, m8 = float(np.median(t1)), float(np.median(t8[1:]))
+            if not bits: _BIG_PROOFS.append({'constraints': n, 'vk': nx.vk_bytes, 'public': [int(v) for v in z[:4]], 'proof': nx.prove(zz, 12), 'proof_8': data, 'max_degree': D})      # for the cpu_baseline leg's verifier
             return {'constraints': n, 'domain_h': nx.n_h, 'domains_k': nx.n_k_m, 'max_degree': D, 'index_s': index_s, 'prove_ms': m1, 'constraints_per_s': n / m1 * 1e3,
                     'rounds_ms': rounds, 'instances_8': {'prove_ms': m8, 'constraints_per_s': 8 * n / m8 * 1e3, 'proof_bytes': len(data)},
                     'host_prep_s': prep_s, 'entry_point': 'aleo_mi355x_varuna_index_build + aleo_mi355x_varuna_prove_indexed'}
@@ -698,6 +702,16 @@ def cpu_baseline(args, pb, scalars, aleo_amd):
         from aleo_amd import synth
         proxy = proof_proxy_cpu(c, aleo_amd, synth, args.proof_proxy_cpu_lg, effective_cpus())
     vcpu = varuna_cpu(synth_mod(), args.varuna_cpu_lg) if (args.varuna_lg and args.varuna_cpu_lg) else None
+    if vcpu is not None and _BIG_PROOFS:
+        # the large circuit's device proofs, checked by the restatement's verifier from the exported verifying key alone (no index, no trapdoor)
+        from oracle import varuna_ref as V
+        b = _BIG_PROOFS[0]; t0 = time.perf_counter()
+        vk = V.VerifyingKey(b['vk'], 4); setup = V.Setup(VARUNA_TAU, VARUNA_S, b['max_degree']); keys = setup.verifier_key(vk.circuit)
+        ok1 = bool(V.verify_pairing(vk, keys, b['public'], b['proof'])); ok8 = bool(V.verify(vk, setup, [b['public']] * 8, b['proof_8']))
+        bad = bytearray(b['proof']); bad[400] ^= 1
+        vcpu['large_circuit'] = {'constraints': b['constraints'], 'device_proof_verifies': ok1, 'eight_instance_proof_verifies': ok8,
+                                 'tampered_proof_refused': not V.verify(vk, setup, b['public'], bytes(bad)), 'verify_s': time.perf_counter() - t0,
+                                 'verifier': 'oracle/varuna_ref.py VerifyingKey: index commitments + domain sizes exported by the library; pairing products for the single proof'}
     return {'proof_proxy': proxy, 'varuna': vcpu, 'one_core': {'value': n1 / dt1, 'unit': 'scalar-muls/s', 'cores': 1, 'seconds': dt1, 'sample': '2^%d-point prefix' % (n1.bit_length() - 1)},
             'value': ns / dt, 'unit': 'scalar-muls/s', 'cores': all_cores, 'kind': 'port', 'seconds': dt,
             'host_cpus': os.cpu_count(), 'usable_cpus': effective_cpus(),

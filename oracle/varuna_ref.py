@@ -108,7 +108,7 @@ class Setup:
         """What a verifier holds (public; derived from the trapdoor here as a ceremony would): γG, H, τH and the negative powers of τ in G2 that
         un-shift degree-bounded commitments [UPSTREAM-RECALL: sonic_pc VerifierKey — h, beta_h, prepared_neg_powers_of_beta_h, gamma_g].
         circuit: one Circuit or the list a batch proof covers (bounds: the largest |H| − 2, every |K_M| − 2)."""
-        circuits = [circuit] if isinstance(circuit, Circuit) else list(circuit)
+        circuits = [circuit] if hasattr(circuit, 'n_h') else list(circuit)
         H = P.G2_GENERATOR; ti = inv(self.tau)
         neg = lambda bound: P.g2_mul(H, pow(ti, self.max_degree - bound, R))
         return {'gamma_g': P.g1_mul(P.G1_GENERATOR, self.s_gamma), 'h': H, 'tau_h': P.g2_mul(H, self.tau),
@@ -162,6 +162,29 @@ class Index:
             for k in ('row', 'col', 'val', 'row_col'): out += _point_bytes(self.commit_scalars[(m, k)])
         c = self.circuit
         return out + b''.join(int(v).to_bytes(8, 'little') for v in (c.n_h, c.n_k_m['a'], c.n_k_m['b'], c.n_k_m['c'], c.n_x))
+
+
+class VerifyingKey:
+    """What a verifier holds of one circuit — nothing of the prover's index: the twelve index commitments and the five domain sizes
+    (Index.vk_bytes(), 616 bytes) and the number of public inputs.  Accepted wherever verify / verify_pairing take an Index, so a proof for a
+    circuit far too large for this module's prover (2^20 constraints) is still checked here in seconds."""
+    def __init__(self, vk_bytes: bytes, n_public: int):
+        assert len(vk_bytes) == 12 * 48 + 40
+        n_h, ka, kb, kc, n_x = (int.from_bytes(vk_bytes[576 + 8 * i:584 + 8 * i], 'little') for i in range(5))
+        assert 1 <= n_public <= n_x
+        self._bytes = bytes(vk_bytes)
+        self.circuit = type('CircuitShape', (), {'n_h': n_h, 'n_k_m': {'a': ka, 'b': kb, 'c': kc}, 'n_k': max(ka, kb, kc), 'n_x': n_x, 'n_public': n_public})()
+        self.H, self.K, self.X = Domain(n_h), Domain(self.circuit.n_k), Domain(n_x)
+        self.K_m = {m: Domain(v) for m, v in self.circuit.n_k_m.items()}
+        self._points = None
+
+    def commit_points(self):
+        if self._points is None:
+            keys = [(m, k) for m in 'abc' for k in ('row', 'col', 'val', 'row_col')]
+            self._points = {mk: P.g1_decompress(self._bytes[48 * i:48 * i + 48]) for i, mk in enumerate(keys)}
+        return self._points
+
+    def vk_bytes(self): return self._bytes
 
 
 _M64 = (1 << 64) - 1
@@ -482,7 +505,7 @@ def parse_proof(data: bytes):
 
 def _as_batch(index, public_inputs):
     """(list of Index, list per circuit of lists of public inputs) from the single-circuit or the batch calling form."""
-    if isinstance(index, Index):
+    if isinstance(index, (Index, VerifyingKey)):
         if public_inputs and not isinstance(public_inputs[0], (list, tuple)): public_inputs = [public_inputs]
         return [index], [list(public_inputs)]
     return list(index), [list(p_) for p_ in public_inputs]

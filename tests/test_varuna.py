@@ -431,7 +431,13 @@ def test_restatement_reproduces_the_frozen_batch_proofs():
         total = sum(len(zz) for _, zz in items)
         data = V.prove_batch(items, setup, V.random_stream(b['proof_seed'], max(ix.circuit.n_h for ix, _ in items), total))[1]
         assert data.hex() == b['proof']
-        assert V.verify([ix for ix, _ in items], setup, [[q[:ix.circuit.n_public] for q in zz] for ix, zz in items], data)
+        pubs = [[q[:ix.circuit.n_public] for q in zz] for ix, zz in items]
+        assert V.verify([ix for ix, _ in items], setup, pubs, data)
+        # a verifier that holds only the verifying keys (index commitments + domain sizes), no index
+        vks = [V.VerifyingKey(bytes.fromhex(cases[j]['vk']), cases[j]['n_public']) for j in b['members']]
+        assert V.verify(vks, setup, pubs, data)
+        if len(set(b['members'])) > 1: assert not V.verify(vks[::-1], setup, pubs[::-1], data)
+    assert V.verify_pairing(vks, setup.verifier_key([v.circuit for v in vks]), pubs, data)
 
 
 @pytest.mark.gpu
@@ -524,4 +530,37 @@ def test_commit_lagrange_in_a_proof_over_circuits(with_small, range_window):
         assert V.verify(idx, setup, [[q[:3] for q in z] for z in zs], want)
     finally:
         for x in nx: x.close()
+        ck.close()
+
+
+@pytest.mark.gpu
+def test_device_proofs_of_large_circuits_are_verified():
+    """Beyond the sizes the restatement's prover reaches: a proof over a 2^18-constraint bit-heavy circuit (two instances) and a 2^15-constraint
+    one, made by the device, is accepted by the restatement's VERIFIER holding only the verifying keys the library exported (trapdoor-free pairing
+    check included), and refused for a changed public input or a flipped byte.  (The single-circuit 2^20 proof of bench.py is checked the same way
+    in its cpu_baseline leg.)"""
+    from aleo_amd import varuna
+    n1, n2 = (1 << 18) - 64, (1 << 15) - 64
+    csr1, z1 = synth.synthetic_r1cs_bits(n1, 4, 501)
+    csr2, z2 = synth.synthetic_r1cs(n2, 3, 502, long_rows=4)
+    D = (1 << 21) - 1
+    nnz = max(int(csr1[m][0][-1]) for m in 'abc'); assert nnz <= D + 1 and 3 * (1 << 18) <= D + 1
+    ck = varuna.synthetic_committer_key(TAU, S_GAMMA, D)
+    lim = lambda a: np.stack([synth.int_to_limbs(v, 4) for v in a])
+    try:
+        with varuna.NativeCircuitIndex(csr1, n1, 4, len(z1) - 4, ck) as x1, varuna.NativeCircuitIndex(csr2, n2, 3, len(z2) - 3, ck) as x2:
+            zz1, zz2 = lim(z1), lim(z2)
+            data = varuna.prove_batch_native([x1, x2], [[zz1, zz1], [zz2]], 77)
+            vks = [V.VerifyingKey(x1.vk_bytes, 4), V.VerifyingKey(x2.vk_bytes, 3)]
+            assert (vks[0].circuit.n_h, vks[1].circuit.n_h) == (1 << 18, 1 << 15)
+            single = x1.prove(zz1, 78)
+        setup = V.Setup(TAU, S_GAMMA, D); pubs = [[z1[:4], z1[:4]], [z2[:3]]]
+        assert V.verify(vks, setup, pubs, data)
+        assert V.verify_pairing(vks, setup.verifier_key([v.circuit for v in vks]), pubs, data)
+        assert V.verify(vks[0], setup, z1[:4], single)
+        wrong = [[list(z1[:4]), list(z1[:4])], [list(z2[:3])]]; wrong[0][1][2] ^= 1
+        assert not V.verify(vks, setup, wrong, data)
+        bad = bytearray(data); bad[-60] ^= 8
+        assert not V.verify(vks, setup, pubs, bytes(bad))
+    finally:
         ck.close()
