@@ -623,16 +623,16 @@ int32_t Batch::second_round() {
 int32_t Batch::third_round() {
   Ctx* c = sh.c; hipStream_t s = sh.s; const size_t m = sh.m;
   for (auto& p : P) RC(p->third_round());
-  HIPCHK(hipStreamSynchronize(s));
   std::vector<uint8_t> buf(96 * m + 144 * m);
   std::vector<MsmSeg> sg(3 * m);
   for (auto& p : P)
     for (size_t M = 0; M < 3; ++M) {
-      HFr v; std::memcpy(v.l, sh.pin_small + 32 * (3 * p->j + M), 32); p->sigma[M] = HFr::mul(v, fr_u64(p->nk[M])); fr_bytes(&buf[32 * (3 * p->j + M)], p->sigma[M]);
       MsmSeg& g = sg[3 * p->j + M]; g.d_ptr = p->f + (p->ko[M] + 1) * 32; g.len = p->nk[M] - 1; g.off = sh.D - (p->nk[M] - 2); g.out = (uint32_t)(3 * p->j + M);
     }
   sh.aff3.assign(312 * m, 0);
   RC(commit(c, sh.pb, sg, (uint32_t)(3 * m), sh.aff3.data(), s));
+  for (auto& p : P)                                                                           // the sums f_{j,M}(0) |K| were copied out ahead of the commitments: no stream sync of their own
+    for (size_t M = 0; M < 3; ++M) { HFr v; std::memcpy(v.l, sh.pin_small + 32 * (3 * p->j + M), 32); p->sigma[M] = HFr::mul(v, fr_u64(p->nk[M])); fr_bytes(&buf[32 * (3 * p->j + M)], p->sigma[M]); }
   RC(aleo_mi355x_g1_compress(&buf[96 * m], sh.aff3.data(), 3 * m));
   sh.tr.absorb(buf.data(), buf.size());
   for (auto& p : P) {

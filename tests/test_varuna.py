@@ -564,3 +564,35 @@ def test_device_proofs_of_large_circuits_are_verified():
         assert not V.verify(vks, setup, pubs, bytes(bad))
     finally:
         ck.close()
+
+
+@pytest.mark.gpu
+def test_batch_proofs_from_concurrent_callers():
+    """Proofs over several circuits from four host threads at once (each call on its own slot of the library, the indexes shared read-only)
+    equal the proofs made one after the other; single-circuit proofs of the same indexes run in between."""
+    import threading
+    from aleo_amd import varuna
+    cs, csrs, zs, D = _batch_case([(700, 3, 41, 2), (90, 2, 42, 1), (300, 4, 43, 1)])
+    ck = varuna.synthetic_committer_key(TAU, S_GAMMA, D)
+    lim = lambda a: np.stack([synth.int_to_limbs(v, 4) for v in a])
+    nx = []
+    try:
+        for (n, npub, _, _), csr, z in zip([(700, 3, 41, 2), (90, 2, 42, 1), (300, 4, 43, 1)], csrs, zs): nx.append(varuna.NativeCircuitIndex(csr, n, npub, len(z[0]) - npub, ck))
+        za = [[lim(z) for z in zz] for zz in zs]
+        want = {(t, r): varuna.prove_batch_native(nx, za, 100 * t + r) for t in range(4) for r in range(3)}
+        single = {t: nx[t % 3].prove(za[t % 3], 7 + t) for t in range(4)}
+        got, got1, err = {}, {}, []
+        def work(t):
+            try:
+                for r in range(3):
+                    got[(t, r)] = varuna.prove_batch_native(nx, za, 100 * t + r)
+                    if r == 1: got1[t] = nx[t % 3].prove(za[t % 3], 7 + t)
+            except Exception as e: err.append(e)
+        th = [threading.Thread(target=work, args=(t,)) for t in range(4)]
+        for x in th: x.start()
+        for x in th: x.join()
+        assert not err, err
+        assert got == want and got1 == single
+    finally:
+        for x in nx: x.close()
+        ck.close()
