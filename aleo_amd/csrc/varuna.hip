@@ -13,6 +13,7 @@
 #include "host_field.hpp"
 #include <cstring>
 #include <vector>
+#include <utility>
 #include <memory>
 #include <chrono>
 
@@ -107,6 +108,19 @@ inline void batch_inverse(HFr* v, size_t n) {               // Montgomery's tric
   for (size_t i = 0; i < n; ++i) { pre[i] = acc; acc = HFr::mul(acc, v[i]); }
   acc = HFr::inv(acc);
   for (size_t i = n; i-- > 0;) { const HFr t = HFr::mul(acc, pre[i]); acc = HFr::mul(acc, v[i]); v[i] = t; }
+}
+// a <- (sum_t a_t w^(t u))_u for a primitive |a|-th root w, |a| a power of two: bit-reversal + radix-2 butterflies, O(n log n) host products
+inline void host_ntt(std::vector<HFr>& a, const HFr& w) {
+  const size_t n = a.size();
+  for (size_t i = 1, j = 0; i < n; ++i) { size_t bit = n >> 1; for (; j & bit; bit >>= 1) j ^= bit; j ^= bit; if (i < j) std::swap(a[i], a[j]); }
+  std::vector<HFr> tw(n > 1 ? n / 2 : 1);
+  tw[0] = HFr::one(); for (size_t i = 1; i < n / 2; ++i) tw[i] = HFr::mul(tw[i - 1], w);
+  for (size_t len = 2; len <= n; len <<= 1)
+    for (size_t i = 0; i < n; i += len)
+      for (size_t t = 0; t < len / 2; ++t) {
+        const HFr u = a[i + t], v = HFr::mul(a[i + t + len / 2], tw[t * (n / len)]);
+        a[i + t] = HFr::add(u, v); a[i + t + len / 2] = HFr::sub(u, v);
+      }
 }
 inline HFr horner(const std::vector<HFr>& p, const HFr& x) { HFr a = HFr::zero(); for (size_t i = p.size(); i-- > 0;) a = HFr::add(HFr::mul(a, x), p[i]); return a; }
 
@@ -341,13 +355,9 @@ int32_t Prover::first_round(const void* const* assignments, std::vector<MsmSeg>&
       }
     std::vector<HFr> xe(n_x, HFr::zero());
     for (size_t t = 0; t < ix.n_public; ++t) { HFr v; std::memcpy(v.l, z + t * 32, 32); if (HFr::geq_p(v.l)) { g_last_error = "varuna_prove: assignment not canonical"; return ALEO_MI355X_ERR_BAD_ARG; } std::memcpy(&x_bytes[(i * n_x + t) * 32], v.l, 32); xe[t] = HFr::to_mont(v); }
-    x_poly[i].assign(n_x, HFr::zero());                    // inverse DFT over X, O(|X|^2): |X| is the (padded) number of public inputs
-    HFr wa = one;                                          // gx_inv^a
-    for (size_t a = 0; a < n_x; ++a) {
-      HFr acc = HFr::zero(), w = one;
-      for (size_t t = 0; t < n_x; ++t) { acc = HFr::add(acc, HFr::mul(xe[t], w)); w = HFr::mul(w, wa); }
-      x_poly[i][a] = HFr::mul(acc, nx_inv); wa = HFr::mul(wa, gx_inv);
-    }
+    x_poly[i] = xe;                                        // inverse DFT over X on the host: |X| is the (padded) number of public inputs
+    host_ntt(x_poly[i], gx_inv);
+    for (auto& v : x_poly[i]) v = HFr::mul(v, nx_inv);
   }
   for (size_t i = 0; i < k; ++i) std::memcpy(stage + (x_off + i * n_x) * 32, x_poly[i].data(), n_x * 32);
   if (host_layout) {

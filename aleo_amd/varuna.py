@@ -48,6 +48,18 @@ class _Vec:
     def host(self, off=0, n=None): return self.t[off:off + (self.n - off if n is None else n)].cpu().numpy().view(np.uint64)
 
 
+def _host_ntt(a, w):
+    """(sum_t a_t w^(t u))_u for a primitive len(a)-th root w (radix 2, python integers)."""
+    n = len(a)
+    if n == 1: return list(a)
+    w2 = w * w % R
+    ev, od = _host_ntt(a[0::2], w2), _host_ntt(a[1::2], w2)
+    out = [0] * n; t = 1
+    for i in range(n // 2):
+        v = t * od[i] % R; out[i] = (ev[i] + v) % R; out[i + n // 2] = (ev[i] - v) % R; t = t * w % R
+    return out
+
+
 def h_positions(n_vars, n_public, n_x, n_h) -> np.ndarray:
     """Index on H of every variable: public i -> i |H|/|X|, the j-th private one -> the j-th element of H \\ X."""
     ratio = n_h // n_x
@@ -385,7 +397,7 @@ class Prover:
         for i, z in enumerate(self.z):
             zh = np.zeros((n_h, 4), dtype=np.uint64); zh[ix.pos[:z.shape[0]]] = z
             xe = [synth.limbs_to_int(z[j]) if j < ix.n_public else 0 for j in range(n_x)]
-            xp = [sum(v * pow(gx_inv, a * j, R) for j, v in enumerate(xe)) * nxi % R for a in range(n_x)]      # O(|X|^2): |X| is tiny
+            xp = [v * nxi % R for v in _host_ntt(xe, gx_inv)]                            # inverse DFT over X on the host (|X| = padded number of public inputs)
             self.x_evals.append(xe); self.x_poly.append(xp)
             zH = _Vec(n_h, zh); fr_lin_device(zH.ptr(), n_h, None, r2, zH.ptr(), stream=s)
             base = 3 * i * n_h

@@ -159,7 +159,7 @@ def test_device_prover_batch_matches_restatement(k):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('domains', ['shared', 'per_matrix'])
-@pytest.mark.parametrize('n_constraints,n_public,seed', [(1, 1, 1), (2, 1, 2), (3, 2, 3), (8, 8, 4), (24, 3, 5), (31, 4, 9), (65, 3, 10), (100, 2, 6), (700, 5, 7), (2000, 9, 8)])
+@pytest.mark.parametrize('n_constraints,n_public,seed', [(1, 1, 1), (2, 1, 2), (3, 2, 3), (8, 8, 4), (24, 3, 5), (31, 4, 9), (65, 3, 10), (100, 2, 6), (700, 5, 7), (2000, 9, 8), (900, 300, 11)])
 def test_device_prover_matches_restatement(n_constraints, n_public, seed, domains):
     from aleo_amd import varuna
     csr, z, c = _circuit(n_constraints, n_public, seed, long_rows=1 if n_constraints > 8 else 0, domains=domains)
