@@ -103,12 +103,6 @@ inline HFr inv_pow2(uint32_t lg) {                          // 1 / 2^lg: lg prod
   static const HFr half = HFr::inv(fr_u64(2));
   HFr r = HFr::one(); for (uint32_t i = 0; i < lg; ++i) r = HFr::mul(r, half); return r;
 }
-inline void batch_inverse(HFr* v, size_t n) {               // Montgomery's trick on the host: one inversion for n non-zero values (n <= 8)
-  HFr pre[8], acc = HFr::one();
-  for (size_t i = 0; i < n; ++i) { pre[i] = acc; acc = HFr::mul(acc, v[i]); }
-  acc = HFr::inv(acc);
-  for (size_t i = n; i-- > 0;) { const HFr t = HFr::mul(acc, pre[i]); acc = HFr::mul(acc, v[i]); v[i] = t; }
-}
 // a <- (sum_t a_t w^(t u))_u for a primitive |a|-th root w, |a| a power of two: bit-reversal + radix-2 butterflies, O(n log n) host products
 inline void host_ntt(std::vector<HFr>& a, const HFr& w) {
   const size_t n = a.size();

@@ -334,7 +334,8 @@ def test_whole_proof_entry_points_refuse_misuse():
     ([(20, 2, 5, 2), (50, 3, 6, 1), (9, 1, 7, 2)], 'auto'),                       # three sizes of H, the largest in the middle
     ([(300, 4, 8, 1), (300, 4, 9, 1)], 'per_matrix'),                              # equal domains
     ([(40, 2, 10, 3), (700, 5, 11, 2), (1, 1, 12, 1), (130, 3, 13, 8)], 'auto'),   # 14 instances: linear combinations beyond one launch (28 terms)
-    ([(2000, 9, 14, 1), (24, 3, 15, 1)], 'per_matrix')])
+    ([(2000, 9, 14, 1), (24, 3, 15, 1)], 'per_matrix'),
+    ([(30, 2, 16, 8), (12, 1, 17, 8), (60, 3, 18, 8), (30, 2, 19, 8)], 'auto')])   # the most a proof takes: 32 instances, 97 first-round commitments in one call
 def test_device_prover_batch_over_circuits(shapes, domains):
     """aleo_mi355x_varuna_prove_batch_indexed: one proof over several circuits, byte for byte the restatement's, accepted by its verifier; an
     assignment that violates any one circuit is refused; a one-circuit batch equals the single-circuit entry point."""
