@@ -167,6 +167,10 @@ def main():
             del d_ws
         del d_scalars
 
+    replicas = None
+    if world > 1 and args.varuna_lg:
+        replicas = prove_replicas(synth, dist, args.varuna_lg, world, gather_dev, barrier)      # every rank takes part in its collectives, whatever happens locally
+
     if rank == 0:
         ms_step = elapsed / args.steps * 1e3
         value = total * args.steps / elapsed if strong else world * n * args.steps / elapsed
@@ -198,6 +202,7 @@ def main():
                                  'measured Fq product peak 81 G/s with 28-bit limbs, 61 G/s with 32-bit limbs (tools/ubench/fq28_mul_bench.hip, fq_mul_bench.hip)' % (16 if args.no_precompute else 13)},
             'phases_ms': {kk: float(np.mean([p_[kk] for p_ in phases])) for kk in phases[0]},
         }
+        if replicas is not None: out['prove_replicas'] = replicas
         if world == 1 and args.concurrent_callers > 1:
             out['concurrent_callers'] = concurrent_callers(aleo_amd, synth, torch, dev, pb, n, args.concurrent_callers)
         if world == 1 and not args.no_kzg_chain:
@@ -217,6 +222,16 @@ def main():
                 try: out['varuna_prove_2^%d' % args.varuna_big_lg] = varuna_prove_big(synth, args.varuna_big_lg)
                 except Exception as e: out['varuna_prove_2^%d' % args.varuna_big_lg] = {'error': repr(e)[:300]}      # secondary: never costs the headline line
             pb = aleo_amd.PinnedBases.generate_multiples(gen, first, n)
+        if world == 1 and 'varuna_prove' in out:
+            # SURVEY.md §8d(ii) in one place: constraints/s of real proofs (one circuit; eight instances; several circuits as Trace::prove_execution batches them)
+            vp = out['varuna_prove']; big = out.get('varuna_prove_2^%d' % args.varuna_big_lg, {})
+            summ = {'2^%d' % args.varuna_lg: vp.get('constraints_per_s'), '8 x 2^%d' % args.varuna_lg: vp.get('instances_8', {}).get('constraints_per_s'),
+                    'several_circuits': vp.get('several_circuits', {}).get('constraints_per_s')}
+            if 'constraints_per_s' in big:
+                summ['2^%d' % args.varuna_big_lg] = big['constraints_per_s']; summ['8 x 2^%d' % args.varuna_big_lg] = big.get('instances_8', {}).get('constraints_per_s')
+                bh = big.get('bit_heavy_witness_commit_lagrange', {})
+                if 'instances_8' in bh: summ['8 x 2^%d bit-heavy, commit_lagrange' % args.varuna_big_lg] = bh['instances_8'].get('constraints_per_s')
+            out['prove_constraints_per_s'] = summ
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args, pb, scalars, aleo_amd)
         print(json.dumps(out), flush=True)
@@ -413,6 +428,35 @@ def varuna_prove(synth, torch, lg, reps=7, in_flight=4):
                 'in_flight_%d' % in_flight: {'proofs_per_s': in_flight * per / dt, 'constraints_per_s': n * in_flight * per / dt}, 'what': VARUNA_NOTE}
     finally:
         ck.close()
+
+
+def prove_replicas(synth, dist, lg, world, gather_dev, barrier, reps=6):
+    """N > 1, secondary (SURVEY.md §8e "independent proofs: replicas"): every rank pins its own committer key and index on its GPU and proves the same
+    2^lg-constraint circuit `reps` times between barriers — no data-path collective; aggregate proofs/s and constraints/s from the slowest rank's time."""
+    import torch
+    from aleo_amd import varuna
+    dt, n, err = -1.0, 0, None
+    try:
+        n, csr, z, zz, ck, D = _varuna_instance(synth, lg, 40 + lg)
+        try:
+            with varuna.NativeCircuitIndex(csr, n, 4, len(z) - 4, ck) as nx:
+                nx.prove(zz, 1); nx.prove(zz, 2)
+                barrier(); t0 = time.perf_counter()
+                for rep in range(reps): nx.prove(zz, 10 + rep)
+                barrier(); dt = time.perf_counter() - t0
+        finally:
+            ck.close()
+    except Exception as e:                                  # a rank that failed before its barriers would leave the others waiting: it still meets them here
+        err = repr(e)[:200]
+        if dt < 0:
+            try: barrier(); barrier()
+            except Exception: pass
+    t = torch.tensor([dt, 1.0 if err is None else 0.0], dtype=torch.float64, device=gather_dev if gather_dev is not None else 'cpu')
+    worst = t.clone(); dist.all_reduce(worst, op=dist.ReduceOp.MAX)
+    ok = t.clone(); dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    if float(ok[1].item()) < 1.0: return {'error': err or 'another rank failed'}
+    el = float(worst[0].item())
+    return {'constraints': n, 'proofs_per_rank': reps, 'proofs_per_s': world * reps / el, 'constraints_per_s': world * reps * n / el, 'sharding': 'replicas: one proof per GPU at a time, no collective'}
 
 
 def varuna_prove_several(synth, ck, lg):
