@@ -14,7 +14,7 @@ EXPORTS = [
     'aleo_mi355x_ntt_fr_device', 'aleo_mi355x_ntt_fr_batch_device', 'aleo_mi355x_fr_grid_scale_device', 'aleo_mi355x_kzg_commit', 'aleo_mi355x_kzg_commit_device', 'aleo_mi355x_kzg_commit_hiding',
     'aleo_mi355x_msm_g1_batch_device', 'aleo_mi355x_kzg_commit_batch_device', 'aleo_mi355x_kzg_commit_batch', 'aleo_mi355x_kzg_commit_segments', 'aleo_mi355x_kzg_commit_segments_device',
     'aleo_mi355x_fr_vec_op_device', 'aleo_mi355x_fr_batch_inverse_device', 'aleo_mi355x_fr_spmv_device', 'aleo_mi355x_fr_divide_by_linear_device', 'aleo_mi355x_kzg_open_device', 'aleo_mi355x_fq_mul',
-    'aleo_mi355x_fr_mul', 'aleo_mi355x_selftest_madd28', 'aleo_mi355x_last_msm_timing', 'aleo_mi355x_strerror', 'aleo_mi355x_last_error',
+    'aleo_mi355x_fr_mul', 'aleo_mi355x_selftest_madd28', 'aleo_mi355x_selftest_addquad', 'aleo_mi355x_last_msm_timing', 'aleo_mi355x_strerror', 'aleo_mi355x_last_error',
     'aleo_mi355x_version',
     'aleo_mi355x_g1_compress', 'aleo_mi355x_g1_decompress', 'aleo_mi355x_fr_to_bytes', 'aleo_mi355x_fr_from_bytes',
     'aleo_mi355x_bech32m_encode', 'aleo_mi355x_bech32m_decode', 'aleo_mi355x_proof_to_bytes',
@@ -105,6 +105,7 @@ def lib():
         'aleo_mi355x_fq_mul': ([vp, vp, vp, sz], i32),
         'aleo_mi355x_fr_mul': ([vp, vp, vp, sz], i32),
         'aleo_mi355x_selftest_madd28': ([u32, u32, u64, ctypes.POINTER(u32)], i32),
+        'aleo_mi355x_selftest_addquad': ([u32, u64, ctypes.POINTER(u32)], i32),
         'aleo_mi355x_last_msm_timing': ([ctypes.POINTER(ctypes.c_double), i32], i32),
         'aleo_mi355x_strerror': ([i32], ctypes.c_char_p),
         'aleo_mi355x_last_error': ([], ctypes.c_char_p),

@@ -889,6 +889,9 @@ int32_t aleo_mi355x_fr_mul(void* r, const void* a, const void* b, size_t n) {
 int32_t aleo_mi355x_selftest_madd28(uint32_t lanes, uint32_t steps, uint64_t seed, uint32_t* failures) {
   try { if (!failures) return ALEO_MI355X_ERR_BAD_ARG; API_BEGIN return selftest_madd28(c, lanes, steps, seed, failures); } catch (...) { return ALEO_MI355X_ERR_HIP; }
 }
+int32_t aleo_mi355x_selftest_addquad(uint32_t ops, uint64_t seed, uint32_t* failures) {
+  try { if (!failures || !ops || ops > (1u << 22)) return ALEO_MI355X_ERR_BAD_ARG; API_BEGIN return selftest_addquad(c, ops, seed, failures); } catch (...) { return ALEO_MI355X_ERR_HIP; }
+}
 
 int32_t aleo_mi355x_last_msm_timing(double* out_ms, int32_t cap) {
   try {

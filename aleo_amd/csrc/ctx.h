@@ -155,6 +155,7 @@ int32_t msm_precompute(Ctx* c, PinnedBases* pb);
 int32_t msm_precompute_range(Ctx* c, PinnedBases* pb, size_t off, size_t n, int window_bits);
 int32_t make_rows28(Ctx* c, PinnedBases* pb);          // fills pb->d_xy28 from pb->d_xy
 int32_t selftest_madd28(Ctx* c, uint32_t lanes, uint32_t steps, uint64_t seed, uint32_t* failures);
+int32_t selftest_addquad(Ctx* c, uint32_t ops, uint64_t seed, uint32_t* failures);
 // g2.hip
 int32_t msm_g2_run(Ctx* c, uint64_t* out_jac36, const void* d_xy192, const uint8_t* d_inf, const void* d_scalars, size_t n, hipStream_t s);
 int32_t g2_sum_host(uint64_t* out36, const uint64_t* pts36, size_t count);

@@ -290,4 +290,62 @@ __device__ __forceinline__ void xyzz28_add_pair(const char* pa, const char* pb, 
   else { store_f28(out + 112, t6); store_f28(out + 168, t7); }
 }
 
+// ---- lane-QUAD cooperative addition: the same fourteen products in four levels instead of seven ---------------------------------------
+// For the chains that are pure latency (slice tree, chunk sums, masked sums, segment folds at <= one wave per SIMD).  Lanes 4k..4k+3 share one
+// addition A + B; lane q of the quad computes
+//   level 1   q0: U1 = X1 ZZ2     q1: U2 = X2 ZZ1      q2: S1 = ZZZ2 Y1     q3: S2 = ZZZ1 Y2
+//   level 2   q0: PP = P P        q1: ZZ1 ZZ2          q2: RR = R R         q3: ZZZ1 ZZZ2           (P = U2 - U1 in q0, R = S2 - S1 in q2)
+//   level 3   q0: PPP = P PP      q1: Q = U1 PP        (q2, q3 repeat q1's product: no divergence)
+//   level 4   q0: R (Q - X3)      q1: ZZ3 = ZZ12 PP    q2: S1 PPP           q3: ZZZ3 = ZZZ12 PPP    (X3 = RR - PPP - 2Q in every lane)
+// with quad_perm DPP moves between the levels (values never leave the quad's registers).  Same formulas, bounds and stored invariants as
+// xyzz28_add_pair; the rare same-x case (doubling / identity) is handed to the pair form on lanes 0, 1 of the quad.
+template <int S0, int S1, int S2, int S3> __device__ __forceinline__ F28 f28_qperm(const F28& a) {
+  F28 r;
+#pragma unroll
+  for (int i = 0; i < 14; ++i) r.v[i] = (uint32_t)__builtin_amdgcn_mov_dpp((int)a.v[i], S0 | (S1 << 2) | (S2 << 4) | (S3 << 6), 0xF, 0xF, true);
+  return r;
+}
+__device__ __forceinline__ void xyzz28_add_quad(const char* pa, const char* pb, char* out) {
+  const uint32_t q = threadIdx.x & 3u; const bool odd = q & 1u, hi = q & 2u;
+  const F28 zzA = load_f28(pa + 112), zzB = load_f28(pb + 112);
+  const bool infA = f28_is_zero_raw(zzA), infB = f28_is_zero_raw(zzB);
+  if (infA || infB) {              // quad-uniform: all four lanes see the same two points
+    const char* src = infB ? pa : pb;          // A + O = A ; O + B = B ; O + O = O (either)
+    if (src != out) {              // each lane copies a quarter of the 224 bytes
+      const uint2* s2 = (const uint2*)(src + 56 * q); uint2* d2 = (uint2*)(out + 56 * q);
+#pragma unroll
+      for (int i = 0; i < 7; ++i) d2[i] = s2[i];
+    }
+    return;
+  }
+  const char* own = odd ? pb : pa; const char* oth = odd ? pa : pb;
+  // level 1 (operand order as in the pair form: X_own * ZZ_other, ZZZ_other * Y_own)
+  const F28 l1a = load_f28(hi ? oth + 168 : own), l1b = hi ? load_f28(own + 56) : (odd ? zzA : zzB);
+  const F28 t1 = f28_mul(l1a, l1b);                                             // q0: U1  q1: U2  q2: S1  q3: S2   (< 2q)
+  const F28 D = f28_sub<4, 1>(f28_qperm<1, 1, 3, 3>(t1), t1);                   // q0: P = U2 - U1   q2: R = S2 - S1   (< 6q, class L3; q1, q3: unused)
+  // level 2
+  const F28 m2a = load_f28(pa + (hi ? 168 : 112)), m2b = load_f28(pb + (hi ? 168 : 112));
+  const F28 t2 = f28_mul(f28_sel(odd, D, m2a), f28_sel(odd, D, m2b));           // q0: PP  q1: ZZ1 ZZ2  q2: RR  q3: ZZZ1 ZZZ2   (L3 x L3: 140 < 256)
+  // level 3
+  const F28 U1 = f28_qperm<0, 0, 0, 0>(t1), PP = f28_qperm<0, 0, 0, 0>(t2);
+  const F28 t3 = f28_mul(f28_sel(q == 0, U1, D), PP);                           // q0: PPP = P PP   q1 (q2, q3): Q = U1 PP
+  const F28 RR = f28_qperm<2, 2, 2, 2>(t2), PPP = f28_qperm<0, 0, 0, 0>(t3), Q = f28_qperm<1, 1, 1, 1>(t3);
+  const F28 X3 = f28_normalise(f28_sub<6, 2>(f28_sub<4, 1>(RR, PPP), f28_add(Q, Q)));   // < 12q, exact digits (every lane)
+  // level 4
+  const F28 R = f28_qperm<2, 2, 2, 2>(D);
+  const F28 a4 = f28_sel(q == 0, f28_sel(q == 2, t2, t1), R);                   // q0: R   q1: ZZ12   q2: S1   q3: ZZZ12
+  const F28 b4 = f28_sel(q == 0, f28_sel(q == 1, PPP, PP), f28_sub<16, 1>(Q, X3));   // q0: Q - X3 (L3)   q1: PP   q2, q3: PPP
+  const F28 t4 = f28_mul(a4, b4);                                               // q0: Rt   q1: ZZ3   q2: SP   q3: ZZZ3
+  // same-x case: ZZ3 == 0 mod q, seen by lane 1 of the quad
+  int z = (q == 1 && f28_is_zero_mod_lt2q(t4)) ? 1 : 0;
+  z = __builtin_amdgcn_mov_dpp(z, 1 | (1 << 2) | (1 << 4) | (1 << 6), 0xF, 0xF, true);
+  if (__builtin_expect(z, 0)) {
+    if (q < 2) xyzz28_add_pair(pa, pb, out);      // lanes 0, 1 of the quad are a lane pair: the pair form doubles or writes the identity
+    return;
+  }
+  const F28 SP = f28_qperm<2, 2, 2, 2>(t4);
+  if (q == 0) { store_f28(out, X3); store_f28(out + 56, f28_sub<4, 1>(t4, SP)); }   // Y3 = Rt - SP: class L3, < 6q
+  else if (q != 2) store_f28(out + (q == 1 ? 112 : 168), t4);
+}
+
 }  // namespace aleo_mi355x

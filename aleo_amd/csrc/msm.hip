@@ -556,14 +556,38 @@ template <uint32_t BYTES = 192> __device__ __forceinline__ void pair_zero(char* 
 template <bool F28> __device__ __forceinline__ void pt_add_pair(const char* pa, const char* pb, char* out) {
   if constexpr (F28) xyzz28_add_pair(pa, pb, out); else xyzz_add_pair(pa, pb, out);
 }
+// The same chains with FOUR lanes per addition (fp28.h xyzz28_add_quad: four product levels instead of seven, 28-bit points only): taken while a
+// launch leaves the chip latency-bound (grp_lanes below), the pair form where the additions of a level already fill it (14 of a quad's 16 product slots work).
+template <uint32_t LANES> __device__ __forceinline__ void pt28_add(const char* pa, const char* pb, char* out) {
+  if constexpr (LANES == 4) xyzz28_add_quad(pa, pb, out); else xyzz28_add_pair(pa, pb, out);
+}
+template <uint32_t LANES, bool F28> __device__ __forceinline__ void pt_add_grp(const char* pa, const char* pb, char* out) {
+  if constexpr (LANES == 4) { static_assert(F28, "quad additions work on 28-bit points"); xyzz28_add_quad(pa, pb, out); } else pt_add_pair<F28>(pa, pb, out);
+}
+template <uint32_t LANES, uint32_t BYTES> __device__ __forceinline__ void grp_copy(const char* src, char* dst) {      // BYTES / LANES per lane
+  const uint32_t o = (threadIdx.x & (LANES - 1)) * (BYTES / LANES);
+  const uint2* s2 = (const uint2*)(src + o); uint2* d2 = (uint2*)(dst + o);
+#pragma unroll
+  for (int i = 0; i < (int)(BYTES / LANES / 8); ++i) d2[i] = s2[i];
+}
+template <uint32_t LANES, uint32_t BYTES> __device__ __forceinline__ void grp_zero(char* dst) {
+  uint2* d2 = (uint2*)(dst + (threadIdx.x & (LANES - 1)) * (BYTES / LANES));
+#pragma unroll
+  for (int i = 0; i < (int)(BYTES / LANES / 8); ++i) d2[i] = make_uint2(0, 0);
+}
+constexpr uint32_t lg_lanes(uint32_t lanes) { return lanes == 4 ? 2u : 1u; }
+// lanes per addition for a launch of `ops` independent additions: quads up to two waves per SIMD (2^17 lanes), pairs beyond.  Measured: k_seg_fold 90 -> 57 us,
+// k_tree_pass 15 -> 11 us, a 2^15-constraint proof 6.9 -> 6.6 ms; with the cut at 2^16 lanes the proof is at 6.8 ms.  (The 2^15-chunk kernel of the
+// widest window is the exception: 2^17 quad lanes take what 2^16 pair lanes take, 330 against 321 us — it keeps the pair form.)
+static inline uint32_t grp_lanes(uint64_t ops) { return ops * 4 <= (1u << 17) ? 4u : 2u; }
 // partial[ft + i] += partial[ft + i + half] inside every multi-slice bucket: one launch per level serves both lists of the scan —
 // the common one (buckets of <= 16 slices, `pairs_a` lane pairs each) and the super-heavy one (`pairs_b` each; skewed scalars).
-template <bool F28>
+template <bool F28, uint32_t LANES = 2>
 __global__ void __launch_bounds__(256) k_tree_pass(char* __restrict__ partial, const uint32_t* __restrict__ list_a, uint32_t len_a, uint32_t pairs_a,
                                                    const uint32_t* __restrict__ list_b, uint32_t len_b, uint32_t pairs_b, const uint2* __restrict__ scan_local,
                                                    const uint2* __restrict__ scan_blk, uint32_t M, const uint32_t* __restrict__ meta, uint32_t pass) {
   constexpr uint32_t PB = PtFmt<F28>::BYTES;
-  uint32_t op = (blockIdx.x * 256 + threadIdx.x) >> 1;
+  uint32_t op = (blockIdx.x * 256 + threadIdx.x) >> lg_lanes(LANES);
   const uint32_t ops_a = len_a * pairs_a;
   const uint32_t* list = list_a; uint32_t max_pairs = pairs_a, list_len = len_a;
   if (op >= ops_a) { op -= ops_a; list = list_b; max_pairs = pairs_b; list_len = len_b; }
@@ -579,32 +603,37 @@ __global__ void __launch_bounds__(256) k_tree_pass(char* __restrict__ partial, c
   uint32_t half = (L + 1) >> 1;
   if (i >= L - half) return;
   char* pa = partial + (size_t)(ft + i) * PB;
-  pt_add_pair<F28>(pa, pa + (size_t)half * PB, pa);
+  pt_add_grp<LANES, F28>(pa, pa + (size_t)half * PB, pa);
 }
 
 // ---- bucket reduction -----------------------------------------------------------------------------
 // One lane PAIR per chunk of S consecutive buckets of one window: running sums run += S_b, acc += run (b descending)
 // kept in LDS between the cooperative additions, so acc = sum_{b in chunk} (b - base + 1) * S_b and run = chunk total.
 // Both go to HBM (V, Vrun); the chunk weights are applied by masked sums (fixed-base path).
-static constexpr uint32_t CHUNK_PAIRS = 128;        // chunks per 256-thread block
-template <bool F28>
+static constexpr uint32_t CHUNK_PAIRS = 128;        // chunks per 256-thread block (LANES = 2; 64 with quads)
+template <bool F28, uint32_t LANES = 2>
 __global__ void __launch_bounds__(256) k_bucket_chunks_pair(const char* __restrict__ partial, const uint32_t* __restrict__ hist, const uint2* __restrict__ scan_local,
                                                        const uint2* __restrict__ scan_blk, uint32_t B, uint32_t S, uint32_t nchunks_total, char* __restrict__ V,
                                                        uint32_t v_set_stride, char* __restrict__ Vrun) {
   constexpr uint32_t PB = PtFmt<F28>::BYTES, PW = PtFmt<F28>::WORDS;
-  __shared__ __attribute__((aligned(16))) uint32_t lds[2 * CHUNK_PAIRS * PW];
-  const uint32_t pr = threadIdx.x >> 1, t = blockIdx.x * CHUNK_PAIRS + pr;
+  constexpr uint32_t CPB = 256 / LANES;                   // chunks per block
+  __shared__ __attribute__((aligned(16))) uint32_t lds[2 * CPB * PW];
+  const uint32_t pr = threadIdx.x >> lg_lanes(LANES), t = blockIdx.x * CPB + pr;
   if (t >= nchunks_total) return;
-  char* run = (char*)(lds + pr * PW); char* acc = (char*)(lds + (CHUNK_PAIRS + pr) * PW);
-  pair_zero<PB>(run); pair_zero<PB>(acc);
+  char* run = (char*)(lds + pr * PW); char* acc = (char*)(lds + (CPB + pr) * PW);
+  grp_zero<LANES, PB>(run); grp_zero<LANES, PB>(acc);
   pair_fence();
   const uint32_t cpw = B / S, w = t / cpw, j = t % cpw, g0 = w * B + j * S;
+  // the address of bucket k + 1's sum (two dependent loads: histogram, scan) is fetched while bucket k's two additions run
+  auto sum_of = [&](uint32_t g) -> const char* { return hist[g] ? partial + (size_t)scan_at(scan_local, scan_blk, g).y * PB : nullptr; };
+  const char* nxt = sum_of(g0 + S - 1);
   for (uint32_t k = 0; k < S; ++k) {
-    const uint32_t g = g0 + (S - 1 - k);
-    if (hist[g]) { pt_add_pair<F28>(run, partial + (size_t)scan_at(scan_local, scan_blk, g).y * PB, run); pair_fence(); }
-    pt_add_pair<F28>(acc, run, acc); pair_fence();
+    const char* cur = nxt;
+    if (k + 1 < S) nxt = sum_of(g0 + S - 2 - k);
+    if (cur) { pt_add_grp<LANES, F28>(run, cur, run); pair_fence(); }
+    pt_add_grp<LANES, F28>(acc, run, acc); pair_fence();
   }
-  pair_copy<PB>(run, Vrun + (size_t)t * PB); pair_copy<PB>(acc, V + ((size_t)w * v_set_stride + j) * PB);
+  grp_copy<LANES, PB>(run, Vrun + (size_t)t * PB); grp_copy<LANES, PB>(acc, V + ((size_t)w * v_set_stride + j) * PB);
 }
 
 // One lane QUAD per chunk of S consecutive buckets: running sums run_k = run_{k-1} + S_b (b descending) and acc += run_{k-1}
@@ -613,32 +642,36 @@ __global__ void __launch_bounds__(256) k_bucket_chunks_pair(const char* __restri
 // SAME addition call with per-lane pointers (a branch per sub-pair would serialise them inside the wave).
 // acc = sum_{b in chunk} (b - base + 1) * S_b and run = chunk total go to HBM (V, Vrun); the chunk weights are applied by
 // masked sums (fixed-base path).
-static constexpr uint32_t CHUNK_QUADS = 64;         // chunks per 256-thread block
-template <bool F28>
+static constexpr uint32_t CHUNK_QUADS = 64;         // chunks per 256-thread block (LANES = 2: two lane pairs per chunk; 32 with LANES = 4: two lane quads)
+template <bool F28, uint32_t LANES = 2>
 __global__ void __launch_bounds__(256) k_bucket_chunks(const char* __restrict__ partial, const uint32_t* __restrict__ hist, const uint2* __restrict__ scan_local,
                                                        const uint2* __restrict__ scan_blk, uint32_t B, uint32_t S, uint32_t nchunks_total, char* __restrict__ V,
                                                        uint32_t v_set_stride, char* __restrict__ Vrun) {
   constexpr uint32_t PB = PtFmt<F28>::BYTES, PW = PtFmt<F28>::WORDS;
-  __shared__ __attribute__((aligned(16))) uint32_t lds[(3 * CHUNK_QUADS + 1) * PW];
-  const uint32_t qd = threadIdx.x >> 2, sp = (threadIdx.x >> 1) & 1u, t = blockIdx.x * CHUNK_QUADS + qd;
-  char* zero = (char*)(lds + 3 * CHUNK_QUADS * PW);
-  if (threadIdx.x < 2) pair_zero<PB>(zero);
+  constexpr uint32_t CPB = 128 / LANES;                  // chunks per block: two groups of LANES lanes each
+  __shared__ __attribute__((aligned(16))) uint32_t lds[(3 * CPB + 1) * PW];
+  const uint32_t qd = threadIdx.x >> (lg_lanes(LANES) + 1), sp = (threadIdx.x >> lg_lanes(LANES)) & 1u, t = blockIdx.x * CPB + qd;
+  char* zero = (char*)(lds + 3 * CPB * PW);
+  if (threadIdx.x < LANES) grp_zero<LANES, PB>(zero);
   __syncthreads();
   if (t >= nchunks_total) return;
   char* buf0 = (char*)(lds + (3 * qd) * PW); char* buf1 = buf0 + PB; char* acc = buf1 + PB;
-  pair_zero<PB>(sp ? acc : buf0); if (!sp) pair_zero<PB>(buf1);
+  grp_zero<LANES, PB>(sp ? acc : buf0); if (!sp) grp_zero<LANES, PB>(buf1);
   pair_fence();
   const uint32_t cpw = B / S, w = t / cpw, j = t % cpw, g0 = w * B + j * S;
+  // the address of the next bucket's sum (two dependent loads: histogram, scan) is fetched one step ahead of the addition that uses it
+  auto sum_of = [&](uint32_t g) -> const char* { return hist[g] ? partial + (size_t)scan_at(scan_local, scan_blk, g).y * PB : zero; };
+  const char* nxt = sp ? zero : sum_of(g0 + S - 1);
   for (uint32_t k = 0; k <= S; ++k) {
     char* rprev = (k & 1) ? buf0 : buf1; char* rnext = (k & 1) ? buf1 : buf0;      // run_k lives in buf[k & 1]; run_{-1} = 0
-    const char* add = zero;
-    if (!sp && k < S) { const uint32_t g = g0 + (S - 1 - k); if (hist[g]) add = partial + (size_t)scan_at(scan_local, scan_blk, g).y * PB; }
+    const char* add = k < S ? nxt : zero;
+    nxt = (!sp && k + 1 < S) ? sum_of(g0 + S - 2 - k) : zero;
     const char* pa = sp ? acc : rprev; const char* pb = sp ? rprev : add; char* out = sp ? acc : rnext;
-    pt_add_pair<F28>(pa, pb, out);
+    pt_add_grp<LANES, F28>(pa, pb, out);
     pair_fence();
   }
   // after step S: buf[S & 1] holds run_{S-1} again (step S copied it forward), acc holds sum_k run_k
-  pair_copy<PB>(sp ? acc : ((S & 1) ? buf1 : buf0), sp ? V + ((size_t)w * v_set_stride + j) * PB : Vrun + (size_t)t * PB);
+  grp_copy<LANES, PB>(sp ? acc : ((S & 1) ? buf1 : buf0), sp ? V + ((size_t)w * v_set_stride + j) * PB : Vrun + (size_t)t * PB);
 }
 
 // Plain path (one window set per window): one lane per chunk, V = sum_{b in chunk} (b+1) * S_b with the chunk base applied
@@ -692,50 +725,54 @@ __global__ void __launch_bounds__(256) k_seg_tree_pass(char* __restrict__ V, uin
 static constexpr uint32_t PB28 = 224, PW28 = 56;
 // Sets (batched calls): set q reads Vrun[q * 2^lgN ...] and writes its lgN sums behind its chunk sums, at
 // V[q * v_set_stride + 2^lgN ...] (v_set_stride = (lgN + 4) * 2^(lgN-2): the set's 4 + lgN segments are contiguous).
+template <uint32_t LANES>
 __global__ void __launch_bounds__(256) k_masked_pairs(const char* __restrict__ Vrun, uint32_t lgN, uint32_t nsets, char* __restrict__ V, uint32_t v_set_stride) {
   const uint32_t seg_len = 1u << (lgN - 2);
-  const uint32_t op = (blockIdx.x * 256 + threadIdx.x) >> 1;
+  const uint32_t op = (blockIdx.x * 256 + threadIdx.x) >> lg_lanes(LANES);
   if (op >= seg_len * lgN * nsets) return;
   const uint32_t q = op / (seg_len * lgN), r = op % (seg_len * lgN), l = r / seg_len, k = r % seg_len;
   auto ins = [&](uint32_t x) { return ((x >> l) << (l + 1)) | (1u << l) | (x & ((1u << l) - 1u)); };
   const char* run = Vrun + ((size_t)q << lgN) * PB28;
-  xyzz28_add_pair(run + (size_t)ins(2 * k) * PB28, run + (size_t)ins(2 * k + 1) * PB28, V + ((size_t)q * v_set_stride + (1u << lgN) + r) * PB28);
+  pt28_add<LANES>(run + (size_t)ins(2 * k) * PB28, run + (size_t)ins(2 * k + 1) * PB28, V + ((size_t)q * v_set_stride + (1u << lgN) + r) * PB28);
 }
 // One block folds up to 256 consecutive points of one segment into a single point: 8 tree levels through two LDS
 // buffers, 128 lane pairs — the latency floor of the chain with no launch gaps.
 static constexpr uint32_t FOLD = 256;
-__global__ void __launch_bounds__(256) k_seg_fold(const char* __restrict__ in, uint32_t in_stride, uint32_t L, uint32_t nseg,
-                                                  char* __restrict__ out, uint32_t out_stride) {
+// (the block has FOLD / 2 lane groups: 256 threads as pairs, 512 as quads — the quad form halves the latency of each of the 8 levels)
+template <uint32_t LANES>
+__global__ void __launch_bounds__(128 * LANES) k_seg_fold(const char* __restrict__ in, uint32_t in_stride, uint32_t L, uint32_t nseg,
+                                                          char* __restrict__ out, uint32_t out_stride) {
   __shared__ __attribute__((aligned(16))) uint32_t lds[2][(FOLD / 2) * PW28];
-  const uint32_t bps = (L + FOLD - 1) / FOLD, seg = blockIdx.x / bps, blk = blockIdx.x % bps, pr = threadIdx.x >> 1;
+  const uint32_t bps = (L + FOLD - 1) / FOLD, seg = blockIdx.x / bps, blk = blockIdx.x % bps, pr = threadIdx.x >> lg_lanes(LANES);
   if (seg >= nseg) return;
   {
     const uint32_t e0 = blk * FOLD + 2 * pr;
     const char* src = in + ((size_t)seg * in_stride + e0) * PB28;
     char* dst = (char*)(lds[0] + pr * PW28);
-    if (e0 + 1 < L) xyzz28_add_pair(src, src + PB28, dst);
-    else if (e0 < L) pair_copy<PB28>(src, dst);
-    else pair_zero<PB28>(dst);
+    if (e0 + 1 < L) pt28_add<LANES>(src, src + PB28, dst);
+    else if (e0 < L) grp_copy<LANES, PB28>(src, dst);
+    else grp_zero<LANES, PB28>(dst);
   }
   uint32_t cur = 0;
   for (uint32_t n = FOLD / 2; n > 1; n >>= 1) {
     __syncthreads();
-    if (pr < (n >> 1)) xyzz28_add_pair((const char*)(lds[cur] + (2 * pr) * PW28), (const char*)(lds[cur] + (2 * pr + 1) * PW28), (char*)(lds[cur ^ 1] + pr * PW28));
+    if (pr < (n >> 1)) pt28_add<LANES>((const char*)(lds[cur] + (2 * pr) * PW28), (const char*)(lds[cur] + (2 * pr + 1) * PW28), (char*)(lds[cur ^ 1] + pr * PW28));
     cur ^= 1;
   }
   __syncthreads();
-  if (pr == 0) pair_copy<PB28>((const char*)lds[cur], out + ((size_t)seg * out_stride + blk) * PB28);
+  if (pr == 0) grp_copy<LANES, PB28>((const char*)lds[cur], out + ((size_t)seg * out_stride + blk) * PB28);
 }
 // out[seg][i] = in[seg][2i] + in[seg][2i+1]: the wide (throughput-bound) levels of the segment sums
+template <uint32_t LANES>
 __global__ void __launch_bounds__(256) k_seg_pair_pass(const char* __restrict__ in, uint32_t in_stride, uint32_t L, uint32_t nseg,
                                                        char* __restrict__ out, uint32_t out_stride) {
   const uint32_t half = (L + 1) >> 1;
-  const uint32_t op = (blockIdx.x * 256 + threadIdx.x) >> 1;
+  const uint32_t op = (blockIdx.x * 256 + threadIdx.x) >> lg_lanes(LANES);
   if (op >= half * nseg) return;
   const uint32_t seg = op / half, i = op % half;
   const char* src = in + ((size_t)seg * in_stride + 2 * i) * PB28;
   char* dst = out + ((size_t)seg * out_stride + i) * PB28;
-  if (2 * i + 1 < L) xyzz28_add_pair(src, src + PB28, dst); else pair_copy<PB28>(src, dst);
+  if (2 * i + 1 < L) pt28_add<LANES>(src, src + PB28, dst); else grp_copy<LANES, PB28>(src, dst);
 }
 __global__ void k_gather_strided(const char* __restrict__ V, uint32_t stride, uint32_t count, char* __restrict__ out) {
   uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -961,10 +998,13 @@ int32_t msm_run(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, const MsmJob
       const uint32_t Lc = sm.super_overflow ? L : (L < 16u ? L : (16u >> (pass < 4 ? pass : 4)));       // longest bucket of the common list at this level
       const uint32_t len_a = (sm.n_heavy && Lc > 1) ? sm.n_heavy : 0, pairs_a = len_a ? Lc >> 1 : 0;
       const uint32_t len_b = sm.n_super, pairs_b = len_b ? L >> 1 : 0;
-      const uint64_t threads = 2ull * ((uint64_t)len_a * pairs_a + (uint64_t)len_b * pairs_b);
+      const uint64_t ops = (uint64_t)len_a * pairs_a + (uint64_t)len_b * pairs_b;
+      const uint32_t lanes = pre ? grp_lanes(ops) : 2u;                                                // quads while the level is latency-bound (28-bit points only)
+      const uint64_t threads = lanes * ops;
       if (!threads) continue;
       if (threads >= (1ull << 32)) { (void)hipStreamSynchronize(s); g_last_error = "msm: slice tree too wide"; return ALEO_MI355X_ERR_HIP; }
-      if (pre) hipLaunchKernelGGL(k_tree_pass<true>, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, s, partial, heavy, len_a, pairs_a, sp.super_list, len_b, pairs_b, scan_local, scan_blk, M, meta, pass);
+      if (pre && lanes == 4) hipLaunchKernelGGL((k_tree_pass<true, 4>), dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, s, partial, heavy, len_a, pairs_a, sp.super_list, len_b, pairs_b, scan_local, scan_blk, M, meta, pass);
+      else if (pre) hipLaunchKernelGGL(k_tree_pass<true>, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, s, partial, heavy, len_a, pairs_a, sp.super_list, len_b, pairs_b, scan_local, scan_blk, M, meta, pass);
       else hipLaunchKernelGGL(k_tree_pass<false>, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, s, partial, heavy, len_a, pairs_a, sp.super_list, len_b, pairs_b, scan_local, scan_blk, M, meta, pass);
     }
   }
@@ -1004,16 +1044,28 @@ int32_t msm_run(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, const MsmJob
     char* Vrun = V + (size_t)K * setw * PB28; char* Tout = Vrun + (size_t)nchunks * PB28;
     // 2^19 buckets keep the chip busy with one lane pair per chunk; the small bucket sets (<= 2^16) are pure latency and take the quad form
     // (masked => pre: the partial sums are 28-bit points)
-    if (P.c >= 20) hipLaunchKernelGGL(k_bucket_chunks_pair<true>, dim3((nchunks + CHUNK_PAIRS - 1) / CHUNK_PAIRS), dim3(256), 0, s, partial, hist, scan_local, scan_blk, P.B, P.S, nchunks, V, setw, Vrun);
-    else hipLaunchKernelGGL(k_bucket_chunks<true>, dim3((nchunks + CHUNK_QUADS - 1) / CHUNK_QUADS), dim3(256), 0, s, partial, hist, scan_local, scan_blk, P.B, P.S, nchunks, V, setw, Vrun);
-    hipLaunchKernelGGL(k_masked_pairs, dim3((2 * tseg * lgN * K + 255) / 256), dim3(256), 0, s, Vrun, lgN, K, V, setw);
+    // every launch below picks lanes per addition by its own width (grp_lanes): four while it is latency-bound, two once the additions fill the chip
+    if (P.c >= 20) {
+      if (grp_lanes(2 * (uint64_t)nchunks) == 4) hipLaunchKernelGGL((k_bucket_chunks_pair<true, 4>), dim3((nchunks + 63) / 64), dim3(256), 0, s, partial, hist, scan_local, scan_blk, P.B, P.S, nchunks, V, setw, Vrun);
+      else hipLaunchKernelGGL(k_bucket_chunks_pair<true>, dim3((nchunks + CHUNK_PAIRS - 1) / CHUNK_PAIRS), dim3(256), 0, s, partial, hist, scan_local, scan_blk, P.B, P.S, nchunks, V, setw, Vrun);
+    } else {
+      if (grp_lanes(2 * (uint64_t)nchunks) == 4) hipLaunchKernelGGL((k_bucket_chunks<true, 4>), dim3((nchunks + 31) / 32), dim3(256), 0, s, partial, hist, scan_local, scan_blk, P.B, P.S, nchunks, V, setw, Vrun);
+      else hipLaunchKernelGGL(k_bucket_chunks<true>, dim3((nchunks + CHUNK_QUADS - 1) / CHUNK_QUADS), dim3(256), 0, s, partial, hist, scan_local, scan_blk, P.B, P.S, nchunks, V, setw, Vrun);
+    }
+    {
+      const uint64_t ops = (uint64_t)tseg * lgN * K;
+      if (grp_lanes(ops) == 4) hipLaunchKernelGGL(k_masked_pairs<4>, dim3((uint32_t)((4 * ops + 255) / 256)), dim3(256), 0, s, Vrun, lgN, K, V, setw);
+      else hipLaunchKernelGGL(k_masked_pairs<2>, dim3((uint32_t)((2 * ops + 255) / 256)), dim3(256), 0, s, Vrun, lgN, K, V, setw);
+    }
     // K * (lgN+4) segment sums: pairwise launches while a level still fills the chip, then ONE block per segment folds the
     // last 256 points through LDS (8 levels of lane-pair additions: the latency floor of the chain, no launch gaps)
     char* F1 = Tout + (size_t)(nseg + 1) * PB28; char* F2 = F1 + (size_t)nseg * (tseg / 2 + 1) * PB28;
     const char* cur = V; uint32_t L = tseg, stride = tseg;
     while (L > FOLD) {
       char* dst = (cur == F1) ? F2 : F1; uint32_t half = (L + 1) >> 1;
-      hipLaunchKernelGGL(k_seg_pair_pass, dim3((2 * half * nseg + 255) / 256), dim3(256), 0, s, cur, stride, L, nseg, dst, half);
+      const uint64_t ops = (uint64_t)half * nseg;
+      if (grp_lanes(ops) == 4) hipLaunchKernelGGL(k_seg_pair_pass<4>, dim3((uint32_t)((4 * ops + 255) / 256)), dim3(256), 0, s, cur, stride, L, nseg, dst, half);
+      else hipLaunchKernelGGL(k_seg_pair_pass<2>, dim3((uint32_t)((2 * ops + 255) / 256)), dim3(256), 0, s, cur, stride, L, nseg, dst, half);
       cur = dst; stride = half; L = half;
     }
     if (L > 1) {
@@ -1021,7 +1073,7 @@ int32_t msm_run(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, const MsmJob
       // mapped), so the result needs neither a gather launch nor a copy — the stream synchronisation below is all that is left
       char* dst = nullptr;
       HIPCHK(hipHostGetDevicePointer((void**)&dst, h_win, 0));
-      hipLaunchKernelGGL(k_seg_fold, dim3(nseg), dim3(256), 0, s, cur, stride, L, nseg, dst, 1u);
+      hipLaunchKernelGGL(k_seg_fold<4>, dim3(nseg), dim3(512), 0, s, cur, stride, L, nseg, dst, 1u);
     } else {
       hipLaunchKernelGGL(k_gather_strided, dim3((nseg * 14 + 255) / 256), dim3(256), 0, s, cur, stride, nseg, Tout);
       HIPCHK(hipMemcpyAsync(h_win, Tout, (size_t)nseg * PB28, hipMemcpyDeviceToHost, s));
@@ -1396,6 +1448,48 @@ int32_t selftest_madd28(Ctx* c, uint32_t lanes, uint32_t steps, uint64_t seed, u
   uint32_t* d = c->scalars_stage.as<uint32_t>();
   HIPCHK(hipMemsetAsync(d, 0, 4, c->stream));
   hipLaunchKernelGGL(k_selftest_madd28, dim3((lanes + 255) / 256), dim3(256), 0, c->stream, d, steps, seed | 1ull);
+  HIPCHK(hipMemcpyAsync(failures, d, 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  HIPCHK(hipGetLastError());
+  return ALEO_MI355X_OK;
+}
+
+// The lane-quad addition against the lane-pair one (which the MSM parity tests pin): same values mod q in all four coordinates, same
+// infinity flag, over random operands and the special cases (either operand the identity, equal points, opposite points).
+__global__ void __launch_bounds__(256) k_selftest_addquad(char* buf, uint32_t ops, uint64_t seed, uint32_t* bad) {
+  const uint32_t op = (blockIdx.x * 256 + threadIdx.x) >> 2, q = threadIdx.x & 3u;
+  if (op >= ops) return;
+  char* A = buf + (size_t)op * 4 * PB28; char* B = A + PB28; char* O4 = B + PB28; char* O2 = O4 + PB28;
+  if (q == 0) {
+    uint64_t s = seed * (op + 1);
+    XYZZ28 a, b;
+    a.X = f28_from_fq(st_rnd_fq(s)); a.Y = f28_from_fq(st_rnd_fq(s)); a.ZZ = f28_from_fq(st_rnd_fq(s)); a.ZZZ = f28_from_fq(st_rnd_fq(s));
+    b.X = f28_from_fq(st_rnd_fq(s)); b.Y = f28_from_fq(st_rnd_fq(s)); b.ZZ = f28_from_fq(st_rnd_fq(s)); b.ZZZ = f28_from_fq(st_rnd_fq(s));
+    const uint32_t kind = op % 16;
+    if (kind == 11) { a.ZZ = f28_const(Limbs14{}); }                                          // A the identity
+    if (kind == 12) { b.ZZ = f28_const(Limbs14{}); }                                          // B the identity
+    if (kind == 13) { a.ZZ = f28_const(Limbs14{}); b.ZZ = a.ZZ; }
+    if (kind == 14) b = a;                                                                    // equal: doubling
+    if (kind == 15) { b = a; b.Y = f28_normalise(f28_sub<2, 1>(f28_const(Limbs14{}), a.Y)); }   // opposite: the identity
+    store_xyzz28(A, a); store_xyzz28(B, b);
+  }
+  pair_fence(); __syncthreads();
+  xyzz28_add_quad(A, B, O4);
+  if (q < 2) xyzz28_add_pair(A, B, O2);
+  pair_fence(); __syncthreads();
+  if (q == 0) {
+    const bool i4 = f28_is_zero_raw(load_f28(O4 + 112)), i2 = f28_is_zero_raw(load_f28(O2 + 112));
+    bool ok = i4 == i2;
+    if (ok && !i4) for (int k = 0; k < 4; ++k) ok = ok && st_same(f28_to_fq(load_f28(O4 + 56 * k)), f28_to_fq(load_f28(O2 + 56 * k)));
+    if (!ok) atomicAdd(bad, 1u);
+  }
+}
+int32_t selftest_addquad(Ctx* c, uint32_t ops, uint64_t seed, uint32_t* failures) {
+  ops = (ops + 63u) & ~63u;                                  // whole blocks: the kernel synchronises its threads
+  int32_t rc; if ((rc = c->scalars_stage.reserve((size_t)ops * 4 * PB28 + 64))) return rc;
+  char* buf = c->scalars_stage.as<char>() + 64; uint32_t* d = c->scalars_stage.as<uint32_t>();
+  HIPCHK(hipMemsetAsync(d, 0, 4, c->stream));
+  hipLaunchKernelGGL(k_selftest_addquad, dim3(ops / 64), dim3(256), 0, c->stream, buf, ops, seed | 1ull, d);
   HIPCHK(hipMemcpyAsync(failures, d, 4, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
   HIPCHK(hipGetLastError());

@@ -346,6 +346,9 @@ int32_t aleo_mi355x_fr_mul(void* r, const void* a, const void* b, size_t n);
  * formulas of the accumulation kernel and through the 32-bit ones, comparing every intermediate as canonical residues
  * (and that both refuse P == acc).  *failures = number of lanes that disagreed. */
 int32_t aleo_mi355x_selftest_madd28(uint32_t lanes, uint32_t steps, uint64_t seed, uint32_t* failures);
+/* The lane-quad XYZZ addition of the reduction chains against the lane-pair one on `ops` random operand pairs and the special cases
+ * (identity operands, equal points, opposite points): *failures = number of disagreements (mod q, all four coordinates). */
+int32_t aleo_mi355x_selftest_addquad(uint32_t ops, uint64_t seed, uint32_t* failures);
 
 /* Per-call instrumentation of the calling thread's most recent MSM: milliseconds per phase
  * [0] total, [1] digit/sort, [2] bucket accumulation incl. slice tree, [3] bucket reduction, [4] host tail,

@@ -57,6 +57,15 @@ def test_accumulation_arithmetic_28bit_limbs_matches_32bit():
     assert bad.value == 0
 
 
+def test_lane_quad_addition_matches_lane_pair():
+    """The reduction chains add XYZZ points with four lanes per addition (fp28.h xyzz28_add_quad); it must agree with the lane-pair form — which every
+    MSM parity test pins — on random operands, identity operands, equal points (doubling) and opposite points."""
+    import ctypes
+    bad = ctypes.c_uint32(123)
+    aleo_amd._lib.check(aleo_amd.lib().aleo_mi355x_selftest_addquad(1 << 16, 0x9E3779B97F4A7C15, ctypes.byref(bad)), 'selftest')
+    assert bad.value == 0
+
+
 # ---- NTT ----------------------------------------------------------------------------------------------
 def test_ntt_golden_vectors():
     fx = json.load(open(os.path.join(G, 'ntt_small.json')))
