@@ -102,8 +102,17 @@ template <uint32_t TE, int G> __device__ __forceinline__ void dif_group(uint32_t
 
 // All radix-2 DIF stages of T length-L transforms held in the tile (row t at [t*L, (t+1)*L)), in register groups of 3
 // stages (then 2 or 1).  Output k of row t ends at position t*L + bitrev(k).  Values in and out are < 2r.
-template <uint32_t TE, uint32_t NT> __device__ __forceinline__ void tile_dif(uint32_t* lds, uint32_t lgL, uint32_t T, const char* __restrict__ inner) {
+// GM = 1 (the latency form for a lone small transform): one stage per LDS round trip, one butterfly per lane — a 512-element tile keeps 256 lanes busy
+// for 9 short steps instead of 64 lanes for 3 long ones (12 dependent products each).
+template <uint32_t TE, uint32_t NT, int GM = 3> __device__ __forceinline__ void tile_dif(uint32_t* lds, uint32_t lgL, uint32_t T, const char* __restrict__ inner) {
   const uint32_t total = T << lgL;
+  if constexpr (GM == 1) {
+    for (uint32_t st = 0; st < lgL; ++st) {
+      for (uint32_t sb = threadIdx.x; sb < (total >> 1); sb += NT) dif_group<TE, 1>(lds, lgL, st, sb, inner);
+      __syncthreads();
+    }
+    return;
+  }
   uint32_t s = 0;
   for (; s + 3 <= lgL; s += 3) {
     for (uint32_t sb = threadIdx.x; sb < (total >> 3); sb += NT) dif_group<TE, 3>(lds, lgL, s, sb, inner);
@@ -120,7 +129,7 @@ template <uint32_t TE, uint32_t NT> __device__ __forceinline__ void tile_dif(uin
 
 // Pass over axis l of the view [A][L][Bn] (index = (a*L + l)*Bn + b), tile = one a, T adjacent b.
 // dst may alias src (same positions).  After the transform, element (k, b) is multiplied by w_n^(tw_scale*k*b).
-template <uint32_t TE, uint32_t NT>
+template <uint32_t TE, uint32_t NT, int GM = 3>
 __global__ void __launch_bounds__(NT) k_ntt_strided(const char* src, char* dst, uint32_t lgL, uint32_t lgBn, uint32_t lgT,
                                                      uint32_t tw_scale, uint32_t lg_n, uint32_t lo_bits, const char* __restrict__ inner,
                                                      const char* __restrict__ tw_hi, const char* __restrict__ tw_lo,
@@ -150,7 +159,7 @@ __global__ void __launch_bounds__(NT) k_ntt_strided(const char* src, char* dst, 
     }
     __syncthreads();
   }
-  tile_dif<TE, NT>(lds, lgL, T, inner);
+  tile_dif<TE, NT, GM>(lds, lgL, T, inner);
   const uint32_t nmask = (lg_n >= 32) ? 0xffffffffu : ((1u << lg_n) - 1u);
   for (uint32_t e = threadIdx.x; e < T * L; e += NT) {
     uint32_t t = e & (T - 1u), k = e >> lgT;
@@ -168,7 +177,7 @@ __global__ void __launch_bounds__(NT) k_ntt_strided(const char* src, char* dst, 
 
 // Last pass: rows a = k1*n2 + k2 are contiguous (Bn == 1); tile = T adjacent k1 at one k2; output k of that row
 // goes to natural position k1 + n1*(k2 + n2*k).  src != dst unless n1 == n2 == 1.
-template <uint32_t TE, uint32_t NT>
+template <uint32_t TE, uint32_t NT, int GM = 3>
 __global__ void __launch_bounds__(NT) k_ntt_final(const char* src, char* dst, uint32_t lgL, uint32_t lgN1, uint32_t lgN2, uint32_t lgT,
                                                    uint32_t lo_bits, const char* __restrict__ inner, const char* __restrict__ cs_hi, const char* __restrict__ cs_lo,
                                                    int pre_coset, int post_coset, int do_scale, FrArg scale) {
@@ -196,7 +205,7 @@ __global__ void __launch_bounds__(NT) k_ntt_final(const char* src, char* dst, ui
     }
     __syncthreads();
   }
-  tile_dif<TE, NT>(lds, lgL, T, inner);
+  tile_dif<TE, NT, GM>(lds, lgL, T, inner);
   Fr sc; for (int i = 0; i < 8; ++i) sc.v[i] = scale.v[i];
   for (uint32_t e = threadIdx.x; e < T * L; e += NT) {
     uint32_t t = e & (T - 1u), k = e >> lgT;
@@ -265,15 +274,15 @@ static int32_t build_tables(NttTables* t, uint32_t lg_n, int direction) {
   return ALEO_MI355X_OK;
 }
 
-template <uint32_t TE, uint32_t NT>
+template <uint32_t TE, uint32_t NT, int GM = 3>
 static int32_t run_passes(Ctx* c, char* buf, char* tmp, uint32_t lg_n, uint32_t batch, const NttTables* t, int pre_coset, int post_coset, int do_scale, FrArg sc, hipStream_t s) {
   constexpr uint32_t lgTE = TE == 4096 ? 12 : (TE == 2048 ? 11 : 9);
   static_assert(TE == 4096 || TE == 2048 || TE == 512, "tile sizes with a kernel instance");
   constexpr size_t lds_bytes = (size_t)TE * 32;
   constexpr int attr_bit = TE == 4096 ? 2 : 1;          // the LDS limit is a property of (kernel, device): remembered per device
   if (lds_bytes > 65536 && !(c->dev->ntt_attr_mask.load() & attr_bit)) {
-    HIPCHK(hipFuncSetAttribute((const void*)k_ntt_strided<TE, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    HIPCHK(hipFuncSetAttribute((const void*)k_ntt_final<TE, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    HIPCHK(hipFuncSetAttribute((const void*)k_ntt_strided<TE, NT, GM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    HIPCHK(hipFuncSetAttribute((const void*)k_ntt_final<TE, NT, GM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     c->dev->ntt_attr_mask.fetch_or(attr_bit);
   }
   const char* inner = (const char*)t->d_inner; const char* twh = (const char*)t->d_tw_hi; const char* twl = (const char*)t->d_tw_lo;
@@ -286,7 +295,7 @@ static int32_t run_passes(Ctx* c, char* buf, char* tmp, uint32_t lg_n, uint32_t 
   else { s1 = (lg_n + 2) / 3; s2 = (lg_n - s1 + 1) / 2; s3 = lg_n - s1 - s2; }
   auto lgT_for = [](uint32_t lgL, uint32_t lg_limit) { uint32_t lgT = lgTE - lgL; return lgT < lg_limit ? lgT : lg_limit; };
   if (npass == 1) {
-    hipLaunchKernelGGL((k_ntt_final<TE, NT>), dim3(1, batch), dim3(NT), lds_bytes, s, buf, buf, s3, 0u, 0u, 0u, t->lo_bits, inner, csh, csl, pre_coset, post_coset, do_scale, sc);
+    hipLaunchKernelGGL((k_ntt_final<TE, NT, GM>), dim3(1, batch), dim3(NT), lds_bytes, s, buf, buf, s3, 0u, 0u, 0u, t->lo_bits, inner, csh, csl, pre_coset, post_coset, do_scale, sc);
   } else if (npass == 2) {
     uint32_t lgBn = s3, lgT = lgT_for(s1, lgBn);
     const char* direct = nullptr;
@@ -301,16 +310,16 @@ static int32_t run_passes(Ctx* c, char* buf, char* tmp, uint32_t lg_n, uint32_t 
       }
       if (tm->direct_lgBn == lgBn) direct = (const char*)tm->d_direct;      // (always: the split of a two-pass size is (lg_n + 1) / 2 whatever the tile)
     }
-    hipLaunchKernelGGL((k_ntt_strided<TE, NT>), dim3(1u << (lgBn - lgT), batch), dim3(NT), lds_bytes, s, buf, tmp, s1, lgBn, lgT, 1u, lg_n, t->lo_bits, inner, twh, twl, csh, csl, pre_coset, direct);
+    hipLaunchKernelGGL((k_ntt_strided<TE, NT, GM>), dim3(1u << (lgBn - lgT), batch), dim3(NT), lds_bytes, s, buf, tmp, s1, lgBn, lgT, 1u, lg_n, t->lo_bits, inner, twh, twl, csh, csl, pre_coset, direct);
     uint32_t lgTf = lgT_for(s3, s1);
-    hipLaunchKernelGGL((k_ntt_final<TE, NT>), dim3(1u << (s1 - lgTf), batch), dim3(NT), lds_bytes, s, tmp, buf, s3, s1, 0u, lgTf, t->lo_bits, inner, csh, csl, 0, post_coset, do_scale, sc);
+    hipLaunchKernelGGL((k_ntt_final<TE, NT, GM>), dim3(1u << (s1 - lgTf), batch), dim3(NT), lds_bytes, s, tmp, buf, s3, s1, 0u, lgTf, t->lo_bits, inner, csh, csl, 0, post_coset, do_scale, sc);
   } else {
     uint32_t lgBn1 = s2 + s3, lgT1 = lgT_for(s1, lgBn1);
-    hipLaunchKernelGGL((k_ntt_strided<TE, NT>), dim3(1u << (lgBn1 - lgT1), batch), dim3(NT), lds_bytes, s, buf, buf, s1, lgBn1, lgT1, 1u, lg_n, t->lo_bits, inner, twh, twl, csh, csl, pre_coset, (const char*)nullptr);
+    hipLaunchKernelGGL((k_ntt_strided<TE, NT, GM>), dim3(1u << (lgBn1 - lgT1), batch), dim3(NT), lds_bytes, s, buf, buf, s1, lgBn1, lgT1, 1u, lg_n, t->lo_bits, inner, twh, twl, csh, csl, pre_coset, (const char*)nullptr);
     uint32_t lgBn2 = s3, lgT2 = lgT_for(s2, lgBn2);
-    hipLaunchKernelGGL((k_ntt_strided<TE, NT>), dim3((1u << s1) << (lgBn2 - lgT2), batch), dim3(NT), lds_bytes, s, buf, tmp, s2, lgBn2, lgT2, 1u << s1, lg_n, t->lo_bits, inner, twh, twl, csh, csl, 0, (const char*)nullptr);
+    hipLaunchKernelGGL((k_ntt_strided<TE, NT, GM>), dim3((1u << s1) << (lgBn2 - lgT2), batch), dim3(NT), lds_bytes, s, buf, tmp, s2, lgBn2, lgT2, 1u << s1, lg_n, t->lo_bits, inner, twh, twl, csh, csl, 0, (const char*)nullptr);
     uint32_t lgTf = lgT_for(s3, s1);
-    hipLaunchKernelGGL((k_ntt_final<TE, NT>), dim3((1u << s2) << (s1 - lgTf), batch), dim3(NT), lds_bytes, s, tmp, buf, s3, s1, s2, lgTf, t->lo_bits, inner, csh, csl, 0, post_coset, do_scale, sc);
+    hipLaunchKernelGGL((k_ntt_final<TE, NT, GM>), dim3((1u << s2) << (s1 - lgTf), batch), dim3(NT), lds_bytes, s, tmp, buf, s3, s1, s2, lgTf, t->lo_bits, inner, csh, csl, 0, post_coset, do_scale, sc);
   }
   return ALEO_MI355X_OK;
 }
@@ -379,6 +388,10 @@ int32_t ntt_run(Ctx* c, void* d_inout, uint32_t lg_n, size_t batch_total, int32_
   return ALEO_MI355X_OK;
 }
 
+// Calls of at most 2^wide_lg() elements in all (transforms of 2^10 … 2^18 points) take the one-butterfly-per-lane tiles: 2^12 52 -> 22 us, 2^15 64 -> 27 us,
+// 3 x 2^15 67 -> 30 us, 8 x 2^16 85 -> 72 us; from 2^20 elements on the three-stage register groups win again (8 x 2^17: 138 against 142 us)
+// (tools/ntt_small_probe.py, profiles/r02_ntt_small_probe.jsonl).  ALEO_MI355X_NTT_WIDE_LG overrides the cut, 0 = never.
+static uint32_t wide_lg() { static const uint32_t v = [] { const char* e = std::getenv("ALEO_MI355X_NTT_WIDE_LG"); int k = e ? std::atoi(e) : 19; return (uint32_t)(k >= 0 && k <= 24 ? k : 19); }(); return v; }
 static int32_t ntt_run_chunk(Ctx* c, void* d_inout, uint32_t lg_n, uint32_t batch, int32_t order, int32_t direction, int32_t type, hipStream_t s) {
   const size_t n = (size_t)1 << lg_n, bytes = n * 32 * batch;
   int32_t rc;
@@ -404,6 +417,7 @@ static int32_t ntt_run_chunk(Ctx* c, void* d_inout, uint32_t lg_n, uint32_t batc
   else if (force_tile == 4096) rc = run_passes<4096, 512>(c, buf, tmp, lg_n, batch, t, pre_coset, post_coset, do_scale, sc, s);
   else if (force_tile == 512 && lg_n <= 18) rc = run_passes<512, 64>(c, buf, tmp, lg_n, batch, t, pre_coset, post_coset, do_scale, sc, s);
   else if (lg_n >= 20 && lg_n <= 22) rc = run_passes<4096, 512>(c, buf, tmp, lg_n, batch, t, pre_coset, post_coset, do_scale, sc, s);
+  else if (lg_n >= 10 && lg_n <= 18 && ((size_t)batch << lg_n) <= ((size_t)1 << wide_lg())) rc = run_passes<512, 256, 1>(c, buf, tmp, lg_n, batch, t, pre_coset, post_coset, do_scale, sc, s);      // latency form
   else if (lg_n >= 10 && lg_n <= 18 && ((size_t)batch << lg_n) <= ((size_t)1 << 18)) rc = run_passes<512, 64>(c, buf, tmp, lg_n, batch, t, pre_coset, post_coset, do_scale, sc, s);
   else rc = run_passes<2048, 256>(c, buf, tmp, lg_n, batch, t, pre_coset, post_coset, do_scale, sc, s);
   if (rc) return rc;
