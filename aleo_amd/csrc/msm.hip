@@ -579,7 +579,8 @@ constexpr uint32_t lg_lanes(uint32_t lanes) { return lanes == 4 ? 2u : 1u; }
 // lanes per addition for a launch of `ops` independent additions: quads up to two waves per SIMD (2^17 lanes), pairs beyond.  Measured: k_seg_fold 90 -> 57 us,
 // k_tree_pass 15 -> 11 us, a 2^15-constraint proof 6.9 -> 6.6 ms; with the cut at 2^16 lanes the proof is at 6.8 ms.  (The 2^15-chunk kernel of the
 // widest window is the exception: 2^17 quad lanes take what 2^16 pair lanes take, 330 against 321 us — it keeps the pair form.)
-static inline uint32_t grp_lanes(uint64_t ops) { return ops * 4 <= (1u << 17) ? 4u : 2u; }
+static inline bool quads_on() { static const bool v = [] { const char* e = std::getenv("ALEO_MI355X_QUAD_ADD"); return !(e && e[0] == '0'); }(); return v; }      // A/B switch: 0 = lane pairs everywhere
+static inline uint32_t grp_lanes(uint64_t ops) { return quads_on() && ops * 4 <= (1u << 17) ? 4u : 2u; }
 // partial[ft + i] += partial[ft + i + half] inside every multi-slice bucket: one launch per level serves both lists of the scan —
 // the common one (buckets of <= 16 slices, `pairs_a` lane pairs each) and the super-heavy one (`pairs_b` each; skewed scalars).
 template <bool F28, uint32_t LANES = 2>
@@ -1073,7 +1074,8 @@ int32_t msm_run(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, const MsmJob
       // mapped), so the result needs neither a gather launch nor a copy — the stream synchronisation below is all that is left
       char* dst = nullptr;
       HIPCHK(hipHostGetDevicePointer((void**)&dst, h_win, 0));
-      hipLaunchKernelGGL(k_seg_fold<4>, dim3(nseg), dim3(512), 0, s, cur, stride, L, nseg, dst, 1u);
+      if (quads_on()) hipLaunchKernelGGL(k_seg_fold<4>, dim3(nseg), dim3(512), 0, s, cur, stride, L, nseg, dst, 1u);
+      else hipLaunchKernelGGL(k_seg_fold<2>, dim3(nseg), dim3(256), 0, s, cur, stride, L, nseg, dst, 1u);
     } else {
       hipLaunchKernelGGL(k_gather_strided, dim3((nseg * 14 + 255) / 256), dim3(256), 0, s, cur, stride, nseg, Tout);
       HIPCHK(hipMemcpyAsync(h_win, Tout, (size_t)nseg * PB28, hipMemcpyDeviceToHost, s));

@@ -503,7 +503,7 @@ def _varuna_big_once(synth, lg, bits, lagrange):
                 t = time.perf_counter(); nx.prove(zz, 10 + rep); t1.append((time.perf_counter() - t) * 1e3)
             rounds = varuna.native_timing()
             t8 = []
-            for rep in range(3):
+            for rep in range(4):
                 t = time.perf_counter(); data = nx.prove([zz] * 8, 20 + rep); t8.append((time.perf_counter() - t) * 1e3)
             m1, m8 = float(np.median(t1)), float(np.median(t8[1:]))
             if not bits: _BIG_PROOFS.append({'constraints': n, 'vk': nx.vk_bytes, 'public': [int(v) for v in z[:4]], 'proof': nx.prove(zz, 12), 'proof_8': data, 'max_degree': D})      # for the cpu_baseline leg's verifier
