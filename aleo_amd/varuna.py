@@ -289,6 +289,30 @@ def prove_batch_native(indexes, assignments, seed: int) -> bytes:
     return out[:n.value].tobytes()
 
 
+class Trace:
+    """snarkvm_synthesizer_process::Trace as the prover sees it (SURVEY.md §8 row a7; the C++ mirror is `aleo_mi355x::Trace`): the transitions of one
+    transaction, each the proving key (NativeCircuitIndex) of its function and the assignment its execution produced.  prove_execution / prove_fee group
+    the assignments per key in order of first appearance and make ONE proof for all of them — the call under `trace.prove_execution::<A, _>(locator, rng)`
+    at /root/reference/rust/src/program/execute.rs:74."""
+    def __init__(self): self._keys, self._assignments = [], []
+
+    def insert_transition(self, index: 'NativeCircuitIndex', assignment: np.ndarray):
+        for i, k in enumerate(self._keys):
+            if k is index: self._assignments[i].append(assignment); return
+        self._keys.append(index); self._assignments.append([assignment])
+
+    @property
+    def transitions(self) -> int: return sum(len(a) for a in self._assignments)
+
+    def prove_execution(self, seed: int) -> bytes:
+        if not self._keys: raise ValueError('Trace.prove_execution: no transitions')
+        return prove_batch_native(self._keys, self._assignments, seed)
+
+    def prove_fee(self, seed: int) -> bytes:
+        if self.transitions != 1: raise ValueError('Trace.prove_fee: a fee is exactly one transition')
+        return prove_batch_native(self._keys, self._assignments, seed)
+
+
 class _R1csMatrix(ctypes.Structure):
     _fields_ = [('row_ptr', ctypes.c_void_p), ('col', ctypes.c_void_p), ('val', ctypes.c_void_p)]
 

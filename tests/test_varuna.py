@@ -361,6 +361,13 @@ def test_device_prover_batch_over_circuits(shapes, domains):
         with pytest.raises(aleo_amd.UnsatisfiedAssignment): varuna.prove_batch_native(nx, bad, seed)
         assert varuna.prove_batch_native(nx, za, seed) == want
         with pytest.raises(aleo_amd.AleoMi355xError): varuna.prove_batch_native(nx * 5, za * 5, seed)      # more than eight circuits
+        tr = varuna.Trace()                                                             # the Trace mirror groups transitions per key, in order of first appearance
+        order = [(j, i) for i in range(max(len(zz) for zz in za)) for j in range(len(za)) if i < len(za[j])]      # interleaved: circuit 0, 1, 2, 0, 1, ...
+        for j, i in order: tr.insert_transition(nx[j], za[j][i])
+        assert tr.transitions == sum(len(zz) for zz in za) and tr.prove_execution(seed) == want
+        with pytest.raises(ValueError): tr.prove_fee(seed)
+        fee = varuna.Trace(); fee.insert_transition(nx[0], za[0][0])
+        assert fee.prove_fee(seed) == nx[0].prove(za[0][0], seed)
     finally:
         for x in nx: x.close()
         ck.close()
