@@ -435,22 +435,22 @@ def prove_replicas(synth, dist, lg, world, gather_dev, barrier, reps=6):
     2^lg-constraint circuit `reps` times between barriers — no data-path collective; aggregate proofs/s and constraints/s from the slowest rank's time."""
     import torch
     from aleo_amd import varuna
-    dt, n, err = -1.0, 0, None
+    dt, n, err, met = -1.0, 0, None, 0
     try:
         n, csr, z, zz, ck, D = _varuna_instance(synth, lg, 40 + lg)
         try:
             with varuna.NativeCircuitIndex(csr, n, 4, len(z) - 4, ck) as nx:
                 nx.prove(zz, 1); nx.prove(zz, 2)
-                barrier(); t0 = time.perf_counter()
+                barrier(); met = 1; t0 = time.perf_counter()
                 for rep in range(reps): nx.prove(zz, 10 + rep)
-                barrier(); dt = time.perf_counter() - t0
+                barrier(); met = 2; dt = time.perf_counter() - t0
         finally:
             ck.close()
-    except Exception as e:                                  # a rank that failed before its barriers would leave the others waiting: it still meets them here
-        err = repr(e)[:200]
-        if dt < 0:
-            try: barrier(); barrier()
-            except Exception: pass
+    except Exception as e:                                  # a rank that failed would leave the others waiting at a barrier: it still meets the ones it has not reached
+        err = repr(e)[:200]; dt = -1.0
+        try:
+            for _ in range(2 - met): barrier()
+        except Exception: pass
     t = torch.tensor([dt, 1.0 if err is None else 0.0], dtype=torch.float64, device=gather_dev if gather_dev is not None else 'cpu')
     worst = t.clone(); dist.all_reduce(worst, op=dist.ReduceOp.MAX)
     ok = t.clone(); dist.all_reduce(ok, op=dist.ReduceOp.MIN)
