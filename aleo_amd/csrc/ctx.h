@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <map>
 #include <memory>
+#include <functional>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -103,6 +104,10 @@ struct Ctx {                           // one concurrency slot
   // MSM workspaces
   DevBuf hist, scan_local, scan_blk, sorted, part_cnt, part_items, partial, task_g, meta, vbuf, scalars_stage, out_stage;
   void* h_pinned = nullptr; size_t h_pinned_cap = 0;    // pinned host staging for small D2H results
+  // Work the caller wants queued on the stream BEHIND the last kernel of a single-chain msm_batch request and BEFORE the host waits for the result (the wait is
+  // then on an event recorded in between): the GPU runs it while the host does the tail of the MSM.  Consumed (reset) by whoever runs it; a request of several
+  // chains leaves it alone and the caller runs it afterwards (varuna.hip commit()).
+  std::function<int32_t()> tail_hook;
   DevBuf prover_ws; void* prover_pin = nullptr; size_t prover_pin_cap = 0;      // varuna.hip: one proof's device workspace, pinned staging of the assignments
   MsmTiming last_msm;
   DevBuf ntt_tmp, ntt_stage;
@@ -139,7 +144,7 @@ int32_t ensure_host_pinned(Ctx* c, size_t bytes);
 //   sum_i scalar[i] * base[off + i],  i < len    (scalars at the DEVICE pointer d_ptr; the segment array itself is host memory).
 // k > 1 needs a table tier that covers every base reached and k <= msm_max_sets(); msm_batch() groups arbitrary requests accordingly.
 struct MsmSeg { const void* d_ptr = nullptr; size_t len = 0, off = 0; uint32_t out = 0; };
-struct MsmJob { const MsmSeg* segs = nullptr; uint32_t nseg = 0, k = 0; bool mont = false; bool sparse = false; };      // sparse: hint — use the set's range table when every segment lies inside it
+struct MsmJob { const MsmSeg* segs = nullptr; uint32_t nseg = 0, k = 0; bool mont = false; bool sparse = false; bool fire_tail = false; };      // fire_tail: this launch chain is the whole request — run Ctx::tail_hook behind its last kernel      // sparse: hint — use the set's range table when every segment lies inside it
 int32_t msm_run(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, const MsmJob& job, hipStream_t s);
 inline int32_t msm_run1(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, const void* d_scalars, size_t n, bool mont, hipStream_t s, bool sparse = false) {
   MsmSeg g; g.d_ptr = d_scalars; g.len = n;

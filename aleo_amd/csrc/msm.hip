@@ -1081,7 +1081,13 @@ int32_t msm_run(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, const MsmJob
       HIPCHK(hipMemcpyAsync(h_win, Tout, (size_t)nseg * PB28, hipMemcpyDeviceToHost, s));
     }
     HIPCHK(hipEventRecord(c->ev[3], s));
-    HIPCHK(hipStreamSynchronize(s));
+    if (job.fire_tail && c->tail_hook) {
+      // the caller's next kernels go behind the fold; the host waits for the fold only (its result sits in pinned memory) and does the tail below while they run
+      std::function<int32_t()> hook = std::move(c->tail_hook); c->tail_hook = nullptr;
+      const int32_t hrc = hook();
+      HIPCHK(hipEventSynchronize(c->ev[3]));
+      if (hrc) { (void)hipStreamSynchronize(s); return hrc; }
+    } else HIPCHK(hipStreamSynchronize(s));
     HIPCHK(hipGetLastError());
     t_host0 = std::chrono::steady_clock::now();
     HXYZZ totals[MAX_SETS];
@@ -1154,7 +1160,7 @@ int32_t msm_batch(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, const MsmJ
         if (sg > MAX_SEGS) { g_last_error = "msm: one result with more than 64 segments"; return ALEO_MI355X_ERR_BAD_ARG; }
         std::vector<MsmSeg> segs; segs.reserve(sg);
         for (uint32_t q = 0; q < job.nseg; ++q) { const MsmSeg& g = job.segs[q]; if (g.len && g.out >= q0 && g.out < q0 + take) { MsmSeg h = g; h.out = g.out - q0; segs.push_back(h); } }
-        MsmJob g; g.segs = segs.data(); g.nseg = (uint32_t)segs.size(); g.k = take; g.mont = job.mont; g.sparse = true;
+        MsmJob g; g.segs = segs.data(); g.nseg = (uint32_t)segs.size(); g.k = take; g.mont = job.mont; g.sparse = true; g.fire_tail = q0 == 0 && take == K;
         int32_t rc = msm_run(c, out_jac18 + 18 * (size_t)q0, pb, g, s);
         if (rc) return rc;
         q0 += take;
@@ -1174,7 +1180,7 @@ int32_t msm_batch(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, const MsmJ
       if (split) {
         std::vector<MsmSeg> segs; segs.reserve(sg);
         for (uint32_t q = 0; q < job.nseg; ++q) if (job.segs[q].len) segs.push_back(job.segs[q]);
-        MsmJob g; g.segs = segs.data(); g.nseg = (uint32_t)segs.size(); g.k = K; g.mont = job.mont;
+        MsmJob g; g.segs = segs.data(); g.nseg = (uint32_t)segs.size(); g.k = K; g.mont = job.mont; g.fire_tail = true;
         return msm_run(c, out_jac18, pb, g, s);
       }
     }
@@ -1200,7 +1206,7 @@ int32_t msm_batch(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, const MsmJ
         for (size_t i = 0; i < take; ++i) if (local[i] == g.out) { MsmSeg h = g; h.out = (uint32_t)i; segs.push_back(h); break; }
       }
       uint64_t res[MAX_SETS * 18];
-      MsmJob g; g.segs = segs.data(); g.nseg = (uint32_t)segs.size(); g.k = (uint32_t)take; g.mont = job.mont;
+      MsmJob g; g.segs = segs.data(); g.nseg = (uint32_t)segs.size(); g.k = (uint32_t)take; g.mont = job.mont; g.fire_tail = take == K;      // every result of the request in this one chain
       int32_t rc = msm_run(c, res, pb, g, s);
       if (rc) return rc;
       for (size_t i = 0; i < take; ++i) std::memcpy(out_jac18 + 18 * (size_t)todo[pos + i], res + 18 * i, 144);

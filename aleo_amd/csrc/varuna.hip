@@ -13,6 +13,7 @@
 #include "host_field.hpp"
 #include <cstring>
 #include <vector>
+#include <functional>
 #include <utility>
 #include <memory>
 #include <chrono>
@@ -131,11 +132,20 @@ double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::
 thread_local double g_varuna_timing[8] = {};
 
 
-static int32_t commit(Ctx* c, const PinnedBases& pb, const std::vector<MsmSeg>& segs, uint32_t k, uint8_t* out104, hipStream_t s, bool sparse = false) {
+// `behind`: kernels of the NEXT round that need no challenge of this one — queued behind the commitment's last kernel, so that they run while the host finishes
+// the MSM's tail, compresses, hashes and derives the challenge (Ctx::tail_hook; a request that takes several launch chains runs them afterwards instead).
+static int32_t commit(Ctx* c, const PinnedBases& pb, const std::vector<MsmSeg>& segs, uint32_t k, uint8_t* out104, hipStream_t s, bool sparse = false,
+                      std::function<int32_t()> behind = nullptr) {
   std::vector<uint64_t> jac(18 * (size_t)k);
   MsmJob j; j.segs = segs.data(); j.nseg = (uint32_t)segs.size(); j.k = k; j.mont = true; j.sparse = sparse;
   const double t0 = now_ms();
-  RC(msm_batch(c, jac.data(), pb, j, s));
+  c->tail_hook = std::move(behind);
+  {
+    const int32_t rc = msm_batch(c, jac.data(), pb, j, s);
+    std::function<int32_t()> left = std::move(c->tail_hook); c->tail_hook = nullptr;
+    if (rc) return rc;
+    if (left) RC(left());
+  }
   jacobian_rows_to_affine104(out104, jac.data(), k);
   g_varuna_timing[6] += now_ms() - t0; g_varuna_timing[7] += c->last_msm.host;      // time inside the commitment calls / their host tails (last chain of each call)
   return ALEO_MI355X_OK;
@@ -299,7 +309,7 @@ struct Prover {                                            // one circuit of the
   Prover(Shared& sh_, const aleo_mi355x_varuna_index& ix_, size_t j_, size_t k_, size_t q0_) : sh(sh_), ix(ix_), j(j_), k(k_), q0(q0_) {}
   size_t n_h = 0, n_x = 0, L = 0, n4 = 0, nk[3] = {}, ko[3] = {}, k_sum = 0, n_k = 0, x_off = 0, pin_off = 0; uint32_t lg_h = 0, lg_km[3] = {};
   char *xp = nullptr, *wit = nullptr, *ext = nullptr, *hq = nullptr, *rq = nullptr, *f = nullptr, *evals_h = nullptr, *rho_dev = nullptr;
-  char *r4_terms[3] = {}; size_t r4_lens[3] = {};
+  char *r4_terms[3] = {}; size_t r4_lens[3] = {}; char *E = nullptr, *F = nullptr;
   std::vector<std::vector<HFr>> x_poly;
   HFr vh_alpha, vh_beta, vv, sigma[3], delta[3];
   size_t run0[3] = {}, runc[3] = {}, nrun = 0;
@@ -309,8 +319,10 @@ struct Prover {                                            // one circuit of the
   int32_t setup();
   size_t workspace_elems() const { return n_h * (41 + 24 * k) + k_sum * 6 + n_k * 4 + 4096; }
   int32_t first_round(const void* const* assignments, std::vector<MsmSeg>& sg);      // AHPForR1CS::prover_first_round for this circuit's instances
+  int32_t second_round_early();                            // its challenge-free part (operands of the sumcheck on 4|H|): queued behind round 1's commitments
   int32_t second_round();                                  // prover_second_round: t, this circuit's summand of the first sumcheck, its quotient and remainder
   int32_t third_round();                                   // prover_third_round: f_M (sigma_M, g_M follow the read-back)
+  int32_t fourth_round_early();                            // its challenge-free part (f_M on the domains of size 2|K_M|): queued behind round 3's commitments
   int32_t fourth_round();                                  // prover_fourth_round: the quotients h_M of this circuit, delta-weighted, run by run
 };
 
@@ -402,11 +414,18 @@ int32_t Prover::first_round(const void* const* assignments, std::vector<MsmSeg>&
   return ALEO_MI355X_OK;
 }
 
+int32_t Prover::second_round_early() {
+  Ctx* c = sh.c; hipStream_t s = sh.s;
+  TAKE_M(E, (2 + 3 * k) * n4)                                                               // rows 0, 1: r, t (second_round); then ẑ_i, z_a,i, z_b,i per instance
+  RC(ahp_sumcheck_operands(c, E + 2 * n4 * 32, wit, xp, n_h, n_x, k, s));                    // ẑ_i = w_i (X^|X| − 1) + x̂_i, z_a,i, z_b,i — every row written in full
+  return ntt_run(c, E + 2 * n4 * 32, lg_h + 2, 3 * k, 0, 0, 0, s);
+}
+
 int32_t Prover::second_round() {
   Ctx* c = sh.c; hipStream_t s = sh.s; Arena& ar = sh.ar; const HFr &alpha = sh.alpha, &eta_b = sh.eta_b, &eta_c = sh.eta_c;
   vh_alpha = vanish(n_h, alpha);
   if (vh_alpha.is_zero()) { g_last_error = "varuna_prove: alpha landed in H"; return ALEO_MI355X_ERR_HIP; }
-  TAKE_M(ext, 3 * n_h) TAKE(rt, 2 * n_h) TAKE(E, (2 + 3 * k) * n4) TAKE(Q, n4)
+  TAKE_M(ext, 3 * n_h) TAKE(rt, 2 * n_h) TAKE(Q, n4)
   if (lead()) { hq = sh.h1; rq = sh.g1; } else { TAKE_M(hq, 2 * n_h) TAKE_M(rq, n_h) }
   {
     const HFr first = HFr::pow_u64(alpha, n_h - 1), ratio = HFr::inv(alpha);
@@ -421,8 +440,7 @@ int32_t Prover::second_round() {
   HIPCHK(hipMemsetAsync(E, 0, 2 * n4 * 32, s));                                             // r, t: |H| coefficients each, zero padded to 4|H|
   HIPCHK(hipMemcpyAsync(E, rt, n_h * 32, hipMemcpyDeviceToDevice, s));
   HIPCHK(hipMemcpyAsync(E + n4 * 32, rt + n_h * 32, n_h * 32, hipMemcpyDeviceToDevice, s));
-  RC(ahp_sumcheck_operands(c, E + 2 * n4 * 32, wit, xp, n_h, n_x, k, s));                    // ẑ_i = w_i (X^|X| − 1) + x̂_i, z_a,i, z_b,i — every row written in full
-  RC(ntt_run(c, E, lg_h + 2, 2 + 3 * k, 0, 0, 0, s));
+  RC(ntt_run(c, E, lg_h + 2, 2, 0, 0, 0, s));                                               // r, t on 4|H| (the operands of the instances are there already: second_round_early)
   for (size_t i = 0; i < k; ++i) {
     char* e_z = E + (2 + 3 * i) * n4 * 32;
     RC(ahp_first_sumcheck(c, e_z + n4 * 32, n4, E, e_z + n4 * 32, e_z + 2 * n4 * 32, E + n4 * 32, e_z, eta_b.l, eta_c.l, s));
@@ -465,20 +483,26 @@ int32_t Prover::third_round() {
   return ALEO_MI355X_OK;
 }
 
+int32_t Prover::fourth_round_early() {
+  Ctx* c = sh.c; hipStream_t s = sh.s;
+  TAKE_M(F, 2 * k_sum)                                                                        // f_M zero-padded to 2|K_M|, then its values there
+  HIPCHK(hipMemsetAsync(F, 0, 2 * k_sum * 32, s));
+  for (size_t m = 0; m < 3; ++m) HIPCHK(hipMemcpyAsync(F + 2 * ko[m] * 32, f + ko[m] * 32, nk[m] * 32, hipMemcpyDeviceToDevice, s));
+  for (size_t r = 0; r < nrun; ++r) RC(ntt_run(c, F + 2 * ko[run0[r]] * 32, lg_km[run0[r]] + 1, runc[r], 0, 0, 0, s));
+  return ALEO_MI355X_OK;
+}
+
 int32_t Prover::fourth_round() {
   Ctx* c = sh.c; hipStream_t s = sh.s; Arena& ar = sh.ar; const HFr &alpha = sh.alpha, &beta = sh.beta;
-  TAKE(F, 2 * k_sum) TAKE(B, 2 * k_sum)                                                       // per matrix on its own domain of size 2|K_M|
-  HIPCHK(hipMemsetAsync(F, 0, 2 * k_sum * 32, s));
+  TAKE(B, 2 * k_sum)                                                                          // per matrix on its own domain of size 2|K_M| (F: fourth_round_early)
   for (size_t r = 0; r < nrun; ++r) {
-    const size_t m0 = run0[r], cnt = runc[r], n2 = 2 * nk[m0]; char* Fr0 = F + 2 * ko[m0] * 32; char* Br = B + 2 * ko[m0] * 32;
+    const size_t m0 = run0[r], cnt = runc[r], n2 = 2 * nk[m0]; char* Br = B + 2 * ko[m0] * 32;
     HFr consts[7] = {HFr::zero(), HFr::zero(), HFr::zero(), HFr::mul(alpha, beta), HFr::neg(alpha), HFr::neg(beta), vv};
     const void* idx[3] = {nullptr, nullptr, nullptr}; const void* ff[3] = {nullptr, nullptr, nullptr};
     for (size_t t = 0; t < cnt; ++t) {
       const size_t m = m0 + t;
-      HIPCHK(hipMemcpyAsync(F + 2 * ko[m] * 32, f + ko[m] * 32, nk[m] * 32, hipMemcpyDeviceToDevice, s));
       idx[t] = (const char*)ix.k2_evals + 8 * ko[m] * 32; ff[t] = F + 2 * ko[m] * 32; consts[t] = delta[m];
     }
-    RC(ntt_run(c, Fr0, lg_km[m0] + 1, cnt, 0, 0, 0, s));
     RC(ahp_matrix_sumcheck(c, Br, n2, idx, n2, ff, consts, s));                                // sum over the run of delta_M (vv val_M − b_M f_M) = h (X^|K| − 1)
     RC(ntt_run(c, Br, lg_km[m0] + 1, 1, 0, 1, 0, s));
     r4_terms[r] = Br + nk[m0] * 32; r4_lens[r] = nk[m0];                                     // its upper half
@@ -581,8 +605,9 @@ int32_t Batch::first_round(const void* const* assignments) {
     std::vector<MsmSeg>& dst = split ? sm : sg;
     MsmSeg a; a.d_ptr = sh.mask; a.len = 3 * N; a.off = 0; a.out = split ? 0u : (uint32_t)(3 * K); dst.push_back(a);
     MsmSeg b; b.d_ptr = sh.bl + 3 * K * HC * 32; b.len = HC; b.off = sh.gamma_offset; b.out = a.out; dst.push_back(b);
-    if (split) { RC(commit(c, pb, sg, (uint32_t)(3 * K), sh.wit_aff.data(), s, true)); RC(commit(c, pb, sm, 1, sh.wit_aff.data() + 104 * 3 * K, s)); }
-    else RC(commit(c, pb, sg, (uint32_t)(3 * K + 1), sh.wit_aff.data(), s));
+    auto early = [this]() -> int32_t { for (auto& p : P) RC(p->second_round_early()); return ALEO_MI355X_OK; };      // needs no challenge: behind the (last) commitment chain
+    if (split) { RC(commit(c, pb, sg, (uint32_t)(3 * K), sh.wit_aff.data(), s, true)); RC(commit(c, pb, sm, 1, sh.wit_aff.data() + 104 * 3 * K, s, false, early)); }
+    else RC(commit(c, pb, sg, (uint32_t)(3 * K + 1), sh.wit_aff.data(), s, false, early));
   }
   std::vector<uint8_t> c1(48 * (3 * K + 1));
   RC(aleo_mi355x_g1_compress(c1.data(), sh.wit_aff.data(), 3 * K + 1));
@@ -634,7 +659,7 @@ int32_t Batch::third_round() {
       MsmSeg& g = sg[3 * p->j + M]; g.d_ptr = p->f + (p->ko[M] + 1) * 32; g.len = p->nk[M] - 1; g.off = sh.D - (p->nk[M] - 2); g.out = (uint32_t)(3 * p->j + M);
     }
   sh.aff3.assign(312 * m, 0);
-  RC(commit(c, sh.pb, sg, (uint32_t)(3 * m), sh.aff3.data(), s));
+  RC(commit(c, sh.pb, sg, (uint32_t)(3 * m), sh.aff3.data(), s, false, [this]() -> int32_t { for (auto& p : P) RC(p->fourth_round_early()); return ALEO_MI355X_OK; }));
   for (auto& p : P)                                                                           // the sums f_{j,M}(0) |K| were copied out ahead of the commitments: no stream sync of their own
     for (size_t M = 0; M < 3; ++M) { HFr v; std::memcpy(v.l, sh.pin_small + 32 * (3 * p->j + M), 32); p->sigma[M] = HFr::mul(v, fr_u64(p->nk[M])); fr_bytes(&buf[32 * (3 * p->j + M)], p->sigma[M]); }
   RC(aleo_mi355x_g1_compress(&buf[96 * m], sh.aff3.data(), 3 * m));
