@@ -616,3 +616,38 @@ def test_frozen_proofs_with_the_alternative_kernel_paths():
     tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools', 'ab_switch_check.py')
     r = subprocess.run([sys.executable, tool], capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0 and 'SWITCHES OK' in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+@pytest.mark.gpu
+def test_batch_entry_point_refuses_misuse():
+    """aleo_mi355x_varuna_prove_batch_indexed: indexes built against different committer keys, a freed index, zero or nine instances of a circuit, a null
+    assignment pointer and an output buffer that is too small all come back as error codes; the next good call is unaffected."""
+    import ctypes
+    from aleo_amd import varuna
+    L = aleo_amd.lib()
+    cs, csrs, zs, D = _batch_case([(40, 2, 51, 1), (25, 2, 52, 2)])
+    ck, ck2 = varuna.synthetic_committer_key(TAU, S_GAMMA, D), varuna.synthetic_committer_key(TAU, S_GAMMA, D)
+    lim = lambda a: np.stack([synth.int_to_limbs(v, 4) for v in a])
+    try:
+        a = varuna.NativeCircuitIndex(csrs[0], 40, 2, len(zs[0][0]) - 2, ck); b = varuna.NativeCircuitIndex(csrs[1], 25, 2, len(zs[1][0]) - 2, ck)
+        b2 = varuna.NativeCircuitIndex(csrs[1], 25, 2, len(zs[1][0]) - 2, ck2)
+        za = [[lim(z) for z in zz] for zz in zs]
+        good = varuna.prove_batch_native([a, b], za, 3)
+        with pytest.raises(aleo_amd.AleoMi355xError): varuna.prove_batch_native([a, b2], za, 3)          # two committer keys in one proof
+        flat = [z for zz in za for z in zz]
+        def call(handles, counts, ptr_list, cap=4096):
+            h = (ctypes.c_uint64 * len(handles))(*handles); k = (ctypes.c_size_t * len(counts))(*counts); p = (ctypes.c_void_p * len(ptr_list))(*ptr_list)
+            out = np.zeros(max(cap, 8), dtype=np.uint8); n = ctypes.c_size_t(cap)
+            return L.aleo_mi355x_varuna_prove_batch_indexed(h, len(handles), p, k, 3, out.ctypes.data_as(ctypes.c_void_p), ctypes.byref(n)), n.value, out
+        ptrs = [z.ctypes.data for z in flat]
+        rc, n, out = call([a.handle, b.handle], [1, 2], ptrs); assert rc == 0 and out[:n].tobytes() == good
+        assert call([a.handle, b.handle], [0, 2], ptrs)[0] == 2 and call([a.handle, b.handle], [1, 9], ptrs + ptrs + ptrs + ptrs)[0] == 2
+        assert call([a.handle, b.handle], [1, 2], [ptrs[0], None, ptrs[2]])[0] == 2
+        rc, n, _ = call([a.handle, b.handle], [1, 2], ptrs, cap=100); assert rc == 2 and n == len(good)      # too small: the size needed comes back
+        hb = b.handle; b.close()
+        assert call([a.handle, hb], [1, 2], ptrs)[0] == 4                                                    # freed index
+        b = varuna.NativeCircuitIndex(csrs[1], 25, 2, len(zs[1][0]) - 2, ck)
+        assert varuna.prove_batch_native([a, b], za, 3) == good
+        for x in (a, b, b2): x.close()
+    finally:
+        ck.close(); ck2.close()
