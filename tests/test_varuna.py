@@ -651,3 +651,27 @@ def test_batch_entry_point_refuses_misuse():
         for x in (a, b, b2): x.close()
     finally:
         ck.close(); ck2.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('seed', [1, 2, 3, 4, 5, 6])
+def test_device_prover_random_batches(seed):
+    """A seeded sweep over the shape of a proof: 1–4 circuits of 1–400 constraints, 1–6 public inputs, 1–3 instances each, either domain policy —
+    the device proof equals the restatement's and verifies."""
+    import random
+    from aleo_amd import varuna
+    rnd = random.Random(7700 + seed)
+    shapes = [(rnd.choice([1, 2, 5, 17, 33, 64, 100, 129, 255, 400]), rnd.randint(1, 6), 600 + 10 * seed + j, rnd.randint(1, 3)) for j in range(rnd.randint(1, 4))]
+    domains = rnd.choice(['auto', 'per_matrix', 'shared'])
+    cs, csrs, zs, D = _batch_case(shapes, seed=seed, domains=domains)
+    setup = V.Setup(TAU, S_GAMMA, D); idx = [V.Index(c, setup) for c in cs]
+    want = V.prove_batch(list(zip(idx, zs)), setup, V.random_stream(seed, max(c.n_h for c in cs), sum(len(z) for z in zs)))[1]
+    ck = varuna.synthetic_committer_key(TAU, S_GAMMA, D); nx = []
+    try:
+        for (n, npub, _, _), csr, z in zip(shapes, csrs, zs): nx.append(varuna.NativeCircuitIndex(csr, n, npub, len(z[0]) - npub, ck, domains=domains))
+        got = varuna.prove_batch_native(nx, [[np.stack([synth.int_to_limbs(v, 4) for v in z]) for z in zz] for zz in zs], seed)
+        assert got == want, shapes
+        assert V.verify(idx, setup, [[z[:c.n_public] for z in zz] for c, zz in zip(cs, zs)], got)
+    finally:
+        for x in nx: x.close()
+        ck.close()
