@@ -139,8 +139,9 @@ static int32_t commit(Ctx* c, const PinnedBases& pb, const std::vector<MsmSeg>& 
   std::vector<uint64_t> jac(18 * (size_t)k);
   MsmJob j; j.segs = segs.data(); j.nseg = (uint32_t)segs.size(); j.k = k; j.mont = true; j.sparse = sparse;
   const double t0 = now_ms();
-  c->tail_hook = std::move(behind);
   {
+    struct Clear { Ctx* c; ~Clear() { c->tail_hook = nullptr; } } clear{c};      // whatever happens below, no hook (it captures this proof's state) outlives the call
+    c->tail_hook = std::move(behind);
     const int32_t rc = msm_batch(c, jac.data(), pb, j, s);
     std::function<int32_t()> left = std::move(c->tail_hook); c->tail_hook = nullptr;
     if (rc) return rc;
@@ -594,7 +595,7 @@ int32_t Batch::first_round(const void* const* assignments) {
   RC(fr_lin(c, sh.mask, 1, nullptr, sh.neg1.l, sh.mask + N * 32, sh.neg1.l, sh.mask + 2 * N * 32, s));   // sum over H* = |H*| (m_0 + m_|H*| + m_2|H*|) = 0
   std::memcpy(sh.stage + sh.st_blind() * 32, sh.blind.data(), sh.blind.size() * 32);
   HIPCHK(hipMemcpyAsync(sh.bl, sh.stage + sh.st_blind() * 32, sh.blind.size() * 32, hipMemcpyHostToDevice, s));
-  sh.wit_aff.assign(104 * (3 * K + 1), 0); sh.comp.assign(48 * (3 * MAX_CIRCUITS > 8 ? 3 * MAX_CIRCUITS : 8), 0);
+  sh.wit_aff.assign(104 * (3 * K + 1), 0); sh.comp.assign(48 * 8, 0);                                  // scratch for the compressed g_1 | h_1 and h_2
   {
     // with the evaluations against the Lagrange powers AND a narrow-window table over [hiding powers | Lagrange powers | v_H G] the 3K witness
     // commitments are one sparse chain (their scalars are mostly 0 / 1), the mask (uniform coefficients against the monomial powers) another
