@@ -7,6 +7,10 @@
   reference_literals.json  other DATA the reference's tests hold: the `...group` / `...field` decimal literals and the bech32m strings
                         (aleo1 addresses, at1 / as1 / ar1 ids, record1 ciphertexts) in transaction.rs:100, rust/src/test_utils/mod.rs:
                         132-142 and wasm/tests/offchain.rs:106, with their decoding (Edwards-BLS12 y for every group x).  Needs /root/reference.
+  reference_account.json  DATA the reference's tests hold about accounts: the (private key, secret, ciphertext) triple at
+                        wasm/src/account/private_key_ciphertext.rs:115-121 and the (private key, view key, address) triples at
+                        wasm/src/account/private_key.rs:182-184, sdk/tests/data/account-data.ts:8-19 — known answers for Poseidon rates 2, 4 and 8
+                        over Fr (oracle/poseidon.py).  Needs /root/reference.
   msm_small.json        Python big-integer MSM known answers (oracle/pyref.py msm_naive: double-and-add, no windows).
   msm_g2_small.json     the same for G2 over Fq2 (oracle/pyref.py msm_naive_g2).
   ntt_small.json        O(n^2) DFT known answers for fft / ifft / coset_fft / coset_ifft.
@@ -88,6 +92,30 @@ def gen_reference_literals():
                 if hrp in ('aleo', 'at', 'as', 'ar'): e['value'] = str(int.from_bytes(raw, 'little'))
                 out['bech32m'].append(e)
     json.dump(out, open(os.path.join(HERE, 'reference_literals.json'), 'w'), indent=1)
+
+
+def gen_reference_account():
+    ref = '/root/reference'
+    if not os.path.exists(ref):
+        print('skip reference_account.json (no /root/reference)'); return
+    src = open(os.path.join(ref, 'wasm/src/account/private_key_ciphertext.rs')).read().split('\n')
+    lo = next(i for i, l in enumerate(src) if 'fn test_private_key_from_string_decryption_edge_cases' in l)
+    body = '\n'.join(src[lo:lo + 20])
+    out = {'ciphertext_kat': {'source': 'wasm/src/account/private_key_ciphertext.rs:%d-%d' % (lo + 1, lo + 8),
+                              'private_key': re.search(r'APrivateKey1[0-9A-Za-z]+', body).group(0),
+                              'secret': re.search(r'decrypt_to_private_key\("([a-z]+)"\)\.unwrap', body).group(1),
+                              'wrong_secret': re.search(r'decrypt_to_private_key\("([a-z]+)"\)\.is_err', body).group(1),
+                              'ciphertext': re.findall(r'ciphertext1[0-9a-z]+', body)[0],
+                              'bad_ciphertext': re.findall(r'ciphertext1[0-9a-z]+', body)[1]},
+           'accounts': []}
+    t = open(os.path.join(ref, 'wasm/src/account/private_key.rs')).read()
+    out['accounts'].append({'source': 'wasm/src/account/private_key.rs:182-184', 'private_key': re.search(r'ALEO_PRIVATE_KEY: &str = "(\w+)"', t).group(1),
+                            'view_key': re.search(r'ALEO_VIEW_KEY: &str = "(\w+)"', t).group(1), 'address': re.search(r'ALEO_ADDRESS: &str = "(\w+)"', t).group(1)})
+    t = open(os.path.join(ref, 'sdk/tests/data/account-data.ts')).read()
+    g = lambda name: re.search(name + r'\s*=\s*"(\w+)"', t).group(1)
+    out['accounts'].append({'source': 'sdk/tests/data/account-data.ts:12-14', 'private_key': g('privateKeyString'), 'view_key': g('viewKeyString'), 'address': g('addressString')})
+    out['accounts'].append({'source': 'sdk/tests/data/account-data.ts:8,17,19', 'private_key': g('beaconPrivateKeyString'), 'view_key': g('beaconViewKeyString'), 'address': g('beaconAddressString')})
+    json.dump(out, open(os.path.join(HERE, 'reference_account.json'), 'w'), indent=1)
 
 
 def gen_msm():
@@ -192,5 +220,5 @@ def gen_varuna():
 
 
 if __name__ == '__main__':
-    gen_reference_proof(); gen_reference_literals(); gen_msm(); gen_msm_g2(); gen_ntt(); gen_varuna()
+    gen_reference_proof(); gen_reference_literals(); gen_reference_account(); gen_msm(); gen_msm_g2(); gen_ntt(); gen_varuna()
     print('golden fixtures written to', HERE)
