@@ -335,3 +335,81 @@ def derive_account(private_key: str, generator):
     sk_prf = hash_to_scalar(4, [pk_sig[0], pr_sig[0]])
     view = (sk_sig + r_sig + sk_prf) % ED_SUBGROUP_ORDER
     return view_key_string(view), address_string(ed_mul(generator, view))
+
+
+# ----------------------------------------------------------------------------------------------
+# The prover's Fiat-Shamir sponge: PoseidonSponge<Fq, 2, 1> behind the AlgebraicSponge interface
+# (algorithms/src/crypto_hash/poseidon.rs, algorithms/src/traits/algebraic_sponge.rs, utilities nonnative params [UPSTREAM-RECALL];
+#  UNPINNED — the reference holds no transcript value).  Fr elements enter as 5 limbs of 51 bits ("weight-optimised" parameters for a
+#  253-bit field inside a 377-bit one), two limbs packed per Fq element; challenges leave as 252-bit (full) or 168-bit (short) integers
+#  cut from the low 376 bits of squeezed Fq elements, most significant bit first.
+# ----------------------------------------------------------------------------------------------
+Q = P.FQ_MODULUS
+FS_RATE = 2
+FQ_CAPACITY_BITS = P.FQ_BITS - 1          # 376
+SHORT_CHALLENGE_BITS = 168
+FULL_CHALLENGE_BITS = P.FR_BITS - 1       # 252
+
+
+def nonnative_parameters(base_bits: int = P.FQ_BITS, target_bits: int = P.FR_BITS):
+    """find_parameters(base, target, OptimizationType::Weight) -> (num_limbs, bits_per_limb): the limb size of least 'weight'."""
+    surfeit, best = 10, None
+    max_limb = min((base_bits - 1 - surfeit - 1) // 2 - 1, target_bits)
+    for limb in range(1, max_limb + 1):
+        nl = (target_bits + limb - 1) // limb
+        group = (base_bits - 1 - surfeit - 1 - 1 - limb + limb - 1) // limb
+        ng = (2 * nl - 1 + group - 1) // group
+        cost = 6 * nl * nl + 2 * (4 * target_bits) + nl + nl * nl + 2 * (2 * nl - 1) + nl + ng + 6 * ng + (ng - 1) * (2 * limb + surfeit) * 4 + 2
+        if best is None or cost < best[0]: best = (cost, nl, limb)
+    return best[1], best[2]
+
+
+NN_LIMBS, NN_LIMB_BITS = nonnative_parameters()          # (5, 51)
+
+
+class FiatShamir:
+    def __init__(self): self.sp = Sponge(Q, FS_RATE)
+
+    def absorb_native(self, elems): self.sp.absorb(list(elems))
+
+    def absorb_points(self, pts):
+        """Affine G1 points as (x, y) pairs (ToConstraintField of a short-Weierstrass affine point); infinity = (0, 1)."""
+        flat = []
+        for p in pts: flat += [0, 1] if p is None else [p[0], p[1]]
+        self.absorb_native(flat)
+
+    def absorb_bytes(self, data: bytes):
+        """absorb_bytes: the bits of every byte most significant first, cut into chunks of 376 bits, each read as a big-endian integer."""
+        bits = ''.join(format(b, '08b') for b in data)
+        self.absorb_native([int(bits[i:i + FQ_CAPACITY_BITS], 2) for i in range(0, len(bits), FQ_CAPACITY_BITS)])
+
+    def absorb_nonnative(self, frs):
+        """push_elements_to_sponge(…, Weight): limbs most significant first, each tagged with one addition; compress_elements packs two
+        neighbouring limbs into one Fq element as first * 2^(bits of the second) + second when both fit 376 bits."""
+        limbs = []
+        for v in frs:
+            v %= R
+            limbs += [(v >> (NN_LIMB_BITS * i)) & ((1 << NN_LIMB_BITS) - 1) for i in reversed(range(NN_LIMBS))]
+        per = NN_LIMB_BITS + 2                                 # bits_per_limb + overhead(1 + 1) = 53
+        out, i = [], 0
+        while i < len(limbs):
+            if i + 1 < len(limbs) and 2 * per <= FQ_CAPACITY_BITS:
+                out.append((limbs[i] << per) + limbs[i + 1]); i += 2
+            else:
+                out.append(limbs[i]); i += 1
+        self.absorb_native(out)
+
+    def _bits(self, n: int) -> str:
+        """get_bits: squeeze ⌈n / 376⌉ elements, keep the low 376 bits of each (most significant first), truncate."""
+        cnt = (n + FQ_CAPACITY_BITS - 1) // FQ_CAPACITY_BITS
+        s = ''.join(format(e & ((1 << FQ_CAPACITY_BITS) - 1), '0%db' % FQ_CAPACITY_BITS) for e in self.sp.squeeze(cnt))
+        return s[:n]
+
+    def _fe(self, n: int, width: int):
+        if n == 0: return []
+        s = self._bits(n * width)
+        return [int(s[i * width:(i + 1) * width], 2) % R for i in range(n)]
+
+    def squeeze_nonnative(self, n: int): return self._fe(n, FULL_CHALLENGE_BITS)
+    def squeeze_short(self, n: int = 1): return self._fe(n, SHORT_CHALLENGE_BITS)
+    def squeeze_short_one(self) -> int: return self._fe(1, SHORT_CHALLENGE_BITS)[0]

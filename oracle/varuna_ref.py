@@ -12,17 +12,23 @@ is a third-party dependency of the reference (Cargo.lock:2200) and absent from /
     two batched KZG openings (at β with the hiding `random_v`, at γ without) — the 901-byte layout of the `proof1…` string held at
     /root/reference/wasm/src/programs/transaction.rs:100 (decoded in tests/golden/reference_proof.json);
   * SonicKZG10 commitments: hiding polynomials of degree 2 against the γ-powers, degree bounds through shifted powers.
-Deliberate differences, because the corresponding upstream data is not available offline: challenges come from a SHA-256 transcript
-(upstream: a Poseidon sponge over Fq whose parameters are not in /root/reference).  Two verifiers:
+The Fiat-Shamir transcript is upstream's construction: the Poseidon sponge over Fq (rate 2, capacity 1; oracle/poseidon.py FiatShamir) behind
+the AlgebraicSponge interface — protocol name and batch sizes as bytes, public inputs / sums / evaluations as non-native limbs, commitments as their
+affine coordinates, 252-bit challenges for the rounds and one 168-bit challenge per polynomial of an opening — in the order recalled from
+varuna.rs / ahp/verifier [UPSTREAM-RECALL]: the Poseidon primitive itself is pinned by reference-held data over Fr (tests/test_poseidon.py), the
+absorb order and the limb packing are not (no transcript value exists in /root/reference).  The prover's randomness is a ChaCha20 stream under a
+32-byte seed (upstream: `Fr::rand` on the caller's CSPRNG, /root/reference/rust/src/program/execute.rs:74 — its draw order is not reproduced: the
+stream layout is this module's).  The setup is synthetic (known trapdoor), upstream's is the universal SRS.  Two verifiers:
 `verify_pairing` checks the openings as pairing products over public G2 elements (oracle/pairing.py); `verify` is the same check with the pairing
 replaced by the equivalent G1 equation under the synthetic setup's trapdoor (fast; used where many proofs are verified).  **Parity unpinned**: the reference holds no proof this restatement could be compared with value
 for value; what pins it is (i) the verifier below accepting its proofs and rejecting tampered ones, and (ii) the byte layout above."""
 from __future__ import annotations
-import hashlib
+import struct
 from . import pyref as P
+from . import poseidon as PS
 
 R = P.FR_MODULUS
-LABEL = b'aleo-mi355x/varuna-synthetic/v1'
+PROTOCOL_NAME = b'VARUNA-2023'
 HIDING_COEFFS = 3            # hiding bound 1 -> random polynomial of degree 2 [UPSTREAM-RECALL: kzg10 calculate_hiding_polynomial_degree]
 
 
@@ -66,12 +72,22 @@ def h_position(var, n_public, n_x, n_h):
     return j + j // (ratio - 1) + 1
 
 
-class Transcript:
-    def __init__(self): self.state = hashlib.sha256(LABEL).digest()
-    def absorb(self, data: bytes): self.state = hashlib.sha256(self.state + bytes(data)).digest()
-    def challenge(self, label: bytes) -> int:
-        self.state = hashlib.sha256(self.state + label).digest()
-        return int.from_bytes(self.state, 'little') % R
+def fs_start(vk_points, ks, x_evals):
+    """Varuna::init_sponge [UPSTREAM-RECALL]: the protocol name; per circuit its batch size (u64 LE bytes) and the padded public inputs of each of its
+    instances (non-native); then every circuit's index commitments.  vk_points: per circuit the twelve points in vk order; x_evals: per instance."""
+    fs = PS.FiatShamir()
+    fs.absorb_bytes(PROTOCOL_NAME)
+    at = 0
+    for kj in ks:
+        fs.absorb_bytes(int(kj).to_bytes(8, 'little'))
+        for xe in x_evals[at:at + kj]: fs.absorb_nonnative(xe)
+        at += kj
+    for pts in vk_points: fs.absorb_points(pts)
+    return fs
+
+
+def vk_points_of(vk_bytes: bytes):
+    return [P.g1_decompress(vk_bytes[48 * i:48 * i + 48]) for i in range(12)]
 
 
 def fr_bytes(v): return int(v % R).to_bytes(32, 'little')
@@ -187,24 +203,43 @@ class VerifyingKey:
     def vk_bytes(self): return self._bytes
 
 
-_M64 = (1 << 64) - 1
+_M32 = 0xFFFFFFFF
 
 
-def _mix(z):
-    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & _M64; z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & _M64
-    return z ^ (z >> 31)
+def chacha20_block(key: bytes, counter: int, nonce: int) -> bytes:
+    """One 64-byte ChaCha20 block (D. J. Bernstein's original layout: words 12-13 = 64-bit block counter, words 14-15 = 64-bit nonce; with
+    counter = 1 | nonce_word0 << 32 it is RFC 7539's block function, whose §2.3.2 vector tests/test_varuna.py checks)."""
+    assert len(key) == 32
+    st = list(struct.unpack('<4I', b'expand 32-byte k')) + list(struct.unpack('<8I', key)) + [counter & _M32, (counter >> 32) & _M32, nonce & _M32, (nonce >> 32) & _M32]
+    x = st[:]
+    def rot(v, n): return ((v << n) | (v >> (32 - n))) & _M32
+    def qr(a, b, c, d):
+        x[a] = (x[a] + x[b]) & _M32; x[d] = rot(x[d] ^ x[a], 16)
+        x[c] = (x[c] + x[d]) & _M32; x[b] = rot(x[b] ^ x[c], 12)
+        x[a] = (x[a] + x[b]) & _M32; x[d] = rot(x[d] ^ x[a], 8)
+        x[c] = (x[c] + x[d]) & _M32; x[b] = rot(x[b] ^ x[c], 7)
+    for _ in range(10):
+        qr(0, 4, 8, 12); qr(1, 5, 9, 13); qr(2, 6, 10, 14); qr(3, 7, 11, 15)
+        qr(0, 5, 10, 15); qr(1, 6, 11, 12); qr(2, 7, 8, 13); qr(3, 4, 9, 14)
+    return struct.pack('<16I', *[(a + b) & _M32 for a, b in zip(x, st)])
 
 
-def random_fr(seed: int, index: int) -> int:
-    """Element `index` of the proof's random stream: the first candidate j = 0, 1, ... below r, a candidate being the low 253 bits of
-    four SplitMix64 outputs mix(seed + (4 index + l + 1) * 0x9E3779B97F4A7C15 + j * 0xD1B54A32D192ED03), l = 0..3, little-endian."""
-    j = 0
+def seed_bytes(seed) -> bytes:
+    """A proof seed is 32 bytes (the ChaCha20 key); tests pass small integers, read as 32 little-endian bytes."""
+    if isinstance(seed, (bytes, bytearray)): assert len(seed) == 32; return bytes(seed)
+    return int(seed).to_bytes(32, 'little')
+
+
+def random_fr(seed, index: int) -> int:
+    """Element `index` of the proof's random stream: ChaCha20 under key = seed, block counter = index, nonce = attempt 0, 1, …; each block holds
+    two candidates (bytes 0-31, 32-63, little-endian, low 253 bits); the first candidate below r is the element (rejection sampling: uniform)."""
+    key = seed_bytes(seed); attempt = 0
     while True:
-        v = 0
-        for l in range(4): v |= _mix((seed + (4 * index + l + 1) * 0x9E3779B97F4A7C15 + j * 0xD1B54A32D192ED03) & _M64) << (64 * l)
-        v &= (1 << 253) - 1
-        if v < R: return v
-        j += 1
+        blk = chacha20_block(key, index, attempt)
+        for h in (0, 1):
+            v = int.from_bytes(blk[32 * h:32 * h + 32], 'little') & ((1 << 253) - 1)
+            if v < R: return v
+        attempt += 1
 
 
 def randomness_layout(n_h, k=1):
@@ -218,7 +253,7 @@ def randomness_layout(n_h, k=1):
     return o
 
 
-def random_stream(seed: int, n_h: int, k: int = 1) -> list:
+def random_stream(seed, n_h: int, k: int = 1) -> list:
     return [random_fr(seed, i) for i in range(randomness_layout(n_h, k)['total'])]
 
 
@@ -232,17 +267,38 @@ def _axpy(dst, k, src):
     for i, v in enumerate(src): dst[i] = (dst[i] + k * v) % R
 
 
-def _challenges_after_round1(tr, k):
-    alpha, eta_b, eta_c = tr.challenge(b'alpha'), tr.challenge(b'eta_b'), tr.challenge(b'eta_c')
-    comb = [1] + [tr.challenge(b'combiner' + i.to_bytes(4, 'little')) for i in range(1, k)]      # batch combiners of the instances (all circuits, in order)
+def _challenges_after_round1(fs, ks):
+    """verifier_first_round [UPSTREAM-RECALL]: per circuit k_j − 1 instance combiners and — for every circuit but the first — a circuit combiner,
+    one squeeze per circuit; then alpha, eta_b, eta_c in one squeeze.  The combiner of an instance = circuit combiner * instance combiner (1 for
+    the first circuit resp. the first instance of a circuit); returned per instance in proof order."""
+    comb = []
+    for j, kj in enumerate(ks):
+        el = fs.squeeze_nonnative(kj - 1 + (1 if j else 0))
+        cc = el[kj - 1] if j else 1
+        comb += [cc] + [cc * e % R for e in el[:kj - 1]]
+    alpha, eta_b, eta_c = fs.squeeze_nonnative(3)
     return alpha, {'a': 1, 'b': eta_b, 'c': eta_c}, comb
 
 
-def _challenges_after_round3(tr, m):
-    """delta_{j,M}: the first is 1; circuit 0 keeps the single-circuit labels."""
-    delta = [{'a': 1, 'b': tr.challenge(b'delta_b'), 'c': tr.challenge(b'delta_c')}]
-    for j in range(1, m): delta.append({M: tr.challenge(b'delta_' + M.encode() + j.to_bytes(4, 'little')) for M in 'abc'})
-    return delta
+def _challenges_after_round3(fs, m):
+    """delta_{j,M}, circuit after circuit: the first is 1, the other 3m − 1 come from one squeeze."""
+    el = [1] + fs.squeeze_nonnative(3 * m - 1)
+    return [dict(zip('abc', el[3 * j:3 * j + 3])) for j in range(m)]
+
+
+def _matrix_major(per_circuit):
+    """[a_0, b_0, c_0, a_1, …] -> [a_0, a_1, …, b_0, …, c_0, …]: upstream's Commitments / Evaluations hold g_a, g_b, g_c as one vector per matrix
+    [UPSTREAM-RECALL]; with one circuit both orders coincide (the reference's proof string)."""
+    return [per_circuit[3 * j + t] for t in range(3) for j in range(len(per_circuit) // 3)]
+
+
+def _circuit_major(per_matrix):
+    m = len(per_matrix) // 3
+    return [per_matrix[t * m + j] for j in range(m) for t in range(3)]
+
+
+def _serialized_evaluations(evals, k, m):
+    return evals[:k + 1] + _matrix_major(evals[k + 1:])
 
 
 def prove(index: Index, setup: Setup, assignments, rand, vk_bytes=None):
@@ -296,10 +352,10 @@ def prove_batch(items, setup: Setup, rand, vk_bytes=None):
     mask[0] = (-(mask[N] + mask[2 * N])) % R                                      # sum over H* = |H*| (m_0 + m_|H*| + m_2|H*|) = 0
     blind_mask = [v % R for v in rand[lay['blind_mask']:lay['blind_mask'] + HIDING_COEFFS]]
     cb = {'mask': _point_bytes(_commit_scalar(setup, mask, blind=blind_mask))}
-    tr = Transcript(); tr.absorb(b''.join(vk_bytes) if vk_bytes is not None else b''.join(ix.vk_bytes() for ix, _ in items))
-    tr.absorb(b''.join(fr_bytes(v) for d in inst for v in d['x_evals']))
-    tr.absorb(b''.join(d['cb']['w'] + d['cb']['za'] + d['cb']['zb'] for d in inst) + cb['mask'])
-    alpha, eta, comb = _challenges_after_round1(tr, k)
+    vkp = [vk_points_of(v) for v in vk_bytes] if vk_bytes is not None else [[ix.commit_points()[(M, kd)] for M in 'abc' for kd in ('row', 'col', 'val', 'row_col')] for ix, _ in items]
+    fs = fs_start(vkp, ks, [d['x_evals'] for d in inst])
+    fs.absorb_points([P.g1_decompress(d['cb'][p_]) for d in inst for p_ in ('w', 'za', 'zb')] + [P.g1_decompress(cb['mask'])])
+    alpha, eta, comb = _challenges_after_round1(fs, ks)
     eta_b, eta_c = eta['b'], eta['c']
     # ---- second round: first sumcheck --------------------------------------------------------------------------------------
     h1 = [0] * (2 * N); rem_all = [0] * N
@@ -337,8 +393,8 @@ def prove_batch(items, setup: Setup, rand, vk_bytes=None):
         for i in range(N): rem_all[i] = (rem_all[i] + rem[i % n_h]) % R          # X (s_j g_j): the remainder block tiled over H*
     g1 = rem_all[1:]
     cb['g_1'], cb['h_1'] = _point_bytes(_commit_scalar(setup, g1, bound=N - 2)), _point_bytes(_commit_scalar(setup, h1))
-    tr.absorb(cb['g_1'] + cb['h_1'])
-    beta = tr.challenge(b'beta')
+    fs.absorb_points([P.g1_decompress(cb['g_1']), P.g1_decompress(cb['h_1'])])
+    beta = fs.squeeze_nonnative(1)[0]
     # ---- third round: the rational sumchecks over the K_{j,M} --------------------------------------------------------------------
     f, sigma, g, gcb = [], [], [], []
     for j, (index, _) in enumerate(items):
@@ -351,8 +407,9 @@ def prove_batch(items, setup: Setup, rand, vk_bytes=None):
             fj[name] = index.K_m[name].ifft(fe); sj[name] = fj[name][0] * nkm % R; gj[name] = fj[name][1:]
             cj[name] = _point_bytes(_commit_scalar(setup, gj[name], bound=nkm - 2))
         f.append(fj); sigma.append(sj); g.append(gj); gcb.append(cj)
-    tr.absorb(b''.join(fr_bytes(sj[M]) for sj in sigma for M in 'abc') + b''.join(cj[M] for cj in gcb for M in 'abc'))
-    delta = _challenges_after_round3(tr, m)
+    fs.absorb_points([P.g1_decompress(cj[M]) for cj in gcb for M in 'abc'])           # absorb_with_msg: the commitments, then the sums circuit by circuit
+    for sj in sigma: fs.absorb_nonnative([sj['a'], sj['b'], sj['c']])
+    delta = _challenges_after_round3(fs, m)
     # ---- fourth round ------------------------------------------------------------------------------------------------------------
     h2 = [0] * n_k                                                                # h_2 = sum_{j,M} delta_{j,M} (a − b f) / v_{K_{j,M}}, each quotient on its own domain
     for j, (index, _) in enumerate(items):
@@ -370,14 +427,17 @@ def prove_batch(items, setup: Setup, rand, vk_bytes=None):
             assert all((pc[i] + hm[i]) % R == 0 for i in range(nkm)), 'fourth round: not divisible by v_K'
             _axpy(h2, delta[j][name], hm)
     cb['h_2'] = _point_bytes(_commit_scalar(setup, h2))
-    tr.absorb(cb['h_2'])
-    gamma = tr.challenge(b'gamma')
+    fs.absorb_points([P.g1_decompress(cb['h_2'])])
+    gamma = fs.squeeze_nonnative(1)[0]
     # ---- evaluations and the two openings --------------------------------------------------------------------------------------
     zb_beta = [poly_eval(d['zb'], beta) for d in inst]
     g1_beta = poly_eval(g1, beta); g_gamma = [{M: poly_eval(gj[M], gamma) for M in 'abc'} for gj in g]
     evals = zb_beta + [g1_beta] + [gg[M] for gg in g_gamma for M in 'abc']
-    tr.absorb(b''.join(fr_bytes(v) for v in evals))
-    xi = tr.challenge(b'xi')
+    fs.absorb_nonnative(_serialized_evaluations(evals, k, m))
+    # one short challenge per polynomial of an opening [UPSTREAM-RECALL: sonic_pc combine_for_open], the point beta first:
+    # beta: g_1, z_b of every instance, the lincheck combination;  gamma: g_{j,M} circuit by circuit, the matrix combination
+    ch_b = [fs.squeeze_short_one() for _ in range(k + 2)]
+    ch_g = [fs.squeeze_short_one() for _ in range(3 * m + 1)]
     circuits = [ix for ix, _ in items]
     lc1 = lincheck_coefficients(circuits, [d['circuit'] for d in inst], HN, alpha, beta, eta, comb, sigma, zb_beta, g1_beta, [poly_eval(d['x_poly'], beta) for d in inst])
     p_beta = [0] * (3 * N)
@@ -385,16 +445,16 @@ def prove_batch(items, setup: Setup, rand, vk_bytes=None):
     for d, kz, kw in zip(inst, lc1['z_a'], lc1['w']): _axpy(p_beta, kz, d['za']); _axpy(p_beta, kw, d['w'])
     p_beta[0] = (p_beta[0] + lc1['const']) % R
     assert poly_eval(p_beta, beta) == 0, 'lincheck linear combination does not vanish at beta'
-    xl = pow(xi, k + 1, R)                                                        # g_1 + sum_i xi^(1+i) z_b,i + xi^(k+1) LC1
+    xl = ch_b[k + 1]                                                              # ch_0 g_1 + sum_i ch_(1+i) z_b,i + ch_(k+1) LC1
     p_beta = [v * xl % R for v in p_beta]
-    _axpy(p_beta, 1, g1)
-    for i, d in enumerate(inst): _axpy(p_beta, pow(xi, 1 + i, R), d['zb'])
-    v_beta = (g1_beta + sum(pow(xi, 1 + i, R) * v for i, v in enumerate(zb_beta))) % R
+    _axpy(p_beta, ch_b[0], g1)
+    for i, d in enumerate(inst): _axpy(p_beta, ch_b[1 + i], d['zb'])
+    v_beta = (ch_b[0] * g1_beta + sum(ch_b[1 + i] * v for i, v in enumerate(zb_beta))) % R
     w_beta = divide_by_linear(p_beta, beta, v_beta)
     bl = [0] * HIDING_COEFFS
     _axpy(bl, xl * lc1['mask'] % R, blind_mask)
     for i, (d, kz, kw) in enumerate(zip(inst, lc1['z_a'], lc1['w'])):
-        _axpy(bl, pow(xi, 1 + i, R), d['blind']['zb']); _axpy(bl, xl * kz % R, d['blind']['za']); _axpy(bl, xl * kw % R, d['blind']['w'])
+        _axpy(bl, ch_b[1 + i], d['blind']['zb']); _axpy(bl, xl * kz % R, d['blind']['za']); _axpy(bl, xl * kw % R, d['blind']['w'])
     random_v = poly_eval(bl, beta)
     bl_w = divide_by_linear(bl, beta, random_v)
     open_beta = (poly_eval(w_beta, setup.tau) + setup.s_gamma * poly_eval(bl_w, setup.tau)) % R
@@ -404,11 +464,11 @@ def prove_batch(items, setup: Setup, rand, vk_bytes=None):
     _axpy(p_gamma, lc2['h_2'], h2)
     p_gamma[0] = (p_gamma[0] + lc2['const']) % R
     assert poly_eval(p_gamma, gamma) == 0, 'matrix sumcheck linear combination does not vanish at gamma'
-    p_gamma = [v * pow(xi, 3 * m, R) % R for v in p_gamma]                       # sum_{j,M} xi^(3j+M) g_{j,M} + xi^(3m) LC2
+    p_gamma = [v * ch_g[3 * m] % R for v in p_gamma]                              # sum_{j,M} ch_(3j+M) g_{j,M} + ch_(3m) LC2
     v_gamma = 0
     for j in range(m):
         for t, M in enumerate('abc'):
-            _axpy(p_gamma, pow(xi, 3 * j + t, R), g[j][M]); v_gamma = (v_gamma + pow(xi, 3 * j + t, R) * g_gamma[j][M]) % R
+            _axpy(p_gamma, ch_g[3 * j + t], g[j][M]); v_gamma = (v_gamma + ch_g[3 * j + t] * g_gamma[j][M]) % R
     open_gamma = poly_eval(divide_by_linear(p_gamma, gamma, v_gamma), setup.tau)
     proof = {'batch_sizes': ks, 'instances': k, 'witness': [(d['cb']['w'], d['cb']['za'], d['cb']['zb']) for d in inst],
              'commitments': {'mask': cb['mask'], 'g_1': cb['g_1'], 'h_1': cb['h_1'], 'h_2': cb['h_2'], 'g_abc': [cj[M] for cj in gcb for M in 'abc']},
@@ -467,11 +527,14 @@ def matrix_coefficients(circuits, KN, alpha, beta, gamma, delta, sigma, g_gamma)
 
 def proof_bytes(proof) -> bytes:
     """The reference's Proof::to_bytes_le layout (SURVEY.md §8c; 901 bytes for one circuit with one instance): version, the batch sizes, the
-    witness commitments instance after instance, mask, g_1, h_1, g_a/g_b/g_c circuit after circuit, h_2, the evaluations, the sums, the openings."""
+    witness commitments instance after instance, mask, g_1, h_1, every g_a, every g_b, every g_c (one vector per matrix over the circuits), h_2, the
+    evaluations (z_b of every instance, g_1, then every g_a, g_b, g_c likewise), the sums circuit by circuit, the openings.  The dicts keep
+    g_abc / evaluations circuit-major; only the bytes are matrix-major."""
     c = proof['commitments']; u64 = lambda v: int(v).to_bytes(8, 'little'); ks = proof['batch_sizes']
     out = b'\x00' + u64(len(ks)) + b''.join(u64(v) for v in ks) + b''.join(w + a + b for w, a, b in proof['witness'])
-    out += b'\x01' + c['mask'] + c['g_1'] + c['h_1'] + b''.join(c['g_abc']) + c['h_2']
-    out += b''.join(fr_bytes(v) for v in proof['evaluations']) + u64(len(ks)) + b''.join(fr_bytes(v) for v in proof['sums']) + u64(len(proof['openings']))
+    k = sum(ks)
+    out += b'\x01' + c['mask'] + c['g_1'] + c['h_1'] + b''.join(_matrix_major(c['g_abc'])) + c['h_2']
+    out += b''.join(fr_bytes(v) for v in _serialized_evaluations(proof['evaluations'], k, len(ks))) + u64(len(ks)) + b''.join(fr_bytes(v) for v in proof['sums']) + u64(len(proof['openings']))
     for pt, rv in proof['openings']:
         out += pt + (b'\x01' + fr_bytes(rv) if rv is not None else b'\x00')
     return out + b'\x00'                                                        # BatchLCProof.evaluations: None
@@ -489,9 +552,9 @@ def parse_proof(data: bytes):
     witness = [(pt(), pt(), pt()) for _ in range(k)]
     assert data[pos] == 1; pos += 1
     for name in ('mask', 'g_1', 'h_1'): c[name] = pt()
-    c['g_abc'] = [pt() for _ in range(3 * m)]; c['h_2'] = pt()
+    c['g_abc'] = _circuit_major([pt() for _ in range(3 * m)]); c['h_2'] = pt()
     if m == 1: c['g_a'], c['g_b'], c['g_c'] = c['g_abc']
-    evals = [fr() for _ in range(k + 1 + 3 * m)]
+    evals = [fr() for _ in range(k + 1 + 3 * m)]; evals = evals[:k + 1] + _circuit_major(evals[k + 1:])
     assert int.from_bytes(data[pos:pos + 8], 'little') == m; pos += 8
     sums = [fr() for _ in range(3 * m)]
     n_open = int.from_bytes(data[pos:pos + 8], 'little'); pos += 8
@@ -530,38 +593,40 @@ def _verifier_state(index, public_inputs, data: bytes, vk_bytes=None):
     x_evals = [[pub[i] % R if i < circuits[j].circuit.n_public else 0 for i in range(circuits[j].circuit.n_x)] for j, pubs in enumerate(publics) for pub in pubs]
     N = max(ix.circuit.n_h for ix in circuits); n_k = max(ix.circuit.n_k for ix in circuits)
     HN, KN = Domain(N), Domain(n_k)
-    tr = Transcript(); tr.absorb(b''.join(vk_bytes) if vk_bytes is not None else b''.join(ix.vk_bytes() for ix in circuits))
-    tr.absorb(b''.join(fr_bytes(v) for xe in x_evals for v in xe))
-    tr.absorb(b''.join(w + a + b for w, a, b in pr['witness']) + cbs['mask'])
-    alpha, eta, comb = _challenges_after_round1(tr, k)
-    tr.absorb(cbs['g_1'] + cbs['h_1']); beta = tr.challenge(b'beta')
+    vkp = [vk_points_of(v) for v in vk_bytes] if vk_bytes is not None else [[ix.commit_points()[(M, kd)] for M in 'abc' for kd in ('row', 'col', 'val', 'row_col')] for ix in circuits]
+    fs = fs_start(vkp, ks, x_evals)
+    fs.absorb_points([p_ for t in wit for p_ in t] + [pts['mask']])
+    alpha, eta, comb = _challenges_after_round1(fs, ks)
+    fs.absorb_points([pts['g_1'], pts['h_1']]); beta = fs.squeeze_nonnative(1)[0]
     sigma = [dict(zip('abc', pr['sums'][3 * j:3 * j + 3])) for j in range(m)]
-    tr.absorb(b''.join(fr_bytes(v) for v in pr['sums']) + b''.join(cbs['g_abc']))
-    delta = _challenges_after_round3(tr, m)
-    tr.absorb(cbs['h_2']); gamma = tr.challenge(b'gamma')
+    fs.absorb_points(pts['g_abc'])
+    for sj in sigma: fs.absorb_nonnative([sj['a'], sj['b'], sj['c']])
+    delta = _challenges_after_round3(fs, m)
+    fs.absorb_points([pts['h_2']]); gamma = fs.squeeze_nonnative(1)[0]
     evals = pr['evaluations']
-    tr.absorb(b''.join(fr_bytes(v) for v in evals)); xi = tr.challenge(b'xi')
+    fs.absorb_nonnative(_serialized_evaluations(evals, k, m))
+    ch_b = [fs.squeeze_short_one() for _ in range(k + 2)]; ch_g = [fs.squeeze_short_one() for _ in range(3 * m + 1)]
     zb_beta = evals[:k]; g1_beta = evals[k]; g_gamma = [dict(zip('abc', evals[k + 1 + 3 * j:k + 4 + 3 * j])) for j in range(m)]
     x_beta = [poly_eval(circuits[j].X.ifft(xe), beta) for j, xe in zip(inst_circuit, x_evals)]
-    return {'k': k, 'm': m, 'circuits': circuits, 'n_h': N, 'pts': pts, 'opn': opn, 'wit': wit, 'beta': beta, 'gamma': gamma, 'xi': xi, 'random_v': pr['openings'][0][1],
+    return {'k': k, 'm': m, 'circuits': circuits, 'n_h': N, 'pts': pts, 'opn': opn, 'wit': wit, 'beta': beta, 'gamma': gamma, 'ch_b': ch_b, 'ch_g': ch_g, 'random_v': pr['openings'][0][1],
             'lc1': lincheck_coefficients(circuits, inst_circuit, HN, alpha, beta, eta, comb, sigma, zb_beta, g1_beta, x_beta),
             'lc2': matrix_coefficients(circuits, KN, alpha, beta, gamma, delta, sigma, g_gamma),
-            'v_beta': (g1_beta + sum(pow(xi, 1 + i, R) * v for i, v in enumerate(zb_beta))) % R,
-            'v_gamma': sum(pow(xi, 3 * j + t, R) * g_gamma[j][M] for j in range(m) for t, M in enumerate('abc')) % R}
+            'v_beta': (ch_b[0] * g1_beta + sum(ch_b[1 + i] * v for i, v in enumerate(zb_beta))) % R,
+            'v_gamma': sum(ch_g[3 * j + t] * g_gamma[j][M] for j in range(m) for t, M in enumerate('abc')) % R}
 
 
 def _unshifted_parts(st):
-    """The G1 sides of the two checks that carry no degree shift: sum_i xi^(1+i) z_b,i + xi^(k+1) LC1  and  xi^(3m) LC2."""
+    """The G1 sides of the two checks that carry no degree shift: sum_i ch_(1+i) z_b,i + ch_(k+1) LC1  and  ch'_(3m) LC2."""
     G = P.G1_GENERATOR; mul, add = P.g1_mul, P.g1_add
-    pts, wit, lc1, lc2, xi, k = st['pts'], st['wit'], st['lc1'], st['lc2'], st['xi'], st['k']
+    pts, wit, lc1, lc2, ch_b, ch_g, k = st['pts'], st['wit'], st['lc1'], st['lc2'], st['ch_b'], st['ch_g'], st['k']
     C1 = add(add(mul(pts['mask'], lc1['mask']), mul(pts['h_1'], lc1['h_1'])), mul(G, lc1['const']))
     for (w_, a_, b_), kz, kw in zip(wit, lc1['z_a'], lc1['w']): C1 = add(C1, add(mul(a_, kz), mul(w_, kw)))
-    Rb = mul(C1, pow(xi, k + 1, R))
-    for i, (w_, a_, b_) in enumerate(wit): Rb = add(Rb, mul(b_, pow(xi, 1 + i, R)))
+    Rb = mul(C1, ch_b[k + 1])
+    for i, (w_, a_, b_) in enumerate(wit): Rb = add(Rb, mul(b_, ch_b[1 + i]))
     C2 = add(mul(G, lc2['const']), mul(pts['h_2'], lc2['h_2']))
     index_points = [ix.commit_points() for ix in st['circuits']]
     for (j, M, kind), coef in lc2['index'].items(): C2 = add(C2, mul(index_points[j][(M, kind)], coef))
-    return Rb, mul(C2, pow(xi, 3 * st['m'], R))
+    return Rb, mul(C2, ch_g[3 * st['m']])
 
 
 def verify_pairing(index, vk, public_inputs, data: bytes, vk_bytes=None) -> bool:
@@ -573,16 +638,16 @@ def verify_pairing(index, vk, public_inputs, data: bytes, vk_bytes=None) -> bool
     st = _verifier_state(index, public_inputs, data, vk_bytes)
     if st is None: return False
     G = P.G1_GENERATOR; mul, add, neg = P.g1_mul, P.g1_add, P.g1_neg
-    pts, xi = st['pts'], st['xi']
+    pts, ch_b, ch_g = st['pts'], st['ch_b'], st['ch_g']
     Rb, Rg = _unshifted_parts(st)
     Rb = add(Rb, neg(add(mul(G, st['v_beta']), mul(vk['gamma_g'], st['random_v']))))
     Rg = add(Rg, neg(mul(G, st['v_gamma'])))
     zh = lambda z: P.g2_add(vk['tau_h'], P.g2_neg(P.g2_mul(vk['h'], z)))
-    if not E.pairing_product_is_one([(pts['g_1'], vk['neg_h']), (Rb, vk['h']), (neg(st['opn'][0]), zh(st['beta']))]): return False
-    shifted = {}                                                                  # sum xi^(3j+M) g_{j,M}, grouped by the shift of their degree bound
+    if not E.pairing_product_is_one([(mul(pts['g_1'], ch_b[0]), vk['neg_h']), (Rb, vk['h']), (neg(st['opn'][0]), zh(st['beta']))]): return False
+    shifted = {}                                                                  # sum ch'_(3j+M) g_{j,M}, grouped by the shift of their degree bound
     for j, ix in enumerate(st['circuits']):
         for t, M in enumerate('abc'):
-            key = ix.circuit.n_k_m[M]; term = mul(pts['g_abc'][3 * j + t], pow(xi, 3 * j + t, R))
+            key = ix.circuit.n_k_m[M]; term = mul(pts['g_abc'][3 * j + t], ch_g[3 * j + t])
             shifted[key] = (add(shifted[key][0], term), shifted[key][1]) if key in shifted else (term, vk['neg_k_by_size'][key])
     return E.pairing_product_is_one(list(shifted.values()) + [(Rg, vk['h']), (neg(st['opn'][1]), zh(st['gamma']))])
 
@@ -593,14 +658,14 @@ def verify(index, setup: Setup, public_inputs, data: bytes, vk_bytes=None) -> bo
     st = _verifier_state(index, public_inputs, data, vk_bytes)
     if st is None: return False
     G = P.G1_GENERATOR; mul, add, neg = P.g1_mul, P.g1_add, P.g1_neg
-    pts, xi = st['pts'], st['xi']
+    pts, ch_b, ch_g = st['pts'], st['ch_b'], st['ch_g']
     tau_inv = inv(setup.tau); D = setup.max_degree
     def unshift(pt, bound): return mul(pt, pow(tau_inv, D - bound, R))
     Rb, Rg = _unshifted_parts(st)
-    lhs = add(add(unshift(pts['g_1'], st['n_h'] - 2), Rb), neg(mul(G, (st['v_beta'] + setup.s_gamma * st['random_v']) % R)))
+    lhs = add(add(mul(unshift(pts['g_1'], st['n_h'] - 2), ch_b[0]), Rb), neg(mul(G, (st['v_beta'] + setup.s_gamma * st['random_v']) % R)))
     if lhs != mul(st['opn'][0], (setup.tau - st['beta']) % R): return False
     Sg = None
     for j, ix in enumerate(st['circuits']):
-        for t, M in enumerate('abc'): Sg = add(Sg, mul(unshift(pts['g_abc'][3 * j + t], ix.circuit.n_k_m[M] - 2), pow(xi, 3 * j + t, R)))
+        for t, M in enumerate('abc'): Sg = add(Sg, mul(unshift(pts['g_abc'][3 * j + t], ix.circuit.n_k_m[M] - 2), ch_g[3 * j + t]))
     lhs = add(add(Sg, Rg), neg(mul(G, st['v_gamma'])))
     return lhs == mul(st['opn'][1], (setup.tau - st['gamma']) % R)
