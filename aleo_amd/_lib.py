@@ -18,6 +18,8 @@ EXPORTS = [
     'aleo_mi355x_version',
     'aleo_mi355x_g1_compress', 'aleo_mi355x_g1_decompress', 'aleo_mi355x_fr_to_bytes', 'aleo_mi355x_fr_from_bytes',
     'aleo_mi355x_bech32m_encode', 'aleo_mi355x_bech32m_decode', 'aleo_mi355x_proof_to_bytes',
+    'aleo_mi355x_poseidon_hash_fr', 'aleo_mi355x_fs_new', 'aleo_mi355x_fs_free', 'aleo_mi355x_fs_absorb_bytes', 'aleo_mi355x_fs_absorb_g1',
+    'aleo_mi355x_fs_absorb_fr', 'aleo_mi355x_fs_squeeze_fr', 'aleo_mi355x_fr_random',
 ]
 
 
@@ -63,15 +65,23 @@ def lib():
         'aleo_mi355x_kzg_commit_segments_sparse_device': ([vp, sz, u64, vp, sz, vp], i32),
         'aleo_mi355x_fr_blind_rows_device': ([vp, vp, sz, sz, vp, vp], i32),
         'aleo_mi355x_ahp_sumcheck_operands_device': ([vp, vp, vp, sz, sz, sz, vp], i32),
-        'aleo_mi355x_varuna_prove': ([vp, ctypes.POINTER(vp), sz, u64, vp, ctypes.POINTER(sz)], i32),
+        'aleo_mi355x_varuna_prove': ([vp, ctypes.POINTER(vp), sz, vp, vp, ctypes.POINTER(sz)], i32),
         'aleo_mi355x_varuna_index_build': ([ctypes.POINTER(u64), u64, u64, u64, u64, vp, sz, sz, sz, ctypes.c_uint32], i32),
         'aleo_mi355x_varuna_index_export': ([u64, vp], i32),
         'aleo_mi355x_varuna_index_vk': ([u64, vp, ctypes.POINTER(sz)], i32),
         'aleo_mi355x_varuna_index_free': ([u64], i32),
-        'aleo_mi355x_varuna_prove_indexed': ([u64, ctypes.POINTER(vp), sz, u64, vp, ctypes.POINTER(sz)], i32),
-        'aleo_mi355x_varuna_prove_batch_indexed': ([ctypes.POINTER(u64), sz, ctypes.POINTER(vp), ctypes.POINTER(sz), u64, vp, ctypes.POINTER(sz)], i32),
+        'aleo_mi355x_varuna_prove_indexed': ([u64, ctypes.POINTER(vp), sz, vp, vp, ctypes.POINTER(sz)], i32),
+        'aleo_mi355x_varuna_prove_batch_indexed': ([ctypes.POINTER(u64), sz, ctypes.POINTER(vp), ctypes.POINTER(sz), vp, vp, ctypes.POINTER(sz)], i32),
         'aleo_mi355x_varuna_last_timing': ([ctypes.POINTER(ctypes.c_double), i32], i32),
-        'aleo_mi355x_fr_random_device': ([vp, sz, u64, u64, i32, vp], i32),
+        'aleo_mi355x_fr_random_device': ([vp, sz, vp, u64, i32, vp], i32),
+        'aleo_mi355x_fr_random': ([vp, sz, vp, u64], i32),
+        'aleo_mi355x_poseidon_hash_fr': ([u32, vp, sz, vp, sz], i32),
+        'aleo_mi355x_fs_new': ([ctypes.POINTER(u64)], i32),
+        'aleo_mi355x_fs_free': ([u64], i32),
+        'aleo_mi355x_fs_absorb_bytes': ([u64, vp, sz], i32),
+        'aleo_mi355x_fs_absorb_g1': ([u64, vp, sz, sz], i32),
+        'aleo_mi355x_fs_absorb_fr': ([u64, vp, sz], i32),
+        'aleo_mi355x_fs_squeeze_fr': ([u64, vp, sz, i32], i32),
         'aleo_mi355x_fr_lincomb_device': ([vp, sz, vp, ctypes.POINTER(vp), ctypes.POINTER(sz), vp, sz, vp], i32),
         'aleo_mi355x_ahp_first_sumcheck_device': ([vp, sz, vp, vp, vp, vp, vp, vp, vp, vp], i32),
         'aleo_mi355x_ahp_matrix_sumcheck_device': ([vp, sz, ctypes.POINTER(vp), sz, ctypes.POINTER(vp), vp, vp], i32),
@@ -131,3 +141,14 @@ def check(status: int, what: str):
             f'{what}: {L.aleo_mi355x_strerror(status).decode()} [{L.aleo_mi355x_last_error().decode()}]')
         e.status = status
         raise e
+
+
+def seed32(seed=None):
+    """A proof's 32-byte seed as a ctypes buffer.  None draws 32 bytes from the OS (what callers should do: a repeated seed repeats the blinding);
+    bytes are taken as they are; an int (tests, benchmarks: reproducible proofs) is read as 32 little-endian bytes."""
+    if seed is None: raw = os.urandom(32)
+    elif isinstance(seed, (bytes, bytearray)):
+        if len(seed) != 32: raise ValueError('a proof seed is 32 bytes')
+        raw = bytes(seed)
+    else: raw = int(seed).to_bytes(32, 'little')
+    return (ctypes.c_uint8 * 32).from_buffer_copy(raw)

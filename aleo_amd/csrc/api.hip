@@ -647,9 +647,9 @@ int32_t aleo_mi355x_fr_eval_batch_device(void* d_out, const void* const* d_polys
   } catch (...) { return ALEO_MI355X_ERR_HIP; }
 }
 
-int32_t aleo_mi355x_varuna_prove(const aleo_mi355x_varuna_index* index, const void* const* assignments, size_t n_instances, uint64_t seed, void* out_proof, size_t* len) {
+int32_t aleo_mi355x_varuna_prove(const aleo_mi355x_varuna_index* index, const void* const* assignments, size_t n_instances, const uint8_t* seed, void* out_proof, size_t* len) {
   try {
-    if (!index || !assignments || !out_proof || !len || !index->positions || !index->vk_bytes) { g_last_error = "varuna_prove: null argument"; return ALEO_MI355X_ERR_BAD_ARG; }
+    if (!index || !assignments || !out_proof || !len || !seed || !index->positions || !index->vk_bytes) { g_last_error = "varuna_prove: null argument"; return ALEO_MI355X_ERR_BAD_ARG; }
     for (size_t i = 0; i < n_instances && i < 8; ++i) if (!assignments[i]) { g_last_error = "varuna_prove: null assignment"; return ALEO_MI355X_ERR_BAD_ARG; }
     API_BEGIN
     FIND_BASES(index->committer_key)
@@ -714,9 +714,9 @@ int32_t aleo_mi355x_varuna_index_free(uint64_t index_handle) {
   } catch (...) { return ALEO_MI355X_ERR_HIP; }
 }
 
-int32_t aleo_mi355x_varuna_prove_indexed(uint64_t index_handle, const void* const* assignments, size_t n_instances, uint64_t seed, void* out_proof, size_t* len) {
+int32_t aleo_mi355x_varuna_prove_indexed(uint64_t index_handle, const void* const* assignments, size_t n_instances, const uint8_t* seed, void* out_proof, size_t* len) {
   try {
-    if (!assignments || !out_proof || !len) return ALEO_MI355X_ERR_BAD_ARG;
+    if (!assignments || !out_proof || !len || !seed) return ALEO_MI355X_ERR_BAD_ARG;
     for (size_t i = 0; i < n_instances && i < 8; ++i) if (!assignments[i]) { g_last_error = "varuna_prove: null assignment"; return ALEO_MI355X_ERR_BAD_ARG; }
     API_BEGIN
     std::shared_ptr<VarunaIndexOwner> ixk; { int32_t rci = find_varuna(d, index_handle, &ixk); if (rci) return rci; }
@@ -726,10 +726,10 @@ int32_t aleo_mi355x_varuna_prove_indexed(uint64_t index_handle, const void* cons
   } catch (...) { return ALEO_MI355X_ERR_HIP; }
 }
 
-int32_t aleo_mi355x_varuna_prove_batch_indexed(const uint64_t* index_handles, size_t n_circuits, const void* const* assignments, const size_t* n_instances, uint64_t seed,
+int32_t aleo_mi355x_varuna_prove_batch_indexed(const uint64_t* index_handles, size_t n_circuits, const void* const* assignments, const size_t* n_instances, const uint8_t* seed,
                                                void* out_proof, size_t* len) {
   try {
-    if (!index_handles || !assignments || !n_instances || !out_proof || !len || n_circuits < 1 || n_circuits > 8) { g_last_error = "varuna_prove_batch: null argument or circuit count outside 1..8"; return ALEO_MI355X_ERR_BAD_ARG; }
+    if (!seed || !index_handles || !assignments || !n_instances || !out_proof || !len || n_circuits < 1 || n_circuits > 8) { g_last_error = "varuna_prove_batch: null argument or circuit count outside 1..8"; return ALEO_MI355X_ERR_BAD_ARG; }
     size_t total = 0;
     for (size_t j = 0; j < n_circuits; ++j) { if (n_instances[j] < 1 || n_instances[j] > 8) { g_last_error = "varuna_prove_batch: 1..8 instances per circuit"; return ALEO_MI355X_ERR_BAD_ARG; } total += n_instances[j]; }
     for (size_t i = 0; i < total; ++i) if (!assignments[i]) { g_last_error = "varuna_prove_batch: null assignment"; return ALEO_MI355X_ERR_BAD_ARG; }
@@ -747,9 +747,9 @@ int32_t aleo_mi355x_varuna_last_timing(double* out_ms, int32_t cap) {
   return n;
 }
 
-int32_t aleo_mi355x_fr_random_device(void* d_dst, size_t n, uint64_t seed, uint64_t first_index, int32_t montgomery, void* stream) {
+int32_t aleo_mi355x_fr_random_device(void* d_dst, size_t n, const uint8_t* seed, uint64_t first_index, int32_t montgomery, void* stream) {
   try {
-    if (!d_dst && n) return ALEO_MI355X_ERR_BAD_ARG;
+    if ((!d_dst && n) || !seed) return ALEO_MI355X_ERR_BAD_ARG;
     API_BEGIN
     return run_enqueue(c, stream, [&](hipStream_t s) { return fr_random(c, d_dst, n, seed, first_index, montgomery, s); });
   } catch (...) { return ALEO_MI355X_ERR_HIP; }

@@ -8,7 +8,7 @@ python3 "$here/../../tools/gen_fp28_asm.py" "$here/fp28_mont_gen.h"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Wno-unused-variable ${ALEO_MI355X_CXXFLAGS:-}"
 objs=(); pids=()
-for f in api msm ntt frops wire g2 varuna; do
+for f in api msm ntt frops wire g2 varuna sponge; do
   rm -f "$out/$f.o"                      # a failed compile must not link a stale object
   "$HIPCC" $FLAGS -c "$here/$f.hip" -o "$out/$f.o" &
   pids+=("$!"); objs+=("$out/$f.o")

@@ -169,22 +169,22 @@ int32_t fr_lin(Ctx* c, void* d_dst, size_t n, const void* c0, const void* c1, co
 int32_t fr_powers(Ctx* c, void* d_dst, size_t n, const void* first, const void* ratio, hipStream_t s);
 int32_t fr_gather_mul(Ctx* c, void* d_dst, size_t n, const void* d_scale, const void* d_t1, const void* d_idx1, const void* d_t2, const void* d_idx2, hipStream_t s);
 int32_t fr_eval_batch(Ctx* c, void* d_out, const void* const* d_polys, const size_t* lens, const void* z_mont, size_t k, hipStream_t s);
-int32_t fr_random(Ctx* c, void* d_dst, size_t n, uint64_t seed, uint64_t first, int32_t mont, hipStream_t s);
+int32_t fr_random(Ctx* c, void* d_dst, size_t n, const uint8_t* seed32, uint64_t first, int32_t mont, hipStream_t s);
 int32_t fr_lincomb(Ctx* c, void* d_dst, size_t n, const void* c0, const void* const* d_terms, const size_t* lens, const void* coeffs, size_t k, hipStream_t s);
 int32_t fr_add_tiled(Ctx* c, void* d_dst, size_t n, const void* d_src, size_t n_src, hipStream_t s);
 int32_t ahp_first_sumcheck(Ctx* c, void* d_dst, size_t n, const void* d_r, const void* d_a, const void* d_b, const void* d_t, const void* d_z, const void* eta_b, const void* eta_c, hipStream_t s);
 int32_t ahp_matrix_sumcheck(Ctx* c, void* d_dst, size_t n, const void* const* d_index, size_t index_stride_elems, const void* const* d_f, const void* consts, hipStream_t s);
 int32_t fr_blind_rows(Ctx* c, void* d_dst, const void* d_src, size_t n, size_t rows, const void* rho_mont, hipStream_t s);
 int32_t ahp_sumcheck_operands(Ctx* c, void* d_dst, const void* d_wit, const void* d_xp, size_t n, size_t n_x, size_t instances, hipStream_t s);
-int32_t fr_scatter_to_mont(Ctx* c, void* d_dst, const void* d_src, const void* d_pos, size_t n, hipStream_t s);
+int32_t fr_scatter_to_mont(Ctx* c, void* d_dst, const void* d_src, const void* d_pos, size_t n, void* d_flag, hipStream_t s);
 int32_t fr_vec_op(Ctx* c, void* d_dst, const void* d_a, const void* d_b, size_t n, int32_t op, hipStream_t s);
 int32_t fr_batch_inverse(Ctx* c, void* d_inout, size_t n, hipStream_t s);
 int32_t fr_divide_by_linear(Ctx* c, void* d_q, void* d_eval, const void* d_p, size_t n, const void* z_mont32, hipStream_t s);
 int32_t fr_spmv(Ctx* c, void* d_y, const void* d_row_ptr, const void* d_col, const void* d_vals, const void* d_x, size_t rows, hipStream_t s);
 // varuna.hip / api.hip
-int32_t varuna_prove(Ctx* c, const PinnedBases& pb, const aleo_mi355x_varuna_index& ix, const void* const* assignments, size_t k, uint64_t seed, uint8_t* out, size_t* out_len);
+int32_t varuna_prove(Ctx* c, const PinnedBases& pb, const aleo_mi355x_varuna_index& ix, const void* const* assignments, size_t k, const uint8_t* seed32, uint8_t* out, size_t* out_len);
 int32_t varuna_prove_batch(Ctx* c, const PinnedBases& pb, const aleo_mi355x_varuna_index* const* ixs, size_t m, const void* const* assignments, const size_t* ks,
-                           uint64_t seed, uint8_t* out, size_t* out_len);
+                           const uint8_t* seed32, uint8_t* out, size_t* out_len);
 extern thread_local double g_varuna_timing[8];
 struct VarunaIndexOwner;
 int32_t varuna_index_build(Ctx* c, const PinnedBases& pb, std::shared_ptr<PinnedOwner> key, uint64_t key_handle, uint64_t max_degree, uint64_t gamma_offset,

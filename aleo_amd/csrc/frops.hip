@@ -13,6 +13,7 @@
 // (a^(r-2), ~380 products) over its K elements: 3 + 380/K products per element.
 #include "ctx.h"
 #include "fp.h"
+#include "chacha.h"
 #include <cstring>
 
 namespace aleo_mi355x {
@@ -20,7 +21,7 @@ namespace aleo_mi355x {
 __device__ __forceinline__ Fr fr_canonical_lt4r(const Fr& a) { return Fr::cond_sub<1>(Fr::cond_sub<2>(a)); }
 
 template <int OP>
-__global__ void __launch_bounds__(256) k_fr_vec_op(char* __restrict__ dst, const char* a, const char* b, size_t n) {
+__global__ void __launch_bounds__(256) k_fr_vec_op(char* dst, const char* a, const char* b, size_t n) {
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
     Fr x = load_fp<Fr>(a + i * 32), y = load_fp<Fr>(b + i * 32), r;
     if constexpr (OP == 0) r = Fr::mul(x, y);               // canonical inputs: < 2r
@@ -84,7 +85,7 @@ int32_t fr_vec_op(Ctx* c, void* d_dst, const void* d_a, const void* d_b, size_t 
 struct FrK { uint32_t v[8]; };
 __device__ __forceinline__ Fr fr_arg(const FrK& k) { Fr r; for (int i = 0; i < 8; ++i) r.v[i] = k.v[i]; return r; }
 template <bool HAS_A, bool HAS_B>
-__global__ void __launch_bounds__(256) k_fr_lin(char* __restrict__ dst, size_t n, FrK k0, FrK k1, const char* a, FrK k2, const char* b) {
+__global__ void __launch_bounds__(256) k_fr_lin(char* dst, size_t n, FrK k0, FrK k1, const char* a, FrK k2, const char* b) {
   const Fr c0 = fr_arg(k0), c1 = fr_arg(k1), c2 = fr_arg(k2);
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
     Fr r = c0;                                                                                    // canonical: < r
@@ -427,35 +428,22 @@ int32_t fr_eval_batch(Ctx* c, void* d_out, const void* const* d_polys, const siz
 }
 
 // ---- prover randomness generated where it is used ------------------------------------------------------------------------------
-// Element i of the stream `seed` is the first of the candidates j = 0, 1, ... that is below r, candidate (i, j) being the 253 low bits
-// of four SplitMix64 outputs mix(seed + (4 i + l + 1) * 0x9E3779B97F4A7C15 + j * 0xD1B54A32D192ED03), l = 0..3 (little-endian limbs).
+// Element i of the stream under the proof's 32-byte seed: ChaCha20 in counter mode with rejection sampling below r (chacha.h).
 // A counter-based definition: any element can be produced anywhere (the host draws the handful of blinding scalars it needs, the device
-// the 3|H| mask coefficients) [UPSTREAM-RECALL: snarkVM draws Fr::rand from the caller's RNG in prover/round_functions/first.rs].
-__device__ __forceinline__ uint64_t splitmix_at(uint64_t z) {
-  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; return z ^ (z >> 31);
-}
-__global__ void __launch_bounds__(256) k_fr_random(char* __restrict__ dst, size_t n, uint64_t seed, uint64_t first, int mont) {
+// the 3|H| mask coefficients) [UPSTREAM-RECALL: snarkVM draws Fr::rand from the caller's CSPRNG in prover/round_functions/first.rs].
+__global__ void __launch_bounds__(256) k_fr_random(char* __restrict__ dst, size_t n, Seed32 seed, uint64_t first, int mont) {
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-    const uint64_t e = first + i;
-    Fr v;
-    for (uint64_t j = 0;; ++j) {
-      uint64_t l[4];
-      for (int k = 0; k < 4; ++k) l[k] = splitmix_at(seed + (4 * e + (uint64_t)k + 1) * 0x9E3779B97F4A7C15ull + j * 0xD1B54A32D192ED03ull);
-      l[3] &= (1ull << 61) - 1;
-      for (int k = 0; k < 4; ++k) { v.v[2 * k] = (uint32_t)l[k]; v.v[2 * k + 1] = (uint32_t)(l[k] >> 32); }
-      bool lt = false, eq = true;                               // v < r ?
-      for (int k = 7; k >= 0; --k) { const uint32_t m = FrParams::P.v[k]; if (eq && v.v[k] != m) { lt = v.v[k] < m; eq = false; } }
-      if (lt) break;                                            // accepted with probability r / 2^253 = 0.58 per candidate
-    }
+    Fr v; chacha_fr(v.v, seed.w, first + i);                    // chacha.h: one ChaCha20 block per attempt, accepted with probability 0.83
     if (mont) v = Fr::to_mont(v);
     store_fp<Fr>(dst + i * 32, v);
   }
 }
-int32_t fr_random(Ctx* c, void* d_dst, size_t n, uint64_t seed, uint64_t first, int32_t mont, hipStream_t s) {
+int32_t fr_random(Ctx* c, void* d_dst, size_t n, const uint8_t* seed32, uint64_t first, int32_t mont, hipStream_t s) {
   (void)c;
   if (n == 0) return ALEO_MI355X_OK;
+  Seed32 sd; std::memcpy(sd.w, seed32, 32);
   size_t want = (n + 255) / 256;
-  hipLaunchKernelGGL(k_fr_random, dim3((uint32_t)(want < 8192 ? want : 8192)), dim3(256), 0, s, (char*)d_dst, n, seed, first, mont ? 1 : 0);
+  hipLaunchKernelGGL(k_fr_random, dim3((uint32_t)(want < 8192 ? want : 8192)), dim3(256), 0, s, (char*)d_dst, n, sd, first, mont ? 1 : 0);
   HIPCHK(hipGetLastError());
   return ALEO_MI355X_OK;
 }
@@ -464,7 +452,7 @@ int32_t fr_random(Ctx* c, void* d_dst, size_t n, uint64_t seed, uint64_t first, 
 // proof opens at beta and gamma, and the delta-weighted sum of the fourth round, in one pass over the data.
 static constexpr uint32_t LC_MAX = 28;
 struct LcArgs { const char* p[LC_MAX]; size_t n[LC_MAX]; FrK k[LC_MAX]; uint32_t terms; };
-__global__ void __launch_bounds__(256) k_fr_lincomb(char* __restrict__ dst, size_t n, LcArgs a, FrK k0) {
+__global__ void __launch_bounds__(256) k_fr_lincomb(char* dst, size_t n, LcArgs a, FrK k0) {
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
     Fr r = i == 0 ? fr_arg(k0) : Fr::zero();
     for (uint32_t j = 0; j < a.terms; ++j)
@@ -490,7 +478,7 @@ int32_t fr_lincomb(Ctx* c, void* d_dst, size_t n, const void* c0, const void* co
 
 // dst[i] += src[i mod n_src] (n_src a power of two dividing n): multiplication of a block of n_src coefficients by 1 + X^n_src + X^(2 n_src) + ...,
 // the selector v_{H*} / v_H that puts a smaller circuit's remainder on the largest constraint domain of a proof (varuna.hip).
-__global__ void __launch_bounds__(256) k_fr_add_tiled(char* __restrict__ dst, size_t n, const char* __restrict__ src, size_t mask) {
+__global__ void __launch_bounds__(256) k_fr_add_tiled(char* dst, size_t n, const char* __restrict__ src, size_t mask) {
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
     store_fp<Fr>(dst + i * 32, Fr::cond_sub<1>(Fr::add(load_fp<Fr>(dst + i * 32), load_fp<Fr>(src + (i & mask) * 32))));      // canonical inputs: < 2r
 }
@@ -507,7 +495,7 @@ int32_t fr_add_tiled(Ctx* c, void* d_dst, size_t n, const void* d_src, size_t n_
 // The two sumcheck numerators, each one pass over evaluations that already sit in HBM (values of the operands on the larger domain):
 //   first  (domain 4|H|): dst = r * (a + eta_b b + eta_c a b) − t * z          [UPSTREAM-RECALL: round_functions/second.rs, the summed polynomial]
 //   matrix (domain 2|K|): dst = sum_M delta_M (vv val_M − (alpha beta − beta row_M − alpha col_M + row_col_M) f_M)   [fourth.rs]
-__global__ void __launch_bounds__(256) k_ahp_first_sumcheck(char* __restrict__ dst, size_t n, const char* r, const char* a, const char* b, const char* t,
+__global__ void __launch_bounds__(256) k_ahp_first_sumcheck(char* dst, size_t n, const char* r, const char* a, const char* b, const char* t,
                                                             const char* z, FrK keb, FrK kec) {
   const Fr eb = fr_arg(keb), ec = fr_arg(kec);
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
@@ -613,16 +601,22 @@ int32_t ahp_sumcheck_operands(Ctx* c, void* d_dst, const void* d_wit, const void
   return ALEO_MI355X_OK;
 }
 
-// dst[pos[v]] = to_mont(src[v]): the assignment (canonical, variable order) laid out on H in Montgomery form — dst zeroed by the caller
-__global__ void __launch_bounds__(256) k_scatter_to_mont(char* __restrict__ dst, const char* __restrict__ src, const uint32_t* __restrict__ pos, size_t n) {
-  for (size_t v = (size_t)blockIdx.x * 256 + threadIdx.x; v < n; v += (size_t)gridDim.x * 256)
-    store_fp<Fr>(dst + (size_t)pos[v] * 32, Fr::to_mont(load_fp<Fr>(src + v * 32)));
+// dst[pos[v]] = to_mont(src[v]): the assignment (canonical, variable order) laid out on H in Montgomery form — dst zeroed by the caller.
+// An entry that is not below r (the Montgomery product assumes bounded inputs) raises *flag: the caller reads it with its next small read-back.
+__global__ void __launch_bounds__(256) k_scatter_to_mont(char* __restrict__ dst, const char* __restrict__ src, const uint32_t* __restrict__ pos, size_t n, uint32_t* flag) {
+  for (size_t v = (size_t)blockIdx.x * 256 + threadIdx.x; v < n; v += (size_t)gridDim.x * 256) {
+    const Fr x = load_fp<Fr>(src + v * 32);
+    bool lt = false;
+    for (int k = 7; k >= 0; --k) { const uint32_t m = FrParams::P.v[k]; if (x.v[k] != m) { lt = x.v[k] < m; break; } }
+    if (!lt && flag) atomicOr(flag, 1u);
+    store_fp<Fr>(dst + (size_t)pos[v] * 32, Fr::to_mont(x));
+  }
 }
-int32_t fr_scatter_to_mont(Ctx* c, void* d_dst, const void* d_src, const void* d_pos, size_t n, hipStream_t s) {
+int32_t fr_scatter_to_mont(Ctx* c, void* d_dst, const void* d_src, const void* d_pos, size_t n, void* d_flag, hipStream_t s) {
   (void)c;
   if (!n) return ALEO_MI355X_OK;
   const size_t want = (n + 255) / 256;
-  hipLaunchKernelGGL(k_scatter_to_mont, dim3((uint32_t)(want < 8192 ? want : 8192)), dim3(256), 0, s, (char*)d_dst, (const char*)d_src, (const uint32_t*)d_pos, n);
+  hipLaunchKernelGGL(k_scatter_to_mont, dim3((uint32_t)(want < 8192 ? want : 8192)), dim3(256), 0, s, (char*)d_dst, (const char*)d_src, (const uint32_t*)d_pos, n, (uint32_t*)d_flag);
   HIPCHK(hipGetLastError());
   return ALEO_MI355X_OK;
 }

@@ -6,11 +6,14 @@
 //   algorithms/src/snark/varuna/ahp/prover/round_functions/*   AHPForR1CS::prover_{first,second,third,fourth}_round   [UPSTREAM-RECALL]
 // reached from /root/reference/rust/src/program/execute.rs:74 (`trace.prove_execution`) and transfer.rs:99.
 // Every circuit-sized step is a kernel of msm.hip / ntt.hip / frops.hip queued on the calling slot's stream; this file keeps what
-// upstream keeps on the CPU between them: the transcript, the challenge-dependent constants (host Fr arithmetic, host_field.hpp)
+// upstream keeps on the CPU between them: the Fiat-Shamir transcript (upstream's Poseidon sponge over Fq, poseidon.hpp), the
+// challenge-dependent constants (host Fr arithmetic, host_field.hpp), the blinding scalars (ChaCha20 under the proof's 32-byte seed, chacha.h)
 // and the O(|X|) public-input polynomial.  aleo_amd/varuna.py is the same sequence written against the public entry points; both
 // must produce the bytes of the restatement in oracle/varuna_ref.py (tests/test_varuna.py).
 #include "ctx.h"
 #include "host_field.hpp"
+#include "poseidon.hpp"
+#include "chacha.h"
 #include <cstring>
 #include <vector>
 #include <functional>
@@ -21,74 +24,13 @@
 namespace aleo_mi355x {
 
 using host::HFr;
+using host::HFq;
 
-// ---- SHA-256 (FIPS 180-4) for the transcript -------------------------------------------------------------------------------------
 namespace {
-struct Sha256 {
-  uint32_t h[8]; uint8_t buf[64]; uint64_t len = 0; size_t fill = 0;
-  static uint32_t rotr(uint32_t x, int n) { return (x >> n) | (x << (32 - n)); }
-  Sha256() { static const uint32_t iv[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19}; std::memcpy(h, iv, 32); }
-  void block(const uint8_t* p) {
-    static const uint32_t K[64] = {
-      0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5, 0xd807aa98, 0x12835b01, 0x243185be, 0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174,
-      0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc, 0x2de92c6f, 0x4a7484aa, 0x5cb0a9dc, 0x76f988da, 0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147, 0x06ca6351, 0x14292967,
-      0x27b70a85, 0x2e1b2138, 0x4d2c6dfc, 0x53380d13, 0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85, 0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3, 0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070,
-      0x19a4c116, 0x1e376c08, 0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f, 0x682e6ff3, 0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208, 0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
-    uint32_t w[64];
-    for (int i = 0; i < 16; ++i) w[i] = ((uint32_t)p[4 * i] << 24) | ((uint32_t)p[4 * i + 1] << 16) | ((uint32_t)p[4 * i + 2] << 8) | p[4 * i + 3];
-    for (int i = 16; i < 64; ++i) {
-      uint32_t s0 = rotr(w[i - 15], 7) ^ rotr(w[i - 15], 18) ^ (w[i - 15] >> 3), s1 = rotr(w[i - 2], 17) ^ rotr(w[i - 2], 19) ^ (w[i - 2] >> 10);
-      w[i] = w[i - 16] + s0 + w[i - 7] + s1;
-    }
-    uint32_t a = h[0], b = h[1], c = h[2], d = h[3], e = h[4], f = h[5], g = h[6], hh = h[7];
-    for (int i = 0; i < 64; ++i) {
-      uint32_t S1 = rotr(e, 6) ^ rotr(e, 11) ^ rotr(e, 25), ch = (e & f) ^ (~e & g), t1 = hh + S1 + ch + K[i] + w[i];
-      uint32_t S0 = rotr(a, 2) ^ rotr(a, 13) ^ rotr(a, 22), mj = (a & b) ^ (a & c) ^ (b & c), t2 = S0 + mj;
-      hh = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
-    }
-    h[0] += a; h[1] += b; h[2] += c; h[3] += d; h[4] += e; h[5] += f; h[6] += g; h[7] += hh;
-  }
-  void update(const void* data, size_t n) {
-    const uint8_t* p = (const uint8_t*)data; len += n;
-    while (n) {
-      size_t take = 64 - fill < n ? 64 - fill : n;
-      std::memcpy(buf + fill, p, take); fill += take; p += take; n -= take;
-      if (fill == 64) { block(buf); fill = 0; }
-    }
-  }
-  void finish(uint8_t out[32]) {
-    uint64_t bits = len * 8; uint8_t pad = 0x80; update(&pad, 1);
-    uint8_t z = 0; while (fill != 56) update(&z, 1);
-    uint8_t lb[8]; for (int i = 0; i < 8; ++i) lb[i] = (uint8_t)(bits >> (56 - 8 * i));
-    update(lb, 8);
-    for (int i = 0; i < 8; ++i) { out[4 * i] = (uint8_t)(h[i] >> 24); out[4 * i + 1] = (uint8_t)(h[i] >> 16); out[4 * i + 2] = (uint8_t)(h[i] >> 8); out[4 * i + 3] = (uint8_t)h[i]; }
-  }
-};
-
-const char LABEL[] = "aleo-mi355x/varuna-synthetic/v1";
-
-// state = SHA-256(state ‖ data); a challenge is the new state read as a little-endian integer mod r
-struct Transcript {
-  uint8_t state[32];
-  Transcript() { Sha256 s; s.update(LABEL, sizeof LABEL - 1); s.finish(state); }
-  void absorb(const void* data, size_t n) { Sha256 s; s.update(state, 32); s.update(data, n); s.finish(state); }
-  HFr challenge(const char* label, size_t n) {           // Montgomery form
-    absorb(label, n);
-    uint64_t v[4]; std::memcpy(v, state, 32);
-    HFr c = HFr::reduce_lazy(v);                           // < 2^256 < 14 r: a few subtractions
-    return HFr::to_mont(c);
-  }
-};
-
-inline uint64_t mix64(uint64_t z) { z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; return z ^ (z >> 31); }
-// element `index` of the proof's random stream (same definition as k_fr_random in frops.hip), Montgomery form
-HFr random_fr(uint64_t seed, uint64_t index) {
-  for (uint64_t j = 0;; ++j) {
-    uint64_t l[4];
-    for (int k = 0; k < 4; ++k) l[k] = mix64(seed + (4 * index + (uint64_t)k + 1) * 0x9E3779B97F4A7C15ull + j * 0xD1B54A32D192ED03ull);
-    l[3] &= (1ull << 61) - 1;
-    if (!HFr::geq_p(l)) { HFr v; std::memcpy(v.l, l, 32); return HFr::to_mont(v); }
-  }
+// element `index` of the proof's random stream (chacha.h; the same definition as k_fr_random in frops.hip), Montgomery form
+HFr random_fr(const Seed32& seed, uint64_t index) {
+  uint32_t w[8]; chacha_fr(w, seed.w, index);
+  HFr v; std::memcpy(v.l, w, 32); return HFr::to_mont(v);
 }
 
 inline HFr fr_u64(uint64_t v) { return HFr::from_u64(v); }
@@ -157,7 +99,7 @@ static int32_t commit(Ctx* c, const PinnedBases& pb, const std::vector<MsmSeg>& 
 // Process::synthesize_key, /root/reference/wasm/src/programs/manager/mod.rs:164-177, rust/src/program/deploy.rs:142,151.]
 struct VarunaIndexOwner {
   aleo_mi355x_varuna_index view{};
-  std::vector<uint32_t> positions; std::vector<uint8_t> vk;
+  std::vector<uint32_t> positions; std::vector<uint8_t> vk, vk_aff;
   std::vector<void*> dev;                                  // every device allocation of the index
   std::shared_ptr<PinnedOwner> key;                        // the committer key stays pinned while the index lives
   ~VarunaIndexOwner() { for (void* p : dev) if (p) (void)hipFree(p); }
@@ -262,7 +204,7 @@ int32_t varuna_index_build(Ctx* c, const PinnedBases& pb, std::shared_ptr<Pinned
   V.k_evals = kev; V.k_idx = kid; V.k_polys = kpo; V.k2_evals = k2; V.positions = o->positions.data();
   { void* dp; RC(up(&dp, o->positions.data(), n_vars * 4)); V.positions_device = dp; }
   // index commitments -> what the transcript absorbs first
-  uint8_t aff[12 * 104];
+  o->vk_aff.assign(12 * 104, 0); uint8_t* aff = o->vk_aff.data();
   {
     std::vector<MsmSeg> sg(12);
     for (int q = 0; q < 12; ++q) { const int m = q / 4, j = q % 4; sg[q].d_ptr = (char*)kpo + (4 * ko[m] + (size_t)j * nk[m]) * 32; sg[q].len = nk[m]; sg[q].off = 0; sg[q].out = (uint32_t)q; }
@@ -272,7 +214,7 @@ int32_t varuna_index_build(Ctx* c, const PinnedBases& pb, std::shared_ptr<Pinned
   o->vk.resize(12 * 48 + 40);
   RC(aleo_mi355x_g1_compress(o->vk.data(), aff, 12));
   const uint64_t dims[5] = {n_h, nk[0], nk[1], nk[2], n_x}; std::memcpy(&o->vk[12 * 48], dims, 40);
-  V.vk_bytes = o->vk.data(); V.vk_len = o->vk.size();
+  V.vk_bytes = o->vk.data(); V.vk_len = o->vk.size(); V.vk_affine = o->vk_aff.data();
   *out = o.release();
   return ALEO_MI355X_OK;
 }
@@ -290,13 +232,13 @@ static constexpr size_t HC = 3;                            // coefficients of a 
 static constexpr size_t MAX_CIRCUITS = 8, MAX_INSTANCES = 8, MAX_TOTAL_INSTANCES = 32;
 
 struct Shared {
-  Ctx* c; const PinnedBases& pb; uint64_t seed;
-  Shared(Ctx* c_, const PinnedBases& pb_, uint64_t seed_) : c(c_), pb(pb_), seed(seed_) {}
+  Ctx* c; const PinnedBases& pb; Seed32 seed;
+  Shared(Ctx* c_, const PinnedBases& pb_, const uint8_t* seed32) : c(c_), pb(pb_) { std::memcpy(seed.w, seed32, 32); }
   size_t m = 0, K = 0, N = 0, n_kmax = 0, lead = 0, x_total = 0; uint64_t D = 0, gamma_offset = 0;
   hipStream_t s = nullptr; double t_mark[7] = {}; Arena ar{nullptr, 0, 0}; char* pin = nullptr; char* stage = nullptr; char* pin_small = nullptr;
-  HFr one, neg1, r2; Transcript tr; uint64_t lay_mask = 0, lay_blind = 0, lay_blind_mask = 0;
-  char *mask = nullptr, *bl = nullptr, *h1 = nullptr, *g1 = nullptr, *h2 = nullptr;
-  std::vector<HFr> blind, comb, evals; std::vector<uint8_t> wit_aff, aff3, comp, x_bytes;
+  HFr one, neg1, r2; host::FiatShamir fs; uint64_t lay_mask = 0, lay_blind = 0, lay_blind_mask = 0;
+  char *mask = nullptr, *bl = nullptr, *h1 = nullptr, *g1 = nullptr, *h2 = nullptr, *flag = nullptr;
+  std::vector<HFr> blind, comb, evals, x_mont, ch_b, ch_g; std::vector<uint8_t> wit_aff, aff3;
   uint8_t aff2[208], aff4[104], aff5[208];
   HFr alpha, eta_b, eta_c, beta, gamma, random_v;
   // staging offsets (elements of 32 bytes inside `stage`): x̂ coefficients | hiding polynomials | the opening's hiding quotient | rho
@@ -337,6 +279,10 @@ int32_t Prover::setup() {
       ix.n_public > n_x || ix.n_vars > n_h || ix.gamma_offset + HC > pb.n || (ix.lagrange_offset && ix.lagrange_offset + n_h + 1 > pb.n) || D + 1 > pb.n || 3 * n_h > D + 1 || n_k > D + 1) {
     g_last_error = "varuna_prove: inconsistent index / key sizes"; return ALEO_MI355X_ERR_BAD_ARG;
   }
+  if (!ix.a_row_ptr || !ix.a_col || !ix.a_val || !ix.b_row_ptr || !ix.b_col || !ix.b_val || !ix.t_row_ptr || !ix.t_col || !ix.t_val || !ix.vx_inv || !ix.k_evals || !ix.k_idx ||
+      !ix.k_polys || !ix.k2_evals || !ix.positions || !ix.vk_bytes || ix.vk_len != 12 * 48 + 40) {
+    g_last_error = "varuna_prove: the index struct has a null array (or vk_len != 616)"; return ALEO_MI355X_ERR_BAD_ARG;
+  }
   lg_h = 0; lg_km[0] = lg_km[1] = lg_km[2] = 0; while ((1ull << lg_h) < n_h) ++lg_h;
   for (int m = 0; m < 3; ++m) while ((1ull << lg_km[m]) < nk[m]) ++lg_km[m];
   return ALEO_MI355X_OK;
@@ -346,7 +292,7 @@ int32_t Prover::first_round(const void* const* assignments, std::vector<MsmSeg>&
   Ctx* c = sh.c; hipStream_t s = sh.s; Arena& ar = sh.ar; char* pin = sh.pin + pin_off * 32; char* stage = sh.stage;
   TAKE(zH, k * n_h) TAKE(ev, 3 * k * n_h) TAKE(xh, k * n_h) TAKE_M(xp, k * n_x) TAKE_M(wit, 3 * k * L)
   x_poly.assign(k, {});
-  const size_t xb0 = sh.x_bytes.size(); sh.x_bytes.resize(xb0 + k * n_x * 32, 0); uint8_t* x_bytes = sh.x_bytes.data() + xb0;
+  const size_t xb0 = sh.x_mont.size(); sh.x_mont.resize(xb0 + k * n_x, HFr::zero());          // the padded public inputs: what the transcript absorbs per instance
   uint32_t lg_x = 0; while ((1ull << lg_x) < n_x) ++lg_x;
   const HFr one = sh.one, gx_inv = HFr::inv(domain_gen(n_x)), nx_inv = inv_pow2(lg_x);
   const uint32_t* pos = (const uint32_t*)ix.positions;
@@ -358,10 +304,11 @@ int32_t Prover::first_round(const void* const* assignments, std::vector<MsmSeg>&
     if (host_layout)
       for (size_t v = 0; v < ix.n_vars; ++v) {
         if (pos[v] >= n_h) { g_last_error = "varuna_prove: variable position outside H"; return ALEO_MI355X_ERR_BAD_ARG; }
+        if (HFr::geq_p((const uint64_t*)(z + v * 32))) { g_last_error = "varuna_prove: assignment not canonical"; return ALEO_MI355X_ERR_BAD_ARG; }
         std::memcpy(pin + (i * n_h + pos[v]) * 32, z + v * 32, 32);
       }
     std::vector<HFr> xe(n_x, HFr::zero());
-    for (size_t t = 0; t < ix.n_public; ++t) { HFr v; std::memcpy(v.l, z + t * 32, 32); if (HFr::geq_p(v.l)) { g_last_error = "varuna_prove: assignment not canonical"; return ALEO_MI355X_ERR_BAD_ARG; } std::memcpy(&x_bytes[(i * n_x + t) * 32], v.l, 32); xe[t] = HFr::to_mont(v); }
+    for (size_t t = 0; t < ix.n_public; ++t) { HFr v; std::memcpy(v.l, z + t * 32, 32); if (HFr::geq_p(v.l)) { g_last_error = "varuna_prove: assignment not canonical"; return ALEO_MI355X_ERR_BAD_ARG; } xe[t] = HFr::to_mont(v); sh.x_mont[xb0 + i * n_x + t] = xe[t]; }
     x_poly[i] = xe;                                        // inverse DFT over X on the host: |X| is the (padded) number of public inputs
     host_ntt(x_poly[i], gx_inv);
     for (auto& v : x_poly[i]) v = HFr::mul(v, nx_inv);
@@ -372,10 +319,11 @@ int32_t Prover::first_round(const void* const* assignments, std::vector<MsmSeg>&
     RC(fr_lin(c, zH, k * n_h, nullptr, sh.r2.l, zH, nullptr, nullptr, s));                // canonical -> Montgomery
   } else {                                                                                  // upload in variable order; scatter + Montgomery form on the device
     TAKE(zraw, k * ix.n_vars)
+    if (!sh.flag) { TAKE_M(sh.flag, 1) HIPCHK(hipMemsetAsync(sh.flag, 0, 32, s)); }          // raised by the scatter when an entry is not below r
     HIPCHK(hipMemsetAsync(zH, 0, k * n_h * 32, s));
     for (size_t i = 0; i < k; ++i) {
       HIPCHK(hipMemcpyAsync(zraw + i * ix.n_vars * 32, assignments[i], ix.n_vars * 32, hipMemcpyHostToDevice, s));
-      RC(fr_scatter_to_mont(c, zH + i * n_h * 32, zraw + i * ix.n_vars * 32, ix.positions_device, ix.n_vars, s));
+      RC(fr_scatter_to_mont(c, zH + i * n_h * 32, zraw + i * ix.n_vars * 32, ix.positions_device, ix.n_vars, sh.flag, s));
     }
   }
   HIPCHK(hipMemcpyAsync(xp, stage + x_off * 32, k * n_x * 32, hipMemcpyHostToDevice, s));
@@ -514,7 +462,8 @@ int32_t Prover::fourth_round() {
 // ---- the proof: rounds over all circuits, commitments and transcript in between -----------------------------------------------------------------------
 struct Batch {
   Shared sh; std::vector<std::unique_ptr<Prover>> P;
-  Batch(Ctx* c, const PinnedBases& pb, uint64_t seed) : sh(c, pb, seed) {}
+  Batch(Ctx* c, const PinnedBases& pb, const uint8_t* seed32) : sh(c, pb, seed32) {}
+  int32_t init_sponge();                                   // Varuna::init_sponge: protocol name, batch sizes, public inputs, index commitments
   int32_t setup(const aleo_mi355x_varuna_index* const* ixs, size_t m, const size_t* ks);
   int32_t first_round(const void* const* assignments);     // + the 3K + 1 hiding commitments
   int32_t second_round();                                  // g_1, h_1
@@ -584,18 +533,38 @@ int32_t Batch::setup(const aleo_mi355x_varuna_index* const* ixs, size_t m, const
   return ALEO_MI355X_OK;
 }
 
+// Varuna::init_sponge [UPSTREAM-RECALL]: the protocol name; per circuit its batch size (u64 LE as bytes) and the padded public inputs of each of its
+// instances (one non-native absorb per instance); then every circuit's twelve index commitments.
+int32_t Batch::init_sponge() {
+  static const uint8_t NAME[] = "VARUNA-2023";
+  sh.fs.absorb_bytes(NAME, sizeof NAME - 1);
+  for (auto& p : P) {
+    const uint64_t k64 = p->k; uint8_t kb[8]; for (int i = 0; i < 8; ++i) kb[i] = (uint8_t)(k64 >> (8 * i));
+    sh.fs.absorb_bytes(kb, 8);
+    for (size_t i = 0; i < p->k; ++i) sh.fs.absorb_fr(&sh.x_mont[p->x_off + i * p->n_x], p->n_x);
+  }
+  for (auto& p : P) {
+    if (p->ix.vk_affine) { sh.fs.absorb_g1((const uint8_t*)p->ix.vk_affine, 104, 12); continue; }
+    uint8_t aff[12 * 104];                                  // an index struct without the affine form: decompress (twelve square roots, ~ 0.5 ms)
+    RC(aleo_mi355x_g1_decompress(aff, p->ix.vk_bytes, 12, 0));
+    sh.fs.absorb_g1(aff, 104, 12);
+  }
+  return ALEO_MI355X_OK;
+}
+
 int32_t Batch::first_round(const void* const* assignments) {
   Ctx* c = sh.c; hipStream_t s = sh.s; const size_t K = sh.K, N = sh.N;
   TAKE_M(sh.bl, (3 * K + 1) * HC) TAKE_M(sh.mask, 3 * N)
-  sh.blind.assign((3 * K + 1) * HC, HFr::zero()); sh.x_bytes.clear();
+  sh.blind.assign((3 * K + 1) * HC, HFr::zero()); sh.x_mont.clear();
   std::vector<MsmSeg> sg, sm;
   for (auto& p : P) RC(p->first_round(assignments + p->q0, sg));
+  if (sh.flag) HIPCHK(hipMemcpyAsync(sh.pin_small + 3840, sh.flag, 4, hipMemcpyDeviceToHost, s));      // read after the round's commitments
   for (size_t t = 0; t < HC; ++t) sh.blind[3 * K * HC + t] = random_fr(sh.seed, sh.lay_blind_mask + t);
-  RC(fr_random(c, sh.mask, 3 * N, sh.seed, sh.lay_mask, 1, s));
+  RC(fr_random(c, sh.mask, 3 * N, (const uint8_t*)sh.seed.w, sh.lay_mask, 1, s));
   RC(fr_lin(c, sh.mask, 1, nullptr, sh.neg1.l, sh.mask + N * 32, sh.neg1.l, sh.mask + 2 * N * 32, s));   // sum over H* = |H*| (m_0 + m_|H*| + m_2|H*|) = 0
   std::memcpy(sh.stage + sh.st_blind() * 32, sh.blind.data(), sh.blind.size() * 32);
   HIPCHK(hipMemcpyAsync(sh.bl, sh.stage + sh.st_blind() * 32, sh.blind.size() * 32, hipMemcpyHostToDevice, s));
-  sh.wit_aff.assign(104 * (3 * K + 1), 0); sh.comp.assign(48 * 8, 0);                                  // scratch for the compressed g_1 | h_1 and h_2
+  sh.wit_aff.assign(104 * (3 * K + 1), 0);
   {
     // with the evaluations against the Lagrange powers AND a narrow-window table over [hiding powers | Lagrange powers | v_H G] the 3K witness
     // commitments are one sparse chain (their scalars are mostly 0 / 1), the mask (uniform coefficients against the monomial powers) another
@@ -606,20 +575,25 @@ int32_t Batch::first_round(const void* const* assignments) {
     std::vector<MsmSeg>& dst = split ? sm : sg;
     MsmSeg a; a.d_ptr = sh.mask; a.len = 3 * N; a.off = 0; a.out = split ? 0u : (uint32_t)(3 * K); dst.push_back(a);
     MsmSeg b; b.d_ptr = sh.bl + 3 * K * HC * 32; b.len = HC; b.off = sh.gamma_offset; b.out = a.out; dst.push_back(b);
-    auto early = [this]() -> int32_t { for (auto& p : P) RC(p->second_round_early()); return ALEO_MI355X_OK; };      // needs no challenge: behind the (last) commitment chain
+    // needs no challenge: behind the (last) commitment chain — the operands of the sumcheck on the device, and on the host the part of the
+    // transcript that precedes the first commitments (Varuna::init_sponge: ~ 20 permutations while the GPU accumulates)
+    auto early = [this]() -> int32_t { for (auto& p : P) RC(p->second_round_early()); return init_sponge(); };
     if (split) { RC(commit(c, pb, sg, (uint32_t)(3 * K), sh.wit_aff.data(), s, true)); RC(commit(c, pb, sm, 1, sh.wit_aff.data() + 104 * 3 * K, s, false, early)); }
     else RC(commit(c, pb, sg, (uint32_t)(3 * K + 1), sh.wit_aff.data(), s, false, early));
   }
-  std::vector<uint8_t> c1(48 * (3 * K + 1));
-  RC(aleo_mi355x_g1_compress(c1.data(), sh.wit_aff.data(), 3 * K + 1));
-  {
-    std::vector<uint8_t> vk; for (auto& p : P) vk.insert(vk.end(), (const uint8_t*)p->ix.vk_bytes, (const uint8_t*)p->ix.vk_bytes + p->ix.vk_len);
-    sh.tr.absorb(vk.data(), vk.size());
-  }
-  sh.tr.absorb(sh.x_bytes.data(), sh.x_bytes.size()); sh.tr.absorb(c1.data(), c1.size());
-  sh.alpha = sh.tr.challenge("alpha", 5); sh.eta_b = sh.tr.challenge("eta_b", 5); sh.eta_c = sh.tr.challenge("eta_c", 5);
+  if (sh.flag) { uint32_t f; std::memcpy(&f, sh.pin_small + 3840, 4); if (f) { g_last_error = "varuna_prove: assignment not canonical (an entry is not below r)"; return ALEO_MI355X_ERR_BAD_ARG; } }
+  sh.fs.absorb_g1(sh.wit_aff.data(), 104, 3 * K + 1);
+  // verifier_first_round [UPSTREAM-RECALL]: per circuit k_j − 1 instance combiners and (but for the first circuit) a circuit combiner in one squeeze,
+  // then alpha, eta_b, eta_c in one squeeze; an instance's combiner = circuit combiner * instance combiner
   sh.comb.assign(K, sh.one);
-  for (size_t i = 1; i < K; ++i) { char lab[12] = "combiner"; uint32_t ii = (uint32_t)i; std::memcpy(lab + 8, &ii, 4); sh.comb[i] = sh.tr.challenge(lab, 12); }
+  for (auto& p : P) {
+    HFr el[MAX_INSTANCES]; const size_t cnt = p->k - 1 + (p->j ? 1 : 0);
+    sh.fs.squeeze_full(el, cnt);
+    const HFr cc = p->j ? el[p->k - 1] : sh.one;
+    sh.comb[p->q0] = cc;
+    for (size_t i = 1; i < p->k; ++i) sh.comb[p->q0 + i] = HFr::mul(cc, el[i - 1]);
+  }
+  { HFr el[3]; sh.fs.squeeze_full(el, 3); sh.alpha = el[0]; sh.eta_b = el[1]; sh.eta_c = el[2]; }
   sh.t_mark[1] = now_ms();
   return ALEO_MI355X_OK;
 }
@@ -644,8 +618,8 @@ int32_t Batch::second_round() {
     uint64_t sum[4]; std::memcpy(sum, sh.pin_small + 3584 + 32 * j, 32);
     if (sum[0] | sum[1] | sum[2] | sum[3]) { g_last_error = "varuna_prove: the assignment does not satisfy the circuit (first sumcheck: the sum over H is not zero)"; return ALEO_MI355X_ERR_UNSATISFIED; }
   }
-  RC(aleo_mi355x_g1_compress(sh.comp.data(), sh.aff2, 2)); sh.tr.absorb(sh.comp.data(), 96);
-  sh.beta = sh.tr.challenge("beta", 4);
+  sh.fs.absorb_g1(sh.aff2, 104, 2);
+  sh.fs.squeeze_full(&sh.beta, 1);
   sh.t_mark[2] = now_ms();
   return ALEO_MI355X_OK;
 }
@@ -653,7 +627,6 @@ int32_t Batch::second_round() {
 int32_t Batch::third_round() {
   Ctx* c = sh.c; hipStream_t s = sh.s; const size_t m = sh.m;
   for (auto& p : P) RC(p->third_round());
-  std::vector<uint8_t> buf(96 * m + 144 * m);
   std::vector<MsmSeg> sg(3 * m);
   for (auto& p : P)
     for (size_t M = 0; M < 3; ++M) {
@@ -662,15 +635,12 @@ int32_t Batch::third_round() {
   sh.aff3.assign(312 * m, 0);
   RC(commit(c, sh.pb, sg, (uint32_t)(3 * m), sh.aff3.data(), s, false, [this]() -> int32_t { for (auto& p : P) RC(p->fourth_round_early()); return ALEO_MI355X_OK; }));
   for (auto& p : P)                                                                           // the sums f_{j,M}(0) |K| were copied out ahead of the commitments: no stream sync of their own
-    for (size_t M = 0; M < 3; ++M) { HFr v; std::memcpy(v.l, sh.pin_small + 32 * (3 * p->j + M), 32); p->sigma[M] = HFr::mul(v, fr_u64(p->nk[M])); fr_bytes(&buf[32 * (3 * p->j + M)], p->sigma[M]); }
-  RC(aleo_mi355x_g1_compress(&buf[96 * m], sh.aff3.data(), 3 * m));
-  sh.tr.absorb(buf.data(), buf.size());
-  for (auto& p : P) {
-    for (size_t M = 0; M < 3; ++M) {
-      if (p->j == 0) { p->delta[M] = M == 0 ? sh.one : sh.tr.challenge(M == 1 ? "delta_b" : "delta_c", 7); continue; }
-      char lab[11] = "delta_a"; lab[6] = (char)('a' + M); uint32_t jj = (uint32_t)p->j; std::memcpy(lab + 7, &jj, 4);
-      p->delta[M] = sh.tr.challenge(lab, 11);
-    }
+    for (size_t M = 0; M < 3; ++M) { HFr v; std::memcpy(v.l, sh.pin_small + 32 * (3 * p->j + M), 32); p->sigma[M] = HFr::mul(v, fr_u64(p->nk[M])); }
+  sh.fs.absorb_g1(sh.aff3.data(), 104, 3 * m);                                                  // absorb_with_msg: the commitments, then the sums circuit by circuit
+  for (auto& p : P) sh.fs.absorb_fr(p->sigma, 3);
+  {
+    std::vector<HFr> el(3 * m); el[0] = sh.one; sh.fs.squeeze_full(el.data() + 1, 3 * m - 1);   // delta_{0,a} = 1, the rest from one squeeze
+    for (auto& p : P) for (size_t M = 0; M < 3; ++M) p->delta[M] = el[3 * p->j + M];
   }
   sh.t_mark[3] = now_ms();
   return ALEO_MI355X_OK;
@@ -686,8 +656,8 @@ int32_t Batch::fourth_round() {
     std::vector<MsmSeg> sg(1); sg[0].d_ptr = sh.h2; sg[0].len = sh.n_kmax; sg[0].off = 0; sg[0].out = 0;
     RC(commit(c, sh.pb, sg, 1, sh.aff4, s));
   }
-  RC(aleo_mi355x_g1_compress(sh.comp.data(), sh.aff4, 1)); sh.tr.absorb(sh.comp.data(), 48);
-  sh.gamma = sh.tr.challenge("gamma", 5);
+  sh.fs.absorb_g1(sh.aff4, 104, 1);
+  sh.fs.squeeze_full(&sh.gamma, 1);
   sh.t_mark[4] = now_ms();
   return ALEO_MI355X_OK;
 }
@@ -706,10 +676,18 @@ int32_t Batch::open() {
   }
   HIPCHK(hipMemcpyAsync(sh.pin_small, evd, ne * 32, hipMemcpyDeviceToHost, s));
   HIPCHK(hipStreamSynchronize(s));
-  sh.evals.assign(ne, HFr::zero()); std::vector<uint8_t> ev_bytes(ne * 32);
-  for (size_t i = 0; i < ne; ++i) { std::memcpy(sh.evals[i].l, sh.pin_small + 32 * i, 32); fr_bytes(&ev_bytes[32 * i], sh.evals[i]); }
-  sh.tr.absorb(ev_bytes.data(), ev_bytes.size());
-  const HFr xi = sh.tr.challenge("xi", 2);
+  sh.evals.assign(ne, HFr::zero());
+  for (size_t i = 0; i < ne; ++i) std::memcpy(sh.evals[i].l, sh.pin_small + 32 * i, 32);
+  {
+    std::vector<HFr> ser(sh.evals.begin(), sh.evals.begin() + K + 1);                          // Evaluations as serialised: z_b's, g_1, every g_a, every g_b, every g_c
+    for (size_t M = 0; M < 3; ++M) for (size_t j = 0; j < m; ++j) ser.push_back(sh.evals[K + 1 + 3 * j + M]);
+    sh.fs.absorb_fr(ser.data(), ser.size());
+  }
+  // one short challenge per polynomial of an opening [UPSTREAM-RECALL: sonic_pc combine_for_open], the point beta first:
+  // beta: g_1, z_b of every instance, the lincheck combination;  gamma: g_{j,M} circuit by circuit, the matrix combination
+  sh.ch_b.resize(K + 2); sh.ch_g.resize(3 * m + 1);
+  for (auto& v : sh.ch_b) v = sh.fs.squeeze_short();
+  for (auto& v : sh.ch_g) v = sh.fs.squeeze_short();
   const HFr g1_beta = sh.evals[K];
   // one inversion for everything the openings divide by: alpha − beta, v_{H_j}(beta) (selectors), v_{K_{j,M}}(gamma)
   std::vector<HFr> inv(1 + 4 * m);
@@ -719,31 +697,29 @@ int32_t Batch::open() {
   if (inv[0].is_zero()) { g_last_error = "varuna_prove: alpha equals beta"; return ALEO_MI355X_ERR_HIP; }
   batch_inverse_vec(inv);
   // ---- the linear combination of the first sumcheck, opened at beta together with g_1 and the z_b,i -----------------------------------------------
-  const HFr xl = HFr::pow_u64(xi, K + 1), vN_beta = vanish(N, beta);
+  const HFr xl = sh.ch_b[K + 1], vN_beta = vanish(N, beta);
   HFr cst = HFr::neg(HFr::mul(beta, g1_beta));
   HFr blw[3];                                                                     // blw: (bl(X) − bl(beta)) / (X − beta), uploaded below
   {
     std::vector<const void*> terms; std::vector<size_t> lens; std::vector<HFr> co;
     auto term = [&](const void* p, size_t n, const HFr& k) { terms.push_back(p); lens.push_back(n); co.push_back(k); };
-    term(sh.mask, 3 * N, xl); term(sh.h1, 2 * N, HFr::neg(HFr::mul(xl, vN_beta))); term(sh.g1 + 32, N - 1, one);
+    term(sh.mask, 3 * N, xl); term(sh.h1, 2 * N, HFr::neg(HFr::mul(xl, vN_beta))); term(sh.g1 + 32, N - 1, sh.ch_b[0]);
     HFr blc[3] = {HFr::zero(), HFr::zero(), HFr::zero()};
     auto axpy = [&](const HFr& coef, const HFr* src) { for (size_t t = 0; t < HC; ++t) blc[t] = HFr::add(blc[t], HFr::mul(coef, src[t])); };
     axpy(xl, &sh.blind[3 * K * HC]);
-    HFr xpow = xi;                                                                           // xi^(1+q)
     for (auto& pp : P) {
       Prover& p = *pp;
       const HFr r_ab = HFr::mul(HFr::sub(p.vh_alpha, p.vh_beta), inv[0]);
       const HFr t_beta = HFr::add(p.sigma[0], HFr::add(HFr::mul(eta_b, p.sigma[1]), HFr::mul(eta_c, p.sigma[2])));
       const HFr sel = p.n_h == N ? one : HFr::mul(vN_beta, inv[1 + p.j]), vx_beta = vanish(p.n_x, beta);      // s_j(beta) = v_{H*}(beta) / v_{H_j}(beta)
       for (size_t i = 0; i < p.k; ++i) {
-        const size_t q = p.q0 + i;
+        const size_t q = p.q0 + i; const HFr& xpow = sh.ch_b[1 + q];
         const HFr x_beta = horner(p.x_poly[i], beta), zb = sh.evals[q], ci = HFr::mul(sh.comb[q], sel);
         const HFr k_za = HFr::mul(HFr::mul(xl, ci), HFr::mul(r_ab, HFr::add(one, HFr::mul(eta_c, zb))));
         const HFr k_w = HFr::neg(HFr::mul(HFr::mul(xl, ci), HFr::mul(t_beta, vx_beta)));
         cst = HFr::add(cst, HFr::mul(ci, HFr::sub(HFr::mul(HFr::mul(r_ab, eta_b), zb), HFr::mul(t_beta, x_beta))));
         term(p.wit + (3 * i + 1) * p.L * 32, p.L, k_za); term(p.wit + (3 * i) * p.L * 32, p.L, k_w); term(p.wit + (3 * i + 2) * p.L * 32, p.L, xpow);
         axpy(k_w, &sh.blind[(3 * q) * HC]); axpy(k_za, &sh.blind[(3 * q + 1) * HC]); axpy(xpow, &sh.blind[(3 * q + 2) * HC]);
-        xpow = HFr::mul(xpow, xi);
       }
     }
     RC(lincomb_any(c, pbeta, 3 * N, HFr::mul(xl, cst), terms, lens, co, s));
@@ -755,7 +731,7 @@ int32_t Batch::open() {
   RC(fr_divide_by_linear(c, wq, evd + (ne + 1) * 32, pbeta, 3 * N, beta.l, s));
   // ---- the linear combination of the second sumcheck, opened at gamma together with every g_{j,M} ------------------------------------------------------
   {
-    const HFr xi3m = HFr::pow_u64(xi, 3 * m), vk_gamma = vanish(n_k, gamma);
+    const HFr xi3m = sh.ch_g[3 * m], vk_gamma = vanish(n_k, gamma);
     std::vector<const void*> terms; std::vector<size_t> lens; std::vector<HFr> co; HFr cg = HFr::zero();
     auto term = [&](const void* p, size_t n, const HFr& k) { terms.push_back(p); lens.push_back(n); co.push_back(k); };
     for (auto& pp : P) {
@@ -770,8 +746,7 @@ int32_t Batch::open() {
       }
     }
     term(sh.h2, n_k, HFr::neg(HFr::mul(xi3m, vk_gamma)));
-    HFr xp = one;                                                                            // xi^(3j+M)
-    for (auto& pp : P) for (size_t M = 0; M < 3; ++M) { term(pp->f + (pp->ko[M] + 1) * 32, pp->nk[M] - 1, xp); xp = HFr::mul(xp, xi); }
+    for (auto& pp : P) for (size_t M = 0; M < 3; ++M) term(pp->f + (pp->ko[M] + 1) * 32, pp->nk[M] - 1, sh.ch_g[3 * pp->j + M]);
     RC(lincomb_any(c, pg, n_k, cg, terms, lens, co, s));
   }
   RC(fr_divide_by_linear(c, gq, evd + (ne + 2) * 32, pg, n_k, gamma.l, s));
@@ -803,17 +778,17 @@ int32_t Batch::write(uint8_t* out, size_t* out_len) {
 
 // assignments: the instances of circuit 0, then of circuit 1, ... (sum of ks pointers)
 int32_t varuna_prove_batch(Ctx* c, const PinnedBases& pb, const aleo_mi355x_varuna_index* const* ixs, size_t m, const void* const* assignments, const size_t* ks,
-                           uint64_t seed, uint8_t* out, size_t* out_len) {
+                           const uint8_t* seed32, uint8_t* out, size_t* out_len) {
   g_varuna_timing[6] = g_varuna_timing[7] = 0;
-  Batch b(c, pb, seed);
+  Batch b(c, pb, seed32);
   RC(b.setup(ixs, m, ks)); RC(b.first_round(assignments)); RC(b.second_round()); RC(b.third_round()); RC(b.fourth_round()); RC(b.open());
   return b.write(out, out_len);
 }
 
-int32_t varuna_prove(Ctx* c, const PinnedBases& pb, const aleo_mi355x_varuna_index& ix, const void* const* assignments, size_t k, uint64_t seed,
+int32_t varuna_prove(Ctx* c, const PinnedBases& pb, const aleo_mi355x_varuna_index& ix, const void* const* assignments, size_t k, const uint8_t* seed32,
                      uint8_t* out, size_t* out_len) {
   const aleo_mi355x_varuna_index* one[1] = {&ix};
-  return varuna_prove_batch(c, pb, one, 1, assignments, &k, seed, out, out_len);
+  return varuna_prove_batch(c, pb, one, 1, assignments, &k, seed32, out, out_len);
 }
 
 }  // namespace aleo_mi355x

@@ -7,8 +7,9 @@
 //   synthesizer/snark/src/proof + algorithms/src/snark/varuna/data_structures/proof.rs    Proof::to_bytes_le, Display = bech32m "proof1..."
 // The reference holds one such string — the `proof` field of TRANSACTION_STRING at /root/reference/wasm/src/programs/transaction.rs:100
 // (round-tripped by its test at :104-120) — and the layout below was read off its 901 payload bytes:
-//   [0] version 0 | u64 #batch sizes | u64 per circuit | per instance (w, z_a, z_b) | option tag + mask_poly | g_1, h_1 | per circuit
-//   (g_a, g_b, g_c) | h_2 | per instance (3 + ...) evaluations ... ; tests/golden/reference_proof.json pins every field.
+//   [0] version 0 | u64 #batch sizes | u64 per circuit | per instance (w, z_a, z_b) | option tag + mask_poly | g_1, h_1 | every g_a, every g_b,
+//   every g_c | h_2 | evaluations: z_b per instance, g_1, every g_a, g_b, g_c | sums per circuit | openings; tests/golden/reference_proof.json
+//   pins every field for one circuit (where "every g_a, g_b, g_c" and "g_a, g_b, g_c per circuit" coincide).
 // Compressed G1: 48 bytes little-endian x; in the last byte bit 7 = "y is the lexicographically larger root", bit 6 = infinity.
 #include "ctx.h"
 #include "host_field.hpp"
@@ -206,8 +207,15 @@ int32_t aleo_mi355x_proof_to_bytes(void* out, size_t* len, const aleo_mi355x_pro
     u64le(p->n_circuits); for (size_t i = 0; i < p->n_circuits; ++i) u64le(p->batch_sizes[i]);
     g1(p->witness_commitments, 3 * instances);
     b.push_back(p->mask_poly ? 1 : 0); if (p->mask_poly) g1(p->mask_poly, 1);
-    g1(p->g_1, 1); g1(p->h_1, 1); g1(p->g_abc, 3 * p->n_circuits); g1(p->h_2, 1);
-    fr(p->evaluations, p->n_evaluations);
+    g1(p->g_1, 1); g1(p->h_1, 1);
+    // the parts list g_a, g_b, g_c (and their evaluations) circuit by circuit; upstream's Commitments / Evaluations hold one vector per matrix
+    // [UPSTREAM-RECALL]: every g_a, then every g_b, then every g_c.  With one circuit — the reference's proof string — both orders coincide.
+    const size_t m = p->n_circuits;
+    for (size_t M = 0; M < 3; ++M) for (size_t j = 0; j < m; ++j) g1((const uint8_t*)p->g_abc + 104 * (3 * j + M), 1);
+    g1(p->h_2, 1);
+    if (p->n_evaluations != instances + 1 + 3 * m) { g_last_error = "proof_to_bytes: expected one z_b evaluation per instance, g_1 and three per circuit"; return ALEO_MI355X_ERR_BAD_ARG; }
+    fr(p->evaluations, instances + 1);
+    for (size_t M = 0; M < 3; ++M) for (size_t j = 0; j < m; ++j) fr((const uint8_t*)p->evaluations + 32 * (instances + 1 + 3 * j + M), 1);
     u64le(p->n_circuits); fr(p->sums, 3 * p->n_circuits);
     u64le(p->n_openings);
     for (size_t i = 0; i < p->n_openings; ++i) {

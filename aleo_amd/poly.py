@@ -44,29 +44,20 @@ def fr_eval_batch_device(d_out: int, d_polys, lens, points_mont, stream: int = 0
     check(lib().aleo_mi355x_fr_eval_batch_device(ctypes.c_void_p(d_out), ptrs, ln, z.ctypes.data_as(ctypes.c_void_p), k, ctypes.c_void_p(stream)), 'fr_eval_batch_device')
 
 
-def fr_random_device(d_dst: int, n: int, seed: int, first_index: int = 0, montgomery: bool = True, stream: int = 0):
-    """Elements first_index.. of the counter-based random stream `seed` (see random_fr for the definition), written in HBM."""
-    check(lib().aleo_mi355x_fr_random_device(ctypes.c_void_p(d_dst), n, seed & 0xFFFFFFFFFFFFFFFF, first_index, 1 if montgomery else 0, ctypes.c_void_p(stream)), 'fr_random_device')
+def fr_random_device(d_dst: int, n: int, seed, first_index: int = 0, montgomery: bool = True, stream: int = 0):
+    """Elements first_index.. of the proof's random stream (ChaCha20 under the 32-byte `seed`, rejection-sampled below r), written in HBM."""
+    from ._lib import seed32
+    check(lib().aleo_mi355x_fr_random_device(ctypes.c_void_p(d_dst), n, seed32(seed), first_index, 1 if montgomery else 0, ctypes.c_void_p(stream)), 'fr_random_device')
 
 
-_M64 = (1 << 64) - 1
-
-
-def _mix(z):
-    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & _M64; z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & _M64
-    return z ^ (z >> 31)
-
-
-def random_fr(seed: int, index: int) -> int:
-    """Element `index` of the stream the device kernel writes, on the host (python int): first candidate below r."""
-    from .synth import FR_MODULUS
-    j = 0
-    while True:
-        v = 0
-        for l in range(4): v |= _mix((seed + (4 * index + l + 1) * 0x9E3779B97F4A7C15 + j * 0xD1B54A32D192ED03) & _M64) << (64 * l)
-        v &= (1 << 253) - 1
-        if v < FR_MODULUS: return v
-        j += 1
+def random_fr(seed, index: int, n: int = 1):
+    """Elements index.. of the same stream on the host (python ints; aleo_mi355x_fr_random): the blinding scalars of a proof."""
+    import numpy as np
+    from ._lib import seed32
+    out = np.zeros((n, 4), dtype=np.uint64)
+    check(lib().aleo_mi355x_fr_random(out.ctypes.data_as(ctypes.c_void_p), n, seed32(seed), index), 'fr_random')
+    vals = [sum(int(out[i, l]) << (64 * l) for l in range(4)) for i in range(n)]
+    return vals[0] if n == 1 else vals
 
 
 def fr_lincomb_device(d_dst: int, n: int, c0, terms, stream: int = 0):

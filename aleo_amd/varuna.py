@@ -6,15 +6,15 @@ Everything that scales with the circuit runs on the device through the C ABI (sp
 kernels, batch inversion, division by X − z, batched SonicKZG10 commitments and the two opening MSMs); the host keeps the transcript, the
 handful of challenge-dependent constants and the O(|X|) public-input polynomial.  The protocol is Marlin's AHP for R1CS in snarkVM's
 arrangement (see oracle/varuna_ref.py for the statement of every identity; that CPU restatement is what tests compare this module with,
-byte for byte).  Differences from upstream that make the proofs NOT interchangeable with snarkVM's: SHA-256 transcript instead of the
-Poseidon sponge, a synthetic SRS.  The proof's byte layout is upstream's (aleo_mi355x_proof_to_bytes)."""
+byte for byte).  The transcript is upstream's construction — the Poseidon sponge over Fq behind the algebraic-sponge interface, run by the
+library (aleo_mi355x_fs_*; absorb order [UPSTREAM-RECALL], not checkable offline) — the blinding comes from a ChaCha20 stream under the proof's
+32-byte seed, the SRS is synthetic.  The proof's byte layout is upstream's (aleo_mi355x_proof_to_bytes)."""
 from __future__ import annotations
 import ctypes
-import hashlib
 import numpy as np
 import torch
 from . import synth, wire
-from ._lib import lib, check, UnsatisfiedAssignment
+from ._lib import lib, check, seed32, UnsatisfiedAssignment
 from .fft import EvaluationDomain, FORWARD, INVERSE
 from .kzg import CommitterKey, SonicKZG10, KZG10
 from .msm import PinnedBases
@@ -24,7 +24,7 @@ from .poly import (fr_vec_op_device, fr_lin_device, fr_powers_device, fr_gather_
 R = synth.FR_MODULUS
 _RM = (1 << 256) % R
 _R2 = _RM * _RM % R
-LABEL = b'aleo-mi355x/varuna-synthetic/v1'
+PROTOCOL_NAME = b'VARUNA-2023'
 HIDING_COEFFS = 3
 TWO_ADIC_ROOT = 8065159656716812877374967518403273466521432693661810619979959746626482506078
 
@@ -67,12 +67,29 @@ def h_positions(n_vars, n_public, n_x, n_h) -> np.ndarray:
     return np.where(v < n_public, v * ratio, j + j // max(ratio - 1, 1) + 1).astype(np.int64)
 
 
-class Transcript:
-    def __init__(self): self.state = hashlib.sha256(LABEL).digest()
-    def absorb(self, data: bytes): self.state = hashlib.sha256(self.state + bytes(data)).digest()
-    def challenge(self, label: bytes) -> int:
-        self.state = hashlib.sha256(self.state + label).digest()
-        return int.from_bytes(self.state, 'little') % R
+class FiatShamir:
+    """The prover's transcript: `PoseidonSponge<Fq, 2, 1>` behind upstream's AlgebraicSponge interface, run by the library (poseidon.hpp through
+    aleo_mi355x_fs_*) — the same sponge aleo_mi355x_varuna_prove* runs internally."""
+    def __init__(self):
+        h = ctypes.c_uint64(0); check(lib().aleo_mi355x_fs_new(ctypes.byref(h)), 'fs_new'); self.h = h.value
+    def __del__(self):
+        try:
+            if getattr(self, 'h', 0): lib().aleo_mi355x_fs_free(self.h); self.h = 0
+        except Exception: pass                                                      # interpreter shutdown
+    def absorb_bytes(self, data: bytes):
+        buf = (ctypes.c_uint8 * max(len(data), 1)).from_buffer_copy(bytes(data) or b'\0')
+        check(lib().aleo_mi355x_fs_absorb_bytes(self.h, buf, len(data)), 'fs_absorb_bytes')
+    def absorb_g1(self, affine104: np.ndarray):
+        a = np.ascontiguousarray(affine104, dtype=np.uint8).reshape(-1, 104)
+        check(lib().aleo_mi355x_fs_absorb_g1(self.h, a.ctypes.data_as(ctypes.c_void_p), 104, a.shape[0]), 'fs_absorb_g1')
+    def absorb_fr(self, values):
+        a = np.stack([synth.int_to_limbs(int(v) % R, 4) for v in values]) if len(values) else np.zeros((0, 4), dtype=np.uint64)
+        check(lib().aleo_mi355x_fs_absorb_fr(self.h, a.ctypes.data_as(ctypes.c_void_p), a.shape[0]), 'fs_absorb_fr')
+    def squeeze(self, n: int, short: bool = False):
+        out = np.zeros((max(n, 1), 4), dtype=np.uint64)
+        check(lib().aleo_mi355x_fs_squeeze_fr(self.h, out.ctypes.data_as(ctypes.c_void_p), n, 1 if short else 0), 'fs_squeeze_fr')
+        return [synth.limbs_to_int(out[i]) for i in range(n)]
+    def squeeze_short(self) -> int: return self.squeeze(1, True)[0]
 
 
 def synthetic_committer_key(tau: int, s_gamma: int, max_degree: int, n_gamma: int = HIDING_COEFFS, lagrange_size: int = 0, range_window: int = 0) -> CommitterKey:
@@ -233,7 +250,7 @@ class _NativeIndex(ctypes.Structure):
     """aleo_mi355x_varuna_index (include/aleo_mi355x.h)."""
     _fields_ = ([(n, ctypes.c_uint64) for n in ('n_h', 'n_k_a', 'n_k_b', 'n_k_c', 'n_x', 'n_public', 'n_vars', 'committer_key', 'max_degree', 'gamma_offset', 'lagrange_offset')] +
                 [(n, ctypes.c_void_p) for n in ('positions', 'positions_device', 'a_row_ptr', 'a_col', 'a_val', 'b_row_ptr', 'b_col', 'b_val', 't_row_ptr', 't_col', 't_val',
-                                                'vx_inv', 'k_evals', 'k_idx', 'k_polys', 'k2_evals', 'vk_bytes')] + [('vk_len', ctypes.c_size_t)])
+                                                'vx_inv', 'k_evals', 'k_idx', 'k_polys', 'k2_evals', 'vk_bytes')] + [('vk_len', ctypes.c_size_t), ('vk_affine', ctypes.c_void_p)])
 
 
 def native_index(ix: CircuitIndex) -> _NativeIndex:
@@ -247,6 +264,7 @@ def native_index(ix: CircuitIndex) -> _NativeIndex:
     ix._pos32 = np.ascontiguousarray(ix.pos, dtype=np.uint32); ix._vk = np.frombuffer(ix.vk_bytes, dtype=np.uint8).copy()
     ix._pos_dev = torch.from_numpy(ix._pos32.view(np.int32)).cuda()
     n.positions = ix._pos32.ctypes.data; n.positions_device = ix._pos_dev.data_ptr(); n.vk_bytes = ix._vk.ctypes.data; n.vk_len = ix._vk.shape[0]
+    ix._vk_aff = np.ascontiguousarray(ix.index_commitments, dtype=np.uint8).reshape(12, 104); n.vk_affine = ix._vk_aff.ctypes.data
     for m in 'ab':
         rp, col, val = ix.fwd[m]
         setattr(n, m + '_row_ptr', rp.data_ptr()); setattr(n, m + '_col', col.data_ptr()); setattr(n, m + '_val', val.ptr())
@@ -256,21 +274,22 @@ def native_index(ix: CircuitIndex) -> _NativeIndex:
     return n
 
 
-def prove_native(index: CircuitIndex, assignment, seed: int) -> bytes:
+def prove_native(index: CircuitIndex, assignment, seed=None) -> bytes:
     """The same proof through ONE call of the C ABI (aleo_mi355x_varuna_prove: transcript, constants and all launches in C++); returns the
-    proof bytes.  Thread-safe: concurrent calls are served by separate slots of the library."""
+    proof bytes.  seed: 32 bytes of entropy (None = os.urandom; an int only for reproducible tests).  Thread-safe: concurrent calls are served
+    by separate slots of the library."""
     if isinstance(assignment, np.ndarray) and assignment.ndim == 2: assignment = [assignment]
     zs = [np.ascontiguousarray(a, dtype=np.uint64).reshape(-1, 4) for a in assignment]
     nv = index.n_public + index.n_private
     if any(z.shape[0] != nv for z in zs): raise ValueError('assignment length differs from the number of variables of the circuit')
     ptrs = (ctypes.c_void_p * len(zs))(*[z.ctypes.data for z in zs])
     out = np.zeros(1100 + 200 * len(zs), dtype=np.uint8); n = ctypes.c_size_t(out.shape[0])
-    check(lib().aleo_mi355x_varuna_prove(ctypes.byref(native_index(index)), ptrs, len(zs), seed & 0xFFFFFFFFFFFFFFFF, out.ctypes.data_as(ctypes.c_void_p),
+    check(lib().aleo_mi355x_varuna_prove(ctypes.byref(native_index(index)), ptrs, len(zs), seed32(seed), out.ctypes.data_as(ctypes.c_void_p),
                                          ctypes.byref(n)), 'varuna_prove')
     return out[:n.value].tobytes()
 
 
-def prove_batch_native(indexes, assignments, seed: int) -> bytes:
+def prove_batch_native(indexes, assignments, seed=None) -> bytes:
     """One proof over several circuits (`Varuna::prove_batch` with a map of proving keys): indexes = NativeCircuitIndex objects built against one
     committer key, assignments[j] = the list of instances (uint64[n_vars, 4] canonical) of circuit j.  One call of the C ABI
     (aleo_mi355x_varuna_prove_batch_indexed); returns the proof bytes."""
@@ -284,7 +303,7 @@ def prove_batch_native(indexes, assignments, seed: int) -> bytes:
     handles = (ctypes.c_uint64 * len(indexes))(*[ix.handle for ix in indexes]); counts = (ctypes.c_size_t * len(ks))(*ks)
     ptrs = (ctypes.c_void_p * len(zs))(*[z.ctypes.data for z in zs])
     out = np.zeros(1200 + 400 * len(ks) + 200 * len(zs), dtype=np.uint8); n = ctypes.c_size_t(out.shape[0])
-    check(lib().aleo_mi355x_varuna_prove_batch_indexed(handles, len(indexes), ptrs, counts, seed & 0xFFFFFFFFFFFFFFFF, out.ctypes.data_as(ctypes.c_void_p), ctypes.byref(n)),
+    check(lib().aleo_mi355x_varuna_prove_batch_indexed(handles, len(indexes), ptrs, counts, seed32(seed), out.ctypes.data_as(ctypes.c_void_p), ctypes.byref(n)),
           'varuna_prove_batch')
     return out[:n.value].tobytes()
 
@@ -304,11 +323,11 @@ class Trace:
     @property
     def transitions(self) -> int: return sum(len(a) for a in self._assignments)
 
-    def prove_execution(self, seed: int) -> bytes:
+    def prove_execution(self, seed=None) -> bytes:
         if not self._keys: raise ValueError('Trace.prove_execution: no transitions')
         return prove_batch_native(self._keys, self._assignments, seed)
 
-    def prove_fee(self, seed: int) -> bytes:
+    def prove_fee(self, seed=None) -> bytes:
         if self.transitions != 1: raise ValueError('Trace.prove_fee: a fee is exactly one transition')
         return prove_batch_native(self._keys, self._assignments, seed)
 
@@ -348,13 +367,13 @@ class NativeCircuitIndex:
         while n_h < max(n_constraints, n_x + n_private, 2 * n_x): n_h *= 2
         return ck.lagrange_offset if ck.lagrange_size == n_h else 0      # only the Lagrange powers of THIS circuit's domain are of use
 
-    def prove(self, assignment, seed: int) -> bytes:
+    def prove(self, assignment, seed=None) -> bytes:
         if isinstance(assignment, np.ndarray) and assignment.ndim == 2: assignment = [assignment]
         zs = [np.ascontiguousarray(a, dtype=np.uint64).reshape(-1, 4) for a in assignment]
         if any(z.shape[0] != self.n_vars for z in zs): raise ValueError('assignment length differs from the number of variables of the circuit')
         ptrs = (ctypes.c_void_p * len(zs))(*[z.ctypes.data for z in zs])
         out = np.zeros(1100 + 200 * len(zs), dtype=np.uint8); n = ctypes.c_size_t(out.shape[0])
-        check(lib().aleo_mi355x_varuna_prove_indexed(self.handle, ptrs, len(zs), seed & 0xFFFFFFFFFFFFFFFF, out.ctypes.data_as(ctypes.c_void_p), ctypes.byref(n)),
+        check(lib().aleo_mi355x_varuna_prove_indexed(self.handle, ptrs, len(zs), seed32(seed), out.ctypes.data_as(ctypes.c_void_p), ctypes.byref(n)),
               'varuna_prove_indexed')
         return out[:n.value].tobytes()
 
@@ -396,7 +415,7 @@ def randomness_layout(n_h, k=1):
 class Prover:
     """State of one proof (one circuit, k instances): the round functions in the order upstream calls them."""
 
-    def __init__(self, index: CircuitIndex, assignments, seed: int, stream: torch.cuda.Stream = None):
+    def __init__(self, index: CircuitIndex, assignments, seed=None, stream: torch.cuda.Stream = None):
         """assignments: one canonical uint64[n_vars,4] array per instance (or a single array), public variables first (z_0 = 1); seed: of the
         proof's random stream (poly.random_fr): the device draws the mask polynomial from it, the host the blinding scalars."""
         self.ix = index; self.stream = stream or index.stream; self.s = self.stream.cuda_stream
@@ -404,11 +423,11 @@ class Prover:
         self.z = [np.ascontiguousarray(a, dtype=np.uint64).reshape(-1, 4) for a in assignments]
         self.k = len(self.z)
         if not 1 <= self.k <= MAX_INSTANCES: raise ValueError('between 1 and %d instances per proof' % MAX_INSTANCES)
-        self.seed = seed & 0xFFFFFFFFFFFFFFFF
+        self.seed = bytes(seed32(seed))
         self.lay = randomness_layout(index.n_h, self.k)
-        self.tr = Transcript(); self.c = {}
+        self.fs = FiatShamir(); self.c = {}
 
-    def _ri(self, first, n=1): return [random_fr(self.seed, first + i) for i in range(n)]
+    def _ri(self, first, n=1): v = random_fr(self.seed, first, n); return v if n > 1 else [v]
 
     # ---- round 1 ------------------------------------------------------------------------------------------------------------------
     def first_round(self):
@@ -461,10 +480,12 @@ class Prover:
             segs += [(self.mask.ptr(), 3 * n_h, 0, 3 * k), (bl.ptr(HIDING_COEFFS * 3 * k), HIDING_COEFFS, ix.ck.gamma_offset, 3 * k)]
             out = SonicKZG10.commit_segments_device(ix.ck, segs, 3 * k + 1, s)
         self.witness_commitments = out[:3 * k]; self.c['mask'] = out[3 * k]
-        self.tr.absorb(ix.vk_bytes); self.tr.absorb(b''.join(_fr_bytes(v) for xe in self.x_evals for v in xe))
-        self.tr.absorb(wire.g1_compress(out).tobytes())
-        self.alpha, self.eta_b, self.eta_c = self.tr.challenge(b'alpha'), self.tr.challenge(b'eta_b'), self.tr.challenge(b'eta_c')
-        self.comb = [1] + [self.tr.challenge(b'combiner' + i.to_bytes(4, 'little')) for i in range(1, k)]
+        fs = self.fs                                                                # Varuna::init_sponge [UPSTREAM-RECALL], then the first commitments
+        fs.absorb_bytes(PROTOCOL_NAME); fs.absorb_bytes(k.to_bytes(8, 'little'))
+        for xe in self.x_evals: fs.absorb_fr(xe)
+        fs.absorb_g1(ix.index_commitments); fs.absorb_g1(out)
+        self.comb = [1] + fs.squeeze(k - 1)                                         # one circuit: k − 1 instance combiners, then alpha, eta_b, eta_c
+        self.alpha, self.eta_b, self.eta_c = fs.squeeze(3)
 
     # ---- round 2: the first sumcheck -----------------------------------------------------------------------------------------------
     def second_round(self):
@@ -507,8 +528,8 @@ class Prover:
         if self.g1.host(0, 1).any():                                                   # after the commitments (the stream has drained): 32 bytes
             raise UnsatisfiedAssignment('the assignment does not satisfy the circuit (first sumcheck: the sum over H is not zero)')
         self.c['g_1'], self.c['h_1'] = out[0], out[1]
-        self.tr.absorb(wire.g1_compress(out).tobytes())
-        self.beta = self.tr.challenge(b'beta')
+        self.fs.absorb_g1(out)
+        self.beta = self.fs.squeeze(1)[0]
 
     # ---- round 3: three rational sumchecks over K -----------------------------------------------------------------------------------
     def third_round(self):
@@ -531,8 +552,8 @@ class Prover:
         self.sigma = [_from_mont(f0[m]) * km[m] % R for m in range(3)]
         out = SonicKZG10.commit(ix.ck, [((self.fp(m, 1), km[m] - 1), km[m] - 2, None) for m in range(3)], device=True, stream=s)
         for k, name in enumerate(('g_a', 'g_b', 'g_c')): self.c[name] = out[k]
-        self.tr.absorb(b''.join(_fr_bytes(v) for v in self.sigma) + wire.g1_compress(out).tobytes())
-        self.delta = [1, self.tr.challenge(b'delta_b'), self.tr.challenge(b'delta_c')]
+        self.fs.absorb_g1(out); self.fs.absorb_fr(self.sigma)
+        self.delta = [1] + self.fs.squeeze(2)
 
     # ---- round 4 ----------------------------------------------------------------------------------------------------------------------
     def fourth_round(self):
@@ -552,8 +573,8 @@ class Prover:
         fr_lincomb_device(self.h2.ptr(), n_k, None, terms, s)                         # h_2 = sum_M delta_M h_M
         out = SonicKZG10.commit(ix.ck, [((self.h2.ptr(), n_k), None, None)], device=True, stream=s)
         self.c['h_2'] = out[0]
-        self.tr.absorb(wire.g1_compress(out).tobytes())
-        self.gamma = self.tr.challenge(b'gamma')
+        self.fs.absorb_g1(out)
+        self.gamma = self.fs.squeeze(1)[0]
 
     # ---- evaluations and openings ------------------------------------------------------------------------------------------------------
     def finish(self) -> Proof:
@@ -566,13 +587,15 @@ class Prover:
         self.stream.synchronize()
         evals = [_from_mont(v) for v in self._ev.host(0, k + 4)]
         zb_beta = evals[:k]; g1_beta, ga, gb, gc = evals[k:]
-        self.tr.absorb(b''.join(_fr_bytes(v) for v in evals)); xi = self.tr.challenge(b'xi')
+        self.fs.absorb_fr(evals)                                                    # one circuit: the serialised order is this one
+        ch_b = [self.fs.squeeze_short() for _ in range(k + 2)]                      # one short challenge per opened polynomial: g_1, z_b,i, LC1 at beta;
+        ch_g = [self.fs.squeeze_short() for _ in range(4)]                          # g_a, g_b, g_c, LC2 at gamma
         alpha, beta, gamma = self.alpha, self.beta, self.gamma
         # linear combination of the first sumcheck, opened at beta together with g_1 and the z_b,i
         r_ab = (_vanish(n_h, alpha) - _vanish(n_h, beta)) * _inv(alpha - beta) % R
         t_beta = (self.sigma[0] + self.eta_b * self.sigma[1] + self.eta_c * self.sigma[2]) % R
-        xl = pow(xi, k + 1, R); const = (-beta * g1_beta) % R
-        terms = [(self.mask.ptr(), 3 * n_h, _mont(xl)), (self.h1.ptr(), 2 * n_h, _mont(-xl * _vanish(n_h, beta))), (self.g1.ptr(1), n_h - 1, one)]
+        xl = ch_b[k + 1]; const = (-beta * g1_beta) % R
+        terms = [(self.mask.ptr(), 3 * n_h, _mont(xl)), (self.h1.ptr(), 2 * n_h, _mont(-xl * _vanish(n_h, beta))), (self.g1.ptr(1), n_h - 1, _mont(ch_b[0]))]
         bl = [0] * HIDING_COEFFS
         def axpy(coef, src):
             for j, v in enumerate(src): bl[j] = (bl[j] + coef * v) % R
@@ -581,7 +604,7 @@ class Prover:
             x_beta = 0
             for v in reversed(self.x_poly[i]): x_beta = (x_beta * beta + v) % R
             ci = self.comb[i]
-            k_za = xl * ci % R * r_ab % R * (1 + self.eta_c * zb_beta[i]) % R; k_w = (-xl * ci % R * t_beta % R * _vanish(n_x, beta)) % R; k_zb = pow(xi, 1 + i, R)
+            k_za = xl * ci % R * r_ab % R * (1 + self.eta_c * zb_beta[i]) % R; k_w = (-xl * ci % R * t_beta % R * _vanish(n_x, beta)) % R; k_zb = ch_b[1 + i]
             const = (const + ci * (r_ab * self.eta_b % R * zb_beta[i] - t_beta * x_beta)) % R
             terms += [(self.za(i), L, _mont(k_za)), (self.w(i), L, _mont(k_w)), (self.zb(i), L, _mont(k_zb))]
             axpy(k_w, self.blind[3 * i]); axpy(k_za, self.blind[3 * i + 1]); axpy(k_zb, self.blind[3 * i + 2])
@@ -594,7 +617,7 @@ class Prover:
         wq = _Vec(3 * n_h); blq = _Vec(HIDING_COEFFS - 1, _mont_rows(blw))
         divide_by_linear_device(wq.ptr(), self._ev.ptr(k + 5), pb.ptr(), 3 * n_h, _mont(beta), s)
         # linear combination of the second sumcheck, opened at gamma together with g_a, g_b, g_c
-        xi2 = xi * xi % R; xi3 = xi2 * xi % R; vk_gamma = _vanish(n_k, gamma)          # K: the largest non-zero domain
+        xi3 = ch_g[3]; vk_gamma = _vanish(n_k, gamma)                                # K: the largest non-zero domain
         pg = _Vec(n_k); const = 0; terms = []
         for m, gk in enumerate((ga, gb, gc)):
             fm = (gamma * gk + self.sigma[m] * _inv(km[m])) % R
@@ -603,7 +626,7 @@ class Prover:
                 terms.append((_kp(ix, ix.k_polys, m, j), km[m], _mont(coef)))
             const = (const - d * fm % R * alpha % R * beta) % R
         terms.append((self.h2.ptr(), n_k, _mont(-xi3 * vk_gamma)))
-        terms += [(self.fp(m, 1), km[m] - 1, _mont(coef)) for m, coef in enumerate((1, xi, xi2))]
+        terms += [(self.fp(m, 1), km[m] - 1, _mont(ch_g[m])) for m in range(3)]
         fr_lincomb_device(pg.ptr(), n_k, _mont(const), terms, s)
         gq = _Vec(n_k)
         divide_by_linear_device(gq.ptr(), self._ev.ptr(k + 6), pg.ptr(), n_k, _mont(gamma), s)
@@ -612,9 +635,9 @@ class Prover:
         return Proof(self.witness_commitments, dict(self.c), evals, list(self.sigma), [(open_beta, random_v), (open_gamma, None)])
 
 
-def prove(index: CircuitIndex, assignment, seed: int, stream: torch.cuda.Stream = None) -> Proof:
-    """Varuna::prove_batch for one circuit with one to eight instances (one assignment array, or a list of them); `seed` selects the proof's
-    random stream.  Proofs of one index may be
+def prove(index: CircuitIndex, assignment, seed=None, stream: torch.cuda.Stream = None) -> Proof:
+    """Varuna::prove_batch for one circuit with one to eight instances (one assignment array, or a list of them); `seed`: 32 bytes of entropy for the proof's
+    random stream (None = os.urandom; an int only for reproducible tests).  Proofs of one index may be
     produced concurrently from several host threads, each on its own `stream` (the index is read-only while proving)."""
     import time
     with torch.cuda.stream(stream or index.stream):

@@ -210,11 +210,14 @@ int32_t aleo_mi355x_fr_gather_mul_device(void* d_dst, size_t n, const void* d_sc
 /* out[q] = p_q(z_q) for k <= 12 polynomials in two launches (d_polys, lens, z_mont: host arrays of k device pointers / lengths /
  * 32-byte Montgomery points; d_out: k x 32 bytes, device): the evaluations a proof carries (z_b, g_1 at beta; g_a, g_b, g_c at gamma). */
 int32_t aleo_mi355x_fr_eval_batch_device(void* d_out, const void* const* d_polys, const size_t* lens, const void* z_mont, size_t k, void* stream);
-/* Prover randomness generated in HBM.  Element i of stream `seed` = the first candidate j = 0, 1, ... below r, candidate (i, j) being the
- * low 253 bits of four SplitMix64 outputs mix(seed + (4 i + l + 1) * 0x9E3779B97F4A7C15 + j * 0xD1B54A32D192ED03), l = 0..3 (little-endian
- * 64-bit limbs; mix = the SplitMix64 finaliser).  Writes elements first_index .. first_index + n - 1, canonical or (montgomery != 0)
- * Montgomery.  Counter-based: the host can draw single elements of the same stream (the blinding scalars) without the device. */
-int32_t aleo_mi355x_fr_random_device(void* d_dst, size_t n, uint64_t seed, uint64_t first_index, int32_t montgomery, void* stream);
+/* Prover randomness.  `seed` is 32 bytes of caller entropy per proof (what `rand::thread_rng()` is to the reference's call sites,
+ * /root/reference/rust/src/program/execute.rs:74): the key of a ChaCha20 stream (20 rounds, 64-bit block counter, 64-bit nonce).  Element i =
+ * the first candidate below r among the two 32-byte halves (little-endian, low 253 bits) of block(counter = i, nonce = attempt), attempt = 0, 1, ...
+ * (rejection sampling: uniform over Fr).  _device writes elements first_index .. first_index + n - 1 in HBM, canonical or (montgomery != 0)
+ * Montgomery; aleo_mi355x_fr_random is the same stream on the host (out: n x 32 bytes canonical) — counter-based, so the host draws the handful
+ * of blinding scalars of a proof while the device draws the 3|H| mask coefficients, and nothing is uploaded.  Never reuse a seed. */
+int32_t aleo_mi355x_fr_random_device(void* d_dst, size_t n, const uint8_t seed[32], uint64_t first_index, int32_t montgomery, void* stream);
+int32_t aleo_mi355x_fr_random(void* out, size_t n, const uint8_t seed[32], uint64_t first_index);
 /* dst[i] = c0 [i == 0] + sum_j coeffs[j] * terms[j][i], term j contributing for i < lens[j] (k <= 28 terms; d_terms / lens / coeffs_mont
  * host arrays; c0_mont may be NULL): the linear combinations opened at beta and gamma, in one pass.  dst may be one of the terms (same offset). */
 int32_t aleo_mi355x_fr_lincomb_device(void* d_dst, size_t n, const void* c0_mont, const void* const* d_terms, const size_t* lens, const void* coeffs_mont, size_t k, void* stream);
@@ -262,8 +265,10 @@ int32_t aleo_mi355x_fr_from_bytes(void* out_fr_mont, const void* in32, size_t n)
 int32_t aleo_mi355x_bech32m_encode(char* out, size_t cap, const char* hrp, const void* data, size_t len);
 int32_t aleo_mi355x_bech32m_decode(void* out, size_t* len, char* hrp_out, size_t hrp_cap, const char* s);
 /* The byte layout of a Varuna proof (Proof::to_bytes_le) from its parts; points as snarkVM Affine (104 bytes), field elements
- * Montgomery Fr.  Field order read off the reference's own proof (one circuit, one instance); for several circuits the order
- * of g_a/g_b/g_c and of the evaluations is [UPSTREAM-RECALL].  *len: in = capacity of out, out = bytes written. */
+ * Montgomery Fr.  Field order read off the reference's own proof (one circuit, one instance).  The parts list g_a, g_b, g_c
+ * and their evaluations circuit by circuit; the BYTES carry every g_a, then every g_b, then every g_c (one vector per matrix, as upstream's
+ * Commitments / Evaluations structs hold them [UPSTREAM-RECALL] — unverified for more than one circuit: no such reference vector exists; with one
+ * circuit both orders coincide).  n_evaluations must be instances + 1 + 3 n_circuits.  *len: in = capacity of out, out = bytes written. */
 typedef struct {
   const uint64_t* batch_sizes; size_t n_circuits;      /* instances per circuit */
   const void* witness_commitments;                      /* 3 per instance: w, z_a, z_b */
@@ -290,12 +295,13 @@ int32_t aleo_mi355x_proof_to_bytes(void* out, size_t* len, const aleo_mi355x_pro
  *                 earlier |K|));  k_idx  device uint32, matrix after matrix: row positions, column positions (|K_M| each; M starts at 2 * sum)
  *   k_polys       the same four polynomials per matrix as coefficients (layout of k_evals);  k2_evals  their values on the domain of size 2|K_M|
  *                 (2|K_M| each; M starts at element 8 * sum)
- *   vk_bytes      host: what the transcript absorbs first (compressed index commitments, domain sizes)
+ *   vk_bytes      host: the circuit's verifying key as bytes (12 compressed index commitments, 5 domain sizes); vk_affine: the commitments as the
+ *                 transcript absorbs them (12 x 104-byte G1Affine; NULL = decompress vk_bytes per proof)
  * committer_key: a pinned set holding powers[0..max_degree] and, from gamma_offset, at least 3 hiding powers; when lagrange_offset != 0 also, from
  * lagrange_offset, the n_h Lagrange-basis powers L_i(tau) G of the domain H followed by v_H(tau) G: w, z_a, z_b are then committed from their
  * EVALUATIONS (KZG10::commit_lagrange: the same group elements; a witness of bits stays a vector of small scalars for the MSM).
- * assignments: n_instances host pointers to n_vars x 32 bytes canonical (public variables first, z_0 = 1).  seed: the proof's random stream
- * (aleo_mi355x_fr_random_device).  out_proof / len: Proof::to_bytes_le layout, 901 + 176 (n_instances - 1) bytes; *len in = capacity.
+ * assignments: n_instances host pointers to n_vars x 32 bytes canonical (public variables first, z_0 = 1).  seed: 32 bytes of fresh
+ * entropy per proof, the key of the proof's random stream (aleo_mi355x_fr_random_device; a repeated seed repeats the blinding).  out_proof / len: Proof::to_bytes_le layout, 901 + 176 (n_instances - 1) bytes; *len in = capacity.
  * Blocking; concurrent calls from several threads run on separate slots.  aleo_mi355x_varuna_last_timing: wall ms of the calling thread's
  * last proof: rounds 1..4, openings, total, time inside the five commitment calls, their host tails. */
 typedef struct {
@@ -306,6 +312,7 @@ typedef struct {
   const void *a_row_ptr, *a_col, *a_val, *b_row_ptr, *b_col, *b_val, *t_row_ptr, *t_col, *t_val;
   const void *vx_inv, *k_evals, *k_idx, *k_polys, *k2_evals;
   const void* vk_bytes; size_t vk_len;
+  const void* vk_affine;             /* the twelve index commitments as 104-byte G1Affine (what the transcript absorbs); may be NULL: decompressed from vk_bytes per proof */
 } aleo_mi355x_varuna_index;
 /* The index built by the library itself from the R1CS (AHPForR1CS::index shape: the arithmetisation above + the twelve index commitments)
  * and kept in HBM under a handle.  Matrices: CSR over the variables (uint32 row_ptr[n_constraints + 1], uint32 col[nnz] = variable index
@@ -322,19 +329,39 @@ int32_t aleo_mi355x_varuna_index_build(uint64_t* index_handle, uint64_t committe
 int32_t aleo_mi355x_varuna_index_export(uint64_t index_handle, aleo_mi355x_varuna_index* out);
 int32_t aleo_mi355x_varuna_index_vk(uint64_t index_handle, void* out, size_t* len);
 int32_t aleo_mi355x_varuna_index_free(uint64_t index_handle);
-int32_t aleo_mi355x_varuna_prove_indexed(uint64_t index_handle, const void* const* assignments, size_t n_instances, uint64_t seed, void* out_proof, size_t* len);
-int32_t aleo_mi355x_varuna_prove(const aleo_mi355x_varuna_index* index, const void* const* assignments, size_t n_instances, uint64_t seed, void* out_proof, size_t* len);
+int32_t aleo_mi355x_varuna_prove_indexed(uint64_t index_handle, const void* const* assignments, size_t n_instances, const uint8_t seed[32], void* out_proof, size_t* len);
+int32_t aleo_mi355x_varuna_prove(const aleo_mi355x_varuna_index* index, const void* const* assignments, size_t n_instances, const uint8_t seed[32], void* out_proof, size_t* len);
 /* One proof over SEVERAL circuits — upstream's `Varuna::prove_batch(keys_to_constraints: BTreeMap<&ProvingKey, &[Assignment]>)`, what
  * `Trace::prove_execution` / `prove_fee` build from the transitions of a transaction (/root/reference/rust/src/program/execute.rs:74).
  * index_handles: 1..8 indexes built against ONE committer key (same max_degree / gamma_offset), in the order the proof lists them;
  * n_instances[j]: 1..8 assignments of circuit j (at most 32 in all); assignments: the pointers of circuit 0's instances, then circuit 1's, ...
  * The circuits share the transcript and every challenge, one mask / g_1 / h_1 over the largest constraint domain, one h_2 over the largest non-zero
  * domain and the two openings; a smaller circuit enters behind the selector v_{H*} / v_{H_j}.  out_proof: Proof::to_bytes_le layout —
- * batch sizes, 3 witness commitments per instance, mask, g_1, h_1, g_a/g_b/g_c per circuit, h_2, evaluations, sums, openings.  With one circuit
+ * batch sizes, 3 witness commitments per instance, mask, g_1, h_1, every g_a, every g_b, every g_c (one vector per matrix over the circuits,
+ * [UPSTREAM-RECALL]; unverifiable offline for more than one circuit — the reference's proof string has one), h_2, evaluations (z_b's, g_1,
+ * then g_a / g_b / g_c likewise), sums per circuit, openings.  With one circuit
  * the bytes are those of aleo_mi355x_varuna_prove_indexed.  ALEO_MI355X_ERR_UNSATISFIED if any assignment violates its circuit. */
-int32_t aleo_mi355x_varuna_prove_batch_indexed(const uint64_t* index_handles, size_t n_circuits, const void* const* assignments, const size_t* n_instances, uint64_t seed,
+int32_t aleo_mi355x_varuna_prove_batch_indexed(const uint64_t* index_handles, size_t n_circuits, const void* const* assignments, const size_t* n_instances, const uint8_t seed[32],
                                                void* out_proof, size_t* len);
 int32_t aleo_mi355x_varuna_last_timing(double* out_ms, int32_t cap);
+
+/* snarkVM's Poseidon on the host (no GPU needed).  Parameters: Grain LFSR, alpha = 17, 8 full + 31 partial rounds, capacity 1 [UPSTREAM-RECALL:
+ * snarkvm-fields poseidon_default; pinned over Fr by the reference's private-key ciphertext and account vectors, tests/test_poseidon.py].
+ *   poseidon_hash_fr: `Network::hash_many_psd{2,4,8}` — rate = 2, 4 or 8; inputs / outputs canonical 32-byte Fr; preimage = [domain
+ *   "AleoPoseidon{rate}", n_inputs, 0.., inputs] (what /root/reference/rust/src/account/encryptor.rs:37-67 calls through hash_psd2).
+ *   fs_*: the prover's Fiat-Shamir sponge — PoseidonSponge<Fq, 2, 1> behind upstream's AlgebraicSponge interface: bytes (bits of every byte most
+ *   significant first, 376-bit chunks), G1Affine points (x, y Montgomery, stride 104 or 96; infinity as (0, 1)), Fr elements as non-native limbs
+ *   (canonical input, 5 x 51 bits packed two per Fq element), challenges (canonical output): `short_` = 0: 252 bits each from ONE squeeze of
+ *   ceil(252 n / 376) elements (squeeze_nonnative_field_elements(n)); 1: 168 bits (squeeze_short_nonnative_field_elements(n)).
+ *   aleo_mi355x_varuna_prove* run this sponge inside the library; the entry points exist for a host side that drives the rounds itself
+ *   (aleo_amd/varuna.py) and for verifiers. */
+int32_t aleo_mi355x_poseidon_hash_fr(uint32_t rate, const void* inputs, size_t n_inputs, void* out, size_t n_out);
+int32_t aleo_mi355x_fs_new(uint64_t* sponge);
+int32_t aleo_mi355x_fs_free(uint64_t sponge);
+int32_t aleo_mi355x_fs_absorb_bytes(uint64_t sponge, const void* data, size_t len);
+int32_t aleo_mi355x_fs_absorb_g1(uint64_t sponge, const void* affine, size_t stride, size_t count);
+int32_t aleo_mi355x_fs_absorb_fr(uint64_t sponge, const void* fr_canonical, size_t count);
+int32_t aleo_mi355x_fs_squeeze_fr(uint64_t sponge, void* out_canonical, size_t count, int32_t short_);
 
 /* Element-wise field products on the device (host pointers): r[i] = a[i]*b[i], Montgomery form, canonical
  * output.  Used by the parity tests to pin the device arithmetic against the oracle limb for limb; when a and b

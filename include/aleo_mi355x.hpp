@@ -15,7 +15,9 @@
 #pragma once
 #include <cstddef>
 #include <cstdint>
+#include <cstring>
 #include <optional>
+#include <random>
 #include <string>
 #include <utility>
 #include <vector>
@@ -189,6 +191,15 @@ class CommitterKey {
   PinnedBases bases_; size_t max_degree_ = 0, lagrange_offset_ = 0;
 };
 
+// The caller's randomness for one proof: 32 bytes, the key of the prover's ChaCha20 stream.  The reference's call sites pass a CSPRNG
+// (`rand::thread_rng()`, /root/reference/rust/src/program/execute.rs:74); from_entropy() is that.  A repeated seed repeats the blinding of a
+// proof: from_u64 exists for reproducible tests only.
+struct Seed {
+  uint8_t bytes[32];
+  static Seed from_entropy() { Seed s; std::random_device rd; for (int i = 0; i < 32; i += 4) { const uint32_t v = rd(); std::memcpy(s.bytes + i, &v, 4); } return s; }
+  static Seed from_u64(uint64_t v) { Seed s; std::memset(s.bytes, 0, 32); for (int i = 0; i < 8; ++i) s.bytes[i] = (uint8_t)(v >> (8 * i)); return s; }
+};
+
 struct Proof {
   std::vector<uint8_t> bytes;                                   // Proof::write_le layout
   Result<std::string> to_string() const {                       // Display: bech32m, hrp "proof"
@@ -213,11 +224,11 @@ class ProvingKey {
     return {std::move(pk), Error{0}};
   }
   // ProvingKey::prove_batch: one assignment (public variables first, z_0 = 1, canonical) per instance; `seed` stands for the caller's RNG
-  Result<Proof> prove_batch(const std::vector<const std::vector<BigInteger256>*>& assignments, uint64_t seed) const {
+  Result<Proof> prove_batch(const std::vector<const std::vector<BigInteger256>*>& assignments, const Seed& seed = Seed::from_entropy()) const {
     std::vector<const void*> p;
     for (auto* a : assignments) { if (!a || a->size() != num_variables_) return {std::nullopt, Error{ALEO_MI355X_ERR_BAD_ARG}}; p.push_back(a->data()); }
     Proof out; out.bytes.resize(1024 + 192 * assignments.size()); size_t len = out.bytes.size();
-    int32_t rc = aleo_mi355x_varuna_prove_indexed(handle_, p.data(), p.size(), seed, out.bytes.data(), &len);
+    int32_t rc = aleo_mi355x_varuna_prove_indexed(handle_, p.data(), p.size(), seed.bytes, out.bytes.data(), &len);
     if (rc) return {std::nullopt, Error{rc}};
     out.bytes.resize(len); return {std::move(out), Error{0}};
   }
@@ -243,7 +254,7 @@ class ProvingKey {
 // Varuna::prove_batch(keys_to_constraints: &BTreeMap<&ProvingKey, &[Assignment]>): ONE proof for several proving keys, each with its instances, in
 // the order given (upstream: the map's key order).  All keys must have been indexed against the same CommitterKey.
 using KeyedAssignments = std::vector<std::pair<const ProvingKey*, std::vector<const std::vector<BigInteger256>*>>>;
-inline Result<Proof> prove_batch(const KeyedAssignments& keyed, uint64_t seed) {
+inline Result<Proof> prove_batch(const KeyedAssignments& keyed, const Seed& seed = Seed::from_entropy()) {
   std::vector<uint64_t> handles; std::vector<size_t> counts; std::vector<const void*> p;
   for (auto& [pk, zs] : keyed) {
     if (!pk || zs.empty()) return {std::nullopt, Error{ALEO_MI355X_ERR_BAD_ARG}};
@@ -251,7 +262,7 @@ inline Result<Proof> prove_batch(const KeyedAssignments& keyed, uint64_t seed) {
     for (auto* a : zs) { if (!a || a->size() != pk->num_variables()) return {std::nullopt, Error{ALEO_MI355X_ERR_BAD_ARG}}; p.push_back(a->data()); }
   }
   Proof out; out.bytes.resize(1024 + 400 * handles.size() + 192 * p.size()); size_t len = out.bytes.size();
-  int32_t rc = aleo_mi355x_varuna_prove_batch_indexed(handles.data(), handles.size(), p.data(), counts.data(), seed, out.bytes.data(), &len);
+  int32_t rc = aleo_mi355x_varuna_prove_batch_indexed(handles.data(), handles.size(), p.data(), counts.data(), seed.bytes, out.bytes.data(), &len);
   if (rc) return {std::nullopt, Error{rc}};
   out.bytes.resize(len); return {std::move(out), Error{0}};
 }
@@ -268,8 +279,8 @@ class Trace {
     keyed_.push_back({&pk, {&assignment}});
   }
   size_t transitions() const { size_t n = 0; for (auto& e : keyed_) n += e.second.size(); return n; }
-  Result<Proof> prove_execution(uint64_t seed) const { return keyed_.empty() ? Result<Proof>{std::nullopt, Error{ALEO_MI355X_ERR_BAD_ARG}} : prove_batch(keyed_, seed); }
-  Result<Proof> prove_fee(uint64_t seed) const {              // a fee is exactly one transition
+  Result<Proof> prove_execution(const Seed& seed = Seed::from_entropy()) const { return keyed_.empty() ? Result<Proof>{std::nullopt, Error{ALEO_MI355X_ERR_BAD_ARG}} : prove_batch(keyed_, seed); }
+  Result<Proof> prove_fee(const Seed& seed = Seed::from_entropy()) const {              // a fee is exactly one transition
     return transitions() != 1 ? Result<Proof>{std::nullopt, Error{ALEO_MI355X_ERR_BAD_ARG}} : prove_batch(keyed_, seed);
   }
  private:

@@ -247,24 +247,25 @@ def plaintext_from_fields(fields):
     return parse(bits)
 
 
-def decrypt_symmetric(ciphertext: str, view_key: int):
-    """Ciphertext::decrypt_symmetric: randomizers = hash_many_psd8([encryption domain, key], #fields); plaintext_i = c_i − randomizer_i."""
+def decrypt_symmetric(ciphertext: str, view_key: int, hasher=None):
+    """Ciphertext::decrypt_symmetric: randomizers = hash_many_psd8([encryption domain, key], #fields); plaintext_i = c_i − randomizer_i.
+    hasher(rate, inputs, n_out): another implementation of Poseidon::hash_many to put through the same known answer (default: this module's)."""
     c = ciphertext_fields(ciphertext)
-    rnd = hash_many_psd8([domain_separator('AleoSymmetricEncryption0'), view_key], len(c))
+    rnd = (hasher or hash_many)(8, [domain_separator('AleoSymmetricEncryption0'), view_key], len(c))
     return plaintext_from_fields([(a - b) % R for a, b in zip(c, rnd)])
 
 
 LITERAL_FIELD = 2                                                   # Literal variants: address 0, boolean 1, field 2, group 3, …
 
 
-def decrypt_private_key(ciphertext: str, secret: str) -> str:
+def decrypt_private_key(ciphertext: str, secret: str, hasher=None) -> str:
     """Encryptor::decrypt_private_key_with_secret (/root/reference/rust/src/account/encryptor.rs:31-67)."""
     dom, sec = domain_separator('private_key'), domain_separator(secret)
-    kind, members = decrypt_symmetric(ciphertext, sec)
+    kind, members = decrypt_symmetric(ciphertext, sec, hasher)
     assert kind == 'struct' and list(members) == ['key', 'nonce']
     for m in members.values():
         assert m[0] == 'literal' and m[1] == LITERAL_FIELD and m[3] == 253 and m[2] < R
-    blinding = hash_psd2([dom, members['nonce'][2], sec])
+    blinding = (hasher or hash_many)(2, [dom, members['nonce'][2], sec], 1)[0]
     return private_key_string(members['key'][2] * pow(blinding, -1, R) % R)
 
 
@@ -319,20 +320,20 @@ def address_point(s: str):
 def address_string(pt) -> str: return P.bech32m_encode('aleo', pt[0].to_bytes(32, 'little'))
 
 
-def hash_to_scalar(rate: int, inputs) -> int:
+def hash_to_scalar(rate: int, inputs, hasher=None) -> int:
     """Poseidon::hash_to_scalar: the low Scalar::size_in_data_bits bits of the hash."""
-    return hash_many(rate, inputs, 1)[0] & ((1 << SCALAR_DATA_BITS) - 1)
+    return (hasher or hash_many)(rate, inputs, 1)[0] & ((1 << SCALAR_DATA_BITS) - 1)
 
 
-def derive_account(private_key: str, generator):
+def derive_account(private_key: str, generator, hasher=None):
     """PrivateKey::try_from(seed) -> ComputeKey -> ViewKey -> Address.  `generator` is the account generator G (upstream derives it
     with Blake2Xs hash-to-curve, not restated: tests recover it from one reference-held (view key, address) pair as view_key^-1 * address
     and check the others against it)."""
     seed = private_key_seed(private_key)
-    sk_sig = hash_to_scalar(2, [domain_separator('AleoAccountSignatureSecretKey0'), seed])
-    r_sig = hash_to_scalar(2, [domain_separator('AleoAccountSignatureRandomizer0.0'), seed])
+    sk_sig = hash_to_scalar(2, [domain_separator('AleoAccountSignatureSecretKey0'), seed], hasher)
+    r_sig = hash_to_scalar(2, [domain_separator('AleoAccountSignatureRandomizer0.0'), seed], hasher)
     pk_sig, pr_sig = ed_mul(generator, sk_sig), ed_mul(generator, r_sig)
-    sk_prf = hash_to_scalar(4, [pk_sig[0], pr_sig[0]])
+    sk_prf = hash_to_scalar(4, [pk_sig[0], pr_sig[0]], hasher)
     view = (sk_sig + r_sig + sk_prf) % ED_SUBGROUP_ORDER
     return view_key_string(view), address_string(ed_mul(generator, view))
 

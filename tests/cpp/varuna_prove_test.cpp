@@ -15,7 +15,8 @@ int main(int argc, char** argv) {
   FILE* f = fopen(argv[1], "rb"); if (!f) return 2;
   uint64_t h[8];          // n_constraints, n_public, n_private, max_degree, n_gamma, seed, instances, reserved
   if (!rd(f, h, sizeof h)) return 2;
-  const uint64_t nc = h[0], npub = h[1], npriv = h[2], D = h[3], ng = h[4], seed = h[5], k = h[6], nv = npub + npriv;
+  const uint64_t nc = h[0], npub = h[1], npriv = h[2], D = h[3], ng = h[4], seed64 = h[5], k = h[6], nv = npub + npriv;
+  const aleo_mi355x::Seed seed = aleo_mi355x::Seed::from_u64(seed64), seed_next = aleo_mi355x::Seed::from_u64(seed64 + 1);
   if (nc > (1ull << 28) || nv > (1ull << 28) || D > (1ull << 28) || ng > 64 || k > 8) return 2;
   std::vector<uint8_t> gen(104), srs((D + 1 + ng) * 32);
   if (!rd(f, gen.data(), 104) || !rd(f, srs.data(), srs.size())) return 2;
@@ -38,11 +39,11 @@ int main(int argc, char** argv) {
   uint8_t vk[12 * 48 + 64]; size_t vk_len = sizeof vk;
   OK(aleo_mi355x_varuna_index_vk(index, vk, &vk_len), "varuna_index_vk");
   std::vector<uint8_t> proof(2048); size_t len = proof.size();
-  OK(aleo_mi355x_varuna_prove_indexed(index, zp.data(), k, seed, proof.data(), &len), "varuna_prove_indexed");
+  OK(aleo_mi355x_varuna_prove_indexed(index, zp.data(), k, seed.bytes, proof.data(), &len), "varuna_prove_indexed");
   size_t len2 = 16;                                          // a buffer that is too small is an error that reports the size needed
-  if (aleo_mi355x_varuna_prove_indexed(index, zp.data(), k, seed, proof.data() + 1024, &len2) == 0 || len2 != len) { fprintf(stderr, "short buffer not refused\n"); return 1; }
+  if (aleo_mi355x_varuna_prove_indexed(index, zp.data(), k, seed.bytes, proof.data() + 1024, &len2) == 0 || len2 != len) { fprintf(stderr, "short buffer not refused\n"); return 1; }
   OK(aleo_mi355x_varuna_index_free(index), "varuna_index_free");
-  if (aleo_mi355x_varuna_prove_indexed(index, zp.data(), k, seed, proof.data(), &len2) == 0) { fprintf(stderr, "freed index still usable\n"); return 1; }
+  if (aleo_mi355x_varuna_prove_indexed(index, zp.data(), k, seed.bytes, proof.data(), &len2) == 0) { fprintf(stderr, "freed index still usable\n"); return 1; }
   OK(aleo_mi355x_bases_unpin(key), "bases_unpin");
   FILE* o = fopen(argv[2], "wb"); if (!o) return 2;
   uint64_t l2[2] = {vk_len, len};
@@ -84,7 +85,7 @@ int main(int argc, char** argv) {
     auto ex = trace.prove_execution(seed);
     if (!ex.is_ok()) { fprintf(stderr, "Trace::prove_execution: %s\n", ex.error.message().c_str()); return 1; }
     Trace fee; fee.insert_transition(*pk.value, za[0]);
-    auto fp = fee.prove_fee(seed + 1), direct = pk.value->prove_batch({&za[0]}, seed + 1);
+    auto fp = fee.prove_fee(seed_next), direct = pk.value->prove_batch({&za[0]}, seed_next);
     if (!fp.is_ok() || !direct.is_ok() || fp.value->bytes != direct.value->bytes) { fprintf(stderr, "Trace::prove_fee differs from prove_batch\n"); return 1; }
     FILE* o2 = fopen(argv[2], "ab"); if (!o2) return 2;
     uint64_t el = ex.value->bytes.size(); fwrite(&el, 8, 1, o2); fwrite(ex.value->bytes.data(), 1, el, o2); fclose(o2);

@@ -295,7 +295,7 @@ def test_whole_proof_entry_points_refuse_misuse():
             with pytest.raises((aleo_amd.AleoMi355xError, ValueError, IndexError)): varuna.prove_native(ix, [zz] * k, 5)
         view = varuna.native_index(ix)
         out = np.zeros(2048, dtype=np.uint8); n = ctypes.c_size_t(2048); ptrs = (ctypes.c_void_p * 1)(zz.ctypes.data)
-        def call(v): n.value = 2048; return L.aleo_mi355x_varuna_prove(ctypes.byref(v), ptrs, 1, 5, out.ctypes.data_as(ctypes.c_void_p), ctypes.byref(n))
+        def call(v): n.value = 2048; return L.aleo_mi355x_varuna_prove(ctypes.byref(v), ptrs, 1, aleo_amd._lib.seed32(5), out.ctypes.data_as(ctypes.c_void_p), ctypes.byref(n))
         def variant(**kw):
             v = varuna._NativeIndex(); ctypes.memmove(ctypes.byref(v), ctypes.byref(view), ctypes.sizeof(v))
             for a, b in kw.items(): setattr(v, a, b)
@@ -304,6 +304,10 @@ def test_whole_proof_entry_points_refuse_misuse():
         assert call(variant(n_h=view.n_h - 1)) == 2 and call(variant(n_vars=view.n_h + 1)) == 2 and call(variant(n_x=view.n_h)) == 2
         assert call(variant(max_degree=view.n_h)) == 2 and call(variant(gamma_offset=1 << 40)) == 2
         assert call(variant(committer_key=987654321)) == 4
+        for field in ('a_row_ptr', 'b_val', 't_col', 'vx_inv', 'k_evals', 'k_idx', 'k_polys', 'k2_evals'):      # a null array is an error code, not a GPU fault
+            assert call(variant(**{field: None})) == 2, field
+        assert call(variant(vk_affine=None)) == 0 and out[:n.value].tobytes() == good                          # without the affine form: decompressed from vk_bytes
+        assert L.aleo_mi355x_varuna_prove(ctypes.byref(variant()), ptrs, 1, None, out.ctypes.data_as(ctypes.c_void_p), ctypes.byref(n)) == 2      # no seed
         bad = zz.copy(); bad[1] = synth.int_to_limbs(V.R, 4)                       # a public input that is not below r
         ptrs[0] = bad.ctypes.data; assert call(variant()) == 2; ptrs[0] = zz.ctypes.data
         def build(rows_a=None, **kw):
@@ -638,7 +642,7 @@ def test_batch_entry_point_refuses_misuse():
         def call(handles, counts, ptr_list, cap=4096):
             h = (ctypes.c_uint64 * len(handles))(*handles); k = (ctypes.c_size_t * len(counts))(*counts); p = (ctypes.c_void_p * len(ptr_list))(*ptr_list)
             out = np.zeros(max(cap, 8), dtype=np.uint8); n = ctypes.c_size_t(cap)
-            return L.aleo_mi355x_varuna_prove_batch_indexed(h, len(handles), p, k, 3, out.ctypes.data_as(ctypes.c_void_p), ctypes.byref(n)), n.value, out
+            return L.aleo_mi355x_varuna_prove_batch_indexed(h, len(handles), p, k, aleo_amd._lib.seed32(3), out.ctypes.data_as(ctypes.c_void_p), ctypes.byref(n)), n.value, out
         ptrs = [z.ctypes.data for z in flat]
         rc, n, out = call([a.handle, b.handle], [1, 2], ptrs); assert rc == 0 and out[:n].tobytes() == good
         assert call([a.handle, b.handle], [0, 2], ptrs)[0] == 2 and call([a.handle, b.handle], [1, 9], ptrs + ptrs + ptrs + ptrs)[0] == 2
