@@ -679,3 +679,44 @@ def test_device_prover_random_batches(seed):
     finally:
         for x in nx: x.close()
         ck.close()
+
+
+def test_random_stream_positions_are_never_shared():
+    """Every use of the proof's random stream has its own positions: rho_w / rho_a / rho_b and the three hiding polynomials of every instance (over
+    all circuits of a proof — the layout is taken over the total instance count and the largest |H|), the 3|H| mask coefficients, the mask's
+    hiding polynomial.  The restatement's layout and the product's (aleo_amd.varuna) are the same."""
+    from aleo_amd import varuna
+    for n_h, k in ((4, 1), (64, 3), (512, 8), (1 << 15, 32)):
+        lay = V.randomness_layout(n_h, k)
+        assert lay == varuna.randomness_layout(n_h, k)
+        used = []
+        for i in range(k): used += list(range(lay['rho'][i], lay['rho'][i] + 3)) + list(range(lay['blind'][i], lay['blind'][i] + 3 * V.HIDING_COEFFS))
+        used += list(range(lay['mask'], lay['mask'] + 3 * n_h)) + list(range(lay['blind_mask'], lay['blind_mask'] + V.HIDING_COEFFS))
+        assert len(used) == len(set(used)) == lay['total'] and max(used) == lay['total'] - 1
+    # the stream itself: no short period, no collision between seeds that differ in one bit (ChaCha20 under a 32-byte key)
+    a = [V.random_fr(b'\x00' * 32, i) for i in range(300)]; b = [V.random_fr(b'\x01' + b'\x00' * 31, i) for i in range(300)]
+    assert len(set(a)) == 300 and len(set(b)) == 300 and not set(a) & set(b)
+
+
+@pytest.mark.gpu
+def test_distinct_seeds_blind_every_element_differently():
+    """Two proofs of the same statement under different 32-byte seeds share nothing that is blinded: every commitment, every evaluation, both
+    openings and random_v differ (the sums differ too: the challenges do); the same seed reproduces the proof; seed = None draws fresh entropy."""
+    from aleo_amd import varuna
+    csr, z, c = _circuit(90, 3, 61)
+    D = _max_degree(c); ck = varuna.synthetic_committer_key(TAU, S_GAMMA, D)
+    try:
+        zz = np.stack([synth.int_to_limbs(v, 4) for v in z])
+        with varuna.NativeCircuitIndex(csr, 90, 3, len(z) - 3, ck) as nx:
+            s1, s2 = bytes(range(32)), bytes(range(1, 33))
+            p1, p2 = V.parse_proof(nx.prove([zz, zz], s1)), V.parse_proof(nx.prove([zz, zz], s2))
+            assert nx.prove([zz, zz], s1) == V.proof_bytes(p1)
+            f1, f2 = nx.prove(zz, None), nx.prove(zz, None)                    # os.urandom seeds
+            assert f1 != f2 and V.parse_proof(f1)['witness'] != V.parse_proof(f2)['witness']
+        flat = lambda p: [x for t in p['witness'] for x in t] + [p['commitments'][n] for n in ('mask', 'g_1', 'h_1', 'h_2')] + p['commitments']['g_abc'] + \
+            p['evaluations'] + p['sums'] + [p['openings'][0][0], p['openings'][0][1], p['openings'][1][0]]
+        a, b = flat(p1), flat(p2)
+        assert len(a) == len(b) and all(x != y for x, y in zip(a, b))
+        w = p1['witness']; assert len({x for t in w for x in t}) == 6               # the two instances carry the same assignment, yet no two of their commitments coincide
+    finally:
+        ck.close()
