@@ -3,6 +3,6 @@
 Product code: HIP kernels + C ABI in aleo_amd/csrc (built to aleo_amd/lib/libaleo_mi355x.so) and the host-side
 mirrors of the reference's operator interfaces (msm.VariableBase, fft.EvaluationDomain, kzg.KZG10)."""
 from ._lib import lib, LIB_PATH, EXPORTS, AleoMi355xError, UnsatisfiedAssignment          # noqa: F401
-from .msm import VariableBase, PinnedBases, g1_sum, last_msm_timing  # noqa: F401
+from .msm import VariableBase, PinnedBases, ShardedBases, g1_sum, last_msm_timing  # noqa: F401
 from .fft import EvaluationDomain                                   # noqa: F401
 from .kzg import KZG10, SonicKZG10, CommitterKey                    # noqa: F401

@@ -20,6 +20,8 @@ EXPORTS = [
     'aleo_mi355x_bech32m_encode', 'aleo_mi355x_bech32m_decode', 'aleo_mi355x_proof_to_bytes',
     'aleo_mi355x_poseidon_hash_fr', 'aleo_mi355x_fs_new', 'aleo_mi355x_fs_free', 'aleo_mi355x_fs_absorb_bytes', 'aleo_mi355x_fs_absorb_g1',
     'aleo_mi355x_fs_absorb_fr', 'aleo_mi355x_fs_squeeze_fr', 'aleo_mi355x_fr_random',
+    'aleo_mi355x_init_device', 'aleo_mi355x_device_count', 'aleo_mi355x_bases_pin_sharded', 'aleo_mi355x_bases_generate_sharded', 'aleo_mi355x_bases_unpin_sharded',
+    'aleo_mi355x_bases_sharded_info', 'aleo_mi355x_msm_g1_sharded',
 ]
 
 
@@ -53,6 +55,13 @@ def lib():
     vp, sz, i32, u32, u64 = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int32, ctypes.c_uint32, ctypes.c_uint64
     sig = {
         'aleo_mi355x_init': ([i32], i32),
+        'aleo_mi355x_init_device': ([i32], i32),
+        'aleo_mi355x_device_count': ([ctypes.POINTER(i32), ctypes.POINTER(i32)], i32),
+        'aleo_mi355x_bases_pin_sharded': ([vp, sz, sz, ctypes.POINTER(i32), sz, i32, ctypes.POINTER(u64)], i32),
+        'aleo_mi355x_bases_generate_sharded': ([vp, u64, sz, ctypes.POINTER(i32), sz, i32, ctypes.POINTER(u64)], i32),
+        'aleo_mi355x_bases_unpin_sharded': ([u64], i32),
+        'aleo_mi355x_bases_sharded_info': ([u64, ctypes.POINTER(u64), i32], i32),
+        'aleo_mi355x_msm_g1_sharded': ([vp, u64, vp, sz, vp], i32),
         'aleo_mi355x_msm_g1': ([vp, vp, sz, vp, sz], i32),
         'aleo_mi355x_bases_pin': ([vp, sz, sz, ctypes.POINTER(u64)], i32),
         'aleo_mi355x_bases_unpin': ([u64], i32),

@@ -281,8 +281,33 @@ template <class F> static int32_t run_enqueue(Ctx* c, void* stream, F&& f) {
 
 extern "C" {
 
-int32_t aleo_mi355x_init(int32_t device) {
+int32_t aleo_mi355x_init_device(int32_t device) {
   try { Device* d = nullptr; return init_device(device, &d); } catch (...) { return ALEO_MI355X_ERR_HIP; }
+}
+
+// init(n_devices, 0 = all).  Initialises the first n visible devices; the calling thread's current device is left as it was.
+int32_t aleo_mi355x_init(int32_t n_devices) {
+  try {
+    int count = 0, cur = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) { g_last_error = "no HIP device visible"; return ALEO_MI355X_ERR_NO_DEVICE; }
+    if (n_devices < 0 || n_devices > count) { g_last_error = "init: n_devices outside 0..visible devices (0 = all)"; return ALEO_MI355X_ERR_BAD_ARG; }
+    if (hipGetDevice(&cur) != hipSuccess) cur = 0;
+    const int n = n_devices ? n_devices : count;
+    int32_t rc = ALEO_MI355X_OK;
+    for (int i = 0; i < n && !rc; ++i) { Device* d = nullptr; rc = init_device(i, &d); }
+    (void)hipSetDevice(cur);
+    return rc;
+  } catch (...) { return ALEO_MI355X_ERR_HIP; }
+}
+
+int32_t aleo_mi355x_device_count(int32_t* visible, int32_t* initialised) {
+  try {
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess) count = 0;
+    if (visible) *visible = count;
+    if (initialised) { std::lock_guard<std::mutex> lk(g_dev_mu); *initialised = (int32_t)g_devs.size(); }
+    return ALEO_MI355X_OK;
+  } catch (...) { return ALEO_MI355X_ERR_HIP; }
 }
 
 int32_t aleo_mi355x_bases_pin(const void* bases, size_t base_stride, size_t n, uint64_t* handle) {
@@ -918,5 +943,130 @@ const char* aleo_mi355x_strerror(int32_t status) {
 }
 const char* aleo_mi355x_last_error(void) { return g_last_error.c_str(); }
 const char* aleo_mi355x_version(void) { return "aleo_mi355x 0.1.0 (gfx950)"; }
+
+
+// ---- one MSM over several devices (BASELINE configs[4]) ------------------------------------------------------------------
+// One process, G device contexts: the base set is cut into G contiguous shards, shard g pinned on devices[g]; an MSM runs the whole Pippenger
+// per shard on its device (one host thread per shard: the runtime's current device is per thread) and the G partial sums — 144 bytes each —
+// are added on the host in shard order, so the result's bytes do not depend on which device finished first.  No collective: inside one
+// process the "all-gather" of SURVEY.md 8(e) is G stores into one host array.  (Ranks in separate processes exchange the same 144-byte
+// partials over RCCL: aleo_amd/dist.py.)  A device may be listed more than once (how the tests rehearse G > 1 on one card).
+}  // extern "C" (reopened below: the helpers are templates)
+namespace {
+struct ShardedSet { std::vector<int> devices; std::vector<uint64_t> handles; std::vector<size_t> first, count; size_t n = 0; };
+std::mutex g_sh_mu; std::map<uint64_t, std::shared_ptr<ShardedSet>> g_sh; uint64_t g_sh_next = 1;
+
+std::shared_ptr<ShardedSet> sharded_find(uint64_t h) {
+  std::lock_guard<std::mutex> lk(g_sh_mu); auto it = g_sh.find(h);
+  if (it == g_sh.end()) { g_last_error = "unknown sharded handle"; return nullptr; }
+  return it->second;
+}
+// runs f(g) for every shard on its own thread with that shard's device current; the first failure's code and text come back
+template <class F> int32_t for_each_shard(const ShardedSet& S, F&& f) {
+  const size_t G = S.devices.size();
+  std::vector<int32_t> rcs(G, ALEO_MI355X_OK); std::vector<std::string> errs(G);
+  std::vector<std::thread> th;
+  for (size_t g = 0; g < G; ++g)
+    th.emplace_back([&, g]() {
+      try {
+        if (hipSetDevice(S.devices[g]) != hipSuccess) { rcs[g] = ALEO_MI355X_ERR_HIP; errs[g] = "hipSetDevice failed"; return; }
+        rcs[g] = f(g); if (rcs[g]) errs[g] = g_last_error;
+      } catch (...) { rcs[g] = ALEO_MI355X_ERR_HIP; errs[g] = "exception in a shard"; }
+    });
+  for (auto& t : th) t.join();
+  for (size_t g = 0; g < G; ++g) if (rcs[g]) { g_last_error = "shard " + std::to_string(g) + " (device " + std::to_string(S.devices[g]) + "): " + errs[g]; return rcs[g]; }
+  return ALEO_MI355X_OK;
+}
+int32_t sharded_layout(ShardedSet& S, size_t n, const int32_t* devices, size_t n_devices) {
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) { g_last_error = "no HIP device visible"; return ALEO_MI355X_ERR_NO_DEVICE; }
+  if (n_devices < 1 || n_devices > 64) { g_last_error = "sharded: 1..64 shards"; return ALEO_MI355X_ERR_BAD_ARG; }
+  S.n = n;
+  for (size_t g = 0; g < n_devices; ++g) {
+    const int dev = devices ? devices[g] : (int)(g % (size_t)count);
+    if (dev < 0 || dev >= count) { g_last_error = "sharded: device index out of range"; return ALEO_MI355X_ERR_BAD_ARG; }
+    S.devices.push_back(dev);
+    const size_t lo = n * g / n_devices, hi = n * (g + 1) / n_devices;      // the split of aleo_amd/dist.py shard_range
+    S.first.push_back(lo); S.count.push_back(hi - lo);
+  }
+  S.handles.assign(n_devices, 0);
+  return ALEO_MI355X_OK;
+}
+uint64_t sharded_register(std::shared_ptr<ShardedSet> S) { std::lock_guard<std::mutex> lk(g_sh_mu); const uint64_t h = g_sh_next++; g_sh[h] = std::move(S); return h; }
+void sharded_release(const ShardedSet& S) {
+  (void)for_each_shard(S, [&](size_t g) -> int32_t { return S.handles[g] ? aleo_mi355x_bases_unpin(S.handles[g]) : ALEO_MI355X_OK; });
+}
+}  // namespace
+extern "C" {
+
+int32_t aleo_mi355x_bases_pin_sharded(const void* bases, size_t base_stride, size_t n, const int32_t* devices, size_t n_devices, int32_t precompute, uint64_t* handle) {
+  try {
+    if (!handle || (!bases && n) || (base_stride != 104 && base_stride != 96)) { g_last_error = "bases_pin_sharded: bad argument"; return ALEO_MI355X_ERR_BAD_ARG; }
+    auto S = std::make_shared<ShardedSet>();
+    int32_t rc = sharded_layout(*S, n, devices, n_devices); if (rc) return rc;
+    rc = for_each_shard(*S, [&](size_t g) -> int32_t {
+      int32_t r = aleo_mi355x_bases_pin((const uint8_t*)bases + S->first[g] * base_stride, base_stride, S->count[g], &S->handles[g]);
+      if (!r && precompute && S->count[g] >= 1024) r = aleo_mi355x_bases_precompute(S->handles[g]);
+      return r;
+    });
+    if (rc) { const std::string keep = g_last_error; sharded_release(*S); g_last_error = keep; return rc; }
+    *handle = sharded_register(std::move(S));
+    return ALEO_MI355X_OK;
+  } catch (...) { return ALEO_MI355X_ERR_HIP; }
+}
+
+int32_t aleo_mi355x_bases_generate_sharded(const void* base_affine104, uint64_t first_multiple, size_t n, const int32_t* devices, size_t n_devices, int32_t precompute, uint64_t* handle) {
+  try {
+    if (!handle || !base_affine104) { g_last_error = "bases_generate_sharded: bad argument"; return ALEO_MI355X_ERR_BAD_ARG; }
+    auto S = std::make_shared<ShardedSet>();
+    int32_t rc = sharded_layout(*S, n, devices, n_devices); if (rc) return rc;
+    rc = for_each_shard(*S, [&](size_t g) -> int32_t {
+      int32_t r = aleo_mi355x_bases_generate(base_affine104, first_multiple + S->first[g], S->count[g], &S->handles[g]);
+      if (!r && precompute && S->count[g] >= 1024) r = aleo_mi355x_bases_precompute(S->handles[g]);
+      return r;
+    });
+    if (rc) { const std::string keep = g_last_error; sharded_release(*S); g_last_error = keep; return rc; }
+    *handle = sharded_register(std::move(S));
+    return ALEO_MI355X_OK;
+  } catch (...) { return ALEO_MI355X_ERR_HIP; }
+}
+
+int32_t aleo_mi355x_bases_unpin_sharded(uint64_t handle) {
+  try {
+    std::shared_ptr<ShardedSet> S;
+    { std::lock_guard<std::mutex> lk(g_sh_mu); auto it = g_sh.find(handle); if (it == g_sh.end()) { g_last_error = "unknown sharded handle"; return ALEO_MI355X_ERR_BAD_HANDLE; } S = it->second; g_sh.erase(it); }
+    sharded_release(*S);
+    return ALEO_MI355X_OK;
+  } catch (...) { return ALEO_MI355X_ERR_HIP; }
+}
+
+// shard_info: out[0] = number of shards, then per shard: device, first point, point count (as much as cap allows); returns the number of values written
+int32_t aleo_mi355x_bases_sharded_info(uint64_t handle, uint64_t* out, int32_t cap) {
+  try {
+    auto S = sharded_find(handle); if (!S || !out) return 0;
+    int32_t w = 0;
+    if (w < cap) out[w++] = S->devices.size();
+    for (size_t g = 0; g < S->devices.size(); ++g) { const uint64_t v[3] = {(uint64_t)S->devices[g], S->first[g], S->count[g]}; for (uint64_t x : v) if (w < cap) out[w++] = x; }
+    return w;
+  } catch (...) { return 0; }
+}
+
+// out: the sum as snarkVM's Projective (x, y, 1 / infinity (1, 1, 0)), 144 bytes; partials (optional, G x 144 bytes): each shard's own sum in shard order
+int32_t aleo_mi355x_msm_g1_sharded(void* out_jacobian, uint64_t handle, const void* scalars, size_t n, void* partials_out) {
+  try {
+    if (!out_jacobian || (!scalars && n)) { g_last_error = "msm_g1_sharded: bad argument"; return ALEO_MI355X_ERR_BAD_ARG; }
+    auto S = sharded_find(handle); if (!S) return ALEO_MI355X_ERR_BAD_HANDLE;
+    if (n > S->n) { g_last_error = "msm_g1_sharded: more scalars than pinned points"; return ALEO_MI355X_ERR_BAD_ARG; }
+    const size_t G = S->devices.size();
+    std::vector<uint64_t> part(18 * G);
+    int32_t rc = for_each_shard(*S, [&](size_t g) -> int32_t {
+      const size_t lo = S->first[g] < n ? S->first[g] : n, hi = S->first[g] + S->count[g] < n ? S->first[g] + S->count[g] : n;      // a prefix of the set: shards past n contribute the identity
+      return aleo_mi355x_msm_g1_pinned(&part[18 * g], S->handles[g], (const uint8_t*)scalars + lo * 32, hi - lo);
+    });
+    if (rc) return rc;
+    if (partials_out) std::memcpy(partials_out, part.data(), part.size() * 8);
+    return aleo_mi355x_g1_sum(out_jacobian, part.data(), G);
+  } catch (...) { return ALEO_MI355X_ERR_HIP; }
+}
 
 }  // extern "C"

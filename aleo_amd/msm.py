@@ -80,12 +80,68 @@ class PinnedBases:
         except Exception: pass
 
 
+class ShardedBases:
+    """One base set cut into contiguous shards over several devices of this process (aleo_mi355x_bases_pin_sharded):
+    shard g = points [n g / G, n (g+1) / G) on devices[g].  devices: a list of HIP device indices (an index may repeat), or a count G
+    (device g mod the visible devices)."""
+
+    def __init__(self, bases: np.ndarray = None, devices=1, precompute: bool = False, _handle: int = 0, _n: int = 0):
+        if bases is None:
+            self.handle, self.n = _handle, _n
+            return
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        assert bases.ndim == 2 and bases.shape[1] in (96, 104)
+        self.n = bases.shape[0]
+        dv, g = self._devices(devices); h = ctypes.c_uint64(0)
+        check(lib().aleo_mi355x_bases_pin_sharded(_p(bases), bases.shape[1], self.n, dv, g, 1 if precompute else 0, ctypes.byref(h)), 'bases_pin_sharded')
+        self.handle = h.value
+
+    @staticmethod
+    def _devices(devices):
+        if isinstance(devices, int): return None, devices
+        arr = (ctypes.c_int32 * len(devices))(*[int(d) for d in devices]); return arr, len(devices)
+
+    @classmethod
+    def generate_multiples(cls, base_affine104: np.ndarray, first_multiple: int, n: int, devices=1, precompute: bool = False) -> 'ShardedBases':
+        b = np.ascontiguousarray(base_affine104, dtype=np.uint8).reshape(104)
+        dv, g = cls._devices(devices); h = ctypes.c_uint64(0)
+        check(lib().aleo_mi355x_bases_generate_sharded(_p(b), first_multiple, n, dv, g, 1 if precompute else 0, ctypes.byref(h)), 'bases_generate_sharded')
+        return cls(None, _handle=h.value, _n=n)
+
+    def shards(self):
+        """[(device, first point, point count)] in shard order."""
+        buf = (ctypes.c_uint64 * 200)(); k = lib().aleo_mi355x_bases_sharded_info(self.handle, buf, 200)
+        if k < 1: raise ValueError('unknown sharded handle')
+        return [(int(buf[1 + 3 * g]), int(buf[2 + 3 * g]), int(buf[3 + 3 * g])) for g in range(int(buf[0]))]
+
+    def close(self):
+        if self.handle:
+            lib().aleo_mi355x_bases_unpin_sharded(self.handle); self.handle = 0
+
+    def __enter__(self): return self
+    def __exit__(self, *a): self.close()
+    def __del__(self):
+        try: self.close()
+        except Exception: pass
+
+
 class VariableBase:
+    @staticmethod
+    def msm_sharded(bases: ShardedBases, scalars: np.ndarray, partials: bool = False):
+        """ONE MSM over the devices of a ShardedBases (aleo_mi355x_msm_g1_sharded): per-device Pippenger, the partial sums added on the host in
+        shard order.  Returns uint64[18] (and the partials uint64[G,18] when asked)."""
+        scalars = np.ascontiguousarray(scalars, dtype=np.uint64).reshape(-1, 4)
+        n = min(bases.n, scalars.shape[0]); out = np.zeros(18, dtype=np.uint64)
+        part = np.zeros((len(bases.shards()), 18), dtype=np.uint64) if partials else None
+        check(lib().aleo_mi355x_msm_g1_sharded(_p(out), bases.handle, _p(scalars), n, _p(part) if partials else None), 'msm_g1_sharded')
+        return (out, part) if partials else out
+
     @staticmethod
     def msm(bases, scalars: np.ndarray) -> np.ndarray:
         """sum_i scalars[i] * bases[i]; zips to the shorter length like the reference."""
         scalars = np.ascontiguousarray(scalars, dtype=np.uint64).reshape(-1, 4)
         out = np.zeros(18, dtype=np.uint64)
+        if isinstance(bases, ShardedBases): return VariableBase.msm_sharded(bases, scalars)
         if isinstance(bases, PinnedBases):
             n = min(bases.n, scalars.shape[0])
             check(lib().aleo_mi355x_msm_g1_pinned(_p(out), bases.handle, _p(scalars), n), 'msm_g1_pinned')

@@ -43,11 +43,15 @@ def main():
     ap.add_argument('--concurrent-callers', type=int, default=4, help='secondary: aggregate rate with this many caller threads (0/1 = skip)')
     ap.add_argument('--sharded-ntt-lg', type=int, default=24, help='size of the secondary sharded-NTT measurement at N > 1 (stderr)')
     ap.add_argument('--aux-sharded-ntt', action='store_true', help=argparse.SUPPRESS)
+    ap.add_argument('--in-process', action='store_true',
+                    help='with --config 4 and no launcher: ONE process drives --gpus N device contexts through aleo_mi355x_msm_g1_sharded (the visible devices are listed cyclically when there are fewer than N)')
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
                     help="'gloo' is only for rehearsing the N>1 path with several ranks sharing one GPU")
     args = ap.parse_args()
     if args.aux_sharded_ntt:
         raise SystemExit(aux_sharded_ntt(args))
+    if args.in_process:
+        raise SystemExit(in_process_sharded(args))
 
     import torch
     import torch.distributed as dist
@@ -70,7 +74,7 @@ def main():
         else:
             dist.init_process_group('gloo', rank=rank, world_size=world)
     L = aleo_amd.lib()
-    aleo_amd._lib.check(L.aleo_mi355x_init(dev_index), 'init')
+    aleo_amd._lib.check(L.aleo_mi355x_init_device(dev_index), 'init')
 
     strong = args.config == 4
     if strong:
@@ -123,8 +127,7 @@ def main():
     if world > 1:
         ks = gather(synth.int_to_limbs(k, 4))                                # 4 limbs per rank, same collective
         k = sum(synth.limbs_to_int(row) for row in ks) % synth.FR_MODULUS
-    kG = aleo_amd.VariableBase.msm(gen.reshape(1, 104), synth.int_to_limbs(k, 4).reshape(1, 4))
-    if not (np.asarray(res) == kG).all():
+    if not result_is_multiple_of_generator(synth, res, k):       # big-integer double-and-add below: independent of the HIP path
         raise SystemExit('bench: MSM result does not equal k*G — refusing to report a number for a wrong result')
 
     # variants of the same MSM, outside the timed region (every rank runs them so the ranks stay in step; rank 0 reports)
@@ -256,6 +259,74 @@ def main():
                 print(json.dumps({'aux': 'sharded_ntt', 'error': 'timeout: the probe did not finish within 150 s (child killed)', 'rank': rank}), file=sys.stderr, flush=True)
 
 
+def _g1_times(P, k, q):
+    """k * P on y^2 = x^3 + 1 over Fq in plain Python integers (Jacobian double-and-add) — the gate's own arithmetic: bench.py's correctness check must
+    not lean on the library it measures, and oracle/ is only for the cpu_baseline leg."""
+    X, Y, Z = 1, 1, 0
+    for bit in bin(k)[2:] if k else '':
+        if Z:                                                   # double (a = 0)
+            A = X * X % q; B = Y * Y % q; C = B * B % q; D = 2 * ((X + B) * (X + B) - A - C) % q; E = 3 * A % q
+            X3 = (E * E - 2 * D) % q; Z = 2 * Y * Z % q; Y = (E * (D - X3) - 8 * C) % q; X = X3
+        if bit == '1':
+            if not Z: X, Y, Z = P[0], P[1], 1
+            else:                                               # mixed addition; P never equals +-acc here (k < r, P of order r) except through the doubling above
+                ZZ = Z * Z % q; U2 = P[0] * ZZ % q; S2 = P[1] * Z % q * ZZ % q; H = (U2 - X) % q; R_ = (S2 - Y) % q
+                HH = H * H % q; HHH = H * HH % q; V = X * HH % q
+                X3 = (R_ * R_ - HHH - 2 * V) % q; Y = (R_ * (V - X3) - Y * HHH) % q; Z = Z * H % q; X = X3
+    if not Z: return None
+    zi = pow(Z, -1, q); return (X * zi * zi % q, Y * zi * zi % q * zi % q)
+
+
+def result_is_multiple_of_generator(synth, res, k) -> bool:
+    """res: uint64[18] Jacobian (x, y, 1) in Montgomery form, or (1, 1, 0); k: the expected discrete logarithm."""
+    q = 0x01AE3A4617C510EAC63B05C06CA1493B1A22D9F300F5138F1EF3622FBA094800170B5D44300000008508C00000000001
+    rinv = pow(1 << 384, -1, q)
+    lim = lambda a: sum(int(v) << (64 * i) for i, v in enumerate(a))
+    r = np.asarray(res, dtype=np.uint64).reshape(18)
+    got = None if not r[12:].any() else (lim(r[:6]) * rinv % q, lim(r[6:12]) * rinv % q)
+    g = np.ascontiguousarray(synth.generator_affine104()[:96]).view(np.uint64)
+    G = (lim(g[:6]) * rinv % q, lim(g[6:12]) * rinv % q)
+    return got == _g1_times(G, k % synth.FR_MODULUS, q)
+
+
+def in_process_sharded(args):
+    """bench.py --config 4 --in-process --gpus N: BASELINE configs[4] driven by ONE process over N device contexts of the C ABI
+    (aleo_mi355x_bases_generate_sharded / aleo_mi355x_msm_g1_sharded: contiguous point shards, per-device Pippenger from one host thread per shard,
+    the 144-byte partials added on the host in shard order — no collective).  With fewer visible devices than N the devices are listed cyclically
+    (several shards share a card: a rehearsal of the path, not a scaling measurement; the line says which)."""
+    import torch
+    import aleo_amd
+    from aleo_amd import synth
+    if not torch.cuda.is_available(): raise SystemExit('bench.py needs an MI355X: the HIP path has no CPU fallback')
+    L = aleo_amd.lib(); aleo_amd._lib.check(L.aleo_mi355x_init(0), 'init')
+    vis = torch.cuda.device_count(); G = max(1, args.gpus)
+    devices = [g % vis for g in range(G)]
+    total = 1 << (args.lg_n if args.lg_n is not None else 26)
+    if (total // G + 1) * 13 >= (1 << 32): raise SystemExit('bench --config 4: the shards exceed one launch; use more devices or --lg-n')
+    gen = synth.generator_affine104()
+    t0 = time.perf_counter()
+    sb = aleo_amd.ShardedBases.generate_multiples(gen, 1, total, devices=devices, precompute=not args.no_precompute)
+    setup_s = time.perf_counter() - t0
+    scalars = (synth.uniform_scalars if args.scalars == 'uniform' else synth.witness_like_scalars)(total, 0xA1E00002)
+    for _ in range(args.warmup): res = aleo_amd.VariableBase.msm_sharded(sb, scalars)
+    t0 = time.perf_counter()
+    for _ in range(args.steps): res = aleo_amd.VariableBase.msm_sharded(sb, scalars)
+    elapsed = time.perf_counter() - t0
+    if not result_is_multiple_of_generator(synth, res, synth.weighted_scalar_sum(scalars, 1)):
+        raise SystemExit('bench: sharded MSM result does not equal k*G — refusing to report a number for a wrong result')
+    print(json.dumps({
+        'metric': 'MSM G1 scalar-muls/sec (2^%d bases total, BLS12-377, bit-exact)' % (total.bit_length() - 1), 'value': total * args.steps / elapsed, 'unit': 'scalar-muls/s',
+        'n_gpus': len(set(devices)), 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'strong',
+        'vs_baseline': None, 'dtype': 'u32', 'data': 'synthetic',
+        'config': {'workload': '2^%d-point BLS12-377 G1 Pippenger MSM split into %d shards over %d device(s) of one process (BASELINE configs[4])' % (total.bit_length() - 1, G, len(set(devices))),
+                   'shards': sb.shards(), 'entry_point': 'aleo_mi355x_msm_g1_sharded', 'scalars': 'host memory, uploaded inside every timed step',
+                   'sharding': 'one process, one host thread and device context per shard; partial sums added on the host in shard order (no collective)',
+                   'rehearsal_on_shared_devices': len(set(devices)) < G},
+        'setup_s': setup_s}), flush=True)
+    sb.close()
+    return 0
+
+
 def aux_sharded_ntt(args):
     """Child-process entry (bench.py --aux-sharded-ntt): only the sharded-NTT probe, on its own process group."""
     import torch
@@ -267,7 +338,7 @@ def aux_sharded_ntt(args):
     dev_index = local_rank % torch.cuda.device_count(); torch.cuda.set_device(dev_index); dev = torch.device('cuda', dev_index)
     if args.backend == 'nccl': dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
     else: dist.init_process_group('gloo', rank=rank, world_size=world)
-    aleo_amd._lib.check(aleo_amd.lib().aleo_mi355x_init(dev_index), 'init')
+    aleo_amd._lib.check(aleo_amd.lib().aleo_mi355x_init_device(dev_index), 'init')
     try:
         sn = sharded_ntt_probe(aleo_amd, adist, synth, torch, dist, dev, rank, world, args.sharded_ntt_lg)
     except Exception as e:      # noqa: BLE001

@@ -68,9 +68,13 @@ extern "C" {
 #define ALEO_NTT_STANDARD 0
 #define ALEO_NTT_COSET 1      /* coset shift g = Fr::multiplicative_generator() = 22 */
 
-/* Selects and initialises a device (-1 = current HIP device).  Idempotent, thread-safe; every other entry
- * point initialises lazily on the current device if this was never called. */
-int32_t aleo_mi355x_init(int32_t device);
+/* initialises the first n_devices visible devices (0 = all of them).  Idempotent, thread-safe; the calling thread's current
+ * HIP device is left as it was.  Every single-device entry point below works on the CALLING THREAD's current HIP device (hipSetDevice is per
+ * thread) and initialises it lazily if neither init call was made.  init_device selects and initialises one device (-1 = the current one).
+ * device_count: visible devices / devices initialised so far (either pointer may be NULL). */
+int32_t aleo_mi355x_init(int32_t n_devices);
+int32_t aleo_mi355x_init_device(int32_t device);
+int32_t aleo_mi355x_device_count(int32_t* visible, int32_t* initialised);
 
 /* a1 — VariableBase::msm(bases: &[G1Affine], scalars: &[BigInteger256]) -> G1Projective.
  * Host pointers.  n = min(len(bases), len(scalars)) is the caller's job (the reference zips the slices).
@@ -125,6 +129,19 @@ int32_t aleo_mi355x_msm_g1_device_sparse(void* out_jacobian, uint64_t handle, co
 /* Sum of `count` Jacobian points (144 bytes each, host memory): the local group-add that follows the
  * all-gather of per-GPU partial MSM results.  Result affine-normalised as above. */
 int32_t aleo_mi355x_g1_sum(void* out_jacobian, const void* jacobian_points, size_t count);
+/* e — ONE MSM over several devices of this process (BASELINE configs[4]: 2^26 points over 8 GPUs).  The base set is cut into
+ * n_devices contiguous shards [n g / G, n (g+1) / G); shard g is pinned on devices[g] (devices == NULL: device g mod visible; a device may be
+ * listed more than once), with its fixed-base table when precompute != 0.  msm_g1_sharded multiplies scalars[0..n) (n <= the pinned count:
+ * shards past n contribute the identity) — every shard runs the whole Pippenger on its device from its own host thread, the G partial sums
+ * (144 bytes each; copied to partials_out in shard order when it is not NULL) are added on the host in shard order by aleo_mi355x_g1_sum, so the
+ * result is the affine-normalised sum, bit for bit what a single device gives.  No collective: within one process the exchange is G stores
+ * into host memory (ranks in separate processes exchange the same partials over RCCL: aleo_amd/dist.py).  generate_sharded: the synthetic set
+ * P_i = (first_multiple + i) * base built shard by shard in each device's HBM.  sharded_info: [G, then per shard device, first point, count]. */
+int32_t aleo_mi355x_bases_pin_sharded(const void* bases, size_t base_stride, size_t n, const int32_t* devices, size_t n_devices, int32_t precompute, uint64_t* handle);
+int32_t aleo_mi355x_bases_generate_sharded(const void* base_affine104, uint64_t first_multiple, size_t n, const int32_t* devices, size_t n_devices, int32_t precompute, uint64_t* handle);
+int32_t aleo_mi355x_bases_unpin_sharded(uint64_t handle);
+int32_t aleo_mi355x_bases_sharded_info(uint64_t handle, uint64_t* out, int32_t cap);
+int32_t aleo_mi355x_msm_g1_sharded(void* out_jacobian, uint64_t handle, const void* scalars, size_t n, void* partials_out);
 
 /* VariableBase::msm::<G2Affine> (SRS / setup paths; the prover itself never runs one).  BLS12-377 G2 over
  * Fq2 = Fq[u]/(u^2 + 5).  bases: snarkVM G2Affine {x: Fq2 (c0, c1), y: Fq2, infinity: bool}, Montgomery limbs, stride 200 (flag byte

@@ -69,7 +69,40 @@ class PinnedBases {
   uint64_t handle_ = 0; size_t n_ = 0;
 };
 
+// One base set over several devices of this process: contiguous point shards, shard g on devices[g] (aleo_mi355x_bases_pin_sharded).
+class ShardedBases {
+ public:
+  ShardedBases() = default;
+  static Result<ShardedBases> pin(const G1Affine* bases, size_t n, const std::vector<int32_t>& devices, bool precompute = true) {
+    ShardedBases p; int32_t rc = aleo_mi355x_bases_pin_sharded(bases, sizeof(G1Affine), n, devices.data(), devices.size(), precompute ? 1 : 0, &p.handle_);
+    if (rc) return {std::nullopt, Error{rc}};
+    p.n_ = n; p.shards_ = devices.size(); return {std::move(p), Error{0}};
+  }
+  static Result<ShardedBases> generate_multiples(const G1Affine& base, uint64_t first, size_t n, const std::vector<int32_t>& devices, bool precompute = true) {
+    ShardedBases p; int32_t rc = aleo_mi355x_bases_generate_sharded(&base, first, n, devices.data(), devices.size(), precompute ? 1 : 0, &p.handle_);
+    if (rc) return {std::nullopt, Error{rc}};
+    p.n_ = n; p.shards_ = devices.size(); return {std::move(p), Error{0}};
+  }
+  ShardedBases(ShardedBases&& o) noexcept : handle_(o.handle_), n_(o.n_), shards_(o.shards_) { o.handle_ = 0; }
+  ShardedBases& operator=(ShardedBases&& o) noexcept { release(); handle_ = o.handle_; n_ = o.n_; shards_ = o.shards_; o.handle_ = 0; return *this; }
+  ShardedBases(const ShardedBases&) = delete; ShardedBases& operator=(const ShardedBases&) = delete;
+  ~ShardedBases() { release(); }
+  uint64_t handle() const { return handle_; }
+  size_t len() const { return n_; }
+  size_t shards() const { return shards_; }
+ private:
+  void release() { if (handle_) { aleo_mi355x_bases_unpin_sharded(handle_); handle_ = 0; } }
+  uint64_t handle_ = 0; size_t n_ = 0, shards_ = 0;
+};
+
 struct VariableBase {
+  // ONE msm over the devices of a sharded set: per-device Pippenger, partial sums added on the host in shard order
+  static Result<G1Projective> msm(const ShardedBases& bases, const BigInteger256* scalars, size_t n_scalars) {
+    G1Projective out{}; size_t n = bases.len() < n_scalars ? bases.len() : n_scalars;
+    int32_t rc = aleo_mi355x_msm_g1_sharded(&out, bases.handle(), scalars, n, nullptr);
+    if (rc) return {std::nullopt, Error{rc}};
+    return {out, Error{0}};
+  }
   // VariableBase::msm(bases, scalars): sum_i scalars[i] * bases[i] over the shorter of the two slices.
   static Result<G1Projective> msm(const G1Affine* bases, size_t n_bases, const BigInteger256* scalars, size_t n_scalars) {
     G1Projective out{}; size_t n = n_bases < n_scalars ? n_bases : n_scalars;

@@ -35,7 +35,7 @@ static void mac_mod_r(uint64_t acc[4], const uint64_t s[4], uint64_t w) {
 #define CHECK(cond, what) do { if (!(cond)) { printf("FAIL: %s\n", what); return 1; } else printf("ok: %s\n", what); } while (0)
 
 int main() {
-  if (aleo_mi355x_init(-1) != 0) { printf("FAIL: init: %s\n", aleo_mi355x_last_error()); return 2; }
+  if (aleo_mi355x_init_device(-1) != 0) { printf("FAIL: init: %s\n", aleo_mi355x_last_error()); return 2; }
   // G1 generator in Montgomery form (curves/src/bls12_377/g1.rs)
   G1Affine g{}; const uint64_t gx[6] = {0x1042a645ec301b95ULL, 0x5a990780c1060f28ULL, 0x684a8ab3a9007a5bULL, 0x1c35a184257ba63fULL, 0xb2b2abd2fea8e32eULL, 0x017df3a223fb2017ULL};
   const uint64_t gy[6] = {0xbc5a1ae8e2801ab9ULL, 0xd4f3c861cbfe13b0ULL, 0xecdd5ffc4e949f13ULL, 0x8f87199b7503667dULL, 0x0f0b1b837dc4fe1cULL, 0x004bcc7e053eaabeULL};
@@ -61,6 +61,16 @@ int main() {
   CHECK(z.is_ok() && z.value->is_zero(), "all-zero scalars give the identity");
   auto empty = VariableBase::msm(bases.data(), 0, s.data(), 0);
   CHECK(empty.is_ok() && empty.value->is_zero(), "empty msm is the identity");
+  {                                                                       // the same MSM as three shards (all on device 0) through the sharded entry points
+    CHECK(aleo_mi355x_init(0) == 0, "init(0) initialises every visible device");
+    auto sh = ShardedBases::pin(bases.data(), n, {0, 0, 0}, true);
+    CHECK(sh.is_ok() && sh.value->shards() == 3, "bases_pin_sharded");
+    auto c3 = VariableBase::msm(*sh.value, s.data(), n + 7);
+    CHECK(c3.is_ok() && memcmp(&*a.value, &*c3.value, sizeof(G1Projective)) == 0, "sharded msm == one-shot msm");
+    auto gen3 = ShardedBases::generate_multiples(g, 1, n, {0, 0}, false);
+    auto c2 = gen3.is_ok() ? VariableBase::msm(*gen3.value, s.data(), n) : Result<G1Projective>{std::nullopt, Error{1}};
+    CHECK(c2.is_ok() && memcmp(&*a.value, &*c2.value, sizeof(G1Projective)) == 0, "sharded msm over generated shards == one-shot msm");
+  }
   auto bad = VariableBase::msm(PinnedBases(), s.data(), 1);
   CHECK(!bad.is_ok() && bad.error.code == ALEO_MI355X_ERR_BAD_HANDLE, "an unknown handle is an Err (caller falls back to the CPU)");
 

@@ -31,7 +31,7 @@ int main(int argc, char** argv) {
   for (uint64_t i = 0; i < k; ++i) { if (!rd(f, z[i].data(), nv * 32)) return 2; zp[i] = z[i].data(); }
   fclose(f);
 
-  OK(aleo_mi355x_init(0), "init");
+  OK(aleo_mi355x_init_device(0), "init");
   uint64_t key = 0, index = 0;
   OK(aleo_mi355x_bases_from_scalars(gen.data(), srs.data(), D + 1 + ng, &key), "bases_from_scalars");       // powers | hiding powers
   OK(aleo_mi355x_bases_precompute(key), "bases_precompute");

@@ -2,6 +2,7 @@
 against the oracle on the same seeded inputs, against the committed golden vectors, and — at BASELINE.json's full
 sizes — through size-independent identities.  Integer work: every comparison is bit-exact."""
 import json, os
+import ctypes
 import numpy as np
 import pytest
 
@@ -20,7 +21,7 @@ def _ints(hexes): return [int(h, 16) for h in hexes]
 @pytest.fixture(scope='module', autouse=True)
 def device():
     L = aleo_amd.lib()
-    aleo_amd._lib.check(L.aleo_mi355x_init(-1), 'init')     # no GPU -> hard failure, never a fallback
+    aleo_amd._lib.check(L.aleo_mi355x_init_device(-1), 'init')     # no GPU -> hard failure, never a fallback
 
 
 def _fq_random(n, seed):
@@ -464,8 +465,41 @@ def test_large_sizes_properties():
         S = util.uniform_scalars(n, 2323)
         dS = torch.from_numpy(S.view(np.int64)).cuda(); torch.cuda.synchronize()
         got = M.VariableBase.msm_device(pb, dS.data_ptr(), n)
-        kG = M.VariableBase.msm(synth.generator_affine104().reshape(1, 104), synth.int_to_limbs(synth.weighted_scalar_sum(S, 1), 4).reshape(1, 4))
-        assert (got == kG).all()
+        assert c.jac_to_int_point(got) == util.expected_multiples_msm(S, n)           # big-integer k*G (oracle/pyref.g1_mul), not the library's own product
+
+
+def test_sharded_msm_over_device_contexts_matches_single_device():
+    """aleo_mi355x_bases_pin_sharded / _generate_sharded + aleo_mi355x_msm_g1_sharded (BASELINE configs[4] in one process): the set cut
+    into G contiguous shards — here every shard on the one visible device, listed G times — gives, for G = 1..5, ragged sizes, a prefix of the set,
+    table and plain paths, the bytes of the single-device MSM and the oracle's point; the partials are the shards' own sums; misuse is refused."""
+    L = aleo_amd.lib()
+    vis, ini = ctypes.c_int32(0), ctypes.c_int32(0)
+    aleo_amd._lib.check(L.aleo_mi355x_init(0), 'init'); aleo_amd._lib.check(L.aleo_mi355x_device_count(ctypes.byref(vis), ctypes.byref(ini)), 'device_count')
+    assert vis.value >= 1 and ini.value == vis.value and L.aleo_mi355x_init(vis.value + 1) == 2 and L.aleo_mi355x_init(-1) == 2
+    n = 5000 + 37
+    B = util.multiples_bases(n); S = util.uniform_scalars(n, 9191); S[::7] = 0; S[1::11] = util.uniform_scalars(1, 5)[0]
+    want = c.jac_to_int_point(c.msm_g1(B, S, threads=4, variant=1))
+    with M.PinnedBases(B) as pb: single = M.VariableBase.msm(pb, S)
+    assert c.jac_to_int_point(single) == want
+    for G, pre in ((1, False), (2, True), (3, False), (5, True)):
+        with aleo_amd.ShardedBases(B, devices=[0] * G, precompute=pre) as sb:
+            sh = sb.shards()
+            assert len(sh) == G and sh[0][1] == 0 and sum(x[2] for x in sh) == n and all(sh[g][1] + sh[g][2] == sh[g + 1][1] for g in range(G - 1))
+            got, part = M.VariableBase.msm_sharded(sb, S, partials=True)
+            assert (got == single).all()
+            for g, (dev, lo, cnt) in enumerate(sh):
+                assert c.jac_to_int_point(part[g]) == c.jac_to_int_point(c.msm_g1(B[lo:lo + cnt], S[lo:lo + cnt], threads=2, variant=1))
+            m = n // 3 + 1                                                          # a prefix: the later shards contribute the identity
+            assert c.jac_to_int_point(M.VariableBase.msm_sharded(sb, S[:m])) == c.jac_to_int_point(c.msm_g1(B[:m], S[:m], threads=2, variant=1))
+            assert c.jac_to_int_point(M.VariableBase.msm_sharded(sb, S[:0])) is None
+            out = np.zeros(18, dtype=np.uint64); big = np.zeros((n + 1, 4), dtype=np.uint64)
+            assert L.aleo_mi355x_msm_g1_sharded(out.ctypes.data_as(ctypes.c_void_p), sb.handle, big.ctypes.data_as(ctypes.c_void_p), n + 1, None) == 2      # more scalars than points
+    with aleo_amd.ShardedBases.generate_multiples(synth.generator_affine104(), 1, 1 << 16, devices=4, precompute=True) as sb:      # P_i = (i + 1) G built shard by shard
+        S2 = util.uniform_scalars(1 << 16, 4242)
+        assert c.jac_to_int_point(M.VariableBase.msm(sb, S2)) == util.expected_multiples_msm(S2, 1 << 16)
+    h = ctypes.c_uint64(0); bad = (ctypes.c_int32 * 2)(0, 99)
+    assert L.aleo_mi355x_bases_pin_sharded(B.ctypes.data_as(ctypes.c_void_p), 104, n, bad, 2, 0, ctypes.byref(h)) == 2                 # no such device
+    assert L.aleo_mi355x_bases_unpin_sharded(123456) == 4 and L.aleo_mi355x_msm_g1_sharded(out.ctypes.data_as(ctypes.c_void_p), 123456, None, 0, None) == 4
 
 
 # ---- batched / sharded NTT -------------------------------------------------------------------------------------

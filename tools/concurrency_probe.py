@@ -7,7 +7,7 @@ import aleo_amd
 from aleo_amd import synth, msm as M
 
 torch.cuda.set_device(0)
-aleo_amd._lib.check(aleo_amd.lib().aleo_mi355x_init(0), 'init')
+aleo_amd._lib.check(aleo_amd.lib().aleo_mi355x_init_device(0), 'init')
 for lg in (14, 16, 18, 20):
     n = 1 << lg
     pb = M.PinnedBases.generate_multiples(synth.generator_affine104(), 1, n).precompute()

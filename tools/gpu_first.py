@@ -9,7 +9,7 @@ from oracle import coracle as c, pyref as p
 import util
 
 L = aleo_amd.lib()
-print(L.aleo_mi355x_version(), 'init', L.aleo_mi355x_init(-1), L.aleo_mi355x_last_error())
+print(L.aleo_mi355x_version(), 'init', L.aleo_mi355x_init_device(-1), L.aleo_mi355x_last_error())
 n = 5000
 a = util.uniform_scalars(n, 1); b = util.uniform_scalars(n, 2)
 r = M.fr_mul(a, b); e = np.zeros_like(a); c.lib().oracle_fr_mul(c._p(e), c._p(a), c._p(b), n)

@@ -7,7 +7,7 @@ from aleo_amd import synth, msm as M
 lg = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 pre = (sys.argv[2] != 'plain') if len(sys.argv) > 2 else True
 n = 1 << lg
-aleo_amd._lib.check(aleo_amd.lib().aleo_mi355x_init(0), 'init')
+aleo_amd._lib.check(aleo_amd.lib().aleo_mi355x_init_device(0), 'init')
 pb = M.PinnedBases.generate_multiples(synth.generator_affine104(), 1, n)
 if pre: pb.precompute()
 seed = int(sys.argv[3], 0) if len(sys.argv) > 3 else 5

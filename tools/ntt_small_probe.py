@@ -10,7 +10,7 @@ L = aleo_amd.lib()
 def ntt_fr_batch_device(ptr, lg, batch, order, direction, type_, stream):
     aleo_amd._lib.check(L.aleo_mi355x_ntt_fr_batch_device(ctypes.c_void_p(ptr), lg, batch, order, direction, type_, ctypes.c_void_p(stream)), 'ntt')
 dev = torch.device('cuda', 0); torch.cuda.set_device(0)
-aleo_amd._lib.check(aleo_amd.lib().aleo_mi355x_init(0), 'init')
+aleo_amd._lib.check(aleo_amd.lib().aleo_mi355x_init_device(0), 'init')
 ts = torch.cuda.Stream(); torch.cuda.set_stream(ts); st = ts.cuda_stream
 out = {'wide_lg': os.environ.get('ALEO_MI355X_NTT_WIDE_LG', 'default')}
 for lg in (10, 12, 13, 14, 15, 16, 17, 18):

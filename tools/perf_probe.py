@@ -6,7 +6,7 @@ import aleo_amd
 from aleo_amd import synth, msm as M
 
 dev = torch.device('cuda', 0); torch.cuda.set_device(0)
-aleo_amd._lib.check(aleo_amd.lib().aleo_mi355x_init(0), 'init')
+aleo_amd._lib.check(aleo_amd.lib().aleo_mi355x_init_device(0), 'init')
 tstream = torch.cuda.Stream(); torch.cuda.set_stream(tstream); st = tstream.cuda_stream   # a real (non-null) stream: HIP events and the library share it
 what = sys.argv[1] if len(sys.argv) > 1 else 'all'
 if what in ('all', 'ntt'):

@@ -12,7 +12,7 @@ import aleo_amd
 from aleo_amd import synth, msm as M
 
 dev = torch.device('cuda', 0); torch.cuda.set_device(0)
-aleo_amd._lib.check(aleo_amd.lib().aleo_mi355x_init(0), 'init')
+aleo_amd._lib.check(aleo_amd.lib().aleo_mi355x_init_device(0), 'init')
 name = sys.argv[1]; reps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 f = name.split(':')
 out = {'workload': name, 'reps': reps}

@@ -8,7 +8,7 @@ import bench
 
 lg = int(sys.argv[1]) if len(sys.argv) > 1 else 15
 dev = torch.device('cuda', 0); torch.cuda.set_device(0)
-aleo_amd._lib.check(aleo_amd.lib().aleo_mi355x_init(0), 'init')
+aleo_amd._lib.check(aleo_amd.lib().aleo_mi355x_init_device(0), 'init')
 H = 1 << lg
 pb = aleo_amd.PinnedBases.generate_multiples(synth.generator_affine104(), 1, 3 * H).precompute()
 buf = torch.from_numpy(synth.uniform_scalars(4 * H, 1).view(np.int64)).to(dev)

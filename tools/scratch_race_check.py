@@ -10,7 +10,7 @@ from oracle import coracle as c
 import util
 
 assert os.environ.get('ALEO_MI355X_SLOTS') == '1'
-aleo_amd._lib.check(aleo_amd.lib().aleo_mi355x_init(0), 'init')
+aleo_amd._lib.check(aleo_amd.lib().aleo_mi355x_init_device(0), 'init')
 lg = 18; n = 1 << lg; batch = 4                       # 4 x 2^18 = 2^20 elements per call
 errs = []
 x = [c.fr_to_mont(util.uniform_scalars(n * batch, 40 + t)) for t in range(2)]

@@ -5,7 +5,7 @@ import numpy as np, torch
 import aleo_amd
 from aleo_amd import synth, msm as M
 torch.cuda.set_device(0)
-aleo_amd._lib.check(aleo_amd.lib().aleo_mi355x_init(0), 'init')
+aleo_amd._lib.check(aleo_amd.lib().aleo_mi355x_init_device(0), 'init')
 N = 1 << 20
 S = synth.uniform_scalars(N, 71)
 dS = torch.from_numpy(S.view(np.int64)).cuda(); torch.cuda.synchronize()
