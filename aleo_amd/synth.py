@@ -183,3 +183,73 @@ def synthetic_r1cs_bits(n_constraints: int, n_public: int, seed: int):
         for limb in range(4): val[:, limb] = np.array([(c_ >> (64 * limb)) & _M64 for c_ in flat], dtype=np.uint64)
         csr[m] = (ptr, col, val)
     return csr, z
+
+
+def _csr_from_rows(rows, n_constraints):
+    csr = {}
+    for m, rr in rows.items():
+        ptr = np.zeros(n_constraints + 1, dtype=np.uint32); ptr[1:] = np.cumsum([len(x) for x in rr])
+        col = np.array([v for x in rr for v, _ in x], dtype=np.uint32)
+        flat = [c_ for x in rr for _, c_ in x]
+        val = np.zeros((len(flat), 4), dtype=np.uint64)
+        for limb in range(4): val[:, limb] = np.array([(c_ >> (64 * limb)) & _M64 for c_ in flat], dtype=np.uint64)
+        csr[m] = (ptr, col, val)
+    return csr
+
+
+def synthetic_r1cs_density(n_constraints: int, n_public: int, seed: int, nnz_a: int, nnz_b: int):
+    """The circuit of synthetic_r1cs with the row density as a parameter: constraint i multiplies a combination of nnz_a earlier variables by a
+    combination of nnz_b earlier variables into a new private variable (row of C = that variable).  For the density sweep of the prover: the
+    non-zero domains |K_A|, |K_B| — and with them the MSM points per constraint — grow with nnz_a, nnz_b."""
+    r = FR_MODULUS
+    rnd = splitmix_limbs(seed, (nnz_a + nnz_b) * n_constraints + 64)
+    coef = [limbs_to_int(x) for x in uniform_scalars(4096, seed ^ 0x55)]
+    z = [1] + [coef[i] for i in range(1, n_public)]
+    rows = {'a': [], 'b': [], 'c': []}; at = 0
+    for i in range(n_constraints):
+        nv = len(z)
+        def lc(k):
+            nonlocal at
+            out = {}
+            for j in range(min(k, nv)):
+                v = int(rnd[at] % np.uint64(nv)); at += 1
+                out[v] = (out.get(v, 0) + coef[(at + 7 * j) & 4095]) % r or 1
+            return sorted(out.items())
+        a, b = lc(nnz_a), lc(nnz_b)
+        z.append(sum(c_ * z[v] for v, c_ in a) % r * (sum(c_ * z[v] for v, c_ in b) % r) % r)
+        rows['a'].append(a); rows['b'].append(b); rows['c'].append([(nv, 1)])
+    return _csr_from_rows(rows, n_constraints), z
+
+
+def synthetic_r1cs_poseidon(n_constraints: int, n_public: int, seed: int, width: int = 9):
+    """A circuit shaped like Poseidon gadgets (what Aleo programs are full of: hash_psd2/4/8, BHP commitments have the same flavour): a state of
+    `width` elements goes through rounds; in a round every element becomes (MDS row . state + round constant)^17 — five constraints:
+    L * L = t2 (both sides the dense row: width + 1 non-zeros, the constant on variable 0), t2 * t2 = t4, t4 * t4 = t8, t8 * t8 = t16,
+    t16 * L = t17.  Dense MDS rows, x^17 chains; 2.8 / 4.6 non-zeros per constraint in A / B at width 9."""
+    r = FR_MODULUS
+    coef = [limbs_to_int(x) | 1 for x in uniform_scalars(width * width + 64, seed ^ 0x99)]
+    z = [1] + [coef[-1 - i] for i in range(1, n_public)]
+    while len(z) < max(n_public, 1) + width: z.append(coef[len(z) % len(coef)])      # initial state: the public inputs, then private seeds
+    first_state = len(z) - width
+    rows = {'a': [], 'b': [], 'c': []}
+    state = list(range(first_state, first_state + width)); rnd_c = 0
+    for v in range(n_public, len(z)):                                                # the private seeds are pinned by (seed) * 1 = v-style constraints later: here they are free inputs
+        pass
+    while len(rows['a']) + 5 <= n_constraints:
+        nxt = []
+        for i in range(width):
+            if len(rows['a']) + 5 > n_constraints: break
+            L = sorted([(0, coef[(rnd_c + i) % len(coef)])] + [(state[j], coef[i * width + j]) for j in range(width)]); rnd_c += 1
+            lv = sum(c_ * z[v] for v, c_ in L) % r
+            t = lv
+            for step in range(4):                                                    # t2, t4, t8, t16
+                nv = len(z); a = L if step == 0 else [(nv - 1, 1)]; z.append(t * t % r); t = z[-1]
+                rows['a'].append(a); rows['b'].append(a); rows['c'].append([(nv, 1)])
+            nv = len(z); z.append(t * lv % r)
+            rows['a'].append([(nv - 1, 1)]); rows['b'].append(L); rows['c'].append([(nv, 1)]); nxt.append(nv)
+        if len(nxt) == width: state = nxt
+        else: break
+    while len(rows['a']) < n_constraints:                                            # fill: squares of the last variable
+        nv = len(z); z.append(z[-1] * z[-1] % r)
+        rows['a'].append([(nv - 1, 1)]); rows['b'].append([(nv - 1, 1)]); rows['c'].append([(nv, 1)])
+    return _csr_from_rows(rows, n_constraints), z

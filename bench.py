@@ -150,6 +150,13 @@ def main():
             dt = timed(lambda: aleo_amd.VariableBase.msm(pb2, scalars))
             variants['value_no_table'] = n / dt; variants['ms_no_table'] = dt * 1e3
             pb2.close()
+        if world == 1 and n <= (1 << 22):
+            # the two-line drop-in of INTEGRATION.md 2 as it stands: plain aleo_mi355x_msm_g1 on host bases AND host scalars, nothing cached
+            # (104 B/point uploaded and converted to the 28-bit rows inside every call, no table)
+            host_bases = pb.download()
+            dt = timed(lambda: aleo_amd.VariableBase.msm(host_bases, scalars))
+            variants['value_one_shot_cold'] = n / dt; variants['ms_one_shot_cold'] = dt * 1e3
+            del host_bases
         if world == 1 and not args.no_precompute and n <= (1 << 22):
             # witness-like scalars (60 % zero, 20 % one, 10 % < 2^16, 10 % uniform), resident: on the wide window, and on a 16-bit range
             # table over the whole set with the sparse hint (bases_precompute_range; built after every number above was taken)
@@ -491,14 +498,44 @@ def varuna_prove(synth, torch, lg, reps=7, in_flight=4):
             dt = time.perf_counter() - t
         try: several = varuna_prove_several(synth, ck, lg)
         except Exception as e: several = {'error': repr(e)[:300]}
+        try: sweep = density_sweep(synth, lg)
+        except Exception as e: sweep = {'error': repr(e)[:300]}
         return {'constraints': n, 'domain_h': ix.n_h, 'domain_k': ix.n_k, 'max_degree': D, 'index_s': index_s, 'prove_ms': med, 'constraints_per_s': n / med * 1e3,
-                'rounds_ms': rounds, 'proof_bytes': len(data), 'entry_point': 'aleo_mi355x_varuna_prove', 'several_circuits': several,
+                'rounds_ms': rounds, 'proof_bytes': len(data), 'entry_point': 'aleo_mi355x_varuna_prove', 'several_circuits': several, 'density_sweep': sweep,
+                'circuit': 'synthetic_r1cs: 2.02 / 1.5 / 1 non-zeros per row of A / B / C (every constraint multiplies two short combinations into a new variable); density_sweep holds denser ones',
                 'python_host_ms': float(np.median(tp[1:])),
                 'instances_4': {'prove_ms': mb, 'constraints_per_s': 4 * n / mb * 1e3, 'proof_bytes': len(datab)},
                 'instances_8': {'prove_ms': mb8, 'constraints_per_s': 8 * n / mb8 * 1e3},
                 'in_flight_%d' % in_flight: {'proofs_per_s': in_flight * per / dt, 'constraints_per_s': n * in_flight * per / dt}, 'what': VARUNA_NOTE}
     finally:
         ck.close()
+
+
+def density_sweep(synth, lg, reps=5):
+    """constraints/s against circuit density (tools/density_sweep.py holds the full sweep, profiles/r03_density_sweep.jsonl its 2^15 / 2^18 results):
+    the headline circuit has ~2 non-zeros per row; programs built from hash gadgets have denser A / B rows, hence larger non-zero domains |K_M| and
+    more MSM points per constraint.  Here: 8 and 16 non-zeros per row of A and B, and a Poseidon-gadget-shaped circuit (dense MDS rows, x^17 chains)."""
+    from aleo_amd import varuna
+    n = (1 << lg) - 64; out = []
+    for name, make in (('density 8 / 8', lambda: synth.synthetic_r1cs_density(n, 4, 908, 8, 8)), ('density 16 / 16', lambda: synth.synthetic_r1cs_density(n, 4, 916, 16, 16)),
+                       ('poseidon-shaped, width 9', lambda: synth.synthetic_r1cs_poseidon(n, 4, 77, 9))):
+        csr, z = make(); zz = np.stack([synth.int_to_limbs(v, 4) for v in z])
+        nnz = [int(csr[m][0][-1]) for m in 'abc']; n_k = 2
+        while n_k < max(nnz): n_k *= 2
+        D = 1
+        while D < max(3 << lg, n_k): D *= 2
+        ck = varuna.synthetic_committer_key(0x1F3A9C0D5E7B24681357ACE02468BDF013579BDF02468ACE1234567, 0x0FEDCBA9876543210123456789ABCDEF55AA, D - 1)
+        try:
+            with varuna.NativeCircuitIndex(csr, n, 4, len(z) - 4, ck) as nx:
+                ts = []
+                for r_ in range(reps + 2):
+                    t = time.perf_counter(); nx.prove(zz, 100 + r_); ts.append((time.perf_counter() - t) * 1e3)
+                ms = float(np.median(ts[2:])); km = nx.n_k_m; nh = nx.n_h
+                pts = 3 * (nh + 1) + 3 * nh + (nh - 1) + 2 * nh + sum(k - 1 for k in km) + max(km) + (3 * nh - 1) + (max(km) - 1)
+                out.append({'circuit': name, 'nnz_per_row': [round(v / n, 2) for v in nnz], 'n_k': km, 'msm_points_per_constraint': round(pts / n, 1), 'prove_ms': ms, 'constraints_per_s': n / ms * 1e3})
+        finally:
+            ck.close()
+    return out
 
 
 def prove_replicas(synth, dist, lg, world, gather_dev, barrier, reps=6):
@@ -738,7 +775,7 @@ def index_proxy_gpu(aleo_amd, synth, torch, dev, lg, reps=3):
 
 
 def proof_proxy_cpu(c, aleo_amd, synth, lg, cores):
-    """The same schedule through the oracle (MSMs on `cores` threads, transforms and field ops on one)."""
+    """The same schedule through the oracle on `cores` host threads (MSMs, transforms, element-wise field work)."""
     H = 1 << lg
     with aleo_amd.PinnedBases.generate_multiples(synth.generator_affine104(), 1, 3 * H) as pb:
         bases = pb.download()
@@ -759,15 +796,18 @@ def proof_proxy_cpu(c, aleo_amd, synth, lg, cores):
             t_msm += time.perf_counter() - t1
         elif op == 'spmv':
             rp, ci = _proxy_csr(o[2], arg)
-            aux[:o[2]] = c.fr_spmv(rp, ci, s_uni[:ci.shape[0]], buf[:o[2]])
+            aux[:o[2]] = c.fr_spmv_mt(rp, ci, s_uni[:ci.shape[0]], buf[:o[2]], cores)
         elif op == 'ntt':
-            for _ in range(o[3]): buf[:o[2]] = c.ntt_fr(buf[:o[2]], 0, arg[0], arg[1])
+            for _ in range(o[3]): buf[:o[2]] = c.ntt_fr(buf[:o[2]], 0, arg[0], arg[1], threads=cores)
         elif op == 'vec':
-            aux[:o[2]] = c.fr_vec_op(aux[:o[2]], buf[:o[2]], 0)
+            aux[:o[2]] = c.fr_vec_op_mt(aux[:o[2]], buf[:o[2]], 0, cores)
         else:
-            aux[:o[2]] = c.fr_batch_inverse(aux[:o[2]])
+            aux[:o[2]] = c.fr_batch_inverse_mt(aux[:o[2]], cores)
     dt = time.perf_counter() - t0
-    return {'constraints': H, 'seconds': dt, 'constraints_per_s': H / dt, 'msm_seconds': t_msm, 'msm_threads': cores, 'other_threads': 1}
+    return {'constraints': H, 'seconds': dt, 'constraints_per_s': H / dt, 'msm_seconds': t_msm, 'msm_threads': cores, 'other_threads': cores,
+            'host_cpus': os.cpu_count(), 'usable_cpus': effective_cpus(),
+            'what': 'restatement (oracle.c), not the Rust binary: MSMs with every window split over the threads, transforms with the butterflies of every stage split over the threads, '
+                    'element-wise field work / batch inversion / matrix rows in per-thread chunks; the division by X - z stays serial'}
 
 
 def effective_cpus():

@@ -35,6 +35,7 @@ def lib():
         for f in ('oracle_fr_mul', 'oracle_fq_mul'):
             getattr(L, f).argtypes = [vp, vp, vp, sz]; getattr(L, f).restype = None
         L.oracle_ntt_fr.argtypes = [vp, cu, ci, ci, ci]; L.oracle_ntt_fr.restype = ci
+        L.oracle_ntt_fr_mt.argtypes = [vp, cu, ci, ci, ci, ci]; L.oracle_ntt_fr_mt.restype = ci
         L.oracle_kzg_commit.argtypes = [vp, vp, vp, sz, ci]; L.oracle_kzg_commit.restype = ci
         L.oracle_fr_batch_inverse.argtypes = [vp, sz]; L.oracle_fr_batch_inverse.restype = None
         L.oracle_fr_vec_op.argtypes = [vp, vp, vp, sz, ci]; L.oracle_fr_vec_op.restype = None
@@ -131,12 +132,46 @@ def g1_mul(base104, scalar4) -> np.ndarray:
     lib().oracle_g1_mul(_p(out), _p(b), _p(s)); return out
 
 
-def ntt_fr(data, order=0, direction=0, type=0) -> np.ndarray:
-    """data uint64[n,4] Montgomery -> transformed copy."""
+def ntt_fr(data, order=0, direction=0, type=0, threads=1) -> np.ndarray:
+    """data uint64[n,4] Montgomery -> transformed copy.  threads > 1: the rayon-style parallel transform (oracle_ntt_fr_mt), same values."""
     a = np.ascontiguousarray(data, dtype=np.uint64).copy()
     n = a.shape[0]; lg = n.bit_length() - 1; assert 1 << lg == n
-    rc = lib().oracle_ntt_fr(_p(a), lg, order, direction, type); assert rc == 0
+    rc = lib().oracle_ntt_fr(_p(a), lg, order, direction, type) if threads <= 1 else lib().oracle_ntt_fr_mt(_p(a), lg, order, direction, type, threads)
+    assert rc == 0
     return a
+
+
+def _chunks(n, parts):
+    return [(n * i // parts, n * (i + 1) // parts) for i in range(parts) if n * (i + 1) // parts > n * i // parts]
+
+
+def parallel_rows(fn, n, threads):
+    """fn(lo, hi) over `threads` contiguous row ranges on a thread pool (ctypes calls release the GIL): how the CPU baseline spreads the
+    element-wise field work of a proof over the host cores, as snarkVM's rayon iterators do."""
+    if threads <= 1 or n < 4096: fn(0, n); return
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(threads) as ex: list(ex.map(lambda r: fn(*r), _chunks(n, threads)))
+
+
+def fr_vec_op_mt(a, b, op: int, threads: int) -> np.ndarray:
+    a = np.ascontiguousarray(a, dtype=np.uint64); b = np.ascontiguousarray(b, dtype=np.uint64); r = np.zeros_like(a)
+    parallel_rows(lambda lo, hi: lib().oracle_fr_vec_op(_p(r[lo:hi]), _p(a[lo:hi]), _p(b[lo:hi]), hi - lo, op), a.shape[0], threads); return r
+
+
+def fr_batch_inverse_mt(a, threads: int) -> np.ndarray:
+    """snarkvm_fields::batch_inversion splits the slice into chunks (rayon) and inverts each with its own shared inversion: the same here."""
+    a = np.ascontiguousarray(a, dtype=np.uint64).copy()
+    parallel_rows(lambda lo, hi: lib().oracle_fr_batch_inverse(_p(a[lo:hi]), hi - lo), a.shape[0], threads); return a
+
+
+def fr_spmv_mt(row_ptr, col_idx, vals, x, threads: int) -> np.ndarray:
+    rp = np.ascontiguousarray(row_ptr, dtype=np.uint32); ci = np.ascontiguousarray(col_idx, dtype=np.uint32)
+    v = np.ascontiguousarray(vals, dtype=np.uint64); xx = np.ascontiguousarray(x, dtype=np.uint64)
+    n = rp.shape[0] - 1; y = np.zeros((n, 4), dtype=np.uint64)
+    def rows(lo, hi):
+        sub = (rp[lo:hi + 1] - rp[lo]).astype(np.uint32); k0, k1 = int(rp[lo]), int(rp[hi])
+        lib().oracle_fr_spmv(_p(y[lo:hi]), _p(sub), _p(np.ascontiguousarray(ci[k0:k1])), _p(np.ascontiguousarray(v[k0:k1])), _p(xx), hi - lo)
+    parallel_rows(rows, n, threads); return y
 
 
 def kzg_commit(bases104, coeffs_mont, threads=1) -> np.ndarray:

@@ -474,6 +474,70 @@ int oracle_ntt_fr(void* inout, unsigned lg_n, int order, int direction, int type
   return 0;
 }
 
+/* The same transform on `threads` host threads (EvaluationDomain's rayon-parallel butterflies, restated with a barrier per stage): every stage's
+ * n/2 butterflies, the powers, the permutations and the scalings are cut into contiguous ranges, one per thread.  Same results as oracle_ntt_fr
+ * (tests/test_oracle.py); used for the all-cores CPU baseline of the proof schedule. */
+typedef struct { Fr* x; Fr* roots; size_t n; unsigned lg; int order, direction, type, threads, id; Fr w, g; pthread_barrier_t* bar; } ntt_job;
+static void fr_pow_u64(Fr* r, const Fr* a, u64 e) { Fr acc = Fr_R1, b = *a; while (e) { if (e & 1) Fr_mul(&acc, &acc, &b); Fr_sqr(&b, &b); e >>= 1; } *r = acc; }
+static void bitrev_range(Fr* x, size_t lo, size_t hi, unsigned lg) {
+  for (size_t i = lo; i < hi; ++i) {
+    size_t j = 0; for (unsigned b = 0; b < lg; ++b) j |= ((i >> b) & 1) << (lg - 1 - b);
+    if (i < j) { Fr t = x[i]; x[i] = x[j]; x[j] = t; }                /* the pair (i, j) is touched only by the owner of min(i, j) */
+  }
+}
+static void powers_range(Fr* x, size_t lo, size_t hi, const Fr* g) {     /* x[i] *= g^i */
+  Fr pw; fr_pow_u64(&pw, g, (u64)lo);
+  for (size_t i = lo; i < hi; ++i) { Fr_mul(&x[i], &x[i], &pw); Fr_mul(&pw, &pw, g); }
+}
+static void* ntt_worker(void* arg) {
+  ntt_job* J = (ntt_job*)arg; const size_t n = J->n, T = (size_t)J->threads, id = (size_t)J->id; Fr* x = J->x;
+  const size_t lo = n * id / T, hi = n * (id + 1) / T, hlo = (n / 2) * id / T, hhi = (n / 2) * (id + 1) / T;
+  const int in_rev = (J->order == 2 || J->order == 3), out_rev = (J->order == 1 || J->order == 3);
+  if (in_rev) { bitrev_range(x, lo, hi, J->lg); pthread_barrier_wait(J->bar); }
+  if (J->direction == 0 && J->type == 1) { powers_range(x, lo, hi, &J->g); pthread_barrier_wait(J->bar); }
+  bitrev_range(x, lo, hi, J->lg);
+  { Fr pw; fr_pow_u64(&pw, &J->w, (u64)hlo); for (size_t i = hlo; i < hhi; ++i) { J->roots[i] = pw; Fr_mul(&pw, &pw, &J->w); } }
+  pthread_barrier_wait(J->bar);
+  for (size_t len = 2; len <= n; len <<= 1) {
+    const size_t half = len / 2, step = n / len;
+    for (size_t b = hlo; b < hhi; ++b) {
+      const size_t s = (b / half) * len, k = b % half;
+      Fr t; Fr_mul(&t, &x[s + k + half], &J->roots[k * step]);
+      Fr u = x[s + k];
+      Fr_add(&x[s + k], &u, &t); Fr_sub(&x[s + k + half], &u, &t);
+    }
+    pthread_barrier_wait(J->bar);
+  }
+  if (J->direction == 1) {
+    Fr ninv, nn; fr_from_u64(&nn, (u64)n); Fr_inv(&ninv, &nn);
+    for (size_t i = lo; i < hi; ++i) Fr_mul(&x[i], &x[i], &ninv);
+    if (J->type == 1) { Fr gi; Fr_inv(&gi, &J->g); powers_range(x, lo, hi, &gi); }
+    pthread_barrier_wait(J->bar);
+  }
+  if (out_rev) bitrev_range(x, lo, hi, J->lg);
+  return NULL;
+}
+int oracle_ntt_fr_mt(void* inout, unsigned lg_n, int order, int direction, int type, int threads) {
+  if (lg_n > FR_TWO_ADICITY) return -1;
+  const size_t n = (size_t)1 << lg_n;
+  if (threads > (int)(n / 2)) threads = (int)(n / 2);
+  if (threads <= 1) return oracle_ntt_fr(inout, lg_n, order, direction, type);
+  Fr w; Fr_to_mont(&w, &FR_ROOT_CANON);
+  for (unsigned i = lg_n; i < FR_TWO_ADICITY; ++i) Fr_sqr(&w, &w);
+  if (direction == 1) Fr_inv(&w, &w);
+  Fr* roots = (Fr*)malloc(sizeof(Fr) * (n / 2));
+  pthread_barrier_t bar; pthread_barrier_init(&bar, NULL, (unsigned)threads);
+  ntt_job* jobs = (ntt_job*)malloc(sizeof(ntt_job) * threads); pthread_t* th = (pthread_t*)malloc(sizeof(pthread_t) * threads);
+  for (int t = 0; t < threads; ++t) {
+    ntt_job* J = &jobs[t]; J->x = (Fr*)inout; J->roots = roots; J->n = n; J->lg = lg_n; J->order = order; J->direction = direction; J->type = type;
+    J->threads = threads; J->id = t; J->w = w; fr_from_u64(&J->g, FR_GENERATOR); J->bar = &bar;
+    pthread_create(&th[t], NULL, ntt_worker, J);
+  }
+  for (int t = 0; t < threads; ++t) pthread_join(th[t], NULL);
+  pthread_barrier_destroy(&bar); free(jobs); free(th); free(roots);
+  return 0;
+}
+
 /* KZG10::commit shape (polycommit/kzg10): coefficients arrive in Montgomery form, are converted to canonical
  * bigints, and fed to VariableBase::msm over powers_of_beta_g[..len]; result -> affine. */
 int oracle_kzg_commit(void* out104, const void* bases104, const void* coeffs_mont, size_t n, int threads) {

@@ -175,3 +175,22 @@ def test_pairing_is_bilinear_and_of_order_r():
     assert E.pairing(None, H) == E.ONE12 and E.pairing(G, None) == E.ONE12
     assert E.pairing_product_is_one([(p.g1_mul(G, a), H), (p.g1_neg(G), p.g2_mul(H, a))])
     assert not E.pairing_product_is_one([(p.g1_mul(G, a), H), (p.g1_neg(G), p.g2_mul(H, a + 1))])
+
+
+def test_threaded_oracle_legs_equal_the_serial_ones(oracle):
+    """The all-cores CPU baseline of the proof schedule (bench.py cpu_baseline.proof_proxy) runs the oracle's transforms with the butterflies of
+    every stage split over threads, and the element-wise field work / batch inversion / matrix rows in per-thread chunks: same values."""
+    from aleo_amd import synth
+    c = oracle
+    x = c.fr_to_mont(synth.uniform_scalars(1 << 12, 5))
+    for order in range(4):
+        for direction in (0, 1):
+            for typ in (0, 1):
+                assert (c.ntt_fr(x, order, direction, typ) == c.ntt_fr(x, order, direction, typ, threads=5)).all()
+    for lg in (1, 2, 3):
+        y = c.fr_to_mont(synth.uniform_scalars(1 << lg, 6)); assert (c.ntt_fr(y, 0, 1, 1) == c.ntt_fr(y, 0, 1, 1, threads=8)).all()
+    a = c.fr_to_mont(synth.uniform_scalars(9001, 7)); b = c.fr_to_mont(synth.uniform_scalars(9001, 8)); a[17] = 0
+    assert (c.fr_vec_op(a, b, 0) == c.fr_vec_op_mt(a, b, 0, 4)).all() and (c.fr_batch_inverse(a) == c.fr_batch_inverse_mt(a, 4)).all()
+    rp = np.arange(0, 2 * 9001 + 1, 2, dtype=np.uint32); ci = (np.arange(2 * 9001, dtype=np.uint32) * 7) % 9001
+    v = c.fr_to_mont(synth.uniform_scalars(2 * 9001, 9))
+    assert (c.fr_spmv(rp, ci, v, a) == c.fr_spmv_mt(rp, ci, v, a, 3)).all()
