@@ -352,6 +352,10 @@ int32_t aleo_mi355x_varuna_prove(const aleo_mi355x_varuna_index* index, const vo
  * `Trace::prove_execution` / `prove_fee` build from the transitions of a transaction (/root/reference/rust/src/program/execute.rs:74).
  * index_handles: 1..8 indexes built against ONE committer key (same max_degree / gamma_offset), in the order the proof lists them;
  * n_instances[j]: 1..8 assignments of circuit j (at most 32 in all); assignments: the pointers of circuit 0's instances, then circuit 1's, ...
+ * These are caps of this library, not of the protocol (upstream has none): a request outside them is refused with ALEO_MI355X_ERR_BAD_ARG before any
+ * launch, and the caller falls back (CPU prover) or lists a proving key twice — the same index handle may appear more than once, each occurrence
+ * carrying up to 8 instances — as long as 8 entries and 32 instances suffice.  One proof is one object: the library never splits a request into
+ * several proofs on its own.
  * The circuits share the transcript and every challenge, one mask / g_1 / h_1 over the largest constraint domain, one h_2 over the largest non-zero
  * domain and the two openings; a smaller circuit enters behind the selector v_{H*} / v_{H_j}.  out_proof: Proof::to_bytes_le layout —
  * batch sizes, 3 witness commitments per instance, mask, g_1, h_1, every g_a, every g_b, every g_c (one vector per matrix over the circuits,

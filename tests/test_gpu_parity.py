@@ -709,6 +709,17 @@ def test_async_device_calls_order_their_scratch_across_streams(tmp_path):
     assert r.returncode == 0 and 'SCRATCH OK' in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
+@pytest.mark.parametrize('mode', ['null', 'stream'])
+def test_first_call_of_a_process_is_a_batched_transform(mode):
+    """Regression for the host segfault of round 2 (gpurun_out/r02_t1.log: inside aleo_mi355x_ntt_fr_batch_device while the stream-ordered slot
+    scratch was being introduced): a fresh process with ONE slot whose first library call is a batched transform on stream NULL / on a created
+    stream (tools/first_call_check.py) — the first-use path of the slot's stream, events and scratch."""
+    import subprocess, sys
+    env = dict(os.environ, ALEO_MI355X_SLOTS='1')
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(G), '..', 'tools', 'first_call_check.py'), mode], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and 'FIRST CALL OK' in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 # ---- reference-held data through the HIP path ------------------------------------------------------------------------------
 def _reference_g1_points():
     """The twelve G1 points of the reference's own proof string (wasm/src/programs/transaction.rs:100): ten commitments and

@@ -120,3 +120,15 @@ def test_reference_field_and_group_literals_pin_fr():
     den = c.fr_vec_op(one, mul(d, XX), 2)                                      # 1 - d x^2
     inv = c.fr_batch_inverse(den)
     assert (mul(c.fr_vec_op(one, XX, 1), inv) == YY).all()                     # (1 + x^2) / (1 - d x^2) == y^2, limb for limb
+
+
+def test_host_parsers_under_address_and_ub_sanitizers(tmp_path):
+    """SURVEY.md 5 (sanitizers on the CPU build): aleo_amd/csrc/wire.hip and sponge.hip — host-only code of the product that parses untrusted bytes
+    (bech32m_decode, g1_decompress, fr_from_bytes, proof_to_bytes) or hashes (Poseidon, the Fiat-Shamir sponge, the ChaCha20 stream) — compiled as
+    plain C++ with -fsanitize=address,undefined and driven by tests/cpp/wire_fuzz.cpp: the reference's proof string, malformed variants, a
+    4000-step mutation loop, buffer-size edge cases (tools/asan_host.sh).  Any sanitizer report fails the run."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    proof = json.load(open(os.path.join(root, 'tests', 'golden', 'reference_proof.json')))['proof']
+    r = subprocess.run([os.path.join(root, 'tools', 'asan_host.sh'), str(tmp_path), proof], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and 'SANITIZED OK' in r.stdout and 'runtime error' not in r.stderr and 'AddressSanitizer' not in r.stderr, r.stdout[-1500:] + r.stderr[-3000:]
