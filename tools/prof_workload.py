@@ -4,6 +4,7 @@
   batch:<lg_n>:<k>[:<lg_set>]                              one batched commit of k polynomials of 2^lg_n coefficients
   ntt:<lg_n>[:<batch>]                                     forward NTT, device resident
   host_msm:<lg_n>                                          msm_g1_pinned with HOST scalars (upload inside the call)
+  msm_range:<lg_n>[:<window>]                              witness-like scalars on the narrow-window range table over the whole set (sparse hint)
 Prints one JSON line with the wall time per repetition."""
 import os, sys, time, json
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
@@ -25,6 +26,17 @@ if f[0] == 'round1':
     uni = torch.from_numpy(synth.uniform_scalars(3 * H, 9).view(np.int64)).to(dev); torch.cuda.synchronize()
     ptrs = [w.data_ptr() for w in wit] + [uni.data_ptr()]; lens = [H, H, H, 3 * H]
     run = lambda: kzg.KZG10.commit_batch_device(pb, ptrs, lens)
+    run(); run()
+    t0 = time.perf_counter(); tms = []
+    for _ in range(reps):
+        run(); tms.append(M.last_msm_timing())
+    out['wall_ms'] = (time.perf_counter() - t0) / reps * 1e3
+    out.update({k_: float(np.mean([t[k_] for t in tms])) for k_ in tms[0]})
+elif f[0] == 'msm_range':
+    lg = int(f[1]); n = 1 << lg; win = int(f[2]) if len(f) > 2 else 16
+    pb = M.PinnedBases.generate_multiples(synth.generator_affine104(), 1, n).precompute(); pb.precompute_range(0, n, win)
+    ds = torch.from_numpy(synth.witness_like_scalars(n, 77 + lg).view(np.int64)).to(dev); torch.cuda.synchronize()
+    run = lambda: M.VariableBase.msm_device(pb, ds.data_ptr(), n, sparse=True)
     run(); run()
     t0 = time.perf_counter(); tms = []
     for _ in range(reps):
