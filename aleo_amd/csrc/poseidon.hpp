@@ -10,77 +10,11 @@
 // private-key-ciphertext known answer through THIS code (rates 2 and 8 over Fr) via the C ABI.
 #pragma once
 #include "host_field.hpp"
-#include <immintrin.h>
 #include <vector>
 #include <mutex>
 #include <memory>
 
 namespace aleo_mi355x { namespace host {
-
-// ---- wide products: a dot product of W pairs costs W half-products and ONE Montgomery reduction --------------------------------------------
-// Separated operand scanning on mulx / adc chains (x86-64 BMI2 + ADX: every server CPU since 2015; build.sh passes -mbmi2 -madx to the host
-// pass): a row of N mulx, one carry chain for the low halves, one for the high halves.  ~35 ns per Fq product on a 2.1 GHz core against
-// ~60 ns for the generic unsigned __int128 form of host_field.hpp (which stays for everything that is not a hot chain).
-typedef unsigned long long ull;
-template <int N> struct Wide {
-  ull t[2 * N + 1];
-  __attribute__((always_inline)) static inline void product(ull* __restrict o, const ull* __restrict a, const ull* __restrict b) {      // o[0..2N) = a * b
-    ull lo[N], hi[N]; unsigned char c = 0;
-#pragma unroll
-    for (int j = 0; j < N; ++j) lo[j] = _mulx_u64(a[j], b[0], &hi[j]);
-    o[0] = lo[0];
-#pragma unroll
-    for (int j = 1; j < N; ++j) c = _addcarry_u64(c, lo[j], hi[j - 1], &o[j]);
-    _addcarry_u64(c, hi[N - 1], 0, &o[N]);
-#pragma unroll
-    for (int i = 1; i < N; ++i) {
-#pragma unroll
-      for (int j = 0; j < N; ++j) lo[j] = _mulx_u64(a[j], b[i], &hi[j]);
-      c = 0;
-#pragma unroll
-      for (int j = 0; j < N; ++j) c = _addcarry_u64(c, o[i + j], lo[j], &o[i + j]);
-      ull top; _addcarry_u64(c, 0, 0, &top);
-      c = 0;
-#pragma unroll
-      for (int j = 0; j < N - 1; ++j) c = _addcarry_u64(c, o[i + j + 1], hi[j], &o[i + j + 1]);
-      _addcarry_u64(c, top, hi[N - 1], &o[i + N]);                                                         // a row's product has no carry beyond limb i + N
-    }
-  }
-  __attribute__((always_inline)) inline void set_mul(const uint64_t* a, const uint64_t* b) { product(t, (const ull*)a, (const ull*)b); t[2 * N] = 0; }
-  __attribute__((always_inline)) inline void add_mul(const uint64_t* a, const uint64_t* b) {
-    ull u[2 * N]; product(u, (const ull*)a, (const ull*)b);
-    unsigned char c = 0;
-#pragma unroll
-    for (int i = 0; i < 2 * N; ++i) c = _addcarry_u64(c, t[i], u[i], &t[i]);
-    t[2 * N] += c;
-  }
-  // Montgomery reduction of a value < W p^2 with W p < R (R/q = 152, R/r = 13.7; W <= 9): result < 2p before the final subtraction
-  __attribute__((always_inline)) inline HFp<N> redc() {
-    using Pm = HParams<N>;
-    const ull* P = (const ull*)Pm::P;
-    ull pending = 0;                                         // carries out of the previous row, due at limb i + N
-#pragma unroll
-    for (int i = 0; i < N; ++i) {
-      const ull m = t[i] * Pm::INV; ull lo[N], hi[N]; unsigned char c = 0;
-#pragma unroll
-      for (int j = 0; j < N; ++j) lo[j] = _mulx_u64(m, P[j], &hi[j]);
-#pragma unroll
-      for (int j = 0; j < N; ++j) c = _addcarry_u64(c, t[i + j], lo[j], &t[i + j]);
-      const unsigned char k1 = _addcarry_u64(c, t[i + N], pending, &t[i + N]);
-      c = 0;
-#pragma unroll
-      for (int j = 0; j < N; ++j) c = _addcarry_u64(c, t[i + j + 1], hi[j], &t[i + j + 1]);
-      pending = (ull)k1 + c;
-    }
-    t[2 * N] += pending;
-    HFp<N> r;
-#pragma unroll
-    for (int i = 0; i < N; ++i) r.l[i] = t[N + i];
-    if (t[2 * N] || HFp<N>::geq_p(r.l)) HFp<N>::sub_p(r.l);
-    return r;
-  }
-};
-template <int N> __attribute__((always_inline)) inline HFp<N> fmul(const HFp<N>& a, const HFp<N>& b) { Wide<N> w; w.set_mul(a.l, b.l); return w.redc(); }
 
 // ---- parameters ---------------------------------------------------------------------------------------------------------------------------
 struct GrainLFSR {                                         // 80 bits: [01 | s-box 0000 | field bits (12) | width (12) | full (10) | partial (10) | thirty ones]
