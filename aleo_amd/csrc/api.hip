@@ -102,19 +102,17 @@ static int32_t upload_bases(Ctx* c, const void* bases, size_t stride, size_t n, 
   bool any_inf = false;
   if (stride == 96) {
     HIPCHK(hipMemcpy(pb.d_xy, bases, n * 96, hipMemcpyHostToDevice));
-  } else {
-    // strip the infinity byte + padding of snarkVM's 104-byte Affine on the host, one pass
-    std::vector<uint8_t> packed(bytes), inf(n ? n : 1, 0);
-    const uint8_t* src = (const uint8_t*)bases;
-    for (size_t i = 0; i < n; ++i) {
-      std::memcpy(&packed[i * 96], src + i * stride, 96);
-      if (src[i * stride + 96]) { inf[i] = 1; any_inf = true; }
-    }
-    HIPCHK(hipMemcpy(pb.d_xy, packed.data(), n * 96, hipMemcpyHostToDevice));
-    if (any_inf) {
-      HIPCHK(hipMalloc((void**)&pb.d_inf, n));
-      HIPCHK(hipMemcpy(pb.d_inf, inf.data(), n, hipMemcpyHostToDevice));
-    }
+  } else if (n) {
+    // snarkVM's 104-byte Affine: the rows go up as they are (one copy at PCIe rate; a host loop that strips the infinity byte + padding first
+    // cost 30 ms per 2^20 points — the one-shot call of the two-line drop-in spent most of its time there) and are unpacked on the device
+    DevTmp raw, flags; int32_t rcu;
+    if ((rcu = raw.alloc(n * 104)) || (rcu = flags.alloc(n + 8))) return rcu;
+    HIPCHK(hipMemcpyAsync(raw.p, bases, n * 104, hipMemcpyHostToDevice, c->stream));
+    if ((rcu = unpack_affine104(c, raw.p, pb.d_xy, flags.p, n, c->stream))) return rcu;      // rows -> 96-byte x | y, flag bytes, their count behind the flags
+    uint32_t n_inf = 0;
+    HIPCHK(hipMemcpyAsync(&n_inf, (char*)flags.p + ((n + 3) & ~(size_t)3), 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (n_inf) { pb.d_inf = (uint8_t*)flags.release(); any_inf = true; }
   }
   { int32_t rc28 = make_rows28(c, &pb); if (rc28) return rc28; }
   *out = std::move(o); return ALEO_MI355X_OK;

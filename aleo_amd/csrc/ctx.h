@@ -158,6 +158,7 @@ int32_t generate_multiples(Ctx* c, const void* base104, uint64_t first, size_t n
 int32_t generate_from_scalars(Ctx* c, const void* base104, const void* scalars32, size_t n, PinnedBases* out);
 int32_t msm_precompute(Ctx* c, PinnedBases* pb);
 int32_t msm_precompute_range(Ctx* c, PinnedBases* pb, size_t off, size_t n, int window_bits);
+int32_t unpack_affine104(Ctx* c, const void* d_rows104, void* d_xy96, void* d_flags, size_t n, hipStream_t s);      // d_flags: n bytes + a uint32 count at the next multiple of 4
 int32_t make_rows28(Ctx* c, PinnedBases* pb);          // fills pb->d_xy28 from pb->d_xy
 int32_t selftest_madd28(Ctx* c, uint32_t lanes, uint32_t steps, uint64_t seed, uint32_t* failures);
 int32_t selftest_addquad(Ctx* c, uint32_t ops, uint64_t seed, uint32_t* failures);

@@ -1356,6 +1356,27 @@ __global__ void __launch_bounds__(256) k_pre_double(char* __restrict__ cur, uint
   store_xyzz(cur + (size_t)i * 192, a);
 }
 
+// 104-byte Affine rows (x | y | infinity byte | padding) -> 96-byte rows, the flag bytes, and the number of flagged rows
+__global__ void __launch_bounds__(256) k_unpack104(const char* __restrict__ src, char* __restrict__ dst, uint8_t* __restrict__ flags, uint32_t* __restrict__ count, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const uint2* s2 = (const uint2*)(src + i * 104); uint2* d2 = (uint2*)(dst + i * 96);
+#pragma unroll
+    for (int k = 0; k < 12; ++k) d2[k] = s2[k];
+    const uint8_t f = (uint8_t)(s2[12].x & 0xffu) ? 1 : 0;
+    flags[i] = f;
+    if (f) atomicAdd(count, 1u);
+  }
+}
+int32_t unpack_affine104(Ctx* c, const void* d_rows104, void* d_xy96, void* d_flags, size_t n, hipStream_t s) {
+  (void)c;
+  uint32_t* count = (uint32_t*)((char*)d_flags + ((n + 3) & ~(size_t)3));
+  HIPCHK(hipMemsetAsync(count, 0, 4, s));
+  const size_t want = (n + 255) / 256;
+  hipLaunchKernelGGL(k_unpack104, dim3((uint32_t)(want < 16384 ? want : 16384)), dim3(256), 0, s, (const char*)d_rows104, (char*)d_xy96, (uint8_t*)d_flags, count, n);
+  HIPCHK(hipGetLastError());
+  return ALEO_MI355X_OK;
+}
+
 int32_t make_rows28(Ctx* c, PinnedBases* pb) {
   if (pb->d_xy28 || pb->n == 0) return ALEO_MI355X_OK;
   DevTmp rows; int32_t rc;
