@@ -709,6 +709,21 @@ def test_async_device_calls_order_their_scratch_across_streams(tmp_path):
     assert r.returncode == 0 and 'SCRATCH OK' in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
+def test_config4_full_size_as_eight_shards_in_one_process():
+    """BASELINE configs[4] at its full size through the multi-device entry of the C ABI: 2^26 points, P_i = (i + 1) G generated shard by shard, as
+    EIGHT shards of 2^23 points with their fixed-base tables — all eight on the one visible card (no 8-GPU node here: the split, the per-shard
+    Pippenger, the host merge and the sizes are the real ones, the device is shared) — against the structured identity in big integers."""
+    n = 1 << 26
+    with aleo_amd.ShardedBases.generate_multiples(synth.generator_affine104(), 1, n, devices=[0] * 8, precompute=True) as sb:
+        sh = sb.shards()
+        assert len(sh) == 8 and all(cnt == 1 << 23 for _, _, cnt in sh)
+        S = util.uniform_scalars(n, 2626)
+        got, part = M.VariableBase.msm_sharded(sb, S, partials=True)
+        assert c.jac_to_int_point(got) == util.expected_multiples_msm(S, n)
+        lo = 3 << 23                                                              # one partial against its own identity: sum_i s_i (lo + i + 1) G over shard 3
+        assert c.jac_to_int_point(part[3]) == p.g1_mul(p.G1_GENERATOR, synth.weighted_scalar_sum(S[lo:lo + (1 << 23)], lo + 1))
+
+
 @pytest.mark.parametrize('mode', ['null', 'stream'])
 def test_first_call_of_a_process_is_a_batched_transform(mode):
     """Regression for the host segfault of round 2 (gpurun_out/r02_t1.log: inside aleo_mi355x_ntt_fr_batch_device while the stream-ordered slot
