@@ -21,7 +21,7 @@ EXPORTS = [
     'aleo_mi355x_poseidon_hash_fr', 'aleo_mi355x_fs_new', 'aleo_mi355x_fs_free', 'aleo_mi355x_fs_absorb_bytes', 'aleo_mi355x_fs_absorb_g1',
     'aleo_mi355x_fs_absorb_fr', 'aleo_mi355x_fs_squeeze_fr', 'aleo_mi355x_fr_random',
     'aleo_mi355x_init_device', 'aleo_mi355x_device_count', 'aleo_mi355x_bases_pin_sharded', 'aleo_mi355x_bases_generate_sharded', 'aleo_mi355x_bases_unpin_sharded',
-    'aleo_mi355x_bases_sharded_info', 'aleo_mi355x_msm_g1_sharded',
+    'aleo_mi355x_bases_sharded_info', 'aleo_mi355x_msm_g1_sharded', 'aleo_mi355x_fr_transpose_device', 'aleo_mi355x_ntt_fr_sharded',
 ]
 
 
@@ -62,6 +62,8 @@ def lib():
         'aleo_mi355x_bases_unpin_sharded': ([u64], i32),
         'aleo_mi355x_bases_sharded_info': ([u64, ctypes.POINTER(u64), i32], i32),
         'aleo_mi355x_msm_g1_sharded': ([vp, u64, vp, sz, vp], i32),
+        'aleo_mi355x_fr_transpose_device': ([vp, vp, u64, u64, vp], i32),
+        'aleo_mi355x_ntt_fr_sharded': ([vp, u32, i32, i32, ctypes.POINTER(i32), sz], i32),
         'aleo_mi355x_msm_g1': ([vp, vp, sz, vp, sz], i32),
         'aleo_mi355x_bases_pin': ([vp, sz, sz, ctypes.POINTER(u64)], i32),
         'aleo_mi355x_bases_unpin': ([u64], i32),

@@ -902,6 +902,15 @@ int32_t aleo_mi355x_fr_grid_scale_device(void* d_data, uint32_t lg_n, uint64_t r
   } catch (...) { return ALEO_MI355X_ERR_HIP; }
 }
 
+int32_t aleo_mi355x_fr_transpose_device(void* d_dst, const void* d_src, uint64_t rows, uint64_t cols, void* stream) {
+  try {
+    if ((!d_dst || !d_src) && rows && cols) { g_last_error = "fr_transpose_device: bad argument"; return ALEO_MI355X_ERR_BAD_ARG; }
+    if (d_dst == d_src && rows > 1 && cols > 1) { g_last_error = "fr_transpose_device: in place is not supported"; return ALEO_MI355X_ERR_BAD_ARG; }
+    API_BEGIN
+    return run_enqueue(c, stream, [&](hipStream_t s) { return fr_transpose(c, d_dst, d_src, rows, cols, s); });
+  } catch (...) { return ALEO_MI355X_ERR_HIP; }
+}
+
 int32_t aleo_mi355x_fq_mul(void* r, const void* a, const void* b, size_t n) {
   try { if ((!r || !a || !b) && n) return ALEO_MI355X_ERR_BAD_ARG; API_BEGIN return launch_fq_mul(c, r, a, b, n); } catch (...) { return ALEO_MI355X_ERR_HIP; }
 }
@@ -1064,6 +1073,79 @@ int32_t aleo_mi355x_msm_g1_sharded(void* out_jacobian, uint64_t handle, const vo
     if (rc) return rc;
     if (partials_out) std::memcpy(partials_out, part.data(), part.size() * 8);
     return aleo_mi355x_g1_sum(out_jacobian, part.data(), G);
+  } catch (...) { return ALEO_MI355X_ERR_HIP; }
+}
+
+
+// ---- one transform over several devices of this process: the 4-step schedule of aleo_amd/dist.py ShardedDomain behind the C ABI --------------------
+// n = R * C (R = 2^floor(lg n / 2)), G devices, natural order in and out of ONE host buffer:
+//   device g uploads the coefficient COLUMNS c in [g C / G, (g + 1) C / G) of the R x C matrix x[r C + c] (a strided copy: its 1/G of the PCIe traffic),
+//   transposes them, runs its C / G column transforms of length R, multiplies by w_n^(c k_r) and cuts the result into G blocks by k_r range;
+//   block h goes to device h (one peer copy per pair: the all-to-all of SURVEY.md 8(e), G - 1 peers per device, one per xGMI link);
+//   device h transposes what it received into rows k_r, runs its R / G row transforms of length C, transposes once more and stores X[k_c R + k_r]
+//   straight into the host buffer (strided copy).  Coset shift and n^-1 as in the single-device transform (fr_grid_scale mode 1 / the batched inverse).
+// Threads: one per shard and phase (the runtime's current device is per thread); phases are separated by joins, so no peer copy starts before
+// every column transform has finished.  A device may be listed more than once (the tests: one card).
+}  // extern "C" (helpers of the sharded transform follow)
+namespace {
+struct NttShard { int dev = 0; hipStream_t st = nullptr; void *a = nullptr, *b = nullptr; };      // two buffers of n / G elements each, ping-pong
+int32_t peer_copy(void* dst, int dst_dev, const void* src, int src_dev, size_t bytes, hipStream_t s) {
+  if (dst_dev == src_dev) { HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, s)); }
+  else { HIPCHK(hipMemcpyPeerAsync(dst, dst_dev, src, src_dev, bytes, s)); }
+  return ALEO_MI355X_OK;
+}
+}  // namespace
+extern "C" {
+
+int32_t aleo_mi355x_ntt_fr_sharded(void* inout, uint32_t lg_n, int32_t direction, int32_t type, const int32_t* devices, size_t n_devices) {
+  try {
+    if (!inout || lg_n < 2 || lg_n > 30 || direction < 0 || direction > 1 || type < 0 || type > 1) { g_last_error = "ntt_fr_sharded: bad argument"; return ALEO_MI355X_ERR_BAD_ARG; }
+    if (n_devices < 1 || n_devices > 64 || (n_devices & (n_devices - 1))) { g_last_error = "ntt_fr_sharded: the number of shards must be a power of two (1..64)"; return ALEO_MI355X_ERR_BAD_ARG; }
+    uint32_t lg_g = 0; while ((1u << lg_g) < n_devices) ++lg_g;
+    const uint32_t lg_r = lg_n / 2, lg_c = lg_n - lg_r;
+    if (lg_r < lg_g) { g_last_error = "ntt_fr_sharded: domain too small for this many shards"; return ALEO_MI355X_ERR_BAD_ARG; }
+    ShardedSet S; int32_t rc = sharded_layout(S, (size_t)1 << lg_n, devices, n_devices); if (rc) return rc;      // (only its device list is used)
+    const size_t G = n_devices, R = (size_t)1 << lg_r, C = (size_t)1 << lg_c, Rg = R / G, Cg = C / G, per = R * Cg;   // per = elements per shard (= Rg * C)
+    std::vector<NttShard> sh(G);
+    char* host = (char*)inout;
+    auto cleanup = [&]() { (void)for_each_shard(S, [&](size_t g) -> int32_t { if (sh[g].st) { (void)hipStreamSynchronize(sh[g].st); (void)hipStreamDestroy(sh[g].st); } if (sh[g].a) (void)hipFree(sh[g].a); if (sh[g].b) (void)hipFree(sh[g].b); return ALEO_MI355X_OK; }); };
+    // phase 1: columns in, column transforms, twiddle, blocks by destination
+    rc = for_each_shard(S, [&](size_t g) -> int32_t {
+      NttShard& d = sh[g]; d.dev = S.devices[g];
+      HIPCHK(hipStreamCreateWithFlags(&d.st, hipStreamNonBlocking));
+      HIPCHK(hipMalloc(&d.a, per * 32)); HIPCHK(hipMalloc(&d.b, per * 32));
+      HIPCHK(hipMemcpy2DAsync(d.a, Cg * 32, host + g * Cg * 32, C * 32, Cg * 32, R, hipMemcpyHostToDevice, d.st));               // a = [R][Cg]
+      int32_t r;
+      if (type == ALEO_NTT_COSET && direction == ALEO_NTT_FORWARD && (r = aleo_mi355x_fr_grid_scale_device(d.a, lg_n, R, Cg, 0, g * Cg, C, 1, 0, d.st))) return r;
+      if ((r = aleo_mi355x_fr_transpose_device(d.b, d.a, R, Cg, d.st))) return r;                                                   // b = [Cg][R]
+      if ((r = aleo_mi355x_ntt_fr_batch_device(d.b, lg_r, Cg, ALEO_NTT_ORDER_NN, direction, ALEO_NTT_STANDARD, d.st))) return r;     // [c][k_r] (inverse: x R^-1)
+      if ((r = aleo_mi355x_fr_grid_scale_device(d.b, lg_n, Cg, R, g * Cg, 0, 0, 0, direction, d.st))) return r;                     // *= w_n^(+-c k_r)
+      for (size_t h = 0; h < G; ++h)                                                                                                // a = [h][Cg][Rg]: block h = my columns, device h's k_r range
+        HIPCHK(hipMemcpy2DAsync((char*)d.a + h * Cg * Rg * 32, Rg * 32, (char*)d.b + h * Rg * 32, R * 32, Rg * 32, Cg, hipMemcpyDeviceToDevice, d.st));
+      HIPCHK(hipStreamSynchronize(d.st));
+      return ALEO_MI355X_OK;
+    });
+    if (rc) { const std::string keep = g_last_error; cleanup(); g_last_error = keep; return rc; }
+    // phase 2: the exchange — device h pulls block h of every device g into b = [g][Cg][Rg] = [C][Rg]
+    rc = for_each_shard(S, [&](size_t h) -> int32_t {
+      for (size_t g = 0; g < G; ++g) { int32_t r = peer_copy((char*)sh[h].b + g * Cg * Rg * 32, sh[h].dev, (char*)sh[g].a + h * Cg * Rg * 32, sh[g].dev, Cg * Rg * 32, sh[h].st); if (r) return r; }
+      HIPCHK(hipStreamSynchronize(sh[h].st));
+      return ALEO_MI355X_OK;
+    });
+    if (rc) { const std::string keep = g_last_error; cleanup(); g_last_error = keep; return rc; }
+    // phase 3: row transforms, natural order out
+    rc = for_each_shard(S, [&](size_t h) -> int32_t {
+      NttShard& d = sh[h]; int32_t r;
+      if ((r = aleo_mi355x_fr_transpose_device(d.a, d.b, C, Rg, d.st))) return r;                                                   // a = [Rg][C]
+      if ((r = aleo_mi355x_ntt_fr_batch_device(d.a, lg_c, Rg, ALEO_NTT_ORDER_NN, direction, ALEO_NTT_STANDARD, d.st))) return r;     // [k_r][k_c] (inverse: x C^-1)
+      if ((r = aleo_mi355x_fr_transpose_device(d.b, d.a, Rg, C, d.st))) return r;                                                   // b = [k_c][k_r local]: X[k_c R + k_r]
+      if (type == ALEO_NTT_COSET && direction == ALEO_NTT_INVERSE && (r = aleo_mi355x_fr_grid_scale_device(d.b, lg_n, C, Rg, 0, h * Rg, R, 1, 1, d.st))) return r;
+      HIPCHK(hipMemcpy2DAsync(host + h * Rg * 32, R * 32, d.b, Rg * 32, Rg * 32, C, hipMemcpyDeviceToHost, d.st));
+      HIPCHK(hipStreamSynchronize(d.st));
+      return ALEO_MI355X_OK;
+    });
+    const std::string keep = g_last_error; cleanup(); if (rc) g_last_error = keep;
+    return rc;
   } catch (...) { return ALEO_MI355X_ERR_HIP; }
 }
 

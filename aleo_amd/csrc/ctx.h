@@ -197,6 +197,7 @@ void jacobian_rows_to_affine104(void* out104, const uint64_t* jac18, size_t k);
 // ntt.hip
 int32_t ntt_run(Ctx* c, void* d_inout, uint32_t lg_n, size_t batch, int32_t order, int32_t direction, int32_t type, hipStream_t s);
 
+int32_t fr_transpose(Ctx* c, void* d_dst, const void* d_src, uint64_t rows, uint64_t cols, hipStream_t s);      // dst[c][r] = src[r][c], 32-byte elements
 int32_t fr_grid_scale(Ctx* c, void* d_data, uint32_t lg_n, uint64_t rows, uint64_t cols, uint64_t row0, uint64_t col0, uint64_t ld, int32_t mode,
                       int32_t direction, hipStream_t s);
 

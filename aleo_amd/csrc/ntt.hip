@@ -325,6 +325,31 @@ static int32_t run_passes(Ctx* c, char* buf, char* tmp, uint32_t lg_n, uint32_t 
 }
 
 
+// dst[c][r] = src[r][c] for 32-byte elements (rows x cols -> cols x rows): the three layout changes of a 4-step transform (columns contiguous for the
+// column transforms, rows for the row transforms, natural order out).  32 x 32-element tiles through LDS: both sides move 1-KiB runs.
+__global__ void __launch_bounds__(256) k_transpose32(const char* __restrict__ src, char* __restrict__ dst, uint64_t rows, uint64_t cols) {
+  __shared__ uint4 tile[32][33][2];
+  const uint64_t r0 = (uint64_t)blockIdx.y * 32, c0 = (uint64_t)blockIdx.x * 32;
+  const uint32_t tx = threadIdx.x & 31u, ty = threadIdx.x >> 5;                     // 32 x 8 threads
+  for (uint32_t j = ty; j < 32; j += 8) {
+    const uint64_t r = r0 + j, c = c0 + tx;
+    if (r < rows && c < cols) { const uint4* e = (const uint4*)(src + (r * cols + c) * 32); tile[j][tx][0] = e[0]; tile[j][tx][1] = e[1]; }
+  }
+  __syncthreads();
+  for (uint32_t j = ty; j < 32; j += 8) {
+    const uint64_t c = c0 + j, r = r0 + tx;
+    if (r < rows && c < cols) { uint4* e = (uint4*)(dst + (c * rows + r) * 32); e[0] = tile[tx][j][0]; e[1] = tile[tx][j][1]; }
+  }
+}
+int32_t fr_transpose(Ctx* c, void* d_dst, const void* d_src, uint64_t rows, uint64_t cols, hipStream_t s) {
+  (void)c;
+  if (!rows || !cols) return ALEO_MI355X_OK;
+  if ((rows + 31) / 32 > 65535) { g_last_error = "fr_transpose: more than 2^21 rows"; return ALEO_MI355X_ERR_BAD_ARG; }
+  hipLaunchKernelGGL(k_transpose32, dim3((uint32_t)((cols + 31) / 32), (uint32_t)((rows + 31) / 32)), dim3(256), 0, s, (const char*)d_src, (char*)d_dst, rows, cols);
+  HIPCHK(hipGetLastError());
+  return ALEO_MI355X_OK;
+}
+
 // ---- sharded (4-step) transform support: per-element factors over a 2-D block of the size-n index space -----------
 // mode 0: x[r][c] *= w_n^((row0 + r) * (col0 + c))       (the twiddle between the column and the row transforms)
 // mode 1: x[r][c] *= g^((row0 + r) * ld + col0 + c)      (coset shift of a block of the coefficient matrix)

@@ -56,6 +56,14 @@ class EvaluationDomain:
     def coset_fft_in_place(self, x: np.ndarray): self._run_in_place(x, FORWARD, COSET)
     def coset_ifft_in_place(self, x: np.ndarray): self._run_in_place(x, INVERSE, COSET)
 
+    def ntt_sharded_in_place(self, x: np.ndarray, devices, direction=FORWARD, type_=STANDARD):
+        """The same in-place transform split over several devices of this process (aleo_mi355x_ntt_fr_sharded: 4-step, every device uploads its
+        columns, one peer exchange, natural order out).  devices: a list of HIP device indices (an index may repeat) or a count; a power of two."""
+        if not (isinstance(x, np.ndarray) and x.dtype == np.uint64 and x.flags.c_contiguous and x.size == 4 * self.size): raise ValueError('a contiguous uint64[size, 4] buffer')
+        if isinstance(devices, int): dv, g = None, devices
+        else: dv, g = (ctypes.c_int32 * len(devices))(*[int(d) for d in devices]), len(devices)
+        check(lib().aleo_mi355x_ntt_fr_sharded(_p(x), self.log_size_of_group, direction, type_, dv, g), 'ntt_fr_sharded')
+
     def ntt(self, x, order=ORDER_NN, direction=FORWARD, type_=STANDARD):
         """The snarkvm_algorithms_cuda::NTT shape: explicit order / direction / type."""
         return self._run(x, direction, type_, order)

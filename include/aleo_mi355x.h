@@ -165,6 +165,14 @@ int32_t aleo_mi355x_ntt_fr_batch_device(void* d_inout, uint32_t lg_n, size_t bat
  * may be larger than one GPU's share (exponents are carried in 32 bits). */
 int32_t aleo_mi355x_fr_grid_scale_device(void* d_data, uint32_t lg_n, uint64_t rows, uint64_t cols, uint64_t row0, uint64_t col0, uint64_t ld,
                                          int32_t mode, int32_t direction, void* stream);
+/* dst[c][r] = src[r][c] for 32-byte elements (rows x cols -> cols x rows; dst != src): the layout changes of a 4-step transform. */
+int32_t aleo_mi355x_fr_transpose_device(void* d_dst, const void* d_src, uint64_t rows, uint64_t cols, void* stream);
+/* e — ONE transform over several devices of this process (SURVEY.md 8(e) "NTT (if sharded): 4-step"): EvaluationDomain::{fft,ifft,coset_fft,coset_ifft}_in_place
+ * on a host buffer of 2^lg_n Montgomery elements, natural order in and out, split over n_devices (a power of two, <= 2^floor(lg_n / 2); devices == NULL:
+ * device g mod visible; a device may be listed more than once).  n = R C: device g uploads the coefficient columns [g C / G, (g + 1) C / G) — its 1/G of the
+ * PCIe traffic —, runs its column transforms and the twiddle, the devices exchange one block per pair (peer copies: one per xGMI link), every device
+ * runs its row transforms and stores its k_r range of X[k_c R + k_r] straight into the host buffer.  Same values as aleo_mi355x_ntt_fr. */
+int32_t aleo_mi355x_ntt_fr_sharded(void* inout, uint32_t lg_n, int32_t direction, int32_t type, const int32_t* devices, size_t n_devices);
 
 /* a5 — KZG10::commit shape (commit_lagrange is the same call over the pinned Lagrange-basis powers with evaluations as
  * the scalars): coefficients in Montgomery form (as polynomials are stored), converted to canonical

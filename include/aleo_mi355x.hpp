@@ -178,6 +178,14 @@ class EvaluationDomain {
   Result<bool> ifft_in_place(std::vector<Fr>& x) const { return run(x, NTTDirection::Inverse, NTTType::Standard); }
   Result<bool> coset_fft_in_place(std::vector<Fr>& x) const { return run(x, NTTDirection::Forward, NTTType::Coset); }
   Result<bool> coset_ifft_in_place(std::vector<Fr>& x) const { return run(x, NTTDirection::Inverse, NTTType::Coset); }
+  // the same transforms split over several devices of this process (4-step, one peer exchange): devices.size() a power of two
+  Result<bool> in_place_sharded(std::vector<Fr>& x, NTTDirection d, NTTType t, const std::vector<int32_t>& devices) const {
+    if (x.size() > size) return {std::nullopt, Error{ALEO_MI355X_ERR_BAD_ARG}};
+    x.resize(size, Fr{{0, 0, 0, 0}});
+    int32_t rc = aleo_mi355x_ntt_fr_sharded(x.data(), log_size_of_group, (int32_t)d, (int32_t)t, devices.data(), devices.size());
+    if (rc) return {std::nullopt, Error{rc}};
+    return {true, Error{0}};
+  }
  private:
   Result<bool> run(std::vector<Fr>& x, NTTDirection d, NTTType t) const {
     if (x.size() > size) return {std::nullopt, Error{ALEO_MI355X_ERR_BAD_ARG}};

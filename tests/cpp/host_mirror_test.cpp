@@ -105,6 +105,16 @@ int main() {
   CHECK(de.is_ok() && memcmp(&*de.value, &*c0.value, 104) == 0, "deserialize_compressed(serialize_compressed(C)) == C (subgroup checked)");
   CompressedG1 junk = *ser.value; junk.b[47] |= 0x40;
   CHECK(!deserialize_compressed(junk).is_ok(), "an infinity flag with a non-zero x is an Err");
+  {                                                                       // the 4-step transform over four shards (all on device 0) == the single-device transform
+    std::vector<Fr> a(1 << 12), b;
+    for (auto& e : a) { BigInteger256 v = rand_scalar(); memcpy(e.l, v.l, 32); }
+    b = a;
+    auto d12 = EvaluationDomain::new_(1 << 12);
+    CHECK(d12->coset_fft_in_place(a).is_ok() && d12->in_place_sharded(b, NTTDirection::Forward, NTTType::Coset, {0, 0, 0, 0}).is_ok(), "sharded coset_fft returns Ok");
+    CHECK(memcmp(a.data(), b.data(), a.size() * 32) == 0, "sharded coset_fft == coset_fft, bit for bit");
+    CHECK(d12->in_place_sharded(b, NTTDirection::Inverse, NTTType::Coset, {0, 0}).is_ok() && d12->coset_ifft_in_place(a).is_ok() && memcmp(a.data(), b.data(), a.size() * 32) == 0, "sharded coset_ifft == coset_ifft");
+    CHECK(!d12->in_place_sharded(b, NTTDirection::Forward, NTTType::Standard, {0, 0, 0}).is_ok(), "three shards are refused (power of two)");
+  }
   printf("ALL OK\n");
   return 0;
 }

@@ -709,6 +709,34 @@ def test_async_device_calls_order_their_scratch_across_streams(tmp_path):
     assert r.returncode == 0 and 'SCRATCH OK' in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
+def test_sharded_ntt_over_device_contexts_matches_single_device():
+    """aleo_mi355x_ntt_fr_sharded (the 4-step transform with one exchange, one process, G device contexts — here the one visible card listed
+    G times): fft / ifft / coset_fft / coset_ifft on a host buffer, natural order in and out, against the oracle at small sizes and against the
+    single-device transform up to 2^20, G = 1, 2, 4, 8; the transpose kernel on ragged shapes; misuse refused."""
+    import torch
+    L = aleo_amd.lib()
+    for lg, Gs in ((2, (1, 2)), (3, (1, 2)), (6, (1, 2, 4, 8)), (9, (2, 4)), (13, (1, 4, 8)), (16, (2, 8))):
+        x = c.fr_to_mont(util.uniform_scalars(1 << lg, 7000 + lg)); d = aleo_amd.EvaluationDomain(1 << lg)
+        for G_ in Gs:
+            for direction in (0, 1):
+                for typ in (0, 1):
+                    y = x.copy(); d.ntt_sharded_in_place(y, [0] * G_, direction, typ)
+                    assert (y == c.ntt_fr(x, 0, direction, typ)).all(), (lg, G_, direction, typ)
+    x = c.fr_to_mont(util.uniform_scalars(1 << 20, 7020)); d = aleo_amd.EvaluationDomain(1 << 20)
+    want = d.coset_fft(x)
+    y = x.copy(); d.ntt_sharded_in_place(y, 4, 0, 1); assert (y == want).all()            # devices given as a count: device g mod visible
+    d.ntt_sharded_in_place(y, [0, 0], 1, 1); assert (y == x).all()                          # coset_ifft brings it back
+    for rows, cols in ((1, 1), (3, 5), (32, 32), (33, 31), (100, 7), (1, 64)):              # dst[c][r] = src[r][c]
+        a = util.uniform_scalars(rows * cols, 9).reshape(rows, cols, 4)
+        src = torch.from_numpy(a.view(np.int64).copy()).cuda(); dst = torch.zeros((cols, rows, 4), dtype=torch.int64, device='cuda'); torch.cuda.synchronize()
+        aleo_amd._lib.check(L.aleo_mi355x_fr_transpose_device(ctypes.c_void_p(dst.data_ptr()), ctypes.c_void_p(src.data_ptr()), rows, cols, None), 'fr_transpose_device')
+        assert (dst.cpu().numpy().view(np.uint64) == a.transpose(1, 0, 2)).all(), (rows, cols)
+    buf = x[:64].copy()
+    assert L.aleo_mi355x_ntt_fr_sharded(buf.ctypes.data_as(ctypes.c_void_p), 6, 0, 0, None, 3) == 2          # not a power of two
+    assert L.aleo_mi355x_ntt_fr_sharded(buf.ctypes.data_as(ctypes.c_void_p), 6, 0, 0, None, 16) == 2         # more shards than rows
+    assert L.aleo_mi355x_ntt_fr_sharded(None, 6, 0, 0, None, 2) == 2
+
+
 def test_config4_full_size_as_eight_shards_in_one_process():
     """BASELINE configs[4] at its full size through the multi-device entry of the C ABI: 2^26 points, P_i = (i + 1) G generated shard by shard, as
     EIGHT shards of 2^23 points with their fixed-base tables — all eight on the one visible card (no 8-GPU node here: the split, the per-shard
