@@ -42,6 +42,21 @@ int32_t aleo_mi355x_poseidon_hash_fr(uint32_t rate, const void* inputs, size_t n
   } catch (...) { return ALEO_MI355X_ERR_HIP; }
 }
 
+// The parameters themselves (canonical 32-byte values): ark[39][rate + 1] then mds[rate + 1][rate + 1], row-major — what a circuit that constrains
+// the permutation needs (aleo_amd/synth.py poseidon_chain_r1cs builds the R1CS of hash_psd2 gadgets from them).
+int32_t aleo_mi355x_poseidon_parameters_fr(uint32_t rate, void* ark_out, void* mds_out) {
+  try {
+    if (!ark_out || !mds_out || (rate != 2 && rate != 4 && rate != 8)) { g_last_error = "poseidon_parameters_fr: rate 2, 4 or 8; non-null buffers"; return ALEO_MI355X_ERR_BAD_ARG; }
+    auto emit = [&](auto& P, uint32_t W) {
+      uint8_t* a = (uint8_t*)ark_out; uint8_t* m = (uint8_t*)mds_out;
+      for (int r = 0; r < host::POSEIDON_ROUNDS; ++r) for (uint32_t i = 0; i < W; ++i) { const HFr c = HFr::from_mont(P.ark[r][i]); std::memcpy(a + 32 * (r * W + i), c.l, 32); }
+      for (uint32_t i = 0; i < W; ++i) for (uint32_t j = 0; j < W; ++j) { const HFr c = HFr::from_mont(P.mds[i][j]); std::memcpy(m + 32 * (i * W + j), c.l, 32); }
+    };
+    if (rate == 2) emit(host::PoseidonParams<4, 2>::get(), 3); else if (rate == 4) emit(host::PoseidonParams<4, 4>::get(), 5); else emit(host::PoseidonParams<4, 8>::get(), 9);
+    return ALEO_MI355X_OK;
+  } catch (...) { return ALEO_MI355X_ERR_HIP; }
+}
+
 int32_t aleo_mi355x_fs_new(uint64_t* sponge) {
   try {
     if (!sponge) return ALEO_MI355X_ERR_BAD_ARG;

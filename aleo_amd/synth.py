@@ -253,3 +253,71 @@ def synthetic_r1cs_poseidon(n_constraints: int, n_public: int, seed: int, width:
         nv = len(z); z.append(z[-1] * z[-1] % r)
         rows['a'].append([(nv - 1, 1)]); rows['b'].append([(nv - 1, 1)]); rows['c'].append([(nv, 1)])
     return _csr_from_rows(rows, n_constraints), z
+
+
+def poseidon_parameters(rate: int = 2):
+    """(ark 39 x (rate + 1), mds (rate + 1) x (rate + 1)) of snarkVM's Poseidon over Fr as python ints, from the library (aleo_mi355x_poseidon_parameters_fr)."""
+    import ctypes
+    from ._lib import lib, check
+    w = rate + 1
+    ark = np.zeros((39 * w, 4), dtype=np.uint64); mds = np.zeros((w * w, 4), dtype=np.uint64)
+    check(lib().aleo_mi355x_poseidon_parameters_fr(rate, ark.ctypes.data_as(ctypes.c_void_p), mds.ctypes.data_as(ctypes.c_void_p)), 'poseidon_parameters_fr')
+    A = [limbs_to_int(x) for x in ark]; Mx = [limbs_to_int(x) for x in mds]
+    return [A[r * w:(r + 1) * w] for r in range(39)], [Mx[i * w:(i + 1) * w] for i in range(w)]
+
+
+def poseidon_chain_r1cs(n_hashes: int, seed: int):
+    """The R1CS of a REAL gadget instead of a synthetic shape: a chain of `hash_psd2` (snarkVM's Poseidon, rate 2 — the `hash.psd2` opcode of Aleo
+    instructions, the hash of the state-tree paths `Trace::prepare` attaches): h_0 private, h_(k+1) = hash_psd2([h_k, s_k]) with private siblings s_k,
+    the final value public — a Merkle path without the left / right bits.  Per hash: the permutation over the constant-prefix state (the first
+    permutation of [domain, 2] has no variable input and folds into constants), 8 full rounds x 3 + 31 partial rounds x 1 s-boxes, each x^17 as
+    five constraints (L * L = x2, x2 * x2 = x4, x4 * x4 = x8, x8 * x8 = x16, x16 * L = x17) over linear combinations L that grow through the
+    partial rounds exactly as in the gadget (up to ~35 terms: the dense rows of real circuits), + one constraint binding the output.
+    276 constraints per hash.  Variables: [1, root] public.  Returns (csr, z, root); the witness is computed in python integers."""
+    r = FR_MODULUS
+    ark, mds = poseidon_parameters(2)
+    dom = int.from_bytes(b'AleoPoseidon2', 'little') % r
+    def permute_plain(st):
+        for i in range(39):
+            st = [(a + b) % r for a, b in zip(st, ark[i])]
+            if 4 <= i < 35: st[0] = pow(st[0], 17, r)
+            else: st = [pow(v, 17, r) for v in st]
+            st = [sum(st[j] * mds[k][j] for j in range(3)) % r for k in range(3)]
+        return st
+    pre = permute_plain([0, dom, 2])                                  # constant: the state after absorbing [domain, length]
+    coef = [limbs_to_int(x) for x in uniform_scalars(n_hashes + 1, seed)]
+    z = [1, 0]                                                         # z[1] = root, filled at the end
+    rows = {'a': [], 'b': [], 'c': []}
+    def lc_add(a, b):
+        out = dict(a)
+        for v, c_ in b.items(): out[v] = (out.get(v, 0) + c_) % r
+        return out
+    def lc_scale(a, k): return {v: c_ * k % r for v, c_ in a.items()}
+    def lc_val(a): return sum(c_ * z[v] for v, c_ in a.items()) % r
+    def lc_row(a): return sorted((v, c_) for v, c_ in a.items() if c_)
+    def new_var(val): z.append(val % r); return len(z) - 1
+    def sbox(L):
+        x = lc_val(L); cur_lc, cur = L, x
+        for _ in range(4):                                            # x2, x4, x8, x16
+            v = new_var(cur * cur); rows['a'].append(lc_row(cur_lc)); rows['b'].append(lc_row(cur_lc)); rows['c'].append([(v, 1)])
+            cur_lc, cur = {v: 1}, z[v]
+        v = new_var(cur * x); rows['a'].append(lc_row(cur_lc)); rows['b'].append(lc_row(L)); rows['c'].append([(v, 1)])
+        return {v: 1}
+    h = new_var(coef[0]); h_lc = {h: 1}
+    for k in range(n_hashes):
+        s = new_var(coef[k + 1])
+        st = [{0: pre[0]}, lc_add({0: pre[1]}, h_lc), lc_add({0: pre[2]}, {s: 1})]      # absorb [h_k, s_k] into the rate part
+        for i in range(39):
+            st = [lc_add(st[j], {0: ark[i][j]}) for j in range(3)]
+            if 4 <= i < 35: st[0] = sbox(st[0])
+            else: st = [sbox(x) for x in st]
+            st = [lc_add(lc_add(lc_scale(st[0], mds[kk][0]), lc_scale(st[1], mds[kk][1])), lc_scale(st[2], mds[kk][2])) for kk in range(3)]
+        out_lc = st[1]                                                 # squeeze: the first rate element
+        if k + 1 < n_hashes:
+            v = new_var(lc_val(out_lc)); rows['a'].append(lc_row(out_lc)); rows['b'].append([(0, 1)]); rows['c'].append([(v, 1)])
+            h_lc = {v: 1}
+        else:
+            z[1] = lc_val(out_lc); rows['a'].append(lc_row(out_lc)); rows['b'].append([(0, 1)]); rows['c'].append([(1, 1)])
+    n = len(rows['a'])
+    # the prover's layout wants the public variables first: they are (0 = the constant 1, 1 = root) already
+    return _csr_from_rows(rows, n), z, z[1]

@@ -518,21 +518,23 @@ def density_sweep(synth, lg, reps=5):
     from aleo_amd import varuna
     n = (1 << lg) - 64; out = []
     for name, make in (('density 8 / 8', lambda: synth.synthetic_r1cs_density(n, 4, 908, 8, 8)), ('density 16 / 16', lambda: synth.synthetic_r1cs_density(n, 4, 916, 16, 16)),
-                       ('poseidon-shaped, width 9', lambda: synth.synthetic_r1cs_poseidon(n, 4, 77, 9))):
+                       ('poseidon-shaped, width 9', lambda: synth.synthetic_r1cs_poseidon(n, 4, 77, 9)),
+                       ('hash_psd2 chain: the real Poseidon gadget (rate 2), %d hashes' % (n // 276), lambda: synth.poseidon_chain_r1cs(n // 276, 79)[:2])):
         csr, z = make(); zz = np.stack([synth.int_to_limbs(v, 4) for v in z])
+        n_c = len(csr['a'][0]) - 1; n_pub = 2 if 'hash_psd2' in name else 4
         nnz = [int(csr[m][0][-1]) for m in 'abc']; n_k = 2
         while n_k < max(nnz): n_k *= 2
         D = 1
         while D < max(3 << lg, n_k): D *= 2
         ck = varuna.synthetic_committer_key(0x1F3A9C0D5E7B24681357ACE02468BDF013579BDF02468ACE1234567, 0x0FEDCBA9876543210123456789ABCDEF55AA, D - 1)
         try:
-            with varuna.NativeCircuitIndex(csr, n, 4, len(z) - 4, ck) as nx:
+            with varuna.NativeCircuitIndex(csr, n_c, n_pub, len(z) - n_pub, ck) as nx:
                 ts = []
                 for r_ in range(reps + 2):
                     t = time.perf_counter(); nx.prove(zz, 100 + r_); ts.append((time.perf_counter() - t) * 1e3)
                 ms = float(np.median(ts[2:])); km = nx.n_k_m; nh = nx.n_h
                 pts = 3 * (nh + 1) + 3 * nh + (nh - 1) + 2 * nh + sum(k - 1 for k in km) + max(km) + (3 * nh - 1) + (max(km) - 1)
-                out.append({'circuit': name, 'nnz_per_row': [round(v / n, 2) for v in nnz], 'n_k': km, 'msm_points_per_constraint': round(pts / n, 1), 'prove_ms': ms, 'constraints_per_s': n / ms * 1e3})
+                out.append({'circuit': name, 'constraints': n_c, 'nnz_per_row': [round(v / n_c, 2) for v in nnz], 'n_k': km, 'msm_points_per_constraint': round(pts / n_c, 1), 'prove_ms': ms, 'constraints_per_s': n_c / ms * 1e3})
         finally:
             ck.close()
     return out

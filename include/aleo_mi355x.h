@@ -385,6 +385,8 @@ int32_t aleo_mi355x_varuna_last_timing(double* out_ms, int32_t cap);
  *   aleo_mi355x_varuna_prove* run this sponge inside the library; the entry points exist for a host side that drives the rounds itself
  *   (aleo_amd/varuna.py) and for verifiers. */
 int32_t aleo_mi355x_poseidon_hash_fr(uint32_t rate, const void* inputs, size_t n_inputs, void* out, size_t n_out);
+/* the round constants ark[39][rate + 1] and the matrix mds[rate + 1][rate + 1] (row-major, canonical 32-byte Fr) of that hash: what a circuit constraining it needs */
+int32_t aleo_mi355x_poseidon_parameters_fr(uint32_t rate, void* ark_out, void* mds_out);
 int32_t aleo_mi355x_fs_new(uint64_t* sponge);
 int32_t aleo_mi355x_fs_free(uint64_t sponge);
 int32_t aleo_mi355x_fs_absorb_bytes(uint64_t sponge, const void* data, size_t len);

@@ -720,3 +720,42 @@ def test_distinct_seeds_blind_every_element_differently():
         w = p1['witness']; assert len({x for t in w for x in t}) == 6               # the two instances carry the same assignment, yet no two of their commitments coincide
     finally:
         ck.close()
+
+
+@pytest.mark.gpu
+def test_proof_of_a_real_poseidon_gadget_circuit():
+    """Not a synthetic shape: the R1CS of a chain of hash_psd2 gadgets (snarkVM's Poseidon, rate 2, with the library's own round constants and matrix —
+    synth.poseidon_chain_r1cs: x^17 s-boxes as five constraints each, linear layers as growing linear combinations), its public input the final hash.
+    The witness satisfies it, the public root equals hash_psd2 iterated by the restatement AND by the product's host Poseidon, the device proof equals
+    the restatement's byte for byte and verifies (pairing products) for that root and for no other."""
+    import ctypes
+    from aleo_amd import varuna
+    from oracle import poseidon as ps
+    k = 3
+    csr, z, root = synth.poseidon_chain_r1cs(k, 4242)
+    n = len(csr['a'][0]) - 1
+    assert n == 276 * k
+    coef = [synth.limbs_to_int(x) for x in synth.uniform_scalars(k + 1, 4242)]
+    h = coef[0]; hp = coef[0]; L = aleo_amd.lib()
+    for j in range(k):
+        h = ps.hash_psd2([h, coef[j + 1]])
+        a = np.stack([synth.int_to_limbs(hp, 4), synth.int_to_limbs(coef[j + 1], 4)]); o = np.zeros((1, 4), dtype=np.uint64)
+        aleo_amd._lib.check(L.aleo_mi355x_poseidon_hash_fr(2, a.ctypes.data_as(ctypes.c_void_p), 2, o.ctypes.data_as(ctypes.c_void_p), 1), 'poseidon_hash_fr')
+        hp = synth.limbs_to_int(o[0])
+    assert h == hp == root == z[1]
+    rows = lambda m: [[(int(csr[m][1][q]), synth.limbs_to_int(csr[m][2][q])) for q in range(csr[m][0][i], csr[m][0][i + 1])] for i in range(n)]
+    c = V.Circuit(n, 2, len(z) - 2, rows('a'), rows('b'), rows('c'))
+    for i in range(n):                                                       # the witness satisfies every constraint
+        va, vb, vc = (sum(val * z[v] for v, val in c.m[m][i]) % V.R for m in 'abc')
+        assert va * vb % V.R == vc
+    D = _max_degree(c); setup = V.Setup(TAU, S_GAMMA, D); idx = V.Index(c, setup)
+    ck = varuna.synthetic_committer_key(TAU, S_GAMMA, D)
+    try:
+        with varuna.NativeCircuitIndex(csr, n, 2, len(z) - 2, ck) as nx:
+            assert nx.vk_bytes == idx.vk_bytes()
+            data = nx.prove(np.stack([synth.int_to_limbs(v, 4) for v in z]), 99)
+    finally:
+        ck.close()
+    assert data == V.prove(idx, setup, z, _rand(c, 99))[1]
+    vk = setup.verifier_key(c)
+    assert V.verify_pairing(idx, vk, [1, root], data) and not V.verify_pairing(idx, vk, [1, (root + 1) % V.R], data)

@@ -17,6 +17,7 @@ def circuits(lg):
         yield 'density %d / %d' % (d, d), (lambda d=d: synth.synthetic_r1cs_density(n, 4, 900 + d, d, d))
     yield 'poseidon-shaped, width 9 (2.8 / 4.6 / 1)', lambda: synth.synthetic_r1cs_poseidon(n, 4, 77, 9)
     yield 'poseidon-shaped, width 3 (1.8 / 2.6 / 1)', lambda: synth.synthetic_r1cs_poseidon(n, 4, 78, 3)
+    yield 'hash_psd2 chain: the real Poseidon gadget, %d hashes (3.6 / 6.2 / 1)' % (n // 276), lambda: synth.poseidon_chain_r1cs(n // 276, 79)[:2]
 
 
 def msm_points(n_h, km):
@@ -30,13 +31,14 @@ def run(lg, reps=8):
     for name, make in circuits(lg):
         t0 = time.perf_counter(); csr, z = make(); gen_s = time.perf_counter() - t0
         zz = np.stack([synth.int_to_limbs(v, 4) for v in z])
+        n = len(csr['a'][0]) - 1; n_pub = 2 if 'hash_psd2' in name else 4
         nnz = [int(csr[m][0][-1]) for m in 'abc']; n_k = 2
         while n_k < max(nnz): n_k *= 2
         D = 1
         while D < max(3 << lg, n_k): D *= 2
         ck = varuna.synthetic_committer_key(TAU, S_GAMMA, D - 1)
         t0 = time.perf_counter()
-        with varuna.NativeCircuitIndex(csr, n, 4, len(z) - 4, ck) as nx:
+        with varuna.NativeCircuitIndex(csr, n, n_pub, len(z) - n_pub, ck) as nx:
             index_s = time.perf_counter() - t0
             ts = []
             for rep in range(reps + 2):
