@@ -21,7 +21,7 @@ EXPORTS = [
     'aleo_mi355x_poseidon_hash_fr', 'aleo_mi355x_fs_new', 'aleo_mi355x_fs_free', 'aleo_mi355x_fs_absorb_bytes', 'aleo_mi355x_fs_absorb_g1',
     'aleo_mi355x_fs_absorb_fr', 'aleo_mi355x_fs_squeeze_fr', 'aleo_mi355x_fr_random', 'aleo_mi355x_poseidon_parameters_fr',
     'aleo_mi355x_init_device', 'aleo_mi355x_device_count', 'aleo_mi355x_bases_pin_sharded', 'aleo_mi355x_bases_generate_sharded', 'aleo_mi355x_bases_unpin_sharded',
-    'aleo_mi355x_bases_sharded_info', 'aleo_mi355x_msm_g1_sharded', 'aleo_mi355x_fr_transpose_device', 'aleo_mi355x_ntt_fr_sharded',
+    'aleo_mi355x_bases_sharded_info', 'aleo_mi355x_msm_g1_sharded', 'aleo_mi355x_fr_transpose_device', 'aleo_mi355x_ntt_fr_sharded', 'aleo_mi355x_varuna_prove_many',
 ]
 
 
@@ -84,6 +84,7 @@ def lib():
         'aleo_mi355x_varuna_prove_indexed': ([u64, ctypes.POINTER(vp), sz, vp, vp, ctypes.POINTER(sz)], i32),
         'aleo_mi355x_varuna_prove_batch_indexed': ([ctypes.POINTER(u64), sz, ctypes.POINTER(vp), ctypes.POINTER(sz), vp, vp, ctypes.POINTER(sz)], i32),
         'aleo_mi355x_varuna_last_timing': ([ctypes.POINTER(ctypes.c_double), i32], i32),
+        'aleo_mi355x_varuna_prove_many': ([vp, sz], i32),
         'aleo_mi355x_fr_random_device': ([vp, sz, vp, u64, i32, vp], i32),
         'aleo_mi355x_fr_random': ([vp, sz, vp, u64], i32),
         'aleo_mi355x_poseidon_hash_fr': ([u32, vp, sz, vp, sz], i32),

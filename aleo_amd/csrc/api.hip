@@ -764,6 +764,44 @@ int32_t aleo_mi355x_varuna_prove_batch_indexed(const uint64_t* index_handles, si
   } catch (...) { return ALEO_MI355X_ERR_HIP; }
 }
 
+int32_t aleo_mi355x_varuna_prove_many(aleo_mi355x_prove_request* requests, size_t n_requests) {
+  try {
+    if (!requests || n_requests < 1 || n_requests > 64) { g_last_error = "varuna_prove_many: 1..64 requests"; return ALEO_MI355X_ERR_BAD_ARG; }
+    API_BEGIN
+    std::vector<ProveRequest> rq(n_requests); std::vector<std::vector<std::shared_ptr<VarunaIndexOwner>>> keep_ix(n_requests);
+    uint64_t key = 0; bool have_key = false;
+    for (size_t p = 0; p < n_requests; ++p) {
+      aleo_mi355x_prove_request& r = requests[p]; r.status = ALEO_MI355X_OK;
+      auto bad = [&](const char* why) { r.status = ALEO_MI355X_ERR_BAD_ARG; rq[p].status = r.status; rq[p].error = why; };
+      if (!r.index_handles || !r.assignments || !r.n_instances || !r.seed || !r.out_proof || r.n_circuits < 1 || r.n_circuits > 8) { bad("varuna_prove_many: null argument or circuit count outside 1..8"); continue; }
+      size_t total = 0; bool ok = true;
+      for (size_t j = 0; j < r.n_circuits; ++j) { if (r.n_instances[j] < 1 || r.n_instances[j] > 8) ok = false; total += r.n_instances[j]; }
+      for (size_t i = 0; ok && i < total; ++i) if (!r.assignments[i]) ok = false;
+      if (!ok) { bad("varuna_prove_many: 1..8 instances per circuit, no null assignment"); continue; }
+      keep_ix[p].resize(r.n_circuits);
+      for (size_t j = 0; j < r.n_circuits && !rq[p].status; ++j) {
+        const int32_t rci = find_varuna(d, r.index_handles[j], &keep_ix[p][j]);
+        if (rci) { r.status = rci; rq[p].status = rci; rq[p].error = g_last_error; break; }
+        rq[p].ixs.push_back(varuna_index_view(keep_ix[p][j].get()));
+      }
+      if (rq[p].status) continue;
+      if (!have_key) { key = rq[p].ixs[0]->committer_key; have_key = true; }
+      if (rq[p].ixs[0]->committer_key != key) { bad("varuna_prove_many: every request must use indexes of ONE committer key"); continue; }
+      rq[p].assignments = r.assignments; rq[p].ks = r.n_instances; rq[p].seed32 = r.seed; rq[p].out = (uint8_t*)r.out_proof; rq[p].out_len = &r.len;
+    }
+    if (!have_key) { g_last_error = rq[0].error; return rq[0].status ? rq[0].status : ALEO_MI355X_ERR_BAD_ARG; }
+    FIND_BASES(key)
+    std::vector<ProveRequest> live; std::vector<size_t> where;
+    for (size_t p = 0; p < n_requests; ++p) if (!rq[p].status) { live.push_back(rq[p]); where.push_back(p); }
+    int32_t rc = live.empty() ? ALEO_MI355X_OK : varuna_prove_many(c, pb, live);
+    std::string first_error;
+    for (size_t i = 0; i < live.size(); ++i) { requests[where[i]].status = live[i].status; if (live[i].status && first_error.empty()) first_error = live[i].error; }
+    for (size_t p = 0; p < n_requests; ++p) if (rq[p].status && first_error.empty()) first_error = rq[p].error;
+    if (!first_error.empty()) g_last_error = first_error;
+    return rc;
+  } catch (...) { return ALEO_MI355X_ERR_HIP; }
+}
+
 int32_t aleo_mi355x_varuna_last_timing(double* out_ms, int32_t cap) {
   int32_t n = cap < 8 ? cap : 8;
   for (int32_t i = 0; i < n; ++i) out_ms[i] = g_varuna_timing[i];

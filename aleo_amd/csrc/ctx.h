@@ -184,6 +184,10 @@ int32_t fr_divide_by_linear(Ctx* c, void* d_q, void* d_eval, const void* d_p, si
 int32_t fr_spmv(Ctx* c, void* d_y, const void* d_row_ptr, const void* d_col, const void* d_vals, const void* d_x, size_t rows, hipStream_t s);
 // varuna.hip / api.hip
 int32_t varuna_prove(Ctx* c, const PinnedBases& pb, const aleo_mi355x_varuna_index& ix, const void* const* assignments, size_t k, const uint8_t* seed32, uint8_t* out, size_t* out_len);
+// one request of a lockstep call (varuna_prove_many): the circuits of ONE proof, its assignments, seed and output; status / error come back per request
+struct ProveRequest { std::vector<const aleo_mi355x_varuna_index*> ixs; const void* const* assignments = nullptr; const size_t* ks = nullptr; const uint8_t* seed32 = nullptr;
+                      uint8_t* out = nullptr; size_t* out_len = nullptr; int32_t status = 0; std::string error; };
+int32_t varuna_prove_many(Ctx* c, const PinnedBases& pb, std::vector<ProveRequest>& requests);
 int32_t varuna_prove_batch(Ctx* c, const PinnedBases& pb, const aleo_mi355x_varuna_index* const* ixs, size_t m, const void* const* assignments, const size_t* ks,
                            const uint8_t* seed32, uint8_t* out, size_t* out_len);
 extern thread_local double g_varuna_timing[8];

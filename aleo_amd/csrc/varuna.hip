@@ -237,7 +237,7 @@ struct Shared {
   size_t m = 0, K = 0, N = 0, n_kmax = 0, lead = 0, x_total = 0; uint64_t D = 0, gamma_offset = 0;
   hipStream_t s = nullptr; double t_mark[7] = {}; Arena ar{nullptr, 0, 0}; char* pin = nullptr; char* stage = nullptr; char* pin_small = nullptr;
   HFr one, neg1, r2; host::FiatShamir fs; uint64_t lay_mask = 0, lay_blind = 0, lay_blind_mask = 0;
-  char *mask = nullptr, *bl = nullptr, *h1 = nullptr, *g1 = nullptr, *h2 = nullptr, *flag = nullptr;
+  char *mask = nullptr, *bl = nullptr, *h1 = nullptr, *g1 = nullptr, *h2 = nullptr, *flag = nullptr, *evd = nullptr;
   std::vector<HFr> blind, comb, evals, x_mont, ch_b, ch_g; std::vector<uint8_t> wit_aff, aff3;
   uint8_t aff2[208], aff4[104], aff5[208];
   HFr alpha, eta_b, eta_c, beta, gamma, random_v;
@@ -460,16 +460,24 @@ int32_t Prover::fourth_round() {
 }
 
 // ---- the proof: rounds over all circuits, commitments and transcript in between -----------------------------------------------------------------------
+// Every round is three steps: prepare (queue the round's kernels on the stream, list the commitments it needs as RoundJobs), the commitment(s)
+// (run_commits below: ONE launch chain for the jobs of every proof that takes part — a single proof, or several independent proofs in lockstep,
+// aleo_mi355x_varuna_prove_many), finish (absorb the commitments, squeeze the challenges).
+struct RoundJob { std::vector<MsmSeg> segs; uint32_t k = 0; bool sparse = false; uint8_t* out = nullptr; };      // k results (104-byte affine) to `out`
 struct Batch {
   Shared sh; std::vector<std::unique_ptr<Prover>> P;
+  RoundJob job[2]; int njobs = 0; std::function<int32_t()> hook;      // this round's commitments; kernels to queue behind the last commitment chain
+  size_t need_ws_bytes = 0, need_pin_bytes = 0, pin_elems = 0, stage_elems = 0;
   Batch(Ctx* c, const PinnedBases& pb, const uint8_t* seed32) : sh(c, pb, seed32) {}
   int32_t init_sponge();                                   // Varuna::init_sponge: protocol name, batch sizes, public inputs, index commitments
-  int32_t setup(const aleo_mi355x_varuna_index* const* ixs, size_t m, const size_t* ks);
-  int32_t first_round(const void* const* assignments);     // + the 3K + 1 hiding commitments
-  int32_t second_round();                                  // g_1, h_1
-  int32_t third_round();                                   // sigma_{j,M}, g_{j,M}
-  int32_t fourth_round();                                  // h_2
-  int32_t open();                                          // evaluations, the two linear combinations, both KZG openings
+  int32_t setup(const aleo_mi355x_varuna_index* const* ixs, size_t m, const size_t* ks);      // checks + sizes (need_ws_bytes, need_pin_bytes)
+  void attach(char* ws, size_t ws_bytes, char* pin);       // the slices of the slot's device workspace and pinned staging this proof works in
+  int32_t first_prepare(const void* const* assignments); int32_t first_finish();      // the 3K + 1 hiding commitments
+  int32_t second_prepare(); int32_t second_finish();       // g_1, h_1
+  int32_t third_prepare(); int32_t third_finish();         // sigma_{j,M}, g_{j,M}
+  int32_t fourth_prepare(); int32_t fourth_finish();       // h_2
+  int32_t open_evaluate();                                 // the evaluation kernels and their read-back (queued; the caller synchronises)
+  int32_t open_prepare();                                  // evaluations into the transcript, the two linear combinations, both witness polynomials
   int32_t write(uint8_t* out, size_t* out_len);            // Proof::write_le
 };
 
@@ -516,20 +524,30 @@ int32_t Batch::setup(const aleo_mi355x_varuna_index* const* ixs, size_t m, const
   }
   sh.s = c->stream;
   sh.t_mark[0] = now_ms();
-  // ---- workspace ------------------------------------------------------------------------------------------------------------------
+  // ---- workspace sizes (attach() places the proof in its slices) ---------------------------------------------------------------------
   elems += m > 1 ? 16 * sh.N + 4 * sh.n_kmax + 4096 : 0;                                  // the shared polynomials beside the per-circuit accounting (which already covers one circuit's)
-  RC(c->prover_ws.reserve(elems * 32 + (64 << 10)));
-  sh.ar = Arena{(char*)c->prover_ws.p, 0, c->prover_ws.cap};
-  const size_t stage_elems = sh.x_total + (3 * sh.K + 1) * HC + HC + 3 * sh.K;             // x̂ coefficients, hiding polynomials, the opening's hiding quotient, rho: staged through pinned memory
-  const size_t pin_need = (pin_elems + stage_elems) * 32 + 4096;
-  if (c->prover_pin_cap < pin_need) {
-    if (c->prover_pin) { HIPCHK(hipStreamSynchronize(sh.s)); (void)hipHostFree(c->prover_pin); c->prover_pin = nullptr; c->prover_pin_cap = 0; }
-    HIPCHK(hipHostMalloc(&c->prover_pin, pin_need + pin_need / 8, hipHostMallocDefault)); c->prover_pin_cap = pin_need + pin_need / 8;
-  }
-  sh.pin = (char*)c->prover_pin; sh.stage = sh.pin + pin_elems * 32; sh.pin_small = sh.stage + stage_elems * 32;      // 4 KB for small read-backs
+  need_ws_bytes = elems * 32 + (64 << 10);
+  this->pin_elems = pin_elems;
+  stage_elems = sh.x_total + (3 * sh.K + 1) * HC + HC + 3 * sh.K;                          // x̂ coefficients, hiding polynomials, the opening's hiding quotient, rho: staged through pinned memory
+  need_pin_bytes = (pin_elems + stage_elems) * 32 + 4096;
   sh.one = HFr::one(); sh.neg1 = HFr::neg(sh.one); std::memcpy(sh.r2.l, host::HParams<4>::R2, 32);
   // randomness layout (oracle/varuna_ref.py randomness_layout over the largest |H| and all instances)
   sh.lay_mask = 3 * sh.K; sh.lay_blind = 3 * sh.K + 3 * sh.N; sh.lay_blind_mask = sh.lay_blind + 3 * HC * sh.K;
+  return ALEO_MI355X_OK;
+}
+
+void Batch::attach(char* ws, size_t ws_bytes, char* pin) {
+  sh.ar = Arena{ws, 0, ws_bytes};
+  sh.pin = pin; sh.stage = sh.pin + pin_elems * 32; sh.pin_small = sh.stage + stage_elems * 32;      // 4 KB for small read-backs
+}
+
+// The slot's grow-only device workspace and pinned staging, sized for `ws_bytes` / `pin_bytes` (one proof, or the sum over the proofs of a lockstep call)
+static int32_t reserve_prover_memory(Ctx* c, size_t ws_bytes, size_t pin_bytes) {
+  RC(c->prover_ws.reserve(ws_bytes));
+  if (c->prover_pin_cap < pin_bytes) {
+    if (c->prover_pin) { HIPCHK(hipStreamSynchronize(c->stream)); (void)hipHostFree(c->prover_pin); c->prover_pin = nullptr; c->prover_pin_cap = 0; }
+    HIPCHK(hipHostMalloc(&c->prover_pin, pin_bytes + pin_bytes / 8, hipHostMallocDefault)); c->prover_pin_cap = pin_bytes + pin_bytes / 8;
+  }
   return ALEO_MI355X_OK;
 }
 
@@ -552,11 +570,11 @@ int32_t Batch::init_sponge() {
   return ALEO_MI355X_OK;
 }
 
-int32_t Batch::first_round(const void* const* assignments) {
+int32_t Batch::first_prepare(const void* const* assignments) {
   Ctx* c = sh.c; hipStream_t s = sh.s; const size_t K = sh.K, N = sh.N;
   TAKE_M(sh.bl, (3 * K + 1) * HC) TAKE_M(sh.mask, 3 * N)
   sh.blind.assign((3 * K + 1) * HC, HFr::zero()); sh.x_mont.clear();
-  std::vector<MsmSeg> sg, sm;
+  std::vector<MsmSeg>& sg = job[0].segs; std::vector<MsmSeg>& sm = job[1].segs; sg.clear(); sm.clear();
   for (auto& p : P) RC(p->first_round(assignments + p->q0, sg));
   if (sh.flag) HIPCHK(hipMemcpyAsync(sh.pin_small + 3840, sh.flag, 4, hipMemcpyDeviceToHost, s));      // read after the round's commitments
   for (size_t t = 0; t < HC; ++t) sh.blind[3 * K * HC + t] = random_fr(sh.seed, sh.lay_blind_mask + t);
@@ -577,10 +595,15 @@ int32_t Batch::first_round(const void* const* assignments) {
     MsmSeg b; b.d_ptr = sh.bl + 3 * K * HC * 32; b.len = HC; b.off = sh.gamma_offset; b.out = a.out; dst.push_back(b);
     // needs no challenge: behind the (last) commitment chain — the operands of the sumcheck on the device, and on the host the part of the
     // transcript that precedes the first commitments (Varuna::init_sponge: ~ 20 permutations while the GPU accumulates)
-    auto early = [this]() -> int32_t { for (auto& p : P) RC(p->second_round_early()); return init_sponge(); };
-    if (split) { RC(commit(c, pb, sg, (uint32_t)(3 * K), sh.wit_aff.data(), s, true)); RC(commit(c, pb, sm, 1, sh.wit_aff.data() + 104 * 3 * K, s, false, early)); }
-    else RC(commit(c, pb, sg, (uint32_t)(3 * K + 1), sh.wit_aff.data(), s, false, early));
+    hook = [this]() -> int32_t { for (auto& p : P) RC(p->second_round_early()); return init_sponge(); };
+    if (split) { njobs = 2; job[0].k = (uint32_t)(3 * K); job[0].sparse = true; job[0].out = sh.wit_aff.data(); job[1].k = 1; job[1].sparse = false; job[1].out = sh.wit_aff.data() + 104 * 3 * K; }
+    else { njobs = 1; job[0].k = (uint32_t)(3 * K + 1); job[0].sparse = false; job[0].out = sh.wit_aff.data(); }
   }
+  return ALEO_MI355X_OK;
+}
+
+int32_t Batch::first_finish() {
+  const size_t K = sh.K;
   if (sh.flag) { uint32_t f; std::memcpy(&f, sh.pin_small + 3840, 4); if (f) { g_last_error = "varuna_prove: assignment not canonical (an entry is not below r)"; return ALEO_MI355X_ERR_BAD_ARG; } }
   sh.fs.absorb_g1(sh.wit_aff.data(), 104, 3 * K + 1);
   // verifier_first_round [UPSTREAM-RECALL]: per circuit k_j − 1 instance combiners and (but for the first circuit) a circuit combiner in one squeeze,
@@ -598,7 +621,7 @@ int32_t Batch::first_round(const void* const* assignments) {
   return ALEO_MI355X_OK;
 }
 
-int32_t Batch::second_round() {
+int32_t Batch::second_prepare() {
   Ctx* c = sh.c; hipStream_t s = sh.s; const size_t N = sh.N;
   TAKE_M(sh.h1, 2 * N) TAKE_M(sh.g1, N)
   RC(P[sh.lead]->second_round());                                                             // writes h_1, X g_1 (with the mask) in place
@@ -609,12 +632,16 @@ int32_t Batch::second_round() {
     RC(fr_add_tiled(c, sh.g1, N, p->rq, p->n_h, s));                                          // s_j (X g_j): the remainder block repeated |H*| / |H_j| times
   }
   {
-    std::vector<MsmSeg> sg(2);
+    std::vector<MsmSeg>& sg = job[0].segs; sg.assign(2, MsmSeg{});
     sg[0].d_ptr = sh.g1 + 32; sg[0].len = N - 1; sg[0].off = sh.D - (N - 2); sg[0].out = 0;    // degree bound |H*| − 2: shifted powers
     sg[1].d_ptr = sh.h1; sg[1].len = 2 * N; sg[1].off = 0; sg[1].out = 1;
-    RC(commit(c, sh.pb, sg, 2, sh.aff2, s));
+    njobs = 1; job[0].k = 2; job[0].sparse = false; job[0].out = sh.aff2; hook = nullptr;
   }
-  for (size_t j = 0; j < sh.m; ++j) {                                                         // commit() returned after the stream drained: the copies have landed
+  return ALEO_MI355X_OK;
+}
+
+int32_t Batch::second_finish() {
+  for (size_t j = 0; j < sh.m; ++j) {                                                         // the commitments returned after the stream drained: the copies have landed
     uint64_t sum[4]; std::memcpy(sum, sh.pin_small + 3584 + 32 * j, 32);
     if (sum[0] | sum[1] | sum[2] | sum[3]) { g_last_error = "varuna_prove: the assignment does not satisfy the circuit (first sumcheck: the sum over H is not zero)"; return ALEO_MI355X_ERR_UNSATISFIED; }
   }
@@ -624,16 +651,22 @@ int32_t Batch::second_round() {
   return ALEO_MI355X_OK;
 }
 
-int32_t Batch::third_round() {
-  Ctx* c = sh.c; hipStream_t s = sh.s; const size_t m = sh.m;
+int32_t Batch::third_prepare() {
+  const size_t m = sh.m;
   for (auto& p : P) RC(p->third_round());
-  std::vector<MsmSeg> sg(3 * m);
+  std::vector<MsmSeg>& sg = job[0].segs; sg.assign(3 * m, MsmSeg{});
   for (auto& p : P)
     for (size_t M = 0; M < 3; ++M) {
       MsmSeg& g = sg[3 * p->j + M]; g.d_ptr = p->f + (p->ko[M] + 1) * 32; g.len = p->nk[M] - 1; g.off = sh.D - (p->nk[M] - 2); g.out = (uint32_t)(3 * p->j + M);
     }
   sh.aff3.assign(312 * m, 0);
-  RC(commit(c, sh.pb, sg, (uint32_t)(3 * m), sh.aff3.data(), s, false, [this]() -> int32_t { for (auto& p : P) RC(p->fourth_round_early()); return ALEO_MI355X_OK; }));
+  njobs = 1; job[0].k = (uint32_t)(3 * m); job[0].sparse = false; job[0].out = sh.aff3.data();
+  hook = [this]() -> int32_t { for (auto& p : P) RC(p->fourth_round_early()); return ALEO_MI355X_OK; };
+  return ALEO_MI355X_OK;
+}
+
+int32_t Batch::third_finish() {
+  const size_t m = sh.m;
   for (auto& p : P)                                                                           // the sums f_{j,M}(0) |K| were copied out ahead of the commitments: no stream sync of their own
     for (size_t M = 0; M < 3; ++M) { HFr v; std::memcpy(v.l, sh.pin_small + 32 * (3 * p->j + M), 32); p->sigma[M] = HFr::mul(v, fr_u64(p->nk[M])); }
   sh.fs.absorb_g1(sh.aff3.data(), 104, 3 * m);                                                  // absorb_with_msg: the commitments, then the sums circuit by circuit
@@ -646,27 +679,32 @@ int32_t Batch::third_round() {
   return ALEO_MI355X_OK;
 }
 
-int32_t Batch::fourth_round() {
+int32_t Batch::fourth_prepare() {
   Ctx* c = sh.c; hipStream_t s = sh.s;
   TAKE_M(sh.h2, sh.n_kmax)
   std::vector<const void*> terms; std::vector<size_t> lens; std::vector<HFr> co;
   for (auto& p : P) { RC(p->fourth_round()); for (size_t r = 0; r < p->nrun; ++r) { terms.push_back(p->r4_terms[r]); lens.push_back(p->r4_lens[r]); co.push_back(sh.one); } }
   RC(lincomb_any(c, sh.h2, sh.n_kmax, HFr::zero(), terms, lens, co, s));                       // h_2 = sum_{j,M} delta_{j,M} h_{j,M}
   {
-    std::vector<MsmSeg> sg(1); sg[0].d_ptr = sh.h2; sg[0].len = sh.n_kmax; sg[0].off = 0; sg[0].out = 0;
-    RC(commit(c, sh.pb, sg, 1, sh.aff4, s));
+    std::vector<MsmSeg>& sg = job[0].segs; sg.assign(1, MsmSeg{}); sg[0].d_ptr = sh.h2; sg[0].len = sh.n_kmax; sg[0].off = 0; sg[0].out = 0;
+    njobs = 1; job[0].k = 1; job[0].sparse = false; job[0].out = sh.aff4; hook = nullptr;
   }
+  return ALEO_MI355X_OK;
+}
+
+int32_t Batch::fourth_finish() {
   sh.fs.absorb_g1(sh.aff4, 104, 1);
   sh.fs.squeeze_full(&sh.gamma, 1);
   sh.t_mark[4] = now_ms();
   return ALEO_MI355X_OK;
 }
 
-int32_t Batch::open() {
-  Ctx* c = sh.c; hipStream_t s = sh.s; const size_t K = sh.K, N = sh.N, m = sh.m, n_k = sh.n_kmax, ne = K + 1 + 3 * m;
-  const HFr &alpha = sh.alpha, &beta = sh.beta, &gamma = sh.gamma, &eta_b = sh.eta_b, &eta_c = sh.eta_c, &one = sh.one;
+int32_t Batch::open_evaluate() {
+  Ctx* c = sh.c; hipStream_t s = sh.s; const size_t K = sh.K, N = sh.N, m = sh.m, ne = K + 1 + 3 * m;
+  const HFr &beta = sh.beta, &gamma = sh.gamma;
   // ---- evaluations -------------------------------------------------------------------------------------------------------------------------------
-  TAKE_S(evd, ne + 8) TAKE_S(pbeta, 3 * N) TAKE_S(wq, 3 * N) TAKE_S(blq, HC) TAKE_S(pg, n_k) TAKE_S(gq, n_k)
+  TAKE_M(sh.evd, ne + 8)
+  char* evd = sh.evd;
   {
     std::vector<const void*> polys; std::vector<size_t> lens; std::vector<HFr> pts;
     for (auto& p : P) for (size_t i = 0; i < p->k; ++i) { polys.push_back(p->wit + (3 * i + 2) * p->L * 32); lens.push_back(p->L); pts.push_back(beta); }
@@ -675,7 +713,14 @@ int32_t Batch::open() {
     for (size_t at = 0; at < ne; at += 12) { const size_t cnt = ne - at < 12 ? ne - at : 12; RC(fr_eval_batch(c, evd + at * 32, polys.data() + at, lens.data() + at, pts.data() + at, cnt, s)); }
   }
   HIPCHK(hipMemcpyAsync(sh.pin_small, evd, ne * 32, hipMemcpyDeviceToHost, s));
-  HIPCHK(hipStreamSynchronize(s));
+  return ALEO_MI355X_OK;                                                                      // the caller synchronises the stream (once for all proofs of a lockstep call)
+}
+
+int32_t Batch::open_prepare() {
+  Ctx* c = sh.c; hipStream_t s = sh.s; const size_t K = sh.K, N = sh.N, m = sh.m, n_k = sh.n_kmax, ne = K + 1 + 3 * m;
+  const HFr &alpha = sh.alpha, &beta = sh.beta, &gamma = sh.gamma, &eta_b = sh.eta_b, &eta_c = sh.eta_c, &one = sh.one;
+  char* evd = sh.evd;
+  TAKE_S(pbeta, 3 * N) TAKE_S(wq, 3 * N) TAKE_S(blq, HC) TAKE_S(pg, n_k) TAKE_S(gq, n_k)
   sh.evals.assign(ne, HFr::zero());
   for (size_t i = 0; i < ne; ++i) std::memcpy(sh.evals[i].l, sh.pin_small + 32 * i, 32);
   {
@@ -751,13 +796,12 @@ int32_t Batch::open() {
   }
   RC(fr_divide_by_linear(c, gq, evd + (ne + 2) * 32, pg, n_k, gamma.l, s));
   {
-    std::vector<MsmSeg> sg(3);
+    std::vector<MsmSeg>& sg = job[0].segs; sg.assign(3, MsmSeg{});
     sg[0].d_ptr = wq; sg[0].len = 3 * N - 1; sg[0].off = 0; sg[0].out = 0;
     sg[1].d_ptr = blq; sg[1].len = HC - 1; sg[1].off = sh.gamma_offset; sg[1].out = 0;
     sg[2].d_ptr = gq; sg[2].len = n_k - 1; sg[2].off = 0; sg[2].out = 1;
-    RC(commit(c, sh.pb, sg, 2, sh.aff5, s));                                                 // both witness commitments in one call
+    njobs = 1; job[0].k = 2; job[0].sparse = false; job[0].out = sh.aff5; hook = nullptr;      // both witness commitments in one call
   }
-  sh.t_mark[5] = now_ms();
   return ALEO_MI355X_OK;
 }
 
@@ -776,13 +820,95 @@ int32_t Batch::write(uint8_t* out, size_t* out_len) {
   return ALEO_MI355X_OK;
 }
 
+// The commitments of one round for every proof that is still alive: job q of all of them in ONE launch chain (the results of proof p follow those
+// of proof p - 1), the hooks of all of them behind the last chain.  Proofs whose job lists differ in shape (one splits its first round into the
+// sparse witness chain + the mask chain, another does not) cannot share: the caller (prove_many) falls back to one proof at a time.
+static int32_t run_commits(Ctx* c, const PinnedBases& pb, std::vector<Batch*>& bs, hipStream_t s) {
+  if (bs.empty()) return ALEO_MI355X_OK;
+  const int nj = bs[0]->njobs;
+  for (int q = 0; q < nj; ++q) {
+    std::vector<MsmSeg> all; uint32_t k = 0; const bool sparse = bs[0]->job[q].sparse;
+    for (Batch* b : bs) { for (MsmSeg sg : b->job[q].segs) { sg.out += k; all.push_back(sg); } k += b->job[q].k; }
+    std::function<int32_t()> behind = nullptr;
+    if (q == nj - 1) behind = [&bs]() -> int32_t { for (Batch* b : bs) if (b->hook) RC(b->hook()); return ALEO_MI355X_OK; };
+    if (bs.size() == 1) { RC(commit(c, pb, all, k, bs[0]->job[q].out, s, sparse, std::move(behind))); continue; }
+    std::vector<uint8_t> out((size_t)104 * k);
+    RC(commit(c, pb, all, k, out.data(), s, sparse, std::move(behind)));
+    size_t at = 0;
+    for (Batch* b : bs) { std::memcpy(b->job[q].out, out.data() + 104 * at, (size_t)104 * b->job[q].k); at += b->job[q].k; }
+  }
+  return ALEO_MI355X_OK;
+}
+
 // assignments: the instances of circuit 0, then of circuit 1, ... (sum of ks pointers)
 int32_t varuna_prove_batch(Ctx* c, const PinnedBases& pb, const aleo_mi355x_varuna_index* const* ixs, size_t m, const void* const* assignments, const size_t* ks,
                            const uint8_t* seed32, uint8_t* out, size_t* out_len) {
   g_varuna_timing[6] = g_varuna_timing[7] = 0;
-  Batch b(c, pb, seed32);
-  RC(b.setup(ixs, m, ks)); RC(b.first_round(assignments)); RC(b.second_round()); RC(b.third_round()); RC(b.fourth_round()); RC(b.open());
+  Batch b(c, pb, seed32); std::vector<Batch*> one{&b}; hipStream_t s = c->stream;
+  RC(b.setup(ixs, m, ks));
+  RC(reserve_prover_memory(c, b.need_ws_bytes, b.need_pin_bytes));
+  b.attach((char*)c->prover_ws.p, c->prover_ws.cap, (char*)c->prover_pin);
+  RC(b.first_prepare(assignments)); RC(run_commits(c, pb, one, s)); RC(b.first_finish());
+  RC(b.second_prepare()); RC(run_commits(c, pb, one, s)); RC(b.second_finish());
+  RC(b.third_prepare()); RC(run_commits(c, pb, one, s)); RC(b.third_finish());
+  RC(b.fourth_prepare()); RC(run_commits(c, pb, one, s)); RC(b.fourth_finish());
+  RC(b.open_evaluate()); HIPCHK(hipStreamSynchronize(s)); RC(b.open_prepare()); RC(run_commits(c, pb, one, s));
+  b.sh.t_mark[5] = now_ms();
   return b.write(out, out_len);
+}
+
+// Several INDEPENDENT proofs in lockstep (aleo_mi355x_varuna_prove_many): every proof keeps its own transcript, challenges, randomness and workspace
+// slice; what they share is every commitment launch chain (round r of all proofs is one batched MSM: its sort, slice tree, reduction, host tail and
+// stream synchronisation are paid once, not once per proof) and the stream.  A proof that fails (unsatisfied assignment, bad argument) drops out
+// with its status; the others go on.  Byte for byte the proofs of the single-proof entry points under the same seeds.
+int32_t varuna_prove_many(Ctx* c, const PinnedBases& pb, std::vector<ProveRequest>& rq) {
+  g_varuna_timing[6] = g_varuna_timing[7] = 0;
+  const double t0 = now_ms();
+  hipStream_t s = c->stream;
+  std::vector<std::unique_ptr<Batch>> B; std::vector<Batch*> alive; std::vector<size_t> owner;
+  size_t ws_total = 0, pin_total = 0;
+  for (size_t p = 0; p < rq.size(); ++p) {
+    B.emplace_back(new Batch(c, pb, rq[p].seed32));
+    rq[p].status = B[p]->setup(rq[p].ixs.data(), rq[p].ixs.size(), rq[p].ks);
+    if (rq[p].status) { rq[p].error = g_last_error; continue; }
+    ws_total += (B[p]->need_ws_bytes + 255) & ~(size_t)255; pin_total += (B[p]->need_pin_bytes + 255) & ~(size_t)255;
+  }
+  RC(reserve_prover_memory(c, ws_total ? ws_total : 256, pin_total ? pin_total : 256));
+  size_t ws_at = 0, pin_at = 0;
+  for (size_t p = 0; p < rq.size(); ++p) {
+    if (rq[p].status) continue;
+    const size_t w = (B[p]->need_ws_bytes + 255) & ~(size_t)255, h = (B[p]->need_pin_bytes + 255) & ~(size_t)255;
+    B[p]->attach((char*)c->prover_ws.p + ws_at, w, (char*)c->prover_pin + pin_at); ws_at += w; pin_at += h;
+    alive.push_back(B[p].get()); owner.push_back(p);
+  }
+  // one step of every live proof; a failure removes the proof and records its status
+  auto each = [&](const std::function<int32_t(Batch&, size_t)>& f) {
+    std::vector<Batch*> a2; std::vector<size_t> o2;
+    for (size_t i = 0; i < alive.size(); ++i) {
+      const int32_t rc = f(*alive[i], owner[i]);
+      if (rc) { rq[owner[i]].status = rc; rq[owner[i]].error = g_last_error; } else { a2.push_back(alive[i]); o2.push_back(owner[i]); }
+    }
+    alive.swap(a2); owner.swap(o2);
+  };
+  auto commits = [&]() -> int32_t {
+    if (alive.empty()) return ALEO_MI355X_OK;
+    bool uniform = true;
+    for (Batch* b : alive) { uniform = uniform && b->njobs == alive[0]->njobs; for (int q = 0; uniform && q < b->njobs; ++q) uniform = b->job[q].sparse == alive[0]->job[q].sparse; }
+    if (uniform) return run_commits(c, pb, alive, s);
+    for (Batch* b : alive) { std::vector<Batch*> one{b}; RC(run_commits(c, pb, one, s)); }      // mixed shapes: one proof at a time for this round
+    return ALEO_MI355X_OK;
+  };
+  each([&](Batch& b, size_t p) { return b.first_prepare(rq[p].assignments); }); RC(commits()); each([](Batch& b, size_t) { return b.first_finish(); });
+  each([](Batch& b, size_t) { return b.second_prepare(); }); RC(commits()); each([](Batch& b, size_t) { return b.second_finish(); });
+  each([](Batch& b, size_t) { return b.third_prepare(); }); RC(commits()); each([](Batch& b, size_t) { return b.third_finish(); });
+  each([](Batch& b, size_t) { return b.fourth_prepare(); }); RC(commits()); each([](Batch& b, size_t) { return b.fourth_finish(); });
+  each([](Batch& b, size_t) { return b.open_evaluate(); });
+  HIPCHK(hipStreamSynchronize(s));
+  each([](Batch& b, size_t) { return b.open_prepare(); }); RC(commits());
+  each([&](Batch& b, size_t p) { b.sh.t_mark[5] = now_ms(); return b.write(rq[p].out, rq[p].out_len); });
+  for (int i = 0; i < 5; ++i) g_varuna_timing[i] = 0;
+  g_varuna_timing[5] = now_ms() - t0;
+  return ALEO_MI355X_OK;
 }
 
 int32_t varuna_prove(Ctx* c, const PinnedBases& pb, const aleo_mi355x_varuna_index& ix, const void* const* assignments, size_t k, const uint8_t* seed32,

@@ -308,6 +308,34 @@ def prove_batch_native(indexes, assignments, seed=None) -> bytes:
     return out[:n.value].tobytes()
 
 
+class _ProveRequest(ctypes.Structure):
+    """aleo_mi355x_prove_request (include/aleo_mi355x.h)."""
+    _fields_ = [('index_handles', ctypes.c_void_p), ('n_circuits', ctypes.c_size_t), ('assignments', ctypes.c_void_p), ('n_instances', ctypes.c_void_p),
+                ('seed', ctypes.c_void_p), ('out_proof', ctypes.c_void_p), ('len', ctypes.c_size_t), ('status', ctypes.c_int32)]
+
+
+def prove_many_native(requests):
+    """Several independent proofs in lockstep (aleo_mi355x_varuna_prove_many): requests = [(indexes, assignments, seed), ...] with the arguments of
+    prove_batch_native each.  Returns a list with, per request, the proof bytes — or the status code (int) of a request that dropped out (6: an
+    assignment violates its circuit).  Every proof equals what prove_batch_native gives for the same arguments."""
+    keep = []; arr = (_ProveRequest * len(requests))()
+    for q, (indexes, assignments, seed) in enumerate(requests):
+        zs, ks = [], []
+        for ix, inst in zip(indexes, assignments):
+            if isinstance(inst, np.ndarray) and inst.ndim == 2: inst = [inst]
+            rows = [np.ascontiguousarray(a, dtype=np.uint64).reshape(-1, 4) for a in inst]
+            if any(z.shape[0] != ix.n_vars for z in rows): raise ValueError('assignment length differs from the number of variables of its circuit')
+            zs += rows; ks.append(len(rows))
+        handles = (ctypes.c_uint64 * len(indexes))(*[ix.handle for ix in indexes]); counts = (ctypes.c_size_t * len(ks))(*ks)
+        ptrs = (ctypes.c_void_p * len(zs))(*[z.ctypes.data for z in zs]); sd = seed32(seed)
+        out = np.zeros(1200 + 400 * len(ks) + 200 * len(zs), dtype=np.uint8)
+        keep.append((zs, handles, counts, ptrs, sd, out))
+        r = arr[q]; r.index_handles = ctypes.addressof(handles); r.n_circuits = len(indexes); r.assignments = ctypes.addressof(ptrs); r.n_instances = ctypes.addressof(counts)
+        r.seed = ctypes.addressof(sd); r.out_proof = out.ctypes.data; r.len = out.shape[0]; r.status = 0
+    check(lib().aleo_mi355x_varuna_prove_many(ctypes.byref(arr), len(requests)), 'varuna_prove_many')
+    return [keep[q][5][:arr[q].len].tobytes() if arr[q].status == 0 else int(arr[q].status) for q in range(len(requests))]
+
+
 class Trace:
     """snarkvm_synthesizer_process::Trace as the prover sees it (SURVEY.md §8 row a7; the C++ mirror is `aleo_mi355x::Trace`): the transitions of one
     transaction, each the proving key (NativeCircuitIndex) of its function and the assignment its execution produced.  prove_execution / prove_fee group

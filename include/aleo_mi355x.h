@@ -372,6 +372,19 @@ int32_t aleo_mi355x_varuna_prove(const aleo_mi355x_varuna_index* index, const vo
  * the bytes are those of aleo_mi355x_varuna_prove_indexed.  ALEO_MI355X_ERR_UNSATISFIED if any assignment violates its circuit. */
 int32_t aleo_mi355x_varuna_prove_batch_indexed(const uint64_t* index_handles, size_t n_circuits, const void* const* assignments, const size_t* n_instances, const uint8_t seed[32],
                                                void* out_proof, size_t* len);
+/* Several INDEPENDENT proofs in one call, proved in lockstep (a serving path: the reference's dev server proves concurrent requests from
+ * tokio::task::spawn_blocking threads, /root/reference/rust/develop/src/routes.rs:119,149,229 — a front end that collects them calls this instead of
+ * n separate proves).  Every request is one prove_batch_indexed call's worth — its own circuits, assignments, 32-byte seed, transcript and output —
+ * and comes out byte for byte as that call would give it; what the requests share is every commitment launch chain: round r of all of them is ONE
+ * batched MSM, so its sort, slice tree, reduction, host tail and stream synchronisation are paid once per round instead of once per proof
+ * (eight 2^15-constraint proofs: see DESIGN.md 4d).  All indexes must belong to one committer key.  len: in = capacity of out_proof, out = bytes
+ * written.  status (out): per request — a request that fails (unsatisfied assignment: ALEO_MI355X_ERR_UNSATISFIED; bad argument) drops out, the
+ * others complete; the call itself returns non-zero only when nothing could be started or a device call failed.  1..64 requests. */
+typedef struct {
+  const uint64_t* index_handles; size_t n_circuits; const void* const* assignments; const size_t* n_instances; const uint8_t* seed;
+  void* out_proof; size_t len; int32_t status;
+} aleo_mi355x_prove_request;
+int32_t aleo_mi355x_varuna_prove_many(aleo_mi355x_prove_request* requests, size_t n_requests);
 int32_t aleo_mi355x_varuna_last_timing(double* out_ms, int32_t cap);
 
 /* snarkVM's Poseidon on the host (no GPU needed).  Parameters: Grain LFSR, alpha = 17, 8 full + 31 partial rounds, capacity 1 [UPSTREAM-RECALL:

@@ -759,3 +759,36 @@ def test_proof_of_a_real_poseidon_gadget_circuit():
     assert data == V.prove(idx, setup, z, _rand(c, 99))[1]
     vk = setup.verifier_key(c)
     assert V.verify_pairing(idx, vk, [1, root], data) and not V.verify_pairing(idx, vk, [1, (root + 1) % V.R], data)
+
+
+@pytest.mark.gpu
+def test_independent_proofs_in_lockstep_equal_the_single_calls():
+    """aleo_mi355x_varuna_prove_many: independent proofs — different circuits, instance counts, several circuits per proof, different seeds — proved in
+    lockstep (every round's commitments of all of them in one launch chain) come out byte for byte as the single-proof entry points give them and as the
+    restatement gives them; a request with an assignment that violates its circuit drops out with ALEO_MI355X_ERR_UNSATISFIED and one with an unknown
+    index handle with BAD_HANDLE while the others complete; the same once more in another order."""
+    from aleo_amd import varuna
+    cs, csrs, zs, D = _batch_case([(60, 3, 71, 2), (25, 2, 72, 1), (130, 4, 73, 1)])
+    setup = V.Setup(TAU, S_GAMMA, D); idx = [V.Index(c, setup) for c in cs]
+    ck = varuna.synthetic_committer_key(TAU, S_GAMMA, D)
+    lim = lambda a: np.stack([synth.int_to_limbs(v, 4) for v in a])
+    try:
+        nx = [varuna.NativeCircuitIndex(csrs[j], cs[j].n_constraints, cs[j].n_public, len(zs[j][0]) - cs[j].n_public, ck) for j in range(3)]
+        za = [[lim(z) for z in zz] for zz in zs]
+        reqs = [([nx[0]], [za[0]], 11), ([nx[1]], [za[1]], 12), ([nx[2], nx[0]], [za[2], za[0][:1]], 13), ([nx[1]], [za[1]], 14), ([nx[0], nx[1], nx[2]], [za[0], za[1], za[2]], 15)]
+        single = [varuna.prove_batch_native(ix, a, sd) for ix, a, sd in reqs]
+        assert single[1] != single[3]                                               # same statement, different seeds
+        got = varuna.prove_many_native(reqs)
+        assert got == single
+        want2 = V.prove_batch([(idx[2], zs[2]), (idx[0], zs[0][:1])], setup, V.random_stream(13, max(cs[2].n_h, cs[0].n_h), 2))[1]
+        assert got[2] == want2 and V.verify([idx[2], idx[0]], setup, [[z[:cs[2].n_public] for z in zs[2]], [zs[0][0][:cs[0].n_public]]], got[2])
+        bad = za[1][0].copy(); bad[cs[1].n_public + 3] = synth.int_to_limbs(12345, 4)     # breaks a constraint of circuit 1
+        class Ghost: handle = 987654321; n_vars = nx[1].n_vars
+        mixed = [reqs[0], ([nx[1]], [[bad]], 21), reqs[2], ([Ghost()], [za[1]], 22), reqs[4]]
+        out = varuna.prove_many_native(mixed)
+        assert out[0] == single[0] and out[2] == single[2] and out[4] == single[4] and out[1] == 6 and out[3] == 4
+        assert varuna.prove_many_native(list(reversed(reqs))) == list(reversed(single))
+        assert varuna.prove_many_native(reqs[:1]) == single[:1]
+        for x in nx: x.close()
+    finally:
+        ck.close()
