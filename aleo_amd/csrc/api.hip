@@ -56,7 +56,7 @@ static int32_t init_device(int device, Device** out) {
   std::unique_ptr<Device> d(new Device());
   d->device = device;
   if (const char* e = std::getenv("ALEO_MI355X_SLOTS")) { int k = std::atoi(e); if (k >= 1 && k <= MAX_SLOTS) d->n_slots = k; }
-  for (int i = 0; i < MAX_SLOTS; ++i) { d->slots[i].dev = d.get(); d->slots[i].device = device; }
+  for (int i = 0; i < MAX_SLOTS; ++i) { d->slots[i].dev = d.get(); d->slots[i].device = device; d->helpers[i].dev = d.get(); d->helpers[i].device = device; }
   *out = d.get();
   g_devs[device] = d.release();
   return ALEO_MI355X_OK;
@@ -73,6 +73,15 @@ static int32_t get_device(Device** out) {
   return init_device(device, out);
 }
 
+static int32_t first_use(Ctx* c) {          // streams and events of a slot, created when it is first handed out (the device is current)
+  if (c->stream) return ALEO_MI355X_OK;
+  HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  HIPCHK(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+  for (auto& e : c->ev) HIPCHK(hipEventCreate(&e));
+  HIPCHK(hipEventCreateWithFlags(&c->scratch_ev, hipEventDisableTiming));
+  return ALEO_MI355X_OK;
+}
+
 // Picks a free slot (or waits on one chosen by thread id) and locks it for the duration of the call.
 static int32_t acquire_slot(Device* d, Ctx** out, std::unique_lock<std::mutex>& lk) {
   Ctx* c = nullptr;
@@ -85,13 +94,18 @@ static int32_t acquire_slot(Device* d, Ctx** out, std::unique_lock<std::mutex>& 
     lk = std::unique_lock<std::mutex>(d->slots[i].mu); c = &d->slots[i];
   }
   if (hipSetDevice(d->device) != hipSuccess) { g_last_error = "hipSetDevice failed"; return ALEO_MI355X_ERR_HIP; }
-  if (!c->stream) {                         // first use of this slot
-    HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    HIPCHK(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
-    for (auto& e : c->ev) HIPCHK(hipEventCreate(&e));
-    HIPCHK(hipEventCreateWithFlags(&c->scratch_ev, hipEventDisableTiming));
-  }
+  { const int32_t rc = first_use(c); if (rc) return rc; }
   *out = c; return ALEO_MI355X_OK;
+}
+
+int32_t acquire_helpers(Device* d, int want, HelperSet& hs) {
+  for (int i = 0; i < MAX_SLOTS && (int)hs.ctx.size() < want; ++i) {
+    std::unique_lock<std::mutex> t(d->helpers[i].mu, std::try_to_lock);
+    if (!t.owns_lock()) continue;
+    { const int32_t rc = first_use(&d->helpers[i]); if (rc) return rc; }
+    hs.ctx.push_back(&d->helpers[i]); hs.locks.push_back(std::move(t));
+  }
+  return ALEO_MI355X_OK;
 }
 
 // ---- pinned base sets (shared by all slots) ----------------------------------------------------------

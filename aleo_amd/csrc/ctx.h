@@ -134,7 +134,11 @@ struct Device {
   std::map<uint64_t, std::shared_ptr<struct VarunaIndexOwner>> varuna; uint64_t next_varuna = 1;      // circuit indices (varuna.hip)
   std::atomic<int> ntt_attr_mask{0};   // which NTT kernel instances had their LDS limit raised on THIS device
   Ctx slots[MAX_SLOTS];
+  Ctx helpers[MAX_SLOTS];              // extra streams + scratch a lockstep call borrows for its worker threads (never handed out as API slots)
 };
+// Borrows up to `want` idle helper contexts of the device (try-lock: none is waited for); they are released when `hs` goes out of scope.
+struct HelperSet { std::vector<Ctx*> ctx; std::vector<std::unique_lock<std::mutex>> locks; };
+int32_t acquire_helpers(Device* d, int want, HelperSet& hs);
 
 extern thread_local MsmTiming g_last_msm;   // phase times of the calling thread's most recent MSM
 int32_t ensure_host_pinned(Ctx* c, size_t bytes);
@@ -187,7 +191,7 @@ int32_t varuna_prove(Ctx* c, const PinnedBases& pb, const aleo_mi355x_varuna_ind
 // one request of a lockstep call (varuna_prove_many): the circuits of ONE proof, its assignments, seed and output; status / error come back per request
 struct ProveRequest { std::vector<const aleo_mi355x_varuna_index*> ixs; const void* const* assignments = nullptr; const size_t* ks = nullptr; const uint8_t* seed32 = nullptr;
                       uint8_t* out = nullptr; size_t* out_len = nullptr; int32_t status = 0; std::string error; };
-int32_t varuna_prove_many(Ctx* c, const PinnedBases& pb, std::vector<ProveRequest>& requests);
+int32_t varuna_prove_many(Ctx* c, const PinnedBases& pb, std::vector<ProveRequest>& requests, int workers = 0);      // workers: 0 = ALEO_MI355X_LOCKSTEP_WORKERS or 4
 int32_t varuna_prove_batch(Ctx* c, const PinnedBases& pb, const aleo_mi355x_varuna_index* const* ixs, size_t m, const void* const* assignments, const size_t* ks,
                            const uint8_t* seed32, uint8_t* out, size_t* out_len);
 extern thread_local double g_varuna_timing[8];

@@ -20,6 +20,10 @@
 #include <utility>
 #include <memory>
 #include <chrono>
+#include <thread>
+#include <mutex>
+#include <condition_variable>
+#include <algorithm>
 
 namespace aleo_mi355x {
 
@@ -859,53 +863,98 @@ int32_t varuna_prove_batch(Ctx* c, const PinnedBases& pb, const aleo_mi355x_varu
 
 // Several INDEPENDENT proofs in lockstep (aleo_mi355x_varuna_prove_many): every proof keeps its own transcript, challenges, randomness and workspace
 // slice; what they share is every commitment launch chain (round r of all proofs is one batched MSM: its sort, slice tree, reduction, host tail and
-// stream synchronisation are paid once, not once per proof) and the stream.  A proof that fails (unsatisfied assignment, bad argument) drops out
-// with its status; the others go on.  Byte for byte the proofs of the single-proof entry points under the same seeds.
-int32_t varuna_prove_many(Ctx* c, const PinnedBases& pb, std::vector<ProveRequest>& rq) {
+// stream synchronisation are paid once, not once per proof).  Between the commitments the proofs are independent, so they are dealt to W worker
+// threads (the caller's thread is worker 0; the others borrow helper contexts of the device: own stream, own scratch): the transcripts — host
+// Poseidon, the serial part of a proof — run W at a time and the small field / NTT kernels of different proofs overlap on the card.  The workers meet
+// at a barrier before and after each round's commitments, which worker 0 launches on the slot's stream behind an event of every helper stream.
+// A proof that fails (unsatisfied assignment, bad argument) drops out with its status; the others go on.  Byte for byte the proofs of the
+// single-proof entry points under the same seeds.
+namespace {
+struct Barrier {                                           // reusable; C++17 has none
+  std::mutex mu; std::condition_variable cv; size_t n, waiting = 0, phase = 0;
+  explicit Barrier(size_t n_) : n(n_) {}
+  void wait() {
+    std::unique_lock<std::mutex> lk(mu); const size_t ph = phase;
+    if (++waiting == n) { waiting = 0; ++phase; cv.notify_all(); } else cv.wait(lk, [&] { return phase != ph; });
+  }
+};
+}  // namespace
+
+int32_t varuna_prove_many(Ctx* c, const PinnedBases& pb, std::vector<ProveRequest>& rq, int workers) {
   g_varuna_timing[6] = g_varuna_timing[7] = 0;
   const double t0 = now_ms();
-  hipStream_t s = c->stream;
-  std::vector<std::unique_ptr<Batch>> B; std::vector<Batch*> alive; std::vector<size_t> owner;
+  hipStream_t s = c->stream; const size_t n = rq.size();
+  if (workers <= 0) { workers = 4; if (const char* e = std::getenv("ALEO_MI355X_LOCKSTEP_WORKERS")) { const int k = std::atoi(e); if (k >= 1 && k <= MAX_SLOTS + 1) workers = k; } }
+  HelperSet hs;
+  if (workers > 1 && n > 1) RC(acquire_helpers(c->dev, (int)std::min<size_t>(n, (size_t)workers) - 1, hs));
+  std::vector<Ctx*> wc{c}; for (Ctx* h : hs.ctx) wc.push_back(h);
+  const size_t W = wc.size();
+  std::vector<std::unique_ptr<Batch>> B(n); std::vector<char> alive(n, 0);
   size_t ws_total = 0, pin_total = 0;
-  for (size_t p = 0; p < rq.size(); ++p) {
-    B.emplace_back(new Batch(c, pb, rq[p].seed32));
+  for (size_t p = 0; p < n; ++p) {
+    B[p].reset(new Batch(wc[p % W], pb, rq[p].seed32));
     rq[p].status = B[p]->setup(rq[p].ixs.data(), rq[p].ixs.size(), rq[p].ks);
     if (rq[p].status) { rq[p].error = g_last_error; continue; }
-    ws_total += (B[p]->need_ws_bytes + 255) & ~(size_t)255; pin_total += (B[p]->need_pin_bytes + 255) & ~(size_t)255;
+    alive[p] = 1; ws_total += (B[p]->need_ws_bytes + 255) & ~(size_t)255; pin_total += (B[p]->need_pin_bytes + 255) & ~(size_t)255;
   }
   RC(reserve_prover_memory(c, ws_total ? ws_total : 256, pin_total ? pin_total : 256));
   size_t ws_at = 0, pin_at = 0;
-  for (size_t p = 0; p < rq.size(); ++p) {
-    if (rq[p].status) continue;
+  for (size_t p = 0; p < n; ++p) {
+    if (!alive[p]) continue;
     const size_t w = (B[p]->need_ws_bytes + 255) & ~(size_t)255, h = (B[p]->need_pin_bytes + 255) & ~(size_t)255;
     B[p]->attach((char*)c->prover_ws.p + ws_at, w, (char*)c->prover_pin + pin_at); ws_at += w; pin_at += h;
-    alive.push_back(B[p].get()); owner.push_back(p);
   }
-  // one step of every live proof; a failure removes the proof and records its status
-  auto each = [&](const std::function<int32_t(Batch&, size_t)>& f) {
-    std::vector<Batch*> a2; std::vector<size_t> o2;
-    for (size_t i = 0; i < alive.size(); ++i) {
-      const int32_t rc = f(*alive[i], owner[i]);
-      if (rc) { rq[owner[i]].status = rc; rq[owner[i]].error = g_last_error; } else { a2.push_back(alive[i]); o2.push_back(owner[i]); }
-    }
-    alive.swap(a2); owner.swap(o2);
-  };
+  Barrier bar(W); int32_t fatal = ALEO_MI355X_OK; std::string fatal_error;      // fatal: written by worker 0 between two barriers, read by all after the second
+  // the commitments of one round, by worker 0 while the others wait: the helper streams' events first (their kernels wrote this round's scalars)
   auto commits = [&]() -> int32_t {
-    if (alive.empty()) return ALEO_MI355X_OK;
+    std::vector<Batch*> live; for (size_t p = 0; p < n; ++p) if (alive[p]) live.push_back(B[p].get());
+    if (live.empty()) return ALEO_MI355X_OK;
+    for (size_t w = 1; w < W; ++w) HIPCHK(hipStreamWaitEvent(s, wc[w]->ev[0], 0));
     bool uniform = true;
-    for (Batch* b : alive) { uniform = uniform && b->njobs == alive[0]->njobs; for (int q = 0; uniform && q < b->njobs; ++q) uniform = b->job[q].sparse == alive[0]->job[q].sparse; }
-    if (uniform) return run_commits(c, pb, alive, s);
-    for (Batch* b : alive) { std::vector<Batch*> one{b}; RC(run_commits(c, pb, one, s)); }      // mixed shapes: one proof at a time for this round
+    for (Batch* b : live) { uniform = uniform && b->njobs == live[0]->njobs; for (int q = 0; uniform && q < b->njobs; ++q) uniform = b->job[q].sparse == live[0]->job[q].sparse; }
+    if (uniform) return run_commits(c, pb, live, s);
+    for (Batch* b : live) { std::vector<Batch*> one{b}; RC(run_commits(c, pb, one, s)); }      // mixed shapes: one proof at a time for this round
     return ALEO_MI355X_OK;
   };
-  each([&](Batch& b, size_t p) { return b.first_prepare(rq[p].assignments); }); RC(commits()); each([](Batch& b, size_t) { return b.first_finish(); });
-  each([](Batch& b, size_t) { return b.second_prepare(); }); RC(commits()); each([](Batch& b, size_t) { return b.second_finish(); });
-  each([](Batch& b, size_t) { return b.third_prepare(); }); RC(commits()); each([](Batch& b, size_t) { return b.third_finish(); });
-  each([](Batch& b, size_t) { return b.fourth_prepare(); }); RC(commits()); each([](Batch& b, size_t) { return b.fourth_finish(); });
-  each([](Batch& b, size_t) { return b.open_evaluate(); });
-  HIPCHK(hipStreamSynchronize(s));
-  each([](Batch& b, size_t) { return b.open_prepare(); }); RC(commits());
-  each([&](Batch& b, size_t p) { b.sh.t_mark[5] = now_ms(); return b.write(rq[p].out, rq[p].out_len); });
+  auto worker = [&](size_t w) {
+    if (w && hipSetDevice(c->device) != hipSuccess) { for (size_t p = w; p < n; p += W) if (alive[p]) { alive[p] = 0; rq[p].status = ALEO_MI355X_ERR_HIP; rq[p].error = "hipSetDevice failed"; } }
+    hipStream_t sw = wc[w]->stream;
+    // one step of this worker's live proofs; a failure removes the proof and records its status (alive[p] is only written by p's worker, and read by
+    // worker 0 behind a barrier)
+    auto each = [&](const std::function<int32_t(Batch&, size_t)>& f) {
+      for (size_t p = w; p < n; p += W) {
+        if (!alive[p]) continue;
+        int32_t rc;
+        try { rc = f(*B[p], p); } catch (...) { rc = ALEO_MI355X_ERR_HIP; g_last_error = "varuna_prove_many: exception in a worker"; }      // never past the barrier protocol
+        if (rc) { rq[p].status = rc; rq[p].error = g_last_error; alive[p] = 0; }
+      }
+    };
+    auto fail_mine = [&](int32_t rc, const char* why) { for (size_t p = w; p < n; p += W) if (alive[p]) { alive[p] = 0; rq[p].status = rc; rq[p].error = why; } };
+    auto round = [&](const std::function<int32_t(Batch&, size_t)>& prepare, const std::function<int32_t(Batch&, size_t)>& finish) -> bool {
+      each(prepare);
+      if (w && hipEventRecord(wc[w]->ev[0], sw) != hipSuccess) fail_mine(ALEO_MI355X_ERR_HIP, "hipEventRecord failed");
+      bar.wait();
+      if (w == 0) { try { fatal = commits(); } catch (...) { fatal = ALEO_MI355X_ERR_HIP; g_last_error = "varuna_prove_many: exception in the commitments"; } if (fatal) fatal_error = g_last_error; }
+      bar.wait();
+      if (fatal) return false;
+      if (finish) each(finish);
+      return true;
+    };
+    if (!round([&](Batch& b, size_t p) { return b.first_prepare(rq[p].assignments); }, [](Batch& b, size_t) { return b.first_finish(); })) return;
+    if (!round([](Batch& b, size_t) { return b.second_prepare(); }, [](Batch& b, size_t) { return b.second_finish(); })) return;
+    if (!round([](Batch& b, size_t) { return b.third_prepare(); }, [](Batch& b, size_t) { return b.third_finish(); })) return;
+    if (!round([](Batch& b, size_t) { return b.fourth_prepare(); }, [](Batch& b, size_t) { return b.fourth_finish(); })) return;
+    each([](Batch& b, size_t) { return b.open_evaluate(); });
+    if (hipStreamSynchronize(sw) != hipSuccess) fail_mine(ALEO_MI355X_ERR_HIP, "hipStreamSynchronize failed");
+    if (!round([](Batch& b, size_t) { return b.open_prepare(); }, nullptr)) return;
+    each([&](Batch& b, size_t p) { b.sh.t_mark[5] = now_ms(); return b.write(rq[p].out, rq[p].out_len); });
+  };
+  std::vector<std::thread> th;
+  for (size_t w = 1; w < W; ++w) th.emplace_back(worker, w);
+  worker(0);
+  for (auto& t : th) t.join();
+  for (size_t w = 1; w < W; ++w) (void)hipStreamSynchronize(wc[w]->stream);      // nothing of this call is left on a helper stream when it goes back to the pool
+  if (fatal) { g_last_error = fatal_error; return fatal; }
   for (int i = 0; i < 5; ++i) g_varuna_timing[i] = 0;
   g_varuna_timing[5] = now_ms() - t0;
   return ALEO_MI355X_OK;

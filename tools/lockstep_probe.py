@@ -1,5 +1,6 @@
 """Independent proofs per second (not a test): one at a time, T caller threads in flight, and P proofs per aleo_mi355x_varuna_prove_many call (lockstep:
-every round's commitments of the P proofs in one launch chain), also from several threads.  Usage: python tools/lockstep_probe.py [lg]"""
+every round's commitments of the P proofs in one launch chain), also from several threads.  Usage: python tools/lockstep_probe.py [lg]
+`python3 tools/lockstep_probe.py <lg> trace <P> [reps]` only repeats the P-proof call (for rocprofv3 --kernel-trace + tools/trace_busy.py)."""
 import os, sys, json, time, threading
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import numpy as np
@@ -15,6 +16,13 @@ with varuna.NativeCircuitIndex(csr, n, 4, len(z) - 4, ck) as nx:
         for _ in range(reps): fn()
         dt = (time.perf_counter() - t) / reps
         return {'ms_per_call': round(dt * 1e3, 3), 'proofs_per_s': round(proofs / dt, 1), 'constraints_per_s': round(n * proofs / dt)}
+    if len(sys.argv) > 2 and sys.argv[2] == 'trace':
+        P = int(sys.argv[3]); reps = int(sys.argv[4]) if len(sys.argv) > 4 else 12
+        reqs = [([nx], [[zz]], 100 + q) for q in range(P)]
+        varuna.prove_many_native(reqs); t = time.perf_counter()
+        for _ in range(reps): varuna.prove_many_native(reqs)
+        print(json.dumps({'lg': lg, 'P': P, 'ms_per_call': round((time.perf_counter() - t) / reps * 1e3, 3)}), flush=True)
+        ck.close(); sys.exit(0)
     out['single'] = rate(lambda: nx.prove(zz, 5), 1, 8)
     for P in (2, 4, 8, 16, 32):
         reqs = [([nx], [[zz]], 100 + q) for q in range(P)]
