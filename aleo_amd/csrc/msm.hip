@@ -353,7 +353,7 @@ __global__ void __launch_bounds__(256) k_scan_tiles(const uint32_t* hist, uint32
   __shared__ uint2 wsum[4];
   uint32_t base = blockIdx.x * SCAN_TILE + threadIdx.x * 8;
   const SliceRule rule = pick_rule(total_pairs, M);
-  uint32_t c[8]; uint32_t mx = 0;
+  uint32_t c[8]; uint32_t mx = 0, mxc = 0;
 #pragma unroll
   for (int k = 0; k < 8; ++k) c[k] = (base + k < M) ? hist[base + k] : 0u;
   uint2 pre[8]; uint2 run = make_uint2(0, 0);
@@ -363,8 +363,9 @@ __global__ void __launch_bounds__(256) k_scan_tiles(const uint32_t* hist, uint32
     // multi-slice buckets are the only work of the slice tree; the few with > 16 slices (skewed scalars) get their own
     // list so that the launch width of the common list stays at 8 pairs per bucket
     if (m > 16) { uint32_t q = atomicAdd(&meta[5], 1u); if (q < SUPER_CAP) heavy[M + 2048 + q] = base + k; else heavy[atomicAdd(&meta[3], 1u)] = base + k; }
-    else if (m > 1) heavy[atomicAdd(&meta[3], 1u)] = base + k;
+    else if (m > 1) { heavy[atomicAdd(&meta[3], 1u)] = base + k; mxc = mxc > m ? mxc : m; }
   }
+  if (mxc > 1) atomicMax(&meta[6], mxc);                   // most slices of a common-list bucket: the depth of ITS tree (msm_run)
   // wave inclusive scan of the per-thread totals
   uint2 inc = run; int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #pragma unroll
@@ -580,23 +581,25 @@ constexpr uint32_t lg_lanes(uint32_t lanes) { return lanes == 4 ? 2u : 1u; }
 // k_tree_pass 15 -> 11 us, a 2^15-constraint proof 6.9 -> 6.6 ms; with the cut at 2^16 lanes the proof is at 6.8 ms.  (The 2^15-chunk kernel of the
 // widest window is the exception: 2^17 quad lanes take what 2^16 pair lanes take, 330 against 321 us — it keeps the pair form.)
 static inline bool quads_on() { static const bool v = [] { const char* e = std::getenv("ALEO_MI355X_QUAD_ADD"); return !(e && e[0] == '0'); }(); return v; }      // A/B switch: 0 = lane pairs everywhere
+static constexpr uint32_t ASIDE_MAX = 8;          // super-heavy buckets whose slice trees may run beside the reduction (msm_run)
+static inline bool aside_on() { static const bool v = [] { const char* e = std::getenv("ALEO_MI355X_ASIDE"); return !(e && e[0] == '0'); }(); return v; }      // A/B switch
 static inline uint32_t grp_lanes(uint64_t ops) { return quads_on() && ops * 4 <= (1u << 17) ? 4u : 2u; }
 // partial[ft + i] += partial[ft + i + half] inside every multi-slice bucket: one launch per level serves both lists of the scan —
 // the common one (buckets of <= 16 slices, `pairs_a` lane pairs each) and the super-heavy one (`pairs_b` each; skewed scalars).
 template <bool F28, uint32_t LANES = 2>
 __global__ void __launch_bounds__(256) k_tree_pass(char* __restrict__ partial, const uint32_t* __restrict__ list_a, uint32_t len_a, uint32_t pairs_a,
                                                    const uint32_t* __restrict__ list_b, uint32_t len_b, uint32_t pairs_b, const uint2* __restrict__ scan_local,
-                                                   const uint2* __restrict__ scan_blk, uint32_t M, const uint32_t* __restrict__ meta, uint32_t pass) {
+                                                   const uint2* __restrict__ scan_blk, uint32_t M, const uint32_t* __restrict__ meta, uint32_t pass, uint32_t skip_b) {
   constexpr uint32_t PB = PtFmt<F28>::BYTES;
   uint32_t op = (blockIdx.x * 256 + threadIdx.x) >> lg_lanes(LANES);
   const uint32_t ops_a = len_a * pairs_a;
-  const uint32_t* list = list_a; uint32_t max_pairs = pairs_a, list_len = len_a;
-  if (op >= ops_a) { op -= ops_a; list = list_b; max_pairs = pairs_b; list_len = len_b; }
+  const uint32_t* list = list_a; uint32_t max_pairs = pairs_a, list_len = len_a, skip = 0;
+  if (op >= ops_a) { op -= ops_a; list = list_b; max_pairs = pairs_b; list_len = len_b; skip = skip_b; }
   if (max_pairs == 0) return;
   uint32_t h = op / max_pairs, i = op % max_pairs;
   if (h >= list_len) return;
   uint32_t g = list[h];
-  uint32_t ft = scan_at(scan_local, scan_blk, g).y;
+  uint32_t ft = scan_at(scan_local, scan_blk, g).y + skip;      // skip_b = 1: the tree of slices 1.. of a super-heavy bucket (slice 0 stays the bucket's sum for the reduction; msm_run "aside")
   uint32_t fn = (g + 1 < M) ? scan_at(scan_local, scan_blk, g + 1).y : meta[0];
   uint32_t L = fn - ft;
   for (uint32_t p = 0; p < pass; ++p) L = (L + 1) >> 1;
@@ -605,6 +608,16 @@ __global__ void __launch_bounds__(256) k_tree_pass(char* __restrict__ partial, c
   if (i >= L - half) return;
   char* pa = partial + (size_t)(ft + i) * PB;
   pt_add_grp<LANES, F28>(pa, pa + (size_t)half * PB, pa);
+}
+
+// The sums of slices 1.. of the super-heavy buckets (k_tree_pass with skip_b = 1 left them in slice 1) and the buckets' numbers, to the host.
+__global__ void k_gather_super(const char* __restrict__ partial, const uint32_t* __restrict__ list, uint32_t len, const uint2* __restrict__ scan_local,
+                               const uint2* __restrict__ scan_blk, uint32_t* __restrict__ dst) {
+  constexpr uint32_t PW = PtFmt<true>::WORDS;
+  const uint32_t t = blockIdx.x * 256 + threadIdx.x, h = t / (PW + 1), w = t % (PW + 1);
+  if (h >= len) return;
+  const uint32_t g = list[h];
+  dst[h * (PW + 1) + w] = w == PW ? g : ((const uint32_t*)(partial + (size_t)(scan_at(scan_local, scan_blk, g).y + 1) * PtFmt<true>::BYTES))[w];
 }
 
 // ---- bucket reduction -----------------------------------------------------------------------------
@@ -927,6 +940,7 @@ int32_t msm_wait_meta(Ctx* c, const SortPhase& sp, hipStream_t s, SliceMeta* m) 
   HIPCHK(hipEventSynchronize(c->ev[7]));
   const uint32_t* h_meta = (const uint32_t*)c->h_pinned;
   m->NT = h_meta[0]; m->max_m = h_meta[1]; m->n_heavy = h_meta[3];
+  m->max_common = h_meta[6] < 16u ? h_meta[6] : 16u;
   m->n_super = h_meta[5] < SUPER_CAP ? h_meta[5] : SUPER_CAP;
   m->super_overflow = h_meta[5] > SUPER_CAP;          // then the common list also holds very long buckets
   if (m->NT > sp.slices_max) {          // cannot happen (slice_bound); the kernels only touched threads below the bound
@@ -977,7 +991,7 @@ int32_t msm_run(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, const MsmJob
   // table path, per set: [acc of its cpw chunks | lgN masked sums of cpw/4] = (lgN + 4) segments of tseg points
   const uint32_t tseg = cpw / 4, fseg = lgN + 4, nseg = K * fseg, setw = fseg * tseg;
   const size_t vpoints = masked ? (size_t)K * setw + nchunks + (nseg + 1) + (size_t)nseg * (tseg / 2 + tseg / 4 + 2) : (size_t)nchunks + P.W;
-  if ((rc = ensure_host_pinned(c, 64 + (size_t)(masked ? nseg : P.W) * 224))) return rc;      // before the sort phase: its read-back lands in this buffer
+  if ((rc = ensure_host_pinned(c, 64 + (size_t)(masked ? nseg : P.W) * 224 + ASIDE_MAX * 228))) return rc;      // before the sort phase: its read-back lands in this buffer
   SortPhase sp;
   if ((rc = msm_sort_phase(c, segs, pts, job.mont, d_inf, (uint32_t)(pre ? T->cover : pb.n), P, pre, s, &sp))) return rc;
   const uint32_t M = sp.M;
@@ -994,19 +1008,36 @@ int32_t msm_run(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, const MsmJob
   HIPCHK(hipGetLastError());
   SliceMeta sm;
   if ((rc = msm_wait_meta(c, sp, s, &sm))) return rc;
+  // A handful of super-heavy buckets (witness-like scalars: the digit-1 bucket of the lowest window holds a fifth of the points) have a slice tree of
+  // 10+ dependent levels while the common list is done after 4.  Then the long trees run ASIDE, on the slot's side stream, over slices 1.. of their
+  // buckets; the reduction below goes ahead with slice 0 as those buckets' sums, and the host adds (b + 1) * (sum of slices 1..) to the result.
+  const bool aside = masked && aside_on() && sm.n_super >= 1 && sm.n_super <= ASIDE_MAX && !sm.super_overflow && sm.max_m >= 64;
+  uint32_t* h_aside = (uint32_t*)((char*)c->h_pinned + 64 + (size_t)nseg * 224);
+  if (aside) {
+    HIPCHK(hipStreamWaitEvent(c->side, c->ev[5], 0));
+    for (uint32_t pass = 0, L = sm.max_m - 1; L > 1; ++pass, L = (L + 1) >> 1) {
+      const uint64_t ops = (uint64_t)sm.n_super * (L >> 1);
+      if (grp_lanes(ops) == 4) hipLaunchKernelGGL((k_tree_pass<true, 4>), dim3((uint32_t)((4 * ops + 255) / 256)), dim3(256), 0, c->side, partial, heavy, 0u, 0u, sp.super_list, sm.n_super, L >> 1, scan_local, scan_blk, M, meta, pass, 1u);
+      else hipLaunchKernelGGL(k_tree_pass<true>, dim3((uint32_t)((2 * ops + 255) / 256)), dim3(256), 0, c->side, partial, heavy, 0u, 0u, sp.super_list, sm.n_super, L >> 1, scan_local, scan_blk, M, meta, pass, 1u);
+    }
+    uint32_t* dst = nullptr;
+    HIPCHK(hipHostGetDevicePointer((void**)&dst, h_aside, 0));
+    hipLaunchKernelGGL(k_gather_super, dim3((sm.n_super * 57 + 255) / 256), dim3(256), 0, c->side, partial, sp.super_list, sm.n_super, scan_local, scan_blk, dst);
+    HIPCHK(hipEventRecord(c->ev[4], c->side));
+  }
   if (sm.NT) {
-    for (uint32_t pass = 0, L = sm.max_m; L > 1; ++pass, L = (L + 1) >> 1) {
-      const uint32_t Lc = sm.super_overflow ? L : (L < 16u ? L : (16u >> (pass < 4 ? pass : 4)));       // longest bucket of the common list at this level
+    for (uint32_t pass = 0, L = sm.max_m, Lcm = sm.max_common; L > 1; ++pass, L = (L + 1) >> 1, Lcm = (Lcm + 1) >> 1) {
+      const uint32_t Lc = sm.super_overflow ? L : Lcm;       // longest bucket of the common list at this level
       const uint32_t len_a = (sm.n_heavy && Lc > 1) ? sm.n_heavy : 0, pairs_a = len_a ? Lc >> 1 : 0;
-      const uint32_t len_b = sm.n_super, pairs_b = len_b ? L >> 1 : 0;
+      const uint32_t len_b = aside ? 0 : sm.n_super, pairs_b = len_b ? L >> 1 : 0;
       const uint64_t ops = (uint64_t)len_a * pairs_a + (uint64_t)len_b * pairs_b;
       const uint32_t lanes = pre ? grp_lanes(ops) : 2u;                                                // quads while the level is latency-bound (28-bit points only)
       const uint64_t threads = lanes * ops;
       if (!threads) continue;
       if (threads >= (1ull << 32)) { (void)hipStreamSynchronize(s); g_last_error = "msm: slice tree too wide"; return ALEO_MI355X_ERR_HIP; }
-      if (pre && lanes == 4) hipLaunchKernelGGL((k_tree_pass<true, 4>), dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, s, partial, heavy, len_a, pairs_a, sp.super_list, len_b, pairs_b, scan_local, scan_blk, M, meta, pass);
-      else if (pre) hipLaunchKernelGGL(k_tree_pass<true>, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, s, partial, heavy, len_a, pairs_a, sp.super_list, len_b, pairs_b, scan_local, scan_blk, M, meta, pass);
-      else hipLaunchKernelGGL(k_tree_pass<false>, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, s, partial, heavy, len_a, pairs_a, sp.super_list, len_b, pairs_b, scan_local, scan_blk, M, meta, pass);
+      if (pre && lanes == 4) hipLaunchKernelGGL((k_tree_pass<true, 4>), dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, s, partial, heavy, len_a, pairs_a, sp.super_list, len_b, pairs_b, scan_local, scan_blk, M, meta, pass, 0u);
+      else if (pre) hipLaunchKernelGGL(k_tree_pass<true>, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, s, partial, heavy, len_a, pairs_a, sp.super_list, len_b, pairs_b, scan_local, scan_blk, M, meta, pass, 0u);
+      else hipLaunchKernelGGL(k_tree_pass<false>, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, s, partial, heavy, len_a, pairs_a, sp.super_list, len_b, pairs_b, scan_local, scan_blk, M, meta, pass, 0u);
     }
   }
   HIPCHK(hipEventRecord(c->ev[2], s));
@@ -1088,6 +1119,7 @@ int32_t msm_run(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, const MsmJob
       HIPCHK(hipEventSynchronize(c->ev[3]));
       if (hrc) { (void)hipStreamSynchronize(s); return hrc; }
     } else HIPCHK(hipStreamSynchronize(s));
+    if (aside) HIPCHK(hipEventSynchronize(c->ev[4]));
     HIPCHK(hipGetLastError());
     t_host0 = std::chrono::steady_clock::now();
     HXYZZ totals[MAX_SETS];
@@ -1098,6 +1130,13 @@ int32_t msm_run(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, const MsmJob
       for (uint32_t sft = P.S; sft > 1; sft >>= 1) total = hdouble(total);
       for (int r = 0; r < 4; ++r) total = hadd(total, lazy_point28(hw + (size_t)r * PB28));
       totals[q] = total;
+    }
+    for (uint32_t h = 0; aside && h < sm.n_super; ++h) {             // (b + 1) * (slices 1.. of super-heavy bucket b), by double-and-add
+      const uint32_t* rec = h_aside + (size_t)h * 57; const uint32_t g = rec[56], q = g / P.B, wgt = g % P.B + 1;
+      if (q >= K) { g_last_error = "msm: internal: super-heavy bucket outside the sets"; return ALEO_MI355X_ERR_HIP; }
+      const HXYZZ T = lazy_point28((const char*)rec); HXYZZ acc = HXYZZ::infinity();
+      for (int bit = 31 - __builtin_clz(wgt); bit >= 0; --bit) { acc = hdouble(acc); if ((wgt >> bit) & 1u) acc = hadd(acc, T); }
+      totals[q] = hadd(totals[q], acc);
     }
     hstore_jacobian_normalized_batch(out_jac18, totals, K);          // one shared inversion for the K results
   } else {

@@ -56,13 +56,13 @@ __device__ __forceinline__ uint32_t slice_len(uint32_t cnt, uint32_t m, uint32_t
 // What msm_sort_phase leaves in the slot's workspaces (device pointers), enqueued on `s`, nothing synchronised:
 //   hist[g] points of bucket g | scan_local/scan_blk: exclusive (points, slices) prefix per bucket (scan_at) | sorted: the point index
 //   stream (bit 31 = negate), bucket runs contiguous | task_g[sid] bucket of slice sid | order[t] slice ids, longest first |
-//   meta[0] slices, [1] most slices in one bucket, [2] pairs, [3] multi-slice buckets (listed in heavy[]), [5] super-heavy ones
+//   meta[0] slices, [1] most slices in one bucket, [2] pairs, [3] multi-slice buckets (listed in heavy[]), [5] super-heavy ones, [6] most slices of a bucket in heavy[] (<= 16)
 struct SortPhase {
   MsmPlan P; uint32_t M = 0, digitsW = 0, slice_blocks = 0; size_t slices_max = 0, pairs_max = 0;
   uint32_t *hist = nullptr, *heavy = nullptr, *meta = nullptr; uint2 *scan_local = nullptr, *scan_blk = nullptr;
   uint32_t *sorted = nullptr, *task_g = nullptr, *order = nullptr; const uint32_t* total_pairs = nullptr; const uint32_t* super_list = nullptr;
 };
-struct SliceMeta { uint32_t NT = 0, max_m = 0, n_heavy = 0, n_super = 0; bool super_overflow = false; };
+struct SliceMeta { uint32_t NT = 0, max_m = 0, n_heavy = 0, n_super = 0, max_common = 0; bool super_overflow = false; };
 // P: the plan (P.W windows / sets of P.B buckets).  pre: table path (digits address row w * row_stride + i of a table, all windows share
 // a set's buckets).  Records ev[0] before and ev[1] after the sort; ev[7] on the side stream carries the slice metadata back.
 // segs: ptr / n / off / set filled in by the caller; col0, ncol are computed here.  pts = sum of the segment lengths.

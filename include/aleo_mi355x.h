@@ -379,7 +379,9 @@ int32_t aleo_mi355x_varuna_prove_batch_indexed(const uint64_t* index_handles, si
  * batched MSM, so its sort, slice tree, reduction, host tail and stream synchronisation are paid once per round instead of once per proof
  * (eight 2^15-constraint proofs: see DESIGN.md 4d).  All indexes must belong to one committer key.  len: in = capacity of out_proof, out = bytes
  * written.  status (out): per request — a request that fails (unsatisfied assignment: ALEO_MI355X_ERR_UNSATISFIED; bad argument) drops out, the
- * others complete; the call itself returns non-zero only when nothing could be started or a device call failed.  1..64 requests. */
+ * others complete; the call itself returns non-zero only when nothing could be started or a device call failed.  1..64 requests.
+ * Between the commitments the proofs run on up to ALEO_MI355X_LOCKSTEP_WORKERS (default 4, 1..9) threads of the library's own, each with a
+ * borrowed stream of the device: the calling thread blocks until all proofs are written. */
 typedef struct {
   const uint64_t* index_handles; size_t n_circuits; const void* const* assignments; const size_t* n_instances; const uint8_t* seed;
   void* out_proof; size_t len; int32_t status;
