@@ -46,6 +46,8 @@ MsmPlan make_plan(size_t n, int pre_c) {
     // running-sum chunk: 2S dependent additions per lane pair vs. one more level of masked sums per halving; measured
     // best at 16 for 2^19 buckets (enough chunks to fill the chip) and 4 for 2^15..2^16 buckets (latency only)
     p.c = (uint32_t)pre_c; p.W = 1; p.B = 1u << (pre_c - 1); p.M = p.B; p.S = pre_c >= 20 ? 16 : 4;
+    static const int s_env = [] { const char* e = std::getenv("ALEO_MI355X_CHUNK_S"); return e ? std::atoi(e) : 0; }();      // experiment knob (wide tables only)
+    if (pre_c >= 20 && (s_env == 4 || s_env == 8 || s_env == 16 || s_env == 32)) p.S = (uint32_t)s_env;
     return p;
   }
   uint32_t lg = 0; while (((size_t)1 << (lg + 1)) <= n) ++lg;
@@ -1077,7 +1079,10 @@ int32_t msm_run(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, const MsmJob
     // 2^19 buckets keep the chip busy with one lane pair per chunk; the small bucket sets (<= 2^16) are pure latency and take the quad form
     // (masked => pre: the partial sums are 28-bit points)
     // every launch below picks lanes per addition by its own width (grp_lanes): four while it is latency-bound, two once the additions fill the chip
-    if (P.c >= 20) {
+    // wide tables (2^19 buckets, S = 16): one lane pair per chunk (32 dependent additions) against two pairs one step apart (17): reduce phase 0.487 -> 0.460 ms
+    // at 2^20; S = 8 / 32 / 4 with either form: 0.51-0.54 / 0.48-0.55 / 0.66-0.72 ms (ALEO_MI355X_CHUNK_S, ALEO_MI355X_CHUNK_FORM=1: A/B switches)
+    static const bool wide_two_groups = [] { const char* e = std::getenv("ALEO_MI355X_CHUNK_FORM"); return !(e && e[0] == '1'); }();
+    if (P.c >= 20 && !wide_two_groups) {
       if (grp_lanes(2 * (uint64_t)nchunks) == 4) hipLaunchKernelGGL((k_bucket_chunks_pair<true, 4>), dim3((nchunks + 63) / 64), dim3(256), 0, s, partial, hist, scan_local, scan_blk, P.B, P.S, nchunks, V, setw, Vrun);
       else hipLaunchKernelGGL(k_bucket_chunks_pair<true>, dim3((nchunks + CHUNK_PAIRS - 1) / CHUNK_PAIRS), dim3(256), 0, s, partial, hist, scan_local, scan_blk, P.B, P.S, nchunks, V, setw, Vrun);
     } else {

@@ -496,6 +496,20 @@ def varuna_prove(synth, torch, lg, reps=7, in_flight=4):
             for x in th: x.start()
             for x in th: x.join()
             dt = time.perf_counter() - t
+        lock = {}
+        try:                                               # eight independent proofs per aleo_mi355x_varuna_prove_many call (every round's commitments in one launch chain)
+            with varuna.NativeCircuitIndex(csr, n, 4, len(z) - 4, ck) as nx8:
+                reqs = [([nx8], [[zz]], 7000 + q) for q in range(8)]
+                got = varuna.prove_many_native(reqs)
+                if got[3] != varuna.prove_native(ix, zz, 7003): raise SystemExit('bench: a lockstep proof differs from the single call')
+                tl = []
+                for rep in range(4):
+                    t = time.perf_counter(); varuna.prove_many_native(reqs); tl.append(time.perf_counter() - t)
+                ml = float(np.median(tl[1:]))
+                lock = {'proofs_per_call': 8, 'ms_per_call': ml * 1e3, 'proofs_per_s': 8 / ml, 'constraints_per_s': 8 * n / ml, 'entry_point': 'aleo_mi355x_varuna_prove_many',
+                        'what': 'independent proofs (own seed, transcript, output), byte-equal to the single calls; one host thread'}
+        except SystemExit: raise
+        except Exception as e: lock = {'error': repr(e)[:300]}
         try: several = varuna_prove_several(synth, ck, lg)
         except Exception as e: several = {'error': repr(e)[:300]}
         try: sweep = density_sweep(synth, lg)
@@ -506,7 +520,7 @@ def varuna_prove(synth, torch, lg, reps=7, in_flight=4):
                 'python_host_ms': float(np.median(tp[1:])),
                 'instances_4': {'prove_ms': mb, 'constraints_per_s': 4 * n / mb * 1e3, 'proof_bytes': len(datab)},
                 'instances_8': {'prove_ms': mb8, 'constraints_per_s': 8 * n / mb8 * 1e3},
-                'in_flight_%d' % in_flight: {'proofs_per_s': in_flight * per / dt, 'constraints_per_s': n * in_flight * per / dt}, 'what': VARUNA_NOTE}
+                'in_flight_%d' % in_flight: {'proofs_per_s': in_flight * per / dt, 'constraints_per_s': n * in_flight * per / dt}, 'lockstep_8': lock, 'what': VARUNA_NOTE}
     finally:
         ck.close()
 

@@ -308,6 +308,33 @@ inline Result<Proof> prove_batch(const KeyedAssignments& keyed, const Seed& seed
   out.bytes.resize(len); return {std::move(out), Error{0}};
 }
 
+// Independent proofs in lockstep (aleo_mi355x_varuna_prove_many): request i is what prove_batch(keyed[i], seeds[i]) would prove, byte for byte; the
+// proofs share every round's commitment launch chain.  One Result per request: a request that fails carries its own error, the others complete.
+inline std::vector<Result<Proof>> prove_many(const std::vector<KeyedAssignments>& requests, const std::vector<Seed>& seeds) {
+  const size_t n = requests.size();
+  std::vector<Result<Proof>> out; out.reserve(n);
+  if (seeds.size() != n || n == 0) { for (size_t i = 0; i < n; ++i) out.push_back({std::nullopt, Error{ALEO_MI355X_ERR_BAD_ARG}}); return out; }
+  std::vector<std::vector<uint64_t>> handles(n); std::vector<std::vector<size_t>> counts(n); std::vector<std::vector<const void*>> ptrs(n);
+  std::vector<Proof> proofs(n); std::vector<aleo_mi355x_prove_request> rq(n); std::vector<int32_t> pre(n, 0);
+  for (size_t i = 0; i < n; ++i) {
+    for (auto& [pk, zs] : requests[i]) {
+      if (!pk || zs.empty()) { pre[i] = ALEO_MI355X_ERR_BAD_ARG; break; }
+      handles[i].push_back(pk->handle()); counts[i].push_back(zs.size());
+      for (auto* a : zs) { if (!a || a->size() != pk->num_variables()) { pre[i] = ALEO_MI355X_ERR_BAD_ARG; break; } ptrs[i].push_back(a->data()); }
+    }
+    if (requests[i].empty()) pre[i] = ALEO_MI355X_ERR_BAD_ARG;
+    proofs[i].bytes.resize(1024 + 400 * handles[i].size() + 192 * ptrs[i].size());
+    rq[i] = aleo_mi355x_prove_request{handles[i].data(), pre[i] ? 0 : handles[i].size(), ptrs[i].data(), counts[i].data(), seeds[i].bytes, proofs[i].bytes.data(), proofs[i].bytes.size(), 0};
+  }
+  const int32_t rc = aleo_mi355x_varuna_prove_many(rq.data(), n);
+  for (size_t i = 0; i < n; ++i) {
+    const int32_t st = pre[i] ? pre[i] : (rq[i].status ? rq[i].status : rc);
+    if (st) { out.push_back({std::nullopt, Error{st}}); continue; }
+    proofs[i].bytes.resize(rq[i].len); out.push_back({std::move(proofs[i]), Error{0}});
+  }
+  return out;
+}
+
 // snarkvm_synthesizer_process::Trace as the prover sees it: the transitions of one transaction, each the proving key of its
 // function and the assignment its execution produced.  prove_execution / prove_fee group the assignments per proving key (order of first
 // appearance; upstream: BTreeMap order of the keys) and make ONE proof for all of them — the call under

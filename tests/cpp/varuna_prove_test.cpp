@@ -87,6 +87,18 @@ int main(int argc, char** argv) {
     Trace fee; fee.insert_transition(*pk.value, za[0]);
     auto fp = fee.prove_fee(seed_next), direct = pk.value->prove_batch({&za[0]}, seed_next);
     if (!fp.is_ok() || !direct.is_ok() || fp.value->bytes != direct.value->bytes) { fprintf(stderr, "Trace::prove_fee differs from prove_batch\n"); return 1; }
+    // independent proofs in lockstep: the k-instance proof, the two-key execution, a fee, and a request with a violated witness in between — each
+    // result what its own call gives, the bad one refused alone
+    {
+      std::vector<BigInteger256> broken = za[0]; broken[nv - 1].l[0] ^= 1;
+      KeyedAssignments r0 = {{&*pk.value, zs}}, r1 = {{&*pk.value, zs}, {&*pk2.value, {&za[0]}}}, r2 = {{&*pk.value, {&broken}}}, r3 = {{&*pk.value, {&za[0]}}};
+      auto many = prove_many({r0, r1, r2, r3}, {seed, seed, seed, seed_next});
+      if (many.size() != 4 || !many[0].is_ok() || !many[1].is_ok() || !many[3].is_ok()) { fprintf(stderr, "prove_many: a good request failed\n"); return 1; }
+      if (many[0].value->bytes.size() != len || memcmp(many[0].value->bytes.data(), proof.data(), len)) { fprintf(stderr, "prove_many[0] differs from prove_batch\n"); return 1; }
+      if (many[1].value->bytes != ex.value->bytes) { fprintf(stderr, "prove_many[1] differs from Trace::prove_execution\n"); return 1; }
+      if (many[2].is_ok() || !many[2].error.unsatisfied()) { fprintf(stderr, "prove_many[2]: expected ERR_UNSATISFIED\n"); return 1; }
+      if (many[3].value->bytes != direct.value->bytes) { fprintf(stderr, "prove_many[3] differs from the fee proof\n"); return 1; }
+    }
     FILE* o2 = fopen(argv[2], "ab"); if (!o2) return 2;
     uint64_t el = ex.value->bytes.size(); fwrite(&el, 8, 1, o2); fwrite(ex.value->bytes.data(), 1, el, o2); fclose(o2);
   }
