@@ -31,6 +31,9 @@
 #include "msm_common.h"
 #include <chrono>
 #include <cstdlib>
+#include <atomic>
+#include <thread>
+#include <string>
 
 namespace aleo_mi355x {
 
@@ -1182,6 +1185,48 @@ int32_t msm_run(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, const MsmJob
 // Arbitrary request: k results, each the sum of its segments.  Results are grouped by the table tier the bases they reach select
 // (longest tier first) and every group goes through msm_run in chunks of msm_max_sets() results / MAX_SEGS segments; results no tier
 // serves (no table, or fewer than 2^10 bases reached) run one by one.
+// The launch chains of one request.  One chain: on the caller's slot and stream.  Several big ones: dealt to two host threads — the caller's on its
+// slot, one more on a borrowed helper context (own stream and workspaces) — so that the sort, reduction and host tail of one chain run under the
+// accumulation of the other (the accumulation is bound by VALU issue, the sort by memory: `concurrent_callers` in the bench line is the same effect
+// across calls).  The helper stream waits for an event recorded on `s` first (the scalars may still be in flight there); both threads return
+// with their streams drained, so the caller sees the usual synchronous call.
+namespace {
+struct Chain { std::vector<MsmSeg> segs; std::vector<uint32_t> results; size_t points = 0; bool sparse = false, fire_tail = false; };
+inline bool chains_overlap_on() { static const bool v = [] { const char* e = std::getenv("ALEO_MI355X_CHAIN_OVERLAP"); return !(e && e[0] == '0'); }(); return v; }      // A/B switch
+}
+static int32_t run_chains(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, std::vector<Chain>& chains, bool mont, hipStream_t s) {
+  auto run_one = [&](Ctx* cc, Chain& ch, hipStream_t st) -> int32_t {
+    uint64_t res[MAX_SETS * 18];
+    MsmJob g; g.segs = ch.segs.data(); g.nseg = (uint32_t)ch.segs.size(); g.k = (uint32_t)ch.results.size(); g.mont = mont; g.sparse = ch.sparse; g.fire_tail = ch.fire_tail;
+    const int32_t rc = msm_run(cc, res, pb, g, st);
+    if (rc) return rc;
+    for (size_t i = 0; i < ch.results.size(); ++i) std::memcpy(out_jac18 + 18 * (size_t)ch.results[i], res + 18 * i, 144);
+    return ALEO_MI355X_OK;
+  };
+  size_t total = 0; for (auto& ch : chains) total += ch.points;
+  HelperSet hs;
+  if (chains.size() >= 2 && total >= ((size_t)1 << 20) && chains_overlap_on() && c->dev) { const int32_t rc = acquire_helpers(c->dev, 1, hs); if (rc) return rc; }
+  if (hs.ctx.empty()) { for (auto& ch : chains) { const int32_t rc = run_one(c, ch, s); if (rc) return rc; } return ALEO_MI355X_OK; }
+  Ctx* h = hs.ctx[0];
+  HIPCHK(hipEventRecord(c->ev[4], s));                     // ev[4] is free until this chain's own msm_run (which may use it for its aside trees) starts
+  HIPCHK(hipStreamWaitEvent(h->stream, c->ev[4], 0));
+  std::atomic<size_t> next{0}; int32_t rc_h = ALEO_MI355X_OK; std::string err_h; MsmTiming tm_h{};
+  std::thread helper([&] {
+    if (hipSetDevice(c->device) != hipSuccess) { rc_h = ALEO_MI355X_ERR_HIP; err_h = "hipSetDevice failed"; return; }
+    try {
+      for (size_t i; (i = next.fetch_add(1)) < chains.size();) { const int32_t rc = run_one(h, chains[i], h->stream); if (rc) { rc_h = rc; err_h = g_last_error; return; } }
+    } catch (...) { rc_h = ALEO_MI355X_ERR_HIP; err_h = "msm: exception on the helper thread"; }
+    tm_h = h->last_msm;
+  });
+  int32_t rc_m = ALEO_MI355X_OK;
+  for (size_t i; !rc_m && (i = next.fetch_add(1)) < chains.size();) rc_m = run_one(c, chains[i], s);
+  helper.join();
+  (void)hipStreamSynchronize(h->stream);
+  if (rc_m) return rc_m;
+  if (rc_h) { g_last_error = err_h; return rc_h; }
+  return ALEO_MI355X_OK;
+}
+
 int32_t msm_batch(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, const MsmJob& job, hipStream_t s) {
   const uint32_t K = job.k;
   auto tier_of = [&](size_t n) { for (int t = 0; t < 3; ++t) if (pb.tab[t].d && n >= pb.tab[t].min_n && n <= pb.tab[t].cover) return t; return -1; };
@@ -1198,18 +1243,17 @@ int32_t msm_batch(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, const MsmJ
     for (uint32_t q = 0; q < job.nseg && inside; ++q) { const MsmSeg& g = job.segs[q]; if (g.len) inside = g.off >= pb.range_off && g.off + g.len <= pb.range_off + pb.range.cover; }
     if (inside) {
       uint32_t cap = MAX_COARSE_ALL / ((1u << (pb.range.c - 1)) >> 8); cap = cap < MAX_SETS ? cap : MAX_SETS;
+      std::vector<Chain> chains;
       for (uint32_t q0 = 0; q0 < K;) {
         uint32_t take = 0, sg = 0; size_t pts = 0;
         while (q0 + take < K && take < cap && (take == 0 || (pts + points[q0 + take] <= ((size_t)1 << 26) && sg + nsegs[q0 + take] <= MAX_SEGS))) { pts += points[q0 + take]; sg += nsegs[q0 + take]; ++take; }
         if (sg > MAX_SEGS) { g_last_error = "msm: one result with more than 64 segments"; return ALEO_MI355X_ERR_BAD_ARG; }
-        std::vector<MsmSeg> segs; segs.reserve(sg);
-        for (uint32_t q = 0; q < job.nseg; ++q) { const MsmSeg& g = job.segs[q]; if (g.len && g.out >= q0 && g.out < q0 + take) { MsmSeg h = g; h.out = g.out - q0; segs.push_back(h); } }
-        MsmJob g; g.segs = segs.data(); g.nseg = (uint32_t)segs.size(); g.k = take; g.mont = job.mont; g.sparse = true; g.fire_tail = q0 == 0 && take == K;
-        int32_t rc = msm_run(c, out_jac18 + 18 * (size_t)q0, pb, g, s);
-        if (rc) return rc;
+        chains.emplace_back(); Chain& ch = chains.back(); ch.segs.reserve(sg); ch.points = pts; ch.sparse = true; ch.fire_tail = q0 == 0 && take == K;
+        for (uint32_t q = 0; q < job.nseg; ++q) { const MsmSeg& g = job.segs[q]; if (g.len && g.out >= q0 && g.out < q0 + take) { MsmSeg h = g; h.out = g.out - q0; ch.segs.push_back(h); } }
+        for (uint32_t i = 0; i < take; ++i) ch.results.push_back(q0 + i);
         q0 += take;
       }
-      return ALEO_MI355X_OK;
+      return run_chains(c, out_jac18, pb, chains, job.mont, s);
     }
   }
   // Latency-bound requests (one prover round: a few results of <= 2^17 points each): ONE launch chain on the tier that covers the
@@ -1229,7 +1273,7 @@ int32_t msm_batch(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, const MsmJ
       }
     }
   }
-  std::vector<uint32_t> todo; todo.reserve(K);
+  std::vector<uint32_t> todo; todo.reserve(K); std::vector<Chain> chains;
   for (int t = -1; t < 3; ++t) {
     todo.clear();
     for (uint32_t q = 0; q < K; ++q) if (tier_of(reach[q]) == t) todo.push_back(q);
@@ -1242,22 +1286,17 @@ int32_t msm_batch(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, const MsmJ
         pts += points[todo[pos + take]]; sg += nsegs[todo[pos + take]]; ++take;
       }
       if (sg > MAX_SEGS) { g_last_error = "msm: one result with more than 64 segments"; return ALEO_MI355X_ERR_BAD_ARG; }
-      std::vector<MsmSeg> segs; segs.reserve(sg);
-      for (size_t i = 0; i < take; ++i) local[i] = todo[pos + i];
+      chains.emplace_back(); Chain& ch = chains.back(); ch.segs.reserve(sg); ch.points = pts; ch.fire_tail = take == K;      // fire_tail: every result of the request in this one chain
+      for (size_t i = 0; i < take; ++i) { local[i] = todo[pos + i]; ch.results.push_back(local[i]); }
       for (uint32_t q = 0; q < job.nseg; ++q) {
         const MsmSeg& g = job.segs[q];
         if (!g.len) continue;
-        for (size_t i = 0; i < take; ++i) if (local[i] == g.out) { MsmSeg h = g; h.out = (uint32_t)i; segs.push_back(h); break; }
+        for (size_t i = 0; i < take; ++i) if (local[i] == g.out) { MsmSeg h = g; h.out = (uint32_t)i; ch.segs.push_back(h); break; }
       }
-      uint64_t res[MAX_SETS * 18];
-      MsmJob g; g.segs = segs.data(); g.nseg = (uint32_t)segs.size(); g.k = (uint32_t)take; g.mont = job.mont; g.fire_tail = take == K;      // every result of the request in this one chain
-      int32_t rc = msm_run(c, res, pb, g, s);
-      if (rc) return rc;
-      for (size_t i = 0; i < take; ++i) std::memcpy(out_jac18 + 18 * (size_t)todo[pos + i], res + 18 * i, 144);
       pos += take;
     }
   }
-  return ALEO_MI355X_OK;
+  return run_chains(c, out_jac18, pb, chains, job.mont, s);
 }
 
 // ---- synthetic base sets generated in HBM: P_i = (first + i) * G --------------------------------------
