@@ -5,6 +5,7 @@ here="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
 out="$here/../lib"; mkdir -p "$out"
 python3 "$here/../../tools/gen_fp_asm.py" "$here/fp_mont_gen.h"
 python3 "$here/../../tools/gen_fp28_asm.py" "$here/fp28_mont_gen.h"
+python3 "$here/../../tools/gen_fr29_asm.py" "$here/fr29_mont_gen.h"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Xarch_host -mbmi2 -Xarch_host -madx -Wall -Wno-unused-function -Wno-unused-variable ${ALEO_MI355X_CXXFLAGS:-}"
 objs=(); pids=()

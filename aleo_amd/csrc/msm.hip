@@ -586,7 +586,7 @@ constexpr uint32_t lg_lanes(uint32_t lanes) { return lanes == 4 ? 2u : 1u; }
 // k_tree_pass 15 -> 11 us, a 2^15-constraint proof 6.9 -> 6.6 ms; with the cut at 2^16 lanes the proof is at 6.8 ms.  (The 2^15-chunk kernel of the
 // widest window is the exception: 2^17 quad lanes take what 2^16 pair lanes take, 330 against 321 us — it keeps the pair form.)
 static inline bool quads_on() { static const bool v = [] { const char* e = std::getenv("ALEO_MI355X_QUAD_ADD"); return !(e && e[0] == '0'); }(); return v; }      // A/B switch: 0 = lane pairs everywhere
-static constexpr uint32_t ASIDE_MAX = 8;          // super-heavy buckets whose slice trees may run beside the reduction (msm_run)
+static constexpr uint32_t ASIDE_MAX = 8;  // super-heavy buckets whose slice trees may run beside the reduction (msm_run)
 static inline bool aside_on() { static const bool v = [] { const char* e = std::getenv("ALEO_MI355X_ASIDE"); return !(e && e[0] == '0'); }(); return v; }      // A/B switch
 static inline uint32_t grp_lanes(uint64_t ops) { return quads_on() && ops * 4 <= (1u << 17) ? 4u : 2u; }
 // partial[ft + i] += partial[ft + i + half] inside every multi-slice bucket: one launch per level serves both lists of the scan —

@@ -16,6 +16,7 @@
 // HBM traffic: 64 bytes per element per pass (read + write), algorithmic minimum 64 bytes per element.
 #include "ctx.h"
 #include "fp.h"
+#include "fr29.h"
 #include "host_field.hpp"
 #include <cstdlib>
 
@@ -36,6 +37,11 @@ struct NttTables {
   void* d_direct = nullptr;    // two-pass sizes: w_n^(k * b) at the position (k << lgBn) + b of the element it multiplies after pass 1
   uint32_t direct_lgBn = 0;    // the pass split d_direct was built for
   uint32_t scale[8];           // n^-1 (Montgomery): applied at the final store of a plain inverse transform
+  // the same tables for the 29-bit-limb kernels (fr29.h): every entry times 2^5, i.e. in the Montgomery form of R = 2^261; packed 32-byte numbers
+  // except the inner twiddles (9 limbs at a 48-byte stride)
+  void *d_inner29 = nullptr, *d_tw_hi29 = nullptr, *d_tw_lo29 = nullptr, *d_cs_hi29 = nullptr, *d_cs_lo29 = nullptr, *d_direct29 = nullptr;
+  uint32_t direct29_lgBn = 0;
+  uint32_t scale29[9];         // n^-1 in that form, 29-bit limbs
 };
 
 struct FrArg { uint32_t v[8]; };
@@ -218,6 +224,165 @@ __global__ void __launch_bounds__(NT) k_ntt_final(const char* src, char* dst, ui
   }
 }
 
+// ---- the same passes on 29-bit limbs (fr29.h): tiles of 9 limb planes, butterflies without conditional subtractions ------------------------------
+// Bounds inside a register group (dif_group29), for values that enter it normalised and below 4.5 r:
+//   sum  lo = u + x            lazy: limbs and value double per stage (8 x at most: limbs <= 2^32 - 8, value < 36 r)
+//   diff hi = (u + 19 r - x) w  the padded constant keeps every limb non-negative for x with limbs <= 2^30 - 2 and a value < 18 r; the product takes
+//                               a multiplicand with limbs < 2^31.4 and returns a normalised value < (37 / 445 + 1) r
+//   before the third stage of a three-stage group registers 0 and 1 (sums of sums: limbs < 2^31) are normalised; at the end the sums of the last
+//   stage are normalised and register 0 — the only one that was a sum in every stage — is brought below 3 r (f29_reduce_partial).
+//   A stage whose twiddle is 1 (half-size 1) normalises and reduces its differences instead of multiplying them.
+// So every value a group stores is normalised and below 4.5 r (the largest: a sum of two sums of products, 4.4 r).
+template <uint32_t TE> __device__ __forceinline__ F29 lds_load29(const uint32_t* lds, uint32_t e) {
+  F29 r; const uint32_t x = sw(e);
+#pragma unroll
+  for (int l = 0; l < 9; ++l) r.v[l] = lds[l * TE + x];
+  return r;
+}
+template <uint32_t TE> __device__ __forceinline__ void lds_store29(uint32_t* lds, uint32_t e, const F29& a) {
+  const uint32_t x = sw(e);
+#pragma unroll
+  for (int l = 0; l < 9; ++l) lds[l * TE + x] = a.v[l];
+}
+__device__ __forceinline__ F29 two_level29(const char* hi, const char* lo, uint32_t e, uint32_t lo_bits) {
+  return f29_mul(f29_load_packed(hi + (size_t)(e >> lo_bits) * 32), f29_load_packed(lo + (size_t)(e & ((1u << lo_bits) - 1u)) * 32));
+}
+template <uint32_t TE, int G> __device__ __forceinline__ void dif_group29(uint32_t* lds, uint32_t lgL, uint32_t s, uint32_t sb, const char* __restrict__ inner) {
+  constexpr int K = 1 << G;
+  const uint32_t lgq = lgL - s - G, q = 1u << lgq, per_row_lg = lgL - G;
+  const uint32_t row = sb >> per_row_lg, w = sb & ((1u << per_row_lg) - 1u);
+  const uint32_t grp = w >> lgq, pos = w & (q - 1u);
+  const uint32_t base = (row << lgL) + (grp << (lgq + G)) + pos;
+  F29 v[K];
+#pragma unroll
+  for (int j = 0; j < K; ++j) v[j] = lds_load29<TE>(lds, base + ((uint32_t)j << lgq));
+#pragma unroll
+  for (int t = 0; t < G; ++t) {
+    const int d = 1 << (G - 1 - t);
+    const uint32_t lgh = lgq + (uint32_t)(G - 1 - t);
+    if (G == 3 && t == 2) { f29_normalise(v[0]); f29_normalise(v[1]); }
+#pragma unroll
+    for (int r = 0; r < d; ++r) {
+      F29 tw;
+      if (lgh) tw = f29_load48(inner + (size_t)((((uint32_t)r << lgq) + pos) << (INNER_MAX_LG - 1 - lgh)) * 48);
+#pragma unroll
+      for (int blk = 0; blk < K / (2 * d); ++blk) {
+        const int lo = blk * 2 * d + r, hi = lo + d;
+        const F29 u = v[lo], x = v[hi];
+        v[lo] = f29_add(u, x);
+        F29 dif = f29_sub_pad(u, x);
+        if (lgh) v[hi] = f29_mul(dif, tw);
+        else { f29_normalise(dif); f29_reduce_partial(dif); v[hi] = dif; }
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < K; j += 2) f29_normalise(v[j]);       // the sums of the last stage
+  f29_reduce_partial(v[0]);
+#pragma unroll
+  for (int j = 0; j < K; ++j) lds_store29<TE>(lds, base + ((uint32_t)j << lgq), v[j]);
+}
+template <uint32_t TE, uint32_t NT, int GM = 3> __device__ __forceinline__ void tile_dif29(uint32_t* lds, uint32_t lgL, uint32_t T, const char* __restrict__ inner) {
+  const uint32_t total = T << lgL;
+  uint32_t s = 0;
+  if constexpr (GM == 2) {                                // two-stage groups: twice the lanes per tile (four waves per SIMD on a 4096-element tile)
+    for (; s + 2 <= lgL; s += 2) {
+      for (uint32_t sb = threadIdx.x; sb < (total >> 2); sb += NT) dif_group29<TE, 2>(lds, lgL, s, sb, inner);
+      __syncthreads();
+    }
+    if (lgL - s == 1) {
+      for (uint32_t sb = threadIdx.x; sb < (total >> 1); sb += NT) dif_group29<TE, 1>(lds, lgL, s, sb, inner);
+      __syncthreads();
+    }
+    return;
+  }
+  for (; s + 3 <= lgL; s += 3) {
+    for (uint32_t sb = threadIdx.x; sb < (total >> 3); sb += NT) dif_group29<TE, 3>(lds, lgL, s, sb, inner);
+    __syncthreads();
+  }
+  if (lgL - s == 2) {
+    for (uint32_t sb = threadIdx.x; sb < (total >> 2); sb += NT) dif_group29<TE, 2>(lds, lgL, s, sb, inner);
+    __syncthreads();
+  } else if (lgL - s == 1) {
+    for (uint32_t sb = threadIdx.x; sb < (total >> 1); sb += NT) dif_group29<TE, 1>(lds, lgL, s, sb, inner);
+    __syncthreads();
+  }
+}
+// k_ntt_strided on 29-bit limbs: same view, same tiles, same index maps; one lane loads and repacks a whole element
+template <uint32_t TE, uint32_t NT, int GM = 3>
+__global__ void __launch_bounds__(NT) k_ntt29_strided(const char* src, char* dst, uint32_t lgL, uint32_t lgBn, uint32_t lgT,
+                                                       uint32_t tw_scale, uint32_t lg_n, uint32_t lo_bits, const char* __restrict__ inner,
+                                                       const char* __restrict__ tw_hi, const char* __restrict__ tw_lo,
+                                                       const char* __restrict__ cs_hi, const char* __restrict__ cs_lo, int pre_coset,
+                                                       const char* __restrict__ direct) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+  src += (size_t)blockIdx.y << (lg_n + 5); dst += (size_t)blockIdx.y << (lg_n + 5);
+  const uint32_t L = 1u << lgL, T = 1u << lgT, tiles_per_a = 1u << (lgBn - lgT);
+  const uint32_t a = blockIdx.x / tiles_per_a, b0 = (blockIdx.x % tiles_per_a) << lgT;
+  for (uint32_t elem = threadIdx.x; elem < T * L; elem += NT) {
+    const uint32_t t = elem & (T - 1u), l = elem >> lgT;
+    const size_t gi = ((((size_t)a << lgL) + l) << lgBn) + b0 + t;
+    F29 x = f29_load_packed(src + gi * 32);
+    if (pre_coset) x = f29_mul(x, two_level29(cs_hi, cs_lo, (l << lgBn) + b0 + t, lo_bits));      // coset_fft: x[j] *= g^j (only the first pass: A == 1, j = l*Bn + b)
+    lds_store29<TE>(lds, t * L + l, x);
+  }
+  __syncthreads();
+  tile_dif29<TE, NT, GM>(lds, lgL, T, inner);
+  const uint32_t nmask = (lg_n >= 32) ? 0xffffffffu : ((1u << lg_n) - 1u);
+  for (uint32_t e = threadIdx.x; e < T * L; e += NT) {
+    const uint32_t t = e & (T - 1u), k = e >> lgT;
+    F29 x = lds_load29<TE>(lds, t * L + bitrev(k, lgL));
+    const uint32_t b = b0 + t;
+    const size_t gi = ((((size_t)a << lgL) + k) << lgBn) + b;
+    if (direct) x = f29_mul(x, f29_load_packed(direct + gi * 32));
+    else x = f29_mul(x, two_level29(tw_hi, tw_lo, (uint32_t)(((uint64_t)tw_scale * k * b) & nmask), lo_bits));
+    store_fp<Fr>(dst + gi * 32, f29_to_fr(x));               // < 1.1 r: the next pass repacks it
+  }
+}
+// k_ntt_final on 29-bit limbs.  An output that passes a last product (the coset power or n^-1) is below 1.1 r: one conditional subtraction makes it
+// canonical; the others (plain forward transform) are reduced below 3 r first.
+template <uint32_t TE, uint32_t NT, int GM = 3>
+__global__ void __launch_bounds__(NT) k_ntt29_final(const char* src, char* dst, uint32_t lgL, uint32_t lgN1, uint32_t lgN2, uint32_t lgT,
+                                                     uint32_t lo_bits, const char* __restrict__ inner, const char* __restrict__ cs_hi, const char* __restrict__ cs_lo,
+                                                     int pre_coset, int post_coset, int do_scale, F29Arg scale) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+  src += (size_t)blockIdx.y << (lgL + lgN1 + lgN2 + 5); dst += (size_t)blockIdx.y << (lgL + lgN1 + lgN2 + 5);
+  const uint32_t L = 1u << lgL, T = 1u << lgT;
+  const uint32_t tiles_k1 = 1u << (lgN1 - lgT);
+  const uint32_t k2 = blockIdx.x / tiles_k1, k10 = (blockIdx.x % tiles_k1) << lgT;
+  for (uint32_t elem = threadIdx.x; elem < T * L; elem += NT) {
+    const uint32_t l = elem & (L - 1u), t = elem >> lgL;
+    const size_t row = ((size_t)(k10 + t) << lgN2) + k2;
+    F29 x = f29_load_packed(src + ((row << lgL) + l) * 32);
+    if (pre_coset) x = f29_mul(x, two_level29(cs_hi, cs_lo, l, lo_bits));      // single-pass coset_fft: j = l
+    lds_store29<TE>(lds, t * L + l, x);
+  }
+  __syncthreads();
+  tile_dif29<TE, NT, GM>(lds, lgL, T, inner);
+  F29 sc;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) sc.v[i] = scale.v[i];
+  for (uint32_t e = threadIdx.x; e < T * L; e += NT) {
+    const uint32_t t = e & (T - 1u), k = e >> lgT;
+    F29 x = lds_load29<TE>(lds, t * L + bitrev(k, lgL));
+    const size_t o = (size_t)(k10 + t) + (((size_t)k2 + ((size_t)k << lgN2)) << lgN1);
+    if (post_coset) x = f29_mul(x, two_level29(cs_hi, cs_lo, (uint32_t)o, lo_bits));       // g^-o * n^-1
+    else if (do_scale) x = f29_mul(x, sc);
+    else f29_reduce_partial(x);                               // a plain forward transform has no last product: < 4.5 r -> < 3 r here, two conditional subtractions below
+    Fr y = f29_to_fr(x);
+    if (!post_coset && !do_scale) y = Fr::cond_sub<2>(y);
+    store_fp<Fr>(dst + o * 32, Fr::cond_sub<1>(y));
+  }
+}
+__global__ void __launch_bounds__(256) k_build_direct29(char* __restrict__ out, uint32_t lg_n, uint32_t lgBn, uint32_t lo_bits, const char* __restrict__ tw_hi,
+                                                        const char* __restrict__ tw_lo) {
+  const size_t gi = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (gi >> lg_n) return;
+  const uint32_t k = (uint32_t)(gi >> lgBn), b = (uint32_t)(gi & (((size_t)1 << lgBn) - 1));
+  const uint32_t nmask = (lg_n >= 32) ? 0xffffffffu : ((1u << lg_n) - 1u);
+  store_fp<Fr>(out + gi * 32, Fr::cond_sub<1>(f29_to_fr(two_level29(tw_hi, tw_lo, (uint32_t)(((uint64_t)k * b) & nmask), lo_bits))));
+}
+
 // direct[(k << lgBn) + b] = w_n^(k * b): the inter-pass factor of a two-pass transform, one entry per element (built once per
 // (size, direction) on first use; 32 n bytes of HBM buy one product per element per transform)
 __global__ void __launch_bounds__(256) k_build_direct(char* __restrict__ out, uint32_t lg_n, uint32_t lgBn, uint32_t lo_bits, const char* __restrict__ tw_hi,
@@ -271,6 +436,23 @@ static int32_t build_tables(NttTables* t, uint32_t lg_n, int direction) {
   if ((rc = upload_fr(&t->d_tw_lo, lo))) return rc;
   if ((rc = upload_fr(&t->d_cs_hi, chi))) return rc;
   if ((rc = upload_fr(&t->d_cs_lo, clo))) return rc;
+  // the 29-bit-limb kernels' copies: x * 2^261 = (x * 2^256) * 2^5 — one host product by 32 per entry; the number itself is what is uploaded
+  const HFr k32 = HFr::from_u64(32);
+  auto form29 = [&](std::vector<HFr> v) { for (auto& e : v) e = HFr::mul(e, k32); return v; };
+  if ((rc = upload_fr(&t->d_tw_hi29, form29(hi)))) return rc;
+  if ((rc = upload_fr(&t->d_tw_lo29, form29(lo)))) return rc;
+  if ((rc = upload_fr(&t->d_cs_hi29, form29(chi)))) return rc;
+  if ((rc = upload_fr(&t->d_cs_lo29, form29(clo)))) return rc;
+  auto limbs29 = [](const HFr& e, uint32_t* out) {           // canonical number -> 9 x 29-bit limbs
+    for (int i = 0; i < 9; ++i) { const int bit = 29 * i, w = bit >> 6, sh = bit & 63; uint64_t x = e.l[w] >> sh; if (sh > 35 && w + 1 < 4) x |= e.l[w + 1] << (64 - sh); out[i] = (uint32_t)x & 0x1fffffffu; }
+  };
+  {
+    std::vector<uint32_t> in29(12 * inner.size(), 0);
+    for (size_t i = 0; i < inner.size(); ++i) limbs29(HFr::mul(inner[i], k32), &in29[12 * i]);
+    HIPCHK(hipMalloc(&t->d_inner29, in29.size() * 4));
+    HIPCHK(hipMemcpy(t->d_inner29, in29.data(), in29.size() * 4, hipMemcpyHostToDevice));
+  }
+  limbs29(HFr::mul(ninv, k32), t->scale29);
   return ALEO_MI355X_OK;
 }
 
@@ -324,6 +506,59 @@ static int32_t run_passes(Ctx* c, char* buf, char* tmp, uint32_t lg_n, uint32_t 
   return ALEO_MI355X_OK;
 }
 
+
+// run_passes on the 29-bit-limb kernels (tiles of 9 planes: 144 KiB / 72 KiB); same pass splits, same launch geometry
+template <uint32_t TE, uint32_t NT, int GM = 3>
+static int32_t run_passes29(Ctx* c, char* buf, char* tmp, uint32_t lg_n, uint32_t batch, const NttTables* t, int pre_coset, int post_coset, int do_scale, hipStream_t s) {
+  constexpr uint32_t lgTE = TE == 4096 ? 12 : 11;
+  static_assert(TE == 4096 || TE == 2048, "tile sizes with a kernel instance");
+  constexpr size_t lds_bytes = (size_t)TE * 36;
+  constexpr int attr_bit = (TE == 4096 ? 8 : 4) << (GM == 2 ? 2 : 0);
+  if (!(c->dev->ntt_attr_mask.load() & attr_bit)) {
+    HIPCHK(hipFuncSetAttribute((const void*)k_ntt29_strided<TE, NT, GM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    HIPCHK(hipFuncSetAttribute((const void*)k_ntt29_final<TE, NT, GM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    c->dev->ntt_attr_mask.fetch_or(attr_bit);
+  }
+  const char* inner = (const char*)t->d_inner29; const char* twh = (const char*)t->d_tw_hi29; const char* twl = (const char*)t->d_tw_lo29;
+  const char* csh = (const char*)t->d_cs_hi29; const char* csl = (const char*)t->d_cs_lo29;
+  F29Arg sc; std::memcpy(sc.v, t->scale29, 36);
+  const uint32_t maxL = lgTE < INNER_MAX_LG ? lgTE : INNER_MAX_LG;
+  uint32_t npass = lg_n <= maxL ? 1 : (lg_n <= 2 * maxL ? 2 : 3);
+  uint32_t s1 = 0, s2 = 0, s3 = 0;
+  if (npass == 1) s3 = lg_n;
+  else if (npass == 2) { s1 = (lg_n + 1) / 2; s3 = lg_n - s1; }
+  else { s1 = (lg_n + 2) / 3; s2 = (lg_n - s1 + 1) / 2; s3 = lg_n - s1 - s2; }
+  auto lgT_for = [](uint32_t lgL, uint32_t lg_limit) { uint32_t lgT = lgTE - lgL; return lgT < lg_limit ? lgT : lg_limit; };
+  if (npass == 1) {
+    hipLaunchKernelGGL((k_ntt29_final<TE, NT, GM>), dim3(1, batch), dim3(NT), lds_bytes, s, buf, buf, s3, 0u, 0u, 0u, t->lo_bits, inner, csh, csl, pre_coset, post_coset, do_scale, sc);
+  } else if (npass == 2) {
+    uint32_t lgBn = s3, lgT = lgT_for(s1, lgBn);
+    const char* direct = nullptr;
+    static const uint32_t direct_max = [] { const char* e = std::getenv("ALEO_MI355X_NTT_DIRECT_MAX"); const int k = e ? std::atoi(e) : 21; return (uint32_t)(k >= 0 && k <= 22 ? k : 21); }();      // 2^21: 0.286 -> 0.271 ms with the table, 2^22: 0.549 -> 0.564 ms (the extra 32 B per element of HBM reads cost more than the product)
+    if (lg_n >= 12 && lg_n <= direct_max) {
+      std::lock_guard<std::mutex> lk(c->dev->mu);
+      NttTables* tm = const_cast<NttTables*>(t);
+      if (!tm->d_direct29) {
+        HIPCHK(hipMalloc(&tm->d_direct29, (size_t)32 << lg_n));
+        hipLaunchKernelGGL(k_build_direct29, dim3((uint32_t)((((size_t)1 << lg_n) + 255) / 256)), dim3(256), 0, s, (char*)tm->d_direct29, lg_n, lgBn, t->lo_bits, twh, twl);
+        HIPCHK(hipStreamSynchronize(s));
+        tm->direct29_lgBn = lgBn;
+      }
+      if (tm->direct29_lgBn == lgBn) direct = (const char*)tm->d_direct29;
+    }
+    hipLaunchKernelGGL((k_ntt29_strided<TE, NT, GM>), dim3(1u << (lgBn - lgT), batch), dim3(NT), lds_bytes, s, buf, tmp, s1, lgBn, lgT, 1u, lg_n, t->lo_bits, inner, twh, twl, csh, csl, pre_coset, direct);
+    uint32_t lgTf = lgT_for(s3, s1);
+    hipLaunchKernelGGL((k_ntt29_final<TE, NT, GM>), dim3(1u << (s1 - lgTf), batch), dim3(NT), lds_bytes, s, tmp, buf, s3, s1, 0u, lgTf, t->lo_bits, inner, csh, csl, 0, post_coset, do_scale, sc);
+  } else {
+    uint32_t lgBn1 = s2 + s3, lgT1 = lgT_for(s1, lgBn1);
+    hipLaunchKernelGGL((k_ntt29_strided<TE, NT, GM>), dim3(1u << (lgBn1 - lgT1), batch), dim3(NT), lds_bytes, s, buf, buf, s1, lgBn1, lgT1, 1u, lg_n, t->lo_bits, inner, twh, twl, csh, csl, pre_coset, (const char*)nullptr);
+    uint32_t lgBn2 = s3, lgT2 = lgT_for(s2, lgBn2);
+    hipLaunchKernelGGL((k_ntt29_strided<TE, NT, GM>), dim3((1u << s1) << (lgBn2 - lgT2), batch), dim3(NT), lds_bytes, s, buf, tmp, s2, lgBn2, lgT2, 1u << s1, lg_n, t->lo_bits, inner, twh, twl, csh, csl, 0, (const char*)nullptr);
+    uint32_t lgTf = lgT_for(s3, s1);
+    hipLaunchKernelGGL((k_ntt29_final<TE, NT, GM>), dim3((1u << s2) << (s1 - lgTf), batch), dim3(NT), lds_bytes, s, tmp, buf, s3, s1, s2, lgTf, t->lo_bits, inner, csh, csl, 0, post_coset, do_scale, sc);
+  }
+  return ALEO_MI355X_OK;
+}
 
 // dst[c][r] = src[r][c] for 32-byte elements (rows x cols -> cols x rows): the three layout changes of a 4-step transform (columns contiguous for the
 // column transforms, rows for the row transforms, natural order out).  32 x 32-element tiles through LDS: both sides move 1-KiB runs.
@@ -438,7 +673,16 @@ static int32_t ntt_run_chunk(Ctx* c, void* d_inout, uint32_t lg_n, uint32_t batc
   // small transforms are latency-bound on the few blocks a 2048-element tile leaves them (2^16: 32 blocks on 256 CUs): 512-element
   // tiles of one wave each spread them over the chip (2^16: 0.085 -> see profiles/); batches already have the blocks
   static const int force_tile = [] { const char* e = std::getenv("ALEO_MI355X_NTT_TILE"); return e ? std::atoi(e) : 0; }();      // experiments only
-  if (force_tile == 2048) rc = run_passes<2048, 256>(c, buf, tmp, lg_n, batch, t, pre_coset, post_coset, do_scale, sc, s);
+  static const bool limbs29 = [] { const char* e = std::getenv("ALEO_MI355X_NTT29"); return !(e && e[0] == '0'); }();      // A/B switch: 0 = the 32-bit-limb kernels everywhere
+  const bool big_tile_default = !(lg_n >= 10 && lg_n <= 18 && ((size_t)batch << lg_n) <= ((size_t)1 << 18)) &&
+                                !(lg_n >= 10 && lg_n <= 18 && ((size_t)batch << lg_n) <= ((size_t)1 << wide_lg()));
+  if (limbs29 && (force_tile == 2048 || force_tile == 4096 || (force_tile == 0 && big_tile_default))) {
+    static const int gm = [] { const char* e = std::getenv("ALEO_MI355X_NTT29_GM"); return e ? std::atoi(e) : 3; }();      // experiment knob
+    if ((force_tile == 4096 || (force_tile == 0 && lg_n >= 20 && lg_n <= 22)) && gm == 2) rc = run_passes29<4096, 1024, 2>(c, buf, tmp, lg_n, batch, t, pre_coset, post_coset, do_scale, s);
+    else if (force_tile == 4096 || (force_tile == 0 && lg_n >= 20 && lg_n <= 22)) rc = run_passes29<4096, 512>(c, buf, tmp, lg_n, batch, t, pre_coset, post_coset, do_scale, s);
+    else rc = run_passes29<2048, 256>(c, buf, tmp, lg_n, batch, t, pre_coset, post_coset, do_scale, s);
+  }
+  else if (force_tile == 2048) rc = run_passes<2048, 256>(c, buf, tmp, lg_n, batch, t, pre_coset, post_coset, do_scale, sc, s);
   else if (force_tile == 4096) rc = run_passes<4096, 512>(c, buf, tmp, lg_n, batch, t, pre_coset, post_coset, do_scale, sc, s);
   else if (force_tile == 512 && lg_n <= 18) rc = run_passes<512, 64>(c, buf, tmp, lg_n, batch, t, pre_coset, post_coset, do_scale, sc, s);
   else if (lg_n >= 20 && lg_n <= 22) rc = run_passes<4096, 512>(c, buf, tmp, lg_n, batch, t, pre_coset, post_coset, do_scale, sc, s);

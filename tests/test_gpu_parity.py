@@ -88,6 +88,53 @@ def test_ntt_matches_oracle_all_variants(lg):
             assert (d.ntt(x, 0, direction, type_) == c.ntt_fr(x, 0, direction, type_)).all(), (lg, direction, type_)
 
 
+def _extreme_fr(n, kind):
+    """Raw 32-byte values that push the lazy sums of the 29-bit-limb butterflies (fr29.h) to their bounds: the largest canonical number everywhere,
+    alternating with zero, or in one half only."""
+    top = c.ints_to_limbs([p.FR_MODULUS - 1], 4)[0]
+    x = np.zeros((n, 4), dtype=np.uint64)
+    if kind == 'all': x[:] = top
+    elif kind == 'alternate': x[0::2] = top
+    elif kind == 'half': x[:n // 2] = top
+    else: x[0] = top
+    return x
+
+
+@pytest.mark.parametrize('lg,batch', [(11, 512), (16, 16), (19, 1), (20, 1), (21, 1)])
+def test_ntt_large_tiles_extreme_inputs(lg, batch):
+    """The large-tile kernels (9 x 29-bit limbs, no conditional subtraction inside a butterfly) on inputs whose sums grow as fast as they can:
+    one pass (2^11 in a batch), two passes on 72 KiB tiles (2^16 in a batch, 2^19), two passes on 144 KiB tiles (2^20, 2^21) — every variant
+    against the restatement."""
+    import torch
+    from aleo_amd import dist as adist
+    n = 1 << lg
+    if batch > 1:
+        ops = adist.HipLocalOps()
+        kinds = ['all', 'alternate', 'half', 'one']
+        x = np.concatenate([_extreme_fr(n, kinds[b % 4]) if b < 8 else c.fr_to_mont(util.uniform_scalars(n, 9100 + b)) for b in range(batch)])
+        for direction in (0, 1):
+            t = torch.from_numpy(x.view(np.int64).copy()).cuda()
+            ops.batch_ntt(t, lg, batch, direction); torch.cuda.synchronize()
+            got = t.cpu().numpy().view(np.uint64).reshape(batch, n, 4)
+            for b in list(range(9)) + [batch - 1]:
+                assert (got[b] == c.ntt_fr(x[b << lg:(b + 1) << lg], 0, direction, 0)).all(), (lg, b, direction)
+        return
+    d = aleo_amd.EvaluationDomain(n)
+    for kind in ('all', 'alternate', 'half'):
+        x = _extreme_fr(n, kind)
+        for direction in (0, 1):
+            for type_ in (0, 1):
+                assert (d.ntt(x, 0, direction, type_) == c.ntt_fr(x, 0, direction, type_, threads=8)).all(), (lg, kind, direction, type_)
+
+
+def test_ntt_three_passes_matches_oracle_2_23():
+    """2^23: three passes on 72 KiB tiles (29-bit limbs), uniform and all-maximal inputs against the restatement (threaded)."""
+    lg = 23; n = 1 << lg
+    d = aleo_amd.EvaluationDomain(n)
+    for x, direction, type_ in ((c.fr_to_mont(util.uniform_scalars(n, 2323)), 0, 1), (_extreme_fr(n, 'all'), 1, 0)):
+        assert (d.ntt(x, 0, direction, type_) == c.ntt_fr(x, 0, direction, type_, threads=16)).all(), (direction, type_)
+
+
 @pytest.mark.parametrize('lg', [3, 9, 13])
 def test_ntt_orders(lg):
     x = c.fr_to_mont(util.uniform_scalars(1 << lg, 300 + lg))
