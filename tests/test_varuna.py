@@ -792,3 +792,44 @@ def test_independent_proofs_in_lockstep_equal_the_single_calls():
         for x in nx: x.close()
     finally:
         ck.close()
+
+
+@pytest.mark.gpu
+def test_helper_contexts_under_contention():
+    """The borrowed helper contexts (lockstep workers, the second context of a multi-chain commitment) when several calls want them at once: three
+    threads run lockstep calls of different sizes while a fourth commits batches big enough to split into several launch chains (two sets per chain
+    on the 2^19-bucket table) — every result equals the one computed alone."""
+    import threading, torch
+    from aleo_amd import varuna, msm as M, kzg
+    cs, csrs, zs, D = _batch_case([(60, 3, 81, 2), (130, 4, 82, 1)])
+    ck = varuna.synthetic_committer_key(TAU, S_GAMMA, D)
+    lim = lambda a: np.stack([synth.int_to_limbs(v, 4) for v in a])
+    n = 1 << 20
+    pb = M.PinnedBases.generate_multiples(synth.generator_affine104(), 1, n).precompute()
+    try:
+        nx = [varuna.NativeCircuitIndex(csrs[j], cs[j].n_constraints, cs[j].n_public, len(zs[j][0]) - cs[j].n_public, ck) for j in range(2)]
+        za = [[lim(z) for z in zz] for zz in zs]
+        reqs = [[([nx[q % 2]], [za[q % 2]], 100 * t + q) for q in range(3 + 2 * t)] for t in range(3)]
+        want = [varuna.prove_many_native(r) for r in reqs]
+        polys = torch.from_numpy(synth.uniform_scalars(5 * n, 4242).view(np.int64)).cuda(); torch.cuda.synchronize()
+        ptrs = [polys.data_ptr() + j * n * 32 for j in range(5)]
+        commit = lambda: M.VariableBase.msm_batch_device(pb, ptrs, [n] * 5)          # five results, two per chain: three chains
+        want_c = commit()
+        got = [None] * 3; got_c = []; errs = []
+        def prover(t):
+            try:
+                for _ in range(3): got[t] = varuna.prove_many_native(reqs[t])
+            except Exception as e: errs.append(repr(e))
+        def committer():
+            try:
+                for _ in range(4): got_c.append(commit())
+            except Exception as e: errs.append(repr(e))
+        th = [threading.Thread(target=prover, args=(t,)) for t in range(3)] + [threading.Thread(target=committer)]
+        for x in th: x.start()
+        for x in th: x.join()
+        assert not errs, errs
+        assert got == want
+        assert all(np.array_equal(np.asarray(g), np.asarray(want_c)) for g in got_c)
+        for x in nx: x.close()
+    finally:
+        pb.close(); ck.close()
