@@ -174,11 +174,9 @@ static bool looks_sparse(const void* scalars, size_t n) {
   return small >= 129;
 }
 static int32_t msm_host_scalars(Ctx* c, void* out, const PinnedBases& pb, const void* scalars, size_t n, bool mont) {
-  int32_t rc;
-  if ((rc = c->scalars_stage.reserve((n ? n : 1) * 32))) return rc;
   const bool sparse = !mont && pb.range.d && pb.range_off == 0 && n <= pb.range.cover && looks_sparse(scalars, n);
-  if (n) HIPCHK(hipMemcpyAsync(c->scalars_stage.p, scalars, n * 32, hipMemcpyHostToDevice, c->stream));
-  return msm_run1(c, (uint64_t*)out, pb, c->scalars_stage.p, n, mont, c->stream, sparse);
+  if (!n) return msm_run1(c, (uint64_t*)out, pb, nullptr, 0, mont, c->stream, false);
+  return msm_run1_split(c, (uint64_t*)out, pb, nullptr, n, mont, c->stream, sparse, scalars);      // uploads inside (whole, or in halves from 2^20 points on)
 }
 
 // ---- SRS cache for the one-shot entry point ----------------------------------------------------------
@@ -448,7 +446,7 @@ int32_t aleo_mi355x_msm_g1_device(void* out, uint64_t handle, const void* d_scal
     API_BEGIN
     FIND_BASES(handle)
     PICK_STREAM(s)
-    return msm_run1(c, (uint64_t*)out, pb, d_scalars, n, false, s);
+    return msm_run1_split(c, (uint64_t*)out, pb, d_scalars, n, false, s, false, nullptr);
   } catch (...) { return ALEO_MI355X_ERR_HIP; }
 }
 

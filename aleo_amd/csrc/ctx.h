@@ -148,13 +148,16 @@ int32_t ensure_host_pinned(Ctx* c, size_t bytes);
 //   sum_i scalar[i] * base[off + i],  i < len    (scalars at the DEVICE pointer d_ptr; the segment array itself is host memory).
 // k > 1 needs a table tier that covers every base reached and k <= msm_max_sets(); msm_batch() groups arbitrary requests accordingly.
 struct MsmSeg { const void* d_ptr = nullptr; size_t len = 0, off = 0; uint32_t out = 0; };
-struct MsmJob { const MsmSeg* segs = nullptr; uint32_t nseg = 0, k = 0; bool mont = false; bool sparse = false; bool fire_tail = false; };      // fire_tail: this launch chain is the whole request — run Ctx::tail_hook behind its last kernel      // sparse: hint — use the set's range table when every segment lies inside it
+struct MsmJob { const MsmSeg* segs = nullptr; uint32_t nseg = 0, k = 0; bool mont = false; bool sparse = false; bool fire_tail = false; size_t tier_n = 0; };      // tier_n: pick the table tier as for a reach of tier_n (a part of a split request keeps the whole request's window)      // fire_tail: this launch chain is the whole request — run Ctx::tail_hook behind its last kernel      // sparse: hint — use the set's range table when every segment lies inside it
 int32_t msm_run(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, const MsmJob& job, hipStream_t s);
 inline int32_t msm_run1(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, const void* d_scalars, size_t n, bool mont, hipStream_t s, bool sparse = false) {
   MsmSeg g; g.d_ptr = d_scalars; g.len = n;
   MsmJob j; j.segs = &g; j.nseg = 1; j.k = 1; j.mont = mont; j.sparse = sparse; return msm_run(c, out_jac18, pb, j, s);
 }
 int32_t msm_batch(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, const MsmJob& job, hipStream_t s);
+// One result over n points, scalars on the device (host_src == nullptr) or still on the host (then d_scalars is ignored and the scalars are uploaded into the
+// contexts' staging buffers): host scalars from 2^21 points on go in two halves on two contexts — msm.hip msm_run1_split
+int32_t msm_run1_split(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, const void* d_scalars, size_t n, bool mont, hipStream_t s, bool sparse, const void* host_src);
 uint32_t msm_max_sets(const PinnedBases& pb, size_t n);
 int32_t launch_fq_mul(Ctx* c, void* r, const void* a, const void* b, size_t n);
 int32_t launch_fr_mul(Ctx* c, void* r, const void* a, const void* b, size_t n);

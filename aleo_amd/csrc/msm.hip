@@ -969,6 +969,7 @@ int32_t msm_run(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, const MsmJob
     n = g.off + g.len > n ? g.off + g.len : n; pts += g.len;
   }
   if (n == 0) { for (uint32_t q = 0; q < K; ++q) hstore_jacobian_normalized(out_jac18 + 18 * q, HXYZZ::infinity()); return ALEO_MI355X_OK; }
+  if (job.tier_n > n && job.tier_n <= pb.n) n = job.tier_n;
   if (n > pb.n) { g_last_error = "msm: a segment reaches past the pinned bases"; return ALEO_MI355X_ERR_BAD_ARG; }
   // the fixed-base table serves any prefix of the pinned set (row stride = pinned count) as long as the prefix still
   // puts about one point into every bucket; shorter prefixes use the plain path with its small bucket count
@@ -1224,6 +1225,63 @@ static int32_t run_chains(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, st
   (void)hipStreamSynchronize(h->stream);
   if (rc_m) return rc_m;
   if (rc_h) { g_last_error = err_h; return rc_h; }
+  return ALEO_MI355X_OK;
+}
+
+// A single big result in two halves.  The second half runs on a borrowed helper context from a second host thread: its upload (host scalars) goes under
+// the first half's sort and accumulation, its sort under the first half's accumulation, and the first half's bucket reduction — latency-bound, a
+// fraction of the chip — under the second half's accumulation.  Both halves use the window of the whole request (tier_n); the two partial results are
+// added on the host.  Measured: HOST scalars 2^22 12.49 -> 11.20 ms (half of the 128-MB upload disappears), 2^20 3.52 -> 3.45 ms (within noise of the
+// thread it costs); scalars already on the DEVICE lose — 2^20 2.77 -> 3.12 ms, 2^22 9.48 -> 9.91 ms: nothing was idle to fill, and two half-size
+// requests pay the sort ramp and the bucket reduction twice.  So: host scalars from 2^21 points on, device scalars never.
+// ALEO_MI355X_SPLIT_MIN_LG (default 21, 0 = never) is the A/B switch.
+static uint32_t split_min_lg() { static const uint32_t v = [] { const char* e = std::getenv("ALEO_MI355X_SPLIT_MIN_LG"); const int k = e ? std::atoi(e) : 21; return (uint32_t)(k >= 0 && k <= 30 ? k : 21); }(); return v; }
+int32_t msm_run1_split(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, const void* d_scalars, size_t n, bool mont, hipStream_t s, bool sparse, const void* host_src) {
+  bool tiered = false;
+  for (const auto& t : pb.tab) if (t.d && n >= t.min_n && n <= t.cover) tiered = true;
+  HelperSet hs;
+  if (host_src && !sparse && tiered && split_min_lg() && n >= ((size_t)1 << split_min_lg()) && c->dev) { const int32_t rc = acquire_helpers(c->dev, 1, hs); if (rc) return rc; }
+  if (hs.ctx.empty()) {
+    if (host_src) {
+      const int32_t rc = c->scalars_stage.reserve((n ? n : 1) * 32); if (rc) return rc;
+      if (n) HIPCHK(hipMemcpyAsync(c->scalars_stage.p, host_src, n * 32, hipMemcpyHostToDevice, s));
+      d_scalars = c->scalars_stage.p;
+    }
+    return msm_run1(c, out_jac18, pb, d_scalars, n, mont, s, sparse);
+  }
+  Ctx* h = hs.ctx[0];
+  const size_t na = (n / 2 + 255) & ~(size_t)255, nb = n - na;
+  uint64_t part[36]; int32_t rc_h = ALEO_MI355X_OK; std::string err_h;
+  auto half = [&](Ctx* cc, hipStream_t st, const void* d_ptr, size_t len, size_t off, uint64_t* out) -> int32_t {
+    MsmSeg g; g.d_ptr = d_ptr; g.len = len; g.off = off;
+    MsmJob j; j.segs = &g; j.nseg = 1; j.k = 1; j.mont = mont; j.tier_n = n;
+    return msm_run(cc, out, pb, j, st);
+  };
+  const void* pa = d_scalars; const void* pbp = (const char*)d_scalars + na * 32;
+  if (host_src) {
+    int32_t rc = c->scalars_stage.reserve(na * 32); if (rc) return rc;
+    if ((rc = h->scalars_stage.reserve(nb * 32))) return rc;
+    HIPCHK(hipMemcpyAsync(c->scalars_stage.p, host_src, na * 32, hipMemcpyHostToDevice, s));      // pageable memory: returns once the bytes are staged — the second upload follows it on the wire
+    pa = c->scalars_stage.p; pbp = h->scalars_stage.p;
+  } else {
+    HIPCHK(hipEventRecord(c->ev[4], s));                   // the scalars may still be in flight on the caller's stream
+    HIPCHK(hipStreamWaitEvent(h->stream, c->ev[4], 0));
+  }
+  std::thread helper([&] {
+    try {
+      if (hipSetDevice(c->device) != hipSuccess) { rc_h = ALEO_MI355X_ERR_HIP; err_h = "hipSetDevice failed"; return; }
+      if (host_src && hipMemcpyAsync(h->scalars_stage.p, (const char*)host_src + na * 32, nb * 32, hipMemcpyHostToDevice, h->stream) != hipSuccess) { rc_h = ALEO_MI355X_ERR_HIP; err_h = "upload of the second half failed"; return; }
+      rc_h = half(h, h->stream, pbp, nb, na, part + 18);
+      if (rc_h) err_h = g_last_error;
+    } catch (...) { rc_h = ALEO_MI355X_ERR_HIP; err_h = "msm: exception on the helper thread"; }
+  });
+  const int32_t rc_m = half(c, s, pa, na, 0, part);
+  helper.join();
+  (void)hipStreamSynchronize(h->stream);
+  if (rc_m) return rc_m;
+  if (rc_h) { g_last_error = err_h; return rc_h; }
+  host::HXYZZ t = host::hadd(host::hfrom_jacobian(part), host::hfrom_jacobian(part + 18));
+  host::hstore_jacobian_normalized(out_jac18, t);
   return ALEO_MI355X_OK;
 }
 
