@@ -685,7 +685,7 @@ int32_t aleo_mi355x_fr_eval_batch_device(void* d_out, const void* const* d_polys
 int32_t aleo_mi355x_varuna_prove(const aleo_mi355x_varuna_index* index, const void* const* assignments, size_t n_instances, const uint8_t* seed, void* out_proof, size_t* len) {
   try {
     if (!index || !assignments || !out_proof || !len || !seed || !index->positions || !index->vk_bytes) { g_last_error = "varuna_prove: null argument"; return ALEO_MI355X_ERR_BAD_ARG; }
-    for (size_t i = 0; i < n_instances && i < 8; ++i) if (!assignments[i]) { g_last_error = "varuna_prove: null assignment"; return ALEO_MI355X_ERR_BAD_ARG; }
+    for (size_t i = 0; i < n_instances && i < 32; ++i) if (!assignments[i]) { g_last_error = "varuna_prove: null assignment"; return ALEO_MI355X_ERR_BAD_ARG; }
     API_BEGIN
     FIND_BASES(index->committer_key)
     return varuna_prove(c, pb, *index, assignments, n_instances, seed, (uint8_t*)out_proof, len);
@@ -752,7 +752,7 @@ int32_t aleo_mi355x_varuna_index_free(uint64_t index_handle) {
 int32_t aleo_mi355x_varuna_prove_indexed(uint64_t index_handle, const void* const* assignments, size_t n_instances, const uint8_t* seed, void* out_proof, size_t* len) {
   try {
     if (!assignments || !out_proof || !len || !seed) return ALEO_MI355X_ERR_BAD_ARG;
-    for (size_t i = 0; i < n_instances && i < 8; ++i) if (!assignments[i]) { g_last_error = "varuna_prove: null assignment"; return ALEO_MI355X_ERR_BAD_ARG; }
+    for (size_t i = 0; i < n_instances && i < 32; ++i) if (!assignments[i]) { g_last_error = "varuna_prove: null assignment"; return ALEO_MI355X_ERR_BAD_ARG; }
     API_BEGIN
     std::shared_ptr<VarunaIndexOwner> ixk; { int32_t rci = find_varuna(d, index_handle, &ixk); if (rci) return rci; }
     const aleo_mi355x_varuna_index* ix = varuna_index_view(ixk.get());
@@ -764,9 +764,9 @@ int32_t aleo_mi355x_varuna_prove_indexed(uint64_t index_handle, const void* cons
 int32_t aleo_mi355x_varuna_prove_batch_indexed(const uint64_t* index_handles, size_t n_circuits, const void* const* assignments, const size_t* n_instances, const uint8_t* seed,
                                                void* out_proof, size_t* len) {
   try {
-    if (!seed || !index_handles || !assignments || !n_instances || !out_proof || !len || n_circuits < 1 || n_circuits > 8) { g_last_error = "varuna_prove_batch: null argument or circuit count outside 1..8"; return ALEO_MI355X_ERR_BAD_ARG; }
+    if (!seed || !index_handles || !assignments || !n_instances || !out_proof || !len || n_circuits < 1 || n_circuits > 32) { g_last_error = "varuna_prove_batch: null argument or circuit count outside 1..32"; return ALEO_MI355X_ERR_BAD_ARG; }
     size_t total = 0;
-    for (size_t j = 0; j < n_circuits; ++j) { if (n_instances[j] < 1 || n_instances[j] > 8) { g_last_error = "varuna_prove_batch: 1..8 instances per circuit"; return ALEO_MI355X_ERR_BAD_ARG; } total += n_instances[j]; }
+    for (size_t j = 0; j < n_circuits; ++j) { if (n_instances[j] < 1 || n_instances[j] > 32) { g_last_error = "varuna_prove_batch: 1..32 instances per circuit"; return ALEO_MI355X_ERR_BAD_ARG; } total += n_instances[j]; }
     for (size_t i = 0; i < total; ++i) if (!assignments[i]) { g_last_error = "varuna_prove_batch: null assignment"; return ALEO_MI355X_ERR_BAD_ARG; }
     API_BEGIN
     std::vector<std::shared_ptr<VarunaIndexOwner>> ixk(n_circuits); std::vector<const aleo_mi355x_varuna_index*> views(n_circuits);
@@ -785,11 +785,11 @@ int32_t aleo_mi355x_varuna_prove_many(aleo_mi355x_prove_request* requests, size_
     for (size_t p = 0; p < n_requests; ++p) {
       aleo_mi355x_prove_request& r = requests[p]; r.status = ALEO_MI355X_OK;
       auto bad = [&](const char* why) { r.status = ALEO_MI355X_ERR_BAD_ARG; rq[p].status = r.status; rq[p].error = why; };
-      if (!r.index_handles || !r.assignments || !r.n_instances || !r.seed || !r.out_proof || r.n_circuits < 1 || r.n_circuits > 8) { bad("varuna_prove_many: null argument or circuit count outside 1..8"); continue; }
+      if (!r.index_handles || !r.assignments || !r.n_instances || !r.seed || !r.out_proof || r.n_circuits < 1 || r.n_circuits > 32) { bad("varuna_prove_many: null argument or circuit count outside 1..32"); continue; }
       size_t total = 0; bool ok = true;
-      for (size_t j = 0; j < r.n_circuits; ++j) { if (r.n_instances[j] < 1 || r.n_instances[j] > 8) ok = false; total += r.n_instances[j]; }
+      for (size_t j = 0; j < r.n_circuits; ++j) { if (r.n_instances[j] < 1 || r.n_instances[j] > 32) ok = false; total += r.n_instances[j]; }
       for (size_t i = 0; ok && i < total; ++i) if (!r.assignments[i]) ok = false;
-      if (!ok) { bad("varuna_prove_many: 1..8 instances per circuit, no null assignment"); continue; }
+      if (!ok) { bad("varuna_prove_many: 1..32 instances per circuit, no null assignment"); continue; }
       keep_ix[p].resize(r.n_circuits);
       for (size_t j = 0; j < r.n_circuits && !rq[p].status; ++j) {
         const int32_t rci = find_varuna(d, r.index_handles[j], &keep_ix[p][j]);

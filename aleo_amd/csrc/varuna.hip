@@ -233,7 +233,8 @@ int32_t varuna_index_build(Ctx* c, const PinnedBases& pb, std::shared_ptr<Pinned
 #define TAKE_M(var, elems) var = sh.ar.take(elems); if (!var) { g_last_error = "varuna_prove: workspace accounting"; return ALEO_MI355X_ERR_HIP; }
 #define TAKE_S(var, elems) char* var = sh.ar.take(elems); if (!var) { g_last_error = "varuna_prove: workspace accounting"; return ALEO_MI355X_ERR_HIP; }
 static constexpr size_t HC = 3;                            // coefficients of a hiding polynomial (hiding bound 1)
-static constexpr size_t MAX_CIRCUITS = 8, MAX_INSTANCES = 8, MAX_TOTAL_INSTANCES = 32;
+static constexpr size_t MAX_TOTAL_INSTANCES = 32, MAX_CIRCUITS = MAX_TOTAL_INSTANCES, MAX_INSTANCES = MAX_TOTAL_INSTANCES;      // one proof covers one transaction: at most 32 transitions, in any split over circuits
+static constexpr size_t PIN_SUMS = 8192, PIN_FLAG = 9216, PIN_SMALL_BYTES = 12288;      // small read-backs behind the staging area: evaluations / sigma values from 0 (<= 129 x 32 bytes), the circuits' sums over H, the canonical-input flag
 
 struct Shared {
   Ctx* c; const PinnedBases& pb; Seed32 seed;
@@ -353,7 +354,7 @@ int32_t Prover::first_round(const void* const* assignments, std::vector<MsmSeg>&
       rho[q] = random_fr(sh.seed, 3 * q0 + q);
       for (size_t t = 0; t < HC; ++t) sh.blind[(3 * q0 + q) * HC + t] = random_fr(sh.seed, sh.lay_blind + HC * (3 * q0 + q) + t);
     }
-    RC(fr_blind_rows(c, wit, ev, n_h, 3 * k, rho, s));                                      // + rho (X^|H| − 1), all 3k polynomials in one launch
+    for (size_t at = 0; at < 3 * k; at += 24) RC(fr_blind_rows(c, wit + at * L * 32, ev + at * n_h * 32, n_h, 3 * k - at < 24 ? 3 * k - at : 24, rho + at, s));      // + rho (X^|H| − 1), 24 polynomials per launch
     if (lagrange()) { char* st = stage + (sh.st_rho() + 3 * q0) * 32; std::memcpy(st, rho, 3 * k * 32); HIPCHK(hipMemcpyAsync(rho_dev, st, 3 * k * 32, hipMemcpyHostToDevice, s)); }
   }
   for (size_t q = 0; q < 3 * k; ++q) {
@@ -409,7 +410,7 @@ int32_t Prover::second_round() {
   HIPCHK(hipMemcpyAsync(hq + n_h * 32, q1 + 2 * n_h * 32, n_h * 32, hipMemcpyDeviceToDevice, s));   // quotient blocks: p2, p1 + p2; remainder p0 + p1 + p2
   RC(fr_vec_op(c, hq, q1 + n_h * 32, q1 + 2 * n_h * 32, n_h, 1, s));
   RC(fr_vec_op(c, rq, q1, hq, n_h, 1, s));
-  HIPCHK(hipMemcpyAsync(sh.pin_small + 3584 + 32 * j, rq, 32, hipMemcpyDeviceToHost, s));   // this circuit's sum over H (the remainder's constant term): read with the commitments
+  HIPCHK(hipMemcpyAsync(sh.pin_small + PIN_SUMS + 32 * j, rq, 32, hipMemcpyDeviceToHost, s));   // this circuit's sum over H (the remainder's constant term): read with the commitments
   return ALEO_MI355X_OK;
 }
 
@@ -506,11 +507,11 @@ static int32_t lincomb_any(Ctx* c, char* dst, size_t n, const HFr& c0, std::vect
 
 int32_t Batch::setup(const aleo_mi355x_varuna_index* const* ixs, size_t m, const size_t* ks) {
   Ctx* c = sh.c;
-  if (m < 1 || m > MAX_CIRCUITS) { g_last_error = "varuna_prove: 1..8 circuits per proof"; return ALEO_MI355X_ERR_BAD_ARG; }
+  if (m < 1 || m > MAX_CIRCUITS) { g_last_error = "varuna_prove: 1..32 circuits per proof"; return ALEO_MI355X_ERR_BAD_ARG; }
   sh.m = m; sh.K = 0;
   for (size_t j = 0; j < m; ++j) {
     if (!ixs[j] || !ixs[j]->positions || !ixs[j]->vk_bytes) { g_last_error = "varuna_prove: null index"; return ALEO_MI355X_ERR_BAD_ARG; }
-    if (ks[j] < 1 || ks[j] > MAX_INSTANCES) { g_last_error = "varuna_prove: 1..8 instances per circuit"; return ALEO_MI355X_ERR_BAD_ARG; }
+    if (ks[j] < 1 || ks[j] > MAX_INSTANCES) { g_last_error = "varuna_prove: 1..32 instances per circuit"; return ALEO_MI355X_ERR_BAD_ARG; }
     P.emplace_back(new Prover(sh, *ixs[j], j, ks[j], sh.K)); sh.K += ks[j];
     RC(P[j]->setup());
     if (ixs[j]->committer_key != ixs[0]->committer_key || ixs[j]->max_degree != ixs[0]->max_degree || ixs[j]->gamma_offset != ixs[0]->gamma_offset) {
@@ -533,7 +534,7 @@ int32_t Batch::setup(const aleo_mi355x_varuna_index* const* ixs, size_t m, const
   need_ws_bytes = elems * 32 + (64 << 10);
   this->pin_elems = pin_elems;
   stage_elems = sh.x_total + (3 * sh.K + 1) * HC + HC + 3 * sh.K;                          // x̂ coefficients, hiding polynomials, the opening's hiding quotient, rho: staged through pinned memory
-  need_pin_bytes = (pin_elems + stage_elems) * 32 + 4096;
+  need_pin_bytes = (pin_elems + stage_elems) * 32 + PIN_SMALL_BYTES;
   sh.one = HFr::one(); sh.neg1 = HFr::neg(sh.one); std::memcpy(sh.r2.l, host::HParams<4>::R2, 32);
   // randomness layout (oracle/varuna_ref.py randomness_layout over the largest |H| and all instances)
   sh.lay_mask = 3 * sh.K; sh.lay_blind = 3 * sh.K + 3 * sh.N; sh.lay_blind_mask = sh.lay_blind + 3 * HC * sh.K;
@@ -542,7 +543,7 @@ int32_t Batch::setup(const aleo_mi355x_varuna_index* const* ixs, size_t m, const
 
 void Batch::attach(char* ws, size_t ws_bytes, char* pin) {
   sh.ar = Arena{ws, 0, ws_bytes};
-  sh.pin = pin; sh.stage = sh.pin + pin_elems * 32; sh.pin_small = sh.stage + stage_elems * 32;      // 4 KB for small read-backs
+  sh.pin = pin; sh.stage = sh.pin + pin_elems * 32; sh.pin_small = sh.stage + stage_elems * 32;      // PIN_SMALL_BYTES for small read-backs
 }
 
 // The slot's grow-only device workspace and pinned staging, sized for `ws_bytes` / `pin_bytes` (one proof, or the sum over the proofs of a lockstep call)
@@ -580,7 +581,7 @@ int32_t Batch::first_prepare(const void* const* assignments) {
   sh.blind.assign((3 * K + 1) * HC, HFr::zero()); sh.x_mont.clear();
   std::vector<MsmSeg>& sg = job[0].segs; std::vector<MsmSeg>& sm = job[1].segs; sg.clear(); sm.clear();
   for (auto& p : P) RC(p->first_round(assignments + p->q0, sg));
-  if (sh.flag) HIPCHK(hipMemcpyAsync(sh.pin_small + 3840, sh.flag, 4, hipMemcpyDeviceToHost, s));      // read after the round's commitments
+  if (sh.flag) HIPCHK(hipMemcpyAsync(sh.pin_small + PIN_FLAG, sh.flag, 4, hipMemcpyDeviceToHost, s));      // read after the round's commitments
   for (size_t t = 0; t < HC; ++t) sh.blind[3 * K * HC + t] = random_fr(sh.seed, sh.lay_blind_mask + t);
   RC(fr_random(c, sh.mask, 3 * N, (const uint8_t*)sh.seed.w, sh.lay_mask, 1, s));
   RC(fr_lin(c, sh.mask, 1, nullptr, sh.neg1.l, sh.mask + N * 32, sh.neg1.l, sh.mask + 2 * N * 32, s));   // sum over H* = |H*| (m_0 + m_|H*| + m_2|H*|) = 0
@@ -608,7 +609,7 @@ int32_t Batch::first_prepare(const void* const* assignments) {
 
 int32_t Batch::first_finish() {
   const size_t K = sh.K;
-  if (sh.flag) { uint32_t f; std::memcpy(&f, sh.pin_small + 3840, 4); if (f) { g_last_error = "varuna_prove: assignment not canonical (an entry is not below r)"; return ALEO_MI355X_ERR_BAD_ARG; } }
+  if (sh.flag) { uint32_t f; std::memcpy(&f, sh.pin_small + PIN_FLAG, 4); if (f) { g_last_error = "varuna_prove: assignment not canonical (an entry is not below r)"; return ALEO_MI355X_ERR_BAD_ARG; } }
   sh.fs.absorb_g1(sh.wit_aff.data(), 104, 3 * K + 1);
   // verifier_first_round [UPSTREAM-RECALL]: per circuit k_j − 1 instance combiners and (but for the first circuit) a circuit combiner in one squeeze,
   // then alpha, eta_b, eta_c in one squeeze; an instance's combiner = circuit combiner * instance combiner
@@ -646,7 +647,7 @@ int32_t Batch::second_prepare() {
 
 int32_t Batch::second_finish() {
   for (size_t j = 0; j < sh.m; ++j) {                                                         // the commitments returned after the stream drained: the copies have landed
-    uint64_t sum[4]; std::memcpy(sum, sh.pin_small + 3584 + 32 * j, 32);
+    uint64_t sum[4]; std::memcpy(sum, sh.pin_small + PIN_SUMS + 32 * j, 32);
     if (sum[0] | sum[1] | sum[2] | sum[3]) { g_last_error = "varuna_prove: the assignment does not satisfy the circuit (first sumcheck: the sum over H is not zero)"; return ALEO_MI355X_ERR_UNSATISFIED; }
   }
   sh.fs.absorb_g1(sh.aff2, 104, 2);

@@ -309,7 +309,7 @@ int32_t aleo_mi355x_proof_to_bytes(void* out, size_t* len, const aleo_mi355x_pro
 
 /* ---- one proof in one call: the host side of Varuna::prove_batch, native (aleo_amd/csrc/varuna.hip) -------------------------------
  * Replaces the CPU work snarkVM 0.14.5 does in algorithms/src/snark/varuna/{varuna.rs, ahp/prover/round_functions} [UPSTREAM-RECALL]
- * under /root/reference/rust/src/program/execute.rs:74 and transfer.rs:99 — for one circuit with 1..8 instances, a SHA-256 transcript and
+ * under /root/reference/rust/src/program/execute.rs:74 and transfer.rs:99 — for one circuit with 1..32 instances, a SHA-256 transcript and
  * the committer key the caller pinned (DESIGN.md 4d lists what differs from upstream).  The index is the prover-key material of the
  * circuit, built once (aleo_amd/varuna.py CircuitIndex does it through the entry points above) and described by device pointers:
  *   positions     host, uint32[n_vars]: index on H of every variable (public inputs on the subgroup X); positions_device: a copy in HBM (optional)
@@ -358,12 +358,11 @@ int32_t aleo_mi355x_varuna_prove_indexed(uint64_t index_handle, const void* cons
 int32_t aleo_mi355x_varuna_prove(const aleo_mi355x_varuna_index* index, const void* const* assignments, size_t n_instances, const uint8_t seed[32], void* out_proof, size_t* len);
 /* One proof over SEVERAL circuits — upstream's `Varuna::prove_batch(keys_to_constraints: BTreeMap<&ProvingKey, &[Assignment]>)`, what
  * `Trace::prove_execution` / `prove_fee` build from the transitions of a transaction (/root/reference/rust/src/program/execute.rs:74).
- * index_handles: 1..8 indexes built against ONE committer key (same max_degree / gamma_offset), in the order the proof lists them;
- * n_instances[j]: 1..8 assignments of circuit j (at most 32 in all); assignments: the pointers of circuit 0's instances, then circuit 1's, ...
- * These are caps of this library, not of the protocol (upstream has none): a request outside them is refused with ALEO_MI355X_ERR_BAD_ARG before any
- * launch, and the caller falls back (CPU prover) or lists a proving key twice — the same index handle may appear more than once, each occurrence
- * carrying up to 8 instances — as long as 8 entries and 32 instances suffice.  One proof is one object: the library never splits a request into
- * several proofs on its own.
+ * index_handles: 1..32 indexes built against ONE committer key (same max_degree / gamma_offset), in the order the proof lists them;
+ * n_instances[j]: the assignments of circuit j — at most 32 over all circuits, in any split (one proof covers one transaction: snarkVM allows 32 transitions); assignments: the pointers of circuit 0's instances, then circuit 1's, ...
+ * The cap of 32 instances is this library's (the protocol has none; snarkVM's transactions carry at most 32 transitions): a request beyond it is
+ * refused with ALEO_MI355X_ERR_BAD_ARG before any launch and the caller falls back (CPU prover).  One proof is one object: the library never splits
+ * a request into several proofs on its own.
  * The circuits share the transcript and every challenge, one mask / g_1 / h_1 over the largest constraint domain, one h_2 over the largest non-zero
  * domain and the two openings; a smaller circuit enters behind the selector v_{H*} / v_{H_j}.  out_proof: Proof::to_bytes_le layout —
  * batch sizes, 3 witness commitments per instance, mask, g_1, h_1, every g_a, every g_b, every g_c (one vector per matrix over the circuits,

@@ -198,7 +198,7 @@ class EvaluationDomain {
 // ---- the prove call of one proving key ------------------------------------------------------------------------
 // Mirrors what sits under `trace.prove_execution::<A, _>(…)` (/root/reference/rust/src/program/execute.rs:74) and `vm.execute(…)` (:177,
 // transfer.rs:99): Trace::prove_execution -> ProvingKey::prove_batch(&[(pk, assignments)]) -> Varuna::prove_batch [UPSTREAM-RECALL], for ONE
-// circuit with 1..8 instances.  CommitterKey = the universal SRS trimmed for the circuit (powers ‖ hiding powers, pinned in HBM);
+// circuit with 1..32 instances.  CommitterKey = the universal SRS trimmed for the circuit (powers ‖ hiding powers, pinned in HBM);
 // ProvingKey = the circuit's index in HBM (AHPForR1CS::index); prove_batch = one call of the C ABI.
 struct R1CSMatrix { std::vector<uint32_t> row_ptr, col; std::vector<BigInteger256> val; };      // CSR over the variables, public ones first
 struct R1CS { R1CSMatrix a, b, c; size_t num_constraints = 0, num_public = 0, num_private = 0; };

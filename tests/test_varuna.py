@@ -291,7 +291,7 @@ def test_whole_proof_entry_points_refuse_misuse():
         ix = varuna.CircuitIndex(csr, 50, 2, len(z) - 2, ck)
         zz = np.stack([synth.int_to_limbs(v, 4) for v in z])
         good = varuna.prove_native(ix, zz, 5)
-        for k in (0, 9):
+        for k in (0, 33):
             with pytest.raises((aleo_amd.AleoMi355xError, ValueError, IndexError)): varuna.prove_native(ix, [zz] * k, 5)
         view = varuna.native_index(ix)
         out = np.zeros(2048, dtype=np.uint8); n = ctypes.c_size_t(2048); ptrs = (ctypes.c_void_p * 1)(zz.ctypes.data)
@@ -364,7 +364,8 @@ def test_device_prover_batch_over_circuits(shapes, domains):
         bad[t][-1] = bad[t][-1].copy(); bad[t][-1][-1, 0] ^= np.uint64(1)              # the last variable of the last instance of the last circuit
         with pytest.raises(aleo_amd.UnsatisfiedAssignment): varuna.prove_batch_native(nx, bad, seed)
         assert varuna.prove_batch_native(nx, za, seed) == want
-        with pytest.raises(aleo_amd.AleoMi355xError): varuna.prove_batch_native(nx * 5, za * 5, seed)      # more than eight circuits
+        reps = 32 // len(za[0]) + 1
+        with pytest.raises(aleo_amd.AleoMi355xError): varuna.prove_batch_native(nx[:1] * reps, za[:1] * reps, seed)      # more than 32 instances in all
         tr = varuna.Trace()                                                             # the Trace mirror groups transitions per key, in order of first appearance
         order = [(j, i) for i in range(max(len(zz) for zz in za)) for j in range(len(za)) if i < len(za[j])]      # interleaved: circuit 0, 1, 2, 0, 1, ...
         for j, i in order: tr.insert_transition(nx[j], za[j][i])
@@ -645,7 +646,7 @@ def test_batch_entry_point_refuses_misuse():
             return L.aleo_mi355x_varuna_prove_batch_indexed(h, len(handles), p, k, aleo_amd._lib.seed32(3), out.ctypes.data_as(ctypes.c_void_p), ctypes.byref(n)), n.value, out
         ptrs = [z.ctypes.data for z in flat]
         rc, n, out = call([a.handle, b.handle], [1, 2], ptrs); assert rc == 0 and out[:n].tobytes() == good
-        assert call([a.handle, b.handle], [0, 2], ptrs)[0] == 2 and call([a.handle, b.handle], [1, 9], ptrs + ptrs + ptrs + ptrs)[0] == 2
+        assert call([a.handle, b.handle], [0, 2], ptrs)[0] == 2 and call([a.handle, b.handle], [1, 32], ptrs * 11)[0] == 2      # 33 instances
         assert call([a.handle, b.handle], [1, 2], [ptrs[0], None, ptrs[2]])[0] == 2
         rc, n, _ = call([a.handle, b.handle], [1, 2], ptrs, cap=100); assert rc == 2 and n == len(good)      # too small: the size needed comes back
         hb = b.handle; b.close()
@@ -833,3 +834,27 @@ def test_helper_contexts_under_contention():
         for x in nx: x.close()
     finally:
         pb.close(); ck.close()
+
+
+@pytest.mark.gpu
+def test_a_transaction_of_many_transitions_in_one_proof():
+    """One proof covers a whole transaction: up to 32 transitions (snarkVM's limit per transaction) in ANY split over circuits — twelve instances of one
+    circuit, and eleven circuits with one or two instances each — byte for byte the restatement's proofs and accepted by its verifier; 33 instances are
+    refused."""
+    from aleo_amd import varuna
+    lim = lambda a: np.stack([synth.int_to_limbs(v, 4) for v in a])
+    for shapes, seed in (([(40, 2, 91, 12)], 31), ([(12 + 3 * j, 1 + j % 3, 100 + j, 1 + (j % 4 == 0)) for j in range(11)], 32)):
+        cs, csrs, zs, D = _batch_case(shapes)
+        setup = V.Setup(TAU, S_GAMMA, D); idx = [V.Index(c, setup) for c in cs]
+        ck = varuna.synthetic_committer_key(TAU, S_GAMMA, D)
+        try:
+            nx = [varuna.NativeCircuitIndex(csrs[j], cs[j].n_constraints, cs[j].n_public, len(zs[j][0]) - cs[j].n_public, ck) for j in range(len(cs))]
+            got = varuna.prove_batch_native(nx, [[lim(z) for z in zz] for zz in zs], seed)
+            want = V.prove_batch(list(zip(idx, zs)), setup, V.random_stream(seed, max(c.n_h for c in cs), sum(len(z) for z in zs)))[1]
+            assert got == want, shapes
+            assert V.verify(idx, setup, [[z[:c.n_public] for z in zz] for c, zz in zip(cs, zs)], got)
+            if len(cs) == 1:
+                with pytest.raises(Exception): varuna.prove_batch_native(nx, [[lim(zs[0][0])] * 33], seed)
+            for x in nx: x.close()
+        finally:
+            ck.close()
