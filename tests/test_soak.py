@@ -1,0 +1,72 @@
+"""Randomised differential soak of the two operators on the GPU (marked gpu): random prefixes / batches / scalar distributions of MSMs against the
+O(n) structured identity sum_i s_i (i+1) G = (sum_i s_i (i+1) mod r) G on a 3 * 2^20-point pinned set — every table tier, the range table, the
+slice trees beside the reduction, multi-chain requests, host scalars split over two contexts — and random transforms (size, variant, order, extreme or
+uniform inputs) against the restatement.  ALEO_SOAK_SECONDS sets the duration (default 20 s; the round's long run: profiles/r03_soak.json)."""
+import os, time, json
+import numpy as np
+import pytest
+from oracle import coracle as c, pyref as p
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+
+def _scalars(rng, n, kind, seed):
+    if kind == 'uniform': return util.uniform_scalars(n, seed)
+    if kind == 'witness': return util.witness_like_scalars(n, seed)
+    if kind == 'equal': return np.tile(util.uniform_scalars(1, seed), (n, 1))
+    if kind == 'small': S = np.zeros((n, 4), dtype=np.uint64); S[:, 0] = rng.integers(0, 1 << 16, size=n, dtype=np.uint64); return S
+    if kind == 'top': S = np.tile(c.ints_to_limbs([p.FR_MODULUS - 1], 4), (n, 1)); S[:, 0] -= rng.integers(0, 4, size=n, dtype=np.uint64); return S
+    if kind == 'ones': S = np.zeros((n, 4), dtype=np.uint64); S[rng.random(n) < 0.7, 0] = 1; return S
+    S = np.zeros((n, 4), dtype=np.uint64); S[n // 2] = util.uniform_scalars(1, seed)[0]; return S
+
+
+def test_soak_msm_and_ntt():
+    import torch
+    import aleo_amd
+    from aleo_amd import msm as M, synth
+    seconds = float(os.environ.get('ALEO_SOAK_SECONDS', '20'))
+    rng = np.random.default_rng(int(os.environ.get('ALEO_SOAK_SEED', '20261004')))
+    N = 3 << 20
+    kinds = ['uniform', 'witness', 'equal', 'small', 'top', 'ones', 'single']
+    stats = {'msm_host': 0, 'msm_device': 0, 'msm_batch_results': 0, 'msm_sparse_hint': 0, 'ntt': 0, 'points': 0, 'ntt_elements': 0}
+    t_end = time.time() + seconds
+    with M.PinnedBases.generate_multiples(synth.generator_affine104(), 1, N) as pb:
+        pb.precompute(); pb.precompute_range(0, 1 << 20, 16)
+        it = 0; t_say = time.time() + 30
+        while time.time() < t_end:
+            it += 1
+            if time.time() > t_say: print('soak progress ' + json.dumps(stats), flush=True); t_say = time.time() + 30      # a long run must keep writing (run with -s)
+            mode = it % 4
+            if mode == 0:                                                              # host scalars (from 2^21 points on: two halves on two contexts)
+                n = int(rng.choice([1, 255, 1 << 14, (1 << 20) + 3, 1 << 21, N, int(rng.integers(1, N))]))
+                kind = kinds[int(rng.integers(len(kinds)))]; S = _scalars(rng, n, kind, 50000 + it)
+                got = c.jac_to_int_point(M.VariableBase.msm(pb, S))
+                assert got == util.expected_multiples_msm(S, n), ('host', n, kind, it)
+                stats['msm_host'] += 1; stats['points'] += n
+            elif mode == 1:                                                            # device scalars, with and without the sparse hint
+                n = int(rng.integers(1, 1 << 20)); kind = kinds[int(rng.integers(len(kinds)))]; S = _scalars(rng, n, kind, 60000 + it)
+                d = torch.from_numpy(S.view(np.int64).copy()).cuda(); torch.cuda.synchronize()
+                sparse = bool(rng.integers(2))
+                got = c.jac_to_int_point(M.VariableBase.msm_device(pb, d.data_ptr(), n, sparse=sparse))
+                assert got == util.expected_multiples_msm(S, n), ('device', n, kind, sparse, it)
+                stats['msm_device'] += 1; stats['msm_sparse_hint'] += int(sparse); stats['points'] += n
+            elif mode == 2:                                                            # one request, several results of different lengths (one or several launch chains)
+                k = int(rng.integers(2, 7)); lens = [int(rng.choice([int(rng.integers(1, 1 << 16)), int(rng.integers(1 << 16, 1 << 21))])) for _ in range(k)]
+                Ss = [_scalars(rng, n, kinds[int(rng.integers(len(kinds)))], 70000 + 10 * it + j) for j, n in enumerate(lens)]
+                ds = [torch.from_numpy(S.view(np.int64).copy()).cuda() for S in Ss]; torch.cuda.synchronize()
+                out = M.VariableBase.msm_batch_device(pb, [d.data_ptr() for d in ds], lens)
+                for j in range(k): assert c.jac_to_int_point(out[j]) == util.expected_multiples_msm(Ss[j], lens[j]), ('batch', lens, j, it)
+                stats['msm_batch_results'] += k; stats['points'] += sum(lens)
+            else:                                                                      # transforms
+                lg = int(rng.integers(1, 23)); n = 1 << lg
+                if rng.random() < 0.3:
+                    x = np.zeros((n, 4), dtype=np.uint64); x[:: int(rng.integers(1, 3))] = c.ints_to_limbs([p.FR_MODULUS - 1], 4)[0]
+                else: x = c.fr_to_mont(util.uniform_scalars(n, 80000 + it))
+                order = int(rng.choice([0, 0, 0, 1, 2, 3])); direction = int(rng.integers(2)); type_ = int(rng.integers(2)) if order == 0 else 0
+                dom = aleo_amd.EvaluationDomain(n)
+                assert (dom.ntt(x, order, direction, type_) == c.ntt_fr(x, order, direction, type_, threads=8)).all(), ('ntt', lg, order, direction, type_, it)
+                stats['ntt'] += 1; stats['ntt_elements'] += n
+    stats.update({'seconds': seconds, 'iterations': it, 'all_equal_to_the_restatement': True})
+    print('SOAK ' + json.dumps(stats))
+    assert it >= 4
