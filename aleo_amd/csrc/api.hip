@@ -45,7 +45,7 @@ static int32_t init_device(int device, Device** out) {
   if (device < 0) { if (hipGetDevice(&device) != hipSuccess) { g_last_error = "hipGetDevice failed"; return ALEO_MI355X_ERR_NO_DEVICE; } }
   if (device >= count) { g_last_error = "device index out of range"; return ALEO_MI355X_ERR_BAD_ARG; }
   auto it = g_devs.find(device);
-  if (it != g_devs.end()) { *out = it->second; return ALEO_MI355X_OK; }
+  if (it != g_devs.end()) { *out = it->second; (void)hipSetDevice(device); return ALEO_MI355X_OK; }      // "selects": the calling thread works on this device from here on
   HIPCHK(hipSetDevice(device));
   hipDeviceProp_t prop;
   HIPCHK(hipGetDeviceProperties(&prop, device));

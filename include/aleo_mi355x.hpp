@@ -13,12 +13,18 @@
 //       keys and `Trace::prove_execution / prove_fee` above it (rows a6 / a7 of SURVEY.md §8)
 // Layouts are snarkVM's: Fr = 4 x u64 Montgomery, scalar = 4 x u64 canonical, G1Affine = 104 bytes, Projective = 144 bytes.
 #pragma once
+#include <chrono>
+#include <condition_variable>
 #include <cstddef>
 #include <cstdint>
 #include <cstring>
+#include <deque>
+#include <future>
+#include <mutex>
 #include <optional>
 #include <random>
 #include <string>
+#include <thread>
 #include <utility>
 #include <vector>
 #include "aleo_mi355x.h"
@@ -334,6 +340,48 @@ inline std::vector<Result<Proof>> prove_many(const std::vector<KeyedAssignments>
   }
   return out;
 }
+
+// The front end that turns concurrent provers into lockstep calls: every proving thread of the host — the dev server proves each request on a
+// tokio::task::spawn_blocking thread, /root/reference/rust/develop/src/routes.rs:119,149,229 — submits its request and waits on a future; ONE drainer
+// thread takes whatever is queued (up to max_batch requests, waiting at most max_wait for company once the first one is there) and proves it with a
+// single prove_many call.  A proof is byte for byte what prove_batch(keyed, seed) returns; only WHO calls the library changes.  The keyed assignments
+// (proving keys and assignment vectors) must stay alive until the future is ready.
+class ProvingQueue {
+ public:
+  explicit ProvingQueue(size_t max_batch = 8, std::chrono::microseconds max_wait = std::chrono::microseconds(200), int32_t device = -1)      // device: the one the proving keys live on (-1: the drainer thread's default)
+      : max_batch_(max_batch < 1 ? 1 : (max_batch > 64 ? 64 : max_batch)), max_wait_(max_wait), device_(device), drainer_([this] { run(); }) {}
+  ~ProvingQueue() { { std::lock_guard<std::mutex> lk(mu_); stop_ = true; } cv_.notify_all(); drainer_.join(); }
+  ProvingQueue(const ProvingQueue&) = delete; ProvingQueue& operator=(const ProvingQueue&) = delete;
+  std::future<Result<Proof>> submit(KeyedAssignments keyed, const Seed& seed = Seed::from_entropy()) {
+    Item it; it.keyed = std::move(keyed); it.seed = seed; auto f = it.done.get_future();
+    { std::lock_guard<std::mutex> lk(mu_); q_.push_back(std::move(it)); }
+    cv_.notify_all(); return f;
+  }
+  size_t calls() const { std::lock_guard<std::mutex> lk(mu_); return calls_; }          // prove_many calls made so far (tests: fewer than requests)
+ private:
+  struct Item { KeyedAssignments keyed; Seed seed; std::promise<Result<Proof>> done; };
+  void run() {
+    (void)aleo_mi355x_init_device(device_);                 // selects the device for this thread; if it fails the requests below come back with the library's error
+    for (;;) {
+      std::vector<Item> batch;
+      {
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_.wait(lk, [&] { return stop_ || !q_.empty(); });
+        if (q_.empty()) return;                                                          // stop requested and nothing left
+        if (q_.size() < max_batch_ && !stop_) cv_.wait_for(lk, max_wait_, [&] { return stop_ || q_.size() >= max_batch_; });
+        while (!q_.empty() && batch.size() < max_batch_) { batch.push_back(std::move(q_.front())); q_.pop_front(); }
+        ++calls_;
+      }
+      std::vector<KeyedAssignments> reqs; std::vector<Seed> seeds;
+      for (auto& it : batch) { reqs.push_back(it.keyed); seeds.push_back(it.seed); }
+      auto out = prove_many(reqs, seeds);
+      for (size_t i = 0; i < batch.size(); ++i) batch[i].done.set_value(std::move(out[i]));
+    }
+  }
+  const size_t max_batch_; const std::chrono::microseconds max_wait_; const int32_t device_;
+  mutable std::mutex mu_; std::condition_variable cv_; std::deque<Item> q_; bool stop_ = false; size_t calls_ = 0;
+  std::thread drainer_;
+};
 
 // snarkvm_synthesizer_process::Trace as the prover sees it: the transitions of one transaction, each the proving key of its
 // function and the assignment its execution produced.  prove_execution / prove_fee group the assignments per proving key (order of first

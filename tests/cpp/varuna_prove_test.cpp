@@ -6,6 +6,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <vector>
+#include <thread>
 
 static bool rd(FILE* f, void* p, size_t n) { return n == 0 || fread(p, 1, n, f) == n; }
 #define OK(call, what) do { int32_t rc_ = (call); if (rc_) { fprintf(stderr, "%s: %s (%s)\n", what, aleo_mi355x_strerror(rc_), aleo_mi355x_last_error()); return 1; } } while (0)
@@ -98,6 +99,20 @@ int main(int argc, char** argv) {
       if (many[1].value->bytes != ex.value->bytes) { fprintf(stderr, "prove_many[1] differs from Trace::prove_execution\n"); return 1; }
       if (many[2].is_ok() || !many[2].error.unsatisfied()) { fprintf(stderr, "prove_many[2]: expected ERR_UNSATISFIED\n"); return 1; }
       if (many[3].value->bytes != direct.value->bytes) { fprintf(stderr, "prove_many[3] differs from the fee proof\n"); return 1; }
+    }
+    // the queue in front of the lockstep call: six threads prove concurrently, each gets the proof its own call would have given, in fewer library calls than requests
+    {
+      ProvingQueue queue(8, std::chrono::microseconds(20000));
+      std::vector<std::thread> th; std::vector<int> okv(6, 0);
+      for (int t = 0; t < 6; ++t) th.emplace_back([&, t] {
+        KeyedAssignments r = (t % 2) ? KeyedAssignments{{&*pk.value, {&za[0]}}} : KeyedAssignments{{&*pk.value, zs}};
+        auto got = queue.submit(r, (t % 2) ? seed_next : seed).get();
+        const auto& want = (t % 2) ? direct.value->bytes : pr.value->bytes;
+        okv[t] = got.is_ok() && got.value->bytes == want;
+      });
+      for (auto& x : th) x.join();
+      for (int t = 0; t < 6; ++t) if (!okv[t]) { fprintf(stderr, "ProvingQueue: request %d differs from its own call\n", t); return 1; }
+      if (queue.calls() >= 6) { fprintf(stderr, "ProvingQueue: %zu library calls for 6 concurrent requests\n", queue.calls()); return 1; }
     }
     FILE* o2 = fopen(argv[2], "ab"); if (!o2) return 2;
     uint64_t el = ex.value->bytes.size(); fwrite(&el, 8, 1, o2); fwrite(ex.value->bytes.data(), 1, el, o2); fclose(o2);
