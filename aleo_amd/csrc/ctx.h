@@ -188,6 +188,10 @@ int32_t fr_scatter_to_mont(Ctx* c, void* d_dst, const void* d_src, const void* d
 int32_t fr_vec_op(Ctx* c, void* d_dst, const void* d_a, const void* d_b, size_t n, int32_t op, hipStream_t s);
 int32_t fr_batch_inverse(Ctx* c, void* d_inout, size_t n, hipStream_t s);
 int32_t fr_divide_by_linear(Ctx* c, void* d_q, void* d_eval, const void* d_p, size_t n, const void* z_mont32, hipStream_t s);
+// key synthesis (varuna_index_build): CSR rows -> (row, column position) pairs + column counts; inclusive scan; column-major scatter of (row, value)
+int32_t index_expand_rows(Ctx* c, const uint32_t* d_row_ptr, const uint32_t* d_col, const uint32_t* d_positions, size_t rows, uint32_t* d_k_row, uint32_t* d_k_col, uint32_t* d_cpos, uint32_t* d_count_plus1, hipStream_t s);
+int32_t index_scan_inclusive(Ctx* c, uint32_t* d_a, size_t n, hipStream_t s);
+int32_t index_transpose_rows(Ctx* c, const uint32_t* d_row_ptr, const uint32_t* d_cpos, const void* d_val, size_t rows, uint32_t row_base, uint32_t* d_cursor, uint32_t* d_tcol, void* d_tval, hipStream_t s);
 int32_t fr_spmv(Ctx* c, void* d_y, const void* d_row_ptr, const void* d_col, const void* d_vals, const void* d_x, size_t rows, hipStream_t s);
 // varuna.hip / api.hip
 int32_t varuna_prove(Ctx* c, const PinnedBases& pb, const aleo_mi355x_varuna_index& ix, const void* const* assignments, size_t k, const uint8_t* seed32, uint8_t* out, size_t* out_len);

@@ -631,4 +631,64 @@ int32_t fr_batch_inverse(Ctx* c, void* d_inout, size_t n, hipStream_t s) {
   return scratch_release(c, s);
 }
 
+// ---- key synthesis: the integer side of the arithmetisation (varuna.hip varuna_index_build) -----------------------------------------------------
+// One lane per CSR row (rows of an R1CS matrix are short; the few long linear combinations cost their lane a loop, not the launch).
+__global__ void __launch_bounds__(256) k_index_expand_rows(const uint32_t* __restrict__ row_ptr, const uint32_t* __restrict__ col, const uint32_t* __restrict__ positions, uint32_t rows,
+                                                           uint32_t* __restrict__ k_row, uint32_t* __restrict__ k_col, uint32_t* __restrict__ cpos, uint32_t* __restrict__ count_plus1) {
+  const uint32_t r = blockIdx.x * 256 + threadIdx.x;
+  if (r >= rows) return;
+  for (uint32_t e = row_ptr[r], end = row_ptr[r + 1]; e < end; ++e) {
+    const uint32_t p = positions[col[e]];
+    k_row[e] = r; k_col[e] = p; cpos[e] = p; atomicAdd(&count_plus1[p + 1], 1u);
+  }
+}
+// a[i] += a[i - 1] over n entries, one block (n is a domain size: a few passes of 1024 lanes x 8 entries)
+__global__ void __launch_bounds__(1024) k_index_scan_inclusive(uint32_t* __restrict__ a, uint32_t n) {
+  __shared__ uint32_t wsum[16]; __shared__ uint32_t carry_s;
+  const uint32_t tid = threadIdx.x; const int lane = tid & 63, wv = tid >> 6;
+  if (tid == 0) carry_s = 0;
+  __syncthreads();
+  for (uint32_t base = 0; base < n; base += 8192) {
+    uint32_t v[8], run = 0; const uint32_t i0 = base + tid * 8;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { v[k] = i0 + k < n ? a[i0 + k] : 0u; run += v[k]; v[k] = run; }
+    uint32_t inc = run;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(inc, d); if (lane >= d) inc += o; }
+    if (lane == 63) wsum[wv] = inc;
+    __syncthreads();
+    uint32_t off = carry_s; for (int k = 0; k < wv; ++k) off += wsum[k];
+    off += inc - run;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) if (i0 + k < n) a[i0 + k] = off + v[k];
+    __syncthreads();
+    if (tid == 1023) carry_s = off + run;
+    __syncthreads();
+  }
+}
+__global__ void __launch_bounds__(256) k_index_transpose_rows(const uint32_t* __restrict__ row_ptr, const uint32_t* __restrict__ cpos, const uint4* __restrict__ val, uint32_t rows, uint32_t row_base,
+                                                              uint32_t* __restrict__ cursor, uint32_t* __restrict__ tcol, uint4* __restrict__ tval) {
+  const uint32_t r = blockIdx.x * 256 + threadIdx.x;
+  if (r >= rows) return;
+  for (uint32_t e = row_ptr[r], end = row_ptr[r + 1]; e < end; ++e) {
+    const uint32_t at = atomicAdd(&cursor[cpos[e]], 1u);
+    tcol[at] = row_base + r; tval[2 * (size_t)at] = val[2 * (size_t)e]; tval[2 * (size_t)at + 1] = val[2 * (size_t)e + 1];
+  }
+}
+int32_t index_expand_rows(Ctx* c, const uint32_t* d_row_ptr, const uint32_t* d_col, const uint32_t* d_positions, size_t rows, uint32_t* d_k_row, uint32_t* d_k_col, uint32_t* d_cpos, uint32_t* d_count_plus1, hipStream_t s) {
+  (void)c; if (!rows) return ALEO_MI355X_OK;
+  hipLaunchKernelGGL(k_index_expand_rows, dim3((uint32_t)((rows + 255) / 256)), dim3(256), 0, s, d_row_ptr, d_col, d_positions, (uint32_t)rows, d_k_row, d_k_col, d_cpos, d_count_plus1);
+  HIPCHK(hipGetLastError()); return ALEO_MI355X_OK;
+}
+int32_t index_scan_inclusive(Ctx* c, uint32_t* d_a, size_t n, hipStream_t s) {
+  (void)c; if (!n) return ALEO_MI355X_OK;
+  hipLaunchKernelGGL(k_index_scan_inclusive, dim3(1), dim3(1024), 0, s, d_a, (uint32_t)n);
+  HIPCHK(hipGetLastError()); return ALEO_MI355X_OK;
+}
+int32_t index_transpose_rows(Ctx* c, const uint32_t* d_row_ptr, const uint32_t* d_cpos, const void* d_val, size_t rows, uint32_t row_base, uint32_t* d_cursor, uint32_t* d_tcol, void* d_tval, hipStream_t s) {
+  (void)c; if (!rows) return ALEO_MI355X_OK;
+  hipLaunchKernelGGL(k_index_transpose_rows, dim3((uint32_t)((rows + 255) / 256)), dim3(256), 0, s, d_row_ptr, d_cpos, (const uint4*)d_val, (uint32_t)rows, row_base, d_cursor, d_tcol, (uint4*)d_tval);
+  HIPCHK(hipGetLastError()); return ALEO_MI355X_OK;
+}
+
 }  // namespace aleo_mi355x

@@ -145,38 +145,35 @@ int32_t varuna_index_build(Ctx* c, const PinnedBases& pb, std::shared_ptr<Pinned
   aleo_mi355x_varuna_index& V = o->view;
   V.n_h = n_h; V.n_k_a = nk[0]; V.n_k_b = nk[1]; V.n_k_c = nk[2]; V.n_x = n_x; V.n_public = n_public; V.n_vars = n_vars; V.committer_key = key_handle; V.max_degree = max_degree; V.gamma_offset = gamma_offset; V.lagrange_offset = lagrange_offset;
   if (lagrange_offset && lagrange_offset + n_h + 1 > pb.n) { g_last_error = "varuna_index: the Lagrange powers do not fit the committer key"; return ALEO_MI355X_ERR_BAD_ARG; }
-  // host staging of everything that is index arithmetic on integers
-  std::vector<uint32_t> rp(n_h + 1), tp(n_h + 1, 0), kidx(2 * k_sum, 0);
-  std::vector<uint32_t> cpos[3]; std::vector<uint32_t> tcol(nnz_sum); std::vector<uint8_t> tval(nnz_sum * 32), kval(k_sum * 32, 0);
-  for (int m = 0; m < 3; ++m) {
-    cpos[m].resize(nnz[m]);
-    for (uint64_t e = 0; e < nnz[m]; ++e) { cpos[m][e] = o->positions[abc[m].col[e]]; tp[cpos[m][e] + 1]++; }
-    for (size_t r = 0; r < n_constraints; ++r)
-      for (uint64_t e = abc[m].row_ptr[r]; e < abc[m].row_ptr[r + 1]; ++e) { kidx[2 * ko[m] + e] = (uint32_t)r; kidx[2 * ko[m] + nk[m] + e] = cpos[m][e]; }
-    if (nnz[m]) std::memcpy(&kval[ko[m] * 32], abc[m].val, nnz[m] * 32);
-  }
-  for (uint64_t i = 0; i < n_h; ++i) tp[i + 1] += tp[i];
-  {
-    std::vector<uint32_t> cur(tp.begin(), tp.end() - 1);
-    for (int m = 0; m < 3; ++m)
-      for (size_t r = 0; r < n_constraints; ++r)
-        for (uint64_t e = abc[m].row_ptr[r]; e < abc[m].row_ptr[r + 1]; ++e) {
-          const uint32_t at = cur[cpos[m][e]]++;
-          tcol[at] = (uint32_t)(m * n_h + r); std::memcpy(&tval[(size_t)at * 32], (const uint8_t*)abc[m].val + e * 32, 32);
-        }
-  }
+  const bool tim = std::getenv("ALEO_MI355X_INDEX_TIMING") != nullptr; double t_prev = now_ms();
+  auto mark = [&](const char* what) { if (tim) { (void)hipStreamSynchronize(s); const double t = now_ms(); fprintf(stderr, "index_build %-28s %8.2f ms\n", what, t - t_prev); t_prev = t; } };
+  // Index arithmetic on integers, on the device since round 3 (the host loops over the non-zeros were half of a 2^20-constraint key synthesis): per
+  // matrix the rows expand into (row, column position on H) pairs and count their columns; one scan turns the counts into the transpose's row
+  // pointers; a second pass drops every entry into its column's range (an atomic cursor per column: the order inside a column is whatever the
+  // hardware makes it, the products M^T v are exact field sums, so every proof byte is independent of it).
+  std::vector<uint32_t> rp(n_h + 1);
   auto up = [&](void** dst, const void* src, size_t bytes) -> int32_t { RC(o->alloc(dst, bytes)); if (bytes) HIPCHK(hipMemcpyAsync(*dst, src, bytes, hipMemcpyHostToDevice, s)); return ALEO_MI355X_OK; };
   auto to_mont = [&](void* p, size_t n) -> int32_t { return fr_lin(c, p, n, nullptr, r2.l, p, nullptr, nullptr, s); };
-  void* d;
-  for (int m = 0; m < 2; ++m) {                            // forward matrices with columns on H, rows padded to |H|
+  void *dpos, *kid, *kv, *dtp, *dcur, *dtcol, *dtval;
+  RC(up(&dpos, o->positions.data(), n_vars * 4)); V.positions_device = dpos;
+  RC(o->alloc(&kid, 2 * k_sum * 4)); RC(o->alloc(&kv, k_sum * 32)); RC(o->alloc(&dtp, (n_h + 1) * 4)); RC(o->alloc(&dtcol, nnz_sum * 4)); RC(o->alloc(&dtval, nnz_sum * 32));
+  HIPCHK(hipMemsetAsync(kid, 0, 2 * k_sum * 4, s)); HIPCHK(hipMemsetAsync(kv, 0, k_sum * 32, s)); HIPCHK(hipMemsetAsync(dtp, 0, (n_h + 1) * 4, s));
+  void *drp[3], *dcolraw[3], *dcol[3], *dval[3];
+  for (int m = 0; m < 3; ++m) {                            // forward matrices with columns on H, rows padded to |H| (C only feeds the transpose and the arithmetisation)
     for (uint64_t i = 0; i <= n_h; ++i) rp[i] = i <= n_constraints ? abc[m].row_ptr[i] : (uint32_t)nnz[m];
-    void *drp, *dcol, *dval;
-    RC(up(&drp, rp.data(), (n_h + 1) * 4)); RC(up(&dcol, cpos[m].data(), nnz[m] * 4)); RC(up(&dval, abc[m].val, nnz[m] * 32)); RC(to_mont(dval, nnz[m]));
+    RC(up(&drp[m], rp.data(), (n_h + 1) * 4)); RC(up(&dcolraw[m], abc[m].col, nnz[m] * 4)); RC(up(&dval[m], abc[m].val, nnz[m] * 32)); RC(o->alloc(&dcol[m], nnz[m] * 4));
     HIPCHK(hipStreamSynchronize(s));                       // rp is reused by the next matrix
-    if (m == 0) { V.a_row_ptr = drp; V.a_col = dcol; V.a_val = dval; } else { V.b_row_ptr = drp; V.b_col = dcol; V.b_val = dval; }
+    RC(index_expand_rows(c, (const uint32_t*)drp[m], (const uint32_t*)dcolraw[m], (const uint32_t*)dpos, n_constraints, (uint32_t*)kid + 2 * ko[m], (uint32_t*)kid + 2 * ko[m] + nk[m],
+                         (uint32_t*)dcol[m], (uint32_t*)dtp, s));
+    if (nnz[m]) HIPCHK(hipMemcpyAsync((char*)kv + ko[m] * 32, dval[m], nnz[m] * 32, hipMemcpyDeviceToDevice, s));      // canonical values: converted with the whole array below
   }
-  RC(up(&d, tp.data(), (n_h + 1) * 4)); V.t_row_ptr = d; RC(up(&d, tcol.data(), nnz_sum * 4)); V.t_col = d;
-  RC(up(&d, tval.data(), nnz_sum * 32)); RC(to_mont(d, nnz_sum)); V.t_val = d;
+  RC(index_scan_inclusive(c, (uint32_t*)dtp, n_h + 1, s));
+  RC(o->alloc(&dcur, (n_h + 1) * 4)); HIPCHK(hipMemcpyAsync(dcur, dtp, (n_h + 1) * 4, hipMemcpyDeviceToDevice, s));
+  for (int m = 0; m < 3; ++m) RC(index_transpose_rows(c, (const uint32_t*)drp[m], (const uint32_t*)dcol[m], dval[m], n_constraints, (uint32_t)(m * n_h), (uint32_t*)dcur, (uint32_t*)dtcol, dtval, s));
+  for (int m = 0; m < 2; ++m) RC(to_mont(dval[m], nnz[m]));
+  V.a_row_ptr = drp[0]; V.a_col = dcol[0]; V.a_val = dval[0]; V.b_row_ptr = drp[1]; V.b_col = dcol[1]; V.b_val = dval[1];
+  RC(to_mont(dtval, nnz_sum)); V.t_row_ptr = dtp; V.t_col = dtcol; V.t_val = dtval;
+  mark("index arithmetic (device)");
   // 1 / v_X on H \ X (v_X(w^p) = wx^p − 1, wx = w^|X|; zeros stay zero through the batch inversion), elements of H
   void *vx, *he;
   RC(o->alloc(&vx, n_h * 32)); RC(o->alloc(&he, n_h * 32));
@@ -184,10 +181,12 @@ int32_t varuna_index_build(Ctx* c, const PinnedBases& pb, std::shared_ptr<Pinned
   RC(fr_powers(c, vx, n_h, one.l, wx.l, s)); RC(fr_lin(c, vx, n_h, neg1.l, one.l, vx, nullptr, nullptr, s)); RC(fr_batch_inverse(c, vx, n_h, s));
   RC(fr_powers(c, he, n_h, one.l, gen_h.l, s));
   V.vx_inv = vx;
+  mark("vx, H elements");
   // arithmetisation over K: row, col, val = M[r,c] col / |H|, row_col — padding: row = col = 1 (position 0), val = 0
-  void *kev, *kid, *kpo, *k2, *kv;
+  void *kev, *kpo, *k2;
   RC(o->alloc(&kev, 4 * k_sum * 32)); RC(o->alloc(&kpo, 4 * k_sum * 32)); RC(o->alloc(&k2, 8 * k_sum * 32));
-  RC(up(&kid, kidx.data(), 2 * k_sum * 4)); RC(up(&kv, kval.data(), k_sum * 32)); RC(to_mont(kv, k_sum));
+  RC(to_mont(kv, k_sum));
+  mark("alloc + upload K arrays");
   uint32_t lg_nh = 0; while ((1ull << lg_nh) < n_h) ++lg_nh;
   const HFr nh_inv = inv_pow2(lg_nh);
   HIPCHK(hipMemsetAsync(k2, 0, 8 * k_sum * 32, s));
@@ -205,8 +204,8 @@ int32_t varuna_index_build(Ctx* c, const PinnedBases& pb, std::shared_ptr<Pinned
     for (int j = 0; j < 4; ++j) HIPCHK(hipMemcpyAsync(e2 + (size_t)j * 2 * n * 32, po + (size_t)j * n * 32, n * 32, hipMemcpyDeviceToDevice, s));
     RC(ntt_run(c, e2, lg + 1, 4, 0, 0, 0, s));
   }
+  mark("arithmetisation + transforms");
   V.k_evals = kev; V.k_idx = kid; V.k_polys = kpo; V.k2_evals = k2; V.positions = o->positions.data();
-  { void* dp; RC(up(&dp, o->positions.data(), n_vars * 4)); V.positions_device = dp; }
   // index commitments -> what the transcript absorbs first
   o->vk_aff.assign(12 * 104, 0); uint8_t* aff = o->vk_aff.data();
   {
@@ -215,6 +214,7 @@ int32_t varuna_index_build(Ctx* c, const PinnedBases& pb, std::shared_ptr<Pinned
     RC(commit(c, pb, sg, 12, aff, s));
   }
   HIPCHK(hipStreamSynchronize(s));
+  mark("12 commitments");
   o->vk.resize(12 * 48 + 40);
   RC(aleo_mi355x_g1_compress(o->vk.data(), aff, 12));
   const uint64_t dims[5] = {n_h, nk[0], nk[1], nk[2], n_x}; std::memcpy(&o->vk[12 * 48], dims, 40);
