@@ -588,6 +588,7 @@ constexpr uint32_t lg_lanes(uint32_t lanes) { return lanes == 4 ? 2u : 1u; }
 static inline bool quads_on() { static const bool v = [] { const char* e = std::getenv("ALEO_MI355X_QUAD_ADD"); return !(e && e[0] == '0'); }(); return v; }      // A/B switch: 0 = lane pairs everywhere
 static constexpr uint32_t ASIDE_MAX = 8;  // super-heavy buckets whose slice trees may run beside the reduction (msm_run)
 static inline bool aside_on() { static const bool v = [] { const char* e = std::getenv("ALEO_MI355X_ASIDE"); return !(e && e[0] == '0'); }(); return v; }      // A/B switch
+static inline bool prog_on() { static const bool v = [] { const char* e = std::getenv("ALEO_MI355X_SUM_TREE"); return !(e && e[0] == '0'); }(); return v; }      // A/B switch: 0 = masked trees on the wide tables too
 static inline uint32_t grp_lanes(uint64_t ops) { return quads_on() && ops * 4 <= (1u << 17) ? 4u : 2u; }
 // partial[ft + i] += partial[ft + i + half] inside every multi-slice bucket: one launch per level serves both lists of the scan —
 // the common one (buckets of <= 16 slices, `pairs_a` lane pairs each) and the super-heavy one (`pairs_b` each; skewed scalars).
@@ -793,6 +794,62 @@ __global__ void __launch_bounds__(256) k_seg_pair_pass(const char* __restrict__ 
   char* dst = out + ((size_t)seg * out_stride + i) * PB28;
   if (2 * i + 1 < L) pt28_add<LANES>(src, src + PB28, dst); else grp_copy<LANES, PB28>(src, dst);
 }
+// ---- the chunk weights by ONE sum tree (wide tables, round 3) -------------------------------------------------------------------------------------
+// sum_j j * run_j = sum_l 2^l T_l, T_l = the sum of run_j over the j with bit l set.  k_masked_pairs builds every T_l as its own tree over half of
+// the chunks: lg(N) / 2 additions per chunk.  But T_l is also the sum of the RIGHT children of level l of the plain sum tree over the chunks — so one
+// pairwise pass per level does it all: node'[i] = node[2i] + node[2i+1], the odd nodes node[2i+1] start the segment T_l, and every segment born
+// earlier (T_0 .. T_{l-1}, and A = the chunks' own weighted sums acc_j) is halved the same way.  After pass s every segment is N / 2^(s+1) long:
+// (s + 3) N / 2^(s+1) additions per pass, 3 N in all instead of (lg N + 4) N / 2 — which is what lets the chunks shrink (fewer dependent additions
+// in k_bucket_chunks) without the weights paying for it.  Layout of a set after pass s: [node | A | T_0 | ... | T_s], contiguous.
+template <uint32_t LANES>
+__global__ void __launch_bounds__(256) k_prog_pass(const char* __restrict__ node, uint32_t node_set_stride, const char* __restrict__ A, uint32_t a_set_stride,
+                                                   const char* __restrict__ T, uint32_t t_set_stride, uint32_t nT, uint32_t L, uint32_t nsets,
+                                                   char* __restrict__ out, uint32_t out_set_stride) {
+  const uint32_t half = L >> 1, per_set = (2 + nT) * half;
+  const uint32_t op = (blockIdx.x * 256 + threadIdx.x) >> lg_lanes(LANES);
+  if (op >= per_set * nsets) return;
+  const uint32_t q = op / per_set, r = op % per_set, g = r / half, i = r % half;
+  const char* src = g == 0 ? node + ((size_t)q * node_set_stride + 2 * i) * PB28
+                  : g == 1 ? A + ((size_t)q * a_set_stride + 2 * i) * PB28
+                           : T + ((size_t)q * t_set_stride + (size_t)(g - 2) * L + 2 * i) * PB28;
+  char* dst = out + ((size_t)q * out_set_stride + (size_t)g * half + i) * PB28;
+  pt28_add<LANES>(src, src + PB28, dst);
+  if (g == 0) grp_copy<LANES, PB28>(src + PB28, out + ((size_t)q * out_set_stride + (size_t)(2 + nT) * half + i) * PB28);      // T_s is born: the right children of this level
+}
+// The last levels, one block per result point: A and every T_l already born are plain folds of their (<= 256-point) segments; the weights of the
+// remaining lg L bits come from the node segment itself, T_(nT + b) = the sum of the nodes whose index has bit b set.  Output point o of set q:
+// 0 = A, 1 + l = T_l.
+template <uint32_t LANES>
+__global__ void __launch_bounds__(128 * LANES) k_prog_final(const char* __restrict__ in, uint32_t in_set_stride, uint32_t L, uint32_t nT, uint32_t lgL, uint32_t nsets,
+                                                            char* __restrict__ out) {
+  __shared__ __attribute__((aligned(16))) uint32_t lds[2][(FOLD / 2) * PW28];
+  const uint32_t per_set = 1 + nT + lgL, q = blockIdx.x / per_set, o = blockIdx.x % per_set, pr = threadIdx.x >> lg_lanes(LANES);
+  if (q >= nsets) return;
+  const char* set = in + (size_t)q * in_set_stride * PB28;
+  {
+    char* dst = (char*)(lds[0] + pr * PW28);
+    if (o <= nT) {                                         // plain fold of segment 1 (A) or 2 + (o - 1) (T_{o-1})
+      const char* seg = set + (size_t)(o == 0 ? 1 : 1 + o) * L * PB28; const uint32_t e0 = 2 * pr;
+      if (e0 + 1 < L) pt28_add<LANES>(seg + (size_t)e0 * PB28, seg + (size_t)(e0 + 1) * PB28, dst);
+      else if (e0 < L) grp_copy<LANES, PB28>(seg + (size_t)e0 * PB28, dst);
+      else grp_zero<LANES, PB28>(dst);
+    } else {                                               // bit b of the node index: the L / 2 nodes that have it set, in pairs
+      const uint32_t b = o - 1 - nT;
+      auto ins = [&](uint32_t x) { return ((x >> b) << (b + 1)) | (1u << b) | (x & ((1u << b) - 1u)); };
+      if (L >= 4 && 4 * pr + 3 < L) pt28_add<LANES>(set + (size_t)ins(2 * pr) * PB28, set + (size_t)ins(2 * pr + 1) * PB28, dst);
+      else if (L == 2 && pr == 0) grp_copy<LANES, PB28>(set + PB28, dst);
+      else grp_zero<LANES, PB28>(dst);
+    }
+  }
+  uint32_t cur = 0;
+  for (uint32_t n = FOLD / 2; n > 1; n >>= 1) {
+    __syncthreads();
+    if (pr < (n >> 1)) pt28_add<LANES>((const char*)(lds[cur] + (2 * pr) * PW28), (const char*)(lds[cur] + (2 * pr + 1) * PW28), (char*)(lds[cur ^ 1] + pr * PW28));
+    cur ^= 1;
+  }
+  __syncthreads();
+  if (pr == 0) grp_copy<LANES, PB28>((const char*)lds[cur], out + ((size_t)q * per_set + o) * PB28);
+}
 __global__ void k_gather_strided(const char* __restrict__ V, uint32_t stride, uint32_t count, char* __restrict__ out) {
   uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= count * 14) return;
@@ -996,7 +1053,7 @@ int32_t msm_run(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, const MsmJob
   int32_t rc;
   // table path, per set: [acc of its cpw chunks | lgN masked sums of cpw/4] = (lgN + 4) segments of tseg points
   const uint32_t tseg = cpw / 4, fseg = lgN + 4, nseg = K * fseg, setw = fseg * tseg;
-  const size_t vpoints = masked ? (size_t)K * setw + nchunks + (nseg + 1) + (size_t)nseg * (tseg / 2 + tseg / 4 + 2) : (size_t)nchunks + P.W;
+  const size_t vpoints = masked ? (size_t)K * setw + nchunks + (nseg + 1) + (size_t)nseg * (tseg / 2 + tseg / 4 + 2) + 3 * (size_t)nchunks + 64 : (size_t)nchunks + P.W;      // + the two buffers of the sum-tree passes (3 cpw / 2 points per set each)
   if ((rc = ensure_host_pinned(c, 64 + (size_t)(masked ? nseg : P.W) * 224 + ASIDE_MAX * 228))) return rc;      // before the sort phase: its read-back lands in this buffer
   SortPhase sp;
   if ((rc = msm_sort_phase(c, segs, pts, job.mont, d_inf, (uint32_t)(pre ? T->cover : pb.n), P, pre, s, &sp))) return rc;
@@ -1093,6 +1150,36 @@ int32_t msm_run(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, const MsmJob
       if (grp_lanes(2 * (uint64_t)nchunks) == 4) hipLaunchKernelGGL((k_bucket_chunks<true, 4>), dim3((nchunks + 31) / 32), dim3(256), 0, s, partial, hist, scan_local, scan_blk, P.B, P.S, nchunks, V, setw, Vrun);
       else hipLaunchKernelGGL(k_bucket_chunks<true>, dim3((nchunks + CHUNK_QUADS - 1) / CHUNK_QUADS), dim3(256), 0, s, partial, hist, scan_local, scan_blk, P.B, P.S, nchunks, V, setw, Vrun);
     }
+    // Measured (ALEO_MI355X_SUM_TREE=0 is the A/B switch; ALEO_MI355X_SUM_TREE_MIN_C limits it to the wider tables): reduce phase of the 2^20 MSM 0.464 -> 0.412 ms at
+    // S = 16 (S = 8: 0.537 -> 0.451, S = 4: 0.720 -> 0.508: the chunk kernel is bound by its 2 additions per bucket, not by their order, so smaller chunks still lose);
+    // on the small tables too: 2^15-constraint proof 6.47 -> 6.35 ms, eight instances at 2^13 7.19 -> 6.88 ms.
+    static const uint32_t prog_min_c = [] { const char* e = std::getenv("ALEO_MI355X_SUM_TREE_MIN_C"); const int k = e ? std::atoi(e) : 13; return (uint32_t)(k >= 13 && k <= 24 ? k : 13); }();
+    const bool prog = P.c >= prog_min_c && prog_on();
+    uint32_t out_pts = fseg;                               // result points per set the host tail reads
+    if (prog) {
+      char* G0 = Tout; char* G1 = G0 + (size_t)K * (3 * (cpw / 2)) * PB28;      // ping-pong: a set is at most 3 segments of cpw / 2 points after the first pass
+      const char* node = Vrun; uint32_t node_ss = cpw; const char* A = V; uint32_t a_ss = setw; const char* T = Vrun; uint32_t t_ss = 0, nT = 0, L = cpw;
+      char* dstbuf = G0;
+      while (L > FOLD) {
+        const uint32_t half = L >> 1, out_ss = (3 + nT) * half; const uint64_t ops = (uint64_t)(2 + nT) * half * K;
+        if (grp_lanes(ops) == 4) hipLaunchKernelGGL(k_prog_pass<4>, dim3((uint32_t)((4 * ops + 255) / 256)), dim3(256), 0, s, node, node_ss, A, a_ss, T, t_ss, nT, L, K, dstbuf, out_ss);
+        else hipLaunchKernelGGL(k_prog_pass<2>, dim3((uint32_t)((2 * ops + 255) / 256)), dim3(256), 0, s, node, node_ss, A, a_ss, T, t_ss, nT, L, K, dstbuf, out_ss);
+        node = dstbuf; node_ss = out_ss; A = dstbuf + (size_t)half * PB28; a_ss = out_ss; T = dstbuf + (size_t)2 * half * PB28; t_ss = out_ss; ++nT; L = half;
+        dstbuf = dstbuf == G0 ? G1 : G0;
+      }
+      uint32_t lgL = 0; while ((1u << lgL) < L) ++lgL;
+      const char* fin = node; uint32_t fin_ss = node_ss;
+      if (nT == 0) {                                       // no pass ran (cpw <= FOLD): bring node and A side by side for the final kernel
+        HIPCHK(hipMemcpy2DAsync(G0, (size_t)2 * L * PB28, Vrun, (size_t)cpw * PB28, (size_t)L * PB28, K, hipMemcpyDeviceToDevice, s));
+        HIPCHK(hipMemcpy2DAsync(G0 + (size_t)L * PB28, (size_t)2 * L * PB28, V, (size_t)setw * PB28, (size_t)L * PB28, K, hipMemcpyDeviceToDevice, s));
+        fin = G0; fin_ss = 2 * L;
+      }
+      out_pts = 1 + nT + lgL;                              // = 1 + lgN
+      char* dst = nullptr;
+      HIPCHK(hipHostGetDevicePointer((void**)&dst, h_win, 0));
+      if (quads_on()) hipLaunchKernelGGL(k_prog_final<4>, dim3(K * out_pts), dim3(512), 0, s, fin, fin_ss, L, nT, lgL, K, dst);
+      else hipLaunchKernelGGL(k_prog_final<2>, dim3(K * out_pts), dim3(256), 0, s, fin, fin_ss, L, nT, lgL, K, dst);
+    } else {
     {
       const uint64_t ops = (uint64_t)tseg * lgN * K;
       if (grp_lanes(ops) == 4) hipLaunchKernelGGL(k_masked_pairs<4>, dim3((uint32_t)((4 * ops + 255) / 256)), dim3(256), 0, s, Vrun, lgN, K, V, setw);
@@ -1120,6 +1207,7 @@ int32_t msm_run(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, const MsmJob
       hipLaunchKernelGGL(k_gather_strided, dim3((nseg * 14 + 255) / 256), dim3(256), 0, s, cur, stride, nseg, Tout);
       HIPCHK(hipMemcpyAsync(h_win, Tout, (size_t)nseg * PB28, hipMemcpyDeviceToHost, s));
     }
+    }
     HIPCHK(hipEventRecord(c->ev[3], s));
     if (job.fire_tail && c->tail_hook) {
       // the caller's next kernels go behind the fold; the host waits for the fold only (its result sits in pinned memory) and does the tail below while they run
@@ -1133,11 +1221,12 @@ int32_t msm_run(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, const MsmJob
     t_host0 = std::chrono::steady_clock::now();
     HXYZZ totals[MAX_SETS];
     for (uint32_t q = 0; q < K; ++q) {
-      const char* hw = h_win + (size_t)q * fseg * PB28;
+      const char* hw = h_win + (size_t)q * out_pts * PB28;
+      const uint32_t na = prog ? 1u : 4u;                  // points that hold sum_j acc_j: one (k_prog_final) or the four segment sums of the masked form
       HXYZZ total = HXYZZ::infinity();
-      for (int l = (int)lgN - 1; l >= 0; --l) { total = hdouble(total); total = hadd(total, lazy_point28(hw + (size_t)(4 + l) * PB28)); }
+      for (int l = (int)lgN - 1; l >= 0; --l) { total = hdouble(total); total = hadd(total, lazy_point28(hw + (size_t)(na + l) * PB28)); }
       for (uint32_t sft = P.S; sft > 1; sft >>= 1) total = hdouble(total);
-      for (int r = 0; r < 4; ++r) total = hadd(total, lazy_point28(hw + (size_t)r * PB28));
+      for (uint32_t r = 0; r < na; ++r) total = hadd(total, lazy_point28(hw + (size_t)r * PB28));
       totals[q] = total;
     }
     for (uint32_t h = 0; aside && h < sm.n_super; ++h) {             // (b + 1) * (slices 1.. of super-heavy bucket b), by double-and-add
