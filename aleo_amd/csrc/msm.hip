@@ -1154,7 +1154,7 @@ int32_t msm_run(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, const MsmJob
     // S = 16 (S = 8: 0.537 -> 0.451, S = 4: 0.720 -> 0.508: the chunk kernel is bound by its 2 additions per bucket, not by their order, so smaller chunks still lose);
     // on the small tables too: 2^15-constraint proof 6.47 -> 6.35 ms, eight instances at 2^13 7.19 -> 6.88 ms.
     static const uint32_t prog_min_c = [] { const char* e = std::getenv("ALEO_MI355X_SUM_TREE_MIN_C"); const int k = e ? std::atoi(e) : 13; return (uint32_t)(k >= 13 && k <= 24 ? k : 13); }();
-    const bool prog = P.c >= prog_min_c && prog_on();
+    const bool prog = P.c >= prog_min_c && prog_on() && cpw > FOLD;      // (a set of <= 256 chunks would go straight to the final fold: the masked form keeps those)
     uint32_t out_pts = fseg;                               // result points per set the host tail reads
     if (prog) {
       char* G0 = Tout; char* G1 = G0 + (size_t)K * (3 * (cpw / 2)) * PB28;      // ping-pong: a set is at most 3 segments of cpw / 2 points after the first pass
@@ -1168,12 +1168,7 @@ int32_t msm_run(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, const MsmJob
         dstbuf = dstbuf == G0 ? G1 : G0;
       }
       uint32_t lgL = 0; while ((1u << lgL) < L) ++lgL;
-      const char* fin = node; uint32_t fin_ss = node_ss;
-      if (nT == 0) {                                       // no pass ran (cpw <= FOLD): bring node and A side by side for the final kernel
-        HIPCHK(hipMemcpy2DAsync(G0, (size_t)2 * L * PB28, Vrun, (size_t)cpw * PB28, (size_t)L * PB28, K, hipMemcpyDeviceToDevice, s));
-        HIPCHK(hipMemcpy2DAsync(G0 + (size_t)L * PB28, (size_t)2 * L * PB28, V, (size_t)setw * PB28, (size_t)L * PB28, K, hipMemcpyDeviceToDevice, s));
-        fin = G0; fin_ss = 2 * L;
-      }
+      const char* fin = node; const uint32_t fin_ss = node_ss;
       out_pts = 1 + nT + lgL;                              // = 1 + lgN
       char* dst = nullptr;
       HIPCHK(hipHostGetDevicePointer((void**)&dst, h_win, 0));
