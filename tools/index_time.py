@@ -1,5 +1,6 @@
+"""Key synthesis (aleo_mi355x_varuna_index_build) timed three times at 2^lg constraints (not a test): python tools/index_time.py <lg>; ALEO_MI355X_INDEX_TIMING=1 prints the phases."""
 import os, sys, time
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import bench
 from aleo_amd import synth, varuna
