@@ -3,7 +3,7 @@ transform through a *_device entry point — once with stream == NULL (the slot'
 child, on a created stream — i.e. the first-use path of a slot's stream, events and stream-ordered scratch (scratch_acquire / scratch_release,
 api.hip), which round 2 crashed in once while it was being introduced ("The host segfault of round 2").  Prints FIRST CALL OK."""
 import os, sys, ctypes
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, ROOT)
 import numpy as np, torch
 from oracle import coracle as co
 from aleo_amd import synth

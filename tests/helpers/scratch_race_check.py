@@ -2,7 +2,7 @@
 slot's scratch buffer to the other thread's next call while its own kernels may still be running.  Results are compared with the
 oracle.  Prints 'SCRATCH OK' (tests/test_gpu_parity.py runs this as a child process)."""
 import os, sys, threading
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import numpy as np, torch
 import aleo_amd
 from aleo_amd import synth, poly, msm as M

@@ -749,10 +749,10 @@ def test_async_device_calls_order_their_scratch_across_streams(tmp_path):
     """The *_device transforms enqueue on the caller's stream and return at once; with ONE slot (ALEO_MI355X_SLOTS=1) two
     threads on two streams keep handing the same scratch buffer to each other while the previous user's kernels are still
     in flight.  Batched 2^20-element NTTs, batch inversions and an NTT -> commit chain with stream == NULL, all against the
-    oracle (tools/scratch_race_check.py, run in a child process because the slot count is read once at init)."""
+    oracle (tests/helpers/scratch_race_check.py, run in a child process because the slot count is read once at init)."""
     import subprocess, sys
     env = dict(os.environ, ALEO_MI355X_SLOTS='1')
-    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(G), '..', 'tools', 'scratch_race_check.py')], capture_output=True, text=True, timeout=900, env=env)
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'helpers', 'scratch_race_check.py')], capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0 and 'SCRATCH OK' in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
@@ -803,10 +803,10 @@ def test_config4_full_size_as_eight_shards_in_one_process():
 def test_first_call_of_a_process_is_a_batched_transform(mode):
     """Regression for the host segfault of round 2 (gpurun_out/r02_t1.log: inside aleo_mi355x_ntt_fr_batch_device while the stream-ordered slot
     scratch was being introduced): a fresh process with ONE slot whose first library call is a batched transform on stream NULL / on a created
-    stream (tools/first_call_check.py) — the first-use path of the slot's stream, events and scratch."""
+    stream (tests/helpers/first_call_check.py) — the first-use path of the slot's stream, events and scratch."""
     import subprocess, sys
     env = dict(os.environ, ALEO_MI355X_SLOTS='1')
-    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(G), '..', 'tools', 'first_call_check.py'), mode], capture_output=True, text=True, timeout=600, env=env)
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'helpers', 'first_call_check.py'), mode], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0 and 'FIRST CALL OK' in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 

@@ -615,10 +615,11 @@ def test_batch_proofs_from_concurrent_callers():
 def test_frozen_proofs_with_the_alternative_kernel_paths():
     """ALEO_MI355X_QUAD_ADD=0 (lane-pair additions in the reduction chains) and ALEO_MI355X_NTT_WIDE_LG=0 (register-group tiles for small transforms)
     are read once per process: a child process proves every frozen case of tests/golden/varuna_small.json with both switched off
-    (tools/ab_switch_check.py), so the paths the defaults no longer take stay byte-exact."""
+    (tests/helpers/ab_switch_check.py), so the paths the defaults no longer take stay byte-exact."""
     import subprocess, sys
-    env = dict(os.environ, ALEO_MI355X_QUAD_ADD='0', ALEO_MI355X_NTT_WIDE_LG='0')
-    tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools', 'ab_switch_check.py')
+    env = dict(os.environ, ALEO_MI355X_QUAD_ADD='0', ALEO_MI355X_NTT_WIDE_LG='0', ALEO_MI355X_SUM_TREE='0', ALEO_MI355X_ASIDE='0', ALEO_MI355X_NTT29='0',
+               ALEO_MI355X_CHAIN_OVERLAP='0', ALEO_MI355X_CHUNK_FORM='1', ALEO_MI355X_LOCKSTEP_WORKERS='1')      # + the round-3 switches
+    tool = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'helpers', 'ab_switch_check.py')
     r = subprocess.run([sys.executable, tool], capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0 and 'SWITCHES OK' in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
 
