@@ -2,6 +2,7 @@
 snarkvm_fields::batch_inversion [UPSTREAM-RECALL]) on device-resident Montgomery Fr vectors (torch tensors or raw pointers)."""
 from __future__ import annotations
 import ctypes
+_FR_MODULUS = 0x12ab655e9a2ca55660b44d1e5c37b00159aa76fed00000010a11800000000001
 from ._lib import lib, check
 
 OP_MUL, OP_ADD, OP_SUB = 0, 1, 2
@@ -36,12 +37,15 @@ def fr_gather_mul_device(d_dst: int, n: int, d_scale: int, d_table1: int, d_idx1
 
 
 def fr_eval_batch_device(d_out: int, d_polys, lens, points_mont, stream: int = 0):
-    """out[q] = p_q(z_q) for up to 8 polynomials; points_mont: uint64[k,4] Montgomery on the host."""
+    """out[q] = p_q(z_q) for any number of polynomials (12 per call of the entry point); points_mont: uint64[k,4] Montgomery on the host."""
     import numpy as np
     k = len(d_polys)
     z = np.ascontiguousarray(points_mont, dtype=np.uint64).reshape(k, 4)
-    ptrs = (ctypes.c_void_p * max(k, 1))(*[int(x) for x in d_polys]); ln = (ctypes.c_size_t * max(k, 1))(*[int(x) for x in lens])
-    check(lib().aleo_mi355x_fr_eval_batch_device(ctypes.c_void_p(d_out), ptrs, ln, z.ctypes.data_as(ctypes.c_void_p), k, ctypes.c_void_p(stream)), 'fr_eval_batch_device')
+    for at in range(0, max(k, 1), 12):                      # the entry point takes 12 polynomials per call
+        m = min(12, k - at)
+        ptrs = (ctypes.c_void_p * max(m, 1))(*[int(x) for x in d_polys[at:at + m]]); ln = (ctypes.c_size_t * max(m, 1))(*[int(x) for x in lens[at:at + m]])
+        zz = np.ascontiguousarray(z[at:at + m]) if m else np.zeros((1, 4), dtype=np.uint64)
+        check(lib().aleo_mi355x_fr_eval_batch_device(ctypes.c_void_p(d_out + 32 * at), ptrs, ln, zz.ctypes.data_as(ctypes.c_void_p), m, ctypes.c_void_p(stream)), 'fr_eval_batch_device')
 
 
 def fr_random_device(d_dst: int, n: int, seed, first_index: int = 0, montgomery: bool = True, stream: int = 0):
@@ -63,6 +67,12 @@ def random_fr(seed, index: int, n: int = 1):
 def fr_lincomb_device(d_dst: int, n: int, c0, terms, stream: int = 0):
     """dst[i] = c0 [i == 0] + sum_j coeff_j term_j[i]; terms: list of (device pointer, length, coeff uint64[4] Montgomery)."""
     import numpy as np
+    terms = list(terms)
+    if len(terms) > 28:                                     # the entry point takes 28 terms per call: later calls carry dst along as a term (as the native host side does)
+        one = np.array([((1 << 256) % _FR_MODULUS >> (64 * i)) & (2 ** 64 - 1) for i in range(4)], dtype=np.uint64)
+        fr_lincomb_device(d_dst, n, c0, terms[:28], stream)
+        for at in range(28, len(terms), 27): fr_lincomb_device(d_dst, n, None, [(d_dst, n, one)] + terms[at:at + 27], stream)
+        return
     k = len(terms)
     ptrs = (ctypes.c_void_p * max(k, 1))(*[int(t[0]) for t in terms]); ln = (ctypes.c_size_t * max(k, 1))(*[int(t[1]) for t in terms])
     co = np.ascontiguousarray(np.stack([np.asarray(t[2], dtype=np.uint64).reshape(4) for t in terms]) if k else np.zeros((1, 4), dtype=np.uint64))
@@ -92,7 +102,9 @@ def fr_blind_rows_device(d_dst: int, d_src: int, n: int, rho_mont, stream: int =
     """dst row q (n + 1 coefficients) = src row q (n coefficients) + rho_q (X^n − 1); rho_mont: uint64[rows,4] Montgomery on the host."""
     import numpy as np
     r = np.ascontiguousarray(rho_mont, dtype=np.uint64).reshape(-1, 4); vp = ctypes.c_void_p
-    check(lib().aleo_mi355x_fr_blind_rows_device(vp(d_dst), vp(d_src), n, r.shape[0], r.ctypes.data_as(vp), vp(stream)), 'fr_blind_rows_device')
+    for at in range(0, r.shape[0], 24):                     # 24 rows per call of the entry point
+        m = min(24, r.shape[0] - at); rr = np.ascontiguousarray(r[at:at + m])
+        check(lib().aleo_mi355x_fr_blind_rows_device(vp(d_dst + at * (n + 1) * 32), vp(d_src + at * n * 32), n, m, rr.ctypes.data_as(vp), vp(stream)), 'fr_blind_rows_device')
 
 
 def ahp_sumcheck_operands_device(d_dst: int, d_witness_polys: int, d_x_polys: int, n: int, n_x: int, instances: int, stream: int = 0):

@@ -238,7 +238,7 @@ class CircuitIndex:
         self.vk_bytes = wire.g1_compress(self.index_commitments).tobytes() + b''.join(int(v).to_bytes(8, 'little') for v in (n_h, *self.n_k_m, n_x))
 
 
-MAX_INSTANCES = 8        # k + 4 evaluations go through one fr_eval_batch call (12 polynomials), 3k + 3 terms through one fr_lincomb call (28)
+MAX_INSTANCES = 32       # as the native host side: one proof covers one transaction (the wrappers in poly.py cut the evaluation / linear-combination / blinding calls into the entry points' 12 / 28 / 24 per call)
 
 
 def _kp(ix, vec, m, j, mult=1):

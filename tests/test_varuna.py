@@ -135,7 +135,7 @@ def test_restatement_batch_over_circuits():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('k', [2, 3, 4, 5, 8])
+@pytest.mark.parametrize('k', [2, 3, 4, 5, 8, 13])
 def test_device_prover_batch_matches_restatement(k):
     from aleo_amd import varuna
     domains = 'per_matrix' if k % 2 else 'auto'
@@ -152,7 +152,7 @@ def test_device_prover_batch_matches_restatement(k):
         zq = [np.stack([synth.int_to_limbs(v, 4) for v in q]) for q in zs]
         assert varuna.prove_native(ix, zq, 500 + k) == want                            # the one-call C++ host side
         with varuna.NativeCircuitIndex(csr, 150, 3, len(z) - 3, ck, domains=domains) as nx: assert nx.prove(zq, 500 + k) == want
-        with pytest.raises(ValueError): varuna.prove(ix, [np.zeros((len(z), 4), dtype=np.uint64)] * 9, 1)
+        with pytest.raises(ValueError): varuna.prove(ix, [np.zeros((len(z), 4), dtype=np.uint64)] * 33, 1)
     finally:
         ck.close()
 
