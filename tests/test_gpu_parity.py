@@ -1132,8 +1132,12 @@ def test_fr_eval_batch_matches_oracle():
     for i, n in enumerate(lens):
         want = c.fr_divide_by_linear(F[i][:n], Z[i])[1] if n else np.zeros(4, dtype=np.uint64)
         assert (got[i] == want).all(), (i, n)
-    with pytest.raises(aleo_amd.AleoMi355xError):
-        poly.fr_eval_batch_device(out.data_ptr(), [D[1].data_ptr()] * 13, [1] * 13, np.zeros((13, 4), dtype=np.uint64))
+    import ctypes                                                              # the entry point refuses a thirteenth polynomial; the wrapper cuts longer lists into calls of twelve
+    ptrs13 = (ctypes.c_void_p * 13)(*[D[1].data_ptr()] * 13); lens13 = (ctypes.c_size_t * 13)(*[1] * 13); z13 = np.zeros((13, 4), dtype=np.uint64)
+    assert aleo_amd.lib().aleo_mi355x_fr_eval_batch_device(ctypes.c_void_p(out.data_ptr()), ptrs13, lens13, z13.ctypes.data_as(ctypes.c_void_p), 13, ctypes.c_void_p(0)) == 2
+    many = [D[i % 8].data_ptr() for i in range(15)]; ml = [lens[i % 8] for i in range(15)]; mz = np.stack([Z[i % 8] for i in range(15)])
+    out.zero_(); poly.fr_eval_batch_device(out.data_ptr(), many, ml, mz); torch.cuda.synchronize()
+    assert (out.cpu().numpy().view(np.uint64)[:15] == np.stack([got[i % 8] for i in range(15)])).all()
     ev = torch.zeros(4, dtype=torch.int64, device='cuda')                      # the division entry point with no quotient: evaluation only
     poly.divide_by_linear_device(0, ev.data_ptr(), D[6].data_ptr(), lens[6], Z[6]); torch.cuda.synchronize()
     assert (ev.cpu().numpy().view(np.uint64) == got[6]).all()
@@ -1196,8 +1200,10 @@ def test_fr_lincomb_ragged_terms():
     for t, l, k in zip(T, lens, K):
         for i, v in enumerate(c.limbs_to_ints(t[:min(l, n)])): want[i] = (want[i] + k * v) % r
     assert c.limbs_to_ints(c.fr_from_mont(dst.cpu().numpy().view(np.uint64))) == want
-    with pytest.raises(aleo_amd.AleoMi355xError):
-        poly.fr_lincomb_device(dst.data_ptr(), n, None, [(D[0].data_ptr(), 1, _mont1(1))] * 29)
+    # 29 terms: more than one call of the entry point takes (28) — the wrapper carries dst along as a term of the next call
+    poly.fr_lincomb_device(dst.data_ptr(), n, None, [(D[0].data_ptr(), 1, _mont1(1))] * 29); torch.cuda.synchronize()
+    first = c.limbs_to_ints(T[0][:1])[0]
+    assert c.limbs_to_ints(c.fr_from_mont(dst.cpu().numpy().view(np.uint64)[:2])) == [29 * first % r, 0]
 
 
 def test_ahp_sumcheck_numerators_match_bigint():
