@@ -70,3 +70,48 @@ def test_soak_msm_and_ntt():
     stats.update({'seconds': seconds, 'iterations': it, 'all_equal_to_the_restatement': True})
     print('SOAK ' + json.dumps(stats))
     assert it >= 4
+
+
+def test_soak_prover():
+    """Random proofs through the native prover — 1 to 4 circuits of random sizes (1 … 400 constraints), public-input counts and domain policies,
+    1 to 4 instances each, single calls and lockstep calls — each byte for byte the restatement's proof and accepted by its verifier.
+    ALEO_SOAK_SECONDS sets the duration (default 20 s; every case costs a second or two of the plain-Python restatement)."""
+    from aleo_amd import varuna, synth
+    from oracle import varuna_ref as V
+    from tests import test_varuna as TV
+    seconds = float(os.environ.get('ALEO_SOAK_SECONDS', '20'))
+    rng = np.random.default_rng(int(os.environ.get('ALEO_SOAK_SEED', '20261004')) + 1)
+    lim = lambda a: np.stack([synth.int_to_limbs(v, 4) for v in a])
+    stats = {'proofs': 0, 'lockstep_calls': 0, 'circuits': 0, 'instances': 0, 'constraints': 0}
+    t_end = time.time() + seconds; t_say = time.time() + 30; it = 0
+    while time.time() < t_end:
+        it += 1
+        if time.time() > t_say: print('soak progress ' + json.dumps(stats), flush=True); t_say = time.time() + 30
+        m = int(rng.integers(1, 5)); domains = ['auto', 'per_matrix', 'shared'][int(rng.integers(3))]
+        shapes = []
+        for j in range(m):
+            n = int(rng.choice([1, 2, 3, 9, int(rng.integers(4, 60)), int(rng.integers(60, 400))])); npub = int(rng.integers(1, min(n, 6) + 1))
+            shapes.append((n, npub, 1000 * it + j, int(rng.integers(1, 5))))
+        cs, csrs, zs, D = TV._batch_case(shapes, seed=it, domains=domains)
+        setup = V.Setup(TV.TAU, TV.S_GAMMA, D); idx = [V.Index(c, setup) for c in cs]
+        seed = 7000 + it
+        want = V.prove_batch(list(zip(idx, zs)), setup, V.random_stream(seed, max(c.n_h for c in cs), sum(len(z) for z in zs)))[1]
+        ck = varuna.synthetic_committer_key(TV.TAU, TV.S_GAMMA, D); nx = []
+        try:
+            for (n, npub, _, _), csr, z in zip(shapes, csrs, zs): nx.append(varuna.NativeCircuitIndex(csr, n, npub, len(z[0]) - npub, ck, domains=domains))
+            za = [[lim(z) for z in zz] for zz in zs]
+            got = varuna.prove_batch_native(nx, za, seed)
+            assert got == want, ('single', shapes, domains, it)
+            assert V.verify(idx, setup, [[z[:c.n_public] for z in zz] for c, zz in zip(cs, zs)], got), ('verify', shapes, it)
+            if it % 3 == 0:                                                            # the same request twice and its first circuit alone, in lockstep
+                alone = varuna.prove_batch_native(nx[:1], za[:1], seed + 1)
+                out = varuna.prove_many_native([(nx, za, seed), (nx[:1], za[:1], seed + 1), (nx, za, seed)])
+                assert out == [want, alone, want], ('lockstep', shapes, it)
+                stats['lockstep_calls'] += 1
+            stats['proofs'] += 1; stats['circuits'] += m; stats['instances'] += sum(s[3] for s in shapes); stats['constraints'] += sum(s[0] * s[3] for s in shapes)
+        finally:
+            for x in nx: x.close()
+            ck.close()
+    stats.update({'seconds': seconds, 'all_equal_to_the_restatement': True})
+    print('SOAK ' + json.dumps(stats))
+    assert stats['proofs'] >= 1
