@@ -115,7 +115,9 @@ int32_t aleo_mi355x_bases_precompute_range(uint64_t handle, size_t offset, size_
 int32_t aleo_mi355x_bases_info(uint64_t handle, uint64_t* out, int32_t cap);
 /* Copies pinned bases [offset, offset+n) back to the host as snarkVM Affine (stride 104). */
 int32_t aleo_mi355x_bases_download(uint64_t handle, size_t offset, size_t n, void* out_affine104);
-/* MSM over the first n pinned bases; scalars: host pointer. */
+/* MSM over the first n pinned bases; scalars: host pointer (pageable memory is fine: the upload runs at the link's rate either way).  From 2^21 points
+ * on the request runs as two halves on two of the device's contexts, so that half of the upload goes under the first half's kernels; the result does not
+ * depend on it. */
 int32_t aleo_mi355x_msm_g1_pinned(void* out_jacobian, uint64_t handle, const void* scalars, size_t n);
 /* Same, scalars already resident in device memory (hipMalloc'ed or a torch CUDA tensor's data_ptr).
  * The result (144 bytes) is written to HOST memory.  `stream` (here and in every *_device entry point) is a hipStream_t;
