@@ -60,6 +60,48 @@ template <int N, int RATE> struct PoseidonParams {
     for (int i = 0; i < W; ++i) mod_p(xs[i]);
     for (int i = 0; i < W; ++i) mod_p(ys[i]);
     for (int i = 0; i < W; ++i) for (int j = 0; j < W; ++j) mds[i][j] = HFp<N>::inv(HFp<N>::add(xs[i], ys[j]));
+    optimise_partial_rounds();
+  }
+  // The partial rounds in their sparse form (the well-known optimisation of the Poseidon paper, derived here for this round order — constants, s-box,
+  // matrix): a partial round is x <- M S(x + c) with S acting on coordinate 0 only.  Write a matrix B = [[b00, v], [w, B^]] as N'' N' with
+  // N' = diag(1, B^) and N'' = [[b00, v B^-1], [w, I]]; N' commutes with S, so with z_j = N'_j x_j the rounds become z_{j+1} = N''_j S(z_j + N'_j c_j)
+  // where B_j = N'_{j+1} M is factored from the last partial round backwards (B_last = M) and the leftover N'_0 goes into the matrix of the full round
+  // before them (pre = N'_0 M).  Constants on coordinates >= 1 pass through S unchanged and are pushed into the next round's constant (at the end: into
+  // the first full round after), so a partial round adds ONE constant, raises ONE element to the 17th and multiplies by a matrix with 2 W - 1 entries
+  // (W = 3: 5 products instead of 9; W = 9: 17 instead of 81).  Same outputs, bit for bit (tests/test_poseidon.py against the plain restatement).
+  HFp<N> pre[W][W], sp_m00[POSEIDON_PARTIAL], sp_v[POSEIDON_PARTIAL][W - 1], sp_w[POSEIDON_PARTIAL][W - 1], sp_c[POSEIDON_PARTIAL], ark_after[W];
+  void optimise_partial_rounds() {
+    using F = HFp<N>; constexpr int T = W - 1, H = POSEIDON_FULL / 2, RP = POSEIDON_PARTIAL;
+    F B[W][W]; for (int i = 0; i < W; ++i) for (int j = 0; j < W; ++j) B[i][j] = mds[i][j];
+    std::vector<std::vector<F>> hat(RP, std::vector<F>(T * T));                     // B^_j: the lower-right block of N'_j
+    for (int j = RP - 1; j >= 0; --j) {
+      F a[T][2 * T];                                                                 // Gauss-Jordan inverse of the lower-right block
+      for (int i = 0; i < T; ++i) for (int k = 0; k < T; ++k) { a[i][k] = B[1 + i][1 + k]; a[i][T + k] = i == k ? F::one() : F::zero(); hat[j][i * T + k] = B[1 + i][1 + k]; }
+      for (int col = 0; col < T; ++col) {
+        int piv = col; while (piv < T && a[piv][col].is_zero()) ++piv;               // an MDS block is invertible: a pivot exists
+        if (piv != col) for (int k = 0; k < 2 * T; ++k) std::swap(a[piv][k], a[col][k]);
+        const F inv = F::inv(a[col][col]);
+        for (int k = 0; k < 2 * T; ++k) a[col][k] = F::mul(a[col][k], inv);
+        for (int r = 0; r < T; ++r) if (r != col && !a[r][col].is_zero()) { const F f = a[r][col]; for (int k = 0; k < 2 * T; ++k) a[r][k] = F::sub(a[r][k], F::mul(f, a[col][k])); }
+      }
+      sp_m00[j] = B[0][0];
+      for (int i = 0; i < T; ++i) { F acc = F::zero(); for (int k = 0; k < T; ++k) acc = F::add(acc, F::mul(B[0][1 + k], a[k][T + i])); sp_v[j][i] = acc; sp_w[j][i] = B[1 + i][0]; }
+      F nb[W][W];                                                                    // N'_j M = [[row 0 of M], [B^_j (rows 1.. of M)]]
+      for (int k = 0; k < W; ++k) nb[0][k] = mds[0][k];
+      for (int i = 0; i < T; ++i) for (int k = 0; k < W; ++k) { F acc = F::zero(); for (int q = 0; q < T; ++q) acc = F::add(acc, F::mul(hat[j][i * T + q], mds[1 + q][k])); nb[1 + i][k] = acc; }
+      for (int i = 0; i < W; ++i) for (int k = 0; k < W; ++k) B[i][k] = nb[i][k];
+    }
+    for (int i = 0; i < W; ++i) for (int k = 0; k < W; ++k) pre[i][k] = B[i][k];
+    F carry[W]; for (auto& v : carry) v = F::zero();
+    for (int j = 0; j < RP; ++j) {
+      F d[W]; d[0] = ark[H + j][0];                                                  // N'_j c_j
+      for (int i = 0; i < T; ++i) { F acc = F::zero(); for (int q = 0; q < T; ++q) acc = F::add(acc, F::mul(hat[j][i * T + q], ark[H + j][1 + q])); d[1 + i] = acc; }
+      for (int i = 0; i < W; ++i) d[i] = F::add(d[i], carry[i]);
+      sp_c[j] = d[0];
+      F c0 = F::zero(); for (int i = 0; i < T; ++i) c0 = F::add(c0, F::mul(sp_v[j][i], d[1 + i]));      // N''_j (0, d_1 ..)
+      carry[0] = c0; for (int i = 0; i < T; ++i) carry[1 + i] = d[1 + i];
+    }
+    for (int i = 0; i < W; ++i) ark_after[i] = F::add(ark[H + RP][i], carry[i]);
   }
   static const PoseidonParams& get() { static const PoseidonParams p; return p; }        // built on first use (thread-safe static)
 };
@@ -71,14 +113,22 @@ template <int N> __attribute__((always_inline)) inline HFp<N> pow17(const HFp<N>
 template <int N, int RATE> inline void poseidon_permute(HFp<N>* s) {
   constexpr int W = RATE + 1;
   const PoseidonParams<N, RATE>& P = PoseidonParams<N, RATE>::get();
-  for (int r = 0; r < POSEIDON_ROUNDS; ++r) {
-    for (int i = 0; i < W; ++i) s[i] = HFp<N>::add(s[i], P.ark[r][i]);
-    if (r >= POSEIDON_FULL / 2 && r < POSEIDON_FULL / 2 + POSEIDON_PARTIAL) s[0] = pow17(s[0]);
-    else for (int i = 0; i < W; ++i) s[i] = pow17(s[i]);
+  constexpr int H = POSEIDON_FULL / 2, RP = POSEIDON_PARTIAL;
+  auto full = [&](const HFp<N> (&ark)[W], const HFp<N> (&m)[W][W]) {
+    for (int i = 0; i < W; ++i) s[i] = pow17(HFp<N>::add(s[i], ark[i]));
     HFp<N> o[W];
-    for (int i = 0; i < W; ++i) { Wide<N> w; w.set_mul(s[0].l, P.mds[i][0].l); for (int j = 1; j < W; ++j) w.add_mul(s[j].l, P.mds[i][j].l); o[i] = w.redc(); }
+    for (int i = 0; i < W; ++i) { Wide<N> w; w.set_mul(s[0].l, m[i][0].l); for (int j = 1; j < W; ++j) w.add_mul(s[j].l, m[i][j].l); o[i] = w.redc(); }
     for (int i = 0; i < W; ++i) s[i] = o[i];
+  };
+  for (int r = 0; r < H; ++r) full(P.ark[r], r == H - 1 ? P.pre : P.mds);
+  for (int j = 0; j < RP; ++j) {                             // sparse form (PoseidonParams::optimise_partial_rounds)
+    const HFp<N> x = pow17(HFp<N>::add(s[0], P.sp_c[j]));
+    Wide<N> w; w.set_mul(x.l, P.sp_m00[j].l); for (int i = 1; i < W; ++i) w.add_mul(s[i].l, P.sp_v[j][i - 1].l);
+    for (int i = 1; i < W; ++i) s[i] = HFp<N>::add(s[i], fmul(P.sp_w[j][i - 1], x));
+    s[0] = w.redc();
   }
+  full(P.ark_after, P.mds);
+  for (int r = H + RP + 1; r < POSEIDON_ROUNDS; ++r) full(P.ark[r], P.mds);
 }
 
 // Duplex sponge; state[0] = capacity, state[1..RATE] = rate; elements in Montgomery form
