@@ -128,11 +128,20 @@ template <int C, bool PRE> struct SortGeom {
   __device__ static uint32_t bin(uint32_t w, uint32_t b) { return PRE ? (b >> LB) : w * CB + (b >> LB); }
 };
 
+// Workgroups are dealt round-robin over the eight XCDs (b and b + 8 share one, with its L2).  The level-1 scatter writes, for every coarse bin, the runs
+// of consecutive TILES next to each other — a run is ~100 bytes, so a 128-byte line holds pieces of two tiles: with tile = workgroup the two pieces
+// come from different L2s and reach HBM as partial lines.  Dealing consecutive tiles to workgroups of ONE XCD lets its L2 merge them.
+#ifdef ALEO_NO_XCD_TILE
+__device__ __forceinline__ uint32_t xcd_tile(uint32_t b, uint32_t) { return b; }
+#else
+__device__ __forceinline__ uint32_t xcd_tile(uint32_t b, uint32_t g) { return (g & 7u) ? b : (b & 7u) * (g >> 3) + (b >> 3); }
+#endif
 template <int C, bool MONT, bool PRE>
 __global__ void __launch_bounds__(256) k_part_count(SegArgs segs, const uint8_t* inf, uint32_t* __restrict__ cnt) {
   using Gm = SortGeom<C, PRE>;
   __shared__ uint32_t h[MAX_COARSE];
-  const uint32_t n = segs.n[blockIdx.y], base = blockIdx.x * PART_TILE;
+  const uint32_t bx = xcd_tile(blockIdx.x, gridDim.x);
+  const uint32_t n = segs.n[blockIdx.y], base = bx * PART_TILE;
   if (base >= n) return;                                      // the grid is as wide as the longest segment
   for (uint32_t i = threadIdx.x; i < Gm::NCB; i += 256) h[i] = 0;
   __syncthreads();
@@ -146,7 +155,7 @@ __global__ void __launch_bounds__(256) k_part_count(SegArgs segs, const uint8_t*
     }
   }
   __syncthreads();
-  for (uint32_t i = threadIdx.x; i < Gm::NCB; i += 256) cnt[(size_t)i * nblk + blockIdx.x] = h[i];     // [bin][block]
+  for (uint32_t i = threadIdx.x; i < Gm::NCB; i += 256) cnt[(size_t)i * nblk + bx] = h[i];     // [bin][tile]
 }
 
 // plain exclusive scan of uint32 (tiles of SCAN_TILE + one top block); position(i) = local[i] + blk[i / SCAN_TILE]
@@ -195,10 +204,11 @@ __global__ void __launch_bounds__(256) k_part_scatter(SegArgs segs, const uint8_
                                                       const uint32_t* __restrict__ off_local, const uint32_t* __restrict__ off_blk, uint2* __restrict__ items) {
   using Gm = SortGeom<C, PRE>;
   __shared__ uint32_t cur[MAX_COARSE];
-  const uint32_t n = segs.n[blockIdx.y], base = blockIdx.x * PART_TILE;
+  const uint32_t bx = xcd_tile(blockIdx.x, gridDim.x);
+  const uint32_t n = segs.n[blockIdx.y], base = bx * PART_TILE;
   if (base >= n) return;
   const char* scalars = segs.ptr[blockIdx.y]; const uint32_t off = segs.off[blockIdx.y], nblk = segs.ncol;
-  const size_t row0 = (size_t)segs.set[blockIdx.y] * Gm::NCB; const uint32_t col = segs.col0[blockIdx.y] + blockIdx.x;
+  const size_t row0 = (size_t)segs.set[blockIdx.y] * Gm::NCB; const uint32_t col = segs.col0[blockIdx.y] + bx;
   for (uint32_t i = threadIdx.x; i < Gm::NCB; i += 256) cur[i] = scan32_at(off_local, off_blk, (row0 + i) * nblk + col);
   __syncthreads();
   for (uint32_t q = 0; q < PART_TILE / 256; ++q) {
