@@ -62,6 +62,26 @@ static int32_t init_device(int device, Device** out) {
   return ALEO_MI355X_OK;
 }
 
+// Direct peer access between every ordered pair of initialised devices (xGMI: hipMemcpyPeerAsync then moves data link to link instead of through a
+// staging buffer; the sharded transform's exchange is one such copy per pair).  "Already enabled" is fine; a refusal (no link, IOMMU) is recorded and
+// the copies fall back to the runtime's staged path — never fatal.  Idempotent: pairs are tried once.
+static std::map<std::pair<int, int>, bool> g_peer;          // (device, peer) -> direct access enabled; guarded by g_dev_mu
+static void enable_peer_access() {
+  std::lock_guard<std::mutex> lk(g_dev_mu);
+  int cur = 0; if (hipGetDevice(&cur) != hipSuccess) cur = 0;
+  for (const auto& a : g_devs) for (const auto& b : g_devs) {
+    if (a.first == b.first || g_peer.count({a.first, b.first})) continue;
+    int can = 0; bool ok = false;
+    if (hipDeviceCanAccessPeer(&can, a.first, b.first) == hipSuccess && can && hipSetDevice(a.first) == hipSuccess) {
+      const hipError_t e = hipDeviceEnablePeerAccess(b.first, 0);
+      ok = e == hipSuccess || e == hipErrorPeerAccessAlreadyEnabled;
+      (void)hipGetLastError();                               // "already enabled" must not linger as the thread's last error
+    }
+    g_peer[{a.first, b.first}] = ok;
+  }
+  (void)hipSetDevice(cur);
+}
+
 static int32_t get_device(Device** out) {
   int device = -1;
   if (hipGetDevice(&device) != hipSuccess) { g_last_error = "no HIP device visible"; return ALEO_MI355X_ERR_NO_DEVICE; }
@@ -92,6 +112,30 @@ static int32_t acquire_slot(Device* d, Ctx** out, std::unique_lock<std::mutex>& 
   if (!c) {
     size_t i = std::hash<std::thread::id>()(std::this_thread::get_id()) % (size_t)d->n_slots;
     lk = std::unique_lock<std::mutex>(d->slots[i].mu); c = &d->slots[i];
+  }
+  if (hipSetDevice(d->device) != hipSuccess) { g_last_error = "hipSetDevice failed"; return ALEO_MI355X_ERR_HIP; }
+  { const int32_t rc = first_use(c); if (rc) return rc; }
+  *out = c; return ALEO_MI355X_OK;
+}
+
+// A context of device d for work done on behalf of a call that already holds `exclude` (a slot of the same device, or nullptr): free slots first, then
+// helper contexts, never `exclude` itself — the holder is waiting for this work.  Blocks only when everything else is taken.
+static int32_t acquire_other(Device* d, const Ctx* exclude, Ctx** out, std::unique_lock<std::mutex>& lk) {
+  Ctx* c = nullptr;
+  for (int i = 0; i < d->n_slots && !c; ++i) {
+    if (&d->slots[i] == exclude) continue;
+    std::unique_lock<std::mutex> t(d->slots[i].mu, std::try_to_lock);
+    if (t.owns_lock()) { lk = std::move(t); c = &d->slots[i]; }
+  }
+  for (int i = 0; i < MAX_SLOTS && !c; ++i) {
+    if (&d->helpers[i] == exclude) continue;
+    std::unique_lock<std::mutex> t(d->helpers[i].mu, std::try_to_lock);
+    if (t.owns_lock()) { lk = std::move(t); c = &d->helpers[i]; }
+  }
+  if (!c) {
+    size_t i = std::hash<std::thread::id>()(std::this_thread::get_id()) % (size_t)MAX_SLOTS;
+    if (&d->helpers[i] == exclude) i = (i + 1) % MAX_SLOTS;
+    lk = std::unique_lock<std::mutex>(d->helpers[i].mu); c = &d->helpers[i];
   }
   if (hipSetDevice(d->device) != hipSuccess) { g_last_error = "hipSetDevice failed"; return ALEO_MI355X_ERR_HIP; }
   { const int32_t rc = first_use(c); if (rc) return rc; }
@@ -305,8 +349,20 @@ int32_t aleo_mi355x_init(int32_t n_devices) {
     const int n = n_devices ? n_devices : count;
     int32_t rc = ALEO_MI355X_OK;
     for (int i = 0; i < n && !rc; ++i) { Device* d = nullptr; rc = init_device(i, &d); }
+    if (!rc) enable_peer_access();
     (void)hipSetDevice(cur);
     return rc;
+  } catch (...) { return ALEO_MI355X_ERR_HIP; }
+}
+
+int32_t aleo_mi355x_peer_info(int32_t* enabled_pairs, int32_t* refused_pairs) {
+  try {
+    std::lock_guard<std::mutex> lk(g_dev_mu);
+    int32_t on = 0, off = 0;
+    for (const auto& kv : g_peer) (kv.second ? on : off)++;
+    if (enabled_pairs) *enabled_pairs = on;
+    if (refused_pairs) *refused_pairs = off;
+    return ALEO_MI355X_OK;
   } catch (...) { return ALEO_MI355X_ERR_HIP; }
 }
 
@@ -999,7 +1055,7 @@ const char* aleo_mi355x_strerror(int32_t status) {
   }
 }
 const char* aleo_mi355x_last_error(void) { return g_last_error.c_str(); }
-const char* aleo_mi355x_version(void) { return "aleo_mi355x 0.1.0 (gfx950)"; }
+const char* aleo_mi355x_version(void) { return "aleo_mi355x 0.2.0 (gfx950)"; }
 
 
 // ---- one MSM over several devices (BASELINE configs[4]) ------------------------------------------------------------------
@@ -1022,15 +1078,22 @@ std::shared_ptr<ShardedSet> sharded_find(uint64_t h) {
 template <class F> int32_t for_each_shard(const ShardedSet& S, F&& f) {
   const size_t G = S.devices.size();
   std::vector<int32_t> rcs(G, ALEO_MI355X_OK); std::vector<std::string> errs(G);
-  std::vector<std::thread> th;
-  for (size_t g = 0; g < G; ++g)
-    th.emplace_back([&, g]() {
+  // the threads wait at a gate until all of them exist (f may meet the other shards at barriers): if one cannot be started, none runs
+  std::vector<std::thread> th; th.reserve(G); std::mutex gate_mu; std::condition_variable gate_cv; int gate = 0;      // 0 wait, 1 go, -1 leave
+  bool started = true;
+  for (size_t g = 0; g < G && started; ++g) {
+    auto body = [&, g]() {
+      { std::unique_lock<std::mutex> lk(gate_mu); gate_cv.wait(lk, [&] { return gate != 0; }); if (gate < 0) return; }
       try {
         if (hipSetDevice(S.devices[g]) != hipSuccess) { rcs[g] = ALEO_MI355X_ERR_HIP; errs[g] = "hipSetDevice failed"; return; }
         rcs[g] = f(g); if (rcs[g]) errs[g] = g_last_error;
       } catch (...) { rcs[g] = ALEO_MI355X_ERR_HIP; errs[g] = "exception in a shard"; }
-    });
+    };
+    try { th.emplace_back(body); } catch (...) { started = false; }
+  }
+  { std::lock_guard<std::mutex> lk(gate_mu); gate = started ? 1 : -1; } gate_cv.notify_all();
   for (auto& t : th) t.join();
+  if (!started) { g_last_error = "could not start a shard's thread"; return ALEO_MI355X_ERR_HIP; }
   for (size_t g = 0; g < G; ++g) if (rcs[g]) { g_last_error = "shard " + std::to_string(g) + " (device " + std::to_string(S.devices[g]) + "): " + errs[g]; return rcs[g]; }
   return ALEO_MI355X_OK;
 }
@@ -1126,6 +1189,99 @@ int32_t aleo_mi355x_msm_g1_sharded(void* out_jacobian, uint64_t handle, const vo
   } catch (...) { return ALEO_MI355X_ERR_HIP; }
 }
 
+}  // extern "C"
+namespace aleo_mi355x {
+// ---- commitments against a sharded committer key (row e2: a proof that spans devices) -------------------------------------------------------------------
+// The scalar vectors live on ONE device (the prover's: `c`'s); the base set is cut over G devices (ShardedSet).  A segment [off, off + len) meets shard g
+// in [max(off, first_g), min(off + len, first_g + count_g)): that piece of the scalars is pulled by device g (peer copy over xGMI — none when g is the
+// scalars' own device) and multiplied there by the ordinary batched Pippenger against shard g's points and tables; what crosses back is k partial
+// results of 144 bytes per shard, added on the host in shard order.  The sum of normalised partials is normalised again, so the bytes are those of
+// the single-device commitment.
+int32_t commit_sharded(Ctx* c, uint64_t sharded_handle, const MsmSeg* segs, uint32_t nseg, uint32_t k, bool mont, uint64_t* out_jac18, hipStream_t s) {
+  auto S = sharded_find(sharded_handle); if (!S) return ALEO_MI355X_ERR_BAD_HANDLE;
+  const size_t G = S->devices.size(); const int home = c->device;
+  for (uint32_t q = 0; q < nseg; ++q) if (segs[q].out >= k || segs[q].off + segs[q].len > S->n) { g_last_error = "commit_sharded: segment out of range"; return ALEO_MI355X_ERR_BAD_ARG; }
+  HIPCHK(hipStreamSynchronize(s));                           // the scalars are complete (and whatever the caller queued before the commitment has landed)
+  std::vector<uint64_t> part((size_t)18 * k * G);
+  std::vector<char> busy(G, 0);                              // shards that hold a piece of some segment
+  for (size_t g = 0; g < G; ++g) for (uint32_t q = 0; q < nseg && !busy[g]; ++q) {
+    const size_t lo = segs[q].off > S->first[g] ? segs[q].off : S->first[g], hi = segs[q].off + segs[q].len < S->first[g] + S->count[g] ? segs[q].off + segs[q].len : S->first[g] + S->count[g];
+    busy[g] = hi > lo;
+  }
+  const int32_t rc = for_each_shard(*S, [&](size_t g) -> int32_t {
+    uint64_t* mine = &part[(size_t)18 * k * g];
+    if (!busy[g]) { for (uint32_t q = 0; q < k; ++q) host::hstore_jacobian_normalized(mine + 18 * q, host::HXYZZ::infinity()); return ALEO_MI355X_OK; }
+    Device* d = nullptr; Ctx* cc = nullptr; std::unique_lock<std::mutex> lk;
+    { int32_t r = get_device(&d); if (r) return r; if ((r = acquire_other(d, c, &cc, lk))) return r; }
+    std::shared_ptr<PinnedOwner> keep; PinnedBases pb; { const int32_t r = find_bases(d, S->handles[g], &keep, &pb); if (r) return r; }
+    std::vector<MsmSeg> sub; size_t total = 0;
+    for (uint32_t q = 0; q < nseg; ++q) {
+      const size_t lo = segs[q].off > S->first[g] ? segs[q].off : S->first[g], hi = segs[q].off + segs[q].len < S->first[g] + S->count[g] ? segs[q].off + segs[q].len : S->first[g] + S->count[g];
+      if (hi <= lo) continue;
+      MsmSeg m; m.d_ptr = (const char*)segs[q].d_ptr + (lo - segs[q].off) * 32; m.len = hi - lo; m.off = lo - S->first[g]; m.out = segs[q].out; sub.push_back(m); total += m.len;
+    }
+    if (d->device != home) {                                 // pull the pieces: one peer copy each, queued back to back on this shard's stream
+      const int32_t r = cc->scalars_stage.reserve(total * 32); if (r) return r;
+      size_t at = 0;
+      for (auto& m : sub) {
+        HIPCHK(hipMemcpyPeerAsync((char*)cc->scalars_stage.p + at * 32, d->device, m.d_ptr, home, m.len * 32, cc->stream));
+        m.d_ptr = (const char*)cc->scalars_stage.p + at * 32; at += m.len;
+      }
+    }
+    MsmJob j; j.segs = sub.data(); j.nseg = (uint32_t)sub.size(); j.k = k; j.mont = mont;
+    return msm_batch(cc, mine, pb, j, cc->stream);
+  });
+  if (rc) return rc;
+  std::vector<host::HXYZZ> tot(k, host::HXYZZ::infinity());
+  for (size_t g = 0; g < G; ++g) { if (!busy[g]) continue; for (uint32_t q = 0; q < k; ++q) tot[q] = host::hadd(tot[q], host::hfrom_jacobian(&part[(size_t)18 * (k * g + q)])); }
+  host::hstore_jacobian_normalized_batch(out_jac18, tot.data(), k);
+  return ALEO_MI355X_OK;
+}
+}  // namespace aleo_mi355x
+extern "C" {
+
+int32_t aleo_mi355x_bases_attach_shards(uint64_t handle, uint64_t sharded_handle, size_t min_points) {
+  try {
+    Device* d = nullptr; { const int32_t rc = get_device(&d); if (rc) return rc; }
+    size_t n_sh = 0;
+    if (sharded_handle) { auto S = sharded_find(sharded_handle); if (!S) return ALEO_MI355X_ERR_BAD_HANDLE; n_sh = S->n; }
+    std::lock_guard<std::mutex> lk(d->mu);
+    auto it = d->bases.find(handle);
+    if (it == d->bases.end()) { g_last_error = "unknown bases handle"; return ALEO_MI355X_ERR_BAD_HANDLE; }
+    if (sharded_handle && n_sh != it->second->pb.n) { g_last_error = "bases_attach_shards: the sharded set must hold the same number of points"; return ALEO_MI355X_ERR_BAD_ARG; }
+    it->second->pb.shards = sharded_handle; it->second->pb.shard_min = min_points;
+    return ALEO_MI355X_OK;
+  } catch (...) { return ALEO_MI355X_ERR_HIP; }
+}
+
+int32_t aleo_mi355x_kzg_commit_segments_sharded_device(void* out104, size_t n_out, uint64_t sharded_handle, const aleo_mi355x_commit_segment* segs, size_t n_segs, void* stream) {
+  try {
+    if (!n_out) return ALEO_MI355X_OK;
+    if (!out104 || (!segs && n_segs) || n_out >= (1u << 20) || n_segs >= (1u << 22)) { g_last_error = "commit_segments_sharded: bad argument"; return ALEO_MI355X_ERR_BAD_ARG; }
+    API_BEGIN
+    PICK_STREAM(s)
+    std::vector<MsmSeg> sg(n_segs);
+    for (size_t q = 0; q < n_segs; ++q) {
+      if (!segs[q].scalars && segs[q].len) { g_last_error = "commit_segments_sharded: null segment"; return ALEO_MI355X_ERR_BAD_ARG; }
+      sg[q].d_ptr = segs[q].scalars; sg[q].len = segs[q].len; sg[q].off = segs[q].base_offset; sg[q].out = segs[q].output;
+    }
+    std::vector<uint64_t> jac(18 * n_out);
+    const int32_t rc = commit_sharded(c, sharded_handle, sg.data(), (uint32_t)n_segs, (uint32_t)n_out, true, jac.data(), s);
+    if (rc) return rc;
+    jac_to_affine_rows(out104, jac.data(), n_out);
+    return ALEO_MI355X_OK;
+  } catch (...) { return ALEO_MI355X_ERR_HIP; }
+}
+
+int32_t aleo_mi355x_kzg_commit_batch_sharded_device(void* out104, uint64_t sharded_handle, const void* const* d_coeffs, const size_t* lens, size_t k, void* stream) {
+  try {
+    int32_t rc = batch_args_ok(out104, d_coeffs, lens, k); if (rc || !k) return rc;
+    std::vector<aleo_mi355x_commit_segment> sg(k);
+    for (size_t q = 0; q < k; ++q) { sg[q].scalars = d_coeffs[q]; sg[q].len = lens[q]; sg[q].base_offset = 0; sg[q].output = (uint32_t)q; }
+    return aleo_mi355x_kzg_commit_segments_sharded_device(out104, k, sharded_handle, sg.data(), k, stream);
+  } catch (...) { return ALEO_MI355X_ERR_HIP; }
+}
+
 
 // ---- one transform over several devices of this process: the 4-step schedule of aleo_amd/dist.py ShardedDomain behind the C ABI --------------------
 // n = R * C (R = 2^floor(lg n / 2)), G devices, natural order in and out of ONE host buffer:
@@ -1138,10 +1294,25 @@ int32_t aleo_mi355x_msm_g1_sharded(void* out_jacobian, uint64_t handle, const vo
 // every column transform has finished.  A device may be listed more than once (the tests: one card).
 }  // extern "C" (helpers of the sharded transform follow)
 namespace {
-struct NttShard { int dev = 0; hipStream_t st = nullptr; void *a = nullptr, *b = nullptr; };      // two buffers of n / G elements each, ping-pong
+struct NttShard { int dev = 0; hipStream_t st = nullptr; void *a = nullptr, *b = nullptr; };      // two buffers of n / G elements each, ping-pong (owned by the device's ShardWs)
+std::mutex g_ntt_sh_mu;                                     // one sharded transform at a time: it occupies every listed device anyway
 int32_t peer_copy(void* dst, int dst_dev, const void* src, int src_dev, size_t bytes, hipStream_t s) {
   if (dst_dev == src_dev) { HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, s)); }
   else { HIPCHK(hipMemcpyPeerAsync(dst, dst_dev, src, src_dev, bytes, s)); }
+  return ALEO_MI355X_OK;
+}
+// the k-th shard workspace of the calling thread's current device (stream created once, buffers grow-only)
+int32_t shard_ws(size_t ordinal, size_t bytes, NttShard* out) {
+  Device* d = nullptr; { const int32_t rc = get_device(&d); if (rc) return rc; }
+  ShardWs* w = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(d->mu);
+    while (d->shard_ws.size() <= ordinal) d->shard_ws.emplace_back(new ShardWs());
+    w = d->shard_ws[ordinal].get();
+  }
+  if (!w->st) HIPCHK(hipStreamCreateWithFlags(&w->st, hipStreamNonBlocking));
+  { int32_t rc; if ((rc = w->a.reserve(bytes)) || (rc = w->b.reserve(bytes))) return rc; }
+  out->dev = d->device; out->st = w->st; out->a = w->a.p; out->b = w->b.p;
   return ALEO_MI355X_OK;
 }
 }  // namespace
@@ -1156,45 +1327,58 @@ int32_t aleo_mi355x_ntt_fr_sharded(void* inout, uint32_t lg_n, int32_t direction
     if (lg_r < lg_g) { g_last_error = "ntt_fr_sharded: domain too small for this many shards"; return ALEO_MI355X_ERR_BAD_ARG; }
     ShardedSet S; int32_t rc = sharded_layout(S, (size_t)1 << lg_n, devices, n_devices); if (rc) return rc;      // (only its device list is used)
     const size_t G = n_devices, R = (size_t)1 << lg_r, C = (size_t)1 << lg_c, Rg = R / G, Cg = C / G, per = R * Cg;   // per = elements per shard (= Rg * C)
+    std::vector<size_t> ordinal(G, 0);                       // shard g is the ordinal[g]-th shard on its device
+    for (size_t g = 0; g < G; ++g) for (size_t e = 0; e < g; ++e) ordinal[g] += S.devices[e] == S.devices[g];
+    std::lock_guard<std::mutex> one(g_ntt_sh_mu);
+    {                                                        // every listed device initialised (and selectable) before any shard thread starts: a thread must not drop out before the barriers
+      int cur = 0; if (hipGetDevice(&cur) != hipSuccess) cur = 0;
+      for (size_t g = 0; g < G; ++g) { Device* dd = nullptr; if ((rc = init_device(S.devices[g], &dd))) { (void)hipSetDevice(cur); return rc; } }
+      (void)hipSetDevice(cur);
+    }
     std::vector<NttShard> sh(G);
     char* host = (char*)inout;
-    auto cleanup = [&]() { (void)for_each_shard(S, [&](size_t g) -> int32_t { if (sh[g].st) { (void)hipStreamSynchronize(sh[g].st); (void)hipStreamDestroy(sh[g].st); } if (sh[g].a) (void)hipFree(sh[g].a); if (sh[g].b) (void)hipFree(sh[g].b); return ALEO_MI355X_OK; }); };
-    // phase 1: columns in, column transforms, twiddle, blocks by destination
+    // One thread per shard for the whole call (the runtime's current device is per thread); the three phases are separated by barriers, so no peer
+    // copy starts before every column transform has finished and no buffer is overwritten before its reader is done.  A shard that fails keeps
+    // meeting the barriers (the others must not hang) and the first failure is returned.
+    Barrier bar(G); std::atomic<int> failed{0};
     rc = for_each_shard(S, [&](size_t g) -> int32_t {
-      NttShard& d = sh[g]; d.dev = S.devices[g];
-      HIPCHK(hipStreamCreateWithFlags(&d.st, hipStreamNonBlocking));
-      HIPCHK(hipMalloc(&d.a, per * 32)); HIPCHK(hipMalloc(&d.b, per * 32));
-      HIPCHK(hipMemcpy2DAsync(d.a, Cg * 32, host + g * Cg * 32, C * 32, Cg * 32, R, hipMemcpyHostToDevice, d.st));               // a = [R][Cg]
-      int32_t r;
-      if (type == ALEO_NTT_COSET && direction == ALEO_NTT_FORWARD && (r = aleo_mi355x_fr_grid_scale_device(d.a, lg_n, R, Cg, 0, g * Cg, C, 1, 0, d.st))) return r;
-      if ((r = aleo_mi355x_fr_transpose_device(d.b, d.a, R, Cg, d.st))) return r;                                                   // b = [Cg][R]
-      if ((r = aleo_mi355x_ntt_fr_batch_device(d.b, lg_r, Cg, ALEO_NTT_ORDER_NN, direction, ALEO_NTT_STANDARD, d.st))) return r;     // [c][k_r] (inverse: x R^-1)
-      if ((r = aleo_mi355x_fr_grid_scale_device(d.b, lg_n, Cg, R, g * Cg, 0, 0, 0, direction, d.st))) return r;                     // *= w_n^(+-c k_r)
-      for (size_t h = 0; h < G; ++h)                                                                                                // a = [h][Cg][Rg]: block h = my columns, device h's k_r range
-        HIPCHK(hipMemcpy2DAsync((char*)d.a + h * Cg * Rg * 32, Rg * 32, (char*)d.b + h * Rg * 32, R * 32, Rg * 32, Cg, hipMemcpyDeviceToDevice, d.st));
-      HIPCHK(hipStreamSynchronize(d.st));
-      return ALEO_MI355X_OK;
+      NttShard& d = sh[g]; int32_t r = ALEO_MI355X_OK; std::string err;
+      auto phase = [&](const std::function<int32_t()>& f) { if (!r && !failed.load()) { r = f(); if (r) { err = g_last_error; failed.store(1); } } bar.wait(); };
+      // phase 1: columns in, column transforms, twiddle, blocks by destination
+      phase([&]() -> int32_t {
+        int32_t q = shard_ws(ordinal[g], per * 32, &d); if (q) return q;
+        HIPCHK(hipMemcpy2DAsync(d.a, Cg * 32, host + g * Cg * 32, C * 32, Cg * 32, R, hipMemcpyHostToDevice, d.st));               // a = [R][Cg]
+        if (type == ALEO_NTT_COSET && direction == ALEO_NTT_FORWARD && (q = aleo_mi355x_fr_grid_scale_device(d.a, lg_n, R, Cg, 0, g * Cg, C, 1, 0, d.st))) return q;
+        if ((q = aleo_mi355x_fr_transpose_device(d.b, d.a, R, Cg, d.st))) return q;                                                   // b = [Cg][R]
+        if ((q = aleo_mi355x_ntt_fr_batch_device(d.b, lg_r, Cg, ALEO_NTT_ORDER_NN, direction, ALEO_NTT_STANDARD, d.st))) return q;     // [c][k_r] (inverse: x R^-1)
+        if ((q = aleo_mi355x_fr_grid_scale_device(d.b, lg_n, Cg, R, g * Cg, 0, 0, 0, direction, d.st))) return q;                     // *= w_n^(+-c k_r)
+        for (size_t h = 0; h < G; ++h)                                                                                                // a = [h][Cg][Rg]: block h = my columns, device h's k_r range
+          HIPCHK(hipMemcpy2DAsync((char*)d.a + h * Cg * Rg * 32, Rg * 32, (char*)d.b + h * Rg * 32, R * 32, Rg * 32, Cg, hipMemcpyDeviceToDevice, d.st));
+        HIPCHK(hipStreamSynchronize(d.st));
+        return ALEO_MI355X_OK;
+      });
+      // phase 2: the exchange — this device pulls its block of every device e into b = [e][Cg][Rg] = [C][Rg]; own block first, then the peers starting
+      // with the next device, so that at any moment every link carries one copy
+      phase([&]() -> int32_t {
+        for (size_t k = 0; k < G; ++k) { const size_t e = (g + k) % G; const int32_t q = peer_copy((char*)d.b + e * Cg * Rg * 32, d.dev, (char*)sh[e].a + g * Cg * Rg * 32, sh[e].dev, Cg * Rg * 32, d.st); if (q) return q; }
+        HIPCHK(hipStreamSynchronize(d.st));
+        return ALEO_MI355X_OK;
+      });
+      // phase 3: row transforms, natural order out
+      phase([&]() -> int32_t {
+        int32_t q;
+        if ((q = aleo_mi355x_fr_transpose_device(d.a, d.b, C, Rg, d.st))) return q;                                                   // a = [Rg][C]
+        if ((q = aleo_mi355x_ntt_fr_batch_device(d.a, lg_c, Rg, ALEO_NTT_ORDER_NN, direction, ALEO_NTT_STANDARD, d.st))) return q;     // [k_r][k_c] (inverse: x C^-1)
+        if ((q = aleo_mi355x_fr_transpose_device(d.b, d.a, Rg, C, d.st))) return q;                                                   // b = [k_c][k_r local]: X[k_c R + k_r]
+        if (type == ALEO_NTT_COSET && direction == ALEO_NTT_INVERSE && (q = aleo_mi355x_fr_grid_scale_device(d.b, lg_n, C, Rg, 0, g * Rg, R, 1, 1, d.st))) return q;
+        HIPCHK(hipMemcpy2DAsync(host + g * Rg * 32, R * 32, d.b, Rg * 32, Rg * 32, C, hipMemcpyDeviceToHost, d.st));
+        HIPCHK(hipStreamSynchronize(d.st));
+        return ALEO_MI355X_OK;
+      });
+      if (d.st) (void)hipStreamSynchronize(d.st);              // whatever happened, nothing of this call is left on the shard's stream
+      if (r) g_last_error = err;
+      return r;
     });
-    if (rc) { const std::string keep = g_last_error; cleanup(); g_last_error = keep; return rc; }
-    // phase 2: the exchange — device h pulls block h of every device g into b = [g][Cg][Rg] = [C][Rg]
-    rc = for_each_shard(S, [&](size_t h) -> int32_t {
-      for (size_t g = 0; g < G; ++g) { int32_t r = peer_copy((char*)sh[h].b + g * Cg * Rg * 32, sh[h].dev, (char*)sh[g].a + h * Cg * Rg * 32, sh[g].dev, Cg * Rg * 32, sh[h].st); if (r) return r; }
-      HIPCHK(hipStreamSynchronize(sh[h].st));
-      return ALEO_MI355X_OK;
-    });
-    if (rc) { const std::string keep = g_last_error; cleanup(); g_last_error = keep; return rc; }
-    // phase 3: row transforms, natural order out
-    rc = for_each_shard(S, [&](size_t h) -> int32_t {
-      NttShard& d = sh[h]; int32_t r;
-      if ((r = aleo_mi355x_fr_transpose_device(d.a, d.b, C, Rg, d.st))) return r;                                                   // a = [Rg][C]
-      if ((r = aleo_mi355x_ntt_fr_batch_device(d.a, lg_c, Rg, ALEO_NTT_ORDER_NN, direction, ALEO_NTT_STANDARD, d.st))) return r;     // [k_r][k_c] (inverse: x C^-1)
-      if ((r = aleo_mi355x_fr_transpose_device(d.b, d.a, Rg, C, d.st))) return r;                                                   // b = [k_c][k_r local]: X[k_c R + k_r]
-      if (type == ALEO_NTT_COSET && direction == ALEO_NTT_INVERSE && (r = aleo_mi355x_fr_grid_scale_device(d.b, lg_n, C, Rg, 0, h * Rg, R, 1, 1, d.st))) return r;
-      HIPCHK(hipMemcpy2DAsync(host + h * Rg * 32, R * 32, d.b, Rg * 32, Rg * 32, C, hipMemcpyDeviceToHost, d.st));
-      HIPCHK(hipStreamSynchronize(d.st));
-      return ALEO_MI355X_OK;
-    });
-    const std::string keep = g_last_error; cleanup(); if (rc) g_last_error = keep;
     return rc;
   } catch (...) { return ALEO_MI355X_ERR_HIP; }
 }

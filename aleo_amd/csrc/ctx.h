@@ -4,6 +4,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <atomic>
+#include <condition_variable>
 #include <cstdint>
 #include <cstdio>
 #include <map>
@@ -73,6 +74,9 @@ struct PinnedBases {
   // scalars are mostly 0 / 1 (a witness in evaluation form against the Lagrange-basis powers) put too few points into the wide windows' buckets
   PreTable range; size_t range_off = 0;
   bool tabled = false;         // msm_precompute has run (a set below 2^10 points gets no table)
+  // a sharded copy of the same points on several devices (aleo_mi355x_bases_attach_shards): commitments of >= shard_min points made against this set by the
+  // prover / the segment entry points go to the shards (api.hip commit_sharded) — 0 = none
+  uint64_t shards = 0; size_t shard_min = 0;
   size_t n = 0;
 };
 
@@ -124,6 +128,19 @@ int32_t scratch_release(Ctx* c, hipStream_t s);
 
 static constexpr int MAX_SLOTS = 8;
 
+struct Barrier {                                           // reusable; C++17 has none
+  std::mutex mu; std::condition_variable cv; size_t n, waiting = 0, phase = 0;
+  explicit Barrier(size_t n_) : n(n_) {}
+  void wait() {
+    std::unique_lock<std::mutex> lk(mu); const size_t ph = phase;
+    if (++waiting == n) { waiting = 0; ++phase; cv.notify_all(); } else cv.wait(lk, [&] { return phase != ph; });
+  }
+};
+
+// What one shard of a transform sharded over devices (aleo_mi355x_ntt_fr_sharded) keeps on its device between calls: a stream and two grow-only
+// buffers of n / G elements.  A device listed k times in a call uses its first k entries.
+struct ShardWs { hipStream_t st = nullptr; DevBuf a, b; };
+
 struct Device {
   int device = -1;
   int n_slots = 4;                     // ALEO_MI355X_SLOTS (1..8)
@@ -134,6 +151,7 @@ struct Device {
   std::map<uint64_t, std::shared_ptr<struct VarunaIndexOwner>> varuna; uint64_t next_varuna = 1;      // circuit indices (varuna.hip)
   std::atomic<int> ntt_attr_mask{0};   // which NTT kernel instances had their LDS limit raised on THIS device
   Ctx slots[MAX_SLOTS];
+  std::vector<std::unique_ptr<ShardWs>> shard_ws;     // grown under mu; used only by the one sharded transform in flight (api.hip g_ntt_sh_mu)
   Ctx helpers[MAX_SLOTS];              // extra streams + scratch a lockstep call borrows for its worker threads (never handed out as API slots)
 };
 // Borrows up to `want` idle helper contexts of the device (try-lock: none is waited for); they are released when `hs` goes out of scope.
@@ -155,6 +173,11 @@ inline int32_t msm_run1(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, cons
   MsmJob j; j.segs = &g; j.nseg = 1; j.k = 1; j.mont = mont; j.sparse = sparse; return msm_run(c, out_jac18, pb, j, s);
 }
 int32_t msm_batch(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, const MsmJob& job, hipStream_t s);
+// api.hip: the same request against a SHARDED copy of the base set (handle of aleo_mi355x_bases_pin_sharded): every segment is cut at the shard boundaries,
+// device g pulls its pieces of the scalar vectors from the calling thread's device (peer copies; same device: none) and runs msm_batch against its shard,
+// the G x k partial results are added on the host in shard order.  `s` (the stream the scalars were produced on) is synchronised first; the results are
+// normalised exactly like msm_batch's, so the bytes equal the single-device call's.  `c` is the caller's slot: shard work never waits for it.
+int32_t commit_sharded(Ctx* c, uint64_t sharded_handle, const MsmSeg* segs, uint32_t nseg, uint32_t k, bool mont, uint64_t* out_jac18, hipStream_t s);
 // One result over n points, scalars on the device (host_src == nullptr) or still on the host (then d_scalars is ignored and the scalars are uploaded into the
 // contexts' staging buffers): host scalars from 2^21 points on go in two halves on two contexts — msm.hip msm_run1_split
 int32_t msm_run1_split(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, const void* d_scalars, size_t n, bool mont, hipStream_t s, bool sparse, const void* host_src);

@@ -1314,7 +1314,8 @@ static int32_t run_chains(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, st
     tm_h = h->last_msm;
   });
   int32_t rc_m = ALEO_MI355X_OK;
-  for (size_t i; !rc_m && (i = next.fetch_add(1)) < chains.size();) rc_m = run_one(c, chains[i], s);
+  try { for (size_t i; !rc_m && (i = next.fetch_add(1)) < chains.size();) rc_m = run_one(c, chains[i], s); }
+  catch (...) { rc_m = ALEO_MI355X_ERR_HIP; g_last_error = "msm: exception on the calling thread"; next.store(chains.size()); }      // never unwind past the joinable helper
   helper.join();
   (void)hipStreamSynchronize(h->stream);
   if (rc_m) return rc_m;
@@ -1369,7 +1370,8 @@ int32_t msm_run1_split(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, const
       if (rc_h) err_h = g_last_error;
     } catch (...) { rc_h = ALEO_MI355X_ERR_HIP; err_h = "msm: exception on the helper thread"; }
   });
-  const int32_t rc_m = half(c, s, pa, na, 0, part);
+  int32_t rc_m;
+  try { rc_m = half(c, s, pa, na, 0, part); } catch (...) { rc_m = ALEO_MI355X_ERR_HIP; g_last_error = "msm: exception on the calling thread"; }      // never unwind past the joinable helper
   helper.join();
   (void)hipStreamSynchronize(h->stream);
   if (rc_m) return rc_m;

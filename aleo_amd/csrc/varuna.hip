@@ -1,5 +1,5 @@
 // varuna.hip — the host side of one proof, native: the four AHP rounds, the evaluations and the two openings of
-// `Varuna::prove_batch` (up to eight circuits, each with up to eight instances) as ONE call of the C ABI (`aleo_mi355x_varuna_prove[_batch_indexed]`).
+// `Varuna::prove_batch` (up to 32 instances in any split over circuits) as ONE call of the C ABI (`aleo_mi355x_varuna_prove[_batch_indexed]`).
 //
 // Replaces (shape, not bytes — see DESIGN.md §4d for what differs from upstream and why) snarkVM 0.14.5
 //   algorithms/src/snark/varuna/varuna.rs                      Varuna::prove_batch
@@ -104,10 +104,12 @@ static int32_t commit(Ctx* c, const PinnedBases& pb, const std::vector<MsmSeg>& 
 struct VarunaIndexOwner {
   aleo_mi355x_varuna_index view{};
   std::vector<uint32_t> positions; std::vector<uint8_t> vk, vk_aff;
-  std::vector<void*> dev;                                  // every device allocation of the index
+  std::vector<void*> dev;                                  // every device allocation the index keeps
+  std::vector<void*> tmp;                                  // scratch of the build (raw columns, C's forward arrays, cursors): freed when the build's stream has drained
   std::shared_ptr<PinnedOwner> key;                        // the committer key stays pinned while the index lives
-  ~VarunaIndexOwner() { for (void* p : dev) if (p) (void)hipFree(p); }
-  int32_t alloc(void** out, size_t bytes) { void* p = nullptr; HIPCHK(hipMalloc(&p, bytes ? bytes : 32)); dev.push_back(p); *out = p; return ALEO_MI355X_OK; }
+  ~VarunaIndexOwner() { free_tmp(); for (void* p : dev) if (p) (void)hipFree(p); }
+  void free_tmp() { for (void* p : tmp) if (p) (void)hipFree(p); tmp.clear(); }
+  int32_t alloc(void** out, size_t bytes, bool scratch = false) { void* p = nullptr; HIPCHK(hipMalloc(&p, bytes ? bytes : 32)); (scratch ? tmp : dev).push_back(p); *out = p; return ALEO_MI355X_OK; }
 };
 void varuna_index_delete(VarunaIndexOwner* o) { delete o; }
 const aleo_mi355x_varuna_index* varuna_index_view(const VarunaIndexOwner* o) { return &o->view; }
@@ -152,23 +154,24 @@ int32_t varuna_index_build(Ctx* c, const PinnedBases& pb, std::shared_ptr<Pinned
   // pointers; a second pass drops every entry into its column's range (an atomic cursor per column: the order inside a column is whatever the
   // hardware makes it, the products M^T v are exact field sums, so every proof byte is independent of it).
   std::vector<uint32_t> rp(n_h + 1);
-  auto up = [&](void** dst, const void* src, size_t bytes) -> int32_t { RC(o->alloc(dst, bytes)); if (bytes) HIPCHK(hipMemcpyAsync(*dst, src, bytes, hipMemcpyHostToDevice, s)); return ALEO_MI355X_OK; };
+  auto up = [&](void** dst, const void* src, size_t bytes, bool scratch = false) -> int32_t { RC(o->alloc(dst, bytes, scratch)); if (bytes) HIPCHK(hipMemcpyAsync(*dst, src, bytes, hipMemcpyHostToDevice, s)); return ALEO_MI355X_OK; };
   auto to_mont = [&](void* p, size_t n) -> int32_t { return fr_lin(c, p, n, nullptr, r2.l, p, nullptr, nullptr, s); };
   void *dpos, *kid, *kv, *dtp, *dcur, *dtcol, *dtval;
   RC(up(&dpos, o->positions.data(), n_vars * 4)); V.positions_device = dpos;
-  RC(o->alloc(&kid, 2 * k_sum * 4)); RC(o->alloc(&kv, k_sum * 32)); RC(o->alloc(&dtp, (n_h + 1) * 4)); RC(o->alloc(&dtcol, nnz_sum * 4)); RC(o->alloc(&dtval, nnz_sum * 32));
+  RC(o->alloc(&kid, 2 * k_sum * 4)); RC(o->alloc(&kv, k_sum * 32, true)); RC(o->alloc(&dtp, (n_h + 1) * 4)); RC(o->alloc(&dtcol, nnz_sum * 4)); RC(o->alloc(&dtval, nnz_sum * 32));
   HIPCHK(hipMemsetAsync(kid, 0, 2 * k_sum * 4, s)); HIPCHK(hipMemsetAsync(kv, 0, k_sum * 32, s)); HIPCHK(hipMemsetAsync(dtp, 0, (n_h + 1) * 4, s));
   void *drp[3], *dcolraw[3], *dcol[3], *dval[3];
   for (int m = 0; m < 3; ++m) {                            // forward matrices with columns on H, rows padded to |H| (C only feeds the transpose and the arithmetisation)
     for (uint64_t i = 0; i <= n_h; ++i) rp[i] = i <= n_constraints ? abc[m].row_ptr[i] : (uint32_t)nnz[m];
-    RC(up(&drp[m], rp.data(), (n_h + 1) * 4)); RC(up(&dcolraw[m], abc[m].col, nnz[m] * 4)); RC(up(&dval[m], abc[m].val, nnz[m] * 32)); RC(o->alloc(&dcol[m], nnz[m] * 4));
+    const bool fwd = m < 2;                                // A and B are kept as forward CSR (z_a, z_b); C's arrays, the raw columns and the cursors are scratch
+    RC(up(&drp[m], rp.data(), (n_h + 1) * 4, !fwd)); RC(up(&dcolraw[m], abc[m].col, nnz[m] * 4, true)); RC(up(&dval[m], abc[m].val, nnz[m] * 32, !fwd)); RC(o->alloc(&dcol[m], nnz[m] * 4, !fwd));
     HIPCHK(hipStreamSynchronize(s));                       // rp is reused by the next matrix
     RC(index_expand_rows(c, (const uint32_t*)drp[m], (const uint32_t*)dcolraw[m], (const uint32_t*)dpos, n_constraints, (uint32_t*)kid + 2 * ko[m], (uint32_t*)kid + 2 * ko[m] + nk[m],
                          (uint32_t*)dcol[m], (uint32_t*)dtp, s));
     if (nnz[m]) HIPCHK(hipMemcpyAsync((char*)kv + ko[m] * 32, dval[m], nnz[m] * 32, hipMemcpyDeviceToDevice, s));      // canonical values: converted with the whole array below
   }
   RC(index_scan_inclusive(c, (uint32_t*)dtp, n_h + 1, s));
-  RC(o->alloc(&dcur, (n_h + 1) * 4)); HIPCHK(hipMemcpyAsync(dcur, dtp, (n_h + 1) * 4, hipMemcpyDeviceToDevice, s));
+  RC(o->alloc(&dcur, (n_h + 1) * 4, true)); HIPCHK(hipMemcpyAsync(dcur, dtp, (n_h + 1) * 4, hipMemcpyDeviceToDevice, s));
   for (int m = 0; m < 3; ++m) RC(index_transpose_rows(c, (const uint32_t*)drp[m], (const uint32_t*)dcol[m], dval[m], n_constraints, (uint32_t)(m * n_h), (uint32_t*)dcur, (uint32_t*)dtcol, dtval, s));
   for (int m = 0; m < 2; ++m) RC(to_mont(dval[m], nnz[m]));
   V.a_row_ptr = drp[0]; V.a_col = dcol[0]; V.a_val = dval[0]; V.b_row_ptr = drp[1]; V.b_col = dcol[1]; V.b_val = dval[1];
@@ -176,7 +179,7 @@ int32_t varuna_index_build(Ctx* c, const PinnedBases& pb, std::shared_ptr<Pinned
   mark("index arithmetic (device)");
   // 1 / v_X on H \ X (v_X(w^p) = wx^p − 1, wx = w^|X|; zeros stay zero through the batch inversion), elements of H
   void *vx, *he;
-  RC(o->alloc(&vx, n_h * 32)); RC(o->alloc(&he, n_h * 32));
+  RC(o->alloc(&vx, n_h * 32)); RC(o->alloc(&he, n_h * 32, true));
   const HFr gen_h = domain_gen(n_h), wx = HFr::pow_u64(gen_h, n_x), neg1 = HFr::neg(one);
   RC(fr_powers(c, vx, n_h, one.l, wx.l, s)); RC(fr_lin(c, vx, n_h, neg1.l, one.l, vx, nullptr, nullptr, s)); RC(fr_batch_inverse(c, vx, n_h, s));
   RC(fr_powers(c, he, n_h, one.l, gen_h.l, s));
@@ -214,6 +217,7 @@ int32_t varuna_index_build(Ctx* c, const PinnedBases& pb, std::shared_ptr<Pinned
     RC(commit(c, pb, sg, 12, aff, s));
   }
   HIPCHK(hipStreamSynchronize(s));
+  o->free_tmp();                                           // nothing queued reads the scratch any more
   mark("12 commitments");
   o->vk.resize(12 * 48 + 40);
   RC(aleo_mi355x_g1_compress(o->vk.data(), aff, 12));
@@ -236,6 +240,7 @@ static constexpr size_t HC = 3;                            // coefficients of a 
 static constexpr size_t MAX_TOTAL_INSTANCES = 32, MAX_CIRCUITS = MAX_TOTAL_INSTANCES, MAX_INSTANCES = MAX_TOTAL_INSTANCES;      // one proof covers one transaction: at most 32 transitions, in any split over circuits
 static constexpr size_t PIN_SUMS = 8192, PIN_FLAG = 9216, PIN_SMALL_BYTES = 12288;      // small read-backs behind the staging area: evaluations / sigma values from 0 (<= 129 x 32 bytes), the circuits' sums over H, the canonical-input flag
 
+static int32_t lincomb_any(Ctx* c, char* dst, size_t n, const HFr& c0, std::vector<const void*>& terms, std::vector<size_t>& lens, std::vector<HFr>& co, hipStream_t s);
 struct Shared {
   Ctx* c; const PinnedBases& pb; Seed32 seed;
   Shared(Ctx* c_, const PinnedBases& pb_, const uint8_t* seed32) : c(c_), pb(pb_) { std::memcpy(seed.w, seed32, 32); }
@@ -401,9 +406,9 @@ int32_t Prover::second_round() {
   }
   char* q1 = E + 3 * n4 * 32;
   if (k > 1 || q0 != 0) {                                                 // sum_i c_i numerator_i (the proof's first instance has c = 1)
-    const void* terms[MAX_INSTANCES]; size_t lens[MAX_INSTANCES]; HFr co[MAX_INSTANCES];
-    for (size_t i = 0; i < k; ++i) { terms[i] = E + (3 + 3 * i) * n4 * 32; lens[i] = n4; co[i] = sh.comb[q0 + i]; }
-    RC(fr_lincomb(c, Q, n4, nullptr, terms, lens, co, k, s)); q1 = Q;
+    std::vector<const void*> terms(k); std::vector<size_t> lens(k, n4); std::vector<HFr> co(k);
+    for (size_t i = 0; i < k; ++i) { terms[i] = E + (3 + 3 * i) * n4 * 32; co[i] = sh.comb[q0 + i]; }
+    RC(lincomb_any(c, Q, n4, HFr::zero(), terms, lens, co, s)); q1 = Q;                     // 29..32 instances of one circuit: more terms than one fr_lincomb launch takes
   }
   RC(ntt_run(c, q1, lg_h + 2, 1, 0, 1, 0, s));
   if (lead()) RC(fr_vec_op(c, q1, q1, sh.mask, 3 * n_h, 1, s));                             // q = h (X^|H| − 1) + X g, degree < 3|H|; the mask rides with the largest domain
@@ -870,16 +875,6 @@ int32_t varuna_prove_batch(Ctx* c, const PinnedBases& pb, const aleo_mi355x_varu
 // at a barrier before and after each round's commitments, which worker 0 launches on the slot's stream behind an event of every helper stream.
 // A proof that fails (unsatisfied assignment, bad argument) drops out with its status; the others go on.  Byte for byte the proofs of the
 // single-proof entry points under the same seeds.
-namespace {
-struct Barrier {                                           // reusable; C++17 has none
-  std::mutex mu; std::condition_variable cv; size_t n, waiting = 0, phase = 0;
-  explicit Barrier(size_t n_) : n(n_) {}
-  void wait() {
-    std::unique_lock<std::mutex> lk(mu); const size_t ph = phase;
-    if (++waiting == n) { waiting = 0; ++phase; cv.notify_all(); } else cv.wait(lk, [&] { return phase != ph; });
-  }
-};
-}  // namespace
 
 int32_t varuna_prove_many(Ctx* c, const PinnedBases& pb, std::vector<ProveRequest>& rq, int workers) {
   g_varuna_timing[6] = g_varuna_timing[7] = 0;
@@ -950,10 +945,18 @@ int32_t varuna_prove_many(Ctx* c, const PinnedBases& pb, std::vector<ProveReques
     if (!round([](Batch& b, size_t) { return b.open_prepare(); }, nullptr)) return;
     each([&](Batch& b, size_t p) { b.sh.t_mark[5] = now_ms(); return b.write(rq[p].out, rq[p].out_len); });
   };
-  std::vector<std::thread> th;
-  for (size_t w = 1; w < W; ++w) th.emplace_back(worker, w);
-  worker(0);
+  // Helper threads wait at a gate until all of them exist: if one cannot be started, the ones that were leave at once (the barrier counts W threads) and
+  // the call fails as a whole instead of unwinding past joinable threads.
+  std::vector<std::thread> th; th.reserve(W); std::mutex gate_mu; std::condition_variable gate_cv; int gate = 0;      // 0 wait, 1 go, -1 leave
+  bool started = true;
+  for (size_t w = 1; w < W && started; ++w) {
+    try { th.emplace_back([&, w] { { std::unique_lock<std::mutex> g(gate_mu); gate_cv.wait(g, [&] { return gate != 0; }); if (gate < 0) return; } worker(w); }); }
+    catch (...) { started = false; }
+  }
+  { std::lock_guard<std::mutex> g(gate_mu); gate = started ? 1 : -1; } gate_cv.notify_all();
+  if (started) worker(0);
   for (auto& t : th) t.join();
+  if (!started) { g_last_error = "varuna_prove_many: could not start a worker thread"; return ALEO_MI355X_ERR_HIP; }
   for (size_t w = 1; w < W; ++w) (void)hipStreamSynchronize(wc[w]->stream);      // nothing of this call is left on a helper stream when it goes back to the pool
   if (fatal) { g_last_error = fatal_error; return fatal; }
   for (int i = 0; i < 5; ++i) g_varuna_timing[i] = 0;

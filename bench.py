@@ -47,11 +47,19 @@ def main():
                     help='with --config 4 and no launcher: ONE process drives --gpus N device contexts through aleo_mi355x_msm_g1_sharded (the visible devices are listed cyclically when there are fewer than N)')
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
                     help="'gloo' is only for rehearsing the N>1 path with several ranks sharing one GPU")
+    ap.add_argument('--launch-check', action='store_true',
+                    help='N > 1 plumbing only (runs without a GPU): spawn / rendezvous / the 144-byte gather / the max-over-ranks reduction under --backend gloo; prints a line with value null')
     args = ap.parse_args()
     if args.aux_sharded_ntt:
         raise SystemExit(aux_sharded_ntt(args))
     if args.in_process:
         raise SystemExit(in_process_sharded(args))
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # Plain `python bench.py --gpus N` (no torchrun): this process becomes the launcher.  It has not imported torch or touched HIP and never does
+        # (no exec either): it starts the N ranks as children, relays rank 0's JSON line and exits with the first non-zero child status.
+        raise SystemExit(spawn_ranks(args.gpus))
+    if args.launch_check:
+        raise SystemExit(launch_check(args))
 
     import torch
     import torch.distributed as dist
@@ -69,6 +77,8 @@ def main():
     gather_dev = dev if args.backend == 'nccl' else None       # RCCL gathers device tensors; gloo gathers host tensors
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        if args.backend == 'nccl' and int(os.environ.get('LOCAL_WORLD_SIZE', world)) > torch.cuda.device_count():
+            raise SystemExit('bench: %d local ranks but %d visible GPU(s): RCCL needs one GPU per rank (rehearse on one card with --backend gloo)' % (int(os.environ.get('LOCAL_WORLD_SIZE', world)), torch.cuda.device_count()))
         if args.backend == 'nccl':
             dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
         else:
@@ -196,7 +206,8 @@ def main():
              ('standalone 2^%d-point BLS12-377 G1 Pippenger MSM (BASELINE configs[1])' % (n.bit_length() - 1))
         out = {
             'metric': 'MSM G1 scalar-muls/sec (2^%d bases%s, BLS12-377, bit-exact)' % ((total.bit_length() - 1, ' total') if strong else (n.bit_length() - 1, ' per GPU')),
-            'value': value, 'unit': 'scalar-muls/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'value': value, 'unit': 'scalar-muls/s', 'n_gpus': world, 'ranks': world, 'rccl_ranks': (dist.get_world_size() if world > 1 and args.backend == 'nccl' else 0),
+            'backend': (args.backend if world > 1 else None), 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': ms_step, 'higher_is_better': True, 'scaling': 'strong' if strong else 'weak', 'vs_baseline': None, 'dtype': 'u32',
             'data': 'synthetic',
             'config': {'workload': wl, 'points_per_gpu': n, 'scalar_distribution': args.scalars,
@@ -269,6 +280,73 @@ def main():
                     print(line[-1] if line else json.dumps({'aux': 'sharded_ntt', 'error': 'probe exited with %d' % r.returncode, 'stderr_tail': r.stderr[-400:]}), file=sys.stderr, flush=True)
             except subprocess.TimeoutExpired:
                 print(json.dumps({'aux': 'sharded_ntt', 'error': 'timeout: the probe did not finish within 150 s (child killed)', 'rank': rank}), file=sys.stderr, flush=True)
+
+
+def spawn_ranks(n: int) -> int:
+    """The launcher half of `python bench.py --gpus N`: N child processes of this same command line, one per GPU, with RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_ADDR / MASTER_PORT set as torch.distributed.run would set them (rank 0 hosts the store on a free port of 127.0.0.1).  Rank 0's stdout is
+    relayed line by line (the ONE JSON line); the other ranks' stdout goes to stderr.  If a rank fails the others are ended (by their own PIDs) and
+    its status is returned; ALEO_BENCH_LAUNCH_TIMEOUT (seconds, default 3000) bounds the whole run."""
+    import socket, subprocess, threading
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0)); port = sk.getsockname()[1]
+    base = dict(os.environ, WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    base.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    cmd = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]
+    procs = []
+    for r in range(n):
+        env = dict(base, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE if r == 0 else sys.stderr, text=(r == 0)))
+
+    def relay():
+        for line in procs[0].stdout:
+            sys.stdout.write(line); sys.stdout.flush()
+    t = threading.Thread(target=relay, daemon=True); t.start()
+    deadline = time.time() + float(os.environ.get('ALEO_BENCH_LAUNCH_TIMEOUT', '3000'))
+    status = 0
+    while True:
+        codes = [p.poll() for p in procs]
+        bad = [c for c in codes if c not in (None, 0)]
+        if bad or all(c is not None for c in codes) or time.time() > deadline:
+            if bad: status = bad[0]
+            elif any(c is None for c in codes): status = 124; print('bench: launcher timeout', file=sys.stderr)
+            break
+        time.sleep(0.2)
+    for p in procs:                                            # only reached with live children after a failure / timeout
+        if p.poll() is None:
+            p.terminate()
+            try: p.wait(timeout=20)
+            except subprocess.TimeoutExpired: p.kill(); p.wait()
+    t.join(timeout=5)
+    return status
+
+
+def launch_check(args) -> int:
+    """bench.py --gpus N --backend gloo --launch-check: everything of the N > 1 path that is not arithmetic — the ranks meet, all-gather a 144-byte partial
+    each (PartialGather: the exchange of a point-sharded MSM), add nothing, reduce the elapsed time with MAX, and rank 0 prints a line with
+    n_gpus = N and value null.  Runs on a CPU box (tests/test_dist_cpu.py); it measures nothing."""
+    import torch
+    import torch.distributed as dist
+    from aleo_amd import dist as adist
+    rank = int(os.environ.get('RANK', '0')); world = int(os.environ.get('WORLD_SIZE', '1'))
+    if args.backend != 'gloo': raise SystemExit('--launch-check is the CPU rehearsal: use --backend gloo')
+    if world > 1: dist.init_process_group('gloo', rank=rank, world_size=world)
+    gather = adist.PartialGather(world, None) if world > 1 else None
+    part = np.full(18, rank + 1, dtype=np.uint64)
+    if world > 1: dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        rows = gather(part) if gather else part.reshape(1, 18)
+    if world > 1: dist.barrier()
+    el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    if world > 1: dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    ok = [int(r[0]) for r in np.asarray(rows).reshape(world, 18)] == list(range(1, world + 1))
+    if rank == 0:
+        print(json.dumps({'metric': 'launch check (no arithmetic)', 'value': None, 'unit': 'scalar-muls/s', 'n_gpus': world, 'ranks': dist.get_world_size() if world > 1 else 1,
+                          'rccl_ranks': 0, 'backend': args.backend, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': float(el.item()) / max(args.steps, 1) * 1e3,
+                          'gather_in_rank_order': ok, 'launch_check': True}), flush=True)
+    if world > 1: dist.barrier(); dist.destroy_process_group()
+    return 0 if ok else 1
 
 
 def _g1_times(P, k, q):
@@ -446,7 +524,7 @@ PROXY_NOTE = ('operator-level proxy for constraints/s (SURVEY.md §8d): the MSM/
 VARUNA_TAU, VARUNA_S = 0x1F3A9C0D5E7B24681357ACE02468BDF013579BDF02468ACE1234567, 0x0FEDCBA9876543210123456789ABCDEF55AA
 VARUNA_NOTE = ('aleo_mi355x_varuna_prove (one C call per proof): the four AHP rounds, evaluations and both KZG openings of one Marlin/Varuna-shaped proof for a synthetic satisfiable R1CS '
                '(every constraint multiplies two short linear combinations; a few wide rows), all circuit-sized work on the device through the C ABI; '
-               'SHA-256 transcript and synthetic SRS, so proofs are checked by the restatement in oracle/varuna_ref.py, not by snarkVM (DESIGN.md)')
+               'Poseidon-over-Fq transcript (upstream construction; absorb order recalled) and synthetic SRS, so proofs are checked by the restatement in oracle/varuna_ref.py, not by snarkVM (DESIGN.md)')
 
 
 def _varuna_instance(synth, lg, seed, bits=False, lagrange=False):

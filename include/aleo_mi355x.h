@@ -75,6 +75,11 @@ extern "C" {
 int32_t aleo_mi355x_init(int32_t n_devices);
 int32_t aleo_mi355x_init_device(int32_t device);
 int32_t aleo_mi355x_device_count(int32_t* visible, int32_t* initialised);
+/* aleo_mi355x_init also turns on direct peer access (xGMI) between every ordered pair of the devices initialised so far, so that the exchange of a
+ * sharded transform and the slice pulls of a sharded commitment are link-to-link copies; a pair the platform refuses is left to the runtime's staged
+ * copies (never an error).  peer_info: ordered pairs with direct access / refused so far (either pointer may be NULL).
+ * ABI note: since 0.2.0 `init` takes a device COUNT; 0.1.x callers that meant "select device d" call init_device(d). */
+int32_t aleo_mi355x_peer_info(int32_t* enabled_pairs, int32_t* refused_pairs);
 
 /* a1 — VariableBase::msm(bases: &[G1Affine], scalars: &[BigInteger256]) -> G1Projective.
  * Host pointers.  n = min(len(bases), len(scalars)) is the caller's job (the reference zips the slices).
@@ -311,8 +316,8 @@ int32_t aleo_mi355x_proof_to_bytes(void* out, size_t* len, const aleo_mi355x_pro
 
 /* ---- one proof in one call: the host side of Varuna::prove_batch, native (aleo_amd/csrc/varuna.hip) -------------------------------
  * Replaces the CPU work snarkVM 0.14.5 does in algorithms/src/snark/varuna/{varuna.rs, ahp/prover/round_functions} [UPSTREAM-RECALL]
- * under /root/reference/rust/src/program/execute.rs:74 and transfer.rs:99 — for one circuit with 1..32 instances, a SHA-256 transcript and
- * the committer key the caller pinned (DESIGN.md 4d lists what differs from upstream).  The index is the prover-key material of the
+ * under /root/reference/rust/src/program/execute.rs:74 and transfer.rs:99 — for one circuit with 1..32 instances, upstream's Fiat-Shamir construction (the Poseidon
+ * sponge over Fq, rate 2: aleo_mi355x_fs_* below) and the committer key the caller pinned (DESIGN.md 4d lists what differs from upstream).  The index is the prover-key material of the
  * circuit, built once (aleo_amd/varuna.py CircuitIndex does it through the entry points above) and described by device pointers:
  *   positions     host, uint32[n_vars]: index on H of every variable (public inputs on the subgroup X); positions_device: a copy in HBM (optional)
  *   a_*, b_*      device CSR of A, B with columns moved to positions on H and rows padded to n_h (uint32 row_ptr[n_h+1], col[], Montgomery val[])

@@ -108,3 +108,32 @@ def test_sharded_ntt_world2_gloo():
             assert (np.array(ev, dtype=np.uint64) == full[idx]).all(), (rank, coset)
         seen |= set(idx.reshape(-1).tolist())
     assert seen == set(range(1 << lg_n))          # the evaluation layout covers the domain exactly once
+
+
+@pytest.mark.timeout(300)
+def test_bench_starts_its_own_ranks_without_a_launcher():
+    """`python bench.py --gpus 2 ...` with no torchrun and no WORLD_SIZE in the environment (how the driver starts the N = 1 bench): the parent must
+    spawn the two ranks itself, stay off the GPU, relay rank 0's ONE JSON line with n_gpus = 2, and exit 0.  --launch-check keeps it arithmetic-free,
+    so it runs here; the same launcher with the real MSM step is a GPU test (tests/test_gpu_parity.py)."""
+    import json, subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_PORT')}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--backend', 'gloo', '--launch-check', '--steps', '2'],
+                       env=env, capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 2 and out['ranks'] == 2 and out['gather_in_rank_order'] and out['value'] is None
+
+
+@pytest.mark.timeout(300)
+def test_bench_launcher_reports_a_failing_rank():
+    """A rank that dies takes the launch down with its status instead of leaving the others at a barrier: without a GPU the real (non --launch-check)
+    step refuses to run in every rank, and the launcher must come back non-zero and print no JSON line."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_PORT')}
+    env['HIP_VISIBLE_DEVICES'] = ''; env['ROCR_VISIBLE_DEVICES'] = ''
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--backend', 'gloo', '--steps', '1', '--warmup', '0'],
+                       env=env, capture_output=True, text=True, timeout=240)
+    assert r.returncode != 0
+    assert not [l for l in r.stdout.splitlines() if l.startswith('{')]

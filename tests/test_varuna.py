@@ -859,3 +859,27 @@ def test_a_transaction_of_many_transitions_in_one_proof():
             for x in nx: x.close()
         finally:
             ck.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('k', [28, 29, 32])
+def test_one_circuit_with_up_to_32_instances_native(k):
+    """29..32 instances of ONE circuit: the second round's sum over c_i * numerator_i has more terms than one fr_lincomb launch takes (28) — the native
+    prover chains launches (lincomb_any) as the step-by-step host side always did.  Both host sides against the restatement's bytes, and its verifier."""
+    from aleo_amd import varuna
+    lim = lambda a: np.stack([synth.int_to_limbs(v, 4) for v in a])
+    cs, csrs, zs, D = _batch_case([(20, 2, 211, k)], seed=5 + k)
+    setup = V.Setup(TAU, S_GAMMA, D); idx = V.Index(cs[0], setup)
+    want = V.prove(idx, setup, zs[0], _rand(cs[0], 900 + k, k))[1]
+    ck = varuna.synthetic_committer_key(TAU, S_GAMMA, D)
+    try:
+        with varuna.NativeCircuitIndex(csrs[0], 20, 2, len(zs[0][0]) - 2, ck) as nx:
+            got = nx.prove([lim(z) for z in zs[0]], 900 + k)
+            assert got == want
+            assert V.verify(idx, setup, [z[:2] for z in zs[0]], got)
+            many = varuna.prove_many_native([([nx], [[lim(z) for z in zs[0]]], 900 + k)])      # the lockstep entry point takes the same path
+            assert many[0] == want
+        ix = varuna.CircuitIndex(csrs[0], 20, 2, len(zs[0][0]) - 2, ck)
+        assert varuna.prove_native(ix, [lim(z) for z in zs[0]], 900 + k) == want
+    finally:
+        ck.close()
