@@ -1197,11 +1197,11 @@ namespace aleo_mi355x {
 // scalars' own device) and multiplied there by the ordinary batched Pippenger against shard g's points and tables; what crosses back is k partial
 // results of 144 bytes per shard, added on the host in shard order.  The sum of normalised partials is normalised again, so the bytes are those of
 // the single-device commitment.
-int32_t commit_sharded(Ctx* c, uint64_t sharded_handle, const MsmSeg* segs, uint32_t nseg, uint32_t k, bool mont, uint64_t* out_jac18, hipStream_t s) {
+int32_t commit_sharded(Ctx* c, uint64_t sharded_handle, const MsmSeg* segs, uint32_t nseg, uint32_t k, bool mont, uint64_t* out_jac18, hipStream_t s, bool s_drain) {
   auto S = sharded_find(sharded_handle); if (!S) return ALEO_MI355X_ERR_BAD_HANDLE;
   const size_t G = S->devices.size(); const int home = c->device;
   for (uint32_t q = 0; q < nseg; ++q) if (segs[q].out >= k || segs[q].off + segs[q].len > S->n) { g_last_error = "commit_sharded: segment out of range"; return ALEO_MI355X_ERR_BAD_ARG; }
-  HIPCHK(hipStreamSynchronize(s));                           // the scalars are complete (and whatever the caller queued before the commitment has landed)
+  if (s_drain) HIPCHK(hipStreamSynchronize(s));              // the scalars are complete (and whatever the caller queued before the commitment has landed)
   std::vector<uint64_t> part((size_t)18 * k * G);
   std::vector<char> busy(G, 0);                              // shards that hold a piece of some segment
   for (size_t g = 0; g < G; ++g) for (uint32_t q = 0; q < nseg && !busy[g]; ++q) {
@@ -1266,7 +1266,7 @@ int32_t aleo_mi355x_kzg_commit_segments_sharded_device(void* out104, size_t n_ou
       sg[q].d_ptr = segs[q].scalars; sg[q].len = segs[q].len; sg[q].off = segs[q].base_offset; sg[q].out = segs[q].output;
     }
     std::vector<uint64_t> jac(18 * n_out);
-    const int32_t rc = commit_sharded(c, sharded_handle, sg.data(), (uint32_t)n_segs, (uint32_t)n_out, true, jac.data(), s);
+    const int32_t rc = commit_sharded(c, sharded_handle, sg.data(), (uint32_t)n_segs, (uint32_t)n_out, true, jac.data(), s, true);
     if (rc) return rc;
     jac_to_affine_rows(out104, jac.data(), n_out);
     return ALEO_MI355X_OK;

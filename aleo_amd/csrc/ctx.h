@@ -175,9 +175,9 @@ inline int32_t msm_run1(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, cons
 int32_t msm_batch(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, const MsmJob& job, hipStream_t s);
 // api.hip: the same request against a SHARDED copy of the base set (handle of aleo_mi355x_bases_pin_sharded): every segment is cut at the shard boundaries,
 // device g pulls its pieces of the scalar vectors from the calling thread's device (peer copies; same device: none) and runs msm_batch against its shard,
-// the G x k partial results are added on the host in shard order.  `s` (the stream the scalars were produced on) is synchronised first; the results are
+// the G x k partial results are added on the host in shard order.  `s` (the stream the scalars were produced on) is synchronised first when s_drain; the results are
 // normalised exactly like msm_batch's, so the bytes equal the single-device call's.  `c` is the caller's slot: shard work never waits for it.
-int32_t commit_sharded(Ctx* c, uint64_t sharded_handle, const MsmSeg* segs, uint32_t nseg, uint32_t k, bool mont, uint64_t* out_jac18, hipStream_t s);
+int32_t commit_sharded(Ctx* c, uint64_t sharded_handle, const MsmSeg* segs, uint32_t nseg, uint32_t k, bool mont, uint64_t* out_jac18, hipStream_t s, bool s_drain);
 // One result over n points, scalars on the device (host_src == nullptr) or still on the host (then d_scalars is ignored and the scalars are uploaded into the
 // contexts' staging buffers): host scalars from 2^21 points on go in two halves on two contexts — msm.hip msm_run1_split
 int32_t msm_run1_split(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, const void* d_scalars, size_t n, bool mont, hipStream_t s, bool sparse, const void* host_src);

@@ -85,6 +85,18 @@ static int32_t commit(Ctx* c, const PinnedBases& pb, const std::vector<MsmSeg>& 
   std::vector<uint64_t> jac(18 * (size_t)k);
   MsmJob j; j.segs = segs.data(); j.nseg = (uint32_t)segs.size(); j.k = k; j.mont = true; j.sparse = sparse;
   const double t0 = now_ms();
+  size_t points = 0; for (const MsmSeg& g : segs) points += g.len;
+  if (pb.shards && points >= pb.shard_min) {
+    // a sharded copy of the committer key is attached (row e2: a proof that spans devices): the coefficient vectors stay here, every device pulls its
+    // slices and runs its own Pippenger, 144 bytes per result and shard come back.  `s` is drained first (the scalars are complete), so the kernels of `behind` — which
+    // only read what the commitment reads and write fresh arena blocks — are queued at once and run on this device beside its own shard.
+    HIPCHK(hipStreamSynchronize(s));
+    if (behind) RC(behind());
+    RC(commit_sharded(c, pb.shards, segs.data(), (uint32_t)segs.size(), k, true, jac.data(), s, false));
+    jacobian_rows_to_affine104(out104, jac.data(), k);
+    g_varuna_timing[6] += now_ms() - t0;
+    return ALEO_MI355X_OK;
+  }
   {
     struct Clear { Ctx* c; ~Clear() { c->tail_hook = nullptr; } } clear{c};      // whatever happens below, no hook (it captures this proof's state) outlives the call
     c->tail_hook = std::move(behind);

@@ -54,6 +54,15 @@ class KZG10:
         return out
 
     @staticmethod
+    def commit_batch_sharded_device(sharded, d_ptrs, lens, stream: int = 0) -> np.ndarray:
+        """commit_batch_device against a sharded copy of the powers (aleo_mi355x_kzg_commit_batch_sharded_device)."""
+        k = len(d_ptrs)
+        ptrs = (ctypes.c_void_p * max(k, 1))(*[int(x) for x in d_ptrs]); ln = (ctypes.c_size_t * max(k, 1))(*[int(x) for x in lens])
+        out = np.zeros((k, 104), dtype=np.uint8)
+        check(lib().aleo_mi355x_kzg_commit_batch_sharded_device(_p(out), sharded.handle, ptrs, ln, k, ctypes.c_void_p(stream)), 'kzg_commit_batch_sharded_device')
+        return out
+
+    @staticmethod
     def open_device(powers: PinnedBases, d_poly_ptr: int, n: int, z_mont: np.ndarray, stream: int = 0):
         """KZG10::open (non-hiding): returns (w as snarkVM Affine uint8[104], p(z) as Montgomery uint64[4])."""
         z = np.ascontiguousarray(z_mont, dtype=np.uint64).reshape(4)
@@ -108,6 +117,15 @@ class SonicKZG10:
         out = np.zeros((k, 104), dtype=np.uint8)
         fn = lib().aleo_mi355x_kzg_commit_segments_sparse_device if sparse else lib().aleo_mi355x_kzg_commit_segments_device      # sparse: hint, see bases_precompute_range
         check(fn(_p(out), k, ck.bases.handle, arr, len(segments), ctypes.c_void_p(stream)), 'kzg_commit_segments_device')
+        return out
+
+    @staticmethod
+    def commit_segments_sharded_device(sharded, segments, k: int, stream: int = 0) -> np.ndarray:
+        """commit_segments_device against a SHARDED copy of the committer key (msm.ShardedBases): the vectors stay on the calling thread's device, every
+        shard's device pulls its pieces and runs its own Pippenger; 144 bytes per result and shard come back (aleo_mi355x_kzg_commit_segments_sharded_device)."""
+        arr = (_Segment * max(len(segments), 1))(*[_Segment(int(p_), int(n_), int(o_), int(q_)) for p_, n_, o_, q_ in segments])
+        out = np.zeros((k, 104), dtype=np.uint8)
+        check(lib().aleo_mi355x_kzg_commit_segments_sharded_device(_p(out), k, sharded.handle, arr, len(segments), ctypes.c_void_p(stream)), 'kzg_commit_segments_sharded_device')
         return out
 
     @staticmethod

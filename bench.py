@@ -723,12 +723,49 @@ def _varuna_big_once(synth, lg, bits, lagrange):
         ck.close()
 
 
+def varuna_sharded_rehearsal(synth, lg, shard_counts=(2, 8)):
+    """SURVEY.md 8 row e2 on ONE card: the 2^lg-constraint proof with a sharded copy of the committer key attached (every commitment of >= 2^16 points cut
+    over G shards, each with its own window tables; here all G on device 0, so this times the path — slices, per-shard Pippenger, host merge — not a
+    speed-up) against the single-device proof of the same seed: bytes must be equal."""
+    import aleo_amd
+    from aleo_amd import varuna
+    n, csr, z, zz, ck, D = _varuna_instance(synth, lg, 40 + lg)
+    out = {'constraints': n, 'min_points_routed_to_shards': 1 << 16, 'devices_visible': 1, 'note': 'all shards on one card: a rehearsal of the multi-device path, not a scaling measurement'}
+    try:
+        def timed(nx, k):
+            nx.prove([zz] * k, 5); ts = []
+            for rep in range(3):
+                t = time.perf_counter(); data = nx.prove([zz] * k, 30 + k); ts.append((time.perf_counter() - t) * 1e3)
+            return float(np.median(ts)), data
+        with varuna.NativeCircuitIndex(csr, n, 4, len(z) - 4, ck) as nx:
+            ms1, want1 = timed(nx, 1); ms8, want8 = timed(nx, 8)
+        out['single_device'] = {'prove_ms': ms1, 'instances_8_ms': ms8}
+        host = ck.bases.download()
+        for G in shard_counts:
+            t0 = time.perf_counter(); sb = aleo_amd.ShardedBases(host, devices=[0] * G, precompute=True); setup_s = time.perf_counter() - t0
+            try:
+                ck.bases.attach_shards(sb, 1 << 16)
+                with varuna.NativeCircuitIndex(csr, n, 4, len(z) - 4, ck) as nx:
+                    a1, d1 = timed(nx, 1); a8, d8 = timed(nx, 8)
+                if d1 != want1 or d8 != want8: raise SystemExit('bench: the proof against the sharded key differs from the single-device proof')
+                out['shards_%d' % G] = {'prove_ms': a1, 'instances_8_ms': a8, 'constraints_per_s_8': 8 * n / a8 * 1e3, 'pin_and_tables_s': setup_s, 'bytes_equal_single_device': True}
+            finally:
+                ck.bases.attach_shards(None); sb.close()
+        del host
+        return out
+    finally:
+        ck.close()
+
+
 def varuna_prove_big(synth, lg):
     """The same prover on a circuit the size of the headline MSM: key synthesis, one proof, eight instances in one proof (native entry points) — on the
     uniform synthetic circuit, and on the bit-heavy one with the Lagrange-basis powers pinned (commit_lagrange in the first round)."""
     out = _varuna_big_once(synth, lg, False, False)
     try: out['bit_heavy_witness_commit_lagrange'] = _varuna_big_once(synth, lg, True, True)
     except Exception as e: out['bit_heavy_witness_commit_lagrange'] = {'error': repr(e)[:300]}
+    try: out['sharded_rehearsal'] = varuna_sharded_rehearsal(synth, lg)
+    except SystemExit: raise
+    except Exception as e: out['sharded_rehearsal'] = {'error': repr(e)[:300]}
     return out
 
 

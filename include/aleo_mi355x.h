@@ -213,6 +213,20 @@ int32_t aleo_mi355x_kzg_commit_segments(void* out_affine104, size_t n_outputs, u
 int32_t aleo_mi355x_kzg_commit_segments_device(void* out_affine104, size_t n_outputs, uint64_t handle, const aleo_mi355x_commit_segment* segments, size_t n_segments, void* stream);
 /* the same with the hint that the scalars are sparse (mostly 0 / 1): served from the set's range table (bases_precompute_range) when all segments lie inside it */
 int32_t aleo_mi355x_kzg_commit_segments_sparse_device(void* out_affine104, size_t n_outputs, uint64_t handle, const aleo_mi355x_commit_segment* segments, size_t n_segments, void* stream);
+/* e2 — commitments, and whole proofs, over several devices of this process (BASELINE north_star: "large proofs shard MSM bases ... across the 8 GPUs";
+ * the reference's host is one process proving under spawn_blocking: /root/reference/rust/develop/src/routes.rs:119,149,229 -> rust/src/program/execute.rs:74).
+ * The committer key is pinned twice: whole on the prover's device (bases_pin / bases_from_scalars — without tables it costs 224 bytes per power) and as
+ * a sharded copy (bases_pin_sharded with precompute: each device holds 1/G of the powers and of the window tables, the part that needs the memory).
+ *   kzg_commit_segments_sharded_device / kzg_commit_batch_sharded_device: the segment / batch commitment of kzg_commit_segments_device against the SHARDED
+ *     set.  The coefficient vectors are device memory of the calling thread's current device; a segment [offset, offset + len) is cut at the shard
+ *     boundaries, device g pulls its pieces (hipMemcpyPeerAsync over xGMI; no copy on the vectors' own device) and runs the ordinary batched Pippenger
+ *     against its shard; n_outputs x 144 bytes per shard come back and are added on the host in shard order.  Same bytes as the single-device call.
+ *   bases_attach_shards(handle, sharded_handle, min_points): from then on every commitment the PROVER makes against `handle` (varuna_index_build,
+ *     varuna_prove*, the lockstep call) with at least min_points scalars in all goes through the sharded copy instead; the rounds' field work, the
+ *     transforms and the transcript stay on the prover's device.  Same proof bytes.  sharded_handle 0 detaches. */
+int32_t aleo_mi355x_kzg_commit_segments_sharded_device(void* out_affine104, size_t n_outputs, uint64_t sharded_handle, const aleo_mi355x_commit_segment* segments, size_t n_segments, void* stream);
+int32_t aleo_mi355x_kzg_commit_batch_sharded_device(void* out_affine104, uint64_t sharded_handle, const void* const* d_coeffs_mont, const size_t* lens, size_t k, void* stream);
+int32_t aleo_mi355x_bases_attach_shards(uint64_t handle, uint64_t sharded_handle, size_t min_points);
 
 /* KZG10::commit with a hiding bound: msm(powers, coeffs) + msm(gamma_powers, blinding_coeffs), affine result.
  * Both coefficient vectors are Montgomery Fr on the host; both base sets are pinned handles. */

@@ -883,3 +883,86 @@ def test_one_circuit_with_up_to_32_instances_native(k):
         assert varuna.prove_native(ix, [lim(z) for z in zs[0]], 900 + k) == want
     finally:
         ck.close()
+
+
+def _shard_the_key(ck, devices):
+    """A sharded copy (with window tables per shard) of a committer key's points, attached so that EVERY commitment of the prover goes through it."""
+    host = ck.bases.download()
+    sb = aleo_amd.ShardedBases(host, devices=devices, precompute=True)
+    ck.bases.attach_shards(sb, 0)
+    return sb
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('G', [2, 4, 8])
+def test_proofs_against_a_sharded_committer_key_equal_the_single_device_proofs(G):
+    """Row e2 (a proof that spans devices): with a sharded copy of the committer key attached, index commitments and every round's commitments are cut
+    at the shard boundaries, each shard's device (here the one card listed G times) pulls its slices of the coefficient vectors and runs its own
+    Pippenger, and the 144-byte partials are added on the host — the frozen fixtures (single proofs and proofs over several circuits), a lockstep call
+    and the verifying keys must come out byte for byte as from the single-device key."""
+    from aleo_amd import varuna
+    tau, sg, cases = _golden_cases()
+    for case in cases:
+        csr, zs, c = _golden_instance(case)
+        zq = [np.stack([synth.int_to_limbs(v, 4) for v in q]) for q in zs]
+        ck = varuna.synthetic_committer_key(tau, sg, case['max_degree'])
+        sb = _shard_the_key(ck, [0] * G)
+        try:
+            with varuna.NativeCircuitIndex(csr, case['n_constraints'], case['n_public'], len(zs[0]) - case['n_public'], ck, domains=case['domains']) as nx:
+                assert nx.vk_bytes.hex() == case['vk'] and nx.prove(zq, case['proof_seed']).hex() == case['proof']
+                assert varuna.prove_many_native([([nx], [zq], case['proof_seed'])] * 3) == [bytes.fromhex(case['proof'])] * 3
+        finally:
+            ck.bases.attach_shards(None); sb.close(); ck.close()
+    cases, batches = _golden_batches()
+    for b in batches:
+        ck = varuna.synthetic_committer_key(TAU, S_GAMMA, b['max_degree']); sb = _shard_the_key(ck, [0] * G); nx, za = [], []
+        try:
+            for j in b['members']:
+                case = cases[j]; csr, zs, c = _golden_instance(case)
+                nx.append(varuna.NativeCircuitIndex(csr, case['n_constraints'], case['n_public'], len(zs[0]) - case['n_public'], ck, domains=case['domains']))
+                za.append([np.stack([synth.int_to_limbs(v, 4) for v in q]) for q in zs])
+            assert varuna.prove_batch_native(nx, za, b['proof_seed']).hex() == b['proof']
+        finally:
+            for x in nx: x.close()
+            ck.bases.attach_shards(None); sb.close(); ck.close()
+
+
+@pytest.mark.gpu
+def test_a_2_18_constraint_proof_against_a_sharded_key():
+    """The size the sharding is for: 2^18 constraints (|K_A| = 2^20: commitments of up to 2^20 points), two instances, the key's 2^21 powers as 4 shards
+    with their own window tables — and only commitments of >= 2^16 points routed to them (min_points), the small ones stay on the prover's device.
+    Byte-equal to the single-device proof; and the segment entry point itself against the single-device commitment (degree bound + hiding segments
+    that straddle shard boundaries)."""
+    import torch
+    from aleo_amd import varuna
+    from aleo_amd.kzg import SonicKZG10
+    n = (1 << 18) - 64
+    csr, z = synth.synthetic_r1cs(n, 4, 618, long_rows=4)
+    zz = np.stack([synth.int_to_limbs(v, 4) for v in z])
+    D = (1 << 21) - 1
+    ck = varuna.synthetic_committer_key(TAU, S_GAMMA, D)
+    try:
+        with varuna.NativeCircuitIndex(csr, n, 4, len(z) - 4, ck) as nx:
+            vk0 = nx.vk_bytes; want = nx.prove([zz, zz], 4242)
+        sb = aleo_amd.ShardedBases(ck.bases.download(), devices=[0] * 4, precompute=True)
+        try:
+            # the entry point alone: three results, segments at offsets that cross shard boundaries (shard size 2^19 + 1)
+            m = 1 << 20
+            d = torch.from_numpy(util_uniform(3 * m + 8, 77).view(np.int64)).cuda(); torch.cuda.synchronize()
+            p0 = d.data_ptr()
+            segs = [(p0, m, 0, 0), (p0 + 32 * m, m - 5, D - (m - 6), 1), (p0 + 64 * m, (1 << 19) + 77, (1 << 19) - 33, 2), (p0 + 96 * m, 3, ck.gamma_offset, 2), (p0 + 96 * m + 96, 1, 0, 1)]
+            a = SonicKZG10.commit_segments_device(ck, segs, 3)
+            b = SonicKZG10.commit_segments_sharded_device(sb, segs, 3)
+            assert (a == b).all()
+            ck.bases.attach_shards(sb, 1 << 16)
+            with varuna.NativeCircuitIndex(csr, n, 4, len(z) - 4, ck) as nx:
+                assert nx.vk_bytes == vk0
+                assert nx.prove([zz, zz], 4242) == want
+        finally:
+            ck.bases.attach_shards(None); sb.close()
+    finally:
+        ck.close()
+
+
+def util_uniform(n, seed):
+    return synth.uniform_scalars(n, seed)
