@@ -97,6 +97,7 @@ static int32_t first_use(Ctx* c) {          // streams and events of a slot, cre
   if (c->stream) return ALEO_MI355X_OK;
   HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   HIPCHK(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+  { int lo = 0, hi = 0; (void)hipDeviceGetStreamPriorityRange(&lo, &hi); HIPCHK(hipStreamCreateWithPriority(&c->hi, hipStreamNonBlocking, hi)); }      // hi = the numerically lowest = highest priority
   for (auto& e : c->ev) HIPCHK(hipEventCreate(&e));
   HIPCHK(hipEventCreateWithFlags(&c->scratch_ev, hipEventDisableTiming));
   return ALEO_MI355X_OK;
@@ -218,9 +219,10 @@ static bool looks_sparse(const void* scalars, size_t n) {
   return small >= 129;
 }
 static int32_t msm_host_scalars(Ctx* c, void* out, const PinnedBases& pb, const void* scalars, size_t n, bool mont) {
-  const bool sparse = !mont && pb.range.d && pb.range_off == 0 && n <= pb.range.cover && looks_sparse(scalars, n);
+  const bool skewed = !mont && looks_sparse(scalars, n);          // witness-like: the few huge buckets (their slice trees beside the reduction) decide, not the upload — one chain
+  const bool sparse = skewed && pb.range.d && pb.range_off == 0 && n <= pb.range.cover;
   if (!n) return msm_run1(c, (uint64_t*)out, pb, nullptr, 0, mont, c->stream, false);
-  return msm_run1_split(c, (uint64_t*)out, pb, nullptr, n, mont, c->stream, sparse, scalars);      // uploads inside (whole, or in halves from 2^20 points on)
+  return msm_run1_split(c, (uint64_t*)out, pb, nullptr, n, mont, c->stream, sparse, scalars, !skewed);      // uploads inside (whole, or in two halves that share one reduction)
 }
 
 // ---- SRS cache for the one-shot entry point ----------------------------------------------------------
@@ -1035,8 +1037,8 @@ int32_t aleo_mi355x_last_msm_timing(double* out_ms, int32_t cap) {
   try {
     if (!out_ms || cap <= 0) return 0;
     const MsmTiming& t = g_last_msm;          // of the calling thread's most recent MSM
-    double v[6] = {t.total, t.sort, t.accum, t.reduce, t.host, t.accum_kernel};
-    int32_t k = cap < 6 ? cap : 6;
+    double v[7] = {t.total, t.sort, t.accum, t.reduce, t.host, t.accum_kernel, (double)t.accum_launches};
+    int32_t k = cap < 7 ? cap : 7;
     for (int32_t i = 0; i < k; ++i) out_ms[i] = v[i];
     return k;
   } catch (...) { return 0; }

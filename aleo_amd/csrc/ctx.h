@@ -93,7 +93,7 @@ struct SrsCacheEntry {
   std::vector<std::pair<size_t, uint64_t>> samples;      // (point index, hash of its 96 bytes)
 };
 
-struct MsmTiming { double total = 0, sort = 0, accum = 0, reduce = 0, host = 0, accum_kernel = 0; };
+struct MsmTiming { double total = 0, sort = 0, accum = 0, reduce = 0, host = 0, accum_kernel = 0; int accum_launches = 1; };      // accum_kernel: mean duration of the accum_launches launches of k_accum28
 
 struct NttTables;   // ntt.hip
 
@@ -121,6 +121,7 @@ struct Ctx {                           // one concurrency slot
   // the buffer is freed to grow.
   hipEvent_t scratch_ev = nullptr; bool scratch_busy = false;
   hipStream_t side = nullptr;          // second stream of the slot: small read-backs that must not wait for the kernels queued behind them
+  hipStream_t hi = nullptr;            // a high-priority stream: the sort of a later chunk must get its workgroups in while an earlier chunk's accumulation fills the chip (msm_run_merged)
 };
 
 int32_t scratch_acquire(Ctx* c, DevBuf& b, size_t bytes, hipStream_t s);
@@ -179,8 +180,8 @@ int32_t msm_batch(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, const MsmJ
 // normalised exactly like msm_batch's, so the bytes equal the single-device call's.  `c` is the caller's slot: shard work never waits for it.
 int32_t commit_sharded(Ctx* c, uint64_t sharded_handle, const MsmSeg* segs, uint32_t nseg, uint32_t k, bool mont, uint64_t* out_jac18, hipStream_t s, bool s_drain);
 // One result over n points, scalars on the device (host_src == nullptr) or still on the host (then d_scalars is ignored and the scalars are uploaded into the
-// contexts' staging buffers): host scalars from 2^21 points on go in two halves on two contexts — msm.hip msm_run1_split
-int32_t msm_run1_split(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, const void* d_scalars, size_t n, bool mont, hipStream_t s, bool sparse, const void* host_src);
+// contexts' staging buffers): host scalars from 2^19 points on go in two halves on two contexts that share one bucket reduction — msm.hip msm_run1_split
+int32_t msm_run1_split(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, const void* d_scalars, size_t n, bool mont, hipStream_t s, bool sparse, const void* host_src, bool may_merge = true);
 uint32_t msm_max_sets(const PinnedBases& pb, size_t n);
 int32_t launch_fq_mul(Ctx* c, void* r, const void* a, const void* b, size_t n);
 int32_t launch_fr_mul(Ctx* c, void* r, const void* a, const void* b, size_t n);

@@ -33,6 +33,8 @@
 #include <cstdlib>
 #include <atomic>
 #include <thread>
+#include <mutex>
+#include <condition_variable>
 #include <string>
 
 namespace aleo_mi355x {
@@ -500,11 +502,21 @@ __device__ __noinline__ void slice_slow_path28(const char* bases, const uint32_t
   *acc_out = acc; *inf_out = inf;
 }
 
-template <bool OUT28>
+// The bucket sums earlier launch chains of the SAME request left behind (msm_run_chunked: one MSM whose scalars arrive in chunks, every chunk sorted and
+// accumulated on its own, all chunks addressing the same buckets): newest first.  The first slice of bucket g in the current chunk starts from the newest
+// earlier sum of g instead of from its own first point, so after the last chunk a bucket's total sits in the newest chunk that touched it.
+struct FrontView { const char* partial; const uint32_t* hist; const uint2* scan_local; const uint2* scan_blk; };
+struct FrontChain { FrontView v[3]; uint32_t n = 0; };
+__device__ __forceinline__ const char* chain_sum(const FrontChain& ch, uint32_t g) {
+  for (uint32_t i = 0; i < ch.n; ++i) if (ch.v[i].hist[g]) return ch.v[i].partial + (size_t)scan_at(ch.v[i].scan_local, ch.v[i].scan_blk, g).y * 224u;
+  return nullptr;
+}
+
+template <bool OUT28, bool SEED = false>
 __global__ void __launch_bounds__(256) k_accum28(const char* __restrict__ bases, const uint32_t* __restrict__ sorted, const uint32_t* __restrict__ hist,
                                                  const uint2* __restrict__ scan_local, const uint2* __restrict__ scan_blk, const uint32_t* __restrict__ total_pairs, uint32_t M,
                                                  const uint32_t* __restrict__ meta, const uint32_t* __restrict__ order, const uint32_t* __restrict__ task_g,
-                                                 char* __restrict__ partial) {
+                                                 char* __restrict__ partial, FrontChain seed) {
   uint32_t t = blockIdx.x * 256 + threadIdx.x;
   if (t >= meta[0]) return;
   const uint32_t sid = order[t], g = task_g[sid];
@@ -516,7 +528,17 @@ __global__ void __launch_bounds__(256) k_accum28(const char* __restrict__ bases,
   F28 xn, yn; load_affine28(bases + (size_t)(e_next & 0x7fffffffu) * ROW28, xn, yn);      // next point's 112-byte gather in flight under the current addition
   XYZZ28 acc; bool ok = true;
   uint32_t j = j0;
-  {   // first point of the slice: acc = (x, +-y, 1, 1)
+  bool seeded = false;
+  if constexpr (SEED) {
+    // first slice of the bucket: continue from what the earlier chunks of this request summed into the same bucket (a stored point: Y may be loose,
+    // class L3 < 6q — one product by R brings it to the loop's invariant, exact digits < 2q); an empty or identity sum starts the usual way
+    const char* sp = k == 0 ? chain_sum(seed, g) : nullptr;
+    if (sp) {
+      acc.ZZ = load_f28(sp + 112);
+      if (!f28_is_zero_raw(acc.ZZ)) { acc.X = load_f28(sp); acc.Y = f28_mul(load_f28(sp + 56), f28_const(ONE28)); acc.ZZZ = load_f28(sp + 168); seeded = true; }
+    }
+  }
+  if (!seeded) {   // first point of the slice: acc = (x, +-y, 1, 1)
     uint32_t e = e_next; F28 x = xn, y = yn;
     if (j + 1 < j1) { e_next = run[j + 1]; load_affine28(bases + (size_t)(e_next & 0x7fffffffu) * ROW28, xn, yn); }
     if (e >> 31) y = f28_sub<2, 1>(f28_const(Limbs14{}), y);                            // 2q - y: limbs < 2^29
@@ -644,7 +666,7 @@ static constexpr uint32_t CHUNK_PAIRS = 128;        // chunks per 256-thread blo
 template <bool F28, uint32_t LANES = 2>
 __global__ void __launch_bounds__(256) k_bucket_chunks_pair(const char* __restrict__ partial, const uint32_t* __restrict__ hist, const uint2* __restrict__ scan_local,
                                                        const uint2* __restrict__ scan_blk, uint32_t B, uint32_t S, uint32_t nchunks_total, char* __restrict__ V,
-                                                       uint32_t v_set_stride, char* __restrict__ Vrun) {
+                                                       uint32_t v_set_stride, char* __restrict__ Vrun, FrontChain older) {
   constexpr uint32_t PB = PtFmt<F28>::BYTES, PW = PtFmt<F28>::WORDS;
   constexpr uint32_t CPB = 256 / LANES;                   // chunks per block
   __shared__ __attribute__((aligned(16))) uint32_t lds[2 * CPB * PW];
@@ -655,7 +677,7 @@ __global__ void __launch_bounds__(256) k_bucket_chunks_pair(const char* __restri
   pair_fence();
   const uint32_t cpw = B / S, w = t / cpw, j = t % cpw, g0 = w * B + j * S;
   // the address of bucket k + 1's sum (two dependent loads: histogram, scan) is fetched while bucket k's two additions run
-  auto sum_of = [&](uint32_t g) -> const char* { return hist[g] ? partial + (size_t)scan_at(scan_local, scan_blk, g).y * PB : nullptr; };
+  auto sum_of = [&](uint32_t g) -> const char* { return hist[g] ? partial + (size_t)scan_at(scan_local, scan_blk, g).y * PB : chain_sum(older, g); };      // older: buckets only earlier chunks of the request touched
   const char* nxt = sum_of(g0 + S - 1);
   for (uint32_t k = 0; k < S; ++k) {
     const char* cur = nxt;
@@ -676,7 +698,7 @@ static constexpr uint32_t CHUNK_QUADS = 64;         // chunks per 256-thread blo
 template <bool F28, uint32_t LANES = 2>
 __global__ void __launch_bounds__(256) k_bucket_chunks(const char* __restrict__ partial, const uint32_t* __restrict__ hist, const uint2* __restrict__ scan_local,
                                                        const uint2* __restrict__ scan_blk, uint32_t B, uint32_t S, uint32_t nchunks_total, char* __restrict__ V,
-                                                       uint32_t v_set_stride, char* __restrict__ Vrun) {
+                                                       uint32_t v_set_stride, char* __restrict__ Vrun, FrontChain older) {
   constexpr uint32_t PB = PtFmt<F28>::BYTES, PW = PtFmt<F28>::WORDS;
   constexpr uint32_t CPB = 128 / LANES;                  // chunks per block: two groups of LANES lanes each
   __shared__ __attribute__((aligned(16))) uint32_t lds[(3 * CPB + 1) * PW];
@@ -690,7 +712,7 @@ __global__ void __launch_bounds__(256) k_bucket_chunks(const char* __restrict__ 
   pair_fence();
   const uint32_t cpw = B / S, w = t / cpw, j = t % cpw, g0 = w * B + j * S;
   // the address of the next bucket's sum (two dependent loads: histogram, scan) is fetched one step ahead of the addition that uses it
-  auto sum_of = [&](uint32_t g) -> const char* { return hist[g] ? partial + (size_t)scan_at(scan_local, scan_blk, g).y * PB : zero; };
+  auto sum_of = [&](uint32_t g) -> const char* { if (hist[g]) return partial + (size_t)scan_at(scan_local, scan_blk, g).y * PB; const char* o = chain_sum(older, g); return o ? o : zero; };
   const char* nxt = sp ? zero : sum_of(g0 + S - 1);
   for (uint32_t k = 0; k <= S; ++k) {
     char* rprev = (k & 1) ? buf0 : buf1; char* rnext = (k & 1) ? buf1 : buf0;      // run_k lives in buf[k & 1]; run_{-1} = 0
@@ -1021,10 +1043,22 @@ int32_t msm_wait_meta(Ctx* c, const SortPhase& sp, hipStream_t s, SliceMeta* m) 
   return ALEO_MI355X_OK;
 }
 
-int32_t msm_run(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, const MsmJob& job, hipStream_t s) {
-  using namespace host;
-  const uint32_t K = job.k;
-  if (K == 0) return ALEO_MI355X_OK;
+// One launch chain in four steps, so that several chains — the chunks of one request whose scalars are still arriving — can share buckets and one
+// bucket reduction (msm_run_chunked below):
+//   msm_front_sort    checks, plan, sort, slice ordering — everything queued, nothing waited for
+//   msm_front_accum   the accumulation kernel (optionally behind an event, optionally seeded with the bucket sums of earlier chains)
+//   msm_front_finish  the slice metadata arrives (side stream), the slice trees follow: bucket b's sum is then the first slice of b
+//   msm_back          bucket reduction, host tail, phase times
+namespace {
+struct Front {
+  const PinnedBases::PreTable* T = nullptr; MsmPlan P{}; SortPhase sp; SliceMeta sm;
+  uint32_t K = 0, cpw = 0, nchunks = 0, lgN = 0, tseg = 0, fseg = 0, nseg = 0, setw = 0; size_t vpoints = 0;
+  bool pre = false, masked = false, aside = false, empty = false; const char* bases = nullptr;
+};
+}
+
+static int32_t msm_front_sort(Ctx* c, const PinnedBases& pb, const MsmJob& job, hipStream_t s, Front& f) {
+  const uint32_t K = f.K = job.k;
   size_t n = 0, pts = 0; SegArgs segs{};
   if (K > MAX_SETS || job.nseg > MAX_SEGS) { g_last_error = "msm: too many sets / segments in one call"; return ALEO_MI355X_ERR_BAD_ARG; }
   for (uint32_t q = 0; q < job.nseg; ++q) {
@@ -1035,7 +1069,7 @@ int32_t msm_run(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, const MsmJob
     segs.ptr[i] = (const char*)g.d_ptr; segs.n[i] = (uint32_t)g.len; segs.off[i] = (uint32_t)g.off; segs.set[i] = (uint8_t)g.out;
     n = g.off + g.len > n ? g.off + g.len : n; pts += g.len;
   }
-  if (n == 0) { for (uint32_t q = 0; q < K; ++q) hstore_jacobian_normalized(out_jac18 + 18 * q, HXYZZ::infinity()); return ALEO_MI355X_OK; }
+  if (n == 0) { f.empty = true; return ALEO_MI355X_OK; }
   if (job.tier_n > n && job.tier_n <= pb.n) n = job.tier_n;
   if (n > pb.n) { g_last_error = "msm: a segment reaches past the pinned bases"; return ALEO_MI355X_ERR_BAD_ARG; }
   // the fixed-base table serves any prefix of the pinned set (row stride = pinned count) as long as the prefix still
@@ -1049,43 +1083,56 @@ int32_t msm_run(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, const MsmJob
     for (uint32_t i = 0; i < segs.nseg; ++i) { segs.off[i] -= (uint32_t)pb.range_off; n = (size_t)segs.off[i] + segs.n[i] > n ? (size_t)segs.off[i] + segs.n[i] : n; }
     if (d_inf) d_inf += pb.range_off;
   } else for (const auto& t : pb.tab) if (t.d && n >= t.min_n && n <= t.cover) { T = &t; break; }
-  const bool pre = T != nullptr;
+  const bool pre = f.pre = T != nullptr; f.T = T;
   const uint32_t set_cap = ranged ? MAX_COARSE_ALL / ((1u << (pb.range.c - 1)) >> 8) : msm_max_sets(pb, n);
   if (K > 1 && (!pre || K > (set_cap < MAX_SETS ? set_cap : MAX_SETS))) { g_last_error = "msm: internal: batch without a table tier (or too many sets)"; return ALEO_MI355X_ERR_BAD_ARG; }
-  MsmPlan P = make_plan(pre ? n : pts, pre ? T->c : 0);
+  MsmPlan& P = f.P; P = make_plan(pre ? n : pts, pre ? T->c : 0);
   if (pre) { P.W = K; P.M = K * P.B; }                       // after the sort a set is "a window with its own buckets"
   if (!pre && !pb.d_xy28) { g_last_error = "msm: pinned set without 28-bit rows"; return ALEO_MI355X_ERR_HIP; }
-  const char* bases = (const char*)(pre ? T->d : pb.d_xy28);          // 112-byte rows either way
-  const uint32_t cpw = P.B / P.S, nchunks = cpw * P.W;
+  f.bases = (const char*)(pre ? T->d : pb.d_xy28);          // 112-byte rows either way
+  const uint32_t cpw = f.cpw = P.B / P.S, nchunks = f.nchunks = cpw * P.W;
   uint32_t lgN = 0; while ((1u << lgN) < cpw) ++lgN;
-  const bool masked = pre && lgN >= 2 && (1u << lgN) == cpw;          // fixed-base path: weights by masked trees
+  f.lgN = lgN;
+  const bool masked = f.masked = pre && lgN >= 2 && (1u << lgN) == cpw;          // fixed-base path: weights by masked trees
   if (pre && !masked) { g_last_error = "msm: internal: table path without masked reduction"; return ALEO_MI355X_ERR_HIP; }
   int32_t rc;
   // table path, per set: [acc of its cpw chunks | lgN masked sums of cpw/4] = (lgN + 4) segments of tseg points
-  const uint32_t tseg = cpw / 4, fseg = lgN + 4, nseg = K * fseg, setw = fseg * tseg;
-  const size_t vpoints = masked ? (size_t)K * setw + nchunks + (nseg + 1) + (size_t)nseg * (tseg / 2 + tseg / 4 + 2) + 3 * (size_t)nchunks + 64 : (size_t)nchunks + P.W;      // + the two buffers of the sum-tree passes (3 cpw / 2 points per set each)
+  const uint32_t tseg = f.tseg = cpw / 4, fseg = f.fseg = lgN + 4, nseg = f.nseg = K * fseg, setw = f.setw = fseg * tseg;
+  f.vpoints = masked ? (size_t)K * setw + nchunks + (nseg + 1) + (size_t)nseg * (tseg / 2 + tseg / 4 + 2) + 3 * (size_t)nchunks + 64 : (size_t)nchunks + P.W;      // + the two buffers of the sum-tree passes (3 cpw / 2 points per set each)
   if ((rc = ensure_host_pinned(c, 64 + (size_t)(masked ? nseg : P.W) * 224 + ASIDE_MAX * 228))) return rc;      // before the sort phase: its read-back lands in this buffer
-  SortPhase sp;
+  SortPhase& sp = f.sp;
   if ((rc = msm_sort_phase(c, segs, pts, job.mont, d_inf, (uint32_t)(pre ? T->cover : pb.n), P, pre, s, &sp))) return rc;
   const uint32_t M = sp.M;
   if ((rc = c->partial.reserve(sp.slices_max * (pre ? 224 : 192)))) return rc;
-  if ((rc = c->vbuf.reserve(vpoints * 224))) return rc;
-  uint32_t* hist = sp.hist; uint32_t* heavy = sp.heavy; uint32_t* meta = sp.meta; uint2* scan_local = sp.scan_local; uint2* scan_blk = sp.scan_blk;
-  const uint32_t* total_pairs = sp.total_pairs;
+  if ((rc = c->vbuf.reserve(f.vpoints * 224))) return rc;
+  return ALEO_MI355X_OK;
+}
+
+// seed: bucket sums of the request's earlier chunks (table path only), complete once `after` has been reached
+static int32_t msm_front_accum(Ctx* c, hipStream_t s, Front& f, const FrontChain* seed, hipEvent_t after) {
+  const SortPhase& sp = f.sp; const uint32_t M = sp.M; const char* bases = f.bases;
   char* partial = c->partial.as<char>();
-  char* V = c->vbuf.as<char>(); char* Vout = V + (size_t)nchunks * 192;
+  if (after) HIPCHK(hipStreamWaitEvent(s, after, 0));
   HIPCHK(hipEventRecord(c->ev[6], s));          // ev[6]..ev[5] bracket k_accum28 alone (bench.py's roofline kernel)
-  if (pre) hipLaunchKernelGGL(k_accum28<true>, dim3(sp.slice_blocks), dim3(256), 0, s, bases, sp.sorted, hist, scan_local, scan_blk, total_pairs, M, meta, sp.order, sp.task_g, partial);
-  else hipLaunchKernelGGL(k_accum28<false>, dim3(sp.slice_blocks), dim3(256), 0, s, bases, sp.sorted, hist, scan_local, scan_blk, total_pairs, M, meta, sp.order, sp.task_g, partial);
+  if (f.pre && seed && seed->n) hipLaunchKernelGGL((k_accum28<true, true>), dim3(sp.slice_blocks), dim3(256), 0, s, bases, sp.sorted, sp.hist, sp.scan_local, sp.scan_blk, sp.total_pairs, M, sp.meta, sp.order, sp.task_g, partial, *seed);
+  else if (f.pre) hipLaunchKernelGGL(k_accum28<true>, dim3(sp.slice_blocks), dim3(256), 0, s, bases, sp.sorted, sp.hist, sp.scan_local, sp.scan_blk, sp.total_pairs, M, sp.meta, sp.order, sp.task_g, partial, FrontChain{});
+  else hipLaunchKernelGGL(k_accum28<false>, dim3(sp.slice_blocks), dim3(256), 0, s, bases, sp.sorted, sp.hist, sp.scan_local, sp.scan_blk, sp.total_pairs, M, sp.meta, sp.order, sp.task_g, partial, FrontChain{});
   HIPCHK(hipEventRecord(c->ev[5], s));
   HIPCHK(hipGetLastError());
-  SliceMeta sm;
+  return ALEO_MI355X_OK;
+}
+
+static int32_t msm_front_finish(Ctx* c, hipStream_t s, Front& f, bool allow_aside) {
+  int32_t rc;
+  const SortPhase& sp = f.sp; SliceMeta& sm = f.sm; const uint32_t M = sp.M; const bool pre = f.pre;
+  uint32_t* heavy = sp.heavy; uint32_t* meta = sp.meta; uint2* scan_local = sp.scan_local; uint2* scan_blk = sp.scan_blk;
+  char* partial = c->partial.as<char>();
   if ((rc = msm_wait_meta(c, sp, s, &sm))) return rc;
   // A handful of super-heavy buckets (witness-like scalars: the digit-1 bucket of the lowest window holds a fifth of the points) have a slice tree of
   // 10+ dependent levels while the common list is done after 4.  Then the long trees run ASIDE, on the slot's side stream, over slices 1.. of their
   // buckets; the reduction below goes ahead with slice 0 as those buckets' sums, and the host adds (b + 1) * (sum of slices 1..) to the result.
-  const bool aside = masked && aside_on() && sm.n_super >= 1 && sm.n_super <= ASIDE_MAX && !sm.super_overflow && sm.max_m >= 64;
-  uint32_t* h_aside = (uint32_t*)((char*)c->h_pinned + 64 + (size_t)nseg * 224);
+  const bool aside = f.aside = allow_aside && f.masked && aside_on() && sm.n_super >= 1 && sm.n_super <= ASIDE_MAX && !sm.super_overflow && sm.max_m >= 64;
+  uint32_t* h_aside = (uint32_t*)((char*)c->h_pinned + 64 + (size_t)f.nseg * 224);
   if (aside) {
     HIPCHK(hipStreamWaitEvent(c->side, c->ev[5], 0));
     for (uint32_t pass = 0, L = sm.max_m - 1; L > 1; ++pass, L = (L + 1) >> 1) {
@@ -1114,6 +1161,19 @@ int32_t msm_run(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, const MsmJob
     }
   }
   HIPCHK(hipEventRecord(c->ev[2], s));
+  return ALEO_MI355X_OK;
+}
+
+// older: the earlier chunks of the same request (msm_run_chunked) — a bucket this chain did not touch keeps its sum there
+static int32_t msm_back(Ctx* c, uint64_t* out_jac18, Front& f, hipStream_t s, bool fire_tail, const FrontChain& older) {
+  using namespace host;
+  const MsmPlan& P = f.P; const SortPhase& sp = f.sp; const SliceMeta& sm = f.sm;
+  const uint32_t K = f.K, cpw = f.cpw, nchunks = f.nchunks, lgN = f.lgN, tseg = f.tseg, fseg = f.fseg, nseg = f.nseg, setw = f.setw;
+  const bool masked = f.masked, aside = f.aside;
+  uint32_t* hist = sp.hist; uint2* scan_local = sp.scan_local; uint2* scan_blk = sp.scan_blk;
+  char* partial = c->partial.as<char>();
+  char* V = c->vbuf.as<char>(); char* Vout = V + (size_t)nchunks * 192;
+  uint32_t* h_aside = (uint32_t*)((char*)c->h_pinned + 64 + (size_t)nseg * 224);
   std::chrono::steady_clock::time_point t_host0;
   char* h_win = (char*)c->h_pinned + 64;
   auto lazy_point = [&](const char* p) {
@@ -1154,11 +1214,11 @@ int32_t msm_run(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, const MsmJob
     // at 2^20; S = 8 / 32 / 4 with either form: 0.51-0.54 / 0.48-0.55 / 0.66-0.72 ms (ALEO_MI355X_CHUNK_S, ALEO_MI355X_CHUNK_FORM=1: A/B switches)
     static const bool wide_two_groups = [] { const char* e = std::getenv("ALEO_MI355X_CHUNK_FORM"); return !(e && e[0] == '1'); }();
     if (P.c >= 20 && !wide_two_groups) {
-      if (grp_lanes(2 * (uint64_t)nchunks) == 4) hipLaunchKernelGGL((k_bucket_chunks_pair<true, 4>), dim3((nchunks + 63) / 64), dim3(256), 0, s, partial, hist, scan_local, scan_blk, P.B, P.S, nchunks, V, setw, Vrun);
-      else hipLaunchKernelGGL(k_bucket_chunks_pair<true>, dim3((nchunks + CHUNK_PAIRS - 1) / CHUNK_PAIRS), dim3(256), 0, s, partial, hist, scan_local, scan_blk, P.B, P.S, nchunks, V, setw, Vrun);
+      if (grp_lanes(2 * (uint64_t)nchunks) == 4) hipLaunchKernelGGL((k_bucket_chunks_pair<true, 4>), dim3((nchunks + 63) / 64), dim3(256), 0, s, partial, hist, scan_local, scan_blk, P.B, P.S, nchunks, V, setw, Vrun, older);
+      else hipLaunchKernelGGL(k_bucket_chunks_pair<true>, dim3((nchunks + CHUNK_PAIRS - 1) / CHUNK_PAIRS), dim3(256), 0, s, partial, hist, scan_local, scan_blk, P.B, P.S, nchunks, V, setw, Vrun, older);
     } else {
-      if (grp_lanes(2 * (uint64_t)nchunks) == 4) hipLaunchKernelGGL((k_bucket_chunks<true, 4>), dim3((nchunks + 31) / 32), dim3(256), 0, s, partial, hist, scan_local, scan_blk, P.B, P.S, nchunks, V, setw, Vrun);
-      else hipLaunchKernelGGL(k_bucket_chunks<true>, dim3((nchunks + CHUNK_QUADS - 1) / CHUNK_QUADS), dim3(256), 0, s, partial, hist, scan_local, scan_blk, P.B, P.S, nchunks, V, setw, Vrun);
+      if (grp_lanes(2 * (uint64_t)nchunks) == 4) hipLaunchKernelGGL((k_bucket_chunks<true, 4>), dim3((nchunks + 31) / 32), dim3(256), 0, s, partial, hist, scan_local, scan_blk, P.B, P.S, nchunks, V, setw, Vrun, older);
+      else hipLaunchKernelGGL(k_bucket_chunks<true>, dim3((nchunks + CHUNK_QUADS - 1) / CHUNK_QUADS), dim3(256), 0, s, partial, hist, scan_local, scan_blk, P.B, P.S, nchunks, V, setw, Vrun, older);
     }
     // Measured (ALEO_MI355X_SUM_TREE=0 is the A/B switch; ALEO_MI355X_SUM_TREE_MIN_C limits it to the wider tables): reduce phase of the 2^20 MSM 0.464 -> 0.412 ms at
     // S = 16 (S = 8: 0.537 -> 0.451, S = 4: 0.720 -> 0.508: the chunk kernel is bound by its 2 additions per bucket, not by their order, so smaller chunks still lose);
@@ -1214,7 +1274,7 @@ int32_t msm_run(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, const MsmJob
     }
     }
     HIPCHK(hipEventRecord(c->ev[3], s));
-    if (job.fire_tail && c->tail_hook) {
+    if (fire_tail && c->tail_hook) {
       // the caller's next kernels go behind the fold; the host waits for the fold only (its result sits in pinned memory) and does the tail below while they run
       std::function<int32_t()> hook = std::move(c->tail_hook); c->tail_hook = nullptr;
       const int32_t hrc = hook();
@@ -1276,6 +1336,67 @@ int32_t msm_run(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, const MsmJob
   return ALEO_MI355X_OK;
 }
 
+int32_t msm_run(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, const MsmJob& job, hipStream_t s) {
+  if (job.k == 0) return ALEO_MI355X_OK;
+  Front f; int32_t rc;
+  if ((rc = msm_front_sort(c, pb, job, s, f))) return rc;
+  if (f.empty) { for (uint32_t q = 0; q < job.k; ++q) host::hstore_jacobian_normalized(out_jac18 + 18 * q, host::HXYZZ::infinity()); return ALEO_MI355X_OK; }
+  if ((rc = msm_front_accum(c, s, f, nullptr, nullptr))) return rc;
+  if ((rc = msm_front_finish(c, s, f, true))) return rc;
+  return msm_back(c, out_jac18, f, s, job.fire_tail, FrontChain{});
+}
+
+// ONE result from HOST scalars, uploaded and processed in Q chunks that share the buckets and one bucket reduction.  The upload (32 bytes per scalar at the
+// link's rate: 0.6 ms of a 3.5 ms call at 2^20) cannot hide under the sort of the same scalars, but a later chunk's upload and sort can run under an
+// earlier chunk's accumulation.  Chunk k goes up and through its own sort on its own context (chunk 0 on the caller's, the others on borrowed ones,
+// on their high-priority streams: their sorts must get workgroups in while an accumulation fills the chip); its accumulation starts when chunk k - 1's
+// bucket sums are final and is SEEDED with them (k_accum28<.., SEED>: the first slice of a bucket continues from the newest earlier sum of that bucket),
+// so after the last chunk every bucket's total sits in the newest chunk that touched it and ONE reduction (+ host tail) follows, reading through the
+// chain.  All chunks use the window of the whole request.  The chunks grow — each must hide its upload + sort under its predecessor's accumulation,
+// which costs ~ 3x as much per point: 2 chunks of 37 / 63 % up to 2^20 points, 3 of 18 / 30 / 52 % beyond.  A copy from pageable memory keeps the calling
+// thread inside the runtime until the bytes are staged, so the order of the calls below IS the schedule: copy, launches, next copy.
+// Measured (2^20 points, host scalars, wall per call; one whole upload: 3.50 ms): this form 3.23 (2^21: 6.51 -> 5.49, 2^22: 12.37 -> 9.84 with three chunks);
+// two halves with a merge kernel (2^19 lane-pair additions into a dense array) before the reduction 3.28; the copies from a thread of their own: no
+// change; every kernel on ONE stream with only the copies beside it 3.74 — each extra sort costs ~0.17 ms of dependent ~10 us launches when nothing
+// hides it.  What is left on the table: a sort queued beside an accumulation that holds every wave slot (248 VGPRs x 2 waves per SIMD, workgroups that
+// live ~250 us) takes ~0.5 ms instead of 0.15, so the next accumulation starts ~0.2 ms late.
+// (Round 3 ran two halves as two complete MSMs on two host threads: that paid the 0.4 ms bucket reduction twice and lost below 2^21 points.)
+static int32_t msm_run_chunked(Ctx* c, HelperSet& hs, uint64_t* out_jac18, const PinnedBases& pb, size_t n, bool mont, hipStream_t s, const void* host_src) {
+  const uint32_t Q = 1 + (uint32_t)hs.ctx.size();           // 2 or 3
+  static const uint32_t share[4][3] = {{0, 0, 0}, {0, 0, 0}, {37, 63, 0}, {18, 30, 52}};
+  Ctx* cx[3] = {c, Q > 1 ? hs.ctx[0] : nullptr, Q > 2 ? hs.ctx[1] : nullptr}; hipStream_t st[3] = {s, Q > 1 ? hs.ctx[0]->hi : nullptr, Q > 2 ? hs.ctx[1]->hi : nullptr};
+  size_t lo[4] = {0, 0, 0, 0};
+  for (uint32_t k = 0, acc = 0; k < Q; ++k) { acc += share[Q][k]; lo[k + 1] = k + 1 == Q ? n : (((size_t)((double)n * acc / 100.0)) + 255) & ~(size_t)255; if (lo[k + 1] > n) lo[k + 1] = n; }
+  Front f[3]; MsmSeg seg[3]; int32_t rc;
+  auto drain = [&](int32_t code) { const std::string keep = g_last_error; for (uint32_t k = 0; k < Q; ++k) (void)hipStreamSynchronize(st[k]); g_last_error = keep; return code; };
+  auto view = [&](uint32_t k) { return FrontView{cx[k]->partial.as<char>(), f[k].sp.hist, f[k].sp.scan_local, f[k].sp.scan_blk}; };
+  auto chain_before = [&](uint32_t k) { FrontChain ch; for (uint32_t i = k; i-- > 0;) ch.v[ch.n++] = view(i); return ch; };      // newest first
+  for (uint32_t k = 0; k < Q; ++k) {
+    const size_t len = lo[k + 1] - lo[k];
+    if ((rc = cx[k]->scalars_stage.reserve((len ? len : 1) * 32))) return drain(rc);
+    if (hipMemcpyAsync(cx[k]->scalars_stage.p, (const char*)host_src + lo[k] * 32, len * 32, hipMemcpyHostToDevice, st[k]) != hipSuccess) { g_last_error = "msm: upload of a chunk failed"; return drain(ALEO_MI355X_ERR_HIP); }
+    seg[k].d_ptr = cx[k]->scalars_stage.p; seg[k].len = len; seg[k].off = lo[k];
+    MsmJob j; j.segs = &seg[k]; j.nseg = 1; j.k = 1; j.mont = mont; j.tier_n = n;
+    if ((rc = msm_front_sort(cx[k], pb, j, st[k], f[k]))) return drain(rc);
+    if (f[k].empty || !f[k].masked || f[k].P.c != f[0].P.c || f[k].sp.M != f[0].sp.M) { g_last_error = "msm: internal: chunks without a shared table window"; return drain(ALEO_MI355X_ERR_HIP); }
+    if (k) { if ((rc = msm_front_finish(cx[k - 1], st[k - 1], f[k - 1], false))) return drain(rc); }      // chunk k - 1's slice trees: its bucket sums are final at its ev[2]
+    const FrontChain seed = chain_before(k);
+    if ((rc = msm_front_accum(cx[k], st[k], f[k], &seed, k ? cx[k - 1]->ev[2] : nullptr))) return drain(rc);
+  }
+  if ((rc = msm_front_finish(cx[Q - 1], st[Q - 1], f[Q - 1], false))) return drain(rc);
+  // the reduction runs where the newest sums are; it synchronises that stream, behind which (event by event) every earlier chunk has finished
+  if ((rc = msm_back(cx[Q - 1], out_jac18, f[Q - 1], st[Q - 1], false, chain_before(Q - 1)))) return drain(rc);
+  HIPCHK(hipStreamSynchronize(s));
+  MsmTiming tm = cx[Q - 1]->last_msm; float ms = 0, kern = 0;
+  for (uint32_t k = 0; k < Q; ++k) { HIPCHK(hipEventElapsedTime(&ms, cx[k]->ev[6], cx[k]->ev[5])); kern += ms; }
+  tm.accum_kernel = kern / Q; tm.accum_launches = (int)Q;
+  HIPCHK(hipEventElapsedTime(&ms, c->ev[0], c->ev[1])); tm.sort = ms;                        // the first chunk's sort: the one nothing hides
+  HIPCHK(hipEventElapsedTime(&ms, c->ev[1], cx[Q - 1]->ev[2])); tm.accum = ms;               // from there to the last chunk's final bucket sums
+  tm.total = tm.sort + tm.accum + tm.reduce + tm.host;
+  c->last_msm = tm; g_last_msm = tm;
+  return ALEO_MI355X_OK;
+}
+
 
 // Arbitrary request: k results, each the sum of its segments.  Results are grouped by the table tier the bases they reach select
 // (longest tier first) and every group goes through msm_run in chunks of msm_max_sets() results / MAX_SEGS segments; results no tier
@@ -1323,62 +1444,23 @@ static int32_t run_chains(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, st
   return ALEO_MI355X_OK;
 }
 
-// A single big result in two halves.  The second half runs on a borrowed helper context from a second host thread: its upload (host scalars) goes under
-// the first half's sort and accumulation, its sort under the first half's accumulation, and the first half's bucket reduction — latency-bound, a
-// fraction of the chip — under the second half's accumulation.  Both halves use the window of the whole request (tier_n); the two partial results are
-// added on the host.  Measured: HOST scalars 2^22 12.49 -> 11.20 ms (half of the 128-MB upload disappears), 2^20 3.52 -> 3.45 ms (within noise of the
-// thread it costs); scalars already on the DEVICE lose — 2^20 2.77 -> 3.12 ms, 2^22 9.48 -> 9.91 ms: nothing was idle to fill, and two half-size
-// requests pay the sort ramp and the bucket reduction twice.  So: host scalars from 2^21 points on, device scalars never.
-// ALEO_MI355X_SPLIT_MIN_LG (default 21, 0 = never) is the A/B switch.
-static uint32_t split_min_lg() { static const uint32_t v = [] { const char* e = std::getenv("ALEO_MI355X_SPLIT_MIN_LG"); const int k = e ? std::atoi(e) : 21; return (uint32_t)(k >= 0 && k <= 30 ? k : 21); }(); return v; }
-int32_t msm_run1_split(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, const void* d_scalars, size_t n, bool mont, hipStream_t s, bool sparse, const void* host_src) {
+// One result over n points.  Scalars already on the device: one launch chain.  HOST scalars against a table tier, from 2^ALEO_MI355X_MERGE_MIN_LG points
+// (default 19; 0 = never): two or three chunks on as many contexts that share the buckets and one bucket reduction (msm_run_chunked) — most of the upload
+// disappears under the earlier chunks' kernels.  Smaller or table-less requests upload whole.
+static uint32_t chunks3_min_lg() { static const uint32_t v = [] { const char* e = std::getenv("ALEO_MI355X_CHUNKS3_MIN_LG"); const int k = e ? std::atoi(e) : 21; return (uint32_t)(k >= 0 && k <= 40 ? k : 21); }(); return v; }      // three chunks from here on (40 = never)
+static uint32_t merge_min_lg() { static const uint32_t v = [] { const char* e = std::getenv("ALEO_MI355X_MERGE_MIN_LG"); const int k = e ? std::atoi(e) : 19; return (uint32_t)(k >= 0 && k <= 30 ? k : 19); }(); return v; }
+int32_t msm_run1_split(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, const void* d_scalars, size_t n, bool mont, hipStream_t s, bool sparse, const void* host_src, bool may_merge) {
   bool tiered = false;
   for (const auto& t : pb.tab) if (t.d && n >= t.min_n && n <= t.cover) tiered = true;
   HelperSet hs;
-  if (host_src && !sparse && tiered && split_min_lg() && n >= ((size_t)1 << split_min_lg()) && c->dev) { const int32_t rc = acquire_helpers(c->dev, 1, hs); if (rc) return rc; }
-  if (hs.ctx.empty()) {
-    if (host_src) {
-      const int32_t rc = c->scalars_stage.reserve((n ? n : 1) * 32); if (rc) return rc;
-      if (n) HIPCHK(hipMemcpyAsync(c->scalars_stage.p, host_src, n * 32, hipMemcpyHostToDevice, s));
-      d_scalars = c->scalars_stage.p;
-    }
-    return msm_run1(c, out_jac18, pb, d_scalars, n, mont, s, sparse);
-  }
-  Ctx* h = hs.ctx[0];
-  const size_t na = (n / 2 + 255) & ~(size_t)255, nb = n - na;
-  uint64_t part[36]; int32_t rc_h = ALEO_MI355X_OK; std::string err_h;
-  auto half = [&](Ctx* cc, hipStream_t st, const void* d_ptr, size_t len, size_t off, uint64_t* out) -> int32_t {
-    MsmSeg g; g.d_ptr = d_ptr; g.len = len; g.off = off;
-    MsmJob j; j.segs = &g; j.nseg = 1; j.k = 1; j.mont = mont; j.tier_n = n;
-    return msm_run(cc, out, pb, j, st);
-  };
-  const void* pa = d_scalars; const void* pbp = (const char*)d_scalars + na * 32;
+  if (host_src && may_merge && !sparse && tiered && merge_min_lg() && n >= ((size_t)1 << merge_min_lg()) && c->dev) { const int32_t rc = acquire_helpers(c->dev, n >= ((size_t)1 << chunks3_min_lg()) ? 2 : 1, hs); if (rc) return rc; }
+  if (!hs.ctx.empty()) return msm_run_chunked(c, hs, out_jac18, pb, n, mont, s, host_src);
   if (host_src) {
-    int32_t rc = c->scalars_stage.reserve(na * 32); if (rc) return rc;
-    if ((rc = h->scalars_stage.reserve(nb * 32))) return rc;
-    HIPCHK(hipMemcpyAsync(c->scalars_stage.p, host_src, na * 32, hipMemcpyHostToDevice, s));      // pageable memory: returns once the bytes are staged — the second upload follows it on the wire
-    pa = c->scalars_stage.p; pbp = h->scalars_stage.p;
-  } else {
-    HIPCHK(hipEventRecord(c->ev[4], s));                   // the scalars may still be in flight on the caller's stream
-    HIPCHK(hipStreamWaitEvent(h->stream, c->ev[4], 0));
+    const int32_t rc = c->scalars_stage.reserve((n ? n : 1) * 32); if (rc) return rc;
+    if (n) HIPCHK(hipMemcpyAsync(c->scalars_stage.p, host_src, n * 32, hipMemcpyHostToDevice, s));
+    d_scalars = c->scalars_stage.p;
   }
-  std::thread helper([&] {
-    try {
-      if (hipSetDevice(c->device) != hipSuccess) { rc_h = ALEO_MI355X_ERR_HIP; err_h = "hipSetDevice failed"; return; }
-      if (host_src && hipMemcpyAsync(h->scalars_stage.p, (const char*)host_src + na * 32, nb * 32, hipMemcpyHostToDevice, h->stream) != hipSuccess) { rc_h = ALEO_MI355X_ERR_HIP; err_h = "upload of the second half failed"; return; }
-      rc_h = half(h, h->stream, pbp, nb, na, part + 18);
-      if (rc_h) err_h = g_last_error;
-    } catch (...) { rc_h = ALEO_MI355X_ERR_HIP; err_h = "msm: exception on the helper thread"; }
-  });
-  int32_t rc_m;
-  try { rc_m = half(c, s, pa, na, 0, part); } catch (...) { rc_m = ALEO_MI355X_ERR_HIP; g_last_error = "msm: exception on the calling thread"; }      // never unwind past the joinable helper
-  helper.join();
-  (void)hipStreamSynchronize(h->stream);
-  if (rc_m) return rc_m;
-  if (rc_h) { g_last_error = err_h; return rc_h; }
-  host::HXYZZ t = host::hadd(host::hfrom_jacobian(part), host::hfrom_jacobian(part + 18));
-  host::hstore_jacobian_normalized(out_jac18, t);
-  return ALEO_MI355X_OK;
+  return msm_run1(c, out_jac18, pb, d_scalars, n, mont, s, sparse);
 }
 
 int32_t msm_batch(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, const MsmJob& job, hipStream_t s) {

@@ -205,9 +205,9 @@ def g1_sum(points: np.ndarray) -> np.ndarray:
 
 
 def last_msm_timing() -> dict:
-    buf = (ctypes.c_double * 6)()
-    k = lib().aleo_mi355x_last_msm_timing(buf, 6)
-    names = ['total_ms', 'sort_ms', 'accum_ms', 'reduce_ms', 'host_ms', 'accum_kernel_ms']
+    buf = (ctypes.c_double * 7)()
+    k = lib().aleo_mi355x_last_msm_timing(buf, 7)
+    names = ['total_ms', 'sort_ms', 'accum_ms', 'reduce_ms', 'host_ms', 'accum_kernel_ms', 'accum_launches']
     return {names[i]: buf[i] for i in range(k)}
 
 

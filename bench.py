@@ -125,7 +125,7 @@ def main():
     barrier(); t0 = time.perf_counter()
     for _ in range(args.steps):
         res = step()
-        tm = aleo_amd.last_msm_timing(); acc_kernel_ms.append(tm['accum_kernel_ms']); phases.append(tm)
+        tm = aleo_amd.last_msm_timing(); acc_kernel_ms.append(tm['accum_kernel_ms']); phases.append(tm)      # accum_kernel_ms: mean over the call's k_accum28 launches (accum_launches)
     barrier(); t1 = time.perf_counter()
     elapsed = t1 - t0
     if world > 1:
@@ -195,7 +195,8 @@ def main():
         ms_step = elapsed / args.steps * 1e3
         value = total * args.steps / elapsed if strong else world * n * args.steps / elapsed
         ak = float(np.mean(acc_kernel_ms)) * 1e-3
-        alg_bytes = 128.0 * n                                  # 32 B scalar + 96 B affine base per point
+        launches = int(round(float(np.mean([p_.get('accum_launches', 1.0) for p_ in phases]))))      # 2 when the host scalars went up in two halves that share one reduction: each launch then covers n / 2 points
+        alg_bytes = 128.0 * n / launches                       # 32 B scalar + 96 B affine base per point, x the points ONE launch processes
         achieved = alg_bytes / ak / 1e9
         traffic = None
         tf = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
@@ -218,7 +219,8 @@ def main():
             'precompute_s': precompute_s, 'table_bytes': info['table_bytes'], 'base_row_bytes': info['row_bytes'], 'table_window_bits': info['tier_window_bits'],
             **variants,
             'roofline': {'bound': 'hbm', 'kernel': 'k_accum28 (bucket accumulation, 28-bit limbs)', 'achieved': achieved, 'peak': 8000.0,
-                         'unit': 'GB/s', 'frac': achieved / 8000.0, 'traffic': traffic, 'alg_bytes_per_launch': alg_bytes, 'kernel_ms': ak * 1e3,
+                         'unit': 'GB/s', 'frac': achieved / 8000.0, 'traffic': (traffic / launches if traffic else traffic), 'alg_bytes_per_launch': alg_bytes, 'kernel_ms': ak * 1e3,
+                         'launches_per_step': launches, 'points_per_launch': n // launches,
                          'note': 'integer-VALU bound by construction (SURVEY.md §8d): %d mixed additions x 10 Fq products per point; '
                                  'measured Fq product peak 81 G/s with 28-bit limbs, 61 G/s with 32-bit limbs (tools/ubench/fq28_mul_bench.hip, fq_mul_bench.hip)' % (16 if args.no_precompute else 13)},
             'phases_ms': {kk: float(np.mean([p_[kk] for p_ in phases])) for kk in phases[0]},
@@ -226,8 +228,8 @@ def main():
         # the bound this kernel actually runs against (secondary; `roofline` keeps the contract's HBM form): Fq products per second against the
         # micro-benchmarked product peak of the same 28-bit-limb block
         rows_ = 16 if args.no_precompute else 13
-        out['roofline']['valu'] = {'fq_products_per_launch': 10.0 * rows_ * n, 'achieved': 10.0 * rows_ * n / ak / 1e9, 'peak': 81.0, 'unit': 'G Fq products/s',
-                                   'frac': 10.0 * rows_ * n / ak / 81e9, 'what': '%d windows x 10 products per mixed addition x points; zero digits (1 in 2^20) not subtracted' % rows_}
+        out['roofline']['valu'] = {'fq_products_per_launch': 10.0 * rows_ * n / launches, 'achieved': 10.0 * rows_ * n / launches / ak / 1e9, 'peak': 81.0, 'unit': 'G Fq products/s',
+                                   'frac': 10.0 * rows_ * n / launches / ak / 81e9, 'what': '%d windows x 10 products per mixed addition x points; zero digits (1 in 2^20) not subtracted' % rows_}
         if replicas is not None: out['prove_replicas'] = replicas
         if world == 1 and args.concurrent_callers > 1:
             out['concurrent_callers'] = concurrent_callers(aleo_amd, synth, torch, dev, pb, n, args.concurrent_callers)

@@ -120,9 +120,9 @@ int32_t aleo_mi355x_bases_precompute_range(uint64_t handle, size_t offset, size_
 int32_t aleo_mi355x_bases_info(uint64_t handle, uint64_t* out, int32_t cap);
 /* Copies pinned bases [offset, offset+n) back to the host as snarkVM Affine (stride 104). */
 int32_t aleo_mi355x_bases_download(uint64_t handle, size_t offset, size_t n, void* out_affine104);
-/* MSM over the first n pinned bases; scalars: host pointer (pageable memory is fine: the upload runs at the link's rate either way).  From 2^21 points
- * on the request runs as two halves on two of the device's contexts, so that half of the upload goes under the first half's kernels; the result does not
- * depend on it. */
+/* MSM over the first n pinned bases; scalars: host pointer (pageable memory is fine: the upload runs at the link's rate either way).  Against a set with
+ * window tables, from 2^19 points on (ALEO_MI355X_MERGE_MIN_LG), the scalars go up in two halves on two of the device's contexts — the second half's upload
+ * and sort run under the first half's accumulation — and the two halves' bucket sums are merged before ONE reduction; the result does not depend on it. */
 int32_t aleo_mi355x_msm_g1_pinned(void* out_jacobian, uint64_t handle, const void* scalars, size_t n);
 /* Same, scalars already resident in device memory (hipMalloc'ed or a torch CUDA tensor's data_ptr).
  * The result (144 bytes) is written to HOST memory.  `stream` (here and in every *_device entry point) is a hipStream_t;
@@ -445,7 +445,8 @@ int32_t aleo_mi355x_selftest_addquad(uint32_t ops, uint64_t seed, uint32_t* fail
 
 /* Per-call instrumentation of the calling thread's most recent MSM: milliseconds per phase
  * [0] total, [1] digit/sort, [2] bucket accumulation incl. slice tree, [3] bucket reduction, [4] host tail,
- * [5] the bucket-accumulation kernel alone (the dominant kernel bench.py prices against the roofline).
+ * [5] the bucket-accumulation kernel alone (the dominant kernel bench.py prices against the roofline): mean duration of its launches,
+ * [6] how many launches of it the call made (2 when host scalars went up in two halves that share one reduction, else 1).
  * Returns the number of doubles written (<= cap). */
 int32_t aleo_mi355x_last_msm_timing(double* out_ms, int32_t cap);
 
