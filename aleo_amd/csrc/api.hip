@@ -527,12 +527,18 @@ int32_t aleo_mi355x_msm_g2(void* out_jac288, const void* bases, size_t base_stri
     DevTmp xy, inf; int32_t rc; bool any_inf = false;
     if ((rc = xy.alloc((n ? n : 1) * 192))) return rc;
     if (base_stride == 192) { if (n) HIPCHK(hipMemcpy(xy.p, bases, n * 192, hipMemcpyHostToDevice)); }
-    else {
-      std::vector<uint8_t> packed((n ? n : 1) * 192), fl(n ? n : 1, 0);
-      const uint8_t* src = (const uint8_t*)bases;
-      for (size_t i = 0; i < n; ++i) { std::memcpy(&packed[i * 192], src + i * 200, 192); if (src[i * 200 + 192]) { fl[i] = 1; any_inf = true; } }
-      if (n) HIPCHK(hipMemcpy(xy.p, packed.data(), n * 192, hipMemcpyHostToDevice));
-      if (any_inf) { if ((rc = inf.alloc(n))) return rc; HIPCHK(hipMemcpy(inf.p, fl.data(), n, hipMemcpyHostToDevice)); }
+    else if (n) {
+      // the 200-byte rows go up as they are and are unpacked on the device (round 4; the host loop that stripped the flag byte + padding first was
+      // ~ 60 of the 91 ms of a 2^20-point call — the same finding as for G1's 104-byte rows in round 3)
+      DevTmp raw;
+      if ((rc = raw.alloc(n * 200)) || (rc = inf.alloc(n + 8))) return rc;
+      HIPCHK(hipMemcpyAsync(raw.p, bases, n * 200, hipMemcpyHostToDevice, c->stream));
+      uint32_t* d_count = (uint32_t*)((char*)inf.p + ((n + 3) & ~(size_t)3));
+      if ((rc = g2_unpack200(c, raw.p, xy.p, inf.p, d_count, n, c->stream))) return rc;
+      uint32_t n_inf = 0;
+      HIPCHK(hipMemcpyAsync(&n_inf, d_count, 4, hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(hipStreamSynchronize(c->stream));
+      any_inf = n_inf != 0;
     }
     if ((rc = c->scalars_stage.reserve((n ? n : 1) * 32))) return rc;
     if (n) HIPCHK(hipMemcpyAsync(c->scalars_stage.p, scalars, n * 32, hipMemcpyHostToDevice, c->stream));

@@ -13,6 +13,7 @@
 // returned affine-normalised (x, y, 1) or (1, 1, 0) for the identity.  HBM: bases n x 192 B; partial sums 384 B per slice.
 #include "ctx.h"
 #include "ec.h"
+#include "fp28.h"
 #include "host_field.hpp"
 #include "msm_common.h"
 #include <vector>
@@ -121,6 +122,87 @@ __device__ __noinline__ void g2_madd_ni(XYZZ2* pa, const G2Affine* pp) {
   *pa = r;
 }
 
+// ---- the accumulation on 28-bit limbs, one LANE PAIR per slice (round 4) -------------------------------------------------------------------------------
+// An Fq2 value lives across the two lanes of a pair: the even lane holds the a-component, the odd lane the b-component, each as 14 x 28-bit limbs in the
+// R' = 2^392 Montgomery form of fp28.h.  Sums, differences and normalisations are component-wise, so they are the F28 operations unchanged; a product
+//   (x.a + x.b u)(y.a + y.b u) = (x.a y.a - 5 x.b y.b) + (x.a y.b + x.b y.a) u
+// is ONE merged block per lane (mont28_muladd: two products under one reduction, 588 mads) after the lanes have swapped copies of their operands:
+//   even lane:  x.a * y.a + x.b * (K q - 5 y.b)          odd lane:  x.b * y.a + x.a * y.b
+// i.e. three product times of work per Fq2 product — what a one-lane Karatsuba costs — at half the registers per lane (an XYZZ accumulator over Fq2 is
+// 112 limbs; one lane per slice with the ten products in line does not fit 256 VGPRs, and the out-of-line 32-bit version this replaces moved every
+// operand through scratch memory).  Every operand of a product is normalised first (exact digits, class L1): a column then holds at most
+// 14 (1 * 1 + 1 * 7) + 14 < 256 (fp28.h); value bounds are written at each step, with a < A q, b < B q -> a b < (A B / 38000 + 1) q.
+// The mixed addition is fp28.h's xyzz28_madd_fast (EFD madd-2008-s) with F28 read as "my component"; P == +-acc (ZZ3 = 0 in BOTH components) leaves the
+// loop for the general 32-bit code on the even lane, as in msm.hip.
+template <uint32_t K> __device__ __forceinline__ F28 f28_neg5(const F28& v) {      // K q - 5 v for an exact-digit v with 5 v < K q: limbs < 7 * 2^28
+  F28 t;
+#pragma unroll
+  for (int i = 0; i < 14; ++i) t.v[i] = 5u * v.v[i];
+  return f28_sub<K, 6>(f28_const(Limbs14{}), t);
+}
+// my component of x * y; x, y: exact digits; KY: 5 * (value bound of y in q) rounded up to a K with a spread constant
+template <uint32_t KY> __device__ __forceinline__ F28 fq2p_mul(const F28& x, const F28& y, bool odd) {
+  const F28 ox = f28_xchg(x), oy = f28_xchg(y);
+  const F28 b1 = f28_sel(odd, y, oy);                      // even: x.a * y.a        odd: x.b * y.a
+  const F28 b2 = f28_sel(odd, f28_neg5<KY>(oy), y);        // even: x.b * (-5 y.b)   odd: x.a * y.b
+  return f28_muladd(x, b1, ox, b2);
+}
+struct XYZZ2P { F28 X, Y, ZZ, ZZZ; };                      // my components of an XYZZ point over Fq2
+// acc += (x2, y2).  In: acc.X exact < 12q, acc.Y exact < 6q, acc.ZZ / ZZZ exact < 2q; x2, y2 exact < 2q.  Out: the same.  false (acc untouched): P == +-acc.
+__device__ __forceinline__ bool g2p_madd_fast(XYZZ2P& acc, const F28& x2, const F28& y2, bool odd) {
+  const F28 U2 = fq2p_mul<16>(x2, acc.ZZ, odd);                                    // (2*2 + 2*16) / 38000 + 1 -> < 2q
+  const F28 S2 = fq2p_mul<16>(y2, acc.ZZZ, odd);                                   // < 2q
+  const F28 P = f28_normalise(f28_sub<16, 1>(U2, acc.X));                          // U2 + 16q - X1 < 18q
+  const F28 R = f28_normalise(f28_sub<8, 1>(S2, acc.Y));                           // S2 + 8q - Y1 < 10q
+  const F28 PP = fq2p_mul<96>(P, P, odd);                                          // (18*18 + 18*96) / 38000 + 1 -> < 2q
+  const F28 ZZ3 = fq2p_mul<16>(acc.ZZ, PP, odd);                                   // < 2q
+  {
+    const bool z = f28_is_zero_mod_lt2q(ZZ3);
+    if (__builtin_expect(z && (bool)__shfl_xor((int)z, 1), 0)) return false;
+  }
+  const F28 PPP = fq2p_mul<16>(P, PP, odd);                                        // (18*2 + 18*16) / 38000 + 1 -> < 2q
+  const F28 Q = fq2p_mul<16>(acc.X, PP, odd);                                      // (12*2 + 12*16) / 38000 + 1 -> < 2q
+  const F28 RR = fq2p_mul<64>(R, R, odd);                                          // (10*10 + 10*64) / 38000 + 1 -> < 2q
+  const F28 t0 = f28_sub<4, 1>(RR, PPP);                                           // < 6q, limbs < 3 * 2^28
+  const F28 X3 = f28_normalise(f28_sub<6, 2>(t0, f28_add(Q, Q)));                  // 2Q: limbs < 2 * 2^28, < 4q; X3 < 12q, exact digits
+  const F28 t1 = f28_normalise(f28_sub<16, 1>(Q, X3));                             // Q + 16q - X3 < 18q
+  const F28 RT = fq2p_mul<96>(R, t1, odd);                                         // (10*18 + 10*96) / 38000 + 1 -> < 2q
+  const F28 YP = fq2p_mul<16>(acc.Y, PPP, odd);                                    // (6*2 + 6*16) / 38000 + 1 -> < 2q
+  acc.Y = f28_normalise(f28_sub<4, 1>(RT, YP));                                    // RT + 4q - YP < 6q
+  acc.X = X3;
+  acc.ZZ = ZZ3;
+  acc.ZZZ = fq2p_mul<16>(acc.ZZZ, PPP, odd);                                       // < 2q
+  return true;
+}
+// 192-byte rows (x.a | x.b | y.a | y.b, 32-bit Montgomery) -> 224-byte rows [x.a | y.a | x.b | y.b] in the 28-bit form: each lane of a pair reads 112 contiguous bytes
+__global__ void __launch_bounds__(256) k_g2_rows_to28(const char* __restrict__ src192, char* __restrict__ dst224, uint32_t n) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x; if (i >= n) return;
+  const char* r = src192 + (size_t)i * 192; char* o = dst224 + (size_t)i * 224;
+  store_affine28(o, f28_from_fq(load_fp<Fq>(r)), f28_from_fq(load_fp<Fq>(r + 96)));
+  store_affine28(o + 112, f28_from_fq(load_fp<Fq>(r + 48)), f28_from_fq(load_fp<Fq>(r + 144)));
+}
+// snarkVM G2Affine rows (200 bytes: x.c0 | x.c1 | y.c0 | y.c1 | infinity byte + padding) -> 192-byte rows + one flag byte per point; *n_inf counts the
+// flagged points (the host drops the flag array when it is zero).  200 = 8 * 25: rows are 8-byte aligned, so a lane moves its row as 25 eight-byte words.
+__global__ void __launch_bounds__(256) k_g2_unpack200(const char* __restrict__ rows200, char* __restrict__ xy192, uint8_t* __restrict__ flags, uint32_t* __restrict__ n_inf, uint32_t n) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x; if (i >= n) return;
+  const uint2* s = (const uint2*)(rows200 + (size_t)i * 200); uint2* d = (uint2*)(xy192 + (size_t)i * 192);
+#pragma unroll
+  for (int k = 0; k < 24; ++k) d[k] = s[k];
+  const uint8_t f = (uint8_t)(s[24].x & 0xffu) ? 1 : 0;
+  flags[i] = f;
+  if (f) atomicAdd(n_inf, 1u);
+}
+int32_t g2_unpack200(Ctx* c, const void* d_rows200, void* d_xy192, void* d_flags, uint32_t* d_count, size_t n, hipStream_t s) {
+  (void)c;
+  HIPCHK(hipMemsetAsync(d_count, 0, 4, s));
+  if (n) hipLaunchKernelGGL(k_g2_unpack200, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, (const char*)d_rows200, (char*)d_xy192, (uint8_t*)d_flags, d_count, (uint32_t)n);
+  HIPCHK(hipGetLastError());
+  return ALEO_MI355X_OK;
+}
+struct G2Affine;
+__device__ __noinline__ void g2_madd_ni(struct XYZZ2* pa, const G2Affine* pp);
+__device__ __noinline__ void g2_slice_slow_path(const char* bases192, const uint32_t* run, uint32_t j, uint32_t j1, char* slot);
+
 // ---- kernels (same bookkeeping as msm.hip, one lane per group operation) ----------------------------------------------------
 __global__ void __launch_bounds__(256) k_g2_accum(const char* __restrict__ bases, const uint32_t* __restrict__ sorted, const uint32_t* __restrict__ hist,
                                                   const uint2* __restrict__ scan_local, const uint2* __restrict__ scan_blk, const uint32_t* __restrict__ total_pairs, uint32_t M,
@@ -141,6 +223,55 @@ __global__ void __launch_bounds__(256) k_g2_accum(const char* __restrict__ bases
     g2_madd_ni(&acc, &p);
   }
   store_xyzz2(partial + (size_t)sid * 384, acc);
+}
+// the rest of a slice whose fast loop met P == +-acc: the general 32-bit code, continuing from the sum the pair stored in the slice's slot
+__device__ __noinline__ void g2_slice_slow_path(const char* bases192, const uint32_t* run, uint32_t j, uint32_t j1, char* slot) {
+  XYZZ2 acc = load_xyzz2(slot);
+  for (; j < j1; ++j) {
+    const uint32_t e = run[j];
+    G2Affine p; const char* row = bases192 + (size_t)(e & 0x7fffffffu) * 192;
+    p.x = load_fq2(row); p.y = load_fq2(row + 96);
+    if (e >> 31) { p.y.a = Fq::sub<1>(Fq::zero(), p.y.a); p.y.b = Fq::sub<1>(Fq::zero(), p.y.b); }
+    g2_madd_ni(&acc, &p);
+  }
+  store_xyzz2(slot, acc);
+}
+// One lane pair per slice on the 28-bit form (rows28: k_g2_rows_to28); the slice sum leaves as a 32-bit XYZZ2 point (384 B: the tree and the
+// reduction kernels below work on those), every lane converting and storing its own components.
+__global__ void __launch_bounds__(256, 2) k_g2_accum28(const char* __restrict__ rows28, const char* __restrict__ bases192, const uint32_t* __restrict__ sorted,
+                                                    const uint32_t* __restrict__ hist, const uint2* __restrict__ scan_local, const uint2* __restrict__ scan_blk,
+                                                    const uint32_t* __restrict__ total_pairs, uint32_t M, const uint32_t* __restrict__ meta, const uint32_t* __restrict__ order,
+                                                    const uint32_t* __restrict__ task_g, char* __restrict__ partial) {
+  const uint32_t t = (blockIdx.x * 256 + threadIdx.x) >> 1; const bool odd = threadIdx.x & 1;
+  if (t >= meta[0]) return;
+  const uint32_t sid = order[t], g = task_g[sid];
+  const uint2 st = scan_at(scan_local, scan_blk, g);
+  const uint32_t cnt = hist[g], m = slices_of(cnt, pick_rule(total_pairs, M)), k = sid - st.y;
+  const uint32_t j0 = (uint32_t)(((uint64_t)k * cnt) / m), j1 = (uint32_t)(((uint64_t)(k + 1) * cnt) / m);
+  const uint32_t* run = sorted + st.x;
+  char* slot = partial + (size_t)sid * 384;
+  auto fetch = [&](uint32_t e, F28& x, F28& y) {
+    load_affine28(rows28 + (size_t)(e & 0x7fffffffu) * 224 + (odd ? 112 : 0), x, y);
+    if (e >> 31) y = f28_normalise(f28_sub<2, 1>(f28_const(Limbs14{}), y));      // 2q - y (canonical rows): exact digits, <= 2q
+  };
+  XYZZ2P acc; uint32_t j = j0; bool ok = true;
+  {
+    F28 x, y; fetch(run[j], x, y);
+    acc.X = x; acc.Y = y; acc.ZZ = odd ? f28_const(Limbs14{}) : f28_const(ONE28); acc.ZZZ = acc.ZZ;      // (x, +-y, 1, 1): the one of Fq2 is (1, 0)
+    ++j;
+  }
+  for (; j < j1; ++j) {
+    F28 x, y; fetch(run[j], x, y);
+    if (!g2p_madd_fast(acc, x, y, odd)) { ok = false; break; }
+  }
+  // my components as lazily reduced 32-bit Montgomery values (< 2q): X.a at 0, X.b at 48, Y at 96 / 144, ZZ at 192 / 240, ZZZ at 288 / 336
+  const uint32_t o = odd ? 48u : 0u;
+  store_fp<Fq>(slot + o, f28_to_fq(acc.X)); store_fp<Fq>(slot + 96 + o, f28_to_fq(acc.Y));
+  store_fp<Fq>(slot + 192 + o, f28_to_fq(acc.ZZ)); store_fp<Fq>(slot + 288 + o, f28_to_fq(acc.ZZZ));
+  if (!ok) {                                               // rare: repeated or opposite bases in one bucket
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // both lanes' halves of the slot are in memory (one wave: its accesses to an address stay in order)
+    if (!odd) g2_slice_slow_path(bases192, run, j, j1, slot);
+  }
 }
 // partial[ft + i] += partial[ft + i + half] inside every multi-slice bucket of the list
 __global__ void __launch_bounds__(256) k_g2_tree_pass(char* __restrict__ partial, const uint32_t* __restrict__ list, const uint2* __restrict__ scan_local,
@@ -282,6 +413,13 @@ int32_t msm_g2_run(Ctx* c, uint64_t* out_jac36, const void* d_xy, const uint8_t*
   if ((rc = c->partial.reserve(sp.slices_max * 384))) return rc;
   if ((rc = c->vbuf.reserve(((size_t)nchunks + P.W) * 384))) return rc;
   char* partial = c->partial.as<char>(); char* V = c->vbuf.as<char>(); char* Vout = V + (size_t)nchunks * 384;
+  static const bool pair28 = [] { const char* e = std::getenv("ALEO_MI355X_G2_PAIR28"); return !(e && e[0] == '0'); }();      // A/B switch: 0 = the round-2 kernel (32-bit limbs, one lane per slice, out-of-line field calls)
+  if (pair28) {
+    if ((rc = c->out_stage.reserve(n * 224))) return rc;                          // the bases in the 28-bit form (per call: a G2 MSM keeps nothing resident)
+    hipLaunchKernelGGL(k_g2_rows_to28, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, (const char*)d_xy, c->out_stage.as<char>(), (uint32_t)n);
+    hipLaunchKernelGGL(k_g2_accum28, dim3(2 * sp.slice_blocks), dim3(256), 0, s, c->out_stage.as<const char>(), (const char*)d_xy, sp.sorted, sp.hist, sp.scan_local, sp.scan_blk,
+                       sp.total_pairs, M, sp.meta, sp.order, sp.task_g, partial);
+  } else
   hipLaunchKernelGGL(k_g2_accum, dim3(sp.slice_blocks), dim3(256), 0, s, (const char*)d_xy, sp.sorted, sp.hist, sp.scan_local, sp.scan_blk, sp.total_pairs, M, sp.meta,
                      sp.order, sp.task_g, partial);
   HIPCHK(hipGetLastError());

@@ -329,28 +329,6 @@ __global__ void __launch_bounds__(NT) k_ntt29_strided(const char* src, char* dst
   __syncthreads();
   tile_dif29<TE, NT, GM>(lds, lgL, T, inner);
   const uint32_t nmask = (lg_n >= 32) ? 0xffffffffu : ((1u << lg_n) - 1u);
-  if (direct && T * L == TE) {
-    // full tile, factor table: the TE / NT table entries of this lane are fetched in one go ahead of the products (a 32-byte HBM read in front of
-    // every product left the loads' latency in the loop: at 2^22 the table lost to the two-level product, 0.564 against 0.549 ms)
-    constexpr uint32_t NE = TE / NT;
-    uint4 d[NE][2];
-#pragma unroll
-    for (uint32_t i = 0; i < NE; ++i) {
-      const uint32_t e = threadIdx.x + i * NT, t = e & (T - 1u), k = e >> lgT;
-      const uint4* p = (const uint4*)(direct + (((((size_t)a << lgL) + k) << lgBn) + b0 + t) * 32);
-      d[i][0] = p[0]; d[i][1] = p[1];
-    }
-#pragma unroll
-    for (uint32_t i = 0; i < NE; ++i) {
-      const uint32_t e = threadIdx.x + i * NT, t = e & (T - 1u), k = e >> lgT;
-      F29 x = lds_load29<TE>(lds, t * L + bitrev(k, lgL));
-      const size_t gi = ((((size_t)a << lgL) + k) << lgBn) + b0 + t;
-      const uint32_t w[8] = {d[i][0].x, d[i][0].y, d[i][0].z, d[i][0].w, d[i][1].x, d[i][1].y, d[i][1].z, d[i][1].w};
-      x = f29_mul(x, f29_from_words(w));
-      store_fp<Fr>(dst + gi * 32, f29_to_fr(x));
-    }
-    return;
-  }
   for (uint32_t e = threadIdx.x; e < T * L; e += NT) {
     const uint32_t t = e & (T - 1u), k = e >> lgT;
     F29 x = lds_load29<TE>(lds, t * L + bitrev(k, lgL));
@@ -556,7 +534,7 @@ static int32_t run_passes29(Ctx* c, char* buf, char* tmp, uint32_t lg_n, uint32_
   } else if (npass == 2) {
     uint32_t lgBn = s3, lgT = lgT_for(s1, lgBn);
     const char* direct = nullptr;
-    static const uint32_t direct_max = [] { const char* e = std::getenv("ALEO_MI355X_NTT_DIRECT_MAX"); const int k = e ? std::atoi(e) : 21; return (uint32_t)(k >= 0 && k <= 22 ? k : 21); }();      // 2^21: 0.286 -> 0.271 ms with the table, 2^22: 0.549 -> 0.564 ms (the extra 32 B per element of HBM reads cost more than the product)
+    static const uint32_t direct_max = [] { const char* e = std::getenv("ALEO_MI355X_NTT_DIRECT_MAX"); const int k = e ? std::atoi(e) : 21; return (uint32_t)(k >= 0 && k <= 22 ? k : 21); }();      // 2^21: 0.286 -> 0.271 ms with the table, 2^22: 0.549 -> 0.564 ms (the extra 32 B per element of HBM reads cost more than the product; round 4: fetching a lane's eight table entries in one go ahead of the products changes nothing — 2^22 0.581 / 0.588 ms without / with the table, 2^21 0.277 / 0.283 ms with the entries fetched late / ahead)
     if (lg_n >= 12 && lg_n <= direct_max) {
       std::lock_guard<std::mutex> lk(c->dev->mu);
       NttTables* tm = const_cast<NttTables*>(t);

@@ -321,3 +321,72 @@ def poseidon_chain_r1cs(n_hashes: int, seed: int):
     n = len(rows['a'])
     # the prover's layout wants the public variables first: they are (0 = the constant 1, 1 = root) already
     return _csr_from_rows(rows, n), z, z[1]
+
+
+# ---- G2 (BLS12-377 twist over Fq2 = Fq[u] / (u^2 + 5)): synthetic base sets and an O(n) result gate for benchmarks ---------------------------------
+# Plain Python integers, independent of the library and of oracle/ (bench.py may use oracle/ only in its cpu_baseline leg).
+G2_GENERATOR = ((233578398248691099356572568220835526895379068987715365179118596935057653620464273615301663571204657964920925606294,
+                 140913150380207355837477652521042157274541796891053068589147167627541651775299824604154852141315666357241556069118),
+                (63160294768292073209381361943935198908131692476676907196754037919244929611450776219210369229519898517858833747423,
+                 149157405641012693445398062341192467754805999074082136895788947234480009303640899064710353187729182149407503257491))
+
+
+def _f2mul(a, b): q = FQ_MODULUS; return ((a[0] * b[0] - 5 * a[1] * b[1]) % q, (a[0] * b[1] + a[1] * b[0]) % q)
+def _f2sub(a, b): q = FQ_MODULUS; return ((a[0] - b[0]) % q, (a[1] - b[1]) % q)
+def _f2inv(a):
+    q = FQ_MODULUS; n = pow((a[0] * a[0] + 5 * a[1] * a[1]) % q, -1, q)
+    return (a[0] * n % q, (-a[1] * n) % q)
+
+
+def g2_add_affine(P, S):
+    """P + S on y^2 = x^3 + b' over Fq2 (affine tuples ((x0, x1), (y0, y1)), None = the identity)."""
+    if P is None: return S
+    if S is None: return P
+    if P[0] == S[0]:
+        if P[1] != S[1] or P[1] == (0, 0): return None
+        lam = _f2mul(_f2mul((3, 0), _f2mul(P[0], P[0])), _f2inv(_f2mul((2, 0), P[1])))
+    else:
+        lam = _f2mul(_f2sub(S[1], P[1]), _f2inv(_f2sub(S[0], P[0])))
+    x = _f2sub(_f2sub(_f2mul(lam, lam), P[0]), S[0])
+    return (x, _f2sub(_f2mul(lam, _f2sub(P[0], x)), P[1]))
+
+
+def g2_times(P, k: int):
+    acc = None
+    for bit in bin(k % FR_MODULUS)[2:] if k % FR_MODULUS else '':
+        acc = g2_add_affine(acc, acc)
+        if bit == '1': acc = g2_add_affine(acc, P)
+    return acc
+
+
+def g2_affine200(points) -> np.ndarray:
+    """Affine tuples -> snarkVM G2Affine rows (x.c0 | x.c1 | y.c0 | y.c1 Montgomery, infinity byte at 192), uint8[n, 200]."""
+    out = np.zeros((len(points), 200), dtype=np.uint8)
+    for i, P in enumerate(points):
+        if P is None: out[i, 192] = 1; continue
+        for j, v in enumerate((P[0][0], P[0][1], P[1][0], P[1][1])): out[i, 48 * j: 48 * j + 48] = int_to_limbs(v * FQ_R % FQ_MODULUS, 6).view(np.uint8)
+    return out
+
+
+def g2_multiples_affine200(n: int, distinct: int = 1 << 12) -> np.ndarray:
+    """n G2 bases P_i = ((i mod distinct) + 1) * G2 as snarkVM rows: `distinct` points by repeated affine addition (~ 40 us each), tiled to n — the
+    discrete logarithm of base i is known, so sum_i s_i * ((i mod distinct) + 1) * G2 is the expected MSM result (g2_result_gate)."""
+    d = min(n, distinct); pts, acc = [], None
+    for _ in range(d): acc = g2_add_affine(acc, G2_GENERATOR); pts.append(acc)
+    rows = g2_affine200(pts)
+    return np.ascontiguousarray(np.tile(rows, ((n + d - 1) // d, 1))[:n])
+
+
+def g2_result_gate(result_jac288, scalars: np.ndarray, distinct: int = 1 << 12) -> bool:
+    """True iff the library's G2 result (Jacobian x, y, z: Fq2, affine-normalised) equals (sum_i s_i * ((i mod distinct) + 1)) * G2 in Python integers."""
+    s = np.ascontiguousarray(scalars, dtype=np.uint64).reshape(-1, 4); n = s.shape[0]
+    w = (np.arange(n, dtype=np.uint64) % np.uint64(max(1, min(n, distinct)))) + np.uint64(1)
+    q = s.view(np.uint16).reshape(n, 16).astype(np.uint64); k = 0      # 16-bit pieces x weights below 2^31, 2^15 terms per dot product: exact in uint64
+    for lo in range(0, n, 1 << 15):
+        part = w[lo:lo + (1 << 15)] @ q[lo:lo + (1 << 15)]
+        k += sum(int(v) << (16 * j) for j, v in enumerate(part))
+    want = g2_times(G2_GENERATOR, k % FR_MODULUS)
+    r = np.asarray(result_jac288, dtype=np.uint64).reshape(36); rinv = pow(FQ_R, -1, FQ_MODULUS)
+    lim = lambda a: sum(int(v) << (64 * i) for i, v in enumerate(a)) * rinv % FQ_MODULUS
+    got = None if not r[24:].any() else ((lim(r[0:6]), lim(r[6:12])), (lim(r[12:18]), lim(r[18:24])))
+    return got == want

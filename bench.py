@@ -235,6 +235,10 @@ def main():
             out['concurrent_callers'] = concurrent_callers(aleo_amd, synth, torch, dev, pb, n, args.concurrent_callers)
         if world == 1 and not args.no_kzg_chain:
             out['kzg_chain_2^22'] = kzg_chain(aleo_amd, synth, torch, dev)
+        if world == 1 and not args.no_variants:
+            try: out['msm_g2'] = msm_g2_bench(aleo_amd, synth)
+            except SystemExit: raise
+            except Exception as e: out['msm_g2'] = {'error': repr(e)[:300]}
         if world == 1 and args.proof_proxy_lg:
             pb.close()
             out['proof_proxy'] = {'2^%d' % lg_: proof_proxy_gpu(aleo_amd, synth, torch, dev, lg_)
@@ -486,6 +490,27 @@ def sharded_ntt_probe(aleo_amd, adist, synth, torch, dist, dev, rank, world, lg_
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return {'lg_n': lg_n, 'ranks': world, 'ms': float(t[0]) * 1e3, 'alg_GBps_aggregate': 64.0 * n / float(t[0]) / 1e9,
             'matches_single_gpu_transform_on_all_ranks': float(t[1]) == 0.0}
+
+
+def msm_g2_bench(aleo_amd, synth):
+    """VariableBase::msm::<G2Affine> (SURVEY.md 8f row 4: SRS / setup paths, never in the prover's loop) through the one-shot entry point — host bases
+    (200-byte snarkVM rows) and host scalars, nothing resident — at 2^16 and 2^20 points; results gated against (sum s_i w_i) G2 in Python integers.
+    fq_product_equivalents_per_s: 30 Fq products per mixed addition (ten Fq2 products) x points x windows / WALL time of the call — a lower bound of what
+    the accumulation kernel sustains (the 81 G/s of roofline.valu is the G1 block's peak)."""
+    from aleo_amd import msm as M
+    out = {'entry_point': 'aleo_mi355x_msm_g2', 'bases': 'P_i = ((i mod 4096) + 1) G2, host memory, uploaded and unpacked inside every call',
+           'round3_kernel_same_box_r04': {'2^16_ms': 7.99, '2^20_ms': 95.27, 'file': 'profiles/r04_g2_round2_kernel.jsonl'}}
+    for lg in (16, 20):
+        n = 1 << lg
+        B = synth.g2_multiples_affine200(n); S = synth.uniform_scalars(n, 0xA1E00077)
+        res = M.msm_g2(B, S)
+        if not synth.g2_result_gate(res, S): raise SystemExit('bench: G2 MSM result differs from its discrete logarithm times the generator')
+        reps = 3 if lg >= 18 else 6; t0 = time.perf_counter()
+        for _ in range(reps): M.msm_g2(B, S)
+        dt = (time.perf_counter() - t0) / reps
+        c = min(16, lg - 4); W = (254 + c - 1) // c
+        out['2^%d' % lg] = {'ms': dt * 1e3, 'scalar_muls_per_s': n / dt, 'windows': W, 'fq_product_equivalents_per_s': 30.0 * n * W / dt}
+    return out
 
 
 def kzg_chain(aleo_amd, synth, torch, dev, lg=22, reps=5):
