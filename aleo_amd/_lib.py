@@ -14,13 +14,13 @@ EXPORTS = [
     'aleo_mi355x_ntt_fr_device', 'aleo_mi355x_ntt_fr_batch_device', 'aleo_mi355x_fr_grid_scale_device', 'aleo_mi355x_kzg_commit', 'aleo_mi355x_kzg_commit_device', 'aleo_mi355x_kzg_commit_hiding',
     'aleo_mi355x_msm_g1_batch_device', 'aleo_mi355x_kzg_commit_batch_device', 'aleo_mi355x_kzg_commit_batch', 'aleo_mi355x_kzg_commit_segments', 'aleo_mi355x_kzg_commit_segments_device',
     'aleo_mi355x_fr_vec_op_device', 'aleo_mi355x_fr_batch_inverse_device', 'aleo_mi355x_fr_spmv_device', 'aleo_mi355x_fr_divide_by_linear_device', 'aleo_mi355x_kzg_open_device', 'aleo_mi355x_fq_mul',
-    'aleo_mi355x_fr_mul', 'aleo_mi355x_selftest_madd28', 'aleo_mi355x_selftest_addquad', 'aleo_mi355x_last_msm_timing', 'aleo_mi355x_strerror', 'aleo_mi355x_last_error',
+    'aleo_mi355x_fr_mul', 'aleo_mi355x_selftest_madd28', 'aleo_mi355x_selftest_addquad', 'aleo_mi355x_selftest_g2pair', 'aleo_mi355x_last_msm_timing', 'aleo_mi355x_strerror', 'aleo_mi355x_last_error',
     'aleo_mi355x_version',
     'aleo_mi355x_g1_compress', 'aleo_mi355x_g1_decompress', 'aleo_mi355x_fr_to_bytes', 'aleo_mi355x_fr_from_bytes',
     'aleo_mi355x_bech32m_encode', 'aleo_mi355x_bech32m_decode', 'aleo_mi355x_proof_to_bytes',
     'aleo_mi355x_poseidon_hash_fr', 'aleo_mi355x_fs_new', 'aleo_mi355x_fs_free', 'aleo_mi355x_fs_absorb_bytes', 'aleo_mi355x_fs_absorb_g1',
     'aleo_mi355x_fs_absorb_fr', 'aleo_mi355x_fs_squeeze_fr', 'aleo_mi355x_fr_random', 'aleo_mi355x_poseidon_parameters_fr',
-    'aleo_mi355x_init_device', 'aleo_mi355x_device_count', 'aleo_mi355x_peer_info', 'aleo_mi355x_kzg_commit_segments_sharded_device', 'aleo_mi355x_kzg_commit_batch_sharded_device', 'aleo_mi355x_bases_attach_shards', 'aleo_mi355x_bases_pin_sharded', 'aleo_mi355x_bases_generate_sharded', 'aleo_mi355x_bases_unpin_sharded',
+    'aleo_mi355x_init_device', 'aleo_mi355x_device_count', 'aleo_mi355x_peer_info', 'aleo_mi355x_min_msm', 'aleo_mi355x_min_ntt', 'aleo_mi355x_kzg_commit_segments_sharded_device', 'aleo_mi355x_kzg_commit_batch_sharded_device', 'aleo_mi355x_bases_attach_shards', 'aleo_mi355x_bases_pin_sharded', 'aleo_mi355x_bases_generate_sharded', 'aleo_mi355x_bases_unpin_sharded',
     'aleo_mi355x_bases_sharded_info', 'aleo_mi355x_msm_g1_sharded', 'aleo_mi355x_fr_transpose_device', 'aleo_mi355x_ntt_fr_sharded', 'aleo_mi355x_varuna_prove_many',
 ]
 
@@ -58,6 +58,8 @@ def lib():
         'aleo_mi355x_init_device': ([i32], i32),
         'aleo_mi355x_device_count': ([ctypes.POINTER(i32), ctypes.POINTER(i32)], i32),
         'aleo_mi355x_peer_info': ([ctypes.POINTER(i32), ctypes.POINTER(i32)], i32),
+        'aleo_mi355x_min_msm': ([], sz),
+        'aleo_mi355x_min_ntt': ([], sz),
         'aleo_mi355x_kzg_commit_segments_sharded_device': ([vp, sz, u64, vp, sz, vp], i32),
         'aleo_mi355x_kzg_commit_batch_sharded_device': ([vp, u64, vp, vp, sz, vp], i32),
         'aleo_mi355x_bases_attach_shards': ([u64, u64, sz], i32),
@@ -133,6 +135,7 @@ def lib():
         'aleo_mi355x_fr_mul': ([vp, vp, vp, sz], i32),
         'aleo_mi355x_selftest_madd28': ([u32, u32, u64, ctypes.POINTER(u32)], i32),
         'aleo_mi355x_selftest_addquad': ([u32, u64, ctypes.POINTER(u32)], i32),
+        'aleo_mi355x_selftest_g2pair': ([vp, u32, u32, ctypes.POINTER(u32)], i32),
         'aleo_mi355x_last_msm_timing': ([ctypes.POINTER(ctypes.c_double), i32], i32),
         'aleo_mi355x_strerror': ([i32], ctypes.c_char_p),
         'aleo_mi355x_last_error': ([], ctypes.c_char_p),

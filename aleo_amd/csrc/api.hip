@@ -1039,6 +1039,10 @@ int32_t aleo_mi355x_selftest_addquad(uint32_t ops, uint64_t seed, uint32_t* fail
   try { if (!failures || !ops || ops > (1u << 22)) return ALEO_MI355X_ERR_BAD_ARG; API_BEGIN return selftest_addquad(c, ops, seed, failures); } catch (...) { return ALEO_MI355X_ERR_HIP; }
 }
 
+int32_t aleo_mi355x_selftest_g2pair(const void* affine192, uint32_t n_points, uint32_t n_pairs, uint32_t* failures2) {
+  try { if (!affine192 || !failures2 || n_points < 3 || !n_pairs || n_pairs > (1u << 20)) return ALEO_MI355X_ERR_BAD_ARG; API_BEGIN return selftest_g2pair(c, affine192, n_points, n_pairs, failures2); } catch (...) { return ALEO_MI355X_ERR_HIP; }
+}
+
 int32_t aleo_mi355x_last_msm_timing(double* out_ms, int32_t cap) {
   try {
     if (!out_ms || cap <= 0) return 0;
@@ -1062,6 +1066,11 @@ const char* aleo_mi355x_strerror(int32_t status) {
     default: return "unknown status";
   }
 }
+// The sizes from which the drop-in's two arms should take the GPU: measured crossovers of the COLD one-shot calls against the CPU
+// path on the same box (bench.py cpu_baseline.crossover, profiles/r04_crossover.json), overridable per deployment.
+static size_t env_size(const char* name, size_t dflt) { const char* e = std::getenv(name); if (!e || !*e) return dflt; char* end = nullptr; const unsigned long long v = std::strtoull(e, &end, 10); return end && *end == 0 ? (size_t)v : dflt; }
+size_t aleo_mi355x_min_msm(void) { return env_size("ALEO_MI355X_MIN_MSM", (size_t)1 << 10); }
+size_t aleo_mi355x_min_ntt(void) { return env_size("ALEO_MI355X_MIN_NTT", (size_t)1 << 12); }
 const char* aleo_mi355x_last_error(void) { return g_last_error.c_str(); }
 const char* aleo_mi355x_version(void) { return "aleo_mi355x 0.2.0 (gfx950)"; }
 

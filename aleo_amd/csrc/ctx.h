@@ -196,6 +196,7 @@ int32_t selftest_addquad(Ctx* c, uint32_t ops, uint64_t seed, uint32_t* failures
 // g2.hip
 int32_t msm_g2_run(Ctx* c, uint64_t* out_jac36, const void* d_xy192, const uint8_t* d_inf, const void* d_scalars, size_t n, hipStream_t s);
 int32_t g2_sum_host(uint64_t* out36, const uint64_t* pts36, size_t count);
+int32_t selftest_g2pair(Ctx* c, const void* aff192_host, uint32_t n, uint32_t npairs, uint32_t* failures2);      // [0] pairs that disagreed, [1] OR of the failing steps
 int32_t g2_unpack200(Ctx* c, const void* d_rows200, void* d_xy192, void* d_flags, uint32_t* d_count, size_t n, hipStream_t s);      // 200-byte G2Affine rows -> 192-byte rows + flag bytes + their count
 // frops.hip
 int32_t fr_lin(Ctx* c, void* d_dst, size_t n, const void* c0, const void* c1, const void* d_a, const void* c2, const void* d_b, hipStream_t s);

@@ -142,11 +142,13 @@ template <uint32_t K> __device__ __forceinline__ F28 f28_neg5(const F28& v) {   
 }
 // my component of x * y; x, y: exact digits; KY: 5 * (value bound of y in q) rounded up to a K with a spread constant
 template <uint32_t KY> __device__ __forceinline__ F28 fq2p_mul(const F28& x, const F28& y, bool odd) {
-  const F28 ox = f28_xchg(x), oy = f28_xchg(y);
+  const F28 ox = f28_qperm<1, 0, 3, 2>(x), oy = f28_qperm<1, 0, 3, 2>(y);      // the partner lane's copies: DPP quad_perm moves (full-rate VALU; __shfl_xor compiled to ds_bpermute: an LDS-crossbar round trip per limb)
   const F28 b1 = f28_sel(odd, y, oy);                      // even: x.a * y.a        odd: x.b * y.a
   const F28 b2 = f28_sel(odd, f28_neg5<KY>(oy), y);        // even: x.b * (-5 y.b)   odd: x.a * y.b
   return f28_muladd(x, b1, ox, b2);
 }
+// both lanes exchange their flags FIRST, then decide: `z && shfl(z)` would skip the exchange on the lane whose flag is false and leave its partner reading an inactive lane
+__device__ __forceinline__ bool g2p_zero_mod_early(const F28& v_lt2q_exact) { const bool z = f28_is_zero_mod_lt2q(v_lt2q_exact), zo = (bool)__shfl_xor((int)z, 1); return z && zo; }
 struct XYZZ2P { F28 X, Y, ZZ, ZZZ; };                      // my components of an XYZZ point over Fq2
 // acc += (x2, y2).  In: acc.X exact < 12q, acc.Y exact < 6q, acc.ZZ / ZZZ exact < 2q; x2, y2 exact < 2q.  Out: the same.  false (acc untouched): P == +-acc.
 __device__ __forceinline__ bool g2p_madd_fast(XYZZ2P& acc, const F28& x2, const F28& y2, bool odd) {
@@ -157,8 +159,7 @@ __device__ __forceinline__ bool g2p_madd_fast(XYZZ2P& acc, const F28& x2, const 
   const F28 PP = fq2p_mul<96>(P, P, odd);                                          // (18*18 + 18*96) / 38000 + 1 -> < 2q
   const F28 ZZ3 = fq2p_mul<16>(acc.ZZ, PP, odd);                                   // < 2q
   {
-    const bool z = f28_is_zero_mod_lt2q(ZZ3);
-    if (__builtin_expect(z && (bool)__shfl_xor((int)z, 1), 0)) return false;
+    if (__builtin_expect(g2p_zero_mod_early(ZZ3), 0)) return false;
   }
   const F28 PPP = fq2p_mul<16>(P, PP, odd);                                        // (18*2 + 18*16) / 38000 + 1 -> < 2q
   const F28 Q = fq2p_mul<16>(acc.X, PP, odd);                                      // (12*2 + 12*16) / 38000 + 1 -> < 2q
@@ -174,6 +175,102 @@ __device__ __forceinline__ bool g2p_madd_fast(XYZZ2P& acc, const F28& x2, const 
   acc.ZZZ = fq2p_mul<16>(acc.ZZZ, PPP, odd);                                       // < 2q
   return true;
 }
+// ---- stored points of the pair form: 448 bytes = X.a | X.b | Y.a | Y.b | ZZ.a | ZZ.b | ZZZ.a | ZZZ.b, 14 x 28-bit limbs each --------------------------------
+// Stored invariant (what g2p_madd_fast keeps for its accumulator): X exact digits < 12q, Y exact < 6q, ZZ / ZZZ exact < 2q; the identity = all zero.
+// Everything below is pair-cooperative: both lanes of a pair call with the same pointers, each moves and computes its own component.
+static constexpr uint32_t P2B = 448;
+__device__ __forceinline__ XYZZ2P g2p_load(const char* p, bool odd) {
+  const char* c = p + (odd ? 56 : 0); XYZZ2P r; r.X = load_f28(c); r.Y = load_f28(c + 112); r.ZZ = load_f28(c + 224); r.ZZZ = load_f28(c + 336); return r;
+}
+__device__ __forceinline__ void g2p_store(char* p, bool odd, const XYZZ2P& a) {
+  char* c = p + (odd ? 56 : 0); store_f28(c, a.X); store_f28(c + 112, a.Y); store_f28(c + 224, a.ZZ); store_f28(c + 336, a.ZZZ);
+}
+__device__ __forceinline__ void g2p_store_inf(char* p, bool odd) { XYZZ2P z; z.X = f28_const(Limbs14{}); z.Y = z.X; z.ZZ = z.X; z.ZZZ = z.X; g2p_store(p, odd, z); }
+__device__ __forceinline__ bool pair_and(bool v) { const bool o = (bool)__shfl_xor((int)v, 1); return v && o; }      // the exchange first, by BOTH lanes: `v && shfl(..)` would skip it on the lane whose v is false and leave its partner reading an inactive lane
+__device__ __forceinline__ bool g2p_is_inf(const XYZZ2P& a) { return pair_and(f28_is_zero_raw(a.ZZ)); }
+__device__ __forceinline__ bool g2p_zero_mod(const F28& v_lt2q_exact) { return pair_and(f28_is_zero_mod_lt2q(v_lt2q_exact)); }      // an Fq2 value is 0 iff both components are
+// 2a (EFD dbl-2008-s-1, a = 0); a not the identity
+__device__ __forceinline__ XYZZ2P g2p_double(const XYZZ2P& a, bool odd, bool* is_inf) {
+  const F28 U = f28_normalise(f28_add(a.Y, a.Y));                                  // < 12q
+  const F28 V = fq2p_mul<64>(U, U, odd);                                           // (12*12 + 12*64) / 38000 + 1 -> < 2q
+  const F28 W = fq2p_mul<16>(U, V, odd);                                           // < 2q
+  const F28 S = fq2p_mul<16>(a.X, V, odd);                                         // X < 12q -> < 2q
+  const F28 XX = fq2p_mul<64>(a.X, a.X, odd);                                      // < 2q
+  const F28 M = f28_normalise(f28_add(f28_add(XX, XX), XX));                       // < 6q
+  const F28 MM = fq2p_mul<32>(M, M, odd);                                          // < 2q
+  XYZZ2P r;
+  r.X = f28_normalise(f28_sub<6, 2>(MM, f28_add(S, S)));                           // MM + 6q - 2S < 8q
+  const F28 t1 = f28_normalise(f28_sub<8, 1>(S, r.X));                             // S + 8q - X3 < 10q
+  const F28 MT = fq2p_mul<64>(M, t1, odd);                                         // (6*10 + 6*64) / 38000 + 1 -> < 2q
+  const F28 WY = fq2p_mul<32>(W, a.Y, odd);                                        // (2*6 + 2*32) / 38000 + 1 -> < 2q
+  r.Y = f28_normalise(f28_sub<4, 1>(MT, WY));                                      // < 6q
+  r.ZZ = fq2p_mul<16>(V, a.ZZ, odd);
+  r.ZZZ = fq2p_mul<16>(W, a.ZZZ, odd);
+  *is_inf = g2p_zero_mod(r.ZZ);                                                    // y = 0: a 2-torsion point
+  return r;
+}
+// a + b (EFD add-2008-s), neither the identity.  false: a == +-b (then *same tells which) and r is not written.
+__device__ __forceinline__ bool g2p_add(const XYZZ2P& a, const XYZZ2P& b, bool odd, XYZZ2P& r, bool* same) {
+  const F28 U1 = fq2p_mul<16>(a.X, b.ZZ, odd), U2 = fq2p_mul<16>(b.X, a.ZZ, odd);  // X < 12q: (12*2 + 12*16) / 38000 + 1 -> < 2q
+  const F28 S1 = fq2p_mul<16>(a.Y, b.ZZZ, odd), S2 = fq2p_mul<16>(b.Y, a.ZZZ, odd);
+  const F28 P = f28_normalise(f28_sub<4, 1>(U2, U1)), R = f28_normalise(f28_sub<4, 1>(S2, S1));      // < 6q each
+  const F28 PP = fq2p_mul<32>(P, P, odd);                                          // (6*6 + 6*32) / 38000 + 1 -> < 2q
+  const F28 ZZ12 = fq2p_mul<16>(a.ZZ, b.ZZ, odd);
+  const F28 ZZ3 = fq2p_mul<16>(ZZ12, PP, odd);
+  if (__builtin_expect(g2p_zero_mod(ZZ3), 0)) {                                    // P = 0 (the ZZ's are units): equal or opposite points
+    *same = g2p_zero_mod(f28_mul(R, f28_const(ONE28)));                            // R brought below 2q (exact digits) first
+    return false;
+  }
+  const F28 PPP = fq2p_mul<16>(P, PP, odd);
+  const F28 Q = fq2p_mul<16>(U1, PP, odd);
+  const F28 RR = fq2p_mul<32>(R, R, odd);
+  const F28 t0 = f28_sub<4, 1>(RR, PPP);                                           // < 6q, limbs < 3 * 2^28
+  r.X = f28_normalise(f28_sub<6, 2>(t0, f28_add(Q, Q)));                           // < 12q
+  const F28 t1 = f28_normalise(f28_sub<16, 1>(Q, r.X));                            // < 18q
+  const F28 RT = fq2p_mul<96>(R, t1, odd);                                         // (6*18 + 6*96) / 38000 + 1 -> < 2q
+  const F28 SP = fq2p_mul<16>(S1, PPP, odd);
+  r.Y = f28_normalise(f28_sub<4, 1>(RT, SP));                                      // < 6q
+  r.ZZ = ZZ3;
+  r.ZZZ = fq2p_mul<16>(fq2p_mul<16>(a.ZZZ, b.ZZZ, odd), PPP, odd);
+  return true;
+}
+// out = pa + pb for stored points (any of them may be the identity, they may be equal or opposite; out may alias pa or pb).  Out of line: the reduction
+// kernels are chains of these calls, and one copy of the ~20 product blocks per kernel is enough.
+__device__ __noinline__ void g2p_add_any(const char* pa, const char* pb, char* out) {
+  const bool odd = threadIdx.x & 1;
+  const XYZZ2P a = g2p_load(pa, odd), b = g2p_load(pb, odd);
+  if (g2p_is_inf(a)) { g2p_store(out, odd, b); return; }
+  if (g2p_is_inf(b)) { g2p_store(out, odd, a); return; }
+  XYZZ2P r; bool same = false;
+  if (!g2p_add(a, b, odd, r, &same)) {
+    bool inf = true;
+    if (same) r = g2p_double(a, odd, &inf);
+    if (inf) { g2p_store_inf(out, odd); return; }
+  }
+  g2p_store(out, odd, r);
+}
+__device__ __noinline__ void g2p_double_any(const char* pa, char* out) {
+  const bool odd = threadIdx.x & 1;
+  const XYZZ2P a = g2p_load(pa, odd);
+  if (g2p_is_inf(a)) { g2p_store(out, odd, a); return; }
+  bool inf = false; const XYZZ2P r = g2p_double(a, odd, &inf);
+  if (inf) g2p_store_inf(out, odd); else g2p_store(out, odd, r);
+}
+// conversions between the pair form and the 32-bit XYZZ2 the slow path of the accumulation works in (one lane does the whole point)
+__device__ __noinline__ void g2_p2_to_xyzz2(const char* p, XYZZ2* out) {
+  XYZZ2 r;
+  if (f28_is_zero_raw(load_f28(p + 224)) && f28_is_zero_raw(load_f28(p + 280))) { *out = g2_infinity(); return; }
+  r.X.a = f28_to_fq(load_f28(p)); r.X.b = f28_to_fq(load_f28(p + 56)); r.Y.a = f28_to_fq(load_f28(p + 112)); r.Y.b = f28_to_fq(load_f28(p + 168));
+  r.ZZ.a = f28_to_fq(load_f28(p + 224)); r.ZZ.b = f28_to_fq(load_f28(p + 280)); r.ZZZ.a = f28_to_fq(load_f28(p + 336)); r.ZZZ.b = f28_to_fq(load_f28(p + 392));
+  *out = r;
+}
+__device__ __noinline__ void g2_xyzz2_to_p2(const XYZZ2* in, char* p) {
+  const XYZZ2 a = *in;
+  if (g2_is_inf(a) || fq2_is_zero(a.ZZ)) { for (int i = 0; i < 8; ++i) store_f28(p + 56 * i, f28_const(Limbs14{})); return; }
+  store_f28(p, f28_from_fq(a.X.a)); store_f28(p + 56, f28_from_fq(a.X.b)); store_f28(p + 112, f28_from_fq(a.Y.a)); store_f28(p + 168, f28_from_fq(a.Y.b));
+  store_f28(p + 224, f28_from_fq(a.ZZ.a)); store_f28(p + 280, f28_from_fq(a.ZZ.b)); store_f28(p + 336, f28_from_fq(a.ZZZ.a)); store_f28(p + 392, f28_from_fq(a.ZZZ.b));
+}
+
 // 192-byte rows (x.a | x.b | y.a | y.b, 32-bit Montgomery) -> 224-byte rows [x.a | y.a | x.b | y.b] in the 28-bit form: each lane of a pair reads 112 contiguous bytes
 __global__ void __launch_bounds__(256) k_g2_rows_to28(const char* __restrict__ src192, char* __restrict__ dst224, uint32_t n) {
   const uint32_t i = blockIdx.x * 256 + threadIdx.x; if (i >= n) return;
@@ -226,7 +323,7 @@ __global__ void __launch_bounds__(256) k_g2_accum(const char* __restrict__ bases
 }
 // the rest of a slice whose fast loop met P == +-acc: the general 32-bit code, continuing from the sum the pair stored in the slice's slot
 __device__ __noinline__ void g2_slice_slow_path(const char* bases192, const uint32_t* run, uint32_t j, uint32_t j1, char* slot) {
-  XYZZ2 acc = load_xyzz2(slot);
+  XYZZ2 acc; g2_p2_to_xyzz2(slot, &acc);
   for (; j < j1; ++j) {
     const uint32_t e = run[j];
     G2Affine p; const char* row = bases192 + (size_t)(e & 0x7fffffffu) * 192;
@@ -234,10 +331,10 @@ __device__ __noinline__ void g2_slice_slow_path(const char* bases192, const uint
     if (e >> 31) { p.y.a = Fq::sub<1>(Fq::zero(), p.y.a); p.y.b = Fq::sub<1>(Fq::zero(), p.y.b); }
     g2_madd_ni(&acc, &p);
   }
-  store_xyzz2(slot, acc);
+  g2_xyzz2_to_p2(&acc, slot);
 }
-// One lane pair per slice on the 28-bit form (rows28: k_g2_rows_to28); the slice sum leaves as a 32-bit XYZZ2 point (384 B: the tree and the
-// reduction kernels below work on those), every lane converting and storing its own components.
+// One lane pair per slice on the 28-bit form (rows28: k_g2_rows_to28); the slice sum leaves as a 448-byte pair-form point: the slice trees and the bucket
+// reduction below (k_g2p_*) continue in that form.
 __global__ void __launch_bounds__(256, 2) k_g2_accum28(const char* __restrict__ rows28, const char* __restrict__ bases192, const uint32_t* __restrict__ sorted,
                                                     const uint32_t* __restrict__ hist, const uint2* __restrict__ scan_local, const uint2* __restrict__ scan_blk,
                                                     const uint32_t* __restrict__ total_pairs, uint32_t M, const uint32_t* __restrict__ meta, const uint32_t* __restrict__ order,
@@ -249,7 +346,7 @@ __global__ void __launch_bounds__(256, 2) k_g2_accum28(const char* __restrict__ 
   const uint32_t cnt = hist[g], m = slices_of(cnt, pick_rule(total_pairs, M)), k = sid - st.y;
   const uint32_t j0 = (uint32_t)(((uint64_t)k * cnt) / m), j1 = (uint32_t)(((uint64_t)(k + 1) * cnt) / m);
   const uint32_t* run = sorted + st.x;
-  char* slot = partial + (size_t)sid * 384;
+  char* slot = partial + (size_t)sid * P2B;
   auto fetch = [&](uint32_t e, F28& x, F28& y) {
     load_affine28(rows28 + (size_t)(e & 0x7fffffffu) * 224 + (odd ? 112 : 0), x, y);
     if (e >> 31) y = f28_normalise(f28_sub<2, 1>(f28_const(Limbs14{}), y));      // 2q - y (canonical rows): exact digits, <= 2q
@@ -260,14 +357,15 @@ __global__ void __launch_bounds__(256, 2) k_g2_accum28(const char* __restrict__ 
     acc.X = x; acc.Y = y; acc.ZZ = odd ? f28_const(Limbs14{}) : f28_const(ONE28); acc.ZZZ = acc.ZZ;      // (x, +-y, 1, 1): the one of Fq2 is (1, 0)
     ++j;
   }
+  // Pin the accumulator to registers here.  Without it hipcc (ROCm 7.2) drops the initial value of two limbs of acc.Y on the path that skips the loop
+  // (a one-point slice): the store below then reads a register no instruction of the kernel writes — seen in the ISA and as 0x5a5a5a5a in the slice sums.
+#pragma unroll
+  for (int i = 0; i < 14; ++i) asm volatile("" : "+v"(acc.X.v[i]), "+v"(acc.Y.v[i]), "+v"(acc.ZZ.v[i]), "+v"(acc.ZZZ.v[i]));
   for (; j < j1; ++j) {
     F28 x, y; fetch(run[j], x, y);
     if (!g2p_madd_fast(acc, x, y, odd)) { ok = false; break; }
   }
-  // my components as lazily reduced 32-bit Montgomery values (< 2q): X.a at 0, X.b at 48, Y at 96 / 144, ZZ at 192 / 240, ZZZ at 288 / 336
-  const uint32_t o = odd ? 48u : 0u;
-  store_fp<Fq>(slot + o, f28_to_fq(acc.X)); store_fp<Fq>(slot + 96 + o, f28_to_fq(acc.Y));
-  store_fp<Fq>(slot + 192 + o, f28_to_fq(acc.ZZ)); store_fp<Fq>(slot + 288 + o, f28_to_fq(acc.ZZZ));
+  g2p_store(slot, odd, acc);                               // the stored invariant is the loop's own
   if (!ok) {                                               // rare: repeated or opposite bases in one bucket
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // both lanes' halves of the slot are in memory (one wave: its accesses to an address stay in order)
     if (!odd) g2_slice_slow_path(bases192, run, j, j1, slot);
@@ -313,6 +411,73 @@ __global__ void __launch_bounds__(256) k_g2_bucket_chunks(const char* __restrict
   }
   store_xyzz2(V + (size_t)t * 384, acc);
 }
+// (debug / A-B aid, ALEO_MI355X_G2_PAIR28=2: the pair-form accumulation followed by the one-lane reduction) slice sums 448 B pair form -> 384 B XYZZ2
+__global__ void __launch_bounds__(256) k_g2_p2_to_32(const char* __restrict__ src, char* __restrict__ dst, const uint32_t* __restrict__ meta) {
+  const uint32_t t = blockIdx.x * 256 + threadIdx.x; if (t >= meta[0]) return;
+  XYZZ2 v; g2_p2_to_xyzz2(src + (size_t)t * P2B, &v); store_xyzz2(dst + (size_t)t * 384, v);
+}
+// (debug, ALEO_MI355X_G2_PAIR28=3) slice sums of the two accumulation kernels compared as group elements: out[0] = slices that differ, out[1] = the first such slice
+__global__ void __launch_bounds__(256) k_g2_compare(const char* __restrict__ a384, const char* __restrict__ b384, const uint32_t* __restrict__ meta, uint32_t* __restrict__ out) {
+  const uint32_t t = blockIdx.x * 256 + threadIdx.x; if (t >= meta[0]) return;
+  XYZZ2 a = load_xyzz2(a384 + (size_t)t * 384), b = load_xyzz2(b384 + (size_t)t * 384);
+  b.Y.a = lt2q(Fq::sub<2>(Fq::zero(), b.Y.a)); b.Y.b = lt2q(Fq::sub<2>(Fq::zero(), b.Y.b));
+  g2_add_ni(&a, &b);
+  if (!(g2_is_inf(a) || fq2_is_zero(a.ZZ))) { atomicAdd(out, 1u); atomicMin(out + 1, t); }
+}
+// ---- the reduction in the pair form (round 4): the same bookkeeping as the one-lane kernels above, one lane pair per operation, points of 448 bytes ------
+__global__ void __launch_bounds__(256) k_g2p_tree_pass(char* __restrict__ partial, const uint32_t* __restrict__ list, const uint2* __restrict__ scan_local,
+                                                       const uint2* __restrict__ scan_blk, uint32_t M, const uint32_t* __restrict__ meta, uint32_t pass, uint32_t max_pairs,
+                                                       uint32_t list_len) {
+  const uint32_t op = (blockIdx.x * 256 + threadIdx.x) >> 1;
+  uint32_t h = op / max_pairs, i = op % max_pairs;
+  if (h >= list_len) return;
+  uint32_t g = list[h];
+  uint32_t ft = scan_at(scan_local, scan_blk, g).y;
+  uint32_t fn = (g + 1 < M) ? scan_at(scan_local, scan_blk, g + 1).y : meta[0];
+  uint32_t L = fn - ft;
+  for (uint32_t p = 0; p < pass; ++p) L = (L + 1) >> 1;
+  if (L <= 1) return;
+  uint32_t half = (L + 1) >> 1;
+  if (i >= L - half) return;
+  char* pa = partial + (size_t)(ft + i) * P2B;
+  g2p_add_any(pa, pa + (size_t)half * P2B, pa);
+}
+// one lane pair per chunk of S consecutive buckets: run / acc / the double-and-add register live in a per-pair work area between the cooperative operations
+__global__ void __launch_bounds__(128) k_g2p_bucket_chunks(const char* __restrict__ partial, const uint32_t* __restrict__ hist, const uint2* __restrict__ scan_local,
+                                                           const uint2* __restrict__ scan_blk, uint32_t B, uint32_t S, uint32_t nchunks_total, char* __restrict__ V,
+                                                           char* __restrict__ work) {
+  const uint32_t pr = threadIdx.x >> 1, t = blockIdx.x * 64 + pr; const bool odd = threadIdx.x & 1;
+  if (t >= nchunks_total) return;
+  char* run = work + (size_t)t * 3 * P2B; char* acc = run + P2B; char* r = acc + P2B;      // the pair's three working points (global memory: L2-resident)
+  g2p_store_inf(run, odd); g2p_store_inf(acc, odd); g2p_store_inf(r, odd);
+  const uint32_t cpw = B / S, w = t / cpw, j = t % cpw, g0 = w * B + j * S;
+  for (uint32_t k = 0; k < S; ++k) {
+    const uint32_t g = g0 + (S - 1 - k);
+    if (hist[g]) g2p_add_any(run, partial + (size_t)scan_at(scan_local, scan_blk, g).y * P2B, run);
+    g2p_add_any(acc, run, acc);
+  }
+  const uint32_t base = j * S;
+  if (base) {
+    for (int bit = 31 - __clz(base); bit >= 0; --bit) { g2p_double_any(r, r); if ((base >> bit) & 1) g2p_add_any(r, run, r); }
+    g2p_add_any(acc, r, acc);
+  }
+  const XYZZ2P v = g2p_load(acc, odd); g2p_store(V + (size_t)t * P2B, odd, v);
+}
+__global__ void __launch_bounds__(256) k_g2p_seg_tree_pass(char* __restrict__ V, uint32_t seg_len, uint32_t nseg, uint32_t L) {
+  const uint32_t half = (L + 1) >> 1, pairs = L - half;
+  const uint32_t op = (blockIdx.x * 256 + threadIdx.x) >> 1;
+  if (op >= pairs * nseg) return;
+  const uint32_t seg = op / pairs, i = op % pairs;
+  char* pa = V + ((size_t)seg * seg_len + i) * P2B;
+  g2p_add_any(pa, pa + (size_t)half * P2B, pa);
+}
+__global__ void k_g2p_gather_windows(const char* __restrict__ V, uint32_t seg_len, uint32_t W, char* __restrict__ out) {
+  uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= W * 28) return;
+  uint32_t w = t / 28, q = t % 28;
+  ((uint4*)out)[t] = ((const uint4*)(V + (size_t)w * seg_len * P2B))[q];
+}
+
 // V[seg*seg_len + i] += V[seg*seg_len + i + half] for i < L - half
 __global__ void __launch_bounds__(256) k_g2_seg_tree_pass(char* __restrict__ V, uint32_t seg_len, uint32_t nseg, uint32_t L) {
   const uint32_t half = (L + 1) >> 1, pairs = L - half;
@@ -329,6 +494,57 @@ __global__ void k_g2_gather_windows(const char* __restrict__ V, uint32_t seg_len
   if (t >= W * 24) return;
   uint32_t w = t / 24, q = t % 24;
   ((uint4*)out)[t] = ((const uint4*)(V + (size_t)w * seg_len * 384))[q];
+}
+
+// Test hook: the pair-form addition / doubling against the one-lane 32-bit code on chains of real curve points (aleo_mi355x_selftest_g2pair).
+// Pair t takes the affine points i = t, t + 1, t + 2 (mod n): s = (P_i + P_j) + P_k, u = s + (P_i + P_j), d = 2u, e = u + u (the same-point case),
+// z = u + (-u) (the opposite case), w = z + s (identity operand) — every result compared with the 32-bit code's by subtracting and asking for the identity.
+__global__ void __launch_bounds__(128) k_g2p_selftest(const char* __restrict__ aff192, uint32_t n, uint32_t npairs, char* __restrict__ scratch, uint32_t* __restrict__ failures) {
+  const uint32_t t = (blockIdx.x * 128 + threadIdx.x) >> 1; const bool odd = threadIdx.x & 1;
+  if (t >= npairs) return;
+  char* sl = scratch + (size_t)t * 9 * P2B;                  // nine pair-form slots per pair
+  auto aff = [&](uint32_t i) { XYZZ2 r; const char* row = aff192 + (size_t)(i % n) * 192; r.X = load_fq2(row); r.Y = load_fq2(row + 96); r.ZZ = fq2_one(); r.ZZZ = fq2_one(); return r; };
+  XYZZ2 Pi = aff(t), Pj = aff(t + 1), Pk = aff(t + 2);
+  if (!odd) { g2_xyzz2_to_p2(&Pi, sl); g2_xyzz2_to_p2(&Pj, sl + P2B); g2_xyzz2_to_p2(&Pk, sl + 2 * P2B); }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  bool okm;
+  { XYZZ2P m = g2p_load(sl, odd); const XYZZ2P pj = g2p_load(sl + P2B, odd); okm = g2p_madd_fast(m, pj.X, pj.Y, odd); g2p_store(sl + 8 * P2B, odd, m); }      // the mixed addition of the accumulation loop on the same operands
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  g2p_add_any(sl, sl + P2B, sl + 3 * P2B);                   // a = Pi + Pj
+  if (!okm) { const XYZZ2P v = g2p_load(sl + 3 * P2B, odd); g2p_store(sl + 8 * P2B, odd, v); }      // P_i = +-P_j: the fast form refuses (the accumulation kernel leaves its loop there); the general sum stands in
+  g2p_add_any(sl + 3 * P2B, sl + 2 * P2B, sl + 4 * P2B);     // s = a + Pk
+  g2p_add_any(sl + 4 * P2B, sl + 3 * P2B, sl + 5 * P2B);     // u = s + a
+  g2p_double_any(sl + 5 * P2B, sl + 6 * P2B);                // d = 2u
+  g2p_add_any(sl + 5 * P2B, sl + 5 * P2B, sl + 7 * P2B);     // e = u + u
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (odd) return;
+  XYZZ2 a = Pi; g2_add_ni(&a, &Pj); XYZZ2 sref = a; g2_add_ni(&sref, &Pk); XYZZ2 u = sref; g2_add_ni(&u, &a); XYZZ2 d = u; g2_double_ni(&d);
+  auto differs = [&](const char* slot, const XYZZ2& want) {
+    XYZZ2 got; g2_p2_to_xyzz2(slot, &got);
+    XYZZ2 neg = want; neg.Y.a = lt2q(Fq::sub<2>(Fq::zero(), neg.Y.a)); neg.Y.b = lt2q(Fq::sub<2>(Fq::zero(), neg.Y.b));
+    g2_add_ni(&got, &neg);
+    return !(g2_is_inf(got) || fq2_is_zero(got.ZZ));
+  };
+  uint32_t bad = 0;
+  if (differs(sl + 8 * P2B, a)) bad |= 64;                  // g2p_madd_fast
+  if (differs(sl, Pi)) bad |= 32;                           // the conversions alone
+  if (differs(sl + 3 * P2B, a)) bad |= 1;
+  if (differs(sl + 4 * P2B, sref)) bad |= 2;
+  if (differs(sl + 5 * P2B, u)) bad |= 4;
+  if (differs(sl + 6 * P2B, d)) bad |= 8;
+  if (differs(sl + 7 * P2B, d)) bad |= 16;
+  if (bad) { atomicAdd(failures, 1u); atomicOr(failures + 1, bad); }
+}
+int32_t selftest_g2pair(Ctx* c, const void* aff192_host, uint32_t n, uint32_t npairs, uint32_t* failures2) {
+  DevTmp pts, scr, fl; int32_t rc;
+  if ((rc = pts.alloc((size_t)n * 192)) || (rc = scr.alloc((size_t)npairs * 9 * P2B)) || (rc = fl.alloc(8))) return rc;
+  HIPCHK(hipMemcpyAsync(pts.p, aff192_host, (size_t)n * 192, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemsetAsync(fl.p, 0, 8, c->stream));
+  hipLaunchKernelGGL(k_g2p_selftest, dim3((2 * npairs + 127) / 128), dim3(128), 0, c->stream, (const char*)pts.p, n, npairs, (char*)scr.p, (uint32_t*)fl.p);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(failures2, fl.p, 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return ALEO_MI355X_OK;
 }
 
 // ---- host tail: Fq2 and G2 on the host -----------------------------------------------------------------------------------------
@@ -406,19 +622,35 @@ int32_t msm_g2_run(Ctx* c, uint64_t* out_jac36, const void* d_xy, const uint8_t*
   MsmPlan P = make_plan(n, 0);
   SegArgs segs{}; segs.nseg = 1; segs.ptr[0] = (const char*)d_scalars; segs.n[0] = (uint32_t)n;
   int32_t rc;
-  if ((rc = ensure_host_pinned(c, 64 + (size_t)P.W * 384))) return rc;
+  if ((rc = ensure_host_pinned(c, 64 + (size_t)P.W * 448))) return rc;
   SortPhase sp;
   if ((rc = msm_sort_phase(c, segs, n, false, d_inf, (uint32_t)n, P, false, s, &sp))) return rc;
   const uint32_t M = sp.M, cpw = P.B / P.S, nchunks = cpw * P.W;
-  if ((rc = c->partial.reserve(sp.slices_max * 384))) return rc;
-  if ((rc = c->vbuf.reserve(((size_t)nchunks + P.W) * 384))) return rc;
-  char* partial = c->partial.as<char>(); char* V = c->vbuf.as<char>(); char* Vout = V + (size_t)nchunks * 384;
-  static const bool pair28 = [] { const char* e = std::getenv("ALEO_MI355X_G2_PAIR28"); return !(e && e[0] == '0'); }();      // A/B switch: 0 = the round-2 kernel (32-bit limbs, one lane per slice, out-of-line field calls)
-  if (pair28) {
-    if ((rc = c->out_stage.reserve(n * 224))) return rc;                          // the bases in the 28-bit form (per call: a G2 MSM keeps nothing resident)
+  if ((rc = c->partial.reserve(sp.slices_max * 448))) return rc;
+  if ((rc = c->vbuf.reserve(((size_t)nchunks * 4 + P.W) * 448))) return rc;      // chunk sums | window sums | three working points per chunk (pair form)
+  static const int pair_mode = [] { const char* e = std::getenv("ALEO_MI355X_G2_PAIR28"); return e ? std::atoi(e) : 1; }();      // A/B switch: 0 = the round-2 kernels (32-bit limbs, one lane per operation, out-of-line field calls); 2 = pair-form accumulation + one-lane reduction
+  const bool pair_accum = pair_mode != 0; const bool pair28 = pair_mode == 1;      // (3: mode 2 + a comparison of the two accumulation kernels' slice sums on stderr)
+  const size_t PBY = pair28 ? 448 : 384;                    // bytes per stored point of the reduction
+  char* partial = c->partial.as<char>(); char* V = c->vbuf.as<char>(); char* Vout = V + (size_t)nchunks * PBY;
+  if (pair_accum) {
+    if ((rc = c->out_stage.reserve(n * 224 + (pair28 ? 0 : sp.slices_max * 384)))) return rc;                          // the bases in the 28-bit form (per call: a G2 MSM keeps nothing resident)
     hipLaunchKernelGGL(k_g2_rows_to28, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, (const char*)d_xy, c->out_stage.as<char>(), (uint32_t)n);
     hipLaunchKernelGGL(k_g2_accum28, dim3(2 * sp.slice_blocks), dim3(256), 0, s, c->out_stage.as<const char>(), (const char*)d_xy, sp.sorted, sp.hist, sp.scan_local, sp.scan_blk,
                        sp.total_pairs, M, sp.meta, sp.order, sp.task_g, partial);
+    if (!pair28) {                                         // mode 2: hand the slice sums to the one-lane kernels
+      char* p32 = c->out_stage.as<char>() + n * 224;
+      hipLaunchKernelGGL(k_g2_p2_to_32, dim3(sp.slice_blocks), dim3(256), 0, s, partial, p32, sp.meta);
+      if (pair_mode == 3) {                                // debug: the round-2 kernel's slice sums beside them
+        DevTmp ref, cnt; if ((rc = ref.alloc(sp.slices_max * 384)) || (rc = cnt.alloc(8))) return rc;
+        uint32_t init[2] = {0u, 0xffffffffu}; HIPCHK(hipMemcpyAsync(cnt.p, init, 8, hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(k_g2_accum, dim3(sp.slice_blocks), dim3(256), 0, s, (const char*)d_xy, sp.sorted, sp.hist, sp.scan_local, sp.scan_blk, sp.total_pairs, M, sp.meta, sp.order, sp.task_g, (char*)ref.p);
+        hipLaunchKernelGGL(k_g2_compare, dim3(sp.slice_blocks), dim3(256), 0, s, (const char*)ref.p, (const char*)p32, sp.meta, (uint32_t*)cnt.p);
+        uint32_t res[2], hm[8]; HIPCHK(hipMemcpyAsync(res, cnt.p, 8, hipMemcpyDeviceToHost, s)); HIPCHK(hipMemcpyAsync(hm, sp.meta, 32, hipMemcpyDeviceToHost, s)); HIPCHK(hipStreamSynchronize(s));
+        fprintf(stderr, "g2 debug: n = %zu, slices = %u, differing = %u, first = %u\n", n, hm[0], res[0], res[1]);
+        uint32_t ra[96], rb[96], rp[112]; HIPCHK(hipMemcpy(ra, ref.p, 384, hipMemcpyDeviceToHost)); HIPCHK(hipMemcpy(rb, p32, 384, hipMemcpyDeviceToHost)); HIPCHK(hipMemcpy(rp, c->partial.p, 448, hipMemcpyDeviceToHost));
+      }
+      partial = p32;
+    }
   } else
   hipLaunchKernelGGL(k_g2_accum, dim3(sp.slice_blocks), dim3(256), 0, s, (const char*)d_xy, sp.sorted, sp.hist, sp.scan_local, sp.scan_blk, sp.total_pairs, M, sp.meta,
                      sp.order, sp.task_g, partial);
@@ -429,30 +661,56 @@ int32_t msm_g2_run(Ctx* c, uint64_t* out_jac36, const void* d_xy, const uint8_t*
     const uint32_t Lc = sm.super_overflow ? L : (L < 16u ? L : (16u >> (pass < 4 ? pass : 4)));
     if (sm.n_heavy && Lc > 1) {
       uint32_t mp = Lc >> 1; uint64_t threads = (uint64_t)sm.n_heavy * mp;
-      hipLaunchKernelGGL(k_g2_tree_pass, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, s, partial, sp.heavy, sp.scan_local, sp.scan_blk, M, sp.meta, pass, mp, sm.n_heavy);
+      if (pair28) hipLaunchKernelGGL(k_g2p_tree_pass, dim3((uint32_t)((2 * threads + 255) / 256)), dim3(256), 0, s, partial, sp.heavy, sp.scan_local, sp.scan_blk, M, sp.meta, pass, mp, sm.n_heavy);
+      else hipLaunchKernelGGL(k_g2_tree_pass, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, s, partial, sp.heavy, sp.scan_local, sp.scan_blk, M, sp.meta, pass, mp, sm.n_heavy);
     }
     if (sm.n_super) {
       uint32_t mp = L >> 1; uint64_t threads = (uint64_t)sm.n_super * mp;
-      hipLaunchKernelGGL(k_g2_tree_pass, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, s, partial, sp.super_list, sp.scan_local, sp.scan_blk, M, sp.meta, pass, mp, sm.n_super);
+      if (pair28) hipLaunchKernelGGL(k_g2p_tree_pass, dim3((uint32_t)((2 * threads + 255) / 256)), dim3(256), 0, s, partial, sp.super_list, sp.scan_local, sp.scan_blk, M, sp.meta, pass, mp, sm.n_super);
+      else hipLaunchKernelGGL(k_g2_tree_pass, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, s, partial, sp.super_list, sp.scan_local, sp.scan_blk, M, sp.meta, pass, mp, sm.n_super);
     }
   }
-  hipLaunchKernelGGL(k_g2_bucket_chunks, dim3((nchunks + 255) / 256), dim3(256), 0, s, partial, sp.hist, sp.scan_local, sp.scan_blk, P.B, P.S, nchunks, V);
+  if (pair28) hipLaunchKernelGGL(k_g2p_bucket_chunks, dim3((nchunks + 63) / 64), dim3(128), 0, s, partial, sp.hist, sp.scan_local, sp.scan_blk, P.B, P.S, nchunks, V, Vout + (size_t)P.W * 448);
+  else hipLaunchKernelGGL(k_g2_bucket_chunks, dim3((nchunks + 255) / 256), dim3(256), 0, s, partial, sp.hist, sp.scan_local, sp.scan_blk, P.B, P.S, nchunks, V);
   for (uint32_t L = cpw; L > 1; L = (L + 1) >> 1) {
     uint32_t pairs = (L - ((L + 1) >> 1)) * P.W;
-    hipLaunchKernelGGL(k_g2_seg_tree_pass, dim3((pairs + 255) / 256), dim3(256), 0, s, V, cpw, P.W, L);
+    if (pair28) hipLaunchKernelGGL(k_g2p_seg_tree_pass, dim3((2 * pairs + 255) / 256), dim3(256), 0, s, V, cpw, P.W, L);
+    else hipLaunchKernelGGL(k_g2_seg_tree_pass, dim3((pairs + 255) / 256), dim3(256), 0, s, V, cpw, P.W, L);
   }
-  hipLaunchKernelGGL(k_g2_gather_windows, dim3((P.W * 24 + 255) / 256), dim3(256), 0, s, V, cpw, P.W, Vout);
+  if (pair28) hipLaunchKernelGGL(k_g2p_gather_windows, dim3((P.W * 28 + 255) / 256), dim3(256), 0, s, V, cpw, P.W, Vout);
+  else hipLaunchKernelGGL(k_g2_gather_windows, dim3((P.W * 24 + 255) / 256), dim3(256), 0, s, V, cpw, P.W, Vout);
   char* h_win = (char*)c->h_pinned + 64;
-  HIPCHK(hipMemcpyAsync(h_win, Vout, (size_t)P.W * 384, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipMemcpyAsync(h_win, Vout, (size_t)P.W * PBY, hipMemcpyDeviceToHost, s));
   HIPCHK(hipStreamSynchronize(s));
   HIPCHK(hipGetLastError());
   // host tail: total = sum_w 2^(c w) * S_w (Horner from the top window); device coordinates are lazily reduced (< 2q)
   auto lazy2 = [](const uint64_t* p) { HFq2 r; r.a = HFq::reduce_lazy(p); r.b = HFq::reduce_lazy(p + 6); return r; };
+  // a 56-byte component of the pair form: value * 2^392 (+ a few q) as 14 x 28-bit limbs; * 2^376 under the 2^-384 of the host Montgomery product gives the HFq form
+  auto comp28 = [](const char* p) {
+    const uint32_t* w = (const uint32_t*)p; uint64_t big[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < 14; ++i) {
+      const int pos = 28 * i, j = pos >> 6, sh = pos & 63;
+      const unsigned __int128 add = (unsigned __int128)w[i] << sh;
+      unsigned __int128 t = (unsigned __int128)big[j] + (uint64_t)add; big[j] = (uint64_t)t;
+      t = (unsigned __int128)big[j + 1] + (uint64_t)(add >> 64) + (uint64_t)(t >> 64); big[j + 1] = (uint64_t)t;
+      uint64_t cr = (uint64_t)(t >> 64);
+      for (int q = j + 2; q < 8 && cr; ++q) { t = (unsigned __int128)big[q] + cr; big[q] = (uint64_t)t; cr = (uint64_t)(t >> 64); }
+    }
+    HFq c376 = HFq::zero(); c376.l[5] = 1ull << 56;
+    return HFq::mul(HFq::reduce_lazy(big), c376);
+  };
+  auto point28 = [&](const char* p) {
+    HXYZZ2 v; HFq2* f[4] = {&v.X, &v.Y, &v.ZZ, &v.ZZZ};
+    for (int i = 0; i < 4; ++i) { f[i]->a = comp28(p + 112 * i); f[i]->b = comp28(p + 112 * i + 56); }
+    if (v.ZZ.is_zero()) return HXYZZ2::infinity();
+    return v;
+  };
   HXYZZ2 total = HXYZZ2::infinity();
   for (int w = (int)P.W - 1; w >= 0; --w) {
     for (int d = 0; d < plan_win_width((int)P.c, w); ++d) total = h2double(total);
-    const uint64_t* src = (const uint64_t*)(h_win + (size_t)w * 384);
-    HXYZZ2 v; v.X = lazy2(src); v.Y = lazy2(src + 12); v.ZZ = lazy2(src + 24); v.ZZZ = lazy2(src + 36);
+    HXYZZ2 v;
+    if (pair28) v = point28(h_win + (size_t)w * 448);
+    else { const uint64_t* src = (const uint64_t*)(h_win + (size_t)w * 384); v.X = lazy2(src); v.Y = lazy2(src + 12); v.ZZ = lazy2(src + 24); v.ZZZ = lazy2(src + 36); }
     total = h2add(total, v);
   }
   h2store_jacobian_normalized(out_jac36, total);

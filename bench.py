@@ -31,6 +31,7 @@ def main():
     ap.add_argument('--lg-n', type=int, default=None, help='log2 of the points per GPU (default 20; with --config 4: log2 of the TOTAL, default 26)')
     ap.add_argument('--scalars', default='uniform', choices=['uniform', 'witness'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-crossover', action='store_true', help='skip the one-shot GPU vs CPU crossover table of the cpu_baseline leg')
     ap.add_argument('--cpu-sample-lg', type=int, default=20)
     ap.add_argument('--no-precompute', action='store_true', help='headline without the fixed-base window table')
     ap.add_argument('--no-variants', action='store_true', help='skip the resident-scalars / no-table variants')
@@ -499,7 +500,8 @@ def msm_g2_bench(aleo_amd, synth):
     the accumulation kernel sustains (the 81 G/s of roofline.valu is the G1 block's peak)."""
     from aleo_amd import msm as M
     out = {'entry_point': 'aleo_mi355x_msm_g2', 'bases': 'P_i = ((i mod 4096) + 1) G2, host memory, uploaded and unpacked inside every call',
-           'round3_kernel_same_box_r04': {'2^16_ms': 7.99, '2^20_ms': 95.27, 'file': 'profiles/r04_g2_round2_kernel.jsonl'}}
+           'before_round4': {'2^16_ms': 7.99, '2^20_ms': 95.27, 'file': 'profiles/r04_g2_round2_kernel.jsonl', 'what': 'round-3 state measured at the start of round 4: one-lane 32-bit kernels, 200-byte rows repacked by a host loop'},
+           'round2_kernels_with_device_unpack': {'2^16_ms': 7.28, '2^20_ms': 30.61, 'file': 'profiles/r04_g2_round2_kernels_device_unpack.jsonl', 'what': 'ALEO_MI355X_G2_PAIR28=0 on the same box as profiles/r04_g2_pair28.jsonl'}}
     for lg in (16, 20):
         n = 1 << lg
         B = synth.g2_multiples_affine200(n); S = synth.uniform_scalars(n, 0xA1E00077)
@@ -989,6 +991,41 @@ def effective_cpus():
     return n
 
 
+def crossover(c, aleo_amd, bases, scalars, cores):
+    """Where the drop-in pays (`if n >= MI355X_MIN_MSM` / `size >= MI355X_MIN_NTT` in the Rust stub): the ONE-SHOT entry points on host
+    buffers — aleo_mi355x_msm_g1 (104-byte bases + scalars uploaded, nothing cached) and aleo_mi355x_ntt_fr (in place on host memory) — against the
+    restatement on all usable host cores, 2^6 .. 2^20.  The first size from which the GPU call is faster for good is the threshold a maintainer sets
+    (the library's defaults: aleo_mi355x_min_msm / aleo_mi355x_min_ntt, overridable by ALEO_MI355X_MIN_MSM / ALEO_MI355X_MIN_NTT)."""
+    from aleo_amd import synth
+    rows = []
+    def best(fn, reps):
+        fn(); ts = []
+        for _ in range(reps):
+            t = time.perf_counter(); fn(); ts.append(time.perf_counter() - t)
+        return float(np.median(ts)) * 1e3
+    x_all = c.fr_to_mont(synth.uniform_scalars(1 << 20, 0xA1E00090))
+    for lg in range(6, 21, 2):
+        n = 1 << lg; B = np.ascontiguousarray(bases[:n]); S = np.ascontiguousarray(scalars[:n]); reps = 5 if lg <= 16 else 3
+        g_msm = best(lambda: aleo_amd.VariableBase.msm(B, S), reps)
+        c_msm = best(lambda: c.msm_g1(B, S, threads=cores, variant=3), reps)
+        c_msm1 = best(lambda: c.msm_g1(B, S, threads=1, variant=1), 2) if lg <= 14 else None
+        d = aleo_amd.EvaluationDomain(n); x = x_all[:n].copy()
+        g_ntt = best(lambda: d.fft_in_place(x), reps)
+        c_ntt = best(lambda: c.ntt_fr(x, 0, 0, 0, threads=cores), reps)
+        c_ntt1 = best(lambda: c.ntt_fr(x, 0, 0, 0), reps)
+        rows.append({'lg_n': lg, 'msm_gpu_one_shot_ms': g_msm, 'msm_cpu_ms': c_msm if c_msm1 is None else min(c_msm, c_msm1), 'ntt_gpu_host_buffer_ms': g_ntt, 'ntt_cpu_ms': min(c_ntt, c_ntt1)})
+    def first_win(gk, ck):
+        lg_win = None
+        for r in reversed(rows):
+            if r[gk] < r[ck]: lg_win = r['lg_n']
+            else: break
+        return lg_win
+    return {'rows': rows, 'cpu_threads': cores, 'msm_gpu_wins_from_lg': first_win('msm_gpu_one_shot_ms', 'msm_cpu_ms'), 'ntt_gpu_wins_from_lg': first_win('ntt_gpu_host_buffer_ms', 'ntt_cpu_ms'),
+            'library_defaults': {'min_msm': int(aleo_amd.lib().aleo_mi355x_min_msm()), 'min_ntt': int(aleo_amd.lib().aleo_mi355x_min_ntt())},
+            'note': 'CPU = the C restatement (best of one thread and all usable threads), not the Rust binary: snarkVM on the same cores may be faster or slower by a small factor; '
+                    'the GPU side is the cold two-line drop-in (no pinned SRS, no table) — with bases_pin the MSM crossover moves down to the launch-latency floor'}
+
+
 def synth_mod():
     from aleo_amd import synth
     return synth
@@ -1030,7 +1067,11 @@ def cpu_baseline(args, pb, scalars, aleo_amd):
         vcpu['large_circuit'] = {'constraints': b['constraints'], 'device_proof_verifies': ok1, 'eight_instance_proof_verifies': ok8,
                                  'tampered_proof_refused': not V.verify(vk, setup, b['public'], bytes(bad)), 'verify_s': time.perf_counter() - t0,
                                  'verifier': 'oracle/varuna_ref.py VerifyingKey: index commitments + domain sizes exported by the library; pairing products for the single proof'}
-    return {'proof_proxy': proxy, 'varuna': vcpu, 'one_core': {'value': n1 / dt1, 'unit': 'scalar-muls/s', 'cores': 1, 'seconds': dt1, 'sample': '2^%d-point prefix' % (n1.bit_length() - 1)},
+    cross = None
+    if not args.no_crossover:
+        try: cross = crossover(c, aleo_amd, bases, s, all_cores)
+        except Exception as e: cross = {'error': repr(e)[:300]}
+    return {'crossover': cross, 'proof_proxy': proxy, 'varuna': vcpu, 'one_core': {'value': n1 / dt1, 'unit': 'scalar-muls/s', 'cores': 1, 'seconds': dt1, 'sample': '2^%d-point prefix' % (n1.bit_length() - 1)},
             'value': ns / dt, 'unit': 'scalar-muls/s', 'cores': all_cores, 'kind': 'port', 'seconds': dt,
             'host_cpus': os.cpu_count(), 'usable_cpus': effective_cpus(),
             'window_parallel_only': {'value': ns / dt_ref, 'unit': 'scalar-muls/s', 'cores': cores, 'seconds': dt_ref,

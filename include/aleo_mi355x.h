@@ -443,6 +443,11 @@ int32_t aleo_mi355x_selftest_madd28(uint32_t lanes, uint32_t steps, uint64_t see
  * (identity operands, equal points, opposite points): *failures = number of disagreements (mod q, all four coordinates). */
 int32_t aleo_mi355x_selftest_addquad(uint32_t ops, uint64_t seed, uint32_t* failures);
 
+/* The lane-pair Fq2 arithmetic of the G2 path (g2.hip: components of an Fq2 value across two lanes, 28-bit limbs) against the one-lane 32-bit code on
+ * chains over n_points affine G2 points (192-byte rows, host memory, >= 3 of them, all on the curve): sums, a sum with a shared operand, a doubling, the
+ * same-point case of the addition.  failures2[0] = pairs that disagreed, failures2[1] = OR of the failing steps (1 a, 2 s, 4 u, 8 2u, 16 u + u). */
+int32_t aleo_mi355x_selftest_g2pair(const void* affine192, uint32_t n_points, uint32_t n_pairs, uint32_t* failures2);
+
 /* Per-call instrumentation of the calling thread's most recent MSM: milliseconds per phase
  * [0] total, [1] digit/sort, [2] bucket accumulation incl. slice tree, [3] bucket reduction, [4] host tail,
  * [5] the bucket-accumulation kernel alone (the dominant kernel bench.py prices against the roofline): mean duration of its launches,
@@ -450,6 +455,11 @@ int32_t aleo_mi355x_selftest_addquad(uint32_t ops, uint64_t seed, uint32_t* fail
  * Returns the number of doubles written (<= cap). */
 int32_t aleo_mi355x_last_msm_timing(double* out_ms, int32_t cap);
 
+/* Routing thresholds for the drop-in: below these sizes the Rust arms keep the CPU path — a 2^6..2^12 host-buffer call costs two PCIe
+ * copies and 20-50 us of launches against microseconds on a core.  Defaults = the crossovers measured for the cold one-shot calls against the CPU path on
+ * the GPU box's host cores (bench.py cpu_baseline.crossover; profiles/r04_crossover.json); ALEO_MI355X_MIN_MSM / ALEO_MI355X_MIN_NTT override them. */
+size_t aleo_mi355x_min_msm(void);
+size_t aleo_mi355x_min_ntt(void);
 const char* aleo_mi355x_strerror(int32_t status);
 const char* aleo_mi355x_last_error(void);   /* thread-local detail string of the last failure */
 const char* aleo_mi355x_version(void);

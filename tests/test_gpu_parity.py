@@ -1022,6 +1022,21 @@ def test_msm_g2_edge_cases():
     assert (M.g2_sum(parts) == M.msm_g2(B, S)).all()
 
 
+def test_g2_lane_pair_arithmetic_matches_the_one_lane_code():
+    """The lane-pair Fq2 arithmetic of the G2 path (components across two lanes, 28-bit limbs: full addition, doubling, the same-point case of the addition,
+    the mixed addition of the accumulation loop) against the one-lane 32-bit code on chains over real curve points, every intermediate compared as a
+    group element.  (Round 4's first version exchanged the lanes' zero flags behind a short-circuit `&&`: the lane whose flag was false skipped the
+    exchange and its partner read an inactive lane — every affine operand, whose ZZ is (1, 0), looked like the identity to one lane of the pair.)"""
+    B = _g2_multiples(200)
+    rows = np.ascontiguousarray(B[:, :192]); f = (ctypes.c_uint32 * 2)()
+    assert aleo_amd.lib().aleo_mi355x_selftest_g2pair(rows.ctypes.data_as(ctypes.c_void_p), 200, 198, f) == 0
+    assert (f[0], f[1]) == (0, 0), 'pairs that disagreed: %d, failing steps mask %d' % (f[0], f[1])
+    same = np.ascontiguousarray(np.repeat(rows[:1], 8, axis=0))            # P_i = P_j = P_k: every addition of the chain is a doubling or meets equal operands
+    assert aleo_amd.lib().aleo_mi355x_selftest_g2pair(same.ctypes.data_as(ctypes.c_void_p), 8, 4, f) == 0
+    assert (f[0], f[1]) == (0, 0)
+    assert aleo_amd.lib().aleo_mi355x_selftest_g2pair(None, 8, 4, f) == 2
+
+
 def test_msm_g2_2_16_structured_identity():
     n = 1 << 16
     B = _g2_multiples(n); S = util.uniform_scalars(n, 16999)
