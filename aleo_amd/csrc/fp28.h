@@ -194,8 +194,13 @@ __device__ __forceinline__ XYZZ load_xyzz_from28(const void* p) {
 // ---- lane-pair cooperative addition in the 28-bit form (same level plan as ec.h xyzz_add_pair) ---------------------------
 __device__ __forceinline__ F28 f28_xchg(const F28& a) {
   F28 r;
+#ifdef ALEO_XCHG_BPERMUTE
 #pragma unroll
-  for (int i = 0; i < 14; ++i) r.v[i] = (uint32_t)__shfl_xor((int)a.v[i], 1);
+  for (int i = 0; i < 14; ++i) r.v[i] = (uint32_t)__shfl_xor((int)a.v[i], 1);      // (rounds 1-3: compiled to ds_bpermute_b32 — an LDS-crossbar round trip per limb)
+#else
+#pragma unroll
+  for (int i = 0; i < 14; ++i) r.v[i] = (uint32_t)__builtin_amdgcn_mov_dpp((int)a.v[i], 0xB1 /* quad_perm [1, 0, 3, 2] */, 0xF, 0xF, true);
+#endif
   return r;
 }
 __device__ __forceinline__ F28 f28_sel(bool take_b, const F28& a, const F28& b) {

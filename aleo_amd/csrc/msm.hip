@@ -1336,8 +1336,26 @@ static int32_t msm_back(Ctx* c, uint64_t* out_jac18, Front& f, hipStream_t s, bo
   return ALEO_MI355X_OK;
 }
 
+static int32_t msm_run_chunked(Ctx* c, HelperSet& hs, uint64_t* out_jac18, const PinnedBases& pb, size_t n, bool mont, hipStream_t s, const void* host_src, const MsmJob* dev_job = nullptr);
+static uint32_t chunks3_min_lg();
+// Requests with the scalars already on the device CAN go in chunks too (msm_run_chunked with dev_job): the sort of the later chunks then runs beside the
+// accumulation of the earlier ones instead of in front of everything.  Measured and OFF by default (round 4, resident uniform scalars, whole / chunked):
+// 2^20 2.82 / 3.03 ms, 2^21 5.12 / 5.24, 2^22 9.41 / 9.51 — without an upload to hide, the seeded launches (+5 % accumulation time: shorter slices, a seed
+// read and a product per bucket) and the sort that crawls beside an accumulation holding every wave slot cost more than the 0.3-1.0 ms of sort they
+// move out of the way.  ALEO_MI355X_CHUNK_DEV_MIN_LG: lg of the smallest such request (default 0 = never; the GPU suite passes with 20).
+static uint32_t chunk_dev_min_lg() { static const uint32_t v = [] { const char* e = std::getenv("ALEO_MI355X_CHUNK_DEV_MIN_LG"); const int k = e ? std::atoi(e) : 0; return (uint32_t)(k >= 0 && k <= 40 ? k : 0); }(); return v; }
 int32_t msm_run(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, const MsmJob& job, hipStream_t s) {
   if (job.k == 0) return ALEO_MI355X_OK;
+  if (chunk_dev_min_lg() && !job.sparse && c->dev && job.k <= MAX_SETS && job.nseg <= MAX_SEGS) {
+    size_t pts = 0, reach = 0; bool in_range = true;
+    for (uint32_t q = 0; q < job.nseg; ++q) { const MsmSeg& g = job.segs[q]; if (!g.len) continue; pts += g.len; reach = g.off + g.len > reach ? g.off + g.len : reach; in_range = in_range && g.out < job.k; }
+    if (job.tier_n > reach && job.tier_n <= pb.n) reach = job.tier_n;
+    bool tiered = false; for (const auto& t : pb.tab) if (t.d && reach >= t.min_n && reach <= t.cover) { tiered = job.k <= 1 || job.k <= msm_max_sets(pb, reach); break; }
+    if (in_range && tiered && pts >= ((size_t)1 << chunk_dev_min_lg())) {
+      HelperSet hs; { const int32_t rc = acquire_helpers(c->dev, pts >= ((size_t)1 << chunks3_min_lg()) ? 2 : 1, hs); if (rc) return rc; }
+      if (!hs.ctx.empty()) return msm_run_chunked(c, hs, out_jac18, pb, reach, job.mont, s, nullptr, &job);
+    }
+  }
   Front f; int32_t rc;
   if ((rc = msm_front_sort(c, pb, job, s, f))) return rc;
   if (f.empty) { for (uint32_t q = 0; q < job.k; ++q) host::hstore_jacobian_normalized(out_jac18 + 18 * q, host::HXYZZ::infinity()); return ALEO_MI355X_OK; }
@@ -1361,22 +1379,42 @@ int32_t msm_run(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, const MsmJob
 // hides it.  What is left on the table: a sort queued beside an accumulation that holds every wave slot (248 VGPRs x 2 waves per SIMD, workgroups that
 // live ~250 us) takes ~0.5 ms instead of 0.15, so the next accumulation starts ~0.2 ms late.
 // (Round 3 ran two halves as two complete MSMs on two host threads: that paid the 0.4 ms bucket reduction twice and lost below 2^21 points.)
-static int32_t msm_run_chunked(Ctx* c, HelperSet& hs, uint64_t* out_jac18, const PinnedBases& pb, size_t n, bool mont, hipStream_t s, const void* host_src) {
+// dev_job != nullptr: the scalars are already on the device (any number of sets and segments: every segment is cut at the same fractions; n = the request's
+// reach, its tier) — nothing is uploaded, and what the later chunks hide under the earlier chunks' accumulation is their sort alone, so the first chunk is
+// smaller (28 / 72 %, 12 / 28 / 60 %); the helper streams first wait for an event on `s`, where the caller's scalars may still be in flight.
+static int32_t msm_run_chunked(Ctx* c, HelperSet& hs, uint64_t* out_jac18, const PinnedBases& pb, size_t n, bool mont, hipStream_t s, const void* host_src, const MsmJob* dev_job) {
   const uint32_t Q = 1 + (uint32_t)hs.ctx.size();           // 2 or 3
-  static const uint32_t share[4][3] = {{0, 0, 0}, {0, 0, 0}, {37, 63, 0}, {18, 30, 52}};
+  static const uint32_t share_host[4][3] = {{0, 0, 0}, {0, 0, 0}, {37, 63, 0}, {18, 30, 52}}, share_dev[4][3] = {{0, 0, 0}, {0, 0, 0}, {28, 72, 0}, {12, 28, 60}};
+  const uint32_t (*share)[3] = dev_job ? share_dev : share_host;
+  const uint32_t K = dev_job ? dev_job->k : 1u;
   Ctx* cx[3] = {c, Q > 1 ? hs.ctx[0] : nullptr, Q > 2 ? hs.ctx[1] : nullptr}; hipStream_t st[3] = {s, Q > 1 ? hs.ctx[0]->hi : nullptr, Q > 2 ? hs.ctx[1]->hi : nullptr};
   size_t lo[4] = {0, 0, 0, 0};
   for (uint32_t k = 0, acc = 0; k < Q; ++k) { acc += share[Q][k]; lo[k + 1] = k + 1 == Q ? n : (((size_t)((double)n * acc / 100.0)) + 255) & ~(size_t)255; if (lo[k + 1] > n) lo[k + 1] = n; }
-  Front f[3]; MsmSeg seg[3]; int32_t rc;
+  Front f[3]; MsmSeg seg[3]; std::vector<MsmSeg> dsegs[3]; int32_t rc; uint32_t cum[4] = {0, 0, 0, 0};
+  for (uint32_t k = 0; k < Q; ++k) cum[k + 1] = k + 1 == Q ? 100u : cum[k] + share[Q][k];
+  if (dev_job) {
+    HIPCHK(hipEventRecord(c->ev[4], s));                     // ev[4]: free here (no slice trees aside in a chunked request)
+    for (uint32_t k = 1; k < Q; ++k) HIPCHK(hipStreamWaitEvent(st[k], c->ev[4], 0));
+  }
   auto drain = [&](int32_t code) { const std::string keep = g_last_error; for (uint32_t k = 0; k < Q; ++k) (void)hipStreamSynchronize(st[k]); g_last_error = keep; return code; };
   auto view = [&](uint32_t k) { return FrontView{cx[k]->partial.as<char>(), f[k].sp.hist, f[k].sp.scan_local, f[k].sp.scan_blk}; };
   auto chain_before = [&](uint32_t k) { FrontChain ch; for (uint32_t i = k; i-- > 0;) ch.v[ch.n++] = view(i); return ch; };      // newest first
   for (uint32_t k = 0; k < Q; ++k) {
-    const size_t len = lo[k + 1] - lo[k];
-    if ((rc = cx[k]->scalars_stage.reserve((len ? len : 1) * 32))) return drain(rc);
-    if (hipMemcpyAsync(cx[k]->scalars_stage.p, (const char*)host_src + lo[k] * 32, len * 32, hipMemcpyHostToDevice, st[k]) != hipSuccess) { g_last_error = "msm: upload of a chunk failed"; return drain(ALEO_MI355X_ERR_HIP); }
-    seg[k].d_ptr = cx[k]->scalars_stage.p; seg[k].len = len; seg[k].off = lo[k];
-    MsmJob j; j.segs = &seg[k]; j.nseg = 1; j.k = 1; j.mont = mont; j.tier_n = n;
+    MsmJob j; j.mont = mont; j.tier_n = n; j.k = K;
+    if (dev_job) {                                           // every segment cut at the same fractions (boundaries on multiples of 256 scalars)
+      auto cut = [&](size_t len, uint32_t pc) { const size_t v = pc >= 100u ? len : ((size_t)((double)len * pc / 100.0)) & ~(size_t)255; return v < len ? v : len; };
+      for (uint32_t q = 0; q < dev_job->nseg; ++q) {
+        const MsmSeg& g = dev_job->segs[q]; const size_t a0 = cut(g.len, cum[k]), a1 = cut(g.len, cum[k + 1]);
+        if (a1 > a0) { MsmSeg h = g; h.d_ptr = (const char*)g.d_ptr + a0 * 32; h.len = a1 - a0; h.off = g.off + a0; dsegs[k].push_back(h); }
+      }
+      j.segs = dsegs[k].data(); j.nseg = (uint32_t)dsegs[k].size();
+    } else {
+      const size_t len = lo[k + 1] - lo[k];
+      if ((rc = cx[k]->scalars_stage.reserve((len ? len : 1) * 32))) return drain(rc);
+      if (hipMemcpyAsync(cx[k]->scalars_stage.p, (const char*)host_src + lo[k] * 32, len * 32, hipMemcpyHostToDevice, st[k]) != hipSuccess) { g_last_error = "msm: upload of a chunk failed"; return drain(ALEO_MI355X_ERR_HIP); }
+      seg[k].d_ptr = cx[k]->scalars_stage.p; seg[k].len = len; seg[k].off = lo[k];
+      j.segs = &seg[k]; j.nseg = 1;
+    }
     if ((rc = msm_front_sort(cx[k], pb, j, st[k], f[k]))) return drain(rc);
     if (f[k].empty || !f[k].masked || f[k].P.c != f[0].P.c || f[k].sp.M != f[0].sp.M) { g_last_error = "msm: internal: chunks without a shared table window"; return drain(ALEO_MI355X_ERR_HIP); }
     if (k) { if ((rc = msm_front_finish(cx[k - 1], st[k - 1], f[k - 1], false))) return drain(rc); }      // chunk k - 1's slice trees: its bucket sums are final at its ev[2]
@@ -1385,8 +1423,12 @@ static int32_t msm_run_chunked(Ctx* c, HelperSet& hs, uint64_t* out_jac18, const
   }
   if ((rc = msm_front_finish(cx[Q - 1], st[Q - 1], f[Q - 1], false))) return drain(rc);
   // the reduction runs where the newest sums are; it synchronises that stream, behind which (event by event) every earlier chunk has finished
-  if ((rc = msm_back(cx[Q - 1], out_jac18, f[Q - 1], st[Q - 1], false, chain_before(Q - 1)))) return drain(rc);
-  HIPCHK(hipStreamSynchronize(s));
+  const bool fire = dev_job && dev_job->fire_tail && c->tail_hook;
+  if (fire) cx[Q - 1]->tail_hook = std::move(c->tail_hook);      // the caller's next kernels (queued on ITS stream by the hook) go out when the reduction has been queued
+  c->tail_hook = fire ? nullptr : c->tail_hook;
+  if ((rc = msm_back(cx[Q - 1], out_jac18, f[Q - 1], st[Q - 1], fire, chain_before(Q - 1)))) { cx[Q - 1]->tail_hook = nullptr; return drain(rc); }
+  cx[Q - 1]->tail_hook = nullptr;
+  if (!fire) HIPCHK(hipStreamSynchronize(s));                // (with a hook the caller's stream carries the hook's kernels: the caller orders its own work behind them)
   MsmTiming tm = cx[Q - 1]->last_msm; float ms = 0, kern = 0;
   for (uint32_t k = 0; k < Q; ++k) { HIPCHK(hipEventElapsedTime(&ms, cx[k]->ev[6], cx[k]->ev[5])); kern += ms; }
   tm.accum_kernel = kern / Q; tm.accum_launches = (int)Q;

@@ -196,13 +196,16 @@ def main():
         ms_step = elapsed / args.steps * 1e3
         value = total * args.steps / elapsed if strong else world * n * args.steps / elapsed
         ak = float(np.mean(acc_kernel_ms)) * 1e-3
-        launches = int(round(float(np.mean([p_.get('accum_launches', 1.0) for p_ in phases]))))      # 2 when the host scalars went up in two halves that share one reduction: each launch then covers n / 2 points
+        launches = int(round(float(np.mean([p_.get('accum_launches', 1.0) for p_ in phases]))))      # 2 (3 from 2^21 points) when the host scalars go up in chunks that share one reduction: a launch then covers n / launches points on average
         alg_bytes = 128.0 * n / launches                       # 32 B scalar + 96 B affine base per point, x the points ONE launch processes
         achieved = alg_bytes / ak / 1e9
         traffic = None
         tf = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
         if os.path.exists(tf):
-            try: traffic = json.load(open(tf)).get('k_accum_hbm_bytes_per_launch')
+            try:
+                pm = json.load(open(tf))
+                # per LAUNCH of k_accum28, like `achieved`: the chunked host-scalar call makes `launches` of them per step (round-4 passes: the mean of the step's launches)
+                traffic = pm.get('round4', {}).get('k_accum_hbm_bytes_per_launch_mean') if launches == 2 else pm.get('k_accum_hbm_bytes_per_launch')
             except Exception: traffic = None
         wl = ('2^%d-point BLS12-377 G1 Pippenger MSM split over %d GPUs (BASELINE configs[4])' % (total.bit_length() - 1, world)) if strong else \
              ('standalone 2^%d-point BLS12-377 G1 Pippenger MSM (BASELINE configs[1])' % (n.bit_length() - 1))
@@ -220,7 +223,7 @@ def main():
             'precompute_s': precompute_s, 'table_bytes': info['table_bytes'], 'base_row_bytes': info['row_bytes'], 'table_window_bits': info['tier_window_bits'],
             **variants,
             'roofline': {'bound': 'hbm', 'kernel': 'k_accum28 (bucket accumulation, 28-bit limbs)', 'achieved': achieved, 'peak': 8000.0,
-                         'unit': 'GB/s', 'frac': achieved / 8000.0, 'traffic': (traffic / launches if traffic else traffic), 'alg_bytes_per_launch': alg_bytes, 'kernel_ms': ak * 1e3,
+                         'unit': 'GB/s', 'frac': achieved / 8000.0, 'traffic': traffic, 'alg_bytes_per_launch': alg_bytes, 'kernel_ms': ak * 1e3,
                          'launches_per_step': launches, 'points_per_launch': n // launches,
                          'note': 'integer-VALU bound by construction (SURVEY.md §8d): %d mixed additions x 10 Fq products per point; '
                                  'measured Fq product peak 81 G/s with 28-bit limbs, 61 G/s with 32-bit limbs (tools/ubench/fq28_mul_bench.hip, fq_mul_bench.hip)' % (16 if args.no_precompute else 13)},
