@@ -1385,7 +1385,9 @@ int32_t msm_run(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, const MsmJob
 static int32_t msm_run_chunked(Ctx* c, HelperSet& hs, uint64_t* out_jac18, const PinnedBases& pb, size_t n, bool mont, hipStream_t s, const void* host_src, const MsmJob* dev_job) {
   const uint32_t Q = 1 + (uint32_t)hs.ctx.size();           // 2 or 3
   static const uint32_t share_host[4][3] = {{0, 0, 0}, {0, 0, 0}, {37, 63, 0}, {18, 30, 52}}, share_dev[4][3] = {{0, 0, 0}, {0, 0, 0}, {28, 72, 0}, {12, 28, 60}};
-  const uint32_t (*share)[3] = dev_job ? share_dev : share_host;
+  static const uint32_t share0_env = [] { const char* e = std::getenv("ALEO_MI355X_CHUNK_SHARE0"); const int k = e ? std::atoi(e) : 0; return (uint32_t)(k >= 5 && k <= 95 ? k : 0); }();      // experiment knob: first chunk's percentage of a two-chunk host-scalar request
+  uint32_t share_env[4][3] = {{0, 0, 0}, {0, 0, 0}, {share0_env, 100 - share0_env, 0}, {18, 30, 52}};
+  const uint32_t (*share)[3] = dev_job ? share_dev : (share0_env ? share_env : share_host);
   const uint32_t K = dev_job ? dev_job->k : 1u;
   Ctx* cx[3] = {c, Q > 1 ? hs.ctx[0] : nullptr, Q > 2 ? hs.ctx[1] : nullptr}; hipStream_t st[3] = {s, Q > 1 ? hs.ctx[0]->hi : nullptr, Q > 2 ? hs.ctx[1]->hi : nullptr};
   size_t lo[4] = {0, 0, 0, 0};

@@ -88,3 +88,18 @@ def test_cpp_host_mirror_compiles_and_links(tmp_path):
     exe = build_cpp_host_mirror(tmp_path)
     assert os.path.exists(exe)
     assert os.path.exists(build_cpp_host_mirror(tmp_path, 'varuna_prove_test'))      # the whole-proof entry points from plain C++
+
+
+def test_routing_thresholds_and_their_environment_overrides():
+    """aleo_mi355x_min_msm / _min_ntt (the sizes from which the Rust arms route to the GPU): the measured defaults, and
+    ALEO_MI355X_MIN_MSM / ALEO_MI355X_MIN_NTT read per call (no GPU involved)."""
+    import os, subprocess, sys
+    code = ("import aleo_amd; L = aleo_amd.lib(); print(int(L.aleo_mi355x_min_msm()), int(L.aleo_mi355x_min_ntt()))")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    def run(extra):
+        env = dict(os.environ, PYTHONPATH=root, **extra); env.pop('ALEO_MI355X_MIN_MSM', None) if 'ALEO_MI355X_MIN_MSM' not in extra else None
+        if 'ALEO_MI355X_MIN_NTT' not in extra: env.pop('ALEO_MI355X_MIN_NTT', None)
+        return subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=300).stdout.split()
+    assert run({}) == ['1024', '4096']
+    assert run({'ALEO_MI355X_MIN_MSM': '65536', 'ALEO_MI355X_MIN_NTT': '32'}) == ['65536', '32']
+    assert run({'ALEO_MI355X_MIN_MSM': 'nonsense'}) == ['1024', '4096']

@@ -807,6 +807,20 @@ def test_bench_spawns_two_ranks_on_one_card_without_a_launcher():
     assert on.value + off.value == g * (g - 1)
 
 
+def test_rccl_runs_the_exchange_with_one_rank():
+    """backend='nccl' is RCCL on ROCm.  A one-GPU box cannot hold two RCCL ranks (one device per rank), so until round 4 every rehearsal of the N > 1 path ran
+    under gloo and RCCL itself had never executed.  This runs the real library with a world of one rank: the all-gather of the 144-byte partial, the MAX
+    all-reduce of the timing and the all-to-all of the sharded transform are RCCL launches on the card (tests/helpers/rccl_one_rank.py, a child process:
+    the process group must not leak into this one)."""
+    import subprocess, sys, socket
+    s_ = socket.socket(); s_.bind(('127.0.0.1', 0)); port = s_.getsockname()[1]; s_.close()
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE')}
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'helpers', 'rccl_one_rank.py'), str(port)], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
+    assert out == {'backend': 'nccl', 'world': 1, 'gathered_equals_partial': True, 'sum_equals_partial': True, 'all_reduce_max': 3.25, 'sharded_ntt_matches': True}, out
+
+
 def test_config4_full_size_as_eight_shards_in_one_process():
     """BASELINE configs[4] at its full size through the multi-device entry of the C ABI: 2^26 points, P_i = (i + 1) G generated shard by shard, as
     EIGHT shards of 2^23 points with their fixed-base tables — all eight on the one visible card (no 8-GPU node here: the split, the per-shard
