@@ -234,6 +234,51 @@ def test_msm_edge_cases():
     assert c.jac_to_int_point(M.VariableBase.msm(B[:100], S)) == c.jac_to_int_point(c.msm_g1(B[:100], S[:100], variant=1))
 
 
+@pytest.mark.parametrize('lg', [19, 21])
+def test_chunked_host_scalar_msm_edge_cases(lg):
+    """The headline path from 2^19 points on: host scalars uploaded and processed in two (2^19) or three (2^21) chunks that share the buckets — every later
+    chunk's accumulation is seeded with the earlier chunks' bucket sums — and ONE reduction.  Cases the seeding has to survive, each against the result's
+    discrete logarithm in big integers: uniform scalars (also equal to the one-chain result), every scalar equal (one bucket per window: slice trees in
+    every chunk), a first chunk of zeros (nothing to seed from), zeros in the LAST chunk (buckets only earlier chunks touched), one base repeated
+    (the seed equals the next point: the mixed addition refuses and the slice finishes in the general code), P / -P alternating (sums that cancel
+    across chunk boundaries), and a ragged length."""
+    n = 1 << lg
+    gen = synth.generator_affine104()
+    with M.PinnedBases.generate_multiples(gen, 1, n) as pb:
+        pb.precompute()
+        S = util.uniform_scalars(n, 4000 + lg)
+        got = M.VariableBase.msm(pb, S)
+        assert M.last_msm_timing()['accum_launches'] == (2 if lg < 21 else 3)
+        assert c.jac_to_int_point(got) == util.expected_multiples_msm(S, n)
+        import torch
+        d = torch.from_numpy(S.view(np.int64).copy()).cuda(); torch.cuda.synchronize()
+        assert (M.VariableBase.msm_device(pb, d.data_ptr(), n) == got).all()                       # the one-chain path: same bytes
+        eq = np.tile(util.uniform_scalars(1, 4100 + lg), (n, 1))
+        assert c.jac_to_int_point(M.VariableBase.msm(pb, eq)) == util.expected_multiples_msm(eq, n)
+        z0 = S.copy(); z0[: n // 2] = 0
+        assert c.jac_to_int_point(M.VariableBase.msm(pb, z0)) == util.expected_multiples_msm(z0, n)
+        z1 = S.copy(); z1[n // 3:] = 0
+        assert c.jac_to_int_point(M.VariableBase.msm(pb, z1)) == util.expected_multiples_msm(z1, n)
+        m = n - 12345
+        assert c.jac_to_int_point(M.VariableBase.msm(pb, S[:m])) == util.expected_multiples_msm(S[:m], m)
+    if lg > 19: return
+    # repeated and opposite bases need a set pinned from host rows
+    one = util.multiples_bases(1); neg = c.affine_from_ints([p.g1_neg(p.G1_GENERATOR)])
+    same = np.ascontiguousarray(np.repeat(one, n, axis=0))
+    with M.PinnedBases(same) as pb:
+        pb.precompute()
+        S = util.uniform_scalars(n, 4200)
+        assert c.jac_to_int_point(M.VariableBase.msm(pb, S)) == p.g1_mul(p.G1_GENERATOR, sum(c.limbs_to_ints(S)) % p.FR_MODULUS)
+    pm = np.ascontiguousarray(np.concatenate([one, neg] * (n // 2), axis=0))
+    with M.PinnedBases(pm) as pb:
+        pb.precompute()
+        s77 = np.tile(util.uniform_scalars(1, 4300), (n, 1))
+        assert c.jac_to_int_point(M.VariableBase.msm(pb, s77)) is None
+        S = util.uniform_scalars(n, 4301); ints = c.limbs_to_ints(S)
+        k = (sum(ints[0::2]) - sum(ints[1::2])) % p.FR_MODULUS
+        assert c.jac_to_int_point(M.VariableBase.msm(pb, S)) == p.g1_mul(p.G1_GENERATOR, k)
+
+
 def test_msm_heavy_buckets_witness_like_2_17():
     n = 1 << 17
     with M.PinnedBases.generate_multiples(synth.generator_affine104(), 1, n) as pb:
