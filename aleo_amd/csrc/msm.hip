@@ -1377,7 +1377,9 @@ int32_t msm_run(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, const MsmJob
 // two halves with a merge kernel (2^19 lane-pair additions into a dense array) before the reduction 3.28; the copies from a thread of their own: no
 // change; every kernel on ONE stream with only the copies beside it 3.74 — each extra sort costs ~0.17 ms of dependent ~10 us launches when nothing
 // hides it.  What is left on the table: a sort queued beside an accumulation that holds every wave slot (248 VGPRs x 2 waves per SIMD, workgroups that
-// live ~250 us) takes ~0.5 ms instead of 0.15, so the next accumulation starts ~0.2 ms late.
+// live ~250 us) takes ~0.5 ms instead of 0.15, so the next accumulation starts ~0.2 ms late.  CU-masked streams do not recover it (hipExtStreamCreateWithCUMask,
+// profiles/r04_chunk_cumask_ab.jsonl): sorts confined to 16-64 reserved CUs are 4-8x slower (2^20: 4.5 / 3.8 / 3.4 ms with 16 / 32 / 64 CUs against 3.26), and
+// keeping the accumulations off 8-32 CUs while the sorts run anywhere changes nothing at 2^20 and costs 5-8 % beyond.
 // (Round 3 ran two halves as two complete MSMs on two host threads: that paid the 0.4 ms bucket reduction twice and lost below 2^21 points.)
 // dev_job != nullptr: the scalars are already on the device (any number of sets and segments: every segment is cut at the same fractions; n = the request's
 // reach, its tier) — nothing is uploaded, and what the later chunks hide under the earlier chunks' accumulation is their sort alone, so the first chunk is
