@@ -367,7 +367,9 @@ typedef struct {
  * (domain_flags 1), all three the largest of them (2), or (0) shared below 2^18 — latency-bound rounds, one batched transform beats three short
  * ones — and per matrix from there on.  The
  * committer key (powers[0..max_degree], >= 3 hiding powers from gamma_offset) must hold max(3|H|, max |K_M|) powers and stays pinned while the index lives.
- * index_export fills the struct view (pointers owned by the library, valid until index_free); index_vk copies the bytes the transcript absorbs
+ * index_export fills the struct view (pointers owned by the library, valid until index_free; the transposed matrices t_* list the entries of a column in no
+ * fixed order — they are written through an atomic cursor — which the exact field sums over them do not see, but two builds of one circuit may differ there);
+ * index_vk copies the bytes the transcript absorbs
  * first: 12 compressed index commitments (row, col, val, row_col of A, B, C) then |H|, |K_A|, |K_B|, |K_C|, |X| as u64 LE.  prove_indexed = varuna_prove. */
 typedef struct { const uint32_t* row_ptr; const uint32_t* col; const void* val; } aleo_mi355x_r1cs_matrix;
 int32_t aleo_mi355x_varuna_index_build(uint64_t* index_handle, uint64_t committer_key, uint64_t max_degree, uint64_t gamma_offset, uint64_t lagrange_offset,

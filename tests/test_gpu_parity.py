@@ -761,6 +761,58 @@ def test_batched_commit_matches_oracle_per_polynomial(k):
         assert (got_d == got).all()
 
 
+@pytest.mark.parametrize('G', [1, 3, 5, 8])
+def test_sharded_commit_entry_points_match_the_single_device_commitments(G):
+    """aleo_mi355x_kzg_commit_batch_sharded_device / _segments_sharded_device by themselves (row e2 below the prover): coefficient vectors on the calling
+    thread's device, the powers cut into G contiguous shards — shard counts that are no powers of two, so the cuts fall at odd offsets — with and without
+    per-shard window tables; ragged, empty, all-zero, one-element vectors and segments that straddle every cut.  Bases (i+1) G: each result against the
+    O(n) identity in big integers AND byte-equal to the single-device entry point.  Then the misuse the C ABI must refuse."""
+    import torch
+    from aleo_amd.kzg import SonicKZG10
+    N = (1 << 17) + 321
+    lens = [N, 1, 0, 255, (1 << 16) + 3, N // G + 1 if G > 1 else 77, 4096]
+    polys = [util.uniform_scalars(max(m, 1), 14000 + 31 * G + i)[:m] for i, m in enumerate(lens)]
+    polys[6] = np.zeros((lens[6], 4), dtype=np.uint64)
+    mont = [c.fr_to_mont(f) if len(f) else f for f in polys]
+    d = [torch.from_numpy(np.ascontiguousarray(f).view(np.int64).copy()).cuda() if len(f) else torch.zeros((1, 4), dtype=torch.int64, device='cuda') for f in mont]
+    torch.cuda.synchronize()
+    ptrs = [t.data_ptr() for t in d]
+    L = aleo_amd.lib()
+    with M.PinnedBases.generate_multiples(synth.generator_affine104(), 1, N) as pb:
+        pb.precompute()
+        single = aleo_amd.KZG10.commit_batch_device(pb, ptrs, lens)
+        as_points = c.affine_to_ints(single)
+        for i, m in enumerate(lens):
+            want = util.expected_multiples_msm(polys[i], m) if m else None
+            assert as_points[i] == want, (i, m)
+        host = pb.download()
+        for pre in (True, False):
+            with aleo_amd.ShardedBases(host, devices=[0] * G, precompute=pre) as sb:
+                assert len(sb.shards()) == G and sum(cnt for _, _, cnt in sb.shards()) == N
+                got = aleo_amd.KZG10.commit_batch_sharded_device(sb, ptrs, lens)
+                assert (got == single).all(), (G, pre)
+                # segments: every result a sum of pieces placed across the cuts (offsets chosen around each shard boundary)
+                cuts = [first for _, first, _ in sb.shards()][1:]
+                segs = [(ptrs[0], 1000, 0, 0)]
+                for j, cut in enumerate(cuts[:6]): segs.append((ptrs[0] + 32 * 1000 * (j + 1), 777, cut - 300 - j, 1 + j % 2))
+                segs.append((ptrs[4], lens[4], N - lens[4], 2)); segs.append((ptrs[3], 0, 5, 0))
+                a = SonicKZG10.commit_segments_device(type('CK', (), {'bases': pb})(), segs, 3)
+                b = SonicKZG10.commit_segments_sharded_device(sb, segs, 3)
+                assert (a == b).all(), (G, pre)
+                if pre:
+                    out = np.zeros((2, 104), dtype=np.uint8); vp = ctypes.c_void_p
+                    pa = (ctypes.c_void_p * 2)(ptrs[0], ptrs[1]); la = (ctypes.c_size_t * 2)(N + 1, 1)
+                    assert L.aleo_mi355x_kzg_commit_batch_sharded_device(out.ctypes.data_as(vp), sb.handle, pa, la, 2, None) == 2            # a vector longer than the set
+                    la = (ctypes.c_size_t * 2)(10, 1)
+                    assert L.aleo_mi355x_kzg_commit_batch_sharded_device(out.ctypes.data_as(vp), 987654321, pa, la, 2, None) == 4           # no such sharded set
+                    assert L.aleo_mi355x_kzg_commit_batch_sharded_device(None, sb.handle, pa, la, 2, None) == 2
+                    assert L.aleo_mi355x_kzg_commit_batch_sharded_device(out.ctypes.data_as(vp), sb.handle, pa, la, 0, None) == 0           # nothing asked
+                    assert L.aleo_mi355x_bases_attach_shards(pb.handle, 987654321, 0) == 4
+                    with aleo_amd.ShardedBases(host[: N - 1], devices=[0, 0]) as other:
+                        assert L.aleo_mi355x_bases_attach_shards(pb.handle, other.handle, 0) == 2                                           # not the same number of points
+                    assert L.aleo_mi355x_bases_attach_shards(123456789, sb.handle, 0) == 4
+
+
 def test_batched_msm_mixed_tiers_and_degenerate_sets():
     """One batched call whose vectors select different table tiers (c = 13 / 16 / 17), a vector too short for any tier
     (plain path), an empty one, an all-zero one and an all-equal one; more vectors than one launch can hold (chunking).

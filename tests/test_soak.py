@@ -1,7 +1,8 @@
 """Randomised differential soak of the two operators on the GPU (marked gpu): random prefixes / batches / scalar distributions of MSMs against the
 O(n) structured identity sum_i s_i (i+1) G = (sum_i s_i (i+1) mod r) G on a 3 * 2^20-point pinned set — every table tier, the range table, the
-slice trees beside the reduction, multi-chain requests, host scalars split over two contexts — and random transforms (size, variant, order, extreme or
-uniform inputs) against the restatement.  ALEO_SOAK_SECONDS sets the duration (default 20 s; the round's long run: profiles/r03_soak.json)."""
+slice trees beside the reduction, multi-chain requests, host scalars in chunks over two or three contexts —, random transforms (size, variant, order,
+extreme or uniform inputs) against the restatement, random G2 MSMs against the identity over Fq2 in Python integers, and random commitment requests
+(segments at random offsets) against a sharded copy of the set, byte-equal to the single-device call.  ALEO_SOAK_SECONDS sets the duration (default 20 s; the round's long run: profiles/r03_soak.json)."""
 import os, time, json
 import numpy as np
 import pytest
@@ -29,15 +30,20 @@ def test_soak_msm_and_ntt():
     rng = np.random.default_rng(int(os.environ.get('ALEO_SOAK_SEED', '20261004')))
     N = 3 << 20
     kinds = ['uniform', 'witness', 'equal', 'small', 'top', 'ones', 'single']
-    stats = {'msm_host': 0, 'msm_device': 0, 'msm_batch_results': 0, 'msm_sparse_hint': 0, 'ntt': 0, 'points': 0, 'ntt_elements': 0}
+    stats = {'msm_host': 0, 'msm_device': 0, 'msm_batch_results': 0, 'msm_sparse_hint': 0, 'ntt': 0, 'points': 0, 'ntt_elements': 0, 'msm_g2': 0, 'g2_points': 0,
+             'sharded_commit_results': 0, 'sharded_points': 0}
+    from aleo_amd.kzg import SonicKZG10
+    G2B = synth.g2_multiples_affine200(1 << 12)                  # P_i = ((i mod 4096) + 1) G2, repeated to the length asked
     t_end = time.time() + seconds
     with M.PinnedBases.generate_multiples(synth.generator_affine104(), 1, N) as pb:
         pb.precompute(); pb.precompute_range(0, 1 << 20, 16)
+        sharded = [aleo_amd.ShardedBases(pb.download(0, 1 << 20), devices=[0] * g, precompute=True) for g in (3, 8)]      # the first 2^20 points once more, cut in 3 and in 8
+        class _CK: bases = pb
         it = 0; t_say = time.time() + 30
         while time.time() < t_end:
             it += 1
             if time.time() > t_say: print('soak progress ' + json.dumps(stats), flush=True); t_say = time.time() + 30      # a long run must keep writing (run with -s)
-            mode = it % 4
+            mode = it % 6
             if mode == 0:                                                              # host scalars (from 2^21 points on: two halves on two contexts)
                 n = int(rng.choice([1, 255, 1 << 14, (1 << 20) + 3, 1 << 21, N, int(rng.integers(1, N))]))
                 kind = kinds[int(rng.integers(len(kinds)))]; S = _scalars(rng, n, kind, 50000 + it)
@@ -58,6 +64,21 @@ def test_soak_msm_and_ntt():
                 out = M.VariableBase.msm_batch_device(pb, [d.data_ptr() for d in ds], lens)
                 for j in range(k): assert c.jac_to_int_point(out[j]) == util.expected_multiples_msm(Ss[j], lens[j]), ('batch', lens, j, it)
                 stats['msm_batch_results'] += k; stats['points'] += sum(lens)
+            elif mode == 4:                                                            # G2 (lane-pair kernels): host bases + scalars, one-shot
+                n = int(rng.choice([1, 2, 63, 4096, int(rng.integers(1, 1 << 16)), int(rng.integers(1 << 16, 1 << 18))]))
+                kind = kinds[int(rng.integers(len(kinds)))]; S = _scalars(rng, n, kind, 90000 + it)
+                B = np.tile(G2B, ((n + 4095) // 4096, 1))[:n]
+                assert synth.g2_result_gate(M.msm_g2(B, S), S), ('g2', n, kind, it)
+                stats['msm_g2'] += 1; stats['g2_points'] += n
+            elif mode == 5:                                                            # commitments against a sharded copy of the first 2^20 points
+                sb = sharded[int(rng.integers(2))]; k = int(rng.integers(1, 5)); segs = []; keep = []
+                for _ in range(int(rng.integers(1, 9))):
+                    m = int(rng.choice([0, 1, int(rng.integers(1, 1 << 12)), int(rng.integers(1 << 12, 1 << 19))])); off = int(rng.integers(0, (1 << 20) - m + 1))
+                    x = c.fr_to_mont(_scalars(rng, max(m, 1), kinds[int(rng.integers(len(kinds)))], 95000 + 16 * it + len(segs)))
+                    t = torch.from_numpy(x.view(np.int64).copy()).cuda(); keep.append(t); segs.append((t.data_ptr(), m, off, int(rng.integers(k)))); stats['sharded_points'] += m
+                torch.cuda.synchronize()
+                assert (SonicKZG10.commit_segments_sharded_device(sb, segs, k) == SonicKZG10.commit_segments_device(_CK, segs, k)).all(), ('sharded', segs, k, it)
+                stats['sharded_commit_results'] += k
             else:                                                                      # transforms
                 lg = int(rng.integers(1, 23)); n = 1 << lg
                 if rng.random() < 0.3:
@@ -67,9 +88,10 @@ def test_soak_msm_and_ntt():
                 dom = aleo_amd.EvaluationDomain(n)
                 assert (dom.ntt(x, order, direction, type_) == c.ntt_fr(x, order, direction, type_, threads=8)).all(), ('ntt', lg, order, direction, type_, it)
                 stats['ntt'] += 1; stats['ntt_elements'] += n
+        for sb in sharded: sb.close()
     stats.update({'seconds': seconds, 'iterations': it, 'all_equal_to_the_restatement': True})
     print('SOAK ' + json.dumps(stats))
-    assert it >= 4
+    assert it >= 6
 
 
 def test_soak_prover():
