@@ -229,13 +229,35 @@ class CommitterKey {
   size_t gamma_offset() const { return max_degree_ + 1; }
   size_t lagrange_offset() const { return lagrange_offset_; }      // 0: no Lagrange-basis powers pinned (commitments from coefficients)
   void set_lagrange_offset(size_t off) { lagrange_offset_ = off; }  // the set pinned holds L_i(tau) G of the circuit's domain H, then v_H(tau) G, from `off`
+  // Large proofs over several devices (`north_star`: "large proofs shard MSM bases ... across the 8 GPUs"): a second copy of the key's
+  // points cut into contiguous shards over `devices` (each device holds 1/G of the powers and of their window tables), owned by this key.  From then
+  // on every commitment a prover makes against this key with at least min_points scalars in all is computed shard by shard — each device pulls its
+  // slices of the coefficient vectors, 144 bytes per shard and result come back — and the proof bytes do not change (aleo_mi355x_bases_attach_shards).
+  Error shard_over(const std::vector<int32_t>& devices, size_t min_points = (size_t)1 << 16) {
+    unshard();
+    std::vector<G1Affine> host(bases_.len());
+    int32_t rc = aleo_mi355x_bases_download(bases_.handle(), 0, host.size(), host.data());
+    if (rc) return Error{rc};
+    auto sh = ShardedBases::pin(host.data(), host.size(), devices, true);
+    if (!sh.is_ok()) return sh.error;
+    rc = aleo_mi355x_bases_attach_shards(bases_.handle(), sh.value->handle(), min_points);
+    if (rc) return Error{rc};
+    shards_ = std::move(*sh.value);
+    return Error{0};
+  }
+  void unshard() { if (shards_.handle()) { aleo_mi355x_bases_attach_shards(bases_.handle(), 0, 0); shards_ = ShardedBases(); } }
+  size_t shards() const { return shards_.shards(); }
+  CommitterKey() = default;
+  CommitterKey(CommitterKey&&) noexcept = default;
+  CommitterKey& operator=(CommitterKey&& o) noexcept { if (this != &o) { unshard(); bases_ = std::move(o.bases_); shards_ = std::move(o.shards_); max_degree_ = o.max_degree_; lagrange_offset_ = o.lagrange_offset_; } return *this; }
+  ~CommitterKey() { unshard(); }                                    // detach before the shards (and then the points) go
  private:
   static Result<CommitterKey> finish(PinnedBases b, size_t max_degree, size_t n_gamma) {
     if (n_gamma < 3) return {std::nullopt, Error{ALEO_MI355X_ERR_BAD_ARG}};
     int32_t rc = b.precompute(); if (rc) return {std::nullopt, Error{rc}};
     CommitterKey k; k.bases_ = std::move(b); k.max_degree_ = max_degree; return {std::move(k), Error{0}};
   }
-  PinnedBases bases_; size_t max_degree_ = 0, lagrange_offset_ = 0;
+  PinnedBases bases_; ShardedBases shards_; size_t max_degree_ = 0, lagrange_offset_ = 0;
 };
 
 // The caller's randomness for one proof: 32 bytes, the key of the prover's ChaCha20 stream.  The reference's call sites pass a CSPRNG

@@ -114,6 +114,22 @@ int main(int argc, char** argv) {
       for (int t = 0; t < 6; ++t) if (!okv[t]) { fprintf(stderr, "ProvingQueue: request %d differs from its own call\n", t); return 1; }
       if (queue.calls() >= 6) { fprintf(stderr, "ProvingQueue: %zu library calls for 6 concurrent requests\n", queue.calls()); return 1; }
     }
+    // the key sharded over "three devices" (the one card listed three times; min_points 0: every commitment goes through the shards): same proofs
+    {
+      Error e = ck.value->shard_over({0, 0, 0}, 0);
+      if (e.code || ck.value->shards() != 3) { fprintf(stderr, "CommitterKey::shard_over: %s\n", e.message().c_str()); return 1; }
+      auto sharded = pk.value->prove_batch(zs, seed);
+      if (!sharded.is_ok() || sharded.value->bytes != pr.value->bytes) { fprintf(stderr, "proof against the sharded key differs\n"); return 1; }
+      KeyedAssignments q0 = {{&*pk.value, zs}}, q1 = {{&*pk.value, {&za[0]}}};
+      auto many = prove_many({q0, q1}, {seed, seed_next});
+      if (many.size() != 2 || !many[0].is_ok() || !many[1].is_ok() || many[0].value->bytes != pr.value->bytes || many[1].value->bytes != direct.value->bytes) { fprintf(stderr, "lockstep proofs against the sharded key differ\n"); return 1; }
+      auto pk3 = ProvingKey::index(*ck.value, cs, (DomainPolicy)h[7]);      // the index commitments through the shards too: same verifying key
+      auto vk3 = pk3.is_ok() ? pk3.value->verifying_key_bytes() : Result<std::vector<uint8_t>>{std::nullopt, pk3.error};
+      if (!vk3.is_ok() || vk3.value->size() != vk_len || memcmp(vk3.value->data(), vk, vk_len)) { fprintf(stderr, "verifying key of an index built against the sharded key differs\n"); return 1; }
+      ck.value->unshard();
+      auto back = pk.value->prove_batch(zs, seed);
+      if (!back.is_ok() || back.value->bytes != pr.value->bytes || ck.value->shards() != 0) { fprintf(stderr, "proof after unshard differs\n"); return 1; }
+    }
     FILE* o2 = fopen(argv[2], "ab"); if (!o2) return 2;
     uint64_t el = ex.value->bytes.size(); fwrite(&el, 8, 1, o2); fwrite(ex.value->bytes.data(), 1, el, o2); fclose(o2);
   }
