@@ -100,6 +100,7 @@ static int32_t first_use(Ctx* c) {          // streams and events of a slot, cre
   { int lo = 0, hi = 0; (void)hipDeviceGetStreamPriorityRange(&lo, &hi); HIPCHK(hipStreamCreateWithPriority(&c->hi, hipStreamNonBlocking, hi)); }      // hi = the numerically lowest = highest priority
   for (auto& e : c->ev) HIPCHK(hipEventCreate(&e));
   HIPCHK(hipEventCreateWithFlags(&c->scratch_ev, hipEventDisableTiming));
+  HIPCHK(hipEventCreateWithFlags(&c->ev_hop, hipEventDisableTiming));
   return ALEO_MI355X_OK;
 }
 

@@ -121,7 +121,8 @@ struct Ctx {                           // one concurrency slot
   // the buffer is freed to grow.
   hipEvent_t scratch_ev = nullptr; bool scratch_busy = false;
   hipStream_t side = nullptr;          // second stream of the slot: small read-backs that must not wait for the kernels queued behind them
-  hipStream_t hi = nullptr;            // a high-priority stream: the sort of a later chunk must get its workgroups in while an earlier chunk's accumulation fills the chip (msm_run_merged)
+  hipStream_t hi = nullptr;            // a high-priority stream: the sort of a later chunk / the next launch chain must get its workgroups in while an accumulation fills the chip (msm_run_chunked, run_chains)
+  hipEvent_t ev_hop = nullptr;         // run_chains: a chain's sort (on hi) -> its accumulation (on the normal-priority stream)
 };
 
 int32_t scratch_acquire(Ctx* c, DevBuf& b, size_t bytes, hipStream_t s);

@@ -1164,8 +1164,10 @@ static int32_t msm_front_finish(Ctx* c, hipStream_t s, Front& f, bool allow_asid
   return ALEO_MI355X_OK;
 }
 
-// older: the earlier chunks of the same request (msm_run_chunked) — a bucket this chain did not touch keeps its sum there
-static int32_t msm_back(Ctx* c, uint64_t* out_jac18, Front& f, hipStream_t s, bool fire_tail, const FrontChain& older) {
+// older: the earlier chunks of the same request (msm_run_chunked) — a bucket this chain did not touch keeps its sum there.
+// Two halves: `collect` false = queue the bucket reduction (table path) and return with ev[3] recorded behind it; `enqueued` true = that has been done by
+// an earlier call, only wait for the result and run the host tail (run_chains queues other chains' work in between).
+static int32_t msm_back(Ctx* c, uint64_t* out_jac18, Front& f, hipStream_t s, bool fire_tail, const FrontChain& older, bool collect = true, bool enqueued = false) {
   using namespace host;
   const MsmPlan& P = f.P; const SortPhase& sp = f.sp; const SliceMeta& sm = f.sm;
   const uint32_t K = f.K, cpw = f.cpw, nchunks = f.nchunks, lgN = f.lgN, tseg = f.tseg, fseg = f.fseg, nseg = f.nseg, setw = f.setw;
@@ -1212,6 +1214,10 @@ static int32_t msm_back(Ctx* c, uint64_t* out_jac18, Front& f, hipStream_t s, bo
     // every launch below picks lanes per addition by its own width (grp_lanes): four while it is latency-bound, two once the additions fill the chip
     // wide tables (2^19 buckets, S = 16): one lane pair per chunk (32 dependent additions) against two pairs one step apart (17): reduce phase 0.487 -> 0.460 ms
     // at 2^20; S = 8 / 32 / 4 with either form: 0.51-0.54 / 0.48-0.55 / 0.66-0.72 ms (ALEO_MI355X_CHUNK_S, ALEO_MI355X_CHUNK_FORM=1: A/B switches)
+    static const uint32_t prog_min_c = [] { const char* e = std::getenv("ALEO_MI355X_SUM_TREE_MIN_C"); const int k = e ? std::atoi(e) : 13; return (uint32_t)(k >= 13 && k <= 24 ? k : 13); }();
+    const bool prog = P.c >= prog_min_c && prog_on() && cpw > FOLD;      // (a set of <= 256 chunks would go straight to the final fold: the masked form keeps those)
+    uint32_t out_pts = fseg;                               // result points per set the host tail reads
+    if (!enqueued) {
     static const bool wide_two_groups = [] { const char* e = std::getenv("ALEO_MI355X_CHUNK_FORM"); return !(e && e[0] == '1'); }();
     if (P.c >= 20 && !wide_two_groups) {
       if (grp_lanes(2 * (uint64_t)nchunks) == 4) hipLaunchKernelGGL((k_bucket_chunks_pair<true, 4>), dim3((nchunks + 63) / 64), dim3(256), 0, s, partial, hist, scan_local, scan_blk, P.B, P.S, nchunks, V, setw, Vrun, older);
@@ -1223,9 +1229,6 @@ static int32_t msm_back(Ctx* c, uint64_t* out_jac18, Front& f, hipStream_t s, bo
     // Measured (ALEO_MI355X_SUM_TREE=0 is the A/B switch; ALEO_MI355X_SUM_TREE_MIN_C limits it to the wider tables): reduce phase of the 2^20 MSM 0.464 -> 0.412 ms at
     // S = 16 (S = 8: 0.537 -> 0.451, S = 4: 0.720 -> 0.508: the chunk kernel is bound by its 2 additions per bucket, not by their order, so smaller chunks still lose);
     // on the small tables too: 2^15-constraint proof 6.47 -> 6.35 ms, eight instances at 2^13 7.19 -> 6.88 ms.
-    static const uint32_t prog_min_c = [] { const char* e = std::getenv("ALEO_MI355X_SUM_TREE_MIN_C"); const int k = e ? std::atoi(e) : 13; return (uint32_t)(k >= 13 && k <= 24 ? k : 13); }();
-    const bool prog = P.c >= prog_min_c && prog_on() && cpw > FOLD;      // (a set of <= 256 chunks would go straight to the final fold: the masked form keeps those)
-    uint32_t out_pts = fseg;                               // result points per set the host tail reads
     if (prog) {
       char* G0 = Tout; char* G1 = G0 + (size_t)K * (3 * (cpw / 2)) * PB28;      // ping-pong: a set is at most 3 segments of cpw / 2 points after the first pass
       const char* node = Vrun; uint32_t node_ss = cpw; const char* A = V; uint32_t a_ss = setw; const char* T = Vrun; uint32_t t_ss = 0, nT = 0, L = cpw;
@@ -1274,13 +1277,16 @@ static int32_t msm_back(Ctx* c, uint64_t* out_jac18, Front& f, hipStream_t s, bo
     }
     }
     HIPCHK(hipEventRecord(c->ev[3], s));
+    } else if (prog) { uint32_t L = cpw, nT = 0; while (L > FOLD) { ++nT; L >>= 1; } uint32_t lgL = 0; while ((1u << lgL) < L) ++lgL; out_pts = 1 + nT + lgL; }
+    if (!collect) return ALEO_MI355X_OK;
     if (fire_tail && c->tail_hook) {
       // the caller's next kernels go behind the fold; the host waits for the fold only (its result sits in pinned memory) and does the tail below while they run
       std::function<int32_t()> hook = std::move(c->tail_hook); c->tail_hook = nullptr;
       const int32_t hrc = hook();
       HIPCHK(hipEventSynchronize(c->ev[3]));
       if (hrc) { (void)hipStreamSynchronize(s); return hrc; }
-    } else HIPCHK(hipStreamSynchronize(s));
+    } else if (enqueued) HIPCHK(hipEventSynchronize(c->ev[3]));      // (other chains' work may already be queued behind it on other streams; this chain's is all in front of ev[3])
+    else HIPCHK(hipStreamSynchronize(s));
     if (aside) HIPCHK(hipEventSynchronize(c->ev[4]));
     HIPCHK(hipGetLastError());
     t_host0 = std::chrono::steady_clock::now();
@@ -1456,6 +1462,68 @@ namespace {
 struct Chain { std::vector<MsmSeg> segs; std::vector<uint32_t> results; size_t points = 0; bool sparse = false, fire_tail = false; };
 inline bool chains_overlap_on() { static const bool v = [] { const char* e = std::getenv("ALEO_MI355X_CHAIN_OVERLAP"); return !(e && e[0] == '0'); }(); return v; }      // A/B switch
 }
+// The pipelined form (round 4; ALEO_MI355X_CHAIN_PIPELINE=0 restores the two host threads).  A 2^20-constraint proof showed what the two threads leave on
+// the table (profiles/r04_varuna_2^20_timeline_two_threads.txt): both chains of a round sort first (2.6 ms with no accumulation running), then their accumulations
+// share the chip, then both reductions trail — 28 of 80 ms per proof with no accumulation kernel on the card.  Here ONE host thread queues the chains so that
+// the accumulations run back to back and everything else runs beside them:
+//   chain i on context i mod 2: sort + slice ordering on the context's HIGH-priority stream, the accumulation on its normal-priority stream behind the
+//   previous chain's accumulation, slice trees + bucket reduction on the high-priority stream again; the host collects chain i - 1 (waits for its
+//   reduction, Horner, normalisation) and only then queues the sort of chain i + 1 on the context that just became free — by then accumulation i is
+//   running, so sort i + 1 and reduction i - 1 hide under it.
+static bool chain_pipeline_on() { static const bool v = [] { const char* e = std::getenv("ALEO_MI355X_CHAIN_PIPELINE"); return !(e && e[0] == '0'); }(); return v; }
+static int32_t run_chains_pipelined(Ctx* c, Ctx* h, uint64_t* out_jac18, const PinnedBases& pb, std::vector<Chain>& chains, bool mont, hipStream_t s) {
+  const size_t n = chains.size();
+  Ctx* cx[2] = {c, h}; hipStream_t acc_st[2] = {s, h->stream};
+  std::vector<Front> f(n); std::vector<MsmJob> job(n); std::vector<char> live(n, 0);
+  auto drain = [&](int32_t code) { const std::string keep = g_last_error; for (int k = 0; k < 2; ++k) { (void)hipStreamSynchronize(cx[k]->hi); (void)hipStreamSynchronize(acc_st[k]); (void)hipStreamSynchronize(cx[k]->side); } g_last_error = keep; return code; };
+  HIPCHK(hipEventRecord(c->ev[4], s));                       // the scalars may still be in flight on the caller's stream
+  for (int k = 0; k < 2; ++k) { HIPCHK(hipStreamWaitEvent(cx[k]->hi, c->ev[4], 0)); }
+  HIPCHK(hipStreamWaitEvent(h->stream, c->ev[4], 0));
+  int32_t rc;
+  auto sort_of = [&](size_t i) -> int32_t {
+    Chain& ch = chains[i]; MsmJob& g = job[i];
+    g.segs = ch.segs.data(); g.nseg = (uint32_t)ch.segs.size(); g.k = (uint32_t)ch.results.size(); g.mont = mont; g.sparse = ch.sparse; g.fire_tail = false;
+    Ctx* cc = cx[i & 1];
+    const int32_t r = msm_front_sort(cc, pb, g, cc->hi, f[i]);
+    if (r) return r;
+    if (f[i].empty) { for (size_t q = 0; q < ch.results.size(); ++q) host::hstore_jacobian_normalized(out_jac18 + 18 * (size_t)ch.results[q], host::HXYZZ::infinity()); return ALEO_MI355X_OK; }
+    if (!f[i].masked) { g_last_error = "msm: internal: a pipelined chain without a table tier"; return ALEO_MI355X_ERR_HIP; }
+    live[i] = 1;
+    HIPCHK(hipEventRecord(cc->ev_hop, cc->hi));
+    return ALEO_MI355X_OK;
+  };
+  auto collect = [&](size_t i) -> int32_t {
+    if (!live[i]) return ALEO_MI355X_OK;
+    uint64_t res[MAX_SETS * 18]; Ctx* cc = cx[i & 1];
+    const int32_t r = msm_back(cc, res, f[i], cc->hi, false, FrontChain{}, true, true);
+    if (r) return r;
+    for (size_t q = 0; q < chains[i].results.size(); ++q) std::memcpy(out_jac18 + 18 * (size_t)chains[i].results[q], res + 18 * q, 144);
+    return ALEO_MI355X_OK;
+  };
+  if ((rc = sort_of(0))) return drain(rc);
+  hipEvent_t prev_accum = nullptr;
+  for (size_t i = 0; i < n; ++i) {
+    Ctx* cc = cx[i & 1]; hipStream_t as = acc_st[i & 1];
+    if (live[i]) {
+      HIPCHK(hipStreamWaitEvent(as, cc->ev_hop, 0));
+      if ((rc = msm_front_accum(cc, as, f[i], nullptr, prev_accum))) return drain(rc);
+      prev_accum = cc->ev[5];
+    }
+    if (i + 1 < n) {
+      if (i >= 1 && (rc = collect(i - 1))) return drain(rc);       // frees context (i + 1) mod 2
+      if (live[i]) HIPCHK(hipStreamWaitEvent(cx[(i + 1) & 1]->hi, cc->ev[6], 0));      // not before accumulation i starts: two sorts side by side only delay the first accumulation
+      if ((rc = sort_of(i + 1))) return drain(rc);
+    }
+    if (live[i]) {
+      HIPCHK(hipStreamWaitEvent(cc->hi, cc->ev[5], 0));
+      if ((rc = msm_front_finish(cc, cc->hi, f[i], true))) return drain(rc);
+      if ((rc = msm_back(cc, nullptr, f[i], cc->hi, false, FrontChain{}, false, false))) return drain(rc);
+    }
+  }
+  if (n >= 2 && (rc = collect(n - 2))) return drain(rc);
+  if ((rc = collect(n - 1))) return drain(rc);
+  return drain(ALEO_MI355X_OK);
+}
 static int32_t run_chains(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, std::vector<Chain>& chains, bool mont, hipStream_t s) {
   auto run_one = [&](Ctx* cc, Chain& ch, hipStream_t st) -> int32_t {
     uint64_t res[MAX_SETS * 18];
@@ -1470,6 +1538,16 @@ static int32_t run_chains(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, st
   if (chains.size() >= 2 && total >= ((size_t)1 << 20) && chains_overlap_on() && c->dev) { const int32_t rc = acquire_helpers(c->dev, 1, hs); if (rc) return rc; }
   if (hs.ctx.empty()) { for (auto& ch : chains) { const int32_t rc = run_one(c, ch, s); if (rc) return rc; } return ALEO_MI355X_OK; }
   Ctx* h = hs.ctx[0];
+  if (chain_pipeline_on()) {
+    bool all_tiered = true;                                   // every chain on a table tier (the grouping of msm_batch makes them so, except the tier-less singles)
+    for (auto& ch : chains) {
+      size_t reach = 0; for (auto& g : ch.segs) if (g.len) reach = g.off + g.len > reach ? g.off + g.len : reach;
+      bool t_ok = reach == 0;                                 // (an empty chain: its results are the identity)
+      if (reach) for (const auto& t : pb.tab) if (t.d && reach >= t.min_n && reach <= t.cover) { t_ok = ch.results.size() <= 1 || ch.results.size() <= msm_max_sets(pb, reach); break; }
+      all_tiered = all_tiered && t_ok && ch.results.size() <= MAX_SETS;
+    }
+    if (all_tiered) return run_chains_pipelined(c, h, out_jac18, pb, chains, mont, s);
+  }
   HIPCHK(hipEventRecord(c->ev[4], s));                     // ev[4] is free until this chain's own msm_run (which may use it for its aside trees) starts
   HIPCHK(hipStreamWaitEvent(h->stream, c->ev[4], 0));
   std::atomic<size_t> next{0}; int32_t rc_h = ALEO_MI355X_OK; std::string err_h; MsmTiming tm_h{};
@@ -1556,12 +1634,16 @@ int32_t msm_batch(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, const MsmJ
     }
   }
   std::vector<uint32_t> todo; todo.reserve(K); std::vector<Chain> chains;
+  size_t total_points = 0; for (uint32_t q = 0; q < K; ++q) total_points += points[q];
   for (int t = -1; t < 3; ++t) {
     todo.clear();
     for (uint32_t q = 0; q < K; ++q) if (tier_of(reach[q]) == t) todo.push_back(q);
     size_t pos = 0;
     while (pos < todo.size()) {
-      const size_t cap = t < 0 ? 1 : msm_max_sets(pb, reach[todo[pos]]);
+      size_t cap = t < 0 ? 1 : msm_max_sets(pb, reach[todo[pos]]);
+      // big requests go out as a pipeline of launch chains (run_chains): smaller chains expose a shorter first sort and a shorter last reduction
+      static const size_t pipe_sets = [] { const char* e = std::getenv("ALEO_MI355X_CHAIN_MAX_SETS"); const int k = e ? std::atoi(e) : 0; return (size_t)(k >= 0 && k <= (int)MAX_SETS ? k : 0); }();
+      if (pipe_sets && t >= 0 && total_points >= ((size_t)1 << 22) && cap > pipe_sets) cap = pipe_sets;
       size_t take = 0, pts = 0, sg = 0; uint32_t local[MAX_SETS];
       // 2^32 pairs and MAX_SEGS segments per launch chain: chunks are also cut by total points and segments
       while (pos + take < todo.size() && take < cap && (take == 0 || (pts + points[todo[pos + take]] <= ((size_t)1 << 26) && sg + nsegs[todo[pos + take]] <= MAX_SEGS))) {

@@ -842,6 +842,33 @@ def test_batched_msm_mixed_tiers_and_degenerate_sets():
         for i, m in enumerate(lens): assert c.jac_to_int_point(got[i]) == util.expected_multiples_msm(S[i], m)
 
 
+def test_big_batched_request_runs_as_a_pipeline_of_launch_chains():
+    """A request of >= 2^20 points in several launch chains (different table tiers, more results than one chain holds) goes through run_chains' pipeline:
+    chain i + 1 is sorted and chain i - 1 reduced beside the accumulation of chain i, on two contexts.  Results of every tier, an empty vector, an all-zero
+    one, an all-equal one and witness-like ones against the O(n) identity; the same request twice (the contexts are reused); and a request with a
+    tier-less member, which must take the two-thread path and still be right."""
+    import torch
+    N = 1 << 20
+    with M.PinnedBases.generate_multiples(synth.generator_affine104(), 1, N) as pb:
+        pb.precompute()
+        lens = [N, (1 << 19) + 7, 1 << 17, (1 << 17) + 64, 0, 1 << 15, 3 << 18, N - 1, 40000, 1 << 20, 5000, (1 << 16) + 1]
+        S = [util.uniform_scalars(max(m, 1), 15000 + i)[:m] for i, m in enumerate(lens)]
+        S[2] = np.zeros((lens[2], 4), dtype=np.uint64)
+        S[5] = np.tile(util.uniform_scalars(1, 15999), (lens[5], 1))
+        S[6] = util.witness_like_scalars(lens[6], 15998); S[9] = util.witness_like_scalars(lens[9], 15997)
+        d = [torch.from_numpy(np.ascontiguousarray(x).view(np.int64).copy()).cuda() if len(x) else torch.zeros((1, 4), dtype=torch.int64, device='cuda') for x in S]
+        torch.cuda.synchronize()
+        exp = [util.expected_multiples_msm(S[i], m) if m else None for i, m in enumerate(lens)]
+        for rep in range(2):
+            got = M.VariableBase.msm_batch_device(pb, [t.data_ptr() for t in d], lens)
+            for i, m in enumerate(lens): assert c.jac_to_int_point(got[i]) == exp[i], (rep, i, m)
+        lens2 = lens[:4] + [300]                                                        # 300 points: below every tier -> the plain path -> not a pipeline
+        S2 = S[:4] + [util.uniform_scalars(300, 15500)]
+        d2 = d[:4] + [torch.from_numpy(S2[4].view(np.int64).copy()).cuda()]; torch.cuda.synchronize()
+        got = M.VariableBase.msm_batch_device(pb, [t.data_ptr() for t in d2], lens2)
+        for i, m in enumerate(lens2): assert c.jac_to_int_point(got[i]) == util.expected_multiples_msm(S2[i], m), (i, m)
+
+
 def test_async_device_calls_order_their_scratch_across_streams(tmp_path):
     """The *_device transforms enqueue on the caller's stream and return at once; with ONE slot (ALEO_MI355X_SLOTS=1) two
     threads on two streams keep handing the same scratch buffer to each other while the previous user's kernels are still

@@ -11,7 +11,19 @@ for r in seg:
     nm = r['Kernel_Name'].split('(')[0].replace('void ', '').replace('aleo_mi355x::', '')[:48]
     agg[nm] += int(r['End_Timestamp']) - int(r['Start_Timestamp']); cnt[nm] += 1
 busy = sum(agg.values()) / 2e6
-print('per proof: span %.3f ms, GPU busy %.3f ms, %d launches' % (span, busy, len(seg) // 2))
+iv = sorted((int(r['Start_Timestamp']), int(r['End_Timestamp'])) for r in seg); union = 0; cs, ce = iv[0]
+for s_, e_ in iv[1:]:
+    if s_ > ce: union += ce - cs; cs, ce = s_, e_
+    else: ce = max(ce, e_)
+union = (union + ce - cs) / 2e6                 # kernels of different streams overlap: the union is the time the card had anything to do
+accum = sorted((int(r['Start_Timestamp']), int(r['End_Timestamp'])) for r in seg if 'k_accum' in r['Kernel_Name']); au = 0
+if accum:
+    cs, ce = accum[0]
+    for s_, e_ in accum[1:]:
+        if s_ > ce: au += ce - cs; cs, ce = s_, e_
+        else: ce = max(ce, e_)
+    au = (au + ce - cs) / 2e6
+print('per proof: span %.3f ms, sum of kernel times %.3f ms, union busy %.3f ms, an accumulation kernel running %.3f ms, %d launches' % (span, busy, union, au, len(seg) // 2))
 groups = {'msm': ('k_accum', 'k_seg', 'k_tree', 'k_bucket', 'k_masked', 'k_part', 'k_bin', 'k_scan', 'k_slice', 'k_gather', 'k_mont', 'k_task', 'k_order', 'k_canon'),
           'ntt': ('k_ntt',), 'field': ('k_fr_', 'k_ahp', 'k_spmv', 'k_div', 'k_eval'), 'copies/fills': ('copyBuffer', 'fillBuffer', 'elementwise')}
 tot = collections.Counter()
