@@ -1466,24 +1466,27 @@ inline bool chains_overlap_on() { static const bool v = [] { const char* e = std
 // the table (profiles/r04_varuna_2^20_timeline_two_threads.txt): both chains of a round sort first (2.6 ms with no accumulation running), then their accumulations
 // share the chip, then both reductions trail — 28 of 80 ms per proof with no accumulation kernel on the card.  Here ONE host thread queues the chains so that
 // the accumulations run back to back and everything else runs beside them:
-//   chain i on context i mod 2: sort + slice ordering on the context's HIGH-priority stream, the accumulation on its normal-priority stream behind the
-//   previous chain's accumulation, slice trees + bucket reduction on the high-priority stream again; the host collects chain i - 1 (waits for its
-//   reduction, Horner, normalisation) and only then queues the sort of chain i + 1 on the context that just became free — by then accumulation i is
-//   running, so sort i + 1 and reduction i - 1 hide under it.
+//   chain i on context i mod R (R = 3: the caller's and two borrowed ones): sort + slice ordering on the context's HIGH-priority stream, the accumulation on
+//   its normal-priority stream behind the previous chain's accumulation, slice trees + bucket reduction on the high-priority stream again.  Before the
+//   host queues the sort of chain i + 1 it collects chain i + 1 - R (waits for its reduction; Horner, normalisation), whose context it takes over.  With
+//   R = 3 that reduction ran beside accumulation i - 1, so sort i + 1 is queued when accumulation i starts and has all of it to finish; with R = 2 the
+//   host would wait for reduction i - 1, which crawls beside accumulation i (an accumulation holds every wave slot: a 512-thread k_prog_final block waits
+//   milliseconds for a whole CU to drain), and sort i + 1 would run exposed after it — measured: 1.3 ms gaps between the accumulations of an
+//   8-instance round.
 static bool chain_pipeline_on() { static const bool v = [] { const char* e = std::getenv("ALEO_MI355X_CHAIN_PIPELINE"); return !(e && e[0] == '0'); }(); return v; }
-static int32_t run_chains_pipelined(Ctx* c, Ctx* h, uint64_t* out_jac18, const PinnedBases& pb, std::vector<Chain>& chains, bool mont, hipStream_t s) {
-  const size_t n = chains.size();
-  Ctx* cx[2] = {c, h}; hipStream_t acc_st[2] = {s, h->stream};
+static int32_t run_chains_pipelined(Ctx* c, const std::vector<Ctx*>& helpers, uint64_t* out_jac18, const PinnedBases& pb, std::vector<Chain>& chains, bool mont, hipStream_t s) {
+  const size_t n = chains.size(), R = 1 + helpers.size();   // a ring of R contexts: chain i on context i mod R
+  std::vector<Ctx*> cx(R); std::vector<hipStream_t> acc_st(R);
+  cx[0] = c; acc_st[0] = s; for (size_t k = 1; k < R; ++k) { cx[k] = helpers[k - 1]; acc_st[k] = helpers[k - 1]->stream; }
   std::vector<Front> f(n); std::vector<MsmJob> job(n); std::vector<char> live(n, 0);
-  auto drain = [&](int32_t code) { const std::string keep = g_last_error; for (int k = 0; k < 2; ++k) { (void)hipStreamSynchronize(cx[k]->hi); (void)hipStreamSynchronize(acc_st[k]); (void)hipStreamSynchronize(cx[k]->side); } g_last_error = keep; return code; };
+  auto drain = [&](int32_t code) { const std::string keep = g_last_error; for (size_t k = 0; k < R; ++k) { (void)hipStreamSynchronize(cx[k]->hi); (void)hipStreamSynchronize(acc_st[k]); (void)hipStreamSynchronize(cx[k]->side); } g_last_error = keep; return code; };
   HIPCHK(hipEventRecord(c->ev[4], s));                       // the scalars may still be in flight on the caller's stream
-  for (int k = 0; k < 2; ++k) { HIPCHK(hipStreamWaitEvent(cx[k]->hi, c->ev[4], 0)); }
-  HIPCHK(hipStreamWaitEvent(h->stream, c->ev[4], 0));
+  for (size_t k = 0; k < R; ++k) { HIPCHK(hipStreamWaitEvent(cx[k]->hi, c->ev[4], 0)); if (k) HIPCHK(hipStreamWaitEvent(acc_st[k], c->ev[4], 0)); }
   int32_t rc;
   auto sort_of = [&](size_t i) -> int32_t {
     Chain& ch = chains[i]; MsmJob& g = job[i];
     g.segs = ch.segs.data(); g.nseg = (uint32_t)ch.segs.size(); g.k = (uint32_t)ch.results.size(); g.mont = mont; g.sparse = ch.sparse; g.fire_tail = false;
-    Ctx* cc = cx[i & 1];
+    Ctx* cc = cx[i % R];
     const int32_t r = msm_front_sort(cc, pb, g, cc->hi, f[i]);
     if (r) return r;
     if (f[i].empty) { for (size_t q = 0; q < ch.results.size(); ++q) host::hstore_jacobian_normalized(out_jac18 + 18 * (size_t)ch.results[q], host::HXYZZ::infinity()); return ALEO_MI355X_OK; }
@@ -1494,24 +1497,25 @@ static int32_t run_chains_pipelined(Ctx* c, Ctx* h, uint64_t* out_jac18, const P
   };
   auto collect = [&](size_t i) -> int32_t {
     if (!live[i]) return ALEO_MI355X_OK;
-    uint64_t res[MAX_SETS * 18]; Ctx* cc = cx[i & 1];
+    uint64_t res[MAX_SETS * 18]; Ctx* cc = cx[i % R];
     const int32_t r = msm_back(cc, res, f[i], cc->hi, false, FrontChain{}, true, true);
     if (r) return r;
     for (size_t q = 0; q < chains[i].results.size(); ++q) std::memcpy(out_jac18 + 18 * (size_t)chains[i].results[q], res + 18 * q, 144);
+    live[i] = 0;
     return ALEO_MI355X_OK;
   };
   if ((rc = sort_of(0))) return drain(rc);
-  hipEvent_t prev_accum = nullptr;
+  hipEvent_t prev_accum = nullptr; size_t collected = 0;     // chains [0, collected) are done
   for (size_t i = 0; i < n; ++i) {
-    Ctx* cc = cx[i & 1]; hipStream_t as = acc_st[i & 1];
+    Ctx* cc = cx[i % R]; hipStream_t as = acc_st[i % R];
     if (live[i]) {
       HIPCHK(hipStreamWaitEvent(as, cc->ev_hop, 0));
       if ((rc = msm_front_accum(cc, as, f[i], nullptr, prev_accum))) return drain(rc);
       prev_accum = cc->ev[5];
     }
     if (i + 1 < n) {
-      if (i >= 1 && (rc = collect(i - 1))) return drain(rc);       // frees context (i + 1) mod 2
-      if (live[i]) HIPCHK(hipStreamWaitEvent(cx[(i + 1) & 1]->hi, cc->ev[6], 0));      // not before accumulation i starts: two sorts side by side only delay the first accumulation
+      for (; collected + R <= i + 1; ++collected) if ((rc = collect(collected))) return drain(rc);       // the context of chain i + 1 must be free: chain i + 1 - R collected
+      if (live[i]) HIPCHK(hipStreamWaitEvent(cx[(i + 1) % R]->hi, cc->ev[6], 0));      // not before accumulation i starts: two sorts side by side only delay the first accumulation
       if ((rc = sort_of(i + 1))) return drain(rc);
     }
     if (live[i]) {
@@ -1520,8 +1524,7 @@ static int32_t run_chains_pipelined(Ctx* c, Ctx* h, uint64_t* out_jac18, const P
       if ((rc = msm_back(cc, nullptr, f[i], cc->hi, false, FrontChain{}, false, false))) return drain(rc);
     }
   }
-  if (n >= 2 && (rc = collect(n - 2))) return drain(rc);
-  if ((rc = collect(n - 1))) return drain(rc);
+  for (; collected < n; ++collected) if ((rc = collect(collected))) return drain(rc);
   return drain(ALEO_MI355X_OK);
 }
 static int32_t run_chains(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, std::vector<Chain>& chains, bool mont, hipStream_t s) {
@@ -1535,7 +1538,7 @@ static int32_t run_chains(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, st
   };
   size_t total = 0; for (auto& ch : chains) total += ch.points;
   HelperSet hs;
-  if (chains.size() >= 2 && total >= ((size_t)1 << 20) && chains_overlap_on() && c->dev) { const int32_t rc = acquire_helpers(c->dev, 1, hs); if (rc) return rc; }
+  if (chains.size() >= 2 && total >= ((size_t)1 << 20) && chains_overlap_on() && c->dev) { const int32_t rc = acquire_helpers(c->dev, chain_pipeline_on() && chains.size() >= 3 ? 2 : 1, hs); if (rc) return rc; }
   if (hs.ctx.empty()) { for (auto& ch : chains) { const int32_t rc = run_one(c, ch, s); if (rc) return rc; } return ALEO_MI355X_OK; }
   Ctx* h = hs.ctx[0];
   if (chain_pipeline_on()) {
@@ -1546,7 +1549,7 @@ static int32_t run_chains(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, st
       if (reach) for (const auto& t : pb.tab) if (t.d && reach >= t.min_n && reach <= t.cover) { t_ok = ch.results.size() <= 1 || ch.results.size() <= msm_max_sets(pb, reach); break; }
       all_tiered = all_tiered && t_ok && ch.results.size() <= MAX_SETS;
     }
-    if (all_tiered) return run_chains_pipelined(c, h, out_jac18, pb, chains, mont, s);
+    if (all_tiered) return run_chains_pipelined(c, hs.ctx, out_jac18, pb, chains, mont, s);
   }
   HIPCHK(hipEventRecord(c->ev[4], s));                     // ev[4] is free until this chain's own msm_run (which may use it for its aside trees) starts
   HIPCHK(hipStreamWaitEvent(h->stream, c->ev[4], 0));
