@@ -1348,7 +1348,9 @@ static uint32_t chunks3_min_lg();
 // accumulation of the earlier ones instead of in front of everything.  Measured and OFF by default (round 4, resident uniform scalars, whole / chunked):
 // 2^20 2.82 / 3.03 ms, 2^21 5.12 / 5.24, 2^22 9.41 / 9.51 — without an upload to hide, the seeded launches (+5 % accumulation time: shorter slices, a seed
 // read and a product per bucket) and the sort that crawls beside an accumulation holding every wave slot cost more than the 0.3-1.0 ms of sort they
-// move out of the way.  ALEO_MI355X_CHUNK_DEV_MIN_LG: lg of the smallest such request (default 0 = never; the GPU suite passes with 20).
+// move out of the way; holding a later chunk's sort until the previous accumulation starts (as run_chains does for whole chains) makes it worse
+// (2^20 3.07, 2^21 5.91, 2^22 9.83 ms against 2.83 / 5.04 / 9.32 whole: tools/resident_ab.py).  ALEO_MI355X_CHUNK_DEV_MIN_LG: lg of the smallest such
+// request (default 0 = never; the GPU suite passes with 20).
 static uint32_t chunk_dev_min_lg() { static const uint32_t v = [] { const char* e = std::getenv("ALEO_MI355X_CHUNK_DEV_MIN_LG"); const int k = e ? std::atoi(e) : 0; return (uint32_t)(k >= 0 && k <= 40 ? k : 0); }(); return v; }
 int32_t msm_run(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, const MsmJob& job, hipStream_t s) {
   if (job.k == 0) return ALEO_MI355X_OK;
@@ -1637,16 +1639,12 @@ int32_t msm_batch(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, const MsmJ
     }
   }
   std::vector<uint32_t> todo; todo.reserve(K); std::vector<Chain> chains;
-  size_t total_points = 0; for (uint32_t q = 0; q < K; ++q) total_points += points[q];
   for (int t = -1; t < 3; ++t) {
     todo.clear();
     for (uint32_t q = 0; q < K; ++q) if (tier_of(reach[q]) == t) todo.push_back(q);
     size_t pos = 0;
     while (pos < todo.size()) {
-      size_t cap = t < 0 ? 1 : msm_max_sets(pb, reach[todo[pos]]);
-      // big requests go out as a pipeline of launch chains (run_chains): smaller chains expose a shorter first sort and a shorter last reduction
-      static const size_t pipe_sets = [] { const char* e = std::getenv("ALEO_MI355X_CHAIN_MAX_SETS"); const int k = e ? std::atoi(e) : 0; return (size_t)(k >= 0 && k <= (int)MAX_SETS ? k : 0); }();
-      if (pipe_sets && t >= 0 && total_points >= ((size_t)1 << 22) && cap > pipe_sets) cap = pipe_sets;
+      const size_t cap = t < 0 ? 1 : msm_max_sets(pb, reach[todo[pos]]);      // (chains of one set instead of two for the pipeline of run_chains: measured slower, 8 x 2^20 constraints 155 -> 160 ms)
       size_t take = 0, pts = 0, sg = 0; uint32_t local[MAX_SETS];
       // 2^32 pairs and MAX_SEGS segments per launch chain: chunks are also cut by total points and segments
       while (pos + take < todo.size() && take < cap && (take == 0 || (pts + points[todo[pos + take]] <= ((size_t)1 << 26) && sg + nsegs[todo[pos + take]] <= MAX_SEGS))) {
