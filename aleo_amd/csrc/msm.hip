@@ -1057,6 +1057,17 @@ struct Front {
 };
 }
 
+// Work queued on borrowed contexts must have finished before their locks are released, whatever way the function is left (an early HIPCHK return, an
+// exception on its way to the C ABI's catch): the guard synchronises the listed streams in its destructor unless the normal path — which ends
+// synchronised anyway — dismissed it.
+namespace {
+struct StreamDrainGuard {
+  std::vector<hipStream_t> streams; bool armed = true;
+  ~StreamDrainGuard() { if (!armed) return; const std::string keep = g_last_error; for (hipStream_t st : streams) if (st) (void)hipStreamSynchronize(st); g_last_error = keep; }
+  void add(hipStream_t st) { streams.push_back(st); }
+  void dismiss() { armed = false; }
+};
+}
 static int32_t msm_front_sort(Ctx* c, const PinnedBases& pb, const MsmJob& job, hipStream_t s, Front& f) {
   const uint32_t K = f.K = job.k;
   size_t n = 0, pts = 0; SegArgs segs{};
@@ -1400,6 +1411,7 @@ static int32_t msm_run_chunked(Ctx* c, HelperSet& hs, uint64_t* out_jac18, const
   const uint32_t (*share)[3] = dev_job ? share_dev : (share0_env ? share_env : share_host);
   const uint32_t K = dev_job ? dev_job->k : 1u;
   Ctx* cx[3] = {c, Q > 1 ? hs.ctx[0] : nullptr, Q > 2 ? hs.ctx[1] : nullptr}; hipStream_t st[3] = {s, Q > 1 ? hs.ctx[0]->hi : nullptr, Q > 2 ? hs.ctx[1]->hi : nullptr};
+  StreamDrainGuard guard; for (uint32_t k = 0; k < Q; ++k) { guard.add(st[k]); guard.add(cx[k]->side); }
   size_t lo[4] = {0, 0, 0, 0};
   for (uint32_t k = 0, acc = 0; k < Q; ++k) { acc += share[Q][k]; lo[k + 1] = k + 1 == Q ? n : (((size_t)((double)n * acc / 100.0)) + 255) & ~(size_t)255; if (lo[k + 1] > n) lo[k + 1] = n; }
   Front f[3]; MsmSeg seg[3]; std::vector<MsmSeg> dsegs[3]; int32_t rc; uint32_t cum[4] = {0, 0, 0, 0};
@@ -1448,6 +1460,7 @@ static int32_t msm_run_chunked(Ctx* c, HelperSet& hs, uint64_t* out_jac18, const
   HIPCHK(hipEventElapsedTime(&ms, c->ev[1], cx[Q - 1]->ev[2])); tm.accum = ms;               // from there to the last chunk's final bucket sums
   tm.total = tm.sort + tm.accum + tm.reduce + tm.host;
   c->last_msm = tm; g_last_msm = tm;
+  guard.dismiss();
   return ALEO_MI355X_OK;
 }
 
@@ -1480,8 +1493,9 @@ static int32_t run_chains_pipelined(Ctx* c, const std::vector<Ctx*>& helpers, ui
   const size_t n = chains.size(), R = 1 + helpers.size();   // a ring of R contexts: chain i on context i mod R
   std::vector<Ctx*> cx(R); std::vector<hipStream_t> acc_st(R);
   cx[0] = c; acc_st[0] = s; for (size_t k = 1; k < R; ++k) { cx[k] = helpers[k - 1]; acc_st[k] = helpers[k - 1]->stream; }
+  StreamDrainGuard guard; for (size_t k = 0; k < R; ++k) { guard.add(cx[k]->hi); guard.add(acc_st[k]); guard.add(cx[k]->side); }      // also on an exception or an early return below
   std::vector<Front> f(n); std::vector<MsmJob> job(n); std::vector<char> live(n, 0);
-  auto drain = [&](int32_t code) { const std::string keep = g_last_error; for (size_t k = 0; k < R; ++k) { (void)hipStreamSynchronize(cx[k]->hi); (void)hipStreamSynchronize(acc_st[k]); (void)hipStreamSynchronize(cx[k]->side); } g_last_error = keep; return code; };
+  auto drain = [&](int32_t code) { return code; };           // (the guard drains)
   HIPCHK(hipEventRecord(c->ev[4], s));                       // the scalars may still be in flight on the caller's stream
   for (size_t k = 0; k < R; ++k) { HIPCHK(hipStreamWaitEvent(cx[k]->hi, c->ev[4], 0)); if (k) HIPCHK(hipStreamWaitEvent(acc_st[k], c->ev[4], 0)); }
   int32_t rc;
