@@ -113,7 +113,8 @@ template <int C, int W_IDX, class F> __device__ __forceinline__ void for_each_di
 // scalars in LDS, an exclusive scan over the [bin][block] count matrix gives each block a private output run per
 // bin, and the scatter pass ranks items with LDS atomics.  Level 2 gives one block per coarse bin: an LDS
 // histogram over the low 8 bucket bits yields the final per-bucket counts and positions.
-static constexpr uint32_t PART_TILE = 2048;       // scalars per block in the level-1 passes
+static constexpr uint32_t PART_TILE = 2048;       // scalars per block in the level-1 passes (SegArgs::tile: 2048, or 4096 / 8192 for chains of >= 2^21 / 2^22 points — a block's run in a
+                                                  // coarse bin is tile * windows / bins items of 8 bytes: ~100 bytes at 2048, and the PMC write counter showed 3.3 x the bytes stored)
 static constexpr uint32_t MAX_COARSE = 2048;      // coarse bins of ONE set: W * (B >> LB) at c = 16 (the LDS tables of the level-1 passes)
 static constexpr uint32_t MAX_COARSE_ALL = 4096;  // coarse bins of all sets of a chain (k_bin_parts: one block, 16 bins per lane): 32 sets at c = 16, 16 at c = 17
 
@@ -143,13 +144,13 @@ __global__ void __launch_bounds__(256) k_part_count(SegArgs segs, const uint8_t*
   using Gm = SortGeom<C, PRE>;
   __shared__ uint32_t h[MAX_COARSE];
   const uint32_t bx = xcd_tile(blockIdx.x, gridDim.x);
-  const uint32_t n = segs.n[blockIdx.y], base = bx * PART_TILE;
+  const uint32_t n = segs.n[blockIdx.y], base = bx * segs.tile;
   if (base >= n) return;                                      // the grid is as wide as the longest segment
   for (uint32_t i = threadIdx.x; i < Gm::NCB; i += 256) h[i] = 0;
   __syncthreads();
   const char* scalars = segs.ptr[blockIdx.y]; const uint32_t off = segs.off[blockIdx.y], nblk = segs.ncol;
   cnt += (size_t)segs.set[blockIdx.y] * Gm::NCB * nblk + segs.col0[blockIdx.y];
-  for (uint32_t q = 0; q < PART_TILE / 256; ++q) {
+  for (uint32_t q = 0; q < segs.tile / 256; ++q) {
     uint32_t i = base + q * 256 + threadIdx.x;
     if (i < n && !(inf && inf[off + i])) {
       uint32_t s[8]; load_scalar<MONT>(scalars, i, s);
@@ -207,13 +208,13 @@ __global__ void __launch_bounds__(256) k_part_scatter(SegArgs segs, const uint8_
   using Gm = SortGeom<C, PRE>;
   __shared__ uint32_t cur[MAX_COARSE];
   const uint32_t bx = xcd_tile(blockIdx.x, gridDim.x);
-  const uint32_t n = segs.n[blockIdx.y], base = bx * PART_TILE;
+  const uint32_t n = segs.n[blockIdx.y], base = bx * segs.tile;
   if (base >= n) return;
   const char* scalars = segs.ptr[blockIdx.y]; const uint32_t off = segs.off[blockIdx.y], nblk = segs.ncol;
   const size_t row0 = (size_t)segs.set[blockIdx.y] * Gm::NCB; const uint32_t col = segs.col0[blockIdx.y] + bx;
   for (uint32_t i = threadIdx.x; i < Gm::NCB; i += 256) cur[i] = scan32_at(off_local, off_blk, (row0 + i) * nblk + col);
   __syncthreads();
-  for (uint32_t q = 0; q < PART_TILE / 256; ++q) {
+  for (uint32_t q = 0; q < segs.tile / 256; ++q) {
     uint32_t i = base + q * 256 + threadIdx.x;
     if (i < n && !(inf && inf[off + i])) {
       uint32_t s[8]; load_scalar<MONT>(scalars, i, s);
@@ -958,8 +959,11 @@ int32_t msm_sort_phase(Ctx* c, SegArgs& segs, size_t pts, bool mont, const uint8
   SortPhase& sp = *out; sp.P = P;
   // columns of the level-1 count matrix: the blocks of a set's segments side by side; every row is as wide as the widest set
   uint32_t width[MAX_SETS] = {}, nblk_x = 0;
+  static const uint32_t tile_max = [] { const char* e = std::getenv("ALEO_MI355X_PART_TILE_MAX"); const int k = e ? std::atoi(e) : 8192; return (uint32_t)(k == 2048 || k == 4096 || k == 8192 ? k : 8192); }();      // A/B switch
+  uint32_t tile = pts >= ((size_t)1 << 22) ? 8192u : (pts >= ((size_t)1 << 21) ? 4096u : PART_TILE);
+  segs.tile = tile < tile_max ? tile : tile_max;
   for (uint32_t q = 0; q < segs.nseg; ++q) {
-    const uint32_t nb = (segs.n[q] + PART_TILE - 1) / PART_TILE, st = pre ? segs.set[q] : 0;
+    const uint32_t nb = (segs.n[q] + segs.tile - 1) / segs.tile, st = pre ? segs.set[q] : 0;
     segs.col0[q] = width[st]; width[st] += nb; nblk_x = nb > nblk_x ? nb : nblk_x;
   }
   uint32_t nblk = 1; for (uint32_t w : width) nblk = w > nblk ? w : nblk;

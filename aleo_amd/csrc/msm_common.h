@@ -20,7 +20,7 @@ MsmPlan make_plan(size_t n, int pre_c);
 // Several segments may feed one set (KZG10::commit with hiding: the polynomial against the powers and the blinding polynomial against
 // the gamma powers behind them; a degree-bounded polynomial is one segment at the shifted powers' offset).  col0: first column of the
 // segment's blocks in its set's rows of the level-1 count matrix [set][bin][columns of the set's segments].  (kernel argument)
-struct SegArgs { const char* ptr[MAX_SEGS]; uint32_t n[MAX_SEGS], off[MAX_SEGS], col0[MAX_SEGS]; uint8_t set[MAX_SEGS]; uint32_t nseg = 0, ncol = 0; };
+struct SegArgs { const char* ptr[MAX_SEGS]; uint32_t n[MAX_SEGS], off[MAX_SEGS], col0[MAX_SEGS]; uint8_t set[MAX_SEGS]; uint32_t nseg = 0, ncol = 0, tile = 2048; };      // tile: scalars per block in the level-1 passes (msm_sort_phase picks it)
 
 // Slice sizing.  A bucket of <= single points is one slice (one lane); larger buckets are cut into slices of <= split.
 struct SliceRule { uint32_t single, split; };
