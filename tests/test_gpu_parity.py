@@ -862,6 +862,21 @@ def test_big_batched_request_runs_as_a_pipeline_of_launch_chains():
         for rep in range(2):
             got = M.VariableBase.msm_batch_device(pb, [t.data_ptr() for t in d], lens)
             for i, m in enumerate(lens): assert c.jac_to_int_point(got[i]) == exp[i], (rep, i, m)
+        # the same pipeline on the narrow-window range table (sparse hint; witness-like and small scalars, every segment inside the range)
+        from aleo_amd.kzg import SonicKZG10
+        pb.precompute_range(0, N, 16)
+        lens3 = [N, 3 << 18, (1 << 19) + 5, N - 7, 1 << 20, 1 << 18, 12345]
+        S3 = [util.witness_like_scalars(m, 15600 + i) for i, m in enumerate(lens3)]
+        S3[2] = np.zeros((lens3[2], 4), dtype=np.uint64); S3[2][:, 0] = np.arange(lens3[2], dtype=np.uint64) % 65536
+        m3 = [c.fr_to_mont(x) for x in S3]
+        d3 = [torch.from_numpy(x.view(np.int64).copy()).cuda() for x in m3]; torch.cuda.synchronize()
+        segs3 = [(t.data_ptr(), m, 0, i) for i, (t, m) in enumerate(zip(d3, lens3))]
+        class _CK: bases = pb
+        dense = SonicKZG10.commit_segments_device(_CK, segs3, len(lens3))
+        sparse = SonicKZG10.commit_segments_device(_CK, segs3, len(lens3), sparse=True)
+        assert (dense == sparse).all()
+        pts3 = c.affine_to_ints(sparse)
+        for i, m in enumerate(lens3): assert pts3[i] == util.expected_multiples_msm(S3[i], m), (i, m)
         lens2 = lens[:4] + [300]                                                        # 300 points: below every tier -> the plain path -> not a pipeline
         S2 = S[:4] + [util.uniform_scalars(300, 15500)]
         d2 = d[:4] + [torch.from_numpy(S2[4].view(np.int64).copy()).cuda()]; torch.cuda.synchronize()
