@@ -623,6 +623,16 @@ def varuna_prove(synth, torch, lg, reps=7, in_flight=4):
                 ml = float(np.median(tl[1:]))
                 lock = {'proofs_per_call': 8, 'ms_per_call': ml * 1e3, 'proofs_per_s': 8 / ml, 'constraints_per_s': 8 * n / ml, 'entry_point': 'aleo_mi355x_varuna_prove_many',
                         'what': 'independent proofs (own seed, transcript, output), byte-equal to the single calls; one host thread'}
+                def two(k):                                # two such calls in flight (what aleo_mi355x::ProvingQueue does with its two drainer threads)
+                    rq = [([nx8], [[zz]], 7100 + 10 * k + q) for q in range(8)]
+                    for rep in range(3): varuna.prove_many_native(rq)
+                for _ in range(2):
+                    th = [threading.Thread(target=two, args=(k,)) for k in range(2)]
+                    t = time.perf_counter()
+                    for x in th: x.start()
+                    for x in th: x.join()
+                    d2 = time.perf_counter() - t
+                lock['two_callers'] = {'proofs_per_s': 2 * 3 * 8 / d2, 'constraints_per_s': n * 2 * 3 * 8 / d2}
         except SystemExit: raise
         except Exception as e: lock = {'error': repr(e)[:300]}
         try: several = varuna_prove_several(synth, ck, lg)
