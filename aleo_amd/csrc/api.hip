@@ -82,6 +82,10 @@ static void enable_peer_access() {
   (void)hipSetDevice(cur);
 }
 
+// GPU_MAX_HW_QUEUES (read by the HIP runtime when it initialises; default 4): 8 unless the host has set it — see aleo_amd/__init__.py.  Runs when the
+// library is loaded; without effect if the process has already initialised HIP.
+namespace { struct EnvDefaults { EnvDefaults() { (void)setenv("GPU_MAX_HW_QUEUES", "8", 0); } } g_env_defaults; }
+
 static int32_t get_device(Device** out) {
   int device = -1;
   if (hipGetDevice(&device) != hipSuccess) { g_last_error = "no HIP device visible"; return ALEO_MI355X_ERR_NO_DEVICE; }

@@ -15,6 +15,7 @@ partials are all-gathered (RCCL) and added locally.  Default: w
 scaling).  value = points processed by all ranks / max-over-ranks wall time.  Prints ONE JSON line on rank 0."""
 from __future__ import annotations
 import argparse, json, os, sys, time
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')          # as aleo_amd/__init__.py does (read by the HIP runtime at its initialisation, which torch may trigger before the package is imported)
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
