@@ -29,13 +29,19 @@ int32_t ensure_host_pinned(Ctx* c, size_t bytes) {
 // ---- slot scratch shared by asynchronous calls (ctx.h) --------------------------------------------------
 int32_t scratch_acquire(Ctx* c, DevBuf& b, size_t bytes, hipStream_t s) {
   if (c->scratch_busy) {
-    if (bytes > b.cap) { HIPCHK(hipEventSynchronize(c->scratch_ev)); c->scratch_busy = false; }   // reserve() is about to free it
-    else HIPCHK(hipStreamWaitEvent(s, c->scratch_ev, 0));
+    const bool grows = bytes > b.cap;
+    if (c->scratch_stream && (grows || c->scratch_stream != s)) { HIPCHK(hipEventRecord(c->scratch_ev, c->scratch_stream)); c->scratch_stream = nullptr; }      // the deferred record: behind everything queued there so far
+    if (grows) { HIPCHK(hipEventSynchronize(c->scratch_ev)); c->scratch_busy = false; }   // reserve() is about to free it
+    else if (!c->scratch_stream) HIPCHK(hipStreamWaitEvent(s, c->scratch_ev, 0));
+    // (same stream as the last user: stream order is the order)
   }
   return b.reserve(bytes);
 }
 int32_t scratch_release(Ctx* c, hipStream_t s) {
-  HIPCHK(hipEventRecord(c->scratch_ev, s)); c->scratch_busy = true; return ALEO_MI355X_OK;
+  c->scratch_busy = true;
+  if (s && (s == c->stream || s == c->side || s == c->hi)) { c->scratch_stream = s; return ALEO_MI355X_OK; }      // a stream the slot owns: it outlives the deferred record
+  c->scratch_stream = nullptr;
+  HIPCHK(hipEventRecord(c->scratch_ev, s)); return ALEO_MI355X_OK;      // a caller's stream may be gone by the next call: record now
 }
 
 static int32_t init_device(int device, Device** out) {
@@ -82,9 +88,9 @@ static void enable_peer_access() {
   (void)hipSetDevice(cur);
 }
 
-// GPU_MAX_HW_QUEUES (read by the HIP runtime when it initialises; default 4): 8 unless the host has set it — see aleo_amd/__init__.py.  Runs when the
-// library is loaded; without effect if the process has already initialised HIP.
-namespace { struct EnvDefaults { EnvDefaults() { (void)setenv("GPU_MAX_HW_QUEUES", "8", 0); } } g_env_defaults; }
+// GPU_MAX_HW_QUEUES (read by the HIP runtime when it initialises; default 4) is an environment REQUIREMENT of the host, documented in the header and in
+// the library never touches the process environment (setenv from a loaded library races with getenv in the host's other threads).
+// The Python package and bench.py set their own default before HIP starts.
 
 static int32_t get_device(Device** out) {
   int device = -1;
@@ -1009,6 +1015,21 @@ int32_t aleo_mi355x_ntt_fr_batch_device(void* d_inout, uint32_t lg_n, size_t bat
     if ((!d_inout && batch) || lg_n > 30 || order < 0 || order > 3 || direction < 0 || direction > 1 || type < 0 || type > 1) { g_last_error = "ntt_fr_batch_device: bad argument"; return ALEO_MI355X_ERR_BAD_ARG; }
     API_BEGIN
     return run_enqueue(c, stream, [&](hipStream_t s) { return ntt_run(c, d_inout, lg_n, batch, order, direction, type, s); });
+  } catch (...) { return ALEO_MI355X_ERR_HIP; }
+}
+
+int32_t aleo_mi355x_ntt_fr_from_device(void* d_out, const void* d_src, size_t src_stride, size_t src_len, uint32_t lg_n, size_t batch, int32_t direction, int32_t type, void* stream) {
+  try {
+    if (((!d_out || !d_src) && batch) || lg_n > 30 || direction < 0 || direction > 1 || type < 0 || type > 1 || src_len > ((size_t)1 << lg_n) || src_stride >= (1ull << 32)) {
+      g_last_error = "ntt_fr_from_device: bad argument"; return ALEO_MI355X_ERR_BAD_ARG;
+    }
+    if (batch) {                                             // the output must not overlap the source (the first pass reads while later blocks of the same launch already write)
+      const char* o0 = (const char*)d_out; const char* o1 = o0 + ((batch << lg_n) * 32);
+      const char* s0 = (const char*)d_src; const char* s1 = s0 + ((batch - 1) * src_stride + src_len) * 32;
+      if (src_len && o0 < s1 && s0 < o1) { g_last_error = "ntt_fr_from_device: d_out overlaps d_src"; return ALEO_MI355X_ERR_BAD_ARG; }
+    }
+    API_BEGIN
+    return run_enqueue(c, stream, [&](hipStream_t s) { return ntt_run_from(c, d_out, d_src, src_stride, src_len, lg_n, batch, direction, type, s); });
   } catch (...) { return ALEO_MI355X_ERR_HIP; }
 }
 

@@ -105,6 +105,7 @@ struct Ctx {                           // one concurrency slot
   hipStream_t stream = nullptr;
   std::mutex mu;                       // held for the duration of one API call
   hipEvent_t ev[8] = {};
+  uint32_t meta_seq = 0;               // msm_sort_phase: sequence number of the slice metadata k_scan_top stores into h_pinned
   // MSM workspaces
   DevBuf hist, scan_local, scan_blk, sorted, part_cnt, part_items, partial, task_g, meta, vbuf, scalars_stage, out_stage;
   void* h_pinned = nullptr; size_t h_pinned_cap = 0;    // pinned host staging for small D2H results
@@ -119,7 +120,9 @@ struct Ctx {                           // one concurrency slot
   // the slot is then handed to the next call, possibly on another stream.  scratch_ev is recorded after the last kernel that
   // touches the scratch; the next user waits on it (scratch_acquire) before its first kernel, or synchronises on it before
   // the buffer is freed to grow.
-  hipEvent_t scratch_ev = nullptr; bool scratch_busy = false;
+  // The record is LAZY when the last user ran on one of the slot's own streams (scratch_stream): a later user on the same stream needs no event at all (stream
+  // order), a user on another stream records it then — an event record between two kernels costs ~6 us of idle GPU, and a proof made ~17 of them.
+  hipEvent_t scratch_ev = nullptr; bool scratch_busy = false; hipStream_t scratch_stream = nullptr;
   hipStream_t side = nullptr;          // second stream of the slot: small read-backs that must not wait for the kernels queued behind them
   hipStream_t hi = nullptr;            // a high-priority stream: the sort of a later chunk / the next launch chain must get its workgroups in while an accumulation fills the chip (msm_run_chunked, run_chains)
   hipEvent_t ev_hop = nullptr;         // run_chains: a chain's sort (on hi) -> its accumulation (on the normal-priority stream)
@@ -168,7 +171,7 @@ int32_t ensure_host_pinned(Ctx* c, size_t bytes);
 //   sum_i scalar[i] * base[off + i],  i < len    (scalars at the DEVICE pointer d_ptr; the segment array itself is host memory).
 // k > 1 needs a table tier that covers every base reached and k <= msm_max_sets(); msm_batch() groups arbitrary requests accordingly.
 struct MsmSeg { const void* d_ptr = nullptr; size_t len = 0, off = 0; uint32_t out = 0; };
-struct MsmJob { const MsmSeg* segs = nullptr; uint32_t nseg = 0, k = 0; bool mont = false; bool sparse = false; bool fire_tail = false; size_t tier_n = 0; };      // tier_n: pick the table tier as for a reach of tier_n (a part of a split request keeps the whole request's window)      // fire_tail: this launch chain is the whole request — run Ctx::tail_hook behind its last kernel      // sparse: hint — use the set's range table when every segment lies inside it
+struct MsmJob { const MsmSeg* segs = nullptr; uint32_t nseg = 0, k = 0; bool mont = false; bool sparse = false; bool fire_tail = false; size_t tier_n = 0; bool lean = false; };      // lean: no phase-timing events on the stream (the prover's commitments: MsmTiming then only carries the host tail)      // tier_n: pick the table tier as for a reach of tier_n (a part of a split request keeps the whole request's window)      // fire_tail: this launch chain is the whole request — run Ctx::tail_hook behind its last kernel      // sparse: hint — use the set's range table when every segment lies inside it
 int32_t msm_run(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, const MsmJob& job, hipStream_t s);
 inline int32_t msm_run1(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, const void* d_scalars, size_t n, bool mont, hipStream_t s, bool sparse = false) {
   MsmSeg g; g.d_ptr = d_scalars; g.len = n;
@@ -219,7 +222,12 @@ int32_t fr_divide_by_linear(Ctx* c, void* d_q, void* d_eval, const void* d_p, si
 int32_t index_expand_rows(Ctx* c, const uint32_t* d_row_ptr, const uint32_t* d_col, const uint32_t* d_positions, size_t rows, uint32_t* d_k_row, uint32_t* d_k_col, uint32_t* d_cpos, uint32_t* d_count_plus1, hipStream_t s);
 int32_t index_scan_inclusive(Ctx* c, uint32_t* d_a, size_t n, hipStream_t s);
 int32_t index_transpose_rows(Ctx* c, const uint32_t* d_row_ptr, const uint32_t* d_cpos, const void* d_val, size_t rows, uint32_t row_base, uint32_t* d_cursor, uint32_t* d_tcol, void* d_tval, hipStream_t s);
-int32_t fr_spmv(Ctx* c, void* d_y, const void* d_row_ptr, const void* d_col, const void* d_vals, const void* d_x, size_t rows, hipStream_t s);
+int32_t fr_spmv(Ctx* c, void* d_y, const void* d_row_ptr, const void* d_col, const void* d_vals, const void* d_x, size_t rows, hipStream_t s, size_t max_row = 0);      // max_row: bound of the longest row (0 = unknown): skips the long / huge-row launches that cannot have work
+int32_t fr_divide_by_linear_many(Ctx* c, void* const* d_q, void* const* d_eval, const void* const* d_p, const size_t* n, const void* const* z_mont32, size_t count, hipStream_t s);      // <= 4 divisions in three launches
+int32_t fr_scale_rows(Ctx* c, void* d_dst, const void* d_src, size_t n, size_t rows, const void* consts_mont, hipStream_t s);
+int32_t fr_split_quotient(Ctx* c, void* d_hq, void* d_rq, const void* d_q, const void* d_mask, size_t n, void* host_sum_devptr, hipStream_t s);
+int32_t fr_sub_mul(Ctx* c, void* d_dst, const void* d_a, const void* d_b, const void* d_m, size_t n, hipStream_t s);
+int32_t fr_pick(Ctx* c, void* dst_devptr, const void* const* d_src, size_t count, hipStream_t s);
 // varuna.hip / api.hip
 int32_t varuna_prove(Ctx* c, const PinnedBases& pb, const aleo_mi355x_varuna_index& ix, const void* const* assignments, size_t k, const uint8_t* seed32, uint8_t* out, size_t* out_len);
 // one request of a lockstep call (varuna_prove_many): the circuits of ONE proof, its assignments, seed and output; status / error come back per request
@@ -238,6 +246,7 @@ const std::vector<uint8_t>& varuna_index_vk(const VarunaIndexOwner* o);
 void jacobian_rows_to_affine104(void* out104, const uint64_t* jac18, size_t k);
 // ntt.hip
 int32_t ntt_run(Ctx* c, void* d_inout, uint32_t lg_n, size_t batch, int32_t order, int32_t direction, int32_t type, hipStream_t s);
+int32_t ntt_run_from(Ctx* c, void* d_out, const void* d_src, size_t src_stride_elems, size_t src_len, uint32_t lg_n, size_t batch, int32_t direction, int32_t type, hipStream_t s);      // out of place, input zero-padded from src_len to 2^lg_n
 
 int32_t fr_transpose(Ctx* c, void* d_dst, const void* d_src, uint64_t rows, uint64_t cols, hipStream_t s);      // dst[c][r] = src[r][c], 32-byte elements
 int32_t fr_grid_scale(Ctx* c, void* d_data, uint32_t lg_n, uint64_t rows, uint64_t cols, uint64_t row0, uint64_t col0, uint64_t ld, int32_t mode,

@@ -199,20 +199,25 @@ __global__ void __launch_bounds__(256) k_spmv_huge_fold(char* __restrict__ y, co
   }
 }
 
-int32_t fr_spmv(Ctx* c, void* d_y, const void* d_row_ptr, const void* d_col, const void* d_vals, const void* d_x, size_t rows, hipStream_t s) {
+// max_row: an upper bound of the longest row when the caller knows one (the prover's index does), 0 = unknown.  The kernels for long and huge rows are
+// launched only when such rows can exist — at the sizes of real circuits an empty launch still costs ~4.5 us of GPU time, and a proof runs 3k + 1 products.
+int32_t fr_spmv(Ctx* c, void* d_y, const void* d_row_ptr, const void* d_col, const void* d_vals, const void* d_x, size_t rows, hipStream_t s, size_t max_row) {
   if (rows == 0) return ALEO_MI355X_OK;
   if (rows >= (1ull << 32)) { g_last_error = "fr_spmv: row count exceeds 2^32"; return ALEO_MI355X_ERR_BAD_ARG; }
+  const bool may_long = max_row == 0 || max_row > SPMV_LANE_MAX, may_huge = max_row == 0 || max_row > SPMV_WAVE_MAX;
   const size_t head = ((rows + 16 + SPMV_HUGE_ROWS) * 4 + 255) & ~(size_t)255;
   int32_t rc; if ((rc = scratch_acquire(c, c->ntt_tmp, head + (size_t)SPMV_HUGE_ROWS * SPMV_HUGE_WAVES * 32, s))) return rc;
   uint32_t* counters = c->ntt_tmp.as<uint32_t>(); uint32_t* huge_rows = counters + 16; uint32_t* long_rows = huge_rows + SPMV_HUGE_ROWS;
   char* partial = c->ntt_tmp.as<char>() + head;
-  HIPCHK(hipMemsetAsync(counters, 0, 8, s));
+  if (may_long) HIPCHK(hipMemsetAsync(counters, 0, 8, s));
   const size_t want = (rows + 255) / 256; const uint32_t grid = (uint32_t)(want < 16384 ? want : 16384);
   const uint32_t* rp = (const uint32_t*)d_row_ptr; const uint32_t* cl = (const uint32_t*)d_col; const char* vl = (const char*)d_vals; const char* xx = (const char*)d_x;
   hipLaunchKernelGGL(k_spmv_rows, dim3(grid), dim3(256), 0, s, (char*)d_y, rp, cl, vl, xx, (uint32_t)rows, long_rows, huge_rows, counters);
-  hipLaunchKernelGGL(k_spmv_long, dim3(1024), dim3(256), 0, s, (char*)d_y, rp, cl, vl, xx, long_rows, counters);
-  hipLaunchKernelGGL(k_spmv_huge_partial, dim3(SPMV_HUGE_WAVES / 4), dim3(256), 0, s, rp, cl, vl, xx, huge_rows, counters, partial);
-  hipLaunchKernelGGL(k_spmv_huge_fold, dim3(SPMV_HUGE_ROWS), dim3(256), 0, s, (char*)d_y, huge_rows, counters, (const char*)partial);
+  if (may_long) hipLaunchKernelGGL(k_spmv_long, dim3(1024), dim3(256), 0, s, (char*)d_y, rp, cl, vl, xx, long_rows, counters);
+  if (may_huge) {
+    hipLaunchKernelGGL(k_spmv_huge_partial, dim3(SPMV_HUGE_WAVES / 4), dim3(256), 0, s, rp, cl, vl, xx, huge_rows, counters, partial);
+    hipLaunchKernelGGL(k_spmv_huge_fold, dim3(SPMV_HUGE_ROWS), dim3(256), 0, s, (char*)d_y, huge_rows, counters, (const char*)partial);
+  }
   HIPCHK(hipGetLastError());
   return scratch_release(c, s);
 }
@@ -240,10 +245,9 @@ __device__ __forceinline__ Fr div_lane_fold(const char* __restrict__ p, size_t l
   }
   return h;
 }
-__global__ void __launch_bounds__(256) k_div_blocks(const char* __restrict__ p, size_t n, FrK zk, char* __restrict__ E) {
-  __shared__ uint32_t l[8 * DIV_B];
+__device__ __forceinline__ void div_blocks_body(uint32_t* l, uint32_t blk, const char* __restrict__ p, size_t n, const FrK& zk, char* __restrict__ E) {
   const uint32_t t = threadIdx.x; const Fr z = fr_arg(zk);
-  Fr x = fr_lt2r(div_lane_fold(p, ((size_t)blockIdx.x * DIV_B + t) * DIV_K, n, z));
+  Fr x = fr_lt2r(div_lane_fold(p, ((size_t)blk * DIV_B + t) * DIV_K, n, z));
   Fr w = z; for (int i = 0; i < 4; ++i) w = Fr::sqr(w);     // Z = z^16, < 2r
   for (uint32_t d = 1; d < DIV_B; d <<= 1) {               // x_t += Z^d * x_(t+d) on the lanes that are multiples of 2d
     lds_put(l, t, x); __syncthreads();
@@ -251,11 +255,14 @@ __global__ void __launch_bounds__(256) k_div_blocks(const char* __restrict__ p, 
     __syncthreads();
     w = Fr::sqr(w);
   }
-  if (t == 0) store_fp<Fr>(E + (size_t)blockIdx.x * 32, x);
+  if (t == 0) store_fp<Fr>(E + (size_t)blk * 32, x);
+}
+__global__ void __launch_bounds__(256) k_div_blocks(const char* __restrict__ p, size_t n, FrK zk, char* __restrict__ E) {
+  __shared__ uint32_t l[8 * DIV_B];
+  div_blocks_body(l, blockIdx.x, p, n, zk, E);
 }
 // One block.  C[b] = sum_(u > b) E[u] * ZB^(u - b - 1), ZB = z^(16 * 256): lane q owns `per` consecutive blocks.
-__global__ void __launch_bounds__(256) k_div_carries(const char* __restrict__ E, uint32_t nb, uint32_t per, FrK zk, char* __restrict__ C) {
-  __shared__ uint32_t l[8 * DIV_B];
+__device__ __forceinline__ void div_carries_body(uint32_t* l, const char* __restrict__ E, uint32_t nb, uint32_t per, const FrK& zk, char* __restrict__ C) {
   const uint32_t t = threadIdx.x; Fr zb = fr_arg(zk);
   for (int i = 0; i < 12; ++i) zb = Fr::sqr(zb);            // z^4096, < 2r
   const uint32_t lo = t * per, hi = lo + per < nb ? lo + per : nb;
@@ -277,13 +284,16 @@ __global__ void __launch_bounds__(256) k_div_carries(const char* __restrict__ E,
     c = fr_lt2r(Fr::add(Fr::mul(c, zb), load_fp<Fr>(E + (size_t)b * 32)));
   }
 }
-__global__ void __launch_bounds__(256) k_div_finish(const char* __restrict__ p, size_t n, FrK zk, const char* __restrict__ C, char* __restrict__ q, char* __restrict__ eval) {
+__global__ void __launch_bounds__(256) k_div_carries(const char* __restrict__ E, uint32_t nb, uint32_t per, FrK zk, char* __restrict__ C) {
   __shared__ uint32_t l[8 * DIV_B];
+  div_carries_body(l, E, nb, per, zk, C);
+}
+__device__ __forceinline__ void div_finish_body(uint32_t* l, uint32_t blk, const char* __restrict__ p, size_t n, const FrK& zk, const char* __restrict__ C, char* __restrict__ q, char* __restrict__ eval) {
   const uint32_t t = threadIdx.x; const Fr z = fr_arg(zk);
-  const size_t lo = ((size_t)blockIdx.x * DIV_B + t) * DIV_K;
+  const size_t lo = ((size_t)blk * DIV_B + t) * DIV_K;
   Fr x = fr_lt2r(div_lane_fold(p, lo, n, z));
   Fr w = z; for (int i = 0; i < 4; ++i) w = Fr::sqr(w);     // Z = z^16
-  if (t == DIV_B - 1) x = fr_lt2r(Fr::add(x, Fr::mul(load_fp<Fr>(C + (size_t)blockIdx.x * 32), w)));     // the block's carry enters behind its last lane
+  if (t == DIV_B - 1) x = fr_lt2r(Fr::add(x, Fr::mul(load_fp<Fr>(C + (size_t)blk * 32), w)));     // the block's carry enters behind its last lane
   for (uint32_t d = 1; d < DIV_B; d <<= 1) {
     lds_put(l, t, x); __syncthreads();
     if (t + d < DIV_B) x = fr_lt2r(Fr::add(x, Fr::mul(lds_get(l, t + d), w)));
@@ -291,13 +301,39 @@ __global__ void __launch_bounds__(256) k_div_finish(const char* __restrict__ p, 
     w = Fr::sqr(w);
   }
   lds_put(l, t, x); __syncthreads();
-  Fr s = t + 1 < DIV_B ? lds_get(l, t + 1) : load_fp<Fr>(C + (size_t)blockIdx.x * 32);      // s_(lo + 16)
+  Fr s = t + 1 < DIV_B ? lds_get(l, t + 1) : load_fp<Fr>(C + (size_t)blk * 32);      // s_(lo + 16)
   for (int k = (int)DIV_K - 1; k >= 0; --k) {              // s_j = p_j + z s_(j+1);  w_(j-1) = s_j;  p(z) = s_0
     const size_t j = lo + (size_t)k;
     if (j >= n) continue;
     s = Fr::add(Fr::mul(s, z), load_fp<Fr>(p + j * 32));    // < 3r
     if (j) { if (q) store_fp<Fr>(q + (j - 1) * 32, Fr::reduce(s)); } else if (eval) store_fp<Fr>(eval, Fr::reduce(s));
   }
+}
+__global__ void __launch_bounds__(256) k_div_finish(const char* __restrict__ p, size_t n, FrK zk, const char* __restrict__ C, char* __restrict__ q, char* __restrict__ eval) {
+  __shared__ uint32_t l[8 * DIV_B];
+  div_finish_body(l, blockIdx.x, p, n, zk, C, q, eval);
+}
+// Up to DIV_MANY independent divisions in the same three launches (blockIdx.y picks the division): the two witness polynomials of a proof's openings are
+// latency-bound chains of ~100 us each (the middle kernel is ONE block) that used to run one after the other.
+static constexpr uint32_t DIV_MANY = 4;
+struct DivJob { const char* p; size_t n; FrK z; char* q; char* eval; char* E; char* C; uint32_t nb, per; };
+struct DivJobs { DivJob j[DIV_MANY]; };
+__global__ void __launch_bounds__(256) k_div_blocks_many(DivJobs J) {
+  __shared__ uint32_t l[8 * DIV_B];
+  const DivJob& d = J.j[blockIdx.y];
+  if (blockIdx.x >= d.nb) return;
+  div_blocks_body(l, blockIdx.x, d.p, d.n, d.z, d.E);
+}
+__global__ void __launch_bounds__(256) k_div_carries_many(DivJobs J) {
+  __shared__ uint32_t l[8 * DIV_B];
+  const DivJob& d = J.j[blockIdx.x];
+  div_carries_body(l, d.E, d.nb, d.per, d.z, d.C);
+}
+__global__ void __launch_bounds__(256) k_div_finish_many(DivJobs J) {
+  __shared__ uint32_t l[8 * DIV_B];
+  const DivJob& d = J.j[blockIdx.y];
+  if (blockIdx.x >= d.nb) return;
+  div_finish_body(l, blockIdx.x, d.p, d.n, d.z, d.C, d.q, d.eval);
 }
 
 int32_t fr_divide_by_linear(Ctx* c, void* d_q, void* d_eval, const void* d_p, size_t n, const void* z_mont32, hipStream_t s) {
@@ -313,6 +349,101 @@ int32_t fr_divide_by_linear(Ctx* c, void* d_q, void* d_eval, const void* d_p, si
   hipLaunchKernelGGL(k_div_finish, dim3((uint32_t)nb), dim3(256), 0, s, (const char*)d_p, n, zk, (const char*)C, (char*)d_q, (char*)d_eval);
   HIPCHK(hipGetLastError());
   return scratch_release(c, s);
+}
+
+int32_t fr_divide_by_linear_many(Ctx* c, void* const* d_q, void* const* d_eval, const void* const* d_p, const size_t* n, const void* const* z_mont32, size_t count, hipStream_t s) {
+  if (count == 0) return ALEO_MI355X_OK;
+  if (count > DIV_MANY) { g_last_error = "fr_divide_by_linear_many: at most 4 divisions per call"; return ALEO_MI355X_ERR_BAD_ARG; }
+  DivJobs J{}; size_t tot = 0, nb_max = 0;
+  for (size_t i = 0; i < count; ++i) {
+    if (n[i] == 0) { g_last_error = "fr_divide_by_linear_many: empty polynomial"; return ALEO_MI355X_ERR_BAD_ARG; }
+    const size_t nb = (n[i] + DIV_TILE - 1) / DIV_TILE;
+    if (nb >= (1ull << 31)) { g_last_error = "fr_divide_by_linear: polynomial too long"; return ALEO_MI355X_ERR_BAD_ARG; }
+    J.j[i].nb = (uint32_t)nb; J.j[i].per = (uint32_t)((nb + DIV_B - 1) / DIV_B); tot += 2 * nb; nb_max = nb > nb_max ? nb : nb_max;
+  }
+  int32_t rc; if ((rc = scratch_acquire(c, c->ntt_tmp, tot * 32, s))) return rc;
+  char* at = c->ntt_tmp.as<char>();
+  for (size_t i = 0; i < count; ++i) {
+    DivJob& d = J.j[i]; d.p = (const char*)d_p[i]; d.n = n[i]; std::memcpy(d.z.v, z_mont32[i], 32); d.q = (char*)d_q[i]; d.eval = d_eval ? (char*)d_eval[i] : nullptr;
+    d.E = at; d.C = at + (size_t)d.nb * 32; at += 2 * (size_t)d.nb * 32;
+  }
+  hipLaunchKernelGGL(k_div_blocks_many, dim3((uint32_t)nb_max, (uint32_t)count), dim3(256), 0, s, J);
+  hipLaunchKernelGGL(k_div_carries_many, dim3((uint32_t)count), dim3(256), 0, s, J);
+  hipLaunchKernelGGL(k_div_finish_many, dim3((uint32_t)nb_max, (uint32_t)count), dim3(256), 0, s, J);
+  HIPCHK(hipGetLastError());
+  return scratch_release(c, s);
+}
+
+// ---- small fused kernels of the prover's rounds (round 5: every launch of a real-circuit-sized proof is ~4.5 us of GPU time even when it moves a few KB) ----
+// dst[r][i] = k_r * src[i], r < rows <= 4 (the eta-scaled copies of u_H(alpha, .) the transpose product reads)
+struct FrK4 { FrK k[4]; };
+__global__ void __launch_bounds__(256) k_fr_scale_rows(char* __restrict__ dst, const char* __restrict__ src, size_t n, uint32_t rows, FrK4 K) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const Fr x = load_fp<Fr>(src + i * 32);
+    for (uint32_t r = 0; r < rows; ++r) store_fp<Fr>(dst + ((size_t)r * n + i) * 32, Fr::reduce(Fr::mul(fr_arg(K.k[r]), x)));
+  }
+}
+int32_t fr_scale_rows(Ctx* c, void* d_dst, const void* d_src, size_t n, size_t rows, const void* consts_mont, hipStream_t s) {
+  (void)c;
+  if (n == 0 || rows == 0) return ALEO_MI355X_OK;
+  if (rows > 4) { g_last_error = "fr_scale_rows: at most 4 rows"; return ALEO_MI355X_ERR_BAD_ARG; }
+  FrK4 K{}; std::memcpy(K.k, consts_mont, rows * 32);
+  const size_t want = (n + 255) / 256;
+  hipLaunchKernelGGL(k_fr_scale_rows, dim3((uint32_t)(want < 8192 ? want : 8192)), dim3(256), 0, s, (char*)d_dst, (const char*)d_src, n, (uint32_t)rows, K);
+  HIPCHK(hipGetLastError());
+  return ALEO_MI355X_OK;
+}
+// The quotient and remainder of q (3n coefficients, blocks p0 | p1 | p2; + mask when given) by X^n - 1:  hq = [p1 + p2 | p2],  rq = p0 + p1 + p2;
+// rq[0] — the sum of the first sumcheck's summand over H — also goes to `host_sum` (a device pointer of pinned host memory) when given.
+__global__ void __launch_bounds__(256) k_split_quotient(const char* __restrict__ q, const char* __restrict__ mask, size_t n, char* __restrict__ hq, char* __restrict__ rq, char* __restrict__ host_sum) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    Fr p0 = load_fp<Fr>(q + i * 32), p1 = load_fp<Fr>(q + (n + i) * 32), p2 = load_fp<Fr>(q + (2 * n + i) * 32);
+    if (mask) {
+      p0 = Fr::cond_sub<1>(Fr::add(p0, load_fp<Fr>(mask + i * 32))); p1 = Fr::cond_sub<1>(Fr::add(p1, load_fp<Fr>(mask + (n + i) * 32)));
+      p2 = Fr::cond_sub<1>(Fr::add(p2, load_fp<Fr>(mask + (2 * n + i) * 32)));
+    }
+    const Fr h0 = Fr::cond_sub<1>(Fr::add(p1, p2)), r0 = Fr::cond_sub<1>(Fr::add(p0, h0));
+    store_fp<Fr>(hq + (n + i) * 32, p2); store_fp<Fr>(hq + i * 32, h0); store_fp<Fr>(rq + i * 32, r0);
+    if (i == 0 && host_sum) store_fp<Fr>(host_sum, r0);
+  }
+}
+int32_t fr_split_quotient(Ctx* c, void* d_hq, void* d_rq, const void* d_q, const void* d_mask, size_t n, void* host_sum_devptr, hipStream_t s) {
+  (void)c;
+  if (n == 0) return ALEO_MI355X_OK;
+  const size_t want = (n + 255) / 256;
+  hipLaunchKernelGGL(k_split_quotient, dim3((uint32_t)(want < 8192 ? want : 8192)), dim3(256), 0, s, (const char*)d_q, (const char*)d_mask, n, (char*)d_hq, (char*)d_rq, (char*)host_sum_devptr);
+  HIPCHK(hipGetLastError());
+  return ALEO_MI355X_OK;
+}
+// dst = (a - b) * m element-wise (the witness polynomial's values: (z - x̂) / v_X off X)
+__global__ void __launch_bounds__(256) k_fr_sub_mul(char* __restrict__ dst, const char* __restrict__ a, const char* __restrict__ b, const char* __restrict__ m, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const Fr d = Fr::cond_sub<1>(Fr::sub<1>(load_fp<Fr>(a + i * 32), load_fp<Fr>(b + i * 32)));
+    store_fp<Fr>(dst + i * 32, Fr::cond_sub<1>(Fr::mul(d, load_fp<Fr>(m + i * 32))));
+  }
+}
+int32_t fr_sub_mul(Ctx* c, void* d_dst, const void* d_a, const void* d_b, const void* d_m, size_t n, hipStream_t s) {
+  (void)c;
+  if (n == 0) return ALEO_MI355X_OK;
+  const size_t want = (n + 255) / 256;
+  hipLaunchKernelGGL(k_fr_sub_mul, dim3((uint32_t)(want < 8192 ? want : 8192)), dim3(256), 0, s, (char*)d_dst, (const char*)d_a, (const char*)d_b, (const char*)d_m, n);
+  HIPCHK(hipGetLastError());
+  return ALEO_MI355X_OK;
+}
+// up to 8 single elements gathered into consecutive 32-byte slots of dst (device memory, or the device pointer of pinned host memory: a read-back without a copy launch each)
+struct PickArgs { const char* src[8]; };
+__global__ void k_fr_pick(char* __restrict__ dst, PickArgs a, uint32_t count) {
+  const uint32_t t = threadIdx.x;
+  if (t < count * 8) ((uint32_t*)dst)[t] = ((const uint32_t*)a.src[t >> 3])[t & 7];
+}
+int32_t fr_pick(Ctx* c, void* dst_devptr, const void* const* d_src, size_t count, hipStream_t s) {
+  (void)c;
+  if (count == 0) return ALEO_MI355X_OK;
+  if (count > 8) { g_last_error = "fr_pick: at most 8 elements"; return ALEO_MI355X_ERR_BAD_ARG; }
+  PickArgs a{}; for (size_t i = 0; i < count; ++i) a.src[i] = (const char*)d_src[i];
+  hipLaunchKernelGGL(k_fr_pick, dim3(1), dim3(64), 0, s, (char*)dst_devptr, a, (uint32_t)count);
+  HIPCHK(hipGetLastError());
+  return ALEO_MI355X_OK;
 }
 
 // ---- geometric sequences, gathers and batched evaluation: what lets the AHP rounds run without a single field inversion on the device ----

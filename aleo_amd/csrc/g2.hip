@@ -359,8 +359,10 @@ __global__ void __launch_bounds__(256, 2) k_g2_accum28(const char* __restrict__ 
   }
   // Pin the accumulator to registers here.  Without it hipcc (ROCm 7.2) drops the initial value of two limbs of acc.Y on the path that skips the loop
   // (a one-point slice): the store below then reads a register no instruction of the kernel writes — seen in the ISA and as 0x5a5a5a5a in the slice sums.
+#ifndef ALEO_G2_NO_PIN      // (probe build: tools/isa_undef_check.py shows the unwritten registers without it)
 #pragma unroll
   for (int i = 0; i < 14; ++i) asm volatile("" : "+v"(acc.X.v[i]), "+v"(acc.Y.v[i]), "+v"(acc.ZZ.v[i]), "+v"(acc.ZZZ.v[i]));
+#endif
   for (; j < j1; ++j) {
     F28 x, y; fetch(run[j], x, y);
     if (!g2p_madd_fast(acc, x, y, odd)) { ok = false; break; }

@@ -403,7 +403,9 @@ __global__ void __launch_bounds__(256) k_scan_tiles(const uint32_t* hist, uint32
   if (lane == 0 && mx) atomicMax(&meta[1], mx);
 }
 
-__global__ void __launch_bounds__(256) k_scan_top(const uint2* tile_tot, uint32_t ntiles, uint2* scan_blk, uint32_t* meta) {
+// host_meta (device pointer of the slot's mapped pinned buffer): meta[0..7] go there followed by the call's sequence number at word 8, so the host reads the
+// slice counts by polling — no copy on a side stream, no event on the launch stream (an event record between two kernels costs ~6 us of idle GPU on this runtime)
+__global__ void __launch_bounds__(256) k_scan_top(const uint2* tile_tot, uint32_t ntiles, uint2* scan_blk, uint32_t* meta, volatile uint32_t* host_meta, uint32_t seq) {
   // one block; ntiles <= a few thousand: serial chunks of 256 with a running offset
   __shared__ uint2 sh[256]; __shared__ uint2 carry;
   if (threadIdx.x == 0) carry = make_uint2(0, 0);
@@ -423,7 +425,15 @@ __global__ void __launch_bounds__(256) k_scan_top(const uint2* tile_tot, uint32_
     if (threadIdx.x == 255) { carry.x = cr.x + inc.x; carry.y = cr.y + inc.y; }
     __syncthreads();
   }
-  if (threadIdx.x == 0) { meta[0] = carry.y; meta[2] = carry.x; }
+  if (threadIdx.x == 0) {
+    meta[0] = carry.y; meta[2] = carry.x;
+    if (host_meta) {
+      host_meta[0] = carry.y; host_meta[2] = carry.x;
+      for (int i : {1, 3, 4, 5, 6, 7}) host_meta[i] = meta[i];      // written by k_scan_tiles (the launch before this one)
+      __threadfence_system();
+      host_meta[8] = seq;
+    }
+  }
 }
 
 // ---- slice ordering: lanes of one wave should run the same trip count --------------------------------
@@ -955,7 +965,7 @@ uint32_t msm_max_sets(const PinnedBases& pb, size_t n) {
 }
 
 int32_t msm_sort_phase(Ctx* c, SegArgs& segs, size_t pts, bool mont, const uint8_t* d_inf, uint32_t row_stride,
-                       const MsmPlan& P, bool pre, hipStream_t s, SortPhase* out) {
+                       const MsmPlan& P, bool pre, hipStream_t s, SortPhase* out, bool lean) {
   SortPhase& sp = *out; sp.P = P;
   // columns of the level-1 count matrix: the blocks of a set's segments side by side; every row is as wide as the widest set
   uint32_t width[MAX_SETS] = {}, nblk_x = 0;
@@ -975,9 +985,8 @@ int32_t msm_sort_phase(Ctx* c, SegArgs& segs, size_t pts, bool mont, const uint8
   const size_t slices_max = sp.slices_max = slice_bound(pairs_max, M);
   sp.slice_blocks = (uint32_t)((slices_max + 255) / 256);
   int32_t rc;
-  // hist | heavy list | meta | super list | level-2 cursors live in one zero-initialised allocation
+  // hist | heavy list | meta | super list | level-2 cursors | the level-1 count matrix live in one allocation, zeroed by ONE fill
   const size_t hist_words = 3 * (size_t)M + 2048 + SUPER_CAP;
-  if ((rc = c->hist.reserve(hist_words * 4))) return rc;
   if ((rc = c->scan_local.reserve((size_t)M * 8))) return rc;
   if ((rc = c->scan_blk.reserve(2 * (size_t)ntiles * 8 + 64))) return rc;
   if ((rc = c->sorted.reserve(pairs_max * 4))) return rc;
@@ -985,7 +994,8 @@ int32_t msm_sort_phase(Ctx* c, SegArgs& segs, size_t pts, bool mont, const uint8
   const size_t cnt_len = (size_t)ncb * nblk;
   if (ncb > MAX_COARSE_ALL || cnt_len >= (1ull << 32)) { g_last_error = "msm: partition table too large"; return ALEO_MI355X_ERR_BAD_ARG; }
   const uint32_t cnt_tiles = (uint32_t)((cnt_len + SCAN_TILE - 1) / SCAN_TILE);
-  if ((rc = c->part_cnt.reserve((2 * cnt_len + 2 * (size_t)cnt_tiles + 16 + MAX_COARSE_ALL) * 4))) return rc;     // cnt | off_local | tile_tot | off_blk | part_start
+  if ((rc = c->hist.reserve((hist_words + cnt_len) * 4))) return rc;
+  if ((rc = c->part_cnt.reserve((cnt_len + 2 * (size_t)cnt_tiles + 16 + MAX_COARSE_ALL) * 4))) return rc;     // off_local | tile_tot | off_blk | part_start
   if ((rc = c->part_items.reserve(pairs_max * 8))) return rc;
   if ((rc = c->task_g.reserve(2 * slices_max * 4))) return rc;     // task_g | order
   if ((rc = ensure_host_pinned(c, 64))) return rc;
@@ -997,13 +1007,12 @@ int32_t msm_sort_phase(Ctx* c, SegArgs& segs, size_t pts, bool mont, const uint8
   uint2* tile_tot = c->scan_blk.as<uint2>(); uint2* scan_blk = sp.scan_blk = tile_tot + ntiles;
   uint32_t* sorted = sp.sorted = c->sorted.as<uint32_t>(); uint32_t* task_g = sp.task_g = c->task_g.as<uint32_t>(); uint32_t* order = sp.order = task_g + slices_max;
 
-  HIPCHK(hipEventRecord(c->ev[0], s));
-  HIPCHK(hipMemsetAsync(hist, 0, hist_words * 4, s));
-  HIPCHK(hipMemsetAsync(c->part_cnt.p, 0, cnt_len * 4, s));          // columns no block of a set owns (and tiles past a segment's end) count zero
+  if (!lean) HIPCHK(hipEventRecord(c->ev[0], s));
+  HIPCHK(hipMemsetAsync(hist, 0, (hist_words + cnt_len) * 4, s));          // (count matrix: columns no block of a set owns, and tiles past a segment's end, count zero)
   SortArgs sa;
   sa.segs = segs; sa.nblk_x = nblk_x ? nblk_x : 1;
   sa.inf = d_inf; sa.row_stride = row_stride;
-  sa.cnt = c->part_cnt.as<uint32_t>(); sa.off_local = sa.cnt + cnt_len;
+  sa.cnt = hist + hist_words; sa.off_local = c->part_cnt.as<uint32_t>();
   uint32_t* cnt_tile_tot = sa.off_local + cnt_len; sa.off_blk = cnt_tile_tot + cnt_tiles;
   sa.items = c->part_items.as<uint2>();
   const uint32_t* total_pairs = sp.total_pairs = sa.off_blk + cnt_tiles;          // grand total of the level-1 scan
@@ -1017,15 +1026,16 @@ int32_t msm_sort_phase(Ctx* c, SegArgs& segs, size_t pts, bool mont, const uint8
   hipLaunchKernelGGL(k_bin_hist, dim3(nparts_max), dim3(256), 0, s, sa.items, sa.off_local, sa.off_blk, nblk, ncb, cnt_tiles, LB, part_start, hist);
   hipLaunchKernelGGL(k_bin_scatter, dim3(nparts_max), dim3(256), 0, s, sa.items, sa.off_local, sa.off_blk, nblk, ncb, cnt_tiles, LB, part_start, hist, bin_cursor, sorted);
   hipLaunchKernelGGL(k_scan_tiles, dim3(ntiles), dim3(256), 0, s, hist, M, total_pairs, scan_local, tile_tot, meta, heavy);
-  hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(256), 0, s, tile_tot, ntiles, scan_blk, meta);
+  // The slice count, the longest bucket and the list lengths size the slice-tree launches.  k_scan_top stores them (and this call's sequence number behind them)
+  // into the slot's pinned, device-mapped buffer; the slice kernels and the accumulation — launched with grids from slice_bound() — follow on `s` at once, and
+  // the host polls the sequence number long before the accumulation ends (msm_wait_meta): the GPU never waits for the round trip, and nothing but kernels
+  // sits on the stream (rounds 1-4 copied the words back on the side stream behind an event of `s`: a copy launch and ~6 us of idle GPU per chain).
+  uint32_t* host_meta = nullptr;
+  HIPCHK(hipHostGetDevicePointer((void**)&host_meta, c->h_pinned, 0));
+  sp.meta_seq = ++c->meta_seq;
+  hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(256), 0, s, tile_tot, ntiles, scan_blk, meta, (volatile uint32_t*)host_meta, sp.meta_seq);
   HIPCHK(hipGetLastError());
-  HIPCHK(hipEventRecord(c->ev[1], s));
-  // The slice count, the longest bucket and the list lengths size the slice-tree launches.  They come back on the slot's side
-  // stream while the slice kernels and the accumulation — launched with grids from slice_bound() — already run on `s`:
-  // the host reads them long before the accumulation ends, so the GPU never waits for the round trip.
-  HIPCHK(hipStreamWaitEvent(c->side, c->ev[1], 0));
-  HIPCHK(hipMemcpyAsync(c->h_pinned, meta, 32, hipMemcpyDeviceToHost, c->side));
-  HIPCHK(hipEventRecord(c->ev[7], c->side));
+  if (!lean) HIPCHK(hipEventRecord(c->ev[1], s));
   uint32_t* len_count = meta + 16; uint32_t* len_cursor = len_count + MAX_SLICE + 1; uint32_t* len_start = len_cursor + MAX_SLICE + 1;   // zeroed with hist/meta
   hipLaunchKernelGGL(k_slice_count, dim3(sp.slice_blocks), dim3(256), 0, s, hist, scan_local, scan_blk, M, total_pairs, meta, task_g, len_count);
   hipLaunchKernelGGL(k_len_starts, dim3(1), dim3(256), 0, s, len_count, len_start);
@@ -1035,8 +1045,19 @@ int32_t msm_sort_phase(Ctx* c, SegArgs& segs, size_t pts, bool mont, const uint8
 }
 
 int32_t msm_wait_meta(Ctx* c, const SortPhase& sp, hipStream_t s, SliceMeta* m) {
-  HIPCHK(hipEventSynchronize(c->ev[7]));
-  const uint32_t* h_meta = (const uint32_t*)c->h_pinned;
+  const volatile uint32_t* h_meta = (const volatile uint32_t*)c->h_pinned;
+  // poll the sequence number (it arrives ~0.15 ms after the sort was queued).  A stream that has drained or failed without delivering it is an error, not a hang.
+  for (uint64_t spins = 0; h_meta[8] != sp.meta_seq; ++spins) {
+    __builtin_ia32_pause();
+    if ((spins & 0xfff) == 0xfff) {
+      const hipError_t q = hipStreamQuery(s);
+      if (q == hipErrorNotReady) continue;
+      if (q == hipSuccess && h_meta[8] == sp.meta_seq) break;
+      if (q == hipSuccess) { (void)hipStreamSynchronize(s); if (h_meta[8] == sp.meta_seq) break; }
+      g_last_error = std::string("msm: the slice metadata never arrived (") + hipGetErrorString(q) + ")"; return ALEO_MI355X_ERR_HIP;
+    }
+  }
+  std::atomic_thread_fence(std::memory_order_acquire);
   m->NT = h_meta[0]; m->max_m = h_meta[1]; m->n_heavy = h_meta[3];
   m->max_common = h_meta[6] < 16u ? h_meta[6] : 16u;
   m->n_super = h_meta[5] < SUPER_CAP ? h_meta[5] : SUPER_CAP;
@@ -1057,7 +1078,7 @@ namespace {
 struct Front {
   const PinnedBases::PreTable* T = nullptr; MsmPlan P{}; SortPhase sp; SliceMeta sm;
   uint32_t K = 0, cpw = 0, nchunks = 0, lgN = 0, tseg = 0, fseg = 0, nseg = 0, setw = 0; size_t vpoints = 0;
-  bool pre = false, masked = false, aside = false, empty = false; const char* bases = nullptr;
+  bool pre = false, masked = false, aside = false, empty = false, lean = false; const char* bases = nullptr;      // lean: MsmJob::lean of a single-chain request (no phase-timing events)
 };
 }
 
@@ -1116,7 +1137,7 @@ static int32_t msm_front_sort(Ctx* c, const PinnedBases& pb, const MsmJob& job, 
   f.vpoints = masked ? (size_t)K * setw + nchunks + (nseg + 1) + (size_t)nseg * (tseg / 2 + tseg / 4 + 2) + 3 * (size_t)nchunks + 64 : (size_t)nchunks + P.W;      // + the two buffers of the sum-tree passes (3 cpw / 2 points per set each)
   if ((rc = ensure_host_pinned(c, 64 + (size_t)(masked ? nseg : P.W) * 224 + ASIDE_MAX * 228))) return rc;      // before the sort phase: its read-back lands in this buffer
   SortPhase& sp = f.sp;
-  if ((rc = msm_sort_phase(c, segs, pts, job.mont, d_inf, (uint32_t)(pre ? T->cover : pb.n), P, pre, s, &sp))) return rc;
+  if ((rc = msm_sort_phase(c, segs, pts, job.mont, d_inf, (uint32_t)(pre ? T->cover : pb.n), P, pre, s, &sp, f.lean))) return rc;
   const uint32_t M = sp.M;
   if ((rc = c->partial.reserve(sp.slices_max * (pre ? 224 : 192)))) return rc;
   if ((rc = c->vbuf.reserve(f.vpoints * 224))) return rc;
@@ -1128,11 +1149,11 @@ static int32_t msm_front_accum(Ctx* c, hipStream_t s, Front& f, const FrontChain
   const SortPhase& sp = f.sp; const uint32_t M = sp.M; const char* bases = f.bases;
   char* partial = c->partial.as<char>();
   if (after) HIPCHK(hipStreamWaitEvent(s, after, 0));
-  HIPCHK(hipEventRecord(c->ev[6], s));          // ev[6]..ev[5] bracket k_accum28 alone (bench.py's roofline kernel)
+  if (!f.lean) HIPCHK(hipEventRecord(c->ev[6], s));          // ev[6]..ev[5] bracket k_accum28 alone (bench.py's roofline kernel)
   if (f.pre && seed && seed->n) hipLaunchKernelGGL((k_accum28<true, true>), dim3(sp.slice_blocks), dim3(256), 0, s, bases, sp.sorted, sp.hist, sp.scan_local, sp.scan_blk, sp.total_pairs, M, sp.meta, sp.order, sp.task_g, partial, *seed);
   else if (f.pre) hipLaunchKernelGGL(k_accum28<true>, dim3(sp.slice_blocks), dim3(256), 0, s, bases, sp.sorted, sp.hist, sp.scan_local, sp.scan_blk, sp.total_pairs, M, sp.meta, sp.order, sp.task_g, partial, FrontChain{});
   else hipLaunchKernelGGL(k_accum28<false>, dim3(sp.slice_blocks), dim3(256), 0, s, bases, sp.sorted, sp.hist, sp.scan_local, sp.scan_blk, sp.total_pairs, M, sp.meta, sp.order, sp.task_g, partial, FrontChain{});
-  HIPCHK(hipEventRecord(c->ev[5], s));
+  if (!f.lean) HIPCHK(hipEventRecord(c->ev[5], s));
   HIPCHK(hipGetLastError());
   return ALEO_MI355X_OK;
 }
@@ -1149,6 +1170,7 @@ static int32_t msm_front_finish(Ctx* c, hipStream_t s, Front& f, bool allow_asid
   const bool aside = f.aside = allow_aside && f.masked && aside_on() && sm.n_super >= 1 && sm.n_super <= ASIDE_MAX && !sm.super_overflow && sm.max_m >= 64;
   uint32_t* h_aside = (uint32_t*)((char*)c->h_pinned + 64 + (size_t)f.nseg * 224);
   if (aside) {
+    if (f.lean) HIPCHK(hipEventRecord(c->ev[5], s));          // (nothing has been queued behind the accumulation yet: the same position)
     HIPCHK(hipStreamWaitEvent(c->side, c->ev[5], 0));
     for (uint32_t pass = 0, L = sm.max_m - 1; L > 1; ++pass, L = (L + 1) >> 1) {
       const uint64_t ops = (uint64_t)sm.n_super * (L >> 1);
@@ -1175,7 +1197,7 @@ static int32_t msm_front_finish(Ctx* c, hipStream_t s, Front& f, bool allow_asid
       else hipLaunchKernelGGL(k_tree_pass<false>, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, s, partial, heavy, len_a, pairs_a, sp.super_list, len_b, pairs_b, scan_local, scan_blk, M, meta, pass, 0u);
     }
   }
-  HIPCHK(hipEventRecord(c->ev[2], s));
+  if (!f.lean) HIPCHK(hipEventRecord(c->ev[2], s));
   return ALEO_MI355X_OK;
 }
 
@@ -1348,6 +1370,7 @@ static int32_t msm_back(Ctx* c, uint64_t* out_jac18, Front& f, hipStream_t s, bo
   const double host_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_host0).count();
   float ms;
   MsmTiming tm;
+  if (f.lean) { tm.host = host_ms; tm.total = host_ms; c->last_msm = tm; g_last_msm = tm; return ALEO_MI355X_OK; }      // no phase events were recorded
   HIPCHK(hipEventElapsedTime(&ms, c->ev[0], c->ev[1])); tm.sort = ms;
   HIPCHK(hipEventElapsedTime(&ms, c->ev[1], c->ev[2])); tm.accum = ms;
   HIPCHK(hipEventElapsedTime(&ms, c->ev[2], c->ev[3])); tm.reduce = ms;
@@ -1366,6 +1389,20 @@ static uint32_t chunks3_min_lg();
 // move out of the way; holding a later chunk's sort until the previous accumulation starts (as run_chains does for whole chains) makes it worse
 // (2^20 3.07, 2^21 5.91, 2^22 9.83 ms against 2.83 / 5.04 / 9.32 whole: tools/resident_ab.py).  ALEO_MI355X_CHUNK_DEV_MIN_LG: lg of the smallest such
 // request (default 0 = never; the GPU suite passes with 20).
+// the cut of a device-scalar request: segment of `len` scalars up to `pc` percent, on a multiple of 256 scalars (msm_run_chunked)
+static inline size_t chunk_cut(size_t len, uint32_t pc) { const size_t v = pc >= 100u ? len : ((size_t)((double)len * pc / 100.0)) & ~(size_t)255; return v < len ? v : len; }
+static const uint32_t CHUNK_SHARE_DEV[4][3] = {{0, 0, 0}, {0, 0, 0}, {28, 72, 0}, {12, 28, 60}};
+// every chunk of a Q-chunk device-scalar request must hold at least one scalar (a request of many short segments can leave the first chunk empty: then the
+// whole-request chain runs instead)
+static bool chunks_all_nonempty(const MsmJob& job, uint32_t Q) {
+  uint32_t cum = 0;
+  for (uint32_t k = 0; k < Q; ++k) {
+    const uint32_t lo = cum, hi = k + 1 == Q ? 100u : cum + CHUNK_SHARE_DEV[Q][k]; cum = hi; bool any = false;
+    for (uint32_t q = 0; q < job.nseg && !any; ++q) any = chunk_cut(job.segs[q].len, hi) > chunk_cut(job.segs[q].len, lo);
+    if (!any) return false;
+  }
+  return true;
+}
 static uint32_t chunk_dev_min_lg() { static const uint32_t v = [] { const char* e = std::getenv("ALEO_MI355X_CHUNK_DEV_MIN_LG"); const int k = e ? std::atoi(e) : 0; return (uint32_t)(k >= 0 && k <= 40 ? k : 0); }(); return v; }
 int32_t msm_run(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, const MsmJob& job, hipStream_t s) {
   if (job.k == 0) return ALEO_MI355X_OK;
@@ -1376,10 +1413,12 @@ int32_t msm_run(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, const MsmJob
     bool tiered = false; for (const auto& t : pb.tab) if (t.d && reach >= t.min_n && reach <= t.cover) { tiered = job.k <= 1 || job.k <= msm_max_sets(pb, reach); break; }
     if (in_range && tiered && pts >= ((size_t)1 << chunk_dev_min_lg())) {
       HelperSet hs; { const int32_t rc = acquire_helpers(c->dev, pts >= ((size_t)1 << chunks3_min_lg()) ? 2 : 1, hs); if (rc) return rc; }
-      if (!hs.ctx.empty()) return msm_run_chunked(c, hs, out_jac18, pb, reach, job.mont, s, nullptr, &job);
+      if (!hs.ctx.empty() && chunks_all_nonempty(job, 1 + (uint32_t)hs.ctx.size())) return msm_run_chunked(c, hs, out_jac18, pb, reach, job.mont, s, nullptr, &job);
     }
   }
   Front f; int32_t rc;
+  static const bool lean_off = [] { const char* e = std::getenv("ALEO_MI355X_LEAN"); return e && e[0] == '0'; }();      // A/B switch: 0 = phase-timing events in the prover's chains too (round 4)
+  f.lean = job.lean && !lean_off;
   if ((rc = msm_front_sort(c, pb, job, s, f))) return rc;
   if (f.empty) { for (uint32_t q = 0; q < job.k; ++q) host::hstore_jacobian_normalized(out_jac18 + 18 * q, host::HXYZZ::infinity()); return ALEO_MI355X_OK; }
   if ((rc = msm_front_accum(c, s, f, nullptr, nullptr))) return rc;
@@ -1409,7 +1448,7 @@ int32_t msm_run(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, const MsmJob
 // smaller (28 / 72 %, 12 / 28 / 60 %); the helper streams first wait for an event on `s`, where the caller's scalars may still be in flight.
 static int32_t msm_run_chunked(Ctx* c, HelperSet& hs, uint64_t* out_jac18, const PinnedBases& pb, size_t n, bool mont, hipStream_t s, const void* host_src, const MsmJob* dev_job) {
   const uint32_t Q = 1 + (uint32_t)hs.ctx.size();           // 2 or 3
-  static const uint32_t share_host[4][3] = {{0, 0, 0}, {0, 0, 0}, {37, 63, 0}, {18, 30, 52}}, share_dev[4][3] = {{0, 0, 0}, {0, 0, 0}, {28, 72, 0}, {12, 28, 60}};
+  static const uint32_t share_host[4][3] = {{0, 0, 0}, {0, 0, 0}, {37, 63, 0}, {18, 30, 52}}; const uint32_t (*share_dev)[3] = CHUNK_SHARE_DEV;
   static const uint32_t share0_env = [] { const char* e = std::getenv("ALEO_MI355X_CHUNK_SHARE0"); const int k = e ? std::atoi(e) : 0; return (uint32_t)(k >= 5 && k <= 95 ? k : 0); }();      // experiment knob: first chunk's percentage of a two-chunk host-scalar request
   uint32_t share_env[4][3] = {{0, 0, 0}, {0, 0, 0}, {share0_env, 100 - share0_env, 0}, {18, 30, 52}};
   const uint32_t (*share)[3] = dev_job ? share_dev : (share0_env ? share_env : share_host);
@@ -1430,9 +1469,8 @@ static int32_t msm_run_chunked(Ctx* c, HelperSet& hs, uint64_t* out_jac18, const
   for (uint32_t k = 0; k < Q; ++k) {
     MsmJob j; j.mont = mont; j.tier_n = n; j.k = K;
     if (dev_job) {                                           // every segment cut at the same fractions (boundaries on multiples of 256 scalars)
-      auto cut = [&](size_t len, uint32_t pc) { const size_t v = pc >= 100u ? len : ((size_t)((double)len * pc / 100.0)) & ~(size_t)255; return v < len ? v : len; };
       for (uint32_t q = 0; q < dev_job->nseg; ++q) {
-        const MsmSeg& g = dev_job->segs[q]; const size_t a0 = cut(g.len, cum[k]), a1 = cut(g.len, cum[k + 1]);
+        const MsmSeg& g = dev_job->segs[q]; const size_t a0 = chunk_cut(g.len, cum[k]), a1 = chunk_cut(g.len, cum[k + 1]);
         if (a1 > a0) { MsmSeg h = g; h.d_ptr = (const char*)g.d_ptr + a0 * 32; h.len = a1 - a0; h.off = g.off + a0; dsegs[k].push_back(h); }
       }
       j.segs = dsegs[k].data(); j.nseg = (uint32_t)dsegs[k].size();
@@ -1547,10 +1585,11 @@ static int32_t run_chains_pipelined(Ctx* c, const std::vector<Ctx*>& helpers, ui
   for (; collected < n; ++collected) if ((rc = collect(collected))) return drain(rc);
   return drain(ALEO_MI355X_OK);
 }
-static int32_t run_chains(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, std::vector<Chain>& chains, bool mont, hipStream_t s) {
+static int32_t run_chains(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, std::vector<Chain>& chains, bool mont, hipStream_t s, bool lean = false) {
+  bool lean_now = false;                                    // chains run one after another on the caller's context keep MsmJob::lean; overlapped / pipelined chains order themselves by the phase events
   auto run_one = [&](Ctx* cc, Chain& ch, hipStream_t st) -> int32_t {
     uint64_t res[MAX_SETS * 18];
-    MsmJob g; g.segs = ch.segs.data(); g.nseg = (uint32_t)ch.segs.size(); g.k = (uint32_t)ch.results.size(); g.mont = mont; g.sparse = ch.sparse; g.fire_tail = ch.fire_tail;
+    MsmJob g; g.segs = ch.segs.data(); g.nseg = (uint32_t)ch.segs.size(); g.k = (uint32_t)ch.results.size(); g.mont = mont; g.sparse = ch.sparse; g.fire_tail = ch.fire_tail; g.lean = lean_now;
     const int32_t rc = msm_run(cc, res, pb, g, st);
     if (rc) return rc;
     for (size_t i = 0; i < ch.results.size(); ++i) std::memcpy(out_jac18 + 18 * (size_t)ch.results[i], res + 18 * i, 144);
@@ -1559,7 +1598,7 @@ static int32_t run_chains(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, st
   size_t total = 0; for (auto& ch : chains) total += ch.points;
   HelperSet hs;
   if (chains.size() >= 2 && total >= ((size_t)1 << 20) && chains_overlap_on() && c->dev) { const int32_t rc = acquire_helpers(c->dev, chain_pipeline_on() && chains.size() >= 3 ? 2 : 1, hs); if (rc) return rc; }
-  if (hs.ctx.empty()) { for (auto& ch : chains) { const int32_t rc = run_one(c, ch, s); if (rc) return rc; } return ALEO_MI355X_OK; }
+  if (hs.ctx.empty()) { lean_now = lean; for (auto& ch : chains) { const int32_t rc = run_one(c, ch, s); if (rc) return rc; } return ALEO_MI355X_OK; }
   Ctx* h = hs.ctx[0];
   if (chain_pipeline_on()) {
     bool all_tiered = true;                                   // every chain on a table tier (the grouping of msm_batch makes them so, except the tier-less singles)
@@ -1636,7 +1675,7 @@ int32_t msm_batch(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, const MsmJ
         for (uint32_t i = 0; i < take; ++i) ch.results.push_back(q0 + i);
         q0 += take;
       }
-      return run_chains(c, out_jac18, pb, chains, job.mont, s);
+      return run_chains(c, out_jac18, pb, chains, job.mont, s, job.lean);
     }
   }
   // Latency-bound requests (one prover round: a few results of <= 2^17 points each): ONE launch chain on the tier that covers the
@@ -1651,7 +1690,7 @@ int32_t msm_batch(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, const MsmJ
       if (split) {
         std::vector<MsmSeg> segs; segs.reserve(sg);
         for (uint32_t q = 0; q < job.nseg; ++q) if (job.segs[q].len) segs.push_back(job.segs[q]);
-        MsmJob g; g.segs = segs.data(); g.nseg = (uint32_t)segs.size(); g.k = K; g.mont = job.mont; g.fire_tail = true;
+        MsmJob g; g.segs = segs.data(); g.nseg = (uint32_t)segs.size(); g.k = K; g.mont = job.mont; g.fire_tail = true; g.lean = job.lean;
         return msm_run(c, out_jac18, pb, g, s);
       }
     }
@@ -1679,7 +1718,7 @@ int32_t msm_batch(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, const MsmJ
       pos += take;
     }
   }
-  return run_chains(c, out_jac18, pb, chains, job.mont, s);
+  return run_chains(c, out_jac18, pb, chains, job.mont, s, job.lean);
 }
 
 // ---- synthetic base sets generated in HBM: P_i = (first + i) * G --------------------------------------

@@ -61,13 +61,15 @@ struct SortPhase {
   MsmPlan P; uint32_t M = 0, digitsW = 0, slice_blocks = 0; size_t slices_max = 0, pairs_max = 0;
   uint32_t *hist = nullptr, *heavy = nullptr, *meta = nullptr; uint2 *scan_local = nullptr, *scan_blk = nullptr;
   uint32_t *sorted = nullptr, *task_g = nullptr, *order = nullptr; const uint32_t* total_pairs = nullptr; const uint32_t* super_list = nullptr;
+  uint32_t meta_seq = 0;      // the sequence number k_scan_top stores behind the slice metadata in the slot's pinned buffer (msm_wait_meta polls for it)
 };
 struct SliceMeta { uint32_t NT = 0, max_m = 0, n_heavy = 0, n_super = 0, max_common = 0; bool super_overflow = false; };
 // P: the plan (P.W windows / sets of P.B buckets).  pre: table path (digits address row w * row_stride + i of a table, all windows share
-// a set's buckets).  Records ev[0] before and ev[1] after the sort; ev[7] on the side stream carries the slice metadata back.
+// a set's buckets).  Records ev[0] before and ev[1] after the sort unless `lean` (phase timing off: every event record between two kernels is ~6 us of
+// idle GPU); the slice metadata comes back through the slot's pinned, device-mapped buffer (k_scan_top stores it, msm_wait_meta polls).
 // segs: ptr / n / off / set filled in by the caller; col0, ncol are computed here.  pts = sum of the segment lengths.
 int32_t msm_sort_phase(Ctx* c, SegArgs& segs, size_t pts, bool mont, const uint8_t* d_inf, uint32_t row_stride,
-                       const MsmPlan& P, bool pre, hipStream_t s, SortPhase* out);
+                       const MsmPlan& P, bool pre, hipStream_t s, SortPhase* out, bool lean = false);
 int32_t msm_wait_meta(Ctx* c, const SortPhase& sp, hipStream_t s, SliceMeta* m);
 
 }  // namespace aleo_mi355x

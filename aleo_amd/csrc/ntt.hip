@@ -45,6 +45,10 @@ struct NttTables {
 };
 
 struct FrArg { uint32_t v[8]; };
+// Out-of-place, zero-padded input of a transform's FIRST pass (ntt_run_from): transform b of the batch reads element i from p + (b * stride + i) * 32 when
+// i < len and takes 0 otherwise; p == nullptr = the ordinary in-place call.  (A prover round pads |H| coefficients to 4|H| and |K| to 2|K| before it
+// evaluates: a fill and one copy per polynomial in rounds 1-4 — launches of ~4.5 us each at the sizes of real circuits.)
+struct NttSrc { const char* p = nullptr; uint32_t len = 0, stride = 0; };
 
 __device__ __forceinline__ uint32_t bitrev(uint32_t x, uint32_t bits) { return bits ? (__brev(x) >> (32 - bits)) : 0u; }
 
@@ -140,16 +144,17 @@ __global__ void __launch_bounds__(NT) k_ntt_strided(const char* src, char* dst, 
                                                      uint32_t tw_scale, uint32_t lg_n, uint32_t lo_bits, const char* __restrict__ inner,
                                                      const char* __restrict__ tw_hi, const char* __restrict__ tw_lo,
                                                      const char* __restrict__ cs_hi, const char* __restrict__ cs_lo, int pre_coset,
-                                                     const char* __restrict__ direct) {
+                                                     const char* __restrict__ direct, NttSrc ext) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-  src += (size_t)blockIdx.y << (lg_n + 5); dst += (size_t)blockIdx.y << (lg_n + 5);      // blockIdx.y: independent transform of a batch
+  src = ext.p ? ext.p + (size_t)blockIdx.y * ext.stride * 32 : src + ((size_t)blockIdx.y << (lg_n + 5)); dst += (size_t)blockIdx.y << (lg_n + 5);      // blockIdx.y: independent transform of a batch
   const uint32_t L = 1u << lgL, T = 1u << lgT, tiles_per_a = 1u << (lgBn - lgT);
   const uint32_t a = blockIdx.x / tiles_per_a, b0 = (blockIdx.x % tiles_per_a) << lgT;
   const uint32_t nq = (T * L) << 1;
   for (uint32_t q = threadIdx.x; q < nq; q += NT) {
     uint32_t elem = q >> 1, hf = q & 1, t = elem & (T - 1u), l = elem >> lgT;
     size_t gi = ((((size_t)a << lgL) + l) << lgBn) + b0 + t;
-    uint4 v = *(const uint4*)(src + gi * 32 + hf * 16);
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    if (!ext.p || gi < ext.len) v = *(const uint4*)(src + gi * 32 + hf * 16);
     uint32_t e = t * L + l, p = hf * 4;
     const uint32_t ex = sw(e);
     lds[(p + 0) * TE + ex] = v.x; lds[(p + 1) * TE + ex] = v.y; lds[(p + 2) * TE + ex] = v.z; lds[(p + 3) * TE + ex] = v.w;
@@ -186,9 +191,9 @@ __global__ void __launch_bounds__(NT) k_ntt_strided(const char* src, char* dst, 
 template <uint32_t TE, uint32_t NT, int GM = 3>
 __global__ void __launch_bounds__(NT) k_ntt_final(const char* src, char* dst, uint32_t lgL, uint32_t lgN1, uint32_t lgN2, uint32_t lgT,
                                                    uint32_t lo_bits, const char* __restrict__ inner, const char* __restrict__ cs_hi, const char* __restrict__ cs_lo,
-                                                   int pre_coset, int post_coset, int do_scale, FrArg scale) {
+                                                   int pre_coset, int post_coset, int do_scale, FrArg scale, NttSrc ext) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-  src += (size_t)blockIdx.y << (lgL + lgN1 + lgN2 + 5); dst += (size_t)blockIdx.y << (lgL + lgN1 + lgN2 + 5);
+  src = ext.p ? ext.p + (size_t)blockIdx.y * ext.stride * 32 : src + ((size_t)blockIdx.y << (lgL + lgN1 + lgN2 + 5)); dst += (size_t)blockIdx.y << (lgL + lgN1 + lgN2 + 5);
   const uint32_t L = 1u << lgL, T = 1u << lgT;
   const uint32_t tiles_k1 = 1u << (lgN1 - lgT);
   const uint32_t k2 = blockIdx.x / tiles_k1, k10 = (blockIdx.x % tiles_k1) << lgT;
@@ -196,7 +201,8 @@ __global__ void __launch_bounds__(NT) k_ntt_final(const char* src, char* dst, ui
   for (uint32_t q = threadIdx.x; q < nq; q += NT) {
     uint32_t elem = q >> 1, hf = q & 1, l = elem & (L - 1u), t = elem >> lgL;
     size_t row = ((size_t)(k10 + t) << lgN2) + k2;
-    uint4 v = *(const uint4*)(src + ((row << lgL) + l) * 32 + hf * 16);
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    if (!ext.p || (row << lgL) + l < ext.len) v = *(const uint4*)(src + ((row << lgL) + l) * 32 + hf * 16);
     uint32_t e = t * L + l, p = hf * 4;
     const uint32_t ex = sw(e);
     lds[(p + 0) * TE + ex] = v.x; lds[(p + 1) * TE + ex] = v.y; lds[(p + 2) * TE + ex] = v.z; lds[(p + 3) * TE + ex] = v.w;
@@ -317,9 +323,9 @@ __global__ void __launch_bounds__(NT) k_ntt29_strided(const char* src, char* dst
                                                        uint32_t tw_scale, uint32_t lg_n, uint32_t lo_bits, const char* __restrict__ inner,
                                                        const char* __restrict__ tw_hi, const char* __restrict__ tw_lo,
                                                        const char* __restrict__ cs_hi, const char* __restrict__ cs_lo, int pre_coset,
-                                                       const char* __restrict__ direct) {
+                                                       const char* __restrict__ direct, NttSrc ext) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-  src += (size_t)blockIdx.y << (lg_n + 5); dst += (size_t)blockIdx.y << (lg_n + 5);
+  src = ext.p ? ext.p + (size_t)blockIdx.y * ext.stride * 32 : src + ((size_t)blockIdx.y << (lg_n + 5)); dst += (size_t)blockIdx.y << (lg_n + 5);
   const uint32_t L = 1u << lgL, T = 1u << lgT, tiles_per_a = 1u << (lgBn - lgT);
   const uint32_t a = blockIdx.x / tiles_per_a, b0 = (blockIdx.x % tiles_per_a) << lgT;
   for (uint32_t elem = threadIdx.x; elem < T * L; elem += NT) {
@@ -328,7 +334,9 @@ __global__ void __launch_bounds__(NT) k_ntt29_strided(const char* src, char* dst
 #if defined(ALEO_NTT_PROBE) && ALEO_NTT_PROBE == 3
     F29 x; for (int i = 0; i < 9; ++i) x.v[i] = (uint32_t)(gi * 2654435761u + i) & 0x1fffffffu;      // timing probe: no HBM reads
 #else
-    F29 x = f29_load_packed(src + gi * 32);
+    F29 x;
+    if (!ext.p || gi < ext.len) x = f29_load_packed(src + gi * 32);
+    else { for (int i = 0; i < 9; ++i) x.v[i] = 0u; }
 #endif
     if (pre_coset) x = f29_mul(x, two_level29(cs_hi, cs_lo, (l << lgBn) + b0 + t, lo_bits));      // coset_fft: x[j] *= g^j (only the first pass: A == 1, j = l*Bn + b)
     lds_store29<TE>(lds, t * L + l, x);
@@ -356,9 +364,9 @@ __global__ void __launch_bounds__(NT) k_ntt29_strided(const char* src, char* dst
 template <uint32_t TE, uint32_t NT, int GM = 3>
 __global__ void __launch_bounds__(NT) k_ntt29_final(const char* src, char* dst, uint32_t lgL, uint32_t lgN1, uint32_t lgN2, uint32_t lgT,
                                                      uint32_t lo_bits, const char* __restrict__ inner, const char* __restrict__ cs_hi, const char* __restrict__ cs_lo,
-                                                     int pre_coset, int post_coset, int do_scale, F29Arg scale) {
+                                                     int pre_coset, int post_coset, int do_scale, F29Arg scale, NttSrc ext) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-  src += (size_t)blockIdx.y << (lgL + lgN1 + lgN2 + 5); dst += (size_t)blockIdx.y << (lgL + lgN1 + lgN2 + 5);
+  src = ext.p ? ext.p + (size_t)blockIdx.y * ext.stride * 32 : src + ((size_t)blockIdx.y << (lgL + lgN1 + lgN2 + 5)); dst += (size_t)blockIdx.y << (lgL + lgN1 + lgN2 + 5);
   const uint32_t L = 1u << lgL, T = 1u << lgT;
   const uint32_t tiles_k1 = 1u << (lgN1 - lgT);
   const uint32_t k2 = blockIdx.x / tiles_k1, k10 = (blockIdx.x % tiles_k1) << lgT;
@@ -368,7 +376,9 @@ __global__ void __launch_bounds__(NT) k_ntt29_final(const char* src, char* dst, 
 #if defined(ALEO_NTT_PROBE) && ALEO_NTT_PROBE == 3
     F29 x; for (int i = 0; i < 9; ++i) x.v[i] = (uint32_t)((row + l) * 2654435761u + i) & 0x1fffffffu;
 #else
-    F29 x = f29_load_packed(src + ((row << lgL) + l) * 32);
+    F29 x;
+    if (!ext.p || (row << lgL) + l < ext.len) x = f29_load_packed(src + ((row << lgL) + l) * 32);
+    else { for (int i = 0; i < 9; ++i) x.v[i] = 0u; }
 #endif
     if (pre_coset) x = f29_mul(x, two_level29(cs_hi, cs_lo, l, lo_bits));      // single-pass coset_fft: j = l
     lds_store29<TE>(lds, t * L + l, x);
@@ -476,7 +486,7 @@ static int32_t build_tables(NttTables* t, uint32_t lg_n, int direction) {
 }
 
 template <uint32_t TE, uint32_t NT, int GM = 3>
-static int32_t run_passes(Ctx* c, char* buf, char* tmp, uint32_t lg_n, uint32_t batch, const NttTables* t, int pre_coset, int post_coset, int do_scale, FrArg sc, hipStream_t s) {
+static int32_t run_passes(Ctx* c, char* buf, char* tmp, uint32_t lg_n, uint32_t batch, const NttTables* t, int pre_coset, int post_coset, int do_scale, FrArg sc, hipStream_t s, NttSrc ext = NttSrc{}) {
   constexpr uint32_t lgTE = TE == 4096 ? 12 : (TE == 2048 ? 11 : 9);
   static_assert(TE == 4096 || TE == 2048 || TE == 512, "tile sizes with a kernel instance");
   constexpr size_t lds_bytes = (size_t)TE * 32;
@@ -496,7 +506,7 @@ static int32_t run_passes(Ctx* c, char* buf, char* tmp, uint32_t lg_n, uint32_t 
   else { s1 = (lg_n + 2) / 3; s2 = (lg_n - s1 + 1) / 2; s3 = lg_n - s1 - s2; }
   auto lgT_for = [](uint32_t lgL, uint32_t lg_limit) { uint32_t lgT = lgTE - lgL; return lgT < lg_limit ? lgT : lg_limit; };
   if (npass == 1) {
-    hipLaunchKernelGGL((k_ntt_final<TE, NT, GM>), dim3(1, batch), dim3(NT), lds_bytes, s, buf, buf, s3, 0u, 0u, 0u, t->lo_bits, inner, csh, csl, pre_coset, post_coset, do_scale, sc);
+    hipLaunchKernelGGL((k_ntt_final<TE, NT, GM>), dim3(1, batch), dim3(NT), lds_bytes, s, buf, buf, s3, 0u, 0u, 0u, t->lo_bits, inner, csh, csl, pre_coset, post_coset, do_scale, sc, ext);
   } else if (npass == 2) {
     uint32_t lgBn = s3, lgT = lgT_for(s1, lgBn);
     const char* direct = nullptr;
@@ -511,16 +521,16 @@ static int32_t run_passes(Ctx* c, char* buf, char* tmp, uint32_t lg_n, uint32_t 
       }
       if (tm->direct_lgBn == lgBn) direct = (const char*)tm->d_direct;      // (always: the split of a two-pass size is (lg_n + 1) / 2 whatever the tile)
     }
-    hipLaunchKernelGGL((k_ntt_strided<TE, NT, GM>), dim3(1u << (lgBn - lgT), batch), dim3(NT), lds_bytes, s, buf, tmp, s1, lgBn, lgT, 1u, lg_n, t->lo_bits, inner, twh, twl, csh, csl, pre_coset, direct);
+    hipLaunchKernelGGL((k_ntt_strided<TE, NT, GM>), dim3(1u << (lgBn - lgT), batch), dim3(NT), lds_bytes, s, buf, tmp, s1, lgBn, lgT, 1u, lg_n, t->lo_bits, inner, twh, twl, csh, csl, pre_coset, direct, ext);
     uint32_t lgTf = lgT_for(s3, s1);
-    hipLaunchKernelGGL((k_ntt_final<TE, NT, GM>), dim3(1u << (s1 - lgTf), batch), dim3(NT), lds_bytes, s, tmp, buf, s3, s1, 0u, lgTf, t->lo_bits, inner, csh, csl, 0, post_coset, do_scale, sc);
+    hipLaunchKernelGGL((k_ntt_final<TE, NT, GM>), dim3(1u << (s1 - lgTf), batch), dim3(NT), lds_bytes, s, tmp, buf, s3, s1, 0u, lgTf, t->lo_bits, inner, csh, csl, 0, post_coset, do_scale, sc, NttSrc{});
   } else {
     uint32_t lgBn1 = s2 + s3, lgT1 = lgT_for(s1, lgBn1);
-    hipLaunchKernelGGL((k_ntt_strided<TE, NT, GM>), dim3(1u << (lgBn1 - lgT1), batch), dim3(NT), lds_bytes, s, buf, buf, s1, lgBn1, lgT1, 1u, lg_n, t->lo_bits, inner, twh, twl, csh, csl, pre_coset, (const char*)nullptr);
+    hipLaunchKernelGGL((k_ntt_strided<TE, NT, GM>), dim3(1u << (lgBn1 - lgT1), batch), dim3(NT), lds_bytes, s, buf, buf, s1, lgBn1, lgT1, 1u, lg_n, t->lo_bits, inner, twh, twl, csh, csl, pre_coset, (const char*)nullptr, ext);
     uint32_t lgBn2 = s3, lgT2 = lgT_for(s2, lgBn2);
-    hipLaunchKernelGGL((k_ntt_strided<TE, NT, GM>), dim3((1u << s1) << (lgBn2 - lgT2), batch), dim3(NT), lds_bytes, s, buf, tmp, s2, lgBn2, lgT2, 1u << s1, lg_n, t->lo_bits, inner, twh, twl, csh, csl, 0, (const char*)nullptr);
+    hipLaunchKernelGGL((k_ntt_strided<TE, NT, GM>), dim3((1u << s1) << (lgBn2 - lgT2), batch), dim3(NT), lds_bytes, s, buf, tmp, s2, lgBn2, lgT2, 1u << s1, lg_n, t->lo_bits, inner, twh, twl, csh, csl, 0, (const char*)nullptr, NttSrc{});
     uint32_t lgTf = lgT_for(s3, s1);
-    hipLaunchKernelGGL((k_ntt_final<TE, NT, GM>), dim3((1u << s2) << (s1 - lgTf), batch), dim3(NT), lds_bytes, s, tmp, buf, s3, s1, s2, lgTf, t->lo_bits, inner, csh, csl, 0, post_coset, do_scale, sc);
+    hipLaunchKernelGGL((k_ntt_final<TE, NT, GM>), dim3((1u << s2) << (s1 - lgTf), batch), dim3(NT), lds_bytes, s, tmp, buf, s3, s1, s2, lgTf, t->lo_bits, inner, csh, csl, 0, post_coset, do_scale, sc, NttSrc{});
   }
   return ALEO_MI355X_OK;
 }
@@ -528,7 +538,7 @@ static int32_t run_passes(Ctx* c, char* buf, char* tmp, uint32_t lg_n, uint32_t 
 
 // run_passes on the 29-bit-limb kernels (tiles of 9 planes: 144 KiB / 72 KiB); same pass splits, same launch geometry
 template <uint32_t TE, uint32_t NT, int GM = 3>
-static int32_t run_passes29(Ctx* c, char* buf, char* tmp, uint32_t lg_n, uint32_t batch, const NttTables* t, int pre_coset, int post_coset, int do_scale, hipStream_t s) {
+static int32_t run_passes29(Ctx* c, char* buf, char* tmp, uint32_t lg_n, uint32_t batch, const NttTables* t, int pre_coset, int post_coset, int do_scale, hipStream_t s, NttSrc ext = NttSrc{}) {
   constexpr uint32_t lgTE = TE == 4096 ? 12 : 11;
   static_assert(TE == 4096 || TE == 2048, "tile sizes with a kernel instance");
   constexpr size_t lds_bytes = (size_t)TE * 36;
@@ -549,7 +559,7 @@ static int32_t run_passes29(Ctx* c, char* buf, char* tmp, uint32_t lg_n, uint32_
   else { s1 = (lg_n + 2) / 3; s2 = (lg_n - s1 + 1) / 2; s3 = lg_n - s1 - s2; }
   auto lgT_for = [](uint32_t lgL, uint32_t lg_limit) { uint32_t lgT = lgTE - lgL; return lgT < lg_limit ? lgT : lg_limit; };
   if (npass == 1) {
-    hipLaunchKernelGGL((k_ntt29_final<TE, NT, GM>), dim3(1, batch), dim3(NT), lds_bytes, s, buf, buf, s3, 0u, 0u, 0u, t->lo_bits, inner, csh, csl, pre_coset, post_coset, do_scale, sc);
+    hipLaunchKernelGGL((k_ntt29_final<TE, NT, GM>), dim3(1, batch), dim3(NT), lds_bytes, s, buf, buf, s3, 0u, 0u, 0u, t->lo_bits, inner, csh, csl, pre_coset, post_coset, do_scale, sc, ext);
   } else if (npass == 2) {
     uint32_t lgBn = s3, lgT = lgT_for(s1, lgBn);
     const char* direct = nullptr;
@@ -565,16 +575,16 @@ static int32_t run_passes29(Ctx* c, char* buf, char* tmp, uint32_t lg_n, uint32_
       }
       if (tm->direct29_lgBn == lgBn) direct = (const char*)tm->d_direct29;
     }
-    hipLaunchKernelGGL((k_ntt29_strided<TE, NT, GM>), dim3(1u << (lgBn - lgT), batch), dim3(NT), lds_bytes, s, buf, tmp, s1, lgBn, lgT, 1u, lg_n, t->lo_bits, inner, twh, twl, csh, csl, pre_coset, direct);
+    hipLaunchKernelGGL((k_ntt29_strided<TE, NT, GM>), dim3(1u << (lgBn - lgT), batch), dim3(NT), lds_bytes, s, buf, tmp, s1, lgBn, lgT, 1u, lg_n, t->lo_bits, inner, twh, twl, csh, csl, pre_coset, direct, ext);
     uint32_t lgTf = lgT_for(s3, s1);
-    hipLaunchKernelGGL((k_ntt29_final<TE, NT, GM>), dim3(1u << (s1 - lgTf), batch), dim3(NT), lds_bytes, s, tmp, buf, s3, s1, 0u, lgTf, t->lo_bits, inner, csh, csl, 0, post_coset, do_scale, sc);
+    hipLaunchKernelGGL((k_ntt29_final<TE, NT, GM>), dim3(1u << (s1 - lgTf), batch), dim3(NT), lds_bytes, s, tmp, buf, s3, s1, 0u, lgTf, t->lo_bits, inner, csh, csl, 0, post_coset, do_scale, sc, NttSrc{});
   } else {
     uint32_t lgBn1 = s2 + s3, lgT1 = lgT_for(s1, lgBn1);
-    hipLaunchKernelGGL((k_ntt29_strided<TE, NT, GM>), dim3(1u << (lgBn1 - lgT1), batch), dim3(NT), lds_bytes, s, buf, buf, s1, lgBn1, lgT1, 1u, lg_n, t->lo_bits, inner, twh, twl, csh, csl, pre_coset, (const char*)nullptr);
+    hipLaunchKernelGGL((k_ntt29_strided<TE, NT, GM>), dim3(1u << (lgBn1 - lgT1), batch), dim3(NT), lds_bytes, s, buf, buf, s1, lgBn1, lgT1, 1u, lg_n, t->lo_bits, inner, twh, twl, csh, csl, pre_coset, (const char*)nullptr, ext);
     uint32_t lgBn2 = s3, lgT2 = lgT_for(s2, lgBn2);
-    hipLaunchKernelGGL((k_ntt29_strided<TE, NT, GM>), dim3((1u << s1) << (lgBn2 - lgT2), batch), dim3(NT), lds_bytes, s, buf, tmp, s2, lgBn2, lgT2, 1u << s1, lg_n, t->lo_bits, inner, twh, twl, csh, csl, 0, (const char*)nullptr);
+    hipLaunchKernelGGL((k_ntt29_strided<TE, NT, GM>), dim3((1u << s1) << (lgBn2 - lgT2), batch), dim3(NT), lds_bytes, s, buf, tmp, s2, lgBn2, lgT2, 1u << s1, lg_n, t->lo_bits, inner, twh, twl, csh, csl, 0, (const char*)nullptr, NttSrc{});
     uint32_t lgTf = lgT_for(s3, s1);
-    hipLaunchKernelGGL((k_ntt29_final<TE, NT, GM>), dim3((1u << s2) << (s1 - lgTf), batch), dim3(NT), lds_bytes, s, tmp, buf, s3, s1, s2, lgTf, t->lo_bits, inner, csh, csl, 0, post_coset, do_scale, sc);
+    hipLaunchKernelGGL((k_ntt29_final<TE, NT, GM>), dim3((1u << s2) << (s1 - lgTf), batch), dim3(NT), lds_bytes, s, tmp, buf, s3, s1, s2, lgTf, t->lo_bits, inner, csh, csl, 0, post_coset, do_scale, sc, NttSrc{});
   }
   return ALEO_MI355X_OK;
 }
@@ -654,7 +664,7 @@ static int32_t get_tables(Ctx* c, uint32_t lg_n, int32_t direction, NttTables** 
   return ALEO_MI355X_OK;
 }
 
-static int32_t ntt_run_chunk(Ctx* c, void* d_inout, uint32_t lg_n, uint32_t batch, int32_t order, int32_t direction, int32_t type, hipStream_t s);
+static int32_t ntt_run_chunk(Ctx* c, void* d_inout, uint32_t lg_n, uint32_t batch, int32_t order, int32_t direction, int32_t type, hipStream_t s, NttSrc ext = NttSrc{});
 // `batch` independent transforms of 2^lg_n elements each, contiguous in d_inout (blockIdx.y walks them)
 int32_t ntt_run(Ctx* c, void* d_inout, uint32_t lg_n, size_t batch_total, int32_t order, int32_t direction, int32_t type, hipStream_t s) {
   if (lg_n == 0 || batch_total == 0) return ALEO_MI355X_OK;     // n = 1: every variant is the identity (g^0 = 1, 1^-1 = 1)
@@ -667,11 +677,27 @@ int32_t ntt_run(Ctx* c, void* d_inout, uint32_t lg_n, size_t batch_total, int32_
   return ALEO_MI355X_OK;
 }
 
+// The same with the first pass reading transform b's coefficients from d_src + b * src_stride elements, zero beyond src_len (natural order in and out; d_out
+// must not overlap d_src): what `memset + copy + ntt_run` did in three or more launches.
+int32_t ntt_run_from(Ctx* c, void* d_out, const void* d_src, size_t src_stride, size_t src_len, uint32_t lg_n, size_t batch_total, int32_t direction, int32_t type, hipStream_t s) {
+  if (batch_total == 0) return ALEO_MI355X_OK;
+  const size_t n = (size_t)1 << lg_n;
+  if (src_len > n || src_stride >= (1ull << 32) || !d_src || !d_out) { g_last_error = "ntt_run_from: bad argument"; return ALEO_MI355X_ERR_BAD_ARG; }
+  if (lg_n == 0) { for (size_t b = 0; b < batch_total; ++b) { if (src_len) HIPCHK(hipMemcpyAsync((char*)d_out + b * 32, (const char*)d_src + b * src_stride * 32, 32, hipMemcpyDeviceToDevice, s)); else HIPCHK(hipMemsetAsync((char*)d_out + b * 32, 0, 32, s)); } return ALEO_MI355X_OK; }
+  for (size_t b0 = 0; b0 < batch_total; b0 += 32768) {
+    const uint32_t batch = (uint32_t)(batch_total - b0 < 32768 ? batch_total - b0 : 32768);
+    NttSrc ext; ext.p = (const char*)d_src + b0 * src_stride * 32; ext.len = (uint32_t)src_len; ext.stride = (uint32_t)src_stride;
+    const int32_t rcb = ntt_run_chunk(c, (char*)d_out + b0 * n * 32, lg_n, batch, ALEO_NTT_ORDER_NN, direction, type, s, ext);
+    if (rcb) return rcb;
+  }
+  return ALEO_MI355X_OK;
+}
+
 // Calls of at most 2^wide_lg() elements in all (transforms of 2^10 … 2^18 points) take the one-butterfly-per-lane tiles: 2^12 52 -> 22 us, 2^15 64 -> 27 us,
 // 3 x 2^15 67 -> 30 us, 8 x 2^16 85 -> 72 us; from 2^20 elements on the three-stage register groups win again (8 x 2^17: 138 against 142 us)
 // (tools/ntt_small_probe.py, profiles/r02_ntt_small_probe.jsonl).  ALEO_MI355X_NTT_WIDE_LG overrides the cut, 0 = never.
 static uint32_t wide_lg() { static const uint32_t v = [] { const char* e = std::getenv("ALEO_MI355X_NTT_WIDE_LG"); int k = e ? std::atoi(e) : 19; return (uint32_t)(k >= 0 && k <= 24 ? k : 19); }(); return v; }
-static int32_t ntt_run_chunk(Ctx* c, void* d_inout, uint32_t lg_n, uint32_t batch, int32_t order, int32_t direction, int32_t type, hipStream_t s) {
+static int32_t ntt_run_chunk(Ctx* c, void* d_inout, uint32_t lg_n, uint32_t batch, int32_t order, int32_t direction, int32_t type, hipStream_t s, NttSrc ext) {
   const size_t n = (size_t)1 << lg_n, bytes = n * 32 * batch;
   int32_t rc;
   NttTables* t = nullptr;
@@ -697,17 +723,17 @@ static int32_t ntt_run_chunk(Ctx* c, void* d_inout, uint32_t lg_n, uint32_t batc
                                 !(lg_n >= 10 && lg_n <= 18 && ((size_t)batch << lg_n) <= ((size_t)1 << wide_lg()));
   if (limbs29 && (force_tile == 2048 || force_tile == 4096 || (force_tile == 0 && big_tile_default))) {
     static const int gm = [] { const char* e = std::getenv("ALEO_MI355X_NTT29_GM"); return e ? std::atoi(e) : 3; }();      // experiment knob
-    if ((force_tile == 4096 || (force_tile == 0 && lg_n >= 20 && lg_n <= 22)) && gm == 2) rc = run_passes29<4096, 1024, 2>(c, buf, tmp, lg_n, batch, t, pre_coset, post_coset, do_scale, s);
-    else if (force_tile == 4096 || (force_tile == 0 && lg_n >= 20 && lg_n <= 22)) rc = run_passes29<4096, 512>(c, buf, tmp, lg_n, batch, t, pre_coset, post_coset, do_scale, s);
-    else rc = run_passes29<2048, 256>(c, buf, tmp, lg_n, batch, t, pre_coset, post_coset, do_scale, s);
+    if ((force_tile == 4096 || (force_tile == 0 && lg_n >= 20 && lg_n <= 22)) && gm == 2) rc = run_passes29<4096, 1024, 2>(c, buf, tmp, lg_n, batch, t, pre_coset, post_coset, do_scale, s, ext);
+    else if (force_tile == 4096 || (force_tile == 0 && lg_n >= 20 && lg_n <= 22)) rc = run_passes29<4096, 512>(c, buf, tmp, lg_n, batch, t, pre_coset, post_coset, do_scale, s, ext);
+    else rc = run_passes29<2048, 256>(c, buf, tmp, lg_n, batch, t, pre_coset, post_coset, do_scale, s, ext);
   }
-  else if (force_tile == 2048) rc = run_passes<2048, 256>(c, buf, tmp, lg_n, batch, t, pre_coset, post_coset, do_scale, sc, s);
-  else if (force_tile == 4096) rc = run_passes<4096, 512>(c, buf, tmp, lg_n, batch, t, pre_coset, post_coset, do_scale, sc, s);
-  else if (force_tile == 512 && lg_n <= 18) rc = run_passes<512, 64>(c, buf, tmp, lg_n, batch, t, pre_coset, post_coset, do_scale, sc, s);
-  else if (lg_n >= 20 && lg_n <= 22) rc = run_passes<4096, 512>(c, buf, tmp, lg_n, batch, t, pre_coset, post_coset, do_scale, sc, s);
-  else if (lg_n >= 10 && lg_n <= 18 && ((size_t)batch << lg_n) <= ((size_t)1 << wide_lg())) rc = run_passes<512, 256, 1>(c, buf, tmp, lg_n, batch, t, pre_coset, post_coset, do_scale, sc, s);      // latency form
-  else if (lg_n >= 10 && lg_n <= 18 && ((size_t)batch << lg_n) <= ((size_t)1 << 18)) rc = run_passes<512, 64>(c, buf, tmp, lg_n, batch, t, pre_coset, post_coset, do_scale, sc, s);
-  else rc = run_passes<2048, 256>(c, buf, tmp, lg_n, batch, t, pre_coset, post_coset, do_scale, sc, s);
+  else if (force_tile == 2048) rc = run_passes<2048, 256>(c, buf, tmp, lg_n, batch, t, pre_coset, post_coset, do_scale, sc, s, ext);
+  else if (force_tile == 4096) rc = run_passes<4096, 512>(c, buf, tmp, lg_n, batch, t, pre_coset, post_coset, do_scale, sc, s, ext);
+  else if (force_tile == 512 && lg_n <= 18) rc = run_passes<512, 64>(c, buf, tmp, lg_n, batch, t, pre_coset, post_coset, do_scale, sc, s, ext);
+  else if (lg_n >= 20 && lg_n <= 22) rc = run_passes<4096, 512>(c, buf, tmp, lg_n, batch, t, pre_coset, post_coset, do_scale, sc, s, ext);
+  else if (lg_n >= 10 && lg_n <= 18 && ((size_t)batch << lg_n) <= ((size_t)1 << wide_lg())) rc = run_passes<512, 256, 1>(c, buf, tmp, lg_n, batch, t, pre_coset, post_coset, do_scale, sc, s, ext);      // latency form
+  else if (lg_n >= 10 && lg_n <= 18 && ((size_t)batch << lg_n) <= ((size_t)1 << 18)) rc = run_passes<512, 64>(c, buf, tmp, lg_n, batch, t, pre_coset, post_coset, do_scale, sc, s, ext);
+  else rc = run_passes<2048, 256>(c, buf, tmp, lg_n, batch, t, pre_coset, post_coset, do_scale, sc, s, ext);
   if (rc) return rc;
   if (out_rev) {
     hipLaunchKernelGGL(k_bitrev_copy, gperm, dim3(256), 0, s, buf, tmp, lg_n);

@@ -83,7 +83,7 @@ thread_local double g_varuna_timing[8] = {};
 static int32_t commit(Ctx* c, const PinnedBases& pb, const std::vector<MsmSeg>& segs, uint32_t k, uint8_t* out104, hipStream_t s, bool sparse = false,
                       std::function<int32_t()> behind = nullptr) {
   std::vector<uint64_t> jac(18 * (size_t)k);
-  MsmJob j; j.segs = segs.data(); j.nseg = (uint32_t)segs.size(); j.k = k; j.mont = true; j.sparse = sparse;
+  MsmJob j; j.segs = segs.data(); j.nseg = (uint32_t)segs.size(); j.k = k; j.mont = true; j.sparse = sparse; j.lean = true;      // lean: no phase-timing events between the chain's kernels
   const double t0 = now_ms();
   size_t points = 0; for (const MsmSeg& g : segs) points += g.len;
   if (pb.shards && points >= pb.shard_min) {
@@ -136,14 +136,19 @@ int32_t varuna_index_build(Ctx* c, const PinnedBases& pb, std::shared_ptr<Pinned
   if (!n_constraints || !n_public || n_constraints >= (1ull << 28)) { g_last_error = "varuna_index: bad sizes"; return ALEO_MI355X_ERR_BAD_ARG; }
   const uint64_t n_vars = n_public + n_private, n_x = pow2_at_least(n_public, 1);
   uint64_t n_h = pow2_at_least(n_constraints, 2); n_h = pow2_at_least(n_x + n_private, n_h); n_h = pow2_at_least(2 * n_x, n_h);
-  uint64_t nnz[3], nnz_max = 0, nnz_sum = 0;
+  uint64_t nnz[3], nnz_max = 0, nnz_sum = 0, max_row[3] = {1, 1, 1};      // max_row: the longest row of A, B and of the stacked transpose (hints for the sparse products; >= 1 = known)
+  std::vector<uint32_t> col_count(n_vars, 0);
   for (int m = 0; m < 3; ++m) {
     if (!abc[m].row_ptr || abc[m].row_ptr[0] != 0) { g_last_error = "varuna_index: row_ptr must start at 0"; return ALEO_MI355X_ERR_BAD_ARG; }
     nnz[m] = abc[m].row_ptr[n_constraints]; nnz_max = nnz[m] > nnz_max ? nnz[m] : nnz_max; nnz_sum += nnz[m];
     if (nnz[m] && (!abc[m].col || !abc[m].val)) { g_last_error = "varuna_index: null matrix arrays"; return ALEO_MI355X_ERR_BAD_ARG; }
-    for (uint64_t e = 0; e < nnz[m]; ++e) if (abc[m].col[e] >= n_vars) { g_last_error = "varuna_index: column outside the variables"; return ALEO_MI355X_ERR_BAD_ARG; }
-    for (size_t r = 0; r < n_constraints; ++r) if (abc[m].row_ptr[r + 1] < abc[m].row_ptr[r]) { g_last_error = "varuna_index: row_ptr not monotone"; return ALEO_MI355X_ERR_BAD_ARG; }
+    for (uint64_t e = 0; e < nnz[m]; ++e) { if (abc[m].col[e] >= n_vars) { g_last_error = "varuna_index: column outside the variables"; return ALEO_MI355X_ERR_BAD_ARG; } ++col_count[abc[m].col[e]]; }
+    for (size_t r = 0; r < n_constraints; ++r) {
+      if (abc[m].row_ptr[r + 1] < abc[m].row_ptr[r]) { g_last_error = "varuna_index: row_ptr not monotone"; return ALEO_MI355X_ERR_BAD_ARG; }
+      const uint64_t len = abc[m].row_ptr[r + 1] - abc[m].row_ptr[r]; if (m < 2 && len > max_row[m]) max_row[m] = len;
+    }
   }
+  for (uint32_t cnt : col_count) if (cnt > max_row[2]) max_row[2] = cnt;      // a row of the stacked transpose = every use of one variable in A, B and C
   uint64_t nk[3], ko[3], k_sum = 0, n_k = 0;                 // one non-zero domain per matrix; ko: elements of the earlier matrices
   for (int m = 0; m < 3; ++m) { nk[m] = pow2_at_least(nnz[m], 2); n_k = nk[m] > n_k ? nk[m] : n_k; }
   if (domain_flags == 2 || (domain_flags == 0 && n_k < (1ull << 18))) nk[0] = nk[1] = nk[2] = n_k;      // shared: latency-bound sizes (header)
@@ -157,6 +162,7 @@ int32_t varuna_index_build(Ctx* c, const PinnedBases& pb, std::shared_ptr<Pinned
   HFr r2; std::memcpy(r2.l, host::HParams<4>::R2, 32);
   const HFr one = HFr::one();
   aleo_mi355x_varuna_index& V = o->view;
+  for (int m = 0; m < 3; ++m) V.max_row[m] = max_row[m];
   V.n_h = n_h; V.n_k_a = nk[0]; V.n_k_b = nk[1]; V.n_k_c = nk[2]; V.n_x = n_x; V.n_public = n_public; V.n_vars = n_vars; V.committer_key = key_handle; V.max_degree = max_degree; V.gamma_offset = gamma_offset; V.lagrange_offset = lagrange_offset;
   if (lagrange_offset && lagrange_offset + n_h + 1 > pb.n) { g_last_error = "varuna_index: the Lagrange powers do not fit the committer key"; return ALEO_MI355X_ERR_BAD_ARG; }
   const bool tim = std::getenv("ALEO_MI355X_INDEX_TIMING") != nullptr; double t_prev = now_ms();
@@ -257,7 +263,7 @@ struct Shared {
   Ctx* c; const PinnedBases& pb; Seed32 seed;
   Shared(Ctx* c_, const PinnedBases& pb_, const uint8_t* seed32) : c(c_), pb(pb_) { std::memcpy(seed.w, seed32, 32); }
   size_t m = 0, K = 0, N = 0, n_kmax = 0, lead = 0, x_total = 0; uint64_t D = 0, gamma_offset = 0;
-  hipStream_t s = nullptr; double t_mark[7] = {}; Arena ar{nullptr, 0, 0}; char* pin = nullptr; char* stage = nullptr; char* pin_small = nullptr;
+  hipStream_t s = nullptr; double t_mark[7] = {}; Arena ar{nullptr, 0, 0}; char* pin = nullptr; char* stage = nullptr; char* pin_small = nullptr; char* pin_small_dev = nullptr;      // pin_small_dev: the device's address of pin_small (kernels store small read-backs there)
   HFr one, neg1, r2; host::FiatShamir fs; uint64_t lay_mask = 0, lay_blind = 0, lay_blind_mask = 0;
   char *mask = nullptr, *bl = nullptr, *h1 = nullptr, *g1 = nullptr, *h2 = nullptr, *flag = nullptr, *evd = nullptr;
   std::vector<HFr> blind, comb, evals, x_mont, ch_b, ch_g; std::vector<uint8_t> wit_aff, aff3;
@@ -312,7 +318,7 @@ int32_t Prover::setup() {
 
 int32_t Prover::first_round(const void* const* assignments, std::vector<MsmSeg>& sg) {
   Ctx* c = sh.c; hipStream_t s = sh.s; Arena& ar = sh.ar; char* pin = sh.pin + pin_off * 32; char* stage = sh.stage;
-  TAKE(zH, k * n_h) TAKE(ev, 3 * k * n_h) TAKE(xh, k * n_h) TAKE_M(xp, k * n_x) TAKE_M(wit, 3 * k * L)
+  TAKE(zH, k * n_h + 8) TAKE(ev, 3 * k * n_h) TAKE(xh, k * n_h) TAKE_M(xp, k * n_x) TAKE_M(wit, 3 * k * L)      // (+ 8: the canonical-input flag sits behind z on H, cleared by the same fill)
   x_poly.assign(k, {});
   const size_t xb0 = sh.x_mont.size(); sh.x_mont.resize(xb0 + k * n_x, HFr::zero());          // the padded public inputs: what the transcript absorbs per instance
   uint32_t lg_x = 0; while ((1ull << lg_x) < n_x) ++lg_x;
@@ -341,23 +347,20 @@ int32_t Prover::first_round(const void* const* assignments, std::vector<MsmSeg>&
     RC(fr_lin(c, zH, k * n_h, nullptr, sh.r2.l, zH, nullptr, nullptr, s));                // canonical -> Montgomery
   } else {                                                                                  // upload in variable order; scatter + Montgomery form on the device
     TAKE(zraw, k * ix.n_vars)
-    if (!sh.flag) { TAKE_M(sh.flag, 1) HIPCHK(hipMemsetAsync(sh.flag, 0, 32, s)); }          // raised by the scatter when an entry is not below r
-    HIPCHK(hipMemsetAsync(zH, 0, k * n_h * 32, s));
+    if (!sh.flag) sh.flag = zH + k * n_h * 32;                                               // raised by the scatter when an entry is not below r
+    HIPCHK(hipMemsetAsync(zH, 0, (k * n_h + 8) * 32, s));
     for (size_t i = 0; i < k; ++i) {
       HIPCHK(hipMemcpyAsync(zraw + i * ix.n_vars * 32, assignments[i], ix.n_vars * 32, hipMemcpyHostToDevice, s));
       RC(fr_scatter_to_mont(c, zH + i * n_h * 32, zraw + i * ix.n_vars * 32, ix.positions_device, ix.n_vars, sh.flag, s));
     }
   }
   HIPCHK(hipMemcpyAsync(xp, stage + x_off * 32, k * n_x * 32, hipMemcpyHostToDevice, s));
-  HIPCHK(hipMemsetAsync(xh, 0, k * n_h * 32, s));
+  RC(ntt_run_from(c, xh, xp, n_x, n_x, lg_h, k, ALEO_NTT_FORWARD, ALEO_NTT_STANDARD, s));      // x̂ of every instance on H: |X| coefficients each, zero-padded by the transform's first pass
   for (size_t i = 0; i < k; ++i) {
     char* e0 = ev + 3 * i * n_h * 32; char* z_i = zH + i * n_h * 32; char* xh_i = xh + i * n_h * 32;
-    RC(fr_spmv(c, e0 + n_h * 32, ix.a_row_ptr, ix.a_col, ix.a_val, z_i, n_h, s));
-    RC(fr_spmv(c, e0 + 2 * n_h * 32, ix.b_row_ptr, ix.b_col, ix.b_val, z_i, n_h, s));
-    HIPCHK(hipMemcpyAsync(xh_i, xp + i * n_x * 32, n_x * 32, hipMemcpyDeviceToDevice, s));
-    RC(ntt_run(c, xh_i, lg_h, 1, 0, 0, 0, s));
-    RC(fr_vec_op(c, e0, z_i, xh_i, n_h, 2, s));                                             // z − x̂ on H
-    RC(fr_vec_op(c, e0, e0, ix.vx_inv, n_h, 0, s));                                         // / v_X off X, 0 on X
+    RC(fr_spmv(c, e0 + n_h * 32, ix.a_row_ptr, ix.a_col, ix.a_val, z_i, n_h, s, ix.max_row[0]));
+    RC(fr_spmv(c, e0 + 2 * n_h * 32, ix.b_row_ptr, ix.b_col, ix.b_val, z_i, n_h, s, ix.max_row[1]));
+    RC(fr_sub_mul(c, e0, z_i, xh_i, ix.vx_inv, n_h, s));                                    // (z − x̂) / v_X off X, 0 on X
   }
   if (lagrange()) {                                        // KZG10::commit_lagrange for w, z_a, z_b: commit the evaluations (kept here) against L_i(tau) G
     evals_h = ar.take(3 * k * n_h); rho_dev = ar.take(3 * k);
@@ -402,16 +405,11 @@ int32_t Prover::second_round() {
     const HFr first = HFr::pow_u64(alpha, n_h - 1), ratio = HFr::inv(alpha);
     RC(fr_powers(c, rt, n_h, first.l, ratio.l, s));                                          // r(alpha, X) = sum_k alpha^(|H|-1-k) X^k
   }
-  HIPCHK(hipMemcpyAsync(ext, rt, n_h * 32, hipMemcpyDeviceToDevice, s));
-  RC(ntt_run(c, ext, lg_h, 1, 0, 0, 0, s));                                                 // v_H(alpha) / (alpha − h) on H: no inversion on the device
-  RC(fr_lin(c, ext + n_h * 32, n_h, nullptr, eta_b.l, ext, nullptr, nullptr, s));
-  RC(fr_lin(c, ext + 2 * n_h * 32, n_h, nullptr, eta_c.l, ext, nullptr, nullptr, s));
-  RC(fr_spmv(c, rt + n_h * 32, ix.t_row_ptr, ix.t_col, ix.t_val, ext, n_h, s));
+  RC(ntt_run_from(c, ext, rt, n_h, n_h, lg_h, 1, ALEO_NTT_FORWARD, ALEO_NTT_STANDARD, s));    // v_H(alpha) / (alpha − h) on H: no inversion on the device
+  { const HFr eta[2] = {eta_b, eta_c}; RC(fr_scale_rows(c, ext + n_h * 32, ext, n_h, 2, eta, s)); }      // the eta_b- and eta_c-scaled copies B^T and C^T multiply
+  RC(fr_spmv(c, rt + n_h * 32, ix.t_row_ptr, ix.t_col, ix.t_val, ext, n_h, s, ix.max_row[2]));
   RC(ntt_run(c, rt + n_h * 32, lg_h, 1, 0, 1, 0, s));                                       // t(X)
-  HIPCHK(hipMemsetAsync(E, 0, 2 * n4 * 32, s));                                             // r, t: |H| coefficients each, zero padded to 4|H|
-  HIPCHK(hipMemcpyAsync(E, rt, n_h * 32, hipMemcpyDeviceToDevice, s));
-  HIPCHK(hipMemcpyAsync(E + n4 * 32, rt + n_h * 32, n_h * 32, hipMemcpyDeviceToDevice, s));
-  RC(ntt_run(c, E, lg_h + 2, 2, 0, 0, 0, s));                                               // r, t on 4|H| (the operands of the instances are there already: second_round_early)
+  RC(ntt_run_from(c, E, rt, n_h, n_h, lg_h + 2, 2, ALEO_NTT_FORWARD, ALEO_NTT_STANDARD, s));  // r, t on 4|H|: |H| coefficients each, zero-padded by the first pass (the operands of the instances are there already: second_round_early)
   for (size_t i = 0; i < k; ++i) {
     char* e_z = E + (2 + 3 * i) * n4 * 32;
     RC(ahp_first_sumcheck(c, e_z + n4 * 32, n4, E, e_z + n4 * 32, e_z + 2 * n4 * 32, E + n4 * 32, e_z, eta_b.l, eta_c.l, s));
@@ -423,11 +421,9 @@ int32_t Prover::second_round() {
     RC(lincomb_any(c, Q, n4, HFr::zero(), terms, lens, co, s)); q1 = Q;                     // 29..32 instances of one circuit: more terms than one fr_lincomb launch takes
   }
   RC(ntt_run(c, q1, lg_h + 2, 1, 0, 1, 0, s));
-  if (lead()) RC(fr_vec_op(c, q1, q1, sh.mask, 3 * n_h, 1, s));                             // q = h (X^|H| − 1) + X g, degree < 3|H|; the mask rides with the largest domain
-  HIPCHK(hipMemcpyAsync(hq + n_h * 32, q1 + 2 * n_h * 32, n_h * 32, hipMemcpyDeviceToDevice, s));   // quotient blocks: p2, p1 + p2; remainder p0 + p1 + p2
-  RC(fr_vec_op(c, hq, q1 + n_h * 32, q1 + 2 * n_h * 32, n_h, 1, s));
-  RC(fr_vec_op(c, rq, q1, hq, n_h, 1, s));
-  HIPCHK(hipMemcpyAsync(sh.pin_small + PIN_SUMS + 32 * j, rq, 32, hipMemcpyDeviceToHost, s));   // this circuit's sum over H (the remainder's constant term): read with the commitments
+  // q (+ the mask, which rides with the largest domain) = h (X^|H| − 1) + X g, degree < 3|H|: quotient blocks p1 + p2 | p2, remainder p0 + p1 + p2; the remainder's
+  // constant term — this circuit's sum over H — goes straight into pinned host memory (read with the commitments).  One launch (rounds 1-4: a copy, three vector ops, a read-back)
+  RC(fr_split_quotient(c, hq, rq, q1, lead() ? sh.mask : nullptr, n_h, sh.pin_small_dev + PIN_SUMS + 32 * j, s));
   return ALEO_MI355X_OK;
 }
 
@@ -450,16 +446,15 @@ int32_t Prover::third_round() {
   nrun = 0;
   for (size_t m = 0; m < 3;) { size_t cnt = 1; while (m + cnt < 3 && nk[m + cnt] == nk[m]) ++cnt; run0[nrun] = m; runc[nrun++] = cnt; m += cnt; }
   for (size_t r = 0; r < nrun; ++r) RC(ntt_run(c, f + ko[run0[r]] * 32, lg_km[run0[r]], runc[r], 0, 1, 0, s));
-  for (size_t m = 0; m < 3; ++m) HIPCHK(hipMemcpyAsync(sh.pin_small + 32 * (3 * j + m), f + ko[m] * 32, 32, hipMemcpyDeviceToHost, s));
+  { const void* src[3] = {f + ko[0] * 32, f + ko[1] * 32, f + ko[2] * 32}; RC(fr_pick(c, sh.pin_small_dev + 32 * (3 * j), src, 3, s)); }      // f_M(0): one launch into pinned host memory
   return ALEO_MI355X_OK;
 }
 
 int32_t Prover::fourth_round_early() {
   Ctx* c = sh.c; hipStream_t s = sh.s;
   TAKE_M(F, 2 * k_sum)                                                                        // f_M zero-padded to 2|K_M|, then its values there
-  HIPCHK(hipMemsetAsync(F, 0, 2 * k_sum * 32, s));
-  for (size_t m = 0; m < 3; ++m) HIPCHK(hipMemcpyAsync(F + 2 * ko[m] * 32, f + ko[m] * 32, nk[m] * 32, hipMemcpyDeviceToDevice, s));
-  for (size_t r = 0; r < nrun; ++r) RC(ntt_run(c, F + 2 * ko[run0[r]] * 32, lg_km[run0[r]] + 1, runc[r], 0, 0, 0, s));
+  for (size_t r = 0; r < nrun; ++r)                          // the polynomials of a run are contiguous in f (|K| apart): zero-padded to 2|K| by the transform's first pass
+    RC(ntt_run_from(c, F + 2 * ko[run0[r]] * 32, f + ko[run0[r]] * 32, nk[run0[r]], nk[run0[r]], lg_km[run0[r]] + 1, runc[r], ALEO_NTT_FORWARD, ALEO_NTT_STANDARD, s));
   return ALEO_MI355X_OK;
 }
 
@@ -493,7 +488,7 @@ struct Batch {
   Batch(Ctx* c, const PinnedBases& pb, const uint8_t* seed32) : sh(c, pb, seed32) {}
   int32_t init_sponge();                                   // Varuna::init_sponge: protocol name, batch sizes, public inputs, index commitments
   int32_t setup(const aleo_mi355x_varuna_index* const* ixs, size_t m, const size_t* ks);      // checks + sizes (need_ws_bytes, need_pin_bytes)
-  void attach(char* ws, size_t ws_bytes, char* pin);       // the slices of the slot's device workspace and pinned staging this proof works in
+  int32_t attach(char* ws, size_t ws_bytes, char* pin);    // the slices of the slot's device workspace and pinned staging this proof works in
   int32_t first_prepare(const void* const* assignments); int32_t first_finish();      // the 3K + 1 hiding commitments
   int32_t second_prepare(); int32_t second_finish();       // g_1, h_1
   int32_t third_prepare(); int32_t third_finish();         // sigma_{j,M}, g_{j,M}
@@ -558,9 +553,11 @@ int32_t Batch::setup(const aleo_mi355x_varuna_index* const* ixs, size_t m, const
   return ALEO_MI355X_OK;
 }
 
-void Batch::attach(char* ws, size_t ws_bytes, char* pin) {
+int32_t Batch::attach(char* ws, size_t ws_bytes, char* pin) {
   sh.ar = Arena{ws, 0, ws_bytes};
   sh.pin = pin; sh.stage = sh.pin + pin_elems * 32; sh.pin_small = sh.stage + stage_elems * 32;      // PIN_SMALL_BYTES for small read-backs
+  void* dp = nullptr; HIPCHK(hipHostGetDevicePointer(&dp, sh.pin_small, 0)); sh.pin_small_dev = (char*)dp;
+  return ALEO_MI355X_OK;
 }
 
 // The slot's grow-only device workspace and pinned staging, sized for `ws_bytes` / `pin_bytes` (one proof, or the sum over the proofs of a lockstep call)
@@ -568,7 +565,7 @@ static int32_t reserve_prover_memory(Ctx* c, size_t ws_bytes, size_t pin_bytes) 
   RC(c->prover_ws.reserve(ws_bytes));
   if (c->prover_pin_cap < pin_bytes) {
     if (c->prover_pin) { HIPCHK(hipStreamSynchronize(c->stream)); (void)hipHostFree(c->prover_pin); c->prover_pin = nullptr; c->prover_pin_cap = 0; }
-    HIPCHK(hipHostMalloc(&c->prover_pin, pin_bytes + pin_bytes / 8, hipHostMallocDefault)); c->prover_pin_cap = pin_bytes + pin_bytes / 8;
+    HIPCHK(hipHostMalloc(&c->prover_pin, pin_bytes + pin_bytes / 8, hipHostMallocMapped)); c->prover_pin_cap = pin_bytes + pin_bytes / 8;      // mapped: kernels store small read-backs into it
   }
   return ALEO_MI355X_OK;
 }
@@ -795,7 +792,6 @@ int32_t Batch::open_prepare() {
     char* st = sh.stage + sh.st_blq() * 32; std::memcpy(st, blw, HC * 32);
     HIPCHK(hipMemcpyAsync(blq, st, HC * 32, hipMemcpyHostToDevice, s));
   }
-  RC(fr_divide_by_linear(c, wq, evd + (ne + 1) * 32, pbeta, 3 * N, beta.l, s));
   // ---- the linear combination of the second sumcheck, opened at gamma together with every g_{j,M} ------------------------------------------------------
   {
     const HFr xi3m = sh.ch_g[3 * m], vk_gamma = vanish(n_k, gamma);
@@ -816,7 +812,10 @@ int32_t Batch::open_prepare() {
     for (auto& pp : P) for (size_t M = 0; M < 3; ++M) term(pp->f + (pp->ko[M] + 1) * 32, pp->nk[M] - 1, sh.ch_g[3 * pp->j + M]);
     RC(lincomb_any(c, pg, n_k, cg, terms, lens, co, s));
   }
-  RC(fr_divide_by_linear(c, gq, evd + (ne + 2) * 32, pg, n_k, gamma.l, s));
+  {                                                                                          // both witness polynomials in the same three launches
+    void* q[2] = {wq, gq}; void* ev2[2] = {evd + (ne + 1) * 32, evd + (ne + 2) * 32}; const void* pp[2] = {pbeta, pg}; const size_t nn[2] = {3 * N, n_k}; const void* zz[2] = {beta.l, gamma.l};
+    RC(fr_divide_by_linear_many(c, q, ev2, pp, nn, zz, 2, s));
+  }
   {
     std::vector<MsmSeg>& sg = job[0].segs; sg.assign(3, MsmSeg{});
     sg[0].d_ptr = wq; sg[0].len = 3 * N - 1; sg[0].off = 0; sg[0].out = 0;
@@ -869,7 +868,7 @@ int32_t varuna_prove_batch(Ctx* c, const PinnedBases& pb, const aleo_mi355x_varu
   Batch b(c, pb, seed32); std::vector<Batch*> one{&b}; hipStream_t s = c->stream;
   RC(b.setup(ixs, m, ks));
   RC(reserve_prover_memory(c, b.need_ws_bytes, b.need_pin_bytes));
-  b.attach((char*)c->prover_ws.p, c->prover_ws.cap, (char*)c->prover_pin);
+  RC(b.attach((char*)c->prover_ws.p, c->prover_ws.cap, (char*)c->prover_pin));
   RC(b.first_prepare(assignments)); RC(run_commits(c, pb, one, s)); RC(b.first_finish());
   RC(b.second_prepare()); RC(run_commits(c, pb, one, s)); RC(b.second_finish());
   RC(b.third_prepare()); RC(run_commits(c, pb, one, s)); RC(b.third_finish());
@@ -910,7 +909,7 @@ int32_t varuna_prove_many(Ctx* c, const PinnedBases& pb, std::vector<ProveReques
   for (size_t p = 0; p < n; ++p) {
     if (!alive[p]) continue;
     const size_t w = (B[p]->need_ws_bytes + 255) & ~(size_t)255, h = (B[p]->need_pin_bytes + 255) & ~(size_t)255;
-    B[p]->attach((char*)c->prover_ws.p + ws_at, w, (char*)c->prover_pin + pin_at); ws_at += w; pin_at += h;
+    RC(B[p]->attach((char*)c->prover_ws.p + ws_at, w, (char*)c->prover_pin + pin_at)); ws_at += w; pin_at += h;
   }
   Barrier bar(W); int32_t fatal = ALEO_MI355X_OK; std::string fatal_error;      // fatal: written by worker 0 between two barriers, read by all after the second
   // the commitments of one round, by worker 0 while the others wait: the helper streams' events first (their kernels wrote this round's scalars)

@@ -76,3 +76,9 @@ class EvaluationDomain:
         """`batch` contiguous transforms of this domain's size in one call."""
         check(lib().aleo_mi355x_ntt_fr_batch_device(ctypes.c_void_p(d_ptr), self.log_size_of_group, batch, order, direction, type_,
                                                     ctypes.c_void_p(stream)), 'ntt_fr_batch_device')
+
+    def ntt_from_device(self, d_out: int, d_src: int, src_stride: int, src_len: int, batch: int = 1, direction=FORWARD, type_=STANDARD, stream: int = 0):
+        """Out of place with a zero-padded input (EvaluationDomain::fft of polynomials with fewer coefficients than the domain): transform b reads
+        src_len elements at d_src + b * src_stride * 32 and writes this domain's size to d_out + b * size * 32."""
+        check(lib().aleo_mi355x_ntt_fr_from_device(ctypes.c_void_p(d_out), ctypes.c_void_p(d_src), src_stride, src_len, self.log_size_of_group, batch, direction, type_,
+                                                   ctypes.c_void_p(stream)), 'ntt_fr_from_device')

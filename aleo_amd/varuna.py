@@ -250,7 +250,7 @@ class _NativeIndex(ctypes.Structure):
     """aleo_mi355x_varuna_index (include/aleo_mi355x.h)."""
     _fields_ = ([(n, ctypes.c_uint64) for n in ('n_h', 'n_k_a', 'n_k_b', 'n_k_c', 'n_x', 'n_public', 'n_vars', 'committer_key', 'max_degree', 'gamma_offset', 'lagrange_offset')] +
                 [(n, ctypes.c_void_p) for n in ('positions', 'positions_device', 'a_row_ptr', 'a_col', 'a_val', 'b_row_ptr', 'b_col', 'b_val', 't_row_ptr', 't_col', 't_val',
-                                                'vx_inv', 'k_evals', 'k_idx', 'k_polys', 'k2_evals', 'vk_bytes')] + [('vk_len', ctypes.c_size_t), ('vk_affine', ctypes.c_void_p)])
+                                                'vx_inv', 'k_evals', 'k_idx', 'k_polys', 'k2_evals', 'vk_bytes')] + [('vk_len', ctypes.c_size_t), ('vk_affine', ctypes.c_void_p), ('max_row', ctypes.c_uint64 * 3)])
 
 
 def native_index(ix: CircuitIndex) -> _NativeIndex:
@@ -269,6 +269,8 @@ def native_index(ix: CircuitIndex) -> _NativeIndex:
         rp, col, val = ix.fwd[m]
         setattr(n, m + '_row_ptr', rp.data_ptr()); setattr(n, m + '_col', col.data_ptr()); setattr(n, m + '_val', val.ptr())
     n.t_row_ptr, n.t_col, n.t_val = ix.tr[0].data_ptr(), ix.tr[1].data_ptr(), ix.tr[2].ptr()
+    for i, rp in enumerate((ix.fwd['a'][0], ix.fwd['b'][0], ix.tr[0])):          # hints: the longest row of each sparse product (the prover skips launches that cannot have work)
+        n.max_row[i] = max(1, int((rp[1:] - rp[:-1]).max().item())) if rp.numel() > 1 else 1
     n.vx_inv, n.k_evals, n.k_idx, n.k_polys, n.k2_evals = ix.vx_inv.ptr(), ix.k_evals.ptr(), ix.k_idx.data_ptr(), ix.k_polys.ptr(), ix.k2_evals.ptr()
     ix._native = n
     return n

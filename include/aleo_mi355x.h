@@ -68,6 +68,11 @@ extern "C" {
 #define ALEO_NTT_STANDARD 0
 #define ALEO_NTT_COSET 1      /* coset shift g = Fr::multiplicative_generator() = 22 */
 
+/* ENVIRONMENT (set by the HOST before its first HIP call; the library never edits the process environment): GPU_MAX_HW_QUEUES=8 is recommended.  The HIP
+ * runtime maps a process's streams onto that many hardware queues (4 by default) and reads the variable once, when it initialises; the library runs a
+ * caller's stream, a side stream, high-priority streams and the lockstep prover's worker streams at once (lockstep proofs -5 % with 8 queues, everything
+ * else within noise; results never depend on it).  aleo_amd/__init__.py and bench.py set it as their own default; INTEGRATION.md 4 shows the Rust side. */
+
 /* initialises the first n_devices visible devices (0 = all of them).  Idempotent, thread-safe; the calling thread's current
  * HIP device is left as it was.  Every single-device entry point below works on the CALLING THREAD's current HIP device (hipSetDevice is per
  * thread) and initialises it lazily if neither init call was made.  init_device selects and initialises one device (-1 = the current one).
@@ -121,8 +126,10 @@ int32_t aleo_mi355x_bases_info(uint64_t handle, uint64_t* out, int32_t cap);
 /* Copies pinned bases [offset, offset+n) back to the host as snarkVM Affine (stride 104). */
 int32_t aleo_mi355x_bases_download(uint64_t handle, size_t offset, size_t n, void* out_affine104);
 /* MSM over the first n pinned bases; scalars: host pointer (pageable memory is fine: the upload runs at the link's rate either way).  Against a set with
- * window tables, from 2^19 points on (ALEO_MI355X_MERGE_MIN_LG), the scalars go up in two halves on two of the device's contexts — the second half's upload
- * and sort run under the first half's accumulation — and the two halves' bucket sums are merged before ONE reduction; the result does not depend on it. */
+ * window tables, from 2^19 points on (ALEO_MI355X_MERGE_MIN_LG), the scalars go up and through in 2 chunks of 37 / 63 % (3 of 18 / 30 / 52 % from 2^21
+ * points, ALEO_MI355X_CHUNKS3_MIN_LG) on contexts of their own: a later chunk's upload and sort run under the previous chunk's accumulation, each
+ * accumulation is SEEDED with the bucket sums of the chunk before it (no merge kernel), and ONE bucket reduction follows the last chunk; the result
+ * does not depend on it. */
 int32_t aleo_mi355x_msm_g1_pinned(void* out_jacobian, uint64_t handle, const void* scalars, size_t n);
 /* Same, scalars already resident in device memory (hipMalloc'ed or a torch CUDA tensor's data_ptr).
  * The result (144 bytes) is written to HOST memory.  `stream` (here and in every *_device entry point) is a hipStream_t;
@@ -164,6 +171,11 @@ int32_t aleo_mi355x_ntt_fr_device(void* d_inout, uint32_t lg_n, int32_t order, i
 /* `batch` independent transforms of 2^lg_n elements each, contiguous in d_inout (the local row / column transforms of a
  * transform sharded over several GPUs, SURVEY.md §8e "4-step"; also one call for the polynomials of a prover round). */
 int32_t aleo_mi355x_ntt_fr_batch_device(void* d_inout, uint32_t lg_n, size_t batch, int32_t order, int32_t direction, int32_t type, void* stream);
+/* The same OUT OF PLACE with a zero-padded input (natural order in and out): transform b reads element i from d_src + (b * src_stride + i) * 32 for
+ * i < src_len <= 2^lg_n and takes 0 beyond, and writes its 2^lg_n values to d_out + b * 2^lg_n * 32.  EvaluationDomain::fft of a polynomial of fewer
+ * coefficients than the domain (snarkVM resizes the coefficient vector with zeros first: `coeffs.resize(self.size(), F::zero())` in fft / coset_fft); the
+ * padding costs no launch and no HBM traffic here — the first pass simply does not read past src_len.  d_out must not overlap the source. */
+int32_t aleo_mi355x_ntt_fr_from_device(void* d_out, const void* d_src, size_t src_stride, size_t src_len, uint32_t lg_n, size_t batch, int32_t direction, int32_t type, void* stream);
 /* Factors over a rows x cols block (row-major, in place) of the index space of the size-2^lg_n domain:
  *   mode 0: x[r][c] *= w^((row0 + r) * (col0 + c))   — the twiddle between the two axes of a 4-step transform
  *   mode 1: x[r][c] *= g^((row0 + r) * ld + col0 + c) — the coset shift (g = 22) of a block of the coefficient matrix
@@ -359,6 +371,8 @@ typedef struct {
   const void *vx_inv, *k_evals, *k_idx, *k_polys, *k2_evals;
   const void* vk_bytes; size_t vk_len;
   const void* vk_affine;             /* the twelve index commitments as 104-byte G1Affine (what the transcript absorbs); may be NULL: decompressed from vk_bytes per proof */
+  uint64_t max_row[3];               /* hints (0 = unknown): an upper bound of the longest row of a_*, b_*, t_* — the prover skips the launches for long (> 64) / huge (> 8192) rows of a
+                                      * sparse product that cannot have any (index_build fills them; a caller-built struct may leave them 0) */
 } aleo_mi355x_varuna_index;
 /* The index built by the library itself from the R1CS (AHPForR1CS::index shape: the arithmetisation above + the twelve index commitments)
  * and kept in HBM under a handle.  Matrices: CSR over the variables (uint32 row_ptr[n_constraints + 1], uint32 col[nnz] = variable index
@@ -453,7 +467,7 @@ int32_t aleo_mi355x_selftest_g2pair(const void* affine192, uint32_t n_points, ui
 /* Per-call instrumentation of the calling thread's most recent MSM: milliseconds per phase
  * [0] total, [1] digit/sort, [2] bucket accumulation incl. slice tree, [3] bucket reduction, [4] host tail,
  * [5] the bucket-accumulation kernel alone (the dominant kernel bench.py prices against the roofline): mean duration of its launches,
- * [6] how many launches of it the call made (2 when host scalars went up in two halves that share one reduction, else 1).
+ * [6] how many launches of it the call made (2 or 3 when host scalars went up in chunks whose accumulations are seeded from one another and share one reduction, else 1).
  * Returns the number of doubles written (<= cap). */
 int32_t aleo_mi355x_last_msm_timing(double* out_ms, int32_t cap);
 

@@ -88,6 +88,37 @@ def test_ntt_matches_oracle_all_variants(lg):
             assert (d.ntt(x, 0, direction, type_) == c.ntt_fr(x, 0, direction, type_)).all(), (lg, direction, type_)
 
 
+@pytest.mark.parametrize('lg,batch,src_len,stride', [(3, 2, 5, 7), (9, 3, 128, 128), (11, 4, 2047, 2048), (13, 3, 2048, 4096), (15, 2, 1 << 13, 1 << 13), (17, 3, 1 << 15, 1 << 15),
+                                                     (17, 1, 1 << 17, 1 << 17), (16, 16, 1 << 14, 1 << 14), (19, 2, 1 << 18, 1 << 18), (20, 1, (1 << 18) + 3, 1 << 19),
+                                                     (21, 1, 1 << 20, 1 << 20), (23, 1, 1 << 21, 1 << 21), (10, 2, 0, 0)])
+def test_ntt_from_zero_padded_source_matches_oracle(lg, batch, src_len, stride):
+    """aleo_mi355x_ntt_fr_from_device: out of place, the input zero-padded from src_len to the domain (EvaluationDomain::fft on a shorter coefficient vector),
+    on every kernel family (one pass, latency tiles, 64-lane tiles, 29-bit 72 / 144 KiB tiles, three passes) against the restatement fed the padded vector."""
+    import torch
+    n = 1 << lg
+    src = c.fr_to_mont(util.uniform_scalars(max(1, (batch - 1) * stride + src_len), 4100 + lg))
+    d_src = torch.from_numpy(src.view(np.int64)).cuda()
+    d_out = torch.full((batch * n, 4), -1, dtype=torch.int64, device='cuda')
+    dom = aleo_amd.EvaluationDomain(n)
+    for direction, type_ in ((0, 0), (0, 1), (1, 0), (1, 1)) if lg <= 17 else ((0, 0), (1, 1)):
+        d_out.fill_(-1)
+        dom.ntt_from_device(d_out.data_ptr(), d_src.data_ptr(), stride, src_len, batch, direction, type_, stream=torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        got = d_out.cpu().numpy().view(np.uint64)
+        for b in range(batch):
+            x = np.zeros((n, 4), dtype=np.uint64); x[:src_len] = src[b * stride:b * stride + src_len]
+            assert (got[b * n:(b + 1) * n] == c.ntt_fr(x, 0, direction, type_)).all(), (lg, b, direction, type_)
+    assert (d_src.cpu().numpy().view(np.uint64) == src).all()          # the source is only read
+
+
+def test_ntt_from_rejects_overlap_and_bad_sizes():
+    import torch
+    buf = torch.zeros((1 << 12, 4), dtype=torch.int64, device='cuda')
+    dom = aleo_amd.EvaluationDomain(1 << 10)
+    with pytest.raises(aleo_amd.AleoMi355xError): dom.ntt_from_device(buf.data_ptr(), buf.data_ptr() + 32 * 512, 1024, 1024)        # output overlaps the source
+    with pytest.raises(aleo_amd.AleoMi355xError): dom.ntt_from_device(buf.data_ptr(), buf.data_ptr() + 32 * 2048, 1024, 1025)       # more coefficients than the domain
+
+
 def _extreme_fr(n, kind):
     """Raw 32-byte values that push the lazy sums of the 29-bit-limb butterflies (fr29.h) to their bounds: the largest canonical number everywhere,
     alternating with zero, or in one half only."""
