@@ -3,16 +3,28 @@
 #include "ctx.h"
 #include "host_field.hpp"
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <memory>
 #include <thread>
 #include <functional>
 #include <vector>
+#include <deque>
 
 namespace aleo_mi355x {
 
 thread_local std::string g_last_error;
 thread_local MsmTiming g_last_msm;
+
+bool g_host_trace_on = [] { const char* e = std::getenv("ALEO_MI355X_HOSTTRACE"); return e && e[0] == '1'; }();
+namespace { thread_local std::vector<std::pair<const char*, double>> g_host_trace; }
+void host_trace_mark(const char* label) {
+  const double t = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
+  if (label) { g_host_trace.emplace_back(label, t); return; }
+  // nullptr: print and clear
+  for (size_t i = 0; i < g_host_trace.size(); ++i) fprintf(stderr, "hosttrace %9.1f us  +%7.1f  %s\n", g_host_trace[i].second - g_host_trace[0].second, i ? g_host_trace[i].second - g_host_trace[i - 1].second : 0.0, g_host_trace[i].first);
+  g_host_trace.clear();
+}
 
 static std::mutex g_dev_mu;
 static std::map<int, Device*> g_devs;
@@ -131,24 +143,27 @@ static int32_t acquire_slot(Device* d, Ctx** out, std::unique_lock<std::mutex>& 
 }
 
 // A context of device d for work done on behalf of a call that already holds `exclude` (a slot of the same device, or nullptr): free slots first, then
-// helper contexts, never `exclude` itself — the holder is waiting for this work.  Blocks only when everything else is taken.
-static int32_t acquire_other(Device* d, const Ctx* exclude, Ctx** out, std::unique_lock<std::mutex>& lk) {
-  Ctx* c = nullptr;
-  for (int i = 0; i < d->n_slots && !c; ++i) {
-    if (&d->slots[i] == exclude) continue;
-    std::unique_lock<std::mutex> t(d->slots[i].mu, std::try_to_lock);
-    if (t.owns_lock()) { lk = std::move(t); c = &d->slots[i]; }
+// helper contexts, never `exclude` itself — the holder is waiting for this work.  It never blocks on ONE context: the contexts of the caller's own device
+// may all be held by workers of the very call this work belongs to (a lockstep call parked at its round barrier, waiting for the commitment this shard is
+// part of — the round-4 form blocked on helpers[hash(tid) % 8] and could deadlock there).  `may_wait`: poll all of them until one is free (another device:
+// whoever holds its contexts is an independent call and will finish); otherwise *out stays nullptr and the caller lends its own context (commit_sharded).
+static int32_t acquire_other(Device* d, const Ctx* exclude, Ctx** out, std::unique_lock<std::mutex>& lk, bool may_wait) {
+  Ctx* c = nullptr; *out = nullptr;
+  for (;;) {
+    for (int i = 0; i < d->n_slots && !c; ++i) {
+      if (&d->slots[i] == exclude) continue;
+      std::unique_lock<std::mutex> t(d->slots[i].mu, std::try_to_lock);
+      if (t.owns_lock()) { lk = std::move(t); c = &d->slots[i]; }
+    }
+    for (int i = 0; i < MAX_SLOTS && !c; ++i) {
+      if (&d->helpers[i] == exclude) continue;
+      std::unique_lock<std::mutex> t(d->helpers[i].mu, std::try_to_lock);
+      if (t.owns_lock()) { lk = std::move(t); c = &d->helpers[i]; }
+    }
+    if (c || !may_wait) break;
+    std::this_thread::sleep_for(std::chrono::microseconds(50));
   }
-  for (int i = 0; i < MAX_SLOTS && !c; ++i) {
-    if (&d->helpers[i] == exclude) continue;
-    std::unique_lock<std::mutex> t(d->helpers[i].mu, std::try_to_lock);
-    if (t.owns_lock()) { lk = std::move(t); c = &d->helpers[i]; }
-  }
-  if (!c) {
-    size_t i = std::hash<std::thread::id>()(std::this_thread::get_id()) % (size_t)MAX_SLOTS;
-    if (&d->helpers[i] == exclude) i = (i + 1) % MAX_SLOTS;
-    lk = std::unique_lock<std::mutex>(d->helpers[i].mu); c = &d->helpers[i];
-  }
+  if (!c) return ALEO_MI355X_OK;
   if (hipSetDevice(d->device) != hipSuccess) { g_last_error = "hipSetDevice failed"; return ALEO_MI355X_ERR_HIP; }
   { const int32_t rc = first_use(c); if (rc) return rc; }
   *out = c; return ALEO_MI355X_OK;
@@ -1117,26 +1132,59 @@ std::shared_ptr<ShardedSet> sharded_find(uint64_t h) {
   if (it == g_sh.end()) { g_last_error = "unknown sharded handle"; return nullptr; }
   return it->second;
 }
-// runs f(g) for every shard on its own thread with that shard's device current; the first failure's code and text come back
-template <class F> int32_t for_each_shard(const ShardedSet& S, F&& f) {
+// Shard work runs on LONG-LIVED worker threads, one per (device, ordinal among the shards a call lists on that device): created on first use, bound to their
+// device once, parked on a condition variable between calls.  (Rounds 3-4 started G std::threads per call: every commitment of a proof against a sharded key
+// paid G thread creations — on one card 8 shards cost +19 % per 2^20-constraint proof.)  The pool is never destroyed: its threads are detached and sleep until
+// the process ends.  Submission is serialised (g_pool_submit_mu) so that every worker's queue holds the calls in ONE global order — two calls whose shard bodies
+// meet at barriers cannot interleave into a deadlock.
+struct ShardWorker {
+  std::mutex mu; std::condition_variable cv; std::deque<std::function<void()>> q; int device = -1; bool started = false;
+  void loop() {
+    (void)hipSetDevice(device);                              // a failure shows up again in the task (it sets the device itself and reports)
+    for (;;) {
+      std::function<void()> job;
+      { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return !q.empty(); }); job = std::move(q.front()); q.pop_front(); }
+      job();
+    }
+  }
+};
+std::mutex g_pool_mu, g_pool_submit_mu; std::map<std::pair<int, size_t>, ShardWorker*> g_pool;
+ShardWorker* shard_worker(int device, size_t ordinal) {
+  std::lock_guard<std::mutex> lk(g_pool_mu);
+  auto it = g_pool.find({device, ordinal});
+  if (it != g_pool.end()) return it->second;
+  ShardWorker* w = new ShardWorker(); w->device = device;      // leaked on purpose: lives as long as the process
+  std::thread([w] { w->loop(); }).detach();                    // (throws std::system_error if no thread can be started: caught by the entry point's try)
+  w->started = true; g_pool[{device, ordinal}] = w; return w;
+}
+// runs f(g) for every shard on that shard's worker with its device current and waits for all of them; the first failure's code and text come back.
+// on_skip(g): called for a shard whose body could not run (its device could not be selected, an exception) — a body that meets the other shards at barriers
+// passes one that drops the shard from them.
+template <class F> int32_t for_each_shard(const ShardedSet& S, F&& f, std::function<void(size_t)> on_skip = nullptr) {
   const size_t G = S.devices.size();
   std::vector<int32_t> rcs(G, ALEO_MI355X_OK); std::vector<std::string> errs(G);
-  // the threads wait at a gate until all of them exist (f may meet the other shards at barriers): if one cannot be started, none runs
-  std::vector<std::thread> th; th.reserve(G); std::mutex gate_mu; std::condition_variable gate_cv; int gate = 0;      // 0 wait, 1 go, -1 leave
-  bool started = true;
-  for (size_t g = 0; g < G && started; ++g) {
-    auto body = [&, g]() {
-      { std::unique_lock<std::mutex> lk(gate_mu); gate_cv.wait(lk, [&] { return gate != 0; }); if (gate < 0) return; }
-      try {
-        if (hipSetDevice(S.devices[g]) != hipSuccess) { rcs[g] = ALEO_MI355X_ERR_HIP; errs[g] = "hipSetDevice failed"; return; }
-        rcs[g] = f(g); if (rcs[g]) errs[g] = g_last_error;
-      } catch (...) { rcs[g] = ALEO_MI355X_ERR_HIP; errs[g] = "exception in a shard"; }
-    };
-    try { th.emplace_back(body); } catch (...) { started = false; }
+  std::vector<ShardWorker*> ws(G); std::vector<size_t> ordinal(G, 0);
+  for (size_t g = 0; g < G; ++g) for (size_t e = 0; e < g; ++e) ordinal[g] += S.devices[e] == S.devices[g];
+  try { for (size_t g = 0; g < G; ++g) ws[g] = shard_worker(S.devices[g], ordinal[g]); }
+  catch (...) { g_last_error = "could not start a shard's thread"; return ALEO_MI355X_ERR_HIP; }      // nothing was queued: none runs
+  std::mutex done_mu; std::condition_variable done_cv; size_t done = 0;
+  {
+    std::lock_guard<std::mutex> order(g_pool_submit_mu);
+    for (size_t g = 0; g < G; ++g) {
+      auto body = [&, g]() {
+        bool ran = false;
+        try {
+          if (hipSetDevice(S.devices[g]) != hipSuccess) { rcs[g] = ALEO_MI355X_ERR_HIP; errs[g] = "hipSetDevice failed"; }
+          else { ran = true; rcs[g] = f(g); if (rcs[g]) errs[g] = g_last_error; }
+        } catch (...) { rcs[g] = ALEO_MI355X_ERR_HIP; errs[g] = "exception in a shard"; ran = false; }
+        if (!ran && on_skip) { try { on_skip(g); } catch (...) {} }
+        { std::lock_guard<std::mutex> lk(done_mu); ++done; } done_cv.notify_one();
+      };
+      { std::lock_guard<std::mutex> lk(ws[g]->mu); ws[g]->q.emplace_back(std::move(body)); }
+      ws[g]->cv.notify_one();
+    }
   }
-  { std::lock_guard<std::mutex> lk(gate_mu); gate = started ? 1 : -1; } gate_cv.notify_all();
-  for (auto& t : th) t.join();
-  if (!started) { g_last_error = "could not start a shard's thread"; return ALEO_MI355X_ERR_HIP; }
+  { std::unique_lock<std::mutex> lk(done_mu); done_cv.wait(lk, [&] { return done == G; }); }
   for (size_t g = 0; g < G; ++g) if (rcs[g]) { g_last_error = "shard " + std::to_string(g) + " (device " + std::to_string(S.devices[g]) + "): " + errs[g]; return rcs[g]; }
   return ALEO_MI355X_OK;
 }
@@ -1251,11 +1299,13 @@ int32_t commit_sharded(Ctx* c, uint64_t sharded_handle, const MsmSeg* segs, uint
     const size_t lo = segs[q].off > S->first[g] ? segs[q].off : S->first[g], hi = segs[q].off + segs[q].len < S->first[g] + S->count[g] ? segs[q].off + segs[q].len : S->first[g] + S->count[g];
     busy[g] = hi > lo;
   }
+  std::mutex lend_mu;                                         // shards that find no free context on the caller's device take turns on the caller's own (idle while it waits here)
   const int32_t rc = for_each_shard(*S, [&](size_t g) -> int32_t {
     uint64_t* mine = &part[(size_t)18 * k * g];
     if (!busy[g]) { for (uint32_t q = 0; q < k; ++q) host::hstore_jacobian_normalized(mine + 18 * q, host::HXYZZ::infinity()); return ALEO_MI355X_OK; }
-    Device* d = nullptr; Ctx* cc = nullptr; std::unique_lock<std::mutex> lk;
-    { int32_t r = get_device(&d); if (r) return r; if ((r = acquire_other(d, c, &cc, lk))) return r; }
+    Device* d = nullptr; Ctx* cc = nullptr; std::unique_lock<std::mutex> lk, lend;
+    { int32_t r = get_device(&d); if (r) return r; if ((r = acquire_other(d, c, &cc, lk, d->device != home))) return r; }
+    if (!cc) { lend = std::unique_lock<std::mutex>(lend_mu); cc = c; }      // (only on the home device: every other context there may belong to this very call)
     std::shared_ptr<PinnedOwner> keep; PinnedBases pb; { const int32_t r = find_bases(d, S->handles[g], &keep, &pb); if (r) return r; }
     std::vector<MsmSeg> sub; size_t total = 0;
     for (uint32_t q = 0; q < nseg; ++q) {
@@ -1380,9 +1430,10 @@ int32_t aleo_mi355x_ntt_fr_sharded(void* inout, uint32_t lg_n, int32_t direction
     }
     std::vector<NttShard> sh(G);
     char* host = (char*)inout;
-    // One thread per shard for the whole call (the runtime's current device is per thread); the three phases are separated by barriers, so no peer
-    // copy starts before every column transform has finished and no buffer is overwritten before its reader is done.  A shard that fails keeps
-    // meeting the barriers (the others must not hang) and the first failure is returned.
+    // One worker thread per shard for the whole call (the runtime's current device is per thread; the workers are the persistent ones of for_each_shard);
+    // the three phases are separated by barriers, so no peer copy starts before every column transform has finished and no buffer is overwritten
+    // before its reader is done.  A shard that fails keeps meeting the barriers (the others must not hang) and the first failure is returned; a shard
+    // that cannot even start, or leaves by an exception, is dropped from the barriers (Barrier::drop).
     Barrier bar(G); std::atomic<int> failed{0};
     rc = for_each_shard(S, [&](size_t g) -> int32_t {
       NttShard& d = sh[g]; int32_t r = ALEO_MI355X_OK; std::string err;
@@ -1421,8 +1472,107 @@ int32_t aleo_mi355x_ntt_fr_sharded(void* inout, uint32_t lg_n, int32_t direction
       if (d.st) (void)hipStreamSynchronize(d.st);              // whatever happened, nothing of this call is left on the shard's stream
       if (r) g_last_error = err;
       return r;
-    });
+    }, [&](size_t) { failed.store(1); bar.drop(); });          // a shard whose body never ran, or left by an exception, stops counting at the barriers: the others finish (and fail) instead of hanging
     return rc;
+  } catch (...) { return ALEO_MI355X_ERR_HIP; }
+}
+
+}  // extern "C"
+namespace aleo_mi355x {
+// ---- the same 4-step transform on data that is RESIDENT on the calling thread's device ("home"): row e2, a proof whose transforms span devices -----------
+// n = R * C elements in natural order at d_inout on home.  Home (the caller's context and stream) transposes x[R][C] into T[C][R] in a scratch of its own
+// (coset: g^j applied first, in place), so that shard g's coefficient columns are ONE contiguous slab T[g Cg .. (g + 1) Cg][R]:
+//   phase 1  device g pulls its slab (hipMemcpyPeerAsync; same device: a plain copy), runs its Cg column transforms of length R, multiplies by w_n^(c k_r)
+//            and cuts the result into G blocks by k_r range
+//   phase 2  the exchange: device h pulls block h of every device (one peer copy per ordered pair — the all-to-all of SURVEY.md 8(e) over xGMI)
+//   phase 3  device h transposes to rows k_r, runs its Rg row transforms of length C and pushes the [Rg][C] block back into home's scratch at row h Rg
+// and home transposes the scratch [R][C] (k_r major) into d_inout [C][R] = X[k_c R + k_r], natural order (coset inverse: g^-o n^-1 fix-up in place).
+// No host buffer anywhere.  Shard work runs on the persistent shard workers with contexts taken by acquire_other (never the caller's `c`, never blocking on one
+// context: the caller may be a prover that holds `c` for the whole proof).  Blocking: the result is complete when the call returns.
+int32_t ntt_sharded_device(Ctx* c, void* d_inout, uint32_t lg_n, int32_t direction, int32_t type, const int* devices, size_t n_devices, hipStream_t s) {
+  if (!d_inout || lg_n < 2 || lg_n > 30 || direction < 0 || direction > 1 || type < 0 || type > 1) { g_last_error = "ntt_fr_sharded_device: bad argument"; return ALEO_MI355X_ERR_BAD_ARG; }
+  if (n_devices < 1 || n_devices > 64 || (n_devices & (n_devices - 1))) { g_last_error = "ntt_fr_sharded_device: the number of shards must be a power of two (1..64)"; return ALEO_MI355X_ERR_BAD_ARG; }
+  uint32_t lg_g = 0; while ((1u << lg_g) < n_devices) ++lg_g;
+  const uint32_t lg_r = lg_n / 2, lg_c = lg_n - lg_r;
+  if (lg_r < lg_g) { g_last_error = "ntt_fr_sharded_device: domain too small for this many shards"; return ALEO_MI355X_ERR_BAD_ARG; }
+  std::vector<int32_t> devs(devices, devices + n_devices);
+  ShardedSet S; int32_t rc = sharded_layout(S, (size_t)1 << lg_n, devs.data(), n_devices); if (rc) return rc;
+  const size_t G = n_devices, n = (size_t)1 << lg_n, R = (size_t)1 << lg_r, C = (size_t)1 << lg_c, Rg = R / G, Cg = C / G, per = R * Cg;
+  const int home = c->device;
+  std::lock_guard<std::mutex> one(g_ntt_sh_mu);
+  {
+    int cur = home;
+    for (size_t g = 0; g < G; ++g) { Device* dd = nullptr; if ((rc = init_device(S.devices[g], &dd))) { (void)hipSetDevice(cur); return rc; } }
+    (void)hipSetDevice(cur);
+  }
+  enable_peer_access();
+  if ((rc = c->dev->shard_home.reserve(n * 32))) return rc;
+  char* T = c->dev->shard_home.as<char>(); char* x = (char*)d_inout;
+  if (type == ALEO_NTT_COSET && direction == ALEO_NTT_FORWARD && (rc = fr_grid_scale(c, x, lg_n, R, C, 0, 0, C, 1, 0, s))) return rc;      // x[j] *= g^j
+  if ((rc = fr_transpose(c, T, x, R, C, s))) return rc;                                                                                      // T[c][r]
+  HIPCHK(hipStreamSynchronize(s));
+  std::vector<NttShard> sh(G); std::vector<size_t> ordinal(G, 0);
+  for (size_t g = 0; g < G; ++g) for (size_t e = 0; e < g; ++e) ordinal[g] += S.devices[e] == S.devices[g];
+  Barrier bar(G); std::atomic<int> failed{0};
+  rc = for_each_shard(S, [&](size_t g) -> int32_t {
+    NttShard& d = sh[g]; int32_t r = ALEO_MI355X_OK; std::string err;
+    Device* dv = nullptr; Ctx* cc = nullptr; std::unique_lock<std::mutex> lk;
+    auto phase = [&](const std::function<int32_t()>& f) { if (!r && !failed.load()) { r = f(); if (r) { err = g_last_error; failed.store(1); } } bar.wait(); };
+    phase([&]() -> int32_t {
+      int32_t q = get_device(&dv); if (q) return q;
+      if ((q = acquire_other(dv, c, &cc, lk, true))) return q;
+      if ((q = shard_ws(ordinal[g], per * 32, &d))) return q;
+      if ((q = peer_copy(d.b, d.dev, T + g * Cg * R * 32, home, per * 32, d.st))) return q;                                                  // b = [Cg][R]: my columns
+      if ((q = ntt_run(cc, d.b, lg_r, Cg, ALEO_NTT_ORDER_NN, direction, ALEO_NTT_STANDARD, d.st))) return q;                                 // [c][k_r] (inverse: x R^-1)
+      if ((q = fr_grid_scale(cc, d.b, lg_n, Cg, R, g * Cg, 0, 0, 0, direction, d.st))) return q;                                             // *= w_n^(+-c k_r)
+      for (size_t h = 0; h < G; ++h)                                                                                                        // a = [h][Cg][Rg]
+        HIPCHK(hipMemcpy2DAsync((char*)d.a + h * Cg * Rg * 32, Rg * 32, (char*)d.b + h * Rg * 32, R * 32, Rg * 32, Cg, hipMemcpyDeviceToDevice, d.st));
+      HIPCHK(hipStreamSynchronize(d.st));
+      return ALEO_MI355X_OK;
+    });
+    phase([&]() -> int32_t {
+      for (size_t k = 0; k < G; ++k) { const size_t e = (g + k) % G; const int32_t q = peer_copy((char*)d.b + e * Cg * Rg * 32, d.dev, (char*)sh[e].a + g * Cg * Rg * 32, sh[e].dev, Cg * Rg * 32, d.st); if (q) return q; }
+      HIPCHK(hipStreamSynchronize(d.st));
+      return ALEO_MI355X_OK;
+    });
+    phase([&]() -> int32_t {
+      int32_t q;
+      if ((q = fr_transpose(cc, d.a, d.b, C, Rg, d.st))) return q;                                                                           // a = [Rg][C]
+      if ((q = ntt_run(cc, d.a, lg_c, Rg, ALEO_NTT_ORDER_NN, direction, ALEO_NTT_STANDARD, d.st))) return q;                                 // [k_r][k_c] (inverse: x C^-1)
+      if ((q = peer_copy(T + g * Rg * C * 32, home, d.a, d.dev, per * 32, d.st))) return q;                                                  // home scratch [R][C], k_r major (T is dead: every slab was pulled before the first barrier)
+      HIPCHK(hipStreamSynchronize(d.st));
+      return ALEO_MI355X_OK;
+    });
+    if (d.st) (void)hipStreamSynchronize(d.st);
+    if (r) g_last_error = err;
+    return r;
+  }, [&](size_t) { failed.store(1); bar.drop(); });
+  if (rc) return rc;
+  if (hipSetDevice(home) != hipSuccess) { g_last_error = "hipSetDevice failed"; return ALEO_MI355X_ERR_HIP; }
+  if ((rc = fr_transpose(c, x, T, R, C, s))) return rc;                                                                                      // x[k_c][k_r] = X[k_c R + k_r]
+  if (type == ALEO_NTT_COSET && direction == ALEO_NTT_INVERSE && (rc = fr_grid_scale(c, x, lg_n, C, R, 0, 0, R, 1, 1, s))) return rc;        // g^-o (the n^-1 of the inverse came with the two batched transforms)
+  HIPCHK(hipStreamSynchronize(s));
+  return ALEO_MI355X_OK;
+}
+// the devices of a sharded base set (the prover routes its large transforms over the devices its committer key is spread over)
+int32_t sharded_devices(uint64_t sharded_handle, std::vector<int>* out) {
+  auto S = sharded_find(sharded_handle); if (!S) return ALEO_MI355X_ERR_BAD_HANDLE;
+  *out = S->devices; return ALEO_MI355X_OK;
+}
+}  // namespace aleo_mi355x
+extern "C" {
+
+int32_t aleo_mi355x_ntt_fr_sharded_device(void* d_inout, uint32_t lg_n, int32_t direction, int32_t type, const int32_t* devices, size_t n_devices, void* stream) {
+  try {
+    if (!devices && n_devices > 1) {                         // NULL: the first n_devices visible devices, cyclically
+      int count = 0; if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) { g_last_error = "no HIP device visible"; return ALEO_MI355X_ERR_NO_DEVICE; }
+      std::vector<int32_t> dv(n_devices); for (size_t g = 0; g < n_devices; ++g) dv[g] = (int32_t)(g % (size_t)count);
+      return aleo_mi355x_ntt_fr_sharded_device(d_inout, lg_n, direction, type, dv.data(), n_devices, stream);
+    }
+    int32_t one = 0; if (!devices) { if (hipGetDevice(&one) != hipSuccess) one = 0; devices = &one; }
+    API_BEGIN
+    PICK_STREAM(s)
+    return ntt_sharded_device(c, d_inout, lg_n, direction, type, (const int*)devices, n_devices, s);
   } catch (...) { return ALEO_MI355X_ERR_HIP; }
 }
 

@@ -138,7 +138,13 @@ struct Barrier {                                           // reusable; C++17 ha
   explicit Barrier(size_t n_) : n(n_) {}
   void wait() {
     std::unique_lock<std::mutex> lk(mu); const size_t ph = phase;
-    if (++waiting == n) { waiting = 0; ++phase; cv.notify_all(); } else cv.wait(lk, [&] { return phase != ph; });
+    if (++waiting >= n) { waiting = 0; ++phase; cv.notify_all(); } else cv.wait(lk, [&] { return phase != ph; });
+  }
+  // a party that leaves for good (it failed before or between the phases): the others stop waiting for it, now and at every later phase
+  void drop() {
+    std::lock_guard<std::mutex> lk(mu);
+    if (n) --n;
+    if (n && waiting >= n) { waiting = 0; ++phase; cv.notify_all(); }
   }
 };
 
@@ -157,6 +163,7 @@ struct Device {
   std::atomic<int> ntt_attr_mask{0};   // which NTT kernel instances had their LDS limit raised on THIS device
   Ctx slots[MAX_SLOTS];
   std::vector<std::unique_ptr<ShardWs>> shard_ws;     // grown under mu; used only by the one sharded transform in flight (api.hip g_ntt_sh_mu)
+  DevBuf shard_home;                   // ntt_sharded_device: the home device's transposed copy of the data (n elements), same lock
   Ctx helpers[MAX_SLOTS];              // extra streams + scratch a lockstep call borrows for its worker threads (never handed out as API slots)
 };
 // Borrows up to `want` idle helper contexts of the device (try-lock: none is waited for); they are released when `hs` goes out of scope.
@@ -164,6 +171,11 @@ struct HelperSet { std::vector<Ctx*> ctx; std::vector<std::unique_lock<std::mute
 int32_t acquire_helpers(Device* d, int want, HelperSet& hs);
 
 extern thread_local MsmTiming g_last_msm;   // phase times of the calling thread's most recent MSM
+// Host-side trace of one proof (ALEO_MI355X_HOSTTRACE=1): labelled timestamps of the calling thread, printed to stderr by varuna_prove_batch — where the
+// host spends the turn-arounds between a commitment's last kernel and the next round's first (tools/proof_timeline_full.py shows the GPU's side of the same gaps).
+void host_trace_mark(const char* label);
+#define HT(label) do { if (::aleo_mi355x::g_host_trace_on) ::aleo_mi355x::host_trace_mark(label); } while (0)
+extern bool g_host_trace_on;
 int32_t ensure_host_pinned(Ctx* c, size_t bytes);
 
 // msm.hip
@@ -183,6 +195,9 @@ int32_t msm_batch(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, const MsmJ
 // the G x k partial results are added on the host in shard order.  `s` (the stream the scalars were produced on) is synchronised first when s_drain; the results are
 // normalised exactly like msm_batch's, so the bytes equal the single-device call's.  `c` is the caller's slot: shard work never waits for it.
 int32_t commit_sharded(Ctx* c, uint64_t sharded_handle, const MsmSeg* segs, uint32_t nseg, uint32_t k, bool mont, uint64_t* out_jac18, hipStream_t s, bool s_drain);
+// api.hip: one transform of 2^lg_n elements resident at d_inout on the caller's device, computed over the listed devices (4-step, peer copies, no host buffer); blocking
+int32_t ntt_sharded_device(Ctx* c, void* d_inout, uint32_t lg_n, int32_t direction, int32_t type, const int* devices, size_t n_devices, hipStream_t s);
+int32_t sharded_devices(uint64_t sharded_handle, std::vector<int>* out);      // the device list of a sharded base set
 // One result over n points, scalars on the device (host_src == nullptr) or still on the host (then d_scalars is ignored and the scalars are uploaded into the
 // contexts' staging buffers): host scalars from 2^19 points on go in two halves on two contexts that share one bucket reduction — msm.hip msm_run1_split
 int32_t msm_run1_split(Ctx* c, uint64_t* out_jac18, const PinnedBases& pb, const void* d_scalars, size_t n, bool mont, hipStream_t s, bool sparse, const void* host_src, bool may_merge = true);

@@ -1319,13 +1319,16 @@ static int32_t msm_back(Ctx* c, uint64_t* out_jac18, Front& f, hipStream_t s, bo
     if (fire_tail && c->tail_hook) {
       // the caller's next kernels go behind the fold; the host waits for the fold only (its result sits in pinned memory) and does the tail below while they run
       std::function<int32_t()> hook = std::move(c->tail_hook); c->tail_hook = nullptr;
+      HT("msm: reduction queued");
       const int32_t hrc = hook();
+      HT("msm: hook queued");
       HIPCHK(hipEventSynchronize(c->ev[3]));
       if (hrc) { (void)hipStreamSynchronize(s); return hrc; }
     } else if (enqueued) HIPCHK(hipEventSynchronize(c->ev[3]));      // (other chains' work may already be queued behind it on other streams; this chain's is all in front of ev[3])
     else HIPCHK(hipStreamSynchronize(s));
     if (aside) HIPCHK(hipEventSynchronize(c->ev[4]));
     HIPCHK(hipGetLastError());
+    HT("msm: result arrived");
     t_host0 = std::chrono::steady_clock::now();
     HXYZZ totals[MAX_SETS];
     for (uint32_t q = 0; q < K; ++q) {
@@ -1344,7 +1347,9 @@ static int32_t msm_back(Ctx* c, uint64_t* out_jac18, Front& f, hipStream_t s, bo
       for (int bit = 31 - __builtin_clz(wgt); bit >= 0; --bit) { acc = hdouble(acc); if ((wgt >> bit) & 1u) acc = hadd(acc, T); }
       totals[q] = hadd(totals[q], acc);
     }
+    HT("msm: horner done");
     hstore_jacobian_normalized_batch(out_jac18, totals, K);          // one shared inversion for the K results
+    HT("msm: normalised");
   } else {
     HXYZZ total = HXYZZ::infinity();
     hipLaunchKernelGGL(k_bucket_chunks_plain, dim3((nchunks + 255) / 256), dim3(256), 0, s, partial, hist, scan_local, scan_blk, P.B, P.S, nchunks, V);

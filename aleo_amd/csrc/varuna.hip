@@ -865,17 +865,22 @@ static int32_t run_commits(Ctx* c, const PinnedBases& pb, std::vector<Batch*>& b
 int32_t varuna_prove_batch(Ctx* c, const PinnedBases& pb, const aleo_mi355x_varuna_index* const* ixs, size_t m, const void* const* assignments, const size_t* ks,
                            const uint8_t* seed32, uint8_t* out, size_t* out_len) {
   g_varuna_timing[6] = g_varuna_timing[7] = 0;
+  HT("prove: enter");
   Batch b(c, pb, seed32); std::vector<Batch*> one{&b}; hipStream_t s = c->stream;
   RC(b.setup(ixs, m, ks));
   RC(reserve_prover_memory(c, b.need_ws_bytes, b.need_pin_bytes));
   RC(b.attach((char*)c->prover_ws.p, c->prover_ws.cap, (char*)c->prover_pin));
-  RC(b.first_prepare(assignments)); RC(run_commits(c, pb, one, s)); RC(b.first_finish());
-  RC(b.second_prepare()); RC(run_commits(c, pb, one, s)); RC(b.second_finish());
-  RC(b.third_prepare()); RC(run_commits(c, pb, one, s)); RC(b.third_finish());
-  RC(b.fourth_prepare()); RC(run_commits(c, pb, one, s)); RC(b.fourth_finish());
-  RC(b.open_evaluate()); HIPCHK(hipStreamSynchronize(s)); RC(b.open_prepare()); RC(run_commits(c, pb, one, s));
+  HT("prove: setup done");
+  RC(b.first_prepare(assignments)); HT("r1 prepared"); RC(run_commits(c, pb, one, s)); HT("r1 committed"); RC(b.first_finish()); HT("r1 transcript");
+  RC(b.second_prepare()); HT("r2 prepared"); RC(run_commits(c, pb, one, s)); HT("r2 committed"); RC(b.second_finish()); HT("r2 transcript");
+  RC(b.third_prepare()); HT("r3 prepared"); RC(run_commits(c, pb, one, s)); HT("r3 committed"); RC(b.third_finish()); HT("r3 transcript");
+  RC(b.fourth_prepare()); HT("r4 prepared"); RC(run_commits(c, pb, one, s)); HT("r4 committed"); RC(b.fourth_finish()); HT("r4 transcript");
+  RC(b.open_evaluate()); HT("evals queued"); HIPCHK(hipStreamSynchronize(s)); HT("evals arrived"); RC(b.open_prepare()); HT("open prepared"); RC(run_commits(c, pb, one, s)); HT("open committed");
   b.sh.t_mark[5] = now_ms();
-  return b.write(out, out_len);
+  const int32_t wrc = b.write(out, out_len);
+  HT("proof written");
+  if (g_host_trace_on) host_trace_mark(nullptr);
+  return wrc;
 }
 
 // Several INDEPENDENT proofs in lockstep (aleo_mi355x_varuna_prove_many): every proof keeps its own transcript, challenges, randomness and workspace

@@ -113,7 +113,7 @@ class ShardedDomain:
     `exchange(blocks) -> blocks` performs the all-to-all (default: torch.distributed.all_to_all_single on `group`);
     `ops` performs the local steps (default: the HIP library)."""
 
-    def __init__(self, lg_n: int, rank: int, world: int, ops=None, group=None, lg_rows: int = None, exchange=None):
+    def __init__(self, lg_n: int, rank: int, world: int, ops=None, group=None, lg_rows: int = None, exchange=None, always_collective: bool = False):
         if world & (world - 1): raise ValueError('world size must be a power of two')
         lg_g = world.bit_length() - 1
         self.lg_n, self.rank, self.world, self.group = lg_n, rank, world, group
@@ -124,6 +124,8 @@ class ShardedDomain:
         self.Rg, self.Cg = self.R // world, self.C // world
         self.ops = ops if ops is not None else HipLocalOps()
         self.exchange = exchange                 # tests: exchange(send[world, ...], rank) -> recv, instead of torch.distributed
+        self.always_collective = always_collective      # a world of one rank still calls torch.distributed.all_to_all_single (how a one-GPU box runs the RCCL launch)
+        self.collective_calls = 0                # all_to_all_single calls made so far
 
     # -- layouts (host helpers for tests / loading) --------------------------------------------------------------
     def coefficient_shard(self, x_full: np.ndarray) -> np.ndarray:
@@ -143,7 +145,7 @@ class ShardedDomain:
         import torch
         import torch.distributed as dist
         send = send.contiguous()
-        if self.world == 1: return send
+        if self.world == 1 and not self.always_collective: return send
         if self.exchange is not None: return self.exchange(send, self.rank)
         if send.is_cuda and dist.get_backend(self.group) == 'gloo':      # rehearsal backend: stage through the host
             h = send.cpu(); r = torch.empty_like(h)
@@ -151,6 +153,7 @@ class ShardedDomain:
             return r.to(send.device)
         recv = torch.empty_like(send)
         dist.all_to_all_single(recv, send, group=self.group)                # RCCL over xGMI
+        self.collective_calls += 1
         return recv
 
     # -- transforms -----------------------------------------------------------------------------------------------------

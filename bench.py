@@ -44,6 +44,7 @@ def main():
     ap.add_argument('--varuna-cpu-lg', type=int, default=10, help='size at which the CPU restatement of the prover is timed and the device proof verified (cpu_baseline leg)')
     ap.add_argument('--concurrent-callers', type=int, default=4, help='secondary: aggregate rate with this many caller threads (0/1 = skip)')
     ap.add_argument('--sharded-ntt-lg', type=int, default=24, help='size of the secondary sharded-NTT measurement at N > 1 (stderr)')
+    ap.add_argument('--config4-lg', type=int, default=26, help='at N > 1 (default --config 1 run): log2 of the ONE MSM of BASELINE configs[4] that is also split over the ranks and reported as config4_2^K in the same line (0 = skip)')
     ap.add_argument('--aux-sharded-ntt', action='store_true', help=argparse.SUPPRESS)
     ap.add_argument('--in-process', action='store_true',
                     help='with --config 4 and no launcher: ONE process drives --gpus N device contexts through aleo_mi355x_msm_g1_sharded (the visible devices are listed cyclically when there are fewer than N)')
@@ -189,6 +190,13 @@ def main():
             del d_ws
         del d_scalars
 
+    cfg4 = None
+    if world > 1 and not strong and args.config4_lg:
+        # BASELINE configs[4] in the driver's plain `--gpus N` line: ONE 2^26-point MSM split over the ranks (strong scaling), after the weak-scaling steps
+        pb.close(); pb = None
+        cfg4 = config4_split(aleo_amd, synth, adist, dist, torch, rank, world, gather_dev, barrier, args.config4_lg, args.backend, no_precompute=args.no_precompute)
+        pb = aleo_amd.PinnedBases.generate_multiples(gen, first, n)
+        if not args.no_precompute: pb.precompute()
     replicas = None
     if world > 1 and args.varuna_lg:
         replicas = prove_replicas(synth, dist, args.varuna_lg, world, gather_dev, barrier)      # every rank takes part in its collectives, whatever happens locally
@@ -236,6 +244,7 @@ def main():
         out['roofline']['valu'] = {'fq_products_per_launch': 10.0 * rows_ * n / launches, 'achieved': 10.0 * rows_ * n / launches / ak / 1e9, 'peak': 81.0, 'unit': 'G Fq products/s',
                                    'frac': 10.0 * rows_ * n / launches / ak / 81e9, 'what': '%d windows x 10 products per mixed addition x points; zero digits (1 in 2^20) not subtracted' % rows_}
         if replicas is not None: out['prove_replicas'] = replicas
+        if cfg4 is not None: out['config4_2^%d' % args.config4_lg] = cfg4
         if world == 1 and args.concurrent_callers > 1:
             out['concurrent_callers'] = concurrent_callers(aleo_amd, synth, torch, dev, pb, n, args.concurrent_callers)
         if world == 1 and not args.no_kzg_chain:
@@ -291,6 +300,42 @@ def main():
                     print(line[-1] if line else json.dumps({'aux': 'sharded_ntt', 'error': 'probe exited with %d' % r.returncode, 'stderr_tail': r.stderr[-400:]}), file=sys.stderr, flush=True)
             except subprocess.TimeoutExpired:
                 print(json.dumps({'aux': 'sharded_ntt', 'error': 'timeout: the probe did not finish within 150 s (child killed)', 'rank': rank}), file=sys.stderr, flush=True)
+
+
+def config4_split(aleo_amd, synth, adist, dist, torch, rank, world, gather_dev, barrier, lg_total, backend, steps=3, no_precompute=False):
+    """BASELINE configs[4] inside the default multi-rank run: one MSM of 2^lg_total points, rank r owning the contiguous shard adist.shard_range gives it
+    (P_i = (i + 1) G generated in its HBM, fixed-base tables built), host scalars uploaded inside every timed step, the 144-byte partials all-gathered
+    (RCCL when backend is nccl) and added in rank order.  Every rank runs it (collectives inside); returns the dict rank 0 reports: whole-MSM time = max over
+    the ranks of the barrier-to-barrier time, each rank's own time per step, and the result gate (k G in big integers)."""
+    import numpy as np
+    total = 1 << lg_total
+    lo, hi = adist.shard_range(total, rank, world); n = hi - lo
+    if n * 13 >= (1 << 32): return {'error': '%d points per rank exceed one launch chain (2^32 (bucket, point) pairs): more ranks needed' % n}
+    pb4 = aleo_amd.PinnedBases.generate_multiples(synth.generator_affine104(), lo + 1, n)
+    try:
+        if not no_precompute: pb4.precompute()
+        sc = synth.uniform_scalars(n, 0xA1E00004 + rank)                   # SURVEY 8d: seed 0xA1E00000 + config id (+ rank: every shard its own stream)
+        gather = adist.PartialGather(world, gather_dev)
+        def step(): return aleo_amd.g1_sum(gather(aleo_amd.VariableBase.msm(pb4, sc)))
+        res = step(); mine = []
+        barrier(); t0 = time.perf_counter()
+        for _ in range(steps):
+            t1 = time.perf_counter(); part = aleo_amd.VariableBase.msm(pb4, sc); mine.append(time.perf_counter() - t1)
+            res = aleo_amd.g1_sum(gather(part))
+        barrier(); el = time.perf_counter() - t0
+        t = torch.tensor([el, float(np.mean(mine))], dtype=torch.float64, device=gather_dev if gather_dev is not None else 'cpu')
+        per = torch.zeros((world, 2), dtype=torch.float64, device=t.device)
+        dist.all_gather_into_tensor(per.view(-1), t)
+        per = per.cpu().numpy(); el_max = float(per[:, 0].max())
+        k = synth.weighted_scalar_sum(sc, lo + 1)
+        ks = gather(synth.int_to_limbs(k, 4)); k = sum(synth.limbs_to_int(row) for row in ks) % synth.FR_MODULUS
+        ok = bool(result_is_multiple_of_generator(synth, res, k))
+        return {'workload': '2^%d-point BLS12-377 G1 Pippenger MSM split over %d ranks (BASELINE configs[4]), host scalars uploaded inside the step' % (lg_total, world),
+                'ms': el_max / steps * 1e3, 'scalar_muls_per_s': total * steps / el_max, 'per_rank_msm_ms': [float(x) * 1e3 for x in per[:, 1]], 'points_per_rank': n,
+                'steps': steps, 'scaling': 'strong', 'rccl_ranks': (dist.get_world_size() if backend == 'nccl' else 0), 'backend': backend,
+                'result_is_k_times_generator': ok}
+    finally:
+        pb4.close()
 
 
 def spawn_ranks(n: int) -> int:
@@ -352,10 +397,15 @@ def launch_check(args) -> int:
     el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
     if world > 1: dist.all_reduce(el, op=dist.ReduceOp.MAX)
     ok = [int(r[0]) for r in np.asarray(rows).reshape(world, 18)] == list(range(1, world + 1))
+    # the extra exchange of config4_split (the per-rank times of the 2^26-point MSM the default N > 1 run also reports): an all-gather of two doubles per rank
+    per = torch.zeros((world, 2), dtype=torch.float64)
+    if world > 1: dist.all_gather_into_tensor(per.view(-1), torch.tensor([float(rank), 1.0], dtype=torch.float64))
+    cfg4_ok = world == 1 or [float(x) for x in per[:, 0]] == [float(r) for r in range(world)]
+    ok = ok and cfg4_ok
     if rank == 0:
         print(json.dumps({'metric': 'launch check (no arithmetic)', 'value': None, 'unit': 'scalar-muls/s', 'n_gpus': world, 'ranks': dist.get_world_size() if world > 1 else 1,
                           'rccl_ranks': 0, 'backend': args.backend, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': float(el.item()) / max(args.steps, 1) * 1e3,
-                          'gather_in_rank_order': ok, 'launch_check': True}), flush=True)
+                          'gather_in_rank_order': ok, 'config4_per_rank_gather': cfg4_ok, 'launch_check': True}), flush=True)
     if world > 1: dist.barrier(); dist.destroy_process_group()
     return 0 if ok else 1
 

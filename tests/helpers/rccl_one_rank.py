@@ -1,7 +1,9 @@
 """Child process of test_rccl_runs_the_exchange_with_one_rank: a world of ONE rank under backend 'nccl' (= RCCL on ROCm) on the visible MI355X.  One rank
 is all a one-GPU box allows (RCCL refuses two ranks on one device), but it is the real library: communicator creation, the all-gather of the 144-byte
 partial (aleo_amd.dist.PartialGather — the exchange of the point-sharded MSM), the MAX all-reduce of bench.py's timing and the all-to-all of the 4-step
-transform (ShardedDomain with world 1) all launch RCCL kernels on the card.  Prints one JSON line."""
+transform (ShardedDomain with world 1 and always_collective=True: torch.distributed.all_to_all_single under 'nccl' is really called — until round 5 a world of
+one returned before it) all launch RCCL kernels on the card.  The transform's values are compared with the CPU restatement (oracle), forward and inverse, plain
+and coset.  Prints one JSON line."""
 import os, sys, json
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, ROOT)
 import numpy as np, torch
@@ -20,12 +22,18 @@ with aleo_amd.PinnedBases.generate_multiples(synth.generator_affine104(), 1, n) 
     out['gathered_equals_partial'] = bool((np.asarray(rows).reshape(-1)[:18] == np.asarray(part).reshape(-1)).all())
     out['sum_equals_partial'] = bool((aleo_amd.g1_sum(rows) == part).all())
 t = torch.tensor([3.25, 1.0], dtype=torch.float64, device=dev); dist.all_reduce(t, op=dist.ReduceOp.MAX); out['all_reduce_max'] = float(t[0].item())
-lg = 12; x = synth.uniform_scalars(1 << lg, 99)
-dom = adist.ShardedDomain(lg, 0, 1)
-mine = torch.from_numpy(dom.coefficient_shard(x).view(np.int64).copy()).to(dev)
-ev = dom.forward(mine.clone()); torch.cuda.synchronize()
-full = torch.from_numpy(x.view(np.int64).copy()).to(dev); aleo_amd.EvaluationDomain(1 << lg).ntt_device(full.data_ptr(), 0, 0, 0, adist._torch_stream_handle()); torch.cuda.synchronize()
-idx = torch.from_numpy(dom.evaluation_indices()).to(dev)
-out['sharded_ntt_matches'] = bool((ev == full[idx]).all())
+from oracle import coracle as orc                            # the checker (CPU restatement), never the thing that runs
+lg = 12; x = orc.fr_to_mont(synth.uniform_scalars(1 << lg, 99))
+dom = adist.ShardedDomain(lg, 0, 1, always_collective=True)
+idx = dom.evaluation_indices(); ok = True
+for coset in (False, True):
+    mine = torch.from_numpy(dom.coefficient_shard(x).view(np.int64).copy()).to(dev)
+    ev = dom.forward(mine.clone(), coset=coset); torch.cuda.synchronize()
+    want = orc.ntt_fr(x, 0, 0, 1 if coset else 0)            # natural order, forward, standard / coset
+    ok = ok and bool((ev.cpu().numpy().view(np.uint64) == want[idx]).all())
+    back = dom.inverse(ev, coset=coset); torch.cuda.synchronize()
+    ok = ok and bool((back.cpu().numpy().view(np.uint64) == dom.coefficient_shard(x)).all())
+out['sharded_ntt_matches_oracle'] = ok
+out['all_to_all_single_calls'] = dom.collective_calls
 dist.barrier(); dist.destroy_process_group()
 print(json.dumps(out), flush=True)

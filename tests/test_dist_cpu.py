@@ -124,6 +124,7 @@ def test_bench_starts_its_own_ranks_without_a_launcher():
     assert len(lines) == 1, r.stdout
     out = json.loads(lines[0])
     assert out['n_gpus'] == 2 and out['ranks'] == 2 and out['gather_in_rank_order'] and out['value'] is None
+    assert out['config4_per_rank_gather'] is True          # the per-rank exchange of the 2^26-point MSM the default N > 1 run also reports (config4_split)
 
 
 @pytest.mark.timeout(300)

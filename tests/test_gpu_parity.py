@@ -963,12 +963,14 @@ def test_bench_spawns_two_ranks_on_one_card_without_a_launcher():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_PORT')}
     r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--backend', 'gloo', '--lg-n', '12', '--steps', '2', '--warmup', '1', '--no-variants',
-                        '--no-cpu-baseline', '--varuna-lg', '0', '--sharded-ntt-lg', '0'], env=env, capture_output=True, text=True, timeout=900)
+                        '--no-cpu-baseline', '--varuna-lg', '0', '--sharded-ntt-lg', '0', '--config4-lg', '14'], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
     assert len(lines) == 1, r.stdout
     out = json.loads(lines[0])
     assert out['n_gpus'] == 2 and out['ranks'] == 2 and out['rccl_ranks'] == 0 and out['backend'] == 'gloo' and out['value'] > 0
+    c4 = out['config4_2^14']                                   # BASELINE configs[4] (here 2^14 points) split over the two ranks, in the same line
+    assert c4['result_is_k_times_generator'] is True and c4['points_per_rank'] == 1 << 13 and c4['scaling'] == 'strong' and len(c4['per_rank_msm_ms']) == 2 and c4['scalar_muls_per_s'] > 0
     L = aleo_amd.lib()
     on, off = ctypes.c_int32(-1), ctypes.c_int32(-1)
     assert L.aleo_mi355x_init(0) == 0 and L.aleo_mi355x_init(0) == 0 and L.aleo_mi355x_peer_info(ctypes.byref(on), ctypes.byref(off)) == 0
@@ -980,15 +982,17 @@ def test_bench_spawns_two_ranks_on_one_card_without_a_launcher():
 def test_rccl_runs_the_exchange_with_one_rank():
     """backend='nccl' is RCCL on ROCm.  A one-GPU box cannot hold two RCCL ranks (one device per rank), so until round 4 every rehearsal of the N > 1 path ran
     under gloo and RCCL itself had never executed.  This runs the real library with a world of one rank: the all-gather of the 144-byte partial, the MAX
-    all-reduce of the timing and the all-to-all of the sharded transform are RCCL launches on the card (tests/helpers/rccl_one_rank.py, a child process:
-    the process group must not leak into this one)."""
+    all-reduce of the timing and the all-to-all of the sharded transform (ShardedDomain(always_collective=True): all_to_all_single is called, counted, and the
+    values compared with the CPU restatement) are RCCL launches on the card (tests/helpers/rccl_one_rank.py, a child process: the process group must not leak
+    into this one)."""
     import subprocess, sys, socket
     s_ = socket.socket(); s_.bind(('127.0.0.1', 0)); port = s_.getsockname()[1]; s_.close()
     env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE')}
     r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'helpers', 'rccl_one_rank.py'), str(port)], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
     out = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
-    assert out == {'backend': 'nccl', 'world': 1, 'gathered_equals_partial': True, 'sum_equals_partial': True, 'all_reduce_max': 3.25, 'sharded_ntt_matches': True}, out
+    assert out == {'backend': 'nccl', 'world': 1, 'gathered_equals_partial': True, 'sum_equals_partial': True, 'all_reduce_max': 3.25, 'sharded_ntt_matches_oracle': True,
+                   'all_to_all_single_calls': 4}, out      # 4: forward and inverse, plain and coset — each one torch.distributed.all_to_all_single under 'nccl'
 
 
 def test_config4_full_size_as_eight_shards_in_one_process():

@@ -928,6 +928,34 @@ def test_proofs_against_a_sharded_committer_key_equal_the_single_device_proofs(G
 
 
 @pytest.mark.gpu
+def test_lockstep_with_every_context_taken_and_a_sharded_key_makes_progress():
+    """Round-4 advisor finding: a shard thread of commit_sharded that found no free context on the prover's device blocked on ONE helper context, which a worker
+    of the same lockstep call — parked at the round barrier, waiting for that very commitment — could hold: a deadlock with 8 lockstep workers, 8 shards on one
+    device and a second caller.  Now such a shard borrows the caller's own context (idle while it waits).  Eight workers, the key as 8 shards of the one card,
+    two caller threads at once: both calls must return the frozen proofs within the time limit."""
+    import threading
+    from aleo_amd import varuna
+    tau, sg, cases = _golden_cases()
+    case = cases[0]; csr, zs, c = _golden_instance(case)
+    zq = [np.stack([synth.int_to_limbs(v, 4) for v in q]) for q in zs]
+    ck = varuna.synthetic_committer_key(tau, sg, case['max_degree']); sb = _shard_the_key(ck, [0] * 8)
+    keep = os.environ.get('ALEO_MI355X_LOCKSTEP_WORKERS'); os.environ['ALEO_MI355X_LOCKSTEP_WORKERS'] = '8'
+    try:
+        with varuna.NativeCircuitIndex(csr, case['n_constraints'], case['n_public'], len(zs[0]) - case['n_public'], ck, domains=case['domains']) as nx:
+            got = [None, None]
+            def call(i): got[i] = varuna.prove_many_native([([nx], [zq], case['proof_seed'])] * 8)
+            th = [threading.Thread(target=call, args=(i,), daemon=True) for i in range(2)]
+            for t in th: t.start()
+            for t in th: t.join(timeout=240)
+            assert not any(t.is_alive() for t in th), 'a lockstep call against a sharded key hangs when every context of the device is taken'
+            assert got[0] == [bytes.fromhex(case['proof'])] * 8 and got[1] == got[0]
+    finally:
+        if keep is None: os.environ.pop('ALEO_MI355X_LOCKSTEP_WORKERS', None)
+        else: os.environ['ALEO_MI355X_LOCKSTEP_WORKERS'] = keep
+        ck.bases.attach_shards(None); sb.close(); ck.close()
+
+
+@pytest.mark.gpu
 def test_a_2_18_constraint_proof_against_a_sharded_key():
     """The size the sharding is for: 2^18 constraints (|K_A| = 2^20: commitments of up to 2^20 points), two instances, the key's 2^21 powers as 4 shards
     with their own window tables — and only commitments of >= 2^16 points routed to them (min_points), the small ones stay on the prover's device.
