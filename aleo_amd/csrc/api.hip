@@ -26,6 +26,40 @@ void host_trace_mark(const char* label) {
   g_host_trace.clear();
 }
 
+// ---- a small persistent pool for host-side loops -------------------------------------------------------------------------------------------------------
+namespace {
+struct HostPool {
+  static constexpr int T = 3;
+  std::mutex mu; std::condition_variable cv_work, cv_done; const std::function<void(size_t)>* f = nullptr; size_t n = 0; std::atomic<size_t> next{0}; int active = 0; uint64_t gen = 0; bool started = false;
+  std::mutex call_mu;                                       // one parallel loop at a time (concurrent callers fall back to their own thread)
+  void worker() {
+    uint64_t seen = 0;
+    for (;;) {
+      const std::function<void(size_t)>* fn; size_t cnt;
+      { std::unique_lock<std::mutex> lk(mu); cv_work.wait(lk, [&] { return gen != seen; }); seen = gen; fn = f; cnt = n; }
+      for (size_t i; (i = next.fetch_add(1)) < cnt;) (*fn)(i);
+      { std::lock_guard<std::mutex> lk(mu); if (--active == 0) cv_done.notify_all(); }
+    }
+  }
+};
+HostPool* g_host_pool = nullptr; std::once_flag g_host_pool_once;
+}  // namespace
+void host_parallel_for(size_t n, const std::function<void(size_t)>& f) {
+  if (n < 4) { for (size_t i = 0; i < n; ++i) f(i); return; }
+  std::call_once(g_host_pool_once, [] {
+    HostPool* p = new HostPool();                            // leaked on purpose: its threads sleep until the process ends
+    try { for (int t = 0; t < HostPool::T; ++t) std::thread([p] { p->worker(); }).detach(); p->started = true; } catch (...) { p->started = false; }
+    g_host_pool = p;
+  });
+  HostPool* p = g_host_pool;
+  std::unique_lock<std::mutex> one(p->call_mu, std::try_to_lock);
+  if (!p->started || !one.owns_lock()) { for (size_t i = 0; i < n; ++i) f(i); return; }
+  { std::lock_guard<std::mutex> lk(p->mu); p->f = &f; p->n = n; p->next.store(0); p->active = HostPool::T; ++p->gen; }
+  p->cv_work.notify_all();
+  for (size_t i; (i = p->next.fetch_add(1)) < n;) f(i);
+  { std::unique_lock<std::mutex> lk(p->mu); p->cv_done.wait(lk, [&] { return p->active == 0; }); }
+}
+
 static std::mutex g_dev_mu;
 static std::map<int, Device*> g_devs;
 
@@ -361,6 +395,35 @@ template <class F> static int32_t run_enqueue(Ctx* c, void* stream, F&& f) {
   return ALEO_MI355X_OK;
 }
 
+namespace {      // aleo_mi355x_selftest_host_inverse
+template <int N> void inverse_selftest(uint32_t count, uint64_t seed, uint32_t* failures, double* ns) {
+  using F = host::HFp<N>; using Pm = host::HParams<N>;
+  std::vector<F> v;
+  auto from_canon = [](const uint64_t* c) { F x; std::memcpy(x.l, c, sizeof x.l); return x; };
+  { uint64_t e[N]; std::memset(e, 0, sizeof e); v.push_back(from_canon(e)); e[0] = 1; v.push_back(from_canon(e)); e[0] = 2; v.push_back(from_canon(e));
+    std::memcpy(e, Pm::P, sizeof e); e[0] -= 1; v.push_back(from_canon(e)); e[0] -= 1; v.push_back(from_canon(e)); }
+  uint64_t st = seed * 0x9e3779b97f4a7c15ull + N;
+  auto next = [&]() { st += 0x9e3779b97f4a7c15ull; uint64_t z = st; z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull; z = (z ^ (z >> 27)) * 0x94d049bb133111ebull; return z ^ (z >> 31); };
+  for (uint32_t i = 0; i < count; ++i) {
+    F x; for (int k = 0; k < N; ++k) x.l[k] = next();
+    x.l[N - 1] &= (1ull << (N == 4 ? 60 : 56)) - 1;        // below the modulus' top limb: a valid residue
+    if (i % 7 == 3) { for (int k = 1; k < N; ++k) x.l[k] = 0; }      // short values too
+    v.push_back(x);
+  }
+  std::vector<F> a(v.size()), b(v.size());
+  auto t0 = std::chrono::steady_clock::now();
+  for (size_t i = 0; i < v.size(); ++i) a[i] = F::inv(v[i]);
+  auto t1 = std::chrono::steady_clock::now();
+  for (size_t i = 0; i < v.size(); ++i) b[i] = F::inv_fermat(v[i]);
+  auto t2 = std::chrono::steady_clock::now();
+  for (size_t i = 0; i < v.size(); ++i) {
+    bool ok = a[i] == b[i];
+    if (ok && !v[i].is_zero()) ok = F::mul(a[i], v[i]) == F::one();      // and it IS the inverse
+    if (!ok) ++*failures;
+  }
+  if (ns) { ns[0] = std::chrono::duration<double, std::nano>(t1 - t0).count() / v.size(); ns[1] = std::chrono::duration<double, std::nano>(t2 - t1).count() / v.size(); }
+}
+}  // namespace
 extern "C" {
 
 int32_t aleo_mi355x_init_device(int32_t device) {
@@ -1112,6 +1175,15 @@ const char* aleo_mi355x_strerror(int32_t status) {
 static size_t env_size(const char* name, size_t dflt) { const char* e = std::getenv(name); if (!e || !*e) return dflt; char* end = nullptr; const unsigned long long v = std::strtoull(e, &end, 10); return end && *end == 0 ? (size_t)v : dflt; }
 size_t aleo_mi355x_min_msm(void) { return env_size("ALEO_MI355X_MIN_MSM", (size_t)1 << 10); }
 size_t aleo_mi355x_min_ntt(void) { return env_size("ALEO_MI355X_MIN_NTT", (size_t)1 << 12); }
+int32_t aleo_mi355x_selftest_host_inverse(uint32_t count, uint64_t seed, uint32_t* failures, double* ns_per_inverse) {
+  try {
+    if (!failures) { g_last_error = "selftest_host_inverse: bad argument"; return ALEO_MI355X_ERR_BAD_ARG; }
+    *failures = 0;
+    inverse_selftest<6>(count, seed, failures, ns_per_inverse);
+    inverse_selftest<4>(count, seed, failures, ns_per_inverse ? ns_per_inverse + 2 : nullptr);
+    return ALEO_MI355X_OK;
+  } catch (...) { return ALEO_MI355X_ERR_HIP; }
+}
 const char* aleo_mi355x_last_error(void) { return g_last_error.c_str(); }
 const char* aleo_mi355x_version(void) { return "aleo_mi355x 0.2.0 (gfx950)"; }
 
@@ -1178,7 +1250,7 @@ template <class F> int32_t for_each_shard(const ShardedSet& S, F&& f, std::funct
           else { ran = true; rcs[g] = f(g); if (rcs[g]) errs[g] = g_last_error; }
         } catch (...) { rcs[g] = ALEO_MI355X_ERR_HIP; errs[g] = "exception in a shard"; ran = false; }
         if (!ran && on_skip) { try { on_skip(g); } catch (...) {} }
-        { std::lock_guard<std::mutex> lk(done_mu); ++done; } done_cv.notify_one();
+        { std::lock_guard<std::mutex> lk(done_mu); ++done; done_cv.notify_one(); }      // notified under the lock: the waiter cannot return (and destroy the condition variable) before the call is over
       };
       { std::lock_guard<std::mutex> lk(ws[g]->mu); ws[g]->q.emplace_back(std::move(body)); }
       ws[g]->cv.notify_one();
@@ -1513,14 +1585,22 @@ int32_t ntt_sharded_device(Ctx* c, void* d_inout, uint32_t lg_n, int32_t directi
   HIPCHK(hipStreamSynchronize(s));
   std::vector<NttShard> sh(G); std::vector<size_t> ordinal(G, 0);
   for (size_t g = 0; g < G; ++g) for (size_t e = 0; e < g; ++e) ordinal[g] += S.devices[e] == S.devices[g];
-  Barrier bar(G); std::atomic<int> failed{0};
+  Barrier bar(G); std::atomic<int> failed{0}; std::mutex lend_mu;
   rc = for_each_shard(S, [&](size_t g) -> int32_t {
     NttShard& d = sh[g]; int32_t r = ALEO_MI355X_OK; std::string err;
-    Device* dv = nullptr; Ctx* cc = nullptr; std::unique_lock<std::mutex> lk;
     auto phase = [&](const std::function<int32_t()>& f) { if (!r && !failed.load()) { r = f(); if (r) { err = g_last_error; failed.store(1); } } bar.wait(); };
-    phase([&]() -> int32_t {
+    // A context of this shard's device for the kernels of ONE phase (their scratch), given back before the barrier.  Never the caller's `c` — unless nothing else on
+    // the home device is free: every other context there may be held by workers of the very call this transform belongs to (a lockstep proof), so a shard then
+    // takes turns on `c`, which is idle while its owner waits here (the same rule as commit_sharded).  Every phase ends with its stream drained.
+    auto with_ctx = [&](const std::function<int32_t(Ctx*)>& f) -> int32_t {
+      Device* dv = nullptr; Ctx* cc = nullptr; std::unique_lock<std::mutex> lk, lend;
       int32_t q = get_device(&dv); if (q) return q;
-      if ((q = acquire_other(dv, c, &cc, lk, true))) return q;
+      if ((q = acquire_other(dv, c, &cc, lk, dv->device != home))) return q;
+      if (!cc) { lend = std::unique_lock<std::mutex>(lend_mu); cc = c; }
+      return f(cc);
+    };
+    phase([&]() -> int32_t { return with_ctx([&](Ctx* cc) -> int32_t {
+      int32_t q;
       if ((q = shard_ws(ordinal[g], per * 32, &d))) return q;
       if ((q = peer_copy(d.b, d.dev, T + g * Cg * R * 32, home, per * 32, d.st))) return q;                                                  // b = [Cg][R]: my columns
       if ((q = ntt_run(cc, d.b, lg_r, Cg, ALEO_NTT_ORDER_NN, direction, ALEO_NTT_STANDARD, d.st))) return q;                                 // [c][k_r] (inverse: x R^-1)
@@ -1529,20 +1609,20 @@ int32_t ntt_sharded_device(Ctx* c, void* d_inout, uint32_t lg_n, int32_t directi
         HIPCHK(hipMemcpy2DAsync((char*)d.a + h * Cg * Rg * 32, Rg * 32, (char*)d.b + h * Rg * 32, R * 32, Rg * 32, Cg, hipMemcpyDeviceToDevice, d.st));
       HIPCHK(hipStreamSynchronize(d.st));
       return ALEO_MI355X_OK;
-    });
+    }); });
     phase([&]() -> int32_t {
       for (size_t k = 0; k < G; ++k) { const size_t e = (g + k) % G; const int32_t q = peer_copy((char*)d.b + e * Cg * Rg * 32, d.dev, (char*)sh[e].a + g * Cg * Rg * 32, sh[e].dev, Cg * Rg * 32, d.st); if (q) return q; }
       HIPCHK(hipStreamSynchronize(d.st));
       return ALEO_MI355X_OK;
     });
-    phase([&]() -> int32_t {
+    phase([&]() -> int32_t { return with_ctx([&](Ctx* cc) -> int32_t {
       int32_t q;
       if ((q = fr_transpose(cc, d.a, d.b, C, Rg, d.st))) return q;                                                                           // a = [Rg][C]
       if ((q = ntt_run(cc, d.a, lg_c, Rg, ALEO_NTT_ORDER_NN, direction, ALEO_NTT_STANDARD, d.st))) return q;                                 // [k_r][k_c] (inverse: x C^-1)
       if ((q = peer_copy(T + g * Rg * C * 32, home, d.a, d.dev, per * 32, d.st))) return q;                                                  // home scratch [R][C], k_r major (T is dead: every slab was pulled before the first barrier)
       HIPCHK(hipStreamSynchronize(d.st));
       return ALEO_MI355X_OK;
-    });
+    }); });
     if (d.st) (void)hipStreamSynchronize(d.st);
     if (r) g_last_error = err;
     return r;

@@ -173,6 +173,10 @@ int32_t acquire_helpers(Device* d, int want, HelperSet& hs);
 extern thread_local MsmTiming g_last_msm;   // phase times of the calling thread's most recent MSM
 // Host-side trace of one proof (ALEO_MI355X_HOSTTRACE=1): labelled timestamps of the calling thread, printed to stderr by varuna_prove_batch — where the
 // host spends the turn-arounds between a commitment's last kernel and the next round's first (tools/proof_timeline_full.py shows the GPU's side of the same gaps).
+// f(i) for i in [0, n) on the calling thread and up to 3 parked helper threads of the library (created on first use, never destroyed); returns when all are done.
+// For the host tails of many-result launch chains (a lockstep round's 8 x k results: ~15 us of Horner each while every other thread of the call waits at a barrier).
+// f must not throw and must not call back into this function.
+void host_parallel_for(size_t n, const std::function<void(size_t)>& f);
 void host_trace_mark(const char* label);
 #define HT(label) do { if (::aleo_mi355x::g_host_trace_on) ::aleo_mi355x::host_trace_mark(label); } while (0)
 extern bool g_host_trace_on;

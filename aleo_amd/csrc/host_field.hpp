@@ -10,6 +10,7 @@
 #include <cstdint>
 #include <cstring>
 #include <immintrin.h>
+#include "host_modinv.hpp"
 
 namespace aleo_mi355x { namespace host {
 
@@ -79,7 +80,13 @@ template <int N> struct HFp {
     return acc;
   }
   static HFp pow_u64(const HFp& a, uint64_t e) { return pow(a, &e, 1); }
-  static HFp inv(const HFp& a) { uint64_t e[N]; std::memcpy(e, Pm::P, sizeof e); e[0] -= 2; return pow(a, e, N); }
+  static HFp inv_fermat(const HFp& a) { uint64_t e[N]; std::memcpy(e, Pm::P, sizeof e); e[0] -= 2; return pow(a, e, N); }      // a^(p-2): ~570 products for Fq (the reference the fast one is checked against)
+  // Bernstein-Yang divsteps on the Montgomery representative x = a R: x^-1 = a^-1 R^-1 as a plain integer, times R^3 under one Montgomery product = a^-1 R.  0 -> 0.
+  static HFp inv(const HFp& a) {
+    static const HFp r3 = [] { HFp r2; std::memcpy(r2.l, Pm::R2, sizeof r2.l); return mul(r2, r2); }();
+    HFp y; ModInv<N>::inverse(y.l, a.l, Pm::P);
+    return mul(y, r3);
+  }
   static HFp to_mont(const HFp& a) { HFp r2; std::memcpy(r2.l, Pm::R2, sizeof r2.l); return mul(a, r2); }
   static HFp from_mont(const HFp& a) { HFp o = zero(); o.l[0] = 1; return mul(a, o); }
 };

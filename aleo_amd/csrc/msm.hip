@@ -1331,15 +1331,18 @@ static int32_t msm_back(Ctx* c, uint64_t* out_jac18, Front& f, hipStream_t s, bo
     HT("msm: result arrived");
     t_host0 = std::chrono::steady_clock::now();
     HXYZZ totals[MAX_SETS];
-    for (uint32_t q = 0; q < K; ++q) {
-      const char* hw = h_win + (size_t)q * out_pts * PB28;
+    // one Horner chain per result (~15 us): from 8 results on (the rounds of a lockstep call, many-instance proofs) they are spread over the library's parked helper threads
+    auto horner = [&](size_t q) {
+      const char* hw = h_win + q * out_pts * PB28;
       const uint32_t na = prog ? 1u : 4u;                  // points that hold sum_j acc_j: one (k_prog_final) or the four segment sums of the masked form
       HXYZZ total = HXYZZ::infinity();
       for (int l = (int)lgN - 1; l >= 0; --l) { total = hdouble(total); total = hadd(total, lazy_point28(hw + (size_t)(na + l) * PB28)); }
       for (uint32_t sft = P.S; sft > 1; sft >>= 1) total = hdouble(total);
       for (uint32_t r = 0; r < na; ++r) total = hadd(total, lazy_point28(hw + (size_t)r * PB28));
       totals[q] = total;
-    }
+    };
+    static const bool tail_pool = [] { const char* e = std::getenv("ALEO_MI355X_TAIL_POOL"); return !(e && e[0] == '0'); }();      // A/B switch
+    if (K >= 8 && tail_pool) host_parallel_for(K, horner); else for (uint32_t q = 0; q < K; ++q) horner(q);
     for (uint32_t h = 0; aside && h < sm.n_super; ++h) {             // (b + 1) * (slices 1.. of super-heavy bucket b), by double-and-add
       const uint32_t* rec = h_aside + (size_t)h * 57; const uint32_t g = rec[56], q = g / P.B, wgt = g % P.B + 1;
       if (q >= K) { g_last_error = "msm: internal: super-heavy bucket outside the sets"; return ALEO_MI355X_ERR_HIP; }

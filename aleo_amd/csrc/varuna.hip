@@ -77,6 +77,35 @@ double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::
 
 thread_local double g_varuna_timing[8] = {};
 
+// The prover's transforms.  With a sharded copy of the committer key attached (row e2: a proof that spans devices) a transform of >= shard_min elements runs over
+// the devices the key is spread over (api.hip ntt_sharded_device: slabs pulled and pushed by peer copies, the coefficient vector stays on the prover's device
+// between the rounds) — the "NTT coefficients" half of north_star's "large proofs shard MSM bases and NTT coefficients"; everything else, and any device list
+// that is not a power of two, takes the single-device kernels.  Same values either way (tests: proofs byte-equal).
+static bool ntt_routed(const PinnedBases& pb, uint32_t lg, std::vector<int>* devs) {
+  if (!pb.shards || lg < 2 || ((size_t)1 << lg) < pb.shard_min) return false;
+  if (sharded_devices(pb.shards, devs)) return false;
+  const size_t G = devs->size(); uint32_t lg_g = 0; while (((size_t)1 << lg_g) < G) ++lg_g;
+  return G >= 1 && !(G & (G - 1)) && lg / 2 >= lg_g;
+}
+static int32_t p_ntt(Ctx* c, const PinnedBases& pb, void* data, uint32_t lg, size_t batch, int32_t direction, int32_t type, hipStream_t s) {
+  std::vector<int> devs;
+  if (!ntt_routed(pb, lg, &devs)) return ntt_run(c, data, lg, batch, ALEO_NTT_ORDER_NN, direction, type, s);
+  for (size_t b = 0; b < batch; ++b) { const int32_t rc = ntt_sharded_device(c, (char*)data + (b << lg) * 32, lg, direction, type, devs.data(), devs.size(), s); if (rc) return rc; }
+  return ALEO_MI355X_OK;
+}
+static int32_t p_ntt_from(Ctx* c, const PinnedBases& pb, void* out, const void* src, size_t src_stride, size_t src_len, uint32_t lg, size_t batch, hipStream_t s) {
+  std::vector<int> devs;
+  if (!ntt_routed(pb, lg, &devs)) return ntt_run_from(c, out, src, src_stride, src_len, lg, batch, ALEO_NTT_FORWARD, ALEO_NTT_STANDARD, s);
+  const size_t n = (size_t)1 << lg;
+  for (size_t b = 0; b < batch; ++b) {                        // pad by hand (sizes where a fill and a copy are noise), then the sharded transform in place
+    char* o = (char*)out + b * n * 32;
+    if (src_len < n) HIPCHK(hipMemsetAsync(o + src_len * 32, 0, (n - src_len) * 32, s));
+    if (src_len) HIPCHK(hipMemcpyAsync(o, (const char*)src + b * src_stride * 32, src_len * 32, hipMemcpyDeviceToDevice, s));
+    const int32_t rc = ntt_sharded_device(c, o, lg, ALEO_NTT_FORWARD, ALEO_NTT_STANDARD, devs.data(), devs.size(), s); if (rc) return rc;
+  }
+  return ALEO_MI355X_OK;
+}
+
 
 // `behind`: kernels of the NEXT round that need no challenge of this one — queued behind the commitment's last kernel, so that they run while the host finishes
 // the MSM's tail, compresses, hashes and derives the challenge (Ctx::tail_hook; a request that takes several launch chains runs them afterwards instead).
@@ -221,9 +250,9 @@ int32_t varuna_index_build(Ctx* c, const PinnedBases& pb, std::shared_ptr<Pinned
     RC(fr_vec_op(c, e + 3 * n * 32, e, e + n * 32, n, 0, s));
     char* po = (char*)kpo + 4 * ko[m] * 32; char* e2 = (char*)k2 + 8 * ko[m] * 32;
     HIPCHK(hipMemcpyAsync(po, e, 4 * n * 32, hipMemcpyDeviceToDevice, s));
-    RC(ntt_run(c, po, lg, 4, 0, 1, 0, s));
+    RC(p_ntt(c, pb, po, lg, 4, 1, 0, s));
     for (int j = 0; j < 4; ++j) HIPCHK(hipMemcpyAsync(e2 + (size_t)j * 2 * n * 32, po + (size_t)j * n * 32, n * 32, hipMemcpyDeviceToDevice, s));
-    RC(ntt_run(c, e2, lg + 1, 4, 0, 0, 0, s));
+    RC(p_ntt(c, pb, e2, lg + 1, 4, 0, 0, s));
   }
   mark("arithmetisation + transforms");
   V.k_evals = kev; V.k_idx = kid; V.k_polys = kpo; V.k2_evals = k2; V.positions = o->positions.data();
@@ -355,7 +384,7 @@ int32_t Prover::first_round(const void* const* assignments, std::vector<MsmSeg>&
     }
   }
   HIPCHK(hipMemcpyAsync(xp, stage + x_off * 32, k * n_x * 32, hipMemcpyHostToDevice, s));
-  RC(ntt_run_from(c, xh, xp, n_x, n_x, lg_h, k, ALEO_NTT_FORWARD, ALEO_NTT_STANDARD, s));      // x̂ of every instance on H: |X| coefficients each, zero-padded by the transform's first pass
+  RC(p_ntt_from(c, sh.pb, xh, xp, n_x, n_x, lg_h, k, s));      // x̂ of every instance on H: |X| coefficients each, zero-padded by the transform's first pass
   for (size_t i = 0; i < k; ++i) {
     char* e0 = ev + 3 * i * n_h * 32; char* z_i = zH + i * n_h * 32; char* xh_i = xh + i * n_h * 32;
     RC(fr_spmv(c, e0 + n_h * 32, ix.a_row_ptr, ix.a_col, ix.a_val, z_i, n_h, s, ix.max_row[0]));
@@ -367,7 +396,7 @@ int32_t Prover::first_round(const void* const* assignments, std::vector<MsmSeg>&
     if (!evals_h || !rho_dev) { g_last_error = "varuna_prove: workspace accounting"; return ALEO_MI355X_ERR_HIP; }
     HIPCHK(hipMemcpyAsync(evals_h, ev, 3 * k * n_h * 32, hipMemcpyDeviceToDevice, s));
   }
-  RC(ntt_run(c, ev, lg_h, 3 * k, 0, 1, 0, s));
+  RC(p_ntt(c, sh.pb, ev, lg_h, 3 * k, 1, 0, s));
   {
     HFr rho[3 * MAX_INSTANCES];                                                             // rho_w, rho_a, rho_b of instance q / 3
     for (size_t q = 0; q < 3 * k; ++q) {
@@ -392,7 +421,7 @@ int32_t Prover::second_round_early() {
   Ctx* c = sh.c; hipStream_t s = sh.s;
   TAKE_M(E, (2 + 3 * k) * n4)                                                               // rows 0, 1: r, t (second_round); then ẑ_i, z_a,i, z_b,i per instance
   RC(ahp_sumcheck_operands(c, E + 2 * n4 * 32, wit, xp, n_h, n_x, k, s));                    // ẑ_i = w_i (X^|X| − 1) + x̂_i, z_a,i, z_b,i — every row written in full
-  return ntt_run(c, E + 2 * n4 * 32, lg_h + 2, 3 * k, 0, 0, 0, s);
+  return p_ntt(c, sh.pb, E + 2 * n4 * 32, lg_h + 2, 3 * k, 0, 0, s);
 }
 
 int32_t Prover::second_round() {
@@ -405,11 +434,11 @@ int32_t Prover::second_round() {
     const HFr first = HFr::pow_u64(alpha, n_h - 1), ratio = HFr::inv(alpha);
     RC(fr_powers(c, rt, n_h, first.l, ratio.l, s));                                          // r(alpha, X) = sum_k alpha^(|H|-1-k) X^k
   }
-  RC(ntt_run_from(c, ext, rt, n_h, n_h, lg_h, 1, ALEO_NTT_FORWARD, ALEO_NTT_STANDARD, s));    // v_H(alpha) / (alpha − h) on H: no inversion on the device
+  RC(p_ntt_from(c, sh.pb, ext, rt, n_h, n_h, lg_h, 1, s));    // v_H(alpha) / (alpha − h) on H: no inversion on the device
   { const HFr eta[2] = {eta_b, eta_c}; RC(fr_scale_rows(c, ext + n_h * 32, ext, n_h, 2, eta, s)); }      // the eta_b- and eta_c-scaled copies B^T and C^T multiply
   RC(fr_spmv(c, rt + n_h * 32, ix.t_row_ptr, ix.t_col, ix.t_val, ext, n_h, s, ix.max_row[2]));
-  RC(ntt_run(c, rt + n_h * 32, lg_h, 1, 0, 1, 0, s));                                       // t(X)
-  RC(ntt_run_from(c, E, rt, n_h, n_h, lg_h + 2, 2, ALEO_NTT_FORWARD, ALEO_NTT_STANDARD, s));  // r, t on 4|H|: |H| coefficients each, zero-padded by the first pass (the operands of the instances are there already: second_round_early)
+  RC(p_ntt(c, sh.pb, rt + n_h * 32, lg_h, 1, 1, 0, s));                                       // t(X)
+  RC(p_ntt_from(c, sh.pb, E, rt, n_h, n_h, lg_h + 2, 2, s));  // r, t on 4|H|: |H| coefficients each, zero-padded by the first pass (the operands of the instances are there already: second_round_early)
   for (size_t i = 0; i < k; ++i) {
     char* e_z = E + (2 + 3 * i) * n4 * 32;
     RC(ahp_first_sumcheck(c, e_z + n4 * 32, n4, E, e_z + n4 * 32, e_z + 2 * n4 * 32, E + n4 * 32, e_z, eta_b.l, eta_c.l, s));
@@ -420,7 +449,7 @@ int32_t Prover::second_round() {
     for (size_t i = 0; i < k; ++i) { terms[i] = E + (3 + 3 * i) * n4 * 32; co[i] = sh.comb[q0 + i]; }
     RC(lincomb_any(c, Q, n4, HFr::zero(), terms, lens, co, s)); q1 = Q;                     // 29..32 instances of one circuit: more terms than one fr_lincomb launch takes
   }
-  RC(ntt_run(c, q1, lg_h + 2, 1, 0, 1, 0, s));
+  RC(p_ntt(c, sh.pb, q1, lg_h + 2, 1, 1, 0, s));
   // q (+ the mask, which rides with the largest domain) = h (X^|H| − 1) + X g, degree < 3|H|: quotient blocks p1 + p2 | p2, remainder p0 + p1 + p2; the remainder's
   // constant term — this circuit's sum over H — goes straight into pinned host memory (read with the commitments).  One launch (rounds 1-4: a copy, three vector ops, a read-back)
   RC(fr_split_quotient(c, hq, rq, q1, lead() ? sh.mask : nullptr, n_h, sh.pin_small_dev + PIN_SUMS + 32 * j, s));
@@ -437,7 +466,7 @@ int32_t Prover::third_round() {
     const HFr first = HFr::pow_u64(beta, n_h - 1), ratio = HFr::inv(beta);
     RC(fr_powers(c, rb, n_h, first.l, ratio.l, s));
   }
-  RC(ntt_run(c, rb, lg_h, 1, 0, 0, 0, s));
+  RC(p_ntt(c, sh.pb, rb, lg_h, 1, 0, 0, s));
   for (size_t m = 0; m < 3; ++m) {                                                           // f_M = val u_H(alpha, row) u_H(beta, col) on K_M: two gathers
     const uint32_t* ri = (const uint32_t*)ix.k_idx + 2 * ko[m];
     RC(fr_gather_mul(c, f + ko[m] * 32, nk[m], (const char*)ix.k_evals + (4 * ko[m] + 2 * nk[m]) * 32, ext, ri, rb, ri + nk[m], s));
@@ -445,7 +474,7 @@ int32_t Prover::third_round() {
   // maximal runs of consecutive matrices with equal domains share batched transforms (and, in round 4, one numerator pass)
   nrun = 0;
   for (size_t m = 0; m < 3;) { size_t cnt = 1; while (m + cnt < 3 && nk[m + cnt] == nk[m]) ++cnt; run0[nrun] = m; runc[nrun++] = cnt; m += cnt; }
-  for (size_t r = 0; r < nrun; ++r) RC(ntt_run(c, f + ko[run0[r]] * 32, lg_km[run0[r]], runc[r], 0, 1, 0, s));
+  for (size_t r = 0; r < nrun; ++r) RC(p_ntt(c, sh.pb, f + ko[run0[r]] * 32, lg_km[run0[r]], runc[r], 1, 0, s));
   { const void* src[3] = {f + ko[0] * 32, f + ko[1] * 32, f + ko[2] * 32}; RC(fr_pick(c, sh.pin_small_dev + 32 * (3 * j), src, 3, s)); }      // f_M(0): one launch into pinned host memory
   return ALEO_MI355X_OK;
 }
@@ -454,7 +483,7 @@ int32_t Prover::fourth_round_early() {
   Ctx* c = sh.c; hipStream_t s = sh.s;
   TAKE_M(F, 2 * k_sum)                                                                        // f_M zero-padded to 2|K_M|, then its values there
   for (size_t r = 0; r < nrun; ++r)                          // the polynomials of a run are contiguous in f (|K| apart): zero-padded to 2|K| by the transform's first pass
-    RC(ntt_run_from(c, F + 2 * ko[run0[r]] * 32, f + ko[run0[r]] * 32, nk[run0[r]], nk[run0[r]], lg_km[run0[r]] + 1, runc[r], ALEO_NTT_FORWARD, ALEO_NTT_STANDARD, s));
+    RC(p_ntt_from(c, sh.pb, F + 2 * ko[run0[r]] * 32, f + ko[run0[r]] * 32, nk[run0[r]], nk[run0[r]], lg_km[run0[r]] + 1, runc[r], s));
   return ALEO_MI355X_OK;
 }
 
@@ -470,7 +499,7 @@ int32_t Prover::fourth_round() {
       idx[t] = (const char*)ix.k2_evals + 8 * ko[m] * 32; ff[t] = F + 2 * ko[m] * 32; consts[t] = delta[m];
     }
     RC(ahp_matrix_sumcheck(c, Br, n2, idx, n2, ff, consts, s));                                // sum over the run of delta_M (vv val_M − b_M f_M) = h (X^|K| − 1)
-    RC(ntt_run(c, Br, lg_km[m0] + 1, 1, 0, 1, 0, s));
+    RC(p_ntt(c, sh.pb, Br, lg_km[m0] + 1, 1, 1, 0, s));
     r4_terms[r] = Br + nk[m0] * 32; r4_lens[r] = nk[m0];                                     // its upper half
   }
   return ALEO_MI355X_OK;

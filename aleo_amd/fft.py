@@ -82,3 +82,10 @@ class EvaluationDomain:
         src_len elements at d_src + b * src_stride * 32 and writes this domain's size to d_out + b * size * 32."""
         check(lib().aleo_mi355x_ntt_fr_from_device(ctypes.c_void_p(d_out), ctypes.c_void_p(d_src), src_stride, src_len, self.log_size_of_group, batch, direction, type_,
                                                    ctypes.c_void_p(stream)), 'ntt_fr_from_device')
+
+    def ntt_sharded_device(self, d_ptr: int, devices, direction=FORWARD, type_=STANDARD, stream: int = 0):
+        """In place on device-resident data (this domain's size at d_ptr on the current device), computed over several devices by peer copies — no host buffer
+        (aleo_mi355x_ntt_fr_sharded_device).  devices: a list of HIP device indices (an index may repeat) or a count; a power of two.  Blocking."""
+        if isinstance(devices, int): dv, g = None, devices
+        else: dv, g = (ctypes.c_int32 * len(devices))(*[int(d) for d in devices]), len(devices)
+        check(lib().aleo_mi355x_ntt_fr_sharded_device(ctypes.c_void_p(d_ptr), self.log_size_of_group, direction, type_, dv, g, ctypes.c_void_p(stream)), 'ntt_fr_sharded_device')

@@ -192,6 +192,14 @@ int32_t aleo_mi355x_fr_transpose_device(void* d_dst, const void* d_src, uint64_t
  * PCIe traffic —, runs its column transforms and the twiddle, the devices exchange one block per pair (peer copies: one per xGMI link), every device
  * runs its row transforms and stores its k_r range of X[k_c R + k_r] straight into the host buffer.  Same values as aleo_mi355x_ntt_fr. */
 int32_t aleo_mi355x_ntt_fr_sharded(void* inout, uint32_t lg_n, int32_t direction, int32_t type, const int32_t* devices, size_t n_devices);
+/* e2 — the same transform on data RESIDENT in HBM: 2^lg_n Montgomery elements in natural order at d_inout on the calling thread's current device ("home"),
+ * transformed in place over the listed devices with no host buffer: home transposes the coefficient matrix once so that every device's columns are one
+ * contiguous slab, device g pulls its slab (hipMemcpyPeerAsync over xGMI; the home device itself: a plain copy), column transforms + twiddle, the all-to-all
+ * as one peer copy per ordered pair, row transforms, every device pushes its rows back and home restores the natural order.  Same values as
+ * aleo_mi355x_ntt_fr_device.  Blocking (the result is complete on return); `stream`: the stream the data was produced on (NULL = the slot's own).  The prover
+ * routes its transforms of >= min_points elements through this entry when its committer key has shards attached (aleo_mi355x_bases_attach_shards): the
+ * "NTT coefficients" half of "large proofs shard MSM bases and NTT coefficients across the GPUs". */
+int32_t aleo_mi355x_ntt_fr_sharded_device(void* d_inout, uint32_t lg_n, int32_t direction, int32_t type, const int32_t* devices, size_t n_devices, void* stream);
 
 /* a5 — KZG10::commit shape (commit_lagrange is the same call over the pinned Lagrange-basis powers with evaluations as
  * the scalars): coefficients in Montgomery form (as polynomials are stored), converted to canonical
@@ -463,6 +471,11 @@ int32_t aleo_mi355x_selftest_addquad(uint32_t ops, uint64_t seed, uint32_t* fail
  * chains over n_points affine G2 points (192-byte rows, host memory, >= 3 of them, all on the curve): sums, a sum with a shared operand, a doubling, the
  * same-point case of the addition.  failures2[0] = pairs that disagreed, failures2[1] = OR of the failing steps (1 a, 2 s, 4 u, 8 2u, 16 u + u). */
 int32_t aleo_mi355x_selftest_g2pair(const void* affine192, uint32_t n_points, uint32_t n_pairs, uint32_t* failures2);
+
+/* Host arithmetic (no device needed): the inversion the host tails use — Bernstein-Yang divsteps on 62-bit limbs (csrc/host_modinv.hpp) — against the Fermat
+ * chain a^(p-2) on `count` pseudo-random elements of Fq and of Fr plus the edge values 0, 1, 2, p - 1, p - 2: *failures = results that differ; ns_per_inverse
+ * (optional, 4 doubles): divsteps / Fermat for Fq, divsteps / Fermat for Fr. */
+int32_t aleo_mi355x_selftest_host_inverse(uint32_t count, uint64_t seed, uint32_t* failures, double* ns_per_inverse);
 
 /* Per-call instrumentation of the calling thread's most recent MSM: milliseconds per phase
  * [0] total, [1] digit/sort, [2] bucket accumulation incl. slice tree, [3] bucket reduction, [4] host tail,

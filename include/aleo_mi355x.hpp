@@ -185,6 +185,12 @@ class EvaluationDomain {
   Result<bool> coset_fft_in_place(std::vector<Fr>& x) const { return run(x, NTTDirection::Forward, NTTType::Coset); }
   Result<bool> coset_ifft_in_place(std::vector<Fr>& x) const { return run(x, NTTDirection::Inverse, NTTType::Coset); }
   // the same transforms split over several devices of this process (4-step, one peer exchange): devices.size() a power of two
+  // device-resident data (2^log_size_of_group elements at d_inout on the current device): the transform over several devices, no host buffer
+  Result<bool> in_place_sharded_device(void* d_inout, NTTDirection d, NTTType t, const std::vector<int32_t>& devices, void* stream = nullptr) const {
+    int32_t rc = aleo_mi355x_ntt_fr_sharded_device(d_inout, log_size_of_group, (int32_t)d, (int32_t)t, devices.data(), devices.size(), stream);
+    if (rc) return {std::nullopt, Error{rc}};
+    return {true, Error{0}};
+  }
   Result<bool> in_place_sharded(std::vector<Fr>& x, NTTDirection d, NTTType t, const std::vector<int32_t>& devices) const {
     if (x.size() > size) return {std::nullopt, Error{ALEO_MI355X_ERR_BAD_ARG}};
     x.resize(size, Fr{{0, 0, 0, 0}});

@@ -119,6 +119,21 @@ def test_ntt_from_rejects_overlap_and_bad_sizes():
     with pytest.raises(aleo_amd.AleoMi355xError): dom.ntt_from_device(buf.data_ptr(), buf.data_ptr() + 32 * 2048, 1024, 1025)       # more coefficients than the domain
 
 
+@pytest.mark.parametrize('lg,G', [(4, 1), (4, 4), (10, 2), (11, 8), (16, 4), (17, 2), (20, 8)])
+def test_ntt_sharded_device_resident_matches_oracle(lg, G):
+    """aleo_mi355x_ntt_fr_sharded_device: the data stays in HBM on the caller's device, the 4-step transform runs over G shard contexts (the one card listed G
+    times: slab pulls, the pairwise exchange and the pushes are same-device copies here) — every variant against the restatement, in place."""
+    import torch
+    n = 1 << lg
+    x = c.fr_to_mont(util.uniform_scalars(n, 5200 + lg))
+    dom = aleo_amd.EvaluationDomain(n)
+    for direction, type_ in ((0, 0), (0, 1), (1, 0), (1, 1)):
+        d = torch.from_numpy(x.view(np.int64).copy()).cuda()
+        dom.ntt_sharded_device(d.data_ptr(), [0] * G, direction, type_, stream=torch.cuda.current_stream().cuda_stream)
+        assert (d.cpu().numpy().view(np.uint64) == c.ntt_fr(x, 0, direction, type_)).all(), (lg, G, direction, type_)
+    with pytest.raises(aleo_amd.AleoMi355xError): dom.ntt_sharded_device(d.data_ptr(), [0] * 3)      # not a power of two
+
+
 def _extreme_fr(n, kind):
     """Raw 32-byte values that push the lazy sums of the 29-bit-limb butterflies (fr29.h) to their bounds: the largest canonical number everywhere,
     alternating with zero, or in one half only."""

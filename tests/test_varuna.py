@@ -956,11 +956,13 @@ def test_lockstep_with_every_context_taken_and_a_sharded_key_makes_progress():
 
 
 @pytest.mark.gpu
-def test_a_2_18_constraint_proof_against_a_sharded_key():
-    """The size the sharding is for: 2^18 constraints (|K_A| = 2^20: commitments of up to 2^20 points), two instances, the key's 2^21 powers as 4 shards
-    with their own window tables — and only commitments of >= 2^16 points routed to them (min_points), the small ones stay on the prover's device.
-    Byte-equal to the single-device proof; and the segment entry point itself against the single-device commitment (degree bound + hiding segments
-    that straddle shard boundaries)."""
+@pytest.mark.parametrize('G', [2, 4, 8])
+def test_a_2_18_constraint_proof_against_a_sharded_key(G):
+    """The size the sharding is for: 2^18 constraints (|K_A| = 2^20: commitments of up to 2^20 points), two instances, the key's 2^21 powers as G shards
+    with their own window tables — and only commitments AND TRANSFORMS of >= 2^16 elements routed to them (min_points): the small ones stay on the
+    prover's device, every transform on H (2^18), 4|H| (2^20), K and 2|K| (2^20, 2^21) runs through aleo_mi355x_ntt_fr_sharded_device's path (slabs pulled and
+    pushed by peer copies; here the one card listed G times).  Byte-equal to the single-device proof and verifying key; and the segment entry point itself
+    against the single-device commitment (degree bound + hiding segments that straddle shard boundaries)."""
     import torch
     from aleo_amd import varuna
     from aleo_amd.kzg import SonicKZG10
@@ -972,9 +974,9 @@ def test_a_2_18_constraint_proof_against_a_sharded_key():
     try:
         with varuna.NativeCircuitIndex(csr, n, 4, len(z) - 4, ck) as nx:
             vk0 = nx.vk_bytes; want = nx.prove([zz, zz], 4242)
-        sb = aleo_amd.ShardedBases(ck.bases.download(), devices=[0] * 4, precompute=True)
+        sb = aleo_amd.ShardedBases(ck.bases.download(), devices=[0] * G, precompute=True)
         try:
-            # the entry point alone: three results, segments at offsets that cross shard boundaries (shard size 2^19 + 1)
+            # the entry point alone: three results, segments at offsets that cross shard boundaries (shard size 2^21 / G)
             m = 1 << 20
             d = torch.from_numpy(util_uniform(3 * m + 8, 77).view(np.int64)).cuda(); torch.cuda.synchronize()
             p0 = d.data_ptr()
