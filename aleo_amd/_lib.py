@@ -5,7 +5,8 @@ from __future__ import annotations
 import ctypes, os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'lib', 'libaleo_mi355x.so')
+# ALEO_MI355X_LIB: another build of the same library (the probe builds of tools/ntt_phase_probe.sh, an A/B build) — never a fallback: it must exist and export every symbol
+LIB_PATH = os.environ.get('ALEO_MI355X_LIB') or os.path.join(_HERE, 'lib', 'libaleo_mi355x.so')
 
 EXPORTS = [
     'aleo_mi355x_init', 'aleo_mi355x_msm_g1', 'aleo_mi355x_bases_pin', 'aleo_mi355x_bases_unpin',

@@ -419,6 +419,7 @@ template <int N> void inverse_selftest(uint32_t count, uint64_t seed, uint32_t* 
   for (size_t i = 0; i < v.size(); ++i) {
     bool ok = a[i] == b[i];
     if (ok && !v[i].is_zero()) ok = F::mul(a[i], v[i]) == F::one();      // and it IS the inverse
+    ok = ok && F::sqr(v[i]) == F::mul(v[i], v[i]) && F::sqr(a[i]) == F::mul(a[i], a[i]);      // the dedicated squaring against the product
     if (!ok) ++*failures;
   }
   if (ns) { ns[0] = std::chrono::duration<double, std::nano>(t1 - t0).count() / v.size(); ns[1] = std::chrono::duration<double, std::nano>(t2 - t1).count() / v.size(); }
@@ -958,7 +959,39 @@ int32_t aleo_mi355x_varuna_prove_many(aleo_mi355x_prove_request* requests, size_
     FIND_BASES(key)
     std::vector<ProveRequest> live; std::vector<size_t> where;
     for (size_t p = 0; p < n_requests; ++p) if (!rq[p].status) { live.push_back(rq[p]); where.push_back(p); }
-    int32_t rc = live.empty() ? ALEO_MI355X_OK : varuna_prove_many(c, pb, live);
+    // From 4 proofs on the call runs as TWO lockstep groups on two threads (the caller's and one more, on a second context of the device): while one group's
+    // commitments hold the card, the other group's field kernels, sorts, reductions and transcripts — a third of a lockstep round — run in their shadow.  What
+    // two callers with half the proofs each achieve (8 proofs of 2^15 constraints: 254 proofs/s as one group, 275 as two calls of 4 in flight,
+    // profiles/r05_lockstep_probe_2^15_groups.json), without asking the host for a second thread.  ALEO_MI355X_LOCKSTEP_GROUPS=1: one group.  Proof bytes do not depend on it.
+    static const int groups_env = [] { const char* e = std::getenv("ALEO_MI355X_LOCKSTEP_GROUPS"); const int k = e ? std::atoi(e) : 2; return k >= 1 && k <= 2 ? k : 2; }();
+    int32_t rc = ALEO_MI355X_OK; bool split_done = false;
+    if (groups_env == 2 && live.size() >= 4) {
+      Ctx* c2 = nullptr; std::unique_lock<std::mutex> lk2;
+      if (acquire_other(d, c, &c2, lk2, false) == ALEO_MI355X_OK && c2) {
+        const size_t half = (live.size() + 1) / 2;
+        std::vector<ProveRequest> ga(live.begin(), live.begin() + half), gb(live.begin() + half, live.end());
+        int32_t rc_b = ALEO_MI355X_OK; std::string err_b; bool started = true;
+        std::thread tb;
+        try {
+          tb = std::thread([&] {
+            try {
+              if (hipSetDevice(d->device) != hipSuccess) { rc_b = ALEO_MI355X_ERR_HIP; err_b = "hipSetDevice failed"; return; }
+              rc_b = varuna_prove_many(c2, pb, gb); if (rc_b) err_b = g_last_error;
+            } catch (...) { rc_b = ALEO_MI355X_ERR_HIP; err_b = "varuna_prove_many: exception in the second group"; }
+          });
+        } catch (...) { started = false; }
+        if (started) {
+          int32_t rc_a;
+          try { rc_a = varuna_prove_many(c, pb, ga); } catch (...) { rc_a = ALEO_MI355X_ERR_HIP; g_last_error = "varuna_prove_many: exception in the first group"; }      // never unwind past the joinable thread
+          tb.join();
+          for (size_t i = 0; i < ga.size(); ++i) live[i] = ga[i];
+          for (size_t i = 0; i < gb.size(); ++i) live[half + i] = gb[i];
+          rc = rc_a ? rc_a : rc_b; if (!rc_a && rc_b) g_last_error = err_b;
+          split_done = true;
+        }
+      }
+    }
+    if (!split_done) rc = live.empty() ? ALEO_MI355X_OK : varuna_prove_many(c, pb, live);
     std::string first_error;
     for (size_t i = 0; i < live.size(); ++i) { requests[where[i]].status = live[i].status; if (live[i].status && first_error.empty()) first_error = live[i].error; }
     for (size_t p = 0; p < n_requests; ++p) if (rq[p].status && first_error.empty()) first_error = rq[p].error;

@@ -73,7 +73,7 @@ template <int N> struct HFp {
   // Montgomery product: separated operand scanning on mulx / adc chains (Wide<N> below) — ~35 ns for Fq on a 2.1 GHz core against ~60 ns for the
   // interleaved unsigned __int128 form this file used before: the host tails of the MSMs and the transcript are chains of these
   static inline HFp mul(const HFp& a, const HFp& b);
-  static HFp sqr(const HFp& a) { return mul(a, a); }
+  static inline HFp sqr(const HFp& a);                       // dedicated squaring (Wide<N>::square)
   static HFp pow(const HFp& a, const uint64_t* e, int nl) {
     HFp acc = one();
     for (int i = nl * 64 - 1; i >= 0; --i) { acc = sqr(acc); if ((e[i / 64] >> (i % 64)) & 1) acc = mul(acc, a); }
@@ -120,6 +120,37 @@ template <int N> struct Wide {
       _addcarry_u64(c, top, hi[N - 1], &o[i + N]);                                                         // a row's product has no carry beyond limb i + N
     }
   }
+  // o[0..2N) = a^2: the N (N - 1) / 2 cross products once, doubled, plus the N squares — 21 + 6 multiplications for Fq instead of 36 (the Montgomery
+  // reduction behind it stays 36): the s-boxes of the transcript's Poseidon (x^17 = four squarings and a product) and the point doublings of the host tails
+  __attribute__((always_inline)) static inline void square(ull* __restrict o, const ull* __restrict a) {
+    ull c[2 * N];                                            // cross products sum_{i < j} a_i a_j 2^(64 (i + j)), limbs 1 .. 2N - 2
+#pragma unroll
+    for (int k = 0; k < 2 * N; ++k) c[k] = 0;
+#pragma unroll
+    for (int i = 0; i < N - 1; ++i) {
+      ull lo[N], hi[N]; unsigned char cy = 0;
+#pragma unroll
+      for (int j = i + 1; j < N; ++j) lo[j] = _mulx_u64(a[i], a[j], &hi[j]);
+#pragma unroll
+      for (int j = i + 1; j < N; ++j) cy = _addcarry_u64(cy, c[i + j], lo[j], &c[i + j]);
+      ull top; _addcarry_u64(cy, 0, 0, &top);
+      cy = 0;
+#pragma unroll
+      for (int j = i + 1; j < N - 1; ++j) cy = _addcarry_u64(cy, c[i + j + 1], hi[j], &c[i + j + 1]);
+      _addcarry_u64(cy, top, hi[N - 1], &c[i + N]);          // c[i + N] is still zero here: the row's top limb
+    }
+    ull prev = 0;                                            // double
+#pragma unroll
+    for (int k = 1; k < 2 * N; ++k) { const ull v = c[k]; c[k] = (v << 1) | (prev >> 63); prev = v; }
+    unsigned char cy = 0;                                    // + the squares
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      ull h; const ull l = _mulx_u64(a[i], a[i], &h);
+      cy = _addcarry_u64(cy, c[2 * i], l, &o[2 * i]);
+      cy = _addcarry_u64(cy, c[2 * i + 1], h, &o[2 * i + 1]);
+    }
+  }
+  __attribute__((always_inline)) inline void set_sqr(const uint64_t* a) { square(t, (const ull*)a); t[2 * N] = 0; }
   __attribute__((always_inline)) inline void set_mul(const uint64_t* a, const uint64_t* b) { product(t, (const ull*)a, (const ull*)b); t[2 * N] = 0; }
   __attribute__((always_inline)) inline void add_mul(const uint64_t* a, const uint64_t* b) {
     ull u[2 * N]; product(u, (const ull*)a, (const ull*)b);
@@ -155,7 +186,9 @@ template <int N> struct Wide {
   }
 };
 template <int N> __attribute__((always_inline)) inline HFp<N> fmul(const HFp<N>& a, const HFp<N>& b) { Wide<N> w; w.set_mul(a.l, b.l); return w.redc(); }
+template <int N> __attribute__((always_inline)) inline HFp<N> fsqr(const HFp<N>& a) { Wide<N> w; w.set_sqr(a.l); return w.redc(); }
 template <int N> inline HFp<N> HFp<N>::mul(const HFp<N>& a, const HFp<N>& b) { return fmul<N>(a, b); }
+template <int N> inline HFp<N> HFp<N>::sqr(const HFp<N>& a) { return fsqr<N>(a); }
 
 using HFr = HFp<4>;
 using HFq = HFp<6>;

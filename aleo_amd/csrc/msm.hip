@@ -462,21 +462,27 @@ __global__ void __launch_bounds__(256) k_slice_count(const uint32_t* __restrict_
   for (uint32_t i = threadIdx.x; i <= MAX_SLICE; i += 256) if (h[i]) atomicAdd(&len_count[i], h[i]);
 }
 
-// len_start[l] = number of slices longer than l (they come first); one block
-__global__ void __launch_bounds__(256) k_len_starts(const uint32_t* __restrict__ len_count, uint32_t* __restrict__ len_start) {
-  __shared__ uint32_t c[MAX_SLICE + 2];
-  for (uint32_t i = threadIdx.x; i <= MAX_SLICE; i += 256) c[i] = len_count[i];
-  __syncthreads();
-  if (threadIdx.x == 0) { uint32_t run = 0; for (int l = (int)MAX_SLICE; l >= 0; --l) { uint32_t v = c[l]; c[l] = run; run += v; } }
-  __syncthreads();
-  for (uint32_t i = threadIdx.x; i <= MAX_SLICE; i += 256) len_start[i] = c[i];
-}
-
 // order[pos] = sid, longest slices first
+// (len_start[l] = number of slices longer than l is recomputed by every block from the ~257 length counts — a single-block launch of its own, k_len_starts,
+//  cost ~6 us per chain at the sizes of real circuits)
 __global__ void __launch_bounds__(256) k_slice_order(const uint32_t* __restrict__ hist, const uint2* __restrict__ scan_local, const uint2* __restrict__ scan_blk,
                                                      const uint32_t* __restrict__ total_pairs, uint32_t M, const uint32_t* __restrict__ meta, const uint32_t* __restrict__ task_g,
-                                                     const uint32_t* __restrict__ len_start, uint32_t* __restrict__ len_cursor, uint32_t* __restrict__ order) {
-  __shared__ uint32_t h[MAX_SLICE + 1], base[MAX_SLICE + 1];
+                                                     const uint32_t* __restrict__ len_count, uint32_t* __restrict__ len_cursor, uint32_t* __restrict__ order) {
+  __shared__ uint32_t h[MAX_SLICE + 1], base[MAX_SLICE + 1], len_start[MAX_SLICE + 2], wtot[4];
+  {                                                        // suffix sums of len_count: lane t owns the lengths PER t .. PER t + PER - 1
+    constexpr uint32_t PER = (MAX_SLICE + 1 + 255) / 256;
+    const uint32_t t = threadIdx.x; uint32_t cnt[PER], tot = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < PER; ++k) { const uint32_t l = PER * t + k; cnt[k] = l <= MAX_SLICE ? len_count[l] : 0u; tot += cnt[k]; }
+    uint32_t inc = tot; const int lane = t & 63, wv = t >> 6;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_down(inc, d); if (lane + d < 64) inc += o; }      // inclusive suffix sum inside the wave
+    if (lane == 0) wtot[wv] = inc;
+    __syncthreads();
+    uint32_t run = inc - tot; for (int k = wv + 1; k < 4; ++k) run += wtot[k];      // slices longer than this lane's last length
+#pragma unroll
+    for (uint32_t k = PER; k-- > 0;) { const uint32_t l = PER * t + k; if (l <= MAX_SLICE) len_start[l] = run; run += cnt[k]; }
+  }
   for (uint32_t i = threadIdx.x; i <= MAX_SLICE; i += 256) h[i] = 0;
   __syncthreads();
   uint32_t t = blockIdx.x * 256 + threadIdx.x, len = 0, rank = 0;
@@ -657,6 +663,22 @@ __global__ void __launch_bounds__(256) k_tree_pass(char* __restrict__ partial, c
   if (i >= L - half) return;
   char* pa = partial + (size_t)(ft + i) * PB;
   pt_add_grp<LANES, F28>(pa, pa + (size_t)half * PB, pa);
+}
+
+// What is left of the common list's trees after the first level (at most 4 partial sums per bucket when no bucket had more than 8 slices) folded by ONE launch:
+// a lane quad per multi-slice bucket adds its partials 1.. into partial 0 one after the other.  Two or three dependent additions of ~7 us inside one launch
+// instead of two launches of one level each (~10 us of launch floor + its addition per level): the chains of real-circuit-sized proofs are made of such steps.
+template <uint32_t LANES>
+__global__ void __launch_bounds__(256) k_tree_rest(char* __restrict__ partial, const uint32_t* __restrict__ list, uint32_t list_len, const uint2* __restrict__ scan_local,
+                                                   const uint2* __restrict__ scan_blk, uint32_t M, const uint32_t* __restrict__ meta) {
+  constexpr uint32_t PB = PtFmt<true>::BYTES;
+  const uint32_t h = (blockIdx.x * 256 + threadIdx.x) >> lg_lanes(LANES);
+  if (h >= list_len) return;
+  const uint32_t g = list[h];
+  const uint32_t ft = scan_at(scan_local, scan_blk, g).y, fn = (g + 1 < M) ? scan_at(scan_local, scan_blk, g + 1).y : meta[0];
+  const uint32_t L1 = (fn - ft + 1) >> 1;                   // partial sums the first level left at ft .. ft + L1 - 1
+  char* pa = partial + (size_t)ft * PB;
+  for (uint32_t i = 1; i < L1; ++i) pt_add_grp<LANES, true>(pa, pa + (size_t)i * PB, pa);
 }
 
 // The sums of slices 1.. of the super-heavy buckets (k_tree_pass with skip_b = 1 left them in slice 1) and the buckets' numbers, to the host.
@@ -1036,10 +1058,9 @@ int32_t msm_sort_phase(Ctx* c, SegArgs& segs, size_t pts, bool mont, const uint8
   hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(256), 0, s, tile_tot, ntiles, scan_blk, meta, (volatile uint32_t*)host_meta, sp.meta_seq);
   HIPCHK(hipGetLastError());
   if (!lean) HIPCHK(hipEventRecord(c->ev[1], s));
-  uint32_t* len_count = meta + 16; uint32_t* len_cursor = len_count + MAX_SLICE + 1; uint32_t* len_start = len_cursor + MAX_SLICE + 1;   // zeroed with hist/meta
+  uint32_t* len_count = meta + 16; uint32_t* len_cursor = len_count + MAX_SLICE + 1;   // zeroed with hist/meta
   hipLaunchKernelGGL(k_slice_count, dim3(sp.slice_blocks), dim3(256), 0, s, hist, scan_local, scan_blk, M, total_pairs, meta, task_g, len_count);
-  hipLaunchKernelGGL(k_len_starts, dim3(1), dim3(256), 0, s, len_count, len_start);
-  hipLaunchKernelGGL(k_slice_order, dim3(sp.slice_blocks), dim3(256), 0, s, hist, scan_local, scan_blk, total_pairs, M, meta, task_g, len_start, len_cursor, order);
+  hipLaunchKernelGGL(k_slice_order, dim3(sp.slice_blocks), dim3(256), 0, s, hist, scan_local, scan_blk, total_pairs, M, meta, task_g, len_count, len_cursor, order);
   HIPCHK(hipGetLastError());
   return ALEO_MI355X_OK;
 }
@@ -1182,8 +1203,15 @@ static int32_t msm_front_finish(Ctx* c, hipStream_t s, Front& f, bool allow_asid
     hipLaunchKernelGGL(k_gather_super, dim3((sm.n_super * 57 + 255) / 256), dim3(256), 0, c->side, partial, sp.super_list, sm.n_super, scan_local, scan_blk, dst);
     HIPCHK(hipEventRecord(c->ev[4], c->side));
   }
+  // the levels behind the first in one launch (k_tree_rest) when only the common list is left and no bucket has more than 8 slices (ALEO_MI355X_TREE_REST=0: one launch per level)
+  static const bool tree_rest = [] { const char* e = std::getenv("ALEO_MI355X_TREE_REST"); return !(e && e[0] == '0'); }();
+  const bool rest_ok = tree_rest && pre && quads_on() && !sm.super_overflow && (aside || sm.n_super == 0) && sm.n_heavy && sm.max_common > 2 && sm.max_common <= 8;
   if (sm.NT) {
     for (uint32_t pass = 0, L = sm.max_m, Lcm = sm.max_common; L > 1; ++pass, L = (L + 1) >> 1, Lcm = (Lcm + 1) >> 1) {
+      if (rest_ok && pass == 1) {
+        hipLaunchKernelGGL(k_tree_rest<4>, dim3((uint32_t)((4ull * sm.n_heavy + 255) / 256)), dim3(256), 0, s, partial, heavy, sm.n_heavy, scan_local, scan_blk, M, meta);
+        break;
+      }
       const uint32_t Lc = sm.super_overflow ? L : Lcm;       // longest bucket of the common list at this level
       const uint32_t len_a = (sm.n_heavy && Lc > 1) ? sm.n_heavy : 0, pairs_a = len_a ? Lc >> 1 : 0;
       const uint32_t len_b = aside ? 0 : sm.n_super, pairs_b = len_b ? L >> 1 : 0;

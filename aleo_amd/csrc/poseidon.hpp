@@ -107,7 +107,7 @@ template <int N, int RATE> struct PoseidonParams {
 };
 
 template <int N> __attribute__((always_inline)) inline HFp<N> pow17(const HFp<N>& x) {
-  HFp<N> a = fmul(x, x); a = fmul(a, a); a = fmul(a, a); a = fmul(a, a); return fmul(a, x);
+  HFp<N> a = fsqr(x); a = fsqr(a); a = fsqr(a); a = fsqr(a); return fmul(a, x);
 }
 
 template <int N, int RATE> inline void poseidon_permute(HFp<N>* s) {

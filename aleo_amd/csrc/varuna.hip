@@ -924,6 +924,7 @@ int32_t varuna_prove_batch(Ctx* c, const PinnedBases& pb, const aleo_mi355x_varu
 int32_t varuna_prove_many(Ctx* c, const PinnedBases& pb, std::vector<ProveRequest>& rq, int workers) {
   g_varuna_timing[6] = g_varuna_timing[7] = 0;
   const double t0 = now_ms();
+  HT("many: enter");
   hipStream_t s = c->stream; const size_t n = rq.size();
   if (workers <= 0) { workers = 4; if (const char* e = std::getenv("ALEO_MI355X_LOCKSTEP_WORKERS")) { const int k = std::atoi(e); if (k >= 1 && k <= MAX_SLOTS + 1) workers = k; } }
   HelperSet hs;
@@ -973,12 +974,16 @@ int32_t varuna_prove_many(Ctx* c, const PinnedBases& pb, std::vector<ProveReques
     auto fail_mine = [&](int32_t rc, const char* why) { for (size_t p = w; p < n; p += W) if (alive[p]) { alive[p] = 0; rq[p].status = rc; rq[p].error = why; } };
     auto round = [&](const std::function<int32_t(Batch&, size_t)>& prepare, const std::function<int32_t(Batch&, size_t)>& finish) -> bool {
       each(prepare);
+      if (!w) HT("many: my proofs prepared");
       if (w && hipEventRecord(wc[w]->ev[0], sw) != hipSuccess) fail_mine(ALEO_MI355X_ERR_HIP, "hipEventRecord failed");
       bar.wait();
+      if (!w) HT("many: all prepared");
       if (w == 0) { try { fatal = commits(); } catch (...) { fatal = ALEO_MI355X_ERR_HIP; g_last_error = "varuna_prove_many: exception in the commitments"; } if (fatal) fatal_error = g_last_error; }
+      if (!w) HT("many: committed");
       bar.wait();
       if (fatal) return false;
       if (finish) each(finish);
+      if (!w) HT("many: my transcripts");
       return true;
     };
     if (!round([&](Batch& b, size_t p) { return b.first_prepare(rq[p].assignments); }, [](Batch& b, size_t) { return b.first_finish(); })) return;
@@ -999,13 +1004,17 @@ int32_t varuna_prove_many(Ctx* c, const PinnedBases& pb, std::vector<ProveReques
     catch (...) { started = false; }
   }
   { std::lock_guard<std::mutex> g(gate_mu); gate = started ? 1 : -1; } gate_cv.notify_all();
+  HT("many: threads started");
   if (started) worker(0);
+  HT("many: worker 0 done");
   for (auto& t : th) t.join();
+  HT("many: joined");
   if (!started) { g_last_error = "varuna_prove_many: could not start a worker thread"; return ALEO_MI355X_ERR_HIP; }
   for (size_t w = 1; w < W; ++w) (void)hipStreamSynchronize(wc[w]->stream);      // nothing of this call is left on a helper stream when it goes back to the pool
   if (fatal) { g_last_error = fatal_error; return fatal; }
   for (int i = 0; i < 5; ++i) g_varuna_timing[i] = 0;
   g_varuna_timing[5] = now_ms() - t0;
+  if (g_host_trace_on) host_trace_mark(nullptr);
   return ALEO_MI355X_OK;
 }
 

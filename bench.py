@@ -214,7 +214,8 @@ def main():
             try:
                 pm = json.load(open(tf))
                 # per LAUNCH of k_accum28, like `achieved`: the chunked host-scalar call makes `launches` of them per step (round-4 passes: the mean of the step's launches)
-                traffic = pm.get('round4', {}).get('k_accum_hbm_bytes_per_launch_mean') if launches == 2 else pm.get('k_accum_hbm_bytes_per_launch')
+                # (a chunked call of 3 launches — from 2^21 points — has no PMC pass of its own: null rather than a figure for another launch shape)
+                traffic = pm.get('round4', {}).get('k_accum_hbm_bytes_per_launch_mean') if launches == 2 else (pm.get('k_accum_hbm_bytes_per_launch') if launches == 1 else None)
             except Exception: traffic = None
         wl = ('2^%d-point BLS12-377 G1 Pippenger MSM split over %d GPUs (BASELINE configs[4])' % (total.bit_length() - 1, world)) if strong else \
              ('standalone 2^%d-point BLS12-377 G1 Pippenger MSM (BASELINE configs[1])' % (n.bit_length() - 1))
@@ -228,6 +229,10 @@ def main():
                        'scalars': 'host memory (pageable), uploaded inside every timed step (SURVEY.md 8d(i)); value_scalars_resident is the variant with scalars already in HBM',
                        'bases': 'pinned in HBM, P_i=(i+1)G generated on device' + ('' if args.no_precompute else '; fixed-base window tables built at pin time (precompute_s, table_bytes)'),
                        'entry_point': 'aleo_mi355x_msm_g1_pinned',
+                       # the headline is a FIXED-BASE call (window tables built once per pinned SRS: precompute_s, table_bytes).  The seam the reference has today —
+                       # VariableBase::msm(bases, scalars) with nothing pinned — costs what these two say (same points, same scalars, ms per call):
+                       'unpinned_seam_ms': {'one_shot_cold (host bases + host scalars, nothing cached: aleo_mi355x_msm_g1)': variants.get('ms_one_shot_cold'),
+                                            'pinned_without_tables': variants.get('ms_no_table')},
                        'sharding': ('point-sharded, all-gather of 144-byte partials' if world > 1 else 'single GPU')},
             'precompute_s': precompute_s, 'table_bytes': info['table_bytes'], 'base_row_bytes': info['row_bytes'], 'table_window_bits': info['tier_window_bits'],
             **variants,

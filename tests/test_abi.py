@@ -103,3 +103,51 @@ def test_routing_thresholds_and_their_environment_overrides():
     assert run({}) == ['1024', '4096']
     assert run({'ALEO_MI355X_MIN_MSM': '65536', 'ALEO_MI355X_MIN_NTT': '32'}) == ['65536', '32']
     assert run({'ALEO_MI355X_MIN_MSM': 'nonsense'}) == ['1024', '4096']
+
+
+# ---- INTEGRATION.md's Rust stub against the header (row f2: the only form the Rust side can take in this image) ---------------------------------------------
+_C2RUST = {'int32_t': 'i32', 'uint32_t': 'u32', 'uint64_t': 'u64', 'size_t': 'usize', 'int64_t': 'i64', 'double': 'f64', 'uint8_t': 'u8'}
+
+
+def _c_prototypes():
+    """name -> (return type, [normalised parameter types]) for every function include/aleo_mi355x.h declares."""
+    src = open(os.path.join(ROOT, 'include', 'aleo_mi355x.h')).read()
+    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    out = {}
+    for m in re.finditer(r'\b(int32_t|size_t|const char\*)\s+(aleo_mi355x_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;', src, flags=re.S):
+        ret, name, params = m.group(1), m.group(2), ' '.join(m.group(3).split())
+        ps = [] if params in ('', 'void') else [p.strip() for p in params.split(',')]
+        out[name] = (ret, ps)
+    return out
+
+
+def _c_param_kind(p):
+    """'ptr' for any pointer / array parameter, else the Rust scalar name of the C integer type."""
+    if '*' in p or '[' in p: return 'ptr'
+    t = re.sub(r'\bconst\b', '', p).split()
+    return _C2RUST.get(t[0], t[0])
+
+
+def _rust_param_kind(p):
+    t = p.split(':', 1)[1]
+    t = re.sub(r'/\*.*?\*/', '', t).strip()
+    return 'ptr' if t.startswith('*') else t
+
+
+def test_integration_md_rust_stub_matches_the_header():
+    """Every `fn aleo_mi355x_*` of the extern "C" blocks in INTEGRATION.md must name a function the header declares, with the same number of parameters,
+    a pointer where the header has a pointer, the same integer width elsewhere, and an i32 status where the header returns int32_t."""
+    md = open(os.path.join(ROOT, 'INTEGRATION.md')).read()
+    protos = _c_prototypes()
+    decls = re.findall(r'\bfn\s+(aleo_mi355x_[a-z0-9_]+)\s*\((.*?)\)\s*(?:->\s*([A-Za-z0-9_*\s]+?))?\s*;', md, flags=re.S)
+    assert len(decls) >= 19
+    for name, params, ret in decls:
+        assert name in protos, f'INTEGRATION.md binds {name}, which include/aleo_mi355x.h does not declare'
+        c_ret, c_params = protos[name]
+        params = re.sub(r'//[^\n]*', '', params)
+        rp = [p.strip() for p in re.sub(r'/\*.*?\*/', '', params, flags=re.S).split(',') if p.strip()]
+        assert len(rp) == len(c_params), (name, rp, c_params)
+        for r, c_ in zip(rp, c_params):
+            assert _rust_param_kind(r) == _c_param_kind(c_), (name, r, c_)
+        want_ret = {'int32_t': 'i32', 'size_t': 'usize', 'const char*': None}[c_ret]
+        if want_ret: assert ret.strip() == want_ret, (name, ret, c_ret)

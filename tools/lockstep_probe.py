@@ -29,8 +29,8 @@ with varuna.NativeCircuitIndex(csr, n, 4, len(z) - 4, ck) as nx:
         got = varuna.prove_many_native(reqs)
         assert got[0] == nx.prove(zz, 100) and got[-1] == nx.prove(zz, 100 + P - 1)
         out['lockstep_%d' % P] = rate(lambda: varuna.prove_many_native(reqs), P)
-    for T, P in ((2, 8), (4, 8), (2, 16)):                      # several lockstep calls in flight
-        per = 3
+    for T, P in ((2, 4), (4, 2), (2, 8), (4, 8), (2, 16)):      # several lockstep calls in flight
+        per = 6 if P <= 4 else 3
         def work(k):
             reqs = [([nx], [[zz]], 1000 * k + q) for q in range(P)]
             for _ in range(per): varuna.prove_many_native(reqs)

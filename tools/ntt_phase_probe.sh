@@ -18,6 +18,5 @@ fi
 out="gpurun_out/$2"; mkdir -p "$out"; shift 2
 python3 tools/ntt_ab.py "$@" > "$out/full.jsonl"
 for v in 1 2 3; do
-  cp $ab/libprobe$v.so $lib/libaleo_mi355x.so
-  python3 tools/ntt_ab.py "$@" > "$out/probe$v.jsonl"
+  ALEO_MI355X_LIB="$PWD/$ab/libprobe$v.so" python3 tools/ntt_ab.py "$@" > "$out/probe$v.jsonl"      # loaded through the override: the in-tree library is never replaced
 done
