@@ -21,7 +21,7 @@ EXPORTS = [
     'aleo_mi355x_bech32m_encode', 'aleo_mi355x_bech32m_decode', 'aleo_mi355x_proof_to_bytes',
     'aleo_mi355x_poseidon_hash_fr', 'aleo_mi355x_fs_new', 'aleo_mi355x_fs_free', 'aleo_mi355x_fs_absorb_bytes', 'aleo_mi355x_fs_absorb_g1',
     'aleo_mi355x_fs_absorb_fr', 'aleo_mi355x_fs_squeeze_fr', 'aleo_mi355x_fr_random', 'aleo_mi355x_poseidon_parameters_fr',
-    'aleo_mi355x_init_device', 'aleo_mi355x_device_count', 'aleo_mi355x_peer_info', 'aleo_mi355x_min_msm', 'aleo_mi355x_min_ntt', 'aleo_mi355x_kzg_commit_segments_sharded_device', 'aleo_mi355x_kzg_commit_batch_sharded_device', 'aleo_mi355x_bases_attach_shards', 'aleo_mi355x_bases_pin_sharded', 'aleo_mi355x_bases_generate_sharded', 'aleo_mi355x_bases_unpin_sharded',
+    'aleo_mi355x_init_device', 'aleo_mi355x_device_count', 'aleo_mi355x_peer_info', 'aleo_mi355x_min_msm', 'aleo_mi355x_min_ntt', 'aleo_mi355x_kzg_commit_segments_sharded_device', 'aleo_mi355x_kzg_commit_batch_sharded_device', 'aleo_mi355x_bases_attach_shards', 'aleo_mi355x_bases_shard_transforms', 'aleo_mi355x_bases_pin_sharded', 'aleo_mi355x_bases_generate_sharded', 'aleo_mi355x_bases_unpin_sharded',
     'aleo_mi355x_bases_sharded_info', 'aleo_mi355x_msm_g1_sharded', 'aleo_mi355x_fr_transpose_device', 'aleo_mi355x_ntt_fr_sharded', 'aleo_mi355x_ntt_fr_sharded_device', 'aleo_mi355x_selftest_host_inverse', 'aleo_mi355x_varuna_prove_many',
 ]
 
@@ -64,6 +64,7 @@ def lib():
         'aleo_mi355x_kzg_commit_segments_sharded_device': ([vp, sz, u64, vp, sz, vp], i32),
         'aleo_mi355x_kzg_commit_batch_sharded_device': ([vp, u64, vp, vp, sz, vp], i32),
         'aleo_mi355x_bases_attach_shards': ([u64, u64, sz], i32),
+        'aleo_mi355x_bases_shard_transforms': ([u64, sz], i32),
         'aleo_mi355x_bases_pin_sharded': ([vp, sz, sz, ctypes.POINTER(i32), sz, i32, ctypes.POINTER(u64)], i32),
         'aleo_mi355x_bases_generate_sharded': ([vp, u64, sz, ctypes.POINTER(i32), sz, i32, ctypes.POINTER(u64)], i32),
         'aleo_mi355x_bases_unpin_sharded': ([u64], i32),

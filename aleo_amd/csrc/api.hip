@@ -420,6 +420,7 @@ template <int N> void inverse_selftest(uint32_t count, uint64_t seed, uint32_t* 
     bool ok = a[i] == b[i];
     if (ok && !v[i].is_zero()) ok = F::mul(a[i], v[i]) == F::one();      // and it IS the inverse
     ok = ok && F::sqr(v[i]) == F::mul(v[i], v[i]) && F::sqr(a[i]) == F::mul(a[i], a[i]);      // the dedicated squaring against the product
+    { host::Wide<N> w; w.set_sqr(v[i].l); host::Wide<N> u; u.set_mul(v[i].l, v[i].l); ok = ok && w.redc() == u.redc(); }
     if (!ok) ++*failures;
   }
   if (ns) { ns[0] = std::chrono::duration<double, std::nano>(t1 - t0).count() / v.size(); ns[1] = std::chrono::duration<double, std::nano>(t2 - t1).count() / v.size(); }
@@ -1447,7 +1448,18 @@ int32_t aleo_mi355x_bases_attach_shards(uint64_t handle, uint64_t sharded_handle
     auto it = d->bases.find(handle);
     if (it == d->bases.end()) { g_last_error = "unknown bases handle"; return ALEO_MI355X_ERR_BAD_HANDLE; }
     if (sharded_handle && n_sh != it->second->pb.n) { g_last_error = "bases_attach_shards: the sharded set must hold the same number of points"; return ALEO_MI355X_ERR_BAD_ARG; }
-    it->second->pb.shards = sharded_handle; it->second->pb.shard_min = min_points;
+    it->second->pb.shards = sharded_handle; it->second->pb.shard_min = min_points; it->second->pb.shard_ntt_min = (size_t)1 << 24;
+    return ALEO_MI355X_OK;
+  } catch (...) { return ALEO_MI355X_ERR_HIP; }
+}
+
+int32_t aleo_mi355x_bases_shard_transforms(uint64_t handle, size_t min_elements) {
+  try {
+    Device* d = nullptr; { const int32_t rc = get_device(&d); if (rc) return rc; }
+    std::lock_guard<std::mutex> lk(d->mu);
+    auto it = d->bases.find(handle);
+    if (it == d->bases.end()) { g_last_error = "unknown bases handle"; return ALEO_MI355X_ERR_BAD_HANDLE; }
+    it->second->pb.shard_ntt_min = min_elements ? min_elements : (size_t)1 << 24;
     return ALEO_MI355X_OK;
   } catch (...) { return ALEO_MI355X_ERR_HIP; }
 }
@@ -1492,7 +1504,7 @@ int32_t aleo_mi355x_kzg_commit_batch_sharded_device(void* out104, uint64_t shard
 // every column transform has finished.  A device may be listed more than once (the tests: one card).
 }  // extern "C" (helpers of the sharded transform follow)
 namespace {
-struct NttShard { int dev = 0; hipStream_t st = nullptr; void *a = nullptr, *b = nullptr; };      // two buffers of n / G elements each, ping-pong (owned by the device's ShardWs)
+struct NttShard { int dev = 0; hipStream_t st = nullptr; void *a = nullptr, *b = nullptr; ShardWs* w = nullptr; };      // two buffers of n / G elements each, ping-pong (owned by the device's ShardWs)
 std::mutex g_ntt_sh_mu;                                     // one sharded transform at a time: it occupies every listed device anyway
 int32_t peer_copy(void* dst, int dst_dev, const void* src, int src_dev, size_t bytes, hipStream_t s) {
   if (dst_dev == src_dev) { HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, s)); }
@@ -1510,7 +1522,45 @@ int32_t shard_ws(size_t ordinal, size_t bytes, NttShard* out) {
   }
   if (!w->st) HIPCHK(hipStreamCreateWithFlags(&w->st, hipStreamNonBlocking));
   { int32_t rc; if ((rc = w->a.reserve(bytes)) || (rc = w->b.reserve(bytes))) return rc; }
-  out->dev = d->device; out->st = w->st; out->a = w->a.p; out->b = w->b.p;
+  out->dev = d->device; out->st = w->st; out->a = w->a.p; out->b = w->b.p; out->w = w;
+  return ALEO_MI355X_OK;
+}
+// The strided moves between ONE pageable host buffer and a shard's device buffer through two pinned bounce buffers of the shard (A/B switch ALEO_MI355X_SHARD_BOUNCE=1;
+// default: hipMemcpy2DAsync on the pageable buffer, which the runtime stages itself).  The shard's own thread gathers / scatters the rows with memcpy while the previous
+// chunk is on the link, so G shards on G devices move their 1/G of the buffer in parallel without sharing the runtime's staging path.  rows x row_bytes, host pitch in bytes.
+static constexpr size_t BOUNCE_BYTES = (size_t)8 << 20;
+bool bounce_on() { static const bool v = [] { const char* e = std::getenv("ALEO_MI355X_SHARD_BOUNCE"); return e && e[0] == '1'; }(); return v; }
+int32_t bounce_reserve(ShardWs* w) {
+  if (w->pin_cap) return ALEO_MI355X_OK;
+  for (int b = 0; b < 2; ++b) { HIPCHK(hipHostMalloc(&w->pin[b], BOUNCE_BYTES, hipHostMallocDefault)); HIPCHK(hipEventCreateWithFlags(&w->pin_ev[b], hipEventDisableTiming)); }
+  w->pin_cap = BOUNCE_BYTES; return ALEO_MI355X_OK;
+}
+int32_t bounce_upload(ShardWs* w, char* d_dst, const char* h_src, size_t h_pitch, size_t row_bytes, size_t rows, hipStream_t st) {
+  int32_t rc = bounce_reserve(w); if (rc) return rc;
+  if (row_bytes > BOUNCE_BYTES) { HIPCHK(hipMemcpy2DAsync(d_dst, row_bytes, h_src, h_pitch, row_bytes, rows, hipMemcpyHostToDevice, st)); return ALEO_MI355X_OK; }
+  const size_t per = BOUNCE_BYTES / row_bytes;
+  for (size_t r0 = 0, i = 0; r0 < rows; r0 += per, ++i) {
+    const int b = (int)(i & 1); const size_t nr = rows - r0 < per ? rows - r0 : per;
+    if (i >= 2) HIPCHK(hipEventSynchronize(w->pin_ev[b]));
+    for (size_t r = 0; r < nr; ++r) std::memcpy((char*)w->pin[b] + r * row_bytes, h_src + (r0 + r) * h_pitch, row_bytes);
+    HIPCHK(hipMemcpyAsync(d_dst + r0 * row_bytes, w->pin[b], nr * row_bytes, hipMemcpyHostToDevice, st));
+    HIPCHK(hipEventRecord(w->pin_ev[b], st));
+  }
+  return ALEO_MI355X_OK;
+}
+int32_t bounce_download(ShardWs* w, char* h_dst, size_t h_pitch, const char* d_src, size_t row_bytes, size_t rows, hipStream_t st) {
+  int32_t rc = bounce_reserve(w); if (rc) return rc;
+  if (row_bytes > BOUNCE_BYTES) { HIPCHK(hipMemcpy2DAsync(h_dst, h_pitch, d_src, row_bytes, row_bytes, rows, hipMemcpyDeviceToHost, st)); return ALEO_MI355X_OK; }
+  const size_t per = BOUNCE_BYTES / row_bytes; size_t prev_r0 = 0, prev_nr = 0; int prev_b = -1;
+  auto scatter = [&](int b, size_t r0, size_t nr) { for (size_t r = 0; r < nr; ++r) std::memcpy(h_dst + (r0 + r) * h_pitch, (const char*)w->pin[b] + r * row_bytes, row_bytes); };
+  for (size_t r0 = 0, i = 0; r0 < rows; r0 += per, ++i) {
+    const int b = (int)(i & 1); const size_t nr = rows - r0 < per ? rows - r0 : per;
+    HIPCHK(hipMemcpyAsync(w->pin[b], d_src + r0 * row_bytes, nr * row_bytes, hipMemcpyDeviceToHost, st));      // (buffer b was scattered out two chunks ago)
+    HIPCHK(hipEventRecord(w->pin_ev[b], st));
+    if (prev_b >= 0) { HIPCHK(hipEventSynchronize(w->pin_ev[prev_b])); scatter(prev_b, prev_r0, prev_nr); }
+    prev_b = b; prev_r0 = r0; prev_nr = nr;
+  }
+  if (prev_b >= 0) { HIPCHK(hipEventSynchronize(w->pin_ev[prev_b])); scatter(prev_b, prev_r0, prev_nr); }
   return ALEO_MI355X_OK;
 }
 }  // namespace
@@ -1546,7 +1596,8 @@ int32_t aleo_mi355x_ntt_fr_sharded(void* inout, uint32_t lg_n, int32_t direction
       // phase 1: columns in, column transforms, twiddle, blocks by destination
       phase([&]() -> int32_t {
         int32_t q = shard_ws(ordinal[g], per * 32, &d); if (q) return q;
-        HIPCHK(hipMemcpy2DAsync(d.a, Cg * 32, host + g * Cg * 32, C * 32, Cg * 32, R, hipMemcpyHostToDevice, d.st));               // a = [R][Cg]
+        if (bounce_on()) { if ((q = bounce_upload(d.w, (char*)d.a, host + g * Cg * 32, C * 32, Cg * 32, R, d.st))) return q; }
+        else HIPCHK(hipMemcpy2DAsync(d.a, Cg * 32, host + g * Cg * 32, C * 32, Cg * 32, R, hipMemcpyHostToDevice, d.st));          // a = [R][Cg]
         if (type == ALEO_NTT_COSET && direction == ALEO_NTT_FORWARD && (q = aleo_mi355x_fr_grid_scale_device(d.a, lg_n, R, Cg, 0, g * Cg, C, 1, 0, d.st))) return q;
         if ((q = aleo_mi355x_fr_transpose_device(d.b, d.a, R, Cg, d.st))) return q;                                                   // b = [Cg][R]
         if ((q = aleo_mi355x_ntt_fr_batch_device(d.b, lg_r, Cg, ALEO_NTT_ORDER_NN, direction, ALEO_NTT_STANDARD, d.st))) return q;     // [c][k_r] (inverse: x R^-1)
@@ -1570,7 +1621,8 @@ int32_t aleo_mi355x_ntt_fr_sharded(void* inout, uint32_t lg_n, int32_t direction
         if ((q = aleo_mi355x_ntt_fr_batch_device(d.a, lg_c, Rg, ALEO_NTT_ORDER_NN, direction, ALEO_NTT_STANDARD, d.st))) return q;     // [k_r][k_c] (inverse: x C^-1)
         if ((q = aleo_mi355x_fr_transpose_device(d.b, d.a, Rg, C, d.st))) return q;                                                   // b = [k_c][k_r local]: X[k_c R + k_r]
         if (type == ALEO_NTT_COSET && direction == ALEO_NTT_INVERSE && (q = aleo_mi355x_fr_grid_scale_device(d.b, lg_n, C, Rg, 0, g * Rg, R, 1, 1, d.st))) return q;
-        HIPCHK(hipMemcpy2DAsync(host + g * Rg * 32, R * 32, d.b, Rg * 32, Rg * 32, C, hipMemcpyDeviceToHost, d.st));
+        if (bounce_on()) { if ((q = bounce_download(d.w, host + g * Rg * 32, R * 32, (const char*)d.b, Rg * 32, C, d.st))) return q; }
+        else HIPCHK(hipMemcpy2DAsync(host + g * Rg * 32, R * 32, d.b, Rg * 32, Rg * 32, C, hipMemcpyDeviceToHost, d.st));
         HIPCHK(hipStreamSynchronize(d.st));
         return ALEO_MI355X_OK;
       });

@@ -77,6 +77,7 @@ struct PinnedBases {
   // a sharded copy of the same points on several devices (aleo_mi355x_bases_attach_shards): commitments of >= shard_min points made against this set by the
   // prover / the segment entry points go to the shards (api.hip commit_sharded) — 0 = none
   uint64_t shards = 0; size_t shard_min = 0;
+  size_t shard_ntt_min = (size_t)1 << 24;      // transforms of at least this many elements take the shards' devices too (aleo_mi355x_bases_shard_transforms; default 2^24: below it the 4-step split costs more in barriers and copies than a 0.1-2 ms single-device transform does)
   size_t n = 0;
 };
 
@@ -150,7 +151,7 @@ struct Barrier {                                           // reusable; C++17 ha
 
 // What one shard of a transform sharded over devices (aleo_mi355x_ntt_fr_sharded) keeps on its device between calls: a stream and two grow-only
 // buffers of n / G elements.  A device listed k times in a call uses its first k entries.
-struct ShardWs { hipStream_t st = nullptr; DevBuf a, b; };
+struct ShardWs { hipStream_t st = nullptr; DevBuf a, b; void* pin[2] = {nullptr, nullptr}; size_t pin_cap = 0; hipEvent_t pin_ev[2] = {nullptr, nullptr}; };      // pin: two pinned bounce buffers for the strided host <-> device moves of the host-buffer transform (ALEO_MI355X_SHARD_BOUNCE=1)
 
 struct Device {
   int device = -1;

@@ -77,12 +77,12 @@ double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::
 
 thread_local double g_varuna_timing[8] = {};
 
-// The prover's transforms.  With a sharded copy of the committer key attached (row e2: a proof that spans devices) a transform of >= shard_min elements runs over
+// The prover's transforms.  With a sharded copy of the committer key attached (row e2: a proof that spans devices) a transform of >= shard_ntt_min elements (default 2^24, aleo_mi355x_bases_shard_transforms) runs over
 // the devices the key is spread over (api.hip ntt_sharded_device: slabs pulled and pushed by peer copies, the coefficient vector stays on the prover's device
 // between the rounds) — the "NTT coefficients" half of north_star's "large proofs shard MSM bases and NTT coefficients"; everything else, and any device list
 // that is not a power of two, takes the single-device kernels.  Same values either way (tests: proofs byte-equal).
 static bool ntt_routed(const PinnedBases& pb, uint32_t lg, std::vector<int>* devs) {
-  if (!pb.shards || lg < 2 || ((size_t)1 << lg) < pb.shard_min) return false;
+  if (!pb.shards || lg < 2 || ((size_t)1 << lg) < pb.shard_ntt_min) return false;
   if (sharded_devices(pb.shards, devs)) return false;
   const size_t G = devs->size(); uint32_t lg_g = 0; while (((size_t)1 << lg_g) < G) ++lg_g;
   return G >= 1 && !(G & (G - 1)) && lg / 2 >= lg_g;

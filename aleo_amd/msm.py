@@ -63,10 +63,13 @@ class PinnedBases:
         if k < 7: raise ValueError('unknown bases handle')
         return {'points': int(buf[0]), 'row_bytes': int(buf[1]), 'table_bytes': int(buf[2]), 'tier_window_bits': [int(buf[3 + i]) for i in range(int(buf[6]))]}
 
-    def attach_shards(self, sharded: 'ShardedBases' = None, min_points: int = 0) -> 'PinnedBases':
+    def attach_shards(self, sharded: 'ShardedBases' = None, min_points: int = 0, transforms_from: int = None) -> 'PinnedBases':
         """From now on the prover's commitments against this set with >= min_points scalars go through `sharded` — the same points cut over several
-        devices (aleo_mi355x_bases_attach_shards).  None detaches.  The sharded set must outlive the attachment."""
+        devices (aleo_mi355x_bases_attach_shards).  None detaches.  The sharded set must outlive the attachment.
+        transforms_from: the prover's transforms of at least that many elements run over the same devices (aleo_mi355x_bases_shard_transforms; default 2^24)."""
         check(lib().aleo_mi355x_bases_attach_shards(self.handle, sharded.handle if sharded is not None else 0, int(min_points)), 'bases_attach_shards')
+        if sharded is not None and transforms_from is not None:
+            check(lib().aleo_mi355x_bases_shard_transforms(self.handle, int(transforms_from)), 'bases_shard_transforms')
         return self
 
     def download(self, offset: int = 0, n: int = None) -> np.ndarray:

@@ -847,6 +847,13 @@ def varuna_sharded_rehearsal(synth, lg, shard_counts=(2, 8)):
                     a1, d1 = timed(nx, 1); a8, d8 = timed(nx, 8)
                 if d1 != want1 or d8 != want8: raise SystemExit('bench: the proof against the sharded key differs from the single-device proof')
                 out['shards_%d' % G] = {'prove_ms': a1, 'instances_8_ms': a8, 'constraints_per_s_8': 8 * n / a8 * 1e3, 'pin_and_tables_s': setup_s, 'bytes_equal_single_device': True}
+                if G == 2:                                   # the same with every transform of >= 2^16 elements over the shards too (aleo_mi355x_ntt_fr_sharded_device's path: slabs by peer copy)
+                    ck.bases.attach_shards(sb, 1 << 16, transforms_from=1 << 16)
+                    with varuna.NativeCircuitIndex(csr, n, 4, len(z) - 4, ck) as nx:
+                        t1, e1 = timed(nx, 1)
+                    if e1 != want1: raise SystemExit('bench: the proof with sharded transforms differs from the single-device proof')
+                    out['shards_2_with_transforms'] = {'prove_ms': t1, 'bytes_equal_single_device': True,
+                                                       'what': 'commitments AND transforms of >= 2^16 elements over the shards (default: transforms from 2^24 elements); one card: pure overhead of the split'}
             finally:
                 ck.bases.attach_shards(None); sb.close()
         del host

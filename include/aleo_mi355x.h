@@ -197,7 +197,7 @@ int32_t aleo_mi355x_ntt_fr_sharded(void* inout, uint32_t lg_n, int32_t direction
  * contiguous slab, device g pulls its slab (hipMemcpyPeerAsync over xGMI; the home device itself: a plain copy), column transforms + twiddle, the all-to-all
  * as one peer copy per ordered pair, row transforms, every device pushes its rows back and home restores the natural order.  Same values as
  * aleo_mi355x_ntt_fr_device.  Blocking (the result is complete on return); `stream`: the stream the data was produced on (NULL = the slot's own).  The prover
- * routes its transforms of >= min_points elements through this entry when its committer key has shards attached (aleo_mi355x_bases_attach_shards): the
+ * routes its transforms of >= 2^24 elements (aleo_mi355x_bases_shard_transforms sets the size) through this entry when its committer key has shards attached (aleo_mi355x_bases_attach_shards): the
  * "NTT coefficients" half of "large proofs shard MSM bases and NTT coefficients across the GPUs". */
 int32_t aleo_mi355x_ntt_fr_sharded_device(void* d_inout, uint32_t lg_n, int32_t direction, int32_t type, const int32_t* devices, size_t n_devices, void* stream);
 
@@ -242,11 +242,16 @@ int32_t aleo_mi355x_kzg_commit_segments_sparse_device(void* out_affine104, size_
  *     boundaries, device g pulls its pieces (hipMemcpyPeerAsync over xGMI; no copy on the vectors' own device) and runs the ordinary batched Pippenger
  *     against its shard; n_outputs x 144 bytes per shard come back and are added on the host in shard order.  Same bytes as the single-device call.
  *   bases_attach_shards(handle, sharded_handle, min_points): from then on every commitment the PROVER makes against `handle` (varuna_index_build,
- *     varuna_prove*, the lockstep call) with at least min_points scalars in all goes through the sharded copy instead; the rounds' field work, the
- *     transforms and the transcript stay on the prover's device.  Same proof bytes.  sharded_handle 0 detaches. */
+ *     varuna_prove*, the lockstep call) with at least min_points scalars in all goes through the sharded copy instead; the rounds' field work and the
+ *     transcript stay on the prover's device, its transforms from a size of their own on take the shards' devices too (bases_shard_transforms below).  Same proof bytes.  sharded_handle 0 detaches. */
 int32_t aleo_mi355x_kzg_commit_segments_sharded_device(void* out_affine104, size_t n_outputs, uint64_t sharded_handle, const aleo_mi355x_commit_segment* segments, size_t n_segments, void* stream);
 int32_t aleo_mi355x_kzg_commit_batch_sharded_device(void* out_affine104, uint64_t sharded_handle, const void* const* d_coeffs_mont, const size_t* lens, size_t k, void* stream);
 int32_t aleo_mi355x_bases_attach_shards(uint64_t handle, uint64_t sharded_handle, size_t min_points);
+/* With shards attached the prover also runs its TRANSFORMS of at least min_elements elements over the shards' devices (aleo_mi355x_ntt_fr_sharded_device above;
+ * the device list must be a power of two, else they stay on the prover's device).  Default (also restored by every attach, and by min_elements = 0): 2^24 —
+ * below that a single-device transform takes 0.1-2 ms and the three barriers and 2 (G - 1) peer copies per device of the split cost more than they save; a
+ * deployment whose vectors do not fit one card sets it lower.  Same proof bytes for every value. */
+int32_t aleo_mi355x_bases_shard_transforms(uint64_t handle, size_t min_elements);
 
 /* KZG10::commit with a hiding bound: msm(powers, coeffs) + msm(gamma_powers, blinding_coeffs), affine result.
  * Both coefficient vectors are Montgomery Fr on the host; both base sets are pinned handles. */

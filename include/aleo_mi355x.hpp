@@ -239,7 +239,8 @@ class CommitterKey {
   // points cut into contiguous shards over `devices` (each device holds 1/G of the powers and of their window tables), owned by this key.  From then
   // on every commitment a prover makes against this key with at least min_points scalars in all is computed shard by shard — each device pulls its
   // slices of the coefficient vectors, 144 bytes per shard and result come back — and the proof bytes do not change (aleo_mi355x_bases_attach_shards).
-  Error shard_over(const std::vector<int32_t>& devices, size_t min_points = (size_t)1 << 16) {
+  // transforms_from: the prover's transforms of at least that many elements take the same devices (0 = the library's default, 2^24)
+  Error shard_over(const std::vector<int32_t>& devices, size_t min_points = (size_t)1 << 16, size_t transforms_from = 0) {
     unshard();
     std::vector<G1Affine> host(bases_.len());
     int32_t rc = aleo_mi355x_bases_download(bases_.handle(), 0, host.size(), host.data());
@@ -248,6 +249,7 @@ class CommitterKey {
     if (!sh.is_ok()) return sh.error;
     rc = aleo_mi355x_bases_attach_shards(bases_.handle(), sh.value->handle(), min_points);
     if (rc) return Error{rc};
+    if (transforms_from) { rc = aleo_mi355x_bases_shard_transforms(bases_.handle(), transforms_from); if (rc) return Error{rc}; }
     shards_ = std::move(*sh.value);
     return Error{0};
   }

@@ -886,10 +886,10 @@ def test_one_circuit_with_up_to_32_instances_native(k):
 
 
 def _shard_the_key(ck, devices):
-    """A sharded copy (with window tables per shard) of a committer key's points, attached so that EVERY commitment of the prover goes through it."""
+    """A sharded copy (with window tables per shard) of a committer key's points, attached so that EVERY commitment and EVERY transform of the prover goes through it."""
     host = ck.bases.download()
     sb = aleo_amd.ShardedBases(host, devices=devices, precompute=True)
-    ck.bases.attach_shards(sb, 0)
+    ck.bases.attach_shards(sb, 0, transforms_from=1)          # and every transform over the shards' devices (power-of-two device lists)
     return sb
 
 
@@ -984,7 +984,7 @@ def test_a_2_18_constraint_proof_against_a_sharded_key(G):
             a = SonicKZG10.commit_segments_device(ck, segs, 3)
             b = SonicKZG10.commit_segments_sharded_device(sb, segs, 3)
             assert (a == b).all()
-            ck.bases.attach_shards(sb, 1 << 16)
+            ck.bases.attach_shards(sb, 1 << 16, transforms_from=1 << 16)
             with varuna.NativeCircuitIndex(csr, n, 4, len(z) - 4, ck) as nx:
                 assert nx.vk_bytes == vk0
                 assert nx.prove([zz, zz], 4242) == want
