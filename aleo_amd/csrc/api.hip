@@ -45,7 +45,7 @@ struct HostPool {
 HostPool* g_host_pool = nullptr; std::once_flag g_host_pool_once;
 }  // namespace
 void host_parallel_for(size_t n, const std::function<void(size_t)>& f) {
-  if (n < 4) { for (size_t i = 0; i < n; ++i) f(i); return; }
+  if (n < 2) { for (size_t i = 0; i < n; ++i) f(i); return; }
   std::call_once(g_host_pool_once, [] {
     HostPool* p = new HostPool();                            // leaked on purpose: its threads sleep until the process ends
     try { for (int t = 0; t < HostPool::T; ++t) std::thread([p] { p->worker(); }).detach(); p->started = true; } catch (...) { p->started = false; }

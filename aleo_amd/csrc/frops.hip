@@ -14,6 +14,7 @@
 #include "ctx.h"
 #include "fp.h"
 #include "chacha.h"
+#include "host_field.hpp"
 #include <cstring>
 
 namespace aleo_mi355x {
@@ -469,10 +470,35 @@ __global__ void __launch_bounds__(256) k_fr_powers(char* __restrict__ dst, size_
     x = Fr::mul(x, ratio);
   }
 }
+// The latency form for sequences of up to 2^26 elements (the prover's r(alpha, X), r(beta, X): 2^15 elements took 29 us as ~30 dependent products per lane for
+// the lane's starting power + 16 for its walk): the squarings ratio^(4 2^i) come from the host (28 constants by value), a lane multiplies the ones its index
+// selects (no squaring on the device: ~lg(n) / 2 products) and walks 4 elements.
+static constexpr uint32_t POW_KS = 4, POW_SQ = 24;
+struct FrSq { FrK v[POW_SQ]; };
+__global__ void __launch_bounds__(256) k_fr_powers_fast(char* __restrict__ dst, uint32_t n, FrK kfirst, FrK kratio, FrSq sq) {
+  const uint32_t t = blockIdx.x * 256 + threadIdx.x, lo = t * POW_KS;
+  if (lo >= n) return;
+  Fr x = fr_arg(kfirst);
+  for (uint32_t i = 0, b = t; b; ++i, b >>= 1) if (b & 1u) x = Fr::mul(x, fr_arg(sq.v[i]));      // first * ratio^(4 t)
+  const Fr ratio = fr_arg(kratio);
+  for (uint32_t k = 0; k < POW_KS && lo + k < n; ++k) {
+    store_fp<Fr>(dst + (size_t)(lo + k) * 32, Fr::reduce(x));
+    x = Fr::mul(x, ratio);
+  }
+}
 int32_t fr_powers(Ctx* c, void* d_dst, size_t n, const void* first, const void* ratio, hipStream_t s) {
   (void)c;
   if (n == 0) return ALEO_MI355X_OK;
   FrK kf, kr; std::memcpy(kf.v, first, 32); std::memcpy(kr.v, ratio, 32);
+  if (n <= ((size_t)POW_KS << POW_SQ)) {
+    FrSq sq; host::HFr r; std::memcpy(r.l, ratio, 32);
+    r = host::HFr::sqr(host::HFr::sqr(r));                   // ratio^4
+    for (uint32_t i = 0; i < POW_SQ; ++i) { std::memcpy(sq.v[i].v, r.l, 32); r = host::HFr::sqr(r); }
+    const size_t lanes = (n + POW_KS - 1) / POW_KS;
+    hipLaunchKernelGGL(k_fr_powers_fast, dim3((uint32_t)((lanes + 255) / 256)), dim3(256), 0, s, (char*)d_dst, (uint32_t)n, kf, kr, sq);
+    HIPCHK(hipGetLastError());
+    return ALEO_MI355X_OK;
+  }
   const size_t lanes = (n + POW_K - 1) / POW_K;
   hipLaunchKernelGGL(k_fr_powers, dim3((uint32_t)((lanes + 255) / 256)), dim3(256), 0, s, (char*)d_dst, n, kf, kr);
   HIPCHK(hipGetLastError());

@@ -1359,7 +1359,7 @@ static int32_t msm_back(Ctx* c, uint64_t* out_jac18, Front& f, hipStream_t s, bo
     HT("msm: result arrived");
     t_host0 = std::chrono::steady_clock::now();
     HXYZZ totals[MAX_SETS];
-    // one Horner chain per result (~15 us): from 8 results on (the rounds of a lockstep call, many-instance proofs) they are spread over the library's parked helper threads
+    // one Horner chain per result (~15 us): from 3 results on they are spread over the library's parked helper threads (a lockstep round has 8 x k of them)
     auto horner = [&](size_t q) {
       const char* hw = h_win + q * out_pts * PB28;
       const uint32_t na = prog ? 1u : 4u;                  // points that hold sum_j acc_j: one (k_prog_final) or the four segment sums of the masked form
@@ -1369,8 +1369,8 @@ static int32_t msm_back(Ctx* c, uint64_t* out_jac18, Front& f, hipStream_t s, bo
       for (uint32_t r = 0; r < na; ++r) total = hadd(total, lazy_point28(hw + (size_t)r * PB28));
       totals[q] = total;
     };
-    static const bool tail_pool = [] { const char* e = std::getenv("ALEO_MI355X_TAIL_POOL"); return !(e && e[0] == '0'); }();      // A/B switch
-    if (K >= 8 && tail_pool) host_parallel_for(K, horner); else for (uint32_t q = 0; q < K; ++q) horner(q);
+    static const uint32_t tail_pool_min = [] { const char* e = std::getenv("ALEO_MI355X_TAIL_POOL"); const int k = e ? std::atoi(e) : 3; return (uint32_t)(k <= 0 ? 0x7fffffff : k); }();      // A/B switch: results from which the pool is used (0 = never; 2^15 proof: 5.68 / 5.65 / 5.74 ms with 8 / 3 / 2, profiles/r05_tailpool_min_ab.txt)
+    if (K >= tail_pool_min) host_parallel_for(K, horner); else for (uint32_t q = 0; q < K; ++q) horner(q);
     for (uint32_t h = 0; aside && h < sm.n_super; ++h) {             // (b + 1) * (slices 1.. of super-heavy bucket b), by double-and-add
       const uint32_t* rec = h_aside + (size_t)h * 57; const uint32_t g = rec[56], q = g / P.B, wgt = g % P.B + 1;
       if (q >= K) { g_last_error = "msm: internal: super-heavy bucket outside the sets"; return ALEO_MI355X_ERR_HIP; }
