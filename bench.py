@@ -215,7 +215,7 @@ def main():
                 pm = json.load(open(tf))
                 # per LAUNCH of k_accum28, like `achieved`: the chunked host-scalar call makes `launches` of them per step (round-4 passes: the mean of the step's launches)
                 # (a chunked call of 3 launches — from 2^21 points — has no PMC pass of its own: null rather than a figure for another launch shape)
-                traffic = pm.get('round4', {}).get('k_accum_hbm_bytes_per_launch_mean') if launches == 2 else (pm.get('k_accum_hbm_bytes_per_launch') if launches == 1 else None)
+                traffic = pm.get('round5', pm.get('round4', {})).get('k_accum_hbm_bytes_per_launch_mean') if launches == 2 else (pm.get('k_accum_hbm_bytes_per_launch') if launches == 1 else None)
             except Exception: traffic = None
         wl = ('2^%d-point BLS12-377 G1 Pippenger MSM split over %d GPUs (BASELINE configs[4])' % (total.bit_length() - 1, world)) if strong else \
              ('standalone 2^%d-point BLS12-377 G1 Pippenger MSM (BASELINE configs[1])' % (n.bit_length() - 1))
