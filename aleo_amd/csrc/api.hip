@@ -960,36 +960,43 @@ int32_t aleo_mi355x_varuna_prove_many(aleo_mi355x_prove_request* requests, size_
     FIND_BASES(key)
     std::vector<ProveRequest> live; std::vector<size_t> where;
     for (size_t p = 0; p < n_requests; ++p) if (!rq[p].status) { live.push_back(rq[p]); where.push_back(p); }
-    // From 4 proofs on the call runs as TWO lockstep groups on two threads (the caller's and one more, on a second context of the device): while one group's
+    // From 4 proofs on the call runs as up to FOUR lockstep groups (ALEO_MI355X_LOCKSTEP_GROUPS, default 4; never fewer than 2 proofs per group) on as many threads (the caller's and one per further group, each on a context of its own): while one group's
     // commitments hold the card, the other group's field kernels, sorts, reductions and transcripts — a third of a lockstep round — run in their shadow.  What
-    // two callers with half the proofs each achieve (8 proofs of 2^15 constraints: 254 proofs/s as one group, 275 as two calls of 4 in flight,
-    // profiles/r05_lockstep_probe_2^15_groups.json), without asking the host for a second thread.  ALEO_MI355X_LOCKSTEP_GROUPS=1: one group.  Proof bytes do not depend on it.
-    static const int groups_env = [] { const char* e = std::getenv("ALEO_MI355X_LOCKSTEP_GROUPS"); const int k = e ? std::atoi(e) : 2; return k >= 1 && k <= 2 ? k : 2; }();
+    // several callers with a share of the proofs each achieve (8 proofs of 2^15 constraints: 254 proofs/s as one group, 275 as two calls of 4 in flight, 280 as four calls of 2:
+    // profiles/r05_lockstep_probe_2^15_lean_folded.json; groups 1 / 2 / 3 / 4 on one box: 32.7 / 36.0 / 33.6 / 32.1 ms per 8 proofs, 68.7 / 65.6 / 62.1 / 58.7 per 16 — two groups are
+    // box-dependent, four never lose: profiles/r05_lockstep_groups_ab.txt), without asking the host for more threads.  ALEO_MI355X_LOCKSTEP_GROUPS=1: one group.  Proof bytes do not depend on it.
+    static const int groups_env = [] { const char* e = std::getenv("ALEO_MI355X_LOCKSTEP_GROUPS"); const int k = e ? std::atoi(e) : 4; return k >= 1 && k <= 4 ? k : 4; }();
     int32_t rc = ALEO_MI355X_OK; bool split_done = false;
-    if (groups_env == 2 && live.size() >= 4) {
-      Ctx* c2 = nullptr; std::unique_lock<std::mutex> lk2;
-      if (acquire_other(d, c, &c2, lk2, false) == ALEO_MI355X_OK && c2) {
-        const size_t half = (live.size() + 1) / 2;
-        std::vector<ProveRequest> ga(live.begin(), live.begin() + half), gb(live.begin() + half, live.end());
-        int32_t rc_b = ALEO_MI355X_OK; std::string err_b; bool started = true;
-        std::thread tb;
-        try {
-          tb = std::thread([&] {
-            try {
-              if (hipSetDevice(d->device) != hipSuccess) { rc_b = ALEO_MI355X_ERR_HIP; err_b = "hipSetDevice failed"; return; }
-              rc_b = varuna_prove_many(c2, pb, gb); if (rc_b) err_b = g_last_error;
-            } catch (...) { rc_b = ALEO_MI355X_ERR_HIP; err_b = "varuna_prove_many: exception in the second group"; }
-          });
-        } catch (...) { started = false; }
-        if (started) {
-          int32_t rc_a;
-          try { rc_a = varuna_prove_many(c, pb, ga); } catch (...) { rc_a = ALEO_MI355X_ERR_HIP; g_last_error = "varuna_prove_many: exception in the first group"; }      // never unwind past the joinable thread
-          tb.join();
-          for (size_t i = 0; i < ga.size(); ++i) live[i] = ga[i];
-          for (size_t i = 0; i < gb.size(); ++i) live[half + i] = gb[i];
-          rc = rc_a ? rc_a : rc_b; if (!rc_a && rc_b) g_last_error = err_b;
-          split_done = true;
+    const size_t want_groups = live.size() >= 4 ? std::min<size_t>((size_t)groups_env, live.size() / 2) : 1;
+    if (want_groups >= 2) {
+      // contexts for groups 1..: never waited for (whatever is free now); fewer groups if fewer are free
+      std::vector<Ctx*> gc{c}; std::vector<std::unique_lock<std::mutex>> glk;
+      for (size_t g = 1; g < want_groups; ++g) {
+        Ctx* c2 = nullptr; std::unique_lock<std::mutex> lk2;
+        if (acquire_other(d, c, &c2, lk2, false) != ALEO_MI355X_OK || !c2) break;
+        gc.push_back(c2); glk.push_back(std::move(lk2));
+      }
+      const size_t G = gc.size();
+      if (G >= 2) {
+        std::vector<std::vector<ProveRequest>> grp(G); std::vector<std::vector<size_t>> at(G);
+        for (size_t i = 0; i < live.size(); ++i) { const size_t g = i * G / live.size(); grp[g].push_back(live[i]); at[g].push_back(i); }      // contiguous, balanced
+        std::vector<int32_t> rcs(G, ALEO_MI355X_OK); std::vector<std::string> errs(G); std::vector<std::thread> th; bool started = true;
+        for (size_t g = 1; g < G && started; ++g) {
+          try {
+            th.emplace_back([&, g] {
+              try {
+                if (hipSetDevice(d->device) != hipSuccess) { rcs[g] = ALEO_MI355X_ERR_HIP; errs[g] = "hipSetDevice failed"; return; }
+                rcs[g] = varuna_prove_many(gc[g], pb, grp[g]); if (rcs[g]) errs[g] = g_last_error;
+              } catch (...) { rcs[g] = ALEO_MI355X_ERR_HIP; errs[g] = "varuna_prove_many: exception in a lockstep group"; }
+            });
+          } catch (...) { started = false; }
         }
+        // (a thread that could not be started: its group and the ones behind it run here, after group 0)
+        try { rcs[0] = varuna_prove_many(c, pb, grp[0]); if (rcs[0]) errs[0] = g_last_error; } catch (...) { rcs[0] = ALEO_MI355X_ERR_HIP; errs[0] = "varuna_prove_many: exception in the first group"; }      // never unwind past the joinable threads
+        for (auto& t : th) t.join();
+        for (size_t g = th.size() + 1; g < G; ++g) { try { rcs[g] = varuna_prove_many(c, pb, grp[g]); if (rcs[g]) errs[g] = g_last_error; } catch (...) { rcs[g] = ALEO_MI355X_ERR_HIP; errs[g] = "varuna_prove_many: exception in a lockstep group"; } }
+        for (size_t g = 0; g < G; ++g) { for (size_t i = 0; i < grp[g].size(); ++i) live[at[g][i]] = grp[g][i]; if (rcs[g] && !rc) { rc = rcs[g]; g_last_error = errs[g]; } }
+        split_done = true;
       }
     }
     if (!split_done) rc = live.empty() ? ALEO_MI355X_OK : varuna_prove_many(c, pb, live);
