@@ -107,6 +107,9 @@ struct Ctx {                           // one concurrency slot
   std::mutex mu;                       // held for the duration of one API call
   hipEvent_t ev[8] = {};
   uint32_t meta_seq = 0;               // msm_sort_phase: sequence number of the slice metadata k_scan_top stores into h_pinned
+  // The sort's zero-initialised block (hist | lists | meta | cursors | count matrix) cleared AHEAD: the table path queues the fill for the NEXT chain behind its last
+  // reader (the bucket reduction), where the GPU would otherwise idle under the host tail; the next sort on the same stream within the cleared size skips its own fill.
+  size_t hist_clean = 0; hipStream_t hist_clean_stream = nullptr; void* hist_clean_ptr = nullptr;
   // MSM workspaces
   DevBuf hist, scan_local, scan_blk, sorted, part_cnt, part_items, partial, task_g, meta, vbuf, scalars_stage, out_stage;
   void* h_pinned = nullptr; size_t h_pinned_cap = 0;    // pinned host staging for small D2H results

@@ -1030,7 +1030,10 @@ int32_t msm_sort_phase(Ctx* c, SegArgs& segs, size_t pts, bool mont, const uint8
   uint32_t* sorted = sp.sorted = c->sorted.as<uint32_t>(); uint32_t* task_g = sp.task_g = c->task_g.as<uint32_t>(); uint32_t* order = sp.order = task_g + slices_max;
 
   if (!lean) HIPCHK(hipEventRecord(c->ev[0], s));
-  HIPCHK(hipMemsetAsync(hist, 0, (hist_words + cnt_len) * 4, s));          // (count matrix: columns no block of a set owns, and tiles past a segment's end, count zero)
+  sp.zero_bytes = (hist_words + cnt_len) * 4;
+  const bool cleared_ahead = c->hist_clean >= sp.zero_bytes && c->hist_clean_stream == s && c->hist_clean_ptr == (void*)hist;      // the previous chain on this stream left it clean (msm_back)
+  c->hist_clean = 0;                                        // (about to be dirtied)
+  if (!cleared_ahead) HIPCHK(hipMemsetAsync(hist, 0, sp.zero_bytes, s));          // (count matrix: columns no block of a set owns, and tiles past a segment's end, count zero)
   SortArgs sa;
   sa.segs = segs; sa.nblk_x = nblk_x ? nblk_x : 1;
   sa.inf = d_inf; sa.row_stride = row_stride;
@@ -1342,6 +1345,10 @@ static int32_t msm_back(Ctx* c, uint64_t* out_jac18, Front& f, hipStream_t s, bo
     }
     }
     HIPCHK(hipEventRecord(c->ev[3], s));
+    if (f.lean && older.n == 0 && !aside) {                  // single-chain prover commitments: clear the sort's block for the next chain now, under the host tail (ev[3] sits in front of it; not with trees still running aside: they read the lists in that block)
+      static const bool clear_ahead = [] { const char* e = std::getenv("ALEO_MI355X_CLEAR_AHEAD"); return !(e && e[0] == '0'); }();      // A/B switch
+      if (clear_ahead) { HIPCHK(hipMemsetAsync(sp.hist, 0, sp.zero_bytes, s)); c->hist_clean = sp.zero_bytes; c->hist_clean_stream = s; c->hist_clean_ptr = (void*)sp.hist; }
+    }
     } else if (prog) { uint32_t L = cpw, nT = 0; while (L > FOLD) { ++nT; L >>= 1; } uint32_t lgL = 0; while ((1u << lgL) < L) ++lgL; out_pts = 1 + nT + lgL; }
     if (!collect) return ALEO_MI355X_OK;
     if (fire_tail && c->tail_hook) {

@@ -62,6 +62,7 @@ struct SortPhase {
   uint32_t *hist = nullptr, *heavy = nullptr, *meta = nullptr; uint2 *scan_local = nullptr, *scan_blk = nullptr;
   uint32_t *sorted = nullptr, *task_g = nullptr, *order = nullptr; const uint32_t* total_pairs = nullptr; const uint32_t* super_list = nullptr;
   uint32_t meta_seq = 0;      // the sequence number k_scan_top stores behind the slice metadata in the slot's pinned buffer (msm_wait_meta polls for it)
+  size_t zero_bytes = 0;      // size of the zero-initialised block at `hist` this chain used
 };
 struct SliceMeta { uint32_t NT = 0, max_m = 0, n_heavy = 0, n_super = 0, max_common = 0; bool super_overflow = false; };
 // P: the plan (P.W windows / sets of P.B buckets).  pre: table path (digits address row w * row_stride + i of a table, all windows share
