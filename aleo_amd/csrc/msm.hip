@@ -441,20 +441,65 @@ __global__ void __launch_bounds__(256) k_scan_top(const uint2* tile_tot, uint32_
 // taken in bucket order (measured: 31 % of the accumulation's lanes idle).  A counting sort by length (longest
 // first) costs two tiny launches: block-local LDS histograms + a handful of global atomics per block.
 // sid -> bucket (binary search over first_slice), stores task_g[sid], counts slice lengths
-__global__ void __launch_bounds__(256) k_slice_count(const uint32_t* __restrict__ hist, const uint2* __restrict__ scan_local, const uint2* __restrict__ scan_blk,
-                                                     uint32_t M, const uint32_t* __restrict__ total_pairs, const uint32_t* __restrict__ meta, uint32_t* __restrict__ task_g,
-                                                     uint32_t* __restrict__ len_count) {
+// FUSED (round 5, <= 512 scan tiles — every chain of a prover round): the exclusive scan of the tile totals, a single-block launch of its own until now (k_scan_top,
+// ~5-8 us per chain at real-circuit sizes), runs in every block's prologue over LDS; block 0 also leaves scan_blk, the totals and the host's copy of the slice
+// metadata behind for the kernels that follow (k_slice_order, the accumulation, the trees and the reduction read them from memory as before).
+static constexpr uint32_t FUSED_TILES = 512;
+template <bool FUSED>
+__global__ void __launch_bounds__(256) k_slice_count(const uint32_t* __restrict__ hist, const uint2* __restrict__ scan_local, const uint2* scan_blk_in,
+                                                     uint32_t M, const uint32_t* __restrict__ total_pairs, uint32_t* meta, uint32_t* __restrict__ task_g,
+                                                     uint32_t* __restrict__ len_count, const uint2* __restrict__ tile_tot, uint32_t ntiles, uint2* scan_blk_out,
+                                                     volatile uint32_t* host_meta, uint32_t seq) {
   __shared__ uint32_t h[MAX_SLICE + 1];
+  __shared__ uint2 sblk[FUSED ? FUSED_TILES : 1]; __shared__ uint2 wtot[4]; __shared__ uint32_t s_total;
   for (uint32_t i = threadIdx.x; i <= MAX_SLICE; i += 256) h[i] = 0;
-  __syncthreads();
+  uint32_t total_slices;
+  if constexpr (FUSED) {
+    const uint32_t tid = threadIdx.x; const int lane = tid & 63, wv = tid >> 6;
+    const uint2 v0 = 2 * tid < ntiles ? tile_tot[2 * tid] : make_uint2(0u, 0u), v1 = 2 * tid + 1 < ntiles ? tile_tot[2 * tid + 1] : make_uint2(0u, 0u);
+    uint2 inc = make_uint2(v0.x + v1.x, v0.y + v1.y);
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t ox = __shfl_up(inc.x, d), oy = __shfl_up(inc.y, d); if (lane >= d) { inc.x += ox; inc.y += oy; } }
+    if (lane == 63) wtot[wv] = inc;
+    __syncthreads();
+    uint2 off = make_uint2(0u, 0u); for (int k = 0; k < wv; ++k) { off.x += wtot[k].x; off.y += wtot[k].y; }
+    const uint2 excl = make_uint2(off.x + inc.x - v0.x - v1.x, off.y + inc.y - v0.y - v1.y);
+    if (2 * tid < FUSED_TILES) sblk[2 * tid] = excl;
+    if (2 * tid + 1 < FUSED_TILES) sblk[2 * tid + 1] = make_uint2(excl.x + v0.x, excl.y + v0.y);
+    if (tid == 255) s_total = off.y + inc.y;
+    if (blockIdx.x == 0) {
+      if (2 * tid < ntiles) scan_blk_out[2 * tid] = excl;
+      if (2 * tid + 1 < ntiles) scan_blk_out[2 * tid + 1] = make_uint2(excl.x + v0.x, excl.y + v0.y);
+      if (tid == 255) {
+        const uint32_t slices = off.y + inc.y, pairs = off.x + inc.x;
+        meta[0] = slices; meta[2] = pairs;
+        if (host_meta) {
+          host_meta[0] = slices; host_meta[2] = pairs;
+          for (int i : {1, 3, 4, 5, 6, 7}) host_meta[i] = meta[i];      // written by k_scan_tiles (the launch before this one)
+          __threadfence_system();
+          host_meta[8] = seq;
+        }
+      }
+    }
+    __syncthreads();
+    total_slices = s_total;
+  } else {
+    __syncthreads();
+    total_slices = meta[0];
+  }
+  auto at = [&](uint32_t g) -> uint2 {
+    const uint2 a = scan_local[g]; uint2 b;
+    if constexpr (FUSED) b = sblk[g / SCAN_TILE]; else b = scan_blk_in[g / SCAN_TILE];
+    return make_uint2(a.x + b.x, a.y + b.y);
+  };
   uint32_t t = blockIdx.x * 256 + threadIdx.x;
-  if (t < meta[0]) {
+  if (t < total_slices) {
     uint32_t lo = 0, hi = M - 1;        // largest g with first_slice(g) <= t
     while (lo < hi) {
       uint32_t mid = (lo + hi + 1) >> 1;
-      if (scan_at(scan_local, scan_blk, mid).y <= t) lo = mid; else hi = mid - 1;
+      if (at(mid).y <= t) lo = mid; else hi = mid - 1;
     }
-    uint32_t g = lo, cnt = hist[g], m = slices_of(cnt, pick_rule(total_pairs, M)), k = t - scan_at(scan_local, scan_blk, g).y;
+    uint32_t g = lo, cnt = hist[g], m = slices_of(cnt, pick_rule(total_pairs, M)), k = t - at(g).y;
     task_g[t] = g;
     atomicAdd(&h[slice_len(cnt, m, k)], 1u);
   }
@@ -1058,11 +1103,14 @@ int32_t msm_sort_phase(Ctx* c, SegArgs& segs, size_t pts, bool mont, const uint8
   uint32_t* host_meta = nullptr;
   HIPCHK(hipHostGetDevicePointer((void**)&host_meta, c->h_pinned, 0));
   sp.meta_seq = ++c->meta_seq;
-  hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(256), 0, s, tile_tot, ntiles, scan_blk, meta, (volatile uint32_t*)host_meta, sp.meta_seq);
+  static const bool fuse_top_env = [] { const char* e = std::getenv("ALEO_MI355X_FUSE_SCAN_TOP"); return !(e && e[0] == '0'); }();      // A/B switch
+  const bool fuse_top = fuse_top_env && lean && ntiles <= FUSED_TILES;      // (calls that time their phases keep the sort / slice-order boundary at ev[1])
+  if (!fuse_top) hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(256), 0, s, tile_tot, ntiles, scan_blk, meta, (volatile uint32_t*)host_meta, sp.meta_seq);
   HIPCHK(hipGetLastError());
   if (!lean) HIPCHK(hipEventRecord(c->ev[1], s));
   uint32_t* len_count = meta + 16; uint32_t* len_cursor = len_count + MAX_SLICE + 1;   // zeroed with hist/meta
-  hipLaunchKernelGGL(k_slice_count, dim3(sp.slice_blocks), dim3(256), 0, s, hist, scan_local, scan_blk, M, total_pairs, meta, task_g, len_count);
+  if (fuse_top) hipLaunchKernelGGL(k_slice_count<true>, dim3(sp.slice_blocks), dim3(256), 0, s, hist, scan_local, (const uint2*)scan_blk, M, total_pairs, meta, task_g, len_count, (const uint2*)tile_tot, ntiles, scan_blk, (volatile uint32_t*)host_meta, sp.meta_seq);
+  else hipLaunchKernelGGL(k_slice_count<false>, dim3(sp.slice_blocks), dim3(256), 0, s, hist, scan_local, (const uint2*)scan_blk, M, total_pairs, meta, task_g, len_count, (const uint2*)tile_tot, ntiles, scan_blk, (volatile uint32_t*)nullptr, 0u);
   hipLaunchKernelGGL(k_slice_order, dim3(sp.slice_blocks), dim3(256), 0, s, hist, scan_local, scan_blk, total_pairs, M, meta, task_g, len_count, len_cursor, order);
   HIPCHK(hipGetLastError());
   return ALEO_MI355X_OK;
