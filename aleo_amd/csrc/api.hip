@@ -85,7 +85,7 @@ int32_t scratch_acquire(Ctx* c, DevBuf& b, size_t bytes, hipStream_t s) {
 }
 int32_t scratch_release(Ctx* c, hipStream_t s) {
   c->scratch_busy = true;
-  if (s && (s == c->stream || s == c->side || s == c->hi)) { c->scratch_stream = s; return ALEO_MI355X_OK; }      // a stream the slot owns: it outlives the deferred record
+  if (s && (s == c->stream || s == c->side || s == c->aux || s == c->hi)) { c->scratch_stream = s; return ALEO_MI355X_OK; }      // a stream the slot owns: it outlives the deferred record
   c->scratch_stream = nullptr;
   HIPCHK(hipEventRecord(c->scratch_ev, s)); return ALEO_MI355X_OK;      // a caller's stream may be gone by the next call: record now
 }
@@ -149,11 +149,46 @@ static int32_t get_device(Device** out) {
   return init_device(device, out);
 }
 
+// ---- streams -------------------------------------------------------------------------------------------------------------------------------------------
+// The runtime deals the streams of one priority onto at most GPU_MAX_HW_QUEUES hardware queues (to the queue with the fewest streams, so in creation order), and what shares a
+// hardware queue runs in queue order.  Measured on this pool (profiles/r05_stream_order_*.txt, r05_hw_queues_ab.txt, r05_hi_priority_ab.txt):
+//   * the MAIN streams are the ones that run side by side (lockstep groups and their workers, concurrent callers): created first — the slots', then as many helpers' — they get a
+//     queue each; with every context creating stream | side | hi at its first use they collided: a lockstep call of 8 proofs 31.8 -> 28.0 ms, of 16 58.5 -> 54.0;
+//   * more hardware queues than ~20 in all (GPU_MAX_HW_QUEUES >= 12, or a third priority level) and the same call takes 43-65 ms: the queues are oversubscribed;
+//   * EIGHT high-priority streams created in a row (one per context) made a 2^20-constraint proof — whose chains' sorts run on them — take 1.1-2.5 s instead of 80 ms; at normal
+//     priority the same arrangement is harmless.  So the device keeps a small POOL of high-priority streams (ALEO_MI355X_HI_POOL, default 4; chunked uploads need one per later
+//     chunk) that its contexts share round-robin, slot i and helper i + 1 on different ones.
+static bool hi_priority_on() { static const bool v = [] { const char* e = std::getenv("ALEO_MI355X_HI_PRIORITY"); return !(e && e[0] == '0'); }(); return v; }      // A/B: 0 = the `hi` streams at normal priority
+static int hi_pool_size() { static const int v = [] { const char* e = std::getenv("ALEO_MI355X_HI_POOL"); const int k = e ? std::atoi(e) : 4; return k >= 1 && k <= MAX_SLOTS ? k : 4; }(); return v; }
+static std::mutex g_stream_mu;
+static int32_t create_streams_in_order(Device* d) {
+  static const bool on = [] { const char* e = std::getenv("ALEO_MI355X_STREAM_ORDER"); return !(e && e[0] == '0'); }();      // A/B: 0 = every context creates its streams at its first use
+  if (!on) return ALEO_MI355X_OK;
+  std::lock_guard<std::mutex> lk(g_stream_mu);
+  if (d->slots[0].stream) return ALEO_MI355X_OK;
+  for (int i = 0; i < d->n_slots; ++i) HIPCHK(hipStreamCreateWithFlags(&d->slots[i].stream, hipStreamNonBlocking));
+  for (int i = 0; i < d->n_slots; ++i) HIPCHK(hipStreamCreateWithFlags(&d->helpers[i].stream, hipStreamNonBlocking));
+  return ALEO_MI355X_OK;
+}
+static int32_t hi_stream_for(Ctx* c, hipStream_t* out) {
+  Device* d = c->dev;
+  if (!d) { int lo = 0, hi = 0; (void)hipDeviceGetStreamPriorityRange(&lo, &hi); if (!hi_priority_on()) hi = 0; HIPCHK(hipStreamCreateWithPriority(out, hipStreamNonBlocking, hi)); return ALEO_MI355X_OK; }
+  std::lock_guard<std::mutex> lk(g_stream_mu);
+  const bool helper = c >= &d->helpers[0] && c < &d->helpers[MAX_SLOTS];
+  const int idx = helper ? (int)(c - &d->helpers[0]) + 1 : (int)(c - &d->slots[0]), k = idx % hi_pool_size();      // slot i and helpers i, i + 1 (a pipeline's ring, a chunked call's later chunks) on different ones
+  while (d->hi_made <= k) {
+    int lo = 0, hi = 0; (void)hipDeviceGetStreamPriorityRange(&lo, &hi); if (!hi_priority_on()) hi = 0;      // hi = the numerically lowest = highest priority
+    HIPCHK(hipStreamCreateWithPriority(&d->hi_pool[d->hi_made], hipStreamNonBlocking, hi)); ++d->hi_made;
+  }
+  *out = d->hi_pool[k]; return ALEO_MI355X_OK;
+}
 static int32_t first_use(Ctx* c) {          // streams and events of a slot, created when it is first handed out (the device is current)
-  if (c->stream) return ALEO_MI355X_OK;
-  HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-  HIPCHK(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
-  { int lo = 0, hi = 0; (void)hipDeviceGetStreamPriorityRange(&lo, &hi); HIPCHK(hipStreamCreateWithPriority(&c->hi, hipStreamNonBlocking, hi)); }      // hi = the numerically lowest = highest priority
+  if (c->ev[0]) return ALEO_MI355X_OK;
+  if (c->dev) { const int32_t rc = create_streams_in_order(c->dev); if (rc) return rc; }
+  if (!c->stream) HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  if (!c->side) HIPCHK(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+  if (!c->aux) HIPCHK(hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking));
+  if (!c->hi) { const int32_t rc = hi_stream_for(c, &c->hi); if (rc) return rc; }
   for (auto& e : c->ev) HIPCHK(hipEventCreate(&e));
   HIPCHK(hipEventCreateWithFlags(&c->scratch_ev, hipEventDisableTiming));
   HIPCHK(hipEventCreateWithFlags(&c->ev_hop, hipEventDisableTiming));

@@ -129,6 +129,7 @@ struct Ctx {                           // one concurrency slot
   hipEvent_t scratch_ev = nullptr; bool scratch_busy = false; hipStream_t scratch_stream = nullptr;
   hipStream_t side = nullptr;          // second stream of the slot: small read-backs that must not wait for the kernels queued behind them
   hipStream_t hi = nullptr;            // a high-priority stream: the sort of a later chunk / the next launch chain must get its workgroups in while an accumulation fills the chip (msm_run_chunked, run_chains)
+  hipStream_t aux = nullptr;           // a third normal-priority stream: run_chains_pipelined's sorts and reductions (ALEO_MI355X_PIPELINE_HI=1 puts them on `hi`)
   hipEvent_t ev_hop = nullptr;         // run_chains: a chain's sort (on hi) -> its accumulation (on the normal-priority stream)
 };
 
@@ -168,6 +169,7 @@ struct Device {
   Ctx slots[MAX_SLOTS];
   std::vector<std::unique_ptr<ShardWs>> shard_ws;     // grown under mu; used only by the one sharded transform in flight (api.hip g_ntt_sh_mu)
   DevBuf shard_home;                   // ntt_sharded_device: the home device's transposed copy of the data (n elements), same lock
+  hipStream_t hi_pool[MAX_SLOTS] = {}; int hi_made = 0;      // the high-priority streams of the device, dealt to the contexts round-robin (api.hip first_use): at most ALEO_MI355X_HI_POOL of them exist
   Ctx helpers[MAX_SLOTS];              // extra streams + scratch a lockstep call borrows for its worker threads (never handed out as API slots)
 };
 // Borrows up to `want` idle helper contexts of the device (try-lock: none is waited for); they are released when `hs` goes out of scope.

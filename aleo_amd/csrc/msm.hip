@@ -926,6 +926,37 @@ __global__ void __launch_bounds__(256) k_prog_pass(const char* __restrict__ node
   pt28_add<LANES>(src, src + PB28, dst);
   if (g == 0) grp_copy<LANES, PB28>(src + PB28, out + ((size_t)q * out_set_stride + (size_t)(2 + nT) * half + i) * PB28);      // T_s is born: the right children of this level
 }
+// TWO levels in one launch while the passes are latency-bound (lane quads): an octet of lanes per four consecutive points of a segment.  Step 1: quad 0 adds points
+// 0 + 1, quad 1 adds 2 + 3, into LDS; step 2: quad 0 adds the two halves (the point of the segment two levels up) while quad 1, on the node segment, adds points
+// 1 + 3 (T_nT, born at the first of the two levels, already halved by the second) and copies 2 + 3 out (T_(nT+1), born at the second).  Same sums as two k_prog_pass
+// launches — the grouping of the additions differs, the points they represent do not — for two dependent additions and ONE launch instead of two and two:
+// ~9 us less per pair of levels (a launch boundary costs about as much as a lane-quad addition).  Output layout as after two single passes:
+// [node | A | T_0 .. T_(nT-1) | T_nT | T_(nT+1)], every segment L / 4 long.
+__global__ void __launch_bounds__(256) k_prog_pass2(const char* __restrict__ node, uint32_t node_set_stride, const char* __restrict__ A, uint32_t a_set_stride,
+                                                    const char* __restrict__ T, uint32_t t_set_stride, uint32_t nT, uint32_t L, uint32_t nsets,
+                                                    char* __restrict__ out, uint32_t out_set_stride) {
+  __shared__ __attribute__((aligned(16))) uint32_t lds[(2 * 32 + 1) * PW28];
+  char* zero = (char*)(lds + 64 * PW28);
+  if (threadIdx.x < 4) grp_zero<4, PB28>(zero);
+  __syncthreads();
+  const uint32_t quarter = L >> 2, per_set = (2 + nT) * quarter;
+  const uint32_t oct = threadIdx.x >> 3, y = (threadIdx.x >> 2) & 1u, op = blockIdx.x * 32 + oct;
+  if (op >= per_set * nsets) return;
+  const uint32_t q = op / per_set, r = op % per_set, g = r / quarter, i = r % quarter;
+  const char* src = g == 0 ? node + ((size_t)q * node_set_stride + 4 * i) * PB28
+                  : g == 1 ? A + ((size_t)q * a_set_stride + 4 * i) * PB28
+                           : T + ((size_t)q * t_set_stride + (size_t)(g - 2) * L + 4 * i) * PB28;
+  char* slot = (char*)(lds + (2 * oct) * PW28);
+  pt28_add<4>(src + (size_t)(2 * y) * PB28, src + (size_t)(2 * y + 1) * PB28, slot + y * PB28);
+  pair_fence();
+  char* base = out + (size_t)q * out_set_stride * PB28;
+  const bool born = y && g == 0;
+  const char* pa = y ? (born ? src + PB28 : zero) : slot;
+  const char* pb = y ? (born ? src + 3 * PB28 : zero) : slot + PB28;
+  char* dst = y ? (born ? base + ((size_t)(2 + nT) * quarter + i) * PB28 : zero) : base + ((size_t)g * quarter + i) * PB28;      // (an idle quad: 0 + 0 onto the zero point, nothing is written)
+  pt28_add<4>(pa, pb, dst);
+  if (born) grp_copy<4, PB28>(slot + PB28, base + ((size_t)(3 + nT) * quarter + i) * PB28);
+}
 // The last levels, one block per result point: A and every T_l already born are plain folds of their (<= 256-point) segments; the weights of the
 // remaining lg L bits come from the node segment itself, T_(nT + b) = the sum of the nodes whose index has bit b set.  Output point o of set q:
 // 0 = A, 1 + l = T_l.
@@ -1349,8 +1380,17 @@ static int32_t msm_back(Ctx* c, uint64_t* out_jac18, Front& f, hipStream_t s, bo
       char* G0 = Tout; char* G1 = G0 + (size_t)K * (3 * (cpw / 2)) * PB28;      // ping-pong: a set is at most 3 segments of cpw / 2 points after the first pass
       const char* node = Vrun; uint32_t node_ss = cpw; const char* A = V; uint32_t a_ss = setw; const char* T = Vrun; uint32_t t_ss = 0, nT = 0, L = cpw;
       char* dstbuf = G0;
+      // ALEO_MI355X_PROG_PASS2=0: one level per launch throughout (A/B switch)
+      static const bool pass2_on = [] { const char* e = std::getenv("ALEO_MI355X_PROG_PASS2"); return !(e && e[0] == '0'); }();
       while (L > FOLD) {
         const uint32_t half = L >> 1, out_ss = (3 + nT) * half; const uint64_t ops = (uint64_t)(2 + nT) * half * K;
+        if (pass2_on && (L >> 2) >= FOLD && grp_lanes(ops) == 4) {      // two levels at once: L -> L / 4
+          const uint32_t quarter = L >> 2, out2 = (4 + nT) * quarter; const uint64_t octs = (uint64_t)(2 + nT) * quarter * K;
+          hipLaunchKernelGGL(k_prog_pass2, dim3((uint32_t)((octs + 31) / 32)), dim3(256), 0, s, node, node_ss, A, a_ss, T, t_ss, nT, L, K, dstbuf, out2);
+          node = dstbuf; node_ss = out2; A = dstbuf + (size_t)quarter * PB28; a_ss = out2; T = dstbuf + (size_t)2 * quarter * PB28; t_ss = out2; nT += 2; L = quarter;
+          dstbuf = dstbuf == G0 ? G1 : G0;
+          continue;
+        }
         if (grp_lanes(ops) == 4) hipLaunchKernelGGL(k_prog_pass<4>, dim3((uint32_t)((4 * ops + 255) / 256)), dim3(256), 0, s, node, node_ss, A, a_ss, T, t_ss, nT, L, K, dstbuf, out_ss);
         else hipLaunchKernelGGL(k_prog_pass<2>, dim3((uint32_t)((2 * ops + 255) / 256)), dim3(256), 0, s, node, node_ss, A, a_ss, T, t_ss, nT, L, K, dstbuf, out_ss);
         node = dstbuf; node_ss = out_ss; A = dstbuf + (size_t)half * PB28; a_ss = out_ss; T = dstbuf + (size_t)2 * half * PB28; t_ss = out_ss; ++nT; L = half;
@@ -1623,31 +1663,33 @@ inline bool chains_overlap_on() { static const bool v = [] { const char* e = std
 //   8-instance round.
 static bool chain_pipeline_on() { static const bool v = [] { const char* e = std::getenv("ALEO_MI355X_CHAIN_PIPELINE"); return !(e && e[0] == '0'); }(); return v; }
 static int32_t run_chains_pipelined(Ctx* c, const std::vector<Ctx*>& helpers, uint64_t* out_jac18, const PinnedBases& pb, std::vector<Chain>& chains, bool mont, hipStream_t s) {
+  static const bool on_hi = [] { const char* e = std::getenv("ALEO_MI355X_PIPELINE_HI"); return e && e[0] == '1'; }();      // A/B: the chains' sorts and reductions on the high-priority streams (rounds 3-4) instead of normal-priority ones
+  auto SS = [&](Ctx* x) { return on_hi ? x->hi : x->aux; };
   const size_t n = chains.size(), R = 1 + helpers.size();   // a ring of R contexts: chain i on context i mod R
   std::vector<Ctx*> cx(R); std::vector<hipStream_t> acc_st(R);
   cx[0] = c; acc_st[0] = s; for (size_t k = 1; k < R; ++k) { cx[k] = helpers[k - 1]; acc_st[k] = helpers[k - 1]->stream; }
-  StreamDrainGuard guard; for (size_t k = 0; k < R; ++k) { guard.add(cx[k]->hi); guard.add(acc_st[k]); guard.add(cx[k]->side); }      // also on an exception or an early return below
+  StreamDrainGuard guard; for (size_t k = 0; k < R; ++k) { guard.add(SS(cx[k])); guard.add(acc_st[k]); guard.add(cx[k]->side); }      // also on an exception or an early return below
   std::vector<Front> f(n); std::vector<MsmJob> job(n); std::vector<char> live(n, 0);
   auto drain = [&](int32_t code) { return code; };           // (the guard drains)
   HIPCHK(hipEventRecord(c->ev[4], s));                       // the scalars may still be in flight on the caller's stream
-  for (size_t k = 0; k < R; ++k) { HIPCHK(hipStreamWaitEvent(cx[k]->hi, c->ev[4], 0)); if (k) HIPCHK(hipStreamWaitEvent(acc_st[k], c->ev[4], 0)); }
+  for (size_t k = 0; k < R; ++k) { HIPCHK(hipStreamWaitEvent(SS(cx[k]), c->ev[4], 0)); if (k) HIPCHK(hipStreamWaitEvent(acc_st[k], c->ev[4], 0)); }
   int32_t rc;
   auto sort_of = [&](size_t i) -> int32_t {
     Chain& ch = chains[i]; MsmJob& g = job[i];
     g.segs = ch.segs.data(); g.nseg = (uint32_t)ch.segs.size(); g.k = (uint32_t)ch.results.size(); g.mont = mont; g.sparse = ch.sparse; g.fire_tail = false;
     Ctx* cc = cx[i % R];
-    const int32_t r = msm_front_sort(cc, pb, g, cc->hi, f[i]);
+    const int32_t r = msm_front_sort(cc, pb, g, SS(cc), f[i]);
     if (r) return r;
     if (f[i].empty) { for (size_t q = 0; q < ch.results.size(); ++q) host::hstore_jacobian_normalized(out_jac18 + 18 * (size_t)ch.results[q], host::HXYZZ::infinity()); return ALEO_MI355X_OK; }
     if (!f[i].masked) { g_last_error = "msm: internal: a pipelined chain without a table tier"; return ALEO_MI355X_ERR_HIP; }
     live[i] = 1;
-    HIPCHK(hipEventRecord(cc->ev_hop, cc->hi));
+    HIPCHK(hipEventRecord(cc->ev_hop, SS(cc)));
     return ALEO_MI355X_OK;
   };
   auto collect = [&](size_t i) -> int32_t {
     if (!live[i]) return ALEO_MI355X_OK;
     uint64_t res[MAX_SETS * 18]; Ctx* cc = cx[i % R];
-    const int32_t r = msm_back(cc, res, f[i], cc->hi, false, FrontChain{}, true, true);
+    const int32_t r = msm_back(cc, res, f[i], SS(cc), false, FrontChain{}, true, true);
     if (r) return r;
     for (size_t q = 0; q < chains[i].results.size(); ++q) std::memcpy(out_jac18 + 18 * (size_t)chains[i].results[q], res + 18 * q, 144);
     live[i] = 0;
@@ -1664,13 +1706,13 @@ static int32_t run_chains_pipelined(Ctx* c, const std::vector<Ctx*>& helpers, ui
     }
     if (i + 1 < n) {
       for (; collected + R <= i + 1; ++collected) if ((rc = collect(collected))) return drain(rc);       // the context of chain i + 1 must be free: chain i + 1 - R collected
-      if (live[i]) HIPCHK(hipStreamWaitEvent(cx[(i + 1) % R]->hi, cc->ev[6], 0));      // not before accumulation i starts: two sorts side by side only delay the first accumulation
+      if (live[i]) HIPCHK(hipStreamWaitEvent(SS(cx[(i + 1) % R]), cc->ev[6], 0));      // not before accumulation i starts: two sorts side by side only delay the first accumulation
       if ((rc = sort_of(i + 1))) return drain(rc);
     }
     if (live[i]) {
-      HIPCHK(hipStreamWaitEvent(cc->hi, cc->ev[5], 0));
-      if ((rc = msm_front_finish(cc, cc->hi, f[i], true))) return drain(rc);
-      if ((rc = msm_back(cc, nullptr, f[i], cc->hi, false, FrontChain{}, false, false))) return drain(rc);
+      HIPCHK(hipStreamWaitEvent(SS(cc), cc->ev[5], 0));
+      if ((rc = msm_front_finish(cc, SS(cc), f[i], true))) return drain(rc);
+      if ((rc = msm_back(cc, nullptr, f[i], SS(cc), false, FrontChain{}, false, false))) return drain(rc);
     }
   }
   for (; collected < n; ++collected) if ((rc = collect(collected))) return drain(rc);
