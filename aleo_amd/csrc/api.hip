@@ -1016,20 +1016,22 @@ int32_t aleo_mi355x_varuna_prove_many(aleo_mi355x_prove_request* requests, size_
         std::vector<std::vector<ProveRequest>> grp(G); std::vector<std::vector<size_t>> at(G);
         for (size_t i = 0; i < live.size(); ++i) { const size_t g = i * G / live.size(); grp[g].push_back(live[i]); at[g].push_back(i); }      // contiguous, balanced
         std::vector<int32_t> rcs(G, ALEO_MI355X_OK); std::vector<std::string> errs(G); std::vector<std::thread> th; bool started = true;
+        // inside a group ONE thread runs the group's proofs (ALEO_MI355X_GROUP_WORKERS): the groups are the call's parallelism, and four busy streams beat eight (profiles/r05_lockstep_retune.txt: 29.4 / 28.5 / 27.5 ms per 8 proofs with 4 / 2 / 1 workers per group, 54.0 / 53.9 / 52.8 per 16)
+        static const int group_workers = [] { const char* e = std::getenv("ALEO_MI355X_GROUP_WORKERS"); const int k = e ? std::atoi(e) : 1; return k >= 1 && k <= MAX_SLOTS + 1 ? k : 1; }();
         for (size_t g = 1; g < G && started; ++g) {
           try {
             th.emplace_back([&, g] {
               try {
                 if (hipSetDevice(d->device) != hipSuccess) { rcs[g] = ALEO_MI355X_ERR_HIP; errs[g] = "hipSetDevice failed"; return; }
-                rcs[g] = varuna_prove_many(gc[g], pb, grp[g]); if (rcs[g]) errs[g] = g_last_error;
+                rcs[g] = varuna_prove_many(gc[g], pb, grp[g], group_workers); if (rcs[g]) errs[g] = g_last_error;
               } catch (...) { rcs[g] = ALEO_MI355X_ERR_HIP; errs[g] = "varuna_prove_many: exception in a lockstep group"; }
             });
           } catch (...) { started = false; }
         }
         // (a thread that could not be started: its group and the ones behind it run here, after group 0)
-        try { rcs[0] = varuna_prove_many(c, pb, grp[0]); if (rcs[0]) errs[0] = g_last_error; } catch (...) { rcs[0] = ALEO_MI355X_ERR_HIP; errs[0] = "varuna_prove_many: exception in the first group"; }      // never unwind past the joinable threads
+        try { rcs[0] = varuna_prove_many(c, pb, grp[0], group_workers); if (rcs[0]) errs[0] = g_last_error; } catch (...) { rcs[0] = ALEO_MI355X_ERR_HIP; errs[0] = "varuna_prove_many: exception in the first group"; }      // never unwind past the joinable threads
         for (auto& t : th) t.join();
-        for (size_t g = th.size() + 1; g < G; ++g) { try { rcs[g] = varuna_prove_many(c, pb, grp[g]); if (rcs[g]) errs[g] = g_last_error; } catch (...) { rcs[g] = ALEO_MI355X_ERR_HIP; errs[g] = "varuna_prove_many: exception in a lockstep group"; } }
+        for (size_t g = th.size() + 1; g < G; ++g) { try { rcs[g] = varuna_prove_many(c, pb, grp[g], group_workers); if (rcs[g]) errs[g] = g_last_error; } catch (...) { rcs[g] = ALEO_MI355X_ERR_HIP; errs[g] = "varuna_prove_many: exception in a lockstep group"; } }
         for (size_t g = 0; g < G; ++g) { for (size_t i = 0; i < grp[g].size(); ++i) live[at[g][i]] = grp[g][i]; if (rcs[g] && !rc) { rc = rcs[g]; g_last_error = errs[g]; } }
         split_done = true;
       }
