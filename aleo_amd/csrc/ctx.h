@@ -109,6 +109,7 @@ struct Ctx {                           // one concurrency slot
   uint32_t meta_seq = 0;               // msm_sort_phase: sequence number of the slice metadata k_scan_top stores into h_pinned
   // The sort's zero-initialised block (hist | lists | meta | cursors | count matrix) cleared AHEAD: the table path queues the fill for the NEXT chain behind its last
   // reader (the bucket reduction), where the GPU would otherwise idle under the host tail; the next sort on the same stream within the cleared size skips its own fill.
+  size_t hist_zero_max = 0;            // the largest zero-initialised block a chain on this context has needed (clear-ahead clears that much)
   size_t hist_clean = 0; hipStream_t hist_clean_stream = nullptr; void* hist_clean_ptr = nullptr;
   // MSM workspaces
   DevBuf hist, scan_local, scan_blk, sorted, part_cnt, part_items, partial, task_g, meta, vbuf, scalars_stage, out_stage;
@@ -231,6 +232,7 @@ int32_t g2_unpack200(Ctx* c, const void* d_rows200, void* d_xy192, void* d_flags
 int32_t fr_lin(Ctx* c, void* d_dst, size_t n, const void* c0, const void* c1, const void* d_a, const void* c2, const void* d_b, hipStream_t s);
 int32_t fr_powers(Ctx* c, void* d_dst, size_t n, const void* first, const void* ratio, hipStream_t s);
 int32_t fr_gather_mul(Ctx* c, void* d_dst, size_t n, const void* d_scale, const void* d_t1, const void* d_idx1, const void* d_t2, const void* d_idx2, hipStream_t s);
+int32_t fr_gather_mul3(Ctx* c, void* const* d_dst, const size_t* n, const void* const* d_scale, const void* d_t1, const void* const* d_idx1, const void* d_t2, const void* const* d_idx2, uint32_t count, hipStream_t s);      // the same for up to three ranges (scale and both tables present) in one launch
 int32_t fr_eval_batch(Ctx* c, void* d_out, const void* const* d_polys, const size_t* lens, const void* z_mont, size_t k, hipStream_t s);
 int32_t fr_random(Ctx* c, void* d_dst, size_t n, const uint8_t* seed32, uint64_t first, int32_t mont, hipStream_t s);
 int32_t fr_lincomb(Ctx* c, void* d_dst, size_t n, const void* c0, const void* const* d_terms, const size_t* lens, const void* coeffs, size_t k, hipStream_t s);

@@ -530,6 +530,33 @@ int32_t fr_gather_mul(Ctx* c, void* d_dst, size_t n, const void* d_scale, const 
   return ALEO_MI355X_OK;
 }
 
+// The same for up to three index ranges in ONE launch (the third round's f_A, f_B, f_C: three short launches were three times the ~4.5 us launch floor)
+struct GatherMul3 { char* dst[3]; const char* scale[3]; const uint32_t* idx1[3]; const uint32_t* idx2[3]; uint32_t n[3]; uint32_t cnt; };
+__global__ void __launch_bounds__(256) k_fr_gather_mul3(GatherMul3 a, const char* __restrict__ t1, const char* __restrict__ t2) {
+  const uint32_t total = a.n[0] + a.n[1] + a.n[2];
+  for (size_t g = (size_t)blockIdx.x * 256 + threadIdx.x; g < total; g += (size_t)gridDim.x * 256) {
+    const uint32_t m = g < a.n[0] ? 0u : (g < a.n[0] + a.n[1] ? 1u : 2u); const size_t i = g - (m == 0 ? 0u : (m == 1 ? a.n[0] : a.n[0] + a.n[1]));
+    Fr r = Fr::mul(load_fp<Fr>(t1 + (size_t)a.idx1[m][i] * 32), load_fp<Fr>(t2 + (size_t)a.idx2[m][i] * 32));
+    r = Fr::mul(r, load_fp<Fr>(a.scale[m] + i * 32));
+    store_fp<Fr>(a.dst[m] + i * 32, Fr::reduce(r));
+  }
+}
+int32_t fr_gather_mul3(Ctx* c, void* const* d_dst, const size_t* n, const void* const* d_scale, const void* d_t1, const void* const* d_idx1, const void* d_t2, const void* const* d_idx2, uint32_t count, hipStream_t s) {
+  (void)c;
+  if (count == 0 || count > 3) { g_last_error = "fr_gather_mul3: one to three ranges"; return ALEO_MI355X_ERR_BAD_ARG; }
+  GatherMul3 a{}; a.cnt = count; size_t total = 0;
+  for (uint32_t m = 0; m < count; ++m) {
+    if (n[m] >= (1ull << 31)) { g_last_error = "fr_gather_mul3: range too long"; return ALEO_MI355X_ERR_BAD_ARG; }
+    a.dst[m] = (char*)d_dst[m]; a.scale[m] = (const char*)d_scale[m]; a.idx1[m] = (const uint32_t*)d_idx1[m]; a.idx2[m] = (const uint32_t*)d_idx2[m]; a.n[m] = (uint32_t)n[m]; total += n[m];
+  }
+  if (total == 0) return ALEO_MI355X_OK;
+  if (total >= (1ull << 32)) { g_last_error = "fr_gather_mul3: ranges too long"; return ALEO_MI355X_ERR_BAD_ARG; }
+  const size_t want = (total + 255) / 256;
+  hipLaunchKernelGGL(k_fr_gather_mul3, dim3((uint32_t)(want < 16384 ? want : 16384)), dim3(256), 0, s, a, (const char*)d_t1, (const char*)d_t2);
+  HIPCHK(hipGetLastError());
+  return ALEO_MI355X_OK;
+}
+
 // p_q(z_q) for up to EVAL_MAX (12) polynomials in two launches: the per-block folds of k_div_blocks for all of them at once, then one
 // block per polynomial combines its folds (Horner over its lanes' runs of blocks, then a sum over the lanes weighted by powers of z^4096).
 static constexpr uint32_t EVAL_MAX = 12;

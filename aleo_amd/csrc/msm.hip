@@ -1435,7 +1435,12 @@ static int32_t msm_back(Ctx* c, uint64_t* out_jac18, Front& f, hipStream_t s, bo
     HIPCHK(hipEventRecord(c->ev[3], s));
     if (f.lean && older.n == 0 && !aside) {                  // single-chain prover commitments: clear the sort's block for the next chain now, under the host tail (ev[3] sits in front of it; not with trees still running aside: they read the lists in that block)
       static const bool clear_ahead = [] { const char* e = std::getenv("ALEO_MI355X_CLEAR_AHEAD"); return !(e && e[0] == '0'); }();      // A/B switch
-      if (clear_ahead) { HIPCHK(hipMemsetAsync(sp.hist, 0, sp.zero_bytes, s)); c->hist_clean = sp.zero_bytes; c->hist_clean_stream = s; c->hist_clean_ptr = (void*)sp.hist; }
+      // (as much as the largest chain seen on this context needs, within the allocation: a proof's chains differ in size, and a chain larger than its predecessor would fill again)
+      if (clear_ahead) {
+        if (sp.zero_bytes > c->hist_zero_max) c->hist_zero_max = sp.zero_bytes;
+        const size_t z = c->hist_zero_max <= c->hist.cap && (void*)sp.hist == c->hist.p ? c->hist_zero_max : sp.zero_bytes;
+        HIPCHK(hipMemsetAsync(sp.hist, 0, z, s)); c->hist_clean = z; c->hist_clean_stream = s; c->hist_clean_ptr = (void*)sp.hist;
+      }
     }
     } else if (prog) { uint32_t L = cpw, nT = 0; while (L > FOLD) { ++nT; L >>= 1; } uint32_t lgL = 0; while ((1u << lgL) < L) ++lgL; out_pts = 1 + nT + lgL; }
     if (!collect) return ALEO_MI355X_OK;

@@ -467,9 +467,13 @@ int32_t Prover::third_round() {
     RC(fr_powers(c, rb, n_h, first.l, ratio.l, s));
   }
   RC(p_ntt(c, sh.pb, rb, lg_h, 1, 0, 0, s));
-  for (size_t m = 0; m < 3; ++m) {                                                           // f_M = val u_H(alpha, row) u_H(beta, col) on K_M: two gathers
-    const uint32_t* ri = (const uint32_t*)ix.k_idx + 2 * ko[m];
-    RC(fr_gather_mul(c, f + ko[m] * 32, nk[m], (const char*)ix.k_evals + (4 * ko[m] + 2 * nk[m]) * 32, ext, ri, rb, ri + nk[m], s));
+  {                                                                                          // f_M = val u_H(alpha, row) u_H(beta, col) on K_M: two gathers; the three matrices in one launch
+    void* dst[3]; size_t cnt[3]; const void* sc[3]; const void* i1[3]; const void* i2[3];
+    for (size_t m = 0; m < 3; ++m) {
+      const uint32_t* ri = (const uint32_t*)ix.k_idx + 2 * ko[m];
+      dst[m] = f + ko[m] * 32; cnt[m] = nk[m]; sc[m] = (const char*)ix.k_evals + (4 * ko[m] + 2 * nk[m]) * 32; i1[m] = ri; i2[m] = ri + nk[m];
+    }
+    RC(fr_gather_mul3(c, dst, cnt, sc, ext, i1, rb, i2, 3, s));
   }
   // maximal runs of consecutive matrices with equal domains share batched transforms (and, in round 4, one numerator pass)
   nrun = 0;
