@@ -62,6 +62,7 @@ void host_parallel_for(size_t n, const std::function<void(size_t)>& f) {
 
 static std::mutex g_dev_mu;
 static std::map<int, Device*> g_devs;
+static int32_t create_streams_in_order(Device* d);
 
 int32_t ensure_host_pinned(Ctx* c, size_t bytes) {
   if (bytes <= c->h_pinned_cap) return ALEO_MI355X_OK;
@@ -111,7 +112,7 @@ static int32_t init_device(int device, Device** out) {
   for (int i = 0; i < MAX_SLOTS; ++i) { d->slots[i].dev = d.get(); d->slots[i].device = device; d->helpers[i].dev = d.get(); d->helpers[i].device = device; }
   *out = d.get();
   g_devs[device] = d.release();
-  return ALEO_MI355X_OK;
+  return create_streams_in_order(*out);                      // the main streams first: a hardware queue each (see "streams" below)
 }
 
 // Direct peer access between every ordered pair of initialised devices (xGMI: hipMemcpyPeerAsync then moves data link to link instead of through a

@@ -71,7 +71,10 @@ extern "C" {
 /* ENVIRONMENT (set by the HOST before its first HIP call; the library never edits the process environment): GPU_MAX_HW_QUEUES=8 is recommended.  The HIP
  * runtime maps a process's streams onto that many hardware queues (4 by default) and reads the variable once, when it initialises; the library runs a
  * caller's stream, a side stream, high-priority streams and the lockstep prover's worker streams at once (lockstep proofs -5 % with 8 queues, everything
- * else within noise; results never depend on it).  aleo_amd/__init__.py and bench.py set it as their own default; INTEGRATION.md 4 shows the Rust side. */
+ * else within noise; results never depend on it; 12 or more oversubscribe the device's queues and cost 1.5-2x on lockstep calls).  The library creates
+ * the main streams of its slots and of as many helper contexts FIRST, at the device's first use, so that each gets a hardware queue of its own (a
+ * lockstep call of 8 proofs: 31.8 -> 27.5 ms): initialise the device (aleo_mi355x_init_device) before the host creates many streams of its own.
+ * aleo_amd/__init__.py and bench.py set the variable as their own default; INTEGRATION.md 4 shows the Rust side. */
 
 /* initialises the first n_devices visible devices (0 = all of them).  Idempotent, thread-safe; the calling thread's current
  * HIP device is left as it was.  Every single-device entry point below works on the CALLING THREAD's current HIP device (hipSetDevice is per
