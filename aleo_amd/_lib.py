@@ -11,7 +11,7 @@ LIB_PATH = os.environ.get('ALEO_MI355X_LIB') or os.path.join(_HERE, 'lib', 'liba
 EXPORTS = [
     'aleo_mi355x_init', 'aleo_mi355x_msm_g1', 'aleo_mi355x_bases_pin', 'aleo_mi355x_bases_unpin',
     'aleo_mi355x_bases_generate', 'aleo_mi355x_bases_from_scalars', 'aleo_mi355x_fr_lin_device', 'aleo_mi355x_msm_g1_device_sparse', 'aleo_mi355x_bases_precompute_range', 'aleo_mi355x_kzg_commit_segments_sparse_device', 'aleo_mi355x_fr_blind_rows_device', 'aleo_mi355x_ahp_sumcheck_operands_device', 'aleo_mi355x_varuna_prove', 'aleo_mi355x_varuna_index_build', 'aleo_mi355x_varuna_index_export', 'aleo_mi355x_varuna_index_vk', 'aleo_mi355x_varuna_index_free', 'aleo_mi355x_varuna_prove_indexed', 'aleo_mi355x_varuna_prove_batch_indexed', 'aleo_mi355x_varuna_last_timing', 'aleo_mi355x_fr_random_device', 'aleo_mi355x_fr_lincomb_device', 'aleo_mi355x_ahp_first_sumcheck_device', 'aleo_mi355x_ahp_matrix_sumcheck_device', 'aleo_mi355x_fr_powers_device', 'aleo_mi355x_fr_gather_mul_device', 'aleo_mi355x_fr_eval_batch_device', 'aleo_mi355x_bases_download', 'aleo_mi355x_bases_info', 'aleo_mi355x_bases_precompute',
-    'aleo_mi355x_msm_g1_pinned', 'aleo_mi355x_msm_g1_device', 'aleo_mi355x_g1_sum', 'aleo_mi355x_msm_g2', 'aleo_mi355x_g2_sum', 'aleo_mi355x_ntt_fr',
+    'aleo_mi355x_msm_g1_pinned', 'aleo_mi355x_msm_g1_device', 'aleo_mi355x_g1_sum', 'aleo_mi355x_msm_g2', 'aleo_mi355x_g2_sum', 'aleo_mi355x_bases_g2_pin', 'aleo_mi355x_bases_g2_unpin', 'aleo_mi355x_msm_g2_pinned', 'aleo_mi355x_ntt_fr',
     'aleo_mi355x_ntt_fr_device', 'aleo_mi355x_ntt_fr_batch_device', 'aleo_mi355x_ntt_fr_from_device', 'aleo_mi355x_fr_grid_scale_device', 'aleo_mi355x_kzg_commit', 'aleo_mi355x_kzg_commit_device', 'aleo_mi355x_kzg_commit_hiding',
     'aleo_mi355x_msm_g1_batch_device', 'aleo_mi355x_kzg_commit_batch_device', 'aleo_mi355x_kzg_commit_batch', 'aleo_mi355x_kzg_commit_segments', 'aleo_mi355x_kzg_commit_segments_device',
     'aleo_mi355x_fr_vec_op_device', 'aleo_mi355x_fr_batch_inverse_device', 'aleo_mi355x_fr_spmv_device', 'aleo_mi355x_fr_divide_by_linear_device', 'aleo_mi355x_kzg_open_device', 'aleo_mi355x_fq_mul',
@@ -118,6 +118,9 @@ def lib():
         'aleo_mi355x_g1_sum': ([vp, vp, sz], i32),
         'aleo_mi355x_msm_g2': ([vp, vp, sz, vp, sz], i32),
         'aleo_mi355x_g2_sum': ([vp, vp, sz], i32),
+        'aleo_mi355x_bases_g2_pin': ([vp, sz, sz, ctypes.POINTER(u64)], i32),
+        'aleo_mi355x_bases_g2_unpin': ([u64], i32),
+        'aleo_mi355x_msm_g2_pinned': ([vp, u64, vp, sz], i32),
         'aleo_mi355x_ntt_fr': ([vp, u32, i32, i32, i32], i32),
         'aleo_mi355x_ntt_fr_device': ([vp, u32, i32, i32, i32, vp], i32),
         'aleo_mi355x_ntt_fr_batch_device': ([vp, u32, sz, i32, i32, i32, vp], i32),

@@ -673,6 +673,62 @@ int32_t aleo_mi355x_msm_g2(void* out_jac288, const void* bases, size_t base_stri
   } catch (...) { return ALEO_MI355X_ERR_HIP; }
 }
 
+// A G2 base set kept on the device (round 5): rows, infinity flags and the 28-bit rows of the accumulation stay in HBM, so a call moves only its scalars
+// (the one-shot entry point above uploads 192-200 bytes per base and rebuilds the 28-bit rows every time: 3.8 + 0.4 of its 22 ms at 2^20).  Any prefix
+// of the set can be multiplied.  G2 appears in SRS setup and verifying keys, never in the prover's loop: no window tables.
+static int32_t g2_upload(Ctx* c, const void* bases, size_t base_stride, size_t n, std::shared_ptr<PinnedG2>* out) {
+  auto o = std::make_shared<PinnedG2>(); o->n = n; int32_t rc;
+  HIPCHK(hipMalloc(&o->d_xy, (n ? n : 1) * 192)); HIPCHK(hipMalloc(&o->d_rows28, (n ? n : 1) * 224));
+  if (base_stride == 192) { if (n) HIPCHK(hipMemcpyAsync(o->d_xy, bases, n * 192, hipMemcpyHostToDevice, c->stream)); }
+  else if (n) {
+    DevTmp raw, inf;
+    if ((rc = raw.alloc(n * 200)) || (rc = inf.alloc(n + 8))) return rc;
+    HIPCHK(hipMemcpyAsync(raw.p, bases, n * 200, hipMemcpyHostToDevice, c->stream));
+    uint32_t* d_count = (uint32_t*)((char*)inf.p + ((n + 3) & ~(size_t)3));
+    if ((rc = g2_unpack200(c, raw.p, o->d_xy, inf.p, d_count, n, c->stream))) return rc;
+    uint32_t n_inf = 0;
+    HIPCHK(hipMemcpyAsync(&n_inf, d_count, 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (n_inf) o->d_inf = (uint8_t*)inf.release();
+  }
+  if ((rc = g2_rows_to28(o->d_xy, o->d_rows28, n, c->stream))) return rc;
+  HIPCHK(hipStreamSynchronize(c->stream));
+  *out = std::move(o); return ALEO_MI355X_OK;
+}
+int32_t aleo_mi355x_bases_g2_pin(const void* bases, size_t base_stride, size_t n, uint64_t* handle) {
+  try {
+    if (!handle || (!bases && n) || (base_stride != 200 && base_stride != 192) || n >= (1ull << 31)) { g_last_error = "bases_g2_pin: bad argument"; return ALEO_MI355X_ERR_BAD_ARG; }
+    API_BEGIN
+    std::shared_ptr<PinnedG2> o;
+    const int32_t rc = g2_upload(c, bases, base_stride, n, &o);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk2(d->mu);
+    *handle = d->next_handle++; d->g2_bases[*handle] = std::move(o);
+    return ALEO_MI355X_OK;
+  } catch (...) { return ALEO_MI355X_ERR_HIP; }
+}
+int32_t aleo_mi355x_bases_g2_unpin(uint64_t handle) {
+  try {
+    API_BEGIN
+    std::shared_ptr<PinnedG2> keep;                          // freed outside the device lock (and after calls still holding it have returned)
+    { std::lock_guard<std::mutex> lk2(d->mu); auto it = d->g2_bases.find(handle); if (it == d->g2_bases.end()) { g_last_error = "unknown G2 bases handle"; return ALEO_MI355X_ERR_BAD_HANDLE; } keep = std::move(it->second); d->g2_bases.erase(it); }
+    return ALEO_MI355X_OK;
+  } catch (...) { return ALEO_MI355X_ERR_HIP; }
+}
+int32_t aleo_mi355x_msm_g2_pinned(void* out_jac288, uint64_t handle, const void* scalars, size_t n) {
+  try {
+    if (!out_jac288 || (!scalars && n)) { g_last_error = "msm_g2_pinned: bad argument"; return ALEO_MI355X_ERR_BAD_ARG; }
+    API_BEGIN
+    std::shared_ptr<PinnedG2> keep;
+    { std::lock_guard<std::mutex> lk2(d->mu); auto it = d->g2_bases.find(handle); if (it == d->g2_bases.end()) { g_last_error = "unknown G2 bases handle"; return ALEO_MI355X_ERR_BAD_HANDLE; } keep = it->second; }
+    if (n > keep->n) { g_last_error = "msm_g2_pinned: more scalars than pinned bases"; return ALEO_MI355X_ERR_BAD_ARG; }
+    int32_t rc;
+    if ((rc = c->scalars_stage.reserve((n ? n : 1) * 32))) return rc;
+    if (n) HIPCHK(hipMemcpyAsync(c->scalars_stage.p, scalars, n * 32, hipMemcpyHostToDevice, c->stream));
+    return msm_g2_run(c, (uint64_t*)out_jac288, keep->d_xy, keep->d_inf, c->scalars_stage.p, n, c->stream, keep->d_rows28);
+  } catch (...) { return ALEO_MI355X_ERR_HIP; }
+}
+
 int32_t aleo_mi355x_g2_sum(void* out, const void* pts, size_t count) {
   try {
     if (!out || (!pts && count)) return ALEO_MI355X_ERR_BAD_ARG;

@@ -89,6 +89,11 @@ struct PinnedOwner {
   ~PinnedOwner() { if (pb.d_xy) (void)hipFree(pb.d_xy); if (pb.d_xy28) (void)hipFree(pb.d_xy28); if (pb.d_inf) (void)hipFree(pb.d_inf); for (auto& t : pb.tab) if (t.d) (void)hipFree(t.d); if (pb.range.d) (void)hipFree(pb.range.d); }
 };
 
+struct PinnedG2 {                        // aleo_mi355x_bases_g2_pin: x | y rows (192 B), infinity flags when any, the 28-bit rows the accumulation reads (224 B)
+  void* d_xy = nullptr; uint8_t* d_inf = nullptr; void* d_rows28 = nullptr; size_t n = 0;
+  ~PinnedG2() { if (d_xy) (void)hipFree(d_xy); if (d_inf) (void)hipFree(d_inf); if (d_rows28) (void)hipFree(d_rows28); }
+};
+
 struct SrsCacheEntry {
   const void* host_ptr = nullptr; size_t n = 0, stride = 0; uint64_t handle = 0, last_use = 0; uint32_t hits = 0;
   std::vector<std::pair<size_t, uint64_t>> samples;      // (point index, hash of its 96 bytes)
@@ -164,6 +169,7 @@ struct Device {
   std::mutex mu;                       // guards everything below; never held across a kernel launch or a copy of bulk data
   std::map<uint64_t, std::shared_ptr<PinnedOwner>> bases; uint64_t next_handle = 1;
   std::vector<SrsCacheEntry> srs_cache; uint64_t srs_clock = 0;
+  std::map<uint64_t, std::shared_ptr<PinnedG2>> g2_bases;      // handles share next_handle's counter with `bases`
   std::map<uint64_t, NttTables*> ntt_tables;
   std::map<uint64_t, std::shared_ptr<struct VarunaIndexOwner>> varuna; uint64_t next_varuna = 1;      // circuit indices (varuna.hip)
   std::atomic<int> ntt_attr_mask{0};   // which NTT kernel instances had their LDS limit raised on THIS device
@@ -224,7 +230,8 @@ int32_t make_rows28(Ctx* c, PinnedBases* pb);          // fills pb->d_xy28 from 
 int32_t selftest_madd28(Ctx* c, uint32_t lanes, uint32_t steps, uint64_t seed, uint32_t* failures);
 int32_t selftest_addquad(Ctx* c, uint32_t ops, uint64_t seed, uint32_t* failures);
 // g2.hip
-int32_t msm_g2_run(Ctx* c, uint64_t* out_jac36, const void* d_xy192, const uint8_t* d_inf, const void* d_scalars, size_t n, hipStream_t s);
+int32_t msm_g2_run(Ctx* c, uint64_t* out_jac36, const void* d_xy, const uint8_t* d_inf, const void* d_scalars, size_t n, hipStream_t s, const void* d_rows28 = nullptr);      // d_rows28: the set's resident 28-bit rows (a pinned G2 set), else built per call
+int32_t g2_rows_to28(const void* d_xy192, void* d_dst224, size_t n, hipStream_t s);
 int32_t g2_sum_host(uint64_t* out36, const uint64_t* pts36, size_t count);
 int32_t selftest_g2pair(Ctx* c, const void* aff192_host, uint32_t n, uint32_t npairs, uint32_t* failures2);      // [0] pairs that disagreed, [1] OR of the failing steps
 int32_t g2_unpack200(Ctx* c, const void* d_rows200, void* d_xy192, void* d_flags, uint32_t* d_count, size_t n, hipStream_t s);      // 200-byte G2Affine rows -> 192-byte rows + flag bytes + their count

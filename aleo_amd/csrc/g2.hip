@@ -617,7 +617,14 @@ static void h2store_jacobian_normalized(uint64_t* j36, const HXYZZ2& p) {
 }  // namespace host
 
 // One G2 MSM: bases d_xy (n x 192 B, device) with optional infinity flags, scalars on the device.  Plain schedule (no table).
-int32_t msm_g2_run(Ctx* c, uint64_t* out_jac36, const void* d_xy, const uint8_t* d_inf, const void* d_scalars, size_t n, hipStream_t s) {
+// the 28-bit rows of n affine points (192-byte x | y rows on the device) into dst224: what a pinned G2 set keeps beside its rows
+int32_t g2_rows_to28(const void* d_xy192, void* d_dst224, size_t n, hipStream_t s) {
+  if (n == 0) return ALEO_MI355X_OK;
+  hipLaunchKernelGGL(k_g2_rows_to28, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, (const char*)d_xy192, (char*)d_dst224, (uint32_t)n);
+  HIPCHK(hipGetLastError());
+  return ALEO_MI355X_OK;
+}
+int32_t msm_g2_run(Ctx* c, uint64_t* out_jac36, const void* d_xy, const uint8_t* d_inf, const void* d_scalars, size_t n, hipStream_t s, const void* d_rows28) {
   using namespace host;
   if (n == 0) { h2store_jacobian_normalized(out_jac36, HXYZZ2::infinity()); return ALEO_MI355X_OK; }
   if (n >= (1ull << 31)) { g_last_error = "msm_g2: n exceeds 2^31"; return ALEO_MI355X_ERR_BAD_ARG; }
@@ -635,9 +642,10 @@ int32_t msm_g2_run(Ctx* c, uint64_t* out_jac36, const void* d_xy, const uint8_t*
   const size_t PBY = pair28 ? 448 : 384;                    // bytes per stored point of the reduction
   char* partial = c->partial.as<char>(); char* V = c->vbuf.as<char>(); char* Vout = V + (size_t)nchunks * PBY;
   if (pair_accum) {
-    if ((rc = c->out_stage.reserve(n * 224 + (pair28 ? 0 : sp.slices_max * 384)))) return rc;                          // the bases in the 28-bit form (per call: a G2 MSM keeps nothing resident)
-    hipLaunchKernelGGL(k_g2_rows_to28, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, (const char*)d_xy, c->out_stage.as<char>(), (uint32_t)n);
-    hipLaunchKernelGGL(k_g2_accum28, dim3(2 * sp.slice_blocks), dim3(256), 0, s, c->out_stage.as<const char>(), (const char*)d_xy, sp.sorted, sp.hist, sp.scan_local, sp.scan_blk,
+    const bool resident = d_rows28 != nullptr && pair28;    // a pinned set (aleo_mi355x_bases_g2_pin) keeps its 28-bit rows
+    if ((rc = c->out_stage.reserve((resident ? 0 : n * 224) + (pair28 ? 0 : sp.slices_max * 384) + 256))) return rc;      // the bases in the 28-bit form (per call for the one-shot entry point)
+    if (!resident) hipLaunchKernelGGL(k_g2_rows_to28, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, (const char*)d_xy, c->out_stage.as<char>(), (uint32_t)n);
+    hipLaunchKernelGGL(k_g2_accum28, dim3(2 * sp.slice_blocks), dim3(256), 0, s, resident ? (const char*)d_rows28 : c->out_stage.as<const char>(), (const char*)d_xy, sp.sorted, sp.hist, sp.scan_local, sp.scan_blk,
                        sp.total_pairs, M, sp.meta, sp.order, sp.task_g, partial);
     if (!pair28) {                                         // mode 2: hand the slice sums to the one-lane kernels
       char* p32 = c->out_stage.as<char>() + n * 224;

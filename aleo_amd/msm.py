@@ -192,6 +192,28 @@ def msm_g2(bases: np.ndarray, scalars: np.ndarray) -> np.ndarray:
     return out
 
 
+class PinnedG2Bases:
+    """A G2 base set resident in HBM (aleo_mi355x_bases_g2_pin): `msm(scalars)` multiplies the first len(scalars) bases, result as msm_g2's."""
+    def __init__(self, bases: np.ndarray):
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        self.n = int(bases.shape[0]); stride = bases.shape[1] if bases.ndim == 2 and bases.shape[0] else 200
+        h = ctypes.c_uint64(0)
+        check(lib().aleo_mi355x_bases_g2_pin(_p(bases), stride, self.n, ctypes.byref(h)), 'bases_g2_pin')
+        self.handle = h.value
+
+    def msm(self, scalars: np.ndarray) -> np.ndarray:
+        scalars = np.ascontiguousarray(scalars, dtype=np.uint64).reshape(-1, 4)
+        out = np.zeros(36, dtype=np.uint64)
+        check(lib().aleo_mi355x_msm_g2_pinned(_p(out), self.handle, _p(scalars), scalars.shape[0]), 'msm_g2_pinned')
+        return out
+
+    def close(self):
+        if self.handle: check(lib().aleo_mi355x_bases_g2_unpin(self.handle), 'bases_g2_unpin'); self.handle = 0
+
+    def __enter__(self): return self
+    def __exit__(self, *a): self.close()
+
+
 def g2_sum(points: np.ndarray) -> np.ndarray:
     pts = np.ascontiguousarray(points, dtype=np.uint64).reshape(-1, 36)
     out = np.zeros(36, dtype=np.uint64)

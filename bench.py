@@ -571,6 +571,12 @@ def msm_g2_bench(aleo_amd, synth):
         dt = (time.perf_counter() - t0) / reps
         c = min(16, lg - 4); W = (254 + c - 1) // c
         out['2^%d' % lg] = {'ms': dt * 1e3, 'scalar_muls_per_s': n / dt, 'windows': W, 'fq_product_equivalents_per_s': 30.0 * n * W / dt}
+        with M.PinnedG2Bases(B) as pg:                      # the same request against a set resident in HBM (aleo_mi355x_msm_g2_pinned: only the scalars move)
+            if not (pg.msm(S) == res).all(): raise SystemExit('bench: the pinned G2 set and the one-shot call disagree')
+            t0 = time.perf_counter()
+            for _ in range(reps): pg.msm(S)
+            dp = (time.perf_counter() - t0) / reps
+        out['2^%d' % lg].update({'pinned_ms': dp * 1e3, 'pinned_scalar_muls_per_s': n / dp, 'pinned_fq_product_equivalents_per_s': 30.0 * n * W / dp})
     return out
 
 

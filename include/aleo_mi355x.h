@@ -166,6 +166,13 @@ int32_t aleo_mi355x_msm_g1_sharded(void* out_jacobian, uint64_t handle, const vo
  * (x, y, 1), or (1, 1, 0) for the identity.  Host pointers; nothing is retained.  g2_sum: the group add after an all-gather. */
 int32_t aleo_mi355x_msm_g2(void* out_jacobian288, const void* bases, size_t base_stride, const void* scalars, size_t n);
 int32_t aleo_mi355x_g2_sum(void* out_jacobian288, const void* jacobian_points288, size_t count);
+/* A G2 base set resident in HBM (what aleo_mi355x_bases_pin is for G1; SRS powers in G2, a verifying key's elements): rows, infinity flags and the
+ * accumulation's 28-bit rows stay on the device, a call uploads its scalars only and multiplies any PREFIX of the set (n <= pinned count).  Same
+ * argument formats and result as aleo_mi355x_msm_g2, byte for byte; no window tables (the prover never runs a G2 MSM).  unpin frees the set once the
+ * calls that hold it have returned. */
+int32_t aleo_mi355x_bases_g2_pin(const void* bases, size_t base_stride, size_t n, uint64_t* handle);
+int32_t aleo_mi355x_bases_g2_unpin(uint64_t handle);
+int32_t aleo_mi355x_msm_g2_pinned(void* out_jacobian288, uint64_t handle, const void* scalars, size_t n);
 
 /* a2 — EvaluationDomain NTT over Fr, in place, n = 2^lg_n elements (lg_n <= 30), host pointer. */
 int32_t aleo_mi355x_ntt_fr(void* inout, uint32_t lg_n, int32_t order, int32_t direction, int32_t type);

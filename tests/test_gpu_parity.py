@@ -1225,6 +1225,34 @@ def test_msm_g2_edge_cases():
     assert (M.g2_sum(parts) == M.msm_g2(B, S)).all()
 
 
+def test_msm_g2_pinned_set_equals_the_one_shot_call():
+    """aleo_mi355x_bases_g2_pin / _msm_g2_pinned: the resident set (rows, infinity flags, 28-bit rows) gives the one-shot call's bytes — on every prefix,
+    with both row strides, with infinity bases in the set, for the empty and the all-zero request; more scalars than pinned bases and unknown or
+    released handles are refused."""
+    n = 5000
+    B = _g2_multiples(n); B[17] = 0; B[17, 192] = 1; B[4096] = 0; B[4096, 192] = 1          # two infinity bases
+    S = util.uniform_scalars(n, 16950); Wt = util.witness_like_scalars(n, 16951)
+    with M.PinnedG2Bases(B) as pg:
+        for m in (n, 4097, 4096, 1000, 33, 18, 17, 1, 0):
+            got = pg.msm(S[:m])
+            assert (got == M.msm_g2(B[:m], S[:m])).all(), m
+            if m in (1000, 33): assert c.g2_jac_to_int_point(got) == c.g2_jac_to_int_point(c.msm_g2(B[:m], S[:m])), m      # and the oracle
+        assert (pg.msm(Wt) == M.msm_g2(B, Wt)).all()
+        assert c.g2_jac_to_int_point(pg.msm(np.zeros((n, 4), dtype=np.uint64))) is None
+        assert (pg.msm(S) == pg.msm(S)).all()                                                  # the set is not consumed
+        out = np.zeros(36, dtype=np.uint64); big = util.uniform_scalars(n + 1, 16952)
+        assert aleo_amd.lib().aleo_mi355x_msm_g2_pinned(out.ctypes.data_as(ctypes.c_void_p), pg.handle, big.ctypes.data_as(ctypes.c_void_p), n + 1) == 2
+        assert aleo_amd.lib().aleo_mi355x_msm_g2_pinned(None, pg.handle, big.ctypes.data_as(ctypes.c_void_p), 4) == 2
+        h = pg.handle
+    assert aleo_amd.lib().aleo_mi355x_msm_g2_pinned(out.ctypes.data_as(ctypes.c_void_p), h, S.ctypes.data_as(ctypes.c_void_p), 4) != 0       # released
+    assert aleo_amd.lib().aleo_mi355x_bases_g2_unpin(h) != 0
+    C = _g2_multiples(300)
+    with M.PinnedG2Bases(np.ascontiguousarray(C[:, :192])) as pg:                              # stride 192: no flags
+        assert c.g2_jac_to_int_point(pg.msm(S[:300])) == p.g2_mul(p.G2_GENERATOR, synth.weighted_scalar_sum(S[:300], 1))
+    hh = ctypes.c_uint64(0)
+    assert aleo_amd.lib().aleo_mi355x_bases_g2_pin(C.ctypes.data_as(ctypes.c_void_p), 104, 300, ctypes.byref(hh)) == 2                          # bad stride
+
+
 def test_g2_lane_pair_arithmetic_matches_the_one_lane_code():
     """The lane-pair Fq2 arithmetic of the G2 path (components across two lanes, 28-bit limbs: full addition, doubling, the same-point case of the addition,
     the mixed addition of the accumulation loop) against the one-lane 32-bit code on chains over real curve points, every intermediate compared as a
