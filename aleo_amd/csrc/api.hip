@@ -272,6 +272,25 @@ static int32_t upload_bases(Ctx* c, const void* bases, size_t stride, size_t n, 
   { int32_t rc28 = make_rows28(c, &pb); if (rc28) return rc28; }
   *out = std::move(o); return ALEO_MI355X_OK;
 }
+// The same into the slot's own buffers, as a view nobody owns (the cold one-shot call: aleo_mi355x_msm_g1 without the SRS cache)
+static int32_t cold_bases(Ctx* c, const void* bases, size_t stride, size_t n, PinnedBases* pb) {
+  *pb = PinnedBases(); pb->n = n; int32_t rc;
+  if ((rc = c->cold_xy.reserve((n ? n : 1) * 96)) || (rc = c->cold_xy28.reserve((n ? n : 1) * ROW28))) return rc;
+  pb->d_xy = c->cold_xy.p;
+  if (stride == 96) { if (n) HIPCHK(hipMemcpyAsync(pb->d_xy, bases, n * 96, hipMemcpyHostToDevice, c->stream)); }
+  else if (n) {
+    if ((rc = c->cold_raw.reserve(n * 104)) || (rc = c->cold_flags.reserve(n + 16))) return rc;
+    HIPCHK(hipMemcpyAsync(c->cold_raw.p, bases, n * 104, hipMemcpyHostToDevice, c->stream));
+    if ((rc = unpack_affine104(c, c->cold_raw.p, pb->d_xy, c->cold_flags.p, n, c->stream))) return rc;
+    uint32_t n_inf = 0;
+    HIPCHK(hipMemcpyAsync(&n_inf, (char*)c->cold_flags.p + ((n + 3) & ~(size_t)3), 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (n_inf) pb->d_inf = (uint8_t*)c->cold_flags.p;
+  }
+  if ((rc = rows_to28_into(pb->d_xy, c->cold_xy28.p, n, c->stream))) return rc;
+  pb->d_xy28 = c->cold_xy28.p;
+  return ALEO_MI355X_OK;
+}
 static uint64_t register_bases(Device* d, std::shared_ptr<PinnedOwner> o) {
   std::lock_guard<std::mutex> lk(d->mu);
   uint64_t h = d->next_handle++; d->bases[h] = std::move(o); return h;
@@ -610,6 +629,15 @@ int32_t aleo_mi355x_msm_g1(void* out, const void* bases, size_t base_stride, con
       PinnedBases pb; { std::lock_guard<std::mutex> g(d->mu); pb = keep->pb; }
       return msm_host_scalars(c, out, pb, scalars, n, false);
     }
+    // Nothing cached (the literal two-line drop-in): the call's copy of the bases lives in the SLOT's grow-only buffers (rows as uploaded, x | y rows, 28-bit rows, flags:
+    // 337 bytes per point, kept by the slot like its other workspaces), not in hipMalloc / hipFree pairs per call — hipFree waits for the device, and the pairs were 0.x ms of a
+    // 7.6 ms call at 2^20 (ALEO_MI355X_COLD_POOL=0: a PinnedOwner per call, as before).
+    static const bool cold_pool = [] { const char* e = std::getenv("ALEO_MI355X_COLD_POOL"); return !(e && e[0] == '0'); }();
+    if (cold_pool) {
+      PinnedBases pbc; const int32_t rc = cold_bases(c, bases, base_stride, n, &pbc);
+      if (rc) return rc;
+      return msm_host_scalars(c, out, pbc, scalars, n, false);
+    }
     std::shared_ptr<PinnedOwner> o; int32_t rc = upload_bases(c, bases, base_stride, n, &o);
     if (rc) return rc;
     return msm_host_scalars(c, out, o->pb, scalars, n, false);
@@ -651,17 +679,18 @@ int32_t aleo_mi355x_msm_g2(void* out_jac288, const void* bases, size_t base_stri
   try {
     if (!out_jac288 || ((!bases || !scalars) && n) || (base_stride != 200 && base_stride != 192)) { g_last_error = "msm_g2: bad argument"; return ALEO_MI355X_ERR_BAD_ARG; }
     API_BEGIN
-    DevTmp xy, inf; int32_t rc; bool any_inf = false;
-    if ((rc = xy.alloc((n ? n : 1) * 192))) return rc;
-    if (base_stride == 192) { if (n) HIPCHK(hipMemcpy(xy.p, bases, n * 192, hipMemcpyHostToDevice)); }
+    // the call's copy of the bases in the slot's grow-only buffers (shared with the cold G1 call: one call per slot at a time), not hipMalloc / hipFree pairs
+    int32_t rc; bool any_inf = false;
+    if ((rc = c->cold_xy.reserve((n ? n : 1) * 192))) return rc;
+    void* xy = c->cold_xy.p;
+    if (base_stride == 192) { if (n) HIPCHK(hipMemcpyAsync(xy, bases, n * 192, hipMemcpyHostToDevice, c->stream)); }
     else if (n) {
       // the 200-byte rows go up as they are and are unpacked on the device (round 4; the host loop that stripped the flag byte + padding first was
       // ~ 60 of the 91 ms of a 2^20-point call — the same finding as for G1's 104-byte rows in round 3)
-      DevTmp raw;
-      if ((rc = raw.alloc(n * 200)) || (rc = inf.alloc(n + 8))) return rc;
-      HIPCHK(hipMemcpyAsync(raw.p, bases, n * 200, hipMemcpyHostToDevice, c->stream));
-      uint32_t* d_count = (uint32_t*)((char*)inf.p + ((n + 3) & ~(size_t)3));
-      if ((rc = g2_unpack200(c, raw.p, xy.p, inf.p, d_count, n, c->stream))) return rc;
+      if ((rc = c->cold_raw.reserve(n * 200)) || (rc = c->cold_flags.reserve(n + 16))) return rc;
+      HIPCHK(hipMemcpyAsync(c->cold_raw.p, bases, n * 200, hipMemcpyHostToDevice, c->stream));
+      uint32_t* d_count = (uint32_t*)((char*)c->cold_flags.p + ((n + 3) & ~(size_t)3));
+      if ((rc = g2_unpack200(c, c->cold_raw.p, xy, c->cold_flags.p, d_count, n, c->stream))) return rc;
       uint32_t n_inf = 0;
       HIPCHK(hipMemcpyAsync(&n_inf, d_count, 4, hipMemcpyDeviceToHost, c->stream));
       HIPCHK(hipStreamSynchronize(c->stream));
@@ -669,7 +698,7 @@ int32_t aleo_mi355x_msm_g2(void* out_jac288, const void* bases, size_t base_stri
     }
     if ((rc = c->scalars_stage.reserve((n ? n : 1) * 32))) return rc;
     if (n) HIPCHK(hipMemcpyAsync(c->scalars_stage.p, scalars, n * 32, hipMemcpyHostToDevice, c->stream));
-    return msm_g2_run(c, (uint64_t*)out_jac288, xy.p, any_inf ? (const uint8_t*)inf.p : nullptr, c->scalars_stage.p, n, c->stream);
+    return msm_g2_run(c, (uint64_t*)out_jac288, xy, any_inf ? (const uint8_t*)c->cold_flags.p : nullptr, c->scalars_stage.p, n, c->stream);
   } catch (...) { return ALEO_MI355X_ERR_HIP; }
 }
 

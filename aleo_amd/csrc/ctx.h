@@ -125,6 +125,7 @@ struct Ctx {                           // one concurrency slot
   std::function<int32_t()> tail_hook;
   DevBuf prover_ws; void* prover_pin = nullptr; size_t prover_pin_cap = 0;      // varuna.hip: one proof's device workspace, pinned staging of the assignments
   MsmTiming last_msm;
+  DevBuf cold_raw, cold_xy, cold_xy28, cold_flags;      // the cold one-shot MSM (api.hip cold_bases): the call's copy of the caller's bases, grow-only like every other workspace of the slot
   DevBuf ntt_tmp, ntt_stage;
   // ntt_tmp is scratch of the *_device entry points, which enqueue on the CALLER's stream and return without synchronising;
   // the slot is then handed to the next call, possibly on another stream.  scratch_ev is recorded after the last kernel that
@@ -226,6 +227,7 @@ int32_t generate_from_scalars(Ctx* c, const void* base104, const void* scalars32
 int32_t msm_precompute(Ctx* c, PinnedBases* pb);
 int32_t msm_precompute_range(Ctx* c, PinnedBases* pb, size_t off, size_t n, int window_bits);
 int32_t unpack_affine104(Ctx* c, const void* d_rows104, void* d_xy96, void* d_flags, size_t n, hipStream_t s);      // d_flags: n bytes + a uint32 count at the next multiple of 4
+int32_t rows_to28_into(const void* d_xy96, void* d_dst, size_t n, hipStream_t s);
 int32_t make_rows28(Ctx* c, PinnedBases* pb);          // fills pb->d_xy28 from pb->d_xy
 int32_t selftest_madd28(Ctx* c, uint32_t lanes, uint32_t steps, uint64_t seed, uint32_t* failures);
 int32_t selftest_addquad(Ctx* c, uint32_t ops, uint64_t seed, uint32_t* failures);

@@ -2020,6 +2020,13 @@ int32_t unpack_affine104(Ctx* c, const void* d_rows104, void* d_xy96, void* d_fl
   return ALEO_MI355X_OK;
 }
 
+// the same conversion into a buffer the caller provides (the cold one-shot call's slot buffers), queued on s
+int32_t rows_to28_into(const void* d_xy96, void* d_dst, size_t n, hipStream_t s) {
+  if (n == 0) return ALEO_MI355X_OK;
+  hipLaunchKernelGGL(k_rows_to28, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, (const char*)d_xy96, (char*)d_dst, (uint32_t)n);
+  HIPCHK(hipGetLastError());
+  return ALEO_MI355X_OK;
+}
 int32_t make_rows28(Ctx* c, PinnedBases* pb) {
   if (pb->d_xy28 || pb->n == 0) return ALEO_MI355X_OK;
   DevTmp rows; int32_t rc;
