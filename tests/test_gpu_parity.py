@@ -541,6 +541,34 @@ def test_concurrent_callers_share_the_device_safely():
     assert got == exp
 
 
+def test_chunked_host_scalar_calls_from_six_threads_share_the_high_priority_streams():
+    """Chunked host-scalar MSMs (the headline call's path: the later chunks run on a borrowed helper's high-priority stream) from six threads at once.  The device
+    keeps a POOL of four high-priority streams (api.hip first_use: eight in a row made pipelined proofs crawl), so helpers 0 and 4, 1 and 5 share one: the calls
+    must still return their own results, and mixed with three-chunk requests (2^21 points: two helpers each)."""
+    import threading
+    n = 1 << 21
+    pb = M.PinnedBases.generate_multiples(synth.generator_affine104(), 1, n).precompute()
+    try:
+        sizes = [1 << 19, (1 << 19) + 1000, 1 << 20, (1 << 20) - 256, 1 << 21, (1 << 19) + 7]
+        S = [util.uniform_scalars(m, 7300 + t) for t, m in enumerate(sizes)]
+        exp = [util.expected_multiples_msm(x, len(x)) for x in S]
+        errs = []; started = threading.Barrier(len(sizes))
+
+        def work(t):
+            try:
+                started.wait()
+                for _ in range(3):
+                    assert c.jac_to_int_point(M.VariableBase.msm(pb, S[t])) == exp[t], t
+            except Exception as e:      # noqa: BLE001
+                errs.append(e)
+        ths = [threading.Thread(target=work, args=(t,)) for t in range(len(sizes))]
+        for t in ths: t.start()
+        for t in ths: t.join()
+        assert not errs, errs
+    finally:
+        pb.close()
+
+
 def test_concurrent_slots_share_one_pinned_set():
     """Calls from different threads run on different slots (own stream + workspaces) against ONE pinned set: the table
     build races with running MSMs, and an unpin from another thread must not free the set under a call in flight."""
