@@ -683,7 +683,8 @@ static inline bool quads_on() { static const bool v = [] { const char* e = std::
 static constexpr uint32_t ASIDE_MAX = 8;  // super-heavy buckets whose slice trees may run beside the reduction (msm_run)
 static inline bool aside_on() { static const bool v = [] { const char* e = std::getenv("ALEO_MI355X_ASIDE"); return !(e && e[0] == '0'); }(); return v; }      // A/B switch
 static inline bool prog_on() { static const bool v = [] { const char* e = std::getenv("ALEO_MI355X_SUM_TREE"); return !(e && e[0] == '0'); }(); return v; }      // A/B switch: 0 = masked trees on the wide tables too
-static inline uint32_t grp_lanes(uint64_t ops) { return quads_on() && ops * 4 <= (1u << 17) ? 4u : 2u; }
+static inline uint32_t quad_max_lg() { static const uint32_t v = [] { const char* e = std::getenv("ALEO_MI355X_QUAD_MAX_LG"); const int k = e ? std::atoi(e) : 17; return (uint32_t)(k >= 10 && k <= 24 ? k : 17); }(); return v; }      // A/B: lg of the most quad lanes a launch may have
+static inline uint32_t grp_lanes(uint64_t ops) { return quads_on() && ops * 4 <= ((uint64_t)1 << quad_max_lg()) ? 4u : 2u; }
 // partial[ft + i] += partial[ft + i + half] inside every multi-slice bucket: one launch per level serves both lists of the scan —
 // the common one (buckets of <= 16 slices, `pairs_a` lane pairs each) and the super-heavy one (`pairs_b` each; skewed scalars).
 template <bool F28, uint32_t LANES = 2>
