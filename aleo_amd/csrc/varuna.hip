@@ -783,8 +783,7 @@ int32_t Batch::open_prepare() {
   // one short challenge per polynomial of an opening [UPSTREAM-RECALL: sonic_pc combine_for_open], the point beta first:
   // beta: g_1, z_b of every instance, the lincheck combination;  gamma: g_{j,M} circuit by circuit, the matrix combination
   sh.ch_b.resize(K + 2); sh.ch_g.resize(3 * m + 1);
-  for (auto& v : sh.ch_b) v = sh.fs.squeeze_short();
-  for (auto& v : sh.ch_g) v = sh.fs.squeeze_short();
+  for (auto& v : sh.ch_b) v = sh.fs.squeeze_short();          // (ch_g: squeezed below, behind the launch of the beta combination — the same sponge calls in the same order, ~2 permutations off the GPU's idle time)
   const HFr g1_beta = sh.evals[K];
   // one inversion for everything the openings divide by: alpha − beta, v_{H_j}(beta) (selectors), v_{K_{j,M}}(gamma)
   std::vector<HFr> inv(1 + 4 * m);
@@ -820,6 +819,7 @@ int32_t Batch::open_prepare() {
       }
     }
     RC(lincomb_any(c, pbeta, 3 * N, HFr::mul(xl, cst), terms, lens, co, s));
+    for (auto& v : sh.ch_g) v = sh.fs.squeeze_short();
     sh.random_v = HFr::add(blc[0], HFr::mul(beta, HFr::add(blc[1], HFr::mul(beta, blc[2]))));
     blw[1] = blc[2]; blw[0] = HFr::add(blc[1], HFr::mul(beta, blc[2])); blw[2] = HFr::zero();
     char* st = sh.stage + sh.st_blq() * 32; std::memcpy(st, blw, HC * 32);
