@@ -627,11 +627,12 @@ int32_t Batch::first_prepare(const void* const* assignments) {
   TAKE_M(sh.bl, (3 * K + 1) * HC) TAKE_M(sh.mask, 3 * N)
   sh.blind.assign((3 * K + 1) * HC, HFr::zero()); sh.x_mont.clear();
   std::vector<MsmSeg>& sg = job[0].segs; std::vector<MsmSeg>& sm = job[1].segs; sg.clear(); sm.clear();
+  // the mask polynomial needs nothing from the assignments: queued FIRST, it runs while the host stages and uploads them (a pageable 1-MB copy keeps the calling thread ~50 us)
+  RC(fr_random(c, sh.mask, 3 * N, (const uint8_t*)sh.seed.w, sh.lay_mask, 1, s));
+  RC(fr_lin(c, sh.mask, 1, nullptr, sh.neg1.l, sh.mask + N * 32, sh.neg1.l, sh.mask + 2 * N * 32, s));   // sum over H* = |H*| (m_0 + m_|H*| + m_2|H*|) = 0
   for (auto& p : P) RC(p->first_round(assignments + p->q0, sg));
   if (sh.flag) HIPCHK(hipMemcpyAsync(sh.pin_small + PIN_FLAG, sh.flag, 4, hipMemcpyDeviceToHost, s));      // read after the round's commitments
   for (size_t t = 0; t < HC; ++t) sh.blind[3 * K * HC + t] = random_fr(sh.seed, sh.lay_blind_mask + t);
-  RC(fr_random(c, sh.mask, 3 * N, (const uint8_t*)sh.seed.w, sh.lay_mask, 1, s));
-  RC(fr_lin(c, sh.mask, 1, nullptr, sh.neg1.l, sh.mask + N * 32, sh.neg1.l, sh.mask + 2 * N * 32, s));   // sum over H* = |H*| (m_0 + m_|H*| + m_2|H*|) = 0
   std::memcpy(sh.stage + sh.st_blind() * 32, sh.blind.data(), sh.blind.size() * 32);
   HIPCHK(hipMemcpyAsync(sh.bl, sh.stage + sh.st_blind() * 32, sh.blind.size() * 32, hipMemcpyHostToDevice, s));
   sh.wit_aff.assign(104 * (3 * K + 1), 0);
