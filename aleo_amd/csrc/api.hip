@@ -1081,14 +1081,17 @@ int32_t aleo_mi355x_varuna_prove_many(aleo_mi355x_prove_request* requests, size_
     FIND_BASES(key)
     std::vector<ProveRequest> live; std::vector<size_t> where;
     for (size_t p = 0; p < n_requests; ++p) if (!rq[p].status) { live.push_back(rq[p]); where.push_back(p); }
-    // From 4 proofs on the call runs as up to FOUR lockstep groups (ALEO_MI355X_LOCKSTEP_GROUPS, default 4; never fewer than 2 proofs per group) on as many threads (the caller's and one per further group, each on a context of its own): while one group's
-    // commitments hold the card, the other group's field kernels, sorts, reductions and transcripts — a third of a lockstep round — run in their shadow.  What
-    // several callers with a share of the proofs each achieve (8 proofs of 2^15 constraints: 254 proofs/s as one group, 275 as two calls of 4 in flight, 280 as four calls of 2:
-    // profiles/r05_lockstep_probe_2^15_lean_folded.json; groups 1 / 2 / 3 / 4 on one box: 32.7 / 36.0 / 33.6 / 32.1 ms per 8 proofs, 68.7 / 65.6 / 62.1 / 58.7 per 16 — two groups are
-    // box-dependent, four never lose: profiles/r05_lockstep_groups_ab.txt), without asking the host for more threads.  ALEO_MI355X_LOCKSTEP_GROUPS=1: one group.  Proof bytes do not depend on it.
+    // The call runs as up to FOUR lockstep groups (ALEO_MI355X_LOCKSTEP_GROUPS, default 4) on as many threads (the caller's and one per further group, each on a context of
+    // its own, whose main stream has a hardware queue of its own: "streams" above): while one group's commitments hold the card, the other groups' field kernels, sorts,
+    // reductions and transcripts — a third of a lockstep round — run in their shadow.  Up to four proofs that is one proof per group; from five on the groups hold two or more
+    // and batch their commitments.  Measured (2^15 constraints, same box; profiles/r05_lockstep_groups_ab.txt, r05_lockstep_retune*.txt, r05_group_min_ab.txt, r05_group_from_ab.txt):
+    // 8 proofs 32.7 ms as one group, 27.3 as four; 2 proofs 10.4 ms in lockstep, 8.55 as two groups of one; 3: 13.5 -> 11.6; 4: 15.1 -> 14.5; 8 groups of one: 29.6.
+    // ALEO_MI355X_LOCKSTEP_GROUPS=1: one group; ALEO_MI355X_LOCKSTEP_GROUP_FROM / _GROUP_MIN: fewest proofs per call that is split / per group.  Proof bytes do not depend on any of it.
     static const int groups_env = [] { const char* e = std::getenv("ALEO_MI355X_LOCKSTEP_GROUPS"); const int k = e ? std::atoi(e) : 4; return k >= 1 && k <= 4 ? k : 4; }();
     int32_t rc = ALEO_MI355X_OK; bool split_done = false;
-    const size_t want_groups = live.size() >= 4 ? std::min<size_t>((size_t)groups_env, live.size() / 2) : 1;
+    static const size_t group_min = [] { const char* e = std::getenv("ALEO_MI355X_LOCKSTEP_GROUP_MIN"); const int k = e ? std::atoi(e) : 1; return (size_t)(k >= 1 && k <= 64 ? k : 1); }();      // fewest proofs per group
+    static const size_t group_from = [] { const char* e = std::getenv("ALEO_MI355X_LOCKSTEP_GROUP_FROM"); const int k = e ? std::atoi(e) : 2; return (size_t)(k >= 2 && k <= 64 ? k : 2); }();      // fewest proofs per call that is split into groups
+    const size_t want_groups = live.size() >= group_from ? std::min<size_t>((size_t)groups_env, live.size() / group_min) : 1;
     if (want_groups >= 2) {
       // contexts for groups 1..: never waited for (whatever is free now); fewer groups if fewer are free
       std::vector<Ctx*> gc{c}; std::vector<std::unique_lock<std::mutex>> glk;

@@ -625,6 +625,18 @@ def test_frozen_proofs_with_the_alternative_kernel_paths():
 
 
 @pytest.mark.gpu
+def test_lockstep_as_one_group_with_worker_threads():
+    """ALEO_MI355X_LOCKSTEP_GROUPS=1 (read once per process): the whole call as ONE lockstep group with worker threads on borrowed contexts — the path small calls took
+    before round 5 made one proof per group the default up to four proofs.  A child process (tests/helpers/lockstep_one_group_check.py) proves frozen cases 2, 3, 5 and 8
+    at a time under different seeds and compares with the single-proof entry point and the frozen bytes."""
+    import subprocess, sys
+    env = dict(os.environ, ALEO_MI355X_LOCKSTEP_GROUPS='1')
+    tool = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'helpers', 'lockstep_one_group_check.py')
+    r = subprocess.run([sys.executable, tool], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0 and 'ONE GROUP OK' in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+@pytest.mark.gpu
 def test_batch_entry_point_refuses_misuse():
     """aleo_mi355x_varuna_prove_batch_indexed: indexes built against different committer keys, a freed index, zero or nine instances of a circuit, a null
     assignment pointer and an output buffer that is too small all come back as error codes; the next good call is unaffected."""
